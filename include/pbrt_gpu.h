@@ -1,0 +1,216 @@
+/*
+ * pbrt_gpu.h -- C ABI of the MI355X-native path-tracing hot path.
+ *
+ * This is the drop-in boundary.  Everything above it
+ * (scene-file front end, graphics state, BVH construction, Film::WriteImage)
+ * is host C++; everything below it is hand-written HIP for gfx950.  The entry
+ * points are what a pbrt-v3 maintainer would bind from
+ *   Integrator::Render          src/core/integrator.h:57, integrator.cpp:228-339
+ *   Scene::Intersect/IntersectP src/core/scene.cpp:45-55
+ * Plain C types only: pointers + sizes, no C++ or torch types.
+ *
+ * Memory rules: every pointer in PgSceneDesc is caller-owned HOST memory and
+ * is copied at pg_scene_create(); the device copy is owned by the PgScene and
+ * freed by pg_scene_destroy().  Film/ray/hit buffers are caller-owned and may
+ * live in host or device memory (PgMemKind).
+ *
+ * Error model (mirrors pbrt's "report and continue", error.cpp:62-102, but
+ * with codes): every call returns PG_OK (0) or a negative PgStatus;
+ * pg_last_error() returns a thread-local message.  No C++ exceptions cross
+ * the ABI.
+ */
+#ifndef PBRT_GPU_H
+#define PBRT_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_ABI_VERSION 1
+
+typedef enum PgStatus {
+    PG_OK = 0,
+    PG_ERR_INVALID = -1,     /* bad argument / malformed scene description   */
+    PG_ERR_UNSUPPORTED = -2, /* feature outside the implemented closed set   */
+    PG_ERR_DEVICE = -3,      /* HIP runtime error (no GPU, OOM, launch fail) */
+    PG_ERR_OVERFLOW = -4     /* a fixed-size device queue overflowed         */
+} PgStatus;
+
+typedef enum PgMemKind { PG_MEM_HOST = 0, PG_MEM_DEVICE = 1 } PgMemKind;
+
+/* ---- flattened scene ---------------------------------------------------- */
+
+/* Bit-identical to pbrt's LinearBVHNode (src/accelerators/bvh.cpp:95-104):
+ * depth-first order, first child = index+1, second child = offset.         */
+typedef struct PgBVHNode {
+    float bmin[3];
+    float bmax[3];
+    int32_t offset;  /* leaf: first primitive; interior: second child index */
+    uint16_t nprims; /* 0 => interior                                        */
+    uint8_t axis;    /* interior: split axis                                 */
+    uint8_t pad;
+} PgBVHNode;
+
+/* Triangle flags (per primitive, BVH order). */
+#define PG_TRI_FLIP_NORMAL 1u /* reverseOrientation ^ transformSwapsHandedness (triangle.cpp:346-348) */
+#define PG_TRI_REVERSE_ORIENTATION 2u /* reverseOrientation alone (triangle.cpp:416)            */
+#define PG_TRI_HAS_N 4u       /* mesh has per-vertex shading normals  */
+#define PG_TRI_HAS_UV 8u      /* mesh has per-vertex uv               */
+#define PG_TRI_HAS_S 16u      /* mesh has per-vertex tangents         */
+
+typedef enum PgMaterialType {
+    PG_MAT_NONE = 0,   /* no material: primitive is a medium boundary (bsdf == nullptr) */
+    PG_MAT_MATTE = 1,  /* materials/matte.cpp:45-62   */
+    PG_MAT_PLASTIC = 2 /* materials/plastic.cpp:45-70 */
+} PgMaterialType;
+
+typedef struct PgMaterial {
+    int32_t type;    /* PgMaterialType */
+    float kd[3];     /* constant-texture value, already clamped >= 0 is NOT assumed */
+    float ks[3];
+    float sigma;     /* matte: Oren-Nayar sigma (degrees); 0 => Lambertian */
+    float roughness; /* plastic */
+    int32_t remap_roughness;
+} PgMaterial;
+
+/* One DiffuseAreaLight per emissive triangle (api.cpp:1353-1363,
+ * lights/diffuse.cpp:43-87), in scene.lights order.                        */
+typedef struct PgLight {
+    int32_t prim;      /* index (BVH order) of the emitting triangle */
+    float L[3];        /* Lemit = L * scale                           */
+    int32_t two_sided;
+    float area;        /* shape->Area() as computed by the host       */
+} PgLight;
+
+typedef enum PgLightStrategy {
+    PG_LIGHTS_UNIFORM = 0,
+    PG_LIGHTS_POWER = 1,
+    PG_LIGHTS_SPATIAL = 2
+} PgLightStrategy;
+
+typedef struct PgSceneDesc {
+    int32_t abi_version;        /* PG_ABI_VERSION */
+    /* acceleration structure, BVHAccel after flattenBVHTree (bvh.cpp:640-658) */
+    int32_t n_nodes;
+    const PgBVHNode *nodes;
+    /* primitives in BVH (orderedPrims) order */
+    int32_t n_tris;
+    const int32_t *indices;     /* 3*n_tris vertex indices                  */
+    const uint32_t *tri_flags;  /* n_tris PG_TRI_* bits                     */
+    const int32_t *tri_material;/* n_tris index into materials              */
+    const int32_t *tri_light;   /* n_tris index into lights, -1 = not emissive */
+    /* vertex data, world space (triangle.cpp:73-74) */
+    int32_t n_verts;
+    const float *P;             /* 3*n_verts                                */
+    const float *N;             /* 3*n_verts or NULL                        */
+    const float *UV;            /* 2*n_verts or NULL                        */
+    const float *S;             /* 3*n_verts or NULL                        */
+    int32_t n_materials;
+    const PgMaterial *materials;
+    int32_t n_lights;
+    const PgLight *lights;
+    int32_t light_strategy;     /* PgLightStrategy as resolved by CreateLightSampleDistribution (lightdistrib.cpp:48-66) */
+    /* Halton digit permutations (lowdiscrepancy.cpp:2490-2504), first n_perm_dims
+     * prime bases concatenated; perm_sums[d] = offset of base d.            */
+    int32_t n_perm_dims;
+    const uint16_t *perms;
+    const int32_t *perm_sums;   /* n_perm_dims+1 entries */
+} PgSceneDesc;
+
+/* ---- render description -------------------------------------------------- */
+
+typedef struct PgRenderDesc {
+    int32_t abi_version;
+    /* camera: PerspectiveCamera (cameras/perspective.cpp:45-144) */
+    float raster_to_camera[16]; /* row-major Matrix4x4 */
+    float camera_to_world[16];
+    float lens_radius, focal_distance;
+    float shutter_open, shutter_close;
+    /* film (film.cpp:45-86) */
+    int32_t full_res[2];
+    int32_t cropped_pixel_bounds[4]; /* x0,y0,x1,y1 */
+    int32_t sample_bounds[4];
+    float filter_radius[2];          /* box filter only in this round */
+    float film_scale;
+    float max_sample_luminance;
+    /* sampler: HaltonSampler (samplers/halton.cpp:65-127) */
+    int32_t spp;
+    int32_t base_scales[2], base_exponents[2];
+    int32_t sample_stride;
+    int32_t mult_inverse[2];
+    int32_t sample_at_pixel_center;
+    /* integrator: PathIntegrator (integrators/path.cpp:190-213) */
+    int32_t max_depth;
+    float rr_threshold;
+    int32_t pixel_bounds[4];
+    /* sharding: this call renders the 16x16 tiles t of the full-frame tiling
+     * with (t % tile_count) == tile_first ... i.e. t = tile_first + k*tile_step.
+     * Single GPU: tile_first=0, tile_step=1.                                 */
+    int32_t tile_first, tile_step;
+} PgRenderDesc;
+
+/* One film pixel as accumulated by FilmTile::AddSample (film.h:121-161):
+ * RGB contribution sum (tile-local, pre-XYZ) and filter weight sum.          */
+typedef struct PgFilmPixel { float rgb[3]; float weight; } PgFilmPixel;
+
+/* A sample whose box-filter footprint also covers a neighbouring pixel
+ * (film.h:127-132 when the sample offset is exactly 0); applied on the host
+ * in the reference's order.                                                  */
+typedef struct PgStraySample { int32_t px, py; int32_t src_px, src_py; float rgb[3]; float weight; } PgStraySample;
+
+/* Ray-traversal statistics; the reference's own counters (scene.cpp:40-42,
+ * integrator.cpp:48, triangle.cpp:45) plus node fetches, which define the
+ * algorithmic byte count of SURVEY.md section 8(d).                          */
+typedef struct PgCounters {
+    uint64_t camera_rays;
+    uint64_t closest_rays; /* Scene::Intersect calls  */
+    uint64_t shadow_rays;  /* Scene::IntersectP calls */
+    uint64_t node_visits;  /* nodes[cur] fetches (bvh.cpp:672/710) */
+    uint64_t tri_tests;    /* Triangle::Intersect[P] calls          */
+    uint64_t closest_launches, shadow_launches;
+    double closest_ms, shadow_ms; /* HIP-event time inside the traversal kernels */
+    double render_ms;
+} PgCounters;
+
+typedef struct PgScene PgScene;
+
+/* Number of visible HIP devices; negative PgStatus on failure. */
+int pg_device_count(void);
+/* Select the device subsequent calls on this thread use. */
+int pg_set_device(int device);
+const char *pg_last_error(void);
+
+int pg_scene_create(const PgSceneDesc *desc, PgScene **out);
+void pg_scene_destroy(PgScene *scene);
+
+/* Number of 16x16 tiles this (tile_first, tile_step) shard owns, and the
+ * number of PgFilmPixel entries (256 per tile) pg_render writes.             */
+int pg_render_tile_count(const PgRenderDesc *desc);
+
+/* SamplerIntegrator::Render for the shard in desc: fills film[256*tiles]
+ * (tile-major, row-major inside the 16x16 tile, zero outside the image) and
+ * up to max_strays stray samples; *n_strays receives the count.
+ * film/strays live in `mem` memory; `stream` is a hipStream_t (NULL = default). */
+int pg_render(PgScene *scene, const PgRenderDesc *desc, PgFilmPixel *film,
+              PgStraySample *strays, int32_t max_strays, int32_t *n_strays,
+              int mem, void *stream);
+
+/* Batched Scene::Intersect: rays as SoA (ox..dz, tmax), n rays.  Outputs
+ * prim (-1 = miss), t, b0, b1, b2 (barycentrics exactly as computed by
+ * Triangle::Intersect, triangle.cpp:280-285).                                */
+int pg_intersect(PgScene *scene, int32_t n, const float *o, const float *d,
+                 const float *tmax, int32_t *prim, float *t, float *bary,
+                 int mem, void *stream);
+/* Batched Scene::IntersectP: occluded[i] = 1 if any hit.                     */
+int pg_intersect_p(PgScene *scene, int32_t n, const float *o, const float *d,
+                   const float *tmax, uint8_t *occluded, int mem, void *stream);
+
+int pg_counters(PgScene *scene, PgCounters *out);
+int pg_counters_reset(PgScene *scene);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBRT_GPU_H */

@@ -1,0 +1,45 @@
+/*
+ * pbrt_host.h -- C entry points of the host front end (libpbrt_host.so).
+ *
+ * The host library is the C++ mirror of pbrt-v3's scene-file front end and
+ * API state machine (src/core/parser.cpp, src/core/api.cpp): it parses a
+ * .pbrt file, builds the BVHAccel and flattens everything into the
+ * PgSceneDesc / PgRenderDesc consumed by the HIP back end (pbrt_gpu.h).
+ * These functions exist so that non-C++ hosts (the Python test-suite and
+ * bench.py through ctypes) can drive the same code the `pbrt_amd` CLI uses.
+ */
+#ifndef PBRT_HOST_H
+#define PBRT_HOST_H
+#include "pbrt_gpu.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct PbrtHostScene PbrtHostScene;
+
+/* pbrtInit + pbrtParseFile + pbrtCleanup with WorldEnd stopping before Render
+ * (main/pbrt.cpp:76-173).  quick = --quick; crop = NULL or {x0,x1,y0,y1}
+ * (--cropwindow).  Returns NULL if the file produced no renderable scene.   */
+PbrtHostScene *pbrt_host_load_file(const char *filename, int quick, const float *crop);
+PbrtHostScene *pbrt_host_load_string(const char *text, int quick, const float *crop);
+void pbrt_host_free(PbrtHostScene *s);
+
+const PgSceneDesc *pbrt_host_scene_desc(PbrtHostScene *s);
+void pbrt_host_render_desc(PbrtHostScene *s, PgRenderDesc *out);
+
+/* Film: cropped image size; MergeFilmTile for one shard; final RGB image
+ * (row-major, top row first, 3 floats per pixel) as Film::WriteImage computes it. */
+void pbrt_host_film_size(PbrtHostScene *s, int *width, int *height);
+void pbrt_host_film_clear(PbrtHostScene *s);
+void pbrt_host_film_merge(PbrtHostScene *s, const PgRenderDesc *rd, const PgFilmPixel *film,
+                          const PgStraySample *strays, int n_strays);
+void pbrt_host_film_image(PbrtHostScene *s, float *rgb);
+int pbrt_host_write_pfm(const char *filename, const float *rgb, int width, int height);
+
+/* Number of distinct Error() messages reported so far in this process. */
+int pbrt_host_error_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,114 @@
+"""ctypes wrapper of liboracle.so (the CPU restatement, pbrt_oracle.c).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+REF_BINARY = os.path.join(_HERE, "_ref", "pbrt_oracle")
+_lib = None
+
+
+def _pkg():
+    sys.path.insert(0, _ROOT) if _ROOT not in sys.path else None
+    from __graft_entry__ import load_package
+    return load_package()
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            subprocess.check_call(["make", "-C", _HERE, "liboracle.so"])
+        pkg = _pkg()
+        abi = pkg.abi
+        L = C.CDLL(LIB_PATH)
+        L.oracle_render_tile_count.restype = C.c_int
+        L.oracle_render_tile_count.argtypes = [C.POINTER(abi.PgRenderDesc)]
+        L.oracle_render.restype = C.c_int
+        L.oracle_render.argtypes = [C.POINTER(abi.PgSceneDesc), C.POINTER(abi.PgRenderDesc), C.c_void_p, C.c_void_p,
+                                    C.c_int32, C.POINTER(C.c_int32), C.POINTER(abi.PgCounters)]
+        L.oracle_intersect.restype = C.c_int
+        L.oracle_intersect.argtypes = [C.POINTER(abi.PgSceneDesc), C.c_int32] + [C.c_void_p] * 6 + [C.POINTER(abi.PgCounters)]
+        L.oracle_intersect_p.restype = C.c_int
+        L.oracle_intersect_p.argtypes = [C.POINTER(abi.PgSceneDesc), C.c_int32] + [C.c_void_p] * 4 + [C.POINTER(abi.PgCounters)]
+        L.oracle_radical_inverse.restype = C.c_float
+        L.oracle_radical_inverse.argtypes = [C.c_int, C.c_uint64]
+        L.oracle_scrambled_radical_inverse.restype = C.c_float
+        L.oracle_scrambled_radical_inverse.argtypes = [C.c_int, C.c_uint64, C.c_void_p]
+        L.oracle_halton_index.restype = C.c_int64
+        L.oracle_halton_index.argtypes = [C.POINTER(abi.PgRenderDesc), C.c_int, C.c_int, C.c_int64]
+        L.oracle_halton_sample.restype = C.c_float
+        L.oracle_halton_sample.argtypes = [C.POINTER(abi.PgSceneDesc), C.POINTER(abi.PgRenderDesc), C.c_int64, C.c_int]
+        L.oracle_triangle_intersect.restype = C.c_int
+        L.oracle_triangle_intersect.argtypes = [C.c_void_p] * 5 + [C.c_float, C.POINTER(C.c_float), C.c_void_p]
+        L.oracle_spawn_ray_origin.restype = None
+        L.oracle_spawn_ray_origin.argtypes = [C.c_void_p] * 5
+        _lib = L
+    return _lib
+
+
+def render(desc, rd, max_strays=None):
+    """oracle_render: same outputs as pg_render (film, strays) plus the reference's counters."""
+    pkg = _pkg()
+    L = lib()
+    n = L.oracle_render_tile_count(C.byref(rd))
+    if max_strays is None:
+        max_strays = n * 256 // 8 + 1024
+    film = np.zeros(n * 256, pkg.FILM_PIXEL_DTYPE)
+    strays = np.zeros(max_strays, pkg.STRAY_DTYPE)
+    ns = C.c_int32(0)
+    cn = pkg.abi.PgCounters()
+    st = L.oracle_render(C.byref(desc), C.byref(rd), film.ctypes.data, strays.ctypes.data, max_strays, C.byref(ns), C.byref(cn))
+    if st != 0:
+        raise RuntimeError(f"oracle_render failed: {st}")
+    return film, strays[:ns.value], cn.as_dict()
+
+
+def render_image(scene):
+    """Full-frame oracle render of a HostScene, merged by the host Film: (h, w, 3) image + counters."""
+    rd = scene.render_desc()
+    film, strays, cn = render(scene.desc, rd)
+    scene.film_clear()
+    scene.film_merge(rd, film, strays)
+    return scene.film_image(), cn
+
+
+def intersect(desc, o, d, tmax):
+    pkg = _pkg()
+    o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32); tmax = np.ascontiguousarray(tmax, np.float32)
+    n = len(tmax)
+    prim = np.empty(n, np.int32); t = np.empty(n, np.float32); bary = np.empty((n, 3), np.float32)
+    cn = pkg.abi.PgCounters()
+    lib().oracle_intersect(C.byref(desc), n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data, prim.ctypes.data, t.ctypes.data,
+                           bary.ctypes.data, C.byref(cn))
+    return prim, t, bary, cn.as_dict()
+
+
+def intersect_p(desc, o, d, tmax):
+    pkg = _pkg()
+    o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32); tmax = np.ascontiguousarray(tmax, np.float32)
+    n = len(tmax)
+    occ = np.empty(n, np.uint8)
+    cn = pkg.abi.PgCounters()
+    lib().oracle_intersect_p(C.byref(desc), n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data, occ.ctypes.data, C.byref(cn))
+    return occ, cn.as_dict()
+
+
+def run_reference(scene_file, out_pfm, nthreads=None, quiet=True):
+    """Render scene_file with the UNMODIFIED reference binary (oracle/_ref/pbrt_oracle). Returns its stdout."""
+    if not os.path.exists(REF_BINARY):
+        raise FileNotFoundError(f"{REF_BINARY} not built (make -C oracle ref; needs /root/reference)")
+    cmd = [REF_BINARY, "--outfile", out_pfm]
+    if nthreads:
+        cmd += ["--nthreads", str(nthreads)]
+    cmd.append(scene_file)
+    return subprocess.run(cmd, check=True, capture_output=True, text=True).stdout

@@ -1,0 +1,114 @@
+"""ctypes mirror of include/pbrt_gpu.h and include/pbrt_host.h.
+
+Layouts must match the C headers field for field; tests/test_abi.py checks
+sizeof() of every struct against values compiled from the headers.
+"""
+import ctypes as C
+
+PG_ABI_VERSION = 1
+PG_OK = 0
+PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
+PG_LIGHTS_UNIFORM, PG_LIGHTS_POWER, PG_LIGHTS_SPATIAL = 0, 1, 2
+PG_MAT_NONE, PG_MAT_MATTE, PG_MAT_PLASTIC = 0, 1, 2
+PG_TRI_FLIP_NORMAL, PG_TRI_REVERSE_ORIENTATION, PG_TRI_HAS_N, PG_TRI_HAS_UV, PG_TRI_HAS_S = 1, 2, 4, 8, 16
+
+
+class PgBVHNode(C.Structure):
+    _fields_ = [("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("offset", C.c_int32),
+                ("nprims", C.c_uint16), ("axis", C.c_uint8), ("pad", C.c_uint8)]
+
+
+class PgMaterial(C.Structure):
+    _fields_ = [("type", C.c_int32), ("kd", C.c_float * 3), ("ks", C.c_float * 3), ("sigma", C.c_float),
+                ("roughness", C.c_float), ("remap_roughness", C.c_int32)]
+
+
+class PgLight(C.Structure):
+    _fields_ = [("prim", C.c_int32), ("L", C.c_float * 3), ("two_sided", C.c_int32), ("area", C.c_float)]
+
+
+class PgSceneDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_int32),
+                ("n_nodes", C.c_int32), ("nodes", C.POINTER(PgBVHNode)),
+                ("n_tris", C.c_int32), ("indices", C.POINTER(C.c_int32)), ("tri_flags", C.POINTER(C.c_uint32)),
+                ("tri_material", C.POINTER(C.c_int32)), ("tri_light", C.POINTER(C.c_int32)),
+                ("n_verts", C.c_int32), ("P", C.POINTER(C.c_float)), ("N", C.POINTER(C.c_float)),
+                ("UV", C.POINTER(C.c_float)), ("S", C.POINTER(C.c_float)),
+                ("n_materials", C.c_int32), ("materials", C.POINTER(PgMaterial)),
+                ("n_lights", C.c_int32), ("lights", C.POINTER(PgLight)),
+                ("light_strategy", C.c_int32),
+                ("n_perm_dims", C.c_int32), ("perms", C.POINTER(C.c_uint16)), ("perm_sums", C.POINTER(C.c_int32))]
+
+
+class PgRenderDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_int32),
+                ("raster_to_camera", C.c_float * 16), ("camera_to_world", C.c_float * 16),
+                ("lens_radius", C.c_float), ("focal_distance", C.c_float),
+                ("shutter_open", C.c_float), ("shutter_close", C.c_float),
+                ("full_res", C.c_int32 * 2), ("cropped_pixel_bounds", C.c_int32 * 4), ("sample_bounds", C.c_int32 * 4),
+                ("filter_radius", C.c_float * 2), ("film_scale", C.c_float), ("max_sample_luminance", C.c_float),
+                ("spp", C.c_int32), ("base_scales", C.c_int32 * 2), ("base_exponents", C.c_int32 * 2),
+                ("sample_stride", C.c_int32), ("mult_inverse", C.c_int32 * 2), ("sample_at_pixel_center", C.c_int32),
+                ("max_depth", C.c_int32), ("rr_threshold", C.c_float), ("pixel_bounds", C.c_int32 * 4),
+                ("tile_first", C.c_int32), ("tile_step", C.c_int32)]
+
+
+class PgFilmPixel(C.Structure):
+    _fields_ = [("rgb", C.c_float * 3), ("weight", C.c_float)]
+
+
+class PgStraySample(C.Structure):
+    _fields_ = [("px", C.c_int32), ("py", C.c_int32), ("src_px", C.c_int32), ("src_py", C.c_int32),
+                ("rgb", C.c_float * 3), ("weight", C.c_float)]
+
+
+class PgCounters(C.Structure):
+    _fields_ = [("camera_rays", C.c_uint64), ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
+                ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("closest_launches", C.c_uint64), ("shadow_launches", C.c_uint64),
+                ("closest_ms", C.c_double), ("shadow_ms", C.c_double), ("render_ms", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# every symbol include/pbrt_gpu.h declares: name -> (restype, argtypes)
+GPU_SYMBOLS = {
+    "pg_device_count": (C.c_int, []),
+    "pg_set_device": (C.c_int, [C.c_int]),
+    "pg_last_error": (C.c_char_p, []),
+    "pg_scene_create": (C.c_int, [C.POINTER(PgSceneDesc), C.POINTER(C.c_void_p)]),
+    "pg_scene_destroy": (None, [C.c_void_p]),
+    "pg_render_tile_count": (C.c_int, [C.POINTER(PgRenderDesc)]),
+    "pg_render": (C.c_int, [C.c_void_p, C.POINTER(PgRenderDesc), C.c_void_p, C.c_void_p, C.c_int32,
+                            C.c_void_p, C.c_int, C.c_void_p]),
+    "pg_intersect": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_int, C.c_void_p]),
+    "pg_intersect_p": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                 C.c_void_p]),
+    "pg_counters": (C.c_int, [C.c_void_p, C.POINTER(PgCounters)]),
+    "pg_counters_reset": (C.c_int, [C.c_void_p]),
+}
+
+HOST_SYMBOLS = {
+    "pbrt_host_load_file": (C.c_void_p, [C.c_char_p, C.c_int, C.POINTER(C.c_float)]),
+    "pbrt_host_load_string": (C.c_void_p, [C.c_char_p, C.c_int, C.POINTER(C.c_float)]),
+    "pbrt_host_free": (None, [C.c_void_p]),
+    "pbrt_host_scene_desc": (C.POINTER(PgSceneDesc), [C.c_void_p]),
+    "pbrt_host_render_desc": (None, [C.c_void_p, C.POINTER(PgRenderDesc)]),
+    "pbrt_host_film_size": (None, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pbrt_host_film_clear": (None, [C.c_void_p]),
+    "pbrt_host_film_merge": (None, [C.c_void_p, C.POINTER(PgRenderDesc), C.c_void_p, C.c_void_p, C.c_int]),
+    "pbrt_host_film_image": (None, [C.c_void_p, C.c_void_p]),
+    "pbrt_host_write_pfm": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int]),
+    "pbrt_host_error_count": (C.c_int, []),
+}
+
+
+def bind(lib, table):
+    """Attach restype/argtypes for every symbol; raises AttributeError if one is missing."""
+    for name, (res, args) in table.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib

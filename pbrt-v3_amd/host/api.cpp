@@ -1,0 +1,556 @@
+// Graphics-state machine and Create*() factories of the scene front end
+// (reference: src/core/api.cpp).  Same directive names, parameter names and
+// defaults, so a .pbrt file means the same thing; plugins outside the
+// hot-path closed set are reported with Error() and
+// skipped, which is pbrt's own behaviour for unknown plugin names.
+#include "api.h"
+#include <libgen.h>
+#include <climits>
+#include <cstring>
+#include <cstdlib>
+#include <map>
+#include "error.h"
+#include "scene.h"
+
+namespace pbrt {
+Options PbrtOptions;
+std::unique_ptr<LoadedScene> lastLoadedScene;
+
+// ---- fileutil.cpp -----------------------------------------------------------
+static std::string searchDirectory;
+std::string DirectoryContaining(const std::string &filename) {
+    char *t = strdup(filename.c_str());
+    std::string result = dirname(t);
+    free(t);
+    return result;
+}
+void SetSearchDirectory(const std::string &dirname) { searchDirectory = dirname; }
+static bool IsAbsolutePath(const std::string &filename) { return !filename.empty() && filename[0] == '/'; }
+std::string ResolveFilename(const std::string &filename) {
+    if (searchDirectory.empty() || filename.empty()) return filename;
+    if (IsAbsolutePath(filename)) return filename;
+    if (searchDirectory.back() == '/') return searchDirectory + filename;
+    return searchDirectory + "/" + filename;
+}
+std::string AbsolutePath(const std::string &filename) {
+    char full[PATH_MAX];
+    if (realpath(filename.c_str(), full)) return std::string(full);
+    return filename;
+}
+
+// ---- API state (api.cpp:120-330) -------------------------------------------------
+namespace {
+constexpr int MaxTransforms = 2;
+constexpr int StartTransformBits = 1, EndTransformBits = 2, AllTransformsBits = 3;
+struct TransformSet {
+    Transform t[MaxTransforms];
+    Transform &operator[](int i) { return t[i]; }
+    const Transform &operator[](int i) const { return t[i]; }
+    bool IsAnimated() const { return !(t[0].GetMatrix() == t[1].GetMatrix()); }
+};
+TransformSet Inverse(const TransformSet &ts) {
+    TransformSet r;
+    for (int i = 0; i < MaxTransforms; ++i) r.t[i] = Inverse(ts.t[i]);
+    return r;
+}
+struct MaterialInstance { std::string name; int material = -1; ParamSet params; };
+struct GraphicsState {
+    std::map<std::string, RGB> spectrumTextures;   // constant textures only
+    std::map<std::string, Float> floatTextures;
+    std::map<std::string, MaterialInstance> namedMaterials;
+    MaterialInstance currentMaterial;
+    ParamSet areaLightParams;
+    std::string areaLight;
+    bool reverseOrientation = false;
+};
+struct RenderOptions {
+    Float transformStartTime = 0, transformEndTime = 1;
+    std::string FilterName = "box"; ParamSet FilterParams;
+    std::string FilmName = "image"; ParamSet FilmParams;
+    std::string SamplerName = "halton"; ParamSet SamplerParams;
+    std::string AcceleratorName = "bvh"; ParamSet AcceleratorParams;
+    std::string IntegratorName = "path"; ParamSet IntegratorParams;
+    std::string CameraName = "perspective"; ParamSet CameraParams;
+    TransformSet CameraToWorld;
+    std::vector<GeometricPrimitive> primitives;
+    std::vector<PgLight> lights;           // prim index filled at flatten time
+    std::vector<size_t> lightPrimSerial;   // serial number of the emitting primitive
+    std::vector<PgMaterial> materials;
+    bool haveScatteringMedia = false;
+};
+enum class APIState { Uninitialized, OptionsBlock, WorldBlock };
+APIState currentApiState = APIState::Uninitialized;
+TransformSet curTransform;
+uint32_t activeTransformBits = AllTransformsBits;
+std::map<std::string, TransformSet> namedCoordinateSystems;
+std::unique_ptr<RenderOptions> renderOptions;
+GraphicsState graphicsState;
+std::vector<GraphicsState> pushedGraphicsStates;
+std::vector<TransformSet> pushedTransforms;
+std::vector<uint32_t> pushedActiveTransformBits;
+}  // namespace
+
+#define VERIFY_INITIALIZED(func)                                                        \
+    if (currentApiState == APIState::Uninitialized) {                                   \
+        Error("pbrtInit() must be before calling \"%s()\". Ignoring.", func);           \
+        return;                                                                         \
+    } else /* swallow trailing semicolon */
+#define VERIFY_OPTIONS(func)                                                            \
+    VERIFY_INITIALIZED(func);                                                           \
+    if (currentApiState == APIState::WorldBlock) {                                      \
+        Error("Options cannot be set inside world block; \"%s\" not allowed.  Ignoring.", func); \
+        return;                                                                         \
+    } else /* swallow trailing semicolon */
+#define VERIFY_WORLD(func)                                                              \
+    VERIFY_INITIALIZED(func);                                                           \
+    if (currentApiState == APIState::OptionsBlock) {                                    \
+        Error("Scene description must be inside world block; \"%s\" not allowed. Ignoring.", func); \
+        return;                                                                         \
+    } else /* swallow trailing semicolon */
+#define FOR_ACTIVE_TRANSFORMS(expr)                  \
+    for (int i = 0; i < MaxTransforms; ++i)          \
+        if (activeTransformBits & (1 << i)) { expr }
+
+// ---- materials (api.cpp:537-620; matte.cpp:64-72; plastic.cpp:72-84) ---------------
+// Textures are restricted to constants: a "texture" parameter must name a
+// constant texture declared with Texture "name" "spectrum|float" "constant".
+static RGB spectrumParam(const ParamSet &geom, const ParamSet &mat, const std::string &n, RGB def,
+                         const GraphicsState &gs) {
+    for (const ParamSet *ps : {&geom, &mat}) {  // shape parameters first (paramset.cpp:729-760)
+        std::string tex = ps->FindTexture(n);
+        if (!tex.empty()) {
+            auto it = gs.spectrumTextures.find(tex);
+            if (it != gs.spectrumTextures.end()) return it->second;
+            Error("Couldn't find spectrum texture named \"%s\" for parameter \"%s\"", tex.c_str(), n.c_str());
+            continue;
+        }
+        RGB s;
+        if (ps->FindSpectrum(n, &s)) return s;
+    }
+    return def;
+}
+static Float floatParam(const ParamSet &geom, const ParamSet &mat, const std::string &n, Float def,
+                        const GraphicsState &gs) {
+    for (const ParamSet *ps : {&geom, &mat}) {
+        std::string tex = ps->FindTexture(n);
+        if (!tex.empty()) {
+            auto it = gs.floatTextures.find(tex);
+            if (it != gs.floatTextures.end()) return it->second;
+            Error("Couldn't find float texture named \"%s\" for parameter \"%s\"", tex.c_str(), n.c_str());
+            continue;
+        }
+        const std::vector<Float> *f = ps->FindFloat(n);
+        if (f && !f->empty()) return (*f)[0];
+    }
+    return def;
+}
+static int internMaterial(const PgMaterial &m) {
+    auto &tab = renderOptions->materials;
+    for (size_t i = 0; i < tab.size(); ++i)
+        if (memcmp(&tab[i], &m, sizeof(m)) == 0) return (int)i;
+    tab.push_back(m);
+    return (int)tab.size() - 1;
+}
+static int MakeMaterial(const std::string &name, const ParamSet &geom, const ParamSet &mat) {
+    PgMaterial m;
+    memset(&m, 0, sizeof(m));
+    if (name == "" || name == "none") { m.type = PG_MAT_NONE; return internMaterial(m); }
+    if (name == "matte") {
+        m.type = PG_MAT_MATTE;
+        RGB kd = spectrumParam(geom, mat, "Kd", RGB{{0.5f, 0.5f, 0.5f}}, graphicsState);
+        for (int i = 0; i < 3; ++i) m.kd[i] = kd.c[i];
+        m.sigma = floatParam(geom, mat, "sigma", 0.f, graphicsState);
+        if (!geom.FindTexture("bumpmap").empty() || !mat.FindTexture("bumpmap").empty())
+            Error("\"bumpmap\" textures are not supported by this build; ignoring.");
+        if (m.sigma != 0) Error("matte \"sigma\" != 0 (Oren-Nayar) is not supported by this build; using Lambertian.");
+    } else if (name == "plastic") {
+        m.type = PG_MAT_PLASTIC;
+        RGB kd = spectrumParam(geom, mat, "Kd", RGB{{0.25f, 0.25f, 0.25f}}, graphicsState);
+        RGB ks = spectrumParam(geom, mat, "Ks", RGB{{0.25f, 0.25f, 0.25f}}, graphicsState);
+        for (int i = 0; i < 3; ++i) { m.kd[i] = kd.c[i]; m.ks[i] = ks.c[i]; }
+        m.roughness = floatParam(geom, mat, "roughness", .1f, graphicsState);
+        bool remap = geom.FindOneBool("remaproughness", mat.FindOneBool("remaproughness", true));
+        m.remap_roughness = remap ? 1 : 0;
+    } else {
+        Error("Material \"%s\" is outside this build's closed set (matte, plastic); using matte.", name.c_str());
+        m.type = PG_MAT_MATTE;
+        m.kd[0] = m.kd[1] = m.kd[2] = 0.5f;
+    }
+    mat.ReportUnused();
+    return internMaterial(m);
+}
+
+// api.cpp:1427-1470
+static bool shapeMaySetMaterialParameters(const ParamSet &ps) {
+    for (auto &kv : ps.textures)
+        if (kv.first != "alpha" && kv.first != "shadowalpha") return true;
+    for (auto &kv : ps.floats)
+        if (kv.second.v.size() == 1 && kv.first != "radius") return true;
+    for (auto &kv : ps.strings)
+        if (kv.second.v.size() == 1 && kv.first != "filename" && kv.first != "type" && kv.first != "scheme") return true;
+    for (auto &kv : ps.bools) if (kv.second.v.size() == 1) return true;
+    for (auto &kv : ps.ints) if (kv.second.v.size() == 1) return true;
+    for (auto &kv : ps.point2s) if (kv.second.v.size() == 2) return true;
+    for (auto &kv : ps.point3s) if (kv.second.v.size() == 3) return true;
+    for (auto &kv : ps.vector3s) if (kv.second.v.size() == 3) return true;
+    for (auto &kv : ps.normals) if (kv.second.v.size() == 3) return true;
+    for (auto &kv : ps.spectra) if (kv.second.v.size() == 3) return true;
+    return false;
+}
+static int GetMaterialForShape(const ParamSet &shapeParams) {  // api.cpp:1472-1487
+    if (shapeMaySetMaterialParameters(shapeParams))
+        return MakeMaterial(graphicsState.currentMaterial.name, shapeParams, graphicsState.currentMaterial.params);
+    return graphicsState.currentMaterial.material;
+}
+
+// ---- API functions ----------------------------------------------------------
+void pbrtInit(const Options &opt) {  // api.cpp:871-886
+    PbrtOptions = opt;
+    quietWarnings = opt.quiet;
+    if (currentApiState != APIState::Uninitialized) Error("pbrtInit() has already been called.");
+    currentApiState = APIState::OptionsBlock;
+    renderOptions.reset(new RenderOptions);
+    graphicsState = GraphicsState();
+    curTransform = TransformSet();
+    activeTransformBits = AllTransformsBits;
+    namedCoordinateSystems.clear();
+    pushedGraphicsStates.clear(); pushedTransforms.clear(); pushedActiveTransformBits.clear();
+}
+void pbrtCleanup() {  // api.cpp:888-897
+    if (currentApiState == APIState::Uninitialized) Error("pbrtCleanup() called without pbrtInit().");
+    else if (currentApiState == APIState::WorldBlock) Error("pbrtCleanup() called while inside world block.");
+    currentApiState = APIState::Uninitialized;
+    renderOptions.reset();
+}
+void pbrtIdentity() { VERIFY_INITIALIZED("Identity"); FOR_ACTIVE_TRANSFORMS(curTransform[i] = Transform();) }
+void pbrtTranslate(Float dx, Float dy, Float dz) {
+    VERIFY_INITIALIZED("Translate");
+    FOR_ACTIVE_TRANSFORMS(curTransform[i] = curTransform[i] * Translate(Vector3f(dx, dy, dz));)
+}
+void pbrtTransform(Float tr[16]) {
+    VERIFY_INITIALIZED("Transform");
+    FOR_ACTIVE_TRANSFORMS(curTransform[i] = Transform(Matrix4x4(tr[0], tr[4], tr[8], tr[12], tr[1], tr[5], tr[9], tr[13],
+                                                               tr[2], tr[6], tr[10], tr[14], tr[3], tr[7], tr[11], tr[15]));)
+}
+void pbrtConcatTransform(Float tr[16]) {
+    VERIFY_INITIALIZED("ConcatTransform");
+    FOR_ACTIVE_TRANSFORMS(curTransform[i] = curTransform[i] *
+        Transform(Matrix4x4(tr[0], tr[4], tr[8], tr[12], tr[1], tr[5], tr[9], tr[13], tr[2], tr[6], tr[10], tr[14],
+                            tr[3], tr[7], tr[11], tr[15]));)
+}
+void pbrtRotate(Float angle, Float dx, Float dy, Float dz) {
+    VERIFY_INITIALIZED("Rotate");
+    FOR_ACTIVE_TRANSFORMS(curTransform[i] = curTransform[i] * Rotate(angle, Vector3f(dx, dy, dz));)
+}
+void pbrtScale(Float sx, Float sy, Float sz) {
+    VERIFY_INITIALIZED("Scale");
+    FOR_ACTIVE_TRANSFORMS(curTransform[i] = curTransform[i] * Scale(sx, sy, sz);)
+}
+void pbrtLookAt(Float ex, Float ey, Float ez, Float lx, Float ly, Float lz, Float ux, Float uy, Float uz) {
+    VERIFY_INITIALIZED("LookAt");
+    Transform lookAt = LookAt(Point3f(ex, ey, ez), Point3f(lx, ly, lz), Vector3f(ux, uy, uz));
+    FOR_ACTIVE_TRANSFORMS(curTransform[i] = curTransform[i] * lookAt;)
+}
+void pbrtCoordinateSystem(const std::string &name) { VERIFY_INITIALIZED("CoordinateSystem"); namedCoordinateSystems[name] = curTransform; }
+void pbrtCoordSysTransform(const std::string &name) {
+    VERIFY_INITIALIZED("CoordSysTransform");
+    if (namedCoordinateSystems.find(name) != namedCoordinateSystems.end()) curTransform = namedCoordinateSystems[name];
+    else Warning("Couldn't find named coordinate system \"%s\"", name.c_str());
+}
+void pbrtActiveTransformAll() { activeTransformBits = AllTransformsBits; }
+void pbrtActiveTransformEndTime() { activeTransformBits = EndTransformBits; }
+void pbrtActiveTransformStartTime() { activeTransformBits = StartTransformBits; }
+void pbrtTransformTimes(Float start, Float end) {
+    VERIFY_OPTIONS("TransformTimes");
+    renderOptions->transformStartTime = start;
+    renderOptions->transformEndTime = end;
+}
+void pbrtPixelFilter(const std::string &name, const ParamSet &params) {
+    VERIFY_OPTIONS("PixelFilter"); renderOptions->FilterName = name; renderOptions->FilterParams = params;
+}
+void pbrtFilm(const std::string &type, const ParamSet &params) {
+    VERIFY_OPTIONS("Film"); renderOptions->FilmParams = params; renderOptions->FilmName = type;
+}
+void pbrtSampler(const std::string &name, const ParamSet &params) {
+    VERIFY_OPTIONS("Sampler"); renderOptions->SamplerName = name; renderOptions->SamplerParams = params;
+}
+void pbrtAccelerator(const std::string &name, const ParamSet &params) {
+    VERIFY_OPTIONS("Accelerator"); renderOptions->AcceleratorName = name; renderOptions->AcceleratorParams = params;
+}
+void pbrtIntegrator(const std::string &name, const ParamSet &params) {
+    VERIFY_OPTIONS("Integrator"); renderOptions->IntegratorName = name; renderOptions->IntegratorParams = params;
+}
+void pbrtCamera(const std::string &name, const ParamSet &params) {  // api.cpp:1076-1087
+    VERIFY_OPTIONS("Camera");
+    renderOptions->CameraName = name;
+    renderOptions->CameraParams = params;
+    renderOptions->CameraToWorld = Inverse(curTransform);
+    namedCoordinateSystems["camera"] = renderOptions->CameraToWorld;
+}
+void pbrtMakeNamedMedium(const std::string &name, const ParamSet &) {
+    VERIFY_INITIALIZED("MakeNamedMedium");
+    Error("MakeNamedMedium \"%s\": participating media are outside this build's scope (PathIntegrator ignores them).", name.c_str());
+}
+void pbrtMediumInterface(const std::string &insideName, const std::string &outsideName) {
+    VERIFY_INITIALIZED("MediumInterface");
+    if (!insideName.empty() || !outsideName.empty()) renderOptions->haveScatteringMedia = true;
+}
+void pbrtWorldBegin() {  // api.cpp:1118-1126
+    VERIFY_OPTIONS("WorldBegin");
+    currentApiState = APIState::WorldBlock;
+    for (int i = 0; i < MaxTransforms; ++i) curTransform[i] = Transform();
+    activeTransformBits = AllTransformsBits;
+    namedCoordinateSystems["world"] = curTransform;
+    // default material: matte (GraphicsState ctor, api.cpp:1596-1601 / :332-340)
+    ParamSet empty;
+    graphicsState.currentMaterial.name = "matte";
+    graphicsState.currentMaterial.params = empty;
+    graphicsState.currentMaterial.material = MakeMaterial("matte", empty, empty);
+}
+void pbrtAttributeBegin() {
+    VERIFY_WORLD("AttributeBegin");
+    pushedGraphicsStates.push_back(graphicsState);
+    pushedTransforms.push_back(curTransform);
+    pushedActiveTransformBits.push_back(activeTransformBits);
+}
+void pbrtAttributeEnd() {
+    VERIFY_WORLD("AttributeEnd");
+    if (!pushedGraphicsStates.size()) { Error("Unmatched pbrtAttributeEnd() encountered. Ignoring it."); return; }
+    graphicsState = std::move(pushedGraphicsStates.back()); pushedGraphicsStates.pop_back();
+    curTransform = pushedTransforms.back(); pushedTransforms.pop_back();
+    activeTransformBits = pushedActiveTransformBits.back(); pushedActiveTransformBits.pop_back();
+}
+void pbrtTransformBegin() {
+    VERIFY_WORLD("TransformBegin");
+    pushedTransforms.push_back(curTransform);
+    pushedActiveTransformBits.push_back(activeTransformBits);
+}
+void pbrtTransformEnd() {
+    VERIFY_WORLD("TransformEnd");
+    if (!pushedTransforms.size()) { Error("Unmatched pbrtTransformEnd() encountered. Ignoring it."); return; }
+    curTransform = pushedTransforms.back(); pushedTransforms.pop_back();
+    activeTransformBits = pushedActiveTransformBits.back(); pushedActiveTransformBits.pop_back();
+}
+void pbrtTexture(const std::string &name, const std::string &type, const std::string &texname, const ParamSet &params) {
+    VERIFY_WORLD("Texture");  // api.cpp:1183-1238
+    if (texname != "constant") {
+        Error("Texture \"%s\": class \"%s\" is outside this build's closed set (constant only); ignoring.", name.c_str(), texname.c_str());
+        return;
+    }
+    if (type == "float") {
+        if (graphicsState.floatTextures.count(name)) Warning("Texture \"%s\" being redefined", name.c_str());
+        graphicsState.floatTextures[name] = params.FindOneFloat("value", 1.f);
+    } else if (type == "color" || type == "spectrum") {
+        if (graphicsState.spectrumTextures.count(name)) Warning("Texture \"%s\" being redefined", name.c_str());
+        graphicsState.spectrumTextures[name] = params.FindOneSpectrum("value", RGB{{1.f, 1.f, 1.f}});
+    } else Error("Texture type \"%s\" unknown.", type.c_str());
+    params.ReportUnused();
+}
+void pbrtMaterial(const std::string &name, const ParamSet &params) {  // api.cpp:1240-1254
+    VERIFY_WORLD("Material");
+    ParamSet emptyParams;
+    graphicsState.currentMaterial.name = name;
+    graphicsState.currentMaterial.params = params;
+    graphicsState.currentMaterial.material = MakeMaterial(name, emptyParams, params);
+}
+void pbrtMakeNamedMaterial(const std::string &name, const ParamSet &params) {  // api.cpp:1256-1284
+    VERIFY_WORLD("MakeNamedMaterial");
+    ParamSet emptyParams;
+    std::string matName = params.FindOneString("type", "");
+    if (matName == "") { Error("No parameter string \"type\" found in MakeNamedMaterial"); return; }
+    if (graphicsState.namedMaterials.count(name)) Warning("Named material \"%s\" redefined.", name.c_str());
+    MaterialInstance mi;
+    mi.name = matName; mi.params = params; mi.material = MakeMaterial(matName, emptyParams, params);
+    graphicsState.namedMaterials[name] = mi;
+}
+void pbrtNamedMaterial(const std::string &name) {  // api.cpp:1286-1296
+    VERIFY_WORLD("NamedMaterial");
+    auto iter = graphicsState.namedMaterials.find(name);
+    if (iter == graphicsState.namedMaterials.end()) { Error("NamedMaterial \"%s\" unknown.", name.c_str()); return; }
+    graphicsState.currentMaterial = iter->second;
+}
+void pbrtLightSource(const std::string &name, const ParamSet &) {
+    VERIFY_WORLD("LightSource");
+    Error("LightSource \"%s\" is outside this build's closed set (diffuse area lights on triangles); ignoring.", name.c_str());
+}
+void pbrtAreaLightSource(const std::string &name, const ParamSet &params) {
+    VERIFY_WORLD("AreaLightSource");
+    graphicsState.areaLight = name;
+    graphicsState.areaLightParams = params;
+}
+
+// shapes/triangle.cpp:647-743 CreateTriangleMeshShape + :94-110 CreateTriangleMesh + :60-92 TriangleMesh ctor
+static std::shared_ptr<TriangleMesh> CreateTriangleMeshShape(const Transform &o2w, bool reverseOrientation, const ParamSet &params) {
+    const std::vector<int> *vi = params.FindInt("indices");
+    const std::vector<Float> *P = params.FindPoint3f("P");
+    const std::vector<Float> *uvs = params.FindPoint2f("uv");
+    if (!uvs) uvs = params.FindPoint2f("st");
+    if (!uvs) { uvs = params.FindFloat("uv"); if (!uvs) uvs = params.FindFloat("st"); }
+    if (!vi) { Error("Vertex indices \"indices\" not provided with triangle mesh shape"); return nullptr; }
+    if (!P) { Error("Vertex positions \"P\" not provided with triangle mesh shape"); return nullptr; }
+    int npi = (int)P->size() / 3, nvi = (int)vi->size();
+    if (uvs) {
+        int nuvi = (int)uvs->size() / 2;
+        if (nuvi < npi) { Error("Not enough of \"uv\"s for triangle mesh.  Expected %d, found %d.  Discarding.", npi, nuvi); uvs = nullptr; }
+        else if (nuvi > npi) Warning("More \"uv\"s provided than will be used for triangle mesh.  (%d expcted, %d found)", npi, nuvi);
+    }
+    const std::vector<Float> *S = params.FindVector3f("S");
+    if (S && (int)S->size() / 3 != npi) { Error("Number of \"S\"s for triangle mesh must match \"P\"s"); S = nullptr; }
+    const std::vector<Float> *N = params.FindNormal3f("N");
+    if (N && (int)N->size() / 3 != npi) { Error("Number of \"N\"s for triangle mesh must match \"P\"s"); N = nullptr; }
+    for (int i = 0; i < nvi; ++i)
+        if ((*vi)[i] >= npi) {
+            Error("trianglemesh has out of-bounds vertex index %d (%d \"P\" values were given", (*vi)[i], npi);
+            return nullptr;
+        }
+    if (!params.FindTexture("alpha").empty() || !params.FindTexture("shadowalpha").empty() ||
+        params.FindOneFloat("alpha", 1.f) == 0.f || params.FindOneFloat("shadowalpha", 1.f) == 0.f)
+        Error("Alpha-mask textures on triangle meshes are not supported by this build; ignoring.");
+    params.FindInt("faceIndices");
+    auto mesh = std::make_shared<TriangleMesh>();
+    mesh->nTriangles = nvi / 3;
+    mesh->nVertices = npi;
+    mesh->vertexIndices.assign(vi->begin(), vi->begin() + 3 * mesh->nTriangles);
+    mesh->reverseOrientation = reverseOrientation;
+    mesh->transformSwapsHandedness = o2w.SwapsHandedness();
+    mesh->p.resize(npi);
+    for (int i = 0; i < npi; ++i) mesh->p[i] = o2w.Pt(Point3f((*P)[3 * i], (*P)[3 * i + 1], (*P)[3 * i + 2]));
+    if (uvs) mesh->uv.assign(uvs->begin(), uvs->begin() + 2 * npi);
+    if (N) { mesh->n.resize(npi); for (int i = 0; i < npi; ++i) mesh->n[i] = o2w.Nrm(Normal3f((*N)[3 * i], (*N)[3 * i + 1], (*N)[3 * i + 2])); }
+    if (S) { mesh->s.resize(npi); for (int i = 0; i < npi; ++i) mesh->s[i] = o2w.Vec(Vector3f((*S)[3 * i], (*S)[3 * i + 1], (*S)[3 * i + 2])); }
+    return mesh;
+}
+
+void pbrtShape(const std::string &name, const ParamSet &params) {  // api.cpp:1329-1421
+    VERIFY_WORLD("Shape");
+    if (curTransform.IsAnimated())
+        Warning("Animated transformations are not supported by this build; using the start transform for shape \"%s\".", name.c_str());
+    std::shared_ptr<TriangleMesh> mesh;
+    if (name == "trianglemesh") mesh = CreateTriangleMeshShape(curTransform[0], graphicsState.reverseOrientation, params);
+    else Error("Shape \"%s\" is outside this build's closed set (trianglemesh); ignoring.", name.c_str());
+    if (!mesh || mesh->nTriangles == 0) return;
+    int mtl = GetMaterialForShape(params);
+    params.ReportUnused();
+    int firstLight = -1;
+    PgLight lightProto;
+    memset(&lightProto, 0, sizeof(lightProto));
+    if (graphicsState.areaLight != "") {
+        // MakeAreaLight (api.cpp:752-768) + CreateDiffuseAreaLight (diffuse.cpp:135-146)
+        if (graphicsState.areaLight == "area" || graphicsState.areaLight == "diffuse") {
+            const ParamSet &lp = graphicsState.areaLightParams;
+            RGB L = lp.FindOneSpectrum("L", RGB{{1.f, 1.f, 1.f}});
+            RGB sc = lp.FindOneSpectrum("scale", RGB{{1.f, 1.f, 1.f}});
+            lp.FindOneInt("samples", lp.FindOneInt("nsamples", 1));
+            lightProto.two_sided = lp.FindOneBool("twosided", false) ? 1 : 0;
+            for (int i = 0; i < 3; ++i) lightProto.L[i] = L.c[i] * sc.c[i];
+            lp.ReportUnused();
+            firstLight = (int)renderOptions->lights.size();
+        } else Warning("Area light \"%s\" unknown.", graphicsState.areaLight.c_str());
+    }
+    static size_t primSerial = 0;
+    for (int i = 0; i < mesh->nTriangles; ++i) {
+        GeometricPrimitive prim;
+        prim.shape.mesh = mesh;
+        prim.shape.triIndex = i;
+        prim.material = mtl;
+        if (firstLight >= 0) {
+            PgLight l = lightProto;
+            l.area = prim.shape.Area();
+            l.prim = -1;
+            prim.areaLight = (int)renderOptions->lights.size();
+            renderOptions->lights.push_back(l);
+        }
+        renderOptions->primitives.push_back(prim);
+    }
+    (void)primSerial;
+}
+void pbrtReverseOrientation() { VERIFY_WORLD("ReverseOrientation"); graphicsState.reverseOrientation = !graphicsState.reverseOrientation; }
+void pbrtObjectBegin(const std::string &name) {
+    VERIFY_WORLD("ObjectBegin");
+    pbrtAttributeBegin();
+    Error("ObjectBegin \"%s\": object instancing is outside this build's scope; its shapes are added to the scene directly.", name.c_str());
+}
+void pbrtObjectEnd() { VERIFY_WORLD("ObjectEnd"); pbrtAttributeEnd(); }
+void pbrtObjectInstance(const std::string &name) {
+    VERIFY_WORLD("ObjectInstance");
+    Error("ObjectInstance \"%s\": object instancing is outside this build's scope; ignoring.", name.c_str());
+}
+
+// RenderOptions::MakeIntegrator / MakeScene / MakeCamera (api.cpp:1651-1727)
+static GpuPathIntegrator *MakeIntegrator() {
+    RenderOptions &ro = *renderOptions;
+    if (ro.FilterName != "box")
+        Error("PixelFilter \"%s\" is outside this build's closed set (box); using box.", ro.FilterName.c_str());
+    Float xw = ro.FilterName == "box" ? ro.FilterParams.FindOneFloat("xwidth", 0.5f) : 0.5f;  // filters/box.cpp:44-48
+    Float yw = ro.FilterName == "box" ? ro.FilterParams.FindOneFloat("ywidth", 0.5f) : 0.5f;
+    ro.FilterParams.ReportUnused();
+    if (ro.FilmName != "image") { Error("Film \"%s\" unknown.", ro.FilmName.c_str()); return nullptr; }
+    Film *film = CreateFilm(ro.FilmParams, xw, yw);
+    ro.FilmParams.ReportUnused();
+    if (ro.CameraName != "perspective") {
+        Error("Camera \"%s\" is outside this build's closed set (perspective).", ro.CameraName.c_str());
+        delete film;
+        return nullptr;
+    }
+    if (ro.CameraToWorld.IsAnimated()) Warning("Animated camera transformations are not supported by this build; using the start transform.");
+    std::shared_ptr<PerspectiveCamera> camera(CreatePerspectiveCamera(ro.CameraParams, ro.CameraToWorld[0], film));
+    ro.CameraParams.ReportUnused();
+    if (ro.SamplerName != "halton")
+        Error("Sampler \"%s\" is outside this build's closed set (halton); using halton with the same \"pixelsamples\".", ro.SamplerName.c_str());
+    int sb[4];
+    film->GetSampleBounds(sb);
+    std::shared_ptr<HaltonSampler> sampler(CreateHaltonSampler(ro.SamplerParams, sb));
+    ro.SamplerParams.ReportUnused();
+    if (ro.IntegratorName != "path") {
+        Error("Integrator \"%s\" is outside this build's closed set (path).", ro.IntegratorName.c_str());
+        return nullptr;
+    }
+    GpuPathIntegrator *integrator = CreatePathIntegrator(ro.IntegratorParams, sampler, camera);
+    if (ro.haveScatteringMedia)
+        Warning("Scene has scattering media but \"path\" integrator doesn't support volume scattering. Consider using \"volpath\".");
+    ro.IntegratorParams.ReportUnused();
+    if (ro.lights.empty())
+        Warning("No light sources defined in scene; rendering a black image.");
+    return integrator;
+}
+static Scene *MakeScene() {
+    RenderOptions &ro = *renderOptions;
+    Scene *scene = new Scene;
+    if (ro.AcceleratorName != "bvh")
+        Warning("Accelerator \"%s\" is outside this build's closed set; using \"bvh\".", ro.AcceleratorName.c_str());
+    scene->aggregate = CreateBVHAccelerator(std::move(ro.primitives), ro.AcceleratorName == "bvh" ? ro.AcceleratorParams : ParamSet());
+    ro.AcceleratorParams.ReportUnused();
+    scene->lights = ro.lights;
+    scene->materials = ro.materials;
+    scene->worldBound = scene->aggregate->WorldBound();
+    // resolve each light's emitting triangle to its index in BVH order
+    const auto &prims = scene->aggregate->primitives;
+    for (size_t i = 0; i < prims.size(); ++i)
+        if (prims[i].areaLight >= 0) scene->lights[prims[i].areaLight].prim = (int)i;
+    ro.primitives.clear();
+    ro.lights.clear();
+    return scene;
+}
+
+void pbrtWorldEnd() {  // api.cpp:1590-1644
+    VERIFY_WORLD("WorldEnd");
+    while (pushedGraphicsStates.size()) { Warning("Missing end to pbrtAttributeBegin()"); pushedGraphicsStates.pop_back(); pushedTransforms.pop_back(); }
+    while (pushedTransforms.size()) { Warning("Missing end to pbrtTransformBegin()"); pushedTransforms.pop_back(); }
+    std::unique_ptr<GpuPathIntegrator> integrator(MakeIntegrator());
+    std::unique_ptr<Scene> scene(MakeScene());
+    if (scene && integrator) {
+        if (PbrtOptions.loadOnly) {
+            lastLoadedScene.reset(new LoadedScene);
+            lastLoadedScene->scene = std::move(scene);
+            lastLoadedScene->integrator = std::move(integrator);
+        } else
+            integrator->Render(*scene);
+    }
+    graphicsState = GraphicsState();
+    currentApiState = APIState::OptionsBlock;
+    for (int i = 0; i < MaxTransforms; ++i) curTransform[i] = Transform();
+    activeTransformBits = AllTransformsBits;
+    namedCoordinateSystems.clear();
+    renderOptions->materials.clear();
+}
+}  // namespace pbrt

@@ -1,0 +1,191 @@
+// BVHAccel construction on the host (the build stays on the CPU; SURVEY.md
+// section 8 row a7).  Restates src/accelerators/bvh.cpp:183-402 (recursive SAH /
+// Middle / EqualCounts build with 12 buckets) and :640-658 (flattenBVHTree)
+// with the same float arithmetic and the same std::partition/std::nth_element
+// calls, so the node array and leaf contents match the reference's tree.
+#include "scene.h"
+#include "error.h"
+
+namespace pbrt {
+
+Bounds3f Triangle::WorldBound() const {  // triangle.cpp:180-186
+    const int *vi = v();
+    return Union(Bounds3f(mesh->p[vi[0]], mesh->p[vi[1]]), mesh->p[vi[2]]);
+}
+Float Triangle::Area() const {  // triangle.cpp:574-580; 0.5 is a double literal there
+    const int *vi = v();
+    const Point3f &p0 = mesh->p[vi[0]], &p1 = mesh->p[vi[1]], &p2 = mesh->p[vi[2]];
+    return 0.5 * Cross(p1 - p0, p2 - p0).Length();
+}
+
+struct BVHAccel::PrimInfo {  // BVHPrimitiveInfo, bvh.cpp:49-59
+    PrimInfo() {}
+    PrimInfo(size_t primitiveNumber, const Bounds3f &bounds)
+        : primitiveNumber(primitiveNumber), bounds(bounds), centroid(.5f * bounds.pMin + .5f * bounds.pMax) {}
+    size_t primitiveNumber;
+    Bounds3f bounds;
+    Point3f centroid;
+};
+struct BVHAccel::BuildNode {  // BVHBuildNode, bvh.cpp:61-83
+    void InitLeaf(int first, int n, const Bounds3f &b) {
+        firstPrimOffset = first; nPrimitives = n; bounds = b; children[0] = children[1] = nullptr;
+    }
+    void InitInterior(int axis, BuildNode *c0, BuildNode *c1) {
+        children[0] = c0; children[1] = c1;
+        bounds = Union(c0->bounds, c1->bounds);
+        splitAxis = axis; nPrimitives = 0;
+    }
+    Bounds3f bounds;
+    BuildNode *children[2];
+    int splitAxis, firstPrimOffset, nPrimitives;
+};
+
+BVHAccel::BuildNode *BVHAccel::allocNode() {
+    const size_t chunk = 1 << 16;
+    if (arena.empty() || arenaUsed == chunk) { arena.emplace_back(new BuildNode[chunk]); arenaUsed = 0; }
+    return &arena.back()[arenaUsed++];
+}
+
+BVHAccel::BVHAccel(std::vector<GeometricPrimitive> p, int maxPrims, SplitMethod sm)
+    : primitives(std::move(p)), maxPrimsInNode(std::min(255, maxPrims)), splitMethod(sm) {
+    if (primitives.empty()) return;
+    std::vector<PrimInfo> primitiveInfo(primitives.size());
+    for (size_t i = 0; i < primitives.size(); ++i) primitiveInfo[i] = {i, primitives[i].shape.WorldBound()};
+    int totalNodes = 0;
+    std::vector<GeometricPrimitive> orderedPrims;
+    orderedPrims.reserve(primitives.size());
+    BuildNode *root = recursiveBuild(primitiveInfo, 0, (int)primitives.size(), &totalNodes, orderedPrims);
+    primitives.swap(orderedPrims);
+    nodes.resize(totalNodes);
+    int offset = 0;
+    flattenBVHTree(root, &offset);
+    arena.clear();
+}
+
+Bounds3f BVHAccel::WorldBound() const {  // bvh.cpp:228-230
+    if (nodes.empty()) return Bounds3f();
+    Bounds3f b;
+    b.pMin = Point3f(nodes[0].bmin[0], nodes[0].bmin[1], nodes[0].bmin[2]);
+    b.pMax = Point3f(nodes[0].bmax[0], nodes[0].bmax[1], nodes[0].bmax[2]);
+    return b;
+}
+
+struct BucketInfo { int count = 0; Bounds3f bounds; };
+
+BVHAccel::BuildNode *BVHAccel::recursiveBuild(std::vector<PrimInfo> &primitiveInfo, int start, int end, int *totalNodes,
+                                              std::vector<GeometricPrimitive> &orderedPrims) {
+    BuildNode *node = allocNode();
+    (*totalNodes)++;
+    Bounds3f bounds;
+    for (int i = start; i < end; ++i) bounds = Union(bounds, primitiveInfo[i].bounds);
+    int nPrimitives = end - start;
+    auto makeLeaf = [&]() {
+        int firstPrimOffset = (int)orderedPrims.size();
+        for (int i = start; i < end; ++i) orderedPrims.push_back(primitives[primitiveInfo[i].primitiveNumber]);
+        node->InitLeaf(firstPrimOffset, nPrimitives, bounds);
+        return node;
+    };
+    if (nPrimitives == 1) return makeLeaf();
+    Bounds3f centroidBounds;
+    for (int i = start; i < end; ++i) centroidBounds = Union(centroidBounds, primitiveInfo[i].centroid);
+    int dim = centroidBounds.MaximumExtent();
+    int mid = (start + end) / 2;
+    if (centroidBounds.pMax[dim] == centroidBounds.pMin[dim]) return makeLeaf();
+
+    auto equalCounts = [&]() {
+        mid = (start + end) / 2;
+        std::nth_element(&primitiveInfo[start], &primitiveInfo[mid], &primitiveInfo[end - 1] + 1,
+                         [dim](const PrimInfo &a, const PrimInfo &b) { return a.centroid[dim] < b.centroid[dim]; });
+    };
+    switch (splitMethod) {
+    case SplitMethod::Middle: {
+        Float pmid = (centroidBounds.pMin[dim] + centroidBounds.pMax[dim]) / 2;
+        PrimInfo *midPtr = std::partition(&primitiveInfo[start], &primitiveInfo[end - 1] + 1,
+                                          [dim, pmid](const PrimInfo &pi) { return pi.centroid[dim] < pmid; });
+        mid = int(midPtr - &primitiveInfo[0]);
+        if (mid != start && mid != end) break;
+        equalCounts();  // fall through to EqualCounts (bvh.cpp:292-296)
+        break;
+    }
+    case SplitMethod::EqualCounts: equalCounts(); break;
+    case SplitMethod::SAH:
+    default: {
+        if (nPrimitives <= 2) { equalCounts(); break; }
+        constexpr int nBuckets = 12;
+        BucketInfo buckets[nBuckets];
+        for (int i = start; i < end; ++i) {
+            int b = nBuckets * centroidBounds.Offset(primitiveInfo[i].centroid)[dim];
+            if (b == nBuckets) b = nBuckets - 1;
+            buckets[b].count++;
+            buckets[b].bounds = Union(buckets[b].bounds, primitiveInfo[i].bounds);
+        }
+        Float cost[nBuckets - 1];
+        for (int i = 0; i < nBuckets - 1; ++i) {
+            Bounds3f b0, b1;
+            int count0 = 0, count1 = 0;
+            for (int j = 0; j <= i; ++j) { b0 = Union(b0, buckets[j].bounds); count0 += buckets[j].count; }
+            for (int j = i + 1; j < nBuckets; ++j) { b1 = Union(b1, buckets[j].bounds); count1 += buckets[j].count; }
+            cost[i] = 1 + (count0 * b0.SurfaceArea() + count1 * b1.SurfaceArea()) / bounds.SurfaceArea();
+        }
+        Float minCost = cost[0];
+        int minCostSplitBucket = 0;
+        for (int i = 1; i < nBuckets - 1; ++i)
+            if (cost[i] < minCost) { minCost = cost[i]; minCostSplitBucket = i; }
+        Float leafCost = nPrimitives;
+        if (nPrimitives > maxPrimsInNode || minCost < leafCost) {
+            PrimInfo *pmid = std::partition(&primitiveInfo[start], &primitiveInfo[end - 1] + 1, [=](const PrimInfo &pi) {
+                int b = nBuckets * centroidBounds.Offset(pi.centroid)[dim];
+                if (b == nBuckets) b = nBuckets - 1;
+                return b <= minCostSplitBucket;
+            });
+            mid = int(pmid - &primitiveInfo[0]);
+        } else
+            return makeLeaf();
+        break;
+    }
+    }
+    // The reference passes both recursive calls as function arguments
+    // (bvh.cpp:393-397); their evaluation order only permutes whole leaf
+    // blocks inside orderedPrims, never a leaf's contents or the tree shape.
+    BuildNode *c0 = recursiveBuild(primitiveInfo, start, mid, totalNodes, orderedPrims);
+    BuildNode *c1 = recursiveBuild(primitiveInfo, mid, end, totalNodes, orderedPrims);
+    node->InitInterior(dim, c0, c1);
+    return node;
+}
+
+int BVHAccel::flattenBVHTree(BuildNode *node, int *offset) {  // bvh.cpp:640-658
+    PgBVHNode *linearNode = &nodes[*offset];
+    for (int i = 0; i < 3; ++i) { linearNode->bmin[i] = node->bounds.pMin[i]; linearNode->bmax[i] = node->bounds.pMax[i]; }
+    linearNode->pad = 0;
+    int myOffset = (*offset)++;
+    if (node->nPrimitives > 0) {
+        linearNode->offset = node->firstPrimOffset;
+        linearNode->nprims = (uint16_t)node->nPrimitives;
+        linearNode->axis = 0;
+    } else {
+        linearNode->axis = (uint8_t)node->splitAxis;
+        linearNode->nprims = 0;
+        flattenBVHTree(node->children[0], offset);
+        linearNode->offset = flattenBVHTree(node->children[1], offset);
+    }
+    return myOffset;
+}
+
+std::shared_ptr<BVHAccel> CreateBVHAccelerator(std::vector<GeometricPrimitive> prims, const ParamSet &ps) {
+    std::string splitMethodName = ps.FindOneString("splitmethod", "sah");
+    BVHAccel::SplitMethod splitMethod;
+    if (splitMethodName == "sah") splitMethod = BVHAccel::SplitMethod::SAH;
+    else if (splitMethodName == "hlbvh") {
+        Warning("BVH split method \"hlbvh\" is not implemented by this build; using \"sah\" "
+                "(intersection results are independent of the tree shape).");
+        splitMethod = BVHAccel::SplitMethod::SAH;
+    } else if (splitMethodName == "middle") splitMethod = BVHAccel::SplitMethod::Middle;
+    else if (splitMethodName == "equal") splitMethod = BVHAccel::SplitMethod::EqualCounts;
+    else {
+        Warning("BVH split method \"%s\" unknown.  Using \"sah\".", splitMethodName.c_str());
+        splitMethod = BVHAccel::SplitMethod::SAH;
+    }
+    int maxPrimsInNode = ps.FindOneInt("maxnodeprims", 4);
+    return std::make_shared<BVHAccel>(std::move(prims), maxPrimsInNode, splitMethod);
+}
+}  // namespace pbrt

@@ -1,0 +1,63 @@
+// C entry points of libpbrt_host.so (include/pbrt_host.h).
+#include "../../include/pbrt_host.h"
+#include "api.h"
+#include "error.h"
+#include "scene.h"
+
+using namespace pbrt;
+struct PbrtHostScene {
+    std::unique_ptr<LoadedScene> loaded;
+    FlatScene flat;
+};
+
+static PbrtHostScene *finishLoad() {
+    if (!lastLoadedScene) return nullptr;
+    PbrtHostScene *s = new PbrtHostScene;
+    s->loaded = std::move(lastLoadedScene);
+    s->loaded->integrator->Flatten(*s->loaded->scene, &s->flat);
+    return s;
+}
+static Options makeOptions(int quick, const float *crop) {
+    Options opt;
+    opt.quickRender = quick != 0;
+    opt.loadOnly = true;
+    if (crop) { opt.cropWindow[0][0] = crop[0]; opt.cropWindow[0][1] = crop[1]; opt.cropWindow[1][0] = crop[2]; opt.cropWindow[1][1] = crop[3]; }
+    return opt;
+}
+extern "C" {
+PbrtHostScene *pbrt_host_load_file(const char *filename, int quick, const float *crop) {
+    lastLoadedScene.reset();
+    pbrtInit(makeOptions(quick, crop));
+    pbrtParseFile(filename);
+    pbrtCleanup();
+    return finishLoad();
+}
+PbrtHostScene *pbrt_host_load_string(const char *text, int quick, const float *crop) {
+    lastLoadedScene.reset();
+    pbrtInit(makeOptions(quick, crop));
+    pbrtParseString(text);
+    pbrtCleanup();
+    return finishLoad();
+}
+void pbrt_host_free(PbrtHostScene *s) { delete s; }
+const PgSceneDesc *pbrt_host_scene_desc(PbrtHostScene *s) { return &s->flat.desc; }
+void pbrt_host_render_desc(PbrtHostScene *s, PgRenderDesc *out) { s->loaded->integrator->FillRenderDesc(out); }
+void pbrt_host_film_size(PbrtHostScene *s, int *w, int *h) {
+    const Film &f = *s->loaded->integrator->camera->film;
+    *w = f.croppedPixelBounds[2] - f.croppedPixelBounds[0];
+    *h = f.croppedPixelBounds[3] - f.croppedPixelBounds[1];
+}
+void pbrt_host_film_clear(PbrtHostScene *s) { s->loaded->integrator->camera->film->Clear(); }
+void pbrt_host_film_merge(PbrtHostScene *s, const PgRenderDesc *rd, const PgFilmPixel *film, const PgStraySample *strays, int n) {
+    s->loaded->integrator->camera->film->MergeShard(*rd, film, strays, n);
+}
+void pbrt_host_film_image(PbrtHostScene *s, float *rgb) {
+    std::vector<Float> img;
+    s->loaded->integrator->camera->film->ComputeImage(&img);
+    std::copy(img.begin(), img.end(), rgb);
+}
+int pbrt_host_write_pfm(const char *filename, const float *rgb, int width, int height) {
+    return WriteImagePFM(filename, rgb, width, height) ? 0 : -1;
+}
+int pbrt_host_error_count(void) { return ErrorCount(); }
+}

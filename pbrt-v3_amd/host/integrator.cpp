@@ -1,0 +1,326 @@
+// Camera / sampler / integrator factories and the host half of
+// Integrator::Render for the MI355X path.
+//   CreatePerspectiveCamera  cameras/perspective.cpp:215-273, camera.h:87-108
+//   CreateHaltonSampler      samplers/halton.cpp:65-92,133-139
+//   Halton permutations      lowdiscrepancy.cpp:2490-2504, rng.h:61-144, sampling.h:151-157
+//   CreatePathIntegrator     integrators/path.cpp:190-213
+//   Render                   core/integrator.cpp:228-339 (tile loop -> device)
+#include <dlfcn.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include "api.h"
+#include "error.h"
+#include "scene.h"
+
+namespace pbrt {
+
+PerspectiveCamera *CreatePerspectiveCamera(const ParamSet &params, const Transform &cam2world, Film *film) {
+    Float shutteropen = params.FindOneFloat("shutteropen", 0.f);
+    Float shutterclose = params.FindOneFloat("shutterclose", 1.f);
+    if (shutterclose < shutteropen) {
+        Warning("Shutter close time [%f] < shutter open [%f].  Swapping them.", shutterclose, shutteropen);
+        std::swap(shutterclose, shutteropen);
+    }
+    Float lensradius = params.FindOneFloat("lensradius", 0.f);
+    Float focaldistance = params.FindOneFloat("focaldistance", 1e6);
+    Float frame = params.FindOneFloat("frameaspectratio", Float(film->fullResolution[0]) / Float(film->fullResolution[1]));
+    Float sxmin, sxmax, symin, symax;
+    if (frame > 1.f) { sxmin = -frame; sxmax = frame; symin = -1.f; symax = 1.f; }
+    else { sxmin = -1.f; sxmax = 1.f; symin = -1.f / frame; symax = 1.f / frame; }
+    const std::vector<Float> *sw = params.FindFloat("screenwindow");
+    if (sw) {
+        if (sw->size() == 4) { sxmin = (*sw)[0]; sxmax = (*sw)[1]; symin = (*sw)[2]; symax = (*sw)[3]; }
+        else Error("\"screenwindow\" should have four values");
+    }
+    Float fov = params.FindOneFloat("fov", 90.);
+    Float halffov = params.FindOneFloat("halffov", -1.f);
+    if (halffov > 0.f) fov = 2.f * halffov;
+    PerspectiveCamera *cam = new PerspectiveCamera;
+    cam->film.reset(film);
+    cam->CameraToWorld = cam2world;
+    cam->lensRadius = lensradius; cam->focalDistance = focaldistance;
+    cam->shutterOpen = shutteropen; cam->shutterClose = shutterclose;
+    // ProjectiveCamera ctor, camera.h:98-107
+    Transform CameraToScreen = Perspective(fov, 1e-2f, 1000.f);
+    Transform ScreenToRaster = Scale(film->fullResolution[0], film->fullResolution[1], 1) *
+                               Scale(1 / (sxmax - sxmin), 1 / (symin - symax), 1) *
+                               Translate(Vector3f(-sxmin, -symax, 0));
+    Transform RasterToScreen = Inverse(ScreenToRaster);
+    cam->RasterToCamera = Inverse(CameraToScreen) * RasterToScreen;
+    return cam;
+}
+
+// ---- Halton ---------------------------------------------------------------
+static void extendedGCD(uint64_t a, uint64_t b, int64_t *x, int64_t *y) {  // halton.cpp:52-62
+    if (b == 0) { *x = 1; *y = 0; return; }
+    int64_t d = a / b, xp, yp;
+    extendedGCD(b, a % b, &xp, &yp);
+    *x = yp;
+    *y = xp - (d * yp);
+}
+static uint64_t multiplicativeInverse(int64_t a, int64_t n) {  // halton.cpp:46-50; Mod() from pbrt.h
+    int64_t x, y;
+    extendedGCD(a, n, &x, &y);
+    int64_t r = x - (x / n) * n;
+    return (uint64_t)((r < 0) ? r + n : r);
+}
+HaltonSampler *CreateHaltonSampler(const ParamSet &params, const int sb[4]) {
+    int nsamp = params.FindOneInt("pixelsamples", 16);
+    if (PbrtOptions.quickRender) nsamp = 1;
+    bool sampleAtCenter = params.FindOneBool("samplepixelcenter", false);
+    HaltonSampler *s = new HaltonSampler;
+    s->samplesPerPixel = nsamp;
+    s->sampleAtPixelCenter = sampleAtCenter;
+    const int kMaxResolution = 128;
+    int res[2] = {sb[2] - sb[0], sb[3] - sb[1]};
+    for (int i = 0; i < 2; ++i) {
+        int base = (i == 0) ? 2 : 3;
+        int scale = 1, exp = 0;
+        while (scale < std::min(res[i], kMaxResolution)) { scale *= base; ++exp; }
+        s->baseScales[i] = scale;
+        s->baseExponents[i] = exp;
+    }
+    s->sampleStride = s->baseScales[0] * s->baseScales[1];
+    s->multInverse[0] = (int)multiplicativeInverse(s->baseScales[1], s->baseScales[0]);
+    s->multInverse[1] = (int)multiplicativeInverse(s->baseScales[0], s->baseScales[1]);
+    return s;
+}
+
+namespace {
+struct RNG {  // PCG32, rng.h:61-144
+    uint64_t state = 0x853c49e6748fea9bULL, inc = 0xda3e39cb94b95bdbULL;
+    uint32_t UniformUInt32() {
+        uint64_t oldstate = state;
+        state = oldstate * 0x5851f42d4c957f2dULL + inc;
+        uint32_t xorshifted = (uint32_t)(((oldstate >> 18u) ^ oldstate) >> 27u);
+        uint32_t rot = (uint32_t)(oldstate >> 59u);
+        return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+    }
+    uint32_t UniformUInt32(uint32_t b) {
+        uint32_t threshold = (~b + 1u) % b;
+        while (true) { uint32_t r = UniformUInt32(); if (r >= threshold) return r % b; }
+    }
+};
+}  // namespace
+void ComputeRadicalInversePermutations(int nDims, std::vector<uint16_t> *perms, std::vector<int32_t> *sums) {
+    const int PrimeTableSize = 1000;  // lowdiscrepancy.h:52
+    if (nDims > PrimeTableSize) nDims = PrimeTableSize;
+    // first 1000 primes (lowdiscrepancy.cpp:40-122 tabulates them)
+    std::vector<int> primes;
+    for (int c = 2; (int)primes.size() < PrimeTableSize; ++c) {
+        bool isPrime = true;
+        for (int p : primes) { if (p * p > c) break; if (c % p == 0) { isPrime = false; break; } }
+        if (isPrime) primes.push_back(c);
+    }
+    // The RNG stream runs through all bases in order, so bases < nDims get the
+    // same permutations as in the full 1000-base table.
+    RNG rng;
+    perms->clear(); sums->clear();
+    int sum = 0;
+    for (int i = 0; i < nDims; ++i) {
+        sums->push_back(sum);
+        size_t base = perms->size();
+        for (int j = 0; j < primes[i]; ++j) perms->push_back((uint16_t)j);
+        uint16_t *p = &(*perms)[base];
+        int count = primes[i];
+        for (int k = 0; k < count; ++k) {  // Shuffle(p, count, 1, rng), sampling.h:151-157
+            int other = k + rng.UniformUInt32(count - k);
+            std::swap(p[k], p[other]);
+        }
+        sum += primes[i];
+    }
+    sums->push_back(sum);
+}
+
+// ---- integrator -------------------------------------------------------------
+GpuPathIntegrator::GpuPathIntegrator(int maxDepth, std::shared_ptr<PerspectiveCamera> camera,
+                                     std::shared_ptr<HaltonSampler> sampler, const int pb[4], Float rrThreshold,
+                                     const std::string &lightSampleStrategy)
+    : camera(camera), sampler(sampler), maxDepth(maxDepth), rrThreshold(rrThreshold), lightSampleStrategy(lightSampleStrategy) {
+    for (int i = 0; i < 4; ++i) pixelBounds[i] = pb[i];
+}
+GpuPathIntegrator *CreatePathIntegrator(const ParamSet &params, std::shared_ptr<HaltonSampler> sampler,
+                                        std::shared_ptr<PerspectiveCamera> camera) {
+    int maxDepth = params.FindOneInt("maxdepth", 5);
+    int pixelBounds[4];
+    camera->film->GetSampleBounds(pixelBounds);
+    const std::vector<int> *pb = params.FindInt("pixelbounds");
+    if (pb) {
+        if (pb->size() != 4) Error("Expected four values for \"pixelbounds\" parameter. Got %d.", (int)pb->size());
+        else {
+            int b[4] = {(*pb)[0], (*pb)[2], (*pb)[1], (*pb)[3]};
+            pixelBounds[0] = std::max(pixelBounds[0], std::min(b[0], b[2]));
+            pixelBounds[1] = std::max(pixelBounds[1], std::min(b[1], b[3]));
+            pixelBounds[2] = std::min(pixelBounds[2], std::max(b[0], b[2]));
+            pixelBounds[3] = std::min(pixelBounds[3], std::max(b[1], b[3]));
+            if ((pixelBounds[2] - pixelBounds[0]) * (pixelBounds[3] - pixelBounds[1]) == 0) Error("Degenerate \"pixelbounds\" specified.");
+        }
+    }
+    Float rrThreshold = params.FindOneFloat("rrthreshold", 1.);
+    std::string lightStrategy = params.FindOneString("lightsamplestrategy", "spatial");
+    return new GpuPathIntegrator(maxDepth, camera, sampler, pixelBounds, rrThreshold, lightStrategy);
+}
+
+void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
+    const BVHAccel &bvh = *scene.aggregate;
+    flat->nodes = bvh.nodes;
+    size_t nTris = bvh.primitives.size();
+    flat->indices.resize(3 * nTris);
+    flat->triFlags.resize(nTris);
+    flat->triMaterial.resize(nTris);
+    flat->triLight.resize(nTris);
+    // concatenate the meshes' vertex arrays in first-use order
+    std::map<const TriangleMesh *, int> meshBase;
+    bool anyN = false, anyUV = false, anyS = false;
+    for (const auto &prim : bvh.primitives) {
+        const TriangleMesh *m = prim.shape.mesh.get();
+        if (meshBase.count(m)) continue;
+        meshBase[m] = (int)(flat->P.size() / 3);
+        for (const Point3f &p : m->p) { flat->P.push_back(p.x); flat->P.push_back(p.y); flat->P.push_back(p.z); }
+        anyN |= !m->n.empty(); anyUV |= !m->uv.empty(); anyS |= !m->s.empty();
+    }
+    size_t nVerts = flat->P.size() / 3;
+    if (anyN) flat->N.assign(3 * nVerts, 0.f);
+    if (anyUV) flat->UV.assign(2 * nVerts, 0.f);
+    if (anyS) flat->S.assign(3 * nVerts, 0.f);
+    for (auto &kv : meshBase) {
+        const TriangleMesh *m = kv.first;
+        size_t b = kv.second;
+        for (size_t i = 0; i < m->n.size(); ++i) { flat->N[3 * (b + i)] = m->n[i].x; flat->N[3 * (b + i) + 1] = m->n[i].y; flat->N[3 * (b + i) + 2] = m->n[i].z; }
+        for (size_t i = 0; i < m->s.size(); ++i) { flat->S[3 * (b + i)] = m->s[i].x; flat->S[3 * (b + i) + 1] = m->s[i].y; flat->S[3 * (b + i) + 2] = m->s[i].z; }
+        for (size_t i = 0; i < m->uv.size(); ++i) flat->UV[2 * b + i] = m->uv[i];
+    }
+    for (size_t k = 0; k < nTris; ++k) {
+        const GeometricPrimitive &prim = bvh.primitives[k];
+        const TriangleMesh *m = prim.shape.mesh.get();
+        int base = meshBase[m];
+        const int *v = prim.shape.v();
+        for (int j = 0; j < 3; ++j) flat->indices[3 * k + j] = base + v[j];
+        uint32_t f = 0;
+        if (m->reverseOrientation ^ m->transformSwapsHandedness) f |= PG_TRI_FLIP_NORMAL;
+        if (m->reverseOrientation) f |= PG_TRI_REVERSE_ORIENTATION;
+        if (!m->n.empty()) f |= PG_TRI_HAS_N;
+        if (!m->uv.empty()) f |= PG_TRI_HAS_UV;
+        if (!m->s.empty()) f |= PG_TRI_HAS_S;
+        flat->triFlags[k] = f;
+        flat->triMaterial[k] = prim.material;
+        flat->triLight[k] = prim.areaLight;
+    }
+    flat->materials = scene.materials;
+    flat->lights = scene.lights;
+    // dimensions a path can consume: 5 camera + per bounce (1+2+2 direct, 2 bsdf, 1 rr); 1000 max (halton.h:71-76)
+    int nDims = std::min(1000, 5 + 8 * (maxDepth + 2));
+    ComputeRadicalInversePermutations(nDims, &flat->perms, &flat->permSums);
+    PgSceneDesc &d = flat->desc;
+    memset(&d, 0, sizeof(d));
+    d.abi_version = PG_ABI_VERSION;
+    d.n_nodes = (int)flat->nodes.size(); d.nodes = flat->nodes.data();
+    d.n_tris = (int)nTris; d.indices = flat->indices.data(); d.tri_flags = flat->triFlags.data();
+    d.tri_material = flat->triMaterial.data(); d.tri_light = flat->triLight.data();
+    d.n_verts = (int)nVerts; d.P = flat->P.data();
+    d.N = anyN ? flat->N.data() : nullptr; d.UV = anyUV ? flat->UV.data() : nullptr; d.S = anyS ? flat->S.data() : nullptr;
+    d.n_materials = (int)flat->materials.size(); d.materials = flat->materials.data();
+    d.n_lights = (int)flat->lights.size(); d.lights = flat->lights.data();
+    // CreateLightSampleDistribution, lightdistrib.cpp:48-66
+    if (lightSampleStrategy == "uniform" || flat->lights.size() == 1) d.light_strategy = PG_LIGHTS_UNIFORM;
+    else if (lightSampleStrategy == "power") d.light_strategy = PG_LIGHTS_POWER;
+    else if (lightSampleStrategy == "spatial") d.light_strategy = PG_LIGHTS_SPATIAL;
+    else {
+        Error("Light sample distribution type \"%s\" unknown. Using \"spatial\".", lightSampleStrategy.c_str());
+        d.light_strategy = PG_LIGHTS_SPATIAL;
+    }
+    d.n_perm_dims = (int)flat->permSums.size() - 1; d.perms = flat->perms.data(); d.perm_sums = flat->permSums.data();
+}
+
+void GpuPathIntegrator::FillRenderDesc(PgRenderDesc *rd) const {
+    memset(rd, 0, sizeof(*rd));
+    rd->abi_version = PG_ABI_VERSION;
+    const Film &film = *camera->film;
+    memcpy(rd->raster_to_camera, camera->RasterToCamera.GetMatrix().m, 16 * sizeof(float));
+    memcpy(rd->camera_to_world, camera->CameraToWorld.GetMatrix().m, 16 * sizeof(float));
+    rd->lens_radius = camera->lensRadius; rd->focal_distance = camera->focalDistance;
+    rd->shutter_open = camera->shutterOpen; rd->shutter_close = camera->shutterClose;
+    rd->full_res[0] = film.fullResolution[0]; rd->full_res[1] = film.fullResolution[1];
+    for (int i = 0; i < 4; ++i) rd->cropped_pixel_bounds[i] = film.croppedPixelBounds[i];
+    film.GetSampleBounds(rd->sample_bounds);
+    rd->filter_radius[0] = film.filterRadius[0]; rd->filter_radius[1] = film.filterRadius[1];
+    rd->film_scale = film.scale; rd->max_sample_luminance = film.maxSampleLuminance;
+    rd->spp = sampler->samplesPerPixel;
+    for (int i = 0; i < 2; ++i) {
+        rd->base_scales[i] = sampler->baseScales[i]; rd->base_exponents[i] = sampler->baseExponents[i];
+        rd->mult_inverse[i] = sampler->multInverse[i];
+    }
+    rd->sample_stride = sampler->sampleStride;
+    rd->sample_at_pixel_center = sampler->sampleAtPixelCenter ? 1 : 0;
+    rd->max_depth = maxDepth; rd->rr_threshold = rrThreshold;
+    for (int i = 0; i < 4; ++i) rd->pixel_bounds[i] = pixelBounds[i];
+    rd->tile_first = 0; rd->tile_step = 1;
+}
+
+// The C ABI is bound at run time, the way a pbrt maintainer's plugin loader
+// would bind it; a missing library is a hard error, never a CPU fallback.
+namespace {
+struct GpuApi {
+    void *lib = nullptr;
+    decltype(&pg_set_device) set_device = nullptr;
+    decltype(&pg_last_error) last_error = nullptr;
+    decltype(&pg_scene_create) scene_create = nullptr;
+    decltype(&pg_scene_destroy) scene_destroy = nullptr;
+    decltype(&pg_render_tile_count) render_tile_count = nullptr;
+    decltype(&pg_render) render = nullptr;
+    decltype(&pg_counters) counters = nullptr;
+    bool Load() {
+        if (lib) return true;
+        std::string path;
+        if (const char *e = getenv("PBRT_GPU_LIB")) path = e;
+        else {
+            Dl_info info;
+            if (dladdr((void *)&CreatePathIntegrator, &info) && info.dli_fname) path = DirectoryContaining(info.dli_fname) + "/libpbrt_gpu.so";
+            else path = "libpbrt_gpu.so";
+        }
+        lib = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!lib) { Error("Unable to load the HIP back end \"%s\": %s", path.c_str(), dlerror()); return false; }
+#define BIND(n) n = (decltype(n))dlsym(lib, "pg_" #n); if (!n) { Error("libpbrt_gpu.so lacks symbol pg_" #n); return false; }
+        BIND(set_device) BIND(last_error) BIND(scene_create) BIND(scene_destroy) BIND(render_tile_count) BIND(render) BIND(counters)
+#undef BIND
+        return true;
+    }
+};
+GpuApi gpuApi;
+}  // namespace
+
+void GpuPathIntegrator::Render(const Scene &scene) {
+    if (!gpuApi.Load()) { Error("Rendering aborted: no HIP back end (there is no CPU fallback)."); exit(1); }
+    FlatScene flat;
+    Flatten(scene, &flat);
+    PgRenderDesc rd;
+    FillRenderDesc(&rd);
+    if (gpuApi.set_device(PbrtOptions.device) != PG_OK) { Error("pg_set_device: %s", gpuApi.last_error()); exit(1); }
+    PgScene *dev = nullptr;
+    if (gpuApi.scene_create(&flat.desc, &dev) != PG_OK) { Error("pg_scene_create: %s", gpuApi.last_error()); exit(1); }
+    int nTiles = gpuApi.render_tile_count(&rd);
+    std::vector<PgFilmPixel> film((size_t)nTiles * 256);
+    int maxStrays = nTiles * 256 / 8 + 1024, nStrays = 0;
+    std::vector<PgStraySample> strays(maxStrays);
+    auto t0 = std::chrono::steady_clock::now();
+    int st = gpuApi.render(dev, &rd, film.data(), strays.data(), maxStrays, &nStrays, PG_MEM_HOST, nullptr);
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (st != PG_OK) { Error("pg_render: %s", gpuApi.last_error()); gpuApi.scene_destroy(dev); exit(1); }
+    PgCounters c;
+    if (gpuApi.counters(dev, &c) == PG_OK && !PbrtOptions.quiet) {
+        // the reference's own statistics (scene.cpp:40-42, integrator.cpp:48, triangle.cpp:45)
+        double rays = double(c.closest_rays + c.shadow_rays);
+        fprintf(stderr, "Statistics:\n  Integrator/Camera rays traced %llu\n  Intersections/Regular ray intersection tests %llu\n"
+                        "  Intersections/Shadow ray intersection tests %llu\n  Intersections/Ray-triangle intersection tests %llu\n"
+                        "  BVH/Node fetches %llu\n  Integrator::Render() %.3f s  (%.2f Mrays/s, %.2f Msamples/s)\n",
+                (unsigned long long)c.camera_rays, (unsigned long long)c.closest_rays, (unsigned long long)c.shadow_rays,
+                (unsigned long long)c.tri_tests, (unsigned long long)c.node_visits, sec, rays / sec / 1e6, double(c.camera_rays) / sec / 1e6);
+    }
+    gpuApi.scene_destroy(dev);
+    camera->film->MergeShard(rd, film.data(), strays.data(), nStrays);
+    camera->film->WriteImage();  // integrator.cpp:338
+}
+}  // namespace pbrt

@@ -1,0 +1,158 @@
+// Host-side scene objects of the MI355X path: the closed set of pbrt plugin
+// classes the hot path needs (TriangleMesh/Triangle, GeometricPrimitive,
+// BVHAccel, Scene, Film, PerspectiveCamera, HaltonSampler, Integrator), with
+// the reference's names and parameter semantics, plus FlatScene -- the SoA
+// hand-off to the C ABI in include/pbrt_gpu.h.
+#ifndef PBRT_AMD_HOST_SCENE_H
+#define PBRT_AMD_HOST_SCENE_H
+#include <memory>
+#include <string>
+#include <vector>
+#include "../../include/pbrt_gpu.h"
+#include "geometry.h"
+#include "paramset.h"
+
+namespace pbrt {
+
+// shapes/triangle.h:51-69.  Vertices are stored in world space (triangle.cpp:73-74).
+struct TriangleMesh {
+    int nTriangles = 0, nVertices = 0;
+    std::vector<int> vertexIndices;
+    std::vector<Point3f> p;
+    std::vector<Normal3f> n;
+    std::vector<Vector3f> s;
+    std::vector<Float> uv;  // 2 per vertex
+    bool reverseOrientation = false, transformSwapsHandedness = false;
+};
+// One Triangle shape per mesh triangle (triangle.cpp:94-110).
+struct Triangle {
+    std::shared_ptr<TriangleMesh> mesh;
+    int triIndex = 0;
+    const int *v() const { return &mesh->vertexIndices[3 * triIndex]; }
+    Bounds3f WorldBound() const;  // triangle.cpp:180-186
+    Float Area() const;           // triangle.cpp:574-580
+};
+// core/primitive.h:68-89: shape + material + area light (indices into tables).
+struct GeometricPrimitive {
+    Triangle shape;
+    int material = -1;
+    int areaLight = -1;
+};
+
+// accelerators/bvh.{h,cpp}: SAH / Middle / EqualCounts build + flattenBVHTree.
+class BVHAccel {
+  public:
+    enum class SplitMethod { SAH, HLBVH, Middle, EqualCounts };
+    BVHAccel(std::vector<GeometricPrimitive> p, int maxPrimsInNode = 1, SplitMethod splitMethod = SplitMethod::SAH);
+    Bounds3f WorldBound() const;
+    std::vector<GeometricPrimitive> primitives;  // orderedPrims after construction
+    std::vector<PgBVHNode> nodes;
+  private:
+    struct BuildNode;
+    struct PrimInfo;
+    BuildNode *recursiveBuild(std::vector<PrimInfo> &primitiveInfo, int start, int end, int *totalNodes,
+                              std::vector<GeometricPrimitive> &orderedPrims);
+    int flattenBVHTree(BuildNode *node, int *offset);
+    const int maxPrimsInNode;
+    const SplitMethod splitMethod;
+    std::vector<std::unique_ptr<BuildNode[]>> arena;
+    size_t arenaUsed = 0;
+    BuildNode *allocNode();
+};
+std::shared_ptr<BVHAccel> CreateBVHAccelerator(std::vector<GeometricPrimitive> prims, const ParamSet &ps);  // bvh.cpp:740-760
+
+struct Scene {  // core/scene.h:50-80
+    std::shared_ptr<BVHAccel> aggregate;
+    std::vector<PgLight> lights;
+    std::vector<PgMaterial> materials;
+    Bounds3f worldBound;
+};
+
+// core/film.{h,cpp} with a box filter (filters/box.cpp).
+class Film {
+  public:
+    Film(const int resolution[2], const Float cropWindow[4], Float filterRadiusX, Float filterRadiusY,
+         const std::string &filename, Float scale, Float maxSampleLuminance);
+    void GetSampleBounds(int out[4]) const;  // film.cpp:80-86
+    // MergeFilmTile (film.cpp:117-130) for one GPU shard's packed tile buffer + stray samples.
+    void MergeShard(const PgRenderDesc &rd, const PgFilmPixel *film, const PgStraySample *strays, int nStrays);
+    void Clear();
+    // WriteImage's arithmetic (film.cpp:169-206): XYZ->RGB, /weight, clamp, *scale.
+    void ComputeImage(std::vector<Float> *rgb) const;
+    void WriteImage() const;
+    int fullResolution[2];
+    int croppedPixelBounds[4];
+    Float filterRadius[2];
+    std::string filename;
+    Float scale, maxSampleLuminance;
+  private:
+    struct Pixel { Float xyz[3] = {0, 0, 0}; Float filterWeightSum = 0; };
+    std::vector<Pixel> pixels;
+};
+Film *CreateFilm(const ParamSet &params, Float filterRadiusX, Float filterRadiusY);  // film.cpp:213-252
+bool WriteImagePFM(const std::string &filename, const Float *rgb, int width, int height);  // imageio.cpp:437-482
+
+struct PerspectiveCamera {  // cameras/perspective.cpp:45-68, core/camera.h:87-108
+    Transform CameraToWorld, RasterToCamera;
+    Float lensRadius, focalDistance, shutterOpen, shutterClose;
+    std::unique_ptr<Film> film;
+};
+PerspectiveCamera *CreatePerspectiveCamera(const ParamSet &params, const Transform &cam2world, Film *film);
+
+struct HaltonSampler {  // samplers/halton.cpp:65-92
+    int samplesPerPixel;
+    int baseScales[2], baseExponents[2];
+    int sampleStride;
+    int multInverse[2];
+    bool sampleAtPixelCenter;
+};
+HaltonSampler *CreateHaltonSampler(const ParamSet &params, const int sampleBounds[4]);  // halton.cpp:133-139
+// lowdiscrepancy.cpp:2490-2504 with the default-seeded RNG (halton.cpp:69-72).
+void ComputeRadicalInversePermutations(int nDims, std::vector<uint16_t> *perms, std::vector<int32_t> *sums);
+
+// Everything pg_scene_create needs, owning the arrays PgSceneDesc points into.
+struct FlatScene {
+    PgSceneDesc desc;
+    std::vector<int32_t> indices, triMaterial, triLight, permSums;
+    std::vector<uint32_t> triFlags;
+    std::vector<float> P, N, UV, S;
+    std::vector<uint16_t> perms;
+    std::vector<PgBVHNode> nodes;
+    std::vector<PgMaterial> materials;
+    std::vector<PgLight> lights;
+};
+
+// core/integrator.h:53-58.
+class Integrator {
+  public:
+    virtual ~Integrator() {}
+    virtual void Render(const Scene &scene) = 0;
+};
+// Stands where SamplerIntegrator+PathIntegrator stand in the reference
+// (integrator.cpp:228-339, path.cpp:64-188): Render flattens the scene, hands
+// it to the HIP back end through the C ABI and merges the film.
+class GpuPathIntegrator : public Integrator {
+  public:
+    GpuPathIntegrator(int maxDepth, std::shared_ptr<PerspectiveCamera> camera, std::shared_ptr<HaltonSampler> sampler,
+                      const int pixelBounds[4], Float rrThreshold, const std::string &lightSampleStrategy);
+    void Render(const Scene &scene) override;
+    void Flatten(const Scene &scene, FlatScene *flat) const;
+    void FillRenderDesc(PgRenderDesc *rd) const;
+    std::shared_ptr<PerspectiveCamera> camera;
+    std::shared_ptr<HaltonSampler> sampler;
+    int maxDepth;
+    int pixelBounds[4];
+    Float rrThreshold;
+    std::string lightSampleStrategy;
+};
+GpuPathIntegrator *CreatePathIntegrator(const ParamSet &params, std::shared_ptr<HaltonSampler> sampler,
+                                        std::shared_ptr<PerspectiveCamera> camera);  // path.cpp:190-213
+
+// Result of a loadOnly parse (Options::loadOnly), consumed by the C API in pbrt_host.h.
+struct LoadedScene {
+    std::unique_ptr<Scene> scene;
+    std::unique_ptr<GpuPathIntegrator> integrator;
+};
+extern std::unique_ptr<LoadedScene> lastLoadedScene;
+}  // namespace pbrt
+#endif
