@@ -167,8 +167,13 @@ typedef struct PgCounters {
     uint64_t camera_rays;
     uint64_t closest_rays; /* Scene::Intersect calls  */
     uint64_t shadow_rays;  /* Scene::IntersectP calls */
-    uint64_t node_visits;  /* nodes[cur] fetches (bvh.cpp:672/710) */
-    uint64_t tri_tests;    /* Triangle::Intersect[P] calls          */
+    uint64_t node_visits;  /* nodes[cur] fetches (bvh.cpp:672/710), both traversal kernels */
+    uint64_t tri_tests;    /* Triangle::Intersect[P] calls as the reference counts them
+                              (triangle.cpp:45), i.e. including light_tri_tests          */
+    uint64_t light_tri_tests; /* of those: Shape::Pdf's single-triangle test outside the BVH (shape.cpp:80) */
+    /* per traversal kernel (closest-hit = BVHAccel::Intersect, shadow = IntersectP) */
+    uint64_t closest_node_visits, closest_tri_tests;
+    uint64_t shadow_node_visits, shadow_tri_tests;
     uint64_t closest_launches, shadow_launches;
     double closest_ms, shadow_ms; /* HIP-event time inside the traversal kernels */
     double render_ms;

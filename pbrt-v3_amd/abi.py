@@ -64,7 +64,9 @@ class PgStraySample(C.Structure):
 
 class PgCounters(C.Structure):
     _fields_ = [("camera_rays", C.c_uint64), ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
-                ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("light_tri_tests", C.c_uint64),
+                ("closest_node_visits", C.c_uint64), ("closest_tri_tests", C.c_uint64),
+                ("shadow_node_visits", C.c_uint64), ("shadow_tri_tests", C.c_uint64),
                 ("closest_launches", C.c_uint64), ("shadow_launches", C.c_uint64),
                 ("closest_ms", C.c_double), ("shadow_ms", C.c_double), ("render_ms", C.c_double)]
 

@@ -1,0 +1,554 @@
+// pg_abi.hip -- the C ABI of include/pbrt_gpu.h: scene upload, the wavefront
+// render loop (SamplerIntegrator::Render, integrator.cpp:228-339, re-ordered
+// into batches of camera samples that advance one bounce per launch), and the
+// batched Scene::Intersect/IntersectP entry points.
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "pg_device.h"
+#include "pg_kernels.h"
+
+static thread_local std::string g_lastError;
+static int setError(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list a;
+    va_start(a, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, a);
+    va_end(a);
+    g_lastError = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return setError(PG_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_));    \
+    } while (0)
+
+struct DeviceBuffer {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t alloc(size_t n) {
+        release();
+        bytes = n;
+        if (n == 0) return hipSuccess;
+        return hipMalloc(&p, n);
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    ~DeviceBuffer() { release(); }
+};
+
+struct PgScene {
+    int device = 0;
+    DScene d;
+    DeviceBuffer nodes, tris, uv, materials, lights, distTable, perms, permSums, primes;
+    // work buffers (sized on first render, reused)
+    int capacity = 0;
+    DeviceBuffer qo[4], qd[4], counts, hitsMain, hitsMis, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
+        lightTests, filmDev, straysDev, nStraysDev;
+    // test-path buffers
+    DeviceBuffer tO, tD, tT, tPrim, tHit, tOcc, tCount;
+    PgCounters counters;
+    std::vector<hipEvent_t> events;
+    bool hasNullMaterial = false;
+};
+
+extern "C" {
+
+const char *pg_last_error(void) { return g_lastError.c_str(); }
+
+int pg_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return setError(PG_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+int pg_set_device(int device) {
+    HIP_TRY(hipSetDevice(device));
+    return PG_OK;
+}
+
+void pg_scene_destroy(PgScene *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
+    delete s;
+}
+
+int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
+    if (!desc || !out) return setError(PG_ERR_INVALID, "pg_scene_create: null argument");
+    *out = nullptr;
+    if (desc->abi_version != PG_ABI_VERSION) return setError(PG_ERR_INVALID, "ABI version %d, expected %d", desc->abi_version, PG_ABI_VERSION);
+    if (desc->n_tris < 0 || desc->n_nodes < 0 || (desc->n_tris > 0 && (!desc->nodes || !desc->indices || !desc->P)))
+        return setError(PG_ERR_INVALID, "pg_scene_create: malformed geometry arrays");
+    if (desc->N || desc->S)
+        return setError(PG_ERR_UNSUPPORTED, "per-vertex shading normals / tangents are outside this build's closed set");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return setError(PG_ERR_DEVICE, "no HIP device visible (there is no CPU fallback)");
+    PgScene *s = new PgScene;
+    HIP_TRY(hipGetDevice(&s->device));
+    memset(&s->counters, 0, sizeof(s->counters));
+    DScene &d = s->d;
+    memset(&d, 0, sizeof(d));
+    const int nt = desc->n_tris;
+#define FAIL(code, ...) do { int c_ = setError(code, __VA_ARGS__); pg_scene_destroy(s); return c_; } while (0)
+#define HIP_TRY_S(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) FAIL(PG_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+    // --- nodes: uploaded verbatim (32 B/node, same bytes as pbrt's LinearBVHNode)
+    HIP_TRY_S(s->nodes.alloc(sizeof(PgBVHNode) * (size_t)desc->n_nodes));
+    if (desc->n_nodes) HIP_TRY_S(hipMemcpy(s->nodes.p, desc->nodes, s->nodes.bytes, hipMemcpyHostToDevice));
+    // --- triangles: gather vertices into BVH order, 48 B per triangle
+    std::vector<float4> tris((size_t)nt * 3);
+    std::vector<float> uv;
+    bool anyUV = false;
+    for (int k = 0; k < nt; ++k) anyUV |= desc->UV && (desc->tri_flags[k] & PG_TRI_HAS_UV);
+    if (anyUV) uv.resize((size_t)nt * 6);
+    for (int k = 0; k < nt; ++k) {
+        const int32_t *v = &desc->indices[3 * k];
+        for (int j = 0; j < 3; ++j)
+            if (v[j] < 0 || v[j] >= desc->n_verts) FAIL(PG_ERR_INVALID, "triangle %d has out-of-range vertex index %d", k, v[j]);
+        uint32_t flags = desc->tri_flags ? desc->tri_flags[k] : 0;
+        int mat = desc->tri_material ? desc->tri_material[k] : 0;
+        int light = desc->tri_light ? desc->tri_light[k] : -1;
+        if (mat < 0 || mat >= desc->n_materials) FAIL(PG_ERR_INVALID, "triangle %d has out-of-range material %d", k, mat);
+        if (light >= desc->n_lights) FAIL(PG_ERR_INVALID, "triangle %d has out-of-range light %d", k, light);
+        V3 p[3];
+        for (int j = 0; j < 3; ++j) p[j] = mk(desc->P[3 * v[j]], desc->P[3 * v[j] + 1], desc->P[3 * v[j] + 2]);
+        float tuv[6] = {0, 0, 1, 0, 1, 1};
+        if (anyUV && (flags & PG_TRI_HAS_UV))
+            for (int j = 0; j < 3; ++j) { tuv[2 * j] = desc->UV[2 * v[j]]; tuv[2 * j + 1] = desc->UV[2 * v[j] + 1]; }
+        if (anyUV) memcpy(&uv[(size_t)k * 6], tuv, sizeof(tuv));
+        V3 dpdu;
+        if (!tri_dpdu(p[0], p[1], p[2], tuv, dpdu)) flags |= PG_TRI_BOGUS;  // triangle.cpp:309-317
+        float fw, mw, lw;
+        memcpy(&fw, &flags, 4); memcpy(&mw, &mat, 4); memcpy(&lw, &light, 4);
+        tris[3 * (size_t)k] = make_float4(p[0].x, p[0].y, p[0].z, fw);
+        tris[3 * (size_t)k + 1] = make_float4(p[1].x, p[1].y, p[1].z, mw);
+        tris[3 * (size_t)k + 2] = make_float4(p[2].x, p[2].y, p[2].z, lw);
+    }
+    HIP_TRY_S(s->tris.alloc(sizeof(float4) * tris.size()));
+    if (nt) HIP_TRY_S(hipMemcpy(s->tris.p, tris.data(), s->tris.bytes, hipMemcpyHostToDevice));
+    if (anyUV) {
+        HIP_TRY_S(s->uv.alloc(sizeof(float) * uv.size()));
+        HIP_TRY_S(hipMemcpy(s->uv.p, uv.data(), s->uv.bytes, hipMemcpyHostToDevice));
+    }
+    // --- materials / lights
+    for (int i = 0; i < desc->n_materials; ++i) {
+        const PgMaterial &m = desc->materials[i];
+        if (m.type == PG_MAT_NONE) s->hasNullMaterial = true;
+        else if (m.type != PG_MAT_MATTE) FAIL(PG_ERR_UNSUPPORTED, "material %d: type %d is outside this build's closed set (matte)", i, m.type);
+        else if (m.sigma != 0) FAIL(PG_ERR_UNSUPPORTED, "material %d: Oren-Nayar (sigma != 0) is outside this build's closed set", i);
+    }
+    for (int i = 0; i < desc->n_lights; ++i)
+        if (desc->lights[i].prim < 0 || desc->lights[i].prim >= nt) FAIL(PG_ERR_INVALID, "light %d has no emitting triangle", i);
+    HIP_TRY_S(s->materials.alloc(sizeof(PgMaterial) * (size_t)desc->n_materials));
+    if (desc->n_materials) HIP_TRY_S(hipMemcpy(s->materials.p, desc->materials, s->materials.bytes, hipMemcpyHostToDevice));
+    HIP_TRY_S(s->lights.alloc(sizeof(PgLight) * (size_t)desc->n_lights));
+    if (desc->n_lights) HIP_TRY_S(hipMemcpy(s->lights.p, desc->lights, s->lights.bytes, hipMemcpyHostToDevice));
+    // --- Halton tables
+    if (desc->n_perm_dims < 5 || !desc->perms || !desc->perm_sums) FAIL(PG_ERR_INVALID, "Halton permutation table missing (need >= 5 dims)");
+    std::vector<int32_t> primes;
+    for (int c = 2; (int)primes.size() < desc->n_perm_dims; ++c) {
+        bool is = true;
+        for (int p : primes) { if (p * p > c) break; if (c % p == 0) { is = false; break; } }
+        if (is) primes.push_back(c);
+    }
+    for (int i = 0; i < desc->n_perm_dims; ++i)
+        if (desc->perm_sums[i + 1] - desc->perm_sums[i] != primes[i]) FAIL(PG_ERR_INVALID, "perm_sums[%d] does not match prime base %d", i, primes[i]);
+    HIP_TRY_S(s->perms.alloc(sizeof(uint16_t) * (size_t)desc->perm_sums[desc->n_perm_dims]));
+    HIP_TRY_S(hipMemcpy(s->perms.p, desc->perms, s->perms.bytes, hipMemcpyHostToDevice));
+    HIP_TRY_S(s->permSums.alloc(sizeof(int32_t) * (size_t)(desc->n_perm_dims + 1)));
+    HIP_TRY_S(hipMemcpy(s->permSums.p, desc->perm_sums, s->permSums.bytes, hipMemcpyHostToDevice));
+    HIP_TRY_S(s->primes.alloc(sizeof(int32_t) * primes.size()));
+    HIP_TRY_S(hipMemcpy(s->primes.p, primes.data(), s->primes.bytes, hipMemcpyHostToDevice));
+
+    d.nodes = (const float4 *)s->nodes.p; d.tris = (const float4 *)s->tris.p; d.uv = (const float *)s->uv.p;
+    d.materials = (const PgMaterial *)s->materials.p; d.lights = (const PgLight *)s->lights.p;
+    d.nNodes = desc->n_nodes; d.nTris = nt; d.nLights = desc->n_lights; d.nMaterials = desc->n_materials;
+    d.perms = (const uint16_t *)s->perms.p; d.permSums = (const int32_t *)s->permSums.p; d.primes = (const int32_t *)s->primes.p;
+    d.nPermDims = desc->n_perm_dims;
+    d.lightStrategy = desc->light_strategy;
+    // --- light sampling distributions (lightdistrib.cpp)
+    const int nl = desc->n_lights;
+    if (nl > 0) {
+        const size_t stride = 2 * (size_t)nl + 2;
+        if (desc->light_strategy == PG_LIGHTS_SPATIAL) {
+            // SpatialLightDistribution ctor, lightdistrib.cpp:96-125 (maxVoxels = 64)
+            const PgBVHNode &root = desc->nodes[0];
+            float diag[3];
+            for (int i = 0; i < 3; ++i) { d.bmin[i] = root.bmin[i]; d.bmax[i] = root.bmax[i]; diag[i] = root.bmax[i] - root.bmin[i]; }
+            int me = (diag[0] > diag[1] && diag[0] > diag[2]) ? 0 : ((diag[1] > diag[2]) ? 1 : 2);
+            float bmax = diag[me];
+            size_t total = 1;
+            for (int i = 0; i < 3; ++i) {
+                int nv = (int)roundf(diag[i] / bmax * 64);
+                d.nVoxels[i] = nv > 1 ? nv : 1;
+                total *= (size_t)d.nVoxels[i];
+            }
+            if (total * stride * sizeof(float) > ((size_t)8 << 30))
+                FAIL(PG_ERR_UNSUPPORTED, "dense spatial light table would need %zu MiB (%d lights x %zu voxels); use "
+                     "\"lightsamplestrategy\" \"power\" or \"uniform\"", total * stride * sizeof(float) >> 20, nl, total);
+            HIP_TRY_S(s->distTable.alloc(total * stride * sizeof(float)));
+            d.distTable = (const float *)s->distTable.p;
+            launch_light_tables(d, (float *)s->distTable.p, (int)total, 0);
+            HIP_TRY_S(hipGetLastError());
+            HIP_TRY_S(hipDeviceSynchronize());
+        } else {
+            // UniformLightDistribution (lightdistrib.cpp:68-71) / PowerLightDistribution (integrator.cpp:217-225, diffuse.cpp:64-66)
+            std::vector<float> tab(stride);
+            float *func = tab.data(), *cdf = func + nl;
+            for (int i = 0; i < nl; ++i) {
+                if (desc->light_strategy == PG_LIGHTS_POWER) {
+                    const PgLight &l = desc->lights[i];
+                    float P[3];
+                    for (int c = 0; c < 3; ++c) { float v = l.L[c]; v *= (float)(l.two_sided ? 2 : 1); v *= l.area; v *= PG_PI; P[c] = v; }
+                    func[i] = 0.212671f * P[0] + 0.715160f * P[1] + 0.072169f * P[2];
+                } else func[i] = 1;
+            }
+            cdf[0] = 0;
+            for (int i = 1; i < nl + 1; ++i) cdf[i] = cdf[i - 1] + func[i - 1] / nl;
+            float funcInt = cdf[nl];
+            if (funcInt == 0) { for (int i = 1; i < nl + 1; ++i) cdf[i] = (float)i / (float)nl; }
+            else { for (int i = 1; i < nl + 1; ++i) cdf[i] /= funcInt; }
+            tab[2 * nl + 1] = funcInt;
+            HIP_TRY_S(s->distTable.alloc(stride * sizeof(float)));
+            HIP_TRY_S(hipMemcpy(s->distTable.p, tab.data(), stride * sizeof(float), hipMemcpyHostToDevice));
+            d.distTable = (const float *)s->distTable.p;
+        }
+    }
+    HIP_TRY_S(s->traceCn.alloc(sizeof(TraceCounters) * 2));
+    HIP_TRY_S(hipMemset(s->traceCn.p, 0, s->traceCn.bytes));
+    HIP_TRY_S(s->lightTests.alloc(sizeof(unsigned long long)));
+    HIP_TRY_S(hipMemset(s->lightTests.p, 0, s->lightTests.bytes));
+    *out = s;
+    return PG_OK;
+#undef FAIL
+#undef HIP_TRY_S
+}
+
+static int tileCount(const PgRenderDesc *rd) {
+    int nx = (rd->sample_bounds[2] - rd->sample_bounds[0] + 15) / 16, ny = (rd->sample_bounds[3] - rd->sample_bounds[1] + 15) / 16;
+    if (nx <= 0 || ny <= 0 || rd->tile_step <= 0 || rd->tile_first < 0) return 0;
+    int total = nx * ny;
+    return rd->tile_first >= total ? 0 : (total - rd->tile_first + rd->tile_step - 1) / rd->tile_step;
+}
+int pg_render_tile_count(const PgRenderDesc *desc) {
+    if (!desc) return setError(PG_ERR_INVALID, "pg_render_tile_count: null argument");
+    return tileCount(desc);
+}
+
+static int ensureWorkBuffers(PgScene *s, int capacity) {
+    if (s->capacity >= capacity) return PG_OK;
+    const size_t n = (size_t)capacity;
+    for (int i = 0; i < 4; ++i) { HIP_TRY(s->qo[i].alloc(n * sizeof(float4))); HIP_TRY(s->qd[i].alloc(n * sizeof(float4))); }
+    HIP_TRY(s->counts.alloc(4 * sizeof(int)));
+    HIP_TRY(s->hitsMain.alloc(n * sizeof(float4)));
+    HIP_TRY(s->hitsMis.alloc(n * sizeof(float4)));
+    HIP_TRY(s->occluded.alloc(n * sizeof(int)));
+    HIP_TRY(s->stL.alloc(n * sizeof(float4)));
+    HIP_TRY(s->stBeta.alloc(n * sizeof(float4)));
+    HIP_TRY(s->stMeta.alloc(n * sizeof(int4)));
+    HIP_TRY(s->pdLight.alloc(n * sizeof(float4)));
+    HIP_TRY(s->pdMis.alloc(n * sizeof(float4)));
+    HIP_TRY(s->pdBeta.alloc(n * sizeof(float4)));
+    HIP_TRY(s->pdInfo.alloc(n * sizeof(int4)));
+    s->capacity = capacity;
+    return PG_OK;
+}
+
+static hipEvent_t getEvent(PgScene *s, size_t idx) {
+    while (s->events.size() <= idx) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        s->events.push_back(e);
+    }
+    return s->events[idx];
+}
+
+int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySample *strays, int32_t maxStrays, int32_t *nStrays,
+              int mem, void *streamPtr) {
+    if (!s || !rd || !film || !nStrays || (maxStrays > 0 && !strays)) return setError(PG_ERR_INVALID, "pg_render: null argument");
+    if (rd->abi_version != PG_ABI_VERSION) return setError(PG_ERR_INVALID, "ABI version %d, expected %d", rd->abi_version, PG_ABI_VERSION);
+    if (rd->filter_radius[0] > 0.5f || rd->filter_radius[1] > 0.5f || rd->filter_radius[0] <= 0 || rd->filter_radius[1] <= 0)
+        return setError(PG_ERR_UNSUPPORTED, "pixel filters wider than 0.5 px are outside this build's closed set (box, radius <= 0.5)");
+    if (rd->spp <= 0 || rd->max_depth < 0 || rd->tile_step <= 0) return setError(PG_ERR_INVALID, "pg_render: bad spp/maxdepth/tile_step");
+    if (5 + 8 * (rd->max_depth + 1) > s->d.nPermDims && s->d.nPermDims < 1000)
+        return setError(PG_ERR_INVALID, "Halton table has %d dimensions; maxdepth %d needs %d", s->d.nPermDims, rd->max_depth, 5 + 8 * (rd->max_depth + 1));
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t stream = (hipStream_t)streamPtr;
+    const int nLocalTiles = tileCount(rd);
+    RenderParams rp;
+    memset(&rp, 0, sizeof(rp));
+    rp.rd = *rd;
+    rp.nTilesX = (rd->sample_bounds[2] - rd->sample_bounds[0] + 15) / 16;
+    rp.nTilesY = (rd->sample_bounds[3] - rd->sample_bounds[1] + 15) / 16;
+
+    // device film / stray buffers (caller's when mem == DEVICE)
+    PgFilmPixel *dFilm = film;
+    PgStraySample *dStrays = strays;
+    int *dNStrays = nStrays;
+    const size_t filmBytes = sizeof(PgFilmPixel) * 256 * (size_t)nLocalTiles;
+    if (mem == PG_MEM_HOST) {
+        HIP_TRY(s->filmDev.alloc(filmBytes));
+        HIP_TRY(s->straysDev.alloc(sizeof(PgStraySample) * (size_t)(maxStrays > 0 ? maxStrays : 1)));
+        HIP_TRY(s->nStraysDev.alloc(sizeof(int)));
+        dFilm = (PgFilmPixel *)s->filmDev.p; dStrays = (PgStraySample *)s->straysDev.p; dNStrays = (int *)s->nStraysDev.p;
+    }
+    if (filmBytes) HIP_TRY(hipMemsetAsync(dFilm, 0, filmBytes, stream));
+    HIP_TRY(hipMemsetAsync(dNStrays, 0, sizeof(int), stream));
+    if (nLocalTiles == 0) {
+        if (mem == PG_MEM_HOST) *nStrays = 0;
+        return PG_OK;
+    }
+    // batch shape: as many whole tiles x samples as fit the path budget
+    size_t budget = (size_t)1 << 22;
+    if (const char *e = getenv("PG_BATCH_PATHS")) { long v = atol(e); if (v >= 256) budget = (size_t)v; }
+    int sPerBatch = rd->spp, tilesPerBatch = nLocalTiles;
+    if ((size_t)tilesPerBatch * 256 * sPerBatch > budget) {
+        // prefer all tiles with fewer samples (keeps primary rays coherent and every pixel busy)
+        sPerBatch = (int)(budget / ((size_t)tilesPerBatch * 256));
+        if (sPerBatch < 1) { sPerBatch = 1; tilesPerBatch = (int)(budget / 256); if (tilesPerBatch < 1) tilesPerBatch = 1; }
+    }
+    const int capacity = tilesPerBatch * 256 * sPerBatch;
+    int st = ensureWorkBuffers(s, capacity);
+    if (st != PG_OK) return st;
+
+    PathState ps;
+    ps.L = (float4 *)s->stL.p; ps.beta = (float4 *)s->stBeta.p; ps.meta = (int4 *)s->stMeta.p;
+    ps.pdLight = (float4 *)s->pdLight.p; ps.pdMis = (float4 *)s->pdMis.p; ps.pdBeta = (float4 *)s->pdBeta.p; ps.pdInfo = (int4 *)s->pdInfo.p;
+    int *counts = (int *)s->counts.p;
+    RayQueue q[4];
+    for (int i = 0; i < 4; ++i) { q[i].o = (float4 *)s->qo[i].p; q[i].d = (float4 *)s->qd[i].p; q[i].count = counts + i; }
+    TraceCounters *cnClosest = (TraceCounters *)s->traceCn.p, *cnShadow = cnClosest + 1;
+    unsigned long long *lightTests = (unsigned long long *)s->lightTests.p;
+
+    size_t ev = 0;
+    std::vector<std::pair<size_t, int>> timed;  // (event index, 0 closest / 1 shadow)
+    hipEvent_t evStart = getEvent(s, ev++), evStop = getEvent(s, ev++);
+    if (!evStart || !evStop) return setError(PG_ERR_DEVICE, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(evStart, stream));
+    uint64_t closestRays = 0, shadowRays = 0, cameraRays = 0, closestLaunches = 0, shadowLaunches = 0;
+    std::vector<int> hostCounts;  // read back once per batch at the end (pinned copy not needed: tiny)
+    DeviceBuffer countLog;        // per-bounce queue sizes, copied back after the batch for the ray statistics
+    const int maxIters = rd->max_depth + 1 + (s->hasNullMaterial ? 64 : 0);
+    HIP_TRY(countLog.alloc(sizeof(int) * 4 * (size_t)(maxIters + 1)));
+
+    for (int tile0 = 0; tile0 < nLocalTiles; tile0 += tilesPerBatch) {
+        for (int s0 = 0; s0 < rd->spp; s0 += sPerBatch) {
+            rp.tileLocal0 = tile0;
+            rp.nTilesBatch = std::min(tilesPerBatch, nLocalTiles - tile0);
+            rp.s0 = s0;
+            rp.sCount = std::min(sPerBatch, rd->spp - s0);
+            rp.capacity = rp.nTilesBatch * 256 * rp.sCount;
+            HIP_TRY(hipMemsetAsync(counts, 0, 4 * sizeof(int), stream));
+            int cur = 0;  // main queue index (0/1 ping-pong); 2 = shadow, 3 = MIS
+            launch_generate(s->d, rp, ps, q[cur], stream);
+            int iters = 0;
+            for (int bounce = 0; bounce < maxIters; ++bounce, ++iters) {
+                const int nxt = cur ^ 1;
+                hipEvent_t a = getEvent(s, ev), b = getEvent(s, ev + 1);
+                timed.push_back({ev, 0}); ev += 2;
+                HIP_TRY(hipEventRecord(a, stream));
+                launch_closest(s->d, q[cur], rp.capacity, (float4 *)s->hitsMain.p, nullptr, nullptr, cnClosest, stream);
+                HIP_TRY(hipEventRecord(b, stream));
+                ++closestLaunches;
+                HIP_TRY(hipMemsetAsync(counts + nxt, 0, sizeof(int), stream));
+                HIP_TRY(hipMemsetAsync(counts + 2, 0, 2 * sizeof(int), stream));
+                launch_shade(s->d, rp, ps, q[cur], (const float4 *)s->hitsMain.p, q[nxt], q[2], q[3], rp.capacity, lightTests, stream);
+                a = getEvent(s, ev); b = getEvent(s, ev + 1);
+                timed.push_back({ev, 1}); ev += 2;
+                HIP_TRY(hipEventRecord(a, stream));
+                launch_anyhit(s->d, q[2], rp.capacity, (int *)s->occluded.p, cnShadow, stream);
+                HIP_TRY(hipEventRecord(b, stream));
+                ++shadowLaunches;
+                a = getEvent(s, ev); b = getEvent(s, ev + 1);
+                timed.push_back({ev, 0}); ev += 2;
+                HIP_TRY(hipEventRecord(a, stream));
+                launch_closest(s->d, q[3], rp.capacity, (float4 *)s->hitsMis.p, nullptr, nullptr, cnClosest, stream);
+                HIP_TRY(hipEventRecord(b, stream));
+                ++closestLaunches;
+                launch_resolve(s->d, ps, q[cur], q[3], (const int *)s->occluded.p, (const float4 *)s->hitsMis.p, rp.capacity, stream);
+                // log this bounce's queue sizes: [cur main, shadow, mis]
+                HIP_TRY(hipMemcpyAsync((int *)countLog.p + 4 * bounce, counts + cur, sizeof(int), hipMemcpyDeviceToDevice, stream));
+                HIP_TRY(hipMemcpyAsync((int *)countLog.p + 4 * bounce + 1, counts + 2, 2 * sizeof(int), hipMemcpyDeviceToDevice, stream));
+                cur = nxt;
+                if (s->hasNullMaterial && bounce >= rd->max_depth) {
+                    int left = 0;
+                    HIP_TRY(hipMemcpyAsync(&left, counts + cur, sizeof(int), hipMemcpyDeviceToHost, stream));
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    if (left == 0) { ++iters; break; }
+                }
+            }
+            launch_film(rp, ps, dFilm, dStrays, maxStrays, dNStrays, stream);
+            hostCounts.resize(4 * (size_t)iters);
+            HIP_TRY(hipMemcpyAsync(hostCounts.data(), countLog.p, sizeof(int) * 4 * (size_t)iters, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            for (int b = 0; b < iters; ++b) {
+                closestRays += (uint64_t)hostCounts[4 * b] + (uint64_t)hostCounts[4 * b + 2];
+                shadowRays += (uint64_t)hostCounts[4 * b + 1];
+            }
+            if (iters > 0) cameraRays += (uint64_t)hostCounts[0];
+        }
+    }
+    HIP_TRY(hipEventRecord(evStop, stream));
+    HIP_TRY(hipGetLastError());
+    int hostNStrays = 0;
+    HIP_TRY(hipMemcpyAsync(&hostNStrays, dNStrays, sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (mem == PG_MEM_HOST) {
+        HIP_TRY(hipMemcpyAsync(film, dFilm, filmBytes, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        int nCopy = std::min(hostNStrays, (int)maxStrays);
+        if (nCopy > 0) HIP_TRY(hipMemcpy(strays, dStrays, sizeof(PgStraySample) * (size_t)nCopy, hipMemcpyDeviceToHost));
+        *nStrays = nCopy;
+    } else {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (hostNStrays > maxStrays) { int v = maxStrays; HIP_TRY(hipMemcpy(dNStrays, &v, sizeof(int), hipMemcpyHostToDevice)); }
+    }
+    // statistics
+    TraceCounters tc[2];
+    unsigned long long lt = 0;
+    HIP_TRY(hipMemcpy(tc, s->traceCn.p, sizeof(tc), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&lt, lightTests, sizeof(lt), hipMemcpyDeviceToHost));
+    PgCounters &c = s->counters;
+    c.camera_rays += cameraRays; c.closest_rays += closestRays; c.shadow_rays += shadowRays;
+    c.node_visits = tc[0].node_visits + tc[1].node_visits;
+    c.tri_tests = tc[0].tri_tests + tc[1].tri_tests + lt;
+    c.light_tri_tests = lt;
+    c.closest_node_visits = tc[0].node_visits; c.closest_tri_tests = tc[0].tri_tests;
+    c.shadow_node_visits = tc[1].node_visits; c.shadow_tri_tests = tc[1].tri_tests;
+    c.closest_launches += closestLaunches; c.shadow_launches += shadowLaunches;
+    for (auto &te : timed) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, s->events[te.first], s->events[te.first + 1]) == hipSuccess) (te.second ? c.shadow_ms : c.closest_ms) += ms;
+    }
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, evStart, evStop) == hipSuccess) c.render_ms += ms;
+    if (hostNStrays > maxStrays) return setError(PG_ERR_OVERFLOW, "%d stray samples, buffer holds %d", hostNStrays, maxStrays);
+    return PG_OK;
+}
+
+// ---- batched Scene::Intersect / IntersectP -------------------------------------------
+static int uploadRays(PgScene *s, int n, const float *o, const float *d, const float *tmax, int mem, hipStream_t stream) {
+    // AoS (3 floats) host/device input -> the kernels' float4 SoA queue layout
+    std::vector<float4> qo((size_t)n), qd((size_t)n);
+    std::vector<float> ho, hd, ht;
+    const float *po = o, *pd = d, *pt = tmax;
+    if (mem == PG_MEM_DEVICE) {
+        ho.resize(3 * (size_t)n); hd.resize(3 * (size_t)n); ht.resize((size_t)n);
+        HIP_TRY(hipMemcpy(ho.data(), o, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(hd.data(), d, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(ht.data(), tmax, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+        po = ho.data(); pd = hd.data(); pt = ht.data();
+    }
+    for (int i = 0; i < n; ++i) {
+        float idf;
+        memcpy(&idf, &i, 4);
+        qo[i] = make_float4(po[3 * i], po[3 * i + 1], po[3 * i + 2], pt[i]);
+        qd[i] = make_float4(pd[3 * i], pd[3 * i + 1], pd[3 * i + 2], idf);
+    }
+    HIP_TRY(s->tO.alloc(sizeof(float4) * (size_t)n));
+    HIP_TRY(s->tD.alloc(sizeof(float4) * (size_t)n));
+    HIP_TRY(s->tCount.alloc(sizeof(int)));
+    HIP_TRY(hipMemcpyAsync(s->tO.p, qo.data(), s->tO.bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(s->tD.p, qd.data(), s->tD.bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(s->tCount.p, &n, sizeof(int), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return PG_OK;
+}
+
+int pg_intersect(PgScene *s, int32_t n, const float *o, const float *d, const float *tmax, int32_t *prim, float *t, float *bary, int mem,
+                 void *streamPtr) {
+    if (!s || n < 0 || (n > 0 && (!o || !d || !tmax || !prim || !t || !bary))) return setError(PG_ERR_INVALID, "pg_intersect: null argument");
+    if (n == 0) return PG_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t stream = (hipStream_t)streamPtr;
+    int st = uploadRays(s, n, o, d, tmax, mem, stream);
+    if (st != PG_OK) return st;
+    HIP_TRY(s->tHit.alloc(sizeof(float4) * (size_t)n));
+    HIP_TRY(s->tT.alloc(sizeof(float) * (size_t)n));
+    RayQueue q;
+    q.o = (float4 *)s->tO.p; q.d = (float4 *)s->tD.p; q.count = (int *)s->tCount.p;
+    hipEvent_t a = getEvent(s, 0), b = getEvent(s, 1);
+    HIP_TRY(hipEventRecord(a, stream));
+    launch_closest(s->d, q, n, (float4 *)s->tHit.p, (float *)s->tT.p, nullptr, (TraceCounters *)s->traceCn.p, stream);
+    HIP_TRY(hipEventRecord(b, stream));
+    HIP_TRY(hipGetLastError());
+    std::vector<float4> hits((size_t)n);
+    std::vector<float> ts((size_t)n);
+    HIP_TRY(hipMemcpyAsync(hits.data(), s->tHit.p, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(ts.data(), s->tT.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    std::vector<int32_t> hp((size_t)n);
+    std::vector<float> hb(3 * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        memcpy(&hp[i], &hits[i].x, 4);
+        bool hit = hp[i] >= 0;
+        hb[3 * i] = hit ? hits[i].y : 0; hb[3 * i + 1] = hit ? hits[i].z : 0; hb[3 * i + 2] = hit ? hits[i].w : 0;
+    }
+    hipMemcpyKind kind = mem == PG_MEM_DEVICE ? hipMemcpyHostToDevice : hipMemcpyHostToHost;
+    HIP_TRY(hipMemcpy(prim, hp.data(), sizeof(int32_t) * (size_t)n, kind));
+    HIP_TRY(hipMemcpy(t, ts.data(), sizeof(float) * (size_t)n, kind));
+    HIP_TRY(hipMemcpy(bary, hb.data(), sizeof(float) * 3 * (size_t)n, kind));
+    TraceCounters tc[2];
+    HIP_TRY(hipMemcpy(tc, s->traceCn.p, sizeof(tc), hipMemcpyDeviceToHost));
+    PgCounters &c = s->counters;
+    c.closest_rays += (uint64_t)n;
+    c.closest_node_visits = tc[0].node_visits; c.closest_tri_tests = tc[0].tri_tests;
+    c.node_visits = tc[0].node_visits + tc[1].node_visits;
+    c.tri_tests = tc[0].tri_tests + tc[1].tri_tests + c.light_tri_tests;
+    c.closest_launches += 1;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, a, b) == hipSuccess) c.closest_ms += ms;
+    return PG_OK;
+}
+
+int pg_intersect_p(PgScene *s, int32_t n, const float *o, const float *d, const float *tmax, uint8_t *occluded, int mem, void *streamPtr) {
+    if (!s || n < 0 || (n > 0 && (!o || !d || !tmax || !occluded))) return setError(PG_ERR_INVALID, "pg_intersect_p: null argument");
+    if (n == 0) return PG_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t stream = (hipStream_t)streamPtr;
+    int st = uploadRays(s, n, o, d, tmax, mem, stream);
+    if (st != PG_OK) return st;
+    HIP_TRY(s->tOcc.alloc(sizeof(int) * (size_t)n));
+    RayQueue q;
+    q.o = (float4 *)s->tO.p; q.d = (float4 *)s->tD.p; q.count = (int *)s->tCount.p;
+    hipEvent_t a = getEvent(s, 0), b = getEvent(s, 1);
+    HIP_TRY(hipEventRecord(a, stream));
+    launch_anyhit(s->d, q, n, (int *)s->tOcc.p, (TraceCounters *)s->traceCn.p + 1, stream);
+    HIP_TRY(hipEventRecord(b, stream));
+    HIP_TRY(hipGetLastError());
+    std::vector<int> occ((size_t)n);
+    HIP_TRY(hipMemcpyAsync(occ.data(), s->tOcc.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    std::vector<uint8_t> o8((size_t)n);
+    for (int i = 0; i < n; ++i) o8[i] = occ[i] ? 1 : 0;
+    HIP_TRY(hipMemcpy(occluded, o8.data(), (size_t)n, mem == PG_MEM_DEVICE ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+    TraceCounters tc[2];
+    HIP_TRY(hipMemcpy(tc, s->traceCn.p, sizeof(tc), hipMemcpyDeviceToHost));
+    PgCounters &c = s->counters;
+    c.shadow_rays += (uint64_t)n;
+    c.shadow_node_visits = tc[1].node_visits; c.shadow_tri_tests = tc[1].tri_tests;
+    c.node_visits = tc[0].node_visits + tc[1].node_visits;
+    c.tri_tests = tc[0].tri_tests + tc[1].tri_tests + c.light_tri_tests;
+    c.shadow_launches += 1;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, a, b) == hipSuccess) c.shadow_ms += ms;
+    return PG_OK;
+}
+
+int pg_counters(PgScene *s, PgCounters *out) {
+    if (!s || !out) return setError(PG_ERR_INVALID, "pg_counters: null argument");
+    *out = s->counters;
+    return PG_OK;
+}
+int pg_counters_reset(PgScene *s) {
+    if (!s) return setError(PG_ERR_INVALID, "pg_counters_reset: null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    memset(&s->counters, 0, sizeof(s->counters));
+    HIP_TRY(hipMemset(s->traceCn.p, 0, s->traceCn.bytes));
+    HIP_TRY(hipMemset(s->lightTests.p, 0, s->lightTests.bytes));
+    return PG_OK;
+}
+}  // extern "C"

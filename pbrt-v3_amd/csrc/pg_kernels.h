@@ -1,0 +1,81 @@
+// pg_kernels.h -- shared declarations between the HIP kernels (pg_kernels.hip)
+// and the C-ABI host code (pg_abi.hip).
+#ifndef PG_KERNELS_H
+#define PG_KERNELS_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pbrt_gpu.h"
+
+// Per-triangle flag bits stored in tris[3*i].w, on top of PG_TRI_*.
+#define PG_TRI_BOGUS 0x100u  // Triangle::Intersect rejects every hit (triangle.cpp:309-317)
+
+// Device-resident scene.  All pointers are device memory.
+struct DScene {
+    // Linearised BVH, 32 B/node exactly as PgBVHNode: two float4 per node
+    //   n[0] = (bmin.x, bmin.y, bmin.z, bmax.x)   n[1] = (bmax.y, bmax.z, offset, nprims|axis<<16)
+    const float4 *nodes;
+    // Triangles in BVH order, 48 B each: three float4
+    //   t[0] = (p0, flags)  t[1] = (p1, material)  t[2] = (p2, light)
+    const float4 *tris;
+    const float *uv;  // 6 floats per triangle, or nullptr when no mesh has uv (default uv, triangle.h:104-106)
+    const PgMaterial *materials;
+    const PgLight *lights;
+    int nNodes, nTris, nLights, nMaterials;
+    // light sampling distributions (lightdistrib.cpp): strategy + tables
+    int lightStrategy;
+    int nVoxels[3];
+    float bmin[3], bmax[3];
+    const float *distTable;  // per distribution: func[nl], cdf[nl+1], funcInt  (stride 2*nl+2)
+    // Halton tables
+    const uint16_t *perms;
+    const int32_t *permSums;
+    const int32_t *primes;
+    int nPermDims;
+};
+
+// A queue of rays in SoA float4 pairs: 32 B per ray
+//   o[i] = (o.x, o.y, o.z, tMax)   d[i] = (d.x, d.y, d.z, slot id bits)
+struct RayQueue {
+    float4 *o;
+    float4 *d;
+    int *count;  // device counter
+};
+
+// Per-path state, indexed by slot.
+struct PathState {
+    float4 *L;      // (L.rgb, pFilm.x)
+    float4 *beta;   // (beta.rgb, pFilm.y)
+    int4 *meta;     // (haltonIndexLo, haltonIndexHi, dimension, bounces | flags<<16)
+    // pending direct-lighting estimate of the current bounce (EstimateDirect, integrator.cpp:108-215)
+    float4 *pdLight;  // (f*Li*weight/lightPdf rgb, light-selection pdf)
+    float4 *pdMis;    // (f*|wi.n| rgb, scatteringPdf)
+    float4 *pdBeta;   // (beta before the bounce rgb, MIS weight)
+    int4 *pdInfo;     // (shadow queue pos or -1, mis queue pos or -1, lightNum, unused)
+};
+
+#define PG_META_SPECULAR 0x10000
+#define PG_META_DONE 0x20000
+
+struct RenderParams {
+    PgRenderDesc rd;
+    int nTilesX, nTilesY;
+    // batch description: tiles [tileLocal0, tileLocal0+nTilesBatch) of this shard, samples [s0, s0+sCount)
+    int tileLocal0, nTilesBatch, s0, sCount;
+    int capacity;  // slots in this batch = nTilesBatch * sCount * 256
+};
+
+struct TraceCounters {
+    unsigned long long node_visits, tri_tests;
+};
+
+void launch_generate(const DScene &sc, const RenderParams &rp, PathState st, RayQueue q, hipStream_t s);
+void launch_closest(const DScene &sc, RayQueue q, int maxCount, float4 *hits, float *tOut, float *b2Out, TraceCounters *cn, hipStream_t s);
+void launch_anyhit(const DScene &sc, RayQueue q, int maxCount, int *occluded, TraceCounters *cn, hipStream_t s);
+void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQueue qin, const float4 *hits, RayQueue qnext,
+                  RayQueue qshadow, RayQueue qmis, int maxCount, unsigned long long *lightTriTests, hipStream_t s);
+void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis, const int *occluded, const float4 *misHits,
+                    int maxCount, hipStream_t s);
+void launch_film(const RenderParams &rp, PathState st, PgFilmPixel *film, PgStraySample *strays, int maxStrays, int *nStrays,
+                 hipStream_t s);
+void launch_light_tables(const DScene &sc, float *table, int nDistributions, hipStream_t s);
+#endif

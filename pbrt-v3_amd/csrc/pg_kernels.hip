@@ -1,0 +1,753 @@
+// pg_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4) of the wavefront
+// PathIntegrator.  One process per GPU; every kernel works on SoA ray queues
+// (32 B/ray as two float4) instead of pbrt's per-ray recursion:
+//
+//   k_generate   HaltonSampler + PerspectiveCamera   (sampler.cpp:46-52, halton.cpp:96-127, perspective.cpp:95-144)
+//   k_traverse   BVHAccel::Intersect / IntersectP + Triangle::Intersect[P]  (bvh.cpp:662-738, triangle.cpp:188-572)
+//   k_shade      PathIntegrator::Li loop body + EstimateDirect set-up      (path.cpp:81-187, integrator.cpp:85-215)
+//   k_resolve    EstimateDirect's visibility / MIS terms once rays are back (integrator.cpp:143-212)
+//   k_film       SamplerIntegrator::Render's scrub + FilmTile::AddSample    (integrator.cpp:294-320, film.h:121-161)
+//   k_light_tables  SpatialLightDistribution::ComputeDistribution per voxel (lightdistrib.cpp:232-300)
+//
+// No MFMA: there is no dense contraction on this path; traversal is a
+// latency/bandwidth-bound gather over the node and triangle arrays.
+#include "pg_device.h"
+#include "pg_kernels.h"
+
+#define PG_BLOCK 256
+// Per-lane traversal stack: the first PG_STACK_LDS entries live in LDS laid out
+// [entry][lane] (conflict-free: bank = lane % 32 for every entry), the rest of
+// pbrt's 64 entries (bvh.cpp:669) spill to a private array that is only
+// touched by unusually deep walks.
+#ifndef PG_STACK_LDS
+#define PG_STACK_LDS 20
+#endif
+#define PG_STACK_TOTAL 64
+
+PG_DEV int lane_id() { return __lane_id(); }
+
+// XCD-aware block remap: the dispatcher places block b on XCD b % 8; give each
+// XCD a contiguous eighth of the queue so its private L2 sees one coherent
+// region of the BVH instead of every eighth block of all of them.
+PG_DEV int swizzled_block(int nblk) {
+    int per = (nblk + 7) >> 3;
+    int b = blockIdx.x;
+    if (b >= per * 8) return -1;
+    int lb = (b & 7) * per + (b >> 3);
+    return lb < nblk ? lb : -1;
+}
+
+// Wave-ballot compaction: one atomicAdd per wave, lanes get consecutive slots.
+PG_DEV int queue_push(int *counter, bool pred) {
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0) return -1;
+    int lane = lane_id();
+    int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(mask));
+    base = __shfl(base, leader);
+    return pred ? base + __popcll(mask & ((1ull << lane) - 1ull)) : -1;
+}
+
+PG_DEV unsigned long long wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+
+struct Tri { V3 p0, p1, p2; uint32_t flags; int material, light; };
+PG_DEV Tri load_tri(const DScene &sc, int prim) {
+    float4 a = sc.tris[3 * prim], b = sc.tris[3 * prim + 1], c = sc.tris[3 * prim + 2];
+    Tri t;
+    t.p0 = mk(a.x, a.y, a.z); t.p1 = mk(b.x, b.y, b.z); t.p2 = mk(c.x, c.y, c.z);
+    t.flags = __float_as_uint(a.w); t.material = __float_as_int(b.w); t.light = __float_as_int(c.w);
+    return t;
+}
+
+// ===========================================================================
+// BVH traversal: BVHAccel::Intersect (ANYHIT=false, bvh.cpp:662-700) and
+// BVHAccel::IntersectP (ANYHIT=true, bvh.cpp:702-738).  One ray per lane.
+// "while-while" scheduling: lanes walk interior nodes until each holds a leaf,
+// then the wave tests triangles together; per-lane visiting order, tMax
+// shrinking and tie-breaking are exactly the reference's.
+// ===========================================================================
+template <bool ANYHIT>
+__global__ __launch_bounds__(PG_BLOCK) void k_traverse(DScene sc, RayQueue q, float4 *__restrict__ hits, float *__restrict__ tOut,
+                                                       int *__restrict__ occluded, TraceCounters *cn) {
+    __shared__ int ldsStack[PG_STACK_LDS][PG_BLOCK];
+    int spill[PG_STACK_TOTAL - PG_STACK_LDS];
+    const int n = *q.count;
+    const int lb = swizzled_block((n + PG_BLOCK - 1) / PG_BLOCK);
+    if (lb < 0) return;
+    const int tid = threadIdx.x;
+    const int i = lb * PG_BLOCK + tid;
+    const bool valid = i < n;
+    float4 o4 = valid ? q.o[i] : make_float4(0, 0, 0, 0);
+    float4 d4 = valid ? q.d[i] : make_float4(1, 1, 1, 0);
+    const V3 o = mk(o4.x, o4.y, o4.z), d = mk(d4.x, d4.y, d4.z);
+    float tMax = o4.w;
+    const V3 invDir = mk(1 / d.x, 1 / d.y, 1 / d.z);
+    const bool nx = invDir.x < 0, ny = invDir.y < 0, nz = invDir.z < 0;
+    int hitPrim = -1;
+    float hb0 = 0, hb1 = 0, hb2 = 0;
+    unsigned int nodeVisits = 0, triTests = 0;
+    int sp = 0, cur = 0;
+    int leafOff = 0, leafN = 0;
+    bool done = !valid || sc.nNodes == 0;
+
+#define PG_PUSH(v) do { int v_ = (v); if (sp < PG_STACK_LDS) ldsStack[sp][tid] = v_; else spill[sp - PG_STACK_LDS] = v_; ++sp; } while (0)
+#define PG_POP_OR_DONE() do { if (sp == 0) done = true; else { --sp; cur = (sp < PG_STACK_LDS) ? ldsStack[sp][tid] : spill[sp - PG_STACK_LDS]; } } while (0)
+
+    while (__any(!done)) {
+        // ---- phase 1: descend through interior nodes until this lane holds a leaf
+        leafN = 0;
+        while (!done && leafN == 0) {
+            const float4 n0 = sc.nodes[2 * cur], n1 = sc.nodes[2 * cur + 1];
+            ++nodeVisits;
+            if (slab_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, o, invDir, nx, ny, nz, tMax)) {
+                const int off = __float_as_int(n1.z);
+                const uint32_t meta = __float_as_uint(n1.w);
+                const int np = meta & 0xffff;
+                if (np > 0) { leafOff = off; leafN = np; }
+                else {
+                    const int axis = (meta >> 16) & 0xff;
+                    const bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);
+                    if (neg) { PG_PUSH(cur + 1); cur = off; }
+                    else { PG_PUSH(off); cur = cur + 1; }
+                }
+            } else PG_POP_OR_DONE();
+        }
+        // ---- phase 2: test the leaf's triangles in order
+        if (leafN > 0) {
+            for (int k = 0; k < leafN; ++k) {
+                const int prim = leafOff + k;
+                const float4 a = sc.tris[3 * prim], b = sc.tris[3 * prim + 1], c = sc.tris[3 * prim + 2];
+                ++triTests;
+                float t, b0, b1, b2;
+                if (tri_test(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), o, d, tMax, t, b0, b1, b2) &&
+                    !(__float_as_uint(a.w) & PG_TRI_BOGUS)) {
+                    if (ANYHIT) { hitPrim = prim; done = true; break; }
+                    hitPrim = prim; tMax = t; hb0 = b0; hb1 = b1; hb2 = b2;  // primitive.cpp:123: r.tMax = tHit
+                }
+            }
+            if (!done) PG_POP_OR_DONE();
+        }
+    }
+#undef PG_PUSH
+#undef PG_POP_OR_DONE
+    if (valid) {
+        if (ANYHIT) occluded[i] = hitPrim >= 0 ? 1 : 0;
+        else {
+            hits[i] = make_float4(__int_as_float(hitPrim), hb0, hb1, hb2);
+            if (tOut) tOut[i] = tMax;
+        }
+    }
+    unsigned long long nv = wave_sum(nodeVisits), nt = wave_sum(triTests);
+    if (lane_id() == 0 && cn) {
+        atomicAdd(&cn->node_visits, nv);
+        atomicAdd(&cn->tri_tests, nt);
+    }
+}
+
+void launch_closest(const DScene &sc, RayQueue q, int maxCount, float4 *hits, float *tOut, float *, TraceCounters *cn, hipStream_t s) {
+    int nblk = (maxCount + PG_BLOCK - 1) / PG_BLOCK;
+    nblk = ((nblk + 7) / 8) * 8;
+    if (nblk == 0) return;
+    hipLaunchKernelGGL(k_traverse<false>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, q, hits, tOut, (int *)nullptr, cn);
+}
+void launch_anyhit(const DScene &sc, RayQueue q, int maxCount, int *occluded, TraceCounters *cn, hipStream_t s) {
+    int nblk = (maxCount + PG_BLOCK - 1) / PG_BLOCK;
+    nblk = ((nblk + 7) / 8) * 8;
+    if (nblk == 0) return;
+    hipLaunchKernelGGL(k_traverse<true>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, q, (float4 *)nullptr, (float *)nullptr, occluded, cn);
+}
+
+// ===========================================================================
+// Sampler
+// ===========================================================================
+PG_DEV uint64_t inverse_radical_inverse(uint32_t base, uint64_t inverse, int nDigits) {  // lowdiscrepancy.h:80-91
+    uint64_t index = 0;
+    for (int i = 0; i < nDigits; ++i) {
+        uint64_t digit = inverse % base;
+        inverse /= base;
+        index = index * base + digit;
+    }
+    return index;
+}
+PG_DEV int pmod(int a, int b) { int r = a - (a / b) * b; return (r < 0) ? r + b : r; }  // pbrt.h:314-317
+
+// HaltonSampler::GetIndexForSample, halton.cpp:96-117
+PG_DEV uint64_t halton_index(const PgRenderDesc &rd, int px, int py, uint64_t sampleNum) {
+    uint64_t offsetForCurrentPixel = 0;
+    if (rd.sample_stride > 1) {
+        int pm0 = pmod(px, 128), pm1 = pmod(py, 128);
+        uint64_t dimOffset0 = inverse_radical_inverse(2, pm0, rd.base_exponents[0]);
+        uint64_t dimOffset1 = inverse_radical_inverse(3, pm1, rd.base_exponents[1]);
+        offsetForCurrentPixel += dimOffset0 * (uint64_t)(rd.sample_stride / rd.base_scales[0]) * (uint64_t)rd.mult_inverse[0];
+        offsetForCurrentPixel += dimOffset1 * (uint64_t)(rd.sample_stride / rd.base_scales[1]) * (uint64_t)rd.mult_inverse[1];
+        offsetForCurrentPixel %= (uint64_t)rd.sample_stride;
+    }
+    return offsetForCurrentPixel + sampleNum * (uint64_t)rd.sample_stride;
+}
+// HaltonSampler::SampleDimension, halton.cpp:119-127
+PG_DEV float halton_sample(const DScene &sc, const PgRenderDesc &rd, uint64_t index, int dim) {
+    if (rd.sample_at_pixel_center && (dim == 0 || dim == 1)) return 0.5f;
+    if (dim == 0) return radical_inverse_base2(index >> rd.base_exponents[0]);
+    if (dim == 1) return radical_inverse(3, index / (uint64_t)rd.base_scales[1]);
+    if (dim >= sc.nPermDims) dim = sc.nPermDims - 1;  // host sizes the table from maxdepth; halton.h:71-76 aborts here
+    return scrambled_radical_inverse((uint32_t)sc.primes[dim], sc.perms + sc.permSums[dim], index);
+}
+
+// ===========================================================================
+// Camera ray generation: one lane per (pixel, sample) slot
+// ===========================================================================
+PG_DEV V3 xform_point(const float *m, V3 p) {  // transform.h:219-231
+    float x = p.x, y = p.y, z = p.z;
+    float xp = m[0] * x + m[1] * y + m[2] * z + m[3];
+    float yp = m[4] * x + m[5] * y + m[6] * z + m[7];
+    float zp = m[8] * x + m[9] * y + m[10] * z + m[11];
+    float wp = m[12] * x + m[13] * y + m[14] * z + m[15];
+    if (wp == 1) return mk(xp, yp, zp);
+    float inv = 1.f / wp;
+    return mk(inv * xp, inv * yp, inv * zp);
+}
+PG_DEV void xform_ray(const float *m, V3 &o, V3 &d, float &tMax) {  // transform.h:249-262,277-300
+    float x = o.x, y = o.y, z = o.z;
+    float xp = (m[0] * x + m[1] * y) + (m[2] * z + m[3]);
+    float yp = (m[4] * x + m[5] * y) + (m[6] * z + m[7]);
+    float zp = (m[8] * x + m[9] * y) + (m[10] * z + m[11]);
+    float wp = (m[12] * x + m[13] * y) + (m[14] * z + m[15]);
+    float xAbsSum = (fabsf(m[0] * x) + fabsf(m[1] * y) + fabsf(m[2] * z) + fabsf(m[3]));
+    float yAbsSum = (fabsf(m[4] * x) + fabsf(m[5] * y) + fabsf(m[6] * z) + fabsf(m[7]));
+    float zAbsSum = (fabsf(m[8] * x) + fabsf(m[9] * y) + fabsf(m[10] * z) + fabsf(m[11]));
+    V3 oError = mk(xAbsSum, yAbsSum, zAbsSum) * pgamma(3);
+    V3 on;
+    if (wp == 1) on = mk(xp, yp, zp);
+    else { float inv = 1.f / wp; on = mk(inv * xp, inv * yp, inv * zp); }
+    float dx = d.x, dy = d.y, dz = d.z;
+    V3 dn = mk(m[0] * dx + m[1] * dy + m[2] * dz, m[4] * dx + m[5] * dy + m[6] * dz, m[8] * dx + m[9] * dy + m[10] * dz);
+    float lengthSquared = lensq(dn);
+    if (lengthSquared > 0) {
+        float dt = dot(vabs(dn), oError) / lengthSquared;
+        on = on + dn * dt;
+        tMax -= dt;
+    }
+    o = on; d = dn;
+}
+
+// slot -> (local tile, sample-in-batch, pixel-in-tile); a wave is 64 pixels of one tile for one sample
+PG_DEV bool slot_to_pixel(const RenderParams &rp, int slot, int &px, int &py, int &sn) {
+    int pix = slot & 255;
+    int rest = slot >> 8;
+    int sIdx = rest % rp.sCount;
+    int tileInBatch = rest / rp.sCount;
+    int local = rp.tileLocal0 + tileInBatch;
+    int t = rp.rd.tile_first + local * rp.rd.tile_step;
+    int tx = t % rp.nTilesX, ty = t / rp.nTilesX;
+    px = rp.rd.sample_bounds[0] + tx * 16 + (pix & 15);
+    py = rp.rd.sample_bounds[1] + ty * 16 + (pix >> 4);
+    sn = rp.s0 + sIdx;
+    if (px >= rp.rd.sample_bounds[2] || py >= rp.rd.sample_bounds[3]) return false;
+    // InsideExclusive(pixel, pixelBounds), integrator.cpp:273
+    return px >= rp.rd.pixel_bounds[0] && px < rp.rd.pixel_bounds[2] && py >= rp.rd.pixel_bounds[1] && py < rp.rd.pixel_bounds[3];
+}
+
+__global__ __launch_bounds__(PG_BLOCK) void k_generate(DScene sc, RenderParams rp, PathState st, RayQueue q) {
+    int slot = blockIdx.x * PG_BLOCK + threadIdx.x;
+    bool valid = slot < rp.capacity;
+    int px = 0, py = 0, sn = 0;
+    if (valid) valid = slot_to_pixel(rp, slot, px, py, sn);
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+    float tMax = PG_INF;
+    if (valid) {
+        const PgRenderDesc &rd = rp.rd;
+        uint64_t index = halton_index(rd, px, py, (uint64_t)sn);
+        // GetCameraSample, sampler.cpp:46-52: dims 0,1 film; 2 time; 3,4 lens
+        float u0 = halton_sample(sc, rd, index, 0), u1 = halton_sample(sc, rd, index, 1);
+        float pFilmX = (float)px + u0, pFilmY = (float)py + u1;
+        // GenerateRayDifferential, perspective.cpp:95-144 (differentials feed only texture filtering; textures are constant)
+        V3 pCamera = xform_point(rd.raster_to_camera, mk(pFilmX, pFilmY, 0));
+        d = normalize(mk(pCamera.x, pCamera.y, pCamera.z));
+        if (rd.lens_radius > 0) {
+            float l0 = halton_sample(sc, rd, index, 3), l1 = halton_sample(sc, rd, index, 4);
+            float lx, ly;
+            concentric_sample_disk(l0, l1, lx, ly);
+            lx = rd.lens_radius * lx; ly = rd.lens_radius * ly;
+            float ft = rd.focal_distance / d.z;
+            V3 pFocus = o + d * ft;
+            o = mk(lx, ly, 0);
+            d = normalize(pFocus - o);
+        }
+        xform_ray(rd.camera_to_world, o, d, tMax);
+        st.L[slot] = make_float4(0, 0, 0, pFilmX);
+        st.beta[slot] = make_float4(1, 1, 1, pFilmY);
+        st.meta[slot] = make_int4((int)(uint32_t)index, (int)(uint32_t)(index >> 32), 5, 0);
+    } else if (slot < rp.capacity) {
+        st.L[slot] = make_float4(0, 0, 0, 0);
+        st.meta[slot] = make_int4(0, 0, 0, PG_META_DONE | 0x40000);  // 0x40000: slot holds no sample
+    }
+    int pos = queue_push(q.count, valid);
+    if (valid) {
+        q.o[pos] = make_float4(o.x, o.y, o.z, tMax);
+        q.d[pos] = make_float4(d.x, d.y, d.z, __int_as_float(slot));
+    }
+}
+void launch_generate(const DScene &sc, const RenderParams &rp, PathState st, RayQueue q, hipStream_t s) {
+    int nblk = (rp.capacity + PG_BLOCK - 1) / PG_BLOCK;
+    hipLaunchKernelGGL(k_generate, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, q);
+}
+
+// ===========================================================================
+// Shading
+// ===========================================================================
+struct Isect { V3 p, pError, wo, n, dpdu; };
+
+PG_DEV V3 tri_normal(const Tri &t) {  // triangle.cpp:346-348
+    V3 n = normalize(cross(t.p0 - t.p2, t.p1 - t.p2));
+    if (t.flags & PG_TRI_FLIP_NORMAL) n = -n;
+    return n;
+}
+PG_DEV void load_uv(const DScene &sc, int prim, uint32_t flags, float uv[6]) {  // triangle.h:98-108
+    if (sc.uv && (flags & PG_TRI_HAS_UV)) { for (int k = 0; k < 6; ++k) uv[k] = sc.uv[6 * prim + k]; }
+    else { uv[0] = 0; uv[1] = 0; uv[2] = 1; uv[3] = 0; uv[4] = 1; uv[5] = 1; }
+}
+// The tail of Triangle::Intersect (triangle.cpp:293-348) for the surviving hit.
+PG_DEV Isect make_isect(const DScene &sc, int prim, const Tri &t, float b0, float b1, float b2, V3 rayD) {
+    Isect is;
+    float uv[6];
+    load_uv(sc, prim, t.flags, uv);
+    tri_dpdu(t.p0, t.p1, t.p2, uv, is.dpdu);
+    float xAbsSum = (fabsf(b0 * t.p0.x) + fabsf(b1 * t.p1.x) + fabsf(b2 * t.p2.x));
+    float yAbsSum = (fabsf(b0 * t.p0.y) + fabsf(b1 * t.p1.y) + fabsf(b2 * t.p2.y));
+    float zAbsSum = (fabsf(b0 * t.p0.z) + fabsf(b1 * t.p1.z) + fabsf(b2 * t.p2.z));
+    is.pError = mk(xAbsSum, yAbsSum, zAbsSum) * pgamma(7);
+    is.p = t.p0 * b0 + t.p1 * b1 + t.p2 * b2;
+    is.wo = normalize(-rayD);  // Interaction ctor, interaction.h:60
+    is.n = tri_normal(t);
+    return is;
+}
+
+// BSDF with a single LambertianReflection lobe (matte, sigma = 0): reflection.h:164-213
+struct Bsdf { V3 ns, ng, ss, ts; Spec R; int nBxDFs; };
+PG_DEV V3 world_to_local(const Bsdf &b, V3 v) { return mk(dot(v, b.ss), dot(v, b.ts), dot(v, b.ns)); }
+PG_DEV V3 local_to_world(const Bsdf &b, V3 v) {
+    return mk(b.ss.x * v.x + b.ts.x * v.y + b.ns.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ns.y * v.z,
+              b.ss.z * v.x + b.ts.z * v.y + b.ns.z * v.z);
+}
+PG_DEV Spec bsdf_f(const Bsdf &b, V3 woW, V3 wiW) {  // reflection.cpp:680-693 + :178-180
+    V3 wo = world_to_local(b, woW);
+    if (wo.z == 0) return sp(0);
+    bool reflect = dot(wiW, b.ng) * dot(woW, b.ng) > 0;
+    Spec f = sp(0);
+    if (b.nBxDFs && reflect) f = f + b.R * PG_INVPI;
+    return f;
+}
+PG_DEV float bsdf_pdf(const Bsdf &b, V3 woW, V3 wiW) {  // reflection.cpp:781-796 + :392-394
+    if (b.nBxDFs == 0) return 0.f;
+    V3 wo = world_to_local(b, woW), wi = world_to_local(b, wiW);
+    if (wo.z == 0) return 0.f;
+    float pdf = 0.f;
+    pdf += (wo.z * wi.z > 0) ? fabsf(wi.z) * PG_INVPI : 0;
+    return pdf / 1;
+}
+PG_DEV Spec bsdf_sample_f(const Bsdf &b, V3 woWorld, V3 &wiWorld, float u0, float u1, float &pdf) {  // reflection.cpp:714-779 + :383-390
+    int matchingComps = b.nBxDFs;
+    pdf = 0;
+    if (matchingComps == 0) return sp(0);
+    int comp = (int)floorf(u0 * matchingComps);
+    if (comp > matchingComps - 1) comp = matchingComps - 1;
+    float ur0 = pmin(u0 * matchingComps - comp, PG_ONE_MINUS_EPS);
+    V3 wo = world_to_local(b, woWorld);
+    if (wo.z == 0) return sp(0);
+    V3 wi = cosine_sample_hemisphere(ur0, u1);
+    if (wo.z < 0) wi.z *= -1;
+    pdf = (wo.z * wi.z > 0) ? fabsf(wi.z) * PG_INVPI : 0;
+    if (pdf == 0) return sp(0);
+    wiWorld = local_to_world(b, wi);
+    bool reflect = dot(wiWorld, b.ng) * dot(woWorld, b.ng) > 0;
+    Spec f = sp(0);
+    if (reflect) f = f + b.R * PG_INVPI;
+    return f;
+}
+
+// Triangle::Sample(u, pdf) + Shape::Sample(ref, u, pdf) + DiffuseAreaLight::Sample_Li
+// (triangle.cpp:582-607, shape.cpp:56-70, diffuse.cpp:68-81).
+struct LightSample { V3 p, n, pError; };
+PG_DEV Spec light_sample_li(const DScene &sc, const PgLight &light, V3 refp, float u0, float u1, V3 &wi, float &pdf, LightSample &ls) {
+    float su0 = sqrtf(u0);  // UniformSampleTriangle, sampling.cpp:154-157
+    float b0 = 1 - su0, b1 = u1 * su0;
+    Tri t = load_tri(sc, light.prim);
+    float b2 = (1 - b0 - b1);
+    ls.p = t.p0 * b0 + t.p1 * b1 + t.p2 * b2;
+    ls.n = normalize(cross(t.p1 - t.p0, t.p2 - t.p0));
+    if (t.flags & PG_TRI_FLIP_NORMAL) ls.n = ls.n * -1.f;
+    V3 pAbsSum = vabs(t.p0 * b0) + vabs(t.p1 * b1) + vabs(t.p2 * b2);
+    ls.pError = pAbsSum * pgamma(6);
+    pdf = 1 / light.area;
+    V3 w = ls.p - refp;
+    if (lensq(w) == 0) pdf = 0;
+    else {
+        w = normalize(w);
+        pdf *= lensq(refp - ls.p) / absdot(ls.n, -w);
+        if (isinf(pdf)) pdf = 0.f;
+    }
+    if (pdf == 0 || lensq(ls.p - refp) == 0) { pdf = 0; return sp(0); }
+    wi = normalize(ls.p - refp);
+    return (light.two_sided || dot(ls.n, -wi) > 0) ? sp3(light.L[0], light.L[1], light.L[2]) : sp(0);
+}
+
+// LightDistribution::Lookup (lightdistrib.cpp:68-82,135-149) -> table of one Distribution1D
+PG_DEV const float *light_distribution(const DScene &sc, V3 p) {
+    if (sc.lightStrategy != PG_LIGHTS_SPATIAL) return sc.distTable;
+    V3 o = p - mk(sc.bmin[0], sc.bmin[1], sc.bmin[2]);  // Bounds3::Offset, geometry.h:801-807
+    if (sc.bmax[0] > sc.bmin[0]) o.x /= sc.bmax[0] - sc.bmin[0];
+    if (sc.bmax[1] > sc.bmin[1]) o.y /= sc.bmax[1] - sc.bmin[1];
+    if (sc.bmax[2] > sc.bmin[2]) o.z /= sc.bmax[2] - sc.bmin[2];
+    int pi0 = (int)(o.x * sc.nVoxels[0]), pi1 = (int)(o.y * sc.nVoxels[1]), pi2 = (int)(o.z * sc.nVoxels[2]);
+    pi0 = pi0 < 0 ? 0 : (pi0 > sc.nVoxels[0] - 1 ? sc.nVoxels[0] - 1 : pi0);
+    pi1 = pi1 < 0 ? 0 : (pi1 > sc.nVoxels[1] - 1 ? sc.nVoxels[1] - 1 : pi1);
+    pi2 = pi2 < 0 ? 0 : (pi2 > sc.nVoxels[2] - 1 ? sc.nVoxels[2] - 1 : pi2);
+    size_t idx = ((size_t)pi2 * sc.nVoxels[1] + pi1) * sc.nVoxels[0] + pi0;
+    return sc.distTable + idx * (size_t)(2 * sc.nLights + 2);
+}
+// Distribution1D::SampleDiscrete, sampling.h:90-100 + FindInterval pbrt.h:403-415
+PG_DEV int sample_discrete(const float *tab, int n, float u, float &pdf) {
+    const float *func = tab, *cdf = tab + n;
+    float funcInt = tab[2 * n + 1];
+    int size = n + 1, first = 0, len = size;
+    while (len > 0) {
+        int half = len >> 1, middle = first + half;
+        if (cdf[middle] <= u) { first = middle + 1; len -= half + 1; }
+        else len = half;
+    }
+    int offset = first - 1;
+    offset = offset < 0 ? 0 : (offset > size - 2 ? size - 2 : offset);
+    pdf = (funcInt > 0) ? func[offset] / (funcInt * n) : 0;
+    return offset;
+}
+
+PG_DEV void spawn_ray(const Isect &is, V3 d, V3 &o) { o = offset_ray_origin(is.p, is.pError, is.n, d); }  // interaction.h:64-67
+
+__global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
+                                                     RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests) {
+    const int n = *qin.count;
+    const int i = blockIdx.x * PG_BLOCK + threadIdx.x;
+    const bool valid = i < n;
+    // outputs of this lane
+    bool pushNext = false, pushShadow = false, pushMis = false;
+    V3 nextO = mk(0, 0, 0), nextD = mk(0, 0, 0);
+    V3 shO = mk(0, 0, 0), shD = mk(0, 0, 0);
+    float shTMax = 0;
+    V3 misO = mk(0, 0, 0), misD = mk(0, 0, 0);
+    int slot = 0;
+    unsigned int nLightTests = 0;
+    float4 pdLight = make_float4(0, 0, 0, 0), pdMis = make_float4(0, 0, 0, 0), pdBeta = make_float4(0, 0, 0, 0);
+    int lightNum = -1;
+    if (valid) {
+        const float4 o4 = qin.o[i], d4 = qin.d[i], h4 = hits[i];
+        slot = __float_as_int(d4.w);
+        const V3 rayD = mk(d4.x, d4.y, d4.z);
+        const int prim = __float_as_int(h4.x);
+        const PgRenderDesc &rd = rp.rd;
+        float4 L4 = st.L[slot], B4 = st.beta[slot];
+        int4 meta = st.meta[slot];
+        Spec L = sp3(L4.x, L4.y, L4.z), beta = sp3(B4.x, B4.y, B4.z);
+        const uint64_t index = (uint64_t)(uint32_t)meta.x | ((uint64_t)(uint32_t)meta.y << 32);
+        int dim = meta.z;
+        int bounces = meta.w & 0xffff;
+        const bool specularBounce = (meta.w & PG_META_SPECULAR) != 0;
+        const bool found = prim >= 0;
+        Tri tri;
+        if (found) tri = load_tri(sc, prim);
+        // path.cpp:91-102 emitted light at the vertex
+        if ((bounces == 0 || specularBounce) && found && tri.light >= 0) {
+            const PgLight &l = sc.lights[tri.light];
+            V3 nrm = tri_normal(tri);
+            Spec Le = (l.two_sided || dot(nrm, -rayD) > 0) ? sp3(l.L[0], l.L[1], l.L[2]) : sp(0);
+            L = L + beta * Le;
+        } else if ((bounces == 0 || specularBounce) && found) L = L + beta * sp(0);
+        bool alive = found && bounces < rd.max_depth;  // path.cpp:104
+        int newFlags = 0;
+        if (alive) {
+            Isect is = make_isect(sc, prim, tri, h4.y, h4.z, h4.w, rayD);
+            const PgMaterial &m = sc.materials[tri.material];
+            if (m.type == PG_MAT_NONE) {  // path.cpp:107-113: skip over medium boundaries
+                spawn_ray(is, rayD, nextO);
+                nextD = rayD;
+                pushNext = true;
+            } else {
+                // MatteMaterial::ComputeScatteringFunctions (matte.cpp:45-62), BSDF ctor (reflection.h:167-172)
+                Bsdf bsdf;
+                bsdf.ns = is.n; bsdf.ng = is.n;
+                bsdf.ss = normalize(is.dpdu);
+                bsdf.ts = cross(bsdf.ns, bsdf.ss);
+                bsdf.R = sp3(m.kd[0] < 0 ? 0 : m.kd[0], m.kd[1] < 0 ? 0 : m.kd[1], m.kd[2] < 0 ? 0 : m.kd[2]);
+                bsdf.nBxDFs = is_black(bsdf.R) ? 0 : 1;
+                // ---- direct lighting: UniformSampleOneLight (integrator.cpp:85-106) + EstimateDirect set-up
+                if (bsdf.nBxDFs > 0 && sc.nLights > 0) {
+                    const float *tab = light_distribution(sc, is.p);
+                    float lightSelPdf;
+                    lightNum = sample_discrete(tab, sc.nLights, halton_sample(sc, rd, index, dim++), lightSelPdf);
+                    if (lightSelPdf != 0) {
+                        float uL0 = halton_sample(sc, rd, index, dim), uL1 = halton_sample(sc, rd, index, dim + 1);
+                        float uS0 = halton_sample(sc, rd, index, dim + 2), uS1 = halton_sample(sc, rd, index, dim + 3);
+                        dim += 4;
+                        const PgLight &light = sc.lights[lightNum];
+                        V3 wi = mk(0, 0, 0);
+                        float lightPdf = 0, scatteringPdf = 0;
+                        LightSample ls;
+                        Spec Li = light_sample_li(sc, light, is.p, uL0, uL1, wi, lightPdf, ls);
+                        if (lightPdf > 0 && !is_black(Li)) {
+                            Spec f = bsdf_f(bsdf, is.wo, wi) * absdot(wi, bsdf.ns);
+                            scatteringPdf = bsdf_pdf(bsdf, is.wo, wi);
+                            if (!is_black(f)) {
+                                // VisibilityTester: p0.SpawnRayTo(p1), interaction.h:73-78
+                                V3 origin = offset_ray_origin(is.p, is.pError, is.n, ls.p - is.p);
+                                V3 target = offset_ray_origin(ls.p, ls.pError, ls.n, origin - ls.p);
+                                shO = origin; shD = target - origin; shTMax = 1 - PG_SHADOW_EPS;
+                                pushShadow = true;
+                                float weight = power_heuristic(1, lightPdf, 1, scatteringPdf);
+                                Spec c = ((f * Li) * weight) / lightPdf;
+                                pdLight = make_float4(c.r, c.g, c.b, 0);
+                            }
+                        }
+                        // BSDF sampling half of MIS (integrator.cpp:164-212)
+                        V3 wi2 = wi;
+                        float sPdf2;
+                        Spec f2 = bsdf_sample_f(bsdf, is.wo, wi2, uS0, uS1, sPdf2);
+                        f2 = f2 * absdot(wi2, bsdf.ns);
+                        if (!is_black(f2) && sPdf2 > 0) {
+                            // light.Pdf_Li -> Shape::Pdf(ref, wi): intersect the light's own triangle (shape.cpp:72-87)
+                            V3 ro;
+                            spawn_ray(is, wi2, ro);
+                            Tri lt = load_tri(sc, light.prim);
+                            float t, lb0, lb1, lb2;
+                            ++nLightTests;
+                            float lightPdf2 = 0;
+                            if (tri_test(lt.p0, lt.p1, lt.p2, ro, wi2, PG_INF, t, lb0, lb1, lb2) && !(lt.flags & PG_TRI_BOGUS)) {
+                                V3 lp = lt.p0 * lb0 + lt.p1 * lb1 + lt.p2 * lb2;
+                                V3 ln = normalize(cross(lt.p0 - lt.p2, lt.p1 - lt.p2));
+                                float pdf = lensq(is.p - lp) / (absdot(ln, -wi2) * light.area);
+                                if (isinf(pdf)) pdf = 0.f;
+                                lightPdf2 = pdf;
+                            }
+                            if (lightPdf2 != 0) {
+                                float weight2 = power_heuristic(1, sPdf2, 1, lightPdf2);
+                                misO = ro; misD = wi2;
+                                pushMis = true;
+                                pdMis = make_float4(f2.r, f2.g, f2.b, sPdf2);
+                                pdBeta.w = weight2;
+                            }
+                        }
+                        pdLight.w = lightSelPdf;
+                        pdBeta.x = beta.r; pdBeta.y = beta.g; pdBeta.z = beta.b;
+                    }
+                }
+                // ---- sample the BSDF for the next direction (path.cpp:130-150)
+                V3 wo = -rayD, wi;
+                float pdf;
+                float u0 = halton_sample(sc, rd, index, dim), u1 = halton_sample(sc, rd, index, dim + 1);
+                dim += 2;
+                Spec f = bsdf_sample_f(bsdf, wo, wi, u0, u1, pdf);
+                if (!(is_black(f) || pdf == 0.f)) {
+                    beta = beta * ((f * absdot(wi, bsdf.ns)) / pdf);
+                    spawn_ray(is, wi, nextO);
+                    nextD = wi;
+                    pushNext = true;
+                    // Russian roulette, path.cpp:176-184 (etaScale == 1: no transmission in the closed set)
+                    Spec rrBeta = beta * 1.f;
+                    if (max_component(rrBeta) < rd.rr_threshold && bounces > 3) {
+                        float qq = pmax(.05f, 1 - max_component(rrBeta));
+                        if (halton_sample(sc, rd, index, dim++) < qq) pushNext = false;
+                        else beta = beta / (1 - qq);
+                    }
+                }
+                bounces += 1;
+            }
+        }
+        st.L[slot] = make_float4(L.r, L.g, L.b, L4.w);
+        st.beta[slot] = make_float4(beta.r, beta.g, beta.b, B4.w);
+        st.meta[slot] = make_int4(meta.x, meta.y, dim, bounces | newFlags);
+    }
+    int posNext = queue_push(qnext.count, pushNext);
+    int posShadow = queue_push(qshadow.count, pushShadow);
+    int posMis = queue_push(qmis.count, pushMis);
+    if (pushNext) {
+        qnext.o[posNext] = make_float4(nextO.x, nextO.y, nextO.z, PG_INF);
+        qnext.d[posNext] = make_float4(nextD.x, nextD.y, nextD.z, __int_as_float(slot));
+    }
+    if (pushShadow) {
+        qshadow.o[posShadow] = make_float4(shO.x, shO.y, shO.z, shTMax);
+        qshadow.d[posShadow] = make_float4(shD.x, shD.y, shD.z, __int_as_float(slot));
+    }
+    if (pushMis) {
+        qmis.o[posMis] = make_float4(misO.x, misO.y, misO.z, PG_INF);
+        qmis.d[posMis] = make_float4(misD.x, misD.y, misD.z, __int_as_float(slot));
+    }
+    if (valid) {
+        st.pdInfo[slot] = make_int4(posShadow, posMis, lightNum, 0);
+        if (pushShadow || pushMis) {
+            st.pdLight[slot] = pdLight;
+            st.pdMis[slot] = pdMis;
+            st.pdBeta[slot] = pdBeta;
+        }
+    }
+    unsigned long long nl = wave_sum(nLightTests);
+    if (lane_id() == 0 && nl) atomicAdd(lightTriTests, nl);
+}
+void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQueue qin, const float4 *hits, RayQueue qnext,
+                  RayQueue qshadow, RayQueue qmis, int maxCount, unsigned long long *lightTriTests, hipStream_t s) {
+    int nblk = (maxCount + PG_BLOCK - 1) / PG_BLOCK;
+    if (nblk == 0) return;
+    hipLaunchKernelGGL(k_shade, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests);
+}
+
+// EstimateDirect's two "Add ... contribution" steps (integrator.cpp:143-161, 196-212) and
+// L += beta * Ld / lightPdf (integrator.cpp:104, path.cpp:122-126), once both rays are back.
+__global__ __launch_bounds__(PG_BLOCK) void k_resolve(DScene sc, PathState st, RayQueue qin, RayQueue qmis, const int *__restrict__ occluded,
+                                                       const float4 *__restrict__ misHits) {
+    const int n = *qin.count;
+    const int i = blockIdx.x * PG_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int slot = __float_as_int(qin.d[i].w);
+    const int4 info = st.pdInfo[slot];
+    if (info.x < 0 && info.y < 0) return;  // Ld == 0: L += beta * 0 leaves L unchanged
+    const float4 pl = st.pdLight[slot], pm = st.pdMis[slot], pb = st.pdBeta[slot];
+    Spec Ld = sp(0);
+    if (info.x >= 0 && !occluded[info.x]) Ld = Ld + sp3(pl.x, pl.y, pl.z);
+    if (info.y >= 0) {
+        const float4 h = misHits[info.y];
+        const int prim = __float_as_int(h.x);
+        if (prim >= 0) {
+            Tri t = load_tri(sc, prim);
+            if (t.light == info.z) {  // lightIsect.primitive->GetAreaLight() == &light
+                const PgLight &l = sc.lights[t.light];
+                const float4 d4 = qmis.d[info.y];
+                V3 wi = mk(d4.x, d4.y, d4.z);
+                V3 nrm = tri_normal(t);
+                Spec Li = (l.two_sided || dot(nrm, -wi) > 0) ? sp3(l.L[0], l.L[1], l.L[2]) : sp(0);
+                if (!is_black(Li)) Ld = Ld + ((((sp3(pm.x, pm.y, pm.z) * Li) * sp(1.f)) * pb.w) / pm.w);
+            }
+        }
+    }
+    float4 L4 = st.L[slot];
+    Spec L = sp3(L4.x, L4.y, L4.z) + sp3(pb.x, pb.y, pb.z) * (Ld / pl.w);
+    st.L[slot] = make_float4(L.r, L.g, L.b, L4.w);
+}
+void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis, const int *occluded, const float4 *misHits, int maxCount,
+                    hipStream_t s) {
+    int nblk = (maxCount + PG_BLOCK - 1) / PG_BLOCK;
+    if (nblk == 0) return;
+    hipLaunchKernelGGL(k_resolve, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, qin, qmis, occluded, misHits);
+}
+
+// ===========================================================================
+// Film: one lane per pixel of the batch's tiles; samples are added in sample
+// order so a pixel's sum is the reference's (integrator.cpp:276-325).
+// ===========================================================================
+__global__ __launch_bounds__(PG_BLOCK) void k_film(RenderParams rp, PathState st, PgFilmPixel *film, PgStraySample *strays, int maxStrays,
+                                                    int *nStrays) {
+    const int tileInBatch = blockIdx.x;
+    const int pix = threadIdx.x;
+    const PgRenderDesc &rd = rp.rd;
+    int px, py, sn;
+    const int slot0 = (tileInBatch * rp.sCount) * 256 + pix;
+    if (!slot_to_pixel(rp, slot0, px, py, sn)) return;
+    const int local = rp.tileLocal0 + tileInBatch;
+    const int t = rd.tile_first + local * rd.tile_step;
+    const int tx = t % rp.nTilesX, ty = t / rp.nTilesX;
+    const int x0 = rd.sample_bounds[0] + tx * 16, y0 = rd.sample_bounds[1] + ty * 16;
+    const int x1 = min(x0 + 16, rd.sample_bounds[2]), y1 = min(y0 + 16, rd.sample_bounds[3]);
+    const float frx = rd.filter_radius[0], fry = rd.filter_radius[1];
+    // FilmTile pixel bounds, film.cpp:95-106
+    const int tp0x = max((int)ceilf((float)x0 - 0.5f - frx), rd.cropped_pixel_bounds[0]);
+    const int tp0y = max((int)ceilf((float)y0 - 0.5f - fry), rd.cropped_pixel_bounds[1]);
+    const int tp1x = min((int)floorf((float)x1 - 0.5f + frx) + 1, rd.cropped_pixel_bounds[2]);
+    const int tp1y = min((int)floorf((float)y1 - 0.5f + fry) + 1, rd.cropped_pixel_bounds[3]);
+    PgFilmPixel *fp = &film[(size_t)local * 256 + pix];
+    float r = fp->rgb[0], g = fp->rgb[1], b = fp->rgb[2], w = fp->weight;
+    for (int sIdx = 0; sIdx < rp.sCount; ++sIdx) {
+        const int slot = (tileInBatch * rp.sCount + sIdx) * 256 + pix;
+        const float4 L4 = st.L[slot];
+        const float pFilmX = L4.w, pFilmY = st.beta[slot].w;
+        Spec L = sp3(L4.x, L4.y, L4.z);
+        // integrator.cpp:294-315
+        if (isnan(L.r) || isnan(L.g) || isnan(L.b)) L = sp(0);
+        else if ((double)lum(L) < -1e-5) L = sp(0);
+        else if (isinf(lum(L))) L = sp(0);
+        // FilmTile::AddSample, film.h:121-161; box filter => every filterTable entry is 1, sampleWeight = rayWeight = 1
+        if (lum(L) > rd.max_sample_luminance) L = L * (rd.max_sample_luminance / lum(L));
+        const float dx = pFilmX - 0.5f, dy = pFilmY - 0.5f;
+        const int p0x = max((int)ceilf(dx - frx), tp0x), p0y = max((int)ceilf(dy - fry), tp0y);
+        const int p1x = min((int)floorf(dx + frx) + 1, tp1x), p1y = min((int)floorf(dy + fry) + 1, tp1y);
+        Spec c = (L * 1.f) * 1.f;
+        for (int y = p0y; y < p1y; ++y)
+            for (int x = p0x; x < p1x; ++x) {
+                if (x == px && y == py) { r += c.r; g += c.g; b += c.b; w += 1.f; }
+                else {
+                    int k = atomicAdd(nStrays, 1);
+                    if (k < maxStrays) {
+                        PgStraySample s;
+                        s.px = x; s.py = y; s.src_px = px; s.src_py = py;
+                        s.rgb[0] = c.r; s.rgb[1] = c.g; s.rgb[2] = c.b; s.weight = 1.f;
+                        strays[k] = s;
+                    }
+                }
+            }
+    }
+    fp->rgb[0] = r; fp->rgb[1] = g; fp->rgb[2] = b; fp->weight = w;
+}
+void launch_film(const RenderParams &rp, PathState st, PgFilmPixel *film, PgStraySample *strays, int maxStrays, int *nStrays,
+                 hipStream_t s) {
+    if (rp.nTilesBatch == 0) return;
+    hipLaunchKernelGGL(k_film, dim3(rp.nTilesBatch), dim3(PG_BLOCK), 0, s, rp, st, film, strays, maxStrays, nStrays);
+}
+
+// ===========================================================================
+// SpatialLightDistribution::ComputeDistribution for every voxel up front
+// (lightdistrib.cpp:232-300).  The reference fills voxels lazily through a
+// hash table; the distribution is a pure function of the voxel, so a dense
+// table holds the same values.  One lane per voxel.
+// ===========================================================================
+__global__ __launch_bounds__(PG_BLOCK) void k_light_tables(DScene sc, float *table, int nDistributions) {
+    const int v = blockIdx.x * PG_BLOCK + threadIdx.x;
+    if (v >= nDistributions) return;
+    const int nl = sc.nLights;
+    float *func = table + (size_t)v * (2 * nl + 2), *cdf = func + nl;
+    int pi0 = v % sc.nVoxels[0], pi1 = (v / sc.nVoxels[0]) % sc.nVoxels[1], pi2 = v / (sc.nVoxels[0] * sc.nVoxels[1]);
+    V3 p0 = mk((float)pi0 / (float)sc.nVoxels[0], (float)pi1 / (float)sc.nVoxels[1], (float)pi2 / (float)sc.nVoxels[2]);
+    V3 p1 = mk((float)(pi0 + 1) / (float)sc.nVoxels[0], (float)(pi1 + 1) / (float)sc.nVoxels[1], (float)(pi2 + 1) / (float)sc.nVoxels[2]);
+    V3 a = mk(plerp(p0.x, sc.bmin[0], sc.bmax[0]), plerp(p0.y, sc.bmin[1], sc.bmax[1]), plerp(p0.z, sc.bmin[2], sc.bmax[2]));
+    V3 b = mk(plerp(p1.x, sc.bmin[0], sc.bmax[0]), plerp(p1.y, sc.bmin[1], sc.bmax[1]), plerp(p1.z, sc.bmin[2], sc.bmax[2]));
+    V3 vmin = mk(pmin(a.x, b.x), pmin(a.y, b.y), pmin(a.z, b.z)), vmax = mk(pmax(a.x, b.x), pmax(a.y, b.y), pmax(a.z, b.z));
+    for (int j = 0; j < nl; ++j) func[j] = 0;
+    const int nSamples = 128;
+    for (int i = 0; i < nSamples; ++i) {
+        V3 t = mk(radical_inverse_base2(i), radical_inverse(3, i), radical_inverse(5, i));
+        V3 po = mk(plerp(t.x, vmin.x, vmax.x), plerp(t.y, vmin.y, vmax.y), plerp(t.z, vmin.z, vmax.z));
+        float u0 = radical_inverse(7, i), u1 = radical_inverse(11, i);
+        for (int j = 0; j < nl; ++j) {
+            float pdf;
+            V3 wi;
+            LightSample ls;
+            Spec Li = light_sample_li(sc, sc.lights[j], po, u0, u1, wi, pdf, ls);
+            if (pdf > 0) func[j] += lum(Li) / pdf;
+        }
+    }
+    float sumContrib = 0;
+    for (int j = 0; j < nl; ++j) sumContrib = sumContrib + func[j];
+    float avgContrib = sumContrib / (float)((size_t)nSamples * (size_t)nl);
+    float minContrib = (avgContrib > 0) ? (float)(.001 * (double)avgContrib) : 1.f;
+    for (int j = 0; j < nl; ++j) func[j] = pmax(func[j], minContrib);
+    // Distribution1D ctor, sampling.h:57-70
+    cdf[0] = 0;
+    for (int i = 1; i < nl + 1; ++i) cdf[i] = cdf[i - 1] + func[i - 1] / nl;
+    float funcInt = cdf[nl];
+    if (funcInt == 0) { for (int i = 1; i < nl + 1; ++i) cdf[i] = (float)i / (float)nl; }
+    else { for (int i = 1; i < nl + 1; ++i) cdf[i] /= funcInt; }
+    func[2 * nl + 1] = funcInt;
+}
+void launch_light_tables(const DScene &sc, float *table, int nDistributions, hipStream_t s) {
+    int nblk = (nDistributions + PG_BLOCK - 1) / PG_BLOCK;
+    hipLaunchKernelGGL(k_light_tables, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, table, nDistributions);
+}
+
