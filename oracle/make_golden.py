@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/: small scenes rendered by the UNMODIFIED reference binary
+(oracle/_ref/pbrt_oracle, built from /root/reference by Makefile.ref) plus its own ray statistics.
+
+Run in the build container (needs /root/reference); the outputs are committed so the GPU box,
+which has no /root/reference, can still check against real reference output.
+"""
+import json
+import os
+import re
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, os.path.join(ROOT, "scenes"))
+import gen_synthetic  # noqa: E402
+
+CORNELL = open(os.path.join(ROOT, "scenes", "cornell.pbrt")).read()
+
+
+def cornell(xres, yres, spp, extra_film="", integrator='Integrator "path" "integer maxdepth" [ 5 ]', world_edit=None):
+    s = CORNELL
+    s = s.replace('"integer xresolution" [ 512 ] "integer yresolution" [ 512 ]',
+                  f'"integer xresolution" [ {xres} ] "integer yresolution" [ {yres} ] {extra_film}')
+    s = s.replace('"integer pixelsamples" [ 256 ]', f'"integer pixelsamples" [ {spp} ]')
+    s = s.replace('Integrator "path" "integer maxdepth" [ 5 ]', integrator)
+    if world_edit:
+        s = world_edit(s)
+    return s
+
+
+SCENES = {
+    # plain Cornell, tile-aligned and not
+    "cornell_32": cornell(32, 32, 8),
+    "cornell_40x24": cornell(40, 24, 4),
+    # crop window + non-default light strategies + depth variants (RR kicks in after 4 bounces)
+    "cornell_crop": cornell(48, 48, 4, extra_film='"float cropwindow" [ 0.25 0.8 0.1 0.6 ]'),
+    "cornell_uniform": cornell(24, 24, 4, integrator='Integrator "path" "integer maxdepth" [ 3 ] "string lightsamplestrategy" "uniform"'),
+    "cornell_power": cornell(24, 24, 4, integrator='Integrator "path" "integer maxdepth" [ 8 ] "string lightsamplestrategy" "power"'),
+    "cornell_depth1": cornell(24, 24, 4, integrator='Integrator "path" "integer maxdepth" [ 1 ]'),
+    "cornell_rr": cornell(24, 24, 8, integrator='Integrator "path" "integer maxdepth" [ 12 ] "float rrthreshold" [ 0.5 ]'),
+    # two-sided light, reversed orientation, transforms, black material, scaled light, maxsampleluminance, film scale
+    "cornell_twosided": cornell(24, 24, 4, world_edit=lambda s: s.replace('"rgb L" [ 17 12 4 ]', '"rgb L" [ 17 12 4 ] "bool twosided" "true" "rgb scale" [ 0.5 0.5 2 ]')),
+    "cornell_reverse": cornell(24, 24, 4, world_edit=lambda s: s.replace("# short box", "ReverseOrientation\n# short box")),
+    "cornell_xform": cornell(24, 24, 4, world_edit=lambda s: s.replace("# tall box", "Translate 30 0 -20\nRotate 15 0 1 0\nScale 1 0.8 -1\n# tall box")),
+    "cornell_black": cornell(24, 24, 4, world_edit=lambda s: s.replace('Material "matte" "rgb Kd" [ 0.65 0.05 0.05 ]', 'Material "matte" "rgb Kd" [ 0 0 0 ]')),
+    "cornell_filmopts": cornell(24, 24, 8, extra_film='"float scale" [ 1.5 ] "float maxsampleluminance" [ 2.0 ]'),
+    "cornell_center": cornell(20, 20, 4).replace('Sampler "halton"', 'Sampler "halton" "bool samplepixelcenter" "true"'),
+    "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
+}
+
+
+def run(name, scene_path):
+    ref = os.path.join(HERE, "_ref", "pbrt_oracle")
+    out = os.path.join(GOLD, name + ".pfm")
+    txt = subprocess.run([ref, "--nthreads", "4", "--outfile", out, scene_path], capture_output=True, text=True, check=True).stdout
+    g = lambda pat: int(re.search(pat, txt).group(1))
+    stats = {"camera_rays": g(r"Camera rays traced\s+(\d+)"),
+             "closest_rays": g(r"Regular ray intersection tests\s+(\d+)"),
+             "shadow_rays": g(r"Shadow ray intersection tests\s+(\d+)"),
+             "tri_tests": g(r"Ray-triangle intersection tests\s+\d+ /\s+(\d+)")}
+    json.dump(stats, open(os.path.join(GOLD, name + ".json"), "w"))
+    print(name, stats)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    for name, text in SCENES.items():
+        p = os.path.join(GOLD, name + ".pbrt")
+        open(p, "w").write(text)
+        run(name, p)
+    # small synthetic heightfield (3 042 + 12 triangles): SAH BVH with real depth
+    p = os.path.join(GOLD, "synthetic_n40.pbrt")
+    gen_synthetic.write_scene(p, n=40, xres=48, yres=27, spp=4, filename="synthetic_n40.pfm")
+    run("synthetic_n40", p)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,45 @@
+import glob
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "scenes"))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    """The product package; host library built on demand (g++, seconds)."""
+    from __graft_entry__ import PKG_DIR, load_package
+    if not os.path.exists(os.path.join(PKG_DIR, "libpbrt_host.so")):
+        subprocess.check_call(["make", "-C", PKG_DIR, "host"])
+    return load_package()
+
+
+@pytest.fixture(scope="session")
+def oracle(pkg):
+    """The CPU restatement (test infrastructure)."""
+    from oracle import oracle as o
+    o.lib()
+    return o
+
+
+def golden_names():
+    return sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLD, "*.json")))
+
+
+@pytest.fixture(scope="session")
+def gpu(pkg):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    pkg.gpu_lib()  # raises if libpbrt_gpu.so is missing -- never a silent fallback
+    return pkg

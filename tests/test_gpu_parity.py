@@ -1,0 +1,219 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle, the reference's golden images and the
+reference's own test vectors.  Bars: bit-exact for hits / indices / counts of the traversal kernels; per-pixel
+|delta| <= 1e-4 * max(1, |ref|) for images (BASELINE.json's tolerance; the only non-bit-exact inputs are libm
+sin/cos in ConcentricSampleDisk)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, golden_names
+from kat_util import jittered_sphere  # noqa: F401
+from test_reference_kats import sphere_scene, watertight_rays
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def rel_err(img, ref):
+    return np.abs(img - ref) / np.maximum(1.0, np.abs(ref))
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_images(gpu, name):
+    scene = gpu.HostScene(os.path.join(GOLD, name + ".pbrt"))
+    img, cn = gpu.render_scene(scene)
+    ref = gpu.read_pfm(os.path.join(GOLD, name + ".pfm"))
+    err = rel_err(img, ref)
+    assert err.max() <= TOL, f"max rel err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+    # nearly every pixel is bit-identical; the rest differ in the last ulps only
+    assert (err.max(axis=2) > 0).mean() < 0.25
+    stats = json.load(open(os.path.join(GOLD, name + ".json")))
+    assert cn["camera_rays"] == stats["camera_rays"]
+    for k in ("closest_rays", "shadow_rays", "tri_tests"):  # a 1-ulp direction change may add/remove a handful of rays
+        assert abs(cn[k] - stats[k]) <= max(4, 2e-3 * stats[k]), (k, cn[k], stats[k])
+
+
+@pytest.mark.parametrize("name", ["cornell_32", "cornell_crop", "synthetic_n40", "cornell_lens"])
+def test_film_buffers_vs_oracle(gpu, oracle, name):
+    scene = gpu.HostScene(os.path.join(GOLD, name + ".pbrt"))
+    gs = gpu.GpuScene(scene.desc)
+    rd = scene.render_desc()
+    film, strays = gs.render(rd)
+    ofilm, ostrays, _ = oracle.render(scene.desc, rd)
+    assert np.array_equal(film["weight"], ofilm["weight"])
+    spp = rd.spp
+    assert np.abs(film["rgb"] - ofilm["rgb"]).max() <= TOL * spp * max(1.0, np.abs(ofilm["rgb"]).max() / spp)
+    key = lambda s: np.lexsort((s["src_px"], s["src_py"], s["px"], s["py"]))
+    a, b = strays[key(strays)], ostrays[key(ostrays)]
+    assert len(a) == len(b)
+    for f in ("px", "py", "src_px", "src_py", "weight"):
+        assert np.array_equal(a[f], b[f]), f
+    assert np.abs(a["rgb"] - b["rgb"]).max() <= TOL * max(1.0, np.abs(b["rgb"]).max()) if len(a) else True
+    gs.close()
+
+
+def random_rays(scene, n, seed):
+    rng = np.random.default_rng(seed)
+    nodes = scene.nodes()
+    lo, hi = nodes["bmin"][0], nodes["bmax"][0]
+    ext = hi - lo
+    o = (lo - 0.2 * ext + 1.4 * ext * rng.random((n, 3))).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    # axis-parallel and single-zero-component directions: invDir = +-inf paths of Bounds3::IntersectP
+    d[: n // 20, 0] = 0
+    d[n // 20: n // 10, 1:] = 0
+    d[n // 10: n // 8] *= np.float32(1e-3)
+    return o, d
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 256, 257, 10000])
+def test_intersect_bit_exact(gpu, oracle, n):
+    scene = gpu.HostScene(os.path.join(GOLD, "synthetic_n40.pbrt"))
+    gs = gpu.GpuScene(scene.desc)
+    o, d = random_rays(scene, n, 7 + n)
+    tmax = np.full(n, np.inf, np.float32)
+    tmax[::7] = 0.75
+    gs.counters_reset()
+    prim, t, bary = gs.intersect(o, d, tmax)
+    oprim, ot, obary, ocn = oracle.intersect(scene.desc, o, d, tmax)
+    assert np.array_equal(prim, oprim)
+    assert np.array_equal(t, ot) and np.array_equal(bary, obary)
+    cn = gs.counters()
+    assert cn["closest_node_visits"] == ocn["node_visits"] and cn["closest_tri_tests"] == ocn["tri_tests"]
+    occ = gs.intersect_p(o, d, tmax)
+    oocc, ocn2 = oracle.intersect_p(scene.desc, o, d, tmax)
+    assert np.array_equal(occ, oocc)
+    cn = gs.counters()
+    assert cn["shadow_node_visits"] == ocn2["node_visits"] and cn["shadow_tri_tests"] == ocn2["tri_tests"]
+    if n:
+        assert (prim >= 0).any() and (prim < 0).any()
+        assert ((prim >= 0) == (occ == 1)).all()  # closest-hit and any-hit agree on hit/miss
+    gs.close()
+
+
+def test_watertight_and_degenerate(gpu, oracle):
+    """Triangle.Watertight (tests/shapes.cpp:28-129) through the BVH kernel, plus zero-area triangles
+    (Triangle::Intersect's 'bogus intersection' rejection, triangle.cpp:309-317) and tMax edge cases."""
+    verts, idx = jittered_sphere()
+    scene = gpu.HostScene(text=sphere_scene(verts, idx))
+    gs = gpu.GpuScene(scene.desc)
+    o, d = watertight_rays(verts, 20000)
+    inf = np.full(len(o), np.inf, np.float32)
+    prim, t, bary = gs.intersect(o, d, inf)
+    assert (prim >= 0).all()
+    oprim, ot, obary, _ = oracle.intersect(scene.desc, o, d, inf)
+    assert np.array_equal(prim, oprim) and np.array_equal(t, ot) and np.array_equal(bary, obary)
+    zero = np.zeros(len(o), np.float32)
+    assert (gs.intersect(o, d, zero)[0] < 0).all() and not gs.intersect_p(o, d, zero).any()
+    gs.close()
+    degenerate = ('Film "image" "integer xresolution" [8] "integer yresolution" [8] "string filename" "d.pfm"\nWorldBegin\n'
+                  'Shape "trianglemesh" "integer indices" [ 0 1 2  3 4 5 ] "point P" [ 0 0 1  1 1 1  2 2 1   -1 -1 2  1 -1 2  0 1 2 ]\nWorldEnd\n')
+    scene = gpu.HostScene(text=degenerate)
+    gs = gpu.GpuScene(scene.desc)
+    o = np.array([[1, 1, 0], [0, 0, 0], [0.5, 0.5, 0]], np.float32)
+    d = np.array([[0, 0, 1]] * 3, np.float32)
+    prim, t, _ = gs.intersect(o, d, np.full(3, np.inf, np.float32))
+    oprim, ot, _, _ = oracle.intersect(scene.desc, o, d, np.full(3, np.inf, np.float32))
+    assert np.array_equal(prim, oprim) and np.array_equal(t, ot)
+    assert (t[prim >= 0] == 2).all()  # only the real triangle at z = 2 is ever hit
+    gs.close()
+
+
+def test_sharded_render_equals_whole(gpu):
+    scene = gpu.HostScene(os.path.join(GOLD, "cornell_40x24.pbrt"))
+    gs = gpu.GpuScene(scene.desc)
+    whole, _ = gpu.render_scene(scene)
+    for world in (2, 3, 5):
+        scene.film_clear()
+        for r in range(world):
+            rd = scene.render_desc(r, world)
+            film, strays = gs.render(rd)
+            scene.film_merge(rd, film, strays)
+        assert np.array_equal(scene.film_image(), whole), world
+    gs.close()
+
+
+def test_device_buffers_and_determinism(gpu):
+    import torch
+    scene = gpu.HostScene(os.path.join(GOLD, "synthetic_n40.pbrt"))
+    gs = gpu.GpuScene(scene.desc)
+    rd = scene.render_desc()
+    film_h, strays_h = gs.render(rd)
+    n = gs.tile_count(rd)
+    film = torch.zeros((n * 256, 4), device="cuda")
+    strays = torch.zeros((4096, 8), dtype=torch.int32, device="cuda")
+    ns = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for _ in range(2):
+        gs.render_device(rd, film.data_ptr(), strays.data_ptr(), 4096, ns.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(film.cpu().numpy().reshape(-1), film_h.view(np.float32).reshape(-1))
+        assert int(ns.item()) == len(strays_h)
+    # small batches (several sample passes and tile groups) give the same film
+    os.environ["PG_BATCH_PATHS"] = "1024"
+    try:
+        film_b, strays_b = gs.render(rd)
+    finally:
+        del os.environ["PG_BATCH_PATHS"]
+    assert np.array_equal(film_b, film_h) and len(strays_b) == len(strays_h)
+    gs.close()
+
+
+def test_unsupported_inputs_fail_loudly(gpu):
+    scene = gpu.HostScene(os.path.join(GOLD, "cornell_32.pbrt"))
+    desc = scene.desc
+    mats = (gpu.abi.PgMaterial * desc.n_materials)(*[desc.materials[i] for i in range(desc.n_materials)])
+    mats[0].type = 7
+    bad = gpu.abi.PgSceneDesc.from_buffer_copy(desc)
+    bad.materials = mats
+    with pytest.raises(gpu.PbrtGpuError, match="closed set"):
+        gpu.GpuScene(bad)
+    gs = gpu.GpuScene(desc)
+    rd = scene.render_desc()
+    rd.filter_radius[0] = 2.0
+    with pytest.raises(gpu.PbrtGpuError, match="filters"):
+        gs.render(rd)
+    gs.close()
+
+
+def test_full_size_properties(gpu, oracle, tmp_path):
+    """BASELINE.json config 3 geometry at full frame size (1920x1080, ~1M triangles), 1 spp: size-independent
+    properties -- every pixel receives exactly its samples, two renders are bit-identical, primary hits of a
+    random subset equal the oracle's, and the image agrees with a sharded render."""
+    import gen_synthetic
+    path = str(tmp_path / "full.pbrt")
+    gen_synthetic.write_scene(path, n=708, xres=1920, yres=1080, spp=1)
+    scene = gpu.HostScene(path)
+    assert scene.desc.n_tris == 999698 + 12
+    gs = gpu.GpuScene(scene.desc)
+    rd = scene.render_desc()
+    film, strays = gs.render(rd)
+    cn = gs.counters()
+    assert cn["camera_rays"] == 1920 * 1080
+    w = film["weight"].reshape(-1, 16, 16)
+    nx, ny = 120, 68
+    assert w.shape[0] == nx * ny
+    assert (w[: nx * (ny - 1)] == 1).all()              # full tiles: one sample per pixel
+    assert (w[nx * (ny - 1):, :8] == 1).all() and (w[nx * (ny - 1):, 8:] == 0).all()  # 1080 = 67*16 + 8
+    assert np.isfinite(film["rgb"]).all() and (film["rgb"] >= 0).all()
+    film2, strays2 = gs.render(rd)
+    assert np.array_equal(film, film2) and len(strays) == len(strays2)
+    scene.film_clear(); scene.film_merge(rd, film, strays); whole = scene.film_image()
+    scene.film_clear()
+    for r in range(2):
+        rdr = scene.render_desc(r, 2)
+        f, s = gs.render(rdr)
+        scene.film_merge(rdr, f, s)
+    assert np.array_equal(scene.film_image(), whole)
+    rng = np.random.default_rng(3)
+    n = 50000
+    o = np.tile(np.array([0, -2.6, 1.4], np.float32), (n, 1))
+    tgt = np.stack([rng.uniform(-1.1, 1.1, n), rng.uniform(-1.1, 1.1, n), rng.uniform(-0.25, 0.3, n)], 1)
+    d = (tgt - o).astype(np.float32)
+    inf = np.full(n, np.inf, np.float32)
+    prim, t, bary = gs.intersect(o, d, inf)
+    oprim, ot, obary, _ = oracle.intersect(scene.desc, o, d, inf)
+    assert np.array_equal(prim, oprim) and np.array_equal(t, ot) and np.array_equal(bary, obary)
+    gs.close()

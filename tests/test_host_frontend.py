@@ -1,0 +1,139 @@
+"""Host logic: .pbrt parser / API state machine, BVHAccel build invariants, Halton set-up, Film merge,
+tile sharding.  CPU only."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, ROOT
+
+MINI = '''
+LookAt 0 0 -5  0 0 0  0 1 0
+Camera "perspective" "float fov" [ 45 ]
+Film "image" "integer xresolution" [ %d ] "integer yresolution" [ %d ] "string filename" "t.pfm"
+Sampler "halton" "integer pixelsamples" [ %d ]
+WorldBegin
+AttributeBegin
+  AreaLightSource "diffuse" "rgb L" [ 5 5 5 ]
+  Shape "trianglemesh" "integer indices" [ 0 1 2 ] "point P" [ -1 2 -1  1 2 -1  0 2 1 ]
+AttributeEnd
+Shape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ] "point P" [ -2 -1 -2  2 -1 -2  2 -1 2  -2 -1 2 ]
+WorldEnd
+'''
+
+
+def test_defaults_and_descs(pkg):
+    s = pkg.HostScene(text=MINI % (33, 17, 4))
+    d, rd = s.desc, s.render_desc()
+    assert (d.n_tris, d.n_lights, d.n_materials) == (3, 1, 1)
+    assert d.light_strategy == pkg.abi.PG_LIGHTS_UNIFORM  # one light => uniform (lightdistrib.cpp:50)
+    assert d.materials[0].type == pkg.abi.PG_MAT_MATTE and tuple(d.materials[0].kd) == (0.5, 0.5, 0.5)  # api.cpp default
+    assert (rd.spp, rd.max_depth, rd.rr_threshold) == (4, 5, 1.0)  # path.cpp:193-209
+    assert tuple(rd.filter_radius) == (0.5, 0.5) and tuple(rd.sample_bounds) == (0, 0, 33, 17)
+    # HaltonSampler ctor (halton.cpp:75-92): 33 -> 64 = 2^6, 17 -> 27 = 3^3
+    assert tuple(rd.base_scales) == (64, 27) and tuple(rd.base_exponents) == (6, 3) and rd.sample_stride == 64 * 27
+    assert (rd.mult_inverse[0] * 27) % 64 == 1 and (rd.mult_inverse[1] * 64) % 27 == 1
+    assert pkg.GpuScene.tile_count is not None
+    light = d.lights[0]
+    assert d.tri_light[light.prim] == 0 and abs(light.area - 2.0) < 1e-6
+
+
+def test_halton_permutations_are_permutations(pkg):
+    s = pkg.HostScene(text=MINI % (16, 16, 1))
+    d = s.desc
+    sums = np.ctypeslib.as_array(d.perm_sums, (d.n_perm_dims + 1,))
+    perms = np.ctypeslib.as_array(d.perms, (sums[-1],))
+    assert d.n_perm_dims >= 5 + 8 * 6
+    for i in range(d.n_perm_dims):
+        p = perms[sums[i]:sums[i + 1]]
+        assert sorted(p.tolist()) == list(range(len(p)))
+    # first bases of the default-seeded table (RNG(), lowdiscrepancy.cpp:2490-2504) are not the identity
+    assert perms[:2].tolist() in ([0, 1], [1, 0]) and not np.array_equal(perms[sums[5]:sums[6]], np.arange(13))
+
+
+def test_bvh_invariants(pkg):
+    s = pkg.HostScene(os.path.join(GOLD, "synthetic_n40.pbrt"))
+    nodes, idx, P = s.nodes(), s.indices(), s.positions()
+    n_tris = s.desc.n_tris
+    seen = np.zeros(n_tris, int)
+    stack = [0]
+    while stack:
+        i = stack.pop()
+        nd = nodes[i]
+        if nd["nprims"] > 0:
+            for k in range(nd["offset"], nd["offset"] + nd["nprims"]):
+                seen[k] += 1
+                v = P[idx[k]]
+                assert (v >= nd["bmin"]).all() and (v <= nd["bmax"]).all()
+            assert nd["nprims"] <= 4  # maxnodeprims default (bvh.cpp:757)
+        else:
+            for c in (i + 1, nd["offset"]):  # first child adjacent, second at offset (bvh.cpp:640-658)
+                assert (nodes[c]["bmin"] >= nd["bmin"]).all() and (nodes[c]["bmax"] <= nd["bmax"]).all()
+                stack.append(c)
+            assert nd["axis"] in (0, 1, 2)
+    assert (seen == 1).all()
+
+
+@pytest.mark.parametrize("split", ["sah", "middle", "equal", "hlbvh"])
+def test_split_methods_give_same_image(pkg, oracle, split):
+    txt = open(os.path.join(GOLD, "cornell_40x24.pbrt")).read().replace('Accelerator "bvh"', f'Accelerator "bvh" "string splitmethod" "{split}" "integer maxnodeprims" [ 2 ]')
+    img, _ = oracle.render_image(pkg.HostScene(text=txt))
+    assert np.array_equal(img, pkg.read_pfm(os.path.join(GOLD, "cornell_40x24.pfm")))
+
+
+def test_errors_are_reported_not_thrown(pkg):
+    before = pkg.host_lib().pbrt_host_error_count()
+    s = pkg.HostScene(text=(MINI % (16, 16, 1)).replace("WorldEnd", 'Shape "sphere" "float radius" [ 1 ]\nLightSource "point"\nTexture "t" "spectrum" "imagemap"\nWorldEnd'))
+    assert s.desc.n_tris == 3  # unsupported plugins are skipped, the scene still loads (error.cpp:62-102 semantics)
+    assert pkg.host_lib().pbrt_host_error_count() >= before + 3
+    with pytest.raises(pkg.PbrtGpuError):
+        pkg.HostScene(text="WorldBegin\nWorldEnd\n" if False else "Camera \"perspective\"\n")  # no WorldEnd => nothing to render
+
+
+def test_empty_world_loads(pkg, oracle):
+    s = pkg.HostScene(text='Film "image" "integer xresolution" [ 8 ] "integer yresolution" [ 8 ] "string filename" "e.pfm"\nWorldBegin\nWorldEnd\n')
+    assert s.desc.n_tris == 0 and s.desc.n_nodes == 0
+    img, cn = oracle.render_image(s)
+    assert img.shape == (8, 8, 3) and not img.any() and cn["camera_rays"] == 64 * 16
+
+
+def test_tile_sharding_partitions_frame(pkg, oracle):
+    s = pkg.HostScene(text=MINI % (70, 37, 1))
+    total = oracle.lib().oracle_render_tile_count(C.byref(s.render_desc()))
+    assert total == 5 * 3
+    for world in (1, 2, 3, 4, 8, 16):
+        counts = [oracle.lib().oracle_render_tile_count(C.byref(s.render_desc(r, world))) for r in range(world)]
+        assert sum(counts) == total and max(counts) - min(counts) <= 1
+
+
+def test_film_merge_stray_samples(pkg):
+    """A sample whose film offset is exactly 0 also lands in the previous pixel (film.h:127-132): same-tile strays add
+    in RGB after the pixel's own samples, cross-tile strays add in XYZ."""
+    s = pkg.HostScene(text=MINI % (32, 16, 1))
+    rd = s.render_desc()
+    film = np.zeros(2 * 256, pkg.FILM_PIXEL_DTYPE)
+    film["rgb"] = 1.0
+    film["weight"] = 1.0
+    strays = np.zeros(2, pkg.STRAY_DTYPE)
+    strays[0] = (4, 4, 5, 4, (0.5, 0.25, 0.125), 1.0)     # same tile
+    strays[1] = (15, 3, 16, 3, (2.0, 2.0, 2.0), 1.0)       # from tile 1 into tile 0
+    s.film_clear(); s.film_merge(rd, film, strays)
+    img = s.film_image()
+    to_xyz = lambda c: np.array([0.412453 * c[0] + 0.357580 * c[1] + 0.180423 * c[2], 0.212671 * c[0] + 0.715160 * c[1] + 0.072169 * c[2],
+                                 0.019334 * c[0] + 0.119193 * c[1] + 0.950227 * c[2]], np.float32)
+    to_rgb = lambda x: np.array([3.240479 * x[0] - 1.537150 * x[1] - 0.498535 * x[2], -0.969256 * x[0] + 1.875991 * x[1] + 0.041556 * x[2],
+                                 0.055648 * x[0] - 0.204043 * x[1] + 1.057311 * x[2]], np.float32)
+    np.testing.assert_allclose(img[4, 4], to_rgb(to_xyz(np.array([1.5, 1.25, 1.125], np.float32))) / 2, rtol=1e-6)
+    np.testing.assert_allclose(img[3, 15], to_rgb(to_xyz(np.ones(3, np.float32)) + to_xyz(np.full(3, 2.0, np.float32))) / 2, rtol=1e-6)
+    np.testing.assert_allclose(img[0, 0], to_rgb(to_xyz(np.ones(3, np.float32))), rtol=1e-6)
+
+
+def test_cli_refuses_without_backend(pkg, tmp_path):
+    """pbrt_amd never renders on the CPU: with no HIP back end reachable it exits non-zero."""
+    import subprocess
+    exe = os.path.join(ROOT, "pbrt-v3_amd", "pbrt_amd")
+    scene = tmp_path / "m.pbrt"
+    scene.write_text(MINI % (16, 16, 1))
+    r = subprocess.run([exe, "--quiet", str(scene)], env=dict(os.environ, PBRT_GPU_LIB="/nonexistent.so"), capture_output=True, text=True)
+    assert r.returncode != 0 and "no HIP back end" in r.stderr

@@ -1,0 +1,134 @@
+"""The reference's own known-answer / property tests for this path, re-run against
+the CPU oracle (and, under -m gpu, against the HIP kernels in test_gpu_parity.py):
+  Triangle.BadCases        src/tests/shapes.cpp:544-559   literal vector, must NOT hit
+  Triangle.Watertight      src/tests/shapes.cpp:28-129    seeded jittered sphere, every ray hits
+  Triangle.Reintersect     src/tests/shapes.cpp:154-205   spawned rays never re-hit their triangle
+  LowDiscrepancy.RadicalInverse / ScrambledRadicalInverse  src/tests/sampling.cpp:15-74
+  FloatingPoint Next{Up,Down}  src/tests/fp_tests.cpp (via OffsetRayOrigin rounding)
+"""
+import ctypes as C
+
+import numpy as np
+
+from kat_util import PCG32, jittered_sphere, uniform_sample_sphere
+
+
+def tri_hit(oracle, p0, p1, p2, o, d, tmax=np.inf):
+    t = C.c_float()
+    b = (C.c_float * 3)()
+    arr = [np.ascontiguousarray(x, np.float32) for x in (p0, p1, p2, o, d)]
+    r = oracle.lib().oracle_triangle_intersect(*[a.ctypes.data for a in arr], C.c_float(tmax), C.byref(t), b)
+    return bool(r), t.value, tuple(b)
+
+
+def test_triangle_bad_cases(oracle):
+    p = [(-1113.45459, -79.049614, -56.2431908), (-1113.45459, -87.0922699, -56.2431908), (-1113.45459, -79.2090149, -56.2431908)]
+    hit, _, _ = tri_hit(oracle, *p, (-1081.47925, 99.9999542, 87.7701111), (-32.1072998, -183.355865, -144.607635), 0.9999)
+    assert not hit
+
+
+def test_triangle_watertight(pkg, oracle):
+    """Every ray from inside the closed jittered sphere hits (also when aimed exactly at a vertex)."""
+    verts, idx = jittered_sphere()
+    scene = pkg.HostScene(text=sphere_scene(verts, idx))
+    o, d = watertight_rays(verts, 4000)
+    prim, t, bary, _ = oracle.intersect(scene.desc, o, d, np.full(len(o), np.inf, np.float32))
+    assert (prim >= 0).all()
+
+
+def sphere_scene(verts, idx):
+    P = " ".join("%.9g" % v for v in np.asarray(verts, np.float32).reshape(-1))
+    I = " ".join(str(i) for i in idx)
+    return ('Camera "perspective"\nFilm "image" "integer xresolution" [16] "integer yresolution" [16] "string filename" "x.pfm"\n'
+            'WorldBegin\nShape "trianglemesh" "integer indices" [ %s ] "point P" [ %s ]\nWorldEnd\n' % (I, P))
+
+
+def watertight_rays(verts, n):
+    os_, ds = [], []
+    for i in range(n // 2):
+        rng = PCG32(i)
+        u = (rng.uniform_float(), rng.uniform_float())
+        p = np.float32(0.5) * uniform_sample_sphere(u)
+        u = (rng.uniform_float(), rng.uniform_float())
+        os_.append(p); ds.append(uniform_sample_sphere(u))
+        v = verts[rng.uniform_uint32_bounded(len(verts))]
+        os_.append(p); ds.append((np.asarray(v, np.float32) - p).astype(np.float32))
+    return np.asarray(os_, np.float32), np.asarray(ds, np.float32)
+
+
+def test_triangle_reintersect(oracle):
+    """SpawnRay / SpawnRayTo from a hit point never re-intersect the same triangle (pins pError,
+    OffsetRayOrigin and the conservative t > deltaT test)."""
+    lib = oracle.lib()
+    checked = 0
+    for i in range(60):
+        rng = PCG32(i)
+        def pexp():
+            logu = np.float32((1 - (u := rng.uniform_float())) * -8.0 + u * 8)  # Lerp(u, -8, 8)
+            sign = -1.0 if rng.uniform_float() < 0.5 else 1.0
+            return np.float32(sign * 10.0 ** float(logu))
+        v = np.array([[pexp() for _ in range(3)] for _ in range(3)], np.float32)
+        if np.sum(np.cross((v[1] - v[0]).astype(np.float64), (v[2] - v[0]).astype(np.float64)) ** 2) < 1e-20:
+            continue
+        u0, u1 = rng.uniform_float(), rng.uniform_float()
+        su0 = np.float32(np.sqrt(np.float32(u0)))
+        b0, b1 = np.float32(1) - su0, np.float32(u1) * su0
+        ptri = (b0 * v[0] + b1 * v[1] + (np.float32(1) - b0 - b1) * v[2]).astype(np.float32)
+        o = np.array([pexp() for _ in range(3)], np.float32)
+        hit, t, b = tri_hit(oracle, v[0], v[1], v[2], o, (ptri - o).astype(np.float32))
+        if not hit:
+            continue
+        b = np.asarray(b, np.float32)
+        phit = (b[0] * v[0] + b[1] * v[1] + b[2] * v[2]).astype(np.float32)
+        gamma7 = np.float32(7 * 2.0 ** -24) / np.float32(1 - 7 * 2.0 ** -24)
+        perr = (gamma7 * (np.abs(b[0] * v[0]) + np.abs(b[1] * v[1]) + np.abs(b[2] * v[2]))).astype(np.float32)
+        n = np.cross((v[0] - v[2]).astype(np.float64), (v[1] - v[2]).astype(np.float64))
+        n = (n / np.linalg.norm(n)).astype(np.float32)
+        out = np.zeros(3, np.float32)
+        for j in range(200):
+            w = uniform_sample_sphere((rng.uniform_float(), rng.uniform_float()))
+            lib.oracle_spawn_ray_origin(phit.ctypes.data, perr.ctypes.data, n.ctypes.data, w.ctypes.data, out.ctypes.data)
+            assert not tri_hit(oracle, v[0], v[1], v[2], out.copy(), w)[0]
+            p2 = np.array([pexp() for _ in range(3)], np.float32)
+            dvec = (p2 - phit).astype(np.float32)
+            lib.oracle_spawn_ray_origin(phit.ctypes.data, perr.ctypes.data, n.ctypes.data, dvec.ctypes.data, out.ctypes.data)
+            assert not tri_hit(oracle, v[0], v[1], v[2], out.copy(), dvec, tmax=1 - 0.0001)[0]
+            checked += 1
+    assert checked > 2000
+
+
+def test_radical_inverse_base2_is_bit_reversal(oracle):
+    lib = oracle.lib()
+    for a in range(1024):
+        rev = int(f"{a:032b}"[::-1], 2)
+        assert lib.oracle_radical_inverse(0, a) == np.float32(np.float32(rev) * np.float32(2.3283064365386963e-10))
+
+
+def test_scrambled_radical_inverse_vs_naive(oracle):
+    lib = oracle.lib()
+    primes = [p for p in range(2, 800) if all(p % q for q in range(2, int(p ** 0.5) + 1))][:128]
+    for dim, base in enumerate(primes):
+        rng = PCG32(dim)
+        perm = list(range(base - 1, -1, -1))
+        for i in range(base):  # Shuffle, sampling.h:151-157
+            other = i + rng.uniform_uint32_bounded(base - i)
+            perm[i], perm[other] = perm[other], perm[i]
+        parr = np.asarray(perm, np.uint16)
+        for index in (0, 1, 2, 1151, 32351, 4363211, 681122):
+            val, inv_base, a = 0.0, 1.0 / base, index
+            inv_bi = inv_base
+            for _ in range(32):
+                val += perm[a % base] * inv_bi
+                a //= base
+                inv_bi *= inv_base
+            got = lib.oracle_scrambled_radical_inverse(dim, index, parr.ctypes.data)
+            assert abs(val - got) < 1e-5
+
+
+def test_radical_inverse_unscrambled_matches_identity_permutation(oracle):
+    """ScrambledRadicalInverse with the identity permutation == RadicalInverse (generator identity)."""
+    lib = oracle.lib()
+    for dim, base in ((1, 3), (2, 5), (5, 13)):
+        ident = np.arange(base, dtype=np.uint16)
+        for a in (0, 1, 7, 1000, 123456, 2 ** 31 + 5, 2 ** 40 + 12345):
+            assert lib.oracle_radical_inverse(dim, a) == lib.oracle_scrambled_radical_inverse(dim, a, ident.ctypes.data)
