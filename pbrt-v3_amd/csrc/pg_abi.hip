@@ -43,7 +43,7 @@ struct DeviceBuffer {
 struct PgScene {
     int device = 0;
     DScene d;
-    DeviceBuffer nodes, tris, uv, materials, lights, distTable, perms, permSums, primes;
+    DeviceBuffer nodes, wnodes, tris, uv, materials, lights, distTable, perms, permSums, primes;
     // work buffers (sized on first render, reused)
     int capacity = 0;
     DeviceBuffer qo[4], qd[4], counts, hitsMain, hitsMis, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
@@ -53,6 +53,7 @@ struct PgScene {
     PgCounters counters;
     std::vector<hipEvent_t> events;
     bool hasNullMaterial = false;
+    bool legacyTraversal = false;  // PG_TRAVERSE_LEGACY=1: the round-1 32-B-node kernels (A/B only)
 };
 
 extern "C" {
@@ -99,6 +100,55 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     // --- nodes: uploaded verbatim (32 B/node, same bytes as pbrt's LinearBVHNode)
     HIP_TRY_S(s->nodes.alloc(sizeof(PgBVHNode) * (size_t)desc->n_nodes));
     if (desc->n_nodes) HIP_TRY_S(hipMemcpy(s->nodes.p, desc->nodes, s->nodes.bytes, hipMemcpyHostToDevice));
+    // --- child-pair records for k_trace (pg_traverse.hip): one 64-B record per interior node
+    {
+        const int nn = desc->n_nodes;
+        int maxLeaf = 1;
+        for (int i = 0; i < nn; ++i) if (desc->nodes[i].nprims > maxLeaf) maxLeaf = desc->nodes[i].nprims;
+        int leafBits = 0;
+        while ((1 << leafBits) < maxLeaf) ++leafBits;
+        if ((uint64_t)nt >= ((uint64_t)1 << (31 - leafBits)) - 1)
+            FAIL(PG_ERR_UNSUPPORTED, "%d triangles with up to %d per leaf exceed the 31-bit leaf reference", nt, maxLeaf);
+        std::vector<int> recIndex((size_t)nn, -1);
+        int nInterior = 0;
+        for (int i = 0; i < nn; ++i) if (desc->nodes[i].nprims == 0) recIndex[i] = nInterior++;
+        auto refOf = [&](int i) -> int {
+            const PgBVHNode &nd = desc->nodes[i];
+            return nd.nprims == 0 ? recIndex[i] : ~((nd.offset << leafBits) | (nd.nprims - 1));
+        };
+        std::vector<float4> w((size_t)nInterior * 4);
+        for (int i = 0; i < nn; ++i) {
+            const PgBVHNode &nd = desc->nodes[i];
+            if (nd.nprims != 0) continue;
+            const int c0 = i + 1, c1 = nd.offset;
+            if (c0 >= nn || c1 <= i || c1 >= nn) FAIL(PG_ERR_INVALID, "BVH node %d has out-of-range children", i);
+            const PgBVHNode &a = desc->nodes[c0], &b = desc->nodes[c1];
+            float4 *r = &w[(size_t)recIndex[i] * 4];
+            r[0] = make_float4(a.bmin[0], a.bmax[0], b.bmin[0], b.bmax[0]);
+            r[1] = make_float4(a.bmin[1], a.bmax[1], b.bmin[1], b.bmax[1]);
+            r[2] = make_float4(a.bmin[2], a.bmax[2], b.bmin[2], b.bmax[2]);
+            int r0 = refOf(c0), r1 = refOf(c1), ax = nd.axis;
+            float f0, f1, f2;
+            memcpy(&f0, &r0, 4); memcpy(&f1, &r1, 4); memcpy(&f2, &ax, 4);
+            r[3] = make_float4(f0, f1, f2, 0.f);
+        }
+        HIP_TRY_S(s->wnodes.alloc(sizeof(float4) * w.size()));
+        if (!w.empty()) HIP_TRY_S(hipMemcpy(s->wnodes.p, w.data(), s->wnodes.bytes, hipMemcpyHostToDevice));
+        d.wnodes = (const float4 *)s->wnodes.p;
+        d.leafBits = leafBits;
+        if (nn > 0) {
+            for (int k = 0; k < 3; ++k) { d.rootBox[k] = desc->nodes[0].bmin[k]; d.rootBox[3 + k] = desc->nodes[0].bmax[k]; }
+            d.rootRef = refOf(0);
+        }
+        if (const char *e = getenv("PG_TRAVERSE_LEGACY")) s->legacyTraversal = atoi(e) != 0;
+        TraceConfig tc = get_trace_config();
+        if (const char *e = getenv("PG_TRACE_DEPTH")) { int v = atoi(e); if (v >= 0 && v <= 64) tc.depth = v; }
+        if (const char *e = getenv("PG_TRACE_SEG")) { int v = atoi(e); if (v >= 64) tc.segRays = v; }
+        if (const char *e = getenv("PG_TRACE_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) tc.refillAt = v; }
+        if (const char *e = getenv("PG_TRACE_TRIW")) { int v = atoi(e); if (v >= 0) tc.triW = v; }
+        if (const char *e = getenv("PG_TRACE_CULLK")) { float v = (float)atof(e); if (v >= 1.f) tc.cullK = v; }
+        set_trace_config(tc);
+    }
     // --- triangles: gather vertices into BVH order, 48 B per triangle
     std::vector<float4> tris((size_t)nt * 3);
     std::vector<float> uv;
@@ -228,6 +278,15 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
 #undef HIP_TRY_S
 }
 
+static void traceClosest(PgScene *s, RayQueue q, int maxCount, float4 *hits, float *tOut, TraceCounters *cn, hipStream_t st) {
+    if (s->legacyTraversal) launch_closest(s->d, q, maxCount, hits, tOut, nullptr, cn, st);
+    else launch_closest_wide(s->d, q, maxCount, hits, tOut, cn, st);
+}
+static void traceAnyhit(PgScene *s, RayQueue q, int maxCount, int *occluded, TraceCounters *cn, hipStream_t st) {
+    if (s->legacyTraversal) launch_anyhit(s->d, q, maxCount, occluded, cn, st);
+    else launch_anyhit_wide(s->d, q, maxCount, occluded, cn, st);
+}
+
 static int tileCount(const PgRenderDesc *rd) {
     int nx = (rd->sample_bounds[2] - rd->sample_bounds[0] + 15) / 16, ny = (rd->sample_bounds[3] - rd->sample_bounds[1] + 15) / 16;
     if (nx <= 0 || ny <= 0 || rd->tile_step <= 0 || rd->tile_first < 0) return 0;
@@ -351,7 +410,7 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
                 hipEvent_t a = getEvent(s, ev), b = getEvent(s, ev + 1);
                 timed.push_back({ev, 0}); ev += 2;
                 HIP_TRY(hipEventRecord(a, stream));
-                launch_closest(s->d, q[cur], rp.capacity, (float4 *)s->hitsMain.p, nullptr, nullptr, cnClosest, stream);
+                traceClosest(s, q[cur], rp.capacity, (float4 *)s->hitsMain.p, nullptr, cnClosest, stream);
                 HIP_TRY(hipEventRecord(b, stream));
                 ++closestLaunches;
                 HIP_TRY(hipMemsetAsync(counts + nxt, 0, sizeof(int), stream));
@@ -360,13 +419,13 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
                 a = getEvent(s, ev); b = getEvent(s, ev + 1);
                 timed.push_back({ev, 1}); ev += 2;
                 HIP_TRY(hipEventRecord(a, stream));
-                launch_anyhit(s->d, q[2], rp.capacity, (int *)s->occluded.p, cnShadow, stream);
+                traceAnyhit(s, q[2], rp.capacity, (int *)s->occluded.p, cnShadow, stream);
                 HIP_TRY(hipEventRecord(b, stream));
                 ++shadowLaunches;
                 a = getEvent(s, ev); b = getEvent(s, ev + 1);
                 timed.push_back({ev, 0}); ev += 2;
                 HIP_TRY(hipEventRecord(a, stream));
-                launch_closest(s->d, q[3], rp.capacity, (float4 *)s->hitsMis.p, nullptr, nullptr, cnClosest, stream);
+                traceClosest(s, q[3], rp.capacity, (float4 *)s->hitsMis.p, nullptr, cnClosest, stream);
                 HIP_TRY(hipEventRecord(b, stream));
                 ++closestLaunches;
                 launch_resolve(s->d, ps, q[cur], q[3], (const int *)s->occluded.p, (const float4 *)s->hitsMis.p, rp.capacity, stream);
@@ -472,7 +531,7 @@ int pg_intersect(PgScene *s, int32_t n, const float *o, const float *d, const fl
     q.o = (float4 *)s->tO.p; q.d = (float4 *)s->tD.p; q.count = (int *)s->tCount.p;
     hipEvent_t a = getEvent(s, 0), b = getEvent(s, 1);
     HIP_TRY(hipEventRecord(a, stream));
-    launch_closest(s->d, q, n, (float4 *)s->tHit.p, (float *)s->tT.p, nullptr, (TraceCounters *)s->traceCn.p, stream);
+    traceClosest(s, q, n, (float4 *)s->tHit.p, (float *)s->tT.p, (TraceCounters *)s->traceCn.p, stream);
     HIP_TRY(hipEventRecord(b, stream));
     HIP_TRY(hipGetLastError());
     std::vector<float4> hits((size_t)n);
@@ -516,7 +575,7 @@ int pg_intersect_p(PgScene *s, int32_t n, const float *o, const float *d, const 
     q.o = (float4 *)s->tO.p; q.d = (float4 *)s->tD.p; q.count = (int *)s->tCount.p;
     hipEvent_t a = getEvent(s, 0), b = getEvent(s, 1);
     HIP_TRY(hipEventRecord(a, stream));
-    launch_anyhit(s->d, q, n, (int *)s->tOcc.p, (TraceCounters *)s->traceCn.p + 1, stream);
+    traceAnyhit(s, q, n, (int *)s->tOcc.p, (TraceCounters *)s->traceCn.p + 1, stream);
     HIP_TRY(hipEventRecord(b, stream));
     HIP_TRY(hipGetLastError());
     std::vector<int> occ((size_t)n);

@@ -14,6 +14,14 @@ struct DScene {
     // Linearised BVH, 32 B/node exactly as PgBVHNode: two float4 per node
     //   n[0] = (bmin.x, bmin.y, bmin.z, bmax.x)   n[1] = (bmax.y, bmax.z, offset, nprims|axis<<16)
     const float4 *nodes;
+    // Child-pair records (pg_traverse.hip), 64 B per INTERIOR node, depth-first order:
+    //   w[0] = (c0.lo.x, c0.hi.x, c1.lo.x, c1.hi.x)  w[1] = same for y  w[2] = same for z
+    //   w[3] = (ref0, ref1, split axis, 0)   c0 = first child (index+1), c1 = second child (offset)
+    // ref >= 0: record index of an interior child; ref < 0: leaf child, ~ref = firstPrim << leafBits | (nPrims-1)
+    const float4 *wnodes;
+    float rootBox[6];  // nodes[0].bounds: (min.xyz, max.xyz)
+    int rootRef;       // ref of nodes[0]
+    int leafBits;
     // Triangles in BVH order, 48 B each: three float4
     //   t[0] = (p0, flags)  t[1] = (p1, material)  t[2] = (p2, light)
     const float4 *tris;
@@ -68,6 +76,14 @@ struct TraceCounters {
     unsigned long long node_visits, tri_tests;
 };
 
+// Tunables of k_trace: LDS stack entries per lane, rays per wave segment, idle-lane count that triggers a refill.
+// cullK: closest-hit far-child early-cull margin (pg_traverse.hip); exact while a ray's tMax never grows by more than
+// this factor through rounding (each accepted hit can raise it by <= 3 roundings, i.e. ~5000 successive raises).
+struct TraceConfig { int depth, segRays, refillAt, triW; float cullK; };
+void set_trace_config(const TraceConfig &c);
+TraceConfig get_trace_config();
+void launch_closest_wide(const DScene &sc, RayQueue q, int maxCount, float4 *hits, float *tOut, TraceCounters *cn, hipStream_t s);
+void launch_anyhit_wide(const DScene &sc, RayQueue q, int maxCount, int *occluded, TraceCounters *cn, hipStream_t s);
 void launch_generate(const DScene &sc, const RenderParams &rp, PathState st, RayQueue q, hipStream_t s);
 void launch_closest(const DScene &sc, RayQueue q, int maxCount, float4 *hits, float *tOut, float *b2Out, TraceCounters *cn, hipStream_t s);
 void launch_anyhit(const DScene &sc, RayQueue q, int maxCount, int *occluded, TraceCounters *cn, hipStream_t s);

@@ -1,0 +1,231 @@
+// pg_traverse.hip -- BVH traversal kernels of the MI355X path tracer (gfx950):
+// BVHAccel::Intersect (closest hit, bvh.cpp:662-700) and BVHAccel::IntersectP
+// (any hit, bvh.cpp:702-738) with Triangle::Intersect[P] (triangle.cpp:188-572)
+// over an SoA ray queue, one ray per lane.
+//
+// Design (DESIGN.md "k_trace"):
+//  * child-pair node records (64 B): an interior record holds the boxes and
+//    references of BOTH children, so one dependent fetch replaces the
+//    reference's two node fetches per level, and a leaf's (first prim, count)
+//    sits in its parent's record -- a leaf costs no node fetch at all;
+//  * per-ray visiting order, tMax shrinking and tie-breaking are exactly the
+//    reference's: the far child's slab interval is computed when its parent is
+//    read, its entry tMin goes on the stack, and the reference's later
+//    `tMin < ray.tMax` decision is re-taken with the then-current tMax at pop
+//    time (the other terms of Bounds3::IntersectP do not depend on ray.tMax);
+//  * the reference's node-visit count (one per nodes[cur] read, bvh.cpp:672/710)
+//    is reproduced exactly: it defines the algorithmic bytes of the roofline;
+//  * every wave owns a contiguous segment of the queue and refills lanes whose
+//    ray has finished from it, so lane occupancy does not decay to the longest
+//    ray of the first 64; segments map to XCDs in contiguous eighths so each
+//    private L2 sees one coherent region of the queue;
+//  * traversal stack: first `depth` entries per lane in LDS ([entry][lane],
+//    8 B entries, bank-conflict-free), the rest of pbrt's 64 in scratch.
+#include "pg_device.h"
+#include "pg_kernels.h"
+
+#define TR_BLOCK 256
+#define TR_NONE ((int)0x80000000)
+#define TR_STACK_TOTAL 64
+
+// Bounds3::IntersectP(ray, invDir, dirIsNeg), geometry.h:1412-1438, split into
+// the part that does not depend on ray.tMax (returns ok, tMin) and the final
+// `tMin < ray.tMax`, which the caller evaluates when the reference would.
+PG_DEV bool slab_interval(float lox, float hix, float loy, float hiy, float loz, float hiz, float ox, float oy, float oz,
+                          float ix, float iy, float iz, bool nx, bool ny, bool nz, float &tMinOut) {
+    float tMin = ((nx ? hix : lox) - ox) * ix;
+    float tMax = ((nx ? lox : hix) - ox) * ix;
+    float tyMin = ((ny ? hiy : loy) - oy) * iy;
+    float tyMax = ((ny ? loy : hiy) - oy) * iy;
+    const float widen = 1 + 2 * pgamma(3);
+    tMax *= widen;
+    tyMax *= widen;
+    bool ok = !(tMin > tyMax || tyMin > tMax);
+    if (tyMin > tMin) tMin = tyMin;
+    if (tyMax < tMax) tMax = tyMax;
+    float tzMin = ((nz ? hiz : loz) - oz) * iz;
+    float tzMax = ((nz ? loz : hiz) - oz) * iz;
+    tzMax *= widen;
+    ok = ok && !(tMin > tzMax || tzMin > tMax);
+    if (tzMin > tMin) tMin = tzMin;
+    if (tzMax < tMax) tMax = tzMax;
+    tMinOut = tMin;
+    return ok && (tMax > 0);
+}
+
+PG_DEV int tr_swizzled_block(int nblk) {  // contiguous eighth of the grid per XCD (block b runs on XCD b % 8)
+    int per = (nblk + 7) >> 3;
+    int b = blockIdx.x;
+    if (b >= per * 8) return -1;
+    int lb = (b & 7) * per + (b >> 3);
+    return lb < nblk ? lb : -1;
+}
+
+PG_DEV unsigned long long tr_wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+
+template <bool ANYHIT>
+__global__ __launch_bounds__(TR_BLOCK) void k_trace(DScene sc, RayQueue q, float4 *__restrict__ hits, float *__restrict__ tOut,
+                                                    int *__restrict__ occluded, TraceCounters *cn, int depth, int segRays, int refillAt,
+                                                    int triW, float cullK) {
+    extern __shared__ uint2 ldsStack[];  // [depth][TR_BLOCK]
+    uint2 spill[TR_STACK_TOTAL];
+    const int n = *q.count;
+    const int nSeg = (n + segRays - 1) / segRays;
+    const int lb = tr_swizzled_block((nSeg + TR_BLOCK / 64 - 1) / (TR_BLOCK / 64));
+    if (lb < 0) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int seg = __builtin_amdgcn_readfirstlane(lb * (TR_BLOCK / 64) + (tid >> 6));
+    int next = seg * segRays;
+    const int segEnd = min(n, next + segRays);
+    if (next >= segEnd) return;
+    const unsigned long long laneLt = (1ull << lane) - 1ull;
+
+    // per-lane ray state.  A lane is in exactly one of three states:
+    //   cur >= 0                 : holds an interior record to expand (its box test already passed)
+    //   cur == NONE, triLeft > 0 : holds a leaf with triLeft untested triangles starting at triNext
+    //   cur == NONE, triLeft == 0: idle (ray finished or none assigned)
+    int ray = -1, cur = TR_NONE, triNext = 0, triLeft = 0;
+    float ox = 0, oy = 0, oz = 0, dx = 1, dy = 1, dz = 1, ix = 1, iy = 1, iz = 1, tMax = 0;
+    bool nx = false, ny = false, nz = false;
+    int hitPrim = -1;
+    float hb0 = 0, hb1 = 0, hb2 = 0;
+    int sp = 0;                       // real stack entries
+    int vd = 0;                       // ANYHIT: reference stack depth (real + culled entries)
+    unsigned long long vmask = 0;     // ANYHIT: bit i set = the reference's entry at depth i was culled early
+    unsigned int nodeVisits = 0, triTests = 0;
+    const int leafBits = sc.leafBits, leafMask = (1 << leafBits) - 1;
+
+#define TR_PUSH(ref_, t_) do { uint2 e_ = make_uint2((unsigned)(ref_), __float_as_uint(t_)); \
+        if (sp < depth) ldsStack[sp * TR_BLOCK + tid] = e_; else spill[sp - depth] = e_; ++sp; } while (0)
+#define TR_TOP(e_) do { --sp; e_ = (sp < depth) ? ldsStack[sp * TR_BLOCK + tid] : spill[sp - depth]; } while (0)
+    // The reference's "pop or finish" (bvh.cpp:694-697): next node whose deferred `tMin < ray.tMax` test passes.
+#define TR_POP() do { cur = TR_NONE; \
+        if (!ANYHIT) { while (sp > 0) { uint2 e_; TR_TOP(e_); if (__uint_as_float(e_.y) < tMax) { cur = (int)e_.x; break; } } } \
+        else { while (vd > 0) { --vd; ++nodeVisits; if ((vmask >> vd) & 1ull) { vmask &= ~(1ull << vd); continue; } \
+                                uint2 e_; TR_TOP(e_); cur = (int)e_.x; break; } } } while (0)
+    // A negative reference is a leaf: unpack (first prim, count) into the lane's triangle state.
+#define TR_SETTLE() do { if (cur < 0 && cur != TR_NONE) { const int code_ = ~cur; triNext = code_ >> leafBits; triLeft = (code_ & leafMask) + 1; cur = TR_NONE; } } while (0)
+
+    for (;;) {
+        // ---- retire finished rays, refill idle lanes from this wave's segment
+        const bool idle = cur == TR_NONE && triLeft == 0;
+        if (idle && ray >= 0) {
+            if (ANYHIT) occluded[ray] = hitPrim >= 0 ? 1 : 0;
+            else {
+                hits[ray] = make_float4(__int_as_float(hitPrim), hb0, hb1, hb2);
+                if (tOut) tOut[ray] = tMax;
+            }
+            ray = -1;
+        }
+        const unsigned long long idleMask = __ballot(idle);
+        const int nIdle = __popcll(idleMask);
+        if (next < segEnd) {
+            if (nIdle >= refillAt) {
+                const int idx = next + __popcll(idleMask & laneLt);
+                next += nIdle;
+                if (idle && idx < segEnd) {
+                    const float4 o4 = q.o[idx], d4 = q.d[idx];
+                    ray = idx;
+                    ox = o4.x; oy = o4.y; oz = o4.z; tMax = o4.w;
+                    dx = d4.x; dy = d4.y; dz = d4.z;
+                    ix = 1 / dx; iy = 1 / dy; iz = 1 / dz;   // bvh.cpp:666
+                    nx = ix < 0; ny = iy < 0; nz = iz < 0;   // bvh.cpp:667
+                    hitPrim = -1; hb0 = hb1 = hb2 = 0;
+                    sp = 0; vd = 0; vmask = 0;
+                    if (sc.nNodes > 0) {
+                        ++nodeVisits;  // nodes[0]
+                        float t0;
+                        if (slab_interval(sc.rootBox[0], sc.rootBox[3], sc.rootBox[1], sc.rootBox[4], sc.rootBox[2], sc.rootBox[5], ox, oy, oz,
+                                          ix, iy, iz, nx, ny, nz, t0) && t0 < tMax) {
+                            cur = sc.rootRef;
+                            TR_SETTLE();
+                        }
+                    }
+                }
+                continue;  // lanes that finished at once (root miss) retire at the top
+            }
+        } else if (nIdle == 64) break;
+
+        // ---- one step for the wave: either every lane holding an interior record expands it, or every lane
+        //      holding a leaf tests its next triangle.  The larger group goes first (weighted by triW/16), so
+        //      at least about half of the busy lanes are active in every step and neither group starves.
+        const int nInt = __popcll(__ballot(cur >= 0));
+        const int nTri = __popcll(__ballot(triLeft > 0));
+        if (nTri > 0 && (nInt == 0 || nTri * 16 >= nInt * triW)) {
+            if (triLeft > 0) {  // Triangle::Intersect[P] on the leaf's next primitive, in order (bvh.cpp:677-680)
+                const int prim = triNext;
+                const float4 a = sc.tris[3 * prim], b = sc.tris[3 * prim + 1], c = sc.tris[3 * prim + 2];
+                ++triTests; ++triNext; --triLeft;
+                float t, b0, b1, b2;
+                if (tri_test(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), mk(ox, oy, oz), mk(dx, dy, dz), tMax, t, b0, b1, b2) &&
+                    !(__float_as_uint(a.w) & PG_TRI_BOGUS)) {
+                    hitPrim = prim;
+                    if (ANYHIT) { triLeft = 0; sp = 0; vd = 0; }  // bvh.cpp:717: return true
+                    else { tMax = t; hb0 = b0; hb1 = b1; hb2 = b2; }  // primitive.cpp:123: r.tMax = tHit
+                }
+                if (triLeft == 0 && !(ANYHIT && hitPrim >= 0)) { TR_POP(); TR_SETTLE(); }
+            }
+        } else if (cur >= 0) {
+            const float4 *rec = sc.wnodes + 4 * (size_t)cur;
+            const float4 bx = rec[0], by = rec[1], bz = rec[2];
+            const float4 rf = rec[3];
+            float t0, t1;
+            const bool ok0 = slab_interval(bx.x, bx.y, by.x, by.y, bz.x, bz.y, ox, oy, oz, ix, iy, iz, nx, ny, nz, t0);
+            const bool ok1 = slab_interval(bx.z, bx.w, by.z, by.w, bz.z, bz.w, ox, oy, oz, ix, iy, iz, nx, ny, nz, t1);
+            const int axis = __float_as_int(rf.z);
+            const bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);  // bvh.cpp:686: near child first
+            const int nearRef = __float_as_int(neg ? rf.y : rf.x), farRef = __float_as_int(neg ? rf.x : rf.y);
+            const float nearT = neg ? t1 : t0, farT = neg ? t0 : t1;
+            const bool nearHit = (neg ? ok1 : ok0) && nearT < tMax;
+            // Early cull of the far child.  ray.tMax is not monotone: Triangle::Intersect accepts tScaled <= tMax*det and then
+            // returns t = tScaled*invDet, which can round to a few ulps ABOVE the old tMax (triangle.cpp:262-283), so an entry
+            // that fails `tMin < tMax` now could still pass when the reference pops it.  Cull only beyond the margin cullK
+            // (any-hit: tMax is constant, cullK = 1); survivors are re-tested exactly at pop time.
+            const bool farMaybe = (neg ? ok0 : ok1) && farT < tMax * cullK;
+            if (!ANYHIT) {
+                nodeVisits += 2;  // near now, far when the reference pops it (it always does)
+                if (farMaybe) TR_PUSH(farRef, farT);
+            } else {
+                nodeVisits += 1;
+                if (farMaybe) TR_PUSH(farRef, farT); else vmask |= 1ull << vd;
+                ++vd;
+            }
+            if (nearHit) cur = nearRef; else TR_POP();
+            TR_SETTLE();
+        }
+    }
+#undef TR_PUSH
+#undef TR_TOP
+#undef TR_POP
+#undef TR_SETTLE
+    unsigned long long nv = tr_wave_sum(nodeVisits), nt = tr_wave_sum(triTests);
+    if (lane == 0 && cn) {
+        atomicAdd(&cn->node_visits, nv);
+        atomicAdd(&cn->tri_tests, nt);
+    }
+}
+
+static TraceConfig g_cfg = {12, 256, 24, 16, 1.0009765625f};
+void set_trace_config(const TraceConfig &c) { g_cfg = c; }
+TraceConfig get_trace_config() { return g_cfg; }
+
+template <bool ANYHIT>
+static void launch_trace(const DScene &sc, RayQueue q, int maxCount, float4 *hits, float *tOut, int *occluded, TraceCounters *cn, hipStream_t s) {
+    const TraceConfig c = g_cfg;
+    int nSeg = (maxCount + c.segRays - 1) / c.segRays;
+    int nblk = (nSeg + TR_BLOCK / 64 - 1) / (TR_BLOCK / 64);
+    nblk = ((nblk + 7) / 8) * 8;
+    if (nblk == 0) return;
+    size_t lds = sizeof(uint2) * (size_t)c.depth * TR_BLOCK;
+    hipLaunchKernelGGL(k_trace<ANYHIT>, dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q, hits, tOut, occluded, cn, c.depth, c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK);
+}
+void launch_closest_wide(const DScene &sc, RayQueue q, int maxCount, float4 *hits, float *tOut, TraceCounters *cn, hipStream_t s) {
+    launch_trace<false>(sc, q, maxCount, hits, tOut, nullptr, cn, s);
+}
+void launch_anyhit_wide(const DScene &sc, RayQueue q, int maxCount, int *occluded, TraceCounters *cn, hipStream_t s) {
+    launch_trace<true>(sc, q, maxCount, nullptr, nullptr, occluded, cn, s);
+}
