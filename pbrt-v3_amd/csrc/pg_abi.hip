@@ -47,7 +47,7 @@ struct PgScene {
     // work buffers (sized on first render, reused)
     int capacity = 0;
     DeviceBuffer qo[4], qd[4], counts, hitsMain, hitsMis, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
-        lightTests, filmDev, straysDev, nStraysDev;
+        lightTests, filmDev, straysDev, nStraysDev, cullGuard, cursors;
     // test-path buffers
     DeviceBuffer tO, tD, tT, tPrim, tHit, tOcc, tCount;
     PgCounters counters;
@@ -145,8 +145,9 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         if (const char *e = getenv("PG_TRACE_DEPTH")) { int v = atoi(e); if (v >= 0 && v <= 64) tc.depth = v; }
         if (const char *e = getenv("PG_TRACE_SEG")) { int v = atoi(e); if (v >= 64) tc.segRays = v; }
         if (const char *e = getenv("PG_TRACE_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) tc.refillAt = v; }
+        if (const char *e = getenv("PG_TRACE_GRID")) { int v = atoi(e); if (v >= 8) tc.gridBlocks = v; }
         if (const char *e = getenv("PG_TRACE_TRIW")) { int v = atoi(e); if (v >= 0) tc.triW = v; }
-        if (const char *e = getenv("PG_TRACE_CULLK")) { float v = (float)atof(e); if (v >= 1.f) tc.cullK = v; }
+        if (const char *e = getenv("PG_TRACE_CULLK")) { float v = (float)atof(e); if (v >= 1.f) tc.cullK = v < 3e38f ? v : 3e38f; }  // finite: 0*inf would be NaN
         set_trace_config(tc);
     }
     // --- triangles: gather vertices into BVH order, 48 B per triangle
@@ -270,6 +271,9 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     }
     HIP_TRY_S(s->traceCn.alloc(sizeof(TraceCounters) * 2));
     HIP_TRY_S(hipMemset(s->traceCn.p, 0, s->traceCn.bytes));
+    HIP_TRY_S(s->cursors.alloc(8 * sizeof(int)));
+    HIP_TRY_S(s->cullGuard.alloc(sizeof(int)));
+    HIP_TRY_S(hipMemset(s->cullGuard.p, 0, sizeof(int)));
     HIP_TRY_S(s->lightTests.alloc(sizeof(unsigned long long)));
     HIP_TRY_S(hipMemset(s->lightTests.p, 0, s->lightTests.bytes));
     *out = s;
@@ -280,11 +284,24 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
 
 static void traceClosest(PgScene *s, RayQueue q, int maxCount, float4 *hits, float *tOut, TraceCounters *cn, hipStream_t st) {
     if (s->legacyTraversal) launch_closest(s->d, q, maxCount, hits, tOut, nullptr, cn, st);
-    else launch_closest_wide(s->d, q, maxCount, hits, tOut, cn, st);
+    else launch_closest_wide(s->d, q, maxCount, hits, tOut, cn, (int *)s->cursors.p, (int *)s->cullGuard.p, st);
 }
 static void traceAnyhit(PgScene *s, RayQueue q, int maxCount, int *occluded, TraceCounters *cn, hipStream_t st) {
     if (s->legacyTraversal) launch_anyhit(s->d, q, maxCount, occluded, cn, st);
-    else launch_anyhit_wide(s->d, q, maxCount, occluded, cn, st);
+    else launch_anyhit_wide(s->d, q, maxCount, occluded, cn, (int *)s->cursors.p, st);
+}
+
+// k_trace's early-cull margin is exact while no ray accepts more than TR_MAX_ACCEPTED hits (pg_traverse.hip); otherwise
+// the kernel raises this flag and the call fails instead of returning a possibly different image.
+static int checkCullGuard(PgScene *s) {
+    int g = 0;
+    HIP_TRY(hipMemcpy(&g, s->cullGuard.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (g) {
+        HIP_TRY(hipMemset(s->cullGuard.p, 0, sizeof(int)));
+        return setError(PG_ERR_OVERFLOW, "a ray accepted more than 4096 successive hits: the far-child cull margin is no longer provably exact; "
+                                         "set PG_TRACE_CULLK=inf to disable the margin");
+    }
+    return PG_OK;
 }
 
 static int tileCount(const PgRenderDesc *rd) {
@@ -362,7 +379,7 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
         return PG_OK;
     }
     // batch shape: as many whole tiles x samples as fit the path budget
-    size_t budget = (size_t)1 << 22;
+    size_t budget = (size_t)1 << 27;
     if (const char *e = getenv("PG_BATCH_PATHS")) { long v = atol(e); if (v >= 256) budget = (size_t)v; }
     int sPerBatch = rd->spp, tilesPerBatch = nLocalTiles;
     if ((size_t)tilesPerBatch * 256 * sPerBatch > budget) {
@@ -484,6 +501,7 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
     }
     float ms = 0;
     if (hipEventElapsedTime(&ms, evStart, evStop) == hipSuccess) c.render_ms += ms;
+    if (int st2 = checkCullGuard(s)) return st2;
     if (hostNStrays > maxStrays) return setError(PG_ERR_OVERFLOW, "%d stray samples, buffer holds %d", hostNStrays, maxStrays);
     return PG_OK;
 }
@@ -560,7 +578,7 @@ int pg_intersect(PgScene *s, int32_t n, const float *o, const float *d, const fl
     c.closest_launches += 1;
     float ms = 0;
     if (hipEventElapsedTime(&ms, a, b) == hipSuccess) c.closest_ms += ms;
-    return PG_OK;
+    return checkCullGuard(s);
 }
 
 int pg_intersect_p(PgScene *s, int32_t n, const float *o, const float *d, const float *tmax, uint8_t *occluded, int mem, void *streamPtr) {

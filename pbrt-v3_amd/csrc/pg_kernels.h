@@ -79,11 +79,12 @@ struct TraceCounters {
 // Tunables of k_trace: LDS stack entries per lane, rays per wave segment, idle-lane count that triggers a refill.
 // cullK: closest-hit far-child early-cull margin (pg_traverse.hip); exact while a ray's tMax never grows by more than
 // this factor through rounding (each accepted hit can raise it by <= 3 roundings, i.e. ~5000 successive raises).
-struct TraceConfig { int depth, segRays, refillAt, triW; float cullK; };
+struct TraceConfig { int depth, segRays /* rays per chunk */, refillAt, triW; float cullK; int gridBlocks; };
 void set_trace_config(const TraceConfig &c);
 TraceConfig get_trace_config();
-void launch_closest_wide(const DScene &sc, RayQueue q, int maxCount, float4 *hits, float *tOut, TraceCounters *cn, hipStream_t s);
-void launch_anyhit_wide(const DScene &sc, RayQueue q, int maxCount, int *occluded, TraceCounters *cn, hipStream_t s);
+void launch_closest_wide(const DScene &sc, RayQueue q, int maxCount, float4 *hits, float *tOut, TraceCounters *cn, int *cursors, int *cullGuard,
+                         hipStream_t s);
+void launch_anyhit_wide(const DScene &sc, RayQueue q, int maxCount, int *occluded, TraceCounters *cn, int *cursors, hipStream_t s);
 void launch_generate(const DScene &sc, const RenderParams &rp, PathState st, RayQueue q, hipStream_t s);
 void launch_closest(const DScene &sc, RayQueue q, int maxCount, float4 *hits, float *tOut, float *b2Out, TraceCounters *cn, hipStream_t s);
 void launch_anyhit(const DScene &sc, RayQueue q, int maxCount, int *occluded, TraceCounters *cn, hipStream_t s);

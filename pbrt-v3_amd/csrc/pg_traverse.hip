@@ -22,11 +22,13 @@
 //  * traversal stack: first `depth` entries per lane in LDS ([entry][lane],
 //    8 B entries, bank-conflict-free), the rest of pbrt's 64 in scratch.
 #include "pg_device.h"
+#include <algorithm>
 #include "pg_kernels.h"
 
 #define TR_BLOCK 256
 #define TR_NONE ((int)0x80000000)
 #define TR_STACK_TOTAL 64
+#define TR_MAX_ACCEPTED 4096  // (1+2^-24)^(3*4096) < 1+2^-10
 
 // Bounds3::IntersectP(ray, invDir, dirIsNeg), geometry.h:1412-1438, split into
 // the part that does not depend on ray.tMax (returns ok, tMin) and the final
@@ -68,22 +70,21 @@ PG_DEV unsigned long long tr_wave_sum(unsigned long long v) {
 
 template <bool ANYHIT>
 __global__ __launch_bounds__(TR_BLOCK) void k_trace(DScene sc, RayQueue q, float4 *__restrict__ hits, float *__restrict__ tOut,
-                                                    int *__restrict__ occluded, TraceCounters *cn, int depth, int segRays, int refillAt,
-                                                    int triW, float cullK) {
+                                                    int *__restrict__ occluded, TraceCounters *cn, int *__restrict__ cursors, int depth, int chunk,
+                                                    int refillAt, int triW, float cullK, int *cullGuard) {
     extern __shared__ uint2 ldsStack[];  // [depth][TR_BLOCK]
     uint2 spill[TR_STACK_TOTAL];
     const int n = *q.count;
-    const int nSeg = (n + segRays - 1) / segRays;
-    const int lb = tr_swizzled_block((nSeg + TR_BLOCK / 64 - 1) / (TR_BLOCK / 64));
-    if (lb < 0) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int seg = __builtin_amdgcn_readfirstlane(lb * (TR_BLOCK / 64) + (tid >> 6));
-    int next = seg * segRays;
-    const int segEnd = min(n, next + segRays);
-    if (next >= segEnd) return;
     const unsigned long long laneLt = (1ull << lane) - 1ull;
-
+    // Work distribution: the queue is cut into 8 contiguous regions, one per XCD (block b runs on XCD b % 8, so each
+    // private L2 sees one coherent part of the queue); a wave takes `chunk` rays at a time from its region's cursor
+    // and moves on to the next region when its own is drained.  Waves are persistent: the grid only has to fill the chip.
+    const int per = (((n + 7) >> 3) + chunk - 1) / chunk * chunk;
+    int region = blockIdx.x & 7, regionsTried = 0;
+    int next = 0, segEnd = 0;  // the wave's current chunk [next, segEnd)
+    bool exhausted = n == 0;
     // per-lane ray state.  A lane is in exactly one of three states:
     //   cur >= 0                 : holds an interior record to expand (its box test already passed)
     //   cur == NONE, triLeft > 0 : holds a leaf with triLeft untested triangles starting at triNext
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_trace(DScene sc, RayQueue q, float
     int vd = 0;                       // ANYHIT: reference stack depth (real + culled entries)
     unsigned long long vmask = 0;     // ANYHIT: bit i set = the reference's entry at depth i was culled early
     unsigned int nodeVisits = 0, triTests = 0;
+    int nAccepted = 0;  // hits accepted by this lane's current ray (bounds the rounding growth of tMax, see cullK below)
     const int leafBits = sc.leafBits, leafMask = (1 << leafBits) - 1;
 
 #define TR_PUSH(ref_, t_) do { uint2 e_ = make_uint2((unsigned)(ref_), __float_as_uint(t_)); \
@@ -123,8 +125,19 @@ __global__ __launch_bounds__(TR_BLOCK) void k_trace(DScene sc, RayQueue q, float
         }
         const unsigned long long idleMask = __ballot(idle);
         const int nIdle = __popcll(idleMask);
-        if (next < segEnd) {
-            if (nIdle >= refillAt) {
+        if (!exhausted && nIdle >= refillAt) {
+            if (next >= segEnd) {  // wave-uniform: take the next chunk
+                for (;;) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&cursors[region], chunk);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    const int r0 = region * per, r1 = min(n, r0 + per);
+                    if (r0 + base < r1) { next = r0 + base; segEnd = min(next + chunk, r1); break; }
+                    region = (region + 1) & 7;
+                    if (++regionsTried == 8) { exhausted = true; break; }
+                }
+            }
+            if (!exhausted) {
                 const int idx = next + __popcll(idleMask & laneLt);
                 next += nIdle;
                 if (idle && idx < segEnd) {
@@ -134,7 +147,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_trace(DScene sc, RayQueue q, float
                     dx = d4.x; dy = d4.y; dz = d4.z;
                     ix = 1 / dx; iy = 1 / dy; iz = 1 / dz;   // bvh.cpp:666
                     nx = ix < 0; ny = iy < 0; nz = iz < 0;   // bvh.cpp:667
-                    hitPrim = -1; hb0 = hb1 = hb2 = 0;
+                    hitPrim = -1; hb0 = hb1 = hb2 = 0; nAccepted = 0;
                     sp = 0; vd = 0; vmask = 0;
                     if (sc.nNodes > 0) {
                         ++nodeVisits;  // nodes[0]
@@ -146,9 +159,10 @@ __global__ __launch_bounds__(TR_BLOCK) void k_trace(DScene sc, RayQueue q, float
                         }
                     }
                 }
-                continue;  // lanes that finished at once (root miss) retire at the top
             }
-        } else if (nIdle == 64) break;
+            continue;  // lanes that finished at once (root miss) retire at the top
+        }
+        if (exhausted && nIdle == 64) break;
 
         // ---- one step for the wave: either every lane holding an interior record expands it, or every lane
         //      holding a leaf tests its next triangle.  The larger group goes first (weighted by triW/16), so
@@ -165,7 +179,10 @@ __global__ __launch_bounds__(TR_BLOCK) void k_trace(DScene sc, RayQueue q, float
                     !(__float_as_uint(a.w) & PG_TRI_BOGUS)) {
                     hitPrim = prim;
                     if (ANYHIT) { triLeft = 0; sp = 0; vd = 0; }  // bvh.cpp:717: return true
-                    else { tMax = t; hb0 = b0; hb1 = b1; hb2 = b2; }  // primitive.cpp:123: r.tMax = tHit
+                    else {
+                        tMax = t; hb0 = b0; hb1 = b1; hb2 = b2;  // primitive.cpp:123: r.tMax = tHit
+                        if (++nAccepted == TR_MAX_ACCEPTED) atomicOr(cullGuard, 1);
+                    }
                 }
                 if (triLeft == 0 && !(ANYHIT && hitPrim >= 0)) { TR_POP(); TR_SETTLE(); }
             }
@@ -183,8 +200,10 @@ __global__ __launch_bounds__(TR_BLOCK) void k_trace(DScene sc, RayQueue q, float
             const bool nearHit = (neg ? ok1 : ok0) && nearT < tMax;
             // Early cull of the far child.  ray.tMax is not monotone: Triangle::Intersect accepts tScaled <= tMax*det and then
             // returns t = tScaled*invDet, which can round to a few ulps ABOVE the old tMax (triangle.cpp:262-283), so an entry
-            // that fails `tMin < tMax` now could still pass when the reference pops it.  Cull only beyond the margin cullK
-            // (any-hit: tMax is constant, cullK = 1); survivors are re-tested exactly at pop time.
+            // that fails `tMin < tMax` now could still pass when the reference pops it.  Each accepted hit raises tMax by at
+            // most three roundings, (1+2^-24)^3, so after <= TR_MAX_ACCEPTED accepted hits tMax < (1+2^-10) * any earlier
+            // value: cull only beyond cullK = 1+2^-10 (any-hit: tMax is constant, cullK = 1); survivors are re-tested
+            // exactly at pop time, and a ray that accepts more hits than that raises cullGuard so the host fails loudly.
             const bool farMaybe = (neg ? ok0 : ok1) && farT < tMax * cullK;
             if (!ANYHIT) {
                 nodeVisits += 2;  // near now, far when the reference pops it (it always does)
@@ -209,23 +228,28 @@ __global__ __launch_bounds__(TR_BLOCK) void k_trace(DScene sc, RayQueue q, float
     }
 }
 
-static TraceConfig g_cfg = {12, 256, 24, 16, 1.0009765625f};
+static TraceConfig g_cfg = {12, 128, 8, 8, 1.0009765625f, 2048};
 void set_trace_config(const TraceConfig &c) { g_cfg = c; }
 TraceConfig get_trace_config() { return g_cfg; }
 
 template <bool ANYHIT>
-static void launch_trace(const DScene &sc, RayQueue q, int maxCount, float4 *hits, float *tOut, int *occluded, TraceCounters *cn, hipStream_t s) {
+static void launch_trace(const DScene &sc, RayQueue q, int maxCount, float4 *hits, float *tOut, int *occluded, TraceCounters *cn, int *cursors,
+                         int *cullGuard, hipStream_t s) {
     const TraceConfig c = g_cfg;
-    int nSeg = (maxCount + c.segRays - 1) / c.segRays;
-    int nblk = (nSeg + TR_BLOCK / 64 - 1) / (TR_BLOCK / 64);
+    if (maxCount <= 0) return;
+    // persistent grid: enough blocks to fill 256 CUs at 8 blocks each, never more than the queue can feed
+    long long need = ((long long)maxCount + c.segRays - 1) / c.segRays;      // chunks
+    int nblk = (int)std::min<long long>((need + TR_BLOCK / 64 - 1) / (TR_BLOCK / 64), (long long)c.gridBlocks);
     nblk = ((nblk + 7) / 8) * 8;
-    if (nblk == 0) return;
     size_t lds = sizeof(uint2) * (size_t)c.depth * TR_BLOCK;
-    hipLaunchKernelGGL(k_trace<ANYHIT>, dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q, hits, tOut, occluded, cn, c.depth, c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK);
+    (void)hipMemsetAsync(cursors, 0, 8 * sizeof(int), s);
+    hipLaunchKernelGGL(k_trace<ANYHIT>, dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q, hits, tOut, occluded, cn, cursors, c.depth, c.segRays,
+                       c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard);
 }
-void launch_closest_wide(const DScene &sc, RayQueue q, int maxCount, float4 *hits, float *tOut, TraceCounters *cn, hipStream_t s) {
-    launch_trace<false>(sc, q, maxCount, hits, tOut, nullptr, cn, s);
+void launch_closest_wide(const DScene &sc, RayQueue q, int maxCount, float4 *hits, float *tOut, TraceCounters *cn, int *cursors, int *cullGuard,
+                         hipStream_t s) {
+    launch_trace<false>(sc, q, maxCount, hits, tOut, nullptr, cn, cursors, cullGuard, s);
 }
-void launch_anyhit_wide(const DScene &sc, RayQueue q, int maxCount, int *occluded, TraceCounters *cn, hipStream_t s) {
-    launch_trace<true>(sc, q, maxCount, nullptr, nullptr, occluded, cn, s);
+void launch_anyhit_wide(const DScene &sc, RayQueue q, int maxCount, int *occluded, TraceCounters *cn, int *cursors, hipStream_t s) {
+    launch_trace<true>(sc, q, maxCount, nullptr, nullptr, occluded, cn, cursors, nullptr, s);
 }
