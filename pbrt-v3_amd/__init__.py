@@ -24,7 +24,7 @@ from .abi import (PgCounters, PgFilmPixel, PgRenderDesc, PgSceneDesc, PgStraySam
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_LIB_PATH = os.path.join(_HERE, "libpbrt_host.so")
-GPU_LIB_PATH = os.path.join(_HERE, "libpbrt_gpu.so")
+GPU_LIB_PATH = os.environ.get("PBRT_GPU_LIB") or os.path.join(_HERE, "libpbrt_gpu.so")  # override: kernel A/B builds only
 
 FILM_PIXEL_DTYPE = np.dtype([("rgb", np.float32, 3), ("weight", np.float32)])
 STRAY_DTYPE = np.dtype([("px", np.int32), ("py", np.int32), ("src_px", np.int32), ("src_py", np.int32),

@@ -2,6 +2,7 @@
 // render loop (SamplerIntegrator::Render, integrator.cpp:228-339, re-ordered
 // into batches of camera samples that advance one bounce per launch), and the
 // batched Scene::Intersect/IntersectP entry points.
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -53,7 +54,6 @@ struct PgScene {
     PgCounters counters;
     std::vector<hipEvent_t> events;
     bool hasNullMaterial = false;
-    bool legacyTraversal = false;  // PG_TRAVERSE_LEGACY=1: the round-1 32-B-node kernels (A/B only)
 };
 
 extern "C" {
@@ -140,7 +140,6 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
             for (int k = 0; k < 3; ++k) { d.rootBox[k] = desc->nodes[0].bmin[k]; d.rootBox[3 + k] = desc->nodes[0].bmax[k]; }
             d.rootRef = refOf(0);
         }
-        if (const char *e = getenv("PG_TRAVERSE_LEGACY")) s->legacyTraversal = atoi(e) != 0;
         TraceConfig tc = get_trace_config();
         if (const char *e = getenv("PG_TRACE_DEPTH")) { int v = atoi(e); if (v >= 0 && v <= 64) tc.depth = v; }
         if (const char *e = getenv("PG_TRACE_SEG")) { int v = atoi(e); if (v >= 64) tc.segRays = v; }
@@ -271,7 +270,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     }
     HIP_TRY_S(s->traceCn.alloc(sizeof(TraceCounters) * 2));
     HIP_TRY_S(hipMemset(s->traceCn.p, 0, s->traceCn.bytes));
-    HIP_TRY_S(s->cursors.alloc(8 * sizeof(int)));
+    HIP_TRY_S(s->cursors.alloc(PG_REGIONS * PG_COUNT_STRIDE * sizeof(int)));
     HIP_TRY_S(s->cullGuard.alloc(sizeof(int)));
     HIP_TRY_S(hipMemset(s->cullGuard.p, 0, sizeof(int)));
     HIP_TRY_S(s->lightTests.alloc(sizeof(unsigned long long)));
@@ -282,13 +281,11 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
 #undef HIP_TRY_S
 }
 
-static void traceClosest(PgScene *s, RayQueue q, int maxCount, float4 *hits, float *tOut, TraceCounters *cn, hipStream_t st) {
-    if (s->legacyTraversal) launch_closest(s->d, q, maxCount, hits, tOut, nullptr, cn, st);
-    else launch_closest_wide(s->d, q, maxCount, hits, tOut, cn, (int *)s->cursors.p, (int *)s->cullGuard.p, st);
+static void traceClosest(PgScene *s, RayQueue q, float4 *hits, float *tOut, TraceCounters *cn, hipStream_t st) {
+    launch_closest(s->d, q, hits, tOut, cn, (int *)s->cursors.p, (int *)s->cullGuard.p, st);
 }
-static void traceAnyhit(PgScene *s, RayQueue q, int maxCount, int *occluded, TraceCounters *cn, hipStream_t st) {
-    if (s->legacyTraversal) launch_anyhit(s->d, q, maxCount, occluded, cn, st);
-    else launch_anyhit_wide(s->d, q, maxCount, occluded, cn, (int *)s->cursors.p, st);
+static void traceAnyhit(PgScene *s, RayQueue q, int *occluded, TraceCounters *cn, hipStream_t st) {
+    launch_anyhit(s->d, q, occluded, cn, (int *)s->cursors.p, st);
 }
 
 // k_trace's early-cull margin is exact while no ray accepts more than TR_MAX_ACCEPTED hits (pg_traverse.hip); otherwise
@@ -315,11 +312,17 @@ int pg_render_tile_count(const PgRenderDesc *desc) {
     return tileCount(desc);
 }
 
+// Queue geometry for a batch of `capacity` path slots: PG_REGIONS regions of regionCap entries (multiple of 256) such
+// that the blocks of one XCD (b % 8) can never overflow their region.
+static int regionCapFor(int capacity) {
+    int nblk = (capacity + 255) / 256;
+    return ((nblk + PG_REGIONS - 1) / PG_REGIONS) * 256;
+}
 static int ensureWorkBuffers(PgScene *s, int capacity) {
     if (s->capacity >= capacity) return PG_OK;
-    const size_t n = (size_t)capacity;
+    const size_t n = (size_t)regionCapFor(capacity) * PG_REGIONS;  // >= capacity
     for (int i = 0; i < 4; ++i) { HIP_TRY(s->qo[i].alloc(n * sizeof(float4))); HIP_TRY(s->qd[i].alloc(n * sizeof(float4))); }
-    HIP_TRY(s->counts.alloc(4 * sizeof(int)));
+    HIP_TRY(s->counts.alloc(4 * PG_REGIONS * PG_COUNT_STRIDE * sizeof(int)));
     HIP_TRY(s->hitsMain.alloc(n * sizeof(float4)));
     HIP_TRY(s->hitsMis.alloc(n * sizeof(float4)));
     HIP_TRY(s->occluded.alloc(n * sizeof(int)));
@@ -396,7 +399,10 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
     ps.pdLight = (float4 *)s->pdLight.p; ps.pdMis = (float4 *)s->pdMis.p; ps.pdBeta = (float4 *)s->pdBeta.p; ps.pdInfo = (int4 *)s->pdInfo.p;
     int *counts = (int *)s->counts.p;
     RayQueue q[4];
-    for (int i = 0; i < 4; ++i) { q[i].o = (float4 *)s->qo[i].p; q[i].d = (float4 *)s->qd[i].p; q[i].count = counts + i; }
+    const int QSTRIDE = PG_REGIONS * PG_COUNT_STRIDE;  // ints of counter storage per queue
+    for (int i = 0; i < 4; ++i) { q[i].o = (float4 *)s->qo[i].p; q[i].d = (float4 *)s->qd[i].p; q[i].counts = counts + i * QSTRIDE; }
+    // sum of a queue's region counters in a host copy of the counter block
+    auto queueTotal = [&](const int *blk, int qi) { uint64_t t = 0; for (int r = 0; r < PG_REGIONS; ++r) t += (uint64_t)blk[qi * QSTRIDE + r * PG_COUNT_STRIDE]; return t; };
     TraceCounters *cnClosest = (TraceCounters *)s->traceCn.p, *cnShadow = cnClosest + 1;
     unsigned long long *lightTests = (unsigned long long *)s->lightTests.p;
 
@@ -409,7 +415,8 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
     std::vector<int> hostCounts;  // read back once per batch at the end (pinned copy not needed: tiny)
     DeviceBuffer countLog;        // per-bounce queue sizes, copied back after the batch for the ray statistics
     const int maxIters = rd->max_depth + 1 + (s->hasNullMaterial ? 64 : 0);
-    HIP_TRY(countLog.alloc(sizeof(int) * 4 * (size_t)(maxIters + 1)));
+    HIP_TRY(countLog.alloc(sizeof(int) * 4 * QSTRIDE * (size_t)(maxIters + 1)));
+    std::vector<int> curQueueOfBounce;
 
     for (int tile0 = 0; tile0 < nLocalTiles; tile0 += tilesPerBatch) {
         for (int s0 = 0; s0 < rd->spp; s0 += sPerBatch) {
@@ -418,7 +425,9 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
             rp.s0 = s0;
             rp.sCount = std::min(sPerBatch, rd->spp - s0);
             rp.capacity = rp.nTilesBatch * 256 * rp.sCount;
-            HIP_TRY(hipMemsetAsync(counts, 0, 4 * sizeof(int), stream));
+            for (int i = 0; i < 4; ++i) q[i].regionCap = regionCapFor(rp.capacity);
+            curQueueOfBounce.clear();
+            HIP_TRY(hipMemsetAsync(counts, 0, 4 * QSTRIDE * sizeof(int), stream));
             int cur = 0;  // main queue index (0/1 ping-pong); 2 = shadow, 3 = MIS
             launch_generate(s->d, rp, ps, q[cur], stream);
             int iters = 0;
@@ -427,45 +436,46 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
                 hipEvent_t a = getEvent(s, ev), b = getEvent(s, ev + 1);
                 timed.push_back({ev, 0}); ev += 2;
                 HIP_TRY(hipEventRecord(a, stream));
-                traceClosest(s, q[cur], rp.capacity, (float4 *)s->hitsMain.p, nullptr, cnClosest, stream);
+                traceClosest(s, q[cur], (float4 *)s->hitsMain.p, nullptr, cnClosest, stream);
                 HIP_TRY(hipEventRecord(b, stream));
                 ++closestLaunches;
-                HIP_TRY(hipMemsetAsync(counts + nxt, 0, sizeof(int), stream));
-                HIP_TRY(hipMemsetAsync(counts + 2, 0, 2 * sizeof(int), stream));
-                launch_shade(s->d, rp, ps, q[cur], (const float4 *)s->hitsMain.p, q[nxt], q[2], q[3], rp.capacity, lightTests, stream);
+                HIP_TRY(hipMemsetAsync(counts + nxt * QSTRIDE, 0, QSTRIDE * sizeof(int), stream));
+                HIP_TRY(hipMemsetAsync(counts + 2 * QSTRIDE, 0, 2 * QSTRIDE * sizeof(int), stream));
+                launch_shade(s->d, rp, ps, q[cur], (const float4 *)s->hitsMain.p, q[nxt], q[2], q[3], lightTests, stream);
                 a = getEvent(s, ev); b = getEvent(s, ev + 1);
                 timed.push_back({ev, 1}); ev += 2;
                 HIP_TRY(hipEventRecord(a, stream));
-                traceAnyhit(s, q[2], rp.capacity, (int *)s->occluded.p, cnShadow, stream);
+                traceAnyhit(s, q[2], (int *)s->occluded.p, cnShadow, stream);
                 HIP_TRY(hipEventRecord(b, stream));
                 ++shadowLaunches;
                 a = getEvent(s, ev); b = getEvent(s, ev + 1);
                 timed.push_back({ev, 0}); ev += 2;
                 HIP_TRY(hipEventRecord(a, stream));
-                traceClosest(s, q[3], rp.capacity, (float4 *)s->hitsMis.p, nullptr, cnClosest, stream);
+                traceClosest(s, q[3], (float4 *)s->hitsMis.p, nullptr, cnClosest, stream);
                 HIP_TRY(hipEventRecord(b, stream));
                 ++closestLaunches;
-                launch_resolve(s->d, ps, q[cur], q[3], (const int *)s->occluded.p, (const float4 *)s->hitsMis.p, rp.capacity, stream);
+                launch_resolve(s->d, ps, q[cur], q[3], (const int *)s->occluded.p, (const float4 *)s->hitsMis.p, stream);
                 // log this bounce's queue sizes: [cur main, shadow, mis]
-                HIP_TRY(hipMemcpyAsync((int *)countLog.p + 4 * bounce, counts + cur, sizeof(int), hipMemcpyDeviceToDevice, stream));
-                HIP_TRY(hipMemcpyAsync((int *)countLog.p + 4 * bounce + 1, counts + 2, 2 * sizeof(int), hipMemcpyDeviceToDevice, stream));
+                HIP_TRY(hipMemcpyAsync((int *)countLog.p + 4 * QSTRIDE * (size_t)bounce, counts, 4 * QSTRIDE * sizeof(int), hipMemcpyDeviceToDevice, stream));
+                curQueueOfBounce.push_back(cur);
                 cur = nxt;
                 if (s->hasNullMaterial && bounce >= rd->max_depth) {
-                    int left = 0;
-                    HIP_TRY(hipMemcpyAsync(&left, counts + cur, sizeof(int), hipMemcpyDeviceToHost, stream));
+                    std::vector<int> blk(4 * QSTRIDE);
+                    HIP_TRY(hipMemcpyAsync(blk.data(), counts, 4 * QSTRIDE * sizeof(int), hipMemcpyDeviceToHost, stream));
                     HIP_TRY(hipStreamSynchronize(stream));
-                    if (left == 0) { ++iters; break; }
+                    if (queueTotal(blk.data(), cur) == 0) { ++iters; break; }
                 }
             }
             launch_film(rp, ps, dFilm, dStrays, maxStrays, dNStrays, stream);
-            hostCounts.resize(4 * (size_t)iters);
-            HIP_TRY(hipMemcpyAsync(hostCounts.data(), countLog.p, sizeof(int) * 4 * (size_t)iters, hipMemcpyDeviceToHost, stream));
+            hostCounts.resize(4 * QSTRIDE * (size_t)iters);
+            HIP_TRY(hipMemcpyAsync(hostCounts.data(), countLog.p, sizeof(int) * 4 * QSTRIDE * (size_t)iters, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             for (int b = 0; b < iters; ++b) {
-                closestRays += (uint64_t)hostCounts[4 * b] + (uint64_t)hostCounts[4 * b + 2];
-                shadowRays += (uint64_t)hostCounts[4 * b + 1];
+                const int *blk = hostCounts.data() + 4 * QSTRIDE * (size_t)b;
+                closestRays += queueTotal(blk, curQueueOfBounce[b]) + queueTotal(blk, 3);
+                shadowRays += queueTotal(blk, 2);
             }
-            if (iters > 0) cameraRays += (uint64_t)hostCounts[0];
+            if (iters > 0) cameraRays += queueTotal(hostCounts.data(), curQueueOfBounce[0]);
         }
     }
     HIP_TRY(hipEventRecord(evStop, stream));
@@ -527,12 +537,21 @@ static int uploadRays(PgScene *s, int n, const float *o, const float *d, const f
     }
     HIP_TRY(s->tO.alloc(sizeof(float4) * (size_t)n));
     HIP_TRY(s->tD.alloc(sizeof(float4) * (size_t)n));
-    HIP_TRY(s->tCount.alloc(sizeof(int)));
+    // the rays fill the regions front to back: region r holds rays [r*cap, r*cap + count(r))
+    const int cap = regionCapFor(n);
+    int hc[PG_REGIONS * PG_COUNT_STRIDE] = {0};
+    for (int r = 0; r < PG_REGIONS; ++r) hc[r * PG_COUNT_STRIDE] = std::max(0, std::min(cap, n - r * cap));
+    HIP_TRY(s->tCount.alloc(sizeof(hc)));
     HIP_TRY(hipMemcpyAsync(s->tO.p, qo.data(), s->tO.bytes, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(s->tD.p, qd.data(), s->tD.bytes, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(s->tCount.p, &n, sizeof(int), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(s->tCount.p, hc, sizeof(hc), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return PG_OK;
+}
+static RayQueue testQueue(PgScene *s, int n) {
+    RayQueue q;
+    q.o = (float4 *)s->tO.p; q.d = (float4 *)s->tD.p; q.counts = (int *)s->tCount.p; q.regionCap = regionCapFor(n);
+    return q;
 }
 
 int pg_intersect(PgScene *s, int32_t n, const float *o, const float *d, const float *tmax, int32_t *prim, float *t, float *bary, int mem,
@@ -545,11 +564,10 @@ int pg_intersect(PgScene *s, int32_t n, const float *o, const float *d, const fl
     if (st != PG_OK) return st;
     HIP_TRY(s->tHit.alloc(sizeof(float4) * (size_t)n));
     HIP_TRY(s->tT.alloc(sizeof(float) * (size_t)n));
-    RayQueue q;
-    q.o = (float4 *)s->tO.p; q.d = (float4 *)s->tD.p; q.count = (int *)s->tCount.p;
+    RayQueue q = testQueue(s, n);
     hipEvent_t a = getEvent(s, 0), b = getEvent(s, 1);
     HIP_TRY(hipEventRecord(a, stream));
-    traceClosest(s, q, n, (float4 *)s->tHit.p, (float *)s->tT.p, (TraceCounters *)s->traceCn.p, stream);
+    traceClosest(s, q, (float4 *)s->tHit.p, (float *)s->tT.p, (TraceCounters *)s->traceCn.p, stream);
     HIP_TRY(hipEventRecord(b, stream));
     HIP_TRY(hipGetLastError());
     std::vector<float4> hits((size_t)n);
@@ -589,11 +607,10 @@ int pg_intersect_p(PgScene *s, int32_t n, const float *o, const float *d, const 
     int st = uploadRays(s, n, o, d, tmax, mem, stream);
     if (st != PG_OK) return st;
     HIP_TRY(s->tOcc.alloc(sizeof(int) * (size_t)n));
-    RayQueue q;
-    q.o = (float4 *)s->tO.p; q.d = (float4 *)s->tD.p; q.count = (int *)s->tCount.p;
+    RayQueue q = testQueue(s, n);
     hipEvent_t a = getEvent(s, 0), b = getEvent(s, 1);
     HIP_TRY(hipEventRecord(a, stream));
-    traceAnyhit(s, q, n, (int *)s->tOcc.p, (TraceCounters *)s->traceCn.p + 1, stream);
+    traceAnyhit(s, q, (int *)s->tOcc.p, (TraceCounters *)s->traceCn.p + 1, stream);
     HIP_TRY(hipEventRecord(b, stream));
     HIP_TRY(hipGetLastError());
     std::vector<int> occ((size_t)n);

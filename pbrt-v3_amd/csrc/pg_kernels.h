@@ -43,11 +43,18 @@ struct DScene {
 
 // A queue of rays in SoA float4 pairs: 32 B per ray
 //   o[i] = (o.x, o.y, o.z, tMax)   d[i] = (d.x, d.y, d.z, slot id bits)
+// The queue is PG_REGIONS sub-queues ("regions"), one per XCD: region r owns entries [r*regionCap, r*regionCap + count(r))
+// and its own append counter on its own 128-B line.  A producer block b appends to region b % 8 (= the XCD it runs on)
+// with ONE atomic per block, so no counter sees more than 1/8 of the blocks; consumers walk the regions the same way.
+#define PG_REGIONS 8
+#define PG_COUNT_STRIDE 32  // ints between two region counters (128 B)
 struct RayQueue {
     float4 *o;
     float4 *d;
-    int *count;  // device counter
+    int *counts;    // PG_REGIONS counters, PG_COUNT_STRIDE ints apart
+    int regionCap;  // entries per region (multiple of 256)
 };
+__host__ __device__ inline int queue_region_count(const RayQueue &q, int r) { return q.counts[r * PG_COUNT_STRIDE]; }
 
 // Per-path state, indexed by slot.
 struct PathState {
@@ -82,16 +89,12 @@ struct TraceCounters {
 struct TraceConfig { int depth, segRays /* rays per chunk */, refillAt, triW; float cullK; int gridBlocks; };
 void set_trace_config(const TraceConfig &c);
 TraceConfig get_trace_config();
-void launch_closest_wide(const DScene &sc, RayQueue q, int maxCount, float4 *hits, float *tOut, TraceCounters *cn, int *cursors, int *cullGuard,
-                         hipStream_t s);
-void launch_anyhit_wide(const DScene &sc, RayQueue q, int maxCount, int *occluded, TraceCounters *cn, int *cursors, hipStream_t s);
+void launch_closest(const DScene &sc, RayQueue q, float4 *hits, float *tOut, TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s);
+void launch_anyhit(const DScene &sc, RayQueue q, int *occluded, TraceCounters *cn, int *cursors, hipStream_t s);
 void launch_generate(const DScene &sc, const RenderParams &rp, PathState st, RayQueue q, hipStream_t s);
-void launch_closest(const DScene &sc, RayQueue q, int maxCount, float4 *hits, float *tOut, float *b2Out, TraceCounters *cn, hipStream_t s);
-void launch_anyhit(const DScene &sc, RayQueue q, int maxCount, int *occluded, TraceCounters *cn, hipStream_t s);
 void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQueue qin, const float4 *hits, RayQueue qnext,
-                  RayQueue qshadow, RayQueue qmis, int maxCount, unsigned long long *lightTriTests, hipStream_t s);
-void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis, const int *occluded, const float4 *misHits,
-                    int maxCount, hipStream_t s);
+                  RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s);
+void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis, const int *occluded, const float4 *misHits, hipStream_t s);
 void launch_film(const RenderParams &rp, PathState st, PgFilmPixel *film, PgStraySample *strays, int maxStrays, int *nStrays,
                  hipStream_t s);
 void launch_light_tables(const DScene &sc, float *table, int nDistributions, hipStream_t s);

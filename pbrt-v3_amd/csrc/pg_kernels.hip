@@ -3,7 +3,7 @@
 // (32 B/ray as two float4) instead of pbrt's per-ray recursion:
 //
 //   k_generate   HaltonSampler + PerspectiveCamera   (sampler.cpp:46-52, halton.cpp:96-127, perspective.cpp:95-144)
-//   k_traverse   BVHAccel::Intersect / IntersectP + Triangle::Intersect[P]  (bvh.cpp:662-738, triangle.cpp:188-572)
+//   k_trace      BVHAccel::Intersect / IntersectP + Triangle::Intersect[P]  (pg_traverse.hip)
 //   k_shade      PathIntegrator::Li loop body + EstimateDirect set-up      (path.cpp:81-187, integrator.cpp:85-215)
 //   k_resolve    EstimateDirect's visibility / MIS terms once rays are back (integrator.cpp:143-212)
 //   k_film       SamplerIntegrator::Render's scrub + FilmTile::AddSample    (integrator.cpp:294-320, film.h:121-161)
@@ -15,38 +15,45 @@
 #include "pg_kernels.h"
 
 #define PG_BLOCK 256
-// Per-lane traversal stack: the first PG_STACK_LDS entries live in LDS laid out
-// [entry][lane] (conflict-free: bank = lane % 32 for every entry), the rest of
-// pbrt's 64 entries (bvh.cpp:669) spill to a private array that is only
-// touched by unusually deep walks.
-#ifndef PG_STACK_LDS
-#define PG_STACK_LDS 20
-#endif
-#define PG_STACK_TOTAL 64
-
 PG_DEV int lane_id() { return __lane_id(); }
 
-// XCD-aware block remap: the dispatcher places block b on XCD b % 8; give each
-// XCD a contiguous eighth of the queue so its private L2 sees one coherent
-// region of the BVH instead of every eighth block of all of them.
-PG_DEV int swizzled_block(int nblk) {
-    int per = (nblk + 7) >> 3;
-    int b = blockIdx.x;
-    if (b >= per * 8) return -1;
-    int lb = (b & 7) * per + (b >> 3);
-    return lb < nblk ? lb : -1;
+// Queue append, aggregated per block: every wave ballots its pushes, the block sums them through LDS and ONE lane per
+// queue does the atomicAdd on the block's region counter (region = blockIdx.x % 8); lanes get consecutive entries in
+// (wave, lane) order.  NQ queues are appended to in one exchange (two barriers).  Must be reached by all threads.
+// Consumers and producers share one mapping: block b owns entries [(b>>3)*256, +256) of region b & 7.
+template <int NQ>
+PG_DEV void block_push(const RayQueue *q, const bool *pred, int *pos) {
+    __shared__ int s_cnt[NQ][PG_BLOCK / 64];
+    __shared__ int s_base[NQ];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    unsigned long long mask[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        mask[k] = __ballot(pred[k]);
+        if (lane == 0) s_cnt[k][wave] = __popcll(mask[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x < NQ) {
+        const int k = threadIdx.x;
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < PG_BLOCK / 64; ++w) total += s_cnt[k][w];
+        const int r = blockIdx.x & (PG_REGIONS - 1);
+        s_base[k] = total ? r * q[k].regionCap + atomicAdd(&q[k].counts[r * PG_COUNT_STRIDE], total) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        int off = s_base[k];
+        for (int w = 0; w < wave; ++w) off += s_cnt[k][w];
+        pos[k] = pred[k] ? off + __popcll(mask[k] & ((1ull << lane) - 1ull)) : -1;
+    }
 }
-
-// Wave-ballot compaction: one atomicAdd per wave, lanes get consecutive slots.
-PG_DEV int queue_push(int *counter, bool pred) {
-    unsigned long long mask = __ballot(pred);
-    if (mask == 0) return -1;
-    int lane = lane_id();
-    int leader = __ffsll((long long)mask) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(counter, __popcll(mask));
-    base = __shfl(base, leader);
-    return pred ? base + __popcll(mask & ((1ull << lane) - 1ull)) : -1;
+// The queue entry this thread consumes (or -1): block b walks region b & 7.
+PG_DEV int queue_item(const RayQueue &q) {
+    const int r = blockIdx.x & (PG_REGIONS - 1);
+    const int j = (blockIdx.x >> 3) * PG_BLOCK + threadIdx.x;
+    return j < q.counts[r * PG_COUNT_STRIDE] ? r * q.regionCap + j : -1;
 }
 
 PG_DEV unsigned long long wave_sum(unsigned long long v) {
@@ -61,104 +68,6 @@ PG_DEV Tri load_tri(const DScene &sc, int prim) {
     t.p0 = mk(a.x, a.y, a.z); t.p1 = mk(b.x, b.y, b.z); t.p2 = mk(c.x, c.y, c.z);
     t.flags = __float_as_uint(a.w); t.material = __float_as_int(b.w); t.light = __float_as_int(c.w);
     return t;
-}
-
-// ===========================================================================
-// BVH traversal: BVHAccel::Intersect (ANYHIT=false, bvh.cpp:662-700) and
-// BVHAccel::IntersectP (ANYHIT=true, bvh.cpp:702-738).  One ray per lane.
-// "while-while" scheduling: lanes walk interior nodes until each holds a leaf,
-// then the wave tests triangles together; per-lane visiting order, tMax
-// shrinking and tie-breaking are exactly the reference's.
-// ===========================================================================
-template <bool ANYHIT>
-__global__ __launch_bounds__(PG_BLOCK) void k_traverse(DScene sc, RayQueue q, float4 *__restrict__ hits, float *__restrict__ tOut,
-                                                       int *__restrict__ occluded, TraceCounters *cn) {
-    __shared__ int ldsStack[PG_STACK_LDS][PG_BLOCK];
-    int spill[PG_STACK_TOTAL - PG_STACK_LDS];
-    const int n = *q.count;
-    const int lb = swizzled_block((n + PG_BLOCK - 1) / PG_BLOCK);
-    if (lb < 0) return;
-    const int tid = threadIdx.x;
-    const int i = lb * PG_BLOCK + tid;
-    const bool valid = i < n;
-    float4 o4 = valid ? q.o[i] : make_float4(0, 0, 0, 0);
-    float4 d4 = valid ? q.d[i] : make_float4(1, 1, 1, 0);
-    const V3 o = mk(o4.x, o4.y, o4.z), d = mk(d4.x, d4.y, d4.z);
-    float tMax = o4.w;
-    const V3 invDir = mk(1 / d.x, 1 / d.y, 1 / d.z);
-    const bool nx = invDir.x < 0, ny = invDir.y < 0, nz = invDir.z < 0;
-    int hitPrim = -1;
-    float hb0 = 0, hb1 = 0, hb2 = 0;
-    unsigned int nodeVisits = 0, triTests = 0;
-    int sp = 0, cur = 0;
-    int leafOff = 0, leafN = 0;
-    bool done = !valid || sc.nNodes == 0;
-
-#define PG_PUSH(v) do { int v_ = (v); if (sp < PG_STACK_LDS) ldsStack[sp][tid] = v_; else spill[sp - PG_STACK_LDS] = v_; ++sp; } while (0)
-#define PG_POP_OR_DONE() do { if (sp == 0) done = true; else { --sp; cur = (sp < PG_STACK_LDS) ? ldsStack[sp][tid] : spill[sp - PG_STACK_LDS]; } } while (0)
-
-    while (__any(!done)) {
-        // ---- phase 1: descend through interior nodes until this lane holds a leaf
-        leafN = 0;
-        while (!done && leafN == 0) {
-            const float4 n0 = sc.nodes[2 * cur], n1 = sc.nodes[2 * cur + 1];
-            ++nodeVisits;
-            if (slab_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, o, invDir, nx, ny, nz, tMax)) {
-                const int off = __float_as_int(n1.z);
-                const uint32_t meta = __float_as_uint(n1.w);
-                const int np = meta & 0xffff;
-                if (np > 0) { leafOff = off; leafN = np; }
-                else {
-                    const int axis = (meta >> 16) & 0xff;
-                    const bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);
-                    if (neg) { PG_PUSH(cur + 1); cur = off; }
-                    else { PG_PUSH(off); cur = cur + 1; }
-                }
-            } else PG_POP_OR_DONE();
-        }
-        // ---- phase 2: test the leaf's triangles in order
-        if (leafN > 0) {
-            for (int k = 0; k < leafN; ++k) {
-                const int prim = leafOff + k;
-                const float4 a = sc.tris[3 * prim], b = sc.tris[3 * prim + 1], c = sc.tris[3 * prim + 2];
-                ++triTests;
-                float t, b0, b1, b2;
-                if (tri_test(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), o, d, tMax, t, b0, b1, b2) &&
-                    !(__float_as_uint(a.w) & PG_TRI_BOGUS)) {
-                    if (ANYHIT) { hitPrim = prim; done = true; break; }
-                    hitPrim = prim; tMax = t; hb0 = b0; hb1 = b1; hb2 = b2;  // primitive.cpp:123: r.tMax = tHit
-                }
-            }
-            if (!done) PG_POP_OR_DONE();
-        }
-    }
-#undef PG_PUSH
-#undef PG_POP_OR_DONE
-    if (valid) {
-        if (ANYHIT) occluded[i] = hitPrim >= 0 ? 1 : 0;
-        else {
-            hits[i] = make_float4(__int_as_float(hitPrim), hb0, hb1, hb2);
-            if (tOut) tOut[i] = tMax;
-        }
-    }
-    unsigned long long nv = wave_sum(nodeVisits), nt = wave_sum(triTests);
-    if (lane_id() == 0 && cn) {
-        atomicAdd(&cn->node_visits, nv);
-        atomicAdd(&cn->tri_tests, nt);
-    }
-}
-
-void launch_closest(const DScene &sc, RayQueue q, int maxCount, float4 *hits, float *tOut, float *, TraceCounters *cn, hipStream_t s) {
-    int nblk = (maxCount + PG_BLOCK - 1) / PG_BLOCK;
-    nblk = ((nblk + 7) / 8) * 8;
-    if (nblk == 0) return;
-    hipLaunchKernelGGL(k_traverse<false>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, q, hits, tOut, (int *)nullptr, cn);
-}
-void launch_anyhit(const DScene &sc, RayQueue q, int maxCount, int *occluded, TraceCounters *cn, hipStream_t s) {
-    int nblk = (maxCount + PG_BLOCK - 1) / PG_BLOCK;
-    nblk = ((nblk + 7) / 8) * 8;
-    if (nblk == 0) return;
-    hipLaunchKernelGGL(k_traverse<true>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, q, (float4 *)nullptr, (float *)nullptr, occluded, cn);
 }
 
 // ===========================================================================
@@ -285,7 +194,8 @@ __global__ __launch_bounds__(PG_BLOCK) void k_generate(DScene sc, RenderParams r
         st.L[slot] = make_float4(0, 0, 0, 0);
         st.meta[slot] = make_int4(0, 0, 0, PG_META_DONE | 0x40000);  // 0x40000: slot holds no sample
     }
-    int pos = queue_push(q.count, valid);
+    int pos;
+    block_push<1>(&q, &valid, &pos);
     if (valid) {
         q.o[pos] = make_float4(o.x, o.y, o.z, tMax);
         q.d[pos] = make_float4(d.x, d.y, d.z, __int_as_float(slot));
@@ -429,9 +339,8 @@ PG_DEV void spawn_ray(const Isect &is, V3 d, V3 &o) { o = offset_ray_origin(is.p
 
 __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
                                                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests) {
-    const int n = *qin.count;
-    const int i = blockIdx.x * PG_BLOCK + threadIdx.x;
-    const bool valid = i < n;
+    const int i = queue_item(qin);
+    const bool valid = i >= 0;
     // outputs of this lane
     bool pushNext = false, pushShadow = false, pushMis = false;
     V3 nextO = mk(0, 0, 0), nextD = mk(0, 0, 0);
@@ -443,7 +352,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
     float4 pdLight = make_float4(0, 0, 0, 0), pdMis = make_float4(0, 0, 0, 0), pdBeta = make_float4(0, 0, 0, 0);
     int lightNum = -1;
     if (valid) {
-        const float4 o4 = qin.o[i], d4 = qin.d[i], h4 = hits[i];
+        const float4 d4 = qin.d[i], h4 = hits[i];
         slot = __float_as_int(d4.w);
         const V3 rayD = mk(d4.x, d4.y, d4.z);
         const int prim = __float_as_int(h4.x);
@@ -568,9 +477,11 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
         st.beta[slot] = make_float4(beta.r, beta.g, beta.b, B4.w);
         st.meta[slot] = make_int4(meta.x, meta.y, dim, bounces | newFlags);
     }
-    int posNext = queue_push(qnext.count, pushNext);
-    int posShadow = queue_push(qshadow.count, pushShadow);
-    int posMis = queue_push(qmis.count, pushMis);
+    const RayQueue outQ[3] = {qnext, qshadow, qmis};
+    const bool outPred[3] = {pushNext, pushShadow, pushMis};
+    int outPos[3];
+    block_push<3>(outQ, outPred, outPos);
+    const int posNext = outPos[0], posShadow = outPos[1], posMis = outPos[2];
     if (pushNext) {
         qnext.o[posNext] = make_float4(nextO.x, nextO.y, nextO.z, PG_INF);
         qnext.d[posNext] = make_float4(nextD.x, nextD.y, nextD.z, __int_as_float(slot));
@@ -595,8 +506,8 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
     if (lane_id() == 0 && nl) atomicAdd(lightTriTests, nl);
 }
 void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQueue qin, const float4 *hits, RayQueue qnext,
-                  RayQueue qshadow, RayQueue qmis, int maxCount, unsigned long long *lightTriTests, hipStream_t s) {
-    int nblk = (maxCount + PG_BLOCK - 1) / PG_BLOCK;
+                  RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s) {
+    int nblk = PG_REGIONS * (qin.regionCap / PG_BLOCK);
     if (nblk == 0) return;
     hipLaunchKernelGGL(k_shade, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests);
 }
@@ -605,9 +516,8 @@ void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQue
 // L += beta * Ld / lightPdf (integrator.cpp:104, path.cpp:122-126), once both rays are back.
 __global__ __launch_bounds__(PG_BLOCK) void k_resolve(DScene sc, PathState st, RayQueue qin, RayQueue qmis, const int *__restrict__ occluded,
                                                        const float4 *__restrict__ misHits) {
-    const int n = *qin.count;
-    const int i = blockIdx.x * PG_BLOCK + threadIdx.x;
-    if (i >= n) return;
+    const int i = queue_item(qin);
+    if (i < 0) return;
     const int slot = __float_as_int(qin.d[i].w);
     const int4 info = st.pdInfo[slot];
     if (info.x < 0 && info.y < 0) return;  // Ld == 0: L += beta * 0 leaves L unchanged
@@ -633,9 +543,8 @@ __global__ __launch_bounds__(PG_BLOCK) void k_resolve(DScene sc, PathState st, R
     Spec L = sp3(L4.x, L4.y, L4.z) + sp3(pb.x, pb.y, pb.z) * (Ld / pl.w);
     st.L[slot] = make_float4(L.r, L.g, L.b, L4.w);
 }
-void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis, const int *occluded, const float4 *misHits, int maxCount,
-                    hipStream_t s) {
-    int nblk = (maxCount + PG_BLOCK - 1) / PG_BLOCK;
+void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis, const int *occluded, const float4 *misHits, hipStream_t s) {
+    int nblk = PG_REGIONS * (qin.regionCap / PG_BLOCK);
     if (nblk == 0) return;
     hipLaunchKernelGGL(k_resolve, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, qin, qmis, occluded, misHits);
 }

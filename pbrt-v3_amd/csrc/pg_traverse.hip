@@ -15,10 +15,13 @@
 //    time (the other terms of Bounds3::IntersectP do not depend on ray.tMax);
 //  * the reference's node-visit count (one per nodes[cur] read, bvh.cpp:672/710)
 //    is reproduced exactly: it defines the algorithmic bytes of the roofline;
-//  * every wave owns a contiguous segment of the queue and refills lanes whose
-//    ray has finished from it, so lane occupancy does not decay to the longest
-//    ray of the first 64; segments map to XCDs in contiguous eighths so each
-//    private L2 sees one coherent region of the queue;
+//  * one step per iteration for the whole wave -- either every lane holding an
+//    interior record expands it or every lane holding a leaf tests its next
+//    triangle (the larger group goes) -- instead of nested per-lane loops whose
+//    trip counts diverge across 64 lanes;
+//  * persistent waves: a wave takes chunks of rays from its XCD's region of the
+//    queue (one atomic per chunk) and refills lanes whose ray has finished, so
+//    lane occupancy does not decay to the longest ray of the first 64;
 //  * traversal stack: first `depth` entries per lane in LDS ([entry][lane],
 //    8 B entries, bank-conflict-free), the rest of pbrt's 64 in scratch.
 #include "pg_device.h"
@@ -55,14 +58,6 @@ PG_DEV bool slab_interval(float lox, float hix, float loy, float hiy, float loz,
     return ok && (tMax > 0);
 }
 
-PG_DEV int tr_swizzled_block(int nblk) {  // contiguous eighth of the grid per XCD (block b runs on XCD b % 8)
-    int per = (nblk + 7) >> 3;
-    int b = blockIdx.x;
-    if (b >= per * 8) return -1;
-    int lb = (b & 7) * per + (b >> 3);
-    return lb < nblk ? lb : -1;
-}
-
 PG_DEV unsigned long long tr_wave_sum(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     return v;
@@ -74,17 +69,17 @@ __global__ __launch_bounds__(TR_BLOCK) void k_trace(DScene sc, RayQueue q, float
                                                     int refillAt, int triW, float cullK, int *cullGuard) {
     extern __shared__ uint2 ldsStack[];  // [depth][TR_BLOCK]
     uint2 spill[TR_STACK_TOTAL];
-    const int n = *q.count;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const unsigned long long laneLt = (1ull << lane) - 1ull;
-    // Work distribution: the queue is cut into 8 contiguous regions, one per XCD (block b runs on XCD b % 8, so each
-    // private L2 sees one coherent part of the queue); a wave takes `chunk` rays at a time from its region's cursor
-    // and moves on to the next region when its own is drained.  Waves are persistent: the grid only has to fill the chip.
-    const int per = (((n + 7) >> 3) + chunk - 1) / chunk * chunk;
-    int region = blockIdx.x & 7, regionsTried = 0;
+    // Work distribution: the queue is PG_REGIONS sub-queues, one per XCD (block b runs on XCD b % 8, and the producers
+    // appended from that XCD, so each private L2 sees one coherent part of the queue); a wave takes `chunk` rays at a time
+    // from its region's cursor and moves on to the next region when its own is drained.  Waves are persistent: the grid
+    // only has to fill the chip.
+    const int per = q.regionCap;
+    int region = blockIdx.x & (PG_REGIONS - 1), regionsTried = 0;
     int next = 0, segEnd = 0;  // the wave's current chunk [next, segEnd)
-    bool exhausted = n == 0;
+    bool exhausted = false;
     // per-lane ray state.  A lane is in exactly one of three states:
     //   cur >= 0                 : holds an interior record to expand (its box test already passed)
     //   cur == NONE, triLeft > 0 : holds a leaf with triLeft untested triangles starting at triNext
@@ -129,12 +124,12 @@ __global__ __launch_bounds__(TR_BLOCK) void k_trace(DScene sc, RayQueue q, float
             if (next >= segEnd) {  // wave-uniform: take the next chunk
                 for (;;) {
                     int base = 0;
-                    if (lane == 0) base = atomicAdd(&cursors[region], chunk);
+                    if (lane == 0) base = atomicAdd(&cursors[region * PG_COUNT_STRIDE], chunk);
                     base = __builtin_amdgcn_readfirstlane(base);
-                    const int r0 = region * per, r1 = min(n, r0 + per);
+                    const int r0 = region * per, r1 = r0 + q.counts[region * PG_COUNT_STRIDE];
                     if (r0 + base < r1) { next = r0 + base; segEnd = min(next + chunk, r1); break; }
-                    region = (region + 1) & 7;
-                    if (++regionsTried == 8) { exhausted = true; break; }
+                    region = (region + 1) & (PG_REGIONS - 1);
+                    if (++regionsTried == PG_REGIONS) { exhausted = true; break; }
                 }
             }
             if (!exhausted) {
@@ -233,23 +228,22 @@ void set_trace_config(const TraceConfig &c) { g_cfg = c; }
 TraceConfig get_trace_config() { return g_cfg; }
 
 template <bool ANYHIT>
-static void launch_trace(const DScene &sc, RayQueue q, int maxCount, float4 *hits, float *tOut, int *occluded, TraceCounters *cn, int *cursors,
-                         int *cullGuard, hipStream_t s) {
+static void launch_trace(const DScene &sc, RayQueue q, float4 *hits, float *tOut, int *occluded, TraceCounters *cn, int *cursors, int *cullGuard,
+                         hipStream_t s) {
     const TraceConfig c = g_cfg;
-    if (maxCount <= 0) return;
+    if (q.regionCap <= 0) return;
     // persistent grid: enough blocks to fill 256 CUs at 8 blocks each, never more than the queue can feed
-    long long need = ((long long)maxCount + c.segRays - 1) / c.segRays;      // chunks
+    long long need = ((long long)q.regionCap * PG_REGIONS + c.segRays - 1) / c.segRays;  // chunks
     int nblk = (int)std::min<long long>((need + TR_BLOCK / 64 - 1) / (TR_BLOCK / 64), (long long)c.gridBlocks);
     nblk = ((nblk + 7) / 8) * 8;
     size_t lds = sizeof(uint2) * (size_t)c.depth * TR_BLOCK;
-    (void)hipMemsetAsync(cursors, 0, 8 * sizeof(int), s);
+    (void)hipMemsetAsync(cursors, 0, PG_REGIONS * PG_COUNT_STRIDE * sizeof(int), s);
     hipLaunchKernelGGL(k_trace<ANYHIT>, dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q, hits, tOut, occluded, cn, cursors, c.depth, c.segRays,
                        c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard);
 }
-void launch_closest_wide(const DScene &sc, RayQueue q, int maxCount, float4 *hits, float *tOut, TraceCounters *cn, int *cursors, int *cullGuard,
-                         hipStream_t s) {
-    launch_trace<false>(sc, q, maxCount, hits, tOut, nullptr, cn, cursors, cullGuard, s);
+void launch_closest(const DScene &sc, RayQueue q, float4 *hits, float *tOut, TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s) {
+    launch_trace<false>(sc, q, hits, tOut, nullptr, cn, cursors, cullGuard, s);
 }
-void launch_anyhit_wide(const DScene &sc, RayQueue q, int maxCount, int *occluded, TraceCounters *cn, int *cursors, hipStream_t s) {
-    launch_trace<true>(sc, q, maxCount, nullptr, nullptr, occluded, cn, cursors, nullptr, s);
+void launch_anyhit(const DScene &sc, RayQueue q, int *occluded, TraceCounters *cn, int *cursors, hipStream_t s) {
+    launch_trace<true>(sc, q, nullptr, nullptr, occluded, cn, cursors, nullptr, s);
 }
