@@ -164,22 +164,25 @@ def main():
                 shards = [(film, strays, int(nstrays.item()))]
             img = pdist.merge_shards(pkg, scene, gs.tile_count, shards)
             pkg.write_pfm(args.out, img)
-        # roofline of the dominant kernel (k_traverse<false>, BVHAccel::Intersect) on rank 0:
+        # roofline of the dominant kernel (k_trace<false>, BVHAccel::Intersect) on rank 0:
         # algorithmic bytes = 32 B/node fetch + 48 B/triangle test + 32 B/ray in + 16 B/hit out
         n_ray = cn["closest_rays"]
         alg_bytes = 32 * cn["closest_node_visits"] + 48 * cn["closest_tri_tests"] + 32 * n_ray + 16 * n_ray
         launches = max(1, cn["closest_launches"])
         achieved = alg_bytes / (cn["closest_ms"] * 1e-3) / 1e9 if cn["closest_ms"] > 0 else 0.0
-        traffic = None
+        workload = ((f"synthetic heightfield-in-a-box, {scene.desc.n_tris} triangles" if args.workload == "synthetic"
+                     else "Cornell box, 36 triangles") +
+                    f", PathIntegrator maxdepth 5, halton, box filter, {args.xres}x{args.yres} @ {args.spp} spp")
+        traffic = None  # HBM-side bytes per launch from the committed PMC passes of this same workload (tools/pmc_traffic.sh)
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                if j.get("workload") == f"{args.workload}-{args.grid}-{args.xres}x{args.yres}@{args.spp}":
+                if j.get("workload") == workload:
                     traffic = j.get("hbm_bytes_per_launch")
             except Exception:
                 pass
-        roofline = {"bound": "hbm", "kernel": "k_traverse<false> (BVHAccel::Intersect + Triangle::Intersect)",
+        roofline = {"bound": "hbm", "kernel": "k_trace<false> (BVHAccel::Intersect + Triangle::Intersect)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes / launches,
                     "avg_launch_ms": cn["closest_ms"] / launches, "launches": launches,
@@ -191,9 +194,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "samples_per_s": samples / elapsed,
-            "config": {"workload": (f"synthetic heightfield-in-a-box, {scene.desc.n_tris} triangles" if args.workload == "synthetic"
-                                    else "Cornell box, 36 triangles") +
-                                   f", PathIntegrator maxdepth 5, halton, box filter, {args.xres}x{args.yres} @ {args.spp} spp",
+            "config": {"workload": workload,
                        "sharding": f"16x16 film tiles round-robin over {world} GPU(s), RCCL gather to rank 0",
                        "rays_per_sample": rays / max(1.0, samples), "host_parse_and_bvh_s": t_parse},
             "roofline": roofline,

@@ -99,20 +99,23 @@ PG_DEV float max_component(Spec a) { float m = a.r; m = pmax(m, a.g); m = pmax(m
 // of :309-317 is a property of the triangle alone and is carried as a
 // precomputed per-triangle flag by the caller.
 // ---------------------------------------------------------------------------
-PG_DEV bool tri_test(V3 p0, V3 p1, V3 p2, V3 o, V3 dir, float tMax, float &t, float &b0, float &b1, float &b2) {
-    V3 p0t = p0 - o, p1t = p1 - o, p2t = p2 - o;
-    // permute so that the largest |d| component is z (:205-214)
+// The ray-only part of the test (:205-220): the permutation that makes the largest |d| component z, and the
+// shear constants.  Computed once per ray by the traversal kernel, per call elsewhere.
+struct TriRay { int kz; float Sx, Sy, Sz; };
+PG_DEV TriRay tri_ray_setup(V3 dir) {
     float ax = fabsf(dir.x), ay = fabsf(dir.y), az = fabsf(dir.z);
-    int kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
-    V3 d;
-    if (kz == 0) {  // kx=1, ky=2
-        d = mk(dir.y, dir.z, dir.x);
-        p0t = mk(p0t.y, p0t.z, p0t.x); p1t = mk(p1t.y, p1t.z, p1t.x); p2t = mk(p2t.y, p2t.z, p2t.x);
-    } else if (kz == 1) {  // kx=2, ky=0
-        d = mk(dir.z, dir.x, dir.y);
-        p0t = mk(p0t.z, p0t.x, p0t.y); p1t = mk(p1t.z, p1t.x, p1t.y); p2t = mk(p2t.z, p2t.x, p2t.y);
-    } else d = dir;
-    float Sx = -d.x / d.z, Sy = -d.y / d.z, Sz = 1.f / d.z;
+    TriRay r;
+    r.kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);  // MaxDimension(Abs(d)), geometry.h:998-1000
+    V3 d = r.kz == 0 ? mk(dir.y, dir.z, dir.x) : (r.kz == 1 ? mk(dir.z, dir.x, dir.y) : dir);  // kx = kz+1, ky = kx+1 (mod 3)
+    r.Sx = -d.x / d.z; r.Sy = -d.y / d.z; r.Sz = 1.f / d.z;
+    return r;
+}
+PG_DEV V3 tri_permute(V3 v, int kz) {
+    return mk(kz == 0 ? v.y : (kz == 1 ? v.z : v.x), kz == 0 ? v.z : (kz == 1 ? v.x : v.y), kz == 0 ? v.x : (kz == 1 ? v.y : v.z));
+}
+PG_DEV bool tri_test_pre(V3 p0, V3 p1, V3 p2, V3 o, TriRay tr, float tMax, float &t, float &b0, float &b1, float &b2) {
+    V3 p0t = tri_permute(p0 - o, tr.kz), p1t = tri_permute(p1 - o, tr.kz), p2t = tri_permute(p2 - o, tr.kz);
+    const float Sx = tr.Sx, Sy = tr.Sy, Sz = tr.Sz;
     p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
     p1t.x += Sx * p1t.z; p1t.y += Sy * p1t.z;
     p2t.x += Sx * p2t.z; p2t.y += Sy * p2t.z;
@@ -151,6 +154,9 @@ PG_DEV bool tri_test(V3 p0, V3 p1, V3 p2, V3 o, V3 dir, float tMax, float &t, fl
     float deltaT = 3 * (pgamma(3) * maxE * maxZt + deltaE * maxZt + deltaZ * maxE) * fabsf(invDet);
     if (t <= deltaT) return false;
     return true;
+}
+PG_DEV bool tri_test(V3 p0, V3 p1, V3 p2, V3 o, V3 dir, float tMax, float &t, float &b0, float &b1, float &b2) {
+    return tri_test_pre(p0, p1, p2, o, tri_ray_setup(dir), tMax, t, b0, b1, b2);
 }
 
 // Whether Triangle::Intersect would reject every hit on this triangle as

@@ -31,6 +31,9 @@
 #define TR_BLOCK 256
 #define TR_NONE ((int)0x80000000)
 #define TR_STACK_TOTAL 64
+#ifndef TR_MIN_WAVES
+#define TR_MIN_WAVES 2
+#endif
 #define TR_MAX_ACCEPTED 4096  // (1+2^-24)^(3*4096) < 1+2^-10
 
 // Bounds3::IntersectP(ray, invDir, dirIsNeg), geometry.h:1412-1438, split into
@@ -64,7 +67,7 @@ PG_DEV unsigned long long tr_wave_sum(unsigned long long v) {
 }
 
 template <bool ANYHIT>
-__global__ __launch_bounds__(TR_BLOCK) void k_trace(DScene sc, RayQueue q, float4 *__restrict__ hits, float *__restrict__ tOut,
+__global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(DScene sc, RayQueue q, float4 *__restrict__ hits, float *__restrict__ tOut,
                                                     int *__restrict__ occluded, TraceCounters *cn, int *__restrict__ cursors, int depth, int chunk,
                                                     int refillAt, int triW, float cullK, int *cullGuard) {
     extern __shared__ uint2 ldsStack[];  // [depth][TR_BLOCK]
@@ -85,7 +88,8 @@ __global__ __launch_bounds__(TR_BLOCK) void k_trace(DScene sc, RayQueue q, float
     //   cur == NONE, triLeft > 0 : holds a leaf with triLeft untested triangles starting at triNext
     //   cur == NONE, triLeft == 0: idle (ray finished or none assigned)
     int ray = -1, cur = TR_NONE, triNext = 0, triLeft = 0;
-    float ox = 0, oy = 0, oz = 0, dx = 1, dy = 1, dz = 1, ix = 1, iy = 1, iz = 1, tMax = 0;
+    float ox = 0, oy = 0, oz = 0, ix = 1, iy = 1, iz = 1, tMax = 0;
+    TriRay tr = {2, 0.f, 0.f, 1.f};  // Triangle::Intersect's per-ray permutation and shear (triangle.cpp:205-220)
     bool nx = false, ny = false, nz = false;
     int hitPrim = -1;
     float hb0 = 0, hb1 = 0, hb2 = 0;
@@ -139,8 +143,8 @@ __global__ __launch_bounds__(TR_BLOCK) void k_trace(DScene sc, RayQueue q, float
                     const float4 o4 = q.o[idx], d4 = q.d[idx];
                     ray = idx;
                     ox = o4.x; oy = o4.y; oz = o4.z; tMax = o4.w;
-                    dx = d4.x; dy = d4.y; dz = d4.z;
-                    ix = 1 / dx; iy = 1 / dy; iz = 1 / dz;   // bvh.cpp:666
+                    tr = tri_ray_setup(mk(d4.x, d4.y, d4.z));
+                    ix = 1 / d4.x; iy = 1 / d4.y; iz = 1 / d4.z;   // bvh.cpp:666
                     nx = ix < 0; ny = iy < 0; nz = iz < 0;   // bvh.cpp:667
                     hitPrim = -1; hb0 = hb1 = hb2 = 0; nAccepted = 0;
                     sp = 0; vd = 0; vmask = 0;
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_trace(DScene sc, RayQueue q, float
                 const float4 a = sc.tris[3 * prim], b = sc.tris[3 * prim + 1], c = sc.tris[3 * prim + 2];
                 ++triTests; ++triNext; --triLeft;
                 float t, b0, b1, b2;
-                if (tri_test(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), mk(ox, oy, oz), mk(dx, dy, dz), tMax, t, b0, b1, b2) &&
+                if (tri_test_pre(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), mk(ox, oy, oz), tr, tMax, t, b0, b1, b2) &&
                     !(__float_as_uint(a.w) & PG_TRI_BOGUS)) {
                     hitPrim = prim;
                     if (ANYHIT) { triLeft = 0; sp = 0; vd = 0; }  // bvh.cpp:717: return true
