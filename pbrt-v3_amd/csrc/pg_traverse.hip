@@ -102,12 +102,15 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(DScene sc, Ray
 
 #define TR_PUSH(ref_, t_) do { uint2 e_ = make_uint2((unsigned)(ref_), __float_as_uint(t_)); \
         if (sp < depth) ldsStack[sp * TR_BLOCK + tid] = e_; else spill[sp - depth] = e_; ++sp; } while (0)
-#define TR_TOP(e_) do { --sp; e_ = (sp < depth) ? ldsStack[sp * TR_BLOCK + tid] : spill[sp - depth]; } while (0)
+    // Pops are written as one loop per address space (scratch part first, then LDS): a single `sp < depth ? lds : spill`
+    // expression makes the compiler build a generic pointer and issue slow flat loads.
     // The reference's "pop or finish" (bvh.cpp:694-697): next node whose deferred `tMin < ray.tMax` test passes.
 #define TR_POP() do { cur = TR_NONE; \
-        if (!ANYHIT) { while (sp > 0) { uint2 e_; TR_TOP(e_); if (__uint_as_float(e_.y) < tMax) { cur = (int)e_.x; break; } } } \
-        else { while (vd > 0) { --vd; ++nodeVisits; if ((vmask >> vd) & 1ull) { vmask &= ~(1ull << vd); continue; } \
-                                uint2 e_; TR_TOP(e_); cur = (int)e_.x; break; } } } while (0)
+        if (!ANYHIT) { \
+            while (sp > depth) { --sp; const uint2 e_ = spill[sp - depth]; if (__uint_as_float(e_.y) < tMax) { cur = (int)e_.x; break; } } \
+            if (cur == TR_NONE) while (sp > 0) { --sp; const uint2 e_ = ldsStack[sp * TR_BLOCK + tid]; if (__uint_as_float(e_.y) < tMax) { cur = (int)e_.x; break; } } \
+        } else { while (vd > 0) { --vd; ++nodeVisits; if ((vmask >> vd) & 1ull) { vmask &= ~(1ull << vd); continue; } \
+                                 --sp; if (sp >= depth) cur = (int)spill[sp - depth].x; else cur = (int)ldsStack[sp * TR_BLOCK + tid].x; break; } } } while (0)
     // A negative reference is a leaf: unpack (first prim, count) into the lane's triangle state.
 #define TR_SETTLE() do { if (cur < 0 && cur != TR_NONE) { const int code_ = ~cur; triNext = code_ >> leafBits; triLeft = (code_ & leafMask) + 1; cur = TR_NONE; } } while (0)
 
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(DScene sc, Ray
     }
 }
 
-static TraceConfig g_cfg = {12, 128, 8, 8, 1.0009765625f, 2048};
+static TraceConfig g_cfg = {10, 128, 8, 8, 1.0009765625f, 2048};
 void set_trace_config(const TraceConfig &c) { g_cfg = c; }
 TraceConfig get_trace_config() { return g_cfg; }
 

@@ -11,3 +11,4 @@ export TMPDIR=/tmp
 find $OUT/prof -name '*kernel_stats*' -exec cp {} $OUT/kernel_stats.csv \;
 find $OUT/prof -name '*kernel_trace*' -size +8M -delete
 tail -5 $OUT/pytest_gpu.log; cat $OUT/bench.json; head -12 $OUT/kernel_stats.csv
+bash tools/pmc_traffic.sh $TAG/traffic > $OUT/traffic.log 2>&1; cp $OUT/traffic/pmc_traffic.json $OUT/pmc_traffic.json 2>/dev/null
