@@ -48,6 +48,15 @@ SCENES = {
     "cornell_black": cornell(24, 24, 4, world_edit=lambda s: s.replace('Material "matte" "rgb Kd" [ 0.65 0.05 0.05 ]', 'Material "matte" "rgb Kd" [ 0 0 0 ]')),
     "cornell_filmopts": cornell(24, 24, 8, extra_film='"float scale" [ 1.5 ] "float maxsampleluminance" [ 2.0 ]'),
     "cornell_center": cornell(20, 20, 4).replace('Sampler "halton"', 'Sampler "halton" "bool samplepixelcenter" "true"'),
+    # plastic = Lambertian + TrowbridgeReitz microfacet lobe (plastic.cpp:45-70): defaults; specular-only without roughness
+    # remapping; and a camera looking straight down at a plastic floor (normal-incidence branch of TrowbridgeReitzSample11)
+    "cornell_plastic": cornell(32, 32, 8, world_edit=lambda s: s.replace('Material "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', 'Material "plastic"')
+                               .replace('Material "matte" "rgb Kd" [ 0.65 0.05 0.05 ]', 'Material "plastic" "rgb Kd" [ 0.65 0.05 0.05 ] "rgb Ks" [ 0.3 0.3 0.3 ] "float roughness" [ 0.05 ]')),
+    "cornell_plastic_spec": cornell(24, 24, 8, integrator='Integrator "path" "integer maxdepth" [ 7 ]',
+                                    world_edit=lambda s: s.replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]',
+                                        '# short box\nMaterial "plastic" "rgb Kd" [ 0 0 0 ] "rgb Ks" [ 0.6 0.7 0.8 ] "float roughness" [ 0.3 ] "bool remaproughness" "false"')),
+    "plastic_topdown": cornell(24, 24, 8, world_edit=lambda s: s.replace('Material "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', 'Material "plastic" "rgb Kd" [ 0.2 0.3 0.4 ] "rgb Ks" [ 0.5 0.5 0.5 ] "float roughness" [ 0.02 ]', 1))
+        .replace("LookAt 278 273 -800  278 273 0  0 1 0", "LookAt 278 500 279  278 0 279  0 0 1"),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 
@@ -67,11 +76,14 @@ def run(name, scene_path):
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    only = sys.argv[1:]
     for name, text in SCENES.items():
+        if only and name not in only: continue
         p = os.path.join(GOLD, name + ".pbrt")
         open(p, "w").write(text)
         run(name, p)
     # small synthetic heightfield (3 042 + 12 triangles): SAH BVH with real depth
+    if only and "synthetic_n40" not in only: return
     p = os.path.join(GOLD, "synthetic_n40.pbrt")
     gen_synthetic.write_scene(p, n=40, xres=48, yres=27, spp=4, filename="synthetic_n40.pfm")
     run("synthetic_n40", p)

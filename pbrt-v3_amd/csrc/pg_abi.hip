@@ -3,6 +3,7 @@
 // into batches of camera samples that advance one bounce per launch), and the
 // batched Scene::Intersect/IntersectP entry points.
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -188,13 +189,28 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     for (int i = 0; i < desc->n_materials; ++i) {
         const PgMaterial &m = desc->materials[i];
         if (m.type == PG_MAT_NONE) s->hasNullMaterial = true;
-        else if (m.type != PG_MAT_MATTE) FAIL(PG_ERR_UNSUPPORTED, "material %d: type %d is outside this build's closed set (matte)", i, m.type);
-        else if (m.sigma != 0) FAIL(PG_ERR_UNSUPPORTED, "material %d: Oren-Nayar (sigma != 0) is outside this build's closed set", i);
+        else if (m.type != PG_MAT_MATTE && m.type != PG_MAT_PLASTIC)
+            FAIL(PG_ERR_UNSUPPORTED, "material %d: type %d is outside this build's closed set (matte, plastic)", i, m.type);
+        else if (m.type == PG_MAT_MATTE && m.sigma != 0)
+            FAIL(PG_ERR_UNSUPPORTED, "material %d: Oren-Nayar (sigma != 0) is outside this build's closed set", i);
+    }
+    // device copy: a plastic's `roughness` becomes the TrowbridgeReitz alpha.  RoughnessToAlpha (microfacet.h:127-132) calls
+    // logf; evaluating it here on the host uses the same libm as the reference build.
+    std::vector<PgMaterial> devMaterials(desc->materials, desc->materials + desc->n_materials);
+    for (PgMaterial &m : devMaterials) {
+        if (m.type != PG_MAT_PLASTIC) continue;
+        float rough = m.roughness;
+        if (m.remap_roughness) {
+            rough = (rough < 1e-3f) ? 1e-3f : rough;  // std::max(roughness, (Float)1e-3)
+            float x = logf(rough);
+            rough = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+        }
+        m.roughness = (0.001f < rough) ? rough : 0.001f;  // TrowbridgeReitzDistribution ctor: std::max(Float(0.001), alpha)
     }
     for (int i = 0; i < desc->n_lights; ++i)
         if (desc->lights[i].prim < 0 || desc->lights[i].prim >= nt) FAIL(PG_ERR_INVALID, "light %d has no emitting triangle", i);
     HIP_TRY_S(s->materials.alloc(sizeof(PgMaterial) * (size_t)desc->n_materials));
-    if (desc->n_materials) HIP_TRY_S(hipMemcpy(s->materials.p, desc->materials, s->materials.bytes, hipMemcpyHostToDevice));
+    if (desc->n_materials) HIP_TRY_S(hipMemcpy(s->materials.p, devMaterials.data(), s->materials.bytes, hipMemcpyHostToDevice));
     HIP_TRY_S(s->lights.alloc(sizeof(PgLight) * (size_t)desc->n_lights));
     if (desc->n_lights) HIP_TRY_S(hipMemcpy(s->lights.p, desc->lights, s->lights.bytes, hipMemcpyHostToDevice));
     // --- Halton tables

@@ -236,47 +236,169 @@ PG_DEV Isect make_isect(const DScene &sc, int prim, const Tri &t, float b0, floa
     return is;
 }
 
-// BSDF with a single LambertianReflection lobe (matte, sigma = 0): reflection.h:164-213
-struct Bsdf { V3 ns, ng, ss, ts; Spec R; int nBxDFs; };
+// BSDF: LambertianReflection and/or MicrofacetReflection(TrowbridgeReitz, FresnelDielectric(1.5, 1)) lobes in the order
+// the materials add them (matte.cpp:45-62, plastic.cpp:45-70); reflection.h:164-213, reflection.cpp:680-796.
+struct Bsdf { V3 ns, ng, ss, ts; Spec R, Ks; float alpha; int nBxDFs; bool hasDiff, hasSpec; };
 PG_DEV V3 world_to_local(const Bsdf &b, V3 v) { return mk(dot(v, b.ss), dot(v, b.ts), dot(v, b.ns)); }
 PG_DEV V3 local_to_world(const Bsdf &b, V3 v) {
     return mk(b.ss.x * v.x + b.ts.x * v.y + b.ns.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ns.y * v.z,
               b.ss.z * v.x + b.ts.z * v.y + b.ns.z * v.z);
 }
-PG_DEV Spec bsdf_f(const Bsdf &b, V3 woW, V3 wiW) {  // reflection.cpp:680-693 + :178-180
-    V3 wo = world_to_local(b, woW);
-    if (wo.z == 0) return sp(0);
-    bool reflect = dot(wiW, b.ng) * dot(woW, b.ng) > 0;
+// reflection.h:52-83
+PG_DEV float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }  // pbrt.h:305-311
+PG_DEV float cos2_theta(V3 w) { return w.z * w.z; }
+PG_DEV float sin2_theta(V3 w) { return pmax(0.f, 1.f - cos2_theta(w)); }
+PG_DEV float sin_theta(V3 w) { return sqrtf(sin2_theta(w)); }
+PG_DEV float tan_theta(V3 w) { return sin_theta(w) / w.z; }
+PG_DEV float tan2_theta(V3 w) { return sin2_theta(w) / cos2_theta(w); }
+PG_DEV float cos_phi(V3 w) { float st = sin_theta(w); return (st == 0) ? 1 : clampf(w.x / st, -1, 1); }
+PG_DEV float sin_phi(V3 w) { float st = sin_theta(w); return (st == 0) ? 0 : clampf(w.y / st, -1, 1); }
+PG_DEV float cos2_phi(V3 w) { return cos_phi(w) * cos_phi(w); }
+PG_DEV float sin2_phi(V3 w) { return sin_phi(w) * sin_phi(w); }
+PG_DEV float fr_dielectric(float cosThetaI, float etaI, float etaT) {  // reflection.cpp:47-68
+    cosThetaI = clampf(cosThetaI, -1, 1);
+    if (!(cosThetaI > 0.f)) { float t = etaI; etaI = etaT; etaT = t; cosThetaI = fabsf(cosThetaI); }
+    float sinThetaI = sqrtf(pmax(0.f, 1 - cosThetaI * cosThetaI));
+    float sinThetaT = etaI / etaT * sinThetaI;
+    if (sinThetaT >= 1) return 1;
+    float cosThetaT = sqrtf(pmax(0.f, 1 - sinThetaT * sinThetaT));
+    float Rparl = ((etaT * cosThetaI) - (etaI * cosThetaT)) / ((etaT * cosThetaI) + (etaI * cosThetaT));
+    float Rperp = ((etaI * cosThetaI) - (etaT * cosThetaT)) / ((etaI * cosThetaI) + (etaT * cosThetaT));
+    return (Rparl * Rparl + Rperp * Rperp) / 2;
+}
+// TrowbridgeReitzDistribution with alphax == alphay == a, microfacet.cpp:155-184, microfacet.h:57-63
+PG_DEV float tr_D(float a, V3 wh) {
+    float tan2Theta = tan2_theta(wh);
+    if (isinf(tan2Theta)) return 0.f;
+    const float cos4Theta = cos2_theta(wh) * cos2_theta(wh);
+    float e = (cos2_phi(wh) / (a * a) + sin2_phi(wh) / (a * a)) * tan2Theta;
+    return 1 / (PG_PI * a * a * cos4Theta * (1 + e) * (1 + e));
+}
+PG_DEV float tr_lambda(float a, V3 w) {
+    float absTanTheta = fabsf(tan_theta(w));
+    if (isinf(absTanTheta)) return 0.f;
+    float alpha = sqrtf(cos2_phi(w) * a * a + sin2_phi(w) * a * a);
+    float alpha2Tan2Theta = (alpha * absTanTheta) * (alpha * absTanTheta);
+    return (-1 + sqrtf(1.f + alpha2Tan2Theta)) / 2;
+}
+PG_DEV float tr_G1(float a, V3 w) { return 1 / (1 + tr_lambda(a, w)); }
+PG_DEV float tr_G(float a, V3 wo, V3 wi) { return 1 / (1 + tr_lambda(a, wo) + tr_lambda(a, wi)); }
+PG_DEV float tr_pdf(float a, V3 wo, V3 wh) { return tr_D(a, wh) * tr_G1(a, wo) * absdot(wo, wh) / fabsf(wo.z); }  // microfacet.cpp:339-345
+// TrowbridgeReitzSample11 / TrowbridgeReitzSample / Sample_wh (visible area), microfacet.cpp:238-336.  The
+// normal-incidence branch evaluates sqrt/cos/sin in double on float arguments, as the reference's source does.
+PG_DEV void tr_sample11(float cosTheta, float U1, float U2, float &slope_x, float &slope_y) {
+    if ((double)cosTheta > .9999) {
+        float r = (float)sqrt((double)(U1 / (1 - U1)));
+        float phi = (float)(6.28318530718 * (double)U2);
+        double s, c;
+        sincos((double)phi, &s, &c);
+        slope_x = (float)((double)r * c);
+        slope_y = (float)((double)r * s);
+        return;
+    }
+    float sinTheta = sqrtf(pmax(0.f, 1.f - cosTheta * cosTheta));
+    float tanTheta = sinTheta / cosTheta;
+    float a = 1 / tanTheta;
+    float G1 = 2 / (1 + sqrtf(1.f + 1.f / (a * a)));
+    float A = 2 * U1 / G1 - 1;
+    float tmp = 1.f / (A * A - 1.f);
+    if (tmp > 1e10f) tmp = 1e10f;
+    float B = tanTheta;
+    float D = sqrtf(pmax(B * B * tmp * tmp - (A * A - B * B) * tmp, 0.f));
+    float slope_x_1 = B * tmp - D;
+    float slope_x_2 = B * tmp + D;
+    slope_x = (A < 0 || slope_x_2 > 1.f / tanTheta) ? slope_x_1 : slope_x_2;
+    float S;
+    if (U2 > 0.5f) { S = 1.f; U2 = 2.f * (U2 - .5f); }
+    else { S = -1.f; U2 = 2.f * (.5f - U2); }
+    float z = (U2 * (U2 * (U2 * 0.27385f - 0.73369f) + 0.46341f)) /
+              (U2 * (U2 * (U2 * 0.093073f + 0.309420f) - 1.000000f) + 0.597999f);
+    slope_y = S * z * sqrtf(1.f + slope_x * slope_x);
+}
+PG_DEV V3 tr_sample_wh(float a, V3 wo, float u0, float u1) {
+    const bool flip = wo.z < 0;
+    V3 wi = flip ? -wo : wo;
+    V3 wiStretched = normalize(mk(a * wi.x, a * wi.y, wi.z));
+    float slope_x, slope_y;
+    tr_sample11(wiStretched.z, u0, u1, slope_x, slope_y);
+    float tmp = cos_phi(wiStretched) * slope_x - sin_phi(wiStretched) * slope_y;
+    slope_y = sin_phi(wiStretched) * slope_x + cos_phi(wiStretched) * slope_y;
+    slope_x = tmp;
+    slope_x = a * slope_x;
+    slope_y = a * slope_y;
+    V3 wh = normalize(mk(-slope_x, -slope_y, 1.f));
+    return flip ? -wh : wh;
+}
+// MicrofacetReflection::f / Pdf / Sample_f, reflection.cpp:226-238, :410-429 (local coordinates)
+PG_DEV Spec mf_f(const Bsdf &b, V3 wo, V3 wi) {
+    float cosThetaO = fabsf(wo.z), cosThetaI = fabsf(wi.z);
+    V3 wh = wi + wo;
+    if (cosThetaI == 0 || cosThetaO == 0) return sp(0);
+    if (wh.x == 0 && wh.y == 0 && wh.z == 0) return sp(0);
+    wh = normalize(wh);
+    V3 whf = (dot(wh, mk(0, 0, 1)) < 0.f) ? -wh : wh;  // Faceforward
+    Spec F = sp(fr_dielectric(dot(wi, whf), 1.5f, 1.f));  // FresnelDielectric(1.5f, 1.f)
+    return (((b.Ks * tr_D(b.alpha, wh)) * tr_G(b.alpha, wo, wi)) * F) / (4 * cosThetaI * cosThetaO);
+}
+PG_DEV float mf_pdf(const Bsdf &b, V3 wo, V3 wi) {
+    if (!(wo.z * wi.z > 0)) return 0;
+    V3 wh = normalize(wo + wi);
+    return tr_pdf(b.alpha, wo, wh) / (4 * dot(wo, wh));
+}
+PG_DEV void mf_sample(const Bsdf &b, V3 wo, V3 &wi, float u0, float u1, float &pdf) {  // leaves pdf = 0 when no sample
+    if (wo.z == 0) return;
+    V3 wh = tr_sample_wh(b.alpha, wo, u0, u1);
+    if (dot(wo, wh) < 0) return;
+    wi = -wo + wh * (2 * dot(wo, wh));  // Reflect, reflection.h:93-95
+    if (!(wo.z * wi.z > 0)) return;
+    pdf = tr_pdf(b.alpha, wo, wh) / (4 * dot(wo, wh));
+}
+PG_DEV float lambert_pdf(V3 wo, V3 wi) { return (wo.z * wi.z > 0) ? fabsf(wi.z) * PG_INVPI : 0; }  // reflection.cpp:392-394
+PG_DEV Spec bsdf_f_local(const Bsdf &b, V3 wo, V3 wi, bool reflect) {
     Spec f = sp(0);
-    if (b.nBxDFs && reflect) f = f + b.R * PG_INVPI;
+    if (b.hasDiff && reflect) f = f + b.R * PG_INVPI;  // LambertianReflection::f, :178-180
+    if (b.hasSpec && reflect) f = f + mf_f(b, wo, wi);
     return f;
 }
-PG_DEV float bsdf_pdf(const Bsdf &b, V3 woW, V3 wiW) {  // reflection.cpp:781-796 + :392-394
+PG_DEV Spec bsdf_f(const Bsdf &b, V3 woW, V3 wiW) {  // reflection.cpp:680-693
+    V3 wi = world_to_local(b, wiW), wo = world_to_local(b, woW);
+    if (wo.z == 0) return sp(0);
+    bool reflect = dot(wiW, b.ng) * dot(woW, b.ng) > 0;
+    return bsdf_f_local(b, wo, wi, reflect);
+}
+PG_DEV float bsdf_pdf(const Bsdf &b, V3 woW, V3 wiW) {  // reflection.cpp:781-796
     if (b.nBxDFs == 0) return 0.f;
     V3 wo = world_to_local(b, woW), wi = world_to_local(b, wiW);
     if (wo.z == 0) return 0.f;
     float pdf = 0.f;
-    pdf += (wo.z * wi.z > 0) ? fabsf(wi.z) * PG_INVPI : 0;
-    return pdf / 1;
+    if (b.hasDiff) pdf += lambert_pdf(wo, wi);
+    if (b.hasSpec) pdf += mf_pdf(b, wo, wi);
+    return pdf / b.nBxDFs;
 }
-PG_DEV Spec bsdf_sample_f(const Bsdf &b, V3 woWorld, V3 &wiWorld, float u0, float u1, float &pdf) {  // reflection.cpp:714-779 + :383-390
+PG_DEV Spec bsdf_sample_f(const Bsdf &b, V3 woWorld, V3 &wiWorld, float u0, float u1, float &pdf) {  // reflection.cpp:714-779
     int matchingComps = b.nBxDFs;
     pdf = 0;
     if (matchingComps == 0) return sp(0);
     int comp = (int)floorf(u0 * matchingComps);
     if (comp > matchingComps - 1) comp = matchingComps - 1;
+    const bool useSpec = b.hasSpec && (comp == 1 || !b.hasDiff);  // lobe order: Lambertian, then microfacet
     float ur0 = pmin(u0 * matchingComps - comp, PG_ONE_MINUS_EPS);
-    V3 wo = world_to_local(b, woWorld);
+    V3 wo = world_to_local(b, woWorld), wi = mk(0, 0, 0);
     if (wo.z == 0) return sp(0);
-    V3 wi = cosine_sample_hemisphere(ur0, u1);
-    if (wo.z < 0) wi.z *= -1;
-    pdf = (wo.z * wi.z > 0) ? fabsf(wi.z) * PG_INVPI : 0;
+    if (useSpec) mf_sample(b, wo, wi, ur0, u1, pdf);
+    else {  // BxDF::Sample_f, :383-390
+        wi = cosine_sample_hemisphere(ur0, u1);
+        if (wo.z < 0) wi.z *= -1;
+        pdf = lambert_pdf(wo, wi);
+    }
     if (pdf == 0) return sp(0);
     wiWorld = local_to_world(b, wi);
+    if (matchingComps > 1) {
+        pdf += useSpec ? lambert_pdf(wo, wi) : mf_pdf(b, wo, wi);
+        pdf /= matchingComps;
+    }
     bool reflect = dot(wiWorld, b.ng) * dot(woWorld, b.ng) > 0;
-    Spec f = sp(0);
-    if (reflect) f = f + b.R * PG_INVPI;
-    return f;
+    return bsdf_f_local(b, wo, wi, reflect);
 }
 
 // Triangle::Sample(u, pdf) + Shape::Sample(ref, u, pdf) + DiffuseAreaLight::Sample_Li
@@ -390,7 +512,12 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                 bsdf.ss = normalize(is.dpdu);
                 bsdf.ts = cross(bsdf.ns, bsdf.ss);
                 bsdf.R = sp3(m.kd[0] < 0 ? 0 : m.kd[0], m.kd[1] < 0 ? 0 : m.kd[1], m.kd[2] < 0 ? 0 : m.kd[2]);
-                bsdf.nBxDFs = is_black(bsdf.R) ? 0 : 1;
+                bsdf.hasDiff = !is_black(bsdf.R);
+                // PlasticMaterial (plastic.cpp:57-69): m.roughness already holds the distribution's alpha (host: RoughnessToAlpha)
+                bsdf.Ks = sp3(m.ks[0] < 0 ? 0 : m.ks[0], m.ks[1] < 0 ? 0 : m.ks[1], m.ks[2] < 0 ? 0 : m.ks[2]);
+                bsdf.hasSpec = m.type == PG_MAT_PLASTIC && !is_black(bsdf.Ks);
+                bsdf.alpha = m.roughness;
+                bsdf.nBxDFs = (bsdf.hasDiff ? 1 : 0) + (bsdf.hasSpec ? 1 : 0);
                 // ---- direct lighting: UniformSampleOneLight (integrator.cpp:85-106) + EstimateDirect set-up
                 if (bsdf.nBxDFs > 0 && sc.nLights > 0) {
                     const float *tab = light_distribution(sc, is.p);
