@@ -490,6 +490,9 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
                 const int *blk = hostCounts.data() + 4 * QSTRIDE * (size_t)b;
                 closestRays += queueTotal(blk, curQueueOfBounce[b]) + queueTotal(blk, 3);
                 shadowRays += queueTotal(blk, 2);
+                if (getenv("PG_PRINT_COUNTS"))
+                    fprintf(stderr, "pg_render: bounce %d main %llu shadow %llu mis %llu\n", b, (unsigned long long)queueTotal(blk, curQueueOfBounce[b]),
+                            (unsigned long long)queueTotal(blk, 2), (unsigned long long)queueTotal(blk, 3));
             }
             if (iters > 0) cameraRays += queueTotal(hostCounts.data(), curQueueOfBounce[0]);
         }

@@ -33,14 +33,15 @@ PG_DEV void block_push(const RayQueue *q, const bool *pred, int *pos) {
         if (lane == 0) s_cnt[k][wave] = __popcll(mask[k]);
     }
     __syncthreads();
-    if (threadIdx.x < NQ) {
-        const int k = threadIdx.x;
-        int total = 0;
 #pragma unroll
-        for (int w = 0; w < PG_BLOCK / 64; ++w) total += s_cnt[k][w];
-        const int r = blockIdx.x & (PG_REGIONS - 1);
-        s_base[k] = total ? r * q[k].regionCap + atomicAdd(&q[k].counts[r * PG_COUNT_STRIDE], total) : 0;
-    }
+    for (int k = 0; k < NQ; ++k)  // one lane per queue; written without dynamic indexing so q[] stays in registers
+        if (threadIdx.x == k) {
+            int total = 0;
+#pragma unroll
+            for (int w = 0; w < PG_BLOCK / 64; ++w) total += s_cnt[k][w];
+            const int r = blockIdx.x & (PG_REGIONS - 1);
+            s_base[k] = total ? r * q[k].regionCap + atomicAdd(&q[k].counts[r * PG_COUNT_STRIDE], total) : 0;
+        }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < NQ; ++k) {
@@ -463,16 +464,21 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                                                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests) {
     const int i = queue_item(qin);
     const bool valid = i >= 0;
-    // outputs of this lane
+    // Output rays are staged in LDS ([queue][o|d][thread]) the moment they are known and copied to their queues after the
+    // block-wide append at the end: holding three rays plus the pending direct-light terms in registers until then had
+    // pushed the kernel to 130 VGPRs with scratch spills (3 waves/SIMD).
+    __shared__ float4 s_ray[3][2][PG_BLOCK];
+    const int tid = threadIdx.x;
     bool pushNext = false, pushShadow = false, pushMis = false;
-    V3 nextO = mk(0, 0, 0), nextD = mk(0, 0, 0);
-    V3 shO = mk(0, 0, 0), shD = mk(0, 0, 0);
-    float shTMax = 0;
-    V3 misO = mk(0, 0, 0), misD = mk(0, 0, 0);
     int slot = 0;
     unsigned int nLightTests = 0;
-    float4 pdLight = make_float4(0, 0, 0, 0), pdMis = make_float4(0, 0, 0, 0), pdBeta = make_float4(0, 0, 0, 0);
     int lightNum = -1;
+    // candidate of the BSDF-sampling half of MIS, tested against the light's triangle at the end
+    bool misCand = false;
+    V3 misRo = mk(0, 0, 0), misWi = mk(0, 0, 1), misP = mk(0, 0, 0);
+    Spec misF = sp(0);
+    float misPdf = 0, misLightArea = 1;
+    int misLightPrim = 0;
     if (valid) {
         const float4 d4 = qin.d[i], h4 = hits[i];
         slot = __float_as_int(d4.w);
@@ -502,8 +508,10 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
             Isect is = make_isect(sc, prim, tri, h4.y, h4.z, h4.w, rayD);
             const PgMaterial &m = sc.materials[tri.material];
             if (m.type == PG_MAT_NONE) {  // path.cpp:107-113: skip over medium boundaries
+                V3 nextO;
                 spawn_ray(is, rayD, nextO);
-                nextD = rayD;
+                s_ray[0][0][tid] = make_float4(nextO.x, nextO.y, nextO.z, PG_INF);
+                s_ray[0][1][tid] = make_float4(rayD.x, rayD.y, rayD.z, __int_as_float(slot));
                 pushNext = true;
             } else {
                 // MatteMaterial::ComputeScatteringFunctions (matte.cpp:45-62), BSDF ctor (reflection.h:167-172)
@@ -530,6 +538,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                         const PgLight &light = sc.lights[lightNum];
                         V3 wi = mk(0, 0, 0);
                         float lightPdf = 0, scatteringPdf = 0;
+                        float4 pdLight = make_float4(0, 0, 0, 0);
                         LightSample ls;
                         Spec Li = light_sample_li(sc, light, is.p, uL0, uL1, wi, lightPdf, ls);
                         if (lightPdf > 0 && !is_black(Li)) {
@@ -539,43 +548,31 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                                 // VisibilityTester: p0.SpawnRayTo(p1), interaction.h:73-78
                                 V3 origin = offset_ray_origin(is.p, is.pError, is.n, ls.p - is.p);
                                 V3 target = offset_ray_origin(ls.p, ls.pError, ls.n, origin - ls.p);
-                                shO = origin; shD = target - origin; shTMax = 1 - PG_SHADOW_EPS;
+                                const V3 shD = target - origin;
+                                s_ray[1][0][tid] = make_float4(origin.x, origin.y, origin.z, 1 - PG_SHADOW_EPS);
+                                s_ray[1][1][tid] = make_float4(shD.x, shD.y, shD.z, __int_as_float(slot));
                                 pushShadow = true;
                                 float weight = power_heuristic(1, lightPdf, 1, scatteringPdf);
                                 Spec c = ((f * Li) * weight) / lightPdf;
                                 pdLight = make_float4(c.r, c.g, c.b, 0);
                             }
                         }
-                        // BSDF sampling half of MIS (integrator.cpp:164-212)
+                        // BSDF sampling half of MIS (integrator.cpp:164-212): sample now, while the BSDF is live; the
+                        // light.Pdf_Li triangle test runs at the end of the kernel, when little else is (register pressure)
                         V3 wi2 = wi;
                         float sPdf2;
                         Spec f2 = bsdf_sample_f(bsdf, is.wo, wi2, uS0, uS1, sPdf2);
                         f2 = f2 * absdot(wi2, bsdf.ns);
                         if (!is_black(f2) && sPdf2 > 0) {
-                            // light.Pdf_Li -> Shape::Pdf(ref, wi): intersect the light's own triangle (shape.cpp:72-87)
-                            V3 ro;
-                            spawn_ray(is, wi2, ro);
-                            Tri lt = load_tri(sc, light.prim);
-                            float t, lb0, lb1, lb2;
-                            ++nLightTests;
-                            float lightPdf2 = 0;
-                            if (tri_test(lt.p0, lt.p1, lt.p2, ro, wi2, PG_INF, t, lb0, lb1, lb2) && !(lt.flags & PG_TRI_BOGUS)) {
-                                V3 lp = lt.p0 * lb0 + lt.p1 * lb1 + lt.p2 * lb2;
-                                V3 ln = normalize(cross(lt.p0 - lt.p2, lt.p1 - lt.p2));
-                                float pdf = lensq(is.p - lp) / (absdot(ln, -wi2) * light.area);
-                                if (isinf(pdf)) pdf = 0.f;
-                                lightPdf2 = pdf;
-                            }
-                            if (lightPdf2 != 0) {
-                                float weight2 = power_heuristic(1, sPdf2, 1, lightPdf2);
-                                misO = ro; misD = wi2;
-                                pushMis = true;
-                                pdMis = make_float4(f2.r, f2.g, f2.b, sPdf2);
-                                pdBeta.w = weight2;
-                            }
+                            misCand = true;
+                            spawn_ray(is, wi2, misRo);
+                            misWi = wi2; misF = f2; misPdf = sPdf2; misP = is.p;
+                            misLightPrim = light.prim; misLightArea = light.area;
                         }
+                        // pending terms of this vertex, consumed by k_resolve (pdMis and the MIS weight follow below)
                         pdLight.w = lightSelPdf;
-                        pdBeta.x = beta.r; pdBeta.y = beta.g; pdBeta.z = beta.b;
+                        st.pdLight[slot] = pdLight;
+                        st.pdBeta[slot] = make_float4(beta.r, beta.g, beta.b, 0.f);
                     }
                 }
                 // ---- sample the BSDF for the next direction (path.cpp:130-150)
@@ -586,8 +583,10 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                 Spec f = bsdf_sample_f(bsdf, wo, wi, u0, u1, pdf);
                 if (!(is_black(f) || pdf == 0.f)) {
                     beta = beta * ((f * absdot(wi, bsdf.ns)) / pdf);
+                    V3 nextO;
                     spawn_ray(is, wi, nextO);
-                    nextD = wi;
+                    s_ray[0][0][tid] = make_float4(nextO.x, nextO.y, nextO.z, PG_INF);
+                    s_ray[0][1][tid] = make_float4(wi.x, wi.y, wi.z, __int_as_float(slot));
                     pushNext = true;
                     // Russian roulette, path.cpp:176-184 (etaScale == 1: no transmission in the closed set)
                     Spec rrBeta = beta * 1.f;
@@ -604,31 +603,36 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
         st.beta[slot] = make_float4(beta.r, beta.g, beta.b, B4.w);
         st.meta[slot] = make_int4(meta.x, meta.y, dim, bounces | newFlags);
     }
+    if (misCand) {
+        // light.Pdf_Li -> Shape::Pdf(ref, wi): intersect the light's own triangle (shape.cpp:72-87, diffuse.cpp:83-87)
+        Tri lt = load_tri(sc, misLightPrim);
+        float t, lb0, lb1, lb2;
+        ++nLightTests;
+        float lightPdf2 = 0;
+        if (tri_test(lt.p0, lt.p1, lt.p2, misRo, misWi, PG_INF, t, lb0, lb1, lb2) && !(lt.flags & PG_TRI_BOGUS)) {
+            V3 lp = lt.p0 * lb0 + lt.p1 * lb1 + lt.p2 * lb2;
+            V3 ln = normalize(cross(lt.p0 - lt.p2, lt.p1 - lt.p2));
+            float pdf = lensq(misP - lp) / (absdot(ln, -misWi) * misLightArea);
+            if (isinf(pdf)) pdf = 0.f;
+            lightPdf2 = pdf;
+        }
+        if (lightPdf2 != 0) {
+            s_ray[2][0][tid] = make_float4(misRo.x, misRo.y, misRo.z, PG_INF);
+            s_ray[2][1][tid] = make_float4(misWi.x, misWi.y, misWi.z, __int_as_float(slot));
+            pushMis = true;
+            st.pdMis[slot] = make_float4(misF.r, misF.g, misF.b, misPdf);
+            st.pdBeta[slot].w = power_heuristic(1, misPdf, 1, lightPdf2);
+        }
+    }
     const RayQueue outQ[3] = {qnext, qshadow, qmis};
     const bool outPred[3] = {pushNext, pushShadow, pushMis};
     int outPos[3];
     block_push<3>(outQ, outPred, outPos);
     const int posNext = outPos[0], posShadow = outPos[1], posMis = outPos[2];
-    if (pushNext) {
-        qnext.o[posNext] = make_float4(nextO.x, nextO.y, nextO.z, PG_INF);
-        qnext.d[posNext] = make_float4(nextD.x, nextD.y, nextD.z, __int_as_float(slot));
-    }
-    if (pushShadow) {
-        qshadow.o[posShadow] = make_float4(shO.x, shO.y, shO.z, shTMax);
-        qshadow.d[posShadow] = make_float4(shD.x, shD.y, shD.z, __int_as_float(slot));
-    }
-    if (pushMis) {
-        qmis.o[posMis] = make_float4(misO.x, misO.y, misO.z, PG_INF);
-        qmis.d[posMis] = make_float4(misD.x, misD.y, misD.z, __int_as_float(slot));
-    }
-    if (valid) {
-        st.pdInfo[slot] = make_int4(posShadow, posMis, lightNum, 0);
-        if (pushShadow || pushMis) {
-            st.pdLight[slot] = pdLight;
-            st.pdMis[slot] = pdMis;
-            st.pdBeta[slot] = pdBeta;
-        }
-    }
+    if (pushNext) { qnext.o[posNext] = s_ray[0][0][tid]; qnext.d[posNext] = s_ray[0][1][tid]; }
+    if (pushShadow) { qshadow.o[posShadow] = s_ray[1][0][tid]; qshadow.d[posShadow] = s_ray[1][1][tid]; }
+    if (pushMis) { qmis.o[posMis] = s_ray[2][0][tid]; qmis.d[posMis] = s_ray[2][1][tid]; }
+    if (valid) st.pdInfo[slot] = make_int4(posShadow, posMis, lightNum, 0);
     unsigned long long nl = wave_sum(nLightTests);
     if (lane_id() == 0 && nl) atomicAdd(lightTriTests, nl);
 }
