@@ -61,16 +61,16 @@ SCENES = {
 }
 
 
-def run(name, scene_path):
+def run(name, scene_path, outdir=GOLD):
     ref = os.path.join(HERE, "_ref", "pbrt_oracle")
-    out = os.path.join(GOLD, name + ".pfm")
+    out = os.path.join(outdir, name + ".pfm")
     txt = subprocess.run([ref, "--nthreads", "4", "--outfile", out, scene_path], capture_output=True, text=True, check=True).stdout
     g = lambda pat: int(re.search(pat, txt).group(1))
     stats = {"camera_rays": g(r"Camera rays traced\s+(\d+)"),
              "closest_rays": g(r"Regular ray intersection tests\s+(\d+)"),
              "shadow_rays": g(r"Shadow ray intersection tests\s+(\d+)"),
              "tri_tests": g(r"Ray-triangle intersection tests\s+\d+ /\s+(\d+)")}
-    json.dump(stats, open(os.path.join(GOLD, name + ".json"), "w"))
+    json.dump(stats, open(os.path.join(outdir, name + ".json"), "w"))
     print(name, stats)
 
 
@@ -83,10 +83,27 @@ def main():
         open(p, "w").write(text)
         run(name, p)
     # small synthetic heightfield (3 042 + 12 triangles): SAH BVH with real depth
-    if only and "synthetic_n40" not in only: return
-    p = os.path.join(GOLD, "synthetic_n40.pbrt")
-    gen_synthetic.write_scene(p, n=40, xres=48, yres=27, spp=4, filename="synthetic_n40.pfm")
-    run("synthetic_n40", p)
+    if not only or "synthetic_n40" in only:
+        p = os.path.join(GOLD, "synthetic_n40.pbrt")
+        gen_synthetic.write_scene(p, n=40, xres=48, yres=27, spp=4, filename="synthetic_n40.pfm")
+        run("synthetic_n40", p)
+    # full-size geometry of BASELINE.json config 3 (999 710 triangles) at a small resolution: the 40 MB scene file is
+    # regenerated by scenes/gen_synthetic.py at test time, only the reference's image and statistics are committed
+    if not only or "synthetic_1m" in only:
+        import tempfile
+        large = os.path.join(ROOT, "tests", "golden_large")
+        os.makedirs(large, exist_ok=True)
+        with tempfile.TemporaryDirectory() as d:
+            p = os.path.join(d, "synthetic_1m.pbrt")
+            gen_synthetic.write_scene(p, n=708, xres=96, yres=54, spp=4, filename="synthetic_1m.pfm")
+            run("synthetic_1m", p, outdir=large)
+    # BASELINE.json config 2 (Cornell box) at a quarter of its resolution and spp
+    if not only or "cornell_128" in only:
+        large = os.path.join(ROOT, "tests", "golden_large")
+        os.makedirs(large, exist_ok=True)
+        p = os.path.join(large, "cornell_128.pbrt")
+        open(p, "w").write(cornell(128, 128, 64))
+        run("cornell_128", p, outdir=large)
 
 
 if __name__ == "__main__":

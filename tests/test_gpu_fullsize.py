@@ -1,0 +1,150 @@
+"""GPU checks at BASELINE.json's sizes.  The oracle cannot render these in seconds, so the full-size runs are checked through
+size-independent properties of the path (determinism, tile-shard invariance, exact linearity in the emitted radiance, film
+weights, closest-hit / any-hit agreement, the reference's ray accounting), and the full-size GEOMETRY is checked against
+the unmodified reference at a small resolution (tests/golden_large, rendered by oracle/make_golden.py) and against the CPU
+oracle on a ray subset (bit-exact)."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+LARGE = os.path.join(ROOT, "tests", "golden_large")
+TOL = 1e-4
+
+
+def rel_err(img, ref):
+    return np.abs(img - ref) / np.maximum(1.0, np.abs(ref))
+
+
+@pytest.fixture(scope="module")
+def synthetic_dir(tmp_path_factory):
+    import gen_synthetic
+    d = tmp_path_factory.mktemp("synthetic_1m")
+    gen_synthetic.write_scene(str(d / "small.pbrt"), n=708, xres=96, yres=54, spp=4, filename="synthetic_1m.pfm")
+    return d
+
+
+def scene_text(synthetic_dir, xres, yres, spp, light_scale=None):
+    txt = open(synthetic_dir / "small.pbrt").read()
+    txt = re.sub(r'"integer xresolution" \[ \d+ \]', f'"integer xresolution" [ {xres} ]', txt)
+    txt = re.sub(r'"integer yresolution" \[ \d+ \]', f'"integer yresolution" [ {yres} ]', txt)
+    txt = re.sub(r'"integer pixelsamples" \[ \d+ \]', f'"integer pixelsamples" [ {spp} ]', txt)
+    txt = txt.replace('Include "small_mesh.pbrt"', f'Include "{synthetic_dir / "small_mesh.pbrt"}"')
+    if light_scale is not None:
+        assert '"rgb L" [ 17 12 4 ]' in txt
+        txt = txt.replace('"rgb L" [ 17 12 4 ]', f'"rgb L" [ 17 12 4 ] "rgb scale" [ {light_scale} {light_scale} {light_scale} ]')
+    return txt
+
+
+def test_million_triangle_geometry_matches_reference(gpu, synthetic_dir):
+    """999 710 triangles, SAH BVH of 1.48 M nodes: the image of the unmodified reference and its ray counters."""
+    scene = gpu.HostScene(str(synthetic_dir / "small.pbrt"))
+    assert scene.desc.n_tris == 999710
+    img, cn = gpu.render_scene(scene)
+    ref = gpu.read_pfm(os.path.join(LARGE, "synthetic_1m.pfm"))
+    err = rel_err(img, ref)
+    assert err.max() <= TOL, f"max rel err {err.max():.3e}"
+    stats = json.load(open(os.path.join(LARGE, "synthetic_1m.json")))
+    assert cn["camera_rays"] == stats["camera_rays"]
+    for k in ("closest_rays", "shadow_rays", "tri_tests"):
+        assert abs(cn[k] - stats[k]) <= max(4, 2e-3 * stats[k]), (k, cn[k], stats[k])
+
+
+def test_million_triangle_rays_bit_exact_vs_oracle(gpu, oracle, synthetic_dir):
+    scene = gpu.HostScene(str(synthetic_dir / "small.pbrt"))
+    gs = gpu.GpuScene(scene.desc)
+    rng = np.random.default_rng(11)
+    n = 1 << 20
+    nodes = scene.nodes()
+    lo, hi = nodes["bmin"][0], nodes["bmax"][0]
+    o = (lo + (hi - lo) * rng.random((n, 3))).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[: n // 16, 2] *= np.float32(0.02)  # grazing rays along the heightfield: long traversals, deep stacks
+    inf = np.full(n, np.inf, np.float32)
+    prim, t, bary = gs.intersect(o, d, inf)
+    occ = gs.intersect_p(o, d, inf)
+    assert ((prim >= 0) == (occ == 1)).all()  # BVHAccel::Intersect and IntersectP agree on hit / miss for every ray
+    assert (t[prim >= 0] > 0).all() and np.isinf(t[prim < 0]).all()
+    sub = slice(0, 40000)  # the CPU oracle on a subset (first 1/16 grazing), bit-exact incl. counters
+    gs.counters_reset()
+    p2, t2, b2 = gs.intersect(o[sub], d[sub], inf[sub])
+    op, ot, ob, ocn = oracle.intersect(scene.desc, o[sub], d[sub], inf[sub])
+    assert np.array_equal(p2, prim[sub]) and np.array_equal(t2, t[sub])  # same ray, same answer regardless of batch
+    assert np.array_equal(p2, op) and np.array_equal(t2, ot) and np.array_equal(b2, ob)
+    cn = gs.counters()
+    assert cn["closest_node_visits"] == ocn["node_visits"] and cn["closest_tri_tests"] == ocn["tri_tests"]
+    gs.close()
+
+
+def test_config3_full_size_properties(gpu, synthetic_dir):
+    """BASELINE.json config 3 itself: 1920x1080 @ 64 spp on the 999 710-triangle scene."""
+    xres, yres, spp = 1920, 1080, 64
+    scene = gpu.HostScene(text=scene_text(synthetic_dir, xres, yres, spp))
+    gs = gpu.GpuScene(scene.desc)
+    rd = scene.render_desc()
+    film, strays = gs.render(rd)
+    cn = gs.counters()
+    # the reference's accounting: one camera ray per pixel sample, every pixel weighted spp times by the box filter
+    assert cn["camera_rays"] == xres * yres * spp
+    ntx, nty = (xres + 15) // 16, (yres + 15) // 16
+    w = film["weight"].reshape(nty, ntx, 16, 16).transpose(0, 2, 1, 3).reshape(nty * 16, ntx * 16)
+    assert (w[:yres, :xres] == spp).all() and (w[yres:] == 0).all()
+    assert np.isfinite(film["rgb"]).all() and (film["rgb"] >= 0).all()
+    assert 5.0 < (cn["closest_rays"] + cn["shadow_rays"]) / cn["camera_rays"] < 8.0  # closed box, maxdepth 5
+    scene.film_clear(); scene.film_merge(rd, film, strays)
+    whole = scene.film_image()
+    # determinism: a second render is bit-identical
+    film2, strays2 = gs.render(rd)
+    assert np.array_equal(film["rgb"], film2["rgb"]) and len(strays) == len(strays2)
+    # tile sharding (the multi-GPU decomposition) does not change a single bit
+    scene.film_clear()
+    for r in range(3):
+        rdr = scene.render_desc(r, 3)
+        f, s = gs.render(rdr)
+        scene.film_merge(rdr, f, s)
+    assert np.array_equal(scene.film_image(), whole)
+    gs.close()
+    # exact linearity in emitted radiance: scaling every light by 2 (a power of two) scales every pixel by exactly 2
+    scene2 = gpu.HostScene(text=scene_text(synthetic_dir, xres, yres, spp, light_scale=2))
+    img2, _ = gpu.render_scene(scene2)
+    assert np.array_equal(img2, whole * np.float32(2))
+
+
+def test_config2_cornell_quarter_size_vs_reference(gpu):
+    """BASELINE.json config 2 (Cornell box) at 128x128 @ 64 spp against the unmodified reference's image."""
+    scene = gpu.HostScene(os.path.join(LARGE, "cornell_128.pbrt"))
+    img, cn = gpu.render_scene(scene)
+    ref = gpu.read_pfm(os.path.join(LARGE, "cornell_128.pfm"))
+    err = rel_err(img, ref)
+    assert err.max() <= TOL, f"max rel err {err.max():.3e}"
+    assert np.percentile(err, 99.99) <= 1e-5
+    stats = json.load(open(os.path.join(LARGE, "cornell_128.json")))
+    assert cn["camera_rays"] == stats["camera_rays"]
+    for k in ("closest_rays", "shadow_rays", "tri_tests"):
+        assert abs(cn[k] - stats[k]) <= max(4, 2e-3 * stats[k]), (k, cn[k], stats[k])
+
+
+def test_config2_cornell_full_size_properties(gpu):
+    """Cornell box at its full 512x512 @ 256 spp: accounting, determinism and shard invariance."""
+    scene = gpu.HostScene(os.path.join(ROOT, "scenes", "cornell.pbrt"))
+    gs = gpu.GpuScene(scene.desc)
+    rd = scene.render_desc()
+    film, strays = gs.render(rd)
+    cn = gs.counters()
+    assert cn["camera_rays"] == 512 * 512 * 256
+    assert (film["weight"] == 256).all()
+    scene.film_clear(); scene.film_merge(rd, film, strays)
+    whole = scene.film_image()
+    assert np.isfinite(whole).all() and whole.min() >= 0 and 0.1 < whole.mean() < 2.0
+    scene.film_clear()
+    for r in range(8):
+        rdr = scene.render_desc(r, 8)
+        f, s = gs.render(rdr)
+        scene.film_merge(rdr, f, s)
+    assert np.array_equal(scene.film_image(), whole)
+    gs.close()
