@@ -48,7 +48,7 @@ struct PgScene {
     DeviceBuffer nodes, wnodes, tris, uv, materials, lights, distTable, perms, permSums, primes;
     // work buffers (sized on first render, reused)
     int capacity = 0;
-    DeviceBuffer qo[4], qd[4], counts, hitsMain, hitsMis, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
+    DeviceBuffer qo[4], qd[4], counts, hitsMain, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
         lightTests, filmDev, straysDev, nStraysDev, cullGuard, cursors;
     // test-path buffers
     DeviceBuffer tO, tD, tT, tPrim, tHit, tOcc, tCount;
@@ -286,7 +286,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     }
     HIP_TRY_S(s->traceCn.alloc(sizeof(TraceCounters) * 2));
     HIP_TRY_S(hipMemset(s->traceCn.p, 0, s->traceCn.bytes));
-    HIP_TRY_S(s->cursors.alloc(PG_REGIONS * PG_COUNT_STRIDE * sizeof(int)));
+    HIP_TRY_S(s->cursors.alloc(2 * PG_REGIONS * PG_COUNT_STRIDE * sizeof(int)));
     HIP_TRY_S(s->cullGuard.alloc(sizeof(int)));
     HIP_TRY_S(hipMemset(s->cullGuard.p, 0, sizeof(int)));
     HIP_TRY_S(s->lightTests.alloc(sizeof(unsigned long long)));
@@ -339,8 +339,7 @@ static int ensureWorkBuffers(PgScene *s, int capacity) {
     const size_t n = (size_t)regionCapFor(capacity) * PG_REGIONS;  // >= capacity
     for (int i = 0; i < 4; ++i) { HIP_TRY(s->qo[i].alloc(n * sizeof(float4))); HIP_TRY(s->qd[i].alloc(n * sizeof(float4))); }
     HIP_TRY(s->counts.alloc(4 * PG_REGIONS * PG_COUNT_STRIDE * sizeof(int)));
-    HIP_TRY(s->hitsMain.alloc(n * sizeof(float4)));
-    HIP_TRY(s->hitsMis.alloc(n * sizeof(float4)));
+    HIP_TRY(s->hitsMain.alloc(2 * n * sizeof(float4)));  // main-queue hits, then MIS-queue hits at offset n (one launch fills both)
     HIP_TRY(s->occluded.alloc(n * sizeof(int)));
     HIP_TRY(s->stL.alloc(n * sizeof(float4)));
     HIP_TRY(s->stBeta.alloc(n * sizeof(float4)));
@@ -410,6 +409,7 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
     int st = ensureWorkBuffers(s, capacity);
     if (st != PG_OK) return st;
 
+    float4 *const hitsMis = (float4 *)s->hitsMain.p + (size_t)regionCapFor(capacity) * PG_REGIONS;
     PathState ps;
     ps.L = (float4 *)s->stL.p; ps.beta = (float4 *)s->stBeta.p; ps.meta = (int4 *)s->stMeta.p;
     ps.pdLight = (float4 *)s->pdLight.p; ps.pdMis = (float4 *)s->pdMis.p; ps.pdBeta = (float4 *)s->pdBeta.p; ps.pdInfo = (int4 *)s->pdInfo.p;
@@ -446,32 +446,38 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
             HIP_TRY(hipMemsetAsync(counts, 0, 4 * QSTRIDE * sizeof(int), stream));
             int cur = 0;  // main queue index (0/1 ping-pong); 2 = shadow, 3 = MIS
             launch_generate(s->d, rp, ps, q[cur], stream);
-            int iters = 0;
-            for (int bounce = 0; bounce < maxIters; ++bounce, ++iters) {
-                const int nxt = cur ^ 1;
+            // Launch order per bounce b (one stream): shade(b) -> any-hit(shadow rays of b) -> closest-hit(main rays of b+1
+            // and MIS rays of b in ONE launch) -> resolve(b).  The first closest-hit launch traces the camera rays alone.
+            auto timedClosest = [&](RayQueue qa, float4 *ha, const RayQueue *qb, float4 *hb) -> int {
                 hipEvent_t a = getEvent(s, ev), b = getEvent(s, ev + 1);
                 timed.push_back({ev, 0}); ev += 2;
                 HIP_TRY(hipEventRecord(a, stream));
-                traceClosest(s, q[cur], (float4 *)s->hitsMain.p, nullptr, cnClosest, stream);
+                if (qb) launch_closest2(s->d, qa, *qb, ha, (int)(hb - ha), cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream);
+                else traceClosest(s, qa, ha, nullptr, cnClosest, stream);
                 HIP_TRY(hipEventRecord(b, stream));
                 ++closestLaunches;
+                return PG_OK;
+            };
+            if (int e = timedClosest(q[cur], (float4 *)s->hitsMain.p, nullptr, nullptr)) return e;
+            int iters = 0;
+            for (int bounce = 0; bounce < maxIters; ++bounce, ++iters) {
+                const int nxt = cur ^ 1;
                 HIP_TRY(hipMemsetAsync(counts + nxt * QSTRIDE, 0, QSTRIDE * sizeof(int), stream));
                 HIP_TRY(hipMemsetAsync(counts + 2 * QSTRIDE, 0, 2 * QSTRIDE * sizeof(int), stream));
                 launch_shade(s->d, rp, ps, q[cur], (const float4 *)s->hitsMain.p, q[nxt], q[2], q[3], lightTests, stream);
-                a = getEvent(s, ev); b = getEvent(s, ev + 1);
-                timed.push_back({ev, 1}); ev += 2;
-                HIP_TRY(hipEventRecord(a, stream));
-                traceAnyhit(s, q[2], (int *)s->occluded.p, cnShadow, stream);
-                HIP_TRY(hipEventRecord(b, stream));
-                ++shadowLaunches;
-                a = getEvent(s, ev); b = getEvent(s, ev + 1);
-                timed.push_back({ev, 0}); ev += 2;
-                HIP_TRY(hipEventRecord(a, stream));
-                traceClosest(s, q[3], (float4 *)s->hitsMis.p, nullptr, cnClosest, stream);
-                HIP_TRY(hipEventRecord(b, stream));
-                ++closestLaunches;
-                launch_resolve(s->d, ps, q[cur], q[3], (const int *)s->occluded.p, (const float4 *)s->hitsMis.p, stream);
-                // log this bounce's queue sizes: [cur main, shadow, mis]
+                // paths that reach maxdepth neither continue nor sample lights (path.cpp:104): nothing left to trace
+                const bool lastDepth = !s->hasNullMaterial && bounce >= rd->max_depth;
+                if (!lastDepth) {
+                    hipEvent_t a = getEvent(s, ev), b = getEvent(s, ev + 1);
+                    timed.push_back({ev, 1}); ev += 2;
+                    HIP_TRY(hipEventRecord(a, stream));
+                    traceAnyhit(s, q[2], (int *)s->occluded.p, cnShadow, stream);
+                    HIP_TRY(hipEventRecord(b, stream));
+                    ++shadowLaunches;
+                    if (int e = timedClosest(q[nxt], (float4 *)s->hitsMain.p, &q[3], hitsMis)) return e;
+                    launch_resolve(s->d, ps, q[cur], q[3], (const int *)s->occluded.p, (const float4 *)hitsMis, stream);
+                }
+                // log this bounce's queue sizes
                 HIP_TRY(hipMemcpyAsync((int *)countLog.p + 4 * QSTRIDE * (size_t)bounce, counts, 4 * QSTRIDE * sizeof(int), hipMemcpyDeviceToDevice, stream));
                 curQueueOfBounce.push_back(cur);
                 cur = nxt;

@@ -90,6 +90,9 @@ struct TraceConfig { int depth, segRays /* rays per chunk */, refillAt, triW; fl
 void set_trace_config(const TraceConfig &c);
 TraceConfig get_trace_config();
 void launch_closest(const DScene &sc, RayQueue q, float4 *hits, float *tOut, TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s);
+// two queues in one launch; q1's results land at hits[hitOffset1 + i]
+void launch_closest2(const DScene &sc, RayQueue q0, RayQueue q1, float4 *hits, int hitOffset1, TraceCounters *cn, int *cursors, int *cullGuard,
+                     hipStream_t s);
 void launch_anyhit(const DScene &sc, RayQueue q, int *occluded, TraceCounters *cn, int *cursors, hipStream_t s);
 void launch_generate(const DScene &sc, const RenderParams &rp, PathState st, RayQueue q, hipStream_t s);
 void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQueue qin, const float4 *hits, RayQueue qnext,

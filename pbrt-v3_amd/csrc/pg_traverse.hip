@@ -31,6 +31,11 @@
 #define TR_BLOCK 256
 #define TR_NONE ((int)0x80000000)
 #define TR_STACK_TOTAL 64
+// 256-thread blocks resident per CU = min(8, floor(800 / (ceil(sgpr/16)*16 + 16))) (MI355X_MICROARCH.md): 106 SGPRs admit 6,
+// <= 96 admit 7.  The cap makes the compiler keep the excess in VGPR lanes (measured: +2.5 % whole-frame).
+#ifndef TR_SGPR_ATTR
+#define TR_SGPR_ATTR __attribute__((amdgpu_num_sgpr(96)))
+#endif
 #ifndef TR_MIN_WAVES
 #define TR_MIN_WAVES 2
 #endif
@@ -67,9 +72,10 @@ PG_DEV unsigned long long tr_wave_sum(unsigned long long v) {
 }
 
 template <bool ANYHIT>
-__global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(DScene sc, RayQueue q, float4 *__restrict__ hits, float *__restrict__ tOut,
-                                                    int *__restrict__ occluded, TraceCounters *cn, int *__restrict__ cursors, int depth, int chunk,
-                                                    int refillAt, int triW, float cullK, int *cullGuard) {
+__global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(DScene sc, RayQueue q0, RayQueue q1, float4 *__restrict__ hits,
+                                                    int hitOffset1, float *__restrict__ tOut, int *__restrict__ occluded,
+                                                    TraceCounters *cn, int *__restrict__ cursors, int depth, int chunk, int refillAt, int triW,
+                                                    float cullK, int *cullGuard) {
     extern __shared__ uint2 ldsStack[];  // [depth][TR_BLOCK]
     uint2 spill[TR_STACK_TOTAL];
     const int tid = threadIdx.x;
@@ -78,10 +84,12 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(DScene sc, Ray
     // Work distribution: the queue is PG_REGIONS sub-queues, one per XCD (block b runs on XCD b % 8, and the producers
     // appended from that XCD, so each private L2 sees one coherent part of the queue); a wave takes `chunk` rays at a time
     // from its region's cursor and moves on to the next region when its own is drained.  Waves are persistent: the grid
-    // only has to fill the chip.
-    const int per = q.regionCap;
+    // only has to fill the chip.  One launch can drain two queues (closest hit: the next bounce's rays and the previous
+    // bounce's MIS rays): regions 0-7 are q0's, 8-15 are q1's; q1's results go to hits[hitOffset1 + i].
+    const int nRegions = q1.regionCap > 0 ? 2 * PG_REGIONS : PG_REGIONS;
     int region = blockIdx.x & (PG_REGIONS - 1), regionsTried = 0;
-    int next = 0, segEnd = 0;  // the wave's current chunk [next, segEnd)
+    bool fresh = false;  // moved to a region this wave has not taken a chunk from yet: look before the atomic
+    int next = 0, segEnd = 0, curQ = 0;  // the wave's current chunk [next, segEnd) of queue curQ
     bool exhausted = false;
     // per-lane ray state.  A lane is in exactly one of three states:
     //   cur >= 0                 : holds an interior record to expand (its box test already passed)
@@ -130,21 +138,36 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(DScene sc, Ray
         if (!exhausted && nIdle >= refillAt) {
             if (next >= segEnd) {  // wave-uniform: take the next chunk
                 for (;;) {
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(&cursors[region * PG_COUNT_STRIDE], chunk);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    const int r0 = region * per, r1 = r0 + q.counts[region * PG_COUNT_STRIDE];
-                    if (r0 + base < r1) { next = r0 + base; segEnd = min(next + chunk, r1); break; }
-                    region = (region + 1) & (PG_REGIONS - 1);
-                    if (++regionsTried == PG_REGIONS) { exhausted = true; break; }
+                    const int qsel = region >> 3, rr = region & (PG_REGIONS - 1);
+                    const RayQueue &cq = qsel ? q1 : q0;
+                    const int count = cq.counts[rr * PG_COUNT_STRIDE];
+                    int *cursor = &cursors[region * PG_COUNT_STRIDE];
+                    // a drained region costs a load, not an atomic: cursors only grow, so a stale value can only under-report
+                    bool drained = fresh && __hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= count;
+                    if (!drained) {
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(cursor, chunk);
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        if (base < count) {
+                            next = rr * cq.regionCap + base; segEnd = next + min(chunk, count - base);
+                            curQ = qsel; fresh = false;
+                            break;
+                        }
+                    }
+                    // next region: the other regions of this queue first (same XCD-local L2 contents last), then the other queue
+                    ++regionsTried;
+                    if (regionsTried == nRegions) { exhausted = true; break; }
+                    const int own = blockIdx.x & (PG_REGIONS - 1);
+                    region = ((regionsTried >> 3) << 3) | ((own + regionsTried) & (PG_REGIONS - 1));
+                    fresh = true;
                 }
             }
             if (!exhausted) {
                 const int idx = next + __popcll(idleMask & laneLt);
                 next += nIdle;
                 if (idle && idx < segEnd) {
-                    const float4 o4 = q.o[idx], d4 = q.d[idx];
-                    ray = idx;
+                    const float4 o4 = curQ ? q1.o[idx] : q0.o[idx], d4 = curQ ? q1.d[idx] : q0.d[idx];
+                    ray = idx + (curQ ? hitOffset1 : 0);  // index of this ray's result
                     ox = o4.x; oy = o4.y; oz = o4.z; tMax = o4.w;
                     tr = tri_ray_setup(mk(d4.x, d4.y, d4.z));
                     ix = 1 / d4.x; iy = 1 / d4.y; iz = 1 / d4.z;   // bvh.cpp:666
@@ -235,22 +258,27 @@ void set_trace_config(const TraceConfig &c) { g_cfg = c; }
 TraceConfig get_trace_config() { return g_cfg; }
 
 template <bool ANYHIT>
-static void launch_trace(const DScene &sc, RayQueue q, float4 *hits, float *tOut, int *occluded, TraceCounters *cn, int *cursors, int *cullGuard,
-                         hipStream_t s) {
+static void launch_trace(const DScene &sc, RayQueue q0, RayQueue q1, float4 *hits, int hitOffset1, float *tOut, int *occluded, TraceCounters *cn,
+                         int *cursors, int *cullGuard, hipStream_t s) {
     const TraceConfig c = g_cfg;
-    if (q.regionCap <= 0) return;
-    // persistent grid: enough blocks to fill 256 CUs at 8 blocks each, never more than the queue can feed
-    long long need = ((long long)q.regionCap * PG_REGIONS + c.segRays - 1) / c.segRays;  // chunks
+    if (q0.regionCap <= 0) return;
+    // persistent grid: enough blocks to fill 256 CUs at 8 blocks each, never more than the queues can feed
+    long long need = ((long long)(q0.regionCap + q1.regionCap) * PG_REGIONS + c.segRays - 1) / c.segRays;  // chunks
     int nblk = (int)std::min<long long>((need + TR_BLOCK / 64 - 1) / (TR_BLOCK / 64), (long long)c.gridBlocks);
     nblk = ((nblk + 7) / 8) * 8;
     size_t lds = sizeof(uint2) * (size_t)c.depth * TR_BLOCK;
-    (void)hipMemsetAsync(cursors, 0, PG_REGIONS * PG_COUNT_STRIDE * sizeof(int), s);
-    hipLaunchKernelGGL(k_trace<ANYHIT>, dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q, hits, tOut, occluded, cn, cursors, c.depth, c.segRays,
-                       c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard);
+    (void)hipMemsetAsync(cursors, 0, 2 * PG_REGIONS * PG_COUNT_STRIDE * sizeof(int), s);
+    hipLaunchKernelGGL(k_trace<ANYHIT>, dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q0, q1, hits, hitOffset1, tOut, occluded, cn, cursors, c.depth,
+                       c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard);
 }
+static RayQueue noQueue() { RayQueue q; q.o = q.d = nullptr; q.counts = nullptr; q.regionCap = 0; return q; }
 void launch_closest(const DScene &sc, RayQueue q, float4 *hits, float *tOut, TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s) {
-    launch_trace<false>(sc, q, hits, tOut, nullptr, cn, cursors, cullGuard, s);
+    launch_trace<false>(sc, q, noQueue(), hits, 0, tOut, nullptr, cn, cursors, cullGuard, s);
+}
+void launch_closest2(const DScene &sc, RayQueue q0, RayQueue q1, float4 *hits, int hitOffset1, TraceCounters *cn, int *cursors, int *cullGuard,
+                     hipStream_t s) {
+    launch_trace<false>(sc, q0, q1, hits, hitOffset1, nullptr, nullptr, cn, cursors, cullGuard, s);
 }
 void launch_anyhit(const DScene &sc, RayQueue q, int *occluded, TraceCounters *cn, int *cursors, hipStream_t s) {
-    launch_trace<true>(sc, q, nullptr, nullptr, occluded, cn, cursors, nullptr, s);
+    launch_trace<true>(sc, q, noQueue(), nullptr, 0, nullptr, occluded, cn, cursors, nullptr, s);
 }
