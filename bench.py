@@ -186,9 +186,7 @@ def main():
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes / launches,
                     "avg_launch_ms": cn["closest_ms"] / launches, "launches": launches,
-                    "bytes_per_ray": alg_bytes / max(1, n_ray),
-                    "shadow_kernel_GBps": ((32 * cn["shadow_node_visits"] + 48 * cn["shadow_tri_tests"] + 32 * cn["shadow_rays"] + 4 * cn["shadow_rays"])
-                                           / (cn["shadow_ms"] * 1e-3) / 1e9) if cn["shadow_ms"] > 0 else 0.0}
+                    "bytes_per_ray": alg_bytes / max(1, n_ray)}
         result = {
             "metric": "Mrays/s", "value": rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,

@@ -49,7 +49,10 @@ struct PgScene {
     // work buffers (sized on first render, reused)
     int capacity = 0;
     DeviceBuffer qo[4], qd[4], counts, hitsMain, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
-        lightTests, filmDev, straysDev, nStraysDev, cullGuard, cursors;
+        lightTests, filmDev, straysDev, nStraysDev, cullGuard, cursors, cursors2;
+    hipStream_t shadowStream = nullptr;  // any-hit launches run here, concurrently with the next closest-hit launch
+    hipEvent_t evShaded = nullptr, evShadowed = nullptr;
+    bool overlapShadow = true;
     // test-path buffers
     DeviceBuffer tO, tD, tT, tPrim, tHit, tOcc, tCount;
     PgCounters counters;
@@ -76,6 +79,9 @@ void pg_scene_destroy(PgScene *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
+    if (s->evShaded) (void)hipEventDestroy(s->evShaded);
+    if (s->evShadowed) (void)hipEventDestroy(s->evShadowed);
+    if (s->shadowStream) (void)hipStreamDestroy(s->shadowStream);
     delete s;
 }
 
@@ -287,6 +293,11 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     HIP_TRY_S(s->traceCn.alloc(sizeof(TraceCounters) * 2));
     HIP_TRY_S(hipMemset(s->traceCn.p, 0, s->traceCn.bytes));
     HIP_TRY_S(s->cursors.alloc(2 * PG_REGIONS * PG_COUNT_STRIDE * sizeof(int)));
+    HIP_TRY_S(s->cursors2.alloc(2 * PG_REGIONS * PG_COUNT_STRIDE * sizeof(int)));
+    HIP_TRY_S(hipStreamCreateWithFlags(&s->shadowStream, hipStreamNonBlocking));
+    HIP_TRY_S(hipEventCreateWithFlags(&s->evShaded, hipEventDisableTiming));
+    HIP_TRY_S(hipEventCreateWithFlags(&s->evShadowed, hipEventDisableTiming));
+    if (const char *e = getenv("PG_OVERLAP_SHADOW")) s->overlapShadow = atoi(e) != 0;
     HIP_TRY_S(s->cullGuard.alloc(sizeof(int)));
     HIP_TRY_S(hipMemset(s->cullGuard.p, 0, sizeof(int)));
     HIP_TRY_S(s->lightTests.alloc(sizeof(unsigned long long)));
@@ -468,13 +479,23 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
                 // paths that reach maxdepth neither continue nor sample lights (path.cpp:104): nothing left to trace
                 const bool lastDepth = !s->hasNullMaterial && bounce >= rd->max_depth;
                 if (!lastDepth) {
+                    // The shadow rays of this bounce and the closest-hit rays of the next depend only on shade(b): the any-hit
+                    // launch goes to a second stream so that its blocks fill the chip while the closest-hit launch's
+                    // persistent waves drain (and vice versa); resolve(b) joins both.
+                    hipStream_t sst = s->overlapShadow ? s->shadowStream : stream;
+                    if (s->overlapShadow) {
+                        HIP_TRY(hipEventRecord(s->evShaded, stream));
+                        HIP_TRY(hipStreamWaitEvent(sst, s->evShaded, 0));
+                    }
                     hipEvent_t a = getEvent(s, ev), b = getEvent(s, ev + 1);
                     timed.push_back({ev, 1}); ev += 2;
-                    HIP_TRY(hipEventRecord(a, stream));
-                    traceAnyhit(s, q[2], (int *)s->occluded.p, cnShadow, stream);
-                    HIP_TRY(hipEventRecord(b, stream));
+                    HIP_TRY(hipEventRecord(a, sst));
+                    launch_anyhit(s->d, q[2], (int *)s->occluded.p, cnShadow, (int *)s->cursors2.p, sst);
+                    HIP_TRY(hipEventRecord(b, sst));
                     ++shadowLaunches;
+                    if (s->overlapShadow) HIP_TRY(hipEventRecord(s->evShadowed, sst));
                     if (int e = timedClosest(q[nxt], (float4 *)s->hitsMain.p, &q[3], hitsMis)) return e;
+                    if (s->overlapShadow) HIP_TRY(hipStreamWaitEvent(stream, s->evShadowed, 0));
                     launch_resolve(s->d, ps, q[cur], q[3], (const int *)s->occluded.p, (const float4 *)hitsMis, stream);
                 }
                 // log this bounce's queue sizes

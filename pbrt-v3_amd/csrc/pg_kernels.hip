@@ -21,10 +21,15 @@ PG_DEV int lane_id() { return __lane_id(); }
 // queue does the atomicAdd on the block's region counter (region = blockIdx.x % 8); lanes get consecutive entries in
 // (wave, lane) order.  NQ queues are appended to in one exchange (two barriers).  Must be reached by all threads.
 // Consumers and producers share one mapping: block b owns entries [(b>>3)*256, +256) of region b & 7.
-template <int NQ>
-PG_DEV void block_push(const RayQueue *q, const bool *pred, int *pos) {
-    __shared__ int s_cnt[NQ][PG_BLOCK / 64];
+// With BINNED, queue 0's entries are additionally grouped by `bin0` (0..7) inside the block's range: k_shade bins the next
+// bounce's rays by direction octant, so the 64 consecutive rays a traversal wave picks up come from one tile AND mostly
+// one octant (same near/far child order, same subtrees) instead of four to eight.
+template <int NQ, bool BINNED>
+PG_DEV void block_push(const RayQueue *q, const bool *pred, int *pos, int bin0 = 0) {
+    constexpr int NW = PG_BLOCK / 64;
+    __shared__ int s_cnt[NQ][NW];
     __shared__ int s_base[NQ];
+    __shared__ int s_bin[BINNED ? 8 : 1][NW];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     unsigned long long mask[NQ];
 #pragma unroll
@@ -32,13 +37,22 @@ PG_DEV void block_push(const RayQueue *q, const bool *pred, int *pos) {
         mask[k] = __ballot(pred[k]);
         if (lane == 0) s_cnt[k][wave] = __popcll(mask[k]);
     }
+    unsigned long long binMask = 0;
+    if (BINNED) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long m = __ballot(pred[0] && bin0 == b);
+            if (lane == 0) s_bin[b][wave] = __popcll(m);
+            if (bin0 == b) binMask = m;
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < NQ; ++k)  // one lane per queue; written without dynamic indexing so q[] stays in registers
         if (threadIdx.x == k) {
             int total = 0;
 #pragma unroll
-            for (int w = 0; w < PG_BLOCK / 64; ++w) total += s_cnt[k][w];
+            for (int w = 0; w < NW; ++w) total += s_cnt[k][w];
             const int r = blockIdx.x & (PG_REGIONS - 1);
             s_base[k] = total ? r * q[k].regionCap + atomicAdd(&q[k].counts[r * PG_COUNT_STRIDE], total) : 0;
         }
@@ -46,8 +60,15 @@ PG_DEV void block_push(const RayQueue *q, const bool *pred, int *pos) {
 #pragma unroll
     for (int k = 0; k < NQ; ++k) {
         int off = s_base[k];
-        for (int w = 0; w < wave; ++w) off += s_cnt[k][w];
-        pos[k] = pred[k] ? off + __popcll(mask[k] & ((1ull << lane) - 1ull)) : -1;
+        if (BINNED && k == 0) {
+            for (int b = 0; b < 8; ++b)
+                for (int w = 0; w < NW; ++w)
+                    if (b < bin0 || (b == bin0 && w < wave)) off += s_bin[b][w];
+            pos[k] = pred[k] ? off + __popcll(binMask & ((1ull << lane) - 1ull)) : -1;
+        } else {
+            for (int w = 0; w < wave; ++w) off += s_cnt[k][w];
+            pos[k] = pred[k] ? off + __popcll(mask[k] & ((1ull << lane) - 1ull)) : -1;
+        }
     }
 }
 // The queue entry this thread consumes (or -1): block b walks region b & 7.
@@ -196,7 +217,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_generate(DScene sc, RenderParams r
         st.meta[slot] = make_int4(0, 0, 0, PG_META_DONE | 0x40000);  // 0x40000: slot holds no sample
     }
     int pos;
-    block_push<1>(&q, &valid, &pos);
+    block_push<1, false>(&q, &valid, &pos);
     if (valid) {
         q.o[pos] = make_float4(o.x, o.y, o.z, tMax);
         q.d[pos] = make_float4(d.x, d.y, d.z, __int_as_float(slot));
@@ -473,6 +494,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
     int slot = 0;
     unsigned int nLightTests = 0;
     int lightNum = -1;
+    int nextBin = 0;  // direction octant of the continuation ray (groups the next queue, see block_push)
     // candidate of the BSDF-sampling half of MIS, tested against the light's triangle at the end
     bool misCand = false;
     V3 misRo = mk(0, 0, 0), misWi = mk(0, 0, 1), misP = mk(0, 0, 0);
@@ -587,6 +609,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                     spawn_ray(is, wi, nextO);
                     s_ray[0][0][tid] = make_float4(nextO.x, nextO.y, nextO.z, PG_INF);
                     s_ray[0][1][tid] = make_float4(wi.x, wi.y, wi.z, __int_as_float(slot));
+                    nextBin = (wi.x < 0 ? 1 : 0) | (wi.y < 0 ? 2 : 0) | (wi.z < 0 ? 4 : 0);
                     pushNext = true;
                     // Russian roulette, path.cpp:176-184 (etaScale == 1: no transmission in the closed set)
                     Spec rrBeta = beta * 1.f;
@@ -627,7 +650,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
     const RayQueue outQ[3] = {qnext, qshadow, qmis};
     const bool outPred[3] = {pushNext, pushShadow, pushMis};
     int outPos[3];
-    block_push<3>(outQ, outPred, outPos);
+    block_push<3, true>(outQ, outPred, outPos, nextBin);
     const int posNext = outPos[0], posShadow = outPos[1], posMis = outPos[2];
     if (pushNext) { qnext.o[posNext] = s_ray[0][0][tid]; qnext.d[posNext] = s_ray[0][1][tid]; }
     if (pushShadow) { qshadow.o[posShadow] = s_ray[1][0][tid]; qshadow.d[posShadow] = s_ray[1][1][tid]; }
