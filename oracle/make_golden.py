@@ -31,6 +31,28 @@ def cornell(xres, yres, spp, extra_film="", integrator='Integrator "path" "integ
     return s
 
 
+def with_normals(s, tangents=False, uv=False):
+    """Give both Cornell boxes smooth-ish per-vertex normals (outward from the box centre, one of them zero), optionally
+    tangents and a uv parameterisation."""
+    import re
+    def edit(m):
+        pts = [float(x) for x in m.group(2).split()]
+        n = len(pts) // 3
+        c = [sum(pts[k::3]) / n for k in range(3)]
+        N, S, UV = [], [], []
+        for i in range(n):
+            d = [pts[3 * i + k] - c[k] for k in range(3)]
+            N += ([0, 0, 0] if i == 5 else [d[0], d[1] * 0.5, d[2]])
+            S += [d[2] + 1, 0.25 * d[1], -d[0]]
+            UV += [0.01 * pts[3 * i] + 0.002 * pts[3 * i + 1], 0.01 * pts[3 * i + 2]]
+        extra = ' "normal N" [ ' + " ".join(f"{x:.6g}" for x in N) + " ]"
+        if tangents: extra += ' "vector S" [ ' + " ".join(f"{x:.6g}" for x in S) + " ]"
+        if uv: extra += ' "float uv" [ ' + " ".join(f"{x:.6g}" for x in UV) + " ]"
+        return m.group(1) + m.group(2) + " ]" + extra
+    # the two 24-vertex box meshes
+    return re.sub(r'("point P" \[ )((?:[-\d.]+\s+){71}[-\d.]+) \]', edit, s)
+
+
 SCENES = {
     # plain Cornell, tile-aligned and not
     "cornell_32": cornell(32, 32, 8),
@@ -57,6 +79,13 @@ SCENES = {
                                         '# short box\nMaterial "plastic" "rgb Kd" [ 0 0 0 ] "rgb Ks" [ 0.6 0.7 0.8 ] "float roughness" [ 0.3 ] "bool remaproughness" "false"')),
     "plastic_topdown": cornell(24, 24, 8, world_edit=lambda s: s.replace('Material "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', 'Material "plastic" "rgb Kd" [ 0.2 0.3 0.4 ] "rgb Ks" [ 0.5 0.5 0.5 ] "float roughness" [ 0.02 ]', 1))
         .replace("LookAt 278 273 -800  278 273 0  0 1 0", "LookAt 278 500 279  278 0 279  0 0 1"),
+    # per-vertex shading normals N, tangents S and uv on the boxes (triangle.cpp:350-419), incl. reversed orientation,
+    # an emitter with normals (Triangle::Sample's Faceforward, triangle.cpp:593-597) and a zero normal
+    "cornell_normals": cornell(32, 32, 8, world_edit=lambda s: with_normals(s)),
+    "cornell_tangents": cornell(24, 24, 8, world_edit=lambda s: with_normals(s, tangents=True, uv=True).replace("# tall box", "ReverseOrientation\n# tall box")),
+    "cornell_lightnormals": cornell(24, 24, 8, world_edit=lambda s: s.replace(
+        '"point P" [ 343 548.7 227   343 548.7 332   213 548.7 332   213 548.7 227 ]',
+        '"point P" [ 343 548.7 227   343 548.7 332   213 548.7 332   213 548.7 227 ] "normal N" [ 0.2 -1 0  0 -1 0.3  0 1 0  -0.2 -1 -0.1 ]')),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 

@@ -45,7 +45,7 @@ struct DeviceBuffer {
 struct PgScene {
     int device = 0;
     DScene d;
-    DeviceBuffer nodes, wnodes, tris, uv, materials, lights, distTable, perms, permSums, primes;
+    DeviceBuffer nodes, wnodes, tris, triN, triS, uv, materials, lights, distTable, perms, permSums, primes;
     // work buffers (sized on first render, reused)
     int capacity = 0;
     DeviceBuffer qo[4], qd[4], counts, hitsMain, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
@@ -91,8 +91,6 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     if (desc->abi_version != PG_ABI_VERSION) return setError(PG_ERR_INVALID, "ABI version %d, expected %d", desc->abi_version, PG_ABI_VERSION);
     if (desc->n_tris < 0 || desc->n_nodes < 0 || (desc->n_tris > 0 && (!desc->nodes || !desc->indices || !desc->P)))
         return setError(PG_ERR_INVALID, "pg_scene_create: malformed geometry arrays");
-    if (desc->N || desc->S)
-        return setError(PG_ERR_UNSUPPORTED, "per-vertex shading normals / tangents are outside this build's closed set");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev <= 0) return setError(PG_ERR_DEVICE, "no HIP device visible (there is no CPU fallback)");
@@ -185,6 +183,23 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         tris[3 * (size_t)k + 1] = make_float4(p[1].x, p[1].y, p[1].z, mw);
         tris[3 * (size_t)k + 2] = make_float4(p[2].x, p[2].y, p[2].z, lw);
     }
+    // per-vertex normals / tangents, de-indexed like the positions (only when some mesh has them)
+    for (int pass = 0; pass < 2; ++pass) {
+        const float *src = pass == 0 ? desc->N : desc->S;
+        const uint32_t bit = pass == 0 ? PG_TRI_HAS_N : PG_TRI_HAS_S;
+        bool any = false;
+        for (int k = 0; k < nt && src; ++k) any |= desc->tri_flags && (desc->tri_flags[k] & bit);
+        if (!any) continue;
+        std::vector<float4> a((size_t)nt * 3, make_float4(0, 0, 0, 0));
+        for (int k = 0; k < nt; ++k) {
+            if (!(desc->tri_flags[k] & bit)) continue;
+            const int32_t *v = &desc->indices[3 * k];
+            for (int j = 0; j < 3; ++j) a[3 * (size_t)k + j] = make_float4(src[3 * v[j]], src[3 * v[j] + 1], src[3 * v[j] + 2], 0.f);
+        }
+        DeviceBuffer &buf = pass == 0 ? s->triN : s->triS;
+        HIP_TRY_S(buf.alloc(sizeof(float4) * a.size()));
+        HIP_TRY_S(hipMemcpy(buf.p, a.data(), buf.bytes, hipMemcpyHostToDevice));
+    }
     HIP_TRY_S(s->tris.alloc(sizeof(float4) * tris.size()));
     if (nt) HIP_TRY_S(hipMemcpy(s->tris.p, tris.data(), s->tris.bytes, hipMemcpyHostToDevice));
     if (anyUV) {
@@ -237,6 +252,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     HIP_TRY_S(hipMemcpy(s->primes.p, primes.data(), s->primes.bytes, hipMemcpyHostToDevice));
 
     d.nodes = (const float4 *)s->nodes.p; d.tris = (const float4 *)s->tris.p; d.uv = (const float *)s->uv.p;
+    d.triN = (const float4 *)s->triN.p; d.triS = (const float4 *)s->triS.p;
     d.materials = (const PgMaterial *)s->materials.p; d.lights = (const PgLight *)s->lights.p;
     d.nNodes = desc->n_nodes; d.nTris = nt; d.nLights = desc->n_lights; d.nMaterials = desc->n_materials;
     d.perms = (const uint16_t *)s->perms.p; d.permSums = (const int32_t *)s->permSums.p; d.primes = (const int32_t *)s->primes.p;

@@ -25,6 +25,8 @@ struct DScene {
     // Triangles in BVH order, 48 B each: three float4
     //   t[0] = (p0, flags)  t[1] = (p1, material)  t[2] = (p2, light)
     const float4 *tris;
+    // per-vertex shading normals N / tangents S de-indexed per triangle (3 float4 each, BVH order), or nullptr when no mesh has them
+    const float4 *triN, *triS;
     const float *uv;  // 6 floats per triangle, or nullptr when no mesh has uv (default uv, triangle.h:104-106)
     const PgMaterial *materials;
     const PgLight *lights;

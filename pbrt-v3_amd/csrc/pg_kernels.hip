@@ -231,7 +231,7 @@ void launch_generate(const DScene &sc, const RenderParams &rp, PathState st, Ray
 // ===========================================================================
 // Shading
 // ===========================================================================
-struct Isect { V3 p, pError, wo, n, dpdu; };
+struct Isect { V3 p, pError, wo, n, ns, sdpdu; };  // n: geometric normal; ns, sdpdu: shading.n, shading.dpdu
 
 PG_DEV V3 tri_normal(const Tri &t) {  // triangle.cpp:346-348
     V3 n = normalize(cross(t.p0 - t.p2, t.p1 - t.p2));
@@ -243,11 +243,21 @@ PG_DEV void load_uv(const DScene &sc, int prim, uint32_t flags, float uv[6]) {  
     else { uv[0] = 0; uv[1] = 0; uv[2] = 1; uv[3] = 0; uv[4] = 1; uv[5] = 1; }
 }
 // The tail of Triangle::Intersect (triangle.cpp:293-348) for the surviving hit.
+// Per-vertex attribute a (N or S) of triangle prim interpolated with weights (w0, w1, w2): w0*a0 + w1*a1 + w2*a2.
+PG_DEV V3 tri_interp(const float4 *attr, int prim, float w0, float w1, float w2) {
+    const float4 a = attr[3 * prim], b = attr[3 * prim + 1], c = attr[3 * prim + 2];
+    return mk(a.x, a.y, a.z) * w0 + mk(b.x, b.y, b.z) * w1 + mk(c.x, c.y, c.z) * w2;
+}
+// Triangle::Intersect's geometric normal for a hit with barycentrics (b0,b1,b2): Normalize(Cross(dp02, dp12)), flipped by
+// reverseOrientation ^ transformSwapsHandedness (triangle.cpp:346-348), then made to face the interpolated shading normal
+// when the mesh has per-vertex normals (SetShadingGeometry's Faceforward, interaction.cpp:79-81) -- full version below.
+// The tail of Triangle::Intersect (triangle.cpp:293-419) for the surviving hit.
 PG_DEV Isect make_isect(const DScene &sc, int prim, const Tri &t, float b0, float b1, float b2, V3 rayD) {
     Isect is;
     float uv[6];
     load_uv(sc, prim, t.flags, uv);
-    tri_dpdu(t.p0, t.p1, t.p2, uv, is.dpdu);
+    V3 dpdu;
+    tri_dpdu(t.p0, t.p1, t.p2, uv, dpdu);
     float xAbsSum = (fabsf(b0 * t.p0.x) + fabsf(b1 * t.p1.x) + fabsf(b2 * t.p2.x));
     float yAbsSum = (fabsf(b0 * t.p0.y) + fabsf(b1 * t.p1.y) + fabsf(b2 * t.p2.y));
     float zAbsSum = (fabsf(b0 * t.p0.z) + fabsf(b1 * t.p1.z) + fabsf(b2 * t.p2.z));
@@ -255,7 +265,34 @@ PG_DEV Isect make_isect(const DScene &sc, int prim, const Tri &t, float b0, floa
     is.p = t.p0 * b0 + t.p1 * b1 + t.p2 * b2;
     is.wo = normalize(-rayD);  // Interaction ctor, interaction.h:60
     is.n = tri_normal(t);
+    is.ns = is.n;
+    is.sdpdu = dpdu;
+    const bool hasN = sc.triN && (t.flags & PG_TRI_HAS_N), hasS = sc.triS && (t.flags & PG_TRI_HAS_S);
+    if (hasN || hasS) {  // shading geometry, triangle.cpp:350-419 (dndu/dndv only feed ray differentials)
+        V3 ns = is.n, ss = normalize(dpdu), ts;
+        if (hasN) {
+            V3 v = tri_interp(sc.triN, prim, b0, b1, b2);
+            if (lensq(v) > 0) ns = normalize(v);
+        }
+        if (hasS) {
+            V3 v = tri_interp(sc.triS, prim, b0, b1, b2);
+            if (lensq(v) > 0) ss = normalize(v);
+        }
+        ts = cross(ss, ns);
+        if (lensq(ts) > 0.f) { ts = normalize(ts); ss = cross(ts, ns); }
+        else coordinate_system(ns, ss, ts);
+        if (t.flags & PG_TRI_REVERSE_ORIENTATION) ts = -ts;
+        // SetShadingGeometry(ss, ts, ..., orientationIsAuthoritative = true), interaction.cpp:74-90
+        is.ns = normalize(cross(ss, ts));
+        if (dot(is.n, is.ns) < 0.f) is.n = -is.n;
+        is.sdpdu = ss;
+    }
     return is;
+}
+// The geometric normal alone, as make_isect leaves it in isect.n (for Le() at a hit that is not shaded further).
+PG_DEV V3 hit_normal(const DScene &sc, int prim, const Tri &t, float b0, float b1, float b2) {
+    if ((sc.triN && (t.flags & PG_TRI_HAS_N)) || (sc.triS && (t.flags & PG_TRI_HAS_S))) return make_isect(sc, prim, t, b0, b1, b2, mk(0, 0, 1)).n;
+    return tri_normal(t);
 }
 
 // BSDF: LambertianReflection and/or MicrofacetReflection(TrowbridgeReitz, FresnelDielectric(1.5, 1)) lobes in the order
@@ -433,7 +470,10 @@ PG_DEV Spec light_sample_li(const DScene &sc, const PgLight &light, V3 refp, flo
     float b2 = (1 - b0 - b1);
     ls.p = t.p0 * b0 + t.p1 * b1 + t.p2 * b2;
     ls.n = normalize(cross(t.p1 - t.p0, t.p2 - t.p0));
-    if (t.flags & PG_TRI_FLIP_NORMAL) ls.n = ls.n * -1.f;
+    if (sc.triN && (t.flags & PG_TRI_HAS_N)) {  // triangle.cpp:593-597: orientation follows the shading normal
+        V3 ns = tri_interp(sc.triN, light.prim, b0, b1, b2);
+        if (dot(ls.n, ns) < 0.f) ls.n = -ls.n;
+    } else if (t.flags & PG_TRI_FLIP_NORMAL) ls.n = ls.n * -1.f;
     V3 pAbsSum = vabs(t.p0 * b0) + vabs(t.p1 * b1) + vabs(t.p2 * b2);
     ls.pError = pAbsSum * pgamma(6);
     pdf = 1 / light.area;
@@ -520,7 +560,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
         // path.cpp:91-102 emitted light at the vertex
         if ((bounces == 0 || specularBounce) && found && tri.light >= 0) {
             const PgLight &l = sc.lights[tri.light];
-            V3 nrm = tri_normal(tri);
+            V3 nrm = hit_normal(sc, prim, tri, h4.y, h4.z, h4.w);
             Spec Le = (l.two_sided || dot(nrm, -rayD) > 0) ? sp3(l.L[0], l.L[1], l.L[2]) : sp(0);
             L = L + beta * Le;
         } else if ((bounces == 0 || specularBounce) && found) L = L + beta * sp(0);
@@ -538,8 +578,8 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
             } else {
                 // MatteMaterial::ComputeScatteringFunctions (matte.cpp:45-62), BSDF ctor (reflection.h:167-172)
                 Bsdf bsdf;
-                bsdf.ns = is.n; bsdf.ng = is.n;
-                bsdf.ss = normalize(is.dpdu);
+                bsdf.ns = is.ns; bsdf.ng = is.n;
+                bsdf.ss = normalize(is.sdpdu);
                 bsdf.ts = cross(bsdf.ns, bsdf.ss);
                 bsdf.R = sp3(m.kd[0] < 0 ? 0 : m.kd[0], m.kd[1] < 0 ? 0 : m.kd[1], m.kd[2] < 0 ? 0 : m.kd[2]);
                 bsdf.hasDiff = !is_black(bsdf.R);
@@ -687,7 +727,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_resolve(DScene sc, PathState st, R
                 const PgLight &l = sc.lights[t.light];
                 const float4 d4 = qmis.d[info.y];
                 V3 wi = mk(d4.x, d4.y, d4.z);
-                V3 nrm = tri_normal(t);
+                V3 nrm = hit_normal(sc, prim, t, h.y, h.z, h.w);
                 Spec Li = (l.two_sided || dot(nrm, -wi) > 0) ? sp3(l.L[0], l.L[1], l.L[2]) : sp(0);
                 if (!is_black(Li)) Ld = Ld + ((((sp3(pm.x, pm.y, pm.z) * Li) * sp(1.f)) * pb.w) / pm.w);
             }

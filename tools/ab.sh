@@ -12,7 +12,7 @@ for CFG in "$@"; do
 import json, sys
 try:
     j = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1]); r = j["roofline"]
-    print(f"{sys.argv[1]:50s} | {j['value']:8.1f} Mrays/s  step {j['ms_per_step']:8.1f} ms  closest {r["avg_launch_ms"]:7.3f} ms/launch {r["achieved"]:7.1f} GB/s")
+    print(f"{sys.argv[1]:50s} | {j['value']:8.1f} Mrays/s  step {j['ms_per_step']:8.1f} ms  closest {r['avg_launch_ms']:7.3f} ms/launch {r['achieved']:7.1f} GB/s")
 except Exception as e:
     print(f"{sys.argv[1]:50s} | FAILED {e}")
 PY
