@@ -53,6 +53,53 @@ def with_normals(s, tangents=False, uv=False):
     return re.sub(r'("point P" \[ )((?:[-\d.]+\s+){71}[-\d.]+) \]', edit, s)
 
 
+TALL = [423, 330, 247, 265, 330, 296, 314, 330, 456, 472, 330, 406, 423, 0, 247, 423, 330, 247, 472, 330, 406, 472, 0, 406,
+        472, 0, 406, 472, 330, 406, 314, 330, 456, 314, 0, 456, 314, 0, 456, 314, 330, 456, 265, 330, 296, 265, 0, 296,
+        265, 0, 296, 265, 330, 296, 423, 330, 247, 423, 0, 247, 423, 0, 247, 472, 0, 406, 314, 0, 456, 265, 0, 296]
+SHORT = [130, 165, 65, 82, 165, 225, 240, 165, 272, 290, 165, 114, 290, 0, 114, 290, 165, 114, 240, 165, 272, 240, 0, 272,
+         130, 0, 65, 130, 165, 65, 290, 165, 114, 290, 0, 114, 82, 0, 225, 82, 165, 225, 130, 165, 65, 130, 0, 65,
+         240, 0, 272, 240, 165, 272, 82, 165, 225, 82, 0, 225, 130, 0, 65, 290, 0, 114, 240, 0, 272, 82, 0, 225]
+
+
+def write_plys():
+    """The PLY fixtures of cornell_ply (committed next to the scene)."""
+    import struct
+    # tall box: ASCII, 6 quads, a comment, an extra per-vertex property and an extra element that must be skipped
+    with open(os.path.join(GOLD, "tall_quads.ply"), "w") as f:
+        f.write("ply\nformat ascii 1.0\ncomment tall Cornell box as quads\nelement vertex 24\nproperty float x\nproperty float y\n"
+                "property float z\nproperty uchar red\nelement face 7\nproperty list uchar int vertex_indices\n"
+                "element edge 1\nproperty int vertex1\nproperty int vertex2\nend_header\n")
+        for i in range(24):
+            f.write(f"{TALL[3 * i]} {TALL[3 * i + 1]} {TALL[3 * i + 2]} {i}\n")
+        for q in range(6):
+            f.write(f"4 {4 * q} {4 * q + 1} {4 * q + 2} {4 * q + 3}\n")
+        f.write("5 0 1 2 3 4\n0 1\n")  # a pentagon (ignored with a warning), then the edge element
+    # short box: binary, normals + uv; one file per endianness, split in two meshes of 3 quads (as 6 triangles) each
+    c = [sum(SHORT[k::3]) / 24 for k in range(3)]
+    for name, end, half in (("short_le.ply", "<", 0), ("short_be.ply", ">", 1)):
+        with open(os.path.join(GOLD, name), "wb") as f:
+            fmt = "binary_little_endian" if end == "<" else "binary_big_endian"
+            f.write((f"ply\nformat {fmt} 1.0\nelement vertex 24\nproperty double x\nproperty float y\nproperty float z\n"
+                     "property float nx\nproperty float ny\nproperty float nz\nproperty float s\nproperty float t\n"
+                     "element face 6\nproperty list uchar ushort vertex_indices\nend_header\n").encode())
+            for i in range(24):
+                x, y, z = SHORT[3 * i:3 * i + 3]
+                f.write(struct.pack(end + "dfffffff", x, y, z, x - c[0], 0.5 * (y - c[1]), z - c[2], 0.01 * x, 0.01 * z))
+            for q in range(3 * half, 3 * half + 3):
+                for tri in ((0, 1, 2), (0, 2, 3)):
+                    f.write(struct.pack(end + "BHHH", 3, *(4 * q + k for k in tri)))
+
+
+def with_ply(s):
+    write_plys()
+    import re
+    boxes = list(re.finditer(r'Shape "trianglemesh"\s+"integer indices" \[ 0 1 2 0 2 3  4 5 6[^\]]*\]\s+"point P" \[[^\]]*\]', s))
+    assert len(boxes) == 2
+    s = s[:boxes[1].start()] + 'Shape "plymesh" "string filename" "tall_quads.ply"' + s[boxes[1].end():]
+    s = s[:boxes[0].start()] + 'Shape "plymesh" "string filename" "short_le.ply"\nShape "plymesh" "string filename" "short_be.ply"' + s[boxes[0].end():]
+    return s
+
+
 SCENES = {
     # plain Cornell, tile-aligned and not
     "cornell_32": cornell(32, 32, 8),
@@ -86,6 +133,9 @@ SCENES = {
     "cornell_lightnormals": cornell(24, 24, 8, world_edit=lambda s: s.replace(
         '"point P" [ 343 548.7 227   343 548.7 332   213 548.7 332   213 548.7 227 ]',
         '"point P" [ 343 548.7 227   343 548.7 332   213 548.7 332   213 548.7 227 ] "normal N" [ 0.2 -1 0  0 -1 0.3  0 1 0  -0.2 -1 -0.1 ]')),
+    # Shape "plymesh" (plymesh.cpp): the tall box as an ASCII PLY of quads, the short box as binary PLYs (little and big
+    # endian, doubles and uchar/ushort index types) with normals and texture coordinates
+    "cornell_ply": cornell(32, 32, 8, world_edit=lambda s: with_ply(s)),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 

@@ -379,7 +379,25 @@ void pbrtAreaLightSource(const std::string &name, const ParamSet &params) {
     graphicsState.areaLightParams = params;
 }
 
-// shapes/triangle.cpp:647-743 CreateTriangleMeshShape + :94-110 CreateTriangleMesh + :60-92 TriangleMesh ctor
+// TriangleMesh ctor, shapes/triangle.cpp:60-92: vertices, normals and tangents go to world space once, here
+std::shared_ptr<TriangleMesh> BuildTriangleMesh(const Transform &o2w, bool reverseOrientation, int nTriangles, const int *indices,
+                                                int nVertices, const Float *P, const Float *S, const Float *N, const Float *UV) {
+    auto mesh = std::make_shared<TriangleMesh>();
+    mesh->nTriangles = nTriangles;
+    mesh->nVertices = nVertices;
+    mesh->vertexIndices.assign(indices, indices + 3 * nTriangles);
+    mesh->reverseOrientation = reverseOrientation;
+    mesh->transformSwapsHandedness = o2w.SwapsHandedness();
+    mesh->p.resize(nVertices);
+    for (int i = 0; i < nVertices; ++i) mesh->p[i] = o2w.Pt(Point3f(P[3 * i], P[3 * i + 1], P[3 * i + 2]));
+    if (UV) mesh->uv.assign(UV, UV + 2 * nVertices);
+    if (N) { mesh->n.resize(nVertices); for (int i = 0; i < nVertices; ++i) mesh->n[i] = o2w.Nrm(Normal3f(N[3 * i], N[3 * i + 1], N[3 * i + 2])); }
+    if (S) { mesh->s.resize(nVertices); for (int i = 0; i < nVertices; ++i) mesh->s[i] = o2w.Vec(Vector3f(S[3 * i], S[3 * i + 1], S[3 * i + 2])); }
+    return mesh;
+}
+std::shared_ptr<TriangleMesh> CreatePLYMesh(const Transform &o2w, bool reverseOrientation, const ParamSet &params);  // plymesh.cpp
+
+// shapes/triangle.cpp:647-743 CreateTriangleMeshShape + :94-110 CreateTriangleMesh
 static std::shared_ptr<TriangleMesh> CreateTriangleMeshShape(const Transform &o2w, bool reverseOrientation, const ParamSet &params) {
     const std::vector<int> *vi = params.FindInt("indices");
     const std::vector<Float> *P = params.FindPoint3f("P");
@@ -407,18 +425,8 @@ static std::shared_ptr<TriangleMesh> CreateTriangleMeshShape(const Transform &o2
         params.FindOneFloat("alpha", 1.f) == 0.f || params.FindOneFloat("shadowalpha", 1.f) == 0.f)
         Error("Alpha-mask textures on triangle meshes are not supported by this build; ignoring.");
     params.FindInt("faceIndices");
-    auto mesh = std::make_shared<TriangleMesh>();
-    mesh->nTriangles = nvi / 3;
-    mesh->nVertices = npi;
-    mesh->vertexIndices.assign(vi->begin(), vi->begin() + 3 * mesh->nTriangles);
-    mesh->reverseOrientation = reverseOrientation;
-    mesh->transformSwapsHandedness = o2w.SwapsHandedness();
-    mesh->p.resize(npi);
-    for (int i = 0; i < npi; ++i) mesh->p[i] = o2w.Pt(Point3f((*P)[3 * i], (*P)[3 * i + 1], (*P)[3 * i + 2]));
-    if (uvs) mesh->uv.assign(uvs->begin(), uvs->begin() + 2 * npi);
-    if (N) { mesh->n.resize(npi); for (int i = 0; i < npi; ++i) mesh->n[i] = o2w.Nrm(Normal3f((*N)[3 * i], (*N)[3 * i + 1], (*N)[3 * i + 2])); }
-    if (S) { mesh->s.resize(npi); for (int i = 0; i < npi; ++i) mesh->s[i] = o2w.Vec(Vector3f((*S)[3 * i], (*S)[3 * i + 1], (*S)[3 * i + 2])); }
-    return mesh;
+    return BuildTriangleMesh(o2w, reverseOrientation, nvi / 3, vi->data(), npi, P->data(), S ? S->data() : nullptr, N ? N->data() : nullptr,
+                             uvs ? uvs->data() : nullptr);
 }
 
 void pbrtShape(const std::string &name, const ParamSet &params) {  // api.cpp:1329-1421
@@ -427,7 +435,8 @@ void pbrtShape(const std::string &name, const ParamSet &params) {  // api.cpp:13
         Warning("Animated transformations are not supported by this build; using the start transform for shape \"%s\".", name.c_str());
     std::shared_ptr<TriangleMesh> mesh;
     if (name == "trianglemesh") mesh = CreateTriangleMeshShape(curTransform[0], graphicsState.reverseOrientation, params);
-    else Error("Shape \"%s\" is outside this build's closed set (trianglemesh); ignoring.", name.c_str());
+    else if (name == "plymesh") mesh = CreatePLYMesh(curTransform[0], graphicsState.reverseOrientation, params);
+    else Error("Shape \"%s\" is outside this build's closed set (trianglemesh, plymesh); ignoring.", name.c_str());
     if (!mesh || mesh->nTriangles == 0) return;
     int mtl = GetMaterialForShape(params);
     params.ReportUnused();

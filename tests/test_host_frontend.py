@@ -91,6 +91,25 @@ def test_errors_are_reported_not_thrown(pkg):
         pkg.HostScene(text="WorldBegin\nWorldEnd\n" if False else "Camera \"perspective\"\n")  # no WorldEnd => nothing to render
 
 
+def test_plymesh_loader(pkg, tmp_path):
+    """Shape "plymesh" (plymesh.cpp:158-290): quads split as (a b c)(d a c), other polygons skipped, bad files reported."""
+    ply = tmp_path / "m.ply"
+    ply.write_text("ply\nformat ascii 1.0\nelement vertex 5\nproperty float x\nproperty float y\nproperty float z\n"
+                   "element face 3\nproperty list uchar int vertex_indices\nend_header\n"
+                   "0 0 0\n1 0 0\n1 1 0\n0 1 0\n2 2 2\n4 0 1 2 3\n3 0 1 4\n5 0 1 2 3 4\n")
+    mini = (MINI % (16, 16, 1)).replace("WorldEnd", f'Shape "plymesh" "string filename" "{ply}"\nWorldEnd')
+    s = pkg.HostScene(text=mini)
+    assert s.desc.n_tris == 3 + 3  # the scene's own 3 + quad (2) + triangle (1); the pentagon is ignored
+    before = pkg.host_lib().pbrt_host_error_count()
+    bad = tmp_path / "bad.ply"
+    bad.write_text("ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\n"
+                   "element face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n0 1 0\n3 0 1 7\n")
+    for fn in (bad, tmp_path / "missing.ply"):
+        s2 = pkg.HostScene(text=(MINI % (16, 16, 1)).replace("WorldEnd", f'Shape "plymesh" "string filename" "{fn}"\nWorldEnd'))
+        assert s2.desc.n_tris == 3  # out-of-range index / unreadable file: reported, shape dropped, scene still loads
+    assert pkg.host_lib().pbrt_host_error_count() >= before + 2
+
+
 def test_empty_world_loads(pkg, oracle):
     s = pkg.HostScene(text='Film "image" "integer xresolution" [ 8 ] "integer yresolution" [ 8 ] "string filename" "e.pfm"\nWorldBegin\nWorldEnd\n')
     assert s.desc.n_tris == 0 and s.desc.n_nodes == 0
