@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 1
+#define PG_ABI_VERSION 2
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -75,13 +75,26 @@ typedef struct PgMaterial {
     int32_t remap_roughness;
 } PgMaterial;
 
-/* One DiffuseAreaLight per emissive triangle (api.cpp:1353-1363,
- * lights/diffuse.cpp:43-87), in scene.lights order.                        */
+/* scene.lights, in declaration order (api.cpp:1308-1327 for LightSource, :1353-1363 for area lights):
+ * one DiffuseAreaLight per emissive triangle (lights/diffuse.cpp:43-87), plus the delta lights
+ * PointLight (lights/point.cpp), SpotLight (lights/spot.cpp) and DistantLight (lights/distant.cpp). */
+typedef enum PgLightType {
+    PG_LIGHT_AREA = 0,   /* DiffuseAreaLight on triangle `prim`           */
+    PG_LIGHT_POINT = 1,
+    PG_LIGHT_SPOT = 2,
+    PG_LIGHT_DISTANT = 3
+} PgLightType;
+
 typedef struct PgLight {
-    int32_t prim;      /* index (BVH order) of the emitting triangle */
-    float L[3];        /* Lemit = L * scale                           */
-    int32_t two_sided;
-    float area;        /* shape->Area() as computed by the host       */
+    int32_t type;      /* PgLightType                                               */
+    int32_t prim;      /* area: index (BVH order) of the emitting triangle, else -1 */
+    float L[3];        /* area: Lemit = L * scale; point/spot: I * scale; distant: L * scale */
+    int32_t two_sided; /* area                                                      */
+    float area;        /* area: shape->Area() as computed by the host               */
+    float pos[3];      /* point/spot: pLight (world); distant: wLight (unit, world) */
+    float w2l[9];      /* spot: upper 3x3 of WorldToLight, row-major (Falloff)      */
+    float cos_total_width, cos_falloff_start; /* spot (spot.cpp:48-49)              */
+    float world_radius; /* distant: Preprocess()'s bounding-sphere radius (distant.h:55-57) */
 } PgLight;
 
 typedef enum PgLightStrategy {

@@ -31,6 +31,12 @@ def cornell(xres, yres, spp, extra_film="", integrator='Integrator "path" "integ
     return s
 
 
+DELTA_POINT = 'AttributeBegin\n  Translate 0 -60 0\n  LightSource "point" "point from" [ 150 500 150 ] "rgb I" [ 40000 60000 90000 ] "rgb scale" [ 2 1 0.5 ]\nAttributeEnd\n'
+DELTA_SPOT = ('AttributeBegin\n  Rotate 10 0 0 1\n  LightSource "spot" "point from" [ 400 480 100 ] "point to" [ 200 0 300 ] "rgb I" [ 300000 250000 200000 ] '
+              '"float coneangle" [ 35 ] "float conedeltaangle" [ 12 ]\nAttributeEnd\n')
+DELTA_DISTANT = 'LightSource "distant" "point from" [ 0.3 1 -0.6 ] "point to" [ 0 0 0 ] "rgb L" [ 0.6 0.7 0.9 ]\n'
+
+
 def with_normals(s, tangents=False, uv=False):
     """Give both Cornell boxes smooth-ish per-vertex normals (outward from the box centre, one of them zero), optionally
     tangents and a uv parameterisation."""
@@ -136,6 +142,12 @@ SCENES = {
     # Shape "plymesh" (plymesh.cpp): the tall box as an ASCII PLY of quads, the short box as binary PLYs (little and big
     # endian, doubles and uchar/ushort index types) with normals and texture coordinates
     "cornell_ply": cornell(32, 32, 8, world_edit=lambda s: with_ply(s)),
+    # delta lights (point.cpp, spot.cpp, distant.cpp) alone and mixed with the area light under every light-sampling strategy
+    "cornell_point": cornell(24, 24, 8, world_edit=lambda s: s.replace("# light\nAttributeBegin", DELTA_POINT + "# light\nAttributeBegin")),
+    "cornell_spot_power": cornell(24, 24, 8, integrator='Integrator "path" "integer maxdepth" [ 4 ] "string lightsamplestrategy" "power"',
+                                  world_edit=lambda s: s.replace("# light\nAttributeBegin", DELTA_SPOT + DELTA_DISTANT + "# light\nAttributeBegin")),
+    "cornell_delta_only": cornell(24, 24, 8, integrator='Integrator "path" "integer maxdepth" [ 3 ] "string lightsamplestrategy" "uniform"',
+                                  world_edit=lambda s: s.replace("  AreaLightSource", "#  AreaLightSource").replace("# light\nAttributeBegin", DELTA_SPOT + DELTA_POINT + DELTA_DISTANT + "# light\nAttributeBegin")),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 

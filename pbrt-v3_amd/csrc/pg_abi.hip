@@ -229,7 +229,9 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         m.roughness = (0.001f < rough) ? rough : 0.001f;  // TrowbridgeReitzDistribution ctor: std::max(Float(0.001), alpha)
     }
     for (int i = 0; i < desc->n_lights; ++i)
-        if (desc->lights[i].prim < 0 || desc->lights[i].prim >= nt) FAIL(PG_ERR_INVALID, "light %d has no emitting triangle", i);
+        if (desc->lights[i].type < PG_LIGHT_AREA || desc->lights[i].type > PG_LIGHT_DISTANT) FAIL(PG_ERR_UNSUPPORTED, "light %d: unknown type %d", i, desc->lights[i].type);
+        else if (desc->lights[i].type == PG_LIGHT_AREA && (desc->lights[i].prim < 0 || desc->lights[i].prim >= nt))
+            FAIL(PG_ERR_INVALID, "light %d has no emitting triangle", i);
     HIP_TRY_S(s->materials.alloc(sizeof(PgMaterial) * (size_t)desc->n_materials));
     if (desc->n_materials) HIP_TRY_S(hipMemcpy(s->materials.p, devMaterials.data(), s->materials.bytes, hipMemcpyHostToDevice));
     HIP_TRY_S(s->lights.alloc(sizeof(PgLight) * (size_t)desc->n_lights));
@@ -290,8 +292,15 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
             for (int i = 0; i < nl; ++i) {
                 if (desc->light_strategy == PG_LIGHTS_POWER) {
                     const PgLight &l = desc->lights[i];
-                    float P[3];
-                    for (int c = 0; c < 3; ++c) { float v = l.L[c]; v *= (float)(l.two_sided ? 2 : 1); v *= l.area; v *= PG_PI; P[c] = v; }
+                    float P[3];  // Light::Power(): diffuse.cpp:64-66, point.cpp:54, spot.cpp:74-76, distant.cpp:62-64
+                    for (int c = 0; c < 3; ++c) {
+                        float v = l.L[c];
+                        if (l.type == PG_LIGHT_POINT) v *= 4 * PG_PI;
+                        else if (l.type == PG_LIGHT_SPOT) { v *= 2; v *= PG_PI; v *= (1 - .5f * (l.cos_falloff_start + l.cos_total_width)); }
+                        else if (l.type == PG_LIGHT_DISTANT) { v *= PG_PI; v *= l.world_radius; v *= l.world_radius; }
+                        else { v *= (float)(l.two_sided ? 2 : 1); v *= l.area; v *= PG_PI; }
+                        P[c] = v;
+                    }
                     func[i] = 0.212671f * P[0] + 0.715160f * P[1] + 0.072169f * P[2];
                 } else func[i] = 1;
             }

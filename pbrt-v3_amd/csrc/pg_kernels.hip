@@ -463,7 +463,33 @@ PG_DEV Spec bsdf_sample_f(const Bsdf &b, V3 woWorld, V3 &wiWorld, float u0, floa
 // Triangle::Sample(u, pdf) + Shape::Sample(ref, u, pdf) + DiffuseAreaLight::Sample_Li
 // (triangle.cpp:582-607, shape.cpp:56-70, diffuse.cpp:68-81).
 struct LightSample { V3 p, n, pError; };
+// SpotLight::Falloff, spot.cpp:62-72
+PG_DEV float spot_falloff(const PgLight &l, V3 w) {
+    V3 wl = normalize(mk(l.w2l[0] * w.x + l.w2l[1] * w.y + l.w2l[2] * w.z, l.w2l[3] * w.x + l.w2l[4] * w.y + l.w2l[5] * w.z,
+                         l.w2l[6] * w.x + l.w2l[7] * w.y + l.w2l[8] * w.z));  // Transform::operator()(Vector3), transform.h:233-239
+    float cosTheta = wl.z;
+    if (cosTheta < l.cos_total_width) return 0;
+    if (cosTheta >= l.cos_falloff_start) return 1;
+    float delta = (cosTheta - l.cos_total_width) / (l.cos_falloff_start - l.cos_total_width);
+    return (delta * delta) * (delta * delta);
+}
 PG_DEV Spec light_sample_li(const DScene &sc, const PgLight &light, V3 refp, float u0, float u1, V3 &wi, float &pdf, LightSample &ls) {
+    if (light.type != PG_LIGHT_AREA) {  // delta lights: point.cpp:43-52, spot.cpp:51-60, distant.cpp:50-60
+        const Spec I = sp3(light.L[0], light.L[1], light.L[2]);
+        const V3 pos = mk(light.pos[0], light.pos[1], light.pos[2]);
+        ls.n = mk(0, 0, 0); ls.pError = mk(0, 0, 0);  // VisibilityTester end point: Interaction(p, time, mediumInterface)
+        pdf = 1.f;
+        if (light.type == PG_LIGHT_DISTANT) {
+            wi = pos;  // wLight
+            ls.p = refp + pos * (2 * light.world_radius);  // pOutside
+            return I;
+        }
+        wi = normalize(pos - refp);
+        ls.p = pos;
+        const float d2 = lensq(pos - refp);
+        if (light.type == PG_LIGHT_SPOT) return (I * spot_falloff(light, -wi)) / d2;
+        return I / d2;
+    }
     float su0 = sqrtf(u0);  // UniformSampleTriangle, sampling.cpp:154-157
     float b0 = 1 - su0, b1 = u1 * su0;
     Tri t = load_tri(sc, light.prim);
@@ -614,17 +640,21 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                                 s_ray[1][0][tid] = make_float4(origin.x, origin.y, origin.z, 1 - PG_SHADOW_EPS);
                                 s_ray[1][1][tid] = make_float4(shD.x, shD.y, shD.z, __int_as_float(slot));
                                 pushShadow = true;
-                                float weight = power_heuristic(1, lightPdf, 1, scatteringPdf);
-                                Spec c = ((f * Li) * weight) / lightPdf;
+                                // delta lights take no MIS weight (integrator.cpp:155-160)
+                                Spec c = light.type != PG_LIGHT_AREA ? (f * Li) / lightPdf
+                                                                     : ((f * Li) * power_heuristic(1, lightPdf, 1, scatteringPdf)) / lightPdf;
                                 pdLight = make_float4(c.r, c.g, c.b, 0);
                             }
                         }
                         // BSDF sampling half of MIS (integrator.cpp:164-212): sample now, while the BSDF is live; the
                         // light.Pdf_Li triangle test runs at the end of the kernel, when little else is (register pressure)
                         V3 wi2 = wi;
-                        float sPdf2;
-                        Spec f2 = bsdf_sample_f(bsdf, is.wo, wi2, uS0, uS1, sPdf2);
-                        f2 = f2 * absdot(wi2, bsdf.ns);
+                        float sPdf2 = 0;
+                        Spec f2 = sp(0);
+                        if (light.type == PG_LIGHT_AREA) {  // integrator.cpp:164: if (!IsDeltaLight(light.flags))
+                            f2 = bsdf_sample_f(bsdf, is.wo, wi2, uS0, uS1, sPdf2);
+                            f2 = f2 * absdot(wi2, bsdf.ns);
+                        }
                         if (!is_black(f2) && sPdf2 > 0) {
                             misCand = true;
                             spawn_ray(is, wi2, misRo);

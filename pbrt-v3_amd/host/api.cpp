@@ -369,9 +369,69 @@ void pbrtNamedMaterial(const std::string &name) {  // api.cpp:1286-1296
     if (iter == graphicsState.namedMaterials.end()) { Error("NamedMaterial \"%s\" unknown.", name.c_str()); return; }
     graphicsState.currentMaterial = iter->second;
 }
-void pbrtLightSource(const std::string &name, const ParamSet &) {
+// geometry.h:1020-1028
+static void CoordinateSystem(const Vector3f &v1, Vector3f *v2, Vector3f *v3) {
+    if (std::abs(v1.x) > std::abs(v1.y)) *v2 = Vector3f(-v1.z, 0, v1.x) / std::sqrt(v1.x * v1.x + v1.z * v1.z);
+    else *v2 = Vector3f(0, v1.z, -v1.y) / std::sqrt(v1.y * v1.y + v1.z * v1.z);
+    *v3 = Cross(v1, *v2);
+}
+static Point3f point3Param(const ParamSet &ps, const std::string &n, Point3f d) {
+    const std::vector<Float> *v = ps.FindPoint3f(n);
+    return v && v->size() >= 3 ? Point3f((*v)[0], (*v)[1], (*v)[2]) : d;
+}
+// MakeLight (api.cpp:690-750): the delta lights PointLight (point.cpp:80-88), SpotLight (spot.cpp:106-127, :42-49) and
+// DistantLight (distant.cpp:96-104, :43-48), appended to scene.lights in declaration order (api.cpp:1308-1327).
+void pbrtLightSource(const std::string &name, const ParamSet &params) {
     VERIFY_WORLD("LightSource");
-    Error("LightSource \"%s\" is outside this build's closed set (diffuse area lights on triangles); ignoring.", name.c_str());
+    if (curTransform.IsAnimated()) Warning("Animated transformations are not supported by this build; using the start transform for the light.");
+    const Transform &light2world = curTransform[0];
+    PgLight l;
+    memset(&l, 0, sizeof(l));
+    l.prim = -1;
+    RGB sc = params.FindOneSpectrum("scale", RGB{{1.f, 1.f, 1.f}});
+    if (name == "point") {
+        RGB I = params.FindOneSpectrum("I", RGB{{1.f, 1.f, 1.f}});
+        Point3f P = point3Param(params, "from", Point3f(0, 0, 0));
+        Transform l2w = Translate(Vector3f(P.x, P.y, P.z)) * light2world;
+        l.type = PG_LIGHT_POINT;
+        for (int i = 0; i < 3; ++i) l.L[i] = I.c[i] * sc.c[i];
+        Point3f pLight = l2w.Pt(Point3f(0, 0, 0));  // point.h:51
+        l.pos[0] = pLight.x; l.pos[1] = pLight.y; l.pos[2] = pLight.z;
+    } else if (name == "spot") {
+        RGB I = params.FindOneSpectrum("I", RGB{{1.f, 1.f, 1.f}});
+        Float coneangle = params.FindOneFloat("coneangle", 30.);
+        Float conedelta = params.FindOneFloat("conedeltaangle", 5.);
+        Point3f from = point3Param(params, "from", Point3f(0, 0, 0));
+        Point3f to = point3Param(params, "to", Point3f(0, 0, 1));
+        Vector3f dir = Normalize(to - from);
+        Vector3f du, dv;
+        CoordinateSystem(dir, &du, &dv);
+        Transform dirToZ = Transform(Matrix4x4(du.x, du.y, du.z, 0., dv.x, dv.y, dv.z, 0., dir.x, dir.y, dir.z, 0., 0, 0, 0, 1.));
+        Transform l2w = light2world * Translate(Vector3f(from.x, from.y, from.z)) * Inverse(dirToZ);
+        l.type = PG_LIGHT_SPOT;
+        for (int i = 0; i < 3; ++i) l.L[i] = I.c[i] * sc.c[i];
+        Point3f pLight = l2w.Pt(Point3f(0, 0, 0));
+        l.pos[0] = pLight.x; l.pos[1] = pLight.y; l.pos[2] = pLight.z;
+        const Matrix4x4 &w2l = l2w.GetInverseMatrix();  // Light::WorldToLight = Inverse(LightToWorld), light.cpp:46-52
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) l.w2l[3 * r + c] = w2l.m[r][c];
+        l.cos_total_width = std::cos(Radians(coneangle));
+        l.cos_falloff_start = std::cos(Radians(coneangle - conedelta));
+    } else if (name == "distant") {
+        RGB L = params.FindOneSpectrum("L", RGB{{1.f, 1.f, 1.f}});
+        Point3f from = point3Param(params, "from", Point3f(0, 0, 0));
+        Point3f to = point3Param(params, "to", Point3f(0, 0, 1));
+        Vector3f dir = from - to;
+        Vector3f wLight = Normalize(light2world.Vec(dir));
+        l.type = PG_LIGHT_DISTANT;
+        for (int i = 0; i < 3; ++i) l.L[i] = L.c[i] * sc.c[i];
+        l.pos[0] = wLight.x; l.pos[1] = wLight.y; l.pos[2] = wLight.z;
+        // world_radius is filled in when the scene is flattened (DistantLight::Preprocess needs the world bound)
+    } else {
+        Error("LightSource \"%s\" is outside this build's closed set (point, spot, distant, and diffuse area lights); ignoring.", name.c_str());
+        return;
+    }
+    params.ReportUnused();
+    renderOptions->lights.push_back(l);
 }
 void pbrtAreaLightSource(const std::string &name, const ParamSet &params) {
     VERIFY_WORLD("AreaLightSource");

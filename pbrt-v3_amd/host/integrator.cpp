@@ -211,6 +211,16 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     }
     flat->materials = scene.materials;
     flat->lights = scene.lights;
+    // Light::Preprocess (scene.h:57-60): DistantLight keeps the world's bounding sphere (distant.h:55-57, geometry.h:803-806)
+    if (!flat->nodes.empty()) {
+        const PgBVHNode &root = flat->nodes[0];
+        Point3f pMin(root.bmin[0], root.bmin[1], root.bmin[2]), pMax(root.bmax[0], root.bmax[1], root.bmax[2]);
+        Point3f center = (pMin + pMax) / 2;
+        bool inside = center.x >= pMin.x && center.x <= pMax.x && center.y >= pMin.y && center.y <= pMax.y && center.z >= pMin.z &&
+                      center.z <= pMax.z;
+        Float radius = inside ? (center - pMax).Length() : 0;
+        for (PgLight &l : flat->lights) if (l.type == PG_LIGHT_DISTANT) l.world_radius = radius;
+    }
     // dimensions a path can consume: 5 camera + per bounce (1+2+2 direct, 2 bsdf, 1 rr); 1000 max (halton.h:71-76)
     int nDims = std::min(1000, 5 + 8 * (maxDepth + 2));
     ComputeRadicalInversePermutations(nDims, &flat->perms, &flat->permSums);
