@@ -63,7 +63,9 @@ typedef struct PgBVHNode {
 typedef enum PgMaterialType {
     PG_MAT_NONE = 0,   /* no material: primitive is a medium boundary (bsdf == nullptr) */
     PG_MAT_MATTE = 1,  /* materials/matte.cpp:45-62   */
-    PG_MAT_PLASTIC = 2 /* materials/plastic.cpp:45-70 */
+    PG_MAT_PLASTIC = 2,/* materials/plastic.cpp:45-70 */
+    PG_MAT_MIRROR = 3, /* materials/mirror.cpp:44-56: SpecularReflection(Kr, FresnelNoOp)              */
+    PG_MAT_GLASS = 4   /* materials/glass.cpp:45-96, smooth only: FresnelSpecular(Kr, Kt, 1, eta)      */
 } PgMaterialType;
 
 typedef struct PgMaterial {
@@ -73,6 +75,9 @@ typedef struct PgMaterial {
     float sigma;     /* matte: Oren-Nayar sigma (degrees); 0 => Lambertian */
     float roughness; /* plastic */
     int32_t remap_roughness;
+    float kr[3];     /* mirror, glass */
+    float kt[3];     /* glass */
+    float eta;       /* glass: index of refraction */
 } PgMaterial;
 
 /* scene.lights, in declaration order (api.cpp:1308-1327 for LightSource, :1353-1363 for area lights):

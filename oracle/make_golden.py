@@ -148,6 +148,14 @@ SCENES = {
                                   world_edit=lambda s: s.replace("# light\nAttributeBegin", DELTA_SPOT + DELTA_DISTANT + "# light\nAttributeBegin")),
     "cornell_delta_only": cornell(24, 24, 8, integrator='Integrator "path" "integer maxdepth" [ 3 ] "string lightsamplestrategy" "uniform"',
                                   world_edit=lambda s: s.replace("  AreaLightSource", "#  AreaLightSource").replace("# light\nAttributeBegin", DELTA_SPOT + DELTA_POINT + DELTA_DISTANT + "# light\nAttributeBegin")),
+    # specular BSDFs: mirror (SpecularReflection) on the tall box, glass (FresnelSpecular: reflection + refraction, etaScale in
+    # the Russian roulette, emission seen through specular bounces) on the short box; deep paths
+    "cornell_mirror_glass": cornell(32, 32, 16, integrator='Integrator "path" "integer maxdepth" [ 9 ] "float rrthreshold" [ 0.8 ]',
+                                    world_edit=lambda s: s.replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\nMaterial "glass" "float index" [ 1.45 ] "rgb Kt" [ 0.9 1 0.9 ]')
+                                    .replace("# tall box", 'Material "mirror" "rgb Kr" [ 0.8 0.8 0.9 ]\n# tall box')),
+    "cornell_glass_eta": cornell(24, 24, 8, integrator='Integrator "path" "integer maxdepth" [ 6 ]',
+                                 world_edit=lambda s: s.replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\nMaterial "glass" "float eta" [ 2.2 ] "rgb Kr" [ 0 0 0 ]')
+                                 .replace("# tall box", 'Material "mirror" "rgb Kr" [ 0 0 0 ]\n# tall box')),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 

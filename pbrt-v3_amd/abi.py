@@ -9,7 +9,7 @@ PG_ABI_VERSION = 2
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
 PG_LIGHTS_UNIFORM, PG_LIGHTS_POWER, PG_LIGHTS_SPATIAL = 0, 1, 2
-PG_MAT_NONE, PG_MAT_MATTE, PG_MAT_PLASTIC = 0, 1, 2
+PG_MAT_NONE, PG_MAT_MATTE, PG_MAT_PLASTIC, PG_MAT_MIRROR, PG_MAT_GLASS = 0, 1, 2, 3, 4
 PG_LIGHT_AREA, PG_LIGHT_POINT, PG_LIGHT_SPOT, PG_LIGHT_DISTANT = 0, 1, 2, 3
 PG_TRI_FLIP_NORMAL, PG_TRI_REVERSE_ORIENTATION, PG_TRI_HAS_N, PG_TRI_HAS_UV, PG_TRI_HAS_S = 1, 2, 4, 8, 16
 
@@ -21,7 +21,8 @@ class PgBVHNode(C.Structure):
 
 class PgMaterial(C.Structure):
     _fields_ = [("type", C.c_int32), ("kd", C.c_float * 3), ("ks", C.c_float * 3), ("sigma", C.c_float),
-                ("roughness", C.c_float), ("remap_roughness", C.c_int32)]
+                ("roughness", C.c_float), ("remap_roughness", C.c_int32), ("kr", C.c_float * 3), ("kt", C.c_float * 3),
+                ("eta", C.c_float)]
 
 
 class PgLight(C.Structure):

@@ -210,8 +210,8 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     for (int i = 0; i < desc->n_materials; ++i) {
         const PgMaterial &m = desc->materials[i];
         if (m.type == PG_MAT_NONE) s->hasNullMaterial = true;
-        else if (m.type != PG_MAT_MATTE && m.type != PG_MAT_PLASTIC)
-            FAIL(PG_ERR_UNSUPPORTED, "material %d: type %d is outside this build's closed set (matte, plastic)", i, m.type);
+        else if (m.type < PG_MAT_MATTE || m.type > PG_MAT_GLASS)
+            FAIL(PG_ERR_UNSUPPORTED, "material %d: type %d is outside this build's closed set (matte, plastic, mirror, glass)", i, m.type);
         else if (m.type == PG_MAT_MATTE && m.sigma != 0)
             FAIL(PG_ERR_UNSUPPORTED, "material %d: Oren-Nayar (sigma != 0) is outside this build's closed set", i);
     }

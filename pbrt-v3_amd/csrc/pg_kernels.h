@@ -62,7 +62,7 @@ __host__ __device__ inline int queue_region_count(const RayQueue &q, int r) { re
 struct PathState {
     float4 *L;      // (L.rgb, pFilm.x)
     float4 *beta;   // (beta.rgb, pFilm.y)
-    int4 *meta;     // (haltonIndexLo, haltonIndexHi, dimension, bounces | flags<<16)
+    int4 *meta;     // (haltonIndexLo, haltonIndexHi, etaScale bits, dimension<<20 | flags | bounces)
     // pending direct-lighting estimate of the current bounce (EstimateDirect, integrator.cpp:108-215)
     float4 *pdLight;  // (f*Li*weight/lightPdf rgb, light-selection pdf)
     float4 *pdMis;    // (f*|wi.n| rgb, scatteringPdf)

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_generate(DScene sc, RenderParams r
         xform_ray(rd.camera_to_world, o, d, tMax);
         st.L[slot] = make_float4(0, 0, 0, pFilmX);
         st.beta[slot] = make_float4(1, 1, 1, pFilmY);
-        st.meta[slot] = make_int4((int)(uint32_t)index, (int)(uint32_t)(index >> 32), 5, 0);
+        st.meta[slot] = make_int4((int)(uint32_t)index, (int)(uint32_t)(index >> 32), __float_as_int(1.f), 5 << 20);
     } else if (slot < rp.capacity) {
         st.L[slot] = make_float4(0, 0, 0, 0);
         st.meta[slot] = make_int4(0, 0, 0, PG_META_DONE | 0x40000);  // 0x40000: slot holds no sample
@@ -297,7 +297,14 @@ PG_DEV V3 hit_normal(const DScene &sc, int prim, const Tri &t, float b0, float b
 
 // BSDF: LambertianReflection and/or MicrofacetReflection(TrowbridgeReitz, FresnelDielectric(1.5, 1)) lobes in the order
 // the materials add them (matte.cpp:45-62, plastic.cpp:45-70); reflection.h:164-213, reflection.cpp:680-796.
-struct Bsdf { V3 ns, ng, ss, ts; Spec R, Ks; float alpha; int nBxDFs; bool hasDiff, hasSpec; };
+struct Bsdf {
+    V3 ns, ng, ss, ts; Spec R, Ks; float alpha; int nBxDFs; bool hasDiff, hasSpec;
+    int specular;  // 0; 1 = SpecularReflection(Kr, FresnelNoOp) (mirror.cpp:44-56); 2 = FresnelSpecular(Kr, Kt, 1, eta) (glass.cpp:45-65)
+    Spec Kr, Kt; float eta;
+};
+#define PG_BSDF_REFLECTION 1
+#define PG_BSDF_TRANSMISSION 2
+#define PG_BSDF_SPECULAR 16
 PG_DEV V3 world_to_local(const Bsdf &b, V3 v) { return mk(dot(v, b.ss), dot(v, b.ts), dot(v, b.ns)); }
 PG_DEV V3 local_to_world(const Bsdf &b, V3 v) {
     return mk(b.ss.x * v.x + b.ts.x * v.y + b.ns.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ns.y * v.z,
@@ -433,6 +440,49 @@ PG_DEV float bsdf_pdf(const Bsdf &b, V3 woW, V3 wiW) {  // reflection.cpp:781-79
     if (b.hasDiff) pdf += lambert_pdf(wo, wi);
     if (b.hasSpec) pdf += mf_pdf(b, wo, wi);
     return pdf / b.nBxDFs;
+}
+// A BSDF whose only lobe is specular: SpecularReflection::Sample_f (reflection.cpp:136-143) or FresnelSpecular::Sample_f
+// (:487-521) inside BSDF::Sample_f (:714-779).
+PG_DEV Spec bsdf_sample_specular(const Bsdf &b, V3 woWorld, V3 &wiWorld, float u0, float &pdf, int &sampledType) {
+    V3 wo = world_to_local(b, woWorld), wi;
+    Spec f;
+    pdf = 0; sampledType = 0;
+    if (wo.z == 0) return sp(0);
+    if (b.specular == 1) {
+        wi = mk(-wo.x, -wo.y, wo.z);
+        pdf = 1;
+        f = (sp(1.f) * b.Kr) / fabsf(wi.z);
+        sampledType = PG_BSDF_SPECULAR | PG_BSDF_REFLECTION;
+    } else {
+        const float ur = pmin(u0 * 1 - 0, PG_ONE_MINUS_EPS);
+        const float F = fr_dielectric(wo.z, 1.f, b.eta);
+        if (ur < F) {
+            wi = mk(-wo.x, -wo.y, wo.z);
+            sampledType = PG_BSDF_SPECULAR | PG_BSDF_REFLECTION;
+            pdf = F;
+            f = (b.Kr * F) / fabsf(wi.z);
+        } else {
+            const bool entering = wo.z > 0;
+            const float etaI = entering ? 1.f : b.eta, etaT = entering ? b.eta : 1.f;
+            const V3 n = (wo.z < 0.f) ? mk(0, 0, -1) : mk(0, 0, 1);  // Faceforward(Normal3f(0, 0, 1), wo)
+            const float eta = etaI / etaT;
+            // Refract, reflection.h:97-109
+            const float cosThetaI = dot(n, wo);
+            const float sin2ThetaI = pmax(0.f, 1 - cosThetaI * cosThetaI);
+            const float sin2ThetaT = eta * eta * sin2ThetaI;
+            if (sin2ThetaT >= 1) return sp(0);
+            const float cosThetaT = sqrtf(1 - sin2ThetaT);
+            wi = (-wo) * eta + n * (eta * cosThetaI - cosThetaT);
+            Spec ft = b.Kt * (1 - F);
+            ft = ft * ((etaI * etaI) / (etaT * etaT));  // TransportMode::Radiance
+            sampledType = PG_BSDF_SPECULAR | PG_BSDF_TRANSMISSION;
+            pdf = 1 - F;
+            f = ft / fabsf(wi.z);
+        }
+    }
+    if (pdf == 0) { sampledType = 0; return sp(0); }
+    wiWorld = local_to_world(b, wi);
+    return f;
 }
 PG_DEV Spec bsdf_sample_f(const Bsdf &b, V3 woWorld, V3 &wiWorld, float u0, float u1, float &pdf) {  // reflection.cpp:714-779
     int matchingComps = b.nBxDFs;
@@ -577,7 +627,8 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
         int4 meta = st.meta[slot];
         Spec L = sp3(L4.x, L4.y, L4.z), beta = sp3(B4.x, B4.y, B4.z);
         const uint64_t index = (uint64_t)(uint32_t)meta.x | ((uint64_t)(uint32_t)meta.y << 32);
-        int dim = meta.z;
+        int dim = (int)((uint32_t)meta.w >> 20);
+        float etaScale = __int_as_float(meta.z);  // path.cpp:79
         int bounces = meta.w & 0xffff;
         const bool specularBounce = (meta.w & PG_META_SPECULAR) != 0;
         const bool found = prim >= 0;
@@ -614,8 +665,17 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                 bsdf.hasSpec = m.type == PG_MAT_PLASTIC && !is_black(bsdf.Ks);
                 bsdf.alpha = m.roughness;
                 bsdf.nBxDFs = (bsdf.hasDiff ? 1 : 0) + (bsdf.hasSpec ? 1 : 0);
+                bsdf.specular = 0; bsdf.eta = 1;
+                bsdf.Kr = sp3(m.kr[0] < 0 ? 0 : m.kr[0], m.kr[1] < 0 ? 0 : m.kr[1], m.kr[2] < 0 ? 0 : m.kr[2]);
+                bsdf.Kt = sp3(m.kt[0] < 0 ? 0 : m.kt[0], m.kt[1] < 0 ? 0 : m.kt[1], m.kt[2] < 0 ? 0 : m.kt[2]);
+                if (m.type == PG_MAT_MIRROR || m.type == PG_MAT_GLASS) {  // mirror.cpp:44-56, glass.cpp:45-65 (smooth)
+                    bsdf.hasDiff = false;
+                    if (m.type == PG_MAT_MIRROR) bsdf.specular = is_black(bsdf.Kr) ? 0 : 1;
+                    else { bsdf.eta = m.eta; bsdf.specular = (is_black(bsdf.Kr) && is_black(bsdf.Kt)) ? 0 : 2; }
+                    bsdf.nBxDFs = bsdf.specular ? 1 : 0;
+                }
                 // ---- direct lighting: UniformSampleOneLight (integrator.cpp:85-106) + EstimateDirect set-up
-                if (bsdf.nBxDFs > 0 && sc.nLights > 0) {
+                if (bsdf.nBxDFs > 0 && !bsdf.specular && sc.nLights > 0) {  // path.cpp:119: only with non-specular lobes
                     const float *tab = light_distribution(sc, is.p);
                     float lightSelPdf;
                     lightNum = sample_discrete(tab, sc.nLights, halton_sample(sc, rd, index, dim++), lightSelPdf);
@@ -672,17 +732,21 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                 float pdf;
                 float u0 = halton_sample(sc, rd, index, dim), u1 = halton_sample(sc, rd, index, dim + 1);
                 dim += 2;
-                Spec f = bsdf_sample_f(bsdf, wo, wi, u0, u1, pdf);
+                int sampledType = 0;
+                Spec f = bsdf.specular ? bsdf_sample_specular(bsdf, wo, wi, u0, pdf, sampledType) : bsdf_sample_f(bsdf, wo, wi, u0, u1, pdf);
                 if (!(is_black(f) || pdf == 0.f)) {
                     beta = beta * ((f * absdot(wi, bsdf.ns)) / pdf);
+                    if (sampledType & PG_BSDF_SPECULAR) newFlags |= PG_META_SPECULAR;  // path.cpp:142
+                    if ((sampledType & PG_BSDF_SPECULAR) && (sampledType & PG_BSDF_TRANSMISSION))  // path.cpp:143-149
+                        etaScale *= (dot(wo, is.n) > 0) ? (bsdf.eta * bsdf.eta) : 1 / (bsdf.eta * bsdf.eta);
                     V3 nextO;
                     spawn_ray(is, wi, nextO);
                     s_ray[0][0][tid] = make_float4(nextO.x, nextO.y, nextO.z, PG_INF);
                     s_ray[0][1][tid] = make_float4(wi.x, wi.y, wi.z, __int_as_float(slot));
                     nextBin = (wi.x < 0 ? 1 : 0) | (wi.y < 0 ? 2 : 0) | (wi.z < 0 ? 4 : 0);
                     pushNext = true;
-                    // Russian roulette, path.cpp:176-184 (etaScale == 1: no transmission in the closed set)
-                    Spec rrBeta = beta * 1.f;
+                    // Russian roulette, path.cpp:176-184
+                    Spec rrBeta = beta * etaScale;
                     if (max_component(rrBeta) < rd.rr_threshold && bounces > 3) {
                         float qq = pmax(.05f, 1 - max_component(rrBeta));
                         if (halton_sample(sc, rd, index, dim++) < qq) pushNext = false;
@@ -694,7 +758,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
         }
         st.L[slot] = make_float4(L.r, L.g, L.b, L4.w);
         st.beta[slot] = make_float4(beta.r, beta.g, beta.b, B4.w);
-        st.meta[slot] = make_int4(meta.x, meta.y, dim, bounces | newFlags);
+        st.meta[slot] = make_int4(meta.x, meta.y, __float_as_int(etaScale), (dim << 20) | bounces | newFlags);
     }
     if (misCand) {
         // light.Pdf_Li -> Shape::Pdf(ref, wi): intersect the light's own triangle (shape.cpp:72-87, diffuse.cpp:83-87)

@@ -171,8 +171,22 @@ static int MakeMaterial(const std::string &name, const ParamSet &geom, const Par
         m.roughness = floatParam(geom, mat, "roughness", .1f, graphicsState);
         bool remap = geom.FindOneBool("remaproughness", mat.FindOneBool("remaproughness", true));
         m.remap_roughness = remap ? 1 : 0;
+    } else if (name == "mirror") {  // mirror.cpp:58-64
+        m.type = PG_MAT_MIRROR;
+        RGB kr = spectrumParam(geom, mat, "Kr", RGB{{0.9f, 0.9f, 0.9f}}, graphicsState);
+        for (int i = 0; i < 3; ++i) m.kr[i] = kr.c[i];
+    } else if (name == "glass") {  // glass.cpp:98-115
+        m.type = PG_MAT_GLASS;
+        RGB kr = spectrumParam(geom, mat, "Kr", RGB{{1.f, 1.f, 1.f}}, graphicsState);
+        RGB kt = spectrumParam(geom, mat, "Kt", RGB{{1.f, 1.f, 1.f}}, graphicsState);
+        for (int i = 0; i < 3; ++i) { m.kr[i] = kr.c[i]; m.kt[i] = kt.c[i]; }
+        bool hasEta = geom.FindFloat("eta") || mat.FindFloat("eta") || !geom.FindTexture("eta").empty() || !mat.FindTexture("eta").empty();
+        m.eta = hasEta ? floatParam(geom, mat, "eta", 1.5f, graphicsState) : floatParam(geom, mat, "index", 1.5f, graphicsState);
+        Float ur = floatParam(geom, mat, "uroughness", 0.f, graphicsState), vr = floatParam(geom, mat, "vroughness", 0.f, graphicsState);
+        geom.FindOneBool("remaproughness", mat.FindOneBool("remaproughness", true));
+        if (ur != 0 || vr != 0) Error("Rough glass (microfacet transmission) is not supported by this build; using smooth glass.");
     } else {
-        Error("Material \"%s\" is outside this build's closed set (matte, plastic); using matte.", name.c_str());
+        Error("Material \"%s\" is outside this build's closed set (matte, plastic, mirror, glass); using matte.", name.c_str());
         m.type = PG_MAT_MATTE;
         m.kd[0] = m.kd[1] = m.kd[2] = 0.5f;
     }
