@@ -122,7 +122,7 @@ def main():
     n_tiles = gs.tile_count(rd)
     max_tiles = gs.tile_count(scene.render_desc(0, world))  # rank 0 owns the most
     from pbrt_v3_amd import distributed as pdist
-    film, strays, nstrays, max_strays = pdist.shard_buffers(max_tiles, dev)
+    film, strays, nstrays, max_strays = pdist.shard_buffers(max_tiles, dev, rd.tile_pixels)
     gathered = [pdist.gather_lists(film, strays, nstrays) if world > 1 else None]
 
     def step():

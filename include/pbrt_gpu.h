@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 2
+#define PG_ABI_VERSION 3
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -150,7 +150,17 @@ typedef struct PgRenderDesc {
     int32_t full_res[2];
     int32_t cropped_pixel_bounds[4]; /* x0,y0,x1,y1 */
     int32_t sample_bounds[4];
-    float filter_radius[2];          /* box filter only in this round */
+    float filter_radius[2];          /* Filter::radius (filter.h:50-66)                                        */
+    /* Film's 16x16 filterTable (film.cpp:68-77), filled by the host for box / gaussian / mitchell / sinc / triangle.
+     * filter_general = 0: box filter with radius <= 0.5 -- every sample lands in its own pixel (a rare second pixel
+     * is reported as a PgStraySample) and a tile's film block is its 16x16 pixels.
+     * filter_general = 1: any other filter -- a tile's film block is its FilmTile pixel bounds (film.cpp:95-106)
+     * before clipping: (16 + halo[0] + halo[2]) x (16 + halo[1] + halo[3]) entries, row-major, entry (0,0) = pixel
+     * (tile.x0 - halo[0], tile.y0 - halo[1]); no stray samples are produced.                                     */
+    int32_t filter_general;
+    int32_t tile_halo[4];            /* x-low, y-low, x-high, y-high                                            */
+    int32_t tile_pixels;             /* PgFilmPixel entries per tile: 256, or the block size above              */
+    float filter_table[256];
     float film_scale;
     float max_sample_luminance;
     /* sampler: HaltonSampler (samplers/halton.cpp:65-127) */
@@ -208,12 +218,12 @@ const char *pg_last_error(void);
 int pg_scene_create(const PgSceneDesc *desc, PgScene **out);
 void pg_scene_destroy(PgScene *scene);
 
-/* Number of 16x16 tiles this (tile_first, tile_step) shard owns, and the
- * number of PgFilmPixel entries (256 per tile) pg_render writes.             */
+/* Number of 16x16 tiles this (tile_first, tile_step) shard owns; pg_render
+ * writes desc->tile_pixels PgFilmPixel entries per tile.                     */
 int pg_render_tile_count(const PgRenderDesc *desc);
 
-/* SamplerIntegrator::Render for the shard in desc: fills film[256*tiles]
- * (tile-major, row-major inside the 16x16 tile, zero outside the image) and
+/* SamplerIntegrator::Render for the shard in desc: fills film[tile_pixels*tiles]
+ * (tile-major, row-major inside the tile's block, zero outside the image) and
  * up to max_strays stray samples; *n_strays receives the count.
  * film/strays live in `mem` memory; `stream` is a hipStream_t (NULL = default). */
 int pg_render(PgScene *scene, const PgRenderDesc *desc, PgFilmPixel *film,

@@ -156,6 +156,12 @@ SCENES = {
     "cornell_glass_eta": cornell(24, 24, 8, integrator='Integrator "path" "integer maxdepth" [ 6 ]',
                                  world_edit=lambda s: s.replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\nMaterial "glass" "float eta" [ 2.2 ] "rgb Kr" [ 0 0 0 ]')
                                  .replace("# tall box", 'Material "mirror" "rgb Kr" [ 0 0 0 ]\n# tall box')),
+    # pixel filters other than the default box (filters/*.cpp, FilmTile::AddSample's table path, overlapping tile merges)
+    "filter_gaussian": cornell(40, 24, 4).replace('PixelFilter "box"', 'PixelFilter "gaussian"'),
+    "filter_mitchell_crop": cornell(48, 48, 4, extra_film='"float cropwindow" [ 0.2 0.75 0.3 0.9 ]').replace('PixelFilter "box"', 'PixelFilter "mitchell" "float xwidth" [ 1.5 ] "float ywidth" [ 2.5 ] "float B" [ 0.2 ]'),
+    "filter_sinc": cornell(24, 24, 4).replace('PixelFilter "box"', 'PixelFilter "sinc" "float xwidth" [ 3 ] "float ywidth" [ 3 ]'),
+    "filter_triangle_box": cornell(24, 24, 4).replace('PixelFilter "box"', 'PixelFilter "triangle" "float xwidth" [ 0.5 ] "float ywidth" [ 1 ]'),
+    "filter_widebox": cornell(24, 24, 4).replace('PixelFilter "box"', 'PixelFilter "box" "float xwidth" [ 1.25 ] "float ywidth" [ 0.75 ]'),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 
@@ -163,7 +169,9 @@ SCENES = {
 def run(name, scene_path, outdir=GOLD):
     ref = os.path.join(HERE, "_ref", "pbrt_oracle")
     out = os.path.join(outdir, name + ".pfm")
-    txt = subprocess.run([ref, "--nthreads", "4", "--outfile", out, scene_path], capture_output=True, text=True, check=True).stdout
+    # one thread for the wide-filter scenes: overlapping FilmTiles are then merged in tile order (film.cpp:117-130)
+    nthreads = "1" if name.startswith("filter_") else "4"
+    txt = subprocess.run([ref, "--nthreads", nthreads, "--outfile", out, scene_path], capture_output=True, text=True, check=True).stdout
     g = lambda pat: int(re.search(pat, txt).group(1))
     stats = {"camera_rays": g(r"Camera rays traced\s+(\d+)"),
              "closest_rays": g(r"Regular ray intersection tests\s+(\d+)"),

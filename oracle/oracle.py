@@ -63,7 +63,7 @@ def render(desc, rd, max_strays=None):
     n = L.oracle_render_tile_count(C.byref(rd))
     if max_strays is None:
         max_strays = n * 256 // 8 + 1024
-    film = np.zeros(n * 256, pkg.FILM_PIXEL_DTYPE)
+    film = np.zeros(n * rd.tile_pixels, pkg.FILM_PIXEL_DTYPE)
     strays = np.zeros(max_strays, pkg.STRAY_DTYPE)
     ns = C.c_int32(0)
     cn = pkg.abi.PgCounters()

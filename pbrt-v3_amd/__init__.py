@@ -170,7 +170,7 @@ class GpuScene:
         n = self.tile_count(rd)
         if max_strays is None:
             max_strays = n * 256 // 8 + 1024
-        film = np.zeros(n * 256, FILM_PIXEL_DTYPE)
+        film = np.zeros(n * rd.tile_pixels, FILM_PIXEL_DTYPE)
         strays = np.zeros(max_strays, STRAY_DTYPE)
         ns = C.c_int32(0)
         _check(gpu_lib().pg_render(self._h, C.byref(rd), film.ctypes.data, strays.ctypes.data, max_strays, C.byref(ns),

@@ -5,7 +5,7 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 2
+PG_ABI_VERSION = 3
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
 PG_LIGHTS_UNIFORM, PG_LIGHTS_POWER, PG_LIGHTS_SPATIAL = 0, 1, 2
@@ -50,7 +50,8 @@ class PgRenderDesc(C.Structure):
                 ("lens_radius", C.c_float), ("focal_distance", C.c_float),
                 ("shutter_open", C.c_float), ("shutter_close", C.c_float),
                 ("full_res", C.c_int32 * 2), ("cropped_pixel_bounds", C.c_int32 * 4), ("sample_bounds", C.c_int32 * 4),
-                ("filter_radius", C.c_float * 2), ("film_scale", C.c_float), ("max_sample_luminance", C.c_float),
+                ("filter_radius", C.c_float * 2), ("filter_general", C.c_int32), ("tile_halo", C.c_int32 * 4),
+                ("tile_pixels", C.c_int32), ("filter_table", C.c_float * 256), ("film_scale", C.c_float), ("max_sample_luminance", C.c_float),
                 ("spp", C.c_int32), ("base_scales", C.c_int32 * 2), ("base_exponents", C.c_int32 * 2),
                 ("sample_stride", C.c_int32), ("mult_inverse", C.c_int32 * 2), ("sample_at_pixel_center", C.c_int32),
                 ("max_depth", C.c_int32), ("rr_threshold", C.c_float), ("pixel_bounds", C.c_int32 * 4),

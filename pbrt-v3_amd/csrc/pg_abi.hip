@@ -401,8 +401,11 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
               int mem, void *streamPtr) {
     if (!s || !rd || !film || !nStrays || (maxStrays > 0 && !strays)) return setError(PG_ERR_INVALID, "pg_render: null argument");
     if (rd->abi_version != PG_ABI_VERSION) return setError(PG_ERR_INVALID, "ABI version %d, expected %d", rd->abi_version, PG_ABI_VERSION);
-    if (rd->filter_radius[0] > 0.5f || rd->filter_radius[1] > 0.5f || rd->filter_radius[0] <= 0 || rd->filter_radius[1] <= 0)
-        return setError(PG_ERR_UNSUPPORTED, "pixel filters wider than 0.5 px are outside this build's closed set (box, radius <= 0.5)");
+    if (rd->filter_radius[0] <= 0 || rd->filter_radius[1] <= 0) return setError(PG_ERR_INVALID, "pg_render: filter radius must be positive");
+    if (!rd->filter_general && (rd->filter_radius[0] > 0.5f || rd->filter_radius[1] > 0.5f || rd->tile_pixels != 256))
+        return setError(PG_ERR_INVALID, "pg_render: filter_general = 0 is the box filter of radius <= 0.5 with 256-entry tile blocks");
+    if (rd->filter_general && rd->tile_pixels != (16 + rd->tile_halo[0] + rd->tile_halo[2]) * (16 + rd->tile_halo[1] + rd->tile_halo[3]))
+        return setError(PG_ERR_INVALID, "pg_render: tile_pixels does not match tile_halo");
     if (rd->spp <= 0 || rd->max_depth < 0 || rd->tile_step <= 0) return setError(PG_ERR_INVALID, "pg_render: bad spp/maxdepth/tile_step");
     if (5 + 8 * (rd->max_depth + 1) > s->d.nPermDims && s->d.nPermDims < 1000)
         return setError(PG_ERR_INVALID, "Halton table has %d dimensions; maxdepth %d needs %d", s->d.nPermDims, rd->max_depth, 5 + 8 * (rd->max_depth + 1));
@@ -419,7 +422,7 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
     PgFilmPixel *dFilm = film;
     PgStraySample *dStrays = strays;
     int *dNStrays = nStrays;
-    const size_t filmBytes = sizeof(PgFilmPixel) * 256 * (size_t)nLocalTiles;
+    const size_t filmBytes = sizeof(PgFilmPixel) * (size_t)rd->tile_pixels * (size_t)nLocalTiles;
     if (mem == PG_MEM_HOST) {
         HIP_TRY(s->filmDev.alloc(filmBytes));
         HIP_TRY(s->straysDev.alloc(sizeof(PgStraySample) * (size_t)(maxStrays > 0 ? maxStrays : 1)));
@@ -437,9 +440,15 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
     if (const char *e = getenv("PG_BATCH_PATHS")) { long v = atol(e); if (v >= 256) budget = (size_t)v; }
     int sPerBatch = rd->spp, tilesPerBatch = nLocalTiles;
     if ((size_t)tilesPerBatch * 256 * sPerBatch > budget) {
-        // prefer all tiles with fewer samples (keeps primary rays coherent and every pixel busy)
-        sPerBatch = (int)(budget / ((size_t)tilesPerBatch * 256));
-        if (sPerBatch < 1) { sPerBatch = 1; tilesPerBatch = (int)(budget / 256); if (tilesPerBatch < 1) tilesPerBatch = 1; }
+        if (rd->filter_general) {
+            // the gathering film kernel needs all samples of a tile in one batch (reference summation order): split by tiles
+            tilesPerBatch = (int)(budget / ((size_t)256 * sPerBatch));
+            if (tilesPerBatch < 1) tilesPerBatch = 1;
+        } else {
+            // prefer all tiles with fewer samples (keeps primary rays coherent and every pixel busy)
+            sPerBatch = (int)(budget / ((size_t)tilesPerBatch * 256));
+            if (sPerBatch < 1) { sPerBatch = 1; tilesPerBatch = (int)(budget / 256); if (tilesPerBatch < 1) tilesPerBatch = 1; }
+        }
     }
     const int capacity = tilesPerBatch * 256 * sPerBatch;
     int st = ensureWorkBuffers(s, capacity);
@@ -534,7 +543,8 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
                     if (queueTotal(blk.data(), cur) == 0) { ++iters; break; }
                 }
             }
-            launch_film(rp, ps, dFilm, dStrays, maxStrays, dNStrays, stream);
+            if (rd->filter_general) launch_film_general(rp, ps, dFilm, stream);
+            else launch_film(rp, ps, dFilm, dStrays, maxStrays, dNStrays, stream);
             hostCounts.resize(4 * QSTRIDE * (size_t)iters);
             HIP_TRY(hipMemcpyAsync(hostCounts.data(), countLog.p, sizeof(int) * 4 * QSTRIDE * (size_t)iters, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));

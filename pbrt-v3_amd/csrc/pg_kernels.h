@@ -102,5 +102,6 @@ void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQue
 void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis, const int *occluded, const float4 *misHits, hipStream_t s);
 void launch_film(const RenderParams &rp, PathState st, PgFilmPixel *film, PgStraySample *strays, int maxStrays, int *nStrays,
                  hipStream_t s);
+void launch_film_general(const RenderParams &rp, PathState st, PgFilmPixel *film, hipStream_t s);
 void launch_light_tables(const DScene &sc, float *table, int nDistributions, hipStream_t s);
 #endif

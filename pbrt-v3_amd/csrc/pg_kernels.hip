@@ -893,6 +893,68 @@ __global__ __launch_bounds__(PG_BLOCK) void k_film(RenderParams rp, PathState st
     }
     fp->rgb[0] = r; fp->rgb[1] = g; fp->rgb[2] = b; fp->weight = w;
 }
+// ---------------------------------------------------------------------------------------------------------------
+// Film for every other pixel filter (gaussian, mitchell, sinc, triangle, wide box): FilmTile::AddSample with the 16x16
+// filter table (film.h:121-161).  A sample now lands in every pixel within the filter radius, including pixels owned by
+// neighbouring tiles, so a tile's block is its FilmTile pixel bounds (16 + halo), and the kernel GATHERS: one lane per
+// block pixel walks the tile's samples in the reference's order (pixels row-major, samples in order) and adds those whose
+// footprint covers it.  Deterministic, no atomics, and a pixel's tile-local sum has the reference's summation order;
+// the host merges the overlapping blocks in tile order (Film::MergeFilmTile).  All samples of a tile are in one batch.
+__global__ __launch_bounds__(PG_BLOCK) void k_film_general(RenderParams rp, PathState st, PgFilmPixel *film) {
+    const int tileInBatch = blockIdx.x;
+    const PgRenderDesc &rd = rp.rd;
+    const int local = rp.tileLocal0 + tileInBatch;
+    const int t = rd.tile_first + local * rd.tile_step;
+    const int tx = t % rp.nTilesX, ty = t / rp.nTilesX;
+    const int x0 = rd.sample_bounds[0] + tx * 16, y0 = rd.sample_bounds[1] + ty * 16;
+    const int x1 = min(x0 + 16, rd.sample_bounds[2]), y1 = min(y0 + 16, rd.sample_bounds[3]);
+    const float frx = rd.filter_radius[0], fry = rd.filter_radius[1];
+    const float invRx = 1 / frx, invRy = 1 / fry;  // FilmTile::invFilterRadius, film.h:113
+    // FilmTile pixel bounds, film.cpp:95-106
+    const int tp0x = max((int)ceilf((float)x0 - 0.5f - frx), rd.cropped_pixel_bounds[0]);
+    const int tp0y = max((int)ceilf((float)y0 - 0.5f - fry), rd.cropped_pixel_bounds[1]);
+    const int tp1x = min((int)floorf((float)x1 - 0.5f + frx) + 1, rd.cropped_pixel_bounds[2]);
+    const int tp1y = min((int)floorf((float)y1 - 0.5f + fry) + 1, rd.cropped_pixel_bounds[3]);
+    const int tw = 16 + rd.tile_halo[0] + rd.tile_halo[2];
+    const int reachX = (int)floorf(0.5f + frx) + 1, reachY = (int)floorf(0.5f + fry) + 1;  // source pixels that can reach a pixel
+    for (int e = threadIdx.x; e < rd.tile_pixels; e += PG_BLOCK) {
+        const int X = x0 - rd.tile_halo[0] + e % tw, Y = y0 - rd.tile_halo[1] + e / tw;
+        if (X < tp0x || X >= tp1x || Y < tp0y || Y >= tp1y) continue;
+        float r = 0, g = 0, b = 0, w = 0;
+        for (int py = max(y0, Y - reachY); py <= min(y1 - 1, Y + reachY); ++py)
+            for (int px = max(x0, X - reachX); px <= min(x1 - 1, X + reachX); ++px) {
+                // InsideExclusive(pixel, pixelBounds), integrator.cpp:273
+                if (px < rd.pixel_bounds[0] || px >= rd.pixel_bounds[2] || py < rd.pixel_bounds[1] || py >= rd.pixel_bounds[3]) continue;
+                const int pix = (py - y0) * 16 + (px - x0);
+                for (int sIdx = 0; sIdx < rp.sCount; ++sIdx) {
+                    const int slot = (tileInBatch * rp.sCount + sIdx) * 256 + pix;
+                    const float4 L4 = st.L[slot];
+                    const float dx = L4.w - 0.5f, dy = st.beta[slot].w - 0.5f;  // pFilmDiscrete
+                    const int p0x = max((int)ceilf(dx - frx), tp0x), p1x = min((int)floorf(dx + frx) + 1, tp1x);
+                    if (X < p0x || X >= p1x) continue;
+                    const int p0y = max((int)ceilf(dy - fry), tp0y), p1y = min((int)floorf(dy + fry) + 1, tp1y);
+                    if (Y < p0y || Y >= p1y) continue;
+                    Spec L = sp3(L4.x, L4.y, L4.z);
+                    // integrator.cpp:294-315
+                    if (isnan(L.r) || isnan(L.g) || isnan(L.b)) L = sp(0);
+                    else if ((double)lum(L) < -1e-5) L = sp(0);
+                    else if (isinf(lum(L))) L = sp(0);
+                    if (lum(L) > rd.max_sample_luminance) L = L * (rd.max_sample_luminance / lum(L));
+                    const float fx = fabsf(((float)X - dx) * invRx * 16), fy = fabsf(((float)Y - dy) * invRy * 16);
+                    const int ifx = min((int)floorf(fx), 15), ify = min((int)floorf(fy), 15);
+                    const float fw = rd.filter_table[ify * 16 + ifx];
+                    const Spec c = (L * 1.f) * fw;
+                    r += c.r; g += c.g; b += c.b; w += fw;
+                }
+            }
+        PgFilmPixel *fp = &film[(size_t)local * rd.tile_pixels + e];
+        fp->rgb[0] = r; fp->rgb[1] = g; fp->rgb[2] = b; fp->weight = w;
+    }
+}
+void launch_film_general(const RenderParams &rp, PathState st, PgFilmPixel *film, hipStream_t s) {
+    if (rp.nTilesBatch == 0) return;
+    hipLaunchKernelGGL(k_film_general, dim3(rp.nTilesBatch), dim3(PG_BLOCK), 0, s, rp, st, film);
+}
 void launch_film(const RenderParams &rp, PathState st, PgFilmPixel *film, PgStraySample *strays, int maxStrays, int *nStrays,
                  hipStream_t s) {
     if (rp.nTilesBatch == 0) return;

@@ -12,10 +12,10 @@ import torch
 import torch.distributed as dist
 
 
-def shard_buffers(n_tiles_max, device):
-    """Fixed-size per-rank buffers (equal on every rank so one gather suffices)."""
+def shard_buffers(n_tiles_max, device, tile_pixels=256):
+    """Fixed-size per-rank buffers (equal on every rank so one gather suffices); tile_pixels = PgRenderDesc.tile_pixels."""
     max_strays = n_tiles_max * 256 // 8 + 1024
-    film = torch.zeros((n_tiles_max * 256, 4), dtype=torch.float32, device=device)
+    film = torch.zeros((n_tiles_max * tile_pixels, 4), dtype=torch.float32, device=device)
     strays = torch.zeros((max_strays, 8), dtype=torch.int32, device=device)  # PgStraySample = 8 x 4 bytes
     nstrays = torch.zeros(1, dtype=torch.int32, device=device)
     return film, strays, nstrays, max_strays
@@ -48,7 +48,7 @@ def merge_shards(pkg, scene, tile_count, shards):
     for r, (film, strays, n) in enumerate(shards):
         rd = scene.render_desc(tile_first=r, tile_step=world)
         nt = tile_count(rd)
-        f = np.ascontiguousarray(film.detach().cpu().numpy()[:nt * 256]).view(pkg.FILM_PIXEL_DTYPE).reshape(-1)
+        f = np.ascontiguousarray(film.detach().cpu().numpy()[:nt * rd.tile_pixels]).view(pkg.FILM_PIXEL_DTYPE).reshape(-1)
         s = np.ascontiguousarray(strays.detach().cpu().numpy()[:int(n)]).view(pkg.STRAY_DTYPE).reshape(-1)
         scene.film_merge(rd, f, s)
     return scene.film_image()

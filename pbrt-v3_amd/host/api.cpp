@@ -562,13 +562,18 @@ void pbrtObjectInstance(const std::string &name) {
 // RenderOptions::MakeIntegrator / MakeScene / MakeCamera (api.cpp:1651-1727)
 static GpuPathIntegrator *MakeIntegrator() {
     RenderOptions &ro = *renderOptions;
-    if (ro.FilterName != "box")
-        Error("PixelFilter \"%s\" is outside this build's closed set (box); using box.", ro.FilterName.c_str());
-    Float xw = ro.FilterName == "box" ? ro.FilterParams.FindOneFloat("xwidth", 0.5f) : 0.5f;  // filters/box.cpp:44-48
-    Float yw = ro.FilterName == "box" ? ro.FilterParams.FindOneFloat("ywidth", 0.5f) : 0.5f;
-    ro.FilterParams.ReportUnused();
+    // MakeFilter, api.cpp:785-803
+    std::string filterName = ro.FilterName;
+    if (filterName != "box" && filterName != "gaussian" && filterName != "mitchell" && filterName != "sinc" && filterName != "triangle") {
+        Error("Filter \"%s\" unknown.", filterName.c_str());
+        filterName = "box";
+    }
+    Float xw, yw;
+    FilterRadiusFor(filterName, ro.FilterParams, &xw, &yw);
     if (ro.FilmName != "image") { Error("Film \"%s\" unknown.", ro.FilmName.c_str()); return nullptr; }
     Film *film = CreateFilm(ro.FilmParams, xw, yw);
+    SetFilmFilter(film, filterName, ro.FilterParams);
+    ro.FilterParams.ReportUnused();
     ro.FilmParams.ReportUnused();
     if (ro.CameraName != "perspective") {
         Error("Camera \"%s\" is outside this build's closed set (perspective).", ro.CameraName.c_str());

@@ -4,7 +4,9 @@
 // and WriteImage's normalisation (film.cpp:169-211) with the same arithmetic,
 // and writes PFM (core/imageio.cpp:437-482).
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
+#include <functional>
 #include <map>
 #include "api.h"
 #include "error.h"
@@ -43,8 +45,89 @@ void Film::GetSampleBounds(int out[4]) const {  // film.cpp:80-86
 }
 void Film::Clear() { for (auto &p : pixels) p = Pixel(); }
 
+// ---- pixel filters: filters/{box,gaussian,mitchell,sinc,triangle}.{h,cpp}, filter.h:50-66 ------------------------
+void FilterRadiusFor(const std::string &name, const ParamSet &ps, Float *xw, Float *yw) {
+    Float d = name == "box" ? 0.5f : (name == "sinc" ? 4.f : 2.f);  // each Create*Filter's default "xwidth"/"ywidth"
+    *xw = ps.FindOneFloat("xwidth", d);
+    *yw = ps.FindOneFloat("ywidth", d);
+}
+bool SetFilmFilter(Film *film, const std::string &name, const ParamSet &ps) {
+    const Float rx = film->filterRadius[0], ry = film->filterRadius[1];
+    std::function<Float(Float, Float)> eval;
+    if (name == "box") eval = [](Float, Float) { return (Float)1.; };
+    else if (name == "gaussian") {  // gaussian.h:50-68
+        Float alpha = ps.FindOneFloat("alpha", 2.f);
+        Float expX = std::exp(-alpha * rx * rx), expY = std::exp(-alpha * ry * ry);
+        auto G = [alpha](Float d, Float expv) { return std::max((Float)0, Float(std::exp(-alpha * d * d) - expv)); };
+        eval = [=](Float x, Float y) { return G(x, expX) * G(y, expY); };
+    } else if (name == "mitchell") {  // mitchell.h:51-67
+        Float B = ps.FindOneFloat("B", 1.f / 3.f), C = ps.FindOneFloat("C", 1.f / 3.f);
+        Float invX = 1 / rx, invY = 1 / ry;
+        auto M = [B, C](Float x) {
+            x = std::abs(2 * x);
+            if (x > 1) return ((-B - 6 * C) * x * x * x + (6 * B + 30 * C) * x * x + (-12 * B - 48 * C) * x + (8 * B + 24 * C)) * (1.f / 6.f);
+            else return ((12 - 9 * B - 6 * C) * x * x * x + (-18 + 12 * B + 6 * C) * x * x + (6 - 2 * B)) * (1.f / 6.f);
+        };
+        eval = [=](Float x, Float y) { return M(x * invX) * M(y * invY); };
+    } else if (name == "sinc") {  // sinc.h:50-66
+        Float tau = ps.FindOneFloat("tau", 3.f);
+        auto Sinc = [](Float x) { x = std::abs(x); if (x < 1e-5) return (Float)1; return std::sin(Pi * x) / (Pi * x); };
+        auto W = [=](Float x, Float radius) { x = std::abs(x); if (x > radius) return (Float)0; Float lanczos = Sinc(x / tau); return Sinc(x) * lanczos; };
+        eval = [=](Float x, Float y) { return W(x, rx) * W(y, ry); };
+    } else if (name == "triangle")  // triangle.cpp:41-45
+        eval = [=](Float x, Float y) { return std::max((Float)0, rx - std::abs(x)) * std::max((Float)0, ry - std::abs(y)); };
+    else return false;
+    const int filterTableWidth = 16;
+    int offset = 0;
+    for (int y = 0; y < filterTableWidth; ++y)  // film.cpp:68-77
+        for (int x = 0; x < filterTableWidth; ++x, ++offset) {
+            Float px = (x + 0.5f) * rx / filterTableWidth, py = (y + 0.5f) * ry / filterTableWidth;
+            film->filterTable[offset] = eval(px, py);
+        }
+    film->filterGeneral = !(name == "box" && rx <= 0.5f && ry <= 0.5f && rx > 0 && ry > 0);
+    return true;
+}
+void Film::TileHalo(int h[4]) const {  // GetFilmTile, film.cpp:95-106, for a tile [x0, x0+16) x [y0, y0+16)
+    // low: x0 - ceil(x0 - 0.5 - r); high: floor(x1 - 0.5 + r) + 1 - x1 (integers x0, x1 drop out)
+    h[0] = -(int)std::ceil(-0.5f - filterRadius[0]); h[1] = -(int)std::ceil(-0.5f - filterRadius[1]);
+    h[2] = (int)std::floor(-0.5f + filterRadius[0]) + 1; h[3] = (int)std::floor(-0.5f + filterRadius[1]) + 1;
+}
+int Film::TilePixels() const {
+    if (!filterGeneral) return 256;
+    int h[4];
+    TileHalo(h);
+    return (16 + h[0] + h[2]) * (16 + h[1] + h[3]);
+}
+
 void Film::MergeShard(const PgRenderDesc &rd, const PgFilmPixel *film, const PgStraySample *strays, int nStrays) {
     const int tileSize = 16;
+    if (rd.filter_general) {
+        // MergeFilmTile (film.cpp:117-130) for every tile of the shard in tile order: each FilmTile pixel is converted to
+        // XYZ and added to the film, clipped to the cropped pixel bounds as GetFilmTile's Intersect does.
+        const int sx0 = rd.sample_bounds[0], sy0 = rd.sample_bounds[1];
+        const int nTilesX = (rd.sample_bounds[2] - sx0 + tileSize - 1) / tileSize;
+        const int nTilesY = (rd.sample_bounds[3] - sy0 + tileSize - 1) / tileSize;
+        const int width = croppedPixelBounds[2] - croppedPixelBounds[0];
+        const int tw = tileSize + rd.tile_halo[0] + rd.tile_halo[2];
+        int local = 0;
+        for (int t = rd.tile_first; t < nTilesX * nTilesY; t += rd.tile_step, ++local) {
+            int tx = t % nTilesX, ty = t / nTilesX;
+            int x0 = sx0 + tx * tileSize, y0 = sy0 + ty * tileSize;
+            int x1 = std::min(x0 + tileSize, rd.sample_bounds[2]), y1 = std::min(y0 + tileSize, rd.sample_bounds[3]);
+            int px0 = std::max(x0 - rd.tile_halo[0], croppedPixelBounds[0]), py0 = std::max(y0 - rd.tile_halo[1], croppedPixelBounds[1]);
+            int px1 = std::min(x1 + rd.tile_halo[2], croppedPixelBounds[2]), py1 = std::min(y1 + rd.tile_halo[3], croppedPixelBounds[3]);
+            for (int y = py0; y < py1; ++y)
+                for (int x = px0; x < px1; ++x) {
+                    const PgFilmPixel &fp = film[(size_t)local * rd.tile_pixels + (size_t)(y - (y0 - rd.tile_halo[1])) * tw + (x - (x0 - rd.tile_halo[0]))];
+                    Float xyz[3];
+                    RGBToXYZ(fp.rgb, xyz);
+                    Pixel &mp = pixels[(size_t)(y - croppedPixelBounds[1]) * width + (x - croppedPixelBounds[0])];
+                    for (int c = 0; c < 3; ++c) mp.xyz[c] += xyz[c];
+                    mp.filterWeightSum += fp.weight;
+                }
+        }
+        return;
+    }
     const int sx0 = rd.sample_bounds[0], sy0 = rd.sample_bounds[1];
     const int nTilesX = (rd.sample_bounds[2] - sx0 + tileSize - 1) / tileSize;
     const int nTilesY = (rd.sample_bounds[3] - sy0 + tileSize - 1) / tileSize;

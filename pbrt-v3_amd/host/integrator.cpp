@@ -257,6 +257,10 @@ void GpuPathIntegrator::FillRenderDesc(PgRenderDesc *rd) const {
     for (int i = 0; i < 4; ++i) rd->cropped_pixel_bounds[i] = film.croppedPixelBounds[i];
     film.GetSampleBounds(rd->sample_bounds);
     rd->filter_radius[0] = film.filterRadius[0]; rd->filter_radius[1] = film.filterRadius[1];
+    rd->filter_general = film.filterGeneral ? 1 : 0;
+    if (film.filterGeneral) film.TileHalo(rd->tile_halo);
+    rd->tile_pixels = film.TilePixels();
+    memcpy(rd->filter_table, film.filterTable, sizeof(rd->filter_table));
     rd->film_scale = film.scale; rd->max_sample_luminance = film.maxSampleLuminance;
     rd->spp = sampler->samplesPerPixel;
     for (int i = 0; i < 2; ++i) {

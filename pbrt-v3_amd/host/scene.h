@@ -83,6 +83,11 @@ class Film {
     int fullResolution[2];
     int croppedPixelBounds[4];
     Float filterRadius[2];
+    // filterTable (film.cpp:68-77) and whether the general FilmTile path is needed (anything but a box of radius <= 0.5)
+    Float filterTable[256];
+    bool filterGeneral = false;
+    void TileHalo(int halo[4]) const;  // FilmTile pixel bounds relative to the tile's 16x16 sample block (film.cpp:95-106)
+    int TilePixels() const;
     std::string filename;
     Float scale, maxSampleLuminance;
   private:
@@ -90,6 +95,9 @@ class Film {
     std::vector<Pixel> pixels;
 };
 Film *CreateFilm(const ParamSet &params, Float filterRadiusX, Float filterRadiusY);  // film.cpp:213-252
+// MakeFilter (api.cpp:785-803) + the filters' Evaluate(): fills film->filterTable / filterGeneral; returns false for unknown names
+bool SetFilmFilter(Film *film, const std::string &name, const ParamSet &params);
+void FilterRadiusFor(const std::string &name, const ParamSet &params, Float *xw, Float *yw);
 bool WriteImagePFM(const std::string &filename, const Float *rgb, int width, int height);  // imageio.cpp:437-482
 
 struct PerspectiveCamera {  // cameras/perspective.cpp:45-68, core/camera.h:87-108

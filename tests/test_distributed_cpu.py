@@ -25,7 +25,7 @@ def _worker(rank, world, port, name, out):
     scene = pkg.HostScene(os.path.join(GOLD, name + ".pbrt"))
     tile_count = lambda rd: oracle.lib().oracle_render_tile_count(C.byref(rd))
     rd = scene.render_desc(tile_first=rank, tile_step=world)
-    film, strays, nstrays, max_strays = pdist.shard_buffers(tile_count(scene.render_desc(0, world)), "cpu")
+    film, strays, nstrays, max_strays = pdist.shard_buffers(tile_count(scene.render_desc(0, world)), "cpu", rd.tile_pixels)
     f, s, _ = oracle.render(scene.desc, rd, max_strays=max_strays)
     film[:len(f)] = torch.from_numpy(f.view(np.float32).reshape(-1, 4))
     strays[:len(s)] = torch.from_numpy(s.view(np.int32).reshape(-1, 8))

@@ -36,7 +36,7 @@ def test_golden_images(gpu, name):
         assert abs(cn[k] - stats[k]) <= max(4, 2e-3 * stats[k]), (k, cn[k], stats[k])
 
 
-@pytest.mark.parametrize("name", ["cornell_32", "cornell_crop", "synthetic_n40", "cornell_lens", "cornell_plastic", "plastic_topdown", "cornell_normals", "cornell_tangents", "cornell_lightnormals", "cornell_point", "cornell_spot_power", "cornell_delta_only", "cornell_mirror_glass", "cornell_glass_eta"])
+@pytest.mark.parametrize("name", ["cornell_32", "cornell_crop", "synthetic_n40", "cornell_lens", "cornell_plastic", "plastic_topdown", "cornell_normals", "cornell_tangents", "cornell_lightnormals", "cornell_point", "cornell_spot_power", "cornell_delta_only", "cornell_mirror_glass", "cornell_glass_eta", "filter_gaussian", "filter_mitchell_crop", "filter_widebox"])
 def test_film_buffers_vs_oracle(gpu, oracle, name):
     scene = gpu.HostScene(os.path.join(GOLD, name + ".pbrt"))
     gs = gpu.GpuScene(scene.desc)
@@ -172,8 +172,8 @@ def test_unsupported_inputs_fail_loudly(gpu):
         gpu.GpuScene(bad)
     gs = gpu.GpuScene(desc)
     rd = scene.render_desc()
-    rd.filter_radius[0] = 2.0
-    with pytest.raises(gpu.PbrtGpuError, match="filters"):
+    rd.filter_radius[0] = 2.0  # a wide filter must come with filter_general / its tile block geometry
+    with pytest.raises(gpu.PbrtGpuError, match="filter_general"):
         gs.render(rd)
     gs.close()
 
