@@ -44,6 +44,9 @@ def make_scene_file(workdir, args):
         open(path, "w").write(txt)
     else:
         gen_synthetic.write_scene(path, n=args.grid, xres=args.xres, yres=args.yres, spp=args.spp)
+    if args.filter != "box":
+        txt = open(path).read().replace('PixelFilter "box"', f'PixelFilter "{args.filter}"')
+        open(path, "w").write(txt)
     return path
 
 
@@ -94,6 +97,7 @@ def main():
     ap.add_argument("--xres", type=int, default=1920)
     ap.add_argument("--yres", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--filter", default="box", help='PixelFilter of the scene (BASELINE config: "box")')
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--out", default=None, help="write the rendered image (PFM) here")
     args = ap.parse_args()
@@ -172,7 +176,7 @@ def main():
         achieved = alg_bytes / (cn["closest_ms"] * 1e-3) / 1e9 if cn["closest_ms"] > 0 else 0.0
         workload = ((f"synthetic heightfield-in-a-box, {scene.desc.n_tris} triangles" if args.workload == "synthetic"
                      else "Cornell box, 36 triangles") +
-                    f", PathIntegrator maxdepth 5, halton, box filter, {args.xres}x{args.yres} @ {args.spp} spp")
+                    f", PathIntegrator maxdepth 5, halton, {args.filter} filter, {args.xres}x{args.yres} @ {args.spp} spp")
         traffic = None  # HBM-side bytes per launch from the committed PMC passes of this same workload (tools/pmc_traffic.sh)
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
