@@ -316,7 +316,7 @@ void GpuPathIntegrator::Render(const Scene &scene) {
     PgScene *dev = nullptr;
     if (gpuApi.scene_create(&flat.desc, &dev) != PG_OK) { Error("pg_scene_create: %s", gpuApi.last_error()); exit(1); }
     int nTiles = gpuApi.render_tile_count(&rd);
-    std::vector<PgFilmPixel> film((size_t)nTiles * 256);
+    std::vector<PgFilmPixel> film((size_t)nTiles * (size_t)rd.tile_pixels);
     int maxStrays = nTiles * 256 / 8 + 1024, nStrays = 0;
     std::vector<PgStraySample> strays(maxStrays);
     auto t0 = std::chrono::steady_clock::now();

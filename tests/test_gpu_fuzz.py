@@ -1,0 +1,112 @@
+"""Differential fuzzing of the HIP path against the CPU oracle: seeded random scenes (triangle soups with degenerate, duplicate
+and extreme-scale triangles; every material, light type, filter and light strategy of the closed set; random cameras) and
+random rays.  Traversal results are compared bit for bit, film buffers within the image tolerance."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, ROOT
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def random_scene(seed, res=16, spp=4):
+    rng = np.random.default_rng(seed)
+    f = lambda a: " ".join(f"{x:.9g}" for x in np.asarray(a, np.float32).ravel())
+    eye = rng.normal(size=3) * 3 + np.array([0, 0, -6])
+    filt = ['PixelFilter "box"', 'PixelFilter "gaussian"', 'PixelFilter "mitchell" "float xwidth" [ 1.2 ]', 'PixelFilter "triangle"',
+            'PixelFilter "box" "float xwidth" [ 0.9 ] "float ywidth" [ 0.3 ]'][seed % 5]
+    strat = ["spatial", "power", "uniform"][seed % 3]
+    lens = '"float lensradius" [ 0.05 ] "float focaldistance" [ 6 ]' if seed % 4 == 0 else ""
+    out = [f"LookAt {f(eye)}  0 0 0  0 1 0", f'Camera "perspective" "float fov" [ {30 + 40 * rng.random():.4g} ] {lens}',
+           f'Film "image" "integer xresolution" [ {res} ] "integer yresolution" [ {res + seed % 7} ] "string filename" "fuzz.pfm"',
+           f'Sampler "halton" "integer pixelsamples" [ {spp} ]', filt,
+           f'Integrator "path" "integer maxdepth" [ {1 + seed % 6} ] "string lightsamplestrategy" "{strat}"', "WorldBegin"]
+    mats = ['Material "matte" "rgb Kd" [ %s ]' % f(rng.random(3)), 'Material "plastic" "rgb Kd" [ %s ] "rgb Ks" [ %s ] "float roughness" [ %.4g ]'
+            % (f(rng.random(3) * 0.6), f(rng.random(3) * 0.4), 0.02 + 0.5 * rng.random()), 'Material "mirror"',
+            'Material "glass" "float index" [ %.4g ]' % (1.1 + rng.random()), 'Material "matte" "rgb Kd" [ 0 0 0 ]']
+    if seed % 3 == 1:
+        out.append(f'LightSource "point" "point from" [ {f(rng.normal(size=3) * 2 + [0, 4, 0])} ] "rgb I" [ {f(20 + 40 * rng.random(3))} ]')
+    if seed % 3 == 2:
+        out.append(f'LightSource "spot" "point from" [ {f(rng.normal(size=3) + [0, 5, -2])} ] "point to" [ 0 0 0 ] "rgb I" [ {f(80 + 80 * rng.random(3))} ] "float coneangle" [ 40 ]')
+        out.append(f'LightSource "distant" "point from" [ {f(rng.normal(size=3) + [0, 3, 0])} ] "rgb L" [ {f(rng.random(3))} ]')
+    # an emissive quad above (every third scene relies on delta lights only)
+    if seed % 3 != 1 or seed % 2 == 0:
+        two = '"bool twosided" "true"' if seed % 5 == 2 else ""
+        out.append(f'AttributeBegin\n AreaLightSource "diffuse" "rgb L" [ {f(5 + 10 * rng.random(3))} ] {two}\n Shape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ] '
+                   f'"point P" [ -1 3 -1  1 3 -1  1 3 1  -1 3 1 ]\nAttributeEnd')
+    # floor + random soup in a few meshes, with degenerate / duplicate / tiny / huge triangles mixed in
+    out.append(mats[0])
+    out.append('Shape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ] "point P" [ -6 -2 -6  6 -2 -6  6 -2 6  -6 -2 6 ]')
+    for m in range(1 + seed % 4):
+        out.append(mats[int(rng.integers(len(mats)))])
+        nt = int(rng.integers(1, 40))
+        P = rng.normal(size=(nt, 3, 3)) * 0.7 + rng.normal(size=(nt, 1, 3)) * 1.5
+        P[::7, 2] = P[::7, 1]                      # zero-area triangles
+        if nt > 3: P[3] = P[2]                     # exact duplicate (ties)
+        P[::11] *= 1e-3                            # tiny
+        if seed % 6 == 0: P[::13] *= 1e3           # huge
+        extra = ""
+        if m % 2 == 1:
+            N = rng.normal(size=(nt * 3, 3)); N[::5] = 0
+            extra += f' "normal N" [ {f(N)} ]'
+        if m % 3 == 2:
+            extra += f' "vector S" [ {f(rng.normal(size=(nt * 3, 3)))} ] "float uv" [ {f(rng.random((nt * 3, 2)))} ]'
+        if m == 1 and seed % 2: out.append("ReverseOrientation")
+        out.append(f'AttributeBegin\n Rotate {90 * rng.random():.4g} 0 1 0\n Scale 1 {1 - 2 * (seed % 2)} 1\n Shape "trianglemesh" "integer indices" [ {" ".join(map(str, range(3 * nt)))} ] '
+                   f'"point P" [ {f(P)} ]{extra}\nAttributeEnd')
+    out.append("WorldEnd")
+    return "\n".join(out) + "\n"
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_scene_film_matches_oracle(gpu, oracle, seed):
+    scene = gpu.HostScene(text=random_scene(seed))
+    gs = gpu.GpuScene(scene.desc)
+    rd = scene.render_desc()
+    film, strays = gs.render(rd)
+    cn = gs.counters()
+    ofilm, ostrays, ocn = oracle.render(scene.desc, rd)
+    assert np.array_equal(film["weight"], ofilm["weight"])
+    scale = max(1.0, float(np.abs(ofilm["rgb"]).max()) / rd.spp)
+    assert np.abs(film["rgb"] - ofilm["rgb"]).max() <= TOL * rd.spp * scale
+    assert len(strays) == len(ostrays)
+    assert cn["camera_rays"] == ocn["camera_rays"]
+    for k in ("closest_rays", "shadow_rays"):  # a last-ulp sin/cos difference may add or remove a handful of rays
+        assert abs(cn[k] - ocn[k]) <= max(4, 2e-3 * ocn[k]), (k, cn[k], ocn[k])
+    # rays through the same soup: bit-exact, including the reference's counters
+    rng = np.random.default_rng(1000 + seed)
+    n = 4096
+    nodes = scene.nodes()
+    lo, hi = nodes["bmin"][0], nodes["bmax"][0]
+    o = (lo + (hi - lo) * (rng.random((n, 3)) * 1.4 - 0.2)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[:64, seed % 3] = 0  # axis-parallel directions: infinite inverse components
+    tmax = np.where(rng.random(n) < 0.3, rng.random(n) * 3, np.inf).astype(np.float32)
+    gs.counters_reset()
+    prim, t, bary = gs.intersect(o, d, tmax)
+    op, ot, ob, on = oracle.intersect(scene.desc, o, d, tmax)
+    assert np.array_equal(prim, op) and np.array_equal(t, ot) and np.array_equal(bary, ob)
+    c2 = gs.counters()
+    assert c2["closest_node_visits"] == on["node_visits"] and c2["closest_tri_tests"] == on["tri_tests"]
+    occ = gs.intersect_p(o, d, tmax)
+    oocc, on2 = oracle.intersect_p(scene.desc, o, d, tmax)
+    assert np.array_equal(occ, oocc)
+    c3 = gs.counters()
+    assert c3["shadow_node_visits"] == on2["node_visits"] and c3["shadow_tri_tests"] == on2["tri_tests"]
+    gs.close()
+
+
+def test_cli_end_to_end(gpu, tmp_path):
+    """pbrt_amd scene.pbrt --outfile x.pfm, the drop-in for `pbrt scene.pbrt --outfile x.pfm`."""
+    exe = os.path.join(ROOT, "pbrt-v3_amd", "pbrt_amd")
+    out = tmp_path / "cli.pfm"
+    for name in ("cornell_32", "filter_gaussian", "cornell_ply"):
+        r = subprocess.run([exe, "--quiet", "--outfile", str(out), os.path.join(GOLD, name + ".pbrt")], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        img, ref = gpu.read_pfm(str(out)), gpu.read_pfm(os.path.join(GOLD, name + ".pfm"))
+        assert img.shape == ref.shape
+        assert (np.abs(img - ref) / np.maximum(1, np.abs(ref))).max() <= TOL, name
