@@ -96,6 +96,23 @@ def write_plys():
                     f.write(struct.pack(end + "BHHH", 3, *(4 * q + k for k in tri)))
 
 
+def with_subdiv(s):
+    import re
+    boxes = list(re.finditer(r'Shape "trianglemesh"\s+"integer indices" \[ 0 1 2 0 2 3  4 5 6[^\]]*\]\s+"point P" \[[^\]]*\]', s))
+    assert len(boxes) == 2
+    octa = ('AttributeBegin\n Translate 370 200 350\n Scale 120 190 120\n Shape "loopsubdiv" "integer levels" [ 3 ] '
+            '"integer indices" [ 0 2 4  2 1 4  1 3 4  3 0 4  2 0 5  1 2 5  3 1 5  0 3 5 ] '
+            '"point P" [ 1 0 0  -1 0 0  0 0 1  0 0 -1  0 1 0  0 -1 0 ]\nAttributeEnd\n')
+    fan = ('AttributeBegin\n Translate 180 90 170\n Rotate 25 0 1 0\n Scale 95 60 95\n Shape "loopsubdiv" "integer nlevels" [ 2 ] '
+           '"integer indices" [ 0 1 2  0 2 3  0 3 4  0 4 5  0 5 6  0 6 1  1 7 2  2 7 8  3 2 8  9 5 4  6 5 10 ] '
+           '"point P" [ 0 1 0  1 0 0  0.5 0.2 0.87  -0.5 0 0.87  -1 0.3 0  -0.5 0 -0.87  0.5 0.1 -0.87  1.4 -0.5 0.9  0.2 -0.4 1.7  -1.6 -0.2 -0.7  0.4 -0.3 -1.8 ]\nAttributeEnd\n'
+           'AttributeBegin\n Translate 160 40 90\n Scale 40 40 40\n ReverseOrientation\n Shape "loopsubdiv" "integer levels" [ 1 ] '
+           '"integer indices" [ 0 1 2  0 3 1  0 2 3  1 3 2 ] "point P" [ 1 1 1  -1 -1 1  -1 1 -1  1 -1 -1 ]\nAttributeEnd\n')
+    s = s[:boxes[1].start()] + octa + s[boxes[1].end():]
+    s = s[:boxes[0].start()] + fan + s[boxes[0].end():]
+    return s
+
+
 def with_ply(s):
     write_plys()
     import re
@@ -162,6 +179,9 @@ SCENES = {
     "filter_sinc": cornell(24, 24, 4).replace('PixelFilter "box"', 'PixelFilter "sinc" "float xwidth" [ 3 ] "float ywidth" [ 3 ]'),
     "filter_triangle_box": cornell(24, 24, 4).replace('PixelFilter "box"', 'PixelFilter "triangle" "float xwidth" [ 0.5 ] "float ywidth" [ 1 ]'),
     "filter_widebox": cornell(24, 24, 4).replace('PixelFilter "box"', 'PixelFilter "box" "float xwidth" [ 1.25 ] "float ywidth" [ 0.75 ]'),
+    # Shape "loopsubdiv" (loopsubdiv.cpp): a closed octahedron (valence-4 extraordinary vertices), an open fan with boundary
+    # vertices of valence 2, 3, 4 and 6, and a tetrahedron (valence 3), at several levels, replacing the Cornell boxes
+    "cornell_loopsubdiv": cornell(40, 40, 8, world_edit=lambda s: with_subdiv(s)),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 

@@ -470,6 +470,7 @@ std::shared_ptr<TriangleMesh> BuildTriangleMesh(const Transform &o2w, bool rever
     return mesh;
 }
 std::shared_ptr<TriangleMesh> CreatePLYMesh(const Transform &o2w, bool reverseOrientation, const ParamSet &params);  // plymesh.cpp
+std::shared_ptr<TriangleMesh> CreateLoopSubdiv(const Transform &o2w, bool reverseOrientation, const ParamSet &params);  // loopsubdiv.cpp
 
 // shapes/triangle.cpp:647-743 CreateTriangleMeshShape + :94-110 CreateTriangleMesh
 static std::shared_ptr<TriangleMesh> CreateTriangleMeshShape(const Transform &o2w, bool reverseOrientation, const ParamSet &params) {
@@ -510,7 +511,8 @@ void pbrtShape(const std::string &name, const ParamSet &params) {  // api.cpp:13
     std::shared_ptr<TriangleMesh> mesh;
     if (name == "trianglemesh") mesh = CreateTriangleMeshShape(curTransform[0], graphicsState.reverseOrientation, params);
     else if (name == "plymesh") mesh = CreatePLYMesh(curTransform[0], graphicsState.reverseOrientation, params);
-    else Error("Shape \"%s\" is outside this build's closed set (trianglemesh, plymesh); ignoring.", name.c_str());
+    else if (name == "loopsubdiv") mesh = CreateLoopSubdiv(curTransform[0], graphicsState.reverseOrientation, params);
+    else Error("Shape \"%s\" is outside this build's closed set (trianglemesh, plymesh, loopsubdiv); ignoring.", name.c_str());
     if (!mesh || mesh->nTriangles == 0) return;
     int mtl = GetMaterialForShape(params);
     params.ReportUnused();
