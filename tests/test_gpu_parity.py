@@ -217,3 +217,19 @@ def test_full_size_properties(gpu, oracle, tmp_path):
     oprim, ot, obary, _ = oracle.intersect(scene.desc, o, d, inf)
     assert np.array_equal(prim, oprim) and np.array_equal(t, ot) and np.array_equal(bary, obary)
     gs.close()
+
+
+@pytest.mark.parametrize("name", ["cornell_40x24", "filter_gaussian", "cornell_mirror_glass"])
+def test_path_batching_does_not_change_the_film(gpu, name, monkeypatch):
+    """pg_render splits a frame into batches of paths when it exceeds the work-buffer budget (by samples for the box filter,
+    by tiles for the other filters).  Any split must give the film of the single-batch render, bit for bit."""
+    scene = gpu.HostScene(os.path.join(GOLD, name + ".pbrt"))
+    gs = gpu.GpuScene(scene.desc)
+    rd = scene.render_desc()
+    whole, strays = gs.render(rd)
+    for budget in ("256", "768", "5000"):
+        monkeypatch.setenv("PG_BATCH_PATHS", budget)
+        part, strays2 = gs.render(rd)
+        assert np.array_equal(part["rgb"], whole["rgb"]) and np.array_equal(part["weight"], whole["weight"]), budget
+        assert len(strays2) == len(strays)
+    gs.close()
