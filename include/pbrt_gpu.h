@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 3
+#define PG_ABI_VERSION 4
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -141,7 +141,8 @@ typedef struct PgSceneDesc {
 
 typedef struct PgRenderDesc {
     int32_t abi_version;
-    /* camera: PerspectiveCamera (cameras/perspective.cpp:45-144) */
+    /* camera: PerspectiveCamera (cameras/perspective.cpp:45-144) or OrthographicCamera (cameras/orthographic.cpp:44-118) */
+    int32_t camera_type;        /* 0 = perspective, 1 = orthographic */
     float raster_to_camera[16]; /* row-major Matrix4x4 */
     float camera_to_world[16];
     float lens_radius, focal_distance;

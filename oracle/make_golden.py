@@ -182,6 +182,12 @@ SCENES = {
     # Shape "loopsubdiv" (loopsubdiv.cpp): a closed octahedron (valence-4 extraordinary vertices), an open fan with boundary
     # vertices of valence 2, 3, 4 and 6, and a tetrahedron (valence 3), at several levels, replacing the Cornell boxes
     "cornell_loopsubdiv": cornell(40, 40, 8, world_edit=lambda s: with_subdiv(s)),
+    # matte with sigma != 0: the OrenNayar BRDF (reflection.cpp:197-219), incl. sigma clamped to 90
+    "cornell_orennayar": cornell(24, 24, 8, world_edit=lambda s: s.replace('Material "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', 'Material "matte" "rgb Kd" [ 0.73 0.73 0.73 ] "float sigma" [ 35 ]')
+                                 .replace('Material "matte" "rgb Kd" [ 0.12 0.45 0.15 ]', 'Material "matte" "rgb Kd" [ 0.12 0.45 0.15 ] "float sigma" [ 120 ]')),
+    # OrthographicCamera (orthographic.cpp), plain and with a thin lens and a screen window
+    "cornell_ortho": cornell(24, 24, 8).replace('Camera "perspective" "float fov" [ 39.3 ]', 'Camera "orthographic" "float screenwindow" [ -300 300 -290 310 ]'),
+    "cornell_ortho_lens": cornell(20, 28, 8).replace('Camera "perspective" "float fov" [ 39.3 ]', 'Camera "orthographic" "float screenwindow" [ -280 280 -280 280 ] "float lensradius" [ 12 ] "float focaldistance" [ 1100 ]'),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 

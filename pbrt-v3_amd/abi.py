@@ -5,7 +5,7 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 3
+PG_ABI_VERSION = 4
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
 PG_LIGHTS_UNIFORM, PG_LIGHTS_POWER, PG_LIGHTS_SPATIAL = 0, 1, 2
@@ -45,7 +45,7 @@ class PgSceneDesc(C.Structure):
 
 
 class PgRenderDesc(C.Structure):
-    _fields_ = [("abi_version", C.c_int32),
+    _fields_ = [("abi_version", C.c_int32), ("camera_type", C.c_int32),
                 ("raster_to_camera", C.c_float * 16), ("camera_to_world", C.c_float * 16),
                 ("lens_radius", C.c_float), ("focal_distance", C.c_float),
                 ("shutter_open", C.c_float), ("shutter_close", C.c_float),

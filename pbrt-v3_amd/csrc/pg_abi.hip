@@ -212,8 +212,6 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         if (m.type == PG_MAT_NONE) s->hasNullMaterial = true;
         else if (m.type < PG_MAT_MATTE || m.type > PG_MAT_GLASS)
             FAIL(PG_ERR_UNSUPPORTED, "material %d: type %d is outside this build's closed set (matte, plastic, mirror, glass)", i, m.type);
-        else if (m.type == PG_MAT_MATTE && m.sigma != 0)
-            FAIL(PG_ERR_UNSUPPORTED, "material %d: Oren-Nayar (sigma != 0) is outside this build's closed set", i);
     }
     // device copy: a plastic's `roughness` becomes the TrowbridgeReitz alpha.  RoughnessToAlpha (microfacet.h:127-132) calls
     // logf; evaluating it here on the host uses the same libm as the reference build.

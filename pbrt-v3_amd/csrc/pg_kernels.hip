@@ -198,6 +198,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_generate(DScene sc, RenderParams r
         // GenerateRayDifferential, perspective.cpp:95-144 (differentials feed only texture filtering; textures are constant)
         V3 pCamera = xform_point(rd.raster_to_camera, mk(pFilmX, pFilmY, 0));
         d = normalize(mk(pCamera.x, pCamera.y, pCamera.z));
+        if (rd.camera_type == 1) { o = pCamera; d = mk(0, 0, 1); }  // OrthographicCamera, orthographic.cpp:76-78
         if (rd.lens_radius > 0) {
             float l0 = halton_sample(sc, rd, index, 3), l1 = halton_sample(sc, rd, index, 4);
             float lx, ly;
@@ -299,6 +300,7 @@ PG_DEV V3 hit_normal(const DScene &sc, int prim, const Tri &t, float b0, float b
 // the materials add them (matte.cpp:45-62, plastic.cpp:45-70); reflection.h:164-213, reflection.cpp:680-796.
 struct Bsdf {
     V3 ns, ng, ss, ts; Spec R, Ks; float alpha; int nBxDFs; bool hasDiff, hasSpec;
+    bool orenNayar; float onA, onB;  // the diffuse lobe is OrenNayar(R, sigma) (reflection.h:425-431) instead of LambertianReflection
     int specular;  // 0; 1 = SpecularReflection(Kr, FresnelNoOp) (mirror.cpp:44-56); 2 = FresnelSpecular(Kr, Kt, 1, eta) (glass.cpp:45-65)
     Spec Kr, Kt; float eta;
 };
@@ -420,9 +422,25 @@ PG_DEV void mf_sample(const Bsdf &b, V3 wo, V3 &wi, float u0, float u1, float &p
     pdf = tr_pdf(b.alpha, wo, wh) / (4 * dot(wo, wh));
 }
 PG_DEV float lambert_pdf(V3 wo, V3 wi) { return (wo.z * wi.z > 0) ? fabsf(wi.z) * PG_INVPI : 0; }  // reflection.cpp:392-394
+// the diffuse lobe: LambertianReflection::f (reflection.cpp:178-180) or OrenNayar::f (:197-219)
+PG_DEV Spec diffuse_f(const Bsdf &b, V3 wo, V3 wi) {
+    if (!b.orenNayar) return b.R * PG_INVPI;
+    float sinThetaI = sin_theta(wi), sinThetaO = sin_theta(wo);
+    float maxCos = 0;
+    if ((double)sinThetaI > 1e-4 && (double)sinThetaO > 1e-4) {
+        float sinPhiI = sin_phi(wi), cosPhiI = cos_phi(wi);
+        float sinPhiO = sin_phi(wo), cosPhiO = cos_phi(wo);
+        float dCos = cosPhiI * cosPhiO + sinPhiI * sinPhiO;
+        maxCos = pmax(0.f, dCos);
+    }
+    float sinAlpha, tanBeta;
+    if (fabsf(wi.z) > fabsf(wo.z)) { sinAlpha = sinThetaO; tanBeta = sinThetaI / fabsf(wi.z); }
+    else { sinAlpha = sinThetaI; tanBeta = sinThetaO / fabsf(wo.z); }
+    return (b.R * PG_INVPI) * (b.onA + b.onB * maxCos * sinAlpha * tanBeta);
+}
 PG_DEV Spec bsdf_f_local(const Bsdf &b, V3 wo, V3 wi, bool reflect) {
     Spec f = sp(0);
-    if (b.hasDiff && reflect) f = f + b.R * PG_INVPI;  // LambertianReflection::f, :178-180
+    if (b.hasDiff && reflect) f = f + diffuse_f(b, wo, wi);
     if (b.hasSpec && reflect) f = f + mf_f(b, wo, wi);
     return f;
 }
@@ -660,6 +678,16 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                 bsdf.ts = cross(bsdf.ns, bsdf.ss);
                 bsdf.R = sp3(m.kd[0] < 0 ? 0 : m.kd[0], m.kd[1] < 0 ? 0 : m.kd[1], m.kd[2] < 0 ? 0 : m.kd[2]);
                 bsdf.hasDiff = !is_black(bsdf.R);
+                bsdf.orenNayar = false; bsdf.onA = 1; bsdf.onB = 0;
+                if (m.type == PG_MAT_MATTE) {  // matte.cpp:55-61; OrenNayar ctor, reflection.h:425-431
+                    const float sig = clampf(m.sigma, 0, 90);
+                    if (sig != 0) {
+                        const float sigma = (PG_PI / 180) * sig, sigma2 = sigma * sigma;
+                        bsdf.orenNayar = true;
+                        bsdf.onA = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
+                        bsdf.onB = 0.45f * sigma2 / (sigma2 + 0.09f);
+                    }
+                }
                 // PlasticMaterial (plastic.cpp:57-69): m.roughness already holds the distribution's alpha (host: RoughnessToAlpha)
                 bsdf.Ks = sp3(m.ks[0] < 0 ? 0 : m.ks[0], m.ks[1] < 0 ? 0 : m.ks[1], m.ks[2] < 0 ? 0 : m.ks[2]);
                 bsdf.hasSpec = m.type == PG_MAT_PLASTIC && !is_black(bsdf.Ks);

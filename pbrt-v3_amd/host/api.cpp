@@ -162,7 +162,6 @@ static int MakeMaterial(const std::string &name, const ParamSet &geom, const Par
         m.sigma = floatParam(geom, mat, "sigma", 0.f, graphicsState);
         if (!geom.FindTexture("bumpmap").empty() || !mat.FindTexture("bumpmap").empty())
             Error("\"bumpmap\" textures are not supported by this build; ignoring.");
-        if (m.sigma != 0) Error("matte \"sigma\" != 0 (Oren-Nayar) is not supported by this build; using Lambertian.");
     } else if (name == "plastic") {
         m.type = PG_MAT_PLASTIC;
         RGB kd = spectrumParam(geom, mat, "Kd", RGB{{0.25f, 0.25f, 0.25f}}, graphicsState);
@@ -577,13 +576,13 @@ static GpuPathIntegrator *MakeIntegrator() {
     SetFilmFilter(film, filterName, ro.FilterParams);
     ro.FilterParams.ReportUnused();
     ro.FilmParams.ReportUnused();
-    if (ro.CameraName != "perspective") {
-        Error("Camera \"%s\" is outside this build's closed set (perspective).", ro.CameraName.c_str());
+    if (ro.CameraName != "perspective" && ro.CameraName != "orthographic") {
+        Error("Camera \"%s\" is outside this build's closed set (perspective, orthographic).", ro.CameraName.c_str());
         delete film;
         return nullptr;
     }
     if (ro.CameraToWorld.IsAnimated()) Warning("Animated camera transformations are not supported by this build; using the start transform.");
-    std::shared_ptr<PerspectiveCamera> camera(CreatePerspectiveCamera(ro.CameraParams, ro.CameraToWorld[0], film));
+    std::shared_ptr<PerspectiveCamera> camera(CreatePerspectiveCamera(ro.CameraParams, ro.CameraToWorld[0], film, ro.CameraName == "orthographic"));
     ro.CameraParams.ReportUnused();
     if (ro.SamplerName != "halton")
         Error("Sampler \"%s\" is outside this build's closed set (halton); using halton with the same \"pixelsamples\".", ro.SamplerName.c_str());

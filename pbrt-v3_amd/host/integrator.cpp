@@ -17,7 +17,7 @@
 
 namespace pbrt {
 
-PerspectiveCamera *CreatePerspectiveCamera(const ParamSet &params, const Transform &cam2world, Film *film) {
+PerspectiveCamera *CreatePerspectiveCamera(const ParamSet &params, const Transform &cam2world, Film *film, bool orthographic) {
     Float shutteropen = params.FindOneFloat("shutteropen", 0.f);
     Float shutterclose = params.FindOneFloat("shutterclose", 1.f);
     if (shutterclose < shutteropen) {
@@ -35,16 +35,21 @@ PerspectiveCamera *CreatePerspectiveCamera(const ParamSet &params, const Transfo
         if (sw->size() == 4) { sxmin = (*sw)[0]; sxmax = (*sw)[1]; symin = (*sw)[2]; symax = (*sw)[3]; }
         else Error("\"screenwindow\" should have four values");
     }
-    Float fov = params.FindOneFloat("fov", 90.);
-    Float halffov = params.FindOneFloat("halffov", -1.f);
-    if (halffov > 0.f) fov = 2.f * halffov;
+    Float fov = 90.f;
+    if (!orthographic) {  // perspective.cpp:253-257
+        fov = params.FindOneFloat("fov", 90.);
+        Float halffov = params.FindOneFloat("halffov", -1.f);
+        if (halffov > 0.f) fov = 2.f * halffov;
+    }
     PerspectiveCamera *cam = new PerspectiveCamera;
+    cam->orthographic = orthographic;
     cam->film.reset(film);
     cam->CameraToWorld = cam2world;
     cam->lensRadius = lensradius; cam->focalDistance = focaldistance;
     cam->shutterOpen = shutteropen; cam->shutterClose = shutterclose;
     // ProjectiveCamera ctor, camera.h:98-107
-    Transform CameraToScreen = Perspective(fov, 1e-2f, 1000.f);
+    // perspective.cpp:52 Perspective(fov, 1e-2f, 1000.f); orthographic.cpp:53 Orthographic(0, 1) = Scale(1, 1, 1/(1-0)) * Translate(0, 0, -0)
+    Transform CameraToScreen = orthographic ? Scale(1, 1, 1 / (1.f - 0.f)) * Translate(Vector3f(0, 0, -0.f)) : Perspective(fov, 1e-2f, 1000.f);
     Transform ScreenToRaster = Scale(film->fullResolution[0], film->fullResolution[1], 1) *
                                Scale(1 / (sxmax - sxmin), 1 / (symin - symax), 1) *
                                Translate(Vector3f(-sxmin, -symax, 0));
@@ -249,6 +254,7 @@ void GpuPathIntegrator::FillRenderDesc(PgRenderDesc *rd) const {
     memset(rd, 0, sizeof(*rd));
     rd->abi_version = PG_ABI_VERSION;
     const Film &film = *camera->film;
+    rd->camera_type = camera->orthographic ? 1 : 0;
     memcpy(rd->raster_to_camera, camera->RasterToCamera.GetMatrix().m, 16 * sizeof(float));
     memcpy(rd->camera_to_world, camera->CameraToWorld.GetMatrix().m, 16 * sizeof(float));
     rd->lens_radius = camera->lensRadius; rd->focal_distance = camera->focalDistance;

@@ -100,12 +100,13 @@ bool SetFilmFilter(Film *film, const std::string &name, const ParamSet &params);
 void FilterRadiusFor(const std::string &name, const ParamSet &params, Float *xw, Float *yw);
 bool WriteImagePFM(const std::string &filename, const Float *rgb, int width, int height);  // imageio.cpp:437-482
 
-struct PerspectiveCamera {  // cameras/perspective.cpp:45-68, core/camera.h:87-108
+struct PerspectiveCamera {  // ProjectiveCamera (core/camera.h:87-108): cameras/perspective.cpp:45-68 or orthographic.cpp:44-62
+    bool orthographic = false;
     Transform CameraToWorld, RasterToCamera;
     Float lensRadius, focalDistance, shutterOpen, shutterClose;
     std::unique_ptr<Film> film;
 };
-PerspectiveCamera *CreatePerspectiveCamera(const ParamSet &params, const Transform &cam2world, Film *film);
+PerspectiveCamera *CreatePerspectiveCamera(const ParamSet &params, const Transform &cam2world, Film *film, bool orthographic = false);
 
 struct HaltonSampler {  // samplers/halton.cpp:65-92
     int samplesPerPixel;
