@@ -253,7 +253,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
     }
 }
 
-static TraceConfig g_cfg = {10, 128, 8, 8, 1.0009765625f, 2048};
+static TraceConfig g_cfg = {11, 128, 8, 8, 1.0009765625f, 2048};  // depth 11: 7 resident blocks x 22.5 KB of stack fill the 160 KB LDS
 void set_trace_config(const TraceConfig &c) { g_cfg = c; }
 TraceConfig get_trace_config() { return g_cfg; }
 
