@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 4
+#define PG_ABI_VERSION 5
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -87,7 +87,8 @@ typedef enum PgLightType {
     PG_LIGHT_AREA = 0,   /* DiffuseAreaLight on triangle `prim`           */
     PG_LIGHT_POINT = 1,
     PG_LIGHT_SPOT = 2,
-    PG_LIGHT_DISTANT = 3
+    PG_LIGHT_DISTANT = 3,
+    PG_LIGHT_INFINITE = 4 /* InfiniteAreaLight with constant radiance (lights/infinite.cpp, no "mapname") */
 } PgLightType;
 
 typedef struct PgLight {
@@ -99,7 +100,13 @@ typedef struct PgLight {
     float pos[3];      /* point/spot: pLight (world); distant: wLight (unit, world) */
     float w2l[9];      /* spot: upper 3x3 of WorldToLight, row-major (Falloff)      */
     float cos_total_width, cos_falloff_start; /* spot (spot.cpp:48-49)              */
-    float world_radius; /* distant: Preprocess()'s bounding-sphere radius (distant.h:55-57) */
+    float world_radius; /* distant, infinite: Preprocess()'s bounding-sphere radius (distant.h:55-57) */
+    /* infinite (constant L => a 1x1 Lmap): upper 3x3 of LightToWorld, and the 2x2 Distribution2D the constructor builds
+     * from Lmap lookups * sin(theta) (infinite.cpp:66-84): per row v the function values, cdf and integral, then the
+     * marginal over rows (sampling.cpp:159-171, sampling.h:57-70).                                                     */
+    float l2w[9];
+    float env_func[2][2], env_cdf[2][3], env_int[2];
+    float env_marg_cdf[3], env_marg_int;
 } PgLight;
 
 typedef enum PgLightStrategy {

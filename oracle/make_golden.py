@@ -188,6 +188,16 @@ SCENES = {
     # OrthographicCamera (orthographic.cpp), plain and with a thin lens and a screen window
     "cornell_ortho": cornell(24, 24, 8).replace('Camera "perspective" "float fov" [ 39.3 ]', 'Camera "orthographic" "float screenwindow" [ -300 300 -290 310 ]'),
     "cornell_ortho_lens": cornell(20, 28, 8).replace('Camera "perspective" "float fov" [ 39.3 ]', 'Camera "orthographic" "float screenwindow" [ -280 280 -280 280 ] "float lensradius" [ 12 ] "float focaldistance" [ 1100 ]'),
+    # InfiniteAreaLight with constant radiance (infinite.cpp): alone (camera rays that escape see it, MIS against BSDF samples
+    # that escape), rotated, and mixed with area + spot lights under the power strategy with mirror/glass (specular escapes)
+    "env_only": cornell(32, 32, 8, world_edit=lambda s: s.replace("  AreaLightSource", "#  AreaLightSource")
+                        .replace("# light\nAttributeBegin", 'AttributeBegin\n  Rotate 30 1 0.3 0\n  LightSource "infinite" "rgb L" [ 0.6 0.8 1.2 ] "rgb scale" [ 1.5 1.5 1.5 ]\nAttributeEnd\n# light\nAttributeBegin')),
+    "env_mixed_power": cornell(24, 24, 8, integrator='Integrator "path" "integer maxdepth" [ 6 ] "string lightsamplestrategy" "power"',
+                               world_edit=lambda s: s.replace("# light\nAttributeBegin", 'LightSource "infinite" "rgb L" [ 0.3 0.3 0.35 ]\n' + DELTA_SPOT + "# light\nAttributeBegin")
+                               .replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\nMaterial "glass"').replace("# tall box", 'Material "mirror"\n# tall box')),
+    "env_uniform_open": cornell(24, 24, 8, integrator='Integrator "path" "integer maxdepth" [ 4 ] "string lightsamplestrategy" "uniform"',
+                                world_edit=lambda s: s.replace("# light\nAttributeBegin", 'LightSource "infinite"\n# light\nAttributeBegin')
+                                .replace('Shape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ]\n  "point P" [ 556 548.8 0   556 548.8 559.2   0 548.8 559.2   0 548.8 0 ]', "")),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 

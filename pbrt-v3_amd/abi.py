@@ -5,12 +5,12 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 4
+PG_ABI_VERSION = 5
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
 PG_LIGHTS_UNIFORM, PG_LIGHTS_POWER, PG_LIGHTS_SPATIAL = 0, 1, 2
 PG_MAT_NONE, PG_MAT_MATTE, PG_MAT_PLASTIC, PG_MAT_MIRROR, PG_MAT_GLASS = 0, 1, 2, 3, 4
-PG_LIGHT_AREA, PG_LIGHT_POINT, PG_LIGHT_SPOT, PG_LIGHT_DISTANT = 0, 1, 2, 3
+PG_LIGHT_AREA, PG_LIGHT_POINT, PG_LIGHT_SPOT, PG_LIGHT_DISTANT, PG_LIGHT_INFINITE = 0, 1, 2, 3, 4
 PG_TRI_FLIP_NORMAL, PG_TRI_REVERSE_ORIENTATION, PG_TRI_HAS_N, PG_TRI_HAS_UV, PG_TRI_HAS_S = 1, 2, 4, 8, 16
 
 
@@ -28,7 +28,8 @@ class PgMaterial(C.Structure):
 class PgLight(C.Structure):
     _fields_ = [("type", C.c_int32), ("prim", C.c_int32), ("L", C.c_float * 3), ("two_sided", C.c_int32), ("area", C.c_float),
                 ("pos", C.c_float * 3), ("w2l", C.c_float * 9), ("cos_total_width", C.c_float), ("cos_falloff_start", C.c_float),
-                ("world_radius", C.c_float)]
+                ("world_radius", C.c_float), ("l2w", C.c_float * 9), ("env_func", C.c_float * 4), ("env_cdf", C.c_float * 6),
+                ("env_int", C.c_float * 2), ("env_marg_cdf", C.c_float * 3), ("env_marg_int", C.c_float)]
 
 
 class PgSceneDesc(C.Structure):

@@ -226,8 +226,11 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         }
         m.roughness = (0.001f < rough) ? rough : 0.001f;  // TrowbridgeReitzDistribution ctor: std::max(Float(0.001), alpha)
     }
+    d.hasInfinite = 0;
     for (int i = 0; i < desc->n_lights; ++i)
-        if (desc->lights[i].type < PG_LIGHT_AREA || desc->lights[i].type > PG_LIGHT_DISTANT) FAIL(PG_ERR_UNSUPPORTED, "light %d: unknown type %d", i, desc->lights[i].type);
+        if (desc->lights[i].type == PG_LIGHT_INFINITE) d.hasInfinite = 1;
+    for (int i = 0; i < desc->n_lights; ++i)
+        if (desc->lights[i].type < PG_LIGHT_AREA || desc->lights[i].type > PG_LIGHT_INFINITE) FAIL(PG_ERR_UNSUPPORTED, "light %d: unknown type %d", i, desc->lights[i].type);
         else if (desc->lights[i].type == PG_LIGHT_AREA && (desc->lights[i].prim < 0 || desc->lights[i].prim >= nt))
             FAIL(PG_ERR_INVALID, "light %d has no emitting triangle", i);
     HIP_TRY_S(s->materials.alloc(sizeof(PgMaterial) * (size_t)desc->n_materials));
@@ -296,6 +299,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
                         if (l.type == PG_LIGHT_POINT) v *= 4 * PG_PI;
                         else if (l.type == PG_LIGHT_SPOT) { v *= 2; v *= PG_PI; v *= (1 - .5f * (l.cos_falloff_start + l.cos_total_width)); }
                         else if (l.type == PG_LIGHT_DISTANT) { v *= PG_PI; v *= l.world_radius; v *= l.world_radius; }
+                        else if (l.type == PG_LIGHT_INFINITE) v = v * (PG_PI * l.world_radius * l.world_radius);  // Lookup((.5,.5), .5) == L, infinite.cpp:87-91
                         else { v *= (float)(l.two_sided ? 2 : 1); v *= l.area; v *= PG_PI; }
                         P[c] = v;
                     }

@@ -31,6 +31,7 @@ struct DScene {
     const PgMaterial *materials;
     const PgLight *lights;
     int nNodes, nTris, nLights, nMaterials;
+    int hasInfinite;  // some light is an InfiniteAreaLight (Scene::infiniteLights non-empty)
     // light sampling distributions (lightdistrib.cpp): strategy + tables
     int lightStrategy;
     int nVoxels[3];

@@ -541,7 +541,73 @@ PG_DEV float spot_falloff(const PgLight &l, V3 w) {
     float delta = (cosTheta - l.cos_total_width) / (l.cos_falloff_start - l.cos_total_width);
     return (delta * delta) * (delta * delta);
 }
+// ---- InfiniteAreaLight with constant radiance: Lmap is a 1x1 MIPMap (lights/infinite.cpp, core/mipmap.h:245-274).
+// sinf/cosf/acosf/atan2f of the reference (glibc) are matched by evaluating in double and rounding once.
+PG_DEV V3 mat3_mul(const float *m, V3 w) {  // Transform::operator()(Vector3), transform.h:233-239
+    return mk(m[0] * w.x + m[1] * w.y + m[2] * w.z, m[3] * w.x + m[4] * w.y + m[5] * w.z, m[6] * w.x + m[7] * w.y + m[8] * w.z);
+}
+PG_DEV Spec env_lookup(const PgLight &l, float s0_, float t0_) {  // MIPMap::Lookup(st, 0) -> triangle(0, st); every texel is L
+    float s = s0_ * 1 - 0.5f, t = t0_ * 1 - 0.5f;
+    int s0 = (int)floorf(s), t0 = (int)floorf(t);
+    float ds = s - s0, dt = t - t0;
+    const Spec L = sp3(l.L[0], l.L[1], l.L[2]);
+    Spec r = L * ((1 - ds) * (1 - dt));
+    r = r + L * ((1 - ds) * dt);
+    r = r + L * (ds * (1 - dt));
+    r = r + L * (ds * dt);
+    return r;
+}
+#define PG_INV2PI 0.15915494309189533577f
+PG_DEV float spherical_theta(V3 v) { return (float)acos((double)clampf(v.z, -1, 1)); }  // geometry.h:1468-1470
+PG_DEV float spherical_phi(V3 v) { float p = (float)atan2((double)v.y, (double)v.x); return (p < 0) ? (p + 2 * PG_PI) : p; }  // :1472-1475
+PG_DEV Spec env_le(const PgLight &l, V3 rayD) {  // InfiniteAreaLight::Le, infinite.cpp:93-97
+    V3 w = normalize(mat3_mul(l.w2l, rayD));
+    return env_lookup(l, spherical_phi(w) * PG_INV2PI, spherical_theta(w) * PG_INVPI);
+}
+PG_DEV float env_sample_1d(const float *func, const float *cdf, float funcInt, float u, float &pdf, int *off) {  // sampling.h:72-89, n = 2
+    int size = 3, first = 0, len = size;
+    while (len > 0) {
+        int half = len >> 1, middle = first + half;
+        if (cdf[middle] <= u) { first = middle + 1; len -= half + 1; } else len = half;
+    }
+    int offset = first - 1; offset = offset < 0 ? 0 : (offset > size - 2 ? size - 2 : offset);
+    if (off) *off = offset;
+    float du = u - cdf[offset];
+    if ((cdf[offset + 1] - cdf[offset]) > 0) du /= (cdf[offset + 1] - cdf[offset]);
+    pdf = (funcInt > 0) ? func[offset] / funcInt : 0;
+    return (offset + du) / 2;
+}
+PG_DEV float env_pdf_li(const PgLight &l, V3 w) {  // InfiniteAreaLight::Pdf_Li, infinite.cpp:127-135; Distribution2D::Pdf, sampling.h:135-141
+    V3 wi = mat3_mul(l.w2l, w);
+    float theta = spherical_theta(wi), phi = spherical_phi(wi);
+    float sinTheta = (float)sin((double)theta);
+    if (sinTheta == 0) return 0;
+    float p0 = phi * PG_INV2PI, p1 = theta * PG_INVPI;
+    int iu = (int)(p0 * 2); iu = iu < 0 ? 0 : (iu > 1 ? 1 : iu);
+    int iv = (int)(p1 * 2); iv = iv < 0 ? 0 : (iv > 1 ? 1 : iv);
+    return (l.env_func[iv][iu] / l.env_marg_int) / (2 * PG_PI * PG_PI * sinTheta);
+}
 PG_DEV Spec light_sample_li(const DScene &sc, const PgLight &light, V3 refp, float u0, float u1, V3 &wi, float &pdf, LightSample &ls) {
+    if (light.type == PG_LIGHT_INFINITE) {  // InfiniteAreaLight::Sample_Li, infinite.cpp:99-125
+        float pdf0, pdf1;
+        int v;
+        float d1 = env_sample_1d(light.env_int, light.env_marg_cdf, light.env_marg_int, u1, pdf1, &v);
+        float d0 = env_sample_1d(light.env_func[v], light.env_cdf[v], light.env_int[v], u0, pdf0, nullptr);
+        float mapPdf = pdf0 * pdf1;
+        ls.n = mk(0, 0, 0); ls.pError = mk(0, 0, 0); ls.p = refp;
+        pdf = 0;
+        if (mapPdf == 0) return sp(0);
+        float theta = d1 * PG_PI, phi = d0 * 2 * PG_PI;
+        double sT, cT, sP, cP;
+        sincos((double)theta, &sT, &cT);
+        sincos((double)phi, &sP, &cP);
+        float cosTheta = (float)cT, sinTheta = (float)sT, sinPhi = (float)sP, cosPhi = (float)cP;
+        wi = mat3_mul(light.l2w, mk(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta));
+        pdf = mapPdf / (2 * PG_PI * PG_PI * sinTheta);
+        if (sinTheta == 0) pdf = 0;
+        ls.p = refp + wi * (2 * light.world_radius);
+        return env_lookup(light, d0, d1);
+    }
     if (light.type != PG_LIGHT_AREA) {  // delta lights: point.cpp:43-52, spot.cpp:51-60, distant.cpp:50-60
         const Spec I = sp3(light.L[0], light.L[1], light.L[2]);
         const V3 pos = mk(light.pos[0], light.pos[1], light.pos[2]);
@@ -659,6 +725,10 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
             Spec Le = (l.two_sided || dot(nrm, -rayD) > 0) ? sp3(l.L[0], l.L[1], l.L[2]) : sp(0);
             L = L + beta * Le;
         } else if ((bounces == 0 || specularBounce) && found) L = L + beta * sp(0);
+        else if ((bounces == 0 || specularBounce) && !found && sc.hasInfinite) {  // path.cpp:96-100: every infinite light's Le(ray)
+            for (int li = 0; li < sc.nLights; ++li)
+                if (sc.lights[li].type == PG_LIGHT_INFINITE) L = L + beta * env_le(sc.lights[li], rayD);
+        }
         bool alive = found && bounces < rd.max_depth;  // path.cpp:104
         int newFlags = 0;
         if (alive) {
@@ -729,8 +799,8 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                                 s_ray[1][1][tid] = make_float4(shD.x, shD.y, shD.z, __int_as_float(slot));
                                 pushShadow = true;
                                 // delta lights take no MIS weight (integrator.cpp:155-160)
-                                Spec c = light.type != PG_LIGHT_AREA ? (f * Li) / lightPdf
-                                                                     : ((f * Li) * power_heuristic(1, lightPdf, 1, scatteringPdf)) / lightPdf;
+                                const bool isDelta = light.type == PG_LIGHT_POINT || light.type == PG_LIGHT_SPOT || light.type == PG_LIGHT_DISTANT;
+                                Spec c = isDelta ? (f * Li) / lightPdf : ((f * Li) * power_heuristic(1, lightPdf, 1, scatteringPdf)) / lightPdf;
                                 pdLight = make_float4(c.r, c.g, c.b, 0);
                             }
                         }
@@ -739,7 +809,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                         V3 wi2 = wi;
                         float sPdf2 = 0;
                         Spec f2 = sp(0);
-                        if (light.type == PG_LIGHT_AREA) {  // integrator.cpp:164: if (!IsDeltaLight(light.flags))
+                        if (light.type == PG_LIGHT_AREA || light.type == PG_LIGHT_INFINITE) {  // integrator.cpp:164: if (!IsDeltaLight(light.flags))
                             f2 = bsdf_sample_f(bsdf, is.wo, wi2, uS0, uS1, sPdf2);
                             f2 = f2 * absdot(wi2, bsdf.ns);
                         }
@@ -747,7 +817,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                             misCand = true;
                             spawn_ray(is, wi2, misRo);
                             misWi = wi2; misF = f2; misPdf = sPdf2; misP = is.p;
-                            misLightPrim = light.prim; misLightArea = light.area;
+                            misLightPrim = light.type == PG_LIGHT_INFINITE ? -1 - lightNum : light.prim; misLightArea = light.area;
                         }
                         // pending terms of this vertex, consumed by k_resolve (pdMis and the MIS weight follow below)
                         pdLight.w = lightSelPdf;
@@ -790,11 +860,12 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
     }
     if (misCand) {
         // light.Pdf_Li -> Shape::Pdf(ref, wi): intersect the light's own triangle (shape.cpp:72-87, diffuse.cpp:83-87)
-        Tri lt = load_tri(sc, misLightPrim);
-        float t, lb0, lb1, lb2;
-        ++nLightTests;
         float lightPdf2 = 0;
-        if (tri_test(lt.p0, lt.p1, lt.p2, misRo, misWi, PG_INF, t, lb0, lb1, lb2) && !(lt.flags & PG_TRI_BOGUS)) {
+        if (misLightPrim < 0) lightPdf2 = env_pdf_li(sc.lights[-1 - misLightPrim], misWi);  // infinite light: no geometry to test
+        Tri lt = load_tri(sc, misLightPrim < 0 ? 0 : misLightPrim);
+        float t, lb0, lb1, lb2;
+        if (misLightPrim >= 0) ++nLightTests;
+        if (misLightPrim >= 0 && tri_test(lt.p0, lt.p1, lt.p2, misRo, misWi, PG_INF, t, lb0, lb1, lb2) && !(lt.flags & PG_TRI_BOGUS)) {
             V3 lp = lt.p0 * lb0 + lt.p1 * lb1 + lt.p2 * lb2;
             V3 ln = normalize(cross(lt.p0 - lt.p2, lt.p1 - lt.p2));
             float pdf = lensq(misP - lp) / (absdot(ln, -misWi) * misLightArea);
@@ -853,6 +924,10 @@ __global__ __launch_bounds__(PG_BLOCK) void k_resolve(DScene sc, PathState st, R
                 Spec Li = (l.two_sided || dot(nrm, -wi) > 0) ? sp3(l.L[0], l.L[1], l.L[2]) : sp(0);
                 if (!is_black(Li)) Ld = Ld + ((((sp3(pm.x, pm.y, pm.z) * Li) * sp(1.f)) * pb.w) / pm.w);
             }
+        } else if (sc.lights[info.z].type == PG_LIGHT_INFINITE) {  // integrator.cpp:207-208: no surface hit: Li = light.Le(ray)
+            const float4 d4 = qmis.d[info.y];
+            Spec Li = env_le(sc.lights[info.z], mk(d4.x, d4.y, d4.z));
+            if (!is_black(Li)) Ld = Ld + ((((sp3(pm.x, pm.y, pm.z) * Li) * sp(1.f)) * pb.w) / pm.w);
         }
     }
     float4 L4 = st.L[slot];

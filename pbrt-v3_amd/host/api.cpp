@@ -439,8 +439,50 @@ void pbrtLightSource(const std::string &name, const ParamSet &params) {
         for (int i = 0; i < 3; ++i) l.L[i] = L.c[i] * sc.c[i];
         l.pos[0] = wLight.x; l.pos[1] = wLight.y; l.pos[2] = wLight.z;
         // world_radius is filled in when the scene is flattened (DistantLight::Preprocess needs the world bound)
+    } else if (name == "infinite" || name == "exinfinite") {  // CreateInfiniteLight, infinite.cpp:176-188; ctor :44-85
+        RGB L = params.FindOneSpectrum("L", RGB{{1.f, 1.f, 1.f}});
+        params.FindOneInt("samples", params.FindOneInt("nsamples", 1));
+        if (!params.FindOneString("mapname", "").empty())
+            Error("Environment maps (\"mapname\") are not supported by this build; using the constant radiance \"L\".");
+        l.type = PG_LIGHT_INFINITE;
+        for (int i = 0; i < 3; ++i) l.L[i] = L.c[i] * sc.c[i];
+        const Matrix4x4 &m = light2world.GetMatrix(), &mi = light2world.GetInverseMatrix();
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { l.l2w[3 * r + c] = m.m[r][c]; l.w2l[3 * r + c] = mi.m[r][c]; }
+        // Lmap is the 1x1 MIPMap of L; img[u + v*2] = Lmap->Lookup((u+.5)/2, (v+.5)/2, fwidth = 0.25).y() * sin(Pi*(v+.5)/2)
+        const int width = 2, height = 2;
+        float fwidth = 0.5f / std::min(width, height);
+        (void)fwidth;  // level = Log2(0.25) < 0: MIPMap::Lookup takes the triangle(0, st) branch (mipmap.h:245-274)
+        Float img[4];
+        for (int v = 0; v < height; ++v) {
+            Float vp = (v + .5f) / (Float)height;
+            Float sinTheta = std::sin(Pi * (v + .5f) / height);
+            for (int u = 0; u < width; ++u) {
+                Float up = (u + .5f) / (Float)width;
+                // triangle(0, (up, vp)) on a 1x1 texture: every Texel() is L
+                Float s_ = up * 1 - 0.5f, t_ = vp * 1 - 0.5f;
+                int s0 = (int)std::floor(s_), t0 = (int)std::floor(t_);
+                Float ds = s_ - s0, dt = t_ - t0;
+                Float rgb[3];
+                for (int c = 0; c < 3; ++c)
+                    rgb[c] = (1 - ds) * (1 - dt) * l.L[c] + (1 - ds) * dt * l.L[c] + ds * (1 - dt) * l.L[c] + ds * dt * l.L[c];
+                Float y = 0.212671f * rgb[0] + 0.715160f * rgb[1] + 0.072169f * rgb[2];
+                img[u + v * width] = y;
+                img[u + v * width] *= sinTheta;
+            }
+        }
+        auto dist1d = [](const Float *f, int n, Float *func, Float *cdf, Float *funcInt) {  // Distribution1D ctor, sampling.h:57-70
+            for (int i = 0; i < n; ++i) func[i] = f[i];
+            cdf[0] = 0;
+            for (int i = 1; i < n + 1; ++i) cdf[i] = cdf[i - 1] + func[i - 1] / n;
+            *funcInt = cdf[n];
+            if (*funcInt == 0) { for (int i = 1; i < n + 1; ++i) cdf[i] = Float(i) / Float(n); }
+            else { for (int i = 1; i < n + 1; ++i) cdf[i] /= *funcInt; }
+        };
+        for (int v = 0; v < 2; ++v) dist1d(&img[2 * v], 2, l.env_func[v], l.env_cdf[v], &l.env_int[v]);
+        Float margFunc[2];
+        dist1d(l.env_int, 2, margFunc, l.env_marg_cdf, &l.env_marg_int);
     } else {
-        Error("LightSource \"%s\" is outside this build's closed set (point, spot, distant, and diffuse area lights); ignoring.", name.c_str());
+        Error("LightSource \"%s\" is outside this build's closed set (point, spot, distant, infinite, and diffuse area lights); ignoring.", name.c_str());
         return;
     }
     params.ReportUnused();

@@ -224,7 +224,7 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
         bool inside = center.x >= pMin.x && center.x <= pMax.x && center.y >= pMin.y && center.y <= pMax.y && center.z >= pMin.z &&
                       center.z <= pMax.z;
         Float radius = inside ? (center - pMax).Length() : 0;
-        for (PgLight &l : flat->lights) if (l.type == PG_LIGHT_DISTANT) l.world_radius = radius;
+        for (PgLight &l : flat->lights) if (l.type == PG_LIGHT_DISTANT || l.type == PG_LIGHT_INFINITE) l.world_radius = radius;
     }
     // dimensions a path can consume: 5 camera + per bounce (1+2+2 direct, 2 bsdf, 1 rr); 1000 max (halton.h:71-76)
     int nDims = std::min(1000, 5 + 8 * (maxDepth + 2));

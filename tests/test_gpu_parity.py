@@ -36,7 +36,7 @@ def test_golden_images(gpu, name):
         assert abs(cn[k] - stats[k]) <= max(4, 2e-3 * stats[k]), (k, cn[k], stats[k])
 
 
-@pytest.mark.parametrize("name", ["cornell_32", "cornell_crop", "synthetic_n40", "cornell_lens", "cornell_plastic", "plastic_topdown", "cornell_normals", "cornell_tangents", "cornell_lightnormals", "cornell_point", "cornell_spot_power", "cornell_delta_only", "cornell_mirror_glass", "cornell_glass_eta", "filter_gaussian", "filter_mitchell_crop", "filter_widebox", "cornell_orennayar", "cornell_ortho_lens", "cornell_loopsubdiv"])
+@pytest.mark.parametrize("name", ["cornell_32", "cornell_crop", "synthetic_n40", "cornell_lens", "cornell_plastic", "plastic_topdown", "cornell_normals", "cornell_tangents", "cornell_lightnormals", "cornell_point", "cornell_spot_power", "cornell_delta_only", "cornell_mirror_glass", "cornell_glass_eta", "filter_gaussian", "filter_mitchell_crop", "filter_widebox", "cornell_orennayar", "cornell_ortho_lens", "cornell_loopsubdiv", "env_only", "env_mixed_power", "env_uniform_open"])
 def test_film_buffers_vs_oracle(gpu, oracle, name):
     scene = gpu.HostScene(os.path.join(GOLD, name + ".pbrt"))
     gs = gpu.GpuScene(scene.desc)
