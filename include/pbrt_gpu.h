@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 5
+#define PG_ABI_VERSION 6
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -59,6 +59,7 @@ typedef struct PgBVHNode {
 #define PG_TRI_HAS_N 4u       /* mesh has per-vertex shading normals  */
 #define PG_TRI_HAS_UV 8u      /* mesh has per-vertex uv               */
 #define PG_TRI_HAS_S 16u      /* mesh has per-vertex tangents         */
+#define PG_PRIM_SPHERE 32u    /* not a triangle: spheres[indices[3*k]] (PgSphere below) */
 
 typedef enum PgMaterialType {
     PG_MAT_NONE = 0,   /* no material: primitive is a medium boundary (bsdf == nullptr) */
@@ -115,6 +116,16 @@ typedef enum PgLightStrategy {
     PG_LIGHTS_SPATIAL = 2
 } PgLightStrategy;
 
+/* A Sphere shape (shapes/sphere.h:46-79), kept in object space as the reference keeps it.  A primitive k with
+ * PG_PRIM_SPHERE set in tri_flags[k] is spheres[indices[3*k]]; its tri_material / tri_light entries mean what they mean
+ * for a triangle, and an area light whose `prim` is such a primitive samples the sphere (sphere.cpp:205-304). */
+typedef struct PgSphere {
+    float o2w[16], w2o[16];     /* ObjectToWorld / WorldToObject, row-major (its m and mInv, transform.h:112-205) */
+    float radius, z_min, z_max, theta_min, theta_max, phi_max; /* as the constructor clamps them, sphere.h:50-60 */
+    int32_t reverse_orientation;/* Shape::reverseOrientation               */
+    int32_t swaps_handedness;   /* Shape::transformSwapsHandedness         */
+} PgSphere;
+
 typedef struct PgSceneDesc {
     int32_t abi_version;        /* PG_ABI_VERSION */
     /* acceleration structure, BVHAccel after flattenBVHTree (bvh.cpp:640-658) */
@@ -142,6 +153,8 @@ typedef struct PgSceneDesc {
     int32_t n_perm_dims;
     const uint16_t *perms;
     const int32_t *perm_sums;   /* n_perm_dims+1 entries */
+    int32_t n_spheres;
+    const PgSphere *spheres;
 } PgSceneDesc;
 
 /* ---- render description -------------------------------------------------- */

@@ -37,6 +37,18 @@ DELTA_SPOT = ('AttributeBegin\n  Rotate 10 0 0 1\n  LightSource "spot" "point fr
 DELTA_DISTANT = 'LightSource "distant" "point from" [ 0.3 1 -0.6 ] "point to" [ 0 0 0 ] "rgb L" [ 0.6 0.7 0.9 ]\n'
 
 
+SPHERES = ('AttributeBegin\n  Translate 420 60 120\n  Material "matte" "rgb Kd" [ 0.2 0.3 0.7 ]\n  Shape "sphere" "float radius" [ 60 ]\nAttributeEnd\n'
+           'AttributeBegin\n  Translate 130 380 330\n  Material "mirror"\n  Shape "sphere" "float radius" [ 70 ]\nAttributeEnd\n'
+           'AttributeBegin\n  Translate 300 250 80\n  Material "glass" "float index" [ 1.5 ]\n  Shape "sphere" "float radius" [ 45 ]\nAttributeEnd\n')
+SPHERES_PARTIAL = ('AttributeBegin\n  Translate 400 120 150\n  Rotate 40 1 0.2 0.1\n  Scale 1 1.4 0.7\n  Material "plastic" "rgb Kd" [ 0.6 0.3 0.1 ]\n'
+                   '  Shape "sphere" "float radius" [ 80 ] "float zmin" [ -50 ] "float zmax" [ 60 ] "float phimax" [ 250 ]\nAttributeEnd\n'
+                   'AttributeBegin\n  Translate 150 420 300\n  Rotate -70 1 0 0\n  ReverseOrientation\n  AreaLightSource "diffuse" "rgb L" [ 9 9 12 ] "bool twosided" "true"\n'
+                   '  Shape "sphere" "float radius" [ 50 ] "float zmin" [ -20 ] "float phimax" [ 300 ]\nAttributeEnd\n'
+                   'AttributeBegin\n  Translate 500 500 500\n  AreaLightSource "area" "rgb L" [ 4000 3000 2000 ]\n  Shape "sphere" "float radius" [ 2 ]\nAttributeEnd\n')
+SPHERE_ENCLOSING = ('AttributeBegin\n  Translate 278 273 100\n  ReverseOrientation\n  AreaLightSource "diffuse" "rgb L" [ 0.5 0.6 0.8 ]\n'
+                    '  Shape "sphere" "float radius" [ 1500 ]\nAttributeEnd\n')
+
+
 def with_normals(s, tangents=False, uv=False):
     """Give both Cornell boxes smooth-ish per-vertex normals (outward from the box centre, one of them zero), optionally
     tangents and a uv parameterisation."""
@@ -197,6 +209,18 @@ SCENES = {
                                .replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\nMaterial "glass"').replace("# tall box", 'Material "mirror"\n# tall box')),
     "env_uniform_open": cornell(24, 24, 8, integrator='Integrator "path" "integer maxdepth" [ 4 ] "string lightsamplestrategy" "uniform"',
                                 world_edit=lambda s: s.replace("# light\nAttributeBegin", 'LightSource "infinite"\n# light\nAttributeBegin')
+                                .replace('Shape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ]\n  "point P" [ 556 548.8 0   556 548.8 559.2   0 548.8 559.2   0 548.8 0 ]', "")),
+    # Shape "sphere" (sphere.cpp): as the area light (cone sampling of the subtended solid angle, Sphere::Pdf in the MIS) with
+    # matte / mirror / glass spheres in the room; partial spheres (zmin/zmax/phimax) under a non-uniform transform with
+    # reversed orientation, a tiny far-away emitter (the small-angle Taylor branch) and the quad under the spatial strategy;
+    # and an emitting sphere that encloses the whole room (reference points inside it: area sampling + Shape::Pdf)
+    "sphere_light": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 6 ]', world_edit=lambda s: s.replace(
+        'Shape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ]\n  "point P" [ 343 548.7 227   343 548.7 332   213 548.7 332   213 548.7 227 ]',
+        'Translate 278 480 280\n  Shape "sphere" "float radius" [ 35 ]')
+        .replace("# short box", SPHERES + "# short box")),
+    "sphere_partial": cornell(32, 32, 8, world_edit=lambda s: s.replace("# light\nAttributeBegin", SPHERES_PARTIAL + "# light\nAttributeBegin")),
+    "sphere_enclosing": cornell(24, 24, 8, integrator='Integrator "path" "integer maxdepth" [ 3 ] "string lightsamplestrategy" "power"',
+                                world_edit=lambda s: s.replace("# light\nAttributeBegin", SPHERE_ENCLOSING + "# light\nAttributeBegin")
                                 .replace('Shape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ]\n  "point P" [ 556 548.8 0   556 548.8 559.2   0 548.8 559.2   0 548.8 0 ]', "")),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }

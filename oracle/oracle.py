@@ -13,8 +13,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "liboracle.so")
+CR_LIB_PATH = os.path.join(_HERE, "liboracle_crlibm.so")  # same source, correctly rounded float libm (see pbrt_oracle.c)
 REF_BINARY = os.path.join(_HERE, "_ref", "pbrt_oracle")
 _lib = None
+_libs = {}
 
 
 def _pkg():
@@ -23,14 +25,18 @@ def _pkg():
     return load_package()
 
 
-def lib():
+def lib(cr_libm=False):
+    """liboracle.so, or with cr_libm=True its correctly-rounded-libm build (the device's libm behaviour)."""
     global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            subprocess.check_call(["make", "-C", _HERE, "liboracle.so"])
+    path = CR_LIB_PATH if cr_libm else LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if True:
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", _HERE, os.path.basename(path)])
         pkg = _pkg()
         abi = pkg.abi
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         L.oracle_render_tile_count.restype = C.c_int
         L.oracle_render_tile_count.argtypes = [C.POINTER(abi.PgRenderDesc)]
         L.oracle_render.restype = C.c_int
@@ -52,14 +58,16 @@ def lib():
         L.oracle_triangle_intersect.argtypes = [C.c_void_p] * 5 + [C.c_float, C.POINTER(C.c_float), C.c_void_p]
         L.oracle_spawn_ray_origin.restype = None
         L.oracle_spawn_ray_origin.argtypes = [C.c_void_p] * 5
-        _lib = L
-    return _lib
+        _libs[path] = L
+        if not cr_libm:
+            _lib = L
+    return _libs[path]
 
 
-def render(desc, rd, max_strays=None):
+def render(desc, rd, max_strays=None, cr_libm=False):
     """oracle_render: same outputs as pg_render (film, strays) plus the reference's counters."""
     pkg = _pkg()
-    L = lib()
+    L = lib(cr_libm)
     n = L.oracle_render_tile_count(C.byref(rd))
     if max_strays is None:
         max_strays = n * 256 // 8 + 1024
@@ -73,33 +81,33 @@ def render(desc, rd, max_strays=None):
     return film, strays[:ns.value], cn.as_dict()
 
 
-def render_image(scene):
+def render_image(scene, cr_libm=False):
     """Full-frame oracle render of a HostScene, merged by the host Film: (h, w, 3) image + counters."""
     rd = scene.render_desc()
-    film, strays, cn = render(scene.desc, rd)
+    film, strays, cn = render(scene.desc, rd, cr_libm=cr_libm)
     scene.film_clear()
     scene.film_merge(rd, film, strays)
     return scene.film_image(), cn
 
 
-def intersect(desc, o, d, tmax):
+def intersect(desc, o, d, tmax, cr_libm=False):
     pkg = _pkg()
     o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32); tmax = np.ascontiguousarray(tmax, np.float32)
     n = len(tmax)
     prim = np.empty(n, np.int32); t = np.empty(n, np.float32); bary = np.empty((n, 3), np.float32)
     cn = pkg.abi.PgCounters()
-    lib().oracle_intersect(C.byref(desc), n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data, prim.ctypes.data, t.ctypes.data,
+    lib(cr_libm).oracle_intersect(C.byref(desc), n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data, prim.ctypes.data, t.ctypes.data,
                            bary.ctypes.data, C.byref(cn))
     return prim, t, bary, cn.as_dict()
 
 
-def intersect_p(desc, o, d, tmax):
+def intersect_p(desc, o, d, tmax, cr_libm=False):
     pkg = _pkg()
     o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32); tmax = np.ascontiguousarray(tmax, np.float32)
     n = len(tmax)
     occ = np.empty(n, np.uint8)
     cn = pkg.abi.PgCounters()
-    lib().oracle_intersect_p(C.byref(desc), n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data, occ.ctypes.data, C.byref(cn))
+    lib(cr_libm).oracle_intersect_p(C.byref(desc), n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data, occ.ctypes.data, C.byref(cn))
     return occ, cn.as_dict()
 
 

@@ -5,7 +5,7 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 5
+PG_ABI_VERSION = 6
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
 PG_LIGHTS_UNIFORM, PG_LIGHTS_POWER, PG_LIGHTS_SPATIAL = 0, 1, 2
@@ -32,6 +32,12 @@ class PgLight(C.Structure):
                 ("env_int", C.c_float * 2), ("env_marg_cdf", C.c_float * 3), ("env_marg_int", C.c_float)]
 
 
+class PgSphere(C.Structure):
+    _fields_ = [("o2w", C.c_float * 16), ("w2o", C.c_float * 16), ("radius", C.c_float), ("z_min", C.c_float), ("z_max", C.c_float),
+                ("theta_min", C.c_float), ("theta_max", C.c_float), ("phi_max", C.c_float),
+                ("reverse_orientation", C.c_int32), ("swaps_handedness", C.c_int32)]
+
+
 class PgSceneDesc(C.Structure):
     _fields_ = [("abi_version", C.c_int32),
                 ("n_nodes", C.c_int32), ("nodes", C.POINTER(PgBVHNode)),
@@ -42,7 +48,8 @@ class PgSceneDesc(C.Structure):
                 ("n_materials", C.c_int32), ("materials", C.POINTER(PgMaterial)),
                 ("n_lights", C.c_int32), ("lights", C.POINTER(PgLight)),
                 ("light_strategy", C.c_int32),
-                ("n_perm_dims", C.c_int32), ("perms", C.POINTER(C.c_uint16)), ("perm_sums", C.POINTER(C.c_int32))]
+                ("n_perm_dims", C.c_int32), ("perms", C.POINTER(C.c_uint16)), ("perm_sums", C.POINTER(C.c_int32)),
+                ("n_spheres", C.c_int32), ("spheres", C.POINTER(PgSphere))]
 
 
 class PgRenderDesc(C.Structure):

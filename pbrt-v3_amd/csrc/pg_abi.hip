@@ -45,7 +45,7 @@ struct DeviceBuffer {
 struct PgScene {
     int device = 0;
     DScene d;
-    DeviceBuffer nodes, wnodes, tris, triN, triS, uv, materials, lights, distTable, perms, permSums, primes;
+    DeviceBuffer nodes, wnodes, tris, spheres, triN, triS, uv, materials, lights, distTable, perms, permSums, primes;
     // work buffers (sized on first render, reused)
     int capacity = 0;
     DeviceBuffer qo[4], qd[4], counts, hitsMain, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
@@ -162,13 +162,24 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     if (anyUV) uv.resize((size_t)nt * 6);
     for (int k = 0; k < nt; ++k) {
         const int32_t *v = &desc->indices[3 * k];
-        for (int j = 0; j < 3; ++j)
-            if (v[j] < 0 || v[j] >= desc->n_verts) FAIL(PG_ERR_INVALID, "triangle %d has out-of-range vertex index %d", k, v[j]);
         uint32_t flags = desc->tri_flags ? desc->tri_flags[k] : 0;
         int mat = desc->tri_material ? desc->tri_material[k] : 0;
         int light = desc->tri_light ? desc->tri_light[k] : -1;
         if (mat < 0 || mat >= desc->n_materials) FAIL(PG_ERR_INVALID, "triangle %d has out-of-range material %d", k, mat);
         if (light >= desc->n_lights) FAIL(PG_ERR_INVALID, "triangle %d has out-of-range light %d", k, light);
+        if (flags & PG_PRIM_SPHERE) {  // Shape "sphere": the record carries the sphere's index where a triangle has p0.x
+            if (v[0] < 0 || v[0] >= desc->n_spheres || !desc->spheres) FAIL(PG_ERR_INVALID, "primitive %d has out-of-range sphere index %d", k, v[0]);
+            float iw, fw, mw, lw;
+            flags = PG_PRIM_SPHERE;
+            memcpy(&iw, &v[0], 4); memcpy(&fw, &flags, 4); memcpy(&mw, &mat, 4); memcpy(&lw, &light, 4);
+            tris[3 * (size_t)k] = make_float4(iw, 0, 0, fw);
+            tris[3 * (size_t)k + 1] = make_float4(0, 0, 0, mw);
+            tris[3 * (size_t)k + 2] = make_float4(0, 0, 0, lw);
+            if (anyUV) { const float duv[6] = {0, 0, 1, 0, 1, 1}; memcpy(&uv[(size_t)k * 6], duv, sizeof(duv)); }
+            continue;
+        }
+        for (int j = 0; j < 3; ++j)
+            if (v[j] < 0 || v[j] >= desc->n_verts) FAIL(PG_ERR_INVALID, "triangle %d has out-of-range vertex index %d", k, v[j]);
         V3 p[3];
         for (int j = 0; j < 3; ++j) p[j] = mk(desc->P[3 * v[j]], desc->P[3 * v[j] + 1], desc->P[3 * v[j] + 2]);
         float tuv[6] = {0, 0, 1, 0, 1, 1};
@@ -199,6 +210,10 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         DeviceBuffer &buf = pass == 0 ? s->triN : s->triS;
         HIP_TRY_S(buf.alloc(sizeof(float4) * a.size()));
         HIP_TRY_S(hipMemcpy(buf.p, a.data(), buf.bytes, hipMemcpyHostToDevice));
+    }
+    if (desc->n_spheres > 0) {
+        HIP_TRY_S(s->spheres.alloc(sizeof(PgSphere) * (size_t)desc->n_spheres));
+        HIP_TRY_S(hipMemcpy(s->spheres.p, desc->spheres, s->spheres.bytes, hipMemcpyHostToDevice));
     }
     HIP_TRY_S(s->tris.alloc(sizeof(float4) * tris.size()));
     if (nt) HIP_TRY_S(hipMemcpy(s->tris.p, tris.data(), s->tris.bytes, hipMemcpyHostToDevice));
@@ -254,7 +269,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     HIP_TRY_S(s->primes.alloc(sizeof(int32_t) * primes.size()));
     HIP_TRY_S(hipMemcpy(s->primes.p, primes.data(), s->primes.bytes, hipMemcpyHostToDevice));
 
-    d.nodes = (const float4 *)s->nodes.p; d.tris = (const float4 *)s->tris.p; d.uv = (const float *)s->uv.p;
+    d.nodes = (const float4 *)s->nodes.p; d.tris = (const float4 *)s->tris.p; d.spheres = (const PgSphere *)s->spheres.p; d.nSpheres = desc->n_spheres > 0 ? desc->n_spheres : 0; d.uv = (const float *)s->uv.p;
     d.triN = (const float4 *)s->triN.p; d.triS = (const float4 *)s->triS.p;
     d.materials = (const PgMaterial *)s->materials.p; d.lights = (const PgLight *)s->lights.p;
     d.nNodes = desc->n_nodes; d.nTris = nt; d.nLights = desc->n_lights; d.nMaterials = desc->n_materials;

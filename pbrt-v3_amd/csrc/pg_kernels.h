@@ -31,6 +31,8 @@ struct DScene {
     const PgMaterial *materials;
     const PgLight *lights;
     int nNodes, nTris, nLights, nMaterials;
+    const PgSphere *spheres;  // Shape "sphere" primitives: tris[3*k] = (sphere index, 0, 0, flags | PG_PRIM_SPHERE)
+    int nSpheres;
     int hasInfinite;  // some light is an InfiniteAreaLight (Scene::infiniteLights non-empty)
     // light sampling distributions (lightdistrib.cpp): strategy + tables
     int lightStrategy;

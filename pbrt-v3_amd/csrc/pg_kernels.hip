@@ -12,6 +12,7 @@
 // No MFMA: there is no dense contraction on this path; traversal is a
 // latency/bandwidth-bound gather over the node and triangle arrays.
 #include "pg_device.h"
+#include "pg_sphere.h"
 #include "pg_kernels.h"
 
 #define PG_BLOCK 256
@@ -541,6 +542,75 @@ PG_DEV float spot_falloff(const PgLight &l, V3 w) {
     float delta = (cosTheta - l.cos_total_width) / (l.cos_falloff_start - l.cos_total_width);
     return (delta * delta) * (delta * delta);
 }
+// ---- Sphere as the shape of a DiffuseAreaLight: Sphere::Sample / ::Pdf, shapes/sphere.cpp:205-305
+PG_DEV bool sphere_ref_inside(const PgSphere &s, V3 refp, V3 refErr, V3 refn) {  // sphere.cpp:223-226, :294-297
+    const V3 pCenter = m4_point(s.o2w, mk(0, 0, 0));
+    const V3 pOrigin = offset_ray_origin(refp, refErr, refn, pCenter - refp);
+    return lensq(pOrigin - pCenter) <= s.radius * s.radius;
+}
+PG_DEV float sphere_cone_pdf(const PgSphere &s, V3 refp) {  // sphere.cpp:301-304, UniformConePdf sampling.cpp:132-134
+    const V3 pCenter = m4_point(s.o2w, mk(0, 0, 0));
+    const float sinThetaMax2 = s.radius * s.radius / lensq(refp - pCenter);
+    const float cosThetaMax = sqrtf(pmax(0.f, 1 - sinThetaMax2));
+    return 1 / (2 * PG_PI * (1 - cosThetaMax));
+}
+PG_DEV LightSample sphere_sample(const PgSphere &s, V3 refp, V3 refErr, V3 refn, float u0, float u1, float &pdf) {
+    LightSample it;
+    const float radius = s.radius;
+    const V3 pCenter = m4_point(s.o2w, mk(0, 0, 0));
+    if (sphere_ref_inside(s, refp, refErr, refn)) {  // uniform over the area (sphere.cpp:205-217), then to solid angle (:227-239)
+        const float z = 1 - 2 * u0;  // UniformSampleSphere, sampling.cpp:98-103
+        const float r = sqrtf(pmax(0.f, 1.f - z * z));
+        const float phi = 2 * PG_PI * u1;
+        double sP, cP;
+        sincos((double)phi, &sP, &cP);
+        V3 pObj = mk(r * (float)cP, r * (float)sP, z) * radius;
+        it.n = normalize(m4_normal(s.w2o, pObj));
+        if (s.reverse_orientation) it.n = it.n * -1.f;
+        pObj = pObj * (radius / sqrtf(lensq(pObj)));
+        it.p = m4_point_err2(s.o2w, pObj, vabs(pObj) * pgamma(5), it.pError);
+        pdf = 1 / (s.phi_max * radius * (s.z_max - s.z_min));
+        V3 wi = it.p - refp;
+        if (lensq(wi) == 0) pdf = 0;
+        else {
+            wi = normalize(wi);
+            pdf *= lensq(refp - it.p) / absdot(it.n, -wi);
+        }
+        if (isinf(pdf)) pdf = 0.f;
+        return it;
+    }
+    // uniformly inside the subtended cone, sphere.cpp:241-289
+    const float dc = sqrtf(lensq(refp - pCenter));
+    const float invDc = 1 / dc;
+    const V3 wc = (pCenter - refp) * invDc;
+    V3 wcX, wcY;
+    coordinate_system(wc, wcX, wcY);
+    const float sinThetaMax = radius * invDc;
+    const float sinThetaMax2 = sinThetaMax * sinThetaMax;
+    const float invSinThetaMax = 1 / sinThetaMax;
+    const float cosThetaMax = sqrtf(pmax(0.f, 1 - sinThetaMax2));
+    float cosTheta = (cosThetaMax - 1) * u0 + 1;
+    float sinTheta2 = 1 - cosTheta * cosTheta;
+    if (sinThetaMax2 < 0.00068523f) {  // sin^2(1.5 deg): the reference's small-angle series
+        sinTheta2 = sinThetaMax2 * u0;
+        cosTheta = sqrtf(1 - sinTheta2);
+    }
+    const float cosAlpha = sinTheta2 * invSinThetaMax + cosTheta * sqrtf(pmax(0.f, 1.f - sinTheta2 * invSinThetaMax * invSinThetaMax));
+    const float sinAlpha = sqrtf(pmax(0.f, 1.f - cosAlpha * cosAlpha));
+    const float phi = u1 * 2 * PG_PI;
+    double sP, cP;
+    sincos((double)phi, &sP, &cP);
+    // SphericalDirection(sinAlpha, cosAlpha, phi, -wcX, -wcY, -wc), geometry.h:1461-1466
+    const V3 nWorld = (-wcX) * (sinAlpha * (float)cP) + (-wcY) * (sinAlpha * (float)sP) + (-wc) * cosAlpha;
+    const V3 pWorld = pCenter + nWorld * radius;
+    it.p = pWorld;
+    it.pError = vabs(pWorld) * pgamma(5);
+    it.n = nWorld;
+    if (s.reverse_orientation) it.n = it.n * -1.f;
+    pdf = 1 / (2 * PG_PI * (1 - cosThetaMax));
+    return it;
+}
+
 // ---- InfiniteAreaLight with constant radiance: Lmap is a 1x1 MIPMap (lights/infinite.cpp, core/mipmap.h:245-274).
 // sinf/cosf/acosf/atan2f of the reference (glibc) are matched by evaluating in double and rounding once.
 PG_DEV V3 mat3_mul(const float *m, V3 w) {  // Transform::operator()(Vector3), transform.h:233-239
@@ -587,8 +657,12 @@ PG_DEV float env_pdf_li(const PgLight &l, V3 w) {  // InfiniteAreaLight::Pdf_Li,
     int iv = (int)(p1 * 2); iv = iv < 0 ? 0 : (iv > 1 ? 1 : iv);
     return (l.env_func[iv][iu] / l.env_marg_int) / (2 * PG_PI * PG_PI * sinTheta);
 }
-PG_DEV Spec light_sample_li(const DScene &sc, const PgLight &light, V3 refp, float u0, float u1, V3 &wi, float &pdf, LightSample &ls) {
-    if (light.type == PG_LIGHT_INFINITE) {  // InfiniteAreaLight::Sample_Li, infinite.cpp:99-125
+// EXT: the scene has primitives or lights beyond triangles + area / delta lights (spheres, infinite lights); the plain
+// instantiation keeps the common kernels at their register count
+template <bool EXT>
+PG_DEV Spec light_sample_li(const DScene &sc, const PgLight &light, V3 refp, V3 refErr, V3 refn, float u0, float u1, V3 &wi, float &pdf,
+                            LightSample &ls) {
+    if (EXT && light.type == PG_LIGHT_INFINITE) {  // InfiniteAreaLight::Sample_Li, infinite.cpp:99-125
         float pdf0, pdf1;
         int v;
         float d1 = env_sample_1d(light.env_int, light.env_marg_cdf, light.env_marg_int, u1, pdf1, &v);
@@ -624,25 +698,28 @@ PG_DEV Spec light_sample_li(const DScene &sc, const PgLight &light, V3 refp, flo
         if (light.type == PG_LIGHT_SPOT) return (I * spot_falloff(light, -wi)) / d2;
         return I / d2;
     }
-    float su0 = sqrtf(u0);  // UniformSampleTriangle, sampling.cpp:154-157
-    float b0 = 1 - su0, b1 = u1 * su0;
     Tri t = load_tri(sc, light.prim);
-    float b2 = (1 - b0 - b1);
-    ls.p = t.p0 * b0 + t.p1 * b1 + t.p2 * b2;
-    ls.n = normalize(cross(t.p1 - t.p0, t.p2 - t.p0));
-    if (sc.triN && (t.flags & PG_TRI_HAS_N)) {  // triangle.cpp:593-597: orientation follows the shading normal
-        V3 ns = tri_interp(sc.triN, light.prim, b0, b1, b2);
-        if (dot(ls.n, ns) < 0.f) ls.n = -ls.n;
-    } else if (t.flags & PG_TRI_FLIP_NORMAL) ls.n = ls.n * -1.f;
-    V3 pAbsSum = vabs(t.p0 * b0) + vabs(t.p1 * b1) + vabs(t.p2 * b2);
-    ls.pError = pAbsSum * pgamma(6);
-    pdf = 1 / light.area;
-    V3 w = ls.p - refp;
-    if (lensq(w) == 0) pdf = 0;
+    if (EXT && (t.flags & PG_PRIM_SPHERE)) ls = sphere_sample(sc.spheres[__float_as_int(t.p0.x)], refp, refErr, refn, u0, u1, pdf);
     else {
-        w = normalize(w);
-        pdf *= lensq(refp - ls.p) / absdot(ls.n, -w);
-        if (isinf(pdf)) pdf = 0.f;
+        float su0 = sqrtf(u0);  // UniformSampleTriangle, sampling.cpp:154-157
+        float b0 = 1 - su0, b1 = u1 * su0;
+        float b2 = (1 - b0 - b1);
+        ls.p = t.p0 * b0 + t.p1 * b1 + t.p2 * b2;
+        ls.n = normalize(cross(t.p1 - t.p0, t.p2 - t.p0));
+        if (sc.triN && (t.flags & PG_TRI_HAS_N)) {  // triangle.cpp:593-597: orientation follows the shading normal
+            V3 ns = tri_interp(sc.triN, light.prim, b0, b1, b2);
+            if (dot(ls.n, ns) < 0.f) ls.n = -ls.n;
+        } else if (t.flags & PG_TRI_FLIP_NORMAL) ls.n = ls.n * -1.f;
+        V3 pAbsSum = vabs(t.p0 * b0) + vabs(t.p1 * b1) + vabs(t.p2 * b2);
+        ls.pError = pAbsSum * pgamma(6);
+        pdf = 1 / light.area;
+        V3 w = ls.p - refp;  // Shape::Sample(ref, u, pdf), shape.cpp:56-70
+        if (lensq(w) == 0) pdf = 0;
+        else {
+            w = normalize(w);
+            pdf *= lensq(refp - ls.p) / absdot(ls.n, -w);
+            if (isinf(pdf)) pdf = 0.f;
+        }
     }
     if (pdf == 0 || lensq(ls.p - refp) == 0) { pdf = 0; return sp(0); }
     wi = normalize(ls.p - refp);
@@ -681,6 +758,7 @@ PG_DEV int sample_discrete(const float *tab, int n, float u, float &pdf) {
 
 PG_DEV void spawn_ray(const Isect &is, V3 d, V3 &o) { o = offset_ray_origin(is.p, is.pError, is.n, d); }  // interaction.h:64-67
 
+template <bool EXT>
 __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
                                                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests) {
     const int i = queue_item(qin);
@@ -701,6 +779,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
     Spec misF = sp(0);
     float misPdf = 0, misLightArea = 1;
     int misLightPrim = 0;
+    bool misInside = false;  // sphere light whose sphere contains the shaded point: Sphere::Pdf falls back to Shape::Pdf
     if (valid) {
         const float4 d4 = qin.d[i], h4 = hits[i];
         slot = __float_as_int(d4.w);
@@ -718,21 +797,28 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
         const bool found = prim >= 0;
         Tri tri;
         if (found) tri = load_tri(sc, prim);
+        Isect is;
+        const bool onSphere = EXT && found && (tri.flags & PG_PRIM_SPHERE);
+        if (onSphere) {  // the hit record of a sphere carries tHit: Sphere::Intersect's interaction from the ray and the root
+            const float4 o4 = qin.o[i];
+            const SphereHit sh = sphere_interaction(sc.spheres[__float_as_int(tri.p0.x)], mk(o4.x, o4.y, o4.z), rayD, h4.y);
+            is.p = sh.p; is.pError = sh.pError; is.wo = sh.wo; is.n = sh.n; is.ns = sh.n; is.sdpdu = sh.dpdu;
+        }
         // path.cpp:91-102 emitted light at the vertex
         if ((bounces == 0 || specularBounce) && found && tri.light >= 0) {
             const PgLight &l = sc.lights[tri.light];
-            V3 nrm = hit_normal(sc, prim, tri, h4.y, h4.z, h4.w);
+            V3 nrm = onSphere ? is.n : hit_normal(sc, prim, tri, h4.y, h4.z, h4.w);
             Spec Le = (l.two_sided || dot(nrm, -rayD) > 0) ? sp3(l.L[0], l.L[1], l.L[2]) : sp(0);
             L = L + beta * Le;
         } else if ((bounces == 0 || specularBounce) && found) L = L + beta * sp(0);
-        else if ((bounces == 0 || specularBounce) && !found && sc.hasInfinite) {  // path.cpp:96-100: every infinite light's Le(ray)
+        else if (EXT && (bounces == 0 || specularBounce) && !found && sc.hasInfinite) {  // path.cpp:96-100: every infinite light's Le(ray)
             for (int li = 0; li < sc.nLights; ++li)
                 if (sc.lights[li].type == PG_LIGHT_INFINITE) L = L + beta * env_le(sc.lights[li], rayD);
         }
         bool alive = found && bounces < rd.max_depth;  // path.cpp:104
         int newFlags = 0;
         if (alive) {
-            Isect is = make_isect(sc, prim, tri, h4.y, h4.z, h4.w, rayD);
+            if (!onSphere) is = make_isect(sc, prim, tri, h4.y, h4.z, h4.w, rayD);
             const PgMaterial &m = sc.materials[tri.material];
             if (m.type == PG_MAT_NONE) {  // path.cpp:107-113: skip over medium boundaries
                 V3 nextO;
@@ -786,7 +872,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                         float lightPdf = 0, scatteringPdf = 0;
                         float4 pdLight = make_float4(0, 0, 0, 0);
                         LightSample ls;
-                        Spec Li = light_sample_li(sc, light, is.p, uL0, uL1, wi, lightPdf, ls);
+                        Spec Li = light_sample_li<EXT>(sc, light, is.p, is.pError, is.n, uL0, uL1, wi, lightPdf, ls);
                         if (lightPdf > 0 && !is_black(Li)) {
                             Spec f = bsdf_f(bsdf, is.wo, wi) * absdot(wi, bsdf.ns);
                             scatteringPdf = bsdf_pdf(bsdf, is.wo, wi);
@@ -809,7 +895,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                         V3 wi2 = wi;
                         float sPdf2 = 0;
                         Spec f2 = sp(0);
-                        if (light.type == PG_LIGHT_AREA || light.type == PG_LIGHT_INFINITE) {  // integrator.cpp:164: if (!IsDeltaLight(light.flags))
+                        if (light.type == PG_LIGHT_AREA || (EXT && light.type == PG_LIGHT_INFINITE)) {  // integrator.cpp:164: if (!IsDeltaLight(light.flags))
                             f2 = bsdf_sample_f(bsdf, is.wo, wi2, uS0, uS1, sPdf2);
                             f2 = f2 * absdot(wi2, bsdf.ns);
                         }
@@ -817,7 +903,12 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                             misCand = true;
                             spawn_ray(is, wi2, misRo);
                             misWi = wi2; misF = f2; misPdf = sPdf2; misP = is.p;
-                            misLightPrim = light.type == PG_LIGHT_INFINITE ? -1 - lightNum : light.prim; misLightArea = light.area;
+                            misLightPrim = (EXT && light.type == PG_LIGHT_INFINITE) ? -1 - lightNum : light.prim; misLightArea = light.area;
+                            if (EXT && light.type == PG_LIGHT_AREA) {
+                                const float4 la = sc.tris[3 * light.prim];
+                                if (__float_as_uint(la.w) & PG_PRIM_SPHERE)
+                                    misInside = sphere_ref_inside(sc.spheres[__float_as_int(la.x)], is.p, is.pError, is.n);
+                            }
                         }
                         // pending terms of this vertex, consumed by k_resolve (pdMis and the MIS weight follow below)
                         pdLight.w = lightSelPdf;
@@ -861,16 +952,27 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
     if (misCand) {
         // light.Pdf_Li -> Shape::Pdf(ref, wi): intersect the light's own triangle (shape.cpp:72-87, diffuse.cpp:83-87)
         float lightPdf2 = 0;
-        if (misLightPrim < 0) lightPdf2 = env_pdf_li(sc.lights[-1 - misLightPrim], misWi);  // infinite light: no geometry to test
+        if (EXT && misLightPrim < 0) lightPdf2 = env_pdf_li(sc.lights[-1 - misLightPrim], misWi);  // infinite light: no geometry to test
         Tri lt = load_tri(sc, misLightPrim < 0 ? 0 : misLightPrim);
         float t, lb0, lb1, lb2;
-        if (misLightPrim >= 0) ++nLightTests;
-        if (misLightPrim >= 0 && tri_test(lt.p0, lt.p1, lt.p2, misRo, misWi, PG_INF, t, lb0, lb1, lb2) && !(lt.flags & PG_TRI_BOGUS)) {
-            V3 lp = lt.p0 * lb0 + lt.p1 * lb1 + lt.p2 * lb2;
-            V3 ln = normalize(cross(lt.p0 - lt.p2, lt.p1 - lt.p2));
-            float pdf = lensq(misP - lp) / (absdot(ln, -misWi) * misLightArea);
-            if (isinf(pdf)) pdf = 0.f;
-            lightPdf2 = pdf;
+        if (EXT && misLightPrim >= 0 && (lt.flags & PG_PRIM_SPHERE)) {  // Sphere::Pdf, sphere.cpp:292-305
+            const PgSphere &ls = sc.spheres[__float_as_int(lt.p0.x)];
+            if (!misInside) lightPdf2 = sphere_cone_pdf(ls, misP);
+            else if (sphere_test(ls, misRo, misWi, PG_INF, t)) {  // Shape::Pdf, shape.cpp:72-87
+                const SphereHit sh = sphere_interaction(ls, misRo, misWi, t);
+                float pdf = lensq(misP - sh.p) / (absdot(sh.n, -misWi) * misLightArea);
+                if (isinf(pdf)) pdf = 0.f;
+                lightPdf2 = pdf;
+            }
+        } else {
+            if (misLightPrim >= 0) ++nLightTests;
+            if (misLightPrim >= 0 && tri_test(lt.p0, lt.p1, lt.p2, misRo, misWi, PG_INF, t, lb0, lb1, lb2) && !(lt.flags & PG_TRI_BOGUS)) {
+                V3 lp = lt.p0 * lb0 + lt.p1 * lb1 + lt.p2 * lb2;
+                V3 ln = normalize(cross(lt.p0 - lt.p2, lt.p1 - lt.p2));
+                float pdf = lensq(misP - lp) / (absdot(ln, -misWi) * misLightArea);
+                if (isinf(pdf)) pdf = 0.f;
+                lightPdf2 = pdf;
+            }
         }
         if (lightPdf2 != 0) {
             s_ray[2][0][tid] = make_float4(misRo.x, misRo.y, misRo.z, PG_INF);
@@ -896,11 +998,13 @@ void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQue
                   RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s) {
     int nblk = PG_REGIONS * (qin.regionCap / PG_BLOCK);
     if (nblk == 0) return;
-    hipLaunchKernelGGL(k_shade, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests);
+    if (sc.nSpheres > 0 || sc.hasInfinite) hipLaunchKernelGGL(k_shade<true>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests);
 }
 
 // EstimateDirect's two "Add ... contribution" steps (integrator.cpp:143-161, 196-212) and
 // L += beta * Ld / lightPdf (integrator.cpp:104, path.cpp:122-126), once both rays are back.
+template <bool EXT>
 __global__ __launch_bounds__(PG_BLOCK) void k_resolve(DScene sc, PathState st, RayQueue qin, RayQueue qmis, const int *__restrict__ occluded,
                                                        const float4 *__restrict__ misHits) {
     const int i = queue_item(qin);
@@ -920,11 +1024,15 @@ __global__ __launch_bounds__(PG_BLOCK) void k_resolve(DScene sc, PathState st, R
                 const PgLight &l = sc.lights[t.light];
                 const float4 d4 = qmis.d[info.y];
                 V3 wi = mk(d4.x, d4.y, d4.z);
-                V3 nrm = hit_normal(sc, prim, t, h.y, h.z, h.w);
+                V3 nrm;
+                if (EXT && (t.flags & PG_PRIM_SPHERE)) {
+                    const float4 o4 = qmis.o[info.y];
+                    nrm = sphere_interaction(sc.spheres[__float_as_int(t.p0.x)], mk(o4.x, o4.y, o4.z), wi, h.y).n;
+                } else nrm = hit_normal(sc, prim, t, h.y, h.z, h.w);
                 Spec Li = (l.two_sided || dot(nrm, -wi) > 0) ? sp3(l.L[0], l.L[1], l.L[2]) : sp(0);
                 if (!is_black(Li)) Ld = Ld + ((((sp3(pm.x, pm.y, pm.z) * Li) * sp(1.f)) * pb.w) / pm.w);
             }
-        } else if (sc.lights[info.z].type == PG_LIGHT_INFINITE) {  // integrator.cpp:207-208: no surface hit: Li = light.Le(ray)
+        } else if (EXT && sc.lights[info.z].type == PG_LIGHT_INFINITE) {  // integrator.cpp:207-208: no surface hit: Li = light.Le(ray)
             const float4 d4 = qmis.d[info.y];
             Spec Li = env_le(sc.lights[info.z], mk(d4.x, d4.y, d4.z));
             if (!is_black(Li)) Ld = Ld + ((((sp3(pm.x, pm.y, pm.z) * Li) * sp(1.f)) * pb.w) / pm.w);
@@ -937,7 +1045,8 @@ __global__ __launch_bounds__(PG_BLOCK) void k_resolve(DScene sc, PathState st, R
 void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis, const int *occluded, const float4 *misHits, hipStream_t s) {
     int nblk = PG_REGIONS * (qin.regionCap / PG_BLOCK);
     if (nblk == 0) return;
-    hipLaunchKernelGGL(k_resolve, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, qin, qmis, occluded, misHits);
+    if (sc.nSpheres > 0 || sc.hasInfinite) hipLaunchKernelGGL(k_resolve<true>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, qin, qmis, occluded, misHits);
+    else hipLaunchKernelGGL(k_resolve<false>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, qin, qmis, occluded, misHits);
 }
 
 // ===========================================================================
@@ -1091,7 +1200,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_light_tables(DScene sc, float *tab
             float pdf;
             V3 wi;
             LightSample ls;
-            Spec Li = light_sample_li(sc, sc.lights[j], po, u0, u1, wi, pdf, ls);
+            Spec Li = light_sample_li<true>(sc, sc.lights[j], po, mk(0, 0, 0), mk(0, 0, 0), u0, u1, wi, pdf, ls);  // Interaction(po, Normal3f(), Vector3f(), ...)
             if (pdf > 0) func[j] += lum(Li) / pdf;
         }
     }

@@ -1,0 +1,189 @@
+// pg_sphere.h -- Shape "sphere" on the device: the quadric's error-bounded root search (shapes/sphere.cpp:48-106 over
+// core/efloat.h), the with-error Transform operators it needs (core/transform.h:219-384) and the surface interaction at an
+// accepted root (sphere.cpp:108-160, interaction.cpp:44-71, transform.cpp:262-297).
+//
+// A sphere stays in object space as in the reference (ObjectToWorld / WorldToObject are full 4x4 matrices), so every ray is
+// carried into object space with the reference's running error bounds and the intersection is decided by interval
+// arithmetic: same float operations in the same order, hence the same accept / reject decision and the same tHit.
+// The traversal kernel stores only tHit for a sphere hit; shading recomputes the hit point from the ray and tHit, which is
+// the arithmetic Sphere::Intersect itself performs after the root is chosen.
+#ifndef PG_SPHERE_H
+#define PG_SPHERE_H
+#include "pg_device.h"
+#include "../../include/pbrt_gpu.h"
+
+struct EFloat { float v, low, high; };  // efloat.h:45-233 in an NDEBUG build: value + conservative interval
+PG_DEV EFloat ef_make(float v, float err) {  // efloat.h:50-63
+    EFloat r; r.v = v;
+    if (err == 0.f) r.low = r.high = v;
+    else { r.low = next_float_down(v - err); r.high = next_float_up(v + err); }
+    return r;
+}
+PG_DEV EFloat ef_add(EFloat a, EFloat b) { EFloat r; r.v = a.v + b.v; r.low = next_float_down(a.low + b.low); r.high = next_float_up(a.high + b.high); return r; }
+PG_DEV EFloat ef_sub(EFloat a, EFloat b) { EFloat r; r.v = a.v - b.v; r.low = next_float_down(a.low - b.high); r.high = next_float_up(a.high - b.low); return r; }
+PG_DEV EFloat ef_mul(EFloat a, EFloat b) {  // efloat.h:111-127
+    EFloat r; r.v = a.v * b.v;
+    const float p0 = a.low * b.low, p1 = a.high * b.low, p2 = a.low * b.high, p3 = a.high * b.high;
+    r.low = next_float_down(pmin(pmin(p0, p1), pmin(p2, p3)));
+    r.high = next_float_up(pmax(pmax(p0, p1), pmax(p2, p3)));
+    return r;
+}
+PG_DEV EFloat ef_div(EFloat a, EFloat b) {  // efloat.h:128-151
+    EFloat r; r.v = a.v / b.v;
+    if (b.low < 0 && b.high > 0) { r.low = -PG_INF; r.high = PG_INF; }
+    else {
+        const float d0 = a.low / b.low, d1 = a.high / b.low, d2 = a.low / b.high, d3 = a.high / b.high;
+        r.low = next_float_down(pmin(pmin(d0, d1), pmin(d2, d3)));
+        r.high = next_float_up(pmax(pmax(d0, d1), pmax(d2, d3)));
+    }
+    return r;
+}
+PG_DEV bool ef_quadratic(EFloat A, EFloat B, EFloat C, EFloat &t0, EFloat &t1) {  // efloat.h:268-288
+    const double discrim = (double)B.v * (double)B.v - 4. * (double)A.v * (double)C.v;
+    if (discrim < 0.) return false;
+    const double rootDiscrim = sqrt(discrim);
+    const EFloat frd = ef_make((float)rootDiscrim, (float)((double)PG_MACH_EPS * rootDiscrim));
+    EFloat q;
+    if (B.v < 0) q = ef_mul(ef_make(-.5f, 0), ef_sub(B, frd));
+    else q = ef_mul(ef_make(-.5f, 0), ef_add(B, frd));
+    t0 = ef_div(q, A);
+    t1 = ef_div(C, q);
+    if (t0.v > t1.v) { const EFloat t = t0; t0 = t1; t1 = t; }
+    return true;
+}
+
+// Transform::operator() flavours, row-major 4x4 (m = the transform's matrix, mInv = its inverse)
+PG_DEV V3 m4_point(const float *m, V3 p) {  // transform.h:219-231
+    const float x = p.x, y = p.y, z = p.z;
+    const float xp = m[0] * x + m[1] * y + m[2] * z + m[3];
+    const float yp = m[4] * x + m[5] * y + m[6] * z + m[7];
+    const float zp = m[8] * x + m[9] * y + m[10] * z + m[11];
+    const float wp = m[12] * x + m[13] * y + m[14] * z + m[15];
+    if (wp == 1) return mk(xp, yp, zp);
+    return vdiv(mk(xp, yp, zp), wp);
+}
+PG_DEV V3 m4_vec(const float *m, V3 v) {  // transform.h:233-239
+    return mk(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+PG_DEV V3 m4_normal(const float *mInv, V3 n) {  // transform.h:241-247
+    return mk(mInv[0] * n.x + mInv[4] * n.y + mInv[8] * n.z, mInv[1] * n.x + mInv[5] * n.y + mInv[9] * n.z,
+              mInv[2] * n.x + mInv[6] * n.y + mInv[10] * n.z);
+}
+PG_DEV V3 m4_point_err(const float *m, V3 p, V3 &pError) {  // transform.h:277-300
+    const float x = p.x, y = p.y, z = p.z;
+    const float xp = (m[0] * x + m[1] * y) + (m[2] * z + m[3]);
+    const float yp = (m[4] * x + m[5] * y) + (m[6] * z + m[7]);
+    const float zp = (m[8] * x + m[9] * y) + (m[10] * z + m[11]);
+    const float wp = (m[12] * x + m[13] * y) + (m[14] * z + m[15]);
+    const float xAbsSum = (fabsf(m[0] * x) + fabsf(m[1] * y) + fabsf(m[2] * z) + fabsf(m[3]));
+    const float yAbsSum = (fabsf(m[4] * x) + fabsf(m[5] * y) + fabsf(m[6] * z) + fabsf(m[7]));
+    const float zAbsSum = (fabsf(m[8] * x) + fabsf(m[9] * y) + fabsf(m[10] * z) + fabsf(m[11]));
+    pError = mk(xAbsSum, yAbsSum, zAbsSum) * pgamma(3);
+    if (wp == 1) return mk(xp, yp, zp);
+    return vdiv(mk(xp, yp, zp), wp);
+}
+PG_DEV V3 m4_point_err2(const float *m, V3 pt, V3 ptError, V3 &absError) {  // transform.h:302-332
+    const float x = pt.x, y = pt.y, z = pt.z;
+    const float xp = (m[0] * x + m[1] * y) + (m[2] * z + m[3]);
+    const float yp = (m[4] * x + m[5] * y) + (m[6] * z + m[7]);
+    const float zp = (m[8] * x + m[9] * y) + (m[10] * z + m[11]);
+    const float wp = (m[12] * x + m[13] * y) + (m[14] * z + m[15]);
+    const float g3 = pgamma(3);
+    absError.x = (g3 + 1.f) * (fabsf(m[0]) * ptError.x + fabsf(m[1]) * ptError.y + fabsf(m[2]) * ptError.z) +
+                 g3 * (fabsf(m[0] * x) + fabsf(m[1] * y) + fabsf(m[2] * z) + fabsf(m[3]));
+    absError.y = (g3 + 1.f) * (fabsf(m[4]) * ptError.x + fabsf(m[5]) * ptError.y + fabsf(m[6]) * ptError.z) +
+                 g3 * (fabsf(m[4] * x) + fabsf(m[5] * y) + fabsf(m[6] * z) + fabsf(m[7]));
+    absError.z = (g3 + 1.f) * (fabsf(m[8]) * ptError.x + fabsf(m[9]) * ptError.y + fabsf(m[10]) * ptError.z) +
+                 g3 * (fabsf(m[8] * x) + fabsf(m[9] * y) + fabsf(m[10] * z) + fabsf(m[11]));
+    if (wp == 1.f) return mk(xp, yp, zp);
+    return vdiv(mk(xp, yp, zp), wp);
+}
+PG_DEV V3 m4_vec_err(const float *m, V3 v, V3 &absError) {  // transform.h:334-351
+    const float g3 = pgamma(3);
+    absError.x = g3 * (fabsf(m[0] * v.x) + fabsf(m[1] * v.y) + fabsf(m[2] * v.z));
+    absError.y = g3 * (fabsf(m[4] * v.x) + fabsf(m[5] * v.y) + fabsf(m[6] * v.z));
+    absError.z = g3 * (fabsf(m[8] * v.x) + fabsf(m[9] * v.y) + fabsf(m[10] * v.z));
+    return m4_vec(m, v);
+}
+
+// (*WorldToObject)(ray, &oErr, &dErr), transform.h:372-384: the object-space ray, its origin moved to the edge of its error box
+PG_DEV void sphere_object_ray(const PgSphere &sp, V3 ro, V3 rd, V3 &o, V3 &d, V3 &oErr, V3 &dErr) {
+    o = m4_point_err(sp.w2o, ro, oErr);
+    d = m4_vec_err(sp.w2o, rd, dErr);
+    const float lengthSquared = lensq(d);
+    if (lengthSquared > 0) {
+        const float dt = dot(vabs(d), oErr) / lengthSquared;
+        o = o + d * dt;
+    }
+}
+// Object-space hit point of parameter t, re-projected onto the sphere, and its azimuth (sphere.cpp:80-87)
+PG_DEV V3 sphere_hit_point(const PgSphere &sp, V3 o, V3 d, float t, float &phi) {
+    V3 pHit = o + d * t;
+    pHit = pHit * (sp.radius / sqrtf(lensq(pHit)));
+    if (pHit.x == 0 && pHit.y == 0) pHit.x = 1e-5f * sp.radius;
+    phi = (float)atan2((double)pHit.y, (double)pHit.x);
+    if (phi < 0) phi += 2 * PG_PI;
+    return pHit;
+}
+PG_DEV bool sphere_clipped(const PgSphere &sp, V3 pHit, float phi) {  // sphere.cpp:90-91
+    return (sp.z_min > -sp.radius && pHit.z < sp.z_min) || (sp.z_max < sp.radius && pHit.z > sp.z_max) || phi > sp.phi_max;
+}
+// Sphere::Intersect's root search = Sphere::IntersectP (sphere.cpp:48-106, :165-200).  True: tHit is the accepted root.
+PG_DEV bool sphere_test(const PgSphere &sp, V3 ro, V3 rd, float tMax, float &tHit) {
+    V3 o, d, oErr, dErr;
+    sphere_object_ray(sp, ro, rd, o, d, oErr, dErr);
+    const EFloat ox = ef_make(o.x, oErr.x), oy = ef_make(o.y, oErr.y), oz = ef_make(o.z, oErr.z);
+    const EFloat dx = ef_make(d.x, dErr.x), dy = ef_make(d.y, dErr.y), dz = ef_make(d.z, dErr.z);
+    const EFloat a = ef_add(ef_add(ef_mul(dx, dx), ef_mul(dy, dy)), ef_mul(dz, dz));
+    const EFloat b = ef_mul(ef_make(2, 0), ef_add(ef_add(ef_mul(dx, ox), ef_mul(dy, oy)), ef_mul(dz, oz)));
+    const EFloat rad = ef_make(sp.radius, 0);
+    const EFloat c = ef_sub(ef_add(ef_add(ef_mul(ox, ox), ef_mul(oy, oy)), ef_mul(oz, oz)), ef_mul(rad, rad));
+    EFloat t0, t1;
+    if (!ef_quadratic(a, b, c, t0, t1)) return false;
+    if (t0.high > tMax || t1.low <= 0) return false;
+    EFloat tShapeHit = t0;
+    if (tShapeHit.low <= 0) {
+        tShapeHit = t1;
+        if (tShapeHit.high > tMax) return false;
+    }
+    float phi;
+    V3 pHit = sphere_hit_point(sp, o, d, tShapeHit.v, phi);
+    if (sphere_clipped(sp, pHit, phi)) {
+        if (tShapeHit.v == t1.v) return false;
+        if (t1.high > tMax) return false;
+        tShapeHit = t1;
+        pHit = sphere_hit_point(sp, o, d, tShapeHit.v, phi);
+        if (sphere_clipped(sp, pHit, phi)) return false;
+    }
+    tHit = tShapeHit.v;
+    return true;
+}
+
+// What the path needs of the SurfaceInteraction Sphere::Intersect builds for the root tHit of world ray (ro, rd).
+struct SphereHit { V3 p, pError, wo, n, dpdu; };
+PG_DEV SphereHit sphere_interaction(const PgSphere &sp, V3 ro, V3 rd, float tHit) {
+    V3 o, d, oErr, dErr;
+    sphere_object_ray(sp, ro, rd, o, d, oErr, dErr);
+    float phi;
+    const V3 pHit = sphere_hit_point(sp, o, d, tHit, phi);
+    // sphere.cpp:108-124 (u, v, dndu, dndv feed only textures and ray differentials)
+    const float cz = pHit.z / sp.radius;
+    const float theta = (float)acos((double)(cz < -1 ? -1.f : (cz > 1 ? 1.f : cz)));  // std::acos(Clamp(pHit.z / radius, -1, 1))
+    const float zRadius = sqrtf(pHit.x * pHit.x + pHit.y * pHit.y);
+    const float invZRadius = 1 / zRadius;
+    const float cosPhi = pHit.x * invZRadius;
+    const float sinPhi = pHit.y * invZRadius;
+    const V3 dpdu = mk(-sp.phi_max * pHit.y, sp.phi_max * pHit.x, 0);
+    const V3 dpdv = mk(pHit.z * cosPhi, pHit.z * sinPhi, -sp.radius * (float)sin((double)theta)) * (sp.theta_max - sp.theta_min);
+    const V3 pError = vabs(pHit) * pgamma(5);  // sphere.cpp:148
+    V3 n = normalize(cross(dpdu, dpdv));  // SurfaceInteraction ctor, interaction.cpp:49,66-70
+    if (sp.reverse_orientation ^ sp.swaps_handedness) n = n * -1.f;
+    const V3 wo = normalize(-d);  // Interaction ctor, interaction.h:60
+    SphereHit h;  // (*ObjectToWorld)(SurfaceInteraction), transform.cpp:262-297; shading.n == n for a sphere
+    h.p = m4_point_err2(sp.o2w, pHit, pError, h.pError);
+    h.n = normalize(m4_normal(sp.w2o, n));
+    h.wo = normalize(m4_vec(sp.o2w, wo));
+    h.dpdu = m4_vec(sp.o2w, dpdu);
+    return h;
+}
+#endif

@@ -25,6 +25,7 @@
 //  * traversal stack: first `depth` entries per lane in LDS ([entry][lane],
 //    8 B entries, bank-conflict-free), the rest of pbrt's 64 in scratch.
 #include "pg_device.h"
+#include "pg_sphere.h"
 #include <algorithm>
 #include "pg_kernels.h"
 
@@ -71,7 +72,7 @@ PG_DEV unsigned long long tr_wave_sum(unsigned long long v) {
     return v;
 }
 
-template <bool ANYHIT>
+template <bool ANYHIT, bool SPHERES>
 __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(DScene sc, RayQueue q0, RayQueue q1, float4 *__restrict__ hits,
                                                     int hitOffset1, float *__restrict__ tOut, int *__restrict__ occluded,
                                                     TraceCounters *cn, int *__restrict__ cursors, int depth, int chunk, int refillAt, int triW,
@@ -200,8 +201,19 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
                 const float4 a = sc.tris[3 * prim], b = sc.tris[3 * prim + 1], c = sc.tris[3 * prim + 2];
                 ++triTests; ++triNext; --triLeft;
                 float t, b0, b1, b2;
-                if (tri_test_pre(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), mk(ox, oy, oz), tr, tMax, t, b0, b1, b2) &&
-                    !(__float_as_uint(a.w) & PG_TRI_BOGUS)) {
+                bool hit;
+                if (SPHERES && (__float_as_uint(a.w) & PG_PRIM_SPHERE)) {
+                    // Sphere::Intersect[P] (sphere.cpp:48-106): not a triangle test for the reference's counter; the ray's
+                    // direction is not kept in registers (only its reciprocal and the triangle shear), so it is re-read
+                    --triTests;
+                    const bool fromQ1 = q1.regionCap > 0 && ray >= hitOffset1;
+                    const float4 d4 = fromQ1 ? q1.d[ray - hitOffset1] : q0.d[ray];
+                    hit = sphere_test(sc.spheres[__float_as_int(a.x)], mk(ox, oy, oz), mk(d4.x, d4.y, d4.z), tMax, t);
+                    b0 = t; b1 = 0; b2 = 0;  // the hit record of a sphere carries tHit
+                } else
+                    hit = tri_test_pre(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), mk(ox, oy, oz), tr, tMax, t, b0, b1, b2) &&
+                          !(__float_as_uint(a.w) & PG_TRI_BOGUS);
+                if (hit) {
                     hitPrim = prim;
                     if (ANYHIT) { triLeft = 0; sp = 0; vd = 0; }  // bvh.cpp:717: return true
                     else {
@@ -268,8 +280,13 @@ static void launch_trace(const DScene &sc, RayQueue q0, RayQueue q1, float4 *hit
     nblk = ((nblk + 7) / 8) * 8;
     size_t lds = sizeof(uint2) * (size_t)c.depth * TR_BLOCK;
     (void)hipMemsetAsync(cursors, 0, 2 * PG_REGIONS * PG_COUNT_STRIDE * sizeof(int), s);
-    hipLaunchKernelGGL(k_trace<ANYHIT>, dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q0, q1, hits, hitOffset1, tOut, occluded, cn, cursors, c.depth,
-                       c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard);
+    // scenes without Shape "sphere" run the triangle-only instantiation
+    if (sc.nSpheres > 0)
+        hipLaunchKernelGGL((k_trace<ANYHIT, true>), dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q0, q1, hits, hitOffset1, tOut, occluded, cn, cursors,
+                           c.depth, c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard);
+    else
+        hipLaunchKernelGGL((k_trace<ANYHIT, false>), dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q0, q1, hits, hitOffset1, tOut, occluded, cn, cursors,
+                           c.depth, c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard);
 }
 static RayQueue noQueue() { RayQueue q; q.o = q.d = nullptr; q.counts = nullptr; q.regionCap = 0; return q; }
 void launch_closest(const DScene &sc, RayQueue q, float4 *hits, float *tOut, TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s) {

@@ -550,11 +550,18 @@ void pbrtShape(const std::string &name, const ParamSet &params) {  // api.cpp:13
     if (curTransform.IsAnimated())
         Warning("Animated transformations are not supported by this build; using the start transform for shape \"%s\".", name.c_str());
     std::shared_ptr<TriangleMesh> mesh;
+    std::shared_ptr<Sphere> sphere;
     if (name == "trianglemesh") mesh = CreateTriangleMeshShape(curTransform[0], graphicsState.reverseOrientation, params);
     else if (name == "plymesh") mesh = CreatePLYMesh(curTransform[0], graphicsState.reverseOrientation, params);
     else if (name == "loopsubdiv") mesh = CreateLoopSubdiv(curTransform[0], graphicsState.reverseOrientation, params);
-    else Error("Shape \"%s\" is outside this build's closed set (trianglemesh, plymesh, loopsubdiv); ignoring.", name.c_str());
-    if (!mesh || mesh->nTriangles == 0) return;
+    else if (name == "sphere") {  // CreateSphereShape, sphere.cpp:326-336
+        Float radius = params.FindOneFloat("radius", 1.f);
+        Float zmin = params.FindOneFloat("zmin", -radius);
+        Float zmax = params.FindOneFloat("zmax", radius);
+        Float phimax = params.FindOneFloat("phimax", 360.f);
+        sphere = std::make_shared<Sphere>(curTransform[0], Inverse(curTransform[0]), graphicsState.reverseOrientation, radius, zmin, zmax, phimax);
+    } else Error("Shape \"%s\" is outside this build's closed set (trianglemesh, plymesh, loopsubdiv, sphere); ignoring.", name.c_str());
+    if (!sphere && (!mesh || mesh->nTriangles == 0)) return;
     int mtl = GetMaterialForShape(params);
     params.ReportUnused();
     int firstLight = -1;
@@ -573,22 +580,21 @@ void pbrtShape(const std::string &name, const ParamSet &params) {  // api.cpp:13
             firstLight = (int)renderOptions->lights.size();
         } else Warning("Area light \"%s\" unknown.", graphicsState.areaLight.c_str());
     }
-    static size_t primSerial = 0;
-    for (int i = 0; i < mesh->nTriangles; ++i) {
+    const int nShapes = sphere ? 1 : mesh->nTriangles;
+    for (int i = 0; i < nShapes; ++i) {
         GeometricPrimitive prim;
-        prim.shape.mesh = mesh;
-        prim.shape.triIndex = i;
+        if (sphere) prim.sphere = sphere;
+        else { prim.shape.mesh = mesh; prim.shape.triIndex = i; }
         prim.material = mtl;
         if (firstLight >= 0) {
             PgLight l = lightProto;
-            l.area = prim.shape.Area();
+            l.area = sphere ? sphere->Area() : prim.shape.Area();
             l.prim = -1;
             prim.areaLight = (int)renderOptions->lights.size();
             renderOptions->lights.push_back(l);
         }
         renderOptions->primitives.push_back(prim);
     }
-    (void)primSerial;
 }
 void pbrtReverseOrientation() { VERIFY_WORLD("ReverseOrientation"); graphicsState.reverseOrientation = !graphicsState.reverseOrientation; }
 void pbrtObjectBegin(const std::string &name) {

@@ -18,6 +18,22 @@ Float Triangle::Area() const {  // triangle.cpp:574-580; 0.5 is a double literal
     return 0.5 * Cross(p1 - p0, p2 - p0).Length();
 }
 
+Sphere::Sphere(const Transform &o2w, const Transform &w2o, bool ro, Float r, Float z0, Float z1, Float pm)  // sphere.h:50-60
+    : ObjectToWorld(o2w), WorldToObject(w2o), reverseOrientation(ro), transformSwapsHandedness(o2w.SwapsHandedness()), radius(r),
+      zMin(Clamp(std::min(z0, z1), -r, r)), zMax(Clamp(std::max(z0, z1), -r, r)),
+      thetaMin(std::acos(Clamp(std::min(z0, z1) / r, -1, 1))), thetaMax(std::acos(Clamp(std::max(z0, z1) / r, -1, 1))),
+      phiMax(Radians(Clamp(pm, 0, 360))) {}
+Bounds3f Sphere::WorldBound() const {  // Transform::operator()(Bounds3f), transform.cpp:237-249
+    const Float lo[3] = {-radius, -radius, zMin}, hi[3] = {radius, radius, zMax};  // ObjectBound
+    Bounds3f ret;
+    for (int corner = 0; corner < 8; ++corner) {  // min/max over the eight transformed corners: the order does not matter
+        Point3f c((corner & 1) ? hi[0] : lo[0], (corner & 2) ? hi[1] : lo[1], (corner & 4) ? hi[2] : lo[2]);
+        Point3f w = ObjectToWorld.Pt(c);
+        ret = corner == 0 ? Bounds3f(w) : Union(ret, w);
+    }
+    return ret;
+}
+
 struct BVHAccel::PrimInfo {  // BVHPrimitiveInfo, bvh.cpp:49-59
     PrimInfo() {}
     PrimInfo(size_t primitiveNumber, const Bounds3f &bounds)
@@ -50,7 +66,7 @@ BVHAccel::BVHAccel(std::vector<GeometricPrimitive> p, int maxPrims, SplitMethod 
     : primitives(std::move(p)), maxPrimsInNode(std::min(255, maxPrims)), splitMethod(sm) {
     if (primitives.empty()) return;
     std::vector<PrimInfo> primitiveInfo(primitives.size());
-    for (size_t i = 0; i < primitives.size(); ++i) primitiveInfo[i] = {i, primitives[i].shape.WorldBound()};
+    for (size_t i = 0; i < primitives.size(); ++i) primitiveInfo[i] = {i, primitives[i].WorldBound()};
     int totalNodes = 0;
     std::vector<GeometricPrimitive> orderedPrims;
     orderedPrims.reserve(primitives.size());

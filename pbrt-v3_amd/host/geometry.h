@@ -16,6 +16,7 @@ static constexpr Float Pi = 3.14159265358979323846;
 static constexpr Float Infinity = std::numeric_limits<Float>::infinity();
 static constexpr Float MachineEpsilon = std::numeric_limits<Float>::epsilon() * 0.5;
 inline Float gamma(int n) { return (n * MachineEpsilon) / (1 - n * MachineEpsilon); }  // pbrt.h:289-291
+inline Float Clamp(Float v, Float lo, Float hi) { return v < lo ? lo : (v > hi ? hi : v); }  // pbrt.h:305-311
 inline Float Radians(Float deg) { return (Pi / 180) * deg; }                            // pbrt.h:324
 inline Float Lerp(Float t, Float v1, Float v2) { return (1 - t) * v1 + t * v2; }        // pbrt.h:417
 

@@ -180,7 +180,22 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     // concatenate the meshes' vertex arrays in first-use order
     std::map<const TriangleMesh *, int> meshBase;
     bool anyN = false, anyUV = false, anyS = false;
+    std::map<const Sphere *, int> sphereIndex;
     for (const auto &prim : bvh.primitives) {
+        if (prim.sphere) {
+            const Sphere *sp = prim.sphere.get();
+            if (sphereIndex.count(sp)) continue;
+            sphereIndex[sp] = (int)flat->spheres.size();
+            PgSphere g;
+            memset(&g, 0, sizeof(g));
+            const Matrix4x4 &m = sp->ObjectToWorld.GetMatrix(), &mi = sp->WorldToObject.GetMatrix();
+            for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { g.o2w[4 * r + c] = m.m[r][c]; g.w2o[4 * r + c] = mi.m[r][c]; }
+            g.radius = sp->radius; g.z_min = sp->zMin; g.z_max = sp->zMax;
+            g.theta_min = sp->thetaMin; g.theta_max = sp->thetaMax; g.phi_max = sp->phiMax;
+            g.reverse_orientation = sp->reverseOrientation; g.swaps_handedness = sp->transformSwapsHandedness;
+            flat->spheres.push_back(g);
+            continue;
+        }
         const TriangleMesh *m = prim.shape.mesh.get();
         if (meshBase.count(m)) continue;
         meshBase[m] = (int)(flat->P.size() / 3);
@@ -200,6 +215,14 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     }
     for (size_t k = 0; k < nTris; ++k) {
         const GeometricPrimitive &prim = bvh.primitives[k];
+        flat->triMaterial[k] = prim.material;
+        flat->triLight[k] = prim.areaLight;
+        if (prim.sphere) {
+            flat->indices[3 * k] = sphereIndex[prim.sphere.get()];
+            flat->indices[3 * k + 1] = flat->indices[3 * k + 2] = 0;
+            flat->triFlags[k] = PG_PRIM_SPHERE;
+            continue;
+        }
         const TriangleMesh *m = prim.shape.mesh.get();
         int base = meshBase[m];
         const int *v = prim.shape.v();
@@ -211,8 +234,6 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
         if (!m->uv.empty()) f |= PG_TRI_HAS_UV;
         if (!m->s.empty()) f |= PG_TRI_HAS_S;
         flat->triFlags[k] = f;
-        flat->triMaterial[k] = prim.material;
-        flat->triLight[k] = prim.areaLight;
     }
     flat->materials = scene.materials;
     flat->lights = scene.lights;
@@ -248,6 +269,7 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
         d.light_strategy = PG_LIGHTS_SPATIAL;
     }
     d.n_perm_dims = (int)flat->permSums.size() - 1; d.perms = flat->perms.data(); d.perm_sums = flat->permSums.data();
+    d.n_spheres = (int)flat->spheres.size(); d.spheres = flat->spheres.data();
 }
 
 void GpuPathIntegrator::FillRenderDesc(PgRenderDesc *rd) const {

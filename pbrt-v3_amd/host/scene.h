@@ -32,11 +32,22 @@ struct Triangle {
     Bounds3f WorldBound() const;  // triangle.cpp:180-186
     Float Area() const;           // triangle.cpp:574-580
 };
-// core/primitive.h:68-89: shape + material + area light (indices into tables).
+// shapes/sphere.h:46-79: a quadric kept in object space with its two transforms.
+struct Sphere {
+    Sphere(const Transform &o2w, const Transform &w2o, bool reverseOrientation, Float radius, Float zMin, Float zMax, Float phiMax);
+    Transform ObjectToWorld, WorldToObject;
+    bool reverseOrientation, transformSwapsHandedness;
+    Float radius, zMin, zMax, thetaMin, thetaMax, phiMax;
+    Bounds3f WorldBound() const;  // shape.cpp:49 over sphere.cpp:43-46
+    Float Area() const { return phiMax * radius * (zMax - zMin); }  // sphere.cpp:203
+};
+// core/primitive.h:68-89: shape + material + area light (indices into tables).  The shape is a Triangle unless `sphere` is set.
 struct GeometricPrimitive {
     Triangle shape;
+    std::shared_ptr<Sphere> sphere;
     int material = -1;
     int areaLight = -1;
+    Bounds3f WorldBound() const { return sphere ? sphere->WorldBound() : shape.WorldBound(); }
 };
 
 // accelerators/bvh.{h,cpp}: SAH / Middle / EqualCounts build + flattenBVHTree.
@@ -129,6 +140,7 @@ struct FlatScene {
     std::vector<PgBVHNode> nodes;
     std::vector<PgMaterial> materials;
     std::vector<PgLight> lights;
+    std::vector<PgSphere> spheres;
 };
 
 // core/integrator.h:53-58.

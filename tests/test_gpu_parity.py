@@ -22,12 +22,22 @@ def rel_err(img, ref):
 
 
 @pytest.mark.parametrize("name", golden_names())
-def test_golden_images(gpu, name):
+def test_golden_images(gpu, oracle, name):
+    """The device image against the image the UNMODIFIED reference rendered: per-pixel |d| <= 1e-4 * max(1, |ref|).
+    The only arithmetic the device does not share bit for bit with the reference is glibc's sinf/cosf/acosf/atan2f (not
+    correctly rounded; the device evaluates them in double and rounds once).  A last-bit difference there can, a few
+    bounces later, tip one discrete event of one sample (a ray passing an edge): such a pixel is accepted only when the
+    CPU oracle built with correctly rounded libm (liboracle_crlibm.so) reproduces the device's value exactly, and at most
+    2 pixels per image."""
     scene = gpu.HostScene(os.path.join(GOLD, name + ".pbrt"))
     img, cn = gpu.render_scene(scene)
     ref = gpu.read_pfm(os.path.join(GOLD, name + ".pfm"))
     err = rel_err(img, ref)
-    assert err.max() <= TOL, f"max rel err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+    bad = err.max(axis=2) > TOL
+    if bad.any():
+        cr_img, _ = oracle.render_image(scene, cr_libm=True)
+        assert bad.sum() <= 2 and np.array_equal(img[bad], cr_img[bad]), f"max rel err {err.max():.3e} at {np.argwhere(bad)[:4].tolist()}"
+        err[bad] = 0
     # nearly every pixel is bit-identical; the rest differ in the last ulps only
     assert (err.max(axis=2) > 0).mean() < 0.25
     stats = json.load(open(os.path.join(GOLD, name + ".json")))
@@ -36,7 +46,7 @@ def test_golden_images(gpu, name):
         assert abs(cn[k] - stats[k]) <= max(4, 2e-3 * stats[k]), (k, cn[k], stats[k])
 
 
-@pytest.mark.parametrize("name", ["cornell_32", "cornell_crop", "synthetic_n40", "cornell_lens", "cornell_plastic", "plastic_topdown", "cornell_normals", "cornell_tangents", "cornell_lightnormals", "cornell_point", "cornell_spot_power", "cornell_delta_only", "cornell_mirror_glass", "cornell_glass_eta", "filter_gaussian", "filter_mitchell_crop", "filter_widebox", "cornell_orennayar", "cornell_ortho_lens", "cornell_loopsubdiv", "env_only", "env_mixed_power", "env_uniform_open"])
+@pytest.mark.parametrize("name", ["cornell_32", "cornell_crop", "synthetic_n40", "cornell_lens", "cornell_plastic", "plastic_topdown", "cornell_normals", "cornell_tangents", "cornell_lightnormals", "cornell_point", "cornell_spot_power", "cornell_delta_only", "cornell_mirror_glass", "cornell_glass_eta", "filter_gaussian", "filter_mitchell_crop", "filter_widebox", "cornell_orennayar", "cornell_ortho_lens", "cornell_loopsubdiv", "env_only", "env_mixed_power", "env_uniform_open", "sphere_light", "sphere_partial", "sphere_enclosing"])
 def test_film_buffers_vs_oracle(gpu, oracle, name):
     scene = gpu.HostScene(os.path.join(GOLD, name + ".pbrt"))
     gs = gpu.GpuScene(scene.desc)
@@ -52,6 +62,29 @@ def test_film_buffers_vs_oracle(gpu, oracle, name):
     for f in ("px", "py", "src_px", "src_py", "weight"):
         assert np.array_equal(a[f], b[f]), f
     assert np.abs(a["rgb"] - b["rgb"]).max() <= TOL * max(1.0, np.abs(b["rgb"]).max()) if len(a) else True
+    gs.close()
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_film_bit_identical_to_correctly_rounded_oracle(gpu, oracle, name):
+    """Every film pixel and stray sample of the device equals, bit for bit, the CPU oracle built with correctly rounded
+    sinf/cosf/acosf/atan2f (oracle/liboracle_crlibm.so: same source as the oracle pinned against the reference, only those
+    four libm calls differ): apart from libm's last bit the device computes the reference's arithmetic exactly."""
+    scene = gpu.HostScene(os.path.join(GOLD, name + ".pbrt"))
+    gs = gpu.GpuScene(scene.desc)
+    rd = scene.render_desc()
+    film, strays = gs.render(rd)
+    cn = gs.counters()
+    ofilm, ostrays, ocn = oracle.render(scene.desc, rd, cr_libm=True)
+    assert np.array_equal(film["weight"], ofilm["weight"])
+    assert np.array_equal(film["rgb"], ofilm["rgb"]), f"{(film['rgb'] != ofilm['rgb']).any(axis=1).sum()} pixels differ"
+    key = lambda s: np.lexsort((s["src_px"], s["src_py"], s["px"], s["py"]))
+    a, b = strays[key(strays)], ostrays[key(ostrays)]
+    assert len(a) == len(b)
+    for f in ("px", "py", "src_px", "src_py", "weight", "rgb"):
+        assert np.array_equal(a[f], b[f]), f
+    for k in ("camera_rays", "closest_rays", "shadow_rays", "tri_tests", "node_visits"):  # the reference's counters, exactly
+        assert cn[k] == ocn[k], (k, cn[k], ocn[k])
     gs.close()
 
 
@@ -91,6 +124,35 @@ def test_intersect_bit_exact(gpu, oracle, n):
     if n > 1:
         assert (prim >= 0).any() and (prim < 0).any()
         assert ((prim >= 0) == (occ == 1)).all()  # closest-hit and any-hit agree on hit/miss
+    gs.close()
+
+
+@pytest.mark.parametrize("name", ["sphere_light", "sphere_partial", "sphere_enclosing"])
+def test_sphere_rays_bit_exact(gpu, oracle, name):
+    """Shape "sphere" in the BVH next to triangles: Sphere::Intersect / IntersectP (error-bounded quadratic, partial-sphere
+    clipping, transforms) decide every ray as the oracle does, tHit included; a sphere hit reports (tHit, 0, 0) as its bary."""
+    scene = gpu.HostScene(os.path.join(GOLD, name + ".pbrt"))
+    assert scene.desc.n_spheres >= 1
+    gs = gpu.GpuScene(scene.desc)
+    n = 20000
+    o, d = random_rays(scene, n, 99)
+    flags = np.ctypeslib.as_array(scene.desc.tri_flags, (scene.desc.n_tris,))
+    tmax = np.full(n, np.inf, np.float32)
+    tmax[::5] = 300.0
+    gs.counters_reset()
+    prim, t, bary = gs.intersect(o, d, tmax)
+    oprim, ot, obary, ocn = oracle.intersect(scene.desc, o, d, tmax)
+    on_sphere = (prim >= 0) & ((flags[np.maximum(prim, 0)] & 32) != 0)
+    assert on_sphere.sum() > 200
+    assert np.array_equal(prim, oprim) and np.array_equal(t, ot) and np.array_equal(bary, obary)
+    assert np.array_equal(bary[on_sphere, 0], t[on_sphere])
+    cn = gs.counters()
+    assert cn["closest_node_visits"] == ocn["node_visits"] and cn["closest_tri_tests"] == ocn["tri_tests"]
+    occ = gs.intersect_p(o, d, tmax)
+    oocc, ocn2 = oracle.intersect_p(scene.desc, o, d, tmax)
+    assert np.array_equal(occ, oocc)
+    cn = gs.counters()
+    assert cn["shadow_node_visits"] == ocn2["node_visits"] and cn["shadow_tri_tests"] == ocn2["tri_tests"]
     gs.close()
 
 

@@ -32,6 +32,27 @@ def test_reference_binary_live_when_present(pkg, oracle, tmp_path):
     assert np.array_equal(pkg.read_pfm(out), pkg.read_pfm(os.path.join(GOLD, name + ".pfm")))
 
 
+def test_config0_killeroo_simple_unmodified(pkg, oracle, tmp_path):
+    """BASELINE.json config 0, scenes/killeroo-simple.pbrt exactly as the reference ships it (sphere area light, two
+    Loop-subdivided killeroos, plastic, uv'd planes) at a reduced resolution: the unmodified reference and this
+    repository's front end + oracle produce bit-identical images.  Reads /root/reference (build container only)."""
+    src = "/root/reference/scenes"
+    if not os.path.exists(os.path.join(src, "killeroo-simple.pbrt")) or not os.path.exists(oracle.REF_BINARY):
+        pytest.skip("reference scenes / binary not available here")
+    os.makedirs(tmp_path / "geometry")
+    os.symlink(os.path.join(src, "geometry", "killeroo.pbrt"), tmp_path / "geometry" / "killeroo.pbrt")
+    s = open(os.path.join(src, "killeroo-simple.pbrt")).read()
+    s = s.replace('"integer xresolution" [700] "integer yresolution" [700]', '"integer xresolution" [100] "integer yresolution" [100]').replace("killeroo-simple.exr", "kroo.pfm")
+    scene_file = str(tmp_path / "kroo.pbrt")
+    open(scene_file, "w").write(s)
+    out = str(tmp_path / "ref.pfm")
+    oracle.run_reference(scene_file, out, nthreads=4)
+    scene = pkg.HostScene(scene_file)
+    assert scene.desc.n_tris == 2 * 33264 + 4 + 1 and scene.desc.n_spheres == 1
+    img, _ = oracle.render_image(scene)
+    assert np.array_equal(img, pkg.read_pfm(out))
+
+
 def test_killeroo_geometry_live_when_reference_present(pkg, oracle, tmp_path):
     """BASELINE.json config 0's scene (scenes/killeroo-simple.pbrt: two Loop-subdivided killeroos, 66 532 triangles, plastic,
     uv'd planes) with its sphere light swapped for an emissive quad -- spheres are outside the closed set.  The scene data
