@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 6
+#define PG_ABI_VERSION 7
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -66,8 +66,46 @@ typedef enum PgMaterialType {
     PG_MAT_MATTE = 1,  /* materials/matte.cpp:45-62   */
     PG_MAT_PLASTIC = 2,/* materials/plastic.cpp:45-70 */
     PG_MAT_MIRROR = 3, /* materials/mirror.cpp:44-56: SpecularReflection(Kr, FresnelNoOp)              */
-    PG_MAT_GLASS = 4   /* materials/glass.cpp:45-96, smooth only: FresnelSpecular(Kr, Kt, 1, eta)      */
+    PG_MAT_GLASS = 4,  /* materials/glass.cpp:45-96, smooth only: FresnelSpecular(Kr, Kt, 1, eta)      */
+    PG_MAT_LOBES = 5   /* any other material (uber, metal, substrate, translucent, mix, rough glass ...): defined by
+                          its BxDF list alone, bxdfs[first_bxdf .. first_bxdf + n_bxdfs)                          */
 } PgMaterialType;
+
+/* One BxDF of a material's BSDF (core/reflection.h).  With constant textures Material::ComputeScatteringFunctions adds
+ * the same BxDFs with the same parameters at every point, so a material IS its BxDF list (in the order of the Add()
+ * calls) plus BSDF::eta; only the shading frame varies per hit.  Every material carries its list, also types 1-4, whose
+ * `type` additionally tells the device that the list has that material's fixed shape (a specialised kernel then reads the
+ * legacy fields instead). */
+typedef enum PgBxDFType {
+    PG_BXDF_LAMBERT_R = 1,     /* LambertianReflection(R),                     reflection.h:355-374 */
+    PG_BXDF_LAMBERT_T = 2,     /* LambertianTransmission(T),                   reflection.h:376-395 */
+    PG_BXDF_OREN_NAYAR = 3,    /* OrenNayar(R, sigma): on_a, on_b = its A, B,  reflection.h:397-433 */
+    PG_BXDF_SPECULAR_R = 4,    /* SpecularReflection(R, fresnel),              reflection.h:274-298 */
+    PG_BXDF_SPECULAR_T = 5,    /* SpecularTransmission(T, etaA, etaB, Radiance), reflection.h:300-329 */
+    PG_BXDF_FRESNEL_SPECULAR = 6, /* FresnelSpecular(R, T, etaA, etaB, Radiance), reflection.h:331-353 */
+    PG_BXDF_MICROFACET_R = 7,  /* MicrofacetReflection(R, TrowbridgeReitz(alpha_x, alpha_y), fresnel), reflection.h:435-457 */
+    PG_BXDF_MICROFACET_T = 8,  /* MicrofacetTransmission(T, TrowbridgeReitz, etaA, etaB, Radiance),    reflection.h:459-484 */
+    PG_BXDF_FRESNEL_BLEND = 9  /* FresnelBlend(Rd = R, Rs = T, TrowbridgeReitz),                         reflection.h:486-510 */
+} PgBxDFType;
+typedef enum PgFresnelType {
+    PG_FRESNEL_NOOP = 0,       /* FresnelNoOp: 1 */
+    PG_FRESNEL_DIELECTRIC = 1, /* FresnelDielectric(eta_a, eta_b) */
+    PG_FRESNEL_CONDUCTOR = 2   /* FresnelConductor(1, cond_eta, cond_k) */
+} PgFresnelType;
+#define PG_MAX_BXDFS 8         /* BSDF::MaxBxDFs, reflection.h:209 */
+#define PG_MAX_BXDF_SCALES 3   /* nesting depth of MixMaterial this ABI carries */
+typedef struct PgBxDF {
+    int32_t type;        /* PgBxDFType */
+    int32_t fresnel;     /* PgFresnelType, for SPECULAR_R and MICROFACET_R */
+    float R[3];          /* R; Rd of FresnelBlend */
+    float T[3];          /* T; Rs of FresnelBlend */
+    float eta_a, eta_b;  /* dielectric indices: Fresnel term and refraction */
+    float cond_eta[3], cond_k[3]; /* conductor */
+    float alpha_x, alpha_y;       /* TrowbridgeReitzDistribution's alphas as its constructor leaves them (microfacet.h:112-116) */
+    float on_a, on_b;    /* OrenNayar A, B */
+    int32_t n_scales;    /* ScaledBxDF wrappers around this BxDF (mixmat.cpp:60-65), innermost first */
+    float scale[PG_MAX_BXDF_SCALES][3];
+} PgBxDF;
 
 typedef struct PgMaterial {
     int32_t type;    /* PgMaterialType */
@@ -79,6 +117,8 @@ typedef struct PgMaterial {
     float kr[3];     /* mirror, glass */
     float kt[3];     /* glass */
     float eta;       /* glass: index of refraction */
+    int32_t first_bxdf, n_bxdfs; /* this material's BxDFs in PgSceneDesc.bxdfs, n_bxdfs <= PG_MAX_BXDFS */
+    float bsdf_eta;  /* BSDF::eta (reflection.h:167-172): the index the path's Russian roulette sees */
 } PgMaterial;
 
 /* scene.lights, in declaration order (api.cpp:1308-1327 for LightSource, :1353-1363 for area lights):
@@ -155,6 +195,8 @@ typedef struct PgSceneDesc {
     const int32_t *perm_sums;   /* n_perm_dims+1 entries */
     int32_t n_spheres;
     const PgSphere *spheres;
+    int32_t n_bxdfs;
+    const PgBxDF *bxdfs;
 } PgSceneDesc;
 
 /* ---- render description -------------------------------------------------- */

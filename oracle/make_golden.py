@@ -45,6 +45,14 @@ SPHERES_PARTIAL = ('AttributeBegin\n  Translate 400 120 150\n  Rotate 40 1 0.2 0
                    'AttributeBegin\n  Translate 150 420 300\n  Rotate -70 1 0 0\n  ReverseOrientation\n  AreaLightSource "diffuse" "rgb L" [ 9 9 12 ] "bool twosided" "true"\n'
                    '  Shape "sphere" "float radius" [ 50 ] "float zmin" [ -20 ] "float phimax" [ 300 ]\nAttributeEnd\n'
                    'AttributeBegin\n  Translate 500 500 500\n  AreaLightSource "area" "rgb L" [ 4000 3000 2000 ]\n  Shape "sphere" "float radius" [ 2 ]\nAttributeEnd\n')
+MIX_MATERIALS = ('MakeNamedMaterial "m_matte" "string type" "matte" "rgb Kd" [ 0.7 0.2 0.2 ]\n'
+                 'MakeNamedMaterial "m_metal" "string type" "metal" "float roughness" [ 0.05 ]\n'
+                 'MakeNamedMaterial "m_plastic" "string type" "plastic" "rgb Kd" [ 0.1 0.4 0.1 ]\n'
+                 'MakeNamedMaterial "m_mirror" "string type" "mirror"\n'
+                 'MakeNamedMaterial "m_glass" "string type" "glass"\n'
+                 'MakeNamedMaterial "mixA" "string type" "mix" "string namedmaterial1" "m_matte" "string namedmaterial2" "m_metal" "rgb amount" [ 0.3 0.5 0.7 ]\n'
+                 'MakeNamedMaterial "mixNested" "string type" "mix" "string namedmaterial1" "mixA" "string namedmaterial2" "m_plastic"\n'
+                 'MakeNamedMaterial "mixSpec" "string type" "mix" "string namedmaterial1" "m_mirror" "string namedmaterial2" "m_glass" "rgb amount" [ 0.4 0.4 0.4 ]\n')
 SPHERE_ENCLOSING = ('AttributeBegin\n  Translate 278 273 100\n  ReverseOrientation\n  AreaLightSource "diffuse" "rgb L" [ 0.5 0.6 0.8 ]\n'
                     '  Shape "sphere" "float radius" [ 1500 ]\nAttributeEnd\n')
 
@@ -222,6 +230,32 @@ SCENES = {
     "sphere_enclosing": cornell(24, 24, 8, integrator='Integrator "path" "integer maxdepth" [ 3 ] "string lightsamplestrategy" "power"',
                                 world_edit=lambda s: s.replace("# light\nAttributeBegin", SPHERE_ENCLOSING + "# light\nAttributeBegin")
                                 .replace('Shape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ]\n  "point P" [ 556 548.8 0   556 548.8 559.2   0 548.8 559.2   0 548.8 0 ]', "")),
+    # the materials that are BxDF lists only (PG_MAT_LOBES): uber (opacity, specular reflection + transmission lobes,
+    # anisotropic roughness), metal (FresnelConductor; the default copper spectra), substrate (FresnelBlend), translucent
+    # (Lambertian + microfacet transmission), rough glass (MicrofacetTransmission) and mix (ScaledBxDF, nested, with specular lobes)
+    "mat_uber": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 6 ]', world_edit=lambda s: s
+                        .replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\nMaterial "uber" "rgb Kd" [ 0.3 0.5 0.2 ] "rgb Kr" [ 0.2 0.2 0.2 ] "rgb Kt" [ 0.4 0.4 0.5 ] "rgb opacity" [ 0.6 0.7 1 ] "float uroughness" [ 0.05 ] "float vroughness" [ 0.3 ] "float index" [ 1.3 ]')
+                        .replace("# tall box", 'Material "uber"\n# tall box')
+                        .replace('Material "matte" "rgb Kd" [ 0.65 0.05 0.05 ]', 'Material "uber" "rgb Kd" [ 0.65 0.05 0.05 ] "rgb Ks" [ 0.4 0.4 0.4 ] "float roughness" [ 0.2 ] "bool remaproughness" "false" "float eta" [ 2 ]')),
+    "mat_metal": cornell(32, 32, 8, world_edit=lambda s: s
+                         .replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\nMaterial "metal" "rgb eta" [ 0.2 0.9 1.1 ] "rgb k" [ 3.9 2.4 2.1 ] "float uroughness" [ 0.02 ] "float vroughness" [ 0.2 ]')
+                         .replace("# tall box", 'Material "metal"\n# tall box')
+                         .replace('Material "matte" "rgb Kd" [ 0.12 0.45 0.15 ]', 'Material "metal" "float roughness" [ 0.3 ] "bool remaproughness" "false" "rgb eta" [ 1.5 0.4 0.3 ] "rgb k" [ 1.8 2.5 3 ]')),
+    "mat_substrate": cornell(32, 32, 8, world_edit=lambda s: s
+                             .replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\nMaterial "substrate" "rgb Kd" [ 0.1 0.3 0.6 ] "rgb Ks" [ 0.2 0.2 0.2 ] "float uroughness" [ 0.02 ] "float vroughness" [ 0.4 ]')
+                             .replace("# tall box", 'Material "substrate"\n# tall box')
+                             .replace('Material "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', 'Material "substrate" "rgb Kd" [ 0.7 0.7 0.7 ] "rgb Ks" [ 0 0 0 ] "bool remaproughness" "false"', 1)),
+    "mat_translucent": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 7 ]', world_edit=lambda s: s
+                               .replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\nMaterial "translucent" "rgb Kd" [ 0.5 0.6 0.3 ] "rgb Ks" [ 0.3 0.3 0.3 ] "rgb reflect" [ 0.3 0.3 0.3 ] "rgb transmit" [ 0.8 0.8 0.8 ] "float roughness" [ 0.15 ]')
+                               .replace("# tall box", 'Material "translucent" "rgb reflect" [ 0 0 0 ]\n# tall box')),
+    "mat_roughglass": cornell(32, 32, 16, integrator='Integrator "path" "integer maxdepth" [ 8 ]', world_edit=lambda s: s
+                              .replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\nMaterial "glass" "float uroughness" [ 0.1 ] "float vroughness" [ 0.35 ] "float index" [ 1.4 ] "rgb Kt" [ 0.9 1 0.9 ]')
+                              .replace("# tall box", 'Material "glass" "float uroughness" [ 0.05 ] "float vroughness" [ 0.05 ] "bool remaproughness" "false" "rgb Kr" [ 0 0 0 ]\n# tall box')),
+    "mat_mix": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 7 ]', world_edit=lambda s: s
+                       .replace("# light\nAttributeBegin", MIX_MATERIALS + "# light\nAttributeBegin")
+                       .replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\nNamedMaterial "mixA"')
+                       .replace("# tall box", 'NamedMaterial "mixNested"\n# tall box')
+                       .replace('Material "matte" "rgb Kd" [ 0.12 0.45 0.15 ]', 'NamedMaterial "mixSpec"')),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 

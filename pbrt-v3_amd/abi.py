@@ -5,7 +5,7 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 6
+PG_ABI_VERSION = 7
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
 PG_LIGHTS_UNIFORM, PG_LIGHTS_POWER, PG_LIGHTS_SPATIAL = 0, 1, 2
@@ -22,7 +22,7 @@ class PgBVHNode(C.Structure):
 class PgMaterial(C.Structure):
     _fields_ = [("type", C.c_int32), ("kd", C.c_float * 3), ("ks", C.c_float * 3), ("sigma", C.c_float),
                 ("roughness", C.c_float), ("remap_roughness", C.c_int32), ("kr", C.c_float * 3), ("kt", C.c_float * 3),
-                ("eta", C.c_float)]
+                ("eta", C.c_float), ("first_bxdf", C.c_int32), ("n_bxdfs", C.c_int32), ("bsdf_eta", C.c_float)]
 
 
 class PgLight(C.Structure):
@@ -30,6 +30,13 @@ class PgLight(C.Structure):
                 ("pos", C.c_float * 3), ("w2l", C.c_float * 9), ("cos_total_width", C.c_float), ("cos_falloff_start", C.c_float),
                 ("world_radius", C.c_float), ("l2w", C.c_float * 9), ("env_func", C.c_float * 4), ("env_cdf", C.c_float * 6),
                 ("env_int", C.c_float * 2), ("env_marg_cdf", C.c_float * 3), ("env_marg_int", C.c_float)]
+
+
+class PgBxDF(C.Structure):
+    _fields_ = [("type", C.c_int32), ("fresnel", C.c_int32), ("R", C.c_float * 3), ("T", C.c_float * 3),
+                ("eta_a", C.c_float), ("eta_b", C.c_float), ("cond_eta", C.c_float * 3), ("cond_k", C.c_float * 3),
+                ("alpha_x", C.c_float), ("alpha_y", C.c_float), ("on_a", C.c_float), ("on_b", C.c_float),
+                ("n_scales", C.c_int32), ("scale", C.c_float * 9)]
 
 
 class PgSphere(C.Structure):
@@ -49,7 +56,8 @@ class PgSceneDesc(C.Structure):
                 ("n_lights", C.c_int32), ("lights", C.POINTER(PgLight)),
                 ("light_strategy", C.c_int32),
                 ("n_perm_dims", C.c_int32), ("perms", C.POINTER(C.c_uint16)), ("perm_sums", C.POINTER(C.c_int32)),
-                ("n_spheres", C.c_int32), ("spheres", C.POINTER(PgSphere))]
+                ("n_spheres", C.c_int32), ("spheres", C.POINTER(PgSphere)),
+                ("n_bxdfs", C.c_int32), ("bxdfs", C.POINTER(PgBxDF))]
 
 
 class PgRenderDesc(C.Structure):

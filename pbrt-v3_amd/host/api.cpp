@@ -76,6 +76,7 @@ struct RenderOptions {
     std::vector<PgLight> lights;           // prim index filled at flatten time
     std::vector<size_t> lightPrimSerial;   // serial number of the emitting primitive
     std::vector<PgMaterial> materials;
+    std::vector<PgBxDF> bxdfs;  // the materials' BxDF lists, concatenated
     bool haveScatteringMedia = false;
 };
 enum class APIState { Uninitialized, OptionsBlock, WorldBlock };
@@ -144,53 +145,225 @@ static Float floatParam(const ParamSet &geom, const ParamSet &mat, const std::st
     }
     return def;
 }
-static int internMaterial(const PgMaterial &m) {
+// A material is interned with its BxDF list: equal parameters and equal lists share one table entry.
+static int internMaterial(PgMaterial m, const std::vector<PgBxDF> &lobes) {
     auto &tab = renderOptions->materials;
-    for (size_t i = 0; i < tab.size(); ++i)
-        if (memcmp(&tab[i], &m, sizeof(m)) == 0) return (int)i;
+    auto &bx = renderOptions->bxdfs;
+    m.n_bxdfs = (int)lobes.size();
+    for (size_t i = 0; i < tab.size(); ++i) {
+        PgMaterial probe = m;
+        probe.first_bxdf = tab[i].first_bxdf;
+        if (memcmp(&tab[i], &probe, sizeof(m)) != 0) continue;
+        if (lobes.empty() || memcmp(&bx[tab[i].first_bxdf], lobes.data(), lobes.size() * sizeof(PgBxDF)) == 0) return (int)i;
+    }
+    m.first_bxdf = (int)bx.size();
+    bx.insert(bx.end(), lobes.begin(), lobes.end());
     tab.push_back(m);
     return (int)tab.size() - 1;
+}
+// ---- BxDF lists: what each material's ComputeScatteringFunctions adds, with its constant textures evaluated ----------
+static RGB rgbClamp(RGB v) { for (int i = 0; i < 3; ++i) v.c[i] = v.c[i] < 0 ? 0 : v.c[i]; return v; }  // Spectrum::Clamp(), spectrum.h:180-186
+static RGB rgbMul(RGB a, RGB b) { RGB r; for (int i = 0; i < 3; ++i) r.c[i] = a.c[i] * b.c[i]; return r; }
+static bool rgbBlack(RGB v) { return v.c[0] == 0 && v.c[1] == 0 && v.c[2] == 0; }
+static PgBxDF lobe(int type) { PgBxDF b; memset(&b, 0, sizeof(b)); b.type = type; b.eta_a = b.eta_b = 1; b.alpha_x = b.alpha_y = 1; b.on_a = 1; return b; }
+static void setR(PgBxDF &b, RGB v) { for (int i = 0; i < 3; ++i) b.R[i] = v.c[i]; }
+static void setT(PgBxDF &b, RGB v) { for (int i = 0; i < 3; ++i) b.T[i] = v.c[i]; }
+static Float RoughnessToAlpha(Float roughness) {  // TrowbridgeReitzDistribution::RoughnessToAlpha, microfacet.h:127-132
+    roughness = std::max(roughness, (Float)1e-3);
+    Float x = std::log(roughness);
+    return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+}
+static void setTR(PgBxDF &b, Float ax, Float ay) {  // TrowbridgeReitzDistribution ctor, microfacet.h:109-113
+    b.alpha_x = std::max(Float(0.001), ax);
+    b.alpha_y = std::max(Float(0.001), ay);
+}
+static void setDielectric(PgBxDF &b, Float etaA, Float etaB) { b.fresnel = PG_FRESNEL_DIELECTRIC; b.eta_a = etaA; b.eta_b = etaB; }
+static PgBxDF lambertOrOrenNayar(RGB r, Float sigmaDeg) {  // matte.cpp:55-61, OrenNayar ctor reflection.h:425-431
+    Float sig = Clamp(sigmaDeg, 0, 90);
+    PgBxDF b = lobe(sig == 0 ? PG_BXDF_LAMBERT_R : PG_BXDF_OREN_NAYAR);
+    setR(b, r);
+    if (sig != 0) {
+        Float sigma = Radians(sig), sigma2 = sigma * sigma;
+        b.on_a = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
+        b.on_b = 0.45f * sigma2 / (sigma2 + 0.09f);
+    }
+    return b;
+}
+// MetalMaterial's default spectra as the reference's RGB build derives them (Spectrum::FromSampled of metal.cpp's copper
+// tables over the CIE curves); printed from the unmodified reference by oracle/ref_probe.cpp
+static const RGB kCopperN = {{0.19999069f, 0.92208463f, 1.09987593f}};
+static const RGB kCopperK = {{3.90463543f, 2.44763327f, 2.13765264f}};
+
+static bool hasParam(const ParamSet &geom, const ParamSet &mat, const std::string &n) {  // GetFloatTextureOrNull finds something
+    return geom.FindFloat(n) || mat.FindFloat(n) || !geom.FindTexture(n).empty() || !mat.FindTexture(n).empty();
 }
 static int MakeMaterial(const std::string &name, const ParamSet &geom, const ParamSet &mat) {
     PgMaterial m;
     memset(&m, 0, sizeof(m));
-    if (name == "" || name == "none") { m.type = PG_MAT_NONE; return internMaterial(m); }
-    if (name == "matte") {
-        m.type = PG_MAT_MATTE;
-        RGB kd = spectrumParam(geom, mat, "Kd", RGB{{0.5f, 0.5f, 0.5f}}, graphicsState);
+    std::vector<PgBxDF> lobes;
+    m.bsdf_eta = 1;  // BSDF(si, eta = 1), reflection.h:167
+    if (name == "" || name == "none") { m.type = PG_MAT_NONE; return internMaterial(m, lobes); }
+    const GraphicsState &gs = graphicsState;
+    auto spec = [&](const char *n, Float d) { return spectrumParam(geom, mat, n, RGB{{d, d, d}}, gs); };
+    auto flt = [&](const char *n, Float d) { return floatParam(geom, mat, n, d, gs); };
+    auto remapParam = [&]() { return geom.FindOneBool("remaproughness", mat.FindOneBool("remaproughness", true)); };
+    if (!geom.FindTexture("bumpmap").empty() || !mat.FindTexture("bumpmap").empty())
+        Error("\"bumpmap\" textures are not supported by this build; ignoring.");
+    if (name == "matte" || (name != "plastic" && name != "mirror" && name != "glass" && name != "uber" && name != "metal" &&
+                            name != "substrate" && name != "translucent" && name != "mix")) {
+        if (name != "matte") {
+            if (name == "hair" || name == "disney" || name == "subsurface" || name == "kdsubsurface" || name == "fourier")
+                Error("Material \"%s\" is outside this build's closed set (matte, plastic, mirror, glass, uber, metal, substrate, translucent, mix); using matte.", name.c_str());
+            else Warning("Material \"%s\" unknown. Using \"matte\".", name.c_str());  // api.cpp:588-591
+        }
+        m.type = PG_MAT_MATTE;  // matte.cpp:45-72
+        RGB kd = spec("Kd", 0.5f);
         for (int i = 0; i < 3; ++i) m.kd[i] = kd.c[i];
-        m.sigma = floatParam(geom, mat, "sigma", 0.f, graphicsState);
-        if (!geom.FindTexture("bumpmap").empty() || !mat.FindTexture("bumpmap").empty())
-            Error("\"bumpmap\" textures are not supported by this build; ignoring.");
-    } else if (name == "plastic") {
+        m.sigma = flt("sigma", 0.f);
+        RGB r = rgbClamp(kd);
+        if (!rgbBlack(r)) lobes.push_back(lambertOrOrenNayar(r, m.sigma));
+    } else if (name == "plastic") {  // plastic.cpp:45-84
         m.type = PG_MAT_PLASTIC;
-        RGB kd = spectrumParam(geom, mat, "Kd", RGB{{0.25f, 0.25f, 0.25f}}, graphicsState);
-        RGB ks = spectrumParam(geom, mat, "Ks", RGB{{0.25f, 0.25f, 0.25f}}, graphicsState);
+        RGB kd = spec("Kd", 0.25f), ks = spec("Ks", 0.25f);
         for (int i = 0; i < 3; ++i) { m.kd[i] = kd.c[i]; m.ks[i] = ks.c[i]; }
-        m.roughness = floatParam(geom, mat, "roughness", .1f, graphicsState);
-        bool remap = geom.FindOneBool("remaproughness", mat.FindOneBool("remaproughness", true));
-        m.remap_roughness = remap ? 1 : 0;
-    } else if (name == "mirror") {  // mirror.cpp:58-64
+        m.roughness = flt("roughness", .1f);
+        m.remap_roughness = remapParam() ? 1 : 0;
+        if (!rgbBlack(rgbClamp(kd))) { PgBxDF b = lobe(PG_BXDF_LAMBERT_R); setR(b, rgbClamp(kd)); lobes.push_back(b); }
+        if (!rgbBlack(rgbClamp(ks))) {
+            PgBxDF b = lobe(PG_BXDF_MICROFACET_R);
+            setR(b, rgbClamp(ks));
+            setDielectric(b, 1.5f, 1.f);
+            Float rough = m.roughness;
+            if (m.remap_roughness) rough = RoughnessToAlpha(rough);
+            setTR(b, rough, rough);
+            lobes.push_back(b);
+        }
+    } else if (name == "mirror") {  // mirror.cpp:44-64
         m.type = PG_MAT_MIRROR;
-        RGB kr = spectrumParam(geom, mat, "Kr", RGB{{0.9f, 0.9f, 0.9f}}, graphicsState);
+        RGB kr = spec("Kr", 0.9f);
         for (int i = 0; i < 3; ++i) m.kr[i] = kr.c[i];
-    } else if (name == "glass") {  // glass.cpp:98-115
-        m.type = PG_MAT_GLASS;
-        RGB kr = spectrumParam(geom, mat, "Kr", RGB{{1.f, 1.f, 1.f}}, graphicsState);
-        RGB kt = spectrumParam(geom, mat, "Kt", RGB{{1.f, 1.f, 1.f}}, graphicsState);
+        if (!rgbBlack(rgbClamp(kr))) { PgBxDF b = lobe(PG_BXDF_SPECULAR_R); setR(b, rgbClamp(kr)); b.fresnel = PG_FRESNEL_NOOP; lobes.push_back(b); }
+    } else if (name == "glass") {  // glass.cpp:45-115
+        RGB kr = spec("Kr", 1.f), kt = spec("Kt", 1.f);
         for (int i = 0; i < 3; ++i) { m.kr[i] = kr.c[i]; m.kt[i] = kt.c[i]; }
-        bool hasEta = geom.FindFloat("eta") || mat.FindFloat("eta") || !geom.FindTexture("eta").empty() || !mat.FindTexture("eta").empty();
-        m.eta = hasEta ? floatParam(geom, mat, "eta", 1.5f, graphicsState) : floatParam(geom, mat, "index", 1.5f, graphicsState);
-        Float ur = floatParam(geom, mat, "uroughness", 0.f, graphicsState), vr = floatParam(geom, mat, "vroughness", 0.f, graphicsState);
-        geom.FindOneBool("remaproughness", mat.FindOneBool("remaproughness", true));
-        if (ur != 0 || vr != 0) Error("Rough glass (microfacet transmission) is not supported by this build; using smooth glass.");
-    } else {
-        Error("Material \"%s\" is outside this build's closed set (matte, plastic, mirror, glass); using matte.", name.c_str());
-        m.type = PG_MAT_MATTE;
-        m.kd[0] = m.kd[1] = m.kd[2] = 0.5f;
+        m.eta = hasParam(geom, mat, "eta") ? flt("eta", 1.5f) : flt("index", 1.5f);
+        Float ur = flt("uroughness", 0.f), vr = flt("vroughness", 0.f);
+        const bool remap = remapParam();
+        const RGB R = rgbClamp(kr), T = rgbClamp(kt);
+        m.bsdf_eta = m.eta;
+        const bool isSpecular = ur == 0 && vr == 0;
+        m.type = isSpecular ? PG_MAT_GLASS : PG_MAT_LOBES;
+        if (!(rgbBlack(R) && rgbBlack(T))) {
+            if (isSpecular) {  // allowMultipleLobes is true on the path integrator's call (path.cpp:106)
+                PgBxDF b = lobe(PG_BXDF_FRESNEL_SPECULAR); setR(b, R); setT(b, T); b.eta_a = 1.f; b.eta_b = m.eta; lobes.push_back(b);
+            } else {
+                if (remap) { ur = RoughnessToAlpha(ur); vr = RoughnessToAlpha(vr); }
+                if (!rgbBlack(R)) { PgBxDF b = lobe(PG_BXDF_MICROFACET_R); setR(b, R); setDielectric(b, 1.f, m.eta); setTR(b, ur, vr); lobes.push_back(b); }
+                if (!rgbBlack(T)) { PgBxDF b = lobe(PG_BXDF_MICROFACET_T); setT(b, T); b.eta_a = 1.f; b.eta_b = m.eta; setTR(b, ur, vr); lobes.push_back(b); }
+            }
+        }
+    } else if (name == "uber") {  // uber.cpp:45-128
+        m.type = PG_MAT_LOBES;
+        RGB Kd = spec("Kd", 0.25f), Ks = spec("Ks", 0.25f), Kr = spec("Kr", 0.f), Kt = spec("Kt", 0.f);
+        Float roughness = flt("roughness", .1f);
+        const bool hasU = hasParam(geom, mat, "uroughness"), hasV = hasParam(geom, mat, "vroughness");
+        Float uro = hasU ? flt("uroughness", 0.f) : 0.f, vro = hasV ? flt("vroughness", 0.f) : 0.f;
+        Float e = hasParam(geom, mat, "eta") ? flt("eta", 1.5f) : flt("index", 1.5f);
+        RGB opacity = spec("opacity", 1.f);
+        const bool remap = remapParam();
+        RGB op = rgbClamp(opacity), t;
+        for (int i = 0; i < 3; ++i) t.c[i] = -op.c[i] + 1.f;
+        t = rgbClamp(t);
+        if (!rgbBlack(t)) { PgBxDF b = lobe(PG_BXDF_SPECULAR_T); setT(b, t); b.eta_a = 1.f; b.eta_b = 1.f; lobes.push_back(b); m.bsdf_eta = 1.f; }
+        else m.bsdf_eta = e;
+        RGB kd = rgbMul(op, rgbClamp(Kd));
+        if (!rgbBlack(kd)) { PgBxDF b = lobe(PG_BXDF_LAMBERT_R); setR(b, kd); lobes.push_back(b); }
+        RGB ks = rgbMul(op, rgbClamp(Ks));
+        if (!rgbBlack(ks)) {
+            Float roughu = hasU ? uro : roughness, roughv = hasV ? vro : roughu;
+            if (remap) { roughu = RoughnessToAlpha(roughu); roughv = RoughnessToAlpha(roughv); }
+            PgBxDF b = lobe(PG_BXDF_MICROFACET_R); setR(b, ks); setDielectric(b, 1.f, e); setTR(b, roughu, roughv); lobes.push_back(b);
+        }
+        RGB kr = rgbMul(op, rgbClamp(Kr));
+        if (!rgbBlack(kr)) { PgBxDF b = lobe(PG_BXDF_SPECULAR_R); setR(b, kr); setDielectric(b, 1.f, e); lobes.push_back(b); }
+        RGB kt = rgbMul(op, rgbClamp(Kt));
+        if (!rgbBlack(kt)) { PgBxDF b = lobe(PG_BXDF_SPECULAR_T); setT(b, kt); b.eta_a = 1.f; b.eta_b = e; lobes.push_back(b); }
+    } else if (name == "metal") {  // metal.cpp:61-136
+        m.type = PG_MAT_LOBES;
+        RGB eta = spectrumParam(geom, mat, "eta", kCopperN, gs), k = spectrumParam(geom, mat, "k", kCopperK, gs);
+        Float roughness = flt("roughness", .01f);
+        const bool hasU = hasParam(geom, mat, "uroughness"), hasV = hasParam(geom, mat, "vroughness");
+        Float uRough = hasU ? flt("uroughness", 0.f) : roughness, vRough = hasV ? flt("vroughness", 0.f) : roughness;
+        if (remapParam()) { uRough = RoughnessToAlpha(uRough); vRough = RoughnessToAlpha(vRough); }
+        PgBxDF b = lobe(PG_BXDF_MICROFACET_R);
+        setR(b, RGB{{1.f, 1.f, 1.f}});
+        b.fresnel = PG_FRESNEL_CONDUCTOR;
+        for (int i = 0; i < 3; ++i) { b.cond_eta[i] = eta.c[i]; b.cond_k[i] = k.c[i]; }
+        setTR(b, uRough, vRough);
+        lobes.push_back(b);
+    } else if (name == "substrate") {  // substrate.cpp:45-82
+        m.type = PG_MAT_LOBES;
+        RGB d = rgbClamp(spec("Kd", .5f)), sp = rgbClamp(spec("Ks", .5f));
+        Float roughu = flt("uroughness", .1f), roughv = flt("vroughness", .1f);
+        const bool remap = remapParam();
+        if (!rgbBlack(d) || !rgbBlack(sp)) {
+            if (remap) { roughu = RoughnessToAlpha(roughu); roughv = RoughnessToAlpha(roughv); }
+            PgBxDF b = lobe(PG_BXDF_FRESNEL_BLEND); setR(b, d); setT(b, sp); setTR(b, roughu, roughv); lobes.push_back(b);
+        }
+    } else if (name == "translucent") {  // translucent.cpp:45-99
+        m.type = PG_MAT_LOBES;
+        const Float eta = 1.5f;
+        m.bsdf_eta = eta;
+        RGB Kd = spec("Kd", 0.25f), Ks = spec("Ks", 0.25f), refl = spec("reflect", 0.5f), trans = spec("transmit", 0.5f);
+        Float rough = flt("roughness", .1f);
+        const bool remap = remapParam();
+        RGB r = rgbClamp(refl), t = rgbClamp(trans);
+        if (!(rgbBlack(r) && rgbBlack(t))) {
+            RGB kd = rgbClamp(Kd);
+            if (!rgbBlack(kd)) {
+                if (!rgbBlack(r)) { PgBxDF b = lobe(PG_BXDF_LAMBERT_R); setR(b, rgbMul(r, kd)); lobes.push_back(b); }
+                if (!rgbBlack(t)) { PgBxDF b = lobe(PG_BXDF_LAMBERT_T); setT(b, rgbMul(t, kd)); lobes.push_back(b); }
+            }
+            RGB ks = rgbClamp(Ks);
+            if (!rgbBlack(ks) && (!rgbBlack(r) || !rgbBlack(t))) {
+                if (remap) rough = RoughnessToAlpha(rough);
+                if (!rgbBlack(r)) { PgBxDF b = lobe(PG_BXDF_MICROFACET_R); setR(b, rgbMul(r, ks)); setDielectric(b, 1.f, eta); setTR(b, rough, rough); lobes.push_back(b); }
+                if (!rgbBlack(t)) { PgBxDF b = lobe(PG_BXDF_MICROFACET_T); setT(b, rgbMul(t, ks)); b.eta_a = 1.f; b.eta_b = eta; setTR(b, rough, rough); lobes.push_back(b); }
+            }
+        }
+    } else if (name == "mix") {  // api.cpp:556-577, mixmat.cpp:45-73
+        m.type = PG_MAT_LOBES;
+        int sub[2];
+        const char *pn[2] = {"namedmaterial1", "namedmaterial2"};
+        for (int j = 0; j < 2; ++j) {
+            std::string mn = geom.FindOneString(pn[j], mat.FindOneString(pn[j], ""));
+            auto it = gs.namedMaterials.find(mn);
+            if (it == gs.namedMaterials.end()) {
+                Error("Named material \"%s\" undefined.  Using \"matte\"", mn.c_str());
+                sub[j] = MakeMaterial("matte", geom, mat);
+            } else sub[j] = it->second.material;
+        }
+        RGB s1 = rgbClamp(spec("amount", 0.5f)), s2;
+        for (int i = 0; i < 3; ++i) s2.c[i] = 1.f - s1.c[i];
+        s2 = rgbClamp(s2);
+        bool bad = false;
+        for (int j = 0; j < 2; ++j) {
+            const PgMaterial sm = renderOptions->materials[sub[j]];  // copy: the table may grow
+            if (sm.type == PG_MAT_NONE) { Error("mix: a \"none\" material cannot be mixed; ignoring it."); continue; }
+            if (j == 0) m.bsdf_eta = sm.bsdf_eta;  // si->bsdf stays m1's BSDF
+            const RGB &sc = j == 0 ? s1 : s2;
+            for (int i = 0; i < sm.n_bxdfs; ++i) {
+                PgBxDF b = renderOptions->bxdfs[sm.first_bxdf + i];
+                if (b.n_scales >= PG_MAX_BXDF_SCALES) { bad = true; continue; }
+                for (int c = 0; c < 3; ++c) b.scale[b.n_scales][c] = sc.c[c];
+                ++b.n_scales;
+                if ((int)lobes.size() < PG_MAX_BXDFS) lobes.push_back(b); else bad = true;
+            }
+        }
+        if (bad) Error("mix: more than %d BxDFs or more than %d nested mixes; the excess is dropped.", PG_MAX_BXDFS, PG_MAX_BXDF_SCALES);
     }
     mat.ReportUnused();
-    return internMaterial(m);
+    return internMaterial(m, lobes);
 }
 
 // api.cpp:1427-1470
@@ -659,6 +832,7 @@ static Scene *MakeScene() {
     ro.AcceleratorParams.ReportUnused();
     scene->lights = ro.lights;
     scene->materials = ro.materials;
+    scene->bxdfs = ro.bxdfs;
     scene->worldBound = scene->aggregate->WorldBound();
     // resolve each light's emitting triangle to its index in BVH order
     const auto &prims = scene->aggregate->primitives;

@@ -236,6 +236,7 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
         flat->triFlags[k] = f;
     }
     flat->materials = scene.materials;
+    flat->bxdfs = scene.bxdfs;
     flat->lights = scene.lights;
     // Light::Preprocess (scene.h:57-60): DistantLight keeps the world's bounding sphere (distant.h:55-57, geometry.h:803-806)
     if (!flat->nodes.empty()) {
@@ -270,6 +271,7 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     }
     d.n_perm_dims = (int)flat->permSums.size() - 1; d.perms = flat->perms.data(); d.perm_sums = flat->permSums.data();
     d.n_spheres = (int)flat->spheres.size(); d.spheres = flat->spheres.data();
+    d.n_bxdfs = (int)flat->bxdfs.size(); d.bxdfs = flat->bxdfs.data();
 }
 
 void GpuPathIntegrator::FillRenderDesc(PgRenderDesc *rd) const {

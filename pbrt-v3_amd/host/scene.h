@@ -76,6 +76,7 @@ struct Scene {  // core/scene.h:50-80
     std::shared_ptr<BVHAccel> aggregate;
     std::vector<PgLight> lights;
     std::vector<PgMaterial> materials;
+    std::vector<PgBxDF> bxdfs;
     Bounds3f worldBound;
 };
 
@@ -141,6 +142,7 @@ struct FlatScene {
     std::vector<PgMaterial> materials;
     std::vector<PgLight> lights;
     std::vector<PgSphere> spheres;
+    std::vector<PgBxDF> bxdfs;
 };
 
 // core/integrator.h:53-58.
