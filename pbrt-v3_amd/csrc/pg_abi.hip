@@ -45,7 +45,7 @@ struct DeviceBuffer {
 struct PgScene {
     int device = 0;
     DScene d;
-    DeviceBuffer nodes, wnodes, tris, spheres, triN, triS, uv, materials, lights, distTable, perms, permSums, primes;
+    DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, triN, triS, uv, materials, lights, distTable, perms, permSums, primes;
     // work buffers (sized on first render, reused)
     int capacity = 0;
     DeviceBuffer qo[4], qd[4], counts, hitsMain, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
@@ -211,6 +211,10 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         HIP_TRY_S(buf.alloc(sizeof(float4) * a.size()));
         HIP_TRY_S(hipMemcpy(buf.p, a.data(), buf.bytes, hipMemcpyHostToDevice));
     }
+    if (desc->n_bxdfs > 0 && desc->bxdfs) {
+        HIP_TRY_S(s->bxdfs.alloc(sizeof(PgBxDF) * (size_t)desc->n_bxdfs));
+        HIP_TRY_S(hipMemcpy(s->bxdfs.p, desc->bxdfs, s->bxdfs.bytes, hipMemcpyHostToDevice));
+    }
     if (desc->n_spheres > 0) {
         HIP_TRY_S(s->spheres.alloc(sizeof(PgSphere) * (size_t)desc->n_spheres));
         HIP_TRY_S(hipMemcpy(s->spheres.p, desc->spheres, s->spheres.bytes, hipMemcpyHostToDevice));
@@ -222,11 +226,21 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         HIP_TRY_S(hipMemcpy(s->uv.p, uv.data(), s->uv.bytes, hipMemcpyHostToDevice));
     }
     // --- materials / lights
+    bool anyLobeMaterial = false;
     for (int i = 0; i < desc->n_materials; ++i) {
         const PgMaterial &m = desc->materials[i];
         if (m.type == PG_MAT_NONE) s->hasNullMaterial = true;
-        else if (m.type < PG_MAT_MATTE || m.type > PG_MAT_GLASS)
-            FAIL(PG_ERR_UNSUPPORTED, "material %d: type %d is outside this build's closed set (matte, plastic, mirror, glass)", i, m.type);
+        else if (m.type < PG_MAT_MATTE || m.type > PG_MAT_LOBES)
+            FAIL(PG_ERR_UNSUPPORTED, "material %d: unknown type %d", i, m.type);
+        if (m.type == PG_MAT_LOBES) anyLobeMaterial = true;
+        if (m.n_bxdfs < 0 || m.n_bxdfs > PG_MAX_BXDFS || (m.n_bxdfs > 0 && (m.first_bxdf < 0 || m.first_bxdf + m.n_bxdfs > desc->n_bxdfs || !desc->bxdfs)))
+            FAIL(PG_ERR_INVALID, "material %d: BxDF list [%d, +%d) is outside the scene's %d BxDFs", i, m.first_bxdf, m.n_bxdfs, desc->n_bxdfs);
+        for (int j = 0; j < m.n_bxdfs; ++j) {
+            const PgBxDF &bx = desc->bxdfs[m.first_bxdf + j];
+            if (bx.type < PG_BXDF_LAMBERT_R || bx.type > PG_BXDF_FRESNEL_BLEND || bx.fresnel < PG_FRESNEL_NOOP || bx.fresnel > PG_FRESNEL_CONDUCTOR ||
+                bx.n_scales < 0 || bx.n_scales > PG_MAX_BXDF_SCALES)
+                FAIL(PG_ERR_UNSUPPORTED, "material %d: BxDF %d has unknown type %d / fresnel %d / %d scales", i, j, bx.type, bx.fresnel, bx.n_scales);
+        }
     }
     // device copy: a plastic's `roughness` becomes the TrowbridgeReitz alpha.  RoughnessToAlpha (microfacet.h:127-132) calls
     // logf; evaluating it here on the host uses the same libm as the reference build.
@@ -269,7 +283,12 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     HIP_TRY_S(s->primes.alloc(sizeof(int32_t) * primes.size()));
     HIP_TRY_S(hipMemcpy(s->primes.p, primes.data(), s->primes.bytes, hipMemcpyHostToDevice));
 
-    d.nodes = (const float4 *)s->nodes.p; d.tris = (const float4 *)s->tris.p; d.spheres = (const PgSphere *)s->spheres.p; d.nSpheres = desc->n_spheres > 0 ? desc->n_spheres : 0; d.uv = (const float *)s->uv.p;
+    d.nodes = (const float4 *)s->nodes.p; d.tris = (const float4 *)s->tris.p; d.spheres = (const PgSphere *)s->spheres.p; d.nSpheres = desc->n_spheres > 0 ? desc->n_spheres : 0;
+    d.bxdfs = (const PgBxDF *)s->bxdfs.p;
+    {  // PG_FORCE_EXT=1 runs the general kernels on scenes that do not need them (tests: both paths agree bit for bit)
+        const char *fe = getenv("PG_FORCE_EXT");
+        d.ext = (d.nSpheres > 0 || d.hasInfinite || anyLobeMaterial || (fe && atoi(fe) != 0)) ? 1 : 0;
+    } d.uv = (const float *)s->uv.p;
     d.triN = (const float4 *)s->triN.p; d.triS = (const float4 *)s->triS.p;
     d.materials = (const PgMaterial *)s->materials.p; d.lights = (const PgLight *)s->lights.p;
     d.nNodes = desc->n_nodes; d.nTris = nt; d.nLights = desc->n_lights; d.nMaterials = desc->n_materials;

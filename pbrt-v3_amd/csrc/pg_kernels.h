@@ -33,6 +33,8 @@ struct DScene {
     int nNodes, nTris, nLights, nMaterials;
     const PgSphere *spheres;  // Shape "sphere" primitives: tris[3*k] = (sphere index, 0, 0, flags | PG_PRIM_SPHERE)
     int nSpheres;
+    const PgBxDF *bxdfs;      // the materials' BxDF lists (PgMaterial.first_bxdf / n_bxdfs)
+    int ext;          // the EXT shading kernels are needed: spheres, infinite lights or PG_MAT_LOBES materials (or PG_FORCE_EXT=1)
     int hasInfinite;  // some light is an InfiniteAreaLight (Scene::infiniteLights non-empty)
     // light sampling distributions (lightdistrib.cpp): strategy + tables
     int lightStrategy;

@@ -531,6 +531,333 @@ PG_DEV Spec bsdf_sample_f(const Bsdf &b, V3 woWorld, V3 &wiWorld, float u0, floa
 
 // Triangle::Sample(u, pdf) + Shape::Sample(ref, u, pdf) + DiffuseAreaLight::Sample_Li
 // (triangle.cpp:582-607, shape.cpp:56-70, diffuse.cpp:68-81).
+// ===========================================================================
+// BSDF over a material's BxDF list (PgBxDF, include/pbrt_gpu.h): every BxDF of core/reflection.cpp the closed set of
+// materials can add, and BSDF::f / Pdf / Sample_f over the list (reflection.cpp:680-796).  Used by the EXT kernels for
+// every material; the specialised Bsdf above is the same arithmetic with the list shape of matte/plastic/mirror/glass
+// baked in.
+// ===========================================================================
+#define PG_BSDF_DIFFUSE 4
+#define PG_BSDF_GLOSSY 8
+#define PG_BSDF_ALL 31
+struct LobeBsdf { V3 ns, ng, ss, ts; const PgBxDF *lobes; int n; float eta; };
+PG_DEV V3 world_to_local(const LobeBsdf &b, V3 v) { return mk(dot(v, b.ss), dot(v, b.ts), dot(v, b.ns)); }
+PG_DEV V3 local_to_world(const LobeBsdf &b, V3 v) {
+    return mk(b.ss.x * v.x + b.ts.x * v.y + b.ns.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ns.y * v.z,
+              b.ss.z * v.x + b.ts.z * v.y + b.ns.z * v.z);
+}
+PG_DEV Spec operator-(Spec a, Spec b) { return sp3(a.r - b.r, a.g - b.g, a.b - b.b); }
+PG_DEV Spec operator/(Spec a, Spec b) { return sp3(a.r / b.r, a.g / b.g, a.b / b.b); }
+PG_DEV Spec sp_sqrt(Spec a) { return sp3(sqrtf(a.r), sqrtf(a.g), sqrtf(a.b)); }
+PG_DEV Spec sp_of(const float *c) { return sp3(c[0], c[1], c[2]); }
+PG_DEV Spec fr_conductor(float cosThetaI, Spec etai, Spec etat, Spec k) {  // reflection.cpp:71-96
+    cosThetaI = clampf(cosThetaI, -1, 1);
+    const Spec eta = etat / etai;
+    const Spec etak = k / etai;
+    const float cosThetaI2 = cosThetaI * cosThetaI;
+    const float sinThetaI2 = 1.f - cosThetaI2;
+    const Spec eta2 = eta * eta;
+    const Spec etak2 = etak * etak;
+    const Spec t0 = (eta2 - etak2) - sp(sinThetaI2);
+    const Spec a2plusb2 = sp_sqrt(t0 * t0 + (eta2 * 4.f) * etak2);
+    const Spec t1 = a2plusb2 + sp(cosThetaI2);
+    const Spec a = sp_sqrt((a2plusb2 + t0) * 0.5f);
+    const Spec t2 = a * (2.f * cosThetaI);
+    const Spec Rs = (t1 - t2) / (t1 + t2);
+    const Spec t3 = a2plusb2 * cosThetaI2 + sp(sinThetaI2 * sinThetaI2);
+    const Spec t4 = t2 * sinThetaI2;
+    const Spec Rp = (Rs * (t3 - t4)) / (t3 + t4);
+    return (Rp + Rs) * 0.5f;
+}
+// TrowbridgeReitzDistribution(alphax, alphay), microfacet.cpp:155-184, :310-345
+PG_DEV float tr2_D(float ax, float ay, V3 wh) {
+    float tan2Theta = tan2_theta(wh);
+    if (isinf(tan2Theta)) return 0.f;
+    const float cos4Theta = cos2_theta(wh) * cos2_theta(wh);
+    float e = (cos2_phi(wh) / (ax * ax) + sin2_phi(wh) / (ay * ay)) * tan2Theta;
+    return 1 / (PG_PI * ax * ay * cos4Theta * (1 + e) * (1 + e));
+}
+PG_DEV float tr2_lambda(float ax, float ay, V3 w) {
+    float absTanTheta = fabsf(tan_theta(w));
+    if (isinf(absTanTheta)) return 0.f;
+    float alpha = sqrtf(cos2_phi(w) * ax * ax + sin2_phi(w) * ay * ay);
+    float alpha2Tan2Theta = (alpha * absTanTheta) * (alpha * absTanTheta);
+    return (-1 + sqrtf(1.f + alpha2Tan2Theta)) / 2;
+}
+PG_DEV float tr2_G1(float ax, float ay, V3 w) { return 1 / (1 + tr2_lambda(ax, ay, w)); }
+PG_DEV float tr2_G(float ax, float ay, V3 wo, V3 wi) { return 1 / (1 + tr2_lambda(ax, ay, wo) + tr2_lambda(ax, ay, wi)); }
+PG_DEV float tr2_pdf(float ax, float ay, V3 wo, V3 wh) { return tr2_D(ax, ay, wh) * tr2_G1(ax, ay, wo) * absdot(wo, wh) / fabsf(wo.z); }
+PG_DEV V3 tr2_sample_wh(float ax, float ay, V3 wo, float u0, float u1) {
+    const bool flip = wo.z < 0;
+    V3 wi = flip ? -wo : wo;
+    V3 wiStretched = normalize(mk(ax * wi.x, ay * wi.y, wi.z));
+    float slope_x, slope_y;
+    tr_sample11(wiStretched.z, u0, u1, slope_x, slope_y);
+    float tmp = cos_phi(wiStretched) * slope_x - sin_phi(wiStretched) * slope_y;
+    slope_y = sin_phi(wiStretched) * slope_x + cos_phi(wiStretched) * slope_y;
+    slope_x = tmp;
+    slope_x = ax * slope_x;
+    slope_y = ay * slope_y;
+    V3 wh = normalize(mk(-slope_x, -slope_y, 1.f));
+    return flip ? -wh : wh;
+}
+PG_DEV bool same_hemisphere(V3 w, V3 wp) { return w.z * wp.z > 0; }  // reflection.h:111-113
+PG_DEV V3 reflect_about(V3 wo, V3 n) { return -wo + n * (2 * dot(wo, n)); }  // reflection.h:93-95
+PG_DEV bool refract_dir(V3 wi, V3 n, float eta, V3 &wt) {  // reflection.h:97-109
+    float cosThetaI = dot(n, wi);
+    float sin2ThetaI = pmax(0.f, 1 - cosThetaI * cosThetaI);
+    float sin2ThetaT = eta * eta * sin2ThetaI;
+    if (sin2ThetaT >= 1) return false;
+    float cosThetaT = sqrtf(1 - sin2ThetaT);
+    wt = (-wi) * eta + n * (eta * cosThetaI - cosThetaT);
+    return true;
+}
+PG_DEV int lobe_type(const PgBxDF &b) {  // the BxDFType each constructor passes to BxDF()
+    switch (b.type) {
+    case PG_BXDF_LAMBERT_R: case PG_BXDF_OREN_NAYAR: return PG_BSDF_REFLECTION | PG_BSDF_DIFFUSE;
+    case PG_BXDF_LAMBERT_T: return PG_BSDF_TRANSMISSION | PG_BSDF_DIFFUSE;
+    case PG_BXDF_SPECULAR_R: return PG_BSDF_REFLECTION | PG_BSDF_SPECULAR;
+    case PG_BXDF_SPECULAR_T: return PG_BSDF_TRANSMISSION | PG_BSDF_SPECULAR;
+    case PG_BXDF_FRESNEL_SPECULAR: return PG_BSDF_REFLECTION | PG_BSDF_TRANSMISSION | PG_BSDF_SPECULAR;
+    case PG_BXDF_MICROFACET_R: case PG_BXDF_FRESNEL_BLEND: return PG_BSDF_REFLECTION | PG_BSDF_GLOSSY;
+    case PG_BXDF_MICROFACET_T: return PG_BSDF_TRANSMISSION | PG_BSDF_GLOSSY;
+    }
+    return 0;
+}
+PG_DEV bool lobe_matches(const PgBxDF &b, int t) { const int type = lobe_type(b); return (type & t) == type; }  // reflection.h:225
+PG_DEV Spec lobe_fresnel(const PgBxDF &b, float cosI) {  // Fresnel::Evaluate, reflection.cpp:120-135
+    if (b.fresnel == PG_FRESNEL_DIELECTRIC) return sp(fr_dielectric(cosI, b.eta_a, b.eta_b));
+    if (b.fresnel == PG_FRESNEL_CONDUCTOR) return fr_conductor(fabsf(cosI), sp(1.f), sp_of(b.cond_eta), sp_of(b.cond_k));
+    return sp(1.f);
+}
+PG_DEV float pow5f(float v) { return (v * v) * (v * v) * v; }
+PG_DEV Spec lobe_f(const PgBxDF &b, V3 wo, V3 wi) {  // BxDF::f of the wrapped BxDF, local frame
+    const float ax = b.alpha_x, ay = b.alpha_y;
+    switch (b.type) {
+    case PG_BXDF_LAMBERT_R: return sp_of(b.R) * PG_INVPI;  // reflection.cpp:178-180
+    case PG_BXDF_LAMBERT_T: return sp_of(b.T) * PG_INVPI;  // :188-190
+    case PG_BXDF_OREN_NAYAR: {  // :197-219
+        float sinThetaI = sin_theta(wi), sinThetaO = sin_theta(wo);
+        float maxCos = 0;
+        if (sinThetaI > 1e-4f && sinThetaO > 1e-4f) {
+            float sinPhiI = sin_phi(wi), cosPhiI = cos_phi(wi);
+            float sinPhiO = sin_phi(wo), cosPhiO = cos_phi(wo);
+            float dCos = cosPhiI * cosPhiO + sinPhiI * sinPhiO;
+            maxCos = pmax(0.f, dCos);
+        }
+        float sinAlpha, tanBeta;
+        if (fabsf(wi.z) > fabsf(wo.z)) { sinAlpha = sinThetaO; tanBeta = sinThetaI / fabsf(wi.z); }
+        else { sinAlpha = sinThetaI; tanBeta = sinThetaO / fabsf(wo.z); }
+        return (sp_of(b.R) * PG_INVPI) * (b.on_a + b.on_b * maxCos * sinAlpha * tanBeta);
+    }
+    case PG_BXDF_MICROFACET_R: {  // :226-238
+        float cosThetaO = fabsf(wo.z), cosThetaI = fabsf(wi.z);
+        V3 wh = wi + wo;
+        if (cosThetaI == 0 || cosThetaO == 0) return sp(0);
+        if (wh.x == 0 && wh.y == 0 && wh.z == 0) return sp(0);
+        wh = normalize(wh);
+        V3 whf = (wh.z < 0.f) ? -wh : wh;  // Faceforward(wh, (0,0,1))
+        Spec F = lobe_fresnel(b, dot(wi, whf));
+        return (((sp_of(b.R) * tr2_D(ax, ay, wh)) * tr2_G(ax, ay, wo, wi)) * F) / (4 * cosThetaI * cosThetaO);
+    }
+    case PG_BXDF_MICROFACET_T: {  // :247-274, TransportMode::Radiance
+        if (same_hemisphere(wo, wi)) return sp(0);
+        float cosThetaO = wo.z, cosThetaI = wi.z;
+        if (cosThetaI == 0 || cosThetaO == 0) return sp(0);
+        float eta = wo.z > 0 ? (b.eta_b / b.eta_a) : (b.eta_a / b.eta_b);
+        V3 wh = normalize(wo + wi * eta);
+        if (wh.z < 0) wh = -wh;
+        if (dot(wo, wh) * dot(wi, wh) > 0) return sp(0);
+        Spec F = sp(fr_dielectric(dot(wo, wh), b.eta_a, b.eta_b));
+        float sqrtDenom = dot(wo, wh) + eta * dot(wi, wh);
+        float factor = 1 / eta;
+        return ((sp(1.f) - F) * sp_of(b.T)) *
+               fabsf(tr2_D(ax, ay, wh) * tr2_G(ax, ay, wo, wi) * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor /
+                     (cosThetaI * cosThetaO * sqrtDenom * sqrtDenom));
+    }
+    case PG_BXDF_FRESNEL_BLEND: {  // :295-310; Rd = R, Rs = T
+        const Spec Rd = sp_of(b.R), Rs = sp_of(b.T);
+        Spec diffuse = (((Rd * (28.f / (23.f * PG_PI))) * (sp(1.f) - Rs)) * (1 - pow5f(1 - .5f * fabsf(wi.z)))) * (1 - pow5f(1 - .5f * fabsf(wo.z)));
+        V3 wh = wi + wo;
+        if (wh.x == 0 && wh.y == 0 && wh.z == 0) return sp(0);
+        wh = normalize(wh);
+        Spec schlick = Rs + (sp(1.f) - Rs) * pow5f(1 - dot(wi, wh));  // SchlickFresnel, reflection.h:496-499
+        Spec specular = schlick * (tr2_D(ax, ay, wh) / (4 * absdot(wi, wh) * pmax(fabsf(wi.z), fabsf(wo.z))));
+        return diffuse + specular;
+    }
+    }
+    return sp(0);  // specular BxDFs: f() = 0
+}
+PG_DEV float lobe_pdf(const PgBxDF &b, V3 wo, V3 wi) {
+    const float ax = b.alpha_x, ay = b.alpha_y;
+    switch (b.type) {
+    case PG_BXDF_LAMBERT_R: case PG_BXDF_OREN_NAYAR: return same_hemisphere(wo, wi) ? fabsf(wi.z) * PG_INVPI : 0;  // :392-394
+    case PG_BXDF_LAMBERT_T: return !same_hemisphere(wo, wi) ? fabsf(wi.z) * PG_INVPI : 0;  // :405-408
+    case PG_BXDF_MICROFACET_R: {  // :425-429
+        if (!same_hemisphere(wo, wi)) return 0;
+        V3 wh = normalize(wo + wi);
+        return tr2_pdf(ax, ay, wo, wh) / (4 * dot(wo, wh));
+    }
+    case PG_BXDF_MICROFACET_T: {  // :444-458
+        if (same_hemisphere(wo, wi)) return 0;
+        float eta = wo.z > 0 ? (b.eta_b / b.eta_a) : (b.eta_a / b.eta_b);
+        V3 wh = normalize(wo + wi * eta);
+        if (dot(wo, wh) * dot(wi, wh) > 0) return 0;
+        float sqrtDenom = dot(wo, wh) + eta * dot(wi, wh);
+        float dwh_dwi = fabsf((eta * eta * dot(wi, wh)) / (sqrtDenom * sqrtDenom));
+        return tr2_pdf(ax, ay, wo, wh) * dwh_dwi;
+    }
+    case PG_BXDF_FRESNEL_BLEND: {  // :480-485
+        if (!same_hemisphere(wo, wi)) return 0;
+        V3 wh = normalize(wo + wi);
+        float pdf_wh = tr2_pdf(ax, ay, wo, wh);
+        return .5f * (fabsf(wi.z) * PG_INVPI + pdf_wh / (4 * dot(wo, wh)));
+    }
+    }
+    return 0;
+}
+// BxDF::Sample_f of the wrapped BxDF; pdf keeps the caller's 0 on the reference's early `return 0` paths
+PG_DEV Spec lobe_sample_f(const PgBxDF &b, V3 wo, V3 &wi, float u0, float u1, float &pdf, int &sampledType) {
+    const float ax = b.alpha_x, ay = b.alpha_y;
+    switch (b.type) {
+    case PG_BXDF_LAMBERT_R: case PG_BXDF_OREN_NAYAR:  // BxDF::Sample_f, :383-390
+        wi = cosine_sample_hemisphere(u0, u1);
+        if (wo.z < 0) wi.z *= -1;
+        pdf = lobe_pdf(b, wo, wi);
+        return lobe_f(b, wo, wi);
+    case PG_BXDF_LAMBERT_T:  // :396-403
+        wi = cosine_sample_hemisphere(u0, u1);
+        if (wo.z > 0) wi.z *= -1;
+        pdf = lobe_pdf(b, wo, wi);
+        return lobe_f(b, wo, wi);
+    case PG_BXDF_SPECULAR_R:  // :136-143
+        wi = mk(-wo.x, -wo.y, wo.z);
+        pdf = 1;
+        return (lobe_fresnel(b, wi.z) * sp_of(b.R)) / fabsf(wi.z);
+    case PG_BXDF_SPECULAR_T: {  // :151-167
+        const bool entering = wo.z > 0;
+        const float etaI = entering ? b.eta_a : b.eta_b, etaT = entering ? b.eta_b : b.eta_a;
+        const V3 n = (wo.z < 0.f) ? mk(0, 0, -1) : mk(0, 0, 1);
+        if (!refract_dir(wo, n, etaI / etaT, wi)) return sp(0);
+        pdf = 1;
+        Spec ft = sp_of(b.T) * (sp(1.f) - sp(fr_dielectric(wi.z, b.eta_a, b.eta_b)));
+        ft = ft * ((etaI * etaI) / (etaT * etaT));
+        return ft / fabsf(wi.z);
+    }
+    case PG_BXDF_FRESNEL_SPECULAR: {  // :487-521
+        const float F = fr_dielectric(wo.z, b.eta_a, b.eta_b);
+        if (u0 < F) {
+            wi = mk(-wo.x, -wo.y, wo.z);
+            sampledType = PG_BSDF_SPECULAR | PG_BSDF_REFLECTION;
+            pdf = F;
+            return (sp_of(b.R) * F) / fabsf(wi.z);
+        }
+        const bool entering = wo.z > 0;
+        const float etaI = entering ? b.eta_a : b.eta_b, etaT = entering ? b.eta_b : b.eta_a;
+        const V3 n = (wo.z < 0.f) ? mk(0, 0, -1) : mk(0, 0, 1);
+        if (!refract_dir(wo, n, etaI / etaT, wi)) return sp(0);
+        Spec ft = sp_of(b.T) * (1 - F);
+        ft = ft * ((etaI * etaI) / (etaT * etaT));
+        sampledType = PG_BSDF_SPECULAR | PG_BSDF_TRANSMISSION;
+        pdf = 1 - F;
+        return ft / fabsf(wi.z);
+    }
+    case PG_BXDF_MICROFACET_R: {  // :410-423
+        if (wo.z == 0) return sp(0);
+        V3 wh = tr2_sample_wh(ax, ay, wo, u0, u1);
+        if (dot(wo, wh) < 0) return sp(0);
+        wi = reflect_about(wo, wh);
+        if (!same_hemisphere(wo, wi)) return sp(0);
+        pdf = tr2_pdf(ax, ay, wo, wh) / (4 * dot(wo, wh));
+        return lobe_f(b, wo, wi);
+    }
+    case PG_BXDF_MICROFACET_T: {  // :431-442
+        if (wo.z == 0) return sp(0);
+        V3 wh = tr2_sample_wh(ax, ay, wo, u0, u1);
+        if (dot(wo, wh) < 0) return sp(0);
+        float eta = wo.z > 0 ? (b.eta_a / b.eta_b) : (b.eta_b / b.eta_a);
+        if (!refract_dir(wo, wh, eta, wi)) return sp(0);
+        pdf = lobe_pdf(b, wo, wi);
+        return lobe_f(b, wo, wi);
+    }
+    case PG_BXDF_FRESNEL_BLEND: {  // :460-478
+        if ((double)u0 < .5) {
+            u0 = pmin(2 * u0, PG_ONE_MINUS_EPS);
+            wi = cosine_sample_hemisphere(u0, u1);
+            if (wo.z < 0) wi.z *= -1;
+        } else {
+            u0 = pmin(2 * (u0 - .5f), PG_ONE_MINUS_EPS);
+            V3 wh = tr2_sample_wh(ax, ay, wo, u0, u1);
+            wi = reflect_about(wo, wh);
+            if (!same_hemisphere(wo, wi)) return sp(0);
+        }
+        pdf = lobe_pdf(b, wo, wi);
+        return lobe_f(b, wo, wi);
+    }
+    }
+    return sp(0);
+}
+PG_DEV Spec lobe_scale(const PgBxDF &b, Spec f) {  // ScaledBxDF, reflection.cpp:98-107: innermost wrapper first
+    for (int i = 0; i < b.n_scales; ++i) f = sp_of(b.scale[i]) * f;
+    return f;
+}
+PG_DEV int lbsdf_num_components(const LobeBsdf &b, int flags) {  // reflection.cpp:672-678
+    int num = 0;
+    for (int i = 0; i < b.n; ++i) if (lobe_matches(b.lobes[i], flags)) ++num;
+    return num;
+}
+PG_DEV Spec lbsdf_f_local(const LobeBsdf &b, V3 wo, V3 wi, bool reflect, int flags) {
+    Spec f = sp(0);
+    for (int i = 0; i < b.n; ++i) {
+        const int type = lobe_type(b.lobes[i]);
+        if ((type & flags) == type && ((reflect && (type & PG_BSDF_REFLECTION)) || (!reflect && (type & PG_BSDF_TRANSMISSION))))
+            f = f + lobe_scale(b.lobes[i], lobe_f(b.lobes[i], wo, wi));
+    }
+    return f;
+}
+PG_DEV Spec lbsdf_f(const LobeBsdf &b, V3 woW, V3 wiW, int flags) {  // reflection.cpp:680-693
+    V3 wi = world_to_local(b, wiW), wo = world_to_local(b, woW);
+    if (wo.z == 0) return sp(0);
+    return lbsdf_f_local(b, wo, wi, dot(wiW, b.ng) * dot(woW, b.ng) > 0, flags);
+}
+PG_DEV float lbsdf_pdf(const LobeBsdf &b, V3 woW, V3 wiW, int flags) {  // reflection.cpp:781-796
+    if (b.n == 0) return 0.f;
+    V3 wo = world_to_local(b, woW), wi = world_to_local(b, wiW);
+    if (wo.z == 0) return 0.f;
+    float pdf = 0.f;
+    int matchingComps = 0;
+    for (int i = 0; i < b.n; ++i)
+        if (lobe_matches(b.lobes[i], flags)) { ++matchingComps; pdf += lobe_pdf(b.lobes[i], wo, wi); }
+    return matchingComps > 0 ? pdf / matchingComps : 0.f;
+}
+// BSDF::Sample_f, reflection.cpp:714-779: returns f, pdf = 0 when there is no sample
+PG_DEV Spec lbsdf_sample_f(const LobeBsdf &b, V3 woWorld, V3 &wiWorld, float u0, float u1, float &pdf, int flags, int &sampledType) {
+    const int matchingComps = lbsdf_num_components(b, flags);
+    sampledType = 0;
+    pdf = 0;
+    if (matchingComps == 0) return sp(0);
+    int comp = (int)floorf(u0 * matchingComps);
+    if (comp > matchingComps - 1) comp = matchingComps - 1;
+    int chosen = 0, count = comp;
+    for (int i = 0; i < b.n; ++i)
+        if (lobe_matches(b.lobes[i], flags) && count-- == 0) { chosen = i; break; }
+    const PgBxDF &bxdf = b.lobes[chosen];
+    const float uR0 = pmin(u0 * matchingComps - comp, PG_ONE_MINUS_EPS);
+    V3 wi = mk(0, 0, 0), wo = world_to_local(b, woWorld);
+    if (wo.z == 0) return sp(0);
+    sampledType = lobe_type(bxdf);
+    Spec f = lobe_scale(bxdf, lobe_sample_f(bxdf, wo, wi, uR0, u1, pdf, sampledType));
+    if (pdf == 0) { sampledType = 0; return sp(0); }
+    wiWorld = local_to_world(b, wi);
+    const bool bxdfSpecular = (lobe_type(bxdf) & PG_BSDF_SPECULAR) != 0;
+    if (!bxdfSpecular && matchingComps > 1)
+        for (int i = 0; i < b.n; ++i)
+            if (i != chosen && lobe_matches(b.lobes[i], flags)) pdf += lobe_pdf(b.lobes[i], wo, wi);
+    if (matchingComps > 1) pdf /= matchingComps;
+    if (!bxdfSpecular) f = lbsdf_f_local(b, wo, wi, dot(wiWorld, b.ng) * dot(woWorld, b.ng) > 0, flags);
+    return f;
+}
+
 struct LightSample { V3 p, n, pError; };
 // SpotLight::Falloff, spot.cpp:62-72
 PG_DEV float spot_falloff(const PgLight &l, V3 w) {
@@ -828,38 +1155,53 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                 pushNext = true;
             } else {
                 // MatteMaterial::ComputeScatteringFunctions (matte.cpp:45-62), BSDF ctor (reflection.h:167-172)
+                // BSDF: the EXT kernel evaluates the material's BxDF list (any material); the plain kernel has the list
+                // shapes of matte / plastic / mirror / glass baked in (same arithmetic, fewer registers)
                 Bsdf bsdf;
-                bsdf.ns = is.ns; bsdf.ng = is.n;
-                bsdf.ss = normalize(is.sdpdu);
-                bsdf.ts = cross(bsdf.ns, bsdf.ss);
-                bsdf.R = sp3(m.kd[0] < 0 ? 0 : m.kd[0], m.kd[1] < 0 ? 0 : m.kd[1], m.kd[2] < 0 ? 0 : m.kd[2]);
-                bsdf.hasDiff = !is_black(bsdf.R);
-                bsdf.orenNayar = false; bsdf.onA = 1; bsdf.onB = 0;
-                if (m.type == PG_MAT_MATTE) {  // matte.cpp:55-61; OrenNayar ctor, reflection.h:425-431
-                    const float sig = clampf(m.sigma, 0, 90);
-                    if (sig != 0) {
-                        const float sigma = (PG_PI / 180) * sig, sigma2 = sigma * sigma;
-                        bsdf.orenNayar = true;
-                        bsdf.onA = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
-                        bsdf.onB = 0.45f * sigma2 / (sigma2 + 0.09f);
+                LobeBsdf lb;
+                if constexpr (EXT) {
+                    lb.ns = is.ns; lb.ng = is.n;
+                    lb.ss = normalize(is.sdpdu);
+                    lb.ts = cross(lb.ns, lb.ss);
+                    lb.lobes = sc.bxdfs + m.first_bxdf; lb.n = m.n_bxdfs; lb.eta = m.bsdf_eta;
+                } else {
+                    bsdf.ns = is.ns; bsdf.ng = is.n;
+                    bsdf.ss = normalize(is.sdpdu);
+                    bsdf.ts = cross(bsdf.ns, bsdf.ss);
+                    bsdf.R = sp3(m.kd[0] < 0 ? 0 : m.kd[0], m.kd[1] < 0 ? 0 : m.kd[1], m.kd[2] < 0 ? 0 : m.kd[2]);
+                    bsdf.hasDiff = !is_black(bsdf.R);
+                    bsdf.orenNayar = false; bsdf.onA = 1; bsdf.onB = 0;
+                    if (m.type == PG_MAT_MATTE) {  // matte.cpp:55-61; OrenNayar ctor, reflection.h:425-431
+                        const float sig = clampf(m.sigma, 0, 90);
+                        if (sig != 0) {
+                            const float sigma = (PG_PI / 180) * sig, sigma2 = sigma * sigma;
+                            bsdf.orenNayar = true;
+                            bsdf.onA = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
+                            bsdf.onB = 0.45f * sigma2 / (sigma2 + 0.09f);
+                        }
+                    }
+                    // PlasticMaterial (plastic.cpp:57-69): m.roughness already holds the distribution's alpha (host: RoughnessToAlpha)
+                    bsdf.Ks = sp3(m.ks[0] < 0 ? 0 : m.ks[0], m.ks[1] < 0 ? 0 : m.ks[1], m.ks[2] < 0 ? 0 : m.ks[2]);
+                    bsdf.hasSpec = m.type == PG_MAT_PLASTIC && !is_black(bsdf.Ks);
+                    bsdf.alpha = m.roughness;
+                    bsdf.nBxDFs = (bsdf.hasDiff ? 1 : 0) + (bsdf.hasSpec ? 1 : 0);
+                    bsdf.specular = 0; bsdf.eta = 1;
+                    bsdf.Kr = sp3(m.kr[0] < 0 ? 0 : m.kr[0], m.kr[1] < 0 ? 0 : m.kr[1], m.kr[2] < 0 ? 0 : m.kr[2]);
+                    bsdf.Kt = sp3(m.kt[0] < 0 ? 0 : m.kt[0], m.kt[1] < 0 ? 0 : m.kt[1], m.kt[2] < 0 ? 0 : m.kt[2]);
+                    if (m.type == PG_MAT_MIRROR || m.type == PG_MAT_GLASS) {  // mirror.cpp:44-56, glass.cpp:45-65 (smooth)
+                        bsdf.hasDiff = false;
+                        if (m.type == PG_MAT_MIRROR) bsdf.specular = is_black(bsdf.Kr) ? 0 : 1;
+                        else { bsdf.eta = m.eta; bsdf.specular = (is_black(bsdf.Kr) && is_black(bsdf.Kt)) ? 0 : 2; }
+                        bsdf.nBxDFs = bsdf.specular ? 1 : 0;
                     }
                 }
-                // PlasticMaterial (plastic.cpp:57-69): m.roughness already holds the distribution's alpha (host: RoughnessToAlpha)
-                bsdf.Ks = sp3(m.ks[0] < 0 ? 0 : m.ks[0], m.ks[1] < 0 ? 0 : m.ks[1], m.ks[2] < 0 ? 0 : m.ks[2]);
-                bsdf.hasSpec = m.type == PG_MAT_PLASTIC && !is_black(bsdf.Ks);
-                bsdf.alpha = m.roughness;
-                bsdf.nBxDFs = (bsdf.hasDiff ? 1 : 0) + (bsdf.hasSpec ? 1 : 0);
-                bsdf.specular = 0; bsdf.eta = 1;
-                bsdf.Kr = sp3(m.kr[0] < 0 ? 0 : m.kr[0], m.kr[1] < 0 ? 0 : m.kr[1], m.kr[2] < 0 ? 0 : m.kr[2]);
-                bsdf.Kt = sp3(m.kt[0] < 0 ? 0 : m.kt[0], m.kt[1] < 0 ? 0 : m.kt[1], m.kt[2] < 0 ? 0 : m.kt[2]);
-                if (m.type == PG_MAT_MIRROR || m.type == PG_MAT_GLASS) {  // mirror.cpp:44-56, glass.cpp:45-65 (smooth)
-                    bsdf.hasDiff = false;
-                    if (m.type == PG_MAT_MIRROR) bsdf.specular = is_black(bsdf.Kr) ? 0 : 1;
-                    else { bsdf.eta = m.eta; bsdf.specular = (is_black(bsdf.Kr) && is_black(bsdf.Kt)) ? 0 : 2; }
-                    bsdf.nBxDFs = bsdf.specular ? 1 : 0;
-                }
+                const V3 shNs = EXT ? lb.ns : bsdf.ns;
+                const int nonSpecular = PG_BSDF_ALL & ~PG_BSDF_SPECULAR;
+                bool hasNonSpecular;
+                if constexpr (EXT) hasNonSpecular = lbsdf_num_components(lb, nonSpecular) > 0;
+                else hasNonSpecular = bsdf.nBxDFs > 0 && !bsdf.specular;
                 // ---- direct lighting: UniformSampleOneLight (integrator.cpp:85-106) + EstimateDirect set-up
-                if (bsdf.nBxDFs > 0 && !bsdf.specular && sc.nLights > 0) {  // path.cpp:119: only with non-specular lobes
+                if (hasNonSpecular && sc.nLights > 0) {  // path.cpp:119: only with non-specular lobes
                     const float *tab = light_distribution(sc, is.p);
                     float lightSelPdf;
                     lightNum = sample_discrete(tab, sc.nLights, halton_sample(sc, rd, index, dim++), lightSelPdf);
@@ -874,8 +1216,9 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                         LightSample ls;
                         Spec Li = light_sample_li<EXT>(sc, light, is.p, is.pError, is.n, uL0, uL1, wi, lightPdf, ls);
                         if (lightPdf > 0 && !is_black(Li)) {
-                            Spec f = bsdf_f(bsdf, is.wo, wi) * absdot(wi, bsdf.ns);
-                            scatteringPdf = bsdf_pdf(bsdf, is.wo, wi);
+                            Spec f;
+                            if constexpr (EXT) { f = lbsdf_f(lb, is.wo, wi, nonSpecular) * absdot(wi, shNs); scatteringPdf = lbsdf_pdf(lb, is.wo, wi, nonSpecular); }
+                            else { f = bsdf_f(bsdf, is.wo, wi) * absdot(wi, shNs); scatteringPdf = bsdf_pdf(bsdf, is.wo, wi); }
                             if (!is_black(f)) {
                                 // VisibilityTester: p0.SpawnRayTo(p1), interaction.h:73-78
                                 V3 origin = offset_ray_origin(is.p, is.pError, is.n, ls.p - is.p);
@@ -896,8 +1239,9 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                         float sPdf2 = 0;
                         Spec f2 = sp(0);
                         if (light.type == PG_LIGHT_AREA || (EXT && light.type == PG_LIGHT_INFINITE)) {  // integrator.cpp:164: if (!IsDeltaLight(light.flags))
-                            f2 = bsdf_sample_f(bsdf, is.wo, wi2, uS0, uS1, sPdf2);
-                            f2 = f2 * absdot(wi2, bsdf.ns);
+                            if constexpr (EXT) { int st2; f2 = lbsdf_sample_f(lb, is.wo, wi2, uS0, uS1, sPdf2, nonSpecular, st2); }
+                            else f2 = bsdf_sample_f(bsdf, is.wo, wi2, uS0, uS1, sPdf2);
+                            f2 = f2 * absdot(wi2, shNs);
                         }
                         if (!is_black(f2) && sPdf2 > 0) {
                             misCand = true;
@@ -922,12 +1266,15 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                 float u0 = halton_sample(sc, rd, index, dim), u1 = halton_sample(sc, rd, index, dim + 1);
                 dim += 2;
                 int sampledType = 0;
-                Spec f = bsdf.specular ? bsdf_sample_specular(bsdf, wo, wi, u0, pdf, sampledType) : bsdf_sample_f(bsdf, wo, wi, u0, u1, pdf);
+                Spec f;
+                float bsdfEta;
+                if constexpr (EXT) { f = lbsdf_sample_f(lb, wo, wi, u0, u1, pdf, PG_BSDF_ALL, sampledType); bsdfEta = lb.eta; }
+                else { f = bsdf.specular ? bsdf_sample_specular(bsdf, wo, wi, u0, pdf, sampledType) : bsdf_sample_f(bsdf, wo, wi, u0, u1, pdf); bsdfEta = bsdf.eta; }
                 if (!(is_black(f) || pdf == 0.f)) {
-                    beta = beta * ((f * absdot(wi, bsdf.ns)) / pdf);
+                    beta = beta * ((f * absdot(wi, shNs)) / pdf);
                     if (sampledType & PG_BSDF_SPECULAR) newFlags |= PG_META_SPECULAR;  // path.cpp:142
                     if ((sampledType & PG_BSDF_SPECULAR) && (sampledType & PG_BSDF_TRANSMISSION))  // path.cpp:143-149
-                        etaScale *= (dot(wo, is.n) > 0) ? (bsdf.eta * bsdf.eta) : 1 / (bsdf.eta * bsdf.eta);
+                        etaScale *= (dot(wo, is.n) > 0) ? (bsdfEta * bsdfEta) : 1 / (bsdfEta * bsdfEta);
                     V3 nextO;
                     spawn_ray(is, wi, nextO);
                     s_ray[0][0][tid] = make_float4(nextO.x, nextO.y, nextO.z, PG_INF);
@@ -998,7 +1345,7 @@ void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQue
                   RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s) {
     int nblk = PG_REGIONS * (qin.regionCap / PG_BLOCK);
     if (nblk == 0) return;
-    if (sc.nSpheres > 0 || sc.hasInfinite) hipLaunchKernelGGL(k_shade<true>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests);
+    if (sc.ext) hipLaunchKernelGGL(k_shade<true>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests);
     else hipLaunchKernelGGL(k_shade<false>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests);
 }
 
@@ -1045,7 +1392,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_resolve(DScene sc, PathState st, R
 void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis, const int *occluded, const float4 *misHits, hipStream_t s) {
     int nblk = PG_REGIONS * (qin.regionCap / PG_BLOCK);
     if (nblk == 0) return;
-    if (sc.nSpheres > 0 || sc.hasInfinite) hipLaunchKernelGGL(k_resolve<true>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, qin, qmis, occluded, misHits);
+    if (sc.ext) hipLaunchKernelGGL(k_resolve<true>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, qin, qmis, occluded, misHits);
     else hipLaunchKernelGGL(k_resolve<false>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, qin, qmis, occluded, misHits);
 }
 

@@ -88,6 +88,29 @@ def test_film_bit_identical_to_correctly_rounded_oracle(gpu, oracle, name):
     gs.close()
 
 
+@pytest.mark.parametrize("name", ["cornell_32", "cornell_plastic", "plastic_topdown", "cornell_mirror_glass", "cornell_glass_eta", "cornell_orennayar",
+                                  "cornell_tangents", "cornell_spot_power", "synthetic_n40"])
+def test_general_kernels_equal_specialised_kernels(gpu, name, monkeypatch):
+    """matte / plastic / mirror / glass run in shading kernels specialised to those materials' BxDF lists; PG_FORCE_EXT=1 sends
+    the same scenes through the general kernels (BxDF-list BSDF, sphere / infinite-light support compiled in): same film, bit
+    for bit, same counters."""
+    scene = gpu.HostScene(os.path.join(GOLD, name + ".pbrt"))
+    rd = scene.render_desc()
+    gs = gpu.GpuScene(scene.desc)
+    film, strays = gs.render(rd)
+    cn = gs.counters()
+    gs.close()
+    monkeypatch.setenv("PG_FORCE_EXT", "1")
+    gs2 = gpu.GpuScene(scene.desc)
+    film2, strays2 = gs2.render(rd)
+    cn2 = gs2.counters()
+    gs2.close()
+    assert np.array_equal(film["rgb"], film2["rgb"]) and np.array_equal(film["weight"], film2["weight"])
+    assert len(strays) == len(strays2)
+    for k in ("camera_rays", "closest_rays", "shadow_rays", "tri_tests", "node_visits"):
+        assert cn[k] == cn2[k], k
+
+
 def random_rays(scene, n, seed):
     rng = np.random.default_rng(seed)
     nodes = scene.nodes()
@@ -230,7 +253,12 @@ def test_unsupported_inputs_fail_loudly(gpu):
     mats[0].type = 7
     bad = gpu.abi.PgSceneDesc.from_buffer_copy(desc)
     bad.materials = mats
-    with pytest.raises(gpu.PbrtGpuError, match="closed set"):
+    with pytest.raises(gpu.PbrtGpuError, match="unknown type 7"):
+        gpu.GpuScene(bad)
+    mats[0].type = 1
+    mats[0].first_bxdf = desc.n_bxdfs  # a BxDF list that runs off the end of the scene's table
+    mats[0].n_bxdfs = 2
+    with pytest.raises(gpu.PbrtGpuError, match="BxDF list"):
         gpu.GpuScene(bad)
     gs = gpu.GpuScene(desc)
     rd = scene.render_desc()
