@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 7
+#define PG_ABI_VERSION 8
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -60,6 +60,7 @@ typedef struct PgBVHNode {
 #define PG_TRI_HAS_UV 8u      /* mesh has per-vertex uv               */
 #define PG_TRI_HAS_S 16u      /* mesh has per-vertex tangents         */
 #define PG_PRIM_SPHERE 32u    /* not a triangle: spheres[indices[3*k]] (PgSphere below) */
+#define PG_PRIM_INSTANCE 64u  /* a TransformedPrimitive: instances[indices[3*k]] (PgInstance below); top level only */
 
 typedef enum PgMaterialType {
     PG_MAT_NONE = 0,   /* no material: primitive is a medium boundary (bsdf == nullptr) */
@@ -166,6 +167,20 @@ typedef struct PgSphere {
     int32_t swaps_handedness;   /* Shape::transformSwapsHandedness         */
 } PgSphere;
 
+/* Object instancing (api.cpp:1509-1588).  An object definition is a run of primitives in the primitive arrays after the
+ * n_tris top-level ones and, when it has more than one primitive, its own BVHAccel: a run of nodes after the n_nodes
+ * top-level ones, laid out exactly as that BVHAccel's LinearBVHNode array (child / primitive offsets relative to the
+ * object's own first node / first primitive).  An instance is a top-level primitive with PG_PRIM_INSTANCE. */
+typedef struct PgObject {
+    int32_t first_node, n_nodes; /* n_nodes == 0: a single primitive without an accelerator (api.cpp:1567) */
+    int32_t first_prim, n_prims;
+} PgObject;
+typedef struct PgInstance {      /* TransformedPrimitive (primitive.h:92-117), start transform only */
+    float i2w[16], w2i[16];      /* InstanceToWorld and its inverse, row-major */
+    int32_t object;
+    int32_t identity;            /* Transform::IsIdentity() of InstanceToWorld (primitive.cpp:86-87) */
+} PgInstance;
+
 typedef struct PgSceneDesc {
     int32_t abi_version;        /* PG_ABI_VERSION */
     /* acceleration structure, BVHAccel after flattenBVHTree (bvh.cpp:640-658) */
@@ -197,6 +212,12 @@ typedef struct PgSceneDesc {
     const PgSphere *spheres;
     int32_t n_bxdfs;
     const PgBxDF *bxdfs;
+    /* instancing: nodes[] holds n_nodes_all >= n_nodes entries, the primitive arrays n_prims_all >= n_tris entries */
+    int32_t n_nodes_all, n_prims_all;
+    int32_t n_objects;
+    const PgObject *objects;
+    int32_t n_instances;
+    const PgInstance *instances;
 } PgSceneDesc;
 
 /* ---- render description -------------------------------------------------- */

@@ -57,6 +57,24 @@ SPHERE_ENCLOSING = ('AttributeBegin\n  Translate 278 273 100\n  ReverseOrientati
                     '  Shape "sphere" "float radius" [ 1500 ]\nAttributeEnd\n')
 
 
+def with_instances(s):
+    """Move the two boxes into `ObjectBegin "boxes"`, add a one-sphere object, and instance both several times."""
+    i = s.index("# short box")
+    j = s.index("WorldEnd")
+    boxes = s[i:j].replace("# tall box", 'Material "glass" "float index" [ 1.4 ]\n# tall box')
+    inst = ('ObjectBegin "boxes"\n' + boxes + 'ObjectEnd\n'
+            'ObjectBegin "ball"\n  Material "mirror"\n  Translate 0 40 0\n  Shape "sphere" "float radius" [ 40 ]\nObjectEnd\n'
+            'ObjectBegin "tri"\n  Material "matte" "rgb Kd" [ 0.8 0.6 0.1 ]\n  Shape "trianglemesh" "integer indices" [ 0 1 2 ] "point P" [ 0 0 0  90 0 0  0 120 30 ]\nObjectEnd\n'
+            'ObjectInstance "boxes"\n'
+            'AttributeBegin\n  Translate 50 230 -40\n  Rotate 25 0 1 0.2\n  Scale 0.45 0.45 0.45\n  ObjectInstance "boxes"\nAttributeEnd\n'
+            'AttributeBegin\n  Translate 520 330 120\n  Scale -0.4 0.3 0.5\n  ObjectInstance "boxes"\nAttributeEnd\n'
+            'AttributeBegin\n  Translate 120 0 420\n  ObjectInstance "ball"\nAttributeEnd\n'
+            'AttributeBegin\n  Translate 420 300 80\n  Scale 1.5 0.6 1\n  ObjectInstance "ball"\nAttributeEnd\n'
+            'AttributeBegin\n  Translate 40 20 100\n  Rotate -30 0 1 0\n  ObjectInstance "tri"\nAttributeEnd\n'
+            'AttributeBegin\n  Translate 330 380 300\n  Scale 1 -1 1\n  ObjectInstance "tri"\nAttributeEnd\n')
+    return s[:i] + inst + s[j:]
+
+
 def with_normals(s, tangents=False, uv=False):
     """Give both Cornell boxes smooth-ish per-vertex normals (outward from the box centre, one of them zero), optionally
     tangents and a uv parameterisation."""
@@ -256,6 +274,11 @@ SCENES = {
                        .replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\nNamedMaterial "mixA"')
                        .replace("# tall box", 'NamedMaterial "mixNested"\n# tall box')
                        .replace('Material "matte" "rgb Kd" [ 0.12 0.45 0.15 ]', 'NamedMaterial "mixSpec"')),
+    # object instancing (api.cpp:1509-1588, TransformedPrimitive primitive.cpp:76-103): the two boxes become an object
+    # definition with its own BVH, instanced under translations, a rotation, a non-uniform and a mirroring scale and the
+    # identity; a one-primitive object (no accelerator) holding a sphere; materials bound inside the definition
+    "instance_boxes": cornell(40, 40, 8, integrator='Integrator "path" "integer maxdepth" [ 6 ]', world_edit=lambda s: with_instances(s)),
+    "instance_accel": cornell(32, 32, 8, world_edit=lambda s: with_instances(s)).replace('WorldBegin', 'Accelerator "bvh" "integer maxnodeprims" [ 3 ] "string splitmethod" "middle"\nWorldBegin'),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 

@@ -5,7 +5,7 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 7
+PG_ABI_VERSION = 8
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
 PG_LIGHTS_UNIFORM, PG_LIGHTS_POWER, PG_LIGHTS_SPATIAL = 0, 1, 2
@@ -45,6 +45,14 @@ class PgSphere(C.Structure):
                 ("reverse_orientation", C.c_int32), ("swaps_handedness", C.c_int32)]
 
 
+class PgObject(C.Structure):
+    _fields_ = [("first_node", C.c_int32), ("n_nodes", C.c_int32), ("first_prim", C.c_int32), ("n_prims", C.c_int32)]
+
+
+class PgInstance(C.Structure):
+    _fields_ = [("i2w", C.c_float * 16), ("w2i", C.c_float * 16), ("object", C.c_int32), ("identity", C.c_int32)]
+
+
 class PgSceneDesc(C.Structure):
     _fields_ = [("abi_version", C.c_int32),
                 ("n_nodes", C.c_int32), ("nodes", C.POINTER(PgBVHNode)),
@@ -57,7 +65,9 @@ class PgSceneDesc(C.Structure):
                 ("light_strategy", C.c_int32),
                 ("n_perm_dims", C.c_int32), ("perms", C.POINTER(C.c_uint16)), ("perm_sums", C.POINTER(C.c_int32)),
                 ("n_spheres", C.c_int32), ("spheres", C.POINTER(PgSphere)),
-                ("n_bxdfs", C.c_int32), ("bxdfs", C.POINTER(PgBxDF))]
+                ("n_bxdfs", C.c_int32), ("bxdfs", C.POINTER(PgBxDF)),
+                ("n_nodes_all", C.c_int32), ("n_prims_all", C.c_int32), ("n_objects", C.c_int32), ("objects", C.POINTER(PgObject)),
+                ("n_instances", C.c_int32), ("instances", C.POINTER(PgInstance))]
 
 
 class PgRenderDesc(C.Structure):

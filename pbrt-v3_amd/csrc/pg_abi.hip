@@ -45,10 +45,10 @@ struct DeviceBuffer {
 struct PgScene {
     int device = 0;
     DScene d;
-    DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, triN, triS, uv, materials, lights, distTable, perms, permSums, primes;
+    DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, triN, triS, uv, materials, lights, distTable, perms, permSums, primes;
     // work buffers (sized on first render, reused)
     int capacity = 0;
-    DeviceBuffer qo[4], qd[4], counts, hitsMain, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
+    DeviceBuffer qo[4], qd[4], counts, hitsMain, hitInst, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
         lightTests, filmDev, straysDev, nStraysDev, cullGuard, cursors, cursors2;
     hipStream_t shadowStream = nullptr;  // any-hit launches run here, concurrently with the next closest-hit launch
     hipEvent_t evShaded = nullptr, evShadowed = nullptr;
@@ -99,51 +99,99 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     memset(&s->counters, 0, sizeof(s->counters));
     DScene &d = s->d;
     memset(&d, 0, sizeof(d));
-    const int nt = desc->n_tris;
+    // primitives / nodes of object definitions follow the top-level ones (hosts that know no instancing leave the _all counts 0)
+    const int nt = desc->n_prims_all > desc->n_tris ? desc->n_prims_all : desc->n_tris;
+    const int nnAll = desc->n_nodes_all > desc->n_nodes ? desc->n_nodes_all : desc->n_nodes;
 #define FAIL(code, ...) do { int c_ = setError(code, __VA_ARGS__); pg_scene_destroy(s); return c_; } while (0)
 #define HIP_TRY_S(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) FAIL(PG_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
     // --- nodes: uploaded verbatim (32 B/node, same bytes as pbrt's LinearBVHNode)
-    HIP_TRY_S(s->nodes.alloc(sizeof(PgBVHNode) * (size_t)desc->n_nodes));
-    if (desc->n_nodes) HIP_TRY_S(hipMemcpy(s->nodes.p, desc->nodes, s->nodes.bytes, hipMemcpyHostToDevice));
+    HIP_TRY_S(s->nodes.alloc(sizeof(PgBVHNode) * (size_t)nnAll));
+    if (nnAll) HIP_TRY_S(hipMemcpy(s->nodes.p, desc->nodes, s->nodes.bytes, hipMemcpyHostToDevice));
     // --- child-pair records for k_trace (pg_traverse.hip): one 64-B record per interior node
     {
-        const int nn = desc->n_nodes;
         int maxLeaf = 1;
-        for (int i = 0; i < nn; ++i) if (desc->nodes[i].nprims > maxLeaf) maxLeaf = desc->nodes[i].nprims;
+        for (int i = 0; i < nnAll; ++i) if (desc->nodes[i].nprims > maxLeaf) maxLeaf = desc->nodes[i].nprims;
         int leafBits = 0;
         while ((1 << leafBits) < maxLeaf) ++leafBits;
         if ((uint64_t)nt >= ((uint64_t)1 << (31 - leafBits)) - 1)
             FAIL(PG_ERR_UNSUPPORTED, "%d triangles with up to %d per leaf exceed the 31-bit leaf reference", nt, maxLeaf);
-        std::vector<int> recIndex((size_t)nn, -1);
-        int nInterior = 0;
-        for (int i = 0; i < nn; ++i) if (desc->nodes[i].nprims == 0) recIndex[i] = nInterior++;
-        auto refOf = [&](int i) -> int {
-            const PgBVHNode &nd = desc->nodes[i];
-            return nd.nprims == 0 ? recIndex[i] : ~((nd.offset << leafBits) | (nd.nprims - 1));
+        std::vector<float4> w;
+        // one BVHAccel's nodes [firstNode, +nn) -> records appended to w; leaf references carry GLOBAL primitive indices
+        // (firstPrim + the node's own offset).  Returns the reference of the BVH's root.
+        bool badChildren = false;
+        auto buildRecords = [&](int firstNode, int nn, int firstPrim) -> int {
+            const PgBVHNode *nodes = desc->nodes + firstNode;
+            std::vector<int> recIndex((size_t)nn, -1);
+            int nInterior = 0;
+            const int base = (int)(w.size() / 4);
+            for (int i = 0; i < nn; ++i) if (nodes[i].nprims == 0) recIndex[i] = base + nInterior++;
+            auto refOf = [&](int i) -> int {
+                const PgBVHNode &nd = nodes[i];
+                return nd.nprims == 0 ? recIndex[i] : ~(((firstPrim + nd.offset) << leafBits) | (nd.nprims - 1));
+            };
+            w.resize((size_t)(base + nInterior) * 4);
+            for (int i = 0; i < nn; ++i) {
+                const PgBVHNode &nd = nodes[i];
+                if (nd.nprims != 0) continue;
+                const int c0 = i + 1, c1 = nd.offset;
+                if (c0 >= nn || c1 <= i || c1 >= nn) { badChildren = true; continue; }
+                const PgBVHNode &a = nodes[c0], &b = nodes[c1];
+                float4 *r = &w[(size_t)recIndex[i] * 4];
+                r[0] = make_float4(a.bmin[0], a.bmax[0], b.bmin[0], b.bmax[0]);
+                r[1] = make_float4(a.bmin[1], a.bmax[1], b.bmin[1], b.bmax[1]);
+                r[2] = make_float4(a.bmin[2], a.bmax[2], b.bmin[2], b.bmax[2]);
+                int r0 = refOf(c0), r1 = refOf(c1), ax = nd.axis;
+                float f0, f1, f2;
+                memcpy(&f0, &r0, 4); memcpy(&f1, &r1, 4); memcpy(&f2, &ax, 4);
+                r[3] = make_float4(f0, f1, f2, 0.f);
+            }
+            return nn > 0 ? refOf(0) : TR_NO_ROOT;
         };
-        std::vector<float4> w((size_t)nInterior * 4);
-        for (int i = 0; i < nn; ++i) {
-            const PgBVHNode &nd = desc->nodes[i];
-            if (nd.nprims != 0) continue;
-            const int c0 = i + 1, c1 = nd.offset;
-            if (c0 >= nn || c1 <= i || c1 >= nn) FAIL(PG_ERR_INVALID, "BVH node %d has out-of-range children", i);
-            const PgBVHNode &a = desc->nodes[c0], &b = desc->nodes[c1];
-            float4 *r = &w[(size_t)recIndex[i] * 4];
-            r[0] = make_float4(a.bmin[0], a.bmax[0], b.bmin[0], b.bmax[0]);
-            r[1] = make_float4(a.bmin[1], a.bmax[1], b.bmin[1], b.bmax[1]);
-            r[2] = make_float4(a.bmin[2], a.bmax[2], b.bmin[2], b.bmax[2]);
-            int r0 = refOf(c0), r1 = refOf(c1), ax = nd.axis;
-            float f0, f1, f2;
-            memcpy(&f0, &r0, 4); memcpy(&f1, &r1, 4); memcpy(&f2, &ax, 4);
-            r[3] = make_float4(f0, f1, f2, 0.f);
+        const int nn = desc->n_nodes;
+        const int topRef = buildRecords(0, nn, 0);
+        // object definitions (instancing): each with its own records, root box and root reference
+        std::vector<DObject> objs((size_t)(desc->n_objects > 0 ? desc->n_objects : 0));
+        for (size_t k = 0; k < objs.size(); ++k) {
+            const PgObject &o = desc->objects[k];
+            if (o.first_prim < desc->n_tris || o.n_prims < 1 || o.first_prim + o.n_prims > nt || o.n_nodes < 0 ||
+                (o.n_nodes > 0 && (o.first_node < desc->n_nodes || o.first_node + o.n_nodes > nnAll)) || (o.n_nodes == 0 && o.n_prims != 1))
+                FAIL(PG_ERR_INVALID, "object %d: nodes [%d, +%d) / primitives [%d, +%d) out of range", (int)k, o.first_node, o.n_nodes, o.first_prim, o.n_prims);
+            DObject &dobj = objs[k];
+            memset(&dobj, 0, sizeof(dobj));
+            dobj.firstPrim = o.first_prim;
+            dobj.nNodes = o.n_nodes;
+            if (o.n_nodes > 0) {
+                dobj.rootRef = buildRecords(o.first_node, o.n_nodes, o.first_prim);
+                for (int c = 0; c < 3; ++c) { dobj.box[c] = desc->nodes[o.first_node].bmin[c]; dobj.box[3 + c] = desc->nodes[o.first_node].bmax[c]; }
+            }
         }
+        if (badChildren) FAIL(PG_ERR_INVALID, "a BVH node has out-of-range children");
+        for (int k = 0; k < nt; ++k) {
+            const uint32_t f = desc->tri_flags ? desc->tri_flags[k] : 0;
+            if (!(f & PG_PRIM_INSTANCE)) continue;
+            const int ii = desc->indices[3 * k];
+            if (k >= desc->n_tris) FAIL(PG_ERR_UNSUPPORTED, "primitive %d: an object definition cannot contain an object instance", k);
+            if (ii < 0 || ii >= desc->n_instances || !desc->instances || desc->instances[ii].object < 0 || desc->instances[ii].object >= desc->n_objects)
+                FAIL(PG_ERR_INVALID, "primitive %d: instance %d / its object out of range", k, ii);
+        }
+        if (!objs.empty()) {
+            HIP_TRY_S(s->objects.alloc(sizeof(DObject) * objs.size()));
+            HIP_TRY_S(hipMemcpy(s->objects.p, objs.data(), s->objects.bytes, hipMemcpyHostToDevice));
+        }
+        if (desc->n_instances > 0 && desc->instances) {
+            HIP_TRY_S(s->instances.alloc(sizeof(PgInstance) * (size_t)desc->n_instances));
+            HIP_TRY_S(hipMemcpy(s->instances.p, desc->instances, s->instances.bytes, hipMemcpyHostToDevice));
+        }
+        d.objects = (const DObject *)s->objects.p;
+        d.instances = (const PgInstance *)s->instances.p;
+        d.nInstances = s->instances.p ? desc->n_instances : 0;
         HIP_TRY_S(s->wnodes.alloc(sizeof(float4) * w.size()));
         if (!w.empty()) HIP_TRY_S(hipMemcpy(s->wnodes.p, w.data(), s->wnodes.bytes, hipMemcpyHostToDevice));
         d.wnodes = (const float4 *)s->wnodes.p;
         d.leafBits = leafBits;
         if (nn > 0) {
             for (int k = 0; k < 3; ++k) { d.rootBox[k] = desc->nodes[0].bmin[k]; d.rootBox[3 + k] = desc->nodes[0].bmax[k]; }
-            d.rootRef = refOf(0);
+            d.rootRef = topRef;
         }
         TraceConfig tc = get_trace_config();
         if (const char *e = getenv("PG_TRACE_DEPTH")) { int v = atoi(e); if (v >= 0 && v <= 64) tc.depth = v; }
@@ -167,6 +215,17 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         int light = desc->tri_light ? desc->tri_light[k] : -1;
         if (mat < 0 || mat >= desc->n_materials) FAIL(PG_ERR_INVALID, "triangle %d has out-of-range material %d", k, mat);
         if (light >= desc->n_lights) FAIL(PG_ERR_INVALID, "triangle %d has out-of-range light %d", k, light);
+        if (flags & PG_PRIM_INSTANCE) {  // TransformedPrimitive: the record carries the instance's index
+            float iw, fw, mw, lw;
+            const int none = -1;
+            flags = PG_PRIM_INSTANCE;
+            memcpy(&iw, &v[0], 4); memcpy(&fw, &flags, 4); memcpy(&mw, &mat, 4); memcpy(&lw, &none, 4);
+            tris[3 * (size_t)k] = make_float4(iw, 0, 0, fw);
+            tris[3 * (size_t)k + 1] = make_float4(0, 0, 0, mw);
+            tris[3 * (size_t)k + 2] = make_float4(0, 0, 0, lw);
+            if (anyUV) { const float duv[6] = {0, 0, 1, 0, 1, 1}; memcpy(&uv[(size_t)k * 6], duv, sizeof(duv)); }
+            continue;
+        }
         if (flags & PG_PRIM_SPHERE) {  // Shape "sphere": the record carries the sphere's index where a triangle has p0.x
             if (v[0] < 0 || v[0] >= desc->n_spheres || !desc->spheres) FAIL(PG_ERR_INVALID, "primitive %d has out-of-range sphere index %d", k, v[0]);
             float iw, fw, mw, lw;
@@ -287,7 +346,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     d.bxdfs = (const PgBxDF *)s->bxdfs.p;
     {  // PG_FORCE_EXT=1 runs the general kernels on scenes that do not need them (tests: both paths agree bit for bit)
         const char *fe = getenv("PG_FORCE_EXT");
-        d.ext = (d.nSpheres > 0 || d.hasInfinite || anyLobeMaterial || (fe && atoi(fe) != 0)) ? 1 : 0;
+        d.ext = (d.nSpheres > 0 || d.nInstances > 0 || d.hasInfinite || anyLobeMaterial || (fe && atoi(fe) != 0)) ? 1 : 0;
     } d.uv = (const float *)s->uv.p;
     d.triN = (const float4 *)s->triN.p; d.triS = (const float4 *)s->triS.p;
     d.materials = (const PgMaterial *)s->materials.p; d.lights = (const PgLight *)s->lights.p;
@@ -370,7 +429,9 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
 }
 
 static void traceClosest(PgScene *s, RayQueue q, float4 *hits, float *tOut, TraceCounters *cn, hipStream_t st) {
-    launch_closest(s->d, q, hits, tOut, cn, (int *)s->cursors.p, (int *)s->cullGuard.p, st);
+    DScene d = s->d;
+    d.hitInst = nullptr;  // the unit entry points report primitive, t and barycentrics only
+    launch_closest(d, q, hits, tOut, cn, (int *)s->cursors.p, (int *)s->cullGuard.p, st);
 }
 static void traceAnyhit(PgScene *s, RayQueue q, int *occluded, TraceCounters *cn, hipStream_t st) {
     launch_anyhit(s->d, q, occluded, cn, (int *)s->cursors.p, st);
@@ -411,7 +472,8 @@ static int ensureWorkBuffers(PgScene *s, int capacity) {
     const size_t n = (size_t)regionCapFor(capacity) * PG_REGIONS;  // >= capacity
     for (int i = 0; i < 4; ++i) { HIP_TRY(s->qo[i].alloc(n * sizeof(float4))); HIP_TRY(s->qd[i].alloc(n * sizeof(float4))); }
     HIP_TRY(s->counts.alloc(4 * PG_REGIONS * PG_COUNT_STRIDE * sizeof(int)));
-    HIP_TRY(s->hitsMain.alloc(2 * n * sizeof(float4)));  // main-queue hits, then MIS-queue hits at offset n (one launch fills both)
+    HIP_TRY(s->hitsMain.alloc(2 * n * sizeof(float4)));
+    if (s->d.nInstances > 0) { HIP_TRY(s->hitInst.alloc(2 * n * sizeof(int))); s->d.hitInst = (int *)s->hitInst.p; }  // main-queue hits, then MIS-queue hits at offset n (one launch fills both)
     HIP_TRY(s->occluded.alloc(n * sizeof(int)));
     HIP_TRY(s->stL.alloc(n * sizeof(float4)));
     HIP_TRY(s->stBeta.alloc(n * sizeof(float4)));
@@ -534,7 +596,7 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
                 timed.push_back({ev, 0}); ev += 2;
                 HIP_TRY(hipEventRecord(a, stream));
                 if (qb) launch_closest2(s->d, qa, *qb, ha, (int)(hb - ha), cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream);
-                else traceClosest(s, qa, ha, nullptr, cnClosest, stream);
+                else launch_closest(s->d, qa, ha, nullptr, cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream);
                 HIP_TRY(hipEventRecord(b, stream));
                 ++closestLaunches;
                 return PG_OK;

@@ -9,6 +9,10 @@
 // Per-triangle flag bits stored in tris[3*i].w, on top of PG_TRI_*.
 #define PG_TRI_BOGUS 0x100u  // Triangle::Intersect rejects every hit (triangle.cpp:309-317)
 
+// One object definition (instancing) on the device: its BVHAccel's root, or its lone primitive when nNodes == 0.
+struct DObject { float box[6]; int rootRef; int firstPrim; int nNodes; int pad; };
+#define TR_NO_ROOT 0x7fffffff
+
 // Device-resident scene.  All pointers are device memory.
 struct DScene {
     // Linearised BVH, 32 B/node exactly as PgBVHNode: two float4 per node
@@ -33,6 +37,10 @@ struct DScene {
     int nNodes, nTris, nLights, nMaterials;
     const PgSphere *spheres;  // Shape "sphere" primitives: tris[3*k] = (sphere index, 0, 0, flags | PG_PRIM_SPHERE)
     int nSpheres;
+    const PgInstance *instances;  // TransformedPrimitives: tris[3*k] = (instance index, 0, 0, PG_PRIM_INSTANCE), top level only
+    const DObject *objects;
+    int nInstances;
+    int *hitInst;  // per closest-hit result: the instance the hit primitive was reached through, or -1 (written by k_trace<.., true>)
     const PgBxDF *bxdfs;      // the materials' BxDF lists (PgMaterial.first_bxdf / n_bxdfs)
     int ext;          // the EXT shading kernels are needed: spheres, infinite lights or PG_MAT_LOBES materials (or PG_FORCE_EXT=1)
     int hasInfinite;  // some light is an InfiniteAreaLight (Scene::infiniteLights non-empty)

@@ -1126,9 +1126,15 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
         if (found) tri = load_tri(sc, prim);
         Isect is;
         const bool onSphere = EXT && found && (tri.flags & PG_PRIM_SPHERE);
+        // a hit reached through an object instance was computed on the instance-space ray (primitive.cpp:80-82)
+        const int inst = (EXT && found && sc.hitInst) ? sc.hitInst[i] : -1;
+        V3 shapeRayD = rayD;
+        if (inst >= 0) shapeRayD = m4_vec(sc.instances[inst].w2i, rayD);
         if (onSphere) {  // the hit record of a sphere carries tHit: Sphere::Intersect's interaction from the ray and the root
             const float4 o4 = qin.o[i];
-            const SphereHit sh = sphere_interaction(sc.spheres[__float_as_int(tri.p0.x)], mk(o4.x, o4.y, o4.z), rayD, h4.y);
+            V3 shapeRayO = mk(o4.x, o4.y, o4.z);
+            if (inst >= 0) { float dt; instance_ray(sc.instances[inst].w2i, shapeRayO, rayD, shapeRayO, shapeRayD, dt); }
+            const SphereHit sh = sphere_interaction(sc.spheres[__float_as_int(tri.p0.x)], shapeRayO, shapeRayD, h4.y);
             is.p = sh.p; is.pError = sh.pError; is.wo = sh.wo; is.n = sh.n; is.ns = sh.n; is.sdpdu = sh.dpdu;
         }
         // path.cpp:91-102 emitted light at the vertex
@@ -1145,7 +1151,18 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
         bool alive = found && bounces < rd.max_depth;  // path.cpp:104
         int newFlags = 0;
         if (alive) {
-            if (!onSphere) is = make_isect(sc, prim, tri, h4.y, h4.z, h4.w, rayD);
+            if (!onSphere) is = make_isect(sc, prim, tri, h4.y, h4.z, h4.w, shapeRayD);
+            if (inst >= 0 && !sc.instances[inst].identity) {  // InterpolatedPrimToWorld(*isect), transform.cpp:262-297
+                const PgInstance &in = sc.instances[inst];
+                Isect w;
+                w.p = m4_point_err2(in.i2w, is.p, is.pError, w.pError);
+                w.n = normalize(m4_normal(in.w2i, is.n));
+                w.wo = normalize(m4_vec(in.i2w, is.wo));
+                w.sdpdu = m4_vec(in.i2w, is.sdpdu);
+                w.ns = normalize(m4_normal(in.w2i, is.ns));
+                if (dot(w.ns, w.n) < 0.f) w.ns = -w.ns;  // Faceforward(shading.n, n)
+                is = w;
+            }
             const PgMaterial &m = sc.materials[tri.material];
             if (m.type == PG_MAT_NONE) {  // path.cpp:107-113: skip over medium boundaries
                 V3 nextO;

@@ -106,6 +106,19 @@ PG_DEV V3 m4_vec_err(const float *m, V3 v, V3 &absError) {  // transform.h:334-3
     return m4_vec(m, v);
 }
 
+// Transform::operator()(const Ray &), transform.h:249-262, as TransformedPrimitive applies it with WorldToInstance
+// (primitive.cpp:80): origin moved to the edge of its error box; dt is what the caller takes off tMax
+PG_DEV void instance_ray(const float *w2i, V3 ro, V3 rd, V3 &o, V3 &d, float &dt) {
+    V3 oErr;
+    o = m4_point_err(w2i, ro, oErr);
+    d = m4_vec(w2i, rd);
+    const float lengthSquared = lensq(d);
+    dt = 0;
+    if (lengthSquared > 0) {
+        dt = dot(vabs(d), oErr) / lengthSquared;
+        o = o + d * dt;
+    }
+}
 // (*WorldToObject)(ray, &oErr, &dErr), transform.h:372-384: the object-space ray, its origin moved to the edge of its error box
 PG_DEV void sphere_object_ray(const PgSphere &sp, V3 ro, V3 rd, V3 &o, V3 &d, V3 &oErr, V3 &dErr) {
     o = m4_point_err(sp.w2o, ro, oErr);

@@ -72,7 +72,9 @@ PG_DEV unsigned long long tr_wave_sum(unsigned long long v) {
     return v;
 }
 
-template <bool ANYHIT, bool SPHERES>
+// XPRIM: the scene has primitives other than triangles -- spheres and object instances (TransformedPrimitive over an
+// object definition's own BVH): a separate instantiation, so that triangle-only scenes keep the lean kernel.
+template <bool ANYHIT, bool XPRIM>
 __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(DScene sc, RayQueue q0, RayQueue q1, float4 *__restrict__ hits,
                                                     int hitOffset1, float *__restrict__ tOut, int *__restrict__ occluded,
                                                     TraceCounters *cn, int *__restrict__ cursors, int depth, int chunk, int refillAt, int triW,
@@ -107,6 +109,14 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
     unsigned long long vmask = 0;     // ANYHIT: bit i set = the reference's entry at depth i was culled early
     unsigned int nodeVisits = 0, triTests = 0;
     int nAccepted = 0;  // hits accepted by this lane's current ray (bounds the rounding growth of tMax, see cullK below)
+    // XPRIM: object instances.  While a lane traverses an instance's BVH its ray registers hold the instance-space ray
+    // (TransformedPrimitive::Intersect, primitive.cpp:76-96); the world ray, the rest of the world leaf and (any-hit) the
+    // world BVH's visit bookkeeping wait here.  Entries of the instance's traversal sit on the same stack above spBase.
+    int inInst = -1, hitInstCur = -1, spBase = 0, wTriNext = 0, wTriLeft = 0, wvd = 0;
+    bool instHit = false;
+    float wox = 0, woy = 0, woz = 0, wix = 1, wiy = 1, wiz = 1, wtMax = 0;
+    TriRay wtr = tr;
+    unsigned long long wvmask = 0;
     const int leafBits = sc.leafBits, leafMask = (1 << leafBits) - 1;
 
 #define TR_PUSH(ref_, t_) do { uint2 e_ = make_uint2((unsigned)(ref_), __float_as_uint(t_)); \
@@ -116,20 +126,30 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
     // The reference's "pop or finish" (bvh.cpp:694-697): next node whose deferred `tMin < ray.tMax` test passes.
 #define TR_POP() do { cur = TR_NONE; \
         if (!ANYHIT) { \
-            while (sp > depth) { --sp; const uint2 e_ = spill[sp - depth]; if (__uint_as_float(e_.y) < tMax) { cur = (int)e_.x; break; } } \
-            if (cur == TR_NONE) while (sp > 0) { --sp; const uint2 e_ = ldsStack[sp * TR_BLOCK + tid]; if (__uint_as_float(e_.y) < tMax) { cur = (int)e_.x; break; } } \
+            while (sp > depth && sp > spBase) { --sp; const uint2 e_ = spill[sp - depth]; if (__uint_as_float(e_.y) < tMax) { cur = (int)e_.x; break; } } \
+            if (cur == TR_NONE) while (sp > spBase && sp <= depth) { --sp; const uint2 e_ = ldsStack[sp * TR_BLOCK + tid]; if (__uint_as_float(e_.y) < tMax) { cur = (int)e_.x; break; } } \
         } else { while (vd > 0) { --vd; ++nodeVisits; if ((vmask >> vd) & 1ull) { vmask &= ~(1ull << vd); continue; } \
                                  --sp; if (sp >= depth) cur = (int)spill[sp - depth].x; else cur = (int)ldsStack[sp * TR_BLOCK + tid].x; break; } } } while (0)
     // A negative reference is a leaf: unpack (first prim, count) into the lane's triangle state.
 #define TR_SETTLE() do { if (cur < 0 && cur != TR_NONE) { const int code_ = ~cur; triNext = code_ >> leafBits; triLeft = (code_ & leafMask) + 1; cur = TR_NONE; } } while (0)
 
     for (;;) {
+        // ---- a lane that has finished an instance's BVH goes back to its world ray (primitive.cpp:83-88)
+        if (XPRIM && inInst >= 0 && cur == TR_NONE && triLeft == 0) {
+            if (!ANYHIT && instHit) wtMax = tMax;  // r.tMax = ray.tMax
+            ox = wox; oy = woy; oz = woz; ix = wix; iy = wiy; iz = wiz; tr = wtr; tMax = wtMax;
+            nx = ix < 0; ny = iy < 0; nz = iz < 0;
+            if (ANYHIT) { vd = wvd; vmask = wvmask; }
+            triNext = wTriNext; triLeft = wTriLeft; inInst = -1; spBase = 0;
+            if (triLeft == 0) { TR_POP(); TR_SETTLE(); }
+        }
         // ---- retire finished rays, refill idle lanes from this wave's segment
         const bool idle = cur == TR_NONE && triLeft == 0;
         if (idle && ray >= 0) {
             if (ANYHIT) occluded[ray] = hitPrim >= 0 ? 1 : 0;
             else {
                 hits[ray] = make_float4(__int_as_float(hitPrim), hb0, hb1, hb2);
+                if (XPRIM && sc.hitInst) sc.hitInst[ray] = hitInstCur;
                 if (tOut) tOut[ray] = tMax;
             }
             ray = -1;
@@ -174,6 +194,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
                     ix = 1 / d4.x; iy = 1 / d4.y; iz = 1 / d4.z;   // bvh.cpp:666
                     nx = ix < 0; ny = iy < 0; nz = iz < 0;   // bvh.cpp:667
                     hitPrim = -1; hb0 = hb1 = hb2 = 0; nAccepted = 0;
+                    inInst = -1; hitInstCur = -1; spBase = 0;
                     sp = 0; vd = 0; vmask = 0;
                     if (sc.nNodes > 0) {
                         ++nodeVisits;  // nodes[0]
@@ -200,28 +221,71 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
                 const int prim = triNext;
                 const float4 a = sc.tris[3 * prim], b = sc.tris[3 * prim + 1], c = sc.tris[3 * prim + 2];
                 ++triTests; ++triNext; --triLeft;
-                float t, b0, b1, b2;
-                bool hit;
-                if (SPHERES && (__float_as_uint(a.w) & PG_PRIM_SPHERE)) {
-                    // Sphere::Intersect[P] (sphere.cpp:48-106): not a triangle test for the reference's counter; the ray's
-                    // direction is not kept in registers (only its reciprocal and the triangle shear), so it is re-read
+                const uint32_t pflags = __float_as_uint(a.w);
+                if (XPRIM && (pflags & PG_PRIM_INSTANCE)) {
+                    // TransformedPrimitive::Intersect[P]: carry the ray into the instance's space (Transform::operator()(Ray),
+                    // transform.h:249-262) and start on its BVH; not a triangle test for the reference's counter
                     --triTests;
                     const bool fromQ1 = q1.regionCap > 0 && ray >= hitOffset1;
                     const float4 d4 = fromQ1 ? q1.d[ray - hitOffset1] : q0.d[ray];
-                    hit = sphere_test(sc.spheres[__float_as_int(a.x)], mk(ox, oy, oz), mk(d4.x, d4.y, d4.z), tMax, t);
-                    b0 = t; b1 = 0; b2 = 0;  // the hit record of a sphere carries tHit
-                } else
-                    hit = tri_test_pre(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), mk(ox, oy, oz), tr, tMax, t, b0, b1, b2) &&
-                          !(__float_as_uint(a.w) & PG_TRI_BOGUS);
-                if (hit) {
-                    hitPrim = prim;
-                    if (ANYHIT) { triLeft = 0; sp = 0; vd = 0; }  // bvh.cpp:717: return true
-                    else {
-                        tMax = t; hb0 = b0; hb1 = b1; hb2 = b2;  // primitive.cpp:123: r.tMax = tHit
-                        if (++nAccepted == TR_MAX_ACCEPTED) atomicOr(cullGuard, 1);
+                    const int idx = __float_as_int(a.x);
+                    const PgInstance &in = sc.instances[idx];
+                    const DObject &ob = sc.objects[in.object];
+                    wox = ox; woy = oy; woz = oz; wix = ix; wiy = iy; wiz = iz; wtr = tr; wtMax = tMax;
+                    wTriNext = triNext; wTriLeft = triLeft;
+                    if (ANYHIT) { wvd = vd; wvmask = vmask; vd = 0; vmask = 0; }
+                    V3 oErr;
+                    V3 o = m4_point_err(in.w2i, mk(ox, oy, oz), oErr);
+                    const V3 dd = m4_vec(in.w2i, mk(d4.x, d4.y, d4.z));
+                    const float lengthSquared = lensq(dd);
+                    if (lengthSquared > 0) {
+                        const float dt = dot(vabs(dd), oErr) / lengthSquared;
+                        o = o + dd * dt;
+                        tMax -= dt;
                     }
+                    ox = o.x; oy = o.y; oz = o.z;
+                    tr = tri_ray_setup(dd);
+                    ix = 1 / dd.x; iy = 1 / dd.y; iz = 1 / dd.z;
+                    nx = ix < 0; ny = iy < 0; nz = iz < 0;
+                    inInst = idx; spBase = sp; instHit = false;
+                    triLeft = 0; cur = TR_NONE;
+                    if (ob.nNodes == 0) { triNext = ob.firstPrim; triLeft = 1; }  // a lone primitive, no accelerator (api.cpp:1567)
+                    else {
+                        ++nodeVisits;  // the instance BVH's nodes[0]
+                        float t0;
+                        if (slab_interval(ob.box[0], ob.box[3], ob.box[1], ob.box[4], ob.box[2], ob.box[5], ox, oy, oz, ix, iy, iz, nx, ny, nz, t0) &&
+                            t0 < tMax) {
+                            cur = ob.rootRef;
+                            TR_SETTLE();
+                        }
+                    }
+                } else {
+                    float t, b0, b1, b2;
+                    bool hit;
+                    if (XPRIM && (pflags & PG_PRIM_SPHERE)) {
+                        // Sphere::Intersect[P] (sphere.cpp:48-106): not a triangle test for the reference's counter; the ray's
+                        // direction is not kept in registers (only its reciprocal and the triangle shear), so it is re-read
+                        --triTests;
+                        const bool fromQ1 = q1.regionCap > 0 && ray >= hitOffset1;
+                        const float4 d4 = fromQ1 ? q1.d[ray - hitOffset1] : q0.d[ray];
+                        V3 dd = mk(d4.x, d4.y, d4.z);
+                        if (inInst >= 0) dd = m4_vec(sc.instances[inInst].w2i, dd);
+                        hit = sphere_test(sc.spheres[__float_as_int(a.x)], mk(ox, oy, oz), dd, tMax, t);
+                        b0 = t; b1 = 0; b2 = 0;  // the hit record of a sphere carries tHit
+                    } else
+                        hit = tri_test_pre(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), mk(ox, oy, oz), tr, tMax, t, b0, b1, b2) &&
+                              !(pflags & PG_TRI_BOGUS);
+                    if (hit) {
+                        hitPrim = prim;
+                        if (ANYHIT) { triLeft = 0; sp = 0; vd = 0; inInst = -1; }  // bvh.cpp:717: return true
+                        else {
+                            tMax = t; hb0 = b0; hb1 = b1; hb2 = b2;  // primitive.cpp:123: r.tMax = tHit
+                            if (XPRIM) { hitInstCur = inInst; instHit = true; }
+                            if (++nAccepted == TR_MAX_ACCEPTED) atomicOr(cullGuard, 1);
+                        }
+                    }
+                    if (triLeft == 0 && !(ANYHIT && hitPrim >= 0)) { TR_POP(); TR_SETTLE(); }
                 }
-                if (triLeft == 0 && !(ANYHIT && hitPrim >= 0)) { TR_POP(); TR_SETTLE(); }
             }
         } else if (cur >= 0) {
             const float4 *rec = sc.wnodes + 4 * (size_t)cur;
@@ -280,8 +344,8 @@ static void launch_trace(const DScene &sc, RayQueue q0, RayQueue q1, float4 *hit
     nblk = ((nblk + 7) / 8) * 8;
     size_t lds = sizeof(uint2) * (size_t)c.depth * TR_BLOCK;
     (void)hipMemsetAsync(cursors, 0, 2 * PG_REGIONS * PG_COUNT_STRIDE * sizeof(int), s);
-    // scenes without Shape "sphere" run the triangle-only instantiation
-    if (sc.nSpheres > 0)
+    // scenes without spheres and object instances run the triangle-only instantiation
+    if (sc.nSpheres > 0 || sc.nInstances > 0)
         hipLaunchKernelGGL((k_trace<ANYHIT, true>), dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q0, q1, hits, hitOffset1, tOut, occluded, cn, cursors,
                            c.depth, c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard);
     else

@@ -73,6 +73,8 @@ struct RenderOptions {
     std::string CameraName = "perspective"; ParamSet CameraParams;
     TransformSet CameraToWorld;
     std::vector<GeometricPrimitive> primitives;
+    std::map<std::string, std::shared_ptr<ObjectDefinition>> instances;  // api.cpp:129
+    std::shared_ptr<ObjectDefinition> currentInstance;
     std::vector<PgLight> lights;           // prim index filled at flatten time
     std::vector<size_t> lightPrimSerial;   // serial number of the emitting primitive
     std::vector<PgMaterial> materials;
@@ -759,26 +761,55 @@ void pbrtShape(const std::string &name, const ParamSet &params) {  // api.cpp:13
         if (sphere) prim.sphere = sphere;
         else { prim.shape.mesh = mesh; prim.shape.triIndex = i; }
         prim.material = mtl;
-        if (firstLight >= 0) {
+        if (firstLight >= 0 && !renderOptions->currentInstance) {
             PgLight l = lightProto;
             l.area = sphere ? sphere->Area() : prim.shape.Area();
             l.prim = -1;
             prim.areaLight = (int)renderOptions->lights.size();
             renderOptions->lights.push_back(l);
         }
-        renderOptions->primitives.push_back(prim);
+        // api.cpp:1405-1418: to the scene, or to the instance definition being collected
+        if (renderOptions->currentInstance) renderOptions->currentInstance->prims.push_back(prim);
+        else renderOptions->primitives.push_back(prim);
     }
+    if (firstLight >= 0 && renderOptions->currentInstance)
+        Warning("Area lights not supported with object instancing");  // api.cpp:1407-1408 (here the shapes are added without emission)
 }
 void pbrtReverseOrientation() { VERIFY_WORLD("ReverseOrientation"); graphicsState.reverseOrientation = !graphicsState.reverseOrientation; }
-void pbrtObjectBegin(const std::string &name) {
+void pbrtObjectBegin(const std::string &name) {  // api.cpp:1509-1519
     VERIFY_WORLD("ObjectBegin");
     pbrtAttributeBegin();
-    Error("ObjectBegin \"%s\": object instancing is outside this build's scope; its shapes are added to the scene directly.", name.c_str());
+    if (renderOptions->currentInstance) Error("ObjectBegin called inside of instance definition");
+    renderOptions->instances[name] = std::make_shared<ObjectDefinition>();
+    renderOptions->currentInstance = renderOptions->instances[name];
 }
-void pbrtObjectEnd() { VERIFY_WORLD("ObjectEnd"); pbrtAttributeEnd(); }
-void pbrtObjectInstance(const std::string &name) {
+void pbrtObjectEnd() {  // api.cpp:1523-1532
+    VERIFY_WORLD("ObjectEnd");
+    if (!renderOptions->currentInstance) Error("ObjectEnd called outside of instance definition");
+    renderOptions->currentInstance = nullptr;
+    pbrtAttributeEnd();
+}
+void pbrtObjectInstance(const std::string &name) {  // api.cpp:1546-1588
     VERIFY_WORLD("ObjectInstance");
-    Error("ObjectInstance \"%s\": object instancing is outside this build's scope; ignoring.", name.c_str());
+    if (renderOptions->currentInstance) { Error("ObjectInstance can't be called inside instance definition"); return; }
+    auto it = renderOptions->instances.find(name);
+    if (it == renderOptions->instances.end()) { Error("Unable to find instance named \"%s\"", name.c_str()); return; }
+    std::shared_ptr<ObjectDefinition> obj = it->second;
+    if (obj->prims.empty() && !obj->accel) return;
+    if (obj->prims.size() > 1) {  // the first use builds the instance's own accelerator over its primitives
+        RenderOptions &ro = *renderOptions;
+        if (ro.AcceleratorName != "bvh")
+            Warning("Accelerator \"%s\" is outside this build's closed set; using \"bvh\".", ro.AcceleratorName.c_str());
+        obj->accel = CreateBVHAccelerator(std::move(obj->prims), ro.AcceleratorName == "bvh" ? ro.AcceleratorParams : ParamSet());
+        obj->prims.clear();
+    }
+    if (curTransform.IsAnimated())
+        Warning("Animated transformations are not supported by this build; using the start transform for instance \"%s\".", name.c_str());
+    GeometricPrimitive prim;
+    prim.object = obj;
+    prim.InstanceToWorld = curTransform[0];
+    prim.WorldToInstance = Inverse(curTransform[0]);
+    renderOptions->primitives.push_back(prim);
 }
 
 // RenderOptions::MakeIntegrator / MakeScene / MakeCamera (api.cpp:1651-1727)

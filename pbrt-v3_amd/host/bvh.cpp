@@ -34,6 +34,25 @@ Bounds3f Sphere::WorldBound() const {  // Transform::operator()(Bounds3f), trans
     return ret;
 }
 
+static Bounds3f TransformBounds(const Transform &t, const Bounds3f &b) {  // Transform::operator()(Bounds3f), transform.cpp:237-249
+    Bounds3f ret;
+    for (int corner = 0; corner < 8; ++corner) {
+        Point3f c((corner & 1) ? b.pMax.x : b.pMin.x, (corner & 2) ? b.pMax.y : b.pMin.y, (corner & 4) ? b.pMax.z : b.pMin.z);
+        Point3f w = t.Pt(c);
+        ret = corner == 0 ? Bounds3f(w) : Union(ret, w);
+    }
+    return ret;
+}
+Bounds3f ObjectDefinition::WorldBound() const {  // the BVHAccel's root bounds, or the lone primitive's
+    if (accel) return accel->WorldBound();
+    return prims.empty() ? Bounds3f() : prims[0].WorldBound();
+}
+Bounds3f GeometricPrimitive::WorldBound() const {
+    // TransformedPrimitive::WorldBound (primitive.h:107-109) -> AnimatedTransform::MotionBounds, not animated (transform.cpp:1190-1192)
+    if (object) return TransformBounds(InstanceToWorld, object->WorldBound());
+    return sphere ? sphere->WorldBound() : shape.WorldBound();
+}
+
 struct BVHAccel::PrimInfo {  // BVHPrimitiveInfo, bvh.cpp:49-59
     PrimInfo() {}
     PrimInfo(size_t primitiveNumber, const Bounds3f &bounds)

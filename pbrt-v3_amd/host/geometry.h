@@ -106,7 +106,10 @@ struct Matrix4x4 {  // transform.h:58-110
         m[2][0] = t20; m[2][1] = t21; m[2][2] = t22; m[2][3] = t23;
         m[3][0] = t30; m[3][1] = t31; m[3][2] = t32; m[3][3] = t33;
     }
-    bool operator==(const Matrix4x4 &o) const { return std::memcmp(m, o.m, sizeof(m)) == 0; }
+    bool operator==(const Matrix4x4 &o) const {  // transform.h:77-82: float ==, so -0 equals 0
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) if (m[i][j] != o.m[i][j]) return false;
+        return true;
+    }
     static Matrix4x4 Mul(const Matrix4x4 &m1, const Matrix4x4 &m2) {  // transform.h:86-93
         Matrix4x4 r;
         for (int i = 0; i < 4; ++i)

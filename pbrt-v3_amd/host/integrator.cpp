@@ -171,8 +171,32 @@ GpuPathIntegrator *CreatePathIntegrator(const ParamSet &params, std::shared_ptr<
 
 void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     const BVHAccel &bvh = *scene.aggregate;
+    // primitives: the top-level BVH's (in its order), then every object definition's in first-use order
+    std::vector<const GeometricPrimitive *> all;
+    for (const auto &prim : bvh.primitives) all.push_back(&prim);
     flat->nodes = bvh.nodes;
-    size_t nTris = bvh.primitives.size();
+    std::map<const ObjectDefinition *, int> objectIndex;
+    for (const auto &prim : bvh.primitives) {
+        if (!prim.object) continue;
+        const ObjectDefinition *od = prim.object.get();
+        if (!objectIndex.count(od)) {
+            objectIndex[od] = (int)flat->objects.size();
+            PgObject o;
+            o.first_prim = (int)all.size();
+            o.first_node = (int)flat->nodes.size();
+            if (od->accel) {
+                o.n_nodes = (int)od->accel->nodes.size();
+                o.n_prims = (int)od->accel->primitives.size();
+                flat->nodes.insert(flat->nodes.end(), od->accel->nodes.begin(), od->accel->nodes.end());
+                for (const auto &p2 : od->accel->primitives) all.push_back(&p2);
+            } else {
+                o.n_nodes = 0; o.n_prims = (int)od->prims.size();
+                for (const auto &p2 : od->prims) all.push_back(&p2);
+            }
+            flat->objects.push_back(o);
+        }
+    }
+    const size_t nTop = bvh.primitives.size(), nTris = all.size();
     flat->indices.resize(3 * nTris);
     flat->triFlags.resize(nTris);
     flat->triMaterial.resize(nTris);
@@ -181,7 +205,9 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     std::map<const TriangleMesh *, int> meshBase;
     bool anyN = false, anyUV = false, anyS = false;
     std::map<const Sphere *, int> sphereIndex;
-    for (const auto &prim : bvh.primitives) {
+    for (const GeometricPrimitive *pp : all) {
+        const GeometricPrimitive &prim = *pp;
+        if (prim.object) continue;
         if (prim.sphere) {
             const Sphere *sp = prim.sphere.get();
             if (sphereIndex.count(sp)) continue;
@@ -214,9 +240,22 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
         for (size_t i = 0; i < m->uv.size(); ++i) flat->UV[2 * b + i] = m->uv[i];
     }
     for (size_t k = 0; k < nTris; ++k) {
-        const GeometricPrimitive &prim = bvh.primitives[k];
-        flat->triMaterial[k] = prim.material;
+        const GeometricPrimitive &prim = *all[k];
+        flat->triMaterial[k] = prim.material < 0 ? 0 : prim.material;
         flat->triLight[k] = prim.areaLight;
+        if (prim.object) {  // TransformedPrimitive: one PgInstance per use
+            PgInstance inst;
+            memset(&inst, 0, sizeof(inst));
+            const Matrix4x4 &m = prim.InstanceToWorld.GetMatrix(), &mi = prim.WorldToInstance.GetMatrix();
+            for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { inst.i2w[4 * r + c] = m.m[r][c]; inst.w2i[4 * r + c] = mi.m[r][c]; }
+            inst.object = objectIndex[prim.object.get()];
+            inst.identity = prim.InstanceToWorld.IsIdentity() ? 1 : 0;
+            flat->indices[3 * k] = (int)flat->instances.size();
+            flat->indices[3 * k + 1] = flat->indices[3 * k + 2] = 0;
+            flat->triFlags[k] = PG_PRIM_INSTANCE;
+            flat->instances.push_back(inst);
+            continue;
+        }
         if (prim.sphere) {
             flat->indices[3 * k] = sphereIndex[prim.sphere.get()];
             flat->indices[3 * k + 1] = flat->indices[3 * k + 2] = 0;
@@ -254,8 +293,11 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     PgSceneDesc &d = flat->desc;
     memset(&d, 0, sizeof(d));
     d.abi_version = PG_ABI_VERSION;
-    d.n_nodes = (int)flat->nodes.size(); d.nodes = flat->nodes.data();
-    d.n_tris = (int)nTris; d.indices = flat->indices.data(); d.tri_flags = flat->triFlags.data();
+    d.n_nodes = (int)bvh.nodes.size(); d.nodes = flat->nodes.data();
+    d.n_nodes_all = (int)flat->nodes.size(); d.n_prims_all = (int)nTris;
+    d.n_objects = (int)flat->objects.size(); d.objects = flat->objects.data();
+    d.n_instances = (int)flat->instances.size(); d.instances = flat->instances.data();
+    d.n_tris = (int)nTop; d.indices = flat->indices.data(); d.tri_flags = flat->triFlags.data();
     d.tri_material = flat->triMaterial.data(); d.tri_light = flat->triLight.data();
     d.n_verts = (int)nVerts; d.P = flat->P.data();
     d.N = anyN ? flat->N.data() : nullptr; d.UV = anyUV ? flat->UV.data() : nullptr; d.S = anyS ? flat->S.data() : nullptr;

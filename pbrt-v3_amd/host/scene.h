@@ -41,13 +41,25 @@ struct Sphere {
     Bounds3f WorldBound() const;  // shape.cpp:49 over sphere.cpp:43-46
     Float Area() const { return phiMax * radius * (zMax - zMin); }  // sphere.cpp:203
 };
-// core/primitive.h:68-89: shape + material + area light (indices into tables).  The shape is a Triangle unless `sphere` is set.
+class BVHAccel;
+struct GeometricPrimitive;
+// What ObjectBegin ... ObjectEnd collects (api.cpp:1509-1544); the first ObjectInstance turns more than one primitive
+// into a BVHAccel (api.cpp:1567-1575), which every later instance shares.
+struct ObjectDefinition {
+    std::vector<GeometricPrimitive> prims;  // before the accelerator is built; afterwards they live in accel->primitives
+    std::shared_ptr<BVHAccel> accel;        // null while unbuilt, and for a single primitive
+    Bounds3f WorldBound() const;
+};
+// core/primitive.h:68-89: shape + material + area light (indices into tables).  The shape is a Triangle unless `sphere` is
+// set; with `object` set the primitive is a TransformedPrimitive (primitive.h:92-117) of that object definition.
 struct GeometricPrimitive {
     Triangle shape;
     std::shared_ptr<Sphere> sphere;
+    std::shared_ptr<ObjectDefinition> object;
+    Transform InstanceToWorld, WorldToInstance;
     int material = -1;
     int areaLight = -1;
-    Bounds3f WorldBound() const { return sphere ? sphere->WorldBound() : shape.WorldBound(); }
+    Bounds3f WorldBound() const;
 };
 
 // accelerators/bvh.{h,cpp}: SAH / Middle / EqualCounts build + flattenBVHTree.
@@ -143,6 +155,8 @@ struct FlatScene {
     std::vector<PgLight> lights;
     std::vector<PgSphere> spheres;
     std::vector<PgBxDF> bxdfs;
+    std::vector<PgObject> objects;
+    std::vector<PgInstance> instances;
 };
 
 // core/integrator.h:53-58.

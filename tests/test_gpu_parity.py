@@ -150,6 +150,33 @@ def test_intersect_bit_exact(gpu, oracle, n):
     gs.close()
 
 
+@pytest.mark.parametrize("name", ["instance_boxes", "instance_accel"])
+def test_instance_rays_bit_exact(gpu, oracle, name):
+    """Object instances (TransformedPrimitive over an object definition's own BVH, or over a lone primitive): the ray is
+    carried into instance space, traverses the second-level BVH and comes back with r.tMax = the instance-space tHit --
+    primitive, t, barycentrics and the node-visit / triangle-test counters equal the oracle's for every ray."""
+    scene = gpu.HostScene(os.path.join(GOLD, name + ".pbrt"))
+    assert scene.desc.n_instances >= 7 and scene.desc.n_objects == 3 and scene.desc.n_prims_all > scene.desc.n_tris
+    gs = gpu.GpuScene(scene.desc)
+    n = 20000
+    o, d = random_rays(scene, n, 123)
+    tmax = np.full(n, np.inf, np.float32)
+    tmax[::5] = 300.0
+    gs.counters_reset()
+    prim, t, bary = gs.intersect(o, d, tmax)
+    oprim, ot, obary, ocn = oracle.intersect(scene.desc, o, d, tmax)
+    assert (prim >= scene.desc.n_tris).sum() > 500  # hits on primitives of object definitions
+    assert np.array_equal(prim, oprim) and np.array_equal(t, ot) and np.array_equal(bary, obary)
+    cn = gs.counters()
+    assert cn["closest_node_visits"] == ocn["node_visits"] and cn["closest_tri_tests"] == ocn["tri_tests"]
+    occ = gs.intersect_p(o, d, tmax)
+    oocc, ocn2 = oracle.intersect_p(scene.desc, o, d, tmax)
+    assert np.array_equal(occ, oocc)
+    cn = gs.counters()
+    assert cn["shadow_node_visits"] == ocn2["node_visits"] and cn["shadow_tri_tests"] == ocn2["tri_tests"]
+    gs.close()
+
+
 @pytest.mark.parametrize("name", ["sphere_light", "sphere_partial", "sphere_enclosing"])
 def test_sphere_rays_bit_exact(gpu, oracle, name):
     """Shape "sphere" in the BVH next to triangles: Sphere::Intersect / IntersectP (error-bounded quadratic, partial-sphere
