@@ -62,9 +62,66 @@ def random_scene(seed, res=16, spp=4):
     return "\n".join(out) + "\n"
 
 
+def random_scene_ext(seed, res=16, spp=4):
+    """The wider closed set on top of random_scene: the BxDF-list materials, spheres (geometry, partial, as emitters), the
+    infinite light and object instances (of soups, of single spheres, mirrored / non-uniformly scaled)."""
+    rng = np.random.default_rng(7000 + seed)
+    f = lambda a: " ".join(f"{x:.9g}" for x in np.asarray(a, np.float32).ravel())
+    base = random_scene(seed, res, spp)
+    head, world = base.split("WorldBegin\n")
+    world = world.replace("WorldEnd\n", "")
+    mats = ['Material "uber" "rgb Kd" [ %s ] "rgb Kr" [ %s ] "rgb Kt" [ %s ] "rgb opacity" [ %s ] "float uroughness" [ %.4g ] "float vroughness" [ %.4g ]'
+            % (f(rng.random(3)), f(rng.random(3) * 0.4), f(rng.random(3) * 0.5), f(0.5 + 0.5 * rng.random(3)), 0.01 + 0.3 * rng.random(), 0.01 + 0.5 * rng.random()),
+            'Material "metal" "float uroughness" [ %.4g ] "float vroughness" [ %.4g ]' % (0.005 + 0.2 * rng.random(), 0.005 + 0.4 * rng.random()),
+            'Material "metal" "rgb eta" [ %s ] "rgb k" [ %s ] "float roughness" [ %.4g ] "bool remaproughness" "false"' % (f(0.2 + 2 * rng.random(3)), f(1 + 3 * rng.random(3)), 0.05 + 0.3 * rng.random()),
+            'Material "substrate" "rgb Kd" [ %s ] "rgb Ks" [ %s ] "float uroughness" [ %.4g ]' % (f(rng.random(3)), f(rng.random(3) * 0.5), 0.01 + 0.4 * rng.random()),
+            'Material "translucent" "rgb Kd" [ %s ] "rgb reflect" [ %s ] "rgb transmit" [ %s ]' % (f(rng.random(3)), f(rng.random(3)), f(rng.random(3))),
+            'Material "glass" "float uroughness" [ %.4g ] "float vroughness" [ %.4g ] "float index" [ %.4g ]' % (0.02 + 0.3 * rng.random(), 0.02 + 0.3 * rng.random(), 1.2 + 0.6 * rng.random()),
+            'NamedMaterial "fzmix"', 'NamedMaterial "fzmix2"']
+    out = [head, "WorldBegin",
+           'MakeNamedMaterial "fza" "string type" "plastic" "rgb Kd" [ %s ]' % f(rng.random(3)),
+           'MakeNamedMaterial "fzb" "string type" "metal"', 'MakeNamedMaterial "fzc" "string type" "glass"',
+           'MakeNamedMaterial "fzmix" "string type" "mix" "string namedmaterial1" "fza" "string namedmaterial2" "fzb" "rgb amount" [ %s ]' % f(rng.random(3)),
+           'MakeNamedMaterial "fzmix2" "string type" "mix" "string namedmaterial1" "fzmix" "string namedmaterial2" "fzc"']
+    if seed % 4 == 0:
+        out.append('AttributeBegin\n Rotate %.4g 1 0.3 0\n LightSource "infinite" "rgb L" [ %s ]\nAttributeEnd' % (360 * rng.random(), f(0.2 + 0.5 * rng.random(3))))
+    out.append(world)
+    # spheres: plain, partial under a non-uniform transform, and an emitter
+    for k in range(1 + seed % 3):
+        out.append(mats[int(rng.integers(len(mats)))])
+        part = ' "float zmin" [ -0.3 ] "float zmax" [ 0.5 ] "float phimax" [ 240 ]' if (seed + k) % 3 == 0 else ""
+        out.append('AttributeBegin\n Translate %s\n Rotate %.4g 1 1 0\n Scale 1 %.4g %.4g\n Shape "sphere" "float radius" [ %.4g ]%s\nAttributeEnd'
+                   % (f(rng.normal(size=3) * 1.5), 90 * rng.random(), 0.6 + rng.random(), 0.6 + rng.random(), 0.3 + 0.7 * rng.random(), part))
+    if seed % 2 == 0:
+        out.append('AttributeBegin\n Translate %s\n AreaLightSource "diffuse" "rgb L" [ %s ]\n Shape "sphere" "float radius" [ %.4g ]\nAttributeEnd'
+                   % (f(rng.normal(size=3) + [0, 2.5, 0]), f(4 + 8 * rng.random(3)), 0.05 + 0.4 * rng.random()))
+    # object definitions: a soup with its own BVH, and a lone sphere; instanced a few times
+    nt = int(rng.integers(2, 30))
+    P = rng.normal(size=(nt, 3, 3)) * 0.4
+    out.append('ObjectBegin "soup"\n %s\n Shape "trianglemesh" "integer indices" [ %s ] "point P" [ %s ]\n %s\n Translate 0.5 0 0\n Shape "sphere" "float radius" [ 0.3 ]\nObjectEnd'
+               % (mats[int(rng.integers(len(mats)))], " ".join(map(str, range(3 * nt))), f(P), mats[int(rng.integers(len(mats)))]))
+    out.append('ObjectBegin "ball"\n %s\n Shape "sphere" "float radius" [ 0.4 ]\nObjectEnd' % mats[int(rng.integers(len(mats)))])
+    for k in range(2 + seed % 3):
+        sx = -1 if (seed + k) % 2 else 1
+        out.append('AttributeBegin\n Translate %s\n Rotate %.4g 0 1 1\n Scale %.4g %.4g %.4g\n ObjectInstance "%s"\nAttributeEnd'
+                   % (f(rng.normal(size=3) * 2), 360 * rng.random(), sx * (0.5 + rng.random()), 0.5 + rng.random(), 0.5 + rng.random(), "soup" if k % 2 == 0 else "ball"))
+    if seed % 5 == 0: out.append('ObjectInstance "soup"')  # identity transform
+    out.append("WorldEnd")
+    return "\n".join(out) + "\n"
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_random_scene_film_matches_oracle(gpu, oracle, seed):
-    scene = gpu.HostScene(text=random_scene(seed))
+    check_scene(gpu, oracle, random_scene(seed), seed)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_extended_scene_film_matches_oracle(gpu, oracle, seed):
+    check_scene(gpu, oracle, random_scene_ext(seed), seed)
+
+
+def check_scene(gpu, oracle, text, seed):
+    scene = gpu.HostScene(text=text)
     gs = gpu.GpuScene(scene.desc)
     rd = scene.render_desc()
     film, strays = gs.render(rd)
@@ -77,6 +134,11 @@ def test_random_scene_film_matches_oracle(gpu, oracle, seed):
     assert cn["camera_rays"] == ocn["camera_rays"]
     for k in ("closest_rays", "shadow_rays"):  # a last-ulp sin/cos difference may add or remove a handful of rays
         assert abs(cn[k] - ocn[k]) <= max(4, 2e-3 * ocn[k]), (k, cn[k], ocn[k])
+    # against the oracle built with correctly rounded libm (= the device's libm behaviour): bit for bit, counters included
+    cfilm, cstrays, ccn = oracle.render(scene.desc, rd, cr_libm=True)
+    assert np.array_equal(film["rgb"], cfilm["rgb"]), f"{(film['rgb'] != cfilm['rgb']).any(axis=1).sum()} pixels differ from the correctly-rounded oracle"
+    for k in ("closest_rays", "shadow_rays", "tri_tests", "node_visits"):
+        assert cn[k] == ccn[k], (k, cn[k], ccn[k])
     # rays through the same soup: bit-exact, including the reference's counters
     rng = np.random.default_rng(1000 + seed)
     n = 4096
