@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 8
+#define PG_ABI_VERSION 9
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -160,11 +160,19 @@ typedef enum PgLightStrategy {
 /* A Sphere shape (shapes/sphere.h:46-79), kept in object space as the reference keeps it.  A primitive k with
  * PG_PRIM_SPHERE set in tri_flags[k] is spheres[indices[3*k]]; its tri_material / tri_light entries mean what they mean
  * for a triangle, and an area light whose `prim` is such a primitive samples the sphere (sphere.cpp:205-304). */
-typedef struct PgSphere {
+typedef enum PgQuadricShape {
+    PG_SHAPE_SPHERE = 0,        /* shapes/sphere.cpp   */
+    PG_SHAPE_CYLINDER = 1,      /* shapes/cylinder.cpp: radius, z_min, z_max, phi_max */
+    PG_SHAPE_DISK = 2           /* shapes/disk.cpp: height, radius, inner_radius, phi_max */
+} PgQuadricShape;
+typedef struct PgSphere {       /* a quadric: the record began as the sphere's and kept its name */
     float o2w[16], w2o[16];     /* ObjectToWorld / WorldToObject, row-major (its m and mInv, transform.h:112-205) */
     float radius, z_min, z_max, theta_min, theta_max, phi_max; /* as the constructor clamps them, sphere.h:50-60 */
     int32_t reverse_orientation;/* Shape::reverseOrientation               */
     int32_t swaps_handedness;   /* Shape::transformSwapsHandedness         */
+    int32_t shape;              /* PgQuadricShape */
+    float height, inner_radius; /* disk */
+    float area;                 /* Shape::Area() */
 } PgSphere;
 
 /* Object instancing (api.cpp:1509-1588).  An object definition is a run of primitives in the primitive arrays after the

@@ -45,6 +45,13 @@ SPHERES_PARTIAL = ('AttributeBegin\n  Translate 400 120 150\n  Rotate 40 1 0.2 0
                    'AttributeBegin\n  Translate 150 420 300\n  Rotate -70 1 0 0\n  ReverseOrientation\n  AreaLightSource "diffuse" "rgb L" [ 9 9 12 ] "bool twosided" "true"\n'
                    '  Shape "sphere" "float radius" [ 50 ] "float zmin" [ -20 ] "float phimax" [ 300 ]\nAttributeEnd\n'
                    'AttributeBegin\n  Translate 500 500 500\n  AreaLightSource "area" "rgb L" [ 4000 3000 2000 ]\n  Shape "sphere" "float radius" [ 2 ]\nAttributeEnd\n')
+QUADRICS = ('AttributeBegin\n  Translate 420 0 130\n  Rotate -90 1 0 0\n  Material "plastic" "rgb Kd" [ 0.2 0.3 0.7 ]\n  Shape "cylinder" "float radius" [ 50 ] "float zmin" [ 0 ] "float zmax" [ 160 ] "float phimax" [ 270 ]\nAttributeEnd\n'
+            'AttributeBegin\n  Translate 130 300 330\n  Rotate 35 1 0.4 0\n  Scale 1 0.6 1.3\n  ReverseOrientation\n  Material "mirror"\n  Shape "cylinder" "float radius" [ 40 ] "float zmin" [ 60 ] "float zmax" [ -60 ]\nAttributeEnd\n'
+            'AttributeBegin\n  Translate 300 120 100\n  Rotate 60 1 0 1\n  Material "glass"\n  Shape "disk" "float radius" [ 60 ] "float height" [ 15 ]\nAttributeEnd\n'
+            'AttributeBegin\n  Translate 100 1 150\n  Rotate -90 1 0 0\n  Material "matte" "rgb Kd" [ 0.8 0.7 0.1 ]\n  Shape "disk" "float radius" [ 90 ] "float innerradius" [ 40 ] "float phimax" [ 200 ]\nAttributeEnd\n')
+QUADRIC_LIGHTS = ('AttributeBegin\n  Translate 100 250 300\n  Rotate 70 0 1 0.3\n  AreaLightSource "diffuse" "rgb L" [ 6 2 2 ] "bool twosided" "true"\n  Shape "cylinder" "float radius" [ 15 ] "float zmin" [ -80 ] "float zmax" [ 80 ] "float phimax" [ 180 ]\nAttributeEnd\n'
+                  'AttributeBegin\n  Translate 450 200 150\n  Rotate 110 1 0 0\n  ReverseOrientation\n  AreaLightSource "diffuse" "rgb L" [ 2 6 3 ]\n  Shape "disk" "float radius" [ 40 ]\nAttributeEnd\n'
+                  'AttributeBegin\n  Translate 300 400 400\n  Scale 1 0.5 2\n  AreaLightSource "diffuse" "rgb L" [ 3 3 8 ]\n  Shape "cylinder" "float radius" [ 20 ] "float zmin" [ -30 ] "float zmax" [ 30 ]\nAttributeEnd\n')
 MIX_MATERIALS = ('MakeNamedMaterial "m_matte" "string type" "matte" "rgb Kd" [ 0.7 0.2 0.2 ]\n'
                  'MakeNamedMaterial "m_metal" "string type" "metal" "float roughness" [ 0.05 ]\n'
                  'MakeNamedMaterial "m_plastic" "string type" "plastic" "rgb Kd" [ 0.1 0.4 0.1 ]\n'
@@ -279,6 +286,14 @@ SCENES = {
     # identity; a one-primitive object (no accelerator) holding a sphere; materials bound inside the definition
     "instance_boxes": cornell(40, 40, 8, integrator='Integrator "path" "integer maxdepth" [ 6 ]', world_edit=lambda s: with_instances(s)),
     "instance_accel": cornell(32, 32, 8, world_edit=lambda s: with_instances(s)).replace('WorldBegin', 'Accelerator "bvh" "integer maxnodeprims" [ 3 ] "string splitmethod" "middle"\nWorldBegin'),
+    # Shape "cylinder" and "disk" (cylinder.cpp, disk.cpp): as geometry (partial sweeps, annulus, non-uniform transforms,
+    # reversed orientation) and as area-light shapes (Shape::Sample / Shape::Pdf over their Sample(u))
+    "quadrics": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 6 ]', world_edit=lambda s: s.replace(
+        'Shape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ]\n  "point P" [ 343 548.7 227   343 548.7 332   213 548.7 332   213 548.7 227 ]',
+        'Translate 278 548 280\n  Rotate 90 1 0 0\n  Shape "disk" "float radius" [ 70 ] "float innerradius" [ 20 ] "float phimax" [ 300 ]')
+        .replace("# short box", QUADRICS + "# short box")),
+    "quadric_lights": cornell(24, 24, 8, integrator='Integrator "path" "integer maxdepth" [ 4 ] "string lightsamplestrategy" "power"',
+                              world_edit=lambda s: s.replace("# short box", QUADRIC_LIGHTS + "# short box")),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 

@@ -938,6 +938,33 @@ PG_DEV LightSample sphere_sample(const PgSphere &s, V3 refp, V3 refErr, V3 refn,
     return it;
 }
 
+// Cylinder::Sample(u, pdf), cylinder.cpp:208-223; Disk::Sample(u, pdf), disk.cpp:128-137
+PG_DEV LightSample quadric_sample_area(const PgSphere &s, float u0, float u1, float &pdf) {
+    LightSample it;
+    if (s.shape == PG_SHAPE_CYLINDER) {
+        const float z = plerp(u0, s.z_min, s.z_max);
+        const float phi = u1 * s.phi_max;
+        double sP, cP;
+        sincos((double)phi, &sP, &cP);
+        V3 pObj = mk(s.radius * (float)cP, s.radius * (float)sP, z);
+        it.n = normalize(m4_normal(s.w2o, mk(pObj.x, pObj.y, 0)));
+        if (s.reverse_orientation) it.n = it.n * -1.f;
+        const float hitRad = sqrtf(pObj.x * pObj.x + pObj.y * pObj.y);
+        pObj.x *= s.radius / hitRad;
+        pObj.y *= s.radius / hitRad;
+        it.p = m4_point_err2(s.o2w, pObj, vabs(mk(pObj.x, pObj.y, 0)) * pgamma(3), it.pError);
+    } else {
+        float px, py;
+        concentric_sample_disk(u0, u1, px, py);
+        const V3 pObj = mk(px * s.radius, py * s.radius, s.height);
+        it.n = normalize(m4_normal(s.w2o, mk(0, 0, 1)));
+        if (s.reverse_orientation) it.n = it.n * -1.f;
+        it.p = m4_point_err2(s.o2w, pObj, mk(0, 0, 0), it.pError);
+    }
+    pdf = 1 / s.area;
+    return it;
+}
+
 // ---- InfiniteAreaLight with constant radiance: Lmap is a 1x1 MIPMap (lights/infinite.cpp, core/mipmap.h:245-274).
 // sinf/cosf/acosf/atan2f of the reference (glibc) are matched by evaluating in double and rounding once.
 PG_DEV V3 mat3_mul(const float *m, V3 w) {  // Transform::operator()(Vector3), transform.h:233-239
@@ -1026,20 +1053,25 @@ PG_DEV Spec light_sample_li(const DScene &sc, const PgLight &light, V3 refp, V3 
         return I / d2;
     }
     Tri t = load_tri(sc, light.prim);
-    if (EXT && (t.flags & PG_PRIM_SPHERE)) ls = sphere_sample(sc.spheres[__float_as_int(t.p0.x)], refp, refErr, refn, u0, u1, pdf);
+    const bool quadric = EXT && (t.flags & PG_PRIM_SPHERE);
+    if (quadric && sc.spheres[__float_as_int(t.p0.x)].shape == PG_SHAPE_SPHERE)
+        ls = sphere_sample(sc.spheres[__float_as_int(t.p0.x)], refp, refErr, refn, u0, u1, pdf);
     else {
-        float su0 = sqrtf(u0);  // UniformSampleTriangle, sampling.cpp:154-157
-        float b0 = 1 - su0, b1 = u1 * su0;
-        float b2 = (1 - b0 - b1);
-        ls.p = t.p0 * b0 + t.p1 * b1 + t.p2 * b2;
-        ls.n = normalize(cross(t.p1 - t.p0, t.p2 - t.p0));
-        if (sc.triN && (t.flags & PG_TRI_HAS_N)) {  // triangle.cpp:593-597: orientation follows the shading normal
-            V3 ns = tri_interp(sc.triN, light.prim, b0, b1, b2);
-            if (dot(ls.n, ns) < 0.f) ls.n = -ls.n;
-        } else if (t.flags & PG_TRI_FLIP_NORMAL) ls.n = ls.n * -1.f;
-        V3 pAbsSum = vabs(t.p0 * b0) + vabs(t.p1 * b1) + vabs(t.p2 * b2);
-        ls.pError = pAbsSum * pgamma(6);
-        pdf = 1 / light.area;
+        if (quadric) ls = quadric_sample_area(sc.spheres[__float_as_int(t.p0.x)], u0, u1, pdf);
+        else {
+            float su0 = sqrtf(u0);  // UniformSampleTriangle, sampling.cpp:154-157
+            float b0 = 1 - su0, b1 = u1 * su0;
+            float b2 = (1 - b0 - b1);
+            ls.p = t.p0 * b0 + t.p1 * b1 + t.p2 * b2;
+            ls.n = normalize(cross(t.p1 - t.p0, t.p2 - t.p0));
+            if (sc.triN && (t.flags & PG_TRI_HAS_N)) {  // triangle.cpp:593-597: orientation follows the shading normal
+                V3 ns = tri_interp(sc.triN, light.prim, b0, b1, b2);
+                if (dot(ls.n, ns) < 0.f) ls.n = -ls.n;
+            } else if (t.flags & PG_TRI_FLIP_NORMAL) ls.n = ls.n * -1.f;
+            V3 pAbsSum = vabs(t.p0 * b0) + vabs(t.p1 * b1) + vabs(t.p2 * b2);
+            ls.pError = pAbsSum * pgamma(6);
+            pdf = 1 / light.area;
+        }
         V3 w = ls.p - refp;  // Shape::Sample(ref, u, pdf), shape.cpp:56-70
         if (lensq(w) == 0) pdf = 0;
         else {
@@ -1267,8 +1299,9 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                             misLightPrim = (EXT && light.type == PG_LIGHT_INFINITE) ? -1 - lightNum : light.prim; misLightArea = light.area;
                             if (EXT && light.type == PG_LIGHT_AREA) {
                                 const float4 la = sc.tris[3 * light.prim];
-                                if (__float_as_uint(la.w) & PG_PRIM_SPHERE)
-                                    misInside = sphere_ref_inside(sc.spheres[__float_as_int(la.x)], is.p, is.pError, is.n);
+                                if (__float_as_uint(la.w) & PG_PRIM_SPHERE)  // only the sphere overrides Shape::Pdf (with its cone pdf, from outside)
+                                    misInside = sc.spheres[__float_as_int(la.x)].shape != PG_SHAPE_SPHERE ||
+                                                sphere_ref_inside(sc.spheres[__float_as_int(la.x)], is.p, is.pError, is.n);
                             }
                         }
                         // pending terms of this vertex, consumed by k_resolve (pdMis and the MIS weight follow below)

@@ -142,7 +142,7 @@ PG_DEV bool sphere_clipped(const PgSphere &sp, V3 pHit, float phi) {  // sphere.
     return (sp.z_min > -sp.radius && pHit.z < sp.z_min) || (sp.z_max < sp.radius && pHit.z > sp.z_max) || phi > sp.phi_max;
 }
 // Sphere::Intersect's root search = Sphere::IntersectP (sphere.cpp:48-106, :165-200).  True: tHit is the accepted root.
-PG_DEV bool sphere_test(const PgSphere &sp, V3 ro, V3 rd, float tMax, float &tHit) {
+PG_DEV bool sphere_test_s(const PgSphere &sp, V3 ro, V3 rd, float tMax, float &tHit) {
     V3 o, d, oErr, dErr;
     sphere_object_ray(sp, ro, rd, o, d, oErr, dErr);
     const EFloat ox = ef_make(o.x, oErr.x), oy = ef_make(o.y, oErr.y), oz = ef_make(o.z, oErr.z);
@@ -172,9 +172,22 @@ PG_DEV bool sphere_test(const PgSphere &sp, V3 ro, V3 rd, float tMax, float &tHi
     return true;
 }
 
-// What the path needs of the SurfaceInteraction Sphere::Intersect builds for the root tHit of world ray (ro, rd).
+// What the path needs of the SurfaceInteraction a quadric's Intersect builds for the root tHit of world ray (ro, rd).
 struct SphereHit { V3 p, pError, wo, n, dpdu; };
-PG_DEV SphereHit sphere_interaction(const PgSphere &sp, V3 ro, V3 rd, float tHit) {
+// the tail the quadrics share: SurfaceInteraction ctor in object space (interaction.cpp:44-71), then
+// (*ObjectToWorld)(SurfaceInteraction) (transform.cpp:262-297); shading.n == n for a quadric
+PG_DEV SphereHit quadric_finish(const PgSphere &sp, V3 d, V3 pHit, V3 pError, V3 dpdu, V3 dpdv) {
+    V3 n = normalize(cross(dpdu, dpdv));
+    if (sp.reverse_orientation ^ sp.swaps_handedness) n = n * -1.f;
+    const V3 wo = normalize(-d);  // Interaction ctor, interaction.h:60
+    SphereHit h;
+    h.p = m4_point_err2(sp.o2w, pHit, pError, h.pError);
+    h.n = normalize(m4_normal(sp.w2o, n));
+    h.wo = normalize(m4_vec(sp.o2w, wo));
+    h.dpdu = m4_vec(sp.o2w, dpdu);
+    return h;
+}
+PG_DEV SphereHit sphere_interaction_s(const PgSphere &sp, V3 ro, V3 rd, float tHit) {
     V3 o, d, oErr, dErr;
     sphere_object_ray(sp, ro, rd, o, d, oErr, dErr);
     float phi;
@@ -189,14 +202,93 @@ PG_DEV SphereHit sphere_interaction(const PgSphere &sp, V3 ro, V3 rd, float tHit
     const V3 dpdu = mk(-sp.phi_max * pHit.y, sp.phi_max * pHit.x, 0);
     const V3 dpdv = mk(pHit.z * cosPhi, pHit.z * sinPhi, -sp.radius * (float)sin((double)theta)) * (sp.theta_max - sp.theta_min);
     const V3 pError = vabs(pHit) * pgamma(5);  // sphere.cpp:148
-    V3 n = normalize(cross(dpdu, dpdv));  // SurfaceInteraction ctor, interaction.cpp:49,66-70
-    if (sp.reverse_orientation ^ sp.swaps_handedness) n = n * -1.f;
-    const V3 wo = normalize(-d);  // Interaction ctor, interaction.h:60
-    SphereHit h;  // (*ObjectToWorld)(SurfaceInteraction), transform.cpp:262-297; shading.n == n for a sphere
-    h.p = m4_point_err2(sp.o2w, pHit, pError, h.pError);
-    h.n = normalize(m4_normal(sp.w2o, n));
-    h.wo = normalize(m4_vec(sp.o2w, wo));
-    h.dpdu = m4_vec(sp.o2w, dpdu);
-    return h;
+    return quadric_finish(sp, d, pHit, pError, dpdu, dpdv);
+}
+
+// ---- Cylinder (shapes/cylinder.cpp:48-198) and Disk (shapes/disk.cpp:48-122): same record, same conventions ----------
+PG_DEV V3 cylinder_hit_point(const PgSphere &sp, V3 o, V3 d, float t, float &phi) {  // cylinder.cpp:79-87
+    V3 pHit = o + d * t;
+    const float hitRad = sqrtf(pHit.x * pHit.x + pHit.y * pHit.y);
+    pHit.x *= sp.radius / hitRad;
+    pHit.y *= sp.radius / hitRad;
+    phi = (float)atan2((double)pHit.y, (double)pHit.x);
+    if (phi < 0) phi += 2 * PG_PI;
+    return pHit;
+}
+PG_DEV bool cylinder_test(const PgSphere &sp, V3 ro, V3 rd, float tMax, float &tHit) {
+    V3 o, d, oErr, dErr;
+    sphere_object_ray(sp, ro, rd, o, d, oErr, dErr);
+    const EFloat ox = ef_make(o.x, oErr.x), oy = ef_make(o.y, oErr.y);
+    const EFloat dx = ef_make(d.x, dErr.x), dy = ef_make(d.y, dErr.y);
+    const EFloat a = ef_add(ef_mul(dx, dx), ef_mul(dy, dy));
+    const EFloat b = ef_mul(ef_make(2, 0), ef_add(ef_mul(dx, ox), ef_mul(dy, oy)));
+    const EFloat rad = ef_make(sp.radius, 0);
+    const EFloat c = ef_sub(ef_add(ef_mul(ox, ox), ef_mul(oy, oy)), ef_mul(rad, rad));
+    EFloat t0, t1;
+    if (!ef_quadratic(a, b, c, t0, t1)) return false;
+    if (t0.high > tMax || t1.low <= 0) return false;
+    EFloat tShapeHit = t0;
+    if (tShapeHit.low <= 0) {
+        tShapeHit = t1;
+        if (tShapeHit.high > tMax) return false;
+    }
+    float phi;
+    V3 pHit = cylinder_hit_point(sp, o, d, tShapeHit.v, phi);
+    if (pHit.z < sp.z_min || pHit.z > sp.z_max || phi > sp.phi_max) {
+        if (tShapeHit.v == t1.v) return false;
+        tShapeHit = t1;
+        if (t1.high > tMax) return false;
+        pHit = cylinder_hit_point(sp, o, d, tShapeHit.v, phi);
+        if (pHit.z < sp.z_min || pHit.z > sp.z_max || phi > sp.phi_max) return false;
+    }
+    tHit = tShapeHit.v;
+    return true;
+}
+PG_DEV SphereHit cylinder_interaction(const PgSphere &sp, V3 ro, V3 rd, float tHit) {
+    V3 o, d, oErr, dErr;
+    sphere_object_ray(sp, ro, rd, o, d, oErr, dErr);
+    float phi;
+    const V3 pHit = cylinder_hit_point(sp, o, d, tHit, phi);
+    const V3 dpdu = mk(-sp.phi_max * pHit.y, sp.phi_max * pHit.x, 0);  // cylinder.cpp:103-104
+    const V3 dpdv = mk(0, 0, sp.z_max - sp.z_min);
+    const V3 pError = vabs(mk(pHit.x, pHit.y, 0)) * pgamma(3);  // :134
+    return quadric_finish(sp, d, pHit, pError, dpdu, dpdv);
+}
+PG_DEV bool disk_test(const PgSphere &sp, V3 ro, V3 rd, float tMax, float &tHit) {  // disk.cpp:48-70
+    V3 o, d, oErr, dErr;
+    sphere_object_ray(sp, ro, rd, o, d, oErr, dErr);
+    if (d.z == 0) return false;
+    const float tShapeHit = (sp.height - o.z) / d.z;
+    if (tShapeHit <= 0 || tShapeHit >= tMax) return false;
+    const V3 pHit = o + d * tShapeHit;
+    const float dist2 = pHit.x * pHit.x + pHit.y * pHit.y;
+    if (dist2 > sp.radius * sp.radius || dist2 < sp.inner_radius * sp.inner_radius) return false;
+    float phi = (float)atan2((double)pHit.y, (double)pHit.x);
+    if (phi < 0) phi += 2 * PG_PI;
+    if (phi > sp.phi_max) return false;
+    tHit = tShapeHit;
+    return true;
+}
+PG_DEV SphereHit disk_interaction(const PgSphere &sp, V3 ro, V3 rd, float tHit) {  // disk.cpp:72-95
+    V3 o, d, oErr, dErr;
+    sphere_object_ray(sp, ro, rd, o, d, oErr, dErr);
+    V3 pHit = o + d * tHit;
+    const float dist2 = pHit.x * pHit.x + pHit.y * pHit.y;
+    const float rHit = sqrtf(dist2);
+    const V3 dpdu = mk(-sp.phi_max * pHit.y, sp.phi_max * pHit.x, 0);
+    const V3 dpdv = vdiv(mk(pHit.x, pHit.y, 0.f) * (sp.inner_radius - sp.radius), rHit);
+    pHit.z = sp.height;
+    return quadric_finish(sp, d, pHit, mk(0, 0, 0), dpdu, dpdv);
+}
+// Shape::Intersect[P] of the quadric record, by shape
+PG_DEV bool sphere_test(const PgSphere &sp, V3 ro, V3 rd, float tMax, float &tHit) {
+    if (sp.shape == PG_SHAPE_CYLINDER) return cylinder_test(sp, ro, rd, tMax, tHit);
+    if (sp.shape == PG_SHAPE_DISK) return disk_test(sp, ro, rd, tMax, tHit);
+    return sphere_test_s(sp, ro, rd, tMax, tHit);
+}
+PG_DEV SphereHit sphere_interaction(const PgSphere &sp, V3 ro, V3 rd, float tHit) {
+    if (sp.shape == PG_SHAPE_CYLINDER) return cylinder_interaction(sp, ro, rd, tHit);
+    if (sp.shape == PG_SHAPE_DISK) return disk_interaction(sp, ro, rd, tHit);
+    return sphere_interaction_s(sp, ro, rd, tHit);
 }
 #endif

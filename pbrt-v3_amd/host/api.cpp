@@ -735,7 +735,19 @@ void pbrtShape(const std::string &name, const ParamSet &params) {  // api.cpp:13
         Float zmax = params.FindOneFloat("zmax", radius);
         Float phimax = params.FindOneFloat("phimax", 360.f);
         sphere = std::make_shared<Sphere>(curTransform[0], Inverse(curTransform[0]), graphicsState.reverseOrientation, radius, zmin, zmax, phimax);
-    } else Error("Shape \"%s\" is outside this build's closed set (trianglemesh, plymesh, loopsubdiv, sphere); ignoring.", name.c_str());
+    } else if (name == "cylinder") {  // CreateCylinderShape, cylinder.cpp:225-235
+        Float radius = params.FindOneFloat("radius", 1);
+        Float zmin = params.FindOneFloat("zmin", -1);
+        Float zmax = params.FindOneFloat("zmax", 1);
+        Float phimax = params.FindOneFloat("phimax", 360);
+        sphere = Sphere::Cylinder(curTransform[0], Inverse(curTransform[0]), graphicsState.reverseOrientation, radius, zmin, zmax, phimax);
+    } else if (name == "disk") {  // CreateDiskShape, disk.cpp:139-149
+        Float height = params.FindOneFloat("height", 0.);
+        Float radius = params.FindOneFloat("radius", 1);
+        Float inner_radius = params.FindOneFloat("innerradius", 0);
+        Float phimax = params.FindOneFloat("phimax", 360);
+        sphere = Sphere::Disk(curTransform[0], Inverse(curTransform[0]), graphicsState.reverseOrientation, height, radius, inner_radius, phimax);
+    } else Error("Shape \"%s\" is outside this build's closed set (trianglemesh, plymesh, loopsubdiv, sphere, cylinder, disk); ignoring.", name.c_str());
     if (!sphere && (!mesh || mesh->nTriangles == 0)) return;
     int mtl = GetMaterialForShape(params);
     params.ReportUnused();

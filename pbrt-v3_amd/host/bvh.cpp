@@ -23,6 +23,26 @@ Sphere::Sphere(const Transform &o2w, const Transform &w2o, bool ro, Float r, Flo
       zMin(Clamp(std::min(z0, z1), -r, r)), zMax(Clamp(std::max(z0, z1), -r, r)),
       thetaMin(std::acos(Clamp(std::min(z0, z1) / r, -1, 1))), thetaMax(std::acos(Clamp(std::max(z0, z1) / r, -1, 1))),
       phiMax(Radians(Clamp(pm, 0, 360))) {}
+std::shared_ptr<Sphere> Sphere::Cylinder(const Transform &o2w, const Transform &w2o, bool ro, Float r, Float z0, Float z1, Float pm) {  // cylinder.h:50-57
+    auto c = std::make_shared<Sphere>(o2w, w2o, ro, r, -r, r, pm);
+    c->shape = PG_SHAPE_CYLINDER;
+    c->zMin = std::min(z0, z1); c->zMax = std::max(z0, z1);
+    c->thetaMin = c->thetaMax = 0;
+    return c;
+}
+std::shared_ptr<Sphere> Sphere::Disk(const Transform &o2w, const Transform &w2o, bool ro, Float h, Float r, Float ri, Float pm) {  // disk.h:50-57
+    auto d = std::make_shared<Sphere>(o2w, w2o, ro, r, -r, r, pm);
+    d->shape = PG_SHAPE_DISK;
+    d->height = h; d->innerRadius = ri;
+    d->zMin = d->zMax = h;  // ObjectBound: z = height on both corners (disk.cpp:43-46)
+    d->thetaMin = d->thetaMax = 0;
+    return d;
+}
+Float Sphere::Area() const {
+    if (shape == PG_SHAPE_CYLINDER) return (zMax - zMin) * radius * phiMax;
+    if (shape == PG_SHAPE_DISK) return phiMax * 0.5 * (radius * radius - innerRadius * innerRadius);  // 0.5 is a double literal there
+    return phiMax * radius * (zMax - zMin);
+}
 Bounds3f Sphere::WorldBound() const {  // Transform::operator()(Bounds3f), transform.cpp:237-249
     const Float lo[3] = {-radius, -radius, zMin}, hi[3] = {radius, radius, zMax};  // ObjectBound
     Bounds3f ret;

@@ -219,6 +219,7 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
             g.radius = sp->radius; g.z_min = sp->zMin; g.z_max = sp->zMax;
             g.theta_min = sp->thetaMin; g.theta_max = sp->thetaMax; g.phi_max = sp->phiMax;
             g.reverse_orientation = sp->reverseOrientation; g.swaps_handedness = sp->transformSwapsHandedness;
+            g.shape = sp->shape; g.height = sp->height; g.inner_radius = sp->innerRadius; g.area = sp->Area();
             flat->spheres.push_back(g);
             continue;
         }

@@ -33,13 +33,17 @@ struct Triangle {
     Float Area() const;           // triangle.cpp:574-580
 };
 // shapes/sphere.h:46-79: a quadric kept in object space with its two transforms.
-struct Sphere {
+struct Sphere {  // also Cylinder (shapes/cylinder.h:46-77) and Disk (shapes/disk.h:46-76): `shape` is a PgQuadricShape
     Sphere(const Transform &o2w, const Transform &w2o, bool reverseOrientation, Float radius, Float zMin, Float zMax, Float phiMax);
+    static std::shared_ptr<Sphere> Cylinder(const Transform &o2w, const Transform &w2o, bool ro, Float radius, Float zMin, Float zMax, Float phiMax);
+    static std::shared_ptr<Sphere> Disk(const Transform &o2w, const Transform &w2o, bool ro, Float height, Float radius, Float innerRadius, Float phiMax);
     Transform ObjectToWorld, WorldToObject;
     bool reverseOrientation, transformSwapsHandedness;
     Float radius, zMin, zMax, thetaMin, thetaMax, phiMax;
-    Bounds3f WorldBound() const;  // shape.cpp:49 over sphere.cpp:43-46
-    Float Area() const { return phiMax * radius * (zMax - zMin); }  // sphere.cpp:203
+    int shape = PG_SHAPE_SPHERE;
+    Float height = 0, innerRadius = 0;
+    Bounds3f WorldBound() const;  // shape.cpp:49 over each shape's ObjectBound()
+    Float Area() const;           // sphere.cpp:203, cylinder.cpp:206, disk.cpp:124-126
 };
 class BVHAccel;
 struct GeometricPrimitive;

@@ -92,6 +92,16 @@ def random_scene_ext(seed, res=16, spp=4):
         part = ' "float zmin" [ -0.3 ] "float zmax" [ 0.5 ] "float phimax" [ 240 ]' if (seed + k) % 3 == 0 else ""
         out.append('AttributeBegin\n Translate %s\n Rotate %.4g 1 1 0\n Scale 1 %.4g %.4g\n Shape "sphere" "float radius" [ %.4g ]%s\nAttributeEnd'
                    % (f(rng.normal(size=3) * 1.5), 90 * rng.random(), 0.6 + rng.random(), 0.6 + rng.random(), 0.3 + 0.7 * rng.random(), part))
+    # cylinders and disks: geometry (partial, annulus) and, every third scene, an emitting disk / cylinder
+    out.append(mats[int(rng.integers(len(mats)))])
+    out.append('AttributeBegin\n Translate %s\n Rotate %.4g 1 0 1\n Scale %.4g 1 1\n Shape "cylinder" "float radius" [ %.4g ] "float zmin" [ -0.5 ] "float zmax" [ 0.7 ] "float phimax" [ %.4g ]\nAttributeEnd'
+               % (f(rng.normal(size=3) * 1.5), 180 * rng.random(), 0.5 + rng.random(), 0.2 + 0.5 * rng.random(), 120 + 240 * rng.random()))
+    out.append('AttributeBegin\n Translate %s\n Rotate %.4g 0 1 1\n Shape "disk" "float radius" [ %.4g ] "float innerradius" [ %.4g ] "float height" [ 0.2 ] "float phimax" [ %.4g ]\nAttributeEnd'
+               % (f(rng.normal(size=3) * 1.5), 180 * rng.random(), 0.5 + 0.5 * rng.random(), 0.3 * rng.random(), 150 + 210 * rng.random()))
+    if seed % 3 == 0:
+        shape = 'Shape "disk" "float radius" [ 0.5 ]' if seed % 2 else 'Shape "cylinder" "float radius" [ 0.1 ] "float zmin" [ -0.6 ] "float zmax" [ 0.6 ]'
+        out.append('AttributeBegin\n Translate %s\n Rotate %.4g 1 0 0\n AreaLightSource "diffuse" "rgb L" [ %s ] "bool twosided" "%s"\n %s\nAttributeEnd'
+                   % (f(rng.normal(size=3) + [0, 2.2, 0]), 60 + 60 * rng.random(), f(4 + 8 * rng.random(3)), "true" if seed % 2 else "false", shape))
     if seed % 2 == 0:
         out.append('AttributeBegin\n Translate %s\n AreaLightSource "diffuse" "rgb L" [ %s ]\n Shape "sphere" "float radius" [ %.4g ]\nAttributeEnd'
                    % (f(rng.normal(size=3) + [0, 2.5, 0]), f(4 + 8 * rng.random(3)), 0.05 + 0.4 * rng.random()))

@@ -177,7 +177,7 @@ def test_instance_rays_bit_exact(gpu, oracle, name):
     gs.close()
 
 
-@pytest.mark.parametrize("name", ["sphere_light", "sphere_partial", "sphere_enclosing"])
+@pytest.mark.parametrize("name", ["sphere_light", "sphere_partial", "sphere_enclosing", "quadrics", "quadric_lights"])
 def test_sphere_rays_bit_exact(gpu, oracle, name):
     """Shape "sphere" in the BVH next to triangles: Sphere::Intersect / IntersectP (error-bounded quadratic, partial-sphere
     clipping, transforms) decide every ray as the oracle does, tHit included; a sphere hit reports (tHit, 0, 0) as its bary."""
@@ -193,7 +193,7 @@ def test_sphere_rays_bit_exact(gpu, oracle, name):
     prim, t, bary = gs.intersect(o, d, tmax)
     oprim, ot, obary, ocn = oracle.intersect(scene.desc, o, d, tmax)
     on_sphere = (prim >= 0) & ((flags[np.maximum(prim, 0)] & 32) != 0)
-    assert on_sphere.sum() > 200
+    assert on_sphere.sum() > 50
     assert np.array_equal(prim, oprim) and np.array_equal(t, ot) and np.array_equal(bary, obary)
     assert np.array_equal(bary[on_sphere, 0], t[on_sphere])
     cn = gs.counters()
