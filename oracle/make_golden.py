@@ -294,6 +294,8 @@ SCENES = {
         .replace("# short box", QUADRICS + "# short box")),
     "quadric_lights": cornell(24, 24, 8, integrator='Integrator "path" "integer maxdepth" [ 4 ] "string lightsamplestrategy" "power"',
                               world_edit=lambda s: s.replace("# short box", QUADRIC_LIGHTS + "# short box")),
+    # Accelerator "bvh" "string splitmethod" "hlbvh" (bvh.cpp:404-638): Morton-sorted LBVH treelets under an SAH top tree
+    "hlbvh_cornell": cornell(24, 24, 8, world_edit=lambda s: with_instances(s)).replace('WorldBegin', 'Accelerator "bvh" "string splitmethod" "hlbvh" "integer maxnodeprims" [ 2 ]\nWorldBegin'),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 
@@ -322,6 +324,12 @@ def main():
         open(p, "w").write(text)
         run(name, p)
     # small synthetic heightfield (3 042 + 12 triangles): SAH BVH with real depth
+    if not only or "hlbvh_synthetic" in only:  # 3 042 triangles: several treelets, deep LBVH bit splits
+        p = os.path.join(GOLD, "hlbvh_synthetic.pbrt")
+        gen_synthetic.write_scene(p, n=40, xres=40, yres=24, spp=4, filename="hlbvh_synthetic.pfm")
+        txt = open(p).read().replace("WorldBegin", 'Accelerator "bvh" "string splitmethod" "hlbvh"\nWorldBegin', 1).replace("synthetic_n40_mesh", "hlbvh_synthetic_mesh")
+        open(p, "w").write(txt)
+        run("hlbvh_synthetic", p)
     if not only or "synthetic_n40" in only:
         p = os.path.join(GOLD, "synthetic_n40.pbrt")
         gen_synthetic.write_scene(p, n=40, xres=48, yres=27, spp=4, filename="synthetic_n40.pfm")

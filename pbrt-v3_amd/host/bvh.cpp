@@ -109,7 +109,9 @@ BVHAccel::BVHAccel(std::vector<GeometricPrimitive> p, int maxPrims, SplitMethod 
     int totalNodes = 0;
     std::vector<GeometricPrimitive> orderedPrims;
     orderedPrims.reserve(primitives.size());
-    BuildNode *root = recursiveBuild(primitiveInfo, 0, (int)primitives.size(), &totalNodes, orderedPrims);
+    BuildNode *root;
+    if (splitMethod == SplitMethod::HLBVH) root = HLBVHBuild(primitiveInfo, &totalNodes, orderedPrims);  // bvh.cpp:207-212
+    else root = recursiveBuild(primitiveInfo, 0, (int)primitives.size(), &totalNodes, orderedPrims);
     primitives.swap(orderedPrims);
     nodes.resize(totalNodes);
     int offset = 0;
@@ -226,15 +228,136 @@ int BVHAccel::flattenBVHTree(BuildNode *node, int *offset) {  // bvh.cpp:640-658
     return myOffset;
 }
 
+// ---- HLBVH (bvh.cpp:107-180, :404-638): Morton codes of the centroids, a stable radix sort, one LBVH treelet per run of
+// equal top-12 Morton bits, an SAH tree over the treelet roots.  The reference builds the treelets on several threads and
+// hands out leaf ranges of orderedPrims with an atomic counter; this is its single-thread order (treelets in index order),
+// in which orderedPrims is simply the Morton-sorted primitive list.  Ray results do not depend on that order.
+struct BVHAccel::MortonPrim { int primitiveIndex; uint32_t mortonCode; };
+static uint32_t LeftShift3(uint32_t x) {  // bvh.cpp:107-131: spread the low 10 bits to every third position
+    if (x == (1 << 10)) --x;
+    x = (x | (x << 16)) & 0x30000ff;
+    x = (x | (x << 8)) & 0x300f00f;
+    x = (x | (x << 4)) & 0x30c30c3;
+    x = (x | (x << 2)) & 0x9249249;
+    return x;
+}
+BVHAccel::BuildNode *BVHAccel::HLBVHBuild(const std::vector<PrimInfo> &primitiveInfo, int *totalNodes, std::vector<GeometricPrimitive> &orderedPrims) {
+    Bounds3f bounds;
+    for (const PrimInfo &pi : primitiveInfo) bounds = Union(bounds, pi.centroid);
+    std::vector<MortonPrim> mortonPrims(primitiveInfo.size());
+    const int mortonScale = 1 << 10;
+    for (size_t i = 0; i < primitiveInfo.size(); ++i) {
+        mortonPrims[i].primitiveIndex = (int)primitiveInfo[i].primitiveNumber;
+        Vector3f o = bounds.Offset(primitiveInfo[i].centroid);
+        Vector3f v(o.x * mortonScale, o.y * mortonScale, o.z * mortonScale);  // centroidOffset * mortonScale
+        mortonPrims[i].mortonCode = (LeftShift3((uint32_t)v.z) << 2) | (LeftShift3((uint32_t)v.y) << 1) | LeftShift3((uint32_t)v.x);
+    }
+    // RadixSort (bvh.cpp:140-180) is a stable LSD sort of the 30-bit codes
+    std::stable_sort(mortonPrims.begin(), mortonPrims.end(), [](const MortonPrim &a, const MortonPrim &b) { return a.mortonCode < b.mortonCode; });
+    struct Treelet { int startIndex, nPrimitives; BuildNode *root; };
+    std::vector<Treelet> treelets;
+    const uint32_t mask = 0x3ffc0000;  // the top 12 of the 30 bits
+    for (int start = 0, end = 1; end <= (int)mortonPrims.size(); ++end)
+        if (end == (int)mortonPrims.size() || ((mortonPrims[start].mortonCode & mask) != (mortonPrims[end].mortonCode & mask))) {
+            treelets.push_back({start, end - start, nullptr});
+            start = end;
+        }
+    int orderedPrimsOffset = 0;
+    orderedPrims.resize(primitives.size());
+    for (Treelet &tr : treelets)
+        tr.root = emitLBVH(primitiveInfo, &mortonPrims[tr.startIndex], tr.nPrimitives, totalNodes, orderedPrims, &orderedPrimsOffset, 29 - 12);
+    std::vector<BuildNode *> finishedTreelets;
+    for (Treelet &tr : treelets) finishedTreelets.push_back(tr.root);
+    return buildUpperSAH(finishedTreelets, 0, (int)finishedTreelets.size(), totalNodes);
+}
+BVHAccel::BuildNode *BVHAccel::emitLBVH(const std::vector<PrimInfo> &primitiveInfo, const MortonPrim *mortonPrims, int nPrimitives, int *totalNodes,
+                                        std::vector<GeometricPrimitive> &orderedPrims, int *orderedPrimsOffset, int bitIndex) {
+    if (bitIndex == -1 || nPrimitives < maxPrimsInNode) {  // a leaf (note: strictly fewer than maxPrimsInNode)
+        (*totalNodes)++;
+        BuildNode *node = allocNode();
+        Bounds3f bounds;
+        int firstPrimOffset = *orderedPrimsOffset;
+        *orderedPrimsOffset += nPrimitives;
+        for (int i = 0; i < nPrimitives; ++i) {
+            int primitiveIndex = mortonPrims[i].primitiveIndex;
+            orderedPrims[firstPrimOffset + i] = primitives[primitiveIndex];
+            bounds = Union(bounds, primitiveInfo[primitiveIndex].bounds);
+        }
+        node->InitLeaf(firstPrimOffset, nPrimitives, bounds);
+        return node;
+    }
+    const uint32_t mask = 1u << bitIndex;
+    if ((mortonPrims[0].mortonCode & mask) == (mortonPrims[nPrimitives - 1].mortonCode & mask))  // no split on this bit
+        return emitLBVH(primitiveInfo, mortonPrims, nPrimitives, totalNodes, orderedPrims, orderedPrimsOffset, bitIndex - 1);
+    int searchStart = 0, searchEnd = nPrimitives - 1;  // first primitive whose bit differs from the run's first
+    while (searchStart + 1 != searchEnd) {
+        int mid = (searchStart + searchEnd) / 2;
+        if ((mortonPrims[searchStart].mortonCode & mask) == (mortonPrims[mid].mortonCode & mask)) searchStart = mid;
+        else searchEnd = mid;
+    }
+    const int splitOffset = searchEnd;
+    (*totalNodes)++;
+    BuildNode *node = allocNode();
+    BuildNode *c0 = emitLBVH(primitiveInfo, mortonPrims, splitOffset, totalNodes, orderedPrims, orderedPrimsOffset, bitIndex - 1);
+    BuildNode *c1 = emitLBVH(primitiveInfo, &mortonPrims[splitOffset], nPrimitives - splitOffset, totalNodes, orderedPrims, orderedPrimsOffset, bitIndex - 1);
+    node->InitInterior(bitIndex % 3, c0, c1);
+    return node;
+}
+BVHAccel::BuildNode *BVHAccel::buildUpperSAH(std::vector<BuildNode *> &treeletRoots, int start, int end, int *totalNodes) {  // bvh.cpp:537-638
+    int nNodes = end - start;
+    if (nNodes == 1) return treeletRoots[start];
+    (*totalNodes)++;
+    BuildNode *node = allocNode();
+    Bounds3f bounds;
+    for (int i = start; i < end; ++i) bounds = Union(bounds, treeletRoots[i]->bounds);
+    Bounds3f centroidBounds;
+    for (int i = start; i < end; ++i) {
+        Point3f centroid = (treeletRoots[i]->bounds.pMin + treeletRoots[i]->bounds.pMax) * 0.5f;
+        centroidBounds = Union(centroidBounds, centroid);
+    }
+    const int dim = centroidBounds.MaximumExtent();
+    const int nBuckets = 12;
+    BucketInfo buckets[nBuckets];
+    auto bucketOf = [&](const BuildNode *n) {
+        Float centroid = (n->bounds.pMin[dim] + n->bounds.pMax[dim]) * 0.5f;
+        int b = nBuckets * ((centroid - centroidBounds.pMin[dim]) / (centroidBounds.pMax[dim] - centroidBounds.pMin[dim]));
+        if (b == nBuckets) b = nBuckets - 1;
+        return b;
+    };
+    for (int i = start; i < end; ++i) {
+        int b = bucketOf(treeletRoots[i]);
+        buckets[b].count++;
+        buckets[b].bounds = Union(buckets[b].bounds, treeletRoots[i]->bounds);
+    }
+    Float cost[nBuckets - 1];
+    for (int i = 0; i < nBuckets - 1; ++i) {
+        Bounds3f b0, b1;
+        int count0 = 0, count1 = 0;
+        for (int j = 0; j <= i; ++j) { b0 = Union(b0, buckets[j].bounds); count0 += buckets[j].count; }
+        for (int j = i + 1; j < nBuckets; ++j) { b1 = Union(b1, buckets[j].bounds); count1 += buckets[j].count; }
+        cost[i] = .125f + (count0 * b0.SurfaceArea() + count1 * b1.SurfaceArea()) / bounds.SurfaceArea();
+    }
+    Float minCost = cost[0];
+    int minCostSplitBucket = 0;
+    for (int i = 1; i < nBuckets - 1; ++i) if (cost[i] < minCost) { minCost = cost[i]; minCostSplitBucket = i; }
+    BuildNode **pmid = std::partition(&treeletRoots[start], &treeletRoots[end - 1] + 1, [&](const BuildNode *n) { return bucketOf(n) <= minCostSplitBucket; });
+    int mid = (int)(pmid - &treeletRoots[0]);
+    if (mid <= start || mid >= end) {  // the reference CHECK-fails here (degenerate centroid bounds)
+        Error("HLBVH: degenerate split of %d treelets; falling back to a median split.", nNodes);
+        mid = (start + end) / 2;
+    }
+    BuildNode *c0 = buildUpperSAH(treeletRoots, start, mid, totalNodes);
+    BuildNode *c1 = buildUpperSAH(treeletRoots, mid, end, totalNodes);
+    node->InitInterior(dim, c0, c1);
+    return node;
+}
+
 std::shared_ptr<BVHAccel> CreateBVHAccelerator(std::vector<GeometricPrimitive> prims, const ParamSet &ps) {
     std::string splitMethodName = ps.FindOneString("splitmethod", "sah");
     BVHAccel::SplitMethod splitMethod;
     if (splitMethodName == "sah") splitMethod = BVHAccel::SplitMethod::SAH;
-    else if (splitMethodName == "hlbvh") {
-        Warning("BVH split method \"hlbvh\" is not implemented by this build; using \"sah\" "
-                "(intersection results are independent of the tree shape).");
-        splitMethod = BVHAccel::SplitMethod::SAH;
-    } else if (splitMethodName == "middle") splitMethod = BVHAccel::SplitMethod::Middle;
+    else if (splitMethodName == "hlbvh") splitMethod = BVHAccel::SplitMethod::HLBVH;
+    else if (splitMethodName == "middle") splitMethod = BVHAccel::SplitMethod::Middle;
     else if (splitMethodName == "equal") splitMethod = BVHAccel::SplitMethod::EqualCounts;
     else {
         Warning("BVH split method \"%s\" unknown.  Using \"sah\".", splitMethodName.c_str());

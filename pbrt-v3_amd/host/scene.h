@@ -80,6 +80,11 @@ class BVHAccel {
     BuildNode *recursiveBuild(std::vector<PrimInfo> &primitiveInfo, int start, int end, int *totalNodes,
                               std::vector<GeometricPrimitive> &orderedPrims);
     int flattenBVHTree(BuildNode *node, int *offset);
+    struct MortonPrim;
+    BuildNode *HLBVHBuild(const std::vector<PrimInfo> &primitiveInfo, int *totalNodes, std::vector<GeometricPrimitive> &orderedPrims);
+    BuildNode *emitLBVH(const std::vector<PrimInfo> &primitiveInfo, const MortonPrim *mortonPrims, int nPrimitives, int *totalNodes,
+                        std::vector<GeometricPrimitive> &orderedPrims, int *orderedPrimsOffset, int bitIndex);
+    BuildNode *buildUpperSAH(std::vector<BuildNode *> &treeletRoots, int start, int end, int *totalNodes);
     const int maxPrimsInNode;
     const SplitMethod splitMethod;
     std::vector<std::unique_ptr<BuildNode[]>> arena;
