@@ -233,7 +233,7 @@ typedef struct PgSceneDesc {
 typedef struct PgRenderDesc {
     int32_t abi_version;
     /* camera: PerspectiveCamera (cameras/perspective.cpp:45-144) or OrthographicCamera (cameras/orthographic.cpp:44-118) */
-    int32_t camera_type;        /* 0 = perspective, 1 = orthographic */
+    int32_t camera_type;        /* 0 = perspective, 1 = orthographic, 2 = environment (cameras/environment.cpp:43-56) */
     float raster_to_camera[16]; /* row-major Matrix4x4 */
     float camera_to_world[16];
     float lens_radius, focal_distance;

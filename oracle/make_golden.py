@@ -296,6 +296,8 @@ SCENES = {
                               world_edit=lambda s: s.replace("# short box", QUADRIC_LIGHTS + "# short box")),
     # Accelerator "bvh" "string splitmethod" "hlbvh" (bvh.cpp:404-638): Morton-sorted LBVH treelets under an SAH top tree
     "hlbvh_cornell": cornell(24, 24, 8, world_edit=lambda s: with_instances(s)).replace('WorldBegin', 'Accelerator "bvh" "string splitmethod" "hlbvh" "integer maxnodeprims" [ 2 ]\nWorldBegin'),
+    # EnvironmentCamera (environment.cpp): the whole sphere of directions from inside the box
+    "cornell_envcam": cornell(48, 24, 8).replace('Camera "perspective" "float fov" [ 39.3 ]', 'Camera "environment"').replace("LookAt 278 273 -800  278 273 0  0 1 0", "LookAt 200 300 150  278 273 400  0 1 0"),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 

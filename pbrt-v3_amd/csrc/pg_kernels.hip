@@ -200,6 +200,15 @@ __global__ __launch_bounds__(PG_BLOCK) void k_generate(DScene sc, RenderParams r
         V3 pCamera = xform_point(rd.raster_to_camera, mk(pFilmX, pFilmY, 0));
         d = normalize(mk(pCamera.x, pCamera.y, pCamera.z));
         if (rd.camera_type == 1) { o = pCamera; d = mk(0, 0, 1); }  // OrthographicCamera, orthographic.cpp:76-78
+        if (rd.camera_type == 2) {  // EnvironmentCamera::GenerateRay, environment.cpp:43-56
+            const float theta = PG_PI * pFilmY / rd.full_res[1];
+            const float phi = 2 * PG_PI * pFilmX / rd.full_res[0];
+            double sT, cT, sP, cP;
+            sincos((double)theta, &sT, &cT);
+            sincos((double)phi, &sP, &cP);
+            o = mk(0, 0, 0);
+            d = mk((float)sT * (float)cP, (float)cT, (float)sT * (float)sP);
+        }
         if (rd.lens_radius > 0) {
             float l0 = halton_sample(sc, rd, index, 3), l1 = halton_sample(sc, rd, index, 4);
             float lx, ly;

@@ -840,13 +840,14 @@ static GpuPathIntegrator *MakeIntegrator() {
     SetFilmFilter(film, filterName, ro.FilterParams);
     ro.FilterParams.ReportUnused();
     ro.FilmParams.ReportUnused();
-    if (ro.CameraName != "perspective" && ro.CameraName != "orthographic") {
-        Error("Camera \"%s\" is outside this build's closed set (perspective, orthographic).", ro.CameraName.c_str());
+    if (ro.CameraName != "perspective" && ro.CameraName != "orthographic" && ro.CameraName != "environment") {
+        Error("Camera \"%s\" is outside this build's closed set (perspective, orthographic, environment).", ro.CameraName.c_str());
         delete film;
         return nullptr;
     }
     if (ro.CameraToWorld.IsAnimated()) Warning("Animated camera transformations are not supported by this build; using the start transform.");
     std::shared_ptr<PerspectiveCamera> camera(CreatePerspectiveCamera(ro.CameraParams, ro.CameraToWorld[0], film, ro.CameraName == "orthographic"));
+    if (ro.CameraName == "environment") { camera->environment = true; camera->lensRadius = 0; }  // environment.cpp:96-97: lens parameters unused
     ro.CameraParams.ReportUnused();
     if (ro.SamplerName != "halton")
         Error("Sampler \"%s\" is outside this build's closed set (halton); using halton with the same \"pixelsamples\".", ro.SamplerName.c_str());

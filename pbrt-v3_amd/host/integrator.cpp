@@ -321,7 +321,7 @@ void GpuPathIntegrator::FillRenderDesc(PgRenderDesc *rd) const {
     memset(rd, 0, sizeof(*rd));
     rd->abi_version = PG_ABI_VERSION;
     const Film &film = *camera->film;
-    rd->camera_type = camera->orthographic ? 1 : 0;
+    rd->camera_type = camera->environment ? 2 : (camera->orthographic ? 1 : 0);
     memcpy(rd->raster_to_camera, camera->RasterToCamera.GetMatrix().m, 16 * sizeof(float));
     memcpy(rd->camera_to_world, camera->CameraToWorld.GetMatrix().m, 16 * sizeof(float));
     rd->lens_radius = camera->lensRadius; rd->focal_distance = camera->focalDistance;

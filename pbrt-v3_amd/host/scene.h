@@ -135,6 +135,7 @@ bool WriteImagePFM(const std::string &filename, const Float *rgb, int width, int
 
 struct PerspectiveCamera {  // ProjectiveCamera (core/camera.h:87-108): cameras/perspective.cpp:45-68 or orthographic.cpp:44-62
     bool orthographic = false;
+    bool environment = false;  // EnvironmentCamera (cameras/environment.cpp): no projection, no lens
     Transform CameraToWorld, RasterToCamera;
     Float lensRadius, focalDistance, shutterOpen, shutterClose;
     std::unique_ptr<Film> film;
