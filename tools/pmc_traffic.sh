@@ -27,7 +27,7 @@ for k in tot["FETCH_SIZE"]:
     f, nf = tot["FETCH_SIZE"][k]; w, nw = tot["WRITE_SIZE"].get(k, (0.0, 1))
     res["kernels"][k] = {"launches": nf, "fetch_KiB_per_launch": f / nf, "write_KiB_per_launch": w / max(1, nw),
                          "hbm_bytes_per_launch": (2 * f / nf + w / max(1, nw)) * 1024}
-dom = [k for k in res["kernels"] if "k_trace<false>" in k]
+dom = [k for k in res["kernels"] if "k_trace<false" in k]
 if dom: res["hbm_bytes_per_launch"] = res["kernels"][dom[0]]["hbm_bytes_per_launch"]
 res["note"] = "FETCH_SIZE, WRITE_SIZE in KiB from separate rocprofv3 --pmc passes; read side x2 (gfx950 correction, calibrated for 16 B/lane streaming reads; an upper bound for this gather pattern)"
 json.dump(res, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
