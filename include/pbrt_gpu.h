@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 9
+#define PG_ABI_VERSION 10
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -68,6 +68,8 @@ typedef enum PgMaterialType {
     PG_MAT_PLASTIC = 2,/* materials/plastic.cpp:45-70 */
     PG_MAT_MIRROR = 3, /* materials/mirror.cpp:44-56: SpecularReflection(Kr, FresnelNoOp)              */
     PG_MAT_GLASS = 4,  /* materials/glass.cpp:45-96, smooth only: FresnelSpecular(Kr, Kt, 1, eta)      */
+    PG_MAT_TEXTURED = 6, /* a material with a non-constant texture among its parameters: its BxDFs are evaluated per hit from
+                          textured[textured_index] (PgTexturedMaterial below) */
     PG_MAT_LOBES = 5   /* any other material (uber, metal, substrate, translucent, mix, rough glass ...): defined by
                           its BxDF list alone, bxdfs[first_bxdf .. first_bxdf + n_bxdfs)                          */
 } PgMaterialType;
@@ -120,7 +122,55 @@ typedef struct PgMaterial {
     float eta;       /* glass: index of refraction */
     int32_t first_bxdf, n_bxdfs; /* this material's BxDFs in PgSceneDesc.bxdfs, n_bxdfs <= PG_MAX_BXDFS */
     float bsdf_eta;  /* BSDF::eta (reflection.h:167-172): the index the path's Russian roulette sees */
+    int32_t textured_index; /* PG_MAT_TEXTURED: index into PgSceneDesc.textured */
 } PgMaterial;
+
+/* ---- textures (core/texture.h and the classes under textures/) ----------------------------------------------------------------------
+ * A parameter of a material or of another texture is either a constant or a reference to a texture node. */
+typedef struct PgTexRef {
+    int32_t tex;     /* >= 0: textures[tex]; -1: the constant v (a float parameter uses v[0]) */
+    float v[3];
+} PgTexRef;
+typedef enum PgTextureType {
+    PG_TEX_SCALE = 1,          /* ScaleTexture: tex1 * tex2,                    textures/scale.h:49-66   */
+    PG_TEX_MIX = 2,            /* MixTexture: (1 - amount) * tex1 + amount * tex2, textures/mix.h:49-68  */
+    PG_TEX_CHECKERBOARD_2D = 3,/* Checkerboard2DTexture, aa_none or closed-form box filter, checkerboard.h:52-110 */
+    PG_TEX_CHECKERBOARD_3D = 4,/* Checkerboard3DTexture,                         checkerboard.h:112-135 */
+    PG_TEX_UV = 5,             /* UVTexture (spectrum),                          textures/uv.h:49-66      */
+    PG_TEX_BILERP = 6          /* BilerpTexture,                                 textures/bilerp.h:49-69  */
+} PgTextureType;
+typedef enum PgMappingType {   /* TextureMapping2D, core/texture.h:51-110 */
+    PG_MAP_UV = 0, PG_MAP_SPHERICAL = 1, PG_MAP_CYLINDRICAL = 2, PG_MAP_PLANAR = 3
+} PgMappingType;
+typedef struct PgTexture {
+    int32_t type;              /* PgTextureType */
+    int32_t is_float;          /* Texture<Float> (1) or Texture<Spectrum> (0) */
+    int32_t mapping;           /* PgMappingType (2D textures) */
+    float su, sv, du, dv;      /* UVMapping2D; du, dv also PlanarMapping2D's ds, dt */
+    float vs[3], vt[3];        /* PlanarMapping2D */
+    float w2t[16];             /* WorldToTexture: spherical / cylindrical mappings and IdentityMapping3D */
+    PgTexRef tex1, tex2, amount; /* operands (amount: the float texture of mix) */
+    int32_t aa_none;           /* checkerboard: AAMethod::None */
+    float v00[3], v01[3], v10[3], v11[3]; /* bilerp */
+} PgTexture;
+/* A material whose BxDF list depends on the hit: the material's kind and its parameters as the Create*Material
+ * functions read them; ComputeScatteringFunctions is evaluated per hit on the device. */
+typedef enum PgMaterialKind {
+    PG_KIND_MATTE = 1, PG_KIND_PLASTIC = 2, PG_KIND_MIRROR = 3, PG_KIND_GLASS = 4, PG_KIND_UBER = 5, PG_KIND_METAL = 6,
+    PG_KIND_SUBSTRATE = 7, PG_KIND_TRANSLUCENT = 8, PG_KIND_MIX = 9
+} PgMaterialKind;
+typedef struct PgTexturedMaterial {
+    int32_t kind;              /* PgMaterialKind */
+    /* spectrum parameters, by kind: matte Kd | plastic Kd Ks | mirror Kr | glass Kr Kt | uber Kd Ks Kr Kt opacity |
+     * metal eta k | substrate Kd Ks | translucent Kd Ks reflect transmit | mix amount */
+    PgTexRef s[5];
+    /* float parameters: matte sigma | plastic roughness | glass uroughness vroughness index | uber roughness uroughness
+     * vroughness eta | metal roughness uroughness vroughness | substrate uroughness vroughness | translucent roughness */
+    PgTexRef f[4];
+    int32_t has_u, has_v;      /* uber / metal: "uroughness" / "vroughness" were given (GetFloatTextureOrNull) */
+    int32_t remap_roughness;
+    int32_t sub[2];            /* mix: the two materials (indices into materials[]) */
+} PgTexturedMaterial;
 
 /* scene.lights, in declaration order (api.cpp:1308-1327 for LightSource, :1353-1363 for area lights):
  * one DiffuseAreaLight per emissive triangle (lights/diffuse.cpp:43-87), plus the delta lights
@@ -226,6 +276,10 @@ typedef struct PgSceneDesc {
     const PgObject *objects;
     int32_t n_instances;
     const PgInstance *instances;
+    int32_t n_textures;
+    const PgTexture *textures;
+    int32_t n_textured;
+    const PgTexturedMaterial *textured;
 } PgSceneDesc;
 
 /* ---- render description -------------------------------------------------- */
@@ -235,6 +289,7 @@ typedef struct PgRenderDesc {
     /* camera: PerspectiveCamera (cameras/perspective.cpp:45-144) or OrthographicCamera (cameras/orthographic.cpp:44-118) */
     int32_t camera_type;        /* 0 = perspective, 1 = orthographic, 2 = environment (cameras/environment.cpp:43-56) */
     float raster_to_camera[16]; /* row-major Matrix4x4 */
+    float dx_camera[3], dy_camera[3]; /* ProjectiveCamera::dxCamera / dyCamera (perspective.cpp:60-63, orthographic.cpp:57-58): ray differentials */
     float camera_to_world[16];
     float lens_radius, focal_distance;
     float shutter_open, shutter_close;

@@ -64,6 +64,71 @@ SPHERE_ENCLOSING = ('AttributeBegin\n  Translate 278 273 100\n  ReverseOrientati
                     '  Shape "sphere" "float radius" [ 1500 ]\nAttributeEnd\n')
 
 
+TEXTURES = ('Texture "chk" "spectrum" "checkerboard" "float uscale" [ 6 ] "float vscale" [ 4 ] "rgb tex1" [ 0.8 0.8 0.8 ] "rgb tex2" [ 0.1 0.2 0.5 ]\n'
+            'Texture "chkpt" "spectrum" "checkerboard" "string aamode" "none" "float uscale" [ 3 ] "float vscale" [ 5 ] "float udelta" [ 0.3 ] "texture tex1" "chk" "rgb tex2" [ 0.7 0.1 0.1 ]\n'
+            'TransformBegin\n  Scale 0.016 0.022 0.0125\n  Texture "chk3" "spectrum" "checkerboard" "integer dimension" [ 3 ] "rgb tex1" [ 0.9 0.9 0.2 ] "rgb tex2" [ 0.2 0.6 0.2 ]\nTransformEnd\n'
+            'Texture "famt" "float" "checkerboard" "float uscale" [ 2 ] "float vscale" [ 2 ] "float tex1" [ 0.2 ] "float tex2" [ 0.9 ]\n'
+            'Texture "mixed" "spectrum" "mix" "texture tex1" "chk" "rgb tex2" [ 0.9 0.4 0.1 ] "texture amount" "famt"\n'
+            'Texture "scaled" "spectrum" "scale" "texture tex1" "chk3" "rgb tex2" [ 0.5 1 1 ]\n'
+            'Texture "fsc" "float" "scale" "texture tex1" "famt" "float tex2" [ 0.5 ]\n'
+            'Texture "fmix" "float" "mix" "float tex1" [ 0.02 ] "float tex2" [ 0.4 ] "texture amount" "famt"\n'
+            'Texture "kconst" "spectrum" "constant" "rgb value" [ 0.3 0.3 0.3 ]\n'
+            'Texture "bil" "spectrum" "bilerp" "rgb v00" [ 1 0 0 ] "rgb v01" [ 0 1 0 ] "rgb v10" [ 0 0 1 ] "rgb v11" [ 1 1 0 ]\n'
+            'Texture "fbil" "float" "bilerp" "float v00" [ 0.1 ] "float v01" [ 0.9 ] "float v10" [ 0.5 ] "float v11" [ 0.3 ]\n'
+            'Texture "uvt" "spectrum" "uv" "float uscale" [ 2.5 ] "float vscale" [ 1.5 ]\n')
+
+
+def with_uv_boxes(s):
+    return with_normals(s, uv=True).replace(' "normal N" [', ' "normal Nunused" [')
+
+
+def with_textures(s):
+    s = with_normals(s, uv=True)
+    s = s.replace("WorldBegin\n", "WorldBegin\n" + TEXTURES, 1)
+    s = s.replace('Material "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', 'Material "matte" "texture Kd" "chk"', 1)        # floor / ceiling / back wall
+    s = s.replace('Material "matte" "rgb Kd" [ 0.12 0.45 0.15 ]', 'Material "matte" "texture Kd" "scaled"')
+    s = s.replace('Material "matte" "rgb Kd" [ 0.65 0.05 0.05 ]', 'Material "matte" "texture Kd" "mixed" "texture sigma" "fsc"')
+    s = s.replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\nMaterial "matte" "texture Kd" "chkpt"')
+    s = s.replace("# tall box", 'Material "matte" "texture Kd" "chk3"\n# tall box')
+    return s
+
+
+def with_textured_materials(s):
+    s = with_normals(s, uv=True)
+    s = s.replace("WorldBegin\n", "WorldBegin\n" + TEXTURES +
+                  'MakeNamedMaterial "ta" "string type" "plastic" "texture Kd" "chk" "texture roughness" "fmix"\n'
+                  'MakeNamedMaterial "tb" "string type" "metal" "texture k" "bil" "float roughness" [ 0.1 ]\n'
+                  'MakeNamedMaterial "tmix" "string type" "mix" "string namedmaterial1" "ta" "string namedmaterial2" "tb" "texture amount" "uvt"\n', 1)
+    s = s.replace('Material "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', 'Material "uber" "texture Kd" "chk" "texture opacity" "bil" "texture Kr" "kconst" "rgb Kt" [ 0.2 0.2 0.2 ] "texture uroughness" "fbil"', 1)
+    s = s.replace('Material "matte" "rgb Kd" [ 0.12 0.45 0.15 ]', 'Material "substrate" "texture Kd" "uvt" "texture Ks" "kconst" "texture vroughness" "fbil"')
+    s = s.replace('Material "matte" "rgb Kd" [ 0.65 0.05 0.05 ]', 'Material "translucent" "texture Kd" "chk" "texture transmit" "bil" "texture roughness" "fmix"')
+    s = s.replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\nMaterial "glass" "texture Kt" "chkpt" "texture Kr" "kconst" "texture index" "fmixidx"')
+    s = s.replace('Texture "kconst"', 'Texture "fmixidx" "float" "mix" "float tex1" [ 1.2 ] "float tex2" [ 1.7 ] "texture amount" "famt"\nTexture "kconst"')
+    s = s.replace("# tall box", 'NamedMaterial "tmix"\n# tall box')
+    return s
+
+
+def with_mappings(s):
+    s = with_normals(s, uv=True)
+    tex = ('Texture "pl" "spectrum" "checkerboard" "string aamode" "none" "string mapping" "planar" "vector v1" [ 0.02 0 0.01 ] "vector v2" [ 0 0.03 0 ] "float udelta" [ 0.25 ] "rgb tex1" [ 0.9 0.9 0.9 ] "rgb tex2" [ 0.2 0.2 0.7 ]\n'
+           'TransformBegin\n  Translate 278 273 280\n  Rotate 30 1 0 0\n'
+           '  Texture "sph" "spectrum" "checkerboard" "string mapping" "spherical" "float uscale" [ 1 ] "rgb tex1" [ 0.9 0.5 0.1 ] "rgb tex2" [ 0.1 0.5 0.9 ]\n'
+           '  Texture "cyl" "spectrum" "checkerboard" "string mapping" "cylindrical" "float uscale" [ 1 ] "rgb tex1" [ 0.8 0.8 0.2 ] "rgb tex2" [ 0.2 0.7 0.3 ]\n'
+           '  Texture "sphuv" "spectrum" "uv" "string mapping" "spherical"\nTransformEnd\n'
+           'Texture "sc" "spectrum" "scale" "texture tex1" "sph" "texture tex2" "cyl"\n')
+    s = s.replace("WorldBegin\n", "WorldBegin\n" + tex, 1)
+    s = s.replace('Material "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', 'Material "matte" "texture Kd" "pl"', 1)
+    s = s.replace('Material "matte" "rgb Kd" [ 0.12 0.45 0.15 ]', 'Material "matte" "texture Kd" "sph"')
+    s = s.replace('Material "matte" "rgb Kd" [ 0.65 0.05 0.05 ]', 'Material "plastic" "texture Kd" "cyl" "texture Ks" "sphuv"')
+    s = s.replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\nMaterial "matte" "texture Kd" "sc"')
+    s = s.replace("# tall box", 'Material "mirror" "texture Kr" "sphuv"\n# tall box')
+    s = s.replace("# short box", 'AttributeBegin\n  Translate 420 70 120\n  Rotate 40 0 1 1\n'
+                  '  Texture "sphball" "spectrum" "checkerboard" "float uscale" [ 8 ] "float vscale" [ 4 ] "rgb tex1" [ 0.9 0.9 0.9 ] "rgb tex2" [ 0.7 0.1 0.1 ]\n  Material "matte" "texture Kd" "sphball"\n'
+                  '  Shape "sphere" "float radius" [ 70 ]\n  Translate -250 0 150\n  Shape "cylinder" "float radius" [ 30 ] "float zmin" [ -60 ] "float zmax" [ 60 ]\n'
+                  '  Translate 0 0 61\n  Shape "disk" "float radius" [ 30 ]\nAttributeEnd\n# short box', 1)
+    return s
+
+
 def with_instances(s):
     """Move the two boxes into `ObjectBegin "boxes"`, add a one-sphere object, and instance both several times."""
     i = s.index("# short box")
@@ -298,6 +363,14 @@ SCENES = {
     "hlbvh_cornell": cornell(24, 24, 8, world_edit=lambda s: with_instances(s)).replace('WorldBegin', 'Accelerator "bvh" "string splitmethod" "hlbvh" "integer maxnodeprims" [ 2 ]\nWorldBegin'),
     # EnvironmentCamera (environment.cpp): the whole sphere of directions from inside the box
     "cornell_envcam": cornell(48, 24, 8).replace('Camera "perspective" "float fov" [ 39.3 ]', 'Camera "environment"').replace("LookAt 278 273 -800  278 273 0  0 1 0", "LookAt 200 300 150  278 273 400  0 1 0"),
+    # textures (core/texture.cpp, textures/): checkerboards (2D closed-form / none, 3D), scale, mix, uv, bilerp under every 2D
+    # mapping, as parameters of every material kind; the camera rays' differentials (perspective with and without a lens,
+    # orthographic, environment) drive the closed-form filter at the first hit
+    "tex_checker": cornell(40, 40, 8, world_edit=lambda s: with_textures(s)),
+    "tex_materials": cornell(40, 40, 8, integrator='Integrator "path" "integer maxdepth" [ 6 ]', world_edit=lambda s: with_textured_materials(s)),
+    "tex_mappings_lens": cornell(36, 36, 8, world_edit=lambda s: with_mappings(s)).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 6 ] "float focaldistance" [ 900 ]'),
+    "tex_ortho": cornell(32, 32, 4, world_edit=lambda s: with_textures(s)).replace('Camera "perspective" "float fov" [ 39.3 ]', 'Camera "orthographic" "float screenwindow" [ -300 300 -290 310 ] "float lensradius" [ 4 ] "float focaldistance" [ 1000 ]'),
+    "tex_envcam": cornell(48, 24, 4, world_edit=lambda s: with_mappings(s)).replace('Camera "perspective" "float fov" [ 39.3 ]', 'Camera "environment"').replace("LookAt 278 273 -800  278 273 0  0 1 0", "LookAt 200 300 150  278 273 400  0 1 0"),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 

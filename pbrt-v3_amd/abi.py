@@ -5,7 +5,7 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 9
+PG_ABI_VERSION = 10
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
 PG_LIGHTS_UNIFORM, PG_LIGHTS_POWER, PG_LIGHTS_SPATIAL = 0, 1, 2
@@ -22,7 +22,7 @@ class PgBVHNode(C.Structure):
 class PgMaterial(C.Structure):
     _fields_ = [("type", C.c_int32), ("kd", C.c_float * 3), ("ks", C.c_float * 3), ("sigma", C.c_float),
                 ("roughness", C.c_float), ("remap_roughness", C.c_int32), ("kr", C.c_float * 3), ("kt", C.c_float * 3),
-                ("eta", C.c_float), ("first_bxdf", C.c_int32), ("n_bxdfs", C.c_int32), ("bsdf_eta", C.c_float)]
+                ("eta", C.c_float), ("first_bxdf", C.c_int32), ("n_bxdfs", C.c_int32), ("bsdf_eta", C.c_float), ("textured_index", C.c_int32)]
 
 
 class PgLight(C.Structure):
@@ -30,6 +30,22 @@ class PgLight(C.Structure):
                 ("pos", C.c_float * 3), ("w2l", C.c_float * 9), ("cos_total_width", C.c_float), ("cos_falloff_start", C.c_float),
                 ("world_radius", C.c_float), ("l2w", C.c_float * 9), ("env_func", C.c_float * 4), ("env_cdf", C.c_float * 6),
                 ("env_int", C.c_float * 2), ("env_marg_cdf", C.c_float * 3), ("env_marg_int", C.c_float)]
+
+
+class PgTexRef(C.Structure):
+    _fields_ = [("tex", C.c_int32), ("v", C.c_float * 3)]
+
+
+class PgTexture(C.Structure):
+    _fields_ = [("type", C.c_int32), ("is_float", C.c_int32), ("mapping", C.c_int32), ("su", C.c_float), ("sv", C.c_float),
+                ("du", C.c_float), ("dv", C.c_float), ("vs", C.c_float * 3), ("vt", C.c_float * 3), ("w2t", C.c_float * 16),
+                ("tex1", PgTexRef), ("tex2", PgTexRef), ("amount", PgTexRef), ("aa_none", C.c_int32),
+                ("v00", C.c_float * 3), ("v01", C.c_float * 3), ("v10", C.c_float * 3), ("v11", C.c_float * 3)]
+
+
+class PgTexturedMaterial(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("s", PgTexRef * 5), ("f", PgTexRef * 4), ("has_u", C.c_int32), ("has_v", C.c_int32),
+                ("remap_roughness", C.c_int32), ("sub", C.c_int32 * 2)]
 
 
 class PgBxDF(C.Structure):
@@ -68,12 +84,13 @@ class PgSceneDesc(C.Structure):
                 ("n_spheres", C.c_int32), ("spheres", C.POINTER(PgSphere)),
                 ("n_bxdfs", C.c_int32), ("bxdfs", C.POINTER(PgBxDF)),
                 ("n_nodes_all", C.c_int32), ("n_prims_all", C.c_int32), ("n_objects", C.c_int32), ("objects", C.POINTER(PgObject)),
-                ("n_instances", C.c_int32), ("instances", C.POINTER(PgInstance))]
+                ("n_instances", C.c_int32), ("instances", C.POINTER(PgInstance)),
+                ("n_textures", C.c_int32), ("textures", C.POINTER(PgTexture)), ("n_textured", C.c_int32), ("textured", C.POINTER(PgTexturedMaterial))]
 
 
 class PgRenderDesc(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("camera_type", C.c_int32),
-                ("raster_to_camera", C.c_float * 16), ("camera_to_world", C.c_float * 16),
+                ("raster_to_camera", C.c_float * 16), ("dx_camera", C.c_float * 3), ("dy_camera", C.c_float * 3), ("camera_to_world", C.c_float * 16),
                 ("lens_radius", C.c_float), ("focal_distance", C.c_float),
                 ("shutter_open", C.c_float), ("shutter_close", C.c_float),
                 ("full_res", C.c_int32 * 2), ("cropped_pixel_bounds", C.c_int32 * 4), ("sample_bounds", C.c_int32 * 4),

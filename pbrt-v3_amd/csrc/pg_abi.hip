@@ -289,7 +289,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     for (int i = 0; i < desc->n_materials; ++i) {
         const PgMaterial &m = desc->materials[i];
         if (m.type == PG_MAT_NONE) s->hasNullMaterial = true;
-        else if (m.type < PG_MAT_MATTE || m.type > PG_MAT_LOBES)
+        else if (m.type < PG_MAT_MATTE || m.type > PG_MAT_TEXTURED)
             FAIL(PG_ERR_UNSUPPORTED, "material %d: unknown type %d", i, m.type);
         if (m.type == PG_MAT_LOBES) anyLobeMaterial = true;
         if (m.n_bxdfs < 0 || m.n_bxdfs > PG_MAX_BXDFS || (m.n_bxdfs > 0 && (m.first_bxdf < 0 || m.first_bxdf + m.n_bxdfs > desc->n_bxdfs || !desc->bxdfs)))

@@ -55,8 +55,9 @@ TransformSet Inverse(const TransformSet &ts) {
 }
 struct MaterialInstance { std::string name; int material = -1; ParamSet params; };
 struct GraphicsState {
-    std::map<std::string, RGB> spectrumTextures;   // constant textures only
-    std::map<std::string, Float> floatTextures;
+    // named textures: a constant (tex == -1) or a node of renderOptions->textures
+    std::map<std::string, PgTexRef> spectrumTextures;
+    std::map<std::string, PgTexRef> floatTextures;
     std::map<std::string, MaterialInstance> namedMaterials;
     MaterialInstance currentMaterial;
     ParamSet areaLightParams;
@@ -79,6 +80,8 @@ struct RenderOptions {
     std::vector<size_t> lightPrimSerial;   // serial number of the emitting primitive
     std::vector<PgMaterial> materials;
     std::vector<PgBxDF> bxdfs;  // the materials' BxDF lists, concatenated
+    std::vector<PgTexture> textures;  // texture nodes (Texture "name" ... with a non-constant class)
+    std::vector<PgTexturedMaterial> textured;
     bool haveScatteringMedia = false;
 };
 enum class APIState { Uninitialized, OptionsBlock, WorldBlock };
@@ -117,35 +120,44 @@ std::vector<uint32_t> pushedActiveTransformBits;
 // ---- materials (api.cpp:537-620; matte.cpp:64-72; plastic.cpp:72-84) ---------------
 // Textures are restricted to constants: a "texture" parameter must name a
 // constant texture declared with Texture "name" "spectrum|float" "constant".
-static RGB spectrumParam(const ParamSet &geom, const ParamSet &mat, const std::string &n, RGB def,
-                         const GraphicsState &gs) {
-    for (const ParamSet *ps : {&geom, &mat}) {  // shape parameters first (paramset.cpp:729-760)
+static PgTexRef constRef(RGB v) { PgTexRef r; r.tex = -1; r.v[0] = v.c[0]; r.v[1] = v.c[1]; r.v[2] = v.c[2]; return r; }
+static PgTexRef constRef(Float v) { PgTexRef r; r.tex = -1; r.v[0] = v; r.v[1] = r.v[2] = 0; return r; }
+// TextureParams::GetSpectrumTexture / GetFloatTexture (paramset.cpp:720-800): shape parameters first, a named texture
+// before a literal value
+static PgTexRef spectrumRef(const ParamSet &geom, const ParamSet &mat, const std::string &n, RGB def, const GraphicsState &gs) {
+    for (const ParamSet *ps : {&geom, &mat}) {
         std::string tex = ps->FindTexture(n);
         if (!tex.empty()) {
             auto it = gs.spectrumTextures.find(tex);
             if (it != gs.spectrumTextures.end()) return it->second;
             Error("Couldn't find spectrum texture named \"%s\" for parameter \"%s\"", tex.c_str(), n.c_str());
-            continue;
+            return constRef(def);  // paramset.cpp:760-764: no further lookup once a texture name was given
         }
-        RGB s;
-        if (ps->FindSpectrum(n, &s)) return s;
+        RGB sp;
+        if (ps->FindSpectrum(n, &sp)) return constRef(sp);
     }
-    return def;
+    return constRef(def);
 }
-static Float floatParam(const ParamSet &geom, const ParamSet &mat, const std::string &n, Float def,
-                        const GraphicsState &gs) {
+static PgTexRef floatRef(const ParamSet &geom, const ParamSet &mat, const std::string &n, Float def, const GraphicsState &gs) {
     for (const ParamSet *ps : {&geom, &mat}) {
         std::string tex = ps->FindTexture(n);
         if (!tex.empty()) {
             auto it = gs.floatTextures.find(tex);
             if (it != gs.floatTextures.end()) return it->second;
             Error("Couldn't find float texture named \"%s\" for parameter \"%s\"", tex.c_str(), n.c_str());
-            continue;
+            return constRef(def);
         }
         const std::vector<Float> *f = ps->FindFloat(n);
-        if (f && !f->empty()) return (*f)[0];
+        if (f && !f->empty()) return constRef((*f)[0]);
     }
-    return def;
+    return constRef(def);
+}
+static RGB spectrumParam(const ParamSet &geom, const ParamSet &mat, const std::string &n, RGB def, const GraphicsState &gs) {
+    PgTexRef r = spectrumRef(geom, mat, n, def, gs);
+    return RGB{{r.v[0], r.v[1], r.v[2]}};
+}
+static Float floatParam(const ParamSet &geom, const ParamSet &mat, const std::string &n, Float def, const GraphicsState &gs) {
+    return floatRef(geom, mat, n, def, gs).v[0];
 }
 // A material is interned with its BxDF list: equal parameters and equal lists share one table entry.
 static int internMaterial(PgMaterial m, const std::vector<PgBxDF> &lobes) {
@@ -206,8 +218,40 @@ static int MakeMaterial(const std::string &name, const ParamSet &geom, const Par
     m.bsdf_eta = 1;  // BSDF(si, eta = 1), reflection.h:167
     if (name == "" || name == "none") { m.type = PG_MAT_NONE; return internMaterial(m, lobes); }
     const GraphicsState &gs = graphicsState;
-    auto spec = [&](const char *n, Float d) { return spectrumParam(geom, mat, n, RGB{{d, d, d}}, gs); };
-    auto flt = [&](const char *n, Float d) { return floatParam(geom, mat, n, d, gs); };
+    // Parameter slots of PgTexturedMaterial (include/pbrt_gpu.h), per material kind.  Every parameter read below is also
+    // recorded in `tm`; when one of them is a non-constant texture the material is handed over as PG_MAT_TEXTURED and its
+    // BxDFs are evaluated per hit, otherwise as the BxDF list built here.
+    struct KindSlots { const char *name; int kind; const char *s[5]; const char *f[4]; };
+    static const KindSlots kSlots[] = {
+        {"matte", PG_KIND_MATTE, {"Kd"}, {"sigma"}}, {"plastic", PG_KIND_PLASTIC, {"Kd", "Ks"}, {"roughness"}},
+        {"mirror", PG_KIND_MIRROR, {"Kr"}, {}}, {"glass", PG_KIND_GLASS, {"Kr", "Kt"}, {"uroughness", "vroughness", "eta"}},
+        {"uber", PG_KIND_UBER, {"Kd", "Ks", "Kr", "Kt", "opacity"}, {"roughness", "uroughness", "vroughness", "eta"}},
+        {"metal", PG_KIND_METAL, {"eta", "k"}, {"roughness", "uroughness", "vroughness"}},
+        {"substrate", PG_KIND_SUBSTRATE, {"Kd", "Ks"}, {"uroughness", "vroughness"}},
+        {"translucent", PG_KIND_TRANSLUCENT, {"Kd", "Ks", "reflect", "transmit"}, {"roughness"}}, {"mix", PG_KIND_MIX, {"amount"}, {}}};
+    const KindSlots *slots = &kSlots[0];  // unknown names fall back to matte (api.cpp:588-591)
+    for (const KindSlots &k : kSlots) if (name == k.name) slots = &k;
+    PgTexturedMaterial tm;
+    memset(&tm, 0, sizeof(tm));
+    tm.kind = slots->kind;
+    for (int i = 0; i < 5; ++i) tm.s[i].tex = -1;
+    for (int i = 0; i < 4; ++i) tm.f[i].tex = -1;
+    tm.sub[0] = tm.sub[1] = -1;
+    bool anyTexture = false;
+    auto specRGB = [&](const char *n, RGB d) {
+        PgTexRef r = spectrumRef(geom, mat, n, d, gs);
+        for (int i = 0; i < 5; ++i) if (slots->s[i] && !strcmp(slots->s[i], n)) tm.s[i] = r;
+        if (r.tex >= 0) anyTexture = true;
+        return RGB{{r.v[0], r.v[1], r.v[2]}};
+    };
+    auto spec = [&](const char *n, Float d) { return specRGB(n, RGB{{d, d, d}}); };
+    auto flt = [&](const char *n, Float d) {
+        PgTexRef r = floatRef(geom, mat, n, d, gs);
+        const char *slotName = !strcmp(n, "index") ? "eta" : n;  // "eta" and its alias "index" share a slot
+        for (int i = 0; i < 4; ++i) if (slots->f[i] && !strcmp(slots->f[i], slotName)) tm.f[i] = r;
+        if (r.tex >= 0) anyTexture = true;
+        return r.v[0];
+    };
     auto remapParam = [&]() { return geom.FindOneBool("remaproughness", mat.FindOneBool("remaproughness", true)); };
     if (!geom.FindTexture("bumpmap").empty() || !mat.FindTexture("bumpmap").empty())
         Error("\"bumpmap\" textures are not supported by this build; ignoring.");
@@ -292,7 +336,7 @@ static int MakeMaterial(const std::string &name, const ParamSet &geom, const Par
         if (!rgbBlack(kt)) { PgBxDF b = lobe(PG_BXDF_SPECULAR_T); setT(b, kt); b.eta_a = 1.f; b.eta_b = e; lobes.push_back(b); }
     } else if (name == "metal") {  // metal.cpp:61-136
         m.type = PG_MAT_LOBES;
-        RGB eta = spectrumParam(geom, mat, "eta", kCopperN, gs), k = spectrumParam(geom, mat, "k", kCopperK, gs);
+        RGB eta = specRGB("eta", kCopperN), k = specRGB("k", kCopperK);
         Float roughness = flt("roughness", .01f);
         const bool hasU = hasParam(geom, mat, "uroughness"), hasV = hasParam(geom, mat, "vroughness");
         Float uRough = hasU ? flt("uroughness", 0.f) : roughness, vRough = hasV ? flt("vroughness", 0.f) : roughness;
@@ -363,8 +407,27 @@ static int MakeMaterial(const std::string &name, const ParamSet &geom, const Par
             }
         }
         if (bad) Error("mix: more than %d BxDFs or more than %d nested mixes; the excess is dropped.", PG_MAX_BXDFS, PG_MAX_BXDF_SCALES);
+        tm.sub[0] = sub[0]; tm.sub[1] = sub[1];
+        for (int j = 0; j < 2; ++j) if (renderOptions->materials[sub[j]].type == PG_MAT_TEXTURED) anyTexture = true;
     }
     mat.ReportUnused();
+    if (anyTexture) {  // a texture among the parameters: ComputeScatteringFunctions runs per hit on the device
+        tm.has_u = hasParam(geom, mat, "uroughness") ? 1 : 0;
+        tm.has_v = hasParam(geom, mat, "vroughness") ? 1 : 0;
+        tm.remap_roughness = geom.FindOneBool("remaproughness", mat.FindOneBool("remaproughness", true)) ? 1 : 0;
+        if (slots->kind == PG_KIND_GLASS && !hasParam(geom, mat, "eta") && !hasParam(geom, mat, "index")) tm.f[2] = constRef(1.5f);
+        if (slots->kind == PG_KIND_UBER && !hasParam(geom, mat, "eta") && !hasParam(geom, mat, "index")) tm.f[3] = constRef(1.5f);
+        PgMaterial t;
+        memset(&t, 0, sizeof(t));
+        t.type = PG_MAT_TEXTURED;
+        t.bsdf_eta = 1;
+        auto &tab = renderOptions->textured;
+        int found = -1;
+        for (size_t i = 0; i < tab.size(); ++i) if (memcmp(&tab[i], &tm, sizeof(tm)) == 0) found = (int)i;
+        if (found < 0) { found = (int)tab.size(); tab.push_back(tm); }
+        t.textured_index = found;
+        return internMaterial(t, std::vector<PgBxDF>());
+    }
     return internMaterial(m, lobes);
 }
 
@@ -519,19 +582,89 @@ void pbrtTransformEnd() {
     curTransform = pushedTransforms.back(); pushedTransforms.pop_back();
     activeTransformBits = pushedActiveTransformBits.back(); pushedActiveTransformBits.pop_back();
 }
+// TextureMapping2D from the texture's parameters: the block every Create*Texture with a 2D mapping repeats (e.g.
+// checkerboard.cpp:52-75)
+static void readMapping2D(const ParamSet &tp, const Transform &tex2world, PgTexture *t) {
+    std::string type = tp.FindOneString("mapping", "uv");
+    t->mapping = PG_MAP_UV; t->su = t->sv = 1; t->du = t->dv = 0;
+    const Matrix4x4 w2t = Inverse(tex2world).GetMatrix();  // a copy: the inverse is a temporary
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) t->w2t[4 * r + c] = w2t.m[r][c];
+    if (type == "uv") {
+        t->su = tp.FindOneFloat("uscale", 1.); t->sv = tp.FindOneFloat("vscale", 1.);
+        t->du = tp.FindOneFloat("udelta", 0.); t->dv = tp.FindOneFloat("vdelta", 0.);
+    } else if (type == "spherical") t->mapping = PG_MAP_SPHERICAL;
+    else if (type == "cylindrical") t->mapping = PG_MAP_CYLINDRICAL;
+    else if (type == "planar") {
+        t->mapping = PG_MAP_PLANAR;
+        const std::vector<Float> *v1 = tp.FindVector3f("v1"), *v2 = tp.FindVector3f("v2");
+        const Float d1[3] = {1, 0, 0}, d2[3] = {0, 1, 0};
+        for (int i = 0; i < 3; ++i) { t->vs[i] = (v1 && v1->size() >= 3) ? (*v1)[i] : d1[i]; t->vt[i] = (v2 && v2->size() >= 3) ? (*v2)[i] : d2[i]; }
+        t->du = tp.FindOneFloat("udelta", 0.f); t->dv = tp.FindOneFloat("vdelta", 0.f);
+    } else Error("2D texture mapping \"%s\" unknown", type.c_str());
+}
 void pbrtTexture(const std::string &name, const std::string &type, const std::string &texname, const ParamSet &params) {
-    VERIFY_WORLD("Texture");  // api.cpp:1183-1238
-    if (texname != "constant") {
-        Error("Texture \"%s\": class \"%s\" is outside this build's closed set (constant only); ignoring.", name.c_str(), texname.c_str());
+    VERIFY_WORLD("Texture");  // api.cpp:1183-1238; MakeFloatTexture / MakeSpectrumTexture, api.cpp:603-679
+    const bool isFloat = type == "float";
+    if (!isFloat && type != "color" && type != "spectrum") { Error("Texture type \"%s\" unknown.", type.c_str()); return; }
+    auto &table = isFloat ? graphicsState.floatTextures : graphicsState.spectrumTextures;
+    if (table.count(name)) Warning("Texture \"%s\" being redefined", name.c_str());
+    if (curTransform.IsAnimated()) Warning("Animated transformations are not supported by this build; using the start transform for texture \"%s\".", name.c_str());
+    const GraphicsState &gs = graphicsState;
+    ParamSet none;
+    auto operand = [&](const char *n, Float d) { return isFloat ? floatRef(params, none, n, d, gs) : spectrumRef(params, none, n, RGB{{d, d, d}}, gs); };
+    PgTexture t;
+    memset(&t, 0, sizeof(t));
+    t.is_float = isFloat ? 1 : 0;
+    t.tex1.tex = t.tex2.tex = t.amount.tex = -1;
+    PgTexRef ref;
+    ref.tex = -1; ref.v[0] = ref.v[1] = ref.v[2] = 0;
+    if (texname == "constant") {  // constant.cpp:40-50
+        if (isFloat) ref = constRef(params.FindOneFloat("value", 1.f));
+        else ref = constRef(params.FindOneSpectrum("value", RGB{{1.f, 1.f, 1.f}}));
+        table[name] = ref;
+        params.ReportUnused();
+        return;
+    } else if (texname == "scale") {
+        t.type = PG_TEX_SCALE; t.tex1 = operand("tex1", 1.f); t.tex2 = operand("tex2", 1.f);
+    } else if (texname == "mix") {
+        t.type = PG_TEX_MIX; t.tex1 = operand("tex1", 0.f); t.tex2 = operand("tex2", 1.f);
+        t.amount = floatRef(params, none, "amount", 0.5f, gs);
+    } else if (texname == "checkerboard") {
+        int dim = params.FindOneInt("dimension", 2);
+        if (dim != 2 && dim != 3) { Error("%d dimensional checkerboard texture not supported", dim); return; }
+        t.tex1 = operand("tex1", 1.f); t.tex2 = operand("tex2", 0.f);
+        readMapping2D(dim == 2 ? params : none, curTransform[0], &t);
+        if (dim == 2) {
+            t.type = PG_TEX_CHECKERBOARD_2D;
+            std::string aa = params.FindOneString("aamode", "closedform");
+            if (aa == "none") t.aa_none = 1;
+            else if (aa != "closedform") Warning("Antialiasing mode \"%s\" not understood by Checkerboard2DTexture; using \"closedform\"", aa.c_str());
+        } else {  // checkerboard.cpp:92: IdentityMapping3D(tex2world) -- the mapping's "WorldToTexture" IS tex2world there
+            t.type = PG_TEX_CHECKERBOARD_3D;
+            const Matrix4x4 &m = curTransform[0].GetMatrix();
+            for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) t.w2t[4 * r + c] = m.m[r][c];
+        }
+    } else if (texname == "uv" && !isFloat) {
+        t.type = PG_TEX_UV;
+        readMapping2D(params, curTransform[0], &t);
+    } else if (texname == "bilerp") {
+        t.type = PG_TEX_BILERP;
+        readMapping2D(params, curTransform[0], &t);
+        const char *names[4] = {"v00", "v01", "v10", "v11"};
+        float *dst[4] = {t.v00, t.v01, t.v10, t.v11};
+        const Float defs[4] = {0.f, 1.f, 0.f, 1.f};
+        for (int k = 0; k < 4; ++k) {
+            if (isFloat) { dst[k][0] = params.FindOneFloat(names[k], defs[k]); dst[k][1] = dst[k][2] = 0; }
+            else { RGB v = params.FindOneSpectrum(names[k], RGB{{defs[k], defs[k], defs[k]}}); for (int c = 0; c < 3; ++c) dst[k][c] = v.c[c]; }
+        }
+    } else {
+        Error("Texture \"%s\": class \"%s\" is outside this build's closed set (constant, scale, mix, checkerboard, uv, bilerp); ignoring.",
+              name.c_str(), texname.c_str());
         return;
     }
-    if (type == "float") {
-        if (graphicsState.floatTextures.count(name)) Warning("Texture \"%s\" being redefined", name.c_str());
-        graphicsState.floatTextures[name] = params.FindOneFloat("value", 1.f);
-    } else if (type == "color" || type == "spectrum") {
-        if (graphicsState.spectrumTextures.count(name)) Warning("Texture \"%s\" being redefined", name.c_str());
-        graphicsState.spectrumTextures[name] = params.FindOneSpectrum("value", RGB{{1.f, 1.f, 1.f}});
-    } else Error("Texture type \"%s\" unknown.", type.c_str());
+    ref.tex = (int)renderOptions->textures.size();
+    renderOptions->textures.push_back(t);
+    table[name] = ref;
     params.ReportUnused();
 }
 void pbrtMaterial(const std::string &name, const ParamSet &params) {  // api.cpp:1240-1254
@@ -877,6 +1010,8 @@ static Scene *MakeScene() {
     scene->lights = ro.lights;
     scene->materials = ro.materials;
     scene->bxdfs = ro.bxdfs;
+    scene->textures = ro.textures;
+    scene->textured = ro.textured;
     scene->worldBound = scene->aggregate->WorldBound();
     // resolve each light's emitting triangle to its index in BVH order
     const auto &prims = scene->aggregate->primitives;

@@ -277,6 +277,8 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     }
     flat->materials = scene.materials;
     flat->bxdfs = scene.bxdfs;
+    flat->textures = scene.textures;
+    flat->textured = scene.textured;
     flat->lights = scene.lights;
     // Light::Preprocess (scene.h:57-60): DistantLight keeps the world's bounding sphere (distant.h:55-57, geometry.h:803-806)
     if (!flat->nodes.empty()) {
@@ -315,6 +317,8 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     d.n_perm_dims = (int)flat->permSums.size() - 1; d.perms = flat->perms.data(); d.perm_sums = flat->permSums.data();
     d.n_spheres = (int)flat->spheres.size(); d.spheres = flat->spheres.data();
     d.n_bxdfs = (int)flat->bxdfs.size(); d.bxdfs = flat->bxdfs.data();
+    d.n_textures = (int)flat->textures.size(); d.textures = flat->textures.data();
+    d.n_textured = (int)flat->textured.size(); d.textured = flat->textured.data();
 }
 
 void GpuPathIntegrator::FillRenderDesc(PgRenderDesc *rd) const {
@@ -324,6 +328,16 @@ void GpuPathIntegrator::FillRenderDesc(PgRenderDesc *rd) const {
     rd->camera_type = camera->environment ? 2 : (camera->orthographic ? 1 : 0);
     memcpy(rd->raster_to_camera, camera->RasterToCamera.GetMatrix().m, 16 * sizeof(float));
     memcpy(rd->camera_to_world, camera->CameraToWorld.GetMatrix().m, 16 * sizeof(float));
+    {  // dxCamera / dyCamera: perspective.cpp:60-63 (difference of two points), orthographic.cpp:57-58 (a transformed vector)
+        Vector3f dx, dy;
+        if (camera->orthographic) { dx = camera->RasterToCamera.Vec(Vector3f(1, 0, 0)); dy = camera->RasterToCamera.Vec(Vector3f(0, 1, 0)); }
+        else {
+            dx = camera->RasterToCamera.Pt(Point3f(1, 0, 0)) - camera->RasterToCamera.Pt(Point3f(0, 0, 0));
+            dy = camera->RasterToCamera.Pt(Point3f(0, 1, 0)) - camera->RasterToCamera.Pt(Point3f(0, 0, 0));
+        }
+        rd->dx_camera[0] = dx.x; rd->dx_camera[1] = dx.y; rd->dx_camera[2] = dx.z;
+        rd->dy_camera[0] = dy.x; rd->dy_camera[1] = dy.y; rd->dy_camera[2] = dy.z;
+    }
     rd->lens_radius = camera->lensRadius; rd->focal_distance = camera->focalDistance;
     rd->shutter_open = camera->shutterOpen; rd->shutter_close = camera->shutterClose;
     rd->full_res[0] = film.fullResolution[0]; rd->full_res[1] = film.fullResolution[1];

@@ -98,6 +98,8 @@ struct Scene {  // core/scene.h:50-80
     std::vector<PgLight> lights;
     std::vector<PgMaterial> materials;
     std::vector<PgBxDF> bxdfs;
+    std::vector<PgTexture> textures;
+    std::vector<PgTexturedMaterial> textured;
     Bounds3f worldBound;
 };
 
@@ -167,6 +169,8 @@ struct FlatScene {
     std::vector<PgBxDF> bxdfs;
     std::vector<PgObject> objects;
     std::vector<PgInstance> instances;
+    std::vector<PgTexture> textures;
+    std::vector<PgTexturedMaterial> textured;
 };
 
 // core/integrator.h:53-58.
