@@ -45,7 +45,7 @@ struct DeviceBuffer {
 struct PgScene {
     int device = 0;
     DScene d;
-    DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, triN, triS, uv, materials, lights, distTable, perms, permSums, primes;
+    DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, textures, textured, triN, triS, uv, materials, lights, distTable, perms, permSums, primes;
     // work buffers (sized on first render, reused)
     int capacity = 0;
     DeviceBuffer qo[4], qd[4], counts, hitsMain, hitInst, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
@@ -270,6 +270,44 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         HIP_TRY_S(buf.alloc(sizeof(float4) * a.size()));
         HIP_TRY_S(hipMemcpy(buf.p, a.data(), buf.bytes, hipMemcpyHostToDevice));
     }
+    {  // texture graph: operands are earlier nodes (no cycles), nesting <= 3 levels (the unrolled evaluator of pg_kernels.hip)
+        std::vector<int> depth((size_t)(desc->n_textures > 0 ? desc->n_textures : 0), 1);
+        auto refDepth = [&](const PgTexRef &r, int self) -> int { return r.tex < 0 ? 0 : ((r.tex >= self) ? 1000 : depth[r.tex]); };
+        for (int i = 0; i < (int)depth.size(); ++i) {
+            const PgTexture &t = desc->textures[i];
+            if (t.type < PG_TEX_SCALE || t.type > PG_TEX_BILERP) FAIL(PG_ERR_UNSUPPORTED, "texture %d: unknown type %d", i, t.type);
+            int dmax = std::max(refDepth(t.tex1, i), std::max(refDepth(t.tex2, i), refDepth(t.amount, i)));
+            if (dmax >= 1000) FAIL(PG_ERR_INVALID, "texture %d refers to a texture that is not defined before it", i);
+            depth[i] = 1 + dmax;
+            if (depth[i] > 3) FAIL(PG_ERR_UNSUPPORTED, "texture %d: operands nested %d deep (this build evaluates 3 levels)", i, depth[i]);
+        }
+        for (int i = 0; i < desc->n_textured; ++i) {
+            const PgTexturedMaterial &tm = desc->textured[i];
+            if (tm.kind < PG_KIND_MATTE || tm.kind > PG_KIND_MIX) FAIL(PG_ERR_UNSUPPORTED, "textured material %d: unknown kind %d", i, tm.kind);
+            for (int k = 0; k < 5; ++k) if (tm.s[k].tex >= desc->n_textures) FAIL(PG_ERR_INVALID, "textured material %d: texture %d out of range", i, tm.s[k].tex);
+            for (int k = 0; k < 4; ++k) if (tm.f[k].tex >= desc->n_textures) FAIL(PG_ERR_INVALID, "textured material %d: texture %d out of range", i, tm.f[k].tex);
+            if (tm.kind == PG_KIND_MIX) {
+                for (int j = 0; j < 2; ++j) {
+                    if (tm.sub[j] < 0 || tm.sub[j] >= desc->n_materials) FAIL(PG_ERR_INVALID, "textured material %d: mixed material %d out of range", i, tm.sub[j]);
+                    const PgMaterial &sm = desc->materials[tm.sub[j]];
+                    if (sm.type == PG_MAT_TEXTURED && sm.textured_index >= 0 && sm.textured_index < desc->n_textured && desc->textured[sm.textured_index].kind == PG_KIND_MIX) {
+                        const PgTexturedMaterial &t2 = desc->textured[sm.textured_index];
+                        for (int q = 0; q < 2; ++q)
+                            if (t2.sub[q] >= 0 && t2.sub[q] < desc->n_materials && desc->materials[t2.sub[q]].type == PG_MAT_TEXTURED)
+                                FAIL(PG_ERR_UNSUPPORTED, "textured material %d: textured mix materials nested more than two deep", i);
+                    }
+                }
+            }
+        }
+    }
+    if (desc->n_textures > 0 && desc->textures) {
+        HIP_TRY_S(s->textures.alloc(sizeof(PgTexture) * (size_t)desc->n_textures));
+        HIP_TRY_S(hipMemcpy(s->textures.p, desc->textures, s->textures.bytes, hipMemcpyHostToDevice));
+    }
+    if (desc->n_textured > 0 && desc->textured) {
+        HIP_TRY_S(s->textured.alloc(sizeof(PgTexturedMaterial) * (size_t)desc->n_textured));
+        HIP_TRY_S(hipMemcpy(s->textured.p, desc->textured, s->textured.bytes, hipMemcpyHostToDevice));
+    }
     if (desc->n_bxdfs > 0 && desc->bxdfs) {
         HIP_TRY_S(s->bxdfs.alloc(sizeof(PgBxDF) * (size_t)desc->n_bxdfs));
         HIP_TRY_S(hipMemcpy(s->bxdfs.p, desc->bxdfs, s->bxdfs.bytes, hipMemcpyHostToDevice));
@@ -285,13 +323,18 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         HIP_TRY_S(hipMemcpy(s->uv.p, uv.data(), s->uv.bytes, hipMemcpyHostToDevice));
     }
     // --- materials / lights
-    bool anyLobeMaterial = false;
+    bool anyLobeMaterial = false, anyTextured = false;
     for (int i = 0; i < desc->n_materials; ++i) {
         const PgMaterial &m = desc->materials[i];
         if (m.type == PG_MAT_NONE) s->hasNullMaterial = true;
         else if (m.type < PG_MAT_MATTE || m.type > PG_MAT_TEXTURED)
             FAIL(PG_ERR_UNSUPPORTED, "material %d: unknown type %d", i, m.type);
         if (m.type == PG_MAT_LOBES) anyLobeMaterial = true;
+        if (m.type == PG_MAT_TEXTURED) {
+            anyTextured = true;
+            if (m.textured_index < 0 || m.textured_index >= desc->n_textured || !desc->textured)
+                FAIL(PG_ERR_INVALID, "material %d: textured_index %d out of range", i, m.textured_index);
+        }
         if (m.n_bxdfs < 0 || m.n_bxdfs > PG_MAX_BXDFS || (m.n_bxdfs > 0 && (m.first_bxdf < 0 || m.first_bxdf + m.n_bxdfs > desc->n_bxdfs || !desc->bxdfs)))
             FAIL(PG_ERR_INVALID, "material %d: BxDF list [%d, +%d) is outside the scene's %d BxDFs", i, m.first_bxdf, m.n_bxdfs, desc->n_bxdfs);
         for (int j = 0; j < m.n_bxdfs; ++j) {
@@ -344,9 +387,11 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
 
     d.nodes = (const float4 *)s->nodes.p; d.tris = (const float4 *)s->tris.p; d.spheres = (const PgSphere *)s->spheres.p; d.nSpheres = desc->n_spheres > 0 ? desc->n_spheres : 0;
     d.bxdfs = (const PgBxDF *)s->bxdfs.p;
+    d.textures = (const PgTexture *)s->textures.p; d.textured = (const PgTexturedMaterial *)s->textured.p;
+    d.hasTextured = anyTextured ? 1 : 0;
     {  // PG_FORCE_EXT=1 runs the general kernels on scenes that do not need them (tests: both paths agree bit for bit)
         const char *fe = getenv("PG_FORCE_EXT");
-        d.ext = (d.nSpheres > 0 || d.nInstances > 0 || d.hasInfinite || anyLobeMaterial || (fe && atoi(fe) != 0)) ? 1 : 0;
+        d.ext = (d.hasTextured || d.nSpheres > 0 || d.nInstances > 0 || d.hasInfinite || anyLobeMaterial || (fe && atoi(fe) != 0)) ? 1 : 0;
     } d.uv = (const float *)s->uv.p;
     d.triN = (const float4 *)s->triN.p; d.triS = (const float4 *)s->triS.p;
     d.materials = (const PgMaterial *)s->materials.p; d.lights = (const PgLight *)s->lights.p;

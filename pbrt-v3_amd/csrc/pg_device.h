@@ -162,8 +162,8 @@ PG_DEV bool tri_test(V3 p0, V3 p1, V3 p2, V3 o, V3 dir, float tMax, float &t, fl
 // Whether Triangle::Intersect would reject every hit on this triangle as
 // "bogus" (shapes/triangle.cpp:293-317): degenerate uv parameterisation (or
 // zero dpdu x dpdv) AND zero geometric normal.  Also yields dpdu for shading.
-PG_HD bool tri_dpdu(V3 p0, V3 p1, V3 p2, const float uv[6], V3 &dpdu) {
-    V3 dpdv = mk(0, 0, 0);
+PG_HD bool tri_dpdu_dpdv(V3 p0, V3 p1, V3 p2, const float uv[6], V3 &dpdu, V3 &dpdv) {
+    dpdv = mk(0, 0, 0);
     dpdu = mk(0, 0, 0);
     float duv02x = uv[0] - uv[4], duv02y = uv[1] - uv[5];
     float duv12x = uv[2] - uv[4], duv12y = uv[3] - uv[5];
@@ -182,6 +182,7 @@ PG_HD bool tri_dpdu(V3 p0, V3 p1, V3 p2, const float uv[6], V3 &dpdu) {
     }
     return true;
 }
+PG_HD bool tri_dpdu(V3 p0, V3 p1, V3 p2, const float uv[6], V3 &dpdu) { V3 dpdv; return tri_dpdu_dpdv(p0, p1, p2, uv, dpdu, dpdv); }
 
 // Bounds3::IntersectP(ray, invDir, dirIsNeg), geometry.h:1412-1438.
 PG_DEV bool slab_test(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 o, V3 invDir, bool nx, bool ny,

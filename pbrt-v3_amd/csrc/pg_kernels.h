@@ -41,6 +41,9 @@ struct DScene {
     const DObject *objects;
     int nInstances;
     int *hitInst;  // per closest-hit result: the instance the hit primitive was reached through, or -1 (written by k_trace<.., true>)
+    const PgTexture *textures;           // texture nodes
+    const PgTexturedMaterial *textured;  // materials evaluated per hit (PG_MAT_TEXTURED)
+    int hasTextured;
     const PgBxDF *bxdfs;      // the materials' BxDF lists (PgMaterial.first_bxdf / n_bxdfs)
     int ext;          // the EXT shading kernels are needed: spheres, infinite lights or PG_MAT_LOBES materials (or PG_FORCE_EXT=1)
     int hasInfinite;  // some light is an InfiniteAreaLight (Scene::infiniteLights non-empty)
@@ -85,6 +88,7 @@ struct PathState {
 
 #define PG_META_SPECULAR 0x10000
 #define PG_META_DONE 0x20000
+#define PG_META_HASDIFF 0x80000  // the ray still is the camera's RayDifferential (cleared by the first SpawnRay)
 
 struct RenderParams {
     PgRenderDesc rd;

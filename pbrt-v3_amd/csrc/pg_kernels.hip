@@ -183,6 +183,99 @@ PG_DEV bool slot_to_pixel(const RenderParams &rp, int slot, int &px, int &py, in
     return px >= rp.rd.pixel_bounds[0] && px < rp.rd.pixel_bounds[2] && py >= rp.rd.pixel_bounds[1] && py < rp.rd.pixel_bounds[3];
 }
 
+// Camera::GenerateRay: PerspectiveCamera (perspective.cpp:95-115,141), OrthographicCamera (orthographic.cpp:68-93,115) and
+// EnvironmentCamera (environment.cpp:43-56), ending in CameraToWorld(ray).  (l0, l1) = CameraSample::pLens.
+PG_DEV void camera_ray(const PgRenderDesc &rd, float pFilmX, float pFilmY, float l0, float l1, V3 &o, V3 &d, float &tMax) {
+    V3 pCamera = xform_point(rd.raster_to_camera, mk(pFilmX, pFilmY, 0));
+    o = mk(0, 0, 0);
+    d = normalize(mk(pCamera.x, pCamera.y, pCamera.z));
+    tMax = PG_INF;
+    if (rd.camera_type == 1) { o = pCamera; d = mk(0, 0, 1); }  // OrthographicCamera, orthographic.cpp:76-78
+    if (rd.camera_type == 2) {  // EnvironmentCamera::GenerateRay, environment.cpp:43-56
+        const float theta = PG_PI * pFilmY / rd.full_res[1];
+        const float phi = 2 * PG_PI * pFilmX / rd.full_res[0];
+        double sT, cT, sP, cP;
+        sincos((double)theta, &sT, &cT);
+        sincos((double)phi, &sP, &cP);
+        o = mk(0, 0, 0);
+        d = mk((float)sT * (float)cP, (float)cT, (float)sT * (float)sP);
+    }
+    if (rd.lens_radius > 0) {
+        float lx, ly;
+        concentric_sample_disk(l0, l1, lx, ly);
+        lx = rd.lens_radius * lx; ly = rd.lens_radius * ly;
+        float ft = rd.focal_distance / d.z;
+        V3 pFocus = o + d * ft;
+        o = mk(lx, ly, 0);
+        d = normalize(pFocus - o);
+    }
+    xform_ray(rd.camera_to_world, o, d, tMax);
+}
+// The camera ray's differentials (GenerateRayDifferential: perspective.cpp:117-140, orthographic.cpp:95-113, the finite
+// difference of camera.cpp:52-93 for the environment camera), carried to world space (transform.h:264-273) and scaled by
+// 1 / sqrt(spp) (integrator.cpp:282-283, geometry.h:908-913).  (o, d) = the world-space camera ray.
+PG_DEV void camera_differentials(const PgRenderDesc &rd, float pFilmX, float pFilmY, float l0, float l1, V3 o, V3 d, V3 &rxO, V3 &rxD, V3 &ryO, V3 &ryD) {
+    if (rd.camera_type == 2) {
+        const float eps = .05f;
+        V3 xo, xd, yo, yd;
+        float tm;
+        camera_ray(rd, pFilmX + eps, pFilmY, l0, l1, xo, xd, tm);
+        camera_ray(rd, pFilmX, pFilmY + eps, l0, l1, yo, yd, tm);
+        rxO = o + vdiv(xo - o, eps); rxD = d + vdiv(xd - d, eps);
+        ryO = o + vdiv(yo - o, eps); ryD = d + vdiv(yd - d, eps);
+    } else {
+        const V3 dxCamera = mk(rd.dx_camera[0], rd.dx_camera[1], rd.dx_camera[2]), dyCamera = mk(rd.dy_camera[0], rd.dy_camera[1], rd.dy_camera[2]);
+        const V3 pCamera = xform_point(rd.raster_to_camera, mk(pFilmX, pFilmY, 0));
+        V3 co = mk(0, 0, 0), cd = normalize(mk(pCamera.x, pCamera.y, pCamera.z));  // the camera-space main ray again
+        if (rd.camera_type == 1) { co = pCamera; cd = mk(0, 0, 1); }
+        float lx = 0, ly = 0;
+        if (rd.lens_radius > 0) {
+            concentric_sample_disk(l0, l1, lx, ly);
+            lx = rd.lens_radius * lx; ly = rd.lens_radius * ly;
+            const float ft = rd.focal_distance / cd.z;
+            const V3 pFocus = co + cd * ft;
+            co = mk(lx, ly, 0);
+            cd = normalize(pFocus - co);
+        }
+        if (rd.camera_type == 0) {
+            if (rd.lens_radius > 0) {
+                const V3 dx = normalize(pCamera + dxCamera);
+                float ft = rd.focal_distance / dx.z;
+                V3 pFocus = mk(0, 0, 0) + dx * ft;
+                rxO = mk(lx, ly, 0);
+                rxD = normalize(pFocus - rxO);
+                const V3 dy = normalize(pCamera + dyCamera);
+                ft = rd.focal_distance / dy.z;
+                pFocus = mk(0, 0, 0) + dy * ft;
+                ryO = mk(lx, ly, 0);
+                ryD = normalize(pFocus - ryO);
+            } else {
+                rxO = ryO = co;
+                rxD = normalize(pCamera + dxCamera);
+                ryD = normalize(pCamera + dyCamera);
+            }
+        } else {
+            if (rd.lens_radius > 0) {
+                const float ft = rd.focal_distance / cd.z;
+                V3 pFocus = (pCamera + dxCamera) + mk(0, 0, 1) * ft;
+                rxO = mk(lx, ly, 0);
+                rxD = normalize(pFocus - rxO);
+                pFocus = (pCamera + dyCamera) + mk(0, 0, 1) * ft;
+                ryO = mk(lx, ly, 0);
+                ryD = normalize(pFocus - ryO);
+            } else {
+                rxO = co + dxCamera;
+                ryO = co + dyCamera;
+                rxD = ryD = cd;
+            }
+        }
+        rxO = xform_point(rd.camera_to_world, rxO); ryO = xform_point(rd.camera_to_world, ryO);
+        rxD = m4_vec(rd.camera_to_world, rxD); ryD = m4_vec(rd.camera_to_world, ryD);
+    }
+    const float sc = 1 / sqrtf((float)rd.spp);
+    rxO = o + (rxO - o) * sc; ryO = o + (ryO - o) * sc;
+    rxD = d + (rxD - d) * sc; ryD = d + (ryD - d) * sc;
+}
 __global__ __launch_bounds__(PG_BLOCK) void k_generate(DScene sc, RenderParams rp, PathState st, RayQueue q) {
     int slot = blockIdx.x * PG_BLOCK + threadIdx.x;
     bool valid = slot < rp.capacity;
@@ -196,33 +289,12 @@ __global__ __launch_bounds__(PG_BLOCK) void k_generate(DScene sc, RenderParams r
         // GetCameraSample, sampler.cpp:46-52: dims 0,1 film; 2 time; 3,4 lens
         float u0 = halton_sample(sc, rd, index, 0), u1 = halton_sample(sc, rd, index, 1);
         float pFilmX = (float)px + u0, pFilmY = (float)py + u1;
-        // GenerateRayDifferential, perspective.cpp:95-144 (differentials feed only texture filtering; textures are constant)
-        V3 pCamera = xform_point(rd.raster_to_camera, mk(pFilmX, pFilmY, 0));
-        d = normalize(mk(pCamera.x, pCamera.y, pCamera.z));
-        if (rd.camera_type == 1) { o = pCamera; d = mk(0, 0, 1); }  // OrthographicCamera, orthographic.cpp:76-78
-        if (rd.camera_type == 2) {  // EnvironmentCamera::GenerateRay, environment.cpp:43-56
-            const float theta = PG_PI * pFilmY / rd.full_res[1];
-            const float phi = 2 * PG_PI * pFilmX / rd.full_res[0];
-            double sT, cT, sP, cP;
-            sincos((double)theta, &sT, &cT);
-            sincos((double)phi, &sP, &cP);
-            o = mk(0, 0, 0);
-            d = mk((float)sT * (float)cP, (float)cT, (float)sT * (float)sP);
-        }
-        if (rd.lens_radius > 0) {
-            float l0 = halton_sample(sc, rd, index, 3), l1 = halton_sample(sc, rd, index, 4);
-            float lx, ly;
-            concentric_sample_disk(l0, l1, lx, ly);
-            lx = rd.lens_radius * lx; ly = rd.lens_radius * ly;
-            float ft = rd.focal_distance / d.z;
-            V3 pFocus = o + d * ft;
-            o = mk(lx, ly, 0);
-            d = normalize(pFocus - o);
-        }
-        xform_ray(rd.camera_to_world, o, d, tMax);
+        float l0 = 0, l1 = 0;
+        if (rd.lens_radius > 0) { l0 = halton_sample(sc, rd, index, 3); l1 = halton_sample(sc, rd, index, 4); }
+        camera_ray(rd, pFilmX, pFilmY, l0, l1, o, d, tMax);
         st.L[slot] = make_float4(0, 0, 0, pFilmX);
         st.beta[slot] = make_float4(1, 1, 1, pFilmY);
-        st.meta[slot] = make_int4((int)(uint32_t)index, (int)(uint32_t)(index >> 32), __float_as_int(1.f), 5 << 20);
+        st.meta[slot] = make_int4((int)(uint32_t)index, (int)(uint32_t)(index >> 32), __float_as_int(1.f), (5 << 20) | PG_META_HASDIFF);
     } else if (slot < rp.capacity) {
         st.L[slot] = make_float4(0, 0, 0, 0);
         st.meta[slot] = make_int4(0, 0, 0, PG_META_DONE | 0x40000);  // 0x40000: slot holds no sample
@@ -867,6 +939,303 @@ PG_DEV Spec lbsdf_sample_f(const LobeBsdf &b, V3 woWorld, V3 &wiWorld, float u0,
     return f;
 }
 
+#define PG_INV2PI 0.15915494309189533577f
+PG_DEV float spherical_theta(V3 v) { return (float)acos((double)clampf(v.z, -1, 1)); }  // geometry.h:1468-1470
+PG_DEV float spherical_phi(V3 v) { float p = (float)atan2((double)v.y, (double)v.x); return (p < 0) ? (p + 2 * PG_PI) : p; }  // :1472-1475
+// ===========================================================================
+// Textures (core/texture.{h,cpp}, textures/{scale,mix,checkerboard,uv,bilerp}.h) and the per-hit evaluation of a textured
+// material's ComputeScatteringFunctions.  Texture nodes reference their operands; the nesting is unrolled over a template
+// depth (PG_TEX_DEPTH levels, the host front end refuses deeper graphs) so the call graph has no recursion.
+// ===========================================================================
+#define PG_TEX_DEPTH 3
+#define PG_DEV_CALL __device__ __noinline__
+struct TexHit { V3 p, dpdx, dpdy; float u, v, dudx, dvdx, dudy, dvdy; };
+PG_DEV void tex_sphere(const PgTexture &t, V3 p, float &s0, float &s1) {  // SphericalMapping2D::sphere, texture.cpp:122-127
+    const V3 vec = normalize(m4_point(t.w2t, p) - mk(0, 0, 0));
+    const float theta = spherical_theta(vec), phi = spherical_phi(vec);
+    s0 = theta * PG_INVPI; s1 = phi * PG_INV2PI;
+}
+PG_DEV void tex_cylinder(const PgTexture &t, V3 p, float &s0, float &s1) {  // CylindricalMapping2D::cylinder, texture.h:93-96
+    const V3 vec = normalize(m4_point(t.w2t, p) - mk(0, 0, 0));
+    s0 = (PG_PI + (float)atan2((double)vec.y, (double)vec.x)) * PG_INV2PI; s1 = vec.z;
+}
+PG_DEV void tex_map2d(const PgTexture &t, const TexHit &h, float st[2], float dstdx[2], float dstdy[2]) {
+    if (t.mapping == PG_MAP_UV) {  // UVMapping2D::Map, texture.cpp:93-100
+        dstdx[0] = t.su * h.dudx; dstdx[1] = t.sv * h.dvdx;
+        dstdy[0] = t.su * h.dudy; dstdy[1] = t.sv * h.dvdy;
+        st[0] = t.su * h.u + t.du; st[1] = t.sv * h.v + t.dv;
+    } else if (t.mapping == PG_MAP_PLANAR) {  // PlanarMapping2D::Map, texture.cpp:150-157
+        const V3 vs = mk(t.vs[0], t.vs[1], t.vs[2]), vt = mk(t.vt[0], t.vt[1], t.vt[2]);
+        dstdx[0] = dot(h.dpdx, vs); dstdx[1] = dot(h.dpdx, vt);
+        dstdy[0] = dot(h.dpdy, vs); dstdy[1] = dot(h.dpdy, vt);
+        st[0] = t.du + dot(h.p, vs); st[1] = t.dv + dot(h.p, vt);
+    } else {  // SphericalMapping2D::Map (texture.cpp:102-120) / CylindricalMapping2D::Map (:129-148)
+        const bool sph = t.mapping == PG_MAP_SPHERICAL;
+        const float delta = sph ? .1f : .01f;
+        float sx0, sx1, sy0, sy1;
+        if (sph) { tex_sphere(t, h.p, st[0], st[1]); tex_sphere(t, h.p + h.dpdx * delta, sx0, sx1); tex_sphere(t, h.p + h.dpdy * delta, sy0, sy1); }
+        else { tex_cylinder(t, h.p, st[0], st[1]); tex_cylinder(t, h.p + h.dpdx * delta, sx0, sx1); tex_cylinder(t, h.p + h.dpdy * delta, sy0, sy1); }
+        const float inv = 1.f / delta;
+        dstdx[0] = (sx0 - st[0]) * inv; dstdx[1] = (sx1 - st[1]) * inv;
+        dstdy[0] = (sy0 - st[0]) * inv; dstdy[1] = (sy1 - st[1]) * inv;
+        if ((double)dstdx[1] > .5) dstdx[1] = 1 - dstdx[1];
+        else if (dstdx[1] < -.5f) dstdx[1] = -(dstdx[1] + 1);
+        if ((double)dstdy[1] > .5) dstdy[1] = 1 - dstdy[1];
+        else if (dstdy[1] < -.5f) dstdy[1] = -(dstdy[1] + 1);
+    }
+}
+PG_DEV float tex_bump_int(float x) {  // checkerboard.h:92-96
+    return (float)(int)floorf(x / 2) + 2 * pmax(x / 2 - (float)(int)floorf(x / 2) - 0.5f, 0.f);
+}
+// Checkerboard2DTexture::Evaluate up to the choice / blend of its operands: which = 0 (tex1), 1 (tex2), 2 (blend by area2)
+PG_DEV int tex_checker2d(const PgTexture &t, const TexHit &h, float &area2) {
+    float st[2], dstdx[2], dstdy[2];
+    tex_map2d(t, h, st, dstdx, dstdy);
+    const int point = (((int)floorf(st[0]) + (int)floorf(st[1])) % 2 == 0) ? 0 : 1;
+    if (t.aa_none) return point;
+    const float ds = pmax(fabsf(dstdx[0]), fabsf(dstdy[0]));
+    const float dt = pmax(fabsf(dstdx[1]), fabsf(dstdy[1]));
+    const float s0 = st[0] - ds, s1 = st[0] + ds;
+    const float t0 = st[1] - dt, t1 = st[1] + dt;
+    if (floorf(s0) == floorf(s1) && floorf(t0) == floorf(t1)) return point;
+    const float sint = (tex_bump_int(s1) - tex_bump_int(s0)) / (2 * ds);
+    const float tint = (tex_bump_int(t1) - tex_bump_int(t0)) / (2 * dt);
+    area2 = sint + tint - 2 * sint * tint;
+    if (ds > 1 || dt > 1) area2 = .5f;
+    return 2;
+}
+PG_DEV int tex_checker3d(const PgTexture &t, const TexHit &h) {  // checkerboard.h:120-129, IdentityMapping3D texture.cpp:159-164
+    const V3 p = m4_point(t.w2t, h.p);
+    return (((int)floorf(p.x) + (int)floorf(p.y) + (int)floorf(p.z)) % 2 == 0) ? 0 : 1;
+}
+template <int D> struct TexEval {
+    static PG_DEV_CALL float f(const DScene &sc, const PgTexRef &r, const TexHit &h) {
+        if (r.tex < 0) return r.v[0];
+        const PgTexture &t = sc.textures[r.tex];
+        switch (t.type) {
+        case PG_TEX_SCALE: return TexEval<D - 1>::f(sc, t.tex1, h) * TexEval<D - 1>::f(sc, t.tex2, h);  // scale.h:58-60
+        case PG_TEX_MIX: {  // mix.h:57-61
+            const float t1 = TexEval<D - 1>::f(sc, t.tex1, h), t2 = TexEval<D - 1>::f(sc, t.tex2, h);
+            const float amt = TexEval<D - 1>::f(sc, t.amount, h);
+            return (1 - amt) * t1 + amt * t2;
+        }
+        case PG_TEX_BILERP: {  // bilerp.h:56-61
+            float st[2], dx[2], dy[2];
+            tex_map2d(t, h, st, dx, dy);
+            return (1 - st[0]) * (1 - st[1]) * t.v00[0] + (1 - st[0]) * (st[1]) * t.v01[0] + (st[0]) * (1 - st[1]) * t.v10[0] + (st[0]) * (st[1]) * t.v11[0];
+        }
+        case PG_TEX_CHECKERBOARD_3D: return tex_checker3d(t, h) == 0 ? TexEval<D - 1>::f(sc, t.tex1, h) : TexEval<D - 1>::f(sc, t.tex2, h);
+        case PG_TEX_CHECKERBOARD_2D: {  // checkerboard.h:63-103
+            float area2 = 0;
+            const int which = tex_checker2d(t, h, area2);
+            if (which == 0) return TexEval<D - 1>::f(sc, t.tex1, h);
+            if (which == 1) return TexEval<D - 1>::f(sc, t.tex2, h);
+            return (1 - area2) * TexEval<D - 1>::f(sc, t.tex1, h) + area2 * TexEval<D - 1>::f(sc, t.tex2, h);
+        }
+        }
+        return 0;
+    }
+    static PG_DEV_CALL Spec s(const DScene &sc, const PgTexRef &r, const TexHit &h) {
+        if (r.tex < 0) return sp3(r.v[0], r.v[1], r.v[2]);
+        const PgTexture &t = sc.textures[r.tex];
+        switch (t.type) {
+        case PG_TEX_SCALE: return TexEval<D - 1>::s(sc, t.tex1, h) * TexEval<D - 1>::s(sc, t.tex2, h);
+        case PG_TEX_MIX: {
+            const Spec t1 = TexEval<D - 1>::s(sc, t.tex1, h), t2 = TexEval<D - 1>::s(sc, t.tex2, h);
+            const float amt = TexEval<D - 1>::f(sc, t.amount, h);
+            return t1 * (1 - amt) + t2 * amt;
+        }
+        case PG_TEX_UV: {  // uv.h:54-60
+            float st[2], dx[2], dy[2];
+            tex_map2d(t, h, st, dx, dy);
+            return sp3(st[0] - floorf(st[0]), st[1] - floorf(st[1]), 0);
+        }
+        case PG_TEX_BILERP: {
+            float st[2], dx[2], dy[2];
+            tex_map2d(t, h, st, dx, dy);
+            return sp_of(t.v00) * ((1 - st[0]) * (1 - st[1])) + sp_of(t.v01) * ((1 - st[0]) * (st[1])) + sp_of(t.v10) * ((st[0]) * (1 - st[1])) +
+                   sp_of(t.v11) * ((st[0]) * (st[1]));
+        }
+        case PG_TEX_CHECKERBOARD_3D: return tex_checker3d(t, h) == 0 ? TexEval<D - 1>::s(sc, t.tex1, h) : TexEval<D - 1>::s(sc, t.tex2, h);
+        case PG_TEX_CHECKERBOARD_2D: {
+            float area2 = 0;
+            const int which = tex_checker2d(t, h, area2);
+            if (which == 0) return TexEval<D - 1>::s(sc, t.tex1, h);
+            if (which == 1) return TexEval<D - 1>::s(sc, t.tex2, h);
+            return TexEval<D - 1>::s(sc, t.tex1, h) * (1 - area2) + TexEval<D - 1>::s(sc, t.tex2, h) * area2;
+        }
+        }
+        return sp(0);
+    }
+};
+template <> struct TexEval<0> {  // the innermost level: operands must be constants (the host front end enforces the depth)
+    static PG_DEV float f(const DScene &, const PgTexRef &r, const TexHit &) { return r.v[0]; }
+    static PG_DEV Spec s(const DScene &, const PgTexRef &r, const TexHit &) { return sp3(r.v[0], r.v[1], r.v[2]); }
+};
+PG_DEV Spec sp_clamp0(Spec v) { return sp3(v.r < 0 ? 0 : v.r, v.g < 0 ? 0 : v.g, v.b < 0 ? 0 : v.b); }  // Spectrum::Clamp()
+PG_DEV void lobe_init(PgBxDF &b, int type) {
+    b.type = type; b.fresnel = PG_FRESNEL_NOOP; b.eta_a = b.eta_b = 1; b.alpha_x = b.alpha_y = 1; b.on_a = 1; b.on_b = 0; b.n_scales = 0;
+    for (int i = 0; i < 3; ++i) { b.R[i] = b.T[i] = b.cond_eta[i] = b.cond_k[i] = 0; }
+}
+PG_DEV void lobe_set(float *dst, Spec v) { dst[0] = v.r; dst[1] = v.g; dst[2] = v.b; }
+PG_DEV float roughness_to_alpha(float roughness) {  // microfacet.h:127-132; std::log evaluated in double, rounded once
+    roughness = pmax(roughness, 1e-3f);
+    const float x = (float)log((double)roughness);
+    return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+}
+PG_DEV void lobe_tr(PgBxDF &b, float ax, float ay) { b.alpha_x = pmax(0.001f, ax); b.alpha_y = pmax(0.001f, ay); }  // microfacet.h:109-113
+// Material::ComputeScatteringFunctions of material `mat` at this hit (materials/): appends its BxDFs to out[n...]; eta receives
+// BSDF::eta.  D bounds the nesting of mix materials.
+template <int D> struct MatEval {
+    static PG_DEV_CALL void run(const DScene &sc, int mat, const TexHit &h, PgBxDF *out, int &n, float &eta) {
+        const PgMaterial &m = sc.materials[mat];
+        if (m.type != PG_MAT_TEXTURED) {  // constant parameters: the list the host built
+            for (int i = 0; i < m.n_bxdfs && n < PG_MAX_BXDFS; ++i) out[n++] = sc.bxdfs[m.first_bxdf + i];
+            eta = m.bsdf_eta;
+            return;
+        }
+        const PgTexturedMaterial &tm = sc.textured[m.textured_index];
+        auto TS = [&](int i) { return TexEval<PG_TEX_DEPTH>::s(sc, tm.s[i], h); };
+        auto TF = [&](int i) { return TexEval<PG_TEX_DEPTH>::f(sc, tm.f[i], h); };
+        auto push = [&](const PgBxDF &b) { if (n < PG_MAX_BXDFS) out[n++] = b; };
+        PgBxDF b;
+        eta = 1;
+        switch (tm.kind) {
+        case PG_KIND_MATTE: {  // matte.cpp:45-62
+            const Spec r = sp_clamp0(TS(0));
+            const float sig = clampf(TF(0), 0, 90);
+            if (!is_black(r)) {
+                lobe_init(b, sig == 0 ? PG_BXDF_LAMBERT_R : PG_BXDF_OREN_NAYAR);
+                lobe_set(b.R, r);
+                if (sig != 0) {
+                    const float sigma = (PG_PI / 180) * sig, sigma2 = sigma * sigma;
+                    b.on_a = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
+                    b.on_b = 0.45f * sigma2 / (sigma2 + 0.09f);
+                }
+                push(b);
+            }
+            break;
+        }
+        case PG_KIND_PLASTIC: {  // plastic.cpp:45-70
+            const Spec kd = sp_clamp0(TS(0));
+            if (!is_black(kd)) { lobe_init(b, PG_BXDF_LAMBERT_R); lobe_set(b.R, kd); push(b); }
+            const Spec ks = sp_clamp0(TS(1));
+            if (!is_black(ks)) {
+                lobe_init(b, PG_BXDF_MICROFACET_R); lobe_set(b.R, ks);
+                b.fresnel = PG_FRESNEL_DIELECTRIC; b.eta_a = 1.5f; b.eta_b = 1.f;
+                float rough = TF(0);
+                if (tm.remap_roughness) rough = roughness_to_alpha(rough);
+                lobe_tr(b, rough, rough);
+                push(b);
+            }
+            break;
+        }
+        case PG_KIND_MIRROR: {  // mirror.cpp:44-56
+            const Spec R = sp_clamp0(TS(0));
+            if (!is_black(R)) { lobe_init(b, PG_BXDF_SPECULAR_R); lobe_set(b.R, R); push(b); }
+            break;
+        }
+        case PG_KIND_GLASS: {  // glass.cpp:45-96
+            const float e = TF(2);
+            float urough = TF(0), vrough = TF(1);
+            const Spec R = sp_clamp0(TS(0)), T = sp_clamp0(TS(1));
+            eta = e;
+            if (is_black(R) && is_black(T)) break;
+            if (urough == 0 && vrough == 0) { lobe_init(b, PG_BXDF_FRESNEL_SPECULAR); lobe_set(b.R, R); lobe_set(b.T, T); b.eta_a = 1.f; b.eta_b = e; push(b); }
+            else {
+                if (tm.remap_roughness) { urough = roughness_to_alpha(urough); vrough = roughness_to_alpha(vrough); }
+                if (!is_black(R)) { lobe_init(b, PG_BXDF_MICROFACET_R); lobe_set(b.R, R); b.fresnel = PG_FRESNEL_DIELECTRIC; b.eta_a = 1.f; b.eta_b = e; lobe_tr(b, urough, vrough); push(b); }
+                if (!is_black(T)) { lobe_init(b, PG_BXDF_MICROFACET_T); lobe_set(b.T, T); b.eta_a = 1.f; b.eta_b = e; lobe_tr(b, urough, vrough); push(b); }
+            }
+            break;
+        }
+        case PG_KIND_UBER: {  // uber.cpp:45-101
+            const float e = TF(3);
+            const Spec op = sp_clamp0(TS(4));
+            const Spec t = sp_clamp0(op * -1.f + sp(1.f));
+            if (!is_black(t)) { lobe_init(b, PG_BXDF_SPECULAR_T); lobe_set(b.T, t); push(b); eta = 1.f; }
+            else eta = e;
+            const Spec kd = op * sp_clamp0(TS(0));
+            if (!is_black(kd)) { lobe_init(b, PG_BXDF_LAMBERT_R); lobe_set(b.R, kd); push(b); }
+            const Spec ks = op * sp_clamp0(TS(1));
+            if (!is_black(ks)) {
+                float roughu = tm.has_u ? TF(1) : TF(0);
+                float roughv = tm.has_v ? TF(2) : roughu;
+                if (tm.remap_roughness) { roughu = roughness_to_alpha(roughu); roughv = roughness_to_alpha(roughv); }
+                lobe_init(b, PG_BXDF_MICROFACET_R); lobe_set(b.R, ks); b.fresnel = PG_FRESNEL_DIELECTRIC; b.eta_a = 1.f; b.eta_b = e; lobe_tr(b, roughu, roughv);
+                push(b);
+            }
+            const Spec kr = op * sp_clamp0(TS(2));
+            if (!is_black(kr)) { lobe_init(b, PG_BXDF_SPECULAR_R); lobe_set(b.R, kr); b.fresnel = PG_FRESNEL_DIELECTRIC; b.eta_a = 1.f; b.eta_b = e; push(b); }
+            const Spec kt = op * sp_clamp0(TS(3));
+            if (!is_black(kt)) { lobe_init(b, PG_BXDF_SPECULAR_T); lobe_set(b.T, kt); b.eta_a = 1.f; b.eta_b = e; push(b); }
+            break;
+        }
+        case PG_KIND_METAL: {  // metal.cpp:61-82
+            float uRough = tm.has_u ? TF(1) : TF(0);
+            float vRough = tm.has_v ? TF(2) : TF(0);
+            if (tm.remap_roughness) { uRough = roughness_to_alpha(uRough); vRough = roughness_to_alpha(vRough); }
+            lobe_init(b, PG_BXDF_MICROFACET_R);
+            lobe_set(b.R, sp(1.f));
+            b.fresnel = PG_FRESNEL_CONDUCTOR;
+            lobe_set(b.cond_eta, TS(0)); lobe_set(b.cond_k, TS(1));
+            lobe_tr(b, uRough, vRough);
+            push(b);
+            break;
+        }
+        case PG_KIND_SUBSTRATE: {  // substrate.cpp:45-65
+            const Spec d = sp_clamp0(TS(0)), s2 = sp_clamp0(TS(1));
+            float roughu = TF(0), roughv = TF(1);
+            if (!is_black(d) || !is_black(s2)) {
+                if (tm.remap_roughness) { roughu = roughness_to_alpha(roughu); roughv = roughness_to_alpha(roughv); }
+                lobe_init(b, PG_BXDF_FRESNEL_BLEND); lobe_set(b.R, d); lobe_set(b.T, s2); lobe_tr(b, roughu, roughv); push(b);
+            }
+            break;
+        }
+        case PG_KIND_TRANSLUCENT: {  // translucent.cpp:45-80
+            const float e = 1.5f;
+            eta = e;
+            const Spec r = sp_clamp0(TS(2)), t = sp_clamp0(TS(3));
+            if (is_black(r) && is_black(t)) break;
+            const Spec kd = sp_clamp0(TS(0));
+            if (!is_black(kd)) {
+                if (!is_black(r)) { lobe_init(b, PG_BXDF_LAMBERT_R); lobe_set(b.R, r * kd); push(b); }
+                if (!is_black(t)) { lobe_init(b, PG_BXDF_LAMBERT_T); lobe_set(b.T, t * kd); push(b); }
+            }
+            const Spec ks = sp_clamp0(TS(1));
+            if (!is_black(ks) && (!is_black(r) || !is_black(t))) {
+                float rough = TF(0);
+                if (tm.remap_roughness) rough = roughness_to_alpha(rough);
+                if (!is_black(r)) { lobe_init(b, PG_BXDF_MICROFACET_R); lobe_set(b.R, r * ks); b.fresnel = PG_FRESNEL_DIELECTRIC; b.eta_a = 1.f; b.eta_b = e; lobe_tr(b, rough, rough); push(b); }
+                if (!is_black(t)) { lobe_init(b, PG_BXDF_MICROFACET_T); lobe_set(b.T, t * ks); b.eta_a = 1.f; b.eta_b = e; lobe_tr(b, rough, rough); push(b); }
+            }
+            break;
+        }
+        case PG_KIND_MIX: {  // mixmat.cpp:45-65
+            const Spec s1 = sp_clamp0(TS(0));
+            const Spec s2 = sp_clamp0(sp(1.f) - s1);
+            for (int j = 0; j < 2; ++j) {
+                const int first = n;
+                float subEta = 1;
+                MatEval<D - 1>::run(sc, tm.sub[j], h, out, n, subEta);
+                if (j == 0) eta = subEta;  // si->bsdf stays m1's
+                const Spec scl = j == 0 ? s1 : s2;
+                for (int i = first; i < n; ++i)
+                    if (out[i].n_scales < PG_MAX_BXDF_SCALES) { lobe_set(out[i].scale[out[i].n_scales], scl); out[i].n_scales++; }
+            }
+            break;
+        }
+        }
+    }
+};
+template <> struct MatEval<0> {  // below the deepest mix the host allows: only constant-parameter materials
+    static PG_DEV void run(const DScene &sc, int mat, const TexHit &, PgBxDF *out, int &n, float &eta) {
+        const PgMaterial &m = sc.materials[mat];
+        for (int i = 0; i < m.n_bxdfs && n < PG_MAX_BXDFS; ++i) out[n++] = sc.bxdfs[m.first_bxdf + i];
+        eta = m.bsdf_eta;
+    }
+};
+
 struct LightSample { V3 p, n, pError; };
 // SpotLight::Falloff, spot.cpp:62-72
 PG_DEV float spot_falloff(const PgLight &l, V3 w) {
@@ -990,9 +1359,6 @@ PG_DEV Spec env_lookup(const PgLight &l, float s0_, float t0_) {  // MIPMap::Loo
     r = r + L * (ds * dt);
     return r;
 }
-#define PG_INV2PI 0.15915494309189533577f
-PG_DEV float spherical_theta(V3 v) { return (float)acos((double)clampf(v.z, -1, 1)); }  // geometry.h:1468-1470
-PG_DEV float spherical_phi(V3 v) { float p = (float)atan2((double)v.y, (double)v.x); return (p < 0) ? (p + 2 * PG_PI) : p; }  // :1472-1475
 PG_DEV Spec env_le(const PgLight &l, V3 rayD) {  // InfiniteAreaLight::Le, infinite.cpp:93-97
     V3 w = normalize(mat3_mul(l.w2l, rayD));
     return env_lookup(l, spherical_phi(w) * PG_INV2PI, spherical_theta(w) * PG_INVPI);
@@ -1126,9 +1492,12 @@ PG_DEV int sample_discrete(const float *tab, int n, float u, float &pdf) {
 
 PG_DEV void spawn_ray(const Isect &is, V3 d, V3 &o) { o = offset_ray_origin(is.p, is.pError, is.n, d); }  // interaction.h:64-67
 
-template <bool EXT>
+// MODE 0: triangles + matte/plastic/mirror/glass + area and delta lights (specialised BSDF).  MODE 1 (EXT): any material as
+// its BxDF list, quadrics, object instances, infinite lights.  MODE 2: MODE 1 + textured materials, evaluated per hit.
+template <int MODE>
 __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
                                                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests) {
+    constexpr bool EXT = MODE >= 1, TEX = MODE == 2;
     const int i = queue_item(qin);
     const bool valid = i >= 0;
     // Output rays are staged in LDS ([queue][o|d][thread]) the moment they are known and copied to their queues after the
@@ -1166,6 +1535,8 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
         Tri tri;
         if (found) tri = load_tri(sc, prim);
         Isect is;
+        float sphU = 0, sphV = 0;  // MODE 2: a quadric hit's (u, v) and geometric dpdu / dpdv, for textures
+        V3 sphDpdu = mk(0, 0, 0), sphDpdv = mk(0, 0, 0);
         const bool onSphere = EXT && found && (tri.flags & PG_PRIM_SPHERE);
         // a hit reached through an object instance was computed on the instance-space ray (primitive.cpp:80-82)
         const int inst = (EXT && found && sc.hitInst) ? sc.hitInst[i] : -1;
@@ -1177,6 +1548,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
             if (inst >= 0) { float dt; instance_ray(sc.instances[inst].w2i, shapeRayO, rayD, shapeRayO, shapeRayD, dt); }
             const SphereHit sh = sphere_interaction(sc.spheres[__float_as_int(tri.p0.x)], shapeRayO, shapeRayD, h4.y);
             is.p = sh.p; is.pError = sh.pError; is.wo = sh.wo; is.n = sh.n; is.ns = sh.n; is.sdpdu = sh.dpdu;
+            if (TEX) { sphU = sh.u; sphV = sh.v; sphDpdu = sh.dpdu; sphDpdv = sh.dpdv; }
         }
         // path.cpp:91-102 emitted light at the vertex
         if ((bounces == 0 || specularBounce) && found && tri.light >= 0) {
@@ -1217,11 +1589,64 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                 // shapes of matte / plastic / mirror / glass baked in (same arithmetic, fewer registers)
                 Bsdf bsdf;
                 LobeBsdf lb;
+                PgBxDF lobeStore[TEX ? PG_MAX_BXDFS : 1];  // MODE 2: this hit's BxDF list (ComputeScatteringFunctions with textures)
                 if constexpr (EXT) {
                     lb.ns = is.ns; lb.ng = is.n;
                     lb.ss = normalize(is.sdpdu);
                     lb.ts = cross(lb.ns, lb.ss);
-                    lb.lobes = sc.bxdfs + m.first_bxdf; lb.n = m.n_bxdfs; lb.eta = m.bsdf_eta;
+                    if constexpr (TEX) {
+                        // what textures read of the SurfaceInteraction: (u, v), p and ComputeDifferentials' outputs
+                        TexHit th;
+                        th.p = is.p;
+                        V3 gdpdu, gdpdv;  // the geometric dpdu / dpdv (not the shading ones)
+                        if (onSphere) { th.u = sphU; th.v = sphV; gdpdu = sphDpdu; gdpdv = sphDpdv; }
+                        else {
+                            float uv[6];
+                            load_uv(sc, prim, tri.flags, uv);
+                            tri_dpdu_dpdv(tri.p0, tri.p1, tri.p2, uv, gdpdu, gdpdv);
+                            th.u = h4.y * uv[0] + h4.z * uv[2] + h4.w * uv[4];  // uvHit, triangle.cpp:332
+                            th.v = h4.y * uv[1] + h4.z * uv[3] + h4.w * uv[5];
+                        }
+                        if (inst >= 0 && !sc.instances[inst].identity) { gdpdu = m4_vec(sc.instances[inst].i2w, gdpdu); gdpdv = m4_vec(sc.instances[inst].i2w, gdpdv); }
+                        th.dpdx = th.dpdy = mk(0, 0, 0);
+                        th.dudx = th.dvdx = th.dudy = th.dvdy = 0;
+                        if (meta.w & PG_META_HASDIFF) {  // SurfaceInteraction::ComputeDifferentials, interaction.cpp:101-147
+                            const float4 o4 = qin.o[i];
+                            const V3 rayO = mk(o4.x, o4.y, o4.z);
+                            float l0 = 0, l1 = 0;
+                            if (rd.lens_radius > 0) { l0 = halton_sample(sc, rd, index, 3); l1 = halton_sample(sc, rd, index, 4); }
+                            V3 rxO, rxD, ryO, ryD;
+                            camera_differentials(rd, L4.w, B4.w, l0, l1, rayO, rayD, rxO, rxD, ryO, ryD);
+                            const V3 n = is.n, p = is.p;
+                            const float dd = dot(n, p);
+                            const float tx = -(dot(n, rxO) - dd) / dot(n, rxD);
+                            const float ty = -(dot(n, ryO) - dd) / dot(n, ryD);
+                            if (!(isinf(tx) || isnan(tx)) && !(isinf(ty) || isnan(ty))) {
+                                const V3 px = rxO + rxD * tx, py = ryO + ryD * ty;
+                                th.dpdx = px - p;
+                                th.dpdy = py - p;
+                                int d0, d1;
+                                if (fabsf(n.x) > fabsf(n.y) && fabsf(n.x) > fabsf(n.z)) { d0 = 1; d1 = 2; }
+                                else if (fabsf(n.y) > fabsf(n.z)) { d0 = 0; d1 = 2; }
+                                else { d0 = 0; d1 = 1; }
+                                auto comp = [](V3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); };
+                                const float A00 = comp(gdpdu, d0), A01 = comp(gdpdv, d0), A10 = comp(gdpdu, d1), A11 = comp(gdpdv, d1);
+                                const float Bx0 = comp(px, d0) - comp(p, d0), Bx1 = comp(px, d1) - comp(p, d1);
+                                const float By0 = comp(py, d0) - comp(p, d0), By1 = comp(py, d1) - comp(p, d1);
+                                const float det = A00 * A11 - A01 * A10;  // SolveLinearSystem2x2, transform.cpp:41-49
+                                if (!(fabsf(det) < 1e-10f)) {
+                                    th.dudx = (A11 * Bx0 - A01 * Bx1) / det; th.dvdx = (A00 * Bx1 - A10 * Bx0) / det;
+                                    if (isnan(th.dudx) || isnan(th.dvdx)) th.dudx = th.dvdx = 0;
+                                    th.dudy = (A11 * By0 - A01 * By1) / det; th.dvdy = (A00 * By1 - A10 * By0) / det;
+                                    if (isnan(th.dudy) || isnan(th.dvdy)) th.dudy = th.dvdy = 0;
+                                }
+                            }
+                        }
+                        int nl = 0;
+                        float etaL = 1;
+                        MatEval<2>::run(sc, tri.material, th, lobeStore, nl, etaL);
+                        lb.lobes = lobeStore; lb.n = nl; lb.eta = etaL;
+                    } else { lb.lobes = sc.bxdfs + m.first_bxdf; lb.n = m.n_bxdfs; lb.eta = m.bsdf_eta; }
                 } else {
                     bsdf.ns = is.ns; bsdf.ng = is.n;
                     bsdf.ss = normalize(is.sdpdu);
@@ -1404,8 +1829,9 @@ void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQue
                   RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s) {
     int nblk = PG_REGIONS * (qin.regionCap / PG_BLOCK);
     if (nblk == 0) return;
-    if (sc.ext) hipLaunchKernelGGL(k_shade<true>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests);
+    if (sc.hasTextured) hipLaunchKernelGGL(k_shade<2>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests);
+    else if (sc.ext) hipLaunchKernelGGL(k_shade<1>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests);
+    else hipLaunchKernelGGL(k_shade<0>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests);
 }
 
 // EstimateDirect's two "Add ... contribution" steps (integrator.cpp:143-161, 196-212) and

@@ -173,10 +173,10 @@ PG_DEV bool sphere_test_s(const PgSphere &sp, V3 ro, V3 rd, float tMax, float &t
 }
 
 // What the path needs of the SurfaceInteraction a quadric's Intersect builds for the root tHit of world ray (ro, rd).
-struct SphereHit { V3 p, pError, wo, n, dpdu; };
+struct SphereHit { V3 p, pError, wo, n, dpdu, dpdv; float u, v; };
 // the tail the quadrics share: SurfaceInteraction ctor in object space (interaction.cpp:44-71), then
 // (*ObjectToWorld)(SurfaceInteraction) (transform.cpp:262-297); shading.n == n for a quadric
-PG_DEV SphereHit quadric_finish(const PgSphere &sp, V3 d, V3 pHit, V3 pError, V3 dpdu, V3 dpdv) {
+PG_DEV SphereHit quadric_finish(const PgSphere &sp, V3 d, V3 pHit, V3 pError, V3 dpdu, V3 dpdv, float u, float v) {
     V3 n = normalize(cross(dpdu, dpdv));
     if (sp.reverse_orientation ^ sp.swaps_handedness) n = n * -1.f;
     const V3 wo = normalize(-d);  // Interaction ctor, interaction.h:60
@@ -185,6 +185,8 @@ PG_DEV SphereHit quadric_finish(const PgSphere &sp, V3 d, V3 pHit, V3 pError, V3
     h.n = normalize(m4_normal(sp.w2o, n));
     h.wo = normalize(m4_vec(sp.o2w, wo));
     h.dpdu = m4_vec(sp.o2w, dpdu);
+    h.dpdv = m4_vec(sp.o2w, dpdv);
+    h.u = u; h.v = v;
     return h;
 }
 PG_DEV SphereHit sphere_interaction_s(const PgSphere &sp, V3 ro, V3 rd, float tHit) {
@@ -202,7 +204,7 @@ PG_DEV SphereHit sphere_interaction_s(const PgSphere &sp, V3 ro, V3 rd, float tH
     const V3 dpdu = mk(-sp.phi_max * pHit.y, sp.phi_max * pHit.x, 0);
     const V3 dpdv = mk(pHit.z * cosPhi, pHit.z * sinPhi, -sp.radius * (float)sin((double)theta)) * (sp.theta_max - sp.theta_min);
     const V3 pError = vabs(pHit) * pgamma(5);  // sphere.cpp:148
-    return quadric_finish(sp, d, pHit, pError, dpdu, dpdv);
+    return quadric_finish(sp, d, pHit, pError, dpdu, dpdv, phi / sp.phi_max, (theta - sp.theta_min) / (sp.theta_max - sp.theta_min));
 }
 
 // ---- Cylinder (shapes/cylinder.cpp:48-198) and Disk (shapes/disk.cpp:48-122): same record, same conventions ----------
@@ -252,7 +254,7 @@ PG_DEV SphereHit cylinder_interaction(const PgSphere &sp, V3 ro, V3 rd, float tH
     const V3 dpdu = mk(-sp.phi_max * pHit.y, sp.phi_max * pHit.x, 0);  // cylinder.cpp:103-104
     const V3 dpdv = mk(0, 0, sp.z_max - sp.z_min);
     const V3 pError = vabs(mk(pHit.x, pHit.y, 0)) * pgamma(3);  // :134
-    return quadric_finish(sp, d, pHit, pError, dpdu, dpdv);
+    return quadric_finish(sp, d, pHit, pError, dpdu, dpdv, phi / sp.phi_max, (pHit.z - sp.z_min) / (sp.z_max - sp.z_min));
 }
 PG_DEV bool disk_test(const PgSphere &sp, V3 ro, V3 rd, float tMax, float &tHit) {  // disk.cpp:48-70
     V3 o, d, oErr, dErr;
@@ -277,8 +279,10 @@ PG_DEV SphereHit disk_interaction(const PgSphere &sp, V3 ro, V3 rd, float tHit) 
     const float rHit = sqrtf(dist2);
     const V3 dpdu = mk(-sp.phi_max * pHit.y, sp.phi_max * pHit.x, 0);
     const V3 dpdv = vdiv(mk(pHit.x, pHit.y, 0.f) * (sp.inner_radius - sp.radius), rHit);
+    float phi = (float)atan2((double)pHit.y, (double)pHit.x);
+    if (phi < 0) phi += 2 * PG_PI;
     pHit.z = sp.height;
-    return quadric_finish(sp, d, pHit, mk(0, 0, 0), dpdu, dpdv);
+    return quadric_finish(sp, d, pHit, mk(0, 0, 0), dpdu, dpdv, phi / sp.phi_max, (sp.radius - rHit) / (sp.radius - sp.inner_radius));
 }
 // Shape::Intersect[P] of the quadric record, by shape
 PG_DEV bool sphere_test(const PgSphere &sp, V3 ro, V3 rd, float tMax, float &tHit) {
