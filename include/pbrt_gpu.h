@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 10
+#define PG_ABI_VERSION 11
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -137,7 +137,8 @@ typedef enum PgTextureType {
     PG_TEX_CHECKERBOARD_2D = 3,/* Checkerboard2DTexture, aa_none or closed-form box filter, checkerboard.h:52-110 */
     PG_TEX_CHECKERBOARD_3D = 4,/* Checkerboard3DTexture,                         checkerboard.h:112-135 */
     PG_TEX_UV = 5,             /* UVTexture (spectrum),                          textures/uv.h:49-66      */
-    PG_TEX_BILERP = 6          /* BilerpTexture,                                 textures/bilerp.h:49-69  */
+    PG_TEX_BILERP = 6,         /* BilerpTexture,                                 textures/bilerp.h:49-69  */
+    PG_TEX_IMAGEMAP = 7        /* ImageTexture over images[image],               textures/imagemap.h:77-123 */
 } PgTextureType;
 typedef enum PgMappingType {   /* TextureMapping2D, core/texture.h:51-110 */
     PG_MAP_UV = 0, PG_MAP_SPHERICAL = 1, PG_MAP_CYLINDRICAL = 2, PG_MAP_PLANAR = 3
@@ -152,7 +153,20 @@ typedef struct PgTexture {
     PgTexRef tex1, tex2, amount; /* operands (amount: the float texture of mix) */
     int32_t aa_none;           /* checkerboard: AAMethod::None */
     float v00[3], v01[3], v10[3], v11[3]; /* bilerp */
+    int32_t image;             /* imagemap: index into PgSceneDesc.images */
 } PgTexture;
+/* MIPMap<Float> / MIPMap<RGBSpectrum> (core/mipmap.h): the pyramid as its constructor leaves it (power-of-two resampling,
+ * box-filtered levels), levels row-major in texels[], 1 or 3 floats per texel; level i is max(1, width >> i) x max(1, height >> i). */
+#define PG_MAX_MIP_LEVELS 16
+typedef struct PgImage {
+    int32_t is_float;          /* MIPMap<Float> */
+    int32_t n_levels;
+    int32_t width, height;     /* level 0 */
+    int32_t wrap;              /* ImageWrap: 0 repeat, 1 black, 2 clamp */
+    int32_t trilinear;         /* doTrilinear; otherwise EWA */
+    float max_anisotropy;
+    int64_t level_offset[PG_MAX_MIP_LEVELS]; /* in floats, into PgSceneDesc.texels */
+} PgImage;
 /* A material whose BxDF list depends on the hit: the material's kind and its parameters as the Create*Material
  * functions read them; ComputeScatteringFunctions is evaluated per hit on the device. */
 typedef enum PgMaterialKind {
@@ -280,6 +294,11 @@ typedef struct PgSceneDesc {
     const PgTexture *textures;
     int32_t n_textured;
     const PgTexturedMaterial *textured;
+    int32_t n_images;
+    const PgImage *images;
+    int64_t n_texel_floats;
+    const float *texels;
+    const float *ewa_lut;       /* MIPMap::weightLut, 128 entries (mipmap.h:178-184); may be NULL without images */
 } PgSceneDesc;
 
 /* ---- render description -------------------------------------------------- */

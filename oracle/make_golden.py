@@ -78,6 +78,103 @@ TEXTURES = ('Texture "chk" "spectrum" "checkerboard" "float uscale" [ 6 ] "float
             'Texture "uvt" "spectrum" "uv" "float uscale" [ 2.5 ] "float vscale" [ 1.5 ]\n')
 
 
+def write_test_images(outdir):
+    """Small synthetic images in every container the front end reads: PNG (RGB8 / RGBA8 / palette / gray16), TGA (24-bit
+    RLE bottom-up, 8-bit mono top-down), PFM (colour little-endian, mono big-endian); non-power-of-two sizes exercise the
+    Lanczos resampling of the MIPMap constructor."""
+    import struct, zlib
+    import numpy as np
+    rng = np.random.default_rng(5)
+    def pattern(w, h, seed):
+        y, x = np.mgrid[0:h, 0:w]
+        r = 0.5 + 0.5 * np.sin(x * 0.7 + seed) * np.cos(y * 0.45)
+        g = ((x // 3 + y // 2 + seed) % 2) * 0.8 + 0.1
+        b = (x + 2 * y) / float(w + 2 * h)
+        return np.stack([r, g, b], axis=2).astype(np.float32)
+    def png(path, w, h, ctype, depth, rows, plte=None):
+        def chunk(t, d): return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+        raw = b""
+        prev = None
+        for i, row in enumerate(rows):  # cycle through the five filter types
+            ft = i % 5
+            bpp = max(1, {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype] * depth // 8)
+            cur = np.frombuffer(row, np.uint8).astype(np.int32)
+            up = np.zeros_like(cur) if prev is None else prev
+            left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+            ul = np.concatenate([np.zeros(bpp, np.int32), up[:-bpp]])
+            if ft == 0: f = cur
+            elif ft == 1: f = cur - left
+            elif ft == 2: f = cur - up
+            elif ft == 3: f = cur - (left + up) // 2
+            else:
+                p = left + up - ul
+                pa, pb, pc = np.abs(p - left), np.abs(p - up), np.abs(p - ul)
+                pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, up, ul))
+                f = cur - pred
+            raw += bytes([ft]) + (f & 255).astype(np.uint8).tobytes()
+            prev = cur
+        data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0))
+        if plte is not None: data += chunk(b"PLTE", plte)
+        data += chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b"")
+        open(path, "wb").write(data)
+    img = (pattern(37, 23, 1) * 255).astype(np.uint8)
+    png(os.path.join(outdir, "img_rgb.png"), 37, 23, 2, 8, [img[y].tobytes() for y in range(23)])
+    img = (pattern(16, 32, 2) * 255).astype(np.uint8)
+    rgba = np.concatenate([img, np.full((32, 16, 1), 200, np.uint8)], axis=2)
+    png(os.path.join(outdir, "img_rgba.png"), 16, 32, 6, 8, [rgba[y].tobytes() for y in range(32)])
+    pal = rng.integers(0, 256, (16, 3)).astype(np.uint8)
+    idx = ((np.mgrid[0:20, 0:24][0] * 3 + np.mgrid[0:20, 0:24][1]) % 16).astype(np.uint8)
+    png(os.path.join(outdir, "img_pal.png"), 24, 20, 3, 8, [idx[y].tobytes() for y in range(20)], pal.tobytes())
+    g16 = (pattern(19, 11, 3)[:, :, 0] * 65535).astype(">u2")
+    png(os.path.join(outdir, "img_gray16.png"), 19, 11, 0, 16, [g16[y].tobytes() for y in range(11)])
+    # TGA 24-bit RLE, bottom-up
+    t = (pattern(21, 13, 4) * 255).astype(np.uint8)[::-1, :, ::-1]  # rows bottom-up, BGR
+    body = b""
+    for row in t:
+        x = 0
+        while x < 21:
+            run = 1
+            while x + run < 21 and run < 128 and (row[x + run] == row[x]).all(): run += 1
+            if run > 1: body += bytes([0x80 | (run - 1)]) + row[x].tobytes(); x += run
+            else:
+                n = 1
+                while x + n < 21 and n < 128 and not (x + n + 1 < 21 and (row[x + n] == row[x + n + 1]).all()): n += 1
+                body += bytes([n - 1]) + row[x:x + n].tobytes(); x += n
+    open(os.path.join(outdir, "img_rle.tga"), "wb").write(struct.pack("<BBBHHBHHHHBB", 0, 0, 10, 0, 0, 0, 0, 0, 21, 13, 24, 0) + body)
+    m = (pattern(8, 8, 5)[:, :, 1] * 255).astype(np.uint8)
+    open(os.path.join(outdir, "img_mono.tga"), "wb").write(struct.pack("<BBBHHBHHHHBB", 0, 0, 3, 0, 0, 0, 0, 0, 8, 8, 8, 0x20) + m.tobytes())
+    # PFM: colour little-endian (scale -2 => values doubled), mono big-endian
+    f = pattern(30, 17, 6)
+    open(os.path.join(outdir, "img_color.pfm"), "wb").write(b"PF\n30 17\n-2.0\n" + f[::-1].astype("<f4").tobytes())
+    f1 = pattern(9, 14, 7)[:, :, 2]
+    open(os.path.join(outdir, "img_mono.pfm"), "wb").write(b"Pf\n9 14\n1.0\n" + f1[::-1].astype(">f4").tobytes())
+
+
+IMAGE_TEXTURES = ('Texture "i_rgb" "spectrum" "imagemap" "string filename" "img_rgb.png" "float uscale" [ 3 ] "float vscale" [ 2 ]\n'
+                  'Texture "i_rgba" "spectrum" "imagemap" "string filename" "img_rgba.png" "bool trilinear" "true" "string wrap" "clamp" "float uscale" [ 2.5 ] "float vscale" [ 2.5 ] "float udelta" [ -0.7 ]\n'
+                  'Texture "i_pal" "spectrum" "imagemap" "string filename" "img_pal.png" "string wrap" "black" "float uscale" [ 1.7 ] "float vscale" [ 1.7 ] "float udelta" [ -0.3 ] "float maxanisotropy" [ 2 ]\n'
+                  'Texture "i_g16" "float" "imagemap" "string filename" "img_gray16.png" "float scale" [ 0.4 ] "bool gamma" "false"\n'
+                  'Texture "i_rle" "spectrum" "imagemap" "string filename" "img_rle.tga" "float scale" [ 0.8 ] "float uscale" [ 4 ] "float vscale" [ 4 ]\n'
+                  'Texture "i_mono" "float" "imagemap" "string filename" "img_mono.tga" "bool trilinear" "true" "float uscale" [ 2 ]\n'
+                  'Texture "i_pfm" "spectrum" "imagemap" "string filename" "img_color.pfm" "float scale" [ 0.3 ]\n'
+                  'Texture "i_pfm1" "spectrum" "imagemap" "string filename" "img_mono.pfm" "string mapping" "spherical"\n'
+                  'Texture "i_missing" "spectrum" "imagemap" "string filename" "does_not_exist.png"\n'
+                  'Texture "i_scaled" "spectrum" "scale" "texture tex1" "i_rgb" "texture tex2" "i_pfm"\n')
+
+
+def with_image_textures(s):
+    s = with_normals(s, uv=True)
+    s = s.replace("WorldBegin\n", "WorldBegin\n" + IMAGE_TEXTURES, 1)
+    s = s.replace('Material "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', 'Material "matte" "texture Kd" "i_rgb"', 1)
+    s = s.replace('Material "matte" "rgb Kd" [ 0.12 0.45 0.15 ]', 'Material "matte" "texture Kd" "i_rgba"')
+    s = s.replace('Material "matte" "rgb Kd" [ 0.65 0.05 0.05 ]', 'Material "plastic" "texture Kd" "i_pal" "texture roughness" "i_g16"')
+    s = s.replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\nMaterial "uber" "texture Kd" "i_rle" "texture opacity" "i_pfm1" "texture roughness" "i_mono"')
+    s = s.replace("# tall box", 'Material "matte" "texture Kd" "i_scaled"\n# tall box')
+    s = s.replace("# short box", 'AttributeBegin\n  Translate 420 70 120\n  Material "matte" "texture Kd" "i_missing"\n  Shape "sphere" "float radius" [ 60 ]\n'
+                  '  Translate -270 0 180\n  Material "matte" "texture Kd" "i_pfm"\n  Shape "sphere" "float radius" [ 50 ]\nAttributeEnd\n# short box', 1)
+    return s
+
+
 def with_uv_boxes(s):
     return with_normals(s, uv=True).replace(' "normal N" [', ' "normal Nunused" [')
 
@@ -371,6 +468,10 @@ SCENES = {
     "tex_mappings_lens": cornell(36, 36, 8, world_edit=lambda s: with_mappings(s)).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 6 ] "float focaldistance" [ 900 ]'),
     "tex_ortho": cornell(32, 32, 4, world_edit=lambda s: with_textures(s)).replace('Camera "perspective" "float fov" [ 39.3 ]', 'Camera "orthographic" "float screenwindow" [ -300 300 -290 310 ] "float lensradius" [ 4 ] "float focaldistance" [ 1000 ]'),
     "tex_envcam": cornell(48, 24, 4, world_edit=lambda s: with_mappings(s)).replace('Camera "perspective" "float fov" [ 39.3 ]', 'Camera "environment"').replace("LookAt 278 273 -800  278 273 0  0 1 0", "LookAt 200 300 150  278 273 400  0 1 0"),
+    # ImageTexture / MIPMap (imagemap.cpp, mipmap.h): PNG / TGA / PFM inputs, Lanczos resampling to powers of two, EWA and
+    # trilinear lookups, the three wrap modes, gamma / scale conversion, float and spectrum textures, a missing file
+    "tex_image": cornell(40, 40, 8, world_edit=lambda s: with_image_textures(s)),
+    "tex_image_lens": cornell(32, 32, 4, world_edit=lambda s: with_image_textures(s)).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 10 ] "float focaldistance" [ 700 ]'),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 
@@ -393,6 +494,7 @@ def run(name, scene_path, outdir=GOLD):
 def main():
     os.makedirs(GOLD, exist_ok=True)
     only = sys.argv[1:]
+    write_test_images(GOLD)
     for name, text in SCENES.items():
         if only and name not in only: continue
         p = os.path.join(GOLD, name + ".pbrt")

@@ -5,7 +5,7 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 10
+PG_ABI_VERSION = 11
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
 PG_LIGHTS_UNIFORM, PG_LIGHTS_POWER, PG_LIGHTS_SPATIAL = 0, 1, 2
@@ -40,7 +40,12 @@ class PgTexture(C.Structure):
     _fields_ = [("type", C.c_int32), ("is_float", C.c_int32), ("mapping", C.c_int32), ("su", C.c_float), ("sv", C.c_float),
                 ("du", C.c_float), ("dv", C.c_float), ("vs", C.c_float * 3), ("vt", C.c_float * 3), ("w2t", C.c_float * 16),
                 ("tex1", PgTexRef), ("tex2", PgTexRef), ("amount", PgTexRef), ("aa_none", C.c_int32),
-                ("v00", C.c_float * 3), ("v01", C.c_float * 3), ("v10", C.c_float * 3), ("v11", C.c_float * 3)]
+                ("v00", C.c_float * 3), ("v01", C.c_float * 3), ("v10", C.c_float * 3), ("v11", C.c_float * 3), ("image", C.c_int32)]
+
+
+class PgImage(C.Structure):
+    _fields_ = [("is_float", C.c_int32), ("n_levels", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("wrap", C.c_int32),
+                ("trilinear", C.c_int32), ("max_anisotropy", C.c_float), ("level_offset", C.c_int64 * 16)]
 
 
 class PgTexturedMaterial(C.Structure):
@@ -85,7 +90,9 @@ class PgSceneDesc(C.Structure):
                 ("n_bxdfs", C.c_int32), ("bxdfs", C.POINTER(PgBxDF)),
                 ("n_nodes_all", C.c_int32), ("n_prims_all", C.c_int32), ("n_objects", C.c_int32), ("objects", C.POINTER(PgObject)),
                 ("n_instances", C.c_int32), ("instances", C.POINTER(PgInstance)),
-                ("n_textures", C.c_int32), ("textures", C.POINTER(PgTexture)), ("n_textured", C.c_int32), ("textured", C.POINTER(PgTexturedMaterial))]
+                ("n_textures", C.c_int32), ("textures", C.POINTER(PgTexture)), ("n_textured", C.c_int32), ("textured", C.POINTER(PgTexturedMaterial)),
+                ("n_images", C.c_int32), ("images", C.POINTER(PgImage)), ("n_texel_floats", C.c_int64), ("texels", C.POINTER(C.c_float)),
+                ("ewa_lut", C.POINTER(C.c_float))]
 
 
 class PgRenderDesc(C.Structure):

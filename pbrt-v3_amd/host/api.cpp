@@ -82,6 +82,9 @@ struct RenderOptions {
     std::vector<PgBxDF> bxdfs;  // the materials' BxDF lists, concatenated
     std::vector<PgTexture> textures;  // texture nodes (Texture "name" ... with a non-constant class)
     std::vector<PgTexturedMaterial> textured;
+    std::vector<PgImage> images;      // MIPMaps of the image textures, shared through imageCache (imagemap.cpp:55-59)
+    std::vector<float> texels;
+    std::map<std::string, int> imageCache;
     bool haveScatteringMedia = false;
 };
 enum class APIState { Uninitialized, OptionsBlock, WorldBlock };
@@ -647,6 +650,51 @@ void pbrtTexture(const std::string &name, const std::string &type, const std::st
     } else if (texname == "uv" && !isFloat) {
         t.type = PG_TEX_UV;
         readMapping2D(params, curTransform[0], &t);
+    } else if (texname == "imagemap") {  // imagemap.cpp:103-188, GetTexture :52-101
+        t.type = PG_TEX_IMAGEMAP;
+        readMapping2D(params, curTransform[0], &t);
+        const Float maxAniso = params.FindOneFloat("maxanisotropy", 8.f);
+        const bool trilerp = params.FindOneBool("trilinear", false);
+        const std::string wrap = params.FindOneString("wrap", "repeat");
+        const int wrapMode = wrap == "black" ? 1 : (wrap == "clamp" ? 2 : 0);
+        const Float scale = params.FindOneFloat("scale", 1.f);
+        const std::string filename = AbsolutePath(ResolveFilename(params.FindOneString("filename", "")));
+        const bool gamma = params.FindOneBool("gamma", ImageGammaDefault(filename));
+        char key[64];
+        snprintf(key, sizeof(key), "|%d|%d|%a|%d|%a|%d", isFloat ? 1 : 0, trilerp ? 1 : 0, (double)maxAniso, wrapMode, (double)scale, gamma ? 1 : 0);
+        const std::string cacheKey = filename + key;
+        auto it = renderOptions->imageCache.find(cacheKey);
+        if (it != renderOptions->imageCache.end()) t.image = it->second;
+        else {
+            int xres = 0, yres = 0;
+            std::vector<RGB> texels;
+            if (!ReadImage(filename, &xres, &yres, &texels)) {
+                Warning("Creating a constant grey texture to replace \"%s\".", filename.c_str());
+                xres = yres = 1;
+                texels.assign(1, RGB{{0.5f, 0.5f, 0.5f}});
+            }
+            for (int y = 0; y < yres / 2; ++y)  // flip in y: texture space has (0,0) at the lower left corner
+                for (int x = 0; x < xres; ++x) std::swap(texels[(size_t)y * xres + x], texels[(size_t)(yres - 1 - y) * xres + x]);
+            auto invGamma = [](Float value) {  // InverseGammaCorrect, pbrt.h:298-301
+                if (value <= 0.04045f) return value * 1.f / 12.92f;
+                return std::pow((value + 0.055f) * 1.f / 1.055f, (Float)2.4f);
+            };
+            const int nc = isFloat ? 1 : 3;
+            std::vector<float> conv((size_t)xres * yres * nc);
+            for (size_t i = 0; i < texels.size(); ++i) {  // convertIn, imagemap.h:98-107
+                if (isFloat) {
+                    const Float yv = 0.212671f * texels[i].c[0] + 0.715160f * texels[i].c[1] + 0.072169f * texels[i].c[2];  // RGBSpectrum::y()
+                    conv[i] = scale * (gamma ? invGamma(yv) : yv);
+                } else for (int c = 0; c < 3; ++c) conv[3 * i + c] = scale * (gamma ? invGamma(texels[i].c[c]) : texels[i].c[c]);
+            }
+            PgImage img;
+            memset(&img, 0, sizeof(img));
+            img.is_float = isFloat ? 1 : 0; img.wrap = wrapMode; img.trilinear = trilerp ? 1 : 0; img.max_anisotropy = maxAniso;
+            BuildMIPMap(xres, yres, nc, conv, wrapMode, &img, &renderOptions->texels);
+            t.image = (int)renderOptions->images.size();
+            renderOptions->images.push_back(img);
+            renderOptions->imageCache[cacheKey] = t.image;
+        }
     } else if (texname == "bilerp") {
         t.type = PG_TEX_BILERP;
         readMapping2D(params, curTransform[0], &t);
@@ -658,7 +706,7 @@ void pbrtTexture(const std::string &name, const std::string &type, const std::st
             else { RGB v = params.FindOneSpectrum(names[k], RGB{{defs[k], defs[k], defs[k]}}); for (int c = 0; c < 3; ++c) dst[k][c] = v.c[c]; }
         }
     } else {
-        Error("Texture \"%s\": class \"%s\" is outside this build's closed set (constant, scale, mix, checkerboard, uv, bilerp); ignoring.",
+        Error("Texture \"%s\": class \"%s\" is outside this build's closed set (constant, scale, mix, checkerboard, uv, bilerp, imagemap); ignoring.",
               name.c_str(), texname.c_str());
         return;
     }
@@ -1012,6 +1060,8 @@ static Scene *MakeScene() {
     scene->bxdfs = ro.bxdfs;
     scene->textures = ro.textures;
     scene->textured = ro.textured;
+    scene->images = ro.images;
+    scene->texels = ro.texels;
     scene->worldBound = scene->aggregate->WorldBound();
     // resolve each light's emitting triangle to its index in BVH order
     const auto &prims = scene->aggregate->primitives;

@@ -279,6 +279,9 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     flat->bxdfs = scene.bxdfs;
     flat->textures = scene.textures;
     flat->textured = scene.textured;
+    flat->images = scene.images;
+    flat->texels = scene.texels;
+    EWAWeightLut(flat->ewaLut);
     flat->lights = scene.lights;
     // Light::Preprocess (scene.h:57-60): DistantLight keeps the world's bounding sphere (distant.h:55-57, geometry.h:803-806)
     if (!flat->nodes.empty()) {
@@ -319,6 +322,9 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     d.n_bxdfs = (int)flat->bxdfs.size(); d.bxdfs = flat->bxdfs.data();
     d.n_textures = (int)flat->textures.size(); d.textures = flat->textures.data();
     d.n_textured = (int)flat->textured.size(); d.textured = flat->textured.data();
+    d.n_images = (int)flat->images.size(); d.images = flat->images.data();
+    d.n_texel_floats = (int64_t)flat->texels.size(); d.texels = flat->texels.data();
+    d.ewa_lut = flat->ewaLut;
 }
 
 void GpuPathIntegrator::FillRenderDesc(PgRenderDesc *rd) const {

@@ -100,6 +100,8 @@ struct Scene {  // core/scene.h:50-80
     std::vector<PgBxDF> bxdfs;
     std::vector<PgTexture> textures;
     std::vector<PgTexturedMaterial> textured;
+    std::vector<PgImage> images;
+    std::vector<float> texels;
     Bounds3f worldBound;
 };
 
@@ -133,6 +135,11 @@ Film *CreateFilm(const ParamSet &params, Float filterRadiusX, Float filterRadius
 // MakeFilter (api.cpp:785-803) + the filters' Evaluate(): fills film->filterTable / filterGeneral; returns false for unknown names
 bool SetFilmFilter(Film *film, const std::string &name, const ParamSet &params);
 void FilterRadiusFor(const std::string &name, const ParamSet &params, Float *xw, Float *yw);
+// host/imageio.cpp: image input + MIPMap construction for ImageTexture
+bool ReadImage(const std::string &name, int *xres, int *yres, std::vector<RGB> *rgb);
+bool ImageGammaDefault(const std::string &filename);
+void BuildMIPMap(int resX, int resY, int nc, const std::vector<float> &data, int wrap, PgImage *img, std::vector<float> *pool);
+void EWAWeightLut(float lut[128]);
 bool WriteImagePFM(const std::string &filename, const Float *rgb, int width, int height);  // imageio.cpp:437-482
 
 struct PerspectiveCamera {  // ProjectiveCamera (core/camera.h:87-108): cameras/perspective.cpp:45-68 or orthographic.cpp:44-62
@@ -171,6 +178,9 @@ struct FlatScene {
     std::vector<PgInstance> instances;
     std::vector<PgTexture> textures;
     std::vector<PgTexturedMaterial> textured;
+    std::vector<PgImage> images;
+    std::vector<float> texels;
+    float ewaLut[128];
 };
 
 // core/integrator.h:53-58.
