@@ -45,7 +45,7 @@ struct DeviceBuffer {
 struct PgScene {
     int device = 0;
     DScene d;
-    DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, textures, textured, triN, triS, uv, materials, lights, distTable, perms, permSums, primes;
+    DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, textures, textured, images, texels, ewaLut, triN, triS, uv, materials, lights, distTable, perms, permSums, primes;
     // work buffers (sized on first render, reused)
     int capacity = 0;
     DeviceBuffer qo[4], qd[4], counts, hitsMain, hitInst, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
@@ -275,7 +275,9 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         auto refDepth = [&](const PgTexRef &r, int self) -> int { return r.tex < 0 ? 0 : ((r.tex >= self) ? 1000 : depth[r.tex]); };
         for (int i = 0; i < (int)depth.size(); ++i) {
             const PgTexture &t = desc->textures[i];
-            if (t.type < PG_TEX_SCALE || t.type > PG_TEX_BILERP) FAIL(PG_ERR_UNSUPPORTED, "texture %d: unknown type %d", i, t.type);
+            if (t.type < PG_TEX_SCALE || t.type > PG_TEX_IMAGEMAP) FAIL(PG_ERR_UNSUPPORTED, "texture %d: unknown type %d", i, t.type);
+            if (t.type == PG_TEX_IMAGEMAP && (t.image < 0 || t.image >= desc->n_images || desc->images[t.image].is_float != (t.is_float ? 1 : 0)))
+                FAIL(PG_ERR_INVALID, "texture %d: image %d out of range or of the wrong texel type", i, t.image);
             int dmax = std::max(refDepth(t.tex1, i), std::max(refDepth(t.tex2, i), refDepth(t.amount, i)));
             if (dmax >= 1000) FAIL(PG_ERR_INVALID, "texture %d refers to a texture that is not defined before it", i);
             depth[i] = 1 + dmax;
@@ -299,6 +301,25 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
                 }
             }
         }
+    }
+    if (desc->n_images > 0) {
+        if (!desc->images || !desc->texels || !desc->ewa_lut) FAIL(PG_ERR_INVALID, "images without texels / EWA weight table");
+        for (int i = 0; i < desc->n_images; ++i) {
+            const PgImage &im = desc->images[i];
+            if (im.n_levels < 1 || im.n_levels > PG_MAX_MIP_LEVELS || im.width < 1 || im.height < 1 || (im.width & (im.width - 1)) || (im.height & (im.height - 1)))
+                FAIL(PG_ERR_INVALID, "image %d: %d levels of %d x %d (MIPMap levels are powers of two)", i, im.n_levels, im.width, im.height);
+            for (int l = 0; l < im.n_levels; ++l) {
+                const int64_t sRes = std::max(1, im.width >> l), tRes = std::max(1, im.height >> l);
+                if (im.level_offset[l] < 0 || im.level_offset[l] + sRes * tRes * (im.is_float ? 1 : 3) > desc->n_texel_floats)
+                    FAIL(PG_ERR_INVALID, "image %d: level %d lies outside the texel array", i, l);
+            }
+        }
+        HIP_TRY_S(s->images.alloc(sizeof(PgImage) * (size_t)desc->n_images));
+        HIP_TRY_S(hipMemcpy(s->images.p, desc->images, s->images.bytes, hipMemcpyHostToDevice));
+        HIP_TRY_S(s->texels.alloc(sizeof(float) * (size_t)desc->n_texel_floats));
+        HIP_TRY_S(hipMemcpy(s->texels.p, desc->texels, s->texels.bytes, hipMemcpyHostToDevice));
+        HIP_TRY_S(s->ewaLut.alloc(sizeof(float) * 128));
+        HIP_TRY_S(hipMemcpy(s->ewaLut.p, desc->ewa_lut, s->ewaLut.bytes, hipMemcpyHostToDevice));
     }
     if (desc->n_textures > 0 && desc->textures) {
         HIP_TRY_S(s->textures.alloc(sizeof(PgTexture) * (size_t)desc->n_textures));
@@ -387,6 +408,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
 
     d.nodes = (const float4 *)s->nodes.p; d.tris = (const float4 *)s->tris.p; d.spheres = (const PgSphere *)s->spheres.p; d.nSpheres = desc->n_spheres > 0 ? desc->n_spheres : 0;
     d.bxdfs = (const PgBxDF *)s->bxdfs.p;
+    d.images = (const PgImage *)s->images.p; d.texels = (const float *)s->texels.p; d.ewaLut = (const float *)s->ewaLut.p;
     d.textures = (const PgTexture *)s->textures.p; d.textured = (const PgTexturedMaterial *)s->textured.p;
     d.hasTextured = anyTextured ? 1 : 0;
     {  // PG_FORCE_EXT=1 runs the general kernels on scenes that do not need them (tests: both paths agree bit for bit)

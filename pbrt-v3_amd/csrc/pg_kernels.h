@@ -41,6 +41,9 @@ struct DScene {
     const DObject *objects;
     int nInstances;
     int *hitInst;  // per closest-hit result: the instance the hit primitive was reached through, or -1 (written by k_trace<.., true>)
+    const PgImage *images;               // MIPMaps of the image textures (pyramid levels in texels[])
+    const float *texels;
+    const float *ewaLut;                 // MIPMap::weightLut (128)
     const PgTexture *textures;           // texture nodes
     const PgTexturedMaterial *textured;  // materials evaluated per hit (PG_MAT_TEXTURED)
     int hasTextured;

@@ -984,6 +984,84 @@ PG_DEV void tex_map2d(const PgTexture &t, const TexHit &h, float st[2], float ds
         else if (dstdy[1] < -.5f) dstdy[1] = -(dstdy[1] + 1);
     }
 }
+// ---- MIPMap<T>::Lookup (core/mipmap.h:189-331) over the pyramid the host built; Spec carries 1 (r only) or 3 channels
+PG_DEV int mod_i(int a, int b) { int r = a - (a / b) * b; return (r < 0) ? r + b : r; }  // pbrt.h:314-317
+PG_DEV Spec mip_texel(const DScene &sc, const PgImage &im, int level, int s, int t) {  // mipmap.h:189-212
+    const int sRes = max(1, im.width >> level), tRes = max(1, im.height >> level);
+    if (im.wrap == 0) { s = mod_i(s, sRes); t = mod_i(t, tRes); }
+    else if (im.wrap == 2) { s = s < 0 ? 0 : (s > sRes - 1 ? sRes - 1 : s); t = t < 0 ? 0 : (t > tRes - 1 ? tRes - 1 : t); }
+    else if (s < 0 || s >= sRes || t < 0 || t >= tRes) return sp(0);
+    const float *p = sc.texels + im.level_offset[level] + ((size_t)t * sRes + s) * (im.is_float ? 1 : 3);
+    return im.is_float ? sp3(p[0], 0, 0) : sp3(p[0], p[1], p[2]);
+}
+PG_DEV Spec mip_triangle(const DScene &sc, const PgImage &im, int level, float st0, float st1) {  // mipmap.h:231-243
+    level = level < 0 ? 0 : (level > im.n_levels - 1 ? im.n_levels - 1 : level);
+    const int sRes = max(1, im.width >> level), tRes = max(1, im.height >> level);
+    const float s = st0 * sRes - 0.5f, t = st1 * tRes - 0.5f;
+    const int s0 = (int)floorf(s), t0 = (int)floorf(t);
+    const float ds = s - s0, dt = t - t0;
+    return mip_texel(sc, im, level, s0, t0) * ((1 - ds) * (1 - dt)) + mip_texel(sc, im, level, s0, t0 + 1) * ((1 - ds) * dt) +
+           mip_texel(sc, im, level, s0 + 1, t0) * (ds * (1 - dt)) + mip_texel(sc, im, level, s0 + 1, t0 + 1) * (ds * dt);
+}
+PG_DEV float log2_pbrt(float x) { return (float)log((double)x) * 1.442695040888963387004650940071f; }  // pbrt.h:328-331
+PG_DEV Spec mip_ewa(const DScene &sc, const PgImage &im, int level, float st0, float st1, float d00, float d01, float d10, float d11) {  // mipmap.h:276-327
+    if (level >= im.n_levels) return mip_texel(sc, im, im.n_levels - 1, 0, 0);
+    const int sRes = max(1, im.width >> level), tRes = max(1, im.height >> level);
+    st0 = st0 * sRes - 0.5f; st1 = st1 * tRes - 0.5f;
+    d00 *= sRes; d01 *= tRes; d10 *= sRes; d11 *= tRes;
+    float A = d01 * d01 + d11 * d11 + 1;
+    float B = -2 * (d00 * d01 + d10 * d11);
+    float C = d00 * d00 + d10 * d10 + 1;
+    const float invF = 1 / (A * C - B * B * 0.25f);
+    A *= invF; B *= invF; C *= invF;
+    const float det = -B * B + 4 * A * C;
+    const float invDet = 1 / det;
+    const float uSqrt = sqrtf(det * C), vSqrt = sqrtf(A * det);
+    const int s0 = (int)ceilf(st0 - 2 * invDet * uSqrt), s1 = (int)floorf(st0 + 2 * invDet * uSqrt);
+    const int t0 = (int)ceilf(st1 - 2 * invDet * vSqrt), t1 = (int)floorf(st1 + 2 * invDet * vSqrt);
+    Spec sum = sp(0);
+    float sumWts = 0;
+    for (int it = t0; it <= t1; ++it) {
+        const float tt = it - st1;
+        for (int is = s0; is <= s1; ++is) {
+            const float ss = is - st0;
+            const float r2 = A * ss * ss + B * ss * tt + C * tt * tt;
+            if (r2 < 1) {
+                int index = (int)(r2 * 128);
+                if (index > 127) index = 127;
+                const float weight = sc.ewaLut[index];
+                sum = sum + mip_texel(sc, im, level, is, it) * weight;
+                sumWts += weight;
+            }
+        }
+    }
+    return sum / sumWts;
+}
+PG_DEV Spec mip_lookup(const DScene &sc, const PgImage &im, const float st[2], const float dstdx[2], const float dstdy[2]) {
+    if (im.trilinear) {  // mipmap.h:245-251 -> :214-229
+        const float width = pmax(pmax(fabsf(dstdx[0]), fabsf(dstdx[1])), pmax(fabsf(dstdy[0]), fabsf(dstdy[1])));
+        const float level = im.n_levels - 1 + log2_pbrt(pmax(width, 1e-8f));
+        if (level < 0) return mip_triangle(sc, im, 0, st[0], st[1]);
+        if (level >= im.n_levels - 1) return mip_texel(sc, im, im.n_levels - 1, 0, 0);
+        const int iLevel = (int)floorf(level);
+        const float delta = level - iLevel;
+        return mip_triangle(sc, im, iLevel, st[0], st[1]) * (1 - delta) + mip_triangle(sc, im, iLevel + 1, st[0], st[1]) * delta;
+    }
+    float d00 = dstdx[0], d01 = dstdx[1], d10 = dstdy[0], d11 = dstdy[1];
+    if (d00 * d00 + d01 * d01 < d10 * d10 + d11 * d11) { float a = d00, b = d01; d00 = d10; d01 = d11; d10 = a; d11 = b; }
+    const float majorLength = sqrtf(d00 * d00 + d01 * d01);
+    float minorLength = sqrtf(d10 * d10 + d11 * d11);
+    if (minorLength * im.max_anisotropy < majorLength && minorLength > 0) {
+        const float scale = majorLength / (minorLength * im.max_anisotropy);
+        d10 *= scale; d11 *= scale;
+        minorLength *= scale;
+    }
+    if (minorLength == 0) return mip_triangle(sc, im, 0, st[0], st[1]);
+    const float lod = pmax(0.f, im.n_levels - 1.f + log2_pbrt(minorLength));
+    const int ilod = (int)floorf(lod);
+    const float dl = lod - ilod;
+    return mip_ewa(sc, im, ilod, st[0], st[1], d00, d01, d10, d11) * (1 - dl) + mip_ewa(sc, im, ilod + 1, st[0], st[1], d00, d01, d10, d11) * dl;
+}
 PG_DEV float tex_bump_int(float x) {  // checkerboard.h:92-96
     return (float)(int)floorf(x / 2) + 2 * pmax(x / 2 - (float)(int)floorf(x / 2) - 0.5f, 0.f);
 }
@@ -1019,6 +1097,11 @@ template <int D> struct TexEval {
             const float amt = TexEval<D - 1>::f(sc, t.amount, h);
             return (1 - amt) * t1 + amt * t2;
         }
+        case PG_TEX_IMAGEMAP: {  // ImageTexture::Evaluate, imagemap.h:86-93
+            float st[2], dx[2], dy[2];
+            tex_map2d(t, h, st, dx, dy);
+            return mip_lookup(sc, sc.images[t.image], st, dx, dy).r;
+        }
         case PG_TEX_BILERP: {  // bilerp.h:56-61
             float st[2], dx[2], dy[2];
             tex_map2d(t, h, st, dx, dy);
@@ -1044,6 +1127,11 @@ template <int D> struct TexEval {
             const Spec t1 = TexEval<D - 1>::s(sc, t.tex1, h), t2 = TexEval<D - 1>::s(sc, t.tex2, h);
             const float amt = TexEval<D - 1>::f(sc, t.amount, h);
             return t1 * (1 - amt) + t2 * amt;
+        }
+        case PG_TEX_IMAGEMAP: {
+            float st[2], dx[2], dy[2];
+            tex_map2d(t, h, st, dx, dy);
+            return mip_lookup(sc, sc.images[t.image], st, dx, dy);
         }
         case PG_TEX_UV: {  // uv.h:54-60
             float st[2], dx[2], dy[2];
