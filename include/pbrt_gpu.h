@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 11
+#define PG_ABI_VERSION 12
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -207,12 +207,15 @@ typedef struct PgLight {
     float w2l[9];      /* spot: upper 3x3 of WorldToLight, row-major (Falloff)      */
     float cos_total_width, cos_falloff_start; /* spot (spot.cpp:48-49)              */
     float world_radius; /* distant, infinite: Preprocess()'s bounding-sphere radius (distant.h:55-57) */
-    /* infinite (constant L => a 1x1 Lmap): upper 3x3 of LightToWorld, and the 2x2 Distribution2D the constructor builds
-     * from Lmap lookups * sin(theta) (infinite.cpp:66-84): per row v the function values, cdf and integral, then the
-     * marginal over rows (sampling.cpp:159-171, sampling.h:57-70).                                                     */
+    /* infinite (infinite.cpp:46-85): upper 3x3 of LightToWorld; Lmap = images[env_image] (MIPMap<RGBSpectrum> of the map
+     * times L * scale, or 1x1 without "mapname"; wrap repeat); the Distribution2D over env_nu x env_nv = (2 width) x
+     * (2 height) scalar values Lmap->Lookup(st, fwidth).y() * sin(theta) at env_tables[env_table]: per row v its func[nu],
+     * cdf[nu+1], funcInt (2 nu + 2 floats), then the marginal over rows: func[nv], cdf[nv+1], funcInt (sampling.h:57-150).
+     * env_power = Lmap->Lookup((.5, .5), .5), the radiance Power() integrates (infinite.cpp:87-91).                      */
     float l2w[9];
-    float env_func[2][2], env_cdf[2][3], env_int[2];
-    float env_marg_cdf[3], env_marg_int;
+    int32_t env_image, env_nu, env_nv;
+    int64_t env_table;
+    float env_power[3];
 } PgLight;
 
 typedef enum PgLightStrategy {
@@ -298,6 +301,8 @@ typedef struct PgSceneDesc {
     const PgImage *images;
     int64_t n_texel_floats;
     const float *texels;
+    int64_t n_env_floats;
+    const float *env_tables;    /* the infinite lights' Distribution2D tables (PgLight.env_table) */
     const float *ewa_lut;       /* MIPMap::weightLut, 128 entries (mipmap.h:178-184); may be NULL without images */
 } PgSceneDesc;
 

@@ -472,6 +472,17 @@ SCENES = {
     # trilinear lookups, the three wrap modes, gamma / scale conversion, float and spectrum textures, a missing file
     "tex_image": cornell(40, 40, 8, world_edit=lambda s: with_image_textures(s)),
     "tex_image_lens": cornell(32, 32, 4, world_edit=lambda s: with_image_textures(s)).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 10 ] "float focaldistance" [ 700 ]'),
+    # InfiniteAreaLight with an environment map (infinite.cpp:46-135): the map's MIPMap times L, the Distribution2D over
+    # 2w x 2h trilinear lookups, importance sampling, escaped-ray Le; a non-power-of-two PFM and a PNG, rotated lights
+    "env_map": cornell(40, 40, 8, integrator='Integrator "path" "integer maxdepth" [ 4 ]',
+                       world_edit=lambda s: s.replace("  AreaLightSource", "#  AreaLightSource")
+                       .replace("# light\nAttributeBegin", 'AttributeBegin\n  Rotate 40 1 0.2 0\n  LightSource "infinite" "string mapname" "img_color.pfm" "rgb L" [ 2 2.5 3 ]\nAttributeEnd\n# light\nAttributeBegin')
+                       .replace('Shape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ]\n  "point P" [ 556 548.8 0   556 548.8 559.2   0 548.8 559.2   0 548.8 0 ]', "")
+                       .replace("# tall box", 'Material "mirror"\n# tall box')),
+    "env_map_mixed": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 5 ] "string lightsamplestrategy" "power"',
+                             world_edit=lambda s: s.replace("# light\nAttributeBegin", 'AttributeBegin\n  Rotate -70 0 0 1\n  LightSource "infinite" "string mapname" "img_rgb.png" "rgb scale" [ 0.5 0.5 0.5 ]\nAttributeEnd\n# light\nAttributeBegin')
+                             .replace('Shape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ]\n  "point P" [ 556 548.8 0   556 548.8 559.2   0 548.8 559.2   0 548.8 0 ]', "")
+                             .replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\nMaterial "glass"')),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 

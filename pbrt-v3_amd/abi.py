@@ -5,7 +5,7 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 11
+PG_ABI_VERSION = 12
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
 PG_LIGHTS_UNIFORM, PG_LIGHTS_POWER, PG_LIGHTS_SPATIAL = 0, 1, 2
@@ -28,8 +28,8 @@ class PgMaterial(C.Structure):
 class PgLight(C.Structure):
     _fields_ = [("type", C.c_int32), ("prim", C.c_int32), ("L", C.c_float * 3), ("two_sided", C.c_int32), ("area", C.c_float),
                 ("pos", C.c_float * 3), ("w2l", C.c_float * 9), ("cos_total_width", C.c_float), ("cos_falloff_start", C.c_float),
-                ("world_radius", C.c_float), ("l2w", C.c_float * 9), ("env_func", C.c_float * 4), ("env_cdf", C.c_float * 6),
-                ("env_int", C.c_float * 2), ("env_marg_cdf", C.c_float * 3), ("env_marg_int", C.c_float)]
+                ("world_radius", C.c_float), ("l2w", C.c_float * 9), ("env_image", C.c_int32), ("env_nu", C.c_int32), ("env_nv", C.c_int32),
+                ("env_table", C.c_int64), ("env_power", C.c_float * 3)]
 
 
 class PgTexRef(C.Structure):
@@ -92,7 +92,7 @@ class PgSceneDesc(C.Structure):
                 ("n_instances", C.c_int32), ("instances", C.POINTER(PgInstance)),
                 ("n_textures", C.c_int32), ("textures", C.POINTER(PgTexture)), ("n_textured", C.c_int32), ("textured", C.POINTER(PgTexturedMaterial)),
                 ("n_images", C.c_int32), ("images", C.POINTER(PgImage)), ("n_texel_floats", C.c_int64), ("texels", C.POINTER(C.c_float)),
-                ("ewa_lut", C.POINTER(C.c_float))]
+                ("n_env_floats", C.c_int64), ("env_tables", C.POINTER(C.c_float)), ("ewa_lut", C.POINTER(C.c_float))]
 
 
 class PgRenderDesc(C.Structure):

@@ -45,7 +45,7 @@ struct DeviceBuffer {
 struct PgScene {
     int device = 0;
     DScene d;
-    DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, textures, textured, images, texels, ewaLut, triN, triS, uv, materials, lights, distTable, perms, permSums, primes;
+    DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, textures, textured, images, texels, ewaLut, envTables, triN, triS, uv, materials, lights, distTable, perms, permSums, primes;
     // work buffers (sized on first render, reused)
     int capacity = 0;
     DeviceBuffer qo[4], qd[4], counts, hitsMain, hitInst, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
@@ -380,7 +380,14 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     }
     d.hasInfinite = 0;
     for (int i = 0; i < desc->n_lights; ++i)
-        if (desc->lights[i].type == PG_LIGHT_INFINITE) d.hasInfinite = 1;
+        if (desc->lights[i].type == PG_LIGHT_INFINITE) {
+            d.hasInfinite = 1;
+            const PgLight &l = desc->lights[i];
+            const int64_t need = (int64_t)(2 * (int64_t)l.env_nu + 2) * l.env_nv + 2 * (int64_t)l.env_nv + 2;
+            if (l.env_image < 0 || l.env_image >= desc->n_images || !desc->images || desc->images[l.env_image].is_float || l.env_nu < 1 || l.env_nv < 1 ||
+                l.env_table < 0 || l.env_table + need > desc->n_env_floats || !desc->env_tables)
+                FAIL(PG_ERR_INVALID, "light %d: infinite light without a valid radiance map / sampling distribution", i);
+        }
     for (int i = 0; i < desc->n_lights; ++i)
         if (desc->lights[i].type < PG_LIGHT_AREA || desc->lights[i].type > PG_LIGHT_INFINITE) FAIL(PG_ERR_UNSUPPORTED, "light %d: unknown type %d", i, desc->lights[i].type);
         else if (desc->lights[i].type == PG_LIGHT_AREA && (desc->lights[i].prim < 0 || desc->lights[i].prim >= nt))
@@ -408,6 +415,11 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
 
     d.nodes = (const float4 *)s->nodes.p; d.tris = (const float4 *)s->tris.p; d.spheres = (const PgSphere *)s->spheres.p; d.nSpheres = desc->n_spheres > 0 ? desc->n_spheres : 0;
     d.bxdfs = (const PgBxDF *)s->bxdfs.p;
+    if (desc->n_env_floats > 0 && desc->env_tables) {
+        HIP_TRY_S(s->envTables.alloc(sizeof(float) * (size_t)desc->n_env_floats));
+        HIP_TRY_S(hipMemcpy(s->envTables.p, desc->env_tables, s->envTables.bytes, hipMemcpyHostToDevice));
+    }
+    d.envTables = (const float *)s->envTables.p;
     d.images = (const PgImage *)s->images.p; d.texels = (const float *)s->texels.p; d.ewaLut = (const float *)s->ewaLut.p;
     d.textures = (const PgTexture *)s->textures.p; d.textured = (const PgTexturedMaterial *)s->textured.p;
     d.hasTextured = anyTextured ? 1 : 0;
@@ -459,7 +471,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
                         if (l.type == PG_LIGHT_POINT) v *= 4 * PG_PI;
                         else if (l.type == PG_LIGHT_SPOT) { v *= 2; v *= PG_PI; v *= (1 - .5f * (l.cos_falloff_start + l.cos_total_width)); }
                         else if (l.type == PG_LIGHT_DISTANT) { v *= PG_PI; v *= l.world_radius; v *= l.world_radius; }
-                        else if (l.type == PG_LIGHT_INFINITE) v = v * (PG_PI * l.world_radius * l.world_radius);  // Lookup((.5,.5), .5) == L, infinite.cpp:87-91
+                        else if (l.type == PG_LIGHT_INFINITE) v = l.env_power[c] * (PG_PI * l.world_radius * l.world_radius);  // infinite.cpp:87-91
                         else { v *= (float)(l.two_sided ? 2 : 1); v *= l.area; v *= PG_PI; }
                         P[c] = v;
                     }

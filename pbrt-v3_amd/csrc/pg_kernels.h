@@ -44,6 +44,7 @@ struct DScene {
     const PgImage *images;               // MIPMaps of the image textures (pyramid levels in texels[])
     const float *texels;
     const float *ewaLut;                 // MIPMap::weightLut (128)
+    const float *envTables;              // the infinite lights' Distribution2D tables (PgLight.env_table)
     const PgTexture *textures;           // texture nodes
     const PgTexturedMaterial *textured;  // materials evaluated per hit (PG_MAT_TEXTURED)
     int hasTextured;

@@ -1436,23 +1436,15 @@ PG_DEV LightSample quadric_sample_area(const PgSphere &s, float u0, float u1, fl
 PG_DEV V3 mat3_mul(const float *m, V3 w) {  // Transform::operator()(Vector3), transform.h:233-239
     return mk(m[0] * w.x + m[1] * w.y + m[2] * w.z, m[3] * w.x + m[4] * w.y + m[5] * w.z, m[6] * w.x + m[7] * w.y + m[8] * w.z);
 }
-PG_DEV Spec env_lookup(const PgLight &l, float s0_, float t0_) {  // MIPMap::Lookup(st, 0) -> triangle(0, st); every texel is L
-    float s = s0_ * 1 - 0.5f, t = t0_ * 1 - 0.5f;
-    int s0 = (int)floorf(s), t0 = (int)floorf(t);
-    float ds = s - s0, dt = t - t0;
-    const Spec L = sp3(l.L[0], l.L[1], l.L[2]);
-    Spec r = L * ((1 - ds) * (1 - dt));
-    r = r + L * ((1 - ds) * dt);
-    r = r + L * (ds * (1 - dt));
-    r = r + L * (ds * dt);
-    return r;
+PG_DEV Spec env_lookup(const DScene &sc, const PgLight &l, float s0_, float t0_) {  // Lmap->Lookup(st): width 0 -> triangle(0, st), mipmap.h:214-243
+    return mip_triangle(sc, sc.images[l.env_image], 0, s0_, t0_);
 }
-PG_DEV Spec env_le(const PgLight &l, V3 rayD) {  // InfiniteAreaLight::Le, infinite.cpp:93-97
+PG_DEV Spec env_le(const DScene &sc, const PgLight &l, V3 rayD) {  // InfiniteAreaLight::Le, infinite.cpp:93-97
     V3 w = normalize(mat3_mul(l.w2l, rayD));
-    return env_lookup(l, spherical_phi(w) * PG_INV2PI, spherical_theta(w) * PG_INVPI);
+    return env_lookup(sc, l, spherical_phi(w) * PG_INV2PI, spherical_theta(w) * PG_INVPI);
 }
-PG_DEV float env_sample_1d(const float *func, const float *cdf, float funcInt, float u, float &pdf, int *off) {  // sampling.h:72-89, n = 2
-    int size = 3, first = 0, len = size;
+PG_DEV float env_sample_1d(const float *func, const float *cdf, float funcInt, int n, float u, float &pdf, int *off) {  // sampling.h:72-89
+    int size = n + 1, first = 0, len = size;
     while (len > 0) {
         int half = len >> 1, middle = first + half;
         if (cdf[middle] <= u) { first = middle + 1; len -= half + 1; } else len = half;
@@ -1462,17 +1454,20 @@ PG_DEV float env_sample_1d(const float *func, const float *cdf, float funcInt, f
     float du = u - cdf[offset];
     if ((cdf[offset + 1] - cdf[offset]) > 0) du /= (cdf[offset + 1] - cdf[offset]);
     pdf = (funcInt > 0) ? func[offset] / funcInt : 0;
-    return (offset + du) / 2;
+    return (offset + du) / n;
 }
-PG_DEV float env_pdf_li(const PgLight &l, V3 w) {  // InfiniteAreaLight::Pdf_Li, infinite.cpp:127-135; Distribution2D::Pdf, sampling.h:135-141
+PG_DEV float env_pdf_li(const DScene &sc, const PgLight &l, V3 w) {  // InfiniteAreaLight::Pdf_Li, infinite.cpp:127-135; Distribution2D::Pdf, sampling.h:135-141
     V3 wi = mat3_mul(l.w2l, w);
     float theta = spherical_theta(wi), phi = spherical_phi(wi);
     float sinTheta = (float)sin((double)theta);
     if (sinTheta == 0) return 0;
     float p0 = phi * PG_INV2PI, p1 = theta * PG_INVPI;
-    int iu = (int)(p0 * 2); iu = iu < 0 ? 0 : (iu > 1 ? 1 : iu);
-    int iv = (int)(p1 * 2); iv = iv < 0 ? 0 : (iv > 1 ? 1 : iv);
-    return (l.env_func[iv][iu] / l.env_marg_int) / (2 * PG_PI * PG_PI * sinTheta);
+    const int nu = l.env_nu, nv = l.env_nv;
+    const float *tab = sc.envTables + l.env_table;
+    int iu = (int)(p0 * nu); iu = iu < 0 ? 0 : (iu > nu - 1 ? nu - 1 : iu);
+    int iv = (int)(p1 * nv); iv = iv < 0 ? 0 : (iv > nv - 1 ? nv - 1 : iv);
+    const float *row = tab + (size_t)(2 * nu + 2) * iv, *marg = tab + (size_t)(2 * nu + 2) * nv;
+    return (row[iu] / marg[2 * nv + 1]) / (2 * PG_PI * PG_PI * sinTheta);
 }
 // EXT: the scene has primitives or lights beyond triangles + area / delta lights (spheres, infinite lights); the plain
 // instantiation keeps the common kernels at their register count
@@ -1482,8 +1477,11 @@ PG_DEV Spec light_sample_li(const DScene &sc, const PgLight &light, V3 refp, V3 
     if (EXT && light.type == PG_LIGHT_INFINITE) {  // InfiniteAreaLight::Sample_Li, infinite.cpp:99-125
         float pdf0, pdf1;
         int v;
-        float d1 = env_sample_1d(light.env_int, light.env_marg_cdf, light.env_marg_int, u1, pdf1, &v);
-        float d0 = env_sample_1d(light.env_func[v], light.env_cdf[v], light.env_int[v], u0, pdf0, nullptr);
+        const int nu = light.env_nu, nv = light.env_nv;
+        const float *tab = sc.envTables + light.env_table, *marg = tab + (size_t)(2 * nu + 2) * nv;
+        float d1 = env_sample_1d(marg, marg + nv, marg[2 * nv + 1], nv, u1, pdf1, &v);  // Distribution2D::SampleContinuous, sampling.h:127-134
+        const float *row = tab + (size_t)(2 * nu + 2) * v;
+        float d0 = env_sample_1d(row, row + nu, row[2 * nu + 1], nu, u0, pdf0, nullptr);
         float mapPdf = pdf0 * pdf1;
         ls.n = mk(0, 0, 0); ls.pError = mk(0, 0, 0); ls.p = refp;
         pdf = 0;
@@ -1497,7 +1495,7 @@ PG_DEV Spec light_sample_li(const DScene &sc, const PgLight &light, V3 refp, V3 
         pdf = mapPdf / (2 * PG_PI * PG_PI * sinTheta);
         if (sinTheta == 0) pdf = 0;
         ls.p = refp + wi * (2 * light.world_radius);
-        return env_lookup(light, d0, d1);
+        return env_lookup(sc, light, d0, d1);
     }
     if (light.type != PG_LIGHT_AREA) {  // delta lights: point.cpp:43-52, spot.cpp:51-60, distant.cpp:50-60
         const Spec I = sp3(light.L[0], light.L[1], light.L[2]);
@@ -1647,7 +1645,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
         } else if ((bounces == 0 || specularBounce) && found) L = L + beta * sp(0);
         else if (EXT && (bounces == 0 || specularBounce) && !found && sc.hasInfinite) {  // path.cpp:96-100: every infinite light's Le(ray)
             for (int li = 0; li < sc.nLights; ++li)
-                if (sc.lights[li].type == PG_LIGHT_INFINITE) L = L + beta * env_le(sc.lights[li], rayD);
+                if (sc.lights[li].type == PG_LIGHT_INFINITE) L = L + beta * env_le(sc, sc.lights[li], rayD);
         }
         bool alive = found && bounces < rd.max_depth;  // path.cpp:104
         int newFlags = 0;
@@ -1871,7 +1869,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
     if (misCand) {
         // light.Pdf_Li -> Shape::Pdf(ref, wi): intersect the light's own triangle (shape.cpp:72-87, diffuse.cpp:83-87)
         float lightPdf2 = 0;
-        if (EXT && misLightPrim < 0) lightPdf2 = env_pdf_li(sc.lights[-1 - misLightPrim], misWi);  // infinite light: no geometry to test
+        if (EXT && misLightPrim < 0) lightPdf2 = env_pdf_li(sc, sc.lights[-1 - misLightPrim], misWi);  // infinite light: no geometry to test
         Tri lt = load_tri(sc, misLightPrim < 0 ? 0 : misLightPrim);
         float t, lb0, lb1, lb2;
         if (EXT && misLightPrim >= 0 && (lt.flags & PG_PRIM_SPHERE)) {  // Sphere::Pdf, sphere.cpp:292-305
@@ -1954,7 +1952,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_resolve(DScene sc, PathState st, R
             }
         } else if (EXT && sc.lights[info.z].type == PG_LIGHT_INFINITE) {  // integrator.cpp:207-208: no surface hit: Li = light.Le(ray)
             const float4 d4 = qmis.d[info.y];
-            Spec Li = env_le(sc.lights[info.z], mk(d4.x, d4.y, d4.z));
+            Spec Li = env_le(sc, sc.lights[info.z], mk(d4.x, d4.y, d4.z));
             if (!is_black(Li)) Ld = Ld + ((((sp3(pm.x, pm.y, pm.z) * Li) * sp(1.f)) * pb.w) / pm.w);
         }
     }

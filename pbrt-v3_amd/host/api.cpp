@@ -84,6 +84,7 @@ struct RenderOptions {
     std::vector<PgTexturedMaterial> textured;
     std::vector<PgImage> images;      // MIPMaps of the image textures, shared through imageCache (imagemap.cpp:55-59)
     std::vector<float> texels;
+    std::vector<float> envTables;     // the infinite lights' Distribution2D tables
     std::map<std::string, int> imageCache;
     bool haveScatteringMedia = false;
 };
@@ -798,35 +799,48 @@ void pbrtLightSource(const std::string &name, const ParamSet &params) {
     } else if (name == "infinite" || name == "exinfinite") {  // CreateInfiniteLight, infinite.cpp:176-188; ctor :44-85
         RGB L = params.FindOneSpectrum("L", RGB{{1.f, 1.f, 1.f}});
         params.FindOneInt("samples", params.FindOneInt("nsamples", 1));
-        if (!params.FindOneString("mapname", "").empty())
-            Error("Environment maps (\"mapname\") are not supported by this build; using the constant radiance \"L\".");
+        std::string texmap = params.FindOneString("mapname", "");
+        if (!texmap.empty()) texmap = AbsolutePath(ResolveFilename(texmap));
         l.type = PG_LIGHT_INFINITE;
         for (int i = 0; i < 3; ++i) l.L[i] = L.c[i] * sc.c[i];
         const Matrix4x4 &m = light2world.GetMatrix(), &mi = light2world.GetInverseMatrix();
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { l.l2w[3 * r + c] = m.m[r][c]; l.w2l[3 * r + c] = mi.m[r][c]; }
-        // Lmap is the 1x1 MIPMap of L; img[u + v*2] = Lmap->Lookup((u+.5)/2, (v+.5)/2, fwidth = 0.25).y() * sin(Pi*(v+.5)/2)
-        const int width = 2, height = 2;
+        // Lmap: the map's texels times L (no vertical flip here), or the single texel L (infinite.cpp:50-64)
+        int resX = 1, resY = 1;
+        std::vector<RGB> texels;
+        if (!texmap.empty() && ReadImage(texmap, &resX, &resY, &texels)) {
+            for (RGB &t : texels) for (int c = 0; c < 3; ++c) t.c[c] *= l.L[c];
+        } else { resX = resY = 1; texels.assign(1, RGB{{l.L[0], l.L[1], l.L[2]}}); }
+        std::vector<float> conv((size_t)resX * resY * 3);
+        for (size_t i = 0; i < texels.size(); ++i) for (int c = 0; c < 3; ++c) conv[3 * i + c] = texels[i].c[c];
+        PgImage lmap;
+        memset(&lmap, 0, sizeof(lmap));
+        lmap.is_float = 0; lmap.wrap = 0; lmap.trilinear = 0; lmap.max_anisotropy = 8.f;  // MIPMap's defaults (mipmap.h:70-71)
+        BuildMIPMap(resX, resY, 3, conv, 0, &lmap, &renderOptions->texels);
+        l.env_image = (int)renderOptions->images.size();
+        renderOptions->images.push_back(lmap);
+        // the scalar image of the sampling distribution (infinite.cpp:66-84)
+        const int width = 2 * lmap.width, height = 2 * lmap.height;
+        std::vector<Float> img((size_t)width * height);
         float fwidth = 0.5f / std::min(width, height);
-        (void)fwidth;  // level = Log2(0.25) < 0: MIPMap::Lookup takes the triangle(0, st) branch (mipmap.h:245-274)
-        Float img[4];
         for (int v = 0; v < height; ++v) {
             Float vp = (v + .5f) / (Float)height;
             Float sinTheta = std::sin(Pi * (v + .5f) / height);
             for (int u = 0; u < width; ++u) {
                 Float up = (u + .5f) / (Float)width;
-                // triangle(0, (up, vp)) on a 1x1 texture: every Texel() is L
-                Float s_ = up * 1 - 0.5f, t_ = vp * 1 - 0.5f;
-                int s0 = (int)std::floor(s_), t0 = (int)std::floor(t_);
-                Float ds = s_ - s0, dt = t_ - t0;
-                Float rgb[3];
-                for (int c = 0; c < 3; ++c)
-                    rgb[c] = (1 - ds) * (1 - dt) * l.L[c] + (1 - ds) * dt * l.L[c] + ds * (1 - dt) * l.L[c] + ds * dt * l.L[c];
-                Float y = 0.212671f * rgb[0] + 0.715160f * rgb[1] + 0.072169f * rgb[2];
-                img[u + v * width] = y;
+                const float st[2] = {up, vp};
+                float rgb[3];
+                MIPMapLookup(lmap, renderOptions->texels, st, fwidth, rgb);
+                img[u + v * width] = 0.212671f * rgb[0] + 0.715160f * rgb[1] + 0.072169f * rgb[2];  // .y()
                 img[u + v * width] *= sinTheta;
             }
         }
-        auto dist1d = [](const Float *f, int n, Float *func, Float *cdf, Float *funcInt) {  // Distribution1D ctor, sampling.h:57-70
+        {   // Power(): Lmap->Lookup(Point2f(.5f, .5f), .5f), infinite.cpp:87-91
+            const float st[2] = {.5f, .5f};
+            MIPMapLookup(lmap, renderOptions->texels, st, .5f, l.env_power);
+        }
+        // Distribution2D (sampling.cpp:159-171) of Distribution1Ds (sampling.h:57-70)
+        auto dist1d = [](const Float *f, int n, Float *func, Float *cdf, Float *funcInt) {
             for (int i = 0; i < n; ++i) func[i] = f[i];
             cdf[0] = 0;
             for (int i = 1; i < n + 1; ++i) cdf[i] = cdf[i - 1] + func[i - 1] / n;
@@ -834,9 +848,18 @@ void pbrtLightSource(const std::string &name, const ParamSet &params) {
             if (*funcInt == 0) { for (int i = 1; i < n + 1; ++i) cdf[i] = Float(i) / Float(n); }
             else { for (int i = 1; i < n + 1; ++i) cdf[i] /= *funcInt; }
         };
-        for (int v = 0; v < 2; ++v) dist1d(&img[2 * v], 2, l.env_func[v], l.env_cdf[v], &l.env_int[v]);
-        Float margFunc[2];
-        dist1d(l.env_int, 2, margFunc, l.env_marg_cdf, &l.env_marg_int);
+        std::vector<float> &tab = renderOptions->envTables;
+        l.env_nu = width; l.env_nv = height; l.env_table = (int64_t)tab.size();
+        const size_t rowStride = 2 * (size_t)width + 2, base = tab.size();
+        tab.resize(base + rowStride * height + 2 * (size_t)height + 2);
+        std::vector<Float> marginalFunc(height);
+        for (int v = 0; v < height; ++v) {
+            float *row = &tab[base + rowStride * v];
+            dist1d(&img[(size_t)v * width], width, row, row + width, row + 2 * width + 1);
+            marginalFunc[v] = row[2 * width + 1];
+        }
+        float *mrow = &tab[base + rowStride * height];
+        dist1d(marginalFunc.data(), height, mrow, mrow + height, mrow + 2 * height + 1);
     } else {
         Error("LightSource \"%s\" is outside this build's closed set (point, spot, distant, infinite, and diffuse area lights); ignoring.", name.c_str());
         return;
@@ -1062,6 +1085,7 @@ static Scene *MakeScene() {
     scene->textured = ro.textured;
     scene->images = ro.images;
     scene->texels = ro.texels;
+    scene->envTables = ro.envTables;
     scene->worldBound = scene->aggregate->WorldBound();
     // resolve each light's emitting triangle to its index in BVH order
     const auto &prims = scene->aggregate->primitives;

@@ -312,6 +312,39 @@ void BuildMIPMap(int resX, int resY, int nc, const std::vector<float> &data, int
         prevOff = off; sPrev = sRes; tPrev = tRes;
     }
 }
+// MIPMap<T>::Lookup(st, width) on the host (mipmap.h:214-243): InfiniteAreaLight's constructor and Power() use it
+static void mipTexel(const PgImage &im, const std::vector<float> &pool, int level, int s, int t, float out[3]) {
+    const int nc = im.is_float ? 1 : 3;
+    const int sRes = std::max(1, im.width >> level), tRes = std::max(1, im.height >> level);
+    out[0] = out[1] = out[2] = 0;
+    if (im.wrap == 0) { s = Mod(s, sRes); t = Mod(t, tRes); }
+    else if (im.wrap == 2) { s = std::min(std::max(s, 0), sRes - 1); t = std::min(std::max(t, 0), tRes - 1); }
+    else if (s < 0 || s >= sRes || t < 0 || t >= tRes) return;
+    const float *p = &pool[(size_t)im.level_offset[level] + ((size_t)t * sRes + s) * nc];
+    for (int c = 0; c < nc; ++c) out[c] = p[c];
+}
+static void mipTriangle(const PgImage &im, const std::vector<float> &pool, int level, const float st[2], float out[3]) {
+    level = std::min(std::max(level, 0), im.n_levels - 1);
+    const int sRes = std::max(1, im.width >> level), tRes = std::max(1, im.height >> level);
+    Float s = st[0] * sRes - 0.5f, t = st[1] * tRes - 0.5f;
+    int s0 = std::floor(s), t0 = std::floor(t);
+    Float ds = s - s0, dt = t - t0;
+    float a[3], b[3], c[3], d[3];
+    mipTexel(im, pool, level, s0, t0, a); mipTexel(im, pool, level, s0, t0 + 1, b);
+    mipTexel(im, pool, level, s0 + 1, t0, c); mipTexel(im, pool, level, s0 + 1, t0 + 1, d);
+    for (int k = 0; k < 3; ++k) out[k] = (1 - ds) * (1 - dt) * a[k] + (1 - ds) * dt * b[k] + ds * (1 - dt) * c[k] + ds * dt * d[k];
+}
+void MIPMapLookup(const PgImage &im, const std::vector<float> &pool, const float st[2], float width, float out[3]) {
+    const Float invLog2 = 1.442695040888963387004650940071;
+    Float level = im.n_levels - 1 + std::log(std::max(width, (Float)1e-8)) * invLog2;  // Log2, pbrt.h:328-331
+    if (level < 0) { mipTriangle(im, pool, 0, st, out); return; }
+    if (level >= im.n_levels - 1) { mipTexel(im, pool, im.n_levels - 1, 0, 0, out); return; }
+    int iLevel = std::floor(level);
+    Float delta = level - iLevel;
+    float a[3], b[3];
+    mipTriangle(im, pool, iLevel, st, a); mipTriangle(im, pool, iLevel + 1, st, b);
+    for (int k = 0; k < 3; ++k) out[k] = (1 - delta) * a[k] + delta * b[k];
+}
 void EWAWeightLut(float lut[128]) {  // mipmap.h:178-184
     for (int i = 0; i < 128; ++i) {
         Float alpha = 2;

@@ -281,6 +281,7 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     flat->textured = scene.textured;
     flat->images = scene.images;
     flat->texels = scene.texels;
+    flat->envTables = scene.envTables;
     EWAWeightLut(flat->ewaLut);
     flat->lights = scene.lights;
     // Light::Preprocess (scene.h:57-60): DistantLight keeps the world's bounding sphere (distant.h:55-57, geometry.h:803-806)
@@ -325,6 +326,7 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     d.n_images = (int)flat->images.size(); d.images = flat->images.data();
     d.n_texel_floats = (int64_t)flat->texels.size(); d.texels = flat->texels.data();
     d.ewa_lut = flat->ewaLut;
+    d.n_env_floats = (int64_t)flat->envTables.size(); d.env_tables = flat->envTables.data();
 }
 
 void GpuPathIntegrator::FillRenderDesc(PgRenderDesc *rd) const {

@@ -102,6 +102,7 @@ struct Scene {  // core/scene.h:50-80
     std::vector<PgTexturedMaterial> textured;
     std::vector<PgImage> images;
     std::vector<float> texels;
+    std::vector<float> envTables;
     Bounds3f worldBound;
 };
 
@@ -140,6 +141,7 @@ bool ReadImage(const std::string &name, int *xres, int *yres, std::vector<RGB> *
 bool ImageGammaDefault(const std::string &filename);
 void BuildMIPMap(int resX, int resY, int nc, const std::vector<float> &data, int wrap, PgImage *img, std::vector<float> *pool);
 void EWAWeightLut(float lut[128]);
+void MIPMapLookup(const PgImage &im, const std::vector<float> &pool, const float st[2], float width, float out[3]);
 bool WriteImagePFM(const std::string &filename, const Float *rgb, int width, int height);  // imageio.cpp:437-482
 
 struct PerspectiveCamera {  // ProjectiveCamera (core/camera.h:87-108): cameras/perspective.cpp:45-68 or orthographic.cpp:44-62
@@ -180,6 +182,7 @@ struct FlatScene {
     std::vector<PgTexturedMaterial> textured;
     std::vector<PgImage> images;
     std::vector<float> texels;
+    std::vector<float> envTables;
     float ewaLut[128];
 };
 

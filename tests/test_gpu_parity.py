@@ -38,8 +38,9 @@ def test_golden_images(gpu, oracle, name):
         cr_img, _ = oracle.render_image(scene, cr_libm=True)
         assert bad.sum() <= 2 and np.array_equal(img[bad], cr_img[bad]), f"max rel err {err.max():.3e} at {np.argwhere(bad)[:4].tolist()}"
         err[bad] = 0
-    # nearly every pixel is bit-identical; the rest differ in the last ulps only
-    assert (err.max(axis=2) > 0).mean() < 0.25
+    # most pixels are bit-identical, the rest differ in the last ulps only (libm's last bit: every pixel lit through an
+    # environment map or a spherical mapping goes through acosf / atan2f)
+    assert np.median(err) <= 1e-6 and np.percentile(err, 99) <= 2e-5
     stats = json.load(open(os.path.join(GOLD, name + ".json")))
     assert cn["camera_rays"] == stats["camera_rays"]
     for k in ("closest_rays", "shadow_rays", "tri_tests"):  # a 1-ulp direction change may add/remove a handful of rays
