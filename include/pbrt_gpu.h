@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 12
+#define PG_ABI_VERSION 13
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -60,6 +60,7 @@ typedef struct PgBVHNode {
 #define PG_TRI_HAS_UV 8u      /* mesh has per-vertex uv               */
 #define PG_TRI_HAS_S 16u      /* mesh has per-vertex tangents         */
 #define PG_PRIM_SPHERE 32u    /* not a triangle: spheres[indices[3*k]] (PgSphere below) */
+#define PG_TRI_ALPHA 128u      /* the mesh has an alpha / shadow-alpha texture: alphas[tri_alpha[k]] (triangle.cpp:333-338, :531-569) */
 #define PG_PRIM_INSTANCE 64u  /* a TransformedPrimitive: instances[indices[3*k]] (PgInstance below); top level only */
 
 typedef enum PgMaterialType {
@@ -173,6 +174,12 @@ typedef enum PgMaterialKind {
     PG_KIND_MATTE = 1, PG_KIND_PLASTIC = 2, PG_KIND_MIRROR = 3, PG_KIND_GLASS = 4, PG_KIND_UBER = 5, PG_KIND_METAL = 6,
     PG_KIND_SUBSTRATE = 7, PG_KIND_TRANSLUCENT = 8, PG_KIND_MIX = 9
 } PgMaterialKind;
+/* TriangleMesh::alphaMask / shadowAlphaMask (shapes/triangle.h:66-67): float textures that cut hits out of a mesh --
+ * Triangle::Intersect rejects a hit whose alpha evaluates to 0, IntersectP one whose alpha or shadow alpha does. */
+typedef struct PgAlphaMask {
+    int32_t has_alpha, has_shadow_alpha;
+    PgTexRef alpha, shadow_alpha;
+} PgAlphaMask;
 typedef struct PgTexturedMaterial {
     int32_t kind;              /* PgMaterialKind */
     /* spectrum parameters, by kind: matte Kd | plastic Kd Ks | mirror Kr | glass Kr Kt | uber Kd Ks Kr Kt opacity |
@@ -301,6 +308,9 @@ typedef struct PgSceneDesc {
     const PgImage *images;
     int64_t n_texel_floats;
     const float *texels;
+    int32_t n_alphas;
+    const PgAlphaMask *alphas;
+    const int32_t *tri_alpha;   /* per primitive (n_prims_all): index into alphas for triangles with PG_TRI_ALPHA; may be NULL */
     int64_t n_env_floats;
     const float *env_tables;    /* the infinite lights' Distribution2D tables (PgLight.env_table) */
     const float *ewa_lut;       /* MIPMap::weightLut, 128 entries (mipmap.h:178-184); may be NULL without images */

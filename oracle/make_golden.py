@@ -175,6 +175,26 @@ def with_image_textures(s):
     return s
 
 
+def with_alpha(s):
+    s = with_normals(s, uv=True)
+    tex = ('Texture "a_chk" "float" "checkerboard" "float uscale" [ 4 ] "float vscale" [ 4 ] "float tex1" [ 0 ] "float tex2" [ 1 ]\n'
+           'Texture "a_chk2" "float" "checkerboard" "string aamode" "none" "float uscale" [ 2 ] "float vscale" [ 6 ] "float tex1" [ 1 ] "float tex2" [ 0 ]\n'
+           'Texture "a_img" "float" "imagemap" "string filename" "img_pal.png" "bool gamma" "false" "float scale" [ 1 ]\n'
+           'Texture "a_cut" "float" "scale" "texture tex1" "a_img" "texture tex2" "a_chk2"\n')
+    s = s.replace("WorldBegin\n", "WorldBegin\n" + tex, 1)
+    # the two boxes are the 24-vertex meshes; give them masks
+    boxes = [m.start() for m in re.finditer(r'Shape "trianglemesh"\n  "integer indices" \[ 0 1 2 0 2 3  4 5 6', s)]
+    assert len(boxes) == 2
+    s = s[:boxes[1]] + 'Shape "trianglemesh" "texture alpha" "a_cut" "texture shadowalpha" "a_chk"\n  "integer indices" [ 0 1 2 0 2 3  4 5 6' + s[boxes[1] + len('Shape "trianglemesh"\n  "integer indices" [ 0 1 2 0 2 3  4 5 6'):]
+    s = s[:boxes[0]] + 'Shape "trianglemesh" "texture alpha" "a_chk"\n  "integer indices" [ 0 1 2 0 2 3  4 5 6' + s[boxes[0] + len('Shape "trianglemesh"\n  "integer indices" [ 0 1 2 0 2 3  4 5 6'):]
+    # a masked emitter, an invisible quad and a shadow-masked quad
+    s = s.replace("# short box", 'AttributeBegin\n  AreaLightSource "diffuse" "rgb L" [ 6 5 3 ]\n  Shape "trianglemesh" "texture alpha" "a_chk2" "integer indices" [ 0 1 2 0 2 3 ] '
+                  '"point P" [ 100 300 200  200 300 200  200 400 250  100 400 250 ] "float uv" [ 0 0 1 0 1 1 0 1 ]\nAttributeEnd\n'
+                  'Shape "trianglemesh" "float alpha" [ 0 ] "integer indices" [ 0 1 2 0 2 3 ] "point P" [ 0 100 100  556 100 100  556 400 100  0 400 100 ]\n'
+                  'Shape "trianglemesh" "texture shadowalpha" "a_chk" "integer indices" [ 0 1 2 0 2 3 ] "point P" [ 350 250 150  500 250 150  500 250 350  350 250 350 ] "float uv" [ 0 0 1 0 1 1 0 1 ]\n# short box', 1)
+    return s
+
+
 def with_uv_boxes(s):
     return with_normals(s, uv=True).replace(' "normal N" [', ' "normal Nunused" [')
 
@@ -483,6 +503,9 @@ SCENES = {
                              world_edit=lambda s: s.replace("# light\nAttributeBegin", 'AttributeBegin\n  Rotate -70 0 0 1\n  LightSource "infinite" "string mapname" "img_rgb.png" "rgb scale" [ 0.5 0.5 0.5 ]\nAttributeEnd\n# light\nAttributeBegin')
                              .replace('Shape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ]\n  "point P" [ 556 548.8 0   556 548.8 559.2   0 548.8 559.2   0 548.8 0 ]', "")
                              .replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\nMaterial "glass"')),
+    # alpha / shadowalpha textures on triangle meshes (triangle.cpp:333-338, :531-569): checkerboard and image masks, a
+    # constant 0 (an invisible mesh), a shadow-only mask, and a masked emitter (sampled and MIS-weighted without the mask)
+    "alpha_masks": cornell(40, 40, 8, integrator='Integrator "path" "integer maxdepth" [ 5 ]', world_edit=lambda s: with_alpha(s)),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 

@@ -5,7 +5,7 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 12
+PG_ABI_VERSION = 13
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
 PG_LIGHTS_UNIFORM, PG_LIGHTS_POWER, PG_LIGHTS_SPATIAL = 0, 1, 2
@@ -46,6 +46,10 @@ class PgTexture(C.Structure):
 class PgImage(C.Structure):
     _fields_ = [("is_float", C.c_int32), ("n_levels", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("wrap", C.c_int32),
                 ("trilinear", C.c_int32), ("max_anisotropy", C.c_float), ("level_offset", C.c_int64 * 16)]
+
+
+class PgAlphaMask(C.Structure):
+    _fields_ = [("has_alpha", C.c_int32), ("has_shadow_alpha", C.c_int32), ("alpha", PgTexRef), ("shadow_alpha", PgTexRef)]
 
 
 class PgTexturedMaterial(C.Structure):
@@ -92,6 +96,7 @@ class PgSceneDesc(C.Structure):
                 ("n_instances", C.c_int32), ("instances", C.POINTER(PgInstance)),
                 ("n_textures", C.c_int32), ("textures", C.POINTER(PgTexture)), ("n_textured", C.c_int32), ("textured", C.POINTER(PgTexturedMaterial)),
                 ("n_images", C.c_int32), ("images", C.POINTER(PgImage)), ("n_texel_floats", C.c_int64), ("texels", C.POINTER(C.c_float)),
+                ("n_alphas", C.c_int32), ("alphas", C.POINTER(PgAlphaMask)), ("tri_alpha", C.POINTER(C.c_int32)),
                 ("n_env_floats", C.c_int64), ("env_tables", C.POINTER(C.c_float)), ("ewa_lut", C.POINTER(C.c_float))]
 
 

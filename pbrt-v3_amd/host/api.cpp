@@ -85,6 +85,7 @@ struct RenderOptions {
     std::vector<PgImage> images;      // MIPMaps of the image textures, shared through imageCache (imagemap.cpp:55-59)
     std::vector<float> texels;
     std::vector<float> envTables;     // the infinite lights' Distribution2D tables
+    std::vector<PgAlphaMask> alphas;  // alpha / shadow-alpha textures of the meshes that have them
     std::map<std::string, int> imageCache;
     bool haveScatteringMedia = false;
 };
@@ -892,6 +893,28 @@ std::shared_ptr<TriangleMesh> BuildTriangleMesh(const Transform &o2w, bool rever
 std::shared_ptr<TriangleMesh> CreatePLYMesh(const Transform &o2w, bool reverseOrientation, const ParamSet &params);  // plymesh.cpp
 std::shared_ptr<TriangleMesh> CreateLoopSubdiv(const Transform &o2w, bool reverseOrientation, const ParamSet &params);  // loopsubdiv.cpp
 
+// The "alpha" / "shadowalpha" parameters of a mesh (triangle.cpp:716-738, plymesh.cpp:259-287): a named float texture, or
+// the literal 0 (a constant-zero mask); returns the index of the mesh's PgAlphaMask or -1
+int MeshAlphaMask(const ParamSet &params) {
+    PgAlphaMask am;
+    memset(&am, 0, sizeof(am));
+    am.alpha.tex = am.shadow_alpha.tex = -1;
+    const char *names[2] = {"alpha", "shadowalpha"};
+    for (int k = 0; k < 2; ++k) {
+        PgTexRef ref; ref.tex = -1; ref.v[0] = ref.v[1] = ref.v[2] = 0;
+        bool has = false;
+        const std::string texName = params.FindTexture(names[k]);
+        if (!texName.empty()) {
+            auto it = graphicsState.floatTextures.find(texName);
+            if (it != graphicsState.floatTextures.end()) { ref = it->second; has = true; }
+            else Error("Couldn't find float texture \"%s\" for \"%s\" parameter", texName.c_str(), names[k]);
+        } else if (params.FindOneFloat(names[k], 1.f) == 0.f) has = true;  // ConstantTexture<Float>(0.f)
+        if (k == 0) { am.has_alpha = has; am.alpha = ref; } else { am.has_shadow_alpha = has; am.shadow_alpha = ref; }
+    }
+    if (!am.has_alpha && !am.has_shadow_alpha) return -1;
+    renderOptions->alphas.push_back(am);
+    return (int)renderOptions->alphas.size() - 1;
+}
 // shapes/triangle.cpp:647-743 CreateTriangleMeshShape + :94-110 CreateTriangleMesh
 static std::shared_ptr<TriangleMesh> CreateTriangleMeshShape(const Transform &o2w, bool reverseOrientation, const ParamSet &params) {
     const std::vector<int> *vi = params.FindInt("indices");
@@ -916,12 +939,12 @@ static std::shared_ptr<TriangleMesh> CreateTriangleMeshShape(const Transform &o2
             Error("trianglemesh has out of-bounds vertex index %d (%d \"P\" values were given", (*vi)[i], npi);
             return nullptr;
         }
-    if (!params.FindTexture("alpha").empty() || !params.FindTexture("shadowalpha").empty() ||
-        params.FindOneFloat("alpha", 1.f) == 0.f || params.FindOneFloat("shadowalpha", 1.f) == 0.f)
-        Error("Alpha-mask textures on triangle meshes are not supported by this build; ignoring.");
+    const int alphaMask = MeshAlphaMask(params);
     params.FindInt("faceIndices");
-    return BuildTriangleMesh(o2w, reverseOrientation, nvi / 3, vi->data(), npi, P->data(), S ? S->data() : nullptr, N ? N->data() : nullptr,
-                             uvs ? uvs->data() : nullptr);
+    auto mesh = BuildTriangleMesh(o2w, reverseOrientation, nvi / 3, vi->data(), npi, P->data(), S ? S->data() : nullptr, N ? N->data() : nullptr,
+                                  uvs ? uvs->data() : nullptr);
+    mesh->alphaMask = alphaMask;
+    return mesh;
 }
 
 void pbrtShape(const std::string &name, const ParamSet &params) {  // api.cpp:1329-1421
@@ -1086,6 +1109,7 @@ static Scene *MakeScene() {
     scene->images = ro.images;
     scene->texels = ro.texels;
     scene->envTables = ro.envTables;
+    scene->alphas = ro.alphas;
     scene->worldBound = scene->aggregate->WorldBound();
     // resolve each light's emitting triangle to its index in BVH order
     const auto &prims = scene->aggregate->primitives;

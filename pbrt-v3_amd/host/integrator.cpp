@@ -273,6 +273,7 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
         if (!m->n.empty()) f |= PG_TRI_HAS_N;
         if (!m->uv.empty()) f |= PG_TRI_HAS_UV;
         if (!m->s.empty()) f |= PG_TRI_HAS_S;
+        if (m->alphaMask >= 0) { f |= PG_TRI_ALPHA; if (flat->triAlpha.empty()) flat->triAlpha.assign(nTris, -1); flat->triAlpha[k] = m->alphaMask; }
         flat->triFlags[k] = f;
     }
     flat->materials = scene.materials;
@@ -282,6 +283,7 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     flat->images = scene.images;
     flat->texels = scene.texels;
     flat->envTables = scene.envTables;
+    flat->alphas = scene.alphas;
     EWAWeightLut(flat->ewaLut);
     flat->lights = scene.lights;
     // Light::Preprocess (scene.h:57-60): DistantLight keeps the world's bounding sphere (distant.h:55-57, geometry.h:803-806)
@@ -327,6 +329,8 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     d.n_texel_floats = (int64_t)flat->texels.size(); d.texels = flat->texels.data();
     d.ewa_lut = flat->ewaLut;
     d.n_env_floats = (int64_t)flat->envTables.size(); d.env_tables = flat->envTables.data();
+    d.n_alphas = (int)flat->alphas.size(); d.alphas = flat->alphas.data();
+    d.tri_alpha = flat->triAlpha.empty() ? nullptr : flat->triAlpha.data();
 }
 
 void GpuPathIntegrator::FillRenderDesc(PgRenderDesc *rd) const {

@@ -15,6 +15,7 @@
 #include "scene.h"
 
 namespace pbrt {
+int MeshAlphaMask(const ParamSet &params);  // api.cpp
 namespace {
 enum PlyType { T_I8, T_U8, T_I16, T_U16, T_I32, T_U32, T_F32, T_F64, T_BAD };
 int typeSize(PlyType t) { static const int sz[] = {1, 1, 2, 2, 4, 4, 4, 8, 0}; return sz[t]; }
@@ -180,10 +181,10 @@ std::shared_ptr<TriangleMesh> CreatePLYMesh(const Transform &o2w, bool reverseOr
     }
     if (!rd.ok) { Error("%s: unable to read the contents of PLY file", filename.c_str()); return nullptr; }
     if (error) return nullptr;
-    if (!params.FindTexture("alpha").empty() || !params.FindTexture("shadowalpha").empty() ||
-        params.FindOneFloat("alpha", 1.f) == 0.f || params.FindOneFloat("shadowalpha", 1.f) == 0.f)
-        Error("Alpha-mask textures on triangle meshes are not supported by this build; ignoring.");
-    return BuildTriangleMesh(o2w, reverseOrientation, (int)indices.size() / 3, indices.data(), (int)vertexCount, P.data(), nullptr,
-                             N.empty() ? nullptr : N.data(), UV.empty() ? nullptr : UV.data());
+    const int alphaMask = MeshAlphaMask(params);  // plymesh.cpp:259-287
+    auto mesh = BuildTriangleMesh(o2w, reverseOrientation, (int)indices.size() / 3, indices.data(), (int)vertexCount, P.data(), nullptr,
+                                  N.empty() ? nullptr : N.data(), UV.empty() ? nullptr : UV.data());
+    mesh->alphaMask = alphaMask;
+    return mesh;
 }
 }  // namespace pbrt

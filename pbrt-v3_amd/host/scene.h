@@ -23,6 +23,7 @@ struct TriangleMesh {
     std::vector<Vector3f> s;
     std::vector<Float> uv;  // 2 per vertex
     bool reverseOrientation = false, transformSwapsHandedness = false;
+    int alphaMask = -1;  // index into the scene's PgAlphaMask table (alphaMask / shadowAlphaMask, triangle.h:66-67), or -1
 };
 // One Triangle shape per mesh triangle (triangle.cpp:94-110).
 struct Triangle {
@@ -103,6 +104,7 @@ struct Scene {  // core/scene.h:50-80
     std::vector<PgImage> images;
     std::vector<float> texels;
     std::vector<float> envTables;
+    std::vector<PgAlphaMask> alphas;
     Bounds3f worldBound;
 };
 
@@ -183,6 +185,8 @@ struct FlatScene {
     std::vector<PgImage> images;
     std::vector<float> texels;
     std::vector<float> envTables;
+    std::vector<PgAlphaMask> alphas;
+    std::vector<int32_t> triAlpha;
     float ewaLut[128];
 };
 
