@@ -45,7 +45,7 @@ struct DeviceBuffer {
 struct PgScene {
     int device = 0;
     DScene d;
-    DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, textures, textured, images, texels, ewaLut, envTables, triN, triS, uv, materials, lights, distTable, perms, permSums, primes;
+    DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, textures, textured, images, texels, ewaLut, envTables, alphas, triAlpha, triN, triS, uv, materials, lights, distTable, perms, permSums, primes;
     // work buffers (sized on first render, reused)
     int capacity = 0;
     DeviceBuffer qo[4], qd[4], counts, hitsMain, hitInst, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
@@ -420,6 +420,24 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         HIP_TRY_S(hipMemcpy(s->envTables.p, desc->env_tables, s->envTables.bytes, hipMemcpyHostToDevice));
     }
     d.envTables = (const float *)s->envTables.p;
+    {  // alpha masks of triangle meshes
+        bool anyAlpha = false;
+        for (int k = 0; k < nt && desc->tri_flags; ++k)
+            if ((desc->tri_flags[k] & PG_TRI_ALPHA) && !(desc->tri_flags[k] & (PG_PRIM_SPHERE | PG_PRIM_INSTANCE))) {
+                anyAlpha = true;
+                if (!desc->tri_alpha || !desc->alphas || desc->tri_alpha[k] < 0 || desc->tri_alpha[k] >= desc->n_alphas)
+                    FAIL(PG_ERR_INVALID, "triangle %d: PG_TRI_ALPHA without a valid alpha mask", k);
+                const PgAlphaMask &am = desc->alphas[desc->tri_alpha[k]];
+                if (am.alpha.tex >= desc->n_textures || am.shadow_alpha.tex >= desc->n_textures) FAIL(PG_ERR_INVALID, "triangle %d: alpha texture out of range", k);
+            }
+        if (anyAlpha) {
+            HIP_TRY_S(s->alphas.alloc(sizeof(PgAlphaMask) * (size_t)desc->n_alphas));
+            HIP_TRY_S(hipMemcpy(s->alphas.p, desc->alphas, s->alphas.bytes, hipMemcpyHostToDevice));
+            HIP_TRY_S(s->triAlpha.alloc(sizeof(int) * (size_t)nt));
+            HIP_TRY_S(hipMemcpy(s->triAlpha.p, desc->tri_alpha, s->triAlpha.bytes, hipMemcpyHostToDevice));
+        }
+        d.alphas = (const PgAlphaMask *)s->alphas.p; d.triAlpha = (const int *)s->triAlpha.p; d.hasAlpha = anyAlpha ? 1 : 0;
+    }
     d.images = (const PgImage *)s->images.p; d.texels = (const float *)s->texels.p; d.ewaLut = (const float *)s->ewaLut.p;
     d.textures = (const PgTexture *)s->textures.p; d.textured = (const PgTexturedMaterial *)s->textured.p;
     d.hasTextured = anyTextured ? 1 : 0;

@@ -41,6 +41,9 @@ struct DScene {
     const DObject *objects;
     int nInstances;
     int *hitInst;  // per closest-hit result: the instance the hit primitive was reached through, or -1 (written by k_trace<.., true>)
+    const PgAlphaMask *alphas;           // alpha / shadow-alpha textures of meshes; triAlpha[k] indexes it for PG_TRI_ALPHA triangles
+    const int *triAlpha;
+    int hasAlpha;
     const PgImage *images;               // MIPMaps of the image textures (pyramid levels in texels[])
     const float *texels;
     const float *ewaLut;                 // MIPMap::weightLut (128)

@@ -28,6 +28,7 @@
 #include "pg_sphere.h"
 #include <algorithm>
 #include "pg_kernels.h"
+#include "pg_texture.h"
 
 #define TR_BLOCK 256
 #define TR_NONE ((int)0x80000000)
@@ -275,6 +276,21 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
                     } else
                         hit = tri_test_pre(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), mk(ox, oy, oz), tr, tMax, t, b0, b1, b2) &&
                               !(pflags & PG_TRI_BOGUS);
+                    if (XPRIM && hit && (pflags & PG_TRI_ALPHA)) {
+                        // the mesh's alpha / shadow-alpha textures at the hit (triangle.cpp:333-338, :531-569): point, (u, v),
+                        // no differentials; a value of exactly 0 rejects the hit and the ray goes on
+                        const PgAlphaMask &am = sc.alphas[sc.triAlpha[prim]];
+                        float uv[6] = {0, 0, 1, 0, 1, 1};
+                        if (sc.uv && (pflags & PG_TRI_HAS_UV)) for (int k = 0; k < 6; ++k) uv[k] = sc.uv[6 * prim + k];
+                        TexHit th;
+                        th.p = mk(a.x, a.y, a.z) * b0 + mk(b.x, b.y, b.z) * b1 + mk(c.x, c.y, c.z) * b2;
+                        th.u = b0 * uv[0] + b1 * uv[2] + b2 * uv[4];
+                        th.v = b0 * uv[1] + b1 * uv[3] + b2 * uv[5];
+                        th.dpdx = th.dpdy = mk(0, 0, 0);
+                        th.dudx = th.dvdx = th.dudy = th.dvdy = 0;
+                        if (am.has_alpha && TexEval<PG_TEX_DEPTH>::f(sc, am.alpha, th) == 0) hit = false;
+                        if (ANYHIT && hit && am.has_shadow_alpha && TexEval<PG_TEX_DEPTH>::f(sc, am.shadow_alpha, th) == 0) hit = false;
+                    }
                     if (hit) {
                         hitPrim = prim;
                         if (ANYHIT) { triLeft = 0; sp = 0; vd = 0; inInst = -1; }  // bvh.cpp:717: return true
@@ -345,7 +361,7 @@ static void launch_trace(const DScene &sc, RayQueue q0, RayQueue q1, float4 *hit
     size_t lds = sizeof(uint2) * (size_t)c.depth * TR_BLOCK;
     (void)hipMemsetAsync(cursors, 0, 2 * PG_REGIONS * PG_COUNT_STRIDE * sizeof(int), s);
     // scenes without spheres and object instances run the triangle-only instantiation
-    if (sc.nSpheres > 0 || sc.nInstances > 0)
+    if (sc.nSpheres > 0 || sc.nInstances > 0 || sc.hasAlpha)
         hipLaunchKernelGGL((k_trace<ANYHIT, true>), dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q0, q1, hits, hitOffset1, tOut, occluded, cn, cursors,
                            c.depth, c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard);
     else

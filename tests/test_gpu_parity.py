@@ -151,6 +151,30 @@ def test_intersect_bit_exact(gpu, oracle, n):
     gs.close()
 
 
+def test_alpha_mask_rays_bit_exact(gpu, oracle):
+    """Alpha / shadow-alpha textures inside the traversal: Triangle::Intersect rejects hits whose alpha texture evaluates to
+    0, IntersectP also those whose shadow alpha does -- same hits, same counters as the oracle for every ray."""
+    scene = gpu.HostScene(os.path.join(GOLD, "alpha_masks.pbrt"))
+    assert scene.desc.n_alphas >= 4
+    gs = gpu.GpuScene(scene.desc)
+    n = 30000
+    o, d = random_rays(scene, n, 321)
+    tmax = np.full(n, np.inf, np.float32)
+    gs.counters_reset()
+    prim, t, bary = gs.intersect(o, d, tmax)
+    oprim, ot, obary, ocn = oracle.intersect(scene.desc, o, d, tmax)
+    assert np.array_equal(prim, oprim) and np.array_equal(t, ot) and np.array_equal(bary, obary)
+    cn = gs.counters()
+    assert cn["closest_node_visits"] == ocn["node_visits"] and cn["closest_tri_tests"] == ocn["tri_tests"]
+    occ = gs.intersect_p(o, d, tmax)
+    oocc, ocn2 = oracle.intersect_p(scene.desc, o, d, tmax)
+    assert np.array_equal(occ, oocc)
+    assert ((prim >= 0) & (occ == 0)).sum() > 20  # rays stopped by a surface that only the shadow-alpha mask lets through
+    cn = gs.counters()
+    assert cn["shadow_node_visits"] == ocn2["node_visits"] and cn["shadow_tri_tests"] == ocn2["tri_tests"]
+    gs.close()
+
+
 @pytest.mark.parametrize("name", ["instance_boxes", "instance_accel"])
 def test_instance_rays_bit_exact(gpu, oracle, name):
     """Object instances (TransformedPrimitive over an object definition's own BVH, or over a lone primitive): the ray is
