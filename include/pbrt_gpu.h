@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 13
+#define PG_ABI_VERSION 14
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -191,6 +191,8 @@ typedef struct PgTexturedMaterial {
     int32_t has_u, has_v;      /* uber / metal: "uroughness" / "vroughness" were given (GetFloatTextureOrNull) */
     int32_t remap_roughness;
     int32_t sub[2];            /* mix: the two materials (indices into materials[]) */
+    int32_t has_bump;          /* "bumpmap" given: Material::Bump (material.cpp:46-85) displaces the shading geometry first */
+    PgTexRef bump;
 } PgTexturedMaterial;
 
 /* scene.lights, in declaration order (api.cpp:1308-1327 for LightSource, :1353-1363 for area lights):

@@ -175,6 +175,28 @@ def with_image_textures(s):
     return s
 
 
+def with_bump(s):
+    s = with_normals(s, uv=True)
+    tex = ('Texture "b_chk" "float" "checkerboard" "float uscale" [ 6 ] "float vscale" [ 6 ] "float tex1" [ 0 ] "float tex2" [ 4 ]\n'
+           'Texture "b_img" "float" "imagemap" "string filename" "img_gray16.png" "float scale" [ 12 ] "float uscale" [ 3 ] "float vscale" [ 3 ]\n'
+           'Texture "b_bil" "float" "bilerp" "float v00" [ 0 ] "float v01" [ 9 ] "float v10" [ 3 ] "float v11" [ -5 ]\n'
+           'Texture "kd_chk" "spectrum" "checkerboard" "float uscale" [ 3 ] "float vscale" [ 3 ] "rgb tex1" [ 0.8 0.8 0.8 ] "rgb tex2" [ 0.3 0.3 0.6 ]\n'
+           'MakeNamedMaterial "bm1" "string type" "plastic" "texture bumpmap" "b_chk" "rgb Kd" [ 0.6 0.2 0.2 ]\n'
+           'MakeNamedMaterial "bm2" "string type" "matte" "texture bumpmap" "b_bil"\n'
+           'MakeNamedMaterial "bmix" "string type" "mix" "string namedmaterial1" "bm1" "string namedmaterial2" "bm2"\n')
+    s = s.replace("WorldBegin\n", "WorldBegin\n" + tex, 1)
+    s = s.replace('Material "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', 'Material "matte" "texture Kd" "kd_chk" "texture bumpmap" "b_img"', 1)
+    s = s.replace('Material "matte" "rgb Kd" [ 0.12 0.45 0.15 ]', 'Material "plastic" "rgb Kd" [ 0.12 0.45 0.15 ] "texture bumpmap" "b_bil"')
+    s = s.replace('Material "matte" "rgb Kd" [ 0.65 0.05 0.05 ]', 'Material "matte" "rgb Kd" [ 0.65 0.05 0.05 ] "float bumpmap" [ 3 ]')
+    s = s.replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\nMaterial "uber" "texture bumpmap" "b_chk"')
+    s = s.replace("# tall box", 'NamedMaterial "bmix"\n# tall box')
+    s = s.replace("# short box", 'AttributeBegin\n  Translate 420 70 120\n  Rotate 30 1 0 1\n  Material "metal" "texture bumpmap" "b_chk" "float roughness" [ 0.1 ]\n  Shape "sphere" "float radius" [ 60 ]\n'
+                  '  Translate -260 10 170\n  Scale 1 1.3 0.8\n  Material "substrate" "texture bumpmap" "b_img"\n  Shape "cylinder" "float radius" [ 40 ] "float zmin" [ -50 ] "float zmax" [ 50 ]\nAttributeEnd\n'
+                  'ObjectBegin "bumpy"\n  Material "plastic" "texture bumpmap" "b_chk"\n  Shape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ] "point P" [ -40 0 -40  40 0 -40  40 0 40  -40 0 40 ] "float uv" [ 0 0 1 0 1 1 0 1 ] "normal N" [ -0.3 1 -0.3  0.3 1 -0.3  0.3 1 0.3  -0.3 1 0.3 ]\nObjectEnd\n'
+                  'AttributeBegin\n  Translate 278 200 100\n  Rotate 50 1 0 0\n  Scale 1.5 1 -1\n  ObjectInstance "bumpy"\nAttributeEnd\n# short box', 1)
+    return s
+
+
 def with_alpha(s):
     s = with_normals(s, uv=True)
     tex = ('Texture "a_chk" "float" "checkerboard" "float uscale" [ 4 ] "float vscale" [ 4 ] "float tex1" [ 0 ] "float tex2" [ 1 ]\n'
@@ -506,6 +528,9 @@ SCENES = {
     # alpha / shadowalpha textures on triangle meshes (triangle.cpp:333-338, :531-569): checkerboard and image masks, a
     # constant 0 (an invisible mesh), a shadow-only mask, and a masked emitter (sampled and MIS-weighted without the mask)
     "alpha_masks": cornell(40, 40, 8, integrator='Integrator "path" "integer maxdepth" [ 5 ]', world_edit=lambda s: with_alpha(s)),
+    # "bumpmap" displacement textures (Material::Bump, material.cpp:46-85) on flat and smooth-shaded triangles, quadrics,
+    # instanced geometry; procedural and image displacements, a constant one, bump on the first material of a mix
+    "bump_maps": cornell(40, 40, 8, integrator='Integrator "path" "integer maxdepth" [ 5 ]', world_edit=lambda s: with_bump(s)),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 

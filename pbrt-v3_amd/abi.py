@@ -5,7 +5,7 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 13
+PG_ABI_VERSION = 14
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
 PG_LIGHTS_UNIFORM, PG_LIGHTS_POWER, PG_LIGHTS_SPATIAL = 0, 1, 2
@@ -54,7 +54,7 @@ class PgAlphaMask(C.Structure):
 
 class PgTexturedMaterial(C.Structure):
     _fields_ = [("kind", C.c_int32), ("s", PgTexRef * 5), ("f", PgTexRef * 4), ("has_u", C.c_int32), ("has_v", C.c_int32),
-                ("remap_roughness", C.c_int32), ("sub", C.c_int32 * 2)]
+                ("remap_roughness", C.c_int32), ("sub", C.c_int32 * 2), ("has_bump", C.c_int32), ("bump", PgTexRef)]
 
 
 class PgBxDF(C.Structure):

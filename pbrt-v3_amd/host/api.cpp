@@ -258,8 +258,10 @@ static int MakeMaterial(const std::string &name, const ParamSet &geom, const Par
         return r.v[0];
     };
     auto remapParam = [&]() { return geom.FindOneBool("remaproughness", mat.FindOneBool("remaproughness", true)); };
-    if (!geom.FindTexture("bumpmap").empty() || !mat.FindTexture("bumpmap").empty())
-        Error("\"bumpmap\" textures are not supported by this build; ignoring.");
+    // GetFloatTextureOrNull("bumpmap") of every Create*Material: a displacement texture (or a literal float)
+    const bool hasBump = hasParam(geom, mat, "bumpmap") && name != "mix";
+    PgTexRef bumpRef = constRef(0.f);
+    if (hasBump) bumpRef = floatRef(geom, mat, "bumpmap", 0.f, gs);
     if (name == "matte" || (name != "plastic" && name != "mirror" && name != "glass" && name != "uber" && name != "metal" &&
                             name != "substrate" && name != "translucent" && name != "mix")) {
         if (name != "matte") {
@@ -416,6 +418,8 @@ static int MakeMaterial(const std::string &name, const ParamSet &geom, const Par
         for (int j = 0; j < 2; ++j) if (renderOptions->materials[sub[j]].type == PG_MAT_TEXTURED) anyTexture = true;
     }
     mat.ReportUnused();
+    if (hasBump) anyTexture = true;
+    tm.has_bump = hasBump ? 1 : 0; tm.bump = bumpRef;
     if (anyTexture) {  // a texture among the parameters: ComputeScatteringFunctions runs per hit on the device
         tm.has_u = hasParam(geom, mat, "uroughness") ? 1 : 0;
         tm.has_v = hasParam(geom, mat, "vroughness") ? 1 : 0;
