@@ -315,7 +315,7 @@ void launch_generate(const DScene &sc, const RenderParams &rp, PathState st, Ray
 // ===========================================================================
 // Shading
 // ===========================================================================
-struct Isect { V3 p, pError, wo, n, ns, sdpdu; };  // n: geometric normal; ns, sdpdu: shading.n, shading.dpdu
+struct Isect { V3 p, pError, wo, n, ns, sdpdu, sdpdv, sdndu, sdndv; };  // n: geometric normal; ns, sd*: shading.n, shading.dpdu/dpdv/dndu/dndv (the last three feed bump mapping only)
 
 PG_DEV V3 tri_normal(const Tri &t) {  // triangle.cpp:346-348
     V3 n = normalize(cross(t.p0 - t.p2, t.p1 - t.p2));
@@ -340,8 +340,8 @@ PG_DEV Isect make_isect(const DScene &sc, int prim, const Tri &t, float b0, floa
     Isect is;
     float uv[6];
     load_uv(sc, prim, t.flags, uv);
-    V3 dpdu;
-    tri_dpdu(t.p0, t.p1, t.p2, uv, dpdu);
+    V3 dpdu, dpdv;
+    tri_dpdu_dpdv(t.p0, t.p1, t.p2, uv, dpdu, dpdv);
     float xAbsSum = (fabsf(b0 * t.p0.x) + fabsf(b1 * t.p1.x) + fabsf(b2 * t.p2.x));
     float yAbsSum = (fabsf(b0 * t.p0.y) + fabsf(b1 * t.p1.y) + fabsf(b2 * t.p2.y));
     float zAbsSum = (fabsf(b0 * t.p0.z) + fabsf(b1 * t.p1.z) + fabsf(b2 * t.p2.z));
@@ -350,7 +350,8 @@ PG_DEV Isect make_isect(const DScene &sc, int prim, const Tri &t, float b0, floa
     is.wo = normalize(-rayD);  // Interaction ctor, interaction.h:60
     is.n = tri_normal(t);
     is.ns = is.n;
-    is.sdpdu = dpdu;
+    is.sdpdu = dpdu; is.sdpdv = dpdv;
+    is.sdndu = is.sdndv = mk(0, 0, 0);
     const bool hasN = sc.triN && (t.flags & PG_TRI_HAS_N), hasS = sc.triS && (t.flags & PG_TRI_HAS_S);
     if (hasN || hasS) {  // shading geometry, triangle.cpp:350-419 (dndu/dndv only feed ray differentials)
         V3 ns = is.n, ss = normalize(dpdu), ts;
@@ -365,11 +366,26 @@ PG_DEV Isect make_isect(const DScene &sc, int prim, const Tri &t, float b0, floa
         ts = cross(ss, ns);
         if (lensq(ts) > 0.f) { ts = normalize(ts); ss = cross(ts, ns); }
         else coordinate_system(ns, ss, ts);
+        if (hasN) {  // dndu, dndv of the shading geometry, triangle.cpp:383-416
+            const float d02x = uv[0] - uv[4], d02y = uv[1] - uv[5], d12x = uv[2] - uv[4], d12y = uv[3] - uv[5];
+            const float4 a4 = sc.triN[3 * prim], b4 = sc.triN[3 * prim + 1], c4 = sc.triN[3 * prim + 2];
+            const V3 n0 = mk(a4.x, a4.y, a4.z), n1 = mk(b4.x, b4.y, b4.z), n2 = mk(c4.x, c4.y, c4.z);
+            const V3 dn1 = n0 - n2, dn2 = n1 - n2;
+            const float determinant = d02x * d12y - d02y * d12x;
+            if ((double)fabsf(determinant) < 1e-8) {
+                const V3 dn = cross(n2 - n0, n1 - n0);
+                if (lensq(dn) != 0) coordinate_system(dn, is.sdndu, is.sdndv);
+            } else {
+                const float invDet = 1 / determinant;
+                is.sdndu = (dn1 * d12y - dn2 * d02y) * invDet;
+                is.sdndv = (dn1 * (-d12x) + dn2 * d02x) * invDet;
+            }
+        }
         if (t.flags & PG_TRI_REVERSE_ORIENTATION) ts = -ts;
         // SetShadingGeometry(ss, ts, ..., orientationIsAuthoritative = true), interaction.cpp:74-90
         is.ns = normalize(cross(ss, ts));
         if (dot(is.n, is.ns) < 0.f) is.n = -is.n;
-        is.sdpdu = ss;
+        is.sdpdu = ss; is.sdpdv = ts;
     }
     return is;
 }
@@ -1412,6 +1428,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
             if (inst >= 0) { float dt; instance_ray(sc.instances[inst].w2i, shapeRayO, rayD, shapeRayO, shapeRayD, dt); }
             const SphereHit sh = sphere_interaction(sc.spheres[__float_as_int(tri.p0.x)], shapeRayO, shapeRayD, h4.y);
             is.p = sh.p; is.pError = sh.pError; is.wo = sh.wo; is.n = sh.n; is.ns = sh.n; is.sdpdu = sh.dpdu;
+            is.sdpdv = sh.dpdv; is.sdndu = sh.dndu; is.sdndv = sh.dndv;
             if (TEX) { sphU = sh.u; sphV = sh.v; sphDpdu = sh.dpdu; sphDpdv = sh.dpdv; }
         }
         // path.cpp:91-102 emitted light at the vertex
@@ -1436,6 +1453,8 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                 w.n = normalize(m4_normal(in.w2i, is.n));
                 w.wo = normalize(m4_vec(in.i2w, is.wo));
                 w.sdpdu = m4_vec(in.i2w, is.sdpdu);
+                w.sdpdv = m4_vec(in.i2w, is.sdpdv);
+                w.sdndu = m4_normal(in.w2i, is.sdndu); w.sdndv = m4_normal(in.w2i, is.sdndv);
                 w.ns = normalize(m4_normal(in.w2i, is.ns));
                 if (dot(w.ns, w.n) < 0.f) w.ns = -w.ns;  // Faceforward(shading.n, n)
                 is = w;
@@ -1455,12 +1474,9 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                 LobeBsdf lb;
                 PgBxDF lobeStore[TEX ? PG_MAX_BXDFS : 1];  // MODE 2: this hit's BxDF list (ComputeScatteringFunctions with textures)
                 if constexpr (EXT) {
-                    lb.ns = is.ns; lb.ng = is.n;
-                    lb.ss = normalize(is.sdpdu);
-                    lb.ts = cross(lb.ns, lb.ss);
+                    TexHit th;
                     if constexpr (TEX) {
                         // what textures read of the SurfaceInteraction: (u, v), p and ComputeDifferentials' outputs
-                        TexHit th;
                         th.p = is.p;
                         V3 gdpdu, gdpdv;  // the geometric dpdu / dpdv (not the shading ones)
                         if (onSphere) { th.u = sphU; th.v = sphV; gdpdu = sphDpdu; gdpdv = sphDpdv; }
@@ -1506,6 +1522,38 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                                 }
                             }
                         }
+                        // Material::Bump (material.cpp:46-85) of the material whose BSDF this is: its own bump map, or -- through
+                        // mix materials, whose BSDF is their first material's -- the first material's
+                        int bm = tri.material;
+                        for (int lvl = 0; lvl < 4; ++lvl) {
+                            const PgMaterial &mm = sc.materials[bm];
+                            if (mm.type != PG_MAT_TEXTURED) break;
+                            const PgTexturedMaterial &tmm = sc.textured[mm.textured_index];
+                            if (tmm.kind == PG_KIND_MIX) { if (tmm.sub[0] < 0) break; bm = tmm.sub[0]; continue; }
+                            if (tmm.has_bump) {
+                                TexHit ev = th;
+                                float du = .5f * (fabsf(th.dudx) + fabsf(th.dudy));
+                                if (du == 0) du = .0005f;
+                                ev.p = th.p + is.sdpdu * du; ev.u = th.u + du; ev.v = th.v + 0.f;
+                                const float uDisplace = TexEval<PG_TEX_DEPTH>::f(sc, tmm.bump, ev);
+                                float dv = .5f * (fabsf(th.dvdx) + fabsf(th.dvdy));
+                                if (dv == 0) dv = .0005f;
+                                ev.p = th.p + is.sdpdv * dv; ev.u = th.u + 0.f; ev.v = th.v + dv;
+                                const float vDisplace = TexEval<PG_TEX_DEPTH>::f(sc, tmm.bump, ev);
+                                const float displace = TexEval<PG_TEX_DEPTH>::f(sc, tmm.bump, th);
+                                const V3 bdpdu = (is.sdpdu + is.ns * ((uDisplace - displace) / du)) + is.sdndu * displace;
+                                const V3 bdpdv = (is.sdpdv + is.ns * ((vDisplace - displace) / dv)) + is.sdndv * displace;
+                                is.ns = normalize(cross(bdpdu, bdpdv));  // SetShadingGeometry(..., false), interaction.cpp:72-89
+                                if (dot(is.ns, is.n) < 0.f) is.ns = -is.ns;
+                                is.sdpdu = bdpdu; is.sdpdv = bdpdv;
+                            }
+                            break;
+                        }
+                    }
+                    lb.ns = is.ns; lb.ng = is.n;
+                    lb.ss = normalize(is.sdpdu);
+                    lb.ts = cross(lb.ns, lb.ss);
+                    if constexpr (TEX) {
                         int nl = 0;
                         float etaL = 1;
                         MatEval<2>::run(sc, tri.material, th, lobeStore, nl, etaL);

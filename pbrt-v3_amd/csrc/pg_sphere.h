@@ -173,10 +173,10 @@ PG_DEV bool sphere_test_s(const PgSphere &sp, V3 ro, V3 rd, float tMax, float &t
 }
 
 // What the path needs of the SurfaceInteraction a quadric's Intersect builds for the root tHit of world ray (ro, rd).
-struct SphereHit { V3 p, pError, wo, n, dpdu, dpdv; float u, v; };
+struct SphereHit { V3 p, pError, wo, n, dpdu, dpdv, dndu, dndv; float u, v; };
 // the tail the quadrics share: SurfaceInteraction ctor in object space (interaction.cpp:44-71), then
 // (*ObjectToWorld)(SurfaceInteraction) (transform.cpp:262-297); shading.n == n for a quadric
-PG_DEV SphereHit quadric_finish(const PgSphere &sp, V3 d, V3 pHit, V3 pError, V3 dpdu, V3 dpdv, float u, float v) {
+PG_DEV SphereHit quadric_finish(const PgSphere &sp, V3 d, V3 pHit, V3 pError, V3 dpdu, V3 dpdv, V3 d2Pduu, V3 d2Pduv, V3 d2Pdvv, float u, float v) {
     V3 n = normalize(cross(dpdu, dpdv));
     if (sp.reverse_orientation ^ sp.swaps_handedness) n = n * -1.f;
     const V3 wo = normalize(-d);  // Interaction ctor, interaction.h:60
@@ -186,6 +186,17 @@ PG_DEV SphereHit quadric_finish(const PgSphere &sp, V3 d, V3 pHit, V3 pError, V3
     h.wo = normalize(m4_vec(sp.o2w, wo));
     h.dpdu = m4_vec(sp.o2w, dpdu);
     h.dpdv = m4_vec(sp.o2w, dpdv);
+    // dndu, dndv from the fundamental forms (sphere.cpp:131-145, cylinder.cpp:111-130); only bump mapping reads them
+    V3 dndu = mk(0, 0, 0), dndv = mk(0, 0, 0);
+    if (sp.shape != PG_SHAPE_DISK) {
+        const float E = dot(dpdu, dpdu), F = dot(dpdu, dpdv), G = dot(dpdv, dpdv);
+        const V3 N = normalize(cross(dpdu, dpdv));
+        const float e = dot(N, d2Pduu), f = dot(N, d2Pduv), g = dot(N, d2Pdvv);
+        const float invEGF2 = 1 / (E * G - F * F);
+        dndu = dpdu * ((f * F - e * G) * invEGF2) + dpdv * ((e * F - f * E) * invEGF2);
+        dndv = dpdu * ((g * F - f * G) * invEGF2) + dpdv * ((f * F - g * E) * invEGF2);
+    }
+    h.dndu = m4_normal(sp.w2o, dndu); h.dndv = m4_normal(sp.w2o, dndv);
     h.u = u; h.v = v;
     return h;
 }
@@ -204,7 +215,10 @@ PG_DEV SphereHit sphere_interaction_s(const PgSphere &sp, V3 ro, V3 rd, float tH
     const V3 dpdu = mk(-sp.phi_max * pHit.y, sp.phi_max * pHit.x, 0);
     const V3 dpdv = mk(pHit.z * cosPhi, pHit.z * sinPhi, -sp.radius * (float)sin((double)theta)) * (sp.theta_max - sp.theta_min);
     const V3 pError = vabs(pHit) * pgamma(5);  // sphere.cpp:148
-    return quadric_finish(sp, d, pHit, pError, dpdu, dpdv, phi / sp.phi_max, (theta - sp.theta_min) / (sp.theta_max - sp.theta_min));
+    const V3 d2Pduu = mk(pHit.x, pHit.y, 0) * (-sp.phi_max * sp.phi_max);
+    const V3 d2Pduv = mk(-sinPhi, cosPhi, 0.f) * ((sp.theta_max - sp.theta_min) * pHit.z * sp.phi_max);
+    const V3 d2Pdvv = mk(pHit.x, pHit.y, pHit.z) * (-(sp.theta_max - sp.theta_min) * (sp.theta_max - sp.theta_min));
+    return quadric_finish(sp, d, pHit, pError, dpdu, dpdv, d2Pduu, d2Pduv, d2Pdvv, phi / sp.phi_max, (theta - sp.theta_min) / (sp.theta_max - sp.theta_min));
 }
 
 // ---- Cylinder (shapes/cylinder.cpp:48-198) and Disk (shapes/disk.cpp:48-122): same record, same conventions ----------
@@ -254,7 +268,8 @@ PG_DEV SphereHit cylinder_interaction(const PgSphere &sp, V3 ro, V3 rd, float tH
     const V3 dpdu = mk(-sp.phi_max * pHit.y, sp.phi_max * pHit.x, 0);  // cylinder.cpp:103-104
     const V3 dpdv = mk(0, 0, sp.z_max - sp.z_min);
     const V3 pError = vabs(mk(pHit.x, pHit.y, 0)) * pgamma(3);  // :134
-    return quadric_finish(sp, d, pHit, pError, dpdu, dpdv, phi / sp.phi_max, (pHit.z - sp.z_min) / (sp.z_max - sp.z_min));
+    return quadric_finish(sp, d, pHit, pError, dpdu, dpdv, mk(pHit.x, pHit.y, 0) * (-sp.phi_max * sp.phi_max), mk(0, 0, 0), mk(0, 0, 0), phi / sp.phi_max,
+                          (pHit.z - sp.z_min) / (sp.z_max - sp.z_min));
 }
 PG_DEV bool disk_test(const PgSphere &sp, V3 ro, V3 rd, float tMax, float &tHit) {  // disk.cpp:48-70
     V3 o, d, oErr, dErr;
@@ -282,7 +297,7 @@ PG_DEV SphereHit disk_interaction(const PgSphere &sp, V3 ro, V3 rd, float tHit) 
     float phi = (float)atan2((double)pHit.y, (double)pHit.x);
     if (phi < 0) phi += 2 * PG_PI;
     pHit.z = sp.height;
-    return quadric_finish(sp, d, pHit, mk(0, 0, 0), dpdu, dpdv, phi / sp.phi_max, (sp.radius - rHit) / (sp.radius - sp.inner_radius));
+    return quadric_finish(sp, d, pHit, mk(0, 0, 0), dpdu, dpdv, mk(0, 0, 0), mk(0, 0, 0), mk(0, 0, 0), phi / sp.phi_max, (sp.radius - rHit) / (sp.radius - sp.inner_radius));
 }
 // Shape::Intersect[P] of the quadric record, by shape
 PG_DEV bool sphere_test(const PgSphere &sp, V3 ro, V3 rd, float tMax, float &tHit) {
