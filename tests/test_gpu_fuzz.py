@@ -78,11 +78,32 @@ def random_scene_ext(seed, res=16, spp=4):
             'Material "translucent" "rgb Kd" [ %s ] "rgb reflect" [ %s ] "rgb transmit" [ %s ]' % (f(rng.random(3)), f(rng.random(3)), f(rng.random(3))),
             'Material "glass" "float uroughness" [ %.4g ] "float vroughness" [ %.4g ] "float index" [ %.4g ]' % (0.02 + 0.3 * rng.random(), 0.02 + 0.3 * rng.random(), 1.2 + 0.6 * rng.random()),
             'NamedMaterial "fzmix"', 'NamedMaterial "fzmix2"']
-    out = [head, "WorldBegin",
+    img = lambda n: os.path.join(GOLD, n)
+    textures = ['Texture "fz_chk" "spectrum" "checkerboard" "float uscale" [ %.4g ] "float vscale" [ %.4g ] "rgb tex1" [ %s ] "rgb tex2" [ %s ]'
+                % (1 + 6 * rng.random(), 1 + 6 * rng.random(), f(rng.random(3)), f(rng.random(3))),
+                'Texture "fz_img" "spectrum" "imagemap" "string filename" "%s" "float uscale" [ %.4g ] "float vscale" [ %.4g ] "bool trilinear" "%s" "string wrap" "%s"'
+                % (img(["img_rgb.png", "img_rle.tga", "img_color.pfm", "img_pal.png"][seed % 4]), 0.5 + 3 * rng.random(), 0.5 + 3 * rng.random(),
+                   "true" if seed % 2 else "false", ["repeat", "black", "clamp"][seed % 3]),
+                'Texture "fz_f" "float" "checkerboard" "string aamode" "none" "float uscale" [ 3 ] "float vscale" [ 2 ] "float tex1" [ 0 ] "float tex2" [ 1 ]',
+                'Texture "fz_fimg" "float" "imagemap" "string filename" "%s" "float scale" [ %.4g ]' % (img("img_gray16.png"), 0.2 + rng.random()),
+                'Texture "fz_mix" "spectrum" "mix" "texture tex1" "fz_chk" "texture tex2" "fz_img" "texture amount" "fz_f"',
+                'Texture "fz_sph" "spectrum" "checkerboard" "string mapping" "%s" "float uscale" [ 1 ] "rgb tex1" [ 0.9 0.6 0.2 ] "rgb tex2" [ 0.1 0.3 0.8 ]'
+                % ["spherical", "cylindrical", "planar"][seed % 3],
+                'Texture "fz_scale" "spectrum" "scale" "texture tex1" "fz_mix" "rgb tex2" [ 0.9 0.8 0.7 ]']
+    mats += ['Material "matte" "texture Kd" "fz_mix"', 'Material "plastic" "texture Kd" "fz_img" "texture roughness" "fz_fimg" "texture bumpmap" "fz_fimg"',
+             'Material "uber" "texture Kd" "fz_chk" "texture opacity" "fz_sph"', 'Material "metal" "texture k" "fz_scale" "float roughness" [ 0.1 ] "texture bumpmap" "fz_f"',
+             'Material "matte" "texture Kd" "fz_sph" "texture sigma" "fz_fimg"', 'Material "glass" "texture Kt" "fz_chk"']
+    out = [head, "WorldBegin"] + textures + [
            'MakeNamedMaterial "fza" "string type" "plastic" "rgb Kd" [ %s ]' % f(rng.random(3)),
            'MakeNamedMaterial "fzb" "string type" "metal"', 'MakeNamedMaterial "fzc" "string type" "glass"',
            'MakeNamedMaterial "fzmix" "string type" "mix" "string namedmaterial1" "fza" "string namedmaterial2" "fzb" "rgb amount" [ %s ]' % f(rng.random(3)),
-           'MakeNamedMaterial "fzmix2" "string type" "mix" "string namedmaterial1" "fzmix" "string namedmaterial2" "fzc"']
+           'MakeNamedMaterial "fzmix2" "string type" "mix" "string namedmaterial1" "fzmix" "string namedmaterial2" "fzc"',
+           'MakeNamedMaterial "fzt" "string type" "matte" "texture Kd" "fz_img" "texture bumpmap" "fz_f"',
+           'MakeNamedMaterial "fzmix3" "string type" "mix" "string namedmaterial1" "fzt" "string namedmaterial2" "fzb" "texture amount" "fz_chk"']
+    mats += ['NamedMaterial "fzmix3"']
+    if seed % 4 == 2:
+        out.append('AttributeBegin\n Rotate %.4g 0 1 0.5\n LightSource "infinite" "string mapname" "%s" "rgb L" [ %s ]\nAttributeEnd'
+                   % (360 * rng.random(), img(["img_color.pfm", "img_rgb.png"][seed % 8 // 4]), f(0.3 + rng.random(3))))
     if seed % 4 == 0:
         out.append('AttributeBegin\n Rotate %.4g 1 0.3 0\n LightSource "infinite" "rgb L" [ %s ]\nAttributeEnd' % (360 * rng.random(), f(0.2 + 0.5 * rng.random(3))))
     out.append(world)
@@ -108,7 +129,9 @@ def random_scene_ext(seed, res=16, spp=4):
     # object definitions: a soup with its own BVH, and a lone sphere; instanced a few times
     nt = int(rng.integers(2, 30))
     P = rng.normal(size=(nt, 3, 3)) * 0.4
-    out.append('ObjectBegin "soup"\n %s\n Shape "trianglemesh" "integer indices" [ %s ] "point P" [ %s ]\n %s\n Translate 0.5 0 0\n Shape "sphere" "float radius" [ 0.3 ]\nObjectEnd'
+    out.append('%s\nShape "trianglemesh" "texture alpha" "fz_f" "texture shadowalpha" "fz_fimg" "integer indices" [ 0 1 2 0 2 3 ] "point P" [ %s ] "float uv" [ 0 0 2 0 2 2 0 2 ]'
+               % (mats[int(rng.integers(len(mats)))], f(rng.normal(size=(4, 3)) * 1.5)))
+    out.append('ObjectBegin "soup"\n %s\n Shape "trianglemesh" "texture alpha" "fz_f" "integer indices" [ %s ] "point P" [ %s ]\n %s\n Translate 0.5 0 0\n Shape "sphere" "float radius" [ 0.3 ]\nObjectEnd'
                % (mats[int(rng.integers(len(mats)))], " ".join(map(str, range(3 * nt))), f(P), mats[int(rng.integers(len(mats)))]))
     out.append('ObjectBegin "ball"\n %s\n Shape "sphere" "float radius" [ 0.4 ]\nObjectEnd' % mats[int(rng.integers(len(mats)))])
     for k in range(2 + seed % 3):
