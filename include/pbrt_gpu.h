@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 14
+#define PG_ABI_VERSION 15
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -265,6 +265,15 @@ typedef struct PgInstance {      /* TransformedPrimitive (primitive.h:92-117), s
     int32_t identity;            /* Transform::IsIdentity() of InstanceToWorld (primitive.cpp:86-87) */
 } PgInstance;
 
+/* HomogeneousMedium (media/homogeneous.h:49-71) with its HenyeyGreenstein phase function (core/medium.h:86-100).
+ * tri_medium_inside / tri_medium_outside give each primitive's MediumInterface (core/medium.h:102-116) as indices into
+ * media[], -1 = no medium (vacuum); a primitive whose two sides agree is not a medium transition and a ray keeps its
+ * current medium across it (primitive.cpp:121-125). */
+typedef struct PgMedium {
+    float sigma_a[3], sigma_s[3], sigma_t[3];
+    float g;
+} PgMedium;
+
 typedef struct PgSceneDesc {
     int32_t abi_version;        /* PG_ABI_VERSION */
     /* acceleration structure, BVHAccel after flattenBVHTree (bvh.cpp:640-658) */
@@ -310,6 +319,9 @@ typedef struct PgSceneDesc {
     const PgImage *images;
     int64_t n_texel_floats;
     const float *texels;
+    int32_t n_media;
+    const PgMedium *media;
+    const int32_t *tri_medium_inside, *tri_medium_outside; /* n_prims_all each, or both NULL when no primitive has a medium */
     int32_t n_alphas;
     const PgAlphaMask *alphas;
     const int32_t *tri_alpha;   /* per primitive (n_prims_all): index into alphas for triangles with PG_TRI_ALPHA; may be NULL */
@@ -323,6 +335,8 @@ typedef struct PgSceneDesc {
 typedef struct PgRenderDesc {
     int32_t abi_version;
     /* camera: PerspectiveCamera (cameras/perspective.cpp:45-144) or OrthographicCamera (cameras/orthographic.cpp:44-118) */
+    int32_t integrator;         /* 0 = PathIntegrator (integrators/path.cpp), 1 = VolPathIntegrator (integrators/volpath.cpp) */
+    int32_t camera_medium;      /* Camera::medium: index into PgSceneDesc.media, -1 = none */
     int32_t camera_type;        /* 0 = perspective, 1 = orthographic, 2 = environment (cameras/environment.cpp:43-56) */
     float raster_to_camera[16]; /* row-major Matrix4x4 */
     float dx_camera[3], dy_camera[3]; /* ProjectiveCamera::dxCamera / dyCamera (perspective.cpp:60-63, orthographic.cpp:57-58): ray differentials */

@@ -197,6 +197,27 @@ def with_bump(s):
     return s
 
 
+FOG = 'MakeNamedMedium "fog" "string type" "homogeneous" "rgb sigma_a" [ 0.0004 0.0006 0.0008 ] "rgb sigma_s" [ 0.0015 0.0012 0.001 ] "float g" [ 0.4 ]\n'
+SMOKE = ('MakeNamedMedium "smoke" "string type" "homogeneous" "rgb sigma_a" [ 0.2 0.5 1.0 ] "rgb sigma_s" [ 3 3 3 ] "float scale" [ 0.01 ] "float g" [ -0.3 ]\n'
+         'MakeNamedMedium "thin" "string type" "homogeneous" "rgb sigma_a" [ 0.001 0.001 0.001 ] "rgb sigma_s" [ 0.004 0.002 0.001 ] "float g" [ 0.0005 ]\n')
+
+
+def with_fog(s, camera_in_fog=True, world_interface='MediumInterface "fog" "fog"\n'):
+    """A homogeneous medium filling the whole scene, the camera inside it (MediumInterface before Camera, api.cpp:785-790)."""
+    s = s.replace("Camera ", FOG + ('MediumInterface "" "fog"\n' if camera_in_fog else "") + "Camera ", 1)
+    return s.replace("WorldBegin\n", "WorldBegin\n" + world_interface, 1)
+
+
+def with_smoke(s):
+    """Media bounded by "none"-material surfaces: a sphere and a triangle-mesh box of smoke, a thin medium inside an
+    instanced object, next to the glass/mirror boxes."""
+    s = s.replace("Camera ", SMOKE + "Camera ", 1)
+    s = s.replace("# short box", 'AttributeBegin\n  Translate 400 330 160\n  MediumInterface "smoke" ""\n  Material "none"\n  Shape "sphere" "float radius" [ 90 ]\nAttributeEnd\n'
+                  'AttributeBegin\n  MediumInterface "thin" ""\n  Material ""\n  Shape "trianglemesh" "integer indices" [ 0 2 1 0 3 2  4 5 6 4 6 7  0 1 5 0 5 4  2 3 7 2 7 6  1 2 6 1 6 5  3 0 4 3 4 7 ]\n'
+                  '    "point P" [ 20 20 20  300 20 20  300 500 20  20 500 20  20 20 300  300 20 300  300 500 300  20 500 300 ]\nAttributeEnd\n# short box', 1)
+    return s
+
+
 def with_alpha(s):
     s = with_normals(s, uv=True)
     tex = ('Texture "a_chk" "float" "checkerboard" "float uscale" [ 4 ] "float vscale" [ 4 ] "float tex1" [ 0 ] "float tex2" [ 1 ]\n'
@@ -531,6 +552,18 @@ SCENES = {
     # "bumpmap" displacement textures (Material::Bump, material.cpp:46-85) on flat and smooth-shaded triangles, quadrics,
     # instanced geometry; procedural and image displacements, a constant one, bump on the first material of a mix
     "bump_maps": cornell(40, 40, 8, integrator='Integrator "path" "integer maxdepth" [ 5 ]', world_edit=lambda s: with_bump(s)),
+    # VolPathIntegrator + HomogeneousMedium (integrators/volpath.cpp, media/homogeneous.cpp): fog everywhere with the camera
+    # inside it; media bounded by "none" surfaces; delta / infinite lights through media; the plain path integrator in a
+    # scene that has medium boundaries (path.cpp:107-113)
+    "vol_fog": cornell(32, 32, 8, integrator='Integrator "volpath" "integer maxdepth" [ 5 ]', world_edit=lambda s: with_fog(s)),
+    "vol_fog_halfspace": cornell(24, 24, 8, integrator='Integrator "volpath" "integer maxdepth" [ 6 ] "string lightsamplestrategy" "power"',
+                                 world_edit=lambda s: with_fog(s, world_interface="")),
+    "vol_smoke": cornell(40, 40, 8, integrator='Integrator "volpath" "integer maxdepth" [ 8 ] "float rrthreshold" [ 0.7 ]',
+                         world_edit=lambda s: with_smoke(s).replace("# tall box", 'Material "glass"\n# tall box')),
+    "vol_smoke_delta": cornell(32, 32, 8, integrator='Integrator "volpath" "integer maxdepth" [ 5 ] "string lightsamplestrategy" "uniform"',
+                               world_edit=lambda s: with_smoke(s).replace("# light\nAttributeBegin", DELTA_POINT + DELTA_SPOT + 'LightSource "infinite" "rgb L" [ 0.3 0.4 0.6 ]\n# light\nAttributeBegin')),
+    "vol_path_none": cornell(24, 24, 8, world_edit=lambda s: with_smoke(s)),
+    "vol_instances": cornell(32, 32, 8, integrator='Integrator "volpath" "integer maxdepth" [ 5 ]', world_edit=lambda s: with_fog(with_instances(s), camera_in_fog=False)),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 
@@ -541,7 +574,7 @@ def run(name, scene_path, outdir=GOLD):
     # one thread for the wide-filter scenes: overlapping FilmTiles are then merged in tile order (film.cpp:117-130)
     nthreads = "1" if name.startswith("filter_") else "4"
     txt = subprocess.run([ref, "--nthreads", nthreads, "--outfile", out, scene_path], capture_output=True, text=True, check=True).stdout
-    g = lambda pat: int(re.search(pat, txt).group(1))
+    g = lambda pat: int(re.search(pat, txt).group(1)) if re.search(pat, txt) else 0  # a counter that stayed 0 is not printed (stats.cpp)
     stats = {"camera_rays": g(r"Camera rays traced\s+(\d+)"),
              "closest_rays": g(r"Regular ray intersection tests\s+(\d+)"),
              "shadow_rays": g(r"Shadow ray intersection tests\s+(\d+)"),

@@ -5,7 +5,7 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 14
+PG_ABI_VERSION = 15
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
 PG_LIGHTS_UNIFORM, PG_LIGHTS_POWER, PG_LIGHTS_SPATIAL = 0, 1, 2
@@ -46,6 +46,10 @@ class PgTexture(C.Structure):
 class PgImage(C.Structure):
     _fields_ = [("is_float", C.c_int32), ("n_levels", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("wrap", C.c_int32),
                 ("trilinear", C.c_int32), ("max_anisotropy", C.c_float), ("level_offset", C.c_int64 * 16)]
+
+
+class PgMedium(C.Structure):
+    _fields_ = [("sigma_a", C.c_float * 3), ("sigma_s", C.c_float * 3), ("sigma_t", C.c_float * 3), ("g", C.c_float)]
 
 
 class PgAlphaMask(C.Structure):
@@ -96,12 +100,13 @@ class PgSceneDesc(C.Structure):
                 ("n_instances", C.c_int32), ("instances", C.POINTER(PgInstance)),
                 ("n_textures", C.c_int32), ("textures", C.POINTER(PgTexture)), ("n_textured", C.c_int32), ("textured", C.POINTER(PgTexturedMaterial)),
                 ("n_images", C.c_int32), ("images", C.POINTER(PgImage)), ("n_texel_floats", C.c_int64), ("texels", C.POINTER(C.c_float)),
+                ("n_media", C.c_int32), ("media", C.POINTER(PgMedium)), ("tri_medium_inside", C.POINTER(C.c_int32)), ("tri_medium_outside", C.POINTER(C.c_int32)),
                 ("n_alphas", C.c_int32), ("alphas", C.POINTER(PgAlphaMask)), ("tri_alpha", C.POINTER(C.c_int32)),
                 ("n_env_floats", C.c_int64), ("env_tables", C.POINTER(C.c_float)), ("ewa_lut", C.POINTER(C.c_float))]
 
 
 class PgRenderDesc(C.Structure):
-    _fields_ = [("abi_version", C.c_int32), ("camera_type", C.c_int32),
+    _fields_ = [("abi_version", C.c_int32), ("integrator", C.c_int32), ("camera_medium", C.c_int32), ("camera_type", C.c_int32),
                 ("raster_to_camera", C.c_float * 16), ("dx_camera", C.c_float * 3), ("dy_camera", C.c_float * 3), ("camera_to_world", C.c_float * 16),
                 ("lens_radius", C.c_float), ("focal_distance", C.c_float),
                 ("shutter_open", C.c_float), ("shutter_close", C.c_float),

@@ -602,6 +602,8 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
     if (rd->filter_general && rd->tile_pixels != (16 + rd->tile_halo[0] + rd->tile_halo[2]) * (16 + rd->tile_halo[1] + rd->tile_halo[3]))
         return setError(PG_ERR_INVALID, "pg_render: tile_pixels does not match tile_halo");
     if (rd->spp <= 0 || rd->max_depth < 0 || rd->tile_step <= 0) return setError(PG_ERR_INVALID, "pg_render: bad spp/maxdepth/tile_step");
+    if (rd->integrator != 0 && rd->integrator != 1) return setError(PG_ERR_INVALID, "pg_render: integrator %d (0 = path, 1 = volpath)", rd->integrator);
+    if (rd->integrator == 1) return setError(PG_ERR_UNSUPPORTED, "pg_render: the volpath integrator is not built into this library yet");
     if (5 + 8 * (rd->max_depth + 1) > s->d.nPermDims && s->d.nPermDims < 1000)
         return setError(PG_ERR_INVALID, "Halton table has %d dimensions; maxdepth %d needs %d", s->d.nPermDims, rd->max_depth, 5 + 8 * (rd->max_depth + 1));
     HIP_TRY(hipSetDevice(s->device));

@@ -63,6 +63,7 @@ struct GraphicsState {
     ParamSet areaLightParams;
     std::string areaLight;
     bool reverseOrientation = false;
+    std::string currentInsideMedium, currentOutsideMedium;  // MediumInterface, api.cpp:1107-1116
 };
 struct RenderOptions {
     Float transformStartTime = 0, transformEndTime = 1;
@@ -86,6 +87,8 @@ struct RenderOptions {
     std::vector<float> texels;
     std::vector<float> envTables;     // the infinite lights' Distribution2D tables
     std::vector<PgAlphaMask> alphas;  // alpha / shadow-alpha textures of the meshes that have them
+    std::vector<PgMedium> media;      // MakeNamedMedium "homogeneous"
+    std::map<std::string, int> namedMedia;
     std::map<std::string, int> imageCache;
     bool haveScatteringMedia = false;
 };
@@ -547,13 +550,50 @@ void pbrtCamera(const std::string &name, const ParamSet &params) {  // api.cpp:1
     renderOptions->CameraToWorld = Inverse(curTransform);
     namedCoordinateSystems["camera"] = renderOptions->CameraToWorld;
 }
-void pbrtMakeNamedMedium(const std::string &name, const ParamSet &) {
+void pbrtMakeNamedMedium(const std::string &name, const ParamSet &params) {  // api.cpp:1087-1105, MakeMedium :681-727
     VERIFY_INITIALIZED("MakeNamedMedium");
-    Error("MakeNamedMedium \"%s\": participating media are outside this build's scope (PathIntegrator ignores them).", name.c_str());
+    std::string type = params.FindOneString("type", "");
+    if (type == "") { Error("No parameter string \"type\" found in MakeNamedMedium"); return; }
+    RGB sig_a{{.0011f, .0024f, .014f}}, sig_s{{2.55f, 3.21f, 3.77f}};
+    std::string preset = params.FindOneString("preset", "");
+    if (preset != "") Warning("Material preset \"%s\" not found.  Using defaults.  (The measured presets of medium.cpp are not part of this build.)", preset.c_str());
+    Float scale = params.FindOneFloat("scale", 1.f);
+    Float g = params.FindOneFloat("g", 0.0f);
+    sig_a = params.FindOneSpectrum("sigma_a", sig_a);
+    sig_s = params.FindOneSpectrum("sigma_s", sig_s);
+    if (type != "homogeneous") {
+        if (type == "heterogeneous") Error("Medium \"heterogeneous\" (GridDensityMedium) is outside this build's closed set; \"%s\" is ignored.", name.c_str());
+        else Warning("Medium \"%s\" unknown.", type.c_str());
+        params.ReportUnused();
+        return;
+    }
+    PgMedium m;
+    for (int i = 0; i < 3; ++i) {
+        m.sigma_a[i] = sig_a.c[i] * scale; m.sigma_s[i] = sig_s.c[i] * scale;
+        m.sigma_t[i] = m.sigma_s[i] + m.sigma_a[i];  // HomogeneousMedium ctor, homogeneous.h:52-56
+    }
+    m.g = g;
+    params.ReportUnused();
+    renderOptions->namedMedia[name] = (int)renderOptions->media.size();
+    renderOptions->media.push_back(m);
 }
 void pbrtMediumInterface(const std::string &insideName, const std::string &outsideName) {
     VERIFY_INITIALIZED("MediumInterface");
-    if (!insideName.empty() || !outsideName.empty()) renderOptions->haveScatteringMedia = true;
+    graphicsState.currentInsideMedium = insideName;
+    graphicsState.currentOutsideMedium = outsideName;
+    renderOptions->haveScatteringMedia = true;
+}
+// GraphicsState::CreateMediumInterface, api.cpp:1492-1511: (inside, outside) as indices into media, -1 = none
+static void CreateMediumInterface(int *inside, int *outside) {
+    *inside = *outside = -1;
+    const std::string *names[2] = {&graphicsState.currentInsideMedium, &graphicsState.currentOutsideMedium};
+    int *dst[2] = {inside, outside};
+    for (int k = 0; k < 2; ++k)
+        if (*names[k] != "") {
+            auto it = renderOptions->namedMedia.find(*names[k]);
+            if (it != renderOptions->namedMedia.end()) *dst[k] = it->second;
+            else Error("Named medium \"%s\" undefined.", names[k]->c_str());
+        }
 }
 void pbrtWorldBegin() {  // api.cpp:1118-1126
     VERIFY_OPTIONS("WorldBegin");
@@ -998,12 +1038,15 @@ void pbrtShape(const std::string &name, const ParamSet &params) {  // api.cpp:13
             firstLight = (int)renderOptions->lights.size();
         } else Warning("Area light \"%s\" unknown.", graphicsState.areaLight.c_str());
     }
+    int mediumInside, mediumOutside;
+    CreateMediumInterface(&mediumInside, &mediumOutside);  // api.cpp:1380
     const int nShapes = sphere ? 1 : mesh->nTriangles;
     for (int i = 0; i < nShapes; ++i) {
         GeometricPrimitive prim;
         if (sphere) prim.sphere = sphere;
         else { prim.shape.mesh = mesh; prim.shape.triIndex = i; }
         prim.material = mtl;
+        prim.mediumInside = mediumInside; prim.mediumOutside = mediumOutside;
         if (firstLight >= 0 && !renderOptions->currentInstance) {
             PgLight l = lightProto;
             l.area = sphere ? sphere->Area() : prim.shape.Area();
@@ -1086,12 +1129,18 @@ static GpuPathIntegrator *MakeIntegrator() {
     film->GetSampleBounds(sb);
     std::shared_ptr<HaltonSampler> sampler(CreateHaltonSampler(ro.SamplerParams, sb));
     ro.SamplerParams.ReportUnused();
-    if (ro.IntegratorName != "path") {
-        Error("Integrator \"%s\" is outside this build's closed set (path).", ro.IntegratorName.c_str());
+    if (ro.IntegratorName != "path" && ro.IntegratorName != "volpath") {
+        Error("Integrator \"%s\" is outside this build's closed set (path, volpath).", ro.IntegratorName.c_str());
         return nullptr;
     }
-    GpuPathIntegrator *integrator = CreatePathIntegrator(ro.IntegratorParams, sampler, camera);
-    if (ro.haveScatteringMedia)
+    GpuPathIntegrator *integrator = CreatePathIntegrator(ro.IntegratorParams, sampler, camera);  // volpath.cpp:191-214 reads the same parameters
+    integrator->volumetric = ro.IntegratorName == "volpath";
+    {   // MakeCamera (api.cpp:785-790): the camera sits in the graphics state's current outside medium
+        int in, out;
+        CreateMediumInterface(&in, &out);
+        integrator->cameraMedium = out;
+    }
+    if (ro.haveScatteringMedia && ro.IntegratorName != "volpath")
         Warning("Scene has scattering media but \"path\" integrator doesn't support volume scattering. Consider using \"volpath\".");
     ro.IntegratorParams.ReportUnused();
     if (ro.lights.empty())
@@ -1114,6 +1163,7 @@ static Scene *MakeScene() {
     scene->texels = ro.texels;
     scene->envTables = ro.envTables;
     scene->alphas = ro.alphas;
+    scene->media = ro.media;
     scene->worldBound = scene->aggregate->WorldBound();
     // resolve each light's emitting triangle to its index in BVH order
     const auto &prims = scene->aggregate->primitives;

@@ -243,6 +243,10 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     for (size_t k = 0; k < nTris; ++k) {
         const GeometricPrimitive &prim = *all[k];
         flat->triMaterial[k] = prim.material < 0 ? 0 : prim.material;
+        if (prim.mediumInside >= 0 || prim.mediumOutside >= 0) {
+            if (flat->triMediumInside.empty()) { flat->triMediumInside.assign(nTris, -1); flat->triMediumOutside.assign(nTris, -1); }
+            flat->triMediumInside[k] = prim.mediumInside; flat->triMediumOutside[k] = prim.mediumOutside;
+        }
         flat->triLight[k] = prim.areaLight;
         if (prim.object) {  // TransformedPrimitive: one PgInstance per use
             PgInstance inst;
@@ -284,6 +288,7 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     flat->texels = scene.texels;
     flat->envTables = scene.envTables;
     flat->alphas = scene.alphas;
+    flat->media = scene.media;
     EWAWeightLut(flat->ewaLut);
     flat->lights = scene.lights;
     // Light::Preprocess (scene.h:57-60): DistantLight keeps the world's bounding sphere (distant.h:55-57, geometry.h:803-806)
@@ -298,6 +303,7 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     }
     // dimensions a path can consume: 5 camera + per bounce (1+2+2 direct, 2 bsdf, 1 rr); 1000 max (halton.h:71-76)
     int nDims = std::min(1000, 5 + 8 * (maxDepth + 2));
+    if (volumetric) nDims = 1000;  // volpath.cpp:77-78,119-123: medium sampling consumes dimensions on uncounted bounces too
     ComputeRadicalInversePermutations(nDims, &flat->perms, &flat->permSums);
     PgSceneDesc &d = flat->desc;
     memset(&d, 0, sizeof(d));
@@ -329,6 +335,9 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     d.n_texel_floats = (int64_t)flat->texels.size(); d.texels = flat->texels.data();
     d.ewa_lut = flat->ewaLut;
     d.n_env_floats = (int64_t)flat->envTables.size(); d.env_tables = flat->envTables.data();
+    d.n_media = (int)flat->media.size(); d.media = flat->media.data();
+    d.tri_medium_inside = flat->triMediumInside.empty() ? nullptr : flat->triMediumInside.data();
+    d.tri_medium_outside = flat->triMediumOutside.empty() ? nullptr : flat->triMediumOutside.data();
     d.n_alphas = (int)flat->alphas.size(); d.alphas = flat->alphas.data();
     d.tri_alpha = flat->triAlpha.empty() ? nullptr : flat->triAlpha.data();
 }
@@ -338,6 +347,8 @@ void GpuPathIntegrator::FillRenderDesc(PgRenderDesc *rd) const {
     rd->abi_version = PG_ABI_VERSION;
     const Film &film = *camera->film;
     rd->camera_type = camera->environment ? 2 : (camera->orthographic ? 1 : 0);
+    rd->integrator = volumetric ? 1 : 0;
+    rd->camera_medium = cameraMedium;
     memcpy(rd->raster_to_camera, camera->RasterToCamera.GetMatrix().m, 16 * sizeof(float));
     memcpy(rd->camera_to_world, camera->CameraToWorld.GetMatrix().m, 16 * sizeof(float));
     {  // dxCamera / dyCamera: perspective.cpp:60-63 (difference of two points), orthographic.cpp:57-58 (a transformed vector)

@@ -64,6 +64,7 @@ struct GeometricPrimitive {
     Transform InstanceToWorld, WorldToInstance;
     int material = -1;
     int areaLight = -1;
+    int mediumInside = -1, mediumOutside = -1;  // MediumInterface (core/medium.h:102-116) as indices into Scene::media
     Bounds3f WorldBound() const;
 };
 
@@ -105,6 +106,7 @@ struct Scene {  // core/scene.h:50-80
     std::vector<float> texels;
     std::vector<float> envTables;
     std::vector<PgAlphaMask> alphas;
+    std::vector<PgMedium> media;
     Bounds3f worldBound;
 };
 
@@ -187,6 +189,8 @@ struct FlatScene {
     std::vector<float> envTables;
     std::vector<PgAlphaMask> alphas;
     std::vector<int32_t> triAlpha;
+    std::vector<PgMedium> media;
+    std::vector<int32_t> triMediumInside, triMediumOutside;
     float ewaLut[128];
 };
 
@@ -206,6 +210,8 @@ class GpuPathIntegrator : public Integrator {
     void Render(const Scene &scene) override;
     void Flatten(const Scene &scene, FlatScene *flat) const;
     void FillRenderDesc(PgRenderDesc *rd) const;
+    bool volumetric = false;  // VolPathIntegrator (integrators/volpath.cpp) instead of PathIntegrator
+    int cameraMedium = -1;
     std::shared_ptr<PerspectiveCamera> camera;
     std::shared_ptr<HaltonSampler> sampler;
     int maxDepth;
