@@ -563,6 +563,8 @@ SCENES = {
     "vol_smoke_delta": cornell(32, 32, 8, integrator='Integrator "volpath" "integer maxdepth" [ 5 ] "string lightsamplestrategy" "uniform"',
                                world_edit=lambda s: with_smoke(s).replace("# light\nAttributeBegin", DELTA_POINT + DELTA_SPOT + 'LightSource "infinite" "rgb L" [ 0.3 0.4 0.6 ]\n# light\nAttributeBegin')),
     "vol_path_none": cornell(24, 24, 8, world_edit=lambda s: with_smoke(s)),
+    "vol_path_none_glass": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 8 ]',
+                                   world_edit=lambda s: with_smoke(s).replace("# tall box", 'Material "glass"\n# tall box').replace('Material "matte" "rgb Kd" [ 0.12 0.45 0.15 ]', 'Material "mirror"')),
     "vol_instances": cornell(32, 32, 8, integrator='Integrator "volpath" "integer maxdepth" [ 5 ]', world_edit=lambda s: with_fog(with_instances(s), camera_in_fog=False)),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }

@@ -45,7 +45,7 @@ struct DeviceBuffer {
 struct PgScene {
     int device = 0;
     DScene d;
-    DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, textures, textured, images, texels, ewaLut, envTables, alphas, triAlpha, triN, triS, uv, materials, lights, distTable, perms, permSums, primes;
+    DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, textures, textured, images, texels, ewaLut, envTables, alphas, triAlpha, triN, triS, uv, materials, lights, distTable, perms, permSums, primes, media, triMediumIn, triMediumOut;
     // work buffers (sized on first render, reused)
     int capacity = 0;
     DeviceBuffer qo[4], qd[4], counts, hitsMain, hitInst, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
@@ -58,6 +58,10 @@ struct PgScene {
     PgCounters counters;
     std::vector<hipEvent_t> events;
     bool hasNullMaterial = false;
+    // VolPathIntegrator work buffers (sized on the first volpath render)
+    int volCapacity = 0;
+    int nMedia = 0;
+    DeviceBuffer vqo[2], vqd[2], vCounts, volMedium, trAcc[2], volP1[3], misLi, pdLi, hitT;
 };
 
 extern "C" {
@@ -438,6 +442,26 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         }
         d.alphas = (const PgAlphaMask *)s->alphas.p; d.triAlpha = (const int *)s->triAlpha.p; d.hasAlpha = anyAlpha ? 1 : 0;
     }
+    {  // participating media (HomogeneousMedium) and the primitives' MediumInterfaces
+        s->nMedia = desc->n_media > 0 ? desc->n_media : 0;
+        if (s->nMedia > 0 && !desc->media) FAIL(PG_ERR_INVALID, "n_media = %d without a media table", desc->n_media);
+        if ((desc->tri_medium_inside != nullptr) != (desc->tri_medium_outside != nullptr)) FAIL(PG_ERR_INVALID, "tri_medium_inside and tri_medium_outside go together");
+        if (desc->tri_medium_inside)
+            for (int k = 0; k < nt; ++k)
+                if (desc->tri_medium_inside[k] < -1 || desc->tri_medium_inside[k] >= s->nMedia || desc->tri_medium_outside[k] < -1 || desc->tri_medium_outside[k] >= s->nMedia)
+                    FAIL(PG_ERR_INVALID, "primitive %d: medium index out of range", k);
+        if (s->nMedia > 0) {
+            HIP_TRY_S(s->media.alloc(sizeof(PgMedium) * (size_t)s->nMedia));
+            HIP_TRY_S(hipMemcpy(s->media.p, desc->media, s->media.bytes, hipMemcpyHostToDevice));
+        }
+        if (desc->tri_medium_inside) {
+            HIP_TRY_S(s->triMediumIn.alloc(sizeof(int) * (size_t)nt));
+            HIP_TRY_S(s->triMediumOut.alloc(sizeof(int) * (size_t)nt));
+            HIP_TRY_S(hipMemcpy(s->triMediumIn.p, desc->tri_medium_inside, s->triMediumIn.bytes, hipMemcpyHostToDevice));
+            HIP_TRY_S(hipMemcpy(s->triMediumOut.p, desc->tri_medium_outside, s->triMediumOut.bytes, hipMemcpyHostToDevice));
+        }
+        d.media = (const PgMedium *)s->media.p; d.triMediumIn = (const int *)s->triMediumIn.p; d.triMediumOut = (const int *)s->triMediumOut.p;
+    }
     d.images = (const PgImage *)s->images.p; d.texels = (const float *)s->texels.p; d.ewaLut = (const float *)s->ewaLut.p;
     d.textures = (const PgTexture *)s->textures.p; d.textured = (const PgTexturedMaterial *)s->textured.p;
     d.hasTextured = anyTextured ? 1 : 0;
@@ -603,7 +627,8 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
         return setError(PG_ERR_INVALID, "pg_render: tile_pixels does not match tile_halo");
     if (rd->spp <= 0 || rd->max_depth < 0 || rd->tile_step <= 0) return setError(PG_ERR_INVALID, "pg_render: bad spp/maxdepth/tile_step");
     if (rd->integrator != 0 && rd->integrator != 1) return setError(PG_ERR_INVALID, "pg_render: integrator %d (0 = path, 1 = volpath)", rd->integrator);
-    if (rd->integrator == 1) return setError(PG_ERR_UNSUPPORTED, "pg_render: the volpath integrator is not built into this library yet");
+    const bool vol = rd->integrator == 1;
+    if (rd->camera_medium < -1 || rd->camera_medium >= s->nMedia) return setError(PG_ERR_INVALID, "pg_render: camera_medium %d out of range", rd->camera_medium);
     if (5 + 8 * (rd->max_depth + 1) > s->d.nPermDims && s->d.nPermDims < 1000)
         return setError(PG_ERR_INVALID, "Halton table has %d dimensions; maxdepth %d needs %d", s->d.nPermDims, rd->max_depth, 5 + 8 * (rd->max_depth + 1));
     HIP_TRY(hipSetDevice(s->device));
@@ -650,6 +675,28 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
     const int capacity = tilesPerBatch * 256 * sPerBatch;
     int st = ensureWorkBuffers(s, capacity);
     if (st != PG_OK) return st;
+    const int QSTRIDE = PG_REGIONS * PG_COUNT_STRIDE;  // ints of counter storage per queue
+    VolState vs;
+    memset(&vs, 0, sizeof(vs));
+    RayQueue vq[2];  // second halves of the through-ray ping-pong (the first halves are q[2] and q[3])
+    if (vol) {
+        const size_t n = (size_t)regionCapFor(capacity) * PG_REGIONS;
+        if (s->volCapacity < capacity) {
+            for (int i = 0; i < 2; ++i) { HIP_TRY(s->vqo[i].alloc(n * sizeof(float4))); HIP_TRY(s->vqd[i].alloc(n * sizeof(float4))); HIP_TRY(s->trAcc[i].alloc(n * sizeof(float4))); }
+            for (int i = 0; i < 3; ++i) HIP_TRY(s->volP1[i].alloc(n * sizeof(float4)));
+            HIP_TRY(s->vCounts.alloc(2 * QSTRIDE * sizeof(int)));
+            HIP_TRY(s->volMedium.alloc(n * sizeof(int)));
+            HIP_TRY(s->misLi.alloc(n * sizeof(float4)));
+            HIP_TRY(s->pdLi.alloc(n * sizeof(float4)));
+            HIP_TRY(s->hitT.alloc(2 * n * sizeof(float)));
+            s->volCapacity = capacity;
+        }
+        vs.medium = (int *)s->volMedium.p;
+        for (int i = 0; i < 2; ++i) vs.trAcc[i] = (float4 *)s->trAcc[i].p;
+        for (int i = 0; i < 3; ++i) vs.p1[i] = (float4 *)s->volP1[i].p;
+        vs.misLi = (float4 *)s->misLi.p; vs.pdLi = (float4 *)s->pdLi.p;
+        for (int i = 0; i < 2; ++i) { vq[i].o = (float4 *)s->vqo[i].p; vq[i].d = (float4 *)s->vqd[i].p; vq[i].counts = (int *)s->vCounts.p + i * QSTRIDE; }
+    }
 
     float4 *const hitsMis = (float4 *)s->hitsMain.p + (size_t)regionCapFor(capacity) * PG_REGIONS;
     PathState ps;
@@ -657,7 +704,6 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
     ps.pdLight = (float4 *)s->pdLight.p; ps.pdMis = (float4 *)s->pdMis.p; ps.pdBeta = (float4 *)s->pdBeta.p; ps.pdInfo = (int4 *)s->pdInfo.p;
     int *counts = (int *)s->counts.p;
     RayQueue q[4];
-    const int QSTRIDE = PG_REGIONS * PG_COUNT_STRIDE;  // ints of counter storage per queue
     for (int i = 0; i < 4; ++i) { q[i].o = (float4 *)s->qo[i].p; q[i].d = (float4 *)s->qd[i].p; q[i].counts = counts + i * QSTRIDE; }
     // sum of a queue's region counters in a host copy of the counter block
     auto queueTotal = [&](const int *blk, int qi) { uint64_t t = 0; for (int r = 0; r < PG_REGIONS; ++r) t += (uint64_t)blk[qi * QSTRIDE + r * PG_COUNT_STRIDE]; return t; };
@@ -688,6 +734,62 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
             HIP_TRY(hipMemsetAsync(counts, 0, 4 * QSTRIDE * sizeof(int), stream));
             int cur = 0;  // main queue index (0/1 ping-pong); 2 = shadow, 3 = MIS
             launch_generate(s->d, rp, ps, q[cur], stream);
+            if (vol) {
+                // VolPathIntegrator::Li (volpath.cpp:72-186).  Per loop iteration: closest-hit(main rays, with the hits' ray
+                // parameters) -> shade with medium sampling -> the transmittance rays of the light samples and of the
+                // BSDF/phase samples, re-traced until none is left under way (light.cpp:63-81, scene.cpp:57-70) -> resolve.
+                // Crossing a surface without a material does not count as a bounce, so the loop runs until the queue is empty.
+                DScene dv = s->d;
+                dv.ext = 1;  // the general shading kernels
+                const int n1 = regionCapFor(capacity) * PG_REGIONS;
+                float *hitT = (float *)s->hitT.p;
+                for (int i = 0; i < 2; ++i) vq[i].regionCap = q[0].regionCap;
+                launch_fill_int(vs.medium, rd->camera_medium + 1, rp.capacity, stream);  // camera rays start in the camera's medium (camera.h:78)
+                std::vector<int> blk(4 * QSTRIDE), vblk(2 * QSTRIDE);
+                auto readCounts = [&]() -> int {
+                    HIP_TRY(hipMemcpyAsync(blk.data(), counts, 4 * QSTRIDE * sizeof(int), hipMemcpyDeviceToHost, stream));
+                    HIP_TRY(hipMemcpyAsync(vblk.data(), s->vCounts.p, 2 * QSTRIDE * sizeof(int), hipMemcpyDeviceToHost, stream));
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    return PG_OK;
+                };
+                if (int e = readCounts()) return e;
+                uint64_t nMain = queueTotal(blk.data(), cur);
+                cameraRays += nMain;
+                for (int iter = 0; nMain > 0; ++iter) {
+                    if (iter > 100000) return setError(PG_ERR_DEVICE, "pg_render: volpath loop did not terminate");
+                    const int nxt = cur ^ 1;
+                    launch_closest(dv, q[cur], (float4 *)s->hitsMain.p, hitT, cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream);
+                    ++closestLaunches; closestRays += nMain;
+                    HIP_TRY(hipMemsetAsync(counts + nxt * QSTRIDE, 0, QSTRIDE * sizeof(int), stream));
+                    HIP_TRY(hipMemsetAsync(counts + 2 * QSTRIDE, 0, 2 * QSTRIDE * sizeof(int), stream));
+                    launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream);
+                    // through rays: kind 0 = light samples (q[2] <-> vq[0]), kind 1 = BSDF / phase samples (q[3] <-> vq[1])
+                    RayQueue tq[2][2] = {{q[2], vq[0]}, {q[3], vq[1]}};
+                    int tcur = 0;
+                    for (int pass = 0;; ++pass) {
+                        if (pass > 100000) return setError(PG_ERR_DEVICE, "pg_render: transmittance loop did not terminate");
+                        if (int e = readCounts()) return e;
+                        const uint64_t n0 = tcur == 0 ? queueTotal(blk.data(), 2) : queueTotal(vblk.data(), 0);
+                        const uint64_t n1q = tcur == 0 ? queueTotal(blk.data(), 3) : queueTotal(vblk.data(), 1);
+                        if (n0 + n1q == 0) break;
+                        launch_closest2(dv, tq[0][tcur], tq[1][tcur], (float4 *)s->hitsMain.p, n1, cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream, hitT);
+                        ++closestLaunches; closestRays += n0 + n1q;
+                        HIP_TRY(hipMemsetAsync(tq[0][tcur ^ 1].counts, 0, QSTRIDE * sizeof(int), stream));
+                        HIP_TRY(hipMemsetAsync(tq[1][tcur ^ 1].counts, 0, QSTRIDE * sizeof(int), stream));
+                        launch_through(dv, ps, vs, 0, tq[0][tcur], (const float4 *)s->hitsMain.p, hitT, 0, tq[0][tcur ^ 1], stream);
+                        launch_through(dv, ps, vs, 1, tq[1][tcur], (const float4 *)s->hitsMain.p, hitT, n1, tq[1][tcur ^ 1], stream);
+                        tcur ^= 1;
+                    }
+                    launch_resolve_vol(dv, ps, vs, q[cur], stream);
+                    // the next pass of the through loop reads counts again; the main queue's size comes from the same block
+                    nMain = queueTotal(blk.data(), nxt);
+                    cur = nxt;
+                }
+                if (rd->filter_general) launch_film_general(rp, ps, dFilm, stream);
+                else launch_film(rp, ps, dFilm, dStrays, maxStrays, dNStrays, stream);
+                HIP_TRY(hipStreamSynchronize(stream));
+                continue;
+            }
             // Launch order per bounce b (one stream): shade(b) -> any-hit(shadow rays of b) -> closest-hit(main rays of b+1
             // and MIS rays of b in ONE launch) -> resolve(b).  The first closest-hit launch traces the camera rays alone.
             auto timedClosest = [&](RayQueue qa, float4 *ha, const RayQueue *qb, float4 *hb) -> int {

@@ -51,6 +51,8 @@ struct DScene {
     const PgTexture *textures;           // texture nodes
     const PgTexturedMaterial *textured;  // materials evaluated per hit (PG_MAT_TEXTURED)
     int hasTextured;
+    const PgMedium *media;               // HomogeneousMedium table; triMediumIn/Out[k] = the primitive's MediumInterface (-1 = none), or nullptr
+    const int *triMediumIn, *triMediumOut;
     const PgBxDF *bxdfs;      // the materials' BxDF lists (PgMaterial.first_bxdf / n_bxdfs)
     int ext;          // the EXT shading kernels are needed: spheres, infinite lights or PG_MAT_LOBES materials (or PG_FORCE_EXT=1)
     int hasInfinite;  // some light is an InfiniteAreaLight (Scene::infiniteLights non-empty)
@@ -93,6 +95,17 @@ struct PathState {
     int4 *pdInfo;     // (shadow queue pos or -1, mis queue pos or -1, lightNum, unused)
 };
 
+// Extra per-path state of the VolPathIntegrator (integrators/volpath.cpp), indexed by slot.  A "through" ray is a ray of
+// VisibilityTester::Tr (light.cpp:63-81, kind 0) or Scene::IntersectTr (scene.cpp:57-70, kind 1): it is re-traced through
+// surfaces without a material until it is blocked, arrives or escapes, accumulating the media's transmittance.
+struct VolState {
+    int *medium;        // medium (index + 1, 0 = none) of the path's current ray
+    float4 *trAcc[2];   // per kind: (Tr so far rgb, the through ray's medium as int bits)
+    float4 *p1[3];      // kind 0: the light sample the ray is heading to (p, pError, n)
+    float4 *misLi;      // kind 1, once finished: radiance of the sampled light along the ray (rgb)
+    float4 *pdLi;       // (Li rgb of the light sample, lightPdf)
+};
+
 #define PG_META_SPECULAR 0x10000
 #define PG_META_DONE 0x20000
 #define PG_META_HASDIFF 0x80000  // the ray still is the camera's RayDifferential (cleared by the first SpawnRay)
@@ -118,12 +131,20 @@ TraceConfig get_trace_config();
 void launch_closest(const DScene &sc, RayQueue q, float4 *hits, float *tOut, TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s);
 // two queues in one launch; q1's results land at hits[hitOffset1 + i]
 void launch_closest2(const DScene &sc, RayQueue q0, RayQueue q1, float4 *hits, int hitOffset1, TraceCounters *cn, int *cursors, int *cullGuard,
-                     hipStream_t s);
+                     hipStream_t s, float *tOut = nullptr);
 void launch_anyhit(const DScene &sc, RayQueue q, int *occluded, TraceCounters *cn, int *cursors, hipStream_t s);
 void launch_generate(const DScene &sc, const RenderParams &rp, PathState st, RayQueue q, hipStream_t s);
 void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQueue qin, const float4 *hits, RayQueue qnext,
                   RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s);
 void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis, const int *occluded, const float4 *misHits, hipStream_t s);
+// VolPathIntegrator: the shading step with medium sampling (hitT = the hits' ray parameters), one step of the through rays of
+// `kind` (results of qin at hits[hitBase + i]; continued rays go to qout), and EstimateDirect's sums with transmittance
+void launch_shade_vol(const DScene &sc, const RenderParams &rp, PathState st, VolState vs, RayQueue qin, const float4 *hits, const float *hitT,
+                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s);
+void launch_through(const DScene &sc, PathState st, VolState vs, int kind, RayQueue qin, const float4 *hits, const float *hitT, int hitBase,
+                    RayQueue qout, hipStream_t s);
+void launch_resolve_vol(const DScene &sc, PathState st, VolState vs, RayQueue qin, hipStream_t s);
+void launch_fill_int(int *p, int value, int n, hipStream_t s);
 void launch_film(const RenderParams &rp, PathState st, PgFilmPixel *film, PgStraySample *strays, int maxStrays, int *nStrays,
                  hipStream_t s);
 void launch_film_general(const RenderParams &rp, PathState st, PgFilmPixel *film, hipStream_t s);

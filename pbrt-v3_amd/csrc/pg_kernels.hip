@@ -1374,9 +1374,50 @@ PG_DEV void spawn_ray(const Isect &is, V3 d, V3 &o) { o = offset_ray_origin(is.p
 
 // MODE 0: triangles + matte/plastic/mirror/glass + area and delta lights (specialised BSDF).  MODE 1 (EXT): any material as
 // its BxDF list, quadrics, object instances, infinite lights.  MODE 2: MODE 1 + textured materials, evaluated per hit.
-template <int MODE>
+
+// ===========================================================================
+// Participating media (VolPathIntegrator): HomogeneousMedium and the Henyey-Greenstein phase function.  expf / logf /
+// sinf / cosf are evaluated in double and rounded once, like every libm call of this file (DESIGN.md "libm").
+// ===========================================================================
+#define PG_MAX_FLOAT 3.40282346638528859811704183484516925e+38f
+PG_DEV Spec sp_exp(Spec a) { return sp3((float)exp((double)a.r), (float)exp((double)a.g), (float)exp((double)a.b)); }  // Exp(), spectrum.h:414-419
+// HomogeneousMedium::Tr, homogeneous.cpp:44-47, for a ray with the given tMax and |d|
+PG_DEV Spec medium_tr(const PgMedium &m, float tMax, float dLen) {
+    const Spec negSt = sp3(-m.sigma_t[0], -m.sigma_t[1], -m.sigma_t[2]);
+    return sp_exp(negSt * pmin(tMax * dLen, PG_MAX_FLOAT));
+}
+PG_DEV float phase_hg(float cosTheta, float g) {  // medium.h:69-72
+    const float denom = 1 + g * g + 2 * g * cosTheta;
+    return 0.07957747154594766788f * (1 - g * g) / (denom * sqrtf(denom));
+}
+PG_DEV float hg_sample_p(float g, V3 wo, V3 &wi, float u0, float u1) {  // HenyeyGreenstein::Sample_p, medium.cpp:194-213
+    float cosTheta;
+    if ((double)fabsf(g) < 1e-3) cosTheta = 1 - 2 * u0;
+    else {
+        const float sqrTerm = (1 - g * g) / (1 + g - 2 * g * u0);
+        cosTheta = -(1 + g * g - sqrTerm * sqrTerm) / (2 * g);
+    }
+    const float sinTheta = sqrtf(pmax(0.f, 1 - cosTheta * cosTheta));
+    const float phi = 2 * PG_PI * u1;
+    V3 v1, v2;
+    coordinate_system(wo, v1, v2);
+    double sP, cP;
+    sincos((double)phi, &sP, &cP);
+    wi = (v1 * (sinTheta * (float)cP) + v2 * (sinTheta * (float)sP)) + wo * cosTheta;  // SphericalDirection, geometry.h:1461-1466
+    return phase_hg(cosTheta, g);
+}
+// GeometricPrimitive::Intersect's mediumInterface (primitive.cpp:121-125): the primitive's own when it marks a transition,
+// else the ray's medium on both sides.  Media are index + 1, 0 = none.
+PG_DEV void prim_interface(const DScene &sc, int prim, int rayMedium, int &mIn, int &mOut) {
+    const int in1 = sc.triMediumIn ? sc.triMediumIn[prim] + 1 : 0, out1 = sc.triMediumOut ? sc.triMediumOut[prim] + 1 : 0;
+    if (in1 != out1) { mIn = in1; mOut = out1; }
+    else mIn = mOut = rayMedium;
+}
+
+template <int MODE, bool VOL>
 __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
-                                                     RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests) {
+                                                     RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, VolState vs,
+                                                     const float *__restrict__ hitT) {
     constexpr bool EXT = MODE >= 1, TEX = MODE == 2;
     const int i = queue_item(qin);
     const bool valid = i >= 0;
@@ -1397,6 +1438,8 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
     float misPdf = 0, misLightArea = 1;
     int misLightPrim = 0;
     bool misInside = false;  // sphere light whose sphere contains the shaded point: Sphere::Pdf falls back to Shape::Pdf
+    int misMedium = 0;       // VOL: medium of the BSDF-sampled ray
+    float volWeight = 0;     // VOL: MIS weight of the light sample (-1: delta light)
     if (valid) {
         const float4 d4 = qin.d[i], h4 = hits[i];
         slot = __float_as_int(d4.w);
@@ -1412,6 +1455,36 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
         int bounces = meta.w & 0xffff;
         const bool specularBounce = (meta.w & PG_META_SPECULAR) != 0;
         const bool found = prim >= 0;
+        // VOL: the ray's medium (index + 1); volpath.cpp:76-78 samples it before anything else happens at the vertex
+        int med = 0;
+        bool volDead = false, inMedium = false;
+        V3 mediumP = mk(0, 0, 0);
+        if constexpr (VOL) {
+            med = vs.medium[slot];
+            if (med) {  // HomogeneousMedium::Sample, homogeneous.cpp:49-74
+                const PgMedium &mm = sc.media[med - 1];
+                const float4 o4 = qin.o[i];
+                int channel = (int)(halton_sample(sc, rd, index, dim) * 3);
+                if (channel > 2) channel = 2;
+                const float ud = halton_sample(sc, rd, index, dim + 1);
+                dim += 2;
+                const float dist = -(float)log((double)(1 - ud)) / mm.sigma_t[channel];
+                const float dLen = sqrtf(lensq(rayD));
+                const float tMaxRay = found ? hitT[i] : o4.w;  // ray.tMax after Scene::Intersect
+                const float t = pmin(dist / dLen, tMaxRay);
+                inMedium = t < tMaxRay;
+                if (inMedium) mediumP = mk(o4.x, o4.y, o4.z) + rayD * t;
+                const Spec sigT = sp3(mm.sigma_t[0], mm.sigma_t[1], mm.sigma_t[2]), sigS = sp3(mm.sigma_s[0], mm.sigma_s[1], mm.sigma_s[2]);
+                const Spec Tr = sp_exp((sp3(-sigT.r, -sigT.g, -sigT.b) * pmin(t, PG_MAX_FLOAT)) * dLen);
+                const Spec density = inMedium ? sigT * Tr : Tr;
+                float pdf = 0;
+                pdf += density.r; pdf += density.g; pdf += density.b;
+                pdf *= 1 / (float)3;
+                if (pdf == 0) pdf = 1;
+                beta = beta * (inMedium ? (Tr * sigS) / pdf : Tr / pdf);
+            }
+            volDead = is_black(beta);  // volpath.cpp:78
+        }
         Tri tri;
         if (found) tri = load_tri(sc, prim);
         Isect is;
@@ -1431,8 +1504,9 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
             is.sdpdv = sh.dpdv; is.sdndu = sh.dndu; is.sdndv = sh.dndv;
             if (TEX) { sphU = sh.u; sphV = sh.v; sphDpdu = sh.dpdu; sphDpdv = sh.dpdv; }
         }
-        // path.cpp:91-102 emitted light at the vertex
-        if ((bounces == 0 || specularBounce) && found && tri.light >= 0) {
+        // path.cpp:91-102 emitted light at the vertex (volpath.cpp:103-110: only when no medium interaction was sampled)
+        if (VOL && (volDead || inMedium)) {
+        } else if ((bounces == 0 || specularBounce) && found && tri.light >= 0) {
             const PgLight &l = sc.lights[tri.light];
             V3 nrm = onSphere ? is.n : hit_normal(sc, prim, tri, h4.y, h4.z, h4.w);
             Spec Le = (l.two_sided || dot(nrm, -rayD) > 0) ? sp3(l.L[0], l.L[1], l.L[2]) : sp(0);
@@ -1444,7 +1518,86 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
         }
         bool alive = found && bounces < rd.max_depth;  // path.cpp:104
         int newFlags = 0;
-        if (alive) {
+        bool handled = false;
+        if constexpr (VOL) {
+            if (volDead) alive = false;
+            else if (inMedium) alive = bounces < rd.max_depth;  // volpath.cpp:83
+            if (alive && inMedium) {
+                // ---- scattering at a point in the medium, volpath.cpp:80-96: MediumInteraction(p, -ray.d, ..., medium, phase)
+                handled = true;
+                const float g = sc.media[med - 1].g;
+                const V3 zero = mk(0, 0, 0), wo = -rayD;
+                if (sc.nLights > 0) {  // UniformSampleOneLight(mi, ..., handleMedia = true), integrator.cpp:85-106
+                    const float *tab = light_distribution(sc, mediumP);
+                    float lightSelPdf;
+                    lightNum = sample_discrete(tab, sc.nLights, halton_sample(sc, rd, index, dim++), lightSelPdf);
+                    if (lightSelPdf != 0) {
+                        float uL0 = halton_sample(sc, rd, index, dim), uL1 = halton_sample(sc, rd, index, dim + 1);
+                        float uS0 = halton_sample(sc, rd, index, dim + 2), uS1 = halton_sample(sc, rd, index, dim + 3);
+                        dim += 4;
+                        const PgLight &light = sc.lights[lightNum];
+                        V3 wi = zero;
+                        float lightPdf = 0;
+                        float4 pdLight = make_float4(0, 0, 0, 0);
+                        LightSample ls;
+                        Spec Li = light_sample_li<true>(sc, light, mediumP, zero, zero, uL0, uL1, wi, lightPdf, ls);
+                        if (lightPdf > 0 && !is_black(Li)) {
+                            const float ph = phase_hg(dot(wo, wi), g);  // integrator.cpp:135-141
+                            if (ph != 0) {
+                                V3 origin = offset_ray_origin(mediumP, zero, zero, ls.p - mediumP);
+                                V3 target = offset_ray_origin(ls.p, ls.pError, ls.n, origin - ls.p);
+                                const V3 shD = target - origin;
+                                s_ray[1][0][tid] = make_float4(origin.x, origin.y, origin.z, 1 - PG_SHADOW_EPS);
+                                s_ray[1][1][tid] = make_float4(shD.x, shD.y, shD.z, __int_as_float(slot));
+                                pushShadow = true;
+                                const bool isDelta = light.type == PG_LIGHT_POINT || light.type == PG_LIGHT_SPOT || light.type == PG_LIGHT_DISTANT;
+                                volWeight = isDelta ? -1.f : power_heuristic(1, lightPdf, 1, ph);
+                                pdLight = make_float4(ph, ph, ph, 0);
+                                vs.pdLi[slot] = make_float4(Li.r, Li.g, Li.b, lightPdf);
+                                vs.p1[0][slot] = make_float4(ls.p.x, ls.p.y, ls.p.z, 0); vs.p1[1][slot] = make_float4(ls.pError.x, ls.pError.y, ls.pError.z, 0);
+                                vs.p1[2][slot] = make_float4(ls.n.x, ls.n.y, ls.n.z, 0);
+                                vs.trAcc[0][slot] = make_float4(1, 1, 1, __int_as_float(med));  // MediumInteraction::GetMedium(): the medium itself
+                            }
+                        }
+                        if (light.type == PG_LIGHT_AREA || light.type == PG_LIGHT_INFINITE) {  // integrator.cpp:164-212 with the phase function
+                            V3 wi2;
+                            const float ph2 = hg_sample_p(g, wo, wi2, uS0, uS1);
+                            if (ph2 != 0 && ph2 > 0) {
+                                misCand = true;
+                                misRo = mediumP; misWi = wi2; misF = sp(ph2); misPdf = ph2; misP = mediumP; misMedium = med;
+                                misLightPrim = light.type == PG_LIGHT_INFINITE ? -1 - lightNum : light.prim; misLightArea = light.area;
+                                if (light.type == PG_LIGHT_AREA) {
+                                    const float4 la = sc.tris[3 * light.prim];
+                                    if (__float_as_uint(la.w) & PG_PRIM_SPHERE)
+                                        misInside = sc.spheres[__float_as_int(la.x)].shape != PG_SHAPE_SPHERE ||
+                                                    sphere_ref_inside(sc.spheres[__float_as_int(la.x)], mediumP, zero, zero);
+                                }
+                            }
+                        }
+                        pdLight.w = lightSelPdf;
+                        st.pdLight[slot] = pdLight;
+                        st.pdBeta[slot] = make_float4(beta.r, beta.g, beta.b, 0.f);
+                    }
+                }
+                // mi.phase->Sample_p for the next direction, volpath.cpp:92-95
+                V3 wi;
+                const float u0 = halton_sample(sc, rd, index, dim), u1 = halton_sample(sc, rd, index, dim + 1);
+                dim += 2;
+                hg_sample_p(g, wo, wi, u0, u1);
+                s_ray[0][0][tid] = make_float4(mediumP.x, mediumP.y, mediumP.z, PG_INF);
+                s_ray[0][1][tid] = make_float4(wi.x, wi.y, wi.z, __int_as_float(slot));
+                nextBin = (wi.x < 0 ? 1 : 0) | (wi.y < 0 ? 2 : 0) | (wi.z < 0 ? 4 : 0);
+                pushNext = true;  // the path stays in `med`
+                Spec rrBeta = beta * etaScale;  // volpath.cpp:178-184
+                if (max_component(rrBeta) < rd.rr_threshold && bounces > 3) {
+                    float qq = pmax(.05f, 1 - max_component(rrBeta));
+                    if (halton_sample(sc, rd, index, dim++) < qq) pushNext = false;
+                    else beta = beta / (1 - qq);
+                }
+                bounces += 1;
+            }
+        }
+        if (alive && !handled) {
             if (!onSphere) is = make_isect(sc, prim, tri, h4.y, h4.z, h4.w, shapeRayD);
             if (inst >= 0 && !sc.instances[inst].identity) {  // InterpolatedPrimToWorld(*isect), transform.cpp:262-297
                 const PgInstance &in = sc.instances[inst];
@@ -1460,12 +1613,16 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                 is = w;
             }
             const PgMaterial &m = sc.materials[tri.material];
+            int mIn = 0, mOut = 0;  // VOL: isect.mediumInterface
+            if constexpr (VOL) prim_interface(sc, prim, med, mIn, mOut);
             if (m.type == PG_MAT_NONE) {  // path.cpp:107-113: skip over medium boundaries
                 V3 nextO;
                 spawn_ray(is, rayD, nextO);
                 s_ray[0][0][tid] = make_float4(nextO.x, nextO.y, nextO.z, PG_INF);
                 s_ray[0][1][tid] = make_float4(rayD.x, rayD.y, rayD.z, __int_as_float(slot));
                 pushNext = true;
+                newFlags = meta.w & PG_META_SPECULAR;  // `continue` leaves specularBounce as it was
+                if constexpr (VOL) vs.medium[slot] = dot(rayD, is.n) > 0 ? mOut : mIn;  // Interaction::GetMedium(w), interaction.h:86-88
             } else {
                 // MatteMaterial::ComputeScatteringFunctions (matte.cpp:45-62), BSDF ctor (reflection.h:167-172)
                 // BSDF: the EXT kernel evaluates the material's BxDF list (any material); the plain kernel has the list
@@ -1596,7 +1753,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                 if constexpr (EXT) hasNonSpecular = lbsdf_num_components(lb, nonSpecular) > 0;
                 else hasNonSpecular = bsdf.nBxDFs > 0 && !bsdf.specular;
                 // ---- direct lighting: UniformSampleOneLight (integrator.cpp:85-106) + EstimateDirect set-up
-                if (hasNonSpecular && sc.nLights > 0) {  // path.cpp:119: only with non-specular lobes
+                if ((VOL || hasNonSpecular) && sc.nLights > 0) {  // path.cpp:119: only with non-specular lobes (volpath.cpp:124-127: always)
                     const float *tab = light_distribution(sc, is.p);
                     float lightSelPdf;
                     lightNum = sample_discrete(tab, sc.nLights, halton_sample(sc, rd, index, dim++), lightSelPdf);
@@ -1624,8 +1781,17 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                                 pushShadow = true;
                                 // delta lights take no MIS weight (integrator.cpp:155-160)
                                 const bool isDelta = light.type == PG_LIGHT_POINT || light.type == PG_LIGHT_SPOT || light.type == PG_LIGHT_DISTANT;
-                                Spec c = isDelta ? (f * Li) / lightPdf : ((f * Li) * power_heuristic(1, lightPdf, 1, scatteringPdf)) / lightPdf;
-                                pdLight = make_float4(c.r, c.g, c.b, 0);
+                                if constexpr (VOL) {  // Li still is to be multiplied by VisibilityTester::Tr (integrator.cpp:146-150): keep the factors apart
+                                    volWeight = isDelta ? -1.f : power_heuristic(1, lightPdf, 1, scatteringPdf);
+                                    pdLight = make_float4(f.r, f.g, f.b, 0);
+                                    vs.pdLi[slot] = make_float4(Li.r, Li.g, Li.b, lightPdf);
+                                    vs.p1[0][slot] = make_float4(ls.p.x, ls.p.y, ls.p.z, 0); vs.p1[1][slot] = make_float4(ls.pError.x, ls.pError.y, ls.pError.z, 0);
+                                    vs.p1[2][slot] = make_float4(ls.n.x, ls.n.y, ls.n.z, 0);
+                                    vs.trAcc[0][slot] = make_float4(1, 1, 1, __int_as_float(dot(shD, is.n) > 0 ? mOut : mIn));
+                                } else {
+                                    Spec c = isDelta ? (f * Li) / lightPdf : ((f * Li) * power_heuristic(1, lightPdf, 1, scatteringPdf)) / lightPdf;
+                                    pdLight = make_float4(c.r, c.g, c.b, 0);
+                                }
                             }
                         }
                         // BSDF sampling half of MIS (integrator.cpp:164-212): sample now, while the BSDF is live; the
@@ -1642,6 +1808,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                             misCand = true;
                             spawn_ray(is, wi2, misRo);
                             misWi = wi2; misF = f2; misPdf = sPdf2; misP = is.p;
+                            if constexpr (VOL) misMedium = dot(wi2, is.n) > 0 ? mOut : mIn;
                             misLightPrim = (EXT && light.type == PG_LIGHT_INFINITE) ? -1 - lightNum : light.prim; misLightArea = light.area;
                             if (EXT && light.type == PG_LIGHT_AREA) {
                                 const float4 la = sc.tris[3 * light.prim];
@@ -1677,6 +1844,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                     s_ray[0][1][tid] = make_float4(wi.x, wi.y, wi.z, __int_as_float(slot));
                     nextBin = (wi.x < 0 ? 1 : 0) | (wi.y < 0 ? 2 : 0) | (wi.z < 0 ? 4 : 0);
                     pushNext = true;
+                    if constexpr (VOL) vs.medium[slot] = dot(wi, is.n) > 0 ? mOut : mIn;
                     // Russian roulette, path.cpp:176-184
                     Spec rrBeta = beta * etaScale;
                     if (max_component(rrBeta) < rd.rr_threshold && bounces > 3) {
@@ -1723,6 +1891,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
             pushMis = true;
             st.pdMis[slot] = make_float4(misF.r, misF.g, misF.b, misPdf);
             st.pdBeta[slot].w = power_heuristic(1, misPdf, 1, lightPdf2);
+            if constexpr (VOL) vs.trAcc[1][slot] = make_float4(1, 1, 1, __int_as_float(misMedium));
         }
     }
     const RayQueue outQ[3] = {qnext, qshadow, qmis};
@@ -1733,7 +1902,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
     if (pushNext) { qnext.o[posNext] = s_ray[0][0][tid]; qnext.d[posNext] = s_ray[0][1][tid]; }
     if (pushShadow) { qshadow.o[posShadow] = s_ray[1][0][tid]; qshadow.d[posShadow] = s_ray[1][1][tid]; }
     if (pushMis) { qmis.o[posMis] = s_ray[2][0][tid]; qmis.d[posMis] = s_ray[2][1][tid]; }
-    if (valid) st.pdInfo[slot] = make_int4(posShadow, posMis, lightNum, 0);
+    if (valid) st.pdInfo[slot] = make_int4(posShadow, posMis, lightNum, VOL ? __float_as_int(volWeight) : 0);
     unsigned long long nl = wave_sum(nLightTests);
     if (lane_id() == 0 && nl) atomicAdd(lightTriTests, nl);
 }
@@ -1741,9 +1910,18 @@ void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQue
                   RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s) {
     int nblk = PG_REGIONS * (qin.regionCap / PG_BLOCK);
     if (nblk == 0) return;
-    if (sc.hasTextured) hipLaunchKernelGGL(k_shade<2>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests);
-    else if (sc.ext) hipLaunchKernelGGL(k_shade<1>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests);
-    else hipLaunchKernelGGL(k_shade<0>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests);
+    const VolState vs = {};
+    const float *noT = nullptr;
+    if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, false>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT);
+    else if (sc.ext) hipLaunchKernelGGL((k_shade<1, false>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT);
+    else hipLaunchKernelGGL((k_shade<0, false>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT);
+}
+void launch_shade_vol(const DScene &sc, const RenderParams &rp, PathState st, VolState vs, RayQueue qin, const float4 *hits, const float *hitT,
+                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s) {
+    int nblk = PG_REGIONS * (qin.regionCap / PG_BLOCK);
+    if (nblk == 0) return;
+    if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, true>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT);
+    else hipLaunchKernelGGL((k_shade<1, true>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT);
 }
 
 // EstimateDirect's two "Add ... contribution" steps (integrator.cpp:143-161, 196-212) and
@@ -1791,6 +1969,150 @@ void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis,
     if (nblk == 0) return;
     if (sc.ext) hipLaunchKernelGGL(k_resolve<true>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, qin, qmis, occluded, misHits);
     else hipLaunchKernelGGL(k_resolve<false>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, qin, qmis, occluded, misHits);
+}
+
+// ===========================================================================
+// VolPathIntegrator's transmittance rays.  VisibilityTester::Tr (light.cpp:63-81) and Scene::IntersectTr (scene.cpp:57-70)
+// are loops of Scene::Intersect calls that step through surfaces without a material; here every loop iteration is one
+// closest-hit launch over the queue of rays still under way followed by this kernel, which finishes a ray or re-spawns it.
+// ===========================================================================
+// p, pError and n of the SurfaceInteraction of a closest hit (Triangle::Intersect / Sphere::Intersect, then the instance's
+// InterpolatedPrimToWorld), as k_shade builds them
+PG_DEV void through_point(const DScene &sc, int ri, float4 o4, V3 rayD, float4 h4, int prim, const Tri &tri, V3 &p, V3 &pError, V3 &n) {
+    const int inst = sc.hitInst ? sc.hitInst[ri] : -1;
+    V3 shapeRayD = rayD;
+    if (inst >= 0) shapeRayD = m4_vec(sc.instances[inst].w2i, rayD);
+    if (tri.flags & PG_PRIM_SPHERE) {
+        V3 shapeRayO = mk(o4.x, o4.y, o4.z);
+        if (inst >= 0) { float dt; instance_ray(sc.instances[inst].w2i, shapeRayO, rayD, shapeRayO, shapeRayD, dt); }
+        const SphereHit sh = sphere_interaction(sc.spheres[__float_as_int(tri.p0.x)], shapeRayO, shapeRayD, h4.y);
+        p = sh.p; pError = sh.pError; n = sh.n;
+    } else {
+        const Isect is = make_isect(sc, prim, tri, h4.y, h4.z, h4.w, shapeRayD);
+        p = is.p; pError = is.pError; n = is.n;
+    }
+    if (inst >= 0 && !sc.instances[inst].identity) {
+        const PgInstance &in = sc.instances[inst];
+        V3 pe;
+        p = m4_point_err2(in.i2w, p, pError, pe);
+        pError = pe;
+        n = normalize(m4_normal(in.w2i, n));
+    }
+}
+template <int KIND>
+__global__ __launch_bounds__(PG_BLOCK) void k_through(DScene sc, PathState st, VolState vs, RayQueue qin, const float4 *__restrict__ hits,
+                                                       const float *__restrict__ hitT, int hitBase, RayQueue qout) {
+    const int i = queue_item(qin);
+    bool push = false;
+    float4 no = make_float4(0, 0, 0, 0), nd = make_float4(0, 0, 0, 0);
+    if (i >= 0) {
+        const float4 o4 = qin.o[i], d4 = qin.d[i];
+        const int slot = __float_as_int(d4.w);
+        const V3 rayD = mk(d4.x, d4.y, d4.z);
+        const int ri = hitBase + i;
+        const float4 h4 = hits[ri];
+        const int prim = __float_as_int(h4.x);
+        const bool surface = prim >= 0;
+        const float4 acc = vs.trAcc[KIND][slot];
+        Spec Tr = sp3(acc.x, acc.y, acc.z);
+        int med = __float_as_int(acc.w);
+        Tri tri;
+        if (surface) tri = load_tri(sc, prim);
+        const bool opaque = surface && sc.materials[tri.material].type != PG_MAT_NONE;  // isect.primitive->GetMaterial() != nullptr
+        if (KIND == 0 && opaque) Tr = sp(0.f);  // light.cpp:70-72: blocked
+        else {
+            if (med) Tr = Tr * medium_tr(sc.media[med - 1], surface ? hitT[ri] : o4.w, sqrtf(lensq(rayD)));
+            if (KIND == 1 && !(surface && !opaque)) {
+                // IntersectTr is over (scene.cpp:64-67): the sampled light's radiance along the ray (integrator.cpp:199-208)
+                const int lightNum = st.pdInfo[slot].z;
+                Spec Li = sp(0);
+                if (surface) {
+                    if (tri.light == lightNum) {
+                        const PgLight &l = sc.lights[tri.light];
+                        V3 nrm;
+                        if (tri.flags & PG_PRIM_SPHERE) nrm = sphere_interaction(sc.spheres[__float_as_int(tri.p0.x)], mk(o4.x, o4.y, o4.z), rayD, h4.y).n;
+                        else nrm = hit_normal(sc, prim, tri, h4.y, h4.z, h4.w);
+                        if (l.two_sided || dot(nrm, -rayD) > 0) Li = sp3(l.L[0], l.L[1], l.L[2]);
+                    }
+                } else if (sc.lights[lightNum].type == PG_LIGHT_INFINITE) Li = env_le(sc, sc.lights[lightNum], rayD);
+                vs.misLi[slot] = make_float4(Li.r, Li.g, Li.b, 0);
+            } else if (surface) {
+                // a surface without a material: step over it (light.cpp:79 isect.SpawnRayTo(p1), scene.cpp:68 isect.SpawnRay(ray.d))
+                V3 p, pError, n;
+                through_point(sc, ri, o4, rayD, h4, prim, tri, p, pError, n);
+                int mIn, mOut;
+                prim_interface(sc, prim, med, mIn, mOut);
+                V3 origin, d;
+                float tMax;
+                if (KIND == 0) {
+                    const float4 a = vs.p1[0][slot], b = vs.p1[1][slot], c = vs.p1[2][slot];
+                    const V3 lp = mk(a.x, a.y, a.z), lpe = mk(b.x, b.y, b.z), ln = mk(c.x, c.y, c.z);
+                    origin = offset_ray_origin(p, pError, n, lp - p);  // interaction.h:73-78
+                    const V3 target = offset_ray_origin(lp, lpe, ln, origin - lp);
+                    d = target - origin;
+                    tMax = 1 - PG_SHADOW_EPS;
+                } else {
+                    origin = offset_ray_origin(p, pError, n, rayD);
+                    d = rayD;
+                    tMax = PG_INF;
+                }
+                med = dot(d, n) > 0 ? mOut : mIn;
+                no = make_float4(origin.x, origin.y, origin.z, tMax);
+                nd = make_float4(d.x, d.y, d.z, __int_as_float(slot));
+                push = true;
+            }
+        }
+        vs.trAcc[KIND][slot] = make_float4(Tr.r, Tr.g, Tr.b, __int_as_float(med));
+    }
+    int pos;
+    block_push<1, false>(&qout, &push, &pos);
+    if (push) { qout.o[pos] = no; qout.d[pos] = nd; }
+}
+void launch_through(const DScene &sc, PathState st, VolState vs, int kind, RayQueue qin, const float4 *hits, const float *hitT, int hitBase,
+                    RayQueue qout, hipStream_t s) {
+    int nblk = PG_REGIONS * (qin.regionCap / PG_BLOCK);
+    if (nblk == 0) return;
+    if (kind == 0) hipLaunchKernelGGL(k_through<0>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, vs, qin, hits, hitT, hitBase, qout);
+    else hipLaunchKernelGGL(k_through<1>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, vs, qin, hits, hitT, hitBase, qout);
+}
+// EstimateDirect's sums with handleMedia = true (integrator.cpp:143-161, 196-212), once the through rays are finished
+__global__ __launch_bounds__(PG_BLOCK) void k_resolve_vol(DScene sc, PathState st, VolState vs, RayQueue qin) {
+    const int i = queue_item(qin);
+    if (i < 0) return;
+    const int slot = __float_as_int(qin.d[i].w);
+    const int4 info = st.pdInfo[slot];
+    if (info.x < 0 && info.y < 0) return;
+    const float4 pl = st.pdLight[slot], pm = st.pdMis[slot], pb = st.pdBeta[slot];
+    Spec Ld = sp(0);
+    if (info.x >= 0) {
+        const float4 li = vs.pdLi[slot], t0 = vs.trAcc[0][slot];
+        const Spec Li = sp3(li.x, li.y, li.z) * sp3(t0.x, t0.y, t0.z);  // Li *= visibility.Tr(scene, sampler)
+        if (!is_black(Li)) {
+            const Spec f = sp3(pl.x, pl.y, pl.z);
+            const float w = __int_as_float(info.w);
+            Ld = Ld + (w < 0 ? (f * Li) / li.w : ((f * Li) * w) / li.w);
+        }
+    }
+    if (info.y >= 0) {
+        const float4 ml = vs.misLi[slot], t1 = vs.trAcc[1][slot];
+        const Spec Li = sp3(ml.x, ml.y, ml.z);
+        if (!is_black(Li)) Ld = Ld + ((((sp3(pm.x, pm.y, pm.z) * Li) * sp3(t1.x, t1.y, t1.z)) * pb.w) / pm.w);
+    }
+    float4 L4 = st.L[slot];
+    Spec L = sp3(L4.x, L4.y, L4.z) + sp3(pb.x, pb.y, pb.z) * (Ld / pl.w);
+    st.L[slot] = make_float4(L.r, L.g, L.b, L4.w);
+}
+void launch_resolve_vol(const DScene &sc, PathState st, VolState vs, RayQueue qin, hipStream_t s) {
+    int nblk = PG_REGIONS * (qin.regionCap / PG_BLOCK);
+    if (nblk == 0) return;
+    hipLaunchKernelGGL(k_resolve_vol, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, vs, qin);
+}
+__global__ void k_fill_int(int *p, int value, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = value;
+}
+void launch_fill_int(int *p, int value, int n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_fill_int, dim3((n + 255) / 256), dim3(256), 0, s, p, value, n);
 }
 
 // ===========================================================================

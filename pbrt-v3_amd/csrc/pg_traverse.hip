@@ -373,8 +373,8 @@ void launch_closest(const DScene &sc, RayQueue q, float4 *hits, float *tOut, Tra
     launch_trace<false>(sc, q, noQueue(), hits, 0, tOut, nullptr, cn, cursors, cullGuard, s);
 }
 void launch_closest2(const DScene &sc, RayQueue q0, RayQueue q1, float4 *hits, int hitOffset1, TraceCounters *cn, int *cursors, int *cullGuard,
-                     hipStream_t s) {
-    launch_trace<false>(sc, q0, q1, hits, hitOffset1, nullptr, nullptr, cn, cursors, cullGuard, s);
+                     hipStream_t s, float *tOut) {
+    launch_trace<false>(sc, q0, q1, hits, hitOffset1, tOut, nullptr, cn, cursors, cullGuard, s);
 }
 void launch_anyhit(const DScene &sc, RayQueue q, int *occluded, TraceCounters *cn, int *cursors, hipStream_t s) {
     launch_trace<true>(sc, q, noQueue(), nullptr, 0, nullptr, occluded, cn, cursors, nullptr, s);

@@ -143,6 +143,29 @@ def random_scene_ext(seed, res=16, spp=4):
     return "\n".join(out) + "\n"
 
 
+def random_scene_vol(seed, res=16, spp=4):
+    """random_scene_ext under the VolPathIntegrator: homogeneous media (isotropic, forward / backward scattering, one absorbing
+    only), the camera inside a medium in every other scene, media bounded by "none" surfaces (a sphere, loose triangles, a
+    sphere inside an instanced object) and medium interfaces on ordinary surfaces."""
+    rng = np.random.default_rng(9000 + seed)
+    f = lambda a: " ".join(f"{x:.9g}" for x in np.asarray(a, np.float32).ravel())
+    text = random_scene_ext(seed, res, spp)
+    media = ['MakeNamedMedium "m0" "string type" "homogeneous" "rgb sigma_a" [ %s ] "rgb sigma_s" [ %s ] "float g" [ %.4g ]' % (f(0.02 * rng.random(3)), f(0.15 * rng.random(3)), 1.6 * rng.random() - 0.8),
+             'MakeNamedMedium "m1" "string type" "homogeneous" "rgb sigma_a" [ %s ] "rgb sigma_s" [ %s ] "float g" [ 0.0002 ] "float scale" [ %.4g ]' % (f(rng.random(3)), f(2 * rng.random(3)), 0.2 + rng.random()),
+             'MakeNamedMedium "m2" "string type" "homogeneous" "rgb sigma_a" [ %s ] "rgb sigma_s" [ 0 0 0 ]' % f(0.5 * rng.random(3)),
+             'MakeNamedMedium "m3" "string type" "homogeneous" "float g" [ %.4g ] "float scale" [ 0.1 ]' % (-0.9 * rng.random())]
+    cam = 'MediumInterface "" "m0"\n' if seed % 2 == 0 else ""
+    text = text.replace("Camera ", "\n".join(media) + "\n" + cam + "Camera ", 1)
+    text = text.replace('Integrator "path"', 'Integrator "volpath"' + (' "float rrthreshold" [ 0.6 ]' if seed % 3 == 0 else ""), 1)
+    extra = ['AttributeBegin\n MediumInterface "m1" "%s"\n Material "none"\n Translate %s\n Shape "sphere" "float radius" [ %.4g ]\nAttributeEnd'
+             % ("m0" if seed % 2 == 0 else "", f(rng.normal(size=3)), 0.5 + rng.random()),
+             'AttributeBegin\n MediumInterface "m2" "m3"\n Material ""\n Shape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ] "point P" [ %s ]\nAttributeEnd' % f(rng.normal(size=(4, 3)) * 2),
+             'AttributeBegin\n MediumInterface "m3" ""\n Shape "trianglemesh" "integer indices" [ 0 1 2 ] "point P" [ %s ]\nAttributeEnd' % f(rng.normal(size=(3, 3)) * 2),
+             'ObjectBegin "cloud"\n MediumInterface "m1" "m2"\n Material "none"\n Shape "sphere" "float radius" [ 0.5 ]\n Material "matte"\n Translate 0 0.6 0\n Shape "disk" "float radius" [ 0.4 ]\nObjectEnd',
+             'AttributeBegin\n Translate %s\n Scale %.4g 1 -1\n ObjectInstance "cloud"\nAttributeEnd' % (f(rng.normal(size=3) * 1.5), 0.5 + rng.random())]
+    return text.replace("WorldEnd\n", "\n".join(extra) + "\nWorldEnd\n")
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_random_scene_film_matches_oracle(gpu, oracle, seed):
     check_scene(gpu, oracle, random_scene(seed), seed)
@@ -151,6 +174,11 @@ def test_random_scene_film_matches_oracle(gpu, oracle, seed):
 @pytest.mark.parametrize("seed", range(24))
 def test_random_extended_scene_film_matches_oracle(gpu, oracle, seed):
     check_scene(gpu, oracle, random_scene_ext(seed), seed)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_volumetric_scene_film_matches_oracle(gpu, oracle, seed):
+    check_scene(gpu, oracle, random_scene_vol(seed), seed)
 
 
 def check_scene(gpu, oracle, text, seed):

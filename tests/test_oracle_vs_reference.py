@@ -80,7 +80,7 @@ def test_killeroo_geometry_live_when_reference_present(pkg, oracle, tmp_path):
 
 def test_fuzz_scenes_live_when_reference_present(pkg, oracle, tmp_path):
     """The random scenes of tests/test_gpu_fuzz.py (degenerate soups, every material / light / filter / strategy, spheres,
-    object instances) rendered by the unmodified reference and by front end + oracle: bit-identical images.  Needs the
+    object instances, participating media under the volpath integrator) rendered by the unmodified reference and by front end + oracle: bit-identical images.  Needs the
     reference binary (build container); on the GPU box those scenes are checked against the oracle only."""
     if not os.path.exists(oracle.REF_BINARY):
         pytest.skip("reference binary not available here")
@@ -89,8 +89,8 @@ def test_fuzz_scenes_live_when_reference_present(pkg, oracle, tmp_path):
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     scene_file, out = str(tmp_path / "fuzz.pbrt"), str(tmp_path / "ref.pfm")
-    for gen in (fz.random_scene, fz.random_scene_ext):
-        for seed in range(0, 24, 2):
+    for gen in (fz.random_scene, fz.random_scene_ext, fz.random_scene_vol):
+        for seed in (range(16) if gen is fz.random_scene_vol else range(0, 24, 2)):
             open(scene_file, "w").write(gen(seed))
             oracle.run_reference(scene_file, out, nthreads=1)  # one thread: overlapping FilmTiles merge in tile order
             img, _ = oracle.render_image(pkg.HostScene(scene_file))
