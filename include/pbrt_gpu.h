@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 15
+#define PG_ABI_VERSION 16
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -328,6 +328,11 @@ typedef struct PgSceneDesc {
     int64_t n_env_floats;
     const float *env_tables;    /* the infinite lights' Distribution2D tables (PgLight.env_table) */
     const float *ewa_lut;       /* MIPMap::weightLut, 128 entries (mipmap.h:178-184); may be NULL without images */
+    /* SobolSampler tables (core/sobolmatrices.h:49-52), NULL unless PgRenderDesc.sampler == 1: SobolMatrices32
+     * [1024 * 52], VdCSobolMatrices [25][52], VdCSobolMatricesInv [26][52] */
+    const uint32_t *sobol_matrices;
+    const uint64_t *vdc_sobol;
+    const uint64_t *vdc_sobol_inv;
 } PgSceneDesc;
 
 /* ---- render description -------------------------------------------------- */
@@ -366,6 +371,9 @@ typedef struct PgRenderDesc {
     int32_t sample_stride;
     int32_t mult_inverse[2];
     int32_t sample_at_pixel_center;
+    /* sampler = 1: SobolSampler (samplers/sobol.h:48-71, sobol.cpp:41-59) instead; spp then is the power of two it rounds up to */
+    int32_t sampler;
+    int32_t sobol_resolution, sobol_log2_resolution;
     /* integrator: PathIntegrator (integrators/path.cpp:190-213) */
     int32_t max_depth;
     float rr_threshold;

@@ -566,6 +566,14 @@ SCENES = {
     "vol_path_none_glass": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 8 ]',
                                    world_edit=lambda s: with_smoke(s).replace("# tall box", 'Material "glass"\n# tall box').replace('Material "matte" "rgb Kd" [ 0.12 0.45 0.15 ]', 'Material "mirror"')),
     "vol_instances": cornell(32, 32, 8, integrator='Integrator "volpath" "integer maxdepth" [ 5 ]', world_edit=lambda s: with_fog(with_instances(s), camera_in_fog=False)),
+    # SobolSampler (samplers/sobol.cpp): power-of-two and rounded-up sample counts, non-square frames, crop windows and wide
+    # filters (sample bounds that start below / above 0), under both integrators
+    "sobol_cornell": cornell(32, 32, 8).replace('Sampler "halton"', 'Sampler "sobol"'),
+    "sobol_round_crop": cornell(40, 24, 6, extra_film='"float cropwindow" [ 0.3 0.9 0.2 0.7 ]').replace('Sampler "halton"', 'Sampler "sobol"'),
+    "filter_sobol_gaussian": cornell(40, 24, 4).replace('PixelFilter "box"', 'PixelFilter "gaussian"').replace('Sampler "halton"', 'Sampler "sobol"'),
+    "sobol_vol_smoke": cornell(32, 32, 4, integrator='Integrator "volpath" "integer maxdepth" [ 6 ]',
+                               world_edit=lambda s: with_fog(with_smoke(s)).replace("# tall box", 'Material "glass"\n# tall box')).replace('Sampler "halton"', 'Sampler "sobol"'),
+    "sobol_tex_lens": cornell(32, 32, 4, world_edit=lambda s: with_image_textures(s)).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 10 ] "float focaldistance" [ 700 ]').replace('Sampler "halton"', 'Sampler "sobol"'),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 

@@ -5,7 +5,7 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 15
+PG_ABI_VERSION = 16
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
 PG_LIGHTS_UNIFORM, PG_LIGHTS_POWER, PG_LIGHTS_SPATIAL = 0, 1, 2
@@ -102,7 +102,8 @@ class PgSceneDesc(C.Structure):
                 ("n_images", C.c_int32), ("images", C.POINTER(PgImage)), ("n_texel_floats", C.c_int64), ("texels", C.POINTER(C.c_float)),
                 ("n_media", C.c_int32), ("media", C.POINTER(PgMedium)), ("tri_medium_inside", C.POINTER(C.c_int32)), ("tri_medium_outside", C.POINTER(C.c_int32)),
                 ("n_alphas", C.c_int32), ("alphas", C.POINTER(PgAlphaMask)), ("tri_alpha", C.POINTER(C.c_int32)),
-                ("n_env_floats", C.c_int64), ("env_tables", C.POINTER(C.c_float)), ("ewa_lut", C.POINTER(C.c_float))]
+                ("n_env_floats", C.c_int64), ("env_tables", C.POINTER(C.c_float)), ("ewa_lut", C.POINTER(C.c_float)),
+                ("sobol_matrices", C.POINTER(C.c_uint32)), ("vdc_sobol", C.POINTER(C.c_uint64)), ("vdc_sobol_inv", C.POINTER(C.c_uint64))]
 
 
 class PgRenderDesc(C.Structure):
@@ -115,6 +116,7 @@ class PgRenderDesc(C.Structure):
                 ("tile_pixels", C.c_int32), ("filter_table", C.c_float * 256), ("film_scale", C.c_float), ("max_sample_luminance", C.c_float),
                 ("spp", C.c_int32), ("base_scales", C.c_int32 * 2), ("base_exponents", C.c_int32 * 2),
                 ("sample_stride", C.c_int32), ("mult_inverse", C.c_int32 * 2), ("sample_at_pixel_center", C.c_int32),
+                ("sampler", C.c_int32), ("sobol_resolution", C.c_int32), ("sobol_log2_resolution", C.c_int32),
                 ("max_depth", C.c_int32), ("rr_threshold", C.c_float), ("pixel_bounds", C.c_int32 * 4),
                 ("tile_first", C.c_int32), ("tile_step", C.c_int32)]
 

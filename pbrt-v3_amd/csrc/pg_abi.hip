@@ -45,7 +45,7 @@ struct DeviceBuffer {
 struct PgScene {
     int device = 0;
     DScene d;
-    DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, textures, textured, images, texels, ewaLut, envTables, alphas, triAlpha, triN, triS, uv, materials, lights, distTable, perms, permSums, primes, media, triMediumIn, triMediumOut;
+    DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, textures, textured, images, texels, ewaLut, envTables, alphas, triAlpha, triN, triS, uv, materials, lights, distTable, perms, permSums, primes, media, triMediumIn, triMediumOut, sobolMatrices, vdcSobol, vdcSobolInv;
     // work buffers (sized on first render, reused)
     int capacity = 0;
     DeviceBuffer qo[4], qd[4], counts, hitsMain, hitInst, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
@@ -462,6 +462,16 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         }
         d.media = (const PgMedium *)s->media.p; d.triMediumIn = (const int *)s->triMediumIn.p; d.triMediumOut = (const int *)s->triMediumOut.p;
     }
+    if (desc->sobol_matrices) {  // SobolSampler tables
+        if (!desc->vdc_sobol || !desc->vdc_sobol_inv) FAIL(PG_ERR_INVALID, "sobol_matrices without vdc_sobol / vdc_sobol_inv");
+        HIP_TRY_S(s->sobolMatrices.alloc(sizeof(uint32_t) * 1024 * 52));
+        HIP_TRY_S(s->vdcSobol.alloc(sizeof(uint64_t) * 25 * 52));
+        HIP_TRY_S(s->vdcSobolInv.alloc(sizeof(uint64_t) * 26 * 52));
+        HIP_TRY_S(hipMemcpy(s->sobolMatrices.p, desc->sobol_matrices, s->sobolMatrices.bytes, hipMemcpyHostToDevice));
+        HIP_TRY_S(hipMemcpy(s->vdcSobol.p, desc->vdc_sobol, s->vdcSobol.bytes, hipMemcpyHostToDevice));
+        HIP_TRY_S(hipMemcpy(s->vdcSobolInv.p, desc->vdc_sobol_inv, s->vdcSobolInv.bytes, hipMemcpyHostToDevice));
+    }
+    d.sobolMatrices = (const uint32_t *)s->sobolMatrices.p; d.vdcSobol = (const uint64_t *)s->vdcSobol.p; d.vdcSobolInv = (const uint64_t *)s->vdcSobolInv.p;
     d.images = (const PgImage *)s->images.p; d.texels = (const float *)s->texels.p; d.ewaLut = (const float *)s->ewaLut.p;
     d.textures = (const PgTexture *)s->textures.p; d.textured = (const PgTexturedMaterial *)s->textured.p;
     d.hasTextured = anyTextured ? 1 : 0;
@@ -629,7 +639,13 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
     if (rd->integrator != 0 && rd->integrator != 1) return setError(PG_ERR_INVALID, "pg_render: integrator %d (0 = path, 1 = volpath)", rd->integrator);
     const bool vol = rd->integrator == 1;
     if (rd->camera_medium < -1 || rd->camera_medium >= s->nMedia) return setError(PG_ERR_INVALID, "pg_render: camera_medium %d out of range", rd->camera_medium);
-    if (5 + 8 * (rd->max_depth + 1) > s->d.nPermDims && s->d.nPermDims < 1000)
+    if (rd->sampler != 0 && rd->sampler != 1) return setError(PG_ERR_INVALID, "pg_render: sampler %d (0 = halton, 1 = sobol)", rd->sampler);
+    if (rd->sampler == 1) {
+        if (!s->d.sobolMatrices) return setError(PG_ERR_INVALID, "pg_render: sampler = sobol, but the scene was created without the Sobol' tables");
+        if (rd->sobol_log2_resolution < 0 || rd->sobol_log2_resolution > 26 || rd->sobol_resolution != (1 << rd->sobol_log2_resolution))
+            return setError(PG_ERR_INVALID, "pg_render: sobol_resolution %d / sobol_log2_resolution %d", rd->sobol_resolution, rd->sobol_log2_resolution);
+    }
+    if (rd->sampler == 0 && 5 + 8 * (rd->max_depth + 1) > s->d.nPermDims && s->d.nPermDims < 1000)
         return setError(PG_ERR_INVALID, "Halton table has %d dimensions; maxdepth %d needs %d", s->d.nPermDims, rd->max_depth, 5 + 8 * (rd->max_depth + 1));
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t stream = (hipStream_t)streamPtr;

@@ -66,6 +66,9 @@ struct DScene {
     const int32_t *permSums;
     const int32_t *primes;
     int nPermDims;
+    // SobolSampler tables (core/sobolmatrices.h:49-52), nullptr unless the scene was created with them
+    const uint32_t *sobolMatrices;
+    const uint64_t *vdcSobol, *vdcSobolInv;
 };
 
 // A queue of rays in SoA float4 pairs: 32 B per ray

@@ -122,7 +122,35 @@ PG_DEV uint64_t halton_index(const PgRenderDesc &rd, int px, int py, uint64_t sa
     return offsetForCurrentPixel + sampleNum * (uint64_t)rd.sample_stride;
 }
 // HaltonSampler::SampleDimension, halton.cpp:119-127
+// SobolSampler (samplers/sobol.cpp:41-59): SobolIntervalToIndex and SobolSampleFloat, lowdiscrepancy.h:229-273
+PG_DEV uint64_t sobol_interval_to_index(const DScene &sc, uint32_t m, uint64_t frame, int px, int py) {
+    if (m == 0) return 0;
+    const uint32_t m2 = m << 1;
+    uint64_t index = frame << m2;
+    uint64_t delta = 0;
+    for (int c = 0; frame; frame >>= 1, ++c)
+        if (frame & 1) delta ^= sc.vdcSobol[(m - 1) * 52 + c];
+    uint64_t b = (((uint64_t)((uint32_t)px) << m) | ((uint32_t)py)) ^ delta;
+    for (int c = 0; b; b >>= 1, ++c)
+        if (b & 1) index ^= sc.vdcSobolInv[(m - 1) * 52 + c];
+    return index;
+}
+PG_DEV float sobol_sample(const DScene &sc, uint64_t a, int dim) {
+    if (dim > 1023) dim = 1023;  // NumSobolDimensions; the reference aborts beyond (sobol.cpp:47-50)
+    uint32_t v = 0;
+    for (int i = dim * 52; a != 0; a >>= 1, i++)
+        if (a & 1) v ^= sc.sobolMatrices[i];
+    return pmin(v * 0x1p-32f, PG_ONE_MINUS_EPS);
+}
+// GlobalSampler::GetIndexForSample of the configured sampler (halton.cpp:96-117, sobol.cpp:41-44)
+PG_DEV uint64_t sampler_index(const DScene &sc, const PgRenderDesc &rd, int px, int py, uint64_t sampleNum) {
+    if (rd.sampler == 1) return sobol_interval_to_index(sc, (uint32_t)rd.sobol_log2_resolution, sampleNum, px - rd.sample_bounds[0], py - rd.sample_bounds[1]);
+    return halton_index(rd, px, py, sampleNum);
+}
+// SampleDimension of the configured sampler for any dimension >= 2 (dimensions 0 and 1, the film position, are drawn by
+// k_generate alone: SobolSampler remaps them with the current pixel, sobol.cpp:53-56)
 PG_DEV float halton_sample(const DScene &sc, const PgRenderDesc &rd, uint64_t index, int dim) {
+    if (rd.sampler == 1) return sobol_sample(sc, index, dim);
     if (rd.sample_at_pixel_center && (dim == 0 || dim == 1)) return 0.5f;
     if (dim == 0) return radical_inverse_base2(index >> rd.base_exponents[0]);
     if (dim == 1) return radical_inverse(3, index / (uint64_t)rd.base_scales[1]);
@@ -286,9 +314,17 @@ __global__ __launch_bounds__(PG_BLOCK) void k_generate(DScene sc, RenderParams r
     float tMax = PG_INF;
     if (valid) {
         const PgRenderDesc &rd = rp.rd;
-        uint64_t index = halton_index(rd, px, py, (uint64_t)sn);
+        uint64_t index = sampler_index(sc, rd, px, py, (uint64_t)sn);
         // GetCameraSample, sampler.cpp:46-52: dims 0,1 film; 2 time; 3,4 lens
         float u0 = halton_sample(sc, rd, index, 0), u1 = halton_sample(sc, rd, index, 1);
+        if (rd.sampler == 1) {  // SobolSampler::SampleDimension, sobol.cpp:53-56
+            u0 = u0 * rd.sobol_resolution + rd.sample_bounds[0];
+            u0 = u0 - px;
+            u0 = u0 < 0.f ? 0.f : (u0 > PG_ONE_MINUS_EPS ? PG_ONE_MINUS_EPS : u0);
+            u1 = u1 * rd.sobol_resolution + rd.sample_bounds[1];
+            u1 = u1 - py;
+            u1 = u1 < 0.f ? 0.f : (u1 > PG_ONE_MINUS_EPS ? PG_ONE_MINUS_EPS : u1);
+        }
         float pFilmX = (float)px + u0, pFilmY = (float)py + u1;
         float l0 = 0, l1 = 0;
         if (rd.lens_radius > 0) { l0 = halton_sample(sc, rd, index, 3); l1 = halton_sample(sc, rd, index, 4); }

@@ -1123,11 +1123,13 @@ static GpuPathIntegrator *MakeIntegrator() {
     std::shared_ptr<PerspectiveCamera> camera(CreatePerspectiveCamera(ro.CameraParams, ro.CameraToWorld[0], film, ro.CameraName == "orthographic"));
     if (ro.CameraName == "environment") { camera->environment = true; camera->lensRadius = 0; }  // environment.cpp:96-97: lens parameters unused
     ro.CameraParams.ReportUnused();
-    if (ro.SamplerName != "halton")
-        Error("Sampler \"%s\" is outside this build's closed set (halton); using halton with the same \"pixelsamples\".", ro.SamplerName.c_str());
+    // the GlobalSamplers (halton, sobol) index every sample by (pixel, sample number) alone; the PixelSamplers (random,
+    // stratified, 02sequence, maxmindist) draw from one RNG stream per tile, which serialises a tile's samples
+    if (ro.SamplerName != "halton" && ro.SamplerName != "sobol")
+        Error("Sampler \"%s\" is outside this build's closed set (halton, sobol); using halton with the same \"pixelsamples\".", ro.SamplerName.c_str());
     int sb[4];
     film->GetSampleBounds(sb);
-    std::shared_ptr<HaltonSampler> sampler(CreateHaltonSampler(ro.SamplerParams, sb));
+    std::shared_ptr<HaltonSampler> sampler(ro.SamplerName == "sobol" ? CreateSobolSampler(ro.SamplerParams, sb) : CreateHaltonSampler(ro.SamplerParams, sb));
     ro.SamplerParams.ReportUnused();
     if (ro.IntegratorName != "path" && ro.IntegratorName != "volpath") {
         Error("Integrator \"%s\" is outside this build's closed set (path, volpath).", ro.IntegratorName.c_str());

@@ -94,6 +94,22 @@ HaltonSampler *CreateHaltonSampler(const ParamSet &params, const int sb[4]) {
     return s;
 }
 
+HaltonSampler *CreateSobolSampler(const ParamSet &params, const int sb[4]) {  // sobol.cpp:64-69, SobolSampler ctor sobol.h:52-63
+    int nsamp = params.FindOneInt("pixelsamples", 16);
+    if (PbrtOptions.quickRender) nsamp = 1;
+    auto roundUpPow2 = [](int64_t v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; v |= v >> 32; return v + 1; };  // pbrt.h:369-388
+    HaltonSampler *s = new HaltonSampler;
+    memset(s->baseScales, 0, sizeof(s->baseScales)); memset(s->baseExponents, 0, sizeof(s->baseExponents)); memset(s->multInverse, 0, sizeof(s->multInverse));
+    s->sampleStride = 0; s->sampleAtPixelCenter = false;
+    s->sobol = true;
+    s->samplesPerPixel = (int)roundUpPow2(nsamp);
+    if (s->samplesPerPixel != nsamp) Warning("Non power-of-two sample count rounded up to %d for SobolSampler.", s->samplesPerPixel);
+    s->resolution = (int)roundUpPow2((int32_t)std::max(sb[2] - sb[0], sb[3] - sb[1]));  // RoundUpPow2(int32_t)
+    s->log2Resolution = 0;
+    while ((1 << (s->log2Resolution + 1)) <= s->resolution) ++s->log2Resolution;  // Log2Int, pbrt.h:333-343
+    return s;
+}
+
 namespace {
 struct RNG {  // PCG32, rng.h:61-144
     uint64_t state = 0x853c49e6748fea9bULL, inc = 0xda3e39cb94b95bdbULL;
@@ -336,6 +352,7 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     d.ewa_lut = flat->ewaLut;
     d.n_env_floats = (int64_t)flat->envTables.size(); d.env_tables = flat->envTables.data();
     d.n_media = (int)flat->media.size(); d.media = flat->media.data();
+    if (sampler->sobol) { const SobolTables &t = GetSobolTables(); d.sobol_matrices = t.matrices32; d.vdc_sobol = t.vdc; d.vdc_sobol_inv = t.vdcInv; }
     d.tri_medium_inside = flat->triMediumInside.empty() ? nullptr : flat->triMediumInside.data();
     d.tri_medium_outside = flat->triMediumOutside.empty() ? nullptr : flat->triMediumOutside.data();
     d.n_alphas = (int)flat->alphas.size(); d.alphas = flat->alphas.data();
@@ -379,6 +396,8 @@ void GpuPathIntegrator::FillRenderDesc(PgRenderDesc *rd) const {
     }
     rd->sample_stride = sampler->sampleStride;
     rd->sample_at_pixel_center = sampler->sampleAtPixelCenter ? 1 : 0;
+    rd->sampler = sampler->sobol ? 1 : 0;
+    rd->sobol_resolution = sampler->resolution; rd->sobol_log2_resolution = sampler->log2Resolution;
     rd->max_depth = maxDepth; rd->rr_threshold = rrThreshold;
     for (int i = 0; i < 4; ++i) rd->pixel_bounds[i] = pixelBounds[i];
     rd->tile_first = 0; rd->tile_step = 1;

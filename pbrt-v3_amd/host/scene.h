@@ -163,7 +163,14 @@ struct HaltonSampler {  // samplers/halton.cpp:65-92
     int sampleStride;
     int multInverse[2];
     bool sampleAtPixelCenter;
+    // SobolSampler (samplers/sobol.h:48-71) when sobol is set: the fields above other than samplesPerPixel are unused then
+    bool sobol = false;
+    int resolution = 0, log2Resolution = 0;
 };
+HaltonSampler *CreateSobolSampler(const ParamSet &params, const int sampleBounds[4]);  // sobol.cpp:64-69
+// The Sobol' generator matrices embedded into this library (host/sobol.cpp, data/sobol_tables.bin; core/sobolmatrices.h:49-52)
+struct SobolTables { const uint32_t *matrices32; const uint64_t *vdc, *vdcInv; int nDims, matrixSize, vdcRows, vdcInvRows; };
+const SobolTables &GetSobolTables();
 HaltonSampler *CreateHaltonSampler(const ParamSet &params, const int sampleBounds[4]);  // halton.cpp:133-139
 // lowdiscrepancy.cpp:2490-2504 with the default-seeded RNG (halton.cpp:69-72).
 void ComputeRadicalInversePermutations(int nDims, std::vector<uint16_t> *perms, std::vector<int32_t> *sums);

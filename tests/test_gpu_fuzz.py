@@ -156,6 +156,7 @@ def random_scene_vol(seed, res=16, spp=4):
              'MakeNamedMedium "m3" "string type" "homogeneous" "float g" [ %.4g ] "float scale" [ 0.1 ]' % (-0.9 * rng.random())]
     cam = 'MediumInterface "" "m0"\n' if seed % 2 == 0 else ""
     text = text.replace("Camera ", "\n".join(media) + "\n" + cam + "Camera ", 1)
+    if seed % 4 == 1: text = text.replace('Sampler "halton"', 'Sampler "sobol"', 1)
     text = text.replace('Integrator "path"', 'Integrator "volpath"' + (' "float rrthreshold" [ 0.6 ]' if seed % 3 == 0 else ""), 1)
     extra = ['AttributeBegin\n MediumInterface "m1" "%s"\n Material "none"\n Translate %s\n Shape "sphere" "float radius" [ %.4g ]\nAttributeEnd'
              % ("m0" if seed % 2 == 0 else "", f(rng.normal(size=3)), 0.5 + rng.random()),
