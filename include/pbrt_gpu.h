@@ -423,6 +423,14 @@ const char *pg_last_error(void);
 int pg_scene_create(const PgSceneDesc *desc, PgScene **out);
 void pg_scene_destroy(PgScene *scene);
 
+/* HLBVH construction on the device: BVHAccel::HLBVHBuild (bvh.cpp:404-483: Morton codes of the centroids :415-429, radix
+ * sort :432 / :140-180, treelets of equal top-12 Morton bits :437-456 built by emitLBVH :485-535, buildUpperSAH over the
+ * treelet roots :537-638) followed by flattenBVHTree (:640-658).  bounds: n x {pMin.xyz, pMax.xyz} world bounds of the
+ * primitives (host memory).  Outputs (host memory): nodes[] with room for 2n entries, *n_nodes, and ordered_prims[k] =
+ * index of the primitive at position k of the leaf order.  The result is the reference's single-thread build bit for bit
+ * (with several threads the reference permutes whole leaf ranges, never the tree).                                  */
+int pg_hlbvh_build(int32_t n, const float *bounds, int32_t max_prims_in_node, PgBVHNode *nodes, int32_t *n_nodes, int32_t *ordered_prims);
+
 /* Number of 16x16 tiles this (tile_first, tile_step) shard owns; pg_render
  * writes desc->tile_pixels PgFilmPixel entries per tile.                     */
 int pg_render_tile_count(const PgRenderDesc *desc);

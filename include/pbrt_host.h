@@ -36,6 +36,12 @@ void pbrt_host_film_merge(PbrtHostScene *s, const PgRenderDesc *rd, const PgFilm
 void pbrt_host_film_image(PbrtHostScene *s, float *rgb);
 int pbrt_host_write_pfm(const char *filename, const float *rgb, int width, int height);
 
+/* The host's own HLBVH build over bare bounds (n x {pMin, pMax}); nodes has room for 2n entries.  Same contract as
+ * pg_hlbvh_build (pbrt_gpu.h), which must reproduce it bit for bit. */
+void pbrt_host_hlbvh_build(int n, const float *bounds, int max_prims_in_node, PgBVHNode *nodes, int *n_nodes, int *ordered_prims);
+/* Build "hlbvh" accelerators of subsequently loaded scenes on the device (the CLI's --devicebvh). */
+void pbrt_host_set_device_bvh(int on);
+
 /* Number of distinct Error() messages reported so far in this process. */
 int pbrt_host_error_count(void);
 

@@ -125,6 +125,31 @@ class HostScene:
         return np.ctypeslib.as_array(self.desc.P, (self.desc.n_verts, 3))
 
 
+NODE_DTYPE = np.dtype([("bmin", np.float32, 3), ("bmax", np.float32, 3), ("offset", np.int32), ("nprims", np.uint16),
+                       ("axis", np.uint8), ("pad", np.uint8)])
+
+
+def hlbvh_build(bounds, max_prims_in_node=4, device=True):
+    """BVHAccel::HLBVHBuild + flattenBVHTree over bare primitive bounds (n x 6 float32: pMin, pMax): on the device through
+    pg_hlbvh_build, or with the host front end's builder (device=False).  Returns (nodes, ordered primitive indices)."""
+    bounds = np.ascontiguousarray(bounds, np.float32).reshape(-1, 6)
+    n = len(bounds)
+    nodes = np.zeros(max(1, 2 * n), NODE_DTYPE)
+    order = np.zeros(max(1, n), np.int32)
+    if device:
+        nn = C.c_int32(0)
+        _check(gpu_lib().pg_hlbvh_build(n, bounds.ctypes.data, max_prims_in_node, nodes.ctypes.data, C.byref(nn), order.ctypes.data), "pg_hlbvh_build")
+    else:
+        nn = C.c_int(0)
+        host_lib().pbrt_host_hlbvh_build(n, bounds.ctypes.data, max_prims_in_node, nodes.ctypes.data, C.byref(nn), order.ctypes.data)
+    return nodes[:nn.value], order[:n]
+
+
+def set_device_bvh(on):
+    """Scenes loaded afterwards build their "hlbvh" accelerators on the device (pbrt_amd --devicebvh)."""
+    host_lib().pbrt_host_set_device_bvh(1 if on else 0)
+
+
 def write_pfm(filename, img):
     img = np.ascontiguousarray(img, np.float32)
     h, w, _ = img.shape

@@ -158,6 +158,7 @@ GPU_SYMBOLS = {
                                  C.c_void_p]),
     "pg_counters": (C.c_int, [C.c_void_p, C.POINTER(PgCounters)]),
     "pg_counters_reset": (C.c_int, [C.c_void_p]),
+    "pg_hlbvh_build": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
 }
 
 HOST_SYMBOLS = {
@@ -172,6 +173,8 @@ HOST_SYMBOLS = {
     "pbrt_host_film_image": (None, [C.c_void_p, C.c_void_p]),
     "pbrt_host_write_pfm": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int]),
     "pbrt_host_error_count": (C.c_int, []),
+    "pbrt_host_hlbvh_build": (None, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
+    "pbrt_host_set_device_bvh": (None, [C.c_int]),
 }
 
 

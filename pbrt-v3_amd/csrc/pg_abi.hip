@@ -23,6 +23,8 @@ static int setError(int code, const char *fmt, ...) {
     g_lastError = buf;
     return code;
 }
+// for the other translation units of this library (pg_hlbvh.hip)
+int pgSetError(int code, const char *msg) { g_lastError = msg; return code; }
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t e_ = (expr);                                                                         \

@@ -152,4 +152,5 @@ void launch_film(const RenderParams &rp, PathState st, PgFilmPixel *film, PgStra
                  hipStream_t s);
 void launch_film_general(const RenderParams &rp, PathState st, PgFilmPixel *film, hipStream_t s);
 void launch_light_tables(const DScene &sc, float *table, int nDistributions, hipStream_t s);
+int pgSetError(int code, const char *msg);  // pg_abi.hip: sets pg_last_error()
 #endif

@@ -19,6 +19,7 @@ struct Options {  // src/core/pbrt.h:171-185
     // additions for the MI355X back end
     bool loadOnly = false;  // WorldEnd keeps the Scene/Integrator instead of rendering
     int device = 0;         // HIP device the integrator renders on
+    bool deviceBVH = false; // build "hlbvh" accelerators on the device (pg_hlbvh_build) instead of on the host
 };
 extern Options PbrtOptions;
 

@@ -5,6 +5,7 @@
 // calls, so the node array and leaf contents match the reference's tree.
 #include "scene.h"
 #include "error.h"
+#include "api.h"
 
 namespace pbrt {
 
@@ -108,15 +109,50 @@ BVHAccel::BVHAccel(std::vector<GeometricPrimitive> p, int maxPrims, SplitMethod 
     for (size_t i = 0; i < primitives.size(); ++i) primitiveInfo[i] = {i, primitives[i].WorldBound()};
     int totalNodes = 0;
     std::vector<GeometricPrimitive> orderedPrims;
+    if (splitMethod == SplitMethod::HLBVH) {  // bvh.cpp:207-212
+        std::vector<int> order;
+        if (PbrtOptions.deviceBVH) {
+            std::vector<float> b(6 * primitives.size());
+            for (size_t i = 0; i < primitives.size(); ++i)
+                for (int k = 0; k < 3; ++k) { b[6 * i + k] = primitiveInfo[i].bounds.pMin[k]; b[6 * i + 3 + k] = primitiveInfo[i].bounds.pMax[k]; }
+            if (!DeviceHLBVHBuild((int)primitives.size(), b.data(), maxPrimsInNode, &nodes, &order)) { Error("HLBVH: the device build failed (there is no silent host fallback)."); exit(1); }
+        } else {
+            BuildNode *root = HLBVHBuild(primitiveInfo, &totalNodes, order);
+            nodes.resize(totalNodes);
+            int offset = 0;
+            flattenBVHTree(root, &offset);
+        }
+        orderedPrims.resize(primitives.size());
+        for (size_t i = 0; i < primitives.size(); ++i) orderedPrims[i] = primitives[order[i]];
+        primitives.swap(orderedPrims);
+        arena.clear();
+        return;
+    }
     orderedPrims.reserve(primitives.size());
-    BuildNode *root;
-    if (splitMethod == SplitMethod::HLBVH) root = HLBVHBuild(primitiveInfo, &totalNodes, orderedPrims);  // bvh.cpp:207-212
-    else root = recursiveBuild(primitiveInfo, 0, (int)primitives.size(), &totalNodes, orderedPrims);
+    BuildNode *root = recursiveBuild(primitiveInfo, 0, (int)primitives.size(), &totalNodes, orderedPrims);
     primitives.swap(orderedPrims);
     nodes.resize(totalNodes);
     int offset = 0;
     flattenBVHTree(root, &offset);
     arena.clear();
+}
+BVHAccel::BVHAccel(int maxPrims, SplitMethod sm) : maxPrimsInNode(std::min(255, maxPrims)), splitMethod(sm) {}
+void BVHAccel::HLBVHFromBounds(int n, const float *bounds, int maxPrimsInNode, std::vector<PgBVHNode> *nodes, std::vector<int> *order) {
+    nodes->clear(); order->clear();
+    if (n <= 0) return;
+    BVHAccel a(maxPrimsInNode, SplitMethod::HLBVH);
+    std::vector<PrimInfo> primitiveInfo((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        Bounds3f b;
+        b.pMin = Point3f(bounds[6 * i], bounds[6 * i + 1], bounds[6 * i + 2]); b.pMax = Point3f(bounds[6 * i + 3], bounds[6 * i + 4], bounds[6 * i + 5]);
+        primitiveInfo[i] = {(size_t)i, b};
+    }
+    int totalNodes = 0;
+    BuildNode *root = a.HLBVHBuild(primitiveInfo, &totalNodes, *order);
+    a.nodes.resize(totalNodes);
+    int offset = 0;
+    a.flattenBVHTree(root, &offset);
+    nodes->swap(a.nodes);
 }
 
 Bounds3f BVHAccel::WorldBound() const {  // bvh.cpp:228-230
@@ -241,7 +277,7 @@ static uint32_t LeftShift3(uint32_t x) {  // bvh.cpp:107-131: spread the low 10 
     x = (x | (x << 2)) & 0x9249249;
     return x;
 }
-BVHAccel::BuildNode *BVHAccel::HLBVHBuild(const std::vector<PrimInfo> &primitiveInfo, int *totalNodes, std::vector<GeometricPrimitive> &orderedPrims) {
+BVHAccel::BuildNode *BVHAccel::HLBVHBuild(const std::vector<PrimInfo> &primitiveInfo, int *totalNodes, std::vector<int> &order) {
     Bounds3f bounds;
     for (const PrimInfo &pi : primitiveInfo) bounds = Union(bounds, pi.centroid);
     std::vector<MortonPrim> mortonPrims(primitiveInfo.size());
@@ -263,15 +299,15 @@ BVHAccel::BuildNode *BVHAccel::HLBVHBuild(const std::vector<PrimInfo> &primitive
             start = end;
         }
     int orderedPrimsOffset = 0;
-    orderedPrims.resize(primitives.size());
+    order.resize(primitiveInfo.size());
     for (Treelet &tr : treelets)
-        tr.root = emitLBVH(primitiveInfo, &mortonPrims[tr.startIndex], tr.nPrimitives, totalNodes, orderedPrims, &orderedPrimsOffset, 29 - 12);
+        tr.root = emitLBVH(primitiveInfo, &mortonPrims[tr.startIndex], tr.nPrimitives, totalNodes, order, &orderedPrimsOffset, 29 - 12);
     std::vector<BuildNode *> finishedTreelets;
     for (Treelet &tr : treelets) finishedTreelets.push_back(tr.root);
     return buildUpperSAH(finishedTreelets, 0, (int)finishedTreelets.size(), totalNodes);
 }
 BVHAccel::BuildNode *BVHAccel::emitLBVH(const std::vector<PrimInfo> &primitiveInfo, const MortonPrim *mortonPrims, int nPrimitives, int *totalNodes,
-                                        std::vector<GeometricPrimitive> &orderedPrims, int *orderedPrimsOffset, int bitIndex) {
+                                        std::vector<int> &order, int *orderedPrimsOffset, int bitIndex) {
     if (bitIndex == -1 || nPrimitives < maxPrimsInNode) {  // a leaf (note: strictly fewer than maxPrimsInNode)
         (*totalNodes)++;
         BuildNode *node = allocNode();
@@ -280,7 +316,7 @@ BVHAccel::BuildNode *BVHAccel::emitLBVH(const std::vector<PrimInfo> &primitiveIn
         *orderedPrimsOffset += nPrimitives;
         for (int i = 0; i < nPrimitives; ++i) {
             int primitiveIndex = mortonPrims[i].primitiveIndex;
-            orderedPrims[firstPrimOffset + i] = primitives[primitiveIndex];
+            order[firstPrimOffset + i] = primitiveIndex;
             bounds = Union(bounds, primitiveInfo[primitiveIndex].bounds);
         }
         node->InitLeaf(firstPrimOffset, nPrimitives, bounds);
@@ -288,7 +324,7 @@ BVHAccel::BuildNode *BVHAccel::emitLBVH(const std::vector<PrimInfo> &primitiveIn
     }
     const uint32_t mask = 1u << bitIndex;
     if ((mortonPrims[0].mortonCode & mask) == (mortonPrims[nPrimitives - 1].mortonCode & mask))  // no split on this bit
-        return emitLBVH(primitiveInfo, mortonPrims, nPrimitives, totalNodes, orderedPrims, orderedPrimsOffset, bitIndex - 1);
+        return emitLBVH(primitiveInfo, mortonPrims, nPrimitives, totalNodes, order, orderedPrimsOffset, bitIndex - 1);
     int searchStart = 0, searchEnd = nPrimitives - 1;  // first primitive whose bit differs from the run's first
     while (searchStart + 1 != searchEnd) {
         int mid = (searchStart + searchEnd) / 2;
@@ -298,8 +334,8 @@ BVHAccel::BuildNode *BVHAccel::emitLBVH(const std::vector<PrimInfo> &primitiveIn
     const int splitOffset = searchEnd;
     (*totalNodes)++;
     BuildNode *node = allocNode();
-    BuildNode *c0 = emitLBVH(primitiveInfo, mortonPrims, splitOffset, totalNodes, orderedPrims, orderedPrimsOffset, bitIndex - 1);
-    BuildNode *c1 = emitLBVH(primitiveInfo, &mortonPrims[splitOffset], nPrimitives - splitOffset, totalNodes, orderedPrims, orderedPrimsOffset, bitIndex - 1);
+    BuildNode *c0 = emitLBVH(primitiveInfo, mortonPrims, splitOffset, totalNodes, order, orderedPrimsOffset, bitIndex - 1);
+    BuildNode *c1 = emitLBVH(primitiveInfo, &mortonPrims[splitOffset], nPrimitives - splitOffset, totalNodes, order, orderedPrimsOffset, bitIndex - 1);
     node->InitInterior(bitIndex % 3, c0, c1);
     return node;
 }

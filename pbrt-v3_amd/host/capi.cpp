@@ -17,8 +17,10 @@ static PbrtHostScene *finishLoad() {
     s->loaded->integrator->Flatten(*s->loaded->scene, &s->flat);
     return s;
 }
+static bool g_deviceBVH = false;
 static Options makeOptions(int quick, const float *crop) {
     Options opt;
+    opt.deviceBVH = g_deviceBVH;
     opt.quickRender = quick != 0;
     opt.loadOnly = true;
     if (crop) { opt.cropWindow[0][0] = crop[0]; opt.cropWindow[0][1] = crop[1]; opt.cropWindow[1][0] = crop[2]; opt.cropWindow[1][1] = crop[3]; }
@@ -59,5 +61,14 @@ void pbrt_host_film_image(PbrtHostScene *s, float *rgb) {
 int pbrt_host_write_pfm(const char *filename, const float *rgb, int width, int height) {
     return WriteImagePFM(filename, rgb, width, height) ? 0 : -1;
 }
+void pbrt_host_hlbvh_build(int n, const float *bounds, int max_prims_in_node, PgBVHNode *nodes, int *n_nodes, int *ordered_prims) {
+    std::vector<PgBVHNode> nv;
+    std::vector<int> order;
+    BVHAccel::HLBVHFromBounds(n, bounds, max_prims_in_node, &nv, &order);
+    for (size_t i = 0; i < nv.size(); ++i) nodes[i] = nv[i];
+    for (size_t i = 0; i < order.size(); ++i) ordered_prims[i] = order[i];
+    *n_nodes = (int)nv.size();
+}
+void pbrt_host_set_device_bvh(int on) { g_deviceBVH = on != 0; }
 int pbrt_host_error_count(void) { return ErrorCount(); }
 }

@@ -415,6 +415,7 @@ struct GpuApi {
     decltype(&pg_render_tile_count) render_tile_count = nullptr;
     decltype(&pg_render) render = nullptr;
     decltype(&pg_counters) counters = nullptr;
+    decltype(&pg_hlbvh_build) hlbvh_build = nullptr;
     bool Load() {
         if (lib) return true;
         std::string path;
@@ -427,13 +428,24 @@ struct GpuApi {
         lib = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (!lib) { Error("Unable to load the HIP back end \"%s\": %s", path.c_str(), dlerror()); return false; }
 #define BIND(n) n = (decltype(n))dlsym(lib, "pg_" #n); if (!n) { Error("libpbrt_gpu.so lacks symbol pg_" #n); return false; }
-        BIND(set_device) BIND(last_error) BIND(scene_create) BIND(scene_destroy) BIND(render_tile_count) BIND(render) BIND(counters)
+        BIND(set_device) BIND(last_error) BIND(scene_create) BIND(scene_destroy) BIND(render_tile_count) BIND(render) BIND(counters) BIND(hlbvh_build)
 #undef BIND
         return true;
     }
 };
 GpuApi gpuApi;
 }  // namespace
+
+bool DeviceHLBVHBuild(int n, const float *bounds, int maxPrimsInNode, std::vector<PgBVHNode> *nodes, std::vector<int> *order) {
+    if (!gpuApi.Load()) return false;
+    if (gpuApi.set_device(PbrtOptions.device) != PG_OK) { Error("pg_set_device: %s", gpuApi.last_error()); return false; }
+    nodes->resize(2 * (size_t)n);
+    order->resize((size_t)n);
+    int nNodes = 0;
+    if (gpuApi.hlbvh_build(n, bounds, maxPrimsInNode, nodes->data(), &nNodes, order->data()) != PG_OK) { Error("pg_hlbvh_build: %s", gpuApi.last_error()); return false; }
+    nodes->resize((size_t)nNodes);
+    return true;
+}
 
 void GpuPathIntegrator::Render(const Scene &scene) {
     if (!gpuApi.Load()) { Error("Rendering aborted: no HIP back end (there is no CPU fallback)."); exit(1); }

@@ -14,6 +14,7 @@ static void usage(const char *msg = nullptr) {
     fprintf(stderr, R"(usage: pbrt_amd [<options>] <filename.pbrt...>
 Rendering options:
   --cropwindow <x0,x1,y0,y1> Specify an image crop window.
+  --devicebvh                Build "hlbvh" accelerators on the GPU instead of on the host.
   --gpu <id>                 HIP device to render on (default 0).
   --help                     Print this help text.
   --nthreads <num>           Accepted for compatibility; host work is single-threaded.
@@ -37,6 +38,7 @@ int main(int argc, char *argv[]) {
             options.cropWindow[1][0] = atof(argv[++i]); options.cropWindow[1][1] = atof(argv[++i]);
         }
         else if (!strcmp(argv[i], "--gpu")) { if (i + 1 == argc) usage("missing value after --gpu argument"); options.device = atoi(argv[++i]); }
+        else if (!strcmp(argv[i], "--devicebvh")) options.deviceBVH = true;
         else if (!strcmp(argv[i], "--quick") || !strcmp(argv[i], "-quick")) options.quickRender = true;
         else if (!strcmp(argv[i], "--quiet") || !strcmp(argv[i], "-quiet")) options.quiet = true;
         else if (!strcmp(argv[i], "--help") || !strcmp(argv[i], "-help") || !strcmp(argv[i], "-h")) usage();

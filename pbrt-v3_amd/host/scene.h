@@ -83,9 +83,15 @@ class BVHAccel {
                               std::vector<GeometricPrimitive> &orderedPrims);
     int flattenBVHTree(BuildNode *node, int *offset);
     struct MortonPrim;
-    BuildNode *HLBVHBuild(const std::vector<PrimInfo> &primitiveInfo, int *totalNodes, std::vector<GeometricPrimitive> &orderedPrims);
+    // the HLBVH build works on primitive numbers: order[k] = number of the k-th primitive of the leaf order
+    BuildNode *HLBVHBuild(const std::vector<PrimInfo> &primitiveInfo, int *totalNodes, std::vector<int> &order);
     BuildNode *emitLBVH(const std::vector<PrimInfo> &primitiveInfo, const MortonPrim *mortonPrims, int nPrimitives, int *totalNodes,
-                        std::vector<GeometricPrimitive> &orderedPrims, int *orderedPrimsOffset, int bitIndex);
+                        std::vector<int> &order, int *orderedPrimsOffset, int bitIndex);
+    BVHAccel(int maxPrimsInNode, SplitMethod splitMethod);  // no primitives: HLBVHFromBounds
+  public:
+    // HLBVHBuild + flattenBVHTree over bare bounds (n x {pMin, pMax}): what pg_hlbvh_build computes on the device
+    static void HLBVHFromBounds(int n, const float *bounds, int maxPrimsInNode, std::vector<PgBVHNode> *nodes, std::vector<int> *order);
+  private:
     BuildNode *buildUpperSAH(std::vector<BuildNode *> &treeletRoots, int start, int end, int *totalNodes);
     const int maxPrimsInNode;
     const SplitMethod splitMethod;
@@ -94,6 +100,9 @@ class BVHAccel {
     BuildNode *allocNode();
 };
 std::shared_ptr<BVHAccel> CreateBVHAccelerator(std::vector<GeometricPrimitive> prims, const ParamSet &ps);  // bvh.cpp:740-760
+// With PbrtOptions.deviceBVH, "hlbvh" accelerators are built by the HIP back end (pg_hlbvh_build, include/pbrt_gpu.h):
+// same nodes and primitive order as HLBVHBuild here.  Returns false (after Error) when the back end is missing or fails.
+bool DeviceHLBVHBuild(int n, const float *bounds, int maxPrimsInNode, std::vector<PgBVHNode> *nodes, std::vector<int> *order);
 
 struct Scene {  // core/scene.h:50-80
     std::shared_ptr<BVHAccel> aggregate;
