@@ -52,6 +52,10 @@ def lib(cr_libm=False):
         L.oracle_scrambled_radical_inverse.argtypes = [C.c_int, C.c_uint64, C.c_void_p]
         L.oracle_halton_index.restype = C.c_int64
         L.oracle_halton_index.argtypes = [C.POINTER(abi.PgRenderDesc), C.c_int, C.c_int, C.c_int64]
+        L.oracle_sobol_sample.restype = C.c_float
+        L.oracle_sobol_sample.argtypes = [C.POINTER(abi.PgSceneDesc), C.c_int64, C.c_int]
+        L.oracle_sampler_dimension.restype = C.c_float
+        L.oracle_sampler_dimension.argtypes = [C.POINTER(abi.PgSceneDesc), C.POINTER(abi.PgRenderDesc), C.c_int, C.c_int, C.c_int64, C.c_int]
         L.oracle_halton_sample.restype = C.c_float
         L.oracle_halton_sample.argtypes = [C.POINTER(abi.PgSceneDesc), C.POINTER(abi.PgRenderDesc), C.c_int64, C.c_int]
         L.oracle_triangle_intersect.restype = C.c_int

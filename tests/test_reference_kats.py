@@ -9,6 +9,7 @@ the CPU oracle (and, under -m gpu, against the HIP kernels in test_gpu_parity.py
 import ctypes as C
 
 import numpy as np
+import pytest
 
 from kat_util import PCG32, jittered_sphere, uniform_sample_sphere
 
@@ -132,3 +133,41 @@ def test_radical_inverse_unscrambled_matches_identity_permutation(oracle):
         ident = np.arange(base, dtype=np.uint16)
         for a in (0, 1, 7, 1000, 123456, 2 ** 31 + 5, 2 ** 40 + 12345):
             assert lib.oracle_radical_inverse(dim, a) == lib.oracle_scrambled_radical_inverse(dim, a, ident.ctypes.data)
+
+
+SOBOL_SCENE = """LookAt 0 0 5  0 0 0  0 1 0
+Camera "perspective"
+Film "image" "integer xresolution" [ 10 ] "integer yresolution" [ 10 ] "string filename" "s.pfm"
+Sampler "sobol" "integer pixelsamples" [ %d ]
+PixelFilter "box"
+Integrator "path"
+WorldBegin
+Shape "trianglemesh" "integer indices" [ 0 1 2 ] "point P" [ -1 -1 0  1 -1 0  0 1 0 ]
+WorldEnd
+"""
+
+
+def test_sobol_first_dimension_is_bit_reversal(pkg, oracle):
+    """LowDiscrepancy.Sobol, tests/sampling.cpp:127-131: dimension 0 of SobolSampleFloat is the base-2 radical inverse."""
+    scene = pkg.HostScene(text=SOBOL_SCENE % 4)
+    lib = oracle.lib()
+    for i in range(8192):
+        rev = int(f"{i:032b}"[::-1], 2)
+        assert lib.oracle_sobol_sample(scene.desc, i, 0) == np.float32(np.float32(rev) * np.float32(2.3283064365386963e-10))
+
+
+@pytest.mark.parametrize("log_samples", range(2, 11))
+def test_sobol_elementary_intervals(pkg, oracle, log_samples):
+    """LowDiscrepancy.ElementaryIntervals for the SobolSampler, tests/sampling.cpp:136-188: SobolSampler(2^k, Bounds2i((0,0),
+    (10,10))), pixel (0, 0): the 2^k samples' first Get2D() puts exactly one sample into every elementary interval of every
+    shape (2^i x 2^(k-i)).  Exercises CreateSobolSampler (resolution 16), SobolIntervalToIndex and the pixel remapping."""
+    scene = pkg.HostScene(text=SOBOL_SCENE % (1 << log_samples))
+    rd = scene.render_desc()
+    assert rd.sampler == 1 and rd.spp == 1 << log_samples and rd.sobol_resolution == 16 and rd.sobol_log2_resolution == 4
+    lib = oracle.lib()
+    pts = np.array([[lib.oracle_sampler_dimension(scene.desc, rd, 0, 0, k, d) for d in (0, 1)] for k in range(rd.spp)], np.float32)
+    assert (pts >= 0).all() and (pts < 1).all()
+    for i in range(log_samples + 1):
+        nx, ny = 1 << i, 1 << (log_samples - i)
+        idx = np.floor(np.float32(ny) * pts[:, 1]).astype(int) * nx + np.floor(np.float32(nx) * pts[:, 0]).astype(int)
+        assert len(set(idx.tolist())) == rd.spp
