@@ -565,6 +565,9 @@ SCENES = {
     "vol_path_none": cornell(24, 24, 8, world_edit=lambda s: with_smoke(s)),
     "vol_path_none_glass": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 8 ]',
                                    world_edit=lambda s: with_smoke(s).replace("# tall box", 'Material "glass"\n# tall box').replace('Material "matte" "rgb Kd" [ 0.12 0.45 0.15 ]', 'Material "mirror"')),
+    "vol_presets": cornell(32, 32, 8, integrator='Integrator "volpath" "integer maxdepth" [ 6 ]', world_edit=lambda s: with_smoke(s))
+                   .replace('"rgb sigma_a" [ 0.2 0.5 1.0 ] "rgb sigma_s" [ 3 3 3 ] "float scale" [ 0.01 ]', '"string preset" "Skin1" "float scale" [ 0.05 ]')
+                   .replace('"rgb sigma_a" [ 0.001 0.001 0.001 ] "rgb sigma_s" [ 0.004 0.002 0.001 ]', '"string preset" "Regular Milk" "rgb sigma_a" [ 0.0005 0.001 0.002 ] "float scale" [ 0.002 ]'),
     "vol_instances": cornell(32, 32, 8, integrator='Integrator "volpath" "integer maxdepth" [ 5 ]', world_edit=lambda s: with_fog(with_instances(s), camera_in_fog=False)),
     # SobolSampler (samplers/sobol.cpp): power-of-two and rounded-up sample counts, non-square frames, crop windows and wide
     # filters (sample bounds that start below / above 0), under both integrators

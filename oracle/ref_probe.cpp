@@ -2,11 +2,25 @@
 // the RGB coefficients the UNMODIFIED reference derives for MetalMaterial's default copper spectra (materials/metal.cpp:
 // CreateMetalMaterial -> Spectrum::FromSampled over the CIE matching curves).  The six numbers are constants of the host
 // front end (pbrt-v3_amd/host/api.cpp, kCopperN / kCopperK); tests/test_oracle_vs_reference.py re-checks them when
-// /root/reference is present.  Build: make -C oracle -f Makefile.ref _ref/ref_probe
+// /root/reference is present.  With arguments `presets NAME...` it prints what GetMediumScatteringProperties (core/medium.cpp:
+// 181-191) returns for each name: `NAME|sigma_a rgb|sigma_prime_s rgb` (tools/extract_medium_presets.py).
+// Build: make -C oracle -f Makefile.ref _ref/ref_probe
 #include "materials/metal.cpp"
+#include "medium.h"
 #include <cstdio>
-int main() {
+#include <cstring>
+int main(int argc, char **argv) {
     using namespace pbrt;
+    if (argc > 1 && !strcmp(argv[1], "presets")) {
+        for (int i = 2; i < argc; ++i) {
+            Spectrum a, s;
+            if (!GetMediumScatteringProperties(argv[i], &a, &s)) { fprintf(stderr, "unknown preset %s\n", argv[i]); return 1; }
+            Float ra[3], rs[3];
+            a.ToRGB(ra); s.ToRGB(rs);
+            printf("%s|%.9g %.9g %.9g|%.9g %.9g %.9g\n", argv[i], ra[0], ra[1], ra[2], rs[0], rs[1], rs[2]);
+        }
+        return 0;
+    }
     Spectrum n = Spectrum::FromSampled(CopperWavelengths, CopperN, CopperSamples);
     Spectrum k = Spectrum::FromSampled(CopperWavelengths, CopperK, CopperSamples);
     Float rgb[3];

@@ -556,7 +556,7 @@ void pbrtMakeNamedMedium(const std::string &name, const ParamSet &params) {  // 
     if (type == "") { Error("No parameter string \"type\" found in MakeNamedMedium"); return; }
     RGB sig_a{{.0011f, .0024f, .014f}}, sig_s{{2.55f, 3.21f, 3.77f}};
     std::string preset = params.FindOneString("preset", "");
-    if (preset != "") Warning("Material preset \"%s\" not found.  Using defaults.  (The measured presets of medium.cpp are not part of this build.)", preset.c_str());
+    if (preset != "" && !GetMediumScatteringProperties(preset, sig_a.c, sig_s.c)) Warning("Material preset \"%s\" not found.  Using defaults.", preset.c_str());
     Float scale = params.FindOneFloat("scale", 1.f);
     Float g = params.FindOneFloat("g", 0.0f);
     sig_a = params.FindOneSpectrum("sigma_a", sig_a);

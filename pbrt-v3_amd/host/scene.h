@@ -180,6 +180,7 @@ HaltonSampler *CreateSobolSampler(const ParamSet &params, const int sampleBounds
 // The Sobol' generator matrices embedded into this library (host/sobol.cpp, data/sobol_tables.bin; core/sobolmatrices.h:49-52)
 struct SobolTables { const uint32_t *matrices32; const uint64_t *vdc, *vdcInv; int nDims, matrixSize, vdcRows, vdcInvRows; };
 const SobolTables &GetSobolTables();
+bool GetMediumScatteringProperties(const std::string &name, Float sigma_a[3], Float sigma_prime_s[3]);  // core/medium.cpp:181-191
 HaltonSampler *CreateHaltonSampler(const ParamSet &params, const int sampleBounds[4]);  // halton.cpp:133-139
 // lowdiscrepancy.cpp:2490-2504 with the default-seeded RNG (halton.cpp:69-72).
 void ComputeRadicalInversePermutations(int nDims, std::vector<uint16_t> *perms, std::vector<int32_t> *sums);

@@ -1,9 +1,11 @@
-// The Sobol' generator matrices (core/sobolmatrices.h:49-52) as a data blob inside libpbrt_host.so.
-// data/sobol_tables.bin is written by tools/extract_sobol_tables.py; its layout is described there.
+// Constant tables embedded into libpbrt_host.so: the Sobol' generator matrices (core/sobolmatrices.h:49-52; data/
+// sobol_tables.bin, written by tools/extract_sobol_tables.py) and the named medium scattering properties (core/medium.cpp:
+// 49-176; data/medium_presets.txt, written by tools/extract_medium_presets.py).
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include "scene.h"
 
 #ifndef PG_SOBOL_BIN
@@ -17,7 +19,15 @@ __asm__(".section .rodata\n"
         ".global pg_sobol_blob_end\n"
         "pg_sobol_blob_end:\n"
         ".previous\n");
+__asm__(".section .rodata\n"
+        ".global pg_presets_blob\n"
+        "pg_presets_blob:\n"
+        ".incbin \"" PG_PRESETS_TXT "\"\n"
+        ".global pg_presets_blob_end\n"
+        "pg_presets_blob_end:\n"
+        ".previous\n");
 extern "C" const unsigned char pg_sobol_blob[], pg_sobol_blob_end[];
+extern "C" const char pg_presets_blob[], pg_presets_blob_end[];
 
 namespace pbrt {
 const SobolTables &GetSobolTables() {
@@ -43,5 +53,23 @@ const SobolTables &GetSobolTables() {
         return r;
     }();
     return t;
+}
+// GetMediumScatteringProperties, core/medium.cpp:181-191
+bool GetMediumScatteringProperties(const std::string &name, Float sigma_a[3], Float sigma_prime_s[3]) {
+    const std::string text(pg_presets_blob, pg_presets_blob_end);
+    size_t pos = 0;
+    while (pos < text.size()) {
+        size_t eol = text.find('\n', pos);
+        if (eol == std::string::npos) eol = text.size();
+        const std::string line = text.substr(pos, eol - pos);
+        pos = eol + 1;
+        const size_t bar = line.find('|');
+        if (bar == std::string::npos || line.compare(0, bar, name) != 0 || bar != name.size()) continue;
+        float a[3], s[3];
+        if (sscanf(line.c_str() + bar + 1, "%f %f %f|%f %f %f", &a[0], &a[1], &a[2], &s[0], &s[1], &s[2]) != 6) return false;
+        for (int k = 0; k < 3; ++k) { sigma_a[k] = a[k]; sigma_prime_s[k] = s[k]; }
+        return true;
+    }
+    return false;
 }
 }  // namespace pbrt
