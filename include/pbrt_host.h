@@ -35,6 +35,8 @@ void pbrt_host_film_merge(PbrtHostScene *s, const PgRenderDesc *rd, const PgFilm
                           const PgStraySample *strays, int n_strays);
 void pbrt_host_film_image(PbrtHostScene *s, float *rgb);
 int pbrt_host_write_pfm(const char *filename, const float *rgb, int width, int height);
+/* WriteImage (core/imageio.cpp:81-122): PFM, or gamma-encoded 8-bit PNG / TGA, chosen by the file name's suffix. */
+int pbrt_host_write_image(const char *filename, const float *rgb, int width, int height);
 
 /* The host's own HLBVH build over bare bounds (n x {pMin, pMax}); nodes has room for 2n entries.  Same contract as
  * pg_hlbvh_build (pbrt_gpu.h), which must reproduce it bit for bit. */

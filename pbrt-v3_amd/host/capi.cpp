@@ -58,6 +58,9 @@ void pbrt_host_film_image(PbrtHostScene *s, float *rgb) {
     s->loaded->integrator->camera->film->ComputeImage(&img);
     std::copy(img.begin(), img.end(), rgb);
 }
+int pbrt_host_write_image(const char *filename, const float *rgb, int width, int height) {
+    return WriteImage(filename, rgb, width, height) ? 0 : -1;
+}
 int pbrt_host_write_pfm(const char *filename, const float *rgb, int width, int height) {
     return WriteImagePFM(filename, rgb, width, height) ? 0 : -1;
 }

@@ -10,6 +10,8 @@
 #include <map>
 #include "api.h"
 #include "error.h"
+#include <zlib.h>
+#include <cstring>
 #include "scene.h"
 
 namespace pbrt {
@@ -228,17 +230,86 @@ bool WriteImagePFM(const std::string &filename, const Float *rgb, int width, int
     return ok;
 }
 
+// ---- 8-bit output formats, imageio.cpp:81-120: gamma-encoded RGB8 as PNG (lodepng_encode24_file in the reference) or TGA
+// (tga_write_bgr, uncompressed 24 bit).  Readers see the same pixels as in the reference's files; the PNG's deflate stream
+// itself comes from zlib here.
+static Float GammaCorrect(Float value) {  // pbrt.h:293-296
+    if (value <= 0.0031308f) return 12.92f * value;
+    return 1.055f * std::pow(value, (Float)(1.f / 2.4f)) - 0.055f;
+}
+static void ToRGB8(const Float *rgb, int width, int height, std::vector<uint8_t> *out) {
+    out->resize((size_t)3 * width * height);
+    for (size_t i = 0; i < out->size(); ++i) {
+        Float v = 255.f * GammaCorrect(rgb[i]) + 0.5f;
+        (*out)[i] = (uint8_t)(v < 0.f ? 0.f : (v > 255.f ? 255.f : v));  // (uint8_t)Clamp(..., 0.f, 255.f)
+    }
+}
+static void put32be(std::vector<uint8_t> &v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); }
+static void pngChunk(std::vector<uint8_t> &file, const char type[4], const std::vector<uint8_t> &data) {
+    put32be(file, (uint32_t)data.size());
+    std::vector<uint8_t> body(type, type + 4);
+    body.insert(body.end(), data.begin(), data.end());
+    file.insert(file.end(), body.begin(), body.end());
+    put32be(file, (uint32_t)crc32(0L, body.data(), (uInt)body.size()));
+}
+bool WriteImagePNG(const std::string &filename, const uint8_t *rgb8, int width, int height) {
+    std::vector<uint8_t> raw;  // filter type 0 in front of every scanline
+    raw.reserve((size_t)height * (3 * (size_t)width + 1));
+    for (int y = 0; y < height; ++y) { raw.push_back(0); raw.insert(raw.end(), rgb8 + (size_t)3 * width * y, rgb8 + (size_t)3 * width * (y + 1)); }
+    uLongf zlen = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(zlen);
+    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK) { Error("Error writing PNG \"%s\": deflate failed", filename.c_str()); return false; }
+    z.resize(zlen);
+    std::vector<uint8_t> file = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'}, ihdr;
+    put32be(ihdr, (uint32_t)width); put32be(ihdr, (uint32_t)height);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);  // 8 bits, RGB, deflate, adaptive, no interlace
+    pngChunk(file, "IHDR", ihdr);
+    pngChunk(file, "IDAT", z);
+    pngChunk(file, "IEND", {});
+    FILE *fp = fopen(filename.c_str(), "wb");
+    if (!fp) { Error("Error writing PNG \"%s\": cannot open the file", filename.c_str()); return false; }
+    bool ok = fwrite(file.data(), 1, file.size(), fp) == file.size();
+    fclose(fp);
+    if (!ok) Error("Error writing PNG \"%s\"", filename.c_str());
+    return ok;
+}
+bool WriteImageTGA(const std::string &filename, const uint8_t *rgb8, int width, int height) {
+    uint8_t hdr[18] = {0};
+    hdr[2] = 2;  // uncompressed true colour
+    hdr[12] = width & 255; hdr[13] = width >> 8; hdr[14] = height & 255; hdr[15] = height >> 8;
+    hdr[16] = 24; hdr[17] = 0x20;  // top-to-bottom rows
+    std::vector<uint8_t> bgr((size_t)3 * width * height);
+    for (size_t i = 0; i < (size_t)width * height; ++i) { bgr[3 * i] = rgb8[3 * i + 2]; bgr[3 * i + 1] = rgb8[3 * i + 1]; bgr[3 * i + 2] = rgb8[3 * i]; }
+    FILE *fp = fopen(filename.c_str(), "wb");
+    if (!fp) { Error("Unable to write output file \"%s\"", filename.c_str()); return false; }
+    bool ok = fwrite(hdr, 1, 18, fp) == 18 && fwrite(bgr.data(), 1, bgr.size(), fp) == bgr.size();
+    fclose(fp);
+    if (!ok) Error("Unable to write output file \"%s\"", filename.c_str());
+    return ok;
+}
+// WriteImage, imageio.cpp:81-122
+bool WriteImage(const std::string &filename, const Float *rgb, int width, int height) {
+    auto hasExt = [&](const char *e) { size_t n = filename.size(), m = strlen(e); return n >= m && filename.compare(n - m, m, e) == 0; };
+    if (hasExt(".pfm")) return WriteImagePFM(filename, rgb, width, height);
+    if (hasExt(".png") || hasExt(".tga")) {
+        std::vector<uint8_t> rgb8;
+        ToRGB8(rgb, width, height, &rgb8);
+        return hasExt(".png") ? WriteImagePNG(filename, rgb8.data(), width, height) : WriteImageTGA(filename, rgb8.data(), width, height);
+    }
+    if (hasExt(".exr")) {  // the reference writes half-float OpenEXR through the OpenEXR library, which this build does not carry
+        std::string alt = filename + ".pfm";
+        Warning("OpenEXR output is not part of this build; writing the float image as \"%s\".", alt.c_str());
+        return WriteImagePFM(alt, rgb, width, height);
+    }
+    Error("Can't determine image file type from suffix of filename \"%s\"", filename.c_str());
+    return false;
+}
+
 void Film::WriteImage() const {
     std::vector<Float> rgb;
     ComputeImage(&rgb);
     int w = croppedPixelBounds[2] - croppedPixelBounds[0], h = croppedPixelBounds[3] - croppedPixelBounds[1];
-    size_t n = filename.size();
-    if (n >= 4 && filename.substr(n - 4) == ".pfm") WriteImagePFM(filename, rgb.data(), w, h);
-    else {
-        std::string alt = filename + ".pfm";
-        Warning("Image format of \"%s\" is not supported by this build (PFM only); writing \"%s\".", filename.c_str(), alt.c_str());
-        WriteImagePFM(alt, rgb.data(), w, h);
-    }
+    pbrt::WriteImage(filename, rgb.data(), w, h);
 }
 
 Film *CreateFilm(const ParamSet &params, Float frx, Float fry) {  // film.cpp:213-252
