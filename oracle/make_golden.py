@@ -78,6 +78,14 @@ TEXTURES = ('Texture "chk" "spectrum" "checkerboard" "float uscale" [ 6 ] "float
             'Texture "uvt" "spectrum" "uv" "float uscale" [ 2.5 ] "float vscale" [ 1.5 ]\n')
 
 
+def write_test_spds(outdir):
+    """Small .spd files (wavelength in nm, value) in the layouts ReadFloatFile accepts: comments, exponents, a missing final
+    newline (whose last number the reference drops), an odd value count."""
+    open(os.path.join(outdir, "test_kd.spd"), "w").write("# reflectance\n380 0.05\n450 0.1\n500 0.6 # green\n550 0.7\n600 2.5e-1\n780 0.1\n")
+    open(os.path.join(outdir, "test_eta.spd"), "w").write("400 1.2\n500 1.0\n600 0.4\n700 0.2\n800 0.25")
+    open(os.path.join(outdir, "test_k.spd"), "w").write("# extinction\n400 2.1 500 2.6\n600 3.0 700 3.9\n12\n")
+
+
 def write_test_images(outdir):
     """Small synthetic images in every container the front end reads: PNG (RGB8 / RGBA8 / palette / gray16), TGA (24-bit
     RLE bottom-up, 8-bit mono top-down), PFM (colour little-endian, mono big-endian); non-power-of-two sizes exercise the
@@ -577,6 +585,13 @@ SCENES = {
     "sobol_vol_smoke": cornell(32, 32, 4, integrator='Integrator "volpath" "integer maxdepth" [ 6 ]',
                                world_edit=lambda s: with_fog(with_smoke(s)).replace("# tall box", 'Material "glass"\n# tall box')).replace('Sampler "halton"', 'Sampler "sobol"'),
     "sobol_tex_lens": cornell(32, 32, 4, world_edit=lambda s: with_image_textures(s)).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 10 ] "float focaldistance" [ 700 ]').replace('Sampler "halton"', 'Sampler "sobol"'),
+    # "blackbody", "xyz" and "spectrum" (inline pairs, unsorted pairs, .spd files) parameters -> RGB (paramset.cpp:122-208)
+    "spectrum_params": cornell(32, 32, 8, world_edit=lambda s: s.replace('"rgb L" [ 17 12 4 ]', '"blackbody L" [ 4500 14 ]')
+                               .replace('Material "matte" "rgb Kd" [ 0.12 0.45 0.15 ]', 'Material "matte" "xyz Kd" [ 0.2 0.35 0.1 ]')
+                               .replace('Material "matte" "rgb Kd" [ 0.65 0.05 0.05 ]', 'Material "matte" "spectrum Kd" [ 400 0.05 700 0.7 550 0.1 620 0.65 ]')
+                               .replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\nMaterial "plastic" "spectrum Kd" "test_kd.spd" "spectrum Ks" [ 300 0.3 900 0.5 ]')
+                               .replace("# tall box", 'Material "metal" "spectrum eta" "test_eta.spd" "spectrum k" "test_k.spd" "float roughness" [ 0.05 ]\n# tall box')
+                               .replace("# light\nAttributeBegin", 'LightSource "point" "point from" [ 100 400 100 ] "blackbody I" [ 2800 30000 ] "xyz scale" [ 1 1 1.2 ]\n# light\nAttributeBegin')),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 
@@ -600,6 +615,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     only = sys.argv[1:]
     write_test_images(GOLD)
+    write_test_spds(GOLD)
     for name, text in SCENES.items():
         if only and name not in only: continue
         p = os.path.join(GOLD, name + ".pbrt")

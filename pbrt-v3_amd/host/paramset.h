@@ -12,6 +12,11 @@
 
 namespace pbrt {
 struct RGB { Float c[3]; };
+// "xyz" / "blackbody" / "spectrum" parameter values as the RGB triples the reference's RGBSpectrum holds (host/spectrum.cpp)
+void XYZToRGBValues(const std::vector<Float> &xyz, std::vector<Float> *rgb);
+void BlackbodyToRGBValues(const std::vector<Float> &temperatureScalePairs, std::vector<Float> *rgb);
+void SampledToRGBValues(const std::vector<Float> &lambdaValuePairs, std::vector<Float> *rgb);
+void SpectrumFilesToRGBValues(const std::vector<std::string> &filenames, std::vector<Float> *rgb);
 
 class ParamSet {
   public:

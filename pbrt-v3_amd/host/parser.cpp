@@ -175,8 +175,24 @@ struct Parser {
             if (strs.size() == 1) ps.textures[name].v = strs;
             else Error("Only one string allowed for \"texture\" parameter \"%s\"", name.c_str());
         }
-        else if (type == "xyz" || type == "blackbody" || type == "spectrum")
-            Error("Parameter \"%s\": spectrum type \"%s\" is not supported by this build (RGB only). Ignoring.", name.c_str(), type.c_str());
+        else if (type == "xyz") {
+            std::vector<Float> v;
+            toFloats(v, 3);
+            XYZToRGBValues(v, &ps.spectra[name].v);
+        } else if (type == "blackbody") {  // (temperature in K, scale) pairs
+            std::vector<Float> v;
+            if (nums.size() % 2) Warning("Excess value given with blackbody parameter \"%s\". Ignoring extra one.", decl.c_str());
+            for (size_t i = 0; i + 1 < nums.size(); i += 2) { v.push_back(nums[i]); v.push_back(nums[i + 1]); }
+            BlackbodyToRGBValues(v, &ps.spectra[name].v);
+        } else if (type == "spectrum") {  // .spd file names, or inline (wavelength in nm, value) pairs
+            if (isString) SpectrumFilesToRGBValues(strs, &ps.spectra[name].v);
+            else {
+                std::vector<Float> v;
+                if (nums.size() % 2) Warning("Non-even number of values given with sampled spectrum parameter \"%s\". Ignoring extra.", decl.c_str());
+                for (size_t i = 0; i + 1 < nums.size(); i += 2) { v.push_back(nums[i]); v.push_back(nums[i + 1]); }
+                SampledToRGBValues(v, &ps.spectra[name].v);
+            }
+        }
         else Error("Unable to decode type for name \"%s\"", decl.c_str());
     }
 

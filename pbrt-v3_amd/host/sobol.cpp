@@ -1,5 +1,5 @@
 // Constant tables embedded into libpbrt_host.so: the Sobol' generator matrices (core/sobolmatrices.h:49-52; data/
-// sobol_tables.bin, written by tools/extract_sobol_tables.py) and the named medium scattering properties (core/medium.cpp:
+// sobol_tables.bin, written by tools/extract_reference_tables.py) and the named medium scattering properties (core/medium.cpp:
 // 49-176; data/medium_presets.txt, written by tools/extract_medium_presets.py).
 #include <cstdint>
 #include <cstdio>

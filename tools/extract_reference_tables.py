@@ -1,5 +1,10 @@
 #!/usr/bin/env python3
-"""Writes pbrt-v3_amd/data/sobol_tables.bin: the Sobol' generator matrices the SobolSampler reads (core/sobolmatrices.h:49-52:
+"""Writes the constant tables of the host front end that are numeric data of the reference rather than code:
+
+pbrt-v3_amd/data/cie_tables.bin: the CIE 1931 colour matching functions at 1 nm from 360 to 830 nm (core/spectrum.cpp:190-...:
+CIE_X, CIE_Y, CIE_Z, CIE_lambda; 471 floats each, in that order), which turn "spectrum" / "blackbody" parameters into RGB.
+
+pbrt-v3_amd/data/sobol_tables.bin: the Sobol' generator matrices the SobolSampler reads (core/sobolmatrices.h:49-52:
 SobolMatrices32, VdCSobolMatrices, VdCSobolMatricesInv -- Gruenschloss' published tables, numeric constants of the sequence
 itself like the table of primes).  They are taken from the read-only data section of the reference binary built by
 oracle/Makefile.ref (oracle/_ref/pbrt_oracle), so this script runs in the build container only; the .bin is committed and
@@ -15,6 +20,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref", "pbrt_oracle")
 OUT = os.path.join(ROOT, "pbrt-v3_amd", "data", "sobol_tables.bin")
+OUT_CIE = os.path.join(ROOT, "pbrt-v3_amd", "data", "cie_tables.bin")
 
 
 def main():
@@ -23,9 +29,10 @@ def main():
     syms = {}
     for line in subprocess.run(["nm", "-S", "-C", REF], capture_output=True, text=True, check=True).stdout.splitlines():
         parts = line.split(None, 3)
-        if len(parts) == 4 and parts[3] in ("pbrt::SobolMatrices32", "pbrt::VdCSobolMatrices", "pbrt::VdCSobolMatricesInv"):
+        if len(parts) == 4 and parts[3] in ("pbrt::SobolMatrices32", "pbrt::VdCSobolMatrices", "pbrt::VdCSobolMatricesInv", "pbrt::CIE_X", "pbrt::CIE_Y",
+                                              "pbrt::CIE_Z", "pbrt::CIE_lambda"):
             syms[parts[3].split("::")[1]] = (int(parts[0], 16), int(parts[1], 16))
-    assert len(syms) == 3, syms
+    assert len(syms) == 7, syms
     # map virtual addresses to file offsets through the section headers
     secs = []
     for line in subprocess.run(["readelf", "-S", "-W", REF], capture_output=True, text=True, check=True).stdout.splitlines():
@@ -50,6 +57,11 @@ def main():
         fo.write(struct.pack("<5i", 0x4C424F53, 1024, size, len(vdc) // (size * 8), len(inv) // (size * 8)))
         fo.write(m32); fo.write(vdc); fo.write(inv)
     print(OUT, os.path.getsize(OUT), "bytes; vdc rows", len(vdc) // (size * 8), "inv rows", len(inv) // (size * 8))
+    cie = [read(n) for n in ("CIE_X", "CIE_Y", "CIE_Z", "CIE_lambda")]
+    assert all(len(c) == 471 * 4 for c in cie)
+    with open(OUT_CIE, "wb") as fo:
+        for c in cie: fo.write(c)
+    print(OUT_CIE, os.path.getsize(OUT_CIE), "bytes")
 
 
 if __name__ == "__main__":
