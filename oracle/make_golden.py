@@ -226,6 +226,28 @@ def with_smoke(s):
     return s
 
 
+def with_mesh_shapes(s):
+    """Shape "heightfield" (6 x 5 samples) and Shape "nurbs": a bicubic patch given by "P", and a rational quadratic x cubic
+    surface given by "Pw" with a restricted parameter range, under transforms; plus ReverseOrientation on the patch."""
+    import math
+    hz = " ".join(f"{0.15 * math.sin(0.9 * i) * math.cos(0.7 * j) + 0.1:.6g}" for j in range(5) for i in range(6))
+    cps = " ".join(f"{x} {y} {40 * math.sin(1.3 * x / 100 + y / 70.0):.6g}" for y in (0, 60, 120, 180) for x in (0, 70, 140, 210))
+    pw = []
+    for j in range(4):
+        for (x, z, w) in ((60, 0, 1), (60, 60, 0.7071), (0, 60, 1)):
+            pw += [x * w, 50.0 * j * w, z * w, w]
+    pw = " ".join(f"{v:.6g}" for v in pw)
+    shapes = ('AttributeBegin\n  Translate 60 166 60\n  Scale 220 200 160\n  Rotate -90 1 0 0\n  Material "plastic" "rgb Kd" [ 0.2 0.5 0.7 ]\n'
+              '  Shape "heightfield" "integer nu" [ 6 ] "integer nv" [ 5 ] "float Pz" [ %s ]\nAttributeEnd\n'
+              'AttributeBegin\n  Translate 300 340 150\n  Rotate 25 0 1 0\n  ReverseOrientation\n  Material "matte" "rgb Kd" [ 0.7 0.6 0.2 ]\n'
+              '  Shape "nurbs" "integer nu" [ 4 ] "integer nv" [ 4 ] "integer uorder" [ 4 ] "integer vorder" [ 4 ]\n'
+              '    "float uknots" [ 0 0 0 0 1 1 1 1 ] "float vknots" [ 0 0 0 0 2 2 2 2 ] "point P" [ %s ]\nAttributeEnd\n'
+              'AttributeBegin\n  Translate 120 20 380\n  Material "mirror"\n'
+              '  Shape "nurbs" "integer nu" [ 3 ] "integer nv" [ 4 ] "integer uorder" [ 3 ] "integer vorder" [ 4 ] "float u0" [ 0.1 ] "float v1" [ 0.9 ]\n'
+              '    "float uknots" [ 0 0 0 1 1 1 ] "float vknots" [ 0 0 0 0 1 1 1 1 ] "float Pw" [ %s ]\nAttributeEnd\n' % (hz, cps, pw))
+    return s.replace("# short box", shapes + "# short box", 1)
+
+
 def with_alpha(s):
     s = with_normals(s, uv=True)
     tex = ('Texture "a_chk" "float" "checkerboard" "float uscale" [ 4 ] "float vscale" [ 4 ] "float tex1" [ 0 ] "float tex2" [ 1 ]\n'
@@ -592,6 +614,7 @@ SCENES = {
                                .replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\nMaterial "plastic" "spectrum Kd" "test_kd.spd" "spectrum Ks" [ 300 0.3 900 0.5 ]')
                                .replace("# tall box", 'Material "metal" "spectrum eta" "test_eta.spd" "spectrum k" "test_k.spd" "float roughness" [ 0.05 ]\n# tall box')
                                .replace("# light\nAttributeBegin", 'LightSource "point" "point from" [ 100 400 100 ] "blackbody I" [ 2800 30000 ] "xyz scale" [ 1 1 1.2 ]\n# light\nAttributeBegin')),
+    "mesh_shapes": cornell(40, 40, 8, world_edit=lambda s: with_mesh_shapes(s)),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 

@@ -936,6 +936,8 @@ std::shared_ptr<TriangleMesh> BuildTriangleMesh(const Transform &o2w, bool rever
 }
 std::shared_ptr<TriangleMesh> CreatePLYMesh(const Transform &o2w, bool reverseOrientation, const ParamSet &params);  // plymesh.cpp
 std::shared_ptr<TriangleMesh> CreateLoopSubdiv(const Transform &o2w, bool reverseOrientation, const ParamSet &params);  // loopsubdiv.cpp
+std::shared_ptr<TriangleMesh> CreateHeightfield(const Transform &o2w, bool reverseOrientation, const ParamSet &params);  // meshshapes.cpp
+std::shared_ptr<TriangleMesh> CreateNURBS(const Transform &o2w, bool reverseOrientation, const ParamSet &params);        // meshshapes.cpp
 
 // The "alpha" / "shadowalpha" parameters of a mesh (triangle.cpp:716-738, plymesh.cpp:259-287): a named float texture, or
 // the literal 0 (a constant-zero mask); returns the index of the mesh's PgAlphaMask or -1
@@ -1000,6 +1002,8 @@ void pbrtShape(const std::string &name, const ParamSet &params) {  // api.cpp:13
     if (name == "trianglemesh") mesh = CreateTriangleMeshShape(curTransform[0], graphicsState.reverseOrientation, params);
     else if (name == "plymesh") mesh = CreatePLYMesh(curTransform[0], graphicsState.reverseOrientation, params);
     else if (name == "loopsubdiv") mesh = CreateLoopSubdiv(curTransform[0], graphicsState.reverseOrientation, params);
+    else if (name == "heightfield") mesh = CreateHeightfield(curTransform[0], graphicsState.reverseOrientation, params);
+    else if (name == "nurbs") mesh = CreateNURBS(curTransform[0], graphicsState.reverseOrientation, params);
     else if (name == "sphere") {  // CreateSphereShape, sphere.cpp:326-336
         Float radius = params.FindOneFloat("radius", 1.f);
         Float zmin = params.FindOneFloat("zmin", -radius);
@@ -1018,7 +1022,7 @@ void pbrtShape(const std::string &name, const ParamSet &params) {  // api.cpp:13
         Float inner_radius = params.FindOneFloat("innerradius", 0);
         Float phimax = params.FindOneFloat("phimax", 360);
         sphere = Sphere::Disk(curTransform[0], Inverse(curTransform[0]), graphicsState.reverseOrientation, height, radius, inner_radius, phimax);
-    } else Error("Shape \"%s\" is outside this build's closed set (trianglemesh, plymesh, loopsubdiv, sphere, cylinder, disk); ignoring.", name.c_str());
+    } else Error("Shape \"%s\" is outside this build's closed set (trianglemesh, plymesh, loopsubdiv, heightfield, nurbs, sphere, cylinder, disk); ignoring.", name.c_str());
     if (!sphere && (!mesh || mesh->nTriangles == 0)) return;
     int mtl = GetMaterialForShape(params);
     params.ReportUnused();
