@@ -320,6 +320,48 @@ def test_unsupported_inputs_fail_loudly(gpu):
     gs.close()
 
 
+def test_invalid_media_and_sampler_descriptions_fail_loudly(gpu):
+    """The v15 / v16 additions to the ABI are validated like the rest: out-of-range medium indices, an unknown integrator or
+    sampler, a Sobol' render on a scene created without the tables, inconsistent Sobol' resolutions."""
+    scene = gpu.HostScene(os.path.join(GOLD, "vol_smoke.pbrt"))
+    desc = scene.desc
+    n = max(desc.n_tris, desc.n_prims_all)
+    inside = (C.c_int32 * n)(*[desc.tri_medium_inside[i] for i in range(n)])
+    inside[0] = desc.n_media
+    bad = gpu.abi.PgSceneDesc.from_buffer_copy(desc)
+    bad.tri_medium_inside = inside
+    with pytest.raises(gpu.PbrtGpuError, match="medium index out of range"):
+        gpu.GpuScene(bad)
+    gs = gpu.GpuScene(desc)
+    rd = scene.render_desc()
+    rd.camera_medium = desc.n_media
+    with pytest.raises(gpu.PbrtGpuError, match="camera_medium"):
+        gs.render(rd)
+    rd = scene.render_desc()
+    rd.integrator = 2
+    with pytest.raises(gpu.PbrtGpuError, match="integrator 2"):
+        gs.render(rd)
+    rd = scene.render_desc()
+    rd.sampler = 1  # vol_smoke uses the Halton sampler: the scene carries no Sobol' matrices
+    rd.sobol_resolution, rd.sobol_log2_resolution = 64, 6
+    with pytest.raises(gpu.PbrtGpuError, match="without the Sobol"):
+        gs.render(rd)
+    gs.close()
+    sob = gpu.HostScene(os.path.join(GOLD, "sobol_cornell.pbrt"))
+    gs = gpu.GpuScene(sob.desc)
+    rd = sob.render_desc()
+    rd.sobol_resolution = 48
+    with pytest.raises(gpu.PbrtGpuError, match="sobol_resolution"):
+        gs.render(rd)
+    rd = sob.render_desc()
+    rd.sampler = 3
+    with pytest.raises(gpu.PbrtGpuError, match="sampler 3"):
+        gs.render(rd)
+    gs.close()
+    with pytest.raises(gpu.PbrtGpuError, match="null argument"):
+        gpu._check(gpu.gpu_lib().pg_hlbvh_build(4, None, 4, None, None, None), "pg_hlbvh_build")
+
+
 def test_full_size_properties(gpu, oracle, tmp_path):
     """BASELINE.json config 3 geometry at full frame size (1920x1080, ~1M triangles), 1 spp: size-independent
     properties -- every pixel receives exactly its samples, two renders are bit-identical, primary hits of a
