@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 16
+#define PG_ABI_VERSION 17
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -239,7 +239,11 @@ typedef enum PgLightStrategy {
 typedef enum PgQuadricShape {
     PG_SHAPE_SPHERE = 0,        /* shapes/sphere.cpp   */
     PG_SHAPE_CYLINDER = 1,      /* shapes/cylinder.cpp: radius, z_min, z_max, phi_max */
-    PG_SHAPE_DISK = 2           /* shapes/disk.cpp: height, radius, inner_radius, phi_max */
+    PG_SHAPE_DISK = 2,          /* shapes/disk.cpp: height, radius, inner_radius, phi_max */
+    /* geometry only: the reference has no Sample() for these three (cone.cpp:205-208 etc.), so they cannot be area lights */
+    PG_SHAPE_CONE = 3,          /* shapes/cone.cpp: radius, height, phi_max (z_min = 0, z_max = height) */
+    PG_SHAPE_PARABOLOID = 4,    /* shapes/paraboloid.cpp: radius, z_min, z_max, phi_max */
+    PG_SHAPE_HYPERBOLOID = 5    /* shapes/hyperboloid.cpp: p1, p2, ah, ch, z_min, z_max, phi_max (radius = rMax) */
 } PgQuadricShape;
 typedef struct PgSphere {       /* a quadric: the record began as the sphere's and kept its name */
     float o2w[16], w2o[16];     /* ObjectToWorld / WorldToObject, row-major (its m and mInv, transform.h:112-205) */
@@ -249,6 +253,7 @@ typedef struct PgSphere {       /* a quadric: the record began as the sphere's a
     int32_t shape;              /* PgQuadricShape */
     float height, inner_radius; /* disk */
     float area;                 /* Shape::Area() */
+    float p1[3], p2[3], ah, ch; /* hyperboloid: the end points as its constructor leaves them and its implicit coefficients (hyperboloid.cpp:43-65) */
 } PgSphere;
 
 /* Object instancing (api.cpp:1509-1588).  An object definition is a run of primitives in the primitive arrays after the

@@ -248,6 +248,15 @@ def with_mesh_shapes(s):
     return s.replace("# short box", shapes + "# short box", 1)
 
 
+QUADRICS3 = ('AttributeBegin\n  Translate 420 0 150\n  Rotate -90 1 0 0\n  Material "plastic" "rgb Kd" [ 0.7 0.3 0.2 ]\n  Shape "cone" "float radius" [ 70 ] "float height" [ 190 ] "float phimax" [ 300 ]\nAttributeEnd\n'
+             'AttributeBegin\n  Translate 150 330 330\n  Rotate 140 1 0.3 0\n  Scale 1 0.7 1.2\n  Material "glass"\n  Shape "paraboloid" "float radius" [ 80 ] "float zmin" [ 20 ] "float zmax" [ 150 ]\nAttributeEnd\n'
+             'AttributeBegin\n  Translate 300 20 90\n  Rotate -90 1 0 0\n  ReverseOrientation\n  Material "mirror"\n'
+             '  Shape "hyperboloid" "point p1" [ 60 10 0 ] "point p2" [ 30 -50 160 ] "float phimax" [ 270 ]\nAttributeEnd\n'
+             'AttributeBegin\n  Translate 110 170 120\n  Material "matte" "rgb Kd" [ 0.2 0.6 0.3 ]\n  Shape "hyperboloid" "point p1" [ 40 0 -30 ] "point p2" [ 10 40 0 ]\n'
+             '  Translate 0 0 60\n  Shape "cone" "float radius" [ 40 ] "float height" [ 80 ]\n  Translate 0 0 150\n  Rotate 180 1 0 0\n  Shape "paraboloid" "float radius" [ 50 ] "float zmax" [ 70 ]\nAttributeEnd\n'
+             'ObjectBegin "q3"\n  Material "uber" "rgb Kd" [ 0.3 0.3 0.8 ]\n  Shape "cone" "float radius" [ 30 ] "float height" [ 60 ]\n  Shape "paraboloid" "float radius" [ 30 ] "float zmax" [ 40 ] "float phimax" [ 200 ]\nObjectEnd\n'
+             'AttributeBegin\n  Translate 470 330 330\n  Rotate 60 0 1 1\n  Scale 1.5 1 -1\n  ObjectInstance "q3"\nAttributeEnd\n')
+
 def with_alpha(s):
     s = with_normals(s, uv=True)
     tex = ('Texture "a_chk" "float" "checkerboard" "float uscale" [ 4 ] "float vscale" [ 4 ] "float tex1" [ 0 ] "float tex2" [ 1 ]\n'
@@ -615,6 +624,8 @@ SCENES = {
                                .replace("# tall box", 'Material "metal" "spectrum eta" "test_eta.spd" "spectrum k" "test_k.spd" "float roughness" [ 0.05 ]\n# tall box')
                                .replace("# light\nAttributeBegin", 'LightSource "point" "point from" [ 100 400 100 ] "blackbody I" [ 2800 30000 ] "xyz scale" [ 1 1 1.2 ]\n# light\nAttributeBegin')),
     "mesh_shapes": cornell(40, 40, 8, world_edit=lambda s: with_mesh_shapes(s)),
+    # cone / paraboloid / hyperboloid: full and partial, transformed, reversed, specular (error bounds), inside an instance
+    "quadrics3": cornell(40, 40, 8, integrator='Integrator "path" "integer maxdepth" [ 6 ]', world_edit=lambda s: s.replace("# short box", QUADRICS3 + "# short box", 1)),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 

@@ -5,7 +5,7 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 16
+PG_ABI_VERSION = 17
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
 PG_LIGHTS_UNIFORM, PG_LIGHTS_POWER, PG_LIGHTS_SPATIAL = 0, 1, 2
@@ -72,7 +72,8 @@ class PgSphere(C.Structure):
     _fields_ = [("o2w", C.c_float * 16), ("w2o", C.c_float * 16), ("radius", C.c_float), ("z_min", C.c_float), ("z_max", C.c_float),
                 ("theta_min", C.c_float), ("theta_max", C.c_float), ("phi_max", C.c_float),
                 ("reverse_orientation", C.c_int32), ("swaps_handedness", C.c_int32),
-                ("shape", C.c_int32), ("height", C.c_float), ("inner_radius", C.c_float), ("area", C.c_float)]
+                ("shape", C.c_int32), ("height", C.c_float), ("inner_radius", C.c_float), ("area", C.c_float),
+                ("p1", C.c_float * 3), ("p2", C.c_float * 3), ("ah", C.c_float), ("ch", C.c_float)]
 
 
 class PgObject(C.Structure):

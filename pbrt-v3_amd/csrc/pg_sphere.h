@@ -299,15 +299,117 @@ PG_DEV SphereHit disk_interaction(const PgSphere &sp, V3 ro, V3 rd, float tHit) 
     pHit.z = sp.height;
     return quadric_finish(sp, d, pHit, mk(0, 0, 0), dpdu, dpdv, mk(0, 0, 0), mk(0, 0, 0), mk(0, 0, 0), phi / sp.phi_max, (sp.radius - rHit) / (sp.radius - sp.inner_radius));
 }
+// ---- Cone (shapes/cone.cpp:56-198), Paraboloid (paraboloid.cpp:57-202) and Hyperboloid (hyperboloid.cpp:73-229): the three
+// quadrics the reference only intersects (no Sample(): they cannot be area lights).  They share the root selection and differ
+// in the implicit coefficients, the inverse mapping / clipping and the parametric derivatives.
+PG_DEV float ef_abs_error(EFloat e) { return next_float_up(pmax(fabsf(e.high - e.v), fabsf(e.v - e.low))); }  // efloat.h:91-92
+struct Q3Roots { V3 o, d; EFloat ox, oy, oz, dx, dy, dz, t0, t1; };
+PG_DEV bool quadric3_roots(const PgSphere &sp, V3 ro, V3 rd, Q3Roots &q) {
+    V3 oErr, dErr;
+    sphere_object_ray(sp, ro, rd, q.o, q.d, oErr, dErr);
+    q.ox = ef_make(q.o.x, oErr.x); q.oy = ef_make(q.o.y, oErr.y); q.oz = ef_make(q.o.z, oErr.z);
+    q.dx = ef_make(q.d.x, dErr.x); q.dy = ef_make(q.d.y, dErr.y); q.dz = ef_make(q.d.z, dErr.z);
+    const EFloat ox = q.ox, oy = q.oy, oz = q.oz, dx = q.dx, dy = q.dy, dz = q.dz, two = ef_make(2, 0);
+    EFloat a, b, c;
+    if (sp.shape == PG_SHAPE_CONE) {  // cone.cpp:66-73
+        const EFloat h = ef_make(sp.height, 0);
+        EFloat k = ef_div(ef_make(sp.radius, 0), h);
+        k = ef_mul(k, k);
+        a = ef_sub(ef_add(ef_mul(dx, dx), ef_mul(dy, dy)), ef_mul(ef_mul(k, dz), dz));
+        b = ef_mul(two, ef_sub(ef_add(ef_mul(dx, ox), ef_mul(dy, oy)), ef_mul(ef_mul(k, dz), ef_sub(oz, h))));
+        c = ef_sub(ef_add(ef_mul(ox, ox), ef_mul(oy, oy)), ef_mul(ef_mul(k, ef_sub(oz, h)), ef_sub(oz, h)));
+    } else if (sp.shape == PG_SHAPE_PARABOLOID) {  // paraboloid.cpp:68-74
+        const EFloat k = ef_div(ef_make(sp.z_max, 0), ef_mul(ef_make(sp.radius, 0), ef_make(sp.radius, 0)));
+        a = ef_mul(k, ef_add(ef_mul(dx, dx), ef_mul(dy, dy)));
+        b = ef_sub(ef_mul(ef_mul(two, k), ef_add(ef_mul(dx, ox), ef_mul(dy, oy))), dz);
+        c = ef_sub(ef_mul(k, ef_add(ef_mul(ox, ox), ef_mul(oy, oy))), oz);
+    } else {  // hyperboloid.cpp:85-91
+        const EFloat ah = ef_make(sp.ah, 0), ch = ef_make(sp.ch, 0);
+        a = ef_sub(ef_add(ef_mul(ef_mul(ah, dx), dx), ef_mul(ef_mul(ah, dy), dy)), ef_mul(ef_mul(ch, dz), dz));
+        b = ef_mul(two, ef_sub(ef_add(ef_mul(ef_mul(ah, dx), ox), ef_mul(ef_mul(ah, dy), oy)), ef_mul(ef_mul(ch, dz), oz)));
+        c = ef_sub(ef_sub(ef_add(ef_mul(ef_mul(ah, ox), ox), ef_mul(ef_mul(ah, oy), oy)), ef_mul(ef_mul(ch, oz), oz)), ef_make(1, 0));
+    }
+    return ef_quadratic(a, b, c, q.t0, q.t1);
+}
+// the hit point of root t, its phi (and the hyperboloid's v); false when it lies outside the clipping parameters
+PG_DEV bool quadric3_map(const PgSphere &sp, V3 o, V3 d, float t, V3 &pHit, float &phi, float &v) {
+    pHit = o + d * t;
+    v = 0;
+    if (sp.shape == PG_SHAPE_HYPERBOLOID) {  // hyperboloid.cpp:106-111
+        const V3 p1 = mk(sp.p1[0], sp.p1[1], sp.p1[2]), p2 = mk(sp.p2[0], sp.p2[1], sp.p2[2]);
+        v = (pHit.z - p1.z) / (p2.z - p1.z);
+        const V3 pr = p1 * (1 - v) + p2 * v;
+        phi = (float)atan2((double)(pr.x * pHit.y - pHit.x * pr.y), (double)(pHit.x * pr.x + pHit.y * pr.y));
+    } else phi = (float)atan2((double)pHit.y, (double)pHit.x);
+    if (phi < 0) phi += 2 * PG_PI;
+    const float zLo = sp.shape == PG_SHAPE_CONE ? 0.f : sp.z_min, zHi = sp.shape == PG_SHAPE_CONE ? sp.height : sp.z_max;
+    return !(pHit.z < zLo || pHit.z > zHi || phi > sp.phi_max);
+}
+PG_DEV bool quadric3_test(const PgSphere &sp, V3 ro, V3 rd, float tMax, float &tHit) {
+    Q3Roots q;
+    if (!quadric3_roots(sp, ro, rd, q)) return false;
+    if (q.t0.high > tMax || q.t1.low <= 0) return false;
+    EFloat tShapeHit = q.t0;
+    if (tShapeHit.low <= 0) {
+        tShapeHit = q.t1;
+        if (tShapeHit.high > tMax) return false;
+    }
+    V3 pHit;
+    float phi, v;
+    if (!quadric3_map(sp, q.o, q.d, tShapeHit.v, pHit, phi, v)) {
+        if (tShapeHit.v == q.t1.v) return false;
+        tShapeHit = q.t1;
+        if (q.t1.high > tMax) return false;
+        if (!quadric3_map(sp, q.o, q.d, tShapeHit.v, pHit, phi, v)) return false;
+    }
+    tHit = tShapeHit.v;
+    return true;
+}
+PG_DEV SphereHit quadric3_interaction(const PgSphere &sp, V3 ro, V3 rd, float tHit) {
+    Q3Roots q;
+    quadric3_roots(sp, ro, rd, q);
+    const EFloat tShapeHit = (q.t0.v == tHit) ? q.t0 : q.t1;  // the root quadric3_test accepted (equal values: the test kept t0)
+    V3 pHit;
+    float phi, v;
+    quadric3_map(sp, q.o, q.d, tHit, pHit, phi, v);
+    const float phiMax = sp.phi_max, u = phi / phiMax;
+    const V3 dpdu = mk(-phiMax * pHit.y, phiMax * pHit.x, 0);
+    const V3 d2Pduu = mk(pHit.x, pHit.y, 0) * (-phiMax * phiMax);
+    V3 dpdv, d2Pduv, d2Pdvv = mk(0, 0, 0);
+    if (sp.shape == PG_SHAPE_CONE) {  // cone.cpp:106-116
+        v = pHit.z / sp.height;
+        dpdv = mk(-pHit.x / (1.f - v), -pHit.y / (1.f - v), sp.height);
+        d2Pduv = mk(pHit.y, -pHit.x, 0.f) * (phiMax / (1.f - v));
+    } else if (sp.shape == PG_SHAPE_PARABOLOID) {  // paraboloid.cpp:107-124
+        const float zMin = sp.z_min, zMax = sp.z_max;
+        v = (pHit.z - zMin) / (zMax - zMin);
+        dpdv = mk(pHit.x / (2 * pHit.z), pHit.y / (2 * pHit.z), 1.f) * (zMax - zMin);
+        d2Pduv = mk(-pHit.y / (2 * pHit.z), pHit.x / (2 * pHit.z), 0) * ((zMax - zMin) * phiMax);
+        d2Pdvv = mk(pHit.x / (4 * pHit.z * pHit.z), pHit.y / (4 * pHit.z * pHit.z), 0) * (-(zMax - zMin) * (zMax - zMin));
+    } else {  // hyperboloid.cpp:128-140
+        double sP, cP;
+        sincos((double)phi, &sP, &cP);
+        const float cosPhi = (float)cP, sinPhi = (float)sP;
+        const float ex = sp.p2[0] - sp.p1[0], ey = sp.p2[1] - sp.p1[1];
+        dpdv = mk(ex * cosPhi - ey * sinPhi, ex * sinPhi + ey * cosPhi, sp.p2[2] - sp.p1[2]);
+        d2Pduv = mk(-dpdv.y, dpdv.x, 0.f) * phiMax;
+    }
+    // error bounds of the point computed with the ray equation (cone.cpp:135-140)
+    const EFloat px = ef_add(q.ox, ef_mul(tShapeHit, q.dx)), py = ef_add(q.oy, ef_mul(tShapeHit, q.dy)), pz = ef_add(q.oz, ef_mul(tShapeHit, q.dz));
+    const V3 pError = mk(ef_abs_error(px), ef_abs_error(py), ef_abs_error(pz));
+    return quadric_finish(sp, q.d, pHit, pError, dpdu, dpdv, d2Pduu, d2Pduv, d2Pdvv, u, v);
+}
 // Shape::Intersect[P] of the quadric record, by shape
 PG_DEV bool sphere_test(const PgSphere &sp, V3 ro, V3 rd, float tMax, float &tHit) {
     if (sp.shape == PG_SHAPE_CYLINDER) return cylinder_test(sp, ro, rd, tMax, tHit);
     if (sp.shape == PG_SHAPE_DISK) return disk_test(sp, ro, rd, tMax, tHit);
+    if (sp.shape >= PG_SHAPE_CONE) return quadric3_test(sp, ro, rd, tMax, tHit);
     return sphere_test_s(sp, ro, rd, tMax, tHit);
 }
 PG_DEV SphereHit sphere_interaction(const PgSphere &sp, V3 ro, V3 rd, float tHit) {
     if (sp.shape == PG_SHAPE_CYLINDER) return cylinder_interaction(sp, ro, rd, tHit);
     if (sp.shape == PG_SHAPE_DISK) return disk_interaction(sp, ro, rd, tHit);
+    if (sp.shape >= PG_SHAPE_CONE) return quadric3_interaction(sp, ro, rd, tHit);
     return sphere_interaction_s(sp, ro, rd, tHit);
 }
 #endif

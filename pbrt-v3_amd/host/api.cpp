@@ -1022,14 +1022,32 @@ void pbrtShape(const std::string &name, const ParamSet &params) {  // api.cpp:13
         Float inner_radius = params.FindOneFloat("innerradius", 0);
         Float phimax = params.FindOneFloat("phimax", 360);
         sphere = Sphere::Disk(curTransform[0], Inverse(curTransform[0]), graphicsState.reverseOrientation, height, radius, inner_radius, phimax);
-    } else Error("Shape \"%s\" is outside this build's closed set (trianglemesh, plymesh, loopsubdiv, heightfield, nurbs, sphere, cylinder, disk); ignoring.", name.c_str());
+    } else if (name == "cone") {  // CreateConeShape, cone.cpp:210-219
+        Float radius = params.FindOneFloat("radius", 1);
+        Float height = params.FindOneFloat("height", 1);
+        Float phimax = params.FindOneFloat("phimax", 360);
+        sphere = Sphere::Cone(curTransform[0], Inverse(curTransform[0]), graphicsState.reverseOrientation, height, radius, phimax);
+    } else if (name == "paraboloid") {  // CreateParaboloidShape, paraboloid.cpp:216-226
+        Float radius = params.FindOneFloat("radius", 1);
+        Float zmin = params.FindOneFloat("zmin", 0);
+        Float zmax = params.FindOneFloat("zmax", 1);
+        Float phimax = params.FindOneFloat("phimax", 360);
+        sphere = Sphere::Paraboloid(curTransform[0], Inverse(curTransform[0]), graphicsState.reverseOrientation, radius, zmin, zmax, phimax);
+    } else if (name == "hyperboloid") {  // CreateHyperboloidShape, hyperboloid.cpp:252-261
+        Point3f p1 = params.FindOnePoint3f("p1", Point3f(0, 0, 0));
+        Point3f p2 = params.FindOnePoint3f("p2", Point3f(1, 1, 1));
+        Float phimax = params.FindOneFloat("phimax", 360);
+        sphere = Sphere::Hyperboloid(curTransform[0], Inverse(curTransform[0]), graphicsState.reverseOrientation, p1, p2, phimax);
+    } else Error("Shape \"%s\" is outside this build's closed set (trianglemesh, plymesh, loopsubdiv, heightfield, nurbs, sphere, cylinder, disk, cone, paraboloid, hyperboloid); ignoring.", name.c_str());
     if (!sphere && (!mesh || mesh->nTriangles == 0)) return;
     int mtl = GetMaterialForShape(params);
     params.ReportUnused();
     int firstLight = -1;
     PgLight lightProto;
     memset(&lightProto, 0, sizeof(lightProto));
-    if (graphicsState.areaLight != "") {
+    if (graphicsState.areaLight != "" && sphere && !sphere->CanEmit())
+        Error("Shape \"%s\" cannot be an area light: pbrt-v3 has no Sample() for it and aborts when the light is sampled. The shape is added without emission.", name.c_str());
+    else if (graphicsState.areaLight != "") {
         // MakeAreaLight (api.cpp:752-768) + CreateDiffuseAreaLight (diffuse.cpp:135-146)
         if (graphicsState.areaLight == "area" || graphicsState.areaLight == "diffuse") {
             const ParamSet &lp = graphicsState.areaLightParams;

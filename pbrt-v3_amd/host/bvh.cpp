@@ -39,7 +39,47 @@ std::shared_ptr<Sphere> Sphere::Disk(const Transform &o2w, const Transform &w2o,
     d->thetaMin = d->thetaMax = 0;
     return d;
 }
+std::shared_ptr<Sphere> Sphere::Cone(const Transform &o2w, const Transform &w2o, bool ro, Float h, Float r, Float pm) {  // cone.cpp:43-53
+    auto c = std::make_shared<Sphere>(o2w, w2o, ro, r, -r, r, pm);
+    c->shape = PG_SHAPE_CONE;
+    c->height = h; c->zMin = 0; c->zMax = h;  // ObjectBound: (-r, -r, 0) .. (r, r, height)
+    c->thetaMin = c->thetaMax = 0;
+    return c;
+}
+std::shared_ptr<Sphere> Sphere::Paraboloid(const Transform &o2w, const Transform &w2o, bool ro, Float r, Float z0, Float z1, Float pm) {  // paraboloid.cpp:43-54
+    auto c = std::make_shared<Sphere>(o2w, w2o, ro, r, -r, r, pm);
+    c->shape = PG_SHAPE_PARABOLOID;
+    c->zMin = std::min(z0, z1); c->zMax = std::max(z0, z1);
+    c->thetaMin = c->thetaMax = 0;
+    return c;
+}
+std::shared_ptr<Sphere> Sphere::Hyperboloid(const Transform &o2w, const Transform &w2o, bool ro, Point3f p1, Point3f p2, Float pm) {  // hyperboloid.cpp:43-71
+    const Float radius1 = std::sqrt(p1.x * p1.x + p1.y * p1.y), radius2 = std::sqrt(p2.x * p2.x + p2.y * p2.y);
+    auto c = std::make_shared<Sphere>(o2w, w2o, ro, std::max(radius1, radius2), -1, 1, pm);  // radius = rMax
+    c->shape = PG_SHAPE_HYPERBOLOID;
+    c->zMin = std::min(p1.z, p2.z); c->zMax = std::max(p1.z, p2.z);
+    c->thetaMin = c->thetaMax = 0;
+    // the implicit form ah (x^2 + y^2) - ch z^2 = 1 through both end points, found from a point further along the line
+    if (p2.z == 0.f) std::swap(p1, p2);
+    Point3f pp = p1;
+    Float ah, ch;
+    int guard = 0;
+    do {
+        pp = pp + (p2 - p1) * (Float)2.;
+        const Float xy1 = pp.x * pp.x + pp.y * pp.y, xy2 = p2.x * p2.x + p2.y * p2.y;
+        ah = (1.f / xy1 - (pp.z * pp.z) / (xy1 * p2.z * p2.z)) / (1 - (xy2 * pp.z * pp.z) / (xy1 * p2.z * p2.z));
+        ch = (ah * xy2 - 1) / (p2.z * p2.z);
+    } while ((std::isinf(ah) || std::isnan(ah)) && ++guard < 1000);  // the reference loops for ever on degenerate end points
+    c->p1 = p1; c->p2 = p2; c->ah = ah; c->ch = ch;
+    return c;
+}
 Float Sphere::Area() const {
+    if (shape == PG_SHAPE_CONE) return radius * std::sqrt((height * height) + (radius * radius)) * phiMax / 2;  // cone.cpp:200-203
+    if (shape == PG_SHAPE_PARABOLOID) {  // paraboloid.cpp:204-209
+        const Float radius2 = radius * radius, k = 4 * zMax / radius2;
+        return (radius2 * radius2 * phiMax / (12 * zMax * zMax)) * (std::pow(k * zMax + 1, 1.5f) - std::pow(k * zMin + 1, 1.5f));
+    }
+    if (shape == PG_SHAPE_HYPERBOLOID) return 0;  // only an emitter would read it, and these shapes cannot emit
     if (shape == PG_SHAPE_CYLINDER) return (zMax - zMin) * radius * phiMax;
     if (shape == PG_SHAPE_DISK) return phiMax * 0.5 * (radius * radius - innerRadius * innerRadius);  // 0.5 is a double literal there
     return phiMax * radius * (zMax - zMin);

@@ -236,6 +236,8 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
             g.theta_min = sp->thetaMin; g.theta_max = sp->thetaMax; g.phi_max = sp->phiMax;
             g.reverse_orientation = sp->reverseOrientation; g.swaps_handedness = sp->transformSwapsHandedness;
             g.shape = sp->shape; g.height = sp->height; g.inner_radius = sp->innerRadius; g.area = sp->Area();
+            for (int k = 0; k < 3; ++k) { g.p1[k] = sp->p1[k]; g.p2[k] = sp->p2[k]; }
+            g.ah = sp->ah; g.ch = sp->ch;
             flat->spheres.push_back(g);
             continue;
         }

@@ -28,6 +28,7 @@ class ParamSet {
     std::map<std::string, Item<bool>> bools;
 
     int FindOneInt(const std::string &n, int d) const { auto p = look(ints, n); return p && !p->v.empty() ? p->v[0] : d; }
+    Point3f FindOnePoint3f(const std::string &n, Point3f d) const { auto p = look(point3s, n); return p && p->v.size() >= 3 ? Point3f(p->v[0], p->v[1], p->v[2]) : d; }
     Float FindOneFloat(const std::string &n, Float d) const { auto p = look(floats, n); return p && !p->v.empty() ? p->v[0] : d; }
     bool FindOneBool(const std::string &n, bool d) const { auto p = look(bools, n); return p && !p->v.empty() ? p->v[0] : d; }
     std::string FindOneString(const std::string &n, const std::string &d) const {

@@ -38,11 +38,18 @@ struct Sphere {  // also Cylinder (shapes/cylinder.h:46-77) and Disk (shapes/dis
     Sphere(const Transform &o2w, const Transform &w2o, bool reverseOrientation, Float radius, Float zMin, Float zMax, Float phiMax);
     static std::shared_ptr<Sphere> Cylinder(const Transform &o2w, const Transform &w2o, bool ro, Float radius, Float zMin, Float zMax, Float phiMax);
     static std::shared_ptr<Sphere> Disk(const Transform &o2w, const Transform &w2o, bool ro, Float height, Float radius, Float innerRadius, Float phiMax);
+    // geometry-only quadrics (no Sample() in the reference): shapes/cone.h:46-73, paraboloid.h:46-74, hyperboloid.h:46-76
+    static std::shared_ptr<Sphere> Cone(const Transform &o2w, const Transform &w2o, bool ro, Float height, Float radius, Float phiMax);
+    static std::shared_ptr<Sphere> Paraboloid(const Transform &o2w, const Transform &w2o, bool ro, Float radius, Float z0, Float z1, Float phiMax);
+    static std::shared_ptr<Sphere> Hyperboloid(const Transform &o2w, const Transform &w2o, bool ro, Point3f point1, Point3f point2, Float phiMax);
+    bool CanEmit() const { return shape <= PG_SHAPE_DISK; }
     Transform ObjectToWorld, WorldToObject;
     bool reverseOrientation, transformSwapsHandedness;
     Float radius, zMin, zMax, thetaMin, thetaMax, phiMax;
     int shape = PG_SHAPE_SPHERE;
     Float height = 0, innerRadius = 0;
+    Point3f p1, p2;    // hyperboloid
+    Float ah = 0, ch = 0;
     Bounds3f WorldBound() const;  // shape.cpp:49 over each shape's ObjectBound()
     Float Area() const;           // sphere.cpp:203, cylinder.cpp:206, disk.cpp:124-126
 };

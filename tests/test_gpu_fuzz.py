@@ -146,7 +146,7 @@ def random_scene_ext(seed, res=16, spp=4):
 def random_scene_vol(seed, res=16, spp=4):
     """random_scene_ext under the VolPathIntegrator: homogeneous media (isotropic, forward / backward scattering, one absorbing
     only), the camera inside a medium in every other scene, media bounded by "none" surfaces (a sphere, loose triangles, a
-    sphere inside an instanced object) and medium interfaces on ordinary surfaces."""
+    sphere inside an instanced object), medium interfaces on ordinary surfaces, and the cone / paraboloid / hyperboloid shapes."""
     rng = np.random.default_rng(9000 + seed)
     f = lambda a: " ".join(f"{x:.9g}" for x in np.asarray(a, np.float32).ravel())
     text = random_scene_ext(seed, res, spp)
@@ -164,6 +164,14 @@ def random_scene_vol(seed, res=16, spp=4):
              'AttributeBegin\n MediumInterface "m3" ""\n Shape "trianglemesh" "integer indices" [ 0 1 2 ] "point P" [ %s ]\nAttributeEnd' % f(rng.normal(size=(3, 3)) * 2),
              'ObjectBegin "cloud"\n MediumInterface "m1" "m2"\n Material "none"\n Shape "sphere" "float radius" [ 0.5 ]\n Material "matte"\n Translate 0 0.6 0\n Shape "disk" "float radius" [ 0.4 ]\nObjectEnd',
              'AttributeBegin\n Translate %s\n Scale %.4g 1 -1\n ObjectInstance "cloud"\nAttributeEnd' % (f(rng.normal(size=3) * 1.5), 0.5 + rng.random())]
+    # the intersect-only quadrics: cone, paraboloid, hyperboloid (full / partial, non-uniform transforms, every material class)
+    extra += ['AttributeBegin\n Translate %s\n Rotate %.4g 1 0.2 0\n Scale 1 %.4g 1\n Material "%s"\n Shape "cone" "float radius" [ %.4g ] "float height" [ %.4g ] "float phimax" [ %.4g ]\nAttributeEnd'
+              % (f(rng.normal(size=3) * 1.5), 360 * rng.random(), 0.5 + rng.random(), ["matte", "glass", "mirror", "plastic"][seed % 4], 0.3 + 0.5 * rng.random(), 0.5 + rng.random(), 150 + 210 * rng.random()),
+              'AttributeBegin\n Translate %s\n Rotate %.4g 0 1 0.3\n Material "%s"\n Shape "paraboloid" "float radius" [ %.4g ] "float zmin" [ %.4g ] "float zmax" [ %.4g ]\nAttributeEnd'
+              % (f(rng.normal(size=3) * 1.5), 360 * rng.random(), ["glass", "mirror", "matte", "uber"][seed % 4], 0.3 + 0.5 * rng.random(), 0.2 * rng.random(), 0.5 + 0.5 * rng.random()),
+              'AttributeBegin\n Translate %s\n Rotate %.4g 1 1 0\n ReverseOrientation\n Material "%s"\n Shape "hyperboloid" "point p1" [ %s ] "point p2" [ %s ] "float phimax" [ %.4g ]\nAttributeEnd'
+              % (f(rng.normal(size=3) * 1.5), 360 * rng.random(), ["mirror", "matte", "glass", "substrate"][seed % 4], f(rng.normal(size=3) * 0.4 + [0.5, 0, -0.4]), f(rng.normal(size=3) * 0.4 + [0.3, 0.2, 0.5]),
+                 200 + 160 * rng.random())]
     return text.replace("WorldEnd\n", "\n".join(extra) + "\nWorldEnd\n")
 
 

@@ -84,7 +84,7 @@ def test_split_methods_give_same_image(pkg, oracle, split):
 
 def test_errors_are_reported_not_thrown(pkg):
     before = pkg.host_lib().pbrt_host_error_count()
-    s = pkg.HostScene(text=(MINI % (16, 16, 1)).replace("WorldEnd", 'Shape "hyperboloid"\nLightSource "infinite" "string mapname" "sky.exr"\nTexture "t" "spectrum" "imagemap"\nWorldEnd'))
+    s = pkg.HostScene(text=(MINI % (16, 16, 1)).replace("WorldEnd", 'Shape "curve"\nLightSource "infinite" "string mapname" "sky.exr"\nTexture "t" "spectrum" "imagemap"\nWorldEnd'))
     assert s.desc.n_tris == 3  # unsupported plugins are skipped, the scene still loads (error.cpp:62-102 semantics)
     assert pkg.host_lib().pbrt_host_error_count() >= before + 3
     with pytest.raises(pkg.PbrtGpuError):
