@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 17
+#define PG_ABI_VERSION 18
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -139,7 +139,13 @@ typedef enum PgTextureType {
     PG_TEX_CHECKERBOARD_3D = 4,/* Checkerboard3DTexture,                         checkerboard.h:112-135 */
     PG_TEX_UV = 5,             /* UVTexture (spectrum),                          textures/uv.h:49-66      */
     PG_TEX_BILERP = 6,         /* BilerpTexture,                                 textures/bilerp.h:49-69  */
-    PG_TEX_IMAGEMAP = 7        /* ImageTexture over images[image],               textures/imagemap.h:77-123 */
+    PG_TEX_IMAGEMAP = 7,       /* ImageTexture over images[image],               textures/imagemap.h:77-123 */
+    /* Perlin-noise textures over IdentityMapping3D (w2t) -- FBm / Turbulence of core/texture.cpp:164-246 */
+    PG_TEX_FBM = 8,            /* FBmTexture: octaves, omega,                    textures/fbm.h:49-65     */
+    PG_TEX_WRINKLED = 9,       /* WrinkledTexture: octaves, omega,               textures/wrinkled.h:49-65 */
+    PG_TEX_WINDY = 10,         /* WindyTexture,                                  textures/windy.h:49-64   */
+    PG_TEX_MARBLE = 11,        /* MarbleTexture (spectrum): octaves, omega, noise_scale, variation, textures/marble.h:49-92 */
+    PG_TEX_DOTS = 12           /* DotsTexture over a 2D mapping: tex1 = outsideDot, tex2 = insideDot, textures/dots.h:49-83 */
 } PgTextureType;
 typedef enum PgMappingType {   /* TextureMapping2D, core/texture.h:51-110 */
     PG_MAP_UV = 0, PG_MAP_SPHERICAL = 1, PG_MAP_CYLINDRICAL = 2, PG_MAP_PLANAR = 3
@@ -155,6 +161,8 @@ typedef struct PgTexture {
     int32_t aa_none;           /* checkerboard: AAMethod::None */
     float v00[3], v01[3], v10[3], v11[3]; /* bilerp */
     int32_t image;             /* imagemap: index into PgSceneDesc.images */
+    int32_t octaves;           /* fbm / wrinkled / marble */
+    float omega, noise_scale, variation; /* "roughness"; marble's "scale" and "variation" */
 } PgTexture;
 /* MIPMap<Float> / MIPMap<RGBSpectrum> (core/mipmap.h): the pyramid as its constructor leaves it (power-of-two resampling,
  * box-filtered levels), levels row-major in texels[], 1 or 3 floats per texel; level i is max(1, width >> i) x max(1, height >> i). */
@@ -338,6 +346,7 @@ typedef struct PgSceneDesc {
     const uint32_t *sobol_matrices;
     const uint64_t *vdc_sobol;
     const uint64_t *vdc_sobol_inv;
+    const int32_t *noise_perm;  /* NoisePerm, 512 entries (core/texture.cpp:51-78); NULL unless a noise texture is present */
 } PgSceneDesc;
 
 /* ---- render description -------------------------------------------------- */

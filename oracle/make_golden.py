@@ -257,6 +257,27 @@ QUADRICS3 = ('AttributeBegin\n  Translate 420 0 150\n  Rotate -90 1 0 0\n  Mater
              'ObjectBegin "q3"\n  Material "uber" "rgb Kd" [ 0.3 0.3 0.8 ]\n  Shape "cone" "float radius" [ 30 ] "float height" [ 60 ]\n  Shape "paraboloid" "float radius" [ 30 ] "float zmax" [ 40 ] "float phimax" [ 200 ]\nObjectEnd\n'
              'AttributeBegin\n  Translate 470 330 330\n  Rotate 60 0 1 1\n  Scale 1.5 1 -1\n  ObjectInstance "q3"\nAttributeEnd\n')
 
+NOISE_TEXTURES = ('TransformBegin\n  Scale 0.02 0.02 0.02\n  Texture "n_fbm" "float" "fbm" "integer octaves" [ 5 ] "float roughness" [ 0.6 ]\n'
+                  '  Texture "n_fbms" "spectrum" "fbm"\n  Texture "n_wr" "spectrum" "wrinkled" "integer octaves" [ 6 ] "float roughness" [ 0.4 ]\n'
+                  '  Texture "n_wrf" "float" "wrinkled"\n  Texture "n_windy" "float" "windy"\nTransformEnd\n'
+                  'TransformBegin\n  Rotate 30 0 1 0\n  Scale 0.03 0.05 0.03\n  Texture "n_marble" "spectrum" "marble" "float scale" [ 1.5 ] "float variation" [ 0.35 ] "integer octaves" [ 4 ]\nTransformEnd\n'
+                  'Texture "n_dots" "spectrum" "dots" "float uscale" [ 5 ] "float vscale" [ 7 ] "rgb inside" [ 0.8 0.1 0.1 ] "texture outside" "n_marble"\n'
+                  'Texture "n_dotsf" "float" "dots" "float uscale" [ 4 ] "float vscale" [ 4 ] "float inside" [ 0.02 ] "float outside" [ 0.5 ]\n'
+                  'Texture "n_abs" "spectrum" "scale" "texture tex1" "n_wr" "rgb tex2" [ 0.9 0.7 0.5 ]\n'
+                  'Texture "n_mix" "spectrum" "mix" "texture tex1" "n_marble" "rgb tex2" [ 0.1 0.4 0.1 ] "texture amount" "n_windy"\n')
+
+
+def with_noise_textures(s):
+    s = with_normals(s, uv=True)
+    s = s.replace("WorldBegin\n", "WorldBegin\n" + NOISE_TEXTURES, 1)
+    s = s.replace('Material "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', 'Material "matte" "texture Kd" "n_marble"', 1)        # floor / ceiling / back wall
+    s = s.replace('Material "matte" "rgb Kd" [ 0.12 0.45 0.15 ]', 'Material "matte" "texture Kd" "n_abs" "texture sigma" "n_windy"')
+    s = s.replace('Material "matte" "rgb Kd" [ 0.65 0.05 0.05 ]', 'Material "matte" "texture Kd" "n_mix"')
+    s = s.replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\nMaterial "plastic" "texture Kd" "n_dots" "texture roughness" "n_dotsf" "texture bumpmap" "n_fbm"')
+    s = s.replace("# tall box", 'Material "uber" "texture Kd" "n_fbms" "texture opacity" "n_wr" "texture bumpmap" "n_wrf"\n# tall box')
+    return s
+
+
 def with_alpha(s):
     s = with_normals(s, uv=True)
     tex = ('Texture "a_chk" "float" "checkerboard" "float uscale" [ 4 ] "float vscale" [ 4 ] "float tex1" [ 0 ] "float tex2" [ 1 ]\n'
@@ -626,6 +647,9 @@ SCENES = {
     "mesh_shapes": cornell(40, 40, 8, world_edit=lambda s: with_mesh_shapes(s)),
     # cone / paraboloid / hyperboloid: full and partial, transformed, reversed, specular (error bounds), inside an instance
     "quadrics3": cornell(40, 40, 8, integrator='Integrator "path" "integer maxdepth" [ 6 ]', world_edit=lambda s: s.replace("# short box", QUADRICS3 + "# short box", 1)),
+    # Perlin-noise textures: fbm, wrinkled, windy, marble, dots (float and spectrum; as Kd, sigma, roughness, opacity, bump maps)
+    "tex_noise": cornell(40, 40, 8, world_edit=lambda s: with_noise_textures(s)),
+    "tex_noise_lens": cornell(32, 32, 4, world_edit=lambda s: with_noise_textures(s)).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 10 ] "float focaldistance" [ 700 ]'),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 

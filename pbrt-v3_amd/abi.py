@@ -5,7 +5,7 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 17
+PG_ABI_VERSION = 18
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
 PG_LIGHTS_UNIFORM, PG_LIGHTS_POWER, PG_LIGHTS_SPATIAL = 0, 1, 2
@@ -40,7 +40,8 @@ class PgTexture(C.Structure):
     _fields_ = [("type", C.c_int32), ("is_float", C.c_int32), ("mapping", C.c_int32), ("su", C.c_float), ("sv", C.c_float),
                 ("du", C.c_float), ("dv", C.c_float), ("vs", C.c_float * 3), ("vt", C.c_float * 3), ("w2t", C.c_float * 16),
                 ("tex1", PgTexRef), ("tex2", PgTexRef), ("amount", PgTexRef), ("aa_none", C.c_int32),
-                ("v00", C.c_float * 3), ("v01", C.c_float * 3), ("v10", C.c_float * 3), ("v11", C.c_float * 3), ("image", C.c_int32)]
+                ("v00", C.c_float * 3), ("v01", C.c_float * 3), ("v10", C.c_float * 3), ("v11", C.c_float * 3), ("image", C.c_int32),
+                ("octaves", C.c_int32), ("omega", C.c_float), ("noise_scale", C.c_float), ("variation", C.c_float)]
 
 
 class PgImage(C.Structure):
@@ -104,7 +105,8 @@ class PgSceneDesc(C.Structure):
                 ("n_media", C.c_int32), ("media", C.POINTER(PgMedium)), ("tri_medium_inside", C.POINTER(C.c_int32)), ("tri_medium_outside", C.POINTER(C.c_int32)),
                 ("n_alphas", C.c_int32), ("alphas", C.POINTER(PgAlphaMask)), ("tri_alpha", C.POINTER(C.c_int32)),
                 ("n_env_floats", C.c_int64), ("env_tables", C.POINTER(C.c_float)), ("ewa_lut", C.POINTER(C.c_float)),
-                ("sobol_matrices", C.POINTER(C.c_uint32)), ("vdc_sobol", C.POINTER(C.c_uint64)), ("vdc_sobol_inv", C.POINTER(C.c_uint64))]
+                ("sobol_matrices", C.POINTER(C.c_uint32)), ("vdc_sobol", C.POINTER(C.c_uint64)), ("vdc_sobol_inv", C.POINTER(C.c_uint64)),
+                ("noise_perm", C.POINTER(C.c_int32))]
 
 
 class PgRenderDesc(C.Structure):

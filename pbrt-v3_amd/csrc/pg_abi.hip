@@ -47,7 +47,7 @@ struct DeviceBuffer {
 struct PgScene {
     int device = 0;
     DScene d;
-    DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, textures, textured, images, texels, ewaLut, envTables, alphas, triAlpha, triN, triS, uv, materials, lights, distTable, perms, permSums, primes, media, triMediumIn, triMediumOut, sobolMatrices, vdcSobol, vdcSobolInv;
+    DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, textures, textured, images, texels, ewaLut, envTables, alphas, triAlpha, triN, triS, uv, materials, lights, distTable, perms, permSums, primes, media, triMediumIn, triMediumOut, sobolMatrices, vdcSobol, vdcSobolInv, noisePerm;
     // work buffers (sized on first render, reused)
     int capacity = 0;
     DeviceBuffer qo[4], qd[4], counts, hitsMain, hitInst, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
@@ -281,7 +281,9 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         auto refDepth = [&](const PgTexRef &r, int self) -> int { return r.tex < 0 ? 0 : ((r.tex >= self) ? 1000 : depth[r.tex]); };
         for (int i = 0; i < (int)depth.size(); ++i) {
             const PgTexture &t = desc->textures[i];
-            if (t.type < PG_TEX_SCALE || t.type > PG_TEX_IMAGEMAP) FAIL(PG_ERR_UNSUPPORTED, "texture %d: unknown type %d", i, t.type);
+            if (t.type < PG_TEX_SCALE || t.type > PG_TEX_DOTS) FAIL(PG_ERR_UNSUPPORTED, "texture %d: unknown type %d", i, t.type);
+            if (t.type >= PG_TEX_FBM && !desc->noise_perm) FAIL(PG_ERR_INVALID, "texture %d is a Perlin-noise texture, but the scene has no noise_perm table", i);
+            if (t.type == PG_TEX_MARBLE && t.is_float) FAIL(PG_ERR_UNSUPPORTED, "texture %d: marble is a spectrum texture only (marble.cpp:39-42)", i);
             if (t.type == PG_TEX_IMAGEMAP && (t.image < 0 || t.image >= desc->n_images || desc->images[t.image].is_float != (t.is_float ? 1 : 0)))
                 FAIL(PG_ERR_INVALID, "texture %d: image %d out of range or of the wrong texel type", i, t.image);
             int dmax = std::max(refDepth(t.tex1, i), std::max(refDepth(t.tex2, i), refDepth(t.amount, i)));
@@ -464,6 +466,12 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         }
         d.media = (const PgMedium *)s->media.p; d.triMediumIn = (const int *)s->triMediumIn.p; d.triMediumOut = (const int *)s->triMediumOut.p;
     }
+    if (desc->noise_perm) {  // NoisePerm of the Perlin-noise textures
+        for (int i = 0; i < 512; ++i) if (desc->noise_perm[i] < 0 || desc->noise_perm[i] > 255) FAIL(PG_ERR_INVALID, "noise_perm[%d] = %d is not a byte", i, desc->noise_perm[i]);
+        HIP_TRY_S(s->noisePerm.alloc(sizeof(int) * 512));
+        HIP_TRY_S(hipMemcpy(s->noisePerm.p, desc->noise_perm, s->noisePerm.bytes, hipMemcpyHostToDevice));
+    }
+    d.noisePerm = (const int *)s->noisePerm.p;
     if (desc->sobol_matrices) {  // SobolSampler tables
         if (!desc->vdc_sobol || !desc->vdc_sobol_inv) FAIL(PG_ERR_INVALID, "sobol_matrices without vdc_sobol / vdc_sobol_inv");
         HIP_TRY_S(s->sobolMatrices.alloc(sizeof(uint32_t) * 1024 * 52));

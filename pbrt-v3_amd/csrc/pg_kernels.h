@@ -49,6 +49,7 @@ struct DScene {
     const float *ewaLut;                 // MIPMap::weightLut (128)
     const float *envTables;              // the infinite lights' Distribution2D tables (PgLight.env_table)
     const PgTexture *textures;           // texture nodes
+    const int *noisePerm;                // NoisePerm (512 entries) of the Perlin-noise textures, or nullptr
     const PgTexturedMaterial *textured;  // materials evaluated per hit (PG_MAT_TEXTURED)
     int hasTextured;
     const PgMedium *media;               // HomogeneousMedium table; triMediumIn/Out[k] = the primitive's MediumInterface (-1 = none), or nullptr

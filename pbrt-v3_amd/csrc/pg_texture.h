@@ -155,6 +155,110 @@ PG_DEV int tex_checker3d(const PgTexture &t, const TexHit &h) {  // checkerboard
     const V3 p = m4_point(t.w2t, h.p);
     return (((int)floorf(p.x) + (int)floorf(p.y) + (int)floorf(p.z)) % 2 == 0) ? 0 : 1;
 }
+// ---- Perlin noise (core/texture.cpp:164-252): Noise, FBm, Turbulence over the reference's permutation table -----------------
+PG_DEV float noise_grad(const int *perm, int x, int y, int z, float dx, float dy, float dz) {  // texture.cpp:194-200
+    int h = perm[perm[perm[x] + y] + z];
+    h &= 15;
+    const float u = h < 8 || h == 12 || h == 13 ? dx : dy;
+    const float v = h < 4 || h == 12 || h == 13 ? dy : dz;
+    return ((h & 1) ? -u : u) + ((h & 2) ? -v : v);
+}
+PG_DEV float noise_weight(float t) {  // texture.cpp:202-206
+    const float t3 = t * t * t;
+    const float t4 = t3 * t;
+    return 6 * t4 * t - 15 * t4 + 10 * t3;
+}
+PG_DEV float noise3(const int *perm, float x, float y, float z) {  // texture.cpp:164-191
+    int ix = (int)floorf(x), iy = (int)floorf(y), iz = (int)floorf(z);
+    const float dx = x - ix, dy = y - iy, dz = z - iz;
+    ix &= 255; iy &= 255; iz &= 255;
+    const float w000 = noise_grad(perm, ix, iy, iz, dx, dy, dz);
+    const float w100 = noise_grad(perm, ix + 1, iy, iz, dx - 1, dy, dz);
+    const float w010 = noise_grad(perm, ix, iy + 1, iz, dx, dy - 1, dz);
+    const float w110 = noise_grad(perm, ix + 1, iy + 1, iz, dx - 1, dy - 1, dz);
+    const float w001 = noise_grad(perm, ix, iy, iz + 1, dx, dy, dz - 1);
+    const float w101 = noise_grad(perm, ix + 1, iy, iz + 1, dx - 1, dy, dz - 1);
+    const float w011 = noise_grad(perm, ix, iy + 1, iz + 1, dx, dy - 1, dz - 1);
+    const float w111 = noise_grad(perm, ix + 1, iy + 1, iz + 1, dx - 1, dy - 1, dz - 1);
+    const float wx = noise_weight(dx), wy = noise_weight(dy), wz = noise_weight(dz);
+    const float x00 = plerp(wx, w000, w100), x10 = plerp(wx, w010, w110), x01 = plerp(wx, w001, w101), x11 = plerp(wx, w011, w111);
+    const float y0 = plerp(wy, x00, x10), y1 = plerp(wy, x01, x11);
+    return plerp(wz, y0, y1);
+}
+PG_DEV float smooth_step(float lo, float hi, float value) {  // texture.cpp:41-44
+    const float v = clampf((value - lo) / (hi - lo), 0, 1);
+    return v * v * (-2 * v + 3);
+}
+PG_DEV float noise_octaves(V3 dpdx, V3 dpdy, int maxOctaves) {  // texture.cpp:210-213
+    const float len2 = pmax(lensq(dpdx), lensq(dpdy));
+    const float n = -1 - .5f * log2_pbrt(len2);
+    return n < 0 ? 0.f : (n > maxOctaves ? (float)maxOctaves : n);
+}
+// FBm (texture.cpp:208-225) with TURB = false, Turbulence (:227-252) with TURB = true
+template <bool TURB>
+PG_DEV float noise_sum(const int *perm, V3 p, V3 dpdx, V3 dpdy, float omega, int maxOctaves) {
+    const float n = noise_octaves(dpdx, dpdy, maxOctaves);
+    const int nInt = (int)floorf(n);
+    float sum = 0, lambda = 1, o = 1;
+    for (int i = 0; i < nInt; ++i) {
+        const float v = noise3(perm, lambda * p.x, lambda * p.y, lambda * p.z);
+        sum += o * (TURB ? fabsf(v) : v);
+        lambda *= 1.99f;
+        o *= omega;
+    }
+    const float nPartial = n - nInt;
+    const float last = noise3(perm, lambda * p.x, lambda * p.y, lambda * p.z);
+    if (!TURB) return sum + o * smooth_step(.3f, .7f, nPartial) * last;
+    sum += o * plerp(smooth_step(.3f, .7f, nPartial), 0.2f, fabsf(last));
+    for (int i = nInt; i < maxOctaves; ++i) {
+        sum += o * 0.2f;
+        o *= omega;
+    }
+    return sum;
+}
+// FBmTexture / WrinkledTexture / WindyTexture::Evaluate (fbm.h:56-60, wrinkled.h:56-60, windy.h:55-61) over IdentityMapping3D
+PG_DEV float tex_noise(const DScene &sc, const PgTexture &t, const TexHit &h) {
+    const V3 P = m4_point(t.w2t, h.p), dpdx = m4_vec(t.w2t, h.dpdx), dpdy = m4_vec(t.w2t, h.dpdy);
+    if (t.type == PG_TEX_FBM) return noise_sum<false>(sc.noisePerm, P, dpdx, dpdy, t.omega, t.octaves);
+    if (t.type == PG_TEX_WRINKLED) return noise_sum<true>(sc.noisePerm, P, dpdx, dpdy, t.omega, t.octaves);
+    const float windStrength = noise_sum<false>(sc.noisePerm, P * .1f, dpdx * .1f, dpdy * .1f, .5f, 3);
+    const float waveHeight = noise_sum<false>(sc.noisePerm, P, dpdx, dpdy, .5f, 6);
+    return fabsf(windStrength) * waveHeight;
+}
+PG_DEV Spec tex_marble(const DScene &sc, const PgTexture &t, const TexHit &h) {  // marble.h:60-91
+    V3 p = m4_point(t.w2t, h.p);
+    const V3 dpdx = m4_vec(t.w2t, h.dpdx), dpdy = m4_vec(t.w2t, h.dpdy);
+    p = p * t.noise_scale;
+    const float marble = p.y + t.variation * noise_sum<false>(sc.noisePerm, p, dpdx * t.noise_scale, dpdy * t.noise_scale, t.omega, t.octaves);
+    float tt = .5f + .5f * (float)sin((double)marble);
+    const float c[9][3] = {{.58f, .58f, .6f}, {.58f, .58f, .6f}, {.58f, .58f, .6f}, {.5f, .5f, .5f}, {.6f, .59f, .58f},
+                           {.58f, .58f, .6f}, {.58f, .58f, .6f}, {.2f, .2f, .33f}, {.58f, .58f, .6f}};
+    int first = (int)floorf(tt * 6);  // NSEG = 6
+    if (first > 1) first = 1;
+    tt = (tt * 6 - first);
+    const Spec c0 = sp_of(c[first]), c1 = sp_of(c[first + 1]), c2 = sp_of(c[first + 2]), c3 = sp_of(c[first + 3]);
+    Spec s0 = c0 * (1.f - tt) + c1 * tt;  // de Casteljau
+    Spec s1 = c1 * (1.f - tt) + c2 * tt;
+    const Spec s2 = c2 * (1.f - tt) + c3 * tt;
+    s0 = s0 * (1.f - tt) + s1 * tt;
+    s1 = s1 * (1.f - tt) + s2 * tt;
+    return (s0 * (1.f - tt) + s1 * tt) * 1.5f;
+}
+// DotsTexture::Evaluate up to the choice of its operand (dots.h:58-79): true = insideDot
+PG_DEV bool tex_dots_inside(const DScene &sc, const PgTexture &t, const TexHit &h) {
+    float st[2], dstdx[2], dstdy[2];
+    tex_map2d(t, h, st, dstdx, dstdy);
+    const int sCell = (int)floorf(st[0] + .5f), tCell = (int)floorf(st[1] + .5f);
+    if (noise3(sc.noisePerm, sCell + .5f, tCell + .5f, .5f) > 0) {
+        const float radius = .35f;
+        const float maxShift = 0.5f - radius;
+        const float sCenter = sCell + maxShift * noise3(sc.noisePerm, sCell + 1.5f, tCell + 2.8f, .5f);
+        const float tCenter = tCell + maxShift * noise3(sc.noisePerm, sCell + 4.5f, tCell + 9.8f, .5f);
+        const float ds = st[0] - sCenter, dt = st[1] - tCenter;
+        if (ds * ds + dt * dt < radius * radius) return true;
+    }
+    return false;
+}
 template <int D> struct TexEval {
     static PG_DEV_CALL float f(const DScene &sc, const PgTexRef &r, const TexHit &h) {
         if (r.tex < 0) return r.v[0];
@@ -176,6 +280,8 @@ template <int D> struct TexEval {
             tex_map2d(t, h, st, dx, dy);
             return (1 - st[0]) * (1 - st[1]) * t.v00[0] + (1 - st[0]) * (st[1]) * t.v01[0] + (st[0]) * (1 - st[1]) * t.v10[0] + (st[0]) * (st[1]) * t.v11[0];
         }
+        case PG_TEX_FBM: case PG_TEX_WRINKLED: case PG_TEX_WINDY: return tex_noise(sc, t, h);
+        case PG_TEX_DOTS: return tex_dots_inside(sc, t, h) ? TexEval<D - 1>::f(sc, t.tex2, h) : TexEval<D - 1>::f(sc, t.tex1, h);
         case PG_TEX_CHECKERBOARD_3D: return tex_checker3d(t, h) == 0 ? TexEval<D - 1>::f(sc, t.tex1, h) : TexEval<D - 1>::f(sc, t.tex2, h);
         case PG_TEX_CHECKERBOARD_2D: {  // checkerboard.h:63-103
             float area2 = 0;
@@ -213,6 +319,9 @@ template <int D> struct TexEval {
             return sp_of(t.v00) * ((1 - st[0]) * (1 - st[1])) + sp_of(t.v01) * ((1 - st[0]) * (st[1])) + sp_of(t.v10) * ((st[0]) * (1 - st[1])) +
                    sp_of(t.v11) * ((st[0]) * (st[1]));
         }
+        case PG_TEX_FBM: case PG_TEX_WRINKLED: case PG_TEX_WINDY: return sp(tex_noise(sc, t, h));
+        case PG_TEX_MARBLE: return tex_marble(sc, t, h);
+        case PG_TEX_DOTS: return tex_dots_inside(sc, t, h) ? TexEval<D - 1>::s(sc, t.tex2, h) : TexEval<D - 1>::s(sc, t.tex1, h);
         case PG_TEX_CHECKERBOARD_3D: return tex_checker3d(t, h) == 0 ? TexEval<D - 1>::s(sc, t.tex1, h) : TexEval<D - 1>::s(sc, t.tex2, h);
         case PG_TEX_CHECKERBOARD_2D: {
             float area2 = 0;

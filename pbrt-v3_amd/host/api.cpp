@@ -91,6 +91,7 @@ struct RenderOptions {
     std::map<std::string, int> namedMedia;
     std::map<std::string, int> imageCache;
     bool haveScatteringMedia = false;
+    bool usesNoise = false;  // a Perlin-noise texture was declared: the scene carries NoisePerm
 };
 enum class APIState { Uninitialized, OptionsBlock, WorldBlock };
 APIState currentApiState = APIState::Uninitialized;
@@ -751,8 +752,22 @@ void pbrtTexture(const std::string &name, const std::string &type, const std::st
             if (isFloat) { dst[k][0] = params.FindOneFloat(names[k], defs[k]); dst[k][1] = dst[k][2] = 0; }
             else { RGB v = params.FindOneSpectrum(names[k], RGB{{defs[k], defs[k], defs[k]}}); for (int c = 0; c < 3; ++c) dst[k][c] = v.c[c]; }
         }
+    } else if (texname == "fbm" || texname == "wrinkled" || texname == "windy" || texname == "marble") {
+        // fbm.cpp:39-54, wrinkled.cpp:39-55, windy.cpp:39-52, marble.cpp:39-54: all over IdentityMapping3D(tex2world)
+        if (texname == "marble" && isFloat) { params.ReportUnused(); return; }  // CreateMarbleFloatTexture returns nullptr: no texture is registered
+        t.type = texname == "fbm" ? PG_TEX_FBM : (texname == "wrinkled" ? PG_TEX_WRINKLED : (texname == "windy" ? PG_TEX_WINDY : PG_TEX_MARBLE));
+        const Matrix4x4 &m = curTransform[0].GetMatrix();
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) t.w2t[4 * r + c] = m.m[r][c];
+        if (texname != "windy") { t.octaves = params.FindOneInt("octaves", 8); t.omega = params.FindOneFloat("roughness", .5f); }
+        if (texname == "marble") { t.noise_scale = params.FindOneFloat("scale", 1.f); t.variation = params.FindOneFloat("variation", .2f); }
+        renderOptions->usesNoise = true;
+    } else if (texname == "dots") {  // dots.cpp:39-100: the constructor's (outsideDot, insideDot) receive "inside" and "outside", in that order
+        t.type = PG_TEX_DOTS;
+        readMapping2D(params, curTransform[0], &t);
+        t.tex1 = operand("inside", 1.f); t.tex2 = operand("outside", 0.f);
+        renderOptions->usesNoise = true;
     } else {
-        Error("Texture \"%s\": class \"%s\" is outside this build's closed set (constant, scale, mix, checkerboard, uv, bilerp, imagemap); ignoring.",
+        Error("Texture \"%s\": class \"%s\" is outside this build's closed set (constant, scale, mix, checkerboard, uv, bilerp, imagemap, fbm, wrinkled, windy, marble, dots); ignoring.",
               name.c_str(), texname.c_str());
         return;
     }
@@ -1184,6 +1199,7 @@ static Scene *MakeScene() {
     scene->textures = ro.textures;
     scene->textured = ro.textured;
     scene->images = ro.images;
+    scene->usesNoise = ro.usesNoise;
     scene->texels = ro.texels;
     scene->envTables = ro.envTables;
     scene->alphas = ro.alphas;

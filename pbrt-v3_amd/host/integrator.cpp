@@ -354,6 +354,7 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     d.ewa_lut = flat->ewaLut;
     d.n_env_floats = (int64_t)flat->envTables.size(); d.env_tables = flat->envTables.data();
     d.n_media = (int)flat->media.size(); d.media = flat->media.data();
+    if (scene.usesNoise) d.noise_perm = GetNoisePermutation();
     if (sampler->sobol) { const SobolTables &t = GetSobolTables(); d.sobol_matrices = t.matrices32; d.vdc_sobol = t.vdc; d.vdc_sobol_inv = t.vdcInv; }
     d.tri_medium_inside = flat->triMediumInside.empty() ? nullptr : flat->triMediumInside.data();
     d.tri_medium_outside = flat->triMediumOutside.empty() ? nullptr : flat->triMediumOutside.data();

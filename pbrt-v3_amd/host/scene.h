@@ -123,6 +123,7 @@ struct Scene {  // core/scene.h:50-80
     std::vector<float> envTables;
     std::vector<PgAlphaMask> alphas;
     std::vector<PgMedium> media;
+    bool usesNoise = false;
     Bounds3f worldBound;
 };
 
@@ -188,6 +189,7 @@ HaltonSampler *CreateSobolSampler(const ParamSet &params, const int sampleBounds
 // The Sobol' generator matrices embedded into this library (host/sobol.cpp, data/sobol_tables.bin; core/sobolmatrices.h:49-52)
 struct SobolTables { const uint32_t *matrices32; const uint64_t *vdc, *vdcInv; int nDims, matrixSize, vdcRows, vdcInvRows; };
 const SobolTables &GetSobolTables();
+const int32_t *GetNoisePermutation();  // 512 entries
 bool GetMediumScatteringProperties(const std::string &name, Float sigma_a[3], Float sigma_prime_s[3]);  // core/medium.cpp:181-191
 HaltonSampler *CreateHaltonSampler(const ParamSet &params, const int sampleBounds[4]);  // halton.cpp:133-139
 // lowdiscrepancy.cpp:2490-2504 with the default-seeded RNG (halton.cpp:69-72).

@@ -26,6 +26,13 @@ __asm__(".section .rodata\n"
         ".global pg_presets_blob_end\n"
         "pg_presets_blob_end:\n"
         ".previous\n");
+__asm__(".section .rodata\n"
+        ".balign 4\n"
+        ".global pg_noise_blob\n"
+        "pg_noise_blob:\n"
+        ".incbin \"" PG_NOISE_BIN "\"\n"
+        ".previous\n");
+extern "C" const int32_t pg_noise_blob[];
 extern "C" const unsigned char pg_sobol_blob[], pg_sobol_blob_end[];
 extern "C" const char pg_presets_blob[], pg_presets_blob_end[];
 
@@ -54,6 +61,7 @@ const SobolTables &GetSobolTables() {
     }();
     return t;
 }
+const int32_t *GetNoisePermutation() { return pg_noise_blob; }  // NoisePerm, core/texture.cpp:51-78 (data/noise_perm.bin)
 // GetMediumScatteringProperties, core/medium.cpp:181-191
 bool GetMediumScatteringProperties(const std::string &name, Float sigma_a[3], Float sigma_prime_s[3]) {
     const std::string text(pg_presets_blob, pg_presets_blob_end);

@@ -172,6 +172,18 @@ def random_scene_vol(seed, res=16, spp=4):
               'AttributeBegin\n Translate %s\n Rotate %.4g 1 1 0\n ReverseOrientation\n Material "%s"\n Shape "hyperboloid" "point p1" [ %s ] "point p2" [ %s ] "float phimax" [ %.4g ]\nAttributeEnd'
               % (f(rng.normal(size=3) * 1.5), 360 * rng.random(), ["mirror", "matte", "glass", "substrate"][seed % 4], f(rng.normal(size=3) * 0.4 + [0.5, 0, -0.4]), f(rng.normal(size=3) * 0.4 + [0.3, 0.2, 0.5]),
                  200 + 160 * rng.random())]
+    # Perlin-noise textures (fbm, wrinkled, windy, marble, dots) as reflectances, float parameters and bump maps
+    extra += ['TransformBegin\n Scale %.4g %.4g %.4g\n Texture "vz_fbm" "float" "fbm" "integer octaves" [ %d ] "float roughness" [ %.4g ]\n Texture "vz_wr" "spectrum" "wrinkled"\n'
+              ' Texture "vz_windy" "float" "windy"\n Texture "vz_marble" "spectrum" "marble" "float scale" [ %.4g ] "float variation" [ %.4g ]\nTransformEnd'
+              % (1 + 3 * rng.random(), 1 + 3 * rng.random(), 1 + 3 * rng.random(), 2 + seed % 6, 0.3 + 0.4 * rng.random(), 0.5 + 2 * rng.random(), 0.1 + 0.4 * rng.random()),
+              'Texture "vz_dots" "spectrum" "dots" "float uscale" [ %.4g ] "float vscale" [ %.4g ] "texture inside" "vz_marble" "rgb outside" [ %s ]'
+              % (2 + 6 * rng.random(), 2 + 6 * rng.random(), f(rng.random(3))),
+              'AttributeBegin\n Translate %s\n Material "plastic" "texture Kd" "vz_dots" "texture roughness" "vz_windy" "texture bumpmap" "vz_fbm"\n Shape "sphere" "float radius" [ %.4g ]\nAttributeEnd'
+              % (f(rng.normal(size=3) * 1.5), 0.4 + 0.5 * rng.random()),
+              'Material "matte" "texture Kd" "vz_wr" "texture sigma" "vz_windy"\nShape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ] "point P" [ %s ] "float uv" [ 0 0 3 0 3 3 0 3 ]'
+              % f(rng.normal(size=(4, 3)) * 1.5),
+              'Material "uber" "texture Kd" "vz_marble" "texture opacity" "vz_wr" "texture bumpmap" "vz_windy"\nShape "trianglemesh" "integer indices" [ 0 1 2 ] "point P" [ %s ]'
+              % f(rng.normal(size=(3, 3)) * 1.5)]
     return text.replace("WorldEnd\n", "\n".join(extra) + "\nWorldEnd\n")
 
 

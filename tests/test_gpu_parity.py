@@ -28,7 +28,8 @@ def test_golden_images(gpu, oracle, name):
     correctly rounded; the device evaluates them in double and rounds once).  A last-bit difference there can, a few
     bounces later, tip one discrete event of one sample (a ray passing an edge): such a pixel is accepted only when the
     CPU oracle built with correctly rounded libm (liboracle_crlibm.so) reproduces the device's value exactly, and at most
-    2 pixels per image."""
+    2 pixels per image -- or 0.5 % of the pixels in the scenes that bump-map with Perlin-noise textures, where Material::Bump
+    divides a last-bit difference of the displacement (logf in FBm's octave count) by du = 0.0005."""
     scene = gpu.HostScene(os.path.join(GOLD, name + ".pbrt"))
     img, cn = gpu.render_scene(scene)
     ref = gpu.read_pfm(os.path.join(GOLD, name + ".pfm"))
@@ -36,7 +37,8 @@ def test_golden_images(gpu, oracle, name):
     bad = err.max(axis=2) > TOL
     if bad.any():
         cr_img, _ = oracle.render_image(scene, cr_libm=True)
-        assert bad.sum() <= 2 and np.array_equal(img[bad], cr_img[bad]), f"max rel err {err.max():.3e} at {np.argwhere(bad)[:4].tolist()}"
+        allowed = max(2, int(0.005 * bad.size)) if name.startswith("tex_noise") else 2
+        assert bad.sum() <= allowed and np.array_equal(img[bad], cr_img[bad]), f"max rel err {err.max():.3e} at {np.argwhere(bad)[:4].tolist()}"
         err[bad] = 0
     # most pixels are bit-identical, the rest differ in the last ulps only (libm's last bit: every pixel lit through an
     # environment map or a spherical mapping goes through acosf / atan2f)

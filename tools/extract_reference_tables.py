@@ -4,6 +4,8 @@
 pbrt-v3_amd/data/cie_tables.bin: the CIE 1931 colour matching functions at 1 nm from 360 to 830 nm (core/spectrum.cpp:190-...:
 CIE_X, CIE_Y, CIE_Z, CIE_lambda; 471 floats each, in that order), which turn "spectrum" / "blackbody" parameters into RGB.
 
+pbrt-v3_amd/data/noise_perm.bin: the 512-entry permutation table of the Perlin noise functions (core/texture.cpp:51-78; int32).
+
 pbrt-v3_amd/data/sobol_tables.bin: the Sobol' generator matrices the SobolSampler reads (core/sobolmatrices.h:49-52:
 SobolMatrices32, VdCSobolMatrices, VdCSobolMatricesInv -- Gruenschloss' published tables, numeric constants of the sequence
 itself like the table of primes).  They are taken from the read-only data section of the reference binary built by
@@ -21,6 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref", "pbrt_oracle")
 OUT = os.path.join(ROOT, "pbrt-v3_amd", "data", "sobol_tables.bin")
 OUT_CIE = os.path.join(ROOT, "pbrt-v3_amd", "data", "cie_tables.bin")
+OUT_NOISE = os.path.join(ROOT, "pbrt-v3_amd", "data", "noise_perm.bin")
 
 
 def main():
@@ -30,9 +33,9 @@ def main():
     for line in subprocess.run(["nm", "-S", "-C", REF], capture_output=True, text=True, check=True).stdout.splitlines():
         parts = line.split(None, 3)
         if len(parts) == 4 and parts[3] in ("pbrt::SobolMatrices32", "pbrt::VdCSobolMatrices", "pbrt::VdCSobolMatricesInv", "pbrt::CIE_X", "pbrt::CIE_Y",
-                                              "pbrt::CIE_Z", "pbrt::CIE_lambda"):
+                                              "pbrt::CIE_Z", "pbrt::CIE_lambda", "pbrt::NoisePerm"):
             syms[parts[3].split("::")[1]] = (int(parts[0], 16), int(parts[1], 16))
-    assert len(syms) == 7, syms
+    assert len(syms) == 8, syms
     # map virtual addresses to file offsets through the section headers
     secs = []
     for line in subprocess.run(["readelf", "-S", "-W", REF], capture_output=True, text=True, check=True).stdout.splitlines():
@@ -62,6 +65,10 @@ def main():
     with open(OUT_CIE, "wb") as fo:
         for c in cie: fo.write(c)
     print(OUT_CIE, os.path.getsize(OUT_CIE), "bytes")
+    perm = read("NoisePerm")  # Perlin's permutation of 0..255, stored twice (core/texture.cpp:51-78)
+    assert len(perm) == 512 * 4
+    open(OUT_NOISE, "wb").write(perm)
+    print(OUT_NOISE, os.path.getsize(OUT_NOISE), "bytes")
 
 
 if __name__ == "__main__":
