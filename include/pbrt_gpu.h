@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 18
+#define PG_ABI_VERSION 19
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -211,8 +211,12 @@ typedef enum PgLightType {
     PG_LIGHT_POINT = 1,
     PG_LIGHT_SPOT = 2,
     PG_LIGHT_DISTANT = 3,
-    PG_LIGHT_INFINITE = 4 /* InfiniteAreaLight with constant radiance (lights/infinite.cpp, no "mapname") */
+    PG_LIGHT_INFINITE = 4, /* InfiniteAreaLight (lights/infinite.cpp), constant or over an environment map */
+    PG_LIGHT_PROJECTION = 5, /* ProjectionLight (lights/projection.cpp:44-101): a point light behind a slide */
+    PG_LIGHT_GONIO = 6     /* GonioPhotometricLight (lights/goniometric.h:50-88): a point light with a measured distribution */
 } PgLightType;
+/* Light::flags & (DeltaPosition | DeltaDirection), light.h:55-58 */
+#define PG_LIGHT_IS_DELTA(type) ((type) == PG_LIGHT_POINT || (type) == PG_LIGHT_SPOT || (type) == PG_LIGHT_DISTANT || (type) == PG_LIGHT_PROJECTION || (type) == PG_LIGHT_GONIO)
 
 typedef struct PgLight {
     int32_t type;      /* PgLightType                                               */
@@ -233,6 +237,12 @@ typedef struct PgLight {
     int32_t env_image, env_nu, env_nv;
     int64_t env_table;
     float env_power[3];
+    /* projection / goniometric: pos = pLight, L = I * scale, w2l = upper 3x3 of WorldToLight; env_image = the MIPMap of
+     * "mapname" (-1: no map, the light is uniform inside its frustum / sphere), env_power = its Lookup((.5, .5), .5) (or 1);
+     * projection only: lightProjection (row-major), screenBounds (x0, y0, x1, y1), hither, cos_total_width (projection.cpp:44-69) */
+    float proj[16];
+    float screen[4];
+    float hither;
 } PgLight;
 
 typedef enum PgLightStrategy {

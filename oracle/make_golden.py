@@ -278,6 +278,11 @@ def with_noise_textures(s):
     return s
 
 
+IMAGE_LIGHTS = ('AttributeBegin\n  Translate 278 500 100\n  Rotate 80 1 0 0\n  Rotate 20 0 0 1\n  LightSource "projection" "rgb I" [ 400000 400000 400000 ] "float fov" [ 70 ] "string mapname" "img_rgb.png"\nAttributeEnd\n'
+                'AttributeBegin\n  Translate 100 300 400\n  Rotate -100 1 0.2 0\n  LightSource "projection" "rgb I" [ 90000 60000 30000 ] "rgb scale" [ 1 2 3 ] "float fov" [ 40 ]\nAttributeEnd\n'
+                'AttributeBegin\n  Translate 450 250 250\n  Rotate 30 0 1 1\n  LightSource "goniometric" "rgb I" [ 150000 150000 200000 ] "string mapname" "img_color.pfm"\nAttributeEnd\n'
+                'AttributeBegin\n  Translate 278 100 450\n  LightSource "goniometric" "rgb I" [ 20000 30000 20000 ]\nAttributeEnd\n')
+
 def with_alpha(s):
     s = with_normals(s, uv=True)
     tex = ('Texture "a_chk" "float" "checkerboard" "float uscale" [ 4 ] "float vscale" [ 4 ] "float tex1" [ 0 ] "float tex2" [ 1 ]\n'
@@ -650,6 +655,10 @@ SCENES = {
     # Perlin-noise textures: fbm, wrinkled, windy, marble, dots (float and spectrum; as Kd, sigma, roughness, opacity, bump maps)
     "tex_noise": cornell(40, 40, 8, world_edit=lambda s: with_noise_textures(s)),
     "tex_noise_lens": cornell(32, 32, 4, world_edit=lambda s: with_noise_textures(s)).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 10 ] "float focaldistance" [ 700 ]'),
+    # ProjectionLight and GonioPhotometricLight: with and without a map, rotated, under the power strategy, through a medium
+    "light_projection": cornell(32, 32, 8, world_edit=lambda s: s.replace("# light\nAttributeBegin", IMAGE_LIGHTS + "# light\nAttributeBegin")),
+    "light_gonio_power": cornell(32, 32, 8, integrator='Integrator "volpath" "integer maxdepth" [ 4 ] "string lightsamplestrategy" "power"',
+                                 world_edit=lambda s: with_fog(s).replace("# light\nAttributeBegin", IMAGE_LIGHTS + "# light\nAttributeBegin").replace("  AreaLightSource", "#  AreaLightSource")),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
 }
 

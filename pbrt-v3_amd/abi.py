@@ -5,7 +5,7 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 18
+PG_ABI_VERSION = 19
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
 PG_LIGHTS_UNIFORM, PG_LIGHTS_POWER, PG_LIGHTS_SPATIAL = 0, 1, 2
@@ -29,7 +29,7 @@ class PgLight(C.Structure):
     _fields_ = [("type", C.c_int32), ("prim", C.c_int32), ("L", C.c_float * 3), ("two_sided", C.c_int32), ("area", C.c_float),
                 ("pos", C.c_float * 3), ("w2l", C.c_float * 9), ("cos_total_width", C.c_float), ("cos_falloff_start", C.c_float),
                 ("world_radius", C.c_float), ("l2w", C.c_float * 9), ("env_image", C.c_int32), ("env_nu", C.c_int32), ("env_nv", C.c_int32),
-                ("env_table", C.c_int64), ("env_power", C.c_float * 3)]
+                ("env_table", C.c_int64), ("env_power", C.c_float * 3), ("proj", C.c_float * 16), ("screen", C.c_float * 4), ("hither", C.c_float)]
 
 
 class PgTexRef(C.Structure):

@@ -396,8 +396,17 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
                 l.env_table < 0 || l.env_table + need > desc->n_env_floats || !desc->env_tables)
                 FAIL(PG_ERR_INVALID, "light %d: infinite light without a valid radiance map / sampling distribution", i);
         }
+    bool anyImageLight = false;  // projection / goniometric lights: sampled by the general shading kernels only
     for (int i = 0; i < desc->n_lights; ++i)
-        if (desc->lights[i].type < PG_LIGHT_AREA || desc->lights[i].type > PG_LIGHT_INFINITE) FAIL(PG_ERR_UNSUPPORTED, "light %d: unknown type %d", i, desc->lights[i].type);
+        if (desc->lights[i].type == PG_LIGHT_PROJECTION || desc->lights[i].type == PG_LIGHT_GONIO) {
+            anyImageLight = true;
+            const PgLight &l = desc->lights[i];
+            if (l.env_image >= desc->n_images || (l.env_image >= 0 && (!desc->images || desc->images[l.env_image].is_float)))
+                FAIL(PG_ERR_INVALID, "light %d: map %d out of range or not an RGB image", i, l.env_image);
+            if (l.type == PG_LIGHT_PROJECTION && !(l.screen[2] > l.screen[0] && l.screen[3] > l.screen[1])) FAIL(PG_ERR_INVALID, "light %d: empty projection screen bounds", i);
+        }
+    for (int i = 0; i < desc->n_lights; ++i)
+        if (desc->lights[i].type < PG_LIGHT_AREA || desc->lights[i].type > PG_LIGHT_GONIO) FAIL(PG_ERR_UNSUPPORTED, "light %d: unknown type %d", i, desc->lights[i].type);
         else if (desc->lights[i].type == PG_LIGHT_AREA && (desc->lights[i].prim < 0 || desc->lights[i].prim >= nt))
             FAIL(PG_ERR_INVALID, "light %d has no emitting triangle", i);
     HIP_TRY_S(s->materials.alloc(sizeof(PgMaterial) * (size_t)desc->n_materials));
@@ -487,7 +496,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     d.hasTextured = anyTextured ? 1 : 0;
     {  // PG_FORCE_EXT=1 runs the general kernels on scenes that do not need them (tests: both paths agree bit for bit)
         const char *fe = getenv("PG_FORCE_EXT");
-        d.ext = (d.hasTextured || d.nSpheres > 0 || d.nInstances > 0 || d.hasInfinite || anyLobeMaterial || (fe && atoi(fe) != 0)) ? 1 : 0;
+        d.ext = (d.hasTextured || d.nSpheres > 0 || d.nInstances > 0 || d.hasInfinite || anyImageLight || anyLobeMaterial || (fe && atoi(fe) != 0)) ? 1 : 0;
     } d.uv = (const float *)s->uv.p;
     d.triN = (const float4 *)s->triN.p; d.triS = (const float4 *)s->triS.p;
     d.materials = (const PgMaterial *)s->materials.p; d.lights = (const PgLight *)s->lights.p;
@@ -533,6 +542,8 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
                         if (l.type == PG_LIGHT_POINT) v *= 4 * PG_PI;
                         else if (l.type == PG_LIGHT_SPOT) { v *= 2; v *= PG_PI; v *= (1 - .5f * (l.cos_falloff_start + l.cos_total_width)); }
                         else if (l.type == PG_LIGHT_DISTANT) { v *= PG_PI; v *= l.world_radius; v *= l.world_radius; }
+                        else if (l.type == PG_LIGHT_PROJECTION) { v = l.env_power[c] * v; v *= 2; v *= PG_PI; v *= (1.f - l.cos_total_width); }  // projection.cpp:93-99
+                        else if (l.type == PG_LIGHT_GONIO) v = (v * (4 * PG_PI)) * l.env_power[c];  // goniometric.cpp:54-58
                         else if (l.type == PG_LIGHT_INFINITE) v = l.env_power[c] * (PG_PI * l.world_radius * l.world_radius);  // infinite.cpp:87-91
                         else { v *= (float)(l.two_sided ? 2 : 1); v *= l.area; v *= PG_PI; }
                         P[c] = v;

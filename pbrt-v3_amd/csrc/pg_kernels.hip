@@ -1273,6 +1273,26 @@ PG_DEV Spec env_le(const DScene &sc, const PgLight &l, V3 rayD) {  // InfiniteAr
     V3 w = normalize(mat3_mul(l.w2l, rayD));
     return env_lookup(sc, l, spherical_phi(w) * PG_INV2PI, spherical_theta(w) * PG_INVPI);
 }
+// ProjectionLight::Projection (projection.cpp:79-91) and GonioPhotometricLight::Scale (goniometric.h:67-76); Lookup(st) of
+// their maps is triangle(0, st) (mipmap.h:214-243 with width 0)
+PG_DEV Spec light_projection(const DScene &sc, const PgLight &l, V3 w) {
+    const V3 wl = mat3_mul(l.w2l, w);
+    if (wl.z < l.hither) return sp(0);
+    const V3 p = m4_point(l.proj, wl);
+    if (!(p.x >= l.screen[0] && p.x <= l.screen[2] && p.y >= l.screen[1] && p.y <= l.screen[3])) return sp(0);
+    if (l.env_image < 0) return sp(1);
+    float ox = p.x - l.screen[0], oy = p.y - l.screen[1];  // Bounds2::Offset
+    if (l.screen[2] > l.screen[0]) ox /= l.screen[2] - l.screen[0];
+    if (l.screen[3] > l.screen[1]) oy /= l.screen[3] - l.screen[1];
+    return env_lookup(sc, l, ox, oy);
+}
+PG_DEV Spec light_gonio_scale(const DScene &sc, const PgLight &l, V3 w) {
+    V3 wp = normalize(mat3_mul(l.w2l, w));
+    const float t = wp.y; wp.y = wp.z; wp.z = t;
+    const float theta = spherical_theta(wp), phi = spherical_phi(wp);
+    if (l.env_image < 0) return sp(1);
+    return env_lookup(sc, l, phi * PG_INV2PI, theta * PG_INVPI);
+}
 PG_DEV float env_sample_1d(const float *func, const float *cdf, float funcInt, int n, float u, float &pdf, int *off) {  // sampling.h:72-89
     int size = n + 1, first = 0, len = size;
     while (len > 0) {
@@ -1341,6 +1361,8 @@ PG_DEV Spec light_sample_li(const DScene &sc, const PgLight &light, V3 refp, V3 
         ls.p = pos;
         const float d2 = lensq(pos - refp);
         if (light.type == PG_LIGHT_SPOT) return (I * spot_falloff(light, -wi)) / d2;
+        if (EXT && light.type == PG_LIGHT_PROJECTION) return (I * light_projection(sc, light, -wi)) / d2;  // projection.cpp:71-77
+        if (EXT && light.type == PG_LIGHT_GONIO) return (I * light_gonio_scale(sc, light, -wi)) / d2;     // goniometric.cpp:43-52
         return I / d2;
     }
     Tri t = load_tri(sc, light.prim);
@@ -1586,7 +1608,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                                 s_ray[1][0][tid] = make_float4(origin.x, origin.y, origin.z, 1 - PG_SHADOW_EPS);
                                 s_ray[1][1][tid] = make_float4(shD.x, shD.y, shD.z, __int_as_float(slot));
                                 pushShadow = true;
-                                const bool isDelta = light.type == PG_LIGHT_POINT || light.type == PG_LIGHT_SPOT || light.type == PG_LIGHT_DISTANT;
+                                const bool isDelta = PG_LIGHT_IS_DELTA(light.type);
                                 volWeight = isDelta ? -1.f : power_heuristic(1, lightPdf, 1, ph);
                                 pdLight = make_float4(ph, ph, ph, 0);
                                 vs.pdLi[slot] = make_float4(Li.r, Li.g, Li.b, lightPdf);
@@ -1816,7 +1838,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                                 s_ray[1][1][tid] = make_float4(shD.x, shD.y, shD.z, __int_as_float(slot));
                                 pushShadow = true;
                                 // delta lights take no MIS weight (integrator.cpp:155-160)
-                                const bool isDelta = light.type == PG_LIGHT_POINT || light.type == PG_LIGHT_SPOT || light.type == PG_LIGHT_DISTANT;
+                                const bool isDelta = PG_LIGHT_IS_DELTA(light.type);
                                 if constexpr (VOL) {  // Li still is to be multiplied by VisibilityTester::Tr (integrator.cpp:146-150): keep the factors apart
                                     volWeight = isDelta ? -1.f : power_heuristic(1, lightPdf, 1, scatteringPdf);
                                     pdLight = make_float4(f.r, f.g, f.b, 0);

@@ -856,6 +856,49 @@ void pbrtLightSource(const std::string &name, const ParamSet &params) {
         for (int i = 0; i < 3; ++i) l.L[i] = L.c[i] * sc.c[i];
         l.pos[0] = wLight.x; l.pos[1] = wLight.y; l.pos[2] = wLight.z;
         // world_radius is filled in when the scene is flattened (DistantLight::Preprocess needs the world bound)
+    } else if (name == "projection" || name == "goniometric") {
+        // CreateProjectionLight (projection.cpp:129-140, ctor :44-69) / CreateGoniometricLight (goniometric.cpp:87-95, ctor goniometric.h:56-66)
+        const bool projection = name == "projection";
+        RGB I = params.FindOneSpectrum("I", RGB{{1.f, 1.f, 1.f}});
+        const Float fov = projection ? params.FindOneFloat("fov", 45.) : 0;
+        std::string texname = params.FindOneString("mapname", "");
+        if (!texname.empty()) texname = AbsolutePath(ResolveFilename(texname));
+        l.type = projection ? PG_LIGHT_PROJECTION : PG_LIGHT_GONIO;
+        for (int i = 0; i < 3; ++i) l.L[i] = I.c[i] * sc.c[i];
+        Point3f pLight = light2world.Pt(Point3f(0, 0, 0));
+        l.pos[0] = pLight.x; l.pos[1] = pLight.y; l.pos[2] = pLight.z;
+        const Matrix4x4 &w2l = light2world.GetInverseMatrix();
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) l.w2l[3 * r + c] = w2l.m[r][c];
+        // the map as a MIPMap<RGBSpectrum> with its defaults (EWA, max anisotropy 8, repeat); ReadImage reports a missing file
+        int resX = 0, resY = 0;
+        std::vector<RGB> texels;
+        l.env_image = -1;
+        l.env_power[0] = l.env_power[1] = l.env_power[2] = 1;
+        if (ReadImage(texname, &resX, &resY, &texels)) {
+            std::vector<float> conv((size_t)resX * resY * 3);
+            for (size_t i = 0; i < texels.size(); ++i) for (int c = 0; c < 3; ++c) conv[3 * i + c] = texels[i].c[c];
+            PgImage map;
+            memset(&map, 0, sizeof(map));
+            map.is_float = 0; map.wrap = 0; map.trilinear = 0; map.max_anisotropy = 8.f;
+            BuildMIPMap(resX, resY, 3, conv, 0, &map, &renderOptions->texels);
+            l.env_image = (int)renderOptions->images.size();
+            renderOptions->images.push_back(map);
+            const float st[2] = {.5f, .5f};  // Power(): Lookup(Point2f(.5f, .5f), .5f)
+            MIPMapLookup(map, renderOptions->texels, st, .5f, l.env_power);
+        }
+        if (projection) {
+            const Float aspect = l.env_image >= 0 ? (Float(resX) / Float(resY)) : 1;
+            if (aspect > 1) { l.screen[0] = -aspect; l.screen[1] = -1; l.screen[2] = aspect; l.screen[3] = 1; }
+            else { l.screen[0] = -1; l.screen[1] = -1 / aspect; l.screen[2] = 1; l.screen[3] = 1 / aspect; }
+            l.hither = 1e-3f;
+            const Float yon = 1e30f;
+            Transform lightProjection = Perspective(fov, l.hither, yon);
+            const Matrix4x4 &pm = lightProjection.GetMatrix();
+            for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) l.proj[4 * r + c] = pm.m[r][c];
+            Transform screenToLight = Inverse(lightProjection);
+            Point3f pc = screenToLight.Pt(Point3f(l.screen[2], l.screen[3], 0));
+            l.cos_total_width = Normalize(Vector3f(pc.x, pc.y, pc.z)).z;
+        }
     } else if (name == "infinite" || name == "exinfinite") {  // CreateInfiniteLight, infinite.cpp:176-188; ctor :44-85
         RGB L = params.FindOneSpectrum("L", RGB{{1.f, 1.f, 1.f}});
         params.FindOneInt("samples", params.FindOneInt("nsamples", 1));
@@ -921,7 +964,7 @@ void pbrtLightSource(const std::string &name, const ParamSet &params) {
         float *mrow = &tab[base + rowStride * height];
         dist1d(marginalFunc.data(), height, mrow, mrow + height, mrow + 2 * height + 1);
     } else {
-        Error("LightSource \"%s\" is outside this build's closed set (point, spot, distant, infinite, and diffuse area lights); ignoring.", name.c_str());
+        Error("LightSource \"%s\" is outside this build's closed set (point, spot, distant, projection, goniometric, infinite, and diffuse area lights); ignoring.", name.c_str());
         return;
     }
     params.ReportUnused();
