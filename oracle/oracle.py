@@ -60,6 +60,12 @@ def lib(cr_libm=False):
         L.oracle_halton_sample.argtypes = [C.POINTER(abi.PgSceneDesc), C.POINTER(abi.PgRenderDesc), C.c_int64, C.c_int]
         L.oracle_triangle_intersect.restype = C.c_int
         L.oracle_triangle_intersect.argtypes = [C.c_void_p] * 5 + [C.c_float, C.POINTER(C.c_float), C.c_void_p]
+        L.oracle_phase_hg.restype = C.c_float
+        L.oracle_phase_hg.argtypes = [C.c_float, C.c_float]
+        L.oracle_hg_sample_p.restype = C.c_float
+        L.oracle_hg_sample_p.argtypes = [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_intersect_interaction.restype = C.c_int
+        L.oracle_intersect_interaction.argtypes = [C.POINTER(abi.PgSceneDesc), C.c_void_p, C.c_void_p, C.c_float, C.POINTER(C.c_float), C.c_void_p]
         L.oracle_spawn_ray_origin.restype = None
         L.oracle_spawn_ray_origin.argtypes = [C.c_void_p] * 5
         _libs[path] = L

@@ -171,3 +171,113 @@ def test_sobol_elementary_intervals(pkg, oracle, log_samples):
         nx, ny = 1 << i, 1 << (log_samples - i)
         idx = np.floor(np.float32(ny) * pts[:, 1]).astype(int) * nx + np.floor(np.float32(nx) * pts[:, 0]).astype(int)
         assert len(set(idx.tolist())) == rd.spp
+
+
+# ---- HenyeyGreenstein.* (tests/hg.cpp) ---------------------------------------------------------------------------------
+def test_hg_sampling_match(oracle):
+    """HenyeyGreenstein.SamplingMatch: the value Sample_p returns is p(wo, wi) of the direction it produced."""
+    lib, rng = oracle.lib(), PCG32()
+    for g in np.arange(-0.75, 0.76, 0.25, dtype=np.float32):
+        for _ in range(100):
+            wo = uniform_sample_sphere((rng.uniform_float(), rng.uniform_float()))
+            u = np.array([rng.uniform_float(), rng.uniform_float()], np.float32)
+            wi = np.zeros(3, np.float32)
+            p0 = lib.oracle_hg_sample_p(float(g), wo.ctypes.data, u.ctypes.data, wi.ctypes.data)
+            assert abs(p0 - lib.oracle_phase_hg(float(np.dot(wo, wi)), float(g))) < 1e-4, g
+
+
+@pytest.mark.parametrize("g", [0.95, -0.95])
+def test_hg_sampling_orientation(oracle, g):
+    """HenyeyGreenstein.SamplingOrientationForward / Backward: with |g| = 0.95 nearly all samples continue / reverse."""
+    lib, rng = oracle.lib(), PCG32()
+    wo = np.array([-1, 0, 0], np.float32)
+    fwd = 0
+    for _ in range(100):
+        u = np.array([rng.uniform_float(), rng.uniform_float()], np.float32)
+        wi = np.zeros(3, np.float32)
+        lib.oracle_hg_sample_p(g, wo.ctypes.data, u.ctypes.data, wi.ctypes.data)
+        fwd += wi[0] > 0
+    assert (fwd >= 10 * (100 - fwd)) if g > 0 else ((100 - fwd) >= 10 * fwd)
+
+
+def test_hg_normalized(oracle):
+    """HenyeyGreenstein.Normalized: the phase function integrates to 1 (its mean over the sphere is 1 / 4 pi)."""
+    lib = oracle.lib()
+    rng = np.random.default_rng(1)
+    z = 1 - 2 * rng.random(100000)
+    for g in (-0.75, -0.5, -0.25, 0.0, 0.25, 0.5, 0.75):
+        mean = np.mean([lib.oracle_phase_hg(float(c), g) for c in z[:20000]])
+        assert abs(mean - 1 / (4 * np.pi)) < 1e-3, g
+
+
+# ---- FullSphere / PartialSphere / Cylinder .Reintersect and PartialSphere.Normal (tests/shapes.cpp:372-513) -----------------
+QUADRIC_SCENE = """LookAt 0 0 5  0 0 0  0 1 0
+Camera "perspective"
+Film "image" "integer xresolution" [ 4 ] "integer yresolution" [ 4 ] "string filename" "q.pfm"
+WorldBegin
+%s
+WorldEnd
+"""
+
+
+def _pexp(rng, e=8.0):
+    u = rng.uniform_float()
+    return np.float32(10.0 ** float(np.float32((1 - u) * -e + u * e)))
+
+
+def _reintersect_convex(pkg, oracle, shape_text, rng, n_out=150):
+    """TestReintersectConvex: no ray leaving a hit point into the normal's hemisphere (SpawnRay / SpawnRayTo) hits the shape again."""
+    import ctypes as C
+    scene = pkg.HostScene(text=QUADRIC_SCENE % shape_text)
+    lib = oracle.lib()
+    o = np.array([_pexp(rng) for _ in range(3)], np.float32)
+    nodes = scene.nodes()
+    lo, hi = nodes["bmin"][0], nodes["bmax"][0]
+    tt = np.array([rng.uniform_float() for _ in range(3)], np.float32)
+    p2 = ((1 - tt) * lo + tt * hi).astype(np.float32)  # bbox.Lerp(t)
+    d = (p2 - o).astype(np.float32)
+    if rng.uniform_float() < .5: d = (d / np.float32(np.sqrt(np.sum(d * d, dtype=np.float32)))).astype(np.float32)
+    t, out = C.c_float(0), np.zeros(9, np.float32)
+    if not lib.oracle_intersect_interaction(scene.desc, o.ctypes.data, d.ctypes.data, np.inf, C.byref(t), out.ctypes.data): return 0, None
+    p, perr, n = out[:3].copy(), out[3:6].copy(), out[6:].copy()
+    orig = np.zeros(3, np.float32)
+    os_, ds, tm = [], [], []
+    for _ in range(n_out):
+        w = uniform_sample_sphere((rng.uniform_float(), rng.uniform_float()))
+        if np.dot(w, n) < 0: w = -w  # Faceforward(w, isect.n)
+        lib.oracle_spawn_ray_origin(p.ctypes.data, perr.ctypes.data, n.ctypes.data, w.ctypes.data, orig.ctypes.data)
+        os_.append(orig.copy()); ds.append(w); tm.append(np.inf)
+        q = np.array([_pexp(rng) for _ in range(3)], np.float32)
+        w = (q - p).astype(np.float32)
+        if np.dot(w, n) < 0: w = -w
+        lib.oracle_spawn_ray_origin(p.ctypes.data, perr.ctypes.data, n.ctypes.data, w.ctypes.data, orig.ctypes.data)
+        os_.append(orig.copy()); ds.append(w); tm.append(1 - 0.0001)  # SpawnRayTo: tMax = 1 - ShadowEpsilon
+    os_, ds, tm = np.asarray(os_, np.float32), np.asarray(ds, np.float32), np.asarray(tm, np.float32)
+    prim, _, _, _ = oracle.intersect(scene.desc, os_, ds, tm)
+    occ, _ = oracle.intersect_p(scene.desc, os_, ds, tm)
+    assert (prim < 0).all() and not occ.any()
+    return len(os_), (p, n)
+
+
+@pytest.mark.parametrize("kind", ["full_sphere", "partial_sphere", "cylinder"])
+def test_quadric_reintersect(pkg, oracle, kind):
+    checked = 0
+    for i in range(40):
+        rng = PCG32(i)
+        radius = _pexp(rng, 4)
+        if kind == "cylinder":
+            zmin = _pexp(rng, 4) * (-1 if rng.uniform_float() < 0.5 else 1)
+            zmax = _pexp(rng, 4) * (-1 if rng.uniform_float() < 0.5 else 1)
+        elif kind == "partial_sphere":
+            zmin = -radius if rng.uniform_float() < 0.5 else (lambda u: (1 - u) * -radius + u * radius)(np.float32(rng.uniform_float()))
+            zmax = radius if rng.uniform_float() < 0.5 else (lambda u: (1 - u) * -radius + u * radius)(np.float32(rng.uniform_float()))
+        else: zmin, zmax = -radius, radius
+        phimax = 360.0 if (kind == "full_sphere" or rng.uniform_float() < 0.5) else rng.uniform_float() * 360.0
+        shape = ('Shape "%s" "float radius" [ %.9g ] "float zmin" [ %.9g ] "float zmax" [ %.9g ] "float phimax" [ %.9g ]'
+                 % ("cylinder" if kind == "cylinder" else "sphere", radius, zmin, zmax, phimax))
+        n, hit = _reintersect_convex(pkg, oracle, shape, rng)
+        checked += n
+        if hit and kind == "partial_sphere":  # ParialSphere.Normal: the normal of an untransformed sphere is radial
+            p, nrm = hit
+            assert abs(1 - np.dot(nrm / np.linalg.norm(nrm), p / np.linalg.norm(p))) < 1e-5
+    assert checked > 1500
