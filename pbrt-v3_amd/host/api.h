@@ -29,48 +29,56 @@ void SetSearchDirectory(const std::string &dirname);
 std::string ResolveFilename(const std::string &filename);
 std::string AbsolutePath(const std::string &filename);
 
-void pbrtInit(const Options &opt);
+// ---- session: pbrtInit .. pbrtCleanup bracket one scene description; the two parse entry points feed the directives below
+void pbrtInit(const Options &options);
+void pbrtParseFile(const std::string &sceneFile);
+void pbrtParseString(const std::string &sceneText);
 void pbrtCleanup();
-void pbrtParseFile(const std::string &filename);
-void pbrtParseString(const std::string &str);
 
-void pbrtIdentity();
-void pbrtTranslate(Float dx, Float dy, Float dz);
-void pbrtRotate(Float angle, Float ax, Float ay, Float az);
-void pbrtScale(Float sx, Float sy, Float sz);
-void pbrtLookAt(Float ex, Float ey, Float ez, Float lx, Float ly, Float lz, Float ux, Float uy, Float uz);
-void pbrtConcatTransform(Float transform[16]);
-void pbrtTransform(Float transform[16]);
-void pbrtCoordinateSystem(const std::string &);
-void pbrtCoordSysTransform(const std::string &);
-void pbrtActiveTransformAll();
-void pbrtActiveTransformEndTime();
-void pbrtActiveTransformStartTime();
-void pbrtTransformTimes(Float start, Float end);
-void pbrtPixelFilter(const std::string &name, const ParamSet &params);
-void pbrtFilm(const std::string &type, const ParamSet &params);
-void pbrtSampler(const std::string &name, const ParamSet &params);
-void pbrtAccelerator(const std::string &name, const ParamSet &params);
-void pbrtIntegrator(const std::string &name, const ParamSet &params);
-void pbrtCamera(const std::string &, const ParamSet &cameraParams);
-void pbrtMakeNamedMedium(const std::string &name, const ParamSet &params);
-void pbrtMediumInterface(const std::string &insideName, const std::string &outsideName);
+// ---- block structure of a scene description
 void pbrtWorldBegin();
+void pbrtWorldEnd();
 void pbrtAttributeBegin();
 void pbrtAttributeEnd();
 void pbrtTransformBegin();
 void pbrtTransformEnd();
-void pbrtTexture(const std::string &name, const std::string &type, const std::string &texname, const ParamSet &params);
-void pbrtMaterial(const std::string &name, const ParamSet &params);
-void pbrtMakeNamedMaterial(const std::string &name, const ParamSet &params);
-void pbrtNamedMaterial(const std::string &name);
-void pbrtLightSource(const std::string &name, const ParamSet &params);
-void pbrtAreaLightSource(const std::string &name, const ParamSet &params);
-void pbrtShape(const std::string &name, const ParamSet &params);
-void pbrtReverseOrientation();
-void pbrtObjectBegin(const std::string &name);
+void pbrtObjectBegin(const std::string &objectName);
 void pbrtObjectEnd();
-void pbrtObjectInstance(const std::string &name);
-void pbrtWorldEnd();
+void pbrtObjectInstance(const std::string &objectName);
+
+// ---- current transformation matrix (CTM) and named coordinate systems
+void pbrtIdentity();
+void pbrtTransform(Float rowMajor4x4[16]);
+void pbrtConcatTransform(Float rowMajor4x4[16]);
+void pbrtTranslate(Float tx, Float ty, Float tz);
+void pbrtScale(Float x, Float y, Float z);
+void pbrtRotate(Float degrees, Float axisX, Float axisY, Float axisZ);
+void pbrtLookAt(Float eyeX, Float eyeY, Float eyeZ, Float atX, Float atY, Float atZ, Float upX, Float upY, Float upZ);
+void pbrtCoordinateSystem(const std::string &csName);
+void pbrtCoordSysTransform(const std::string &csName);
+void pbrtTransformTimes(Float tStart, Float tEnd);
+void pbrtActiveTransformStartTime();
+void pbrtActiveTransformEndTime();
+void pbrtActiveTransformAll();
+void pbrtReverseOrientation();
+
+// ---- render options (before WorldBegin)
+void pbrtCamera(const std::string &cameraType, const ParamSet &params);
+void pbrtFilm(const std::string &filmType, const ParamSet &params);
+void pbrtPixelFilter(const std::string &filterType, const ParamSet &params);
+void pbrtSampler(const std::string &samplerType, const ParamSet &params);
+void pbrtIntegrator(const std::string &integratorType, const ParamSet &params);
+void pbrtAccelerator(const std::string &acceleratorType, const ParamSet &params);
+
+// ---- graphics state and scene content
+void pbrtMakeNamedMedium(const std::string &mediumName, const ParamSet &params);
+void pbrtMediumInterface(const std::string &insideMedium, const std::string &outsideMedium);
+void pbrtTexture(const std::string &textureName, const std::string &valueType, const std::string &textureClass, const ParamSet &params);
+void pbrtMaterial(const std::string &materialType, const ParamSet &params);
+void pbrtMakeNamedMaterial(const std::string &materialName, const ParamSet &params);
+void pbrtNamedMaterial(const std::string &materialName);
+void pbrtLightSource(const std::string &lightType, const ParamSet &params);
+void pbrtAreaLightSource(const std::string &lightType, const ParamSet &params);
+void pbrtShape(const std::string &shapeType, const ParamSet &params);
 }  // namespace pbrt
 #endif
