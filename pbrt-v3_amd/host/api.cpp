@@ -658,7 +658,7 @@ void pbrtTexture(const std::string &name, const std::string &type, const std::st
     if (!isFloat && type != "color" && type != "spectrum") { Error("Texture type \"%s\" unknown.", type.c_str()); return; }
     auto &table = isFloat ? graphicsState.floatTextures : graphicsState.spectrumTextures;
     if (table.count(name)) Warning("Texture \"%s\" being redefined", name.c_str());
-    if (curTransform.IsAnimated()) Warning("Animated transformations are not supported by this build; using the start transform for texture \"%s\".", name.c_str());
+    if (curTransform.IsAnimated()) Error("Animated transformations (motion blur) are not supported by this build; using the start transform for texture \"%s\".", name.c_str());
     const GraphicsState &gs = graphicsState;
     ParamSet none;
     auto operand = [&](const char *n, Float d) { return isFloat ? floatRef(params, none, n, d, gs) : spectrumRef(params, none, n, RGB{{d, d, d}}, gs); };
@@ -813,7 +813,7 @@ static Point3f point3Param(const ParamSet &ps, const std::string &n, Point3f d) 
 // DistantLight (distant.cpp:96-104, :43-48), appended to scene.lights in declaration order (api.cpp:1308-1327).
 void pbrtLightSource(const std::string &name, const ParamSet &params) {
     VERIFY_WORLD("LightSource");
-    if (curTransform.IsAnimated()) Warning("Animated transformations are not supported by this build; using the start transform for the light.");
+    if (curTransform.IsAnimated()) Error("Animated transformations (motion blur) are not supported by this build; using the start transform for the light.");
     const Transform &light2world = curTransform[0];
     PgLight l;
     memset(&l, 0, sizeof(l));
@@ -1054,7 +1054,7 @@ static std::shared_ptr<TriangleMesh> CreateTriangleMeshShape(const Transform &o2
 void pbrtShape(const std::string &name, const ParamSet &params) {  // api.cpp:1329-1421
     VERIFY_WORLD("Shape");
     if (curTransform.IsAnimated())
-        Warning("Animated transformations are not supported by this build; using the start transform for shape \"%s\".", name.c_str());
+        Error("Animated transformations (motion blur) are not supported by this build; using the start transform for shape \"%s\".", name.c_str());
     std::shared_ptr<TriangleMesh> mesh;
     std::shared_ptr<Sphere> sphere;
     if (name == "trianglemesh") mesh = CreateTriangleMeshShape(curTransform[0], graphicsState.reverseOrientation, params);
@@ -1170,7 +1170,7 @@ void pbrtObjectInstance(const std::string &name) {  // api.cpp:1546-1588
         obj->prims.clear();
     }
     if (curTransform.IsAnimated())
-        Warning("Animated transformations are not supported by this build; using the start transform for instance \"%s\".", name.c_str());
+        Error("Animated transformations (motion blur) are not supported by this build; using the start transform for instance \"%s\".", name.c_str());
     GeometricPrimitive prim;
     prim.object = obj;
     prim.InstanceToWorld = curTransform[0];
@@ -1199,7 +1199,7 @@ static GpuPathIntegrator *MakeIntegrator() {
         delete film;
         return nullptr;
     }
-    if (ro.CameraToWorld.IsAnimated()) Warning("Animated camera transformations are not supported by this build; using the start transform.");
+    if (ro.CameraToWorld.IsAnimated()) Error("Animated camera transformations (motion blur) are not supported by this build; using the start transform.");
     std::shared_ptr<PerspectiveCamera> camera(CreatePerspectiveCamera(ro.CameraParams, ro.CameraToWorld[0], film, ro.CameraName == "orthographic"));
     if (ro.CameraName == "environment") { camera->environment = true; camera->lensRadius = 0; }  // environment.cpp:96-97: lens parameters unused
     ro.CameraParams.ReportUnused();
