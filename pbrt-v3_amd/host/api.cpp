@@ -8,6 +8,7 @@
 #include <climits>
 #include <cstring>
 #include <cstdlib>
+#include <chrono>
 #include <map>
 #include "error.h"
 #include "scene.h"
@@ -1173,8 +1174,12 @@ void pbrtObjectInstance(const std::string &name) {  // api.cpp:1546-1588
         Error("Animated transformations (motion blur) are not supported by this build; using the start transform for instance \"%s\".", name.c_str());
     GeometricPrimitive prim;
     prim.object = obj;
-    prim.InstanceToWorld = curTransform[0];
-    prim.WorldToInstance = Inverse(curTransform[0]);
+    {
+        auto xf = std::make_shared<GeometricPrimitive::InstanceTransforms>();
+        xf->InstanceToWorld = curTransform[0];
+        xf->WorldToInstance = Inverse(curTransform[0]);
+        prim.xf = xf;
+    }
     renderOptions->primitives.push_back(prim);
 }
 
@@ -1261,8 +1266,11 @@ void pbrtWorldEnd() {  // api.cpp:1590-1644
     VERIFY_WORLD("WorldEnd");
     while (pushedGraphicsStates.size()) { Warning("Missing end to pbrtAttributeBegin()"); pushedGraphicsStates.pop_back(); pushedTransforms.pop_back(); }
     while (pushedTransforms.size()) { Warning("Missing end to pbrtTransformBegin()"); pushedTransforms.pop_back(); }
+    const bool timing = getenv("PBRT_HOST_TIMING") != nullptr;  // stderr: seconds spent building the accelerators
+    auto tBuild = std::chrono::steady_clock::now();
     std::unique_ptr<GpuPathIntegrator> integrator(MakeIntegrator());
     std::unique_ptr<Scene> scene(MakeScene());
+    if (timing) fprintf(stderr, "pbrt host: MakeScene (BVH build) %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild).count());
     if (scene && integrator) {
         if (PbrtOptions.loadOnly) {
             lastLoadedScene.reset(new LoadedScene);

@@ -3,6 +3,11 @@
 // Middle / EqualCounts build with 12 buckets) and :640-658 (flattenBVHTree)
 // with the same float arithmetic and the same std::partition/std::nth_element
 // calls, so the node array and leaf contents match the reference's tree.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <future>
+#include <thread>
 #include "scene.h"
 #include "error.h"
 #include "api.h"
@@ -110,7 +115,7 @@ Bounds3f ObjectDefinition::WorldBound() const {  // the BVHAccel's root bounds, 
 }
 Bounds3f GeometricPrimitive::WorldBound() const {
     // TransformedPrimitive::WorldBound (primitive.h:107-109) -> AnimatedTransform::MotionBounds, not animated (transform.cpp:1190-1192)
-    if (object) return TransformBounds(InstanceToWorld, object->WorldBound());
+    if (object) return TransformBounds(xf->InstanceToWorld, object->WorldBound());
     return sphere ? sphere->WorldBound() : shape.WorldBound();
 }
 
@@ -137,13 +142,21 @@ struct BVHAccel::BuildNode {  // BVHBuildNode, bvh.cpp:61-83
 };
 
 BVHAccel::BuildNode *BVHAccel::allocNode() {
-    const size_t chunk = 1 << 16;
-    if (arena.empty() || arenaUsed == chunk) { arena.emplace_back(new BuildNode[chunk]); arenaUsed = 0; }
-    return &arena.back()[arenaUsed++];
+    // every thread carves nodes out of its own chunk; only fetching a new chunk takes the lock
+    const size_t chunk = 1 << 14;
+    thread_local uint64_t owner = 0;
+    thread_local BuildNode *cur = nullptr, *chunkEnd = nullptr;
+    if (owner != buildId || cur == chunkEnd) {
+        std::lock_guard<std::mutex> lock(arenaMutex);
+        arena.emplace_back(new BuildNode[chunk]);
+        owner = buildId; cur = arena.back().get(); chunkEnd = cur + chunk;
+    }
+    return cur++;
 }
 
+static std::atomic<uint64_t> g_nextBuildId(1);
 BVHAccel::BVHAccel(std::vector<GeometricPrimitive> p, int maxPrims, SplitMethod sm)
-    : primitives(std::move(p)), maxPrimsInNode(std::min(255, maxPrims)), splitMethod(sm) {
+    : primitives(std::move(p)), maxPrimsInNode(std::min(255, maxPrims)), splitMethod(sm), buildId(g_nextBuildId++) {
     if (primitives.empty()) return;
     std::vector<PrimInfo> primitiveInfo(primitives.size());
     for (size_t i = 0; i < primitives.size(); ++i) primitiveInfo[i] = {i, primitives[i].WorldBound()};
@@ -168,15 +181,26 @@ BVHAccel::BVHAccel(std::vector<GeometricPrimitive> p, int maxPrims, SplitMethod 
         arena.clear();
         return;
     }
-    orderedPrims.reserve(primitives.size());
-    BuildNode *root = recursiveBuild(primitiveInfo, 0, (int)primitives.size(), &totalNodes, orderedPrims);
+    orderedPrims.resize(primitives.size());
+    std::atomic<int> nodeCount(0);
+    // --nthreads (0 = all cores): 2^spawnDepth subtrees are built concurrently
+    int threads = PbrtOptions.nThreads > 0 ? PbrtOptions.nThreads : (int)std::thread::hardware_concurrency();
+    if (const char *e = getenv("PBRT_NTHREADS")) { if (atoi(e) > 0) threads = atoi(e); }  // for hosts that drive the C API (no --nthreads there)
+    int spawnDepth = 0;
+    while ((2 << spawnDepth) <= std::max(1, threads) && spawnDepth < 6) ++spawnDepth;
+    const bool timing = getenv("PBRT_HOST_TIMING") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    BuildNode *root = recursiveBuild(primitiveInfo, 0, (int)primitives.size(), &nodeCount, orderedPrims, spawnDepth);
+    if (timing) fprintf(stderr, "pbrt host: recursiveBuild of %zu primitives, %d threads: %.3f s\n", primitives.size(), 1 << spawnDepth,
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    totalNodes = nodeCount;
     primitives.swap(orderedPrims);
     nodes.resize(totalNodes);
     int offset = 0;
     flattenBVHTree(root, &offset);
     arena.clear();
 }
-BVHAccel::BVHAccel(int maxPrims, SplitMethod sm) : maxPrimsInNode(std::min(255, maxPrims)), splitMethod(sm) {}
+BVHAccel::BVHAccel(int maxPrims, SplitMethod sm) : maxPrimsInNode(std::min(255, maxPrims)), splitMethod(sm), buildId(g_nextBuildId++) {}
 void BVHAccel::HLBVHFromBounds(int n, const float *bounds, int maxPrimsInNode, std::vector<PgBVHNode> *nodes, std::vector<int> *order) {
     nodes->clear(); order->clear();
     if (n <= 0) return;
@@ -205,16 +229,18 @@ Bounds3f BVHAccel::WorldBound() const {  // bvh.cpp:228-230
 
 struct BucketInfo { int count = 0; Bounds3f bounds; };
 
-BVHAccel::BuildNode *BVHAccel::recursiveBuild(std::vector<PrimInfo> &primitiveInfo, int start, int end, int *totalNodes,
-                                              std::vector<GeometricPrimitive> &orderedPrims) {
+BVHAccel::BuildNode *BVHAccel::recursiveBuild(std::vector<PrimInfo> &primitiveInfo, int start, int end, std::atomic<int> *totalNodes,
+                                              std::vector<GeometricPrimitive> &orderedPrims, int spawnDepth) {
     BuildNode *node = allocNode();
     (*totalNodes)++;
     Bounds3f bounds;
     for (int i = start; i < end; ++i) bounds = Union(bounds, primitiveInfo[i].bounds);
     int nPrimitives = end - start;
     auto makeLeaf = [&]() {
-        int firstPrimOffset = (int)orderedPrims.size();
-        for (int i = start; i < end; ++i) orderedPrims.push_back(primitives[primitiveInfo[i].primitiveNumber]);
+        int firstPrimOffset = start;  // == orderedPrims.size() at this point of the reference's depth-first build
+        // moved, not copied: every primitive lands in exactly one leaf, and a copy would bump the mesh's shared reference count from
+        // all threads at once
+        for (int i = start; i < end; ++i) orderedPrims[i] = std::move(primitives[primitiveInfo[i].primitiveNumber]);
         node->InitLeaf(firstPrimOffset, nPrimitives, bounds);
         return node;
     };
@@ -280,8 +306,15 @@ BVHAccel::BuildNode *BVHAccel::recursiveBuild(std::vector<PrimInfo> &primitiveIn
     // The reference passes both recursive calls as function arguments
     // (bvh.cpp:393-397); their evaluation order only permutes whole leaf
     // blocks inside orderedPrims, never a leaf's contents or the tree shape.
-    BuildNode *c0 = recursiveBuild(primitiveInfo, start, mid, totalNodes, orderedPrims);
-    BuildNode *c1 = recursiveBuild(primitiveInfo, mid, end, totalNodes, orderedPrims);
+    BuildNode *c0, *c1;
+    if (spawnDepth > 0 && nPrimitives >= (1 << 15)) {  // the two halves touch disjoint ranges of primitiveInfo / orderedPrims
+        std::future<BuildNode *> first = std::async(std::launch::async, [&]() { return recursiveBuild(primitiveInfo, start, mid, totalNodes, orderedPrims, spawnDepth - 1); });
+        c1 = recursiveBuild(primitiveInfo, mid, end, totalNodes, orderedPrims, spawnDepth - 1);
+        c0 = first.get();
+    } else {
+        c0 = recursiveBuild(primitiveInfo, start, mid, totalNodes, orderedPrims, 0);
+        c1 = recursiveBuild(primitiveInfo, mid, end, totalNodes, orderedPrims, 0);
+    }
     node->InitInterior(dim, c0, c1);
     return node;
 }

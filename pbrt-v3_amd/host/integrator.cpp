@@ -269,10 +269,10 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
         if (prim.object) {  // TransformedPrimitive: one PgInstance per use
             PgInstance inst;
             memset(&inst, 0, sizeof(inst));
-            const Matrix4x4 &m = prim.InstanceToWorld.GetMatrix(), &mi = prim.WorldToInstance.GetMatrix();
+            const Matrix4x4 &m = prim.xf->InstanceToWorld.GetMatrix(), &mi = prim.xf->WorldToInstance.GetMatrix();
             for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { inst.i2w[4 * r + c] = m.m[r][c]; inst.w2i[4 * r + c] = mi.m[r][c]; }
             inst.object = objectIndex[prim.object.get()];
-            inst.identity = prim.InstanceToWorld.IsIdentity() ? 1 : 0;
+            inst.identity = prim.xf->InstanceToWorld.IsIdentity() ? 1 : 0;
             flat->indices[3 * k] = (int)flat->instances.size();
             flat->indices[3 * k + 1] = flat->indices[3 * k + 2] = 0;
             flat->triFlags[k] = PG_PRIM_INSTANCE;

@@ -5,7 +5,9 @@
 // hand-off to the C ABI in include/pbrt_gpu.h.
 #ifndef PBRT_AMD_HOST_SCENE_H
 #define PBRT_AMD_HOST_SCENE_H
+#include <atomic>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/pbrt_gpu.h"
@@ -68,7 +70,10 @@ struct GeometricPrimitive {
     Triangle shape;
     std::shared_ptr<Sphere> sphere;
     std::shared_ptr<ObjectDefinition> object;
-    Transform InstanceToWorld, WorldToInstance;
+    // only object instances carry transforms; kept behind a pointer so that the millions of triangle primitives of a large
+    // scene stay small (the accelerator build moves every one of them)
+    struct InstanceTransforms { Transform InstanceToWorld, WorldToInstance; };
+    std::shared_ptr<const InstanceTransforms> xf;
     int material = -1;
     int areaLight = -1;
     int mediumInside = -1, mediumOutside = -1;  // MediumInterface (core/medium.h:102-116) as indices into Scene::media
@@ -86,8 +91,11 @@ class BVHAccel {
   private:
     struct BuildNode;
     struct PrimInfo;
-    BuildNode *recursiveBuild(std::vector<PrimInfo> &primitiveInfo, int start, int end, int *totalNodes,
-                              std::vector<GeometricPrimitive> &orderedPrims);
+    // orderedPrims is pre-sized: a leaf over [start, end) writes its primitives to those very positions (they are where the
+    // reference's depth-first push_back order puts them), so subtrees can be built on separate threads -- spawnDepth levels
+    // of the recursion hand their first child to a new thread -- with a result that does not depend on the thread count
+    BuildNode *recursiveBuild(std::vector<PrimInfo> &primitiveInfo, int start, int end, std::atomic<int> *totalNodes,
+                              std::vector<GeometricPrimitive> &orderedPrims, int spawnDepth);
     int flattenBVHTree(BuildNode *node, int *offset);
     struct MortonPrim;
     // the HLBVH build works on primitive numbers: order[k] = number of the k-th primitive of the leaf order
@@ -102,8 +110,9 @@ class BVHAccel {
     BuildNode *buildUpperSAH(std::vector<BuildNode *> &treeletRoots, int start, int end, int *totalNodes);
     const int maxPrimsInNode;
     const SplitMethod splitMethod;
-    std::vector<std::unique_ptr<BuildNode[]>> arena;
-    size_t arenaUsed = 0;
+    std::vector<std::unique_ptr<BuildNode[]>> arena;  // chunks of build nodes; threads take whole chunks under arenaMutex
+    std::mutex arenaMutex;
+    const uint64_t buildId;  // distinguishes this accelerator's arena in the threads' chunk caches (addresses get reused)
     BuildNode *allocNode();
 };
 std::shared_ptr<BVHAccel> CreateBVHAccelerator(std::vector<GeometricPrimitive> prims, const ParamSet &ps);  // bvh.cpp:740-760

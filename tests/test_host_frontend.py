@@ -156,3 +156,18 @@ def test_cli_refuses_without_backend(pkg, tmp_path):
     scene.write_text(MINI % (16, 16, 1))
     r = subprocess.run([exe, "--quiet", str(scene)], env=dict(os.environ, PBRT_GPU_LIB="/nonexistent.so"), capture_output=True, text=True)
     assert r.returncode != 0 and "no HIP back end" in r.stderr
+
+
+def test_bvh_build_does_not_depend_on_the_thread_count(pkg, tmp_path, monkeypatch):
+    """The SAH build hands subtrees of >= 32768 primitives to separate threads (--nthreads / PBRT_NTHREADS); leaves write their
+    primitives to the positions the reference's depth-first order gives them, so nodes and primitive order are the same for
+    any thread count."""
+    import gen_synthetic
+    path = str(tmp_path / "s.pbrt")
+    gen_synthetic.write_scene(path, n=220, xres=32, yres=18, spp=1, filename="s.pfm")  # 95 922 triangles
+    built = []
+    for threads in ("1", "3", "16"):
+        monkeypatch.setenv("PBRT_NTHREADS", threads)
+        s = pkg.HostScene(path)
+        built.append((s.nodes().tobytes(), s.indices().tobytes()))
+    assert built[0] == built[1] == built[2]
