@@ -158,8 +158,16 @@ static std::atomic<uint64_t> g_nextBuildId(1);
 BVHAccel::BVHAccel(std::vector<GeometricPrimitive> p, int maxPrims, SplitMethod sm)
     : primitives(std::move(p)), maxPrimsInNode(std::min(255, maxPrims)), splitMethod(sm), buildId(g_nextBuildId++) {
     if (primitives.empty()) return;
+    const bool timing = getenv("PBRT_HOST_TIMING") != nullptr;
+    auto tick = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        auto now = std::chrono::steady_clock::now();
+        if (timing) fprintf(stderr, "pbrt host: BVHAccel %s %.3f s\n", what, std::chrono::duration<double>(now - tick).count());
+        tick = now;
+    };
     std::vector<PrimInfo> primitiveInfo(primitives.size());
     for (size_t i = 0; i < primitives.size(); ++i) primitiveInfo[i] = {i, primitives[i].WorldBound()};
+    lap("primitive bounds");
     int totalNodes = 0;
     std::vector<GeometricPrimitive> orderedPrims;
     if (splitMethod == SplitMethod::HLBVH) {  // bvh.cpp:207-212
@@ -188,17 +196,18 @@ BVHAccel::BVHAccel(std::vector<GeometricPrimitive> p, int maxPrims, SplitMethod 
     if (const char *e = getenv("PBRT_NTHREADS")) { if (atoi(e) > 0) threads = atoi(e); }  // for hosts that drive the C API (no --nthreads there)
     int spawnDepth = 0;
     while ((2 << spawnDepth) <= std::max(1, threads) && spawnDepth < 6) ++spawnDepth;
-    const bool timing = getenv("PBRT_HOST_TIMING") != nullptr;
-    auto t0 = std::chrono::steady_clock::now();
+    lap("set-up");
     BuildNode *root = recursiveBuild(primitiveInfo, 0, (int)primitives.size(), &nodeCount, orderedPrims, spawnDepth);
-    if (timing) fprintf(stderr, "pbrt host: recursiveBuild of %zu primitives, %d threads: %.3f s\n", primitives.size(), 1 << spawnDepth,
-                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    if (timing) fprintf(stderr, "pbrt host: recursiveBuild of %zu primitives on up to %d threads\n", primitives.size(), 1 << spawnDepth);
+    lap("recursiveBuild");
     totalNodes = nodeCount;
     primitives.swap(orderedPrims);
     nodes.resize(totalNodes);
     int offset = 0;
     flattenBVHTree(root, &offset);
+    lap("flatten");
     arena.clear();
+    lap("free build nodes");
 }
 BVHAccel::BVHAccel(int maxPrims, SplitMethod sm) : maxPrimsInNode(std::min(255, maxPrims)), splitMethod(sm), buildId(g_nextBuildId++) {}
 void BVHAccel::HLBVHFromBounds(int n, const float *bounds, int maxPrimsInNode, std::vector<PgBVHNode> *nodes, std::vector<int> *order) {
