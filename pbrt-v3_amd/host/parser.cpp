@@ -22,11 +22,16 @@ struct Tokenizer {
     size_t pos = 0;
     FileLoc loc;
     static std::unique_ptr<Tokenizer> FromFile(const std::string &fn) {
-        std::ifstream f(fn, std::ios::binary);
+        std::ifstream f(fn, std::ios::binary | std::ios::ate);
         if (!f) { Error("%s: unable to open file", fn.c_str()); return nullptr; }
         std::unique_ptr<Tokenizer> t(new Tokenizer);
-        std::stringstream ss; ss << f.rdbuf();
-        t->contents = ss.str();
+        const std::streamoff size = f.tellg();  // one read into the final buffer: mesh files run to hundreds of megabytes
+        if (size > 0) {
+            t->contents.resize((size_t)size);
+            f.seekg(0);
+            f.read(&t->contents[0], size);
+            if (!f) { Error("%s: read error", fn.c_str()); return nullptr; }
+        }
         t->loc.filename = fn; t->loc.line = 1; t->loc.column = 0;
         return t;
     }
