@@ -281,3 +281,49 @@ def test_quadric_reintersect(pkg, oracle, kind):
             p, nrm = hit
             assert abs(1 - np.dot(nrm / np.linalg.norm(nrm), p / np.linalg.norm(p))) < 1e-5
     assert checked > 1500
+
+
+def test_triangle_sampling_solid_angle(pkg, oracle):
+    """Triangle.Sampling, tests/shapes.cpp:210-271: the solid angle a triangle subtends, estimated with Triangle::Sample(ref, u)
+    (sum of 1 / pdf) and with uniform directions (fraction of rays that hit it), agree -- both over radical-inverse points."""
+    lib = oracle.lib()
+    count, n_pdf = 1 << 19, 1 << 13  # uniform directions need many more samples than the importance-sampled estimate
+    js = np.arange(count, dtype=np.uint64)
+    # RadicalInverse bases 2 and 3 (lowdiscrepancy.cpp:389-436), vectorised; the oracle's own function is checked elsewhere
+    def radinv(base, a):
+        inv, v, f = np.zeros(len(a)), a.copy(), 1.0 / base
+        while v.any():
+            inv += (v % base) * f
+            v //= base
+            f /= base
+        return inv
+    us_all = np.stack([radinv(2, js), radinv(3, js)], 1).astype(np.float32)
+    z = 1 - 2 * us_all[:, 0]
+    r = np.sqrt(np.maximum(0, 1 - z * z))
+    phi = 2 * np.pi * us_all[:, 1]
+    dirs = np.stack([r * np.cos(phi), r * np.sin(phi), z], 1).astype(np.float32)
+    us = us_all[:n_pdf]
+    compared = 0
+    for i in range(12):
+        rng = PCG32(i)
+        punif = lambda r=10.0: np.float32((1 - (u := rng.uniform_float())) * -r + u * r)
+        v = np.array([[punif() for _ in range(3)] for _ in range(3)], np.float32)
+        if np.sum(np.cross((v[1] - v[0]).astype(np.float64), (v[2] - v[0]).astype(np.float64)) ** 2) < 1e-20: continue
+        pc = np.array([punif(), punif(), punif()], np.float32)
+        pc[rng.uniform_uint32() % 3] = (-13.0 if rng.uniform_float() > .5 else 13.0)
+        tri = ("AttributeBegin\nAreaLightSource \"diffuse\" \"bool twosided\" \"true\"\nShape \"trianglemesh\" \"integer indices\" [ 0 1 2 ] \"point P\" [ %s ]\nAttributeEnd"
+               % " ".join("%.9g" % x for x in v.ravel()))
+        scene = pkg.HostScene(text=QUADRIC_SCENE % tri)
+        occ, _ = oracle.intersect_p(scene.desc, np.tile(pc, (count, 1)), dirs, np.full(count, np.inf, np.float32))
+        unif = occ.sum() / (count * (1 / (4 * np.pi)))
+        wi = np.zeros(3, np.float32)
+        est = 0.0
+        for u in us:
+            pdf = lib.oracle_light_sample_pdf(scene.desc, 0, pc.ctypes.data, u.ctypes.data, wi.ctypes.data)
+            assert pdf > 0
+            est += 1.0 / (n_pdf * pdf)
+        if est > 1e-3:
+            err = abs(est - unif) if (abs(est) < 1e-4 or abs(unif) < 1e-4) else abs((est - unif) / unif)
+            assert err < .1, (i, est, unif)
+            compared += 1
+    assert compared >= 5
