@@ -67,7 +67,7 @@ def lib(cr_libm=False):
         L.oracle_intersect_interaction.restype = C.c_int
         L.oracle_intersect_interaction.argtypes = [C.POINTER(abi.PgSceneDesc), C.c_void_p, C.c_void_p, C.c_float, C.POINTER(C.c_float), C.c_void_p]
         L.oracle_light_sample_pdf.restype = C.c_float
-        L.oracle_light_sample_pdf.argtypes = [C.POINTER(abi.PgSceneDesc), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_light_sample_pdf.argtypes = [C.POINTER(abi.PgSceneDesc), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_spawn_ray_origin.restype = None
         L.oracle_spawn_ray_origin.argtypes = [C.c_void_p] * 5
         _libs[path] = L

@@ -316,10 +316,10 @@ def test_triangle_sampling_solid_angle(pkg, oracle):
         scene = pkg.HostScene(text=QUADRIC_SCENE % tri)
         occ, _ = oracle.intersect_p(scene.desc, np.tile(pc, (count, 1)), dirs, np.full(count, np.inf, np.float32))
         unif = occ.sum() / (count * (1 / (4 * np.pi)))
-        wi = np.zeros(3, np.float32)
+        wi, ps = np.zeros(3, np.float32), np.zeros(3, np.float32)
         est = 0.0
         for u in us:
-            pdf = lib.oracle_light_sample_pdf(scene.desc, 0, pc.ctypes.data, u.ctypes.data, wi.ctypes.data)
+            pdf = lib.oracle_light_sample_pdf(scene.desc, 0, pc.ctypes.data, u.ctypes.data, wi.ctypes.data, ps.ctypes.data)
             assert pdf > 0
             est += 1.0 / (n_pdf * pdf)
         if est > 1e-3:
@@ -327,3 +327,44 @@ def test_triangle_sampling_solid_angle(pkg, oracle):
             assert err < .1, (i, est, unif)
             compared += 1
     assert compared >= 5
+
+
+@pytest.mark.parametrize("shape,p", [('Shape "sphere" "float radius" [ 1 ]', (-.25, -1, .8)), ('Shape "sphere" "float radius" [ 1 ]', (1, .9, -.8)),
+                                     ('Shape "cylinder" "float radius" [ .25 ] "float zmin" [ -1 ] "float zmax" [ 1 ]', (.5, .25, .5)),
+                                     ('Shape "disk" "float radius" [ 1.25 ]', (.5, -.8, .5))])
+def test_quadric_sampling_solid_angle(pkg, oracle, shape, p):
+    """Sphere / Cylinder / Disk .SolidAngle, tests/shapes.cpp:331-370: Shape::SolidAngle (the mean of 1 / pdf over Sample(ref, u))
+    against the fraction of uniform directions that hit the shape, under Translate(1, .5, -.8) * RotateX(30); a point inside the
+    sphere sees 4 pi."""
+    lib = oracle.lib()
+    text = 'AttributeBegin\nTranslate 1 .5 -.8\nRotate 30 1 0 0\nAreaLightSource "diffuse" "bool twosided" "true"\n%s\nAttributeEnd' % shape
+    scene = pkg.HostScene(text=QUADRIC_SCENE % text)
+    rng = np.random.default_rng(7)
+    n = 1 << 18
+    z = 1 - 2 * rng.random(n)
+    r = np.sqrt(np.maximum(0, 1 - z * z))
+    phi = 2 * np.pi * rng.random(n)
+    dirs = np.stack([r * np.cos(phi), r * np.sin(phi), z], 1).astype(np.float32)
+    pc = np.asarray(p, np.float32)
+    occ, _ = oracle.intersect_p(scene.desc, np.tile(pc, (n, 1)), dirs, np.full(n, np.inf, np.float32))
+    mc = occ.mean() * 4 * np.pi
+    wi, ps = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    m = 1 << 16
+    pdfs, targets = [], []
+    jj = np.arange(m, dtype=np.uint64)
+    def radinv(base, a):
+        inv, v, f = np.zeros(len(a)), a.copy(), 1.0 / base
+        while v.any():
+            inv += (v % base) * f
+            v //= base
+            f /= base
+        return inv
+    for u in np.stack([radinv(2, jj), radinv(3, jj)], 1).astype(np.float32):
+        pdfs.append(lib.oracle_light_sample_pdf(scene.desc, 0, pc.ctypes.data, u.ctypes.data, wi.ctypes.data, ps.ctypes.data))
+        targets.append(ps.copy())
+    pdfs, targets = np.asarray(pdfs), np.asarray(targets, np.float32)
+    # Shape::SolidAngle (shape.cpp:89-103) leaves out samples the shape itself hides: IntersectP(Ray(p, pShape.p - p, .999f))
+    hidden, _ = oracle.intersect_p(scene.desc, np.tile(pc, (m, 1)), (targets - pc).astype(np.float32), np.full(m, .999, np.float32))
+    ok = (pdfs > 0) & ~hidden.astype(bool)
+    est = float(np.sum(1.0 / pdfs[ok]) / m)
+    assert abs(est - mc) < 0.03 * max(1.0, mc), (est, mc)
