@@ -30,7 +30,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "scenes"))
 from __graft_entry__ import load_package  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy ceiling
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy ceiling
+L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth, 8 XCDs x 4 MiB (MI355X_MICROARCH.md "L2 (per XCD)")
+INFINITY_CACHE_BYTES = 256 << 20
+FOG = ('MakeNamedMedium "fog" "string type" "homogeneous" "rgb sigma_a" [ 0.02 0.03 0.04 ] "rgb sigma_s" [ 0.15 0.12 0.1 ] "float g" [ 0.4 ]\n'
+       'MediumInterface "" "fog"\n')
 
 
 def make_scene_file(workdir, args):
@@ -44,6 +48,11 @@ def make_scene_file(workdir, args):
         open(path, "w").write(txt)
     else:
         gen_synthetic.write_scene(path, n=args.grid, xres=args.xres, yres=args.yres, spp=args.spp)
+        if args.workload == "synthetic-vol":  # BASELINE config 4's stand-in: the mesh inside a HomogeneousMedium, VolPathIntegrator
+            txt = open(path).read()
+            txt = txt.replace("Camera ", FOG + "Camera ", 1).replace('Integrator "path"', 'Integrator "volpath"', 1)
+            txt = txt.replace("WorldBegin\n", 'WorldBegin\nMediumInterface "fog" "fog"\n', 1)
+            open(path, "w").write(txt)
     if args.filter != "box":
         txt = open(path).read().replace('PixelFilter "box"', f'PixelFilter "{args.filter}"')
         open(path, "w").write(txt)
@@ -54,8 +63,18 @@ def cpu_baseline(workdir, args):
     """The unmodified reference (oracle/_ref/pbrt_oracle) on the host cores, bounded sample of the same workload."""
     ref = os.path.join(ROOT, "oracle", "_ref", "pbrt_oracle")
     cores = os.cpu_count() or 1
-    xres, yres, spp = max(16, args.xres // 2), max(16, args.yres // 2), max(1, args.spp // 4)
-    sample = f"same scene, {xres}x{yres} @ {spp} spp ({xres * yres * spp / 1e6:.2f} Msamples)"
+    model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    # the whole frame at a quarter of the samples per pixel (the rate does not depend on spp): every one of the 8160 tiles
+    # is rendered, so the reference's thread pool is loaded as in the full job; --cpu-full renders all samples
+    xres, yres, spp = args.xres, args.yres, (args.spp if args.cpu_full else max(1, args.spp // 4))
+    sample = f"same scene, {xres}x{yres} @ {spp} spp ({xres * yres * spp / 1e6:.2f} Msamples) on {model}"
     if os.path.exists(ref):
         src = open(os.path.join(workdir, "synthetic.pbrt")).read()
         src = re.sub(r'"integer xresolution" \[ \d+ \]', f'"integer xresolution" [ {xres} ]', src)
@@ -65,7 +84,7 @@ def cpu_baseline(workdir, args):
         open(small, "w").write(src)
         try:
             out = subprocess.run([ref, "--nthreads", str(cores), "--outfile", os.path.join(workdir, "cpu.pfm"), small],
-                                 capture_output=True, text=True, timeout=900).stdout
+                                 capture_output=True, text=True, timeout=1500).stdout
             reg = int(re.search(r"Regular ray intersection tests\s+(\d+)", out).group(1))
             sh = int(re.search(r"Shadow ray intersection tests\s+(\d+)", out).group(1))
             secs = float(re.findall(r"\((\d+\.\d+)s\)", out)[-1])  # ProgressReporter's final elapsed time = time in Render()
@@ -92,13 +111,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="synthetic", choices=["synthetic", "cornell"])
+    ap.add_argument("--workload", default="synthetic", choices=["synthetic", "synthetic-vol", "cornell"],
+                    help="synthetic: BASELINE config 3 (with --grid 1582 --spp 256: the 5 M-triangle stand-in of config 4); "
+                         "synthetic-vol (--grid 2237 --spp 128): the 10 M-triangle volpath stand-in of config 5; cornell: config 2")
     ap.add_argument("--grid", type=int, default=708, help="heightfield vertices per side (708 -> 999 698 triangles)")
     ap.add_argument("--xres", type=int, default=1920)
     ap.add_argument("--yres", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--filter", default="box", help='PixelFilter of the scene (BASELINE config: "box")')
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline renders every sample of the frame (minutes)")
     ap.add_argument("--out", default=None, help="write the rendered image (PFM) here")
     args = ap.parse_args()
 
@@ -168,29 +190,62 @@ def main():
                 shards = [(film, strays, int(nstrays.item()))]
             img = pdist.merge_shards(pkg, scene, gs.tile_count, shards)
             pkg.write_pfm(args.out, img)
-        # roofline of the dominant kernel (k_trace<false>, BVHAccel::Intersect) on rank 0:
-        # algorithmic bytes = 32 B/node fetch + 48 B/triangle test + 32 B/ray in + 16 B/hit out
-        n_ray = cn["closest_rays"]
-        alg_bytes = 32 * cn["closest_node_visits"] + 48 * cn["closest_tri_tests"] + 32 * n_ray + 16 * n_ray
-        launches = max(1, cn["closest_launches"])
-        achieved = alg_bytes / (cn["closest_ms"] * 1e-3) / 1e9 if cn["closest_ms"] > 0 else 0.0
-        workload = ((f"synthetic heightfield-in-a-box, {scene.desc.n_tris} triangles" if args.workload == "synthetic"
+        # Rooflines of the three hot kernels on rank 0.  Algorithmic bytes:
+        #   k_trace: 32 B per reference node fetch + 48 B per triangle test + 32 B per ray in + 16 B (closest) / 4 B (any) out
+        #   k_shade: per path vertex 16 B ray direction + 16 B hit + 48 B state in + 48 B triangle + 48 B state out + 48 B
+        #            pending direct-light terms, + 32 B per ray pushed (+ 16 B of MIS terms per MIS ray)
+        # Time: HIP events around every launch on the stream it runs on (pg_render), so each kernel is timed alone.
+        # Bound: the BVH + triangle working set against the 256 MiB Infinity Cache -- below it the node/triangle gathers
+        # are served on-die and the binding bandwidth is the L2's; above it they reach HBM.
+        integ = "VolPathIntegrator + HomogeneousMedium" if args.workload == "synthetic-vol" else "PathIntegrator"
+        workload = ((f"synthetic heightfield-in-a-box, {scene.desc.n_tris} triangles" if args.workload != "cornell"
                      else "Cornell box, 36 triangles") +
-                    f", PathIntegrator maxdepth 5, halton, {args.filter} filter, {args.xres}x{args.yres} @ {args.spp} spp")
-        traffic = None  # HBM-side bytes per launch from the committed PMC passes of this same workload (tools/pmc_traffic.sh)
+                    f", {integ} maxdepth 5, halton, {args.filter} filter, {args.xres}x{args.yres} @ {args.spp} spp")
+        n_interior = max(0, (scene.desc.n_nodes - 1) // 2)
+        working_set = 64 * n_interior + 48 * scene.desc.n_tris  # child-pair records + triangle records
+        bound = "l2" if working_set < INFINITY_CACHE_BYTES else "hbm"
+        peak = L2_PEAK_GBS if bound == "l2" else HBM_PEAK_GBS
+        pmc_kernels = {}  # HBM-side bytes per launch from the committed PMC passes of this same workload (tools/pmc_traffic.sh)
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                j = json.load(open(pmc))
-                if j.get("workload") == workload:
-                    traffic = j.get("hbm_bytes_per_launch")
+                pmc_kernels = json.load(open(pmc)).get("workloads", {}).get(workload, {}).get("kernels", {})
             except Exception:
                 pass
-        roofline = {"bound": "hbm", "kernel": "k_trace<false> (BVHAccel::Intersect + Triangle::Intersect)",
-                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes / launches,
-                    "avg_launch_ms": cn["closest_ms"] / launches, "launches": launches,
-                    "bytes_per_ray": alg_bytes / max(1, n_ray)}
+
+        def kernel_roofline(name, tag, alg_bytes, ms, launches, units, unit_name):
+            launches = max(1, launches)
+            achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            traffic = next((v["hbm_bytes_per_launch"] for k, v in pmc_kernels.items() if k.startswith(tag)), None)
+            r = {"kernel": name, "bound": bound, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+                 "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes / launches, "avg_launch_ms": ms / launches,
+                 "launches": launches, "total_ms": ms, f"bytes_per_{unit_name}": alg_bytes / max(1, units)}
+            if traffic is not None and ms > 0:  # what the memory side of the L2 actually moved, against the HBM peak
+                hb = traffic * launches / (ms * 1e-3) / 1e9
+                r["hbm_side"] = {"achieved": hb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / HBM_PEAK_GBS}
+            return r
+
+        n_close, n_shadow, n_mis, n_items = cn["closest_rays"], cn["shadow_rays"], cn["mis_rays"], cn["shade_items"]
+        n_next = max(0, n_close - cn["camera_rays"] - n_mis)
+        kernels = [
+            kernel_roofline("k_trace<false> (BVHAccel::Intersect + Triangle::Intersect)", "void k_trace<false",
+                            32 * cn["closest_node_visits"] + 48 * cn["closest_tri_tests"] + 48 * n_close,
+                            cn["closest_ms"], cn["closest_launches"], n_close, "ray"),
+            kernel_roofline("k_trace<true> (BVHAccel::IntersectP + Triangle::IntersectP)", "void k_trace<true",
+                            32 * cn["shadow_node_visits"] + 48 * cn["shadow_tri_tests"] + 36 * n_shadow,
+                            cn["shadow_ms"], cn["shadow_launches"], n_shadow, "ray"),
+            kernel_roofline("k_shade (PathIntegrator::Li loop body + EstimateDirect set-up)", "void k_shade",
+                            224 * n_items + 32 * (n_next + n_shadow + n_mis) + 16 * n_mis,
+                            cn["shade_ms"], cn["shade_launches"], n_items, "vertex"),
+        ]
+        kernels = [k for k in kernels if k["total_ms"] > 0]
+        kernels.sort(key=lambda k: -k["total_ms"])  # dominant = the most time, each kernel timed alone
+        roofline = dict(kernels[0]) if kernels else {"kernel": None, "bound": bound, "achieved": 0.0, "peak": peak, "unit": "GB/s", "frac": 0.0, "traffic": None}
+        roofline["working_set_bytes"] = working_set
+        roofline["bound_reason"] = (f"BVH + triangle records {working_set / 2**20:.0f} MiB " +
+                                    ("fit the 256 MiB Infinity Cache: gathers are served on-die, L2 bandwidth is the ceiling"
+                                     if bound == "l2" else "exceed the 256 MiB Infinity Cache: gathers reach HBM"))
+        other_ms = {k: cn[k] for k in ("resolve_ms", "generate_ms", "film_ms")}
         result = {
             "metric": "Mrays/s", "value": rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -200,6 +255,9 @@ def main():
                        "sharding": f"16x16 film tiles round-robin over {world} GPU(s), RCCL gather to rank 0",
                        "rays_per_sample": rays / max(1.0, samples), "host_parse_and_bvh_s": t_parse},
             "roofline": roofline,
+            "roofline_kernels": kernels,
+            "kernel_ms_per_step": {**{k["kernel"].split(" ")[0]: k["total_ms"] / args.steps for k in kernels},
+                                   **{k[:-3]: v / args.steps for k, v in other_ms.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(workdir, args)

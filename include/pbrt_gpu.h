@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 19
+#define PG_ABI_VERSION 20
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -434,6 +434,11 @@ typedef struct PgCounters {
     uint64_t closest_launches, shadow_launches;
     double closest_ms, shadow_ms; /* HIP-event time inside the traversal kernels */
     double render_ms;
+    /* the other kernels of the wavefront (path integrator): launches, items and HIP-event times */
+    uint64_t shade_launches, resolve_launches;
+    uint64_t shade_items; /* path vertices handed to the shading kernel (= main-queue rays traced) */
+    uint64_t mis_rays;    /* of closest_rays: the BSDF-sampled rays of EstimateDirect (integrator.cpp:164-212) */
+    double shade_ms, resolve_ms, generate_ms, film_ms;
 } PgCounters;
 
 typedef struct PgScene PgScene;

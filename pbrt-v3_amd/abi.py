@@ -5,7 +5,7 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 19
+PG_ABI_VERSION = 20
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
 PG_LIGHTS_UNIFORM, PG_LIGHTS_POWER, PG_LIGHTS_SPATIAL = 0, 1, 2
@@ -139,7 +139,10 @@ class PgCounters(C.Structure):
                 ("closest_node_visits", C.c_uint64), ("closest_tri_tests", C.c_uint64),
                 ("shadow_node_visits", C.c_uint64), ("shadow_tri_tests", C.c_uint64),
                 ("closest_launches", C.c_uint64), ("shadow_launches", C.c_uint64),
-                ("closest_ms", C.c_double), ("shadow_ms", C.c_double), ("render_ms", C.c_double)]
+                ("closest_ms", C.c_double), ("shadow_ms", C.c_double), ("render_ms", C.c_double),
+                ("shade_launches", C.c_uint64), ("resolve_launches", C.c_uint64), ("shade_items", C.c_uint64),
+                ("mis_rays", C.c_uint64), ("shade_ms", C.c_double), ("resolve_ms", C.c_double),
+                ("generate_ms", C.c_double), ("film_ms", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -54,7 +54,7 @@ struct PgScene {
         lightTests, filmDev, straysDev, nStraysDev, cullGuard, cursors, cursors2;
     hipStream_t shadowStream = nullptr;  // any-hit launches run here, concurrently with the next closest-hit launch
     hipEvent_t evShaded = nullptr, evShadowed = nullptr;
-    bool overlapShadow = true;
+    bool overlapShadow = false;  // PG_OVERLAP_SHADOW=1: any-hit launch on a second stream beside the closest-hit launch (per-kernel times then overlap)
     // test-path buffers
     DeviceBuffer tO, tD, tT, tPrim, tHit, tOcc, tCount;
     PgCounters counters;
@@ -748,11 +748,17 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
     unsigned long long *lightTests = (unsigned long long *)s->lightTests.p;
 
     size_t ev = 0;
-    std::vector<std::pair<size_t, int>> timed;  // (event index, 0 closest / 1 shadow)
+    std::vector<std::pair<size_t, int>> timed;  // (event index, kernel: 0 closest-hit, 1 any-hit, 2 shade, 3 resolve, 4 generate, 5 film)
+    // HIP events around one launch on `st_` (the stream the kernel runs on); per-kernel times are only meaningful while the
+    // any-hit launch does not share the chip with the closest-hit launch (PG_OVERLAP_SHADOW=0, the default)
+#define PG_TIMED(kind_, st_, launch_) do { hipEvent_t a_ = getEvent(s, ev), b_ = getEvent(s, ev + 1); \
+        if (!a_ || !b_) return setError(PG_ERR_DEVICE, "hipEventCreate failed"); \
+        timed.push_back({ev, kind_}); ev += 2; HIP_TRY(hipEventRecord(a_, st_)); launch_; HIP_TRY(hipEventRecord(b_, st_)); } while (0)
     hipEvent_t evStart = getEvent(s, ev++), evStop = getEvent(s, ev++);
     if (!evStart || !evStop) return setError(PG_ERR_DEVICE, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(evStart, stream));
     uint64_t closestRays = 0, shadowRays = 0, cameraRays = 0, closestLaunches = 0, shadowLaunches = 0;
+    uint64_t shadeLaunches = 0, resolveLaunches = 0, shadeItems = 0, misRays = 0;
     std::vector<int> hostCounts;  // read back once per batch at the end (pinned copy not needed: tiny)
     DeviceBuffer countLog;        // per-bounce queue sizes, copied back after the batch for the ray statistics
     const int maxIters = rd->max_depth + 1 + (s->hasNullMaterial ? 64 : 0);
@@ -770,7 +776,7 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
             curQueueOfBounce.clear();
             HIP_TRY(hipMemsetAsync(counts, 0, 4 * QSTRIDE * sizeof(int), stream));
             int cur = 0;  // main queue index (0/1 ping-pong); 2 = shadow, 3 = MIS
-            launch_generate(s->d, rp, ps, q[cur], stream);
+            PG_TIMED(4, stream, launch_generate(s->d, rp, ps, q[cur], stream));
             if (vol) {
                 // VolPathIntegrator::Li (volpath.cpp:72-186).  Per loop iteration: closest-hit(main rays, with the hits' ray
                 // parameters) -> shade with medium sampling -> the transmittance rays of the light samples and of the
@@ -795,11 +801,12 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
                 for (int iter = 0; nMain > 0; ++iter) {
                     if (iter > 100000) return setError(PG_ERR_DEVICE, "pg_render: volpath loop did not terminate");
                     const int nxt = cur ^ 1;
-                    launch_closest(dv, q[cur], (float4 *)s->hitsMain.p, hitT, cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream);
-                    ++closestLaunches; closestRays += nMain;
+                    PG_TIMED(0, stream, launch_closest(dv, q[cur], (float4 *)s->hitsMain.p, hitT, cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream));
+                    ++closestLaunches; closestRays += nMain; shadeItems += nMain;
                     HIP_TRY(hipMemsetAsync(counts + nxt * QSTRIDE, 0, QSTRIDE * sizeof(int), stream));
                     HIP_TRY(hipMemsetAsync(counts + 2 * QSTRIDE, 0, 2 * QSTRIDE * sizeof(int), stream));
-                    launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream);
+                    PG_TIMED(2, stream, launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream));
+                    ++shadeLaunches;
                     // through rays: kind 0 = light samples (q[2] <-> vq[0]), kind 1 = BSDF / phase samples (q[3] <-> vq[1])
                     RayQueue tq[2][2] = {{q[2], vq[0]}, {q[3], vq[1]}};
                     int tcur = 0;
@@ -809,7 +816,7 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
                         const uint64_t n0 = tcur == 0 ? queueTotal(blk.data(), 2) : queueTotal(vblk.data(), 0);
                         const uint64_t n1q = tcur == 0 ? queueTotal(blk.data(), 3) : queueTotal(vblk.data(), 1);
                         if (n0 + n1q == 0) break;
-                        launch_closest2(dv, tq[0][tcur], tq[1][tcur], (float4 *)s->hitsMain.p, n1, cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream, hitT);
+                        PG_TIMED(0, stream, launch_closest2(dv, tq[0][tcur], tq[1][tcur], (float4 *)s->hitsMain.p, n1, cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream, hitT));
                         ++closestLaunches; closestRays += n0 + n1q;
                         HIP_TRY(hipMemsetAsync(tq[0][tcur ^ 1].counts, 0, QSTRIDE * sizeof(int), stream));
                         HIP_TRY(hipMemsetAsync(tq[1][tcur ^ 1].counts, 0, QSTRIDE * sizeof(int), stream));
@@ -817,7 +824,8 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
                         launch_through(dv, ps, vs, 1, tq[1][tcur], (const float4 *)s->hitsMain.p, hitT, n1, tq[1][tcur ^ 1], stream);
                         tcur ^= 1;
                     }
-                    launch_resolve_vol(dv, ps, vs, q[cur], stream);
+                    PG_TIMED(3, stream, launch_resolve_vol(dv, ps, vs, q[cur], stream));
+                    ++resolveLaunches;
                     // the next pass of the through loop reads counts again; the main queue's size comes from the same block
                     nMain = queueTotal(blk.data(), nxt);
                     cur = nxt;
@@ -845,7 +853,8 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
                 const int nxt = cur ^ 1;
                 HIP_TRY(hipMemsetAsync(counts + nxt * QSTRIDE, 0, QSTRIDE * sizeof(int), stream));
                 HIP_TRY(hipMemsetAsync(counts + 2 * QSTRIDE, 0, 2 * QSTRIDE * sizeof(int), stream));
-                launch_shade(s->d, rp, ps, q[cur], (const float4 *)s->hitsMain.p, q[nxt], q[2], q[3], lightTests, stream);
+                PG_TIMED(2, stream, launch_shade(s->d, rp, ps, q[cur], (const float4 *)s->hitsMain.p, q[nxt], q[2], q[3], lightTests, stream));
+                ++shadeLaunches;
                 // paths that reach maxdepth neither continue nor sample lights (path.cpp:104): nothing left to trace
                 const bool lastDepth = !s->hasNullMaterial && bounce >= rd->max_depth;
                 if (!lastDepth) {
@@ -866,7 +875,8 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
                     if (s->overlapShadow) HIP_TRY(hipEventRecord(s->evShadowed, sst));
                     if (int e = timedClosest(q[nxt], (float4 *)s->hitsMain.p, &q[3], hitsMis)) return e;
                     if (s->overlapShadow) HIP_TRY(hipStreamWaitEvent(stream, s->evShadowed, 0));
-                    launch_resolve(s->d, ps, q[cur], q[3], (const int *)s->occluded.p, (const float4 *)hitsMis, stream);
+                    PG_TIMED(3, stream, launch_resolve(s->d, ps, q[cur], q[3], (const int *)s->occluded.p, (const float4 *)hitsMis, stream));
+                    ++resolveLaunches;
                 }
                 // log this bounce's queue sizes
                 HIP_TRY(hipMemcpyAsync((int *)countLog.p + 4 * QSTRIDE * (size_t)bounce, counts, 4 * QSTRIDE * sizeof(int), hipMemcpyDeviceToDevice, stream));
@@ -879,8 +889,8 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
                     if (queueTotal(blk.data(), cur) == 0) { ++iters; break; }
                 }
             }
-            if (rd->filter_general) launch_film_general(rp, ps, dFilm, stream);
-            else launch_film(rp, ps, dFilm, dStrays, maxStrays, dNStrays, stream);
+            PG_TIMED(5, stream, if (rd->filter_general) launch_film_general(rp, ps, dFilm, stream);
+                                else launch_film(rp, ps, dFilm, dStrays, maxStrays, dNStrays, stream));
             hostCounts.resize(4 * QSTRIDE * (size_t)iters);
             HIP_TRY(hipMemcpyAsync(hostCounts.data(), countLog.p, sizeof(int) * 4 * QSTRIDE * (size_t)iters, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
@@ -888,6 +898,8 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
                 const int *blk = hostCounts.data() + 4 * QSTRIDE * (size_t)b;
                 closestRays += queueTotal(blk, curQueueOfBounce[b]) + queueTotal(blk, 3);
                 shadowRays += queueTotal(blk, 2);
+                shadeItems += queueTotal(blk, curQueueOfBounce[b]);
+                misRays += queueTotal(blk, 3);
                 if (getenv("PG_PRINT_COUNTS"))
                     fprintf(stderr, "pg_render: bounce %d main %llu shadow %llu mis %llu\n", b, (unsigned long long)queueTotal(blk, curQueueOfBounce[b]),
                             (unsigned long long)queueTotal(blk, 2), (unsigned long long)queueTotal(blk, 3));
@@ -922,10 +934,14 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
     c.closest_node_visits = tc[0].node_visits; c.closest_tri_tests = tc[0].tri_tests;
     c.shadow_node_visits = tc[1].node_visits; c.shadow_tri_tests = tc[1].tri_tests;
     c.closest_launches += closestLaunches; c.shadow_launches += shadowLaunches;
+    c.shade_launches += shadeLaunches; c.resolve_launches += resolveLaunches; c.shade_items += shadeItems; c.mis_rays += misRays;
     for (auto &te : timed) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, s->events[te.first], s->events[te.first + 1]) == hipSuccess) (te.second ? c.shadow_ms : c.closest_ms) += ms;
+        if (hipEventElapsedTime(&ms, s->events[te.first], s->events[te.first + 1]) != hipSuccess) continue;
+        double *acc[6] = {&c.closest_ms, &c.shadow_ms, &c.shade_ms, &c.resolve_ms, &c.generate_ms, &c.film_ms};
+        *acc[te.second] += ms;
     }
+#undef PG_TIMED
     float ms = 0;
     if (hipEventElapsedTime(&ms, evStart, evStop) == hipSuccess) c.render_ms += ms;
     if (int st2 = checkCullGuard(s)) return st2;

@@ -13,6 +13,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes of host CPU time (the reference binary at full size); PBRT_SKIP_SLOW=1 skips")
 
 
 @pytest.fixture(scope="session")

@@ -1,0 +1,34 @@
+"""BASELINE.json configs 2 and 3 at FULL size against the unmodified reference binary (oracle/_ref/pbrt_oracle travels to the
+GPU box): the device image vs the reference's PFM, per-pixel |d| <= 1e-4 * max(1, |ref|), and the reference's own ray counters.
+The reference needs ~1 min (Cornell 512x512 @ 256 spp) and ~2-3 min (1920x1080 @ 64 spp, 1 M triangles) on the box's host
+cores: slow, so PBRT_SKIP_SLOW=1 skips it.  A pixel outside the tolerance must be reproduced bit for bit by the CPU oracle
+built with correctly rounded libm (tools/fullsize_parity.py)."""
+import json
+import os
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = [pytest.mark.gpu, pytest.mark.slow]
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.mark.parametrize("config", [2, 3])
+def test_full_size_image_matches_reference_binary(gpu, oracle, config):
+    if os.environ.get("PBRT_SKIP_SLOW") == "1":
+        pytest.skip("PBRT_SKIP_SLOW=1")
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "pbrt_oracle")):
+        pytest.fail("oracle/_ref/pbrt_oracle missing: __graft_entry__.build() makes it where /root/reference exists, and it travels with the tree")
+    import fullsize_parity
+    r = fullsize_parity.run(config)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(r, open(os.path.join(ROOT, "gpurun_out", f"fullsize_parity_config{config}.json"), "w"), indent=1)
+    assert r["device_counters"]["camera_rays"] == r["reference_counters"]["camera_rays"]
+    # libm's last bit tips a discrete event once in ~1e4 paths: the counters agree to a few parts in 1e4, not exactly
+    for k in ("closest_rays", "shadow_rays"):
+        assert abs(r["counter_rel_delta"][k]) <= 2e-3, (k, r["counter_rel_delta"][k])
+    assert r["p9999_rel_err"] <= 1e-4
+    assert r["pixels_over_tol"] == r["pixels_over_tol_reproduced_bitwise_by_cr_oracle"], r
+    assert r["pixels_over_tol"] <= 1e-4 * r["compared_pixels"], r

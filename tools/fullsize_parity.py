@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Full-size parity of the device path against the UNMODIFIED reference binary (oracle/_ref/pbrt_oracle), on the GPU box.
+
+  config 2: Cornell box, 512x512 @ 256 spp, whole frame
+  config 3: synthetic 999 710-triangle scene, 1920x1080 @ 64 spp, whole frame
+  config 4: 5 M-triangle stand-in, path, 1920x1080 @ 256 spp -- a 256x144 window of the full frame (Integrator "pixelbounds")
+  config 5: 10 M-triangle stand-in in a HomogeneousMedium, volpath, 1920x1080 @ 128 spp -- the same window
+
+Both renderers read the same .pbrt file; the reference writes a PFM (core/imageio.cpp:437-482), the device film goes through
+the host Film (MergeFilmTile + WriteImage arithmetic).  Reported per config: max / 99.99th percentile / count of pixels with
+|d| > 1e-4 * max(1, |ref|), the share of bit-identical pixels, and the ray counters of both.  A pixel outside the tolerance is
+re-rendered ALONE by the CPU oracle built with correctly rounded libm (the device's libm behaviour): it must reproduce the
+device's pixel bit for bit -- then the difference is a last-bit libm difference that tipped a discrete event, not an error of
+the device path.  TEST INFRASTRUCTURE: uses oracle/.  One JSON line per config.
+
+usage: python tools/fullsize_parity.py [2] [3] [4] [5] [--out FILE.json]"""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "scenes"))
+import gen_synthetic  # noqa: E402
+from __graft_entry__ import load_package  # noqa: E402
+
+TOL = 1e-4
+FOG = ('MakeNamedMedium "fog" "string type" "homogeneous" "rgb sigma_a" [ 0.02 0.03 0.04 ] "rgb sigma_s" [ 0.15 0.12 0.1 ] "float g" [ 0.4 ]\n'
+       'MediumInterface "" "fog"\n')
+WINDOW = (832, 468, 1088, 612)  # 256x144 pixels in the middle of the 1920x1080 frame
+
+
+def write_config(config, d):
+    path = os.path.join(d, f"config{config}.pbrt")
+    window = None
+    if config == 2:
+        open(path, "w").write(open(os.path.join(ROOT, "scenes", "cornell.pbrt")).read())
+    else:
+        n, spp = {3: (708, 64), 4: (1582, 256), 5: (2237, 128)}[config]
+        gen_synthetic.write_scene(path, n=n, xres=1920, yres=1080, spp=spp, filename=f"config{config}.pfm")
+        s = open(path).read()
+        if config == 5:
+            s = s.replace("Camera ", FOG + "Camera ", 1).replace('Integrator "path"', 'Integrator "volpath"', 1)
+            s = s.replace("WorldBegin\n", 'WorldBegin\nMediumInterface "fog" "fog"\n', 1)
+        if config >= 4:
+            window = WINDOW
+            s = re.sub(r'(Integrator "(?:vol)?path")', r'\1 "integer pixelbounds" [ %d %d %d %d ]' % (window[0], window[2], window[1], window[3]), s, count=1)
+        open(path, "w").write(s)
+    return path, window
+
+
+def reference_render(path, out_pfm):
+    ref = os.path.join(ROOT, "oracle", "_ref", "pbrt_oracle")
+    t0 = time.time()
+    out = subprocess.run([ref, "--nthreads", str(os.cpu_count() or 1), "--outfile", out_pfm, path], capture_output=True, text=True, check=True).stdout
+    wall = time.time() - t0
+    stat = lambda pat: int(re.search(pat + r"\s+(\d+)", out).group(1))
+    cn = {"camera_rays": stat(r"Camera rays traced"), "closest_rays": stat(r"Regular ray intersection tests"),
+          "shadow_rays": stat(r"Shadow ray intersection tests")}
+    m = re.search(r"Ray-triangle intersection tests\s+(\d+) /\s+(\d+)", out)
+    if m:
+        cn["tri_tests"] = int(m.group(2))
+    secs = re.findall(r"\((\d+\.\d+)s\)", out)
+    return cn, (float(secs[-1]) if secs else None), wall
+
+
+def run(config):
+    pkg = load_package()
+    from oracle import oracle
+    with tempfile.TemporaryDirectory() as d:
+        path, window = write_config(config, d)
+        scene = pkg.HostScene(path)
+        gs = pkg.GpuScene(scene.desc)
+        rd = scene.render_desc()
+        film, strays = gs.render(rd)
+        cn = gs.counters()
+        scene.film_clear(); scene.film_merge(rd, film, strays)
+        img = scene.film_image()
+        ref_pfm = os.path.join(d, "ref.pfm")
+        rcn, ref_render_s, ref_wall_s = reference_render(path, ref_pfm)
+        ref = pkg.read_pfm(ref_pfm)
+    assert ref.shape == img.shape, (ref.shape, img.shape)
+    if window:  # the reference writes the cropped image only when cropwindow is set; pixelbounds leaves the rest black in both
+        x0, y0, x1, y1 = window
+        img_w, ref_w = img[y0:y1, x0:x1], ref[y0:y1, x0:x1]
+        outside_black = bool((np.delete(img.reshape(-1, 3), np.ravel_multi_index(np.mgrid[y0:y1, x0:x1].reshape(2, -1), img.shape[:2]), axis=0) == 0).all())
+    else:
+        x0 = y0 = 0
+        img_w, ref_w, outside_black = img, ref, True
+    err = (np.abs(img_w - ref_w) / np.maximum(1.0, np.abs(ref_w))).max(axis=2)
+    bad = np.argwhere(err > TOL)
+    # every out-of-tolerance pixel, alone, by the CPU oracle with correctly rounded libm: it must equal the device's pixel
+    explained = 0
+    for (yy, xx) in bad[:64]:
+        rdp = scene.render_desc()
+        px, py = int(xx) + x0, int(yy) + y0
+        rdp.pixel_bounds[0], rdp.pixel_bounds[1], rdp.pixel_bounds[2], rdp.pixel_bounds[3] = px, py, px + 1, py + 1
+        ofilm, ostrays, _ = oracle.render(scene.desc, rdp, cr_libm=True)
+        scene.film_clear(); scene.film_merge(rdp, ofilm, ostrays)
+        if np.array_equal(scene.film_image()[py, px], img[py, px]):
+            explained += 1
+    out = {"config": config, "triangles": int(scene.desc.n_tris), "integrator": "volpath" if config == 5 else "path",
+           "frame": f"{img.shape[1]}x{img.shape[0]}", "spp": int(rd.spp), "compared_pixels": int(err.size),
+           "window": list(window) if window else None, "outside_window_black": outside_black,
+           "max_rel_err": float(err.max()), "p9999_rel_err": float(np.percentile(err, 99.99)), "pixels_over_tol": int(len(bad)), "tol": TOL,
+           "pixels_over_tol_reproduced_bitwise_by_cr_oracle": explained, "bit_identical_pixel_share": float((img_w == ref_w).all(axis=2).mean()),
+           "mean_ref": float(ref_w.mean()), "mean_device": float(img_w.mean()),
+           "device_counters": {k: int(cn[k]) for k in ("camera_rays", "closest_rays", "shadow_rays", "tri_tests")},
+           "reference_counters": rcn,
+           "counter_rel_delta": {k: (cn[k] - rcn[k]) / max(1, rcn[k]) for k in rcn},
+           "device_render_ms": float(cn["render_ms"]), "reference_render_s": ref_render_s, "reference_wall_s": round(ref_wall_s, 1),
+           "reference_threads": os.cpu_count()}
+    gs.close()
+    return out
+
+
+if __name__ == "__main__":
+    outfile = None
+    cfgs = []
+    for a in sys.argv[1:]:
+        if a.startswith("--out="): outfile = a[6:]
+        else: cfgs.append(int(a))
+    res = []
+    for c in cfgs or [2, 3]:
+        r = run(c)
+        res.append(r)
+        print(json.dumps(r), flush=True)
+    if outfile:
+        json.dump(res, open(outfile, "w"), indent=1)

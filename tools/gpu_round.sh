@@ -1,14 +1,32 @@
 #!/bin/bash
-# One gpurun call: GPU parity tests, the headline bench, and the rocprofv3 kernel-trace summary.
-# usage (from the repo root on the GPU box): bash tools/gpu_round.sh [tag]
-TAG=${1:-r01}
+# One gpurun call: GPU parity tests, the headline bench, the rocprofv3 kernel-trace summary and the PMC traffic passes.
+# usage (from the repo root on the GPU box): bash tools/gpu_round.sh TAG [quick|full]
+#   quick: tests (without the slow full-size reference comparison) + bench + kernel stats
+#   full : + PMC passes for config 3, the 5 M-triangle stand-in (bench, kernel stats, PMC) and the slow tests
+TAG=${1:-r02}; MODE=${2:-quick}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-( timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 ) > $OUT/pytest_gpu.log
-( timeout 600 python bench.py --steps 2 --warmup 1 2> $OUT/bench.err ) > $OUT/bench.json
-( timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/prof.err )
-find $OUT/prof -name '*kernel_stats*' -exec cp {} $OUT/kernel_stats.csv \;
-find $OUT/prof -name '*kernel_trace*' -size +8M -delete
-tail -5 $OUT/pytest_gpu.log; cat $OUT/bench.json; head -12 $OUT/kernel_stats.csv
-bash tools/pmc_traffic.sh $TAG/traffic > $OUT/traffic.log 2>&1; cp $OUT/traffic/pmc_traffic.json $OUT/pmc_traffic.json 2>/dev/null
+prof() {  # prof NAME bench-args...: kernel-trace stats of one bench run
+  local name=$1; shift
+  ( timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -o trace -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $OUT/bench_prof_$name.json 2> $OUT/prof_$name.err )
+  find $OUT/prof_$name -name '*kernel_stats*' -exec cp {} $OUT/kernel_stats_$name.csv \;
+  rm -rf $OUT/prof_$name
+}
+( PBRT_SKIP_SLOW=1 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 ) > $OUT/pytest_gpu.log
+( timeout 900 python bench.py --steps 2 --warmup 1 2> $OUT/bench.err ) > $OUT/bench.json
+prof cfg3
+tail -5 $OUT/pytest_gpu.log; cat $OUT/bench.json; head -8 $OUT/kernel_stats_cfg3.csv
+if [ "$MODE" = full ]; then
+  bash tools/pmc_traffic.sh $TAG/traffic_cfg3 > $OUT/traffic_cfg3.log 2>&1
+  ( timeout 900 python bench.py --steps 2 --warmup 1 --grid 1582 --spp 256 --no-cpu-baseline 2> $OUT/bench_5m.err ) > $OUT/bench_5m.json
+  prof 5m --grid 1582 --spp 256
+  cp $OUT/traffic_cfg3/pmc_traffic.json profiles/pmc_traffic.json 2>/dev/null
+  bash tools/pmc_traffic.sh $TAG/traffic_5m --steps 1 --warmup 0 --no-cpu-baseline --grid 1582 --spp 256 > $OUT/traffic_5m.log 2>&1
+  cp $OUT/traffic_5m/pmc_traffic.json $OUT/pmc_traffic.json 2>/dev/null
+  cat $OUT/bench_5m.json; head -6 $OUT/kernel_stats_5m.csv
+  ( timeout 1500 python -m pytest tests/test_gpu_fullsize_reference.py -m gpu -x -q 2>&1 | tail -15 ) > $OUT/pytest_slow.log
+  cp gpurun_out/fullsize_parity_config*.json $OUT/ 2>/dev/null
+  tail -5 $OUT/pytest_slow.log
+  find $OUT -name '*counter_collection.csv' -size +4M -delete
+fi

@@ -1,35 +1,46 @@
 #!/bin/bash
-# HBM-side bytes of the dominant kernel from PMC counters, collected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and
-# WRITE_SIZE in separate --pmc passes (no --stats/trace), units KiB, read side doubled (gfx950: FETCH_SIZE tallies 128-B
-# requests at 64 B).  Writes profiles/pmc_traffic.json, which bench.py reports as roofline.traffic for the same workload.
+# HBM-side bytes of every kernel from PMC counters, collected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in
+# separate --pmc passes (no --stats/trace), units KiB, read side doubled (gfx950: FETCH_SIZE tallies 128-B requests at 64 B).
+# A third pass takes the L2 hit/miss counters.  Merges the result into OUT/pmc_traffic.json under the workload's name; copy
+# that file to profiles/pmc_traffic.json and bench.py reports it as roofline.traffic for the same workload.
 # usage: bash tools/pmc_traffic.sh TAG [bench args]
 TAG=${1:-traffic}; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 ARGS="${@:---steps 1 --warmup 0 --no-cpu-baseline}"
-for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/$C -o pmc -- python bench.py $ARGS > $OUT/$C.json 2> $OUT/$C.err
+for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+  D=$(echo $C | cut -d' ' -f1)
+  timeout 900 rocprofv3 --pmc $C --output-format csv -d $OUT/$D -o pmc -- python bench.py $ARGS > $OUT/$D.json 2> $OUT/$D.err
 done
 python - $OUT "$ARGS" <<'PY'
-import csv, glob, json, os, sys, re
+import csv, glob, json, os, sys
 out, args = sys.argv[1], sys.argv[2]
 tot = {}
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    v = {}; n = {}
-    for f in glob.glob(os.path.join(out, c, "**", "*counter_collection.csv"), recursive=True):
+for d, names in (("FETCH_SIZE", ["FETCH_SIZE"]), ("WRITE_SIZE", ["WRITE_SIZE"]), ("TCC_HIT_sum", ["TCC_HIT_sum", "TCC_MISS_sum"])):
+    for f in glob.glob(os.path.join(out, d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] != c: continue
+            c = r["Counter_Name"]
+            if c not in names: continue
             k = r["Kernel_Name"].split("(")[0]
-            v[k] = v.get(k, 0.0) + float(r["Counter_Value"]); n.setdefault(k, set()).add(r["Dispatch_Id"])
-    tot[c] = {k: (v[k], len(n[k])) for k in v}
+            e = tot.setdefault(c, {}).setdefault(k, [0.0, set()])
+            e[0] += float(r["Counter_Value"]); e[1].add(r["Dispatch_Id"])
 j = json.loads(open(os.path.join(out, "FETCH_SIZE.json")).read().strip().splitlines()[-1])
-res = {"workload": j["config"]["workload"], "kernels": {}}
-for k in tot["FETCH_SIZE"]:
-    f, nf = tot["FETCH_SIZE"][k]; w, nw = tot["WRITE_SIZE"].get(k, (0.0, 1))
-    res["kernels"][k] = {"launches": nf, "fetch_KiB_per_launch": f / nf, "write_KiB_per_launch": w / max(1, nw),
-                         "hbm_bytes_per_launch": (2 * f / nf + w / max(1, nw)) * 1024}
-dom = [k for k in res["kernels"] if "k_trace<false" in k]
-if dom: res["hbm_bytes_per_launch"] = res["kernels"][dom[0]]["hbm_bytes_per_launch"]
-res["note"] = "FETCH_SIZE, WRITE_SIZE in KiB from separate rocprofv3 --pmc passes; read side x2 (gfx950 correction, calibrated for 16 B/lane streaming reads; an upper bound for this gather pattern)"
-json.dump(res, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
-print(json.dumps(res, indent=1))
+res = {"bench_args": args, "kernels": {}}
+for k, (f, nf) in tot.get("FETCH_SIZE", {}).items():
+    w, nw = tot.get("WRITE_SIZE", {}).get(k, (0.0, {0}))
+    e = {"launches": len(nf), "fetch_KiB_per_launch": f / len(nf), "write_KiB_per_launch": w / max(1, len(nw)),
+         "hbm_bytes_per_launch": (2 * f / len(nf) + w / max(1, len(nw))) * 1024}
+    h, m = tot.get("TCC_HIT_sum", {}).get(k, (0.0, 0))[0], tot.get("TCC_MISS_sum", {}).get(k, (0.0, 0))[0]
+    if h + m > 0: e["l2_hit_rate"] = h / (h + m)
+    res["kernels"][k] = e
+res["note"] = ("FETCH_SIZE, WRITE_SIZE in KiB from separate rocprofv3 --pmc passes; read side x2 (gfx950 correction, calibrated for 16 B/lane "
+               "streaming reads; an upper bound for gather patterns); these are the L2's memory-side requests, Infinity-Cache hits included")
+dst = os.path.join(out, "pmc_traffic.json")
+allj = {"workloads": {}}
+for src in (os.path.join("profiles", "pmc_traffic.json"), dst):
+    if os.path.exists(src):
+        try: allj["workloads"].update(json.load(open(src)).get("workloads", {}))
+        except Exception: pass
+allj["workloads"][j["config"]["workload"]] = res
+json.dump(allj, open(dst, "w"), indent=1)
+print(json.dumps({j["config"]["workload"]: res}, indent=1))
 PY
