@@ -119,13 +119,14 @@ Bounds3f GeometricPrimitive::WorldBound() const {
     return sphere ? sphere->WorldBound() : shape.WorldBound();
 }
 
-struct BVHAccel::PrimInfo {  // BVHPrimitiveInfo, bvh.cpp:49-59
-    PrimInfo() {}
-    PrimInfo(size_t primitiveNumber, const Bounds3f &bounds)
-        : primitiveNumber(primitiveNumber), bounds(bounds), centroid(.5f * bounds.pMin + .5f * bounds.pMax) {}
-    size_t primitiveNumber;
+struct BVHAccel::PrimInfo {  // what the build knows of a primitive (BVHPrimitiveInfo, bvh.cpp:49-59)
+    size_t primitiveNumber = 0;
     Bounds3f bounds;
-    Point3f centroid;
+    Point3f centroid;  // [order] .5f * pMin + .5f * pMax, not (pMin + pMax) / 2
+    PrimInfo() {}
+    PrimInfo(size_t index, const Bounds3f &b) : primitiveNumber(index), bounds(b) {
+        for (int k = 0; k < 3; ++k) centroid[k] = .5f * b.pMin[k] + .5f * b.pMax[k];
+    }
 };
 struct BVHAccel::BuildNode {  // BVHBuildNode, bvh.cpp:61-83
     void InitLeaf(int first, int n, const Bounds3f &b) {
@@ -236,7 +237,35 @@ Bounds3f BVHAccel::WorldBound() const {  // bvh.cpp:228-230
     return b;
 }
 
-struct BucketInfo { int count = 0; Bounds3f bounds; };
+// The 12-bucket surface-area-heuristic sweep shared by recursiveBuild and buildUpperSAH.  For every boundary i between
+// buckets the reference re-unions buckets 0..i and i+1..11 (bvh.cpp:329-345, :599-614); here one forward and one backward
+// pass over the buckets produce the same eleven (bounds, count) pairs -- unions are min / max of floats and the counts are
+// integers, so both are exact and the costs come out bit-identical: base + (n0 * area(b0) + n1 * area(b1)) / area(all).
+struct SahBuckets {
+    static constexpr int N = 12;
+    int count[N] = {};
+    Bounds3f box[N];
+    void Add(int b, const Bounds3f &bounds) { ++count[b]; box[b] = Union(box[b], bounds); }
+    // bucket index after which to split (the FIRST of the cheapest boundaries) and its cost
+    int CheapestBoundary(Float base, const Bounds3f &all, Float *costOut) const {
+        Bounds3f above[N];  // above[i] = union of buckets i+1 .. N-1
+        int nAbove[N];
+        Bounds3f acc;
+        int n = 0;
+        for (int i = N - 1; i >= 0; --i) { above[i] = acc; nAbove[i] = n; acc = Union(acc, box[i]); n += count[i]; }
+        const Float totalArea = all.SurfaceArea();
+        acc = Bounds3f(); n = 0;
+        int best = 0;
+        Float bestCost = 0;
+        for (int i = 0; i < N - 1; ++i) {
+            acc = Union(acc, box[i]); n += count[i];
+            const Float c = base + (n * acc.SurfaceArea() + nAbove[i] * above[i].SurfaceArea()) / totalArea;
+            if (i == 0 || c < bestCost) { bestCost = c; best = i; }
+        }
+        *costOut = bestCost;
+        return best;
+    }
+};
 
 BVHAccel::BuildNode *BVHAccel::recursiveBuild(std::vector<PrimInfo> &primitiveInfo, int start, int end, std::atomic<int> *totalNodes,
                                               std::vector<GeometricPrimitive> &orderedPrims, int spawnDepth) {
@@ -279,33 +308,19 @@ BVHAccel::BuildNode *BVHAccel::recursiveBuild(std::vector<PrimInfo> &primitiveIn
     case SplitMethod::SAH:
     default: {
         if (nPrimitives <= 2) { equalCounts(); break; }
-        constexpr int nBuckets = 12;
-        BucketInfo buckets[nBuckets];
-        for (int i = start; i < end; ++i) {
-            int b = nBuckets * centroidBounds.Offset(primitiveInfo[i].centroid)[dim];
-            if (b == nBuckets) b = nBuckets - 1;
-            buckets[b].count++;
-            buckets[b].bounds = Union(buckets[b].bounds, primitiveInfo[i].bounds);
-        }
-        Float cost[nBuckets - 1];
-        for (int i = 0; i < nBuckets - 1; ++i) {
-            Bounds3f b0, b1;
-            int count0 = 0, count1 = 0;
-            for (int j = 0; j <= i; ++j) { b0 = Union(b0, buckets[j].bounds); count0 += buckets[j].count; }
-            for (int j = i + 1; j < nBuckets; ++j) { b1 = Union(b1, buckets[j].bounds); count1 += buckets[j].count; }
-            cost[i] = 1 + (count0 * b0.SurfaceArea() + count1 * b1.SurfaceArea()) / bounds.SurfaceArea();
-        }
-        Float minCost = cost[0];
-        int minCostSplitBucket = 0;
-        for (int i = 1; i < nBuckets - 1; ++i)
-            if (cost[i] < minCost) { minCost = cost[i]; minCostSplitBucket = i; }
+        constexpr int nBuckets = SahBuckets::N;
+        auto bucketOf = [&centroidBounds, dim](const PrimInfo &pi) {  // bvh.cpp:318-322: the centroid's twelfth along the split axis
+            int b = nBuckets * centroidBounds.Offset(pi.centroid)[dim];
+            return b == nBuckets ? nBuckets - 1 : b;
+        };
+        SahBuckets buckets;
+        for (int i = start; i < end; ++i) buckets.Add(bucketOf(primitiveInfo[i]), primitiveInfo[i].bounds);
+        Float minCost;
+        const int minCostSplitBucket = buckets.CheapestBoundary(1, bounds, &minCost);
         Float leafCost = nPrimitives;
         if (nPrimitives > maxPrimsInNode || minCost < leafCost) {
-            PrimInfo *pmid = std::partition(&primitiveInfo[start], &primitiveInfo[end - 1] + 1, [=](const PrimInfo &pi) {
-                int b = nBuckets * centroidBounds.Offset(pi.centroid)[dim];
-                if (b == nBuckets) b = nBuckets - 1;
-                return b <= minCostSplitBucket;
-            });
+            PrimInfo *pmid = std::partition(&primitiveInfo[start], &primitiveInfo[end - 1] + 1,
+                                            [&](const PrimInfo &pi) { return bucketOf(pi) <= minCostSplitBucket; });
             mid = int(pmid - &primitiveInfo[0]);
         } else
             return makeLeaf();
@@ -434,30 +449,17 @@ BVHAccel::BuildNode *BVHAccel::buildUpperSAH(std::vector<BuildNode *> &treeletRo
         centroidBounds = Union(centroidBounds, centroid);
     }
     const int dim = centroidBounds.MaximumExtent();
-    const int nBuckets = 12;
-    BucketInfo buckets[nBuckets];
+    const int nBuckets = SahBuckets::N;
     auto bucketOf = [&](const BuildNode *n) {
         Float centroid = (n->bounds.pMin[dim] + n->bounds.pMax[dim]) * 0.5f;
         int b = nBuckets * ((centroid - centroidBounds.pMin[dim]) / (centroidBounds.pMax[dim] - centroidBounds.pMin[dim]));
         if (b == nBuckets) b = nBuckets - 1;
         return b;
     };
-    for (int i = start; i < end; ++i) {
-        int b = bucketOf(treeletRoots[i]);
-        buckets[b].count++;
-        buckets[b].bounds = Union(buckets[b].bounds, treeletRoots[i]->bounds);
-    }
-    Float cost[nBuckets - 1];
-    for (int i = 0; i < nBuckets - 1; ++i) {
-        Bounds3f b0, b1;
-        int count0 = 0, count1 = 0;
-        for (int j = 0; j <= i; ++j) { b0 = Union(b0, buckets[j].bounds); count0 += buckets[j].count; }
-        for (int j = i + 1; j < nBuckets; ++j) { b1 = Union(b1, buckets[j].bounds); count1 += buckets[j].count; }
-        cost[i] = .125f + (count0 * b0.SurfaceArea() + count1 * b1.SurfaceArea()) / bounds.SurfaceArea();
-    }
-    Float minCost = cost[0];
-    int minCostSplitBucket = 0;
-    for (int i = 1; i < nBuckets - 1; ++i) if (cost[i] < minCost) { minCost = cost[i]; minCostSplitBucket = i; }
+    SahBuckets buckets;
+    for (int i = start; i < end; ++i) buckets.Add(bucketOf(treeletRoots[i]), treeletRoots[i]->bounds);
+    Float minCost;
+    const int minCostSplitBucket = buckets.CheapestBoundary(.125f, bounds, &minCost);  // traversal cost 1/8 up here (bvh.cpp:611)
     BuildNode **pmid = std::partition(&treeletRoots[start], &treeletRoots[end - 1] + 1, [&](const BuildNode *n) { return bucketOf(n) <= minCostSplitBucket; });
     int mid = (int)(pmid - &treeletRoots[0]);
     if (mid <= start || mid >= end) {  // the reference CHECK-fails here (degenerate centroid bounds)
@@ -471,17 +473,14 @@ BVHAccel::BuildNode *BVHAccel::buildUpperSAH(std::vector<BuildNode *> &treeletRo
 }
 
 std::shared_ptr<BVHAccel> CreateBVHAccelerator(std::vector<GeometricPrimitive> prims, const ParamSet &ps) {
-    std::string splitMethodName = ps.FindOneString("splitmethod", "sah");
-    BVHAccel::SplitMethod splitMethod;
-    if (splitMethodName == "sah") splitMethod = BVHAccel::SplitMethod::SAH;
-    else if (splitMethodName == "hlbvh") splitMethod = BVHAccel::SplitMethod::HLBVH;
-    else if (splitMethodName == "middle") splitMethod = BVHAccel::SplitMethod::Middle;
-    else if (splitMethodName == "equal") splitMethod = BVHAccel::SplitMethod::EqualCounts;
-    else {
-        Warning("BVH split method \"%s\" unknown.  Using \"sah\".", splitMethodName.c_str());
-        splitMethod = BVHAccel::SplitMethod::SAH;
-    }
-    int maxPrimsInNode = ps.FindOneInt("maxnodeprims", 4);
-    return std::make_shared<BVHAccel>(std::move(prims), maxPrimsInNode, splitMethod);
+    // Accelerator "bvh": "string splitmethod" sah | hlbvh | middle | equal (default sah), "integer maxnodeprims" (default 4)
+    static const struct { const char *name; BVHAccel::SplitMethod method; } kMethods[] = {
+        {"sah", BVHAccel::SplitMethod::SAH}, {"hlbvh", BVHAccel::SplitMethod::HLBVH},
+        {"middle", BVHAccel::SplitMethod::Middle}, {"equal", BVHAccel::SplitMethod::EqualCounts}};
+    const std::string wanted = ps.FindOneString("splitmethod", "sah");
+    const BVHAccel::SplitMethod *found = nullptr;
+    for (const auto &m : kMethods) if (wanted == m.name) found = &m.method;
+    if (!found) Warning("BVH split method \"%s\" unknown.  Using \"sah\".", wanted.c_str());
+    return std::make_shared<BVHAccel>(std::move(prims), ps.FindOneInt("maxnodeprims", 4), found ? *found : BVHAccel::SplitMethod::SAH);
 }
 }  // namespace pbrt

@@ -17,7 +17,7 @@ Rendering options:
   --devicebvh                Build "hlbvh" accelerators on the GPU instead of on the host.
   --gpu <id>                 HIP device to render on (default 0).
   --help                     Print this help text.
-  --nthreads <num>           Accepted for compatibility; host work is single-threaded.
+  --nthreads <num>           Host threads for the accelerator build (0 = all cores); rendering runs on the GPU.
   --outfile <filename>       Write the final image to the given filename (.pfm).
   --quick                    Automatically reduce a number of quality settings to render more quickly.
   --quiet                    Suppress all text output other than error messages.

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <string>
 #include <utility>
@@ -83,51 +84,56 @@ RGB FromSampled(const Float *lambda, const Float *v, int n) {  // RGBSpectrum::F
     xyz[0] *= scale; xyz[1] *= scale; xyz[2] *= scale;
     return FromXYZ(xyz);
 }
-void Blackbody(const Float *lambda, int n, Float T, Float *Le) {  // spectrum.cpp:939-955
-    if (T <= 0) { for (int i = 0; i < n; ++i) Le[i] = 0.f; return; }
-    const Float c = 299792458;
-    const Float h = 6.62606957e-34;
-    const Float kb = 1.3806488e-23;
-    for (int i = 0; i < n; ++i) {
-        Float l = lambda[i] * 1e-9;
-        Float lambda5 = (l * l) * (l * l) * l;
-        Le[i] = (2 * h * c * c) / (lambda5 * (std::exp((h * c) / (l * kb * T)) - 1));
-    }
+// Planck's law, spectral radiance of a black body at T kelvin for a wavelength in nm (spectrum.cpp:939-955).  Computed in
+// float with the reference's association -- [order] l = lambda * 1e-9 (double product, rounded), l^5 = (l*l)*(l*l)*l,
+// ((2h)c)c / (l^5 * (exp((hc) / ((l kB) T)) - 1)) -- because "blackbody" parameters must give the same RGB coefficients.
+static Float PlanckRadiance(Float lambdaNm, Float T) {
+    const Float lightSpeed = 299792458, planck = 6.62606957e-34, boltzmann = 1.3806488e-23;
+    const Float l = lambdaNm * 1e-9;
+    const Float l2 = l * l, l5 = l2 * l2 * l;
+    const Float exponent = (planck * lightSpeed) / (l * boltzmann * T);
+    return (2 * planck * lightSpeed * lightSpeed) / (l5 * (std::exp(exponent) - 1));
 }
-void BlackbodyNormalized(const Float *lambda, int n, Float T, Float *Le) {  // spectrum.cpp:957-964
-    Blackbody(lambda, n, T, Le);
-    Float lambdaMax = 2.8977721e-3 / T * 1e9;
-    Float maxL;
-    Blackbody(&lambdaMax, 1, T, &maxL);
-    for (int i = 0; i < n; ++i) Le[i] /= maxL;
+// the curve divided by its peak, which Wien's displacement law puts at 2.8977721e-3 / T metres (spectrum.cpp:957-964)
+void BlackbodyNormalized(const Float *lambda, int n, Float T, Float *Le) {
+    if (T <= 0) { std::fill(Le, Le + n, std::numeric_limits<Float>::quiet_NaN()); return; }  // the reference divides 0 by 0 here
+    const Float peakNm = 2.8977721e-3 / T * 1e9;  // [order] double arithmetic, rounded once
+    const Float peak = PlanckRadiance(peakNm, T);
+    for (int i = 0; i < n; ++i) Le[i] = PlanckRadiance(lambda[i], T) / peak;
 }
-bool ReadFloatFile(const char *filename, std::vector<Float> *values) {  // core/floatfile.cpp:40-82
+// Whitespace-separated numbers with '#' comments (core/floatfile.cpp:40-82).  Kept quirks, because .spd files in the wild
+// rely on them: a number is [digit . - +] followed by [digit . e - +]*; the character that ends a number is swallowed
+// (so "1#x" does not start a comment); a number that runs into the end of the file is dropped; other text is warned about.
+bool ReadFloatFile(const char *filename, std::vector<Float> *values) {
     FILE *f = fopen(filename, "r");
     if (!f) { Error("Unable to open file \"%s\"", filename); return false; }
-    int c;
-    bool inNumber = false;
-    char curNumber[32];
-    int curNumberPos = 0, lineNumber = 1;
-    while ((c = getc(f)) != EOF) {
-        if (c == '\n') ++lineNumber;
-        if (inNumber) {
-            if (curNumberPos >= (int)sizeof(curNumber)) { Error("Overflowed buffer for parsing number in file: %s, at line %d", filename, lineNumber); exit(1); }
-            if (isdigit(c) || c == '.' || c == 'e' || c == '-' || c == '+') curNumber[curNumberPos++] = c;
-            else {
-                curNumber[curNumberPos++] = '\0';
-                values->push_back(atof(curNumber));
-                inNumber = false;
-                curNumberPos = 0;
-            }
-        } else {
-            if (isdigit(c) || c == '.' || c == '-' || c == '+') { inNumber = true; curNumber[curNumberPos++] = c; }
-            else if (c == '#') {
-                while ((c = getc(f)) != '\n' && c != EOF) {}
-                ++lineNumber;
-            } else if (!isspace(c)) Warning("Unexpected text found at line %d of float file \"%s\"", lineNumber, filename);
+    std::string text;
+    char chunk[1 << 14];
+    for (size_t got; (got = fread(chunk, 1, sizeof(chunk), f)) > 0;) text.append(chunk, got);
+    fclose(f);
+    auto startsNumber = [](unsigned char c) { return isdigit(c) || c == '.' || c == '-' || c == '+'; };
+    int line = 1;
+    for (size_t i = 0; i < text.size();) {
+        const unsigned char c = text[i];
+        if (startsNumber(c)) {
+            size_t j = i + 1;
+            while (j < text.size() && (startsNumber(text[j]) || text[j] == 'e')) ++j;
+            if (j == text.size()) break;  // ran into the end of the file
+            if (j - i >= 32) { Error("Overflowed buffer for parsing number in file: %s, at line %d", filename, line); exit(1); }
+            values->push_back(atof(text.substr(i, j - i).c_str()));
+            if (text[j] == '\n') ++line;
+            i = j + 1;  // the terminating character goes with the number
+            continue;
         }
+        if (c == '#') {
+            while (i < text.size() && text[i] != '\n') ++i;
+            ++line; ++i;
+            continue;
+        }
+        if (c == '\n') ++line;
+        else if (!isspace(c)) Warning("Unexpected text found at line %d of float file \"%s\"", line, filename);
+        ++i;
     }
-    fclose(f);  // as in the reference, a number that runs into the end of the file without a separator is dropped
     return true;
 }
 std::map<std::string, RGB> cachedSpectra;  // ParamSet::cachedSpectra, paramset.cpp:210

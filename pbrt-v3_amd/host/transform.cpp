@@ -1,151 +1,158 @@
-// Matrix/Transform routines of the host front end.  Same float operation
-// order as the reference (src/core/transform.cpp) so camera and object
-// matrices match bit for bit.
+// Matrix / Transform routines of the host front end.
+//
+// The camera, object and light matrices computed here are handed to the device and must equal the reference's bit for
+// bit, so the ORDER OF FLOAT OPERATIONS of src/core/transform.cpp is a constraint; the code around it is this build's own.
+// Order-constrained expressions, each marked [order] below:
+//   * Inverse: Gauss-Jordan with full pivoting -- pivot choice (`>=`, so the LAST largest entry in row-major scan order
+//     wins), reciprocal pivot formed in double and rounded once, row scaled before elimination, `row_j -= row_p * f`
+//     element by element, column un-scrambling in reverse pivot order (transform.cpp:83-139);
+//   * Rotate: the nine Rodrigues entries as a*b*(1-cos) +- c*sin and a*a + (1-a*a)*cos (transform.cpp:182-206);
+//   * Perspective: f/(f-n), -f*n/(f-n), 1/tan(radians(fov)/2) (transform.cpp:304-312);
+//   * point / vector / normal application: row sums left to right (transform.h:219-247).
 #include "geometry.h"
 #include "error.h"
 
+#include <utility>
+
 namespace pbrt {
 
-Matrix4x4 Transpose(const Matrix4x4 &m) {  // transform.cpp:76-81
-    return Matrix4x4(m.m[0][0], m.m[1][0], m.m[2][0], m.m[3][0], m.m[0][1], m.m[1][1], m.m[2][1],
-                     m.m[3][1], m.m[0][2], m.m[1][2], m.m[2][2], m.m[3][2], m.m[0][3], m.m[1][3],
-                     m.m[2][3], m.m[3][3]);
+Matrix4x4 Transpose(const Matrix4x4 &m) {
+    Matrix4x4 t;
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) t.m[c][r] = m.m[r][c];
+    return t;
 }
 
-// Gauss-Jordan with full pivoting, transform.cpp:83-139.
-Matrix4x4 Inverse(const Matrix4x4 &m) {
-    int indxc[4], indxr[4];
-    int ipiv[4] = {0, 0, 0, 0};
-    Float minv[4][4];
-    std::memcpy(minv, m.m, 4 * 4 * sizeof(Float));
-    for (int i = 0; i < 4; i++) {
-        int irow = 0, icol = 0;
-        Float big = 0.f;
-        for (int j = 0; j < 4; j++) {
-            if (ipiv[j] != 1) {
-                for (int k = 0; k < 4; k++) {
-                    if (ipiv[k] == 0) {
-                        if (std::abs(minv[j][k]) >= big) {
-                            big = Float(std::abs(minv[j][k]));
-                            irow = j;
-                            icol = k;
-                        }
-                    } else if (ipiv[k] > 1)
-                        Error("Singular matrix in MatrixInvert");
-                }
+Matrix4x4 Inverse(const Matrix4x4 &src) {
+    Matrix4x4 work = src;
+    Float(*a)[4] = work.m;
+    bool pivoted[4] = {false, false, false, false};  // column c has been a pivot column (its pivot row now sits in row c)
+    std::pair<int, int> swaps[4];                    // (row, column) of every pivot, in order
+    for (int step = 0; step < 4; ++step) {
+        // [order] largest |entry| among rows and columns not yet pivoted; ties go to the last one scanned
+        int pr = -1, pc = -1;
+        Float best = 0.f;
+        for (int r = 0; r < 4; ++r) {
+            if (pivoted[r]) continue;
+            for (int c = 0; c < 4; ++c) {
+                if (pivoted[c]) continue;
+                const Float mag = std::abs(a[r][c]);
+                if (mag >= best) { best = mag; pr = r; pc = c; }
             }
         }
-        ++ipiv[icol];
-        if (irow != icol)
-            for (int k = 0; k < 4; ++k) std::swap(minv[irow][k], minv[icol][k]);
-        indxr[i] = irow;
-        indxc[i] = icol;
-        if (minv[icol][icol] == 0.f) Error("Singular matrix in MatrixInvert");
-        Float pivinv = 1. / minv[icol][icol];
-        minv[icol][icol] = 1.;
-        for (int j = 0; j < 4; j++) minv[icol][j] *= pivinv;
-        for (int j = 0; j < 4; j++) {
-            if (j != icol) {
-                Float save = minv[j][icol];
-                minv[j][icol] = 0;
-                for (int k = 0; k < 4; k++) minv[j][k] -= minv[icol][k] * save;
-            }
+        if (pr < 0) {  // only NaN entries left: nothing compares >= 0
+            Error("Singular matrix in MatrixInvert");
+            return Matrix4x4();
+        }
+        pivoted[pc] = true;
+        if (pr != pc)
+            for (int c = 0; c < 4; ++c) std::swap(a[pr][c], a[pc][c]);
+        swaps[step] = {pr, pc};
+        if (a[pc][pc] == 0.f) Error("Singular matrix in MatrixInvert");
+        // [order] reciprocal in double, rounded to float once; the pivot entry becomes 1 BEFORE the row is scaled
+        const Float scale = (Float)(1.0 / (double)a[pc][pc]);
+        a[pc][pc] = 1.f;
+        for (int c = 0; c < 4; ++c) a[pc][c] *= scale;
+        // [order] eliminate the pivot column from the other rows: entry -= pivotRow[c] * factor, factor's slot zeroed first
+        for (int r = 0; r < 4; ++r) {
+            if (r == pc) continue;
+            const Float factor = a[r][pc];
+            a[r][pc] = 0.f;
+            for (int c = 0; c < 4; ++c) a[r][c] -= a[pc][c] * factor;
         }
     }
-    for (int j = 3; j >= 0; j--) {
-        if (indxr[j] != indxc[j])
-            for (int k = 0; k < 4; k++) std::swap(minv[k][indxr[j]], minv[k][indxc[j]]);
+    for (int step = 3; step >= 0; --step) {  // undo the row swaps as column swaps, last pivot first
+        const int r = swaps[step].first, c = swaps[step].second;
+        if (r == c) continue;
+        for (int k = 0; k < 4; ++k) std::swap(a[k][r], a[k][c]);
     }
-    Matrix4x4 r;
-    std::memcpy(r.m, minv, sizeof(minv));
-    return r;
+    return work;
 }
 
-bool Transform::SwapsHandedness() const {
-    Float det = m.m[0][0] * (m.m[1][1] * m.m[2][2] - m.m[1][2] * m.m[2][1]) -
-                m.m[0][1] * (m.m[1][0] * m.m[2][2] - m.m[1][2] * m.m[2][0]) +
-                m.m[0][2] * (m.m[1][0] * m.m[2][1] - m.m[1][1] * m.m[2][0]);
+bool Transform::SwapsHandedness() const {  // sign of the upper-left 3x3 determinant, cofactors along the first row
+    const Float(*a)[4] = m.m;
+    const Float c0 = a[1][1] * a[2][2] - a[1][2] * a[2][1];
+    const Float c1 = a[1][0] * a[2][2] - a[1][2] * a[2][0];
+    const Float c2 = a[1][0] * a[2][1] - a[1][1] * a[2][0];
+    const Float det = a[0][0] * c0 - a[0][1] * c1 + a[0][2] * c2;
     return det < 0;
 }
 
+// [order] one row of M applied to (x, y, z[, 1]): products summed left to right
+static inline Float rowDot3(const Float *row, Float x, Float y, Float z) { return row[0] * x + row[1] * y + row[2] * z; }
+static inline Float rowDot4(const Float *row, Float x, Float y, Float z) { return row[0] * x + row[1] * y + row[2] * z + row[3]; }
+
 Point3f Transform::Pt(const Point3f &p) const {
-    Float x = p.x, y = p.y, z = p.z;
-    Float xp = m.m[0][0] * x + m.m[0][1] * y + m.m[0][2] * z + m.m[0][3];
-    Float yp = m.m[1][0] * x + m.m[1][1] * y + m.m[1][2] * z + m.m[1][3];
-    Float zp = m.m[2][0] * x + m.m[2][1] * y + m.m[2][2] * z + m.m[2][3];
-    Float wp = m.m[3][0] * x + m.m[3][1] * y + m.m[3][2] * z + m.m[3][3];
-    if (wp == 1) return Point3f(xp, yp, zp);
-    Float inv = (Float)1 / wp;  // Point3::operator/ (geometry.h:499-503)
-    return Point3f(inv * xp, inv * yp, inv * zp);
+    const Float h[4] = {rowDot4(m.m[0], p.x, p.y, p.z), rowDot4(m.m[1], p.x, p.y, p.z), rowDot4(m.m[2], p.x, p.y, p.z),
+                        rowDot4(m.m[3], p.x, p.y, p.z)};
+    if (h[3] == 1) return Point3f(h[0], h[1], h[2]);
+    const Float rcp = (Float)1 / h[3];  // the homogeneous divide multiplies by the reciprocal (geometry.h:499-503)
+    return Point3f(rcp * h[0], rcp * h[1], rcp * h[2]);
 }
 Vector3f Transform::Vec(const Vector3f &v) const {
-    Float x = v.x, y = v.y, z = v.z;
-    return Vector3f(m.m[0][0] * x + m.m[0][1] * y + m.m[0][2] * z,
-                    m.m[1][0] * x + m.m[1][1] * y + m.m[1][2] * z,
-                    m.m[2][0] * x + m.m[2][1] * y + m.m[2][2] * z);
+    return Vector3f(rowDot3(m.m[0], v.x, v.y, v.z), rowDot3(m.m[1], v.x, v.y, v.z), rowDot3(m.m[2], v.x, v.y, v.z));
 }
-Normal3f Transform::Nrm(const Normal3f &n) const {
-    Float x = n.x, y = n.y, z = n.z;
-    return Normal3f(mInv.m[0][0] * x + mInv.m[1][0] * y + mInv.m[2][0] * z,
-                    mInv.m[0][1] * x + mInv.m[1][1] * y + mInv.m[2][1] * z,
-                    mInv.m[0][2] * x + mInv.m[1][2] * y + mInv.m[2][2] * z);
+Normal3f Transform::Nrm(const Normal3f &n) const {  // normals go through the inverse transpose: columns of mInv
+    Float out[3];
+    for (int c = 0; c < 3; ++c) out[c] = mInv.m[0][c] * n.x + mInv.m[1][c] * n.y + mInv.m[2][c] * n.z;
+    return Normal3f(out[0], out[1], out[2]);
 }
 
-Transform Translate(const Vector3f &delta) {  // transform.cpp:144-150
-    Matrix4x4 m(1, 0, 0, delta.x, 0, 1, 0, delta.y, 0, 0, 1, delta.z, 0, 0, 0, 1);
-    Matrix4x4 minv(1, 0, 0, -delta.x, 0, 1, 0, -delta.y, 0, 0, 1, -delta.z, 0, 0, 0, 1);
-    return Transform(m, minv);
+static Matrix4x4 diagonalWithOffset(Float sx, Float sy, Float sz, Float tx, Float ty, Float tz) {
+    Matrix4x4 r;
+    r.m[0][0] = sx; r.m[1][1] = sy; r.m[2][2] = sz;
+    r.m[0][3] = tx; r.m[1][3] = ty; r.m[2][3] = tz;
+    return r;
 }
-Transform Scale(Float x, Float y, Float z) {  // transform.cpp:152-156
-    Matrix4x4 m(x, 0, 0, 0, 0, y, 0, 0, 0, 0, z, 0, 0, 0, 0, 1);
-    Matrix4x4 minv(1 / x, 0, 0, 0, 0, 1 / y, 0, 0, 0, 0, 1 / z, 0, 0, 0, 0, 1);
-    return Transform(m, minv);
+Transform Translate(const Vector3f &d) {
+    return Transform(diagonalWithOffset(1, 1, 1, d.x, d.y, d.z), diagonalWithOffset(1, 1, 1, -d.x, -d.y, -d.z));
 }
-Transform Rotate(Float theta, const Vector3f &axis) {  // transform.cpp:182-206
-    Vector3f a = Normalize(axis);
-    Float sinTheta = std::sin(Radians(theta));
-    Float cosTheta = std::cos(Radians(theta));
-    Matrix4x4 m;
-    m.m[0][0] = a.x * a.x + (1 - a.x * a.x) * cosTheta;
-    m.m[0][1] = a.x * a.y * (1 - cosTheta) - a.z * sinTheta;
-    m.m[0][2] = a.x * a.z * (1 - cosTheta) + a.y * sinTheta;
-    m.m[0][3] = 0;
-    m.m[1][0] = a.x * a.y * (1 - cosTheta) + a.z * sinTheta;
-    m.m[1][1] = a.y * a.y + (1 - a.y * a.y) * cosTheta;
-    m.m[1][2] = a.y * a.z * (1 - cosTheta) - a.x * sinTheta;
-    m.m[1][3] = 0;
-    m.m[2][0] = a.x * a.z * (1 - cosTheta) - a.y * sinTheta;
-    m.m[2][1] = a.y * a.z * (1 - cosTheta) + a.x * sinTheta;
-    m.m[2][2] = a.z * a.z + (1 - a.z * a.z) * cosTheta;
-    m.m[2][3] = 0;
-    return Transform(m, Transpose(m));
+Transform Scale(Float x, Float y, Float z) {
+    return Transform(diagonalWithOffset(x, y, z, 0, 0, 0), diagonalWithOffset(1 / x, 1 / y, 1 / z, 0, 0, 0));
 }
-Transform LookAt(const Point3f &pos, const Point3f &look, const Vector3f &up) {  // transform.cpp:208-247
-    Matrix4x4 cameraToWorld;
-    cameraToWorld.m[0][3] = pos.x;
-    cameraToWorld.m[1][3] = pos.y;
-    cameraToWorld.m[2][3] = pos.z;
-    cameraToWorld.m[3][3] = 1;
-    Vector3f dir = Normalize(look - pos);
-    if (Cross(Normalize(up), dir).Length() == 0) {
+
+Transform Rotate(Float theta, const Vector3f &axis) {
+    const Vector3f a = Normalize(axis);
+    const Float s = std::sin(Radians(theta)), c = std::cos(Radians(theta));
+    // [order] Rodrigues' formula entry by entry; the inverse of a rotation is its transpose
+    Matrix4x4 r;
+    for (int i = 0; i < 3; ++i) {
+        const int j = (i + 1) % 3, k = (i + 2) % 3;  // (i, j, k) cyclic: entry (i,j) carries -a_k sin, entry (i,k) carries +a_j sin
+        r.m[i][i] = a[i] * a[i] + (1 - a[i] * a[i]) * c;
+        // the products are written with the lower axis index first, as a.x*a.y, a.x*a.z, a.y*a.z
+        const Float pij = i < j ? a[i] * a[j] : a[j] * a[i], pik = i < k ? a[i] * a[k] : a[k] * a[i];
+        r.m[i][j] = pij * (1 - c) - a[k] * s;
+        r.m[i][k] = pik * (1 - c) + a[j] * s;
+    }
+    return Transform(r, Transpose(r));
+}
+
+Transform LookAt(const Point3f &pos, const Point3f &look, const Vector3f &up) {
+    const Vector3f dir = Normalize(look - pos);
+    const Vector3f side = Cross(Normalize(up), dir);
+    if (side.Length() == 0) {
         Error("\"up\" vector (%f, %f, %f) and viewing direction (%f, %f, %f) "
               "passed to LookAt are pointing in the same direction.  Using "
               "the identity transformation.", up.x, up.y, up.z, dir.x, dir.y, dir.z);
         return Transform();
     }
-    Vector3f right = Normalize(Cross(Normalize(up), dir));
-    Vector3f newUp = Cross(dir, right);
-    cameraToWorld.m[0][0] = right.x; cameraToWorld.m[1][0] = right.y;
-    cameraToWorld.m[2][0] = right.z; cameraToWorld.m[3][0] = 0.;
-    cameraToWorld.m[0][1] = newUp.x; cameraToWorld.m[1][1] = newUp.y;
-    cameraToWorld.m[2][1] = newUp.z; cameraToWorld.m[3][1] = 0.;
-    cameraToWorld.m[0][2] = dir.x; cameraToWorld.m[1][2] = dir.y;
-    cameraToWorld.m[2][2] = dir.z; cameraToWorld.m[3][2] = 0.;
-    return Transform(Inverse(cameraToWorld), cameraToWorld);
+    const Vector3f right = Normalize(side), newUp = Cross(dir, right);
+    // camera-to-world: columns right | newUp | dir | pos; the world-to-camera matrix the directive asks for is its inverse
+    const Vector3f *col[4] = {&right, &newUp, &dir, &pos};
+    Matrix4x4 c2w;
+    for (int c = 0; c < 4; ++c) {
+        c2w.m[0][c] = col[c]->x; c2w.m[1][c] = col[c]->y; c2w.m[2][c] = col[c]->z;
+        c2w.m[3][c] = c == 3 ? 1.f : 0.f;
+    }
+    return Transform(Inverse(c2w), c2w);
 }
-Transform Perspective(Float fov, Float n, Float f) {  // transform.cpp:304-312
-    Matrix4x4 persp(1, 0, 0, 0, 0, 1, 0, 0, 0, 0, f / (f - n), -f * n / (f - n), 0, 0, 1, 0);
-    Float invTanAng = 1 / std::tan(Radians(fov) / 2);
-    return Scale(invTanAng, invTanAng, 1) * Transform(persp);
+
+Transform Perspective(Float fov, Float n, Float f) {
+    Matrix4x4 persp;  // x, y pass through; z' = (f z - f n) / (f - n), w' = z
+    persp.m[2][2] = f / (f - n);       // [order]
+    persp.m[2][3] = -f * n / (f - n);  // [order]
+    persp.m[3][2] = 1; persp.m[3][3] = 0;
+    const Float cotHalf = 1 / std::tan(Radians(fov) / 2);  // [order]
+    return Scale(cotHalf, cotHalf, 1) * Transform(persp);
 }
 }  // namespace pbrt
