@@ -320,7 +320,8 @@ typedef struct PgSceneDesc {
     const PgLight *lights;
     int32_t light_strategy;     /* PgLightStrategy as resolved by CreateLightSampleDistribution (lightdistrib.cpp:48-66) */
     /* Halton digit permutations (lowdiscrepancy.cpp:2490-2504), first n_perm_dims
-     * prime bases concatenated; perm_sums[d] = offset of base d.            */
+     * prime bases concatenated; perm_sums[d] = offset of base d.  May be absent
+     * (n_perm_dims = 0) when sobol_matrices is given and only that sampler is used. */
     int32_t n_perm_dims;
     const uint16_t *perms;
     const int32_t *perm_sums;   /* n_perm_dims+1 entries */

@@ -64,6 +64,8 @@ struct PgScene {
     int volCapacity = 0;
     int nMedia = 0;
     DeviceBuffer vqo[2], vqd[2], vCounts, volMedium, trAcc[2], volP1[3], misLi, pdLi, hitT;
+    DeviceBuffer qsL[2], qsBeta[2], qsMeta[2];  // PathIntegrator: path state in queue order
+    int qsCapacity = 0;
 };
 
 extern "C" {
@@ -414,7 +416,9 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     HIP_TRY_S(s->lights.alloc(sizeof(PgLight) * (size_t)desc->n_lights));
     if (desc->n_lights) HIP_TRY_S(hipMemcpy(s->lights.p, desc->lights, s->lights.bytes, hipMemcpyHostToDevice));
     // --- Halton tables
-    if (desc->n_perm_dims < 5 || !desc->perms || !desc->perm_sums) FAIL(PG_ERR_INVALID, "Halton permutation table missing (need >= 5 dims)");
+    // (a scene rendered with the Sobol' sampler only may come without one: pg_render then refuses sampler = halton)
+    const bool haltonTable = !(desc->n_perm_dims == 0 && desc->sobol_matrices);
+    if (haltonTable && (desc->n_perm_dims < 5 || !desc->perms || !desc->perm_sums)) FAIL(PG_ERR_INVALID, "Halton permutation table missing (need >= 5 dims)");
     std::vector<int32_t> primes;
     for (int c = 2; (int)primes.size() < desc->n_perm_dims; ++c) {
         bool is = true;
@@ -423,12 +427,14 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     }
     for (int i = 0; i < desc->n_perm_dims; ++i)
         if (desc->perm_sums[i + 1] - desc->perm_sums[i] != primes[i]) FAIL(PG_ERR_INVALID, "perm_sums[%d] does not match prime base %d", i, primes[i]);
-    HIP_TRY_S(s->perms.alloc(sizeof(uint16_t) * (size_t)desc->perm_sums[desc->n_perm_dims]));
-    HIP_TRY_S(hipMemcpy(s->perms.p, desc->perms, s->perms.bytes, hipMemcpyHostToDevice));
-    HIP_TRY_S(s->permSums.alloc(sizeof(int32_t) * (size_t)(desc->n_perm_dims + 1)));
-    HIP_TRY_S(hipMemcpy(s->permSums.p, desc->perm_sums, s->permSums.bytes, hipMemcpyHostToDevice));
-    HIP_TRY_S(s->primes.alloc(sizeof(int32_t) * primes.size()));
-    HIP_TRY_S(hipMemcpy(s->primes.p, primes.data(), s->primes.bytes, hipMemcpyHostToDevice));
+    if (haltonTable) {
+        HIP_TRY_S(s->perms.alloc(sizeof(uint16_t) * (size_t)desc->perm_sums[desc->n_perm_dims]));
+        HIP_TRY_S(hipMemcpy(s->perms.p, desc->perms, s->perms.bytes, hipMemcpyHostToDevice));
+        HIP_TRY_S(s->permSums.alloc(sizeof(int32_t) * (size_t)(desc->n_perm_dims + 1)));
+        HIP_TRY_S(hipMemcpy(s->permSums.p, desc->perm_sums, s->permSums.bytes, hipMemcpyHostToDevice));
+        HIP_TRY_S(s->primes.alloc(sizeof(int32_t) * primes.size()));
+        HIP_TRY_S(hipMemcpy(s->primes.p, primes.data(), s->primes.bytes, hipMemcpyHostToDevice));
+    }
 
     d.nodes = (const float4 *)s->nodes.p; d.tris = (const float4 *)s->tris.p; d.spheres = (const PgSphere *)s->spheres.p; d.nSpheres = desc->n_spheres > 0 ? desc->n_spheres : 0;
     d.bxdfs = (const PgBxDF *)s->bxdfs.p;
@@ -666,7 +672,7 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
         if (rd->sobol_log2_resolution < 0 || rd->sobol_log2_resolution > 26 || rd->sobol_resolution != (1 << rd->sobol_log2_resolution))
             return setError(PG_ERR_INVALID, "pg_render: sobol_resolution %d / sobol_log2_resolution %d", rd->sobol_resolution, rd->sobol_log2_resolution);
     }
-    if (rd->sampler == 0 && 5 + 8 * (rd->max_depth + 1) > s->d.nPermDims && s->d.nPermDims < 1000)
+    if (rd->sampler == 0 && (!s->d.perms || (5 + 8 * (rd->max_depth + 1) > s->d.nPermDims && s->d.nPermDims < 1000)))
         return setError(PG_ERR_INVALID, "Halton table has %d dimensions; maxdepth %d needs %d", s->d.nPermDims, rd->max_depth, 5 + 8 * (rd->max_depth + 1));
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t stream = (hipStream_t)streamPtr;
@@ -737,6 +743,15 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
 
     float4 *const hitsMis = (float4 *)s->hitsMain.p + (size_t)regionCapFor(capacity) * PG_REGIONS;
     PathState ps;
+    memset(&ps, 0, sizeof(ps));
+    if (!vol) {  // PathIntegrator: L / beta / meta in queue order beside each main queue
+        const size_t n = (size_t)regionCapFor(capacity) * PG_REGIONS;
+        if (s->qsCapacity < capacity) {
+            for (int i = 0; i < 2; ++i) { HIP_TRY(s->qsL[i].alloc(n * sizeof(float4))); HIP_TRY(s->qsBeta[i].alloc(n * sizeof(float4))); HIP_TRY(s->qsMeta[i].alloc(n * sizeof(int4))); }
+            s->qsCapacity = capacity;
+        }
+        for (int i = 0; i < 2; ++i) { ps.qs[i].L = (float4 *)s->qsL[i].p; ps.qs[i].beta = (float4 *)s->qsBeta[i].p; ps.qs[i].meta = (int4 *)s->qsMeta[i].p; }
+    }
     ps.L = (float4 *)s->stL.p; ps.beta = (float4 *)s->stBeta.p; ps.meta = (int4 *)s->stMeta.p;
     ps.pdLight = (float4 *)s->pdLight.p; ps.pdMis = (float4 *)s->pdMis.p; ps.pdBeta = (float4 *)s->pdBeta.p; ps.pdInfo = (int4 *)s->pdInfo.p;
     int *counts = (int *)s->counts.p;
@@ -853,7 +868,7 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
                 const int nxt = cur ^ 1;
                 HIP_TRY(hipMemsetAsync(counts + nxt * QSTRIDE, 0, QSTRIDE * sizeof(int), stream));
                 HIP_TRY(hipMemsetAsync(counts + 2 * QSTRIDE, 0, 2 * QSTRIDE * sizeof(int), stream));
-                PG_TIMED(2, stream, launch_shade(s->d, rp, ps, q[cur], (const float4 *)s->hitsMain.p, q[nxt], q[2], q[3], lightTests, stream));
+                PG_TIMED(2, stream, launch_shade(s->d, rp, ps, q[cur], (const float4 *)s->hitsMain.p, q[nxt], q[2], q[3], lightTests, stream, cur));
                 ++shadeLaunches;
                 // paths that reach maxdepth neither continue nor sample lights (path.cpp:104): nothing left to trace
                 const bool lastDepth = !s->hasNullMaterial && bounce >= rd->max_depth;
@@ -875,7 +890,7 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
                     if (s->overlapShadow) HIP_TRY(hipEventRecord(s->evShadowed, sst));
                     if (int e = timedClosest(q[nxt], (float4 *)s->hitsMain.p, &q[3], hitsMis)) return e;
                     if (s->overlapShadow) HIP_TRY(hipStreamWaitEvent(stream, s->evShadowed, 0));
-                    PG_TIMED(3, stream, launch_resolve(s->d, ps, q[cur], q[3], (const int *)s->occluded.p, (const float4 *)hitsMis, stream));
+                    PG_TIMED(3, stream, launch_resolve(s->d, ps, q[cur], q[3], (const int *)s->occluded.p, (const float4 *)hitsMis, stream, cur));
                     ++resolveLaunches;
                 }
                 // log this bounce's queue sizes

@@ -87,6 +87,14 @@ struct RayQueue {
 };
 __host__ __device__ inline int queue_region_count(const RayQueue &q, int r) { return q.counts[r * PG_COUNT_STRIDE]; }
 
+// Path state in QUEUE order (PathIntegrator only): entry i belongs to ray i of the main queue it accompanies, so the shading
+// kernel reads it with the ray (one coalesced, independent load) instead of gathering it by slot behind the ray's own load.
+struct QueueState {
+    float4 *L;     // (L.rgb, pFilm.x)
+    float4 *beta;  // (beta.rgb, pFilm.y)
+    int4 *meta;    // as PathState::meta
+};
+
 // Per-path state, indexed by slot.
 struct PathState {
     float4 *L;      // (L.rgb, pFilm.x)
@@ -97,6 +105,11 @@ struct PathState {
     float4 *pdMis;    // (f*|wi.n| rgb, scatteringPdf)
     float4 *pdBeta;   // (beta before the bounce rgb, MIS weight)
     int4 *pdInfo;     // (shadow queue pos or -1, mis queue pos or -1, lightNum, unused)
+    // PathIntegrator (not volpath): L / beta / meta travel with the ray in queue order (qs[0] / qs[1] accompany the two main
+    // queues); L[slot] then only receives a path's FINAL radiance, the pd* terms are indexed by the ray's queue position, and
+    // pdInfo.w says where the path's L lives when k_resolve adds the direct lighting: >= 0 entry of the next queue's state,
+    // < 0: ~slot (the path ended).  qs[0].L == nullptr: everything by slot (volpath).
+    QueueState qs[2];
 };
 
 // Extra per-path state of the VolPathIntegrator (integrators/volpath.cpp), indexed by slot.  A "through" ray is a ray of
@@ -138,9 +151,11 @@ void launch_closest2(const DScene &sc, RayQueue q0, RayQueue q1, float4 *hits, i
                      hipStream_t s, float *tOut = nullptr);
 void launch_anyhit(const DScene &sc, RayQueue q, int *occluded, TraceCounters *cn, int *cursors, hipStream_t s);
 void launch_generate(const DScene &sc, const RenderParams &rp, PathState st, RayQueue q, hipStream_t s);
+// cur: which of st.qs[] accompanies qin (the other one accompanies qnext)
 void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQueue qin, const float4 *hits, RayQueue qnext,
-                  RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s);
-void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis, const int *occluded, const float4 *misHits, hipStream_t s);
+                  RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s, int cur = 0);
+void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis, const int *occluded, const float4 *misHits, hipStream_t s,
+                    int cur = 0);
 // VolPathIntegrator: the shading step with medium sampling (hitT = the hits' ray parameters), one step of the through rays of
 // `kind` (results of qin at hits[hitBase + i]; continued rays go to qout), and EstimateDirect's sums with transmittance
 void launch_shade_vol(const DScene &sc, const RenderParams &rp, PathState st, VolState vs, RayQueue qin, const float4 *hits, const float *hitT,

@@ -341,6 +341,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_generate(DScene sc, RenderParams r
     if (valid) {
         q.o[pos] = make_float4(o.x, o.y, o.z, tMax);
         q.d[pos] = make_float4(d.x, d.y, d.z, __int_as_float(slot));
+        if (st.qs[0].L) { st.qs[0].L[pos] = st.L[slot]; st.qs[0].beta[pos] = st.beta[slot]; st.qs[0].meta[pos] = st.meta[slot]; }  // just written by this thread
     }
 }
 void launch_generate(const DScene &sc, const RenderParams &rp, PathState st, RayQueue q, hipStream_t s) {
@@ -1475,17 +1476,20 @@ PG_DEV void prim_interface(const DScene &sc, int prim, int rayMedium, int &mIn, 
 template <int MODE, bool VOL>
 __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
                                                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, VolState vs,
-                                                     const float *__restrict__ hitT) {
+                                                     const float *__restrict__ hitT, QueueState qsIn, QueueState qsOut) {
     constexpr bool EXT = MODE >= 1, TEX = MODE == 2;
+    constexpr bool QSTATE = !VOL;  // path state and pending terms in queue order (see PathState)
     const int i = queue_item(qin);
     const bool valid = i >= 0;
     // Output rays are staged in LDS ([queue][o|d][thread]) the moment they are known and copied to their queues after the
     // block-wide append at the end: holding three rays plus the pending direct-light terms in registers until then had
     // pushed the kernel to 130 VGPRs with scratch spills (3 waves/SIMD).
     __shared__ float4 s_ray[3][2][PG_BLOCK];
+    __shared__ float4 s_state[QSTATE ? 3 : 1][PG_BLOCK];  // QSTATE: (L, beta, meta) until the entry's place in the next queue is known
     const int tid = threadIdx.x;
     bool pushNext = false, pushShadow = false, pushMis = false;
     int slot = 0;
+    int pdi = 0;  // index of this vertex's pending direct-light terms: the ray's queue position (QSTATE), else the slot
     unsigned int nLightTests = 0;
     int lightNum = -1;
     int nextBin = 0;  // direction octant of the continuation ray (groups the next queue, see block_push)
@@ -1501,11 +1505,14 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
     if (valid) {
         const float4 d4 = qin.d[i], h4 = hits[i];
         slot = __float_as_int(d4.w);
+        pdi = QSTATE ? i : slot;
         const V3 rayD = mk(d4.x, d4.y, d4.z);
         const int prim = __float_as_int(h4.x);
         const PgRenderDesc &rd = rp.rd;
-        float4 L4 = st.L[slot], B4 = st.beta[slot];
-        int4 meta = st.meta[slot];
+        float4 L4, B4;
+        int4 meta;
+        if constexpr (QSTATE) { L4 = qsIn.L[i]; B4 = qsIn.beta[i]; meta = qsIn.meta[i]; }
+        else { L4 = st.L[slot]; B4 = st.beta[slot]; meta = st.meta[slot]; }
         Spec L = sp3(L4.x, L4.y, L4.z), beta = sp3(B4.x, B4.y, B4.z);
         const uint64_t index = (uint64_t)(uint32_t)meta.x | ((uint64_t)(uint32_t)meta.y << 32);
         int dim = (int)((uint32_t)meta.w >> 20);
@@ -1877,8 +1884,8 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                         }
                         // pending terms of this vertex, consumed by k_resolve (pdMis and the MIS weight follow below)
                         pdLight.w = lightSelPdf;
-                        st.pdLight[slot] = pdLight;
-                        st.pdBeta[slot] = make_float4(beta.r, beta.g, beta.b, 0.f);
+                        st.pdLight[pdi] = pdLight;
+                        st.pdBeta[pdi] = make_float4(beta.r, beta.g, beta.b, 0.f);
                     }
                 }
                 // ---- sample the BSDF for the next direction (path.cpp:130-150)
@@ -1914,9 +1921,15 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                 bounces += 1;
             }
         }
-        st.L[slot] = make_float4(L.r, L.g, L.b, L4.w);
-        st.beta[slot] = make_float4(beta.r, beta.g, beta.b, B4.w);
-        st.meta[slot] = make_int4(meta.x, meta.y, __float_as_int(etaScale), (dim << 20) | bounces | newFlags);
+        if constexpr (QSTATE) {  // written after the append: to the ray's entry of the next queue, or (path over) L to its slot
+            s_state[0][tid] = make_float4(L.r, L.g, L.b, L4.w);
+            s_state[1][tid] = make_float4(beta.r, beta.g, beta.b, B4.w);
+            s_state[2][tid] = make_float4(__int_as_float(meta.x), __int_as_float(meta.y), etaScale, __int_as_float((dim << 20) | bounces | newFlags));
+        } else {
+            st.L[slot] = make_float4(L.r, L.g, L.b, L4.w);
+            st.beta[slot] = make_float4(beta.r, beta.g, beta.b, B4.w);
+            st.meta[slot] = make_int4(meta.x, meta.y, __float_as_int(etaScale), (dim << 20) | bounces | newFlags);
+        }
     }
     if (misCand) {
         // light.Pdf_Li -> Shape::Pdf(ref, wi): intersect the light's own triangle (shape.cpp:72-87, diffuse.cpp:83-87)
@@ -1947,8 +1960,8 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
             s_ray[2][0][tid] = make_float4(misRo.x, misRo.y, misRo.z, PG_INF);
             s_ray[2][1][tid] = make_float4(misWi.x, misWi.y, misWi.z, __int_as_float(slot));
             pushMis = true;
-            st.pdMis[slot] = make_float4(misF.r, misF.g, misF.b, misPdf);
-            st.pdBeta[slot].w = power_heuristic(1, misPdf, 1, lightPdf2);
+            st.pdMis[pdi] = make_float4(misF.r, misF.g, misF.b, misPdf);
+            st.pdBeta[pdi].w = power_heuristic(1, misPdf, 1, lightPdf2);
             if constexpr (VOL) vs.trAcc[1][slot] = make_float4(1, 1, 1, __int_as_float(misMedium));
         }
     }
@@ -1960,39 +1973,49 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
     if (pushNext) { qnext.o[posNext] = s_ray[0][0][tid]; qnext.d[posNext] = s_ray[0][1][tid]; }
     if (pushShadow) { qshadow.o[posShadow] = s_ray[1][0][tid]; qshadow.d[posShadow] = s_ray[1][1][tid]; }
     if (pushMis) { qmis.o[posMis] = s_ray[2][0][tid]; qmis.d[posMis] = s_ray[2][1][tid]; }
-    if (valid) st.pdInfo[slot] = make_int4(posShadow, posMis, lightNum, VOL ? __float_as_int(volWeight) : 0);
+    if constexpr (QSTATE) {
+        if (valid) {
+            if (pushNext) {
+                const float4 m4 = s_state[2][tid];
+                qsOut.L[posNext] = s_state[0][tid]; qsOut.beta[posNext] = s_state[1][tid];
+                qsOut.meta[posNext] = make_int4(__float_as_int(m4.x), __float_as_int(m4.y), __float_as_int(m4.z), __float_as_int(m4.w));
+            } else st.L[slot] = s_state[0][tid];
+            st.pdInfo[pdi] = make_int4(posShadow, posMis, lightNum, pushNext ? posNext : ~slot);
+        }
+    } else if (valid) st.pdInfo[slot] = make_int4(posShadow, posMis, lightNum, VOL ? __float_as_int(volWeight) : 0);
     unsigned long long nl = wave_sum(nLightTests);
     if (lane_id() == 0 && nl) atomicAdd(lightTriTests, nl);
 }
 void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQueue qin, const float4 *hits, RayQueue qnext,
-                  RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s) {
+                  RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s, int cur) {
     int nblk = PG_REGIONS * (qin.regionCap / PG_BLOCK);
     if (nblk == 0) return;
     const VolState vs = {};
     const float *noT = nullptr;
-    if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, false>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT);
-    else if (sc.ext) hipLaunchKernelGGL((k_shade<1, false>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT);
-    else hipLaunchKernelGGL((k_shade<0, false>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT);
+    const QueueState qi = st.qs[cur], qo = st.qs[cur ^ 1];
+    if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, false>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo);
+    else if (sc.ext) hipLaunchKernelGGL((k_shade<1, false>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo);
+    else hipLaunchKernelGGL((k_shade<0, false>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo);
 }
 void launch_shade_vol(const DScene &sc, const RenderParams &rp, PathState st, VolState vs, RayQueue qin, const float4 *hits, const float *hitT,
                       RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s) {
     int nblk = PG_REGIONS * (qin.regionCap / PG_BLOCK);
     if (nblk == 0) return;
-    if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, true>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT);
-    else hipLaunchKernelGGL((k_shade<1, true>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT);
+    const QueueState none = {nullptr, nullptr, nullptr};
+    if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, true>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none);
+    else hipLaunchKernelGGL((k_shade<1, true>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none);
 }
 
 // EstimateDirect's two "Add ... contribution" steps (integrator.cpp:143-161, 196-212) and
 // L += beta * Ld / lightPdf (integrator.cpp:104, path.cpp:122-126), once both rays are back.
 template <bool EXT>
 __global__ __launch_bounds__(PG_BLOCK) void k_resolve(DScene sc, PathState st, RayQueue qin, RayQueue qmis, const int *__restrict__ occluded,
-                                                       const float4 *__restrict__ misHits) {
+                                                       const float4 *__restrict__ misHits, QueueState qsNext) {
     const int i = queue_item(qin);
     if (i < 0) return;
-    const int slot = __float_as_int(qin.d[i].w);
-    const int4 info = st.pdInfo[slot];
+    const int4 info = st.pdInfo[i];  // the pending terms lie in queue order (PathState)
     if (info.x < 0 && info.y < 0) return;  // Ld == 0: L += beta * 0 leaves L unchanged
-    const float4 pl = st.pdLight[slot], pm = st.pdMis[slot], pb = st.pdBeta[slot];
+    const float4 pl = st.pdLight[i], pm = st.pdMis[i], pb = st.pdBeta[i];
     Spec Ld = sp(0);
     if (info.x >= 0 && !occluded[info.x]) Ld = Ld + sp3(pl.x, pl.y, pl.z);
     if (info.y >= 0) {
@@ -2018,15 +2041,18 @@ __global__ __launch_bounds__(PG_BLOCK) void k_resolve(DScene sc, PathState st, R
             if (!is_black(Li)) Ld = Ld + ((((sp3(pm.x, pm.y, pm.z) * Li) * sp(1.f)) * pb.w) / pm.w);
         }
     }
-    float4 L4 = st.L[slot];
-    Spec L = sp3(L4.x, L4.y, L4.z) + sp3(pb.x, pb.y, pb.z) * (Ld / pl.w);
-    st.L[slot] = make_float4(L.r, L.g, L.b, L4.w);
+    // the path's L: with its ray in the next queue's state, or -- the path is over -- in its slot
+    float4 *Lp = info.w >= 0 ? &qsNext.L[info.w] : &st.L[~info.w];
+    const float4 L4 = *Lp;
+    const Spec L = sp3(L4.x, L4.y, L4.z) + sp3(pb.x, pb.y, pb.z) * (Ld / pl.w);
+    *Lp = make_float4(L.r, L.g, L.b, L4.w);
 }
-void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis, const int *occluded, const float4 *misHits, hipStream_t s) {
+void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis, const int *occluded, const float4 *misHits, hipStream_t s,
+                    int cur) {
     int nblk = PG_REGIONS * (qin.regionCap / PG_BLOCK);
     if (nblk == 0) return;
-    if (sc.ext) hipLaunchKernelGGL(k_resolve<true>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, qin, qmis, occluded, misHits);
-    else hipLaunchKernelGGL(k_resolve<false>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, qin, qmis, occluded, misHits);
+    if (sc.ext) hipLaunchKernelGGL(k_resolve<true>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, qin, qmis, occluded, misHits, st.qs[cur ^ 1]);
+    else hipLaunchKernelGGL(k_resolve<false>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, qin, qmis, occluded, misHits, st.qs[cur ^ 1]);
 }
 
 // ===========================================================================

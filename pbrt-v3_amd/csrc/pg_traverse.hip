@@ -144,20 +144,27 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
             triNext = wTriNext; triLeft = wTriLeft; inInst = -1; spBase = 0;
             if (triLeft == 0) { TR_POP(); TR_SETTLE(); }
         }
-        // ---- retire finished rays, refill idle lanes from this wave's segment
+        // ---- retire finished rays and refill idle lanes from this wave's segment.  A finished ray's result stays in its lane
+        //      until the wave refills (>= refillAt idle lanes) or runs dry, so the stores run with many lanes active instead of
+        //      once per iteration for one or two lanes.  (Copying the hit triangle's 48-B record next to the hit here, to spare
+        //      the shading kernel its gather, was measured: +12 ms per frame in this kernel, no gain in k_shade.)
         const bool idle = cur == TR_NONE && triLeft == 0;
-        if (idle && ray >= 0) {
-            if (ANYHIT) occluded[ray] = hitPrim >= 0 ? 1 : 0;
-            else {
-                hits[ray] = make_float4(__int_as_float(hitPrim), hb0, hb1, hb2);
-                if (XPRIM && sc.hitInst) sc.hitInst[ray] = hitInstCur;
-                if (tOut) tOut[ray] = tMax;
-            }
-            ray = -1;
-        }
         const unsigned long long idleMask = __ballot(idle);
         const int nIdle = __popcll(idleMask);
-        if (!exhausted && nIdle >= refillAt) {
+        const bool refill = !exhausted && nIdle >= refillAt;
+        if (refill || (exhausted && nIdle == 64)) {
+            if (idle && ray >= 0) {
+                if (ANYHIT) occluded[ray] = hitPrim >= 0 ? 1 : 0;
+                else {
+                    hits[ray] = make_float4(__int_as_float(hitPrim), hb0, hb1, hb2);
+                    if (XPRIM && sc.hitInst) sc.hitInst[ray] = hitInstCur;
+                    if (tOut) tOut[ray] = tMax;
+                }
+                ray = -1;
+            }
+            if (exhausted) break;
+        }
+        if (refill) {
             if (next >= segEnd) {  // wave-uniform: take the next chunk
                 for (;;) {
                     const int qsel = region >> 3, rr = region & (PG_REGIONS - 1);
@@ -208,9 +215,8 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
                     }
                 }
             }
-            continue;  // lanes that finished at once (root miss) retire at the top
+            continue;  // lanes that finished at once (root miss) retire at the next refill
         }
-        if (exhausted && nIdle == 64) break;
 
         // ---- one step for the wave: either every lane holding an interior record expands it, or every lane
         //      holding a leaf tests its next triangle.  The larger group goes first (weighted by triW/16), so
@@ -350,8 +356,8 @@ void set_trace_config(const TraceConfig &c) { g_cfg = c; }
 TraceConfig get_trace_config() { return g_cfg; }
 
 template <bool ANYHIT>
-static void launch_trace(const DScene &sc, RayQueue q0, RayQueue q1, float4 *hits, int hitOffset1, float *tOut, int *occluded, TraceCounters *cn,
-                         int *cursors, int *cullGuard, hipStream_t s) {
+static void launch_trace(const DScene &sc, RayQueue q0, RayQueue q1, float4 *hits, int hitOffset1, float *tOut, int *occluded,
+                         TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s) {
     const TraceConfig c = g_cfg;
     if (q0.regionCap <= 0) return;
     // persistent grid: enough blocks to fill 256 CUs at 8 blocks each, never more than the queues can feed
