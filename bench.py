@@ -131,11 +131,23 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible (the HIP path has no CPU fallback)")
+    # one rank per GPU; PBRT_BENCH_OVERSUBSCRIBE=1 lets several ranks share a device (a functional pre-flight of the N > 1
+    # path on a single-GPU box -- RCCL permitting; never a measurement)
+    if local_rank >= torch.cuda.device_count() and os.environ.get("PBRT_BENCH_OVERSUBSCRIBE") != "1":
+        raise SystemExit(f"bench.py: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # RCCL refuses two ranks on one device ("Duplicate GPU detected"), so the single-GPU pre-flight of the N > 1 path
+    # (PBRT_BENCH_OVERSUBSCRIBE=1) moves the film shards through gloo on host copies instead; a real run is RCCL over xGMI
+    backend = "gloo" if os.environ.get("PBRT_BENCH_OVERSUBSCRIBE") == "1" else "nccl"
+    comm_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
 
     pkg = load_package()
     workdir = tempfile.mkdtemp(prefix=f"pbrt_bench_r{rank}_")
@@ -149,13 +161,14 @@ def main():
     max_tiles = gs.tile_count(scene.render_desc(0, world))  # rank 0 owns the most
     from pbrt_v3_amd import distributed as pdist
     film, strays, nstrays, max_strays = pdist.shard_buffers(max_tiles, dev, rd.tile_pixels)
-    gathered = [pdist.gather_lists(film, strays, nstrays) if world > 1 else None]
+    to_comm = (lambda t: t) if backend == "nccl" else (lambda t: t.cpu())
+    gathered = [pdist.gather_lists(to_comm(film), to_comm(strays), to_comm(nstrays)) if world > 1 else None]
 
     def step():
         stream = torch.cuda.current_stream().cuda_stream
         gs.render_device(rd, film.data_ptr(), strays.data_ptr(), max_strays, nstrays.data_ptr(), stream=stream)
         if world > 1:  # Film gather over xGMI: every rank's packed tile buffer to rank 0
-            pdist.gather_film(film, strays, nstrays, lists=gathered[0], dst=0)
+            pdist.gather_film(to_comm(film), to_comm(strays), to_comm(nstrays), lists=gathered[0], dst=0)
 
     def sync():
         if world > 1:
@@ -172,7 +185,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     cn = gs.counters()
-    stats = torch.tensor([elapsed, float(cn["closest_rays"] + cn["shadow_rays"]), float(cn["camera_rays"])], dtype=torch.float64, device=dev)
+    stats = torch.tensor([elapsed, float(cn["closest_rays"] + cn["shadow_rays"]), float(cn["camera_rays"])], dtype=torch.float64, device=comm_dev)
     if world > 1:
         tmax = stats[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -252,7 +265,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "samples_per_s": samples / elapsed,
             "config": {"workload": workload,
-                       "sharding": f"16x16 film tiles round-robin over {world} GPU(s), RCCL gather to rank 0",
+                       "sharding": f"16x16 film tiles round-robin over {world} GPU(s), " + ("RCCL gather to rank 0" if backend == "nccl" else "PRE-FLIGHT: ranks share a GPU, gloo gather of host copies"),
                        "rays_per_sample": rays / max(1.0, samples), "host_parse_and_bvh_s": t_parse},
             "roofline": roofline,
             "roofline_kernels": kernels,

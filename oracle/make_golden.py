@@ -458,7 +458,27 @@ def with_ply(s):
     return s
 
 
+def with_many_lights(s, n=50):
+    """The ceiling light as an n x n grid of cells = 2 n^2 emissive triangles (api.cpp:1353-1363: one DiffuseAreaLight each): under
+    the default "spatial" strategy every touched voxel holds a distribution over all of them (lightdistrib.cpp:232-300)."""
+    xs = [213 + (343 - 213) * i / n for i in range(n + 1)]
+    zs = [227 + (332 - 227) * j / n for j in range(n + 1)]
+    P = " ".join(f"{x:.6g} 548.7 {z:.6g}" for z in zs for x in xs)
+    idx = []
+    for j in range(n):
+        for i in range(n):
+            a, b, c, d = j * (n + 1) + i, j * (n + 1) + i + 1, (j + 1) * (n + 1) + i + 1, (j + 1) * (n + 1) + i
+            idx += [a, c, d, a, b, c]  # normals point down (-y), like the original quad
+    mesh = 'Shape "trianglemesh" "integer indices" [ ' + " ".join(map(str, idx)) + ' ]\n    "point P" [ ' + P + " ]"
+    old = 'Shape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ]\n    "point P" [ 343 548.7 227   343 548.7 332   213 548.7 332   213 548.7 227 ]'
+    assert old in s
+    return s.replace(old, mesh)
+
+
 SCENES = {
+    # 5 000 area lights under the default "spatial" strategy: the device fills its voxel tables on first touch (sparse), as the
+    # reference's hash table does
+    "many_lights": cornell(20, 20, 2, integrator='Integrator "path" "integer maxdepth" [ 2 ]', world_edit=lambda s: with_many_lights(s, 50)),
     # plain Cornell, tile-aligned and not
     "cornell_32": cornell(32, 32, 8),
     "cornell_40x24": cornell(40, 24, 4),

@@ -239,6 +239,28 @@ class GpuScene:
         _check(gpu_lib().pg_counters_reset(self._h), "pg_counters_reset")
 
 
+def render_sharded(gpu_scenes, rd, max_strays=None):
+    """pg_render_sharded: the frame of rd (tile_first 0, tile_step 1) over the devices of gpu_scenes -- one host thread per
+    device, shards gathered peer-to-peer on the first device.  Returns [(shard rd, film, strays)] per rank."""
+    n = len(gpu_scenes)
+    shards = []
+    for r in range(n):
+        srd = PgRenderDesc.from_buffer_copy(rd)
+        srd.tile_first, srd.tile_step = r, n
+        shards.append(srd)
+    counts = [GpuScene.tile_count(s) for s in shards]
+    if max_strays is None:
+        max_strays = max(counts) * 256 // 8 + 1024
+    films = [np.zeros(c * rd.tile_pixels, FILM_PIXEL_DTYPE) for c in counts]
+    strays = [np.zeros(max_strays, STRAY_DTYPE) for _ in range(n)]
+    handles = (C.c_void_p * n)(*[g._h for g in gpu_scenes])
+    fptr = (C.c_void_p * n)(*[f.ctypes.data for f in films])
+    sptr = (C.c_void_p * n)(*[s.ctypes.data for s in strays])
+    ns = (C.c_int32 * n)()
+    _check(gpu_lib().pg_render_sharded(handles, n, C.byref(rd), fptr, sptr, max_strays, ns), "pg_render_sharded")
+    return [(shards[r], films[r], strays[r][:ns[r]]) for r in range(n)]
+
+
 def render_scene(scene, device=0):
     """Whole-frame render of a HostScene on one GPU; returns the final (h, w, 3) image."""
     gs = GpuScene(scene.desc, device)

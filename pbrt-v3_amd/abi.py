@@ -158,6 +158,8 @@ GPU_SYMBOLS = {
     "pg_render_tile_count": (C.c_int, [C.POINTER(PgRenderDesc)]),
     "pg_render": (C.c_int, [C.c_void_p, C.POINTER(PgRenderDesc), C.c_void_p, C.c_void_p, C.c_int32,
                             C.c_void_p, C.c_int, C.c_void_p]),
+    "pg_render_sharded": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(PgRenderDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                    C.c_int32, C.POINTER(C.c_int32)]),
     "pg_intersect": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_int, C.c_void_p]),
     "pg_intersect_p": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 #include "pg_device.h"
 #include "pg_kernels.h"
@@ -65,6 +67,9 @@ struct PgScene {
     int nMedia = 0;
     DeviceBuffer vqo[2], vqd[2], vCounts, volMedium, trAcc[2], volP1[3], misLi, pdLi, hitT;
     DeviceBuffer qsL[2], qsBeta[2], qsMeta[2];  // PathIntegrator: path state in queue order
+    DeviceBuffer voxelSlot, voxelRequests, voxelCounters, retryList;  // sparse "spatial" light tables (DScene::sparseLights)
+    int poolSlots = 0, poolUsed = 0, nVoxelsTotal = 0;
+    DeviceBuffer shardFilm, shardStrays, shardCount, gatherDev;  // pg_render_sharded: this device's shard; on rank 0's device the gathered frame
     int qsCapacity = 0;
 };
 
@@ -214,7 +219,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     std::vector<float4> tris((size_t)nt * 3);
     std::vector<float> uv;
     bool anyUV = false;
-    for (int k = 0; k < nt; ++k) anyUV |= desc->UV && (desc->tri_flags[k] & PG_TRI_HAS_UV);
+    for (int k = 0; k < nt; ++k) anyUV |= desc->UV && desc->tri_flags && (desc->tri_flags[k] & PG_TRI_HAS_UV);
     if (anyUV) uv.resize((size_t)nt * 6);
     for (int k = 0; k < nt; ++k) {
         const int32_t *v = &desc->indices[3 * k];
@@ -516,25 +521,44 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         const size_t stride = 2 * (size_t)nl + 2;
         if (desc->light_strategy == PG_LIGHTS_SPATIAL) {
             // SpatialLightDistribution ctor, lightdistrib.cpp:96-125 (maxVoxels = 64)
-            const PgBVHNode &root = desc->nodes[0];
+            // a scene without geometry has no bound to divide into voxels and no surface to look a voxel up from: one voxel
+            PgBVHNode root;
+            memset(&root, 0, sizeof(root));
+            if (desc->n_nodes > 0 && desc->nodes) root = desc->nodes[0];
             float diag[3];
             for (int i = 0; i < 3; ++i) { d.bmin[i] = root.bmin[i]; d.bmax[i] = root.bmax[i]; diag[i] = root.bmax[i] - root.bmin[i]; }
             int me = (diag[0] > diag[1] && diag[0] > diag[2]) ? 0 : ((diag[1] > diag[2]) ? 1 : 2);
             float bmax = diag[me];
             size_t total = 1;
             for (int i = 0; i < 3; ++i) {
-                int nv = (int)roundf(diag[i] / bmax * 64);
+                int nv = bmax > 0 ? (int)roundf(diag[i] / bmax * 64) : 1;
                 d.nVoxels[i] = nv > 1 ? nv : 1;
                 total *= (size_t)d.nVoxels[i];
             }
-            if (total * stride * sizeof(float) > ((size_t)8 << 30))
-                FAIL(PG_ERR_UNSUPPORTED, "dense spatial light table would need %zu MiB (%d lights x %zu voxels); use "
-                     "\"lightsamplestrategy\" \"power\" or \"uniform\"", total * stride * sizeof(float) >> 20, nl, total);
-            HIP_TRY_S(s->distTable.alloc(total * stride * sizeof(float)));
-            d.distTable = (const float *)s->distTable.p;
-            launch_light_tables(d, (float *)s->distTable.p, (int)total, 0);
-            HIP_TRY_S(hipGetLastError());
-            HIP_TRY_S(hipDeviceSynchronize());
+            // Dense table (every voxel up front: they are pure functions of the voxel) while it is small; beyond that the
+            // voxels are computed on first touch like the reference's hash table (lightdistrib.cpp:135-230), into a pool.
+            size_t denseLimit = (size_t)1 << 30;
+            if (const char *e = getenv("PG_SPARSE_LIGHTS")) { if (atoi(e) != 0) denseLimit = 0; }
+            if (total * stride * sizeof(float) > denseLimit) {
+                const size_t budget = (size_t)16 << 30;
+                s->nVoxelsTotal = (int)total;
+                s->poolSlots = (int)std::min<size_t>(total, std::max<size_t>(1, budget / (stride * sizeof(float))));
+                HIP_TRY_S(s->distTable.alloc((size_t)s->poolSlots * stride * sizeof(float)));
+                HIP_TRY_S(s->voxelSlot.alloc(total * sizeof(int)));
+                HIP_TRY_S(hipMemset(s->voxelSlot.p, 0xff, total * sizeof(int)));  // -1: not requested
+                HIP_TRY_S(s->voxelRequests.alloc(total * sizeof(int)));
+                HIP_TRY_S(s->voxelCounters.alloc(2 * sizeof(int)));
+                HIP_TRY_S(hipMemset(s->voxelCounters.p, 0, 2 * sizeof(int)));
+                d.distTable = (const float *)s->distTable.p;
+                d.sparseLights = 1;
+                d.voxelSlot = (int *)s->voxelSlot.p; d.voxelRequests = (int *)s->voxelRequests.p; d.voxelCounters = (int *)s->voxelCounters.p;
+            } else {
+                HIP_TRY_S(s->distTable.alloc(total * stride * sizeof(float)));
+                d.distTable = (const float *)s->distTable.p;
+                launch_light_tables(d, (float *)s->distTable.p, (int)total, 0);
+                HIP_TRY_S(hipGetLastError());
+                HIP_TRY_S(hipDeviceSynchronize());
+            }
         } else {
             // UniformLightDistribution (lightdistrib.cpp:68-71) / PowerLightDistribution (integrator.cpp:217-225, diffuse.cpp:64-66)
             std::vector<float> tab(stride);
@@ -621,13 +645,15 @@ int pg_render_tile_count(const PgRenderDesc *desc) {
 
 // Queue geometry for a batch of `capacity` path slots: PG_REGIONS regions of regionCap entries (multiple of 256) such
 // that the blocks of one XCD (b % 8) can never overflow their region.
-static int regionCapFor(int capacity) {
+// `slack`: twice the room (sparse light tables: entries re-shaded in a second pass append from other blocks than their own)
+static int regionCapFor(int capacity, bool slack = false) {
     int nblk = (capacity + 255) / 256;
-    return ((nblk + PG_REGIONS - 1) / PG_REGIONS) * 256;
+    return ((nblk + PG_REGIONS - 1) / PG_REGIONS) * 256 * (slack ? 2 : 1);
 }
 static int ensureWorkBuffers(PgScene *s, int capacity) {
     if (s->capacity >= capacity) return PG_OK;
-    const size_t n = (size_t)regionCapFor(capacity) * PG_REGIONS;  // >= capacity
+    const size_t n = (size_t)regionCapFor(capacity, s->d.sparseLights != 0) * PG_REGIONS;  // >= capacity
+    if (s->d.sparseLights) HIP_TRY(s->retryList.alloc(n * sizeof(int)));
     for (int i = 0; i < 4; ++i) { HIP_TRY(s->qo[i].alloc(n * sizeof(float4))); HIP_TRY(s->qd[i].alloc(n * sizeof(float4))); }
     HIP_TRY(s->counts.alloc(4 * PG_REGIONS * PG_COUNT_STRIDE * sizeof(int)));
     HIP_TRY(s->hitsMain.alloc(2 * n * sizeof(float4)));
@@ -723,7 +749,7 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
     memset(&vs, 0, sizeof(vs));
     RayQueue vq[2];  // second halves of the through-ray ping-pong (the first halves are q[2] and q[3])
     if (vol) {
-        const size_t n = (size_t)regionCapFor(capacity) * PG_REGIONS;
+        const size_t n = (size_t)regionCapFor(capacity, s->d.sparseLights != 0) * PG_REGIONS;
         if (s->volCapacity < capacity) {
             for (int i = 0; i < 2; ++i) { HIP_TRY(s->vqo[i].alloc(n * sizeof(float4))); HIP_TRY(s->vqd[i].alloc(n * sizeof(float4))); HIP_TRY(s->trAcc[i].alloc(n * sizeof(float4))); }
             for (int i = 0; i < 3; ++i) HIP_TRY(s->volP1[i].alloc(n * sizeof(float4)));
@@ -741,11 +767,11 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
         for (int i = 0; i < 2; ++i) { vq[i].o = (float4 *)s->vqo[i].p; vq[i].d = (float4 *)s->vqd[i].p; vq[i].counts = (int *)s->vCounts.p + i * QSTRIDE; }
     }
 
-    float4 *const hitsMis = (float4 *)s->hitsMain.p + (size_t)regionCapFor(capacity) * PG_REGIONS;
+    float4 *const hitsMis = (float4 *)s->hitsMain.p + (size_t)regionCapFor(capacity, s->d.sparseLights != 0) * PG_REGIONS;
     PathState ps;
     memset(&ps, 0, sizeof(ps));
     if (!vol) {  // PathIntegrator: L / beta / meta in queue order beside each main queue
-        const size_t n = (size_t)regionCapFor(capacity) * PG_REGIONS;
+        const size_t n = (size_t)regionCapFor(capacity, s->d.sparseLights != 0) * PG_REGIONS;
         if (s->qsCapacity < capacity) {
             for (int i = 0; i < 2; ++i) { HIP_TRY(s->qsL[i].alloc(n * sizeof(float4))); HIP_TRY(s->qsBeta[i].alloc(n * sizeof(float4))); HIP_TRY(s->qsMeta[i].alloc(n * sizeof(int4))); }
             s->qsCapacity = capacity;
@@ -772,6 +798,25 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
     hipEvent_t evStart = getEvent(s, ev++), evStop = getEvent(s, ev++);
     if (!evStart || !evStop) return setError(PG_ERR_DEVICE, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(evStart, stream));
+    // Sparse "spatial" light tables: after a shading launch, compute the distributions of the voxels its lanes asked for and
+    // shade the entries that waited for them (one host round trip per launch while the table warms up; none once every
+    // voxel the image touches exists -- the tables stay with the scene).
+    rp.retryList = (int *)s->retryList.p;
+    auto settleLightTables = [&](const std::function<void()> &reshade) -> int {
+        if (!s->d.sparseLights) return PG_OK;
+        int cnt[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(cnt, s->voxelCounters.p, sizeof(cnt), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (cnt[0] == 0 && cnt[1] == 0) return PG_OK;
+        if (s->poolUsed + cnt[0] > s->poolSlots)
+            return setError(PG_ERR_UNSUPPORTED, "spatial light distribution: %d voxels x %d lights exceed the table pool (%d voxels); use "
+                                                "\"lightsamplestrategy\" \"power\" or \"uniform\"", s->poolUsed + cnt[0], s->d.nLights, s->poolSlots);
+        launch_light_tables_sparse(s->d, (float *)s->distTable.p, (const int *)s->voxelRequests.p, cnt[0], s->poolUsed, stream);
+        s->poolUsed += cnt[0];
+        HIP_TRY(hipMemsetAsync(s->voxelCounters.p, 0, sizeof(cnt), stream));
+        if (cnt[1] > 0) { rp.retryCount = cnt[1]; reshade(); rp.retryCount = 0; }
+        return PG_OK;
+    };
     uint64_t closestRays = 0, shadowRays = 0, cameraRays = 0, closestLaunches = 0, shadowLaunches = 0;
     uint64_t shadeLaunches = 0, resolveLaunches = 0, shadeItems = 0, misRays = 0;
     std::vector<int> hostCounts;  // read back once per batch at the end (pinned copy not needed: tiny)
@@ -787,7 +832,7 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
             rp.s0 = s0;
             rp.sCount = std::min(sPerBatch, rd->spp - s0);
             rp.capacity = rp.nTilesBatch * 256 * rp.sCount;
-            for (int i = 0; i < 4; ++i) q[i].regionCap = regionCapFor(rp.capacity);
+            for (int i = 0; i < 4; ++i) q[i].regionCap = regionCapFor(rp.capacity, s->d.sparseLights != 0);
             curQueueOfBounce.clear();
             HIP_TRY(hipMemsetAsync(counts, 0, 4 * QSTRIDE * sizeof(int), stream));
             int cur = 0;  // main queue index (0/1 ping-pong); 2 = shadow, 3 = MIS
@@ -799,7 +844,7 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
                 // Crossing a surface without a material does not count as a bounce, so the loop runs until the queue is empty.
                 DScene dv = s->d;
                 dv.ext = 1;  // the general shading kernels
-                const int n1 = regionCapFor(capacity) * PG_REGIONS;
+                const int n1 = regionCapFor(capacity, s->d.sparseLights != 0) * PG_REGIONS;
                 float *hitT = (float *)s->hitT.p;
                 for (int i = 0; i < 2; ++i) vq[i].regionCap = q[0].regionCap;
                 launch_fill_int(vs.medium, rd->camera_medium + 1, rp.capacity, stream);  // camera rays start in the camera's medium (camera.h:78)
@@ -822,6 +867,7 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
                     HIP_TRY(hipMemsetAsync(counts + 2 * QSTRIDE, 0, 2 * QSTRIDE * sizeof(int), stream));
                     PG_TIMED(2, stream, launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream));
                     ++shadeLaunches;
+                    if (int e = settleLightTables([&]() { launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream); })) return e;
                     // through rays: kind 0 = light samples (q[2] <-> vq[0]), kind 1 = BSDF / phase samples (q[3] <-> vq[1])
                     RayQueue tq[2][2] = {{q[2], vq[0]}, {q[3], vq[1]}};
                     int tcur = 0;
@@ -870,6 +916,7 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
                 HIP_TRY(hipMemsetAsync(counts + 2 * QSTRIDE, 0, 2 * QSTRIDE * sizeof(int), stream));
                 PG_TIMED(2, stream, launch_shade(s->d, rp, ps, q[cur], (const float4 *)s->hitsMain.p, q[nxt], q[2], q[3], lightTests, stream, cur));
                 ++shadeLaunches;
+                if (int e = settleLightTables([&]() { launch_shade(s->d, rp, ps, q[cur], (const float4 *)s->hitsMain.p, q[nxt], q[2], q[3], lightTests, stream, cur); })) return e;
                 // paths that reach maxdepth neither continue nor sample lights (path.cpp:104): nothing left to trace
                 const bool lastDepth = !s->hasNullMaterial && bounce >= rd->max_depth;
                 if (!lastDepth) {
@@ -961,6 +1008,77 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
     if (hipEventElapsedTime(&ms, evStart, evStop) == hipSuccess) c.render_ms += ms;
     if (int st2 = checkCullGuard(s)) return st2;
     if (hostNStrays > maxStrays) return setError(PG_ERR_OVERFLOW, "%d stray samples, buffer holds %d", hostNStrays, maxStrays);
+    return PG_OK;
+}
+
+// ---- one frame over several devices of the node, from one host process ---------------------------------------------------------
+// One host thread per device (pg_set_device is per thread); every thread renders its tiles into a buffer on its own device and
+// pushes the shard to the gathering device with a peer-to-peer copy (xGMI, once peer access is enabled; staged through the
+// host otherwise).  No per-bounce communication, no reduction: tiles are disjoint.
+int pg_render_sharded(PgScene *const *scenes, int32_t n, const PgRenderDesc *desc, PgFilmPixel *const *film, PgStraySample *const *strays,
+                      int32_t maxStrays, int32_t *nStrays) {
+    if (!scenes || n < 1 || !desc || !film || !nStrays || (maxStrays > 0 && !strays)) return setError(PG_ERR_INVALID, "pg_render_sharded: null argument");
+    if (desc->tile_first != 0 || desc->tile_step != 1) return setError(PG_ERR_INVALID, "pg_render_sharded: desc must describe the whole frame (tile_first 0, tile_step 1)");
+    for (int r = 0; r < n; ++r) if (!scenes[r] || !film[r] || (maxStrays > 0 && !strays[r])) return setError(PG_ERR_INVALID, "pg_render_sharded: null entry for rank %d", r);
+    PgScene *root = scenes[0];
+    const size_t strayBytes = sizeof(PgStraySample) * (size_t)(maxStrays > 0 ? maxStrays : 1);
+    std::vector<PgRenderDesc> rd((size_t)n, *desc);
+    std::vector<size_t> filmBytes((size_t)n), filmOff((size_t)n);
+    size_t total = 0;
+    for (int r = 0; r < n; ++r) {
+        rd[r].tile_first = r; rd[r].tile_step = n;
+        filmBytes[r] = sizeof(PgFilmPixel) * (size_t)desc->tile_pixels * (size_t)tileCount(&rd[r]);
+        filmOff[r] = total; total += filmBytes[r];
+    }
+    const size_t strayOff = total; total += strayBytes * (size_t)n;
+    const size_t countOff = total; total += sizeof(int) * (size_t)n;
+    HIP_TRY(hipSetDevice(root->device));
+    HIP_TRY(root->gatherDev.alloc(total));
+    char *gather = (char *)root->gatherDev.p;
+    std::vector<int> status((size_t)n, PG_OK);
+    std::vector<std::string> message((size_t)n);
+    auto work = [&](int r) {
+        PgScene *s = scenes[r];
+        auto fail = [&](int code) { status[r] = code; message[r] = pg_last_error(); };
+        if (hipSetDevice(s->device) != hipSuccess) { status[r] = PG_ERR_DEVICE; message[r] = "hipSetDevice failed"; return; }
+        if (s->device != root->device) {  // direct xGMI writes into the gathering device's buffer
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, s->device, root->device) == hipSuccess && can) {
+                hipError_t e = hipDeviceEnablePeerAccess(root->device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { status[r] = PG_ERR_DEVICE; message[r] = hipGetErrorString(e); return; }
+                (void)hipGetLastError();
+            }
+        }
+        if (s->shardFilm.bytes < filmBytes[r] && s->shardFilm.alloc(filmBytes[r]) != hipSuccess) { status[r] = PG_ERR_DEVICE; message[r] = "out of device memory (shard film)"; return; }
+        if (s->shardStrays.bytes < strayBytes && s->shardStrays.alloc(strayBytes) != hipSuccess) { status[r] = PG_ERR_DEVICE; message[r] = "out of device memory (shard strays)"; return; }
+        if (!s->shardCount.p && s->shardCount.alloc(sizeof(int)) != hipSuccess) { status[r] = PG_ERR_DEVICE; message[r] = "out of device memory"; return; }
+        int st = pg_render(s, &rd[r], (PgFilmPixel *)s->shardFilm.p, (PgStraySample *)s->shardStrays.p, maxStrays, (int32_t *)s->shardCount.p, PG_MEM_DEVICE, nullptr);
+        if (st != PG_OK) { fail(st); return; }
+        hipError_t e = hipSuccess;
+        if (filmBytes[r]) e = hipMemcpyPeer(gather + filmOff[r], root->device, s->shardFilm.p, s->device, filmBytes[r]);
+        if (e == hipSuccess) e = hipMemcpyPeer(gather + strayOff + strayBytes * (size_t)r, root->device, s->shardStrays.p, s->device, strayBytes);
+        if (e == hipSuccess) e = hipMemcpyPeer(gather + countOff + sizeof(int) * (size_t)r, root->device, s->shardCount.p, s->device, sizeof(int));
+        if (e != hipSuccess) { status[r] = PG_ERR_DEVICE; message[r] = std::string("peer copy of the film shard: ") + hipGetErrorString(e); }
+    };
+    {
+        std::vector<std::thread> threads;
+        for (int r = 1; r < n; ++r) threads.emplace_back(work, r);
+        work(0);
+        for (auto &t : threads) t.join();
+    }
+    for (int r = 0; r < n; ++r) if (status[r] != PG_OK) return setError(status[r], "rank %d: %s", r, message[r].c_str());
+    // the gathered frame back to the host in one piece
+    HIP_TRY(hipSetDevice(root->device));
+    std::vector<char> host(total);
+    HIP_TRY(hipMemcpy(host.data(), gather, total, hipMemcpyDeviceToHost));
+    for (int r = 0; r < n; ++r) {
+        if (filmBytes[r]) memcpy(film[r], host.data() + filmOff[r], filmBytes[r]);
+        int cnt = 0;
+        memcpy(&cnt, host.data() + countOff + sizeof(int) * (size_t)r, sizeof(int));
+        cnt = std::max(0, std::min(cnt, (int)maxStrays));
+        if (cnt > 0) memcpy(strays[r], host.data() + strayOff + strayBytes * (size_t)r, sizeof(PgStraySample) * (size_t)cnt);
+        nStrays[r] = cnt;
+    }
     return PG_OK;
 }
 

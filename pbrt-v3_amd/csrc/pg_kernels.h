@@ -62,6 +62,12 @@ struct DScene {
     int nVoxels[3];
     float bmin[3], bmax[3];
     const float *distTable;  // per distribution: func[nl], cdf[nl+1], funcInt  (stride 2*nl+2)
+    // Sparse "spatial" tables (SpatialLightDistribution fills its voxels on first touch, lightdistrib.cpp:135-230): voxelSlot[v]
+    // >= 0: the voxel's distribution is distTable + slot * stride; -1: nobody asked yet; -2: requested.  A shading lane that
+    // meets a missing voxel appends it to voxelRequests (counter voxelCounters[0]) and its own queue index to the retry list
+    // (RenderParams.retryList, counter voxelCounters[1]); the host computes the requested voxels and re-runs those lanes.
+    int sparseLights;
+    int *voxelSlot, *voxelRequests, *voxelCounters;
     // Halton tables
     const uint16_t *perms;
     const int32_t *permSums;
@@ -133,6 +139,10 @@ struct RenderParams {
     // batch description: tiles [tileLocal0, tileLocal0+nTilesBatch) of this shard, samples [s0, s0+sCount)
     int tileLocal0, nTilesBatch, s0, sCount;
     int capacity;  // slots in this batch = nTilesBatch * sCount * 256
+    // sparse light tables: lanes that met a missing voxel leave their queue index in retryList; a launch with retryCount > 0
+    // shades exactly those entries
+    int *retryList;
+    int retryCount;
 };
 
 struct TraceCounters {
@@ -168,5 +178,7 @@ void launch_film(const RenderParams &rp, PathState st, PgFilmPixel *film, PgStra
                  hipStream_t s);
 void launch_film_general(const RenderParams &rp, PathState st, PgFilmPixel *film, hipStream_t s);
 void launch_light_tables(const DScene &sc, float *table, int nDistributions, hipStream_t s);
+// the distributions of voxels requests[0 .. n) into pool slots firstSlot ..; also publishes voxelSlot[]
+void launch_light_tables_sparse(const DScene &sc, float *pool, const int *requests, int n, int firstSlot, hipStream_t s);
 int pgSetError(int code, const char *msg);  // pg_abi.hip: sets pg_last_error()
 #endif

@@ -1411,6 +1411,12 @@ PG_DEV const float *light_distribution(const DScene &sc, V3 p) {
     pi1 = pi1 < 0 ? 0 : (pi1 > sc.nVoxels[1] - 1 ? sc.nVoxels[1] - 1 : pi1);
     pi2 = pi2 < 0 ? 0 : (pi2 > sc.nVoxels[2] - 1 ? sc.nVoxels[2] - 1 : pi2);
     size_t idx = ((size_t)pi2 * sc.nVoxels[1] + pi1) * sc.nVoxels[0] + pi0;
+    if (sc.sparseLights) {  // computed on first touch, like the reference's hash table: ask for it and let the caller retry
+        const int slot = sc.voxelSlot[idx];
+        if (slot >= 0) return sc.distTable + (size_t)slot * (size_t)(2 * sc.nLights + 2);
+        if (slot == -1 && atomicCAS(&sc.voxelSlot[idx], -1, -2) == -1) sc.voxelRequests[atomicAdd(&sc.voxelCounters[0], 1)] = (int)idx;
+        return nullptr;
+    }
     return sc.distTable + idx * (size_t)(2 * sc.nLights + 2);
 }
 // Distribution1D::SampleDiscrete, sampling.h:90-100 + FindInterval pbrt.h:403-415
@@ -1479,7 +1485,12 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                                                      const float *__restrict__ hitT, QueueState qsIn, QueueState qsOut) {
     constexpr bool EXT = MODE >= 1, TEX = MODE == 2;
     constexpr bool QSTATE = !VOL;  // path state and pending terms in queue order (see PathState)
-    const int i = queue_item(qin);
+    int i;
+    if (rp.retryCount > 0) {  // second pass over the entries that waited for a light-distribution voxel
+        const int j = blockIdx.x * PG_BLOCK + threadIdx.x;
+        i = j < rp.retryCount ? rp.retryList[j] : -1;
+    } else i = queue_item(qin);
+    bool deferred = false;  // sparse light tables: this vertex met a voxel without a distribution; nothing is committed
     const bool valid = i >= 0;
     // Output rays are staged in LDS ([queue][o|d][thread]) the moment they are known and copied to their queues after the
     // block-wide append at the end: holding three rays plus the pending direct-light terms in registers until then had
@@ -1592,8 +1603,9 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                 handled = true;
                 const float g = sc.media[med - 1].g;
                 const V3 zero = mk(0, 0, 0), wo = -rayD;
-                if (sc.nLights > 0) {  // UniformSampleOneLight(mi, ..., handleMedia = true), integrator.cpp:85-106
-                    const float *tab = light_distribution(sc, mediumP);
+                const float *tab = sc.nLights > 0 ? light_distribution(sc, mediumP) : nullptr;
+                if (sc.nLights > 0 && !tab) deferred = true;
+                if (tab) {  // UniformSampleOneLight(mi, ..., handleMedia = true), integrator.cpp:85-106
                     float lightSelPdf;
                     lightNum = sample_discrete(tab, sc.nLights, halton_sample(sc, rd, index, dim++), lightSelPdf);
                     if (lightSelPdf != 0) {
@@ -1818,8 +1830,10 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                 if constexpr (EXT) hasNonSpecular = lbsdf_num_components(lb, nonSpecular) > 0;
                 else hasNonSpecular = bsdf.nBxDFs > 0 && !bsdf.specular;
                 // ---- direct lighting: UniformSampleOneLight (integrator.cpp:85-106) + EstimateDirect set-up
-                if ((VOL || hasNonSpecular) && sc.nLights > 0) {  // path.cpp:119: only with non-specular lobes (volpath.cpp:124-127: always)
-                    const float *tab = light_distribution(sc, is.p);
+                const bool wantLight = (VOL || hasNonSpecular) && sc.nLights > 0;  // path.cpp:119: only with non-specular lobes (volpath.cpp:124-127: always)
+                const float *tab = wantLight ? light_distribution(sc, is.p) : nullptr;
+                if (wantLight && !tab) deferred = true;
+                if (tab) {
                     float lightSelPdf;
                     lightNum = sample_discrete(tab, sc.nLights, halton_sample(sc, rd, index, dim++), lightSelPdf);
                     if (lightSelPdf != 0) {
@@ -1909,7 +1923,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                     s_ray[0][1][tid] = make_float4(wi.x, wi.y, wi.z, __int_as_float(slot));
                     nextBin = (wi.x < 0 ? 1 : 0) | (wi.y < 0 ? 2 : 0) | (wi.z < 0 ? 4 : 0);
                     pushNext = true;
-                    if constexpr (VOL) vs.medium[slot] = dot(wi, is.n) > 0 ? mOut : mIn;
+                    if constexpr (VOL) { if (!deferred) vs.medium[slot] = dot(wi, is.n) > 0 ? mOut : mIn; }
                     // Russian roulette, path.cpp:176-184
                     Spec rrBeta = beta * etaScale;
                     if (max_component(rrBeta) < rd.rr_threshold && bounces > 3) {
@@ -1921,7 +1935,8 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                 bounces += 1;
             }
         }
-        if constexpr (QSTATE) {  // written after the append: to the ray's entry of the next queue, or (path over) L to its slot
+        if (deferred) {
+        } else if constexpr (QSTATE) {  // written after the append: to the ray's entry of the next queue, or (path over) L to its slot
             s_state[0][tid] = make_float4(L.r, L.g, L.b, L4.w);
             s_state[1][tid] = make_float4(beta.r, beta.g, beta.b, B4.w);
             s_state[2][tid] = make_float4(__int_as_float(meta.x), __int_as_float(meta.y), etaScale, __int_as_float((dim << 20) | bounces | newFlags));
@@ -1930,6 +1945,10 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
             st.beta[slot] = make_float4(beta.r, beta.g, beta.b, B4.w);
             st.meta[slot] = make_int4(meta.x, meta.y, __float_as_int(etaScale), (dim << 20) | bounces | newFlags);
         }
+    }
+    if (deferred) {  // retried once the voxel's distribution exists: no ray, no state, no pending term leaves this launch
+        pushNext = pushShadow = misCand = false;
+        rp.retryList[atomicAdd(&sc.voxelCounters[1], 1)] = i;
     }
     if (misCand) {
         // light.Pdf_Li -> Shape::Pdf(ref, wi): intersect the light's own triangle (shape.cpp:72-87, diffuse.cpp:83-87)
@@ -1974,7 +1993,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
     if (pushShadow) { qshadow.o[posShadow] = s_ray[1][0][tid]; qshadow.d[posShadow] = s_ray[1][1][tid]; }
     if (pushMis) { qmis.o[posMis] = s_ray[2][0][tid]; qmis.d[posMis] = s_ray[2][1][tid]; }
     if constexpr (QSTATE) {
-        if (valid) {
+        if (valid && !deferred) {
             if (pushNext) {
                 const float4 m4 = s_state[2][tid];
                 qsOut.L[posNext] = s_state[0][tid]; qsOut.beta[posNext] = s_state[1][tid];
@@ -1982,13 +2001,13 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
             } else st.L[slot] = s_state[0][tid];
             st.pdInfo[pdi] = make_int4(posShadow, posMis, lightNum, pushNext ? posNext : ~slot);
         }
-    } else if (valid) st.pdInfo[slot] = make_int4(posShadow, posMis, lightNum, VOL ? __float_as_int(volWeight) : 0);
+    } else if (valid && !deferred) st.pdInfo[slot] = make_int4(posShadow, posMis, lightNum, VOL ? __float_as_int(volWeight) : 0);
     unsigned long long nl = wave_sum(nLightTests);
     if (lane_id() == 0 && nl) atomicAdd(lightTriTests, nl);
 }
 void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQueue qin, const float4 *hits, RayQueue qnext,
                   RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s, int cur) {
-    int nblk = PG_REGIONS * (qin.regionCap / PG_BLOCK);
+    int nblk = rp.retryCount > 0 ? (rp.retryCount + PG_BLOCK - 1) / PG_BLOCK : PG_REGIONS * (qin.regionCap / PG_BLOCK);
     if (nblk == 0) return;
     const VolState vs = {};
     const float *noT = nullptr;
@@ -1999,7 +2018,7 @@ void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQue
 }
 void launch_shade_vol(const DScene &sc, const RenderParams &rp, PathState st, VolState vs, RayQueue qin, const float4 *hits, const float *hitT,
                       RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s) {
-    int nblk = PG_REGIONS * (qin.regionCap / PG_BLOCK);
+    int nblk = rp.retryCount > 0 ? (rp.retryCount + PG_BLOCK - 1) / PG_BLOCK : PG_REGIONS * (qin.regionCap / PG_BLOCK);
     if (nblk == 0) return;
     const QueueState none = {nullptr, nullptr, nullptr};
     if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, true>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none);
@@ -2366,6 +2385,54 @@ __global__ __launch_bounds__(PG_BLOCK) void k_light_tables(DScene sc, float *tab
     if (funcInt == 0) { for (int i = 1; i < nl + 1; ++i) cdf[i] = (float)i / (float)nl; }
     else { for (int i = 1; i < nl + 1; ++i) cdf[i] /= funcInt; }
     func[2 * nl + 1] = funcInt;
+}
+// The same for a list of voxels, one BLOCK per voxel (sparse tables: few voxels, possibly thousands of lights): the lights are
+// spread over the block's threads -- func[j] is a sum over the 128 sample points in order, independent of the other lights --
+// and one thread then runs the reference's sequential sums over the lights (sumContrib, the cdf).
+__global__ __launch_bounds__(PG_BLOCK) void k_light_tables_sparse(DScene sc, float *pool, const int *requests, int firstSlot) {
+    const int v = requests[blockIdx.x];
+    const int nl = sc.nLights;
+    float *func = pool + (size_t)(firstSlot + (int)blockIdx.x) * (2 * nl + 2), *cdf = func + nl;
+    int pi0 = v % sc.nVoxels[0], pi1 = (v / sc.nVoxels[0]) % sc.nVoxels[1], pi2 = v / (sc.nVoxels[0] * sc.nVoxels[1]);
+    V3 p0 = mk((float)pi0 / (float)sc.nVoxels[0], (float)pi1 / (float)sc.nVoxels[1], (float)pi2 / (float)sc.nVoxels[2]);
+    V3 p1 = mk((float)(pi0 + 1) / (float)sc.nVoxels[0], (float)(pi1 + 1) / (float)sc.nVoxels[1], (float)(pi2 + 1) / (float)sc.nVoxels[2]);
+    V3 a = mk(plerp(p0.x, sc.bmin[0], sc.bmax[0]), plerp(p0.y, sc.bmin[1], sc.bmax[1]), plerp(p0.z, sc.bmin[2], sc.bmax[2]));
+    V3 b = mk(plerp(p1.x, sc.bmin[0], sc.bmax[0]), plerp(p1.y, sc.bmin[1], sc.bmax[1]), plerp(p1.z, sc.bmin[2], sc.bmax[2]));
+    V3 vmin = mk(pmin(a.x, b.x), pmin(a.y, b.y), pmin(a.z, b.z)), vmax = mk(pmax(a.x, b.x), pmax(a.y, b.y), pmax(a.z, b.z));
+    const int nSamples = 128;
+    for (int j = threadIdx.x; j < nl; j += PG_BLOCK) {
+        float f = 0;
+        for (int i = 0; i < nSamples; ++i) {
+            V3 t = mk(radical_inverse_base2(i), radical_inverse(3, i), radical_inverse(5, i));
+            V3 po = mk(plerp(t.x, vmin.x, vmax.x), plerp(t.y, vmin.y, vmax.y), plerp(t.z, vmin.z, vmax.z));
+            float u0 = radical_inverse(7, i), u1 = radical_inverse(11, i);
+            float pdf;
+            V3 wi;
+            LightSample ls;
+            Spec Li = light_sample_li<true>(sc, sc.lights[j], po, mk(0, 0, 0), mk(0, 0, 0), u0, u1, wi, pdf, ls);
+            if (pdf > 0) f += lum(Li) / pdf;
+        }
+        func[j] = f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float sumContrib = 0;
+        for (int j = 0; j < nl; ++j) sumContrib = sumContrib + func[j];
+        float avgContrib = sumContrib / (float)((size_t)nSamples * (size_t)nl);
+        float minContrib = (avgContrib > 0) ? (float)(.001 * (double)avgContrib) : 1.f;
+        for (int j = 0; j < nl; ++j) func[j] = pmax(func[j], minContrib);
+        cdf[0] = 0;  // Distribution1D ctor, sampling.h:57-70
+        for (int i = 1; i < nl + 1; ++i) cdf[i] = cdf[i - 1] + func[i - 1] / nl;
+        float funcInt = cdf[nl];
+        if (funcInt == 0) { for (int i = 1; i < nl + 1; ++i) cdf[i] = (float)i / (float)nl; }
+        else { for (int i = 1; i < nl + 1; ++i) cdf[i] /= funcInt; }
+        func[2 * nl + 1] = funcInt;
+        sc.voxelSlot[v] = firstSlot + (int)blockIdx.x;  // published at the end of the launch (kernel boundary)
+    }
+}
+void launch_light_tables_sparse(const DScene &sc, float *pool, const int *requests, int n, int firstSlot, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_light_tables_sparse, dim3(n), dim3(PG_BLOCK), 0, s, sc, pool, requests, firstSlot);
 }
 void launch_light_tables(const DScene &sc, float *table, int nDistributions, hipStream_t s) {
     int nblk = (nDistributions + PG_BLOCK - 1) / PG_BLOCK;

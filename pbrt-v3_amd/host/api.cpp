@@ -1264,8 +1264,18 @@ static Scene *MakeScene() {
 
 void pbrtWorldEnd() {  // api.cpp:1590-1644
     VERIFY_WORLD("WorldEnd");
-    while (pushedGraphicsStates.size()) { Warning("Missing end to pbrtAttributeBegin()"); pushedGraphicsStates.pop_back(); pushedTransforms.pop_back(); }
-    while (pushedTransforms.size()) { Warning("Missing end to pbrtTransformBegin()"); pushedTransforms.pop_back(); }
+    // unmatched Begins: the three stacks are pushed together (AttributeBegin) or as a pair (TransformBegin) and unwind together
+    while (pushedGraphicsStates.size()) {
+        Warning("Missing end to pbrtAttributeBegin()");
+        pushedGraphicsStates.pop_back(); pushedTransforms.pop_back();
+        if (!pushedActiveTransformBits.empty()) pushedActiveTransformBits.pop_back();
+    }
+    while (pushedTransforms.size()) {
+        Warning("Missing end to pbrtTransformBegin()");
+        pushedTransforms.pop_back();
+        if (!pushedActiveTransformBits.empty()) pushedActiveTransformBits.pop_back();
+    }
+    pushedActiveTransformBits.clear();
     const bool timing = getenv("PBRT_HOST_TIMING") != nullptr;  // stderr: seconds spent building the accelerators
     auto tBuild = std::chrono::steady_clock::now();
     std::unique_ptr<GpuPathIntegrator> integrator(MakeIntegrator());
@@ -1284,6 +1294,8 @@ void pbrtWorldEnd() {  // api.cpp:1590-1644
     for (int i = 0; i < MaxTransforms; ++i) curTransform[i] = Transform();
     activeTransformBits = AllTransformsBits;
     namedCoordinateSystems.clear();
-    renderOptions->materials.clear();
+    // a file may hold several frames: the next WorldBegin starts from fresh options -- camera, film, sampler, integrator,
+    // named media, object instances and every material / texture / image table (api.cpp:1630-1640)
+    renderOptions.reset(new RenderOptions);
 }
 }  // namespace pbrt

@@ -6,6 +6,7 @@
 #ifndef PBRT_AMD_HOST_API_H
 #define PBRT_AMD_HOST_API_H
 #include <string>
+#include <vector>
 #include "geometry.h"
 #include "paramset.h"
 
@@ -19,6 +20,7 @@ struct Options {  // src/core/pbrt.h:171-185
     // additions for the MI355X back end
     bool loadOnly = false;  // WorldEnd keeps the Scene/Integrator instead of rendering
     int device = 0;         // HIP device the integrator renders on
+    std::vector<int> devices;  // --gpus / --gpu-ids: render the frame sharded over these devices (one host thread each); empty = `device` alone
     bool deviceBVH = false; // build "hlbvh" accelerators on the device (pg_hlbvh_build) instead of on the host
 };
 extern Options PbrtOptions;

@@ -11,6 +11,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <string>
+#include <thread>
+#include <vector>
 #include "api.h"
 #include "error.h"
 #include "scene.h"
@@ -417,6 +420,7 @@ struct GpuApi {
     decltype(&pg_scene_destroy) scene_destroy = nullptr;
     decltype(&pg_render_tile_count) render_tile_count = nullptr;
     decltype(&pg_render) render = nullptr;
+    decltype(&pg_render_sharded) render_sharded = nullptr;
     decltype(&pg_counters) counters = nullptr;
     decltype(&pg_hlbvh_build) hlbvh_build = nullptr;
     bool Load() {
@@ -431,7 +435,7 @@ struct GpuApi {
         lib = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (!lib) { Error("Unable to load the HIP back end \"%s\": %s", path.c_str(), dlerror()); return false; }
 #define BIND(n) n = (decltype(n))dlsym(lib, "pg_" #n); if (!n) { Error("libpbrt_gpu.so lacks symbol pg_" #n); return false; }
-        BIND(set_device) BIND(last_error) BIND(scene_create) BIND(scene_destroy) BIND(render_tile_count) BIND(render) BIND(counters) BIND(hlbvh_build)
+        BIND(set_device) BIND(last_error) BIND(scene_create) BIND(scene_destroy) BIND(render_tile_count) BIND(render) BIND(render_sharded) BIND(counters) BIND(hlbvh_build)
 #undef BIND
         return true;
     }
@@ -450,35 +454,74 @@ bool DeviceHLBVHBuild(int n, const float *bounds, int maxPrimsInNode, std::vecto
     return true;
 }
 
+// Prints the reference's own statistics (scene.cpp:40-42, integrator.cpp:48, triangle.cpp:45) summed over the devices used.
+static void ReportStatistics(const std::vector<PgCounters> &all, double sec) {
+    if (PbrtOptions.quiet) return;
+    PgCounters c;
+    memset(&c, 0, sizeof(c));
+    for (const PgCounters &k : all) {
+        c.camera_rays += k.camera_rays; c.closest_rays += k.closest_rays; c.shadow_rays += k.shadow_rays;
+        c.tri_tests += k.tri_tests; c.node_visits += k.node_visits;
+    }
+    const double rays = double(c.closest_rays + c.shadow_rays);
+    fprintf(stderr, "Statistics:\n  Integrator/Camera rays traced %llu\n  Intersections/Regular ray intersection tests %llu\n"
+                    "  Intersections/Shadow ray intersection tests %llu\n  Intersections/Ray-triangle intersection tests %llu\n"
+                    "  BVH/Node fetches %llu\n  Integrator::Render() %.3f s on %d GPU(s)  (%.2f Mrays/s, %.2f Msamples/s)\n",
+            (unsigned long long)c.camera_rays, (unsigned long long)c.closest_rays, (unsigned long long)c.shadow_rays,
+            (unsigned long long)c.tri_tests, (unsigned long long)c.node_visits, sec, (int)all.size(), rays / sec / 1e6, double(c.camera_rays) / sec / 1e6);
+}
+
 void GpuPathIntegrator::Render(const Scene &scene) {
     if (!gpuApi.Load()) { Error("Rendering aborted: no HIP back end (there is no CPU fallback)."); exit(1); }
     FlatScene flat;
     Flatten(scene, &flat);
     PgRenderDesc rd;
     FillRenderDesc(&rd);
-    if (gpuApi.set_device(PbrtOptions.device) != PG_OK) { Error("pg_set_device: %s", gpuApi.last_error()); exit(1); }
-    PgScene *dev = nullptr;
-    if (gpuApi.scene_create(&flat.desc, &dev) != PG_OK) { Error("pg_scene_create: %s", gpuApi.last_error()); exit(1); }
-    int nTiles = gpuApi.render_tile_count(&rd);
-    std::vector<PgFilmPixel> film((size_t)nTiles * (size_t)rd.tile_pixels);
-    int maxStrays = nTiles * 256 / 8 + 1024, nStrays = 0;
-    std::vector<PgStraySample> strays(maxStrays);
-    auto t0 = std::chrono::steady_clock::now();
-    int st = gpuApi.render(dev, &rd, film.data(), strays.data(), maxStrays, &nStrays, PG_MEM_HOST, nullptr);
-    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (st != PG_OK) { Error("pg_render: %s", gpuApi.last_error()); gpuApi.scene_destroy(dev); exit(1); }
-    PgCounters c;
-    if (gpuApi.counters(dev, &c) == PG_OK && !PbrtOptions.quiet) {
-        // the reference's own statistics (scene.cpp:40-42, integrator.cpp:48, triangle.cpp:45)
-        double rays = double(c.closest_rays + c.shadow_rays);
-        fprintf(stderr, "Statistics:\n  Integrator/Camera rays traced %llu\n  Intersections/Regular ray intersection tests %llu\n"
-                        "  Intersections/Shadow ray intersection tests %llu\n  Intersections/Ray-triangle intersection tests %llu\n"
-                        "  BVH/Node fetches %llu\n  Integrator::Render() %.3f s  (%.2f Mrays/s, %.2f Msamples/s)\n",
-                (unsigned long long)c.camera_rays, (unsigned long long)c.closest_rays, (unsigned long long)c.shadow_rays,
-                (unsigned long long)c.tri_tests, (unsigned long long)c.node_visits, sec, rays / sec / 1e6, double(c.camera_rays) / sec / 1e6);
+    // The devices of this node the frame is sharded over: tile t of the full-frame tiling goes to device t mod N, as the
+    // reference shards a frame over machines with crop windows (main/pbrt.cpp:94-100); one host thread per device inside
+    // pg_render_sharded, the shards gathered peer-to-peer on the first device.
+    std::vector<int> devices = PbrtOptions.devices;
+    if (devices.empty()) devices.push_back(PbrtOptions.device);
+    const int n = (int)devices.size();
+    std::vector<PgScene *> dev((size_t)n, nullptr);
+    {   // the scene replicated on every device, uploads in parallel (pg_set_device selects the device per thread)
+        std::vector<std::string> err((size_t)n);
+        auto create = [&](int r) {
+            if (gpuApi.set_device(devices[r]) != PG_OK || gpuApi.scene_create(&flat.desc, &dev[r]) != PG_OK) { err[r] = gpuApi.last_error(); dev[r] = nullptr; }
+        };
+        std::vector<std::thread> threads;
+        for (int r = 1; r < n; ++r) threads.emplace_back(create, r);
+        create(0);
+        for (auto &t : threads) t.join();
+        for (int r = 0; r < n; ++r) if (!dev[r]) { Error("pg_scene_create on device %d: %s", devices[r], err[r].c_str()); exit(1); }
     }
-    gpuApi.scene_destroy(dev);
-    camera->film->MergeShard(rd, film.data(), strays.data(), nStrays);
+    std::vector<std::vector<PgFilmPixel>> film((size_t)n);
+    std::vector<std::vector<PgStraySample>> strays((size_t)n);
+    std::vector<PgFilmPixel *> filmPtr((size_t)n);
+    std::vector<PgStraySample *> strayPtr((size_t)n);
+    std::vector<int> nStrays((size_t)n, 0);
+    std::vector<PgRenderDesc> shard((size_t)n, rd);
+    int maxStrays = 0;
+    for (int r = 0; r < n; ++r) {
+        shard[r].tile_first = r; shard[r].tile_step = n;
+        const int nTiles = gpuApi.render_tile_count(&shard[r]);
+        film[r].resize((size_t)nTiles * (size_t)rd.tile_pixels);
+        maxStrays = std::max(maxStrays, nTiles * 256 / 8 + 1024);
+    }
+    for (int r = 0; r < n; ++r) { strays[r].resize((size_t)maxStrays); filmPtr[r] = film[r].data(); strayPtr[r] = strays[r].data(); }
+    auto t0 = std::chrono::steady_clock::now();
+    int st;
+    if (n == 1) {
+        if (gpuApi.set_device(devices[0]) != PG_OK) { Error("pg_set_device: %s", gpuApi.last_error()); exit(1); }
+        st = gpuApi.render(dev[0], &rd, filmPtr[0], strayPtr[0], maxStrays, &nStrays[0], PG_MEM_HOST, nullptr);
+    } else st = gpuApi.render_sharded(dev.data(), n, &rd, filmPtr.data(), strayPtr.data(), maxStrays, nStrays.data());
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (st != PG_OK) { Error("pg_render: %s", gpuApi.last_error()); for (PgScene *d : dev) gpuApi.scene_destroy(d); exit(1); }
+    std::vector<PgCounters> counters((size_t)n);
+    for (int r = 0; r < n; ++r) if (gpuApi.counters(dev[r], &counters[r]) != PG_OK) memset(&counters[r], 0, sizeof(PgCounters));
+    ReportStatistics(counters, sec);
+    for (PgScene *d : dev) gpuApi.scene_destroy(d);
+    for (int r = 0; r < n; ++r) camera->film->MergeShard(shard[r], film[r].data(), strays[r].data(), nStrays[r]);  // Film::MergeFilmTile per tile, rank by rank
     camera->film->WriteImage();  // integrator.cpp:338
 }
 }  // namespace pbrt

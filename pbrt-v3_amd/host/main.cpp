@@ -16,6 +16,9 @@ Rendering options:
   --cropwindow <x0,x1,y0,y1> Specify an image crop window.
   --devicebvh                Build "hlbvh" accelerators on the GPU instead of on the host.
   --gpu <id>                 HIP device to render on (default 0).
+  --gpus <n>                 Shard the frame's 16x16 tiles over devices 0..n-1 of this node (one host thread per GPU,
+                             film shards gathered peer-to-peer on the first device).
+  --gpu-ids <a,b,...>        The same over the listed devices (an id may repeat: several shards on one GPU).
   --help                     Print this help text.
   --nthreads <num>           Host threads for the accelerator build (0 = all cores); rendering runs on the GPU.
   --outfile <filename>       Write the final image to the given filename (.pfm).
@@ -38,6 +41,18 @@ int main(int argc, char *argv[]) {
             options.cropWindow[1][0] = atof(argv[++i]); options.cropWindow[1][1] = atof(argv[++i]);
         }
         else if (!strcmp(argv[i], "--gpu")) { if (i + 1 == argc) usage("missing value after --gpu argument"); options.device = atoi(argv[++i]); }
+        else if (!strcmp(argv[i], "--gpus")) {
+            if (i + 1 == argc) usage("missing value after --gpus argument");
+            const int n = atoi(argv[++i]);
+            if (n < 1) usage("--gpus needs a positive count");
+            options.devices.clear();
+            for (int d = 0; d < n; ++d) options.devices.push_back(d);
+        } else if (!strcmp(argv[i], "--gpu-ids")) {
+            if (i + 1 == argc) usage("missing value after --gpu-ids argument");
+            options.devices.clear();
+            for (const char *p = argv[++i]; *p;) { options.devices.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
+            if (options.devices.empty()) usage("--gpu-ids needs a comma-separated list of device ids");
+        }
         else if (!strcmp(argv[i], "--devicebvh")) options.deviceBVH = true;
         else if (!strcmp(argv[i], "--quick") || !strcmp(argv[i], "-quick")) options.quickRender = true;
         else if (!strcmp(argv[i], "--quiet") || !strcmp(argv[i], "-quiet")) options.quiet = true;

@@ -148,3 +148,30 @@ def test_config2_cornell_full_size_properties(gpu):
         scene.film_merge(rdr, f, s)
     assert np.array_equal(scene.film_image(), whole)
     gs.close()
+
+
+def test_native_sharded_render_equals_single_device(gpu, tmp_path):
+    """pg_render_sharded -- the in-process multi-GPU path of `pbrt_amd --gpus N`: one host thread per device, peer-to-peer
+    gather of the film shards on the first device.  On a single-GPU box the device id repeats (three shards on GPU 0): the
+    merged film must equal the single-device render bit for bit, and every shard must equal pg_render of that shard."""
+    scene = gpu.HostScene(os.path.join(LARGE, "cornell_128.pbrt"))
+    whole, _ = gpu.render_scene(scene)
+    rd = scene.render_desc()
+    scenes = [gpu.GpuScene(scene.desc, device=0) for _ in range(3)]
+    shards = gpu.render_sharded(scenes, rd)
+    scene.film_clear()
+    for srd, film, strays in shards:
+        alone_film, alone_strays = scenes[0].render(srd)
+        assert np.array_equal(film["rgb"], alone_film["rgb"]) and np.array_equal(film["weight"], alone_film["weight"]) and len(strays) == len(alone_strays)
+        scene.film_merge(srd, film, strays)
+    assert np.array_equal(scene.film_image(), whole)
+    for s in scenes:
+        s.close()
+    # the same through the CLI: pbrt_amd --gpu-ids 0,0 writes the image of pbrt_amd --gpu 0
+    import subprocess
+    exe = os.path.join(ROOT, "pbrt-v3_amd", "pbrt_amd")
+    for flags, out in ((["--gpu", "0"], "one.pfm"), (["--gpu-ids", "0,0"], "two.pfm")):
+        p = subprocess.run([exe, "--quiet", *flags, "--outfile", str(tmp_path / out), os.path.join(LARGE, "cornell_128.pbrt")], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+    assert np.array_equal(gpu.read_pfm(str(tmp_path / "one.pfm")), gpu.read_pfm(str(tmp_path / "two.pfm")))
+    assert np.array_equal(gpu.read_pfm(str(tmp_path / "one.pfm")), whole)

@@ -419,3 +419,27 @@ def test_path_batching_does_not_change_the_film(gpu, name, monkeypatch):
         assert np.array_equal(part["rgb"], whole["rgb"]) and np.array_equal(part["weight"], whole["weight"]), budget
         assert len(strays2) == len(strays)
     gs.close()
+
+
+@pytest.mark.parametrize("name", ["cornell_32", "cornell_spot_power", "sphere_light", "instance_boxes", "tex_materials", "vol_smoke", "vol_fog", "sobol_vol_smoke", "filter_gaussian"])
+def test_sparse_light_tables_equal_dense(gpu, name, monkeypatch):
+    """The "spatial" light distribution filled on first touch (PG_SPARSE_LIGHTS=1 forces the sparse tables that large light
+    counts switch on): lanes that meet a voxel without a distribution are re-shaded once it exists.  Film, strays and the
+    reference's counters must equal the dense-table render bit for bit, in the first (cold) frame and in the second."""
+    scene = gpu.HostScene(os.path.join(GOLD, name + ".pbrt"))
+    rd = scene.render_desc()
+    dense = gpu.GpuScene(scene.desc)
+    film, strays = dense.render(rd)
+    cn = dense.counters()
+    dense.close()
+    monkeypatch.setenv("PG_SPARSE_LIGHTS", "1")
+    sparse = gpu.GpuScene(scene.desc)
+    for frame in range(2):
+        sparse.counters_reset()
+        f2, s2 = sparse.render(rd)
+        c2 = sparse.counters()
+        assert np.array_equal(film["rgb"], f2["rgb"]) and np.array_equal(film["weight"], f2["weight"]), (name, frame)
+        assert len(strays) == len(s2)
+        for k in ("camera_rays", "closest_rays", "shadow_rays", "tri_tests", "node_visits"):
+            assert cn[k] == c2[k], (name, frame, k)
+    sparse.close()
