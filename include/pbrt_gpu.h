@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 20
+#define PG_ABI_VERSION 21
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -166,7 +166,7 @@ typedef struct PgTexture {
 } PgTexture;
 /* MIPMap<Float> / MIPMap<RGBSpectrum> (core/mipmap.h): the pyramid as its constructor leaves it (power-of-two resampling,
  * box-filtered levels), levels row-major in texels[], 1 or 3 floats per texel; level i is max(1, width >> i) x max(1, height >> i). */
-#define PG_MAX_MIP_LEVELS 16
+#define PG_MAX_MIP_LEVELS 32  /* 1 + Log2Int(max resolution) for any int resolution (mipmap.h:141) */
 typedef struct PgImage {
     int32_t is_float;          /* MIPMap<Float> */
     int32_t n_levels;

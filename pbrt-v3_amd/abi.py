@@ -5,7 +5,7 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 20
+PG_ABI_VERSION = 21
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
 PG_LIGHTS_UNIFORM, PG_LIGHTS_POWER, PG_LIGHTS_SPATIAL = 0, 1, 2
@@ -46,7 +46,7 @@ class PgTexture(C.Structure):
 
 class PgImage(C.Structure):
     _fields_ = [("is_float", C.c_int32), ("n_levels", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("wrap", C.c_int32),
-                ("trilinear", C.c_int32), ("max_anisotropy", C.c_float), ("level_offset", C.c_int64 * 16)]
+                ("trilinear", C.c_int32), ("max_anisotropy", C.c_float), ("level_offset", C.c_int64 * 32)]
 
 
 class PgMedium(C.Structure):

@@ -5,7 +5,9 @@ The reference shards a frame across machines by disjoint crop windows stitched w
 16x16 tiles t with t % world == rank of the FULL-frame tiling (sampler and tile indices unchanged, so
 samples are identical to a single-process render) and one gather moves each rank's packed
 (RGB sum, weight) tile buffer to rank 0 -- RCCL over xGMI when the tensors are on GPUs, gloo on CPU.
-No reduction is needed: with a box filter of radius 0.5 every pixel is owned by exactly one tile.
+No reduction is needed on the device: with a box filter of radius 0.5 every pixel is owned by exactly one tile, and for
+wider filters a tile's block carries its halo (PgRenderDesc.tile_pixels entries per tile) and rank 0's host Film adds the
+overlapping blocks in tile order (Film::MergeFilmTile).
 """
 import numpy as np
 import torch
@@ -14,7 +16,7 @@ import torch.distributed as dist
 
 def shard_buffers(n_tiles_max, device, tile_pixels=256):
     """Fixed-size per-rank buffers (equal on every rank so one gather suffices); tile_pixels = PgRenderDesc.tile_pixels."""
-    max_strays = n_tiles_max * 256 // 8 + 1024
+    max_strays = n_tiles_max * tile_pixels // 8 + 1024
     film = torch.zeros((n_tiles_max * tile_pixels, 4), dtype=torch.float32, device=device)
     strays = torch.zeros((max_strays, 8), dtype=torch.int32, device=device)  # PgStraySample = 8 x 4 bytes
     nstrays = torch.zeros(1, dtype=torch.int32, device=device)

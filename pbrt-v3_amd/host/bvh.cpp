@@ -177,7 +177,7 @@ BVHAccel::BVHAccel(std::vector<GeometricPrimitive> p, int maxPrims, SplitMethod 
             std::vector<float> b(6 * primitives.size());
             for (size_t i = 0; i < primitives.size(); ++i)
                 for (int k = 0; k < 3; ++k) { b[6 * i + k] = primitiveInfo[i].bounds.pMin[k]; b[6 * i + 3 + k] = primitiveInfo[i].bounds.pMax[k]; }
-            if (!DeviceHLBVHBuild((int)primitives.size(), b.data(), maxPrimsInNode, &nodes, &order)) { Error("HLBVH: the device build failed (there is no silent host fallback)."); exit(1); }
+            if (!DeviceHLBVHBuild((int)primitives.size(), b.data(), maxPrimsInNode, &nodes, &order)) { Error("HLBVH: the device build failed (there is no silent host fallback)."); Fatal(); }
         } else {
             BuildNode *root = HLBVHBuild(primitiveInfo, &totalNodes, order);
             nodes.resize(totalNodes);

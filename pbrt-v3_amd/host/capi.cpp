@@ -26,20 +26,26 @@ static Options makeOptions(int quick, const float *crop) {
     if (crop) { opt.cropWindow[0][0] = crop[0]; opt.cropWindow[0][1] = crop[1]; opt.cropWindow[1][0] = crop[2]; opt.cropWindow[1][1] = crop[3]; }
     return opt;
 }
+// A fatal scene error (FatalError) or an exhausted allocation ends the load with a null scene; nothing is thrown across the C ABI.
+template <typename Parse> static PbrtHostScene *load(int quick, const float *crop, Parse parse) {
+    lastLoadedScene.reset();
+    try {
+        pbrtInit(makeOptions(quick, crop));
+        parse();
+        pbrtCleanup();
+        return finishLoad();
+    } catch (const FatalError &) {
+    } catch (const std::exception &e) { Error("%s", e.what()); }
+    try { pbrtCleanup(); } catch (...) {}
+    lastLoadedScene.reset();
+    return nullptr;
+}
 extern "C" {
 PbrtHostScene *pbrt_host_load_file(const char *filename, int quick, const float *crop) {
-    lastLoadedScene.reset();
-    pbrtInit(makeOptions(quick, crop));
-    pbrtParseFile(filename);
-    pbrtCleanup();
-    return finishLoad();
+    return load(quick, crop, [&]() { pbrtParseFile(filename); });
 }
 PbrtHostScene *pbrt_host_load_string(const char *text, int quick, const float *crop) {
-    lastLoadedScene.reset();
-    pbrtInit(makeOptions(quick, crop));
-    pbrtParseString(text);
-    pbrtCleanup();
-    return finishLoad();
+    return load(quick, crop, [&]() { pbrtParseString(text); });
 }
 void pbrt_host_free(PbrtHostScene *s) { delete s; }
 const PgSceneDesc *pbrt_host_scene_desc(PbrtHostScene *s) { return &s->flat.desc; }

@@ -33,4 +33,5 @@ void Warning(const char *fmt, ...) {
 void Error(const char *fmt, ...) {
     va_list a; va_start(a, fmt); processError("Error", fmt, a, true); va_end(a);
 }
+void Fatal() { throw FatalError(); }
 }

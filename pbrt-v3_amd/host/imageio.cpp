@@ -161,6 +161,9 @@ static bool ReadImagePNG(const std::string &name, int *width, int *height, std::
     const int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!channels || (depth != 8 && depth != 16 && !(depth < 8 && (ctype == 0 || ctype == 3)))) return false;
     const size_t bitsPerPixel = (size_t)channels * depth, stride = (w * bitsPerPixel + 7) / 8, bppF = std::max<size_t>(1, bitsPerPixel / 8);
+    // the header's size must be plausible for the data that follows (deflate expands by at most ~1032:1): a corrupt IHDR
+    // must not turn into a multi-gigabyte allocation
+    if (w > (1u << 20) || h > (1u << 20) || (stride + 1) * h > idat.size() * 1100 + 4096) return false;
     std::vector<uint8_t> raw((stride + 1) * h);
     uLongf rawLen = raw.size();
     if (uncompress(raw.data(), &rawLen, idat.data(), idat.size()) != Z_OK || rawLen != raw.size()) return false;
@@ -203,7 +206,7 @@ static bool ReadImagePNG(const std::string &name, int *width, int *height, std::
     return true;
 }
 
-bool ReadImage(const std::string &name, int *xres, int *yres, std::vector<RGB> *rgb) {  // imageio.cpp:60-79
+bool ReadImage(const std::string &name, int *xres, int *yres, std::vector<RGB> *rgb) try {  // imageio.cpp:60-79
     bool ok = false;
     if (HasExtension(name, ".tga")) { ok = ReadImageTGA(name, xres, yres, rgb); if (!ok) Error("Unable to read from TGA file \"%s\"", name.c_str()); }
     else if (HasExtension(name, ".png")) { ok = ReadImagePNG(name, xres, yres, rgb); if (!ok) Error("Error reading PNG \"%s\"", name.c_str()); }
@@ -211,6 +214,9 @@ bool ReadImage(const std::string &name, int *xres, int *yres, std::vector<RGB> *
     else if (HasExtension(name, ".exr")) Error("Unable to read \"%s\": OpenEXR is not available in this build.", name.c_str());
     else Error("Unable to load image stored in format \"%s\" for filename \"%s\".", strrchr(name.c_str(), '.') ? (strrchr(name.c_str(), '.') + 1) : "(unknown)", name.c_str());
     return ok;
+} catch (const std::bad_alloc &) {  // no exception leaves the library (it is driven through a C ABI)
+    Error("Out of memory reading image \"%s\"", name.c_str());
+    return false;
 }
 bool ImageGammaDefault(const std::string &filename) { return HasExtension(filename, ".tga") || HasExtension(filename, ".png"); }
 
@@ -286,7 +292,7 @@ void BuildMIPMap(int resX, int resY, int nc, const std::vector<float> &data, int
         level0 = resampled.data();
     }
     int nLevels = 1 + (31 - __builtin_clz((uint32_t)std::max(res[0], res[1])));
-    if (nLevels > PG_MAX_MIP_LEVELS) nLevels = PG_MAX_MIP_LEVELS;
+    static_assert(PG_MAX_MIP_LEVELS >= 32, "PgImage::level_offset holds the pyramid of any int resolution");
     img->n_levels = nLevels; img->width = res[0]; img->height = res[1];
     int sPrev = res[0], tPrev = res[1];
     size_t prevOff = pool->size();

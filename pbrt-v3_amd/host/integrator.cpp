@@ -472,7 +472,7 @@ static void ReportStatistics(const std::vector<PgCounters> &all, double sec) {
 }
 
 void GpuPathIntegrator::Render(const Scene &scene) {
-    if (!gpuApi.Load()) { Error("Rendering aborted: no HIP back end (there is no CPU fallback)."); exit(1); }
+    if (!gpuApi.Load()) { Error("Rendering aborted: no HIP back end (there is no CPU fallback)."); Fatal(); }
     FlatScene flat;
     Flatten(scene, &flat);
     PgRenderDesc rd;
@@ -493,7 +493,7 @@ void GpuPathIntegrator::Render(const Scene &scene) {
         for (int r = 1; r < n; ++r) threads.emplace_back(create, r);
         create(0);
         for (auto &t : threads) t.join();
-        for (int r = 0; r < n; ++r) if (!dev[r]) { Error("pg_scene_create on device %d: %s", devices[r], err[r].c_str()); exit(1); }
+        for (int r = 0; r < n; ++r) if (!dev[r]) { Error("pg_scene_create on device %d: %s", devices[r], err[r].c_str()); Fatal(); }
     }
     std::vector<std::vector<PgFilmPixel>> film((size_t)n);
     std::vector<std::vector<PgStraySample>> strays((size_t)n);
@@ -512,11 +512,11 @@ void GpuPathIntegrator::Render(const Scene &scene) {
     auto t0 = std::chrono::steady_clock::now();
     int st;
     if (n == 1) {
-        if (gpuApi.set_device(devices[0]) != PG_OK) { Error("pg_set_device: %s", gpuApi.last_error()); exit(1); }
+        if (gpuApi.set_device(devices[0]) != PG_OK) { Error("pg_set_device: %s", gpuApi.last_error()); Fatal(); }
         st = gpuApi.render(dev[0], &rd, filmPtr[0], strayPtr[0], maxStrays, &nStrays[0], PG_MEM_HOST, nullptr);
     } else st = gpuApi.render_sharded(dev.data(), n, &rd, filmPtr.data(), strayPtr.data(), maxStrays, nStrays.data());
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (st != PG_OK) { Error("pg_render: %s", gpuApi.last_error()); for (PgScene *d : dev) gpuApi.scene_destroy(d); exit(1); }
+    if (st != PG_OK) { Error("pg_render: %s", gpuApi.last_error()); for (PgScene *d : dev) gpuApi.scene_destroy(d); Fatal(); }
     std::vector<PgCounters> counters((size_t)n);
     for (int r = 0; r < n; ++r) if (gpuApi.counters(dev[r], &counters[r]) != PG_OK) memset(&counters[r], 0, sizeof(PgCounters));
     ReportStatistics(counters, sec);

@@ -60,8 +60,12 @@ int main(int argc, char *argv[]) {
         else filenames.push_back(argv[i]);
     }
     if (filenames.empty()) usage("no scene file given");
-    pbrtInit(options);
-    for (const std::string &f : filenames) pbrtParseFile(f);
-    pbrtCleanup();
+    try {
+        pbrtInit(options);
+        for (const std::string &f : filenames) pbrtParseFile(f);
+        pbrtCleanup();
+    } catch (const FatalError &) {  // already reported through Error(): the reference exits with status 1 here
+        return 1;
+    }
     return ErrorCount() ? 1 : 0;
 }

@@ -92,13 +92,13 @@ struct Tokenizer {
 
 bool isQuoted(const std::string &s) { return s.size() >= 2 && s.front() == '"' && s.back() == '"'; }
 std::string dequote(const std::string &s) {
-    if (!isQuoted(s)) { Error("\"%s\": expected quoted string", s.c_str()); exit(1); }
+    if (!isQuoted(s)) { Error("\"%s\": expected quoted string", s.c_str()); Fatal(); }
     return s.substr(1, s.size() - 2);
 }
 
 double parseNumber(const std::string &str) {  // parser.cpp:322-372
     if (str.size() == 1) {
-        if (!(str[0] >= '0' && str[0] <= '9')) { Error("\"%c\": expected a number", str[0]); exit(1); }
+        if (!(str[0] >= '0' && str[0] <= '9')) { Error("\"%c\": expected a number", str[0]); Fatal(); }
         return str[0] - '0';
     }
     bool isInt = true;
@@ -107,7 +107,7 @@ double parseNumber(const std::string &str) {  // parser.cpp:322-372
     double val;
     if (isInt) val = double(strtol(str.c_str(), &endptr, 10));
     else val = strtof(str.c_str(), &endptr);
-    if (val == 0 && endptr == str.c_str()) { Error("%s: expected a number", str.c_str()); exit(1); }
+    if (val == 0 && endptr == str.c_str()) { Error("%s: expected a number", str.c_str()); Fatal(); }
     return val;
 }
 
@@ -120,7 +120,7 @@ struct Parser {
         if (ungetSet) { ungetSet = false; return ungetValue; }
         while (true) {
             if (fileStack.empty()) {
-                if (required) { Error("premature EOF"); exit(1); }
+                if (required) { Error("premature EOF"); Fatal(); }
                 parserLoc = nullptr;
                 return "";
             }
@@ -210,12 +210,12 @@ struct Parser {
             std::vector<double> nums; std::vector<std::string> strs; bool isString = false;
             auto addVal = [&](const std::string &val) {
                 if (isQuoted(val)) {
-                    if (!nums.empty()) { Error("mixed string and numeric parameters"); exit(1); }
+                    if (!nums.empty()) { Error("mixed string and numeric parameters"); Fatal(); }
                     isString = true; strs.push_back(val.substr(1, val.size() - 2));
                 } else if (val[0] == 't' && val == "true") { isString = true; strs.push_back("true"); }
                 else if (val[0] == 'f' && val == "false") { isString = true; strs.push_back("false"); }
                 else {
-                    if (!strs.empty()) { Error("mixed string and numeric parameters"); exit(1); }
+                    if (!strs.empty()) { Error("mixed string and numeric parameters"); Fatal(); }
                     nums.push_back(parseNumber(val));
                 }
             };
@@ -228,6 +228,7 @@ struct Parser {
     }
 
     void run() {  // parser.cpp:862-1090
+        struct LocGuard { ~LocGuard() { parserLoc = nullptr; } } locGuard;  // also when a fatal error unwinds through here
         parserLoc = &fileStack.back()->loc;
         auto withParams = [&](std::function<void(const std::string &, const ParamSet &)> fn) {
             std::string n = dequote(nextToken(true));
@@ -245,15 +246,15 @@ struct Parser {
                 if (a == "All") pbrtActiveTransformAll();
                 else if (a == "EndTime") pbrtActiveTransformEndTime();
                 else if (a == "StartTime") pbrtActiveTransformStartTime();
-                else { Error("Unexpected token: %s", a.c_str()); exit(1); }
+                else { Error("Unexpected token: %s", a.c_str()); Fatal(); }
             }
             else if (tok == "AreaLightSource") withParams(pbrtAreaLightSource);
             else if (tok == "Accelerator") withParams(pbrtAccelerator);
             else if (tok == "ConcatTransform" || tok == "Transform") {
-                if (nextToken(true) != "[") { Error("Unexpected token"); exit(1); }
+                if (nextToken(true) != "[") { Error("Unexpected token"); Fatal(); }
                 Float m[16];
                 for (int i = 0; i < 16; ++i) m[i] = num();
-                if (nextToken(true) != "]") { Error("Unexpected token"); exit(1); }
+                if (nextToken(true) != "]") { Error("Unexpected token"); Fatal(); }
                 if (tok == "Transform") pbrtTransform(m); else pbrtConcatTransform(m);
             }
             else if (tok == "CoordinateSystem") pbrtCoordinateSystem(dequote(nextToken(true)));
@@ -302,7 +303,7 @@ struct Parser {
             }
             else if (tok == "WorldBegin") pbrtWorldBegin();
             else if (tok == "WorldEnd") pbrtWorldEnd();
-            else { Error("Unexpected token: %s", tok.c_str()); exit(1); }
+            else { Error("Unexpected token: %s", tok.c_str()); Fatal(); }
         }
         parserLoc = nullptr;
     }

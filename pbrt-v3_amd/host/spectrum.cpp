@@ -72,7 +72,7 @@ RGB FromSampled(const Float *lambda, const Float *v, int n) {  // RGBSpectrum::F
         return FromSampled(sl.data(), sv.data(), n);
     }
     for (int i = 0; i < n - 1; ++i)
-        if (!(lambda[i + 1] > lambda[i])) { Error("Spectrum samples with equal wavelengths (%g nm): the reference aborts on this input.", lambda[i]); exit(1); }
+        if (!(lambda[i + 1] > lambda[i])) { Error("Spectrum samples with equal wavelengths (%g nm): the reference aborts on this input.", lambda[i]); Fatal(); }
     Float xyz[3] = {0, 0, 0};
     for (int i = 0; i < nCIESamples; ++i) {
         Float val = InterpolateSpectrumSamples(lambda, v, n, CIE_lambda()[i]);
@@ -119,7 +119,7 @@ bool ReadFloatFile(const char *filename, std::vector<Float> *values) {
             size_t j = i + 1;
             while (j < text.size() && (startsNumber(text[j]) || text[j] == 'e')) ++j;
             if (j == text.size()) break;  // ran into the end of the file
-            if (j - i >= 32) { Error("Overflowed buffer for parsing number in file: %s, at line %d", filename, line); exit(1); }
+            if (j - i >= 32) { Error("Overflowed buffer for parsing number in file: %s, at line %d", filename, line); Fatal(); }
             values->push_back(atof(text.substr(i, j - i).c_str()));
             if (text[j] == '\n') ++line;
             i = j + 1;  // the terminating character goes with the number

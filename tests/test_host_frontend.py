@@ -171,3 +171,25 @@ def test_bvh_build_does_not_depend_on_the_thread_count(pkg, tmp_path, monkeypatc
         s = pkg.HostScene(path)
         built.append((s.nodes().tobytes(), s.indices().tobytes()))
     assert built[0] == built[1] == built[2]
+
+
+def test_malformed_scene_raises_instead_of_exiting(pkg):
+    """A fatal parse error (where the reference calls exit(1)) unwinds to the C entry point: the host process survives, the load
+    returns no scene, and the library is usable afterwards."""
+    for bad in ['Shape "trianglemesh" "integer indices" [ 0 1 2', "LookAt 0 0 0 x", 'WorldBegin\nShape trianglemesh\n']:
+        with pytest.raises(pkg.PbrtGpuError):
+            pkg.HostScene(text=bad)
+    assert pkg.HostScene(os.path.join(GOLD, "cornell_32.pbrt")).desc.n_tris == 36
+
+
+def test_second_frame_starts_from_fresh_render_options(pkg):
+    """Several WorldBegin / WorldEnd frames in one file: pbrtWorldEnd resets RenderOptions (api.cpp:1630-1640), so frame 2 does not
+    inherit frame 1's film, sampler, integrator or material tables.  (A load keeps the last frame.)"""
+    one = open(os.path.join(GOLD, "cornell_32.pbrt")).read()
+    head, world = one.split("WorldBegin", 1)
+    two = head + "WorldBegin" + world + 'Film "image" "integer xresolution" [ 16 ] "integer yresolution" [ 8 ] "string filename" "b.pfm"\nLookAt 278 273 -800 278 273 0 0 1 0\nCamera "perspective" "float fov" [ 39 ]\nWorldBegin' + world
+    s1, s2 = pkg.HostScene(text=one), pkg.HostScene(text=two)
+    assert s2.film_size == (16, 8)
+    rd = s2.render_desc()
+    assert rd.spp == 16 and rd.max_depth == 5  # the defaults again, not frame 1's "pixelsamples" 8 / its Integrator line
+    assert s2.desc.n_materials == s1.desc.n_materials and s2.desc.n_bxdfs == s1.desc.n_bxdfs  # tables not accumulated across frames
