@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 21
+#define PG_ABI_VERSION 22
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -358,9 +358,19 @@ typedef struct PgSceneDesc {
     const uint64_t *vdc_sobol;
     const uint64_t *vdc_sobol_inv;
     const int32_t *noise_perm;  /* NoisePerm, 512 entries (core/texture.cpp:51-78); NULL unless a noise texture is present */
+    const uint32_t *cmaxmin;    /* CMaxMinDist [17][32] (core/lowdiscrepancy.cpp:249-...); NULL unless the sampler is maxmindist */
 } PgSceneDesc;
 
 /* ---- render description -------------------------------------------------- */
+
+typedef enum PgSamplerKind {
+    PG_SAMPLER_HALTON = 0,        /* samplers/halton.cpp  */
+    PG_SAMPLER_SOBOL = 1,         /* samplers/sobol.cpp   */
+    PG_SAMPLER_RANDOM = 2,        /* samplers/random.cpp: every value straight from the tile's RNG */
+    PG_SAMPLER_STRATIFIED = 3,    /* samplers/stratified.cpp */
+    PG_SAMPLER_ZEROTWO = 4,       /* samplers/zerotwosequence.cpp ("02sequence", "lowdiscrepancy"); spp = the power of two it rounds up to */
+    PG_SAMPLER_MAXMINDIST = 5     /* samplers/maxmin.cpp; needs PgSceneDesc.cmaxmin; spp rounded as its constructor does */
+} PgSamplerKind;
 
 typedef struct PgRenderDesc {
     int32_t abi_version;
@@ -396,9 +406,15 @@ typedef struct PgRenderDesc {
     int32_t sample_stride;
     int32_t mult_inverse[2];
     int32_t sample_at_pixel_center;
-    /* sampler = 1: SobolSampler (samplers/sobol.h:48-71, sobol.cpp:41-59) instead; spp then is the power of two it rounds up to */
+    /* sampler = 1: SobolSampler (samplers/sobol.h:48-71, sobol.cpp:41-59) instead; spp then is the power of two it rounds up to.
+     * sampler = 2 .. 5: the samplers that draw from ONE RNG stream per 16x16 tile, seeded with the tile's index in the
+     * full-frame tiling (integrator.cpp:247-248) and consumed pixel by pixel, sample by sample, path by path --
+     * PgSamplerKind below.  The device then keeps one path per tile in flight (the order is part of the result). */
     int32_t sampler;
     int32_t sobol_resolution, sobol_log2_resolution;
+    int32_t sampler_dims;       /* PixelSampler: nSampledDimensions ("integer dimensions"); beyond them Get1D / Get2D fall back to the RNG */
+    int32_t strat_samples[2];   /* StratifiedSampler: xPixelSamples, yPixelSamples (spp = their product) */
+    int32_t strat_jitter;       /* StratifiedSampler: jitterSamples */
     /* integrator: PathIntegrator (integrators/path.cpp:190-213) */
     int32_t max_depth;
     float rr_threshold;

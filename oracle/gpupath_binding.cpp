@@ -460,7 +460,7 @@ void RenderOnDevice(const Scene &scene, const Camera &camera, const Sampler &sam
     if (abi.scene_create(&flat.desc, &dev) != PG_OK) { Error("pg_scene_create: %s", abi.last_error()); Die(); }
     const int nTiles = abi.render_tile_count(&rd);
     std::vector<PgFilmPixel> film((size_t)nTiles * (size_t)rd.tile_pixels);
-    std::vector<PgStraySample> strays((size_t)nTiles * 32 + 1024);
+    std::vector<PgStraySample> strays((size_t)nTiles * (rd.sampler == PG_SAMPLER_MAXMINDIST ? 1024 : 32) + 1024);
     int32_t nStrays = 0;
     if (abi.render(dev, &rd, film.data(), strays.data(), (int32_t)strays.size(), &nStrays, PG_MEM_HOST, nullptr) != PG_OK) {
         Error("pg_render: %s", abi.last_error());

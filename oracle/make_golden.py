@@ -475,7 +475,27 @@ def with_many_lights(s, n=50):
     return s.replace(old, mesh)
 
 
+def with_sampler(s, spec):
+    import re as _re
+    out, n = _re.subn(r'Sampler "halton" "integer pixelsamples" \[ \d+ \]', 'Sampler ' + spec, s)
+    assert n == 1
+    return out
+
+
 SCENES = {
+    # the samplers that draw from one RNG stream per tile (integrator.cpp:247-248): RandomSampler, and the PixelSamplers with their
+    # per-pixel sample arrays and the RNG fallback beyond "dimensions" (sampler.cpp:100-134); clipped edge tiles, crop windows,
+    # pixel bounds (StartPixel runs for skipped pixels too), a lens, wide filters, rounded sample counts, volpath
+    "sampler_random": with_sampler(cornell(24, 24, 4), '"random" "integer pixelsamples" [ 5 ]'),
+    "sampler_stratified": with_sampler(cornell(40, 24, 4), '"stratified" "integer xsamples" [ 3 ] "integer ysamples" [ 2 ]'),
+    "sampler_stratified_dims": with_sampler(cornell(24, 24, 4, integrator='Integrator "path" "integer maxdepth" [ 3 ] "integer pixelbounds" [ 5 20 3 17 ]'),
+                                            '"stratified" "integer xsamples" [ 2 ] "integer ysamples" [ 2 ] "bool jitter" "false" "integer dimensions" [ 14 ]'),
+    "filter_02sequence_lens": with_sampler(cornell(36, 20, 4, extra_film='"float cropwindow" [ 0.1 0.9 0.2 1 ]'), '"02sequence" "integer pixelsamples" [ 6 ]')
+                          .replace('Camera "perspective" "float fov" [ 39.3 ]', 'Camera "perspective" "float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 900 ]')
+                          .replace('PixelFilter "box"', 'PixelFilter "gaussian"'),
+    "sampler_maxmindist": with_sampler(cornell(24, 24, 4), '"maxmindist" "integer pixelsamples" [ 8 ] "integer dimensions" [ 2 ]'),
+    "sampler_lowdisc_vol": with_sampler(cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 4 ]', world_edit=lambda s: with_smoke(s)),
+                                        '"lowdiscrepancy" "integer pixelsamples" [ 4 ] "integer dimensions" [ 3 ]'),
     # 5 000 area lights under the default "spatial" strategy: the device fills its voxel tables on first touch (sparse), as the
     # reference's hash table does
     "many_lights": cornell(20, 20, 2, integrator='Integrator "path" "integer maxdepth" [ 2 ]', world_edit=lambda s: with_many_lights(s, 50)),

@@ -82,7 +82,7 @@ def render(desc, rd, max_strays=None, cr_libm=False):
     L = lib(cr_libm)
     n = L.oracle_render_tile_count(C.byref(rd))
     if max_strays is None:
-        max_strays = n * 256 // 8 + 1024
+        max_strays = pkg.default_max_strays(rd, n)
     film = np.zeros(n * rd.tile_pixels, pkg.FILM_PIXEL_DTYPE)
     strays = np.zeros(max_strays, pkg.STRAY_DTYPE)
     ns = C.c_int32(0)

@@ -168,6 +168,14 @@ def read_pfm(filename):
     return np.ascontiguousarray(data[::-1]).astype(np.float32)
 
 
+def default_max_strays(rd, n_tiles):
+    """Room for the box filter's stray samples (a sample whose offset inside its pixel is exactly 0 also lands in the previous
+    pixel, film.h:127-132): rare, except under the MaxMinDistSampler, whose first sample of every pixel is (0, 0) by construction
+    and lands in up to three neighbours."""
+    per_tile = 256 * 4 if rd.sampler == abi.PG_SAMPLER_MAXMINDIST else 256 // 8
+    return n_tiles * per_tile + 1024
+
+
 class GpuScene:
     """Device-resident scene (pg_scene_create) and the render / intersect entry points."""
 
@@ -194,7 +202,7 @@ class GpuScene:
         """Integrator::Render for the shard in rd into host numpy buffers (film, strays)."""
         n = self.tile_count(rd)
         if max_strays is None:
-            max_strays = n * 256 // 8 + 1024
+            max_strays = default_max_strays(rd, n)
         film = np.zeros(n * rd.tile_pixels, FILM_PIXEL_DTYPE)
         strays = np.zeros(max_strays, STRAY_DTYPE)
         ns = C.c_int32(0)
@@ -250,7 +258,7 @@ def render_sharded(gpu_scenes, rd, max_strays=None):
         shards.append(srd)
     counts = [GpuScene.tile_count(s) for s in shards]
     if max_strays is None:
-        max_strays = max(counts) * 256 // 8 + 1024
+        max_strays = default_max_strays(rd, max(counts))
     films = [np.zeros(c * rd.tile_pixels, FILM_PIXEL_DTYPE) for c in counts]
     strays = [np.zeros(max_strays, STRAY_DTYPE) for _ in range(n)]
     handles = (C.c_void_p * n)(*[g._h for g in gpu_scenes])

@@ -5,7 +5,8 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 21
+PG_ABI_VERSION = 22
+PG_SAMPLER_HALTON, PG_SAMPLER_SOBOL, PG_SAMPLER_RANDOM, PG_SAMPLER_STRATIFIED, PG_SAMPLER_ZEROTWO, PG_SAMPLER_MAXMINDIST = range(6)
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
 PG_LIGHTS_UNIFORM, PG_LIGHTS_POWER, PG_LIGHTS_SPATIAL = 0, 1, 2
@@ -106,7 +107,7 @@ class PgSceneDesc(C.Structure):
                 ("n_alphas", C.c_int32), ("alphas", C.POINTER(PgAlphaMask)), ("tri_alpha", C.POINTER(C.c_int32)),
                 ("n_env_floats", C.c_int64), ("env_tables", C.POINTER(C.c_float)), ("ewa_lut", C.POINTER(C.c_float)),
                 ("sobol_matrices", C.POINTER(C.c_uint32)), ("vdc_sobol", C.POINTER(C.c_uint64)), ("vdc_sobol_inv", C.POINTER(C.c_uint64)),
-                ("noise_perm", C.POINTER(C.c_int32))]
+                ("noise_perm", C.POINTER(C.c_int32)), ("cmaxmin", C.POINTER(C.c_uint32))]
 
 
 class PgRenderDesc(C.Structure):
@@ -120,6 +121,7 @@ class PgRenderDesc(C.Structure):
                 ("spp", C.c_int32), ("base_scales", C.c_int32 * 2), ("base_exponents", C.c_int32 * 2),
                 ("sample_stride", C.c_int32), ("mult_inverse", C.c_int32 * 2), ("sample_at_pixel_center", C.c_int32),
                 ("sampler", C.c_int32), ("sobol_resolution", C.c_int32), ("sobol_log2_resolution", C.c_int32),
+                ("sampler_dims", C.c_int32), ("strat_samples", C.c_int32 * 2), ("strat_jitter", C.c_int32),
                 ("max_depth", C.c_int32), ("rr_threshold", C.c_float), ("pixel_bounds", C.c_int32 * 4),
                 ("tile_first", C.c_int32), ("tile_step", C.c_int32)]
 

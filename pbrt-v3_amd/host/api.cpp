@@ -1210,11 +1210,20 @@ static GpuPathIntegrator *MakeIntegrator() {
     ro.CameraParams.ReportUnused();
     // the GlobalSamplers (halton, sobol) index every sample by (pixel, sample number) alone; the PixelSamplers (random,
     // stratified, 02sequence, maxmindist) draw from one RNG stream per tile, which serialises a tile's samples
-    if (ro.SamplerName != "halton" && ro.SamplerName != "sobol")
-        Error("Sampler \"%s\" is outside this build's closed set (halton, sobol); using halton with the same \"pixelsamples\".", ro.SamplerName.c_str());
     int sb[4];
     film->GetSampleBounds(sb);
-    std::shared_ptr<HaltonSampler> sampler(ro.SamplerName == "sobol" ? CreateSobolSampler(ro.SamplerParams, sb) : CreateHaltonSampler(ro.SamplerParams, sb));
+    // MakeSampler, api.cpp:816-836
+    std::shared_ptr<HaltonSampler> sampler;
+    const std::string &sn = ro.SamplerName;
+    if (sn == "halton") sampler.reset(CreateHaltonSampler(ro.SamplerParams, sb));
+    else if (sn == "sobol") sampler.reset(CreateSobolSampler(ro.SamplerParams, sb));
+    else if (sn == "lowdiscrepancy" || sn == "02sequence") sampler.reset(CreateTileSerialSampler("02sequence", ro.SamplerParams));
+    else if (sn == "maxmindist" || sn == "random" || sn == "stratified") sampler.reset(CreateTileSerialSampler(sn, ro.SamplerParams));
+    else {
+        Warning("Sampler \"%s\" unknown.", sn.c_str());
+        Error("Unable to create sampler.");
+        return nullptr;
+    }
     ro.SamplerParams.ReportUnused();
     if (ro.IntegratorName != "path" && ro.IntegratorName != "volpath") {
         Error("Integrator \"%s\" is outside this build's closed set (path, volpath).", ro.IntegratorName.c_str());

@@ -113,6 +113,47 @@ HaltonSampler *CreateSobolSampler(const ParamSet &params, const int sb[4]) {  //
     return s;
 }
 
+// The samplers of the reference that consume one RNG stream per tile.  Only their parameters are read here; the streams are
+// generated where the paths are traced (oracle / device), tile by tile.
+HaltonSampler *CreateTileSerialSampler(const std::string &name, const ParamSet &params) {
+    auto roundUpPow2 = [](int64_t v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; v |= v >> 32; return v + 1; };  // pbrt.h:369-388
+    auto isPow2 = [](int64_t v) { return v && !(v & (v - 1)); };
+    HaltonSampler *s = new HaltonSampler;
+    memset(s->baseScales, 0, sizeof(s->baseScales)); memset(s->baseExponents, 0, sizeof(s->baseExponents)); memset(s->multInverse, 0, sizeof(s->multInverse));
+    s->sampleStride = 0; s->sampleAtPixelCenter = false;
+    if (name == "random") {  // random.cpp:72-75: no "dimensions", no quick-render clamp
+        s->kind = PG_SAMPLER_RANDOM;
+        s->samplesPerPixel = params.FindOneInt("pixelsamples", 4);
+    } else if (name == "stratified") {  // stratified.cpp:79-87
+        s->kind = PG_SAMPLER_STRATIFIED;
+        s->jitterSamples = params.FindOneBool("jitter", true);
+        s->xPixelSamples = params.FindOneInt("xsamples", 4);
+        s->yPixelSamples = params.FindOneInt("ysamples", 4);
+        s->nSampledDimensions = params.FindOneInt("dimensions", 4);
+        if (PbrtOptions.quickRender) s->xPixelSamples = s->yPixelSamples = 1;
+        s->samplesPerPixel = s->xPixelSamples * s->yPixelSamples;
+    } else {  // zerotwosequence.cpp:78-83, maxmin.cpp:82-87
+        int nsamp = params.FindOneInt("pixelsamples", 16);
+        s->nSampledDimensions = params.FindOneInt("dimensions", 4);
+        if (PbrtOptions.quickRender) nsamp = 1;
+        int64_t spp = nsamp;
+        if (name == "maxmindist") {  // the constructor's lambda, maxmin.h:54-71: at most 2^17 - 1, then a power of two
+            s->kind = PG_SAMPLER_MAXMINDIST;
+            int cIndex = 0;
+            while (((int64_t)1 << (cIndex + 1)) <= spp) ++cIndex;  // Log2Int
+            if (cIndex >= 17) { Warning("No more than %d samples per pixel are supported with MaxMinDistSampler. Rounding down.", (1 << 17) - 1); spp = (1 << 17) - 1; }
+            if (!isPow2(spp)) { spp = roundUpPow2(spp); Warning("Non power-of-two sample count rounded up to %lld for MaxMinDistSampler.", (long long)spp); }
+        } else {
+            s->kind = PG_SAMPLER_ZEROTWO;
+            if (!isPow2(spp)) Warning("Pixel samples being rounded up to power of 2 (from %lld to %lld).", (long long)spp, (long long)roundUpPow2(spp));
+            spp = roundUpPow2(spp);
+        }
+        s->samplesPerPixel = (int)spp;
+    }
+    if (s->samplesPerPixel < 1 || s->nSampledDimensions < 0) { Error("Sampler \"%s\": needs at least one sample per pixel and a non-negative \"dimensions\".", name.c_str()); Fatal(); }
+    return s;
+}
+
 namespace {
 struct RNG {  // PCG32, rng.h:61-144
     uint64_t state = 0x853c49e6748fea9bULL, inc = 0xda3e39cb94b95bdbULL;
@@ -358,6 +399,7 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     d.n_env_floats = (int64_t)flat->envTables.size(); d.env_tables = flat->envTables.data();
     d.n_media = (int)flat->media.size(); d.media = flat->media.data();
     if (scene.usesNoise) d.noise_perm = GetNoisePermutation();
+    if (sampler->kind == PG_SAMPLER_MAXMINDIST) d.cmaxmin = GetMaxMinDistTable();
     if (sampler->sobol) { const SobolTables &t = GetSobolTables(); d.sobol_matrices = t.matrices32; d.vdc_sobol = t.vdc; d.vdc_sobol_inv = t.vdcInv; }
     d.tri_medium_inside = flat->triMediumInside.empty() ? nullptr : flat->triMediumInside.data();
     d.tri_medium_outside = flat->triMediumOutside.empty() ? nullptr : flat->triMediumOutside.data();
@@ -402,7 +444,10 @@ void GpuPathIntegrator::FillRenderDesc(PgRenderDesc *rd) const {
     }
     rd->sample_stride = sampler->sampleStride;
     rd->sample_at_pixel_center = sampler->sampleAtPixelCenter ? 1 : 0;
-    rd->sampler = sampler->sobol ? 1 : 0;
+    rd->sampler = sampler->kind ? sampler->kind : (sampler->sobol ? 1 : 0);
+    rd->sampler_dims = sampler->nSampledDimensions;
+    rd->strat_samples[0] = sampler->xPixelSamples; rd->strat_samples[1] = sampler->yPixelSamples;
+    rd->strat_jitter = sampler->jitterSamples ? 1 : 0;
     rd->sobol_resolution = sampler->resolution; rd->sobol_log2_resolution = sampler->log2Resolution;
     rd->max_depth = maxDepth; rd->rr_threshold = rrThreshold;
     for (int i = 0; i < 4; ++i) rd->pixel_bounds[i] = pixelBounds[i];
@@ -506,7 +551,8 @@ void GpuPathIntegrator::Render(const Scene &scene) {
         shard[r].tile_first = r; shard[r].tile_step = n;
         const int nTiles = gpuApi.render_tile_count(&shard[r]);
         film[r].resize((size_t)nTiles * (size_t)rd.tile_pixels);
-        maxStrays = std::max(maxStrays, nTiles * 256 / 8 + 1024);
+        // stray samples are rare, except under the MaxMinDistSampler: every pixel's first sample is (0, 0) and lands in up to three neighbours
+        maxStrays = std::max(maxStrays, nTiles * (rd.sampler == PG_SAMPLER_MAXMINDIST ? 256 * 4 : 256 / 8) + 1024);
     }
     for (int r = 0; r < n; ++r) { strays[r].resize((size_t)maxStrays); filmPtr[r] = film[r].data(); strayPtr[r] = strays[r].data(); }
     auto t0 = std::chrono::steady_clock::now();

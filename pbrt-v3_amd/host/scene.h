@@ -193,7 +193,14 @@ struct HaltonSampler {  // samplers/halton.cpp:65-92
     // SobolSampler (samplers/sobol.h:48-71) when sobol is set: the fields above other than samplesPerPixel are unused then
     bool sobol = false;
     int resolution = 0, log2Resolution = 0;
+    // the samplers that draw from one RNG stream per tile (PgSamplerKind 2 .. 5): random, stratified, 02sequence, maxmindist
+    int kind = 0;                 // PgSamplerKind; 0 / 1 are the two GlobalSamplers above
+    int nSampledDimensions = 0;   // PixelSampler::samples1D.size() (sampler.cpp:100-106)
+    int xPixelSamples = 1, yPixelSamples = 1;
+    bool jitterSamples = true;
 };
+HaltonSampler *CreateTileSerialSampler(const std::string &name, const ParamSet &params);  // random.cpp:72-75, stratified.cpp:79-87, zerotwosequence.cpp:78-83, maxmin.cpp:82-87
+const uint32_t *GetMaxMinDistTable();  // CMaxMinDist [17][32] (data/cmaxmin.bin)
 HaltonSampler *CreateSobolSampler(const ParamSet &params, const int sampleBounds[4]);  // sobol.cpp:64-69
 // The Sobol' generator matrices embedded into this library (host/sobol.cpp, data/sobol_tables.bin; core/sobolmatrices.h:49-52)
 struct SobolTables { const uint32_t *matrices32; const uint64_t *vdc, *vdcInv; int nDims, matrixSize, vdcRows, vdcInvRows; };

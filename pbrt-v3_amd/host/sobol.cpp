@@ -32,6 +32,13 @@ __asm__(".section .rodata\n"
         "pg_noise_blob:\n"
         ".incbin \"" PG_NOISE_BIN "\"\n"
         ".previous\n");
+__asm__(".section .rodata\n"
+        ".balign 4\n"
+        ".global pg_cmaxmin_blob\n"
+        "pg_cmaxmin_blob:\n"
+        ".incbin \"" PG_CMAXMIN_BIN "\"\n"
+        ".previous\n");
+extern "C" const uint32_t pg_cmaxmin_blob[];
 extern "C" const int32_t pg_noise_blob[];
 extern "C" const unsigned char pg_sobol_blob[], pg_sobol_blob_end[];
 extern "C" const char pg_presets_blob[], pg_presets_blob_end[];
@@ -61,6 +68,7 @@ const SobolTables &GetSobolTables() {
     }();
     return t;
 }
+const uint32_t *GetMaxMinDistTable() { return pg_cmaxmin_blob; }  // CMaxMinDist, core/lowdiscrepancy.cpp:249-... (data/cmaxmin.bin)
 const int32_t *GetNoisePermutation() { return pg_noise_blob; }  // NoisePerm, core/texture.cpp:51-78 (data/noise_perm.bin)
 // GetMediumScatteringProperties, core/medium.cpp:181-191
 bool GetMediumScatteringProperties(const std::string &name, Float sigma_a[3], Float sigma_prime_s[3]) {

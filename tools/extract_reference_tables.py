@@ -6,6 +6,8 @@ CIE_X, CIE_Y, CIE_Z, CIE_lambda; 471 floats each, in that order), which turn "sp
 
 pbrt-v3_amd/data/noise_perm.bin: the 512-entry permutation table of the Perlin noise functions (core/texture.cpp:51-78; int32).
 
+pbrt-v3_amd/data/cmaxmin.bin: CMaxMinDist, the generator matrices of the MaxMinDistSampler (core/lowdiscrepancy.cpp:249-...; uint32 [17][32]).
+
 pbrt-v3_amd/data/sobol_tables.bin: the Sobol' generator matrices the SobolSampler reads (core/sobolmatrices.h:49-52:
 SobolMatrices32, VdCSobolMatrices, VdCSobolMatricesInv -- Gruenschloss' published tables, numeric constants of the sequence
 itself like the table of primes).  They are taken from the read-only data section of the reference binary built by
@@ -24,6 +26,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "pbrt_oracle")
 OUT = os.path.join(ROOT, "pbrt-v3_amd", "data", "sobol_tables.bin")
 OUT_CIE = os.path.join(ROOT, "pbrt-v3_amd", "data", "cie_tables.bin")
 OUT_NOISE = os.path.join(ROOT, "pbrt-v3_amd", "data", "noise_perm.bin")
+OUT_CMAXMIN = os.path.join(ROOT, "pbrt-v3_amd", "data", "cmaxmin.bin")
 
 
 def main():
@@ -33,9 +36,9 @@ def main():
     for line in subprocess.run(["nm", "-S", "-C", REF], capture_output=True, text=True, check=True).stdout.splitlines():
         parts = line.split(None, 3)
         if len(parts) == 4 and parts[3] in ("pbrt::SobolMatrices32", "pbrt::VdCSobolMatrices", "pbrt::VdCSobolMatricesInv", "pbrt::CIE_X", "pbrt::CIE_Y",
-                                              "pbrt::CIE_Z", "pbrt::CIE_lambda", "pbrt::NoisePerm"):
+                                              "pbrt::CIE_Z", "pbrt::CIE_lambda", "pbrt::NoisePerm", "pbrt::CMaxMinDist"):
             syms[parts[3].split("::")[1]] = (int(parts[0], 16), int(parts[1], 16))
-    assert len(syms) == 8, syms
+    assert len(syms) == 9, syms
     # map virtual addresses to file offsets through the section headers
     secs = []
     for line in subprocess.run(["readelf", "-S", "-W", REF], capture_output=True, text=True, check=True).stdout.splitlines():
@@ -69,6 +72,10 @@ def main():
     assert len(perm) == 512 * 4
     open(OUT_NOISE, "wb").write(perm)
     print(OUT_NOISE, os.path.getsize(OUT_NOISE), "bytes")
+    cmm = read("CMaxMinDist")  # the MaxMinDistSampler's generator matrices for 1 .. 2^16 samples (core/lowdiscrepancy.cpp:249-...; uint32 [17][32])
+    assert len(cmm) == 17 * 32 * 4
+    open(OUT_CMAXMIN, "wb").write(cmm)
+    print(OUT_CMAXMIN, os.path.getsize(OUT_CMAXMIN), "bytes")
 
 
 if __name__ == "__main__":
