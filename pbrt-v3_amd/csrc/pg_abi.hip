@@ -67,6 +67,7 @@ struct PgScene {
     int nMedia = 0;
     DeviceBuffer vqo[2], vqd[2], vCounts, volMedium, trAcc[2], volP1[3], misLi, pdLi, hitT;
     DeviceBuffer qsL[2], qsBeta[2], qsMeta[2];  // PathIntegrator: path state in queue order
+    DeviceBuffer cmaxmin, tsState, ts1, ts2;  // tile-serial samplers: CMaxMinDist, the tiles' sampler states and sample arrays
     DeviceBuffer voxelSlot, voxelRequests, voxelCounters, retryList;  // sparse "spatial" light tables (DScene::sparseLights)
     int poolSlots = 0, poolUsed = 0, nVoxelsTotal = 0;
     DeviceBuffer shardFilm, shardStrays, shardCount, gatherDev;  // pg_render_sharded: this device's shard; on rank 0's device the gathered frame
@@ -441,6 +442,11 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         HIP_TRY_S(hipMemcpy(s->primes.p, primes.data(), s->primes.bytes, hipMemcpyHostToDevice));
     }
 
+    if (desc->cmaxmin) {  // the MaxMinDistSampler's generator matrices
+        HIP_TRY_S(s->cmaxmin.alloc(17 * 32 * sizeof(uint32_t)));
+        HIP_TRY_S(hipMemcpy(s->cmaxmin.p, desc->cmaxmin, s->cmaxmin.bytes, hipMemcpyHostToDevice));
+    }
+
     d.nodes = (const float4 *)s->nodes.p; d.tris = (const float4 *)s->tris.p; d.spheres = (const PgSphere *)s->spheres.p; d.nSpheres = desc->n_spheres > 0 ? desc->n_spheres : 0;
     d.bxdfs = (const PgBxDF *)s->bxdfs.p;
     if (desc->n_env_floats > 0 && desc->env_tables) {
@@ -514,6 +520,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     d.nNodes = desc->n_nodes; d.nTris = nt; d.nLights = desc->n_lights; d.nMaterials = desc->n_materials;
     d.perms = (const uint16_t *)s->perms.p; d.permSums = (const int32_t *)s->permSums.p; d.primes = (const int32_t *)s->primes.p;
     d.nPermDims = desc->n_perm_dims;
+    d.cmaxmin = (const uint32_t *)s->cmaxmin.p;
     d.lightStrategy = desc->light_strategy;
     // --- light sampling distributions (lightdistrib.cpp)
     const int nl = desc->n_lights;
@@ -692,7 +699,17 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
     if (rd->integrator != 0 && rd->integrator != 1) return setError(PG_ERR_INVALID, "pg_render: integrator %d (0 = path, 1 = volpath)", rd->integrator);
     const bool vol = rd->integrator == 1;
     if (rd->camera_medium < -1 || rd->camera_medium >= s->nMedia) return setError(PG_ERR_INVALID, "pg_render: camera_medium %d out of range", rd->camera_medium);
-    if (rd->sampler != 0 && rd->sampler != 1) return setError(PG_ERR_INVALID, "pg_render: sampler %d (0 = halton, 1 = sobol)", rd->sampler);
+    if (rd->sampler < PG_SAMPLER_HALTON || rd->sampler > PG_SAMPLER_MAXMINDIST) return setError(PG_ERR_INVALID, "pg_render: sampler %d (PgSamplerKind 0 .. 5)", rd->sampler);
+    const bool tileSerial = rd->sampler >= PG_SAMPLER_RANDOM;
+    if (tileSerial) {
+        if (rd->sampler != PG_SAMPLER_RANDOM && (rd->sampler_dims < 0 || rd->sampler_dims > 4096)) return setError(PG_ERR_INVALID, "pg_render: sampler_dims %d", rd->sampler_dims);
+        if (rd->sampler == PG_SAMPLER_STRATIFIED && (rd->strat_samples[0] < 1 || rd->strat_samples[1] < 1 || rd->strat_samples[0] * rd->strat_samples[1] != rd->spp))
+            return setError(PG_ERR_INVALID, "pg_render: stratified sampler %d x %d samples, spp %d", rd->strat_samples[0], rd->strat_samples[1], rd->spp);
+        if ((rd->sampler == PG_SAMPLER_ZEROTWO || rd->sampler == PG_SAMPLER_MAXMINDIST) && (rd->spp & (rd->spp - 1)))
+            return setError(PG_ERR_INVALID, "pg_render: sampler %d needs a power-of-two spp (the reference rounds up), got %d", rd->sampler, rd->spp);
+        if (rd->sampler == PG_SAMPLER_MAXMINDIST && (!s->cmaxmin.p || rd->sampler_dims < 1 || rd->spp >= (1 << 17)))
+            return setError(PG_ERR_INVALID, "pg_render: maxmindist needs PgSceneDesc.cmaxmin, sampler_dims >= 1 and spp < 2^17");
+    }
     if (rd->sampler == 1) {
         if (!s->d.sobolMatrices) return setError(PG_ERR_INVALID, "pg_render: sampler = sobol, but the scene was created without the Sobol' tables");
         if (rd->sobol_log2_resolution < 0 || rd->sobol_log2_resolution > 26 || rd->sobol_resolution != (1 << rd->sobol_log2_resolution))
@@ -741,7 +758,8 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
             if (sPerBatch < 1) { sPerBatch = 1; tilesPerBatch = (int)(budget / 256); if (tilesPerBatch < 1) tilesPerBatch = 1; }
         }
     }
-    const int capacity = tilesPerBatch * 256 * sPerBatch;
+    // tile-serial samplers: one path per tile in flight, slot = the tile's local index
+    const int capacity = tileSerial ? std::max(nLocalTiles, 256) : tilesPerBatch * 256 * sPerBatch;
     int st = ensureWorkBuffers(s, capacity);
     if (st != PG_OK) return st;
     const int QSTRIDE = PG_REGIONS * PG_COUNT_STRIDE;  // ints of counter storage per queue
@@ -792,7 +810,9 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
     std::vector<std::pair<size_t, int>> timed;  // (event index, kernel: 0 closest-hit, 1 any-hit, 2 shade, 3 resolve, 4 generate, 5 film)
     // HIP events around one launch on `st_` (the stream the kernel runs on); per-kernel times are only meaningful while the
     // any-hit launch does not share the chip with the closest-hit launch (PG_OVERLAP_SHADOW=0, the default)
-#define PG_TIMED(kind_, st_, launch_) do { hipEvent_t a_ = getEvent(s, ev), b_ = getEvent(s, ev + 1); \
+    // (not in the tile-serial mode: its hundreds of thousands of small launches would each need a pair of events)
+    const bool timing = !tileSerial;
+#define PG_TIMED(kind_, st_, launch_) do { if (!timing) { launch_; break; } hipEvent_t a_ = getEvent(s, ev), b_ = getEvent(s, ev + 1); \
         if (!a_ || !b_) return setError(PG_ERR_DEVICE, "hipEventCreate failed"); \
         timed.push_back({ev, kind_}); ev += 2; HIP_TRY(hipEventRecord(a_, st_)); launch_; HIP_TRY(hipEventRecord(b_, st_)); } while (0)
     hipEvent_t evStart = getEvent(s, ev++), evStop = getEvent(s, ev++);
@@ -825,18 +845,15 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
     HIP_TRY(countLog.alloc(sizeof(int) * 4 * QSTRIDE * (size_t)(maxIters + 1)));
     std::vector<int> curQueueOfBounce;
 
-    for (int tile0 = 0; tile0 < nLocalTiles; tile0 += tilesPerBatch) {
-        for (int s0 = 0; s0 < rd->spp; s0 += sPerBatch) {
-            rp.tileLocal0 = tile0;
-            rp.nTilesBatch = std::min(tilesPerBatch, nLocalTiles - tile0);
-            rp.s0 = s0;
-            rp.sCount = std::min(sPerBatch, rd->spp - s0);
-            rp.capacity = rp.nTilesBatch * 256 * rp.sCount;
+    // One batch of paths from their camera rays (`generate` fills the first main queue) to their film samples (`film`): all the
+    // bounces of the rp.capacity path slots described by rp.
+    auto tracePaths = [&](const std::function<void()> &generate, const std::function<void()> &filmSamples) -> int {
+        {
             for (int i = 0; i < 4; ++i) q[i].regionCap = regionCapFor(rp.capacity, s->d.sparseLights != 0);
             curQueueOfBounce.clear();
             HIP_TRY(hipMemsetAsync(counts, 0, 4 * QSTRIDE * sizeof(int), stream));
             int cur = 0;  // main queue index (0/1 ping-pong); 2 = shadow, 3 = MIS
-            PG_TIMED(4, stream, launch_generate(s->d, rp, ps, q[cur], stream));
+            PG_TIMED(4, stream, generate());
             if (vol) {
                 // VolPathIntegrator::Li (volpath.cpp:72-186).  Per loop iteration: closest-hit(main rays, with the hits' ray
                 // parameters) -> shade with medium sampling -> the transmittance rays of the light samples and of the
@@ -891,20 +908,18 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
                     nMain = queueTotal(blk.data(), nxt);
                     cur = nxt;
                 }
-                if (rd->filter_general) launch_film_general(rp, ps, dFilm, stream);
-                else launch_film(rp, ps, dFilm, dStrays, maxStrays, dNStrays, stream);
+                filmSamples();
                 HIP_TRY(hipStreamSynchronize(stream));
-                continue;
+                return PG_OK;
             }
             // Launch order per bounce b (one stream): shade(b) -> any-hit(shadow rays of b) -> closest-hit(main rays of b+1
             // and MIS rays of b in ONE launch) -> resolve(b).  The first closest-hit launch traces the camera rays alone.
             auto timedClosest = [&](RayQueue qa, float4 *ha, const RayQueue *qb, float4 *hb) -> int {
-                hipEvent_t a = getEvent(s, ev), b = getEvent(s, ev + 1);
-                timed.push_back({ev, 0}); ev += 2;
-                HIP_TRY(hipEventRecord(a, stream));
+                hipEvent_t a = nullptr, b = nullptr;
+                if (timing) { a = getEvent(s, ev); b = getEvent(s, ev + 1); timed.push_back({ev, 0}); ev += 2; HIP_TRY(hipEventRecord(a, stream)); }
                 if (qb) launch_closest2(s->d, qa, *qb, ha, (int)(hb - ha), cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream);
                 else launch_closest(s->d, qa, ha, nullptr, cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream);
-                HIP_TRY(hipEventRecord(b, stream));
+                if (timing) HIP_TRY(hipEventRecord(b, stream));
                 ++closestLaunches;
                 return PG_OK;
             };
@@ -928,11 +943,10 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
                         HIP_TRY(hipEventRecord(s->evShaded, stream));
                         HIP_TRY(hipStreamWaitEvent(sst, s->evShaded, 0));
                     }
-                    hipEvent_t a = getEvent(s, ev), b = getEvent(s, ev + 1);
-                    timed.push_back({ev, 1}); ev += 2;
-                    HIP_TRY(hipEventRecord(a, sst));
+                    hipEvent_t a = nullptr, b = nullptr;
+                    if (timing) { a = getEvent(s, ev); b = getEvent(s, ev + 1); timed.push_back({ev, 1}); ev += 2; HIP_TRY(hipEventRecord(a, sst)); }
                     launch_anyhit(s->d, q[2], (int *)s->occluded.p, cnShadow, (int *)s->cursors2.p, sst);
-                    HIP_TRY(hipEventRecord(b, sst));
+                    if (timing) HIP_TRY(hipEventRecord(b, sst));
                     ++shadowLaunches;
                     if (s->overlapShadow) HIP_TRY(hipEventRecord(s->evShadowed, sst));
                     if (int e = timedClosest(q[nxt], (float4 *)s->hitsMain.p, &q[3], hitsMis)) return e;
@@ -951,8 +965,7 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
                     if (queueTotal(blk.data(), cur) == 0) { ++iters; break; }
                 }
             }
-            PG_TIMED(5, stream, if (rd->filter_general) launch_film_general(rp, ps, dFilm, stream);
-                                else launch_film(rp, ps, dFilm, dStrays, maxStrays, dNStrays, stream));
+            PG_TIMED(5, stream, filmSamples());
             hostCounts.resize(4 * QSTRIDE * (size_t)iters);
             HIP_TRY(hipMemcpyAsync(hostCounts.data(), countLog.p, sizeof(int) * 4 * QSTRIDE * (size_t)iters, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
@@ -968,6 +981,46 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
             }
             if (iters > 0) cameraRays += queueTotal(hostCounts.data(), curQueueOfBounce[0]);
         }
+        return PG_OK;
+    };
+    const std::function<void()> filmBatch = [&]() {
+        if (rd->filter_general) launch_film_general(rp, ps, dFilm, stream);
+        else launch_film(rp, ps, dFilm, dStrays, maxStrays, dNStrays, stream);
+    };
+    if (!tileSerial) {
+        for (int tile0 = 0; tile0 < nLocalTiles; tile0 += tilesPerBatch)
+            for (int s0 = 0; s0 < rd->spp; s0 += sPerBatch) {
+                rp.tileLocal0 = tile0;
+                rp.nTilesBatch = std::min(tilesPerBatch, nLocalTiles - tile0);
+                rp.s0 = s0;
+                rp.sCount = std::min(sPerBatch, rd->spp - s0);
+                rp.capacity = rp.nTilesBatch * 256 * rp.sCount;
+                if (int e = tracePaths([&]() { launch_generate(s->d, rp, ps, q[0], stream); }, filmBatch)) return e;
+            }
+    } else {
+        // The samplers that draw from one RNG stream per tile (random, stratified, 02sequence, maxmindist): a tile's pixels, a
+        // pixel's samples and a sample's draws consume the stream in order, and how many numbers a path takes depends on the
+        // path -- so a tile has ONE path in flight, and the wavefront is one path of every tile: pixel (lx, ly) of all tiles,
+        // sample by sample (integrator.cpp:247-332).  Tiles clipped by the image skip the pixels they do not have.
+        const int nd = rd->sampler == PG_SAMPLER_RANDOM ? 0 : rd->sampler_dims;
+        HIP_TRY(s->tsState.alloc(sizeof(TileSamplerState) * (size_t)nLocalTiles));
+        HIP_TRY(s->ts1.alloc(sizeof(float) * ((size_t)nLocalTiles * nd * rd->spp + 1)));
+        HIP_TRY(s->ts2.alloc(sizeof(float) * 2 * ((size_t)nLocalTiles * nd * rd->spp + 1)));
+        s->d.ts = (TileSamplerState *)s->tsState.p; s->d.ts1 = (float *)s->ts1.p; s->d.ts2 = (float *)s->ts2.p;
+        s->d.tsDims = nd; s->d.tsSpp = rd->spp;
+        rp.tileLocal0 = 0; rp.nTilesBatch = nLocalTiles; rp.s0 = 0; rp.sCount = 1; rp.capacity = nLocalTiles;
+        launch_ts_init(s->d, rp, stream);
+        int err = PG_OK;
+        for (int ly = 0; ly < 16 && !err; ++ly)
+            for (int lx = 0; lx < 16 && !err; ++lx) {
+                if (rd->sample_bounds[0] + lx >= rd->sample_bounds[2] || rd->sample_bounds[1] + ly >= rd->sample_bounds[3]) continue;  // no tile has this pixel
+                launch_ts_start_pixel(s->d, rp, lx, ly, stream);
+                for (int sn = 0; sn < rd->spp && !err; ++sn)
+                    err = tracePaths([&]() { launch_ts_generate(s->d, rp, ps, q[0], sn, stream); },
+                                     [&]() { launch_ts_film(s->d, rp, ps, dFilm, dStrays, maxStrays, dNStrays, stream); });
+            }
+        s->d.ts = nullptr; s->d.ts1 = s->d.ts2 = nullptr;
+        if (err) return err;
     }
     HIP_TRY(hipEventRecord(evStop, stream));
     HIP_TRY(hipGetLastError());

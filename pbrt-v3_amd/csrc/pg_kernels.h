@@ -13,6 +13,16 @@
 struct DObject { float box[6]; int rootRef; int firstPrim; int nNodes; int pad; };
 #define TR_NO_ROOT 0x7fffffff
 
+// One tile's sampler when the sampler draws from one RNG stream per tile (PgSamplerKind 2 .. 5): the tile's PCG32 state
+// (core/rng.h:61-144), PixelSampler's current1DDimension / current2DDimension / currentPixelSampleIndex (sampler.cpp:100-134),
+// the pixel the tile is at, and the camera sample's lens point (kept for the ray differentials at the first hit).
+struct TileSamplerState {
+    unsigned long long state, inc;
+    int cur1D, cur2D, sampleIndex, active;  // active: the current pixel exists and lies inside the integrator's pixel bounds
+    float lens0, lens1;
+    int px, py;
+};
+
 // Device-resident scene.  All pointers are device memory.
 struct DScene {
     // Linearised BVH, 32 B/node exactly as PgBVHNode: two float4 per node
@@ -76,6 +86,12 @@ struct DScene {
     // SobolSampler tables (core/sobolmatrices.h:49-52), nullptr unless the scene was created with them
     const uint32_t *sobolMatrices;
     const uint64_t *vdcSobol, *vdcSobolInv;
+    // Tile-serial samplers: set by pg_render for the duration of a frame.  One path per tile is in flight and slot = the
+    // tile's local index; ts1 / ts2 hold the current pixel's sample arrays, per tile [tsDims][tsSpp] floats / float pairs.
+    TileSamplerState *ts;
+    float *ts1, *ts2;
+    int tsDims, tsSpp;
+    const uint32_t *cmaxmin;  // CMaxMinDist [17][32]
 };
 
 // A queue of rays in SoA float4 pairs: 32 B per ray
@@ -161,6 +177,13 @@ void launch_closest2(const DScene &sc, RayQueue q0, RayQueue q1, float4 *hits, i
                      hipStream_t s, float *tOut = nullptr);
 void launch_anyhit(const DScene &sc, RayQueue q, int *occluded, TraceCounters *cn, int *cursors, hipStream_t s);
 void launch_generate(const DScene &sc, const RenderParams &rp, PathState st, RayQueue q, hipStream_t s);
+// tile-serial samplers: seed the tiles' streams; StartPixel for pixel (lx, ly) of every tile; the camera sample + ray of sample
+// `sampleIndex` of that pixel; FilmTile::AddSample of the finished paths
+void launch_ts_init(const DScene &sc, const RenderParams &rp, hipStream_t s);
+void launch_ts_start_pixel(const DScene &sc, const RenderParams &rp, int lx, int ly, hipStream_t s);
+void launch_ts_generate(const DScene &sc, const RenderParams &rp, PathState st, RayQueue q, int sampleIndex, hipStream_t s);
+void launch_ts_film(const DScene &sc, const RenderParams &rp, PathState st, PgFilmPixel *film, PgStraySample *strays, int maxStrays, int *nStrays,
+                    hipStream_t s);
 // cur: which of st.qs[] accompanies qin (the other one accompanies qnext)
 void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQueue qin, const float4 *hits, RayQueue qnext,
                   RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s, int cur = 0);

@@ -158,6 +158,144 @@ PG_DEV float halton_sample(const DScene &sc, const PgRenderDesc &rd, uint64_t in
     return scrambled_radical_inverse((uint32_t)sc.primes[dim], sc.perms + sc.permSums[dim], index);
 }
 
+// ---- the samplers that draw from one RNG stream per tile (RandomSampler; the PixelSamplers, sampler.cpp:100-134) ------------
+PG_DEV uint32_t rng_u32(TileSamplerState &t) {  // RNG::UniformUInt32, rng.h:137-143
+    const unsigned long long oldstate = t.state;
+    t.state = oldstate * 0x5851f42d4c957f2dULL + t.inc;
+    const uint32_t xorshifted = (uint32_t)(((oldstate >> 18u) ^ oldstate) >> 27u);
+    const uint32_t rot = (uint32_t)(oldstate >> 59u);
+    return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+}
+PG_DEV uint32_t rng_u32b(TileSamplerState &t, uint32_t b) {  // rng.h:68-74
+    const uint32_t threshold = (~b + 1u) % b;
+    for (;;) { const uint32_t r = rng_u32(t); if (r >= threshold) return r % b; }
+}
+PG_DEV float rng_float(TileSamplerState &t) { return pmin(PG_ONE_MINUS_EPS, (float)rng_u32(t) * 0x1p-32f); }  // rng.h:75-82
+PG_DEV float ts_get1d(const DScene &sc, int tile) {  // PixelSampler::Get1D (RandomSampler: tsDims = 0)
+    TileSamplerState &t = sc.ts[tile];
+    if (t.cur1D < sc.tsDims) return sc.ts1[((size_t)tile * sc.tsDims + t.cur1D++) * sc.tsSpp + t.sampleIndex];
+    return rng_float(t);
+}
+PG_DEV void ts_get2d(const DScene &sc, int kind, int tile, float &a, float &b) {  // PixelSampler::Get2D
+    TileSamplerState &t = sc.ts[tile];
+    if (t.cur2D < sc.tsDims) {
+        const float *p = sc.ts2 + (((size_t)tile * sc.tsDims + t.cur2D++) * sc.tsSpp + t.sampleIndex) * 2;
+        a = p[0]; b = p[1];
+    } else if (kind == PG_SAMPLER_RANDOM) { a = rng_float(t); b = rng_float(t); }  // random.cpp:50-54: braced list, left to right
+    else { b = rng_float(t); a = rng_float(t); }  // `Point2f(rng.UniformFloat(), rng.UniformFloat())` as the reference build (g++) evaluates it: y first
+}
+PG_DEV void ts_shuffle(float *samp, int count, int width, TileSamplerState &t) {  // Shuffle, sampling.h:151-157
+    for (int i = 0; i < count; ++i) {
+        const int other = i + (int)rng_u32b(t, (uint32_t)(count - i));
+        for (int j = 0; j < width; ++j) { const float v = samp[width * i + j]; samp[width * i + j] = samp[width * other + j]; samp[width * other + j] = v; }
+    }
+}
+PG_DEV void ts_van_der_corput(int n, float *samples, TileSamplerState &t) {  // VanDerCorput(1, n, ...), lowdiscrepancy.h:154-207
+    uint32_t v = rng_u32(t);
+    for (uint32_t i = 0; i < (uint32_t)n; ++i) {  // GrayCodeSample, C[k] = 1 << (31 - k)
+        samples[i] = pmin((float)v * 0x1p-32f, PG_ONE_MINUS_EPS);
+        v ^= 0x80000000u >> __builtin_ctz(i + 1);
+    }
+    for (int i = 0; i < n; ++i) ts_shuffle(samples + i, 1, 1, t);  // a one-element shuffle still draws a number
+    ts_shuffle(samples, n, 1, t);
+}
+PG_DEV void ts_sobol2d(int n, float *samples, TileSamplerState &t) {  // Sobol2D(1, n, ...), lowdiscrepancy.h:209-236
+    uint32_t v0 = rng_u32(t), v1 = rng_u32(t);
+    for (uint32_t i = 0; i < (uint32_t)n; ++i) {
+        samples[2 * i] = pmin((float)v0 * 0x1p-32f, PG_ONE_MINUS_EPS);
+        samples[2 * i + 1] = pmin((float)v1 * 0x1p-32f, PG_ONE_MINUS_EPS);
+        const int k = __builtin_ctz(i + 1);
+        v0 ^= 0x80000000u >> k;
+        uint32_t c = 0x80000000u;  // CSobol[1][k]: c_0 = 2^31, c_j = c_(j-1) ^ (c_(j-1) >> 1)
+        for (int j = 0; j < k; ++j) c ^= c >> 1;
+        v1 ^= c;
+    }
+    for (int i = 0; i < n; ++i) ts_shuffle(samples + 2 * i, 1, 2, t);
+    ts_shuffle(samples, n, 2, t);
+}
+// a tile's global index, pixel (lx, ly) of it and whether that pixel exists (tiles at the image edge are clipped)
+PG_DEV bool ts_tile_pixel(const RenderParams &rp, int local, int lx, int ly, int &t, int &px, int &py) {
+    t = rp.rd.tile_first + local * rp.rd.tile_step;
+    const int tx = t % rp.nTilesX, ty = t / rp.nTilesX;
+    px = rp.rd.sample_bounds[0] + tx * 16 + lx;
+    py = rp.rd.sample_bounds[1] + ty * 16 + ly;
+    return px < rp.rd.sample_bounds[2] && py < rp.rd.sample_bounds[3];
+}
+// tileSampler = sampler->Clone(seed), seed = tile.y * nTiles.x + tile.x (integrator.cpp:247-248); RNG::SetSequence, rng.h:129-135
+__global__ void k_ts_init(DScene sc, RenderParams rp) {
+    const int local = blockIdx.x * blockDim.x + threadIdx.x;
+    if (local >= rp.nTilesBatch) return;
+    TileSamplerState t;
+    t.state = 0u; t.inc = ((unsigned long long)(rp.rd.tile_first + local * rp.rd.tile_step) << 1u) | 1u;
+    rng_u32(t);
+    t.state += 0x853c49e6748fea9bULL;
+    rng_u32(t);
+    t.cur1D = t.cur2D = t.sampleIndex = t.active = 0; t.lens0 = t.lens1 = 0; t.px = t.py = 0;
+    sc.ts[local] = t;
+}
+// <Sampler>::StartPixel for pixel (lx, ly) of every tile: the pixel's sample arrays from the tile's stream -- also for pixels
+// outside the integrator's pixel bounds, which are then skipped (integrator.cpp:264-273)
+__global__ void k_ts_start_pixel(DScene sc, RenderParams rp, int lx, int ly) {
+    const int local = blockIdx.x * blockDim.x + threadIdx.x;
+    if (local >= rp.nTilesBatch) return;
+    TileSamplerState t = sc.ts[local];
+    int tile, px, py;
+    const bool exists = ts_tile_pixel(rp, local, lx, ly, tile, px, py);
+    t.active = 0;
+    if (exists) {
+        const PgRenderDesc &rd = rp.rd;
+        const int n = sc.tsSpp, nd = sc.tsDims;
+        float *s1 = sc.ts1 + (size_t)local * nd * n, *s2 = sc.ts2 + (size_t)local * nd * n * 2;
+        if (rd.sampler == PG_SAMPLER_STRATIFIED) {  // stratified.cpp:43-70, sampling.cpp:42-60
+            const int nx = rd.strat_samples[0], ny = rd.strat_samples[1];
+            for (int i = 0; i < nd; ++i) {
+                float *p = s1 + (size_t)i * n;
+                const float invNSamples = 1.f / (float)n;
+                for (int k = 0; k < n; ++k) { const float delta = rd.strat_jitter ? rng_float(t) : 0.5f; p[k] = pmin(((float)k + delta) * invNSamples, PG_ONE_MINUS_EPS); }
+                ts_shuffle(p, n, 1, t);
+            }
+            for (int i = 0; i < nd; ++i) {
+                float *p = s2 + (size_t)i * n * 2;
+                const float dx = 1.f / (float)nx, dy = 1.f / (float)ny;
+                for (int y = 0; y < ny; ++y)
+                    for (int x = 0; x < nx; ++x) {
+                        const float jx = rd.strat_jitter ? rng_float(t) : 0.5f;
+                        const float jy = rd.strat_jitter ? rng_float(t) : 0.5f;
+                        p[2 * (y * nx + x)] = pmin(((float)x + jx) * dx, PG_ONE_MINUS_EPS);
+                        p[2 * (y * nx + x) + 1] = pmin(((float)y + jy) * dy, PG_ONE_MINUS_EPS);
+                    }
+                ts_shuffle(p, n, 2, t);
+            }
+        } else if (rd.sampler == PG_SAMPLER_ZEROTWO) {  // zerotwosequence.cpp:53-69
+            for (int i = 0; i < nd; ++i) ts_van_der_corput(n, s1 + (size_t)i * n, t);
+            for (int i = 0; i < nd; ++i) ts_sobol2d(n, s2 + (size_t)i * n * 2, t);
+        } else if (rd.sampler == PG_SAMPLER_MAXMINDIST) {  // maxmin.cpp:43-69
+            int cIndex = 0;
+            while ((1 << (cIndex + 1)) <= n) ++cIndex;  // Log2Int(samplesPerPixel)
+            const uint32_t *CPixel = sc.cmaxmin + 32 * cIndex;
+            const float invSPP = 1.f / (float)n;
+            for (int i = 0; i < n; ++i) {
+                uint32_t v = 0, a = (uint32_t)i;
+                for (int k = 0; a != 0; ++k, a >>= 1) if (a & 1) v ^= CPixel[k];  // MultiplyGenerator, lowdiscrepancy.h:93-98
+                s2[2 * i] = (float)i * invSPP;
+                s2[2 * i + 1] = pmin((float)v * 0x1p-32f, PG_ONE_MINUS_EPS);
+            }
+            ts_shuffle(s2, n, 2, t);
+            for (int i = 0; i < nd; ++i) ts_van_der_corput(n, s1 + (size_t)i * n, t);
+            for (int i = 1; i < nd; ++i) ts_sobol2d(n, s2 + (size_t)i * n * 2, t);
+        }  // RandomSampler::StartPixel only fills requested sample arrays: none
+        t.px = px; t.py = py;
+        t.active = px >= rd.pixel_bounds[0] && px < rd.pixel_bounds[2] && py >= rd.pixel_bounds[1] && py < rd.pixel_bounds[3];
+    }
+    sc.ts[local] = t;
+}
+void launch_ts_init(const DScene &sc, const RenderParams &rp, hipStream_t s) {
+    hipLaunchKernelGGL(k_ts_init, dim3((rp.nTilesBatch + 63) / 64), dim3(64), 0, s, sc, rp);
+}
+void launch_ts_start_pixel(const DScene &sc, const RenderParams &rp, int lx, int ly, hipStream_t s) {
+    hipLaunchKernelGGL(k_ts_start_pixel, dim3((rp.nTilesBatch + 63) / 64), dim3(64), 0, s, sc, rp, lx, ly);
+}
+
 // ===========================================================================
 // Camera ray generation: one lane per (pixel, sample) slot
 // ===========================================================================
@@ -347,6 +485,40 @@ __global__ __launch_bounds__(PG_BLOCK) void k_generate(DScene sc, RenderParams r
 void launch_generate(const DScene &sc, const RenderParams &rp, PathState st, RayQueue q, hipStream_t s) {
     int nblk = (rp.capacity + PG_BLOCK - 1) / PG_BLOCK;
     hipLaunchKernelGGL(k_generate, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, q);
+}
+
+// Tile-serial samplers: sample `sampleIndex` of every tile's current pixel -- StartNextSample's reset, GetCameraSample's draws
+// (film 2D, time 1D, lens 2D: always drawn, they advance the stream), the camera ray.  Slot = the tile's local index.
+__global__ __launch_bounds__(PG_BLOCK) void k_ts_generate(DScene sc, RenderParams rp, PathState st, RayQueue q, int sampleIndex) {
+    const int local = blockIdx.x * PG_BLOCK + threadIdx.x;
+    bool valid = local < rp.nTilesBatch && sc.ts[local].active;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+    float tMax = PG_INF;
+    if (valid) {
+        const PgRenderDesc &rd = rp.rd;
+        TileSamplerState &t = sc.ts[local];
+        t.sampleIndex = sampleIndex; t.cur1D = t.cur2D = 0;
+        float u0, u1, l0, l1;
+        ts_get2d(sc, rd.sampler, local, u0, u1);
+        (void)ts_get1d(sc, local);  // time
+        ts_get2d(sc, rd.sampler, local, l0, l1);
+        t.lens0 = l0; t.lens1 = l1;
+        const float pFilmX = (float)t.px + u0, pFilmY = (float)t.py + u1;
+        camera_ray(rd, pFilmX, pFilmY, l0, l1, o, d, tMax);
+        st.L[local] = make_float4(0, 0, 0, pFilmX);
+        st.beta[local] = make_float4(1, 1, 1, pFilmY);
+        st.meta[local] = make_int4(0, 0, __float_as_int(1.f), PG_META_HASDIFF);
+    }
+    int pos;
+    block_push<1, false>(&q, &valid, &pos);
+    if (valid) {
+        q.o[pos] = make_float4(o.x, o.y, o.z, tMax);
+        q.d[pos] = make_float4(d.x, d.y, d.z, __int_as_float(local));
+        if (st.qs[0].L) { st.qs[0].L[pos] = st.L[local]; st.qs[0].beta[pos] = st.beta[local]; st.qs[0].meta[pos] = st.meta[local]; }
+    }
+}
+void launch_ts_generate(const DScene &sc, const RenderParams &rp, PathState st, RayQueue q, int sampleIndex, hipStream_t s) {
+    hipLaunchKernelGGL(k_ts_generate, dim3((rp.nTilesBatch + PG_BLOCK - 1) / PG_BLOCK), dim3(PG_BLOCK), 0, s, sc, rp, st, q, sampleIndex);
 }
 
 // ===========================================================================
@@ -1491,6 +1663,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
         i = j < rp.retryCount ? rp.retryList[j] : -1;
     } else i = queue_item(qin);
     bool deferred = false;  // sparse light tables: this vertex met a voxel without a distribution; nothing is committed
+    TileSamplerState tsSavedOuter = {};
     const bool valid = i >= 0;
     // Output rays are staged in LDS ([queue][o|d][thread]) the moment they are known and copied to their queues after the
     // block-wide append at the end: holding three rays plus the pending direct-light terms in registers until then had
@@ -1527,6 +1700,15 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
         Spec L = sp3(L4.x, L4.y, L4.z), beta = sp3(B4.x, B4.y, B4.z);
         const uint64_t index = (uint64_t)(uint32_t)meta.x | ((uint64_t)(uint32_t)meta.y << 32);
         int dim = (int)((uint32_t)meta.w >> 20);
+        // Sampler::Get1D / Get2D in the order the reference calls them: a GlobalSampler (halton, sobol) is indexed by
+        // (sample index, dimension); the tile-serial samplers advance their tile's state (slot = tile, one path per tile)
+        const bool tileSerial = rd.sampler >= PG_SAMPLER_RANDOM;
+        if (tileSerial) tsSavedOuter = sc.ts[slot];  // restored if this vertex is deferred (sparse light tables)
+        auto draw1 = [&]() -> float { return tileSerial ? ts_get1d(sc, slot) : halton_sample(sc, rd, index, dim++); };
+        auto draw2 = [&](float &a, float &b) {
+            if (tileSerial) ts_get2d(sc, rd.sampler, slot, a, b);
+            else { a = halton_sample(sc, rd, index, dim); b = halton_sample(sc, rd, index, dim + 1); dim += 2; }
+        };
         float etaScale = __int_as_float(meta.z);  // path.cpp:79
         int bounces = meta.w & 0xffff;
         const bool specularBounce = (meta.w & PG_META_SPECULAR) != 0;
@@ -1540,10 +1722,9 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
             if (med) {  // HomogeneousMedium::Sample, homogeneous.cpp:49-74
                 const PgMedium &mm = sc.media[med - 1];
                 const float4 o4 = qin.o[i];
-                int channel = (int)(halton_sample(sc, rd, index, dim) * 3);
+                int channel = (int)(draw1() * 3);
                 if (channel > 2) channel = 2;
-                const float ud = halton_sample(sc, rd, index, dim + 1);
-                dim += 2;
+                const float ud = draw1();
                 const float dist = -(float)log((double)(1 - ud)) / mm.sigma_t[channel];
                 const float dLen = sqrtf(lensq(rayD));
                 const float tMaxRay = found ? hitT[i] : o4.w;  // ray.tMax after Scene::Intersect
@@ -1607,11 +1788,11 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                 if (sc.nLights > 0 && !tab) deferred = true;
                 if (tab) {  // UniformSampleOneLight(mi, ..., handleMedia = true), integrator.cpp:85-106
                     float lightSelPdf;
-                    lightNum = sample_discrete(tab, sc.nLights, halton_sample(sc, rd, index, dim++), lightSelPdf);
+                    lightNum = sample_discrete(tab, sc.nLights, draw1(), lightSelPdf);
                     if (lightSelPdf != 0) {
-                        float uL0 = halton_sample(sc, rd, index, dim), uL1 = halton_sample(sc, rd, index, dim + 1);
-                        float uS0 = halton_sample(sc, rd, index, dim + 2), uS1 = halton_sample(sc, rd, index, dim + 3);
-                        dim += 4;
+                        float uL0, uL1, uS0, uS1;  // uLight, uScattering (integrator.cpp:101-102)
+                        draw2(uL0, uL1);
+                        draw2(uS0, uS1);
                         const PgLight &light = sc.lights[lightNum];
                         V3 wi = zero;
                         float lightPdf = 0;
@@ -1658,8 +1839,8 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                 }
                 // mi.phase->Sample_p for the next direction, volpath.cpp:92-95
                 V3 wi;
-                const float u0 = halton_sample(sc, rd, index, dim), u1 = halton_sample(sc, rd, index, dim + 1);
-                dim += 2;
+                float u0, u1;
+                draw2(u0, u1);
                 hg_sample_p(g, wo, wi, u0, u1);
                 s_ray[0][0][tid] = make_float4(mediumP.x, mediumP.y, mediumP.z, PG_INF);
                 s_ray[0][1][tid] = make_float4(wi.x, wi.y, wi.z, __int_as_float(slot));
@@ -1668,7 +1849,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                 Spec rrBeta = beta * etaScale;  // volpath.cpp:178-184
                 if (max_component(rrBeta) < rd.rr_threshold && bounces > 3) {
                     float qq = pmax(.05f, 1 - max_component(rrBeta));
-                    if (halton_sample(sc, rd, index, dim++) < qq) pushNext = false;
+                    if (draw1() < qq) pushNext = false;
                     else beta = beta / (1 - qq);
                 }
                 bounces += 1;
@@ -1728,7 +1909,8 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                             const float4 o4 = qin.o[i];
                             const V3 rayO = mk(o4.x, o4.y, o4.z);
                             float l0 = 0, l1 = 0;
-                            if (rd.lens_radius > 0) { l0 = halton_sample(sc, rd, index, 3); l1 = halton_sample(sc, rd, index, 4); }
+                            if (tileSerial) { l0 = sc.ts[slot].lens0; l1 = sc.ts[slot].lens1; }  // the camera sample's pLens, kept by k_ts_generate
+                            else if (rd.lens_radius > 0) { l0 = halton_sample(sc, rd, index, 3); l1 = halton_sample(sc, rd, index, 4); }
                             V3 rxO, rxD, ryO, ryD;
                             camera_differentials(rd, L4.w, B4.w, l0, l1, rayO, rayD, rxO, rxD, ryO, ryD);
                             const V3 n = is.n, p = is.p;
@@ -1835,11 +2017,11 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                 if (wantLight && !tab) deferred = true;
                 if (tab) {
                     float lightSelPdf;
-                    lightNum = sample_discrete(tab, sc.nLights, halton_sample(sc, rd, index, dim++), lightSelPdf);
+                    lightNum = sample_discrete(tab, sc.nLights, draw1(), lightSelPdf);
                     if (lightSelPdf != 0) {
-                        float uL0 = halton_sample(sc, rd, index, dim), uL1 = halton_sample(sc, rd, index, dim + 1);
-                        float uS0 = halton_sample(sc, rd, index, dim + 2), uS1 = halton_sample(sc, rd, index, dim + 3);
-                        dim += 4;
+                        float uL0, uL1, uS0, uS1;  // uLight, uScattering (integrator.cpp:101-102)
+                        draw2(uL0, uL1);
+                        draw2(uS0, uS1);
                         const PgLight &light = sc.lights[lightNum];
                         V3 wi = mk(0, 0, 0);
                         float lightPdf = 0, scatteringPdf = 0;
@@ -1905,8 +2087,8 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                 // ---- sample the BSDF for the next direction (path.cpp:130-150)
                 V3 wo = -rayD, wi;
                 float pdf;
-                float u0 = halton_sample(sc, rd, index, dim), u1 = halton_sample(sc, rd, index, dim + 1);
-                dim += 2;
+                float u0, u1;
+                draw2(u0, u1);
                 int sampledType = 0;
                 Spec f;
                 float bsdfEta;
@@ -1928,7 +2110,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
                     Spec rrBeta = beta * etaScale;
                     if (max_component(rrBeta) < rd.rr_threshold && bounces > 3) {
                         float qq = pmax(.05f, 1 - max_component(rrBeta));
-                        if (halton_sample(sc, rd, index, dim++) < qq) pushNext = false;
+                        if (draw1() < qq) pushNext = false;
                         else beta = beta / (1 - qq);
                     }
                 }
@@ -1948,6 +2130,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
     }
     if (deferred) {  // retried once the voxel's distribution exists: no ray, no state, no pending term leaves this launch
         pushNext = pushShadow = misCand = false;
+        if (rp.rd.sampler >= PG_SAMPLER_RANDOM) sc.ts[slot] = tsSavedOuter;  // nor a draw from the tile's stream
         rp.retryList[atomicAdd(&sc.voxelCounters[1], 1)] = i;
     }
     if (misCand) {
@@ -2331,6 +2514,70 @@ __global__ __launch_bounds__(PG_BLOCK) void k_film_general(RenderParams rp, Path
         PgFilmPixel *fp = &film[(size_t)local * rd.tile_pixels + e];
         fp->rgb[0] = r; fp->rgb[1] = g; fp->rgb[2] = b; fp->weight = w;
     }
+}
+// Tile-serial samplers: the one finished sample of every tile, added to the tile's film block exactly as FilmTile::AddSample
+// does it (film.h:121-161) -- one lane per tile walks the sample's footprint, so a block's sums have the reference's order.
+__global__ void k_ts_film(DScene sc, RenderParams rp, PathState st, PgFilmPixel *film, PgStraySample *strays, int maxStrays, int *nStrays) {
+    const int local = blockIdx.x * blockDim.x + threadIdx.x;
+    if (local >= rp.nTilesBatch || !sc.ts[local].active) return;
+    const PgRenderDesc &rd = rp.rd;
+    const int px = sc.ts[local].px, py = sc.ts[local].py;
+    const int t = rd.tile_first + local * rd.tile_step;
+    const int tx = t % rp.nTilesX, ty = t / rp.nTilesX;
+    const int x0 = rd.sample_bounds[0] + tx * 16, y0 = rd.sample_bounds[1] + ty * 16;
+    const int x1 = min(x0 + 16, rd.sample_bounds[2]), y1 = min(y0 + 16, rd.sample_bounds[3]);
+    const float frx = rd.filter_radius[0], fry = rd.filter_radius[1];
+    const int tp0x = max((int)ceilf((float)x0 - 0.5f - frx), rd.cropped_pixel_bounds[0]);
+    const int tp0y = max((int)ceilf((float)y0 - 0.5f - fry), rd.cropped_pixel_bounds[1]);
+    const int tp1x = min((int)floorf((float)x1 - 0.5f + frx) + 1, rd.cropped_pixel_bounds[2]);
+    const int tp1y = min((int)floorf((float)y1 - 0.5f + fry) + 1, rd.cropped_pixel_bounds[3]);
+    const float4 L4 = st.L[local];
+    const float pFilmX = L4.w, pFilmY = st.beta[local].w;
+    Spec L = sp3(L4.x, L4.y, L4.z);
+    if (isnan(L.r) || isnan(L.g) || isnan(L.b)) L = sp(0);  // integrator.cpp:294-315
+    else if ((double)lum(L) < -1e-5) L = sp(0);
+    else if (isinf(lum(L))) L = sp(0);
+    if (lum(L) > rd.max_sample_luminance) L = L * (rd.max_sample_luminance / lum(L));
+    const float dx = pFilmX - 0.5f, dy = pFilmY - 0.5f;
+    const int p0x = max((int)ceilf(dx - frx), tp0x), p0y = max((int)ceilf(dy - fry), tp0y);
+    const int p1x = min((int)floorf(dx + frx) + 1, tp1x), p1y = min((int)floorf(dy + fry) + 1, tp1y);
+    if (rd.filter_general) {
+        const int tw = 16 + rd.tile_halo[0] + rd.tile_halo[2];
+        const float invRx = 1 / frx, invRy = 1 / fry;
+        for (int y = p0y; y < p1y; ++y) {
+            const float fy = fabsf(((float)y - dy) * invRy * 16);
+            const int ify = min((int)floorf(fy), 15);
+            for (int x = p0x; x < p1x; ++x) {
+                const float fx = fabsf(((float)x - dx) * invRx * 16);
+                const int ifx = min((int)floorf(fx), 15);
+                const float fw = rd.filter_table[ify * 16 + ifx];
+                const Spec c = (L * 1.f) * fw;
+                PgFilmPixel *fp = &film[(size_t)local * rd.tile_pixels + (size_t)(y - (y0 - rd.tile_halo[1])) * tw + (x - (x0 - rd.tile_halo[0]))];
+                fp->rgb[0] += c.r; fp->rgb[1] += c.g; fp->rgb[2] += c.b; fp->weight += fw;
+            }
+        }
+        return;
+    }
+    const Spec c = (L * 1.f) * 1.f;
+    for (int y = p0y; y < p1y; ++y)
+        for (int x = p0x; x < p1x; ++x) {
+            if (x == px && y == py) {
+                PgFilmPixel *fp = &film[(size_t)local * 256 + (py - y0) * 16 + (px - x0)];
+                fp->rgb[0] += c.r; fp->rgb[1] += c.g; fp->rgb[2] += c.b; fp->weight += 1.f;
+            } else {
+                const int k = atomicAdd(nStrays, 1);
+                if (k < maxStrays) {
+                    PgStraySample s;
+                    s.px = x; s.py = y; s.src_px = px; s.src_py = py;
+                    s.rgb[0] = c.r; s.rgb[1] = c.g; s.rgb[2] = c.b; s.weight = 1.f;
+                    strays[k] = s;
+                }
+            }
+        }
+}
+void launch_ts_film(const DScene &sc, const RenderParams &rp, PathState st, PgFilmPixel *film, PgStraySample *strays, int maxStrays, int *nStrays,
+                    hipStream_t s) {
+    hipLaunchKernelGGL(k_ts_film, dim3((rp.nTilesBatch + 63) / 64), dim3(64), 0, s, sc, rp, st, film, strays, maxStrays, nStrays);
 }
 void launch_film_general(const RenderParams &rp, PathState st, PgFilmPixel *film, hipStream_t s) {
     if (rp.nTilesBatch == 0) return;

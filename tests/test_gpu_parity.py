@@ -356,8 +356,16 @@ def test_invalid_media_and_sampler_descriptions_fail_loudly(gpu):
     with pytest.raises(gpu.PbrtGpuError, match="sobol_resolution"):
         gs.render(rd)
     rd = sob.render_desc()
-    rd.sampler = 3
-    with pytest.raises(gpu.PbrtGpuError, match="sampler 3"):
+    rd.sampler = 7
+    with pytest.raises(gpu.PbrtGpuError, match="sampler 7"):
+        gs.render(rd)
+    rd = sob.render_desc()
+    rd.sampler, rd.strat_samples[0], rd.strat_samples[1] = 3, 3, 2  # stratified: spp must be the product of the strata
+    with pytest.raises(gpu.PbrtGpuError, match="stratified sampler 3 x 2"):
+        gs.render(rd)
+    rd = sob.render_desc()
+    rd.sampler, rd.sampler_dims = 5, 2  # maxmindist without its generator matrices
+    with pytest.raises(gpu.PbrtGpuError, match="cmaxmin"):
         gs.render(rd)
     gs.close()
     with pytest.raises(gpu.PbrtGpuError, match="null argument"):
