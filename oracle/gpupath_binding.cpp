@@ -17,7 +17,7 @@
 //
 // Closed set of this binding: triangle meshes (with N / S / uv), spheres, cylinders and disks; materials whose parameters are
 // constant textures (their BxDF lists are read off Material::ComputeScatteringFunctions); diffuse area lights, point, spot
-// and distant lights; perspective and orthographic cameras; Halton and Sobol samplers; every pixel filter; homogeneous
+// and distant lights; perspective and orthographic cameras; all six samplers; every pixel filter; homogeneous
 // media.  Anything else is reported with Error() and the process exits -- there is no CPU fallback here either.
 #include <dlfcn.h>
 #include <unistd.h>
@@ -57,7 +57,11 @@
 #include "reflection.h"
 #include "sampler.h"
 #include "samplers/halton.h"
+#include "samplers/maxmin.h"
+#include "samplers/random.h"
 #include "samplers/sobol.h"
+#include "samplers/stratified.h"
+#include "samplers/zerotwosequence.h"
 #include "scene.h"
 #include "shapes/cylinder.h"
 #include "shapes/disk.h"
@@ -346,8 +350,11 @@ void FlattenScene(const Scene &scene, int maxDepth, bool volumetric, const std::
         const int nDims = volumetric ? PrimeTableSize : std::min(PrimeTableSize, 5 + 8 * (maxDepth + 2));
         for (int i = 0; i <= nDims; ++i) flat->permSums.push_back(i < PrimeTableSize ? PrimeSums[i] : PrimeSums[PrimeTableSize - 1] + Primes[PrimeTableSize - 1]);
         d.n_perm_dims = nDims; d.perms = HaltonSampler::radicalInversePermutations.data(); d.perm_sums = flat->permSums.data();
-    } else {  // SobolSampler: the reference's generator matrices
+    } else if (dynamic_cast<const SobolSampler *>(&sampler)) {  // the reference's generator matrices
         d.sobol_matrices = SobolMatrices32; d.vdc_sobol = &VdCSobolMatrices[0][0]; d.vdc_sobol_inv = &VdCSobolMatricesInv[0][0];
+    } else {  // a sampler over one RNG stream per tile: nothing but (for maxmindist) its generator matrices
+        d.sobol_matrices = SobolMatrices32; d.vdc_sobol = &VdCSobolMatrices[0][0]; d.vdc_sobol_inv = &VdCSobolMatricesInv[0][0];  // (lets the Halton table be absent)
+        d.cmaxmin = &CMaxMinDist[0][0];
     }
     d.n_spheres = (int)flat->spheres.size(); d.spheres = flat->spheres.data();
     d.n_bxdfs = (int)flat->bxdfs.size(); d.bxdfs = flat->bxdfs.data();
@@ -399,7 +406,15 @@ void FillRenderDesc(const Camera &camera, const Sampler &sampler, const Bounds2i
         rd->sample_stride = h->sampleStride; rd->sample_at_pixel_center = h->sampleAtPixelCenter;
     } else if (const SobolSampler *s = dynamic_cast<const SobolSampler *>(&sampler)) {
         rd->sampler = 1; rd->sobol_resolution = s->resolution; rd->sobol_log2_resolution = s->log2Resolution;
-    } else Unsupported("a sampler other than halton / sobol in this binding");
+    } else if (dynamic_cast<const RandomSampler *>(&sampler)) rd->sampler = PG_SAMPLER_RANDOM;
+    else if (const PixelSampler *ps = dynamic_cast<const PixelSampler *>(&sampler)) {  // its per-tile clones are seeded by the device, tile by tile
+        rd->sampler_dims = (int)ps->samples1D.size();
+        if (const StratifiedSampler *st = dynamic_cast<const StratifiedSampler *>(ps)) {
+            rd->sampler = PG_SAMPLER_STRATIFIED; rd->strat_samples[0] = st->xPixelSamples; rd->strat_samples[1] = st->yPixelSamples; rd->strat_jitter = st->jitterSamples;
+        } else if (dynamic_cast<const ZeroTwoSequenceSampler *>(ps)) rd->sampler = PG_SAMPLER_ZEROTWO;
+        else if (dynamic_cast<const MaxMinDistSampler *>(ps)) rd->sampler = PG_SAMPLER_MAXMINDIST;
+        else Unsupported("an unknown PixelSampler");
+    } else Unsupported("a sampler outside halton / sobol / random / stratified / 02sequence / maxmindist");
     rd->max_depth = maxDepth; rd->rr_threshold = rrThreshold;
     rd->pixel_bounds[0] = pixelBounds.pMin.x; rd->pixel_bounds[1] = pixelBounds.pMin.y; rd->pixel_bounds[2] = pixelBounds.pMax.x; rd->pixel_bounds[3] = pixelBounds.pMax.y;
     rd->tile_first = 0; rd->tile_step = 1;

@@ -607,8 +607,8 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     HIP_TRY_S(hipEventCreateWithFlags(&s->evShaded, hipEventDisableTiming));
     HIP_TRY_S(hipEventCreateWithFlags(&s->evShadowed, hipEventDisableTiming));
     if (const char *e = getenv("PG_OVERLAP_SHADOW")) s->overlapShadow = atoi(e) != 0;
-    HIP_TRY_S(s->cullGuard.alloc(sizeof(int)));
-    HIP_TRY_S(hipMemset(s->cullGuard.p, 0, sizeof(int)));
+    HIP_TRY_S(s->cullGuard.alloc(sizeof(int) * 2 + 8 * sizeof(unsigned long long)));  // the guard word (+ the counters of the PG_TRACE_STATS experiment build)
+    HIP_TRY_S(hipMemset(s->cullGuard.p, 0, s->cullGuard.bytes));
     HIP_TRY_S(s->lightTests.alloc(sizeof(unsigned long long)));
     HIP_TRY_S(hipMemset(s->lightTests.p, 0, s->lightTests.bytes));
     *out = s;
@@ -1059,6 +1059,15 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
 #undef PG_TIMED
     float ms = 0;
     if (hipEventElapsedTime(&ms, evStart, evStop) == hipSuccess) c.render_ms += ms;
+#ifdef PG_TRACE_STATS
+    {
+        unsigned long long st[8];
+        HIP_TRY(hipMemcpy(st, (char *)s->cullGuard.p + 2 * sizeof(int), sizeof(st), hipMemcpyDeviceToHost));
+        fprintf(stderr, "k_trace<false> lanes: interior steps %llu (%.1f lanes), triangle steps %llu (%.1f lanes), refills %llu (%.1f lanes), busy lanes per step %.1f\n",
+                st[0], st[0] ? (double)st[1] / st[0] : 0., st[2], st[2] ? (double)st[3] / st[2] : 0., st[4], st[4] ? (double)st[5] / st[4] : 0.,
+                (st[0] + st[2]) ? (double)st[6] / (st[0] + st[2]) : 0.);
+    }
+#endif
     if (int st2 = checkCullGuard(s)) return st2;
     if (hostNStrays > maxStrays) return setError(PG_ERR_OVERFLOW, "%d stray samples, buffer holds %d", hostNStrays, maxStrays);
     return PG_OK;

@@ -109,6 +109,9 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
     int vd = 0;                       // ANYHIT: reference stack depth (real + culled entries)
     unsigned long long vmask = 0;     // ANYHIT: bit i set = the reference's entry at depth i was culled early
     unsigned int nodeVisits = 0, triTests = 0;
+#ifdef PG_TRACE_STATS  // experiment build only (tools/trace_stats.sh): where the lanes of a wave go
+    unsigned long long stIntSteps = 0, stIntLanes = 0, stTriSteps = 0, stTriLanes = 0, stRefills = 0, stRefillLanes = 0, stBusyLanes = 0;
+#endif
     int nAccepted = 0;  // hits accepted by this lane's current ray (bounds the rounding growth of tMax, see cullK below)
     // XPRIM: object instances.  While a lane traverses an instance's BVH its ray registers hold the instance-space ray
     // (TransformedPrimitive::Intersect, primitive.cpp:76-96); the world ray, the rest of the world leaf and (any-hit) the
@@ -146,8 +149,10 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
         }
         // ---- retire finished rays and refill idle lanes from this wave's segment.  A finished ray's result stays in its lane
         //      until the wave refills (>= refillAt idle lanes) or runs dry, so the stores run with many lanes active instead of
-        //      once per iteration for one or two lanes.  (Copying the hit triangle's 48-B record next to the hit here, to spare
-        //      the shading kernel its gather, was measured: +12 ms per frame in this kernel, no gain in k_shade.)
+        //      once per iteration for one or two lanes.  Measured and NOT kept: copying the hit triangle's 48-B record next to
+        //      the hit here to spare the shading kernel its gather (+12 ms per frame here, no gain in k_shade); handing invDir
+        //      and the triangle test's shear over from the ray's producer instead of deriving them at refill (no gain:
+        //      the refill costs 9 % of this kernel's issue slots, but the extra 32 B per ray cost as much as the divisions).
         const bool idle = cur == TR_NONE && triLeft == 0;
         const unsigned long long idleMask = __ballot(idle);
         const int nIdle = __popcll(idleMask);
@@ -165,6 +170,9 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
             if (exhausted) break;
         }
         if (refill) {
+#ifdef PG_TRACE_STATS
+            ++stRefills; stRefillLanes += nIdle;
+#endif
             if (next >= segEnd) {  // wave-uniform: take the next chunk
                 for (;;) {
                     const int qsel = region >> 3, rr = region & (PG_REGIONS - 1);
@@ -223,6 +231,10 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
         //      at least about half of the busy lanes are active in every step and neither group starves.
         const int nInt = __popcll(__ballot(cur >= 0));
         const int nTri = __popcll(__ballot(triLeft > 0));
+#ifdef PG_TRACE_STATS
+        if (nTri > 0 && (nInt == 0 || nTri * 16 >= nInt * triW)) { ++stTriSteps; stTriLanes += nTri; } else { ++stIntSteps; stIntLanes += nInt; }
+        stBusyLanes += nInt + nTri;
+#endif
         if (nTri > 0 && (nInt == 0 || nTri * 16 >= nInt * triW)) {
             if (triLeft > 0) {  // Triangle::Intersect[P] on the leaf's next primitive, in order (bvh.cpp:677-680)
                 const int prim = triNext;
@@ -349,9 +361,16 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
         atomicAdd(&cn->node_visits, nv);
         atomicAdd(&cn->tri_tests, nt);
     }
+#ifdef PG_TRACE_STATS
+    if (lane == 0 && cullGuard) {  // closest-hit launches only: 8 counters after the guard word (the experiment allocates them)
+        unsigned long long *st = (unsigned long long *)(cullGuard + 2);
+        atomicAdd(&st[0], stIntSteps); atomicAdd(&st[1], stIntLanes); atomicAdd(&st[2], stTriSteps); atomicAdd(&st[3], stTriLanes);
+        atomicAdd(&st[4], stRefills); atomicAdd(&st[5], stRefillLanes); atomicAdd(&st[6], stBusyLanes);
+    }
+#endif
 }
 
-static TraceConfig g_cfg = {11, 128, 8, 8, 1.0009765625f, 2048};  // depth 11: 7 resident blocks x 22.5 KB of stack fill the 160 KB LDS
+static TraceConfig g_cfg = {11, 128, 16, 8, 1.0009765625f, 2048};  // depth 11: 7 resident blocks x 22.5 KB of stack fill the 160 KB LDS
 void set_trace_config(const TraceConfig &c) { g_cfg = c; }
 TraceConfig get_trace_config() { return g_cfg; }
 

@@ -19,7 +19,8 @@ SCENES = ["cornell_32", "cornell_crop", "cornell_lens", "cornell_plastic", "corn
           "cornell_orennayar", "cornell_ortho_lens", "cornell_twosided", "cornell_reverse", "cornell_xform", "cornell_filmopts",
           "filter_gaussian", "filter_mitchell_crop", "filter_widebox", "mat_uber", "mat_metal", "mat_substrate", "mat_translucent", "mat_mix",
           "mat_roughglass", "sphere_light", "sphere_partial", "quadric_lights", "hlbvh_synthetic", "synthetic_n40", "sobol_cornell",
-          "sobol_round_crop", "vol_fog", "vol_smoke", "vol_path_none_glass", "sobol_vol_smoke"]
+          "sobol_round_crop", "vol_fog", "vol_smoke", "vol_path_none_glass", "sobol_vol_smoke", "sampler_random", "sampler_stratified",
+          "sampler_stratified_dims", "filter_02sequence_lens", "sampler_maxmindist", "sampler_lowdisc_vol", "many_lights"]
 
 
 def run_binding(pkg, scene_file, out):
