@@ -17,6 +17,11 @@
 #include "pg_texture.h"
 
 #define PG_BLOCK 256
+// threads per block of the shading kernel: its blocks meet at two barriers around the queue append, so a block is only as fast
+// as its slowest wave -- measured on the GPU
+#ifndef PG_SHADE_BLOCK
+#define PG_SHADE_BLOCK 128
+#endif
 PG_DEV int lane_id() { return __lane_id(); }
 
 // Queue append, aggregated per block: every wave ballots its pushes, the block sums them through LDS and ONE lane per
@@ -26,9 +31,9 @@ PG_DEV int lane_id() { return __lane_id(); }
 // With BINNED, queue 0's entries are additionally grouped by `bin0` (0..7) inside the block's range: k_shade bins the next
 // bounce's rays by direction octant, so the 64 consecutive rays a traversal wave picks up come from one tile AND mostly
 // one octant (same near/far child order, same subtrees) instead of four to eight.
-template <int NQ, bool BINNED>
+template <int NQ, bool BINNED, int BLOCK = PG_BLOCK>
 PG_DEV void block_push(const RayQueue *q, const bool *pred, int *pos, int bin0 = 0) {
-    constexpr int NW = PG_BLOCK / 64;
+    constexpr int NW = BLOCK / 64;
     __shared__ int s_cnt[NQ][NW];
     __shared__ int s_base[NQ];
     __shared__ int s_bin[BINNED ? 8 : 1][NW];
@@ -74,9 +79,10 @@ PG_DEV void block_push(const RayQueue *q, const bool *pred, int *pos, int bin0 =
     }
 }
 // The queue entry this thread consumes (or -1): block b walks region b & 7.
+template <int BLOCK = PG_BLOCK>
 PG_DEV int queue_item(const RayQueue &q) {
     const int r = blockIdx.x & (PG_REGIONS - 1);
-    const int j = (blockIdx.x >> 3) * PG_BLOCK + threadIdx.x;
+    const int j = (blockIdx.x >> 3) * BLOCK + threadIdx.x;
     return j < q.counts[r * PG_COUNT_STRIDE] ? r * q.regionCap + j : -1;
 }
 
@@ -1652,24 +1658,24 @@ PG_DEV void prim_interface(const DScene &sc, int prim, int rayMedium, int &mIn, 
 }
 
 template <int MODE, bool VOL>
-__global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
+__global__ __launch_bounds__(PG_SHADE_BLOCK) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
                                                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, VolState vs,
                                                      const float *__restrict__ hitT, QueueState qsIn, QueueState qsOut) {
     constexpr bool EXT = MODE >= 1, TEX = MODE == 2;
     constexpr bool QSTATE = !VOL;  // path state and pending terms in queue order (see PathState)
     int i;
     if (rp.retryCount > 0) {  // second pass over the entries that waited for a light-distribution voxel
-        const int j = blockIdx.x * PG_BLOCK + threadIdx.x;
+        const int j = blockIdx.x * PG_SHADE_BLOCK + threadIdx.x;
         i = j < rp.retryCount ? rp.retryList[j] : -1;
-    } else i = queue_item(qin);
+    } else i = queue_item<PG_SHADE_BLOCK>(qin);
     bool deferred = false;  // sparse light tables: this vertex met a voxel without a distribution; nothing is committed
     TileSamplerState tsSavedOuter = {};
     const bool valid = i >= 0;
     // Output rays are staged in LDS ([queue][o|d][thread]) the moment they are known and copied to their queues after the
     // block-wide append at the end: holding three rays plus the pending direct-light terms in registers until then had
     // pushed the kernel to 130 VGPRs with scratch spills (3 waves/SIMD).
-    __shared__ float4 s_ray[3][2][PG_BLOCK];
-    __shared__ float4 s_state[QSTATE ? 3 : 1][PG_BLOCK];  // QSTATE: (L, beta, meta) until the entry's place in the next queue is known
+    __shared__ float4 s_ray[3][2][PG_SHADE_BLOCK];
+    __shared__ float4 s_state[QSTATE ? 3 : 1][PG_SHADE_BLOCK];  // QSTATE: (L, beta, meta) until the entry's place in the next queue is known
     const int tid = threadIdx.x;
     bool pushNext = false, pushShadow = false, pushMis = false;
     int slot = 0;
@@ -2170,7 +2176,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
     const RayQueue outQ[3] = {qnext, qshadow, qmis};
     const bool outPred[3] = {pushNext, pushShadow, pushMis};
     int outPos[3];
-    block_push<3, true>(outQ, outPred, outPos, nextBin);
+    block_push<3, true, PG_SHADE_BLOCK>(outQ, outPred, outPos, nextBin);
     const int posNext = outPos[0], posShadow = outPos[1], posMis = outPos[2];
     if (pushNext) { qnext.o[posNext] = s_ray[0][0][tid]; qnext.d[posNext] = s_ray[0][1][tid]; }
     if (pushShadow) { qshadow.o[posShadow] = s_ray[1][0][tid]; qshadow.d[posShadow] = s_ray[1][1][tid]; }
@@ -2190,22 +2196,22 @@ __global__ __launch_bounds__(PG_BLOCK) void k_shade(DScene sc, RenderParams rp, 
 }
 void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQueue qin, const float4 *hits, RayQueue qnext,
                   RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s, int cur) {
-    int nblk = rp.retryCount > 0 ? (rp.retryCount + PG_BLOCK - 1) / PG_BLOCK : PG_REGIONS * (qin.regionCap / PG_BLOCK);
+    int nblk = rp.retryCount > 0 ? (rp.retryCount + PG_SHADE_BLOCK - 1) / PG_SHADE_BLOCK : PG_REGIONS * (qin.regionCap / PG_SHADE_BLOCK);
     if (nblk == 0) return;
     const VolState vs = {};
     const float *noT = nullptr;
     const QueueState qi = st.qs[cur], qo = st.qs[cur ^ 1];
-    if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, false>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo);
-    else if (sc.ext) hipLaunchKernelGGL((k_shade<1, false>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo);
-    else hipLaunchKernelGGL((k_shade<0, false>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo);
+    if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo);
+    else if (sc.ext) hipLaunchKernelGGL((k_shade<1, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo);
+    else hipLaunchKernelGGL((k_shade<0, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo);
 }
 void launch_shade_vol(const DScene &sc, const RenderParams &rp, PathState st, VolState vs, RayQueue qin, const float4 *hits, const float *hitT,
                       RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s) {
-    int nblk = rp.retryCount > 0 ? (rp.retryCount + PG_BLOCK - 1) / PG_BLOCK : PG_REGIONS * (qin.regionCap / PG_BLOCK);
+    int nblk = rp.retryCount > 0 ? (rp.retryCount + PG_SHADE_BLOCK - 1) / PG_SHADE_BLOCK : PG_REGIONS * (qin.regionCap / PG_SHADE_BLOCK);
     if (nblk == 0) return;
     const QueueState none = {nullptr, nullptr, nullptr};
-    if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, true>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none);
-    else hipLaunchKernelGGL((k_shade<1, true>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none);
+    if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none);
+    else hipLaunchKernelGGL((k_shade<1, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none);
 }
 
 // EstimateDirect's two "Add ... contribution" steps (integrator.cpp:143-161, 196-212) and
@@ -2213,7 +2219,7 @@ void launch_shade_vol(const DScene &sc, const RenderParams &rp, PathState st, Vo
 template <bool EXT>
 __global__ __launch_bounds__(PG_BLOCK) void k_resolve(DScene sc, PathState st, RayQueue qin, RayQueue qmis, const int *__restrict__ occluded,
                                                        const float4 *__restrict__ misHits, QueueState qsNext) {
-    const int i = queue_item(qin);
+    const int i = queue_item<>(qin);
     if (i < 0) return;
     const int4 info = st.pdInfo[i];  // the pending terms lie in queue order (PathState)
     if (info.x < 0 && info.y < 0) return;  // Ld == 0: L += beta * 0 leaves L unchanged
@@ -2288,7 +2294,7 @@ PG_DEV void through_point(const DScene &sc, int ri, float4 o4, V3 rayD, float4 h
 template <int KIND>
 __global__ __launch_bounds__(PG_BLOCK) void k_through(DScene sc, PathState st, VolState vs, RayQueue qin, const float4 *__restrict__ hits,
                                                        const float *__restrict__ hitT, int hitBase, RayQueue qout) {
-    const int i = queue_item(qin);
+    const int i = queue_item<>(qin);
     bool push = false;
     float4 no = make_float4(0, 0, 0, 0), nd = make_float4(0, 0, 0, 0);
     if (i >= 0) {
@@ -2363,7 +2369,7 @@ void launch_through(const DScene &sc, PathState st, VolState vs, int kind, RayQu
 }
 // EstimateDirect's sums with handleMedia = true (integrator.cpp:143-161, 196-212), once the through rays are finished
 __global__ __launch_bounds__(PG_BLOCK) void k_resolve_vol(DScene sc, PathState st, VolState vs, RayQueue qin) {
-    const int i = queue_item(qin);
+    const int i = queue_item<>(qin);
     if (i < 0) return;
     const int slot = __float_as_int(qin.d[i].w);
     const int4 info = st.pdInfo[slot];
