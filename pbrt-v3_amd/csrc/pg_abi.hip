@@ -56,6 +56,7 @@ struct PgScene {
         lightTests, filmDev, straysDev, nStraysDev, cullGuard, cursors, cursors2;
     hipStream_t shadowStream = nullptr;  // any-hit launches run here, concurrently with the next closest-hit launch
     hipEvent_t evShaded = nullptr, evShadowed = nullptr;
+    bool cullTripped = false;  // the last call raised k_trace's cull guard (checkCullGuard)
     bool overlapShadow = false;  // PG_OVERLAP_SHADOW=1: any-hit launch on a second stream beside the closest-hit launch (per-kernel times then overlap)
     // test-path buffers
     DeviceBuffer tO, tD, tT, tPrim, tHit, tOcc, tCount;
@@ -213,6 +214,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         if (const char *e = getenv("PG_TRACE_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) tc.refillAt = v; }
         if (const char *e = getenv("PG_TRACE_GRID")) { int v = atoi(e); if (v >= 8) tc.gridBlocks = v; }
         if (const char *e = getenv("PG_TRACE_TRIW")) { int v = atoi(e); if (v >= 0) tc.triW = v; }
+        if (const char *e = getenv("PG_TRACE_MAXACC")) { int v = atoi(e); if (v >= 1 && v <= 4096) tc.maxAccepted = v; }  // tests: provoke the exact fallback
         if (const char *e = getenv("PG_TRACE_CULLK")) { float v = (float)atof(e); if (v >= 1.f) tc.cullK = v < 3e38f ? v : 3e38f; }  // finite: 0*inf would be NaN
         set_trace_config(tc);
     }
@@ -633,10 +635,35 @@ static int checkCullGuard(PgScene *s) {
     HIP_TRY(hipMemcpy(&g, s->cullGuard.p, sizeof(int), hipMemcpyDeviceToHost));
     if (g) {
         HIP_TRY(hipMemset(s->cullGuard.p, 0, sizeof(int)));
-        return setError(PG_ERR_OVERFLOW, "a ray accepted more than 4096 successive hits: the far-child cull margin is no longer provably exact; "
-                                         "set PG_TRACE_CULLK=inf to disable the margin");
+        s->cullTripped = true;  // the entry points then repeat the call without the margin (exact by construction, slower)
+        return setError(PG_ERR_OVERFLOW, "a ray accepted more than 4096 successive hits: the far-child cull margin is no longer provably exact");
     }
     return PG_OK;
+}
+// Runs `call`; if a ray outran the early-cull margin's proof (sorted stacks of alpha cards can do that), runs it again with the
+// margin disabled -- every far child then waits on the stack for the reference's own test at pop time -- with the counters put
+// back to where they were, so the result and its statistics are those of one exact pass.
+static int withExactFallback(PgScene *s, const std::function<int()> &call) {
+    const PgCounters saved = s->counters;
+    TraceCounters savedDev[2];
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemcpy(savedDev, s->traceCn.p, sizeof(savedDev), hipMemcpyDeviceToHost));
+    unsigned long long savedLt = 0;
+    HIP_TRY(hipMemcpy(&savedLt, s->lightTests.p, sizeof(savedLt), hipMemcpyDeviceToHost));
+    s->cullTripped = false;
+    int st = call();
+    if (st != PG_ERR_OVERFLOW || !s->cullTripped) return st;
+    s->counters = saved;
+    HIP_TRY(hipMemcpy(s->traceCn.p, savedDev, sizeof(savedDev), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->lightTests.p, &savedLt, sizeof(savedLt), hipMemcpyHostToDevice));
+    const TraceConfig cfg = get_trace_config();
+    TraceConfig exact = cfg;
+    exact.cullK = 3e38f;
+    set_trace_config(exact);
+    s->cullTripped = false;
+    st = call();
+    set_trace_config(cfg);
+    return st;
 }
 
 static int tileCount(const PgRenderDesc *rd) {
@@ -686,9 +713,15 @@ static hipEvent_t getEvent(PgScene *s, size_t idx) {
     return s->events[idx];
 }
 
+static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySample *strays, int32_t maxStrays, int32_t *nStrays, int mem,
+                       void *streamPtr);
 int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySample *strays, int32_t maxStrays, int32_t *nStrays,
               int mem, void *streamPtr) {
     if (!s || !rd || !film || !nStrays || (maxStrays > 0 && !strays)) return setError(PG_ERR_INVALID, "pg_render: null argument");
+    return withExactFallback(s, [&]() { return renderFrame(s, rd, film, strays, maxStrays, nStrays, mem, streamPtr); });
+}
+static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySample *strays, int32_t maxStrays, int32_t *nStrays, int mem,
+                       void *streamPtr) {
     if (rd->abi_version != PG_ABI_VERSION) return setError(PG_ERR_INVALID, "ABI version %d, expected %d", rd->abi_version, PG_ABI_VERSION);
     if (rd->filter_radius[0] <= 0 || rd->filter_radius[1] <= 0) return setError(PG_ERR_INVALID, "pg_render: filter radius must be positive");
     if (!rd->filter_general && (rd->filter_radius[0] > 0.5f || rd->filter_radius[1] > 0.5f || rd->tile_pixels != 256))
@@ -1182,10 +1215,16 @@ static RayQueue testQueue(PgScene *s, int n) {
     return q;
 }
 
+static int intersectBatch(PgScene *s, int32_t n, const float *o, const float *d, const float *tmax, int32_t *prim, float *t, float *bary, int mem,
+                          void *streamPtr);
 int pg_intersect(PgScene *s, int32_t n, const float *o, const float *d, const float *tmax, int32_t *prim, float *t, float *bary, int mem,
                  void *streamPtr) {
     if (!s || n < 0 || (n > 0 && (!o || !d || !tmax || !prim || !t || !bary))) return setError(PG_ERR_INVALID, "pg_intersect: null argument");
     if (n == 0) return PG_OK;
+    return withExactFallback(s, [&]() { return intersectBatch(s, n, o, d, tmax, prim, t, bary, mem, streamPtr); });
+}
+static int intersectBatch(PgScene *s, int32_t n, const float *o, const float *d, const float *tmax, int32_t *prim, float *t, float *bary, int mem,
+                          void *streamPtr) {
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t stream = (hipStream_t)streamPtr;
     int st = uploadRays(s, n, o, d, tmax, mem, stream);

@@ -168,7 +168,8 @@ struct TraceCounters {
 // Tunables of k_trace: LDS stack entries per lane, rays per wave segment, idle-lane count that triggers a refill.
 // cullK: closest-hit far-child early-cull margin (pg_traverse.hip); exact while a ray's tMax never grows by more than
 // this factor through rounding (each accepted hit can raise it by <= 3 roundings, i.e. ~5000 successive raises).
-struct TraceConfig { int depth, segRays /* rays per chunk */, refillAt, triW; float cullK; int gridBlocks; };
+// maxAccepted: accepted hits per ray beyond which the margin's proof no longer holds (<= 4096 for cullK = 1 + 2^-10)
+struct TraceConfig { int depth, segRays /* rays per chunk */, refillAt, triW; float cullK; int gridBlocks; int maxAccepted; };
 void set_trace_config(const TraceConfig &c);
 TraceConfig get_trace_config();
 void launch_closest(const DScene &sc, RayQueue q, float4 *hits, float *tOut, TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s);

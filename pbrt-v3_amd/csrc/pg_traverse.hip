@@ -79,7 +79,7 @@ template <bool ANYHIT, bool XPRIM>
 __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(DScene sc, RayQueue q0, RayQueue q1, float4 *__restrict__ hits,
                                                     int hitOffset1, float *__restrict__ tOut, int *__restrict__ occluded,
                                                     TraceCounters *cn, int *__restrict__ cursors, int depth, int chunk, int refillAt, int triW,
-                                                    float cullK, int *cullGuard) {
+                                                    float cullK, int *cullGuard, int maxAccepted) {
     extern __shared__ uint2 ldsStack[];  // [depth][TR_BLOCK]
     uint2 spill[TR_STACK_TOTAL];
     const int tid = threadIdx.x;
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
                         else {
                             tMax = t; hb0 = b0; hb1 = b1; hb2 = b2;  // primitive.cpp:123: r.tMax = tHit
                             if (XPRIM) { hitInstCur = inInst; instHit = true; }
-                            if (++nAccepted == TR_MAX_ACCEPTED) atomicOr(cullGuard, 1);
+                            if (++nAccepted == maxAccepted) atomicOr(cullGuard, 1);
                         }
                     }
                     if (triLeft == 0 && !(ANYHIT && hitPrim >= 0)) { TR_POP(); TR_SETTLE(); }
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
 #endif
 }
 
-static TraceConfig g_cfg = {11, 128, 16, 8, 1.0009765625f, 2048};  // depth 11: 7 resident blocks x 22.5 KB of stack fill the 160 KB LDS
+static TraceConfig g_cfg = {11, 128, 16, 8, 1.0009765625f, 2048, TR_MAX_ACCEPTED};  // depth 11: 7 resident blocks x 22.5 KB of stack fill the 160 KB LDS
 void set_trace_config(const TraceConfig &c) { g_cfg = c; }
 TraceConfig get_trace_config() { return g_cfg; }
 
@@ -388,10 +388,10 @@ static void launch_trace(const DScene &sc, RayQueue q0, RayQueue q1, float4 *hit
     // scenes without spheres and object instances run the triangle-only instantiation
     if (sc.nSpheres > 0 || sc.nInstances > 0 || sc.hasAlpha)
         hipLaunchKernelGGL((k_trace<ANYHIT, true>), dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q0, q1, hits, hitOffset1, tOut, occluded, cn, cursors,
-                           c.depth, c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard);
+                           c.depth, c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard, c.maxAccepted);
     else
         hipLaunchKernelGGL((k_trace<ANYHIT, false>), dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q0, q1, hits, hitOffset1, tOut, occluded, cn, cursors,
-                           c.depth, c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard);
+                           c.depth, c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard, c.maxAccepted);
 }
 static RayQueue noQueue() { RayQueue q; q.o = q.d = nullptr; q.counts = nullptr; q.regionCap = 0; return q; }
 void launch_closest(const DScene &sc, RayQueue q, float4 *hits, float *tOut, TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s) {

@@ -451,3 +451,31 @@ def test_sparse_light_tables_equal_dense(gpu, name, monkeypatch):
         for k in ("camera_rays", "closest_rays", "shadow_rays", "tri_tests", "node_visits"):
             assert cn[k] == c2[k], (name, frame, k)
     sparse.close()
+
+
+def test_exact_fallback_when_a_ray_outruns_the_cull_margin(gpu, oracle, monkeypatch):
+    """k_trace culls far children early with a margin that is provably exact for up to 4096 accepted hits per ray; a ray
+    that accepts more raises a guard and the call is repeated without the margin.  PG_TRACE_MAXACC=1 makes nearly every ray
+    raise it: film, hits and the reference's counters (incl. node visits) must still equal the oracle's bit for bit."""
+    monkeypatch.setenv("PG_TRACE_MAXACC", "1")
+    scene = gpu.HostScene(os.path.join(GOLD, "synthetic_n40.pbrt"))
+    gs = gpu.GpuScene(scene.desc)
+    rd = scene.render_desc()
+    film, strays = gs.render(rd)
+    cn = gs.counters()
+    ofilm, ostrays, ocn = oracle.render(scene.desc, rd, cr_libm=True)
+    assert np.array_equal(film["rgb"], ofilm["rgb"]) and np.array_equal(film["weight"], ofilm["weight"])
+    for k in ("camera_rays", "closest_rays", "shadow_rays", "tri_tests", "node_visits"):
+        assert cn[k] == ocn[k], k
+    rng = np.random.default_rng(5)
+    nodes = scene.nodes()
+    lo, hi = nodes["bmin"][0], nodes["bmax"][0]
+    o = (lo + (hi - lo) * rng.random((4096, 3))).astype(np.float32)
+    d = rng.normal(size=(4096, 3)).astype(np.float32)
+    inf = np.full(4096, np.inf, np.float32)
+    gs.counters_reset()
+    prim, t, bary = gs.intersect(o, d, inf)
+    op, ot, ob, oc = oracle.intersect(scene.desc, o, d, inf)
+    assert np.array_equal(prim, op) and np.array_equal(t, ot) and np.array_equal(bary, ob)
+    assert gs.counters()["closest_node_visits"] == oc["node_visits"]
+    gs.close()
