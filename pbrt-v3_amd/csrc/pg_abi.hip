@@ -68,6 +68,7 @@ struct PgScene {
     int nMedia = 0;
     DeviceBuffer vqo[2], vqd[2], vCounts, volMedium, trAcc[2], volP1[3], misLi, pdLi, hitT;
     DeviceBuffer qsL[2], qsBeta[2], qsMeta[2];  // PathIntegrator: path state in queue order
+    DeviceBuffer lightHot;  // DScene::lightHot
     DeviceBuffer cmaxmin, tsState, ts1, ts2;  // tile-serial samplers: CMaxMinDist, the tiles' sampler states and sample arrays
     DeviceBuffer voxelSlot, voxelRequests, voxelCounters, retryList;  // sparse "spatial" light tables (DScene::sparseLights)
     int poolSlots = 0, poolUsed = 0, nVoxelsTotal = 0;
@@ -423,6 +424,19 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     if (desc->n_materials) HIP_TRY_S(hipMemcpy(s->materials.p, devMaterials.data(), s->materials.bytes, hipMemcpyHostToDevice));
     HIP_TRY_S(s->lights.alloc(sizeof(PgLight) * (size_t)desc->n_lights));
     if (desc->n_lights) HIP_TRY_S(hipMemcpy(s->lights.p, desc->lights, s->lights.bytes, hipMemcpyHostToDevice));
+    {   // DScene::lightHot
+        std::vector<float4> hot((size_t)desc->n_lights * 5, make_float4(0, 0, 0, 0));
+        for (int l = 0; l < desc->n_lights; ++l) {
+            const PgLight &L = desc->lights[l];
+            float ti, pi_, si;
+            memcpy(&ti, &L.type, 4); memcpy(&pi_, &L.prim, 4); memcpy(&si, &L.two_sided, 4);
+            hot[5 * (size_t)l] = make_float4(ti, pi_, si, L.area);
+            hot[5 * (size_t)l + 1] = make_float4(L.L[0], L.L[1], L.L[2], 0.f);
+            if (L.type == PG_LIGHT_AREA && L.prim >= 0 && L.prim < nt) for (int k = 0; k < 3; ++k) hot[5 * (size_t)l + 2 + k] = tris[3 * (size_t)L.prim + k];
+        }
+        HIP_TRY_S(s->lightHot.alloc(sizeof(float4) * hot.size()));
+        if (!hot.empty()) HIP_TRY_S(hipMemcpy(s->lightHot.p, hot.data(), s->lightHot.bytes, hipMemcpyHostToDevice));
+    }
     // --- Halton tables
     // (a scene rendered with the Sobol' sampler only may come without one: pg_render then refuses sampler = halton)
     const bool haltonTable = !(desc->n_perm_dims == 0 && desc->sobol_matrices);
@@ -522,6 +536,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     d.nNodes = desc->n_nodes; d.nTris = nt; d.nLights = desc->n_lights; d.nMaterials = desc->n_materials;
     d.perms = (const uint16_t *)s->perms.p; d.permSums = (const int32_t *)s->permSums.p; d.primes = (const int32_t *)s->primes.p;
     d.nPermDims = desc->n_perm_dims;
+    d.lightHot = (const float4 *)s->lightHot.p;
     d.cmaxmin = (const uint32_t *)s->cmaxmin.p;
     d.lightStrategy = desc->light_strategy;
     // --- light sampling distributions (lightdistrib.cpp)
@@ -971,8 +986,11 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                     // The shadow rays of this bounce and the closest-hit rays of the next depend only on shade(b): the any-hit
                     // launch goes to a second stream so that its blocks fill the chip while the closest-hit launch's
                     // persistent waves drain (and vice versa); resolve(b) joins both.
-                    hipStream_t sst = s->overlapShadow ? s->shadowStream : stream;
-                    if (s->overlapShadow) {
+                    // (tile-serial samplers: a handful of rays per launch, each a chain of dependent fetches -- both launches are
+                    // latency-bound and run side by side)
+                    const bool overlap = s->overlapShadow || tileSerial;
+                    hipStream_t sst = overlap ? s->shadowStream : stream;
+                    if (overlap) {
                         HIP_TRY(hipEventRecord(s->evShaded, stream));
                         HIP_TRY(hipStreamWaitEvent(sst, s->evShaded, 0));
                     }
@@ -981,9 +999,9 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                     launch_anyhit(s->d, q[2], (int *)s->occluded.p, cnShadow, (int *)s->cursors2.p, sst);
                     if (timing) HIP_TRY(hipEventRecord(b, sst));
                     ++shadowLaunches;
-                    if (s->overlapShadow) HIP_TRY(hipEventRecord(s->evShadowed, sst));
+                    if (overlap) HIP_TRY(hipEventRecord(s->evShadowed, sst));
                     if (int e = timedClosest(q[nxt], (float4 *)s->hitsMain.p, &q[3], hitsMis)) return e;
-                    if (s->overlapShadow) HIP_TRY(hipStreamWaitEvent(stream, s->evShadowed, 0));
+                    if (overlap) HIP_TRY(hipStreamWaitEvent(stream, s->evShadowed, 0));
                     PG_TIMED(3, stream, launch_resolve(s->d, ps, q[cur], q[3], (const int *)s->occluded.p, (const float4 *)hitsMis, stream, cur));
                     ++resolveLaunches;
                 }

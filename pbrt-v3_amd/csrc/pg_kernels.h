@@ -44,6 +44,10 @@ struct DScene {
     const float *uv;  // 6 floats per triangle, or nullptr when no mesh has uv (default uv, triangle.h:104-106)
     const PgMaterial *materials;
     const PgLight *lights;
+    // what the shading kernel needs of a light the moment it is chosen, 80 B per light, read in ONE round trip: h[0] = (type,
+    // prim, two_sided, area), h[1] = (L.rgb, 0), h[2..4] = an area light's primitive record (tris[3 prim ..]) -- instead of
+    // PgLight fields, then the emitter's index, then its vertices, each a dependent access
+    const float4 *lightHot;
     int nNodes, nTris, nLights, nMaterials;
     const PgSphere *spheres;  // Shape "sphere" primitives: tris[3*k] = (sphere index, 0, 0, flags | PG_PRIM_SPHERE)
     int nSpheres;

@@ -1440,6 +1440,33 @@ PG_DEV LightSample quadric_sample_area(const PgSphere &s, float u0, float u1, fl
     return it;
 }
 
+// Triangle::Sample(u, pdf), triangle.cpp:582-607 with UniformSampleTriangle, sampling.cpp:154-157
+PG_DEV LightSample tri_sample_area(const DScene &sc, const Tri &t, int prim, float area, float u0, float u1, float &pdf) {
+    LightSample ls;
+    float su0 = sqrtf(u0);
+    float b0 = 1 - su0, b1 = u1 * su0;
+    float b2 = (1 - b0 - b1);
+    ls.p = t.p0 * b0 + t.p1 * b1 + t.p2 * b2;
+    ls.n = normalize(cross(t.p1 - t.p0, t.p2 - t.p0));
+    if (sc.triN && (t.flags & PG_TRI_HAS_N)) {  // triangle.cpp:593-597: orientation follows the shading normal
+        V3 ns = tri_interp(sc.triN, prim, b0, b1, b2);
+        if (dot(ls.n, ns) < 0.f) ls.n = -ls.n;
+    } else if (t.flags & PG_TRI_FLIP_NORMAL) ls.n = ls.n * -1.f;
+    V3 pAbsSum = vabs(t.p0 * b0) + vabs(t.p1 * b1) + vabs(t.p2 * b2);
+    ls.pError = pAbsSum * pgamma(6);
+    pdf = 1 / area;
+    return ls;
+}
+// Shape::Sample(ref, u, pdf), shape.cpp:56-70: the area sample's pdf with respect to solid angle at refp
+PG_DEV void area_to_solid_angle(V3 refp, const LightSample &ls, float &pdf) {
+    V3 w = ls.p - refp;
+    if (lensq(w) == 0) pdf = 0;
+    else {
+        w = normalize(w);
+        pdf *= lensq(refp - ls.p) / absdot(ls.n, -w);
+        if (isinf(pdf)) pdf = 0.f;
+    }
+}
 // ---- InfiniteAreaLight with constant radiance: Lmap is a 1x1 MIPMap (lights/infinite.cpp, core/mipmap.h:245-274).
 // sinf/cosf/acosf/atan2f of the reference (glibc) are matched by evaluating in double and rounding once.
 PG_DEV V3 mat3_mul(const float *m, V3 w) {  // Transform::operator()(Vector3), transform.h:233-239
@@ -1550,31 +1577,36 @@ PG_DEV Spec light_sample_li(const DScene &sc, const PgLight &light, V3 refp, V3 
         ls = sphere_sample(sc.spheres[__float_as_int(t.p0.x)], refp, refErr, refn, u0, u1, pdf);
     else {
         if (quadric) ls = quadric_sample_area(sc.spheres[__float_as_int(t.p0.x)], u0, u1, pdf);
-        else {
-            float su0 = sqrtf(u0);  // UniformSampleTriangle, sampling.cpp:154-157
-            float b0 = 1 - su0, b1 = u1 * su0;
-            float b2 = (1 - b0 - b1);
-            ls.p = t.p0 * b0 + t.p1 * b1 + t.p2 * b2;
-            ls.n = normalize(cross(t.p1 - t.p0, t.p2 - t.p0));
-            if (sc.triN && (t.flags & PG_TRI_HAS_N)) {  // triangle.cpp:593-597: orientation follows the shading normal
-                V3 ns = tri_interp(sc.triN, light.prim, b0, b1, b2);
-                if (dot(ls.n, ns) < 0.f) ls.n = -ls.n;
-            } else if (t.flags & PG_TRI_FLIP_NORMAL) ls.n = ls.n * -1.f;
-            V3 pAbsSum = vabs(t.p0 * b0) + vabs(t.p1 * b1) + vabs(t.p2 * b2);
-            ls.pError = pAbsSum * pgamma(6);
-            pdf = 1 / light.area;
-        }
-        V3 w = ls.p - refp;  // Shape::Sample(ref, u, pdf), shape.cpp:56-70
-        if (lensq(w) == 0) pdf = 0;
-        else {
-            w = normalize(w);
-            pdf *= lensq(refp - ls.p) / absdot(ls.n, -w);
-            if (isinf(pdf)) pdf = 0.f;
-        }
+        else ls = tri_sample_area(sc, t, light.prim, light.area, u0, u1, pdf);
+        area_to_solid_angle(refp, ls, pdf);
     }
     if (pdf == 0 || lensq(ls.p - refp) == 0) { pdf = 0; return sp(0); }
     wi = normalize(ls.p - refp);
     return (light.two_sided || dot(ls.n, -wi) > 0) ? sp3(light.L[0], light.L[1], light.L[2]) : sp(0);
+}
+// The light as the shading kernel first meets it: DScene::lightHot's record, fetched in one round trip.
+struct LightHot { int type, prim, two_sided; float area; Spec L; Tri tri; };
+PG_DEV LightHot load_light_hot(const DScene &sc, int lightNum) {
+    const float4 *h = sc.lightHot + 5 * (size_t)lightNum;
+    const float4 h0 = h[0], h1 = h[1], a = h[2], b = h[3], c = h[4];
+    LightHot lh;
+    lh.type = __float_as_int(h0.x); lh.prim = __float_as_int(h0.y); lh.two_sided = __float_as_int(h0.z); lh.area = h0.w;
+    lh.L = sp3(h1.x, h1.y, h1.z);
+    lh.tri.p0 = mk(a.x, a.y, a.z); lh.tri.p1 = mk(b.x, b.y, b.z); lh.tri.p2 = mk(c.x, c.y, c.z);
+    lh.tri.flags = __float_as_uint(a.w); lh.tri.material = __float_as_int(b.w); lh.tri.light = __float_as_int(c.w);
+    return lh;
+}
+// light_sample_li for a light whose hot record is at hand: a diffuse area light on a triangle -- the common case -- is sampled
+// from the record alone; everything else goes through the general routine (same arithmetic either way)
+template <bool EXT>
+PG_DEV Spec light_sample_li_hot(const DScene &sc, const LightHot &lh, const PgLight &light, V3 refp, V3 refErr, V3 refn, float u0, float u1, V3 &wi,
+                                float &pdf, LightSample &ls) {
+    if (lh.type != PG_LIGHT_AREA || (lh.tri.flags & PG_PRIM_SPHERE)) return light_sample_li<EXT>(sc, light, refp, refErr, refn, u0, u1, wi, pdf, ls);
+    ls = tri_sample_area(sc, lh.tri, lh.prim, lh.area, u0, u1, pdf);
+    area_to_solid_angle(refp, ls, pdf);
+    if (pdf == 0 || lensq(ls.p - refp) == 0) { pdf = 0; return sp(0); }
+    wi = normalize(ls.p - refp);
+    return (lh.two_sided || dot(ls.n, -wi) > 0) ? lh.L : sp(0);
 }
 
 // LightDistribution::Lookup (lightdistrib.cpp:68-82,135-149) -> table of one Distribution1D
@@ -1669,7 +1701,8 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_shade(DScene sc, RenderParam
         i = j < rp.retryCount ? rp.retryList[j] : -1;
     } else i = queue_item<PG_SHADE_BLOCK>(qin);
     bool deferred = false;  // sparse light tables: this vertex met a voxel without a distribution; nothing is committed
-    TileSamplerState tsSavedOuter = {};
+    unsigned long long tsState0 = 0;  // tile-serial samplers: the tile's stream position and dimension counters on entry
+    int tsCur1D0 = 0, tsCur2D0 = 0;
     const bool valid = i >= 0;
     // Output rays are staged in LDS ([queue][o|d][thread]) the moment they are known and copied to their queues after the
     // block-wide append at the end: holding three rays plus the pending direct-light terms in registers until then had
@@ -1709,7 +1742,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_shade(DScene sc, RenderParam
         // Sampler::Get1D / Get2D in the order the reference calls them: a GlobalSampler (halton, sobol) is indexed by
         // (sample index, dimension); the tile-serial samplers advance their tile's state (slot = tile, one path per tile)
         const bool tileSerial = rd.sampler >= PG_SAMPLER_RANDOM;
-        if (tileSerial) tsSavedOuter = sc.ts[slot];  // restored if this vertex is deferred (sparse light tables)
+        if (tileSerial) { tsState0 = sc.ts[slot].state; tsCur1D0 = sc.ts[slot].cur1D; tsCur2D0 = sc.ts[slot].cur2D; }  // restored if this vertex is deferred (sparse light tables)
         auto draw1 = [&]() -> float { return tileSerial ? ts_get1d(sc, slot) : halton_sample(sc, rd, index, dim++); };
         auto draw2 = [&](float &a, float &b) {
             if (tileSerial) ts_get2d(sc, rd.sampler, slot, a, b);
@@ -1750,6 +1783,9 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_shade(DScene sc, RenderParam
         }
         Tri tri;
         if (found) tri = load_tri(sc, prim);
+        // the hit's material record, fetched as soon as its index is known (one round trip, overlapped with the interaction's
+        // arithmetic) instead of field by field where each is used
+        const PgMaterial mtl = sc.materials[found ? tri.material : 0];
         Isect is;
         float sphU = 0, sphV = 0;  // MODE 2: a quadric hit's (u, v) and geometric dpdu / dpdv, for textures
         V3 sphDpdu = mk(0, 0, 0), sphDpdv = mk(0, 0, 0);
@@ -1876,7 +1912,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_shade(DScene sc, RenderParam
                 if (dot(w.ns, w.n) < 0.f) w.ns = -w.ns;  // Faceforward(shading.n, n)
                 is = w;
             }
-            const PgMaterial &m = sc.materials[tri.material];
+            const PgMaterial &m = mtl;
             int mIn = 0, mOut = 0;  // VOL: isect.mediumInterface
             if constexpr (VOL) prim_interface(sc, prim, med, mIn, mOut);
             if (m.type == PG_MAT_NONE) {  // path.cpp:107-113: skip over medium boundaries
@@ -2028,12 +2064,13 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_shade(DScene sc, RenderParam
                         float uL0, uL1, uS0, uS1;  // uLight, uScattering (integrator.cpp:101-102)
                         draw2(uL0, uL1);
                         draw2(uS0, uS1);
+                        const LightHot lh = load_light_hot(sc, lightNum);
                         const PgLight &light = sc.lights[lightNum];
                         V3 wi = mk(0, 0, 0);
                         float lightPdf = 0, scatteringPdf = 0;
                         float4 pdLight = make_float4(0, 0, 0, 0);
                         LightSample ls;
-                        Spec Li = light_sample_li<EXT>(sc, light, is.p, is.pError, is.n, uL0, uL1, wi, lightPdf, ls);
+                        Spec Li = light_sample_li_hot<EXT>(sc, lh, light, is.p, is.pError, is.n, uL0, uL1, wi, lightPdf, ls);
                         if (lightPdf > 0 && !is_black(Li)) {
                             Spec f;
                             if constexpr (EXT) { f = lbsdf_f(lb, is.wo, wi, nonSpecular) * absdot(wi, shNs); scatteringPdf = lbsdf_pdf(lb, is.wo, wi, nonSpecular); }
@@ -2047,7 +2084,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_shade(DScene sc, RenderParam
                                 s_ray[1][1][tid] = make_float4(shD.x, shD.y, shD.z, __int_as_float(slot));
                                 pushShadow = true;
                                 // delta lights take no MIS weight (integrator.cpp:155-160)
-                                const bool isDelta = PG_LIGHT_IS_DELTA(light.type);
+                                const bool isDelta = PG_LIGHT_IS_DELTA(lh.type);
                                 if constexpr (VOL) {  // Li still is to be multiplied by VisibilityTester::Tr (integrator.cpp:146-150): keep the factors apart
                                     volWeight = isDelta ? -1.f : power_heuristic(1, lightPdf, 1, scatteringPdf);
                                     pdLight = make_float4(f.r, f.g, f.b, 0);
@@ -2066,7 +2103,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_shade(DScene sc, RenderParam
                         V3 wi2 = wi;
                         float sPdf2 = 0;
                         Spec f2 = sp(0);
-                        if (light.type == PG_LIGHT_AREA || (EXT && light.type == PG_LIGHT_INFINITE)) {  // integrator.cpp:164: if (!IsDeltaLight(light.flags))
+                        if (lh.type == PG_LIGHT_AREA || (EXT && lh.type == PG_LIGHT_INFINITE)) {  // integrator.cpp:164: if (!IsDeltaLight(light.flags))
                             if constexpr (EXT) { int st2; f2 = lbsdf_sample_f(lb, is.wo, wi2, uS0, uS1, sPdf2, nonSpecular, st2); }
                             else f2 = bsdf_sample_f(bsdf, is.wo, wi2, uS0, uS1, sPdf2);
                             f2 = f2 * absdot(wi2, shNs);
@@ -2076,12 +2113,10 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_shade(DScene sc, RenderParam
                             spawn_ray(is, wi2, misRo);
                             misWi = wi2; misF = f2; misPdf = sPdf2; misP = is.p;
                             if constexpr (VOL) misMedium = dot(wi2, is.n) > 0 ? mOut : mIn;
-                            misLightPrim = (EXT && light.type == PG_LIGHT_INFINITE) ? -1 - lightNum : light.prim; misLightArea = light.area;
-                            if (EXT && light.type == PG_LIGHT_AREA) {
-                                const float4 la = sc.tris[3 * light.prim];
-                                if (__float_as_uint(la.w) & PG_PRIM_SPHERE)  // only the sphere overrides Shape::Pdf (with its cone pdf, from outside)
-                                    misInside = sc.spheres[__float_as_int(la.x)].shape != PG_SHAPE_SPHERE ||
-                                                sphere_ref_inside(sc.spheres[__float_as_int(la.x)], is.p, is.pError, is.n);
+                            misLightPrim = (EXT && lh.type == PG_LIGHT_INFINITE) ? -1 - lightNum : lh.prim; misLightArea = lh.area;
+                            if (EXT && lh.type == PG_LIGHT_AREA && (lh.tri.flags & PG_PRIM_SPHERE)) {  // only the sphere overrides Shape::Pdf (with its cone pdf, from outside)
+                                const PgSphere &lsph = sc.spheres[__float_as_int(lh.tri.p0.x)];
+                                misInside = lsph.shape != PG_SHAPE_SPHERE || sphere_ref_inside(lsph, is.p, is.pError, is.n);
                             }
                         }
                         // pending terms of this vertex, consumed by k_resolve (pdMis and the MIS weight follow below)
@@ -2136,7 +2171,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_shade(DScene sc, RenderParam
     }
     if (deferred) {  // retried once the voxel's distribution exists: no ray, no state, no pending term leaves this launch
         pushNext = pushShadow = misCand = false;
-        if (rp.rd.sampler >= PG_SAMPLER_RANDOM) sc.ts[slot] = tsSavedOuter;  // nor a draw from the tile's stream
+        if (rp.rd.sampler >= PG_SAMPLER_RANDOM) { sc.ts[slot].state = tsState0; sc.ts[slot].cur1D = tsCur1D0; sc.ts[slot].cur2D = tsCur2D0; }  // nor a draw from the tile's stream
         rp.retryList[atomicAdd(&sc.voxelCounters[1], 1)] = i;
     }
     if (misCand) {

@@ -60,7 +60,9 @@ def reference_render(path, out_pfm):
     t0 = time.time()
     out = subprocess.run([ref, "--nthreads", str(os.cpu_count() or 1), "--outfile", out_pfm, path], capture_output=True, text=True, check=True).stdout
     wall = time.time() - t0
-    stat = lambda pat: int(re.search(pat + r"\s+(\d+)", out).group(1))
+    def stat(pat):  # a counter that stayed 0 is not printed (core/stats.cpp)
+        m = re.search(pat + r"\s+(\d+)", out)
+        return int(m.group(1)) if m else 0
     cn = {"camera_rays": stat(r"Camera rays traced"), "closest_rays": stat(r"Regular ray intersection tests"),
           "shadow_rays": stat(r"Shadow ray intersection tests")}
     m = re.search(r"Ray-triangle intersection tests\s+(\d+) /\s+(\d+)", out)
@@ -86,13 +88,17 @@ def run(config):
         rcn, ref_render_s, ref_wall_s = reference_render(path, ref_pfm)
         ref = pkg.read_pfm(ref_pfm)
     assert ref.shape == img.shape, (ref.shape, img.shape)
-    if window:  # the reference writes the cropped image only when cropwindow is set; pixelbounds leaves the rest black in both
-        x0, y0, x1, y1 = window
-        img_w, ref_w = img[y0:y1, x0:x1], ref[y0:y1, x0:x1]
-        outside_black = bool((np.delete(img.reshape(-1, 3), np.ravel_multi_index(np.mgrid[y0:y1, x0:x1].reshape(2, -1), img.shape[:2]), axis=0) == 0).all())
+    # "pixelbounds" restricts the pixels that are SAMPLED; both renderers write the whole frame, black outside the window but for
+    # the rim a box-filter sample with offset 0 reaches (film.h:127-132).  The comparison is over the whole frame.
+    x0 = y0 = 0
+    img_w, ref_w = img, ref
+    if window:
+        wx0, wy0, wx1, wy1 = window
+        mask = np.ones(img.shape[:2], bool)
+        mask[max(0, wy0 - 1):wy1 + 1, max(0, wx0 - 1):wx1 + 1] = False
+        outside_black = bool((img[mask] == 0).all() and (ref[mask] == 0).all())
     else:
-        x0 = y0 = 0
-        img_w, ref_w, outside_black = img, ref, True
+        outside_black = True
     err = (np.abs(img_w - ref_w) / np.maximum(1.0, np.abs(ref_w))).max(axis=2)
     bad = np.argwhere(err > TOL)
     # every out-of-tolerance pixel, alone, by the CPU oracle with correctly rounded libm: it must equal the device's pixel
@@ -110,6 +116,7 @@ def run(config):
             explained += 1
     out = {"config": config, "triangles": int(scene.desc.n_tris), "integrator": "volpath" if config == 5 else "path",
            "frame": f"{img.shape[1]}x{img.shape[0]}", "spp": int(rd.spp), "compared_pixels": int(err.size),
+           "sampled_pixels": int((window[2] - window[0]) * (window[3] - window[1])) if window else int(err.size),
            "window": list(window) if window else None, "outside_window_black": outside_black,
            "max_rel_err": float(err.max()), "p9999_rel_err": float(np.percentile(err, 99.99)), "pixels_over_tol": int(len(bad)), "tol": TOL,
            "pixels_over_tol_reproduced_bitwise_by_cr_oracle": explained, "bit_identical_pixel_share": float((img_w == ref_w).all(axis=2).mean()),
