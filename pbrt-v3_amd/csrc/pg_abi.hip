@@ -674,6 +674,7 @@ static int withExactFallback(PgScene *s, const std::function<int()> &call) {
     const TraceConfig cfg = get_trace_config();
     TraceConfig exact = cfg;
     exact.cullK = 3e38f;
+    exact.maxAccepted = 0x7fffffff;  // nothing to guard: no far child is culled early any more
     set_trace_config(exact);
     s->cullTripped = false;
     st = call();
