@@ -1689,8 +1689,14 @@ PG_DEV void prim_interface(const DScene &sc, int prim, int rayMedium, int &mIn, 
     else mIn = mOut = rayMedium;
 }
 
+// PG_SHADE_MIN_WAVES: waves per SIMD the BxDF-list variants (MODE 1) are compiled for.  Left alone the volumetric one takes 177
+// VGPRs = 2 waves; capped at 168 (3 waves, 20 B of scratch) it is 31 % faster (150 -> 104 ms per frame on the 1 M-triangle volpath
+// workload, profiles/r02p_*); 4 waves (128 VGPRs, 200 B of scratch) lose most of that again.  The surface-only variant is at 3 already.
+#ifndef PG_SHADE_MIN_WAVES
+#define PG_SHADE_MIN_WAVES 3
+#endif
 template <int MODE, bool VOL>
-__global__ __launch_bounds__(PG_SHADE_BLOCK) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
+__global__ __launch_bounds__(PG_SHADE_BLOCK, (MODE == 1 && PG_SHADE_MIN_WAVES > 0) ? PG_SHADE_MIN_WAVES : 1) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
                                                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, VolState vs,
                                                      const float *__restrict__ hitT, QueueState qsIn, QueueState qsOut) {
     constexpr bool EXT = MODE >= 1, TEX = MODE == 2;
