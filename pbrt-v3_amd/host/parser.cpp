@@ -9,7 +9,11 @@
 #include <fstream>
 #include <functional>
 #include <memory>
+#include <chrono>
 #include <sstream>
+#include <thread>
+#include <vector>
+#include <algorithm>
 #include "api.h"
 #include "error.h"
 #include "paramset.h"
@@ -87,6 +91,66 @@ struct Tokenizer {
             }
             return contents.substr(start, pos - start);
         }
+    }
+    // The body of a bracketed array when it holds nothing but numbers -- the vertex and index lists of a mesh, hundreds of
+    // megabytes of text for the scenes this build is meant for.  Called right after the '[': if only number characters and
+    // white space lie before the matching ']', the span is cut at white space into one piece per thread, every piece is
+    // converted with the very calls the token-by-token path makes (parseNumber: strtol for digit strings, strtof otherwise, so
+    // every value rounds as in the reference), `pos` moves behind the ']' and true is returned.  Anything else (strings,
+    // comments, booleans, a malformed number) leaves the tokenizer untouched for the general path.
+    bool NumberArray(std::vector<double> *out) {
+        const char *base = contents.data();
+        const size_t n = contents.size();
+        size_t end = pos;
+        while (end < n && base[end] != ']') {
+            const unsigned char c = (unsigned char)base[end];
+            if (!((c >= '0' && c <= '9') || c == '.' || c == '-' || c == '+' || c == 'e' || c == 'E' || c == ' ' || c == '\n' || c == '\t' || c == '\r')) return false;
+            ++end;
+        }
+        if (end >= n || end - pos < (size_t)1 << 16) return false;  // short arrays: not worth the threads
+        int nThreads = PbrtOptions.nThreads > 0 ? PbrtOptions.nThreads : (int)std::thread::hardware_concurrency();
+        nThreads = std::max(1, std::min(nThreads, 64));
+        auto isSpace = [](char c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r'; };
+        std::vector<size_t> cut((size_t)nThreads + 1);
+        for (int t = 0; t <= nThreads; ++t) {
+            size_t c = pos + (end - pos) * (size_t)t / (size_t)nThreads;
+            while (c > pos && c < end && !isSpace(base[c])) ++c;  // pieces begin at white space (or at the array's ends)
+            cut[t] = c;
+        }
+        std::vector<std::vector<double>> part((size_t)nThreads);
+        std::vector<int> bad((size_t)nThreads, 0);
+        auto work = [&](int t) {
+            std::vector<double> &v = part[t];
+            v.reserve((cut[t + 1] - cut[t]) / 6 + 16);
+            const char *p = base + cut[t], *e = base + cut[t + 1];
+            while (p < e) {
+                if (isSpace(*p)) { ++p; continue; }
+                const char *q = p;
+                bool digits = true;
+                while (q < e && !isSpace(*q)) { if (*q < '0' || *q > '9') digits = false; ++q; }
+                char *stop = nullptr;
+                double val;
+                if (q - p == 1 && digits) val = *p - '0';
+                else if (digits) val = (double)strtol(p, &stop, 10);
+                else val = strtof(p, &stop);  // the token ends at white space or at the ']', which ends the conversion too
+                if (stop && stop != q) { bad[t] = 1; return; }  // not one well-formed number: let the general path report it
+                v.push_back(val);
+                p = q;
+            }
+        };
+        std::vector<std::thread> threads;
+        for (int t = 1; t < nThreads; ++t) threads.emplace_back(work, t);
+        work(0);
+        for (auto &th : threads) th.join();
+        for (int t = 0; t < nThreads; ++t) if (bad[t]) return false;
+        size_t total = 0;
+        for (auto &v : part) total += v.size();
+        out->reserve(out->size() + total);
+        for (auto &v : part) out->insert(out->end(), v.begin(), v.end());
+        for (size_t i = pos; i < end; ++i) if (base[i] == '\n') { ++loc.line; loc.column = 0; }
+        pos = end + 1;  // behind the ']'
+        if (getenv("PBRT_HOST_TIMING")) fprintf(stderr, "pbrt host: %zu numbers of a %.0f MB array converted on %d threads\n", total, (double)(end - (size_t)(base + cut[0] - base)) / 1e6, nThreads);
+        return true;
     }
 };
 
@@ -221,7 +285,9 @@ struct Parser {
             };
             std::string val = nextToken(true);
             if (val == "[") {
-                while (true) { val = nextToken(true); if (val == "]") break; addVal(val); }
+                // (a long, purely numeric array is converted by all threads at once; see Tokenizer::NumberArray)
+                if (!(!ungetSet && !fileStack.empty() && fileStack.back()->NumberArray(&nums)))
+                    while (true) { val = nextToken(true); if (val == "]") break; addVal(val); }
             } else addVal(val);
             addParam(ps, dequote(decl), nums, strs, isString);
         }
@@ -287,7 +353,18 @@ struct Parser {
             else if (tok == "PixelFilter") withParams(pbrtPixelFilter);
             else if (tok == "ReverseOrientation") pbrtReverseOrientation();
             else if (tok == "Rotate") { Float v[4]; for (int i = 0; i < 4; ++i) v[i] = num(); pbrtRotate(v[0], v[1], v[2], v[3]); }
-            else if (tok == "Shape") withParams(pbrtShape);
+            else if (tok == "Shape") {
+                const bool timing = getenv("PBRT_HOST_TIMING") != nullptr;
+                const auto t0 = std::chrono::steady_clock::now();
+                std::string n = dequote(nextToken(true));
+                ParamSet params = parseParams();
+                const auto t1 = std::chrono::steady_clock::now();
+                pbrtShape(n, params);
+                if (timing) {
+                    const double a = std::chrono::duration<double>(t1 - t0).count(), b = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+                    if (a + b > 0.05) fprintf(stderr, "pbrt host: Shape \"%s\": parameters %.3f s, creation %.3f s\n", n.c_str(), a, b);
+                }
+            }
             else if (tok == "Sampler") withParams(pbrtSampler);
             else if (tok == "Scale") { Float v[3]; for (int i = 0; i < 3; ++i) v[i] = num(); pbrtScale(v[0], v[1], v[2]); }
             else if (tok == "TransformBegin") pbrtTransformBegin();
