@@ -34,4 +34,5 @@ if [ "$MODE" = full ]; then
   ( timeout 900 python tools/fullsize_parity.py 4 5 --out=$OUT/fullsize_parity_config4_5.json > $OUT/fullsize_4_5.log 2>&1 ); tail -2 $OUT/fullsize_4_5.log | cut -c1-700
   ( timeout 600 python bench.py --steps 2 --warmup 1 --workload synthetic-vol --grid 2237 --spp 128 --no-cpu-baseline 2> $OUT/bench_10m_vol.err ) > $OUT/bench_10m_vol.json; cut -c1-400 $OUT/bench_10m_vol.json
   ( timeout 600 python tools/ts_timing.py 960 540 16 > $OUT/ts_timing.json 2> $OUT/ts_timing.err ); cat $OUT/ts_timing.json
+  ( timeout 300 python tools/shard_timing.py > $OUT/shard_timing.json 2> $OUT/shard_timing.err ); cat $OUT/shard_timing.json
 fi
