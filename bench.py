@@ -142,7 +142,10 @@ def main():
     # (PBRT_BENCH_OVERSUBSCRIBE=1) moves the film shards through gloo on host copies instead; a real run is RCCL over xGMI
     backend = "gloo" if os.environ.get("PBRT_BENCH_OVERSUBSCRIBE") == "1" else "nccl"
     comm_dev = dev if backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    # PBRT_BENCH_FORCE_DIST=1: run the collective path with however many ranks there are -- with ONE rank on a single-GPU box
+    # this is the only way to execute the RCCL transport (communicator, gather, all_reduce, barrier) before an 8-GPU run
+    multi = world > 1 or os.environ.get("PBRT_BENCH_FORCE_DIST") == "1"
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
@@ -162,16 +165,16 @@ def main():
     from pbrt_v3_amd import distributed as pdist
     film, strays, nstrays, max_strays = pdist.shard_buffers(max_tiles, dev, rd.tile_pixels)
     to_comm = (lambda t: t) if backend == "nccl" else (lambda t: t.cpu())
-    gathered = [pdist.gather_lists(to_comm(film), to_comm(strays), to_comm(nstrays)) if world > 1 else None]
+    gathered = [pdist.gather_lists(to_comm(film), to_comm(strays), to_comm(nstrays)) if multi else None]
 
     def step():
         stream = torch.cuda.current_stream().cuda_stream
         gs.render_device(rd, film.data_ptr(), strays.data_ptr(), max_strays, nstrays.data_ptr(), stream=stream)
-        if world > 1:  # Film gather over xGMI: every rank's packed tile buffer to rank 0
+        if multi:  # Film gather over xGMI: every rank's packed tile buffer to rank 0
             pdist.gather_film(to_comm(film), to_comm(strays), to_comm(nstrays), lists=gathered[0], dst=0)
 
     def sync():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -186,7 +189,7 @@ def main():
     elapsed = time.perf_counter() - t0
     cn = gs.counters()
     stats = torch.tensor([elapsed, float(cn["closest_rays"] + cn["shadow_rays"]), float(cn["camera_rays"])], dtype=torch.float64, device=comm_dev)
-    if world > 1:
+    if multi:
         tmax = stats[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
@@ -197,7 +200,7 @@ def main():
         # final image (outside the timed region): MergeFilmTile per shard + WriteImage arithmetic on the host
         img = None
         if args.out:
-            if world > 1:
+            if multi:
                 shards = [(gathered[0][0][r], gathered[0][1][r], int(gathered[0][2][r].item())) for r in range(world)]
             else:
                 shards = [(film, strays, int(nstrays.item()))]
@@ -275,7 +278,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(workdir, args)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

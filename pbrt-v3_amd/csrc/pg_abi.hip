@@ -33,6 +33,14 @@ int pgSetError(int code, const char *msg) { g_lastError = msg; return code; }
         if (e_ != hipSuccess) return setError(PG_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_));    \
     } while (0)
 
+#ifdef PG_SHADE_PROF  // pg_kernels.hip, experiment build only
+void shade_prof_dump();
+#endif
+#ifdef PG_EXPERIMENT_SORT  // pg_sortexp.hip / pg_traverse.hip, experiment build only
+const int *sortexp_permutation(const DScene &sc, RayQueue q, int which, int mode, int cellBits, hipStream_t s);
+void set_trace_perm(const int *p0, const int *p1);
+const int *sortexp_spatial(const DScene &sc, RayQueue q, int which, int cellBits, hipStream_t s, int **countsOut);
+#endif
 struct DeviceBuffer {
     void *p = nullptr;
     size_t bytes = 0;
@@ -864,6 +872,15 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
 #define PG_TIMED(kind_, st_, launch_) do { if (!timing) { launch_; break; } hipEvent_t a_ = getEvent(s, ev), b_ = getEvent(s, ev + 1); \
         if (!a_ || !b_) return setError(PG_ERR_DEVICE, "hipEventCreate failed"); \
         timed.push_back({ev, kind_}); ev += 2; HIP_TRY(hipEventRecord(a_, st_)); launch_; HIP_TRY(hipEventRecord(b_, st_)); } while (0)
+#ifdef PG_EXPERIMENT_SORT
+    int sortWhat = 0, sortMode = 1, sortBits = 8;  // PG_SORT_RAYS: 1 main rays, 2 shadow rays, 4 MIS rays
+    if (const char *e = getenv("PG_SORT_RAYS")) sortWhat = atoi(e);
+    if (const char *e = getenv("PG_SORT_MODE")) sortMode = atoi(e);
+    if (const char *e = getenv("PG_SORT_BITS")) { int v = atoi(e); if (v >= 1 && v <= 8) sortBits = v; }
+    std::vector<size_t> sortEv;
+#define SORT_TIMED(st_, call_) do { hipEvent_t a_ = getEvent(s, ev), b_ = getEvent(s, ev + 1); sortEv.push_back(ev); ev += 2; \
+        HIP_TRY(hipEventRecord(a_, st_)); call_; HIP_TRY(hipEventRecord(b_, st_)); } while (0)
+#endif
     hipEvent_t evStart = getEvent(s, ev++), evStop = getEvent(s, ev++);
     if (!evStart || !evStop) return setError(PG_ERR_DEVICE, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(evStart, stream));
@@ -995,13 +1012,42 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                         HIP_TRY(hipEventRecord(s->evShaded, stream));
                         HIP_TRY(hipStreamWaitEvent(sst, s->evShaded, 0));
                     }
+#ifdef PG_EXPERIMENT_SORT
+                    RayQueue qShadow = q[2];
+                    if (sortWhat & 2) {
+                        const int *pm = nullptr;
+                        if (sortMode == 3) { int *bc = nullptr; SORT_TIMED(sst, pm = sortexp_spatial(s->d, q[2], 0, sortBits, sst, &bc)); if (pm) qShadow.counts = bc; }
+                        else SORT_TIMED(sst, pm = sortexp_permutation(s->d, q[2], 0, sortMode, sortBits, sst));
+                        set_trace_perm(pm, nullptr);
+                    }
+#define PG_Q_SHADOW qShadow
+#else
+#define PG_Q_SHADOW q[2]
+#endif
                     hipEvent_t a = nullptr, b = nullptr;
                     if (timing) { a = getEvent(s, ev); b = getEvent(s, ev + 1); timed.push_back({ev, 1}); ev += 2; HIP_TRY(hipEventRecord(a, sst)); }
-                    launch_anyhit(s->d, q[2], (int *)s->occluded.p, cnShadow, (int *)s->cursors2.p, sst);
+                    launch_anyhit(s->d, PG_Q_SHADOW, (int *)s->occluded.p, cnShadow, (int *)s->cursors2.p, sst);
                     if (timing) HIP_TRY(hipEventRecord(b, sst));
                     ++shadowLaunches;
                     if (overlap) HIP_TRY(hipEventRecord(s->evShadowed, sst));
+#ifdef PG_EXPERIMENT_SORT
+                    RayQueue qMain = q[nxt], qMisRays = q[3];
+                    if (sortWhat & 5) {
+                        const int *pm0 = nullptr, *pm1 = nullptr;
+                        if (sortMode == 3) {
+                            int *bc = nullptr;
+                            if (sortWhat & 1) { SORT_TIMED(stream, pm0 = sortexp_spatial(s->d, q[nxt], 0, sortBits, stream, &bc)); if (pm0) qMain.counts = bc; }
+                            if (sortWhat & 4) { SORT_TIMED(stream, pm1 = sortexp_spatial(s->d, q[3], 1, sortBits, stream, &bc)); if (pm1) qMisRays.counts = bc; }
+                        } else {
+                            if (sortWhat & 1) SORT_TIMED(stream, pm0 = sortexp_permutation(s->d, q[nxt], 0, sortMode, sortBits, stream));
+                            if (sortWhat & 4) SORT_TIMED(stream, pm1 = sortexp_permutation(s->d, q[3], 1, sortMode, sortBits, stream));
+                        }
+                        set_trace_perm(pm0, pm1);
+                    }
+                    if (int e = timedClosest(qMain, (float4 *)s->hitsMain.p, &qMisRays, hitsMis)) return e;
+#else
                     if (int e = timedClosest(q[nxt], (float4 *)s->hitsMain.p, &q[3], hitsMis)) return e;
+#endif
                     if (overlap) HIP_TRY(hipStreamWaitEvent(stream, s->evShadowed, 0));
                     PG_TIMED(3, stream, launch_resolve(s->d, ps, q[cur], q[3], (const int *)s->occluded.p, (const float4 *)hitsMis, stream, cur));
                     ++resolveLaunches;
@@ -1109,6 +1155,13 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
         *acc[te.second] += ms;
     }
 #undef PG_TIMED
+#ifdef PG_SHADE_PROF
+    shade_prof_dump();
+#endif
+#ifdef PG_EXPERIMENT_SORT
+    { double sm = 0; for (size_t e : sortEv) { float m = 0; if (hipEventElapsedTime(&m, s->events[e], s->events[e + 1]) == hipSuccess) sm += m; }
+      if (!sortEv.empty()) fprintf(stderr, "pg_render: ray-order experiment: %zu sorts, %.2f ms\n", sortEv.size(), sm); }
+#endif
     float ms = 0;
     if (hipEventElapsedTime(&ms, evStart, evStop) == hipSuccess) c.render_ms += ms;
 #ifdef PG_TRACE_STATS

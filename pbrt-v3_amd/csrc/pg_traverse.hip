@@ -68,6 +68,31 @@ PG_DEV bool slab_interval(float lox, float hix, float loy, float hiy, float loz,
     return ok && (tMax > 0);
 }
 
+// The same test for the lanes of a wave at once, as a lane mask: every comparison is balloted on its own and the masks are
+// combined with scalar instructions (a per-lane `bool` that is the AND of several comparisons costs two vector
+// instructions each time it is selected or balloted; the masks cost none).
+PG_DEV unsigned long long slab_mask(float lox, float hix, float loy, float hiy, float loz, float hiz, float ox, float oy, float oz, float ix,
+                                    float iy, float iz, bool nx, bool ny, bool nz, float &tMinOut) {
+    float tMin = ((nx ? hix : lox) - ox) * ix;
+    float tMax = ((nx ? lox : hix) - ox) * ix;
+    float tyMin = ((ny ? hiy : loy) - oy) * iy;
+    float tyMax = ((ny ? loy : hiy) - oy) * iy;
+    const float widen = 1 + 2 * pgamma(3);
+    tMax *= widen;
+    tyMax *= widen;
+    unsigned long long ok = __ballot(!(tMin > tyMax)) & __ballot(!(tyMin > tMax));
+    if (tyMin > tMin) tMin = tyMin;
+    if (tyMax < tMax) tMax = tyMax;
+    float tzMin = ((nz ? hiz : loz) - oz) * iz;
+    float tzMax = ((nz ? loz : hiz) - oz) * iz;
+    tzMax *= widen;
+    ok &= __ballot(!(tMin > tzMax)) & __ballot(!(tzMin > tMax));
+    if (tzMin > tMin) tMin = tzMin;
+    if (tzMax < tMax) tMax = tzMax;
+    tMinOut = tMin;
+    return ok & __ballot(tMax > 0);
+}
+
 PG_DEV unsigned long long tr_wave_sum(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     return v;
@@ -79,7 +104,11 @@ template <bool ANYHIT, bool XPRIM>
 __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(DScene sc, RayQueue q0, RayQueue q1, float4 *__restrict__ hits,
                                                     int hitOffset1, float *__restrict__ tOut, int *__restrict__ occluded,
                                                     TraceCounters *cn, int *__restrict__ cursors, int depth, int chunk, int refillAt, int triW,
-                                                    float cullK, int *cullGuard, int maxAccepted) {
+                                                    float cullK, int *cullGuard, int maxAccepted
+#ifdef PG_EXPERIMENT_SORT  // tools/sort_experiment.sh: position i of a region takes entry perm[i] (pg_sortexp.hip)
+                                                    , const int *__restrict__ perm0, const int *__restrict__ perm1
+#endif
+                                                    ) {
     extern __shared__ uint2 ldsStack[];  // [depth][TR_BLOCK]
     uint2 spill[TR_STACK_TOTAL];
     const int tid = threadIdx.x;
@@ -95,6 +124,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
     bool fresh = false;  // moved to a region this wave has not taken a chunk from yet: look before the atomic
     int next = 0, segEnd = 0, curQ = 0;  // the wave's current chunk [next, segEnd) of queue curQ
     bool exhausted = false;
+    int idleThreshold = refillAt;
     // per-lane ray state.  A lane is in exactly one of three states:
     //   cur >= 0                 : holds an interior record to expand (its box test already passed)
     //   cur == NONE, triLeft > 0 : holds a leaf with triLeft untested triangles starting at triNext
@@ -103,6 +133,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
     float ox = 0, oy = 0, oz = 0, ix = 1, iy = 1, iz = 1, tMax = 0;
     TriRay tr = {2, 0.f, 0.f, 1.f};  // Triangle::Intersect's per-ray permutation and shear (triangle.cpp:205-220)
     bool nx = false, ny = false, nz = false;
+    unsigned negBits = 0;  // nx | ny << 1 | nz << 2: dirIsNeg[] indexed by a node's split axis
     int hitPrim = -1;
     float hb0 = 0, hb1 = 0, hb2 = 0;
     int sp = 0;                       // real stack entries
@@ -142,7 +173,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
         if (XPRIM && inInst >= 0 && cur == TR_NONE && triLeft == 0) {
             if (!ANYHIT && instHit) wtMax = tMax;  // r.tMax = ray.tMax
             ox = wox; oy = woy; oz = woz; ix = wix; iy = wiy; iz = wiz; tr = wtr; tMax = wtMax;
-            nx = ix < 0; ny = iy < 0; nz = iz < 0;
+            nx = ix < 0; ny = iy < 0; nz = iz < 0; negBits = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
             if (ANYHIT) { vd = wvd; vmask = wvmask; }
             triNext = wTriNext; triLeft = wTriLeft; inInst = -1; spBase = 0;
             if (triLeft == 0) { TR_POP(); TR_SETTLE(); }
@@ -156,8 +187,9 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
         const bool idle = cur == TR_NONE && triLeft == 0;
         const unsigned long long idleMask = __ballot(idle);
         const int nIdle = __popcll(idleMask);
-        const bool refill = !exhausted && nIdle >= refillAt;
-        if (refill || (exhausted && nIdle == 64)) {
+        // one scalar comparison decides between the step and the (rarer) retire / refill path: the threshold is refillAt
+        // while the queues still have rays and 64 -- every lane idle -- once they are exhausted
+        if (nIdle >= idleThreshold) {
             if (idle && ray >= 0) {
                 if (ANYHIT) occluded[ray] = hitPrim >= 0 ? 1 : 0;
                 else {
@@ -169,7 +201,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
             }
             if (exhausted) break;
         }
-        if (refill) {
+        if (nIdle >= idleThreshold) {  // (refill: the queues were not exhausted on entry)
 #ifdef PG_TRACE_STATS
             ++stRefills; stRefillLanes += nIdle;
 #endif
@@ -193,22 +225,25 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
                     }
                     // next region: the other regions of this queue first (same XCD-local L2 contents last), then the other queue
                     ++regionsTried;
-                    if (regionsTried == nRegions) { exhausted = true; break; }
+                    if (regionsTried == nRegions) { exhausted = true; idleThreshold = 64; break; }
                     const int own = blockIdx.x & (PG_REGIONS - 1);
                     region = ((regionsTried >> 3) << 3) | ((own + regionsTried) & (PG_REGIONS - 1));
                     fresh = true;
                 }
             }
             if (!exhausted) {
-                const int idx = next + __popcll(idleMask & laneLt);
+                int idx = next + __popcll(idleMask & laneLt);
                 next += nIdle;
                 if (idle && idx < segEnd) {
+#ifdef PG_EXPERIMENT_SORT
+                    { const int *pm = curQ ? perm1 : perm0; if (pm) idx = pm[idx]; }
+#endif
                     const float4 o4 = curQ ? q1.o[idx] : q0.o[idx], d4 = curQ ? q1.d[idx] : q0.d[idx];
                     ray = idx + (curQ ? hitOffset1 : 0);  // index of this ray's result
                     ox = o4.x; oy = o4.y; oz = o4.z; tMax = o4.w;
                     tr = tri_ray_setup(mk(d4.x, d4.y, d4.z));
                     ix = 1 / d4.x; iy = 1 / d4.y; iz = 1 / d4.z;   // bvh.cpp:666
-                    nx = ix < 0; ny = iy < 0; nz = iz < 0;   // bvh.cpp:667
+                    nx = ix < 0; ny = iy < 0; nz = iz < 0; negBits = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);   // bvh.cpp:667
                     hitPrim = -1; hb0 = hb1 = hb2 = 0; nAccepted = 0;
                     inInst = -1; hitInstCur = -1; spBase = 0;
                     sp = 0; vd = 0; vmask = 0;
@@ -229,6 +264,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
         // ---- one step for the wave: either every lane holding an interior record expands it, or every lane
         //      holding a leaf tests its next triangle.  The larger group goes first (weighted by triW/16), so
         //      at least about half of the busy lanes are active in every step and neither group starves.
+        bool needPop = false, settle = false;
         const int nInt = __popcll(__ballot(cur >= 0));
         const int nTri = __popcll(__ballot(triLeft > 0));
 #ifdef PG_TRACE_STATS
@@ -265,7 +301,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
                     ox = o.x; oy = o.y; oz = o.z;
                     tr = tri_ray_setup(dd);
                     ix = 1 / dd.x; iy = 1 / dd.y; iz = 1 / dd.z;
-                    nx = ix < 0; ny = iy < 0; nz = iz < 0;
+                    nx = ix < 0; ny = iy < 0; nz = iz < 0; negBits = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
                     inInst = idx; spBase = sp; instHit = false;
                     triLeft = 0; cur = TR_NONE;
                     if (ob.nNodes == 0) { triNext = ob.firstPrim; triLeft = 1; }  // a lone primitive, no accelerator (api.cpp:1567)
@@ -309,16 +345,19 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
                         if (am.has_alpha && TexEval<PG_TEX_DEPTH>::f(sc, am.alpha, th) == 0) hit = false;
                         if (ANYHIT && hit && am.has_shadow_alpha && TexEval<PG_TEX_DEPTH>::f(sc, am.shadow_alpha, th) == 0) hit = false;
                     }
-                    if (hit) {
-                        hitPrim = prim;
-                        if (ANYHIT) { triLeft = 0; sp = 0; vd = 0; inInst = -1; }  // bvh.cpp:717: return true
-                        else {
-                            tMax = t; hb0 = b0; hb1 = b1; hb2 = b2;  // primitive.cpp:123: r.tMax = tHit
-                            if (XPRIM) { hitInstCur = inInst; instHit = true; }
-                            if (++nAccepted == maxAccepted) atomicOr(cullGuard, 1);
-                        }
+                    // the accepted hit, written with selects (in place: a branch here makes the compiler copy the whole hit
+                    // record aside before the test and back after it)
+                    hitPrim = hit ? prim : hitPrim;
+                    if (ANYHIT) {  // bvh.cpp:717: return true
+                        triLeft = hit ? 0 : triLeft; sp = hit ? 0 : sp; vd = hit ? 0 : vd;
+                        if (XPRIM) inInst = hit ? -1 : inInst;
+                    } else {
+                        tMax = hit ? t : tMax; hb0 = hit ? b0 : hb0; hb1 = hit ? b1 : hb1; hb2 = hit ? b2 : hb2;  // primitive.cpp:123: r.tMax = tHit
+                        if (XPRIM) { hitInstCur = hit ? inInst : hitInstCur; instHit = instHit || hit; }
+                        nAccepted += hit ? 1 : 0;
+                        if (hit && nAccepted == maxAccepted) atomicOr(cullGuard, 1);
                     }
-                    if (triLeft == 0 && !(ANYHIT && hitPrim >= 0)) { TR_POP(); TR_SETTLE(); }
+                    needPop = triLeft == 0 && !(ANYHIT && hitPrim >= 0);
                 }
             }
         } else if (cur >= 0) {
@@ -326,20 +365,26 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
             const float4 bx = rec[0], by = rec[1], bz = rec[2];
             const float4 rf = rec[3];
             float t0, t1;
-            const bool ok0 = slab_interval(bx.x, bx.y, by.x, by.y, bz.x, bz.y, ox, oy, oz, ix, iy, iz, nx, ny, nz, t0);
-            const bool ok1 = slab_interval(bx.z, bx.w, by.z, by.w, bz.z, bz.w, ox, oy, oz, ix, iy, iz, nx, ny, nz, t1);
+            const unsigned long long ok0 = slab_mask(bx.x, bx.y, by.x, by.y, bz.x, bz.y, ox, oy, oz, ix, iy, iz, nx, ny, nz, t0);
+            const unsigned long long ok1 = slab_mask(bx.z, bx.w, by.z, by.w, bz.z, bz.w, ox, oy, oz, ix, iy, iz, nx, ny, nz, t1);
             const int axis = __float_as_int(rf.z);
-            const bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);  // bvh.cpp:686: near child first
+            const bool neg = ((negBits >> axis) & 1u) != 0;  // bvh.cpp:686: near child first (dirIsNeg[axis])
             const int nearRef = __float_as_int(neg ? rf.y : rf.x), farRef = __float_as_int(neg ? rf.x : rf.y);
-            const float nearT = neg ? t1 : t0, farT = neg ? t0 : t1;
-            const bool nearHit = (neg ? ok1 : ok0) && nearT < tMax;
+            const float farT = neg ? t0 : t1;
+            // the four comparisons as lane masks, picked by `neg` with scalar mask arithmetic (instead of selecting the
+            // operands per lane first)
+            const float tMaxK = tMax * cullK;
+            const unsigned long long mNeg = __ballot(neg);
+            const unsigned long long mNear = (mNeg & ok1 & __ballot(t1 < tMax)) | (~mNeg & ok0 & __ballot(t0 < tMax));
+            const unsigned long long mFar = (mNeg & ok0 & __ballot(t0 < tMaxK)) | (~mNeg & ok1 & __ballot(t1 < tMaxK));
+            const bool nearHit = __builtin_amdgcn_inverse_ballot_w64(mNear);
             // Early cull of the far child.  ray.tMax is not monotone: Triangle::Intersect accepts tScaled <= tMax*det and then
             // returns t = tScaled*invDet, which can round to a few ulps ABOVE the old tMax (triangle.cpp:262-283), so an entry
             // that fails `tMin < tMax` now could still pass when the reference pops it.  Each accepted hit raises tMax by at
             // most three roundings, (1+2^-24)^3, so after <= TR_MAX_ACCEPTED accepted hits tMax < (1+2^-10) * any earlier
             // value: cull only beyond cullK = 1+2^-10 (any-hit: tMax is constant, cullK = 1); survivors are re-tested
             // exactly at pop time, and a ray that accepts more hits than that raises cullGuard so the host fails loudly.
-            const bool farMaybe = (neg ? ok0 : ok1) && farT < tMax * cullK;
+            const bool farMaybe = __builtin_amdgcn_inverse_ballot_w64(mFar);
             if (!ANYHIT) {
                 nodeVisits += 2;  // near now, far when the reference pops it (it always does)
                 if (farMaybe) TR_PUSH(farRef, farT);
@@ -348,9 +393,13 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
                 if (farMaybe) TR_PUSH(farRef, farT); else vmask |= 1ull << vd;
                 ++vd;
             }
-            if (nearHit) cur = nearRef; else TR_POP();
-            TR_SETTLE();
+            if (nearHit) cur = nearRef;
+            needPop = !nearHit;
+            settle = true;
         }
+        // the reference's "pop or finish" and the unpacking of a leaf reference, once for both kinds of step
+        if (needPop) { TR_POP(); settle = true; }
+        if (settle) TR_SETTLE();
     }
 #undef TR_PUSH
 #undef TR_TOP
@@ -374,6 +423,13 @@ static TraceConfig g_cfg = {11, 128, 16, 8, 1.0009765625f, 2048, TR_MAX_ACCEPTED
 void set_trace_config(const TraceConfig &c) { g_cfg = c; }
 TraceConfig get_trace_config() { return g_cfg; }
 
+#ifdef PG_EXPERIMENT_SORT
+static const int *g_perm[2] = {nullptr, nullptr};
+void set_trace_perm(const int *p0, const int *p1) { g_perm[0] = p0; g_perm[1] = p1; }  // applies to the next launch only
+#define TR_PERM_ARGS , g_perm[0], g_perm[1]
+#else
+#define TR_PERM_ARGS
+#endif
 template <bool ANYHIT>
 static void launch_trace(const DScene &sc, RayQueue q0, RayQueue q1, float4 *hits, int hitOffset1, float *tOut, int *occluded,
                          TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s) {
@@ -388,10 +444,13 @@ static void launch_trace(const DScene &sc, RayQueue q0, RayQueue q1, float4 *hit
     // scenes without spheres and object instances run the triangle-only instantiation
     if (sc.nSpheres > 0 || sc.nInstances > 0 || sc.hasAlpha)
         hipLaunchKernelGGL((k_trace<ANYHIT, true>), dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q0, q1, hits, hitOffset1, tOut, occluded, cn, cursors,
-                           c.depth, c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard, c.maxAccepted);
+                           c.depth, c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard, c.maxAccepted TR_PERM_ARGS);
     else
         hipLaunchKernelGGL((k_trace<ANYHIT, false>), dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q0, q1, hits, hitOffset1, tOut, occluded, cn, cursors,
-                           c.depth, c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard, c.maxAccepted);
+                           c.depth, c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard, c.maxAccepted TR_PERM_ARGS);
+#ifdef PG_EXPERIMENT_SORT
+    g_perm[0] = g_perm[1] = nullptr;
+#endif
 }
 static RayQueue noQueue() { RayQueue q; q.o = q.d = nullptr; q.counts = nullptr; q.regionCap = 0; return q; }
 void launch_closest(const DScene &sc, RayQueue q, float4 *hits, float *tOut, TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s) {
