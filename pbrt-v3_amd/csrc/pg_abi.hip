@@ -77,6 +77,7 @@ struct PgScene {
     DeviceBuffer vqo[2], vqd[2], vCounts, volMedium, trAcc[2], volP1[3], misLi, pdLi, hitT;
     DeviceBuffer qsL[2], qsBeta[2], qsMeta[2];  // PathIntegrator: path state in queue order
     DeviceBuffer lightHot;  // DScene::lightHot
+    DeviceBuffer haltonDims;  // DScene::haltonDims
     DeviceBuffer cmaxmin, tsState, ts1, ts2;  // tile-serial samplers: CMaxMinDist, the tiles' sampler states and sample arrays
     DeviceBuffer voxelSlot, voxelRequests, voxelCounters, retryList;  // sparse "spatial" light tables (DScene::sparseLights)
     int poolSlots = 0, poolUsed = 0, nVoxelsTotal = 0;
@@ -464,6 +465,19 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         HIP_TRY_S(hipMemcpy(s->permSums.p, desc->perm_sums, s->permSums.bytes, hipMemcpyHostToDevice));
         HIP_TRY_S(s->primes.alloc(sizeof(int32_t) * primes.size()));
         HIP_TRY_S(hipMemcpy(s->primes.p, primes.data(), s->primes.bytes, hipMemcpyHostToDevice));
+        // per dimension: (base, offset of its digit permutation, m, L) with floor(a / base) = (t + ((a - t) >> 1)) >> (L - 1),
+        // t = mulhi(m, a), for every 32-bit a (division by an invariant integer with a 33-bit multiplier: L = ceil(log2 base),
+        // m = floor(2^32 (2^L - base) / base) + 1): the digit loops of the radical inverse divide without dividing
+        std::vector<int32_t> hd(4 * primes.size());
+        for (size_t i = 0; i < primes.size(); ++i) {
+            const uint64_t b = (uint64_t)primes[i];
+            int L = 0;
+            while (((uint64_t)1 << L) < b) ++L;
+            const uint64_t m = (((uint64_t)1 << 32) * (((uint64_t)1 << L) - b)) / b + 1;
+            hd[4 * i] = primes[i]; hd[4 * i + 1] = desc->perm_sums[i]; hd[4 * i + 2] = (int32_t)(uint32_t)m; hd[4 * i + 3] = L;
+        }
+        HIP_TRY_S(s->haltonDims.alloc(sizeof(int32_t) * hd.size()));
+        HIP_TRY_S(hipMemcpy(s->haltonDims.p, hd.data(), s->haltonDims.bytes, hipMemcpyHostToDevice));
     }
 
     if (desc->cmaxmin) {  // the MaxMinDistSampler's generator matrices
@@ -542,7 +556,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     d.triN = (const float4 *)s->triN.p; d.triS = (const float4 *)s->triS.p;
     d.materials = (const PgMaterial *)s->materials.p; d.lights = (const PgLight *)s->lights.p;
     d.nNodes = desc->n_nodes; d.nTris = nt; d.nLights = desc->n_lights; d.nMaterials = desc->n_materials;
-    d.perms = (const uint16_t *)s->perms.p; d.permSums = (const int32_t *)s->permSums.p; d.primes = (const int32_t *)s->primes.p;
+    d.perms = (const uint16_t *)s->perms.p; d.permSums = (const int32_t *)s->permSums.p; d.primes = (const int32_t *)s->primes.p; d.haltonDims = (const int4 *)s->haltonDims.p;
     d.nPermDims = desc->n_perm_dims;
     d.lightHot = (const float4 *)s->lightHot.p;
     d.cmaxmin = (const uint32_t *)s->cmaxmin.p;
@@ -634,7 +648,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     if (const char *e = getenv("PG_OVERLAP_SHADOW")) s->overlapShadow = atoi(e) != 0;
     HIP_TRY_S(s->cullGuard.alloc(sizeof(int) * 2 + 8 * sizeof(unsigned long long)));  // the guard word (+ the counters of the PG_TRACE_STATS experiment build)
     HIP_TRY_S(hipMemset(s->cullGuard.p, 0, s->cullGuard.bytes));
-    HIP_TRY_S(s->lightTests.alloc(sizeof(unsigned long long)));
+    HIP_TRY_S(s->lightTests.alloc(sizeof(unsigned long long) * PG_LIGHT_TEST_SHARDS * PG_LIGHT_TEST_STRIDE));
     HIP_TRY_S(hipMemset(s->lightTests.p, 0, s->lightTests.bytes));
     *out = s;
     return PG_OK;
@@ -671,14 +685,14 @@ static int withExactFallback(PgScene *s, const std::function<int()> &call) {
     TraceCounters savedDev[2];
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipMemcpy(savedDev, s->traceCn.p, sizeof(savedDev), hipMemcpyDeviceToHost));
-    unsigned long long savedLt = 0;
-    HIP_TRY(hipMemcpy(&savedLt, s->lightTests.p, sizeof(savedLt), hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> savedLt(PG_LIGHT_TEST_SHARDS * PG_LIGHT_TEST_STRIDE);
+    HIP_TRY(hipMemcpy(savedLt.data(), s->lightTests.p, s->lightTests.bytes, hipMemcpyDeviceToHost));
     s->cullTripped = false;
     int st = call();
     if (st != PG_ERR_OVERFLOW || !s->cullTripped) return st;
     s->counters = saved;
     HIP_TRY(hipMemcpy(s->traceCn.p, savedDev, sizeof(savedDev), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(s->lightTests.p, &savedLt, sizeof(savedLt), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->lightTests.p, savedLt.data(), s->lightTests.bytes, hipMemcpyHostToDevice));
     const TraceConfig cfg = get_trace_config();
     TraceConfig exact = cfg;
     exact.cullK = 3e38f;
@@ -1138,7 +1152,11 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
     TraceCounters tc[2];
     unsigned long long lt = 0;
     HIP_TRY(hipMemcpy(tc, s->traceCn.p, sizeof(tc), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&lt, lightTests, sizeof(lt), hipMemcpyDeviceToHost));
+    {
+        std::vector<unsigned long long> shards(PG_LIGHT_TEST_SHARDS * PG_LIGHT_TEST_STRIDE);
+        HIP_TRY(hipMemcpy(shards.data(), lightTests, s->lightTests.bytes, hipMemcpyDeviceToHost));
+        for (int i = 0; i < PG_LIGHT_TEST_SHARDS; ++i) lt += shards[(size_t)i * PG_LIGHT_TEST_STRIDE];
+    }
     PgCounters &c = s->counters;
     c.camera_rays += cameraRays; c.closest_rays += closestRays; c.shadow_rays += shadowRays;
     c.node_visits = tc[0].node_visits + tc[1].node_visits;

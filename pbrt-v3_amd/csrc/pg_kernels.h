@@ -87,6 +87,9 @@ struct DScene {
     const int32_t *permSums;
     const int32_t *primes;
     int nPermDims;
+    // per Halton dimension (base, offset of its permutation in perms, m, L): floor(a / base) = (t + ((a - t) >> 1)) >> (L - 1)
+    // with t = mulhi(m, a), exact for every 32-bit a -- the digit loops divide by multiplying (pg_abi.hip builds the table)
+    const int4 *haltonDims;
     // SobolSampler tables (core/sobolmatrices.h:49-52), nullptr unless the scene was created with them
     const uint32_t *sobolMatrices;
     const uint64_t *vdcSobol, *vdcSobolInv;
@@ -165,6 +168,11 @@ struct RenderParams {
     int retryCount;
 };
 
+// The shading kernels count Triangle::Intersect calls of light.Pdf_Li (the reference's nTests statistic) into PG_LIGHT_TEST_SHARDS
+// counters, one per 128-B line, picked by the block index: every wave of a shading launch adds to the count, and two million
+// atomics per launch on ONE word (about 88 per microsecond, MI355X_MICROARCH.md) had made k_shade wait for them for half its time.
+#define PG_LIGHT_TEST_SHARDS 256
+#define PG_LIGHT_TEST_STRIDE 16  // unsigned long longs between two shards (128 B)
 struct TraceCounters {
     unsigned long long node_visits, tri_tests;
 };

@@ -22,6 +22,9 @@
 #ifndef PG_SHADE_BLOCK
 #define PG_SHADE_BLOCK 128
 #endif
+#ifndef PG_ABL  // ablation builds (tools/_run_exp8.sh): time k_shade with one of its parts left out -- results are WRONG, timing only
+#define PG_ABL 0
+#endif
 PG_DEV int lane_id() { return __lane_id(); }
 
 // Queue append, aggregated per block: every wave ballots its pushes, the block sums them through LDS and ONE lane per
@@ -161,7 +164,73 @@ PG_DEV float halton_sample(const DScene &sc, const PgRenderDesc &rd, uint64_t in
     if (dim == 0) return radical_inverse_base2(index >> rd.base_exponents[0]);
     if (dim == 1) return radical_inverse(3, index / (uint64_t)rd.base_scales[1]);
     if (dim >= sc.nPermDims) dim = sc.nPermDims - 1;  // host sizes the table from maxdepth; halton.h:71-76 aborts here
-    return scrambled_radical_inverse((uint32_t)sc.primes[dim], sc.perms + sc.permSums[dim], index);
+    if ((index >> 32) != 0) return scrambled_radical_inverse((uint32_t)sc.primes[dim], sc.perms + sc.permSums[dim], index);
+    // 32-bit index: scrambled_radical_inverse's loop with the division done by multiplication (DScene::haltonDims)
+    const int4 hd = sc.haltonDims[dim];
+    const uint32_t base = (uint32_t)hd.x, mul = (uint32_t)hd.z, sh = (uint32_t)hd.w - 1u;
+    const uint16_t *perm = sc.perms + hd.y;
+    const float invBase = 1.f / (float)base;
+    uint64_t reversedDigits = 0;
+    float invBaseN = 1;
+    uint32_t a32 = (uint32_t)index;
+    while (a32) {
+        const uint32_t t = __umulhi(mul, a32);
+        const uint32_t next = (t + ((a32 - t) >> 1)) >> sh;
+        reversedDigits = reversedDigits * base + perm[a32 - next * base];
+        invBaseN *= invBase;
+        a32 = next;
+    }
+    return pmin(invBaseN * ((float)reversedDigits + invBase * (float)perm[0] / (1 - invBase)), PG_ONE_MINUS_EPS);
+}
+
+// The N Halton dimensions dim0 .. dim0+N-1 of one sample index at once (HaltonSampler::SampleDimension for each, halton.cpp:119-127
+// + ScrambledRadicalInverse, lowdiscrepancy.cpp:405-424): the digit loops of the N dimensions run side by side, so the N
+// permutation-table loads of a digit position are in flight together and the wave waits once per digit position instead of
+// once per digit of every dimension (a shading wave spent a third of its time in these loops, profiles/r02s_*).  Per
+// dimension the operations and their order are those of scrambled_radical_inverse().  dim0 is the same in every lane
+// (the caller checks), so bases and table offsets are scalar; the index must fit 32 bits.
+template <int N>
+PG_DEV void halton_batch(const DScene &sc, uint32_t a0, int dim0, float *out) {
+    uint32_t base[N], off[N], mul[N], sh[N], a[N];
+    uint64_t rev[N];
+    float invBase[N], invBaseN[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        int d = dim0 + j;
+        if (d >= sc.nPermDims) d = sc.nPermDims - 1;
+        const int4 hd = sc.haltonDims[d];
+        base[j] = (uint32_t)hd.x; off[j] = (uint32_t)hd.y; mul[j] = (uint32_t)hd.z; sh[j] = (uint32_t)hd.w - 1u;
+        invBase[j] = 1.f / (float)base[j];
+        a[j] = a0; rev[j] = 0; invBaseN[j] = 1;
+    }
+    uint32_t any = a0;
+    while (any) {
+        any = 0;
+        uint32_t next[N], p[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {  // the digit of every dimension, and its table entry on the way
+            const uint32_t t = __umulhi(mul[j], a[j]);
+            next[j] = (t + ((a[j] - t) >> 1)) >> sh[j];  // = a[j] / base[j] (DScene::haltonDims)
+            p[j] = sc.perms[off[j] + (a[j] - next[j] * base[j])];
+        }
+        // all N loads are issued before the first is used (left alone, the compiler sinks each into the branch it makes of the
+        // select below and waits for them one by one)
+        static_assert(N == 7, "halton_batch: the barrier below names seven values");
+        asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]));
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const bool act = a[j] != 0;  // a dimension whose digits are used up stays as it is
+            const uint64_t r2 = rev[j] * base[j] + p[j];
+            const float n2 = invBaseN[j] * invBase[j];
+            rev[j] = act ? r2 : rev[j];
+            invBaseN[j] = act ? n2 : invBaseN[j];
+            a[j] = next[j];
+            any |= next[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+        out[j] = pmin(invBaseN[j] * ((float)rev[j] + invBase[j] * (float)sc.perms[off[j]] / (1 - invBase[j])), PG_ONE_MINUS_EPS);
 }
 
 // ---- the samplers that draw from one RNG stream per tile (RandomSampler; the PixelSamplers, sampler.cpp:100-134) ------------
@@ -1631,6 +1700,28 @@ PG_DEV const float *light_distribution(const DScene &sc, V3 p) {
 }
 // Distribution1D::SampleDiscrete, sampling.h:90-100 + FindInterval pbrt.h:403-415
 PG_DEV int sample_discrete(const float *tab, int n, float u, float &pdf) {
+#ifndef PG_NO_ROW
+    if (n <= 3) {
+        // a table of at most 8 floats (func[n], cdf[n+1], funcInt) is fetched in ONE round trip and searched in registers; the
+        // general path below meets it with three or four dependent loads (funcInt, the cdf entries of the search, func)
+        float row[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) row[k] = k < 2 * n + 2 ? tab[k] : 0.f;
+        asm volatile("" : "+v"(row[0]), "+v"(row[1]), "+v"(row[2]), "+v"(row[3]), "+v"(row[4]), "+v"(row[5]), "+v"(row[6]), "+v"(row[7]));
+        auto at = [&](int k) { return k == 0 ? row[0] : (k == 1 ? row[1] : (k == 2 ? row[2] : (k == 3 ? row[3] : (k == 4 ? row[4] : (k == 5 ? row[5] : (k == 6 ? row[6] : row[7])))))); };
+        const float funcInt = at(2 * n + 1);
+        int size = n + 1, first = 0, len = size;
+        while (len > 0) {
+            int half = len >> 1, middle = first + half;
+            if (at(n + middle) <= u) { first = middle + 1; len -= half + 1; }
+            else len = half;
+        }
+        int offset = first - 1;
+        offset = offset < 0 ? 0 : (offset > size - 2 ? size - 2 : offset);
+        pdf = (funcInt > 0) ? at(offset) / (funcInt * n) : 0;
+        return offset;
+    }
+#endif
     const float *func = tab, *cdf = tab + n;
     float funcInt = tab[2 * n + 1];
     int size = n + 1, first = 0, len = size;
@@ -1715,7 +1806,7 @@ void shade_prof_dump() {
 #define PROF(k) do { } while (0)
 #endif
 template <int MODE, bool VOL>
-__global__ __launch_bounds__(PG_SHADE_BLOCK, (MODE == 1 && PG_SHADE_MIN_WAVES > 0) ? PG_SHADE_MIN_WAVES : 1) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
+__global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? 4 : ((MODE == 1 && PG_SHADE_MIN_WAVES > 0) ? PG_SHADE_MIN_WAVES : 1)) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
                                                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, VolState vs,
                                                      const float *__restrict__ hitT, QueueState qsIn, QueueState qsOut) {
     constexpr bool EXT = MODE >= 1, TEX = MODE == 2;
@@ -1772,10 +1863,21 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, (MODE == 1 && PG_SHADE_MIN_WAVES > 
         // (sample index, dimension); the tile-serial samplers advance their tile's state (slot = tile, one path per tile)
         const bool tileSerial = rd.sampler >= PG_SAMPLER_RANDOM;
         if (tileSerial) { tsState0 = sc.ts[slot].state; tsCur1D0 = sc.ts[slot].cur1D; tsCur2D0 = sc.ts[slot].cur2D; }  // restored if this vertex is deferred (sparse light tables)
-        auto draw1 = [&]() -> float { return tileSerial ? ts_get1d(sc, slot) : halton_sample(sc, rd, index, dim++); };
+        // PathIntegrator + Halton: the PG_NPRE dimensions a surface vertex usually draws (light choice, uLight, uScattering, the
+        // next direction) are computed together before the first draw (halton_batch); preDim0 < 0: not computed
+        constexpr int PG_NPRE = 7;
+        float pre[PG_NPRE];
+        int preDim0 = -1;
+        auto sample_dim = [&](int d) -> float {
+            const int k = d - preDim0;
+            if (!VOL && preDim0 >= 0 && k >= 0 && k < PG_NPRE)
+                return k == 0 ? pre[0] : (k == 1 ? pre[1] : (k == 2 ? pre[2] : (k == 3 ? pre[3] : (k == 4 ? pre[4] : (k == 5 ? pre[5] : pre[6])))));
+            return halton_sample(sc, rd, index, d);
+        };
+        auto draw1 = [&]() -> float { return tileSerial ? ts_get1d(sc, slot) : sample_dim(dim++); };
         auto draw2 = [&](float &a, float &b) {
             if (tileSerial) ts_get2d(sc, rd.sampler, slot, a, b);
-            else { a = halton_sample(sc, rd, index, dim); b = halton_sample(sc, rd, index, dim + 1); dim += 2; }
+            else { a = sample_dim(dim); b = sample_dim(dim + 1); dim += 2; }
         };
         float etaScale = __int_as_float(meta.z);  // path.cpp:79
         int bounces = meta.w & 0xffff;
@@ -1815,7 +1917,11 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, (MODE == 1 && PG_SHADE_MIN_WAVES > 
             volDead = is_black(beta);  // volpath.cpp:78
         }
         Tri tri;
+#if PG_ABL == 4
+        if (found) tri = load_tri(sc, prim & 1023);
+#else
         if (found) tri = load_tri(sc, prim);
+#endif
         // the hit's material record, fetched as soon as its index is known (one round trip, overlapped with the interaction's
         // arithmetic) instead of field by field where each is used
         const PgMaterial mtl = sc.materials[found ? tri.material : 0];
@@ -1848,7 +1954,11 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, (MODE == 1 && PG_SHADE_MIN_WAVES > 
             for (int li = 0; li < sc.nLights; ++li)
                 if (sc.lights[li].type == PG_LIGHT_INFINITE) L = L + beta * env_le(sc, sc.lights[li], rayD);
         }
+#if PG_ABL == 6
+        bool alive = false;
+#else
         bool alive = found && bounces < rd.max_depth;  // path.cpp:104
+#endif
         int newFlags = 0;
         bool handled = false;
         if constexpr (VOL) {
@@ -1960,6 +2070,12 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, (MODE == 1 && PG_SHADE_MIN_WAVES > 
                 // MatteMaterial::ComputeScatteringFunctions (matte.cpp:45-62), BSDF ctor (reflection.h:167-172)
                 // BSDF: the EXT kernel evaluates the material's BxDF list (any material); the plain kernel has the list
                 // shapes of matte / plastic / mirror / glass baked in (same arithmetic, fewer registers)
+                if constexpr (!VOL) {
+                    // every lane here draws at least the next direction; the batch needs one dimension for the whole wave
+                    const int dimU = __builtin_amdgcn_readfirstlane(dim);
+                    const bool can = !tileSerial && rd.sampler == 0 && (index >> 32) == 0 && dim >= 2;
+                    if (__ballot(!can || dim != dimU) == 0) { halton_batch<PG_NPRE>(sc, (uint32_t)index, dimU, pre); preDim0 = dimU; }
+                }
                 Bsdf bsdf;
                 LobeBsdf lb;
                 PgBxDF lobeStore[TEX ? PG_MAX_BXDFS : 1];  // MODE 2: this hit's BxDF list (ComputeScatteringFunctions with textures)
@@ -2087,9 +2203,17 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, (MODE == 1 && PG_SHADE_MIN_WAVES > 
                 if constexpr (EXT) hasNonSpecular = lbsdf_num_components(lb, nonSpecular) > 0;
                 else hasNonSpecular = bsdf.nBxDFs > 0 && !bsdf.specular;
                 // ---- direct lighting: UniformSampleOneLight (integrator.cpp:85-106) + EstimateDirect set-up
+#if PG_ABL == 5
+                const bool wantLight = false;
+#else
                 const bool wantLight = (VOL || hasNonSpecular) && sc.nLights > 0;  // path.cpp:119: only with non-specular lobes (volpath.cpp:124-127: always)
+#endif
                 PROF(1);
+#if PG_ABL == 7
+                const float *tab = wantLight ? sc.distTable : nullptr;
+#else
                 const float *tab = wantLight ? light_distribution(sc, is.p) : nullptr;
+#endif
                 if (wantLight && !tab) deferred = true;
                 if (tab) {
                     float lightSelPdf;
@@ -2107,7 +2231,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, (MODE == 1 && PG_SHADE_MIN_WAVES > 
                         float4 pdLight = make_float4(0, 0, 0, 0);
                         LightSample ls;
                         Spec Li = light_sample_li_hot<EXT>(sc, lh, light, is.p, is.pError, is.n, uL0, uL1, wi, lightPdf, ls);
-                        if (lightPdf > 0 && !is_black(Li)) {
+                        if ((PG_ABL != 9) && lightPdf > 0 && !is_black(Li)) {
                             Spec f;
                             if constexpr (EXT) { f = lbsdf_f(lb, is.wo, wi, nonSpecular) * absdot(wi, shNs); scatteringPdf = lbsdf_pdf(lb, is.wo, wi, nonSpecular); }
                             else { f = bsdf_f(bsdf, is.wo, wi) * absdot(wi, shNs); scatteringPdf = bsdf_pdf(bsdf, is.wo, wi); }
@@ -2140,7 +2264,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, (MODE == 1 && PG_SHADE_MIN_WAVES > 
                         V3 wi2 = wi;
                         float sPdf2 = 0;
                         Spec f2 = sp(0);
-                        if (lh.type == PG_LIGHT_AREA || (EXT && lh.type == PG_LIGHT_INFINITE)) {  // integrator.cpp:164: if (!IsDeltaLight(light.flags))
+                        if ((PG_ABL != 8) && (lh.type == PG_LIGHT_AREA || (EXT && lh.type == PG_LIGHT_INFINITE))) {  // integrator.cpp:164: if (!IsDeltaLight(light.flags))
                             if constexpr (EXT) { int st2; f2 = lbsdf_sample_f(lb, is.wo, wi2, uS0, uS1, sPdf2, nonSpecular, st2); }
                             else f2 = bsdf_sample_f(bsdf, is.wo, wi2, uS0, uS1, sPdf2);
                             f2 = f2 * absdot(wi2, shNs);
@@ -2158,8 +2282,10 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, (MODE == 1 && PG_SHADE_MIN_WAVES > 
                         }
                         // pending terms of this vertex, consumed by k_resolve (pdMis and the MIS weight follow below)
                         pdLight.w = lightSelPdf;
+#if PG_ABL != 1
                         st.pdLight[pdi] = pdLight;
                         st.pdBeta[pdi] = make_float4(beta.r, beta.g, beta.b, 0.f);
+#endif
                     }
                 }
                 PROF(5);
@@ -2214,7 +2340,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, (MODE == 1 && PG_SHADE_MIN_WAVES > 
         if (rp.rd.sampler >= PG_SAMPLER_RANDOM) { sc.ts[slot].state = tsState0; sc.ts[slot].cur1D = tsCur1D0; sc.ts[slot].cur2D = tsCur2D0; }  // nor a draw from the tile's stream
         rp.retryList[atomicAdd(&sc.voxelCounters[1], 1)] = i;
     }
-    if (misCand) {
+    if ((PG_ABL != 10) && misCand) {
         // light.Pdf_Li -> Shape::Pdf(ref, wi): intersect the light's own triangle (shape.cpp:72-87, diffuse.cpp:83-87)
         float lightPdf2 = 0;
         if (EXT && misLightPrim < 0) lightPdf2 = env_pdf_li(sc, sc.lights[-1 - misLightPrim], misWi);  // infinite light: no geometry to test
@@ -2239,7 +2365,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, (MODE == 1 && PG_SHADE_MIN_WAVES > 
                 lightPdf2 = pdf;
             }
         }
-        if (lightPdf2 != 0) {
+        if ((PG_ABL != 12) && lightPdf2 != 0) {
             s_ray[2][0][tid] = make_float4(misRo.x, misRo.y, misRo.z, PG_INF);
             s_ray[2][1][tid] = make_float4(misWi.x, misWi.y, misWi.z, __int_as_float(slot));
             pushMis = true;
@@ -2252,9 +2378,14 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, (MODE == 1 && PG_SHADE_MIN_WAVES > 
     const RayQueue outQ[3] = {qnext, qshadow, qmis};
     const bool outPred[3] = {pushNext, pushShadow, pushMis};
     int outPos[3];
+#if PG_ABL == 3
+    for (int k = 0; k < 3; ++k) outPos[k] = outPred[k] ? (i >= 0 ? i : 0) : -1;
+#else
     block_push<3, true, PG_SHADE_BLOCK>(outQ, outPred, outPos, nextBin);
+#endif
     PROF(9);
     const int posNext = outPos[0], posShadow = outPos[1], posMis = outPos[2];
+#if PG_ABL != 2
     if (pushNext) { qnext.o[posNext] = s_ray[0][0][tid]; qnext.d[posNext] = s_ray[0][1][tid]; }
     if (pushShadow) { qshadow.o[posShadow] = s_ray[1][0][tid]; qshadow.d[posShadow] = s_ray[1][1][tid]; }
     if (pushMis) { qmis.o[posMis] = s_ray[2][0][tid]; qmis.d[posMis] = s_ray[2][1][tid]; }
@@ -2268,8 +2399,9 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, (MODE == 1 && PG_SHADE_MIN_WAVES > 
             st.pdInfo[pdi] = make_int4(posShadow, posMis, lightNum, pushNext ? posNext : ~slot);
         }
     } else if (valid && !deferred) st.pdInfo[slot] = make_int4(posShadow, posMis, lightNum, VOL ? __float_as_int(volWeight) : 0);
+#endif
     unsigned long long nl = wave_sum(nLightTests);
-    if (lane_id() == 0 && nl) atomicAdd(lightTriTests, nl);
+    if (lane_id() == 0 && nl) atomicAdd(lightTriTests + (blockIdx.x & (PG_LIGHT_TEST_SHARDS - 1)) * PG_LIGHT_TEST_STRIDE, nl);
 #ifdef PG_SHADE_PROF
     PROF(10);
     if (profOn && lane_id() == 0) { for (int k = 0; k < PG_NPROF; ++k) atomicAdd(&g_shadeProf[k], (unsigned long long)profAcc[k]); atomicAdd(&g_shadeProf[PG_NPROF], 1ull); }

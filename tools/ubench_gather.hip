@@ -13,13 +13,15 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-__device__ inline unsigned next_index(unsigned idx, float4 v, unsigned n) {
-    return (idx * 1664525u + 1013904223u + (unsigned)__float_as_int(v.x)) % n;
+__device__ inline unsigned next_index(unsigned idx, float4 v, unsigned n) {  // a 32-bit mixer (an LCG modulo n cycles through few records for some n)
+    unsigned h = idx + 0x9e3779b9u + (unsigned)__float_as_int(v.x);
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h % n;
 }
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_gather(const float4 *__restrict__ table, unsigned n, int iters, float *out) {
-    unsigned idx = (blockIdx.x * 256u + threadIdx.x) * 2654435761u % n;
+    unsigned idx = next_index(blockIdx.x * 256u + threadIdx.x, make_float4(0, 0, 0, 0), n);
     float acc = 0;
     const int lane4 = threadIdx.x & 3;
     for (int it = 0; it < iters; ++it) {
