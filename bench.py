@@ -256,10 +256,30 @@ def main():
                             224 * n_items + 32 * (n_next + n_shadow + n_mis) + 16 * n_mis,
                             cn["shade_ms"], cn["shade_launches"], n_items, "vertex"),
         ]
+        # The traversal kernels are gathers of 64-B child-pair records and 48-B triangle records, one per lane and step.  What bounds
+        # them is the chip's rate of random record fetches at this working-set size, measured live by tools/ubench_gather.hip
+        # (pbrt-v3_amd/ubench_gather: every lane chases its own chain of records through a table of that size): DESIGN.md section 5.
+        # Closest hit: an interior step counts two reference node visits (both children), the root one per ray, so
+        # record fetches = (node visits - rays) / 2 + triangle tests.
+        gather = None
+        ub = os.path.join(ROOT, "pbrt-v3_amd", "ubench_gather")
+        if os.path.exists(ub) and cn["closest_ms"] > 0:
+            try:
+                ws_mb = max(1, int(round(working_set / 2**20)))
+                ceil = json.loads(subprocess.run([ub, "--json", str(ws_mb)], capture_output=True, text=True, timeout=120).stdout)[str(ws_mb)]
+                fetches = max(0, cn["closest_node_visits"] - n_close) / 2 + cn["closest_tri_tests"]
+                rate = fetches / (cn["closest_ms"] * 1e-3)
+                gather = {"kernel": "k_trace<false>", "record_fetches_per_s": rate, "ceiling_records_per_s": ceil["together"],
+                          "frac": rate / ceil["together"], "table_MiB": ws_mb, "ceilings": ceil,
+                          "note": "ceiling = random 64-B record fetches per second, one chain per lane, table of the working set's size"}
+            except Exception as e:  # the measurement tool is optional; the bench line is not
+                gather = {"error": str(e)}
         kernels = [k for k in kernels if k["total_ms"] > 0]
         kernels.sort(key=lambda k: -k["total_ms"])  # dominant = the most time, each kernel timed alone
         roofline = dict(kernels[0]) if kernels else {"kernel": None, "bound": bound, "achieved": 0.0, "peak": peak, "unit": "GB/s", "frac": 0.0, "traffic": None}
         roofline["working_set_bytes"] = working_set
+        if gather is not None:
+            roofline["gather"] = gather
         roofline["bound_reason"] = (f"BVH + triangle records {working_set / 2**20:.0f} MiB " +
                                     ("fit the 256 MiB Infinity Cache: gathers are served on-die, L2 bandwidth is the ceiling"
                                      if bound == "l2" else "exceed the 256 MiB Infinity Cache: gathers reach HBM"))

@@ -22,9 +22,6 @@
 #ifndef PG_SHADE_BLOCK
 #define PG_SHADE_BLOCK 128
 #endif
-#ifndef PG_ABL  // ablation builds (tools/_run_exp8.sh): time k_shade with one of its parts left out -- results are WRONG, timing only
-#define PG_ABL 0
-#endif
 PG_DEV int lane_id() { return __lane_id(); }
 
 // Queue append, aggregated per block: every wave ballots its pushes, the block sums them through LDS and ONE lane per
@@ -57,15 +54,21 @@ PG_DEV void block_push(const RayQueue *q, const bool *pred, int *pos, int bin0 =
         }
     }
     __syncthreads();
+    // lanes 0 .. NQ-1 reserve the NQ queues' entries with ONE atomic instruction (one round trip to the counters instead of
+    // NQ dependent ones); the queue's fields are picked by compare-and-select on named copies so that they stay in registers
+    if (threadIdx.x < NQ) {
+        const int k = threadIdx.x;
+        int total = 0;
 #pragma unroll
-    for (int k = 0; k < NQ; ++k)  // one lane per queue; written without dynamic indexing so q[] stays in registers
-        if (threadIdx.x == k) {
-            int total = 0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) total += s_cnt[k][w];
-            const int r = blockIdx.x & (PG_REGIONS - 1);
-            s_base[k] = total ? r * q[k].regionCap + atomicAdd(&q[k].counts[r * PG_COUNT_STRIDE], total) : 0;
-        }
+        for (int w = 0; w < NW; ++w) total += s_cnt[k][w];
+        static_assert(NQ <= 3, "block_push: at most three queues");
+        int *const c0 = q[0].counts, *const c1 = q[NQ > 1 ? 1 : 0].counts, *const c2 = q[NQ > 2 ? 2 : 0].counts;
+        const int cap0 = q[0].regionCap, cap1 = q[NQ > 1 ? 1 : 0].regionCap, cap2 = q[NQ > 2 ? 2 : 0].regionCap;
+        int *const cnt = k == 0 ? c0 : (k == 1 ? c1 : c2);
+        const int cap = k == 0 ? cap0 : (k == 1 ? cap1 : cap2);
+        const int r = blockIdx.x & (PG_REGIONS - 1);
+        s_base[k] = total ? r * cap + atomicAdd(&cnt[r * PG_COUNT_STRIDE], total) : 0;
+    }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < NQ; ++k) {
@@ -1700,7 +1703,6 @@ PG_DEV const float *light_distribution(const DScene &sc, V3 p) {
 }
 // Distribution1D::SampleDiscrete, sampling.h:90-100 + FindInterval pbrt.h:403-415
 PG_DEV int sample_discrete(const float *tab, int n, float u, float &pdf) {
-#ifndef PG_NO_ROW
     if (n <= 3) {
         // a table of at most 8 floats (func[n], cdf[n+1], funcInt) is fetched in ONE round trip and searched in registers; the
         // general path below meets it with three or four dependent loads (funcInt, the cdf entries of the search, func)
@@ -1721,7 +1723,6 @@ PG_DEV int sample_discrete(const float *tab, int n, float u, float &pdf) {
         pdf = (funcInt > 0) ? at(offset) / (funcInt * n) : 0;
         return offset;
     }
-#endif
     const float *func = tab, *cdf = tab + n;
     float funcInt = tab[2 * n + 1];
     int size = n + 1, first = 0, len = size;
@@ -1917,11 +1918,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? 4 : ((MODE == 1 && PG_S
             volDead = is_black(beta);  // volpath.cpp:78
         }
         Tri tri;
-#if PG_ABL == 4
-        if (found) tri = load_tri(sc, prim & 1023);
-#else
         if (found) tri = load_tri(sc, prim);
-#endif
         // the hit's material record, fetched as soon as its index is known (one round trip, overlapped with the interaction's
         // arithmetic) instead of field by field where each is used
         const PgMaterial mtl = sc.materials[found ? tri.material : 0];
@@ -1954,11 +1951,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? 4 : ((MODE == 1 && PG_S
             for (int li = 0; li < sc.nLights; ++li)
                 if (sc.lights[li].type == PG_LIGHT_INFINITE) L = L + beta * env_le(sc, sc.lights[li], rayD);
         }
-#if PG_ABL == 6
-        bool alive = false;
-#else
         bool alive = found && bounces < rd.max_depth;  // path.cpp:104
-#endif
         int newFlags = 0;
         bool handled = false;
         if constexpr (VOL) {
@@ -2203,17 +2196,9 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? 4 : ((MODE == 1 && PG_S
                 if constexpr (EXT) hasNonSpecular = lbsdf_num_components(lb, nonSpecular) > 0;
                 else hasNonSpecular = bsdf.nBxDFs > 0 && !bsdf.specular;
                 // ---- direct lighting: UniformSampleOneLight (integrator.cpp:85-106) + EstimateDirect set-up
-#if PG_ABL == 5
-                const bool wantLight = false;
-#else
                 const bool wantLight = (VOL || hasNonSpecular) && sc.nLights > 0;  // path.cpp:119: only with non-specular lobes (volpath.cpp:124-127: always)
-#endif
                 PROF(1);
-#if PG_ABL == 7
-                const float *tab = wantLight ? sc.distTable : nullptr;
-#else
                 const float *tab = wantLight ? light_distribution(sc, is.p) : nullptr;
-#endif
                 if (wantLight && !tab) deferred = true;
                 if (tab) {
                     float lightSelPdf;
@@ -2231,7 +2216,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? 4 : ((MODE == 1 && PG_S
                         float4 pdLight = make_float4(0, 0, 0, 0);
                         LightSample ls;
                         Spec Li = light_sample_li_hot<EXT>(sc, lh, light, is.p, is.pError, is.n, uL0, uL1, wi, lightPdf, ls);
-                        if ((PG_ABL != 9) && lightPdf > 0 && !is_black(Li)) {
+                        if (lightPdf > 0 && !is_black(Li)) {
                             Spec f;
                             if constexpr (EXT) { f = lbsdf_f(lb, is.wo, wi, nonSpecular) * absdot(wi, shNs); scatteringPdf = lbsdf_pdf(lb, is.wo, wi, nonSpecular); }
                             else { f = bsdf_f(bsdf, is.wo, wi) * absdot(wi, shNs); scatteringPdf = bsdf_pdf(bsdf, is.wo, wi); }
@@ -2264,7 +2249,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? 4 : ((MODE == 1 && PG_S
                         V3 wi2 = wi;
                         float sPdf2 = 0;
                         Spec f2 = sp(0);
-                        if ((PG_ABL != 8) && (lh.type == PG_LIGHT_AREA || (EXT && lh.type == PG_LIGHT_INFINITE))) {  // integrator.cpp:164: if (!IsDeltaLight(light.flags))
+                        if (lh.type == PG_LIGHT_AREA || (EXT && lh.type == PG_LIGHT_INFINITE)) {  // integrator.cpp:164: if (!IsDeltaLight(light.flags))
                             if constexpr (EXT) { int st2; f2 = lbsdf_sample_f(lb, is.wo, wi2, uS0, uS1, sPdf2, nonSpecular, st2); }
                             else f2 = bsdf_sample_f(bsdf, is.wo, wi2, uS0, uS1, sPdf2);
                             f2 = f2 * absdot(wi2, shNs);
@@ -2282,10 +2267,8 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? 4 : ((MODE == 1 && PG_S
                         }
                         // pending terms of this vertex, consumed by k_resolve (pdMis and the MIS weight follow below)
                         pdLight.w = lightSelPdf;
-#if PG_ABL != 1
                         st.pdLight[pdi] = pdLight;
                         st.pdBeta[pdi] = make_float4(beta.r, beta.g, beta.b, 0.f);
-#endif
                     }
                 }
                 PROF(5);
@@ -2340,7 +2323,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? 4 : ((MODE == 1 && PG_S
         if (rp.rd.sampler >= PG_SAMPLER_RANDOM) { sc.ts[slot].state = tsState0; sc.ts[slot].cur1D = tsCur1D0; sc.ts[slot].cur2D = tsCur2D0; }  // nor a draw from the tile's stream
         rp.retryList[atomicAdd(&sc.voxelCounters[1], 1)] = i;
     }
-    if ((PG_ABL != 10) && misCand) {
+    if (misCand) {
         // light.Pdf_Li -> Shape::Pdf(ref, wi): intersect the light's own triangle (shape.cpp:72-87, diffuse.cpp:83-87)
         float lightPdf2 = 0;
         if (EXT && misLightPrim < 0) lightPdf2 = env_pdf_li(sc, sc.lights[-1 - misLightPrim], misWi);  // infinite light: no geometry to test
@@ -2365,7 +2348,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? 4 : ((MODE == 1 && PG_S
                 lightPdf2 = pdf;
             }
         }
-        if ((PG_ABL != 12) && lightPdf2 != 0) {
+        if (lightPdf2 != 0) {
             s_ray[2][0][tid] = make_float4(misRo.x, misRo.y, misRo.z, PG_INF);
             s_ray[2][1][tid] = make_float4(misWi.x, misWi.y, misWi.z, __int_as_float(slot));
             pushMis = true;
@@ -2378,14 +2361,9 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? 4 : ((MODE == 1 && PG_S
     const RayQueue outQ[3] = {qnext, qshadow, qmis};
     const bool outPred[3] = {pushNext, pushShadow, pushMis};
     int outPos[3];
-#if PG_ABL == 3
-    for (int k = 0; k < 3; ++k) outPos[k] = outPred[k] ? (i >= 0 ? i : 0) : -1;
-#else
     block_push<3, true, PG_SHADE_BLOCK>(outQ, outPred, outPos, nextBin);
-#endif
     PROF(9);
     const int posNext = outPos[0], posShadow = outPos[1], posMis = outPos[2];
-#if PG_ABL != 2
     if (pushNext) { qnext.o[posNext] = s_ray[0][0][tid]; qnext.d[posNext] = s_ray[0][1][tid]; }
     if (pushShadow) { qshadow.o[posShadow] = s_ray[1][0][tid]; qshadow.d[posShadow] = s_ray[1][1][tid]; }
     if (pushMis) { qmis.o[posMis] = s_ray[2][0][tid]; qmis.d[posMis] = s_ray[2][1][tid]; }
@@ -2399,7 +2377,6 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? 4 : ((MODE == 1 && PG_S
             st.pdInfo[pdi] = make_int4(posShadow, posMis, lightNum, pushNext ? posNext : ~slot);
         }
     } else if (valid && !deferred) st.pdInfo[slot] = make_int4(posShadow, posMis, lightNum, VOL ? __float_as_int(volWeight) : 0);
-#endif
     unsigned long long nl = wave_sum(nLightTests);
     if (lane_id() == 0 && nl) atomicAdd(lightTriTests + (blockIdx.x & (PG_LIGHT_TEST_SHARDS - 1)) * PG_LIGHT_TEST_STRIDE, nl);
 #ifdef PG_SHADE_PROF

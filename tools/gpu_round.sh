@@ -1,8 +1,9 @@
 #!/bin/bash
 # One gpurun call: GPU parity tests, the headline bench, the rocprofv3 kernel-trace summary and the PMC traffic passes.
-# usage (from the repo root on the GPU box): bash tools/gpu_round.sh TAG [quick|full]
+# usage (from the repo root on the GPU box): bash tools/gpu_round.sh TAG [quick|std|full]
 #   quick: tests (without the slow full-size reference comparison) + bench + kernel stats
-#   full : + PMC passes for config 3, the 5 M-triangle stand-in (bench, kernel stats, PMC) and the slow tests
+#   std  : + PMC traffic passes for config 3, the 5 M-triangle stand-in (bench + kernel stats) and the 10 M-triangle volpath stand-in (bench)
+#   full : + PMC passes for the 5 M stand-in, the slow full-size comparisons with the reference binary, tile-serial and shard timing
 TAG=${1:-r02}; MODE=${2:-quick}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -14,25 +15,26 @@ prof() {  # prof NAME bench-args...: kernel-trace stats of one bench run
   rm -rf $OUT/prof_$name
 }
 ( PBRT_SKIP_SLOW=1 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 ) > $OUT/pytest_gpu.log
-( timeout 900 python bench.py --steps 2 --warmup 1 2> $OUT/bench.err ) > $OUT/bench.json
+( timeout 900 python bench.py --steps 3 --warmup 1 2> $OUT/bench.err ) > $OUT/bench.json
 prof cfg3
 tail -5 $OUT/pytest_gpu.log; cat $OUT/bench.json; head -8 $OUT/kernel_stats_cfg3.csv
-if [ "$MODE" = full ]; then
+if [ "$MODE" != quick ]; then
   bash tools/pmc_traffic.sh $TAG/traffic_cfg3 > $OUT/traffic_cfg3.log 2>&1
+  cp $OUT/traffic_cfg3/pmc_traffic.json profiles/pmc_traffic.json 2>/dev/null
   ( timeout 900 python bench.py --steps 2 --warmup 1 --grid 1582 --spp 256 --no-cpu-baseline 2> $OUT/bench_5m.err ) > $OUT/bench_5m.json
   prof 5m --grid 1582 --spp 256
-  cp $OUT/traffic_cfg3/pmc_traffic.json profiles/pmc_traffic.json 2>/dev/null
+  cat $OUT/bench_5m.json; head -6 $OUT/kernel_stats_5m.csv
+  ( timeout 600 python bench.py --steps 2 --warmup 1 --workload synthetic-vol --grid 2237 --spp 128 --no-cpu-baseline 2> $OUT/bench_10m_vol.err ) > $OUT/bench_10m_vol.json; cut -c1-400 $OUT/bench_10m_vol.json
+  find $OUT -name '*counter_collection.csv' -size +4M -delete
+fi
+if [ "$MODE" = full ]; then
   bash tools/pmc_traffic.sh $TAG/traffic_5m --steps 1 --warmup 0 --no-cpu-baseline --grid 1582 --spp 256 > $OUT/traffic_5m.log 2>&1
   cp $OUT/traffic_5m/pmc_traffic.json $OUT/pmc_traffic.json 2>/dev/null
-  cat $OUT/bench_5m.json; head -6 $OUT/kernel_stats_5m.csv
   ( timeout 1500 python -m pytest tests/test_gpu_fullsize_reference.py -m gpu -x -q 2>&1 | tail -15 ) > $OUT/pytest_slow.log
   cp gpurun_out/fullsize_parity_config*.json $OUT/ 2>/dev/null
   tail -5 $OUT/pytest_slow.log
   find $OUT -name '*counter_collection.csv' -size +4M -delete
-fi
-if [ "$MODE" = full ]; then
   ( timeout 900 python tools/fullsize_parity.py 4 5 --out=$OUT/fullsize_parity_config4_5.json > $OUT/fullsize_4_5.log 2>&1 ); tail -2 $OUT/fullsize_4_5.log | cut -c1-700
-  ( timeout 600 python bench.py --steps 2 --warmup 1 --workload synthetic-vol --grid 2237 --spp 128 --no-cpu-baseline 2> $OUT/bench_10m_vol.err ) > $OUT/bench_10m_vol.json; cut -c1-400 $OUT/bench_10m_vol.json
   ( timeout 600 python tools/ts_timing.py 960 540 16 > $OUT/ts_timing.json 2> $OUT/ts_timing.err ); cat $OUT/ts_timing.json
   ( timeout 300 python tools/shard_timing.py > $OUT/shard_timing.json 2> $OUT/shard_timing.err ); cat $OUT/shard_timing.json
 fi

@@ -5,10 +5,12 @@
 //      (one 64-byte access per quad and round); the pieces are NOT exchanged back -- this is the fetch cost alone
 //   D  one 16-byte load per lane (a quarter of the data: the floor for "one access per lane")
 // Every lane chases its own chain: the next record index depends on the data just loaded, as in a traversal.
-// Build: hipcc --offload-arch=gfx950 -O3 tools/ubench_gather.hip -o gpurun_in_ubench.so   Run: ./gpurun_in_ubench.so
+// Built by pbrt-v3_amd/Makefile into pbrt-v3_amd/ubench_gather; bench.py runs it (--json, the scene's working-set size) for the
+// record-fetch ceiling it quotes next to k_trace's rate.  (records per second with --json)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -61,12 +63,22 @@ static double run(const float4 *table, unsigned n, int iters, float *out, int bl
     return ms;
 }
 
-int main() {
+int main(int argc, char **argv) {
+    // usage: ubench_gather [--json] [table sizes in MiB ...]   (default: L2-resident, config 3's working set, the 5 M / 10 M-triangle sets)
     const int blocks = 256 * 7, iters = 512;
+    bool json = false;
+    std::vector<size_t> sizesMB;
+    for (int i = 1; i < argc; ++i) {
+        if (std::string(argv[i]) == "--json") json = true;
+        else sizesMB.push_back((size_t)atol(argv[i]));
+    }
+    if (sizesMB.empty()) sizesMB = {2, 24, 91, 459, 925};
     float *out;
     CHECK(hipMalloc(&out, sizeof(float) * 256 * blocks));
-    const size_t sizesMB[5] = {2, 24, 91, 459, 925};  // L2-resident, Infinity-Cache-resident (config 3's BVH), HBM
+    if (json) printf("{");
+    bool first = true;
     for (size_t mb : sizesMB) {
+        if (mb < 1) mb = 1;
         const unsigned n = (unsigned)(mb * 1024 * 1024 / 64);
         float4 *table;
         CHECK(hipMalloc(&table, (size_t)n * 64));
@@ -74,9 +86,15 @@ int main() {
         const double fetches = (double)blocks * 256 * iters;
         const double a = run<0>(table, n, iters, out, blocks), b = run<1>(table, n, iters, out, blocks), c = run<2>(table, n, iters, out, blocks),
                      d = run<3>(table, n, iters, out, blocks);
-        printf("table %4zu MB: A together %.2f ms (%.1f G rec/s, %.0f GB/s) | B staged %.2f ms (%.1f) | C quad-cooperative %.2f ms (%.1f) | D 16 B only %.2f ms (%.1f)\n",
-               mb, a, fetches / a * 1e-6, fetches * 64 / a * 1e-6, b, fetches / b * 1e-6, c, fetches / c * 1e-6, d, fetches / d * 1e-6);
+        if (json)
+            printf("%s\"%zu\": {\"together\": %.4g, \"staged\": %.4g, \"quad_cooperative\": %.4g, \"first_16_bytes_only\": %.4g}", first ? "" : ", ", mb,
+                   fetches / a * 1e3, fetches / b * 1e3, fetches / c * 1e3, fetches / d * 1e3);
+        else
+            printf("table %4zu MB: A together %.2f ms (%.1f G rec/s, %.0f GB/s) | B staged %.2f ms (%.1f) | C quad-cooperative %.2f ms (%.1f) | D 16 B only %.2f ms (%.1f)\n",
+                   mb, a, fetches / a * 1e-6, fetches * 64 / a * 1e-6, b, fetches / b * 1e-6, c, fetches / c * 1e-6, d, fetches / d * 1e-6);
+        first = false;
         CHECK(hipFree(table));
     }
+    if (json) printf("}\n");
     return 0;
 }
