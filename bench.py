@@ -220,7 +220,7 @@ def main():
                      else "Cornell box, 36 triangles") +
                     f", {integ} maxdepth 5, halton, {args.filter} filter, {args.xres}x{args.yres} @ {args.spp} spp")
         n_interior = max(0, (scene.desc.n_nodes - 1) // 2)
-        working_set = 64 * n_interior + 48 * scene.desc.n_tris  # child-pair records + triangle records
+        working_set = 64 * n_interior + 64 * scene.desc.n_tris  # child-pair records + triangle records, one 64-B line each
         bound = "l2" if working_set < INFINITY_CACHE_BYTES else "hbm"
         peak = L2_PEAK_GBS if bound == "l2" else HBM_PEAK_GBS
         pmc_kernels = {}  # HBM-side bytes per launch from the committed PMC passes of this same workload (tools/pmc_traffic.sh)
@@ -265,13 +265,21 @@ def main():
         ub = os.path.join(ROOT, "pbrt-v3_amd", "ubench_gather")
         if os.path.exists(ub) and cn["closest_ms"] > 0:
             try:
-                ws_mb = max(1, int(round(working_set / 2**20)))
-                ceil = json.loads(subprocess.run([ub, "--json", str(ws_mb)], capture_output=True, text=True, timeout=120).stdout)[str(ws_mb)]
+                ws_mb = max(3, int(round(working_set / 2**20)))
+                ceil = json.loads(subprocess.run([ub, "--json", "2", str(ws_mb)], capture_output=True, text=True, timeout=120).stdout)
+                c_l2, c_ws = ceil["2"]["together"], ceil[str(ws_mb)]["together"]
                 fetches = max(0, cn["closest_node_visits"] - n_close) / 2 + cn["closest_tri_tests"]
                 rate = fetches / (cn["closest_ms"] * 1e-3)
-                gather = {"kernel": "k_trace<false>", "record_fetches_per_s": rate, "ceiling_records_per_s": ceil["together"],
-                          "frac": rate / ceil["together"], "table_MiB": ws_mb, "ceilings": ceil,
-                          "note": "ceiling = random 64-B record fetches per second, one chain per lane, table of the working set's size"}
+                # A traversal is not a uniformly random walk: the top of the tree stays in the L2s.  With the kernel's measured L2 hit
+                # rate h (committed PMC pass of this workload) the ceiling is the harmonic blend of the L2-resident rate and the rate
+                # at the working set's size; without h only the L2-resident rate is a safe upper bound.
+                h = next((v.get("l2_hit_rate") for k, v in pmc_kernels.items() if k.startswith("void k_trace<false")), None)
+                ceiling = 1.0 / (h / c_l2 + (1.0 - h) / c_ws) if h is not None else c_l2
+                gather = {"kernel": "k_trace<false>", "record_fetches_per_s": rate, "ceiling_records_per_s": ceiling, "frac": rate / ceiling,
+                          "ceiling_kind": ("1 / (h / C(2 MiB) + (1 - h) / C(working set)), h = L2 hit rate of the kernel from profiles/pmc_traffic.json"
+                                           if h is not None else "C(2 MiB): L2-resident table (no PMC pass of this workload committed: upper bound)"),
+                          "l2_hit_rate": h, "table_MiB": ws_mb, "ceiling_l2_resident": c_l2, "ceiling_at_working_set": c_ws,
+                          "note": "C(x) = random 64-B record fetches per second measured live by pbrt-v3_amd/ubench_gather: one chain per lane, table of x MiB"}
             except Exception as e:  # the measurement tool is optional; the bench line is not
                 gather = {"error": str(e)}
         kernels = [k for k in kernels if k["total_ms"] > 0]

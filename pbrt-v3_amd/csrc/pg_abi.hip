@@ -229,7 +229,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         set_trace_config(tc);
     }
     // --- triangles: gather vertices into BVH order, 48 B per triangle
-    std::vector<float4> tris((size_t)nt * 3);
+    std::vector<float4> tris((size_t)nt * PG_TRI_STRIDE, make_float4(0, 0, 0, 0));
     std::vector<float> uv;
     bool anyUV = false;
     for (int k = 0; k < nt; ++k) anyUV |= desc->UV && desc->tri_flags && (desc->tri_flags[k] & PG_TRI_HAS_UV);
@@ -246,9 +246,9 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
             const int none = -1;
             flags = PG_PRIM_INSTANCE;
             memcpy(&iw, &v[0], 4); memcpy(&fw, &flags, 4); memcpy(&mw, &mat, 4); memcpy(&lw, &none, 4);
-            tris[3 * (size_t)k] = make_float4(iw, 0, 0, fw);
-            tris[3 * (size_t)k + 1] = make_float4(0, 0, 0, mw);
-            tris[3 * (size_t)k + 2] = make_float4(0, 0, 0, lw);
+            tris[PG_TRI_STRIDE * (size_t)k] = make_float4(iw, 0, 0, fw);
+            tris[PG_TRI_STRIDE * (size_t)k + 1] = make_float4(0, 0, 0, mw);
+            tris[PG_TRI_STRIDE * (size_t)k + 2] = make_float4(0, 0, 0, lw);
             if (anyUV) { const float duv[6] = {0, 0, 1, 0, 1, 1}; memcpy(&uv[(size_t)k * 6], duv, sizeof(duv)); }
             continue;
         }
@@ -257,9 +257,9 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
             float iw, fw, mw, lw;
             flags = PG_PRIM_SPHERE;
             memcpy(&iw, &v[0], 4); memcpy(&fw, &flags, 4); memcpy(&mw, &mat, 4); memcpy(&lw, &light, 4);
-            tris[3 * (size_t)k] = make_float4(iw, 0, 0, fw);
-            tris[3 * (size_t)k + 1] = make_float4(0, 0, 0, mw);
-            tris[3 * (size_t)k + 2] = make_float4(0, 0, 0, lw);
+            tris[PG_TRI_STRIDE * (size_t)k] = make_float4(iw, 0, 0, fw);
+            tris[PG_TRI_STRIDE * (size_t)k + 1] = make_float4(0, 0, 0, mw);
+            tris[PG_TRI_STRIDE * (size_t)k + 2] = make_float4(0, 0, 0, lw);
             if (anyUV) { const float duv[6] = {0, 0, 1, 0, 1, 1}; memcpy(&uv[(size_t)k * 6], duv, sizeof(duv)); }
             continue;
         }
@@ -275,9 +275,9 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         if (!tri_dpdu(p[0], p[1], p[2], tuv, dpdu)) flags |= PG_TRI_BOGUS;  // triangle.cpp:309-317
         float fw, mw, lw;
         memcpy(&fw, &flags, 4); memcpy(&mw, &mat, 4); memcpy(&lw, &light, 4);
-        tris[3 * (size_t)k] = make_float4(p[0].x, p[0].y, p[0].z, fw);
-        tris[3 * (size_t)k + 1] = make_float4(p[1].x, p[1].y, p[1].z, mw);
-        tris[3 * (size_t)k + 2] = make_float4(p[2].x, p[2].y, p[2].z, lw);
+        tris[PG_TRI_STRIDE * (size_t)k] = make_float4(p[0].x, p[0].y, p[0].z, fw);
+        tris[PG_TRI_STRIDE * (size_t)k + 1] = make_float4(p[1].x, p[1].y, p[1].z, mw);
+        tris[PG_TRI_STRIDE * (size_t)k + 2] = make_float4(p[2].x, p[2].y, p[2].z, lw);
     }
     // per-vertex normals / tangents, de-indexed like the positions (only when some mesh has them)
     for (int pass = 0; pass < 2; ++pass) {
@@ -441,7 +441,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
             memcpy(&ti, &L.type, 4); memcpy(&pi_, &L.prim, 4); memcpy(&si, &L.two_sided, 4);
             hot[5 * (size_t)l] = make_float4(ti, pi_, si, L.area);
             hot[5 * (size_t)l + 1] = make_float4(L.L[0], L.L[1], L.L[2], 0.f);
-            if (L.type == PG_LIGHT_AREA && L.prim >= 0 && L.prim < nt) for (int k = 0; k < 3; ++k) hot[5 * (size_t)l + 2 + k] = tris[3 * (size_t)L.prim + k];
+            if (L.type == PG_LIGHT_AREA && L.prim >= 0 && L.prim < nt) for (int k = 0; k < 3; ++k) hot[5 * (size_t)l + 2 + k] = tris[PG_TRI_STRIDE * (size_t)L.prim + k];
         }
         HIP_TRY_S(s->lightHot.alloc(sizeof(float4) * hot.size()));
         if (!hot.empty()) HIP_TRY_S(hipMemcpy(s->lightHot.p, hot.data(), s->lightHot.bytes, hipMemcpyHostToDevice));

@@ -7,6 +7,9 @@
 #include "../../include/pbrt_gpu.h"
 
 // Per-triangle flag bits stored in tris[3*i].w, on top of PG_TRI_*.
+#ifndef PG_TRI_STRIDE
+#define PG_TRI_STRIDE 4
+#endif
 #define PG_TRI_BOGUS 0x100u  // Triangle::Intersect rejects every hit (triangle.cpp:309-317)
 
 // One object definition (instancing) on the device: its BVHAccel's root, or its lone primitive when nNodes == 0.
@@ -38,6 +41,8 @@ struct DScene {
     int leafBits;
     // Triangles in BVH order, 48 B each: three float4
     //   t[0] = (p0, flags)  t[1] = (p1, material)  t[2] = (p2, light)
+    // stored PG_TRI_STRIDE float4 apart: 4 puts every record into one 64-B line (of 48-B records packed back to back half
+    // straddle two lines, and the traversal is bound by lines fetched)
     const float4 *tris;
     // per-vertex shading normals N / tangents S de-indexed per triangle (3 float4 each, BVH order), or nullptr when no mesh has them
     const float4 *triN, *triS;

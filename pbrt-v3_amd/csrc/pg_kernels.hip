@@ -99,7 +99,7 @@ PG_DEV unsigned long long wave_sum(unsigned long long v) {
 
 struct Tri { V3 p0, p1, p2; uint32_t flags; int material, light; };
 PG_DEV Tri load_tri(const DScene &sc, int prim) {
-    float4 a = sc.tris[3 * prim], b = sc.tris[3 * prim + 1], c = sc.tris[3 * prim + 2];
+    float4 a = sc.tris[PG_TRI_STRIDE * prim], b = sc.tris[PG_TRI_STRIDE * prim + 1], c = sc.tris[PG_TRI_STRIDE * prim + 2];
     Tri t;
     t.p0 = mk(a.x, a.y, a.z); t.p1 = mk(b.x, b.y, b.z); t.p2 = mk(c.x, c.y, c.z);
     t.flags = __float_as_uint(a.w); t.material = __float_as_int(b.w); t.light = __float_as_int(c.w);
@@ -1864,14 +1864,14 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? 4 : ((MODE == 1 && PG_S
         // (sample index, dimension); the tile-serial samplers advance their tile's state (slot = tile, one path per tile)
         const bool tileSerial = rd.sampler >= PG_SAMPLER_RANDOM;
         if (tileSerial) { tsState0 = sc.ts[slot].state; tsCur1D0 = sc.ts[slot].cur1D; tsCur2D0 = sc.ts[slot].cur2D; }  // restored if this vertex is deferred (sparse light tables)
-        // PathIntegrator + Halton: the PG_NPRE dimensions a surface vertex usually draws (light choice, uLight, uScattering, the
+        // Halton: the PG_NPRE dimensions a surface vertex usually draws (light choice, uLight, uScattering, the
         // next direction) are computed together before the first draw (halton_batch); preDim0 < 0: not computed
         constexpr int PG_NPRE = 7;
         float pre[PG_NPRE];
         int preDim0 = -1;
         auto sample_dim = [&](int d) -> float {
             const int k = d - preDim0;
-            if (!VOL && preDim0 >= 0 && k >= 0 && k < PG_NPRE)
+            if (preDim0 >= 0 && k >= 0 && k < PG_NPRE)
                 return k == 0 ? pre[0] : (k == 1 ? pre[1] : (k == 2 ? pre[2] : (k == 3 ? pre[3] : (k == 4 ? pre[4] : (k == 5 ? pre[5] : pre[6])))));
             return halton_sample(sc, rd, index, d);
         };
@@ -1960,6 +1960,11 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? 4 : ((MODE == 1 && PG_S
             if (alive && inMedium) {
                 // ---- scattering at a point in the medium, volpath.cpp:80-96: MediumInteraction(p, -ray.d, ..., medium, phase)
                 handled = true;
+                {   // the dimensions of this vertex's draws side by side (as at a surface vertex, below)
+                    const int dimU = __builtin_amdgcn_readfirstlane(dim);
+                    const bool can = !tileSerial && rd.sampler == 0 && (index >> 32) == 0 && dim >= 2;
+                    if (__ballot(!can || dim != dimU) == 0) { halton_batch<PG_NPRE>(sc, (uint32_t)index, dimU, pre); preDim0 = dimU; }
+                }
                 const float g = sc.media[med - 1].g;
                 const V3 zero = mk(0, 0, 0), wo = -rayD;
                 const float *tab = sc.nLights > 0 ? light_distribution(sc, mediumP) : nullptr;
@@ -2003,7 +2008,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? 4 : ((MODE == 1 && PG_S
                                 misRo = mediumP; misWi = wi2; misF = sp(ph2); misPdf = ph2; misP = mediumP; misMedium = med;
                                 misLightPrim = light.type == PG_LIGHT_INFINITE ? -1 - lightNum : light.prim; misLightArea = light.area;
                                 if (light.type == PG_LIGHT_AREA) {
-                                    const float4 la = sc.tris[3 * light.prim];
+                                    const float4 la = sc.tris[PG_TRI_STRIDE * light.prim];
                                     if (__float_as_uint(la.w) & PG_PRIM_SPHERE)
                                         misInside = sc.spheres[__float_as_int(la.x)].shape != PG_SHAPE_SPHERE ||
                                                     sphere_ref_inside(sc.spheres[__float_as_int(la.x)], mediumP, zero, zero);
@@ -2063,7 +2068,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? 4 : ((MODE == 1 && PG_S
                 // MatteMaterial::ComputeScatteringFunctions (matte.cpp:45-62), BSDF ctor (reflection.h:167-172)
                 // BSDF: the EXT kernel evaluates the material's BxDF list (any material); the plain kernel has the list
                 // shapes of matte / plastic / mirror / glass baked in (same arithmetic, fewer registers)
-                if constexpr (!VOL) {
+                {
                     // every lane here draws at least the next direction; the batch needs one dimension for the whole wave
                     const int dimU = __builtin_amdgcn_readfirstlane(dim);
                     const bool can = !tileSerial && rd.sampler == 0 && (index >> 32) == 0 && dim >= 2;

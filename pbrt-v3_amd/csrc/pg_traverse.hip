@@ -274,7 +274,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
         if (nTri > 0 && (nInt == 0 || nTri * 16 >= nInt * triW)) {
             if (triLeft > 0) {  // Triangle::Intersect[P] on the leaf's next primitive, in order (bvh.cpp:677-680)
                 const int prim = triNext;
-                const float4 a = sc.tris[3 * prim], b = sc.tris[3 * prim + 1], c = sc.tris[3 * prim + 2];
+                const float4 a = sc.tris[PG_TRI_STRIDE * prim], b = sc.tris[PG_TRI_STRIDE * prim + 1], c = sc.tris[PG_TRI_STRIDE * prim + 2];
                 ++triTests; ++triNext; --triLeft;
                 const uint32_t pflags = __float_as_uint(a.w);
                 if (XPRIM && (pflags & PG_PRIM_INSTANCE)) {
