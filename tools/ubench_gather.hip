@@ -4,6 +4,7 @@
 //   C  quad-cooperative: in round r the four lanes of a quad fetch the four 16-byte pieces of quad-lane r's record
 //      (one 64-byte access per quad and round); the pieces are NOT exchanged back -- this is the fetch cost alone
 //   D  one 16-byte load per lane (a quarter of the data: the floor for "one access per lane")
+//   E  C followed by the exchange of the pieces inside the quad (DPP quad broadcasts + selects): what a traversal would pay
 // Every lane chases its own chain: the next record index depends on the data just loaded, as in a traversal.
 // Built by pbrt-v3_amd/Makefile into pbrt-v3_amd/ubench_gather; bench.py runs it (--json, the scene's working-set size) for the
 // record-fetch ceiling it quotes next to k_trace's rate.  (records per second with --json)
@@ -41,13 +42,63 @@ __global__ __launch_bounds__(256) void k_gather(const float4 *__restrict__ table
             const unsigned i0 = __shfl(idx, (threadIdx.x & 60) + 0), i1 = __shfl(idx, (threadIdx.x & 60) + 1), i2 = __shfl(idx, (threadIdx.x & 60) + 2),
                            i3 = __shfl(idx, (threadIdx.x & 60) + 3);
             a = table[4 * (size_t)i0 + lane4]; b = table[4 * (size_t)i1 + lane4]; c = table[4 * (size_t)i2 + lane4]; d = table[4 * (size_t)i3 + lane4];
+        } else if (MODE == 4) {
+            // C + the exchange: afterwards every lane holds the four pieces of ITS OWN record, as a traversal needs them.
+            // In round r the quad fetched quad-lane r's record, lane j piece j; lane l takes piece p of its record from lane p's
+            // round-l registers (a quad broadcast), selected by its position in the quad.
+            const unsigned i0 = __shfl(idx, (threadIdx.x & 60) + 0), i1 = __shfl(idx, (threadIdx.x & 60) + 1), i2 = __shfl(idx, (threadIdx.x & 60) + 2),
+                           i3 = __shfl(idx, (threadIdx.x & 60) + 3);
+            float4 r[4] = {table[4 * (size_t)i0 + lane4], table[4 * (size_t)i1 + lane4], table[4 * (size_t)i2 + lane4], table[4 * (size_t)i3 + lane4]};
+            float4 o[4] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+#define BC(v, P) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), (P) | ((P) << 2) | ((P) << 4) | ((P) << 6), 0xf, 0xf, true))
+#define TAKE(L, P) { const bool me = lane4 == (L); const float x = BC(r[L].x, P), y = BC(r[L].y, P), z = BC(r[L].z, P), w = BC(r[L].w, P); \
+                     o[P].x = me ? x : o[P].x; o[P].y = me ? y : o[P].y; o[P].z = me ? z : o[P].z; o[P].w = me ? w : o[P].w; }
+            TAKE(0, 0) TAKE(0, 1) TAKE(0, 2) TAKE(0, 3) TAKE(1, 0) TAKE(1, 1) TAKE(1, 2) TAKE(1, 3)
+            TAKE(2, 0) TAKE(2, 1) TAKE(2, 2) TAKE(2, 3) TAKE(3, 0) TAKE(3, 1) TAKE(3, 2) TAKE(3, 3)
+#undef TAKE
+#undef BC
+            a = o[0]; b = o[1]; c = o[2]; d = o[3];
+        } else if (MODE == 5) {
+            // E with each select and its quad broadcast fused into ONE v_cndmask_b32_dpp (the compiler emits a v_mov_b32_dpp and a
+            // v_cndmask_b32): D = vcc ? old : broadcast(r), vcc = the lanes that are NOT quad-lane L
+            const unsigned i0 = __shfl(idx, (threadIdx.x & 60) + 0), i1 = __shfl(idx, (threadIdx.x & 60) + 1), i2 = __shfl(idx, (threadIdx.x & 60) + 2),
+                           i3 = __shfl(idx, (threadIdx.x & 60) + 3);
+            float4 r[4] = {table[4 * (size_t)i0 + lane4], table[4 * (size_t)i1 + lane4], table[4 * (size_t)i2 + lane4], table[4 * (size_t)i3 + lane4]};
+            float4 o[4] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+#define ROW(P) "v_cndmask_b32_dpp %" #P "0, %16, %" #P "0, vcc quad_perm:[" #P "," #P "," #P "," #P "] row_mask:0xf bank_mask:0xf\n\t" \
+               "v_cndmask_b32_dpp %" #P "1, %17, %" #P "1, vcc quad_perm:[" #P "," #P "," #P "," #P "] row_mask:0xf bank_mask:0xf\n\t" \
+               "v_cndmask_b32_dpp %" #P "2, %18, %" #P "2, vcc quad_perm:[" #P "," #P "," #P "," #P "] row_mask:0xf bank_mask:0xf\n\t" \
+               "v_cndmask_b32_dpp %" #P "3, %19, %" #P "3, vcc quad_perm:[" #P "," #P "," #P "," #P "] row_mask:0xf bank_mask:0xf\n\t"
+            // operands: %0..%3 = o[0].xyzw, %4..%7 = o[1], %8..%11 = o[2], %12..%15 = o[3], %16..%19 = r[L].xyzw, %20 = mask
+#define TAKE_ROW(L) { const unsigned long long notMe = ~(0x1111111111111111ull << (L)); \
+            asm volatile("s_nop 1\n\ts_mov_b64 vcc, %20\n\t" \
+                "v_cndmask_b32_dpp %0, %16, %0, vcc quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\tv_cndmask_b32_dpp %1, %17, %1, vcc quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t" \
+                "v_cndmask_b32_dpp %2, %18, %2, vcc quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\tv_cndmask_b32_dpp %3, %19, %3, vcc quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t" \
+                "v_cndmask_b32_dpp %4, %16, %4, vcc quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\tv_cndmask_b32_dpp %5, %17, %5, vcc quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t" \
+                "v_cndmask_b32_dpp %6, %18, %6, vcc quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\tv_cndmask_b32_dpp %7, %19, %7, vcc quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t" \
+                "v_cndmask_b32_dpp %8, %16, %8, vcc quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\tv_cndmask_b32_dpp %9, %17, %9, vcc quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t" \
+                "v_cndmask_b32_dpp %10, %18, %10, vcc quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\tv_cndmask_b32_dpp %11, %19, %11, vcc quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t" \
+                "v_cndmask_b32_dpp %12, %16, %12, vcc quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\tv_cndmask_b32_dpp %13, %17, %13, vcc quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t" \
+                "v_cndmask_b32_dpp %14, %18, %14, vcc quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\tv_cndmask_b32_dpp %15, %19, %15, vcc quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" \
+                : "+v"(o[0].x), "+v"(o[0].y), "+v"(o[0].z), "+v"(o[0].w), "+v"(o[1].x), "+v"(o[1].y), "+v"(o[1].z), "+v"(o[1].w), \
+                  "+v"(o[2].x), "+v"(o[2].y), "+v"(o[2].z), "+v"(o[2].w), "+v"(o[3].x), "+v"(o[3].y), "+v"(o[3].z), "+v"(o[3].w) \
+                : "v"(r[L].x), "v"(r[L].y), "v"(r[L].z), "v"(r[L].w), "s"(notMe) : "vcc"); }
+            TAKE_ROW(0) TAKE_ROW(1) TAKE_ROW(2) TAKE_ROW(3)
+#undef TAKE_ROW
+#undef ROW
+            a = o[0]; b = o[1]; c = o[2]; d = o[3];
         } else { a = rec[0]; b = c = d = a; }
-        acc += a.y + b.y + c.y + d.y;
+        acc += (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w) + (c.x + c.y + c.z + c.w) + (d.x + d.y + d.z + d.w);  // every dword is used, as in a traversal
         idx = next_index(idx, a, n);
     }
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
+__global__ void k_fill(float4 *table, size_t n4) {  // distinct small integers per dword, so that a wrong exchange changes the sums
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) table[i] = make_float4((float)((4 * i) % 251), (float)((4 * i + 1) % 241), (float)((4 * i + 2) % 239), (float)((4 * i + 3) % 233));
+}
+static double g_checksum[8];
 template <int MODE>
 static double run(const float4 *table, unsigned n, int iters, float *out, int blocks) {
     hipEvent_t e0, e1;
@@ -60,6 +111,11 @@ static double run(const float4 *table, unsigned n, int iters, float *out, int bl
     CHECK(hipEventSynchronize(e1));
     float ms = 0;
     CHECK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<float> h((size_t)blocks * 256);
+    CHECK(hipMemcpy(h.data(), out, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+    double sum = 0;
+    for (float v : h) sum += v;
+    g_checksum[MODE] = sum;
     return ms;
 }
 
@@ -82,16 +138,21 @@ int main(int argc, char **argv) {
         const unsigned n = (unsigned)(mb * 1024 * 1024 / 64);
         float4 *table;
         CHECK(hipMalloc(&table, (size_t)n * 64));
-        CHECK(hipMemset(table, 0, (size_t)n * 64));
+        hipLaunchKernelGGL(k_fill, dim3((unsigned)(((size_t)n * 4 + 255) / 256)), dim3(256), 0, 0, table, (size_t)n * 4);
         const double fetches = (double)blocks * 256 * iters;
         const double a = run<0>(table, n, iters, out, blocks), b = run<1>(table, n, iters, out, blocks), c = run<2>(table, n, iters, out, blocks),
-                     d = run<3>(table, n, iters, out, blocks);
+                     d = run<3>(table, n, iters, out, blocks), e = run<4>(table, n, iters, out, blocks), f = run<5>(table, n, iters, out, blocks);
         if (json)
-            printf("%s\"%zu\": {\"together\": %.4g, \"staged\": %.4g, \"quad_cooperative\": %.4g, \"first_16_bytes_only\": %.4g}", first ? "" : ", ", mb,
-                   fetches / a * 1e3, fetches / b * 1e3, fetches / c * 1e3, fetches / d * 1e3);
+            printf("%s\"%zu\": {\"together\": %.4g, \"staged\": %.4g, \"quad_cooperative\": %.4g, \"first_16_bytes_only\": %.4g, \"quad_cooperative_exchanged\": %.4g, \"quad_cooperative_exchanged_fused\": %.4g}",
+                   first ? "" : ", ", mb, fetches / a * 1e3, fetches / b * 1e3, fetches / c * 1e3, fetches / d * 1e3, fetches / e * 1e3, fetches / f * 1e3);
         else
-            printf("table %4zu MB: A together %.2f ms (%.1f G rec/s, %.0f GB/s) | B staged %.2f ms (%.1f) | C quad-cooperative %.2f ms (%.1f) | D 16 B only %.2f ms (%.1f)\n",
-                   mb, a, fetches / a * 1e-6, fetches * 64 / a * 1e-6, b, fetches / b * 1e-6, c, fetches / c * 1e-6, d, fetches / d * 1e-6);
+            printf("table %4zu MB: A together %.2f ms (%.1f G rec/s, %.0f GB/s) | B staged %.2f ms (%.1f) | C quad-cooperative %.2f ms (%.1f) | D 16 B only %.2f ms (%.1f) | E C + exchange %.2f ms (%.1f) | F fused %.2f ms (%.1f)\n",
+                   mb, a, fetches / a * 1e-6, fetches * 64 / a * 1e-6, b, fetches / b * 1e-6, c, fetches / c * 1e-6, d, fetches / d * 1e-6, e, fetches / e * 1e-6, f, fetches / f * 1e-6);
+        // modes A, B, E, F deliver the same 64 bytes to every lane: their sums must agree (C and D read other bytes by design)
+        if (g_checksum[0] != g_checksum[1] || g_checksum[0] != g_checksum[4] || g_checksum[0] != g_checksum[5]) {
+            fprintf(stderr, "ubench_gather: the modes disagree at %zu MiB: A %.17g B %.17g E %.17g F %.17g\n", mb, g_checksum[0], g_checksum[1], g_checksum[4], g_checksum[5]);
+            return 1;
+        }
         first = false;
         CHECK(hipFree(table));
     }
