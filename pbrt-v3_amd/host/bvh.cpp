@@ -131,15 +131,18 @@ struct BVHAccel::PrimInfo {  // what the build knows of a primitive (BVHPrimitiv
 struct BVHAccel::BuildNode {  // BVHBuildNode, bvh.cpp:61-83
     void InitLeaf(int first, int n, const Bounds3f &b) {
         firstPrimOffset = first; nPrimitives = n; bounds = b; children[0] = children[1] = nullptr;
+        nNodes = 1;
     }
     void InitInterior(int axis, BuildNode *c0, BuildNode *c1) {
         children[0] = c0; children[1] = c1;
         bounds = Union(c0->bounds, c1->bounds);
         splitAxis = axis; nPrimitives = 0;
+        nNodes = 1 + c0->nNodes + c1->nNodes;
     }
     Bounds3f bounds;
     BuildNode *children[2];
     int splitAxis, firstPrimOffset, nPrimitives;
+    int nNodes;  // nodes of this subtree: where its second child lands in the depth-first array is known before it is written
 };
 
 BVHAccel::BuildNode *BVHAccel::allocNode() {
@@ -181,8 +184,7 @@ BVHAccel::BVHAccel(std::vector<GeometricPrimitive> p, int maxPrims, SplitMethod 
         } else {
             BuildNode *root = HLBVHBuild(primitiveInfo, &totalNodes, order);
             nodes.resize(totalNodes);
-            int offset = 0;
-            flattenBVHTree(root, &offset);
+            flattenBVHTree(root, 0, 0);
         }
         orderedPrims.resize(primitives.size());
         for (size_t i = 0; i < primitives.size(); ++i) orderedPrims[i] = primitives[order[i]];
@@ -201,11 +203,10 @@ BVHAccel::BVHAccel(std::vector<GeometricPrimitive> p, int maxPrims, SplitMethod 
     BuildNode *root = recursiveBuild(primitiveInfo, 0, (int)primitives.size(), &nodeCount, orderedPrims, spawnDepth);
     if (timing) fprintf(stderr, "pbrt host: recursiveBuild of %zu primitives on up to %d threads\n", primitives.size(), 1 << spawnDepth);
     lap("recursiveBuild");
-    totalNodes = nodeCount;
+    totalNodes = root->nNodes;
     primitives.swap(orderedPrims);
     nodes.resize(totalNodes);
-    int offset = 0;
-    flattenBVHTree(root, &offset);
+    flattenBVHTree(root, 0, spawnDepth);
     lap("flatten");
     arena.clear();
     lap("free build nodes");
@@ -224,8 +225,7 @@ void BVHAccel::HLBVHFromBounds(int n, const float *bounds, int maxPrimsInNode, s
     int totalNodes = 0;
     BuildNode *root = a.HLBVHBuild(primitiveInfo, &totalNodes, *order);
     a.nodes.resize(totalNodes);
-    int offset = 0;
-    a.flattenBVHTree(root, &offset);
+    a.flattenBVHTree(root, 0, 0);
     nodes->swap(a.nodes);
 }
 
@@ -269,8 +269,7 @@ struct SahBuckets {
 
 BVHAccel::BuildNode *BVHAccel::recursiveBuild(std::vector<PrimInfo> &primitiveInfo, int start, int end, std::atomic<int> *totalNodes,
                                               std::vector<GeometricPrimitive> &orderedPrims, int spawnDepth) {
-    BuildNode *node = allocNode();
-    (*totalNodes)++;
+    BuildNode *node = allocNode();  // (counted through BuildNode::nNodes: an atomic counter here is bumped by every thread for every node)
     Bounds3f bounds;
     for (int i = start; i < end; ++i) bounds = Union(bounds, primitiveInfo[i].bounds);
     int nPrimitives = end - start;
@@ -343,22 +342,37 @@ BVHAccel::BuildNode *BVHAccel::recursiveBuild(std::vector<PrimInfo> &primitiveIn
     return node;
 }
 
-int BVHAccel::flattenBVHTree(BuildNode *node, int *offset) {  // bvh.cpp:640-658
-    PgBVHNode *linearNode = &nodes[*offset];
-    for (int i = 0; i < 3; ++i) { linearNode->bmin[i] = node->bounds.pMin[i]; linearNode->bmax[i] = node->bounds.pMax[i]; }
-    linearNode->pad = 0;
-    int myOffset = (*offset)++;
-    if (node->nPrimitives > 0) {
-        linearNode->offset = node->firstPrimOffset;
-        linearNode->nprims = (uint16_t)node->nPrimitives;
-        linearNode->axis = 0;
-    } else {
+// flattenBVHTree (bvh.cpp:640-658): the same depth-first layout, written at offsets computed from the subtree sizes -- a node at
+// `offset` has its first child at offset + 1 and its second at offset + 1 + nodes(first child) -- so subtrees do not wait for
+// one another and the large ones go to their own threads (the serial recursion was half of a 5 M-triangle scene's load time
+// on the GPU box's 256 threads).
+void BVHAccel::flattenBVHTree(BuildNode *node, int offset, int spawnDepth) {
+    for (;;) {
+        PgBVHNode *linearNode = &nodes[offset];
+        for (int i = 0; i < 3; ++i) { linearNode->bmin[i] = node->bounds.pMin[i]; linearNode->bmax[i] = node->bounds.pMax[i]; }
+        linearNode->pad = 0;
+        if (node->nPrimitives > 0) {
+            linearNode->offset = node->firstPrimOffset;
+            linearNode->nprims = (uint16_t)node->nPrimitives;
+            linearNode->axis = 0;
+            return;
+        }
         linearNode->axis = (uint8_t)node->splitAxis;
         linearNode->nprims = 0;
-        flattenBVHTree(node->children[0], offset);
-        linearNode->offset = flattenBVHTree(node->children[1], offset);
+        const int second = offset + 1 + node->children[0]->nNodes;
+        linearNode->offset = second;
+        if (spawnDepth > 0 && node->nNodes >= (1 << 16)) {
+            BuildNode *c0 = node->children[0];
+            std::future<void> first = std::async(std::launch::async, [this, c0, offset, spawnDepth]() { flattenBVHTree(c0, offset + 1, spawnDepth - 1); });
+            flattenBVHTree(node->children[1], second, spawnDepth - 1);
+            first.get();
+            return;
+        }
+        flattenBVHTree(node->children[0], offset + 1, 0);
+        node = node->children[1];  // (tail call)
+        offset = second;
+        spawnDepth = 0;
     }
-    return myOffset;
 }
 
 // ---- HLBVH (bvh.cpp:107-180, :404-638): Morton codes of the centroids, a stable radix sort, one LBVH treelet per run of

@@ -96,7 +96,7 @@ class BVHAccel {
     // of the recursion hand their first child to a new thread -- with a result that does not depend on the thread count
     BuildNode *recursiveBuild(std::vector<PrimInfo> &primitiveInfo, int start, int end, std::atomic<int> *totalNodes,
                               std::vector<GeometricPrimitive> &orderedPrims, int spawnDepth);
-    int flattenBVHTree(BuildNode *node, int *offset);
+    void flattenBVHTree(BuildNode *node, int offset, int spawnDepth);
     struct MortonPrim;
     // the HLBVH build works on primitive numbers: order[k] = number of the k-th primitive of the leaf order
     BuildNode *HLBVHBuild(const std::vector<PrimInfo> &primitiveInfo, int *totalNodes, std::vector<int> &order);
