@@ -1787,6 +1787,10 @@ PG_DEV void prim_interface(const DScene &sc, int prim, int rayMedium, int &mIn, 
 #ifndef PG_SHADE_MIN_WAVES
 #define PG_SHADE_MIN_WAVES 3
 #endif
+// the specialised surface kernel (MODE 0): 125 VGPRs = four waves per SIMD without the cap; the cap keeps later edits there
+#ifndef PG_SHADE0_WAVES
+#define PG_SHADE0_WAVES 4
+#endif
 #ifdef PG_SHADE_PROF  // experiment build (tools/shade_phases.sh): where a shading wave's time goes -- s_memtime deltas per phase of one
 // block in 128 (so that the instrumentation's own atomics do not disturb what they measure), summed over those waves
 #define PG_NPROF 12
@@ -1807,7 +1811,7 @@ void shade_prof_dump() {
 #define PROF(k) do { } while (0)
 #endif
 template <int MODE, bool VOL>
-__global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? 4 : ((MODE == 1 && PG_SHADE_MIN_WAVES > 0) ? PG_SHADE_MIN_WAVES : 1)) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
+__global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MODE == 1 && PG_SHADE_MIN_WAVES > 0) ? PG_SHADE_MIN_WAVES : 1)) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
                                                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, VolState vs,
                                                      const float *__restrict__ hitT, QueueState qsIn, QueueState qsOut) {
     constexpr bool EXT = MODE >= 1, TEX = MODE == 2;
