@@ -47,7 +47,7 @@ def make_scene_file(workdir, args):
                   .replace('"integer pixelsamples" [ 256 ]', f'"integer pixelsamples" [ {args.spp} ]'))
         open(path, "w").write(txt)
     else:
-        # (PBRT_BENCH_MAXDEPTH: kernel diagnostics only -- tools/_run_exp8.sh; the benchmark is maxdepth 5)
+        # (PBRT_BENCH_MAXDEPTH: kernel diagnostics only; the benchmark is maxdepth 5)
         gen_synthetic.write_scene(path, n=args.grid, xres=args.xres, yres=args.yres, spp=args.spp,
                                   maxdepth=int(os.environ.get("PBRT_BENCH_MAXDEPTH", "5")))
         if args.workload == "synthetic-vol":  # BASELINE config 4's stand-in: the mesh inside a HomogeneousMedium, VolPathIntegrator

@@ -1791,7 +1791,7 @@ PG_DEV void prim_interface(const DScene &sc, int prim, int rayMedium, int &mIn, 
 #ifndef PG_SHADE0_WAVES
 #define PG_SHADE0_WAVES 4
 #endif
-#ifdef PG_SHADE_PROF  // experiment build (tools/shade_phases.sh): where a shading wave's time goes -- s_memtime deltas per phase of one
+#ifdef PG_SHADE_PROF  // experiment build (make GPUEXTRA=-DPG_SHADE_PROF): where a shading wave's time goes -- s_memtime deltas per phase of one
 // block in 128 (so that the instrumentation's own atomics do not disturb what they measure), summed over those waves
 #define PG_NPROF 12
 __device__ unsigned long long g_shadeProf[PG_NPROF + 1];

@@ -1,4 +1,4 @@
-// pg_sortexp.hip -- EXPERIMENT build only (-DPG_EXPERIMENT_SORT, tools/sort_experiment.sh): what would k_trace gain if the
+// pg_sortexp.hip -- EXPERIMENT build only (make GPUEXTRA=-DPG_EXPERIMENT_SORT, tools/experiments/r02s_exp4_*.sh): what would k_trace gain if the
 // rays of a queue were handed to its waves in an order that keeps neighbours together (origin cell + direction octant)?
 // The rays stay where they are; a permutation (radix sort of a 27-bit key per ray, hipCUB) tells k_trace which entry to
 // take for position i of a region, and results go to the entry's own index, so nothing else of the pipeline changes.

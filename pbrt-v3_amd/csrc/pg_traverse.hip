@@ -105,7 +105,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
                                                     int hitOffset1, float *__restrict__ tOut, int *__restrict__ occluded,
                                                     TraceCounters *cn, int *__restrict__ cursors, int depth, int chunk, int refillAt, int triW,
                                                     float cullK, int *cullGuard, int maxAccepted
-#ifdef PG_EXPERIMENT_SORT  // tools/sort_experiment.sh: position i of a region takes entry perm[i] (pg_sortexp.hip)
+#ifdef PG_EXPERIMENT_SORT  // make GPUEXTRA=-DPG_EXPERIMENT_SORT: position i of a region takes entry perm[i] (pg_sortexp.hip)
                                                     , const int *__restrict__ perm0, const int *__restrict__ perm1
 #endif
                                                     ) {
