@@ -1040,7 +1040,7 @@ static std::shared_ptr<TriangleMesh> CreateTriangleMeshShape(const Transform &o2
     const std::vector<Float> *N = params.FindNormal3f("N");
     if (N && (int)N->size() / 3 != npi) { Error("Number of \"N\"s for triangle mesh must match \"P\"s"); N = nullptr; }
     for (int i = 0; i < nvi; ++i)
-        if ((*vi)[i] >= npi) {
+        if ((*vi)[i] >= npi || (*vi)[i] < 0) {  // (the reference only checks the upper bound and reads out of bounds below zero)
             Error("trianglemesh has out of-bounds vertex index %d (%d \"P\" values were given", (*vi)[i], npi);
             return nullptr;
         }

@@ -310,7 +310,11 @@ BVHAccel::BuildNode *BVHAccel::recursiveBuild(std::vector<PrimInfo> &primitiveIn
         constexpr int nBuckets = SahBuckets::N;
         auto bucketOf = [&centroidBounds, dim](const PrimInfo &pi) {  // bvh.cpp:318-322: the centroid's twelfth along the split axis
             int b = nBuckets * centroidBounds.Offset(pi.centroid)[dim];
-            return b == nBuckets ? nBuckets - 1 : b;
+            if (b == nBuckets) b = nBuckets - 1;
+            // bvh.cpp:323-324 CHECK_GE(b, 0), CHECK_LT(b, nBuckets): non-finite or overflowing vertex coordinates end here in the
+            // reference too (it aborts); the library reports the scene instead of indexing out of bounds
+            if (b < 0 || b >= nBuckets) { Error("BVHAccel: a primitive's centroid falls into no SAH bucket (non-finite or overflowing bounds)"); Fatal(); }
+            return b;
         };
         SahBuckets buckets;
         for (int i = start; i < end; ++i) buckets.Add(bucketOf(primitiveInfo[i]), primitiveInfo[i].bounds);
@@ -468,6 +472,7 @@ BVHAccel::BuildNode *BVHAccel::buildUpperSAH(std::vector<BuildNode *> &treeletRo
         Float centroid = (n->bounds.pMin[dim] + n->bounds.pMax[dim]) * 0.5f;
         int b = nBuckets * ((centroid - centroidBounds.pMin[dim]) / (centroidBounds.pMax[dim] - centroidBounds.pMin[dim]));
         if (b == nBuckets) b = nBuckets - 1;
+        if (b < 0 || b >= nBuckets) { Error("HLBVH: a treelet's centroid falls into no SAH bucket (non-finite or overflowing bounds)"); Fatal(); }  // bvh.cpp:583-584 CHECKs
         return b;
     };
     SahBuckets buckets;

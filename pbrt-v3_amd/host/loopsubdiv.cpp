@@ -24,12 +24,18 @@ struct Level {  // one level of the mesh tree: vertices and faces refer to each 
     std::vector<SDVertex> V;
     std::vector<SDFace> F;
     int vnum(int f, int vert) const {
-        for (int i = 0; i < 3; ++i) if (F[f].v[i] == vert) return i;
-        Error("Basic logic error in SDFace::vnum()");
-        return 0;
+        // a walk around a vertex of a non-manifold mesh arrives at a face that does not hold the vertex, or at no face at all:
+        // the reference aborts here (LOG(FATAL), loopsubdiv.cpp:92-97); the library reports the mesh
+        if (f >= 0 && f < (int)F.size()) for (int i = 0; i < 3; ++i) if (F[f].v[i] == vert) return i;
+        Error("Basic logic error in SDFace::vnum(): the loopsubdiv control mesh is not a manifold");
+        Fatal();
     }
-    int nextFace(int f, int vert) const { return F[f].f[vnum(f, vert)]; }
-    int prevFace(int f, int vert) const { return F[f].f[PREV(vnum(f, vert))]; }
+    // every walk around a vertex visits a face at most once on a manifold; on anything else it can circle without ever
+    // meeting its start again (the reference then hangs): `steps` is reset by the walks' callers and checked here
+    mutable size_t steps = 0;
+    void step() const { if (++steps > 2 * F.size() + 8) { Error("loopsubdiv: a walk around a vertex does not close: the control mesh is not a manifold"); Fatal(); } }
+    int nextFace(int f, int vert) const { step(); return F[f].f[vnum(f, vert)]; }
+    int prevFace(int f, int vert) const { step(); return F[f].f[PREV(vnum(f, vert))]; }
     int nextVert(int f, int vert) const { return F[f].v[NEXT(vnum(f, vert))]; }
     int prevVert(int f, int vert) const { return F[f].v[PREV(vnum(f, vert))]; }
     int otherVert(int f, int v0, int v1) const {
@@ -38,6 +44,7 @@ struct Level {  // one level of the mesh tree: vertices and faces refer to each 
         return F[f].v[0];
     }
     int valence(int vi) const {  // loopsubdiv.cpp:121-136
+        steps = 0;
         const SDVertex &v = V[vi];
         int f = v.startFace;
         if (!v.boundary) {
@@ -52,6 +59,7 @@ struct Level {  // one level of the mesh tree: vertices and faces refer to each 
         return nf + 1;
     }
     void oneRing(int vi, Point3f *p) const {  // loopsubdiv.cpp:435-453
+        steps = 0;
         const SDVertex &v = V[vi];
         if (!v.boundary) {
             int face = v.startFace;
@@ -131,6 +139,7 @@ std::shared_ptr<TriangleMesh> CreateLoopSubdiv(const Transform &o2w, bool revers
         SDVertex &v = cur.V[i];
         if (v.startFace < 0) { Error("loopsubdiv: vertex %d is not used by any face", i); return nullptr; }
         int f = v.startFace;
+        cur.steps = 0;
         do { f = cur.nextFace(f, i); } while (f != -1 && f != v.startFace);
         v.boundary = (f == -1);
         if (!v.boundary && cur.valence(i) == 6) v.regular = true;

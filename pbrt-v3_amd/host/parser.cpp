@@ -190,8 +190,8 @@ struct Parser {
             }
             std::string tok = fileStack.back()->Next();
             if (tok.empty()) {
-                fileStack.pop_back();
-                if (!fileStack.empty()) parserLoc = &fileStack.back()->loc;
+                fileStack.pop_back();  // (the location the error routines print lived in the tokenizer just destroyed)
+                parserLoc = fileStack.empty() ? nullptr : &fileStack.back()->loc;
                 continue;
             }
             return tok;

@@ -182,6 +182,28 @@ def test_malformed_scene_raises_instead_of_exiting(pkg):
     assert pkg.HostScene(os.path.join(GOLD, "cornell_32.pbrt")).desc.n_tris == 36
 
 
+def test_hostile_geometry_is_reported_not_read_out_of_bounds(pkg):
+    """Inputs a fuzzer found (mutated golden scenes under AddressSanitizer, tools/fuzz_host_frontend.py): the reference reads out of
+    bounds, trips a CHECK or hangs on them; the library reports them and stays usable."""
+    head = MINI.split("WorldBegin")[0] % (8, 8, 1) + "WorldBegin\n"
+    # a negative vertex index (the reference checks only the upper bound): the mesh is refused, the scene has no geometry
+    s = pkg.HostScene(text=head + 'Shape "trianglemesh" "integer indices" [ 0 -1 2 ] "point P" [ 0 0 0 1 0 0 0 1 0 ]\nWorldEnd\n')
+    assert s.desc.n_tris == 0
+    # non-finite vertices: no SAH bucket holds the centroid (bvh.cpp:323-324 CHECKs in the reference)
+    tris = " ".join(f"{i} 0 0  {i} 1 0  {i} 0 1" for i in range(6))
+    idx = " ".join(str(k) for k in range(18))
+    with pytest.raises(pkg.PbrtGpuError):
+        pkg.HostScene(text=head + f'Shape "trianglemesh" "integer indices" [ {idx} ] "point P" [ nan 0 0 {tris[5:]} ]\nWorldEnd\n')
+    # a file that ends inside a directive after its last tokenizer is gone: the error message must not read the freed location
+    with pytest.raises(pkg.PbrtGpuError):
+        pkg.HostScene(text=head + 'Shape "trianglemesh" "integer indices"')
+    # a control mesh that is not a manifold (three faces on one edge): the reference aborts in SDFace::vnum() or walks forever
+    with pytest.raises(pkg.PbrtGpuError):
+        pkg.HostScene(text=head + 'Shape "loopsubdiv" "integer levels" [ 1 ] "integer indices" [ 0 1 2  0 1 3  0 1 4  1 0 2 ] '
+                                  '"point P" [ 0 0 0  1 0 0  0 1 0  0 0 1  1 1 1 ]\nWorldEnd\n')
+    assert pkg.HostScene(os.path.join(GOLD, "cornell_32.pbrt")).desc.n_tris == 36
+
+
 def test_second_frame_starts_from_fresh_render_options(pkg):
     """Several WorldBegin / WorldEnd frames in one file: pbrtWorldEnd resets RenderOptions (api.cpp:1630-1640), so frame 2 does not
     inherit frame 1's film, sampler, integrator or material tables.  (A load keeps the last frame.)"""
