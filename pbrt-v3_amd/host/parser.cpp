@@ -331,6 +331,8 @@ struct Parser {
             else if (tok == "Include") {
                 std::string fn = dequote(nextToken(true));
                 fn = AbsolutePath(ResolveFilename(fn));
+                // a file that includes itself (directly or not) nests without end; the reference reads files until memory runs out
+                if (fileStack.size() >= 256) { Error("Include \"%s\": more than 256 nested files (a file that includes itself?)", fn.c_str()); Fatal(); }
                 auto t = Tokenizer::FromFile(fn);
                 if (t) { fileStack.push_back(std::move(t)); parserLoc = &fileStack.back()->loc; }
             }

@@ -204,6 +204,13 @@ def test_hostile_geometry_is_reported_not_read_out_of_bounds(pkg):
     assert pkg.HostScene(os.path.join(GOLD, "cornell_32.pbrt")).desc.n_tris == 36
 
 
+def test_file_that_includes_itself_is_an_error(pkg, tmp_path):
+    f = tmp_path / "self.pbrt"
+    f.write_text(f'Include "{f}"\n')
+    with pytest.raises(pkg.PbrtGpuError):
+        pkg.HostScene(str(f))
+
+
 def test_second_frame_starts_from_fresh_render_options(pkg):
     """Several WorldBegin / WorldEnd frames in one file: pbrtWorldEnd resets RenderOptions (api.cpp:1630-1640), so frame 2 does not
     inherit frame 1's film, sampler, integrator or material tables.  (A load keeps the last frame.)"""
