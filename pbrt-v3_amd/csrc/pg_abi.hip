@@ -465,16 +465,24 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         HIP_TRY_S(hipMemcpy(s->permSums.p, desc->perm_sums, s->permSums.bytes, hipMemcpyHostToDevice));
         HIP_TRY_S(s->primes.alloc(sizeof(int32_t) * primes.size()));
         HIP_TRY_S(hipMemcpy(s->primes.p, primes.data(), s->primes.bytes, hipMemcpyHostToDevice));
-        // per dimension: (base, offset of its digit permutation, m, L) with floor(a / base) = (t + ((a - t) >> 1)) >> (L - 1),
+        // per dimension, two int4: (base, offset of its digit permutation, m, L) with floor(a / base) = (t + ((a - t) >> 1)) >> (L - 1),
         // t = mulhi(m, a), for every 32-bit a (division by an invariant integer with a 33-bit multiplier: L = ceil(log2 base),
-        // m = floor(2^32 (2^L - base) / base) + 1): the digit loops of the radical inverse divide without dividing
-        std::vector<int32_t> hd(4 * primes.size());
+        // m = floor(2^32 (2^L - base) / base) + 1), and (invBase, invBase * perm[0] / (1 - invBase), 0, 0) as float bits: the two
+        // per-dimension constants of ScrambledRadicalInverse (lowdiscrepancy.cpp:411, :422), evaluated here with the same float
+        // operations in the same order as the kernels would (contraction off, IEEE division)
+        std::vector<int32_t> hd(8 * primes.size(), 0);
         for (size_t i = 0; i < primes.size(); ++i) {
             const uint64_t b = (uint64_t)primes[i];
             int L = 0;
             while (((uint64_t)1 << L) < b) ++L;
             const uint64_t m = (((uint64_t)1 << 32) * (((uint64_t)1 << L) - b)) / b + 1;
-            hd[4 * i] = primes[i]; hd[4 * i + 1] = desc->perm_sums[i]; hd[4 * i + 2] = (int32_t)(uint32_t)m; hd[4 * i + 3] = L;
+            hd[8 * i] = primes[i]; hd[8 * i + 1] = desc->perm_sums[i]; hd[8 * i + 2] = (int32_t)(uint32_t)m; hd[8 * i + 3] = L;
+            volatile float invBase = 1.f / (float)(uint32_t)primes[i];
+            volatile float t1 = invBase * (float)desc->perms[desc->perm_sums[i]];
+            volatile float t2 = 1 - invBase;
+            volatile float tail = t1 / t2;
+            const float ib = invBase, tl = tail;
+            memcpy(&hd[8 * i + 4], &ib, 4); memcpy(&hd[8 * i + 5], &tl, 4);
         }
         HIP_TRY_S(s->haltonDims.alloc(sizeof(int32_t) * hd.size()));
         HIP_TRY_S(hipMemcpy(s->haltonDims.p, hd.data(), s->haltonDims.bytes, hipMemcpyHostToDevice));

@@ -92,8 +92,9 @@ struct DScene {
     const int32_t *permSums;
     const int32_t *primes;
     int nPermDims;
-    // per Halton dimension (base, offset of its permutation in perms, m, L): floor(a / base) = (t + ((a - t) >> 1)) >> (L - 1)
-    // with t = mulhi(m, a), exact for every 32-bit a -- the digit loops divide by multiplying (pg_abi.hip builds the table)
+    // per Halton dimension two int4: (base, offset of its permutation in perms, m, L) -- floor(a / base) = (t + ((a - t) >> 1))
+    // >> (L - 1) with t = mulhi(m, a), exact for every 32-bit a: the digit loops divide by multiplying -- and, as float bits,
+    // (1 / base, (1 / base) * perm[0] / (1 - 1 / base), 0, 0): ScrambledRadicalInverse's two constants (pg_abi.hip builds the table)
     const int4 *haltonDims;
     // SobolSampler tables (core/sobolmatrices.h:49-52), nullptr unless the scene was created with them
     const uint32_t *sobolMatrices;

@@ -169,10 +169,10 @@ PG_DEV float halton_sample(const DScene &sc, const PgRenderDesc &rd, uint64_t in
     if (dim >= sc.nPermDims) dim = sc.nPermDims - 1;  // host sizes the table from maxdepth; halton.h:71-76 aborts here
     if ((index >> 32) != 0) return scrambled_radical_inverse((uint32_t)sc.primes[dim], sc.perms + sc.permSums[dim], index);
     // 32-bit index: scrambled_radical_inverse's loop with the division done by multiplication (DScene::haltonDims)
-    const int4 hd = sc.haltonDims[dim];
+    const int4 hd = sc.haltonDims[2 * dim], hc = sc.haltonDims[2 * dim + 1];
     const uint32_t base = (uint32_t)hd.x, mul = (uint32_t)hd.z, sh = (uint32_t)hd.w - 1u;
     const uint16_t *perm = sc.perms + hd.y;
-    const float invBase = 1.f / (float)base;
+    const float invBase = __int_as_float(hc.x);  // 1.f / (float)base
     uint64_t reversedDigits = 0;
     float invBaseN = 1;
     uint32_t a32 = (uint32_t)index;
@@ -183,7 +183,7 @@ PG_DEV float halton_sample(const DScene &sc, const PgRenderDesc &rd, uint64_t in
         invBaseN *= invBase;
         a32 = next;
     }
-    return pmin(invBaseN * ((float)reversedDigits + invBase * (float)perm[0] / (1 - invBase)), PG_ONE_MINUS_EPS);
+    return pmin(invBaseN * ((float)reversedDigits + __int_as_float(hc.y) /* invBase * perm[0] / (1 - invBase) */), PG_ONE_MINUS_EPS);
 }
 
 // The N Halton dimensions dim0 .. dim0+N-1 of one sample index at once (HaltonSampler::SampleDimension for each, halton.cpp:119-127
@@ -196,14 +196,14 @@ template <int N>
 PG_DEV void halton_batch(const DScene &sc, uint32_t a0, int dim0, float *out) {
     uint32_t base[N], off[N], mul[N], sh[N], a[N];
     uint64_t rev[N];
-    float invBase[N], invBaseN[N];
+    float invBase[N], tail[N], invBaseN[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         int d = dim0 + j;
         if (d >= sc.nPermDims) d = sc.nPermDims - 1;
-        const int4 hd = sc.haltonDims[d];
+        const int4 hd = sc.haltonDims[2 * d], hc = sc.haltonDims[2 * d + 1];
         base[j] = (uint32_t)hd.x; off[j] = (uint32_t)hd.y; mul[j] = (uint32_t)hd.z; sh[j] = (uint32_t)hd.w - 1u;
-        invBase[j] = 1.f / (float)base[j];
+        invBase[j] = __int_as_float(hc.x); tail[j] = __int_as_float(hc.y);
         a[j] = a0; rev[j] = 0; invBaseN[j] = 1;
     }
     uint32_t any = a0;
@@ -222,18 +222,18 @@ PG_DEV void halton_batch(const DScene &sc, uint32_t a0, int dim0, float *out) {
         asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]));
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            const bool act = a[j] != 0;  // a dimension whose digits are used up stays as it is
-            const uint64_t r2 = rev[j] * base[j] + p[j];
-            const float n2 = invBaseN[j] * invBase[j];
-            rev[j] = act ? r2 : rev[j];
-            invBaseN[j] = act ? n2 : invBaseN[j];
+            // a dimension whose digits are used up stays as it is: it is multiplied by one and gets zero added (exact), which
+            // keeps the loop body free of branches
+            const bool act = a[j] != 0;
+            rev[j] = rev[j] * (act ? base[j] : 1u) + (act ? p[j] : 0u);
+            invBaseN[j] *= act ? invBase[j] : 1.f;
             a[j] = next[j];
             any |= next[j];
         }
     }
 #pragma unroll
     for (int j = 0; j < N; ++j)
-        out[j] = pmin(invBaseN[j] * ((float)rev[j] + invBase[j] * (float)sc.perms[off[j]] / (1 - invBase[j])), PG_ONE_MINUS_EPS);
+        out[j] = pmin(invBaseN[j] * ((float)rev[j] + tail[j]), PG_ONE_MINUS_EPS);
 }
 
 // ---- the samplers that draw from one RNG stream per tile (RandomSampler; the PixelSamplers, sampler.cpp:100-134) ------------
