@@ -619,6 +619,12 @@ void pbrtAttributeEnd() {
     VERIFY_WORLD("AttributeEnd");
     if (!pushedGraphicsStates.size()) { Error("Unmatched pbrtAttributeEnd() encountered. Ignoring it."); return; }
     graphicsState = std::move(pushedGraphicsStates.back()); pushedGraphicsStates.pop_back();
+    // a TransformEnd inside the block may already have taken the transform this block pushed (the reference reads the
+    // empty stack's back() there, api.cpp:1158-1163): report it, keep the current transform
+    if (pushedTransforms.empty() || pushedActiveTransformBits.empty()) {
+        Error("AttributeEnd: the transform saved by its AttributeBegin was popped by an unmatched TransformEnd. Keeping the current transform.");
+        return;
+    }
     curTransform = pushedTransforms.back(); pushedTransforms.pop_back();
     activeTransformBits = pushedActiveTransformBits.back(); pushedActiveTransformBits.pop_back();
 }

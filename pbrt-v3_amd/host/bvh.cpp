@@ -170,7 +170,18 @@ BVHAccel::BVHAccel(std::vector<GeometricPrimitive> p, int maxPrims, SplitMethod 
         tick = now;
     };
     std::vector<PrimInfo> primitiveInfo(primitives.size());
-    for (size_t i = 0; i < primitives.size(); ++i) primitiveInfo[i] = {i, primitives[i].WorldBound()};
+    {   // every primitive's bound on its own: split over the build's threads
+        int nt = PbrtOptions.nThreads > 0 ? PbrtOptions.nThreads : (int)std::thread::hardware_concurrency();
+        if (const char *e = getenv("PBRT_NTHREADS")) { if (atoi(e) > 0) nt = atoi(e); }
+        nt = std::max(1, std::min(nt, 64));
+        if (primitives.size() < (size_t)(1 << 16)) nt = 1;
+        auto fill = [&](size_t b, size_t e) { for (size_t i = b; i < e; ++i) primitiveInfo[i] = {i, primitives[i].WorldBound()}; };
+        std::vector<std::thread> pool;
+        const size_t per = (primitives.size() + nt - 1) / nt;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(fill, std::min(primitives.size(), t * per), std::min(primitives.size(), (t + 1) * per));
+        fill(0, std::min(primitives.size(), per));
+        for (auto &th : pool) th.join();
+    }
     lap("primitive bounds");
     int totalNodes = 0;
     std::vector<GeometricPrimitive> orderedPrims;

@@ -211,6 +211,15 @@ def test_file_that_includes_itself_is_an_error(pkg, tmp_path):
         pkg.HostScene(str(f))
 
 
+def test_transform_end_inside_attribute_block_does_not_read_an_empty_stack(pkg):
+    """AttributeBegin pushes a transform too; a stray TransformEnd inside the block takes it, and the reference's AttributeEnd then
+    reads back() of the empty stack (api.cpp:1141-1163).  Here: reported, the scene still loads with its geometry."""
+    one = open(os.path.join(GOLD, "cornell_32.pbrt")).read()
+    head, world = one.split("WorldBegin", 1)
+    s = pkg.HostScene(text=head + "WorldBegin\nAttributeBegin\nTransformEnd\nAttributeEnd\n" + world)
+    assert s.desc.n_tris == 36
+
+
 def test_second_frame_starts_from_fresh_render_options(pkg):
     """Several WorldBegin / WorldEnd frames in one file: pbrtWorldEnd resets RenderOptions (api.cpp:1630-1640), so frame 2 does not
     inherit frame 1's film, sampler, integrator or material tables.  (A load keeps the last frame.)"""
