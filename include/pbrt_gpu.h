@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 22
+#define PG_ABI_VERSION 23
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -297,6 +297,21 @@ typedef struct PgMedium {
     float g;
 } PgMedium;
 
+/* GridDensityMedium (media/grid.h:49-96), the "heterogeneous" medium of MakeMedium (api.cpp:700-722).  Its PgMedium entry holds
+ * sigma_a, sigma_s (after "scale"), g, and sigma_t = sigma_a + sigma_s in all three channels -- the constructor requires a
+ * spectrally uniform sigma_t (grid.h:64-68), the host reports the same error; PgSceneDesc.media_grid[m] is the index of medium
+ * m's grid here, -1 for a HomogeneousMedium.
+ * libpbrt_gpu.so of this ABI version has no kernels for it: pg_scene_create answers PG_ERR_UNSUPPORTED when n_grids > 0
+ * (the CPU oracle renders it). */
+typedef struct PgDensityGrid {
+    int32_t nx, ny, nz;
+    int32_t reserved;
+    int64_t density_offset;     /* first of nx*ny*nz floats in PgSceneDesc.grid_density, x fastest: density[(z*ny + y)*nx + x] (grid.h:77-81) */
+    float sigma_t;              /* (sigma_a + sigma_s)[0] */
+    float inv_max_density;      /* 1 / max of the density values (grid.h:69-72) */
+    float world_to_medium[16];  /* Inverse(medium2world * Translate(p0) * Scale(p1 - p0)).m, row-major: world -> the unit cube */
+} PgDensityGrid;
+
 typedef struct PgSceneDesc {
     int32_t abi_version;        /* PG_ABI_VERSION */
     /* acceleration structure, BVHAccel after flattenBVHTree (bvh.cpp:640-658) */
@@ -359,6 +374,12 @@ typedef struct PgSceneDesc {
     const uint64_t *vdc_sobol_inv;
     const int32_t *noise_perm;  /* NoisePerm, 512 entries (core/texture.cpp:51-78); NULL unless a noise texture is present */
     const uint32_t *cmaxmin;    /* CMaxMinDist [17][32] (core/lowdiscrepancy.cpp:249-...); NULL unless the sampler is maxmindist */
+    /* ABI 23: GridDensityMedium tables; all zero / NULL when every medium is homogeneous */
+    int32_t n_grids;
+    const PgDensityGrid *grids;
+    const int32_t *media_grid;  /* n_media entries: index into grids, -1 = HomogeneousMedium; NULL when n_grids == 0 */
+    int64_t n_density_floats;
+    const float *grid_density;
 } PgSceneDesc;
 
 /* ---- render description -------------------------------------------------- */

@@ -18,7 +18,7 @@
 // Closed set of this binding: triangle meshes (with N / S / uv), spheres, cylinders and disks; materials whose parameters are
 // constant textures (their BxDF lists are read off Material::ComputeScatteringFunctions); diffuse area lights, point, spot
 // and distant lights; perspective and orthographic cameras; all six samplers; every pixel filter; homogeneous
-// media.  Anything else is reported with Error() and the process exits -- there is no CPU fallback here either.
+// and grid-density media.  Anything else is reported with Error() and the process exits -- there is no CPU fallback here either.
 #include <dlfcn.h>
 #include <unistd.h>
 #include <algorithm>
@@ -49,6 +49,7 @@
 #include "lights/spot.h"
 #include "lowdiscrepancy.h"
 #include "material.h"
+#include "media/grid.h"
 #include "media/homogeneous.h"
 #include "memory.h"
 #include "microfacet.h"
@@ -186,21 +187,49 @@ struct Flat {
     std::vector<PgLight> lights;
     std::vector<PgSphere> spheres;
     std::vector<PgMedium> media;
+    std::vector<int32_t> mediaGrid;   // per medium: index into grids, -1 = HomogeneousMedium
+    std::vector<PgDensityGrid> grids;
+    std::vector<float> gridDensity;
+    std::map<const Medium *, int> mediumIndex;
     std::vector<int32_t> permSums;
     PgSceneDesc desc;
 };
 
-int InternMedium(const Medium *m, std::map<const Medium *, int> *index, Flat *flat) {
+int InternMedium(const Medium *m, Flat *flat) {
     if (!m) return -1;
-    auto it = index->find(m);
-    if (it != index->end()) return it->second;
-    const HomogeneousMedium *h = dynamic_cast<const HomogeneousMedium *>(m);
-    if (!h) Unsupported("a medium other than HomogeneousMedium");
+    auto it = flat->mediumIndex.find(m);
+    if (it != flat->mediumIndex.end()) return it->second;
     PgMedium pm;
-    CopyRGB(h->sigma_a, pm.sigma_a); CopyRGB(h->sigma_s, pm.sigma_s); CopyRGB(h->sigma_t, pm.sigma_t);
-    pm.g = h->g;
+    int grid = -1;
+    if (const HomogeneousMedium *h = dynamic_cast<const HomogeneousMedium *>(m)) {
+        CopyRGB(h->sigma_a, pm.sigma_a); CopyRGB(h->sigma_s, pm.sigma_s); CopyRGB(h->sigma_t, pm.sigma_t);
+        pm.g = h->g;
+    } else if (const GridDensityMedium *gm = dynamic_cast<const GridDensityMedium *>(m)) {  // media/grid.h:49-96
+        CopyRGB(gm->sigma_a, pm.sigma_a); CopyRGB(gm->sigma_s, pm.sigma_s); CopyRGB(gm->sigma_a + gm->sigma_s, pm.sigma_t);
+        pm.g = gm->g;
+        PgDensityGrid gd;
+        gd.nx = gm->nx; gd.ny = gm->ny; gd.nz = gm->nz; gd.reserved = 0;
+        gd.density_offset = (int64_t)flat->gridDensity.size();
+        gd.sigma_t = gm->sigma_t; gd.inv_max_density = gm->invMaxDensity;
+        const Matrix4x4 &w2m = gm->WorldToMedium.GetMatrix();
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) gd.world_to_medium[4 * r + c] = w2m.m[r][c];
+        const Float *den = gm->density.get();
+        flat->gridDensity.insert(flat->gridDensity.end(), den, den + (size_t)gm->nx * gm->ny * gm->nz);
+        grid = (int)flat->grids.size();
+        flat->grids.push_back(gd);
+    } else Unsupported("a medium other than HomogeneousMedium / GridDensityMedium");
     flat->media.push_back(pm);
-    return (*index)[m] = (int)flat->media.size() - 1;
+    flat->mediaGrid.push_back(grid);
+    return flat->mediumIndex[m] = (int)flat->media.size() - 1;
+}
+// the media tables of the description (again after the camera's medium was added)
+void SetMediaTables(Flat *flat) {
+    PgSceneDesc &d = flat->desc;
+    d.n_media = (int)flat->media.size(); d.media = flat->media.data();
+    if (!flat->grids.empty()) {
+        d.n_grids = (int)flat->grids.size(); d.grids = flat->grids.data(); d.media_grid = flat->mediaGrid.data();
+        d.n_density_floats = (int64_t)flat->gridDensity.size(); d.grid_density = flat->gridDensity.data();
+    }
 }
 
 void FlattenScene(const Scene &scene, int maxDepth, bool volumetric, const std::string &strategy, const Sampler &sampler, Flat *flat) {
@@ -217,7 +246,6 @@ void FlattenScene(const Scene &scene, int maxDepth, bool volumetric, const std::
     for (PgLight &l : flat->lights) { memset(&l, 0, sizeof(l)); l.prim = -1; l.env_image = -1; }
     std::map<const TriangleMesh *, int> meshBase;
     std::map<const Material *, int> materialIndex;
-    std::map<const Medium *, int> mediumIndex;
     std::vector<const TriangleMesh *> meshes;
     bool anyN = false, anyUV = false, anyS = false, anyMedium = false;
     // pass 1: vertex arrays of the meshes in first-use order
@@ -311,7 +339,7 @@ void FlattenScene(const Scene &scene, int maxDepth, bool volumetric, const std::
             l.type = PG_LIGHT_AREA; l.prim = (int)k; CopyRGB(al->Lemit, l.L); l.two_sided = al->twoSided; l.area = al->area;
             flat->triLight[k] = li;
         }
-        const int mIn = InternMedium(gp->mediumInterface.inside, &mediumIndex, flat), mOut = InternMedium(gp->mediumInterface.outside, &mediumIndex, flat);
+        const int mIn = InternMedium(gp->mediumInterface.inside, flat), mOut = InternMedium(gp->mediumInterface.outside, flat);
         if (mIn >= 0 || mOut >= 0) {
             if (!anyMedium) { flat->triMedIn.assign(n, -1); flat->triMedOut.assign(n, -1); anyMedium = true; }
             flat->triMedIn[k] = mIn; flat->triMedOut[k] = mOut;
@@ -358,7 +386,7 @@ void FlattenScene(const Scene &scene, int maxDepth, bool volumetric, const std::
     }
     d.n_spheres = (int)flat->spheres.size(); d.spheres = flat->spheres.data();
     d.n_bxdfs = (int)flat->bxdfs.size(); d.bxdfs = flat->bxdfs.data();
-    d.n_media = (int)flat->media.size(); d.media = flat->media.data();
+    SetMediaTables(flat);
     d.tri_medium_inside = anyMedium ? flat->triMedIn.data() : nullptr; d.tri_medium_outside = anyMedium ? flat->triMedOut.data() : nullptr;
 }
 
@@ -457,16 +485,9 @@ void RenderOnDevice(const Scene &scene, const Camera &camera, const Sampler &sam
     static Abi abi;
     Flat flat;
     FlattenScene(scene, maxDepth, volumetric, strategy, sampler, &flat);
-    std::map<const Medium *, int> seen;
-    int cameraMedium = -1;
-    if (camera.medium) {  // Camera::medium: one of the media already interned through the primitives, or a new one
-        const HomogeneousMedium *h = dynamic_cast<const HomogeneousMedium *>(camera.medium);
-        if (!h) Unsupported("a camera medium other than HomogeneousMedium");
-        PgMedium pm;
-        CopyRGB(h->sigma_a, pm.sigma_a); CopyRGB(h->sigma_s, pm.sigma_s); CopyRGB(h->sigma_t, pm.sigma_t); pm.g = h->g;
-        for (size_t i = 0; i < flat.media.size(); ++i) if (!memcmp(&flat.media[i], &pm, sizeof(pm))) cameraMedium = (int)i;
-        if (cameraMedium < 0) { flat.media.push_back(pm); cameraMedium = (int)flat.media.size() - 1; flat.desc.n_media = (int)flat.media.size(); flat.desc.media = flat.media.data(); }
-    }
+    // Camera::medium: one of the media already interned through the primitives (the same Medium object), or a new one
+    const int cameraMedium = InternMedium(camera.medium, &flat);
+    SetMediaTables(&flat);
     PgRenderDesc rd;
     FillRenderDesc(camera, sampler, pixelBounds, maxDepth, rrThreshold, volumetric, cameraMedium, &rd);
     const int device = getenv("PBRT_GPU_DEVICE") ? atoi(getenv("PBRT_GPU_DEVICE")) : 0;

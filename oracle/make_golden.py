@@ -703,6 +703,83 @@ SCENES = {
 }
 
 
+# ---- GridDensityMedium ("heterogeneous", media/grid.cpp).  ABI 23 carries its tables and the CPU oracle renders it; the device
+# library refuses it (PG_ERR_UNSUPPORTED), so these goldens live in tests/golden_grid/, outside the device parity list. ----
+GOLD_GRID = os.path.join(ROOT, "tests", "golden_grid")
+
+
+def density_values(nx, ny, nz, peak, seed):
+    """A puff with some structure: a smooth blob times a lattice pattern, one empty slab, deterministic."""
+    import math
+    out = []
+    for z in range(nz):
+        for y in range(ny):
+            for x in range(nx):
+                u, v, w = (x + .5) / nx - .5, (y + .5) / ny - .5, (z + .5) / nz - .5
+                blob = math.exp(-6 * (u * u + v * v + w * w))
+                lat = 0.55 + 0.45 * math.sin(3.1 * x + seed) * math.cos(2.3 * y - seed) * math.sin(1.7 * z + 0.5 * seed)
+                out.append(0.0 if (y == 1 and ny > 3) else peak * blob * lat)
+    return " ".join(f"{v:.6g}" for v in out)
+
+
+def grid_medium(name, nx, ny, nz, p0, p1, sigma_a, sigma_s, g, peak, seed, extra=""):
+    return (f'MakeNamedMedium "{name}" "string type" "heterogeneous" "rgb sigma_a" [ {sigma_a} ] "rgb sigma_s" [ {sigma_s} ] "float g" [ {g} ] {extra}\n'
+            f'  "integer nx" [ {nx} ] "integer ny" [ {ny} ] "integer nz" [ {nz} ] "point p0" [ {p0} ] "point p1" [ {p1} ]\n'
+            f'  "float density" [ {density_values(nx, ny, nz, peak, seed)} ]\n')
+
+
+BOX_MESH = ('Shape "trianglemesh" "integer indices" [ 0 2 1 0 3 2  4 5 6 4 6 7  0 1 5 0 5 4  2 3 7 2 7 6  1 2 6 1 6 5  3 0 4 3 4 7 ]\n'
+            '    "point P" [ %(x0)g %(y0)g %(z0)g  %(x1)g %(y0)g %(z0)g  %(x1)g %(y1)g %(z0)g  %(x0)g %(y1)g %(z0)g  %(x0)g %(y0)g %(z1)g  %(x1)g %(y0)g %(z1)g  %(x1)g %(y1)g %(z1)g  %(x0)g %(y1)g %(z1)g ]\n')
+
+
+def with_grid_puff(s, dense=False):
+    """A GridDensityMedium inside a "none"-material box in front of the tall box (medium defined in the world block: identity CTM)."""
+    if dense:  # optical depth ~ 20 through the middle: VisibilityTester::Tr's roulette (grid.cpp:108-116) decides most shadow rays
+        med = grid_medium("puff", 5, 4, 6, "150 20 100", "400 350 400", "0.03125 0.0625 0.015625", "0.0625 0.03125 0.078125", 0.6, 3.0, 1.0)
+    else:
+        med = grid_medium("puff", 6, 5, 4, "150 20 100", "400 350 400", "0.0078125 0.015625 0.00390625", "0.015625 0.0078125 0.01953125", -0.3, 1.5, 2.0)
+    box = 'AttributeBegin\n  MediumInterface "puff" ""\n  Material "none"\n  ' + BOX_MESH % dict(x0=150, y0=20, z0=100, x1=400, y1=350, z1=400) + 'AttributeEnd\n'
+    return s.replace("WorldBegin\n", "WorldBegin\n" + med, 1).replace("# short box", box + "# short box", 1)
+
+
+def with_grid_fog(s):
+    """The whole box filled by a coarse GridDensityMedium, the camera inside it; the medium is declared before LookAt (identity CTM)."""
+    med = grid_medium("gfog", 4, 4, 8, "-50 -50 -900", "600 600 600", "0.00048828125 0.00048828125 0.00048828125", "0.00146484375 0.00146484375 0.00146484375", 0.2, 1.0, 0.7)
+    s = med + s
+    s = s.replace("Camera ", 'MediumInterface "" "gfog"\nCamera ', 1)
+    return s.replace("WorldBegin\n", 'WorldBegin\nMediumInterface "gfog" "gfog"\n', 1)
+
+
+def with_grid_transformed(s):
+    """The medium declared under a rotated, non-uniformly scaled CTM with "scale" and a preset's coefficients replaced by uniform
+    ones; a HomogeneousMedium next to it in the table (media_grid = -1 for that one); the grid's box is a "none" sphere that is
+    larger than the grid in places, so rays enter the medium but miss the unit cube."""
+    med = ('AttributeBegin\n  Translate 278 200 250\n  Rotate 35 0.3 1 0.2\n  Scale 160 120 140\n' +
+           grid_medium("cloud", 3, 7, 5, "-1 -1 -1", "1 1 1", "0.125 0.125 0.125", "1.875 1.875 1.875", 0.4, 1.2, 3.0, extra='"float scale" [ 0.01 ]') +
+           'AttributeEnd\n'
+           'MakeNamedMedium "thin" "string type" "homogeneous" "rgb sigma_a" [ 0.001 0.002 0.001 ] "rgb sigma_s" [ 0.003 0.002 0.004 ]\n')
+    ball = ('AttributeBegin\n  Translate 278 200 250\n  MediumInterface "cloud" "thin"\n  Material "none"\n  Shape "sphere" "float radius" [ 170 ]\nAttributeEnd\n')
+    s = s.replace("WorldBegin\n", 'WorldBegin\n' + med + 'MediumInterface "thin" "thin"\n', 1)
+    s = s.replace("Camera ", 'MakeNamedMedium "thin0" "string type" "homogeneous" "rgb sigma_a" [ 0.001 0.002 0.001 ] "rgb sigma_s" [ 0.003 0.002 0.004 ]\nMediumInterface "" "thin0"\nCamera ', 1)
+    return s.replace("# short box", ball + "# short box", 1)
+
+
+GRID_SCENES = {
+    "grid_puff": cornell(32, 32, 8, integrator='Integrator "volpath" "integer maxdepth" [ 5 ]', world_edit=with_grid_puff),
+    "grid_puff_dense": cornell(32, 32, 8, integrator='Integrator "volpath" "integer maxdepth" [ 6 ] "string lightsamplestrategy" "uniform"',
+                               world_edit=lambda s: with_grid_puff(s, dense=True).replace("# light\nAttributeBegin", DELTA_POINT + DELTA_SPOT + "# light\nAttributeBegin")),
+    "grid_fog_camera": cornell(32, 24, 8, integrator='Integrator "volpath" "integer maxdepth" [ 4 ]',
+                               world_edit=lambda s: with_grid_fog(s).replace("# light\nAttributeBegin", DELTA_POINT + "# light\nAttributeBegin")),
+    "grid_transformed": cornell(32, 32, 8, integrator='Integrator "volpath" "integer maxdepth" [ 5 ] "float rrthreshold" [ 0.5 ]', world_edit=with_grid_transformed),
+    "grid_puff_sobol": cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 5 ]', world_edit=with_grid_puff).replace('Sampler "halton"', 'Sampler "sobol"'),
+    "grid_puff_random": cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 5 ]', world_edit=with_grid_puff).replace('Sampler "halton"', 'Sampler "random"'),
+    "grid_puff_stratified": cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 5 ]', world_edit=lambda s: with_grid_puff(s, dense=True))
+                            .replace('Sampler "halton" "integer pixelsamples" [ 4 ]', 'Sampler "stratified" "integer xsamples" [ 2 ] "integer ysamples" [ 2 ] "integer dimensions" [ 3 ]'),
+    # PathIntegrator ignores media (path.cpp): the "none" box is simply passed through
+    "grid_path_ignores": cornell(24, 24, 4, world_edit=with_grid_puff),
+}
+
+
 def run(name, scene_path, outdir=GOLD):
     ref = os.path.join(HERE, "_ref", "pbrt_oracle")
     out = os.path.join(outdir, name + ".pfm")
@@ -728,6 +805,12 @@ def main():
         p = os.path.join(GOLD, name + ".pbrt")
         open(p, "w").write(text)
         run(name, p)
+    os.makedirs(GOLD_GRID, exist_ok=True)
+    for name, text in GRID_SCENES.items():
+        if only and name not in only: continue
+        p = os.path.join(GOLD_GRID, name + ".pbrt")
+        open(p, "w").write(text)
+        run(name, p, outdir=GOLD_GRID)
     # small synthetic heightfield (3 042 + 12 triangles): SAH BVH with real depth
     if not only or "hlbvh_synthetic" in only:  # 3 042 triangles: several treelets, deep LBVH bit splits
         p = os.path.join(GOLD, "hlbvh_synthetic.pbrt")

@@ -5,7 +5,7 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 22
+PG_ABI_VERSION = 23
 PG_SAMPLER_HALTON, PG_SAMPLER_SOBOL, PG_SAMPLER_RANDOM, PG_SAMPLER_STRATIFIED, PG_SAMPLER_ZEROTWO, PG_SAMPLER_MAXMINDIST = range(6)
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
@@ -52,6 +52,11 @@ class PgImage(C.Structure):
 
 class PgMedium(C.Structure):
     _fields_ = [("sigma_a", C.c_float * 3), ("sigma_s", C.c_float * 3), ("sigma_t", C.c_float * 3), ("g", C.c_float)]
+
+
+class PgDensityGrid(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32), ("reserved", C.c_int32), ("density_offset", C.c_int64),
+                ("sigma_t", C.c_float), ("inv_max_density", C.c_float), ("world_to_medium", C.c_float * 16)]
 
 
 class PgAlphaMask(C.Structure):
@@ -107,7 +112,9 @@ class PgSceneDesc(C.Structure):
                 ("n_alphas", C.c_int32), ("alphas", C.POINTER(PgAlphaMask)), ("tri_alpha", C.POINTER(C.c_int32)),
                 ("n_env_floats", C.c_int64), ("env_tables", C.POINTER(C.c_float)), ("ewa_lut", C.POINTER(C.c_float)),
                 ("sobol_matrices", C.POINTER(C.c_uint32)), ("vdc_sobol", C.POINTER(C.c_uint64)), ("vdc_sobol_inv", C.POINTER(C.c_uint64)),
-                ("noise_perm", C.POINTER(C.c_int32)), ("cmaxmin", C.POINTER(C.c_uint32))]
+                ("noise_perm", C.POINTER(C.c_int32)), ("cmaxmin", C.POINTER(C.c_uint32)),
+                ("n_grids", C.c_int32), ("grids", C.POINTER(PgDensityGrid)), ("media_grid", C.POINTER(C.c_int32)),
+                ("n_density_floats", C.c_int64), ("grid_density", C.POINTER(C.c_float))]
 
 
 class PgRenderDesc(C.Structure):

@@ -88,7 +88,10 @@ struct RenderOptions {
     std::vector<float> texels;
     std::vector<float> envTables;     // the infinite lights' Distribution2D tables
     std::vector<PgAlphaMask> alphas;  // alpha / shadow-alpha textures of the meshes that have them
-    std::vector<PgMedium> media;      // MakeNamedMedium "homogeneous"
+    std::vector<PgMedium> media;      // MakeNamedMedium "homogeneous" / "heterogeneous"
+    std::vector<int32_t> mediaGrid;   // per medium: index into grids, -1 = homogeneous
+    std::vector<PgDensityGrid> grids; // GridDensityMedium (media/grid.h)
+    std::vector<float> gridDensity;
     std::map<std::string, int> namedMedia;
     std::map<std::string, int> imageCache;
     bool haveScatteringMedia = false;
@@ -563,21 +566,50 @@ void pbrtMakeNamedMedium(const std::string &name, const ParamSet &params) {  // 
     Float g = params.FindOneFloat("g", 0.0f);
     sig_a = params.FindOneSpectrum("sigma_a", sig_a);
     sig_s = params.FindOneSpectrum("sigma_s", sig_s);
-    if (type != "homogeneous") {
-        if (type == "heterogeneous") Error("Medium \"heterogeneous\" (GridDensityMedium) is outside this build's closed set; \"%s\" is ignored.", name.c_str());
-        else Warning("Medium \"%s\" unknown.", type.c_str());
+    if (type != "homogeneous" && type != "heterogeneous") {
+        Warning("Medium \"%s\" unknown.", type.c_str());
         params.ReportUnused();
         return;
     }
     PgMedium m;
     for (int i = 0; i < 3; ++i) {
         m.sigma_a[i] = sig_a.c[i] * scale; m.sigma_s[i] = sig_s.c[i] * scale;
-        m.sigma_t[i] = m.sigma_s[i] + m.sigma_a[i];  // HomogeneousMedium ctor, homogeneous.h:52-56
+        m.sigma_t[i] = m.sigma_s[i] + m.sigma_a[i];  // HomogeneousMedium ctor, homogeneous.h:52-56; GridDensityMedium: grid.h:64
     }
     m.g = g;
+    int grid = -1;
+    if (type == "heterogeneous") {  // MakeMedium, api.cpp:700-722 + the GridDensityMedium constructor, grid.h:49-73
+        const std::vector<Float> *data = params.FindFloat("density");
+        if (!data) { Error("No \"density\" values provided for heterogeneous medium?"); return; }
+        const int nx = params.FindOneInt("nx", 1), ny = params.FindOneInt("ny", 1), nz = params.FindOneInt("nz", 1);
+        const Point3f p0 = params.FindOnePoint3f("p0", Point3f(0.f, 0.f, 0.f)), p1 = params.FindOnePoint3f("p1", Point3f(1.f, 1.f, 1.f));
+        // (the reference multiplies the three ints unchecked; counts that do not fit are an error here, never an overflow)
+        const long long nVox = nx > 0 && ny > 0 && nz > 0 ? (long long)nx * ny * nz : -1;
+        if (nVox < 0 || nVox > 0x7fffffffLL || (long long)data->size() != nVox) {
+            Error("GridDensityMedium has %d density values; expected nx*ny*nz = %lld", (int)data->size(), nVox < 0 ? 0LL : nVox);
+            return;
+        }
+        const Transform data2Medium = Translate(Vector3f(p0.x, p0.y, p0.z)) * Scale(p1.x - p0.x, p1.y - p0.y, p1.z - p0.z);
+        const Transform worldToMedium = Inverse(curTransform[0] * data2Medium);
+        PgDensityGrid gd;
+        gd.nx = nx; gd.ny = ny; gd.nz = nz; gd.reserved = 0;
+        gd.density_offset = (int64_t)renderOptions->gridDensity.size();
+        gd.sigma_t = m.sigma_a[0] + m.sigma_s[0];
+        if (m.sigma_t[1] != m.sigma_t[0] || m.sigma_t[2] != m.sigma_t[0])
+            Error("GridDensityMedium requires a spectrally uniform attenuation coefficient!");  // (as the reference: reported, then used)
+        Float maxDensity = 0;
+        for (Float v : *data) maxDensity = std::max(maxDensity, v);
+        gd.inv_max_density = 1 / maxDensity;
+        const Matrix4x4 &w2m = worldToMedium.GetMatrix();
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) gd.world_to_medium[4 * r + c] = w2m.m[r][c];
+        renderOptions->gridDensity.insert(renderOptions->gridDensity.end(), data->begin(), data->end());
+        grid = (int)renderOptions->grids.size();
+        renderOptions->grids.push_back(gd);
+    }
     params.ReportUnused();
     renderOptions->namedMedia[name] = (int)renderOptions->media.size();
     renderOptions->media.push_back(m);
+    renderOptions->mediaGrid.push_back(grid);
 }
 void pbrtMediumInterface(const std::string &insideName, const std::string &outsideName) {
     VERIFY_INITIALIZED("MediumInterface");
@@ -1267,6 +1299,7 @@ static Scene *MakeScene() {
     scene->envTables = ro.envTables;
     scene->alphas = ro.alphas;
     scene->media = ro.media;
+    scene->mediaGrid = ro.mediaGrid; scene->grids = ro.grids; scene->gridDensity = ro.gridDensity;
     scene->worldBound = scene->aggregate->WorldBound();
     // resolve each light's emitting triangle to its index in BVH order
     const auto &prims = scene->aggregate->primitives;

@@ -351,6 +351,7 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     flat->envTables = scene.envTables;
     flat->alphas = scene.alphas;
     flat->media = scene.media;
+    flat->mediaGrid = scene.mediaGrid; flat->grids = scene.grids; flat->gridDensity = scene.gridDensity;
     EWAWeightLut(flat->ewaLut);
     flat->lights = scene.lights;
     // Light::Preprocess (scene.h:57-60): DistantLight keeps the world's bounding sphere (distant.h:55-57, geometry.h:803-806)
@@ -398,6 +399,10 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     d.ewa_lut = flat->ewaLut;
     d.n_env_floats = (int64_t)flat->envTables.size(); d.env_tables = flat->envTables.data();
     d.n_media = (int)flat->media.size(); d.media = flat->media.data();
+    if (!flat->grids.empty()) {  // GridDensityMedium tables (ABI 23)
+        d.n_grids = (int)flat->grids.size(); d.grids = flat->grids.data(); d.media_grid = flat->mediaGrid.data();
+        d.n_density_floats = (int64_t)flat->gridDensity.size(); d.grid_density = flat->gridDensity.data();
+    }
     if (scene.usesNoise) d.noise_perm = GetNoisePermutation();
     if (sampler->kind == PG_SAMPLER_MAXMINDIST) d.cmaxmin = GetMaxMinDistTable();
     if (sampler->sobol) { const SobolTables &t = GetSobolTables(); d.sobol_matrices = t.matrices32; d.vdc_sobol = t.vdc; d.vdc_sobol_inv = t.vdcInv; }

@@ -132,6 +132,9 @@ struct Scene {  // core/scene.h:50-80
     std::vector<float> envTables;
     std::vector<PgAlphaMask> alphas;
     std::vector<PgMedium> media;
+    std::vector<int32_t> mediaGrid;    // per medium: its GridDensityMedium's index in grids, -1 = HomogeneousMedium
+    std::vector<PgDensityGrid> grids;
+    std::vector<float> gridDensity;
     bool usesNoise = false;
     Bounds3f worldBound;
 };
@@ -233,6 +236,9 @@ struct FlatScene {
     std::vector<PgAlphaMask> alphas;
     std::vector<int32_t> triAlpha;
     std::vector<PgMedium> media;
+    std::vector<int32_t> mediaGrid;
+    std::vector<PgDensityGrid> grids;
+    std::vector<float> gridDensity;
     std::vector<int32_t> triMediumInside, triMediumOutside;
     float ewaLut[128];
 };

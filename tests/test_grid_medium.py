@@ -1,0 +1,98 @@
+"""GridDensityMedium (`MakeNamedMedium ... "string type" "heterogeneous"`, /root/reference/src/media/grid.{h,cpp}): the host front
+end parses it into the ABI-23 tables (PgDensityGrid, PgSceneDesc.media_grid / grid_density), the CPU oracle renders it -- delta
+tracking in Sample, ratio tracking with roulette in Tr -- bit-identically to the UNMODIFIED reference (tests/golden_grid/*, rendered
+by oracle/_ref/pbrt_oracle through oracle/make_golden.py), and the device library says loudly that it has no kernels for it.
+All of this runs without a GPU: it is the oracle-first half of the row; the device half is next."""
+import glob
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from test_gpu_binding import BINDING
+
+GRID = os.path.join(ROOT, "tests", "golden_grid")
+NAMES = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GRID, "*.json")))
+
+
+def test_goldens_present():
+    assert len(NAMES) >= 8
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_matches_reference_image_and_stats(pkg, oracle, name):
+    scene = pkg.HostScene(os.path.join(GRID, name + ".pbrt"))
+    kinds = [scene.desc.media_grid[i] for i in range(scene.desc.n_media)]  # one grid; the other media (if any) are homogeneous
+    assert scene.desc.n_grids == 1 and sorted(kinds) == [-1] * (len(kinds) - 1) + [0]
+    img, cn = oracle.render_image(scene)
+    ref = pkg.read_pfm(os.path.join(GRID, name + ".pfm"))
+    assert img.shape == ref.shape and np.array_equal(img, ref), f"max |diff| {np.abs(img - ref).max()}"
+    for k, v in json.load(open(os.path.join(GRID, name + ".json"))).items():
+        assert cn[k] == v, k
+
+
+def test_tables_are_the_constructors(pkg):
+    """grid.h:49-73 / api.cpp:700-722: sigma_t from channel 0, 1 / max density, WorldToMedium = Inverse(CTM * Translate(p0) * Scale(p1 - p0))."""
+    scene = pkg.HostScene(os.path.join(GRID, "grid_puff.pbrt"))  # (owns the tables desc points into)
+    d = scene.desc
+    g = d.grids[0]
+    assert (g.nx, g.ny, g.nz) == (6, 5, 4) and d.n_density_floats == 120 and g.density_offset == 0
+    den = np.ctypeslib.as_array(d.grid_density, shape=(120,))
+    assert g.inv_max_density == np.float32(1) / den.max() and g.sigma_t == np.float32(0.0234375)
+    m = np.array(list(g.world_to_medium), dtype=np.float64).reshape(4, 4)
+    corner = m @ np.array([400.0, 350.0, 400.0, 1.0])
+    assert np.allclose(corner[:3], 1.0, atol=1e-5) and np.allclose((m @ np.array([150.0, 20.0, 100.0, 1.0]))[:3], 0.0, atol=1e-5)
+    assert d.media[0].sigma_t[0] == d.media[0].sigma_t[1] == d.media[0].sigma_t[2] == g.sigma_t
+
+
+@pytest.mark.parametrize("edit,message", [
+    (lambda s: s.replace('"float density"', '"float densty"'), 'No "density" values provided'),
+    (lambda s: s.replace('"integer nx" [ 6 ]', '"integer nx" [ 7 ]'), "expected nx*ny*nz = 140"),
+    (lambda s: s.replace('"integer nx" [ 6 ]', '"integer nx" [ -6 ]'), "expected nx*ny*nz"),
+    (lambda s: s.replace('"integer nx" [ 6 ] "integer ny" [ 5 ] "integer nz" [ 4 ]', '"integer nx" [ 65536 ] "integer ny" [ 65536 ] "integer nz" [ 4 ]'), "expected nx*ny*nz"),
+])
+def test_malformed_grid_is_reported(pkg, capfd, edit, message):
+    """api.cpp:702-718: the medium is not created (the MediumInterface naming it then finds no such medium).  (Counts whose
+    product overflows an int are an error here instead of the reference's unchecked multiplication.)"""
+    text = edit(open(os.path.join(GRID, "grid_puff.pbrt")).read())
+    scene = pkg.HostScene(text=text)  # errors are reported and counted, the load itself goes on as the reference's does
+    assert message in capfd.readouterr().err
+    assert scene.desc.n_media == 0 and scene.desc.n_grids == 0 and not scene.desc.media_grid
+
+
+def test_spectrally_varying_sigma_t_is_reported(pkg, capfd):
+    text = open(os.path.join(GRID, "grid_puff.pbrt")).read().replace('"rgb sigma_a" [ 0.0078125 0.015625 0.00390625 ]', '"rgb sigma_a" [ 0.0078125 0.015625 0.5 ]')
+    try:
+        pkg.HostScene(text=text)
+    except pkg.PbrtGpuError:
+        pass
+    assert "GridDensityMedium requires a spectrally uniform attenuation coefficient!" in capfd.readouterr().err
+
+
+def test_device_library_refuses_grid_media_loudly(pkg):
+    """No kernels for it in this ABI version: pg_scene_create answers PG_ERR_UNSUPPORTED before touching a device (so the check
+    runs here too) -- never a silent render without the medium, never a CPU fallback."""
+    import ctypes as C
+    scene = pkg.HostScene(os.path.join(GRID, "grid_puff.pbrt"))
+    lib, handle = pkg.gpu_lib(), C.c_void_p()
+    assert lib.pg_scene_create(C.byref(scene.desc), C.byref(handle)) == -2 and not handle  # PG_ERR_UNSUPPORTED
+    assert b"GridDensityMedium" in lib.pg_last_error()
+
+
+@pytest.mark.parametrize("name", ["grid_puff", "grid_fog_camera", "grid_transformed"])
+def test_reference_side_binding_flattens_the_reference_grid(pkg, name, tmp_path):
+    """The reference's own GridDensityMedium objects (parser, MakeMedium and constructor unchanged), flattened by the compiled
+    binding into the same tables and rendered by the oracle behind the C ABI: bit-identical to the reference's image."""
+    if os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "-f", "Makefile.ref", "-j8", "_ref/pbrt_gpubind"])
+    if not os.path.exists(BINDING):
+        pytest.skip("oracle/_ref/pbrt_gpubind is built only where /root/reference exists")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle_abi_shim.so"])
+    out = str(tmp_path / "bound.pfm")
+    p = subprocess.run([BINDING, "--outfile", out, os.path.join(GRID, name + ".pbrt")], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, PBRT_GPU_LIB=os.path.join(ROOT, "oracle", "liboracle_abi_shim.so")))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert np.array_equal(pkg.read_pfm(out), pkg.read_pfm(os.path.join(GRID, name + ".pfm")))

@@ -38,6 +38,10 @@ int main(int argc, char **argv) {
         for (int i = 0; i < d->n_tris; ++i) acc += d->tri_material ? d->tri_material[i] : 0;
         for (int i = 0; i < d->n_materials; ++i) acc += d->materials[i].type;
         for (int i = 0; i < d->n_lights; ++i) acc += d->lights[i].type;
+        for (int i = 0; i < d->n_media; ++i) if (d->media_grid && d->media_grid[i] >= 0) {  // GridDensityMedium tables: every voxel
+            const PgDensityGrid &g = d->grids[d->media_grid[i]];
+            for (long long k = 0; k < (long long)g.nx * g.ny * g.nz; ++k) acc += d->grid_density[g.density_offset + k];
+        }
     }
     int w, h; pbrt_host_film_size(s, &w, &h);
     printf("ok %%g %%d %%d\n", acc, w, h);
@@ -87,7 +91,10 @@ def main():
     exe = build()
     rng = random.Random(seed)
     gold = os.path.join(ROOT, "tests", "golden")
-    srcs = [s for s in sorted(glob.glob(os.path.join(gold, "*.pbrt"))) if os.path.getsize(s) < 20000]
+    dirs = [gold, os.path.join(ROOT, "tests", "golden_grid")]
+    if os.environ.get("FUZZ_ONLY"):  # e.g. FUZZ_ONLY=golden_grid: mutate only that directory's scenes
+        dirs = [d for d in dirs if os.path.basename(d) == os.environ["FUZZ_ONLY"]]
+    srcs = [s for d in dirs for s in sorted(glob.glob(os.path.join(d, "*.pbrt"))) if os.path.getsize(s) < 20000]
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1")
     bad = []
     for n in range(count):
