@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 23
+#define PG_ABI_VERSION 24
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -312,6 +312,27 @@ typedef struct PgDensityGrid {
     float world_to_medium[16];  /* Inverse(medium2world * Translate(p0) * Scale(p1 - p0)).m, row-major: world -> the unit cube */
 } PgDensityGrid;
 
+/* SubsurfaceMaterial / KdSubsurfaceMaterial (materials/subsurface.cpp, kdsubsurface.cpp) with constant parameters.  The
+ * surface BSDF is the material's BxDF list like any other material's (FresnelSpecular, or the two microfacet lobes:
+ * subsurface.cpp:57-86); PgSceneDesc.material_bssrdf[m] >= 0 says that ComputeScatteringFunctions also sets
+ * si->bssrdf = TabulatedBSSRDF(si, material, mode, eta, sigma_a, sigma_s, table) (core/bssrdf.h:141-165) -- unless R and T are
+ * both black (the early return at subsurface.cpp:55: then the material has no BxDFs and no BSSRDF).  Identity matters: the probe
+ * rays of SeparableBSSRDF::Sample_Sp accept hits on primitives with the SAME Material object (bssrdf.cpp:301), so every
+ * Material / MakeNamedMaterial directive of these two types owns its own PgMaterial entry.
+ * `table` is BSSRDFTable(n_rho, n_radius) after ComputeBeamDiffusionBSSRDF(g, eta) (bssrdf.cpp:149-180), laid out in
+ * bssrdf_tables as rhoSamples[n_rho], radiusSamples[n_radius], profile[n_rho * n_radius], rhoEff[n_rho],
+ * profileCDF[n_rho * n_radius]; materials with equal (g, eta) share one table.
+ * libpbrt_gpu.so of this ABI version has no kernels for the BSSRDF branch of Li (path.cpp:152-174): pg_scene_create answers
+ * PG_ERR_UNSUPPORTED when n_bssrdfs > 0 (the CPU oracle renders it). */
+typedef struct PgBSSRDF {
+    float eta;
+    /* TabulatedBSSRDF::sigma_t and ::rho as its constructor derives them (bssrdf.h:146-150) from the coefficients the material hands
+     * it: scale * Clamp(sigma_a / sigma_s) (subsurface.cpp:87-88), or SubsurfaceFromDiffuse(Kd, scale * mfp) (kdsubsurface.cpp:88-91) */
+    float sigma_t[3], rho[3];
+    int32_t n_rho, n_radius;      /* 100, 64 (subsurface.h:73) */
+    int64_t table;                /* first float of the table in PgSceneDesc.bssrdf_tables */
+} PgBSSRDF;
+
 typedef struct PgSceneDesc {
     int32_t abi_version;        /* PG_ABI_VERSION */
     /* acceleration structure, BVHAccel after flattenBVHTree (bvh.cpp:640-658) */
@@ -380,6 +401,12 @@ typedef struct PgSceneDesc {
     const int32_t *media_grid;  /* n_media entries: index into grids, -1 = HomogeneousMedium; NULL when n_grids == 0 */
     int64_t n_density_floats;
     const float *grid_density;
+    /* ABI 24: subsurface scattering tables; all zero / NULL when no material has a BSSRDF */
+    int32_t n_bssrdfs;
+    const PgBSSRDF *bssrdfs;
+    const int32_t *material_bssrdf; /* n_materials entries: index into bssrdfs, -1 = none; NULL when n_bssrdfs == 0 */
+    int64_t n_bssrdf_floats;
+    const float *bssrdf_tables;
 } PgSceneDesc;
 
 /* ---- render description -------------------------------------------------- */

@@ -16,7 +16,7 @@
 // `Integrator "path"` / `"volpath"` of any .pbrt file then selects the device path.
 //
 // Closed set of this binding: triangle meshes (with N / S / uv), spheres, cylinders and disks; materials whose parameters are
-// constant textures (their BxDF lists are read off Material::ComputeScatteringFunctions); diffuse area lights, point, spot
+// constant textures (their BxDF lists and, for the subsurface materials, their TabulatedBSSRDF are read off Material::ComputeScatteringFunctions); diffuse area lights, point, spot
 // and distant lights; perspective and orthographic cameras; all six samplers; every pixel filter; homogeneous
 // and grid-density media.  Anything else is reported with Error() and the process exits -- there is no CPU fallback here either.
 #include <dlfcn.h>
@@ -34,6 +34,7 @@
 #include "pbrt.h"
 #include "accelerators/bvh.h"
 #include "api.h"
+#include "bssrdf.h"
 #include "camera.h"
 #include "cameras/orthographic.h"
 #include "cameras/perspective.h"
@@ -164,14 +165,29 @@ PgBxDF ConvertBxDF(const BxDF *bx) {
     }
     Unsupported("a BxDF outside reflection.h's Lambertian / Oren-Nayar / specular / microfacet / Fresnel-blend set");
 }
+// What a subsurface material leaves in si->bssrdf (subsurface.cpp:87-90): TabulatedBSSRDF's members (bssrdf.h:141-165)
+struct BssrdfProbe {
+    bool present = false;
+    float eta = 0, sigma_t[3] = {0, 0, 0}, rho[3] = {0, 0, 0};
+    const BSSRDFTable *table = nullptr;
+    bool operator==(const BssrdfProbe &o) const {
+        return present == o.present && eta == o.eta && !memcmp(sigma_t, o.sigma_t, sizeof(sigma_t)) && !memcmp(rho, o.rho, sizeof(rho)) && table == o.table;
+    }
+};
 // the material's BxDF list at one (arbitrary) surface point
-void ListBxDFs(const Material *mat, Float u, Float v, std::vector<PgBxDF> *out, float *eta) {
+void ListBxDFs(const Material *mat, Float u, Float v, std::vector<PgBxDF> *out, float *eta, BssrdfProbe *bss = nullptr) {
     MemoryArena arena;
     SurfaceInteraction si(Point3f(u, v, 0.25f), Vector3f(0, 0, 0), Point2f(u, v), Vector3f(0, 0, 1), Vector3f(1, 0, 0), Vector3f(0, 1, 0),
                           Normal3f(0, 0, 0), Normal3f(0, 0, 0), 0, nullptr);
     mat->ComputeScatteringFunctions(&si, arena, TransportMode::Radiance, true);
     out->clear();
     *eta = 1;
+    if (bss && si.bssrdf) {
+        const TabulatedBSSRDF *t = dynamic_cast<const TabulatedBSSRDF *>(si.bssrdf);
+        if (!t) Unsupported("a BSSRDF other than TabulatedBSSRDF");
+        bss->present = true; bss->eta = t->eta; bss->table = &t->table;
+        CopyRGB(t->sigma_t, bss->sigma_t); CopyRGB(t->rho, bss->rho);
+    }
     if (!si.bsdf) return;
     for (int i = 0; i < si.bsdf->nBxDFs; ++i) out->push_back(ConvertBxDF(si.bsdf->bxdfs[i]));
     *eta = si.bsdf->eta;
@@ -191,6 +207,10 @@ struct Flat {
     std::vector<PgDensityGrid> grids;
     std::vector<float> gridDensity;
     std::map<const Medium *, int> mediumIndex;
+    std::vector<PgBSSRDF> bssrdfs;          // one per material with a TabulatedBSSRDF
+    std::vector<int32_t> materialBssrdf;    // per material, -1 = none
+    std::vector<float> bssrdfTables;
+    std::map<const BSSRDFTable *, int64_t> bssrdfTableOf;
     std::vector<int32_t> permSums;
     PgSceneDesc desc;
 };
@@ -320,10 +340,30 @@ void FlattenScene(const Scene &scene, int maxDepth, bool volumetric, const std::
             else {
                 std::vector<PgBxDF> a, b;
                 float etaA, etaB;
-                ListBxDFs(mat, 0.125f, 0.25f, &a, &etaA);
-                ListBxDFs(mat, 0.625f, 0.75f, &b, &etaB);  // a second point: a non-constant texture shows up as a different list
-                if (a.size() != b.size() || etaA != etaB || (a.size() && memcmp(a.data(), b.data(), a.size() * sizeof(PgBxDF))))
+                BssrdfProbe sa, sb;
+                ListBxDFs(mat, 0.125f, 0.25f, &a, &etaA, &sa);
+                ListBxDFs(mat, 0.625f, 0.75f, &b, &etaB, &sb);  // a second point: a non-constant texture shows up as a different list
+                if (a.size() != b.size() || etaA != etaB || (a.size() && memcmp(a.data(), b.data(), a.size() * sizeof(PgBxDF))) || !(sa == sb))
                     Unsupported("a material with non-constant textures in this binding");
+                if (sa.present) {  // SubsurfaceMaterial / KdSubsurfaceMaterial: the table is the material's own BSSRDFTable (subsurface.h:73-75)
+                    PgBSSRDF pb;
+                    memset(&pb, 0, sizeof(pb));
+                    pb.eta = sa.eta;
+                    for (int c = 0; c < 3; ++c) { pb.sigma_t[c] = sa.sigma_t[c]; pb.rho[c] = sa.rho[c]; }
+                    const BSSRDFTable &t = *sa.table;
+                    pb.n_rho = t.nRhoSamples; pb.n_radius = t.nRadiusSamples;
+                    auto ti = flat->bssrdfTableOf.find(&t);
+                    if (ti == flat->bssrdfTableOf.end()) {
+                        ti = flat->bssrdfTableOf.insert({&t, (int64_t)flat->bssrdfTables.size()}).first;
+                        auto put = [&](const Float *v, size_t n) { flat->bssrdfTables.insert(flat->bssrdfTables.end(), v, v + n); };
+                        const size_t nr = t.nRhoSamples, nd = t.nRadiusSamples;
+                        put(t.rhoSamples.get(), nr); put(t.radiusSamples.get(), nd); put(t.profile.get(), nr * nd); put(t.rhoEff.get(), nr); put(t.profileCDF.get(), nr * nd);
+                    }
+                    pb.table = ti->second;
+                    flat->materialBssrdf.resize(flat->materials.size() + 1, -1);
+                    flat->materialBssrdf[flat->materials.size()] = (int)flat->bssrdfs.size();
+                    flat->bssrdfs.push_back(pb);
+                }
                 pm.type = PG_MAT_LOBES; pm.first_bxdf = (int)flat->bxdfs.size(); pm.n_bxdfs = (int)a.size(); pm.bsdf_eta = etaA;
                 flat->bxdfs.insert(flat->bxdfs.end(), a.begin(), a.end());
             }
@@ -375,7 +415,7 @@ void FlattenScene(const Scene &scene, int maxDepth, bool volumetric, const std::
     else d.light_strategy = PG_LIGHTS_SPATIAL;
     // the reference's own digit permutations (HaltonSampler::radicalInversePermutations, halton.cpp:69-72) and PrimeSums
     if (dynamic_cast<const HaltonSampler *>(&sampler)) {
-        const int nDims = volumetric ? PrimeTableSize : std::min(PrimeTableSize, 5 + 8 * (maxDepth + 2));
+        const int nDims = volumetric || !flat->bssrdfs.empty() ? PrimeTableSize : std::min(PrimeTableSize, 5 + 8 * (maxDepth + 2));  // (a subsurface vertex draws 10 more values)
         for (int i = 0; i <= nDims; ++i) flat->permSums.push_back(i < PrimeTableSize ? PrimeSums[i] : PrimeSums[PrimeTableSize - 1] + Primes[PrimeTableSize - 1]);
         d.n_perm_dims = nDims; d.perms = HaltonSampler::radicalInversePermutations.data(); d.perm_sums = flat->permSums.data();
     } else if (dynamic_cast<const SobolSampler *>(&sampler)) {  // the reference's generator matrices
@@ -387,6 +427,11 @@ void FlattenScene(const Scene &scene, int maxDepth, bool volumetric, const std::
     d.n_spheres = (int)flat->spheres.size(); d.spheres = flat->spheres.data();
     d.n_bxdfs = (int)flat->bxdfs.size(); d.bxdfs = flat->bxdfs.data();
     SetMediaTables(flat);
+    if (!flat->bssrdfs.empty()) {  // subsurface scattering tables (ABI 24)
+        flat->materialBssrdf.resize(flat->materials.size(), -1);
+        d.n_bssrdfs = (int)flat->bssrdfs.size(); d.bssrdfs = flat->bssrdfs.data(); d.material_bssrdf = flat->materialBssrdf.data();
+        d.n_bssrdf_floats = (int64_t)flat->bssrdfTables.size(); d.bssrdf_tables = flat->bssrdfTables.data();
+    }
     d.tri_medium_inside = anyMedium ? flat->triMedIn.data() : nullptr; d.tri_medium_outside = anyMedium ? flat->triMedOut.data() : nullptr;
 }
 

@@ -780,6 +780,50 @@ GRID_SCENES = {
 }
 
 
+# ---- Subsurface scattering: SubsurfaceMaterial / KdSubsurfaceMaterial + the BSSRDF branch of PathIntegrator::Li / VolPathIntegrator::Li
+# (path.cpp:152-174, core/bssrdf.cpp).  ABI 24 carries the tables and the CPU oracle renders it; the device library refuses it
+# (PG_ERR_UNSUPPORTED), so these goldens live in tests/golden_sss/, outside the device parity list. ----
+GOLD_SSS = os.path.join(ROOT, "tests", "golden_sss")
+SHORT_BOX_MATTE = '# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]'
+SSS_PLAIN = 'Material "subsurface" "rgb sigma_a" [ 0.002 0.004 0.02 ] "rgb sigma_s" [ 0.05 0.06 0.08 ] "float eta" [ 1.33 ]'
+
+
+def with_sss(s, mat, tall=None):
+    """The short box (and, unless `tall` names another material, the tall box after it -- the same Material object) made of `mat`."""
+    assert SHORT_BOX_MATTE in s
+    s = s.replace(SHORT_BOX_MATTE, "# short box\n" + mat, 1)
+    if tall is not None:
+        s = s.replace("# tall box", tall + "\n# tall box", 1)
+    return s
+
+
+SSS_SCENES = {
+    # both boxes share one SubsurfaceMaterial: probe rays started on one box may leave through the other (bssrdf.cpp:301)
+    "sss_subsurface": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 6 ]', world_edit=lambda s: with_sss(s, SSS_PLAIN)),
+    # the same parameters declared twice: two Material objects, the probe rays of one never accept the other
+    "sss_two_materials": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 6 ]', world_edit=lambda s: with_sss(s, SSS_PLAIN, tall=SSS_PLAIN)),
+    "sss_preset_volpath": cornell(32, 32, 8, integrator='Integrator "volpath" "integer maxdepth" [ 6 ]',
+                                  world_edit=lambda s: with_fog(with_sss(s, 'Material "subsurface" "string name" "Skin1" "float scale" [ 0.05 ] "float eta" [ 1.4 ]', tall='Material "matte" "rgb Kd" [ 0.6 0.6 0.6 ]'))),
+    "sss_kd_rough": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 6 ]',
+                            world_edit=lambda s: with_sss(s, 'Material "kdsubsurface" "rgb Kd" [ 0.6 0.4 0.3 ] "rgb mfp" [ 8 12 20 ] "float uroughness" [ 0.1 ] "float vroughness" [ 0.2 ] "float g" [ 0.3 ]',
+                                                          tall='Material "kdsubsurface" "rgb Kd" [ 0.2 0.5 0.7 ] "rgb mfp" [ 30 30 30 ] "float scale" [ 0.5 ] "float eta" [ 1.2 ] "bool remaproughness" "false" "float uroughness" [ 0.05 ] "float vroughness" [ 0.05 ]')),
+    "sss_g_power_delta": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 8 ] "string lightsamplestrategy" "power"',
+                                 world_edit=lambda s: with_sss(s, 'Material "subsurface" "rgb sigma_a" [ 0.01 0.004 0.002 ] "rgb sigma_s" [ 0.2 0.3 0.1 ] "float g" [ 0.5 ] "float eta" [ 1.5 ] "float scale" [ 0.5 ] "rgb Kr" [ 0.5 0.5 0.5 ]')
+                                 .replace("# light\nAttributeBegin", DELTA_POINT + DELTA_SPOT + "# light\nAttributeBegin")),
+    # Kr = Kt = 0: ComputeScatteringFunctions returns before it sets the BSSRDF (subsurface.cpp:55): a black, BxDF-less surface
+    "sss_black_no_bssrdf": cornell(24, 24, 4, world_edit=lambda s: with_sss(s, 'Material "subsurface" "rgb Kr" [ 0 0 0 ] "rgb Kt" [ 0 0 0 ]', tall='Material "matte" "rgb Kd" [ 0.6 0.6 0.6 ]')),
+    "sss_named_spheres": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 6 ]',
+                                 world_edit=lambda s: s.replace("# short box", 'MakeNamedMaterial "wax" "string type" "subsurface" "rgb sigma_a" [ 0.004 0.01 0.03 ] "rgb sigma_s" [ 0.08 0.08 0.06 ] "float eta" [ 1.45 ]\n'
+                                                                'AttributeBegin\n  NamedMaterial "wax"\n  Translate 420 70 120\n  Shape "sphere" "float radius" [ 70 ]\nAttributeEnd\n'
+                                                                'AttributeBegin\n  NamedMaterial "wax"\n  Translate 150 390 330\n  Rotate 30 1 0 0\n  Shape "sphere" "float radius" [ 60 ] "float zmax" [ 40 ]\nAttributeEnd\n# short box', 1)),
+    "sss_instances": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 5 ]', world_edit=lambda s: with_instances(with_sss(s, SSS_PLAIN))),
+    "sss_sobol": cornell(24, 24, 4, integrator='Integrator "path" "integer maxdepth" [ 6 ]', world_edit=lambda s: with_sss(s, SSS_PLAIN)).replace('Sampler "halton"', 'Sampler "sobol"'),
+    "sss_random": cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 6 ]', world_edit=lambda s: with_sss(s, SSS_PLAIN)).replace('Sampler "halton"', 'Sampler "random"'),
+    "sss_stratified": cornell(24, 24, 4, integrator='Integrator "path" "integer maxdepth" [ 6 ]', world_edit=lambda s: with_sss(s, SSS_PLAIN))
+                      .replace('Sampler "halton" "integer pixelsamples" [ 4 ]', 'Sampler "stratified" "integer xsamples" [ 2 ] "integer ysamples" [ 2 ] "integer dimensions" [ 6 ]'),
+}
+
+
 def run(name, scene_path, outdir=GOLD):
     ref = os.path.join(HERE, "_ref", "pbrt_oracle")
     out = os.path.join(outdir, name + ".pfm")
@@ -805,6 +849,12 @@ def main():
         p = os.path.join(GOLD, name + ".pbrt")
         open(p, "w").write(text)
         run(name, p)
+    os.makedirs(GOLD_SSS, exist_ok=True)
+    for name, text in SSS_SCENES.items():
+        if only and name not in only: continue
+        p = os.path.join(GOLD_SSS, name + ".pbrt")
+        open(p, "w").write(text)
+        run(name, p, outdir=GOLD_SSS)
     os.makedirs(GOLD_GRID, exist_ok=True)
     for name, text in GRID_SCENES.items():
         if only and name not in only: continue

@@ -4,13 +4,45 @@
 // front end (pbrt-v3_amd/host/api.cpp, kCopperN / kCopperK); tests/test_oracle_vs_reference.py re-checks them when
 // /root/reference is present.  With arguments `presets NAME...` it prints what GetMediumScatteringProperties (core/medium.cpp:
 // 181-191) returns for each name: `NAME|sigma_a rgb|sigma_prime_s rgb` (tools/extract_medium_presets.py).
+// `bssrdf G ETA [KD0 KD1 KD2 MFP0 MFP1 MFP2]` prints BSSRDFTable(100, 64) after ComputeBeamDiffusionBSSRDF(G, ETA) (core/bssrdf.cpp:
+// 149-180) as raw float bit patterns, one array per line (rhoSamples, radiusSamples, profile, rhoEff, profileCDF), and with the six
+// further numbers what SubsurfaceFromDiffuse (:182-191) derives: sigma_a, sigma_s (tests/test_subsurface.py).
 // Build: make -C oracle -f Makefile.ref _ref/ref_probe
 #include "materials/metal.cpp"
+#include "bssrdf.h"
 #include "medium.h"
+#include "parallel.h"
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+static void PrintBits(const char *name, const pbrt::Float *v, int n) {
+    printf("%s", name);
+    for (int i = 0; i < n; ++i) { unsigned u; memcpy(&u, &v[i], 4); printf(" %08x", u); }
+    printf("\n");
+}
 int main(int argc, char **argv) {
     using namespace pbrt;
+    if (argc > 3 && !strcmp(argv[1], "bssrdf")) {
+        ParallelInit();
+        BSSRDFTable t(100, 64);
+        ComputeBeamDiffusionBSSRDF((Float)atof(argv[2]), (Float)atof(argv[3]), &t);
+        PrintBits("rhoSamples", t.rhoSamples.get(), 100);
+        PrintBits("radiusSamples", t.radiusSamples.get(), 64);
+        PrintBits("profile", t.profile.get(), 6400);
+        PrintBits("rhoEff", t.rhoEff.get(), 100);
+        PrintBits("profileCDF", t.profileCDF.get(), 6400);
+        if (argc > 9) {
+            Float kd[3] = {(Float)atof(argv[4]), (Float)atof(argv[5]), (Float)atof(argv[6])}, mfp[3] = {(Float)atof(argv[7]), (Float)atof(argv[8]), (Float)atof(argv[9])};
+            Spectrum a, sc;
+            SubsurfaceFromDiffuse(t, Spectrum::FromRGB(kd), Spectrum::FromRGB(mfp), &a, &sc);
+            Float ra[3], rs[3];
+            a.ToRGB(ra); sc.ToRGB(rs);
+            PrintBits("sigma_a", ra, 3);
+            PrintBits("sigma_s", rs, 3);
+        }
+        ParallelCleanup();
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "presets")) {
         for (int i = 2; i < argc; ++i) {
             Spectrum a, s;

@@ -5,7 +5,7 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 23
+PG_ABI_VERSION = 24
 PG_SAMPLER_HALTON, PG_SAMPLER_SOBOL, PG_SAMPLER_RANDOM, PG_SAMPLER_STRATIFIED, PG_SAMPLER_ZEROTWO, PG_SAMPLER_MAXMINDIST = range(6)
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
@@ -57,6 +57,11 @@ class PgMedium(C.Structure):
 class PgDensityGrid(C.Structure):
     _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32), ("reserved", C.c_int32), ("density_offset", C.c_int64),
                 ("sigma_t", C.c_float), ("inv_max_density", C.c_float), ("world_to_medium", C.c_float * 16)]
+
+
+class PgBSSRDF(C.Structure):
+    _fields_ = [("eta", C.c_float), ("sigma_t", C.c_float * 3), ("rho", C.c_float * 3), ("n_rho", C.c_int32), ("n_radius", C.c_int32),
+                ("table", C.c_int64)]
 
 
 class PgAlphaMask(C.Structure):
@@ -114,7 +119,9 @@ class PgSceneDesc(C.Structure):
                 ("sobol_matrices", C.POINTER(C.c_uint32)), ("vdc_sobol", C.POINTER(C.c_uint64)), ("vdc_sobol_inv", C.POINTER(C.c_uint64)),
                 ("noise_perm", C.POINTER(C.c_int32)), ("cmaxmin", C.POINTER(C.c_uint32)),
                 ("n_grids", C.c_int32), ("grids", C.POINTER(PgDensityGrid)), ("media_grid", C.POINTER(C.c_int32)),
-                ("n_density_floats", C.c_int64), ("grid_density", C.POINTER(C.c_float))]
+                ("n_density_floats", C.c_int64), ("grid_density", C.POINTER(C.c_float)),
+                ("n_bssrdfs", C.c_int32), ("bssrdfs", C.POINTER(PgBSSRDF)), ("material_bssrdf", C.POINTER(C.c_int32)),
+                ("n_bssrdf_floats", C.c_int64), ("bssrdf_tables", C.POINTER(C.c_float))]
 
 
 class PgRenderDesc(C.Structure):

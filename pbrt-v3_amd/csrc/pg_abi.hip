@@ -118,6 +118,8 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         return setError(PG_ERR_INVALID, "pg_scene_create: malformed geometry arrays");
     if (desc->n_grids != 0 || desc->media_grid)  // ABI 23 carries the tables; the two-phase shading they need is not built
         return setError(PG_ERR_UNSUPPORTED, "GridDensityMedium (\"heterogeneous\" medium) has no device kernels in this build");
+    if (desc->n_bssrdfs != 0 || desc->material_bssrdf)  // ABI 24 carries the tables; the BSSRDF branch of Li (path.cpp:152-174) has no kernels yet
+        return setError(PG_ERR_UNSUPPORTED, "subsurface scattering (\"subsurface\" / \"kdsubsurface\" materials) has no device kernels in this build");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev <= 0) return setError(PG_ERR_DEVICE, "no HIP device visible (there is no CPU fallback)");

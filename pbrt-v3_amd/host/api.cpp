@@ -92,6 +92,10 @@ struct RenderOptions {
     std::vector<int32_t> mediaGrid;   // per medium: index into grids, -1 = homogeneous
     std::vector<PgDensityGrid> grids; // GridDensityMedium (media/grid.h)
     std::vector<float> gridDensity;
+    std::vector<PgBSSRDF> bssrdfs;          // SubsurfaceMaterial / KdSubsurfaceMaterial: one per material of those types
+    std::vector<int32_t> materialBssrdf;    // per material (grown on demand): index into bssrdfs, -1 = none
+    std::vector<float> bssrdfTables;        // BSSRDFTable(100, 64) per distinct (g, eta)
+    std::map<std::pair<Float, Float>, int64_t> bssrdfTableOf;
     std::map<std::string, int> namedMedia;
     std::map<std::string, int> imageCache;
     bool haveScatteringMedia = false;
@@ -271,10 +275,10 @@ static int MakeMaterial(const std::string &name, const ParamSet &geom, const Par
     PgTexRef bumpRef = constRef(0.f);
     if (hasBump) bumpRef = floatRef(geom, mat, "bumpmap", 0.f, gs);
     if (name == "matte" || (name != "plastic" && name != "mirror" && name != "glass" && name != "uber" && name != "metal" &&
-                            name != "substrate" && name != "translucent" && name != "mix")) {
+                            name != "substrate" && name != "translucent" && name != "mix" && name != "subsurface" && name != "kdsubsurface")) {
         if (name != "matte") {
-            if (name == "hair" || name == "disney" || name == "subsurface" || name == "kdsubsurface" || name == "fourier")
-                Error("Material \"%s\" is outside this build's closed set (matte, plastic, mirror, glass, uber, metal, substrate, translucent, mix); using matte.", name.c_str());
+            if (name == "hair" || name == "disney" || name == "fourier")
+                Error("Material \"%s\" is outside this build's closed set (matte, plastic, mirror, glass, uber, metal, substrate, translucent, mix, subsurface, kdsubsurface); using matte.", name.c_str());
             else Warning("Material \"%s\" unknown. Using \"matte\".", name.c_str());  // api.cpp:588-591
         }
         m.type = PG_MAT_MATTE;  // matte.cpp:45-72
@@ -323,6 +327,89 @@ static int MakeMaterial(const std::string &name, const ParamSet &geom, const Par
                 if (!rgbBlack(T)) { PgBxDF b = lobe(PG_BXDF_MICROFACET_T); setT(b, T); b.eta_a = 1.f; b.eta_b = m.eta; setTR(b, ur, vr); lobes.push_back(b); }
             }
         }
+    } else if (name == "subsurface" || name == "kdsubsurface") {
+        // CreateSubsurfaceMaterial (subsurface.cpp:93-136) / CreateKdSubsurfaceMaterial (kdsubsurface.cpp:95-123) with constant
+        // parameters: the surface BSDF has glass's shape with "eta" as the index (subsurface.cpp:57-86), the BSSRDF's
+        // coefficients are evaluated here once (:87-90 / kdsubsurface.cpp:88-92), the table is the constructor's
+        // ComputeBeamDiffusionBSSRDF(g, eta) (subsurface.h:73-75).
+        const bool kdForm = name == "kdsubsurface";
+        bool textured = false;
+        auto specC = [&](const char *n, RGB d) { PgTexRef r = spectrumRef(geom, mat, n, d, gs); if (r.tex >= 0) textured = true; return RGB{{r.v[0], r.v[1], r.v[2]}}; };
+        auto fltC = [&](const char *n, Float d) { PgTexRef r = floatRef(geom, mat, n, d, gs); if (r.tex >= 0) textured = true; return r.v[0]; };
+        RGB sig_a{{.0011f, .0024f, .014f}}, sig_s{{2.55f, 3.21f, 3.77f}}, kd{{.5f, .5f, .5f}}, mfp{{1.f, 1.f, 1.f}};
+        Float g;
+        if (!kdForm) {
+            const std::string preset = geom.FindOneString("name", mat.FindOneString("name", ""));
+            const bool found = GetMediumScatteringProperties(preset, sig_a.c, sig_s.c);
+            g = geom.FindOneFloat("g", mat.FindOneFloat("g", 0.0f));
+            if (preset != "") {
+                if (!found) Warning("Named material \"%s\" not found.  Using defaults.", preset.c_str());
+                else g = 0;  // the database specifies reduced scattering coefficients
+            }
+        } else g = 0;
+        const Float scale = geom.FindOneFloat("scale", mat.FindOneFloat("scale", 1.f));
+        const Float eta = geom.FindOneFloat("eta", mat.FindOneFloat("eta", 1.33f));
+        if (kdForm) { kd = specC("Kd", kd); mfp = specC("mfp", mfp); g = geom.FindOneFloat("g", mat.FindOneFloat("g", 0.0f)); }
+        else { sig_a = specC("sigma_a", sig_a); sig_s = specC("sigma_s", sig_s); }
+        const RGB kr = specC("Kr", RGB{{1.f, 1.f, 1.f}}), kt = specC("Kt", RGB{{1.f, 1.f, 1.f}});
+        Float ur = fltC("uroughness", 0.f), vr = fltC("vroughness", 0.f);
+        const bool remap = remapParam();
+        if (textured || hasBump)
+            Error("Material \"%s\": textured parameters and bump maps of subsurface materials are outside this build's closed set; their constant parts are used.", name.c_str());
+        for (int i = 0; i < 3; ++i) { m.kr[i] = kr.c[i]; m.kt[i] = kt.c[i]; }
+        m.eta = eta;
+        m.bsdf_eta = eta;  // BSDF(*si, eta)
+        m.type = PG_MAT_LOBES;
+        const RGB R = rgbClamp(kr), T = rgbClamp(kt);
+        const bool isSpecular = ur == 0 && vr == 0;
+        const bool hasBssrdf = !(rgbBlack(R) && rgbBlack(T));  // the early return of ComputeScatteringFunctions (subsurface.cpp:55)
+        if (hasBssrdf) {
+            if (isSpecular) { PgBxDF b = lobe(PG_BXDF_FRESNEL_SPECULAR); setR(b, R); setT(b, T); b.eta_a = 1.f; b.eta_b = eta; lobes.push_back(b); }
+            else {
+                if (remap) { ur = RoughnessToAlpha(ur); vr = RoughnessToAlpha(vr); }
+                if (!rgbBlack(R)) { PgBxDF b = lobe(PG_BXDF_MICROFACET_R); setR(b, R); setDielectric(b, 1.f, eta); setTR(b, ur, vr); lobes.push_back(b); }
+                if (!rgbBlack(T)) { PgBxDF b = lobe(PG_BXDF_MICROFACET_T); setT(b, T); b.eta_a = 1.f; b.eta_b = eta; setTR(b, ur, vr); lobes.push_back(b); }
+            }
+        }
+        mat.ReportUnused();
+        // never interned: the probe rays of Sample_Sp compare Material objects (bssrdf.cpp:301)
+        m.n_bxdfs = (int)lobes.size();
+        m.first_bxdf = (int)renderOptions->bxdfs.size();
+        renderOptions->bxdfs.insert(renderOptions->bxdfs.end(), lobes.begin(), lobes.end());
+        renderOptions->materials.push_back(m);
+        const int index = (int)renderOptions->materials.size() - 1;
+        if (hasBssrdf) {
+            PgBSSRDF b;
+            memset(&b, 0, sizeof(b));
+            b.eta = eta; b.n_rho = 100; b.n_radius = 64;
+            auto key = std::make_pair(g, eta);
+            auto it = renderOptions->bssrdfTableOf.find(key);
+            if (it == renderOptions->bssrdfTableOf.end()) {
+                std::vector<float> table;
+                ComputeBeamDiffusionTable(g, eta, b.n_rho, b.n_radius, &table);
+                it = renderOptions->bssrdfTableOf.emplace(key, (int64_t)renderOptions->bssrdfTables.size()).first;
+                renderOptions->bssrdfTables.insert(renderOptions->bssrdfTables.end(), table.begin(), table.end());
+            }
+            b.table = it->second;
+            Float sa[3], ss[3];
+            if (kdForm) {
+                const RGB mfree = rgbClamp(mfp), kdc = rgbClamp(kd);
+                Float mf[3];
+                for (int i = 0; i < 3; ++i) mf[i] = scale * mfree.c[i];
+                SubsurfaceFromDiffuse(renderOptions->bssrdfTables.data() + b.table, b.n_rho, b.n_radius, kdc.c, mf, sa, ss);
+            } else {
+                const RGB a = rgbClamp(sig_a), sc = rgbClamp(sig_s);
+                for (int i = 0; i < 3; ++i) { sa[i] = scale * a.c[i]; ss[i] = scale * sc.c[i]; }
+            }
+            for (int i = 0; i < 3; ++i) {  // the TabulatedBSSRDF constructor, bssrdf.h:146-150
+                b.sigma_t[i] = sa[i] + ss[i];
+                b.rho[i] = b.sigma_t[i] != 0 ? (ss[i] / b.sigma_t[i]) : 0;
+            }
+            renderOptions->materialBssrdf.resize(index + 1, -1);
+            renderOptions->materialBssrdf[index] = (int)renderOptions->bssrdfs.size();
+            renderOptions->bssrdfs.push_back(b);
+        }
+        return index;
     } else if (name == "uber") {  // uber.cpp:45-128
         m.type = PG_MAT_LOBES;
         RGB Kd = spec("Kd", 0.25f), Ks = spec("Ks", 0.25f), Kr = spec("Kr", 0.f), Kt = spec("Kt", 0.f);
@@ -411,6 +498,8 @@ static int MakeMaterial(const std::string &name, const ParamSet &geom, const Par
         for (int j = 0; j < 2; ++j) {
             const PgMaterial sm = renderOptions->materials[sub[j]];  // copy: the table may grow
             if (sm.type == PG_MAT_NONE) { Error("mix: a \"none\" material cannot be mixed; ignoring it."); continue; }
+            if (sub[j] < (int)renderOptions->materialBssrdf.size() && renderOptions->materialBssrdf[sub[j]] >= 0)
+                Error("mix: the BSSRDF of a subsurface material is outside this build's closed set inside a mix; only its surface BSDF is mixed.");
             if (j == 0) m.bsdf_eta = sm.bsdf_eta;  // si->bsdf stays m1's BSDF
             const RGB &sc = j == 0 ? s1 : s2;
             for (int i = 0; i < sm.n_bxdfs; ++i) {
@@ -1300,6 +1389,9 @@ static Scene *MakeScene() {
     scene->alphas = ro.alphas;
     scene->media = ro.media;
     scene->mediaGrid = ro.mediaGrid; scene->grids = ro.grids; scene->gridDensity = ro.gridDensity;
+    scene->bssrdfs = ro.bssrdfs; scene->bssrdfTables = ro.bssrdfTables;
+    scene->materialBssrdf = ro.materialBssrdf;
+    if (!scene->bssrdfs.empty()) scene->materialBssrdf.resize(scene->materials.size(), -1);
     scene->worldBound = scene->aggregate->WorldBound();
     // resolve each light's emitting triangle to its index in BVH order
     const auto &prims = scene->aggregate->primitives;

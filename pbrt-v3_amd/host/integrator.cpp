@@ -352,6 +352,7 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     flat->alphas = scene.alphas;
     flat->media = scene.media;
     flat->mediaGrid = scene.mediaGrid; flat->grids = scene.grids; flat->gridDensity = scene.gridDensity;
+    flat->bssrdfs = scene.bssrdfs; flat->materialBssrdf = scene.materialBssrdf; flat->bssrdfTables = scene.bssrdfTables;
     EWAWeightLut(flat->ewaLut);
     flat->lights = scene.lights;
     // Light::Preprocess (scene.h:57-60): DistantLight keeps the world's bounding sphere (distant.h:55-57, geometry.h:803-806)
@@ -367,6 +368,7 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     // dimensions a path can consume: 5 camera + per bounce (1+2+2 direct, 2 bsdf, 1 rr); 1000 max (halton.h:71-76)
     int nDims = std::min(1000, 5 + 8 * (maxDepth + 2));
     if (volumetric) nDims = 1000;  // volpath.cpp:77-78,119-123: medium sampling consumes dimensions on uncounted bounces too
+    if (!scene.bssrdfs.empty()) nDims = 1000;  // path.cpp:152-174: a subsurface vertex draws 10 more values (Sample_S, lights at pi, the exit direction)
     ComputeRadicalInversePermutations(nDims, &flat->perms, &flat->permSums);
     PgSceneDesc &d = flat->desc;
     memset(&d, 0, sizeof(d));
@@ -399,6 +401,10 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     d.ewa_lut = flat->ewaLut;
     d.n_env_floats = (int64_t)flat->envTables.size(); d.env_tables = flat->envTables.data();
     d.n_media = (int)flat->media.size(); d.media = flat->media.data();
+    if (!flat->bssrdfs.empty()) {  // subsurface scattering tables (ABI 24)
+        d.n_bssrdfs = (int)flat->bssrdfs.size(); d.bssrdfs = flat->bssrdfs.data(); d.material_bssrdf = flat->materialBssrdf.data();
+        d.n_bssrdf_floats = (int64_t)flat->bssrdfTables.size(); d.bssrdf_tables = flat->bssrdfTables.data();
+    }
     if (!flat->grids.empty()) {  // GridDensityMedium tables (ABI 23)
         d.n_grids = (int)flat->grids.size(); d.grids = flat->grids.data(); d.media_grid = flat->mediaGrid.data();
         d.n_density_floats = (int64_t)flat->gridDensity.size(); d.grid_density = flat->gridDensity.data();

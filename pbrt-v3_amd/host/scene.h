@@ -135,6 +135,9 @@ struct Scene {  // core/scene.h:50-80
     std::vector<int32_t> mediaGrid;    // per medium: its GridDensityMedium's index in grids, -1 = HomogeneousMedium
     std::vector<PgDensityGrid> grids;
     std::vector<float> gridDensity;
+    std::vector<PgBSSRDF> bssrdfs;           // subsurface materials' TabulatedBSSRDF parameters
+    std::vector<int32_t> materialBssrdf;     // per material, -1 = none (empty when bssrdfs is)
+    std::vector<float> bssrdfTables;
     bool usesNoise = false;
     Bounds3f worldBound;
 };
@@ -210,6 +213,11 @@ struct SobolTables { const uint32_t *matrices32; const uint64_t *vdc, *vdcInv; i
 const SobolTables &GetSobolTables();
 const int32_t *GetNoisePermutation();  // 512 entries
 bool GetMediumScatteringProperties(const std::string &name, Float sigma_a[3], Float sigma_prime_s[3]);  // core/medium.cpp:181-191
+// bssrdf.cpp: the subsurface materials' tables (core/bssrdf.cpp:43-191)
+Float FresnelMoment1(Float eta);
+Float FresnelMoment2(Float eta);
+void ComputeBeamDiffusionTable(Float g, Float eta, int nRho, int nRadius, std::vector<float> *out);
+void SubsurfaceFromDiffuse(const float *table, int nRho, int nRadius, const Float kd[3], const Float mfp[3], Float sigma_a[3], Float sigma_s[3]);
 HaltonSampler *CreateHaltonSampler(const ParamSet &params, const int sampleBounds[4]);  // halton.cpp:133-139
 // lowdiscrepancy.cpp:2490-2504 with the default-seeded RNG (halton.cpp:69-72).
 void ComputeRadicalInversePermutations(int nDims, std::vector<uint16_t> *perms, std::vector<int32_t> *sums);
@@ -239,6 +247,9 @@ struct FlatScene {
     std::vector<int32_t> mediaGrid;
     std::vector<PgDensityGrid> grids;
     std::vector<float> gridDensity;
+    std::vector<PgBSSRDF> bssrdfs;
+    std::vector<int32_t> materialBssrdf;
+    std::vector<float> bssrdfTables;
     std::vector<int32_t> triMediumInside, triMediumOutside;
     float ewaLut[128];
 };

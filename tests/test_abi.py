@@ -18,9 +18,9 @@ def declared_functions(header, prefix):
 
 def test_struct_layouts_match_header(pkg, tmp_path):
     src = tmp_path / "probe.c"
-    names = ["PgBVHNode", "PgMaterial", "PgLight", "PgSphere", "PgTexRef", "PgTexture", "PgImage", "PgMedium", "PgDensityGrid", "PgAlphaMask", "PgTexturedMaterial", "PgBxDF", "PgObject", "PgInstance", "PgSceneDesc", "PgRenderDesc", "PgFilmPixel", "PgStraySample", "PgCounters"]
+    names = ["PgBVHNode", "PgMaterial", "PgLight", "PgSphere", "PgTexRef", "PgTexture", "PgImage", "PgMedium", "PgDensityGrid", "PgBSSRDF", "PgAlphaMask", "PgTexturedMaterial", "PgBxDF", "PgObject", "PgInstance", "PgSceneDesc", "PgRenderDesc", "PgFilmPixel", "PgStraySample", "PgCounters"]
     body = "\n".join(f'size_t size_{n}(void) {{ return sizeof({n}); }}' for n in names)
-    offs = [("PgSceneDesc", "perm_sums"), ("PgSceneDesc", "grid_density"), ("PgDensityGrid", "world_to_medium"), ("PgRenderDesc", "tile_step"), ("PgRenderDesc", "pixel_bounds"), ("PgCounters", "render_ms"),
+    offs = [("PgSceneDesc", "perm_sums"), ("PgSceneDesc", "grid_density"), ("PgSceneDesc", "bssrdf_tables"), ("PgBSSRDF", "table"), ("PgDensityGrid", "world_to_medium"), ("PgRenderDesc", "tile_step"), ("PgRenderDesc", "pixel_bounds"), ("PgCounters", "render_ms"),
             ("PgBVHNode", "axis"), ("PgStraySample", "weight")]
     body += "\n" + "\n".join(f'size_t off_{s}_{f}(void) {{ return offsetof({s}, {f}); }}' for s, f in offs)
     src.write_text(f'#include <stddef.h>\n#include "{ROOT}/include/pbrt_gpu.h"\n{body}\n')

@@ -1,0 +1,124 @@
+"""Subsurface scattering: `Material "subsurface"` / `"kdsubsurface"` (/root/reference/src/materials/subsurface.cpp, kdsubsurface.cpp),
+TabulatedBSSRDF and the BSSRDF branch of PathIntegrator::Li / VolPathIntegrator::Li (core/bssrdf.cpp, integrators/path.cpp:152-174,
+volpath.cpp:150-177).  The host front end computes the photon-beam-diffusion table as the material's constructor does
+(pbrt-v3_amd/host/bssrdf.cpp), hands it over in the ABI-24 tables (PgBSSRDF), the CPU oracle renders it bit-identically to the
+UNMODIFIED reference (tests/golden_sss/*, rendered by oracle/_ref/pbrt_oracle through oracle/make_golden.py), and the device
+library says loudly that it has no kernels for it.  All of this runs without a GPU: the oracle-first half of the row (DESIGN.md
+section 8); the device half is next."""
+import ctypes as C
+import glob
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from test_gpu_binding import BINDING
+
+SSS = os.path.join(ROOT, "tests", "golden_sss")
+NAMES = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(SSS, "*.json")))
+PROBE = os.path.join(ROOT, "oracle", "_ref", "ref_probe")
+
+
+def test_goldens_present():
+    assert len(NAMES) >= 11
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_matches_reference_image_and_stats(pkg, oracle, name):
+    scene = pkg.HostScene(os.path.join(SSS, name + ".pbrt"))
+    img, cn = oracle.render_image(scene)
+    ref = pkg.read_pfm(os.path.join(SSS, name + ".pfm"))
+    assert img.shape == ref.shape and np.array_equal(img, ref), f"max |diff| {np.abs(img - ref).max()}"
+    for k, v in json.load(open(os.path.join(SSS, name + ".json"))).items():  # the probe rays count as regular intersection tests
+        assert cn[k] == v, k
+
+
+def host_table(pkg, material):
+    text = open(os.path.join(SSS, "sss_subsurface.pbrt")).read()
+    old = [l for l in text.splitlines() if l.startswith('Material "subsurface"')][0]
+    scene = pkg.HostScene(text=text.replace(old, material))
+    d = scene.desc
+    b = d.bssrdfs[0]
+    n = b.n_rho + b.n_radius + 2 * b.n_rho * b.n_radius + b.n_rho
+    table = np.ctypeslib.as_array(d.bssrdf_tables, shape=(d.n_bssrdf_floats,))[b.table:b.table + n].copy()
+    return table, np.array(list(b.sigma_t), dtype=np.float32), np.array(list(b.rho), dtype=np.float32), b.eta
+
+
+def test_beam_diffusion_table_equals_the_references(pkg):
+    """BSSRDFTable(100, 64) after ComputeBeamDiffusionBSSRDF(0, 1.33) (bssrdf.cpp:149-180), printed by the unmodified reference through
+    oracle/ref_probe.cpp and committed as bit patterns: rhoSamples, radiusSamples, profile, rhoEff, profileCDF -- all 13 064 floats."""
+    table, sigma_t, rho, eta = host_table(pkg, 'Material "subsurface" "float eta" [ 1.33 ]')
+    ref = np.load(os.path.join(SSS, "table_g0_eta1.33.npy"))
+    assert table.size == ref.size == 13064 and np.array_equal(table.view(np.uint32), ref)
+    # the defaults of CreateSubsurfaceMaterial (subsurface.cpp:94-97) through the TabulatedBSSRDF constructor (bssrdf.h:146-150)
+    sa, ss = np.array([.0011, .0024, .014], dtype=np.float32), np.array([2.55, 3.21, 3.77], dtype=np.float32)
+    assert np.array_equal(sigma_t, sa + ss) and np.array_equal(rho, ss / (sa + ss)) and eta == np.float32(1.33)
+
+
+@pytest.mark.parametrize("g,eta", [(0.4, 1.5), (-0.3, 1.1), (0.0, 0.8)])
+def test_beam_diffusion_table_live(pkg, g, eta):
+    """Further (g, eta) pairs against the reference itself where it is built (eta < 1 runs the branch of FresnelMoment1 with the
+    double-precision literal, bssrdf.cpp:48, and a NaN critical angle in the single-scattering term -- both reproduced)."""
+    if not os.path.exists(PROBE):
+        pytest.skip("oracle/_ref/ref_probe is built only where /root/reference exists")
+    out = subprocess.run([PROBE, "bssrdf", str(g), str(eta)], capture_output=True, text=True, check=True).stdout
+    ref = np.concatenate([np.array([int(x, 16) for x in line.split()[1:]], dtype=np.uint32) for line in out.splitlines()])
+    table, _, _, _ = host_table(pkg, f'Material "subsurface" "float g" [ {g} ] "float eta" [ {eta} ]')
+    assert np.array_equal(table.view(np.uint32), ref)
+
+
+def test_kdsubsurface_inversion_live(pkg):
+    """SubsurfaceFromDiffuse (bssrdf.cpp:182-191): InvertCatmullRom of the effective albedo, per channel."""
+    if not os.path.exists(PROBE):
+        pytest.skip("oracle/_ref/ref_probe is built only where /root/reference exists")
+    out = subprocess.run([PROBE, "bssrdf", "0", "1.33", "0.5", "0.4", "0.3", "1", "2", "3"], capture_output=True, text=True, check=True).stdout
+    vals = {l.split()[0]: np.array([int(x, 16) for x in l.split()[1:]], dtype=np.uint32).view(np.float32) for l in out.splitlines()}
+    _, sigma_t, rho, _ = host_table(pkg, 'Material "kdsubsurface" "rgb Kd" [ 0.5 0.4 0.3 ] "rgb mfp" [ 1 2 3 ] "float eta" [ 1.33 ]')
+    st = vals["sigma_a"] + vals["sigma_s"]
+    assert np.array_equal(sigma_t, st) and np.array_equal(rho, vals["sigma_s"] / st)
+
+
+def test_material_identity_follows_the_directives(pkg):
+    """Sample_Sp's probe rays accept hits on the SAME Material object (bssrdf.cpp:301): one `Material` directive shared by both
+    boxes is one table entry, the same text written twice is two, and materials of these types are never merged."""
+    one = pkg.HostScene(os.path.join(SSS, "sss_subsurface.pbrt"))
+    two = pkg.HostScene(os.path.join(SSS, "sss_two_materials.pbrt"))
+    assert one.desc.n_bssrdfs == 1 and two.desc.n_bssrdfs == 2 and two.desc.n_materials == one.desc.n_materials + 1
+    assert two.desc.n_bssrdf_floats == one.desc.n_bssrdf_floats == 13064  # equal (g, eta): one shared table
+    black = pkg.HostScene(os.path.join(SSS, "sss_black_no_bssrdf.pbrt"))
+    assert black.desc.n_bssrdfs == 0 and not black.desc.material_bssrdf  # the early return of subsurface.cpp:55
+
+
+def test_textured_parameters_are_reported(pkg, capfd):
+    text = open(os.path.join(SSS, "sss_subsurface.pbrt")).read()
+    text = text.replace("WorldBegin\n", 'WorldBegin\nTexture "chk" "spectrum" "checkerboard"\n', 1).replace('"rgb sigma_a" [ 0.002 0.004 0.02 ]', '"texture sigma_a" "chk"')
+    pkg.HostScene(text=text)
+    assert "textured parameters and bump maps of subsurface materials are outside this build's closed set" in capfd.readouterr().err
+
+
+def test_device_library_refuses_subsurface_loudly(pkg):
+    """No kernels for the BSSRDF branch in this ABI version: pg_scene_create answers PG_ERR_UNSUPPORTED before touching a device --
+    never a render that silently treats the material as glass, never a CPU fallback."""
+    scene = pkg.HostScene(os.path.join(SSS, "sss_subsurface.pbrt"))
+    lib, handle = pkg.gpu_lib(), C.c_void_p()
+    assert lib.pg_scene_create(C.byref(scene.desc), C.byref(handle)) == -2 and not handle  # PG_ERR_UNSUPPORTED
+    assert b"subsurface scattering" in lib.pg_last_error()
+
+
+@pytest.mark.parametrize("name", ["sss_subsurface", "sss_kd_rough", "sss_preset_volpath", "sss_two_materials"])
+def test_reference_side_binding_flattens_the_reference_bssrdf(pkg, name, tmp_path):
+    """The reference's own SubsurfaceMaterial / KdSubsurfaceMaterial objects (its constructor's table, its TabulatedBSSRDF's sigma_t and
+    rho), flattened by the compiled binding and rendered by the oracle behind the C ABI: bit-identical to the reference's image."""
+    if os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "-f", "Makefile.ref", "-j8", "_ref/pbrt_gpubind"])
+    if not os.path.exists(BINDING):
+        pytest.skip("oracle/_ref/pbrt_gpubind is built only where /root/reference exists")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle_abi_shim.so"])
+    out = str(tmp_path / "bound.pfm")
+    p = subprocess.run([BINDING, "--outfile", out, os.path.join(SSS, name + ".pbrt")], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, PBRT_GPU_LIB=os.path.join(ROOT, "oracle", "liboracle_abi_shim.so")))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert np.array_equal(pkg.read_pfm(out), pkg.read_pfm(os.path.join(SSS, name + ".pfm")))

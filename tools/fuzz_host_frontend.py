@@ -38,6 +38,10 @@ int main(int argc, char **argv) {
         for (int i = 0; i < d->n_tris; ++i) acc += d->tri_material ? d->tri_material[i] : 0;
         for (int i = 0; i < d->n_materials; ++i) acc += d->materials[i].type;
         for (int i = 0; i < d->n_lights; ++i) acc += d->lights[i].type;
+        for (int i = 0; i < d->n_materials; ++i) if (d->material_bssrdf && d->material_bssrdf[i] >= 0) {  // subsurface tables, whole
+            const PgBSSRDF &b = d->bssrdfs[d->material_bssrdf[i]];
+            for (long long k = 0; k < b.n_rho + b.n_radius + 2LL * b.n_rho * b.n_radius + b.n_rho; ++k) acc += d->bssrdf_tables[b.table + k];
+        }
         for (int i = 0; i < d->n_media; ++i) if (d->media_grid && d->media_grid[i] >= 0) {  // GridDensityMedium tables: every voxel
             const PgDensityGrid &g = d->grids[d->media_grid[i]];
             for (long long k = 0; k < (long long)g.nx * g.ny * g.nz; ++k) acc += d->grid_density[g.density_offset + k];
@@ -91,7 +95,7 @@ def main():
     exe = build()
     rng = random.Random(seed)
     gold = os.path.join(ROOT, "tests", "golden")
-    dirs = [gold, os.path.join(ROOT, "tests", "golden_grid")]
+    dirs = [gold, os.path.join(ROOT, "tests", "golden_grid"), os.path.join(ROOT, "tests", "golden_sss")]
     if os.environ.get("FUZZ_ONLY"):  # e.g. FUZZ_ONLY=golden_grid: mutate only that directory's scenes
         dirs = [d for d in dirs if os.path.basename(d) == os.environ["FUZZ_ONLY"]]
     srcs = [s for d in dirs for s in sorted(glob.glob(os.path.join(d, "*.pbrt"))) if os.path.getsize(s) < 20000]
