@@ -331,6 +331,16 @@ typedef struct PgBSSRDF {
     float sigma_t[3], rho[3];
     int32_t n_rho, n_radius;      /* 100, 64 (subsurface.h:73) */
     int64_t table;                /* first float of the table in PgSceneDesc.bssrdf_tables */
+    /* A texture among the material's parameters (or a bump map): the surface BSDF is then a PG_MAT_TEXTURED material of kind
+     * PG_KIND_GLASS (the two ComputeScatteringFunctions build the same lobes from Kr, Kt, uroughness, vroughness and eta as
+     * glass.cpp does from its parameters), there is a BSSRDF at a hit iff that BSDF has a BxDF (the early return), and sigma_t / rho are
+     * derived per hit as the constructor does from
+     *   textured == 1 (subsurface):   sigma_a = scale * Clamp(a),  sigma_s = scale * Clamp(b)            (subsurface.cpp:87-88)
+     *   textured == 2 (kdsubsurface): SubsurfaceFromDiffuse(table, Clamp(a) = Kd, scale * Clamp(b) = mfp) (kdsubsurface.cpp:88-91)
+     * textured == 0: sigma_t / rho above are final. */
+    int32_t textured;
+    float scale;
+    PgTexRef a, b;
 } PgBSSRDF;
 
 typedef struct PgSceneDesc {

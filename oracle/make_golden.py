@@ -816,6 +816,16 @@ SSS_SCENES = {
                                  world_edit=lambda s: s.replace("# short box", 'MakeNamedMaterial "wax" "string type" "subsurface" "rgb sigma_a" [ 0.004 0.01 0.03 ] "rgb sigma_s" [ 0.08 0.08 0.06 ] "float eta" [ 1.45 ]\n'
                                                                 'AttributeBegin\n  NamedMaterial "wax"\n  Translate 420 70 120\n  Shape "sphere" "float radius" [ 70 ]\nAttributeEnd\n'
                                                                 'AttributeBegin\n  NamedMaterial "wax"\n  Translate 150 390 330\n  Rotate 30 1 0 0\n  Shape "sphere" "float radius" [ 60 ] "float zmax" [ 40 ]\nAttributeEnd\n# short box', 1)),
+    # a texture / a bump map among the parameters: the BSDF and the BSSRDF's coefficients are evaluated per hit
+    "sss_textured_kd_bump": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 6 ]', world_edit=lambda s: with_sss(s,
+        'Texture "chk" "spectrum" "checkerboard" "float uscale" [ 3 ] "float vscale" [ 3 ] "rgb tex1" [ 0.7 0.3 0.2 ] "rgb tex2" [ 0.2 0.5 0.8 ]\n'
+        'Texture "bmp" "float" "fbm" "integer octaves" [ 3 ]\nTexture "bmps" "float" "scale" "texture tex1" "bmp" "float tex2" [ 4 ]\n'
+        'Material "kdsubsurface" "texture Kd" "chk" "rgb mfp" [ 10 14 20 ] "texture bumpmap" "bmps" "float eta" [ 1.3 ]')),
+    # textured sigma_a; Kt is black on half of the squares: there the material returns before it sets the BSSRDF (subsurface.cpp:55)
+    "sss_textured_sigma_kt": cornell(32, 32, 8, integrator='Integrator "volpath" "integer maxdepth" [ 6 ]', world_edit=lambda s: with_sss(s,
+        'Texture "sa" "spectrum" "checkerboard" "integer dimension" [ 3 ] "rgb tex1" [ 0.002 0.004 0.02 ] "rgb tex2" [ 0.02 0.004 0.002 ]\n'
+        'Texture "kt" "spectrum" "checkerboard" "float uscale" [ 2 ] "float vscale" [ 2 ] "rgb tex1" [ 1 1 1 ] "rgb tex2" [ 0 0 0 ]\n'
+        'Material "subsurface" "texture sigma_a" "sa" "rgb sigma_s" [ 0.05 0.06 0.08 ] "float scale" [ 2 ] "texture Kt" "kt" "rgb Kr" [ 0 0 0 ] "float uroughness" [ 0.2 ] "float vroughness" [ 0.1 ]')),
     "sss_instances": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 5 ]', world_edit=lambda s: with_instances(with_sss(s, SSS_PLAIN))),
     "sss_sobol": cornell(24, 24, 4, integrator='Integrator "path" "integer maxdepth" [ 6 ]', world_edit=lambda s: with_sss(s, SSS_PLAIN)).replace('Sampler "halton"', 'Sampler "sobol"'),
     "sss_random": cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 6 ]', world_edit=lambda s: with_sss(s, SSS_PLAIN)).replace('Sampler "halton"', 'Sampler "random"'),

@@ -328,50 +328,68 @@ static int MakeMaterial(const std::string &name, const ParamSet &geom, const Par
             }
         }
     } else if (name == "subsurface" || name == "kdsubsurface") {
-        // CreateSubsurfaceMaterial (subsurface.cpp:93-136) / CreateKdSubsurfaceMaterial (kdsubsurface.cpp:95-123) with constant
-        // parameters: the surface BSDF has glass's shape with "eta" as the index (subsurface.cpp:57-86), the BSSRDF's
-        // coefficients are evaluated here once (:87-90 / kdsubsurface.cpp:88-92), the table is the constructor's
-        // ComputeBeamDiffusionBSSRDF(g, eta) (subsurface.h:73-75).
+        // CreateSubsurfaceMaterial (subsurface.cpp:93-136) / CreateKdSubsurfaceMaterial (kdsubsurface.cpp:95-123).  The surface BSDF
+        // has glass's shape with "eta" as the index (subsurface.cpp:57-86); with constant parameters the BSSRDF's coefficients are
+        // evaluated here once (:87-90 / kdsubsurface.cpp:88-92), with a texture (or a bump map) among them per hit; the table is the
+        // constructor's ComputeBeamDiffusionBSSRDF(g, eta) (subsurface.h:73-75).
         const bool kdForm = name == "kdsubsurface";
         bool textured = false;
-        auto specC = [&](const char *n, RGB d) { PgTexRef r = spectrumRef(geom, mat, n, d, gs); if (r.tex >= 0) textured = true; return RGB{{r.v[0], r.v[1], r.v[2]}}; };
-        auto fltC = [&](const char *n, Float d) { PgTexRef r = floatRef(geom, mat, n, d, gs); if (r.tex >= 0) textured = true; return r.v[0]; };
-        RGB sig_a{{.0011f, .0024f, .014f}}, sig_s{{2.55f, 3.21f, 3.77f}}, kd{{.5f, .5f, .5f}}, mfp{{1.f, 1.f, 1.f}};
-        Float g;
+        auto specC = [&](const char *n, RGB d) { PgTexRef r = spectrumRef(geom, mat, n, d, gs); if (r.tex >= 0) textured = true; return r; };
+        auto fltC = [&](const char *n, Float d) { PgTexRef r = floatRef(geom, mat, n, d, gs); if (r.tex >= 0) textured = true; return r; };
+        auto rgbOf = [](const PgTexRef &r) { return RGB{{r.v[0], r.v[1], r.v[2]}}; };
+        RGB sig_a{{.0011f, .0024f, .014f}}, sig_s{{2.55f, 3.21f, 3.77f}};
+        Float g = geom.FindOneFloat("g", mat.FindOneFloat("g", 0.0f));
         if (!kdForm) {
             const std::string preset = geom.FindOneString("name", mat.FindOneString("name", ""));
             const bool found = GetMediumScatteringProperties(preset, sig_a.c, sig_s.c);
-            g = geom.FindOneFloat("g", mat.FindOneFloat("g", 0.0f));
             if (preset != "") {
                 if (!found) Warning("Named material \"%s\" not found.  Using defaults.", preset.c_str());
                 else g = 0;  // the database specifies reduced scattering coefficients
             }
-        } else g = 0;
+        }
         const Float scale = geom.FindOneFloat("scale", mat.FindOneFloat("scale", 1.f));
         const Float eta = geom.FindOneFloat("eta", mat.FindOneFloat("eta", 1.33f));
-        if (kdForm) { kd = specC("Kd", kd); mfp = specC("mfp", mfp); g = geom.FindOneFloat("g", mat.FindOneFloat("g", 0.0f)); }
-        else { sig_a = specC("sigma_a", sig_a); sig_s = specC("sigma_s", sig_s); }
-        const RGB kr = specC("Kr", RGB{{1.f, 1.f, 1.f}}), kt = specC("Kt", RGB{{1.f, 1.f, 1.f}});
-        Float ur = fltC("uroughness", 0.f), vr = fltC("vroughness", 0.f);
+        // the two coefficient parameters: (sigma_a, sigma_s) or (Kd, mfp)
+        const PgTexRef ca = kdForm ? specC("Kd", RGB{{.5f, .5f, .5f}}) : specC("sigma_a", sig_a);
+        const PgTexRef cb = kdForm ? specC("mfp", RGB{{1.f, 1.f, 1.f}}) : specC("sigma_s", sig_s);
+        const PgTexRef krRef = specC("Kr", RGB{{1.f, 1.f, 1.f}}), ktRef = specC("Kt", RGB{{1.f, 1.f, 1.f}});
+        const PgTexRef urRef = fltC("uroughness", 0.f), vrRef = fltC("vroughness", 0.f);
         const bool remap = remapParam();
-        if (textured || hasBump)
-            Error("Material \"%s\": textured parameters and bump maps of subsurface materials are outside this build's closed set; their constant parts are used.", name.c_str());
-        for (int i = 0; i < 3; ++i) { m.kr[i] = kr.c[i]; m.kt[i] = kt.c[i]; }
-        m.eta = eta;
-        m.bsdf_eta = eta;  // BSDF(*si, eta)
-        m.type = PG_MAT_LOBES;
-        const RGB R = rgbClamp(kr), T = rgbClamp(kt);
-        const bool isSpecular = ur == 0 && vr == 0;
-        const bool hasBssrdf = !(rgbBlack(R) && rgbBlack(T));  // the early return of ComputeScatteringFunctions (subsurface.cpp:55)
-        if (hasBssrdf) {
-            if (isSpecular) { PgBxDF b = lobe(PG_BXDF_FRESNEL_SPECULAR); setR(b, R); setT(b, T); b.eta_a = 1.f; b.eta_b = eta; lobes.push_back(b); }
-            else {
-                if (remap) { ur = RoughnessToAlpha(ur); vr = RoughnessToAlpha(vr); }
-                if (!rgbBlack(R)) { PgBxDF b = lobe(PG_BXDF_MICROFACET_R); setR(b, R); setDielectric(b, 1.f, eta); setTR(b, ur, vr); lobes.push_back(b); }
-                if (!rgbBlack(T)) { PgBxDF b = lobe(PG_BXDF_MICROFACET_T); setT(b, T); b.eta_a = 1.f; b.eta_b = eta; setTR(b, ur, vr); lobes.push_back(b); }
-            }
-        }
         mat.ReportUnused();
+        const bool perHit = textured || hasBump;
+        bool hasBssrdf = true;
+        if (!perHit) {
+            const RGB kr = rgbOf(krRef), kt = rgbOf(ktRef);
+            Float ur = urRef.v[0], vr = vrRef.v[0];
+            for (int i = 0; i < 3; ++i) { m.kr[i] = kr.c[i]; m.kt[i] = kt.c[i]; }
+            m.eta = eta;
+            m.bsdf_eta = eta;  // BSDF(*si, eta)
+            m.type = PG_MAT_LOBES;
+            const RGB R = rgbClamp(kr), T = rgbClamp(kt);
+            const bool isSpecular = ur == 0 && vr == 0;
+            hasBssrdf = !(rgbBlack(R) && rgbBlack(T));  // the early return of ComputeScatteringFunctions (subsurface.cpp:55)
+            if (hasBssrdf) {
+                if (isSpecular) { PgBxDF b = lobe(PG_BXDF_FRESNEL_SPECULAR); setR(b, R); setT(b, T); b.eta_a = 1.f; b.eta_b = eta; lobes.push_back(b); }
+                else {
+                    if (remap) { ur = RoughnessToAlpha(ur); vr = RoughnessToAlpha(vr); }
+                    if (!rgbBlack(R)) { PgBxDF b = lobe(PG_BXDF_MICROFACET_R); setR(b, R); setDielectric(b, 1.f, eta); setTR(b, ur, vr); lobes.push_back(b); }
+                    if (!rgbBlack(T)) { PgBxDF b = lobe(PG_BXDF_MICROFACET_T); setT(b, T); b.eta_a = 1.f; b.eta_b = eta; setTR(b, ur, vr); lobes.push_back(b); }
+                }
+            }
+        } else {  // evaluated per hit: glass's parameter slots (Kr, Kt | uroughness, vroughness, eta), bump map
+            tm.kind = PG_KIND_GLASS;
+            tm.s[0] = krRef; tm.s[1] = ktRef;
+            tm.f[0] = urRef; tm.f[1] = vrRef; tm.f[2] = constRef(eta);
+            tm.remap_roughness = remap ? 1 : 0;
+            tm.has_bump = hasBump ? 1 : 0; tm.bump = bumpRef;
+            auto &tab = renderOptions->textured;
+            int found = -1;
+            for (size_t i = 0; i < tab.size(); ++i) if (memcmp(&tab[i], &tm, sizeof(tm)) == 0) found = (int)i;
+            if (found < 0) { found = (int)tab.size(); tab.push_back(tm); }
+            m.type = PG_MAT_TEXTURED;
+            m.bsdf_eta = 1;
+            m.textured_index = found;
+        }
         // never interned: the probe rays of Sample_Sp compare Material objects (bssrdf.cpp:301)
         m.n_bxdfs = (int)lobes.size();
         m.first_bxdf = (int)renderOptions->bxdfs.size();
@@ -382,6 +400,8 @@ static int MakeMaterial(const std::string &name, const ParamSet &geom, const Par
             PgBSSRDF b;
             memset(&b, 0, sizeof(b));
             b.eta = eta; b.n_rho = 100; b.n_radius = 64;
+            b.scale = scale; b.a = ca; b.b = cb;
+            b.textured = !perHit ? 0 : (kdForm ? 2 : 1);
             auto key = std::make_pair(g, eta);
             auto it = renderOptions->bssrdfTableOf.find(key);
             if (it == renderOptions->bssrdfTableOf.end()) {
@@ -391,16 +411,14 @@ static int MakeMaterial(const std::string &name, const ParamSet &geom, const Par
                 renderOptions->bssrdfTables.insert(renderOptions->bssrdfTables.end(), table.begin(), table.end());
             }
             b.table = it->second;
+            // the constant parts' coefficients (final when nothing is textured)
             Float sa[3], ss[3];
+            const RGB ac = rgbClamp(rgbOf(ca)), bc = rgbClamp(rgbOf(cb));
             if (kdForm) {
-                const RGB mfree = rgbClamp(mfp), kdc = rgbClamp(kd);
                 Float mf[3];
-                for (int i = 0; i < 3; ++i) mf[i] = scale * mfree.c[i];
-                SubsurfaceFromDiffuse(renderOptions->bssrdfTables.data() + b.table, b.n_rho, b.n_radius, kdc.c, mf, sa, ss);
-            } else {
-                const RGB a = rgbClamp(sig_a), sc = rgbClamp(sig_s);
-                for (int i = 0; i < 3; ++i) { sa[i] = scale * a.c[i]; ss[i] = scale * sc.c[i]; }
-            }
+                for (int i = 0; i < 3; ++i) mf[i] = scale * bc.c[i];
+                SubsurfaceFromDiffuse(renderOptions->bssrdfTables.data() + b.table, b.n_rho, b.n_radius, ac.c, mf, sa, ss);
+            } else for (int i = 0; i < 3; ++i) { sa[i] = scale * ac.c[i]; ss[i] = scale * bc.c[i]; }
             for (int i = 0; i < 3; ++i) {  // the TabulatedBSSRDF constructor, bssrdf.h:146-150
                 b.sigma_t[i] = sa[i] + ss[i];
                 b.rho[i] = b.sigma_t[i] != 0 ? (ss[i] / b.sigma_t[i]) : 0;

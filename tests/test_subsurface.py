@@ -23,7 +23,7 @@ PROBE = os.path.join(ROOT, "oracle", "_ref", "ref_probe")
 
 
 def test_goldens_present():
-    assert len(NAMES) >= 11
+    assert len(NAMES) >= 13
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -92,11 +92,16 @@ def test_material_identity_follows_the_directives(pkg):
     assert black.desc.n_bssrdfs == 0 and not black.desc.material_bssrdf  # the early return of subsurface.cpp:55
 
 
-def test_textured_parameters_are_reported(pkg, capfd):
-    text = open(os.path.join(SSS, "sss_subsurface.pbrt")).read()
-    text = text.replace("WorldBegin\n", 'WorldBegin\nTexture "chk" "spectrum" "checkerboard"\n', 1).replace('"rgb sigma_a" [ 0.002 0.004 0.02 ]', '"texture sigma_a" "chk"')
-    pkg.HostScene(text=text)
-    assert "textured parameters and bump maps of subsurface materials are outside this build's closed set" in capfd.readouterr().err
+def test_textured_parameters_are_evaluated_per_hit(pkg):
+    """A texture or a bump map among the parameters: the BSDF becomes a per-hit material with glass's parameter slots, the BSSRDF entry
+    keeps the two coefficient parameters as texture references (goldens sss_textured_*)."""
+    scene = pkg.HostScene(os.path.join(SSS, "sss_textured_kd_bump.pbrt"))
+    d = scene.desc
+    assert d.n_bssrdfs == 1 and d.bssrdfs[0].textured == 2 and d.bssrdfs[0].a.tex >= 0 and d.bssrdfs[0].b.tex == -1
+    mats = [d.materials[i] for i in range(d.n_materials) if d.material_bssrdf[i] >= 0]
+    assert len(mats) == 1 and mats[0].type == 6 and d.textured[mats[0].textured_index].kind == 4 and d.textured[mats[0].textured_index].has_bump == 1
+    plain = pkg.HostScene(os.path.join(SSS, "sss_subsurface.pbrt"))
+    assert plain.desc.bssrdfs[0].textured == 0
 
 
 def test_device_library_refuses_subsurface_loudly(pkg):
