@@ -35,8 +35,12 @@ void pbrt_host_film_merge(PbrtHostScene *s, const PgRenderDesc *rd, const PgFilm
                           const PgStraySample *strays, int n_strays);
 void pbrt_host_film_image(PbrtHostScene *s, float *rgb);
 int pbrt_host_write_pfm(const char *filename, const float *rgb, int width, int height);
-/* WriteImage (core/imageio.cpp:81-122): PFM, or gamma-encoded 8-bit PNG / TGA, chosen by the file name's suffix. */
+/* WriteImage (core/imageio.cpp:81-122): PFM, gamma-encoded 8-bit PNG / TGA, or half-float OpenEXR (uncompressed), chosen by the
+ * file name's suffix. */
 int pbrt_host_write_image(const char *filename, const float *rgb, int width, int height);
+/* The same for a (cropped) film: width x height pixels whose upper left corner sits at (x_offset, y_offset) of a total_x x total_y
+ * frame -- WriteImage's outputBounds / totalResolution arguments, which only OpenEXR files record (data and display window). */
+int pbrt_host_write_image_window(const char *filename, const float *rgb, int width, int height, int x_offset, int y_offset, int total_x, int total_y);
 
 /* The host's own HLBVH build over bare bounds (n x {pMin, pMax}); nodes has room for 2n entries.  Same contract as
  * pg_hlbvh_build (pbrt_gpu.h), which must reproduce it bit for bit. */

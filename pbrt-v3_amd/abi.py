@@ -197,6 +197,7 @@ HOST_SYMBOLS = {
     "pbrt_host_film_image": (None, [C.c_void_p, C.c_void_p]),
     "pbrt_host_write_pfm": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int]),
     "pbrt_host_write_image": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int]),
+    "pbrt_host_write_image_window": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "pbrt_host_error_count": (C.c_int, []),
     "pbrt_host_hlbvh_build": (None, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
     "pbrt_host_set_device_bvh": (None, [C.c_int]),

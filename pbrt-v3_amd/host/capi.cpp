@@ -67,6 +67,9 @@ void pbrt_host_film_image(PbrtHostScene *s, float *rgb) {
 int pbrt_host_write_image(const char *filename, const float *rgb, int width, int height) {
     return WriteImage(filename, rgb, width, height) ? 0 : -1;
 }
+int pbrt_host_write_image_window(const char *filename, const float *rgb, int width, int height, int x_offset, int y_offset, int total_x, int total_y) {
+    return WriteImage(filename, rgb, width, height, x_offset, y_offset, total_x, total_y) ? 0 : -1;
+}
 int pbrt_host_write_pfm(const char *filename, const float *rgb, int width, int height) {
     return WriteImagePFM(filename, rgb, width, height) ? 0 : -1;
 }

@@ -287,8 +287,78 @@ bool WriteImageTGA(const std::string &filename, const uint8_t *rgb8, int width, 
     if (!ok) Error("Unable to write output file \"%s\"", filename.c_str());
     return ok;
 }
-// WriteImage, imageio.cpp:81-122
-bool WriteImage(const std::string &filename, const Float *rgb, int width, int height) {
+// OpenEXR output: the file the reference's WriteImageEXR (imageio.cpp:186-211) asks the OpenEXR library for -- half-float R, G, B
+// (Rgba with WRITE_RGB), display window = the full resolution, data window = the crop window -- written directly as a scanline
+// file WITHOUT compression (the library's default would be PIZ; any reader accepts either).  float -> half rounds to nearest
+// even, overflows to infinity and keeps NaN, like half::half(float).  Unpinned against the reference: the reference build used
+// as the oracle carries no OpenEXR (oracle/ref_stubs); tests/test_image_output.py checks the file against this description.
+static uint16_t FloatToHalf(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? (0x200u | ((x >> 13) & 0x3ffu)) : 0u));  // inf / NaN
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);  // rounds to a value beyond 65504: infinity
+    if (x < 0x38800000u) {  // below the smallest normal half: denormal (or zero)
+        if (x < 0x33000000u) return (uint16_t)sign;  // less than half of the smallest denormal
+        const int shift = 126 - (int)(x >> 23);      // 14 .. 24
+        const uint32_t mant = (x & 0x7fffffu) | 0x800000u;
+        uint32_t h = mant >> shift;
+        const uint32_t rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (h & 1u))) ++h;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((x - 0x38000000u) >> 13);
+    const uint32_t rem = x & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;  // a carry out of the mantissa moves to the next exponent, as it must
+    return (uint16_t)(sign | h);
+}
+bool WriteImageEXR(const std::string &filename, const Float *rgb, int width, int height, int xOffset, int yOffset, int totalX, int totalY) {
+    std::vector<uint8_t> out;
+    auto bytes = [&](const void *p, size_t n) { const uint8_t *b = (const uint8_t *)p; out.insert(out.end(), b, b + n); };
+    auto i32 = [&](int32_t v) { bytes(&v, 4); };
+    auto str = [&](const char *t) { bytes(t, strlen(t) + 1); };
+    auto attr = [&](const char *name, const char *type, int32_t size) { str(name); str(type); i32(size); };
+    const uint8_t magic[8] = {0x76, 0x2f, 0x31, 0x01, 2, 0, 0, 0};  // magic number, version 2, no flags: single-part scanline
+    bytes(magic, 8);
+    attr("channels", "chlist", 3 * 18 + 1);
+    for (const char *c : {"B", "G", "R"}) {  // alphabetical; HALF = 1, pLinear 0, sampling 1 x 1
+        str(c); i32(1);
+        const uint8_t lin[4] = {0, 0, 0, 0};
+        bytes(lin, 4); i32(1); i32(1);
+    }
+    out.push_back(0);
+    attr("compression", "compression", 1); out.push_back(0);  // NO_COMPRESSION
+    attr("dataWindow", "box2i", 16); i32(xOffset); i32(yOffset); i32(xOffset + width - 1); i32(yOffset + height - 1);
+    attr("displayWindow", "box2i", 16); i32(0); i32(0); i32(totalX - 1); i32(totalY - 1);
+    attr("lineOrder", "lineOrder", 1); out.push_back(0);  // INCREASING_Y
+    const float one = 1.f, zero = 0.f;
+    attr("pixelAspectRatio", "float", 4); bytes(&one, 4);
+    attr("screenWindowCenter", "v2f", 8); bytes(&zero, 4); bytes(&zero, 4);
+    attr("screenWindowWidth", "float", 4); bytes(&one, 4);
+    out.push_back(0);  // end of header
+    const size_t rowBytes = 8 + (size_t)3 * 2 * width;
+    uint64_t offset = out.size() + (uint64_t)8 * height;
+    for (int y = 0; y < height; ++y) { bytes(&offset, 8); offset += rowBytes; }
+    std::vector<uint16_t> row((size_t)3 * width);
+    for (int y = 0; y < height; ++y) {
+        i32(yOffset + y); i32((int32_t)(rowBytes - 8));
+        for (int x = 0; x < width; ++x) {
+            const Float *px = rgb + 3 * ((size_t)y * width + x);
+            row[x] = FloatToHalf(px[2]); row[width + x] = FloatToHalf(px[1]); row[2 * (size_t)width + x] = FloatToHalf(px[0]);
+        }
+        bytes(row.data(), row.size() * 2);
+    }
+    FILE *fp = fopen(filename.c_str(), "wb");
+    if (!fp) { Error("Unable to write output file \"%s\"", filename.c_str()); return false; }
+    const bool ok = fwrite(out.data(), 1, out.size(), fp) == out.size();
+    fclose(fp);
+    if (!ok) Error("Unable to write output file \"%s\"", filename.c_str());
+    return ok;
+}
+// WriteImage, imageio.cpp:81-122 (outputBounds = [offset, offset + size), totalResolution)
+bool WriteImage(const std::string &filename, const Float *rgb, int width, int height) { return WriteImage(filename, rgb, width, height, 0, 0, width, height); }
+bool WriteImage(const std::string &filename, const Float *rgb, int width, int height, int xOffset, int yOffset, int totalX, int totalY) {
     auto hasExt = [&](const char *e) { size_t n = filename.size(), m = strlen(e); return n >= m && filename.compare(n - m, m, e) == 0; };
     if (hasExt(".pfm")) return WriteImagePFM(filename, rgb, width, height);
     if (hasExt(".png") || hasExt(".tga")) {
@@ -296,11 +366,7 @@ bool WriteImage(const std::string &filename, const Float *rgb, int width, int he
         ToRGB8(rgb, width, height, &rgb8);
         return hasExt(".png") ? WriteImagePNG(filename, rgb8.data(), width, height) : WriteImageTGA(filename, rgb8.data(), width, height);
     }
-    if (hasExt(".exr")) {  // the reference writes half-float OpenEXR through the OpenEXR library, which this build does not carry
-        std::string alt = filename + ".pfm";
-        Warning("OpenEXR output is not part of this build; writing the float image as \"%s\".", alt.c_str());
-        return WriteImagePFM(alt, rgb, width, height);
-    }
+    if (hasExt(".exr")) return WriteImageEXR(filename, rgb, width, height, xOffset, yOffset, totalX, totalY);
     Error("Can't determine image file type from suffix of filename \"%s\"", filename.c_str());
     return false;
 }
@@ -309,7 +375,7 @@ void Film::WriteImage() const {
     std::vector<Float> rgb;
     ComputeImage(&rgb);
     int w = croppedPixelBounds[2] - croppedPixelBounds[0], h = croppedPixelBounds[3] - croppedPixelBounds[1];
-    pbrt::WriteImage(filename, rgb.data(), w, h);
+    pbrt::WriteImage(filename, rgb.data(), w, h, croppedPixelBounds[0], croppedPixelBounds[1], fullResolution[0], fullResolution[1]);
 }
 
 Film *CreateFilm(const ParamSet &params, Float frx, Float fry) {  // film.cpp:213-252

@@ -179,7 +179,8 @@ void BuildMIPMap(int resX, int resY, int nc, const std::vector<float> &data, int
 void EWAWeightLut(float lut[128]);
 void MIPMapLookup(const PgImage &im, const std::vector<float> &pool, const float st[2], float width, float out[3]);
 bool WriteImagePFM(const std::string &filename, const Float *rgb, int width, int height);  // imageio.cpp:437-482
-bool WriteImage(const std::string &filename, const Float *rgb, int width, int height);     // imageio.cpp:81-122: .pfm / .png / .tga by suffix
+bool WriteImage(const std::string &filename, const Float *rgb, int width, int height);     // imageio.cpp:81-122: .pfm / .png / .tga / .exr by suffix
+bool WriteImage(const std::string &filename, const Float *rgb, int width, int height, int xOffset, int yOffset, int totalX, int totalY);
 
 struct PerspectiveCamera {  // ProjectiveCamera (core/camera.h:87-108): cameras/perspective.cpp:45-68 or orthographic.cpp:44-62
     bool orthographic = false;
