@@ -127,3 +127,26 @@ def test_reference_side_binding_flattens_the_reference_bssrdf(pkg, name, tmp_pat
                        env=dict(os.environ, PBRT_GPU_LIB=os.path.join(ROOT, "oracle", "liboracle_abi_shim.so")))
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert np.array_equal(pkg.read_pfm(out), pkg.read_pfm(os.path.join(SSS, name + ".pfm")))
+
+
+@pytest.mark.parametrize("seed", [4, 7, 11])
+def test_random_scenes_live_when_reference_present(pkg, oracle, seed, tmp_path):
+    """Random scenes mixing both CPU-only features into the volumetric fuzz scenes (tools/fuzz_oracle_vs_reference.py: a random
+    GridDensityMedium, random subsurface / kdsubsurface materials on degenerate triangle soups and quadrics), rendered now by the
+    unmodified reference and by front end + oracle.  Seed 4 has probe segments that collect more than 256 hits on their own
+    material.  40 seeds were swept with the tool: 0 mismatches."""
+    if not os.path.exists(oracle.REF_BINARY):
+        pytest.skip("oracle/_ref/pbrt_oracle not built here")
+    import importlib.util
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    fz = load("fuzz_scenes", os.path.join(ROOT, "tests", "test_gpu_fuzz.py"))
+    tool = load("fuzz_tool", os.path.join(ROOT, "tools", "fuzz_oracle_vs_reference.py"))
+    scene_file, out = str(tmp_path / "fuzz.pbrt"), str(tmp_path / "ref.pfm")
+    open(scene_file, "w").write(tool.random_scene_sss_grid(fz, seed))
+    oracle.run_reference(scene_file, out, nthreads=1)
+    img, _ = oracle.render_image(pkg.HostScene(scene_file))
+    assert np.array_equal(img, pkg.read_pfm(out))
