@@ -341,6 +341,11 @@ typedef struct PgBSSRDF {
     int32_t textured;
     float scale;
     PgTexRef a, b;
+    /* SeparableBSSRDF::material as an index into materials[]: the probe rays keep hits on primitives of THIS material.  The
+     * material's own index -- except for a MixMaterial whose first component is a subsurface material: si->bssrdf is then that
+     * component's (mixmat.cpp:52-53), whose `material` is the component, not the mix, so only primitives that carry the component
+     * itself are admissible exit points. */
+    int32_t match_material;
 } PgBSSRDF;
 
 typedef struct PgSceneDesc {

@@ -170,8 +170,9 @@ struct BssrdfProbe {
     bool present = false;
     float eta = 0, sigma_t[3] = {0, 0, 0}, rho[3] = {0, 0, 0};
     const BSSRDFTable *table = nullptr;
+    const Material *material = nullptr;  // SeparableBSSRDF::material: what the probe rays' hits are compared with (bssrdf.cpp:301)
     bool operator==(const BssrdfProbe &o) const {
-        return present == o.present && eta == o.eta && !memcmp(sigma_t, o.sigma_t, sizeof(sigma_t)) && !memcmp(rho, o.rho, sizeof(rho)) && table == o.table;
+        return present == o.present && eta == o.eta && !memcmp(sigma_t, o.sigma_t, sizeof(sigma_t)) && !memcmp(rho, o.rho, sizeof(rho)) && table == o.table && material == o.material;
     }
 };
 // the material's BxDF list at one (arbitrary) surface point
@@ -185,7 +186,7 @@ void ListBxDFs(const Material *mat, Float u, Float v, std::vector<PgBxDF> *out, 
     if (bss && si.bssrdf) {
         const TabulatedBSSRDF *t = dynamic_cast<const TabulatedBSSRDF *>(si.bssrdf);
         if (!t) Unsupported("a BSSRDF other than TabulatedBSSRDF");
-        bss->present = true; bss->eta = t->eta; bss->table = &t->table;
+        bss->present = true; bss->eta = t->eta; bss->table = &t->table; bss->material = t->material;
         CopyRGB(t->sigma_t, bss->sigma_t); CopyRGB(t->rho, bss->rho);
     }
     if (!si.bsdf) return;
@@ -209,6 +210,7 @@ struct Flat {
     std::map<const Medium *, int> mediumIndex;
     std::vector<PgBSSRDF> bssrdfs;          // one per material with a TabulatedBSSRDF
     std::vector<int32_t> materialBssrdf;    // per material, -1 = none
+    std::vector<const Material *> bssrdfMaterial;  // per PgBSSRDF: the Material its probe rays look for
     std::vector<float> bssrdfTables;
     std::map<const BSSRDFTable *, int64_t> bssrdfTableOf;
     std::vector<int32_t> permSums;
@@ -360,9 +362,11 @@ void FlattenScene(const Scene &scene, int maxDepth, bool volumetric, const std::
                         put(t.rhoSamples.get(), nr); put(t.radiusSamples.get(), nd); put(t.profile.get(), nr * nd); put(t.rhoEff.get(), nr); put(t.profileCDF.get(), nr * nd);
                     }
                     pb.table = ti->second;
+                    pb.match_material = -1;  // resolved below: TabulatedBSSRDF::material among the interned materials
                     flat->materialBssrdf.resize(flat->materials.size() + 1, -1);
                     flat->materialBssrdf[flat->materials.size()] = (int)flat->bssrdfs.size();
                     flat->bssrdfs.push_back(pb);
+                    flat->bssrdfMaterial.push_back(sa.material);
                 }
                 pm.type = PG_MAT_LOBES; pm.first_bxdf = (int)flat->bxdfs.size(); pm.n_bxdfs = (int)a.size(); pm.bsdf_eta = etaA;
                 flat->bxdfs.insert(flat->bxdfs.end(), a.begin(), a.end());
@@ -429,6 +433,10 @@ void FlattenScene(const Scene &scene, int maxDepth, bool volumetric, const std::
     SetMediaTables(flat);
     if (!flat->bssrdfs.empty()) {  // subsurface scattering tables (ABI 24)
         flat->materialBssrdf.resize(flat->materials.size(), -1);
+        for (size_t i = 0; i < flat->bssrdfs.size(); ++i) {  // a component of a mix that no primitive carries itself matches nothing
+            auto mi = materialIndex.find(flat->bssrdfMaterial[i]);
+            flat->bssrdfs[i].match_material = mi != materialIndex.end() ? mi->second : -2;
+        }
         d.n_bssrdfs = (int)flat->bssrdfs.size(); d.bssrdfs = flat->bssrdfs.data(); d.material_bssrdf = flat->materialBssrdf.data();
         d.n_bssrdf_floats = (int64_t)flat->bssrdfTables.size(); d.bssrdf_tables = flat->bssrdfTables.data();
     }

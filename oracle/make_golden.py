@@ -826,6 +826,13 @@ SSS_SCENES = {
         'Texture "sa" "spectrum" "checkerboard" "integer dimension" [ 3 ] "rgb tex1" [ 0.002 0.004 0.02 ] "rgb tex2" [ 0.02 0.004 0.002 ]\n'
         'Texture "kt" "spectrum" "checkerboard" "float uscale" [ 2 ] "float vscale" [ 2 ] "rgb tex1" [ 1 1 1 ] "rgb tex2" [ 0 0 0 ]\n'
         'Material "subsurface" "texture sigma_a" "sa" "rgb sigma_s" [ 0.05 0.06 0.08 ] "float scale" [ 2 ] "texture Kt" "kt" "rgb Kr" [ 0 0 0 ] "float uroughness" [ 0.2 ] "float vroughness" [ 0.1 ]')),
+    # a MixMaterial whose first component is a subsurface material: the mix's BSSRDF is the component's, and its probe rays accept
+    # hits on primitives that carry the component ITSELF (the tall box) -- never the mixed box they start from (mixmat.cpp:52-53, bssrdf.cpp:301)
+    "sss_mix_component": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 6 ]', world_edit=lambda s: with_sss(s,
+        'MakeNamedMaterial "wax" "string type" "subsurface" "rgb sigma_a" [ 0.002 0.004 0.02 ] "rgb sigma_s" [ 0.02 0.03 0.04 ] "float eta" [ 1.33 ]\n'
+        'MakeNamedMaterial "paint" "string type" "matte" "rgb Kd" [ 0.6 0.2 0.2 ]\n'
+        'MakeNamedMaterial "waxpaint" "string type" "mix" "string namedmaterial1" "wax" "string namedmaterial2" "paint" "rgb amount" [ 0.7 0.6 0.5 ]\n'
+        'NamedMaterial "waxpaint"', tall='NamedMaterial "wax"')),
     "sss_instances": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 5 ]', world_edit=lambda s: with_instances(with_sss(s, SSS_PLAIN))),
     "sss_sobol": cornell(24, 24, 4, integrator='Integrator "path" "integer maxdepth" [ 6 ]', world_edit=lambda s: with_sss(s, SSS_PLAIN)).replace('Sampler "halton"', 'Sampler "sobol"'),
     "sss_random": cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 6 ]', world_edit=lambda s: with_sss(s, SSS_PLAIN)).replace('Sampler "halton"', 'Sampler "random"'),

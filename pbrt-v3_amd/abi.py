@@ -61,7 +61,7 @@ class PgDensityGrid(C.Structure):
 
 class PgBSSRDF(C.Structure):
     _fields_ = [("eta", C.c_float), ("sigma_t", C.c_float * 3), ("rho", C.c_float * 3), ("n_rho", C.c_int32), ("n_radius", C.c_int32),
-                ("table", C.c_int64), ("textured", C.c_int32), ("scale", C.c_float), ("a", PgTexRef), ("b", PgTexRef)]
+                ("table", C.c_int64), ("textured", C.c_int32), ("scale", C.c_float), ("a", PgTexRef), ("b", PgTexRef), ("match_material", C.c_int32)]
 
 
 class PgAlphaMask(C.Structure):

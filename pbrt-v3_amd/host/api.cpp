@@ -423,6 +423,7 @@ static int MakeMaterial(const std::string &name, const ParamSet &geom, const Par
                 b.sigma_t[i] = sa[i] + ss[i];
                 b.rho[i] = b.sigma_t[i] != 0 ? (ss[i] / b.sigma_t[i]) : 0;
             }
+            b.match_material = index;
             renderOptions->materialBssrdf.resize(index + 1, -1);
             renderOptions->materialBssrdf[index] = (int)renderOptions->bssrdfs.size();
             renderOptions->bssrdfs.push_back(b);
@@ -516,8 +517,7 @@ static int MakeMaterial(const std::string &name, const ParamSet &geom, const Par
         for (int j = 0; j < 2; ++j) {
             const PgMaterial sm = renderOptions->materials[sub[j]];  // copy: the table may grow
             if (sm.type == PG_MAT_NONE) { Error("mix: a \"none\" material cannot be mixed; ignoring it."); continue; }
-            if (sub[j] < (int)renderOptions->materialBssrdf.size() && renderOptions->materialBssrdf[sub[j]] >= 0)
-                Error("mix: the BSSRDF of a subsurface material is outside this build's closed set inside a mix; only its surface BSDF is mixed.");
+
             if (j == 0) m.bsdf_eta = sm.bsdf_eta;  // si->bsdf stays m1's BSDF
             const RGB &sc = j == 0 ? s1 : s2;
             for (int i = 0; i < sm.n_bxdfs; ++i) {
@@ -531,6 +531,26 @@ static int MakeMaterial(const std::string &name, const ParamSet &geom, const Par
         if (bad) Error("mix: more than %d BxDFs or more than %d nested mixes; the excess is dropped.", PG_MAX_BXDFS, PG_MAX_BXDF_SCALES);
         tm.sub[0] = sub[0]; tm.sub[1] = sub[1];
         for (int j = 0; j < 2; ++j) if (renderOptions->materials[sub[j]].type == PG_MAT_TEXTURED) anyTexture = true;
+        // si->bssrdf stays what the FIRST component's ComputeScatteringFunctions set (mixmat.cpp:52-53; the second one works on a copy
+        // of si): the mix then carries that component's BSSRDF, whose probe rays look for the component itself.  The mix is its own
+        // table entry (never merged), like every material with a BSSRDF.
+        auto bssrdfOf = [&](int mi) { return mi < (int)renderOptions->materialBssrdf.size() ? renderOptions->materialBssrdf[mi] : -1; };
+        if (bssrdfOf(sub[0]) >= 0) {
+            const PgBSSRDF comp = renderOptions->bssrdfs[bssrdfOf(sub[0])];
+            if (comp.textured || anyTexture) Error("mix: a textured subsurface component (or a textured mix around one) is outside this build's closed set; the mix is rendered without the BSSRDF.");
+            else {
+                mat.ReportUnused();
+                m.n_bxdfs = (int)lobes.size();
+                m.first_bxdf = (int)renderOptions->bxdfs.size();
+                renderOptions->bxdfs.insert(renderOptions->bxdfs.end(), lobes.begin(), lobes.end());
+                renderOptions->materials.push_back(m);
+                const int index = (int)renderOptions->materials.size() - 1;
+                renderOptions->materialBssrdf.resize(index + 1, -1);
+                renderOptions->materialBssrdf[index] = (int)renderOptions->bssrdfs.size();
+                renderOptions->bssrdfs.push_back(comp);  // (match_material stays the component)
+                return index;
+            }
+        }
     }
     mat.ReportUnused();
     if (hasBump) anyTexture = true;

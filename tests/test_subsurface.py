@@ -23,7 +23,7 @@ PROBE = os.path.join(ROOT, "oracle", "_ref", "ref_probe")
 
 
 def test_goldens_present():
-    assert len(NAMES) >= 13
+    assert len(NAMES) >= 14
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -113,7 +113,7 @@ def test_device_library_refuses_subsurface_loudly(pkg):
     assert b"subsurface scattering" in lib.pg_last_error()
 
 
-@pytest.mark.parametrize("name", ["sss_subsurface", "sss_kd_rough", "sss_preset_volpath", "sss_two_materials"])
+@pytest.mark.parametrize("name", ["sss_subsurface", "sss_kd_rough", "sss_preset_volpath", "sss_two_materials", "sss_mix_component"])
 def test_reference_side_binding_flattens_the_reference_bssrdf(pkg, name, tmp_path):
     """The reference's own SubsurfaceMaterial / KdSubsurfaceMaterial objects (its constructor's table, its TabulatedBSSRDF's sigma_t and
     rho), flattened by the compiled binding and rendered by the oracle behind the C ABI: bit-identical to the reference's image."""
