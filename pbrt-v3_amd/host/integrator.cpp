@@ -366,7 +366,7 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
         for (PgLight &l : flat->lights) if (l.type == PG_LIGHT_DISTANT || l.type == PG_LIGHT_INFINITE) l.world_radius = radius;
     }
     // dimensions a path can consume: 5 camera + per bounce (1+2+2 direct, 2 bsdf, 1 rr); 1000 max (halton.h:71-76)
-    int nDims = std::min(1000, 5 + 8 * (maxDepth + 2));
+    int nDims = (int)std::min(1000LL, std::max(5LL, 5 + 8 * ((long long)maxDepth + 2)));  // (64-bit: "maxdepth" is the file's to choose)
     if (volumetric) nDims = 1000;  // volpath.cpp:77-78,119-123: medium sampling consumes dimensions on uncounted bounces too
     if (!scene.bssrdfs.empty()) nDims = 1000;  // path.cpp:152-174: a subsurface vertex draws 10 more values (Sample_S, lights at pi, the exit direction)
     ComputeRadicalInversePermutations(nDims, &flat->perms, &flat->permSums);

@@ -220,6 +220,15 @@ def test_transform_end_inside_attribute_block_does_not_read_an_empty_stack(pkg):
     assert s.desc.n_tris == 36
 
 
+def test_hostile_maxdepth_does_not_overflow_the_dimension_count(pkg):
+    """"integer maxdepth" is the file's to choose: the Halton table's size is computed in 64 bits and never below the camera's five
+    dimensions (fuzz seed 101: 8 * (maxdepth + 2) overflowed an int)."""
+    one = open(os.path.join(GOLD, "cornell_32.pbrt")).read()
+    for depth, dims in ((-2147483648, 5), (-7, 5), (2147483647, 1000), (5, 61)):
+        s = pkg.HostScene(text=one.replace('"integer maxdepth" [ 5 ]', f'"integer maxdepth" [ {depth} ]'))
+        assert s.desc.n_perm_dims == dims, depth
+
+
 def test_second_frame_starts_from_fresh_render_options(pkg):
     """Several WorldBegin / WorldEnd frames in one file: pbrtWorldEnd resets RenderOptions (api.cpp:1630-1640), so frame 2 does not
     inherit frame 1's film, sampler, integrator or material tables.  (A load keeps the last frame.)"""
