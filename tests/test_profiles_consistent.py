@@ -1,0 +1,73 @@
+"""The measurement evidence under profiles/ is self-consistent: every roofline fraction of the committed bench lines can be recomputed
+from the fields next to it, none exceeds 1, the event-timed kernel durations of bench.py agree with the rocprofv3 --kernel-trace
+--stats summary of the same command, and kernel time sums to no more than the frame (each kernel is timed alone).  No GPU needed:
+this reads what the GPU runs of the round left behind ("profiles from which every frac in the bench line can be
+recomputed and none exceeds 1")."""
+import csv
+import json
+import os
+
+import pytest
+
+from conftest import ROOT
+
+PROF = os.path.join(ROOT, "profiles")
+BENCHES = {"cfg3": "r02u_bench_cfg3.json", "5m": "r02u_bench_5m.json", "10m_vol": "r02u_bench_10m_vol.json"}
+
+
+def bench(tag):
+    return json.load(open(os.path.join(PROF, BENCHES[tag])))
+
+
+@pytest.mark.parametrize("tag", sorted(BENCHES))
+def test_bench_line_carries_the_contract(tag):
+    b = bench(tag)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in b, k
+    assert b["metric"] == "Mrays/s" and b["dtype"] == "f32" and b["data"] == "synthetic" and b["vs_baseline"] is None and "workload" in b["config"]
+    if tag == "cfg3":
+        cb = b["cpu_baseline"]
+        assert cb["kind"] == "reference" and cb["cores"] >= 1 and cb["value"] > 0 and "spp" in cb["sample"]
+
+
+@pytest.mark.parametrize("tag", sorted(BENCHES))
+def test_every_fraction_recomputes_and_stays_below_one(tag):
+    b = bench(tag)
+    assert b["roofline"]["kernel"] == b["roofline_kernels"][0]["kernel"]  # dominant = the most solo time
+    total = 0.0
+    for k in b["roofline_kernels"]:
+        achieved = k["algorithmic_bytes_per_launch"] * k["launches"] / (k["total_ms"] * 1e-3) / 1e9
+        assert achieved == pytest.approx(k["achieved"], rel=1e-9) and k["frac"] == pytest.approx(k["achieved"] / k["peak"], rel=1e-12)
+        assert 0 < k["frac"] < 1 and k["avg_launch_ms"] == pytest.approx(k["total_ms"] / k["launches"], rel=1e-12)
+        assert (k["bound"], k["peak"]) in (("l2", 34500.0), ("hbm", 8000.0))
+        if k.get("hbm_side"):
+            hb = k["traffic"] * k["launches"] / (k["total_ms"] * 1e-3) / 1e9
+            assert hb == pytest.approx(k["hbm_side"]["achieved"], rel=1e-9) and 0 < k["hbm_side"]["frac"] < 1
+        total += k["total_ms"]
+    # the working set decides the bound: below the 256 MiB Infinity Cache the L2, above it HBM
+    assert (b["roofline"]["working_set_bytes"] < 256 << 20) == (b["roofline"]["bound"] == "l2")
+    # kernels are timed alone (events around each launch): their sum fits into the frames they ran in
+    other = sum(v for k, v in b["kernel_ms_per_step"].items() if k in ("resolve", "generate", "film"))
+    assert total / b["steps"] + other <= b["ms_per_step"] * 1.001
+    g = b["roofline"].get("gather")
+    if g and "frac" in g:
+        assert g["frac"] == pytest.approx(g["record_fetches_per_s"] / g["ceiling_records_per_s"], rel=1e-12) and 0 < g["frac"] < 1
+        if g["l2_hit_rate"] is not None:
+            h = g["l2_hit_rate"]
+            assert g["ceiling_records_per_s"] == pytest.approx(1 / (h / g["ceiling_l2_resident"] + (1 - h) / g["ceiling_at_working_set"]), rel=1e-9)
+
+
+@pytest.mark.parametrize("tag,stats", [("cfg3", "r02u_kernel_stats_cfg3.csv"), ("5m", "r02u_kernel_stats_5m.csv")])
+def test_event_timing_agrees_with_the_rocprof_summary(tag, stats):
+    """bench.py times each kernel with HIP events on its own stream; rocprofv3 --kernel-trace --stats of the same command gives the
+    same average duration per kernel (the profiler's own overhead stays below a few percent)."""
+    rows = {r["Name"]: r for r in csv.DictReader(open(os.path.join(PROF, stats)))}
+    def avg_ms(prefix):
+        hit = [r for n, r in rows.items() if n.startswith(prefix)]
+        assert hit, prefix
+        return sum(float(r["TotalDurationNs"]) for r in hit) / sum(int(r["Calls"]) for r in hit) / 1e6
+    b = bench(tag)
+    by = {k["kernel"].split(" ")[0]: k for k in b["roofline_kernels"]}
+    assert avg_ms("void k_trace<false") == pytest.approx(by["k_trace<false>"]["avg_launch_ms"], rel=0.05)
+    assert avg_ms("void k_trace<true") == pytest.approx(by["k_trace<true>"]["avg_launch_ms"], rel=0.05)
+    assert avg_ms("void k_shade") == pytest.approx(by["k_shade"]["avg_launch_ms"], rel=0.08)
