@@ -70,6 +70,16 @@ def lib(cr_libm=False):
         L.oracle_light_sample_pdf.argtypes = [C.POINTER(abi.PgSceneDesc), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_spawn_ray_origin.restype = None
         L.oracle_spawn_ray_origin.argtypes = [C.c_void_p] * 5
+        L.oracle_find_interval_le.restype = C.c_int
+        L.oracle_find_interval_le.argtypes = [C.c_int, C.c_void_p, C.c_float]
+        L.oracle_catmull_rom_weights.restype = C.c_int
+        L.oracle_catmull_rom_weights.argtypes = [C.c_int, C.c_void_p, C.c_float, C.POINTER(C.c_int), C.c_void_p]
+        L.oracle_sample_catmull_rom_2d.restype = C.c_float
+        L.oracle_sample_catmull_rom_2d.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_float, C.c_float]
+        L.oracle_invert_catmull_rom.restype = C.c_float
+        L.oracle_invert_catmull_rom.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_float]
+        L.oracle_fresnel_moment1.restype = C.c_float
+        L.oracle_fresnel_moment1.argtypes = [C.c_float]
         _libs[path] = L
         if not cr_libm:
             _lib = L

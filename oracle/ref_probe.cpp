@@ -10,6 +10,7 @@
 // Build: make -C oracle -f Makefile.ref _ref/ref_probe
 #include "materials/metal.cpp"
 #include "bssrdf.h"
+#include "interpolation.h"
 #include "medium.h"
 #include "parallel.h"
 #include <cstdio>
@@ -22,6 +23,31 @@ static void PrintBits(const char *name, const pbrt::Float *v, int n) {
 }
 int main(int argc, char **argv) {
     using namespace pbrt;
+    if (argc > 3 && !strcmp(argv[1], "spline")) {
+        // `spline G ETA SEED N`: N pseudo-random queries of the reference's spline routines over the table of (G, ETA), one line each:
+        // alpha u x | CatmullRomWeights(rhoSamples, alpha): ok offset w0..w3 | SampleCatmullRom2D(..., alpha, u) | InvertCatmullRom(rhoSamples, rhoEff, x)
+        // | FresnelMoment1(0.5 + 1.5 alpha) -- all as float bit patterns.  The queries come from a 32-bit LCG the test repeats.
+        ParallelInit();
+        BSSRDFTable t(100, 64);
+        ComputeBeamDiffusionBSSRDF((Float)atof(argv[2]), (Float)atof(argv[3]), &t);
+        uint32_t state = (uint32_t)atoi(argv[4]);
+        auto next = [&]() { state = state * 1664525u + 1013904223u; return (Float)(state >> 8) * (1.f / 16777216.f); };
+        auto bits = [](Float f) { unsigned u; memcpy(&u, &f, 4); return u; };
+        for (int i = 0, n = atoi(argv[5]); i < n; ++i) {
+            Float alpha = next(), u = next(), x = next();
+            if (i % 7 == 0) alpha = i % 14 ? 0.f : 1.f;          // the spline's two ends
+            if (i % 11 == 0) alpha = t.rhoSamples[(i / 11) % 100];  // exactly on a node
+            int offset = -7;
+            Float w[4] = {0, 0, 0, 0};
+            bool ok = CatmullRomWeights(t.nRhoSamples, t.rhoSamples.get(), alpha, &offset, w);
+            Float s2 = SampleCatmullRom2D(t.nRhoSamples, t.nRadiusSamples, t.rhoSamples.get(), t.radiusSamples.get(), t.profile.get(), t.profileCDF.get(), alpha, u);
+            Float inv = InvertCatmullRom(t.nRhoSamples, t.rhoSamples.get(), t.rhoEff.get(), x);
+            printf("%08x %08x %08x | %d %d %08x %08x %08x %08x | %08x | %08x | %08x\n", bits(alpha), bits(u), bits(x), ok ? 1 : 0, offset, bits(w[0]), bits(w[1]), bits(w[2]), bits(w[3]),
+                   bits(s2), bits(inv), bits(FresnelMoment1(0.5f + 1.5f * alpha)));
+        }
+        ParallelCleanup();
+        return 0;
+    }
     if (argc > 3 && !strcmp(argv[1], "bssrdf")) {
         ParallelInit();
         BSSRDFTable t(100, 64);

@@ -150,3 +150,42 @@ def test_random_scenes_live_when_reference_present(pkg, oracle, seed, tmp_path):
     oracle.run_reference(scene_file, out, nthreads=1)
     img, _ = oracle.render_image(pkg.HostScene(scene_file))
     assert np.array_equal(img, pkg.read_pfm(out))
+
+
+def test_find_interval_basics(oracle):
+    """The reference's own FindInterval.Basics (src/tests/find_interval.cpp) on the restatement (predicate a[i] <= x)."""
+    a = np.arange(10, dtype=np.float32)
+    fi = lambda x: oracle.lib().oracle_find_interval_le(a.size, a.ctypes.data, x)
+    assert fi(-1) == 0 and fi(100) == a.size - 2
+    for i in range(a.size - 1):
+        assert fi(i) == i and fi(i + 0.5) == i
+        if i > 0:
+            assert fi(i - 0.5) == i - 1
+
+
+@pytest.mark.parametrize("g,eta,seed", [(0.0, 1.33, 7), (0.4, 1.5, 12345)])
+def test_spline_routines_equal_the_references_live(pkg, oracle, g, eta, seed):
+    """CatmullRomWeights, SampleCatmullRom2D, InvertCatmullRom (core/interpolation.cpp) and FresnelMoment1 (bssrdf.cpp:43-52) of the
+    restatement against the reference's own functions (oracle/ref_probe.cpp `spline`) on 400 pseudo-random queries over the beam-
+    diffusion table -- including albedo 0 and 1 (the spline's ends, where the profile is all zero) and queries exactly on a node."""
+    if not os.path.exists(PROBE):
+        pytest.skip("oracle/_ref/ref_probe is built only where /root/reference exists")
+    n = 400
+    out = subprocess.run([PROBE, "spline", str(g), str(eta), str(seed), str(n)], capture_output=True, text=True, check=True).stdout.splitlines()
+    assert len(out) == n
+    table, _, _, _ = host_table(pkg, f'Material "subsurface" "float g" [ {g} ] "float eta" [ {eta} ]')
+    rho, radius = table[:100].copy(), table[100:164].copy()
+    profile, rho_eff, cdf = table[164:164 + 6400].copy(), table[6564:6664].copy(), table[6664:].copy()
+    L = oracle.lib()
+    f32 = lambda bits: np.array([int(bits, 16)], dtype=np.uint32).view(np.float32)[0]
+    b32 = lambda v: int(np.array([v], dtype=np.float32).view(np.uint32)[0])
+    for line in out:
+        q, cw, s2, inv, fm = [part.split() for part in line.split("|")]
+        alpha, u, x = (f32(t) for t in q)
+        off, w = C.c_int(-7), np.zeros(4, np.float32)
+        ok = L.oracle_catmull_rom_weights(100, rho.ctypes.data, alpha, C.byref(off), w.ctypes.data)
+        assert [ok, off.value] + [b32(v) for v in w] == [int(cw[0]), int(cw[1])] + [int(t, 16) for t in cw[2:]], line
+        got = L.oracle_sample_catmull_rom_2d(100, 64, rho.ctypes.data, radius.ctypes.data, profile.ctypes.data, cdf.ctypes.data, alpha, u)
+        assert b32(got) == int(s2[0], 16) or (np.isnan(got) and np.isnan(f32(s2[0]))), line
+        assert b32(L.oracle_invert_catmull_rom(100, rho.ctypes.data, rho_eff.ctypes.data, x)) == int(inv[0], 16), line
+        assert b32(L.oracle_fresnel_moment1(np.float32(0.5) + np.float32(1.5) * alpha)) == int(fm[0], 16), line
