@@ -11,7 +11,7 @@ import pytest
 
 from conftest import GOLD, golden_names
 from kat_util import jittered_sphere  # noqa: F401
-from test_reference_kats import sphere_scene, watertight_rays
+from test_reference_kats import reintersect_cases, sphere_scene, watertight_rays
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -259,6 +259,26 @@ def test_watertight_and_degenerate(gpu, oracle):
     assert np.array_equal(prim, oprim) and np.array_equal(t, ot)
     assert (t[prim >= 0] == 2).all()  # only the real triangle at z = 2 is ever hit
     gs.close()
+
+
+def test_triangle_reintersect_on_device(gpu, oracle):
+    """Triangle.Reintersect (src/tests/shapes.cpp:154-205) on the HIP traversal kernels: rays spawned from a hit point with the
+    reference's error bounds and OffsetRayOrigin (SpawnRay, and SpawnRayTo with tMax = 1 - ShadowEpsilon) never hit their own triangle
+    again -- 24 triangles with coordinates from 1e-8 to 1e8, 240 rays each, closest-hit and any-hit kernels, and the answers equal the
+    oracle's (tests/test_reference_kats.py::test_triangle_reintersect_through_the_scene is the same check without a GPU)."""
+    n = 0
+    for text, o, d, tmax in reintersect_cases(oracle):
+        scene = gpu.HostScene(text=text)
+        gs = gpu.GpuScene(scene.desc)
+        prim, t, bary = gs.intersect(o, d, tmax)
+        occ = gs.intersect_p(o, d, tmax)
+        gs.close()
+        oprim, ot, obary, _ = oracle.intersect(scene.desc, o, d, tmax)
+        oocc, _ = oracle.intersect_p(scene.desc, o, d, tmax)
+        assert (prim < 0).all() and not np.asarray(occ).any()
+        assert np.array_equal(prim, oprim) and np.array_equal(np.asarray(occ, bool), np.asarray(oocc, bool))
+        n += len(tmax)
+    assert n >= 24 * 240
 
 
 def test_sharded_render_equals_whole(gpu):

@@ -98,6 +98,68 @@ def test_triangle_reintersect(oracle):
     assert checked > 2000
 
 
+def reintersect_cases(oracle, n_tris=24, n_rays=120):
+    """Triangle.Reintersect (src/tests/shapes.cpp:154-205) as scene-level queries: for each random triangle (coordinates from 1e-8 to
+    1e8) a one-triangle scene and the rays the test spawns from a hit point -- SpawnRay in random directions (tMax = inf) and SpawnRayTo
+    random points (tMax = 1 - ShadowEpsilon), origins offset by OffsetRayOrigin.  Yields (scene text, o, d, tmax); no ray may hit."""
+    lib = oracle.lib()
+    made = 0
+    for i in range(200):
+        if made == n_tris:
+            break
+        rng = PCG32(1000 + i)
+        def _pexp(rng):  # shapes.cpp's pExp: +-10^Lerp(u, -8, 8)
+            u = rng.uniform_float()
+            logu = np.float32((1 - u) * -8.0 + u * 8)
+            sign = -1.0 if rng.uniform_float() < 0.5 else 1.0
+            return np.float32(sign * 10.0 ** float(logu))
+        v = np.array([[_pexp(rng) for _ in range(3)] for _ in range(3)], np.float32)
+        if np.sum(np.cross((v[1] - v[0]).astype(np.float64), (v[2] - v[0]).astype(np.float64)) ** 2) < 1e-20:
+            continue
+        u0, u1 = rng.uniform_float(), rng.uniform_float()
+        su0 = np.float32(np.sqrt(np.float32(u0)))
+        b0, b1 = np.float32(1) - su0, np.float32(u1) * su0
+        ptri = (b0 * v[0] + b1 * v[1] + (np.float32(1) - b0 - b1) * v[2]).astype(np.float32)
+        o = np.array([_pexp(rng) for _ in range(3)], np.float32)
+        hit, t, b = tri_hit(oracle, v[0], v[1], v[2], o, (ptri - o).astype(np.float32))
+        if not hit:
+            continue
+        b = np.asarray(b, np.float32)
+        phit = (b[0] * v[0] + b[1] * v[1] + b[2] * v[2]).astype(np.float32)
+        gamma7 = np.float32(7 * 2.0 ** -24) / np.float32(1 - 7 * 2.0 ** -24)
+        perr = (gamma7 * (np.abs(b[0] * v[0]) + np.abs(b[1] * v[1]) + np.abs(b[2] * v[2]))).astype(np.float32)
+        n = np.cross((v[0] - v[2]).astype(np.float64), (v[1] - v[2]).astype(np.float64))
+        n = (n / np.linalg.norm(n)).astype(np.float32)
+        os_, ds, tm = [], [], []
+        out = np.zeros(3, np.float32)
+        for j in range(n_rays):
+            w = uniform_sample_sphere((rng.uniform_float(), rng.uniform_float()))
+            lib.oracle_spawn_ray_origin(phit.ctypes.data, perr.ctypes.data, n.ctypes.data, w.ctypes.data, out.ctypes.data)
+            os_.append(out.copy()); ds.append(w); tm.append(np.inf)
+            p2 = np.array([_pexp(rng) for _ in range(3)], np.float32)
+            dvec = (p2 - phit).astype(np.float32)
+            lib.oracle_spawn_ray_origin(phit.ctypes.data, perr.ctypes.data, n.ctypes.data, dvec.ctypes.data, out.ctypes.data)
+            os_.append(out.copy()); ds.append(dvec); tm.append(np.float32(1 - 0.0001))
+        text = ('Film "image" "integer xresolution" [8] "integer yresolution" [8] "string filename" "r.pfm"\nWorldBegin\n'
+                'Shape "trianglemesh" "integer indices" [ 0 1 2 ] "point P" [ %s ]\nWorldEnd\n' % " ".join("%.9g" % x for x in v.ravel()))
+        made += 1
+        yield text, np.asarray(os_, np.float32), np.asarray(ds, np.float32), np.asarray(tm, np.float32)
+
+
+def test_triangle_reintersect_through_the_scene(pkg, oracle):
+    """The same property through Scene::Intersect / IntersectP over the flattened one-triangle scene (front end, BVH leaf, the oracle's
+    scene-level entry points) -- the form tests/test_gpu_parity.py::test_triangle_reintersect_on_device runs on the HIP kernels."""
+    n = 0
+    for text, o, d, tmax in reintersect_cases(oracle):
+        scene = pkg.HostScene(text=text)
+        assert scene.desc.n_tris == 1
+        prim, _, _, _ = oracle.intersect(scene.desc, o, d, tmax)
+        occ, _ = oracle.intersect_p(scene.desc, o, d, tmax)
+        assert (prim < 0).all() and not occ.any()
+        n += len(tmax)
+    assert n >= 24 * 240
+
+
 def test_radical_inverse_base2_is_bit_reversal(oracle):
     lib = oracle.lib()
     for a in range(1024):
