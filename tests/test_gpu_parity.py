@@ -11,7 +11,7 @@ import pytest
 
 from conftest import GOLD, golden_names
 from kat_util import jittered_sphere  # noqa: F401
-from test_reference_kats import reintersect_cases, sphere_scene, watertight_rays
+from test_reference_kats import quadric_reintersect_run, reintersect_cases, sphere_scene, watertight_rays
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -279,6 +279,15 @@ def test_triangle_reintersect_on_device(gpu, oracle):
         assert np.array_equal(prim, oprim) and np.array_equal(np.asarray(occ, bool), np.asarray(oocc, bool))
         n += len(tmax)
     assert n >= 24 * 240
+
+
+@pytest.mark.parametrize("kind", ["full_sphere", "partial_sphere", "cylinder"])
+def test_quadric_reintersect_on_device(gpu, oracle, kind):
+    """FullSphere / PartialSphere / Cylinder .Reintersect (src/tests/shapes.cpp:372-513) on the HIP kernels: 40 random quadrics each
+    (radius 1e-4 .. 1e4, clipped in z and phi), hit points found with the oracle, 300 rays spawned from each into the normal's
+    hemisphere -- none may hit the shape again, on the closest-hit and the any-hit kernel.  (tests/test_reference_kats.py runs the
+    same rays through the oracle and through its correctly-rounded-libm build, whose arithmetic is the device's.)"""
+    quadric_reintersect_run(gpu, oracle, kind, device=gpu)
 
 
 def test_sharded_render_equals_whole(gpu):

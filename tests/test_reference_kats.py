@@ -287,8 +287,10 @@ def _pexp(rng, e=8.0):
     return np.float32(10.0 ** float(np.float32((1 - u) * -e + u * e)))
 
 
-def _reintersect_convex(pkg, oracle, shape_text, rng, n_out=150):
-    """TestReintersectConvex: no ray leaving a hit point into the normal's hemisphere (SpawnRay / SpawnRayTo) hits the shape again."""
+def _reintersect_convex(pkg, oracle, shape_text, rng, n_out=150, device=None):
+    """TestReintersectConvex: no ray leaving a hit point into the normal's hemisphere (SpawnRay / SpawnRayTo) hits the shape again.
+    The spawned rays are traced by the oracle (also by its correctly-rounded-libm build, whose arithmetic is the device's) and, with
+    `device` = the package on a GPU box, by the HIP kernels."""
     import ctypes as C
     scene = pkg.HostScene(text=QUADRIC_SCENE % shape_text)
     lib = oracle.lib()
@@ -315,14 +317,25 @@ def _reintersect_convex(pkg, oracle, shape_text, rng, n_out=150):
         lib.oracle_spawn_ray_origin(p.ctypes.data, perr.ctypes.data, n.ctypes.data, w.ctypes.data, orig.ctypes.data)
         os_.append(orig.copy()); ds.append(w); tm.append(1 - 0.0001)  # SpawnRayTo: tMax = 1 - ShadowEpsilon
     os_, ds, tm = np.asarray(os_, np.float32), np.asarray(ds, np.float32), np.asarray(tm, np.float32)
-    prim, _, _, _ = oracle.intersect(scene.desc, os_, ds, tm)
-    occ, _ = oracle.intersect_p(scene.desc, os_, ds, tm)
-    assert (prim < 0).all() and not occ.any()
+    for cr in (False, True):
+        prim, _, _, _ = oracle.intersect(scene.desc, os_, ds, tm, cr_libm=cr)
+        occ, _ = oracle.intersect_p(scene.desc, os_, ds, tm, cr_libm=cr)
+        assert (prim < 0).all() and not occ.any()
+    if device is not None:
+        gs = device.GpuScene(scene.desc)
+        dprim, _, _ = gs.intersect(os_, ds, tm)
+        docc = gs.intersect_p(os_, ds, tm)
+        gs.close()
+        assert (dprim < 0).all() and not np.asarray(docc).any()
     return len(os_), (p, n)
 
 
 @pytest.mark.parametrize("kind", ["full_sphere", "partial_sphere", "cylinder"])
 def test_quadric_reintersect(pkg, oracle, kind):
+    quadric_reintersect_run(pkg, oracle, kind)
+
+
+def quadric_reintersect_run(pkg, oracle, kind, device=None):
     checked = 0
     for i in range(40):
         rng = PCG32(i)
@@ -337,7 +350,7 @@ def test_quadric_reintersect(pkg, oracle, kind):
         phimax = 360.0 if (kind == "full_sphere" or rng.uniform_float() < 0.5) else rng.uniform_float() * 360.0
         shape = ('Shape "%s" "float radius" [ %.9g ] "float zmin" [ %.9g ] "float zmax" [ %.9g ] "float phimax" [ %.9g ]'
                  % ("cylinder" if kind == "cylinder" else "sphere", radius, zmin, zmax, phimax))
-        n, hit = _reintersect_convex(pkg, oracle, shape, rng)
+        n, hit = _reintersect_convex(pkg, oracle, shape, rng, device=device)
         checked += n
         if hit and kind == "partial_sphere":  # ParialSphere.Normal: the normal of an untransformed sphere is radial
             p, nrm = hit
