@@ -70,6 +70,10 @@ def lib(cr_libm=False):
         L.oracle_light_sample_pdf.argtypes = [C.POINTER(abi.PgSceneDesc), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_spawn_ray_origin.restype = None
         L.oracle_spawn_ray_origin.argtypes = [C.c_void_p] * 5
+        L.oracle_lobe_f_pdf.restype = None
+        L.oracle_lobe_f_pdf.argtypes = [C.c_void_p] * 4
+        L.oracle_lobe_sample_f.restype = C.c_int
+        L.oracle_lobe_sample_f.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.oracle_find_interval_le.restype = C.c_int
         L.oracle_find_interval_le.argtypes = [C.c_int, C.c_void_p, C.c_float]
         L.oracle_catmull_rom_weights.restype = C.c_int

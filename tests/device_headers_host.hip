@@ -1,0 +1,45 @@
+// TEST INFRASTRUCTURE: the device arithmetic headers of the product (pbrt-v3_amd/csrc/pg_device.h, pg_sphere.h) compiled for the HOST
+// (hipcc --cuda-host-only), so that the very source the HIP kernels execute can be run without a GPU and compared with the oracle
+// -- tests/test_device_headers_on_host.py.  Every PG_DEV function becomes __host__ __device__ (the attribute macro is redefined
+// after the runtime header has been read), and the handful of device-only intrinsics they call get host overloads (clang overloads
+// on the target attribute).  Same flags as the device build: -ffp-contract=off; x86's float divide and sqrt are correctly rounded
+// like the device build's, so a host lane computes the same IEEE results.  Nothing here is linked into the product.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstring>
+__host__ inline unsigned int __float_as_uint(float f) { unsigned int u; memcpy(&u, &f, 4); return u; }
+__host__ inline float __uint_as_float(unsigned int u) { float f; memcpy(&f, &u, 4); return f; }
+__host__ inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+__host__ inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
+__host__ inline bool isinf(float v) { return __builtin_isinf(v); }
+__host__ inline bool isnan(float v) { return __builtin_isnan(v); }
+__host__ inline unsigned long long __brevll(unsigned long long v) { return __builtin_bitreverse64(v); }
+#undef __device__
+#define __device__ __attribute__((device)) __attribute__((host))
+#include "../pbrt-v3_amd/csrc/pg_device.h"
+#include "../pbrt-v3_amd/csrc/pg_sphere.h"
+
+static V3 v3of(const float *p) { return mk(p[0], p[1], p[2]); }
+extern "C" {
+// Triangle::Intersect's arithmetic (tri_ray_setup + tri_test_pre): hit, t, b0, b1, b2
+int hostdev_tri_test(const float *p0, const float *p1, const float *p2, const float *o, const float *d, float tMax, float *out) {
+    float t = 0, b0 = 0, b1 = 0, b2 = 0;
+    const bool hit = tri_test(v3of(p0), v3of(p1), v3of(p2), v3of(o), v3of(d), tMax, t, b0, b1, b2);
+    out[0] = t; out[1] = b0; out[2] = b1; out[3] = b2;
+    return hit ? 1 : 0;
+}
+// Sphere / Cylinder / Disk / Cone / Paraboloid / Hyperboloid ::Intersect up to tHit (the dispatcher the traversal kernel calls)
+int hostdev_quadric_test(const PgSphere *sp, const float *o, const float *d, float tMax, float *tHit) {
+    float t = 0;
+    const bool hit = sphere_test(*sp, v3of(o), v3of(d), tMax, t);
+    *tHit = t;
+    return hit ? 1 : 0;
+}
+void hostdev_offset_ray_origin(const float *p, const float *pError, const float *n, const float *w, float *out) {
+    const V3 r = offset_ray_origin(v3of(p), v3of(pError), v3of(n), v3of(w));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+float hostdev_radical_inverse(unsigned base, unsigned long long a) { return base == 2 ? radical_inverse_base2(a) : radical_inverse(base, a); }
+float hostdev_scrambled_radical_inverse(unsigned base, const uint16_t *perm, unsigned long long a) { return scrambled_radical_inverse(base, perm, a); }
+void hostdev_concentric_sample_disk(float u0, float u1, float *out) { concentric_sample_disk(u0, u1, out[0], out[1]); }
+}
