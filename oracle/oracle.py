@@ -70,6 +70,14 @@ def lib(cr_libm=False):
         L.oracle_light_sample_pdf.argtypes = [C.POINTER(abi.PgSceneDesc), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_spawn_ray_origin.restype = None
         L.oracle_spawn_ray_origin.argtypes = [C.c_void_p] * 5
+        L.oracle_grid_density.restype = C.c_float
+        L.oracle_grid_density.argtypes = [C.c_void_p] * 3
+        L.oracle_grid_tr.restype = C.c_float
+        L.oracle_grid_tr.argtypes = [C.c_void_p] * 4 + [C.c_float, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.oracle_grid_sample.restype = C.c_int
+        L.oracle_grid_sample.argtypes = [C.c_void_p] * 4 + [C.c_float, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)]
+        L.oracle_bssrdf_radial.restype = None
+        L.oracle_bssrdf_radial.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.oracle_lobe_f_pdf.restype = None
         L.oracle_lobe_f_pdf.argtypes = [C.c_void_p] * 4
         L.oracle_lobe_sample_f.restype = C.c_int

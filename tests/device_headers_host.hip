@@ -18,6 +18,8 @@ __host__ inline unsigned long long __brevll(unsigned long long v) { return __bui
 #define __device__ __attribute__((device)) __attribute__((host))
 #include "../pbrt-v3_amd/csrc/pg_device.h"
 #include "../pbrt-v3_amd/csrc/pg_sphere.h"
+#include "../pbrt-v3_amd/csrc/pg_grid.h"
+#include "../pbrt-v3_amd/csrc/pg_bssrdf.h"
 
 static V3 v3of(const float *p) { return mk(p[0], p[1], p[2]); }
 extern "C" {
@@ -42,4 +44,28 @@ void hostdev_offset_ray_origin(const float *p, const float *pError, const float 
 float hostdev_radical_inverse(unsigned base, unsigned long long a) { return base == 2 ? radical_inverse_base2(a) : radical_inverse(base, a); }
 float hostdev_scrambled_radical_inverse(unsigned base, const uint16_t *perm, unsigned long long a) { return scrambled_radical_inverse(base, perm, a); }
 void hostdev_concentric_sample_disk(float u0, float u1, float *out) { concentric_sample_disk(u0, u1, out[0], out[1]); }
+// pg_grid.h on a given stream of draws (0.5 beyond its end); *used = draws consumed
+struct DrawStream { const float *u; int n, used; float operator()() { const float v = used < n ? u[used] : 0.5f; ++used; return v; } };
+float hostdev_grid_density(const PgDensityGrid *g, const float *den, const float *p) { return grid_density(*g, den, v3of(p)); }
+float hostdev_grid_tr(const PgDensityGrid *g, const float *den, const float *o, const float *d, float tMax, const float *draws, int nDraws, int *used) {
+    DrawStream ds{draws, nDraws, 0};
+    const float Tr = grid_tr(*g, den, v3of(o), v3of(d), tMax, ds);
+    *used = ds.used;
+    return Tr;
+}
+int hostdev_grid_sample(const PgDensityGrid *g, const float *den, const float *o, const float *d, float tMax, const float *draws, int nDraws, int *used, float *t) {
+    DrawStream ds{draws, nDraws, 0};
+    float tt = 0;
+    const bool hit = grid_sample(*g, den, v3of(o), v3of(d), tMax, ds, tt);
+    *used = ds.used; *t = hit ? tt : 0.f;
+    return hit ? 1 : 0;
+}
+// pg_bssrdf.h: Sr (3), Pdf_Sr (3), Sample_Sr (3) -- and the spline routines alone
+void hostdev_bssrdf_radial(const PgBSSRDF *d, const float *tables, float r, float u, float *out) {
+    const DBssrdf b = bssrdf_bind(*d, tables);
+    const Spec sr = bssrdf_sr(b, r);
+    out[0] = sr.r; out[1] = sr.g; out[2] = sr.b;
+    for (int c = 0; c < 3; ++c) { out[3 + c] = bssrdf_pdf_sr(b, c, r); out[6 + c] = bssrdf_sample_sr(b, c, u); }
+}
+float hostdev_fresnel_moment1(float eta) { return fresnel_moment1(eta); }
 }
