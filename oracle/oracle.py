@@ -76,6 +76,10 @@ def lib(cr_libm=False):
         L.oracle_grid_tr.argtypes = [C.c_void_p] * 4 + [C.c_float, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.oracle_grid_sample.restype = C.c_int
         L.oracle_grid_sample.argtypes = [C.c_void_p] * 4 + [C.c_float, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)]
+        L.oracle_bssrdf_pdf_sp.restype = C.c_float
+        L.oracle_bssrdf_pdf_sp.argtypes = [C.c_void_p] * 6
+        L.oracle_bssrdf_probe_segment.restype = C.c_int
+        L.oracle_bssrdf_probe_segment.argtypes = [C.c_void_p] * 4 + [C.c_float] * 3 + [C.c_void_p]
         L.oracle_bssrdf_radial.restype = None
         L.oracle_bssrdf_radial.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.oracle_lobe_f_pdf.restype = None

@@ -167,4 +167,69 @@ PG_DEV float bssrdf_pdf_sr(const DBssrdf &b, int ch, float r) {
     if (rOptical != 0) sr /= 2 * PG_PI * rOptical;
     return pmax(0.f, sr * b.sigma_t[ch] * b.sigma_t[ch] / rhoEff);
 }
+// InvertCatmullRom, interpolation.cpp:255-315 (SubsurfaceFromDiffuse of a textured kdsubsurface material, per hit)
+PG_DEV float invert_catmull_rom(int n, const float *x, const float *values, float u) {
+    if (!(u > values[0])) return x[0];
+    if (!(u < values[n - 1])) return x[n - 1];
+    const int i = find_interval_le(n, values, u);
+    const float x0 = x[i], x1 = x[i + 1], f0 = values[i], f1 = values[i + 1];
+    const float width = x1 - x0;
+    const float d0 = i > 0 ? width * (f1 - values[i - 1]) / (x1 - x[i - 1]) : f1 - f0;
+    const float d1 = i + 2 < n ? width * (values[i + 2] - f0) / (x[i + 2] - x0) : f1 - f0;
+    float a = 0, b = 1, t = .5f;
+    for (;;) {
+        if (!(t > a && t < b)) t = 0.5f * (a + b);
+        const float t2 = t * t, t3 = t2 * t;
+        const float Fhat = (2 * t3 - 3 * t2 + 1) * f0 + (-2 * t3 + 3 * t2) * f1 + (t3 - 2 * t2 + t) * d0 + (t3 - t2) * d1;
+        const float fhat = (6 * t2 - 6 * t) * f0 + (-6 * t2 + 6 * t) * f1 + (3 * t2 - 4 * t + 1) * d0 + (3 * t2 - 2 * t) * d1;
+        if (fabsf(Fhat - u) < 1e-6f || b - a < 1e-6f) break;
+        if (Fhat - u < 0) a = t;
+        else b = t;
+        t -= (Fhat - u) / fhat;
+    }
+    return x0 + t * width;
+}
+// SeparableBSSRDF::Pdf_Sp, bssrdf.cpp:330-350: the density of an exit point pi (geometric normal n) under the three projection axes
+// and three channels Sample_Sp chooses from; (ss, ts, ns) = the entry point's shading frame
+PG_DEV float bssrdf_pdf_sp(const DBssrdf &b, V3 ss, V3 ts, V3 ns, V3 poP, V3 piP, V3 piN) {
+    const V3 d = poP - piP;
+    const float dLocal[3] = {dot(ss, d), dot(ts, d), dot(ns, d)};
+    const float nLocal[3] = {dot(ss, piN), dot(ts, piN), dot(ns, piN)};
+    const float rProj[3] = {sqrtf(dLocal[1] * dLocal[1] + dLocal[2] * dLocal[2]), sqrtf(dLocal[2] * dLocal[2] + dLocal[0] * dLocal[0]),
+                            sqrtf(dLocal[0] * dLocal[0] + dLocal[1] * dLocal[1])};
+    const float axisProb[3] = {.25f, .25f, .5f};
+    const float chProb = 1 / (float)3;
+    float pdf = 0;
+    for (int axis = 0; axis < 3; ++axis)
+        for (int ch = 0; ch < 3; ++ch) pdf += bssrdf_pdf_sr(b, ch, rProj[axis]) * fabsf(nLocal[axis]) * chProb * axisProb[axis];
+    return pdf;
+}
+// The first half of SeparableBSSRDF::Sample_Sp, bssrdf.cpp:257-292: projection axis, channel, radius, angle -> the probe segment
+// [baseP, pTarget] through the sphere of radius rMax around po.  u1 comes back remapped for the choice among the hits
+// (selected = Clamp((int)(u1 * nFound), 0, nFound - 1), :321).  cos / sin in double, rounded once (DESIGN.md "libm").
+PG_DEV bool bssrdf_probe_segment(const DBssrdf &b, V3 ss, V3 ts, V3 ns, V3 poP, float &u1, float u2x, float u2y, V3 &baseP, V3 &pTarget) {
+    V3 vx, vy, vz;
+    if (u1 < .5f) { vx = ss; vy = ts; vz = ns; u1 *= 2; }
+    else if (u1 < .75f) { vx = ts; vy = ns; vz = ss; u1 = (u1 - .5f) * 4; }
+    else { vx = ns; vy = ss; vz = ts; u1 = (u1 - .75f) * 4; }
+    int ch = (int)(u1 * 3);
+    ch = ch < 0 ? 0 : (ch > 2 ? 2 : ch);
+    u1 = u1 * 3 - ch;
+    const float r = bssrdf_sample_sr(b, ch, u2x);
+    if (r < 0) return false;
+    const float phi = 2 * PG_PI * u2y;
+    const float rMax = bssrdf_sample_sr(b, ch, 0.999f);
+    if (r >= rMax) return false;
+    const float l = 2 * sqrtf(rMax * rMax - r * r);
+    const float c = (float)cos((double)phi), sn = (float)sin((double)phi);
+    baseP = (poP + (vx * c + vy * sn) * r) - (vz * l) * 0.5f;
+    pTarget = baseP + vz * l;
+    return true;
+}
+// SeparableBSSRDFAdapter::f (bssrdf.h:214-219) = Sw(wi) * eta^2 under TransportMode::Radiance; Sw: bssrdf.h:97-100.  cosThetaI = wi.z
+// in the exit point's shading frame.  (The adapter samples and weighs like a Lambertian lobe: BxDF::Sample_f / Pdf.)
+PG_DEV float bssrdf_adapter_f(float eta, float cosThetaI, float frDielectric) {
+    const float c = 1 - 2 * fresnel_moment1(1 / eta);
+    return ((1 - frDielectric) / (c * PG_PI)) * (eta * eta);
+}
 #endif

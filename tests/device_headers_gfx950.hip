@@ -13,5 +13,10 @@ __global__ void k_instantiate(const PgDensityGrid *g, const float *den, const Pg
     const bool hit = grid_sample(*g, den, o, d, PG_INF, draw, t);
     const DBssrdf b = bssrdf_bind(*bs, tables);
     const Spec sr = bssrdf_sr(b, t);
-    out[i] = Tr + (hit ? t : 0.f) + sr.r + bssrdf_pdf_sr(b, 1, t) + bssrdf_sample_sr(b, 2, draw()) + fresnel_moment1(1 / b.eta) + grid_density(*g, den, o);
+    V3 base, target;
+    float u1 = draw();
+    const bool probe = bssrdf_probe_segment(b, mk(1, 0, 0), mk(0, 1, 0), mk(0, 0, 1), o, u1, draw(), draw(), base, target);
+    out[i] = Tr + (hit ? t : 0.f) + sr.r + bssrdf_pdf_sr(b, 1, t) + bssrdf_sample_sr(b, 2, draw()) + fresnel_moment1(1 / b.eta) + grid_density(*g, den, o) +
+             bssrdf_pdf_sp(b, mk(1, 0, 0), mk(0, 1, 0), mk(0, 0, 1), o, o + d, d) + (probe ? base.x + target.y + u1 : 0.f) +
+             invert_catmull_rom(b.nRho, b.rhoSamples, b.rhoEff, draw()) + bssrdf_adapter_f(b.eta, d.z, 0.04f);
 }

@@ -68,4 +68,15 @@ void hostdev_bssrdf_radial(const PgBSSRDF *d, const float *tables, float r, floa
     for (int c = 0; c < 3; ++c) { out[3 + c] = bssrdf_pdf_sr(b, c, r); out[6 + c] = bssrdf_sample_sr(b, c, u); }
 }
 float hostdev_fresnel_moment1(float eta) { return fresnel_moment1(eta); }
+float hostdev_invert_catmull_rom(int n, const float *x, const float *values, float u) { return invert_catmull_rom(n, x, values, u); }
+// frame = ss, ts, ns
+float hostdev_bssrdf_pdf_sp(const PgBSSRDF *d, const float *tables, const float *frame, const float *po, const float *pi, const float *n) {
+    return bssrdf_pdf_sp(bssrdf_bind(*d, tables), v3of(frame), v3of(frame + 3), v3of(frame + 6), v3of(po), v3of(pi), v3of(n));
+}
+int hostdev_bssrdf_probe_segment(const PgBSSRDF *d, const float *tables, const float *frame, const float *po, float u1, float u2x, float u2y, float *out) {
+    V3 base = mk(0, 0, 0), target = mk(0, 0, 0);
+    const bool ok = bssrdf_probe_segment(bssrdf_bind(*d, tables), v3of(frame), v3of(frame + 3), v3of(frame + 6), v3of(po), u1, u2x, u2y, base, target);
+    out[0] = u1; out[1] = base.x; out[2] = base.y; out[3] = base.z; out[4] = target.x; out[5] = target.y; out[6] = target.z;
+    return ok ? 1 : 0;
+}
 }

@@ -22,6 +22,7 @@ __host__ inline unsigned long long __brevll(unsigned long long v) { return __bui
 #undef hipLaunchKernelGGL
 #define hipLaunchKernelGGL(...) ((void)0)  // the launch wrappers of the translation unit compile to nothing
 #include "../pbrt-v3_amd/csrc/pg_kernels.hip"
+#include "../pbrt-v3_amd/csrc/pg_bssrdf.h"
 
 extern "C" {
 // lobe_f + lobe_pdf of one BxDF in the local frame: f rgb, pdf
@@ -39,4 +40,6 @@ int hostdev_lobe_sample_f(const PgBxDF *b, const float *wo, float u0, float u1, 
     out[0] = f.r; out[1] = f.g; out[2] = f.b; out[3] = pdf; out[4] = wi.x; out[5] = wi.y; out[6] = wi.z;
     return sampledType;
 }
+// SeparableBSSRDFAdapter::f with the shading kernels' own FrDielectric
+float hostdev_bssrdf_adapter_f(float eta, float cosThetaI) { return bssrdf_adapter_f(eta, cosThetaI, fr_dielectric(cosThetaI, 1.f, eta)); }
 }

@@ -44,6 +44,12 @@ def dev(tmp_path_factory):
     lib.hostdev_bssrdf_radial.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
     lib.hostdev_fresnel_moment1.restype = C.c_float
     lib.hostdev_fresnel_moment1.argtypes = [C.c_float]
+    lib.hostdev_invert_catmull_rom.restype = C.c_float
+    lib.hostdev_invert_catmull_rom.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_float]
+    lib.hostdev_bssrdf_pdf_sp.restype = C.c_float
+    lib.hostdev_bssrdf_pdf_sp.argtypes = [C.c_void_p] * 6
+    lib.hostdev_bssrdf_probe_segment.restype = C.c_int
+    lib.hostdev_bssrdf_probe_segment.argtypes = [C.c_void_p] * 4 + [C.c_float] * 3 + [C.c_void_p]
     return lib
 
 
@@ -178,6 +184,8 @@ def devk(tmp_path_factory):
     lib.hostdev_lobe_f_pdf.argtypes = [C.c_void_p] * 4
     lib.hostdev_lobe_sample_f.restype = C.c_int
     lib.hostdev_lobe_sample_f.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+    lib.hostdev_bssrdf_adapter_f.restype = C.c_float
+    lib.hostdev_bssrdf_adapter_f.argtypes = [C.c_float, C.c_float]
     return lib
 
 
@@ -305,3 +313,56 @@ def test_bssrdf_radial_device_functions_equal_the_oracle(dev, pkg, oracle, mater
         assert same.all(), (trial, r, u, a, c)
     for eta in (0.5, 0.75, 0.999, 1.0, 1.33, 2.5):
         assert bits([L.oracle_fresnel_moment1(np.float32(eta))])[0] == bits([dev.hostdev_fresnel_moment1(np.float32(eta))])[0]
+
+
+def test_bssrdf_spatial_device_functions_equal_the_correctly_rounded_oracle(dev, pkg, oracle):
+    """bssrdf_pdf_sp (SeparableBSSRDF::Pdf_Sp), bssrdf_probe_segment (the first half of Sample_Sp: axis, channel, radius, angle -> probe
+    segment, u1 remapped) and invert_catmull_rom of pg_bssrdf.h against the oracle's correctly-rounded-libm build (cos / sin of the angle),
+    around random shading frames, bit for bit."""
+    text = open(os.path.join(ROOT, "tests", "golden_sss", "sss_subsurface.pbrt")).read()
+    scene = pkg.HostScene(text=text)
+    d = scene.desc
+    b = d.bssrdfs[0]
+    L = oracle.lib(cr_libm=True)
+    rng = np.random.default_rng(21)
+    n_ok = 0
+    for trial in range(1500):
+        ns = unit(rng)
+        ss = np.cross(ns, unit(rng)).astype(np.float32); ss = (ss / np.linalg.norm(ss)).astype(np.float32)
+        ts = np.cross(ns.astype(np.float64), ss.astype(np.float64)).astype(np.float32)
+        frame = np.concatenate([ss, ts, ns]).astype(np.float32)
+        po = (rng.normal(size=3) * 100).astype(np.float32)
+        pi = (po + rng.normal(size=3) * 10.0 ** rng.uniform(-2, 2.5)).astype(np.float32)
+        n = unit(rng)
+        a = L.oracle_bssrdf_pdf_sp(C.addressof(b), d.bssrdf_tables, frame.ctypes.data, po.ctypes.data, pi.ctypes.data, n.ctypes.data)
+        c = dev.hostdev_bssrdf_pdf_sp(C.addressof(b), d.bssrdf_tables, frame.ctypes.data, po.ctypes.data, pi.ctypes.data, n.ctypes.data)
+        assert bits([a])[0] == bits([c])[0], trial
+        u1, u2x, u2y = (np.float32(rng.random()) for _ in range(3))
+        oa, oc = np.zeros(7, np.float32), np.zeros(7, np.float32)
+        ka = L.oracle_bssrdf_probe_segment(C.addressof(b), d.bssrdf_tables, frame.ctypes.data, po.ctypes.data, u1, u2x, u2y, oa.ctypes.data)
+        kc = dev.hostdev_bssrdf_probe_segment(C.addressof(b), d.bssrdf_tables, frame.ctypes.data, po.ctypes.data, u1, u2x, u2y, oc.ctypes.data)
+        assert ka == kc and bits(oa[:1])[0] == bits(oc[:1])[0] and (not ka or np.array_equal(bits(oa), bits(oc))), trial
+        n_ok += ka
+    assert n_ok > 1000
+    n = b.n_rho + b.n_radius + 2 * b.n_rho * b.n_radius + b.n_rho
+    table = np.ctypeslib.as_array(d.bssrdf_tables, shape=(d.n_bssrdf_floats,))[b.table:b.table + n].copy()
+    rho, rho_eff = table[:100].copy(), table[6564:6664].copy()
+    for x in list(rng.random(500).astype(np.float32)) + [np.float32(0), np.float32(1), np.float32(2), rho_eff[40]]:
+        want = L.oracle_invert_catmull_rom(100, rho.ctypes.data, rho_eff.ctypes.data, x)
+        assert bits([want])[0] == bits([dev.hostdev_invert_catmull_rom(100, rho.ctypes.data, rho_eff.ctypes.data, x)])[0]
+
+
+def test_bssrdf_adapter_f_equals_oracle(devk, pkg, oracle):
+    """SeparableBSSRDFAdapter::f = Sw(wi) * eta^2 with the shading kernels' own FrDielectric against the oracle's adapter lobe."""
+    L = oracle.lib(cr_libm=True)
+    rng = np.random.default_rng(31)
+    for trial in range(2000):
+        eta = np.float32(1.05 + 1.2 * rng.random())
+        wi = unit(rng)
+        lobe = pkg.abi.PgBxDF()
+        lobe.type = 100  # ORACLE_BXDF_BSSRDF_ADAPTER (oracle/pbrt_oracle.c): eta in eta_b
+        lobe.eta_b = float(eta)
+        out = np.zeros(4, np.float32)
+        wo = np.array([0, 0, 1], np.float32)
+        L.oracle_lobe_f_pdf(C.addressof(lobe), wo.ctypes.data, wi.ctypes.data, out.ctypes.data)
+        assert bits(out[:1])[0] == bits([devk.hostdev_bssrdf_adapter_f(eta, wi[2])])[0], (trial, eta, wi)
