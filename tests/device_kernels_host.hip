@@ -40,6 +40,15 @@ int hostdev_lobe_sample_f(const PgBxDF *b, const float *wo, float u0, float u1, 
     out[0] = f.r; out[1] = f.g; out[2] = f.b; out[3] = pdf; out[4] = wi.x; out[5] = wi.y; out[6] = wi.z;
     return sampledType;
 }
+// HenyeyGreenstein (core/medium.h:69-72, medium.cpp:194-213) and the Halton sample index of a pixel (samplers/halton.cpp:92-116)
+float hostdev_phase_hg(float cosTheta, float g) { return phase_hg(cosTheta, g); }
+float hostdev_hg_sample_p(float g, const float *wo, float u0, float u1, float *wi) {
+    V3 w = mk(0, 0, 0);
+    const float p = hg_sample_p(g, mk(wo[0], wo[1], wo[2]), w, u0, u1);
+    wi[0] = w.x; wi[1] = w.y; wi[2] = w.z;
+    return p;
+}
+long long hostdev_halton_index(const PgRenderDesc *rd, int px, int py, long long sampleNum) { return (long long)halton_index(*rd, px, py, (uint64_t)sampleNum); }
 // SeparableBSSRDFAdapter::f with the shading kernels' own FrDielectric
 float hostdev_bssrdf_adapter_f(float eta, float cosThetaI) { return bssrdf_adapter_f(eta, cosThetaI, fr_dielectric(cosThetaI, 1.f, eta)); }
 }

@@ -186,6 +186,12 @@ def devk(tmp_path_factory):
     lib.hostdev_lobe_sample_f.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
     lib.hostdev_bssrdf_adapter_f.restype = C.c_float
     lib.hostdev_bssrdf_adapter_f.argtypes = [C.c_float, C.c_float]
+    lib.hostdev_phase_hg.restype = C.c_float
+    lib.hostdev_phase_hg.argtypes = [C.c_float, C.c_float]
+    lib.hostdev_hg_sample_p.restype = C.c_float
+    lib.hostdev_hg_sample_p.argtypes = [C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+    lib.hostdev_halton_index.restype = C.c_longlong
+    lib.hostdev_halton_index.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_longlong]
     return lib
 
 
@@ -366,3 +372,32 @@ def test_bssrdf_adapter_f_equals_oracle(devk, pkg, oracle):
         wo = np.array([0, 0, 1], np.float32)
         L.oracle_lobe_f_pdf(C.addressof(lobe), wo.ctypes.data, wi.ctypes.data, out.ctypes.data)
         assert bits(out[:1])[0] == bits([devk.hostdev_bssrdf_adapter_f(eta, wi[2])])[0], (trial, eta, wi)
+
+
+def test_henyey_greenstein_equals_the_correctly_rounded_oracle(devk, oracle):
+    """phase_hg / hg_sample_p of the volpath kernels (HenyeyGreenstein::p / Sample_p) against the oracle, isotropic and both signs of g."""
+    L = oracle.lib(cr_libm=True)
+    rng = np.random.default_rng(41)
+    for trial in range(3000):
+        g = np.float32([0.0, 5e-4, -0.9, 0.9][trial % 4] if trial % 5 == 0 else rng.uniform(-0.95, 0.95))
+        wo = unit(rng)
+        u = rng.random(2).astype(np.float32)
+        a, c = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        pa = L.oracle_hg_sample_p(g, wo.ctypes.data, u.ctypes.data, a.ctypes.data)
+        pc = devk.hostdev_hg_sample_p(g, wo.ctypes.data, u[0], u[1], c.ctypes.data)
+        assert bits([pa])[0] == bits([pc])[0] and np.array_equal(bits(a), bits(c)), (trial, g)
+        ct = np.float32(rng.uniform(-1, 1))
+        assert bits([L.oracle_phase_hg(ct, g)])[0] == bits([devk.hostdev_phase_hg(ct, g)])[0]
+
+
+def test_halton_pixel_index_equals_oracle(devk, pkg, oracle):
+    """HaltonSampler::GetIndexForSample (samplers/halton.cpp:92-116, the multiplicative inverses and the pixel's offset) of the kernels."""
+    L = oracle.lib()
+    rng = np.random.default_rng(51)
+    for golden in ("cornell_32", "cornell_crop", "synthetic_n40"):
+        scene = pkg.HostScene(os.path.join(ROOT, "tests", "golden", golden + ".pbrt"))
+        rd = scene.render_desc()
+        w, h = scene.film_size
+        for _ in range(400):
+            px, py, k = int(rng.integers(0, max(1, w))), int(rng.integers(0, max(1, h))), int(rng.integers(0, 1 << 20))
+            assert L.oracle_halton_index(C.byref(rd), px, py, k) == devk.hostdev_halton_index(C.byref(rd), px, py, k), (golden, px, py, k)
