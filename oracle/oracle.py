@@ -70,6 +70,8 @@ def lib(cr_libm=False):
         L.oracle_light_sample_pdf.argtypes = [C.POINTER(abi.PgSceneDesc), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_spawn_ray_origin.restype = None
         L.oracle_spawn_ray_origin.argtypes = [C.c_void_p] * 5
+        L.oracle_generate_ray.restype = None
+        L.oracle_generate_ray.argtypes = [C.c_void_p] + [C.c_float] * 4 + [C.c_void_p]
         L.oracle_grid_density.restype = C.c_float
         L.oracle_grid_density.argtypes = [C.c_void_p] * 3
         L.oracle_grid_tr.restype = C.c_float

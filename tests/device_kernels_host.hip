@@ -49,6 +49,13 @@ float hostdev_hg_sample_p(float g, const float *wo, float u0, float u1, float *w
     return p;
 }
 long long hostdev_halton_index(const PgRenderDesc *rd, int px, int py, long long sampleNum) { return (long long)halton_index(*rd, px, py, (uint64_t)sampleNum); }
+// Camera::GenerateRay as k_generate computes it: o, d, tMax
+void hostdev_camera_ray(const PgRenderDesc *rd, float fx, float fy, float lx, float ly, float *out) {
+    V3 o, d;
+    float tMax;
+    camera_ray(*rd, fx, fy, lx, ly, o, d, tMax);
+    out[0] = o.x; out[1] = o.y; out[2] = o.z; out[3] = d.x; out[4] = d.y; out[5] = d.z; out[6] = tMax;
+}
 // SeparableBSSRDFAdapter::f with the shading kernels' own FrDielectric
 float hostdev_bssrdf_adapter_f(float eta, float cosThetaI) { return bssrdf_adapter_f(eta, cosThetaI, fr_dielectric(cosThetaI, 1.f, eta)); }
 }

@@ -192,6 +192,8 @@ def devk(tmp_path_factory):
     lib.hostdev_hg_sample_p.argtypes = [C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
     lib.hostdev_halton_index.restype = C.c_longlong
     lib.hostdev_halton_index.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_longlong]
+    lib.hostdev_camera_ray.restype = None
+    lib.hostdev_camera_ray.argtypes = [C.c_void_p] + [C.c_float] * 4 + [C.c_void_p]
     return lib
 
 
@@ -401,3 +403,24 @@ def test_halton_pixel_index_equals_oracle(devk, pkg, oracle):
         for _ in range(400):
             px, py, k = int(rng.integers(0, max(1, w))), int(rng.integers(0, max(1, h))), int(rng.integers(0, 1 << 20))
             assert L.oracle_halton_index(C.byref(rd), px, py, k) == devk.hostdev_halton_index(C.byref(rd), px, py, k), (golden, px, py, k)
+
+
+@pytest.mark.parametrize("golden", ["cornell_32", "cornell_lens", "cornell_ortho", "cornell_ortho_lens", "cornell_envcam", "cornell_crop"])
+def test_camera_rays_equal_the_correctly_rounded_oracle(devk, pkg, oracle, golden):
+    """camera_ray of k_generate (PerspectiveCamera / OrthographicCamera / EnvironmentCamera ::GenerateRay, thin lens included) against
+    the oracle: origin, direction and tMax of 2 000 film / lens samples per camera, bit for bit."""
+    path = os.path.join(ROOT, "tests", "golden", golden + ".pbrt")
+    if not os.path.exists(path):
+        pytest.skip(golden + " is not among the goldens")
+    scene = pkg.HostScene(path)
+    rd = scene.render_desc()
+    L = oracle.lib(cr_libm=True)
+    rng = np.random.default_rng(61)
+    fw, fh = rd.full_res[0], rd.full_res[1]
+    for _ in range(2000):
+        fx, fy = np.float32(rng.random() * fw), np.float32(rng.random() * fh)
+        lx, ly = np.float32(rng.random()), np.float32(rng.random())
+        a, c = np.zeros(7, np.float32), np.zeros(7, np.float32)
+        L.oracle_generate_ray(C.byref(rd), fx, fy, lx, ly, a.ctypes.data)
+        devk.hostdev_camera_ray(C.byref(rd), fx, fy, lx, ly, c.ctypes.data)
+        assert np.array_equal(bits(a), bits(c)), (golden, fx, fy, lx, ly, a, c)
