@@ -114,7 +114,8 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     if (!desc || !out) return setError(PG_ERR_INVALID, "pg_scene_create: null argument");
     *out = nullptr;
     if (desc->abi_version != PG_ABI_VERSION) return setError(PG_ERR_INVALID, "ABI version %d, expected %d", desc->abi_version, PG_ABI_VERSION);
-    if (desc->n_tris < 0 || desc->n_nodes < 0 || (desc->n_tris > 0 && (!desc->nodes || !desc->indices || !desc->P)))
+    // (P may be absent when no primitive is a triangle -- a scene of quadrics only: every triangle's indices are checked against n_verts below)
+    if (desc->n_tris < 0 || desc->n_nodes < 0 || desc->n_verts < 0 || (desc->n_tris > 0 && (!desc->nodes || !desc->indices || (desc->n_verts > 0 && !desc->P))))
         return setError(PG_ERR_INVALID, "pg_scene_create: malformed geometry arrays");
     if (desc->n_grids != 0 || desc->media_grid)  // ABI 23 carries the tables; the two-phase shading they need is not built
         return setError(PG_ERR_UNSUPPORTED, "GridDensityMedium (\"heterogeneous\" medium) has no device kernels in this build");

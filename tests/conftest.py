@@ -41,6 +41,9 @@ def golden_names():
 
 @pytest.fixture(scope="session")
 def gpu(pkg):
+    if os.environ.get("PBRT_EMULATED_DEVICE") == "1":  # tests/test_emulated_device.py: PBRT_GPU_LIB points at the device sources compiled
+        pkg.gpu_lib()                                  # for the host under tests/emu/hip_emu.h -- the same tests, no GPU
+        return pkg
     import torch
     if not torch.cuda.is_available():
         pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")

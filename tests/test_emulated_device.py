@@ -1,0 +1,57 @@
+"""The `-m gpu` tests without a GPU: the product's device translation units compiled for the host under the SIMT emulator of tests/emu
+(kernels, queues, wave-level code and host orchestration included; tests/emu/README.md), loaded through PBRT_GPU_LIB, and the GPU test
+files run unchanged in a child pytest.  A subset runs in the normal CPU suite; PBRT_EMULATE_ALL=1 runs everything that is feasible
+under emulation (about a quarter of an hour)."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+# not under emulation: torch device buffers, the hipCUB-based device BVH build, the CLI (spawns the native binary), the tile-serial
+# samplers (hundreds of thousands of tiny launches: minutes each), full-size runs
+SKIP = "not device_buffers and not cli and not sampler_ and not 02sequence"
+
+
+@pytest.fixture(scope="module")
+def emulated(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = str(tmp_path_factory.mktemp("emulated"))
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tests", "emu", "build_emulated.py"), out], stdout=subprocess.DEVNULL)
+    return os.path.join(out, "libpbrt_gpu_emulated.so")
+
+
+def run_gpu_tests(lib, files, select, timeout):
+    env = dict(os.environ, PBRT_GPU_LIB=lib, PBRT_EMULATED_DEVICE="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", *files, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", select], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=timeout)
+    tail = p.stdout[-3000:] + p.stderr[-1500:]
+    assert p.returncode == 0, tail
+    return tail
+
+
+def test_ray_queries_on_the_emulated_device(emulated):
+    """Closest-hit and any-hit kernels: Triangle / quadric .Reintersect at extreme magnitudes, Watertight + degenerate triangles, rays
+    through instanced objects -- hits, t, barycentrics and the reference's node / triangle counters equal the oracle's."""
+    out = run_gpu_tests(emulated, ["tests/test_gpu_parity.py"], "reintersect_on_device or watertight or instance_rays", 900)
+    assert " passed" in out and "failed" not in out
+
+
+def test_renders_on_the_emulated_device(emulated):
+    """Whole renders through generate / trace / shade / resolve / film: films bit-identical to the correctly-rounded oracle (path and
+    volpath, textures, spheres, instances, a general-filter film) and within tolerance of the reference's goldens."""
+    select = ("(test_film_bit_identical_to_correctly_rounded_oracle or test_golden_images) and "
+              "(cornell_32 or cornell_crop or vol_fog or tex_checker or sphere_light or instance_boxes or filter_gaussian or cornell_mirror_glass or cornell_point)")
+    out = run_gpu_tests(emulated, ["tests/test_gpu_parity.py"], select, 1200)
+    assert " passed" in out and "failed" not in out
+
+
+@pytest.mark.skipif(os.environ.get("PBRT_EMULATE_ALL") != "1", reason="set PBRT_EMULATE_ALL=1 for the whole feasible GPU suite under emulation (~15 min)")
+def test_everything_feasible_on_the_emulated_device(emulated):
+    out = run_gpu_tests(emulated, ["tests/test_gpu_parity.py", "tests/test_gpu_fuzz.py"], SKIP, 7200)
+    assert " passed" in out
