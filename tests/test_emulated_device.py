@@ -55,3 +55,12 @@ def test_renders_on_the_emulated_device(emulated):
 def test_everything_feasible_on_the_emulated_device(emulated):
     out = run_gpu_tests(emulated, ["tests/test_gpu_parity.py", "tests/test_gpu_fuzz.py"], SKIP, 7200)
     assert " passed" in out
+
+
+def test_reference_side_binding_on_the_emulated_device(emulated):
+    """The drop-in end to end without a GPU: the unmodified reference (parser, scene construction, BVHAccel, Film) with the compiled binding
+    of INTEGRATION.md section 2 (oracle/_ref/pbrt_gpubind) driving the device kernels under emulation -- tests/test_gpu_binding.py unchanged."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "pbrt_gpubind")):
+        pytest.skip("oracle/_ref/pbrt_gpubind is built only where /root/reference exists")
+    out = run_gpu_tests(emulated, ["tests/test_gpu_binding.py"], "cornell_32 or vol_fog", 900)
+    assert " passed" in out and "failed" not in out
