@@ -2,6 +2,7 @@
 // thread, switched only at rendezvous points (wave-level operations, __syncthreads) and at a lane's end.  TEST INFRASTRUCTURE.
 #include <ucontext.h>
 #include <cstdio>
+#include <mutex>
 #include <vector>
 #include "hip_emu.h"
 #undef threadIdx
@@ -84,6 +85,10 @@ void block_barrier() {
 }
 
 void launch(const char *name, dim3 grid, dim3 block, size_t dynShared, const std::function<void()> &body) {
+    // one launch at a time: the host code renders on several "devices" from one thread each (pg_render_sharded), the scheduler's state and
+    // the kernels' statics (__shared__) are per process
+    static std::mutex oneLaunch;
+    std::lock_guard<std::mutex> lock(oneLaunch);
     static const bool trace = getenv("HIP_EMU_TRACE") != nullptr;
     if (trace) fprintf(stderr, "hip_emu: %s <<<%u, %u, %zu>>>\n", name, grid.x, block.x, dynShared);
     g_kernel = name;

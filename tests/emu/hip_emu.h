@@ -144,9 +144,12 @@ inline hipError_t Ok() { return hipSuccess; }
 inline hipError_t StreamCreate(hipStream_t *s, unsigned = 0) { *s = (hipStream_t)(uintptr_t)8; return hipSuccess; }  // (never dereferenced)
 inline hipError_t EventCreate(hipEvent_t *e, unsigned = 0) { *e = (hipEvent_t)(uintptr_t)8; return hipSuccess; }
 inline hipError_t EventElapsed(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
-inline hipError_t DeviceCount(int *n) { *n = 1; return hipSuccess; }
-inline hipError_t GetDevice(int *d) { *d = 0; return hipSuccess; }
-inline hipError_t SetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidDevice; }
+// HIP_EMU_DEVICES=N pretends to N devices (all of them this host): the multi-device code paths run, one host thread per "device"
+inline int device_count() { const char *e = getenv("HIP_EMU_DEVICES"); const int n = e ? atoi(e) : 1; return n < 1 ? 1 : n; }
+inline int &current_device() { static thread_local int d = 0; return d; }
+inline hipError_t DeviceCount(int *n) { *n = device_count(); return hipSuccess; }
+inline hipError_t GetDevice(int *d) { *d = current_device(); return hipSuccess; }
+inline hipError_t SetDevice(int d) { if (d < 0 || d >= device_count()) return hipErrorInvalidDevice; current_device() = d; return hipSuccess; }
 inline hipError_t CanAccessPeer(int *can, int, int) { *can = 1; return hipSuccess; }
 }  // namespace emu
 #define hipMalloc emu::Malloc
