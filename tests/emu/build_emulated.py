@@ -65,7 +65,7 @@ def main():
     flags = ["--cuda-host-only", "-O1", "-ffp-contract=off", "-fPIC", "-w"]
     procs = [subprocess.Popen([HIPCC, *flags, "-I" + CS, "-I" + EM, "-include", os.path.join(EM, "hip_emu.h"), "-c", os.path.join(out, f + ".hip"), "-o", os.path.join(out, f + ".o")])
              for f in ("pg_traverse", "pg_kernels", "pg_abi")]
-    procs.append(subprocess.Popen([HIPCC, *flags, "-I" + EM, "-c", os.path.join(EM, "hip_emu.cpp"), "-o", os.path.join(out, "hip_emu.o")]))
+    procs.append(subprocess.Popen([HIPCC, *flags, "-U_FORTIFY_SOURCE", "-D_FORTIFY_SOURCE=0", "-I" + EM, "-c", os.path.join(EM, "hip_emu.cpp"), "-o", os.path.join(out, "hip_emu.o")]))
     procs.append(subprocess.Popen(["g++", "-O1", "-fPIC", "-c", os.path.join(out, "hlbvh_stub.cpp"), "-o", os.path.join(out, "hlbvh_stub.o")]))
     if any(p.wait() for p in procs):
         sys.exit("build_emulated: compilation failed")

@@ -1,5 +1,6 @@
 // hip_emu.cpp -- the scheduler of tests/emu/hip_emu.h: blocks run one after the other, the lanes of a block are ucontext fibers on one OS
 // thread, switched only at rendezvous points (wave-level operations, __syncthreads) and at a lane's end.  TEST INFRASTRUCTURE.
+#include <setjmp.h>
 #include <ucontext.h>
 #include <cstdio>
 #include <mutex>
@@ -13,9 +14,12 @@
 namespace emu {
 namespace {
 const size_t kStack = 1 << 20;
-struct Lane { ucontext_t ctx; unsigned char *stack = nullptr; int tid = 0; bool done = false; };
+// a lane's fiber lives for the whole process: created once (makecontext), entered the first time with swapcontext, afterwards switched
+// with _setjmp / _longjmp (no signal-mask system calls); between launches it waits at the end of lane_main's loop
+struct Lane { ucontext_t ctx; jmp_buf jb; unsigned char *stack = nullptr; int tid = 0; bool done = false, started = false; };
 struct Wave { uint64_t slot[64], pub[64]; int site[64]; bool div[64]; uint64_t present = 0, pubMask = 0; int arrived = 0, live = 0; };
-std::vector<Lane> lanes;
+std::vector<Lane *> lanes;
+jmp_buf schedJb;
 std::vector<Wave> waves;
 ucontext_t sched;
 Lane *cur = nullptr;
@@ -25,7 +29,14 @@ unsigned barGen = 0;
 long progress = 0;  // bumped whenever a rendezvous completes or a lane ends: the deadlock detector's clock
 const std::function<void()> *g_body = nullptr;
 
-void yield() { Lane *me = cur; swapcontext(&me->ctx, &sched); }
+void yield() { Lane *me = cur; if (_setjmp(me->jb) == 0) _longjmp(schedJb, 1); }
+void resume(Lane *l) {
+    if (_setjmp(schedJb) != 0) return;  // the lane yielded
+    cur = l;
+    if (l->started) _longjmp(l->jb, 1);
+    l->started = true;
+    swapcontext(&sched, &l->ctx);
+}
 const char *g_kernel = "";
 // Every live lane of the wave waits at a wave-level call.  All at the same one: serve them.  Otherwise the lanes at a call marked as
 // sitting in divergent code go first (the hardware would be executing their branch while the rest is masked off).
@@ -51,13 +62,15 @@ void resolve(Wave &w) {
     w.pubMask = group; w.present &= ~group; w.arrived -= __builtin_popcountll(group); ++progress;
 }
 void lane_main() {
-    (*g_body)();
-    cur->done = true;
-    Wave &w = waves[cur->tid / 64];
-    --w.live; --barLive; ++progress;
-    if (w.arrived > 0 && w.arrived == w.live) resolve(w);          // the others were waiting for this lane only
-    if (barArrived > 0 && barArrived == barLive) { barArrived = 0; ++barGen; }
-    swapcontext(&cur->ctx, &sched);
+    for (;;) {
+        (*g_body)();
+        cur->done = true;
+        Wave &w = waves[cur->tid / 64];
+        --w.live; --barLive; ++progress;
+        if (w.arrived > 0 && w.arrived == w.live) resolve(w);          // the others were waiting for this lane only
+        if (barArrived > 0 && barArrived == barLive) { barArrived = 0; ++barGen; }
+        yield();  // until the next block / launch gives this lane a new body
+    }
 }
 }  // namespace
 
@@ -94,10 +107,14 @@ void launch(const char *name, dim3 grid, dim3 block, size_t dynShared, const std
     g_kernel = name;
     if (grid.y != 1 || grid.z != 1 || block.y != 1 || block.z != 1) { fprintf(stderr, "hip_emu: only 1-D launches\n"); abort(); }
     const int nt = (int)block.x;
-    if ((int)lanes.size() < nt) {
-        const size_t old = lanes.size();
-        lanes.resize(nt);
-        for (size_t i = old; i < lanes.size(); ++i) lanes[i].stack = (unsigned char *)malloc(kStack);
+    while ((int)lanes.size() < nt) {
+        Lane *L = new Lane;
+        L->tid = (int)lanes.size();
+        L->stack = (unsigned char *)malloc(kStack);
+        getcontext(&L->ctx);
+        L->ctx.uc_stack.ss_sp = L->stack; L->ctx.uc_stack.ss_size = kStack; L->ctx.uc_link = nullptr;
+        makecontext(&L->ctx, (void (*)())lane_main, 0);
+        lanes.push_back(L);
     }
     static std::vector<unsigned char> shared;
     if (shared.size() < dynShared + 64) shared.resize(dynShared + 64);
@@ -107,24 +124,16 @@ void launch(const char *name, dim3 grid, dim3 block, size_t dynShared, const std
     for (unsigned b = 0; b < grid.x; ++b) {
         g_block = Idx{b, 0, 0};
         waves.assign((nt + 63) / 64, Wave());
-        for (int t = 0; t < nt; ++t) {
-            Lane &L = lanes[t];
-            L.tid = t; L.done = false;
-            getcontext(&L.ctx);
-            L.ctx.uc_stack.ss_sp = L.stack; L.ctx.uc_stack.ss_size = kStack; L.ctx.uc_link = &sched;
-            makecontext(&L.ctx, (void (*)())lane_main, 0);
-            ++waves[t / 64].live;
-        }
+        for (int t = 0; t < nt; ++t) { lanes[t]->done = false; ++waves[t / 64].live; }
         barLive = nt; barArrived = 0;
         int remaining = nt;
         long lastProgress = progress; int idleRounds = 0;
         while (remaining > 0) {
             remaining = 0;
             for (int t = 0; t < nt; ++t) {
-                if (lanes[t].done) continue;
-                cur = &lanes[t];
-                swapcontext(&sched, &cur->ctx);
-                if (!lanes[t].done) ++remaining;
+                if (lanes[t]->done) continue;
+                resume(lanes[t]);
+                if (!lanes[t]->done) ++remaining;
             }
             if (progress == lastProgress) {
                 if (++idleRounds > 4) {
