@@ -12,9 +12,9 @@ import pytest
 from conftest import ROOT
 
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-# not under emulation: torch device buffers, the hipCUB-based device BVH build, the CLI (spawns the native binary), the tile-serial
-# samplers (hundreds of thousands of tiny launches: minutes each), full-size runs
-SKIP = "not device_buffers and not cli and not sampler_ and not 02sequence and not full_size and not invalid_media"  # (invalid_media: its last line asks pg_hlbvh_build)
+# not in the PBRT_EMULATE_ALL run: torch device buffers, the hipCUB-based device BVH build, the tile-serial samplers (they pass, but take
+# minutes each: hundreds of thousands of tiny launches), full-size frames
+SKIP = "not device_buffers and not sampler_ and not 02sequence and not full_size and not invalid_media"  # (invalid_media: its last line asks pg_hlbvh_build)
 
 
 @pytest.fixture(scope="module")
