@@ -84,3 +84,43 @@ def test_native_multi_device_render_on_emulated_devices(emulated, pkg, tmp_path)
         images[n] = pkg.read_pfm(out)
     assert np.array_equal(images[1], images[3])
     assert np.array_equal(images[1], pkg.read_pfm(scene[:-5] + ".pfm")) or np.abs(images[1] - pkg.read_pfm(scene[:-5] + ".pfm")).max() < 1e-4
+
+
+def _rank(rank, world, port, lib, name, out):
+    """One rank of bench.py's step(): render this rank's tiles with pg_render into its own buffers (GpuScene.render_device -- the call
+    bench.py makes), gather on rank 0 with the product's pbrt_v3_amd.distributed (gloo here, RCCL there), merge."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PBRT_GPU_LIB=lib, PBRT_EMULATED_DEVICE="1")
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from pbrt_v3_amd import distributed as pdist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene = pkg.HostScene(os.path.join(ROOT, "tests", "golden", name + ".pbrt"))
+    gs = pkg.GpuScene(scene.desc)
+    rd = scene.render_desc(tile_first=rank, tile_step=world)
+    film, strays, nstrays, max_strays = pdist.shard_buffers(gs.tile_count(scene.render_desc(0, world)), "cpu", rd.tile_pixels)
+    gs.render_device(rd, film.data_ptr(), strays.data_ptr(), max_strays, nstrays.data_ptr(), stream=None)
+    lists = pdist.gather_film(film, strays, nstrays, dst=0)
+    if rank == 0:
+        shards = [(lists[0][r], lists[1][r], int(lists[2][r].item())) for r in range(world)]
+        np.save(out, pdist.merge_shards(pkg, scene, gs.tile_count, shards))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_bench_step_on_emulated_devices(emulated, pkg, tmp_path):
+    """bench.py's N > 1 step with everything but the transport real: two processes, each with its own (emulated) device rendering the
+    tiles t = rank (mod 2) through pg_render into its shard buffers, torch.distributed gather to rank 0, Film merge -- the image is
+    the reference's golden within the device tolerance and equals the single-process render bit for bit."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    name, out = "cornell_40x24", str(tmp_path / "two_ranks.npy")
+    mp.spawn(_rank, args=(2, 29561, emulated, name, out), nprocs=2, join=True)
+    img = np.load(out)
+    ref = pkg.read_pfm(os.path.join(ROOT, "tests", "golden", name + ".pfm"))
+    assert img.shape == ref.shape and (np.abs(img - ref) / np.maximum(1, np.abs(ref))).max() <= 1e-4
+    single = str(tmp_path / "one_rank.npy")
+    mp.spawn(_rank, args=(1, 29562, emulated, name, single), nprocs=1, join=True)
+    assert np.array_equal(img, np.load(single))
