@@ -1,27 +1,31 @@
 #!/usr/bin/env python3
 """Headline benchmark: PathIntegrator on the synthetic ~1M-triangle scene, 1920x1080 @ 64 spp
-(BASELINE.json configs[2]), film tiles sharded across the visible ranks, one process per GPU.
+(BASELINE.json configs[2]), film tiles sharded across the ranks, one process per GPU.
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no launcher around it (WORLD_SIZE unset) the script starts its own N ranks
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`); under
+torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
 
 A "step" is one full Integrator::Render of the frame on device-resident scene data: camera-ray
-generation, every bounce's BVH traversal + shading, film accumulation and (N>1) the RCCL gather of
-the per-rank film tiles to rank 0.  Scene parsing, BVH construction, upload and the final
-Film::WriteImage are outside the timed region, as in the reference's own accounting
-(SURVEY.md section 8d).  Rank 0 prints ONE JSON line.
+generation, every bounce's BVH traversal + shading, film accumulation and (N>1) ONE RCCL gather of
+the rank's packed film shard to rank 0, enqueued behind the render and overlapped with the next frame
+(two shard buffers alternate).  Scene parsing, BVH construction, upload and the final Film::WriteImage
+are outside the timed region, as in the reference's own accounting.
+Rank 0 prints ONE JSON line.
 """
 import argparse
-import ctypes as C
 import json
 import os
 import re
+import socket
 import subprocess
 import sys
 import tempfile
 import time
+import types
 
-import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -35,6 +39,7 @@ L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth, 8 XCDs x 4 MiB (MI355X_MICROAR
 INFINITY_CACHE_BYTES = 256 << 20
 FOG = ('MakeNamedMedium "fog" "string type" "homogeneous" "rgb sigma_a" [ 0.02 0.03 0.04 ] "rgb sigma_s" [ 0.15 0.12 0.1 ] "float g" [ 0.4 ]\n'
        'MediumInterface "" "fog"\n')
+EMULATED = os.environ.get("PBRT_EMULATED_DEVICE") == "1"  # tests/emu: the device library compiled for the host (a functional check, never a measurement)
 
 
 def make_scene_file(workdir, args):
@@ -46,11 +51,14 @@ def make_scene_file(workdir, args):
                   .replace('"integer yresolution" [ 512 ]', f'"integer yresolution" [ {args.yres} ]')
                   .replace('"integer pixelsamples" [ 256 ]', f'"integer pixelsamples" [ {args.spp} ]'))
         open(path, "w").write(txt)
+    elif args.workload in ("divergent", "divergent-vol"):
+        import gen_divergent  # BASELINE configs 4 / 5 stand-ins: instanced PLY meshes, textures, alpha masks, a material palette
+        gen_divergent.write_scene(path, tris=args.tris, xres=args.xres, yres=args.yres, spp=args.spp, volumetric=args.workload.endswith("-vol"))
     else:
         # (PBRT_BENCH_MAXDEPTH: kernel diagnostics only; the benchmark is maxdepth 5)
         gen_synthetic.write_scene(path, n=args.grid, xres=args.xres, yres=args.yres, spp=args.spp,
                                   maxdepth=int(os.environ.get("PBRT_BENCH_MAXDEPTH", "5")))
-        if args.workload == "synthetic-vol":  # BASELINE config 4's stand-in: the mesh inside a HomogeneousMedium, VolPathIntegrator
+        if args.workload == "synthetic-vol":  # the mesh inside a HomogeneousMedium, VolPathIntegrator
             txt = open(path).read()
             txt = txt.replace("Camera ", FOG + "Camera ", 1).replace('Integrator "path"', 'Integrator "volpath"', 1)
             txt = txt.replace("WorldBegin\n", 'WorldBegin\nMediumInterface "fog" "fog"\n', 1)
@@ -108,182 +116,286 @@ def cpu_baseline(workdir, args):
             "sample": sample}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher: start N ranks of this same command under torch.distributed.run."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), PBRT_BENCH_SELF_LAUNCHED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+class Context:
+    """Rank, device and transport of this process."""
+
+    def __init__(self, args):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}")
+        self.oversubscribed = os.environ.get("PBRT_BENCH_OVERSUBSCRIBE") == "1"
+        if EMULATED:
+            self.dev, self.device_index = torch.device("cpu"), 0
+        else:
+            if not torch.cuda.is_available():
+                raise SystemExit("bench.py: no GPU visible (the HIP path has no CPU fallback)")
+            # one rank per GPU; PBRT_BENCH_OVERSUBSCRIBE=1 lets several ranks share a device (a functional pre-flight of the
+            # N > 1 path on a single-GPU box; never a measurement)
+            if local_rank >= torch.cuda.device_count() and not self.oversubscribed:
+                raise SystemExit(f"bench.py: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
+            self.device_index = local_rank % torch.cuda.device_count()
+            torch.cuda.set_device(self.device_index)
+            self.dev = torch.device("cuda", self.device_index)
+        # RCCL refuses two ranks on one device ("Duplicate GPU detected"), so the single-GPU pre-flight moves host copies of the
+        # shards through gloo; so does the emulated device.  A real run is RCCL over xGMI ("nccl" is RCCL on ROCm).
+        self.backend = "gloo" if (EMULATED or self.oversubscribed) else "nccl"
+        self.comm_dev = self.dev if self.backend == "nccl" else torch.device("cpu")
+        # PBRT_BENCH_FORCE_DIST=1: run the collective path with ONE rank (the only way to execute the RCCL transport on a 1-GPU box)
+        self.multi = self.world > 1 or os.environ.get("PBRT_BENCH_FORCE_DIST") == "1"
+        if self.multi:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group("gloo")
+
+    def device_sync(self):
+        if not EMULATED:
+            torch.cuda.synchronize()
+
+    def sync(self):
+        """barrier + torch.cuda.synchronize(): both sides of the timed region."""
+        self.device_sync()
+        if self.multi:
+            dist.barrier()
+        self.device_sync()
+
+
+def run_workload(ctx, args, steps, warmup, keep_image=False):
+    """W untimed + K timed frames of one workload on this rank's tile shard.  Returns the measurements (and, on rank 0, the image)."""
+    pkg = load_package()
+    from pbrt_v3_amd import distributed as pdist
+    workdir = tempfile.mkdtemp(prefix=f"pbrt_bench_r{ctx.rank}_")
+    scene_file = make_scene_file(workdir, args)
+    t0 = time.time()
+    scene = pkg.HostScene(scene_file)
+    t_parse = time.time() - t0
+    gs = pkg.GpuScene(scene.desc, device=ctx.device_index)
+    rd = scene.render_desc(tile_first=ctx.rank, tile_step=ctx.world)
+    max_tiles = gs.tile_count(scene.render_desc(0, ctx.world))  # rank 0 owns the most
+    # two shard buffers alternate, so that frame i's gather overlaps frame i+1's render (N = 1: one buffer, no gather)
+    bufs = [pdist.ShardBuffer(max_tiles, ctx.dev, rd.tile_pixels) for _ in range(2 if ctx.multi else 1)]
+    gather = pdist.FilmGather(bufs[0], dst=0, comm_device=ctx.comm_dev) if ctx.multi else None
+    frame = [0]
+
+    def step():
+        b = bufs[frame[0] % len(bufs)]
+        frame[0] += 1
+        stream = None if EMULATED else torch.cuda.current_stream().cuda_stream
+        gs.render_device(rd, b.film.data_ptr(), b.strays.data_ptr(), b.max_strays, b.nstrays.data_ptr(), stream=stream)
+        if gather:  # Film gather over xGMI: the packed shard to rank 0, one collective, behind the render on this stream
+            gather.start(b, async_op=True)
+        return b
+
+    last = None
+    for _ in range(warmup):
+        last = step()
+    if gather:
+        gather.wait()
+    gs.counters_reset()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    if gather:
+        gather.wait()
+    ctx.device_sync()
+    local = time.perf_counter() - t0  # this rank's own frames + gathers done
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    cn = gs.counters()
+    stats = torch.tensor([elapsed, float(cn["closest_rays"] + cn["shadow_rays"]), float(cn["camera_rays"])], dtype=torch.float64, device=ctx.comm_dev)
+    per_rank = [local]
+    if ctx.multi:
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        stats[0] = tmax[0]
+        mine = torch.tensor([local], dtype=torch.float64, device=ctx.comm_dev)
+        every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, mine)
+        per_rank = [float(t.item()) for t in every]
+    elapsed, rays, samples = (float(x) for x in stats.tolist())
+    m = types.SimpleNamespace(elapsed=elapsed, rays=rays, samples=samples, cn=cn, scene=scene, gs=gs, t_parse=t_parse, workdir=workdir,
+                              per_rank_ms=[t / max(1, steps) * 1e3 for t in per_rank], steps=steps, image=None)
+    if ctx.rank == 0 and keep_image and last is not None:  # final image (outside the timed region): MergeFilmTile per shard + WriteImage arithmetic
+        shards = gather.shards(last) if gather else [(last.film, last.strays, int(last.nstrays.item()))]
+        m.image = pdist.merge_shards(pkg, scene, gs.tile_count, shards)
+    return m
+
+
+def describe(args, scene):
+    integ = "VolPathIntegrator + HomogeneousMedium" if args.workload.endswith("-vol") else "PathIntegrator"
+    what = {"cornell": "Cornell box, 36 triangles"}.get(args.workload)
+    if what is None:
+        kind = ("instanced PLY meshes, image / alpha textures, 6-material palette" if args.workload.startswith("divergent")
+                else "synthetic heightfield-in-a-box")
+        n = scene.desc.n_tris if not args.workload.startswith("divergent") else scene.desc.n_prims_all
+        what = f"{kind}, {n} triangles" + (f" ({scene.desc.n_instances} object instances)" if scene.desc.n_instances else "")
+    return f"{what}, {integ} maxdepth 5, halton, {args.filter} filter, {args.xres}x{args.yres} @ {args.spp} spp"
+
+
+def kernel_rooflines(m, workload):
+    """One roofline per hot kernel.  Algorithmic bytes:
+      k_trace: 32 B per reference node fetch + 48 B per triangle test + 32 B per ray in + 16 B (closest) / 4 B (any) out
+      k_shade: per path vertex 16 B ray direction + 16 B hit + 48 B state in + 48 B triangle + 48 B state out + 48 B pending
+               direct-light terms, + 32 B per ray pushed (+ 16 B of MIS terms per MIS ray)
+    Time: HIP events around every launch on the stream it runs on (pg_render), so each kernel is timed alone.
+    Bound: the BVH + triangle working set against the 256 MiB Infinity Cache -- below it the node / triangle gathers are
+    served on-die and the binding bandwidth is the L2's; above it they reach HBM."""
+    cn, desc = m.cn, m.scene.desc
+    n_nodes = max(desc.n_nodes, desc.n_nodes_all)
+    n_prims = max(desc.n_tris, desc.n_prims_all)
+    working_set = 64 * max(0, (n_nodes - 1) // 2) + 64 * n_prims  # child-pair records + triangle records, one 64-B line each (DESIGN.md section 3)
+    bound = "l2" if working_set < INFINITY_CACHE_BYTES else "hbm"
+    peak = L2_PEAK_GBS if bound == "l2" else HBM_PEAK_GBS
+    # Memory-side traffic and L2 hit rates are NOT measured in this run: they are replayed from the committed PMC passes of the same
+    # workload (tools/pmc_traffic.sh -> profiles/pmc_traffic.json; raw FETCH_SIZE / WRITE_SIZE in KiB) and every value that comes
+    # from there carries "source".  FETCH_SIZE is scaled by the factor measured for this access pattern on a known byte count
+    # (tools/pmc_calibrate.sh -> profiles/fetch_size_calibration.json); without that file the guide's streaming-read factor 2 is
+    # used and labelled as uncalibrated.
+    pmc_kernels, pmc_src, factor, factor_src = {}, None, 2.0, "MI355X_MICROARCH.md: x2 for 16 B/lane streaming reads (uncalibrated for gathers)"
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            w = json.load(open(pmc)).get("workloads", {}).get(workload, {})
+            pmc_kernels, pmc_src = w.get("kernels", {}), "profiles/pmc_traffic.json" + (f"@{w['round']}" if "round" in w else "")
+        except Exception:
+            pass
+    cal = os.path.join(ROOT, "profiles", "fetch_size_calibration.json")
+    if os.path.exists(cal):
+        try:
+            c = json.load(open(cal))
+            factor, factor_src = float(c["gather_factor"]), "profiles/fetch_size_calibration.json: " + c.get("note", "")
+        except Exception:
+            pass
+
+    def one(name, tag, alg_bytes, ms, launches, units, unit_name, gather_pattern):
+        launches = max(1, launches)
+        achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        pk = next((v for k, v in pmc_kernels.items() if k.startswith(tag)), None)
+        traffic = None
+        if pk is not None:
+            f = factor if gather_pattern else 2.0
+            traffic = (f * pk["fetch_KiB_per_launch"] + pk["write_KiB_per_launch"]) * 1024 if "fetch_KiB_per_launch" in pk else pk.get("hbm_bytes_per_launch")
+        r = {"kernel": name, "bound": bound, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+             "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes / launches, "avg_launch_ms": ms / launches,
+             "launches": launches, "total_ms": ms, f"bytes_per_{unit_name}": alg_bytes / max(1, units)}
+        if traffic is not None:
+            r["traffic_source"] = {"source": pmc_src, "fetch_size_factor": factor if gather_pattern else 2.0,
+                                   "fetch_size_factor_source": factor_src if gather_pattern else "MI355X_MICROARCH.md (streaming reads)",
+                                   "note": "replayed from a committed PMC pass of this workload, not measured in this run"}
+            if ms > 0:  # what the memory side of the L2 moved, against the HBM peak
+                hb = traffic * launches / (ms * 1e-3) / 1e9
+                r["hbm_side"] = {"achieved": hb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / HBM_PEAK_GBS, "source": pmc_src}
+        return r
+
+    n_close, n_shadow, n_mis, n_items = cn["closest_rays"], cn["shadow_rays"], cn["mis_rays"], cn["shade_items"]
+    n_next = max(0, n_close - cn["camera_rays"] - n_mis)
+    kernels = [
+        one("k_trace<false> (BVHAccel::Intersect + Triangle::Intersect)", "void k_trace<false",
+            32 * cn["closest_node_visits"] + 48 * cn["closest_tri_tests"] + 48 * n_close, cn["closest_ms"], cn["closest_launches"], n_close, "ray", True),
+        one("k_trace<true> (BVHAccel::IntersectP + Triangle::IntersectP)", "void k_trace<true",
+            32 * cn["shadow_node_visits"] + 48 * cn["shadow_tri_tests"] + 36 * n_shadow, cn["shadow_ms"], cn["shadow_launches"], n_shadow, "ray", True),
+        one("k_shade (PathIntegrator::Li loop body + EstimateDirect set-up)", "void k_shade",
+            224 * n_items + 32 * (n_next + n_shadow + n_mis) + 16 * n_mis, cn["shade_ms"], cn["shade_launches"], n_items, "vertex", False),
+    ]
+    kernels = [k for k in kernels if k["total_ms"] > 0]
+    kernels.sort(key=lambda k: -k["total_ms"])  # dominant = the most time, each kernel timed alone
+    return kernels, working_set, bound, peak, pmc_kernels, pmc_src
+
+
+def gather_ceiling(m, working_set, pmc_kernels, pmc_src):
+    """The traversal kernels are gathers of 64-B child-pair records and 48-B triangle records, one per lane and step.  What bounds
+    them is the chip's rate of random record fetches at this working-set size, measured live by tools/ubench_gather.hip
+    (pbrt-v3_amd/ubench_gather: every lane chases its own chain of records through a table of that size): DESIGN.md section 5.
+    Closest hit: an interior step counts two reference node visits (both children), the root one per ray, so
+    record fetches = (node visits - rays) / 2 + triangle tests."""
+    cn = m.cn
+    ub = os.path.join(ROOT, "pbrt-v3_amd", "ubench_gather")
+    if not os.path.exists(ub) or cn["closest_ms"] <= 0 or EMULATED:
+        return None
+    try:
+        ws_mb = max(3, int(round(working_set / 2**20)))
+        ceil = json.loads(subprocess.run([ub, "--json", "2", str(ws_mb)], capture_output=True, text=True, timeout=120).stdout)
+        c_l2, c_ws = ceil["2"]["together"], ceil[str(ws_mb)]["together"]
+        fetches = max(0, cn["closest_node_visits"] - cn["closest_rays"]) / 2 + cn["closest_tri_tests"]
+        rate = fetches / (cn["closest_ms"] * 1e-3)
+        # A traversal is not a uniformly random walk: the top of the tree stays in the L2s.  With the kernel's L2 hit rate h (committed
+        # PMC pass of this workload) the ceiling is the harmonic blend of the L2-resident rate and the rate at the working set's
+        # size; without h only the L2-resident rate is a safe upper bound.
+        h = next((v.get("l2_hit_rate") for k, v in pmc_kernels.items() if k.startswith("void k_trace<false")), None)
+        ceiling = 1.0 / (h / c_l2 + (1.0 - h) / c_ws) if h is not None else c_l2
+        return {"kernel": "k_trace<false>", "record_fetches_per_s": rate, "ceiling_records_per_s": ceiling, "frac": rate / ceiling,
+                "ceiling_kind": ("1 / (h / C(2 MiB) + (1 - h) / C(working set)), h = the kernel's L2 hit rate" if h is not None
+                                 else "C(2 MiB): L2-resident table (no PMC pass of this workload committed: upper bound)"),
+                "l2_hit_rate": h, "l2_hit_rate_source": pmc_src if h is not None else None,
+                "table_MiB": ws_mb, "ceiling_l2_resident": c_l2, "ceiling_at_working_set": c_ws,
+                "note": "C(x) = random 64-B record fetches per second through the vector L1, measured live by pbrt-v3_amd/ubench_gather: one "
+                        "chain per lane, table of x MiB; fetches the kernel serves from its LDS-resident tree top count in its rate, so a value above 1 is possible"}
+    except Exception as e:  # the measurement tool is optional; the bench line is not
+        return {"error": str(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="synthetic", choices=["synthetic", "synthetic-vol", "cornell"],
-                    help="synthetic: BASELINE config 3 (with --grid 1582 --spp 256: the 5 M-triangle stand-in of config 4); "
-                         "synthetic-vol (--grid 2237 --spp 128): the 10 M-triangle volpath stand-in of config 5; cornell: config 2")
+    ap.add_argument("--workload", default="synthetic", choices=["synthetic", "synthetic-vol", "cornell", "divergent", "divergent-vol"],
+                    help="synthetic: BASELINE config 3 (with --grid 1582: the 5 M-triangle HBM-regime stand-in); synthetic-vol (--grid 2237 "
+                         "--spp 128): 10 M triangles in fog under volpath; cornell: config 2; divergent / divergent-vol (--tris 5000000 / "
+                         "10000000): configs 4 / 5 as instanced PLY meshes with textures, alpha masks and a material palette")
     ap.add_argument("--grid", type=int, default=708, help="heightfield vertices per side (708 -> 999 698 triangles)")
+    ap.add_argument("--tris", type=int, default=5000000, help="divergent workloads: instanced triangle count to reach")
     ap.add_argument("--xres", type=int, default=1920)
     ap.add_argument("--yres", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--filter", default="box", help='PixelFilter of the scene (BASELINE config: "box")')
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline renders every sample of the frame (minutes)")
+    ap.add_argument("--no-hbm-regime", action="store_true", help="skip the 3 extra frames of the 5 M-triangle workload behind roofline.hbm_regime")
     ap.add_argument("--out", default=None, help="write the rendered image (PFM) here")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py: no GPU visible (the HIP path has no CPU fallback)")
-    # one rank per GPU; PBRT_BENCH_OVERSUBSCRIBE=1 lets several ranks share a device (a functional pre-flight of the N > 1
-    # path on a single-GPU box -- RCCL permitting; never a measurement)
-    if local_rank >= torch.cuda.device_count() and os.environ.get("PBRT_BENCH_OVERSUBSCRIBE") != "1":
-        raise SystemExit(f"bench.py: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
-    local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # RCCL refuses two ranks on one device ("Duplicate GPU detected"), so the single-GPU pre-flight of the N > 1 path
-    # (PBRT_BENCH_OVERSUBSCRIBE=1) moves the film shards through gloo on host copies instead; a real run is RCCL over xGMI
-    backend = "gloo" if os.environ.get("PBRT_BENCH_OVERSUBSCRIBE") == "1" else "nccl"
-    comm_dev = dev if backend == "nccl" else torch.device("cpu")
-    # PBRT_BENCH_FORCE_DIST=1: run the collective path with however many ranks there are -- with ONE rank on a single-GPU box
-    # this is the only way to execute the RCCL transport (communicator, gather, all_reduce, barrier) before an 8-GPU run
-    multi = world > 1 or os.environ.get("PBRT_BENCH_FORCE_DIST") == "1"
-    if multi:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
-        else:
-            dist.init_process_group("gloo")
-
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    ctx = Context(args)
     pkg = load_package()
-    workdir = tempfile.mkdtemp(prefix=f"pbrt_bench_r{rank}_")
-    scene_file = make_scene_file(workdir, args)
-    t0 = time.time()
-    scene = pkg.HostScene(scene_file)
-    t_parse = time.time() - t0
-    gs = pkg.GpuScene(scene.desc, device=local_rank)
-    rd = scene.render_desc(tile_first=rank, tile_step=world)
-    n_tiles = gs.tile_count(rd)
-    max_tiles = gs.tile_count(scene.render_desc(0, world))  # rank 0 owns the most
-    from pbrt_v3_amd import distributed as pdist
-    film, strays, nstrays, max_strays = pdist.shard_buffers(max_tiles, dev, rd.tile_pixels)
-    to_comm = (lambda t: t) if backend == "nccl" else (lambda t: t.cpu())
-    gathered = [pdist.gather_lists(to_comm(film), to_comm(strays), to_comm(nstrays)) if multi else None]
+    m = run_workload(ctx, args, args.steps, args.warmup, keep_image=bool(args.out))
+    # North star: ">= 40 % of the HBM roofline in the BVH-traversal kernel" is a statement about the regime where the BVH does not
+    # fit the 256 MiB Infinity Cache, which config 3 (106 MiB) is not in.  After the headline steps, rank 0 of a 1-GPU run times 3
+    # frames of the same scene at 5 M triangles (535 MiB of records) at the headline's resolution and spp: roofline.hbm_regime.
+    hbm = None
+    if ctx.world == 1 and not ctx.multi and not args.no_hbm_regime and not EMULATED and args.workload == "synthetic" and args.grid == 708:
+        a5 = argparse.Namespace(**vars(args))
+        a5.grid = 1582
+        m.gs.close()
+        try:
+            hbm = run_workload(ctx, a5, 3, 1)
+            hbm.args = a5
+        except Exception as e:
+            sys.stderr.write(f"bench: hbm-regime workload failed: {e}\n")
 
-    def step():
-        stream = torch.cuda.current_stream().cuda_stream
-        gs.render_device(rd, film.data_ptr(), strays.data_ptr(), max_strays, nstrays.data_ptr(), stream=stream)
-        if multi:  # Film gather over xGMI: every rank's packed tile buffer to rank 0
-            pdist.gather_film(to_comm(film), to_comm(strays), to_comm(nstrays), lists=gathered[0], dst=0)
-
-    def sync():
-        if multi:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    gs.counters_reset()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    cn = gs.counters()
-    stats = torch.tensor([elapsed, float(cn["closest_rays"] + cn["shadow_rays"]), float(cn["camera_rays"])], dtype=torch.float64, device=comm_dev)
-    if multi:
-        tmax = stats[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-        stats[0] = tmax[0]
-    elapsed, rays, samples = (float(x) for x in stats.tolist())
-
-    if rank == 0:
-        # final image (outside the timed region): MergeFilmTile per shard + WriteImage arithmetic on the host
-        img = None
-        if args.out:
-            if multi:
-                shards = [(gathered[0][0][r], gathered[0][1][r], int(gathered[0][2][r].item())) for r in range(world)]
-            else:
-                shards = [(film, strays, int(nstrays.item()))]
-            img = pdist.merge_shards(pkg, scene, gs.tile_count, shards)
-            pkg.write_pfm(args.out, img)
-        # Rooflines of the three hot kernels on rank 0.  Algorithmic bytes:
-        #   k_trace: 32 B per reference node fetch + 48 B per triangle test + 32 B per ray in + 16 B (closest) / 4 B (any) out
-        #   k_shade: per path vertex 16 B ray direction + 16 B hit + 48 B state in + 48 B triangle + 48 B state out + 48 B
-        #            pending direct-light terms, + 32 B per ray pushed (+ 16 B of MIS terms per MIS ray)
-        # Time: HIP events around every launch on the stream it runs on (pg_render), so each kernel is timed alone.
-        # Bound: the BVH + triangle working set against the 256 MiB Infinity Cache -- below it the node/triangle gathers
-        # are served on-die and the binding bandwidth is the L2's; above it they reach HBM.
-        integ = "VolPathIntegrator + HomogeneousMedium" if args.workload == "synthetic-vol" else "PathIntegrator"
-        workload = ((f"synthetic heightfield-in-a-box, {scene.desc.n_tris} triangles" if args.workload != "cornell"
-                     else "Cornell box, 36 triangles") +
-                    f", {integ} maxdepth 5, halton, {args.filter} filter, {args.xres}x{args.yres} @ {args.spp} spp")
-        n_interior = max(0, (scene.desc.n_nodes - 1) // 2)
-        working_set = 64 * n_interior + 64 * scene.desc.n_tris  # child-pair records + triangle records, one 64-B line each
-        bound = "l2" if working_set < INFINITY_CACHE_BYTES else "hbm"
-        peak = L2_PEAK_GBS if bound == "l2" else HBM_PEAK_GBS
-        pmc_kernels = {}  # HBM-side bytes per launch from the committed PMC passes of this same workload (tools/pmc_traffic.sh)
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                pmc_kernels = json.load(open(pmc)).get("workloads", {}).get(workload, {}).get("kernels", {})
-            except Exception:
-                pass
-
-        def kernel_roofline(name, tag, alg_bytes, ms, launches, units, unit_name):
-            launches = max(1, launches)
-            achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            traffic = next((v["hbm_bytes_per_launch"] for k, v in pmc_kernels.items() if k.startswith(tag)), None)
-            r = {"kernel": name, "bound": bound, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-                 "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes / launches, "avg_launch_ms": ms / launches,
-                 "launches": launches, "total_ms": ms, f"bytes_per_{unit_name}": alg_bytes / max(1, units)}
-            if traffic is not None and ms > 0:  # what the memory side of the L2 actually moved, against the HBM peak
-                hb = traffic * launches / (ms * 1e-3) / 1e9
-                r["hbm_side"] = {"achieved": hb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / HBM_PEAK_GBS}
-            return r
-
-        n_close, n_shadow, n_mis, n_items = cn["closest_rays"], cn["shadow_rays"], cn["mis_rays"], cn["shade_items"]
-        n_next = max(0, n_close - cn["camera_rays"] - n_mis)
-        kernels = [
-            kernel_roofline("k_trace<false> (BVHAccel::Intersect + Triangle::Intersect)", "void k_trace<false",
-                            32 * cn["closest_node_visits"] + 48 * cn["closest_tri_tests"] + 48 * n_close,
-                            cn["closest_ms"], cn["closest_launches"], n_close, "ray"),
-            kernel_roofline("k_trace<true> (BVHAccel::IntersectP + Triangle::IntersectP)", "void k_trace<true",
-                            32 * cn["shadow_node_visits"] + 48 * cn["shadow_tri_tests"] + 36 * n_shadow,
-                            cn["shadow_ms"], cn["shadow_launches"], n_shadow, "ray"),
-            kernel_roofline("k_shade (PathIntegrator::Li loop body + EstimateDirect set-up)", "void k_shade",
-                            224 * n_items + 32 * (n_next + n_shadow + n_mis) + 16 * n_mis,
-                            cn["shade_ms"], cn["shade_launches"], n_items, "vertex"),
-        ]
-        # The traversal kernels are gathers of 64-B child-pair records and 48-B triangle records, one per lane and step.  What bounds
-        # them is the chip's rate of random record fetches at this working-set size, measured live by tools/ubench_gather.hip
-        # (pbrt-v3_amd/ubench_gather: every lane chases its own chain of records through a table of that size): DESIGN.md section 5.
-        # Closest hit: an interior step counts two reference node visits (both children), the root one per ray, so
-        # record fetches = (node visits - rays) / 2 + triangle tests.
-        gather = None
-        ub = os.path.join(ROOT, "pbrt-v3_amd", "ubench_gather")
-        if os.path.exists(ub) and cn["closest_ms"] > 0:
-            try:
-                ws_mb = max(3, int(round(working_set / 2**20)))
-                ceil = json.loads(subprocess.run([ub, "--json", "2", str(ws_mb)], capture_output=True, text=True, timeout=120).stdout)
-                c_l2, c_ws = ceil["2"]["together"], ceil[str(ws_mb)]["together"]
-                fetches = max(0, cn["closest_node_visits"] - n_close) / 2 + cn["closest_tri_tests"]
-                rate = fetches / (cn["closest_ms"] * 1e-3)
-                # A traversal is not a uniformly random walk: the top of the tree stays in the L2s.  With the kernel's measured L2 hit
-                # rate h (committed PMC pass of this workload) the ceiling is the harmonic blend of the L2-resident rate and the rate
-                # at the working set's size; without h only the L2-resident rate is a safe upper bound.
-                h = next((v.get("l2_hit_rate") for k, v in pmc_kernels.items() if k.startswith("void k_trace<false")), None)
-                ceiling = 1.0 / (h / c_l2 + (1.0 - h) / c_ws) if h is not None else c_l2
-                gather = {"kernel": "k_trace<false>", "record_fetches_per_s": rate, "ceiling_records_per_s": ceiling, "frac": rate / ceiling,
-                          "ceiling_kind": ("1 / (h / C(2 MiB) + (1 - h) / C(working set)), h = L2 hit rate of the kernel from profiles/pmc_traffic.json"
-                                           if h is not None else "C(2 MiB): L2-resident table (no PMC pass of this workload committed: upper bound)"),
-                          "l2_hit_rate": h, "table_MiB": ws_mb, "ceiling_l2_resident": c_l2, "ceiling_at_working_set": c_ws,
-                          "note": "C(x) = random 64-B record fetches per second measured live by pbrt-v3_amd/ubench_gather: one chain per lane, table of x MiB"}
-            except Exception as e:  # the measurement tool is optional; the bench line is not
-                gather = {"error": str(e)}
-        kernels = [k for k in kernels if k["total_ms"] > 0]
-        kernels.sort(key=lambda k: -k["total_ms"])  # dominant = the most time, each kernel timed alone
+    if ctx.rank == 0:
+        if args.out and m.image is not None:
+            pkg.write_pfm(args.out, m.image)
+        workload = describe(args, m.scene)
+        kernels, working_set, bound, peak, pmc_kernels, pmc_src = kernel_rooflines(m, workload)
+        gather = gather_ceiling(m, working_set, pmc_kernels, pmc_src)
         roofline = dict(kernels[0]) if kernels else {"kernel": None, "bound": bound, "achieved": 0.0, "peak": peak, "unit": "GB/s", "frac": 0.0, "traffic": None}
         roofline["working_set_bytes"] = working_set
         if gather is not None:
@@ -291,24 +403,42 @@ def main():
         roofline["bound_reason"] = (f"BVH + triangle records {working_set / 2**20:.0f} MiB " +
                                     ("fit the 256 MiB Infinity Cache: gathers are served on-die, L2 bandwidth is the ceiling"
                                      if bound == "l2" else "exceed the 256 MiB Infinity Cache: gathers reach HBM"))
-        other_ms = {k: cn[k] for k in ("resolve_ms", "generate_ms", "film_ms")}
+        if hbm is not None:
+            hk, hws, hbound, _, _, _ = kernel_rooflines(hbm, describe(hbm.args, hbm.scene))
+            t = next((k for k in hk if k["kernel"].startswith("k_trace<false>")), None)
+            if t is not None and hbound == "hbm":
+                roofline["hbm_regime"] = {
+                    "kernel": t["kernel"], "workload": describe(hbm.args, hbm.scene), "working_set_bytes": hws, "bound": "hbm",
+                    "achieved": t["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": t["achieved"] / HBM_PEAK_GBS,
+                    "avg_launch_ms": t["avg_launch_ms"], "launches": t["launches"], "algorithmic_bytes_per_launch": t["algorithmic_bytes_per_launch"],
+                    "steps": hbm.steps, "ms_per_step": hbm.elapsed / hbm.steps * 1e3, "Mrays_per_s": hbm.rays / hbm.elapsed / 1e6,
+                    "note": "timed in THIS run (HIP events per launch); algorithmic bytes (SURVEY 8d) / kernel time / 8 TB/s. Algorithmic bytes count "
+                            "every reference node fetch, also those the L2s serve, so this is the north star's roofline fraction, not memory-side traffic"}
+        other_ms = {k: m.cn[k] for k in ("resolve_ms", "generate_ms", "film_ms")}
+        if ctx.world == 1:
+            sharding = "one GPU renders every 16x16 film tile; no gather"
+        else:
+            sharding = (f"16x16 film tiles round-robin over {ctx.world} GPUs, one process per GPU; one packed gather per frame to rank 0 (" +
+                        ("RCCL over xGMI" if ctx.backend == "nccl" else "PRE-FLIGHT: gloo on host copies") + "), overlapped with the next frame")
         result = {
-            "metric": "Mrays/s", "value": rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "metric": "Mrays/s", "value": m.rays / m.elapsed / 1e6, "unit": "Mrays/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": m.elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "samples_per_s": samples / elapsed,
-            "config": {"workload": workload,
-                       "sharding": f"16x16 film tiles round-robin over {world} GPU(s), " + ("RCCL gather to rank 0" if backend == "nccl" else "PRE-FLIGHT: ranks share a GPU, gloo gather of host copies"),
-                       "rays_per_sample": rays / max(1.0, samples), "host_parse_and_bvh_s": t_parse},
+            "samples_per_s": m.samples / m.elapsed,
+            "ranks_seen": dist.get_world_size() if ctx.multi else 1, "per_rank_ms": m.per_rank_ms,
+            "config": {"workload": workload, "sharding": sharding,
+                       "rays_per_sample": m.rays / max(1.0, m.samples), "host_parse_and_bvh_s": m.t_parse},
             "roofline": roofline,
             "roofline_kernels": kernels,
             "kernel_ms_per_step": {**{k["kernel"].split(" ")[0]: k["total_ms"] / args.steps for k in kernels},
                                    **{k[:-3]: v / args.steps for k, v in other_ms.items()}},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(workdir, args)
+        if EMULATED:
+            result["data"] = "synthetic (EMULATED DEVICE: functional check, not a measurement)"
+        if ctx.world == 1 and not args.no_cpu_baseline and not EMULATED:
+            result["cpu_baseline"] = cpu_baseline(m.workdir, args)
         print(json.dumps(result), flush=True)
-    if multi:
+    if ctx.multi:
         dist.barrier()
         dist.destroy_process_group()
 

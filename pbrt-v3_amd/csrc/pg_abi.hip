@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <queue>
 #include <string>
 #include <thread>
 #include <vector>
@@ -36,11 +37,6 @@ int pgSetError(int code, const char *msg) { g_lastError = msg; return code; }
 #ifdef PG_SHADE_PROF  // pg_kernels.hip, experiment build only
 void shade_prof_dump();
 #endif
-#ifdef PG_EXPERIMENT_SORT  // pg_sortexp.hip / pg_traverse.hip, experiment build only
-const int *sortexp_permutation(const DScene &sc, RayQueue q, int which, int mode, int cellBits, hipStream_t s);
-void set_trace_perm(const int *p0, const int *p1);
-const int *sortexp_spatial(const DScene &sc, RayQueue q, int which, int cellBits, hipStream_t s, int **countsOut);
-#endif
 struct DeviceBuffer {
     void *p = nullptr;
     size_t bytes = 0;
@@ -57,6 +53,7 @@ struct DeviceBuffer {
 struct PgScene {
     int device = 0;
     DScene d;
+    TraceConfig trace;  // k_trace's tunables for THIS scene's launches (the exact-fallback retry changes them for one call)
     DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, textures, textured, images, texels, ewaLut, envTables, alphas, triAlpha, triN, triS, uv, materials, lights, distTable, perms, permSums, primes, media, triMediumIn, triMediumOut, sobolMatrices, vdcSobol, vdcSobolInv, noisePerm;
     // work buffers (sized on first render, reused)
     int capacity = 0;
@@ -149,12 +146,40 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         // one BVHAccel's nodes [firstNode, +nn) -> records appended to w; leaf references carry GLOBAL primitive indices
         // (firstPrim + the node's own offset).  Returns the reference of the BVH's root.
         bool badChildren = false;
-        auto buildRecords = [&](int firstNode, int nn, int firstPrim) -> int {
+        // topWanted > 0 (the world BVH only, whose records start at index 0): the interior nodes a ray is most likely to visit get
+        // the first record indices, so that k_trace can keep records [0, nTop) in LDS (DScene::nTop).  They are chosen greedily by
+        // the surface area of their bounds from the root down (the probability that a ray crossing the parent also crosses the
+        // node, the same measure the SAH build minimises): the set is closed under "parent of", at most topWanted records.  The
+        // other records keep their depth-first order behind them.  Record indices are private to k_trace; the reference's node
+        // array, its visiting order and the visit counts do not depend on them.
+        int nTop = 0;
+        auto buildRecords = [&](int firstNode, int nn, int firstPrim, int topWanted) -> int {
             const PgBVHNode *nodes = desc->nodes + firstNode;
             std::vector<int> recIndex((size_t)nn, -1);
             int nInterior = 0;
             const int base = (int)(w.size() / 4);
-            for (int i = 0; i < nn; ++i) if (nodes[i].nprims == 0) recIndex[i] = base + nInterior++;
+            if (topWanted > 0 && nn > 0 && nodes[0].nprims == 0) {
+                auto area = [&](int i) -> double {
+                    const PgBVHNode &b = nodes[i];
+                    const double dx = (double)b.bmax[0] - b.bmin[0], dy = (double)b.bmax[1] - b.bmin[1], dz = (double)b.bmax[2] - b.bmin[2];
+                    const double a = dx * dy + dx * dz + dy * dz;
+                    return a == a ? a : 0.0;
+                };
+                std::priority_queue<std::pair<double, int>> heap;  // largest area first; among equals the later node (any fixed rule will do)
+                heap.push({area(0), 0});
+                while (!heap.empty() && nTop < topWanted) {
+                    const int i = heap.top().second;
+                    heap.pop();
+                    recIndex[i] = base + nTop++;
+                    const int c0 = i + 1, c1 = nodes[i].offset;
+                    if (c0 < nn && c1 > i && c1 < nn) {  // (out-of-range children are reported below)
+                        if (nodes[c0].nprims == 0) heap.push({area(c0), c0});
+                        if (nodes[c1].nprims == 0) heap.push({area(c1), c1});
+                    }
+                }
+                nInterior = nTop;
+            }
+            for (int i = 0; i < nn; ++i) if (nodes[i].nprims == 0 && recIndex[i] < 0) recIndex[i] = base + nInterior++;
             auto refOf = [&](int i) -> int {
                 const PgBVHNode &nd = nodes[i];
                 return nd.nprims == 0 ? recIndex[i] : ~(((firstPrim + nd.offset) << leafBits) | (nd.nprims - 1));
@@ -178,7 +203,8 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
             return nn > 0 ? refOf(0) : TR_NO_ROOT;
         };
         const int nn = desc->n_nodes;
-        const int topRef = buildRecords(0, nn, 0);
+        s->trace = default_trace_config();
+        const int topRef = buildRecords(0, nn, 0, s->trace.topK);
         // object definitions (instancing): each with its own records, root box and root reference
         std::vector<DObject> objs((size_t)(desc->n_objects > 0 ? desc->n_objects : 0));
         for (size_t k = 0; k < objs.size(); ++k) {
@@ -191,7 +217,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
             dobj.firstPrim = o.first_prim;
             dobj.nNodes = o.n_nodes;
             if (o.n_nodes > 0) {
-                dobj.rootRef = buildRecords(o.first_node, o.n_nodes, o.first_prim);
+                dobj.rootRef = buildRecords(o.first_node, o.n_nodes, o.first_prim, 0);
                 for (int c = 0; c < 3; ++c) { dobj.box[c] = desc->nodes[o.first_node].bmin[c]; dobj.box[3 + c] = desc->nodes[o.first_node].bmax[c]; }
             }
         }
@@ -219,19 +245,11 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         if (!w.empty()) HIP_TRY_S(hipMemcpy(s->wnodes.p, w.data(), s->wnodes.bytes, hipMemcpyHostToDevice));
         d.wnodes = (const float4 *)s->wnodes.p;
         d.leafBits = leafBits;
+        d.nTop = nTop;
         if (nn > 0) {
             for (int k = 0; k < 3; ++k) { d.rootBox[k] = desc->nodes[0].bmin[k]; d.rootBox[3 + k] = desc->nodes[0].bmax[k]; }
             d.rootRef = topRef;
         }
-        TraceConfig tc = get_trace_config();
-        if (const char *e = getenv("PG_TRACE_DEPTH")) { int v = atoi(e); if (v >= 0 && v <= 64) tc.depth = v; }
-        if (const char *e = getenv("PG_TRACE_SEG")) { int v = atoi(e); if (v >= 64) tc.segRays = v; }
-        if (const char *e = getenv("PG_TRACE_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) tc.refillAt = v; }
-        if (const char *e = getenv("PG_TRACE_GRID")) { int v = atoi(e); if (v >= 8) tc.gridBlocks = v; }
-        if (const char *e = getenv("PG_TRACE_TRIW")) { int v = atoi(e); if (v >= 0) tc.triW = v; }
-        if (const char *e = getenv("PG_TRACE_MAXACC")) { int v = atoi(e); if (v >= 1 && v <= 4096) tc.maxAccepted = v; }  // tests: provoke the exact fallback
-        if (const char *e = getenv("PG_TRACE_CULLK")) { float v = (float)atof(e); if (v >= 1.f) tc.cullK = v < 3e38f ? v : 3e38f; }  // finite: 0*inf would be NaN
-        set_trace_config(tc);
     }
     // --- triangles: gather vertices into BVH order, 48 B per triangle
     std::vector<float4> tris((size_t)nt * PG_TRI_STRIDE, make_float4(0, 0, 0, 0));
@@ -672,10 +690,10 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
 static void traceClosest(PgScene *s, RayQueue q, float4 *hits, float *tOut, TraceCounters *cn, hipStream_t st) {
     DScene d = s->d;
     d.hitInst = nullptr;  // the unit entry points report primitive, t and barycentrics only
-    launch_closest(d, q, hits, tOut, cn, (int *)s->cursors.p, (int *)s->cullGuard.p, st);
+    launch_closest(d, s->trace, q, hits, tOut, cn, (int *)s->cursors.p, (int *)s->cullGuard.p, st);
 }
 static void traceAnyhit(PgScene *s, RayQueue q, int *occluded, TraceCounters *cn, hipStream_t st) {
-    launch_anyhit(s->d, q, occluded, cn, (int *)s->cursors.p, st);
+    launch_anyhit(s->d, s->trace, q, occluded, cn, (int *)s->cursors.p, st);
 }
 
 // k_trace's early-cull margin is exact while no ray accepts more than TR_MAX_ACCEPTED hits (pg_traverse.hip); otherwise
@@ -706,14 +724,12 @@ static int withExactFallback(PgScene *s, const std::function<int()> &call) {
     s->counters = saved;
     HIP_TRY(hipMemcpy(s->traceCn.p, savedDev, sizeof(savedDev), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->lightTests.p, savedLt.data(), s->lightTests.bytes, hipMemcpyHostToDevice));
-    const TraceConfig cfg = get_trace_config();
-    TraceConfig exact = cfg;
-    exact.cullK = 3e38f;
-    exact.maxAccepted = 0x7fffffff;  // nothing to guard: no far child is culled early any more
-    set_trace_config(exact);
+    const TraceConfig cfg = s->trace;  // per scene: another host thread's scene (pg_render_sharded) keeps its own margin
+    s->trace.cullK = 3e38f;
+    s->trace.maxAccepted = 0x7fffffff;  // nothing to guard: no far child is culled early any more
     s->cullTripped = false;
     st = call();
-    set_trace_config(cfg);
+    s->trace = cfg;
     return st;
 }
 
@@ -799,8 +815,8 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
         if (rd->sobol_log2_resolution < 0 || rd->sobol_log2_resolution > 26 || rd->sobol_resolution != (1 << rd->sobol_log2_resolution))
             return setError(PG_ERR_INVALID, "pg_render: sobol_resolution %d / sobol_log2_resolution %d", rd->sobol_resolution, rd->sobol_log2_resolution);
     }
-    if (rd->sampler == 0 && (!s->d.perms || (5 + 8 * (rd->max_depth + 1) > s->d.nPermDims && s->d.nPermDims < 1000)))
-        return setError(PG_ERR_INVALID, "Halton table has %d dimensions; maxdepth %d needs %d", s->d.nPermDims, rd->max_depth, 5 + 8 * (rd->max_depth + 1));
+    if (rd->sampler == 0 && (!s->d.perms || (5 + 8 * ((long long)rd->max_depth + 1) > s->d.nPermDims && s->d.nPermDims < 1000)))
+        return setError(PG_ERR_INVALID, "Halton table has %d dimensions; maxdepth %d needs %lld", s->d.nPermDims, rd->max_depth, 5 + 8 * ((long long)rd->max_depth + 1));
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t stream = (hipStream_t)streamPtr;
     const int nLocalTiles = tileCount(rd);
@@ -899,15 +915,6 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
 #define PG_TIMED(kind_, st_, launch_) do { if (!timing) { launch_; break; } hipEvent_t a_ = getEvent(s, ev), b_ = getEvent(s, ev + 1); \
         if (!a_ || !b_) return setError(PG_ERR_DEVICE, "hipEventCreate failed"); \
         timed.push_back({ev, kind_}); ev += 2; HIP_TRY(hipEventRecord(a_, st_)); launch_; HIP_TRY(hipEventRecord(b_, st_)); } while (0)
-#ifdef PG_EXPERIMENT_SORT
-    int sortWhat = 0, sortMode = 1, sortBits = 8;  // PG_SORT_RAYS: 1 main rays, 2 shadow rays, 4 MIS rays
-    if (const char *e = getenv("PG_SORT_RAYS")) sortWhat = atoi(e);
-    if (const char *e = getenv("PG_SORT_MODE")) sortMode = atoi(e);
-    if (const char *e = getenv("PG_SORT_BITS")) { int v = atoi(e); if (v >= 1 && v <= 8) sortBits = v; }
-    std::vector<size_t> sortEv;
-#define SORT_TIMED(st_, call_) do { hipEvent_t a_ = getEvent(s, ev), b_ = getEvent(s, ev + 1); sortEv.push_back(ev); ev += 2; \
-        HIP_TRY(hipEventRecord(a_, st_)); call_; HIP_TRY(hipEventRecord(b_, st_)); } while (0)
-#endif
     hipEvent_t evStart = getEvent(s, ev++), evStop = getEvent(s, ev++);
     if (!evStart || !evStop) return setError(PG_ERR_DEVICE, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(evStart, stream));
@@ -934,7 +941,12 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
     uint64_t shadeLaunches = 0, resolveLaunches = 0, shadeItems = 0, misRays = 0;
     std::vector<int> hostCounts;  // read back once per batch at the end (pinned copy not needed: tiny)
     DeviceBuffer countLog;        // per-bounce queue sizes, copied back after the batch for the ray statistics
-    const int maxIters = rd->max_depth + 1 + (s->hasNullMaterial ? 64 : 0);
+    // (64-bit: maxdepth comes from the caller / the scene file.)  Bounce launches are enqueued without looking at the queues, so
+    // a huge maxdepth is bounded here: beyond PG_MAX_BLIND_BOUNCES the host looks at the main queue every 32 bounces and stops
+    // when it is empty (Russian roulette ends every path), and a frame whose paths outlive PG_MAX_BOUNCES fails loudly.
+    const long long PG_MAX_BLIND_BOUNCES = 64, PG_MAX_BOUNCES = 4096;
+    const long long wantIters = (long long)rd->max_depth + 1 + (s->hasNullMaterial ? 64 : 0);
+    const int maxIters = (int)std::min<long long>(wantIters, PG_MAX_BOUNCES);
     HIP_TRY(countLog.alloc(sizeof(int) * 4 * QSTRIDE * (size_t)(maxIters + 1)));
     std::vector<int> curQueueOfBounce;
 
@@ -971,7 +983,7 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                 for (int iter = 0; nMain > 0; ++iter) {
                     if (iter > 100000) return setError(PG_ERR_DEVICE, "pg_render: volpath loop did not terminate");
                     const int nxt = cur ^ 1;
-                    PG_TIMED(0, stream, launch_closest(dv, q[cur], (float4 *)s->hitsMain.p, hitT, cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream));
+                    PG_TIMED(0, stream, launch_closest(dv, s->trace, q[cur], (float4 *)s->hitsMain.p, hitT, cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream));
                     ++closestLaunches; closestRays += nMain; shadeItems += nMain;
                     HIP_TRY(hipMemsetAsync(counts + nxt * QSTRIDE, 0, QSTRIDE * sizeof(int), stream));
                     HIP_TRY(hipMemsetAsync(counts + 2 * QSTRIDE, 0, 2 * QSTRIDE * sizeof(int), stream));
@@ -987,7 +999,7 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                         const uint64_t n0 = tcur == 0 ? queueTotal(blk.data(), 2) : queueTotal(vblk.data(), 0);
                         const uint64_t n1q = tcur == 0 ? queueTotal(blk.data(), 3) : queueTotal(vblk.data(), 1);
                         if (n0 + n1q == 0) break;
-                        PG_TIMED(0, stream, launch_closest2(dv, tq[0][tcur], tq[1][tcur], (float4 *)s->hitsMain.p, n1, cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream, hitT));
+                        PG_TIMED(0, stream, launch_closest2(dv, s->trace, tq[0][tcur], tq[1][tcur], (float4 *)s->hitsMain.p, n1, cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream, hitT));
                         ++closestLaunches; closestRays += n0 + n1q;
                         HIP_TRY(hipMemsetAsync(tq[0][tcur ^ 1].counts, 0, QSTRIDE * sizeof(int), stream));
                         HIP_TRY(hipMemsetAsync(tq[1][tcur ^ 1].counts, 0, QSTRIDE * sizeof(int), stream));
@@ -1010,8 +1022,8 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
             auto timedClosest = [&](RayQueue qa, float4 *ha, const RayQueue *qb, float4 *hb) -> int {
                 hipEvent_t a = nullptr, b = nullptr;
                 if (timing) { a = getEvent(s, ev); b = getEvent(s, ev + 1); timed.push_back({ev, 0}); ev += 2; HIP_TRY(hipEventRecord(a, stream)); }
-                if (qb) launch_closest2(s->d, qa, *qb, ha, (int)(hb - ha), cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream);
-                else launch_closest(s->d, qa, ha, nullptr, cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream);
+                if (qb) launch_closest2(s->d, s->trace, qa, *qb, ha, (int)(hb - ha), cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream);
+                else launch_closest(s->d, s->trace, qa, ha, nullptr, cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream);
                 if (timing) HIP_TRY(hipEventRecord(b, stream));
                 ++closestLaunches;
                 return PG_OK;
@@ -1039,42 +1051,14 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                         HIP_TRY(hipEventRecord(s->evShaded, stream));
                         HIP_TRY(hipStreamWaitEvent(sst, s->evShaded, 0));
                     }
-#ifdef PG_EXPERIMENT_SORT
-                    RayQueue qShadow = q[2];
-                    if (sortWhat & 2) {
-                        const int *pm = nullptr;
-                        if (sortMode == 3) { int *bc = nullptr; SORT_TIMED(sst, pm = sortexp_spatial(s->d, q[2], 0, sortBits, sst, &bc)); if (pm) qShadow.counts = bc; }
-                        else SORT_TIMED(sst, pm = sortexp_permutation(s->d, q[2], 0, sortMode, sortBits, sst));
-                        set_trace_perm(pm, nullptr);
-                    }
-#define PG_Q_SHADOW qShadow
-#else
 #define PG_Q_SHADOW q[2]
-#endif
                     hipEvent_t a = nullptr, b = nullptr;
                     if (timing) { a = getEvent(s, ev); b = getEvent(s, ev + 1); timed.push_back({ev, 1}); ev += 2; HIP_TRY(hipEventRecord(a, sst)); }
-                    launch_anyhit(s->d, PG_Q_SHADOW, (int *)s->occluded.p, cnShadow, (int *)s->cursors2.p, sst);
+                    launch_anyhit(s->d, s->trace, PG_Q_SHADOW, (int *)s->occluded.p, cnShadow, (int *)s->cursors2.p, sst);
                     if (timing) HIP_TRY(hipEventRecord(b, sst));
                     ++shadowLaunches;
                     if (overlap) HIP_TRY(hipEventRecord(s->evShadowed, sst));
-#ifdef PG_EXPERIMENT_SORT
-                    RayQueue qMain = q[nxt], qMisRays = q[3];
-                    if (sortWhat & 5) {
-                        const int *pm0 = nullptr, *pm1 = nullptr;
-                        if (sortMode == 3) {
-                            int *bc = nullptr;
-                            if (sortWhat & 1) { SORT_TIMED(stream, pm0 = sortexp_spatial(s->d, q[nxt], 0, sortBits, stream, &bc)); if (pm0) qMain.counts = bc; }
-                            if (sortWhat & 4) { SORT_TIMED(stream, pm1 = sortexp_spatial(s->d, q[3], 1, sortBits, stream, &bc)); if (pm1) qMisRays.counts = bc; }
-                        } else {
-                            if (sortWhat & 1) SORT_TIMED(stream, pm0 = sortexp_permutation(s->d, q[nxt], 0, sortMode, sortBits, stream));
-                            if (sortWhat & 4) SORT_TIMED(stream, pm1 = sortexp_permutation(s->d, q[3], 1, sortMode, sortBits, stream));
-                        }
-                        set_trace_perm(pm0, pm1);
-                    }
-                    if (int e = timedClosest(qMain, (float4 *)s->hitsMain.p, &qMisRays, hitsMis)) return e;
-#else
                     if (int e = timedClosest(q[nxt], (float4 *)s->hitsMain.p, &q[3], hitsMis)) return e;
-#endif
                     if (overlap) HIP_TRY(hipStreamWaitEvent(stream, s->evShadowed, 0));
                     PG_TIMED(3, stream, launch_resolve(s->d, ps, q[cur], q[3], (const int *)s->occluded.p, (const float4 *)hitsMis, stream, cur));
                     ++resolveLaunches;
@@ -1083,12 +1067,18 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                 HIP_TRY(hipMemcpyAsync((int *)countLog.p + 4 * QSTRIDE * (size_t)bounce, counts, 4 * QSTRIDE * sizeof(int), hipMemcpyDeviceToDevice, stream));
                 curQueueOfBounce.push_back(cur);
                 cur = nxt;
-                if (s->hasNullMaterial && bounce >= rd->max_depth) {
+                if ((s->hasNullMaterial && bounce >= rd->max_depth) || (bounce >= PG_MAX_BLIND_BOUNCES && bounce % 32 == 0)) {
                     std::vector<int> blk(4 * QSTRIDE);
                     HIP_TRY(hipMemcpyAsync(blk.data(), counts, 4 * QSTRIDE * sizeof(int), hipMemcpyDeviceToHost, stream));
                     HIP_TRY(hipStreamSynchronize(stream));
                     if (queueTotal(blk.data(), cur) == 0) { ++iters; break; }
                 }
+            }
+            if (iters == maxIters && wantIters > maxIters) {  // the last allowed bounce: is anything still alive?
+                std::vector<int> blk(4 * QSTRIDE);
+                HIP_TRY(hipMemcpyAsync(blk.data(), counts, 4 * QSTRIDE * sizeof(int), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (queueTotal(blk.data(), cur) != 0) return setError(PG_ERR_UNSUPPORTED, "paths longer than %lld vertices (maxdepth %d)", PG_MAX_BOUNCES, rd->max_depth);
             }
             PG_TIMED(5, stream, filmSamples());
             hostCounts.resize(4 * QSTRIDE * (size_t)iters);
@@ -1189,19 +1179,15 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
 #ifdef PG_SHADE_PROF
     shade_prof_dump();
 #endif
-#ifdef PG_EXPERIMENT_SORT
-    { double sm = 0; for (size_t e : sortEv) { float m = 0; if (hipEventElapsedTime(&m, s->events[e], s->events[e + 1]) == hipSuccess) sm += m; }
-      if (!sortEv.empty()) fprintf(stderr, "pg_render: ray-order experiment: %zu sorts, %.2f ms\n", sortEv.size(), sm); }
-#endif
     float ms = 0;
     if (hipEventElapsedTime(&ms, evStart, evStop) == hipSuccess) c.render_ms += ms;
 #ifdef PG_TRACE_STATS
     {
         unsigned long long st[8];
         HIP_TRY(hipMemcpy(st, (char *)s->cullGuard.p + 2 * sizeof(int), sizeof(st), hipMemcpyDeviceToHost));
-        fprintf(stderr, "k_trace<false> lanes: interior steps %llu (%.1f lanes), triangle steps %llu (%.1f lanes), refills %llu (%.1f lanes), busy lanes per step %.1f\n",
+        fprintf(stderr, "k_trace<false> lanes: interior steps %llu (%.1f lanes), triangle steps %llu (%.1f lanes), refills %llu (%.1f lanes), busy lanes per step %.1f, interior lanes served by the tree top in LDS %.3f\n",
                 st[0], st[0] ? (double)st[1] / st[0] : 0., st[2], st[2] ? (double)st[3] / st[2] : 0., st[4], st[4] ? (double)st[5] / st[4] : 0.,
-                (st[0] + st[2]) ? (double)st[6] / (st[0] + st[2]) : 0.);
+                (st[0] + st[2]) ? (double)st[6] / (st[0] + st[2]) : 0., st[1] ? (double)st[7] / st[1] : 0.);
     }
 #endif
     if (int st2 = checkCullGuard(s)) return st2;
@@ -1217,7 +1203,7 @@ int pg_render_sharded(PgScene *const *scenes, int32_t n, const PgRenderDesc *des
                       int32_t maxStrays, int32_t *nStrays) {
     if (!scenes || n < 1 || !desc || !film || !nStrays || (maxStrays > 0 && !strays)) return setError(PG_ERR_INVALID, "pg_render_sharded: null argument");
     if (desc->tile_first != 0 || desc->tile_step != 1) return setError(PG_ERR_INVALID, "pg_render_sharded: desc must describe the whole frame (tile_first 0, tile_step 1)");
-    for (int r = 0; r < n; ++r) if (!scenes[r] || !film[r] || (maxStrays > 0 && !strays[r])) return setError(PG_ERR_INVALID, "pg_render_sharded: null entry for rank %d", r);
+    for (int r = 0; r < n; ++r) if (!scenes[r] || (maxStrays > 0 && !strays[r])) return setError(PG_ERR_INVALID, "pg_render_sharded: null entry for rank %d", r);
     PgScene *root = scenes[0];
     const size_t strayBytes = sizeof(PgStraySample) * (size_t)(maxStrays > 0 ? maxStrays : 1);
     std::vector<PgRenderDesc> rd((size_t)n, *desc);
@@ -1227,6 +1213,9 @@ int pg_render_sharded(PgScene *const *scenes, int32_t n, const PgRenderDesc *des
         rd[r].tile_first = r; rd[r].tile_step = n;
         filmBytes[r] = sizeof(PgFilmPixel) * (size_t)desc->tile_pixels * (size_t)tileCount(&rd[r]);
         filmOff[r] = total; total += filmBytes[r];
+        // a rank that owns no tile (more devices than tiles: a small image or crop window) has nothing to receive: its film
+        // pointer may be null; it still runs pg_render (which handles an empty shard) so that its counters and stray count are set
+        if (filmBytes[r] && !film[r]) return setError(PG_ERR_INVALID, "pg_render_sharded: null film buffer for rank %d", r);
     }
     const size_t strayOff = total; total += strayBytes * (size_t)n;
     const size_t countOff = total; total += sizeof(int) * (size_t)n;
@@ -1247,7 +1236,8 @@ int pg_render_sharded(PgScene *const *scenes, int32_t n, const PgRenderDesc *des
                 (void)hipGetLastError();
             }
         }
-        if (s->shardFilm.bytes < filmBytes[r] && s->shardFilm.alloc(filmBytes[r]) != hipSuccess) { status[r] = PG_ERR_DEVICE; message[r] = "out of device memory (shard film)"; return; }
+        const size_t filmAlloc = filmBytes[r] ? filmBytes[r] : sizeof(PgFilmPixel);  // never a null buffer, also for an empty shard
+        if (s->shardFilm.bytes < filmAlloc && s->shardFilm.alloc(filmAlloc) != hipSuccess) { status[r] = PG_ERR_DEVICE; message[r] = "out of device memory (shard film)"; return; }
         if (s->shardStrays.bytes < strayBytes && s->shardStrays.alloc(strayBytes) != hipSuccess) { status[r] = PG_ERR_DEVICE; message[r] = "out of device memory (shard strays)"; return; }
         if (!s->shardCount.p && s->shardCount.alloc(sizeof(int)) != hipSuccess) { status[r] = PG_ERR_DEVICE; message[r] = "out of device memory"; return; }
         int st = pg_render(s, &rd[r], (PgFilmPixel *)s->shardFilm.p, (PgStraySample *)s->shardStrays.p, maxStrays, (int32_t *)s->shardCount.p, PG_MEM_DEVICE, nullptr);

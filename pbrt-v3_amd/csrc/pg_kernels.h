@@ -39,6 +39,7 @@ struct DScene {
     float rootBox[6];  // nodes[0].bounds: (min.xyz, max.xyz)
     int rootRef;       // ref of nodes[0]
     int leafBits;
+    int nTop;          // records [0, nTop) are the world BVH's most-visited interior nodes: k_trace keeps them in LDS (TraceConfig::topK)
     // Triangles in BVH order, 48 B each: three float4
     //   t[0] = (p0, flags)  t[1] = (p1, material)  t[2] = (p2, light)
     // stored PG_TRI_STRIDE float4 apart: 4 puts every record into one 64-B line (of 48-B records packed back to back half
@@ -187,14 +188,16 @@ struct TraceCounters {
 // cullK: closest-hit far-child early-cull margin (pg_traverse.hip); exact while a ray's tMax never grows by more than
 // this factor through rounding (each accepted hit can raise it by <= 3 roundings, i.e. ~5000 successive raises).
 // maxAccepted: accepted hits per ray beyond which the margin's proof no longer holds (<= 4096 for cullK = 1 + 2^-10)
-struct TraceConfig { int depth, segRays /* rays per chunk */, refillAt, triW; float cullK; int gridBlocks; int maxAccepted; };
-void set_trace_config(const TraceConfig &c);
-TraceConfig get_trace_config();
-void launch_closest(const DScene &sc, RayQueue q, float4 *hits, float *tOut, TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s);
+struct TraceConfig { int depth, segRays /* rays per chunk */, refillAt, triW; float cullK; int gridBlocks; int maxAccepted;
+                     int topK;  /* child-pair records of the world BVH kept in LDS (DScene::nTop caps it) */ };
+// The defaults, with the PG_TRACE_* environment overrides of experiments and tests applied.  Every scene carries its own copy
+// (PgScene::trace): the exact-fallback retry of one scene must not change what another host thread's launches use.
+TraceConfig default_trace_config();
+void launch_closest(const DScene &sc, const TraceConfig &c, RayQueue q, float4 *hits, float *tOut, TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s);
 // two queues in one launch; q1's results land at hits[hitOffset1 + i]
-void launch_closest2(const DScene &sc, RayQueue q0, RayQueue q1, float4 *hits, int hitOffset1, TraceCounters *cn, int *cursors, int *cullGuard,
+void launch_closest2(const DScene &sc, const TraceConfig &c, RayQueue q0, RayQueue q1, float4 *hits, int hitOffset1, TraceCounters *cn, int *cursors, int *cullGuard,
                      hipStream_t s, float *tOut = nullptr);
-void launch_anyhit(const DScene &sc, RayQueue q, int *occluded, TraceCounters *cn, int *cursors, hipStream_t s);
+void launch_anyhit(const DScene &sc, const TraceConfig &c, RayQueue q, int *occluded, TraceCounters *cn, int *cursors, hipStream_t s);
 void launch_generate(const DScene &sc, const RenderParams &rp, PathState st, RayQueue q, hipStream_t s);
 // tile-serial samplers: seed the tiles' streams; StartPixel for pixel (lx, ly) of every tile; the camera sample + ray of sample
 // `sampleIndex` of that pixel; FilmTile::AddSample of the finished paths

@@ -23,14 +23,21 @@
 //    queue (one atomic per chunk) and refills lanes whose ray has finished, so
 //    lane occupancy does not decay to the longest ray of the first 64;
 //  * traversal stack: first `depth` entries per lane in LDS ([entry][lane],
-//    8 B entries, bank-conflict-free), the rest of pbrt's 64 in scratch.
+//    8 B entries, bank-conflict-free), the rest of pbrt's 64 in scratch;
+//  * tree top in LDS: the `topK` interior records a ray is most likely to visit
+//    (pg_scene_create numbers them first) are copied into the block's LDS once;
+//    a lane whose record is among them reads it there instead of through the
+//    vector L1 -- the kernel is bound by the rate of divergent 64-B record
+//    requests on that path, and every ray starts with a run of these records.
 #include "pg_device.h"
 #include "pg_sphere.h"
 #include <algorithm>
 #include "pg_kernels.h"
 #include "pg_texture.h"
 
+#ifndef TR_BLOCK
 #define TR_BLOCK 256
+#endif
 #define TR_NONE ((int)0x80000000)
 #define TR_STACK_TOTAL 64
 // 256-thread blocks resident per CU = min(8, floor(800 / (ceil(sgpr/16)*16 + 16))) (MI355X_MICROARCH.md): 106 SGPRs admit 6,
@@ -42,6 +49,12 @@
 #define TR_MIN_WAVES 2
 #endif
 #define TR_MAX_ACCEPTED 4096  // (1+2^-24)^(3*4096) < 1+2^-10
+#ifndef TR_DEFAULT_DEPTH
+#define TR_DEFAULT_DEPTH 11
+#endif
+#ifndef TR_DEFAULT_TOPK
+#define TR_DEFAULT_TOPK 0
+#endif
 
 // Bounds3::IntersectP(ray, invDir, dirIsNeg), geometry.h:1412-1438, split into
 // the part that does not depend on ray.tMax (returns ok, tMin) and the final
@@ -104,14 +117,20 @@ template <bool ANYHIT, bool XPRIM>
 __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(DScene sc, RayQueue q0, RayQueue q1, float4 *__restrict__ hits,
                                                     int hitOffset1, float *__restrict__ tOut, int *__restrict__ occluded,
                                                     TraceCounters *cn, int *__restrict__ cursors, int depth, int chunk, int refillAt, int triW,
-                                                    float cullK, int *cullGuard, int maxAccepted
-#ifdef PG_EXPERIMENT_SORT  // make GPUEXTRA=-DPG_EXPERIMENT_SORT: position i of a region takes entry perm[i] (pg_sortexp.hip)
-                                                    , const int *__restrict__ perm0, const int *__restrict__ perm1
-#endif
-                                                    ) {
-    extern __shared__ uint2 ldsStack[];  // [depth][TR_BLOCK]
+                                                    float cullK, int *cullGuard, int maxAccepted, int topK) {
+    extern __shared__ uint2 ldsStack[];  // [depth][TR_BLOCK], then the tree top: topK records of 4 float4
     uint2 spill[TR_STACK_TOTAL];
     const int tid = threadIdx.x;
+    // Tree top: records [0, topK) of the world BVH, 64 B each.  Lanes read DIFFERENT records at once (ds_read_b128, serviced in
+    // groups of 16 lanes over 16 slots of 16 B): piece p of record r sits at slot (p + (r >> 2)) & 3 of the record, so that
+    // the 16-B slot a lane touches, 4 (r & 3) + ((p + (r >> 2)) & 3), is spread over all 16 by the record index instead of over
+    // the 4 that share p (identical records broadcast).
+    float4 *ldsTop = (float4 *)(ldsStack + (size_t)depth * TR_BLOCK);
+    for (int i = tid; i < 4 * topK; i += TR_BLOCK) {
+        const int r = i >> 2, p = i & 3;
+        ldsTop[4 * r + ((p + (r >> 2)) & 3)] = sc.wnodes[i];
+    }
+    if (topK > 0) __syncthreads();
     const int lane = tid & 63;
     const unsigned long long laneLt = (1ull << lane) - 1ull;
     // Work distribution: the queue is PG_REGIONS sub-queues, one per XCD (block b runs on XCD b % 8, and the producers
@@ -141,7 +160,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
     unsigned long long vmask = 0;     // ANYHIT: bit i set = the reference's entry at depth i was culled early
     unsigned int nodeVisits = 0, triTests = 0;
 #ifdef PG_TRACE_STATS  // experiment build only (tools/trace_stats.sh): where the lanes of a wave go
-    unsigned long long stIntSteps = 0, stIntLanes = 0, stTriSteps = 0, stTriLanes = 0, stRefills = 0, stRefillLanes = 0, stBusyLanes = 0;
+    unsigned long long stIntSteps = 0, stIntLanes = 0, stTriSteps = 0, stTriLanes = 0, stRefills = 0, stRefillLanes = 0, stBusyLanes = 0, stTopLanes = 0;
 #endif
     int nAccepted = 0;  // hits accepted by this lane's current ray (bounds the rounding growth of tMax, see cullK below)
     // XPRIM: object instances.  While a lane traverses an instance's BVH its ray registers hold the instance-space ray
@@ -235,9 +254,6 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
                 int idx = next + __popcll(idleMask & laneLt);
                 next += nIdle;
                 if (idle && idx < segEnd) {
-#ifdef PG_EXPERIMENT_SORT
-                    { const int *pm = curQ ? perm1 : perm0; if (pm) idx = pm[idx]; }
-#endif
                     const float4 o4 = curQ ? q1.o[idx] : q0.o[idx], d4 = curQ ? q1.d[idx] : q0.d[idx];
                     ray = idx + (curQ ? hitOffset1 : 0);  // index of this ray's result
                     ox = o4.x; oy = o4.y; oz = o4.z; tMax = o4.w;
@@ -361,9 +377,18 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
                 }
             }
         } else if (cur >= 0) {
-            const float4 *rec = sc.wnodes + 4 * (size_t)cur;
-            const float4 bx = rec[0], by = rec[1], bz = rec[2];
-            const float4 rf = rec[3];
+#ifdef PG_TRACE_STATS
+            stTopLanes += __popcll(__ballot(cur < topK));
+#endif
+            float4 bx, by, bz, rf;
+            if (cur < topK) {  // a resident record: four 16-B LDS reads
+                const float4 *rec = ldsTop + 4 * cur;
+                const int sw = cur >> 2;
+                bx = rec[sw & 3]; by = rec[(sw + 1) & 3]; bz = rec[(sw + 2) & 3]; rf = rec[(sw + 3) & 3];
+            } else {
+                const float4 *rec = sc.wnodes + 4 * (size_t)cur;
+                bx = rec[0]; by = rec[1]; bz = rec[2]; rf = rec[3];
+            }
             float t0, t1;
             const unsigned long long ok0 = slab_mask(bx.x, bx.y, by.x, by.y, bz.x, bz.y, ox, oy, oz, ix, iy, iz, nx, ny, nz, t0);
             const unsigned long long ok1 = slab_mask(bx.z, bx.w, by.z, by.w, bz.z, bz.w, ox, oy, oz, ix, iy, iz, nx, ny, nz, t1);
@@ -414,52 +439,57 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
     if (lane == 0 && cullGuard) {  // closest-hit launches only: 8 counters after the guard word (the experiment allocates them)
         unsigned long long *st = (unsigned long long *)(cullGuard + 2);
         atomicAdd(&st[0], stIntSteps); atomicAdd(&st[1], stIntLanes); atomicAdd(&st[2], stTriSteps); atomicAdd(&st[3], stTriLanes);
-        atomicAdd(&st[4], stRefills); atomicAdd(&st[5], stRefillLanes); atomicAdd(&st[6], stBusyLanes);
+        atomicAdd(&st[4], stRefills); atomicAdd(&st[5], stRefillLanes); atomicAdd(&st[6], stBusyLanes); atomicAdd(&st[7], stTopLanes);
     }
 #endif
 }
 
-static TraceConfig g_cfg = {11, 128, 16, 8, 1.0009765625f, 2048, TR_MAX_ACCEPTED};  // depth 11: 7 resident blocks x 22.5 KB of stack fill the 160 KB LDS
-void set_trace_config(const TraceConfig &c) { g_cfg = c; }
-TraceConfig get_trace_config() { return g_cfg; }
+// depth 11: 7 resident 256-thread blocks x 22.5 KB of stack fill the 160 KB LDS
+TraceConfig default_trace_config() {
+    TraceConfig tc = {TR_DEFAULT_DEPTH, 128, 16, 8, 1.0009765625f, 2048, TR_MAX_ACCEPTED, TR_DEFAULT_TOPK};
+    if (const char *e = getenv("PG_TRACE_DEPTH")) { int v = atoi(e); if (v >= 0 && v <= 64) tc.depth = v; }
+    if (const char *e = getenv("PG_TRACE_SEG")) { int v = atoi(e); if (v >= 64) tc.segRays = v; }
+    if (const char *e = getenv("PG_TRACE_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) tc.refillAt = v; }
+    if (const char *e = getenv("PG_TRACE_GRID")) { int v = atoi(e); if (v >= 8) tc.gridBlocks = v; }
+    if (const char *e = getenv("PG_TRACE_TRIW")) { int v = atoi(e); if (v >= 0) tc.triW = v; }
+    if (const char *e = getenv("PG_TRACE_MAXACC")) { int v = atoi(e); if (v >= 1 && v <= 4096) tc.maxAccepted = v; }  // tests: provoke the exact fallback
+    if (const char *e = getenv("PG_TRACE_CULLK")) { float v = (float)atof(e); if (v >= 1.f) tc.cullK = v < 3e38f ? v : 3e38f; }  // finite: 0*inf would be NaN
+    if (const char *e = getenv("PG_TRACE_TOPK")) { int v = atoi(e); if (v >= 0) tc.topK = v; }
+    // the stack and the tree top share the block's LDS (160 KB per CU, one block must fit in any case)
+    const size_t ldsMax = 160 * 1024;
+    if (sizeof(uint2) * (size_t)tc.depth * TR_BLOCK > ldsMax) tc.depth = (int)(ldsMax / (sizeof(uint2) * TR_BLOCK));
+    const size_t room = ldsMax - sizeof(uint2) * (size_t)tc.depth * TR_BLOCK;
+    if ((size_t)tc.topK * 64 > room) tc.topK = (int)(room / 64);
+    return tc;
+}
 
-#ifdef PG_EXPERIMENT_SORT
-static const int *g_perm[2] = {nullptr, nullptr};
-void set_trace_perm(const int *p0, const int *p1) { g_perm[0] = p0; g_perm[1] = p1; }  // applies to the next launch only
-#define TR_PERM_ARGS , g_perm[0], g_perm[1]
-#else
-#define TR_PERM_ARGS
-#endif
 template <bool ANYHIT>
-static void launch_trace(const DScene &sc, RayQueue q0, RayQueue q1, float4 *hits, int hitOffset1, float *tOut, int *occluded,
+static void launch_trace(const DScene &sc, const TraceConfig &c, RayQueue q0, RayQueue q1, float4 *hits, int hitOffset1, float *tOut, int *occluded,
                          TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s) {
-    const TraceConfig c = g_cfg;
     if (q0.regionCap <= 0) return;
-    // persistent grid: enough blocks to fill 256 CUs at 8 blocks each, never more than the queues can feed
+    // persistent grid: enough blocks to fill 256 CUs (gridBlocks counts 256-thread blocks), never more than the queues can feed
     long long need = ((long long)(q0.regionCap + q1.regionCap) * PG_REGIONS + c.segRays - 1) / c.segRays;  // chunks
-    int nblk = (int)std::min<long long>((need + TR_BLOCK / 64 - 1) / (TR_BLOCK / 64), (long long)c.gridBlocks);
+    int nblk = (int)std::min<long long>((need + TR_BLOCK / 64 - 1) / (TR_BLOCK / 64), (long long)c.gridBlocks * 256 / TR_BLOCK);
     nblk = ((nblk + 7) / 8) * 8;
-    size_t lds = sizeof(uint2) * (size_t)c.depth * TR_BLOCK;
+    const int topK = std::min(c.topK, sc.nTop);
+    size_t lds = sizeof(uint2) * (size_t)c.depth * TR_BLOCK + 64 * (size_t)topK;
     (void)hipMemsetAsync(cursors, 0, 2 * PG_REGIONS * PG_COUNT_STRIDE * sizeof(int), s);
     // scenes without spheres and object instances run the triangle-only instantiation
     if (sc.nSpheres > 0 || sc.nInstances > 0 || sc.hasAlpha)
         hipLaunchKernelGGL((k_trace<ANYHIT, true>), dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q0, q1, hits, hitOffset1, tOut, occluded, cn, cursors,
-                           c.depth, c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard, c.maxAccepted TR_PERM_ARGS);
+                           c.depth, c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard, c.maxAccepted, topK);
     else
         hipLaunchKernelGGL((k_trace<ANYHIT, false>), dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q0, q1, hits, hitOffset1, tOut, occluded, cn, cursors,
-                           c.depth, c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard, c.maxAccepted TR_PERM_ARGS);
-#ifdef PG_EXPERIMENT_SORT
-    g_perm[0] = g_perm[1] = nullptr;
-#endif
+                           c.depth, c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard, c.maxAccepted, topK);
 }
 static RayQueue noQueue() { RayQueue q; q.o = q.d = nullptr; q.counts = nullptr; q.regionCap = 0; return q; }
-void launch_closest(const DScene &sc, RayQueue q, float4 *hits, float *tOut, TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s) {
-    launch_trace<false>(sc, q, noQueue(), hits, 0, tOut, nullptr, cn, cursors, cullGuard, s);
+void launch_closest(const DScene &sc, const TraceConfig &c, RayQueue q, float4 *hits, float *tOut, TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s) {
+    launch_trace<false>(sc, c, q, noQueue(), hits, 0, tOut, nullptr, cn, cursors, cullGuard, s);
 }
-void launch_closest2(const DScene &sc, RayQueue q0, RayQueue q1, float4 *hits, int hitOffset1, TraceCounters *cn, int *cursors, int *cullGuard,
+void launch_closest2(const DScene &sc, const TraceConfig &c, RayQueue q0, RayQueue q1, float4 *hits, int hitOffset1, TraceCounters *cn, int *cursors, int *cullGuard,
                      hipStream_t s, float *tOut) {
-    launch_trace<false>(sc, q0, q1, hits, hitOffset1, tOut, nullptr, cn, cursors, cullGuard, s);
+    launch_trace<false>(sc, c, q0, q1, hits, hitOffset1, tOut, nullptr, cn, cursors, cullGuard, s);
 }
-void launch_anyhit(const DScene &sc, RayQueue q, int *occluded, TraceCounters *cn, int *cursors, hipStream_t s) {
-    launch_trace<true>(sc, q, noQueue(), nullptr, 0, nullptr, occluded, cn, cursors, nullptr, s);
+void launch_anyhit(const DScene &sc, const TraceConfig &c, RayQueue q, int *occluded, TraceCounters *cn, int *cursors, hipStream_t s) {
+    launch_trace<true>(sc, c, q, noQueue(), nullptr, 0, nullptr, occluded, cn, cursors, nullptr, s);
 }

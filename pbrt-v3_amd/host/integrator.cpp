@@ -549,7 +549,12 @@ void GpuPathIntegrator::Render(const Scene &scene) {
         for (int r = 1; r < n; ++r) threads.emplace_back(create, r);
         create(0);
         for (auto &t : threads) t.join();
-        for (int r = 0; r < n; ++r) if (!dev[r]) { Error("pg_scene_create on device %d: %s", devices[r], err[r].c_str()); Fatal(); }
+        for (int r = 0; r < n; ++r)
+            if (!dev[r]) {  // the scenes that were created on the other devices go before the error unwinds (Fatal is an exception at the C ABI)
+                Error("pg_scene_create on device %d: %s", devices[r], err[r].c_str());
+                for (PgScene *d : dev) if (d) gpuApi.scene_destroy(d);
+                Fatal();
+            }
     }
     std::vector<std::vector<PgFilmPixel>> film((size_t)n);
     std::vector<std::vector<PgStraySample>> strays((size_t)n);

@@ -124,3 +124,26 @@ def test_two_rank_bench_step_on_emulated_devices(emulated, pkg, tmp_path):
     single = str(tmp_path / "one_rank.npy")
     mp.spawn(_rank, args=(1, 29562, emulated, name, single), nprocs=1, join=True)
     assert np.array_equal(img, np.load(single))
+
+
+def test_bench_launches_its_own_ranks_on_emulated_devices(emulated, pkg, tmp_path):
+    """`python bench.py --gpus 2` exactly as the driver calls it -- no torchrun around it, WORLD_SIZE unset: the script starts its two
+    ranks itself, each renders its tile shard on its own (emulated) device, ONE packed gather per frame (double-buffered, overlapping
+    the next frame) brings the shards to rank 0, and the JSON line reports both ranks.  The image equals the one-rank run bit for bit."""
+    import json
+    import numpy as np
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PBRT_GPU_LIB=emulated, PBRT_EMULATED_DEVICE="1")
+    images = {}
+    for n in (2, 1):
+        out = str(tmp_path / f"bench{n}.pfm")
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--workload", "cornell",
+                            "--xres", "40", "--yres", "24", "--spp", "4", "--out", out], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, (p.stdout + p.stderr)[-2000:]
+        line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["n_gpus"] == n and line["ranks_seen"] == n and len(line["per_rank_ms"]) == n and line["steps"] == 2
+        assert ("gather" in line["config"]["sharding"]) == (n > 1) or "no gather" in line["config"]["sharding"]
+        images[n] = pkg.read_pfm(out)
+    assert np.array_equal(images[1], images[2])
+    ref = pkg.read_pfm(os.path.join(ROOT, "tests", "golden", "cornell_40x24.pfm"))
+    assert images[1].shape == ref.shape

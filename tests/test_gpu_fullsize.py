@@ -175,3 +175,31 @@ def test_native_sharded_render_equals_single_device(gpu, tmp_path):
         assert p.returncode == 0, p.stdout + p.stderr
     assert np.array_equal(gpu.read_pfm(str(tmp_path / "one.pfm")), gpu.read_pfm(str(tmp_path / "two.pfm")))
     assert np.array_equal(gpu.read_pfm(str(tmp_path / "one.pfm")), whole)
+
+
+def test_sharded_render_with_more_devices_than_tiles(gpu, tmp_path):
+    """More shards than film tiles (a 24x16 image is two 16x16 tiles; four shards): the ranks that own no tile take part with an
+    empty film, the merged frame equals the single-device render bit for bit -- from Python (empty arrays) and through the CLI,
+    whose empty std::vector hands pg_render_sharded a null film pointer for those ranks (ADVICE r02)."""
+    import subprocess
+    text = (open(os.path.join(ROOT, "tests", "golden", "cornell_40x24.pbrt")).read()
+            .replace('"integer xresolution" [ 40 ]', '"integer xresolution" [ 24 ]').replace('"integer yresolution" [ 24 ]', '"integer yresolution" [ 16 ]'))
+    assert '[ 24 ]' in text and '[ 16 ]' in text
+    path = str(tmp_path / "tiny.pbrt")
+    open(path, "w").write(text)
+    scene = gpu.HostScene(path)
+    whole, _ = gpu.render_scene(scene)
+    rd = scene.render_desc()
+    scenes = [gpu.GpuScene(scene.desc, device=0) for _ in range(4)]
+    shards = gpu.render_sharded(scenes, rd)
+    assert [len(f) for _, f, _ in shards] == [256, 256, 0, 0]
+    scene.film_clear()
+    for srd, film, strays in shards:
+        scene.film_merge(srd, film, strays)
+    assert np.array_equal(scene.film_image(), whole)
+    for s in scenes:
+        s.close()
+    exe = os.path.join(ROOT, "pbrt-v3_amd", "pbrt_amd")
+    p = subprocess.run([exe, "--quiet", "--gpu-ids", "0,0,0,0", "--outfile", str(tmp_path / "four.pfm"), path], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert np.array_equal(gpu.read_pfm(str(tmp_path / "four.pfm")), whole)

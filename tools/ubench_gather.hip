@@ -98,6 +98,102 @@ __global__ void k_fill(float4 *table, size_t n4) {  // distinct small integers p
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n4) table[i] = make_float4((float)((4 * i) % 251), (float)((4 * i + 1) % 241), (float)((4 * i + 2) % 239), (float)((4 * i + 3) % 233));
 }
+
+// Round 3 questions: what would k_trace gain from (i) serving a fraction of its record fetches from an LDS-resident
+// table (the top of the tree), (ii) 8 instead of 7 waves per SIMD, (iii) 32-B half records?  Same chain-chasing loop as above;
+//   frac256 / 256 of the steps read a record of an LDS table of `ldsRecs` records (swizzled as in pg_traverse.hip: piece p of
+//   record r at slot (p + (r >> 2)) & 3) instead of the global table; REC16 = 16-B pieces per global record (4 = 64 B, 2 = 32 B).
+template <int REC16>
+__global__ __launch_bounds__(256) void k_gather_lds(const float4 *__restrict__ table, unsigned n, int iters, float *out, int ldsRecs, unsigned frac256) {
+    extern __shared__ float4 ldsTab[];
+    for (int i = threadIdx.x; i < 4 * ldsRecs; i += 256) { const int r = i >> 2, p = i & 3; ldsTab[4 * r + ((p + (r >> 2)) & 3)] = table[i]; }
+    __syncthreads();
+    unsigned idx = next_index(blockIdx.x * 256u + threadIdx.x, make_float4(0, 0, 0, 0), n);
+    float acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        float4 a, b, c, d;
+        const bool fromLds = ((idx * 2654435761u) >> 24) < frac256;
+        if (fromLds) {
+            const unsigned r = idx % (unsigned)ldsRecs, sw = r >> 2;
+            const float4 *rec = ldsTab + 4 * r;
+            a = rec[sw & 3]; b = rec[(sw + 1) & 3]; c = rec[(sw + 2) & 3]; d = rec[(sw + 3) & 3];
+        } else {
+            const float4 *rec = table + 4 * (size_t)idx;
+            a = rec[0]; b = rec[1];
+            if (REC16 == 4) { c = rec[2]; d = rec[3]; } else { c = a; d = b; }
+        }
+        acc += (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w) + (c.x + c.y + c.z + c.w) + (d.x + d.y + d.z + d.w);
+        idx = next_index(idx, a, n);
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+template <int REC16>
+static double run_lds(const float4 *table, unsigned n, int iters, float *out, int blocks, int ldsRecs, unsigned frac256, size_t ldsBytes) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    CHECK(hipFuncSetAttribute((const void *)k_gather_lds<REC16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(k_gather_lds<REC16>, dim3(blocks), dim3(256), ldsBytes, 0, table, n, 8, out, ldsRecs, frac256);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_gather_lds<REC16>, dim3(blocks), dim3(256), ldsBytes, 0, table, n, iters, out, ldsRecs, frac256);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms;
+}
+// --calib: one launch of the 64-B record gather (mode A) and one coalesced 16 B / lane streaming read of the same table, each with an
+// exactly known byte count, for calibrating rocprofv3's FETCH_SIZE on this access pattern (tools/pmc_calibrate.sh).
+__global__ __launch_bounds__(256) void k_stream(const float4 *__restrict__ table, size_t n4, float *out) {
+    float acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) { const float4 v = table[i]; acc += v.x + v.y + v.z + v.w; }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+static void calib(size_t mb, float *out) {
+    const unsigned n = (unsigned)(mb * 1024 * 1024 / 64);
+    const int blocks = 256 * 7, iters = 512;
+    float4 *table;
+    CHECK(hipMalloc(&table, (size_t)n * 64));
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)(((size_t)n * 4 + 255) / 256)), dim3(256), 0, 0, table, (size_t)n * 4);
+    hipLaunchKernelGGL(k_gather<0>, dim3(blocks), dim3(256), 0, 0, table, n, iters, out);
+    hipLaunchKernelGGL(k_stream, dim3(blocks), dim3(256), 0, 0, table, (size_t)n * 4, out);
+    CHECK(hipDeviceSynchronize());
+    printf("{\"table_MiB\": %zu, \"gather_requested_bytes\": %.0f, \"stream_bytes\": %.0f}\n", mb, (double)blocks * 256 * iters * 64, (double)n * 64);
+    CHECK(hipFree(table));
+}
+// --predict: the table profiles/r03*_gather_predictions.txt is made of.  Rates are record fetches per second (LDS-served ones included).
+static void predict(const std::vector<size_t> &sizesMB, float *out) {
+    const int iters = 512;
+    for (size_t mb : sizesMB) {
+        const unsigned n = (unsigned)(mb * 1024 * 1024 / 64);
+        float4 *table;
+        CHECK(hipMalloc(&table, (size_t)n * 64));
+        hipLaunchKernelGGL(k_fill, dim3((unsigned)(((size_t)n * 4 + 255) / 256)), dim3(256), 0, 0, table, (size_t)n * 4);
+        printf("table %zu MB, 64-B records unless noted; G records / s\n", mb);
+        // (blocks per CU, LDS bytes per block incl. a stack stand-in that only sets the occupancy, records in LDS)
+        struct Geo { int perCU; size_t lds; int recs; const char *what; } geos[] = {
+            {7, 22 * 1024 + 512, 1, "7 blocks/CU (28 waves), no tree top"},
+            {8, 19 * 1024, 1, "8 blocks/CU (32 waves), no tree top"},
+            {6, 26 * 1024, 1, "6 blocks/CU (24 waves), no tree top"},
+            {7, 22 * 1024 + 512, 127, "7 blocks/CU, 127 records (8 KB) in LDS"},
+            {6, 26 * 1024, 255, "6 blocks/CU, 255 records (16 KB) in LDS"},
+            {4, 40 * 1024, 511, "4 blocks/CU (16 waves), 511 records (32 KB) in LDS"},
+        };
+        for (const Geo &g : geos) {
+            const int blocks = 256 * g.perCU;
+            const double fetches = (double)blocks * 256 * iters;
+            printf("  %-52s", g.what);
+            for (unsigned f : {0u, 64u, 102u, 128u, 154u}) {
+                if (g.recs == 1 && f > 0) continue;
+                const double ms = run_lds<4>(table, n, iters, out, blocks, g.recs, f, g.lds);
+                printf(" | LDS %2.0f%%: %6.1f", f / 2.56, fetches / ms * 1e-6);
+            }
+            if (g.recs == 1) { const double ms = run_lds<2>(table, n, iters, out, blocks, g.recs, 0, g.lds); printf(" | 32-B records: %6.1f", fetches / ms * 1e-6); }
+            printf("\n");
+        }
+        CHECK(hipFree(table));
+    }
+}
 static double g_checksum[8];
 template <int MODE>
 static double run(const float4 *table, unsigned n, int iters, float *out, int blocks) {
@@ -122,15 +218,19 @@ static double run(const float4 *table, unsigned n, int iters, float *out, int bl
 int main(int argc, char **argv) {
     // usage: ubench_gather [--json] [table sizes in MiB ...]   (default: L2-resident, config 3's working set, the 5 M / 10 M-triangle sets)
     const int blocks = 256 * 7, iters = 512;
-    bool json = false;
+    bool json = false, doPredict = false, doCalib = false;
     std::vector<size_t> sizesMB;
     for (int i = 1; i < argc; ++i) {
         if (std::string(argv[i]) == "--json") json = true;
+        else if (std::string(argv[i]) == "--predict") doPredict = true;
+        else if (std::string(argv[i]) == "--calib") doCalib = true;
         else sizesMB.push_back((size_t)atol(argv[i]));
     }
     if (sizesMB.empty()) sizesMB = {2, 24, 91, 459, 925};
     float *out;
-    CHECK(hipMalloc(&out, sizeof(float) * 256 * blocks));
+    CHECK(hipMalloc(&out, sizeof(float) * 256 * 256 * 8));
+    if (doPredict) { predict(sizesMB, out); return 0; }
+    if (doCalib) { for (size_t mb : sizesMB) calib(mb, out); return 0; }
     if (json) printf("{");
     bool first = true;
     for (size_t mb : sizesMB) {
