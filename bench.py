@@ -241,10 +241,14 @@ def describe(args, scene):
     integ = "VolPathIntegrator + HomogeneousMedium" if args.workload.endswith("-vol") else "PathIntegrator"
     what = {"cornell": "Cornell box, 36 triangles"}.get(args.workload)
     if what is None:
-        kind = ("instanced PLY meshes, image / alpha textures, 6-material palette" if args.workload.startswith("divergent")
-                else "synthetic heightfield-in-a-box")
-        n = scene.desc.n_tris if not args.workload.startswith("divergent") else scene.desc.n_prims_all
-        what = f"{kind}, {n} triangles" + (f" ({scene.desc.n_instances} object instances)" if scene.desc.n_instances else "")
+        d = scene.desc
+        if args.workload.startswith("divergent"):
+            unique = max(d.n_tris, d.n_prims_all)
+            inst = sum(d.objects[d.instances[i].object].n_prims for i in range(d.n_instances))
+            what = (f"PLY meshes under {d.n_instances} object instances ({d.n_tris - d.n_instances + inst} triangles after instancing, {unique - d.n_instances} unique), "
+                    "image / bump / alpha-mask textures, 8-material palette, environment + area light")
+        else:
+            what = f"synthetic heightfield-in-a-box, {d.n_tris} triangles"
     return f"{what}, {integ} maxdepth 5, halton, {args.filter} filter, {args.xres}x{args.yres} @ {args.spp} spp"
 
 

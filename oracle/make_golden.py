@@ -16,6 +16,7 @@ ROOT = os.path.dirname(HERE)
 GOLD = os.path.join(ROOT, "tests", "golden")
 sys.path.insert(0, os.path.join(ROOT, "scenes"))
 import gen_synthetic  # noqa: E402
+import gen_divergent  # noqa: E402
 
 CORNELL = open(os.path.join(ROOT, "scenes", "cornell.pbrt")).read()
 
@@ -889,6 +890,14 @@ def main():
         p = os.path.join(GOLD, "synthetic_n40.pbrt")
         gen_synthetic.write_scene(p, n=40, xres=48, yres=27, spp=4, filename="synthetic_n40.pfm")
         run("synthetic_n40", p)
+    # the stand-ins of BASELINE.json configs 4 / 5 (scenes/gen_divergent.py) in miniature: PLY meshes with normals and uv under 100+ object
+    # instances, image / bump textures, an alpha-masked card mesh (a plain image map: k_trace's inline mask path), eight materials,
+    # environment + area light; "_vol": inside a HomogeneousMedium under volpath.  Assets: tests/golden/div_*.ply / .png / .pfm
+    for name, vol in (("divergent_small", False), ("divergent_small_vol", True)):
+        if only and name not in only: continue
+        p = os.path.join(GOLD, name + ".pbrt")
+        gen_divergent.write_scene(p, tris=6000, xres=48, yres=27, spp=4, volumetric=vol, filename=name + ".pfm", n_defs=6, tex_res=64, prefix="div_")
+        run(name, p)
     # full-size geometry of BASELINE.json config 3 (999 710 triangles) at a small resolution: the 40 MB scene file is
     # regenerated by scenes/gen_synthetic.py at test time, only the reference's image and statistics are committed
     if not only or "synthetic_1m" in only:

@@ -9,7 +9,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
-#include <queue>
 #include <string>
 #include <thread>
 #include <vector>
@@ -54,7 +53,7 @@ struct PgScene {
     int device = 0;
     DScene d;
     TraceConfig trace;  // k_trace's tunables for THIS scene's launches (the exact-fallback retry changes them for one call)
-    DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, textures, textured, images, texels, ewaLut, envTables, alphas, triAlpha, triN, triS, uv, materials, lights, distTable, perms, permSums, primes, media, triMediumIn, triMediumOut, sobolMatrices, vdcSobol, vdcSobolInv, noisePerm;
+    DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, textures, textured, images, texels, ewaLut, envTables, alphas, alphaTex, triAlpha, triN, triS, uv, materials, lights, distTable, perms, permSums, primes, media, triMediumIn, triMediumOut, sobolMatrices, vdcSobol, vdcSobolInv, noisePerm;
     // work buffers (sized on first render, reused)
     int capacity = 0;
     DeviceBuffer qo[4], qd[4], counts, hitsMain, hitInst, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
@@ -146,40 +145,12 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         // one BVHAccel's nodes [firstNode, +nn) -> records appended to w; leaf references carry GLOBAL primitive indices
         // (firstPrim + the node's own offset).  Returns the reference of the BVH's root.
         bool badChildren = false;
-        // topWanted > 0 (the world BVH only, whose records start at index 0): the interior nodes a ray is most likely to visit get
-        // the first record indices, so that k_trace can keep records [0, nTop) in LDS (DScene::nTop).  They are chosen greedily by
-        // the surface area of their bounds from the root down (the probability that a ray crossing the parent also crosses the
-        // node, the same measure the SAH build minimises): the set is closed under "parent of", at most topWanted records.  The
-        // other records keep their depth-first order behind them.  Record indices are private to k_trace; the reference's node
-        // array, its visiting order and the visit counts do not depend on them.
-        int nTop = 0;
-        auto buildRecords = [&](int firstNode, int nn, int firstPrim, int topWanted) -> int {
+        auto buildRecords = [&](int firstNode, int nn, int firstPrim) -> int {
             const PgBVHNode *nodes = desc->nodes + firstNode;
             std::vector<int> recIndex((size_t)nn, -1);
             int nInterior = 0;
             const int base = (int)(w.size() / 4);
-            if (topWanted > 0 && nn > 0 && nodes[0].nprims == 0) {
-                auto area = [&](int i) -> double {
-                    const PgBVHNode &b = nodes[i];
-                    const double dx = (double)b.bmax[0] - b.bmin[0], dy = (double)b.bmax[1] - b.bmin[1], dz = (double)b.bmax[2] - b.bmin[2];
-                    const double a = dx * dy + dx * dz + dy * dz;
-                    return a == a ? a : 0.0;
-                };
-                std::priority_queue<std::pair<double, int>> heap;  // largest area first; among equals the later node (any fixed rule will do)
-                heap.push({area(0), 0});
-                while (!heap.empty() && nTop < topWanted) {
-                    const int i = heap.top().second;
-                    heap.pop();
-                    recIndex[i] = base + nTop++;
-                    const int c0 = i + 1, c1 = nodes[i].offset;
-                    if (c0 < nn && c1 > i && c1 < nn) {  // (out-of-range children are reported below)
-                        if (nodes[c0].nprims == 0) heap.push({area(c0), c0});
-                        if (nodes[c1].nprims == 0) heap.push({area(c1), c1});
-                    }
-                }
-                nInterior = nTop;
-            }
-            for (int i = 0; i < nn; ++i) if (nodes[i].nprims == 0 && recIndex[i] < 0) recIndex[i] = base + nInterior++;
+            for (int i = 0; i < nn; ++i) if (nodes[i].nprims == 0) recIndex[i] = base + nInterior++;
             auto refOf = [&](int i) -> int {
                 const PgBVHNode &nd = nodes[i];
                 return nd.nprims == 0 ? recIndex[i] : ~(((firstPrim + nd.offset) << leafBits) | (nd.nprims - 1));
@@ -204,7 +175,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         };
         const int nn = desc->n_nodes;
         s->trace = default_trace_config();
-        const int topRef = buildRecords(0, nn, 0, s->trace.topK);
+        const int topRef = buildRecords(0, nn, 0);
         // object definitions (instancing): each with its own records, root box and root reference
         std::vector<DObject> objs((size_t)(desc->n_objects > 0 ? desc->n_objects : 0));
         for (size_t k = 0; k < objs.size(); ++k) {
@@ -217,7 +188,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
             dobj.firstPrim = o.first_prim;
             dobj.nNodes = o.n_nodes;
             if (o.n_nodes > 0) {
-                dobj.rootRef = buildRecords(o.first_node, o.n_nodes, o.first_prim, 0);
+                dobj.rootRef = buildRecords(o.first_node, o.n_nodes, o.first_prim);
                 for (int c = 0; c < 3; ++c) { dobj.box[c] = desc->nodes[o.first_node].bmin[c]; dobj.box[3 + c] = desc->nodes[o.first_node].bmax[c]; }
             }
         }
@@ -245,7 +216,6 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         if (!w.empty()) HIP_TRY_S(hipMemcpy(s->wnodes.p, w.data(), s->wnodes.bytes, hipMemcpyHostToDevice));
         d.wnodes = (const float4 *)s->wnodes.p;
         d.leafBits = leafBits;
-        d.nTop = nTop;
         if (nn > 0) {
             for (int k = 0; k < 3; ++k) { d.rootBox[k] = desc->nodes[0].bmin[k]; d.rootBox[3 + k] = desc->nodes[0].bmax[k]; }
             d.rootRef = topRef;
@@ -540,6 +510,31 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
             HIP_TRY_S(hipMemcpy(s->triAlpha.p, desc->tri_alpha, s->triAlpha.bytes, hipMemcpyHostToDevice));
         }
         d.alphas = (const PgAlphaMask *)s->alphas.p; d.triAlpha = (const int *)s->triAlpha.p; d.hasAlpha = anyAlpha ? 1 : 0;
+        if (anyAlpha) {  // the masks in DAlphaTex form, if every one of them is a constant or a float image map under a (u, v) mapping
+            std::vector<DAlphaTex> at((size_t)desc->n_alphas * 2);
+            bool simple = getenv("PG_ALPHA_GENERAL") == nullptr;  // (tests: force the general evaluator)
+            for (int k = 0; k < desc->n_alphas && simple; ++k)
+                for (int which = 0; which < 2; ++which) {
+                    const PgAlphaMask &am = desc->alphas[k];
+                    const PgTexRef &r = which ? am.shadow_alpha : am.alpha;
+                    DAlphaTex &a = at[2 * (size_t)k + which];
+                    memset(&a, 0, sizeof(a));
+                    if (!(which ? am.has_shadow_alpha : am.has_alpha)) { a.image = -2; continue; }
+                    if (r.tex < 0) { a.image = -1; a.constant = r.v[0]; continue; }
+                    const PgTexture &tx = desc->textures[r.tex];
+                    if (tx.type != PG_TEX_IMAGEMAP || tx.mapping != PG_MAP_UV || tx.image < 0 || tx.image >= desc->n_images) { simple = false; break; }
+                    const PgImage &im = desc->images[tx.image];
+                    // (27 levels: beyond that MIPMap::Lookup's trilinear branch no longer lands on level 0 for a zero filter width)
+                    if (!im.is_float || im.n_levels < 1 || im.n_levels > 26 || im.width < 1 || im.height < 1) { simple = false; break; }
+                    a.su = tx.su; a.sv = tx.sv; a.du = tx.du; a.dv = tx.dv;
+                    a.width = im.width; a.height = im.height; a.wrap = im.wrap; a.image = tx.image; a.offset = im.level_offset[0];
+                }
+            if (simple) {
+                HIP_TRY_S(s->alphaTex.alloc(sizeof(DAlphaTex) * at.size()));
+                HIP_TRY_S(hipMemcpy(s->alphaTex.p, at.data(), s->alphaTex.bytes, hipMemcpyHostToDevice));
+                d.alphaTex = (const DAlphaTex *)s->alphaTex.p;
+            }
+        }
     }
     {  // participating media (HomogeneousMedium) and the primitives' MediumInterfaces
         s->nMedia = desc->n_media > 0 ? desc->n_media : 0;
@@ -1181,15 +1176,6 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
 #endif
     float ms = 0;
     if (hipEventElapsedTime(&ms, evStart, evStop) == hipSuccess) c.render_ms += ms;
-#ifdef PG_TRACE_STATS
-    {
-        unsigned long long st[8];
-        HIP_TRY(hipMemcpy(st, (char *)s->cullGuard.p + 2 * sizeof(int), sizeof(st), hipMemcpyDeviceToHost));
-        fprintf(stderr, "k_trace<false> lanes: interior steps %llu (%.1f lanes), triangle steps %llu (%.1f lanes), refills %llu (%.1f lanes), busy lanes per step %.1f, interior lanes served by the tree top in LDS %.3f\n",
-                st[0], st[0] ? (double)st[1] / st[0] : 0., st[2], st[2] ? (double)st[3] / st[2] : 0., st[4], st[4] ? (double)st[5] / st[4] : 0.,
-                (st[0] + st[2]) ? (double)st[6] / (st[0] + st[2]) : 0., st[1] ? (double)st[7] / st[1] : 0.);
-    }
-#endif
     if (int st2 = checkCullGuard(s)) return st2;
     if (hostNStrays > maxStrays) return setError(PG_ERR_OVERFLOW, "%d stray samples, buffer holds %d", hostNStrays, maxStrays);
     return PG_OK;

@@ -12,6 +12,19 @@
 #endif
 #define PG_TRI_BOGUS 0x100u  // Triangle::Intersect rejects every hit (triangle.cpp:309-317)
 
+// An alpha / shadow-alpha mask that is a constant or a plain float image map under a (u, v) mapping -- what cut-out foliage uses --
+// flattened for k_trace: without ray differentials both of MIPMap::Lookup's filters reduce to the bilinear `triangle` lookup on
+// level 0 (mipmap.h:245-251 with width 0; :263 minorLength == 0), so the traversal kernel evaluates four texels inline instead
+// of calling the general texture evaluator (whose registers and scratch every ray of the kernel would pay for).
+struct DAlphaTex {
+    float su, sv, du, dv;  // UVMapping2D
+    int width, height;     // level 0 of the MIPMap<Float>
+    int wrap;              // ImageWrap: 0 repeat, 1 black, 2 clamp
+    int image;             // -1: the constant `constant`; -2: no such mask; >= 0: image map (texels at `offset`, in floats)
+    long long offset;
+    float constant;
+    int pad;
+};
 // One object definition (instancing) on the device: its BVHAccel's root, or its lone primitive when nNodes == 0.
 struct DObject { float box[6]; int rootRef; int firstPrim; int nNodes; int pad; };
 #define TR_NO_ROOT 0x7fffffff
@@ -39,7 +52,6 @@ struct DScene {
     float rootBox[6];  // nodes[0].bounds: (min.xyz, max.xyz)
     int rootRef;       // ref of nodes[0]
     int leafBits;
-    int nTop;          // records [0, nTop) are the world BVH's most-visited interior nodes: k_trace keeps them in LDS (TraceConfig::topK)
     // Triangles in BVH order, 48 B each: three float4
     //   t[0] = (p0, flags)  t[1] = (p1, material)  t[2] = (p2, light)
     // stored PG_TRI_STRIDE float4 apart: 4 puts every record into one 64-B line (of 48-B records packed back to back half
@@ -64,6 +76,9 @@ struct DScene {
     const PgAlphaMask *alphas;           // alpha / shadow-alpha textures of meshes; triAlpha[k] indexes it for PG_TRI_ALPHA triangles
     const int *triAlpha;
     int hasAlpha;
+    // alphaTex[2 k] / [2 k + 1] = the alpha / shadow-alpha mask of alphas[k] in DAlphaTex form, or nullptr when some mask of the
+    // scene is a texture DAlphaTex cannot express (k_trace then evaluates masks through TexEval)
+    const DAlphaTex *alphaTex;
     const PgImage *images;               // MIPMaps of the image textures (pyramid levels in texels[])
     const float *texels;
     const float *ewaLut;                 // MIPMap::weightLut (128)
@@ -188,8 +203,7 @@ struct TraceCounters {
 // cullK: closest-hit far-child early-cull margin (pg_traverse.hip); exact while a ray's tMax never grows by more than
 // this factor through rounding (each accepted hit can raise it by <= 3 roundings, i.e. ~5000 successive raises).
 // maxAccepted: accepted hits per ray beyond which the margin's proof no longer holds (<= 4096 for cullK = 1 + 2^-10)
-struct TraceConfig { int depth, segRays /* rays per chunk */, refillAt, triW; float cullK; int gridBlocks; int maxAccepted;
-                     int topK;  /* child-pair records of the world BVH kept in LDS (DScene::nTop caps it) */ };
+struct TraceConfig { int depth, segRays /* rays per chunk */, refillAt, triW; float cullK; int gridBlocks; int maxAccepted; };
 // The defaults, with the PG_TRACE_* environment overrides of experiments and tests applied.  Every scene carries its own copy
 // (PgScene::trace): the exact-fallback retry of one scene must not change what another host thread's launches use.
 TraceConfig default_trace_config();

@@ -23,12 +23,7 @@
 //    queue (one atomic per chunk) and refills lanes whose ray has finished, so
 //    lane occupancy does not decay to the longest ray of the first 64;
 //  * traversal stack: first `depth` entries per lane in LDS ([entry][lane],
-//    8 B entries, bank-conflict-free), the rest of pbrt's 64 in scratch;
-//  * tree top in LDS: the `topK` interior records a ray is most likely to visit
-//    (pg_scene_create numbers them first) are copied into the block's LDS once;
-//    a lane whose record is among them reads it there instead of through the
-//    vector L1 -- the kernel is bound by the rate of divergent 64-B record
-//    requests on that path, and every ray starts with a run of these records.
+//    8 B entries, bank-conflict-free), the rest of pbrt's 64 in scratch.
 #include "pg_device.h"
 #include "pg_sphere.h"
 #include <algorithm>
@@ -48,12 +43,15 @@
 #ifndef TR_MIN_WAVES
 #define TR_MIN_WAVES 2
 #endif
+// instanced triangle scenes: 5 waves per SIMD (96 VGPRs; the kernels need 85 - 87).  Holding the allocator to 6 waves (80 VGPRs)
+// spills 7 - 10 registers and loses: 351 vs 303 ms per frame in k_trace<false> on the 5 M-triangle divergent stand-in
+// (profiles/r03d_xprim_register_diet.txt)
+#ifndef TR_INST_WAVES
+#define TR_INST_WAVES 5
+#endif
 #define TR_MAX_ACCEPTED 4096  // (1+2^-24)^(3*4096) < 1+2^-10
 #ifndef TR_DEFAULT_DEPTH
 #define TR_DEFAULT_DEPTH 11
-#endif
-#ifndef TR_DEFAULT_TOPK
-#define TR_DEFAULT_TOPK 0
 #endif
 
 // Bounds3::IntersectP(ray, invDir, dirIsNeg), geometry.h:1412-1438, split into
@@ -111,26 +109,43 @@ PG_DEV unsigned long long tr_wave_sum(unsigned long long v) {
     return v;
 }
 
-// XPRIM: the scene has primitives other than triangles -- spheres and object instances (TransformedPrimitive over an
-// object definition's own BVH): a separate instantiation, so that triangle-only scenes keep the lean kernel.
-template <bool ANYHIT, bool XPRIM>
-__global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(DScene sc, RayQueue q0, RayQueue q1, float4 *__restrict__ hits,
+// XP: what the scene has besides plain triangles, one instantiation per combination that occurs, so that a scene pays (in
+// registers, i.e. resident waves) only for what it contains: XP_INST object instances (TransformedPrimitive over an object
+// definition's own BVH), XP_QUADRIC spheres / cylinders / disks / cones / paraboloids / hyperboloids (EFloat arithmetic),
+// XP_ALPHA alpha / shadow-alpha masks that are constants or plain image maps (DAlphaTex: four texels, inline), XP_ALPHATEX masks
+// of any texture type through the general evaluator (a function call: 180+ registers and 1 KB of scratch for the whole kernel).
+// 0 = the lean triangle-only kernel.
+#define XP_INST 1
+#define XP_QUADRIC 2
+#define XP_ALPHA 4
+#define XP_ALPHATEX 8
+#define XP_GENERAL (XP_INST | XP_QUADRIC | XP_ALPHATEX)
+
+// MIPMap<Float>::Lookup(st, 0 width) of a DAlphaTex = `triangle(0, st)` (mipmap.h:231-243) with Texel's wrap modes (:189-212): the
+// operations of mip_triangle / mip_texel (pg_texture.h) on the red channel, in the same order.
+PG_DEV float alpha_texel(const DScene &sc, const DAlphaTex &a, int s, int t) {
+    if (a.wrap == 0) { s = mod_i(s, a.width); t = mod_i(t, a.height); }
+    else if (a.wrap == 2) { s = s < 0 ? 0 : (s > a.width - 1 ? a.width - 1 : s); t = t < 0 ? 0 : (t > a.height - 1 ? a.height - 1 : t); }
+    else if (s < 0 || s >= a.width || t < 0 || t >= a.height) return 0.f;
+    return sc.texels[a.offset + ((size_t)t * a.width + s)];
+}
+PG_DEV float alpha_lookup(const DScene &sc, const DAlphaTex &a, float u, float v) {
+    if (a.image < 0) return a.constant;
+    const float st0 = a.su * u + a.du, st1 = a.sv * v + a.dv;  // UVMapping2D::Map, texture.cpp:93-100
+    const float s = st0 * a.width - 0.5f, t = st1 * a.height - 0.5f;
+    const int s0 = (int)floorf(s), t0 = (int)floorf(t);
+    const float ds = s - s0, dt = t - t0;
+    return alpha_texel(sc, a, s0, t0) * ((1 - ds) * (1 - dt)) + alpha_texel(sc, a, s0, t0 + 1) * ((1 - ds) * dt) +
+           alpha_texel(sc, a, s0 + 1, t0) * (ds * (1 - dt)) + alpha_texel(sc, a, s0 + 1, t0 + 1) * (ds * dt);
+}
+template <bool ANYHIT, int XP>
+__global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_ALPHA)) ? TR_INST_WAVES : TR_MIN_WAVES)) TR_SGPR_ATTR void k_trace(DScene sc, RayQueue q0, RayQueue q1, float4 *__restrict__ hits,
                                                     int hitOffset1, float *__restrict__ tOut, int *__restrict__ occluded,
                                                     TraceCounters *cn, int *__restrict__ cursors, int depth, int chunk, int refillAt, int triW,
-                                                    float cullK, int *cullGuard, int maxAccepted, int topK) {
-    extern __shared__ uint2 ldsStack[];  // [depth][TR_BLOCK], then the tree top: topK records of 4 float4
+                                                    float cullK, int *cullGuard, int maxAccepted) {
+    extern __shared__ uint2 ldsStack[];  // [depth][TR_BLOCK]
     uint2 spill[TR_STACK_TOTAL];
     const int tid = threadIdx.x;
-    // Tree top: records [0, topK) of the world BVH, 64 B each.  Lanes read DIFFERENT records at once (ds_read_b128, serviced in
-    // groups of 16 lanes over 16 slots of 16 B): piece p of record r sits at slot (p + (r >> 2)) & 3 of the record, so that
-    // the 16-B slot a lane touches, 4 (r & 3) + ((p + (r >> 2)) & 3), is spread over all 16 by the record index instead of over
-    // the 4 that share p (identical records broadcast).
-    float4 *ldsTop = (float4 *)(ldsStack + (size_t)depth * TR_BLOCK);
-    for (int i = tid; i < 4 * topK; i += TR_BLOCK) {
-        const int r = i >> 2, p = i & 3;
-        ldsTop[4 * r + ((p + (r >> 2)) & 3)] = sc.wnodes[i];
-    }
-    if (topK > 0) __syncthreads();
     const int lane = tid & 63;
     const unsigned long long laneLt = (1ull << lane) - 1ull;
     // Work distribution: the queue is PG_REGIONS sub-queues, one per XCD (block b runs on XCD b % 8, and the producers
@@ -159,17 +174,17 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
     int vd = 0;                       // ANYHIT: reference stack depth (real + culled entries)
     unsigned long long vmask = 0;     // ANYHIT: bit i set = the reference's entry at depth i was culled early
     unsigned int nodeVisits = 0, triTests = 0;
-#ifdef PG_TRACE_STATS  // experiment build only (tools/trace_stats.sh): where the lanes of a wave go
-    unsigned long long stIntSteps = 0, stIntLanes = 0, stTriSteps = 0, stTriLanes = 0, stRefills = 0, stRefillLanes = 0, stBusyLanes = 0, stTopLanes = 0;
-#endif
     int nAccepted = 0;  // hits accepted by this lane's current ray (bounds the rounding growth of tMax, see cullK below)
-    // XPRIM: object instances.  While a lane traverses an instance's BVH its ray registers hold the instance-space ray
+    // XP_INST: object instances.  While a lane traverses an instance's BVH its ray registers hold the instance-space ray
     // (TransformedPrimitive::Intersect, primitive.cpp:76-96); the world ray, the rest of the world leaf and (any-hit) the
     // world BVH's visit bookkeeping wait here.  Entries of the instance's traversal sit on the same stack above spBase.
-    int inInst = -1, hitInstCur = -1, spBase = 0, wTriNext = 0, wTriLeft = 0, wvd = 0;
+    // Of the world ray only tMax is kept (it shrinks with every hit): origin, reciprocal direction and the triangle shear are
+    // derived again from the queue entry when the lane comes back -- the same operations on the same inputs as at the refill,
+    // so the same bits -- which spares ten registers for the whole kernel (101 -> 5 resident waves per SIMD instead of 4).
+    int inInst = -1, hitInstCur = -1, spBase = 0, wvd = 0;
+    unsigned wLeaf = 0;  // the rest of the world leaf: next primitive << (leafBits + 1) | primitives left
     bool instHit = false;
-    float wox = 0, woy = 0, woz = 0, wix = 1, wiy = 1, wiz = 1, wtMax = 0;
-    TriRay wtr = tr;
+    float wtMax = 0;
     unsigned long long wvmask = 0;
     const int leafBits = sc.leafBits, leafMask = (1 << leafBits) - 1;
 
@@ -189,12 +204,18 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
 
     for (;;) {
         // ---- a lane that has finished an instance's BVH goes back to its world ray (primitive.cpp:83-88)
-        if (XPRIM && inInst >= 0 && cur == TR_NONE && triLeft == 0) {
+        if ((XP & XP_INST) && inInst >= 0 && cur == TR_NONE && triLeft == 0) {
             if (!ANYHIT && instHit) wtMax = tMax;  // r.tMax = ray.tMax
-            ox = wox; oy = woy; oz = woz; ix = wix; iy = wiy; iz = wiz; tr = wtr; tMax = wtMax;
+            {
+                const bool fromQ1 = q1.regionCap > 0 && ray >= hitOffset1;
+                const float4 o4 = fromQ1 ? q1.o[ray - hitOffset1] : q0.o[ray], d4 = fromQ1 ? q1.d[ray - hitOffset1] : q0.d[ray];
+                ox = o4.x; oy = o4.y; oz = o4.z; tMax = wtMax;
+                tr = tri_ray_setup(mk(d4.x, d4.y, d4.z));
+                ix = 1 / d4.x; iy = 1 / d4.y; iz = 1 / d4.z;
+            }
             nx = ix < 0; ny = iy < 0; nz = iz < 0; negBits = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
             if (ANYHIT) { vd = wvd; vmask = wvmask; }
-            triNext = wTriNext; triLeft = wTriLeft; inInst = -1; spBase = 0;
+            triNext = (int)(wLeaf >> (leafBits + 1)); triLeft = (int)(wLeaf & ((2u << leafBits) - 1u)); inInst = -1; spBase = 0;
             if (triLeft == 0) { TR_POP(); TR_SETTLE(); }
         }
         // ---- retire finished rays and refill idle lanes from this wave's segment.  A finished ray's result stays in its lane
@@ -213,7 +234,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
                 if (ANYHIT) occluded[ray] = hitPrim >= 0 ? 1 : 0;
                 else {
                     hits[ray] = make_float4(__int_as_float(hitPrim), hb0, hb1, hb2);
-                    if (XPRIM && sc.hitInst) sc.hitInst[ray] = hitInstCur;
+                    if ((XP & XP_INST) && sc.hitInst) sc.hitInst[ray] = hitInstCur;
                     if (tOut) tOut[ray] = tMax;
                 }
                 ray = -1;
@@ -221,9 +242,6 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
             if (exhausted) break;
         }
         if (nIdle >= idleThreshold) {  // (refill: the queues were not exhausted on entry)
-#ifdef PG_TRACE_STATS
-            ++stRefills; stRefillLanes += nIdle;
-#endif
             if (next >= segEnd) {  // wave-uniform: take the next chunk
                 for (;;) {
                     const int qsel = region >> 3, rr = region & (PG_REGIONS - 1);
@@ -283,17 +301,13 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
         bool needPop = false, settle = false;
         const int nInt = __popcll(__ballot(cur >= 0));
         const int nTri = __popcll(__ballot(triLeft > 0));
-#ifdef PG_TRACE_STATS
-        if (nTri > 0 && (nInt == 0 || nTri * 16 >= nInt * triW)) { ++stTriSteps; stTriLanes += nTri; } else { ++stIntSteps; stIntLanes += nInt; }
-        stBusyLanes += nInt + nTri;
-#endif
         if (nTri > 0 && (nInt == 0 || nTri * 16 >= nInt * triW)) {
             if (triLeft > 0) {  // Triangle::Intersect[P] on the leaf's next primitive, in order (bvh.cpp:677-680)
                 const int prim = triNext;
                 const float4 a = sc.tris[PG_TRI_STRIDE * prim], b = sc.tris[PG_TRI_STRIDE * prim + 1], c = sc.tris[PG_TRI_STRIDE * prim + 2];
                 ++triTests; ++triNext; --triLeft;
                 const uint32_t pflags = __float_as_uint(a.w);
-                if (XPRIM && (pflags & PG_PRIM_INSTANCE)) {
+                if ((XP & XP_INST) && (pflags & PG_PRIM_INSTANCE)) {
                     // TransformedPrimitive::Intersect[P]: carry the ray into the instance's space (Transform::operator()(Ray),
                     // transform.h:249-262) and start on its BVH; not a triangle test for the reference's counter
                     --triTests;
@@ -302,8 +316,8 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
                     const int idx = __float_as_int(a.x);
                     const PgInstance &in = sc.instances[idx];
                     const DObject &ob = sc.objects[in.object];
-                    wox = ox; woy = oy; woz = oz; wix = ix; wiy = iy; wiz = iz; wtr = tr; wtMax = tMax;
-                    wTriNext = triNext; wTriLeft = triLeft;
+                    wtMax = tMax;
+                    wLeaf = ((unsigned)triNext << (leafBits + 1)) | (unsigned)triLeft;
                     if (ANYHIT) { wvd = vd; wvmask = vmask; vd = 0; vmask = 0; }
                     V3 oErr;
                     V3 o = m4_point_err(in.w2i, mk(ox, oy, oz), oErr);
@@ -333,7 +347,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
                 } else {
                     float t, b0, b1, b2;
                     bool hit;
-                    if (XPRIM && (pflags & PG_PRIM_SPHERE)) {
+                    if ((XP & XP_QUADRIC) && (pflags & PG_PRIM_SPHERE)) {
                         // Sphere::Intersect[P] (sphere.cpp:48-106): not a triangle test for the reference's counter; the ray's
                         // direction is not kept in registers (only its reciprocal and the triangle shear), so it is re-read
                         --triTests;
@@ -346,30 +360,36 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
                     } else
                         hit = tri_test_pre(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), mk(ox, oy, oz), tr, tMax, t, b0, b1, b2) &&
                               !(pflags & PG_TRI_BOGUS);
-                    if (XPRIM && hit && (pflags & PG_TRI_ALPHA)) {
+                    if ((XP & (XP_ALPHA | XP_ALPHATEX)) && hit && (pflags & PG_TRI_ALPHA)) {
                         // the mesh's alpha / shadow-alpha textures at the hit (triangle.cpp:333-338, :531-569): point, (u, v),
                         // no differentials; a value of exactly 0 rejects the hit and the ray goes on
-                        const PgAlphaMask &am = sc.alphas[sc.triAlpha[prim]];
                         float uv[6] = {0, 0, 1, 0, 1, 1};
                         if (sc.uv && (pflags & PG_TRI_HAS_UV)) for (int k = 0; k < 6; ++k) uv[k] = sc.uv[6 * prim + k];
-                        TexHit th;
-                        th.p = mk(a.x, a.y, a.z) * b0 + mk(b.x, b.y, b.z) * b1 + mk(c.x, c.y, c.z) * b2;
-                        th.u = b0 * uv[0] + b1 * uv[2] + b2 * uv[4];
-                        th.v = b0 * uv[1] + b1 * uv[3] + b2 * uv[5];
-                        th.dpdx = th.dpdy = mk(0, 0, 0);
-                        th.dudx = th.dvdx = th.dudy = th.dvdy = 0;
-                        if (am.has_alpha && TexEval<PG_TEX_DEPTH>::f(sc, am.alpha, th) == 0) hit = false;
-                        if (ANYHIT && hit && am.has_shadow_alpha && TexEval<PG_TEX_DEPTH>::f(sc, am.shadow_alpha, th) == 0) hit = false;
+                        const float hu = b0 * uv[0] + b1 * uv[2] + b2 * uv[4], hv = b0 * uv[1] + b1 * uv[3] + b2 * uv[5];
+                        if (XP & XP_ALPHATEX) {
+                            const PgAlphaMask &am = sc.alphas[sc.triAlpha[prim]];
+                            TexHit th;
+                            th.p = mk(a.x, a.y, a.z) * b0 + mk(b.x, b.y, b.z) * b1 + mk(c.x, c.y, c.z) * b2;
+                            th.u = hu; th.v = hv;
+                            th.dpdx = th.dpdy = mk(0, 0, 0);
+                            th.dudx = th.dvdx = th.dudy = th.dvdy = 0;
+                            if (am.has_alpha && TexEval<PG_TEX_DEPTH>::f(sc, am.alpha, th) == 0) hit = false;
+                            if (ANYHIT && hit && am.has_shadow_alpha && TexEval<PG_TEX_DEPTH>::f(sc, am.shadow_alpha, th) == 0) hit = false;
+                        } else {
+                            const DAlphaTex *at = sc.alphaTex + 2 * sc.triAlpha[prim];
+                            if (at[0].image != -2 && alpha_lookup(sc, at[0], hu, hv) == 0) hit = false;
+                            if (ANYHIT && hit && at[1].image != -2 && alpha_lookup(sc, at[1], hu, hv) == 0) hit = false;
+                        }
                     }
                     // the accepted hit, written with selects (in place: a branch here makes the compiler copy the whole hit
                     // record aside before the test and back after it)
                     hitPrim = hit ? prim : hitPrim;
                     if (ANYHIT) {  // bvh.cpp:717: return true
                         triLeft = hit ? 0 : triLeft; sp = hit ? 0 : sp; vd = hit ? 0 : vd;
-                        if (XPRIM) inInst = hit ? -1 : inInst;
+                        if (XP & XP_INST) inInst = hit ? -1 : inInst;
                     } else {
                         tMax = hit ? t : tMax; hb0 = hit ? b0 : hb0; hb1 = hit ? b1 : hb1; hb2 = hit ? b2 : hb2;  // primitive.cpp:123: r.tMax = tHit
-                        if (XPRIM) { hitInstCur = hit ? inInst : hitInstCur; instHit = instHit || hit; }
+                        if (XP & XP_INST) { hitInstCur = hit ? inInst : hitInstCur; instHit = instHit || hit; }
                         nAccepted += hit ? 1 : 0;
                         if (hit && nAccepted == maxAccepted) atomicOr(cullGuard, 1);
                     }
@@ -377,18 +397,9 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
                 }
             }
         } else if (cur >= 0) {
-#ifdef PG_TRACE_STATS
-            stTopLanes += __popcll(__ballot(cur < topK));
-#endif
-            float4 bx, by, bz, rf;
-            if (cur < topK) {  // a resident record: four 16-B LDS reads
-                const float4 *rec = ldsTop + 4 * cur;
-                const int sw = cur >> 2;
-                bx = rec[sw & 3]; by = rec[(sw + 1) & 3]; bz = rec[(sw + 2) & 3]; rf = rec[(sw + 3) & 3];
-            } else {
-                const float4 *rec = sc.wnodes + 4 * (size_t)cur;
-                bx = rec[0]; by = rec[1]; bz = rec[2]; rf = rec[3];
-            }
+            const float4 *rec = sc.wnodes + 4 * (size_t)cur;
+            const float4 bx = rec[0], by = rec[1], bz = rec[2];
+            const float4 rf = rec[3];
             float t0, t1;
             const unsigned long long ok0 = slab_mask(bx.x, bx.y, by.x, by.y, bz.x, bz.y, ox, oy, oz, ix, iy, iz, nx, ny, nz, t0);
             const unsigned long long ok1 = slab_mask(bx.z, bx.w, by.z, by.w, bz.z, bz.w, ox, oy, oz, ix, iy, iz, nx, ny, nz, t1);
@@ -435,18 +446,11 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) TR_SGPR_ATTR void k_trace(D
         atomicAdd(&cn->node_visits, nv);
         atomicAdd(&cn->tri_tests, nt);
     }
-#ifdef PG_TRACE_STATS
-    if (lane == 0 && cullGuard) {  // closest-hit launches only: 8 counters after the guard word (the experiment allocates them)
-        unsigned long long *st = (unsigned long long *)(cullGuard + 2);
-        atomicAdd(&st[0], stIntSteps); atomicAdd(&st[1], stIntLanes); atomicAdd(&st[2], stTriSteps); atomicAdd(&st[3], stTriLanes);
-        atomicAdd(&st[4], stRefills); atomicAdd(&st[5], stRefillLanes); atomicAdd(&st[6], stBusyLanes); atomicAdd(&st[7], stTopLanes);
-    }
-#endif
 }
 
 // depth 11: 7 resident 256-thread blocks x 22.5 KB of stack fill the 160 KB LDS
 TraceConfig default_trace_config() {
-    TraceConfig tc = {TR_DEFAULT_DEPTH, 128, 16, 8, 1.0009765625f, 2048, TR_MAX_ACCEPTED, TR_DEFAULT_TOPK};
+    TraceConfig tc = {TR_DEFAULT_DEPTH, 128, 16, 8, 1.0009765625f, 2048, TR_MAX_ACCEPTED};
     if (const char *e = getenv("PG_TRACE_DEPTH")) { int v = atoi(e); if (v >= 0 && v <= 64) tc.depth = v; }
     if (const char *e = getenv("PG_TRACE_SEG")) { int v = atoi(e); if (v >= 64) tc.segRays = v; }
     if (const char *e = getenv("PG_TRACE_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) tc.refillAt = v; }
@@ -454,12 +458,8 @@ TraceConfig default_trace_config() {
     if (const char *e = getenv("PG_TRACE_TRIW")) { int v = atoi(e); if (v >= 0) tc.triW = v; }
     if (const char *e = getenv("PG_TRACE_MAXACC")) { int v = atoi(e); if (v >= 1 && v <= 4096) tc.maxAccepted = v; }  // tests: provoke the exact fallback
     if (const char *e = getenv("PG_TRACE_CULLK")) { float v = (float)atof(e); if (v >= 1.f) tc.cullK = v < 3e38f ? v : 3e38f; }  // finite: 0*inf would be NaN
-    if (const char *e = getenv("PG_TRACE_TOPK")) { int v = atoi(e); if (v >= 0) tc.topK = v; }
-    // the stack and the tree top share the block's LDS (160 KB per CU, one block must fit in any case)
-    const size_t ldsMax = 160 * 1024;
+    const size_t ldsMax = 160 * 1024;  // one block must fit the CU's LDS in any case
     if (sizeof(uint2) * (size_t)tc.depth * TR_BLOCK > ldsMax) tc.depth = (int)(ldsMax / (sizeof(uint2) * TR_BLOCK));
-    const size_t room = ldsMax - sizeof(uint2) * (size_t)tc.depth * TR_BLOCK;
-    if ((size_t)tc.topK * 64 > room) tc.topK = (int)(room / 64);
     return tc;
 }
 
@@ -471,16 +471,19 @@ static void launch_trace(const DScene &sc, const TraceConfig &c, RayQueue q0, Ra
     long long need = ((long long)(q0.regionCap + q1.regionCap) * PG_REGIONS + c.segRays - 1) / c.segRays;  // chunks
     int nblk = (int)std::min<long long>((need + TR_BLOCK / 64 - 1) / (TR_BLOCK / 64), (long long)c.gridBlocks * 256 / TR_BLOCK);
     nblk = ((nblk + 7) / 8) * 8;
-    const int topK = std::min(c.topK, sc.nTop);
-    size_t lds = sizeof(uint2) * (size_t)c.depth * TR_BLOCK + 64 * (size_t)topK;
+    size_t lds = sizeof(uint2) * (size_t)c.depth * TR_BLOCK;
     (void)hipMemsetAsync(cursors, 0, 2 * PG_REGIONS * PG_COUNT_STRIDE * sizeof(int), s);
-    // scenes without spheres and object instances run the triangle-only instantiation
-    if (sc.nSpheres > 0 || sc.nInstances > 0 || sc.hasAlpha)
-        hipLaunchKernelGGL((k_trace<ANYHIT, true>), dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q0, q1, hits, hitOffset1, tOut, occluded, cn, cursors,
-                           c.depth, c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard, c.maxAccepted, topK);
-    else
-        hipLaunchKernelGGL((k_trace<ANYHIT, false>), dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q0, q1, hits, hitOffset1, tOut, occluded, cn, cursors,
-                           c.depth, c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard, c.maxAccepted, topK);
+    const int xp = (sc.nInstances > 0 ? XP_INST : 0) | (sc.nSpheres > 0 ? XP_QUADRIC : 0) | (sc.hasAlpha ? (sc.alphaTex ? XP_ALPHA : XP_ALPHATEX) : 0);
+#define TR_LAUNCH(XPV) hipLaunchKernelGGL((k_trace<ANYHIT, XPV>), dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q0, q1, hits, hitOffset1, tOut, occluded, cn, \
+                                          cursors, c.depth, c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard, c.maxAccepted)
+    switch (xp) {
+    case 0: TR_LAUNCH(0); break;
+    case XP_INST: TR_LAUNCH(XP_INST); break;
+    case XP_ALPHA: TR_LAUNCH(XP_ALPHA); break;
+    case XP_INST | XP_ALPHA: TR_LAUNCH(XP_INST | XP_ALPHA); break;
+    default: TR_LAUNCH(XP_GENERAL); break;  // quadrics, or masks that need the general texture evaluator
+    }
+#undef TR_LAUNCH
 }
 static RayQueue noQueue() { RayQueue q; q.o = q.d = nullptr; q.counts = nullptr; q.regionCap = 0; return q; }
 void launch_closest(const DScene &sc, const TraceConfig &c, RayQueue q, float4 *hits, float *tOut, TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s) {

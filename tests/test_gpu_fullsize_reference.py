@@ -1,4 +1,6 @@
-"""BASELINE.json configs 2 and 3 at FULL size against the unmodified reference binary (oracle/_ref/pbrt_oracle travels to the
+"""BASELINE.json configs 2 and 3 at FULL size, and 256x144 full-spp windows of the config 4 / 5 stand-ins (scenes/gen_divergent.py:
+5 M / 10 M triangles as instanced PLY meshes with image and alpha textures and a material palette; config 5 in a
+HomogeneousMedium under volpath), against the unmodified reference binary (oracle/_ref/pbrt_oracle travels to the
 GPU box): the device image vs the reference's PFM, per-pixel |d| <= 1e-4 * max(1, |ref|), and the reference's own ray counters.
 The reference needs ~1 min (Cornell 512x512 @ 256 spp) and ~2-3 min (1920x1080 @ 64 spp, 1 M triangles) on the box's host
 cores: slow, so PBRT_SKIP_SLOW=1 skips it.  A pixel outside the tolerance must be reproduced bit for bit by the CPU oracle
@@ -15,7 +17,7 @@ pytestmark = [pytest.mark.gpu, pytest.mark.slow]
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-@pytest.mark.parametrize("config", [2, 3])
+@pytest.mark.parametrize("config", [2, 3, 4, 5])
 def test_full_size_image_matches_reference_binary(gpu, oracle, config):
     if os.environ.get("PBRT_SKIP_SLOW") == "1":
         pytest.skip("PBRT_SKIP_SLOW=1")

@@ -3,8 +3,11 @@
 
   config 2: Cornell box, 512x512 @ 256 spp, whole frame
   config 3: synthetic 999 710-triangle scene, 1920x1080 @ 64 spp, whole frame
-  config 4: 5 M-triangle stand-in, path, 1920x1080 @ 256 spp -- a 256x144 window of the full frame (Integrator "pixelbounds")
-  config 5: 10 M-triangle stand-in in a HomogeneousMedium, volpath, 1920x1080 @ 128 spp -- the same window
+  config 4: the 5 M-triangle stand-in of scenes/gen_divergent.py (PLY meshes under > 100 object instances, image / alpha
+            textures, eight-material palette, environment light), path, 1920x1080 @ 256 spp -- a 256x144 window of the full
+            frame (Integrator "pixelbounds")
+  config 5: the same at 10 M triangles inside a HomogeneousMedium, volpath, 1920x1080 @ 128 spp -- the same window
+  config 40 / 50: round 2's stand-ins (config 3's matte heightfield scaled to 5 M / 10 M triangles; 50 in fog under volpath)
 
 Both renderers read the same .pbrt file; the reference writes a PFM (core/imageio.cpp:437-482), the device film goes through
 the host Film (MergeFilmTile + WriteImage arithmetic).  Reported per config: max / 99.99th percentile / count of pixels with
@@ -28,6 +31,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "scenes"))
 import gen_synthetic  # noqa: E402
+import gen_divergent  # noqa: E402
 from __graft_entry__ import load_package  # noqa: E402
 
 TOL = 1e-4
@@ -41,14 +45,21 @@ def write_config(config, d):
     window = None
     if config == 2:
         open(path, "w").write(open(os.path.join(ROOT, "scenes", "cornell.pbrt")).read())
+    elif config in (4, 5):
+        dry = float(os.environ.get("PBRT_PARITY_DRY_RUN_SCALE", "1"))  # < 1: a CPU dry run of this code path under tests/emu
+        gen_divergent.write_scene(path, tris=int({4: 5000000, 5: 10000000}[config] * dry), xres=1920, yres=1080, spp=max(1, int({4: 256, 5: 128}[config] * dry)),
+                                  volumetric=config == 5, filename=f"config{config}.pfm")
+        window = WINDOW
+        s = re.sub(r'(Integrator "(?:vol)?path")', r'\1 "integer pixelbounds" [ %d %d %d %d ]' % (window[0], window[2], window[1], window[3]), open(path).read(), count=1)
+        open(path, "w").write(s)
     else:
-        n, spp = {3: (708, 64), 4: (1582, 256), 5: (2237, 128)}[config]
+        n, spp = {3: (708, 64), 40: (1582, 256), 50: (2237, 128)}[config]
         gen_synthetic.write_scene(path, n=n, xres=1920, yres=1080, spp=spp, filename=f"config{config}.pfm")
         s = open(path).read()
-        if config == 5:
+        if config == 50:
             s = s.replace("Camera ", FOG + "Camera ", 1).replace('Integrator "path"', 'Integrator "volpath"', 1)
             s = s.replace("WorldBegin\n", 'WorldBegin\nMediumInterface "fog" "fog"\n', 1)
-        if config >= 4:
+        if config >= 40:
             window = WINDOW
             s = re.sub(r'(Integrator "(?:vol)?path")', r'\1 "integer pixelbounds" [ %d %d %d %d ]' % (window[0], window[2], window[1], window[3]), s, count=1)
         open(path, "w").write(s)
@@ -114,7 +125,8 @@ def run(config):
         scene.film_clear(); scene.film_merge(rdp, ofilm, ostrays)
         if np.array_equal(scene.film_image()[py, px], img[py, px]):
             explained += 1
-    out = {"config": config, "triangles": int(scene.desc.n_tris), "integrator": "volpath" if config == 5 else "path",
+    out = {"config": config, "triangles": int(max(scene.desc.n_tris, scene.desc.n_prims_all)), "object_instances": int(scene.desc.n_instances),
+           "integrator": "volpath" if config in (5, 50) else "path",
            "frame": f"{img.shape[1]}x{img.shape[0]}", "spp": int(rd.spp), "compared_pixels": int(err.size),
            "sampled_pixels": int((window[2] - window[0]) * (window[3] - window[1])) if window else int(err.size),
            "window": list(window) if window else None, "outside_window_black": outside_black,

@@ -22,7 +22,7 @@ for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive
         val.setdefault(k, {}).setdefault(r["Counter_Name"], 0.0)
         val[k][r["Counter_Name"]] += float(r["Counter_Value"])
 res = {"table_MiB": known["table_MiB"], "kernels": {}}
-for k, req in (("k_gather<0>", known["gather_requested_bytes"]), ("k_stream", known["stream_bytes"])):
+for k, req in (("k_gather<0>", known["gather_requested_bytes"]), ("k_stream", known["stream_bytes"]), ("k_gather_pair", 2 * known["gather_requested_bytes"])):
     v = next((c for n, c in val.items() if n.replace("void ", "").startswith(k)), None)
     if not v: continue
     fetch = v.get("FETCH_SIZE", 0.0) * 1024
@@ -30,6 +30,7 @@ for k, req in (("k_gather<0>", known["gather_requested_bytes"]), ("k_stream", kn
     res["kernels"][k] = {"requested_bytes": req, "FETCH_SIZE_bytes": fetch, "l2_hit_rate": h,
                          "factor_requested_missed_over_FETCH_SIZE": req * (1 - h) / fetch if fetch else None,
                          "factor_requested_over_FETCH_SIZE": req / fetch if fetch else None,
+                         "TCC_HIT": v.get("TCC_HIT_sum"), "TCC_MISS": v.get("TCC_MISS_sum"),
                          "TCC_EA0_RDREQ": v.get("TCC_EA0_RDREQ_sum"), "TCC_EA0_RDREQ_32B": v.get("TCC_EA0_RDREQ_32B_sum")}
 json.dump(res, open(os.path.join(out, "fetch_size_calibration.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))

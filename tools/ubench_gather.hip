@@ -105,25 +105,30 @@ __global__ void k_fill(float4 *table, size_t n4) {  // distinct small integers p
 //   record r at slot (p + (r >> 2)) & 3) instead of the global table; REC16 = 16-B pieces per global record (4 = 64 B, 2 = 32 B).
 template <int REC16>
 __global__ __launch_bounds__(256) void k_gather_lds(const float4 *__restrict__ table, unsigned n, int iters, float *out, int ldsRecs, unsigned frac256) {
-    extern __shared__ float4 ldsTab[];
-    for (int i = threadIdx.x; i < 4 * ldsRecs; i += 256) { const int r = i >> 2, p = i & 3; ldsTab[4 * r + ((p + (r >> 2)) & 3)] = table[i]; }
+    // pointers that carry their address space in the type: from two branches loading through generic pointers the compiler makes one
+    // flat_load through a selected pointer (a third of the rate -- round 3's first run of this table measured exactly that)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    extern __shared__ float4 ldsRaw[];
+    __attribute__((address_space(3))) f4 *ldsTab = (__attribute__((address_space(3))) f4 *)ldsRaw;
+    const __attribute__((address_space(1))) f4 *gtab = (const __attribute__((address_space(1))) f4 *)table;
+    for (int i = threadIdx.x; i < 4 * ldsRecs; i += 256) { const int r = i >> 2, p = i & 3; ldsTab[4 * r + ((p + (r >> 2)) & 3)] = gtab[i]; }
     __syncthreads();
     unsigned idx = next_index(blockIdx.x * 256u + threadIdx.x, make_float4(0, 0, 0, 0), n);
     float acc = 0;
     for (int it = 0; it < iters; ++it) {
-        float4 a, b, c, d;
+        f4 a, b, c, d;
         const bool fromLds = ((idx * 2654435761u) >> 24) < frac256;
         if (fromLds) {
             const unsigned r = idx % (unsigned)ldsRecs, sw = r >> 2;
-            const float4 *rec = ldsTab + 4 * r;
+            const __attribute__((address_space(3))) f4 *rec = ldsTab + 4 * r;
             a = rec[sw & 3]; b = rec[(sw + 1) & 3]; c = rec[(sw + 2) & 3]; d = rec[(sw + 3) & 3];
         } else {
-            const float4 *rec = table + 4 * (size_t)idx;
+            const __attribute__((address_space(1))) f4 *rec = gtab + 4 * (size_t)idx;
             a = rec[0]; b = rec[1];
             if (REC16 == 4) { c = rec[2]; d = rec[3]; } else { c = a; d = b; }
         }
         acc += (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w) + (c.x + c.y + c.z + c.w) + (d.x + d.y + d.z + d.w);
-        idx = next_index(idx, a, n);
+        idx = next_index(idx, make_float4(a.x, a.y, a.z, a.w), n);
     }
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
@@ -149,6 +154,25 @@ __global__ __launch_bounds__(256) void k_stream(const float4 *__restrict__ table
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) { const float4 v = table[i]; acc += v.x + v.y + v.z + v.w; }
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
+// The sibling test: every lane reads its record AND the other 64-B half of the same 128-B line, one after the other.  If an L2
+// miss fills the whole 128-B line, the second read hits in the L2 and the memory-side request count stays that of k_gather<0>;
+// if the L2 fills 64-B sectors, it doubles.  That tells how many bytes one counted request of a record gather really moves.
+__global__ __launch_bounds__(256) void k_gather_pair(const float4 *__restrict__ table, unsigned n, int iters, float *out) {
+    unsigned idx = next_index(blockIdx.x * 256u + threadIdx.x, make_float4(0, 0, 0, 0), n);
+    float acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        const float4 *rec = table + 4 * (size_t)idx;
+        const float4 a = rec[0], b = rec[1], c = rec[2], d = rec[3];
+        acc += (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w) + (c.x + c.y + c.z + c.w) + (d.x + d.y + d.z + d.w);
+        unsigned sib = idx ^ 1u;
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sib) : "v"(acc) : "memory");
+        const float4 *rec2 = table + 4 * (size_t)sib;
+        const float4 e = rec2[0], f = rec2[1], g = rec2[2], h = rec2[3];
+        acc += (e.x + e.y + e.z + e.w) + (f.x + f.y + f.z + f.w) + (g.x + g.y + g.z + g.w) + (h.x + h.y + h.z + h.w);
+        idx = next_index(idx, a, n);
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
 static void calib(size_t mb, float *out) {
     const unsigned n = (unsigned)(mb * 1024 * 1024 / 64);
     const int blocks = 256 * 7, iters = 512;
@@ -157,6 +181,7 @@ static void calib(size_t mb, float *out) {
     hipLaunchKernelGGL(k_fill, dim3((unsigned)(((size_t)n * 4 + 255) / 256)), dim3(256), 0, 0, table, (size_t)n * 4);
     hipLaunchKernelGGL(k_gather<0>, dim3(blocks), dim3(256), 0, 0, table, n, iters, out);
     hipLaunchKernelGGL(k_stream, dim3(blocks), dim3(256), 0, 0, table, (size_t)n * 4, out);
+    hipLaunchKernelGGL(k_gather_pair, dim3(blocks), dim3(256), 0, 0, table, n & ~1u, iters, out);
     CHECK(hipDeviceSynchronize());
     printf("{\"table_MiB\": %zu, \"gather_requested_bytes\": %.0f, \"stream_bytes\": %.0f}\n", mb, (double)blocks * 256 * iters * 64, (double)n * 64);
     CHECK(hipFree(table));
