@@ -688,7 +688,10 @@ static void traceClosest(PgScene *s, RayQueue q, float4 *hits, float *tOut, Trac
     launch_closest(d, s->trace, q, hits, tOut, cn, (int *)s->cursors.p, (int *)s->cullGuard.p, st);
 }
 static void traceAnyhit(PgScene *s, RayQueue q, int *occluded, TraceCounters *cn, hipStream_t st) {
-    launch_anyhit(s->d, s->trace, q, occluded, cn, (int *)s->cursors.p, st);
+    // the unit entry point answers in the reference's visiting order: its counters are the reference's (tests compare them)
+    TraceConfig c = s->trace;
+    c.anyhitFree = 0;
+    launch_anyhit(s->d, c, q, occluded, cn, (int *)s->cursors.p, st);
 }
 
 // k_trace's early-cull margin is exact while no ray accepts more than TR_MAX_ACCEPTED hits (pg_traverse.hip); otherwise

@@ -203,7 +203,8 @@ struct TraceCounters {
 // cullK: closest-hit far-child early-cull margin (pg_traverse.hip); exact while a ray's tMax never grows by more than
 // this factor through rounding (each accepted hit can raise it by <= 3 roundings, i.e. ~5000 successive raises).
 // maxAccepted: accepted hits per ray beyond which the margin's proof no longer holds (<= 4096 for cullK = 1 + 2^-10)
-struct TraceConfig { int depth, segRays /* rays per chunk */, refillAt, triW; float cullK; int gridBlocks; int maxAccepted; };
+struct TraceConfig { int depth, segRays /* rays per chunk */, refillAt, triW; float cullK; int gridBlocks; int maxAccepted;
+                     int anyhitFree;  /* any-hit rays visit the nearer child first instead of the reference's order (same answers) */ };
 // The defaults, with the PG_TRACE_* environment overrides of experiments and tests applied.  Every scene carries its own copy
 // (PgScene::trace): the exact-fallback retry of one scene must not change what another host thread's launches use.
 TraceConfig default_trace_config();

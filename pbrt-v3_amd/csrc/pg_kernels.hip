@@ -1788,6 +1788,15 @@ PG_DEV void prim_interface(const DScene &sc, int prim, int rayMedium, int &mIn, 
 #define PG_SHADE_MIN_WAVES 3
 #endif
 // the specialised surface kernel (MODE 0): 125 VGPRs = four waves per SIMD without the cap; the cap keeps later edits there
+// the per-hit material evaluation (textured materials), path / volpath: the volpath kernel comes out at 259 registers -- three over the
+// edge of 2 waves per SIMD -- and gains 36 % from being held to 248 (10 M-triangle divergent stand-in: 556 -> 357 ms per frame); the
+// path kernel does not answer to 2 or 3 waves (253 / 258 / 268 ms; profiles/r03e_shade2_occupancy_anyhit_order.txt)
+#ifndef PG_SHADE2_WAVES
+#define PG_SHADE2_WAVES 1
+#endif
+#ifndef PG_SHADE2V_WAVES
+#define PG_SHADE2V_WAVES 2
+#endif
 #ifndef PG_SHADE0_WAVES
 #define PG_SHADE0_WAVES 4
 #endif
@@ -1811,7 +1820,7 @@ void shade_prof_dump() {
 #define PROF(k) do { } while (0)
 #endif
 template <int MODE, bool VOL>
-__global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MODE == 1 && PG_SHADE_MIN_WAVES > 0) ? PG_SHADE_MIN_WAVES : 1)) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
+__global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MODE == 1 && PG_SHADE_MIN_WAVES > 0) ? PG_SHADE_MIN_WAVES : (MODE == 2 ? (VOL ? PG_SHADE2V_WAVES : PG_SHADE2_WAVES) : 1))) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
                                                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, VolState vs,
                                                      const float *__restrict__ hitT, QueueState qsIn, QueueState qsOut) {
     constexpr bool EXT = MODE >= 1, TEX = MODE == 2;

@@ -23,10 +23,16 @@
 //    queue (one atomic per chunk) and refills lanes whose ray has finished, so
 //    lane occupancy does not decay to the longest ray of the first 64;
 //  * traversal stack: first `depth` entries per lane in LDS ([entry][lane],
-//    8 B entries, bank-conflict-free), the rest of pbrt's 64 in scratch.
+//    8 B entries, bank-conflict-free), the rest of pbrt's 64 in scratch;
+//  * any-hit rays in two orders (KIND): the reference's (its node and triangle
+//    counters reproduced exactly) and a free one -- the child the ray enters
+//    first -- whose answer is the same by construction: ray.tMax never changes
+//    during IntersectP, so which nodes pass their box test, and with them which
+//    primitives can be met at all, does not depend on the order of the visits.
 #include "pg_device.h"
 #include "pg_sphere.h"
 #include <algorithm>
+#include <cstring>
 #include "pg_kernels.h"
 #include "pg_texture.h"
 
@@ -138,11 +144,14 @@ PG_DEV float alpha_lookup(const DScene &sc, const DAlphaTex &a, float u, float v
     return alpha_texel(sc, a, s0, t0) * ((1 - ds) * (1 - dt)) + alpha_texel(sc, a, s0, t0 + 1) * ((1 - ds) * dt) +
            alpha_texel(sc, a, s0 + 1, t0) * (ds * (1 - dt)) + alpha_texel(sc, a, s0 + 1, t0 + 1) * (ds * dt);
 }
-template <bool ANYHIT, int XP>
-__global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_ALPHA)) ? TR_INST_WAVES : TR_MIN_WAVES)) TR_SGPR_ATTR void k_trace(DScene sc, RayQueue q0, RayQueue q1, float4 *__restrict__ hits,
+// KIND: 0 closest hit (BVHAccel::Intersect), 1 any hit in the reference's order (BVHAccel::IntersectP, counters exact),
+// 2 any hit in free order (same occlusion answers; the counters then say what THIS traversal read)
+template <int KIND, int XP>
+__global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_ALPHA)) ? (KIND == 2 ? TR_INST_WAVES + 1 : TR_INST_WAVES) : TR_MIN_WAVES)) TR_SGPR_ATTR void k_trace(DScene sc, RayQueue q0, RayQueue q1, float4 *__restrict__ hits,
                                                     int hitOffset1, float *__restrict__ tOut, int *__restrict__ occluded,
                                                     TraceCounters *cn, int *__restrict__ cursors, int depth, int chunk, int refillAt, int triW,
                                                     float cullK, int *cullGuard, int maxAccepted) {
+    constexpr bool ANYHIT = KIND != 0, FREE = KIND == 2;
     extern __shared__ uint2 ldsStack[];  // [depth][TR_BLOCK]
     uint2 spill[TR_STACK_TOTAL];
     const int tid = threadIdx.x;
@@ -197,6 +206,7 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
         if (!ANYHIT) { \
             while (sp > depth && sp > spBase) { --sp; const uint2 e_ = spill[sp - depth]; if (__uint_as_float(e_.y) < tMax) { cur = (int)e_.x; break; } } \
             if (cur == TR_NONE) while (sp > spBase && sp <= depth) { --sp; const uint2 e_ = ldsStack[sp * TR_BLOCK + tid]; if (__uint_as_float(e_.y) < tMax) { cur = (int)e_.x; break; } } \
+        } else if (FREE) { if (sp > spBase) { --sp; if (sp >= depth) cur = (int)spill[sp - depth].x; else cur = (int)ldsStack[sp * TR_BLOCK + tid].x; } \
         } else { while (vd > 0) { --vd; ++nodeVisits; if ((vmask >> vd) & 1ull) { vmask &= ~(1ull << vd); continue; } \
                                  --sp; if (sp >= depth) cur = (int)spill[sp - depth].x; else cur = (int)ldsStack[sp * TR_BLOCK + tid].x; break; } } } while (0)
     // A negative reference is a leaf: unpack (first prim, count) into the lane's triangle state.
@@ -424,13 +434,25 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
             if (!ANYHIT) {
                 nodeVisits += 2;  // near now, far when the reference pops it (it always does)
                 if (farMaybe) TR_PUSH(farRef, farT);
-            } else {
+            } else if (!FREE) {
                 nodeVisits += 1;
                 if (farMaybe) TR_PUSH(farRef, farT); else vmask |= 1ull << vd;
                 ++vd;
             }
-            if (nearHit) cur = nearRef;
-            needPop = !nearHit;
+            if (!FREE) {
+                if (nearHit) cur = nearRef;
+                needPop = !nearHit;
+            } else {
+                // free order: of the children whose box the ray crosses, the one it enters first; the other waits on the stack
+                // (no entry distance needed: tMax is constant, a box that passed now passes at any later time)
+                const bool h0 = __builtin_amdgcn_inverse_ballot_w64(ok0 & __ballot(t0 < tMax)), h1 = __builtin_amdgcn_inverse_ballot_w64(ok1 & __ballot(t1 < tMax));
+                const int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y);
+                const bool first0 = h0 && (!h1 || t0 <= t1);
+                if (h0 && h1) TR_PUSH(first0 ? r1 : r0, 0.f);
+                nodeVisits += 2;  // both children's boxes were read and tested
+                if (h0 || h1) cur = first0 ? r0 : r1;
+                needPop = !(h0 || h1);
+            }
             settle = true;
         }
         // the reference's "pop or finish" and the unpacking of a leaf reference, once for both kinds of step
@@ -450,7 +472,7 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
 
 // depth 11: 7 resident 256-thread blocks x 22.5 KB of stack fill the 160 KB LDS
 TraceConfig default_trace_config() {
-    TraceConfig tc = {TR_DEFAULT_DEPTH, 128, 16, 8, 1.0009765625f, 2048, TR_MAX_ACCEPTED};
+    TraceConfig tc = {TR_DEFAULT_DEPTH, 128, 16, 8, 1.0009765625f, 2048, TR_MAX_ACCEPTED, 1};
     if (const char *e = getenv("PG_TRACE_DEPTH")) { int v = atoi(e); if (v >= 0 && v <= 64) tc.depth = v; }
     if (const char *e = getenv("PG_TRACE_SEG")) { int v = atoi(e); if (v >= 64) tc.segRays = v; }
     if (const char *e = getenv("PG_TRACE_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) tc.refillAt = v; }
@@ -458,12 +480,15 @@ TraceConfig default_trace_config() {
     if (const char *e = getenv("PG_TRACE_TRIW")) { int v = atoi(e); if (v >= 0) tc.triW = v; }
     if (const char *e = getenv("PG_TRACE_MAXACC")) { int v = atoi(e); if (v >= 1 && v <= 4096) tc.maxAccepted = v; }  // tests: provoke the exact fallback
     if (const char *e = getenv("PG_TRACE_CULLK")) { float v = (float)atof(e); if (v >= 1.f) tc.cullK = v < 3e38f ? v : 3e38f; }  // finite: 0*inf would be NaN
+    // PG_ANYHIT_ORDER=reference: shadow rays visit the BVH in the reference's order, which reproduces its triangle-test statistic
+    // (and this library's node-visit count) exactly; the default free order gives the same occlusion answers sooner
+    if (const char *e = getenv("PG_ANYHIT_ORDER")) tc.anyhitFree = strcmp(e, "reference") != 0;
     const size_t ldsMax = 160 * 1024;  // one block must fit the CU's LDS in any case
     if (sizeof(uint2) * (size_t)tc.depth * TR_BLOCK > ldsMax) tc.depth = (int)(ldsMax / (sizeof(uint2) * TR_BLOCK));
     return tc;
 }
 
-template <bool ANYHIT>
+template <int KIND>
 static void launch_trace(const DScene &sc, const TraceConfig &c, RayQueue q0, RayQueue q1, float4 *hits, int hitOffset1, float *tOut, int *occluded,
                          TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s) {
     if (q0.regionCap <= 0) return;
@@ -474,8 +499,8 @@ static void launch_trace(const DScene &sc, const TraceConfig &c, RayQueue q0, Ra
     size_t lds = sizeof(uint2) * (size_t)c.depth * TR_BLOCK;
     (void)hipMemsetAsync(cursors, 0, 2 * PG_REGIONS * PG_COUNT_STRIDE * sizeof(int), s);
     const int xp = (sc.nInstances > 0 ? XP_INST : 0) | (sc.nSpheres > 0 ? XP_QUADRIC : 0) | (sc.hasAlpha ? (sc.alphaTex ? XP_ALPHA : XP_ALPHATEX) : 0);
-#define TR_LAUNCH(XPV) hipLaunchKernelGGL((k_trace<ANYHIT, XPV>), dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q0, q1, hits, hitOffset1, tOut, occluded, cn, \
-                                          cursors, c.depth, c.segRays, c.refillAt, c.triW, ANYHIT ? 1.f : c.cullK, cullGuard, c.maxAccepted)
+#define TR_LAUNCH(XPV) hipLaunchKernelGGL((k_trace<KIND, XPV>), dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q0, q1, hits, hitOffset1, tOut, occluded, cn, \
+                                          cursors, c.depth, c.segRays, c.refillAt, c.triW, KIND ? 1.f : c.cullK, cullGuard, c.maxAccepted)
     switch (xp) {
     case 0: TR_LAUNCH(0); break;
     case XP_INST: TR_LAUNCH(XP_INST); break;
@@ -487,12 +512,13 @@ static void launch_trace(const DScene &sc, const TraceConfig &c, RayQueue q0, Ra
 }
 static RayQueue noQueue() { RayQueue q; q.o = q.d = nullptr; q.counts = nullptr; q.regionCap = 0; return q; }
 void launch_closest(const DScene &sc, const TraceConfig &c, RayQueue q, float4 *hits, float *tOut, TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s) {
-    launch_trace<false>(sc, c, q, noQueue(), hits, 0, tOut, nullptr, cn, cursors, cullGuard, s);
+    launch_trace<0>(sc, c, q, noQueue(), hits, 0, tOut, nullptr, cn, cursors, cullGuard, s);
 }
 void launch_closest2(const DScene &sc, const TraceConfig &c, RayQueue q0, RayQueue q1, float4 *hits, int hitOffset1, TraceCounters *cn, int *cursors, int *cullGuard,
                      hipStream_t s, float *tOut) {
-    launch_trace<false>(sc, c, q0, q1, hits, hitOffset1, tOut, nullptr, cn, cursors, cullGuard, s);
+    launch_trace<0>(sc, c, q0, q1, hits, hitOffset1, tOut, nullptr, cn, cursors, cullGuard, s);
 }
 void launch_anyhit(const DScene &sc, const TraceConfig &c, RayQueue q, int *occluded, TraceCounters *cn, int *cursors, hipStream_t s) {
-    launch_trace<true>(sc, c, q, noQueue(), nullptr, 0, nullptr, occluded, cn, cursors, nullptr, s);
+    if (c.anyhitFree) launch_trace<2>(sc, c, q, noQueue(), nullptr, 0, nullptr, occluded, cn, cursors, nullptr, s);
+    else launch_trace<1>(sc, c, q, noQueue(), nullptr, 0, nullptr, occluded, cn, cursors, nullptr, s);
 }

@@ -9,7 +9,7 @@ scheduler cannot take literally (the arithmetic is untouched):
   1. `extern __shared__ uint2 ldsStack[]` (dynamic LDS of k_trace) -> a pointer to the emulator's per-block buffer;
   2. two `asm volatile("" : "+v"(...))` register-scheduling barriers of pg_kernels.hip (no effect on values) are dropped;
   3. wave-level calls that sit in DIVERGENT code are marked, since only the lanes inside the branch take part in them:
-     k_trace's slab masks and near / far masks (every lane uses its own bit only -> emu_ballot_own), and k_shade's
+     k_trace's slab masks, near / far masks and the free-order any-hit masks (every lane uses its own bit only -> emu_ballot_own), and k_shade's
      readfirstlane / ballot pair that decides about the batched Halton draw (-> emu_*_div: served before the lanes that skipped ahead);
   4. one load that the hardware executes in lockstep for the whole wave before lane 0's atomicAdd (k_trace's "is this region drained"
      test) is exchanged explicitly, because fibers reach it at different times.
@@ -39,6 +39,9 @@ def patched_sources(out):
         m = re.search(r"const unsigned long long %s = [^\n]*\n" % name, t)
         assert m and "__ballot(" in m.group(0), name
         t = t[:m.start()] + m.group(0).replace("__ballot(", "emu_ballot_own(") + t[m.end():]
+    m = re.search(r"const bool h0 = [^\n]*\n", t)  # free-order any-hit: the two box-test masks, own bit only
+    assert m and m.group(0).count("__ballot(") == 2
+    t = t[:m.start()] + m.group(0).replace("__ballot(", "emu_ballot_own(") + t[m.end():]
     old = "__hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)"
     assert t.count(old) == 1
     t = t.replace(old, "emu_readfirstlane(" + old + ")")
