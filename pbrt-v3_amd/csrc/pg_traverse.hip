@@ -52,6 +52,9 @@
 // instanced triangle scenes: 5 waves per SIMD (96 VGPRs; the kernels need 85 - 87).  Holding the allocator to 6 waves (80 VGPRs)
 // spills 7 - 10 registers and loses: 351 vs 303 ms per frame in k_trace<false> on the 5 M-triangle divergent stand-in
 // (profiles/r03d_xprim_register_diet.txt)
+#ifndef TR_FREE_EXTRA_WAVES  // the free-order any-hit kernel needs fewer registers: 78 - 81
+#define TR_FREE_EXTRA_WAVES 1
+#endif
 #ifndef TR_INST_WAVES
 #define TR_INST_WAVES 5
 #endif
@@ -147,7 +150,7 @@ PG_DEV float alpha_lookup(const DScene &sc, const DAlphaTex &a, float u, float v
 // KIND: 0 closest hit (BVHAccel::Intersect), 1 any hit in the reference's order (BVHAccel::IntersectP, counters exact),
 // 2 any hit in free order (same occlusion answers; the counters then say what THIS traversal read)
 template <int KIND, int XP>
-__global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_ALPHA)) ? (KIND == 2 ? TR_INST_WAVES + 1 : TR_INST_WAVES) : TR_MIN_WAVES)) TR_SGPR_ATTR void k_trace(DScene sc, RayQueue q0, RayQueue q1, float4 *__restrict__ hits,
+__global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_ALPHA)) ? (KIND == 2 ? TR_INST_WAVES + TR_FREE_EXTRA_WAVES : TR_INST_WAVES) : TR_MIN_WAVES)) TR_SGPR_ATTR void k_trace(DScene sc, RayQueue q0, RayQueue q1, float4 *__restrict__ hits,
                                                     int hitOffset1, float *__restrict__ tOut, int *__restrict__ occluded,
                                                     TraceCounters *cn, int *__restrict__ cursors, int depth, int chunk, int refillAt, int triW,
                                                     float cullK, int *cullGuard, int maxAccepted) {

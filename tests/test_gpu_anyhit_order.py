@@ -25,6 +25,8 @@ def render_both(gpu, monkeypatch, scene):
         gs.close()
     (fa, sa, ca), (fb, sb, cb) = out["reference"], out["free"]
     assert np.array_equal(fa["rgb"], fb["rgb"]) and np.array_equal(fa["weight"], fb["weight"])
+    key = lambda s: np.lexsort((s["src_px"], s["src_py"], s["px"], s["py"]))  # (stray samples are appended in whatever order the blocks finish)
+    sa, sb = sa[key(sa)], sb[key(sb)]
     assert len(sa) == len(sb) and all(np.array_equal(sa[f], sb[f]) for f in ("px", "py", "src_px", "src_py", "weight", "rgb"))
     for k in ("camera_rays", "closest_rays", "shadow_rays", "mis_rays", "shade_items", "closest_node_visits", "closest_tri_tests", "light_tri_tests"):
         assert ca[k] == cb[k], (k, ca[k], cb[k])

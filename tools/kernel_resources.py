@@ -18,7 +18,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def waves_per_simd(vgprs, agprs):
-    total = ((max(vgprs, 1) + 7) // 8) * 8 + ((agprs + 7) // 8) * 8  # unified register file, 8-register granules
+    # .vgpr_count of the metadata is the kernel's TOTAL allocation in the unified file (the compiler's TotalNumVgprs = accum_offset +
+    # AGPRs, which already contains .agpr_count); 8-register granules.  (Round 2's version added the AGPRs a second time and reported
+    # k_shade<2, .> -- 255 registers, 3 of them AGPRs -- at one wave per SIMD; it runs at two.)
+    total = ((max(vgprs, 1) + 7) // 8) * 8
     return max(1, min(8, 512 // total))
 
 
