@@ -72,6 +72,10 @@ struct PgScene {
     int nMedia = 0;
     DeviceBuffer vqo[2], vqd[2], vCounts, volMedium, trAcc[2], volP1[3], misLi, pdLi, hitT;
     DeviceBuffer qsL[2], qsBeta[2], qsMeta[2];  // PathIntegrator: path state in queue order
+    DeviceBuffer bssrdfs, materialBssrdf, bssrdfTables;  // subsurface scattering (ABI 24)
+    // the BSSRDF branch of Li: per-slot state between entry and exit vertex (SssState), the job queue, two probe queues
+    DeviceBuffer sssPo, sssFrame[3], sssCoef[2], sssTarget, sssCount, sssHit, sssHitO, sssHitD, sssHitInst, sssQo[3], sssQd[3], sssCounts, sssTail;
+    int sssCapacity = 0;
     DeviceBuffer lightHot;  // DScene::lightHot
     DeviceBuffer haltonDims;  // DScene::haltonDims
     DeviceBuffer cmaxmin, tsState, ts1, ts2;  // tile-serial samplers: CMaxMinDist, the tiles' sampler states and sample arrays
@@ -115,8 +119,8 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         return setError(PG_ERR_INVALID, "pg_scene_create: malformed geometry arrays");
     if (desc->n_grids != 0 || desc->media_grid)  // ABI 23 carries the tables; the two-phase shading they need is not built
         return setError(PG_ERR_UNSUPPORTED, "GridDensityMedium (\"heterogeneous\" medium) has no device kernels in this build");
-    if (desc->n_bssrdfs != 0 || desc->material_bssrdf)  // ABI 24 carries the tables; the BSSRDF branch of Li (path.cpp:152-174) has no kernels yet
-        return setError(PG_ERR_UNSUPPORTED, "subsurface scattering (\"subsurface\" / \"kdsubsurface\" materials) has no device kernels in this build");
+    if (desc->n_bssrdfs < 0 || (desc->n_bssrdfs > 0 && (!desc->bssrdfs || !desc->material_bssrdf || !desc->bssrdf_tables)))
+        return setError(PG_ERR_INVALID, "pg_scene_create: malformed BSSRDF tables");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev <= 0) return setError(PG_ERR_DEVICE, "no HIP device visible (there is no CPU fallback)");
@@ -536,6 +540,25 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
             }
         }
     }
+    if (desc->n_bssrdfs > 0) {  // subsurface scattering: the BSSRDFs, which material has one, the beam-diffusion tables
+        for (int k = 0; k < desc->n_bssrdfs; ++k) {
+            const PgBSSRDF &b = desc->bssrdfs[k];
+            const int64_t need = (int64_t)b.n_rho + b.n_radius + 2 * (int64_t)b.n_rho * b.n_radius + b.n_rho;
+            if (b.n_rho < 2 || b.n_radius < 2 || b.table < 0 || b.table + need > desc->n_bssrdf_floats || b.match_material < 0 || b.match_material >= desc->n_materials ||
+                b.a.tex >= desc->n_textures || b.b.tex >= desc->n_textures)
+                FAIL(PG_ERR_INVALID, "BSSRDF %d: table / material / texture out of range", k);
+        }
+        for (int m = 0; m < desc->n_materials; ++m)
+            if (desc->material_bssrdf[m] >= desc->n_bssrdfs) FAIL(PG_ERR_INVALID, "material %d: BSSRDF index out of range", m);
+        HIP_TRY_S(s->bssrdfs.alloc(sizeof(PgBSSRDF) * (size_t)desc->n_bssrdfs));
+        HIP_TRY_S(hipMemcpy(s->bssrdfs.p, desc->bssrdfs, s->bssrdfs.bytes, hipMemcpyHostToDevice));
+        HIP_TRY_S(s->materialBssrdf.alloc(sizeof(int32_t) * (size_t)desc->n_materials));
+        HIP_TRY_S(hipMemcpy(s->materialBssrdf.p, desc->material_bssrdf, s->materialBssrdf.bytes, hipMemcpyHostToDevice));
+        HIP_TRY_S(s->bssrdfTables.alloc(sizeof(float) * (size_t)desc->n_bssrdf_floats));
+        HIP_TRY_S(hipMemcpy(s->bssrdfTables.p, desc->bssrdf_tables, s->bssrdfTables.bytes, hipMemcpyHostToDevice));
+        d.bssrdfs = (const PgBSSRDF *)s->bssrdfs.p; d.materialBssrdf = (const int *)s->materialBssrdf.p; d.bssrdfTables = (const float *)s->bssrdfTables.p;
+        d.nBssrdfs = desc->n_bssrdfs;
+    }
     {  // participating media (HomogeneousMedium) and the primitives' MediumInterfaces
         s->nMedia = desc->n_media > 0 ? desc->n_media : 0;
         if (s->nMedia > 0 && !desc->media) FAIL(PG_ERR_INVALID, "n_media = %d without a media table", desc->n_media);
@@ -623,6 +646,8 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
                 HIP_TRY_S(hipMemset(s->voxelCounters.p, 0, 2 * sizeof(int)));
                 d.distTable = (const float *)s->distTable.p;
                 d.sparseLights = 1;
+                // (the exit vertices of subsurface paths look their light distribution up without the deferral the shading kernel has)
+                if (d.nBssrdfs > 0) FAIL(PG_ERR_UNSUPPORTED, "subsurface scattering with a spatial light distribution beyond the dense table's size: use \"lightsamplestrategy\" \"power\" or \"uniform\"");
                 d.voxelSlot = (int *)s->voxelSlot.p; d.voxelRequests = (int *)s->voxelRequests.p; d.voxelCounters = (int *)s->voxelCounters.p;
             } else {
                 HIP_TRY_S(s->distTable.alloc(total * stride * sizeof(float)));
@@ -664,7 +689,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
             d.distTable = (const float *)s->distTable.p;
         }
     }
-    HIP_TRY_S(s->traceCn.alloc(sizeof(TraceCounters) * 2));
+    HIP_TRY_S(s->traceCn.alloc(sizeof(TraceCounters) * 3));  // closest hit, any hit, and launches that are not the reference's (second walk of a BSSRDF probe chain)
     HIP_TRY_S(hipMemset(s->traceCn.p, 0, s->traceCn.bytes));
     HIP_TRY_S(s->cursors.alloc(2 * PG_REGIONS * PG_COUNT_STRIDE * sizeof(int)));
     HIP_TRY_S(s->cursors2.alloc(2 * PG_REGIONS * PG_COUNT_STRIDE * sizeof(int)));
@@ -894,6 +919,32 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
         }
         for (int i = 0; i < 2; ++i) { ps.qs[i].L = (float4 *)s->qsL[i].p; ps.qs[i].beta = (float4 *)s->qsBeta[i].p; ps.qs[i].meta = (int4 *)s->qsMeta[i].p; }
     }
+    // Subsurface scattering (PathIntegrator): per-slot state of the BSSRDF branch, the job queue and the two probe queues
+    const bool sssOn = s->d.nBssrdfs > 0;
+    if (sssOn && vol) return setError(PG_ERR_UNSUPPORTED, "volpath with subsurface (BSSRDF) materials: the device kernels cover the path integrator's BSSRDF branch only");
+    SssState sq;
+    memset(&sq, 0, sizeof(sq));
+    RayQueue sssP[2];
+    if (sssOn) {
+        const size_t n = (size_t)regionCapFor(capacity, s->d.sparseLights != 0) * PG_REGIONS;
+        if (s->sssCapacity < capacity) {
+            HIP_TRY(s->sssPo.alloc(n * sizeof(float4))); HIP_TRY(s->sssTarget.alloc(n * sizeof(float4))); HIP_TRY(s->sssCount.alloc(n * sizeof(int2)));
+            for (int i = 0; i < 3; ++i) HIP_TRY(s->sssFrame[i].alloc(n * sizeof(float4)));
+            for (int i = 0; i < 2; ++i) HIP_TRY(s->sssCoef[i].alloc(n * sizeof(float4)));
+            HIP_TRY(s->sssHit.alloc(n * sizeof(float4))); HIP_TRY(s->sssHitO.alloc(n * sizeof(float4))); HIP_TRY(s->sssHitD.alloc(n * sizeof(float4)));
+            HIP_TRY(s->sssHitInst.alloc(n * sizeof(int)));
+            for (int i = 0; i < 3; ++i) { HIP_TRY(s->sssQo[i].alloc(n * sizeof(float4))); HIP_TRY(s->sssQd[i].alloc(n * sizeof(float4))); }
+            HIP_TRY(s->sssCounts.alloc(3 * QSTRIDE * sizeof(int)));
+            HIP_TRY(s->sssTail.alloc(QSTRIDE * sizeof(int)));
+            s->sssCapacity = capacity;
+        }
+        sq.po = (float4 *)s->sssPo.p; sq.target = (float4 *)s->sssTarget.p; sq.count = (int2 *)s->sssCount.p;
+        for (int i = 0; i < 3; ++i) sq.frame[i] = (float4 *)s->sssFrame[i].p;
+        for (int i = 0; i < 2; ++i) sq.coef[i] = (float4 *)s->sssCoef[i].p;
+        sq.hit = (float4 *)s->sssHit.p; sq.hitO = (float4 *)s->sssHitO.p; sq.hitD = (float4 *)s->sssHitD.p; sq.hitInst = (int *)s->sssHitInst.p;
+        sq.qjob.o = (float4 *)s->sssQo[0].p; sq.qjob.d = (float4 *)s->sssQd[0].p; sq.qjob.counts = (int *)s->sssCounts.p;
+        for (int i = 0; i < 2; ++i) { sssP[i].o = (float4 *)s->sssQo[1 + i].p; sssP[i].d = (float4 *)s->sssQd[1 + i].p; sssP[i].counts = (int *)s->sssCounts.p + (1 + i) * QSTRIDE; }
+    }
     ps.L = (float4 *)s->stL.p; ps.beta = (float4 *)s->stBeta.p; ps.meta = (int4 *)s->stMeta.p;
     ps.pdLight = (float4 *)s->pdLight.p; ps.pdMis = (float4 *)s->pdMis.p; ps.pdBeta = (float4 *)s->pdBeta.p; ps.pdInfo = (int4 *)s->pdInfo.p;
     int *counts = (int *)s->counts.p;
@@ -953,6 +1004,7 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
     auto tracePaths = [&](const std::function<void()> &generate, const std::function<void()> &filmSamples) -> int {
         {
             for (int i = 0; i < 4; ++i) q[i].regionCap = regionCapFor(rp.capacity, s->d.sparseLights != 0);
+            if (sssOn) { sq.qjob.regionCap = q[0].regionCap; sssP[0].regionCap = sssP[1].regionCap = q[0].regionCap; }
             curQueueOfBounce.clear();
             HIP_TRY(hipMemsetAsync(counts, 0, 4 * QSTRIDE * sizeof(int), stream));
             int cur = 0;  // main queue index (0/1 ping-pong); 2 = shadow, 3 = MIS
@@ -1032,9 +1084,11 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                 const int nxt = cur ^ 1;
                 HIP_TRY(hipMemsetAsync(counts + nxt * QSTRIDE, 0, QSTRIDE * sizeof(int), stream));
                 HIP_TRY(hipMemsetAsync(counts + 2 * QSTRIDE, 0, 2 * QSTRIDE * sizeof(int), stream));
-                PG_TIMED(2, stream, launch_shade(s->d, rp, ps, q[cur], (const float4 *)s->hitsMain.p, q[nxt], q[2], q[3], lightTests, stream, cur));
+                if (sssOn) HIP_TRY(hipMemsetAsync(sq.qjob.counts, 0, QSTRIDE * sizeof(int), stream));
+                const SssState *sssArg = sssOn ? &sq : nullptr;
+                PG_TIMED(2, stream, launch_shade(s->d, rp, ps, q[cur], (const float4 *)s->hitsMain.p, q[nxt], q[2], q[3], lightTests, stream, cur, sssArg));
                 ++shadeLaunches;
-                if (int e = settleLightTables([&]() { launch_shade(s->d, rp, ps, q[cur], (const float4 *)s->hitsMain.p, q[nxt], q[2], q[3], lightTests, stream, cur); })) return e;
+                if (int e = settleLightTables([&]() { launch_shade(s->d, rp, ps, q[cur], (const float4 *)s->hitsMain.p, q[nxt], q[2], q[3], lightTests, stream, cur, sssArg); })) return e;
                 // paths that reach maxdepth neither continue nor sample lights (path.cpp:104): nothing left to trace
                 const bool lastDepth = !s->hasNullMaterial && bounce >= rd->max_depth;
                 if (!lastDepth) {
@@ -1064,6 +1118,57 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                 // log this bounce's queue sizes
                 HIP_TRY(hipMemcpyAsync((int *)countLog.p + 4 * QSTRIDE * (size_t)bounce, counts, 4 * QSTRIDE * sizeof(int), hipMemcpyDeviceToDevice, stream));
                 curQueueOfBounce.push_back(cur);
+                if (sssOn && !lastDepth) {
+                    // ---- the BSSRDF branch of Li (path.cpp:152-174) for the paths k_shade handed over: the probe chains of
+                    // SeparableBSSRDF::Sample_Sp walked twice through the traversal kernel (count the hits on the material; stop at
+                    // the chosen one), then the exit vertices: their shadow / MIS rays, the tail of the next bounce's queue that
+                    // their next rays form, and the resolve of their direct lighting.  One counter read-back per step.
+                    std::vector<int> jb(QSTRIDE);
+                    auto regionSum = [&](const int *dev, uint64_t &total) -> int {
+                        HIP_TRY(hipMemcpyAsync(jb.data(), dev, QSTRIDE * sizeof(int), hipMemcpyDeviceToHost, stream));
+                        HIP_TRY(hipStreamSynchronize(stream));
+                        total = 0;
+                        for (int r = 0; r < PG_REGIONS; ++r) total += (uint64_t)jb[r * PG_COUNT_STRIDE];
+                        return PG_OK;
+                    };
+                    uint64_t nJobs = 0;
+                    if (int e = regionSum(sq.qjob.counts, nJobs)) return e;
+                    if (nJobs > 0) {
+                        const size_t n1 = (size_t)q[0].regionCap * PG_REGIONS;
+                        DScene dprobe = s->d;  // the probe rays' hits go where the MIS rays' went (k_resolve is done with those)
+                        if (dprobe.hitInst) dprobe.hitInst += n1;
+                        for (int pass = 1; pass <= 2; ++pass) {
+                            RayQueue curQ = sq.qjob;
+                            uint64_t nRays = nJobs;
+                            for (int step = 0; nRays > 0; ++step) {
+                                if (step > 1000000) return setError(PG_ERR_DEVICE, "pg_render: a BSSRDF probe chain did not terminate");
+                                RayQueue outQ = sssP[step & 1];
+                                HIP_TRY(hipMemsetAsync(outQ.counts, 0, QSTRIDE * sizeof(int), stream));
+                                // the second walk repeats queries the reference makes once: its rays and traversal work are not counted
+                                launch_closest(dprobe, s->trace, curQ, hitsMis, nullptr, pass == 1 ? cnClosest : cnClosest + 2, (int *)s->cursors.p, (int *)s->cullGuard.p, stream);
+                                if (pass == 1) { closestRays += nRays; ++closestLaunches; }
+                                launch_sss_probe(dprobe, sq, pass, curQ, hitsMis, outQ, stream);
+                                if (int e = regionSum(outQ.counts, nRays)) return e;
+                                curQ = outQ;
+                            }
+                        }
+                        HIP_TRY(hipMemcpyAsync(s->sssTail.p, counts + nxt * QSTRIDE, QSTRIDE * sizeof(int), hipMemcpyDeviceToDevice, stream));
+                        HIP_TRY(hipMemsetAsync(counts + 2 * QSTRIDE, 0, 2 * QSTRIDE * sizeof(int), stream));
+                        launch_sss_exit(s->d, rp, ps, sq, q[nxt], q[2], q[3], lightTests, stream, nxt, false, vs);
+                        ++shadeLaunches; shadeItems += nJobs;
+                        launch_anyhit(s->d, s->trace, q[2], (int *)s->occluded.p, cnShadow, (int *)s->cursors2.p, stream);
+                        ++shadowLaunches;
+                        launch_closest2(s->d, s->trace, q[nxt], q[3], (float4 *)s->hitsMain.p, (int)n1, cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream, nullptr,
+                                        (const int *)s->sssTail.p);
+                        ++closestLaunches;
+                        launch_resolve(s->d, ps, sq.qjob, q[3], (const int *)s->occluded.p, (const float4 *)hitsMis, stream, cur);
+                        ++resolveLaunches;
+                        uint64_t nSh = 0, nMis = 0;
+                        if (int e = regionSum(counts + 2 * QSTRIDE, nSh)) return e;
+                        if (int e = regionSum(counts + 3 * QSTRIDE, nMis)) return e;
+                        shadowRays += nSh; closestRays += nMis; misRays += nMis;  // (the next rays are counted with the next bounce's queue)
+                    }
+                }
                 cur = nxt;
                 if ((s->hasNullMaterial && bounce >= rd->max_depth) || (bounce >= PG_MAX_BLIND_BOUNCES && bounce % 32 == 0)) {
                     std::vector<int> blk(4 * QSTRIDE);

@@ -90,6 +90,11 @@ struct DScene {
     const PgMedium *media;               // HomogeneousMedium table; triMediumIn/Out[k] = the primitive's MediumInterface (-1 = none), or nullptr
     const int *triMediumIn, *triMediumOut;
     const PgBxDF *bxdfs;      // the materials' BxDF lists (PgMaterial.first_bxdf / n_bxdfs)
+    // subsurface scattering (ABI 24): materialBssrdf[m] >= 0 = ComputeScatteringFunctions of material m also sets si->bssrdf
+    const PgBSSRDF *bssrdfs;
+    const int *materialBssrdf;
+    const float *bssrdfTables;
+    int nBssrdfs;
     int ext;          // the EXT shading kernels are needed: spheres, infinite lights or PG_MAT_LOBES materials (or PG_FORCE_EXT=1)
     int hasInfinite;  // some light is an InfiniteAreaLight (Scene::infiniteLights non-empty)
     // light sampling distributions (lightdistrib.cpp): strategy + tables
@@ -174,6 +179,22 @@ struct VolState {
     float4 *pdLi;       // (Li rgb of the light sample, lightPdf)
 };
 
+// The BSSRDF branch of PathIntegrator::Li / VolPathIntegrator::Li (path.cpp:152-174, volpath.cpp:151-176) between the vertex po where
+// the path enters the medium and the exit vertex pi that SeparableBSSRDF::Sample_Sp finds (bssrdf.cpp:253-328): indexed by slot.
+// The probe segment of Sample_Sp is a chain of closest-hit queries that keeps every hit on po's material and then picks one
+// uniformly: the chain is walked twice through k_trace -- once to count, once up to the chosen hit.
+struct SssState {
+    float4 *po;        // (po.p, u1 as Sample_Sp leaves it for the choice among the hits)
+    float4 *frame[3];  // (ns, eta) (ss, BSSRDF index as int bits) (ts, SeparableBSSRDF::material as int bits): po's shading frame
+    float4 *coef[2];   // TabulatedBSSRDF::sigma_t, ::rho at po (per hit for textured materials)
+    float4 *target;    // (pTarget, 0): the far end of the probe segment
+    int2 *count;       // (hits on the material found by the first walk, hits on it seen so far by the second)
+    float4 *hit;       // the chosen hit's record as k_trace wrote it, the probe ray that found it (o, d) and the instance it was in
+    float4 *hitO, *hitD;
+    int *hitInst;
+    RayQueue qjob;     // the first probe ray of every path that entered this branch at the current bounce (appended by k_shade)
+};
+
 #define PG_META_SPECULAR 0x10000
 #define PG_META_DONE 0x20000
 #define PG_META_HASDIFF 0x80000  // the ray still is the camera's RayDifferential (cleared by the first SpawnRay)
@@ -208,10 +229,12 @@ struct TraceConfig { int depth, segRays /* rays per chunk */, refillAt, triW; fl
 // The defaults, with the PG_TRACE_* environment overrides of experiments and tests applied.  Every scene carries its own copy
 // (PgScene::trace): the exact-fallback retry of one scene must not change what another host thread's launches use.
 TraceConfig default_trace_config();
-void launch_closest(const DScene &sc, const TraceConfig &c, RayQueue q, float4 *hits, float *tOut, TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s);
+// cursorInit (device, optional): q's region counters as they were before entries were appended -- only the appended entries are traced
+void launch_closest(const DScene &sc, const TraceConfig &c, RayQueue q, float4 *hits, float *tOut, TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s,
+                    const int *cursorInit = nullptr);
 // two queues in one launch; q1's results land at hits[hitOffset1 + i]
 void launch_closest2(const DScene &sc, const TraceConfig &c, RayQueue q0, RayQueue q1, float4 *hits, int hitOffset1, TraceCounters *cn, int *cursors, int *cullGuard,
-                     hipStream_t s, float *tOut = nullptr);
+                     hipStream_t s, float *tOut = nullptr, const int *cursorInit = nullptr);
 void launch_anyhit(const DScene &sc, const TraceConfig &c, RayQueue q, int *occluded, TraceCounters *cn, int *cursors, hipStream_t s);
 void launch_generate(const DScene &sc, const RenderParams &rp, PathState st, RayQueue q, hipStream_t s);
 // tile-serial samplers: seed the tiles' streams; StartPixel for pixel (lx, ly) of every tile; the camera sample + ray of sample
@@ -223,7 +246,13 @@ void launch_ts_film(const DScene &sc, const RenderParams &rp, PathState st, PgFi
                     hipStream_t s);
 // cur: which of st.qs[] accompanies qin (the other one accompanies qnext)
 void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQueue qin, const float4 *hits, RayQueue qnext,
-                  RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s, int cur = 0);
+                  RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s, int cur = 0, const SssState *sss = nullptr);
+// Subsurface scattering: one step of the probe chains (pass 1: count the hits on the material; pass 2: stop at the chosen one) over
+// the rays of qin (results at hits[i], instances at sc.hitInst[i]), continued rays to qout; then the exit vertices of the jobs of
+// sss.qjob: Pdf_Sp / Sr, direct lighting (shadow / MIS rays, pending terms at the job's queue index) and the next ray (appended to qnext)
+void launch_sss_probe(const DScene &sc, SssState sss, int pass, RayQueue qin, const float4 *hits, RayQueue qout, hipStream_t s);
+void launch_sss_exit(const DScene &sc, const RenderParams &rp, PathState st, SssState sss, RayQueue qnext, RayQueue qshadow, RayQueue qmis,
+                     unsigned long long *lightTriTests, hipStream_t s, int nxt, bool vol, VolState vs);
 void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis, const int *occluded, const float4 *misHits, hipStream_t s,
                     int cur = 0);
 // VolPathIntegrator: the shading step with medium sampling (hitT = the hits' ray parameters), one step of the through rays of

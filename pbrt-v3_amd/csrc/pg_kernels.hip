@@ -15,6 +15,7 @@
 #include "pg_sphere.h"
 #include "pg_kernels.h"
 #include "pg_texture.h"
+#include "pg_bssrdf.h"
 
 #define PG_BLOCK 256
 // threads per block of the shading kernel: its blocks meet at two barriers around the queue append, so a block is only as fast
@@ -1819,11 +1820,17 @@ void shade_prof_dump() {
 #else
 #define PROF(k) do { } while (0)
 #endif
-template <int MODE, bool VOL>
+// SSS: the scene has materials with a BSSRDF (subsurface / kdsubsurface): a vertex whose sampled direction is a transmission leaves
+// through the BSSRDF branch of Li (path.cpp:152-174) -- the lane draws Sample_S's numbers, builds the probe segment of Sample_Sp and
+// hands the path over to the probe / exit kernels below instead of pushing its next ray.  A separate instantiation: scenes without
+// such materials run the code they ran before.
+template <int MODE, bool VOL, bool SSS = false>
 __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MODE == 1 && PG_SHADE_MIN_WAVES > 0) ? PG_SHADE_MIN_WAVES : (MODE == 2 ? (VOL ? PG_SHADE2V_WAVES : PG_SHADE2_WAVES) : 1))) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
                                                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, VolState vs,
-                                                     const float *__restrict__ hitT, QueueState qsIn, QueueState qsOut) {
+                                                     const float *__restrict__ hitT, QueueState qsIn, QueueState qsOut, SssState sss) {
     constexpr bool EXT = MODE >= 1, TEX = MODE == 2;
+    static_assert(!SSS || EXT, "materials with a BSSRDF are BxDF-list materials");
+    bool pushJob = false;  // SSS: this lane's path goes on through the BSSRDF (its probe ray waits in s_ray[0])
     constexpr bool QSTATE = !VOL;  // path state and pending terms in queue order (see PathState)
 #ifdef PG_SHADE_PROF
     const bool profOn = (blockIdx.x & 127) == 0;
@@ -2089,6 +2096,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
                 }
                 Bsdf bsdf;
                 LobeBsdf lb;
+                int sssIdx = -1;  // SSS: index of the hit's BSSRDF, or none
                 PgBxDF lobeStore[TEX ? PG_MAX_BXDFS : 1];  // MODE 2: this hit's BxDF list (ComputeScatteringFunctions with textures)
                 if constexpr (EXT) {
                     TexHit th;
@@ -2177,6 +2185,36 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
                         MatEval<2>::run(sc, tri.material, th, lobeStore, nl, etaL);
                         lb.lobes = lobeStore; lb.n = nl; lb.eta = etaL;
                     } else { lb.lobes = sc.bxdfs + m.first_bxdf; lb.n = m.n_bxdfs; lb.eta = m.bsdf_eta; }
+                    if constexpr (SSS) {  // si->bssrdf = TabulatedBSSRDF(...): subsurface.cpp:87-90, kdsubsurface.cpp:88-93
+                        sssIdx = sc.materialBssrdf[tri.material];
+                        if (sssIdx >= 0) {
+                            const PgBSSRDF &bd = sc.bssrdfs[sssIdx];
+                            float sigT[3] = {bd.sigma_t[0], bd.sigma_t[1], bd.sigma_t[2]}, rho[3] = {bd.rho[0], bd.rho[1], bd.rho[2]};
+                            if (bd.textured) {
+                                if (lb.n == 0) sssIdx = -1;  // ComputeScatteringFunctions returned before it set the BSSRDF (R and T both black)
+                                else if constexpr (TEX) {
+                                    const Spec ta = sp_clamp0(TexEval<PG_TEX_DEPTH>::s(sc, bd.a, th)), tb = sp_clamp0(TexEval<PG_TEX_DEPTH>::s(sc, bd.b, th));
+                                    const float a3[3] = {ta.r, ta.g, ta.b}, b3[3] = {tb.r, tb.g, tb.b};
+                                    const DBssrdf tbl = bssrdf_bind(bd, sc.bssrdfTables);
+                                    for (int c = 0; c < 3; ++c) {
+                                        float sa, ssc;
+                                        if (bd.textured == 1) { sa = a3[c] * bd.scale; ssc = b3[c] * bd.scale; }  // subsurface.cpp:87-88
+                                        else {  // SubsurfaceFromDiffuse(table, Kd, scale * mfp), bssrdf.cpp:182-191
+                                            const float mfree = b3[c] * bd.scale;
+                                            const float r = invert_catmull_rom(tbl.nRho, tbl.rhoSamples, tbl.rhoEff, a3[c]);
+                                            ssc = r / mfree; sa = (1 - r) / mfree;
+                                        }
+                                        sigT[c] = sa + ssc;  // TabulatedBSSRDF's constructor, bssrdf.h:146-150
+                                        rho[c] = sigT[c] != 0 ? (ssc / sigT[c]) : 0;
+                                    }
+                                }
+                            }
+                            if (sssIdx >= 0) {
+                                sss.coef[0][slot] = make_float4(sigT[0], sigT[1], sigT[2], 0);
+                                sss.coef[1][slot] = make_float4(rho[0], rho[1], rho[2], 0);
+                            }
+                        }
+                    }
                 } else {
                     bsdf.ns = is.ns; bsdf.ng = is.n;
                     bsdf.ss = normalize(is.sdpdu);
@@ -2312,9 +2350,40 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
                     nextBin = (wi.x < 0 ? 1 : 0) | (wi.y < 0 ? 2 : 0) | (wi.z < 0 ? 4 : 0);
                     pushNext = true;
                     if constexpr (VOL) { if (!deferred) vs.medium[slot] = dot(wi, is.n) > 0 ? mOut : mIn; }
-                    // Russian roulette, path.cpp:176-184
+                    bool throughBssrdf = false;
+                    if constexpr (SSS) {
+                        if (sssIdx >= 0 && (sampledType & PG_BSDF_TRANSMISSION)) {
+                            // path.cpp:152-156: bssrdf->Sample_S(scene, sampler.Get1D(), sampler.Get2D(), ...) -- the reference build
+                            // evaluates the arguments right to left: the 2D sample is drawn first.  Then the first half of
+                            // SeparableBSSRDF::Sample_Sp (bssrdf.cpp:257-292): the probe segment; the path ends here when there is none
+                            throughBssrdf = true;
+                            pushNext = false;
+                            float u2x, u2y;
+                            draw2(u2x, u2y);
+                            float u1 = draw1();
+                            DBssrdf b = bssrdf_bind(sc.bssrdfs[sssIdx], sc.bssrdfTables);
+                            const float4 cs = sss.coef[0][slot], cr = sss.coef[1][slot];
+                            b.sigma_t[0] = cs.x; b.sigma_t[1] = cs.y; b.sigma_t[2] = cs.z; b.rho[0] = cr.x; b.rho[1] = cr.y; b.rho[2] = cr.z;
+                            V3 baseP, pTarget;
+                            if (bssrdf_probe_segment(b, lb.ss, lb.ts, lb.ns, is.p, u1, u2x, u2y, baseP, pTarget)) {
+                                const V3 pd = pTarget - baseP;  // base.SpawnRayTo(pTarget) of an Interaction without normal or error: from baseP itself
+                                if (!(pd.x == 0 && pd.y == 0 && pd.z == 0)) {  // bssrdf.cpp:306: a zero direction ends the chain before it starts
+                                    s_ray[0][0][tid] = make_float4(baseP.x, baseP.y, baseP.z, 1 - PG_SHADOW_EPS);
+                                    s_ray[0][1][tid] = make_float4(pd.x, pd.y, pd.z, __int_as_float(slot));
+                                    pushJob = true;
+                                    sss.po[slot] = make_float4(is.p.x, is.p.y, is.p.z, u1);
+                                    sss.frame[0][slot] = make_float4(lb.ns.x, lb.ns.y, lb.ns.z, b.eta);
+                                    sss.frame[1][slot] = make_float4(lb.ss.x, lb.ss.y, lb.ss.z, __int_as_float(sssIdx));
+                                    sss.frame[2][slot] = make_float4(lb.ts.x, lb.ts.y, lb.ts.z, __int_as_float(sc.bssrdfs[sssIdx].match_material));
+                                    sss.target[slot] = make_float4(pTarget.x, pTarget.y, pTarget.z, 0);
+                                    sss.count[slot] = make_int2(0, 0);
+                                }
+                            }
+                        }
+                    }
+                    // Russian roulette, path.cpp:176-184 (a path inside the BSSRDF branch: at its exit vertex, k_sss_exit)
                     Spec rrBeta = beta * etaScale;
-                    if (max_component(rrBeta) < rd.rr_threshold && bounces > 3) {
+                    if (!throughBssrdf && max_component(rrBeta) < rd.rr_threshold && bounces > 3) {
                         float qq = pmax(.05f, 1 - max_component(rrBeta));
                         if (draw1() < qq) pushNext = false;
                         else beta = beta / (1 - qq);
@@ -2395,6 +2464,21 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
             st.pdInfo[pdi] = make_int4(posShadow, posMis, lightNum, pushNext ? posNext : ~slot);
         }
     } else if (valid && !deferred) st.pdInfo[slot] = make_int4(posShadow, posMis, lightNum, VOL ? __float_as_int(volWeight) : 0);
+    if constexpr (SSS) {
+        // the probe rays of the paths that go on through a BSSRDF, region by region like every other queue; such a path's L went to
+        // its slot above (where k_resolve adds this vertex's direct lighting), beta and meta follow it there
+        if (deferred) pushJob = false;
+        int posJob;
+        block_push<1, false, PG_SHADE_BLOCK>(&sss.qjob, &pushJob, &posJob);
+        if (pushJob) {
+            sss.qjob.o[posJob] = s_ray[0][0][tid]; sss.qjob.d[posJob] = s_ray[0][1][tid];
+            if constexpr (QSTATE) {
+                const float4 m4 = s_state[2][tid];
+                st.beta[slot] = s_state[1][tid];
+                st.meta[slot] = make_int4(__float_as_int(m4.x), __float_as_int(m4.y), __float_as_int(m4.z), __float_as_int(m4.w));
+            }
+        }
+    }
     unsigned long long nl = wave_sum(nLightTests);
     if (lane_id() == 0 && nl) atomicAdd(lightTriTests + (blockIdx.x & (PG_LIGHT_TEST_SHARDS - 1)) * PG_LIGHT_TEST_STRIDE, nl);
 #ifdef PG_SHADE_PROF
@@ -2403,23 +2487,28 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
 #endif
 }
 void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQueue qin, const float4 *hits, RayQueue qnext,
-                  RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s, int cur) {
+                  RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s, int cur, const SssState *sss) {
     int nblk = rp.retryCount > 0 ? (rp.retryCount + PG_SHADE_BLOCK - 1) / PG_SHADE_BLOCK : PG_REGIONS * (qin.regionCap / PG_SHADE_BLOCK);
     if (nblk == 0) return;
     const VolState vs = {};
     const float *noT = nullptr;
     const QueueState qi = st.qs[cur], qo = st.qs[cur ^ 1];
-    if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo);
-    else if (sc.ext) hipLaunchKernelGGL((k_shade<1, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo);
-    else hipLaunchKernelGGL((k_shade<0, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo);
+    const SssState none = {};
+    if (sss && sc.nBssrdfs > 0) {  // materials with a BSSRDF are BxDF-list materials: the general kernels
+        if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, false, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, *sss);
+        else hipLaunchKernelGGL((k_shade<1, false, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, *sss);
+    } else if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, none);
+    else if (sc.ext) hipLaunchKernelGGL((k_shade<1, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, none);
+    else hipLaunchKernelGGL((k_shade<0, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, none);
 }
 void launch_shade_vol(const DScene &sc, const RenderParams &rp, PathState st, VolState vs, RayQueue qin, const float4 *hits, const float *hitT,
                       RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s) {
     int nblk = rp.retryCount > 0 ? (rp.retryCount + PG_SHADE_BLOCK - 1) / PG_SHADE_BLOCK : PG_REGIONS * (qin.regionCap / PG_SHADE_BLOCK);
     if (nblk == 0) return;
     const QueueState none = {nullptr, nullptr, nullptr};
-    if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none);
-    else hipLaunchKernelGGL((k_shade<1, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none);
+    const SssState nosss = {};
+    if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss);
+    else hipLaunchKernelGGL((k_shade<1, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss);
 }
 
 // EstimateDirect's two "Add ... contribution" steps (integrator.cpp:143-161, 196-212) and
@@ -2613,6 +2702,334 @@ __global__ void k_fill_int(int *p, int value, int n) {
 }
 void launch_fill_int(int *p, int value, int n, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_fill_int, dim3((n + 255) / 256), dim3(256), 0, s, p, value, n);
+}
+
+// ===========================================================================
+// Subsurface scattering: the rest of the BSSRDF branch of PathIntegrator::Li (path.cpp:152-174) behind k_shade<., ., true>.
+// SeparableBSSRDF::Sample_Sp (bssrdf.cpp:253-328) intersects the probe segment base -> pTarget again and again from each hit
+// (`base = next->si`), keeps every hit on primitives of the entry point's material in a list and picks entry (int)(u1 * nFound).
+// Here a chain is walked twice by the traversal kernel -- a list per path has no bound (degenerate soups give hundreds of hits) --:
+// pass 1 counts the hits on the material, pass 2 stops at the chosen one.  Each step is one k_trace<0, .> launch over the
+// chains still under way followed by k_sss_probe.
+// ===========================================================================
+template <int PASS>
+__global__ __launch_bounds__(PG_BLOCK) void k_sss_probe(DScene sc, SssState sss, RayQueue qin, const float4 *__restrict__ hits, RayQueue qout) {
+    const int i = queue_item<>(qin);
+    bool push = false;
+    float4 no = make_float4(0, 0, 0, 0), nd = make_float4(0, 0, 0, 0);
+    if (i >= 0) {
+        const float4 o4 = qin.o[i], d4 = qin.d[i];
+        const int slot = __float_as_int(d4.w);
+        const V3 rayD = mk(d4.x, d4.y, d4.z);
+        const float4 h4 = hits[i];
+        const int prim = __float_as_int(h4.x);
+        int2 cnt = sss.count[slot];
+        bool go = prim >= 0;  // bssrdf.cpp:306: no intersection ends the chain
+        if (PASS == 2 && cnt.x == 0) go = false;  // nothing to choose from
+        if (go) {
+            const Tri tri = load_tri(sc, prim);
+            if (tri.material == __float_as_int(sss.frame[2][slot].w)) {  // bssrdf.cpp:311: si.primitive->GetMaterial() == this->material
+                if (PASS == 1) ++cnt.x;
+                else {
+                    const float u1 = sss.po[slot].w;
+                    int selected = (int)(u1 * cnt.x);  // bssrdf.cpp:321
+                    selected = selected < 0 ? 0 : (selected > cnt.x - 1 ? cnt.x - 1 : selected);
+                    if (cnt.y == selected) {
+                        sss.hit[slot] = h4; sss.hitO[slot] = o4; sss.hitD[slot] = d4;
+                        sss.hitInst[slot] = sc.hitInst ? sc.hitInst[i] : -1;
+                        go = false;
+                    }
+                    ++cnt.y;
+                }
+                sss.count[slot] = cnt;
+            }
+            if (go) {  // base = next->si; base.SpawnRayTo(pTarget): interaction.h:65-71
+                V3 p, pError, n;
+                through_point(sc, i, o4, rayD, h4, prim, tri, p, pError, n);
+                const float4 tg = sss.target[slot];
+                const V3 d = mk(tg.x, tg.y, tg.z) - p;
+                if (!(d.x == 0 && d.y == 0 && d.z == 0)) {
+                    const V3 origin = offset_ray_origin(p, pError, n, d);
+                    no = make_float4(origin.x, origin.y, origin.z, 1 - PG_SHADOW_EPS);
+                    nd = make_float4(d.x, d.y, d.z, __int_as_float(slot));
+                    push = true;
+                }
+            }
+        }
+    }
+    int pos;
+    block_push<1, false>(&qout, &push, &pos);
+    if (push) { qout.o[pos] = no; qout.d[pos] = nd; }
+}
+void launch_sss_probe(const DScene &sc, SssState sss, int pass, RayQueue qin, const float4 *hits, RayQueue qout, hipStream_t s) {
+    int nblk = PG_REGIONS * (qin.regionCap / PG_BLOCK);
+    if (nblk == 0) return;
+    if (pass == 1) hipLaunchKernelGGL(k_sss_probe<1>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, sss, qin, hits, qout);
+    else hipLaunchKernelGGL(k_sss_probe<2>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, sss, qin, hits, qout);
+}
+
+// The BSDF at a BSSRDF's exit point: one SeparableBSSRDFAdapter (bssrdf.h:209-225), a BxDF of type BSDF_REFLECTION | BSDF_DIFFUSE
+// with f = Sw(wi) * eta^2 (TransportMode::Radiance) and BxDF's own cosine-hemisphere Sample_f / Pdf (reflection.cpp:383-394), under
+// BSDF::f / ::Pdf / ::Sample_f (reflection.cpp:680-796) for a list of one.
+struct AdapterBsdf { V3 ns, ng, ss, ts; float eta; };
+PG_DEV V3 ad_to_local(const AdapterBsdf &b, V3 v) { return mk(dot(v, b.ss), dot(v, b.ts), dot(v, b.ns)); }
+PG_DEV V3 ad_to_world(const AdapterBsdf &b, V3 v) {
+    return mk(b.ss.x * v.x + b.ts.x * v.y + b.ns.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ns.y * v.z, b.ss.z * v.x + b.ts.z * v.y + b.ns.z * v.z);
+}
+PG_DEV Spec ad_lobe_f(const AdapterBsdf &b, V3 wiLocal) { return sp(bssrdf_adapter_f(b.eta, wiLocal.z, fr_dielectric(wiLocal.z, 1, b.eta))); }
+PG_DEV Spec ad_f(const AdapterBsdf &b, V3 woW, V3 wiW, int flags) {
+    const V3 wi = ad_to_local(b, wiW), wo = ad_to_local(b, woW);
+    if (wo.z == 0) return sp(0);
+    const int type = PG_BSDF_REFLECTION | PG_BSDF_DIFFUSE;
+    const bool reflect = dot(wiW, b.ng) * dot(woW, b.ng) > 0;
+    return ((type & flags) == type && reflect) ? ad_lobe_f(b, wi) : sp(0);
+}
+PG_DEV float ad_pdf(const AdapterBsdf &b, V3 woW, V3 wiW, int flags) {
+    const V3 wo = ad_to_local(b, woW), wi = ad_to_local(b, wiW);
+    if (wo.z == 0) return 0.f;
+    const int type = PG_BSDF_REFLECTION | PG_BSDF_DIFFUSE;
+    if ((type & flags) != type) return 0.f;
+    return same_hemisphere(wo, wi) ? fabsf(wi.z) * PG_INVPI : 0;
+}
+PG_DEV Spec ad_sample_f(const AdapterBsdf &b, V3 woW, V3 &wiW, float u0, float u1, float &pdf, int flags, int &sampledType) {
+    const int type = PG_BSDF_REFLECTION | PG_BSDF_DIFFUSE;
+    sampledType = 0;
+    pdf = 0;
+    if ((type & flags) != type) return sp(0);  // matchingComps == 0
+    const float uR0 = pmin(u0 * 1 - 0, PG_ONE_MINUS_EPS);  // one matching component: comp = 0
+    const V3 wo = ad_to_local(b, woW);
+    if (wo.z == 0) return sp(0);
+    sampledType = type;
+    V3 wi = cosine_sample_hemisphere(uR0, u1);
+    if (wo.z < 0) wi.z *= -1;
+    pdf = same_hemisphere(wo, wi) ? fabsf(wi.z) * PG_INVPI : 0;
+    if (pdf == 0) { sampledType = 0; return sp(0); }
+    wiW = ad_to_world(b, wi);
+    return (dot(wiW, b.ng) * dot(woW, b.ng) > 0) ? ad_lobe_f(b, wi) : sp(0);
+}
+
+// The exit vertex pi of a path that went through a BSSRDF (path.cpp:157-174): Sp and its pdf (bssrdf.cpp:322-327), beta *= S / pdf,
+// direct lighting at pi under the adapter BSDF (UniformSampleOneLight / EstimateDirect: the shadow and MIS rays and their pending terms,
+// indexed by the job's queue position, resolved by k_resolve over the job queue), the next direction, Russian roulette (path.cpp:176-184).
+// The path's L, beta and meta wait in their slot (k_shade put them there; k_resolve added the entry vertex's direct lighting to L).
+__global__ __launch_bounds__(PG_SHADE_BLOCK) void k_sss_exit(DScene sc, RenderParams rp, PathState st, SssState sss, RayQueue qnext, RayQueue qshadow,
+                                                            RayQueue qmis, unsigned long long *lightTriTests, QueueState qsOut) {
+    const int j = queue_item<PG_SHADE_BLOCK>(sss.qjob);
+    __shared__ float4 s_ray[3][2][PG_SHADE_BLOCK];
+    const int tid = threadIdx.x;
+    bool pushNext = false, pushShadow = false, pushMis = false;
+    int slot = 0, lightNum = -1, nextBin = 0;
+    unsigned int nLightTests = 0;
+    float4 outL = make_float4(0, 0, 0, 0), outB = make_float4(0, 0, 0, 0);
+    int4 outM = make_int4(0, 0, 0, 0);
+    bool alive = false;
+    if (j >= 0) {
+        slot = __float_as_int(sss.qjob.d[j].w);
+        st.pdInfo[j] = make_int4(-1, -1, -1, ~slot);
+        const int2 cnt = sss.count[slot];
+        alive = cnt.x > 0;  // bssrdf.cpp:318: no hit on the material: Sample_Sp returns black and the path ends (its L is in its slot)
+    }
+    if (alive) {
+        const PgRenderDesc &rd = rp.rd;
+        const float4 L4 = st.L[slot], B4 = st.beta[slot];
+        const int4 meta = st.meta[slot];
+        Spec L = sp3(L4.x, L4.y, L4.z), beta = sp3(B4.x, B4.y, B4.z);
+        const uint64_t index = (uint64_t)(uint32_t)meta.x | ((uint64_t)(uint32_t)meta.y << 32);
+        int dim = (int)((uint32_t)meta.w >> 20);
+        const float etaScale = __int_as_float(meta.z);
+        const int bounces = meta.w & 0xffff;  // already counts this vertex (k_shade)
+        const bool tileSerial = rd.sampler >= PG_SAMPLER_RANDOM;
+        auto draw1 = [&]() -> float { return tileSerial ? ts_get1d(sc, slot) : halton_sample(sc, rd, index, dim++); };
+        auto draw2 = [&](float &a, float &b) {
+            if (tileSerial) ts_get2d(sc, rd.sampler, slot, a, b);
+            else { a = halton_sample(sc, rd, index, dim); b = halton_sample(sc, rd, index, dim + 1); dim += 2; }
+        };
+        // ---- pi: the chosen hit as a SurfaceInteraction (the tail of Triangle::Intersect / Sphere::Intersect, then the instance's transform)
+        const float4 h4 = sss.hit[slot], o4 = sss.hitO[slot], d4 = sss.hitD[slot];
+        const int prim = __float_as_int(h4.x), inst = sss.hitInst[slot];
+        const V3 rayD = mk(d4.x, d4.y, d4.z);
+        const Tri tri = load_tri(sc, prim);
+        Isect is;
+        V3 shapeRayD = rayD;
+        if (inst >= 0) shapeRayD = m4_vec(sc.instances[inst].w2i, rayD);
+        if (tri.flags & PG_PRIM_SPHERE) {
+            V3 shapeRayO = mk(o4.x, o4.y, o4.z);
+            if (inst >= 0) { float dt; instance_ray(sc.instances[inst].w2i, shapeRayO, rayD, shapeRayO, shapeRayD, dt); }
+            const SphereHit sh = sphere_interaction(sc.spheres[__float_as_int(tri.p0.x)], shapeRayO, shapeRayD, h4.y);
+            is.p = sh.p; is.pError = sh.pError; is.wo = sh.wo; is.n = sh.n; is.ns = sh.n; is.sdpdu = sh.dpdu;
+            is.sdpdv = sh.dpdv; is.sdndu = sh.dndu; is.sdndv = sh.dndv;
+        } else is = make_isect(sc, prim, tri, h4.y, h4.z, h4.w, shapeRayD);
+        if (inst >= 0 && !sc.instances[inst].identity) {  // InterpolatedPrimToWorld(*isect), transform.cpp:262-297
+            const PgInstance &in = sc.instances[inst];
+            Isect w;
+            w.p = m4_point_err2(in.i2w, is.p, is.pError, w.pError);
+            w.n = normalize(m4_normal(in.w2i, is.n));
+            w.wo = normalize(m4_vec(in.i2w, is.wo));
+            w.sdpdu = m4_vec(in.i2w, is.sdpdu);
+            w.sdpdv = m4_vec(in.i2w, is.sdpdv);
+            w.sdndu = m4_normal(in.w2i, is.sdndu); w.sdndv = m4_normal(in.w2i, is.sdndv);
+            w.ns = normalize(m4_normal(in.w2i, is.ns));
+            if (dot(w.ns, w.n) < 0.f) w.ns = -w.ns;
+            is = w;
+        }
+        // ---- Sp(pi) = Sr(|po - pi|) and Pdf_Sp(pi) / nFound (bssrdf.cpp:322-327), beta *= S / pdf (path.cpp:158)
+        const float4 po4 = sss.po[slot], f0 = sss.frame[0][slot], f1 = sss.frame[1][slot], f2 = sss.frame[2][slot];
+        const V3 poP = mk(po4.x, po4.y, po4.z);
+        DBssrdf b = bssrdf_bind(sc.bssrdfs[__float_as_int(f1.w)], sc.bssrdfTables);
+        const float4 cs = sss.coef[0][slot], cr = sss.coef[1][slot];
+        b.sigma_t[0] = cs.x; b.sigma_t[1] = cs.y; b.sigma_t[2] = cs.z; b.rho[0] = cr.x; b.rho[1] = cr.y; b.rho[2] = cr.z;
+        const int nFound = sss.count[slot].x;
+        float pdf = bssrdf_pdf_sp(b, mk(f1.x, f1.y, f1.z), mk(f2.x, f2.y, f2.z), mk(f0.x, f0.y, f0.z), poP, is.p, is.n) / nFound;
+        const Spec S = bssrdf_sr(b, sqrtf(lensq(poP - is.p)));
+        if (is_black(S) || pdf == 0) alive = false;
+        else {
+            beta = beta * (S / pdf);
+            // Sample_S's BSDF at pi (bssrdf.cpp:243-248): shading frame of pi, the adapter; pi.wo = pi.shading.n
+            AdapterBsdf ab;
+            ab.ns = is.ns; ab.ng = is.n; ab.ss = normalize(is.sdpdu); ab.ts = cross(ab.ns, ab.ss); ab.eta = f0.w;
+            is.wo = is.ns;
+            const int nonSpecular = PG_BSDF_ALL & ~PG_BSDF_SPECULAR;
+            // ---- L += beta * UniformSampleOneLight(pi, ...) (path.cpp:161-163; integrator.cpp:85-215)
+            const float *tab = sc.nLights > 0 ? light_distribution(sc, is.p) : nullptr;
+            bool misCand = false;
+            V3 misRo = mk(0, 0, 0), misWi = mk(0, 0, 1);
+            Spec misF = sp(0);
+            float misPdf = 0, misLightArea = 1;
+            int misLightPrim = 0;
+            bool misInside = false;
+            if (tab) {
+                float lightSelPdf;
+                lightNum = sample_discrete(tab, sc.nLights, draw1(), lightSelPdf);
+                if (lightSelPdf != 0) {
+                    float uL0, uL1, uS0, uS1;
+                    draw2(uL0, uL1);
+                    draw2(uS0, uS1);
+                    const LightHot lh = load_light_hot(sc, lightNum);
+                    const PgLight &light = sc.lights[lightNum];
+                    V3 wi = mk(0, 0, 0);
+                    float lightPdf = 0, scatteringPdf = 0;
+                    float4 pdLight = make_float4(0, 0, 0, 0);
+                    LightSample ls;
+                    const Spec Li = light_sample_li_hot<true>(sc, lh, light, is.p, is.pError, is.n, uL0, uL1, wi, lightPdf, ls);
+                    if (lightPdf > 0 && !is_black(Li)) {
+                        const Spec f = ad_f(ab, is.wo, wi, nonSpecular) * absdot(wi, ab.ns);
+                        scatteringPdf = ad_pdf(ab, is.wo, wi, nonSpecular);
+                        if (!is_black(f)) {
+                            const V3 origin = offset_ray_origin(is.p, is.pError, is.n, ls.p - is.p);
+                            const V3 target = offset_ray_origin(ls.p, ls.pError, ls.n, origin - ls.p);
+                            const V3 shD = target - origin;
+                            s_ray[1][0][tid] = make_float4(origin.x, origin.y, origin.z, 1 - PG_SHADOW_EPS);
+                            s_ray[1][1][tid] = make_float4(shD.x, shD.y, shD.z, __int_as_float(slot));
+                            pushShadow = true;
+                            const bool isDelta = PG_LIGHT_IS_DELTA(lh.type);
+                            const Spec c = isDelta ? (f * Li) / lightPdf : ((f * Li) * power_heuristic(1, lightPdf, 1, scatteringPdf)) / lightPdf;
+                            pdLight = make_float4(c.r, c.g, c.b, 0);
+                        }
+                    }
+                    V3 wi2 = wi;
+                    float sPdf2 = 0;
+                    Spec fm = sp(0);
+                    if (lh.type == PG_LIGHT_AREA || lh.type == PG_LIGHT_INFINITE) {
+                        int st2;
+                        fm = ad_sample_f(ab, is.wo, wi2, uS0, uS1, sPdf2, nonSpecular, st2);
+                        fm = fm * absdot(wi2, ab.ns);
+                    }
+                    if (!is_black(fm) && sPdf2 > 0) {
+                        misCand = true;
+                        spawn_ray(is, wi2, misRo);
+                        misWi = wi2; misF = fm; misPdf = sPdf2;
+                        misLightPrim = lh.type == PG_LIGHT_INFINITE ? -1 - lightNum : lh.prim; misLightArea = lh.area;
+                        if (lh.type == PG_LIGHT_AREA && (lh.tri.flags & PG_PRIM_SPHERE)) {
+                            const PgSphere &lsph = sc.spheres[__float_as_int(lh.tri.p0.x)];
+                            misInside = lsph.shape != PG_SHAPE_SPHERE || sphere_ref_inside(lsph, is.p, is.pError, is.n);
+                        }
+                    }
+                    pdLight.w = lightSelPdf;
+                    st.pdLight[j] = pdLight;
+                    st.pdBeta[j] = make_float4(beta.r, beta.g, beta.b, 0.f);
+                }
+            }
+            if (misCand) {  // light.Pdf_Li(pi, wi) of the BSDF-sampled direction (integrator.cpp:175-178): as at the end of k_shade
+                float lightPdf2 = 0;
+                if (misLightPrim < 0) lightPdf2 = env_pdf_li(sc, sc.lights[-1 - misLightPrim], misWi);
+                const Tri lt = load_tri(sc, misLightPrim < 0 ? 0 : misLightPrim);
+                float t, lb0, lb1, lb2;
+                if (misLightPrim >= 0 && (lt.flags & PG_PRIM_SPHERE)) {
+                    const PgSphere &lsp = sc.spheres[__float_as_int(lt.p0.x)];
+                    if (!misInside) lightPdf2 = sphere_cone_pdf(lsp, is.p);
+                    else if (sphere_test(lsp, misRo, misWi, PG_INF, t)) {
+                        const SphereHit sh = sphere_interaction(lsp, misRo, misWi, t);
+                        float pdf2 = lensq(is.p - sh.p) / (absdot(sh.n, -misWi) * misLightArea);
+                        if (isinf(pdf2)) pdf2 = 0.f;
+                        lightPdf2 = pdf2;
+                    }
+                } else {
+                    if (misLightPrim >= 0) ++nLightTests;
+                    if (misLightPrim >= 0 && tri_test(lt.p0, lt.p1, lt.p2, misRo, misWi, PG_INF, t, lb0, lb1, lb2) && !(lt.flags & PG_TRI_BOGUS)) {
+                        const V3 lp = lt.p0 * lb0 + lt.p1 * lb1 + lt.p2 * lb2;
+                        const V3 ln = normalize(cross(lt.p0 - lt.p2, lt.p1 - lt.p2));
+                        float pdf2 = lensq(is.p - lp) / (absdot(ln, -misWi) * misLightArea);
+                        if (isinf(pdf2)) pdf2 = 0.f;
+                        lightPdf2 = pdf2;
+                    }
+                }
+                if (lightPdf2 != 0) {
+                    s_ray[2][0][tid] = make_float4(misRo.x, misRo.y, misRo.z, PG_INF);
+                    s_ray[2][1][tid] = make_float4(misWi.x, misWi.y, misWi.z, __int_as_float(slot));
+                    pushMis = true;
+                    st.pdMis[j] = make_float4(misF.r, misF.g, misF.b, misPdf);
+                    st.pdBeta[j].w = power_heuristic(1, misPdf, 1, lightPdf2);
+                }
+            }
+            // ---- indirect illumination from pi (path.cpp:165-173), then Russian roulette (:176-184)
+            V3 wi;
+            float pdf2, u0, u1;
+            draw2(u0, u1);
+            int sampledType = 0;
+            const Spec f = ad_sample_f(ab, is.wo, wi, u0, u1, pdf2, PG_BSDF_ALL, sampledType);
+            int newFlags = 0;
+            if (!(is_black(f) || pdf2 == 0.f)) {
+                beta = beta * ((f * absdot(wi, ab.ns)) / pdf2);
+                if (sampledType & PG_BSDF_SPECULAR) newFlags |= PG_META_SPECULAR;
+                V3 nextO;
+                spawn_ray(is, wi, nextO);
+                s_ray[0][0][tid] = make_float4(nextO.x, nextO.y, nextO.z, PG_INF);
+                s_ray[0][1][tid] = make_float4(wi.x, wi.y, wi.z, __int_as_float(slot));
+                nextBin = (wi.x < 0 ? 1 : 0) | (wi.y < 0 ? 2 : 0) | (wi.z < 0 ? 4 : 0);
+                pushNext = true;
+                const Spec rrBeta = beta * etaScale;
+                if (max_component(rrBeta) < rd.rr_threshold && bounces - 1 > 3) {  // (`bounces` of the reference's loop: this vertex's, before k_shade's increment)
+                    const float qq = pmax(.05f, 1 - max_component(rrBeta));
+                    if (draw1() < qq) pushNext = false;
+                    else beta = beta / (1 - qq);
+                }
+            }
+            outL = make_float4(L.r, L.g, L.b, L4.w);
+            outB = make_float4(beta.r, beta.g, beta.b, B4.w);
+            outM = make_int4(meta.x, meta.y, __float_as_int(etaScale), (dim << 20) | bounces | newFlags);
+        }
+    }
+    const RayQueue outQ[3] = {qnext, qshadow, qmis};
+    const bool outPred[3] = {pushNext, pushShadow, pushMis};
+    int outPos[3];
+    block_push<3, true, PG_SHADE_BLOCK>(outQ, outPred, outPos, nextBin);
+    const int posNext = outPos[0], posShadow = outPos[1], posMis = outPos[2];
+    if (pushNext) { qnext.o[posNext] = s_ray[0][0][tid]; qnext.d[posNext] = s_ray[0][1][tid]; }
+    if (pushShadow) { qshadow.o[posShadow] = s_ray[1][0][tid]; qshadow.d[posShadow] = s_ray[1][1][tid]; }
+    if (pushMis) { qmis.o[posMis] = s_ray[2][0][tid]; qmis.d[posMis] = s_ray[2][1][tid]; }
+    if (alive) {
+        if (pushNext) { qsOut.L[posNext] = outL; qsOut.beta[posNext] = outB; qsOut.meta[posNext] = outM; }  // (L itself already is in the slot)
+        st.pdInfo[j] = make_int4(posShadow, posMis, lightNum, pushNext ? posNext : ~slot);
+    }
+    unsigned long long nl = wave_sum(nLightTests);
+    if (lane_id() == 0 && nl) atomicAdd(lightTriTests + (blockIdx.x & (PG_LIGHT_TEST_SHARDS - 1)) * PG_LIGHT_TEST_STRIDE, nl);
+}
+void launch_sss_exit(const DScene &sc, const RenderParams &rp, PathState st, SssState sss, RayQueue qnext, RayQueue qshadow, RayQueue qmis,
+                     unsigned long long *lightTriTests, hipStream_t s, int nxt, bool vol, VolState vs) {
+    (void)vol; (void)vs;
+    int nblk = PG_REGIONS * (sss.qjob.regionCap / PG_SHADE_BLOCK);
+    if (nblk == 0) return;
+    hipLaunchKernelGGL(k_sss_exit, dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, sss, qnext, qshadow, qmis, lightTriTests, st.qs[nxt]);
 }
 
 // ===========================================================================

@@ -493,7 +493,7 @@ TraceConfig default_trace_config() {
 
 template <int KIND>
 static void launch_trace(const DScene &sc, const TraceConfig &c, RayQueue q0, RayQueue q1, float4 *hits, int hitOffset1, float *tOut, int *occluded,
-                         TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s) {
+                         TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s, const int *cursorInit = nullptr) {
     if (q0.regionCap <= 0) return;
     // persistent grid: enough blocks to fill 256 CUs (gridBlocks counts 256-thread blocks), never more than the queues can feed
     long long need = ((long long)(q0.regionCap + q1.regionCap) * PG_REGIONS + c.segRays - 1) / c.segRays;  // chunks
@@ -501,6 +501,8 @@ static void launch_trace(const DScene &sc, const TraceConfig &c, RayQueue q0, Ra
     nblk = ((nblk + 7) / 8) * 8;
     size_t lds = sizeof(uint2) * (size_t)c.depth * TR_BLOCK;
     (void)hipMemsetAsync(cursors, 0, 2 * PG_REGIONS * PG_COUNT_STRIDE * sizeof(int), s);
+    // a "tail" launch: q0's cursors start where its regions ended before the latest entries were appended
+    if (cursorInit) (void)hipMemcpyAsync(cursors, cursorInit, PG_REGIONS * PG_COUNT_STRIDE * sizeof(int), hipMemcpyDeviceToDevice, s);
     const int xp = (sc.nInstances > 0 ? XP_INST : 0) | (sc.nSpheres > 0 ? XP_QUADRIC : 0) | (sc.hasAlpha ? (sc.alphaTex ? XP_ALPHA : XP_ALPHATEX) : 0);
 #define TR_LAUNCH(XPV) hipLaunchKernelGGL((k_trace<KIND, XPV>), dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q0, q1, hits, hitOffset1, tOut, occluded, cn, \
                                           cursors, c.depth, c.segRays, c.refillAt, c.triW, KIND ? 1.f : c.cullK, cullGuard, c.maxAccepted)
@@ -514,12 +516,13 @@ static void launch_trace(const DScene &sc, const TraceConfig &c, RayQueue q0, Ra
 #undef TR_LAUNCH
 }
 static RayQueue noQueue() { RayQueue q; q.o = q.d = nullptr; q.counts = nullptr; q.regionCap = 0; return q; }
-void launch_closest(const DScene &sc, const TraceConfig &c, RayQueue q, float4 *hits, float *tOut, TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s) {
-    launch_trace<0>(sc, c, q, noQueue(), hits, 0, tOut, nullptr, cn, cursors, cullGuard, s);
+void launch_closest(const DScene &sc, const TraceConfig &c, RayQueue q, float4 *hits, float *tOut, TraceCounters *cn, int *cursors, int *cullGuard, hipStream_t s,
+                    const int *cursorInit) {
+    launch_trace<0>(sc, c, q, noQueue(), hits, 0, tOut, nullptr, cn, cursors, cullGuard, s, cursorInit);
 }
 void launch_closest2(const DScene &sc, const TraceConfig &c, RayQueue q0, RayQueue q1, float4 *hits, int hitOffset1, TraceCounters *cn, int *cursors, int *cullGuard,
-                     hipStream_t s, float *tOut) {
-    launch_trace<0>(sc, c, q0, q1, hits, hitOffset1, tOut, nullptr, cn, cursors, cullGuard, s);
+                     hipStream_t s, float *tOut, const int *cursorInit) {
+    launch_trace<0>(sc, c, q0, q1, hits, hitOffset1, tOut, nullptr, cn, cursors, cullGuard, s, cursorInit);
 }
 void launch_anyhit(const DScene &sc, const TraceConfig &c, RayQueue q, int *occluded, TraceCounters *cn, int *cursors, hipStream_t s) {
     if (c.anyhitFree) launch_trace<2>(sc, c, q, noQueue(), nullptr, 0, nullptr, occluded, cn, cursors, nullptr, s);
