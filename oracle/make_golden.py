@@ -783,8 +783,8 @@ GRID_SCENES = {
 
 # ---- Subsurface scattering: SubsurfaceMaterial / KdSubsurfaceMaterial + the BSSRDF branch of PathIntegrator::Li / VolPathIntegrator::Li
 # (path.cpp:152-174, core/bssrdf.cpp).  ABI 24 carries the tables and the CPU oracle renders it; the device library refuses it
-# (PG_ERR_UNSUPPORTED), so these goldens live in tests/golden_sss/, outside the device parity list. ----
-GOLD_SSS = os.path.join(ROOT, "tests", "golden_sss")
+# (round 2: PG_ERR_UNSUPPORTED, goldens apart in tests/golden_sss/; round 3: kernels, goldens in tests/golden/ like all others) ----
+GOLD_SSS = GOLD  # (kept apart in tests/golden_sss/ until the device had kernels for the BSSRDF branch: round 3)
 SHORT_BOX_MATTE = '# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]'
 SSS_PLAIN = 'Material "subsurface" "rgb sigma_a" [ 0.002 0.004 0.02 ] "rgb sigma_s" [ 0.05 0.06 0.08 ] "float eta" [ 1.33 ]'
 

@@ -74,7 +74,7 @@ struct PgScene {
     DeviceBuffer qsL[2], qsBeta[2], qsMeta[2];  // PathIntegrator: path state in queue order
     DeviceBuffer bssrdfs, materialBssrdf, bssrdfTables;  // subsurface scattering (ABI 24)
     // the BSSRDF branch of Li: per-slot state between entry and exit vertex (SssState), the job queue, two probe queues
-    DeviceBuffer sssPo, sssFrame[3], sssCoef[2], sssTarget, sssCount, sssHit, sssHitO, sssHitD, sssHitInst, sssQo[3], sssQd[3], sssCounts, sssTail;
+    DeviceBuffer sssPo, sssFrame[3], sssCoef[2], sssTarget, sssCount, sssHit, sssHitO, sssHitD, sssHitInst, sssMedium, sssQo[3], sssQd[3], sssCounts, sssTail;
     int sssCapacity = 0;
     DeviceBuffer lightHot;  // DScene::lightHot
     DeviceBuffer haltonDims;  // DScene::haltonDims
@@ -921,7 +921,6 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
     }
     // Subsurface scattering (PathIntegrator): per-slot state of the BSSRDF branch, the job queue and the two probe queues
     const bool sssOn = s->d.nBssrdfs > 0;
-    if (sssOn && vol) return setError(PG_ERR_UNSUPPORTED, "volpath with subsurface (BSSRDF) materials: the device kernels cover the path integrator's BSSRDF branch only");
     SssState sq;
     memset(&sq, 0, sizeof(sq));
     RayQueue sssP[2];
@@ -933,6 +932,7 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
             for (int i = 0; i < 2; ++i) HIP_TRY(s->sssCoef[i].alloc(n * sizeof(float4)));
             HIP_TRY(s->sssHit.alloc(n * sizeof(float4))); HIP_TRY(s->sssHitO.alloc(n * sizeof(float4))); HIP_TRY(s->sssHitD.alloc(n * sizeof(float4)));
             HIP_TRY(s->sssHitInst.alloc(n * sizeof(int)));
+            HIP_TRY(s->sssMedium.alloc(n * sizeof(int2)));
             for (int i = 0; i < 3; ++i) { HIP_TRY(s->sssQo[i].alloc(n * sizeof(float4))); HIP_TRY(s->sssQd[i].alloc(n * sizeof(float4))); }
             HIP_TRY(s->sssCounts.alloc(3 * QSTRIDE * sizeof(int)));
             HIP_TRY(s->sssTail.alloc(QSTRIDE * sizeof(int)));
@@ -941,7 +941,7 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
         sq.po = (float4 *)s->sssPo.p; sq.target = (float4 *)s->sssTarget.p; sq.count = (int2 *)s->sssCount.p;
         for (int i = 0; i < 3; ++i) sq.frame[i] = (float4 *)s->sssFrame[i].p;
         for (int i = 0; i < 2; ++i) sq.coef[i] = (float4 *)s->sssCoef[i].p;
-        sq.hit = (float4 *)s->sssHit.p; sq.hitO = (float4 *)s->sssHitO.p; sq.hitD = (float4 *)s->sssHitD.p; sq.hitInst = (int *)s->sssHitInst.p;
+        sq.hit = (float4 *)s->sssHit.p; sq.hitO = (float4 *)s->sssHitO.p; sq.hitD = (float4 *)s->sssHitD.p; sq.hitInst = (int *)s->sssHitInst.p; sq.medium = (int2 *)s->sssMedium.p;
         sq.qjob.o = (float4 *)s->sssQo[0].p; sq.qjob.d = (float4 *)s->sssQd[0].p; sq.qjob.counts = (int *)s->sssCounts.p;
         for (int i = 0; i < 2; ++i) { sssP[i].o = (float4 *)s->sssQo[1 + i].p; sssP[i].d = (float4 *)s->sssQd[1 + i].p; sssP[i].counts = (int *)s->sssCounts.p + (1 + i) * QSTRIDE; }
     }
@@ -1037,29 +1037,74 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                     ++closestLaunches; closestRays += nMain; shadeItems += nMain;
                     HIP_TRY(hipMemsetAsync(counts + nxt * QSTRIDE, 0, QSTRIDE * sizeof(int), stream));
                     HIP_TRY(hipMemsetAsync(counts + 2 * QSTRIDE, 0, 2 * QSTRIDE * sizeof(int), stream));
-                    PG_TIMED(2, stream, launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream));
+                    if (sssOn) HIP_TRY(hipMemsetAsync(sq.qjob.counts, 0, QSTRIDE * sizeof(int), stream));
+                    const SssState *sssArg = sssOn ? &sq : nullptr;
+                    PG_TIMED(2, stream, launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream, sssArg));
                     ++shadeLaunches;
-                    if (int e = settleLightTables([&]() { launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream); })) return e;
-                    // through rays: kind 0 = light samples (q[2] <-> vq[0]), kind 1 = BSDF / phase samples (q[3] <-> vq[1])
-                    RayQueue tq[2][2] = {{q[2], vq[0]}, {q[3], vq[1]}};
-                    int tcur = 0;
-                    for (int pass = 0;; ++pass) {
-                        if (pass > 100000) return setError(PG_ERR_DEVICE, "pg_render: transmittance loop did not terminate");
-                        if (int e = readCounts()) return e;
-                        const uint64_t n0 = tcur == 0 ? queueTotal(blk.data(), 2) : queueTotal(vblk.data(), 0);
-                        const uint64_t n1q = tcur == 0 ? queueTotal(blk.data(), 3) : queueTotal(vblk.data(), 1);
-                        if (n0 + n1q == 0) break;
-                        PG_TIMED(0, stream, launch_closest2(dv, s->trace, tq[0][tcur], tq[1][tcur], (float4 *)s->hitsMain.p, n1, cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream, hitT));
-                        ++closestLaunches; closestRays += n0 + n1q;
-                        HIP_TRY(hipMemsetAsync(tq[0][tcur ^ 1].counts, 0, QSTRIDE * sizeof(int), stream));
-                        HIP_TRY(hipMemsetAsync(tq[1][tcur ^ 1].counts, 0, QSTRIDE * sizeof(int), stream));
-                        launch_through(dv, ps, vs, 0, tq[0][tcur], (const float4 *)s->hitsMain.p, hitT, 0, tq[0][tcur ^ 1], stream);
-                        launch_through(dv, ps, vs, 1, tq[1][tcur], (const float4 *)s->hitsMain.p, hitT, n1, tq[1][tcur ^ 1], stream);
-                        tcur ^= 1;
-                    }
+                    if (int e = settleLightTables([&]() { launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream, sssArg); })) return e;
+                    // through rays: kind 0 = light samples (q[2] <-> vq[0]), kind 1 = BSDF / phase samples (q[3] <-> vq[1]), re-traced
+                    // until none is left under way
+                    auto throughRays = [&]() -> int {
+                        RayQueue tq[2][2] = {{q[2], vq[0]}, {q[3], vq[1]}};
+                        int tcur = 0;
+                        for (int pass = 0;; ++pass) {
+                            if (pass > 100000) return setError(PG_ERR_DEVICE, "pg_render: transmittance loop did not terminate");
+                            if (int e = readCounts()) return e;
+                            const uint64_t n0 = tcur == 0 ? queueTotal(blk.data(), 2) : queueTotal(vblk.data(), 0);
+                            const uint64_t n1q = tcur == 0 ? queueTotal(blk.data(), 3) : queueTotal(vblk.data(), 1);
+                            if (n0 + n1q == 0) break;
+                            PG_TIMED(0, stream, launch_closest2(dv, s->trace, tq[0][tcur], tq[1][tcur], (float4 *)s->hitsMain.p, n1, cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream, hitT));
+                            ++closestLaunches; closestRays += n0 + n1q;
+                            HIP_TRY(hipMemsetAsync(tq[0][tcur ^ 1].counts, 0, QSTRIDE * sizeof(int), stream));
+                            HIP_TRY(hipMemsetAsync(tq[1][tcur ^ 1].counts, 0, QSTRIDE * sizeof(int), stream));
+                            launch_through(dv, ps, vs, 0, tq[0][tcur], (const float4 *)s->hitsMain.p, hitT, 0, tq[0][tcur ^ 1], stream);
+                            launch_through(dv, ps, vs, 1, tq[1][tcur], (const float4 *)s->hitsMain.p, hitT, n1, tq[1][tcur ^ 1], stream);
+                            tcur ^= 1;
+                        }
+                        return PG_OK;
+                    };
+                    if (int e = throughRays()) return e;
                     PG_TIMED(3, stream, launch_resolve_vol(dv, ps, vs, q[cur], stream));
                     ++resolveLaunches;
-                    // the next pass of the through loop reads counts again; the main queue's size comes from the same block
+                    if (sssOn) {
+                        // ---- the BSSRDF branch (volpath.cpp:151-176) of the paths k_shade handed over: probe chains (two walks), exit
+                        // vertices, their transmittance rays and resolve; the exit vertices' next rays join q[nxt], which is
+                        // traced as a whole at the start of the next iteration
+                        std::vector<int> jb(QSTRIDE);
+                        auto regionSum = [&](const int *dev, uint64_t &total) -> int {
+                            HIP_TRY(hipMemcpyAsync(jb.data(), dev, QSTRIDE * sizeof(int), hipMemcpyDeviceToHost, stream));
+                            HIP_TRY(hipStreamSynchronize(stream));
+                            total = 0;
+                            for (int r = 0; r < PG_REGIONS; ++r) total += (uint64_t)jb[r * PG_COUNT_STRIDE];
+                            return PG_OK;
+                        };
+                        uint64_t nJobs = 0;
+                        if (int e = regionSum(sq.qjob.counts, nJobs)) return e;
+                        if (nJobs > 0) {
+                            for (int pass = 1; pass <= 2; ++pass) {
+                                RayQueue curQ = sq.qjob;
+                                uint64_t nRays = nJobs;
+                                for (int step = 0; nRays > 0; ++step) {
+                                    if (step > 1000000) return setError(PG_ERR_DEVICE, "pg_render: a BSSRDF probe chain did not terminate");
+                                    RayQueue outQ = sssP[step & 1];
+                                    HIP_TRY(hipMemsetAsync(outQ.counts, 0, QSTRIDE * sizeof(int), stream));
+                                    launch_closest(dv, s->trace, curQ, (float4 *)s->hitsMain.p, nullptr, pass == 1 ? cnClosest : cnClosest + 2, (int *)s->cursors.p, (int *)s->cullGuard.p, stream);
+                                    if (pass == 1) { closestRays += nRays; ++closestLaunches; }
+                                    launch_sss_probe(dv, sq, pass, curQ, (const float4 *)s->hitsMain.p, outQ, stream, true, step == 0);
+                                    if (int e = regionSum(outQ.counts, nRays)) return e;
+                                    curQ = outQ;
+                                }
+                            }
+                            HIP_TRY(hipMemsetAsync(counts + 2 * QSTRIDE, 0, 2 * QSTRIDE * sizeof(int), stream));
+                            launch_sss_exit(dv, rp, ps, sq, q[nxt], q[2], q[3], lightTests, stream, nxt, true, vs);
+                            ++shadeLaunches; shadeItems += nJobs;
+                            if (int e = throughRays()) return e;
+                            launch_resolve_vol(dv, ps, vs, sq.qjob, stream);
+                            ++resolveLaunches;
+                        }
+                        if (int e = readCounts()) return e;
+                    }
+                    // the last pass of the through loop read the counters: the main queue's size comes from the same block
                     nMain = queueTotal(blk.data(), nxt);
                     cur = nxt;
                 }

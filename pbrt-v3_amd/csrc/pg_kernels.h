@@ -192,6 +192,7 @@ struct SssState {
     float4 *hit;       // the chosen hit's record as k_trace wrote it, the probe ray that found it (o, d) and the instance it was in
     float4 *hitO, *hitD;
     int *hitInst;
+    int2 *medium;      // volpath: (medium of the probe ray under way, medium of the probe ray that found the chosen hit); index + 1, 0 = none
     RayQueue qjob;     // the first probe ray of every path that entered this branch at the current bounce (appended by k_shade)
 };
 
@@ -250,7 +251,7 @@ void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQue
 // Subsurface scattering: one step of the probe chains (pass 1: count the hits on the material; pass 2: stop at the chosen one) over
 // the rays of qin (results at hits[i], instances at sc.hitInst[i]), continued rays to qout; then the exit vertices of the jobs of
 // sss.qjob: Pdf_Sp / Sr, direct lighting (shadow / MIS rays, pending terms at the job's queue index) and the next ray (appended to qnext)
-void launch_sss_probe(const DScene &sc, SssState sss, int pass, RayQueue qin, const float4 *hits, RayQueue qout, hipStream_t s);
+void launch_sss_probe(const DScene &sc, SssState sss, int pass, RayQueue qin, const float4 *hits, RayQueue qout, hipStream_t s, bool vol = false, bool first = false);
 void launch_sss_exit(const DScene &sc, const RenderParams &rp, PathState st, SssState sss, RayQueue qnext, RayQueue qshadow, RayQueue qmis,
                      unsigned long long *lightTriTests, hipStream_t s, int nxt, bool vol, VolState vs);
 void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis, const int *occluded, const float4 *misHits, hipStream_t s,
@@ -258,7 +259,7 @@ void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis,
 // VolPathIntegrator: the shading step with medium sampling (hitT = the hits' ray parameters), one step of the through rays of
 // `kind` (results of qin at hits[hitBase + i]; continued rays go to qout), and EstimateDirect's sums with transmittance
 void launch_shade_vol(const DScene &sc, const RenderParams &rp, PathState st, VolState vs, RayQueue qin, const float4 *hits, const float *hitT,
-                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s);
+                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s, const SssState *sss = nullptr);
 void launch_through(const DScene &sc, PathState st, VolState vs, int kind, RayQueue qin, const float4 *hits, const float *hitT, int hitBase,
                     RayQueue qout, hipStream_t s);
 void launch_resolve_vol(const DScene &sc, PathState st, VolState vs, RayQueue qin, hipStream_t s);

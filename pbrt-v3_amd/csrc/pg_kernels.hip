@@ -2377,6 +2377,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
                                     sss.frame[2][slot] = make_float4(lb.ts.x, lb.ts.y, lb.ts.z, __int_as_float(sc.bssrdfs[sssIdx].match_material));
                                     sss.target[slot] = make_float4(pTarget.x, pTarget.y, pTarget.z, 0);
                                     sss.count[slot] = make_int2(0, 0);
+                                    if constexpr (VOL) sss.medium[slot] = make_int2(0, 0);  // Sample_Sp's `base` has no MediumInterface
                                 }
                             }
                         }
@@ -2502,12 +2503,15 @@ void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQue
     else hipLaunchKernelGGL((k_shade<0, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, none);
 }
 void launch_shade_vol(const DScene &sc, const RenderParams &rp, PathState st, VolState vs, RayQueue qin, const float4 *hits, const float *hitT,
-                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s) {
+                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s, const SssState *sss) {
     int nblk = rp.retryCount > 0 ? (rp.retryCount + PG_SHADE_BLOCK - 1) / PG_SHADE_BLOCK : PG_REGIONS * (qin.regionCap / PG_SHADE_BLOCK);
     if (nblk == 0) return;
     const QueueState none = {nullptr, nullptr, nullptr};
     const SssState nosss = {};
-    if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss);
+    if (sss && sc.nBssrdfs > 0) {
+        if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, true, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, *sss);
+        else hipLaunchKernelGGL((k_shade<1, true, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, *sss);
+    } else if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss);
     else hipLaunchKernelGGL((k_shade<1, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss);
 }
 
@@ -2712,8 +2716,8 @@ void launch_fill_int(int *p, int value, int n, hipStream_t s) {
 // pass 1 counts the hits on the material, pass 2 stops at the chosen one.  Each step is one k_trace<0, .> launch over the
 // chains still under way followed by k_sss_probe.
 // ===========================================================================
-template <int PASS>
-__global__ __launch_bounds__(PG_BLOCK) void k_sss_probe(DScene sc, SssState sss, RayQueue qin, const float4 *__restrict__ hits, RayQueue qout) {
+template <int PASS, bool VOL>
+__global__ __launch_bounds__(PG_BLOCK) void k_sss_probe(DScene sc, SssState sss, RayQueue qin, const float4 *__restrict__ hits, RayQueue qout, int first) {
     const int i = queue_item<>(qin);
     bool push = false;
     float4 no = make_float4(0, 0, 0, 0), nd = make_float4(0, 0, 0, 0);
@@ -2724,6 +2728,10 @@ __global__ __launch_bounds__(PG_BLOCK) void k_sss_probe(DScene sc, SssState sss,
         const float4 h4 = hits[i];
         const int prim = __float_as_int(h4.x);
         int2 cnt = sss.count[slot];
+        // volpath: the medium of this probe ray -- base.GetMedium(d) of the previous hit (none for the first ray: Sample_Sp's `base`
+        // carries no MediumInterface) -- is what a hit primitive without a transition of its own reports (primitive.cpp:121-125)
+        int rayMed = 0;
+        if constexpr (VOL) rayMed = first ? 0 : sss.medium[slot].x;
         bool go = prim >= 0;  // bssrdf.cpp:306: no intersection ends the chain
         if (PASS == 2 && cnt.x == 0) go = false;  // nothing to choose from
         if (go) {
@@ -2737,6 +2745,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_sss_probe(DScene sc, SssState sss,
                     if (cnt.y == selected) {
                         sss.hit[slot] = h4; sss.hitO[slot] = o4; sss.hitD[slot] = d4;
                         sss.hitInst[slot] = sc.hitInst ? sc.hitInst[i] : -1;
+                        if constexpr (VOL) sss.medium[slot] = make_int2(rayMed, rayMed);
                         go = false;
                     }
                     ++cnt.y;
@@ -2753,6 +2762,11 @@ __global__ __launch_bounds__(PG_BLOCK) void k_sss_probe(DScene sc, SssState sss,
                     no = make_float4(origin.x, origin.y, origin.z, 1 - PG_SHADOW_EPS);
                     nd = make_float4(d.x, d.y, d.z, __int_as_float(slot));
                     push = true;
+                    if constexpr (VOL) {  // Interaction::GetMedium(d), interaction.h:86-88
+                        int mIn, mOut;
+                        prim_interface(sc, prim, rayMed, mIn, mOut);
+                        sss.medium[slot] = make_int2(dot(d, n) > 0 ? mOut : mIn, 0);
+                    }
                 }
             }
         }
@@ -2761,11 +2775,15 @@ __global__ __launch_bounds__(PG_BLOCK) void k_sss_probe(DScene sc, SssState sss,
     block_push<1, false>(&qout, &push, &pos);
     if (push) { qout.o[pos] = no; qout.d[pos] = nd; }
 }
-void launch_sss_probe(const DScene &sc, SssState sss, int pass, RayQueue qin, const float4 *hits, RayQueue qout, hipStream_t s) {
+void launch_sss_probe(const DScene &sc, SssState sss, int pass, RayQueue qin, const float4 *hits, RayQueue qout, hipStream_t s, bool vol, bool first) {
     int nblk = PG_REGIONS * (qin.regionCap / PG_BLOCK);
     if (nblk == 0) return;
-    if (pass == 1) hipLaunchKernelGGL(k_sss_probe<1>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, sss, qin, hits, qout);
-    else hipLaunchKernelGGL(k_sss_probe<2>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, sss, qin, hits, qout);
+    const int f = first ? 1 : 0;
+    if (vol) {
+        if (pass == 1) hipLaunchKernelGGL((k_sss_probe<1, true>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, sss, qin, hits, qout, f);
+        else hipLaunchKernelGGL((k_sss_probe<2, true>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, sss, qin, hits, qout, f);
+    } else if (pass == 1) hipLaunchKernelGGL((k_sss_probe<1, false>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, sss, qin, hits, qout, f);
+    else hipLaunchKernelGGL((k_sss_probe<2, false>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, sss, qin, hits, qout, f);
 }
 
 // The BSDF at a BSSRDF's exit point: one SeparableBSSRDFAdapter (bssrdf.h:209-225), a BxDF of type BSDF_REFLECTION | BSDF_DIFFUSE
@@ -2812,8 +2830,11 @@ PG_DEV Spec ad_sample_f(const AdapterBsdf &b, V3 woW, V3 &wiW, float u0, float u
 // direct lighting at pi under the adapter BSDF (UniformSampleOneLight / EstimateDirect: the shadow and MIS rays and their pending terms,
 // indexed by the job's queue position, resolved by k_resolve over the job queue), the next direction, Russian roulette (path.cpp:176-184).
 // The path's L, beta and meta wait in their slot (k_shade put them there; k_resolve added the entry vertex's direct lighting to L).
+// VOL (volpath.cpp:151-176): UniformSampleOneLight with handleMedia -- the two rays are transmittance rays (k_through), their factors
+// stay apart for k_resolve_vol, every pending term and the path's state are indexed by slot -- and the next ray starts in pi.GetMedium(wi).
+template <bool VOL>
 __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_sss_exit(DScene sc, RenderParams rp, PathState st, SssState sss, RayQueue qnext, RayQueue qshadow,
-                                                            RayQueue qmis, unsigned long long *lightTriTests, QueueState qsOut) {
+                                                            RayQueue qmis, unsigned long long *lightTriTests, QueueState qsOut, VolState vs) {
     const int j = queue_item<PG_SHADE_BLOCK>(sss.qjob);
     __shared__ float4 s_ray[3][2][PG_SHADE_BLOCK];
     const int tid = threadIdx.x;
@@ -2825,10 +2846,12 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_sss_exit(DScene sc, RenderPa
     bool alive = false;
     if (j >= 0) {
         slot = __float_as_int(sss.qjob.d[j].w);
-        st.pdInfo[j] = make_int4(-1, -1, -1, ~slot);
+        st.pdInfo[VOL ? slot : j] = make_int4(-1, -1, -1, VOL ? 0 : ~slot);
         const int2 cnt = sss.count[slot];
         alive = cnt.x > 0;  // bssrdf.cpp:318: no hit on the material: Sample_Sp returns black and the path ends (its L is in its slot)
     }
+    const int pdi = VOL ? slot : j;  // index of this vertex's pending direct-light terms
+    float volWeight = 0;
     if (alive) {
         const PgRenderDesc &rd = rp.rd;
         const float4 L4 = st.L[slot], B4 = st.beta[slot];
@@ -2889,6 +2912,8 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_sss_exit(DScene sc, RenderPa
             ab.ns = is.ns; ab.ng = is.n; ab.ss = normalize(is.sdpdu); ab.ts = cross(ab.ns, ab.ss); ab.eta = f0.w;
             is.wo = is.ns;
             const int nonSpecular = PG_BSDF_ALL & ~PG_BSDF_SPECULAR;
+            int mIn = 0, mOut = 0;  // VOL: pi's MediumInterface (the primitive's own, or the medium of the probe ray that found it)
+            if constexpr (VOL) prim_interface(sc, prim, sss.medium[slot].y, mIn, mOut);
             // ---- L += beta * UniformSampleOneLight(pi, ...) (path.cpp:161-163; integrator.cpp:85-215)
             const float *tab = sc.nLights > 0 ? light_distribution(sc, is.p) : nullptr;
             bool misCand = false;
@@ -2922,8 +2947,17 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_sss_exit(DScene sc, RenderPa
                             s_ray[1][1][tid] = make_float4(shD.x, shD.y, shD.z, __int_as_float(slot));
                             pushShadow = true;
                             const bool isDelta = PG_LIGHT_IS_DELTA(lh.type);
-                            const Spec c = isDelta ? (f * Li) / lightPdf : ((f * Li) * power_heuristic(1, lightPdf, 1, scatteringPdf)) / lightPdf;
-                            pdLight = make_float4(c.r, c.g, c.b, 0);
+                            if constexpr (VOL) {
+                                volWeight = isDelta ? -1.f : power_heuristic(1, lightPdf, 1, scatteringPdf);
+                                pdLight = make_float4(f.r, f.g, f.b, 0);
+                                vs.pdLi[slot] = make_float4(Li.r, Li.g, Li.b, lightPdf);
+                                vs.p1[0][slot] = make_float4(ls.p.x, ls.p.y, ls.p.z, 0); vs.p1[1][slot] = make_float4(ls.pError.x, ls.pError.y, ls.pError.z, 0);
+                                vs.p1[2][slot] = make_float4(ls.n.x, ls.n.y, ls.n.z, 0);
+                                vs.trAcc[0][slot] = make_float4(1, 1, 1, __int_as_float(dot(shD, is.n) > 0 ? mOut : mIn));
+                            } else {
+                                const Spec c = isDelta ? (f * Li) / lightPdf : ((f * Li) * power_heuristic(1, lightPdf, 1, scatteringPdf)) / lightPdf;
+                                pdLight = make_float4(c.r, c.g, c.b, 0);
+                            }
                         }
                     }
                     V3 wi2 = wi;
@@ -2945,10 +2979,12 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_sss_exit(DScene sc, RenderPa
                         }
                     }
                     pdLight.w = lightSelPdf;
-                    st.pdLight[j] = pdLight;
-                    st.pdBeta[j] = make_float4(beta.r, beta.g, beta.b, 0.f);
+                    st.pdLight[pdi] = pdLight;
+                    st.pdBeta[pdi] = make_float4(beta.r, beta.g, beta.b, 0.f);
                 }
             }
+            int misMedium = 0;
+            if (VOL && misCand) misMedium = dot(misWi, is.n) > 0 ? mOut : mIn;
             if (misCand) {  // light.Pdf_Li(pi, wi) of the BSDF-sampled direction (integrator.cpp:175-178): as at the end of k_shade
                 float lightPdf2 = 0;
                 if (misLightPrim < 0) lightPdf2 = env_pdf_li(sc, sc.lights[-1 - misLightPrim], misWi);
@@ -2977,8 +3013,9 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_sss_exit(DScene sc, RenderPa
                     s_ray[2][0][tid] = make_float4(misRo.x, misRo.y, misRo.z, PG_INF);
                     s_ray[2][1][tid] = make_float4(misWi.x, misWi.y, misWi.z, __int_as_float(slot));
                     pushMis = true;
-                    st.pdMis[j] = make_float4(misF.r, misF.g, misF.b, misPdf);
-                    st.pdBeta[j].w = power_heuristic(1, misPdf, 1, lightPdf2);
+                    st.pdMis[pdi] = make_float4(misF.r, misF.g, misF.b, misPdf);
+                    st.pdBeta[pdi].w = power_heuristic(1, misPdf, 1, lightPdf2);
+                    if constexpr (VOL) vs.trAcc[1][slot] = make_float4(1, 1, 1, __int_as_float(misMedium));
                 }
             }
             // ---- indirect illumination from pi (path.cpp:165-173), then Russian roulette (:176-184)
@@ -2997,6 +3034,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_sss_exit(DScene sc, RenderPa
                 s_ray[0][1][tid] = make_float4(wi.x, wi.y, wi.z, __int_as_float(slot));
                 nextBin = (wi.x < 0 ? 1 : 0) | (wi.y < 0 ? 2 : 0) | (wi.z < 0 ? 4 : 0);
                 pushNext = true;
+                if constexpr (VOL) vs.medium[slot] = dot(wi, is.n) > 0 ? mOut : mIn;
                 const Spec rrBeta = beta * etaScale;
                 if (max_component(rrBeta) < rd.rr_threshold && bounces - 1 > 3) {  // (`bounces` of the reference's loop: this vertex's, before k_shade's increment)
                     const float qq = pmax(.05f, 1 - max_component(rrBeta));
@@ -3018,18 +3056,23 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_sss_exit(DScene sc, RenderPa
     if (pushShadow) { qshadow.o[posShadow] = s_ray[1][0][tid]; qshadow.d[posShadow] = s_ray[1][1][tid]; }
     if (pushMis) { qmis.o[posMis] = s_ray[2][0][tid]; qmis.d[posMis] = s_ray[2][1][tid]; }
     if (alive) {
-        if (pushNext) { qsOut.L[posNext] = outL; qsOut.beta[posNext] = outB; qsOut.meta[posNext] = outM; }  // (L itself already is in the slot)
-        st.pdInfo[j] = make_int4(posShadow, posMis, lightNum, pushNext ? posNext : ~slot);
+        if constexpr (VOL) {  // by slot: L is there already (k_resolve_vol adds to it), beta and meta follow
+            st.beta[slot] = outB; st.meta[slot] = outM;
+            st.pdInfo[slot] = make_int4(posShadow, posMis, lightNum, __float_as_int(volWeight));
+        } else {
+            if (pushNext) { qsOut.L[posNext] = outL; qsOut.beta[posNext] = outB; qsOut.meta[posNext] = outM; }  // (L itself already is in the slot)
+            st.pdInfo[j] = make_int4(posShadow, posMis, lightNum, pushNext ? posNext : ~slot);
+        }
     }
     unsigned long long nl = wave_sum(nLightTests);
     if (lane_id() == 0 && nl) atomicAdd(lightTriTests + (blockIdx.x & (PG_LIGHT_TEST_SHARDS - 1)) * PG_LIGHT_TEST_STRIDE, nl);
 }
 void launch_sss_exit(const DScene &sc, const RenderParams &rp, PathState st, SssState sss, RayQueue qnext, RayQueue qshadow, RayQueue qmis,
                      unsigned long long *lightTriTests, hipStream_t s, int nxt, bool vol, VolState vs) {
-    (void)vol; (void)vs;
     int nblk = PG_REGIONS * (sss.qjob.regionCap / PG_SHADE_BLOCK);
     if (nblk == 0) return;
-    hipLaunchKernelGGL(k_sss_exit, dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, sss, qnext, qshadow, qmis, lightTriTests, st.qs[nxt]);
+    if (vol) hipLaunchKernelGGL(k_sss_exit<true>, dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, sss, qnext, qshadow, qmis, lightTriTests, st.qs[nxt], vs);
+    else hipLaunchKernelGGL(k_sss_exit<false>, dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, sss, qnext, qshadow, qmis, lightTriTests, st.qs[nxt], vs);
 }
 
 // ===========================================================================

@@ -304,7 +304,7 @@ def test_bssrdf_radial_device_functions_equal_the_oracle(dev, pkg, oracle, mater
     """bssrdf_sr / bssrdf_pdf_sr / bssrdf_sample_sr (TabulatedBSSRDF::Sr / Pdf_Sr / Sample_Sr with CatmullRomWeights and
     SampleCatmullRom2D under them) of pg_bssrdf.h against the oracle on the host front end's tables: radii from 0 to far beyond the
     table, every u, a channel without scattering (sigma_t = 0) and one without absorption (albedo 1)."""
-    text = open(os.path.join(ROOT, "tests", "golden_sss", "sss_subsurface.pbrt")).read()
+    text = open(os.path.join(ROOT, "tests", "golden", "sss_subsurface.pbrt")).read()
     old = [l for l in text.splitlines() if l.startswith('Material "subsurface"')][0]
     scene = pkg.HostScene(text=text.replace(old, material))
     d = scene.desc
@@ -327,7 +327,7 @@ def test_bssrdf_spatial_device_functions_equal_the_correctly_rounded_oracle(dev,
     """bssrdf_pdf_sp (SeparableBSSRDF::Pdf_Sp), bssrdf_probe_segment (the first half of Sample_Sp: axis, channel, radius, angle -> probe
     segment, u1 remapped) and invert_catmull_rom of pg_bssrdf.h against the oracle's correctly-rounded-libm build (cos / sin of the angle),
     around random shading frames, bit for bit."""
-    text = open(os.path.join(ROOT, "tests", "golden_sss", "sss_subsurface.pbrt")).read()
+    text = open(os.path.join(ROOT, "tests", "golden", "sss_subsurface.pbrt")).read()
     scene = pkg.HostScene(text=text)
     d = scene.desc
     b = d.bssrdfs[0]

@@ -29,7 +29,8 @@ def test_golden_images(gpu, oracle, name):
     bounces later, tip one discrete event of one sample (a ray passing an edge): such a pixel is accepted only when the
     CPU oracle built with correctly rounded libm (liboracle_crlibm.so) reproduces the device's value exactly, and at most
     2 pixels per image -- or 0.5 % of the pixels in the scenes that bump-map with Perlin-noise textures, where Material::Bump
-    divides a last-bit difference of the displacement (logf in FBm's octave count) by du = 0.0005."""
+    divides a last-bit difference of the displacement (logf in FBm's octave count) by du = 0.0005; 2 % in the subsurface scenes; a
+    whole 16x16 tile (at most two) under the tile-serial samplers, whose stream shifts for the rest of the tile."""
     scene = gpu.HostScene(os.path.join(GOLD, name + ".pbrt"))
     img, cn = gpu.render_scene(scene)
     ref = gpu.read_pfm(os.path.join(GOLD, name + ".pfm"))
@@ -38,15 +39,28 @@ def test_golden_images(gpu, oracle, name):
     if bad.any():
         cr_img, _ = oracle.render_image(scene, cr_libm=True)
         allowed = max(2, int(0.005 * bad.size)) if name.startswith("tex_noise") else 2
+        # subsurface paths: the probe segment's angle goes through sin / cos (bssrdf.cpp:283-286; glibc's float versions differ from
+        # the correctly rounded value for 1.3 % of arguments), and a segment moved by an ulp can meet the surface in another triangle
+        if name.startswith("sss_"): allowed = max(2, int(0.02 * bad.size))
+        if scene.render_desc().sampler >= 2:
+            # The tile-serial samplers (random, stratified, 02sequence, maxmindist) draw from ONE stream per 16x16 tile: a tipped
+            # event changes how many numbers its path takes, and every later sample of that tile draws different ones -- the
+            # rest of the tile differs (sss_stratified: the sin / cos of a probe segment's angle).  Allowed in at most two tiles,
+            # and -- as for single pixels -- only if the correctly-rounded oracle reproduces the device's values exactly.
+            ys, xs = np.nonzero(bad)
+            tiles = {(y // 16, x // 16) for y, x in zip(ys.tolist(), xs.tolist())}
+            assert len(tiles) <= 2, f"{len(tiles)} tiles differ from the reference"
+            allowed = 2 * 256
         assert bad.sum() <= allowed and np.array_equal(img[bad], cr_img[bad]), f"max rel err {err.max():.3e} at {np.argwhere(bad)[:4].tolist()}"
         err[bad] = 0
     # most pixels are bit-identical, the rest differ in the last ulps only (libm's last bit: every pixel lit through an
     # environment map or a spherical mapping goes through acosf / atan2f)
-    assert np.median(err) <= 1e-6 and np.percentile(err, 99) <= 2e-5
+    assert np.median(err) <= 1e-6 and np.percentile(err[~bad] if bad.any() else err, 99) <= 2e-5
     stats = json.load(open(os.path.join(GOLD, name + ".json")))
     assert cn["camera_rays"] == stats["camera_rays"]
+    rel = 2e-2 if (bad.sum() > 2 and scene.render_desc().sampler >= 2) else 2e-3  # (a tile whose stream shifted traces other rays)
     for k in ("closest_rays", "shadow_rays", "tri_tests"):  # a 1-ulp direction change may add/remove a handful of rays
-        assert abs(cn[k] - stats[k]) <= max(4, 2e-3 * stats[k]), (k, cn[k], stats[k])
+        assert abs(cn[k] - stats[k]) <= max(4, rel * stats[k]), (k, cn[k], stats[k])
 
 
 @pytest.mark.parametrize("name", ["cornell_32", "cornell_crop", "synthetic_n40", "cornell_lens", "cornell_plastic", "plastic_topdown", "cornell_normals", "cornell_tangents", "cornell_lightnormals", "cornell_point", "cornell_spot_power", "cornell_delta_only", "cornell_mirror_glass", "cornell_glass_eta", "filter_gaussian", "filter_mitchell_crop", "filter_widebox", "cornell_orennayar", "cornell_ortho_lens", "cornell_loopsubdiv", "env_only", "env_mixed_power", "env_uniform_open", "sphere_light", "sphere_partial", "sphere_enclosing"])

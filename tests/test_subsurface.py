@@ -2,9 +2,9 @@
 TabulatedBSSRDF and the BSSRDF branch of PathIntegrator::Li / VolPathIntegrator::Li (core/bssrdf.cpp, integrators/path.cpp:152-174,
 volpath.cpp:150-177).  The host front end computes the photon-beam-diffusion table as the material's constructor does
 (pbrt-v3_amd/host/bssrdf.cpp), hands it over in the ABI-24 tables (PgBSSRDF), the CPU oracle renders it bit-identically to the
-UNMODIFIED reference (tests/golden_sss/*, rendered by oracle/_ref/pbrt_oracle through oracle/make_golden.py), and the device
-library says loudly that it has no kernels for it.  All of this runs without a GPU: the oracle-first half of the row (DESIGN.md
-section 8); the device half is next."""
+UNMODIFIED reference (tests/golden/sss_*, rendered by oracle/_ref/pbrt_oracle through oracle/make_golden.py).  All of this runs
+without a GPU.  The device half -- k_shade<., ., SSS>, k_sss_probe, k_sss_exit (pbrt-v3_amd/csrc/pg_kernels.hip) -- is checked by the
+GPU parity suite on the same goldens (tests/test_gpu_parity.py: film and counters bit-identical to the correctly-rounded oracle)."""
 import ctypes as C
 import glob
 import json
@@ -17,8 +17,8 @@ import pytest
 from conftest import ROOT
 from test_gpu_binding import BINDING
 
-SSS = os.path.join(ROOT, "tests", "golden_sss")
-NAMES = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(SSS, "*.json")))
+SSS = os.path.join(ROOT, "tests", "golden")
+NAMES = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(SSS, "sss_*.json")))
 PROBE = os.path.join(ROOT, "oracle", "_ref", "ref_probe")
 
 
@@ -51,7 +51,7 @@ def test_beam_diffusion_table_equals_the_references(pkg):
     """BSSRDFTable(100, 64) after ComputeBeamDiffusionBSSRDF(0, 1.33) (bssrdf.cpp:149-180), printed by the unmodified reference through
     oracle/ref_probe.cpp and committed as bit patterns: rhoSamples, radiusSamples, profile, rhoEff, profileCDF -- all 13 064 floats."""
     table, sigma_t, rho, eta = host_table(pkg, 'Material "subsurface" "float eta" [ 1.33 ]')
-    ref = np.load(os.path.join(SSS, "table_g0_eta1.33.npy"))
+    ref = np.load(os.path.join(SSS, "sss_table_g0_eta1.33.npy"))
     assert table.size == ref.size == 13064 and np.array_equal(table.view(np.uint32), ref)
     # the defaults of CreateSubsurfaceMaterial (subsurface.cpp:94-97) through the TabulatedBSSRDF constructor (bssrdf.h:146-150)
     sa, ss = np.array([.0011, .0024, .014], dtype=np.float32), np.array([2.55, 3.21, 3.77], dtype=np.float32)
@@ -102,15 +102,6 @@ def test_textured_parameters_are_evaluated_per_hit(pkg):
     assert len(mats) == 1 and mats[0].type == 6 and d.textured[mats[0].textured_index].kind == 4 and d.textured[mats[0].textured_index].has_bump == 1
     plain = pkg.HostScene(os.path.join(SSS, "sss_subsurface.pbrt"))
     assert plain.desc.bssrdfs[0].textured == 0
-
-
-def test_device_library_refuses_subsurface_loudly(pkg):
-    """No kernels for the BSSRDF branch in this ABI version: pg_scene_create answers PG_ERR_UNSUPPORTED before touching a device --
-    never a render that silently treats the material as glass, never a CPU fallback."""
-    scene = pkg.HostScene(os.path.join(SSS, "sss_subsurface.pbrt"))
-    lib, handle = pkg.gpu_lib(), C.c_void_p()
-    assert lib.pg_scene_create(C.byref(scene.desc), C.byref(handle)) == -2 and not handle  # PG_ERR_UNSUPPORTED
-    assert b"subsurface scattering" in lib.pg_last_error()
 
 
 @pytest.mark.parametrize("name", ["sss_subsurface", "sss_kd_rough", "sss_preset_volpath", "sss_two_materials", "sss_mix_component"])
