@@ -290,7 +290,7 @@ def kernel_rooflines(m, workload):
     def one(name, tag, alg_bytes, ms, launches, units, unit_name, gather_pattern):
         launches = max(1, launches)
         achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        pk = next((v for k, v in pmc_kernels.items() if k.startswith(tag)), None)
+        pk = next((v for k, v in pmc_kernels.items() if k.startswith(tag)), None)  # tag: a tuple of accepted name prefixes
         traffic = None
         if pk is not None:
             f = factor if gather_pattern else 2.0
@@ -310,9 +310,9 @@ def kernel_rooflines(m, workload):
     n_close, n_shadow, n_mis, n_items = cn["closest_rays"], cn["shadow_rays"], cn["mis_rays"], cn["shade_items"]
     n_next = max(0, n_close - cn["camera_rays"] - n_mis)
     kernels = [
-        one("k_trace<false> (BVHAccel::Intersect + Triangle::Intersect)", "void k_trace<false",
+        one("k_trace<0> (closest hit: BVHAccel::Intersect + Triangle::Intersect)", ("void k_trace<0,", "void k_trace<false"),
             32 * cn["closest_node_visits"] + 48 * cn["closest_tri_tests"] + 48 * n_close, cn["closest_ms"], cn["closest_launches"], n_close, "ray", True),
-        one("k_trace<true> (BVHAccel::IntersectP + Triangle::IntersectP)", "void k_trace<true",
+        one(("k_trace<1> (any hit, reference order" if os.environ.get("PG_ANYHIT_ORDER") == "reference" else "k_trace<2> (any hit, free order") + ": BVHAccel::IntersectP + Triangle::IntersectP)", ("void k_trace<2,", "void k_trace<1,", "void k_trace<true"),
             32 * cn["shadow_node_visits"] + 48 * cn["shadow_tri_tests"] + 36 * n_shadow, cn["shadow_ms"], cn["shadow_launches"], n_shadow, "ray", True),
         one("k_shade (PathIntegrator::Li loop body + EstimateDirect set-up)", "void k_shade",
             224 * n_items + 32 * (n_next + n_shadow + n_mis) + 16 * n_mis, cn["shade_ms"], cn["shade_launches"], n_items, "vertex", False),
@@ -341,9 +341,9 @@ def gather_ceiling(m, working_set, pmc_kernels, pmc_src):
         # A traversal is not a uniformly random walk: the top of the tree stays in the L2s.  With the kernel's L2 hit rate h (committed
         # PMC pass of this workload) the ceiling is the harmonic blend of the L2-resident rate and the rate at the working set's
         # size; without h only the L2-resident rate is a safe upper bound.
-        h = next((v.get("l2_hit_rate") for k, v in pmc_kernels.items() if k.startswith("void k_trace<false")), None)
+        h = next((v.get("l2_hit_rate") for k, v in pmc_kernels.items() if k.startswith(("void k_trace<0,", "void k_trace<false"))), None)
         ceiling = 1.0 / (h / c_l2 + (1.0 - h) / c_ws) if h is not None else c_l2
-        return {"kernel": "k_trace<false>", "record_fetches_per_s": rate, "ceiling_records_per_s": ceiling, "frac": rate / ceiling,
+        return {"kernel": "k_trace<0>", "record_fetches_per_s": rate, "ceiling_records_per_s": ceiling, "frac": rate / ceiling,
                 "ceiling_kind": ("1 / (h / C(2 MiB) + (1 - h) / C(working set)), h = the kernel's L2 hit rate" if h is not None
                                  else "C(2 MiB): L2-resident table (no PMC pass of this workload committed: upper bound)"),
                 "l2_hit_rate": h, "l2_hit_rate_source": pmc_src if h is not None else None,
@@ -409,7 +409,7 @@ def main():
                                      if bound == "l2" else "exceed the 256 MiB Infinity Cache: gathers reach HBM"))
         if hbm is not None:
             hk, hws, hbound, _, _, _ = kernel_rooflines(hbm, describe(hbm.args, hbm.scene))
-            t = next((k for k in hk if k["kernel"].startswith("k_trace<false>")), None)
+            t = next((k for k in hk if k["kernel"].startswith("k_trace<0>")), None)
             if t is not None and hbound == "hbm":
                 roofline["hbm_regime"] = {
                     "kernel": t["kernel"], "workload": describe(hbm.args, hbm.scene), "working_set_bytes": hws, "bound": "hbm",

@@ -322,8 +322,8 @@ typedef struct PgDensityGrid {
  * `table` is BSSRDFTable(n_rho, n_radius) after ComputeBeamDiffusionBSSRDF(g, eta) (bssrdf.cpp:149-180), laid out in
  * bssrdf_tables as rhoSamples[n_rho], radiusSamples[n_radius], profile[n_rho * n_radius], rhoEff[n_rho],
  * profileCDF[n_rho * n_radius]; materials with equal (g, eta) share one table.
- * libpbrt_gpu.so of this ABI version has no kernels for the BSSRDF branch of Li (path.cpp:152-174): pg_scene_create answers
- * PG_ERR_UNSUPPORTED when n_bssrdfs > 0 (the CPU oracle renders it). */
+ * libpbrt_gpu.so renders the BSSRDF branch of Li (path.cpp:152-174, volpath.cpp:151-176) since round 3: k_shade<., ., SSS>,
+ * k_sss_probe, k_sss_exit (DESIGN.md section 4 "Subsurface scattering"). */
 typedef struct PgBSSRDF {
     float eta;
     /* TabulatedBSSRDF::sigma_t and ::rho as its constructor derives them (bssrdf.h:146-150) from the coefficients the material hands

@@ -10,11 +10,11 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 prof() {  # prof NAME bench-args...: kernel-trace stats of one bench run
   local name=$1; shift
-  ( timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -o trace -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $OUT/bench_prof_$name.json 2> $OUT/prof_$name.err )
+  ( timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -o trace -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-hbm-regime "$@" > $OUT/bench_prof_$name.json 2> $OUT/prof_$name.err )
   find $OUT/prof_$name -name '*kernel_stats*' -exec cp {} $OUT/kernel_stats_$name.csv \;
   rm -rf $OUT/prof_$name
 }
-( PBRT_SKIP_SLOW=1 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 ) > $OUT/pytest_gpu.log
+[ "$SKIP_TESTS" = 1 ] && echo 'tests skipped (SKIP_TESTS=1)' > $OUT/pytest_gpu.log || ( PBRT_SKIP_SLOW=1 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 ) > $OUT/pytest_gpu.log
 ( timeout 900 python bench.py --steps 3 --warmup 1 2> $OUT/bench.err ) > $OUT/bench.json
 prof cfg3
 tail -5 $OUT/pytest_gpu.log; cat $OUT/bench.json; head -8 $OUT/kernel_stats_cfg3.csv
@@ -25,6 +25,11 @@ if [ "$MODE" != quick ]; then
   prof 5m --grid 1582 --spp 256
   cat $OUT/bench_5m.json; head -6 $OUT/kernel_stats_5m.csv
   ( timeout 600 python bench.py --steps 2 --warmup 1 --workload synthetic-vol --grid 2237 --spp 128 --no-cpu-baseline 2> $OUT/bench_10m_vol.err ) > $OUT/bench_10m_vol.json; cut -c1-400 $OUT/bench_10m_vol.json
+  # the divergent stand-ins of configs 4 / 5 (instanced PLY meshes, textures, alpha masks, 8 materials): bench + kernel stats
+  ( timeout 900 python bench.py --steps 2 --warmup 1 --workload divergent --tris 5000000 --spp 64 --no-cpu-baseline 2> $OUT/bench_div5m.err ) > $OUT/bench_div5m.json; cut -c1-300 $OUT/bench_div5m.json
+  prof div5m --workload divergent --tris 5000000 --spp 64
+  ( timeout 900 python bench.py --steps 2 --warmup 1 --workload divergent-vol --tris 10000000 --spp 32 --no-cpu-baseline 2> $OUT/bench_div10m_vol.err ) > $OUT/bench_div10m_vol.json; cut -c1-300 $OUT/bench_div10m_vol.json
+  prof div10m_vol --workload divergent-vol --tris 10000000 --spp 32
   find $OUT -name '*counter_collection.csv' -size +4M -delete
 fi
 if [ "$MODE" = full ]; then
