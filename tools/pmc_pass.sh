@@ -5,7 +5,7 @@ TAG=${1:-pmc}; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="${@:---steps 1 --warmup 0 --spp 8 --no-cpu-baseline}"
+ARGS="${@:---steps 1 --warmup 0 --spp 8 --no-cpu-baseline --no-hbm-regime}"
 [ -f gpurun_out/counters.txt ] || rocprofv3 -L > gpurun_out/counters.txt 2>&1
 i=0
 MAXP=${PMC_PASSES:-99}
