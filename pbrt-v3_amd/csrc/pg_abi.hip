@@ -33,9 +33,6 @@ int pgSetError(int code, const char *msg) { g_lastError = msg; return code; }
         if (e_ != hipSuccess) return setError(PG_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_));    \
     } while (0)
 
-#ifdef PG_SHADE_PROF  // pg_kernels.hip, experiment build only
-void shade_prof_dump();
-#endif
 struct DeviceBuffer {
     void *p = nullptr;
     size_t bytes = 0;
@@ -1324,9 +1321,6 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
         *acc[te.second] += ms;
     }
 #undef PG_TIMED
-#ifdef PG_SHADE_PROF
-    shade_prof_dump();
-#endif
     float ms = 0;
     if (hipEventElapsedTime(&ms, evStart, evStop) == hipSuccess) c.render_ms += ms;
     if (int st2 = checkCullGuard(s)) return st2;

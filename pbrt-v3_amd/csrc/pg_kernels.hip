@@ -1801,25 +1801,6 @@ PG_DEV void prim_interface(const DScene &sc, int prim, int rayMedium, int &mIn, 
 #ifndef PG_SHADE0_WAVES
 #define PG_SHADE0_WAVES 4
 #endif
-#ifdef PG_SHADE_PROF  // experiment build (make GPUEXTRA=-DPG_SHADE_PROF): where a shading wave's time goes -- s_memtime deltas per phase of one
-// block in 128 (so that the instrumentation's own atomics do not disturb what they measure), summed over those waves
-#define PG_NPROF 12
-__device__ unsigned long long g_shadeProf[PG_NPROF + 1];
-#define PROF(k) do { if (profOn) { const long long now_ = clock64(); profAcc[k] += now_ - profLast; profLast = now_; } } while (0)
-void shade_prof_dump() {
-    unsigned long long h[PG_NPROF + 1];
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_shadeProf), sizeof(h)) != hipSuccess) return;
-    const char *names[PG_NPROF] = {"ray + hit + state in", "triangle, material, interaction", "light table + choice of light", "draws uLight uScattering", "light sample, f, shadow ray",
-                                   "BSDF sample of MIS", "next direction, RR", "state to LDS", "light test of the MIS ray", "append: barriers + atomics", "stores", "-"};
-    double tot = 0; for (int k = 0; k < PG_NPROF; ++k) tot += (double)h[k];
-    fprintf(stderr, "k_shade phases (%llu sampled waves, %.0f cycles per wave):\n", h[PG_NPROF], h[PG_NPROF] ? tot / (double)h[PG_NPROF] : 0.);
-    for (int k = 0; k < PG_NPROF - 1; ++k) fprintf(stderr, "   %-34s %6.1f %%  %9.0f cycles/wave\n", names[k], tot > 0 ? 100. * (double)h[k] / tot : 0., h[PG_NPROF] ? (double)h[k] / (double)h[PG_NPROF] : 0.);
-    for (auto &v : h) v = 0;
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_shadeProf), h, sizeof(h));
-}
-#else
-#define PROF(k) do { } while (0)
-#endif
 // SSS: the scene has materials with a BSSRDF (subsurface / kdsubsurface): a vertex whose sampled direction is a transmission leaves
 // through the BSSRDF branch of Li (path.cpp:152-174) -- the lane draws Sample_S's numbers, builds the probe segment of Sample_Sp and
 // hands the path over to the probe / exit kernels below instead of pushing its next ray.  A separate instantiation: scenes without
@@ -1832,10 +1813,6 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
     static_assert(!SSS || EXT, "materials with a BSSRDF are BxDF-list materials");
     bool pushJob = false;  // SSS: this lane's path goes on through the BSSRDF (its probe ray waits in s_ray[0])
     constexpr bool QSTATE = !VOL;  // path state and pending terms in queue order (see PathState)
-#ifdef PG_SHADE_PROF
-    const bool profOn = (blockIdx.x & 127) == 0;
-    long long profAcc[PG_NPROF] = {0}, profLast = clock64();
-#endif
     int i;
     if (rp.retryCount > 0) {  // second pass over the entries that waited for a light-distribution voxel
         const int j = blockIdx.x * PG_SHADE_BLOCK + threadIdx.x;
@@ -1904,10 +1881,6 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
         int bounces = meta.w & 0xffff;
         const bool specularBounce = (meta.w & PG_META_SPECULAR) != 0;
         const bool found = prim >= 0;
-#ifdef PG_SHADE_PROF
-        if (__float_as_int(L4.x) == 0x7fc12345 || meta.x == 0x7fc12345) profAcc[11] += 1;  // consume the loads here
-#endif
-        PROF(0);
         // VOL: the ray's medium (index + 1); volpath.cpp:76-78 samples it before anything else happens at the vertex
         int med = 0;
         bool volDead = false, inMedium = false;
@@ -2253,18 +2226,15 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
                 else hasNonSpecular = bsdf.nBxDFs > 0 && !bsdf.specular;
                 // ---- direct lighting: UniformSampleOneLight (integrator.cpp:85-106) + EstimateDirect set-up
                 const bool wantLight = (VOL || hasNonSpecular) && sc.nLights > 0;  // path.cpp:119: only with non-specular lobes (volpath.cpp:124-127: always)
-                PROF(1);
                 const float *tab = wantLight ? light_distribution(sc, is.p) : nullptr;
                 if (wantLight && !tab) deferred = true;
                 if (tab) {
                     float lightSelPdf;
                     lightNum = sample_discrete(tab, sc.nLights, draw1(), lightSelPdf);
                     if (lightSelPdf != 0) {
-                        PROF(2);
                         float uL0, uL1, uS0, uS1;  // uLight, uScattering (integrator.cpp:101-102)
                         draw2(uL0, uL1);
                         draw2(uS0, uS1);
-                        PROF(3);
                         const LightHot lh = load_light_hot(sc, lightNum);
                         const PgLight &light = sc.lights[lightNum];
                         V3 wi = mk(0, 0, 0);
@@ -2299,7 +2269,6 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
                                 }
                             }
                         }
-                        PROF(4);
                         // BSDF sampling half of MIS (integrator.cpp:164-212): sample now, while the BSDF is live; the
                         // light.Pdf_Li triangle test runs at the end of the kernel, when little else is (register pressure)
                         V3 wi2 = wi;
@@ -2327,7 +2296,6 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
                         st.pdBeta[pdi] = make_float4(beta.r, beta.g, beta.b, 0.f);
                     }
                 }
-                PROF(5);
                 // ---- sample the BSDF for the next direction (path.cpp:130-150)
                 V3 wo = -rayD, wi;
                 float pdf;
@@ -2393,7 +2361,6 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
                 bounces += 1;
             }
         }
-        PROF(6);
         if (deferred) {
         } else if constexpr (QSTATE) {  // written after the append: to the ray's entry of the next queue, or (path over) L to its slot
             s_state[0][tid] = make_float4(L.r, L.g, L.b, L4.w);
@@ -2405,7 +2372,6 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
             st.meta[slot] = make_int4(meta.x, meta.y, __float_as_int(etaScale), (dim << 20) | bounces | newFlags);
         }
     }
-    PROF(7);
     if (deferred) {  // retried once the voxel's distribution exists: no ray, no state, no pending term leaves this launch
         pushNext = pushShadow = misCand = false;
         if (rp.rd.sampler >= PG_SAMPLER_RANDOM) { sc.ts[slot].state = tsState0; sc.ts[slot].cur1D = tsCur1D0; sc.ts[slot].cur2D = tsCur2D0; }  // nor a draw from the tile's stream
@@ -2445,12 +2411,10 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
             if constexpr (VOL) vs.trAcc[1][slot] = make_float4(1, 1, 1, __int_as_float(misMedium));
         }
     }
-    PROF(8);
     const RayQueue outQ[3] = {qnext, qshadow, qmis};
     const bool outPred[3] = {pushNext, pushShadow, pushMis};
     int outPos[3];
     block_push<3, true, PG_SHADE_BLOCK>(outQ, outPred, outPos, nextBin);
-    PROF(9);
     const int posNext = outPos[0], posShadow = outPos[1], posMis = outPos[2];
     if (pushNext) { qnext.o[posNext] = s_ray[0][0][tid]; qnext.d[posNext] = s_ray[0][1][tid]; }
     if (pushShadow) { qshadow.o[posShadow] = s_ray[1][0][tid]; qshadow.d[posShadow] = s_ray[1][1][tid]; }
@@ -2482,10 +2446,6 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
     }
     unsigned long long nl = wave_sum(nLightTests);
     if (lane_id() == 0 && nl) atomicAdd(lightTriTests + (blockIdx.x & (PG_LIGHT_TEST_SHARDS - 1)) * PG_LIGHT_TEST_STRIDE, nl);
-#ifdef PG_SHADE_PROF
-    PROF(10);
-    if (profOn && lane_id() == 0) { for (int k = 0; k < PG_NPROF; ++k) atomicAdd(&g_shadeProf[k], (unsigned long long)profAcc[k]); atomicAdd(&g_shadeProf[PG_NPROF], 1ull); }
-#endif
 }
 void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQueue qin, const float4 *hits, RayQueue qnext,
                   RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s, int cur, const SssState *sss) {

@@ -12,7 +12,7 @@ import pytest
 from conftest import ROOT
 
 PROF = os.path.join(ROOT, "profiles")
-BENCHES = {"cfg3": "r03h_bench_cfg3.json", "5m": "r03h_bench_5m.json", "10m_vol": "r03h_bench_10m_vol.json", "div5m": "r03h_bench_div5m.json",
+BENCHES = {"cfg3": "r03j_bench_cfg3.json", "5m": "r03h_bench_5m.json", "10m_vol": "r03h_bench_10m_vol.json", "div5m": "r03h_bench_div5m.json",
            "div10m_vol": "r03h_bench_div10m_vol.json", "r02_cfg3": "r02u_bench_cfg3.json", "r02_5m": "r02u_bench_5m.json"}
 
 
@@ -58,7 +58,7 @@ def test_every_fraction_recomputes_and_stays_below_one(tag):
             assert g["ceiling_records_per_s"] == pytest.approx(1 / (h / g["ceiling_l2_resident"] + (1 - h) / g["ceiling_at_working_set"]), rel=1e-9)
 
 
-@pytest.mark.parametrize("tag,stats", [("cfg3", "r03h_kernel_stats_cfg3.csv"), ("5m", "r03h_kernel_stats_5m.csv"), ("div5m", "r03h_kernel_stats_div5m.csv"),
+@pytest.mark.parametrize("tag,stats", [("cfg3", "r03j_kernel_stats_cfg3.csv"), ("5m", "r03h_kernel_stats_5m.csv"), ("div5m", "r03h_kernel_stats_div5m.csv"),
                                        ("div10m_vol", "r03h_kernel_stats_div10m_vol.csv"), ("r02_cfg3", "r02u_kernel_stats_cfg3.csv"), ("r02_5m", "r02u_kernel_stats_5m.csv")])
 def test_event_timing_agrees_with_the_rocprof_summary(tag, stats):
     """bench.py times each kernel with HIP events on its own stream; rocprofv3 --kernel-trace --stats of the same command gives the
