@@ -301,8 +301,8 @@ typedef struct PgMedium {
  * sigma_a, sigma_s (after "scale"), g, and sigma_t = sigma_a + sigma_s in all three channels -- the constructor requires a
  * spectrally uniform sigma_t (grid.h:64-68), the host reports the same error; PgSceneDesc.media_grid[m] is the index of medium
  * m's grid here, -1 for a HomogeneousMedium.
- * libpbrt_gpu.so of this ABI version has no kernels for it: pg_scene_create answers PG_ERR_UNSUPPORTED when n_grids > 0
- * (the CPU oracle renders it). */
+ * libpbrt_gpu.so renders it since round 3: k_shade<., ., ., GRID> in two phases around the transmittance rays, k_through<., GRID>
+ * (DESIGN.md section 4 "Heterogeneous media"). */
 typedef struct PgDensityGrid {
     int32_t nx, ny, nz;
     int32_t reserved;

@@ -705,8 +705,8 @@ SCENES = {
 
 
 # ---- GridDensityMedium ("heterogeneous", media/grid.cpp).  ABI 23 carries its tables and the CPU oracle renders it; the device
-# library refuses it (PG_ERR_UNSUPPORTED), so these goldens live in tests/golden_grid/, outside the device parity list. ----
-GOLD_GRID = os.path.join(ROOT, "tests", "golden_grid")
+# (round 2: refused by the device library, goldens apart in tests/golden_grid/; round 3: two-phase kernels, goldens in tests/golden/) ----
+GOLD_GRID = GOLD  # (apart in tests/golden_grid/ until the device had the two-phase kernels: round 3)
 
 
 def density_values(nx, ny, nz, peak, seed):

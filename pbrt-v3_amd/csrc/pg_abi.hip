@@ -70,6 +70,7 @@ struct PgScene {
     DeviceBuffer vqo[2], vqd[2], vCounts, volMedium, trAcc[2], volP1[3], misLi, pdLi, hitT;
     DeviceBuffer qsL[2], qsBeta[2], qsMeta[2];  // PathIntegrator: path state in queue order
     DeviceBuffer bssrdfs, materialBssrdf, bssrdfTables;  // subsurface scattering (ABI 24)
+    DeviceBuffer grids, mediaGrid, gridDensity, gridVertex;  // GridDensityMedium (ABI 23); the two-phase shading's per-slot vertex record
     // the BSSRDF branch of Li: per-slot state between entry and exit vertex (SssState), the job queue, two probe queues
     DeviceBuffer sssPo, sssFrame[3], sssCoef[2], sssTarget, sssCount, sssHit, sssHitO, sssHitD, sssHitInst, sssMedium, sssQo[3], sssQd[3], sssCounts, sssTail;
     int sssCapacity = 0;
@@ -114,8 +115,10 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     // (P may be absent when no primitive is a triangle -- a scene of quadrics only: every triangle's indices are checked against n_verts below)
     if (desc->n_tris < 0 || desc->n_nodes < 0 || desc->n_verts < 0 || (desc->n_tris > 0 && (!desc->nodes || !desc->indices || (desc->n_verts > 0 && !desc->P))))
         return setError(PG_ERR_INVALID, "pg_scene_create: malformed geometry arrays");
-    if (desc->n_grids != 0 || desc->media_grid)  // ABI 23 carries the tables; the two-phase shading they need is not built
-        return setError(PG_ERR_UNSUPPORTED, "GridDensityMedium (\"heterogeneous\" medium) has no device kernels in this build");
+    if (desc->n_grids < 0 || (desc->n_grids > 0 && (!desc->grids || !desc->media_grid || !desc->grid_density)))
+        return setError(PG_ERR_INVALID, "pg_scene_create: malformed grid-medium tables");
+    if (desc->n_grids > 0 && desc->n_bssrdfs > 0)  // (each needs its own extra phase between a vertex's direct lighting and its next ray)
+        return setError(PG_ERR_UNSUPPORTED, "a scene with both a GridDensityMedium and subsurface (BSSRDF) materials");
     if (desc->n_bssrdfs < 0 || (desc->n_bssrdfs > 0 && (!desc->bssrdfs || !desc->material_bssrdf || !desc->bssrdf_tables)))
         return setError(PG_ERR_INVALID, "pg_scene_create: malformed BSSRDF tables");
     int ndev = 0;
@@ -575,6 +578,25 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
             HIP_TRY_S(hipMemcpy(s->triMediumOut.p, desc->tri_medium_outside, s->triMediumOut.bytes, hipMemcpyHostToDevice));
         }
         d.media = (const PgMedium *)s->media.p; d.triMediumIn = (const int *)s->triMediumIn.p; d.triMediumOut = (const int *)s->triMediumOut.p;
+        if (desc->n_grids > 0) {  // GridDensityMedium: the grids, which medium has one, the density values
+            int64_t nDensity = 0;
+            for (int k = 0; k < desc->n_grids; ++k) {
+                const PgDensityGrid &g = desc->grids[k];
+                if (g.nx < 1 || g.ny < 1 || g.nz < 1 || g.density_offset < 0 || !(g.sigma_t > 0) || !(g.inv_max_density > 0))
+                    FAIL(PG_ERR_INVALID, "grid medium %d: malformed (%d x %d x %d, sigma_t %g)", k, g.nx, g.ny, g.nz, (double)g.sigma_t);
+                nDensity = std::max<int64_t>(nDensity, g.density_offset + (int64_t)g.nx * g.ny * g.nz);
+            }
+            if (nDensity > desc->n_density_floats) FAIL(PG_ERR_INVALID, "grid media: %lld density values, %lld given", (long long)nDensity, (long long)desc->n_density_floats);
+            for (int m = 0; m < s->nMedia; ++m) if (desc->media_grid[m] >= desc->n_grids) FAIL(PG_ERR_INVALID, "medium %d: grid index out of range", m);
+            HIP_TRY_S(s->grids.alloc(sizeof(PgDensityGrid) * (size_t)desc->n_grids));
+            HIP_TRY_S(hipMemcpy(s->grids.p, desc->grids, s->grids.bytes, hipMemcpyHostToDevice));
+            HIP_TRY_S(s->mediaGrid.alloc(sizeof(int32_t) * (size_t)std::max(1, s->nMedia)));
+            if (s->nMedia > 0) HIP_TRY_S(hipMemcpy(s->mediaGrid.p, desc->media_grid, sizeof(int32_t) * (size_t)s->nMedia, hipMemcpyHostToDevice));
+            HIP_TRY_S(s->gridDensity.alloc(sizeof(float) * (size_t)nDensity));
+            HIP_TRY_S(hipMemcpy(s->gridDensity.p, desc->grid_density, s->gridDensity.bytes, hipMemcpyHostToDevice));
+            d.grids = (const PgDensityGrid *)s->grids.p; d.mediaGrid = (const int *)s->mediaGrid.p; d.gridDensity = (const float *)s->gridDensity.p;
+            d.nGrids = desc->n_grids;
+        }
     }
     if (desc->noise_perm) {  // NoisePerm of the Perlin-noise textures
         for (int i = 0; i < 512; ++i) if (desc->noise_perm[i] < 0 || desc->noise_perm[i] > 255) FAIL(PG_ERR_INVALID, "noise_perm[%d] = %d is not a byte", i, desc->noise_perm[i]);
@@ -645,6 +667,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
                 d.sparseLights = 1;
                 // (the exit vertices of subsurface paths look their light distribution up without the deferral the shading kernel has)
                 if (d.nBssrdfs > 0) FAIL(PG_ERR_UNSUPPORTED, "subsurface scattering with a spatial light distribution beyond the dense table's size: use \"lightsamplestrategy\" \"power\" or \"uniform\"");
+                if (d.nGrids > 0) FAIL(PG_ERR_UNSUPPORTED, "a grid medium with a spatial light distribution beyond the dense table's size: use \"lightsamplestrategy\" \"power\" or \"uniform\"");
                 d.voxelSlot = (int *)s->voxelSlot.p; d.voxelRequests = (int *)s->voxelRequests.p; d.voxelCounters = (int *)s->voxelCounters.p;
             } else {
                 HIP_TRY_S(s->distTable.alloc(total * stride * sizeof(float)));
@@ -777,8 +800,10 @@ static int ensureWorkBuffers(PgScene *s, int capacity) {
     if (s->d.sparseLights) HIP_TRY(s->retryList.alloc(n * sizeof(int)));
     for (int i = 0; i < 4; ++i) { HIP_TRY(s->qo[i].alloc(n * sizeof(float4))); HIP_TRY(s->qd[i].alloc(n * sizeof(float4))); }
     HIP_TRY(s->counts.alloc(4 * PG_REGIONS * PG_COUNT_STRIDE * sizeof(int)));
-    HIP_TRY(s->hitsMain.alloc(2 * n * sizeof(float4)));
-    if (s->d.nInstances > 0) { HIP_TRY(s->hitInst.alloc(2 * n * sizeof(int))); s->d.hitInst = (int *)s->hitInst.p; }  // main-queue hits, then MIS-queue hits at offset n (one launch fills both)
+    // (grid media: a third part -- the transmittance rays must leave the main rays' hits alone for the second shading phase)
+    const size_t hitParts = s->d.nGrids > 0 ? 3 : 2;
+    HIP_TRY(s->hitsMain.alloc(hitParts * n * sizeof(float4)));
+    if (s->d.nInstances > 0) { HIP_TRY(s->hitInst.alloc(hitParts * n * sizeof(int))); s->d.hitInst = (int *)s->hitInst.p; }  // main-queue hits, then MIS-queue hits at offset n (one launch fills both)
     HIP_TRY(s->occluded.alloc(n * sizeof(int)));
     HIP_TRY(s->stL.alloc(n * sizeof(float4)));
     HIP_TRY(s->stBeta.alloc(n * sizeof(float4)));
@@ -895,9 +920,10 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
             HIP_TRY(s->volMedium.alloc(n * sizeof(int)));
             HIP_TRY(s->misLi.alloc(n * sizeof(float4)));
             HIP_TRY(s->pdLi.alloc(n * sizeof(float4)));
-            HIP_TRY(s->hitT.alloc(2 * n * sizeof(float)));
+            HIP_TRY(s->hitT.alloc((s->d.nGrids > 0 ? 3 : 2) * n * sizeof(float)));
             s->volCapacity = capacity;
         }
+        if (s->d.nGrids > 0 && s->gridVertex.bytes < n * sizeof(float4)) HIP_TRY(s->gridVertex.alloc(n * sizeof(float4)));
         vs.medium = (int *)s->volMedium.p;
         for (int i = 0; i < 2; ++i) vs.trAcc[i] = (float4 *)s->trAcc[i].p;
         for (int i = 0; i < 3; ++i) vs.p1[i] = (float4 *)s->volP1[i].p;
@@ -1036,12 +1062,40 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                     HIP_TRY(hipMemsetAsync(counts + 2 * QSTRIDE, 0, 2 * QSTRIDE * sizeof(int), stream));
                     if (sssOn) HIP_TRY(hipMemsetAsync(sq.qjob.counts, 0, QSTRIDE * sizeof(int), stream));
                     const SssState *sssArg = sssOn ? &sq : nullptr;
-                    PG_TIMED(2, stream, launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream, sssArg));
+                    // a scene with a grid medium shades in two phases around the transmittance rays (k_shade<., ., ., GRID>)
+                    const bool gridOn = s->d.nGrids > 0;
+                    float4 *gridVertex = (float4 *)s->gridVertex.p;
+                    PG_TIMED(2, stream, launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream, sssArg, gridVertex, gridOn ? 1 : 0));
                     ++shadeLaunches;
-                    if (int e = settleLightTables([&]() { launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream, sssArg); })) return e;
+                    if (int e = settleLightTables([&]() { launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream, sssArg, gridVertex, gridOn ? 1 : 0); })) return e;
                     // through rays: kind 0 = light samples (q[2] <-> vq[0]), kind 1 = BSDF / phase samples (q[3] <-> vq[1]), re-traced
                     // until none is left under way
                     auto throughRays = [&]() -> int {
+                        if (gridOn) {
+                            // ratio tracking draws from the path's sampler: a path's kind-0 ray (visibility.Tr) runs to its end before
+                            // its kind-1 ray (IntersectTr after the BSDF sample) starts, as in EstimateDirect; one queue pair at a time
+                            for (int kind = 0; kind < 2; ++kind) {
+                                RayQueue tk[2] = {kind == 0 ? q[2] : q[3], vq[kind]};
+                                int tc = 0;
+                                for (int pass = 0;; ++pass) {
+                                    if (pass > 100000) return setError(PG_ERR_DEVICE, "pg_render: transmittance loop did not terminate");
+                                    if (int e = readCounts()) return e;
+                                    const uint64_t nk = tc == 0 ? queueTotal(blk.data(), 2 + kind) : queueTotal(vblk.data(), kind);
+                                    if (nk == 0) break;
+                                    // (results at the offset the kind's through kernel reads them from)
+                                    const size_t off = (size_t)(1 + kind) * n1;  // part 0 keeps the main rays' hits for phase 2
+                                    float4 *hk = (float4 *)s->hitsMain.p + off;
+                                    DScene dk = dv;
+                                    if (dk.hitInst) dk.hitInst += off;
+                                    PG_TIMED(0, stream, launch_closest(dk, s->trace, tk[tc], hk, hitT + off, cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream));
+                                    ++closestLaunches; closestRays += nk;
+                                    HIP_TRY(hipMemsetAsync(tk[tc ^ 1].counts, 0, QSTRIDE * sizeof(int), stream));
+                                    launch_through(dv, ps, vs, kind, tk[tc], (const float4 *)s->hitsMain.p, hitT, (int)off, tk[tc ^ 1], stream, &rp);
+                                    tc ^= 1;
+                                }
+                            }
+                            return PG_OK;
+                        }
                         RayQueue tq[2][2] = {{q[2], vq[0]}, {q[3], vq[1]}};
                         int tcur = 0;
                         for (int pass = 0;; ++pass) {
@@ -1063,6 +1117,11 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                     if (int e = throughRays()) return e;
                     PG_TIMED(3, stream, launch_resolve_vol(dv, ps, vs, q[cur], stream));
                     ++resolveLaunches;
+                    if (gridOn) {  // phase 2: the vertices' next directions, drawn behind the transmittance rays' numbers
+                        PG_TIMED(2, stream, launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream, nullptr, gridVertex, 2));
+                        ++shadeLaunches;
+                        if (int e = readCounts()) return e;
+                    }
                     if (sssOn) {
                         // ---- the BSSRDF branch (volpath.cpp:151-176) of the paths k_shade handed over: probe chains (two walks), exit
                         // vertices, their transmittance rays and resolve; the exit vertices' next rays join q[nxt], which is

@@ -1,8 +1,8 @@
 // pg_bssrdf.h -- TabulatedBSSRDF's radial profile (core/bssrdf.cpp:203-236, :352-392) and the spline routines under it
 // (core/interpolation.cpp:77-116, :166-226) as device functions over the ABI's PgBSSRDF table.
 //
-// NOT YET USED BY A KERNEL (ABI v24 carries the tables, pg_scene_create refuses such scenes).  Pinned ahead of
-// the integration: tests/test_device_headers_on_host.py runs this header on the host against the oracle, bit for bit.
+// Used by k_shade<., ., SSS>, k_sss_exit (pg_kernels.hip).  Pinned on the host as well: tests/test_device_headers_on_host.py runs this
+// header on the host against the oracle, bit for bit.
 #ifndef PG_BSSRDF_H
 #define PG_BSSRDF_H
 #include "pg_device.h"

@@ -1,10 +1,8 @@
 // pg_grid.h -- GridDensityMedium (media/grid.{h,cpp} of the reference) as device functions over the ABI's PgDensityGrid.
 //
-// NOT YET USED BY A KERNEL.  The tables arrive through ABI v23 and pg_scene_create still answers PG_ERR_UNSUPPORTED for scenes with a
-// grid medium; these are the tracking loops the volpath kernels will call (tools/experiments/NEXT_ROUND.md).
-// They are pinned already: tests/test_device_headers_on_host.py compiles this header for the host and compares every function with
-// the oracle's correctly-rounded-libm build, bit for bit, on random grids, rays and draw streams -- so the GPU time of the
-// integration goes into the kernels, not into this arithmetic.
+// Used by k_shade<., ., ., GRID> (delta tracking at the start of a vertex) and k_through<., GRID> (ratio tracking of the transmittance
+// rays) in pg_kernels.hip.  Pinned on the host as well: tests/test_device_headers_on_host.py compiles this header for the host and
+// compares every function with the oracle's correctly-rounded-libm build, bit for bit, on random grids, rays and draw streams.
 //
 // `Draw` is the path's sampler.Get1D() (a callable returning float); the loops call it in the reference's order.  logf is
 // evaluated in double and rounded once, like the other libm calls of the device path (DESIGN.md "libm").

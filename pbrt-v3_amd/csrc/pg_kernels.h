@@ -87,6 +87,10 @@ struct DScene {
     const int *noisePerm;                // NoisePerm (512 entries) of the Perlin-noise textures, or nullptr
     const PgTexturedMaterial *textured;  // materials evaluated per hit (PG_MAT_TEXTURED)
     int hasTextured;
+    const PgDensityGrid *grids;          // GridDensityMedium (ABI 23): mediaGrid[m] = index of medium m's grid, -1 = homogeneous
+    const int *mediaGrid;
+    const float *gridDensity;
+    int nGrids;
     const PgMedium *media;               // HomogeneousMedium table; triMediumIn/Out[k] = the primitive's MediumInterface (-1 = none), or nullptr
     const int *triMediumIn, *triMediumOut;
     const PgBxDF *bxdfs;      // the materials' BxDF lists (PgMaterial.first_bxdf / n_bxdfs)
@@ -258,10 +262,12 @@ void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis,
                     int cur = 0);
 // VolPathIntegrator: the shading step with medium sampling (hitT = the hits' ray parameters), one step of the through rays of
 // `kind` (results of qin at hits[hitBase + i]; continued rays go to qout), and EstimateDirect's sums with transmittance
+// gridVertex / phase: scenes with a grid medium shade a vertex in two launches (phase 1, transmittance rays, resolve, phase 2); 0 = one pass
 void launch_shade_vol(const DScene &sc, const RenderParams &rp, PathState st, VolState vs, RayQueue qin, const float4 *hits, const float *hitT,
-                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s, const SssState *sss = nullptr);
+                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s, const SssState *sss = nullptr,
+                      float4 *gridVertex = nullptr, int phase = 0);
 void launch_through(const DScene &sc, PathState st, VolState vs, int kind, RayQueue qin, const float4 *hits, const float *hitT, int hitBase,
-                    RayQueue qout, hipStream_t s);
+                    RayQueue qout, hipStream_t s, const RenderParams *rpGrid = nullptr);
 void launch_resolve_vol(const DScene &sc, PathState st, VolState vs, RayQueue qin, hipStream_t s);
 void launch_fill_int(int *p, int value, int n, hipStream_t s);
 void launch_film(const RenderParams &rp, PathState st, PgFilmPixel *film, PgStraySample *strays, int maxStrays, int *nStrays,

@@ -16,6 +16,7 @@
 #include "pg_kernels.h"
 #include "pg_texture.h"
 #include "pg_bssrdf.h"
+#include "pg_grid.h"
 
 #define PG_BLOCK 256
 // threads per block of the shading kernel: its blocks meet at two barriers around the queue append, so a block is only as fast
@@ -1805,11 +1806,22 @@ PG_DEV void prim_interface(const DScene &sc, int prim, int rayMedium, int &mIn, 
 // through the BSSRDF branch of Li (path.cpp:152-174) -- the lane draws Sample_S's numbers, builds the probe segment of Sample_Sp and
 // hands the path over to the probe / exit kernels below instead of pushing its next ray.  A separate instantiation: scenes without
 // such materials run the code they ran before.
-template <int MODE, bool VOL, bool SSS = false>
+// GRID: the scene has a GridDensityMedium ("heterogeneous" medium, media/grid.cpp).  Its transmittance is estimated by ratio tracking
+// with numbers from the PATH's sampler, drawn inside VisibilityTester::Tr / Scene::IntersectTr -- i.e. after a vertex's uLight /
+// uScattering and before its next-direction sample -- so how many the two transmittance rays take decides which dimension (Halton,
+// Sobol') or stream position (tile-serial samplers) the next direction is drawn at.  Such scenes shade every vertex in two launches:
+// phase 1 = everything up to the MIS candidate (emission, medium sampling incl. delta tracking, the light sample), then the
+// transmittance rays (k_through draws and counts), k_resolve_vol, and phase 2 = the vertex rebuilt, its next direction and the
+// roulette.  Scenes without a grid medium run the single-pass kernels they ran before (phase 0).
+struct GridShade { float4 *vertex; int phase; };  // vertex[slot] = (medium interaction point, kind: 0 none, 1 medium vertex, 2 surface vertex)
+template <int MODE, bool VOL, bool SSS = false, bool GRID = false>
 __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MODE == 1 && PG_SHADE_MIN_WAVES > 0) ? PG_SHADE_MIN_WAVES : (MODE == 2 ? (VOL ? PG_SHADE2V_WAVES : PG_SHADE2_WAVES) : 1))) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
                                                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, VolState vs,
-                                                     const float *__restrict__ hitT, QueueState qsIn, QueueState qsOut, SssState sss) {
+                                                     const float *__restrict__ hitT, QueueState qsIn, QueueState qsOut, SssState sss, GridShade gsh) {
     constexpr bool EXT = MODE >= 1, TEX = MODE == 2;
+    static_assert(!GRID || (VOL && !SSS), "grid media: volpath, without BSSRDF materials");
+    const bool phaseA = GRID && gsh.phase == 1, phaseB = GRID && gsh.phase == 2;
+    int vertexKind = 0;  // GRID: what phase 1 found at this entry (phase 2 reads it back)
     static_assert(!SSS || EXT, "materials with a BSSRDF are BxDF-list materials");
     bool pushJob = false;  // SSS: this lane's path goes on through the BSSRDF (its probe ray waits in s_ray[0])
     constexpr bool QSTATE = !VOL;  // path state and pending terms in queue order (see PathState)
@@ -1887,7 +1899,23 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
         V3 mediumP = mk(0, 0, 0);
         if constexpr (VOL) {
             med = vs.medium[slot];
-            if (med) {  // HomogeneousMedium::Sample, homogeneous.cpp:49-74
+            if (phaseB) {  // the medium was sampled in phase 1: beta carries its weight, the vertex record says what came of it
+                const float4 v4 = gsh.vertex[slot];
+                vertexKind = __float_as_int(v4.w);
+                inMedium = vertexKind == 1;
+                mediumP = mk(v4.x, v4.y, v4.z);
+            } else if (GRID && med && sc.mediaGrid[med - 1] >= 0) {  // GridDensityMedium::Sample, grid.cpp:61-86: delta tracking
+                const PgMedium &mm = sc.media[med - 1];
+                const PgDensityGrid &gd = sc.grids[sc.mediaGrid[med - 1]];
+                const float4 o4 = qin.o[i];
+                const float tMaxRay = found ? hitT[i] : o4.w;
+                float tg = 0;
+                inMedium = grid_sample(gd, sc.gridDensity + gd.density_offset, mk(o4.x, o4.y, o4.z), rayD, tMaxRay, draw1, tg);
+                if (inMedium) {
+                    mediumP = mk(o4.x, o4.y, o4.z) + rayD * tg;
+                    beta = beta * (sp3(mm.sigma_s[0], mm.sigma_s[1], mm.sigma_s[2]) / gd.sigma_t);
+                }
+            } else if (med) {  // HomogeneousMedium::Sample, homogeneous.cpp:49-74
                 const PgMedium &mm = sc.media[med - 1];
                 const float4 o4 = qin.o[i];
                 int channel = (int)(draw1() * 3);
@@ -1933,7 +1961,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
             if (TEX) { sphU = sh.u; sphV = sh.v; sphDpdu = sh.dpdu; sphDpdv = sh.dpdv; }
         }
         // path.cpp:91-102 emitted light at the vertex (volpath.cpp:103-110: only when no medium interaction was sampled)
-        if (VOL && (volDead || inMedium)) {
+        if (phaseB || (VOL && (volDead || inMedium))) {
         } else if ((bounces == 0 || specularBounce) && found && tri.light >= 0) {
             const PgLight &l = sc.lights[tri.light];
             V3 nrm = onSphere ? is.n : hit_normal(sc, prim, tri, h4.y, h4.z, h4.w);
@@ -1950,7 +1978,9 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
         if constexpr (VOL) {
             if (volDead) alive = false;
             else if (inMedium) alive = bounces < rd.max_depth;  // volpath.cpp:83
+            if (phaseB) alive = vertexKind == 1 || vertexKind == 2;
             if (alive && inMedium) {
+                vertexKind = 1;
                 // ---- scattering at a point in the medium, volpath.cpp:80-96: MediumInteraction(p, -ray.d, ..., medium, phase)
                 handled = true;
                 {   // the dimensions of this vertex's draws side by side (as at a surface vertex, below)
@@ -1960,8 +1990,8 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
                 }
                 const float g = sc.media[med - 1].g;
                 const V3 zero = mk(0, 0, 0), wo = -rayD;
-                const float *tab = sc.nLights > 0 ? light_distribution(sc, mediumP) : nullptr;
-                if (sc.nLights > 0 && !tab) deferred = true;
+                const float *tab = (sc.nLights > 0 && !phaseB) ? light_distribution(sc, mediumP) : nullptr;
+                if (sc.nLights > 0 && !phaseB && !tab) deferred = true;
                 if (tab) {  // UniformSampleOneLight(mi, ..., handleMedia = true), integrator.cpp:85-106
                     float lightSelPdf;
                     lightNum = sample_discrete(tab, sc.nLights, draw1(), lightSelPdf);
@@ -2013,6 +2043,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
                         st.pdBeta[slot] = make_float4(beta.r, beta.g, beta.b, 0.f);
                     }
                 }
+                if (!phaseA) {
                 // mi.phase->Sample_p for the next direction, volpath.cpp:92-95
                 V3 wi;
                 float u0, u1;
@@ -2029,6 +2060,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
                     else beta = beta / (1 - qq);
                 }
                 bounces += 1;
+                }
             }
         }
         if (alive && !handled) {
@@ -2050,6 +2082,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
             int mIn = 0, mOut = 0;  // VOL: isect.mediumInterface
             if constexpr (VOL) prim_interface(sc, prim, med, mIn, mOut);
             if (m.type == PG_MAT_NONE) {  // path.cpp:107-113: skip over medium boundaries
+              if (!phaseB) {  // (no draws at such a vertex: phase 1 finishes it)
                 V3 nextO;
                 spawn_ray(is, rayD, nextO);
                 s_ray[0][0][tid] = make_float4(nextO.x, nextO.y, nextO.z, PG_INF);
@@ -2057,7 +2090,9 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
                 pushNext = true;
                 newFlags = meta.w & PG_META_SPECULAR;  // `continue` leaves specularBounce as it was
                 if constexpr (VOL) vs.medium[slot] = dot(rayD, is.n) > 0 ? mOut : mIn;  // Interaction::GetMedium(w), interaction.h:86-88
+              }
             } else {
+                vertexKind = 2;
                 // MatteMaterial::ComputeScatteringFunctions (matte.cpp:45-62), BSDF ctor (reflection.h:167-172)
                 // BSDF: the EXT kernel evaluates the material's BxDF list (any material); the plain kernel has the list
                 // shapes of matte / plastic / mirror / glass baked in (same arithmetic, fewer registers)
@@ -2225,7 +2260,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
                 if constexpr (EXT) hasNonSpecular = lbsdf_num_components(lb, nonSpecular) > 0;
                 else hasNonSpecular = bsdf.nBxDFs > 0 && !bsdf.specular;
                 // ---- direct lighting: UniformSampleOneLight (integrator.cpp:85-106) + EstimateDirect set-up
-                const bool wantLight = (VOL || hasNonSpecular) && sc.nLights > 0;  // path.cpp:119: only with non-specular lobes (volpath.cpp:124-127: always)
+                const bool wantLight = (VOL || hasNonSpecular) && sc.nLights > 0 && !phaseB;  // path.cpp:119: only with non-specular lobes (volpath.cpp:124-127: always)
                 const float *tab = wantLight ? light_distribution(sc, is.p) : nullptr;
                 if (wantLight && !tab) deferred = true;
                 if (tab) {
@@ -2297,6 +2332,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
                     }
                 }
                 // ---- sample the BSDF for the next direction (path.cpp:130-150)
+                if (!phaseA) {
                 V3 wo = -rayD, wi;
                 float pdf;
                 float u0, u1;
@@ -2359,6 +2395,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
                     }
                 }
                 bounces += 1;
+                }
             }
         }
         if (deferred) {
@@ -2367,9 +2404,13 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
             s_state[1][tid] = make_float4(beta.r, beta.g, beta.b, B4.w);
             s_state[2][tid] = make_float4(__int_as_float(meta.x), __int_as_float(meta.y), etaScale, __int_as_float((dim << 20) | bounces | newFlags));
         } else {
-            st.L[slot] = make_float4(L.r, L.g, L.b, L4.w);
+            // (GRID: phase 1 leaves the incoming flags for phase 2's rebuild of the vertex -- a null-material surface, finished in
+            // phase 1, sets its own --; phase 2 leaves L alone: k_resolve_vol has added this vertex's direct lighting to it)
+            if (phaseA && vertexKind != 0) newFlags = meta.w & 0xf0000;
+            if (!phaseB) st.L[slot] = make_float4(L.r, L.g, L.b, L4.w);
             st.beta[slot] = make_float4(beta.r, beta.g, beta.b, B4.w);
             st.meta[slot] = make_int4(meta.x, meta.y, __float_as_int(etaScale), (dim << 20) | bounces | newFlags);
+            if (phaseA) gsh.vertex[slot] = make_float4(mediumP.x, mediumP.y, mediumP.z, __int_as_float(alive ? vertexKind : 0));
         }
     }
     if (deferred) {  // retried once the voxel's distribution exists: no ray, no state, no pending term leaves this launch
@@ -2428,7 +2469,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
             } else st.L[slot] = s_state[0][tid];
             st.pdInfo[pdi] = make_int4(posShadow, posMis, lightNum, pushNext ? posNext : ~slot);
         }
-    } else if (valid && !deferred) st.pdInfo[slot] = make_int4(posShadow, posMis, lightNum, VOL ? __float_as_int(volWeight) : 0);
+    } else if (valid && !deferred && !phaseB) st.pdInfo[slot] = make_int4(posShadow, posMis, lightNum, VOL ? __float_as_int(volWeight) : 0);
     if constexpr (SSS) {
         // the probe rays of the paths that go on through a BSSRDF, region by region like every other queue; such a path's L went to
         // its slot above (where k_resolve adds this vertex's direct lighting), beta and meta follow it there
@@ -2455,24 +2496,30 @@ void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQue
     const float *noT = nullptr;
     const QueueState qi = st.qs[cur], qo = st.qs[cur ^ 1];
     const SssState none = {};
+    const GridShade gsh = {nullptr, 0};
     if (sss && sc.nBssrdfs > 0) {  // materials with a BSSRDF are BxDF-list materials: the general kernels
-        if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, false, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, *sss);
-        else hipLaunchKernelGGL((k_shade<1, false, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, *sss);
-    } else if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, none);
-    else if (sc.ext) hipLaunchKernelGGL((k_shade<1, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, none);
-    else hipLaunchKernelGGL((k_shade<0, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, none);
+        if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, false, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, *sss, gsh);
+        else hipLaunchKernelGGL((k_shade<1, false, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, *sss, gsh);
+    } else if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, none, gsh);
+    else if (sc.ext) hipLaunchKernelGGL((k_shade<1, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, none, gsh);
+    else hipLaunchKernelGGL((k_shade<0, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, none, gsh);
 }
 void launch_shade_vol(const DScene &sc, const RenderParams &rp, PathState st, VolState vs, RayQueue qin, const float4 *hits, const float *hitT,
-                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s, const SssState *sss) {
+                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s, const SssState *sss,
+                      float4 *gridVertex, int phase) {
     int nblk = rp.retryCount > 0 ? (rp.retryCount + PG_SHADE_BLOCK - 1) / PG_SHADE_BLOCK : PG_REGIONS * (qin.regionCap / PG_SHADE_BLOCK);
     if (nblk == 0) return;
     const QueueState none = {nullptr, nullptr, nullptr};
     const SssState nosss = {};
-    if (sss && sc.nBssrdfs > 0) {
-        if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, true, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, *sss);
-        else hipLaunchKernelGGL((k_shade<1, true, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, *sss);
-    } else if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss);
-    else hipLaunchKernelGGL((k_shade<1, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss);
+    const GridShade gsh = {gridVertex, phase};
+    if (phase != 0) {  // a scene with a grid medium: the two-phase kernels
+        if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, true, false, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss, gsh);
+        else hipLaunchKernelGGL((k_shade<1, true, false, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss, gsh);
+    } else if (sss && sc.nBssrdfs > 0) {
+        if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, true, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, *sss, gsh);
+        else hipLaunchKernelGGL((k_shade<1, true, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, *sss, gsh);
+    } else if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss, gsh);
+    else hipLaunchKernelGGL((k_shade<1, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss, gsh);
 }
 
 // EstimateDirect's two "Add ... contribution" steps (integrator.cpp:143-161, 196-212) and
@@ -2552,9 +2599,13 @@ PG_DEV void through_point(const DScene &sc, int ri, float4 o4, V3 rayD, float4 h
         n = normalize(m4_normal(in.w2i, n));
     }
 }
-template <int KIND>
+// GRID: a segment inside a GridDensityMedium is attenuated by ratio tracking (grid.cpp:88-120), whose numbers come from the path's
+// sampler: they are drawn here, at the path's current dimension / stream position, which st.meta[slot] keeps for the shading
+// kernel's second phase.  The host runs the kind-0 rays of a bounce to their ends before the kind-1 rays start (the reference
+// evaluates visibility.Tr before it samples the BSDF: integrator.cpp:146-150, then :164-212).
+template <int KIND, bool GRID>
 __global__ __launch_bounds__(PG_BLOCK) void k_through(DScene sc, PathState st, VolState vs, RayQueue qin, const float4 *__restrict__ hits,
-                                                       const float *__restrict__ hitT, int hitBase, RayQueue qout) {
+                                                       const float *__restrict__ hitT, int hitBase, RayQueue qout, RenderParams rp) {
     const int i = queue_item<>(qin);
     bool push = false;
     float4 no = make_float4(0, 0, 0, 0), nd = make_float4(0, 0, 0, 0);
@@ -2574,7 +2625,17 @@ __global__ __launch_bounds__(PG_BLOCK) void k_through(DScene sc, PathState st, V
         const bool opaque = surface && sc.materials[tri.material].type != PG_MAT_NONE;  // isect.primitive->GetMaterial() != nullptr
         if (KIND == 0 && opaque) Tr = sp(0.f);  // light.cpp:70-72: blocked
         else {
-            if (med) Tr = Tr * medium_tr(sc.media[med - 1], surface ? hitT[ri] : o4.w, sqrtf(lensq(rayD)));
+            if (GRID && med && sc.mediaGrid[med - 1] >= 0) {
+                const PgDensityGrid &gd = sc.grids[sc.mediaGrid[med - 1]];
+                int4 meta = st.meta[slot];
+                const uint64_t index = (uint64_t)(uint32_t)meta.x | ((uint64_t)(uint32_t)meta.y << 32);
+                int dim = (int)((uint32_t)meta.w >> 20);
+                const bool tileSerial = rp.rd.sampler >= PG_SAMPLER_RANDOM;
+                auto draw = [&]() -> float { return tileSerial ? ts_get1d(sc, slot) : halton_sample(sc, rp.rd, index, dim++); };
+                Tr = Tr * sp(grid_tr(gd, sc.gridDensity + gd.density_offset, mk(o4.x, o4.y, o4.z), rayD, surface ? hitT[ri] : o4.w, draw));
+                meta.w = (int)(((uint32_t)dim << 20) | ((uint32_t)meta.w & 0xfffffu));
+                st.meta[slot] = meta;
+            } else if (med) Tr = Tr * medium_tr(sc.media[med - 1], surface ? hitT[ri] : o4.w, sqrtf(lensq(rayD)));
             if (KIND == 1 && !(surface && !opaque)) {
                 // IntersectTr is over (scene.cpp:64-67): the sampled light's radiance along the ray (integrator.cpp:199-208)
                 const int lightNum = st.pdInfo[slot].z;
@@ -2622,11 +2683,17 @@ __global__ __launch_bounds__(PG_BLOCK) void k_through(DScene sc, PathState st, V
     if (push) { qout.o[pos] = no; qout.d[pos] = nd; }
 }
 void launch_through(const DScene &sc, PathState st, VolState vs, int kind, RayQueue qin, const float4 *hits, const float *hitT, int hitBase,
-                    RayQueue qout, hipStream_t s) {
+                    RayQueue qout, hipStream_t s, const RenderParams *rpGrid) {
     int nblk = PG_REGIONS * (qin.regionCap / PG_BLOCK);
     if (nblk == 0) return;
-    if (kind == 0) hipLaunchKernelGGL(k_through<0>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, vs, qin, hits, hitT, hitBase, qout);
-    else hipLaunchKernelGGL(k_through<1>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, vs, qin, hits, hitT, hitBase, qout);
+    if (rpGrid) {
+        if (kind == 0) hipLaunchKernelGGL((k_through<0, true>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, vs, qin, hits, hitT, hitBase, qout, *rpGrid);
+        else hipLaunchKernelGGL((k_through<1, true>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, vs, qin, hits, hitT, hitBase, qout, *rpGrid);
+        return;
+    }
+    const RenderParams none = {};
+    if (kind == 0) hipLaunchKernelGGL((k_through<0, false>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, vs, qin, hits, hitT, hitBase, qout, none);
+    else hipLaunchKernelGGL((k_through<1, false>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, vs, qin, hits, hitT, hitBase, qout, none);
 }
 // EstimateDirect's sums with handleMedia = true (integrator.cpp:143-161, 196-212), once the through rays are finished
 __global__ __launch_bounds__(PG_BLOCK) void k_resolve_vol(DScene sc, PathState st, VolState vs, RayQueue qin) {

@@ -259,7 +259,7 @@ def test_new_device_headers_are_valid_gfx950_code(tmp_path):
                            os.path.join(ROOT, "tests", "device_headers_gfx950.hip"), "-o", str(tmp_path / "check.o")])
 
 
-GRID_GOLD = os.path.join(ROOT, "tests", "golden_grid")
+GRID_GOLD = os.path.join(ROOT, "tests", "golden")
 
 
 @pytest.mark.parametrize("name", ["grid_puff", "grid_puff_dense", "grid_transformed", "grid_fog_camera"])

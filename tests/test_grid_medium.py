@@ -1,8 +1,9 @@
 """GridDensityMedium (`MakeNamedMedium ... "string type" "heterogeneous"`, /root/reference/src/media/grid.{h,cpp}): the host front
 end parses it into the ABI-23 tables (PgDensityGrid, PgSceneDesc.media_grid / grid_density), the CPU oracle renders it -- delta
-tracking in Sample, ratio tracking with roulette in Tr -- bit-identically to the UNMODIFIED reference (tests/golden_grid/*, rendered
-by oracle/_ref/pbrt_oracle through oracle/make_golden.py), and the device library says loudly that it has no kernels for it.
-All of this runs without a GPU: it is the oracle-first half of the row; the device half is next."""
+tracking in Sample, ratio tracking with roulette in Tr -- bit-identically to the UNMODIFIED reference (tests/golden/grid_*, rendered
+by oracle/_ref/pbrt_oracle through oracle/make_golden.py).  All of this runs without a GPU.  The device half -- k_shade<., ., ., GRID> in
+two phases around the transmittance rays, k_through<., GRID> (pbrt-v3_amd/csrc/pg_kernels.hip, pg_grid.h) -- is checked by the GPU parity
+suite on the same goldens (film and counters bit-identical to the correctly-rounded oracle)."""
 import glob
 import json
 import os
@@ -14,8 +15,8 @@ import pytest
 from conftest import ROOT
 from test_gpu_binding import BINDING
 
-GRID = os.path.join(ROOT, "tests", "golden_grid")
-NAMES = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GRID, "*.json")))
+GRID = os.path.join(ROOT, "tests", "golden")
+NAMES = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GRID, "grid_*.json")))
 
 
 def test_goldens_present():
@@ -70,16 +71,6 @@ def test_spectrally_varying_sigma_t_is_reported(pkg, capfd):
     except pkg.PbrtGpuError:
         pass
     assert "GridDensityMedium requires a spectrally uniform attenuation coefficient!" in capfd.readouterr().err
-
-
-def test_device_library_refuses_grid_media_loudly(pkg):
-    """No kernels for it in this ABI version: pg_scene_create answers PG_ERR_UNSUPPORTED before touching a device (so the check
-    runs here too) -- never a silent render without the medium, never a CPU fallback."""
-    import ctypes as C
-    scene = pkg.HostScene(os.path.join(GRID, "grid_puff.pbrt"))
-    lib, handle = pkg.gpu_lib(), C.c_void_p()
-    assert lib.pg_scene_create(C.byref(scene.desc), C.byref(handle)) == -2 and not handle  # PG_ERR_UNSUPPORTED
-    assert b"GridDensityMedium" in lib.pg_last_error()
 
 
 @pytest.mark.parametrize("name", ["grid_puff", "grid_fog_camera", "grid_transformed"])

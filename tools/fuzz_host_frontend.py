@@ -12,7 +12,7 @@ Round 2 found seven defects this way (negative vertex indices, non-finite vertic
 of a destroyed tokenizer, non-manifold loopsubdiv control meshes, a file that includes itself, AttributeEnd after a stray
 TransformEnd -- an empty-stack read the reference shares --, and an int overflow on a hostile "maxdepth");
 tests/test_host_frontend.py keeps one input of each.  The corpus also holds the grid-medium and subsurface scenes
-(tests/golden_grid; FUZZ_ONLY=<directory name> restricts it).  Last sweeps: seeds 111, 121, 131 -- 11 000
+(FUZZ_ONLY=<directory name> restricts it).  Last sweeps: seeds 111, 121, 131 -- 11 000
 mutated scenes, 0 problems."""
 import glob
 import os
@@ -99,8 +99,8 @@ def main():
     exe = build()
     rng = random.Random(seed)
     gold = os.path.join(ROOT, "tests", "golden")
-    dirs = [gold, os.path.join(ROOT, "tests", "golden_grid")]
-    if os.environ.get("FUZZ_ONLY"):  # e.g. FUZZ_ONLY=golden_grid: mutate only that directory's scenes
+    dirs = [gold]
+    if os.environ.get("FUZZ_ONLY"):  # mutate only that directory's scenes
         dirs = [d for d in dirs if os.path.basename(d) == os.environ["FUZZ_ONLY"]]
     srcs = [s for d in dirs for s in sorted(glob.glob(os.path.join(d, "*.pbrt"))) if os.path.getsize(s) < 20000]
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1")
