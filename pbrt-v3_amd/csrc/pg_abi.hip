@@ -53,6 +53,7 @@ struct PgScene {
     DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, textures, textured, images, texels, ewaLut, envTables, alphas, alphaTex, triAlpha, triN, triS, uv, materials, lights, distTable, perms, permSums, primes, media, triMediumIn, triMediumOut, sobolMatrices, vdcSobol, vdcSobolInv, noisePerm;
     // work buffers (sized on first render, reused)
     int capacity = 0;
+    DeviceBuffer shadeOrder, primClass;  // k_shade_order: the order buffer of the main queue, the primitives' material classes
     DeviceBuffer qo[4], qd[4], counts, hitsMain, hitInst, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
         lightTests, filmDev, straysDev, nStraysDev, cullGuard, cursors, cursors2;
     hipStream_t shadowStream = nullptr;  // any-hit launches run here, concurrently with the next closest-hit launch
@@ -617,6 +618,33 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     d.images = (const PgImage *)s->images.p; d.texels = (const float *)s->texels.p; d.ewaLut = (const float *)s->ewaLut.p;
     d.textures = (const PgTexture *)s->textures.p; d.textured = (const PgTexturedMaterial *)s->textured.p;
     d.hasTextured = anyTextured ? 1 : 0;
+    {   // shading classes (k_shade_order): scenes whose materials evaluate textures / BxDF lists shade grouped by material.  Few
+        // materials: each is a class (its textures stay with its waves as well); many: materials that run the same code
+        // (type, kind, bump) share one.  PG_SHADE_ORDER=0: queue order, as scenes without such materials are shaded.
+        const char *so = getenv("PG_SHADE_ORDER");
+        if (d.hasTextured && desc->n_materials > 1 && !(so && atoi(so) == 0)) {
+            const int nClasses = PG_ORDER_CLASSES - 2;
+            std::vector<unsigned char> matClass((size_t)desc->n_materials, 0);
+            if (desc->n_materials <= nClasses) for (int i = 0; i < desc->n_materials; ++i) matClass[i] = (unsigned char)i;
+            else {
+                std::vector<int> sigs;
+                for (int i = 0; i < desc->n_materials; ++i) {
+                    const PgMaterial &m = desc->materials[i];
+                    int sig = m.type;
+                    if (m.type == PG_MAT_TEXTURED) { const PgTexturedMaterial &tm = desc->textured[m.textured_index]; sig |= (tm.kind << 8) | (tm.has_bump ? 1 << 16 : 0); }
+                    size_t k = 0;
+                    while (k < sigs.size() && sigs[k] != sig) ++k;
+                    if (k == sigs.size()) sigs.push_back(sig);
+                    matClass[i] = (unsigned char)(k % (size_t)nClasses);
+                }
+            }
+            std::vector<unsigned char> pc((size_t)nt);
+            for (int k = 0; k < nt; ++k) pc[k] = matClass[desc->tri_material ? desc->tri_material[k] : 0];
+            HIP_TRY_S(s->primClass.alloc(pc.size()));
+            HIP_TRY_S(hipMemcpy(s->primClass.p, pc.data(), pc.size(), hipMemcpyHostToDevice));
+            d.primClass = (const unsigned char *)s->primClass.p;
+        }
+    }
     {  // PG_FORCE_EXT=1 runs the general kernels on scenes that do not need them (tests: both paths agree bit for bit)
         const char *fe = getenv("PG_FORCE_EXT");
         d.ext = (d.hasTextured || d.nSpheres > 0 || d.nInstances > 0 || d.hasInfinite || anyImageLight || anyLobeMaterial || (fe && atoi(fe) != 0)) ? 1 : 0;
@@ -803,6 +831,7 @@ static int ensureWorkBuffers(PgScene *s, int capacity) {
     // (grid media: a third part -- the transmittance rays must leave the main rays' hits alone for the second shading phase)
     const size_t hitParts = s->d.nGrids > 0 ? 3 : 2;
     HIP_TRY(s->hitsMain.alloc(hitParts * n * sizeof(float4)));
+    if (s->d.primClass) HIP_TRY(s->shadeOrder.alloc(n * sizeof(int)));
     if (s->d.nInstances > 0) { HIP_TRY(s->hitInst.alloc(hitParts * n * sizeof(int))); s->d.hitInst = (int *)s->hitInst.p; }  // main-queue hits, then MIS-queue hits at offset n (one launch fills both)
     HIP_TRY(s->occluded.alloc(n * sizeof(int)));
     HIP_TRY(s->stL.alloc(n * sizeof(float4)));
@@ -1065,7 +1094,8 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                     // a scene with a grid medium shades in two phases around the transmittance rays (k_shade<., ., ., GRID>)
                     const bool gridOn = s->d.nGrids > 0;
                     float4 *gridVertex = (float4 *)s->gridVertex.p;
-                    PG_TIMED(2, stream, launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream, sssArg, gridVertex, gridOn ? 1 : 0));
+                    rp.order = s->d.primClass ? (const int *)s->shadeOrder.p : nullptr;  // (the second phase of a grid scene takes the same order)
+                    PG_TIMED(2, stream, (launch_shade_order(dv, q[cur], (const float4 *)s->hitsMain.p, (int *)s->shadeOrder.p, stream), launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream, sssArg, gridVertex, gridOn ? 1 : 0)));
                     ++shadeLaunches;
                     if (int e = settleLightTables([&]() { launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream, sssArg, gridVertex, gridOn ? 1 : 0); })) return e;
                     // through rays: kind 0 = light samples (q[2] <-> vq[0]), kind 1 = BSDF / phase samples (q[3] <-> vq[1]), re-traced
@@ -1187,7 +1217,8 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                 HIP_TRY(hipMemsetAsync(counts + 2 * QSTRIDE, 0, 2 * QSTRIDE * sizeof(int), stream));
                 if (sssOn) HIP_TRY(hipMemsetAsync(sq.qjob.counts, 0, QSTRIDE * sizeof(int), stream));
                 const SssState *sssArg = sssOn ? &sq : nullptr;
-                PG_TIMED(2, stream, launch_shade(s->d, rp, ps, q[cur], (const float4 *)s->hitsMain.p, q[nxt], q[2], q[3], lightTests, stream, cur, sssArg));
+                rp.order = s->d.primClass ? (const int *)s->shadeOrder.p : nullptr;
+                PG_TIMED(2, stream, (launch_shade_order(s->d, q[cur], (const float4 *)s->hitsMain.p, (int *)s->shadeOrder.p, stream), launch_shade(s->d, rp, ps, q[cur], (const float4 *)s->hitsMain.p, q[nxt], q[2], q[3], lightTests, stream, cur, sssArg)));
                 ++shadeLaunches;
                 if (int e = settleLightTables([&]() { launch_shade(s->d, rp, ps, q[cur], (const float4 *)s->hitsMain.p, q[nxt], q[2], q[3], lightTests, stream, cur, sssArg); })) return e;
                 // paths that reach maxdepth neither continue nor sample lights (path.cpp:104): nothing left to trace

@@ -1829,7 +1829,10 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
     if (rp.retryCount > 0) {  // second pass over the entries that waited for a light-distribution voxel
         const int j = blockIdx.x * PG_SHADE_BLOCK + threadIdx.x;
         i = j < rp.retryCount ? rp.retryList[j] : -1;
-    } else i = queue_item<PG_SHADE_BLOCK>(qin);
+    } else {
+        i = queue_item<PG_SHADE_BLOCK>(qin);
+        if (rp.order && i >= 0) i = rp.order[i];  // k_shade_order: the entries of a window grouped by material class
+    }
     bool deferred = false;  // sparse light tables: this vertex met a voxel without a distribution; nothing is committed
     unsigned long long tsState0 = 0;  // tile-serial samplers: the tile's stream position and dimension counters on entry
     int tsCur1D0 = 0, tsCur2D0 = 0;
@@ -2487,6 +2490,58 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
     }
     unsigned long long nl = wave_sum(nLightTests);
     if (lane_id() == 0 && nl) atomicAdd(lightTriTests + (blockIdx.x & (PG_LIGHT_TEST_SHARDS - 1)) * PG_LIGHT_TEST_STRIDE, nl);
+}
+// The order in which a shading launch takes the entries of its queue (RenderParams::order): block b sorts the entry indices of
+// window b >> 3 of region b & 7 by the material class of the entry's hit -- counting sort, stable, so that the entries of a class stay
+// in queue order and neighbouring lanes still read neighbouring entries.  Window and region are those of the consumer's
+// blocks (queue_item): the shading blocks of a window run side by side on the region's XCD and find each other's lines in its L2.
+__global__ __launch_bounds__(1024) void k_shade_order(DScene sc, RayQueue q, const float4 *__restrict__ hits, int *__restrict__ order) {
+    constexpr int NCHUNK = PG_ORDER_WINDOW / 64, ROUNDS = PG_ORDER_WINDOW / 1024, NW = 1024 / 64;
+    static_assert(PG_ORDER_WINDOW % 1024 == 0 && PG_ORDER_CLASSES == 16, "k_shade_order: window of whole blocks, 16 classes");
+    const int r = blockIdx.x & (PG_REGIONS - 1), base = (blockIdx.x >> 3) * PG_ORDER_WINDOW;
+    const int count = q.counts[r * PG_COUNT_STRIDE];
+    if (base >= count) return;
+    __shared__ int s_cnt[NCHUNK][PG_ORDER_CLASSES + 1];  // entries of a class in a 64-entry chunk, then their first place in the window
+    __shared__ int s_total[PG_ORDER_CLASSES];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    int cls[ROUNDS], rank[ROUNDS];
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+        const int chunk = k * NW + wave, j = base + chunk * 64 + lane;
+        int c = PG_ORDER_CLASSES - 1;
+        if (j < count) {
+            const int prim = __float_as_int(hits[(size_t)r * q.regionCap + j].x);
+            c = prim >= 0 ? sc.primClass[prim] : PG_ORDER_CLASSES - 2;
+        }
+        unsigned long long mine = 0;
+        for (int b = 0; b < PG_ORDER_CLASSES; ++b) {
+            const unsigned long long m = __ballot(c == b);
+            if (lane == 0) s_cnt[chunk][b] = __popcll(m);
+            if (c == b) mine = m;
+        }
+        cls[k] = c;
+        rank[k] = __popcll(mine & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (threadIdx.x < PG_ORDER_CLASSES) {  // per class: where each chunk's entries start among the class's
+        int sum = 0;
+        for (int ch = 0; ch < NCHUNK; ++ch) { const int v = s_cnt[ch][threadIdx.x]; s_cnt[ch][threadIdx.x] = sum; sum += v; }
+        s_total[threadIdx.x] = sum;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+        const int chunk = k * NW + wave, j = base + chunk * 64 + lane;
+        if (j >= count) continue;
+        int off = s_cnt[chunk][cls[k]] + rank[k];
+        for (int b = 0; b < PG_ORDER_CLASSES; ++b) if (b < cls[k]) off += s_total[b];
+        order[(size_t)r * q.regionCap + base + off] = r * q.regionCap + j;
+    }
+}
+void launch_shade_order(const DScene &sc, RayQueue qin, const float4 *hits, int *order, hipStream_t s) {
+    const int nblk = PG_REGIONS * ((qin.regionCap + PG_ORDER_WINDOW - 1) / PG_ORDER_WINDOW);
+    if (nblk == 0 || !sc.primClass || !order) return;
+    hipLaunchKernelGGL(k_shade_order, dim3(nblk), dim3(1024), 0, s, sc, qin, hits, order);
 }
 void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQueue qin, const float4 *hits, RayQueue qnext,
                   RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s, int cur, const SssState *sss) {
