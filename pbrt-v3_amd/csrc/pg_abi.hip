@@ -53,7 +53,8 @@ struct PgScene {
     DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, textures, textured, images, texels, ewaLut, envTables, alphas, alphaTex, triAlpha, triN, triS, uv, materials, lights, distTable, perms, permSums, primes, media, triMediumIn, triMediumOut, sobolMatrices, vdcSobol, vdcSobolInv, noisePerm;
     // work buffers (sized on first render, reused)
     int capacity = 0;
-    DeviceBuffer shadeOrder, primClass;  // k_shade_order: the order buffer of the main queue, the primitives' material classes
+    DeviceBuffer shadeOrder, primClass, volPre;  // k_shade_order: the order buffer of the main queue, the primitives' material classes, volpath's pre-drawn medium samples
+    bool volOrder = false;  // volpath launches shade medium vertices and surface vertices in separate waves (scenes with homogeneous media only)
     DeviceBuffer qo[4], qd[4], counts, hitsMain, hitInst, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
         lightTests, filmDev, straysDev, nStraysDev, cullGuard, cursors, cursors2;
     hipStream_t shadowStream = nullptr;  // any-hit launches run here, concurrently with the next closest-hit launch
@@ -622,6 +623,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         // materials: each is a class (its textures stay with its waves as well); many: materials that run the same code
         // (type, kind, bump) share one.  PG_SHADE_ORDER=0: queue order, as scenes without such materials are shaded.
         const char *so = getenv("PG_SHADE_ORDER");
+        s->volOrder = s->nMedia > 0 && d.nGrids == 0 && !(so && atoi(so) == 0);
         if (d.hasTextured && desc->n_materials > 1 && !(so && atoi(so) == 0)) {
             const int nClasses = PG_ORDER_CLASSES - 2;
             std::vector<unsigned char> matClass((size_t)desc->n_materials, 0);
@@ -831,7 +833,8 @@ static int ensureWorkBuffers(PgScene *s, int capacity) {
     // (grid media: a third part -- the transmittance rays must leave the main rays' hits alone for the second shading phase)
     const size_t hitParts = s->d.nGrids > 0 ? 3 : 2;
     HIP_TRY(s->hitsMain.alloc(hitParts * n * sizeof(float4)));
-    if (s->d.primClass) HIP_TRY(s->shadeOrder.alloc(n * sizeof(int)));
+    if (s->d.primClass || s->volOrder) HIP_TRY(s->shadeOrder.alloc(n * sizeof(int)));
+    if (s->volOrder) HIP_TRY(s->volPre.alloc(n * sizeof(float2)));
     if (s->d.nInstances > 0) { HIP_TRY(s->hitInst.alloc(hitParts * n * sizeof(int))); s->d.hitInst = (int *)s->hitInst.p; }  // main-queue hits, then MIS-queue hits at offset n (one launch fills both)
     HIP_TRY(s->occluded.alloc(n * sizeof(int)));
     HIP_TRY(s->stL.alloc(n * sizeof(float4)));
@@ -1094,8 +1097,11 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                     // a scene with a grid medium shades in two phases around the transmittance rays (k_shade<., ., ., GRID>)
                     const bool gridOn = s->d.nGrids > 0;
                     float4 *gridVertex = (float4 *)s->gridVertex.p;
-                    rp.order = s->d.primClass ? (const int *)s->shadeOrder.p : nullptr;  // (the second phase of a grid scene takes the same order)
-                    PG_TIMED(2, stream, (launch_shade_order(dv, q[cur], (const float4 *)s->hitsMain.p, (int *)s->shadeOrder.p, stream), launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream, sssArg, gridVertex, gridOn ? 1 : 0)));
+                    // (GlobalSamplers, dense light tables: the tile-serial streams and the deferred vertices of sparse tables draw in the shading kernel)
+                    float2 *volPre = (s->volOrder && !tileSerial && !s->d.sparseLights) ? (float2 *)s->volPre.p : nullptr;
+                    rp.volPre = volPre;
+                    rp.order = (s->d.primClass || volPre) ? (const int *)s->shadeOrder.p : nullptr;  // (the second phase of a grid scene takes the same order)
+                    PG_TIMED(2, stream, (launch_shade_order_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, (int *)s->shadeOrder.p, volPre, stream), launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream, sssArg, gridVertex, gridOn ? 1 : 0)));
                     ++shadeLaunches;
                     if (int e = settleLightTables([&]() { launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream, sssArg, gridVertex, gridOn ? 1 : 0); })) return e;
                     // through rays: kind 0 = light samples (q[2] <-> vq[0]), kind 1 = BSDF / phase samples (q[3] <-> vq[1]), re-traced

@@ -217,6 +217,9 @@ struct RenderParams {
     int retryCount;
     // shading order (k_shade_order): order[position] = the main-queue entry the thread at that position shades; nullptr: its own
     const int *order;
+    // volpath, GlobalSamplers: k_shade_order has drawn HomogeneousMedium::Sample's two numbers for every entry whose ray is in a
+    // medium -- volPre[entry] = (channel as int bits, sampled distance); the shading kernel takes them from here.  nullptr: it draws.
+    const float2 *volPre;
 };
 
 // The shading kernels count Triangle::Intersect calls of light.Pdf_Li (the reference's nTests statistic) into PG_LIGHT_TEST_SHARDS
@@ -261,6 +264,10 @@ void launch_ts_film(const DScene &sc, const RenderParams &rp, PathState st, PgFi
 #endif
 #define PG_ORDER_CLASSES 16  // 0 .. 13 material classes, 14 = the ray escaped, 15 = no entry
 void launch_shade_order(const DScene &sc, RayQueue qin, const float4 *hits, int *order, hipStream_t s);
+// volpath: additionally draws the medium sample of every entry (RenderParams::volPre) and puts the entries that scatter in the medium
+// into a class of their own (class 13), so that a wave shades medium vertices or surface vertices, not both one after the other
+void launch_shade_order_vol(const DScene &sc, const RenderParams &rp, PathState st, VolState vs, RayQueue qin, const float4 *hits, const float *hitT,
+                            int *order, float2 *volPre, hipStream_t s);
 void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQueue qin, const float4 *hits, RayQueue qnext,
                   RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s, int cur = 0, const SssState *sss = nullptr);
 // Subsurface scattering: one step of the probe chains (pass 1: count the hits on the material; pass 2: stop at the chosen one) over

@@ -1813,6 +1813,12 @@ PG_DEV void prim_interface(const DScene &sc, int prim, int rayMedium, int &mIn, 
 // phase 1 = everything up to the MIS candidate (emission, medium sampling incl. delta tracking, the light sample), then the
 // transmittance rays (k_through draws and counts), k_resolve_vol, and phase 2 = the vertex rebuilt, its next direction and the
 // roulette.  Scenes without a grid medium run the single-pass kernels they ran before (phase 0).
+// HomogeneousMedium::Sample's channel and distance from its two numbers, homogeneous.cpp:51-54
+PG_DEV void homogeneous_sample_distance(const PgMedium &mm, float uChannel, float uDist, int &channel, float &dist) {
+    channel = (int)(uChannel * 3);
+    if (channel > 2) channel = 2;
+    dist = -(float)log((double)(1 - uDist)) / mm.sigma_t[channel];
+}
 struct GridShade { float4 *vertex; int phase; };  // vertex[slot] = (medium interaction point, kind: 0 none, 1 medium vertex, 2 surface vertex)
 template <int MODE, bool VOL, bool SSS = false, bool GRID = false>
 __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MODE == 1 && PG_SHADE_MIN_WAVES > 0) ? PG_SHADE_MIN_WAVES : (MODE == 2 ? (VOL ? PG_SHADE2V_WAVES : PG_SHADE2_WAVES) : 1))) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
@@ -1921,10 +1927,16 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
             } else if (med) {  // HomogeneousMedium::Sample, homogeneous.cpp:49-74
                 const PgMedium &mm = sc.media[med - 1];
                 const float4 o4 = qin.o[i];
-                int channel = (int)(draw1() * 3);
-                if (channel > 2) channel = 2;
-                const float ud = draw1();
-                const float dist = -(float)log((double)(1 - ud)) / mm.sigma_t[channel];
+                int channel;
+                float dist;
+                if (!GRID && rp.volPre) {  // drawn by k_shade_order (same dimensions, same arithmetic)
+                    const float2 pv = rp.volPre[i];
+                    channel = __float_as_int(pv.x); dist = pv.y;
+                    dim += 2;
+                } else {
+                    const float uc = draw1();
+                    homogeneous_sample_distance(mm, uc, draw1(), channel, dist);
+                }
                 const float dLen = sqrtf(lensq(rayD));
                 const float tMaxRay = found ? hitT[i] : o4.w;  // ray.tMax after Scene::Intersect
                 const float t = pmin(dist / dLen, tMaxRay);
@@ -2495,7 +2507,12 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
 // window b >> 3 of region b & 7 by the material class of the entry's hit -- counting sort, stable, so that the entries of a class stay
 // in queue order and neighbouring lanes still read neighbouring entries.  Window and region are those of the consumer's
 // blocks (queue_item): the shading blocks of a window run side by side on the region's XCD and find each other's lines in its L2.
-__global__ __launch_bounds__(1024) void k_shade_order(DScene sc, RayQueue q, const float4 *__restrict__ hits, int *__restrict__ order) {
+// VOL (volpath, GlobalSamplers, no grid medium): the kernel also draws the medium sample of every entry whose ray is in a medium
+// (HomogeneousMedium::Sample's two numbers at the path's current dimension; the shading kernel reads channel and distance from
+// volPre instead of drawing them) and gives the entries that scatter inside the medium a class of their own.
+template <bool VOL>
+__global__ __launch_bounds__(1024) void k_shade_order(DScene sc, RayQueue q, const float4 *__restrict__ hits, int *__restrict__ order,
+                                                      PgRenderDesc rd, PathState st, VolState vs, const float *__restrict__ hitT, float2 *__restrict__ volPre) {
     constexpr int NCHUNK = PG_ORDER_WINDOW / 64, ROUNDS = PG_ORDER_WINDOW / 1024, NW = 1024 / 64;
     static_assert(PG_ORDER_WINDOW % 1024 == 0 && PG_ORDER_CLASSES == 16, "k_shade_order: window of whole blocks, 16 classes");
     const int r = blockIdx.x & (PG_REGIONS - 1), base = (blockIdx.x >> 3) * PG_ORDER_WINDOW;
@@ -2510,8 +2527,25 @@ __global__ __launch_bounds__(1024) void k_shade_order(DScene sc, RayQueue q, con
         const int chunk = k * NW + wave, j = base + chunk * 64 + lane;
         int c = PG_ORDER_CLASSES - 1;
         if (j < count) {
-            const int prim = __float_as_int(hits[(size_t)r * q.regionCap + j].x);
-            c = prim >= 0 ? sc.primClass[prim] : PG_ORDER_CLASSES - 2;
+            const size_t e = (size_t)r * q.regionCap + j;
+            const int prim = __float_as_int(hits[e].x);
+            c = prim < 0 ? PG_ORDER_CLASSES - 2 : (sc.primClass ? sc.primClass[prim] : 0);
+            if constexpr (VOL) {
+                const float4 d4 = q.d[e];
+                const int slot = __float_as_int(d4.w), med = vs.medium[slot];
+                if (med && !(sc.mediaGrid && sc.mediaGrid[med - 1] >= 0)) {
+                    const int4 meta = st.meta[slot];
+                    const uint64_t index = (uint64_t)(uint32_t)meta.x | ((uint64_t)(uint32_t)meta.y << 32);
+                    const int dim = (int)((uint32_t)meta.w >> 20);
+                    const float uc = halton_sample(sc, rd, index, dim);
+                    int channel;
+                    float dist;
+                    homogeneous_sample_distance(sc.media[med - 1], uc, halton_sample(sc, rd, index, dim + 1), channel, dist);
+                    volPre[e] = make_float2(__int_as_float(channel), dist);
+                    const float tMaxRay = prim >= 0 ? hitT[e] : q.o[e].w;
+                    if (dist / sqrtf(lensq(mk(d4.x, d4.y, d4.z))) < tMaxRay) c = PG_ORDER_CLASSES - 3;  // (only the grouping depends on this)
+                }
+            }
         }
         unsigned long long mine = 0;
         for (int b = 0; b < PG_ORDER_CLASSES; ++b) {
@@ -2541,7 +2575,14 @@ __global__ __launch_bounds__(1024) void k_shade_order(DScene sc, RayQueue q, con
 void launch_shade_order(const DScene &sc, RayQueue qin, const float4 *hits, int *order, hipStream_t s) {
     const int nblk = PG_REGIONS * ((qin.regionCap + PG_ORDER_WINDOW - 1) / PG_ORDER_WINDOW);
     if (nblk == 0 || !sc.primClass || !order) return;
-    hipLaunchKernelGGL(k_shade_order, dim3(nblk), dim3(1024), 0, s, sc, qin, hits, order);
+    hipLaunchKernelGGL(k_shade_order<false>, dim3(nblk), dim3(1024), 0, s, sc, qin, hits, order, PgRenderDesc{}, PathState{}, VolState{}, (const float *)nullptr, (float2 *)nullptr);
+}
+void launch_shade_order_vol(const DScene &sc, const RenderParams &rp, PathState st, VolState vs, RayQueue qin, const float4 *hits, const float *hitT,
+                            int *order, float2 *volPre, hipStream_t s) {
+    const int nblk = PG_REGIONS * ((qin.regionCap + PG_ORDER_WINDOW - 1) / PG_ORDER_WINDOW);
+    if (nblk == 0 || !order) return;
+    if (volPre) hipLaunchKernelGGL(k_shade_order<true>, dim3(nblk), dim3(1024), 0, s, sc, qin, hits, order, rp.rd, st, vs, hitT, volPre);
+    else launch_shade_order(sc, qin, hits, order, s);
 }
 void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQueue qin, const float4 *hits, RayQueue qnext,
                   RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s, int cur, const SssState *sss) {
