@@ -151,12 +151,54 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         // one BVHAccel's nodes [firstNode, +nn) -> records appended to w; leaf references carry GLOBAL primitive indices
         // (firstPrim + the node's own offset).  Returns the reference of the BVH's root.
         bool badChildren = false;
+        // which records share a 128-B line (measured, profiles/r03n_record_layout_ab.txt: 1 is 1 - 3 % faster than 0, 2 is no gain)
+        const int recordLayout = getenv("PG_RECORD_LAYOUT") ? atoi(getenv("PG_RECORD_LAYOUT")) : 1;
         auto buildRecords = [&](int firstNode, int nn, int firstPrim) -> int {
             const PgBVHNode *nodes = desc->nodes + firstNode;
             std::vector<int> recIndex((size_t)nn, -1);
             int nInterior = 0;
+            if (recordLayout != 0 && ((w.size() / 4) & 1)) w.resize(w.size() + 4, make_float4(0, 0, 0, 0));
             const int base = (int)(w.size() / 4);
-            for (int i = 0; i < nn; ++i) if (nodes[i].nprims == 0) recIndex[i] = base + nInterior++;
+            for (int i = 0; i < nn; ++i) if (nodes[i].nprims == 0) ++nInterior;
+            if (recordLayout == 0) {  // depth-first: a record's line mate is the next interior node of the reference's array
+                int k = 0;
+                for (int i = 0; i < nn; ++i) if (nodes[i].nprims == 0) recIndex[i] = base + k++;
+            } else {
+                // Two records share a 128-B line, and an L2 miss fills the whole line: choose the line mates.  1: a node with the
+                // child a ray through it is likelier to visit (the one with the larger surface area); 2: the two children of a
+                // node.  Nodes left alone (no interior child / sibling) pair up among themselves in the order they are met.
+                auto area = [&](int i) { const PgBVHNode &b = nodes[i]; const float x = b.bmax[0] - b.bmin[0], y = b.bmax[1] - b.bmin[1], z = b.bmax[2] - b.bmin[2]; return x * y + y * z + z * x; };
+                int nPlaced = 0;  // (base is even: lines are pairs of absolute record indices, and nodes are placed two at a time)
+                auto place = [&](int n) { recIndex[n] = base + nPlaced++; };
+                std::vector<int> singles, stack;
+                if (nn > 0 && nodes[0].nprims == 0) stack.push_back(0);
+                auto placeSingle = [&](int n) { singles.push_back(n); if (singles.size() == 2) { place(singles[0]); place(singles[1]); singles.clear(); } };
+                while (!stack.empty()) {
+                    const int n = stack.back(); stack.pop_back();
+                    const int c0 = n + 1, c1 = nodes[n].offset;
+                    if (c0 >= nn || c1 <= n || c1 >= nn) continue;  // (reported below)
+                    const bool i0 = nodes[c0].nprims == 0, i1 = nodes[c1].nprims == 0;
+                    if (recordLayout == 1) {  // `n` is the head of a line unless it was placed as its parent's mate
+                        int h = -1, o = -1;
+                        if (i0 && i1) { h = area(c0) >= area(c1) ? c0 : c1; o = h == c0 ? c1 : c0; } else if (i0) h = c0; else if (i1) h = c1;
+                        if (recIndex[n] < 0) {
+                            if (h < 0) { placeSingle(n); continue; }
+                            place(n); place(h);
+                            if (o >= 0) stack.push_back(o);
+                            // h's own children head new lines
+                            const int h0 = h + 1, h1 = nodes[h].offset;
+                            if (h1 > h && h1 < nn && h0 < nn) { if (nodes[h1].nprims == 0) stack.push_back(h1); if (nodes[h0].nprims == 0) stack.push_back(h0); }
+                        }
+                    } else {  // siblings share a line
+                        if (n == 0) placeSingle(n);  // (the root; every other node is placed, or waits among the singles, when it is pushed)
+                        if (i0 && i1) { place(c0); place(c1); stack.push_back(c1); stack.push_back(c0); }
+                        else if (i0) { placeSingle(c0); stack.push_back(c0); }
+                        else if (i1) { placeSingle(c1); stack.push_back(c1); }
+                    }
+                }
+                if (singles.size() == 1) place(singles[0]);
+                if (nPlaced != nInterior) badChildren = true;  // every interior node has exactly one slot
+            }
             auto refOf = [&](int i) -> int {
                 const PgBVHNode &nd = nodes[i];
                 return nd.nprims == 0 ? recIndex[i] : ~(((firstPrim + nd.offset) << leafBits) | (nd.nprims - 1));
