@@ -495,6 +495,16 @@ SCENES = {
                           .replace('Camera "perspective" "float fov" [ 39.3 ]', 'Camera "perspective" "float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 900 ]')
                           .replace('PixelFilter "box"', 'PixelFilter "gaussian"'),
     "sampler_maxmindist": with_sampler(cornell(24, 24, 4), '"maxmindist" "integer pixelsamples" [ 8 ] "integer dimensions" [ 2 ]'),
+    # "dimensions" covering every draw a path of this depth can make (1 + 2 maxdepth one-dimensional, 2 + 3 maxdepth two-dimensional): no path
+    # touches the tile's stream after StartPixel -- the device generates a tile's arrays ahead and traces all its pixels as one wavefront
+    "filter_02sequence_dims": with_sampler(cornell(36, 20, 4, extra_film='"float cropwindow" [ 0.1 0.9 0.2 1 ]', integrator='Integrator "path" "integer maxdepth" [ 3 ]'),
+                                           '"02sequence" "integer pixelsamples" [ 4 ] "integer dimensions" [ 11 ]')
+                          .replace('Camera "perspective" "float fov" [ 39.3 ]', 'Camera "perspective" "float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 900 ]')
+                          .replace('PixelFilter "box"', 'PixelFilter "gaussian"'),
+    "sampler_maxmindist_dims": with_sampler(cornell(24, 24, 4), '"maxmindist" "integer pixelsamples" [ 8 ] "integer dimensions" [ 17 ]'),  # maxdepth 5: the roulette draws too
+    "sampler_stratified_dims_tex": with_sampler(cornell(32, 24, 4, integrator='Integrator "path" "integer maxdepth" [ 4 ]', world_edit=lambda s: with_image_textures(s)),
+                                                '"stratified" "integer xsamples" [ 2 ] "integer ysamples" [ 2 ] "integer dimensions" [ 14 ]')
+                          .replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 10 ] "float focaldistance" [ 700 ]'),
     "sampler_lowdisc_vol": with_sampler(cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 4 ]', world_edit=lambda s: with_smoke(s)),
                                         '"lowdiscrepancy" "integer pixelsamples" [ 4 ] "integer dimensions" [ 3 ]'),
     # 5 000 area lights under the default "spatial" strategy: the device fills its voxel tables on first touch (sparse), as the
@@ -846,7 +856,9 @@ def run(name, scene_path, outdir=GOLD):
     ref = os.path.join(HERE, "_ref", "pbrt_oracle")
     out = os.path.join(outdir, name + ".pfm")
     # one thread for the wide-filter scenes: overlapping FilmTiles are then merged in tile order (film.cpp:117-130)
-    nthreads = "1" if name.startswith("filter_") else "4"
+    # (also maxmindist: its first film sample of a pixel lies ON the pixel's edge, i / spp with i = 0, and reaches the neighbouring pixel -- across
+    # a tile boundary that is a sum whose order depends on which thread merges its tile first)
+    nthreads = "1" if name.startswith("filter_") or "maxmindist" in name else "4"
     txt = subprocess.run([ref, "--nthreads", nthreads, "--outfile", out, scene_path], capture_output=True, text=True, check=True).stdout
     g = lambda pat: int(re.search(pat, txt).group(1)) if re.search(pat, txt) else 0  # a counter that stayed 0 is not printed (stats.cpp)
     stats = {"camera_rays": g(r"Camera rays traced\s+(\d+)"),

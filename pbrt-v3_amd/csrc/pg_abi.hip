@@ -53,6 +53,7 @@ struct PgScene {
     DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, textures, textured, images, texels, ewaLut, envTables, alphas, alphaTex, triAlpha, triN, triS, uv, materials, lights, distTable, perms, permSums, primes, media, triMediumIn, triMediumOut, sobolMatrices, vdcSobol, vdcSobolInv, noisePerm;
     // work buffers (sized on first render, reused)
     int capacity = 0;
+    DeviceBuffer tsOverflow;  // tsBatched: the flag a draw beyond the sample arrays raises
     DeviceBuffer shadeOrder, primClass, volPre;  // k_shade_order: the order buffer of the main queue, the primitives' material classes, volpath's pre-drawn medium samples
     bool volOrder = false;  // volpath launches shade medium vertices and surface vertices in separate waves (scenes with homogeneous media only)
     DeviceBuffer qo[4], qd[4], counts, hitsMain, hitInst, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
@@ -919,8 +920,20 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
     const bool vol = rd->integrator == 1;
     if (rd->camera_medium < -1 || rd->camera_medium >= s->nMedia) return setError(PG_ERR_INVALID, "pg_render: camera_medium %d out of range", rd->camera_medium);
     if (rd->sampler < PG_SAMPLER_HALTON || rd->sampler > PG_SAMPLER_MAXMINDIST) return setError(PG_ERR_INVALID, "pg_render: sampler %d (PgSamplerKind 0 .. 5)", rd->sampler);
-    const bool tileSerial = rd->sampler >= PG_SAMPLER_RANDOM;
-    if (tileSerial) {
+    // The PixelSamplers (stratified, 02sequence, maxmindist) fall back to their tile's RNG stream only for draws beyond their
+    // "dimensions" (sampler.cpp:108-134).  PathIntegrator::Li draws at most 1 + 2 maxdepth one-dimensional numbers (time; light choice and
+    // roulette per vertex) and 2 + 3 maxdepth two-dimensional ones (film, lens; uLight, uScattering, the next direction per vertex):
+    // with that many sampled dimensions StartPixel alone consumes the stream, every pixel's arrays can be generated ahead, and the
+    // paths run as one wavefront like the GlobalSamplers' (tsBatched).  Not for volpath (a ray through material-less surfaces samples
+    // its medium an unbounded number of times), materials with a BSSRDF, or sparse light tables (their deferred vertices re-draw).
+    bool tsBatched = false;
+    if (rd->sampler > PG_SAMPLER_RANDOM && rd->integrator == 0 && s->d.nBssrdfs == 0 && !s->d.sparseLights && rd->sampler_dims <= 63 &&
+        rd->sampler_dims >= 2 + 3 * (long long)rd->max_depth && !(getenv("PG_TS_BATCHED") && atoi(getenv("PG_TS_BATCHED")) == 0)) {
+        const size_t arrayBytes = (size_t)tileCount(rd) * 256 * (size_t)rd->sampler_dims * (size_t)rd->spp * 12;
+        tsBatched = arrayBytes <= ((size_t)48 << 30);
+    }
+    const bool tileSerial = rd->sampler >= PG_SAMPLER_RANDOM && !tsBatched;
+    if (rd->sampler >= PG_SAMPLER_RANDOM) {
         if (rd->sampler != PG_SAMPLER_RANDOM && (rd->sampler_dims < 0 || rd->sampler_dims > 4096)) return setError(PG_ERR_INVALID, "pg_render: sampler_dims %d", rd->sampler_dims);
         if (rd->sampler == PG_SAMPLER_STRATIFIED && (rd->strat_samples[0] < 1 || rd->strat_samples[1] < 1 || rd->strat_samples[0] * rd->strat_samples[1] != rd->spp))
             return setError(PG_ERR_INVALID, "pg_render: stratified sampler %d x %d samples, spp %d", rd->strat_samples[0], rd->strat_samples[1], rd->spp);
@@ -942,6 +955,7 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
     RenderParams rp;
     memset(&rp, 0, sizeof(rp));
     rp.rd = *rd;
+    s->d.tsBatched = 0; s->d.tsOverflow = nullptr;  // (a call that failed half-way may have left them set)
     rp.nTilesX = (rd->sample_bounds[2] - rd->sample_bounds[0] + 15) / 16;
     rp.nTilesY = (rd->sample_bounds[3] - rd->sample_bounds[1] + 15) / 16;
 
@@ -1385,6 +1399,19 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
         if (rd->filter_general) launch_film_general(rp, ps, dFilm, stream);
         else launch_film(rp, ps, dFilm, dStrays, maxStrays, dNStrays, stream);
     };
+    if (tsBatched) {  // every pixel's sample arrays, one lane per tile (the tile's stream in the reference's pixel order)
+        const size_t nArr = (size_t)nLocalTiles * 256 * (size_t)rd->sampler_dims * (size_t)rd->spp;
+        HIP_TRY(s->tsState.alloc(sizeof(TileSamplerState) * (size_t)nLocalTiles));
+        HIP_TRY(s->ts1.alloc(sizeof(float) * (nArr + 1)));
+        HIP_TRY(s->ts2.alloc(sizeof(float) * 2 * (nArr + 1)));
+        HIP_TRY(s->tsOverflow.alloc(sizeof(int)));
+        HIP_TRY(hipMemsetAsync(s->tsOverflow.p, 0, sizeof(int), stream));
+        s->d.ts = (TileSamplerState *)s->tsState.p; s->d.ts1 = (float *)s->ts1.p; s->d.ts2 = (float *)s->ts2.p;
+        s->d.tsDims = rd->sampler_dims; s->d.tsSpp = rd->spp; s->d.tsBatched = 1; s->d.tsOverflow = (int *)s->tsOverflow.p;
+        rp.tileLocal0 = 0; rp.nTilesBatch = nLocalTiles; rp.s0 = 0; rp.sCount = 1; rp.capacity = nLocalTiles;
+        launch_ts_init(s->d, rp, stream);
+        launch_ts_start_tile(s->d, rp, stream);
+    }
     if (!tileSerial) {
         for (int tile0 = 0; tile0 < nLocalTiles; tile0 += tilesPerBatch)
             for (int s0 = 0; s0 < rd->spp; s0 += sPerBatch) {
@@ -1419,6 +1446,13 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
             }
         s->d.ts = nullptr; s->d.ts1 = s->d.ts2 = nullptr;
         if (err) return err;
+    }
+    if (tsBatched) {
+        int over = 0;
+        HIP_TRY(hipMemcpyAsync(&over, s->tsOverflow.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        s->d.ts = nullptr; s->d.ts1 = s->d.ts2 = nullptr; s->d.tsBatched = 0; s->d.tsOverflow = nullptr;
+        if (over) return setError(PG_ERR_DEVICE, "pg_render: a path drew beyond the %d sampled dimensions of the batched pixel sampler (internal error)", rd->sampler_dims);
     }
     HIP_TRY(hipEventRecord(evStop, stream));
     HIP_TRY(hipGetLastError());

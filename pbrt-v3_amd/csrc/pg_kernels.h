@@ -130,6 +130,11 @@ struct DScene {
     TileSamplerState *ts;
     float *ts1, *ts2;
     int tsDims, tsSpp;
+    // tsBatched: the PixelSamplers when "dimensions" covers every draw a path can make -- no path touches its tile's stream after
+    // StartPixel, so the sample arrays of ALL pixels are generated ahead (ts1 / ts2 indexed by pixel = local tile * 256 + pixel in tile
+    // instead of by tile) and the paths run as an ordinary wavefront; tsOverflow: set by a draw beyond the arrays (must never happen)
+    int tsBatched;
+    int *tsOverflow;
     const uint32_t *cmaxmin;  // CMaxMinDist [17][32]
 };
 
@@ -251,6 +256,7 @@ void launch_generate(const DScene &sc, const RenderParams &rp, PathState st, Ray
 // tile-serial samplers: seed the tiles' streams; StartPixel for pixel (lx, ly) of every tile; the camera sample + ray of sample
 // `sampleIndex` of that pixel; FilmTile::AddSample of the finished paths
 void launch_ts_init(const DScene &sc, const RenderParams &rp, hipStream_t s);
+void launch_ts_start_tile(const DScene &sc, const RenderParams &rp, hipStream_t s);  // tsBatched: StartPixel for every pixel of every tile, in the tile's order
 void launch_ts_start_pixel(const DScene &sc, const RenderParams &rp, int lx, int ly, hipStream_t s);
 void launch_ts_generate(const DScene &sc, const RenderParams &rp, PathState st, RayQueue q, int sampleIndex, hipStream_t s);
 void launch_ts_film(const DScene &sc, const RenderParams &rp, PathState st, PgFilmPixel *film, PgStraySample *strays, int maxStrays, int *nStrays,

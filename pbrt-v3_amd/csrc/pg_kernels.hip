@@ -264,6 +264,20 @@ PG_DEV void ts_get2d(const DScene &sc, int kind, int tile, float &a, float &b) {
     } else if (kind == PG_SAMPLER_RANDOM) { a = rng_float(t); b = rng_float(t); }  // random.cpp:50-54: braced list, left to right
     else { b = rng_float(t); a = rng_float(t); }  // `Point2f(rng.UniformFloat(), rng.UniformFloat())` as the reference build (g++) evaluates it: y first
 }
+// tsBatched (DScene): PixelSampler::Get1D / Get2D of sample `sample` of pixel `pixel`; dim = current2DDimension << 6 | current1DDimension
+PG_DEV float tsb_get1d(const DScene &sc, int pixel, int sample, int &dim) {
+    const int c = dim & 63;
+    if (c >= sc.tsDims) { *sc.tsOverflow = 1; return 0.5f; }
+    dim += 1;
+    return sc.ts1[((size_t)pixel * sc.tsDims + c) * sc.tsSpp + sample];
+}
+PG_DEV void tsb_get2d(const DScene &sc, int pixel, int sample, int &dim, float &a, float &b) {
+    const int c = dim >> 6;
+    if (c >= sc.tsDims) { *sc.tsOverflow = 1; a = b = 0.5f; return; }
+    dim += 64;
+    const float *p = sc.ts2 + (((size_t)pixel * sc.tsDims + c) * sc.tsSpp + sample) * 2;
+    a = p[0]; b = p[1];
+}
 PG_DEV void ts_shuffle(float *samp, int count, int width, TileSamplerState &t) {  // Shuffle, sampling.h:151-157
     for (int i = 0; i < count; ++i) {
         const int other = i + (int)rng_u32b(t, (uint32_t)(count - i));
@@ -315,17 +329,9 @@ __global__ void k_ts_init(DScene sc, RenderParams rp) {
 }
 // <Sampler>::StartPixel for pixel (lx, ly) of every tile: the pixel's sample arrays from the tile's stream -- also for pixels
 // outside the integrator's pixel bounds, which are then skipped (integrator.cpp:264-273)
-__global__ void k_ts_start_pixel(DScene sc, RenderParams rp, int lx, int ly) {
-    const int local = blockIdx.x * blockDim.x + threadIdx.x;
-    if (local >= rp.nTilesBatch) return;
-    TileSamplerState t = sc.ts[local];
-    int tile, px, py;
-    const bool exists = ts_tile_pixel(rp, local, lx, ly, tile, px, py);
-    t.active = 0;
-    if (exists) {
-        const PgRenderDesc &rd = rp.rd;
+PG_DEV void ts_start_pixel(const DScene &sc, const PgRenderDesc &rd, TileSamplerState &t, float *s1, float *s2) {
+    {
         const int n = sc.tsSpp, nd = sc.tsDims;
-        float *s1 = sc.ts1 + (size_t)local * nd * n, *s2 = sc.ts2 + (size_t)local * nd * n * 2;
         if (rd.sampler == PG_SAMPLER_STRATIFIED) {  // stratified.cpp:43-70, sampling.cpp:42-60
             const int nx = rd.strat_samples[0], ny = rd.strat_samples[1];
             for (int i = 0; i < nd; ++i) {
@@ -364,10 +370,42 @@ __global__ void k_ts_start_pixel(DScene sc, RenderParams rp, int lx, int ly) {
             for (int i = 0; i < nd; ++i) ts_van_der_corput(n, s1 + (size_t)i * n, t);
             for (int i = 1; i < nd; ++i) ts_sobol2d(n, s2 + (size_t)i * n * 2, t);
         }  // RandomSampler::StartPixel only fills requested sample arrays: none
+    }
+}
+__global__ void k_ts_start_pixel(DScene sc, RenderParams rp, int lx, int ly) {
+    const int local = blockIdx.x * blockDim.x + threadIdx.x;
+    if (local >= rp.nTilesBatch) return;
+    TileSamplerState t = sc.ts[local];
+    int tile, px, py;
+    const bool exists = ts_tile_pixel(rp, local, lx, ly, tile, px, py);
+    t.active = 0;
+    if (exists) {
+        const PgRenderDesc &rd = rp.rd;
+        const int n = sc.tsSpp, nd = sc.tsDims;
+        ts_start_pixel(sc, rd, t, sc.ts1 + (size_t)local * nd * n, sc.ts2 + (size_t)local * nd * n * 2);
         t.px = px; t.py = py;
         t.active = px >= rd.pixel_bounds[0] && px < rd.pixel_bounds[2] && py >= rd.pixel_bounds[1] && py < rd.pixel_bounds[3];
     }
     sc.ts[local] = t;
+}
+// tsBatched: <Sampler>::StartPixel for ALL pixels of every tile, one lane per tile walking its pixels in the reference's order
+// (integrator.cpp:264-273; the stream is consumed by StartPixel alone) -- pixel p of local tile l fills the arrays of pixel l * 256 + p
+__global__ void k_ts_start_tile(DScene sc, RenderParams rp) {
+    const int local = blockIdx.x * blockDim.x + threadIdx.x;
+    if (local >= rp.nTilesBatch) return;
+    TileSamplerState t = sc.ts[local];
+    const size_t n = (size_t)sc.tsSpp * sc.tsDims;
+    for (int ly = 0; ly < 16; ++ly)
+        for (int lx = 0; lx < 16; ++lx) {
+            int tile, px, py;
+            if (!ts_tile_pixel(rp, local, lx, ly, tile, px, py)) continue;
+            const size_t pixel = (size_t)local * 256 + ly * 16 + lx;
+            ts_start_pixel(sc, rp.rd, t, sc.ts1 + pixel * n, sc.ts2 + pixel * n * 2);
+        }
+    sc.ts[local] = t;
+}
+void launch_ts_start_tile(const DScene &sc, const RenderParams &rp, hipStream_t s) {
+    hipLaunchKernelGGL(k_ts_start_tile, dim3((rp.nTilesBatch + 63) / 64), dim3(64), 0, s, sc, rp);
 }
 void launch_ts_init(const DScene &sc, const RenderParams &rp, hipStream_t s) {
     hipLaunchKernelGGL(k_ts_init, dim3((rp.nTilesBatch + 63) / 64), dim3(64), 0, s, sc, rp);
@@ -532,9 +570,17 @@ __global__ __launch_bounds__(PG_BLOCK) void k_generate(DScene sc, RenderParams r
     float tMax = PG_INF;
     if (valid) {
         const PgRenderDesc &rd = rp.rd;
-        uint64_t index = sampler_index(sc, rd, px, py, (uint64_t)sn);
+        uint64_t index = sc.tsBatched ? 0 : sampler_index(sc, rd, px, py, (uint64_t)sn);
         // GetCameraSample, sampler.cpp:46-52: dims 0,1 film; 2 time; 3,4 lens
-        float u0 = halton_sample(sc, rd, index, 0), u1 = halton_sample(sc, rd, index, 1);
+        float u0 = 0, u1 = 0, tsl0 = 0, tsl1 = 0;
+        int tsDim = 0;
+        if (sc.tsBatched) {  // a PixelSampler's arrays: film 2D, time 1D, lens 2D; the path's state names its pixel and sample
+            const int pixel = (rp.tileLocal0 + (slot >> 8) / rp.sCount) * 256 + (slot & 255);
+            index = (uint64_t)(uint32_t)pixel | ((uint64_t)(uint32_t)sn << 32);
+            tsb_get2d(sc, pixel, sn, tsDim, u0, u1);
+            (void)tsb_get1d(sc, pixel, sn, tsDim);
+            tsb_get2d(sc, pixel, sn, tsDim, tsl0, tsl1);
+        } else { u0 = halton_sample(sc, rd, index, 0); u1 = halton_sample(sc, rd, index, 1); }
         if (rd.sampler == 1) {  // SobolSampler::SampleDimension, sobol.cpp:53-56
             u0 = u0 * rd.sobol_resolution + rd.sample_bounds[0];
             u0 = u0 - px;
@@ -545,11 +591,12 @@ __global__ __launch_bounds__(PG_BLOCK) void k_generate(DScene sc, RenderParams r
         }
         float pFilmX = (float)px + u0, pFilmY = (float)py + u1;
         float l0 = 0, l1 = 0;
-        if (rd.lens_radius > 0) { l0 = halton_sample(sc, rd, index, 3); l1 = halton_sample(sc, rd, index, 4); }
+        if (sc.tsBatched) { l0 = tsl0; l1 = tsl1; }
+        else if (rd.lens_radius > 0) { l0 = halton_sample(sc, rd, index, 3); l1 = halton_sample(sc, rd, index, 4); }
         camera_ray(rd, pFilmX, pFilmY, l0, l1, o, d, tMax);
         st.L[slot] = make_float4(0, 0, 0, pFilmX);
         st.beta[slot] = make_float4(1, 1, 1, pFilmY);
-        st.meta[slot] = make_int4((int)(uint32_t)index, (int)(uint32_t)(index >> 32), __float_as_int(1.f), (5 << 20) | PG_META_HASDIFF);
+        st.meta[slot] = make_int4((int)(uint32_t)index, (int)(uint32_t)(index >> 32), __float_as_int(1.f), ((sc.tsBatched ? tsDim : 5) << 20) | PG_META_HASDIFF);
     } else if (slot < rp.capacity) {
         st.L[slot] = make_float4(0, 0, 0, 0);
         st.meta[slot] = make_int4(0, 0, 0, PG_META_DONE | 0x40000);  // 0x40000: slot holds no sample
@@ -1880,7 +1927,8 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
         int dim = (int)((uint32_t)meta.w >> 20);
         // Sampler::Get1D / Get2D in the order the reference calls them: a GlobalSampler (halton, sobol) is indexed by
         // (sample index, dimension); the tile-serial samplers advance their tile's state (slot = tile, one path per tile)
-        const bool tileSerial = rd.sampler >= PG_SAMPLER_RANDOM;
+        const bool tileSerial = rd.sampler >= PG_SAMPLER_RANDOM && !sc.tsBatched;
+        const bool pixelArrays = sc.tsBatched != 0;  // a PixelSampler's arrays for this path's pixel: index = (pixel, sample), dim = the two dimension counters
         if (tileSerial) { tsState0 = sc.ts[slot].state; tsCur1D0 = sc.ts[slot].cur1D; tsCur2D0 = sc.ts[slot].cur2D; }  // restored if this vertex is deferred (sparse light tables)
         // Halton: the PG_NPRE dimensions a surface vertex usually draws (light choice, uLight, uScattering, the
         // next direction) are computed together before the first draw (halton_batch); preDim0 < 0: not computed
@@ -1893,9 +1941,10 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
                 return k == 0 ? pre[0] : (k == 1 ? pre[1] : (k == 2 ? pre[2] : (k == 3 ? pre[3] : (k == 4 ? pre[4] : (k == 5 ? pre[5] : pre[6])))));
             return halton_sample(sc, rd, index, d);
         };
-        auto draw1 = [&]() -> float { return tileSerial ? ts_get1d(sc, slot) : sample_dim(dim++); };
+        auto draw1 = [&]() -> float { return tileSerial ? ts_get1d(sc, slot) : (pixelArrays ? tsb_get1d(sc, meta.x, meta.y, dim) : sample_dim(dim++)); };
         auto draw2 = [&](float &a, float &b) {
             if (tileSerial) ts_get2d(sc, rd.sampler, slot, a, b);
+            else if (pixelArrays) tsb_get2d(sc, meta.x, meta.y, dim, a, b);
             else { a = sample_dim(dim); b = sample_dim(dim + 1); dim += 2; }
         };
         float etaScale = __int_as_float(meta.z);  // path.cpp:79
@@ -2000,7 +2049,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
                 handled = true;
                 {   // the dimensions of this vertex's draws side by side (as at a surface vertex, below)
                     const int dimU = __builtin_amdgcn_readfirstlane(dim);
-                    const bool can = !tileSerial && rd.sampler == 0 && (index >> 32) == 0 && dim >= 2;
+                    const bool can = !tileSerial && !pixelArrays && rd.sampler == 0 && (index >> 32) == 0 && dim >= 2;
                     if (__ballot(!can || dim != dimU) == 0) { halton_batch<PG_NPRE>(sc, (uint32_t)index, dimU, pre); preDim0 = dimU; }
                 }
                 const float g = sc.media[med - 1].g;
@@ -2114,7 +2163,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
                 {
                     // every lane here draws at least the next direction; the batch needs one dimension for the whole wave
                     const int dimU = __builtin_amdgcn_readfirstlane(dim);
-                    const bool can = !tileSerial && rd.sampler == 0 && (index >> 32) == 0 && dim >= 2;
+                    const bool can = !tileSerial && !pixelArrays && rd.sampler == 0 && (index >> 32) == 0 && dim >= 2;
                     if (__ballot(!can || dim != dimU) == 0) { halton_batch<PG_NPRE>(sc, (uint32_t)index, dimU, pre); preDim0 = dimU; }
                 }
                 Bsdf bsdf;
@@ -2143,6 +2192,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
                             const V3 rayO = mk(o4.x, o4.y, o4.z);
                             float l0 = 0, l1 = 0;
                             if (tileSerial) { l0 = sc.ts[slot].lens0; l1 = sc.ts[slot].lens1; }  // the camera sample's pLens, kept by k_ts_generate
+                            else if (pixelArrays) { int d2 = 1 << 6; tsb_get2d(sc, meta.x, meta.y, d2, l0, l1); }  // (its second 2D dimension)
                             else if (rd.lens_radius > 0) { l0 = halton_sample(sc, rd, index, 3); l1 = halton_sample(sc, rd, index, 4); }
                             V3 rxO, rxD, ryO, ryD;
                             camera_differentials(rd, L4.w, B4.w, l0, l1, rayO, rayD, rxO, rxD, ryO, ryD);

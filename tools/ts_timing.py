@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Frame time of the tile-serial samplers (one path per tile in flight) next to the Halton sampler on the same scene and
-sample count: python tools/ts_timing.py [xres yres spp]  ->  one JSON line.  GPU box."""
+"""Frame time of the tile-serial samplers (one path per tile in flight; all pixels at once when "dimensions" covers every draw of a path)
+next to the Halton sampler on the same scene and sample count: python tools/ts_timing.py [xres yres spp]  ->  one JSON line.  GPU box."""
 import json
 import os
 import sys
@@ -23,7 +23,11 @@ def main():
         base = open(path).read()
         for name, spec in (("halton", f'"halton" "integer pixelsamples" [ {spp} ]'), ("random", f'"random" "integer pixelsamples" [ {spp} ]'),
                            ("stratified", f'"stratified" "integer xsamples" [ 4 ] "integer ysamples" [ {spp // 4} ]'),
-                           ("02sequence", f'"02sequence" "integer pixelsamples" [ {spp} ]'), ("maxmindist", f'"maxmindist" "integer pixelsamples" [ {spp} ]')):
+                           ("02sequence", f'"02sequence" "integer pixelsamples" [ {spp} ]'), ("maxmindist", f'"maxmindist" "integer pixelsamples" [ {spp} ]'),
+                           # "dimensions" covering every draw of a maxdepth-5 path (2 + 3 * 5): the arrays of all pixels are generated ahead, one wavefront
+                           ("stratified, dimensions 17", f'"stratified" "integer xsamples" [ 4 ] "integer ysamples" [ {spp // 4} ] "integer dimensions" [ 17 ]'),
+                           ("02sequence, dimensions 17", f'"02sequence" "integer pixelsamples" [ {spp} ] "integer dimensions" [ 17 ]'),
+                           ("maxmindist, dimensions 17", f'"maxmindist" "integer pixelsamples" [ {spp} ] "integer dimensions" [ 17 ]')):
             open(path, "w").write(base.replace(f'Sampler "halton" "integer pixelsamples" [ {spp} ]', "Sampler " + spec))
             scene = pkg.HostScene(path)
             out["triangles"] = int(scene.desc.n_tris)
