@@ -1410,6 +1410,7 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
         s->d.tsDims = rd->sampler_dims; s->d.tsSpp = rd->spp; s->d.tsBatched = 1; s->d.tsOverflow = (int *)s->tsOverflow.p;
         rp.tileLocal0 = 0; rp.nTilesBatch = nLocalTiles; rp.s0 = 0; rp.sCount = 1; rp.capacity = nLocalTiles;
         launch_ts_init(s->d, rp, stream);
+        rp.tsGuessSkew = getenv("PG_TS_GUESS_SKEW") ? atoi(getenv("PG_TS_GUESS_SKEW")) : 0;
         launch_ts_start_tile(s->d, rp, stream);
     }
     if (!tileSerial) {

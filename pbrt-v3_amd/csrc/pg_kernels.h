@@ -37,6 +37,7 @@ struct TileSamplerState {
     int cur1D, cur2D, sampleIndex, active;  // active: the current pixel exists and lies inside the integrator's pixel bounds
     float lens0, lens1;
     int px, py;
+    unsigned int draws, pad;  // RNG::UniformUInt32 calls so far (k_ts_start_tile measures what a StartPixel consumed)
 };
 
 // Device-resident scene.  All pointers are device memory.
@@ -225,6 +226,7 @@ struct RenderParams {
     // volpath, GlobalSamplers: k_shade_order has drawn HomogeneousMedium::Sample's two numbers for every entry whose ray is in a
     // medium -- volPre[entry] = (channel as int bits, sampled distance); the shading kernel takes them from here.  nullptr: it draws.
     const float2 *volPre;
+    int tsGuessSkew;  // tests (PG_TS_GUESS_SKEW): added to k_ts_start_tile's first guess of a StartPixel's consumption, so that its correction passes run
 };
 
 // The shading kernels count Triangle::Intersect calls of light.Pdf_Li (the reference's nTests statistic) into PG_LIGHT_TEST_SHARDS

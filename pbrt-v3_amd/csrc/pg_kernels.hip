@@ -241,10 +241,21 @@ PG_DEV void halton_batch(const DScene &sc, uint32_t a0, int dim0, float *out) {
 // ---- the samplers that draw from one RNG stream per tile (RandomSampler; the PixelSamplers, sampler.cpp:100-134) ------------
 PG_DEV uint32_t rng_u32(TileSamplerState &t) {  // RNG::UniformUInt32, rng.h:137-143
     const unsigned long long oldstate = t.state;
+    ++t.draws;
     t.state = oldstate * 0x5851f42d4c957f2dULL + t.inc;
     const uint32_t xorshifted = (uint32_t)(((oldstate >> 18u) ^ oldstate) >> 27u);
     const uint32_t rot = (uint32_t)(oldstate >> 59u);
     return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+}
+// the state after `delta` more UniformUInt32 calls (each is one step of the 64-bit LCG): O(log delta), as PCG's advance()
+PG_DEV void rng_advance(TileSamplerState &t, unsigned long long delta) {
+    unsigned long long accMult = 1, accPlus = 0, curMult = 0x5851f42d4c957f2dULL, curPlus = t.inc;
+    for (; delta > 0; delta >>= 1) {
+        if (delta & 1) { accMult *= curMult; accPlus = accPlus * curMult + curPlus; }
+        curPlus = (curMult + 1) * curPlus;
+        curMult *= curMult;
+    }
+    t.state = accMult * t.state + accPlus;
 }
 PG_DEV uint32_t rng_u32b(TileSamplerState &t, uint32_t b) {  // rng.h:68-74
     const uint32_t threshold = (~b + 1u) % b;
@@ -324,7 +335,7 @@ __global__ void k_ts_init(DScene sc, RenderParams rp) {
     rng_u32(t);
     t.state += 0x853c49e6748fea9bULL;
     rng_u32(t);
-    t.cur1D = t.cur2D = t.sampleIndex = t.active = 0; t.lens0 = t.lens1 = 0; t.px = t.py = 0;
+    t.cur1D = t.cur2D = t.sampleIndex = t.active = 0; t.lens0 = t.lens1 = 0; t.px = t.py = 0; t.draws = t.pad = 0;
     sc.ts[local] = t;
 }
 // <Sampler>::StartPixel for pixel (lx, ly) of every tile: the pixel's sample arrays from the tile's stream -- also for pixels
@@ -388,24 +399,63 @@ __global__ void k_ts_start_pixel(DScene sc, RenderParams rp, int lx, int ly) {
     }
     sc.ts[local] = t;
 }
-// tsBatched: <Sampler>::StartPixel for ALL pixels of every tile, one lane per tile walking its pixels in the reference's order
-// (integrator.cpp:264-273; the stream is consumed by StartPixel alone) -- pixel p of local tile l fills the arrays of pixel l * 256 + p
-__global__ void k_ts_start_tile(DScene sc, RenderParams rp) {
-    const int local = blockIdx.x * blockDim.x + threadIdx.x;
-    if (local >= rp.nTilesBatch) return;
-    TileSamplerState t = sc.ts[local];
-    const size_t n = (size_t)sc.tsSpp * sc.tsDims;
-    for (int ly = 0; ly < 16; ++ly)
-        for (int lx = 0; lx < 16; ++lx) {
-            int tile, px, py;
-            if (!ts_tile_pixel(rp, local, lx, ly, tile, px, py)) continue;
-            const size_t pixel = (size_t)local * 256 + ly * 16 + lx;
-            ts_start_pixel(sc, rp.rd, t, sc.ts1 + pixel * n, sc.ts2 + pixel * n * 2);
+// tsBatched: <Sampler>::StartPixel for ALL pixels of every tile (integrator.cpp:264-273; the tile's stream is consumed by StartPixel
+// alone, pixel after pixel).  One block per tile, one thread per pixel: a StartPixel consumes a fixed count of numbers unless one of
+// RNG::UniformUInt32(b)'s rejection loops repeats (rng.h:68-74: probability < b / 2^32 per call), so thread p starts from the tile's
+// state advanced by (pixels before it) x (that count), generates its pixel's arrays, and reports what it really consumed; a prefix
+// sum over the pixels gives the true starting points, and the pixels whose starting point was wrong run again -- until none is
+// (one pass nearly always; a pass per rejection otherwise; the result is the sequential one whatever the first guess was).
+__global__ __launch_bounds__(256) void k_ts_start_tile(DScene sc, RenderParams rp) {
+    const int local = blockIdx.x, p = threadIdx.x;
+    __shared__ unsigned int s_cnt[256];
+    __shared__ unsigned long long s_start[256];
+    __shared__ unsigned long long s_total;
+    __shared__ int s_dirty;
+    int tile, px, py;
+    const bool exists = ts_tile_pixel(rp, local, p & 15, p >> 4, tile, px, py);
+    const TileSamplerState t0 = sc.ts[local];
+    const PgRenderDesc &rd = rp.rd;
+    const unsigned long long n = (unsigned long long)sc.tsSpp, nd = (unsigned long long)sc.tsDims;
+    // numbers one StartPixel takes when no rejection loop repeats (a first guess only)
+    unsigned long long nominal = 0;
+    if (rd.sampler == PG_SAMPLER_STRATIFIED) nominal = nd * ((rd.strat_jitter ? n : 0) + n) + nd * ((rd.strat_jitter ? 2 * n : 0) + n);
+    else if (rd.sampler == PG_SAMPLER_ZEROTWO) nominal = nd * (2 * n + 1) + nd * (2 * n + 2);
+    else if (rd.sampler == PG_SAMPLER_MAXMINDIST) nominal = n + nd * (2 * n + 1) + (nd - 1) * (2 * n + 2);
+    nominal += (unsigned long long)(long long)rp.tsGuessSkew;
+    const int x0 = rd.sample_bounds[0] + (tile % rp.nTilesX) * 16;
+    const int wE = rd.sample_bounds[2] - x0 < 16 ? rd.sample_bounds[2] - x0 : 16;  // the tile's existing pixels: wE columns
+    unsigned long long start = exists ? (unsigned long long)((p >> 4) * wE + (p & 15)) * nominal : 0;
+    const size_t pixel = (size_t)local * 256 + p, len = (size_t)n * nd;
+    bool dirty = exists;
+    unsigned int cnt = 0;
+    for (int pass = 0; pass < 300; ++pass) {
+        if (dirty) {
+            TileSamplerState t = t0;
+            rng_advance(t, start);
+            t.draws = 0;
+            ts_start_pixel(sc, rd, t, sc.ts1 + pixel * len, sc.ts2 + pixel * len * 2);
+            cnt = t.draws;
         }
-    sc.ts[local] = t;
+        s_cnt[p] = exists ? cnt : 0;
+        if (p == 0) s_dirty = 0;
+        __syncthreads();
+        if (p == 0) {
+            unsigned long long acc = 0;
+            for (int k = 0; k < 256; ++k) { s_start[k] = acc; acc += s_cnt[k]; }
+            s_total = acc;
+        }
+        __syncthreads();
+        dirty = exists && s_start[p] != start;
+        start = s_start[p];
+        if (dirty) s_dirty = 1;
+        __syncthreads();
+        if (!s_dirty) break;
+        __syncthreads();
+    }
+    if (p == 0) { TileSamplerState t = t0; rng_advance(t, s_total); sc.ts[local] = t; }
 }
 void launch_ts_start_tile(const DScene &sc, const RenderParams &rp, hipStream_t s) {
-    hipLaunchKernelGGL(k_ts_start_tile, dim3((rp.nTilesBatch + 63) / 64), dim3(64), 0, s, sc, rp);
+    hipLaunchKernelGGL(k_ts_start_tile, dim3(rp.nTilesBatch), dim3(256), 0, s, sc, rp);
 }
 void launch_ts_init(const DScene &sc, const RenderParams &rp, hipStream_t s) {
     hipLaunchKernelGGL(k_ts_init, dim3((rp.nTilesBatch + 63) / 64), dim3(64), 0, s, sc, rp);

@@ -56,3 +56,15 @@ def test_one_dimension_short_takes_the_serial_form(gpu):
     finally:
         os.chdir(old)
     assert launches[11] <= 16 < launches[10]
+
+
+@pytest.mark.parametrize("skew", [1, -3])
+def test_wrong_first_guess_of_the_stream_positions_is_corrected(gpu, monkeypatch, skew):
+    """k_ts_start_tile starts pixel p of a tile at (pixels before it) x (numbers a StartPixel nominally takes) and re-runs the pixels
+    whose true position -- the prefix sum of what the pixels before them really took -- differs (a repeated rejection loop of
+    RNG::UniformUInt32(b) shifts everything behind it).  A deliberately wrong nominal count makes every pixel but the first re-run."""
+    scene = gpu.HostScene(os.path.join(GOLD, "filter_02sequence_dims.pbrt"))
+    fa, sa, ca = render(gpu, scene)
+    monkeypatch.setenv("PG_TS_GUESS_SKEW", str(skew))
+    fb, sb, cb = render(gpu, scene)
+    assert np.array_equal(fa["rgb"], fb["rgb"]) and np.array_equal(fa["weight"], fb["weight"]) and ca["closest_rays"] == cb["closest_rays"]
