@@ -39,7 +39,6 @@ if [ "$MODE" = full ]; then
   cp gpurun_out/fullsize_parity_config*.json $OUT/ 2>/dev/null
   tail -5 $OUT/pytest_slow.log
   find $OUT -name '*counter_collection.csv' -size +4M -delete
-  ( timeout 900 python tools/fullsize_parity.py 4 5 --out=$OUT/fullsize_parity_config4_5.json > $OUT/fullsize_4_5.log 2>&1 ); tail -2 $OUT/fullsize_4_5.log | cut -c1-700
   ( timeout 600 python tools/ts_timing.py 960 540 16 > $OUT/ts_timing.json 2> $OUT/ts_timing.err ); cat $OUT/ts_timing.json
   ( timeout 300 python tools/shard_timing.py > $OUT/shard_timing.json 2> $OUT/shard_timing.err ); cat $OUT/shard_timing.json
 fi

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Frame time of the tile-serial samplers (one path per tile in flight; all pixels at once when "dimensions" covers every draw of a path)
-next to the Halton sampler on the same scene and sample count: python tools/ts_timing.py [xres yres spp]  ->  one JSON line.  GPU box."""
+next to the Halton sampler on the same scene and sample count: python tools/ts_timing.py [xres yres spp [fast]]  ->  one JSON line.  GPU box."""
 import json
 import os
 import sys
@@ -15,6 +15,7 @@ from __graft_entry__ import load_package  # noqa: E402
 
 def main():
     xres, yres, spp = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (960, 540, 16)
+    only_fast = len(sys.argv) >= 5 and sys.argv[4] == "fast"  # halton and the "dimensions 17" cases only (the serial forms take ~13 s each at 960x540 @ 16)
     pkg = load_package()
     out = {"frame": f"{xres}x{yres}", "spp": spp, "triangles": None, "samplers": {}}
     with tempfile.TemporaryDirectory() as d:
@@ -28,6 +29,7 @@ def main():
                            ("stratified, dimensions 17", f'"stratified" "integer xsamples" [ 4 ] "integer ysamples" [ {spp // 4} ] "integer dimensions" [ 17 ]'),
                            ("02sequence, dimensions 17", f'"02sequence" "integer pixelsamples" [ {spp} ] "integer dimensions" [ 17 ]'),
                            ("maxmindist, dimensions 17", f'"maxmindist" "integer pixelsamples" [ {spp} ] "integer dimensions" [ 17 ]')):
+            if only_fast and name != "halton" and "dimensions" not in name: continue
             open(path, "w").write(base.replace(f'Sampler "halton" "integer pixelsamples" [ {spp} ]', "Sampler " + spec))
             scene = pkg.HostScene(path)
             out["triangles"] = int(scene.desc.n_tris)
