@@ -187,6 +187,39 @@ def random_scene_vol(seed, res=16, spp=4):
     return text.replace("WorldEnd\n", "\n".join(extra) + "\nWorldEnd\n")
 
 
+def random_scene_sss_grid(seed, features="both"):
+    """The volumetric / extended random scenes with two more features mixed in (features = "both", "sss" or "grid"; the device takes one of them per scene): one of the media becomes a GridDensityMedium
+    (random dimensions, densities with empty voxels, box and CTM), and the glass / mirror / plastic / matte materials become
+    subsurface / kdsubsurface materials with random coefficients (smooth and rough, presets, textured Kd)."""
+    rng = np.random.default_rng(77000 + seed)
+    f = lambda a: " ".join(f"{x:.9g}" for x in np.asarray(a, np.float32).ravel())
+    text = random_scene_vol(seed) if seed % 3 else random_scene_ext(seed)
+    if features != "sss" and 'MakeNamedMedium "m1"' in text:
+        line = [l for l in text.splitlines() if l.startswith('MakeNamedMedium "m1"')][0]
+        nx, ny, nz = (int(v) for v in rng.integers(1, 6, size=3))
+        den = rng.random(nx * ny * nz) * (rng.random(nx * ny * nz) > 0.25) * (0.5 + 3 * rng.random())
+        if den.max() == 0: den[0] = 1
+        sa, ss = 0.3 * rng.random(), 0.5 + 3 * rng.random()
+        p0 = rng.normal(size=3) - 1.0
+        grid = ('MakeNamedMedium "m1" "string type" "heterogeneous" "rgb sigma_a" [ %s ] "rgb sigma_s" [ %s ] "float g" [ %.4g ] "integer nx" [ %d ] "integer ny" [ %d ] "integer nz" [ %d ] '
+                '"point p0" [ %s ] "point p1" [ %s ] "float density" [ %s ]' % (f([sa] * 3), f([ss] * 3), 1.4 * rng.random() - 0.7, nx, ny, nz, f(p0), f(p0 + 1 + 2 * rng.random(3)), f(den)))
+        text = text.replace(line, grid, 1)
+    def sss():
+        k = rng.integers(0, 4)
+        rough = ' "float uroughness" [ %.4g ] "float vroughness" [ %.4g ]' % (0.3 * rng.random(), 0.3 * rng.random()) if rng.random() < 0.4 else ""
+        if k == 0: return 'Material "subsurface" "rgb sigma_a" [ %s ] "rgb sigma_s" [ %s ] "float eta" [ %.4g ] "float g" [ %.4g ]%s' % (f(rng.random(3)), f(0.2 + 5 * rng.random(3)), 1.1 + 0.5 * rng.random(), 1.2 * rng.random() - 0.5, rough)
+        if k == 1: return 'Material "kdsubsurface" "rgb Kd" [ %s ] "rgb mfp" [ %s ] "float eta" [ %.4g ]%s' % (f(rng.random(3)), f(0.05 + rng.random(3)), 1.2 + 0.4 * rng.random(), rough)
+        if k == 2: return 'Material "subsurface" "string name" "%s" "float scale" [ %.4g ]%s' % (["Skin1", "Marble", "Ketchup", "Wholemilk"][seed % 4], 0.5 + 20 * rng.random(), rough)
+        return 'Material "kdsubsurface" "rgb Kd" [ %s ] "rgb mfp" [ %s ] "rgb Kr" [ %s ] "float scale" [ %.4g ]' % (f(rng.random(3)), f(0.2 + rng.random(3)), f(rng.random(3)), 0.5 + rng.random())
+    out = []
+    for l in text.splitlines():
+        st = l.strip()
+        if features != "grid" and (st.startswith('Material "glass"') or st.startswith('Material "mirror"') or st.startswith('Material "plastic"') or st.startswith('Material "matte"')) and "texture" not in st and rng.random() < 0.6:
+            l = l[:len(l) - len(l.lstrip())] + sss()
+        out.append(l)
+    return "\n".join(out) + "\n"
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_random_scene_film_matches_oracle(gpu, oracle, seed):
     check_scene(gpu, oracle, random_scene(seed), seed)
@@ -200,6 +233,13 @@ def test_random_extended_scene_film_matches_oracle(gpu, oracle, seed):
 @pytest.mark.parametrize("seed", range(16))
 def test_random_volumetric_scene_film_matches_oracle(gpu, oracle, seed):
     check_scene(gpu, oracle, random_scene_vol(seed), seed)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_sss_or_grid_scene_film_matches_oracle(gpu, oracle, seed):
+    """Subsurface materials (odd seeds) or a GridDensityMedium (even seeds) mixed into the random scenes: BSSRDF probe chains through
+    random soups, ratio tracking through random grids -- against the oracle and, bit for bit, its correctly-rounded build."""
+    check_scene(gpu, oracle, random_scene_sss_grid(seed, "sss" if seed % 2 else "grid"), seed)
 
 
 def check_scene(gpu, oracle, text, seed):
