@@ -53,6 +53,7 @@ struct PgScene {
     DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, textures, textured, images, texels, ewaLut, envTables, alphas, alphaTex, triAlpha, triN, triS, uv, materials, lights, distTable, perms, permSums, primes, media, triMediumIn, triMediumOut, sobolMatrices, vdcSobol, vdcSobolInv, noisePerm;
     // work buffers (sized on first render, reused)
     int capacity = 0;
+    DeviceBuffer sceneCopy;  // DScene::self
     DeviceBuffer tsOverflow;  // tsBatched: the flag a draw beyond the sample arrays raises
     DeviceBuffer shadeOrder, primClass, volPre;  // k_shade_order: the order buffer of the main queue, the primitives' material classes, volpath's pre-drawn medium samples
     bool volOrder = false;  // volpath launches shade medium vertices and surface vertices in separate waves (scenes with homogeneous media only)
@@ -794,6 +795,9 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     HIP_TRY_S(hipMemset(s->cullGuard.p, 0, s->cullGuard.bytes));
     HIP_TRY_S(s->lightTests.alloc(sizeof(unsigned long long) * PG_LIGHT_TEST_SHARDS * PG_LIGHT_TEST_STRIDE));
     HIP_TRY_S(hipMemset(s->lightTests.p, 0, s->lightTests.bytes));
+    HIP_TRY_S(s->sceneCopy.alloc(sizeof(DScene)));
+    d.self = (const DScene *)s->sceneCopy.p;
+    HIP_TRY_S(hipMemcpy(s->sceneCopy.p, &d, sizeof(DScene), hipMemcpyHostToDevice));
     *out = s;
     return PG_OK;
 #undef FAIL

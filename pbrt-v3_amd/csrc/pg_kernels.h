@@ -88,6 +88,11 @@ struct DScene {
     const int *noisePerm;                // NoisePerm (512 entries) of the Perlin-noise textures, or nullptr
     const PgTexturedMaterial *textured;  // materials evaluated per hit (PG_MAT_TEXTURED)
     int hasTextured;
+    // This structure's scene tables once more, in device memory: what the kernels hand to the functions that are CALLED (the texture
+    // and material evaluators, pg_texture.h) -- a reference to a kernel's own by-value DScene would make every lane write the whole
+    // structure to its scratch memory first (688 B per lane per launch: it was most of k_shade<2>'s write traffic).  Only the
+    // tables set by pg_scene_create are valid in it (not hitInst, ts*, which later calls set in the host's copy).
+    const DScene *self;
     const unsigned char *primClass;      // per primitive record: the shading class of its material (k_shade_order), or nullptr
     const PgDensityGrid *grids;          // GridDensityMedium (ABI 23): mediaGrid[m] = index of medium m's grid, -1 = homogeneous
     const int *mediaGrid;

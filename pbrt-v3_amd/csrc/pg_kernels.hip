@@ -2284,12 +2284,12 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
                                 float du = .5f * (fabsf(th.dudx) + fabsf(th.dudy));
                                 if (du == 0) du = .0005f;
                                 ev.p = th.p + is.sdpdu * du; ev.u = th.u + du; ev.v = th.v + 0.f;
-                                const float uDisplace = TexEval<PG_TEX_DEPTH>::f(sc, tmm.bump, ev);
+                                const float uDisplace = TexEval<PG_TEX_DEPTH>::f(*sc.self, tmm.bump, ev);
                                 float dv = .5f * (fabsf(th.dvdx) + fabsf(th.dvdy));
                                 if (dv == 0) dv = .0005f;
                                 ev.p = th.p + is.sdpdv * dv; ev.u = th.u + 0.f; ev.v = th.v + dv;
-                                const float vDisplace = TexEval<PG_TEX_DEPTH>::f(sc, tmm.bump, ev);
-                                const float displace = TexEval<PG_TEX_DEPTH>::f(sc, tmm.bump, th);
+                                const float vDisplace = TexEval<PG_TEX_DEPTH>::f(*sc.self, tmm.bump, ev);
+                                const float displace = TexEval<PG_TEX_DEPTH>::f(*sc.self, tmm.bump, th);
                                 const V3 bdpdu = (is.sdpdu + is.ns * ((uDisplace - displace) / du)) + is.sdndu * displace;
                                 const V3 bdpdv = (is.sdpdv + is.ns * ((vDisplace - displace) / dv)) + is.sdndv * displace;
                                 is.ns = normalize(cross(bdpdu, bdpdv));  // SetShadingGeometry(..., false), interaction.cpp:72-89
@@ -2305,7 +2305,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
                     if constexpr (TEX) {
                         int nl = 0;
                         float etaL = 1;
-                        MatEval<2>::run(sc, tri.material, th, lobeStore, nl, etaL);
+                        MatEval<2>::run(*sc.self, tri.material, th, lobeStore, nl, etaL);
                         lb.lobes = lobeStore; lb.n = nl; lb.eta = etaL;
                     } else { lb.lobes = sc.bxdfs + m.first_bxdf; lb.n = m.n_bxdfs; lb.eta = m.bsdf_eta; }
                     if constexpr (SSS) {  // si->bssrdf = TabulatedBSSRDF(...): subsurface.cpp:87-90, kdsubsurface.cpp:88-93
@@ -2316,7 +2316,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
                             if (bd.textured) {
                                 if (lb.n == 0) sssIdx = -1;  // ComputeScatteringFunctions returned before it set the BSSRDF (R and T both black)
                                 else if constexpr (TEX) {
-                                    const Spec ta = sp_clamp0(TexEval<PG_TEX_DEPTH>::s(sc, bd.a, th)), tb = sp_clamp0(TexEval<PG_TEX_DEPTH>::s(sc, bd.b, th));
+                                    const Spec ta = sp_clamp0(TexEval<PG_TEX_DEPTH>::s(*sc.self, bd.a, th)), tb = sp_clamp0(TexEval<PG_TEX_DEPTH>::s(*sc.self, bd.b, th));
                                     const float a3[3] = {ta.r, ta.g, ta.b}, b3[3] = {tb.r, tb.g, tb.b};
                                     const DBssrdf tbl = bssrdf_bind(bd, sc.bssrdfTables);
                                     for (int c = 0; c < 3; ++c) {

@@ -386,8 +386,8 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                             th.u = hu; th.v = hv;
                             th.dpdx = th.dpdy = mk(0, 0, 0);
                             th.dudx = th.dvdx = th.dudy = th.dvdy = 0;
-                            if (am.has_alpha && TexEval<PG_TEX_DEPTH>::f(sc, am.alpha, th) == 0) hit = false;
-                            if (ANYHIT && hit && am.has_shadow_alpha && TexEval<PG_TEX_DEPTH>::f(sc, am.shadow_alpha, th) == 0) hit = false;
+                            if (am.has_alpha && TexEval<PG_TEX_DEPTH>::f(*sc.self, am.alpha, th) == 0) hit = false;
+                            if (ANYHIT && hit && am.has_shadow_alpha && TexEval<PG_TEX_DEPTH>::f(*sc.self, am.shadow_alpha, th) == 0) hit = false;
                         } else {
                             const DAlphaTex *at = sc.alphaTex + 2 * sc.triAlpha[prim];
                             if (at[0].image != -2 && alpha_lookup(sc, at[0], hu, hv) == 0) hit = false;
