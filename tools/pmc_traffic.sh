@@ -43,6 +43,7 @@ for src in (os.path.join("profiles", "pmc_traffic.json"), dst):
         try: allj["workloads"].update(json.load(open(src)).get("workloads", {}))
         except Exception: pass
 allj["workloads"][j["config"]["workload"]] = res
+allj["round"] = os.path.basename(os.path.dirname(out.rstrip("/"))) or out  # gpurun_out/<round>/traffic_* -> <round>: bench.py quotes it with every replayed value
 json.dump(allj, open(dst, "w"), indent=1)
 print(json.dumps({j["config"]["workload"]: res}, indent=1))
 PY
