@@ -287,7 +287,7 @@ def kernel_rooflines(m, workload):
         except Exception:
             pass
 
-    def one(name, tag, alg_bytes, ms, launches, units, unit_name, gather_pattern):
+    def one(name, tag, alg_bytes, ms, launches, units, unit_name, gather_pattern, bound=bound, peak=peak):
         launches = max(1, launches)
         achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         pk = next((v for k, v in pmc_kernels.items() if k.startswith(tag)), None)  # tag: a tuple of accepted name prefixes
@@ -315,7 +315,9 @@ def kernel_rooflines(m, workload):
         one(("k_trace<1> (any hit, reference order" if os.environ.get("PG_ANYHIT_ORDER") == "reference" else "k_trace<2> (any hit, free order") + ": BVHAccel::IntersectP + Triangle::IntersectP)", ("void k_trace<2,", "void k_trace<1,", "void k_trace<true"),
             32 * cn["shadow_node_visits"] + 48 * cn["shadow_tri_tests"] + 36 * n_shadow, cn["shadow_ms"], cn["shadow_launches"], n_shadow, "ray", True),
         one("k_shade (PathIntegrator::Li loop body + EstimateDirect set-up)", "void k_shade",
-            224 * n_items + 32 * (n_next + n_shadow + n_mis) + 16 * n_mis, cn["shade_ms"], cn["shade_launches"], n_items, "vertex", False),
+            224 * n_items + 32 * (n_next + n_shadow + n_mis) + 16 * n_mis, cn["shade_ms"], cn["shade_launches"], n_items, "vertex", False,
+            # its streams are the queues and the path state (hundreds of bytes per vertex of a 10^8-vertex launch), not the scene: HBM at any scene size
+            bound="hbm", peak=HBM_PEAK_GBS),
     ]
     kernels = [k for k in kernels if k["total_ms"] > 0]
     kernels.sort(key=lambda k: -k["total_ms"])  # dominant = the most time, each kernel timed alone

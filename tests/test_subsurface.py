@@ -122,7 +122,7 @@ def test_reference_side_binding_flattens_the_reference_bssrdf(pkg, name, tmp_pat
 
 @pytest.mark.parametrize("seed", [4, 7, 11])
 def test_random_scenes_live_when_reference_present(pkg, oracle, seed, tmp_path):
-    """Random scenes mixing both CPU-only features into the volumetric fuzz scenes (tools/fuzz_oracle_vs_reference.py: a random
+    """Random scenes mixing both CPU-only features into the volumetric fuzz scenes (tests/test_gpu_fuzz.py::random_scene_sss_grid, swept by tools/fuzz_oracle_vs_reference.py: a random
     GridDensityMedium, random subsurface / kdsubsurface materials on degenerate triangle soups and quadrics), rendered now by the
     unmodified reference and by front end + oracle.  Seed 4 has probe segments that collect more than 256 hits on their own
     material.  40 seeds were swept with the tool: 0 mismatches."""
@@ -135,9 +135,8 @@ def test_random_scenes_live_when_reference_present(pkg, oracle, seed, tmp_path):
         spec.loader.exec_module(mod)
         return mod
     fz = load("fuzz_scenes", os.path.join(ROOT, "tests", "test_gpu_fuzz.py"))
-    tool = load("fuzz_tool", os.path.join(ROOT, "tools", "fuzz_oracle_vs_reference.py"))
     scene_file, out = str(tmp_path / "fuzz.pbrt"), str(tmp_path / "ref.pfm")
-    open(scene_file, "w").write(tool.random_scene_sss_grid(fz, seed))
+    open(scene_file, "w").write(fz.random_scene_sss_grid(seed))
     oracle.run_reference(scene_file, out, nthreads=1)
     img, _ = oracle.render_image(pkg.HostScene(scene_file))
     assert np.array_equal(img, pkg.read_pfm(out))
