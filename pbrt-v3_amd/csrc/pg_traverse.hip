@@ -149,6 +149,9 @@ PG_DEV float alpha_lookup(const DScene &sc, const DAlphaTex &a, float u, float v
 }
 // KIND: 0 closest hit (BVHAccel::Intersect), 1 any hit in the reference's order (BVHAccel::IntersectP, counters exact),
 // 2 any hit in free order (same occlusion answers; the counters then say what THIS traversal read)
+#ifndef TR_INST_GROUP
+#define TR_INST_GROUP 8  // lanes waiting for an instance entry / exit step before the wave runs it (measured 4 / 8 / 12 / 20 / 32: profiles/r03x_*)
+#endif
 template <int KIND, int XP>
 __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_ALPHA)) ? (KIND == 2 ? TR_INST_WAVES + TR_FREE_EXTRA_WAVES : TR_INST_WAVES) : TR_MIN_WAVES)) TR_SGPR_ATTR void k_trace(DScene sc, RayQueue q0, RayQueue q1, float4 *__restrict__ hits,
                                                     int hitOffset1, float *__restrict__ tOut, int *__restrict__ occluded,
@@ -194,6 +197,12 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
     // derived again from the queue entry when the lane comes back -- the same operations on the same inputs as at the refill,
     // so the same bits -- which spares ten registers for the whole kernel (101 -> 5 resident waves per SIMD instead of 4).
     int inInst = -1, hitInstCur = -1, spBase = 0, wvd = 0;
+    // Entering and leaving an instance are steps of their own (like "expand an interior record" and "test a triangle"): a lane
+    // that meets an instance record in a leaf waits with pendInst >= 0, a lane that has finished an instance's BVH waits as it
+    // is, and the wave runs the entry / exit code when TR_INST_GROUP lanes wait for it or nothing else is left to do.  Run
+    // inline where they arose, the two blocks executed in half of all wave iterations of the instanced 5 M-triangle scene with
+    // 2.6 (exit) and 5.3 (entry) active lanes (profiles/r03w_trace_step_statistics.txt; the gain is 3 % closest hit, 10 % any hit).
+    int pendInst = -1;
     unsigned wLeaf = 0;  // the rest of the world leaf: next primitive << (leafBits + 1) | primitives left
     bool instHit = false;
     float wtMax = 0;
@@ -216,28 +225,15 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
 #define TR_SETTLE() do { if (cur < 0 && cur != TR_NONE) { const int code_ = ~cur; triNext = code_ >> leafBits; triLeft = (code_ & leafMask) + 1; cur = TR_NONE; } } while (0)
 
     for (;;) {
-        // ---- a lane that has finished an instance's BVH goes back to its world ray (primitive.cpp:83-88)
-        if ((XP & XP_INST) && inInst >= 0 && cur == TR_NONE && triLeft == 0) {
-            if (!ANYHIT && instHit) wtMax = tMax;  // r.tMax = ray.tMax
-            {
-                const bool fromQ1 = q1.regionCap > 0 && ray >= hitOffset1;
-                const float4 o4 = fromQ1 ? q1.o[ray - hitOffset1] : q0.o[ray], d4 = fromQ1 ? q1.d[ray - hitOffset1] : q0.d[ray];
-                ox = o4.x; oy = o4.y; oz = o4.z; tMax = wtMax;
-                tr = tri_ray_setup(mk(d4.x, d4.y, d4.z));
-                ix = 1 / d4.x; iy = 1 / d4.y; iz = 1 / d4.z;
-            }
-            nx = ix < 0; ny = iy < 0; nz = iz < 0; negBits = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
-            if (ANYHIT) { vd = wvd; vmask = wvmask; }
-            triNext = (int)(wLeaf >> (leafBits + 1)); triLeft = (int)(wLeaf & ((2u << leafBits) - 1u)); inInst = -1; spBase = 0;
-            if (triLeft == 0) { TR_POP(); TR_SETTLE(); }
-        }
         // ---- retire finished rays and refill idle lanes from this wave's segment.  A finished ray's result stays in its lane
         //      until the wave refills (>= refillAt idle lanes) or runs dry, so the stores run with many lanes active instead of
         //      once per iteration for one or two lanes.  Measured and NOT kept: copying the hit triangle's 48-B record next to
         //      the hit here to spare the shading kernel its gather (+12 ms per frame here, no gain in k_shade); handing invDir
         //      and the triangle test's shear over from the ray's producer instead of deriving them at refill (no gain:
         //      the refill costs 9 % of this kernel's issue slots, but the extra 32 B per ray cost as much as the divisions).
-        const bool idle = cur == TR_NONE && triLeft == 0;
+        const bool wantExit = (XP & XP_INST) && inInst >= 0 && cur == TR_NONE && triLeft == 0 && pendInst < 0;  // finished an instance's BVH
+        const bool wantEnter = (XP & XP_INST) && pendInst >= 0;
+        const bool idle = cur == TR_NONE && triLeft == 0 && !wantExit && !wantEnter;
         const unsigned long long idleMask = __ballot(idle);
         const int nIdle = __popcll(idleMask);
         // one scalar comparison decides between the step and the (rarer) retire / refill path: the threshold is refillAt
@@ -311,6 +307,69 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
         // ---- one step for the wave: either every lane holding an interior record expands it, or every lane
         //      holding a leaf tests its next triangle.  The larger group goes first (weighted by triW/16), so
         //      at least about half of the busy lanes are active in every step and neither group starves.
+        // ---- instance steps (see pendInst): leave, then enter, when enough lanes wait or no lane can do anything else
+        if (XP & XP_INST) {
+            const int nExit = __popcll(__ballot(wantExit)), nEnter = __popcll(__ballot(wantEnter));
+            if (nExit | nEnter) {
+                const bool nothingElse = __ballot(cur >= 0 || triLeft > 0) == 0;
+                if (nExit > 0 && (nExit >= TR_INST_GROUP || nothingElse)) {
+                    if (wantExit) {  // back to the world ray (primitive.cpp:83-88)
+                        if (!ANYHIT && instHit) wtMax = tMax;  // r.tMax = ray.tMax
+                        {
+                            const bool fromQ1 = q1.regionCap > 0 && ray >= hitOffset1;
+                            const float4 o4 = fromQ1 ? q1.o[ray - hitOffset1] : q0.o[ray], d4 = fromQ1 ? q1.d[ray - hitOffset1] : q0.d[ray];
+                            ox = o4.x; oy = o4.y; oz = o4.z; tMax = wtMax;
+                            tr = tri_ray_setup(mk(d4.x, d4.y, d4.z));
+                            ix = 1 / d4.x; iy = 1 / d4.y; iz = 1 / d4.z;
+                        }
+                        nx = ix < 0; ny = iy < 0; nz = iz < 0; negBits = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+                        if (ANYHIT) { vd = wvd; vmask = wvmask; }
+                        triNext = (int)(wLeaf >> (leafBits + 1)); triLeft = (int)(wLeaf & ((2u << leafBits) - 1u)); inInst = -1; spBase = 0;
+                        if (triLeft == 0) { TR_POP(); TR_SETTLE(); }
+                    }
+                    continue;
+                }
+                if (nEnter > 0 && (nEnter >= TR_INST_GROUP || nothingElse)) {
+                    if (wantEnter) {
+                        // TransformedPrimitive::Intersect[P]: carry the ray into the instance's space (Transform::operator()(Ray),
+                        // transform.h:249-262) and start on its BVH
+                        const bool fromQ1 = q1.regionCap > 0 && ray >= hitOffset1;
+                        const float4 d4 = fromQ1 ? q1.d[ray - hitOffset1] : q0.d[ray];
+                        const int idx = pendInst;
+                        const PgInstance &in = sc.instances[idx];
+                        const DObject &ob = sc.objects[in.object];
+                        wtMax = tMax;
+                        if (ANYHIT) { wvd = vd; wvmask = vmask; vd = 0; vmask = 0; }
+                        V3 oErr;
+                        V3 o = m4_point_err(in.w2i, mk(ox, oy, oz), oErr);
+                        const V3 dd = m4_vec(in.w2i, mk(d4.x, d4.y, d4.z));
+                        const float lengthSquared = lensq(dd);
+                        if (lengthSquared > 0) {
+                            const float dt = dot(vabs(dd), oErr) / lengthSquared;
+                            o = o + dd * dt;
+                            tMax -= dt;
+                        }
+                        ox = o.x; oy = o.y; oz = o.z;
+                        tr = tri_ray_setup(dd);
+                        ix = 1 / dd.x; iy = 1 / dd.y; iz = 1 / dd.z;
+                        nx = ix < 0; ny = iy < 0; nz = iz < 0; negBits = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+                        inInst = idx; spBase = sp; instHit = false; pendInst = -1;
+                        triLeft = 0; cur = TR_NONE;
+                        if (ob.nNodes == 0) { triNext = ob.firstPrim; triLeft = 1; }  // a lone primitive, no accelerator (api.cpp:1567)
+                        else {
+                            ++nodeVisits;  // the instance BVH's nodes[0]
+                            float t0;
+                            if (slab_interval(ob.box[0], ob.box[3], ob.box[1], ob.box[4], ob.box[2], ob.box[5], ox, oy, oz, ix, iy, iz, nx, ny, nz, t0) &&
+                                t0 < tMax) {
+                                cur = ob.rootRef;
+                                TR_SETTLE();
+                            }
+                        }
+                    }
+                    continue;
+                }
+            }
+        }
         bool needPop = false, settle = false;
         const int nInt = __popcll(__ballot(cur >= 0));
         const int nTri = __popcll(__ballot(triLeft > 0));
@@ -321,42 +380,12 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                 ++triTests; ++triNext; --triLeft;
                 const uint32_t pflags = __float_as_uint(a.w);
                 if ((XP & XP_INST) && (pflags & PG_PRIM_INSTANCE)) {
-                    // TransformedPrimitive::Intersect[P]: carry the ray into the instance's space (Transform::operator()(Ray),
-                    // transform.h:249-262) and start on its BVH; not a triangle test for the reference's counter
+                    // TransformedPrimitive::Intersect[P]: not a triangle test for the reference's counter; the lane waits for the
+                    // wave's next entry step with the rest of the world leaf put aside
                     --triTests;
-                    const bool fromQ1 = q1.regionCap > 0 && ray >= hitOffset1;
-                    const float4 d4 = fromQ1 ? q1.d[ray - hitOffset1] : q0.d[ray];
-                    const int idx = __float_as_int(a.x);
-                    const PgInstance &in = sc.instances[idx];
-                    const DObject &ob = sc.objects[in.object];
-                    wtMax = tMax;
+                    pendInst = __float_as_int(a.x);
                     wLeaf = ((unsigned)triNext << (leafBits + 1)) | (unsigned)triLeft;
-                    if (ANYHIT) { wvd = vd; wvmask = vmask; vd = 0; vmask = 0; }
-                    V3 oErr;
-                    V3 o = m4_point_err(in.w2i, mk(ox, oy, oz), oErr);
-                    const V3 dd = m4_vec(in.w2i, mk(d4.x, d4.y, d4.z));
-                    const float lengthSquared = lensq(dd);
-                    if (lengthSquared > 0) {
-                        const float dt = dot(vabs(dd), oErr) / lengthSquared;
-                        o = o + dd * dt;
-                        tMax -= dt;
-                    }
-                    ox = o.x; oy = o.y; oz = o.z;
-                    tr = tri_ray_setup(dd);
-                    ix = 1 / dd.x; iy = 1 / dd.y; iz = 1 / dd.z;
-                    nx = ix < 0; ny = iy < 0; nz = iz < 0; negBits = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
-                    inInst = idx; spBase = sp; instHit = false;
                     triLeft = 0; cur = TR_NONE;
-                    if (ob.nNodes == 0) { triNext = ob.firstPrim; triLeft = 1; }  // a lone primitive, no accelerator (api.cpp:1567)
-                    else {
-                        ++nodeVisits;  // the instance BVH's nodes[0]
-                        float t0;
-                        if (slab_interval(ob.box[0], ob.box[3], ob.box[1], ob.box[4], ob.box[2], ob.box[5], ox, oy, oz, ix, iy, iz, nx, ny, nz, t0) &&
-                            t0 < tMax) {
-                            cur = ob.rootRef;
-                            TR_SETTLE();
-                        }
-                    }
                 } else {
                     float t, b0, b1, b2;
                     bool hit;
