@@ -248,6 +248,7 @@ struct TraceCounters {
 // this factor through rounding (each accepted hit can raise it by <= 3 roundings, i.e. ~5000 successive raises).
 // maxAccepted: accepted hits per ray beyond which the margin's proof no longer holds (<= 4096 for cullK = 1 + 2^-10)
 struct TraceConfig { int depth, segRays /* rays per chunk */, refillAt, triW; float cullK; int gridBlocks; int maxAccepted;
+                     int refillAtAny, triWAny;  /* the same two for any-hit launches: their rays end at the first hit, a wave waits for more idle lanes and more leaf lanes (profiles/r03z_*) */
                      int anyhitFree;  /* any-hit rays visit the nearer child first instead of the reference's order (same answers) */ };
 // The defaults, with the PG_TRACE_* environment overrides of experiments and tests applied.  Every scene carries its own copy
 // (PgScene::trace): the exact-fallback retry of one scene must not change what another host thread's launches use.

@@ -504,12 +504,14 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
 
 // depth 11: 7 resident 256-thread blocks x 22.5 KB of stack fill the 160 KB LDS
 TraceConfig default_trace_config() {
-    TraceConfig tc = {TR_DEFAULT_DEPTH, 128, 16, 8, 1.0009765625f, 2048, TR_MAX_ACCEPTED, 1};
+    TraceConfig tc = {TR_DEFAULT_DEPTH, 128, 16, 8, 1.0009765625f, 2048, TR_MAX_ACCEPTED, 32, 16, 1};
     if (const char *e = getenv("PG_TRACE_DEPTH")) { int v = atoi(e); if (v >= 0 && v <= 64) tc.depth = v; }
     if (const char *e = getenv("PG_TRACE_SEG")) { int v = atoi(e); if (v >= 64) tc.segRays = v; }
     if (const char *e = getenv("PG_TRACE_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) tc.refillAt = v; }
     if (const char *e = getenv("PG_TRACE_GRID")) { int v = atoi(e); if (v >= 8) tc.gridBlocks = v; }
     if (const char *e = getenv("PG_TRACE_TRIW")) { int v = atoi(e); if (v >= 0) tc.triW = v; }
+    if (const char *e = getenv("PG_TRACE_REFILL_ANY")) { int v = atoi(e); if (v >= 1 && v <= 64) tc.refillAtAny = v; }
+    if (const char *e = getenv("PG_TRACE_TRIW_ANY")) { int v = atoi(e); if (v >= 0) tc.triWAny = v; }
     if (const char *e = getenv("PG_TRACE_MAXACC")) { int v = atoi(e); if (v >= 1 && v <= 4096) tc.maxAccepted = v; }  // tests: provoke the exact fallback
     if (const char *e = getenv("PG_TRACE_CULLK")) { float v = (float)atof(e); if (v >= 1.f) tc.cullK = v < 3e38f ? v : 3e38f; }  // finite: 0*inf would be NaN
     // PG_ANYHIT_ORDER=reference: shadow rays visit the BVH in the reference's order, which reproduces its triangle-test statistic
@@ -534,7 +536,7 @@ static void launch_trace(const DScene &sc, const TraceConfig &c, RayQueue q0, Ra
     if (cursorInit) (void)hipMemcpyAsync(cursors, cursorInit, PG_REGIONS * PG_COUNT_STRIDE * sizeof(int), hipMemcpyDeviceToDevice, s);
     const int xp = (sc.nInstances > 0 ? XP_INST : 0) | (sc.nSpheres > 0 ? XP_QUADRIC : 0) | (sc.hasAlpha ? (sc.alphaTex ? XP_ALPHA : XP_ALPHATEX) : 0);
 #define TR_LAUNCH(XPV) hipLaunchKernelGGL((k_trace<KIND, XPV>), dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q0, q1, hits, hitOffset1, tOut, occluded, cn, \
-                                          cursors, c.depth, c.segRays, c.refillAt, c.triW, KIND ? 1.f : c.cullK, cullGuard, c.maxAccepted)
+                                          cursors, c.depth, c.segRays, KIND ? c.refillAtAny : c.refillAt, KIND ? c.triWAny : c.triW, KIND ? 1.f : c.cullK, cullGuard, c.maxAccepted)
     switch (xp) {
     case 0: TR_LAUNCH(0); break;
     case XP_INST: TR_LAUNCH(XP_INST); break;
