@@ -12,8 +12,8 @@ import pytest
 from conftest import ROOT
 
 PROF = os.path.join(ROOT, "profiles")
-BENCHES = {"cfg3": "r03t_bench_cfg3.json", "5m": "r03t_bench_5m.json", "10m_vol": "r03t_bench_10m_vol.json", "div5m": "r03t_bench_div5m.json",
-           "div10m_vol": "r03t_bench_div10m_vol.json", "r03q_cfg3": "r03q_bench_cfg3.json", "r03q_div5m": "r03q_bench_div5m.json", "r03j_cfg3": "r03j_bench_cfg3.json", "r02_cfg3": "r02u_bench_cfg3.json", "r02_5m": "r02u_bench_5m.json"}
+BENCHES = {"cfg3": "r03A_bench_cfg3.json", "5m": "r03A_bench_5m.json", "10m_vol": "r03A_bench_10m_vol.json", "div5m": "r03A_bench_div5m.json",
+           "div10m_vol": "r03A_bench_div10m_vol.json", "r03q_cfg3": "r03q_bench_cfg3.json", "r03q_div5m": "r03q_bench_div5m.json", "r03j_cfg3": "r03j_bench_cfg3.json", "r02_cfg3": "r02u_bench_cfg3.json", "r02_5m": "r02u_bench_5m.json"}
 
 
 def bench(tag):
@@ -58,8 +58,8 @@ def test_every_fraction_recomputes_and_stays_below_one(tag):
             assert g["ceiling_records_per_s"] == pytest.approx(1 / (h / g["ceiling_l2_resident"] + (1 - h) / g["ceiling_at_working_set"]), rel=1e-9)
 
 
-@pytest.mark.parametrize("tag,stats", [("cfg3", "r03t_kernel_stats_cfg3.csv"), ("5m", "r03t_kernel_stats_5m.csv"), ("div5m", "r03t_kernel_stats_div5m.csv"), ("r03q_cfg3", "r03q_kernel_stats_cfg3.csv"), ("r03q_div5m", "r03q_kernel_stats_div5m.csv"),
-                                       ("div10m_vol", "r03t_kernel_stats_div10m_vol.csv"), ("r03j_cfg3", "r03j_kernel_stats_cfg3.csv"), ("r02_cfg3", "r02u_kernel_stats_cfg3.csv"),
+@pytest.mark.parametrize("tag,stats", [("cfg3", "r03A_kernel_stats_cfg3.csv"), ("5m", "r03A_kernel_stats_5m.csv"), ("div5m", "r03A_kernel_stats_div5m.csv"), ("r03q_cfg3", "r03q_kernel_stats_cfg3.csv"), ("r03q_div5m", "r03q_kernel_stats_div5m.csv"),
+                                       ("div10m_vol", "r03A_kernel_stats_div10m_vol.csv"), ("r03j_cfg3", "r03j_kernel_stats_cfg3.csv"), ("r02_cfg3", "r02u_kernel_stats_cfg3.csv"),
                                        ("r02_5m", "r02u_kernel_stats_5m.csv")])
 def test_event_timing_agrees_with_the_rocprof_summary(tag, stats):
     """bench.py times each kernel with HIP events on its own stream; rocprofv3 --kernel-trace --stats of the same command gives the
@@ -88,7 +88,7 @@ def test_hbm_regime_of_the_headline_line_is_reproducible():
     assert h["bound"] == "hbm" and h["peak"] == 8000.0 and h["working_set_bytes"] > 256 << 20
     assert h["achieved"] == pytest.approx(h["algorithmic_bytes_per_launch"] / (h["avg_launch_ms"] * 1e-3) / 1e9, rel=1e-9)
     assert h["frac"] == pytest.approx(h["achieved"] / 8000.0, rel=1e-12) and 0.40 <= h["frac"] < 1
-    rows = list(csv.DictReader(open(os.path.join(PROF, "r03t_kernel_stats_5m.csv"))))
+    rows = list(csv.DictReader(open(os.path.join(PROF, "r03A_kernel_stats_5m.csv"))))
     k = [r for r in rows if r["Name"].startswith("void k_trace<0,")]
     avg = sum(float(r["TotalDurationNs"]) for r in k) / sum(int(r["Calls"]) for r in k) / 1e6
     assert avg == pytest.approx(h["avg_launch_ms"], rel=0.05)
