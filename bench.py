@@ -35,6 +35,7 @@ sys.path.insert(0, os.path.join(ROOT, "scenes"))
 from __graft_entry__ import load_package  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy ceiling
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2  # MI355X: 256 CUs x 4 SIMD-32 units, a 64-wide vector instruction issues over 2 cycles (MI355X_MICROARCH.md "Wave scheduling"), 2.4 GHz: 1.23e12 per second
 L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth, 8 XCDs x 4 MiB (MI355X_MICROARCH.md "L2 (per XCD)")
 INFINITY_CACHE_BYTES = 256 << 20
 FOG = ('MakeNamedMedium "fog" "string type" "homogeneous" "rgb sigma_a" [ 0.02 0.03 0.04 ] "rgb sigma_s" [ 0.15 0.12 0.1 ] "float g" [ 0.4 ]\n'
@@ -301,6 +302,12 @@ def kernel_rooflines(m, workload):
         r = {"kernel": name, "bound": bound, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
              "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes / launches, "avg_launch_ms": ms / launches,
              "launches": launches, "total_ms": ms, f"bytes_per_{unit_name}": alg_bytes / max(1, units)}
+        if pk is not None and pk.get("valu_insts_per_launch") and ms > 0:
+            # what the SIMDs issued: wave-wide vector instructions per second against 1024 SIMD-32 units x 2.4 GHz / 2 cycles per 64-wide instruction
+            rate = pk["valu_insts_per_launch"] * launches / (ms * 1e-3)
+            r["vector_issue"] = {"insts_per_launch": pk["valu_insts_per_launch"], "achieved": rate, "peak": VALU_ISSUE_PEAK, "unit": "wave instructions/s",
+                                 "frac": rate / VALU_ISSUE_PEAK, "lanes_active_of_64": pk.get("valu_lanes_active"), "source": pmc_src,
+                                 "note": "instruction count replayed from a committed PMC pass of this workload (SQ_INSTS_VALU), divided by this run's kernel time"}
         if served_on_die:
             r["note"] = (f"algorithmic rate above the HBM peak ({HBM_PEAK_GBS:.0f} GB/s) although the scene exceeds the Infinity Cache: the top of the tree is "
                          "served on-die (short traversals), so this kernel is priced against the L2")

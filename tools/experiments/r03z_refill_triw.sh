@@ -1,5 +1,5 @@
 #!/bin/bash
-# r03z: k_trace<0, 0> issues 0.9 of the chip's vector-instruction slots (profiles/r03y_pmc_cfg3_valu.txt) at 55 % lane use: the two knobs that
+# r03z: k_trace<0, 0> issues 0.45 of the chip's vector-instruction slots (profiles/r03y_pmc_cfg3_valu.txt) at 55 % lane use: the two knobs that
 # trade lane use against extra iterations -- the refill threshold (idle lanes before a wave refills) and the interior : leaf weighting.
 OUT=gpurun_out/r03z; mkdir -p $OUT
 run() { local name=$1; shift
