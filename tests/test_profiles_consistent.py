@@ -13,7 +13,7 @@ from conftest import ROOT
 
 PROF = os.path.join(ROOT, "profiles")
 BENCHES = {"cfg3": "r03A_bench_cfg3.json", "5m": "r03A_bench_5m.json", "10m_vol": "r03A_bench_10m_vol.json", "div5m": "r03A_bench_div5m.json",
-           "div10m_vol": "r03A_bench_div10m_vol.json", "r03q_cfg3": "r03q_bench_cfg3.json", "r03q_div5m": "r03q_bench_div5m.json", "r03j_cfg3": "r03j_bench_cfg3.json", "r02_cfg3": "r02u_bench_cfg3.json", "r02_5m": "r02u_bench_5m.json"}
+           "div10m_vol": "r03A_bench_div10m_vol.json", "cfg3_vector_issue": "r03C_bench_cfg3.json", "r03q_cfg3": "r03q_bench_cfg3.json", "r03q_div5m": "r03q_bench_div5m.json", "r03j_cfg3": "r03j_bench_cfg3.json", "r02_cfg3": "r02u_bench_cfg3.json", "r02_5m": "r02u_bench_5m.json"}
 
 
 def bench(tag):
@@ -26,7 +26,7 @@ def test_bench_line_carries_the_contract(tag):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in b, k
     assert b["metric"] == "Mrays/s" and b["dtype"] == "f32" and b["data"] == "synthetic" and b["vs_baseline"] is None and "workload" in b["config"]
-    if tag in ("cfg3", "r03q_cfg3", "r03j_cfg3", "r02_cfg3"):
+    if tag in ("cfg3", "cfg3_vector_issue", "r03q_cfg3", "r03j_cfg3", "r02_cfg3"):
         cb = b["cpu_baseline"]
         assert cb["kind"] == "reference" and cb["cores"] >= 1 and cb["value"] > 0 and "spp" in cb["sample"]
 
@@ -106,3 +106,18 @@ def test_replayed_values_are_labelled():
         assert g["l2_hit_rate_source"].startswith("profiles/pmc_traffic.json")
     cal = json.load(open(os.path.join(PROF, "fetch_size_calibration.json")))
     assert cal["gather_factor"] == 2.0 and "k_gather_pair" in cal["raw"]["kernels"]
+
+
+def test_vector_issue_fraction_recomputes():
+    """roofline_kernels[].vector_issue: wave-wide vector instructions per second (count replayed from the committed PMC pass, SQ_INSTS_VALU)
+    against 1024 SIMD-32 units x 2.4 GHz / 2 cycles per 64-wide instruction (MI355X_MICROARCH.md, "Wave scheduling")."""
+    b = bench("cfg3_vector_issue")
+    seen = 0
+    for k in b["roofline_kernels"]:
+        v = k.get("vector_issue")
+        if not v: continue
+        seen += 1
+        assert v["peak"] == pytest.approx(256 * 4 * 2.4e9 / 2) and v["source"].startswith("profiles/pmc_traffic.json")
+        assert v["achieved"] == pytest.approx(v["insts_per_launch"] * k["launches"] / (k["total_ms"] * 1e-3), rel=1e-9)
+        assert v["frac"] == pytest.approx(v["achieved"] / v["peak"], rel=1e-12) and 0 < v["frac"] < 1 and 1 <= v["lanes_active_of_64"] <= 64
+    assert seen >= 2
