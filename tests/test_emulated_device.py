@@ -51,6 +51,17 @@ def test_renders_on_the_emulated_device(emulated):
     assert " passed" in out and "failed" not in out
 
 
+def test_round3_kernels_on_the_emulated_device(emulated):
+    """What round 3 added to the device, each on one small scene: subsurface scattering (the probe chain walked twice through k_trace, the exit
+    vertex), a GridDensityMedium (two shading phases around the transmittance rays), the divergent stand-in (instances, alpha masks,
+    shading by material class), a PixelSampler whose dimensions cover a path (all pixels' arrays ahead, one wavefront)."""
+    select = "test_golden_images and (sss_preset or grid_puff_sobol or divergent_small_vol or sampler_stratified_dims_tex)"
+    out = run_gpu_tests(emulated, ["tests/test_gpu_parity.py"], select, 1500)
+    assert " passed" in out and "failed" not in out
+    out = run_gpu_tests(emulated, ["tests/test_gpu_shade_order.py"], "golden_scene and (divergent_small or tex_image)", 900)
+    assert " passed" in out and "failed" not in out
+
+
 @pytest.mark.skipif(os.environ.get("PBRT_EMULATE_ALL") != "1", reason="set PBRT_EMULATE_ALL=1 for the whole feasible GPU suite under emulation (~15 min)")
 def test_everything_feasible_on_the_emulated_device(emulated):
     out = run_gpu_tests(emulated, ["tests/test_gpu_parity.py", "tests/test_gpu_fuzz.py"], SKIP, 7200)
