@@ -669,7 +669,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         const char *so = getenv("PG_SHADE_ORDER");
         s->volOrder = s->nMedia > 0 && d.nGrids == 0 && !(so && atoi(so) == 0);
         if (d.hasTextured && desc->n_materials > 1 && !(so && atoi(so) == 0)) {
-            const int nClasses = PG_ORDER_CLASSES - 2;
+            const int nClasses = PG_ORDER_CLASSES - 3;  // 0 .. 12; 13 = scattered in a medium (volpath), 14 = the ray escaped, 15 = no entry
             std::vector<unsigned char> matClass((size_t)desc->n_materials, 0);
             if (desc->n_materials <= nClasses) for (int i = 0; i < desc->n_materials; ++i) matClass[i] = (unsigned char)i;
             else {

@@ -276,7 +276,7 @@ void launch_ts_film(const DScene &sc, const RenderParams &rp, PathState st, PgFi
 #ifndef PG_ORDER_WINDOW
 #define PG_ORDER_WINDOW 16384
 #endif
-#define PG_ORDER_CLASSES 16  // 0 .. 13 material classes, 14 = the ray escaped, 15 = no entry
+#define PG_ORDER_CLASSES 16  // 0 .. 12 material classes, 13 = scattered in a medium (volpath), 14 = the ray escaped, 15 = no entry
 void launch_shade_order(const DScene &sc, RayQueue qin, const float4 *hits, int *order, hipStream_t s);
 // volpath: additionally draws the medium sample of every entry (RenderParams::volPre) and puts the entries that scatter in the medium
 // into a class of their own (class 13), so that a wave shades medium vertices or surface vertices, not both one after the other
