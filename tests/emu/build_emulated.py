@@ -35,9 +35,9 @@ def patched_sources(out):
     j = t.index("\n}\n", i)
     assert t[i:j].count("__ballot(") == 5
     t = t[:i] + t[i:j].replace("__ballot(", "emu_ballot_own(") + t[j:]
-    for name in ("mNeg", "mNear", "mFar"):  # (twice each: the 64-B and the 32-B record forms of the interior step)
+    for name in ("mNeg", "mNear", "mFar"):  # (every form of the interior step that declares them)
         t, n = re.subn(r"const unsigned long long %s = [^\n]*\n" % name, lambda m: m.group(0).replace("__ballot(", "emu_ballot_own("), t)
-        assert n == 2, name
+        assert n >= 1, name
     m = re.search(r"const bool h0 = [^\n]*\n", t)  # free-order any-hit: the two box-test masks, own bit only
     assert m and m.group(0).count("__ballot(") == 2
     t = t[:m.start()] + m.group(0).replace("__ballot(", "emu_ballot_own(") + t[m.end():]
