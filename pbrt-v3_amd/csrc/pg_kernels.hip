@@ -2523,8 +2523,13 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
             // phase 1, sets its own --; phase 2 leaves L alone: k_resolve_vol has added this vertex's direct lighting to it)
             if (phaseA && vertexKind != 0) newFlags = meta.w & 0xf0000;
             if (!phaseB) st.L[slot] = make_float4(L.r, L.g, L.b, L4.w);
-            st.beta[slot] = make_float4(beta.r, beta.g, beta.b, B4.w);
-            st.meta[slot] = make_int4(meta.x, meta.y, __float_as_int(etaScale), (dim << 20) | bounces | newFlags);
+            // (phase 2 has nothing to do for a vertex that phase 1 finished -- a surface without a material, the end of a path -- and must
+            // leave its state alone: writing it back would clear the flags phase 1 set, e.g. "the last bounce was specular", which a
+            // path keeps across a material-less surface, path.cpp:107-113)
+            if (!(phaseB && vertexKind == 0)) {
+                st.beta[slot] = make_float4(beta.r, beta.g, beta.b, B4.w);
+                st.meta[slot] = make_int4(meta.x, meta.y, __float_as_int(etaScale), (dim << 20) | bounces | newFlags);
+            }
             if (phaseA) gsh.vertex[slot] = make_float4(mediumP.x, mediumP.y, mediumP.z, __int_as_float(alive ? vertexKind : 0));
         }
     }

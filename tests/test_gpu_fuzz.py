@@ -242,6 +242,15 @@ def test_random_sss_or_grid_scene_film_matches_oracle(gpu, oracle, seed):
     check_scene(gpu, oracle, random_scene_sss_grid(seed, "sss" if seed % 2 else "grid"), seed)
 
 
+@pytest.mark.parametrize("seed", [59, 68])
+def test_grid_scene_keeps_the_specular_flag_across_a_material_less_surface(gpu, oracle, seed):
+    """Two scenes of a 300-scene sweep on the GPU (tools/fuzz_emulated_device.py): a path leaves a specular surface, crosses the
+    material-less boundary of a medium and hits an area light -- `specularBounce` survives the boundary (path.cpp:107-113: `continue`),
+    so the light's emission counts.  The second shading phase of grid-medium scenes had written the state of vertices that the first
+    phase finished back without their flags."""
+    check_scene(gpu, oracle, random_scene_sss_grid(seed, "grid"), seed)
+
+
 def check_scene(gpu, oracle, text, seed):
     scene = gpu.HostScene(text=text)
     gs = gpu.GpuScene(scene.desc)
