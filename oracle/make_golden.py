@@ -786,6 +786,11 @@ GRID_SCENES = {
     "grid_puff_random": cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 5 ]', world_edit=with_grid_puff).replace('Sampler "halton"', 'Sampler "random"'),
     "grid_puff_stratified": cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 5 ]', world_edit=lambda s: with_grid_puff(s, dense=True))
                             .replace('Sampler "halton" "integer pixelsamples" [ 4 ]', 'Sampler "stratified" "integer xsamples" [ 2 ] "integer ysamples" [ 2 ] "integer dimensions" [ 3 ]'),
+    # a mirror and a glass box INSIDE the puff: specular paths cross the medium's material-less boundary on their way to the light, and
+    # `specularBounce` must survive that surface (path.cpp:107-113) for the light's emission to count
+    "grid_puff_specular": cornell(32, 32, 8, integrator='Integrator "volpath" "integer maxdepth" [ 5 ]',
+                                  world_edit=lambda s: with_grid_puff(s).replace("# tall box", 'Material "mirror"\n# tall box')
+                                  .replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\nMaterial "glass"')),
     # PathIntegrator ignores media (path.cpp): the "none" box is simply passed through
     "grid_path_ignores": cornell(24, 24, 4, world_edit=with_grid_puff),
 }
