@@ -15,6 +15,19 @@ os.environ.setdefault("PG_ANYHIT_ORDER", "reference")  # as tests/conftest.py: t
 from __graft_entry__ import load_package  # noqa: E402
 
 
+def equals_correctly_rounded_oracle(pkg, oracle, text):
+    import numpy as np
+    scene = pkg.HostScene(text=text)
+    gs = pkg.GpuScene(scene.desc)
+    rd = scene.render_desc()
+    film, strays = gs.render(rd)
+    cn = gs.counters()
+    gs.close()
+    cfilm, cstrays, ccn = oracle.render(scene.desc, rd, cr_libm=True)
+    return (np.array_equal(film["rgb"], cfilm["rgb"]) and np.array_equal(film["weight"], cfilm["weight"]) and len(strays) == len(cstrays) and
+            all(cn[k] == ccn[k] for k in ("camera_rays", "closest_rays", "shadow_rays", "tri_tests", "node_visits")))
+
+
 def main():
     a, b = int(sys.argv[1]), int(sys.argv[2])
     pkg = load_package()
@@ -26,17 +39,23 @@ def main():
     gens = {"random_scene": fz.random_scene, "random_scene_ext": fz.random_scene_ext, "random_scene_vol": fz.random_scene_vol,
             "random_scene_sss": lambda s: fz.random_scene_sss_grid(s, "sss"), "random_scene_grid": lambda s: fz.random_scene_sss_grid(s, "grid")}
     if len(sys.argv) > 3: gens = {k: v for k, v in gens.items() if k == sys.argv[3]}
-    bad = 0
+    bad = soft = 0
     for name, gen in gens.items():
         for seed in range(a, b):
             try:
                 fz.check_scene(pkg, oracle, gen(seed), seed)
             except AssertionError as e:
-                bad += 1
-                print(name, seed, "MISMATCH:", str(e)[:200] or traceback.format_exc().splitlines()[-3], flush=True)
+                # check_scene first holds the device against the oracle built on the system's libm, within a tolerance: one last-bit difference in a
+                # sin / cos can send a sample down another path.  What decides is the correctly-rounded oracle, bit for bit:
+                if equals_correctly_rounded_oracle(pkg, oracle, gen(seed)):
+                    soft += 1
+                    print(name, seed, "differs from the system-libm oracle beyond the tolerance, EQUALS the correctly-rounded oracle (film, counters)", flush=True)
+                else:
+                    bad += 1
+                    print(name, seed, "MISMATCH:", str(e)[:200] or traceback.format_exc().splitlines()[-3], flush=True)
             except Exception as e:  # scenes the front end or the device reports as unsupported, degenerate inputs
                 print(name, seed, "skipped:", str(e)[:120], flush=True)
-    print("done, mismatches:", bad, flush=True)
+    print("done, mismatches:", bad, "| beyond the tolerance against the system-libm oracle but equal to the correctly-rounded one:", soft, flush=True)
 
 
 if __name__ == "__main__":
