@@ -220,6 +220,26 @@ def random_scene_sss_grid(seed, features="both"):
     return "\n".join(out) + "\n"
 
 
+def random_scene_pixel_sampler(seed):
+    """The plain / extended random scenes under a PixelSampler whose "dimensions" cover every draw of a path (2 + 3 maxdepth): the form in
+    which the device generates all pixels' sample arrays ahead and traces one wavefront (k_ts_start_tile, DESIGN.md section 4 "Samplers")."""
+    import re
+    text = random_scene_ext(seed) if seed % 2 else random_scene(seed)
+    depth = int(re.search(r'"integer maxdepth" \[ (\d+) \]', text).group(1))
+    dims = 2 + 3 * depth
+    spec = ('"stratified" "integer xsamples" [ 2 ] "integer ysamples" [ 2 ] "bool jitter" "%s" "integer dimensions" [ %d ]' % ("true" if seed % 4 < 2 else "false", dims),
+            '"02sequence" "integer pixelsamples" [ 4 ] "integer dimensions" [ %d ]' % dims,
+            '"maxmindist" "integer pixelsamples" [ 4 ] "integer dimensions" [ %d ]' % dims)[seed % 3]
+    out, n = re.subn(r'Sampler "halton" "integer pixelsamples" \[ 4 \]', "Sampler " + spec, text)
+    assert n == 1
+    return out
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scene_under_a_batched_pixel_sampler(gpu, oracle, seed):
+    check_scene(gpu, oracle, random_scene_pixel_sampler(seed), seed)
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_random_scene_film_matches_oracle(gpu, oracle, seed):
     check_scene(gpu, oracle, random_scene(seed), seed)
