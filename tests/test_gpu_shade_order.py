@@ -54,3 +54,25 @@ def test_golden_scene_same_film_in_both_orders(gpu, monkeypatch, name):
 def test_random_scene_same_film_in_both_orders(gpu, monkeypatch, seed):
     text = (random_scene_ext, random_scene_vol)[seed % 2](seed // 2)
     render_both(gpu, monkeypatch, gpu.HostScene(text=text))
+
+
+def test_more_materials_than_classes(gpu, monkeypatch):
+    """Beyond 13 materials the classes are shared by materials that run the same code (type, kind, bump): 24 small quads, each with a material
+    of its own (matte / plastic / metal / uber / substrate, textured and plain), in front of the textured Cornell box -- both orders, same film."""
+    text = open(os.path.join(GOLD, "tex_materials.pbrt")).read()
+    kinds = ['Material "matte" "texture Kd" "chk" "float sigma" [ %g ]', 'Material "plastic" "texture Kd" "uvt" "float roughness" [ %g ]',
+             'Material "metal" "texture k" "bil" "float roughness" [ %g ]', 'Material "uber" "texture Kd" "mixed" "float roughness" [ %g ]',
+             'Material "substrate" "texture Kd" "uvt" "float uroughness" [ %g ]', 'Material "matte" "rgb Kd" [ 0.5 %g 0.3 ]']
+    quads = []
+    for k in range(24):
+        x, y = 60 + 85 * (k % 6), 60 + 110 * (k // 6)
+        quads.append('AttributeBegin\n  %s\n  Shape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ] "point P" [ %d %d 120  %d %d 120  %d %d 125  %d %d 125 ] '
+                     '"float uv" [ 0 0 1 0 1 1 0 1 ]\nAttributeEnd' % (kinds[k % len(kinds)] % (0.05 + 0.03 * k), x, y, x + 60, y, x + 60, y + 80, x, y + 80))
+    old = os.getcwd()
+    os.chdir(GOLD)  # (the scene's image textures)
+    try:
+        scene = gpu.HostScene(text=text.replace("WorldEnd", "\n".join(quads) + "\nWorldEnd"))
+    finally:
+        os.chdir(old)
+    assert scene.desc.n_materials > 13
+    render_both(gpu, monkeypatch, scene)
