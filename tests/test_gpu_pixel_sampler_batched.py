@@ -68,3 +68,32 @@ def test_wrong_first_guess_of_the_stream_positions_is_corrected(gpu, monkeypatch
     monkeypatch.setenv("PG_TS_GUESS_SKEW", str(skew))
     fb, sb, cb = render(gpu, scene)
     assert np.array_equal(fa["rgb"], fb["rgb"]) and np.array_equal(fa["weight"], fb["weight"]) and ca["closest_rays"] == cb["closest_rays"]
+
+
+@pytest.mark.parametrize("name", ["sampler_stratified_dims_tex", "filter_02sequence_dims"])
+def test_batched_form_under_tile_sharding(gpu, monkeypatch, name):
+    """The multi-GPU decomposition (tiles t = r mod N per rank) with a batched PixelSampler: a tile's sample arrays depend on the tile's
+    own stream only.  Box filter: three shards merged give the unsharded image bit for bit.  Wide filter (overlapping tile blocks are
+    summed in merge order): the three shards of the batched form equal the three shards of the serial form, merged the same way."""
+    scene = gpu.HostScene(os.path.join(GOLD, name + ".pbrt"))
+    gs = gpu.GpuScene(scene.desc)
+
+    def merged_shards():
+        scene.film_clear()
+        for r in range(3):
+            rdr = scene.render_desc(r, 3)
+            f, s = gs.render(rdr)
+            scene.film_merge(rdr, f, s)
+        return scene.film_image().copy()
+
+    batched = merged_shards()
+    assert gs.counters()["closest_launches"] <= 3 * 16
+    if name.startswith("filter_"):
+        monkeypatch.setenv("PG_TS_BATCHED", "0")
+        assert np.array_equal(merged_shards(), batched)
+    else:
+        rd = scene.render_desc()
+        film, strays = gs.render(rd)
+        scene.film_clear(); scene.film_merge(rd, film, strays)
+        assert np.array_equal(scene.film_image(), batched)
+    gs.close()
