@@ -153,10 +153,32 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         // one BVHAccel's nodes [firstNode, +nn) -> records appended to w; leaf references carry GLOBAL primitive indices
         // (firstPrim + the node's own offset).  Returns the reference of the BVH's root.
         bool badChildren = false;
+        int worldPending = 0, objectPending = 0;  // stack entries the world BVH / the deepest object BVH can have pending
         // which records share a 128-B line (measured, profiles/r03n_record_layout_ab.txt: 1 is 1 - 3 % faster than 0, 2 is no gain)
         const int recordLayout = getenv("PG_RECORD_LAYOUT") ? atoi(getenv("PG_RECORD_LAYOUT")) : 1;
         auto buildRecords = [&](int firstNode, int nn, int firstPrim) -> int {
             const PgBVHNode *nodes = desc->nodes + firstNode;
+            // The node array comes from the caller: before anything is indexed by it, require the reference's layout
+            // (bvh.cpp:640-658: first child at i + 1, second child later in the array) and that it is a tree -- every node but
+            // the root the child of exactly one interior node -- so that every interior node is reached from the root once.
+            // The same pass takes the greatest number of entries a traversal can have pending, which the stack must hold.
+            {
+                std::vector<int> level((size_t)nn, 0);
+                std::vector<unsigned char> parents((size_t)nn, 0);
+                int deepest = 0;
+                for (int i = 0; i < nn && !badChildren; ++i) {
+                    if (i > 0 && parents[i] != 1) { badChildren = true; break; }
+                    if (nodes[i].nprims != 0) continue;
+                    const int c0 = i + 1;
+                    const long long c1 = nodes[i].offset;
+                    if (c0 >= nn || c1 <= c0 || c1 >= nn || parents[c0] || parents[c1] || nodes[i].axis > 2) { badChildren = true; break; }
+                    parents[c0] = parents[c1] = 1;
+                    level[c0] = level[c1] = level[i] + 1;  // entries pending while a child of node i is visited: <= level
+                    deepest = std::max(deepest, level[i] + 1);
+                }
+                if (badChildren) return TR_NO_ROOT;
+                (firstNode == 0 ? worldPending : objectPending) = std::max(firstNode == 0 ? worldPending : objectPending, deepest);
+            }
             std::vector<int> recIndex((size_t)nn, -1);
             int nInterior = 0;
             if (recordLayout != 0 && ((w.size() / 4) & 1)) w.resize(w.size() + 4, make_float4(0, 0, 0, 0));
@@ -242,7 +264,16 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
                 for (int c = 0; c < 3; ++c) { dobj.box[c] = desc->nodes[o.first_node].bmin[c]; dobj.box[3 + c] = desc->nodes[o.first_node].bmax[c]; }
             }
         }
-        if (badChildren) FAIL(PG_ERR_INVALID, "a BVH node has out-of-range children");
+        if (badChildren) FAIL(PG_ERR_INVALID, "the BVH node array is not a tree in the reference's layout (a child out of range, shared or unreachable)");
+        // k_trace's stack (csrc/pg_traverse.hip): TR_STACK_TOTAL entries behind the LDS part, shared by the world traversal and the
+        // instance traversal above it; the reference-order any-hit kernel keeps one bit per pending entry of ONE tree in a 64-bit
+        // mask.  The reference itself has int nodesToVisit[64] per BVH (bvh.cpp:670, :708) and no check at all.
+        if (worldPending > 64 || objectPending > 64)
+            FAIL(PG_ERR_UNSUPPORTED, "a BVH is %d levels deep: more than the 64 pending nodes of the reference's traversal stack (bvh.cpp:670)",
+                 std::max(worldPending, objectPending));
+        if (worldPending + objectPending > 64 + s->trace.depth)
+            FAIL(PG_ERR_UNSUPPORTED, "world BVH (%d levels) + object BVH (%d levels) exceed the traversal stack of %d entries", worldPending, objectPending,
+                 64 + s->trace.depth);
         for (int k = 0; k < nt; ++k) {
             const uint32_t f = desc->tri_flags ? desc->tri_flags[k] : 0;
             if (!(f & PG_PRIM_INSTANCE)) continue;

@@ -121,13 +121,13 @@ def textures(d, rng, res=256, prefix=""):
         write_png(os.path.join(d, prefix + name + ".png"), (np.clip(v[..., None] * np.array(base) * 1.2, 0, 1) * 255).astype(np.uint8))
     r = np.hypot(x - 0.5, y - 0.5)
     leaf = ((r < 0.46) & (np.abs(np.sin(14 * np.arctan2(y - 0.5, x - 0.5))) * 0.25 + 0.2 < 0.5 - r * 0.2) | (r < 0.2)).astype(np.uint8) * 255
-    write_png(os.path.join(d, prefix + "{prefix}leaf_alpha.png"), leaf)
-    write_png(os.path.join(d, prefix + "{prefix}bump.png"), ((0.5 + 0.5 * np.sin(2 * np.pi * 24 * x) * np.sin(2 * np.pi * 24 * y)) * 255).astype(np.uint8))
+    write_png(os.path.join(d, prefix + "leaf_alpha.png"), leaf)
+    write_png(os.path.join(d, prefix + "bump.png"), ((0.5 + 0.5 * np.sin(2 * np.pi * 24 * x) * np.sin(2 * np.pi * 24 * y)) * 255).astype(np.uint8))
     th, ph = np.mgrid[0:64, 0:128]
     up = np.cos(th / 64.0 * np.pi)
     sky = np.stack([0.35 + 0.25 * up, 0.45 + 0.3 * up, 0.6 + 0.4 * up], -1) * np.where(up[..., None] > 0, 1.0, 0.15)
     sun = np.exp(-(((th - 14) / 3.0) ** 2 + ((ph - 40) / 3.0) ** 2))
-    write_pfm(os.path.join(d, prefix + "{prefix}sky.pfm"), (sky + 30.0 * sun[..., None] * np.array([1.0, 0.9, 0.7])).astype(np.float32))
+    write_pfm(os.path.join(d, prefix + "sky.pfm"), (sky + 30.0 * sun[..., None] * np.array([1.0, 0.9, 0.7])).astype(np.float32))
 
 
 MATERIALS = [

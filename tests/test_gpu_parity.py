@@ -365,6 +365,68 @@ def test_unsupported_inputs_fail_loudly(gpu):
     gs.close()
 
 
+def _chain_bvh(gpu, desc, k):
+    """A BVH in the reference's array layout (bvh.cpp:640-658) that is a chain of k interior nodes -- what a "middle" or "equal"
+    split degenerates to on hostile input: the first child of interior node j is interior node j + 1, every second child a leaf
+    with the scene's first primitive."""
+    nodes = (gpu.abi.PgBVHNode * (2 * k + 1))()
+    root = desc.nodes[0]
+    for i in range(2 * k + 1):
+        for c in range(3):
+            nodes[i].bmin[c], nodes[i].bmax[c] = root.bmin[c], root.bmax[c]
+        if i < k:
+            nodes[i].nprims, nodes[i].axis = 0, i % 3
+            nodes[i].offset = k + 1 + (k - 1 - i)
+        else:
+            nodes[i].nprims, nodes[i].offset = 1, 0
+    return nodes
+
+
+def test_malformed_or_too_deep_bvh_is_refused(gpu, oracle):
+    """pg_scene_create checks the caller's node array before it indexes anything by it: children out of range, shared by two
+    parents or unreachable from the root are PG_ERR_INVALID; a tree with more than 64 pending entries -- the reference's
+    nodesToVisit[64] (bvh.cpp:670, :708), which the reference itself does not guard -- is PG_ERR_UNSUPPORTED instead of a write past
+    the kernel's stack.  The deepest tree that is accepted (64 entries: 11 in LDS, 53 behind them) traverses like the oracle."""
+    scene = gpu.HostScene(os.path.join(GOLD, "cornell_32.pbrt"))
+    desc = scene.desc
+    nn = desc.n_nodes
+    own = (gpu.abi.PgBVHNode * nn)(*[desc.nodes[i] for i in range(nn)])
+    interior = [i for i in range(nn) if own[i].nprims == 0]
+    bad = gpu.abi.PgSceneDesc.from_buffer_copy(desc)
+    bad.nodes = own
+    # the second child of the root is made the second child of the root's first child too: shared, and a subtree unreachable
+    first = interior[1]
+    saved = own[first].offset
+    own[first].offset = own[0].offset
+    with pytest.raises(gpu.PbrtGpuError, match="not a tree"):
+        gpu.GpuScene(bad)
+    own[first].offset = first + 1  # second child = first child
+    with pytest.raises(gpu.PbrtGpuError, match="not a tree"):
+        gpu.GpuScene(bad)
+    own[first].offset = nn  # out of range
+    with pytest.raises(gpu.PbrtGpuError, match="not a tree"):
+        gpu.GpuScene(bad)
+    own[first].offset = saved
+    gpu.GpuScene(bad).close()
+    deep = gpu.abi.PgSceneDesc.from_buffer_copy(desc)
+    deep.nodes, deep.n_nodes = _chain_bvh(gpu, desc, 65), 131
+    with pytest.raises(gpu.PbrtGpuError, match="65 levels deep"):
+        gpu.GpuScene(deep)
+    deep.nodes, deep.n_nodes = _chain_bvh(gpu, desc, 64), 129
+    gs = gpu.GpuScene(deep)
+    o, d = random_rays(scene, 2000, 5)
+    tmax = np.full(2000, np.inf, np.float32)
+    prim, t, bary = gs.intersect(o, d, tmax)
+    oprim, ot, obary, ocn = oracle.intersect(deep, o, d, tmax)
+    assert np.array_equal(prim, oprim) and np.array_equal(t, ot) and np.array_equal(bary, obary)
+    occ = gs.intersect_p(o, d, tmax)
+    oocc, _ = oracle.intersect_p(deep, o, d, tmax)
+    assert np.array_equal(occ, oocc) and (prim >= 0).any()
+    cn = gs.counters()
+    assert cn["closest_node_visits"] == ocn["node_visits"]
+    gs.close()
+
+
 def test_invalid_media_and_sampler_descriptions_fail_loudly(gpu):
     """The v15 / v16 additions to the ABI are validated like the rest: out-of-range medium indices, an unknown integrator or
     sampler, a Sobol' render on a scene created without the tables, inconsistent Sobol' resolutions."""

@@ -240,3 +240,22 @@ def test_second_frame_starts_from_fresh_render_options(pkg):
     rd = s2.render_desc()
     assert rd.spp == 16 and rd.max_depth == 5  # the defaults again, not frame 1's "pixelsamples" 8 / its Integrator line
     assert s2.desc.n_materials == s1.desc.n_materials and s2.desc.n_bxdfs == s1.desc.n_bxdfs  # tables not accumulated across frames
+
+
+def test_every_golden_scene_loads_without_an_error_message(pkg):
+    """A scene asset that cannot be read (a texture, a PLY mesh, an environment map) is an Error() and a 1x1 / empty fallback in the
+    reference and here (imageio.cpp:60-78, mipmap.h / imagemap.cpp:55-75): the render goes on and LOOKS plausible.  Round 3's divergent
+    stand-ins rendered that way -- their alpha, bump and sky files were written under other names than the scene asked for -- so the
+    goldens are held to loading with no Error() at all."""
+    import glob
+    dirs = [GOLD, os.path.join(ROOT, "tests", "golden_sss"), os.path.join(ROOT, "tests", "golden_grid"), os.path.join(ROOT, "tests", "golden_large")]
+    files = sorted(f for d in dirs for f in glob.glob(os.path.join(d, "*.pbrt")) if os.path.exists(f[:-5] + ".json"))
+    assert len(files) > 100
+    # scenes that ask for the error path on purpose: an absent map name / texture file / named material, with the reference's fallback
+    on_purpose = {"light_gonio_power", "light_projection", "mat_mix", "sampler_stratified_dims_tex", "sobol_tex_lens", "tex_image", "tex_image_lens"}
+    for f in files:
+        before = pkg.host_lib().pbrt_host_error_count()
+        pkg.HostScene(f).close()
+        reported = pkg.host_lib().pbrt_host_error_count() != before
+        name = os.path.basename(f)[:-5]
+        assert name in on_purpose or not reported, f"{name}: the host front end reported an Error() while loading"
