@@ -925,6 +925,22 @@ def main():
             p = os.path.join(d, "synthetic_1m.pbrt")
             gen_synthetic.write_scene(p, n=708, xres=96, yres=54, spp=4, filename="synthetic_1m.pfm")
             run("synthetic_1m", p, outdir=large)
+    # BASELINE.json config 0: scenes/killeroo-simple.pbrt as the reference ships it (two Loop-subdivided killeroos, plastic, a SPHERE
+    # area light, Halton 8 spp) at the 400x400 BASELINE names, written to a PFM.  The two scene files are input DATA of the reference
+    # (a fixture, like a golden vector): copied verbatim but for the film's size and file name; tests/golden_large/config0/
+    ref_scenes = "/root/reference/scenes"
+    if (not only or "config0" in only) and os.path.exists(os.path.join(ref_scenes, "killeroo-simple.pbrt")):
+        import shutil
+        d = os.path.join(ROOT, "tests", "golden_large", "config0")
+        os.makedirs(os.path.join(d, "geometry"), exist_ok=True)
+        shutil.copy(os.path.join(ref_scenes, "geometry", "killeroo.pbrt"), os.path.join(d, "geometry", "killeroo.pbrt"))
+        os.chmod(os.path.join(d, "geometry", "killeroo.pbrt"), 0o644)
+        txt = open(os.path.join(ref_scenes, "killeroo-simple.pbrt")).read()
+        a, b = '"integer xresolution" [700] "integer yresolution" [700]', '"string filename" "killeroo-simple.exr"'
+        assert a in txt and b in txt
+        txt = txt.replace(a, '"integer xresolution" [400] "integer yresolution" [400]').replace(b, '"string filename" "config0.pfm"')
+        open(os.path.join(d, "config0.pbrt"), "w").write(txt)
+        run("config0", os.path.join(d, "config0.pbrt"), outdir=d)
     # BASELINE.json config 2 (Cornell box) at a quarter of its resolution and spp
     if not only or "cornell_128" in only:
         large = os.path.join(ROOT, "tests", "golden_large")

@@ -13,7 +13,6 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "liboracle.so")
-CR_LIB_PATH = os.path.join(_HERE, "liboracle_crlibm.so")  # same source, correctly rounded float libm (see pbrt_oracle.c)
 REF_BINARY = os.path.join(_HERE, "_ref", "pbrt_oracle")
 _lib = None
 _libs = {}
@@ -25,10 +24,10 @@ def _pkg():
     return load_package()
 
 
-def lib(cr_libm=False):
-    """liboracle.so, or with cr_libm=True its correctly-rounded-libm build (the device's libm behaviour)."""
+def lib():
+    """liboracle.so (built on demand)."""
     global _lib
-    path = CR_LIB_PATH if cr_libm else LIB_PATH
+    path = LIB_PATH
     if path in _libs:
         return _libs[path]
     if True:
@@ -99,15 +98,14 @@ def lib(cr_libm=False):
         L.oracle_fresnel_moment1.restype = C.c_float
         L.oracle_fresnel_moment1.argtypes = [C.c_float]
         _libs[path] = L
-        if not cr_libm:
-            _lib = L
+        _lib = L
     return _libs[path]
 
 
-def render(desc, rd, max_strays=None, cr_libm=False):
+def render(desc, rd, max_strays=None):
     """oracle_render: same outputs as pg_render (film, strays) plus the reference's counters."""
     pkg = _pkg()
-    L = lib(cr_libm)
+    L = lib()
     n = L.oracle_render_tile_count(C.byref(rd))
     if max_strays is None:
         max_strays = pkg.default_max_strays(rd, n)
@@ -121,33 +119,33 @@ def render(desc, rd, max_strays=None, cr_libm=False):
     return film, strays[:ns.value], cn.as_dict()
 
 
-def render_image(scene, cr_libm=False):
+def render_image(scene):
     """Full-frame oracle render of a HostScene, merged by the host Film: (h, w, 3) image + counters."""
     rd = scene.render_desc()
-    film, strays, cn = render(scene.desc, rd, cr_libm=cr_libm)
+    film, strays, cn = render(scene.desc, rd)
     scene.film_clear()
     scene.film_merge(rd, film, strays)
     return scene.film_image(), cn
 
 
-def intersect(desc, o, d, tmax, cr_libm=False):
+def intersect(desc, o, d, tmax):
     pkg = _pkg()
     o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32); tmax = np.ascontiguousarray(tmax, np.float32)
     n = len(tmax)
     prim = np.empty(n, np.int32); t = np.empty(n, np.float32); bary = np.empty((n, 3), np.float32)
     cn = pkg.abi.PgCounters()
-    lib(cr_libm).oracle_intersect(C.byref(desc), n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data, prim.ctypes.data, t.ctypes.data,
+    lib().oracle_intersect(C.byref(desc), n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data, prim.ctypes.data, t.ctypes.data,
                            bary.ctypes.data, C.byref(cn))
     return prim, t, bary, cn.as_dict()
 
 
-def intersect_p(desc, o, d, tmax, cr_libm=False):
+def intersect_p(desc, o, d, tmax):
     pkg = _pkg()
     o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32); tmax = np.ascontiguousarray(tmax, np.float32)
     n = len(tmax)
     occ = np.empty(n, np.uint8)
     cn = pkg.abi.PgCounters()
-    lib(cr_libm).oracle_intersect_p(C.byref(desc), n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data, occ.ctypes.data, C.byref(cn))
+    lib().oracle_intersect_p(C.byref(desc), n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data, occ.ctypes.data, C.byref(cn))
     return occ, cn.as_dict()
 
 

@@ -221,7 +221,7 @@ PG_DEV bool bssrdf_probe_segment(const DBssrdf &b, V3 ss, V3 ts, V3 ns, V3 poP, 
     const float rMax = bssrdf_sample_sr(b, ch, 0.999f);
     if (r >= rMax) return false;
     const float l = 2 * sqrtf(rMax * rMax - r * r);
-    const float c = (float)cos((double)phi), sn = (float)sin((double)phi);
+    const float c = pg_cosf(phi), sn = pg_sinf(phi);
     baseP = (poP + (vx * c + vy * sn) * r) - (vz * l) * 0.5f;
     pTarget = baseP + vz * l;
     return true;

@@ -9,6 +9,7 @@
 #define PG_DEVICE_H
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "pg_libm.h"  // sinf / cosf / acosf / atan2f / logf / expf as the reference's libm computes them
 
 #define PG_DEV __device__ __forceinline__
 #define PG_HD __host__ __device__ inline
@@ -272,18 +273,16 @@ PG_DEV float scrambled_radical_inverse(uint32_t base, const uint16_t *perm, uint
     return pmin(invBaseN * ((float)reversedDigits + invBase * (float)perm[0] / (1 - invBase)), PG_ONE_MINUS_EPS);
 }
 
-// ConcentricSampleDisk, sampling.cpp:113-130.  The reference calls libm
-// cosf/sinf; evaluating in double and rounding once gives the correctly
-// rounded float, which is what glibc returns for all but a ~1e-3 fraction of
-// arguments (see DESIGN.md "libm").
+// ConcentricSampleDisk, sampling.cpp:113-130.  The reference calls libm's
+// cosf / sinf: pg_libm.h returns their bits.
 PG_DEV void concentric_sample_disk(float u0, float u1, float &dx, float &dy) {
     float ox = 2.f * u0 - 1, oy = 2.f * u1 - 1;
     if (ox == 0 && oy == 0) { dx = 0; dy = 0; return; }
     float theta, r;
     if (fabsf(ox) > fabsf(oy)) { r = ox; theta = PG_PIOVER4 * (oy / ox); }
     else { r = oy; theta = PG_PIOVER2 - PG_PIOVER4 * (ox / oy); }
-    double s, c;
-    sincos((double)theta, &s, &c);
+    float s, c;
+    pg_sincosf(theta, &s, &c);
     dx = r * (float)c;
     dy = r * (float)s;
 }

@@ -56,7 +56,7 @@ PG_DEV bool grid_enter(const PgDensityGrid &g, V3 ro, V3 rd, float rtMax, V3 &o,
     return true;
 }
 PG_DEV float grid_step(const PgDensityGrid &g, float u) {  // -log(1 - u) * invMaxDensity / sigma_t, log in double
-    return (float)log((double)(1 - u)) * g.inv_max_density / g.sigma_t;
+    return pg_logf((1 - u)) * g.inv_max_density / g.sigma_t;
 }
 // GridDensityMedium::Tr, grid.cpp:88-120: ratio tracking with Russian roulette below 0.1
 template <class Draw>

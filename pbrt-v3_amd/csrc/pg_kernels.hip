@@ -529,9 +529,9 @@ PG_DEV void camera_ray(const PgRenderDesc &rd, float pFilmX, float pFilmY, float
     if (rd.camera_type == 2) {  // EnvironmentCamera::GenerateRay, environment.cpp:43-56
         const float theta = PG_PI * pFilmY / rd.full_res[1];
         const float phi = 2 * PG_PI * pFilmX / rd.full_res[0];
-        double sT, cT, sP, cP;
-        sincos((double)theta, &sT, &cT);
-        sincos((double)phi, &sP, &cP);
+        float sT, cT, sP, cP;
+        pg_sincosf(theta, &sT, &cT);
+        pg_sincosf(phi, &sP, &cP);
         o = mk(0, 0, 0);
         d = mk((float)sT * (float)cP, (float)cT, (float)sT * (float)sP);
     }
@@ -1348,7 +1348,7 @@ PG_DEV void lobe_init(PgBxDF &b, int type) {
 PG_DEV void lobe_set(float *dst, Spec v) { dst[0] = v.r; dst[1] = v.g; dst[2] = v.b; }
 PG_DEV float roughness_to_alpha(float roughness) {  // microfacet.h:127-132; std::log evaluated in double, rounded once
     roughness = pmax(roughness, 1e-3f);
-    const float x = (float)log((double)roughness);
+    const float x = pg_logf(roughness);
     return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
 }
 PG_DEV void lobe_tr(PgBxDF &b, float ax, float ay) { b.alpha_x = pmax(0.001f, ax); b.alpha_y = pmax(0.001f, ay); }  // microfacet.h:109-113
@@ -1535,8 +1535,8 @@ PG_DEV LightSample sphere_sample(const PgSphere &s, V3 refp, V3 refErr, V3 refn,
         const float z = 1 - 2 * u0;  // UniformSampleSphere, sampling.cpp:98-103
         const float r = sqrtf(pmax(0.f, 1.f - z * z));
         const float phi = 2 * PG_PI * u1;
-        double sP, cP;
-        sincos((double)phi, &sP, &cP);
+        float sP, cP;
+        pg_sincosf(phi, &sP, &cP);
         V3 pObj = mk(r * (float)cP, r * (float)sP, z) * radius;
         it.n = normalize(m4_normal(s.w2o, pObj));
         if (s.reverse_orientation) it.n = it.n * -1.f;
@@ -1571,8 +1571,8 @@ PG_DEV LightSample sphere_sample(const PgSphere &s, V3 refp, V3 refErr, V3 refn,
     const float cosAlpha = sinTheta2 * invSinThetaMax + cosTheta * sqrtf(pmax(0.f, 1.f - sinTheta2 * invSinThetaMax * invSinThetaMax));
     const float sinAlpha = sqrtf(pmax(0.f, 1.f - cosAlpha * cosAlpha));
     const float phi = u1 * 2 * PG_PI;
-    double sP, cP;
-    sincos((double)phi, &sP, &cP);
+    float sP, cP;
+    pg_sincosf(phi, &sP, &cP);
     // SphericalDirection(sinAlpha, cosAlpha, phi, -wcX, -wcY, -wc), geometry.h:1461-1466
     const V3 nWorld = (-wcX) * (sinAlpha * (float)cP) + (-wcY) * (sinAlpha * (float)sP) + (-wc) * cosAlpha;
     const V3 pWorld = pCenter + nWorld * radius;
@@ -1590,8 +1590,8 @@ PG_DEV LightSample quadric_sample_area(const PgSphere &s, float u0, float u1, fl
     if (s.shape == PG_SHAPE_CYLINDER) {
         const float z = plerp(u0, s.z_min, s.z_max);
         const float phi = u1 * s.phi_max;
-        double sP, cP;
-        sincos((double)phi, &sP, &cP);
+        float sP, cP;
+        pg_sincosf(phi, &sP, &cP);
         V3 pObj = mk(s.radius * (float)cP, s.radius * (float)sP, z);
         it.n = normalize(m4_normal(s.w2o, mk(pObj.x, pObj.y, 0)));
         if (s.reverse_orientation) it.n = it.n * -1.f;
@@ -1686,7 +1686,7 @@ PG_DEV float env_sample_1d(const float *func, const float *cdf, float funcInt, i
 PG_DEV float env_pdf_li(const DScene &sc, const PgLight &l, V3 w) {  // InfiniteAreaLight::Pdf_Li, infinite.cpp:127-135; Distribution2D::Pdf, sampling.h:135-141
     V3 wi = mat3_mul(l.w2l, w);
     float theta = spherical_theta(wi), phi = spherical_phi(wi);
-    float sinTheta = (float)sin((double)theta);
+    float sinTheta = pg_sinf(theta);
     if (sinTheta == 0) return 0;
     float p0 = phi * PG_INV2PI, p1 = theta * PG_INVPI;
     const int nu = l.env_nu, nv = l.env_nv;
@@ -1714,9 +1714,9 @@ PG_DEV Spec light_sample_li(const DScene &sc, const PgLight &light, V3 refp, V3 
         pdf = 0;
         if (mapPdf == 0) return sp(0);
         float theta = d1 * PG_PI, phi = d0 * 2 * PG_PI;
-        double sT, cT, sP, cP;
-        sincos((double)theta, &sT, &cT);
-        sincos((double)phi, &sP, &cP);
+        float sT, cT, sP, cP;
+        pg_sincosf(theta, &sT, &cT);
+        pg_sincosf(phi, &sP, &cP);
         float cosTheta = (float)cT, sinTheta = (float)sT, sinPhi = (float)sP, cosPhi = (float)cP;
         wi = mat3_mul(light.l2w, mk(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta));
         pdf = mapPdf / (2 * PG_PI * PG_PI * sinTheta);
@@ -1846,7 +1846,7 @@ PG_DEV void spawn_ray(const Isect &is, V3 d, V3 &o) { o = offset_ray_origin(is.p
 // sinf / cosf are evaluated in double and rounded once, like every libm call of this file (DESIGN.md "libm").
 // ===========================================================================
 #define PG_MAX_FLOAT 3.40282346638528859811704183484516925e+38f
-PG_DEV Spec sp_exp(Spec a) { return sp3((float)exp((double)a.r), (float)exp((double)a.g), (float)exp((double)a.b)); }  // Exp(), spectrum.h:414-419
+PG_DEV Spec sp_exp(Spec a) { return sp3(pg_expf(a.r), pg_expf(a.g), pg_expf(a.b)); }  // Exp(), spectrum.h:414-419
 // HomogeneousMedium::Tr, homogeneous.cpp:44-47, for a ray with the given tMax and |d|
 PG_DEV Spec medium_tr(const PgMedium &m, float tMax, float dLen) {
     const Spec negSt = sp3(-m.sigma_t[0], -m.sigma_t[1], -m.sigma_t[2]);
@@ -1867,8 +1867,8 @@ PG_DEV float hg_sample_p(float g, V3 wo, V3 &wi, float u0, float u1) {  // Henye
     const float phi = 2 * PG_PI * u1;
     V3 v1, v2;
     coordinate_system(wo, v1, v2);
-    double sP, cP;
-    sincos((double)phi, &sP, &cP);
+    float sP, cP;
+    pg_sincosf(phi, &sP, &cP);
     wi = (v1 * (sinTheta * (float)cP) + v2 * (sinTheta * (float)sP)) + wo * cosTheta;  // SphericalDirection, geometry.h:1461-1466
     return phase_hg(cosTheta, g);
 }
@@ -1914,7 +1914,7 @@ PG_DEV void prim_interface(const DScene &sc, int prim, int rayMedium, int &mIn, 
 PG_DEV void homogeneous_sample_distance(const PgMedium &mm, float uChannel, float uDist, int &channel, float &dist) {
     channel = (int)(uChannel * 3);
     if (channel > 2) channel = 2;
-    dist = -(float)log((double)(1 - uDist)) / mm.sigma_t[channel];
+    dist = -pg_logf((1 - uDist)) / mm.sigma_t[channel];
 }
 struct GridShade { float4 *vertex; int phase; };  // vertex[slot] = (medium interaction point, kind: 0 none, 1 medium vertex, 2 surface vertex)
 template <int MODE, bool VOL, bool SSS = false, bool GRID = false>

@@ -134,7 +134,7 @@ PG_DEV V3 sphere_hit_point(const PgSphere &sp, V3 o, V3 d, float t, float &phi) 
     V3 pHit = o + d * t;
     pHit = pHit * (sp.radius / sqrtf(lensq(pHit)));
     if (pHit.x == 0 && pHit.y == 0) pHit.x = 1e-5f * sp.radius;
-    phi = (float)atan2((double)pHit.y, (double)pHit.x);
+    phi = pg_atan2f(pHit.y, pHit.x);
     if (phi < 0) phi += 2 * PG_PI;
     return pHit;
 }
@@ -207,13 +207,13 @@ PG_DEV SphereHit sphere_interaction_s(const PgSphere &sp, V3 ro, V3 rd, float tH
     const V3 pHit = sphere_hit_point(sp, o, d, tHit, phi);
     // sphere.cpp:108-124 (u, v, dndu, dndv feed only textures and ray differentials)
     const float cz = pHit.z / sp.radius;
-    const float theta = (float)acos((double)(cz < -1 ? -1.f : (cz > 1 ? 1.f : cz)));  // std::acos(Clamp(pHit.z / radius, -1, 1))
+    const float theta = pg_acosf((cz < -1 ? -1.f : (cz > 1 ? 1.f : cz)));  // std::acos(Clamp(pHit.z / radius, -1, 1))
     const float zRadius = sqrtf(pHit.x * pHit.x + pHit.y * pHit.y);
     const float invZRadius = 1 / zRadius;
     const float cosPhi = pHit.x * invZRadius;
     const float sinPhi = pHit.y * invZRadius;
     const V3 dpdu = mk(-sp.phi_max * pHit.y, sp.phi_max * pHit.x, 0);
-    const V3 dpdv = mk(pHit.z * cosPhi, pHit.z * sinPhi, -sp.radius * (float)sin((double)theta)) * (sp.theta_max - sp.theta_min);
+    const V3 dpdv = mk(pHit.z * cosPhi, pHit.z * sinPhi, -sp.radius * pg_sinf(theta)) * (sp.theta_max - sp.theta_min);
     const V3 pError = vabs(pHit) * pgamma(5);  // sphere.cpp:148
     const V3 d2Pduu = mk(pHit.x, pHit.y, 0) * (-sp.phi_max * sp.phi_max);
     const V3 d2Pduv = mk(-sinPhi, cosPhi, 0.f) * ((sp.theta_max - sp.theta_min) * pHit.z * sp.phi_max);
@@ -227,7 +227,7 @@ PG_DEV V3 cylinder_hit_point(const PgSphere &sp, V3 o, V3 d, float t, float &phi
     const float hitRad = sqrtf(pHit.x * pHit.x + pHit.y * pHit.y);
     pHit.x *= sp.radius / hitRad;
     pHit.y *= sp.radius / hitRad;
-    phi = (float)atan2((double)pHit.y, (double)pHit.x);
+    phi = pg_atan2f(pHit.y, pHit.x);
     if (phi < 0) phi += 2 * PG_PI;
     return pHit;
 }
@@ -280,7 +280,7 @@ PG_DEV bool disk_test(const PgSphere &sp, V3 ro, V3 rd, float tMax, float &tHit)
     const V3 pHit = o + d * tShapeHit;
     const float dist2 = pHit.x * pHit.x + pHit.y * pHit.y;
     if (dist2 > sp.radius * sp.radius || dist2 < sp.inner_radius * sp.inner_radius) return false;
-    float phi = (float)atan2((double)pHit.y, (double)pHit.x);
+    float phi = pg_atan2f(pHit.y, pHit.x);
     if (phi < 0) phi += 2 * PG_PI;
     if (phi > sp.phi_max) return false;
     tHit = tShapeHit;
@@ -294,7 +294,7 @@ PG_DEV SphereHit disk_interaction(const PgSphere &sp, V3 ro, V3 rd, float tHit) 
     const float rHit = sqrtf(dist2);
     const V3 dpdu = mk(-sp.phi_max * pHit.y, sp.phi_max * pHit.x, 0);
     const V3 dpdv = vdiv(mk(pHit.x, pHit.y, 0.f) * (sp.inner_radius - sp.radius), rHit);
-    float phi = (float)atan2((double)pHit.y, (double)pHit.x);
+    float phi = pg_atan2f(pHit.y, pHit.x);
     if (phi < 0) phi += 2 * PG_PI;
     pHit.z = sp.height;
     return quadric_finish(sp, d, pHit, mk(0, 0, 0), dpdu, dpdv, mk(0, 0, 0), mk(0, 0, 0), mk(0, 0, 0), phi / sp.phi_max, (sp.radius - rHit) / (sp.radius - sp.inner_radius));
@@ -339,8 +339,8 @@ PG_DEV bool quadric3_map(const PgSphere &sp, V3 o, V3 d, float t, V3 &pHit, floa
         const V3 p1 = mk(sp.p1[0], sp.p1[1], sp.p1[2]), p2 = mk(sp.p2[0], sp.p2[1], sp.p2[2]);
         v = (pHit.z - p1.z) / (p2.z - p1.z);
         const V3 pr = p1 * (1 - v) + p2 * v;
-        phi = (float)atan2((double)(pr.x * pHit.y - pHit.x * pr.y), (double)(pHit.x * pr.x + pHit.y * pr.y));
-    } else phi = (float)atan2((double)pHit.y, (double)pHit.x);
+        phi = pg_atan2f((pr.x * pHit.y - pHit.x * pr.y), (pHit.x * pr.x + pHit.y * pr.y));
+    } else phi = pg_atan2f(pHit.y, pHit.x);
     if (phi < 0) phi += 2 * PG_PI;
     const float zLo = sp.shape == PG_SHAPE_CONE ? 0.f : sp.z_min, zHi = sp.shape == PG_SHAPE_CONE ? sp.height : sp.z_max;
     return !(pHit.z < zLo || pHit.z > zHi || phi > sp.phi_max);
@@ -387,8 +387,8 @@ PG_DEV SphereHit quadric3_interaction(const PgSphere &sp, V3 ro, V3 rd, float tH
         d2Pduv = mk(-pHit.y / (2 * pHit.z), pHit.x / (2 * pHit.z), 0) * ((zMax - zMin) * phiMax);
         d2Pdvv = mk(pHit.x / (4 * pHit.z * pHit.z), pHit.y / (4 * pHit.z * pHit.z), 0) * (-(zMax - zMin) * (zMax - zMin));
     } else {  // hyperboloid.cpp:128-140
-        double sP, cP;
-        sincos((double)phi, &sP, &cP);
+        float sP, cP;
+        pg_sincosf(phi, &sP, &cP);
         const float cosPhi = (float)cP, sinPhi = (float)sP;
         const float ex = sp.p2[0] - sp.p1[0], ey = sp.p2[1] - sp.p1[1];
         dpdv = mk(ex * cosPhi - ey * sinPhi, ex * sinPhi + ey * cosPhi, sp.p2[2] - sp.p1[2]);

@@ -9,8 +9,8 @@
 PG_DEV float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }  // pbrt.h:305-311
 PG_DEV Spec sp_of(const float *c) { return sp3(c[0], c[1], c[2]); }
 #define PG_INV2PI 0.15915494309189533577f
-PG_DEV float spherical_theta(V3 v) { return (float)acos((double)clampf(v.z, -1, 1)); }  // geometry.h:1468-1470
-PG_DEV float spherical_phi(V3 v) { float p = (float)atan2((double)v.y, (double)v.x); return (p < 0) ? (p + 2 * PG_PI) : p; }  // :1472-1475
+PG_DEV float spherical_theta(V3 v) { return pg_acosf(clampf(v.z, -1, 1)); }  // geometry.h:1468-1470
+PG_DEV float spherical_phi(V3 v) { float p = pg_atan2f(v.y, v.x); return (p < 0) ? (p + 2 * PG_PI) : p; }  // :1472-1475
 // ===========================================================================
 // Textures (core/texture.{h,cpp}, textures/{scale,mix,checkerboard,uv,bilerp}.h) and the per-hit evaluation of a textured
 // material's ComputeScatteringFunctions.  Texture nodes reference their operands; the nesting is unrolled over a template
@@ -26,7 +26,7 @@ PG_DEV void tex_sphere(const PgTexture &t, V3 p, float &s0, float &s1) {  // Sph
 }
 PG_DEV void tex_cylinder(const PgTexture &t, V3 p, float &s0, float &s1) {  // CylindricalMapping2D::cylinder, texture.h:93-96
     const V3 vec = normalize(m4_point(t.w2t, p) - mk(0, 0, 0));
-    s0 = (PG_PI + (float)atan2((double)vec.y, (double)vec.x)) * PG_INV2PI; s1 = vec.z;
+    s0 = (PG_PI + pg_atan2f(vec.y, vec.x)) * PG_INV2PI; s1 = vec.z;
 }
 PG_DEV void tex_map2d(const PgTexture &t, const TexHit &h, float st[2], float dstdx[2], float dstdy[2]) {
     if (t.mapping == PG_MAP_UV) {  // UVMapping2D::Map, texture.cpp:93-100
@@ -72,7 +72,7 @@ PG_DEV Spec mip_triangle(const DScene &sc, const PgImage &im, int level, float s
     return mip_texel(sc, im, level, s0, t0) * ((1 - ds) * (1 - dt)) + mip_texel(sc, im, level, s0, t0 + 1) * ((1 - ds) * dt) +
            mip_texel(sc, im, level, s0 + 1, t0) * (ds * (1 - dt)) + mip_texel(sc, im, level, s0 + 1, t0 + 1) * (ds * dt);
 }
-PG_DEV float log2_pbrt(float x) { return (float)log((double)x) * 1.442695040888963387004650940071f; }  // pbrt.h:328-331
+PG_DEV float log2_pbrt(float x) { return pg_logf(x) * 1.442695040888963387004650940071f; }  // pbrt.h:328-331
 PG_DEV Spec mip_ewa(const DScene &sc, const PgImage &im, int level, float st0, float st1, float d00, float d01, float d10, float d11) {  // mipmap.h:276-327
     if (level >= im.n_levels) return mip_texel(sc, im, im.n_levels - 1, 0, 0);
     const int sRes = max(1, im.width >> level), tRes = max(1, im.height >> level);
@@ -230,7 +230,7 @@ PG_DEV Spec tex_marble(const DScene &sc, const PgTexture &t, const TexHit &h) { 
     const V3 dpdx = m4_vec(t.w2t, h.dpdx), dpdy = m4_vec(t.w2t, h.dpdy);
     p = p * t.noise_scale;
     const float marble = p.y + t.variation * noise_sum<false>(sc.noisePerm, p, dpdx * t.noise_scale, dpdy * t.noise_scale, t.omega, t.octaves);
-    float tt = .5f + .5f * (float)sin((double)marble);
+    float tt = .5f + .5f * pg_sinf(marble);
     const float c[9][3] = {{.58f, .58f, .6f}, {.58f, .58f, .6f}, {.58f, .58f, .6f}, {.5f, .5f, .5f}, {.6f, .59f, .58f},
                            {.58f, .58f, .6f}, {.58f, .58f, .6f}, {.2f, .2f, .33f}, {.58f, .58f, .6f}};
     int first = (int)floorf(tt * 6);  // NSEG = 6

@@ -34,8 +34,8 @@ def pkg():
 def oracle(pkg):
     """The CPU restatement (test infrastructure)."""
     from oracle import oracle as o
-    # keep both builds of the restatement in step with include/pbrt_gpu.h (a no-op when they are up to date)
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle.so", "liboracle_crlibm.so"])
+    # keep the restatement in step with include/pbrt_gpu.h (a no-op when they are up to date)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
     o.lib()
     return o
 

@@ -129,8 +129,8 @@ def test_quadric_intersect_equals_both_oracle_builds(dev, pkg, oracle, kind):
             os_.append(p2); ds.append(uniform_sample_sphere((rng.uniform_float(), rng.uniform_float())))
         os_, ds = np.asarray(os_, np.float32), np.asarray(ds, np.float32)
         tm = np.full(len(os_), np.inf, np.float32)
-        for cr in (False, True):
-            prim, t, _, _ = oracle.intersect(scene.desc, os_, ds, tm, cr_libm=cr)
+        for cr in (False,):  # (one oracle: the device computes libm as the reference does, pg_libm.h)
+            prim, t, _, _ = oracle.intersect(scene.desc, os_, ds, tm)
             for k in range(len(os_)):
                 th = np.zeros(1, np.float32)
                 h = dev.hostdev_quadric_test(C.addressof(sp), os_[k].ctypes.data, ds[k].ctypes.data, C.c_float(np.inf), th.ctypes.data)
@@ -226,7 +226,7 @@ def test_bxdf_library_equals_the_correctly_rounded_oracle(devk, pkg, oracle, kin
     """lobe_f / lobe_pdf / lobe_sample_f of the shading kernels (every BxDF of core/reflection.cpp the ABI carries) run on the host and
     compared bit for bit with the oracle's correctly-rounded-libm build -- the arithmetic the device is required to reproduce
     (tests/test_gpu_parity.py) -- on random parameters and directions of both hemispheres, grazing ones included."""
-    L = oracle.lib(cr_libm=True)
+    L = oracle.lib()
     rng = np.random.default_rng(100 + kind)
     nz = 0
     for trial in range(400):
@@ -272,7 +272,7 @@ def test_grid_medium_device_functions_equal_the_correctly_rounded_oracle(dev, pk
     g = d.grids[0]
     den = np.ctypeslib.as_array(d.grid_density, shape=(d.n_density_floats,))[g.density_offset:].copy()
     m2w = np.linalg.inv(np.array(list(g.world_to_medium), np.float64).reshape(4, 4))
-    L = oracle.lib(cr_libm=True)
+    L = oracle.lib()
     rng = np.random.default_rng(5)
     n_tr = n_hit = 0
     for trial in range(600):
@@ -331,7 +331,7 @@ def test_bssrdf_spatial_device_functions_equal_the_correctly_rounded_oracle(dev,
     scene = pkg.HostScene(text=text)
     d = scene.desc
     b = d.bssrdfs[0]
-    L = oracle.lib(cr_libm=True)
+    L = oracle.lib()
     rng = np.random.default_rng(21)
     n_ok = 0
     for trial in range(1500):
@@ -362,7 +362,7 @@ def test_bssrdf_spatial_device_functions_equal_the_correctly_rounded_oracle(dev,
 
 def test_bssrdf_adapter_f_equals_oracle(devk, pkg, oracle):
     """SeparableBSSRDFAdapter::f = Sw(wi) * eta^2 with the shading kernels' own FrDielectric against the oracle's adapter lobe."""
-    L = oracle.lib(cr_libm=True)
+    L = oracle.lib()
     rng = np.random.default_rng(31)
     for trial in range(2000):
         eta = np.float32(1.05 + 1.2 * rng.random())
@@ -378,7 +378,7 @@ def test_bssrdf_adapter_f_equals_oracle(devk, pkg, oracle):
 
 def test_henyey_greenstein_equals_the_correctly_rounded_oracle(devk, oracle):
     """phase_hg / hg_sample_p of the volpath kernels (HenyeyGreenstein::p / Sample_p) against the oracle, isotropic and both signs of g."""
-    L = oracle.lib(cr_libm=True)
+    L = oracle.lib()
     rng = np.random.default_rng(41)
     for trial in range(3000):
         g = np.float32([0.0, 5e-4, -0.9, 0.9][trial % 4] if trial % 5 == 0 else rng.uniform(-0.95, 0.95))
@@ -414,7 +414,7 @@ def test_camera_rays_equal_the_correctly_rounded_oracle(devk, pkg, oracle, golde
         pytest.skip(golden + " is not among the goldens")
     scene = pkg.HostScene(path)
     rd = scene.render_desc()
-    L = oracle.lib(cr_libm=True)
+    L = oracle.lib()
     rng = np.random.default_rng(61)
     fw, fh = rd.full_res[0], rd.full_res[1]
     for _ in range(2000):

@@ -129,6 +129,38 @@ def test_config2_cornell_quarter_size_vs_reference(gpu):
         assert abs(cn[k] - stats[k]) <= max(4, 2e-3 * stats[k]), (k, cn[k], stats[k])
 
 
+CONFIG0 = os.path.join(LARGE, "config0", "config0.pbrt")
+
+
+@pytest.mark.parametrize("order", ["reference", "free"])
+def test_config0_killeroo_simple_vs_reference(gpu, oracle, order, monkeypatch):
+    """BASELINE.json config 0: scenes/killeroo-simple.pbrt as the reference ships it (66 532 Loop-subdivided triangles, plastic,
+    uv'd planes, a SPHERE area light: every ray runs the quadric instantiation of k_trace) at 400x400 @ 8 spp, against the image
+    and the statistics of the unmodified reference binary (tests/golden_large/config0/, oracle/make_golden.py) and, bit for bit,
+    against the CPU restatement.  Twice: shadow rays in the reference's visiting order (its triangle-test statistic reproduced
+    exactly) and in the product's default free order (same film, same ray counts)."""
+    monkeypatch.setenv("PG_ANYHIT_ORDER", order)
+    scene = gpu.HostScene(CONFIG0)
+    assert scene.desc.n_spheres == 1 and scene.desc.n_tris == 66532 + 1  # (primitives: the sphere counts)
+    gs = gpu.GpuScene(scene.desc)
+    rd = scene.render_desc()
+    film, strays = gs.render(rd)
+    cn = gs.counters()
+    scene.film_clear(); scene.film_merge(rd, film, strays)
+    img = scene.film_image()
+    gs.close()
+    ref = gpu.read_pfm(os.path.join(LARGE, "config0", "config0.pfm"))
+    assert img.shape == ref.shape == (400, 400, 3)
+    assert np.array_equal(img, ref), f"{(img != ref).any(axis=2).sum()} pixels differ from the reference binary's image, max rel err {rel_err(img, ref).max():.3e}"
+    stats = json.load(open(os.path.join(LARGE, "config0", "config0.json")))
+    for k in ("camera_rays", "closest_rays", "shadow_rays") + (("tri_tests",) if order == "reference" else ()):
+        assert cn[k] == stats[k], (k, cn[k], stats[k])
+    ofilm, ostrays, ocn = oracle.render(scene.desc, rd)
+    assert np.array_equal(film["rgb"], ofilm["rgb"]) and np.array_equal(film["weight"], ofilm["weight"]) and len(strays) == len(ostrays)
+    if order == "reference":
+        assert cn["node_visits"] == ocn["node_visits"]
+
+
 def test_config2_cornell_full_size_properties(gpu):
     """Cornell box at its full 512x512 @ 256 spp: accounting, determinism and shard invariance."""
     scene = gpu.HostScene(os.path.join(ROOT, "scenes", "cornell.pbrt"))

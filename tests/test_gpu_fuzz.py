@@ -1,6 +1,6 @@
 """Differential fuzzing of the HIP path against the CPU oracle: seeded random scenes (triangle soups with degenerate, duplicate
 and extreme-scale triangles; every material, light type, filter and light strategy of the closed set; random cameras) and
-random rays.  Traversal results are compared bit for bit, film buffers within the image tolerance."""
+random rays.  Traversal results, film buffers, stray samples and counters are compared bit for bit, in the reference's shadow-ray order and in the product's default (free) order: 500 scenes."""
 import os
 import subprocess
 
@@ -10,7 +10,6 @@ import pytest
 from conftest import GOLD, ROOT
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-4
 
 
 def random_scene(seed, res=16, spp=4):
@@ -235,30 +234,30 @@ def random_scene_pixel_sampler(seed):
     return out
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(60))
 def test_random_scene_under_a_batched_pixel_sampler(gpu, oracle, seed):
     check_scene(gpu, oracle, random_scene_pixel_sampler(seed), seed)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(110))
 def test_random_scene_film_matches_oracle(gpu, oracle, seed):
     check_scene(gpu, oracle, random_scene(seed), seed)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(110))
 def test_random_extended_scene_film_matches_oracle(gpu, oracle, seed):
     check_scene(gpu, oracle, random_scene_ext(seed), seed)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(100))
 def test_random_volumetric_scene_film_matches_oracle(gpu, oracle, seed):
     check_scene(gpu, oracle, random_scene_vol(seed), seed)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(120))
 def test_random_sss_or_grid_scene_film_matches_oracle(gpu, oracle, seed):
     """Subsurface materials (odd seeds) or a GridDensityMedium (even seeds) mixed into the random scenes: BSSRDF probe chains through
-    random soups, ratio tracking through random grids -- against the oracle and, bit for bit, its correctly-rounded build."""
+    random soups, ratio tracking through random grids -- against the oracle, bit for bit."""
     check_scene(gpu, oracle, random_scene_sss_grid(seed, "sss" if seed % 2 else "grid"), seed)
 
 
@@ -273,23 +272,38 @@ def test_grid_scene_keeps_the_specular_flag_across_a_material_less_surface(gpu, 
 
 def check_scene(gpu, oracle, text, seed):
     scene = gpu.HostScene(text=text)
-    gs = gpu.GpuScene(scene.desc)
+    gs = gpu.GpuScene(scene.desc)  # (tests/conftest.py: shadow rays in the reference's visiting order)
     rd = scene.render_desc()
     film, strays = gs.render(rd)
     cn = gs.counters()
+    # the CPU restatement (pinned against the reference binary): film, stray samples and every counter bit for bit
     ofilm, ostrays, ocn = oracle.render(scene.desc, rd)
     assert np.array_equal(film["weight"], ofilm["weight"])
-    scale = max(1.0, float(np.abs(ofilm["rgb"]).max()) / rd.spp)
-    assert np.abs(film["rgb"] - ofilm["rgb"]).max() <= TOL * rd.spp * scale
-    assert len(strays) == len(ostrays)
-    assert cn["camera_rays"] == ocn["camera_rays"]
-    for k in ("closest_rays", "shadow_rays"):  # a last-ulp sin/cos difference may add or remove a handful of rays
-        assert abs(cn[k] - ocn[k]) <= max(4, 2e-3 * ocn[k]), (k, cn[k], ocn[k])
-    # against the oracle built with correctly rounded libm (= the device's libm behaviour): bit for bit, counters included
-    cfilm, cstrays, ccn = oracle.render(scene.desc, rd, cr_libm=True)
-    assert np.array_equal(film["rgb"], cfilm["rgb"]), f"{(film['rgb'] != cfilm['rgb']).any(axis=1).sum()} pixels differ from the correctly-rounded oracle"
-    for k in ("closest_rays", "shadow_rays", "tri_tests", "node_visits"):
-        assert cn[k] == ccn[k], (k, cn[k], ccn[k])
+    assert np.array_equal(film["rgb"], ofilm["rgb"]), f"{(film['rgb'] != ofilm['rgb']).any(axis=1).sum()} pixels differ from the oracle"
+    key = lambda s: np.lexsort((s["src_px"], s["src_py"], s["px"], s["py"]))
+    a, b = strays[key(strays)], ostrays[key(ostrays)]
+    assert len(a) == len(b)
+    for f in ("px", "py", "src_px", "src_py", "weight", "rgb"):
+        assert np.array_equal(a[f], b[f]), f
+    for k in ("camera_rays", "closest_rays", "shadow_rays", "tri_tests", "node_visits"):
+        assert cn[k] == ocn[k], (k, cn[k], ocn[k])
+    # the PRODUCT'S DEFAULT: shadow rays in free order (k_trace<2, .>: the child the ray enters first).  Same occlusion answers, so the
+    # same film, strays and ray counts; only the two statistics that count what a traversal read (triangle tests, node visits) may differ.
+    saved = os.environ.pop("PG_ANYHIT_ORDER", None)
+    try:
+        gf = gpu.GpuScene(scene.desc)
+    finally:
+        if saved is not None: os.environ["PG_ANYHIT_ORDER"] = saved
+    ffilm, fstrays = gf.render(rd)
+    fcn = gf.counters()
+    gf.close()
+    assert np.array_equal(ffilm["rgb"], ofilm["rgb"]) and np.array_equal(ffilm["weight"], ofilm["weight"]), "free-order shadow rays changed the film"
+    c = fstrays[key(fstrays)]
+    assert len(c) == len(b)
+    for f in ("px", "py", "src_px", "src_py", "weight", "rgb"):
+        assert np.array_equal(c[f], b[f]), f
+    for k in ("camera_rays", "closest_rays", "shadow_rays"):
+        assert fcn[k] == ocn[k], (k, fcn[k], ocn[k])
     # rays through the same soup: bit-exact, including the reference's counters
     rng = np.random.default_rng(1000 + seed)
     n = 4096
@@ -322,4 +336,4 @@ def test_cli_end_to_end(gpu, tmp_path):
         assert r.returncode == 0, r.stderr
         img, ref = gpu.read_pfm(str(out)), gpu.read_pfm(os.path.join(GOLD, name + ".pfm"))
         assert img.shape == ref.shape
-        assert (np.abs(img - ref) / np.maximum(1, np.abs(ref))).max() <= TOL, name
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), name  # the reference binary's file, bit for bit

@@ -317,9 +317,9 @@ def _reintersect_convex(pkg, oracle, shape_text, rng, n_out=150, device=None):
         lib.oracle_spawn_ray_origin(p.ctypes.data, perr.ctypes.data, n.ctypes.data, w.ctypes.data, orig.ctypes.data)
         os_.append(orig.copy()); ds.append(w); tm.append(1 - 0.0001)  # SpawnRayTo: tMax = 1 - ShadowEpsilon
     os_, ds, tm = np.asarray(os_, np.float32), np.asarray(ds, np.float32), np.asarray(tm, np.float32)
-    for cr in (False, True):
-        prim, _, _, _ = oracle.intersect(scene.desc, os_, ds, tm, cr_libm=cr)
-        occ, _ = oracle.intersect_p(scene.desc, os_, ds, tm, cr_libm=cr)
+    for cr in (False,):  # (one oracle: the device computes libm as the reference does, pg_libm.h)
+        prim, _, _, _ = oracle.intersect(scene.desc, os_, ds, tm)
+        occ, _ = oracle.intersect_p(scene.desc, os_, ds, tm)
         assert (prim < 0).all() and not occ.any()
     if device is not None:
         gs = device.GpuScene(scene.desc)

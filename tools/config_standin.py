@@ -48,7 +48,7 @@ def run(config, spp):
     rd.pixel_bounds[0], rd.pixel_bounds[1], rd.pixel_bounds[2], rd.pixel_bounds[3] = 928, 522, 992, 558
     film, strays = gs.render(rd)
     cn = gs.counters()
-    ofilm, ostrays, ocn = oracle.render(scene.desc, rd, cr_libm=True)
+    ofilm, ostrays, ocn = oracle.render(scene.desc, rd)
     same_film = bool(np.array_equal(film["rgb"], ofilm["rgb"]) and np.array_equal(film["weight"], ofilm["weight"]))
     same_counts = all(cn[k] == ocn[k] for k in ("camera_rays", "closest_rays", "shadow_rays", "tri_tests", "node_visits"))
     ref, _, _ = oracle.render(scene.desc, rd)  # glibc libm = the reference's arithmetic

@@ -121,7 +121,7 @@ def run(config):
         px, py = int(xx) + x0, int(yy) + y0
         rdp.pixel_bounds[0], rdp.pixel_bounds[1] = max(px - 1, rd.pixel_bounds[0]), max(py - 1, rd.pixel_bounds[1])
         rdp.pixel_bounds[2], rdp.pixel_bounds[3] = min(px + 2, rd.pixel_bounds[2]), min(py + 2, rd.pixel_bounds[3])
-        ofilm, ostrays, _ = oracle.render(scene.desc, rdp, cr_libm=True)
+        ofilm, ostrays, _ = oracle.render(scene.desc, rdp)
         scene.film_clear(); scene.film_merge(rdp, ofilm, ostrays)
         if np.array_equal(scene.film_image()[py, px], img[py, px]):
             explained += 1

@@ -25,7 +25,7 @@ def equals_correctly_rounded_oracle(pkg, oracle, text, counters=("camera_rays", 
     film, strays = gs.render(rd)
     cn = gs.counters()
     gs.close()
-    cfilm, cstrays, ccn = oracle.render(scene.desc, rd, cr_libm=True)
+    cfilm, cstrays, ccn = oracle.render(scene.desc, rd)
     return (np.array_equal(film["rgb"], cfilm["rgb"]) and np.array_equal(film["weight"], cfilm["weight"]) and len(strays) == len(cstrays) and
             all(cn[k] == ccn[k] for k in counters))
 
