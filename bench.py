@@ -46,7 +46,16 @@ EMULATED = os.environ.get("PBRT_EMULATED_DEVICE") == "1"  # tests/emu: the devic
 def make_scene_file(workdir, args):
     import gen_synthetic
     path = os.path.join(workdir, "synthetic.pbrt")
-    if args.workload == "cornell":
+    if args.workload == "config0":  # BASELINE config 0: the reference's own scenes/killeroo-simple.pbrt (fixture: tests/golden_large/config0)
+        import shutil
+        src = os.path.join(ROOT, "tests", "golden_large", "config0")
+        os.makedirs(os.path.join(workdir, "geometry"), exist_ok=True)
+        shutil.copy(os.path.join(src, "geometry", "killeroo.pbrt"), os.path.join(workdir, "geometry", "killeroo.pbrt"))
+        txt = open(os.path.join(src, "config0.pbrt")).read()
+        txt = (txt.replace('"integer xresolution" [400]', f'"integer xresolution" [ {args.xres} ]').replace('"integer yresolution" [400]', f'"integer yresolution" [ {args.yres} ]')
+                  .replace('"integer pixelsamples" [8]', f'"integer pixelsamples" [ {args.spp} ]'))
+        open(path, "w").write(txt)
+    elif args.workload == "cornell":
         txt = open(os.path.join(ROOT, "scenes", "cornell.pbrt")).read()
         txt = (txt.replace('"integer xresolution" [ 512 ]', f'"integer xresolution" [ {args.xres} ]')
                   .replace('"integer yresolution" [ 512 ]', f'"integer yresolution" [ {args.yres} ]')
@@ -70,51 +79,88 @@ def make_scene_file(workdir, args):
     return path
 
 
-def cpu_baseline(workdir, args):
-    """The unmodified reference (oracle/_ref/pbrt_oracle) on the host cores, bounded sample of the same workload."""
-    ref = os.path.join(ROOT, "oracle", "_ref", "pbrt_oracle")
-    cores = os.cpu_count() or 1
-    model = "unknown CPU"
+def host_cpus():
+    """What this process may actually use: logical CPUs, its affinity mask, the cgroup CPU quota (v2 cpu.max / v1 cfs_quota_us)."""
+    info = {"logical": os.cpu_count() or 1, "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None, "cgroup_quota_cpus": None,
+            "model": "unknown CPU"}
     try:
         for line in open("/proc/cpuinfo"):
             if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
+                info["model"] = line.split(":", 1)[1].strip()
                 break
     except OSError:
         pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max": info["cgroup_quota_cpus"] = round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0: info["cgroup_quota_cpus"] = round(q / per, 2)
+        except (OSError, ValueError):
+            pass
+    usable = info["affinity"] or info["logical"]
+    if info["cgroup_quota_cpus"]: usable = max(1, min(usable, int(info["cgroup_quota_cpus"] + 0.5)))
+    info["usable"] = usable
+    return info
+
+
+def cpu_baseline(workdir, args):
+    """The unmodified reference (oracle/_ref/pbrt_oracle) on the host cores, bounded samples of the same workload: a thread sweep
+    (1 / 16 / 64 / all usable CPUs, a few seconds each: the rate per thread and how it scales can be read from the line), then the
+    whole frame at a quarter of the samples per pixel with the best thread count, which is `value`."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "pbrt_oracle")
+    cpus = host_cpus()
+    usable, model = cpus["usable"], cpus["model"]
+    src0 = open(os.path.join(workdir, "synthetic.pbrt")).read()
+
+    def reference_run(nthreads, xres, yres, spp, timeout):
+        src = re.sub(r'"integer xresolution" \[ ?\d+ ?\]', f'"integer xresolution" [ {xres} ]', src0)
+        src = re.sub(r'"integer yresolution" \[ ?\d+ ?\]', f'"integer yresolution" [ {yres} ]', src)
+        src = re.sub(r'"integer pixelsamples" \[ ?\d+ ?\]', f'"integer pixelsamples" [ {spp} ]', src)
+        small = os.path.join(workdir, "cpu_sample.pbrt")
+        open(small, "w").write(src)
+        out = subprocess.run([ref, "--nthreads", str(nthreads), "--outfile", os.path.join(workdir, "cpu.pfm"), small],
+                             capture_output=True, text=True, timeout=timeout).stdout
+        reg = int(re.search(r"Regular ray intersection tests\s+(\d+)", out).group(1))
+        m = re.search(r"Shadow ray intersection tests\s+(\d+)", out)
+        sh = int(m.group(1)) if m else 0
+        secs = float(re.findall(r"\((\d+\.\d+)s\)", out)[-1])  # ProgressReporter's final elapsed time = time in Render()
+        return reg + sh, secs
+
     # the whole frame at a quarter of the samples per pixel (the rate does not depend on spp): every one of the 8160 tiles
     # is rendered, so the reference's thread pool is loaded as in the full job; --cpu-full renders all samples
     xres, yres, spp = args.xres, args.yres, (args.spp if args.cpu_full else max(1, args.spp // 4))
-    sample = f"same scene, {xres}x{yres} @ {spp} spp ({xres * yres * spp / 1e6:.2f} Msamples) on {model}"
     if os.path.exists(ref):
-        src = open(os.path.join(workdir, "synthetic.pbrt")).read()
-        src = re.sub(r'"integer xresolution" \[ \d+ \]', f'"integer xresolution" [ {xres} ]', src)
-        src = re.sub(r'"integer yresolution" \[ \d+ \]', f'"integer yresolution" [ {yres} ]', src)
-        src = re.sub(r'"integer pixelsamples" \[ \d+ \]', f'"integer pixelsamples" [ {spp} ]', src)
-        small = os.path.join(workdir, "cpu_sample.pbrt")
-        open(small, "w").write(src)
         try:
-            out = subprocess.run([ref, "--nthreads", str(cores), "--outfile", os.path.join(workdir, "cpu.pfm"), small],
-                                 capture_output=True, text=True, timeout=1500).stdout
-            reg = int(re.search(r"Regular ray intersection tests\s+(\d+)", out).group(1))
-            sh = int(re.search(r"Shadow ray intersection tests\s+(\d+)", out).group(1))
-            secs = float(re.findall(r"\((\d+\.\d+)s\)", out)[-1])  # ProgressReporter's final elapsed time = time in Render()
+            sweep = {}
+            counts = sorted({n for n in (1, 16, 64, usable) if n <= usable})
+            for n in counts:
+                # sized for seconds: one thread gets a quarter-size frame at 1 spp, the others the whole frame at 1 spp (<= 16 threads) or 4
+                sx, sy, sspp = (max(64, xres // 2), max(64, yres // 2), 1) if n == 1 else (xres, yres, 1 if n <= 16 else min(4, spp))
+                rays, secs = reference_run(n, sx, sy, sspp, 600)
+                if secs > 0: sweep[n] = {"mrays_per_s": round(rays / secs / 1e6, 3), "per_thread": round(rays / secs / 1e6 / n, 4), "sample": f"{sx}x{sy} @ {sspp} spp, {secs:.1f} s"}
+            best = max(sweep, key=lambda n: sweep[n]["mrays_per_s"]) if sweep else usable
+            rays, secs = reference_run(best, xres, yres, spp, 1500)
             if secs > 0:
-                return {"value": (reg + sh) / secs / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "reference",
-                        "sample": sample + f"; {reg + sh} rays in {secs:.1f} s of Integrator::Render()"}
+                return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": best, "kind": "reference",
+                        "host": {"cpu_model": model, "logical_cpus": cpus["logical"], "affinity_cpus": cpus["affinity"], "cgroup_quota_cpus": cpus["cgroup_quota_cpus"]},
+                        "thread_sweep": {str(n): v for n, v in sweep.items()},
+                        "sample": f"same scene, {xres}x{yres} @ {spp} spp ({xres * yres * spp / 1e6:.2f} Msamples) on {model}, --nthreads {best} (the fastest of the sweep; "
+                                  f"`cores` = threads used); {rays} rays in {secs:.1f} s of Integrator::Render()"}
         except Exception as e:  # fall through to the port
             sys.stderr.write(f"bench: reference CPU run failed ({e}); timing the C port instead\n")
     from oracle import oracle
     pkg = load_package()
-    src = open(os.path.join(workdir, "synthetic.pbrt")).read()
-    scene = pkg.HostScene(filename=os.path.join(workdir, "cpu_sample.pbrt")) if os.path.exists(os.path.join(workdir, "cpu_sample.pbrt")) \
-        else pkg.HostScene(text=src)
+    src = re.sub(r'"integer pixelsamples" \[ ?\d+ ?\]', f'"integer pixelsamples" [ {spp} ]', src0)
+    open(os.path.join(workdir, "cpu_sample.pbrt"), "w").write(src)
+    scene = pkg.HostScene(filename=os.path.join(workdir, "cpu_sample.pbrt"))
     rd = scene.render_desc()
     t0 = time.time()
     _, _, cn = oracle.render(scene.desc, rd)
     secs = time.time() - t0
-    return {"value": (cn["closest_rays"] + cn["shadow_rays"]) / secs / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": sample}
+    return {"value": (cn["closest_rays"] + cn["shadow_rays"]) / secs / 1e6, "unit": "Mrays/s", "cores": usable, "kind": "port",
+            "sample": f"same scene, {xres}x{yres} @ {spp} spp on {model} (OpenMP, {usable} threads)"}
 
 
 def self_launch(args):
@@ -240,7 +286,8 @@ def run_workload(ctx, args, steps, warmup, keep_image=False):
 
 def describe(args, scene):
     integ = "VolPathIntegrator + HomogeneousMedium" if args.workload.endswith("-vol") else "PathIntegrator"
-    what = {"cornell": "Cornell box, 36 triangles"}.get(args.workload)
+    what = {"cornell": "Cornell box, 36 triangles",
+            "config0": "scenes/killeroo-simple.pbrt of the reference (66 532 Loop-subdivided triangles, plastic + matte, one sphere area light)"}.get(args.workload)
     if what is None:
         d = scene.desc
         if args.workload.startswith("divergent"):
@@ -374,21 +421,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="synthetic", choices=["synthetic", "synthetic-vol", "cornell", "divergent", "divergent-vol"],
+    ap.add_argument("--workload", default="synthetic", choices=["synthetic", "synthetic-vol", "cornell", "divergent", "divergent-vol", "config0"],
                     help="synthetic: BASELINE config 3 (with --grid 1582: the 5 M-triangle HBM-regime stand-in); synthetic-vol (--grid 2237 "
                          "--spp 128): 10 M triangles in fog under volpath; cornell: config 2; divergent / divergent-vol (--tris 5000000 / "
                          "10000000): configs 4 / 5 as instanced PLY meshes with textures, alpha masks and a material palette")
     ap.add_argument("--grid", type=int, default=708, help="heightfield vertices per side (708 -> 999 698 triangles)")
     ap.add_argument("--tris", type=int, default=5000000, help="divergent workloads: instanced triangle count to reach")
-    ap.add_argument("--xres", type=int, default=1920)
-    ap.add_argument("--yres", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--xres", type=int, default=None, help="default 1920 (config0: 400)")
+    ap.add_argument("--yres", type=int, default=None, help="default 1080 (config0: 400)")
+    ap.add_argument("--spp", type=int, default=None, help="default 64 (config0: 8)")
     ap.add_argument("--filter", default="box", help='PixelFilter of the scene (BASELINE config: "box")')
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline renders every sample of the frame (minutes)")
     ap.add_argument("--no-hbm-regime", action="store_true", help="skip the 3 extra frames of the 5 M-triangle workload behind roofline.hbm_regime")
     ap.add_argument("--out", default=None, help="write the rendered image (PFM) here")
     args = ap.parse_args()
+    dx, dy, dspp = (400, 400, 8) if args.workload == "config0" else (1920, 1080, 64)
+    args.xres, args.yres, args.spp = args.xres or dx, args.yres or dy, args.spp or dspp
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)

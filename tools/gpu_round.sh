@@ -14,10 +14,15 @@ prof() {  # prof NAME bench-args...: kernel-trace stats of one bench run
   find $OUT/prof_$name -name '*kernel_stats*' -exec cp {} $OUT/kernel_stats_$name.csv \;
   rm -rf $OUT/prof_$name
 }
-[ "$SKIP_TESTS" = 1 ] && echo 'tests skipped (SKIP_TESTS=1)' > $OUT/pytest_gpu.log || ( PBRT_SKIP_SLOW=1 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 ) > $OUT/pytest_gpu.log
+[ "$SKIP_TESTS" = 1 ] && echo 'tests skipped (SKIP_TESTS=1)' > $OUT/pytest_gpu.log || ( PBRT_SKIP_SLOW=1 timeout 1800 python -m pytest tests -m gpu -x -q --durations=12 2>&1 | tail -45 ) > $OUT/pytest_gpu.log
 ( timeout 900 python bench.py --steps 3 --warmup 1 2> $OUT/bench.err ) > $OUT/bench.json
 prof cfg3
 tail -5 $OUT/pytest_gpu.log; cat $OUT/bench.json; head -8 $OUT/kernel_stats_cfg3.csv
+# BASELINE config 0 (the reference's own killeroo-simple.pbrt: a sphere light -> the quadric instantiation of k_trace), at its 400x400 @ 8 spp and at 64 spp
+( timeout 300 python bench.py --workload config0 --steps 5 --warmup 2 2> $OUT/bench_config0.err ) > $OUT/bench_config0.json; cut -c1-400 $OUT/bench_config0.json
+( timeout 300 python bench.py --workload config0 --spp 64 --steps 3 --warmup 1 --no-cpu-baseline 2> $OUT/bench_config0_64spp.err ) > $OUT/bench_config0_64spp.json; cut -c1-300 $OUT/bench_config0_64spp.json
+prof config0 --workload config0 --spp 64
+head -6 $OUT/kernel_stats_config0.csv
 if [ "$MODE" != quick ]; then
   bash tools/pmc_traffic.sh $TAG/traffic_cfg3 > $OUT/traffic_cfg3.log 2>&1
   cp $OUT/traffic_cfg3/pmc_traffic.json profiles/pmc_traffic.json 2>/dev/null
