@@ -555,13 +555,18 @@ int pg_render(PgScene *scene, const PgRenderDesc *desc, PgFilmPixel *film,
 /* The frame sharded over n devices of one node from ONE host process -- what main/pbrt.cpp:94-100 + tools/imgtool.cpp:190-285
  * do across machines with crop windows.  scenes[r] is the scene created on device r (pg_set_device + pg_scene_create, the
  * same PgSceneDesc everywhere); desc describes the whole frame (tile_first = 0, tile_step = 1).  One host thread per
- * device renders the tiles t = r (mod n) of the full-frame tiling into a buffer on its own device; the shards are then
- * gathered on scenes[0]'s device with peer-to-peer copies (xGMI) and come back to the host in one transfer:
+ * device renders the tiles t = r (mod n) of the full-frame tiling into a packed shard [film | strays | count] on its own
+ * device; the shards are then gathered on scenes[0]'s device by ONE ncclGather (RCCL over xGMI, rccl.h:745; librccl is opened
+ * on first use) and come back to the host in one transfer:
  * film[r] receives rank r's tile_pixels * pg_render_tile_count(rank r's desc) pixels, strays[r] / n_strays[r] its stray
  * samples (max_strays entries each).  Rendering rank r alone with pg_render(tile_first = r, tile_step = n) gives the same
- * bytes.  Device ids may repeat (several shards on one GPU: a functional check on a single-GPU box).                    */
+ * bytes.  Device ids may repeat (several shards on one GPU: a functional check on a single-GPU box): RCCL wants one rank
+ * per GPU, so such a list -- like a box without librccl, or PG_SHARD_GATHER=peer -- is gathered with one peer-to-peer copy
+ * per rank into the same layout.  PG_SHARD_GATHER=rccl makes the absence of RCCL an error instead.                     */
 int pg_render_sharded(PgScene *const *scenes, int32_t n, const PgRenderDesc *desc, PgFilmPixel *const *film,
                       PgStraySample *const *strays, int32_t max_strays, int32_t *n_strays);
+/* How the last pg_render_sharded of this process gathered: "rccl", "peer (<why RCCL was not used>)", or "none".          */
+const char *pg_shard_transport(void);
 
 /* Batched Scene::Intersect: rays as SoA (ox..dz, tmax), n rays.  Outputs
  * prim (-1 = miss), t, b0, b1, b2 (barycentrics exactly as computed by

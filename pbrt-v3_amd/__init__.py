@@ -249,7 +249,8 @@ class GpuScene:
 
 def render_sharded(gpu_scenes, rd, max_strays=None):
     """pg_render_sharded: the frame of rd (tile_first 0, tile_step 1) over the devices of gpu_scenes -- one host thread per
-    device, shards gathered peer-to-peer on the first device.  Returns [(shard rd, film, strays)] per rank."""
+    device, the packed shards gathered on the first device by one ncclGather (RCCL) or, where RCCL cannot run, peer copies
+    (shard_transport() tells which).  Returns [(shard rd, film, strays)] per rank."""
     n = len(gpu_scenes)
     shards = []
     for r in range(n):
@@ -267,6 +268,11 @@ def render_sharded(gpu_scenes, rd, max_strays=None):
     ns = (C.c_int32 * n)()
     _check(gpu_lib().pg_render_sharded(handles, n, C.byref(rd), fptr, sptr, max_strays, ns), "pg_render_sharded")
     return [(shards[r], films[r], strays[r][:ns[r]]) for r in range(n)]
+
+
+def shard_transport():
+    """How the last render_sharded gathered: "rccl" or "peer (<reason>)"."""
+    return gpu_lib().pg_shard_transport().decode()
 
 
 def render_scene(scene, device=0):

@@ -176,6 +176,7 @@ GPU_SYMBOLS = {
                             C.c_void_p, C.c_int, C.c_void_p]),
     "pg_render_sharded": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(PgRenderDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                     C.c_int32, C.POINTER(C.c_int32)]),
+    "pg_shard_transport": (C.c_char_p, []),
     "pg_intersect": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_int, C.c_void_p]),
     "pg_intersect_p": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

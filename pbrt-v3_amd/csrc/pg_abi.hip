@@ -8,7 +8,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <functional>
+#include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -83,7 +86,7 @@ struct PgScene {
     DeviceBuffer cmaxmin, tsState, ts1, ts2;  // tile-serial samplers: CMaxMinDist, the tiles' sampler states and sample arrays
     DeviceBuffer voxelSlot, voxelRequests, voxelCounters, retryList;  // sparse "spatial" light tables (DScene::sparseLights)
     int poolSlots = 0, poolUsed = 0, nVoxelsTotal = 0;
-    DeviceBuffer shardFilm, shardStrays, shardCount, gatherDev;  // pg_render_sharded: this device's shard; on rank 0's device the gathered frame
+    DeviceBuffer shardFilm, gatherDev;  // pg_render_sharded: this device's packed shard [film | strays | count]; on rank 0's device the gathered frame
     int qsCapacity = 0;
 };
 
@@ -1536,10 +1539,64 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
     return PG_OK;
 }
 
+// ---- the film gather of pg_render_sharded over RCCL (ncclGather, rccl.h:745) ---------------------------------------
+// librccl is opened on the first multi-device render (a single-device process never pays for loading it); one communicator per
+// device list, kept for the life of the process.  Every rank sends ONE packed shard [film | strays | count] of the same size (the
+// largest shard's: tile counts differ by at most one), the first device receives n of them in rank order.
+#ifndef HIP_EMU_H
+namespace {
+typedef struct ncclComm *PgNcclComm;
+struct Rccl {
+    int (*CommInitAll)(PgNcclComm *, int, const int *) = nullptr;
+    int (*Gather)(const void *, void *, size_t, int, int, PgNcclComm, hipStream_t) = nullptr;  // ncclGather, rccl.h:745
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) { r.why = std::string("librccl not found: ") + dlerror(); return; }
+        r.CommInitAll = (decltype(r.CommInitAll))dlsym(h, "ncclCommInitAll");
+        r.Gather = (decltype(r.Gather))dlsym(h, "ncclGather");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+        r.ok = r.CommInitAll && r.Gather && r.GetErrorString;
+        if (!r.ok) r.why = "librccl lacks ncclCommInitAll / ncclGather";
+    });
+    return r;
+}
+std::mutex g_commMutex;
+std::map<std::vector<int>, std::vector<PgNcclComm>> g_comms;
+// communicators of this device list, or null with the reason in `why` (then the caller gathers with peer copies)
+const std::vector<PgNcclComm> *shardComms(const std::vector<int> &devices, std::string &why) {
+    std::vector<int> sorted = devices;
+    std::sort(sorted.begin(), sorted.end());
+    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) { why = "a device appears twice in the list (RCCL wants one rank per GPU)"; return nullptr; }
+    Rccl &r = rccl();
+    if (!r.ok) { why = r.why; return nullptr; }
+    std::lock_guard<std::mutex> lock(g_commMutex);
+    auto it = g_comms.find(devices);
+    if (it != g_comms.end()) return &it->second;
+    std::vector<PgNcclComm> comms(devices.size(), nullptr);
+    const int st = r.CommInitAll(comms.data(), (int)devices.size(), devices.data());
+    if (st != 0) { why = std::string("ncclCommInitAll: ") + r.GetErrorString(st); return nullptr; }
+    return &(g_comms[devices] = comms);
+}
+}  // namespace
+#endif
+static std::string g_shardTransport = "none";
+// "rccl" / "peer" (+ why RCCL was not used): how the last pg_render_sharded of this process gathered its shards
+const char *pg_shard_transport(void) { return g_shardTransport.c_str(); }
+
 // ---- one frame over several devices of the node, from one host process ---------------------------------------------------------
-// One host thread per device (pg_set_device is per thread); every thread renders its tiles into a buffer on its own device and
-// pushes the shard to the gathering device with a peer-to-peer copy (xGMI, once peer access is enabled; staged through the
-// host otherwise).  No per-bounce communication, no reduction: tiles are disjoint.
+// One host thread per device (pg_set_device is per thread); every thread renders its tiles into a packed shard on its own device,
+// then ONE ncclGather (RCCL over xGMI) brings the n shards to the first device -- or, where RCCL cannot run (a device that repeats
+// in the list, no librccl, PG_SHARD_GATHER=peer), one peer-to-peer copy per rank into the same layout.  No per-bounce
+// communication, no reduction: tiles are disjoint.
 int pg_render_sharded(PgScene *const *scenes, int32_t n, const PgRenderDesc *desc, PgFilmPixel *const *film, PgStraySample *const *strays,
                       int32_t maxStrays, int32_t *nStrays) {
     if (!scenes || n < 1 || !desc || !film || !nStrays || (maxStrays > 0 && !strays)) return setError(PG_ERR_INVALID, "pg_render_sharded: null argument");
@@ -1548,28 +1605,48 @@ int pg_render_sharded(PgScene *const *scenes, int32_t n, const PgRenderDesc *des
     PgScene *root = scenes[0];
     const size_t strayBytes = sizeof(PgStraySample) * (size_t)(maxStrays > 0 ? maxStrays : 1);
     std::vector<PgRenderDesc> rd((size_t)n, *desc);
-    std::vector<size_t> filmBytes((size_t)n), filmOff((size_t)n);
-    size_t total = 0;
+    std::vector<size_t> filmBytes((size_t)n);
+    size_t filmMax = sizeof(PgFilmPixel);  // never an empty buffer, also when no rank owns a tile
     for (int r = 0; r < n; ++r) {
         rd[r].tile_first = r; rd[r].tile_step = n;
         filmBytes[r] = sizeof(PgFilmPixel) * (size_t)desc->tile_pixels * (size_t)tileCount(&rd[r]);
-        filmOff[r] = total; total += filmBytes[r];
+        filmMax = std::max(filmMax, filmBytes[r]);
         // a rank that owns no tile (more devices than tiles: a small image or crop window) has nothing to receive: its film
         // pointer may be null; it still runs pg_render (which handles an empty shard) so that its counters and stray count are set
         if (filmBytes[r] && !film[r]) return setError(PG_ERR_INVALID, "pg_render_sharded: null film buffer for rank %d", r);
     }
-    const size_t strayOff = total; total += strayBytes * (size_t)n;
-    const size_t countOff = total; total += sizeof(int) * (size_t)n;
+    // one packed shard per rank, the same size for all: [film (filmMax) | strays | count]; the gathered frame is n of them in rank order
+    const size_t strayOff = filmMax, countOff = strayOff + strayBytes, per = (countOff + sizeof(int) + 255) / 256 * 256;
+    const size_t total = per * (size_t)n;
     HIP_TRY(hipSetDevice(root->device));
     HIP_TRY(root->gatherDev.alloc(total));
     char *gather = (char *)root->gatherDev.p;
+    // transport: RCCL unless PG_SHARD_GATHER=peer, a device repeats (tests on a one-GPU box) or librccl cannot be used -- then peer copies
+    std::string why;
+#ifndef HIP_EMU_H
+    const std::vector<PgNcclComm> *comms = nullptr;
+    {
+        const char *e = getenv("PG_SHARD_GATHER");
+        std::vector<int> devices((size_t)n);
+        for (int r = 0; r < n; ++r) devices[r] = scenes[r]->device;
+        if (e && !strcmp(e, "peer")) why = "PG_SHARD_GATHER=peer";
+        else comms = shardComms(devices, why);
+        if (!comms && e && !strcmp(e, "rccl")) return setError(PG_ERR_DEVICE, "pg_render_sharded: PG_SHARD_GATHER=rccl, but %s", why.c_str());
+    }
+#else
+    why = "emulated devices";
+#endif
     std::vector<int> status((size_t)n, PG_OK);
     std::vector<std::string> message((size_t)n);
     auto work = [&](int r) {
         PgScene *s = scenes[r];
         auto fail = [&](int code) { status[r] = code; message[r] = pg_last_error(); };
         if (hipSetDevice(s->device) != hipSuccess) { status[r] = PG_ERR_DEVICE; message[r] = "hipSetDevice failed"; return; }
-        if (s->device != root->device) {  // direct xGMI writes into the gathering device's buffer
+        bool viaRccl = false;
+#ifndef HIP_EMU_H
+        viaRccl = comms != nullptr;
+#endif
+        if (!viaRccl && s->device != root->device) {  // direct xGMI writes into the gathering device's buffer
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, s->device, root->device) == hipSuccess && can) {
                 hipError_t e = hipDeviceEnablePeerAccess(root->device, 0);
@@ -1577,16 +1654,22 @@ int pg_render_sharded(PgScene *const *scenes, int32_t n, const PgRenderDesc *des
                 (void)hipGetLastError();
             }
         }
-        const size_t filmAlloc = filmBytes[r] ? filmBytes[r] : sizeof(PgFilmPixel);  // never a null buffer, also for an empty shard
-        if (s->shardFilm.bytes < filmAlloc && s->shardFilm.alloc(filmAlloc) != hipSuccess) { status[r] = PG_ERR_DEVICE; message[r] = "out of device memory (shard film)"; return; }
-        if (s->shardStrays.bytes < strayBytes && s->shardStrays.alloc(strayBytes) != hipSuccess) { status[r] = PG_ERR_DEVICE; message[r] = "out of device memory (shard strays)"; return; }
-        if (!s->shardCount.p && s->shardCount.alloc(sizeof(int)) != hipSuccess) { status[r] = PG_ERR_DEVICE; message[r] = "out of device memory"; return; }
-        int st = pg_render(s, &rd[r], (PgFilmPixel *)s->shardFilm.p, (PgStraySample *)s->shardStrays.p, maxStrays, (int32_t *)s->shardCount.p, PG_MEM_DEVICE, nullptr);
+        if (s->shardFilm.bytes < per && s->shardFilm.alloc(per) != hipSuccess) { status[r] = PG_ERR_DEVICE; message[r] = "out of device memory (packed shard)"; return; }
+        char *packed = (char *)s->shardFilm.p;
+        int st = pg_render(s, &rd[r], (PgFilmPixel *)packed, (PgStraySample *)(packed + strayOff), maxStrays, (int32_t *)(packed + countOff), PG_MEM_DEVICE, nullptr);
         if (st != PG_OK) { fail(st); return; }
-        hipError_t e = hipSuccess;
-        if (filmBytes[r]) e = hipMemcpyPeer(gather + filmOff[r], root->device, s->shardFilm.p, s->device, filmBytes[r]);
-        if (e == hipSuccess) e = hipMemcpyPeer(gather + strayOff + strayBytes * (size_t)r, root->device, s->shardStrays.p, s->device, strayBytes);
-        if (e == hipSuccess) e = hipMemcpyPeer(gather + countOff + sizeof(int) * (size_t)r, root->device, s->shardCount.p, s->device, sizeof(int));
+#ifndef HIP_EMU_H
+        if (viaRccl) {
+            // one collective per frame: every rank's thread calls it on its own communicator (the threads are the "different
+            // threads" of rccl.h:213); root 0 receives rank r's shard at gather + r * per
+            const int rs = rccl().Gather(packed, r == 0 ? gather : nullptr, per, /*ncclChar*/ 0, 0, (*comms)[r], nullptr);
+            if (rs != 0) { status[r] = PG_ERR_DEVICE; message[r] = std::string("ncclGather: ") + rccl().GetErrorString(rs); return; }
+            const hipError_t e = hipStreamSynchronize(nullptr);
+            if (e != hipSuccess) { status[r] = PG_ERR_DEVICE; message[r] = std::string("after ncclGather: ") + hipGetErrorString(e); }
+            return;
+        }
+#endif
+        const hipError_t e = hipMemcpyPeer(gather + per * (size_t)r, root->device, packed, s->device, per);
         if (e != hipSuccess) { status[r] = PG_ERR_DEVICE; message[r] = std::string("peer copy of the film shard: ") + hipGetErrorString(e); }
     };
     {
@@ -1596,16 +1679,18 @@ int pg_render_sharded(PgScene *const *scenes, int32_t n, const PgRenderDesc *des
         for (auto &t : threads) t.join();
     }
     for (int r = 0; r < n; ++r) if (status[r] != PG_OK) return setError(status[r], "rank %d: %s", r, message[r].c_str());
+    g_shardTransport = why.empty() ? "rccl" : "peer (" + why + ")";
     // the gathered frame back to the host in one piece
     HIP_TRY(hipSetDevice(root->device));
     std::vector<char> host(total);
     HIP_TRY(hipMemcpy(host.data(), gather, total, hipMemcpyDeviceToHost));
     for (int r = 0; r < n; ++r) {
-        if (filmBytes[r]) memcpy(film[r], host.data() + filmOff[r], filmBytes[r]);
+        const char *shard = host.data() + per * (size_t)r;
+        if (filmBytes[r]) memcpy(film[r], shard, filmBytes[r]);
         int cnt = 0;
-        memcpy(&cnt, host.data() + countOff + sizeof(int) * (size_t)r, sizeof(int));
+        memcpy(&cnt, shard + countOff, sizeof(int));
         cnt = std::max(0, std::min(cnt, (int)maxStrays));
-        if (cnt > 0) memcpy(strays[r], host.data() + strayOff + strayBytes * (size_t)r, sizeof(PgStraySample) * (size_t)cnt);
+        if (cnt > 0) memcpy(strays[r], shard + strayOff, sizeof(PgStraySample) * (size_t)cnt);
         nStrays[r] = cnt;
     }
     return PG_OK;

@@ -542,7 +542,12 @@ static void launch_trace(const DScene &sc, const TraceConfig &c, RayQueue q0, Ra
     case XP_INST: TR_LAUNCH(XP_INST); break;
     case XP_ALPHA: TR_LAUNCH(XP_ALPHA); break;
     case XP_INST | XP_ALPHA: TR_LAUNCH(XP_INST | XP_ALPHA); break;
-    default: TR_LAUNCH(XP_GENERAL); break;  // quadrics, or masks that need the general texture evaluator
+    // quadrics without the general texture evaluator: a sphere light (BASELINE config 0) does not cost a triangle scene that evaluator's registers
+    case XP_QUADRIC: TR_LAUNCH(XP_QUADRIC); break;
+    case XP_QUADRIC | XP_INST: TR_LAUNCH(XP_QUADRIC | XP_INST); break;
+    case XP_QUADRIC | XP_ALPHA: TR_LAUNCH(XP_QUADRIC | XP_ALPHA); break;
+    case XP_QUADRIC | XP_INST | XP_ALPHA: TR_LAUNCH(XP_QUADRIC | XP_INST | XP_ALPHA); break;
+    default: TR_LAUNCH(XP_GENERAL); break;  // masks that need the general texture evaluator
     }
 #undef TR_LAUNCH
 }

@@ -182,7 +182,7 @@ def test_config2_cornell_full_size_properties(gpu):
     gs.close()
 
 
-def test_native_sharded_render_equals_single_device(gpu, tmp_path):
+def test_native_sharded_render_equals_single_device(gpu, tmp_path, monkeypatch):
     """pg_render_sharded -- the in-process multi-GPU path of `pbrt_amd --gpus N`: one host thread per device, peer-to-peer
     gather of the film shards on the first device.  On a single-GPU box the device id repeats (three shards on GPU 0): the
     merged film must equal the single-device render bit for bit, and every shard must equal pg_render of that shard."""
@@ -197,6 +197,16 @@ def test_native_sharded_render_equals_single_device(gpu, tmp_path):
         assert np.array_equal(film["rgb"], alone_film["rgb"]) and np.array_equal(film["weight"], alone_film["weight"]) and len(strays) == len(alone_strays)
         scene.film_merge(srd, film, strays)
     assert np.array_equal(scene.film_image(), whole)
+    assert gpu.shard_transport().startswith("peer (a device appears twice") or os.environ.get("PBRT_EMULATED_DEVICE") == "1", gpu.shard_transport()
+    # the RCCL transport itself on this box's one GPU: a one-rank communicator (ncclCommInitAll + ncclGather through the lazily opened
+    # librccl); PG_SHARD_GATHER=rccl turns "RCCL could not be used" into an error instead of the peer-copy fallback
+    if os.environ.get("PBRT_EMULATED_DEVICE") != "1":
+        monkeypatch.setenv("PG_SHARD_GATHER", "rccl")
+        (srd, film, strays), = gpu.render_sharded(scenes[:1], rd)
+        assert gpu.shard_transport() == "rccl"
+        scene.film_clear(); scene.film_merge(srd, film, strays)
+        assert np.array_equal(scene.film_image(), whole)
+        monkeypatch.delenv("PG_SHARD_GATHER")
     for s in scenes:
         s.close()
     # the same through the CLI: pbrt_amd --gpu-ids 0,0 writes the image of pbrt_amd --gpu 0
