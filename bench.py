@@ -323,8 +323,19 @@ def kernel_rooflines(m, workload):
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            w = json.load(open(pmc)).get("workloads", {}).get(workload, {})
+            allw = json.load(open(pmc)).get("workloads", {})
+            w = allw.get(workload, {})
             pmc_kernels, pmc_src = w.get("kernels", {}), "profiles/pmc_traffic.json" + (f"@{w['round']}" if "round" in w else "")
+            if not pmc_kernels and " @ " in workload:
+                # a pass of the same scene at another sample count (the divergent stand-ins' passes run at a quarter of the spp): hit rates
+                # and lanes per instruction carry over, per-launch totals scale with the launches' size, i.e. with spp
+                base, spp_now = workload.rsplit(" @ ", 1)
+                for k, v in allw.items():
+                    if k.rsplit(" @ ", 1)[0] == base:
+                        scale = float(spp_now.split()[0]) / float(k.rsplit(" @ ", 1)[1].split()[0])
+                        pmc_kernels = {kn: {f: (x * scale if f.endswith("_per_launch") else x) for f, x in kv.items()} for kn, kv in v.get("kernels", {}).items()}
+                        pmc_src = f"profiles/pmc_traffic.json ({k.rsplit(' @ ', 1)[1]} pass, per-launch totals x {scale:g})"
+                        break
         except Exception:
             pass
     cal = os.path.join(ROOT, "profiles", "fetch_size_calibration.json")
