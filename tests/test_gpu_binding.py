@@ -13,7 +13,6 @@ from conftest import GOLD, ROOT
 
 pytestmark = pytest.mark.gpu  # module-level constants are shared with tests/test_binding_cpu.py
 BINDING = os.path.join(ROOT, "oracle", "_ref", "pbrt_gpubind")
-TOL = 1e-4
 SCENES = ["cornell_32", "cornell_crop", "cornell_lens", "cornell_plastic", "cornell_normals", "cornell_tangents", "cornell_ply",
           "cornell_loopsubdiv", "cornell_point", "cornell_spot_power", "cornell_power", "cornell_uniform", "cornell_mirror_glass",
           "cornell_orennayar", "cornell_ortho_lens", "cornell_twosided", "cornell_reverse", "cornell_xform", "cornell_filmopts",
@@ -37,10 +36,8 @@ def test_reference_front_end_plus_device_equals_reference_image(gpu, name, tmp_p
     img = run_binding(gpu, os.path.join(GOLD, name + ".pbrt"), str(tmp_path / "bound.pfm"))
     ref = gpu.read_pfm(os.path.join(GOLD, name + ".pfm"))
     assert img.shape == ref.shape
-    err = (np.abs(img - ref) / np.maximum(1.0, np.abs(ref))).max(axis=2)
-    # libm's last bit may tip a discrete event of one sample in one or two pixels
-    assert (err > TOL).sum() <= 2, f"{(err > TOL).sum()} pixels over tolerance, max {err.max():.3e}"
-    assert np.median(err) <= 1e-6 and np.percentile(err, 99) <= 2e-5
+    # the unmodified reference's parser, scene construction, BVHAccel and Film around the device kernels: the reference's own image, bit for bit
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), f"{(img != ref).any(axis=2).sum()} pixels differ from the reference binary's image"
     # the same scene through this repository's own front end: identical film, bit for bit (same nodes, same primitive order,
     # same BxDF lists -- the specialised matte / plastic / mirror / glass kernels equal the BxDF-list kernels exactly)
     own, _ = gpu.render_scene(gpu.HostScene(os.path.join(GOLD, name + ".pbrt")))

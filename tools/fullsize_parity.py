@@ -10,11 +10,10 @@
   config 40 / 50: round 2's stand-ins (config 3's matte heightfield scaled to 5 M / 10 M triangles; 50 in fog under volpath)
 
 Both renderers read the same .pbrt file; the reference writes a PFM (core/imageio.cpp:437-482), the device film goes through
-the host Film (MergeFilmTile + WriteImage arithmetic).  Reported per config: max / 99.99th percentile / count of pixels with
-|d| > 1e-4 * max(1, |ref|), the share of bit-identical pixels, and the ray counters of both.  A pixel outside the tolerance is
-re-rendered ALONE by the CPU oracle built with correctly rounded libm (the device's libm behaviour): it must reproduce the
-device's pixel bit for bit -- then the difference is a last-bit libm difference that tipped a discrete event, not an error of
-the device path.  TEST INFRASTRUCTURE: uses oracle/.  One JSON line per config.
+the host Film (MergeFilmTile + WriteImage arithmetic).  Reported per config: the share of bit-identical pixels (the bar: all of
+them -- the device computes libm's float functions as the reference's glibc does, csrc/pg_libm.h), max / 99.99th percentile / count
+of pixels with |d| > 1e-4 * max(1, |ref|) (BASELINE.json's tolerance: none), and the ray counters of both (the bar: equal).
+TEST INFRASTRUCTURE: runs oracle/_ref/pbrt_oracle.  One JSON line per config.
 
 usage: python tools/fullsize_parity.py [2] [3] [4] [5] [--out FILE.json]"""
 import json
@@ -66,10 +65,22 @@ def write_config(config, d):
     return path, window
 
 
+def usable_cpus():
+    """CPUs this process may use: the affinity mask, cut by the cgroup quota (the GPU box: 256 logical CPUs, a quota of 16 -- the
+    reference with 256 threads on 16 CPUs' worth of time runs at a third of its 16-thread rate)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max": n = max(1, min(n, int(int(q) / int(per) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def reference_render(path, out_pfm):
     ref = os.path.join(ROOT, "oracle", "_ref", "pbrt_oracle")
     t0 = time.time()
-    out = subprocess.run([ref, "--nthreads", str(os.cpu_count() or 1), "--outfile", out_pfm, path], capture_output=True, text=True, check=True).stdout
+    out = subprocess.run([ref, "--nthreads", str(usable_cpus()), "--outfile", out_pfm, path], capture_output=True, text=True, check=True).stdout
     wall = time.time() - t0
     def stat(pat):  # a counter that stayed 0 is not printed (core/stats.cpp)
         m = re.search(pat + r"\s+(\d+)", out)
@@ -85,7 +96,6 @@ def reference_render(path, out_pfm):
 
 def run(config):
     pkg = load_package()
-    from oracle import oracle
     with tempfile.TemporaryDirectory() as d:
         path, window = write_config(config, d)
         scene = pkg.HostScene(path)
@@ -112,32 +122,19 @@ def run(config):
         outside_black = True
     err = (np.abs(img_w - ref_w) / np.maximum(1.0, np.abs(ref_w))).max(axis=2)
     bad = np.argwhere(err > TOL)
-    # every out-of-tolerance pixel, alone, by the CPU oracle with correctly rounded libm: it must equal the device's pixel
-    explained = 0
-    H, W = img.shape[:2]
-    for (yy, xx) in bad[:512]:
-        # the 3x3 pixels around it: a neighbour's sample with offset exactly 0 also lands in this pixel (film.h:127-132)
-        rdp = scene.render_desc()
-        px, py = int(xx) + x0, int(yy) + y0
-        rdp.pixel_bounds[0], rdp.pixel_bounds[1] = max(px - 1, rd.pixel_bounds[0]), max(py - 1, rd.pixel_bounds[1])
-        rdp.pixel_bounds[2], rdp.pixel_bounds[3] = min(px + 2, rd.pixel_bounds[2]), min(py + 2, rd.pixel_bounds[3])
-        ofilm, ostrays, _ = oracle.render(scene.desc, rdp)
-        scene.film_clear(); scene.film_merge(rdp, ofilm, ostrays)
-        if np.array_equal(scene.film_image()[py, px], img[py, px]):
-            explained += 1
     out = {"config": config, "triangles": int(max(scene.desc.n_tris, scene.desc.n_prims_all)), "object_instances": int(scene.desc.n_instances),
            "integrator": "volpath" if config in (5, 50) else "path",
            "frame": f"{img.shape[1]}x{img.shape[0]}", "spp": int(rd.spp), "compared_pixels": int(err.size),
            "sampled_pixels": int((window[2] - window[0]) * (window[3] - window[1])) if window else int(err.size),
            "window": list(window) if window else None, "outside_window_black": outside_black,
            "max_rel_err": float(err.max()), "p9999_rel_err": float(np.percentile(err, 99.99)), "pixels_over_tol": int(len(bad)), "tol": TOL,
-           "pixels_over_tol_reproduced_bitwise_by_cr_oracle": explained, "bit_identical_pixel_share": float((img_w == ref_w).all(axis=2).mean()),
+           "pixels_differing": int((img_w.view(np.uint32) != ref_w.view(np.uint32)).any(axis=2).sum()), "bit_identical_pixel_share": float((img_w == ref_w).all(axis=2).mean()),
            "mean_ref": float(ref_w.mean()), "mean_device": float(img_w.mean()),
            "device_counters": {k: int(cn[k]) for k in ("camera_rays", "closest_rays", "shadow_rays", "tri_tests")},
            "reference_counters": rcn,
            "counter_rel_delta": {k: (cn[k] - rcn[k]) / max(1, rcn[k]) for k in rcn},
            "device_render_ms": float(cn["render_ms"]), "reference_render_s": ref_render_s, "reference_wall_s": round(ref_wall_s, 1),
-           "reference_threads": os.cpu_count()}
+           "reference_threads": usable_cpus()}
     gs.close()
     return out
 
