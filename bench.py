@@ -275,9 +275,18 @@ def run_workload(ctx, args, steps, warmup, keep_image=False):
         every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
         dist.all_gather(every, mine)
         per_rank = [float(t.item()) for t in every]
+    # every rank's kernel times (its own HIP events): which rank is the straggler, and in which kernel
+    kn = ("closest_ms", "shadow_ms", "shade_ms", "resolve_ms", "generate_ms", "film_ms")
+    per_rank_kernels = [[float(cn[k]) / max(1, steps) for k in kn]]
+    if ctx.multi:
+        mine_k = torch.tensor(per_rank_kernels[0], dtype=torch.float64, device=ctx.comm_dev)
+        every_k = [torch.zeros_like(mine_k) for _ in range(dist.get_world_size())]
+        dist.all_gather(every_k, mine_k)
+        per_rank_kernels = [[float(x) for x in t.tolist()] for t in every_k]
     elapsed, rays, samples = (float(x) for x in stats.tolist())
     m = types.SimpleNamespace(elapsed=elapsed, rays=rays, samples=samples, cn=cn, scene=scene, gs=gs, t_parse=t_parse, workdir=workdir,
-                              per_rank_ms=[t / max(1, steps) * 1e3 for t in per_rank], steps=steps, image=None)
+                              per_rank_ms=[t / max(1, steps) * 1e3 for t in per_rank], steps=steps, image=None,
+                              per_rank_kernel_ms=[{k[:-3]: round(v, 3) for k, v in zip(kn, row)} for row in per_rank_kernels])
     if ctx.rank == 0 and keep_image and last is not None:  # final image (outside the timed region): MergeFilmTile per shard + WriteImage arithmetic
         shards = gather.shards(last) if gather else [(last.film, last.strays, int(last.nstrays.item()))]
         m.image = pdist.merge_shards(pkg, scene, gs.tile_count, shards)
@@ -300,7 +309,50 @@ def describe(args, scene):
     return f"{what}, {integ} maxdepth 5, halton, {args.filter} filter, {args.xres}x{args.yres} @ {args.spp} spp"
 
 
-def kernel_rooflines(m, workload):
+def live_pmc(bench_args, passes, timeout=300):
+    """Hardware counters of ONE frame of this workload, collected by THIS run: one child `rocprofv3 --pmc <counters> -- python bench.py
+    <same workload> --steps 1` per pass -- FETCH_SIZE and WRITE_SIZE in passes of their own, no trace domain beside them, as
+    MI355X_MICROARCH.md prescribes -- summed per kernel and divided by its dispatches.  Returns ({kernel name: {...}}, None) in the
+    layout of profiles/pmc_traffic.json, or (None, why) where rocprofv3 cannot run (then the committed passes are replayed, labelled)."""
+    import csv
+    import glob
+    import shutil
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    tot = {}
+    for counters in passes:
+        d = tempfile.mkdtemp(prefix="pbrt_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", *counters, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), *bench_args,
+               "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-hbm-regime", "--no-live-pmc"]
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+        except Exception as e:
+            return None, f"rocprofv3 --pmc {' '.join(counters)}: {e}"
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if p.returncode != 0 or not files:
+            return None, f"rocprofv3 --pmc {' '.join(counters)}: rc {p.returncode}, {len(files)} counter files; {p.stderr[-300:]}"
+        for f in files:
+            for r in csv.DictReader(open(f)):
+                c = r["Counter_Name"]
+                if c not in counters: continue
+                e = tot.setdefault(c, {}).setdefault(r["Kernel_Name"].split("(")[0], [0.0, set()])
+                e[0] += float(r["Counter_Value"]); e[1].add(r["Dispatch_Id"])
+        shutil.rmtree(d, ignore_errors=True)
+    kernels = {}
+    for k, (f, nf) in tot.get("FETCH_SIZE", {}).items():
+        w, nw = tot.get("WRITE_SIZE", {}).get(k, (0.0, {0}))
+        e = {"launches": len(nf), "fetch_KiB_per_launch": f / len(nf), "write_KiB_per_launch": w / max(1, len(nw))}
+        h, mi = tot.get("TCC_HIT_sum", {}).get(k, (0.0, 0))[0], tot.get("TCC_MISS_sum", {}).get(k, (0.0, 0))[0]
+        if h + mi > 0: e["l2_hit_rate"] = h / (h + mi)
+        vi, vt = tot.get("SQ_INSTS_VALU", {}).get(k, (0.0, {0})), tot.get("SQ_THREAD_CYCLES_VALU", {}).get(k, (0.0, 0))[0]
+        if vi[0] > 0:
+            e["valu_insts_per_launch"] = vi[0] / max(1, len(vi[1])); e["valu_lanes_active"] = vt / vi[0]
+        kernels[k] = e
+    return (kernels, None) if kernels else (None, "no FETCH_SIZE rows in the counter files")
+
+
+def kernel_rooflines(m, workload, live=None):
     """One roofline per hot kernel.  Algorithmic bytes:
       k_trace: 32 B per reference node fetch + 48 B per triangle test + 32 B per ray in + 16 B (closest) / 4 B (any) out
       k_shade: per path vertex 16 B ray direction + 16 B hit + 48 B state in + 48 B triangle + 48 B state out + 48 B pending
@@ -338,6 +390,9 @@ def kernel_rooflines(m, workload):
                         break
         except Exception:
             pass
+    replayed = True
+    if live:  # counters collected by this run's own rocprofv3 --pmc passes (live_pmc): nothing replayed
+        pmc_kernels, pmc_src, replayed = live, "live: rocprofv3 --pmc passes over one frame of this workload, run by this bench.py", False
     cal = os.path.join(ROOT, "profiles", "fetch_size_calibration.json")
     if os.path.exists(cal):
         try:
@@ -365,14 +420,15 @@ def kernel_rooflines(m, workload):
             rate = pk["valu_insts_per_launch"] * launches / (ms * 1e-3)
             r["vector_issue"] = {"insts_per_launch": pk["valu_insts_per_launch"], "achieved": rate, "peak": VALU_ISSUE_PEAK, "unit": "wave instructions/s",
                                  "frac": rate / VALU_ISSUE_PEAK, "lanes_active_of_64": pk.get("valu_lanes_active"), "source": pmc_src,
-                                 "note": "instruction count replayed from a committed PMC pass of this workload (SQ_INSTS_VALU), divided by this run's kernel time"}
+                                 "note": ("instruction count replayed from a committed PMC pass of this workload" if replayed else "instruction count of this run's own PMC pass") + " (SQ_INSTS_VALU), divided by this run's kernel time"}
         if served_on_die:
             r["note"] = (f"algorithmic rate above the HBM peak ({HBM_PEAK_GBS:.0f} GB/s) although the scene exceeds the Infinity Cache: the top of the tree is "
                          "served on-die (short traversals), so this kernel is priced against the L2")
         if traffic is not None:
             r["traffic_source"] = {"source": pmc_src, "fetch_size_factor": factor if gather_pattern else 2.0,
                                    "fetch_size_factor_source": factor_src if gather_pattern else "MI355X_MICROARCH.md (streaming reads)",
-                                   "note": "replayed from a committed PMC pass of this workload, not measured in this run"}
+                                   "note": "replayed from a committed PMC pass of this workload, not measured in this run" if replayed else
+                                           "FETCH_SIZE / WRITE_SIZE (KiB) per launch from this run's own rocprofv3 --pmc passes (separate passes, one frame)"}
             if ms > 0:  # what the memory side of the L2 moved, against the HBM peak
                 hb = traffic * launches / (ms * 1e-3) / 1e9
                 r["hbm_side"] = {"achieved": hb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / HBM_PEAK_GBS, "source": pmc_src}
@@ -445,6 +501,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline renders every sample of the frame (minutes)")
     ap.add_argument("--no-hbm-regime", action="store_true", help="skip the 3 extra frames of the 5 M-triangle workload behind roofline.hbm_regime")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not run the rocprofv3 --pmc child passes; replay profiles/pmc_traffic.json (labelled) instead")
     ap.add_argument("--out", default=None, help="write the rendered image (PFM) here")
     args = ap.parse_args()
     dx, dy, dspp = (400, 400, 8) if args.workload == "config0" else (1920, 1080, 64)
@@ -478,7 +535,19 @@ def main():
         if args.out and m.image is not None:
             pkg.write_pfm(args.out, m.image)
         workload = describe(args, m.scene)
-        kernels, working_set, bound, peak, pmc_kernels, pmc_src = kernel_rooflines(m, workload)
+        # memory-side traffic, L2 hit rates and vector-instruction counts of the hot kernels: measured by this run (child rocprofv3 --pmc
+        # passes over one frame each, after the timed region) unless --no-live-pmc / N > 1 / an emulated device
+        live, live_why, live_hbm = None, "--no-live-pmc", None
+        wl_args = ["--workload", args.workload, "--grid", str(args.grid), "--tris", str(args.tris), "--xres", str(args.xres), "--yres", str(args.yres),
+                   "--spp", str(args.spp), "--filter", args.filter]
+        if ctx.world == 1 and not ctx.multi and not EMULATED and not args.no_live_pmc:
+            live, live_why = live_pmc(wl_args, (["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"], ["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU"]))
+            if live is None: sys.stderr.write(f"bench: live PMC passes failed ({live_why}); replaying profiles/pmc_traffic.json\n")
+            if hbm is not None and live is not None:
+                a5l = ["--workload", "synthetic", "--grid", str(hbm.args.grid), "--xres", str(args.xres), "--yres", str(args.yres), "--spp", str(args.spp), "--filter", args.filter]
+                live_hbm, why5 = live_pmc(a5l, (["FETCH_SIZE"], ["WRITE_SIZE"]))
+                if live_hbm is None: sys.stderr.write(f"bench: live PMC passes of the hbm-regime workload failed ({why5})\n")
+        kernels, working_set, bound, peak, pmc_kernels, pmc_src = kernel_rooflines(m, workload, live)
         gather = gather_ceiling(m, working_set, pmc_kernels, pmc_src)
         roofline = dict(kernels[0]) if kernels else {"kernel": None, "bound": bound, "achieved": 0.0, "peak": peak, "unit": "GB/s", "frac": 0.0, "traffic": None}
         roofline["working_set_bytes"] = working_set
@@ -488,7 +557,7 @@ def main():
                                     ("fit the 256 MiB Infinity Cache: gathers are served on-die, L2 bandwidth is the ceiling"
                                      if bound == "l2" else "exceed the 256 MiB Infinity Cache: gathers reach HBM"))
         if hbm is not None:
-            hk, hws, hbound, _, _, _ = kernel_rooflines(hbm, describe(hbm.args, hbm.scene))
+            hk, hws, hbound, _, _, _ = kernel_rooflines(hbm, describe(hbm.args, hbm.scene), live_hbm)
             t = next((k for k in hk if k["kernel"].startswith("k_trace<0>")), None)
             if t is not None and hbound == "hbm":
                 roofline["hbm_regime"] = {
@@ -497,7 +566,10 @@ def main():
                     "avg_launch_ms": t["avg_launch_ms"], "launches": t["launches"], "algorithmic_bytes_per_launch": t["algorithmic_bytes_per_launch"],
                     "steps": hbm.steps, "ms_per_step": hbm.elapsed / hbm.steps * 1e3, "Mrays_per_s": hbm.rays / hbm.elapsed / 1e6,
                     "note": "timed in THIS run (HIP events per launch); algorithmic bytes (SURVEY 8d) / kernel time / 8 TB/s. Algorithmic bytes count "
-                            "every reference node fetch, also those the L2s serve, so this is the north star's roofline fraction, not memory-side traffic"}
+                            "every reference node fetch, also those the L2s serve, so this is the north star's roofline fraction, NOT memory-side "
+                            "traffic: `hbm_side` is what the L2s' memory side moved for this kernel (FETCH_SIZE x factor + WRITE_SIZE), against the same 8 TB/s"}
+                for f in ("traffic", "hbm_side", "traffic_source"):  # the memory-side companion (weak point of round 3: 0.97 alone reads as HBM utilisation)
+                    if t.get(f) is not None: roofline["hbm_regime"][f] = t[f]
         other_ms = {k: m.cn[k] for k in ("resolve_ms", "generate_ms", "film_ms")}
         if ctx.world == 1:
             sharding = "one GPU renders every 16x16 film tile; no gather"
@@ -511,6 +583,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "samples_per_s": m.samples / m.elapsed,
             "ranks_seen": dist.get_world_size() if ctx.multi else 1, "per_rank_ms": m.per_rank_ms,
+            **({"per_rank_kernel_ms_per_step": m.per_rank_kernel_ms} if ctx.multi else {}),
             "config": {"workload": workload, "sharding": sharding,
                        "rays_per_sample": m.rays / max(1.0, m.samples), "host_parse_and_bvh_s": m.t_parse},
             "roofline": roofline,
