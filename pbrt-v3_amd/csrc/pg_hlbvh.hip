@@ -2,7 +2,7 @@
 //
 //   k_centroid_bounds  Union of the primitives' centroids                      bvh.cpp:408-410
 //   k_morton           Morton code of every centroid                           bvh.cpp:415-429, :107-131
-//   (hipcub radix sort, stable, 30 key bits)                                   bvh.cpp:432, :140-180
+//   k_radix_*          stable LSD radix sort of (code, index) on the 30 code bits  bvh.cpp:432, :140-180
 //   k_treelet_starts   runs of equal top-12 Morton bits                        bvh.cpp:437-456
 //   k_emit_lbvh        one lane per treelet: emitLBVH in pre-order             bvh.cpp:485-535
 //   (host)             buildUpperSAH over <= 4096 treelet roots + the layout   bvh.cpp:537-638, :640-658
@@ -11,7 +11,6 @@
 // Everything a float result depends on (centroids, Bounds3f::Offset, the unions, the SAH costs) is evaluated with the
 // reference's operations in the reference's order, so nodes and primitive order equal the reference's single-thread build.
 // HBM-bound integer / min-max work: no MFMA.
-#include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -82,6 +81,66 @@ __global__ __launch_bounds__(256) void k_morton(int n, const float *__restrict__
     }
     codes[i] = (left_shift3(q[2]) << 2) | (left_shift3(q[1]) << 1) | left_shift3(q[0]);
     idx[i] = i;
+}
+// ---- RadixSort(&mortonPrims), bvh.cpp:140-180: a stable sort of the (Morton code, primitive index) pairs by the 30 code bits.  The
+// reference takes 5 passes of 6 bits; any stable sort gives the same order, here 3 passes of 8 bits and one of 6.  Per pass: every
+// wave counts the digits of its own contiguous segment (k_radix_hist), one block turns the counts -- digit-major, segment-minor,
+// which is the output order -- into offsets (k_radix_scan), and every wave walks its segment again in order, 64 keys at a time:
+// a key's place is its segment's running offset for the digit plus the number of lower lanes holding the same digit, found with
+// eight ballots (k_radix_scatter).  HBM-bound integer work, off the render path (scene set-up).
+constexpr int RS_DIGITS = 256;
+__global__ __launch_bounds__(64) void k_radix_hist(int n, int seg, int nUnits, const uint32_t *__restrict__ keys, int shift, int *__restrict__ counts) {
+    __shared__ int h[RS_DIGITS];
+    const int u = blockIdx.x, lane = threadIdx.x;
+    for (int d = lane; d < RS_DIGITS; d += 64) h[d] = 0;
+    __syncthreads();
+    const int lo = u * seg, hi = min(n, lo + seg);
+    for (int i = lo + lane; i < hi; i += 64) atomicAdd(&h[(keys[i] >> shift) & (RS_DIGITS - 1)], 1);
+    __syncthreads();
+    for (int d = lane; d < RS_DIGITS; d += 64) counts[d * nUnits + u] = h[d];
+}
+__global__ __launch_bounds__(1024) void k_radix_scan(int total, int *__restrict__ counts) {  // exclusive prefix sum, in place, one block
+    __shared__ int s[1024];
+    const int t = threadIdx.x, len = (total + 1023) / 1024, lo = min(total, t * len), hi = min(total, lo + len);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += counts[i];
+    s[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = t >= off ? s[t - off] : 0;
+        __syncthreads();
+        s[t] += v;
+        __syncthreads();
+    }
+    int run = s[t] - sum;
+    for (int i = lo; i < hi; ++i) { const int c = counts[i]; counts[i] = run; run += c; }
+}
+__global__ __launch_bounds__(64) void k_radix_scatter(int n, int seg, int nUnits, const uint32_t *__restrict__ keysIn, const int *__restrict__ valsIn,
+                                                      uint32_t *__restrict__ keysOut, int *__restrict__ valsOut, int shift, const int *__restrict__ offsets) {
+    __shared__ int offs[RS_DIGITS];
+    const int u = blockIdx.x, lane = threadIdx.x;
+    for (int d = lane; d < RS_DIGITS; d += 64) offs[d] = offsets[d * nUnits + u];
+    __syncthreads();
+    const int lo = u * seg, hi = min(n, lo + seg);
+    for (int base = lo; base < hi; base += 64) {
+        const int i = base + lane;
+        const bool in = i < hi;
+        const uint32_t key = in ? keysIn[i] : 0u;
+        const int val = in ? valsIn[i] : 0;
+        const int d = (int)((key >> shift) & (RS_DIGITS - 1));
+        unsigned long long same = __ballot(in);  // the lanes of this step that hold my digit
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1;
+            const unsigned long long m = __ballot(bit);
+            same &= bit ? m : ~m;
+        }
+        const int rank = __popcll(same & ((1ull << lane) - 1ull));
+        const int pos = in ? offs[d] + rank : 0;
+        __syncthreads();  // every lane has read its offset
+        if (in && rank == 0) offs[d] += __popcll(same);
+        __syncthreads();
+        if (in) { keysOut[pos] = key; valsOut[pos] = val; }
+    }
 }
 __global__ __launch_bounds__(256) void k_treelet_starts(int n, const uint32_t *__restrict__ codes, int *__restrict__ starts, int *__restrict__ count, int cap) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -275,12 +334,21 @@ extern "C" int pg_hlbvh_build(int32_t n, const float *bounds, int32_t maxPrimsIn
     for (int i = 0; i < 2; ++i) { HB_TRY(dCodes[i].alloc(sizeof(uint32_t) * (size_t)n)); HB_TRY(dIdx[i].alloc(sizeof(int) * (size_t)n)); }
     const int nBlocks = (n + 255) / 256;
     hipLaunchKernelGGL(k_morton, dim3(nBlocks), dim3(256), 0, stream, n, (const float *)dBounds.p, cb, (uint32_t *)dCodes[0].p, (int *)dIdx[0].p);
-    size_t tempBytes = 0;
-    HB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, (const uint32_t *)dCodes[0].p, (uint32_t *)dCodes[1].p, (const int *)dIdx[0].p, (int *)dIdx[1].p, n, 0, 30, stream));
-    HB_TRY(dTemp.alloc(tempBytes));
-    HB_TRY(hipcub::DeviceRadixSort::SortPairs(dTemp.p, tempBytes, (const uint32_t *)dCodes[0].p, (uint32_t *)dCodes[1].p, (const int *)dIdx[0].p, (int *)dIdx[1].p, n, 0, 30, stream));
-    const uint32_t *codes = (const uint32_t *)dCodes[1].p;
-    const int *idx = (const int *)dIdx[1].p;
+    {
+        const int nUnits = std::max(1, std::min(2048, (n + 1023) / 1024));
+        const int seg = ((n + nUnits - 1) / nUnits + 63) / 64 * 64;
+        HB_TRY(dTemp.alloc(sizeof(int) * (size_t)RS_DIGITS * nUnits));
+        int src = 0;
+        for (int shift = 0; shift < 30; shift += 8, src ^= 1) {  // 8 + 8 + 8 + 6 bits (the codes have 30)
+            hipLaunchKernelGGL(k_radix_hist, dim3(nUnits), dim3(64), 0, stream, n, seg, nUnits, (const uint32_t *)dCodes[src].p, shift, (int *)dTemp.p);
+            hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, stream, RS_DIGITS * nUnits, (int *)dTemp.p);
+            hipLaunchKernelGGL(k_radix_scatter, dim3(nUnits), dim3(64), 0, stream, n, seg, nUnits, (const uint32_t *)dCodes[src].p, (const int *)dIdx[src].p,
+                               (uint32_t *)dCodes[src ^ 1].p, (int *)dIdx[src ^ 1].p, shift, (const int *)dTemp.p);
+        }
+        // four passes: the sorted pairs are back in buffer 0
+    }
+    const uint32_t *codes = (const uint32_t *)dCodes[0].p;
+    const int *idx = (const int *)dIdx[0].p;
     // 4. treelets
     const int cap = 4096;  // 12 bits
     HB_TRY(dStarts.alloc(sizeof(int) * cap));

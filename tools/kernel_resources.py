@@ -47,8 +47,8 @@ def main():
     for r, n in zip(rows, names):
         r["short"] = (re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", "")).replace("void ", "") or r["name"]).strip() or r["name"]
     own = sorted((r for r in rows if "rocprim" not in r["short"] and "hipcub" not in r["short"]), key=lambda r: r["short"])
-    print(f"# {os.path.relpath(lib, ROOT)}: {len(rows)} kernels in {len(starts)} code objects (gfx950), {len(rows) - len(own)} of them hipCUB / rocPRIM")
-    print("# instantiations of the device HLBVH build's radix sort (not listed).  waves = waves per SIMD the register file allows (the launch")
+    print(f"# {os.path.relpath(lib, ROOT)}: {len(rows)} kernels in {len(starts)} code objects (gfx950), {len(rows) - len(own)} of them library (hipCUB / rocPRIM)")
+    print("# instantiations (none since round 4: the HLBVH build sorts with its own k_radix_*).  waves = waves per SIMD the register file allows (the launch")
     print("# bound or the LDS of a kernel may allow fewer); LDS = static bytes per workgroup; scratch in bytes per lane; spills in registers.")
     print("%-44s %5s %5s %5s %6s %8s %8s %7s %7s %6s" % ("kernel", "vgpr", "agpr", "sgpr", "waves", "LDS B", "scratch", "v-spill", "s-spill", "maxWG"))
     for r in own:
