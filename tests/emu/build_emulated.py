@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Builds libpbrt_gpu_emulated.so: the product's device translation units (pbrt-v3_amd/csrc/pg_abi.hip, pg_kernels.hip, pg_traverse.hip)
+"""Builds libpbrt_gpu_emulated.so: the product's device translation units (pbrt-v3_amd/csrc/pg_abi.hip, pg_kernels.hip, pg_traverse.hip, pg_hlbvh.hip)
 compiled for the HOST under tests/emu/hip_emu.h, exporting the same C ABI as libpbrt_gpu.so.  TEST INFRASTRUCTURE.
 
     python tests/emu/build_emulated.py OUTDIR      ->  OUTDIR/libpbrt_gpu_emulated.so
@@ -13,7 +13,7 @@ scheduler cannot take literally (the arithmetic is untouched):
      readfirstlane / ballot pair that decides about the batched Halton draw (-> emu_*_div: served before the lanes that skipped ahead);
   4. one load that the hardware executes in lockstep for the whole wave before lane 0's atomicAdd (k_trace's "is this region drained"
      test) is exchanged explicitly, because fibers reach it at different times.
-pg_hlbvh.hip (hipCUB radix sort) is not emulated: pg_hlbvh_build answers PG_ERR_UNSUPPORTED."""
+pg_hlbvh.hip (the device HLBVH build with its own radix sort) compiles unchanged."""
 import os
 import re
 import shutil
@@ -56,8 +56,7 @@ def patched_sources(out):
         k = k.replace(old, new)
     open(os.path.join(out, "pg_kernels.hip"), "w").write(k)
     shutil.copy(os.path.join(CS, "pg_abi.hip"), os.path.join(out, "pg_abi.hip"))
-    open(os.path.join(out, "hlbvh_stub.cpp"), "w").write(
-        '#include "%s/include/pbrt_gpu.h"\nextern "C" int pg_hlbvh_build(int32_t, const float *, int32_t, PgBVHNode *, int32_t *, int32_t *) { return PG_ERR_UNSUPPORTED; }\n' % ROOT)
+    shutil.copy(os.path.join(CS, "pg_hlbvh.hip"), os.path.join(out, "pg_hlbvh.hip"))  # (its own radix sort since round 4: nothing to stub)
 
 
 def main():
@@ -66,12 +65,11 @@ def main():
     patched_sources(out)
     flags = ["--cuda-host-only", "-O1", "-ffp-contract=off", "-fPIC", "-w"] + os.environ.get("PBRT_EMU_DEFINES", "").split()  # e.g. -DPG_ORDER_WINDOW=1024: several windows on small scenes
     procs = [subprocess.Popen([HIPCC, *flags, "-I" + CS, "-I" + EM, "-include", os.path.join(EM, "hip_emu.h"), "-c", os.path.join(out, f + ".hip"), "-o", os.path.join(out, f + ".o")])
-             for f in ("pg_traverse", "pg_kernels", "pg_abi")]
+             for f in ("pg_traverse", "pg_kernels", "pg_abi", "pg_hlbvh")]
     procs.append(subprocess.Popen([HIPCC, *flags, "-U_FORTIFY_SOURCE", "-D_FORTIFY_SOURCE=0", "-I" + EM, "-c", os.path.join(EM, "hip_emu.cpp"), "-o", os.path.join(out, "hip_emu.o")]))
-    procs.append(subprocess.Popen(["g++", "-O1", "-fPIC", "-c", os.path.join(out, "hlbvh_stub.cpp"), "-o", os.path.join(out, "hlbvh_stub.o")]))
     if any(p.wait() for p in procs):
         sys.exit("build_emulated: compilation failed")
-    subprocess.check_call([HIPCC, "--cuda-host-only", "-shared", "-fPIC", *[os.path.join(out, f + ".o") for f in ("pg_abi", "pg_kernels", "pg_traverse", "hip_emu", "hlbvh_stub")],
+    subprocess.check_call([HIPCC, "--cuda-host-only", "-shared", "-fPIC", *[os.path.join(out, f + ".o") for f in ("pg_abi", "pg_kernels", "pg_traverse", "pg_hlbvh", "hip_emu")],
                            "-o", os.path.join(out, "libpbrt_gpu_emulated.so")])
     print(os.path.join(out, "libpbrt_gpu_emulated.so"))
 

@@ -12,9 +12,9 @@ import pytest
 from conftest import ROOT
 
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-# not in the PBRT_EMULATE_ALL run: torch device buffers, the hipCUB-based device BVH build, the tile-serial samplers (they pass, but take
+# not in the PBRT_EMULATE_ALL run: torch device buffers, the tile-serial samplers (they pass, but take
 # minutes each: hundreds of thousands of tiny launches), full-size frames
-SKIP = "not device_buffers and not sampler_ and not 02sequence and not full_size and not invalid_media"  # (invalid_media: its last line asks pg_hlbvh_build)
+SKIP = "not device_buffers and not sampler_ and not 02sequence and not full_size"
 
 
 @pytest.fixture(scope="module")
@@ -39,6 +39,13 @@ def test_ray_queries_on_the_emulated_device(emulated):
     """Closest-hit and any-hit kernels: Triangle / quadric .Reintersect at extreme magnitudes, Watertight + degenerate triangles, rays
     through instanced objects -- hits, t, barycentrics and the reference's node / triangle counters equal the oracle's."""
     out = run_gpu_tests(emulated, ["tests/test_gpu_parity.py"], "reintersect_on_device or watertight or instance_rays_bit_exact and instance_boxes", 900)
+    assert " passed" in out and "failed" not in out
+
+
+def test_hlbvh_build_on_the_emulated_device(emulated):
+    """pg_hlbvh_build -- Morton codes, the hand-written radix sort (k_radix_*: LDS histograms, the one-block scan, eight ballots per
+    scatter step), treelets, emitLBVH, the upper SAH tree -- equals the host front end's HLBVHBuild node for node."""
+    out = run_gpu_tests(emulated, ["tests/test_hlbvh_build.py"], "not golden", 900)
     assert " passed" in out and "failed" not in out
 
 
