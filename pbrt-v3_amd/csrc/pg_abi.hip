@@ -967,8 +967,17 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
     bool tsBatched = false;
     if (rd->sampler > PG_SAMPLER_RANDOM && rd->integrator == 0 && s->d.nBssrdfs == 0 && !s->d.sparseLights && rd->sampler_dims <= 63 &&
         rd->sampler_dims >= 2 + 3 * (long long)rd->max_depth && !(getenv("PG_TS_BATCHED") && atoi(getenv("PG_TS_BATCHED")) == 0)) {
-        const size_t arrayBytes = (size_t)tileCount(rd) * 256 * (size_t)rd->sampler_dims * (size_t)rd->spp * 12;
-        tsBatched = arrayBytes <= ((size_t)48 << 30);
+        // The arrays of all local tiles are one allocation: taken here, before any state is set, so that a device without the room
+        // (less memory free, a large scene beside them) renders tile by tile as before instead of failing with PG_ERR_DEVICE.
+        const size_t nArr = (size_t)tileCount(rd) * 256 * (size_t)rd->sampler_dims * (size_t)rd->spp;
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) { freeB = 0; (void)hipGetLastError(); }
+        const size_t have = s->ts1.bytes + s->ts2.bytes;  // (buffers of an earlier frame are given back first)
+        if (nArr * 12 <= ((size_t)48 << 30) && nArr * 12 + ((size_t)2 << 30) <= freeB + have) {
+            s->ts1.release(); s->ts2.release();
+            tsBatched = s->ts1.alloc(sizeof(float) * (nArr + 1)) == hipSuccess && s->ts2.alloc(sizeof(float) * 2 * (nArr + 1)) == hipSuccess;
+            if (!tsBatched) { s->ts1.release(); s->ts2.release(); (void)hipGetLastError(); }
+        }
     }
     const bool tileSerial = rd->sampler >= PG_SAMPLER_RANDOM && !tsBatched;
     if (rd->sampler >= PG_SAMPLER_RANDOM) {
@@ -1440,8 +1449,7 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
     if (tsBatched) {  // every pixel's sample arrays, one lane per tile (the tile's stream in the reference's pixel order)
         const size_t nArr = (size_t)nLocalTiles * 256 * (size_t)rd->sampler_dims * (size_t)rd->spp;
         HIP_TRY(s->tsState.alloc(sizeof(TileSamplerState) * (size_t)nLocalTiles));
-        HIP_TRY(s->ts1.alloc(sizeof(float) * (nArr + 1)));
-        HIP_TRY(s->ts2.alloc(sizeof(float) * 2 * (nArr + 1)));
+        if (s->ts1.bytes < sizeof(float) * (nArr + 1) || s->ts2.bytes < sizeof(float) * 2 * (nArr + 1)) return setError(PG_ERR_DEVICE, "pg_render: sample arrays not allocated");  // (taken where tsBatched was decided)
         HIP_TRY(s->tsOverflow.alloc(sizeof(int)));
         HIP_TRY(hipMemsetAsync(s->tsOverflow.p, 0, sizeof(int), stream));
         s->d.ts = (TileSamplerState *)s->tsState.p; s->d.ts1 = (float *)s->ts1.p; s->d.ts2 = (float *)s->ts2.p;
@@ -1491,6 +1499,7 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
         HIP_TRY(hipMemcpyAsync(&over, s->tsOverflow.p, sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         s->d.ts = nullptr; s->d.ts1 = s->d.ts2 = nullptr; s->d.tsBatched = 0; s->d.tsOverflow = nullptr;
+        if (over & 2) return setError(PG_ERR_DEVICE, "pg_render: the start offsets of a tile's pixel sample arrays did not converge (k_ts_start_tile, internal error)");
         if (over) return setError(PG_ERR_DEVICE, "pg_render: a path drew beyond the %d sampled dimensions of the batched pixel sampler (internal error)", rd->sampler_dims);
     }
     HIP_TRY(hipEventRecord(evStop, stream));
@@ -1553,7 +1562,7 @@ struct Rccl {
     bool ok = false;
     std::string why;
 };
-Rccl &rccl() {
+Rccl *rcclApi() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
@@ -1567,7 +1576,7 @@ Rccl &rccl() {
         r.ok = r.CommInitAll && r.Gather && r.GetErrorString;
         if (!r.ok) r.why = "librccl lacks ncclCommInitAll / ncclGather";
     });
-    return r;
+    return &r;
 }
 std::mutex g_commMutex;
 std::map<std::vector<int>, std::vector<PgNcclComm>> g_comms;
@@ -1576,7 +1585,7 @@ const std::vector<PgNcclComm> *shardComms(const std::vector<int> &devices, std::
     std::vector<int> sorted = devices;
     std::sort(sorted.begin(), sorted.end());
     if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) { why = "a device appears twice in the list (RCCL wants one rank per GPU)"; return nullptr; }
-    Rccl &r = rccl();
+    Rccl &r = *rcclApi();
     if (!r.ok) { why = r.why; return nullptr; }
     std::lock_guard<std::mutex> lock(g_commMutex);
     auto it = g_comms.find(devices);
@@ -1662,8 +1671,8 @@ int pg_render_sharded(PgScene *const *scenes, int32_t n, const PgRenderDesc *des
         if (viaRccl) {
             // one collective per frame: every rank's thread calls it on its own communicator (the threads are the "different
             // threads" of rccl.h:213); root 0 receives rank r's shard at gather + r * per
-            const int rs = rccl().Gather(packed, r == 0 ? gather : nullptr, per, /*ncclChar*/ 0, 0, (*comms)[r], nullptr);
-            if (rs != 0) { status[r] = PG_ERR_DEVICE; message[r] = std::string("ncclGather: ") + rccl().GetErrorString(rs); return; }
+            const int rs = rcclApi()->Gather(packed, r == 0 ? gather : nullptr, per, /*ncclChar*/ 0, 0, (*comms)[r], nullptr);
+            if (rs != 0) { status[r] = PG_ERR_DEVICE; message[r] = std::string("ncclGather: ") + rcclApi()->GetErrorString(rs); return; }
             const hipError_t e = hipStreamSynchronize(nullptr);
             if (e != hipSuccess) { status[r] = PG_ERR_DEVICE; message[r] = std::string("after ncclGather: ") + hipGetErrorString(e); }
             return;

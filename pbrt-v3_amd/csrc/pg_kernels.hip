@@ -278,13 +278,13 @@ PG_DEV void ts_get2d(const DScene &sc, int kind, int tile, float &a, float &b) {
 // tsBatched (DScene): PixelSampler::Get1D / Get2D of sample `sample` of pixel `pixel`; dim = current2DDimension << 6 | current1DDimension
 PG_DEV float tsb_get1d(const DScene &sc, int pixel, int sample, int &dim) {
     const int c = dim & 63;
-    if (c >= sc.tsDims) { *sc.tsOverflow = 1; return 0.5f; }
+    if (c >= sc.tsDims) { atomicOr(sc.tsOverflow, 1); return 0.5f; }
     dim += 1;
     return sc.ts1[((size_t)pixel * sc.tsDims + c) * sc.tsSpp + sample];
 }
 PG_DEV void tsb_get2d(const DScene &sc, int pixel, int sample, int &dim, float &a, float &b) {
     const int c = dim >> 6;
-    if (c >= sc.tsDims) { *sc.tsOverflow = 1; a = b = 0.5f; return; }
+    if (c >= sc.tsDims) { atomicOr(sc.tsOverflow, 1); a = b = 0.5f; return; }
     dim += 64;
     const float *p = sc.ts2 + (((size_t)pixel * sc.tsDims + c) * sc.tsSpp + sample) * 2;
     a = p[0]; b = p[1];
@@ -452,6 +452,8 @@ __global__ __launch_bounds__(256) void k_ts_start_tile(DScene sc, RenderParams r
         if (!s_dirty) break;
         __syncthreads();
     }
+    // 300 passes without a fixed point would need ~300 rejection-loop repeats inside one tile (probability < 1e-1000): said, not assumed
+    if (p == 0 && s_dirty && sc.tsOverflow) atomicOr(sc.tsOverflow, 2);
     if (p == 0) { TileSamplerState t = t0; rng_advance(t, s_total); sc.ts[local] = t; }
 }
 void launch_ts_start_tile(const DScene &sc, const RenderParams &rp, hipStream_t s) {

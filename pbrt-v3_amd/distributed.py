@@ -37,21 +37,32 @@ class ShardBuffer:
 
 
 class FilmGather:
-    """The per-frame gather to `dst`.  Receive buffers are allocated once.  With `async_op` the collective is only enqueued
-    (RCCL orders it behind the render on the current stream and runs it on its own stream): the next frame -- rendered into
-    the OTHER ShardBuffer of a pair -- overlaps it, and wait() is called before a buffer is rendered into again."""
+    """The per-frame gather to `dst`.  With `async_op` the collective is only enqueued (RCCL orders it behind the render on the
+    current stream and runs it on its own stream): the next frame -- rendered into the OTHER ShardBuffer of a pair -- overlaps it,
+    and wait() is called before a buffer is rendered into again.  On `dst` every ShardBuffer has its OWN set of receive buffers
+    (allocated on first use, kept): what shards(b) returns stays valid while the next frame is gathered into the other buffer's
+    set -- until `b` itself is gathered again."""
 
     def __init__(self, shard, dst=0, comm_device=None):
         self.dst, self.rank, self.world = dst, dist.get_rank(), dist.get_world_size()
         self.comm_device = torch.device(comm_device) if comm_device is not None else shard.words.device
         self.staged = self.comm_device != shard.words.device  # pre-flight only: ranks sharing one GPU gather host copies through gloo
-        self.recv = [torch.empty(shard.words.shape, dtype=torch.int32, device=self.comm_device) for _ in range(self.world)] if self.rank == dst else None
+        self._recv = {}  # id(ShardBuffer) -> its receive buffers on dst
         self.pending = None
+        self._recv_for(shard)
+
+    def _recv_for(self, shard):
+        if self.rank != self.dst:
+            return None
+        r = self._recv.get(id(shard))
+        if r is None:
+            r = self._recv[id(shard)] = [torch.empty(shard.words.shape, dtype=torch.int32, device=self.comm_device) for _ in range(self.world)]
+        return r
 
     def start(self, shard, async_op=True):
         self.wait()
         src = shard.words.to(self.comm_device) if self.staged else shard.words
-        self.pending = dist.gather(src, self.recv, dst=self.dst, async_op=async_op)
+        self.pending = dist.gather(src, self._recv_for(shard), dst=self.dst, async_op=async_op)
         return self.pending
 
     def wait(self):
@@ -60,9 +71,9 @@ class FilmGather:
             self.pending = None
 
     def shards(self, shard):
-        """[(film, strays, n)] per rank on dst after wait()."""
+        """[(film, strays, n)] per rank on dst after wait(): views of `shard`'s own receive set."""
         self.wait()
-        return [shard.views_of(w) for w in self.recv]
+        return [shard.views_of(w) for w in self._recv_for(shard)]
 
 
 # --- the older three-buffer interface (tests, small tools): same transport, one gather per buffer
