@@ -531,6 +531,8 @@ static void launch_trace(const DScene &sc, const TraceConfig &c, RayQueue q0, Ra
     int nblk = (int)std::min<long long>((need + TR_BLOCK / 64 - 1) / (TR_BLOCK / 64), (long long)c.gridBlocks * 256 / TR_BLOCK);
     nblk = ((nblk + 7) / 8) * 8;
     size_t lds = sizeof(uint2) * (size_t)c.depth * TR_BLOCK;
+    // experiments only (profiles/r04g_*): unused LDS per block, to hold the kernel at fewer resident waves than its registers allow
+    if (const char *e = getenv("PG_TRACE_LDS_PAD")) { const long v = atol(e); if (v > 0 && lds + (size_t)v <= 160 * 1024) lds += (size_t)v; }
     (void)hipMemsetAsync(cursors, 0, 2 * PG_REGIONS * PG_COUNT_STRIDE * sizeof(int), s);
     // a "tail" launch: q0's cursors start where its regions ended before the latest entries were appended
     if (cursorInit) (void)hipMemcpyAsync(cursors, cursorInit, PG_REGIONS * PG_COUNT_STRIDE * sizeof(int), hipMemcpyDeviceToDevice, s);
