@@ -45,7 +45,7 @@ if [ "$MODE" = full ]; then
   tail -5 $OUT/pytest_slow.log
   find $OUT -name '*counter_collection.csv' -size +4M -delete
   ( timeout 600 python tools/ts_timing.py 960 540 16 > $OUT/ts_timing.json 2> $OUT/ts_timing.err ); cat $OUT/ts_timing.json
-  # 240 more random scenes than the suite holds, through the kernels (film, counters, rays against the correctly-rounded oracle): ~2.5 GPU-minutes
-  ( timeout 400 python -u tools/fuzz_emulated_device.py 24 64 2>&1 | grep -v '^Warning' > $OUT/fuzz_gpu.log ); tail -3 $OUT/fuzz_gpu.log
+  # more random scenes than the suite holds, through the kernels (film, counters, rays against the oracle): ~2.5 GPU-minutes
+  ( timeout 600 python -u tools/fuzz_emulated_device.py 120 220 2>&1 | grep -v '^Warning' > $OUT/fuzz_gpu.log ); tail -3 $OUT/fuzz_gpu.log
   ( timeout 300 python tools/shard_timing.py > $OUT/shard_timing.json 2> $OUT/shard_timing.err ); cat $OUT/shard_timing.json
 fi
