@@ -58,6 +58,8 @@ struct PgScene {
     int capacity = 0;
     DeviceBuffer sceneCopy;  // DScene::self
     DeviceBuffer tsOverflow;  // tsBatched: the flag a draw beyond the sample arrays raises
+    DeviceBuffer matLobes, matHead;  // k_material: the BxDF lists and shading frames of the hits on materials with textured parameters (MatPre)
+    int matStride = 0;               // the largest such list of this scene, 0: materials are evaluated inside the shading kernel
     DeviceBuffer shadeOrder, primClass, volPre;  // k_shade_order: the order buffer of the main queue, the primitives' material classes, volpath's pre-drawn medium samples
     bool volOrder = false;  // volpath launches shade medium vertices and surface vertices in separate waves (scenes with homogeneous media only)
     DeviceBuffer qo[4], qd[4], counts, hitsMain, hitInst, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
@@ -697,6 +699,33 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     d.images = (const PgImage *)s->images.p; d.texels = (const float *)s->texels.p; d.ewaLut = (const float *)s->ewaLut.p;
     d.textures = (const PgTexture *)s->textures.p; d.textured = (const PgTexturedMaterial *)s->textured.p;
     d.hasTextured = anyTextured ? 1 : 0;
+    s->matStride = 0;
+    {   // k_material (materials evaluated ahead of the shading launch): room per hit = the longest BxDF list a material of this scene can
+        // build, counted as the materials' ComputeScatteringFunctions add them (materials/*.cpp; MatEval, pg_kernels.hip).  Not for scenes
+        // with BSSRDF materials or grid media (their kernels evaluate inside), PG_MAT_PRE=0: nowhere.
+        const char *mp = getenv("PG_MAT_PRE");
+        if (anyTextured && desc->n_bssrdfs == 0 && d.nGrids == 0 && !(mp && atoi(mp) == 0)) {
+            std::vector<int> bound((size_t)desc->n_materials, -1);
+            std::function<int(int, int)> lobes = [&](int mi, int depth) -> int {
+                if (mi < 0 || mi >= desc->n_materials) return 0;
+                const PgMaterial &m = desc->materials[mi];
+                if (m.type != PG_MAT_TEXTURED) return std::min(std::max(m.n_bxdfs, 0), PG_MAX_BXDFS);
+                const PgTexturedMaterial &tm = desc->textured[m.textured_index];
+                switch (tm.kind) {
+                case PG_KIND_MATTE: case PG_KIND_MIRROR: case PG_KIND_METAL: case PG_KIND_SUBSTRATE: return 1;
+                case PG_KIND_PLASTIC: case PG_KIND_GLASS: return 2;
+                case PG_KIND_UBER: return 5;
+                case PG_KIND_TRANSLUCENT: return 4;
+                case PG_KIND_MIX: return depth >= 3 ? PG_MAX_BXDFS : std::min(PG_MAX_BXDFS, lobes(tm.sub[0], depth + 1) + lobes(tm.sub[1], depth + 1));
+                }
+                return PG_MAX_BXDFS;
+            };
+            int stride = 1;
+            for (int i = 0; i < desc->n_materials; ++i)
+                if (desc->materials[i].type == PG_MAT_TEXTURED) stride = std::max(stride, lobes(i, 0));
+            s->matStride = stride;
+        }
+    }
     {   // shading classes (k_shade_order): scenes whose materials evaluate textures / BxDF lists shade grouped by material.  Few
         // materials: each is a class (its textures stay with its waves as well); many: materials that run the same code
         // (type, kind, bump) share one.  PG_SHADE_ORDER=0: queue order, as scenes without such materials are shaded.
@@ -916,6 +945,17 @@ static int ensureWorkBuffers(PgScene *s, int capacity) {
     HIP_TRY(s->hitsMain.alloc(hitParts * n * sizeof(float4)));
     if (s->d.primClass || s->volOrder) HIP_TRY(s->shadeOrder.alloc(n * sizeof(int)));
     if (s->volOrder) HIP_TRY(s->volPre.alloc(n * sizeof(float2)));
+    if (s->matStride > 0) {  // k_material's lists and frames, one set per main-queue entry; no room: the shading kernel evaluates materials itself
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) { freeB = 0; (void)hipGetLastError(); }
+        const size_t want = n * ((size_t)s->matStride * sizeof(PgBxDF) + 2 * sizeof(float4)), have = s->matLobes.bytes + s->matHead.bytes;
+        s->matLobes.release(); s->matHead.release();
+        // (everything else of this function and the integrator's own state -- about 600 B per slot -- is still to be allocated)
+        const bool fits = want + n * 700 + ((size_t)1 << 30) <= freeB + have;
+        if (!fits || s->matLobes.alloc(n * (size_t)s->matStride * sizeof(PgBxDF)) != hipSuccess || s->matHead.alloc(n * 2 * sizeof(float4)) != hipSuccess) {
+            s->matLobes.release(); s->matHead.release(); (void)hipGetLastError();
+        }
+    }
     if (s->d.nInstances > 0) { HIP_TRY(s->hitInst.alloc(hitParts * n * sizeof(int))); s->d.hitInst = (int *)s->hitInst.p; }  // main-queue hits, then MIS-queue hits at offset n (one launch fills both)
     HIP_TRY(s->occluded.alloc(n * sizeof(int)));
     HIP_TRY(s->stL.alloc(n * sizeof(float4)));
@@ -1129,6 +1169,7 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
     // shade the entries that waited for them (one host round trip per launch while the table warms up; none once every
     // voxel the image touches exists -- the tables stay with the scene).
     rp.retryList = (int *)s->retryList.p;
+    if (s->matLobes.p && s->matHead.p) { rp.matPre.lobes = (PgBxDF *)s->matLobes.p; rp.matPre.head = (float4 *)s->matHead.p; rp.matPre.stride = s->matStride; }
     auto settleLightTables = [&](const std::function<void()> &reshade) -> int {
         if (!s->d.sparseLights) return PG_OK;
         int cnt[2] = {0, 0};

@@ -212,6 +212,14 @@ struct SssState {
     RayQueue qjob;     // the first probe ray of every path that entered this branch at the current bounce (appended by k_shade)
 };
 
+// Materials evaluated ahead of the shading launch (k_material, pg_kernels.hip): for every main-queue entry whose hit has a
+// material with textured parameters (PG_MAT_TEXTURED) and whose path is still alive, Material::ComputeScatteringFunctions' outputs
+// -- the BxDF list, BSDF::eta and the shading frame Material::Bump leaves -- at the ENTRY's index (the index of its hit record):
+//   head[2 e] = (shading.n, BSDF::eta)   head[2 e + 1] = (shading.dpdu, number of BxDFs as int bits)   lobes[e * stride + k]
+// stride = the scene's largest list (PgScene: counted per material kind, <= PG_MAX_BXDFS).  lobes == nullptr: the scene has no
+// such material, or the buffers did not fit -- the shading kernel then evaluates materials itself (k_shade<2, .>).
+struct MatPre { PgBxDF *lobes; float4 *head; int stride; };
+
 #define PG_META_SPECULAR 0x10000
 #define PG_META_DONE 0x20000
 #define PG_META_HASDIFF 0x80000  // the ray still is the camera's RayDifferential (cleared by the first SpawnRay)
@@ -231,6 +239,7 @@ struct RenderParams {
     // volpath, GlobalSamplers: k_shade_order has drawn HomogeneousMedium::Sample's two numbers for every entry whose ray is in a
     // medium -- volPre[entry] = (channel as int bits, sampled distance); the shading kernel takes them from here.  nullptr: it draws.
     const float2 *volPre;
+    MatPre matPre;    // k_material's outputs for this launch's queue (lobes == nullptr: none)
     int tsGuessSkew;  // tests (PG_TS_GUESS_SKEW): added to k_ts_start_tile's first guess of a StartPixel's consumption, so that its correction passes run
 };
 

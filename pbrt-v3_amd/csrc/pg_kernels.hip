@@ -1355,19 +1355,21 @@ PG_DEV float roughness_to_alpha(float roughness) {  // microfacet.h:127-132; std
 }
 PG_DEV void lobe_tr(PgBxDF &b, float ax, float ay) { b.alpha_x = pmax(0.001f, ax); b.alpha_y = pmax(0.001f, ay); }  // microfacet.h:109-113
 // Material::ComputeScatteringFunctions of material `mat` at this hit (materials/): appends its BxDFs to out[n...]; eta receives
-// BSDF::eta.  D bounds the nesting of mix materials.
-template <int D> struct MatEval {
-    static PG_DEV_CALL void run(const DScene &sc, int mat, const TexHit &h, PgBxDF *out, int &n, float &eta) {
+// BSDF::eta.  D bounds the nesting of mix materials; cap = the room in out[] (PG_MAX_BXDFS, or the scene's largest list when the
+// list goes to k_material's buffer).
+template <int D, int W = 0> struct MatEval {
+    static PG_DEV_CALL void run(const DScene &sc, int mat, const TexHit &h, PgBxDF *out, int &n, float &eta, int capArg) {
+        const int cap = W == 0 ? PG_MAX_BXDFS : capArg;  // (the shading kernel's own copies: a constant, no register held for it)
         const PgMaterial &m = sc.materials[mat];
         if (m.type != PG_MAT_TEXTURED) {  // constant parameters: the list the host built
-            for (int i = 0; i < m.n_bxdfs && n < PG_MAX_BXDFS; ++i) out[n++] = sc.bxdfs[m.first_bxdf + i];
+            for (int i = 0; i < m.n_bxdfs && n < cap; ++i) out[n++] = sc.bxdfs[m.first_bxdf + i];
             eta = m.bsdf_eta;
             return;
         }
         const PgTexturedMaterial &tm = sc.textured[m.textured_index];
-        auto TS = [&](int i) { return TexEval<PG_TEX_DEPTH>::s(sc, tm.s[i], h); };
-        auto TF = [&](int i) { return TexEval<PG_TEX_DEPTH>::f(sc, tm.f[i], h); };
-        auto push = [&](const PgBxDF &b) { if (n < PG_MAX_BXDFS) out[n++] = b; };
+        auto TS = [&](int i) { return TexEval<PG_TEX_DEPTH, W>::s(sc, tm.s[i], h); };
+        auto TF = [&](int i) { return TexEval<PG_TEX_DEPTH, W>::f(sc, tm.f[i], h); };
+        auto push = [&](const PgBxDF &b) { if (n < cap) out[n++] = b; };
         PgBxDF b;
         eta = 1;
         switch (tm.kind) {
@@ -1487,7 +1489,7 @@ template <int D> struct MatEval {
             for (int j = 0; j < 2; ++j) {
                 const int first = n;
                 float subEta = 1;
-                MatEval<D - 1>::run(sc, tm.sub[j], h, out, n, subEta);
+                MatEval<D - 1, W>::run(sc, tm.sub[j], h, out, n, subEta, cap);
                 if (j == 0) eta = subEta;  // si->bsdf stays m1's
                 const Spec scl = j == 0 ? s1 : s2;
                 for (int i = first; i < n; ++i)
@@ -1498,10 +1500,11 @@ template <int D> struct MatEval {
         }
     }
 };
-template <> struct MatEval<0> {  // below the deepest mix the host allows: only constant-parameter materials
-    static PG_DEV void run(const DScene &sc, int mat, const TexHit &, PgBxDF *out, int &n, float &eta) {
+template <int W> struct MatEval<0, W> {  // below the deepest mix the host allows: only constant-parameter materials
+    static PG_DEV void run(const DScene &sc, int mat, const TexHit &, PgBxDF *out, int &n, float &eta, int capArg) {
+        const int cap = W == 0 ? PG_MAX_BXDFS : capArg;
         const PgMaterial &m = sc.materials[mat];
-        for (int i = 0; i < m.n_bxdfs && n < PG_MAX_BXDFS; ++i) out[n++] = sc.bxdfs[m.first_bxdf + i];
+        for (int i = 0; i < m.n_bxdfs && n < cap; ++i) out[n++] = sc.bxdfs[m.first_bxdf + i];
         eta = m.bsdf_eta;
     }
 };
@@ -1882,6 +1885,103 @@ PG_DEV void prim_interface(const DScene &sc, int prim, int rayMedium, int &mIn, 
     else mIn = mOut = rayMedium;
 }
 
+// InterpolatedPrimToWorld(*isect) of a hit reached through an object instance, transform.cpp:262-297
+PG_DEV void isect_to_world(const PgInstance &in, Isect &is) {
+    Isect w;
+    w.p = m4_point_err2(in.i2w, is.p, is.pError, w.pError);
+    w.n = normalize(m4_normal(in.w2i, is.n));
+    w.wo = normalize(m4_vec(in.i2w, is.wo));
+    w.sdpdu = m4_vec(in.i2w, is.sdpdu);
+    w.sdpdv = m4_vec(in.i2w, is.sdpdv);
+    w.sdndu = m4_normal(in.w2i, is.sdndu); w.sdndv = m4_normal(in.w2i, is.sdndv);
+    w.ns = normalize(m4_normal(in.w2i, is.ns));
+    if (dot(w.ns, w.n) < 0.f) w.ns = -w.ns;  // Faceforward(shading.n, n)
+    is = w;
+}
+// What textures read of the SurfaceInteraction at main-queue entry i: (u, v), p and ComputeDifferentials' outputs
+// (interaction.cpp:101-147).  sph*: a quadric hit's (u, v) and geometric dpdu / dpdv; filmX / filmY: the camera sample's pFilm
+PG_DEV void tex_hit_setup(const DScene &sc, const PgRenderDesc &rd, const RayQueue &qin, int i, int slot, int prim, const Tri &tri, float4 h4, V3 rayD, int inst,
+                          bool onSphere, float sphU, float sphV, V3 sphDpdu, V3 sphDpdv, const Isect &is, int4 meta, float filmX, float filmY,
+                          bool tileSerial, bool pixelArrays, uint64_t index, TexHit &th) {
+    th.p = is.p;
+    V3 gdpdu, gdpdv;  // the geometric dpdu / dpdv (not the shading ones)
+    if (onSphere) { th.u = sphU; th.v = sphV; gdpdu = sphDpdu; gdpdv = sphDpdv; }
+    else {
+        float uv[6];
+        load_uv(sc, prim, tri.flags, uv);
+        tri_dpdu_dpdv(tri.p0, tri.p1, tri.p2, uv, gdpdu, gdpdv);
+        th.u = h4.y * uv[0] + h4.z * uv[2] + h4.w * uv[4];  // uvHit, triangle.cpp:332
+        th.v = h4.y * uv[1] + h4.z * uv[3] + h4.w * uv[5];
+    }
+    if (inst >= 0 && !sc.instances[inst].identity) { gdpdu = m4_vec(sc.instances[inst].i2w, gdpdu); gdpdv = m4_vec(sc.instances[inst].i2w, gdpdv); }
+    th.dpdx = th.dpdy = mk(0, 0, 0);
+    th.dudx = th.dvdx = th.dudy = th.dvdy = 0;
+    if (meta.w & PG_META_HASDIFF) {  // SurfaceInteraction::ComputeDifferentials, interaction.cpp:101-147
+        const float4 o4 = qin.o[i];
+        const V3 rayO = mk(o4.x, o4.y, o4.z);
+        float l0 = 0, l1 = 0;
+        if (tileSerial) { l0 = sc.ts[slot].lens0; l1 = sc.ts[slot].lens1; }  // the camera sample's pLens, kept by k_ts_generate
+        else if (pixelArrays) { int d2 = 1 << 6; tsb_get2d(sc, meta.x, meta.y, d2, l0, l1); }  // (its second 2D dimension)
+        else if (rd.lens_radius > 0) { l0 = halton_sample(sc, rd, index, 3); l1 = halton_sample(sc, rd, index, 4); }
+        V3 rxO, rxD, ryO, ryD;
+        camera_differentials(rd, filmX, filmY, l0, l1, rayO, rayD, rxO, rxD, ryO, ryD);
+        const V3 n = is.n, p = is.p;
+        const float dd = dot(n, p);
+        const float tx = -(dot(n, rxO) - dd) / dot(n, rxD);
+        const float ty = -(dot(n, ryO) - dd) / dot(n, ryD);
+        if (!(isinf(tx) || isnan(tx)) && !(isinf(ty) || isnan(ty))) {
+            const V3 px = rxO + rxD * tx, py = ryO + ryD * ty;
+            th.dpdx = px - p;
+            th.dpdy = py - p;
+            int d0, d1;
+            if (fabsf(n.x) > fabsf(n.y) && fabsf(n.x) > fabsf(n.z)) { d0 = 1; d1 = 2; }
+            else if (fabsf(n.y) > fabsf(n.z)) { d0 = 0; d1 = 2; }
+            else { d0 = 0; d1 = 1; }
+            auto comp = [](V3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); };
+            const float A00 = comp(gdpdu, d0), A01 = comp(gdpdv, d0), A10 = comp(gdpdu, d1), A11 = comp(gdpdv, d1);
+            const float Bx0 = comp(px, d0) - comp(p, d0), Bx1 = comp(px, d1) - comp(p, d1);
+            const float By0 = comp(py, d0) - comp(p, d0), By1 = comp(py, d1) - comp(p, d1);
+            const float det = A00 * A11 - A01 * A10;  // SolveLinearSystem2x2, transform.cpp:41-49
+            if (!(fabsf(det) < 1e-10f)) {
+                th.dudx = (A11 * Bx0 - A01 * Bx1) / det; th.dvdx = (A00 * Bx1 - A10 * Bx0) / det;
+                if (isnan(th.dudx) || isnan(th.dvdx)) th.dudx = th.dvdx = 0;
+                th.dudy = (A11 * By0 - A01 * By1) / det; th.dvdy = (A00 * By1 - A10 * By0) / det;
+                if (isnan(th.dudy) || isnan(th.dvdy)) th.dudy = th.dvdy = 0;
+            }
+        }
+    }
+}
+// Material::Bump (material.cpp:46-85) of the material whose BSDF this is: its own bump map, or -- through mix materials, whose
+// BSDF is their first material's -- the first material's
+template <int W = 0>
+PG_DEV void material_bump(const DScene &sc, int material, const TexHit &th, Isect &is) {
+    int bm = material;
+    for (int lvl = 0; lvl < 4; ++lvl) {
+        const PgMaterial &mm = sc.materials[bm];
+        if (mm.type != PG_MAT_TEXTURED) break;
+        const PgTexturedMaterial &tmm = sc.textured[mm.textured_index];
+        if (tmm.kind == PG_KIND_MIX) { if (tmm.sub[0] < 0) break; bm = tmm.sub[0]; continue; }
+        if (tmm.has_bump) {
+            TexHit ev = th;
+            float du = .5f * (fabsf(th.dudx) + fabsf(th.dudy));
+            if (du == 0) du = .0005f;
+            ev.p = th.p + is.sdpdu * du; ev.u = th.u + du; ev.v = th.v + 0.f;
+            const float uDisplace = TexEval<PG_TEX_DEPTH, W>::f(*sc.self, tmm.bump, ev);
+            float dv = .5f * (fabsf(th.dvdx) + fabsf(th.dvdy));
+            if (dv == 0) dv = .0005f;
+            ev.p = th.p + is.sdpdv * dv; ev.u = th.u + 0.f; ev.v = th.v + dv;
+            const float vDisplace = TexEval<PG_TEX_DEPTH, W>::f(*sc.self, tmm.bump, ev);
+            const float displace = TexEval<PG_TEX_DEPTH, W>::f(*sc.self, tmm.bump, th);
+            const V3 bdpdu = (is.sdpdu + is.ns * ((uDisplace - displace) / du)) + is.sdndu * displace;
+            const V3 bdpdv = (is.sdpdv + is.ns * ((vDisplace - displace) / dv)) + is.sdndv * displace;
+            is.ns = normalize(cross(bdpdu, bdpdv));  // SetShadingGeometry(..., false), interaction.cpp:72-89
+            if (dot(is.ns, is.n) < 0.f) is.ns = -is.ns;
+            is.sdpdu = bdpdu; is.sdpdv = bdpdv;
+        }
+        break;
+    }
+}
+
 // PG_SHADE_MIN_WAVES: waves per SIMD the BxDF-list variants (MODE 1) are compiled for.  Left alone the volumetric one takes 177
 // VGPRs = 2 waves; capped at 168 (3 waves, 20 B of scratch) it is 31 % faster (150 -> 104 ms per frame on the 1 M-triangle volpath
 // workload, profiles/r02p_*); 4 waves (128 VGPRs, 200 B of scratch) lose most of that again.  The surface-only variant is at 3 already.
@@ -1920,10 +2020,12 @@ PG_DEV void homogeneous_sample_distance(const PgMedium &mm, float uChannel, floa
 }
 struct GridShade { float4 *vertex; int phase; };  // vertex[slot] = (medium interaction point, kind: 0 none, 1 medium vertex, 2 surface vertex)
 template <int MODE, bool VOL, bool SSS = false, bool GRID = false>
-__global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MODE == 1 && PG_SHADE_MIN_WAVES > 0) ? PG_SHADE_MIN_WAVES : (MODE == 2 ? (VOL ? PG_SHADE2V_WAVES : PG_SHADE2_WAVES) : 1))) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
+__global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MODE == 1 || MODE == 3) && PG_SHADE_MIN_WAVES > 0) ? PG_SHADE_MIN_WAVES : (MODE == 2 ? (VOL ? PG_SHADE2V_WAVES : PG_SHADE2_WAVES) : 1))) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
                                                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, VolState vs,
                                                      const float *__restrict__ hitT, QueueState qsIn, QueueState qsOut, SssState sss, GridShade gsh) {
-    constexpr bool EXT = MODE >= 1, TEX = MODE == 2;
+    // MODE 3: MODE 1 over the lists k_material left for the hits on materials with textured parameters (rp.matPre)
+    constexpr bool EXT = MODE >= 1, TEX = MODE == 2, PRE = MODE == 3;
+    static_assert(!PRE || (!SSS && !GRID), "materials evaluated ahead: the plain path / volpath kernels");
     static_assert(!GRID || (VOL && !SSS), "grid media: volpath, without BSSRDF materials");
     const bool phaseA = GRID && gsh.phase == 1, phaseB = GRID && gsh.phase == 2;
     int vertexKind = 0;  // GRID: what phase 1 found at this entry (phase 2 reads it back)
@@ -2181,19 +2283,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
         }
         if (alive && !handled) {
             if (!onSphere) is = make_isect(sc, prim, tri, h4.y, h4.z, h4.w, shapeRayD);
-            if (inst >= 0 && !sc.instances[inst].identity) {  // InterpolatedPrimToWorld(*isect), transform.cpp:262-297
-                const PgInstance &in = sc.instances[inst];
-                Isect w;
-                w.p = m4_point_err2(in.i2w, is.p, is.pError, w.pError);
-                w.n = normalize(m4_normal(in.w2i, is.n));
-                w.wo = normalize(m4_vec(in.i2w, is.wo));
-                w.sdpdu = m4_vec(in.i2w, is.sdpdu);
-                w.sdpdv = m4_vec(in.i2w, is.sdpdv);
-                w.sdndu = m4_normal(in.w2i, is.sdndu); w.sdndv = m4_normal(in.w2i, is.sdndv);
-                w.ns = normalize(m4_normal(in.w2i, is.ns));
-                if (dot(w.ns, w.n) < 0.f) w.ns = -w.ns;  // Faceforward(shading.n, n)
-                is = w;
-            }
+            if (inst >= 0 && !sc.instances[inst].identity) isect_to_world(sc.instances[inst], is);
             const PgMaterial &m = mtl;
             int mIn = 0, mOut = 0;  // VOL: isect.mediumInterface
             if constexpr (VOL) prim_interface(sc, prim, med, mIn, mOut);
@@ -2225,89 +2315,25 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
                 if constexpr (EXT) {
                     TexHit th;
                     if constexpr (TEX) {
-                        // what textures read of the SurfaceInteraction: (u, v), p and ComputeDifferentials' outputs
-                        th.p = is.p;
-                        V3 gdpdu, gdpdv;  // the geometric dpdu / dpdv (not the shading ones)
-                        if (onSphere) { th.u = sphU; th.v = sphV; gdpdu = sphDpdu; gdpdv = sphDpdv; }
-                        else {
-                            float uv[6];
-                            load_uv(sc, prim, tri.flags, uv);
-                            tri_dpdu_dpdv(tri.p0, tri.p1, tri.p2, uv, gdpdu, gdpdv);
-                            th.u = h4.y * uv[0] + h4.z * uv[2] + h4.w * uv[4];  // uvHit, triangle.cpp:332
-                            th.v = h4.y * uv[1] + h4.z * uv[3] + h4.w * uv[5];
-                        }
-                        if (inst >= 0 && !sc.instances[inst].identity) { gdpdu = m4_vec(sc.instances[inst].i2w, gdpdu); gdpdv = m4_vec(sc.instances[inst].i2w, gdpdv); }
-                        th.dpdx = th.dpdy = mk(0, 0, 0);
-                        th.dudx = th.dvdx = th.dudy = th.dvdy = 0;
-                        if (meta.w & PG_META_HASDIFF) {  // SurfaceInteraction::ComputeDifferentials, interaction.cpp:101-147
-                            const float4 o4 = qin.o[i];
-                            const V3 rayO = mk(o4.x, o4.y, o4.z);
-                            float l0 = 0, l1 = 0;
-                            if (tileSerial) { l0 = sc.ts[slot].lens0; l1 = sc.ts[slot].lens1; }  // the camera sample's pLens, kept by k_ts_generate
-                            else if (pixelArrays) { int d2 = 1 << 6; tsb_get2d(sc, meta.x, meta.y, d2, l0, l1); }  // (its second 2D dimension)
-                            else if (rd.lens_radius > 0) { l0 = halton_sample(sc, rd, index, 3); l1 = halton_sample(sc, rd, index, 4); }
-                            V3 rxO, rxD, ryO, ryD;
-                            camera_differentials(rd, L4.w, B4.w, l0, l1, rayO, rayD, rxO, rxD, ryO, ryD);
-                            const V3 n = is.n, p = is.p;
-                            const float dd = dot(n, p);
-                            const float tx = -(dot(n, rxO) - dd) / dot(n, rxD);
-                            const float ty = -(dot(n, ryO) - dd) / dot(n, ryD);
-                            if (!(isinf(tx) || isnan(tx)) && !(isinf(ty) || isnan(ty))) {
-                                const V3 px = rxO + rxD * tx, py = ryO + ryD * ty;
-                                th.dpdx = px - p;
-                                th.dpdy = py - p;
-                                int d0, d1;
-                                if (fabsf(n.x) > fabsf(n.y) && fabsf(n.x) > fabsf(n.z)) { d0 = 1; d1 = 2; }
-                                else if (fabsf(n.y) > fabsf(n.z)) { d0 = 0; d1 = 2; }
-                                else { d0 = 0; d1 = 1; }
-                                auto comp = [](V3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); };
-                                const float A00 = comp(gdpdu, d0), A01 = comp(gdpdv, d0), A10 = comp(gdpdu, d1), A11 = comp(gdpdv, d1);
-                                const float Bx0 = comp(px, d0) - comp(p, d0), Bx1 = comp(px, d1) - comp(p, d1);
-                                const float By0 = comp(py, d0) - comp(p, d0), By1 = comp(py, d1) - comp(p, d1);
-                                const float det = A00 * A11 - A01 * A10;  // SolveLinearSystem2x2, transform.cpp:41-49
-                                if (!(fabsf(det) < 1e-10f)) {
-                                    th.dudx = (A11 * Bx0 - A01 * Bx1) / det; th.dvdx = (A00 * Bx1 - A10 * Bx0) / det;
-                                    if (isnan(th.dudx) || isnan(th.dvdx)) th.dudx = th.dvdx = 0;
-                                    th.dudy = (A11 * By0 - A01 * By1) / det; th.dvdy = (A00 * By1 - A10 * By0) / det;
-                                    if (isnan(th.dudy) || isnan(th.dvdy)) th.dudy = th.dvdy = 0;
-                                }
-                            }
-                        }
-                        // Material::Bump (material.cpp:46-85) of the material whose BSDF this is: its own bump map, or -- through
-                        // mix materials, whose BSDF is their first material's -- the first material's
-                        int bm = tri.material;
-                        for (int lvl = 0; lvl < 4; ++lvl) {
-                            const PgMaterial &mm = sc.materials[bm];
-                            if (mm.type != PG_MAT_TEXTURED) break;
-                            const PgTexturedMaterial &tmm = sc.textured[mm.textured_index];
-                            if (tmm.kind == PG_KIND_MIX) { if (tmm.sub[0] < 0) break; bm = tmm.sub[0]; continue; }
-                            if (tmm.has_bump) {
-                                TexHit ev = th;
-                                float du = .5f * (fabsf(th.dudx) + fabsf(th.dudy));
-                                if (du == 0) du = .0005f;
-                                ev.p = th.p + is.sdpdu * du; ev.u = th.u + du; ev.v = th.v + 0.f;
-                                const float uDisplace = TexEval<PG_TEX_DEPTH>::f(*sc.self, tmm.bump, ev);
-                                float dv = .5f * (fabsf(th.dvdx) + fabsf(th.dvdy));
-                                if (dv == 0) dv = .0005f;
-                                ev.p = th.p + is.sdpdv * dv; ev.u = th.u + 0.f; ev.v = th.v + dv;
-                                const float vDisplace = TexEval<PG_TEX_DEPTH>::f(*sc.self, tmm.bump, ev);
-                                const float displace = TexEval<PG_TEX_DEPTH>::f(*sc.self, tmm.bump, th);
-                                const V3 bdpdu = (is.sdpdu + is.ns * ((uDisplace - displace) / du)) + is.sdndu * displace;
-                                const V3 bdpdv = (is.sdpdv + is.ns * ((vDisplace - displace) / dv)) + is.sdndv * displace;
-                                is.ns = normalize(cross(bdpdu, bdpdv));  // SetShadingGeometry(..., false), interaction.cpp:72-89
-                                if (dot(is.ns, is.n) < 0.f) is.ns = -is.ns;
-                                is.sdpdu = bdpdu; is.sdpdv = bdpdv;
-                            }
-                            break;
-                        }
+                        tex_hit_setup(sc, rd, qin, i, slot, prim, tri, h4, rayD, inst, onSphere, sphU, sphV, sphDpdu, sphDpdv, is, meta, L4.w, B4.w, tileSerial,
+                                      pixelArrays, index, th);
+                        material_bump(sc, tri.material, th, is);
+                    }
+                    const bool preEvaluated = PRE && m.type == PG_MAT_TEXTURED;
+                    float4 head0 = make_float4(0, 0, 0, 0), head1 = head0;
+                    if (preEvaluated) {  // the shading frame after Material::Bump, as k_material left it
+                        head0 = rp.matPre.head[2 * (size_t)i]; head1 = rp.matPre.head[2 * (size_t)i + 1];
+                        is.ns = mk(head0.x, head0.y, head0.z);
+                        is.sdpdu = mk(head1.x, head1.y, head1.z);
                     }
                     lb.ns = is.ns; lb.ng = is.n;
                     lb.ss = normalize(is.sdpdu);
                     lb.ts = cross(lb.ns, lb.ss);
-                    if constexpr (TEX) {
+                    if (preEvaluated) { lb.lobes = rp.matPre.lobes + (size_t)i * rp.matPre.stride; lb.n = __float_as_int(head1.w); lb.eta = head0.w; }
+                    else if constexpr (TEX) {
                         int nl = 0;
                         float etaL = 1;
-                        MatEval<2>::run(*sc.self, tri.material, th, lobeStore, nl, etaL);
+                        MatEval<2>::run(*sc.self, tri.material, th, lobeStore, nl, etaL, PG_MAX_BXDFS);
                         lb.lobes = lobeStore; lb.n = nl; lb.eta = etaL;
                     } else { lb.lobes = sc.bxdfs + m.first_bxdf; lb.n = m.n_bxdfs; lb.eta = m.bsdf_eta; }
                     if constexpr (SSS) {  // si->bssrdf = TabulatedBSSRDF(...): subsurface.cpp:87-90, kdsubsurface.cpp:88-93
@@ -2610,6 +2636,78 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : ((MOD
     unsigned long long nl = wave_sum(nLightTests);
     if (lane_id() == 0 && nl) atomicAdd(lightTriTests + (blockIdx.x & (PG_LIGHT_TEST_SHARDS - 1)) * PG_LIGHT_TEST_STRIDE, nl);
 }
+// Material::ComputeScatteringFunctions ahead of the shading launch, for the main-queue entries whose hit has a material with
+// textured parameters: the interaction (as k_shade builds it), what textures read of it (tex_hit_setup), Material::Bump and the
+// material's BxDF list, written to rp.matPre at the entry's index; k_shade<3, .> takes them from there and is the BxDF-list kernel
+// otherwise.  Why two launches: evaluated inside the shading kernel (k_shade<2, .>) the texture / material evaluators' registers and
+// call frames come on top of a path vertex's whole state -- 251 VGPRs, two waves per SIMD, the list of up to 8 x 120 B in scratch --
+// and the kernel waits on dependent fetches (material -> texture node -> MIP level -> texels) with little else resident to run.
+// Here only the interaction is live across the evaluators, the list is written where it is read from, and the threads take the
+// entries in the same material-class order (rp.order).  An entry the shading kernel will not shade as a surface vertex (the path
+// is over, a null material, volpath: the ray scattered in its medium first) is skipped when that is known without drawing.
+#ifndef PG_MATERIAL_WAVES
+#define PG_MATERIAL_WAVES 3
+#endif
+template <bool VOL>
+__global__ __launch_bounds__(PG_SHADE_BLOCK, PG_MATERIAL_WAVES) void k_material(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
+                                                                               VolState vs, const float *__restrict__ hitT, QueueState qsIn) {
+    int i = queue_item<PG_SHADE_BLOCK>(qin);
+    if (i < 0) return;
+    if (rp.order) i = rp.order[i];
+    const float4 h4 = hits[i];
+    const int prim = __float_as_int(h4.x);
+    if (prim < 0) return;
+    const Tri tri = load_tri(sc, prim);
+    if (sc.materials[tri.material].type != PG_MAT_TEXTURED) return;
+    const float4 d4 = qin.d[i];
+    const int slot = __float_as_int(d4.w);
+    const V3 rayD = mk(d4.x, d4.y, d4.z);
+    const PgRenderDesc &rd = rp.rd;
+    const int4 meta = VOL ? st.meta[slot] : qsIn.meta[i];
+    if ((meta.w & 0xffff) >= rd.max_depth) return;  // path.cpp:104
+    if constexpr (VOL) {
+        if (rp.volPre) {  // the medium sample k_shade_order drew: a ray that scatters before the surface never reaches it (volpath.cpp:76-96)
+            const int med = vs.medium[slot];
+            if (med && !(sc.mediaGrid && sc.mediaGrid[med - 1] >= 0) && rp.volPre[i].y / sqrtf(lensq(rayD)) < hitT[i]) return;
+        }
+    }
+    const bool tileSerial = rd.sampler >= PG_SAMPLER_RANDOM && !sc.tsBatched, pixelArrays = sc.tsBatched != 0;
+    const uint64_t index = (uint64_t)(uint32_t)meta.x | ((uint64_t)(uint32_t)meta.y << 32);
+    Isect is;
+    float sphU = 0, sphV = 0;
+    V3 sphDpdu = mk(0, 0, 0), sphDpdv = mk(0, 0, 0);
+    const bool onSphere = (tri.flags & PG_PRIM_SPHERE) != 0;
+    const int inst = sc.hitInst ? sc.hitInst[i] : -1;
+    V3 shapeRayD = rayD;
+    if (inst >= 0) shapeRayD = m4_vec(sc.instances[inst].w2i, rayD);
+    if (onSphere) {
+        const float4 o4 = qin.o[i];
+        V3 shapeRayO = mk(o4.x, o4.y, o4.z);
+        if (inst >= 0) { float dt; instance_ray(sc.instances[inst].w2i, shapeRayO, rayD, shapeRayO, shapeRayD, dt); }
+        const SphereHit sh = sphere_interaction(sc.spheres[__float_as_int(tri.p0.x)], shapeRayO, shapeRayD, h4.y);
+        is.p = sh.p; is.pError = sh.pError; is.wo = sh.wo; is.n = sh.n; is.ns = sh.n; is.sdpdu = sh.dpdu;
+        is.sdpdv = sh.dpdv; is.sdndu = sh.dndu; is.sdndv = sh.dndv;
+        sphU = sh.u; sphV = sh.v; sphDpdu = sh.dpdu; sphDpdv = sh.dpdv;
+    } else is = make_isect(sc, prim, tri, h4.y, h4.z, h4.w, shapeRayD);
+    if (inst >= 0 && !sc.instances[inst].identity) isect_to_world(sc.instances[inst], is);
+    float filmX = 0, filmY = 0;  // the camera sample's pFilm, for the camera ray's differentials
+    if (meta.w & PG_META_HASDIFF) { filmX = VOL ? st.L[slot].w : qsIn.L[i].w; filmY = VOL ? st.beta[slot].w : qsIn.beta[i].w; }
+    TexHit th;
+    tex_hit_setup(sc, rd, qin, i, slot, prim, tri, h4, rayD, inst, onSphere, sphU, sphV, sphDpdu, sphDpdv, is, meta, filmX, filmY, tileSerial, pixelArrays, index, th);
+    material_bump<1>(sc, tri.material, th, is);
+    int nl = 0;
+    float etaL = 1;
+    MatEval<2, 1>::run(*sc.self, tri.material, th, rp.matPre.lobes + (size_t)i * rp.matPre.stride, nl, etaL, rp.matPre.stride);
+    rp.matPre.head[2 * (size_t)i] = make_float4(is.ns.x, is.ns.y, is.ns.z, etaL);
+    rp.matPre.head[2 * (size_t)i + 1] = make_float4(is.sdpdu.x, is.sdpdu.y, is.sdpdu.z, __int_as_float(nl));
+}
+static void launch_material(const DScene &sc, const RenderParams &rp, PathState st, VolState vs, RayQueue qin, const float4 *hits, const float *hitT, QueueState qi,
+                            bool vol, hipStream_t s) {
+    const int nblk = PG_REGIONS * (qin.regionCap / PG_SHADE_BLOCK);
+    if (nblk == 0) return;
+    if (vol) hipLaunchKernelGGL(k_material<true>, dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, vs, hitT, qi);
+    else hipLaunchKernelGGL(k_material<false>, dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, vs, hitT, qi);
+}
 // The order in which a shading launch takes the entries of its queue (RenderParams::order): block b sorts the entry indices of
 // window b >> 3 of region b & 7 by the material class of the entry's hit -- counting sort, stable, so that the entries of a class stay
 // in queue order and neighbouring lanes still read neighbouring entries.  Window and region are those of the consumer's
@@ -2703,6 +2801,9 @@ void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQue
     if (sss && sc.nBssrdfs > 0) {  // materials with a BSSRDF are BxDF-list materials: the general kernels
         if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, false, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, *sss, gsh);
         else hipLaunchKernelGGL((k_shade<1, false, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, *sss, gsh);
+    } else if (sc.hasTextured && rp.matPre.lobes) {  // materials first (not again for the entries a sparse light table sent back: theirs are there)
+        if (rp.retryCount == 0) launch_material(sc, rp, st, vs, qin, hits, noT, qi, false, s);
+        hipLaunchKernelGGL((k_shade<3, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, none, gsh);
     } else if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, none, gsh);
     else if (sc.ext) hipLaunchKernelGGL((k_shade<1, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, none, gsh);
     else hipLaunchKernelGGL((k_shade<0, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, none, gsh);
@@ -2721,6 +2822,9 @@ void launch_shade_vol(const DScene &sc, const RenderParams &rp, PathState st, Vo
     } else if (sss && sc.nBssrdfs > 0) {
         if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, true, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, *sss, gsh);
         else hipLaunchKernelGGL((k_shade<1, true, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, *sss, gsh);
+    } else if (sc.hasTextured && rp.matPre.lobes) {
+        if (rp.retryCount == 0) launch_material(sc, rp, st, vs, qin, hits, hitT, none, true, s);
+        hipLaunchKernelGGL((k_shade<3, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss, gsh);
     } else if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss, gsh);
     else hipLaunchKernelGGL((k_shade<1, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss, gsh);
 }

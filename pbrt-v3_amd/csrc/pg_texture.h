@@ -259,15 +259,17 @@ PG_DEV bool tex_dots_inside(const DScene &sc, const PgTexture &t, const TexHit &
     }
     return false;
 }
-template <int D> struct TexEval {
+// W: a tag that gives a kernel its own copies of the evaluators -- the compiler allots a CALLED function the registers of the most
+// permissive kernel that reaches it, so k_material (four waves per SIMD) must not share them with k_shade<2, .> (two)
+template <int D, int W = 0> struct TexEval {
     static PG_DEV_CALL float f(const DScene &sc, const PgTexRef &r, const TexHit &h) {
         if (r.tex < 0) return r.v[0];
         const PgTexture &t = sc.textures[r.tex];
         switch (t.type) {
-        case PG_TEX_SCALE: return TexEval<D - 1>::f(sc, t.tex1, h) * TexEval<D - 1>::f(sc, t.tex2, h);  // scale.h:58-60
+        case PG_TEX_SCALE: return TexEval<D - 1, W>::f(sc, t.tex1, h) * TexEval<D - 1, W>::f(sc, t.tex2, h);  // scale.h:58-60
         case PG_TEX_MIX: {  // mix.h:57-61
-            const float t1 = TexEval<D - 1>::f(sc, t.tex1, h), t2 = TexEval<D - 1>::f(sc, t.tex2, h);
-            const float amt = TexEval<D - 1>::f(sc, t.amount, h);
+            const float t1 = TexEval<D - 1, W>::f(sc, t.tex1, h), t2 = TexEval<D - 1, W>::f(sc, t.tex2, h);
+            const float amt = TexEval<D - 1, W>::f(sc, t.amount, h);
             return (1 - amt) * t1 + amt * t2;
         }
         case PG_TEX_IMAGEMAP: {  // ImageTexture::Evaluate, imagemap.h:86-93
@@ -281,14 +283,14 @@ template <int D> struct TexEval {
             return (1 - st[0]) * (1 - st[1]) * t.v00[0] + (1 - st[0]) * (st[1]) * t.v01[0] + (st[0]) * (1 - st[1]) * t.v10[0] + (st[0]) * (st[1]) * t.v11[0];
         }
         case PG_TEX_FBM: case PG_TEX_WRINKLED: case PG_TEX_WINDY: return tex_noise(sc, t, h);
-        case PG_TEX_DOTS: return tex_dots_inside(sc, t, h) ? TexEval<D - 1>::f(sc, t.tex2, h) : TexEval<D - 1>::f(sc, t.tex1, h);
-        case PG_TEX_CHECKERBOARD_3D: return tex_checker3d(t, h) == 0 ? TexEval<D - 1>::f(sc, t.tex1, h) : TexEval<D - 1>::f(sc, t.tex2, h);
+        case PG_TEX_DOTS: return tex_dots_inside(sc, t, h) ? TexEval<D - 1, W>::f(sc, t.tex2, h) : TexEval<D - 1, W>::f(sc, t.tex1, h);
+        case PG_TEX_CHECKERBOARD_3D: return tex_checker3d(t, h) == 0 ? TexEval<D - 1, W>::f(sc, t.tex1, h) : TexEval<D - 1, W>::f(sc, t.tex2, h);
         case PG_TEX_CHECKERBOARD_2D: {  // checkerboard.h:63-103
             float area2 = 0;
             const int which = tex_checker2d(t, h, area2);
-            if (which == 0) return TexEval<D - 1>::f(sc, t.tex1, h);
-            if (which == 1) return TexEval<D - 1>::f(sc, t.tex2, h);
-            return (1 - area2) * TexEval<D - 1>::f(sc, t.tex1, h) + area2 * TexEval<D - 1>::f(sc, t.tex2, h);
+            if (which == 0) return TexEval<D - 1, W>::f(sc, t.tex1, h);
+            if (which == 1) return TexEval<D - 1, W>::f(sc, t.tex2, h);
+            return (1 - area2) * TexEval<D - 1, W>::f(sc, t.tex1, h) + area2 * TexEval<D - 1, W>::f(sc, t.tex2, h);
         }
         }
         return 0;
@@ -297,10 +299,10 @@ template <int D> struct TexEval {
         if (r.tex < 0) return sp3(r.v[0], r.v[1], r.v[2]);
         const PgTexture &t = sc.textures[r.tex];
         switch (t.type) {
-        case PG_TEX_SCALE: return TexEval<D - 1>::s(sc, t.tex1, h) * TexEval<D - 1>::s(sc, t.tex2, h);
+        case PG_TEX_SCALE: return TexEval<D - 1, W>::s(sc, t.tex1, h) * TexEval<D - 1, W>::s(sc, t.tex2, h);
         case PG_TEX_MIX: {
-            const Spec t1 = TexEval<D - 1>::s(sc, t.tex1, h), t2 = TexEval<D - 1>::s(sc, t.tex2, h);
-            const float amt = TexEval<D - 1>::f(sc, t.amount, h);
+            const Spec t1 = TexEval<D - 1, W>::s(sc, t.tex1, h), t2 = TexEval<D - 1, W>::s(sc, t.tex2, h);
+            const float amt = TexEval<D - 1, W>::f(sc, t.amount, h);
             return t1 * (1 - amt) + t2 * amt;
         }
         case PG_TEX_IMAGEMAP: {
@@ -321,20 +323,20 @@ template <int D> struct TexEval {
         }
         case PG_TEX_FBM: case PG_TEX_WRINKLED: case PG_TEX_WINDY: return sp(tex_noise(sc, t, h));
         case PG_TEX_MARBLE: return tex_marble(sc, t, h);
-        case PG_TEX_DOTS: return tex_dots_inside(sc, t, h) ? TexEval<D - 1>::s(sc, t.tex2, h) : TexEval<D - 1>::s(sc, t.tex1, h);
-        case PG_TEX_CHECKERBOARD_3D: return tex_checker3d(t, h) == 0 ? TexEval<D - 1>::s(sc, t.tex1, h) : TexEval<D - 1>::s(sc, t.tex2, h);
+        case PG_TEX_DOTS: return tex_dots_inside(sc, t, h) ? TexEval<D - 1, W>::s(sc, t.tex2, h) : TexEval<D - 1, W>::s(sc, t.tex1, h);
+        case PG_TEX_CHECKERBOARD_3D: return tex_checker3d(t, h) == 0 ? TexEval<D - 1, W>::s(sc, t.tex1, h) : TexEval<D - 1, W>::s(sc, t.tex2, h);
         case PG_TEX_CHECKERBOARD_2D: {
             float area2 = 0;
             const int which = tex_checker2d(t, h, area2);
-            if (which == 0) return TexEval<D - 1>::s(sc, t.tex1, h);
-            if (which == 1) return TexEval<D - 1>::s(sc, t.tex2, h);
-            return TexEval<D - 1>::s(sc, t.tex1, h) * (1 - area2) + TexEval<D - 1>::s(sc, t.tex2, h) * area2;
+            if (which == 0) return TexEval<D - 1, W>::s(sc, t.tex1, h);
+            if (which == 1) return TexEval<D - 1, W>::s(sc, t.tex2, h);
+            return TexEval<D - 1, W>::s(sc, t.tex1, h) * (1 - area2) + TexEval<D - 1, W>::s(sc, t.tex2, h) * area2;
         }
         }
         return sp(0);
     }
 };
-template <> struct TexEval<0> {  // the innermost level: operands must be constants (the host front end enforces the depth)
+template <int W> struct TexEval<0, W> {  // the innermost level: operands must be constants (the host front end enforces the depth)
     static PG_DEV float f(const DScene &, const PgTexRef &r, const TexHit &) { return r.v[0]; }
     static PG_DEV Spec s(const DScene &, const PgTexRef &r, const TexHit &) { return sp3(r.v[0], r.v[1], r.v[2]); }
 };

@@ -141,6 +141,7 @@ inline hipError_t MemcpyPeer(void *d, int, const void *s, int, size_t n) { if (n
 inline hipError_t Memset(void *d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
 inline hipError_t MemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) { if (n) memset(d, v, n); return hipSuccess; }
 inline hipError_t Ok() { return hipSuccess; }
+inline hipError_t MemGetInfo(size_t *freeB, size_t *totalB) { *freeB = (size_t)64 << 30; *totalB = (size_t)64 << 30; return hipSuccess; }  // (host memory: calloc says no when there is none)
 inline hipError_t StreamCreate(hipStream_t *s, unsigned = 0) { *s = (hipStream_t)(uintptr_t)8; return hipSuccess; }  // (never dereferenced)
 inline hipError_t EventCreate(hipEvent_t *e, unsigned = 0) { *e = (hipEvent_t)(uintptr_t)8; return hipSuccess; }
 inline hipError_t EventElapsed(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
@@ -158,6 +159,7 @@ inline hipError_t CanAccessPeer(int *can, int, int) { *can = 1; return hipSucces
 #define hipMemcpyAsync emu::MemcpyAsync
 #define hipMemcpyPeer emu::MemcpyPeer
 #define hipMemset emu::Memset
+#define hipMemGetInfo emu::MemGetInfo
 #define hipMemsetAsync emu::MemsetAsync
 #define hipStreamCreateWithFlags emu::StreamCreate
 #define hipStreamCreate emu::StreamCreate

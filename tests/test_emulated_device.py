@@ -69,6 +69,15 @@ def test_round3_kernels_on_the_emulated_device(emulated):
     assert " passed" in out and "failed" not in out
 
 
+def test_material_pass_on_the_emulated_device(emulated):
+    """Round 4's k_material + k_shade<3, .> (materials with textured parameters evaluated ahead of the shading launch) against the
+    evaluation inside the shading kernel (PG_MAT_PRE=0): same film, strays and counters -- bump maps, the divergent stand-ins (instances,
+    every material kind, path and volpath), an 8-BxDF mix of two uber materials."""
+    select = "longest_lists or bump_maps or divergent_small or tex_materials"
+    out = run_gpu_tests(emulated, ["tests/test_gpu_material_prepass.py"], select, 1500)
+    assert " passed" in out and "failed" not in out
+
+
 @pytest.mark.skipif(os.environ.get("PBRT_EMULATE_ALL") != "1", reason="set PBRT_EMULATE_ALL=1 for the whole feasible GPU suite under emulation (~15 min)")
 def test_everything_feasible_on_the_emulated_device(emulated):
     out = run_gpu_tests(emulated, ["tests/test_gpu_parity.py", "tests/test_gpu_fuzz.py"], SKIP, 7200)

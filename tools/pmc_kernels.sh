@@ -19,7 +19,7 @@ tot = collections.defaultdict(lambda: collections.defaultdict(float)); n = colle
 for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
-        if not ("k_trace" in k or "k_shade" in k or "k_resolve" in k): continue
+        if not ("k_trace" in k or "k_shade" in k or "k_resolve" in k or "k_material" in k): continue
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
 with open(os.path.join(out, "summary.txt"), "w") as fo:
     for k in sorted(tot):
