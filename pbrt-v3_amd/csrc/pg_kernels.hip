@@ -1025,7 +1025,18 @@ PG_DEV Spec bsdf_sample_f(const Bsdf &b, V3 woWorld, V3 &wiWorld, float u0, floa
 #define PG_BSDF_DIFFUSE 4
 #define PG_BSDF_GLOSSY 8
 #define PG_BSDF_ALL 31
-struct LobeBsdf { V3 ns, ng, ss, ts; const PgBxDF *lobes; int n; float eta; };
+// `types`: the PgBxDFType of lobes[i] in bits 4i .. 4i+3, `scaled`: bit i = lobes[i] has ScaledBxDF wrappers -- read once when the
+// list is bound (lbsdf_bind), so that BSDF::NumComponents / the component choice of Sample_f / the matching tests of f and Pdf are
+// register arithmetic instead of a chain of dependent loads through the lane's list pointer
+struct LobeBsdf { V3 ns, ng, ss, ts; const PgBxDF *lobes; int n; float eta; unsigned types, scaled; };
+PG_DEV void lbsdf_bind(LobeBsdf &b, const PgBxDF *lobes, int n, float eta) {
+    b.lobes = lobes; b.n = n; b.eta = eta; b.types = 0; b.scaled = 0;
+    for (int i = 0; i < n; ++i) {
+        b.types |= (unsigned)lobes[i].type << (4 * i);
+        b.scaled |= (lobes[i].n_scales > 0 ? 1u : 0u) << i;
+    }
+}
+PG_DEV int lbsdf_lobe(const LobeBsdf &b, int i) { return (int)((b.types >> (4 * i)) & 15u); }
 PG_DEV V3 world_to_local(const LobeBsdf &b, V3 v) { return mk(dot(v, b.ss), dot(v, b.ts), dot(v, b.ns)); }
 PG_DEV V3 local_to_world(const LobeBsdf &b, V3 v) {
     return mk(b.ss.x * v.x + b.ts.x * v.y + b.ns.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ns.y * v.z,
@@ -1096,8 +1107,8 @@ PG_DEV bool refract_dir(V3 wi, V3 n, float eta, V3 &wt) {  // reflection.h:97-10
     wt = (-wi) * eta + n * (eta * cosThetaI - cosThetaT);
     return true;
 }
-PG_DEV int lobe_type(const PgBxDF &b) {  // the BxDFType each constructor passes to BxDF()
-    switch (b.type) {
+PG_DEV int lobe_type(int type) {  // the BxDFType each constructor passes to BxDF()
+    switch (type) {
     case PG_BXDF_LAMBERT_R: case PG_BXDF_OREN_NAYAR: return PG_BSDF_REFLECTION | PG_BSDF_DIFFUSE;
     case PG_BXDF_LAMBERT_T: return PG_BSDF_TRANSMISSION | PG_BSDF_DIFFUSE;
     case PG_BXDF_SPECULAR_R: return PG_BSDF_REFLECTION | PG_BSDF_SPECULAR;
@@ -1108,16 +1119,16 @@ PG_DEV int lobe_type(const PgBxDF &b) {  // the BxDFType each constructor passes
     }
     return 0;
 }
-PG_DEV bool lobe_matches(const PgBxDF &b, int t) { const int type = lobe_type(b); return (type & t) == type; }  // reflection.h:225
+PG_DEV bool lobe_matches(int lobe, int t) { const int type = lobe_type(lobe); return (type & t) == type; }  // reflection.h:225
 PG_DEV Spec lobe_fresnel(const PgBxDF &b, float cosI) {  // Fresnel::Evaluate, reflection.cpp:120-135
     if (b.fresnel == PG_FRESNEL_DIELECTRIC) return sp(fr_dielectric(cosI, b.eta_a, b.eta_b));
     if (b.fresnel == PG_FRESNEL_CONDUCTOR) return fr_conductor(fabsf(cosI), sp(1.f), sp_of(b.cond_eta), sp_of(b.cond_k));
     return sp(1.f);
 }
 PG_DEV float pow5f(float v) { return (v * v) * (v * v) * v; }
-PG_DEV Spec lobe_f(const PgBxDF &b, V3 wo, V3 wi) {  // BxDF::f of the wrapped BxDF, local frame
+PG_DEV Spec lobe_f(const PgBxDF &b, int lobe, V3 wo, V3 wi) {  // BxDF::f of the wrapped BxDF (lobe = b.type), local frame
     const float ax = b.alpha_x, ay = b.alpha_y;
-    switch (b.type) {
+    switch (lobe) {
     case PG_BXDF_LAMBERT_R: return sp_of(b.R) * PG_INVPI;  // reflection.cpp:178-180
     case PG_BXDF_LAMBERT_T: return sp_of(b.T) * PG_INVPI;  // :188-190
     case PG_BXDF_OREN_NAYAR: {  // :197-219
@@ -1172,9 +1183,9 @@ PG_DEV Spec lobe_f(const PgBxDF &b, V3 wo, V3 wi) {  // BxDF::f of the wrapped B
     }
     return sp(0);  // specular BxDFs: f() = 0
 }
-PG_DEV float lobe_pdf(const PgBxDF &b, V3 wo, V3 wi) {
+PG_DEV float lobe_pdf(const PgBxDF &b, int lobe, V3 wo, V3 wi) {
     const float ax = b.alpha_x, ay = b.alpha_y;
-    switch (b.type) {
+    switch (lobe) {
     case PG_BXDF_LAMBERT_R: case PG_BXDF_OREN_NAYAR: return same_hemisphere(wo, wi) ? fabsf(wi.z) * PG_INVPI : 0;  // :392-394
     case PG_BXDF_LAMBERT_T: return !same_hemisphere(wo, wi) ? fabsf(wi.z) * PG_INVPI : 0;  // :405-408
     case PG_BXDF_MICROFACET_R: {  // :425-429
@@ -1200,20 +1211,22 @@ PG_DEV float lobe_pdf(const PgBxDF &b, V3 wo, V3 wi) {
     }
     return 0;
 }
-// BxDF::Sample_f of the wrapped BxDF; pdf keeps the caller's 0 on the reference's early `return 0` paths
-PG_DEV Spec lobe_sample_f(const PgBxDF &b, V3 wo, V3 &wi, float u0, float u1, float &pdf, int &sampledType) {
+// BxDF::Sample_f of the wrapped BxDF; pdf keeps the caller's 0 on the reference's early `return 0` paths.  wantF = false: the
+// value of a NON-specular BxDF is not computed (0 is returned) -- BSDF::Sample_f throws it away and sums f() over all matching
+// BxDFs instead (reflection.cpp:768-775); direction, pdf and the specular BxDFs' values are what they always are
+PG_DEV Spec lobe_sample_f(const PgBxDF &b, int lobe, V3 wo, V3 &wi, float u0, float u1, float &pdf, int &sampledType, bool wantF = true) {
     const float ax = b.alpha_x, ay = b.alpha_y;
-    switch (b.type) {
+    switch (lobe) {
     case PG_BXDF_LAMBERT_R: case PG_BXDF_OREN_NAYAR:  // BxDF::Sample_f, :383-390
         wi = cosine_sample_hemisphere(u0, u1);
         if (wo.z < 0) wi.z *= -1;
-        pdf = lobe_pdf(b, wo, wi);
-        return lobe_f(b, wo, wi);
+        pdf = lobe_pdf(b, lobe, wo, wi);
+        return wantF ? lobe_f(b, lobe, wo, wi) : sp(0);
     case PG_BXDF_LAMBERT_T:  // :396-403
         wi = cosine_sample_hemisphere(u0, u1);
         if (wo.z > 0) wi.z *= -1;
-        pdf = lobe_pdf(b, wo, wi);
-        return lobe_f(b, wo, wi);
+        pdf = lobe_pdf(b, lobe, wo, wi);
+        return wantF ? lobe_f(b, lobe, wo, wi) : sp(0);
     case PG_BXDF_SPECULAR_R:  // :136-143
         wi = mk(-wo.x, -wo.y, wo.z);
         pdf = 1;
@@ -1253,7 +1266,7 @@ PG_DEV Spec lobe_sample_f(const PgBxDF &b, V3 wo, V3 &wi, float u0, float u1, fl
         wi = reflect_about(wo, wh);
         if (!same_hemisphere(wo, wi)) return sp(0);
         pdf = tr2_pdf(ax, ay, wo, wh) / (4 * dot(wo, wh));
-        return lobe_f(b, wo, wi);
+        return wantF ? lobe_f(b, lobe, wo, wi) : sp(0);
     }
     case PG_BXDF_MICROFACET_T: {  // :431-442
         if (wo.z == 0) return sp(0);
@@ -1261,8 +1274,8 @@ PG_DEV Spec lobe_sample_f(const PgBxDF &b, V3 wo, V3 &wi, float u0, float u1, fl
         if (dot(wo, wh) < 0) return sp(0);
         float eta = wo.z > 0 ? (b.eta_a / b.eta_b) : (b.eta_b / b.eta_a);
         if (!refract_dir(wo, wh, eta, wi)) return sp(0);
-        pdf = lobe_pdf(b, wo, wi);
-        return lobe_f(b, wo, wi);
+        pdf = lobe_pdf(b, lobe, wo, wi);
+        return wantF ? lobe_f(b, lobe, wo, wi) : sp(0);
     }
     case PG_BXDF_FRESNEL_BLEND: {  // :460-478
         if ((double)u0 < .5) {
@@ -1275,8 +1288,8 @@ PG_DEV Spec lobe_sample_f(const PgBxDF &b, V3 wo, V3 &wi, float u0, float u1, fl
             wi = reflect_about(wo, wh);
             if (!same_hemisphere(wo, wi)) return sp(0);
         }
-        pdf = lobe_pdf(b, wo, wi);
-        return lobe_f(b, wo, wi);
+        pdf = lobe_pdf(b, lobe, wo, wi);
+        return wantF ? lobe_f(b, lobe, wo, wi) : sp(0);
     }
     }
     return sp(0);
@@ -1287,15 +1300,62 @@ PG_DEV Spec lobe_scale(const PgBxDF &b, Spec f) {  // ScaledBxDF, reflection.cpp
 }
 PG_DEV int lbsdf_num_components(const LobeBsdf &b, int flags) {  // reflection.cpp:672-678
     int num = 0;
-    for (int i = 0; i < b.n; ++i) if (lobe_matches(b.lobes[i], flags)) ++num;
+    for (int i = 0; i < b.n; ++i) if (lobe_matches(lbsdf_lobe(b, i), flags)) ++num;
     return num;
+}
+PG_DEV Spec lbsdf_scaled(const LobeBsdf &b, int i, Spec f) { return ((b.scaled >> i) & 1u) ? lobe_scale(b.lobes[i], f) : f; }
+// BxDF::f and BxDF::Pdf of one BxDF for the same pair of directions.  Each value is what lobe_f / lobe_pdf compute -- the same
+// operations in the same order --, but the microfacet BxDFs' half vector, D(wh) and Lambda(wo) are computed once for both (a path
+// vertex asks for f AND pdf of the other matching BxDFs inside both of its BSDF::Sample_f calls.  For the light's direction BSDF::f and
+// BSDF::Pdf stay two walks: fused there as well the kernel gained nothing on microfacet scenes and lost 20 % on an all-Lambert one --
+// a matter of what the register allocator makes of it, profiles/r04l_*).
+PG_DEV void lobe_f_pdf(const PgBxDF &b, int lobe, V3 wo, V3 wi, bool wantF, bool wantPdf, Spec &f, float &pdf) {
+    const float ax = b.alpha_x, ay = b.alpha_y;
+    f = sp(0); pdf = 0;
+    switch (lobe) {
+    case PG_BXDF_MICROFACET_R: {  // reflection.cpp:226-238, :425-429
+        V3 wh = wi + wo;  // (= wo + wi of Pdf: the same three sums)
+        const bool whZero = wh.x == 0 && wh.y == 0 && wh.z == 0;
+        wh = normalize(wh);
+        const float D = tr2_D(ax, ay, wh), lambdaO = tr2_lambda(ax, ay, wo);
+        if (wantPdf && same_hemisphere(wo, wi)) pdf = (D * (1 / (1 + lambdaO)) * absdot(wo, wh) / fabsf(wo.z)) / (4 * dot(wo, wh));
+        if (wantF) {
+            const float cosThetaO = fabsf(wo.z), cosThetaI = fabsf(wi.z);
+            if (!(cosThetaI == 0 || cosThetaO == 0 || whZero)) {
+                const V3 whf = (wh.z < 0.f) ? -wh : wh;  // Faceforward(wh, (0,0,1))
+                const Spec F = lobe_fresnel(b, dot(wi, whf));
+                f = (((sp_of(b.R) * D) * (1 / (1 + lambdaO + tr2_lambda(ax, ay, wi)))) * F) / (4 * cosThetaI * cosThetaO);
+            }
+        }
+        return;
+    }
+    case PG_BXDF_FRESNEL_BLEND: {  // :295-310, :480-485
+        V3 wh = wi + wo;
+        const bool whZero = wh.x == 0 && wh.y == 0 && wh.z == 0;
+        wh = normalize(wh);
+        const float D = tr2_D(ax, ay, wh);
+        if (wantPdf && same_hemisphere(wo, wi)) {
+            const float pdf_wh = D * tr2_G1(ax, ay, wo) * absdot(wo, wh) / fabsf(wo.z);
+            pdf = .5f * (fabsf(wi.z) * PG_INVPI + pdf_wh / (4 * dot(wo, wh)));
+        }
+        if (wantF && !whZero) {
+            const Spec Rd = sp_of(b.R), Rs = sp_of(b.T);
+            const Spec diffuse = (((Rd * (28.f / (23.f * PG_PI))) * (sp(1.f) - Rs)) * (1 - pow5f(1 - .5f * fabsf(wi.z)))) * (1 - pow5f(1 - .5f * fabsf(wo.z)));
+            const Spec schlick = Rs + (sp(1.f) - Rs) * pow5f(1 - dot(wi, wh));
+            f = diffuse + schlick * (D / (4 * absdot(wi, wh) * pmax(fabsf(wi.z), fabsf(wo.z))));
+        }
+        return;
+    }
+    }
+    if (wantF) f = lobe_f(b, lobe, wo, wi);
+    if (wantPdf) pdf = lobe_pdf(b, lobe, wo, wi);
 }
 PG_DEV Spec lbsdf_f_local(const LobeBsdf &b, V3 wo, V3 wi, bool reflect, int flags) {
     Spec f = sp(0);
     for (int i = 0; i < b.n; ++i) {
-        const int type = lobe_type(b.lobes[i]);
+        const int lobe = lbsdf_lobe(b, i), type = lobe_type(lobe);
         if ((type & flags) == type && ((reflect && (type & PG_BSDF_REFLECTION)) || (!reflect && (type & PG_BSDF_TRANSMISSION))))
-            f = f + lobe_scale(b.lobes[i], lobe_f(b.lobes[i], wo, wi));
+            f = f + lbsdf_scaled(b, i, lobe_f(b.lobes[i], lobe, wo, wi));
     }
     return f;
 }
@@ -1310,8 +1370,10 @@ PG_DEV float lbsdf_pdf(const LobeBsdf &b, V3 woW, V3 wiW, int flags) {  // refle
     if (wo.z == 0) return 0.f;
     float pdf = 0.f;
     int matchingComps = 0;
-    for (int i = 0; i < b.n; ++i)
-        if (lobe_matches(b.lobes[i], flags)) { ++matchingComps; pdf += lobe_pdf(b.lobes[i], wo, wi); }
+    for (int i = 0; i < b.n; ++i) {
+        const int lobe = lbsdf_lobe(b, i);
+        if (lobe_matches(lobe, flags)) { ++matchingComps; pdf += lobe_pdf(b.lobes[i], lobe, wo, wi); }
+    }
     return matchingComps > 0 ? pdf / matchingComps : 0.f;
 }
 // BSDF::Sample_f, reflection.cpp:714-779: returns f, pdf = 0 when there is no sample
@@ -1324,21 +1386,34 @@ PG_DEV Spec lbsdf_sample_f(const LobeBsdf &b, V3 woWorld, V3 &wiWorld, float u0,
     if (comp > matchingComps - 1) comp = matchingComps - 1;
     int chosen = 0, count = comp;
     for (int i = 0; i < b.n; ++i)
-        if (lobe_matches(b.lobes[i], flags) && count-- == 0) { chosen = i; break; }
+        if (lobe_matches(lbsdf_lobe(b, i), flags) && count-- == 0) { chosen = i; break; }
     const PgBxDF &bxdf = b.lobes[chosen];
+    const int chosenLobe = lbsdf_lobe(b, chosen);
     const float uR0 = pmin(u0 * matchingComps - comp, PG_ONE_MINUS_EPS);
     V3 wi = mk(0, 0, 0), wo = world_to_local(b, woWorld);
     if (wo.z == 0) return sp(0);
-    sampledType = lobe_type(bxdf);
-    Spec f = lobe_scale(bxdf, lobe_sample_f(bxdf, wo, wi, uR0, u1, pdf, sampledType));
+    sampledType = lobe_type(chosenLobe);
+    const bool bxdfSpecular = (sampledType & PG_BSDF_SPECULAR) != 0;
+    Spec f = lbsdf_scaled(b, chosen, lobe_sample_f(bxdf, chosenLobe, wo, wi, uR0, u1, pdf, sampledType, bxdfSpecular));
     if (pdf == 0) { sampledType = 0; return sp(0); }
     wiWorld = local_to_world(b, wi);
-    const bool bxdfSpecular = (lobe_type(bxdf) & PG_BSDF_SPECULAR) != 0;
-    if (!bxdfSpecular && matchingComps > 1)
-        for (int i = 0; i < b.n; ++i)
-            if (i != chosen && lobe_matches(b.lobes[i], flags)) pdf += lobe_pdf(b.lobes[i], wo, wi);
+    if (!bxdfSpecular) {  // :760-775: the other matching BxDFs' pdfs, and f over all matching BxDFs of the hemisphere the pair is in
+        const bool reflect = dot(wiWorld, b.ng) * dot(woWorld, b.ng) > 0;
+        f = sp(0);
+        for (int i = 0; i < b.n; ++i) {
+            const int lobe = lbsdf_lobe(b, i), type = lobe_type(lobe);
+            if ((type & flags) != type) continue;
+            const bool wantPdf = matchingComps > 1 && i != chosen;
+            const bool wantF = (reflect && (type & PG_BSDF_REFLECTION)) || (!reflect && (type & PG_BSDF_TRANSMISSION));
+            if (!(wantPdf || wantF)) continue;
+            Spec fi;
+            float pi;
+            lobe_f_pdf(b.lobes[i], lobe, wo, wi, wantF, wantPdf, fi, pi);
+            if (wantPdf) pdf += pi;
+            if (wantF) f = f + lbsdf_scaled(b, i, fi);
+        }
+    }
     if (matchingComps > 1) pdf /= matchingComps;
-    if (!bxdfSpecular) f = lbsdf_f_local(b, wo, wi, dot(wiWorld, b.ng) * dot(woWorld, b.ng) > 0, flags);
     return f;
 }
 
@@ -2049,6 +2124,10 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
     // pushed the kernel to 130 VGPRs with scratch spills (3 waves/SIMD).
     __shared__ float4 s_ray[3][2][PG_SHADE_BLOCK];
     __shared__ float4 s_state[QSTATE ? 3 : 1][PG_SHADE_BLOCK];  // QSTATE: (L, beta, meta) until the entry's place in the next queue is known
+    // EXT: of the seven Halton numbers a vertex computes ahead (halton_batch) the last four -- uScattering and the next direction's pair,
+    // drawn late -- wait in LDS; they were what the register allocator put into scratch, and any scratch at all costs these
+    // one-vertex-per-lane kernels ~20 % (profiles/r04k_*).  (Not MODE 0: 2 KB more LDS per block would cost it a resident block)
+    __shared__ float s_pre[EXT ? 4 : 1][PG_SHADE_BLOCK];
     const int tid = threadIdx.x;
     bool pushNext = false, pushShadow = false, pushMis = false;
     int slot = 0;
@@ -2091,8 +2170,10 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
         int preDim0 = -1;
         auto sample_dim = [&](int d) -> float {
             const int k = d - preDim0;
-            if (preDim0 >= 0 && k >= 0 && k < PG_NPRE)
+            if (preDim0 >= 0 && k >= 0 && k < PG_NPRE) {
+                if constexpr (EXT) return k == 0 ? pre[0] : (k == 1 ? pre[1] : (k == 2 ? pre[2] : s_pre[k - 3][tid]));
                 return k == 0 ? pre[0] : (k == 1 ? pre[1] : (k == 2 ? pre[2] : (k == 3 ? pre[3] : (k == 4 ? pre[4] : (k == 5 ? pre[5] : pre[6])))));
+            }
             return halton_sample(sc, rd, index, d);
         };
         auto draw1 = [&]() -> float { return tileSerial ? ts_get1d(sc, slot) : (pixelArrays ? tsb_get1d(sc, meta.x, meta.y, dim) : sample_dim(dim++)); };
@@ -2190,6 +2271,14 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
             for (int li = 0; li < sc.nLights; ++li)
                 if (sc.lights[li].type == PG_LIGHT_INFINITE) L = L + beta * env_le(sc, sc.lights[li], rayD);
         }
+        // QSTATE: L is final for this launch here (k_resolve adds the vertex's direct lighting), and the camera sample's film position in
+        // L.w / beta.w is only carried along: both wait in LDS from here on instead of in five registers across the whole BSDF part --
+        // with them the BxDF-list kernels stay under the 168 registers of three waves per SIMD without scratch (any scratch at all costs
+        // these one-vertex-per-lane kernels ~20 %: profiles/r04k_*)
+        if constexpr (QSTATE && !TEX) {
+            s_state[0][tid] = make_float4(L.r, L.g, L.b, L4.w);
+            reinterpret_cast<float *>(&s_state[1][tid])[3] = B4.w;
+        }
         bool alive = found && bounces < rd.max_depth;  // path.cpp:104
         int newFlags = 0;
         bool handled = false;
@@ -2204,7 +2293,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
                 {   // the dimensions of this vertex's draws side by side (as at a surface vertex, below)
                     const int dimU = __builtin_amdgcn_readfirstlane(dim);
                     const bool can = !tileSerial && !pixelArrays && rd.sampler == 0 && (index >> 32) == 0 && dim >= 2;
-                    if (__ballot(!can || dim != dimU) == 0) { halton_batch<PG_NPRE>(sc, (uint32_t)index, dimU, pre); preDim0 = dimU; }
+                    if (__ballot(!can || dim != dimU) == 0) { halton_batch<PG_NPRE>(sc, (uint32_t)index, dimU, pre); preDim0 = dimU; if constexpr (EXT) { s_pre[0][tid] = pre[3]; s_pre[1][tid] = pre[4]; s_pre[2][tid] = pre[5]; s_pre[3][tid] = pre[6]; } }
                 }
                 const float g = sc.media[med - 1].g;
                 const V3 zero = mk(0, 0, 0), wo = -rayD;
@@ -2306,7 +2395,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
                     // every lane here draws at least the next direction; the batch needs one dimension for the whole wave
                     const int dimU = __builtin_amdgcn_readfirstlane(dim);
                     const bool can = !tileSerial && !pixelArrays && rd.sampler == 0 && (index >> 32) == 0 && dim >= 2;
-                    if (__ballot(!can || dim != dimU) == 0) { halton_batch<PG_NPRE>(sc, (uint32_t)index, dimU, pre); preDim0 = dimU; }
+                    if (__ballot(!can || dim != dimU) == 0) { halton_batch<PG_NPRE>(sc, (uint32_t)index, dimU, pre); preDim0 = dimU; if constexpr (EXT) { s_pre[0][tid] = pre[3]; s_pre[1][tid] = pre[4]; s_pre[2][tid] = pre[5]; s_pre[3][tid] = pre[6]; } }
                 }
                 Bsdf bsdf;
                 LobeBsdf lb;
@@ -2329,13 +2418,13 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
                     lb.ns = is.ns; lb.ng = is.n;
                     lb.ss = normalize(is.sdpdu);
                     lb.ts = cross(lb.ns, lb.ss);
-                    if (preEvaluated) { lb.lobes = rp.matPre.lobes + (size_t)i * rp.matPre.stride; lb.n = __float_as_int(head1.w); lb.eta = head0.w; }
+                    if (preEvaluated) lbsdf_bind(lb, rp.matPre.lobes + (size_t)i * rp.matPre.stride, __float_as_int(head1.w), head0.w);
                     else if constexpr (TEX) {
                         int nl = 0;
                         float etaL = 1;
                         MatEval<2>::run(*sc.self, tri.material, th, lobeStore, nl, etaL, PG_MAX_BXDFS);
-                        lb.lobes = lobeStore; lb.n = nl; lb.eta = etaL;
-                    } else { lb.lobes = sc.bxdfs + m.first_bxdf; lb.n = m.n_bxdfs; lb.eta = m.bsdf_eta; }
+                        lbsdf_bind(lb, lobeStore, nl, etaL);
+                    } else lbsdf_bind(lb, sc.bxdfs + m.first_bxdf, m.n_bxdfs, m.bsdf_eta);
                     if constexpr (SSS) {  // si->bssrdf = TabulatedBSSRDF(...): subsurface.cpp:87-90, kdsubsurface.cpp:88-93
                         sssIdx = sc.materialBssrdf[tri.material];
                         if (sssIdx >= 0) {
@@ -2543,8 +2632,13 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
         }
         if (deferred) {
         } else if constexpr (QSTATE) {  // written after the append: to the ray's entry of the next queue, or (path over) L to its slot
-            s_state[0][tid] = make_float4(L.r, L.g, L.b, L4.w);
-            s_state[1][tid] = make_float4(beta.r, beta.g, beta.b, B4.w);
+            if constexpr (TEX) {
+                s_state[0][tid] = make_float4(L.r, L.g, L.b, L4.w);
+                s_state[1][tid] = make_float4(beta.r, beta.g, beta.b, B4.w);
+            } else {  // (L and beta.w are there already, see above)
+                float *sb = reinterpret_cast<float *>(&s_state[1][tid]);
+                sb[0] = beta.r; sb[1] = beta.g; sb[2] = beta.b;
+            }
             s_state[2][tid] = make_float4(__int_as_float(meta.x), __int_as_float(meta.y), etaScale, __int_as_float((dim << 20) | bounces | newFlags));
         } else {
             // (GRID: phase 1 leaves the incoming flags for phase 2's rebuild of the vertex -- a null-material surface, finished in

@@ -25,19 +25,34 @@ __host__ inline unsigned long long __brevll(unsigned long long v) { return __bui
 #include "../pbrt-v3_amd/csrc/pg_bssrdf.h"
 
 extern "C" {
-// lobe_f + lobe_pdf of one BxDF in the local frame: f rgb, pdf
+// f and pdf of one BxDF in the local frame (f rgb, pdf) as the kernels take them: lobe_f_pdf -- one evaluation for both, and for
+// either alone -- and the separate lobe_f / lobe_pdf; a difference between any two of them comes back as NaNs
+static bool same_bits(float a, float b) { return std::memcmp(&a, &b, 4) == 0; }
 void hostdev_lobe_f_pdf(const PgBxDF *b, const float *wo, const float *wi, float *out) {
     const V3 o = mk(wo[0], wo[1], wo[2]), i = mk(wi[0], wi[1], wi[2]);
-    const Spec f = lobe_f(*b, o, i);
-    out[0] = f.r; out[1] = f.g; out[2] = f.b; out[3] = lobe_pdf(*b, o, i);
+    Spec f, fOnly, fNone;
+    float pdf, pdfOnly, pdfNone;
+    lobe_f_pdf(*b, b->type, o, i, true, true, f, pdf);
+    lobe_f_pdf(*b, b->type, o, i, true, false, fOnly, pdfNone);
+    lobe_f_pdf(*b, b->type, o, i, false, true, fNone, pdfOnly);
+    const Spec fs = lobe_f(*b, b->type, o, i);
+    const float ps = lobe_pdf(*b, b->type, o, i);
+    out[0] = f.r; out[1] = f.g; out[2] = f.b; out[3] = pdf;
+    const bool ok = same_bits(f.r, fOnly.r) && same_bits(f.g, fOnly.g) && same_bits(f.b, fOnly.b) && same_bits(pdf, pdfOnly) &&
+                    same_bits(f.r, fs.r) && same_bits(f.g, fs.g) && same_bits(f.b, fs.b) && same_bits(pdf, ps) &&
+                    pdfNone == 0 && fNone.r == 0 && fNone.g == 0 && fNone.b == 0;
+    if (!ok) out[0] = out[1] = out[2] = out[3] = __builtin_nanf("");
 }
-// lobe_sample_f: f rgb, pdf, wi; returns the sampled type
+// lobe_sample_f: f rgb, pdf, wi; returns the sampled type.  Without the value (wantF = false, what BSDF::Sample_f asks of the
+// non-specular BxDFs) direction, pdf and type must be the same
 int hostdev_lobe_sample_f(const PgBxDF *b, const float *wo, float u0, float u1, float *out) {
-    V3 wi = mk(0, 0, 0);
-    float pdf = 0;
-    int sampledType = lobe_type(*b);
-    const Spec f = lobe_sample_f(*b, mk(wo[0], wo[1], wo[2]), wi, u0, u1, pdf, sampledType);
+    V3 wi = mk(0, 0, 0), wi2 = mk(0, 0, 0);
+    float pdf = 0, pdf2 = 0;
+    int sampledType = lobe_type(b->type), sampledType2 = sampledType;
+    const Spec f = lobe_sample_f(*b, b->type, mk(wo[0], wo[1], wo[2]), wi, u0, u1, pdf, sampledType);
+    lobe_sample_f(*b, b->type, mk(wo[0], wo[1], wo[2]), wi2, u0, u1, pdf2, sampledType2, false);
     out[0] = f.r; out[1] = f.g; out[2] = f.b; out[3] = pdf; out[4] = wi.x; out[5] = wi.y; out[6] = wi.z;
+    if (!(same_bits(pdf, pdf2) && same_bits(wi.x, wi2.x) && same_bits(wi.y, wi2.y) && same_bits(wi.z, wi2.z) && sampledType == sampledType2)) out[3] = __builtin_nanf("");
     return sampledType;
 }
 // HenyeyGreenstein (core/medium.h:69-72, medium.cpp:194-213) and the Halton sample index of a pixel (samplers/halton.cpp:92-116)
