@@ -4,6 +4,7 @@
 #   quick: tests (without the slow full-size reference comparison) + bench + kernel stats
 #   std  : + PMC traffic passes for config 3, the 5 M-triangle stand-in (bench + kernel stats) and the 10 M-triangle volpath stand-in (bench)
 #   full : + PMC passes for the 5 M stand-in, the slow full-size comparisons with the reference binary, tile-serial and shard timing
+#   final: quick + bench and kernel stats of the two divergent stand-ins (the bench run measures its PMC passes itself)
 TAG=${1:-r02}; MODE=${2:-quick}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -24,12 +25,14 @@ tail -5 $OUT/pytest_gpu.log; cat $OUT/bench.json; head -8 $OUT/kernel_stats_cfg3
 prof config0 --workload config0 --spp 64
 head -6 $OUT/kernel_stats_config0.csv
 if [ "$MODE" != quick ]; then
+  if [ "$MODE" != final ]; then
   bash tools/pmc_traffic.sh $TAG/traffic_cfg3 > $OUT/traffic_cfg3.log 2>&1
   cp $OUT/traffic_cfg3/pmc_traffic.json profiles/pmc_traffic.json 2>/dev/null
   ( timeout 900 python bench.py --steps 2 --warmup 1 --grid 1582 --spp 256 --no-cpu-baseline 2> $OUT/bench_5m.err ) > $OUT/bench_5m.json
   prof 5m --grid 1582 --spp 256
   cat $OUT/bench_5m.json; head -6 $OUT/kernel_stats_5m.csv
   ( timeout 600 python bench.py --steps 2 --warmup 1 --workload synthetic-vol --grid 2237 --spp 128 --no-cpu-baseline 2> $OUT/bench_10m_vol.err ) > $OUT/bench_10m_vol.json; cut -c1-400 $OUT/bench_10m_vol.json
+  fi
   # the divergent stand-ins of configs 4 / 5 (instanced PLY meshes, textures, alpha masks, 8 materials): bench + kernel stats
   ( timeout 900 python bench.py --steps 2 --warmup 1 --workload divergent --tris 5000000 --spp 64 --no-cpu-baseline 2> $OUT/bench_div5m.err ) > $OUT/bench_div5m.json; cut -c1-300 $OUT/bench_div5m.json
   prof div5m --workload divergent --tris 5000000 --spp 64
