@@ -453,7 +453,10 @@ typedef struct PgRenderDesc {
     float filter_radius[2];          /* Filter::radius (filter.h:50-66)                                        */
     /* Film's 16x16 filterTable (film.cpp:68-77), filled by the host for box / gaussian / mitchell / sinc / triangle.
      * filter_general = 0: box filter with radius <= 0.5 -- every sample lands in its own pixel (a rare second pixel
-     * is reported as a PgStraySample) and a tile's film block is its 16x16 pixels.
+     * is reported as a PgStraySample) and a tile's film block is its 16x16 pixels.  Only for frames in which no film
+     * position `(float)pixel + u` can round UP onto the next pixel: pgh_box_filter_needs_gather() below says so, and
+     * pg_render refuses filter_general = 0 where it returns 1 (such a sample is added to the next pixel BEFORE that
+     * pixel's own samples, FilmTile::AddSample, film.h:121-161: a summation order only the gathering path reproduces).
      * filter_general = 1: any other filter -- a tile's film block is its FilmTile pixel bounds (film.cpp:95-106)
      * before clipping: (16 + halo[0] + halo[2]) x (16 + halo[1] + halo[3]) entries, row-major, entry (0,0) = pixel
      * (tile.x0 - halo[0], tile.y0 - halo[1]); no stray samples are produced.                                     */
@@ -487,6 +490,51 @@ typedef struct PgRenderDesc {
      * Single GPU: tile_first=0, tile_step=1.                                 */
     int32_t tile_first, tile_step;
 } PgRenderDesc;
+
+/* Can a film position `(float)p + u` of GetCameraSample (sampler.cpp:46-52) round up to p + 1 for a pixel and a sample of the
+ * frame `rd` describes (sampler fields, spp and sample_bounds filled in)?  1 = it cannot be ruled out: a box-filter frame must
+ * then be rendered with filter_general = 1 (the tile blocks with their one-pixel halo), see above.  Header-only (a front end
+ * fills its PgRenderDesc without the device library); the library exports the same function as pg_box_filter_needs_gather().
+ *  - HaltonSampler: u0 = RadicalInverse(0, index >> base_exponents[0]), u1 = RadicalInverse(1, index / base_scales[1])
+ *    (halton.cpp:118-127); the largest value either takes over the arguments the frame's sample indices reach is found by going
+ *    through them, evaluated as the sampler evaluates it (lowdiscrepancy.cpp:389-403, 427-436).  The pixel with the largest
+ *    coordinate has the coarsest float spacing, and a tie rounds to p + 1 (its significand is even).  1920 pixels wide: from
+ *    sample index 2 097 024 on, i.e. from 68 samples per pixel;
+ *  - samples at the pixel centre: never;
+ *  - every other sampler (Sobol', the PixelSamplers' RNG): numbers up to OneMinusEpsilon occur, which round up from pixel 1 on. */
+static inline int pgh_box_filter_needs_gather(const PgRenderDesc *rd) {
+    const int xMax = rd->sample_bounds[2] - 1, yMax = rd->sample_bounds[3] - 1;
+    volatile float sx, sy; /* (volatile: the sums are rounded to float whatever the compiler keeps them in) */
+    float u0Max = 0.99999994f, u1Max = 0.99999994f; /* OneMinusEpsilon */
+    if (rd->sample_at_pixel_center || xMax < 0 || yMax < 0) return 0;
+    if (rd->sampler == 0) {
+        const uint64_t stride = rd->sample_stride > 1 ? (uint64_t)rd->sample_stride : 1;
+        const uint64_t maxIndex = (uint64_t)(rd->spp > 0 ? rd->spp : 1) * stride - 1;
+        const uint64_t a0Max = maxIndex >> rd->base_exponents[0], a1Max = maxIndex / (uint64_t)(rd->base_scales[1] > 0 ? rd->base_scales[1] : 1);
+        uint64_t a0;
+        if (a0Max > ((uint64_t)1 << 26) || a1Max > ((uint64_t)1 << 26)) return 1; /* not enumerated */
+        u0Max = u1Max = 0;
+        for (a0 = 0; a0 <= a0Max; ++a0) { /* ReverseBits64(a) * 0x1p-64 */
+            uint64_t r = 0, v = a0;
+            int i;
+            float u;
+            for (i = 0; i < 64 && v; ++i, v >>= 1) if (v & 1) r |= (uint64_t)1 << (63 - i);
+            u = (float)((double)r * 5.4210108624275222e-20);
+            if (u > u0Max) u0Max = u;
+        }
+        for (a0 = 0; a0 <= a1Max; ++a0) { /* RadicalInverseSpecialized<3> */
+            const float invBase = (float)1 / (float)3;
+            uint64_t reversedDigits = 0, a = a0;
+            volatile float invBaseN = 1, u;
+            while (a) { const uint64_t next = a / 3, digit = a - next * 3; reversedDigits = reversedDigits * 3 + digit; invBaseN = invBaseN * invBase; a = next; }
+            u = (float)reversedDigits * invBaseN;
+            if (u > 0.99999994f) u = 0.99999994f;
+            if (u > u1Max) u1Max = u;
+        }
+    }
+    sx = (float)xMax + u0Max; sy = (float)yMax + u1Max;
+    return (sx >= (float)(xMax + 1) || sy >= (float)(yMax + 1)) ? 1 : 0;
+}
 
 /* One film pixel as accumulated by FilmTile::AddSample (film.h:121-161):
  * RGB contribution sum (tile-local, pre-XYZ) and filter weight sum.          */
@@ -567,6 +615,8 @@ int pg_render_sharded(PgScene *const *scenes, int32_t n, const PgRenderDesc *des
                       PgStraySample *const *strays, int32_t max_strays, int32_t *n_strays);
 /* How the last pg_render_sharded of this process gathered: "rccl", "peer (<why RCCL was not used>)", or "none".          */
 const char *pg_shard_transport(void);
+/* pgh_box_filter_needs_gather() above as a symbol, for bindings that cannot use the C header's inline function */
+int pg_box_filter_needs_gather(const PgRenderDesc *rd);
 
 /* Batched Scene::Intersect: rays as SoA (ox..dz, tmax), n rays.  Outputs
  * prim (-1 = miss), t, b0, b1, b2 (barycentrics exactly as computed by

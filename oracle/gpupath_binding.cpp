@@ -498,6 +498,13 @@ void FillRenderDesc(const Camera &camera, const Sampler &sampler, const Bounds2i
     } else Unsupported("a sampler outside halton / sobol / random / stratified / 02sequence / maxmindist");
     rd->max_depth = maxDepth; rd->rr_threshold = rrThreshold;
     rd->pixel_bounds[0] = pixelBounds.pMin.x; rd->pixel_bounds[1] = pixelBounds.pMin.y; rd->pixel_bounds[2] = pixelBounds.pMax.x; rd->pixel_bounds[3] = pixelBounds.pMax.y;
+    // a box-filter frame in which a film position can round up onto the next pixel takes the gathering film path (include/pbrt_gpu.h)
+    if (!rd->filter_general && pgh_box_filter_needs_gather(rd)) {
+        rd->filter_general = 1;
+        rd->tile_halo[0] = -(int)std::ceil(-0.5f - radius.x); rd->tile_halo[1] = -(int)std::ceil(-0.5f - radius.y);
+        rd->tile_halo[2] = (int)std::floor(-0.5f + radius.x) + 1; rd->tile_halo[3] = (int)std::floor(-0.5f + radius.y) + 1;
+        rd->tile_pixels = (16 + rd->tile_halo[0] + rd->tile_halo[2]) * (16 + rd->tile_halo[1] + rd->tile_halo[3]);
+    }
     rd->tile_first = 0; rd->tile_step = 1;
 }
 

@@ -565,6 +565,17 @@ SCENES = {
     "filter_sinc": cornell(24, 24, 4).replace('PixelFilter "box"', 'PixelFilter "sinc" "float xwidth" [ 3 ] "float ywidth" [ 3 ]'),
     "filter_triangle_box": cornell(24, 24, 4).replace('PixelFilter "box"', 'PixelFilter "triangle" "float xwidth" [ 0.5 ] "float ywidth" [ 1 ]'),
     "filter_widebox": cornell(24, 24, 4).replace('PixelFilter "box"', 'PixelFilter "box" "float xwidth" [ 1.25 ] "float ywidth" [ 0.75 ]'),
+    # A box-filter frame in which film positions round UP onto the next pixel: 1920 pixels wide, pixels from x = 1024 on (float
+    # spacing 2^-13), Halton sample indices beyond 2 097 024 (sample 607 of a pixel under a stride of 128 x 27): `1050 + u0` with
+    # u0 = 1 - 2^-14 is 1051.0, and FilmTile::AddSample adds the sample to pixel 1051 BEFORE that pixel's own samples
+    # (film.h:121-161).  Such frames take the gathering film path (pg_box_filter_needs_gather, include/pbrt_gpu.h); found at the
+    # full size of BASELINE config 4 (1920x1080 @ 256 spp: 76 of its 36 864 window pixels)
+    "filter_box_round_up": (
+        'LookAt 0 -17 9  0 -1.5 0.3  0 0 1\nCamera "perspective" "float fov" [ 42 ]\n'
+        'Film "image" "integer xresolution" [ 1920 ] "integer yresolution" [ 1080 ] "float cropwindow" [ 0.53307292 0.59973958 0.43287037 0.44768519 ] '
+        '"string filename" "filter_box_round_up.pfm"\nSampler "halton" "integer pixelsamples" [ 640 ]\nPixelFilter "box"\n'
+        'Integrator "path" "integer maxdepth" [ 1 ]\nWorldBegin\nLightSource "infinite" "rgb L" [ 1 1 1 ]\nMaterial "matte" "rgb Kd" [ 0.5 0.5 0.5 ]\n'
+        'Shape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ] "point P" [ -50 -50 0  50 -50 0  50 50 0  -50 50 0 ]\nWorldEnd\n'),
     # Shape "loopsubdiv" (loopsubdiv.cpp): a closed octahedron (valence-4 extraordinary vertices), an open fan with boundary
     # vertices of valence 2, 3, 4 and 6, and a tetrahedron (valence 3), at several levels, replacing the Cornell boxes
     "cornell_loopsubdiv": cornell(40, 40, 8, world_edit=lambda s: with_subdiv(s)),

@@ -7,8 +7,17 @@
 // `bssrdf G ETA [KD0 KD1 KD2 MFP0 MFP1 MFP2]` prints BSSRDFTable(100, 64) after ComputeBeamDiffusionBSSRDF(G, ETA) (core/bssrdf.cpp:
 // 149-180) as raw float bit patterns, one array per line (rhoSamples, radiusSamples, profile, rhoEff, profileCDF), and with the six
 // further numbers what SubsurfaceFromDiffuse (:182-191) derives: sigma_a, sigma_s (tests/test_subsurface.py).
+// `envlight N` reads N lines `u0 u1` (float bit patterns, hex) from stdin and prints, per line, what a constant-radiance
+// InfiniteAreaLight (identity transform) returns: Sample_Li's wi (3) and pdf, then Pdf_Li(wi) -- all as bit patterns
+// (tests/test_oracle_vs_reference.py::test_infinite_light_sampling_vs_reference).
 // Build: make -C oracle -f Makefile.ref _ref/ref_probe
 #include "materials/metal.cpp"
+#include "sampling.h"
+#include "mipmap.h"
+#include "lights/infinite.h"
+#include "samplers/halton.h"
+#include "interaction.h"
+#include "transform.h"
 #include "bssrdf.h"
 #include "interpolation.h"
 #include "medium.h"
@@ -44,6 +53,36 @@ int main(int argc, char **argv) {
             Float inv = InvertCatmullRom(t.nRhoSamples, t.rhoSamples.get(), t.rhoEff.get(), x);
             printf("%08x %08x %08x | %d %d %08x %08x %08x %08x | %08x | %08x | %08x\n", bits(alpha), bits(u), bits(x), ok ? 1 : 0, offset, bits(w[0]), bits(w[1]), bits(w[2]), bits(w[3]),
                    bits(s2), bits(inv), bits(FresnelMoment1(0.5f + 1.5f * alpha)));
+        }
+        ParallelCleanup();
+        return 0;
+    }
+    if (argc > 9 && !strcmp(argv[1], "halton")) {
+        // `halton X0 X1 Y0 Y1 SPP PX PY K NDIMS`: the first NDIMS numbers HaltonSampler(SPP, sampleBounds) hands out through Get1D() for
+        // sample K of pixel (PX, PY), as bit patterns
+        HaltonSampler hs(atoi(argv[6]), Bounds2i(Point2i(atoi(argv[2]), atoi(argv[4])), Point2i(atoi(argv[3]), atoi(argv[5]))));
+        hs.StartPixel(Point2i(atoi(argv[7]), atoi(argv[8])));
+        hs.SetSampleNumber(atoll(argv[9]));
+        for (int i = 0, n = atoi(argv[10]); i < n; ++i) { Float v = hs.Get1D(); unsigned u; memcpy(&u, &v, 4); printf("%08x ", u); }
+        printf("\n");
+        return 0;
+    }
+    if (argc > 2 && !strcmp(argv[1], "envlight")) {
+        ParallelInit();
+        Float one[3] = {1, 1, 1};
+        InfiniteAreaLight light(Transform(), Spectrum::FromRGB(one), 1, "");
+        Interaction ref(Point3f(0, 0, 0), Normal3f(), Vector3f(), Vector3f(0, 0, 1), 0, MediumInterface());
+        auto bits = [](Float f) { unsigned u; memcpy(&u, &f, 4); return u; };
+        for (int i = 0, n = atoi(argv[2]); i < n; ++i) {
+            unsigned a, b;
+            if (scanf("%x %x", &a, &b) != 2) break;
+            Float u0, u1;
+            memcpy(&u0, &a, 4); memcpy(&u1, &b, 4);
+            Vector3f wi(0, 0, 0);
+            Float pdf = 0;
+            VisibilityTester vis;
+            light.Sample_Li(ref, Point2f(u0, u1), &wi, &pdf, &vis);
+            printf("%08x %08x %08x %08x %08x\n", bits(wi.x), bits(wi.y), bits(wi.z), bits(pdf), bits(light.Pdf_Li(ref, wi)));
         }
         ParallelCleanup();
         return 0;

@@ -177,6 +177,7 @@ GPU_SYMBOLS = {
     "pg_render_sharded": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(PgRenderDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                     C.c_int32, C.POINTER(C.c_int32)]),
     "pg_shard_transport": (C.c_char_p, []),
+    "pg_box_filter_needs_gather": (C.c_int, [C.POINTER(PgRenderDesc)]),
     "pg_intersect": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_int, C.c_void_p]),
     "pg_intersect_p": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

@@ -1036,6 +1036,9 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
     }
     if (rd->sampler == 0 && (!s->d.perms || (5 + 8 * ((long long)rd->max_depth + 1) > s->d.nPermDims && s->d.nPermDims < 1000)))
         return setError(PG_ERR_INVALID, "Halton table has %d dimensions; maxdepth %d needs %lld", s->d.nPermDims, rd->max_depth, 5 + 8 * ((long long)rd->max_depth + 1));
+    if (!rd->filter_general && pgh_box_filter_needs_gather(rd))
+        return setError(PG_ERR_INVALID, "pg_render: filter_general = 0, but in this frame a film position can round up onto the next pixel "
+                                        "(pg_box_filter_needs_gather, include/pbrt_gpu.h): render it with filter_general = 1");
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t stream = (hipStream_t)streamPtr;
     const int nLocalTiles = tileCount(rd);
@@ -1641,6 +1644,7 @@ const std::vector<PgNcclComm> *shardComms(const std::vector<int> &devices, std::
 static std::string g_shardTransport = "none";
 // "rccl" / "peer" (+ why RCCL was not used): how the last pg_render_sharded of this process gathered its shards
 const char *pg_shard_transport(void) { return g_shardTransport.c_str(); }
+int pg_box_filter_needs_gather(const PgRenderDesc *rd) { return rd ? pgh_box_filter_needs_gather(rd) : 0; }
 
 // ---- one frame over several devices of the node, from one host process ---------------------------------------------------------
 // One host thread per device (pg_set_device is per thread); every thread renders its tiles into a packed shard on its own device,

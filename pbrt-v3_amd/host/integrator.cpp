@@ -7,6 +7,7 @@
 //   Render                   core/integrator.cpp:228-339 (tile loop -> device)
 #include <dlfcn.h>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -444,8 +445,6 @@ void GpuPathIntegrator::FillRenderDesc(PgRenderDesc *rd) const {
     film.GetSampleBounds(rd->sample_bounds);
     rd->filter_radius[0] = film.filterRadius[0]; rd->filter_radius[1] = film.filterRadius[1];
     rd->filter_general = film.filterGeneral ? 1 : 0;
-    if (film.filterGeneral) film.TileHalo(rd->tile_halo);
-    rd->tile_pixels = film.TilePixels();
     memcpy(rd->filter_table, film.filterTable, sizeof(rd->filter_table));
     rd->film_scale = film.scale; rd->max_sample_luminance = film.maxSampleLuminance;
     rd->spp = sampler->samplesPerPixel;
@@ -463,6 +462,15 @@ void GpuPathIntegrator::FillRenderDesc(PgRenderDesc *rd) const {
     rd->max_depth = maxDepth; rd->rr_threshold = rrThreshold;
     for (int i = 0; i < 4; ++i) rd->pixel_bounds[i] = pixelBounds[i];
     rd->tile_first = 0; rd->tile_step = 1;
+    // The box filter's fast film path (filter_general = 0: every sample into its own pixel's sum, the rare sample that also lands
+    // in a second pixel appended to that pixel's sum afterwards) has the reference's summation order only while no sample lands in
+    // a pixel the reference visits LATER than the sample's own: FilmTile::AddSample adds in the order the samples are taken
+    // (film.h:121-161), so a sample of pixel x whose film position x + u rounds UP to x + 1 is added to pixel x + 1 BEFORE that
+    // pixel's own samples.  Whether that can happen is a property of sampler, resolution and sample count
+    // (pgh_box_filter_needs_gather, include/pbrt_gpu.h); if it can, the frame takes the gathering film path.
+    if (!rd->filter_general && pgh_box_filter_needs_gather(rd)) rd->filter_general = 1;
+    if (rd->filter_general) film.TileHalo(rd->tile_halo);
+    rd->tile_pixels = rd->filter_general ? (16 + rd->tile_halo[0] + rd->tile_halo[2]) * (16 + rd->tile_halo[1] + rd->tile_halo[3]) : 256;
 }
 
 // The C ABI is bound at run time, the way a pbrt maintainer's plugin loader
