@@ -3582,7 +3582,10 @@ __global__ __launch_bounds__(PG_BLOCK) void k_film_general(RenderParams rp, Path
     const int tp1x = min((int)floorf((float)x1 - 0.5f + frx) + 1, rd.cropped_pixel_bounds[2]);
     const int tp1y = min((int)floorf((float)y1 - 0.5f + fry) + 1, rd.cropped_pixel_bounds[3]);
     const int tw = 16 + rd.tile_halo[0] + rd.tile_halo[2];
-    const int reachX = (int)floorf(0.5f + frx) + 1, reachY = (int)floorf(0.5f + fry) + 1;  // source pixels that can reach a pixel
+    // source pixels that can reach a pixel: a sample of pixel p has pFilmDiscrete in [p - 0.5, p + 0.5] and covers the pixels
+    // ceil(d - r) .. floor(d + r); one more than floor(0.5 + r) against the rounding of those sums -- which a radius <= 0.5 (the box
+    // filter on this path: frames whose film positions can round onto the next pixel) cannot need: p + 0.5 + r <= p + 1 is exact
+    const int reachX = frx <= 0.5f ? 1 : (int)floorf(0.5f + frx) + 1, reachY = fry <= 0.5f ? 1 : (int)floorf(0.5f + fry) + 1;
     for (int e = threadIdx.x; e < rd.tile_pixels; e += PG_BLOCK) {
         const int X = x0 - rd.tile_halo[0] + e % tw, Y = y0 - rd.tile_halo[1] + e / tw;
         if (X < tp0x || X >= tp1x || Y < tp0y || Y >= tp1y) continue;
