@@ -352,6 +352,26 @@ def live_pmc(bench_args, passes, timeout=300):
     return (kernels, None) if kernels else (None, "no FETCH_SIZE rows in the counter files")
 
 
+def merge_pmc(entries):
+    """The counters of the kernels behind ONE timed slot as one entry.  The shading slot is k_shade_order + k_material + k_shade<.>
+    (HIP events around the three launches): their per-launch totals add up -- each weighted by its own dispatch count, over the
+    slot's count (the largest among them) --, lanes per vector instruction are averaged over the instructions."""
+    if not entries:
+        return None
+    if len(entries) == 1:
+        return entries[0]
+    n = max(max(1, e.get("launches", 1)) for e in entries)
+    out = {"launches": n}
+    for f in ("fetch_KiB_per_launch", "write_KiB_per_launch", "hbm_bytes_per_launch", "valu_insts_per_launch"):
+        if any(f in e for e in entries):
+            out[f] = sum(e.get(f, 0.0) * max(1, e.get("launches", 1)) for e in entries) / n
+    insts = [(e["valu_insts_per_launch"] * max(1, e.get("launches", 1)), e["valu_lanes_active"]) for e in entries
+             if e.get("valu_insts_per_launch") and e.get("valu_lanes_active") is not None]
+    if insts:
+        out["valu_lanes_active"] = sum(i * l for i, l in insts) / sum(i for i, _ in insts)
+    return out
+
+
 def kernel_rooflines(m, workload, live=None):
     """One roofline per hot kernel.  Algorithmic bytes:
       k_trace: 32 B per reference node fetch + 48 B per triangle test + 32 B per ray in + 16 B (closest) / 4 B (any) out
@@ -404,7 +424,7 @@ def kernel_rooflines(m, workload, live=None):
     def one(name, tag, alg_bytes, ms, launches, units, unit_name, gather_pattern, bound=bound, peak=peak):
         launches = max(1, launches)
         achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        pk = next((v for k, v in pmc_kernels.items() if k.startswith(tag)), None)  # tag: a tuple of accepted name prefixes
+        pk = merge_pmc([v for k, v in pmc_kernels.items() if k.startswith(tag)])  # tag: a tuple of accepted name prefixes
         traffic = None
         if pk is not None:
             f = factor if gather_pattern else 2.0
@@ -441,7 +461,7 @@ def kernel_rooflines(m, workload, live=None):
             32 * cn["closest_node_visits"] + 48 * cn["closest_tri_tests"] + 48 * n_close, cn["closest_ms"], cn["closest_launches"], n_close, "ray", True),
         one(("k_trace<1> (any hit, reference order" if os.environ.get("PG_ANYHIT_ORDER") == "reference" else "k_trace<2> (any hit, free order") + ": BVHAccel::IntersectP + Triangle::IntersectP)", ("void k_trace<2,", "void k_trace<1,", "void k_trace<true"),
             32 * cn["shadow_node_visits"] + 48 * cn["shadow_tri_tests"] + 36 * n_shadow, cn["shadow_ms"], cn["shadow_launches"], n_shadow, "ray", True),
-        one("k_shade (PathIntegrator::Li loop body + EstimateDirect set-up)", "void k_shade",
+        one("k_shade (PathIntegrator::Li loop body + EstimateDirect set-up; with k_shade_order / k_material where they run)", ("void k_shade<", "void k_shade_order<", "void k_material<"),
             224 * n_items + 32 * (n_next + n_shadow + n_mis) + 16 * n_mis, cn["shade_ms"], cn["shade_launches"], n_items, "vertex", False,
             # its streams are the queues and the path state (hundreds of bytes per vertex of a 10^8-vertex launch), not the scene: HBM at any scene size
             bound="hbm", peak=HBM_PEAK_GBS),
