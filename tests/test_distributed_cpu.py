@@ -55,3 +55,11 @@ def test_two_rank_sharded_render_matches_golden(pkg, tmp_path):
 def test_three_rank_uneven_shards(pkg, tmp_path):
     img = _run("cornell_32", 3, tmp_path, 29541)  # 4 tiles over 3 ranks: 2/1/1
     assert np.array_equal(img, pkg.read_pfm(os.path.join(GOLD, "cornell_32.pfm")))
+
+
+def test_sharded_frame_whose_film_positions_round_onto_the_next_pixel(pkg, tmp_path):
+    """filter_box_round_up (tests/test_film_round_up.py): a box-filter frame on the gathering film path -- every rank's tile blocks
+    carry their one-pixel halo (the sample that rounds up at a tile's last column lands in the NEIGHBOURING rank's pixel), and rank
+    0's merge adds the blocks as the reference merges its FilmTiles: the reference binary's image bit for bit, from 2 ranks."""
+    img = _run("filter_box_round_up", 2, tmp_path, 29551)
+    assert np.array_equal(img, pkg.read_pfm(os.path.join(GOLD, "filter_box_round_up.pfm")))
