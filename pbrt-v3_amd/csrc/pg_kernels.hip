@@ -2125,8 +2125,9 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
     __shared__ float4 s_ray[3][2][PG_SHADE_BLOCK];
     __shared__ float4 s_state[QSTATE ? 3 : 1][PG_SHADE_BLOCK];  // QSTATE: (L, beta, meta) until the entry's place in the next queue is known
     // EXT: of the seven Halton numbers a vertex computes ahead (halton_batch) the last four -- uScattering and the next direction's pair,
-    // drawn late -- wait in LDS; they were what the register allocator put into scratch, and any scratch at all costs these
-    // one-vertex-per-lane kernels ~20 % (profiles/r04k_*).  (Not MODE 0: 2 KB more LDS per block would cost it a resident block)
+    // drawn late -- wait in LDS: they were what the register allocator put into scratch when the BxDF-list body grew; with them (and L,
+    // see below) the kernel stays at 159 - 161 registers without scratch (profiles/r04j_bxdf_list_ab.txt).  (Not MODE 0: 2 KB more LDS
+    // per block would cost it a resident block)
     __shared__ float s_pre[EXT ? 4 : 1][PG_SHADE_BLOCK];
     const int tid = threadIdx.x;
     bool pushNext = false, pushShadow = false, pushMis = false;
@@ -2273,8 +2274,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
         }
         // QSTATE: L is final for this launch here (k_resolve adds the vertex's direct lighting), and the camera sample's film position in
         // L.w / beta.w is only carried along: both wait in LDS from here on instead of in five registers across the whole BSDF part --
-        // with them the BxDF-list kernels stay under the 168 registers of three waves per SIMD without scratch (any scratch at all costs
-        // these one-vertex-per-lane kernels ~20 %: profiles/r04k_*)
+        // with them the BxDF-list kernels stay under the 168 registers of three waves per SIMD without scratch
         if constexpr (QSTATE && !TEX) {
             s_state[0][tid] = make_float4(L.r, L.g, L.b, L4.w);
             reinterpret_cast<float *>(&s_state[1][tid])[3] = B4.w;
