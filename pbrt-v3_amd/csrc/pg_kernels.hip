@@ -3586,6 +3586,27 @@ __global__ __launch_bounds__(PG_BLOCK) void k_film_general(RenderParams rp, Path
     // ceil(d - r) .. floor(d + r); one more than floor(0.5 + r) against the rounding of those sums -- which a radius <= 0.5 (the box
     // filter on this path: frames whose film positions can round onto the next pixel) cannot need: p + 0.5 + r <= p + 1 is exact
     const int reachX = frx <= 0.5f ? 1 : (int)floorf(0.5f + frx) + 1, reachY = fry <= 0.5f ? 1 : (int)floorf(0.5f + fry) + 1;
+    // Radius <= 0.5 (the box filter): almost every sample stays in its own pixel.  Each source pixel's samples are looked at once
+    // first -- does one of them cover a pixel besides its own? --, and the gather below visits the samples of OTHER pixels only
+    // where that is so (the frame of config 3 at 68 spp: 6.45 ms of film kernel for nine source pixels per pixel)
+    __shared__ unsigned char s_reaches[256];
+    const bool narrow = frx <= 0.5f && fry <= 0.5f;
+    if (narrow) {
+        for (int pix = threadIdx.x; pix < 256; pix += PG_BLOCK) {
+            const int px = x0 + (pix & 15), py = y0 + (pix >> 4);
+            bool reaches = false;
+            if (px < x1 && py < y1 && !(px < rd.pixel_bounds[0] || px >= rd.pixel_bounds[2] || py < rd.pixel_bounds[1] || py >= rd.pixel_bounds[3]))
+                for (int sIdx = 0; sIdx < rp.sCount && !reaches; ++sIdx) {
+                    const int slot = (tileInBatch * rp.sCount + sIdx) * 256 + pix;
+                    const float dx = st.L[slot].w - 0.5f, dy = st.beta[slot].w - 0.5f;  // pFilmDiscrete
+                    const int p0x = max((int)ceilf(dx - frx), tp0x), p1x = min((int)floorf(dx + frx) + 1, tp1x);
+                    const int p0y = max((int)ceilf(dy - fry), tp0y), p1y = min((int)floorf(dy + fry) + 1, tp1y);
+                    reaches = p0x < px || p1x > px + 1 || p0y < py || p1y > py + 1;
+                }
+            s_reaches[pix] = reaches ? 1 : 0;
+        }
+        __syncthreads();
+    }
     for (int e = threadIdx.x; e < rd.tile_pixels; e += PG_BLOCK) {
         const int X = x0 - rd.tile_halo[0] + e % tw, Y = y0 - rd.tile_halo[1] + e / tw;
         if (X < tp0x || X >= tp1x || Y < tp0y || Y >= tp1y) continue;
@@ -3595,6 +3616,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_film_general(RenderParams rp, Path
                 // InsideExclusive(pixel, pixelBounds), integrator.cpp:273
                 if (px < rd.pixel_bounds[0] || px >= rd.pixel_bounds[2] || py < rd.pixel_bounds[1] || py >= rd.pixel_bounds[3]) continue;
                 const int pix = (py - y0) * 16 + (px - x0);
+                if (narrow && !(px == X && py == Y) && !s_reaches[pix]) continue;  // none of that pixel's samples leaves it
                 for (int sIdx = 0; sIdx < rp.sCount; ++sIdx) {
                     const int slot = (tileInBatch * rp.sCount + sIdx) * 256 + pix;
                     const float4 L4 = st.L[slot];
