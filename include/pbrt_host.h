@@ -33,6 +33,11 @@ void pbrt_host_film_size(PbrtHostScene *s, int *width, int *height);
 void pbrt_host_film_clear(PbrtHostScene *s);
 void pbrt_host_film_merge(PbrtHostScene *s, const PgRenderDesc *rd, const PgFilmPixel *film,
                           const PgStraySample *strays, int n_strays);
+/* The n shards of ONE frame (shard r = the tiles t = r (mod n) of the frame `full` describes: tile_first 0, tile_step 1), merged in the
+ * frame's own tile order -- what a one-device render merges, bit for bit, also for filters whose tile blocks overlap
+ * (Film::MergeFilmTile, core/film.cpp:117-130; the reference's cross-machine analogue is imgtool assemble, tools/imgtool.cpp:190-285). */
+void pbrt_host_film_merge_shards(PbrtHostScene *s, const PgRenderDesc *full, int n, const PgFilmPixel *const *film,
+                                 const PgStraySample *const *strays, const int *n_strays);
 void pbrt_host_film_image(PbrtHostScene *s, float *rgb);
 int pbrt_host_write_pfm(const char *filename, const float *rgb, int width, int height);
 /* WriteImage (core/imageio.cpp:81-122): PFM, gamma-encoded 8-bit PNG / TGA, or half-float OpenEXR (uncompressed), chosen by the

@@ -105,6 +105,17 @@ class HostScene:
         strays = np.ascontiguousarray(strays)
         host_lib().pbrt_host_film_merge(self._h, C.byref(rd), film.ctypes.data, strays.ctypes.data, len(strays))
 
+    def film_merge_shards(self, full_rd, shards):
+        """The n shards [(film, strays), ...] of ONE frame (shard r = the tiles t = r (mod n)), merged in the frame's own tile order:
+        Film::MergeShards.  `full_rd` describes the whole frame (tile_first 0, tile_step 1)."""
+        n = len(shards)
+        films = [np.ascontiguousarray(f) for f, _ in shards]
+        strays = [np.ascontiguousarray(s) for _, s in shards]
+        fp = (C.c_void_p * n)(*[f.ctypes.data for f in films])
+        sp = (C.c_void_p * n)(*[s.ctypes.data for s in strays])
+        ns = (C.c_int * n)(*[len(s) for s in strays])
+        host_lib().pbrt_host_film_merge_shards(self._h, C.byref(full_rd), n, fp, sp, ns)
+
     def film_image(self):
         """Final RGB image as Film::WriteImage computes it: (h, w, 3) float32, top row first."""
         w, h = self.film_size

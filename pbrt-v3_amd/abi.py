@@ -196,6 +196,7 @@ HOST_SYMBOLS = {
     "pbrt_host_film_size": (None, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pbrt_host_film_clear": (None, [C.c_void_p]),
     "pbrt_host_film_merge": (None, [C.c_void_p, C.POINTER(PgRenderDesc), C.c_void_p, C.c_void_p, C.c_int]),
+    "pbrt_host_film_merge_shards": (None, [C.c_void_p, C.POINTER(PgRenderDesc), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "pbrt_host_film_image": (None, [C.c_void_p, C.c_void_p]),
     "pbrt_host_write_pfm": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int]),
     "pbrt_host_write_image": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int]),

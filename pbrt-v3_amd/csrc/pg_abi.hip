@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
 #include <dlfcn.h>
 #include <functional>
@@ -705,7 +706,6 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         // with BSSRDF materials or grid media (their kernels evaluate inside), PG_MAT_PRE=0: nowhere.
         const char *mp = getenv("PG_MAT_PRE");
         if (anyTextured && desc->n_bssrdfs == 0 && d.nGrids == 0 && !(mp && atoi(mp) == 0)) {
-            std::vector<int> bound((size_t)desc->n_materials, -1);
             std::function<int(int, int)> lobes = [&](int mi, int depth) -> int {
                 if (mi < 0 || mi >= desc->n_materials) return 0;
                 const PgMaterial &m = desc->materials[mi];
@@ -1641,9 +1641,16 @@ const std::vector<PgNcclComm> *shardComms(const std::vector<int> &devices, std::
 }
 }  // namespace
 #endif
+// "rccl" / "peer" (+ why RCCL was not used): how the last pg_render_sharded of this process gathered its shards.  The text is
+// replaced under a lock and handed out as a pointer that stays valid for the calling thread until its next call.
+static std::mutex g_shardTransportMutex;
 static std::string g_shardTransport = "none";
-// "rccl" / "peer" (+ why RCCL was not used): how the last pg_render_sharded of this process gathered its shards
-const char *pg_shard_transport(void) { return g_shardTransport.c_str(); }
+const char *pg_shard_transport(void) {
+    static thread_local std::string mine;
+    std::lock_guard<std::mutex> lock(g_shardTransportMutex);
+    mine = g_shardTransport;
+    return mine.c_str();
+}
 int pg_box_filter_needs_gather(const PgRenderDesc *rd) { return rd ? pgh_box_filter_needs_gather(rd) : 0; }
 
 // ---- one frame over several devices of the node, from one host process ---------------------------------------------------------
@@ -1672,8 +1679,12 @@ int pg_render_sharded(PgScene *const *scenes, int32_t n, const PgRenderDesc *des
     // one packed shard per rank, the same size for all: [film (filmMax) | strays | count]; the gathered frame is n of them in rank order
     const size_t strayOff = filmMax, countOff = strayOff + strayBytes, per = (countOff + sizeof(int) + 255) / 256 * 256;
     const size_t total = per * (size_t)n;
+    // one sharded render at a time per process: the communicators of a device list carry one collective at a time, and the scenes'
+    // shard / gather buffers are per scene
+    static std::mutex shardedMutex;
+    std::lock_guard<std::mutex> shardedLock(shardedMutex);
     HIP_TRY(hipSetDevice(root->device));
-    HIP_TRY(root->gatherDev.alloc(total));
+    if (root->gatherDev.bytes < total) HIP_TRY(root->gatherDev.alloc(total));  // kept between frames (hipFree + hipMalloc synchronise the device)
     char *gather = (char *)root->gatherDev.p;
     // transport: RCCL unless PG_SHARD_GATHER=peer, a device repeats (tests on a one-GPU box) or librccl cannot be used -- then peer copies
     std::string why;
@@ -1692,10 +1703,20 @@ int pg_render_sharded(PgScene *const *scenes, int32_t n, const PgRenderDesc *des
 #endif
     std::vector<int> status((size_t)n, PG_OK);
     std::vector<std::string> message((size_t)n);
-    auto work = [&](int r) {
+    // Every rank reaches the collective or none does: a rank whose render failed (out of memory on one device, say) must not leave
+    // the other n - 1 threads waiting in ncclGather for a peer that already returned.  The threads meet at a host barrier between
+    // the render and the gather; if any of them failed by then, all skip the gather and the caller gets that rank's error.
+    struct { std::mutex m; std::condition_variable cv; int arrived = 0; bool anyFailed = false; } meet;
+    auto meetAll = [&](bool failed) -> bool {  // returns whether any rank failed
+        std::unique_lock<std::mutex> lock(meet.m);
+        meet.anyFailed = meet.anyFailed || failed;
+        if (++meet.arrived == n) meet.cv.notify_all();
+        else meet.cv.wait(lock, [&] { return meet.arrived == n; });
+        return meet.anyFailed;
+    };
+    auto render = [&](int r) -> bool {  // this rank's tiles into its packed shard; false = failed (status / message set)
         PgScene *s = scenes[r];
-        auto fail = [&](int code) { status[r] = code; message[r] = pg_last_error(); };
-        if (hipSetDevice(s->device) != hipSuccess) { status[r] = PG_ERR_DEVICE; message[r] = "hipSetDevice failed"; return; }
+        if (hipSetDevice(s->device) != hipSuccess) { status[r] = PG_ERR_DEVICE; message[r] = "hipSetDevice failed"; return false; }
         bool viaRccl = false;
 #ifndef HIP_EMU_H
         viaRccl = comms != nullptr;
@@ -1704,16 +1725,24 @@ int pg_render_sharded(PgScene *const *scenes, int32_t n, const PgRenderDesc *des
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, s->device, root->device) == hipSuccess && can) {
                 hipError_t e = hipDeviceEnablePeerAccess(root->device, 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { status[r] = PG_ERR_DEVICE; message[r] = hipGetErrorString(e); return; }
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { status[r] = PG_ERR_DEVICE; message[r] = hipGetErrorString(e); return false; }
                 (void)hipGetLastError();
             }
         }
-        if (s->shardFilm.bytes < per && s->shardFilm.alloc(per) != hipSuccess) { status[r] = PG_ERR_DEVICE; message[r] = "out of device memory (packed shard)"; return; }
+        if (const char *e = getenv("PG_TEST_FAIL_RANK")) if (atoi(e) == r) { status[r] = PG_ERR_DEVICE; message[r] = "PG_TEST_FAIL_RANK (a test's injected failure)"; return false; }
+        if (s->shardFilm.bytes < per && s->shardFilm.alloc(per) != hipSuccess) { status[r] = PG_ERR_DEVICE; message[r] = "out of device memory (packed shard)"; return false; }
         char *packed = (char *)s->shardFilm.p;
         int st = pg_render(s, &rd[r], (PgFilmPixel *)packed, (PgStraySample *)(packed + strayOff), maxStrays, (int32_t *)(packed + countOff), PG_MEM_DEVICE, nullptr);
-        if (st != PG_OK) { fail(st); return; }
+        if (st != PG_OK) { status[r] = st; message[r] = pg_last_error(); return false; }
+        return true;
+    };
+    auto work = [&](int r) {
+        const bool ok = render(r);
+        if (meetAll(!ok)) return;  // some rank failed: nobody enters the collective
+        PgScene *s = scenes[r];
+        char *packed = (char *)s->shardFilm.p;
 #ifndef HIP_EMU_H
-        if (viaRccl) {
+        if (comms) {
             // one collective per frame: every rank's thread calls it on its own communicator (the threads are the "different
             // threads" of rccl.h:213); root 0 receives rank r's shard at gather + r * per
             const int rs = rcclApi()->Gather(packed, r == 0 ? gather : nullptr, per, /*ncclChar*/ 0, 0, (*comms)[r], nullptr);
@@ -1733,7 +1762,7 @@ int pg_render_sharded(PgScene *const *scenes, int32_t n, const PgRenderDesc *des
         for (auto &t : threads) t.join();
     }
     for (int r = 0; r < n; ++r) if (status[r] != PG_OK) return setError(status[r], "rank %d: %s", r, message[r].c_str());
-    g_shardTransport = why.empty() ? "rccl" : "peer (" + why + ")";
+    { std::lock_guard<std::mutex> lock(g_shardTransportMutex); g_shardTransport = why.empty() ? "rccl" : "peer (" + why + ")"; }
     // the gathered frame back to the host in one piece
     HIP_TRY(hipSetDevice(root->device));
     std::vector<char> host(total);

@@ -9,7 +9,8 @@ RCCL over xGMI when the tensors are on GPUs (a gather is point-to-point sends in
 hop each), gloo on CPU.
 No reduction is needed on the device: with a box filter of radius 0.5 every pixel is owned by exactly one tile, and for
 wider filters a tile's block carries its halo (PgRenderDesc.tile_pixels entries per tile) and rank 0's host Film adds the
-overlapping blocks in tile order (Film::MergeFilmTile).
+overlapping blocks in the FRAME's tile order (Film::MergeShards: tile t from shard t % world), i.e. the order a one-GPU
+render merges them in: the N-GPU image is the one-GPU image bit for bit for every filter.
 """
 import numpy as np
 import torch
@@ -47,16 +48,16 @@ class FilmGather:
         self.dst, self.rank, self.world = dst, dist.get_rank(), dist.get_world_size()
         self.comm_device = torch.device(comm_device) if comm_device is not None else shard.words.device
         self.staged = self.comm_device != shard.words.device  # pre-flight only: ranks sharing one GPU gather host copies through gloo
-        self._recv = {}  # id(ShardBuffer) -> its receive buffers on dst
         self.pending = None
         self._recv_for(shard)
 
     def _recv_for(self, shard):
         if self.rank != self.dst:
             return None
-        r = self._recv.get(id(shard))
-        if r is None:
-            r = self._recv[id(shard)] = [torch.empty(shard.words.shape, dtype=torch.int32, device=self.comm_device) for _ in range(self.world)]
+        # the receive set lives ON the ShardBuffer (a dict keyed by id() would hand a new buffer of another shape the set of a dead one)
+        r = getattr(shard, "_recv_set", None)
+        if r is None or r[0].shape != shard.words.shape or r[0].device != self.comm_device or len(r) != self.world:
+            r = shard._recv_set = [torch.empty(shard.words.shape, dtype=torch.int32, device=self.comm_device) for _ in range(self.world)]
         return r
 
     def start(self, shard, async_op=True):
@@ -103,14 +104,16 @@ def gather_film(film, strays, nstrays, lists=None, dst=0):
 
 
 def merge_shards(pkg, scene, tile_count, shards):
-    """Film::MergeFilmTile for every rank's shard on the host; shards = [(film, strays, n), ...] per rank.
-    Returns the final (h, w, 3) image."""
+    """Film::MergeFilmTile for the frame's tiles in tile order on the host (tile t from shard t % world: Film::MergeShards);
+    shards = [(film, strays, n), ...] per rank.  Returns the final (h, w, 3) image."""
     world = len(shards)
     scene.film_clear()
+    arrays = []
     for r, (film, strays, n) in enumerate(shards):
         rd = scene.render_desc(tile_first=r, tile_step=world)
         nt = tile_count(rd)
         f = np.ascontiguousarray(film.detach().cpu().numpy()[:nt * rd.tile_pixels]).view(pkg.FILM_PIXEL_DTYPE).reshape(-1)
         s = np.ascontiguousarray(strays.detach().cpu().numpy()[:int(n)]).view(pkg.STRAY_DTYPE).reshape(-1)
-        scene.film_merge(rd, f, s)
+        arrays.append((f, s))
+    scene.film_merge_shards(scene.render_desc(tile_first=0, tile_step=1), arrays)
     return scene.film_image()

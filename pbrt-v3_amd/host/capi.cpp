@@ -59,6 +59,9 @@ void pbrt_host_film_clear(PbrtHostScene *s) { s->loaded->integrator->camera->fil
 void pbrt_host_film_merge(PbrtHostScene *s, const PgRenderDesc *rd, const PgFilmPixel *film, const PgStraySample *strays, int n) {
     s->loaded->integrator->camera->film->MergeShard(*rd, film, strays, n);
 }
+void pbrt_host_film_merge_shards(PbrtHostScene *s, const PgRenderDesc *full, int n, const PgFilmPixel *const *film, const PgStraySample *const *strays, const int *n_strays) {
+    s->loaded->integrator->camera->film->MergeShards(*full, n, film, strays, n_strays);
+}
 void pbrt_host_film_image(PbrtHostScene *s, float *rgb) {
     std::vector<Float> img;
     s->loaded->integrator->camera->film->ComputeImage(&img);

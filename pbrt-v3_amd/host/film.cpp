@@ -102,17 +102,28 @@ int Film::TilePixels() const {
 }
 
 void Film::MergeShard(const PgRenderDesc &rd, const PgFilmPixel *film, const PgStraySample *strays, int nStrays) {
+    // one shard = the tiles tile_first, tile_first + tile_step, ... of the frame, in that order
+    MergeTiles(rd, rd.tile_first, rd.tile_step, [&](int t) { return film + (size_t)((t - rd.tile_first) / rd.tile_step) * rd.tile_pixels; }, &strays, &nStrays, 1);
+}
+void Film::MergeShards(const PgRenderDesc &full, int n, const PgFilmPixel *const *film, const PgStraySample *const *strays, const int *nStrays) {
+    // n shards of one frame (rank r rendered the tiles t = r (mod n)): merged in the frame's own tile order 0, 1, 2, ... -- tile t's
+    // block is the (t / n)-th of shard t % n -- so that overlapping tile blocks of a filter wider than half a pixel (float sums)
+    // add up in the order a one-device render and the single-threaded reference use, whatever n is
+    MergeTiles(full, 0, 1, [&](int t) { return film[t % n] + (size_t)(t / n) * full.tile_pixels; }, strays, nStrays, n);
+}
+void Film::MergeTiles(const PgRenderDesc &rd, int tileFirst, int tileStep, const std::function<const PgFilmPixel *(int)> &blockOf, const PgStraySample *const *strayLists,
+                      const int *nStrayLists, int nLists) {
     const int tileSize = 16;
     if (rd.filter_general) {
-        // MergeFilmTile (film.cpp:117-130) for every tile of the shard in tile order: each FilmTile pixel is converted to
+        // MergeFilmTile (film.cpp:117-130) for every tile in tile order: each FilmTile pixel is converted to
         // XYZ and added to the film, clipped to the cropped pixel bounds as GetFilmTile's Intersect does.
         const int sx0 = rd.sample_bounds[0], sy0 = rd.sample_bounds[1];
         const int nTilesX = (rd.sample_bounds[2] - sx0 + tileSize - 1) / tileSize;
         const int nTilesY = (rd.sample_bounds[3] - sy0 + tileSize - 1) / tileSize;
         const int width = croppedPixelBounds[2] - croppedPixelBounds[0];
         const int tw = tileSize + rd.tile_halo[0] + rd.tile_halo[2];
-        int local = 0;
-        for (int t = rd.tile_first; t < nTilesX * nTilesY; t += rd.tile_step, ++local) {
+        for (int t = tileFirst; t < nTilesX * nTilesY; t += tileStep) {
+            const PgFilmPixel *block = blockOf(t);
             int tx = t % nTilesX, ty = t / nTilesX;
             int x0 = sx0 + tx * tileSize, y0 = sy0 + ty * tileSize;
             int x1 = std::min(x0 + tileSize, rd.sample_bounds[2]), y1 = std::min(y0 + tileSize, rd.sample_bounds[3]);
@@ -120,7 +131,7 @@ void Film::MergeShard(const PgRenderDesc &rd, const PgFilmPixel *film, const PgS
             int px1 = std::min(x1 + rd.tile_halo[2], croppedPixelBounds[2]), py1 = std::min(y1 + rd.tile_halo[3], croppedPixelBounds[3]);
             for (int y = py0; y < py1; ++y)
                 for (int x = px0; x < px1; ++x) {
-                    const PgFilmPixel &fp = film[(size_t)local * rd.tile_pixels + (size_t)(y - (y0 - rd.tile_halo[1])) * tw + (x - (x0 - rd.tile_halo[0]))];
+                    const PgFilmPixel &fp = block[(size_t)(y - (y0 - rd.tile_halo[1])) * tw + (x - (x0 - rd.tile_halo[0]))];
                     Float xyz[3];
                     RGBToXYZ(fp.rgb, xyz);
                     Pixel &mp = pixels[(size_t)(y - croppedPixelBounds[1]) * width + (x - croppedPixelBounds[0])];
@@ -143,24 +154,25 @@ void Film::MergeShard(const PgRenderDesc &rd, const PgFilmPixel *film, const PgS
     // one pixel are summed in RGB in sample order, then merged.
     struct Key { int tile, x, y; bool operator<(const Key &o) const { return tile != o.tile ? tile < o.tile : (y != o.y ? y < o.y : x < o.x); } };
     std::map<Key, std::vector<const PgStraySample *>> groups;
-    for (int i = 0; i < nStrays; ++i) {
-        const PgStraySample &s = strays[i];
-        if (!inCrop(s.px, s.py)) continue;
-        groups[Key{tileOf(s.src_px, s.src_py), s.px, s.py}].push_back(&s);
-    }
+    for (int l = 0; l < nLists; ++l)  // (a tile's strays all come from the one shard that rendered it: their order inside a group is that shard's)
+        for (int i = 0; i < nStrayLists[l]; ++i) {
+            const PgStraySample &s = strayLists[l][i];
+            if (!inCrop(s.px, s.py)) continue;
+            groups[Key{tileOf(s.src_px, s.src_py), s.px, s.py}].push_back(&s);
+        }
     for (auto &kv : groups)  // source order inside a tile = row-major pixel order (integrator.cpp:263)
         std::sort(kv.second.begin(), kv.second.end(), [](const PgStraySample *a, const PgStraySample *b) {
             return a->src_py != b->src_py ? a->src_py < b->src_py : a->src_px < b->src_px;
         });
-    int local = 0;
-    for (int t = rd.tile_first; t < nTilesX * nTilesY; t += rd.tile_step, ++local) {
+    for (int t = tileFirst; t < nTilesX * nTilesY; t += tileStep) {
+        const PgFilmPixel *block = blockOf(t);
         int tx = t % nTilesX, ty = t / nTilesX;
         int x0 = sx0 + tx * tileSize, y0 = sy0 + ty * tileSize;
         int x1 = std::min(x0 + tileSize, rd.sample_bounds[2]), y1 = std::min(y0 + tileSize, rd.sample_bounds[3]);
         for (int y = y0; y < y1; ++y)
             for (int x = x0; x < x1; ++x) {
                 if (!inCrop(x, y)) continue;
-                const PgFilmPixel &fp = film[(size_t)local * 256 + (y - y0) * tileSize + (x - x0)];
+                const PgFilmPixel &fp = block[(y - y0) * tileSize + (x - x0)];
                 Float rgb[3] = {fp.rgb[0], fp.rgb[1], fp.rgb[2]};
                 Float wsum = fp.weight;
                 auto g = groups.find(Key{t, x, y});

@@ -591,7 +591,7 @@ void GpuPathIntegrator::Render(const Scene &scene) {
     for (int r = 0; r < n; ++r) if (gpuApi.counters(dev[r], &counters[r]) != PG_OK) memset(&counters[r], 0, sizeof(PgCounters));
     ReportStatistics(counters, sec);
     for (PgScene *d : dev) gpuApi.scene_destroy(d);
-    for (int r = 0; r < n; ++r) camera->film->MergeShard(shard[r], film[r].data(), strays[r].data(), nStrays[r]);  // Film::MergeFilmTile per tile, rank by rank
+    camera->film->MergeShards(rd, n, filmPtr.data(), strayPtr.data(), nStrays.data());  // Film::MergeFilmTile per tile, in the frame's tile order whatever n is
     camera->film->WriteImage();  // integrator.cpp:338
 }
 }  // namespace pbrt

@@ -9,6 +9,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <functional>
 #include <vector>
 #include "../../include/pbrt_gpu.h"
 #include "geometry.h"
@@ -150,7 +151,13 @@ class Film {
     void GetSampleBounds(int out[4]) const;  // film.cpp:80-86
     // MergeFilmTile (film.cpp:117-130) for one GPU shard's packed tile buffer + stray samples.
     void MergeShard(const PgRenderDesc &rd, const PgFilmPixel *film, const PgStraySample *strays, int nStrays);
+    // The n shards of one frame (shard r = the tiles t = r (mod n)), merged in the frame's tile order: what a one-device render merges.
+    void MergeShards(const PgRenderDesc &full, int n, const PgFilmPixel *const *film, const PgStraySample *const *strays, const int *nStrays);
     void Clear();
+  private:
+    void MergeTiles(const PgRenderDesc &rd, int tileFirst, int tileStep, const std::function<const PgFilmPixel *(int)> &blockOf, const PgStraySample *const *strayLists,
+                    const int *nStrayLists, int nLists);
+  public:
     // WriteImage's arithmetic (film.cpp:169-206): XYZ->RGB, /weight, clamp, *scale.
     void ComputeImage(std::vector<Float> *rgb) const;
     void WriteImage() const;

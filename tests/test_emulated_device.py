@@ -113,6 +113,20 @@ def test_native_multi_device_render_on_emulated_devices(emulated, pkg, tmp_path)
     assert np.array_equal(images[1], pkg.read_pfm(scene[:-5] + ".pfm")) or np.abs(images[1] - pkg.read_pfm(scene[:-5] + ".pfm")).max() < 1e-4
 
 
+def test_a_failing_rank_fails_the_sharded_render_instead_of_hanging_it(emulated, pkg, tmp_path):
+    """pg_render_sharded: a rank whose render fails (here PG_TEST_FAIL_RANK; on hardware an out-of-memory device) must not leave the
+    other ranks' threads waiting in the collective for it.  All threads meet at a host barrier between render and gather; with a failed
+    rank none enters the gather and the call returns that rank's error."""
+    cli = os.path.join(ROOT, "pbrt-v3_amd", "pbrt_amd")
+    if not os.path.exists(cli):
+        pytest.skip("pbrt_amd not built")
+    scene = os.path.join(ROOT, "tests", "golden", "cornell_40x24.pbrt")
+    for bad in (0, 2):
+        p = subprocess.run([cli, "--gpus", "3", "--outfile", str(tmp_path / "x.pfm"), scene], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, PBRT_GPU_LIB=emulated, HIP_EMU_DEVICES="3", PG_TEST_FAIL_RANK=str(bad)))
+        assert p.returncode != 0 and f"rank {bad}: PG_TEST_FAIL_RANK" in p.stdout + p.stderr, (p.stdout + p.stderr)[-1500:]
+
+
 def _rank(rank, world, port, lib, name, out):
     """One rank of bench.py's step(): render this rank's tiles with pg_render into its own buffers (GpuScene.render_device -- the call
     bench.py makes), gather on rank 0 with the product's pbrt_v3_amd.distributed (gloo here, RCCL there), merge."""
