@@ -221,7 +221,7 @@ class Context:
         self.device_sync()
 
 
-def run_workload(ctx, args, steps, warmup, keep_image=False):
+def run_workload(ctx, args, steps, warmup, keep_image=False, serial_frame=False):
     """W untimed + K timed frames of one workload on this rank's tile shard.  Returns the measurements (and, on rank 0, the image)."""
     pkg = load_package()
     from pbrt_v3_amd import distributed as pdist
@@ -264,6 +264,19 @@ def run_workload(ctx, args, steps, warmup, keep_image=False):
     ctx.sync()
     elapsed = time.perf_counter() - t0
     cn = gs.counters()
+    # Per-kernel times (HIP events around every launch) only mean something while kernels do not share the chip.  The timed frames of a
+    # one-GPU run overlap each any-hit launch with the next closest-hit launch (PG_OVERLAP_SHADOW=1: +1.2 % Mrays/s,
+    # profiles/r04b_bench_overlap*.json); the figures the rooflines are made of come from ONE more frame, serialised, after the timed region.
+    serial = None
+    if serial_frame and steps > 0:
+        os.environ["PG_OVERLAP_SHADOW"] = "0"
+        gs.counters_reset()
+        ctx.device_sync()
+        ts = time.perf_counter()
+        step()
+        ctx.device_sync()
+        serial = types.SimpleNamespace(ms=(time.perf_counter() - ts) * 1e3, cn=gs.counters())
+        os.environ["PG_OVERLAP_SHADOW"] = "1"
     stats = torch.tensor([elapsed, float(cn["closest_rays"] + cn["shadow_rays"]), float(cn["camera_rays"])], dtype=torch.float64, device=ctx.comm_dev)
     per_rank = [local]
     if ctx.multi:
@@ -284,7 +297,7 @@ def run_workload(ctx, args, steps, warmup, keep_image=False):
         dist.all_gather(every_k, mine_k)
         per_rank_kernels = [[float(x) for x in t.tolist()] for t in every_k]
     elapsed, rays, samples = (float(x) for x in stats.tolist())
-    m = types.SimpleNamespace(elapsed=elapsed, rays=rays, samples=samples, cn=cn, scene=scene, gs=gs, t_parse=t_parse, workdir=workdir,
+    m = types.SimpleNamespace(elapsed=elapsed, rays=rays, samples=samples, cn=cn, scene=scene, gs=gs, t_parse=t_parse, workdir=workdir, serial=serial,
                               per_rank_ms=[t / max(1, steps) * 1e3 for t in per_rank], steps=steps, image=None,
                               per_rank_kernel_ms=[{k[:-3]: round(v, 3) for k, v in zip(kn, row)} for row in per_rank_kernels])
     if ctx.rank == 0 and keep_image and last is not None:  # final image (outside the timed region): MergeFilmTile per shard + WriteImage arithmetic
@@ -324,7 +337,7 @@ def live_pmc(bench_args, passes, timeout=300):
     for counters in passes:
         d = tempfile.mkdtemp(prefix="pbrt_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", *counters, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), *bench_args,
-               "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-hbm-regime", "--no-live-pmc"]
+               "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-hbm-regime", "--no-live-pmc", "--no-overlap"]
         try:
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
         except Exception as e:
@@ -345,6 +358,8 @@ def live_pmc(bench_args, passes, timeout=300):
         e = {"launches": len(nf), "fetch_KiB_per_launch": f / len(nf), "write_KiB_per_launch": w / max(1, len(nw))}
         h, mi = tot.get("TCC_HIT_sum", {}).get(k, (0.0, 0))[0], tot.get("TCC_MISS_sum", {}).get(k, (0.0, 0))[0]
         if h + mi > 0: e["l2_hit_rate"] = h / (h + mi)
+        dr = tot.get("TCC_EA0_RDREQ_DRAM_32B_sum", {}).get(k)
+        if dr is not None: e["dram_rd_32B_per_launch"] = dr[0] / max(1, len(dr[1]))
         vi, vt = tot.get("SQ_INSTS_VALU", {}).get(k, (0.0, {0})), tot.get("SQ_THREAD_CYCLES_VALU", {}).get(k, (0.0, 0))[0]
         if vi[0] > 0:
             e["valu_insts_per_launch"] = vi[0] / max(1, len(vi[1])); e["valu_lanes_active"] = vt / vi[0]
@@ -362,7 +377,7 @@ def merge_pmc(entries):
         return entries[0]
     n = max(max(1, e.get("launches", 1)) for e in entries)
     out = {"launches": n}
-    for f in ("fetch_KiB_per_launch", "write_KiB_per_launch", "hbm_bytes_per_launch", "valu_insts_per_launch"):
+    for f in ("fetch_KiB_per_launch", "write_KiB_per_launch", "hbm_bytes_per_launch", "valu_insts_per_launch", "dram_rd_32B_per_launch"):
         if any(f in e for e in entries):
             out[f] = sum(e.get(f, 0.0) * max(1, e.get("launches", 1)) for e in entries) / n
     insts = [(e["valu_insts_per_launch"] * max(1, e.get("launches", 1)), e["valu_lanes_active"]) for e in entries
@@ -449,9 +464,19 @@ def kernel_rooflines(m, workload, live=None):
                                    "fetch_size_factor_source": factor_src if gather_pattern else "MI355X_MICROARCH.md (streaming reads)",
                                    "note": "replayed from a committed PMC pass of this workload, not measured in this run" if replayed else
                                            "FETCH_SIZE / WRITE_SIZE (KiB) per launch from this run's own rocprofv3 --pmc passes (separate passes, one frame)"}
-            if ms > 0:  # what the memory side of the L2 moved, against the HBM peak
+            if ms > 0:
+                # What the L2s' memory side (their fabric ports, TCC_EA0_RDREQ / WRREQ) moved.  Infinity-Cache hits are counted here: this
+                # is NOT DRAM traffic (MI355X_MICROARCH.md "Infinity Cache").  The 8 TB/s beside it is the HBM peak, as a yardstick only.
                 hb = traffic * launches / (ms * 1e-3) / 1e9
-                r["hbm_side"] = {"achieved": hb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / HBM_PEAK_GBS, "source": pmc_src}
+                r["l2_memory_side"] = {"achieved": hb, "compared_with": HBM_PEAK_GBS, "unit": "GB/s", "frac_of_hbm_peak": hb / HBM_PEAK_GBS, "source": pmc_src,
+                                       "note": "requests of the L2s to the fabric; Infinity-Cache hits included, so an upper bound of the DRAM traffic"}
+                if pk.get("dram_rd_32B_per_launch") is not None:
+                    # TCC_EA0_RDREQ_DRAM_32B: the L2s' read requests whose target is DRAM-backed memory, in 32-B units ("1 64-byte request
+                    # will be counted to 2, 128-byte as 4").  Still counted at the L2 port: it separates DRAM-backed from other targets,
+                    # not Infinity-Cache hits from misses -- rocprofv3 exposes no memory-controller counter on this image.
+                    db = pk["dram_rd_32B_per_launch"] * 32.0
+                    r["l2_memory_side"]["dram_targeted_read_bytes_per_launch"] = db
+                    r["l2_memory_side"]["dram_targeted_read_GBs"] = db * launches / (ms * 1e-3) / 1e9
         return r
 
     n_close, n_shadow, n_mis, n_items = cn["closest_rays"], cn["shadow_rays"], cn["mis_rays"], cn["shade_items"]
@@ -522,6 +547,8 @@ def main():
     ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline renders every sample of the frame (minutes)")
     ap.add_argument("--no-hbm-regime", action="store_true", help="skip the 3 extra frames of the 5 M-triangle workload behind roofline.hbm_regime")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not run the rocprofv3 --pmc child passes; replay profiles/pmc_traffic.json (labelled) instead")
+    ap.add_argument("--no-overlap", action="store_true", help="one GPU: do not run any-hit launches beside the next closest-hit launch in the timed frames "
+                                                             "(every kernel alone on the chip, as in the serialised frame the rooflines are taken from; what rocprofv3 --stats should profile)")
     ap.add_argument("--out", default=None, help="write the rendered image (PFM) here")
     args = ap.parse_args()
     dx, dy, dspp = (400, 400, 8) if args.workload == "config0" else (1920, 1080, 64)
@@ -530,13 +557,15 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     ctx = Context(args)
-    if ctx.world > 1:
-        # A shard's launches are small and their tails weigh more: with the any-hit launch on a second stream beside the closest-hit
-        # launch one rank of 8 renders its tiles in 48.7 instead of 52.9 ms (profiles/r03j_shard_timing.json).  Per-kernel times then
-        # overlap, which is why the one-GPU line -- whose rooflines need each kernel timed alone -- leaves it off.
-        os.environ.setdefault("PG_OVERLAP_SHADOW", "1")
+    # The any-hit launch of a bounce runs on a second stream beside the next bounce's closest-hit launch: a shard's launches are small
+    # and their tails weigh more (one rank of 8: 48.7 instead of 52.9 ms, profiles/r03j_shard_timing.json), and the whole frame on one
+    # GPU gains 1.2 % (profiles/r04b_bench_overlap*.json).  Per-kernel times then overlap, so a one-GPU run takes them -- and its
+    # rooflines -- from one more frame, serialised, after the timed region (run_workload, serial_frame).
+    overlap = not args.no_overlap and os.environ.get("PG_OVERLAP_SHADOW", "1") != "0"
+    os.environ["PG_OVERLAP_SHADOW"] = "1" if overlap else "0"
     pkg = load_package()
-    m = run_workload(ctx, args, args.steps, args.warmup, keep_image=bool(args.out))
+    one_gpu = ctx.world == 1 and not ctx.multi
+    m = run_workload(ctx, args, args.steps, args.warmup, keep_image=bool(args.out), serial_frame=overlap and one_gpu)
     # North star: ">= 40 % of the HBM roofline in the BVH-traversal kernel" is a statement about the regime where the BVH does not
     # fit the 256 MiB Infinity Cache, which config 3 (106 MiB) is not in.  After the headline steps, rank 0 of a 1-GPU run times 3
     # frames of the same scene at 5 M triangles (535 MiB of records) at the headline's resolution and spp: roofline.hbm_regime.
@@ -546,7 +575,7 @@ def main():
         a5.grid = 1582
         m.gs.close()
         try:
-            hbm = run_workload(ctx, a5, 3, 1)
+            hbm = run_workload(ctx, a5, 3, 1, serial_frame=overlap)
             hbm.args = a5
         except Exception as e:
             sys.stderr.write(f"bench: hbm-regime workload failed: {e}\n")
@@ -565,10 +594,13 @@ def main():
             if live is None: sys.stderr.write(f"bench: live PMC passes failed ({live_why}); replaying profiles/pmc_traffic.json\n")
             if hbm is not None and live is not None:
                 a5l = ["--workload", "synthetic", "--grid", str(hbm.args.grid), "--xres", str(args.xres), "--yres", str(args.yres), "--spp", str(args.spp), "--filter", args.filter]
-                live_hbm, why5 = live_pmc(a5l, (["FETCH_SIZE"], ["WRITE_SIZE"]))
+                live_hbm, why5 = live_pmc(a5l, (["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_EA0_RDREQ_DRAM_32B_sum"]))
                 if live_hbm is None: sys.stderr.write(f"bench: live PMC passes of the hbm-regime workload failed ({why5})\n")
-        kernels, working_set, bound, peak, pmc_kernels, pmc_src = kernel_rooflines(m, workload, live)
-        gather = gather_ceiling(m, working_set, pmc_kernels, pmc_src)
+        # the frame the per-kernel figures come from: the serialised one where the timed frames overlapped kernels
+        km = m if m.serial is None else types.SimpleNamespace(cn=m.serial.cn, scene=m.scene)
+        ksteps = args.steps if m.serial is None else 1
+        kernels, working_set, bound, peak, pmc_kernels, pmc_src = kernel_rooflines(km, workload, live)
+        gather = gather_ceiling(km, working_set, pmc_kernels, pmc_src)
         roofline = dict(kernels[0]) if kernels else {"kernel": None, "bound": bound, "achieved": 0.0, "peak": peak, "unit": "GB/s", "frac": 0.0, "traffic": None}
         roofline["working_set_bytes"] = working_set
         if gather is not None:
@@ -577,7 +609,7 @@ def main():
                                     ("fit the 256 MiB Infinity Cache: gathers are served on-die, L2 bandwidth is the ceiling"
                                      if bound == "l2" else "exceed the 256 MiB Infinity Cache: gathers reach HBM"))
         if hbm is not None:
-            hk, hws, hbound, _, _, _ = kernel_rooflines(hbm, describe(hbm.args, hbm.scene), live_hbm)
+            hk, hws, hbound, _, _, _ = kernel_rooflines(hbm if hbm.serial is None else types.SimpleNamespace(cn=hbm.serial.cn, scene=hbm.scene), describe(hbm.args, hbm.scene), live_hbm)
             t = next((k for k in hk if k["kernel"].startswith("k_trace<0>")), None)
             if t is not None and hbound == "hbm":
                 roofline["hbm_regime"] = {
@@ -587,12 +619,12 @@ def main():
                     "steps": hbm.steps, "ms_per_step": hbm.elapsed / hbm.steps * 1e3, "Mrays_per_s": hbm.rays / hbm.elapsed / 1e6,
                     "note": "timed in THIS run (HIP events per launch); algorithmic bytes (SURVEY 8d) / kernel time / 8 TB/s. Algorithmic bytes count "
                             "every reference node fetch, also those the L2s serve, so this is the north star's roofline fraction, NOT memory-side "
-                            "traffic: `hbm_side` is what the L2s' memory side moved for this kernel (FETCH_SIZE x factor + WRITE_SIZE), against the same 8 TB/s"}
-                for f in ("traffic", "hbm_side", "traffic_source"):  # the memory-side companion (weak point of round 3: 0.97 alone reads as HBM utilisation)
+                            "traffic: `l2_memory_side` is what the L2s' fabric ports moved for this kernel (FETCH_SIZE x factor + WRITE_SIZE; Infinity-Cache hits included), beside the same 8 TB/s"}
+                for f in ("traffic", "l2_memory_side", "traffic_source"):  # the memory-side companion (weak point of round 3: 0.97 alone reads as HBM utilisation)
                     if t.get(f) is not None: roofline["hbm_regime"][f] = t[f]
-        other_ms = {k: m.cn[k] for k in ("resolve_ms", "generate_ms", "film_ms")}
+        other_ms = {k: km.cn[k] for k in ("resolve_ms", "generate_ms", "film_ms")}
         if ctx.world == 1:
-            sharding = "one GPU renders every 16x16 film tile; no gather"
+            sharding = "one GPU renders every 16x16 film tile; no gather" + ("; any-hit launches beside the next closest-hit launches" if overlap else "")
         else:
             sharding = (f"16x16 film tiles round-robin over {ctx.world} GPUs, one process per GPU; one packed gather per frame to rank 0 (" +
                         ("RCCL over xGMI" if ctx.backend == "nccl" else "PRE-FLIGHT: gloo on host copies") + "), overlapped with the next frame" +
@@ -608,9 +640,15 @@ def main():
                        "rays_per_sample": m.rays / max(1.0, m.samples), "host_parse_and_bvh_s": m.t_parse},
             "roofline": roofline,
             "roofline_kernels": kernels,
-            "kernel_ms_per_step": {**{k["kernel"].split(" ")[0]: k["total_ms"] / args.steps for k in kernels},
-                                   **{k[:-3]: v / args.steps for k, v in other_ms.items()}},
+            "kernel_ms_per_step": {**{k["kernel"].split(" ")[0]: k["total_ms"] / ksteps for k in kernels},
+                                   **{k[:-3]: v / ksteps for k, v in other_ms.items()}},
         }
+        if m.serial is not None:
+            result["kernel_times"] = {
+                "from": "ONE extra frame after the timed region with every kernel alone on the chip (PG_OVERLAP_SHADOW=0): kernel_ms_per_step, roofline and "
+                        "roofline_kernels are that frame's HIP-event times; the timed frames (ms_per_step, value) run each any-hit launch beside the next "
+                        "closest-hit launch, so they are shorter than the sum of the kernels",
+                "serialized_frame_ms": m.serial.ms, "sum_of_kernels_ms": sum(result["kernel_ms_per_step"].values()), "overlapped_frame_ms": result["ms_per_step"]}
         if EMULATED:
             result["data"] = "synthetic (EMULATED DEVICE: functional check, not a measurement)"
         if ctx.world == 1 and not args.no_cpu_baseline and not EMULATED:

@@ -996,6 +996,8 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
     if (rd->spp <= 0 || rd->max_depth < 0 || rd->tile_step <= 0) return setError(PG_ERR_INVALID, "pg_render: bad spp/maxdepth/tile_step");
     if (rd->integrator != 0 && rd->integrator != 1) return setError(PG_ERR_INVALID, "pg_render: integrator %d (0 = path, 1 = volpath)", rd->integrator);
     const bool vol = rd->integrator == 1;
+    // read per frame: a caller (bench.py) times frames with the overlap and takes per-kernel times from a serialised frame of the same scene
+    if (const char *e = getenv("PG_OVERLAP_SHADOW")) s->overlapShadow = atoi(e) != 0;
     if (rd->camera_medium < -1 || rd->camera_medium >= s->nMedia) return setError(PG_ERR_INVALID, "pg_render: camera_medium %d out of range", rd->camera_medium);
     if (rd->sampler < PG_SAMPLER_HALTON || rd->sampler > PG_SAMPLER_MAXMINDIST) return setError(PG_ERR_INVALID, "pg_render: sampler %d (PgSamplerKind 0 .. 5)", rd->sampler);
     // The PixelSamplers (stratified, 02sequence, maxmindist) fall back to their tile's RNG stream only for draws beyond their
