@@ -68,6 +68,7 @@ struct GraphicsState {
 };
 struct RenderOptions {
     Float transformStartTime = 0, transformEndTime = 1;
+    bool refused = false;  // the scene asks for something whose absence would change the image (animated shapes / instances / camera): no frame is rendered
     std::string FilterName = "box"; ParamSet FilterParams;
     std::string FilmName = "image"; ParamSet FilmParams;
     std::string SamplerName = "halton"; ParamSet SamplerParams;
@@ -824,7 +825,8 @@ void pbrtTexture(const std::string &name, const std::string &type, const std::st
     if (!isFloat && type != "color" && type != "spectrum") { Error("Texture type \"%s\" unknown.", type.c_str()); return; }
     auto &table = isFloat ? graphicsState.floatTextures : graphicsState.spectrumTextures;
     if (table.count(name)) Warning("Texture \"%s\" being redefined", name.c_str());
-    if (curTransform.IsAnimated()) Error("Animated transformations (motion blur) are not supported by this build; using the start transform for texture \"%s\".", name.c_str());
+    // api.cpp:1031 WARN_IF_ANIMATED_TRANSFORM("Texture"): the reference itself gives textures the start transform
+    if (curTransform.IsAnimated()) Warning("Animated transformations set; ignoring for \"Texture\" and using the start transform only");
     const GraphicsState &gs = graphicsState;
     ParamSet none;
     auto operand = [&](const char *n, Float d) { return isFloat ? floatRef(params, none, n, d, gs) : spectrumRef(params, none, n, RGB{{d, d, d}}, gs); };
@@ -979,7 +981,8 @@ static Point3f point3Param(const ParamSet &ps, const std::string &n, Point3f d) 
 // DistantLight (distant.cpp:96-104, :43-48), appended to scene.lights in declaration order (api.cpp:1308-1327).
 void pbrtLightSource(const std::string &name, const ParamSet &params) {
     VERIFY_WORLD("LightSource");
-    if (curTransform.IsAnimated()) Error("Animated transformations (motion blur) are not supported by this build; using the start transform for the light.");
+    // api.cpp:1296 WARN_IF_ANIMATED_TRANSFORM("LightSource"): the reference itself gives lights the start transform
+    if (curTransform.IsAnimated()) Warning("Animated transformations set; ignoring for \"LightSource\" and using the start transform only");
     const Transform &light2world = curTransform[0];
     PgLight l;
     memset(&l, 0, sizeof(l));
@@ -1219,8 +1222,12 @@ static std::shared_ptr<TriangleMesh> CreateTriangleMeshShape(const Transform &o2
 
 void pbrtShape(const std::string &name, const ParamSet &params) {  // api.cpp:1329-1421
     VERIFY_WORLD("Shape");
-    if (curTransform.IsAnimated())
-        Error("Animated transformations (motion blur) are not supported by this build; using the start transform for shape \"%s\".", name.c_str());
+    // The reference wraps an animated shape in a TransformedPrimitive with an AnimatedTransform (api.cpp:1386-1419, primitive.cpp:76-96):
+    // the device has no per-ray interpolated transform, and a frame without the motion would be an approximation -- the frame is refused
+    if (curTransform.IsAnimated()) {
+        Error("Shape \"%s\" under an animated transformation (motion blur) is outside this build's closed set; the scene will not be rendered.", name.c_str());
+        renderOptions->refused = true;
+    }
     std::shared_ptr<TriangleMesh> mesh;
     std::shared_ptr<Sphere> sphere;
     if (name == "trianglemesh") mesh = CreateTriangleMeshShape(curTransform[0], graphicsState.reverseOrientation, params);
@@ -1335,8 +1342,10 @@ void pbrtObjectInstance(const std::string &name) {  // api.cpp:1546-1588
         obj->accel = CreateBVHAccelerator(std::move(obj->prims), ro.AcceleratorName == "bvh" ? ro.AcceleratorParams : ParamSet());
         obj->prims.clear();
     }
-    if (curTransform.IsAnimated())
-        Error("Animated transformations (motion blur) are not supported by this build; using the start transform for instance \"%s\".", name.c_str());
+    if (curTransform.IsAnimated()) {  // TransformedPrimitive over an AnimatedTransform (api.cpp:1576-1586): refused, never rendered with one end of the motion
+        Error("Object instance \"%s\" under an animated transformation (motion blur) is outside this build's closed set; the scene will not be rendered.", name.c_str());
+        renderOptions->refused = true;
+    }
     GeometricPrimitive prim;
     prim.object = obj;
     {
@@ -1369,7 +1378,10 @@ static GpuPathIntegrator *MakeIntegrator() {
         delete film;
         return nullptr;
     }
-    if (ro.CameraToWorld.IsAnimated()) Error("Animated camera transformations (motion blur) are not supported by this build; using the start transform.");
+    if (ro.CameraToWorld.IsAnimated()) {  // AnimatedTransform CameraToWorld (api.cpp:1725-1730, cameras/perspective.cpp:89,139): refused
+        Error("An animated camera transformation (motion blur) is outside this build's closed set; the scene will not be rendered.");
+        ro.refused = true;
+    }
     std::shared_ptr<PerspectiveCamera> camera(CreatePerspectiveCamera(ro.CameraParams, ro.CameraToWorld[0], film, ro.CameraName == "orthographic"));
     if (ro.CameraName == "environment") { camera->environment = true; camera->lensRadius = 0; }  // environment.cpp:96-97: lens parameters unused
     ro.CameraParams.ReportUnused();
@@ -1396,6 +1408,17 @@ static GpuPathIntegrator *MakeIntegrator() {
     }
     GpuPathIntegrator *integrator = CreatePathIntegrator(ro.IntegratorParams, sampler, camera);  // volpath.cpp:191-214 reads the same parameters
     integrator->volumetric = ro.IntegratorName == "volpath";
+    // A PixelSampler (stratified, 02sequence, maxmindist) whose "dimensions" do not cover a whole path (2 + 3 maxdepth two-dimensional
+    // draws) falls back to its tile's ONE random stream from the first bounce on (sampler.cpp:108-134): a path's later numbers then depend on how many
+    // all earlier paths of the tile drew, and the device can hold one path per tile in flight -- correct, pinned against the reference, and
+    // orders of magnitude slower than the same sampler with enough dimensions.  "random" always draws from the stream.  volpath: no bound.
+    if (sampler->kind > PG_SAMPLER_RANDOM && !integrator->volumetric && sampler->nSampledDimensions < 2 + 3 * (long long)integrator->maxDepth)
+        Warning("Sampler \"%s\" with \"dimensions\" %d samples a path of \"maxdepth\" %d from its tile's random stream after the first bounce: tiles render one "
+                "path at a time on the device. Set \"integer dimensions\" [ %lld ] (2 + 3 maxdepth) or more to render the frame as one wavefront.",
+                sn.c_str(), sampler->nSampledDimensions, integrator->maxDepth, 2 + 3 * (long long)integrator->maxDepth);
+    else if (sampler->kind == PG_SAMPLER_RANDOM || (sampler->kind > PG_SAMPLER_RANDOM && integrator->volumetric))
+        Warning("Sampler \"%s\"%s draws from its tile's random stream: tiles render one path at a time on the device (halton / sobol render the frame as one wavefront).",
+                sn.c_str(), integrator->volumetric ? " under \"volpath\"" : "");
     {   // MakeCamera (api.cpp:785-790): the camera sits in the graphics state's current outside medium
         int in, out;
         CreateMediumInterface(&in, &out);
@@ -1459,6 +1482,10 @@ void pbrtWorldEnd() {  // api.cpp:1590-1644
     std::unique_ptr<GpuPathIntegrator> integrator(MakeIntegrator());
     std::unique_ptr<Scene> scene(MakeScene());
     if (timing) fprintf(stderr, "pbrt host: MakeScene (BVH build) %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild).count());
+    if (renderOptions->refused) {
+        Error("Scene not rendered: it uses features outside this build's closed set (see the errors above); no approximate image is written.");
+        scene.reset(); integrator.reset();
+    }
     if (scene && integrator) {
         if (PbrtOptions.loadOnly) {
             lastLoadedScene.reset(new LoadedScene);

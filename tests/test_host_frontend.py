@@ -259,3 +259,21 @@ def test_every_golden_scene_loads_without_an_error_message(pkg):
         reported = pkg.host_lib().pbrt_host_error_count() != before
         name = os.path.basename(f)[:-5]
         assert name in on_purpose or not reported, f"{name}: the host front end reported an Error() while loading"
+
+
+def test_animated_shapes_instances_and_cameras_are_refused_not_rendered_with_the_start_transform(pkg):
+    """The reference interpolates an AnimatedTransform per ray inside TransformedPrimitive::Intersect (primitive.cpp:76-96) and for the
+    camera (perspective.cpp:89,139); the device does not.  Such a scene is REFUSED (an Error, no frame, no image with one end of the
+    motion).  Textures and lights take the start transform in the reference itself (api.cpp WARN_IF_ANIMATED_TRANSFORM): a Warning."""
+    anim = 'ActiveTransform EndTime\nTranslate 0.3 0 0\nActiveTransform All\n'
+    mini = MINI % (16, 16, 1)
+    for what, txt in (("shape", mini.replace("WorldEnd", "AttributeBegin\n" + anim + 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nAttributeEnd\nWorldEnd')),
+                      ("instance", mini.replace("WorldEnd", 'ObjectBegin "o"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nObjectEnd\nAttributeBegin\n' + anim + 'ObjectInstance "o"\nAttributeEnd\nWorldEnd')),
+                      ("camera", mini.replace("Camera ", anim + "Camera ", 1))):
+        before = pkg.host_lib().pbrt_host_error_count()
+        with pytest.raises(pkg.PbrtGpuError):
+            pkg.HostScene(text=txt)
+        assert pkg.host_lib().pbrt_host_error_count() > before, what
+    before = pkg.host_lib().pbrt_host_error_count()
+    s = pkg.HostScene(text=mini.replace("WorldEnd", "AttributeBegin\n" + anim + 'LightSource "point"\nTexture "t" "float" "checkerboard"\nAttributeEnd\nWorldEnd'))
+    assert s.desc.n_lights >= 1 and pkg.host_lib().pbrt_host_error_count() == before  # the reference's own behaviour: warnings only
