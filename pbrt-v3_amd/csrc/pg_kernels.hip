@@ -2094,14 +2094,22 @@ PG_DEV void homogeneous_sample_distance(const PgMedium &mm, float uChannel, floa
     dist = -pg_logf((1 - uDist)) / mm.sigma_t[channel];
 }
 struct GridShade { float4 *vertex; int phase; };  // vertex[slot] = (medium interaction point, kind: 0 none, 1 medium vertex, 2 surface vertex)
-template <int MODE, bool VOL, bool SSS = false, bool GRID = false>
-__global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MODE == 1 || MODE == 3) && PG_SHADE_MIN_WAVES > 0) ? PG_SHADE_MIN_WAVES : (MODE == 2 ? (VOL ? PG_SHADE2V_WAVES : PG_SHADE2_WAVES) : 1))) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
+// PART (volpath only): 0 = every entry; 1 = only the entries whose ray scattered in its medium (volpath.cpp:80-96: a phase function, no
+// surface) -- a kernel without the interaction, the BSDF and the material evaluators, at a fraction of the registers; 2 = all the others.
+// The two launches together shade the queue exactly once: which part an entry belongs to follows from its medium sample alone, which both
+// compute (or read: RenderParams::volPre).  The surface part no longer carries the medium vertex's code and live values either.
+#ifndef PG_SHADE_MEDIUM_WAVES
+#define PG_SHADE_MEDIUM_WAVES 4
+#endif
+template <int MODE, bool VOL, bool SSS = false, bool GRID = false, int PART = 0>
+__global__ __launch_bounds__(PG_SHADE_BLOCK, PART == 1 ? PG_SHADE_MEDIUM_WAVES : (MODE == 0 ? PG_SHADE0_WAVES : (((MODE == 1 || MODE == 3) && PG_SHADE_MIN_WAVES > 0) ? PG_SHADE_MIN_WAVES : (MODE == 2 ? (VOL ? PG_SHADE2V_WAVES : PG_SHADE2_WAVES) : 1)))) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
                                                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, VolState vs,
                                                      const float *__restrict__ hitT, QueueState qsIn, QueueState qsOut, SssState sss, GridShade gsh) {
     // MODE 3: MODE 1 over the lists k_material left for the hits on materials with textured parameters (rp.matPre)
     constexpr bool EXT = MODE >= 1, TEX = MODE == 2, PRE = MODE == 3;
     static_assert(!PRE || (!SSS && !GRID), "materials evaluated ahead: the plain path / volpath kernels");
     static_assert(!GRID || (VOL && !SSS), "grid media: volpath, without BSSRDF materials");
+    static_assert(PART == 0 || (VOL && !SSS && !GRID), "medium / surface parts: the plain volpath kernels");
     const bool phaseA = GRID && gsh.phase == 1, phaseB = GRID && gsh.phase == 2;
     int vertexKind = 0;  // GRID: what phase 1 found at this entry (phase 2 reads it back)
     static_assert(!SSS || EXT, "materials with a BSSRDF are BxDF-list materials");
@@ -2115,6 +2123,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
         i = queue_item<PG_SHADE_BLOCK>(qin);
         if (rp.order && i >= 0) i = rp.order[i];  // k_shade_order: the entries of a window grouped by material class
     }
+    bool mine = true;       // PART: this entry belongs to this launch
     bool deferred = false;  // sparse light tables: this vertex met a voxel without a distribution; nothing is committed
     unsigned long long tsState0 = 0;  // tile-serial samplers: the tile's stream position and dimension counters on entry
     int tsCur1D0 = 0, tsCur2D0 = 0;
@@ -2123,7 +2132,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
     // block-wide append at the end: holding three rays plus the pending direct-light terms in registers until then had
     // pushed the kernel to 130 VGPRs with scratch spills (3 waves/SIMD).
     __shared__ float4 s_ray[3][2][PG_SHADE_BLOCK];
-    __shared__ float4 s_state[QSTATE ? 3 : 1][PG_SHADE_BLOCK];  // QSTATE: (L, beta, meta) until the entry's place in the next queue is known
+    __shared__ float4 s_state[QSTATE ? 3 : (MODE == 2 ? 1 : 2)][PG_SHADE_BLOCK];  // QSTATE: (L, beta, meta) until the entry's place in the next queue is known; by slot (volpath): L and the film position wait here
     // EXT: of the seven Halton numbers a vertex computes ahead (halton_batch) the last four -- uScattering and the next direction's pair,
     // drawn late -- wait in LDS: they were what the register allocator put into scratch when the BxDF-list body grew; with them (and L,
     // see below) the kernel stays at 159 - 161 registers without scratch (profiles/r04j_bxdf_list_ab.txt).  (Not MODE 0: 2 KB more LDS
@@ -2145,7 +2154,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
     bool misInside = false;  // sphere light whose sphere contains the shaded point: Sphere::Pdf falls back to Shape::Pdf
     int misMedium = 0;       // VOL: medium of the BSDF-sampled ray
     float volWeight = 0;     // VOL: MIS weight of the light sample (-1: delta light)
-    if (valid) {
+    if (valid) do {
         const float4 d4 = qin.d[i], h4 = hits[i];
         slot = __float_as_int(d4.w);
         pdi = QSTATE ? i : slot;
@@ -2189,7 +2198,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
         const bool found = prim >= 0;
         // VOL: the ray's medium (index + 1); volpath.cpp:76-78 samples it before anything else happens at the vertex
         int med = 0;
-        bool volDead = false, inMedium = false;
+        bool volDead = false, inMedium = false, mediumPart = false;
         V3 mediumP = mk(0, 0, 0);
         if constexpr (VOL) {
             med = vs.medium[slot];
@@ -2216,7 +2225,8 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
                 float dist;
                 if (!GRID && rp.volPre) {  // drawn by k_shade_order (same dimensions, same arithmetic)
                     const float2 pv = rp.volPre[i];
-                    channel = __float_as_int(pv.x); dist = pv.y;
+                    channel = __float_as_int(pv.x) & 0xff; dist = pv.y;
+                    mediumPart = (__float_as_int(pv.x) & 0x100) != 0;
                     dim += 2;
                 } else {
                     const float uc = draw1();
@@ -2237,6 +2247,9 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
                 beta = beta * (inMedium ? (Tr * sigS) / pdf : Tr / pdf);
             }
             volDead = is_black(beta);  // volpath.cpp:78
+            if constexpr (PART != 0) {  // the other launch's entry: nothing of it is touched here (see PART; k_shade_order decided)
+                if (mediumPart != (PART == 1)) { mine = false; break; }
+            }
         }
         Tri tri;
         if (found) tri = load_tri(sc, prim);
@@ -2261,7 +2274,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
             if (TEX) { sphU = sh.u; sphV = sh.v; sphDpdu = sh.dpdu; sphDpdv = sh.dpdv; }
         }
         // path.cpp:91-102 emitted light at the vertex (volpath.cpp:103-110: only when no medium interaction was sampled)
-        if (phaseB || (VOL && (volDead || inMedium))) {
+        if (PART == 1 || phaseB || (VOL && (volDead || inMedium))) {
         } else if ((bounces == 0 || specularBounce) && found && tri.light >= 0) {
             const PgLight &l = sc.lights[tri.light];
             V3 nrm = onSphere ? is.n : hit_normal(sc, prim, tri, h4.y, h4.z, h4.w);
@@ -2275,7 +2288,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
         // QSTATE: L is final for this launch here (k_resolve adds the vertex's direct lighting), and the camera sample's film position in
         // L.w / beta.w is only carried along: both wait in LDS from here on instead of in five registers across the whole BSDF part --
         // with them the BxDF-list kernels stay under the 168 registers of three waves per SIMD without scratch
-        if constexpr (QSTATE && !TEX) {
+        if constexpr (!TEX) {
             s_state[0][tid] = make_float4(L.r, L.g, L.b, L4.w);
             reinterpret_cast<float *>(&s_state[1][tid])[3] = B4.w;
         }
@@ -2286,7 +2299,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
             if (volDead) alive = false;
             else if (inMedium) alive = bounces < rd.max_depth;  // volpath.cpp:83
             if (phaseB) alive = vertexKind == 1 || vertexKind == 2;
-            if (alive && inMedium) {
+            if (PART != 2 && alive && inMedium) {
                 vertexKind = 1;
                 // ---- scattering at a point in the medium, volpath.cpp:80-96: MediumInteraction(p, -ray.d, ..., medium, phase)
                 handled = true;
@@ -2370,7 +2383,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
                 }
             }
         }
-        if (alive && !handled) {
+        if (PART != 1 && alive && !handled) {
             if (!onSphere) is = make_isect(sc, prim, tri, h4.y, h4.z, h4.w, shapeRayD);
             if (inst >= 0 && !sc.instances[inst].identity) isect_to_world(sc.instances[inst], is);
             const PgMaterial &m = mtl;
@@ -2644,17 +2657,17 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
             // (GRID: phase 1 leaves the incoming flags for phase 2's rebuild of the vertex -- a null-material surface, finished in
             // phase 1, sets its own --; phase 2 leaves L alone: k_resolve_vol has added this vertex's direct lighting to it)
             if (phaseA && vertexKind != 0) newFlags = meta.w & 0xf0000;
-            if (!phaseB) st.L[slot] = make_float4(L.r, L.g, L.b, L4.w);
+            if (!phaseB) { if constexpr (TEX) st.L[slot] = make_float4(L.r, L.g, L.b, L4.w); else st.L[slot] = s_state[0][tid]; }
             // (phase 2 has nothing to do for a vertex that phase 1 finished -- a surface without a material, the end of a path -- and must
             // leave its state alone: writing it back would clear the flags phase 1 set, e.g. "the last bounce was specular", which a
             // path keeps across a material-less surface, path.cpp:107-113)
             if (!(phaseB && vertexKind == 0)) {
-                st.beta[slot] = make_float4(beta.r, beta.g, beta.b, B4.w);
+                st.beta[slot] = make_float4(beta.r, beta.g, beta.b, TEX ? B4.w : reinterpret_cast<float *>(&s_state[1][tid])[3]);
                 st.meta[slot] = make_int4(meta.x, meta.y, __float_as_int(etaScale), (dim << 20) | bounces | newFlags);
             }
             if (phaseA) gsh.vertex[slot] = make_float4(mediumP.x, mediumP.y, mediumP.z, __int_as_float(alive ? vertexKind : 0));
         }
-    }
+    } while (0);
     if (deferred) {  // retried once the voxel's distribution exists: no ray, no state, no pending term leaves this launch
         pushNext = pushShadow = misCand = false;
         if (rp.rd.sampler >= PG_SAMPLER_RANDOM) { sc.ts[slot].state = tsState0; sc.ts[slot].cur1D = tsCur1D0; sc.ts[slot].cur2D = tsCur2D0; }  // nor a draw from the tile's stream
@@ -2711,7 +2724,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
             } else st.L[slot] = s_state[0][tid];
             st.pdInfo[pdi] = make_int4(posShadow, posMis, lightNum, pushNext ? posNext : ~slot);
         }
-    } else if (valid && !deferred && !phaseB) st.pdInfo[slot] = make_int4(posShadow, posMis, lightNum, VOL ? __float_as_int(volWeight) : 0);
+    } else if (valid && mine && !deferred && !phaseB) st.pdInfo[slot] = make_int4(posShadow, posMis, lightNum, VOL ? __float_as_int(volWeight) : 0);
     if constexpr (SSS) {
         // the probe rays of the paths that go on through a BSSRDF, region by region like every other queue; such a path's L went to
         // its slot above (where k_resolve adds this vertex's direct lighting), beta and meta follow it there
@@ -2840,9 +2853,14 @@ __global__ __launch_bounds__(1024) void k_shade_order(DScene sc, RayQueue q, con
                     int channel;
                     float dist;
                     homogeneous_sample_distance(sc.media[med - 1], uc, halton_sample(sc, rd, index, dim + 1), channel, dist);
-                    volPre[e] = make_float2(__int_as_float(channel), dist);
                     const float tMaxRay = prim >= 0 ? hitT[e] : q.o[e].w;
-                    if (dist / sqrtf(lensq(mk(d4.x, d4.y, d4.z))) < tMaxRay) c = PG_ORDER_CLASSES - 3;  // (only the grouping depends on this)
+                    const bool scattered = dist / sqrtf(lensq(mk(d4.x, d4.y, d4.z))) < tMaxRay;  // the same operations as k_shade's `inMedium`
+                    if (scattered) c = PG_ORDER_CLASSES - 3;
+                    // bit 8: a medium vertex that the path continues from (volpath.cpp:80-96) -- which of k_shade's two PART launches shades
+                    // this entry.  Decided HERE, from the state before either launch: the launch that runs first advances the paths' bounce
+                    // counts, and the other must not read its own membership off them.
+                    const bool mediumPart = scattered && ((uint32_t)meta.w & 0xffffu) < (uint32_t)rd.max_depth;
+                    volPre[e] = make_float2(__int_as_float(channel | (mediumPart ? 0x100 : 0)), dist);
                 }
             }
         }
@@ -2916,11 +2934,21 @@ void launch_shade_vol(const DScene &sc, const RenderParams &rp, PathState st, Vo
     } else if (sss && sc.nBssrdfs > 0) {
         if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, true, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, *sss, gsh);
         else hipLaunchKernelGGL((k_shade<1, true, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, *sss, gsh);
-    } else if (sc.hasTextured && rp.matPre.lobes) {
-        if (rp.retryCount == 0) launch_material(sc, rp, st, vs, qin, hits, hitT, none, true, s);
-        hipLaunchKernelGGL((k_shade<3, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss, gsh);
-    } else if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss, gsh);
-    else hipLaunchKernelGGL((k_shade<1, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss, gsh);
+    } else {
+        // Medium vertices and the rest in two launches (k_shade's PART) where the entries are grouped that way (rp.volPre: k_shade_order_vol has
+        // drawn every entry's medium sample and put the scattered ones into a class of their own, so a wave of either launch finds its own
+        // entries together); PG_VOL_PARTS=0: one launch for all, as before
+        static const bool parts = !(getenv("PG_VOL_PARTS") && atoi(getenv("PG_VOL_PARTS")) == 0);
+        const bool split = parts && rp.volPre != nullptr;
+#define PG_LAUNCH_VOL(MODE_, PART_) hipLaunchKernelGGL((k_shade<MODE_, true, false, false, PART_>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss, gsh)
+        if (sc.hasTextured && rp.matPre.lobes) {
+            if (rp.retryCount == 0) launch_material(sc, rp, st, vs, qin, hits, hitT, none, true, s);
+            if (split) { PG_LAUNCH_VOL(1, 1); PG_LAUNCH_VOL(3, 2); } else PG_LAUNCH_VOL(3, 0);
+        } else if (sc.hasTextured) PG_LAUNCH_VOL(2, 0);
+        else if (split) { PG_LAUNCH_VOL(1, 1); PG_LAUNCH_VOL(1, 2); }
+        else PG_LAUNCH_VOL(1, 0);
+#undef PG_LAUNCH_VOL
+    }
 }
 
 // EstimateDirect's two "Add ... contribution" steps (integrator.cpp:143-161, 196-212) and
