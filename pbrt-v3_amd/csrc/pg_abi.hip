@@ -78,7 +78,7 @@ struct PgScene {
     int volCapacity = 0;
     int nMedia = 0;
     DeviceBuffer vqo[2], vqd[2], vCounts, volMedium, trAcc[2], volP1[3], misLi, pdLi, hitT;
-    DeviceBuffer qsL[2], qsBeta[2], qsMeta[2];  // PathIntegrator: path state in queue order
+    DeviceBuffer qsL[2], qsBeta[2], qsMeta[2], qsMedium[2];  // path state in queue order (qsMedium: volpath)
     DeviceBuffer bssrdfs, materialBssrdf, bssrdfTables;  // subsurface scattering (ABI 24)
     DeviceBuffer grids, mediaGrid, gridDensity, gridVertex;  // GridDensityMedium (ABI 23); the two-phase shading's per-slot vertex record
     // the BSSRDF branch of Li: per-slot state between entry and exit vertex (SssState), the job queue, two probe queues
@@ -1114,13 +1114,19 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
     float4 *const hitsMis = (float4 *)s->hitsMain.p + (size_t)regionCapFor(capacity, s->d.sparseLights != 0) * PG_REGIONS;
     PathState ps;
     memset(&ps, 0, sizeof(ps));
-    if (!vol) {  // PathIntegrator: L / beta / meta in queue order beside each main queue
+    // PathIntegrator, and VolPathIntegrator on scenes without BSSRDF materials or grid media (whose probe-chain / two-phase kernels find a
+    // path's state by its slot): L / beta / meta (/ the ray's medium) in queue order beside each main queue.  (The kernels are compiled for one
+    // or the other: k_shade's QSTATE.)
+    const bool volQ = vol && s->d.nBssrdfs == 0 && s->d.nGrids == 0;
+    if (!vol || volQ) {
         const size_t n = (size_t)regionCapFor(capacity, s->d.sparseLights != 0) * PG_REGIONS;
         if (s->qsCapacity < capacity) {
             for (int i = 0; i < 2; ++i) { HIP_TRY(s->qsL[i].alloc(n * sizeof(float4))); HIP_TRY(s->qsBeta[i].alloc(n * sizeof(float4))); HIP_TRY(s->qsMeta[i].alloc(n * sizeof(int4))); }
             s->qsCapacity = capacity;
         }
-        for (int i = 0; i < 2; ++i) { ps.qs[i].L = (float4 *)s->qsL[i].p; ps.qs[i].beta = (float4 *)s->qsBeta[i].p; ps.qs[i].meta = (int4 *)s->qsMeta[i].p; }
+        if (volQ && s->qsMedium[0].bytes < n * sizeof(int)) for (int i = 0; i < 2; ++i) HIP_TRY(s->qsMedium[i].alloc(n * sizeof(int)));
+        for (int i = 0; i < 2; ++i) { ps.qs[i].L = (float4 *)s->qsL[i].p; ps.qs[i].beta = (float4 *)s->qsBeta[i].p; ps.qs[i].meta = (int4 *)s->qsMeta[i].p;
+                                      ps.qs[i].medium = volQ ? (int *)s->qsMedium[i].p : nullptr; }
     }
     // Subsurface scattering (PathIntegrator): per-slot state of the BSSRDF branch, the job queue and the two probe queues
     const bool sssOn = s->d.nBssrdfs > 0;
@@ -1250,9 +1256,9 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                     float2 *volPre = (s->volOrder && !tileSerial && !s->d.sparseLights) ? (float2 *)s->volPre.p : nullptr;
                     rp.volPre = volPre;
                     rp.order = (s->d.primClass || volPre) ? (const int *)s->shadeOrder.p : nullptr;  // (the second phase of a grid scene takes the same order)
-                    PG_TIMED(2, stream, (launch_shade_order_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, (int *)s->shadeOrder.p, volPre, stream), launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream, sssArg, gridVertex, gridOn ? 1 : 0)));
+                    PG_TIMED(2, stream, (launch_shade_order_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, (int *)s->shadeOrder.p, volPre, stream, cur), launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream, sssArg, gridVertex, gridOn ? 1 : 0, cur)));
                     ++shadeLaunches;
-                    if (int e = settleLightTables([&]() { launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream, sssArg, gridVertex, gridOn ? 1 : 0); })) return e;
+                    if (int e = settleLightTables([&]() { launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream, sssArg, gridVertex, gridOn ? 1 : 0, cur); })) return e;
                     // through rays: kind 0 = light samples (q[2] <-> vq[0]), kind 1 = BSDF / phase samples (q[3] <-> vq[1]), re-traced
                     // until none is left under way
                     auto throughRays = [&]() -> int {
@@ -1300,7 +1306,7 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                         return PG_OK;
                     };
                     if (int e = throughRays()) return e;
-                    PG_TIMED(3, stream, launch_resolve_vol(dv, ps, vs, q[cur], stream));
+                    PG_TIMED(3, stream, launch_resolve_vol(dv, ps, vs, q[cur], stream, cur));
                     ++resolveLaunches;
                     if (gridOn) {  // phase 2: the vertices' next directions, drawn behind the transmittance rays' numbers
                         PG_TIMED(2, stream, launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream, nullptr, gridVertex, 2));

@@ -165,6 +165,7 @@ struct QueueState {
     float4 *L;     // (L.rgb, pFilm.x)
     float4 *beta;  // (beta.rgb, pFilm.y)
     int4 *meta;    // as PathState::meta
+    int *medium;   // volpath: the ray's medium (index + 1, 0 = none), as VolState::medium; nullptr under PathIntegrator
 };
 
 // Per-path state, indexed by slot.
@@ -180,7 +181,9 @@ struct PathState {
     // PathIntegrator (not volpath): L / beta / meta travel with the ray in queue order (qs[0] / qs[1] accompany the two main
     // queues); L[slot] then only receives a path's FINAL radiance, the pd* terms are indexed by the ray's queue position, and
     // pdInfo.w says where the path's L lives when k_resolve adds the direct lighting: >= 0 entry of the next queue's state,
-    // < 0: ~slot (the path ended).  qs[0].L == nullptr: everything by slot (volpath).
+    // < 0: ~slot (the path ended).  VolPathIntegrator without BSSRDF materials or grid media: the same, with the ray's medium as a
+    // fourth array, the pending terms of VolState by the ray's queue position too, and the transmittance rays carrying that position
+    // instead of the slot.  qs[0].L == nullptr: everything by slot (volpath scenes with BSSRDF materials or a GridDensityMedium).
     QueueState qs[2];
 };
 
@@ -190,7 +193,7 @@ struct PathState {
 struct VolState {
     int *medium;        // medium (index + 1, 0 = none) of the path's current ray
     float4 *trAcc[2];   // per kind: (Tr so far rgb, the through ray's medium as int bits)
-    float4 *p1[3];      // kind 0: the light sample the ray is heading to (p, pError, n)
+    float4 *p1[3];      // kind 0: the light sample the ray is heading to (p, pError, n); queue-order state: p1[0].w = the light sample's MIS weight (-1: delta light)
     float4 *misLi;      // kind 1, once finished: radiance of the sampled light along the ray (rgb)
     float4 *pdLi;       // (Li rgb of the light sample, lightPdf)
 };
@@ -290,7 +293,7 @@ void launch_shade_order(const DScene &sc, RayQueue qin, const float4 *hits, int 
 // volpath: additionally draws the medium sample of every entry (RenderParams::volPre) and puts the entries that scatter in the medium
 // into a class of their own (class 13), so that a wave shades medium vertices or surface vertices, not both one after the other
 void launch_shade_order_vol(const DScene &sc, const RenderParams &rp, PathState st, VolState vs, RayQueue qin, const float4 *hits, const float *hitT,
-                            int *order, float2 *volPre, hipStream_t s);
+                            int *order, float2 *volPre, hipStream_t s, int cur = 0);
 void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQueue qin, const float4 *hits, RayQueue qnext,
                   RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s, int cur = 0, const SssState *sss = nullptr);
 // Subsurface scattering: one step of the probe chains (pass 1: count the hits on the material; pass 2: stop at the chosen one) over
@@ -306,10 +309,10 @@ void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis,
 // gridVertex / phase: scenes with a grid medium shade a vertex in two launches (phase 1, transmittance rays, resolve, phase 2); 0 = one pass
 void launch_shade_vol(const DScene &sc, const RenderParams &rp, PathState st, VolState vs, RayQueue qin, const float4 *hits, const float *hitT,
                       RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s, const SssState *sss = nullptr,
-                      float4 *gridVertex = nullptr, int phase = 0);
+                      float4 *gridVertex = nullptr, int phase = 0, int cur = 0);
 void launch_through(const DScene &sc, PathState st, VolState vs, int kind, RayQueue qin, const float4 *hits, const float *hitT, int hitBase,
                     RayQueue qout, hipStream_t s, const RenderParams *rpGrid = nullptr);
-void launch_resolve_vol(const DScene &sc, PathState st, VolState vs, RayQueue qin, hipStream_t s);
+void launch_resolve_vol(const DScene &sc, PathState st, VolState vs, RayQueue qin, hipStream_t s, int cur = 0);
 void launch_fill_int(int *p, int value, int n, hipStream_t s);
 void launch_film(const RenderParams &rp, PathState st, PgFilmPixel *film, PgStraySample *strays, int maxStrays, int *nStrays,
                  hipStream_t s);

@@ -659,6 +659,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_generate(DScene sc, RenderParams r
         q.o[pos] = make_float4(o.x, o.y, o.z, tMax);
         q.d[pos] = make_float4(d.x, d.y, d.z, __int_as_float(slot));
         if (st.qs[0].L) { st.qs[0].L[pos] = st.L[slot]; st.qs[0].beta[pos] = st.beta[slot]; st.qs[0].meta[pos] = st.meta[slot]; }  // just written by this thread
+        if (st.qs[0].medium) st.qs[0].medium[pos] = rp.rd.camera_medium + 1;  // volpath: camera rays start in the camera's medium (camera.h:78)
     }
 }
 void launch_generate(const DScene &sc, const RenderParams &rp, PathState st, RayQueue q, hipStream_t s) {
@@ -694,6 +695,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_ts_generate(DScene sc, RenderParam
         q.o[pos] = make_float4(o.x, o.y, o.z, tMax);
         q.d[pos] = make_float4(d.x, d.y, d.z, __int_as_float(local));
         if (st.qs[0].L) { st.qs[0].L[pos] = st.L[local]; st.qs[0].beta[pos] = st.beta[local]; st.qs[0].meta[pos] = st.meta[local]; }
+        if (st.qs[0].medium) st.qs[0].medium[pos] = rp.rd.camera_medium + 1;
     }
 }
 void launch_ts_generate(const DScene &sc, const RenderParams &rp, PathState st, RayQueue q, int sampleIndex, hipStream_t s) {
@@ -2114,7 +2116,9 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PART == 1 ? PG_SHADE_MEDIUM_WAVES :
     int vertexKind = 0;  // GRID: what phase 1 found at this entry (phase 2 reads it back)
     static_assert(!SSS || EXT, "materials with a BSSRDF are BxDF-list materials");
     bool pushJob = false;  // SSS: this lane's path goes on through the BSSRDF (its probe ray waits in s_ray[0])
-    constexpr bool QSTATE = !VOL;  // path state and pending terms in queue order (see PathState)
+    // path state and pending terms in queue order (see PathState); volpath: unless the scene has BSSRDF materials or a grid medium, whose
+    // kernels (the probe chains, the two shading phases) find a path's state by its slot
+    constexpr bool QSTATE = !VOL || (!SSS && !GRID);
     int i;
     if (rp.retryCount > 0) {  // second pass over the entries that waited for a light-distribution voxel
         const int j = blockIdx.x * PG_SHADE_BLOCK + threadIdx.x;
@@ -2153,8 +2157,12 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PART == 1 ? PG_SHADE_MEDIUM_WAVES :
     int misLightPrim = 0;
     bool misInside = false;  // sphere light whose sphere contains the shaded point: Sphere::Pdf falls back to Shape::Pdf
     int misMedium = 0;       // VOL: medium of the BSDF-sampled ray
+    int newMed = 0;          // VOL, queue-order state: the medium of the path's next ray
     float volWeight = 0;     // VOL: MIS weight of the light sample (-1: delta light)
     if (valid) do {
+        if constexpr (PART != 0) {  // the other launch's entry: nothing of it is read or touched here (see PART; k_shade_order decided)
+            if (((__float_as_int(rp.volPre[i].x) & 0x100) != 0) != (PART == 1)) { mine = false; break; }
+        }
         const float4 d4 = qin.d[i], h4 = hits[i];
         slot = __float_as_int(d4.w);
         pdi = QSTATE ? i : slot;
@@ -2198,10 +2206,11 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PART == 1 ? PG_SHADE_MEDIUM_WAVES :
         const bool found = prim >= 0;
         // VOL: the ray's medium (index + 1); volpath.cpp:76-78 samples it before anything else happens at the vertex
         int med = 0;
-        bool volDead = false, inMedium = false, mediumPart = false;
+        bool volDead = false, inMedium = false;
         V3 mediumP = mk(0, 0, 0);
         if constexpr (VOL) {
-            med = vs.medium[slot];
+            if constexpr (QSTATE) med = qsIn.medium[i]; else med = vs.medium[slot];
+            newMed = med;
             if (phaseB) {  // the medium was sampled in phase 1: beta carries its weight, the vertex record says what came of it
                 const float4 v4 = gsh.vertex[slot];
                 vertexKind = __float_as_int(v4.w);
@@ -2226,7 +2235,6 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PART == 1 ? PG_SHADE_MEDIUM_WAVES :
                 if (!GRID && rp.volPre) {  // drawn by k_shade_order (same dimensions, same arithmetic)
                     const float2 pv = rp.volPre[i];
                     channel = __float_as_int(pv.x) & 0xff; dist = pv.y;
-                    mediumPart = (__float_as_int(pv.x) & 0x100) != 0;
                     dim += 2;
                 } else {
                     const float uc = draw1();
@@ -2247,9 +2255,6 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PART == 1 ? PG_SHADE_MEDIUM_WAVES :
                 beta = beta * (inMedium ? (Tr * sigS) / pdf : Tr / pdf);
             }
             volDead = is_black(beta);  // volpath.cpp:78
-            if constexpr (PART != 0) {  // the other launch's entry: nothing of it is touched here (see PART; k_shade_order decided)
-                if (mediumPart != (PART == 1)) { mine = false; break; }
-            }
         }
         Tri tri;
         if (found) tri = load_tri(sc, prim);
@@ -2332,15 +2337,15 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PART == 1 ? PG_SHADE_MEDIUM_WAVES :
                                 V3 target = offset_ray_origin(ls.p, ls.pError, ls.n, origin - ls.p);
                                 const V3 shD = target - origin;
                                 s_ray[1][0][tid] = make_float4(origin.x, origin.y, origin.z, 1 - PG_SHADOW_EPS);
-                                s_ray[1][1][tid] = make_float4(shD.x, shD.y, shD.z, __int_as_float(slot));
+                                s_ray[1][1][tid] = make_float4(shD.x, shD.y, shD.z, __int_as_float(pdi));  // (transmittance rays find their terms by pdi)
                                 pushShadow = true;
                                 const bool isDelta = PG_LIGHT_IS_DELTA(light.type);
                                 volWeight = isDelta ? -1.f : power_heuristic(1, lightPdf, 1, ph);
                                 pdLight = make_float4(ph, ph, ph, 0);
-                                vs.pdLi[slot] = make_float4(Li.r, Li.g, Li.b, lightPdf);
-                                vs.p1[0][slot] = make_float4(ls.p.x, ls.p.y, ls.p.z, 0); vs.p1[1][slot] = make_float4(ls.pError.x, ls.pError.y, ls.pError.z, 0);
-                                vs.p1[2][slot] = make_float4(ls.n.x, ls.n.y, ls.n.z, 0);
-                                vs.trAcc[0][slot] = make_float4(1, 1, 1, __int_as_float(med));  // MediumInteraction::GetMedium(): the medium itself
+                                vs.pdLi[pdi] = make_float4(Li.r, Li.g, Li.b, lightPdf);
+                                vs.p1[0][pdi] = make_float4(ls.p.x, ls.p.y, ls.p.z, volWeight); vs.p1[1][pdi] = make_float4(ls.pError.x, ls.pError.y, ls.pError.z, 0);
+                                vs.p1[2][pdi] = make_float4(ls.n.x, ls.n.y, ls.n.z, 0);
+                                vs.trAcc[0][pdi] = make_float4(1, 1, 1, __int_as_float(med));  // MediumInteraction::GetMedium(): the medium itself
                             }
                         }
                         if (light.type == PG_LIGHT_AREA || light.type == PG_LIGHT_INFINITE) {  // integrator.cpp:164-212 with the phase function
@@ -2359,8 +2364,8 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PART == 1 ? PG_SHADE_MEDIUM_WAVES :
                             }
                         }
                         pdLight.w = lightSelPdf;
-                        st.pdLight[slot] = pdLight;
-                        st.pdBeta[slot] = make_float4(beta.r, beta.g, beta.b, 0.f);
+                        st.pdLight[pdi] = pdLight;
+                        st.pdBeta[pdi] = make_float4(beta.r, beta.g, beta.b, 0.f);
                     }
                 }
                 if (!phaseA) {
@@ -2397,7 +2402,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PART == 1 ? PG_SHADE_MEDIUM_WAVES :
                 s_ray[0][1][tid] = make_float4(rayD.x, rayD.y, rayD.z, __int_as_float(slot));
                 pushNext = true;
                 newFlags = meta.w & PG_META_SPECULAR;  // `continue` leaves specularBounce as it was
-                if constexpr (VOL) vs.medium[slot] = dot(rayD, is.n) > 0 ? mOut : mIn;  // Interaction::GetMedium(w), interaction.h:86-88
+                if constexpr (VOL) { newMed = dot(rayD, is.n) > 0 ? mOut : mIn; if constexpr (!QSTATE) vs.medium[slot] = newMed; }  // Interaction::GetMedium(w), interaction.h:86-88
               }
             } else {
                 vertexKind = 2;
@@ -2532,17 +2537,17 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PART == 1 ? PG_SHADE_MEDIUM_WAVES :
                                 V3 target = offset_ray_origin(ls.p, ls.pError, ls.n, origin - ls.p);
                                 const V3 shD = target - origin;
                                 s_ray[1][0][tid] = make_float4(origin.x, origin.y, origin.z, 1 - PG_SHADOW_EPS);
-                                s_ray[1][1][tid] = make_float4(shD.x, shD.y, shD.z, __int_as_float(slot));
+                                s_ray[1][1][tid] = make_float4(shD.x, shD.y, shD.z, __int_as_float(VOL ? pdi : slot));
                                 pushShadow = true;
                                 // delta lights take no MIS weight (integrator.cpp:155-160)
                                 const bool isDelta = PG_LIGHT_IS_DELTA(lh.type);
                                 if constexpr (VOL) {  // Li still is to be multiplied by VisibilityTester::Tr (integrator.cpp:146-150): keep the factors apart
                                     volWeight = isDelta ? -1.f : power_heuristic(1, lightPdf, 1, scatteringPdf);
                                     pdLight = make_float4(f.r, f.g, f.b, 0);
-                                    vs.pdLi[slot] = make_float4(Li.r, Li.g, Li.b, lightPdf);
-                                    vs.p1[0][slot] = make_float4(ls.p.x, ls.p.y, ls.p.z, 0); vs.p1[1][slot] = make_float4(ls.pError.x, ls.pError.y, ls.pError.z, 0);
-                                    vs.p1[2][slot] = make_float4(ls.n.x, ls.n.y, ls.n.z, 0);
-                                    vs.trAcc[0][slot] = make_float4(1, 1, 1, __int_as_float(dot(shD, is.n) > 0 ? mOut : mIn));
+                                    vs.pdLi[pdi] = make_float4(Li.r, Li.g, Li.b, lightPdf);
+                                    vs.p1[0][pdi] = make_float4(ls.p.x, ls.p.y, ls.p.z, volWeight); vs.p1[1][pdi] = make_float4(ls.pError.x, ls.pError.y, ls.pError.z, 0);
+                                    vs.p1[2][pdi] = make_float4(ls.n.x, ls.n.y, ls.n.z, 0);
+                                    vs.trAcc[0][pdi] = make_float4(1, 1, 1, __int_as_float(dot(shD, is.n) > 0 ? mOut : mIn));
                                 } else {
                                     Spec c = isDelta ? (f * Li) / lightPdf : ((f * Li) * power_heuristic(1, lightPdf, 1, scatteringPdf)) / lightPdf;
                                     pdLight = make_float4(c.r, c.g, c.b, 0);
@@ -2598,7 +2603,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PART == 1 ? PG_SHADE_MEDIUM_WAVES :
                     s_ray[0][1][tid] = make_float4(wi.x, wi.y, wi.z, __int_as_float(slot));
                     nextBin = (wi.x < 0 ? 1 : 0) | (wi.y < 0 ? 2 : 0) | (wi.z < 0 ? 4 : 0);
                     pushNext = true;
-                    if constexpr (VOL) { if (!deferred) vs.medium[slot] = dot(wi, is.n) > 0 ? mOut : mIn; }
+                    if constexpr (VOL) { newMed = dot(wi, is.n) > 0 ? mOut : mIn; if constexpr (!QSTATE) { if (!deferred) vs.medium[slot] = newMed; } }
                     bool throughBssrdf = false;
                     if constexpr (SSS) {
                         if (sssIdx >= 0 && (sampledType & PG_BSDF_TRANSMISSION)) {
@@ -2700,11 +2705,11 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PART == 1 ? PG_SHADE_MEDIUM_WAVES :
         }
         if (lightPdf2 != 0) {
             s_ray[2][0][tid] = make_float4(misRo.x, misRo.y, misRo.z, PG_INF);
-            s_ray[2][1][tid] = make_float4(misWi.x, misWi.y, misWi.z, __int_as_float(slot));
+            s_ray[2][1][tid] = make_float4(misWi.x, misWi.y, misWi.z, __int_as_float(VOL ? pdi : slot));
             pushMis = true;
             st.pdMis[pdi] = make_float4(misF.r, misF.g, misF.b, misPdf);
             st.pdBeta[pdi].w = power_heuristic(1, misPdf, 1, lightPdf2);
-            if constexpr (VOL) vs.trAcc[1][slot] = make_float4(1, 1, 1, __int_as_float(misMedium));
+            if constexpr (VOL) vs.trAcc[1][pdi] = make_float4(1, 1, 1, __int_as_float(misMedium));
         }
     }
     const RayQueue outQ[3] = {qnext, qshadow, qmis};
@@ -2716,11 +2721,12 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PART == 1 ? PG_SHADE_MEDIUM_WAVES :
     if (pushShadow) { qshadow.o[posShadow] = s_ray[1][0][tid]; qshadow.d[posShadow] = s_ray[1][1][tid]; }
     if (pushMis) { qmis.o[posMis] = s_ray[2][0][tid]; qmis.d[posMis] = s_ray[2][1][tid]; }
     if constexpr (QSTATE) {
-        if (valid && !deferred) {
+        if (valid && mine && !deferred) {
             if (pushNext) {
                 const float4 m4 = s_state[2][tid];
                 qsOut.L[posNext] = s_state[0][tid]; qsOut.beta[posNext] = s_state[1][tid];
                 qsOut.meta[posNext] = make_int4(__float_as_int(m4.x), __float_as_int(m4.y), __float_as_int(m4.z), __float_as_int(m4.w));
+                if constexpr (VOL) qsOut.medium[posNext] = newMed;
             } else st.L[slot] = s_state[0][tid];
             st.pdInfo[pdi] = make_int4(posShadow, posMis, lightNum, pushNext ? posNext : ~slot);
         }
@@ -2770,11 +2776,12 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PG_MATERIAL_WAVES) void k_material(
     const int slot = __float_as_int(d4.w);
     const V3 rayD = mk(d4.x, d4.y, d4.z);
     const PgRenderDesc &rd = rp.rd;
-    const int4 meta = VOL ? st.meta[slot] : qsIn.meta[i];
+    const bool bySlot = VOL && qsIn.L == nullptr;  // volpath scenes with BSSRDF materials or grid media keep their path state by slot
+    const int4 meta = bySlot ? st.meta[slot] : qsIn.meta[i];
     if ((meta.w & 0xffff) >= rd.max_depth) return;  // path.cpp:104
     if constexpr (VOL) {
         if (rp.volPre) {  // the medium sample k_shade_order drew: a ray that scatters before the surface never reaches it (volpath.cpp:76-96)
-            const int med = vs.medium[slot];
+            const int med = bySlot ? vs.medium[slot] : qsIn.medium[i];
             if (med && !(sc.mediaGrid && sc.mediaGrid[med - 1] >= 0) && rp.volPre[i].y / sqrtf(lensq(rayD)) < hitT[i]) return;
         }
     }
@@ -2798,7 +2805,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PG_MATERIAL_WAVES) void k_material(
     } else is = make_isect(sc, prim, tri, h4.y, h4.z, h4.w, shapeRayD);
     if (inst >= 0 && !sc.instances[inst].identity) isect_to_world(sc.instances[inst], is);
     float filmX = 0, filmY = 0;  // the camera sample's pFilm, for the camera ray's differentials
-    if (meta.w & PG_META_HASDIFF) { filmX = VOL ? st.L[slot].w : qsIn.L[i].w; filmY = VOL ? st.beta[slot].w : qsIn.beta[i].w; }
+    if (meta.w & PG_META_HASDIFF) { filmX = bySlot ? st.L[slot].w : qsIn.L[i].w; filmY = bySlot ? st.beta[slot].w : qsIn.beta[i].w; }
     TexHit th;
     tex_hit_setup(sc, rd, qin, i, slot, prim, tri, h4, rayD, inst, onSphere, sphU, sphV, sphDpdu, sphDpdv, is, meta, filmX, filmY, tileSerial, pixelArrays, index, th);
     material_bump<1>(sc, tri.material, th, is);
@@ -2824,7 +2831,7 @@ static void launch_material(const DScene &sc, const RenderParams &rp, PathState 
 // volPre instead of drawing them) and gives the entries that scatter inside the medium a class of their own.
 template <bool VOL>
 __global__ __launch_bounds__(1024) void k_shade_order(DScene sc, RayQueue q, const float4 *__restrict__ hits, int *__restrict__ order,
-                                                      PgRenderDesc rd, PathState st, VolState vs, const float *__restrict__ hitT, float2 *__restrict__ volPre) {
+                                                      PgRenderDesc rd, PathState st, VolState vs, const float *__restrict__ hitT, float2 *__restrict__ volPre, QueueState qs) {
     constexpr int NCHUNK = PG_ORDER_WINDOW / 64, ROUNDS = PG_ORDER_WINDOW / 1024, NW = 1024 / 64;
     static_assert(PG_ORDER_WINDOW % 1024 == 0 && PG_ORDER_CLASSES == 16, "k_shade_order: window of whole blocks, 16 classes");
     const int r = blockIdx.x & (PG_REGIONS - 1), base = (blockIdx.x >> 3) * PG_ORDER_WINDOW;
@@ -2844,9 +2851,10 @@ __global__ __launch_bounds__(1024) void k_shade_order(DScene sc, RayQueue q, con
             c = prim < 0 ? PG_ORDER_CLASSES - 2 : (sc.primClass ? sc.primClass[prim] : 0);
             if constexpr (VOL) {
                 const float4 d4 = q.d[e];
-                const int slot = __float_as_int(d4.w), med = vs.medium[slot];
+                const int slot = __float_as_int(d4.w), med = qs.L ? qs.medium[e] : vs.medium[slot];  // (path state in queue order, or by slot)
+                volPre[e] = make_float2(0.f, 0.f);  // (every entry has its part bit; the rest is only read for a ray inside a homogeneous medium)
                 if (med && !(sc.mediaGrid && sc.mediaGrid[med - 1] >= 0)) {
-                    const int4 meta = st.meta[slot];
+                    const int4 meta = qs.L ? qs.meta[e] : st.meta[slot];
                     const uint64_t index = (uint64_t)(uint32_t)meta.x | ((uint64_t)(uint32_t)meta.y << 32);
                     const int dim = (int)((uint32_t)meta.w >> 20);
                     const float uc = halton_sample(sc, rd, index, dim);
@@ -2892,13 +2900,13 @@ __global__ __launch_bounds__(1024) void k_shade_order(DScene sc, RayQueue q, con
 void launch_shade_order(const DScene &sc, RayQueue qin, const float4 *hits, int *order, hipStream_t s) {
     const int nblk = PG_REGIONS * ((qin.regionCap + PG_ORDER_WINDOW - 1) / PG_ORDER_WINDOW);
     if (nblk == 0 || !sc.primClass || !order) return;
-    hipLaunchKernelGGL(k_shade_order<false>, dim3(nblk), dim3(1024), 0, s, sc, qin, hits, order, PgRenderDesc{}, PathState{}, VolState{}, (const float *)nullptr, (float2 *)nullptr);
+    hipLaunchKernelGGL(k_shade_order<false>, dim3(nblk), dim3(1024), 0, s, sc, qin, hits, order, PgRenderDesc{}, PathState{}, VolState{}, (const float *)nullptr, (float2 *)nullptr, QueueState{});
 }
 void launch_shade_order_vol(const DScene &sc, const RenderParams &rp, PathState st, VolState vs, RayQueue qin, const float4 *hits, const float *hitT,
-                            int *order, float2 *volPre, hipStream_t s) {
+                            int *order, float2 *volPre, hipStream_t s, int cur) {
     const int nblk = PG_REGIONS * ((qin.regionCap + PG_ORDER_WINDOW - 1) / PG_ORDER_WINDOW);
     if (nblk == 0 || !order) return;
-    if (volPre) hipLaunchKernelGGL(k_shade_order<true>, dim3(nblk), dim3(1024), 0, s, sc, qin, hits, order, rp.rd, st, vs, hitT, volPre);
+    if (volPre) hipLaunchKernelGGL(k_shade_order<true>, dim3(nblk), dim3(1024), 0, s, sc, qin, hits, order, rp.rd, st, vs, hitT, volPre, st.qs[cur]);
     else launch_shade_order(sc, qin, hits, order, s);
 }
 void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQueue qin, const float4 *hits, RayQueue qnext,
@@ -2922,10 +2930,11 @@ void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQue
 }
 void launch_shade_vol(const DScene &sc, const RenderParams &rp, PathState st, VolState vs, RayQueue qin, const float4 *hits, const float *hitT,
                       RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s, const SssState *sss,
-                      float4 *gridVertex, int phase) {
+                      float4 *gridVertex, int phase, int cur) {
     int nblk = rp.retryCount > 0 ? (rp.retryCount + PG_SHADE_BLOCK - 1) / PG_SHADE_BLOCK : PG_REGIONS * (qin.regionCap / PG_SHADE_BLOCK);
     if (nblk == 0) return;
-    const QueueState none = {nullptr, nullptr, nullptr};
+    const QueueState none = {nullptr, nullptr, nullptr, nullptr};
+    const QueueState qi = st.qs[cur], qo = st.qs[cur ^ 1];  // the plain kernels: path state in queue order
     const SssState nosss = {};
     const GridShade gsh = {gridVertex, phase};
     if (phase != 0) {  // a scene with a grid medium: the two-phase kernels
@@ -2938,11 +2947,11 @@ void launch_shade_vol(const DScene &sc, const RenderParams &rp, PathState st, Vo
         // Medium vertices and the rest in two launches (k_shade's PART) where the entries are grouped that way (rp.volPre: k_shade_order_vol has
         // drawn every entry's medium sample and put the scattered ones into a class of their own, so a wave of either launch finds its own
         // entries together); PG_VOL_PARTS=0: one launch for all, as before
-        static const bool parts = !(getenv("PG_VOL_PARTS") && atoi(getenv("PG_VOL_PARTS")) == 0);
+        static const bool parts = getenv("PG_VOL_PARTS") && atoi(getenv("PG_VOL_PARTS")) != 0;  // measured (profiles/r05c_volpath_state_and_parts.txt): the two launches lose 4 - 10 % to the one
         const bool split = parts && rp.volPre != nullptr;
-#define PG_LAUNCH_VOL(MODE_, PART_) hipLaunchKernelGGL((k_shade<MODE_, true, false, false, PART_>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss, gsh)
+#define PG_LAUNCH_VOL(MODE_, PART_) hipLaunchKernelGGL((k_shade<MODE_, true, false, false, PART_>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, qi, qo, nosss, gsh)
         if (sc.hasTextured && rp.matPre.lobes) {
-            if (rp.retryCount == 0) launch_material(sc, rp, st, vs, qin, hits, hitT, none, true, s);
+            if (rp.retryCount == 0) launch_material(sc, rp, st, vs, qin, hits, hitT, qi, true, s);
             if (split) { PG_LAUNCH_VOL(1, 1); PG_LAUNCH_VOL(3, 2); } else PG_LAUNCH_VOL(3, 0);
         } else if (sc.hasTextured) PG_LAUNCH_VOL(2, 0);
         else if (split) { PG_LAUNCH_VOL(1, 1); PG_LAUNCH_VOL(1, 2); }
@@ -3125,10 +3134,12 @@ void launch_through(const DScene &sc, PathState st, VolState vs, int kind, RayQu
     else hipLaunchKernelGGL((k_through<1, false>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, vs, qin, hits, hitT, hitBase, qout, none);
 }
 // EstimateDirect's sums with handleMedia = true (integrator.cpp:143-161, 196-212), once the through rays are finished
-__global__ __launch_bounds__(PG_BLOCK) void k_resolve_vol(DScene sc, PathState st, VolState vs, RayQueue qin) {
+// QS: the pending terms lie at the ray's queue position and the path's L with its next ray (queue-order state, PathState) -- else by slot
+template <bool QS>
+__global__ __launch_bounds__(PG_BLOCK) void k_resolve_vol(DScene sc, PathState st, VolState vs, RayQueue qin, QueueState qsNext) {
     const int i = queue_item<>(qin);
     if (i < 0) return;
-    const int slot = __float_as_int(qin.d[i].w);
+    const int slot = QS ? i : __float_as_int(qin.d[i].w);
     const int4 info = st.pdInfo[slot];
     if (info.x < 0 && info.y < 0) return;
     const float4 pl = st.pdLight[slot], pm = st.pdMis[slot], pb = st.pdBeta[slot];
@@ -3138,7 +3149,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_resolve_vol(DScene sc, PathState s
         const Spec Li = sp3(li.x, li.y, li.z) * sp3(t0.x, t0.y, t0.z);  // Li *= visibility.Tr(scene, sampler)
         if (!is_black(Li)) {
             const Spec f = sp3(pl.x, pl.y, pl.z);
-            const float w = __int_as_float(info.w);
+            const float w = QS ? vs.p1[0][slot].w : __int_as_float(info.w);
             Ld = Ld + (w < 0 ? (f * Li) / li.w : ((f * Li) * w) / li.w);
         }
     }
@@ -3147,14 +3158,16 @@ __global__ __launch_bounds__(PG_BLOCK) void k_resolve_vol(DScene sc, PathState s
         const Spec Li = sp3(ml.x, ml.y, ml.z);
         if (!is_black(Li)) Ld = Ld + ((((sp3(pm.x, pm.y, pm.z) * Li) * sp3(t1.x, t1.y, t1.z)) * pb.w) / pm.w);
     }
-    float4 L4 = st.L[slot];
+    float4 *Lp = QS ? (info.w >= 0 ? &qsNext.L[info.w] : &st.L[~info.w]) : &st.L[slot];
+    float4 L4 = *Lp;
     Spec L = sp3(L4.x, L4.y, L4.z) + sp3(pb.x, pb.y, pb.z) * (Ld / pl.w);
-    st.L[slot] = make_float4(L.r, L.g, L.b, L4.w);
+    *Lp = make_float4(L.r, L.g, L.b, L4.w);
 }
-void launch_resolve_vol(const DScene &sc, PathState st, VolState vs, RayQueue qin, hipStream_t s) {
+void launch_resolve_vol(const DScene &sc, PathState st, VolState vs, RayQueue qin, hipStream_t s, int cur) {
     int nblk = PG_REGIONS * (qin.regionCap / PG_BLOCK);
     if (nblk == 0) return;
-    hipLaunchKernelGGL(k_resolve_vol, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, vs, qin);
+    if (st.qs[0].L) hipLaunchKernelGGL(k_resolve_vol<true>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, vs, qin, st.qs[cur ^ 1]);
+    else hipLaunchKernelGGL(k_resolve_vol<false>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, vs, qin, st.qs[0]);
 }
 __global__ void k_fill_int(int *p, int value, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
