@@ -2096,22 +2096,14 @@ PG_DEV void homogeneous_sample_distance(const PgMedium &mm, float uChannel, floa
     dist = -pg_logf((1 - uDist)) / mm.sigma_t[channel];
 }
 struct GridShade { float4 *vertex; int phase; };  // vertex[slot] = (medium interaction point, kind: 0 none, 1 medium vertex, 2 surface vertex)
-// PART (volpath only): 0 = every entry; 1 = only the entries whose ray scattered in its medium (volpath.cpp:80-96: a phase function, no
-// surface) -- a kernel without the interaction, the BSDF and the material evaluators, at a fraction of the registers; 2 = all the others.
-// The two launches together shade the queue exactly once: which part an entry belongs to follows from its medium sample alone, which both
-// compute (or read: RenderParams::volPre).  The surface part no longer carries the medium vertex's code and live values either.
-#ifndef PG_SHADE_MEDIUM_WAVES
-#define PG_SHADE_MEDIUM_WAVES 4
-#endif
-template <int MODE, bool VOL, bool SSS = false, bool GRID = false, int PART = 0>
-__global__ __launch_bounds__(PG_SHADE_BLOCK, PART == 1 ? PG_SHADE_MEDIUM_WAVES : (MODE == 0 ? PG_SHADE0_WAVES : (((MODE == 1 || MODE == 3) && PG_SHADE_MIN_WAVES > 0) ? PG_SHADE_MIN_WAVES : (MODE == 2 ? (VOL ? PG_SHADE2V_WAVES : PG_SHADE2_WAVES) : 1)))) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
+template <int MODE, bool VOL, bool SSS = false, bool GRID = false>
+__global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MODE == 1 || MODE == 3) && PG_SHADE_MIN_WAVES > 0) ? PG_SHADE_MIN_WAVES : (MODE == 2 ? (VOL ? PG_SHADE2V_WAVES : PG_SHADE2_WAVES) : 1))) void k_shade(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
                                                      RayQueue qnext, RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, VolState vs,
                                                      const float *__restrict__ hitT, QueueState qsIn, QueueState qsOut, SssState sss, GridShade gsh) {
     // MODE 3: MODE 1 over the lists k_material left for the hits on materials with textured parameters (rp.matPre)
     constexpr bool EXT = MODE >= 1, TEX = MODE == 2, PRE = MODE == 3;
     static_assert(!PRE || (!SSS && !GRID), "materials evaluated ahead: the plain path / volpath kernels");
     static_assert(!GRID || (VOL && !SSS), "grid media: volpath, without BSSRDF materials");
-    static_assert(PART == 0 || (VOL && !SSS && !GRID), "medium / surface parts: the plain volpath kernels");
     const bool phaseA = GRID && gsh.phase == 1, phaseB = GRID && gsh.phase == 2;
     int vertexKind = 0;  // GRID: what phase 1 found at this entry (phase 2 reads it back)
     static_assert(!SSS || EXT, "materials with a BSSRDF are BxDF-list materials");
@@ -2127,7 +2119,6 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PART == 1 ? PG_SHADE_MEDIUM_WAVES :
         i = queue_item<PG_SHADE_BLOCK>(qin);
         if (rp.order && i >= 0) i = rp.order[i];  // k_shade_order: the entries of a window grouped by material class
     }
-    bool mine = true;       // PART: this entry belongs to this launch
     bool deferred = false;  // sparse light tables: this vertex met a voxel without a distribution; nothing is committed
     unsigned long long tsState0 = 0;  // tile-serial samplers: the tile's stream position and dimension counters on entry
     int tsCur1D0 = 0, tsCur2D0 = 0;
@@ -2159,10 +2150,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PART == 1 ? PG_SHADE_MEDIUM_WAVES :
     int misMedium = 0;       // VOL: medium of the BSDF-sampled ray
     int newMed = 0;          // VOL, queue-order state: the medium of the path's next ray
     float volWeight = 0;     // VOL: MIS weight of the light sample (-1: delta light)
-    if (valid) do {
-        if constexpr (PART != 0) {  // the other launch's entry: nothing of it is read or touched here (see PART; k_shade_order decided)
-            if (((__float_as_int(rp.volPre[i].x) & 0x100) != 0) != (PART == 1)) { mine = false; break; }
-        }
+    if (valid) {
         const float4 d4 = qin.d[i], h4 = hits[i];
         slot = __float_as_int(d4.w);
         pdi = QSTATE ? i : slot;
@@ -2234,7 +2222,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PART == 1 ? PG_SHADE_MEDIUM_WAVES :
                 float dist;
                 if (!GRID && rp.volPre) {  // drawn by k_shade_order (same dimensions, same arithmetic)
                     const float2 pv = rp.volPre[i];
-                    channel = __float_as_int(pv.x) & 0xff; dist = pv.y;
+                    channel = __float_as_int(pv.x); dist = pv.y;
                     dim += 2;
                 } else {
                     const float uc = draw1();
@@ -2279,7 +2267,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PART == 1 ? PG_SHADE_MEDIUM_WAVES :
             if (TEX) { sphU = sh.u; sphV = sh.v; sphDpdu = sh.dpdu; sphDpdv = sh.dpdv; }
         }
         // path.cpp:91-102 emitted light at the vertex (volpath.cpp:103-110: only when no medium interaction was sampled)
-        if (PART == 1 || phaseB || (VOL && (volDead || inMedium))) {
+        if (phaseB || (VOL && (volDead || inMedium))) {
         } else if ((bounces == 0 || specularBounce) && found && tri.light >= 0) {
             const PgLight &l = sc.lights[tri.light];
             V3 nrm = onSphere ? is.n : hit_normal(sc, prim, tri, h4.y, h4.z, h4.w);
@@ -2304,7 +2292,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PART == 1 ? PG_SHADE_MEDIUM_WAVES :
             if (volDead) alive = false;
             else if (inMedium) alive = bounces < rd.max_depth;  // volpath.cpp:83
             if (phaseB) alive = vertexKind == 1 || vertexKind == 2;
-            if (PART != 2 && alive && inMedium) {
+            if (alive && inMedium) {
                 vertexKind = 1;
                 // ---- scattering at a point in the medium, volpath.cpp:80-96: MediumInteraction(p, -ray.d, ..., medium, phase)
                 handled = true;
@@ -2388,7 +2376,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PART == 1 ? PG_SHADE_MEDIUM_WAVES :
                 }
             }
         }
-        if (PART != 1 && alive && !handled) {
+        if (alive && !handled) {
             if (!onSphere) is = make_isect(sc, prim, tri, h4.y, h4.z, h4.w, shapeRayD);
             if (inst >= 0 && !sc.instances[inst].identity) isect_to_world(sc.instances[inst], is);
             const PgMaterial &m = mtl;
@@ -2672,7 +2660,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PART == 1 ? PG_SHADE_MEDIUM_WAVES :
             }
             if (phaseA) gsh.vertex[slot] = make_float4(mediumP.x, mediumP.y, mediumP.z, __int_as_float(alive ? vertexKind : 0));
         }
-    } while (0);
+    }
     if (deferred) {  // retried once the voxel's distribution exists: no ray, no state, no pending term leaves this launch
         pushNext = pushShadow = misCand = false;
         if (rp.rd.sampler >= PG_SAMPLER_RANDOM) { sc.ts[slot].state = tsState0; sc.ts[slot].cur1D = tsCur1D0; sc.ts[slot].cur2D = tsCur2D0; }  // nor a draw from the tile's stream
@@ -2721,7 +2709,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PART == 1 ? PG_SHADE_MEDIUM_WAVES :
     if (pushShadow) { qshadow.o[posShadow] = s_ray[1][0][tid]; qshadow.d[posShadow] = s_ray[1][1][tid]; }
     if (pushMis) { qmis.o[posMis] = s_ray[2][0][tid]; qmis.d[posMis] = s_ray[2][1][tid]; }
     if constexpr (QSTATE) {
-        if (valid && mine && !deferred) {
+        if (valid && !deferred) {
             if (pushNext) {
                 const float4 m4 = s_state[2][tid];
                 qsOut.L[posNext] = s_state[0][tid]; qsOut.beta[posNext] = s_state[1][tid];
@@ -2730,7 +2718,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PART == 1 ? PG_SHADE_MEDIUM_WAVES :
             } else st.L[slot] = s_state[0][tid];
             st.pdInfo[pdi] = make_int4(posShadow, posMis, lightNum, pushNext ? posNext : ~slot);
         }
-    } else if (valid && mine && !deferred && !phaseB) st.pdInfo[slot] = make_int4(posShadow, posMis, lightNum, VOL ? __float_as_int(volWeight) : 0);
+    } else if (valid && !deferred && !phaseB) st.pdInfo[slot] = make_int4(posShadow, posMis, lightNum, VOL ? __float_as_int(volWeight) : 0);
     if constexpr (SSS) {
         // the probe rays of the paths that go on through a BSSRDF, region by region like every other queue; such a path's L went to
         // its slot above (where k_resolve adds this vertex's direct lighting), beta and meta follow it there
@@ -2852,7 +2840,6 @@ __global__ __launch_bounds__(1024) void k_shade_order(DScene sc, RayQueue q, con
             if constexpr (VOL) {
                 const float4 d4 = q.d[e];
                 const int slot = __float_as_int(d4.w), med = qs.L ? qs.medium[e] : vs.medium[slot];  // (path state in queue order, or by slot)
-                volPre[e] = make_float2(0.f, 0.f);  // (every entry has its part bit; the rest is only read for a ray inside a homogeneous medium)
                 if (med && !(sc.mediaGrid && sc.mediaGrid[med - 1] >= 0)) {
                     const int4 meta = qs.L ? qs.meta[e] : st.meta[slot];
                     const uint64_t index = (uint64_t)(uint32_t)meta.x | ((uint64_t)(uint32_t)meta.y << 32);
@@ -2862,13 +2849,8 @@ __global__ __launch_bounds__(1024) void k_shade_order(DScene sc, RayQueue q, con
                     float dist;
                     homogeneous_sample_distance(sc.media[med - 1], uc, halton_sample(sc, rd, index, dim + 1), channel, dist);
                     const float tMaxRay = prim >= 0 ? hitT[e] : q.o[e].w;
-                    const bool scattered = dist / sqrtf(lensq(mk(d4.x, d4.y, d4.z))) < tMaxRay;  // the same operations as k_shade's `inMedium`
-                    if (scattered) c = PG_ORDER_CLASSES - 3;
-                    // bit 8: a medium vertex that the path continues from (volpath.cpp:80-96) -- which of k_shade's two PART launches shades
-                    // this entry.  Decided HERE, from the state before either launch: the launch that runs first advances the paths' bounce
-                    // counts, and the other must not read its own membership off them.
-                    const bool mediumPart = scattered && ((uint32_t)meta.w & 0xffffu) < (uint32_t)rd.max_depth;
-                    volPre[e] = make_float2(__int_as_float(channel | (mediumPart ? 0x100 : 0)), dist);
+                    volPre[e] = make_float2(__int_as_float(channel), dist);
+                    if (dist / sqrtf(lensq(mk(d4.x, d4.y, d4.z))) < tMaxRay) c = PG_ORDER_CLASSES - 3;  // (only the grouping depends on this)
                 }
             }
         }
@@ -2944,18 +2926,12 @@ void launch_shade_vol(const DScene &sc, const RenderParams &rp, PathState st, Vo
         if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, true, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, *sss, gsh);
         else hipLaunchKernelGGL((k_shade<1, true, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, *sss, gsh);
     } else {
-        // Medium vertices and the rest in two launches (k_shade's PART) where the entries are grouped that way (rp.volPre: k_shade_order_vol has
-        // drawn every entry's medium sample and put the scattered ones into a class of their own, so a wave of either launch finds its own
-        // entries together); PG_VOL_PARTS=0: one launch for all, as before
-        static const bool parts = getenv("PG_VOL_PARTS") && atoi(getenv("PG_VOL_PARTS")) != 0;  // measured (profiles/r05c_volpath_state_and_parts.txt): the two launches lose 4 - 10 % to the one
-        const bool split = parts && rp.volPre != nullptr;
-#define PG_LAUNCH_VOL(MODE_, PART_) hipLaunchKernelGGL((k_shade<MODE_, true, false, false, PART_>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, qi, qo, nosss, gsh)
+#define PG_LAUNCH_VOL(MODE_) hipLaunchKernelGGL((k_shade<MODE_, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, qi, qo, nosss, gsh)
         if (sc.hasTextured && rp.matPre.lobes) {
             if (rp.retryCount == 0) launch_material(sc, rp, st, vs, qin, hits, hitT, qi, true, s);
-            if (split) { PG_LAUNCH_VOL(1, 1); PG_LAUNCH_VOL(3, 2); } else PG_LAUNCH_VOL(3, 0);
-        } else if (sc.hasTextured) PG_LAUNCH_VOL(2, 0);
-        else if (split) { PG_LAUNCH_VOL(1, 1); PG_LAUNCH_VOL(1, 2); }
-        else PG_LAUNCH_VOL(1, 0);
+            PG_LAUNCH_VOL(3);
+        } else if (sc.hasTextured) PG_LAUNCH_VOL(2);
+        else PG_LAUNCH_VOL(1);
 #undef PG_LAUNCH_VOL
     }
 }
