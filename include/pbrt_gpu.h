@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 24
+#define PG_ABI_VERSION 25
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -443,9 +443,20 @@ typedef struct PgRenderDesc {
     int32_t camera_type;        /* 0 = perspective, 1 = orthographic, 2 = environment (cameras/environment.cpp:43-56) */
     float raster_to_camera[16]; /* row-major Matrix4x4 */
     float dx_camera[3], dy_camera[3]; /* ProjectiveCamera::dxCamera / dyCamera (perspective.cpp:60-63, orthographic.cpp:57-58): ray differentials */
-    float camera_to_world[16];
+    float camera_to_world[16];  /* AnimatedTransform CameraToWorld: its startTransform (the only one of a camera that does not move) */
     float lens_radius, focal_distance;
     float shutter_open, shutter_close;
+    /* A moving camera (ABI 25): Camera::CameraToWorld is an AnimatedTransform (core/transform.h:331-362, api.cpp:1725-1730) that every
+     * camera ray is carried through at its own time = Lerp(CameraSample::time, shutterOpen, shutterClose) (perspective.cpp:89-91, :139):
+     * AnimatedTransform::operator()(Ray) (transform.cpp:1171-1181) = the start transform up to camera_time[0], the end transform from
+     * camera_time[1] on, and in between Translate(lerp T) * Slerp(R).ToTransform() * Transform(lerp S) (Interpolate, :1144-1169) of the
+     * two transforms' decompositions (Decompose, :1103-1142), which the host computes once.  camera_animated = 0: the fields are unused. */
+    int32_t camera_animated;         /* AnimatedTransform::actuallyAnimated */
+    float camera_time[2];            /* startTime, endTime (the file's TransformTimes) */
+    float camera_to_world_end[16];   /* endTransform */
+    float camera_T[2][3];            /* T[0], T[1] */
+    float camera_R[2][4];            /* R[0], R[1] as (v.x, v.y, v.z, w); R[1] already flipped onto R[0]'s hemisphere (transform.cpp:410) */
+    float camera_S[2][9];            /* the upper 3x3 of S[0], S[1], row-major */
     /* film (film.cpp:45-86) */
     int32_t full_res[2];
     int32_t cropped_pixel_bounds[4]; /* x0,y0,x1,y1 */

@@ -451,9 +451,19 @@ void FillRenderDesc(const Camera &camera, const Sampler &sampler, const Bounds2i
     rd->camera_medium = cameraMedium;
     const ProjectiveCamera *pc = dynamic_cast<const ProjectiveCamera *>(&camera);
     if (!pc) Unsupported("a camera other than perspective / orthographic in this binding");
-    if (camera.CameraToWorld.actuallyAnimated) Unsupported("an animated camera transform");
     CopyMatrix(pc->RasterToCamera.m, rd->raster_to_camera);
     CopyMatrix(camera.CameraToWorld.startTransform->m, rd->camera_to_world);
+    if (camera.CameraToWorld.actuallyAnimated) {  // the reference's own decomposition (AnimatedTransform's constructor, transform.cpp:396-411)
+        const AnimatedTransform &a = camera.CameraToWorld;
+        rd->camera_animated = 1;
+        rd->camera_time[0] = a.startTime; rd->camera_time[1] = a.endTime;
+        CopyMatrix(a.endTransform->m, rd->camera_to_world_end);
+        for (int k = 0; k < 2; ++k) {
+            rd->camera_T[k][0] = a.T[k].x; rd->camera_T[k][1] = a.T[k].y; rd->camera_T[k][2] = a.T[k].z;
+            rd->camera_R[k][0] = a.R[k].v.x; rd->camera_R[k][1] = a.R[k].v.y; rd->camera_R[k][2] = a.R[k].v.z; rd->camera_R[k][3] = a.R[k].w;
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) rd->camera_S[k][3 * i + j] = a.S[k].m[i][j];
+        }
+    }
     Vector3f dx, dy;
     if (const PerspectiveCamera *p = dynamic_cast<const PerspectiveCamera *>(pc)) { rd->camera_type = 0; dx = p->dxCamera; dy = p->dyCamera; }
     else if (const OrthographicCamera *o = dynamic_cast<const OrthographicCamera *>(pc)) { rd->camera_type = 1; dx = o->dxCamera; dy = o->dyCamera; }

@@ -476,6 +476,13 @@ def with_many_lights(s, n=50):
     return s.replace(old, mesh)
 
 
+def cam_anim(s, end_motion, times=""):
+    """Give the camera an end-of-motion transform: the directives `end_motion` act on the END transform only (ActiveTransform
+    EndTime, api.cpp:395-403) on top of the LookAt both share, so CameraToWorld[0] != CameraToWorld[1]."""
+    assert "Camera " in s
+    return s.replace("Camera ", times + "ActiveTransform EndTime\n" + end_motion + "\nActiveTransform All\nCamera ", 1)
+
+
 def with_sampler(s, spec):
     import re as _re
     out, n = _re.subn(r'Sampler "halton" "integer pixelsamples" \[ \d+ \]', 'Sampler ' + spec, s)
@@ -722,6 +729,27 @@ SCENES = {
     "light_gonio_power": cornell(32, 32, 8, integrator='Integrator "volpath" "integer maxdepth" [ 4 ] "string lightsamplestrategy" "power"',
                                  world_edit=lambda s: with_fog(s).replace("# light\nAttributeBegin", IMAGE_LIGHTS + "# light\nAttributeBegin").replace("  AreaLightSource", "#  AreaLightSource")),
     "cornell_lens": cornell(24, 24, 8).replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 8 ] "float focaldistance" [ 1000 ]'),
+    # A moving camera: CameraToWorld is an AnimatedTransform interpolated at every camera ray's time (transform.cpp:1144-1181,
+    # perspective.cpp:89-91, :139).  Translation only; a rotation large enough for Slerp's acos / sin / cos branch; one so small that
+    # Slerp normalises the blend (cosTheta > .9995); translation + rotation + scale with TransformTimes inside the shutter interval
+    # (rays before the start time and after the end time take the end transforms themselves); then the rays' differentials through
+    # the same interpolated transform (filtered image textures) under every sampler family, a lens, the other two cameras, and volpath.
+    "camanim_translate": cam_anim(cornell(32, 32, 8), "Translate 40 -20 60"),
+    "camanim_rotate": cam_anim(cornell(32, 32, 8), "Translate 30 0 -40\nRotate 25 0.1 1 0.2"),
+    "camanim_small_rotate": cam_anim(cornell(24, 24, 8), "Rotate 1 0 1 0"),
+    "camanim_times_scale": cam_anim(cornell(32, 24, 8), "Translate -35 10 20\nRotate -18 1 0.3 0\nScale 1.1 0.9 1", times="TransformTimes 0.2 0.7\n")
+                           .replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float shutteropen" [ 0 ] "float shutterclose" [ 1 ]'),
+    "camanim_lens_tex": cam_anim(cornell(32, 32, 4, world_edit=lambda s: with_image_textures(s)), "Translate 25 15 0\nRotate 12 0 1 0.1")
+                        .replace('"float fov" [ 39.3 ]', '"float fov" [ 39.3 ] "float lensradius" [ 10 ] "float focaldistance" [ 700 ] "float shutteropen" [ 0.1 ] "float shutterclose" [ 0.9 ]'),
+    "camanim_sobol_tex": cam_anim(cornell(32, 32, 4, world_edit=lambda s: with_image_textures(s)), "Rotate 15 0.2 1 0").replace('Sampler "halton"', 'Sampler "sobol"'),
+    "camanim_strat_dims_tex": with_sampler(cam_anim(cornell(32, 24, 4, integrator='Integrator "path" "integer maxdepth" [ 4 ]', world_edit=lambda s: with_image_textures(s)), "Translate 20 0 30\nRotate 10 0 1 0"),
+                                           '"stratified" "integer xsamples" [ 2 ] "integer ysamples" [ 2 ] "integer dimensions" [ 14 ]'),
+    "camanim_random_tex": with_sampler(cam_anim(cornell(24, 24, 4, integrator='Integrator "path" "integer maxdepth" [ 3 ]', world_edit=lambda s: with_image_textures(s)), "Rotate 20 0 1 0"),
+                                       '"random" "integer pixelsamples" [ 3 ]'),
+    "camanim_ortho": cam_anim(cornell(24, 24, 8).replace('Camera "perspective" "float fov" [ 39.3 ]', 'Camera "orthographic" "float screenwindow" [ -300 300 -290 310 ]'), "Translate 0 40 0\nRotate 14 0 0 1"),
+    "camanim_env": cam_anim(cornell(32, 16, 8, world_edit=lambda s: with_image_textures(s)).replace("LookAt 278 273 -800  278 273 0  0 1 0", "LookAt 278 273 100  278 273 400  0 1 0")
+                            .replace('Camera "perspective" "float fov" [ 39.3 ]', 'Camera "environment"'), "Translate 60 0 0\nRotate 30 0 1 0"),
+    "camanim_vol": cam_anim(cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 4 ]', world_edit=lambda s: with_fog(s)), "Translate 0 0 50\nRotate 16 0.3 1 0"),
 }
 
 

@@ -5,7 +5,7 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 24
+PG_ABI_VERSION = 25
 PG_SAMPLER_HALTON, PG_SAMPLER_SOBOL, PG_SAMPLER_RANDOM, PG_SAMPLER_STRATIFIED, PG_SAMPLER_ZEROTWO, PG_SAMPLER_MAXMINDIST = range(6)
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
@@ -129,6 +129,8 @@ class PgRenderDesc(C.Structure):
                 ("raster_to_camera", C.c_float * 16), ("dx_camera", C.c_float * 3), ("dy_camera", C.c_float * 3), ("camera_to_world", C.c_float * 16),
                 ("lens_radius", C.c_float), ("focal_distance", C.c_float),
                 ("shutter_open", C.c_float), ("shutter_close", C.c_float),
+                ("camera_animated", C.c_int32), ("camera_time", C.c_float * 2), ("camera_to_world_end", C.c_float * 16),
+                ("camera_T", (C.c_float * 3) * 2), ("camera_R", (C.c_float * 4) * 2), ("camera_S", (C.c_float * 9) * 2),
                 ("full_res", C.c_int32 * 2), ("cropped_pixel_bounds", C.c_int32 * 4), ("sample_bounds", C.c_int32 * 4),
                 ("filter_radius", C.c_float * 2), ("filter_general", C.c_int32), ("tile_halo", C.c_int32 * 4),
                 ("tile_pixels", C.c_int32), ("filter_table", C.c_float * 256), ("film_scale", C.c_float), ("max_sample_luminance", C.c_float),

@@ -37,7 +37,8 @@ struct TileSamplerState {
     int cur1D, cur2D, sampleIndex, active;  // active: the current pixel exists and lies inside the integrator's pixel bounds
     float lens0, lens1;
     int px, py;
-    unsigned int draws, pad;  // RNG::UniformUInt32 calls so far (k_ts_start_tile measures what a StartPixel consumed)
+    unsigned int draws;  // RNG::UniformUInt32 calls so far (k_ts_start_tile measures what a StartPixel consumed)
+    float time;          // the camera sample's time number (kept like the lens point: a moving camera's differentials need its transform again)
 };
 
 // Device-resident scene.  All pointers are device memory.

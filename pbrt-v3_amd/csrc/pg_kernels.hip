@@ -335,7 +335,7 @@ __global__ void k_ts_init(DScene sc, RenderParams rp) {
     rng_u32(t);
     t.state += 0x853c49e6748fea9bULL;
     rng_u32(t);
-    t.cur1D = t.cur2D = t.sampleIndex = t.active = 0; t.lens0 = t.lens1 = 0; t.px = t.py = 0; t.draws = t.pad = 0;
+    t.cur1D = t.cur2D = t.sampleIndex = t.active = 0; t.lens0 = t.lens1 = 0; t.px = t.py = 0; t.draws = 0; t.time = 0;
     sc.ts[local] = t;
 }
 // <Sampler>::StartPixel for pixel (lx, ly) of every tile: the pixel's sample arrays from the tile's stream -- also for pixels
@@ -520,9 +520,59 @@ PG_DEV bool slot_to_pixel(const RenderParams &rp, int slot, int &px, int &py, in
     return px >= rp.rd.pixel_bounds[0] && px < rp.rd.pixel_bounds[2] && py >= rp.rd.pixel_bounds[1] && py < rp.rd.pixel_bounds[3];
 }
 
+// r = m1 m2, Matrix4x4::Mul (transform.h:86-93): every entry the four products summed left to right
+PG_DEV void m4_mul(const float *m1, const float *m2, float *r) {
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            r[4 * i + j] = m1[4 * i] * m2[j] + m1[4 * i + 1] * m2[4 + j] + m1[4 * i + 2] * m2[8 + j] + m1[4 * i + 3] * m2[12 + j];
+}
+// The matrix AnimatedTransform CameraToWorld carries a ray of time `time` to world space with (AnimatedTransform::operator()(Ray),
+// transform.cpp:1171-1181): the start transform up to startTime, the end transform from endTime on, in between
+// Interpolate (:1144-1169) = Translate(lerp T) * Slerp(dt, R0, R1).ToTransform() * Transform(lerp S) -- only .m is formed: a ray is
+// transformed by m alone (transform.h:249-262), so Transform(scale)'s inverse is never looked at.  Quaternion arithmetic as
+// quaternion.h:52-99 spells it (v /= f multiplies by 1 / f, w /= f divides), Slerp quaternion.cpp:94-104, ToTransform :41-59.
+PG_DEV void camera_matrix_at(const PgRenderDesc &rd, float time, float *m) {
+    if (!rd.camera_animated || time <= rd.camera_time[0]) { for (int k = 0; k < 16; ++k) m[k] = rd.camera_to_world[k]; return; }
+    if (time >= rd.camera_time[1]) { for (int k = 0; k < 16; ++k) m[k] = rd.camera_to_world_end[k]; return; }
+    const float dt = (time - rd.camera_time[0]) / (rd.camera_time[1] - rd.camera_time[0]);
+    const float tx = (1 - dt) * rd.camera_T[0][0] + dt * rd.camera_T[1][0], ty = (1 - dt) * rd.camera_T[0][1] + dt * rd.camera_T[1][1],
+                tz = (1 - dt) * rd.camera_T[0][2] + dt * rd.camera_T[1][2];
+    const float *q1 = rd.camera_R[0], *q2 = rd.camera_R[1];
+    const float cosTheta = (q1[0] * q2[0] + q1[1] * q2[1] + q1[2] * q2[2]) + q1[3] * q2[3];  // Dot(q1, q2) = Dot(q1.v, q2.v) + q1.w * q2.w
+    float qx, qy, qz, qw;
+    if (cosTheta > .9995f) {  // Normalize((1 - t) * q1 + t * q2)
+        const float a = 1 - dt;
+        const float sx = q1[0] * a + q2[0] * dt, sy = q1[1] * a + q2[1] * dt, sz = q1[2] * a + q2[2] * dt, sw = q1[3] * a + q2[3] * dt;
+        const float len = sqrtf((sx * sx + sy * sy + sz * sz) + sw * sw), inv = 1.f / len;
+        qx = sx * inv; qy = sy * inv; qz = sz * inv; qw = sw / len;
+    } else {
+        const float theta = pg_acosf(cosTheta < -1 ? -1.f : (cosTheta > 1 ? 1.f : cosTheta));
+        const float thetap = theta * dt;
+        // qperp = Normalize(q2 - q1 * cosTheta)
+        const float px = q2[0] - q1[0] * cosTheta, py = q2[1] - q1[1] * cosTheta, pz = q2[2] - q1[2] * cosTheta, pw = q2[3] - q1[3] * cosTheta;
+        const float len = sqrtf((px * px + py * py + pz * pz) + pw * pw), inv = 1.f / len;
+        const float ux = px * inv, uy = py * inv, uz = pz * inv, uw = pw / len;
+        float sn, cs;
+        pg_sincosf(thetap, &sn, &cs);
+        qx = q1[0] * cs + ux * sn; qy = q1[1] * cs + uy * sn; qz = q1[2] * cs + uz * sn; qw = q1[3] * cs + uw * sn;
+    }
+    const float xx = qx * qx, yy = qy * qy, zz = qz * qz, xy = qx * qy, xz = qx * qz, yz = qy * qz, wx = qx * qw, wy = qy * qw, wz = qz * qw;
+    // rotate.ToTransform().m = Transpose(the matrix of quaternion.cpp:47-55)
+    const float rot[16] = {1 - 2 * (yy + zz), 2 * (xy - wz), 2 * (xz + wy), 0, 2 * (xy + wz), 1 - 2 * (xx + zz), 2 * (yz - wx), 0,
+                           2 * (xz - wy), 2 * (yz + wx), 1 - 2 * (xx + yy), 0, 0, 0, 0, 1};
+    const float trn[16] = {1, 0, 0, tx, 0, 1, 0, ty, 0, 0, 1, tz, 0, 0, 0, 1};
+    float scl[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) scl[4 * i + j] = (1 - dt) * rd.camera_S[0][3 * i + j] + dt * rd.camera_S[1][3 * i + j];  // Lerp, pbrt.h:417
+    float tr[16];
+    m4_mul(trn, rot, tr);
+    m4_mul(tr, scl, m);
+}
+// CameraSample::time -> the ray's time, perspective.cpp:90 / :121: Lerp(sample.time, shutterOpen, shutterClose)
+PG_DEV float camera_time(const PgRenderDesc &rd, float u) { return (1 - u) * rd.shutter_open + u * rd.shutter_close; }
 // Camera::GenerateRay: PerspectiveCamera (perspective.cpp:95-115,141), OrthographicCamera (orthographic.cpp:68-93,115) and
-// EnvironmentCamera (environment.cpp:43-56), ending in CameraToWorld(ray).  (l0, l1) = CameraSample::pLens.
-PG_DEV void camera_ray(const PgRenderDesc &rd, float pFilmX, float pFilmY, float l0, float l1, V3 &o, V3 &d, float &tMax) {
+// EnvironmentCamera (environment.cpp:43-56), ending in CameraToWorld(ray) -- c2w: the matrix of the ray's time (camera_matrix_at).
+// (l0, l1) = CameraSample::pLens.
+PG_DEV void camera_ray(const PgRenderDesc &rd, const float *c2w, float pFilmX, float pFilmY, float l0, float l1, V3 &o, V3 &d, float &tMax) {
     V3 pCamera = xform_point(rd.raster_to_camera, mk(pFilmX, pFilmY, 0));
     o = mk(0, 0, 0);
     d = normalize(mk(pCamera.x, pCamera.y, pCamera.z));
@@ -546,18 +596,18 @@ PG_DEV void camera_ray(const PgRenderDesc &rd, float pFilmX, float pFilmY, float
         o = mk(lx, ly, 0);
         d = normalize(pFocus - o);
     }
-    xform_ray(rd.camera_to_world, o, d, tMax);
+    xform_ray(c2w, o, d, tMax);
 }
 // The camera ray's differentials (GenerateRayDifferential: perspective.cpp:117-140, orthographic.cpp:95-113, the finite
 // difference of camera.cpp:52-93 for the environment camera), carried to world space (transform.h:264-273) and scaled by
 // 1 / sqrt(spp) (integrator.cpp:282-283, geometry.h:908-913).  (o, d) = the world-space camera ray.
-PG_DEV void camera_differentials(const PgRenderDesc &rd, float pFilmX, float pFilmY, float l0, float l1, V3 o, V3 d, V3 &rxO, V3 &rxD, V3 &ryO, V3 &ryD) {
+PG_DEV void camera_differentials(const PgRenderDesc &rd, const float *c2w, float pFilmX, float pFilmY, float l0, float l1, V3 o, V3 d, V3 &rxO, V3 &rxD, V3 &ryO, V3 &ryD) {
     if (rd.camera_type == 2) {
         const float eps = .05f;
         V3 xo, xd, yo, yd;
         float tm;
-        camera_ray(rd, pFilmX + eps, pFilmY, l0, l1, xo, xd, tm);
-        camera_ray(rd, pFilmX, pFilmY + eps, l0, l1, yo, yd, tm);
+        camera_ray(rd, c2w, pFilmX + eps, pFilmY, l0, l1, xo, xd, tm);
+        camera_ray(rd, c2w, pFilmX, pFilmY + eps, l0, l1, yo, yd, tm);
         rxO = o + vdiv(xo - o, eps); rxD = d + vdiv(xd - d, eps);
         ryO = o + vdiv(yo - o, eps); ryD = d + vdiv(yd - d, eps);
     } else {
@@ -606,13 +656,16 @@ PG_DEV void camera_differentials(const PgRenderDesc &rd, float pFilmX, float pFi
                 rxD = ryD = cd;
             }
         }
-        rxO = xform_point(rd.camera_to_world, rxO); ryO = xform_point(rd.camera_to_world, ryO);
-        rxD = m4_vec(rd.camera_to_world, rxD); ryD = m4_vec(rd.camera_to_world, ryD);
+        rxO = xform_point(c2w, rxO); ryO = xform_point(c2w, ryO);
+        rxD = m4_vec(c2w, rxD); ryD = m4_vec(c2w, ryD);
     }
     const float sc = 1 / sqrtf((float)rd.spp);
     rxO = o + (rxO - o) * sc; ryO = o + (ryO - o) * sc;
     rxD = d + (rxD - d) * sc; ryD = d + (ryD - d) * sc;
 }
+// ANIM: the camera moves (PgRenderDesc::camera_animated) -- every sample's camera-to-world matrix is interpolated at its time; the still
+// camera's kernel does not carry that code (64 instead of 39 registers, 113 spilled scalars)
+template <bool ANIM>
 __global__ __launch_bounds__(PG_BLOCK) void k_generate(DScene sc, RenderParams rp, PathState st, RayQueue q) {
     int slot = blockIdx.x * PG_BLOCK + threadIdx.x;
     bool valid = slot < rp.capacity;
@@ -624,15 +677,15 @@ __global__ __launch_bounds__(PG_BLOCK) void k_generate(DScene sc, RenderParams r
         const PgRenderDesc &rd = rp.rd;
         uint64_t index = sc.tsBatched ? 0 : sampler_index(sc, rd, px, py, (uint64_t)sn);
         // GetCameraSample, sampler.cpp:46-52: dims 0,1 film; 2 time; 3,4 lens
-        float u0 = 0, u1 = 0, tsl0 = 0, tsl1 = 0;
+        float u0 = 0, u1 = 0, tsl0 = 0, tsl1 = 0, uTime = 0;
         int tsDim = 0;
         if (sc.tsBatched) {  // a PixelSampler's arrays: film 2D, time 1D, lens 2D; the path's state names its pixel and sample
             const int pixel = (rp.tileLocal0 + (slot >> 8) / rp.sCount) * 256 + (slot & 255);
             index = (uint64_t)(uint32_t)pixel | ((uint64_t)(uint32_t)sn << 32);
             tsb_get2d(sc, pixel, sn, tsDim, u0, u1);
-            (void)tsb_get1d(sc, pixel, sn, tsDim);
+            uTime = tsb_get1d(sc, pixel, sn, tsDim);
             tsb_get2d(sc, pixel, sn, tsDim, tsl0, tsl1);
-        } else { u0 = halton_sample(sc, rd, index, 0); u1 = halton_sample(sc, rd, index, 1); }
+        } else { u0 = halton_sample(sc, rd, index, 0); u1 = halton_sample(sc, rd, index, 1); if (ANIM) uTime = halton_sample(sc, rd, index, 2); }
         if (rd.sampler == 1) {  // SobolSampler::SampleDimension, sobol.cpp:53-56
             u0 = u0 * rd.sobol_resolution + rd.sample_bounds[0];
             u0 = u0 - px;
@@ -645,7 +698,11 @@ __global__ __launch_bounds__(PG_BLOCK) void k_generate(DScene sc, RenderParams r
         float l0 = 0, l1 = 0;
         if (sc.tsBatched) { l0 = tsl0; l1 = tsl1; }
         else if (rd.lens_radius > 0) { l0 = halton_sample(sc, rd, index, 3); l1 = halton_sample(sc, rd, index, 4); }
-        camera_ray(rd, pFilmX, pFilmY, l0, l1, o, d, tMax);
+        if constexpr (ANIM) {
+            float c2w[16];
+            camera_matrix_at(rd, camera_time(rd, uTime), c2w);
+            camera_ray(rd, c2w, pFilmX, pFilmY, l0, l1, o, d, tMax);
+        } else camera_ray(rd, rd.camera_to_world, pFilmX, pFilmY, l0, l1, o, d, tMax);
         st.L[slot] = make_float4(0, 0, 0, pFilmX);
         st.beta[slot] = make_float4(1, 1, 1, pFilmY);
         st.meta[slot] = make_int4((int)(uint32_t)index, (int)(uint32_t)(index >> 32), __float_as_int(1.f), ((sc.tsBatched ? tsDim : 5) << 20) | PG_META_HASDIFF);
@@ -664,7 +721,8 @@ __global__ __launch_bounds__(PG_BLOCK) void k_generate(DScene sc, RenderParams r
 }
 void launch_generate(const DScene &sc, const RenderParams &rp, PathState st, RayQueue q, hipStream_t s) {
     int nblk = (rp.capacity + PG_BLOCK - 1) / PG_BLOCK;
-    hipLaunchKernelGGL(k_generate, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, q);
+    if (rp.rd.camera_animated) hipLaunchKernelGGL(k_generate<true>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, q);
+    else hipLaunchKernelGGL(k_generate<false>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, q);
 }
 
 // Tile-serial samplers: sample `sampleIndex` of every tile's current pixel -- StartNextSample's reset, GetCameraSample's draws
@@ -680,11 +738,13 @@ __global__ __launch_bounds__(PG_BLOCK) void k_ts_generate(DScene sc, RenderParam
         t.sampleIndex = sampleIndex; t.cur1D = t.cur2D = 0;
         float u0, u1, l0, l1;
         ts_get2d(sc, rd.sampler, local, u0, u1);
-        (void)ts_get1d(sc, local);  // time
+        const float uTime = ts_get1d(sc, local);  // time
         ts_get2d(sc, rd.sampler, local, l0, l1);
-        t.lens0 = l0; t.lens1 = l1;
+        t.lens0 = l0; t.lens1 = l1; t.time = uTime;
         const float pFilmX = (float)t.px + u0, pFilmY = (float)t.py + u1;
-        camera_ray(rd, pFilmX, pFilmY, l0, l1, o, d, tMax);
+        float c2w[16];
+        camera_matrix_at(rd, camera_time(rd, uTime), c2w);
+        camera_ray(rd, c2w, pFilmX, pFilmY, l0, l1, o, d, tMax);
         st.L[local] = make_float4(0, 0, 0, pFilmX);
         st.beta[local] = make_float4(1, 1, 1, pFilmY);
         st.meta[local] = make_int4(0, 0, __float_as_int(1.f), PG_META_HASDIFF);
@@ -2000,8 +2060,19 @@ PG_DEV void tex_hit_setup(const DScene &sc, const PgRenderDesc &rd, const RayQue
         if (tileSerial) { l0 = sc.ts[slot].lens0; l1 = sc.ts[slot].lens1; }  // the camera sample's pLens, kept by k_ts_generate
         else if (pixelArrays) { int d2 = 1 << 6; tsb_get2d(sc, meta.x, meta.y, d2, l0, l1); }  // (its second 2D dimension)
         else if (rd.lens_radius > 0) { l0 = halton_sample(sc, rd, index, 3); l1 = halton_sample(sc, rd, index, 4); }
+        // the camera sample's time again (its third number), for the camera-to-world transform of that moment
+        float uTime = 0;
+        if (rd.camera_animated) {
+            if (tileSerial) uTime = sc.ts[slot].time;
+            else if (pixelArrays) { int d1 = 0; uTime = tsb_get1d(sc, meta.x, meta.y, d1); }
+            else uTime = halton_sample(sc, rd, index, 2);
+        }
         V3 rxO, rxD, ryO, ryD;
-        camera_differentials(rd, filmX, filmY, l0, l1, rayO, rayD, rxO, rxD, ryO, ryD);
+        if (rd.camera_animated) {  // (two calls: one pointer that is either the description's matrix or a private array would be a generic one)
+            float c2w[16];
+            camera_matrix_at(rd, camera_time(rd, uTime), c2w);
+            camera_differentials(rd, c2w, filmX, filmY, l0, l1, rayO, rayD, rxO, rxD, ryO, ryD);
+        } else camera_differentials(rd, rd.camera_to_world, filmX, filmY, l0, l1, rayO, rayD, rxO, rxD, ryO, ryD);
         const V3 n = is.n, p = is.p;
         const float dd = dot(n, p);
         const float tx = -(dot(n, rxO) - dd) / dot(n, rxD);

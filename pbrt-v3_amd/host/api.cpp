@@ -1378,11 +1378,13 @@ static GpuPathIntegrator *MakeIntegrator() {
         delete film;
         return nullptr;
     }
-    if (ro.CameraToWorld.IsAnimated()) {  // AnimatedTransform CameraToWorld (api.cpp:1725-1730, cameras/perspective.cpp:89,139): refused
-        Error("An animated camera transformation (motion blur) is outside this build's closed set; the scene will not be rendered.");
-        ro.refused = true;
-    }
     std::shared_ptr<PerspectiveCamera> camera(CreatePerspectiveCamera(ro.CameraParams, ro.CameraToWorld[0], film, ro.CameraName == "orthographic"));
+    // AnimatedTransform animatedCam2World(CameraToWorld[0], transformStartTime, CameraToWorld[1], transformEndTime), api.cpp:1725-1730: every
+    // camera ray is carried to world space by the transform interpolated at its time (cameras/perspective.cpp:89-91, :139)
+    camera->CameraToWorldEnd = ro.CameraToWorld[1];
+    camera->transformStartTime = ro.transformStartTime; camera->transformEndTime = ro.transformEndTime;
+    camera->animated = !(ro.CameraToWorld[0].GetMatrix() == ro.CameraToWorld[1].GetMatrix() &&
+                         ro.CameraToWorld[0].GetInverseMatrix() == ro.CameraToWorld[1].GetInverseMatrix());  // Transform::operator!=, transform.h:152-154
     if (ro.CameraName == "environment") { camera->environment = true; camera->lensRadius = 0; }  // environment.cpp:96-97: lens parameters unused
     ro.CameraParams.ReportUnused();
     // the GlobalSamplers (halton, sobol) index every sample by (pixel, sample number) alone; the PixelSamplers (random,

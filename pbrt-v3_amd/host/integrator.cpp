@@ -428,6 +428,16 @@ void GpuPathIntegrator::FillRenderDesc(PgRenderDesc *rd) const {
     rd->camera_medium = cameraMedium;
     memcpy(rd->raster_to_camera, camera->RasterToCamera.GetMatrix().m, 16 * sizeof(float));
     memcpy(rd->camera_to_world, camera->CameraToWorld.GetMatrix().m, 16 * sizeof(float));
+    rd->camera_animated = camera->animated ? 1 : 0;
+    if (camera->animated) {  // AnimatedTransform's constructor, transform.cpp:396-411
+        rd->camera_time[0] = camera->transformStartTime; rd->camera_time[1] = camera->transformEndTime;
+        memcpy(rd->camera_to_world_end, camera->CameraToWorldEnd.GetMatrix().m, 16 * sizeof(float));
+        DecomposeTransform(camera->CameraToWorld.GetMatrix(), rd->camera_T[0], rd->camera_R[0], rd->camera_S[0]);
+        DecomposeTransform(camera->CameraToWorldEnd.GetMatrix(), rd->camera_T[1], rd->camera_R[1], rd->camera_S[1]);
+        const float *q0 = rd->camera_R[0];
+        float *q1 = rd->camera_R[1];
+        if ((q0[0] * q1[0] + q0[1] * q1[1] + q0[2] * q1[2]) + q0[3] * q1[3] < 0) for (int i = 0; i < 4; ++i) q1[i] = -q1[i];  // the shortest path
+    }
     {  // dxCamera / dyCamera: perspective.cpp:60-63 (difference of two points), orthographic.cpp:57-58 (a transformed vector)
         Vector3f dx, dy;
         if (camera->orthographic) { dx = camera->RasterToCamera.Vec(Vector3f(1, 0, 0)); dy = camera->RasterToCamera.Vec(Vector3f(0, 1, 0)); }

@@ -193,6 +193,10 @@ struct PerspectiveCamera {  // ProjectiveCamera (core/camera.h:87-108): cameras/
     bool orthographic = false;
     bool environment = false;  // EnvironmentCamera (cameras/environment.cpp): no projection, no lens
     Transform CameraToWorld, RasterToCamera;
+    // AnimatedTransform CameraToWorld (camera.h:72, transform.h:331-362): the end transform and the two times of a camera that moves
+    Transform CameraToWorldEnd;
+    Float transformStartTime = 0, transformEndTime = 1;
+    bool animated = false;
     Float lensRadius, focalDistance, shutterOpen, shutterClose;
     std::unique_ptr<Film> film;
 };

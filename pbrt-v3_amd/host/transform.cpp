@@ -155,4 +155,56 @@ Transform Perspective(Float fov, Float n, Float f) {
     const Float cotHalf = 1 / std::tan(Radians(fov) / 2);  // [order]
     return Scale(cotHalf, cotHalf, 1) * Transform(persp);
 }
+// AnimatedTransform::Decompose, transform.cpp:1103-1142: translation off the last column, rotation by polar decomposition (R <- (R +
+// (R^T)^-1) / 2 until the rows move by less than 1e-4, at most 100 times), scale = R^-1 M; the rotation as a quaternion the way
+// Quaternion(const Transform &) builds it (quaternion.cpp:61-92).  Float arithmetic in the reference's order: the device blends these
+// numbers per camera ray and must arrive at the reference's matrices.
+void DecomposeTransform(const Matrix4x4 &m, Float T[3], Float Rq[4], Float S[9]) {
+    T[0] = m.m[0][3]; T[1] = m.m[1][3]; T[2] = m.m[2][3];
+    Matrix4x4 M = m;
+    for (int i = 0; i < 3; ++i) M.m[i][3] = M.m[3][i] = 0.f;
+    M.m[3][3] = 1.f;
+    Float norm;
+    int count = 0;
+    Matrix4x4 R = M;
+    do {
+        Matrix4x4 Rnext;
+        Matrix4x4 Rit = Inverse(Transpose(R));
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) Rnext.m[i][j] = 0.5f * (R.m[i][j] + Rit.m[i][j]);
+        norm = 0;
+        for (int i = 0; i < 3; ++i) {
+            Float n = std::abs(R.m[i][0] - Rnext.m[i][0]) + std::abs(R.m[i][1] - Rnext.m[i][1]) + std::abs(R.m[i][2] - Rnext.m[i][2]);
+            norm = std::max(norm, n);
+        }
+        R = Rnext;
+    } while (++count < 100 && norm > .0001);
+    {   // Quaternion(Transform(R)): from the trace, or from the largest diagonal entry
+        const Float trace = R.m[0][0] + R.m[1][1] + R.m[2][2];
+        if (trace > 0.f) {
+            Float s = std::sqrt(trace + 1.0f);
+            Rq[3] = s / 2.0f;
+            s = 0.5f / s;
+            Rq[0] = (R.m[2][1] - R.m[1][2]) * s;
+            Rq[1] = (R.m[0][2] - R.m[2][0]) * s;
+            Rq[2] = (R.m[1][0] - R.m[0][1]) * s;
+        } else {
+            const int nxt[3] = {1, 2, 0};
+            Float q[3];
+            int i = 0;
+            if (R.m[1][1] > R.m[0][0]) i = 1;
+            if (R.m[2][2] > R.m[i][i]) i = 2;
+            const int j = nxt[i], k = nxt[j];
+            Float s = std::sqrt((R.m[i][i] - (R.m[j][j] + R.m[k][k])) + 1.0f);
+            q[i] = s * 0.5f;
+            if (s != 0.f) s = 0.5f / s;
+            Rq[3] = (R.m[k][j] - R.m[j][k]) * s;
+            q[j] = (R.m[j][i] + R.m[i][j]) * s;
+            q[k] = (R.m[k][i] + R.m[i][k]) * s;
+            Rq[0] = q[0]; Rq[1] = q[1]; Rq[2] = q[2];
+        }
+    }
+    const Matrix4x4 Sm = Matrix4x4::Mul(Inverse(R), M);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) S[3 * i + j] = Sm.m[i][j];
+}
 }  // namespace pbrt

@@ -19,7 +19,9 @@ SCENES = ["cornell_32", "cornell_crop", "cornell_lens", "cornell_plastic", "corn
           "filter_gaussian", "filter_mitchell_crop", "filter_widebox", "mat_uber", "mat_metal", "mat_substrate", "mat_translucent", "mat_mix",
           "mat_roughglass", "sphere_light", "sphere_partial", "quadric_lights", "hlbvh_synthetic", "synthetic_n40", "sobol_cornell",
           "sobol_round_crop", "vol_fog", "vol_smoke", "vol_path_none_glass", "sobol_vol_smoke", "sampler_random", "sampler_stratified",
-          "sampler_stratified_dims", "filter_02sequence_lens", "sampler_maxmindist", "sampler_lowdisc_vol", "many_lights"]
+          "sampler_stratified_dims", "filter_02sequence_lens", "sampler_maxmindist", "sampler_lowdisc_vol", "many_lights",
+          # a moving camera: the binding hands over the REFERENCE's own decomposition of the two camera transforms (AnimatedTransform's T / R / S)
+          "camanim_translate", "camanim_rotate", "camanim_small_rotate", "camanim_times_scale", "camanim_ortho", "camanim_vol"]
 
 
 def run_binding(pkg, scene_file, out):

@@ -252,7 +252,8 @@ def test_every_golden_scene_loads_without_an_error_message(pkg):
     files = sorted(f for d in dirs for f in glob.glob(os.path.join(d, "*.pbrt")) if os.path.exists(f[:-5] + ".json"))
     assert len(files) > 100
     # scenes that ask for the error path on purpose: an absent map name / texture file / named material, with the reference's fallback
-    on_purpose = {"light_gonio_power", "light_projection", "mat_mix", "sampler_stratified_dims_tex", "sobol_tex_lens", "tex_image", "tex_image_lens"}
+    on_purpose = {"light_gonio_power", "light_projection", "mat_mix", "sampler_stratified_dims_tex", "sobol_tex_lens", "tex_image", "tex_image_lens",
+                  "camanim_lens_tex", "camanim_sobol_tex", "camanim_strat_dims_tex", "camanim_random_tex", "camanim_env"}
     for f in files:
         before = pkg.host_lib().pbrt_host_error_count()
         pkg.HostScene(f).close()
@@ -261,15 +262,15 @@ def test_every_golden_scene_loads_without_an_error_message(pkg):
         assert name in on_purpose or not reported, f"{name}: the host front end reported an Error() while loading"
 
 
-def test_animated_shapes_instances_and_cameras_are_refused_not_rendered_with_the_start_transform(pkg):
-    """The reference interpolates an AnimatedTransform per ray inside TransformedPrimitive::Intersect (primitive.cpp:76-96) and for the
-    camera (perspective.cpp:89,139); the device does not.  Such a scene is REFUSED (an Error, no frame, no image with one end of the
-    motion).  Textures and lights take the start transform in the reference itself (api.cpp WARN_IF_ANIMATED_TRANSFORM): a Warning."""
+def test_animated_shapes_and_instances_are_refused_not_rendered_with_the_start_transform(pkg):
+    """The reference interpolates an AnimatedTransform per ray inside TransformedPrimitive::Intersect (primitive.cpp:76-96); the device
+    does not.  Such a scene is REFUSED (an Error, no frame, no image with one end of the motion).  A moving CAMERA is rendered (the
+    camanim_* goldens); textures and lights take the start transform in the reference itself (api.cpp WARN_IF_ANIMATED_TRANSFORM): a Warning."""
     anim = 'ActiveTransform EndTime\nTranslate 0.3 0 0\nActiveTransform All\n'
     mini = MINI % (16, 16, 1)
     for what, txt in (("shape", mini.replace("WorldEnd", "AttributeBegin\n" + anim + 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nAttributeEnd\nWorldEnd')),
                       ("instance", mini.replace("WorldEnd", 'ObjectBegin "o"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nObjectEnd\nAttributeBegin\n' + anim + 'ObjectInstance "o"\nAttributeEnd\nWorldEnd')),
-                      ("camera", mini.replace("Camera ", anim + "Camera ", 1))):
+                      ):
         before = pkg.host_lib().pbrt_host_error_count()
         with pytest.raises(pkg.PbrtGpuError):
             pkg.HostScene(text=txt)
@@ -277,3 +278,7 @@ def test_animated_shapes_instances_and_cameras_are_refused_not_rendered_with_the
     before = pkg.host_lib().pbrt_host_error_count()
     s = pkg.HostScene(text=mini.replace("WorldEnd", "AttributeBegin\n" + anim + 'LightSource "point"\nTexture "t" "float" "checkerboard"\nAttributeEnd\nWorldEnd'))
     assert s.desc.n_lights >= 1 and pkg.host_lib().pbrt_host_error_count() == before  # the reference's own behaviour: warnings only
+    s = pkg.HostScene(text=mini.replace("Camera ", anim + "Camera ", 1))  # a moving camera: AnimatedTransform CameraToWorld, rendered
+    rd = s.render_desc()
+    assert rd.camera_animated == 1 and pkg.host_lib().pbrt_host_error_count() == before
+    assert list(rd.camera_time) == [0.0, 1.0] and abs(rd.camera_T[1][0] - rd.camera_T[0][0]) > 0.2 and list(rd.camera_R[0]) == list(rd.camera_R[1])
