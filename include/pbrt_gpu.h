@@ -531,7 +531,7 @@ static inline int pgh_box_filter_needs_gather(const PgRenderDesc *rd) {
             float u;
             for (i = 0; i < 64 && v; ++i, v >>= 1) if (v & 1) r |= (uint64_t)1 << (63 - i);
             u = (float)((double)r * 5.4210108624275222e-20);
-            if (u > u0Max) u0Max = u;
+            if (u > u0Max) { u0Max = u; sx = (float)xMax + u0Max; if (sx >= (float)(xMax + 1)) return 1; } /* one such sample decides */
         }
         for (a0 = 0; a0 <= a1Max; ++a0) { /* RadicalInverseSpecialized<3> */
             const float invBase = (float)1 / (float)3;
@@ -540,7 +540,7 @@ static inline int pgh_box_filter_needs_gather(const PgRenderDesc *rd) {
             while (a) { const uint64_t next = a / 3, digit = a - next * 3; reversedDigits = reversedDigits * 3 + digit; invBaseN = invBaseN * invBase; a = next; }
             u = (float)reversedDigits * invBaseN;
             if (u > 0.99999994f) u = 0.99999994f;
-            if (u > u1Max) u1Max = u;
+            if (u > u1Max) { u1Max = u; sy = (float)yMax + u1Max; if (sy >= (float)(yMax + 1)) return 1; }
         }
     }
     sx = (float)xMax + u0Max; sy = (float)yMax + u1Max;

@@ -37,6 +37,11 @@ def oracle(pkg):
     # keep the restatement in step with include/pbrt_gpu.h (a no-op when they are up to date)
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
     o.lib()
+    # liboracle.so (and the reference binary) compute with THIS host's libm; the goldens and the device with glibc 2.35's FMA variants
+    # (csrc/pg_libm.h).  On a host whose libm differs, a live oracle differs from the device in last bits although nothing is wrong:
+    # those comparisons are skipped there, the device-vs-golden-file tests (host-independent) still run.  INTEGRATION.md section 5.
+    if not o.host_libm_matches() and os.environ.get("PBRT_IGNORE_LIBM_MISMATCH") != "1":
+        pytest.skip("this host's libm is not the one csrc/pg_libm.h restates (another glibc, or a CPU without FMA3): live-oracle comparisons skipped")
     return o
 
 
