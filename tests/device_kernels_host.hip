@@ -68,7 +68,7 @@ long long hostdev_halton_index(const PgRenderDesc *rd, int px, int py, long long
 void hostdev_camera_ray(const PgRenderDesc *rd, float fx, float fy, float lx, float ly, float *out) {
     V3 o, d;
     float tMax;
-    camera_ray(*rd, fx, fy, lx, ly, o, d, tMax);
+    camera_ray(*rd, rd->camera_to_world, fx, fy, lx, ly, o, d, tMax);
     out[0] = o.x; out[1] = o.y; out[2] = o.z; out[3] = d.x; out[4] = d.y; out[5] = d.z; out[6] = tMax;
 }
 // SeparableBSSRDFAdapter::f with the shading kernels' own FrDielectric

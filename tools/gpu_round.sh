@@ -7,11 +7,14 @@
 #   final: quick + bench and kernel stats of the two divergent stand-ins (the bench run measures its PMC passes itself)
 TAG=${1:-r02}; MODE=${2:-quick}
 OUT=gpurun_out/$TAG
+ulimit -c 0  # a GPU core dump fills the box
 mkdir -p $OUT
 export TMPDIR=/tmp
 prof() {  # prof NAME bench-args...: kernel-trace stats of one bench run
   local name=$1; shift
-  ( timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -o trace -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-hbm-regime "$@" > $OUT/bench_prof_$name.json 2> $OUT/prof_$name.err )
+  # --no-overlap: every kernel alone on the chip, as in the serialised frame bench.py takes its per-kernel times from (the timed frames of
+  # a default run overlap any-hit with closest-hit launches: their durations under the profiler would not be the kernels' own)
+  ( timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -o trace -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-hbm-regime --no-live-pmc --no-overlap "$@" > $OUT/bench_prof_$name.json 2> $OUT/prof_$name.err )
   find $OUT/prof_$name -name '*kernel_stats*' -exec cp {} $OUT/kernel_stats_$name.csv \;
   rm -rf $OUT/prof_$name
 }
@@ -39,6 +42,14 @@ if [ "$MODE" != quick ]; then
   ( timeout 900 python bench.py --steps 2 --warmup 1 --workload divergent-vol --tris 10000000 --spp 32 --no-cpu-baseline 2> $OUT/bench_div10m_vol.err ) > $OUT/bench_div10m_vol.json; cut -c1-300 $OUT/bench_div10m_vol.json
   prof div10m_vol --workload divergent-vol --tris 10000000 --spp 32
   find $OUT -name '*counter_collection.csv' -size +4M -delete
+fi
+if [ "$MODE" = final ] || [ "$MODE" = full ]; then
+  # configs 4 / 5 over the WHOLE frame at their own spp against the reference binary's image (its fingerprint, rendered beforehand where host
+  # time is free: tools/fullsize_parity.py --reference-only), and what a 1/8 shard costs on one GPU
+  ( timeout 900 python tools/fullsize_parity.py 41 51 "--fingerprint-in=tests/golden_large/fullframe_reference_fingerprint_config{config}.json" --out=$OUT/fullframe_parity_config4_5.json > $OUT/fullframe_parity.log 2>&1 ); cut -c1-400 $OUT/fullframe_parity.log | tail -2
+  ( timeout 300 python tools/shard_timing.py > $OUT/shard_timing.json 2> $OUT/shard_timing.err ); cut -c1-600 $OUT/shard_timing.json
+  ( timeout 600 python bench.py --steps 2 --warmup 1 --grid 1582 --no-cpu-baseline --no-hbm-regime 2> $OUT/bench_5m.err ) > $OUT/bench_5m.json; cut -c1-300 $OUT/bench_5m.json
+  prof 5m --grid 1582
 fi
 if [ "$MODE" = full ]; then
   bash tools/pmc_traffic.sh $TAG/traffic_5m --steps 1 --warmup 0 --no-cpu-baseline --grid 1582 --spp 256 > $OUT/traffic_5m.log 2>&1
