@@ -121,3 +121,58 @@ def test_vector_issue_fraction_recomputes():
         assert v["achieved"] == pytest.approx(v["insts_per_launch"] * k["launches"] / (k["total_ms"] * 1e-3), rel=1e-9)
         assert v["frac"] == pytest.approx(v["achieved"] / v["peak"], rel=1e-12) and 0 < v["frac"] < 1 and 1 <= v["lanes_active_of_64"] <= 64
     assert seen >= 2
+
+
+# ---- round 5: the timed frames overlap any-hit with closest-hit launches; per-kernel figures come from one serialised frame --------------
+R05 = {"cfg3": "r05z_bench.json", "div5m": "r05z_bench_div5m.json", "div10m_vol": "r05z_bench_div10m_vol.json"}
+
+
+@pytest.mark.parametrize("tag", sorted(R05))
+def test_round5_lines_recompute(tag):
+    """kernel_ms_per_step / roofline_kernels of a round-5 line are ONE serialised frame's HIP-event times (kernel_times says so): they sum
+    to no more than that frame, every fraction recomputes and stays below 1, and `l2_memory_side` (what round 4 called hbm_side: the L2s'
+    fabric ports, Infinity-Cache hits included) is traffic / time beside the 8 TB/s yardstick."""
+    b = json.load(open(os.path.join(PROF, R05[tag])))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in b, k
+    kt = b["kernel_times"]
+    assert "every kernel alone on the chip" in kt["from"] and kt["sum_of_kernels_ms"] <= kt["serialized_frame_ms"] * 1.001
+    assert kt["sum_of_kernels_ms"] == pytest.approx(sum(b["kernel_ms_per_step"].values()), rel=1e-9)
+    assert kt["overlapped_frame_ms"] == pytest.approx(b["ms_per_step"], rel=1e-12)
+    assert b["value"] == pytest.approx(b["config"]["rays_per_sample"] * b["samples_per_s"] / 1e6, rel=1e-6)
+    assert b["roofline"]["kernel"] == b["roofline_kernels"][0]["kernel"]
+    for k in b["roofline_kernels"]:
+        achieved = k["algorithmic_bytes_per_launch"] * k["launches"] / (k["total_ms"] * 1e-3) / 1e9
+        assert achieved == pytest.approx(k["achieved"], rel=1e-9) and k["frac"] == pytest.approx(k["achieved"] / k["peak"], rel=1e-12) and 0 < k["frac"] < 1
+        assert "hbm_side" not in k
+        m = k.get("l2_memory_side")
+        if m:
+            assert m["achieved"] == pytest.approx(k["traffic"] * k["launches"] / (k["total_ms"] * 1e-3) / 1e9, rel=1e-9) and m["compared_with"] == 8000.0
+            assert "Infinity-Cache hits included" in m["note"] and m["source"].startswith("live")
+
+
+def test_round5_event_timing_agrees_with_the_rocprof_summary():
+    """profiles/r05z_kernel_stats_cfg3.csv: rocprofv3 --kernel-trace --stats of `bench.py --no-overlap` (every kernel alone, as in the
+    serialised frame the line's per-kernel times come from) gives the same average duration for the dominant kernel."""
+    rows = {r["Name"]: r for r in csv.DictReader(open(os.path.join(PROF, "r05z_kernel_stats_cfg3.csv")))}
+    hit = [r for n, r in rows.items() if n.startswith("void k_trace<0,")]
+    avg = sum(float(r["TotalDurationNs"]) for r in hit) / sum(int(r["Calls"]) for r in hit) / 1e6
+    b = json.load(open(os.path.join(PROF, R05["cfg3"])))
+    assert avg == pytest.approx(b["roofline"]["avg_launch_ms"], rel=0.05)
+    h = b["roofline"]["hbm_regime"]
+    assert h["bound"] == "hbm" and h["frac"] == pytest.approx(h["achieved"] / 8000.0, rel=1e-12) and 0.40 <= h["frac"] < 1
+    assert "l2_memory_side" in h and "hbm_side" not in h
+
+
+def test_round5_whole_frame_parity_of_configs_4_and_5():
+    """profiles/r05z_fullframe_parity_config4_5.json: the device's whole 1920x1080 frame of both stand-ins at their own 256 / 128 spp against the
+    fingerprint of the reference binary's image (tests/golden_large/fullframe_reference_fingerprint_config{41,51}.json)."""
+    res = json.load(open(os.path.join(PROF, "r05z_fullframe_parity_config4_5.json")))
+    assert [r["config"] for r in res] == [41, 51]
+    for r in res:
+        fp = json.load(open(os.path.join(ROOT, "tests", "golden_large", f"fullframe_reference_fingerprint_config{r['config']}.json")))
+        assert r["same_scene_file"] and r["sha256_equal"] and r["tiles_differing"] == 0 and r["pixels_differing"] == 0 and r["window"] is None
+        assert r["compared_pixels"] == 1920 * 1080 and r["spp"] == (256 if r["config"] == 41 else 128) and len(fp["tile_crc32"]) == r["tiles"] == 8160
+        for c in ("camera_rays", "closest_rays", "shadow_rays"):
+            assert r["device_counters"][c] == fp["reference_counters"][c]
+
