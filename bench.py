@@ -586,6 +586,11 @@ def main():
         workload = describe(args, m.scene)
         # memory-side traffic, L2 hit rates and vector-instruction counts of the hot kernels: measured by this run (child rocprofv3 --pmc
         # passes over one frame each, after the timed region) unless --no-live-pmc / N > 1 / an emulated device
+        # (this process's device scenes go first: a child pass renders the same workload in a process of its own, and with 100+ GB of
+        # buffers still held here pg_render's k_material lists would not fit there -- it would measure the k_shade<2> fallback instead)
+        m.gs.close()
+        if hbm is not None: hbm.gs.close()
+        if not EMULATED: torch.cuda.empty_cache()
         live, live_why, live_hbm = None, "--no-live-pmc", None
         wl_args = ["--workload", args.workload, "--grid", str(args.grid), "--tris", str(args.tris), "--xres", str(args.xres), "--yres", str(args.yres),
                    "--spp", str(args.spp), "--filter", args.filter]
@@ -643,6 +648,10 @@ def main():
             "kernel_ms_per_step": {**{k["kernel"].split(" ")[0]: k["total_ms"] / ksteps for k in kernels},
                                    **{k[:-3]: v / ksteps for k, v in other_ms.items()}},
         }
+        if live:
+            # the counters of this run's own PMC passes, kernel by kernel (the shading slot's roofline merges k_shade_order + k_material + k_shade<.>)
+            result["pmc_by_kernel"] = {k.replace("void ", "")[:48]: {f: (round(v, 4) if isinstance(v, float) else v) for f, v in e.items()} for k, e in sorted(live.items())
+                                       if e.get("fetch_KiB_per_launch", 0) * e.get("launches", 1) > 1e5}
         if m.serial is not None:
             result["kernel_times"] = {
                 "from": "ONE extra frame after the timed region with every kernel alone on the chip (PG_OVERLAP_SHADOW=0): kernel_ms_per_step, roofline and "
