@@ -234,6 +234,33 @@ def random_scene_pixel_sampler(seed):
     return out
 
 
+def random_scene_moving_camera(seed):
+    """One of the random scenes above under a camera that moves (AnimatedTransform CameraToWorld, interpolated at every camera ray's
+    time): a random end-of-motion transform -- translation, a rotation that is sometimes tiny (Slerp's normalised-lerp branch), sometimes a
+    scale --, TransformTimes that lie inside, across or outside the shutter interval, and every sampler family the front end has."""
+    rng = np.random.default_rng(1000 + seed)
+    gen = (random_scene, random_scene_ext, random_scene_vol, random_scene_pixel_sampler)[seed % 4]
+    text = gen(seed)
+    motion = ["Translate %.6g %.6g %.6g" % tuple(rng.normal(size=3) * 0.6)]
+    if seed % 3 != 2:
+        angle = rng.choice([0.7, 6.0, 25.0, 70.0]) * (1 if rng.random() < 0.5 else -1)
+        motion.append("Rotate %.6g %.6g %.6g %.6g" % (angle, *(rng.normal(size=3) + np.array([0, 1e-3, 0]))))
+    if seed % 5 == 0:
+        motion.append("Scale %.6g %.6g %.6g" % tuple(1 + 0.2 * rng.random(3)))
+    t0, t1 = sorted(rng.random(2) * 1.4 - 0.2)
+    times = "TransformTimes %.6g %.6g\n" % (t0, max(t1, t0 + 1e-3)) if seed % 2 else ""
+    shutter = ' "float shutteropen" [ %.6g ] "float shutterclose" [ %.6g ]' % (0.1 * (seed % 3), 1 - 0.15 * (seed % 4)) if seed % 3 else ""
+    assert "Camera " in text
+    head, rest = text.split("Camera ", 1)
+    line, tail = rest.split("\n", 1)
+    return head + times + "ActiveTransform EndTime\n" + "\n".join(motion) + "\nActiveTransform All\nCamera " + line + shutter + "\n" + tail
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_scene_with_a_moving_camera(gpu, oracle, seed):
+    check_scene(gpu, oracle, random_scene_moving_camera(seed), seed)
+
+
 @pytest.mark.parametrize("seed", range(60))
 def test_random_scene_under_a_batched_pixel_sampler(gpu, oracle, seed):
     check_scene(gpu, oracle, random_scene_pixel_sampler(seed), seed)
