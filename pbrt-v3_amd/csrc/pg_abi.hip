@@ -59,6 +59,7 @@ struct PgScene {
     int capacity = 0;
     DeviceBuffer sceneCopy;  // DScene::self
     DeviceBuffer tsOverflow;  // tsBatched: the flag a draw beyond the sample arrays raises
+    DeviceBuffer bxdfsPk, matPk;     // the constant BxDF lists as PkLobe records + where each material's starts (k_shade<3>)
     DeviceBuffer matLobes, matHead;  // k_material: the BxDF lists and shading frames of the hits on materials with textured parameters (MatPre)
     int matStride = 0;               // the largest such list of this scene, 0: materials are evaluated inside the shading kernel
     DeviceBuffer shadeOrder, primClass, volPre;  // k_shade_order: the order buffer of the main queue, the primitives' material classes, volpath's pre-drawn medium samples
@@ -720,10 +721,35 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
                 }
                 return PG_MAX_BXDFS;
             };
+            // in RECORDS of 48 B (LobeBsdfT, pg_kernels.hip): one per BxDF, two where the hit's material is a mix (the ScaledBxDF factors)
             int stride = 1;
             for (int i = 0; i < desc->n_materials; ++i)
-                if (desc->materials[i].type == PG_MAT_TEXTURED) stride = std::max(stride, lobes(i, 0));
+                if (desc->materials[i].type == PG_MAT_TEXTURED)
+                    stride = std::max(stride, lobes(i, 0) * (desc->textured[desc->materials[i].textured_index].kind == PG_KIND_MIX ? 2 : 1));
             s->matStride = stride;
+            // the constant lists once more as PkLobe records, for the kernel that reads k_material's (k_shade<3>)
+            std::vector<float> pk;
+            std::vector<int2> matPk((size_t)desc->n_materials, make_int2(0, 1));
+            for (int i = 0; i < desc->n_materials; ++i) {
+                const PgMaterial &m = desc->materials[i];
+                if (m.type == PG_MAT_TEXTURED || m.n_bxdfs <= 0 || !desc->bxdfs) continue;
+                bool scaled = false;
+                for (int k = 0; k < m.n_bxdfs; ++k) scaled |= desc->bxdfs[m.first_bxdf + k].n_scales > 0;
+                matPk[i] = make_int2((int)(pk.size() / 12), scaled ? 2 : 1);
+                for (int k = 0; k < m.n_bxdfs; ++k) {
+                    const PgBxDF &b = desc->bxdfs[m.first_bxdf + k];
+                    pk.resize(pk.size() + (scaled ? 24 : 12));
+                    float *q = pk.data() + pk.size() - (scaled ? 24 : 12);
+                    pg_pack_lobe(b, q);
+                    if (scaled) pg_pack_lobe_scales(b, q + 12);
+                }
+            }
+            if (pk.empty()) pk.resize(12, 0.f);
+            HIP_TRY_S(s->bxdfsPk.alloc(pk.size() * sizeof(float)));
+            HIP_TRY_S(hipMemcpy(s->bxdfsPk.p, pk.data(), s->bxdfsPk.bytes, hipMemcpyHostToDevice));
+            HIP_TRY_S(s->matPk.alloc(matPk.size() * sizeof(int2)));
+            HIP_TRY_S(hipMemcpy(s->matPk.p, matPk.data(), s->matPk.bytes, hipMemcpyHostToDevice));
+            d.bxdfsPk = (const float4 *)s->bxdfsPk.p; d.matPk = (const int2 *)s->matPk.p;
         }
     }
     {   // shading classes (k_shade_order): scenes whose materials evaluate textures / BxDF lists shade grouped by material.  Few
@@ -948,11 +974,12 @@ static int ensureWorkBuffers(PgScene *s, int capacity) {
     if (s->matStride > 0) {  // k_material's lists and frames, one set per main-queue entry; no room: the shading kernel evaluates materials itself
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) { freeB = 0; (void)hipGetLastError(); }
-        const size_t want = n * ((size_t)s->matStride * sizeof(PgBxDF) + 2 * sizeof(float4)), have = s->matLobes.bytes + s->matHead.bytes;
+        const size_t recBytes = 3 * sizeof(float4);  // one packed BxDF record
+        const size_t want = n * ((size_t)s->matStride * recBytes + 2 * sizeof(float4)), have = s->matLobes.bytes + s->matHead.bytes;
         s->matLobes.release(); s->matHead.release();
         // (everything else of this function and the integrator's own state -- about 600 B per slot -- is still to be allocated)
         const bool fits = want + n * 700 + ((size_t)1 << 30) <= freeB + have;
-        if (!fits || s->matLobes.alloc(n * (size_t)s->matStride * sizeof(PgBxDF)) != hipSuccess || s->matHead.alloc(n * 2 * sizeof(float4)) != hipSuccess) {
+        if (!fits || s->matLobes.alloc(n * (size_t)s->matStride * recBytes) != hipSuccess || s->matHead.alloc(n * 2 * sizeof(float4)) != hipSuccess) {
             s->matLobes.release(); s->matHead.release(); (void)hipGetLastError();
         }
     }
@@ -1180,7 +1207,7 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
     // shade the entries that waited for them (one host round trip per launch while the table warms up; none once every
     // voxel the image touches exists -- the tables stay with the scene).
     rp.retryList = (int *)s->retryList.p;
-    if (s->matLobes.p && s->matHead.p) { rp.matPre.lobes = (PgBxDF *)s->matLobes.p; rp.matPre.head = (float4 *)s->matHead.p; rp.matPre.stride = s->matStride; }
+    if (s->matLobes.p && s->matHead.p) { rp.matPre.lobes = (float4 *)s->matLobes.p; rp.matPre.head = (float4 *)s->matHead.p; rp.matPre.stride = s->matStride; }
     auto settleLightTables = [&](const std::function<void()> &reshade) -> int {
         if (!s->d.sparseLights) return PG_OK;
         int cnt[2] = {0, 0};

@@ -4,6 +4,7 @@
 #define PG_KERNELS_H
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include "../../include/pbrt_gpu.h"
 
 // Per-triangle flag bits stored in tris[3*i].w, on top of PG_TRI_*.
@@ -102,6 +103,10 @@ struct DScene {
     const PgMedium *media;               // HomogeneousMedium table; triMediumIn/Out[k] = the primitive's MediumInterface (-1 = none), or nullptr
     const int *triMediumIn, *triMediumOut;
     const PgBxDF *bxdfs;      // the materials' BxDF lists (PgMaterial.first_bxdf / n_bxdfs)
+    // the same lists as PkLobe records for k_shade<3> (scenes whose textured materials are evaluated ahead, MatPre): material m's list starts
+    // at record matPk[m].x and takes matPk[m].y (1 or 2: its lobes carry ScaledBxDF factors) records per lobe; nullptr otherwise
+    const float4 *bxdfsPk;
+    const int2 *matPk;
     // subsurface scattering (ABI 24): materialBssrdf[m] >= 0 = ComputeScatteringFunctions of material m also sets si->bssrdf
     const PgBSSRDF *bssrdfs;
     const int *materialBssrdf;
@@ -216,13 +221,45 @@ struct SssState {
     RayQueue qjob;     // the first probe ray of every path that entered this branch at the current bounce (appended by k_shade)
 };
 
+// One BxDF of a list in 48 bytes: what k_material writes for a hit on a material with textured parameters and what k_shade<3> reads --
+// and, packed once at pg_scene_create, the constant lists of the other materials for the same kernel (DScene::bxdfsPk).  The members carry
+// PgBxDF's names over a layout that depends on the type, so the BxDF functions (lobe_f, lobe_pdf, lobe_sample_f, lobe_fresnel: templates on
+// the record type) read each field where it is used:
+//   hdr = type | fresnel << 4 | n_scales << 6        R
+//   T | the conductor's eta | OrenNayar's A, B       alpha_x
+//   eta_a, eta_b | the conductor's k                 alpha_y
+// Every field a BxDF of that type reads, nothing else.  A MixMaterial's ScaledBxDF factors (scale[0 .. 2], nine floats) take a record of their
+// own BEHIND the lobe's; a hit's lobes all have one or none has.
+struct PkLobe {
+    uint32_t hdr;
+    float R[3];
+    union { float T[3]; float cond_eta[3]; struct { float on_a, on_b, on_unused; }; };
+    float alpha_x;
+    union { struct { float eta_a, eta_b, eta_unused; }; float cond_k[3]; };
+    float alpha_y;
+};
+static_assert(sizeof(PkLobe) == 48, "PkLobe is three float4");
+__host__ __device__ inline void pg_pack_lobe(const PgBxDF &b, float *q) {  // q[12]
+    const uint32_t hdr = (uint32_t)b.type | ((uint32_t)b.fresnel << 4) | ((uint32_t)b.n_scales << 6);
+    memcpy(&q[0], &hdr, 4);
+    q[1] = b.R[0]; q[2] = b.R[1]; q[3] = b.R[2];
+    q[7] = b.alpha_x; q[11] = b.alpha_y;
+    if (b.type == PG_BXDF_OREN_NAYAR) { q[4] = b.on_a; q[5] = b.on_b; q[6] = 0.f; q[8] = b.eta_a; q[9] = b.eta_b; q[10] = 0.f; }
+    else if (b.fresnel == PG_FRESNEL_CONDUCTOR) { for (int c = 0; c < 3; ++c) { q[4 + c] = b.cond_eta[c]; q[8 + c] = b.cond_k[c]; } }
+    else { for (int c = 0; c < 3; ++c) q[4 + c] = b.T[c]; q[8] = b.eta_a; q[9] = b.eta_b; q[10] = 0.f; }
+}
+__host__ __device__ inline void pg_pack_lobe_scales(const PgBxDF &b, float *q) {  // q[12]: the record behind the lobe's
+    for (int i = 0; i < PG_MAX_BXDF_SCALES; ++i) for (int c = 0; c < 3; ++c) q[3 * i + c] = b.scale[i][c];
+    q[9] = q[10] = q[11] = 0.f;
+}
+
 // Materials evaluated ahead of the shading launch (k_material, pg_kernels.hip): for every main-queue entry whose hit has a
 // material with textured parameters (PG_MAT_TEXTURED) and whose path is still alive, Material::ComputeScatteringFunctions' outputs
 // -- the BxDF list, BSDF::eta and the shading frame Material::Bump leaves -- at the ENTRY's index (the index of its hit record):
-//   head[2 e] = (shading.n, BSDF::eta)   head[2 e + 1] = (shading.dpdu, number of BxDFs as int bits)   lobes[e * stride + k]
-// stride = the scene's largest list (PgScene: counted per material kind, <= PG_MAX_BXDFS).  lobes == nullptr: the scene has no
+//   head[2 e] = (shading.n, BSDF::eta)   head[2 e + 1] = (shading.dpdu, number of BxDFs | 0x100 for a mix, as int bits)   lobes[(e * stride + r) * 3 ..]
+// stride = the records the scene's largest list needs (PgScene: counted per material kind, <= PG_MAX_BXDFS lobes, two records per lobe of a mix).  lobes == nullptr: the scene has no
 // such material, or the buffers did not fit -- the shading kernel then evaluates materials itself (k_shade<2, .>).
-struct MatPre { PgBxDF *lobes; float4 *head; int stride; };
+struct MatPre { float4 *lobes; float4 *head; int stride; };  // lobes: packed 48-B records (LobeBsdfT, pg_kernels.hip), `stride` RECORDS of three float4 per entry
 
 #define PG_META_SPECULAR 0x10000
 #define PG_META_DONE 0x20000

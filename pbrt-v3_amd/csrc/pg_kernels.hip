@@ -1090,17 +1090,35 @@ PG_DEV Spec bsdf_sample_f(const Bsdf &b, V3 woWorld, V3 &wiWorld, float u0, floa
 // `types`: the PgBxDFType of lobes[i] in bits 4i .. 4i+3, `scaled`: bit i = lobes[i] has ScaledBxDF wrappers -- read once when the
 // list is bound (lbsdf_bind), so that BSDF::NumComponents / the component choice of Sample_f / the matching tests of f and Pdf are
 // register arithmetic instead of a chain of dependent loads through the lane's list pointer
-struct LobeBsdf { V3 ns, ng, ss, ts; const PgBxDF *lobes; int n; float eta; unsigned types, scaled; };
-PG_DEV void lbsdf_bind(LobeBsdf &b, const PgBxDF *lobes, int n, float eta) {
-    b.lobes = lobes; b.n = n; b.eta = eta; b.types = 0; b.scaled = 0;
+// LB: what a list is made of.  PgBxDF (120 B, the ABI's record: the scene's constant lists, the shading kernel's own copies) or PkLobe,
+// the 48-B record k_material writes and k_shade<3> reads (pg_kernels.h) -- the same member NAMES over a type-dependent layout, so that
+// lobe_f / lobe_pdf / lobe_sample_f / lobe_fresnel below are ONE text for both and read each field where it is used.  A MixMaterial's
+// ScaledBxDF factors take a record of their own behind a PkLobe; all lobes of a hit have them or none has (the hit's material is a mix or
+// it is not): recStride = 2 or 1 records per lobe.  (Round 5: the lists were up to 5 x 120 B + 32 B per textured hit, written by k_material
+// and read back line by line -- 4.9 x the slot's algorithmic bytes at the L2s' memory side.)
+template <class LB> struct LobeBsdfT { V3 ns, ng, ss, ts; const LB *lobes; int recStride; int n; float eta; unsigned types, scaled; };
+typedef LobeBsdfT<PgBxDF> LobeBsdf;
+PG_DEV int lobe_fresnel_kind(const PgBxDF &b) { return b.fresnel; }
+PG_DEV int lobe_fresnel_kind(const PkLobe &b) { return (int)((b.hdr >> 4) & 3u); }
+PG_DEV void lbsdf_bind(LobeBsdfT<PgBxDF> &b, const PgBxDF *lobes, int n, float eta) {
+    b.lobes = lobes; b.recStride = 1; b.n = n; b.eta = eta; b.types = 0; b.scaled = 0;
     for (int i = 0; i < n; ++i) {
         b.types |= (unsigned)lobes[i].type << (4 * i);
         b.scaled |= (lobes[i].n_scales > 0 ? 1u : 0u) << i;
     }
 }
-PG_DEV int lbsdf_lobe(const LobeBsdf &b, int i) { return (int)((b.types >> (4 * i)) & 15u); }
-PG_DEV V3 world_to_local(const LobeBsdf &b, V3 v) { return mk(dot(v, b.ss), dot(v, b.ts), dot(v, b.ns)); }
-PG_DEV V3 local_to_world(const LobeBsdf &b, V3 v) {
+PG_DEV void lbsdf_bind(LobeBsdfT<PkLobe> &b, const PkLobe *rec, int n, float eta, int recStride) {
+    b.lobes = rec; b.recStride = recStride; b.n = n; b.eta = eta; b.types = 0; b.scaled = 0;
+    for (int i = 0; i < n; ++i) {
+        const unsigned hdr = rec[i * recStride].hdr;
+        b.types |= (hdr & 15u) << (4 * i);
+        b.scaled |= (((hdr >> 6) & 3u) > 0 ? 1u : 0u) << i;
+    }
+}
+template <class LB> PG_DEV const LB &lobe_at(const LobeBsdfT<LB> &b, int i) { return b.lobes[i * b.recStride]; }
+template <class LB> PG_DEV int lbsdf_lobe(const LobeBsdfT<LB> &b, int i) { return (int)((b.types >> (4 * i)) & 15u); }
+template <class LB> PG_DEV V3 world_to_local(const LobeBsdfT<LB> &b, V3 v) { return mk(dot(v, b.ss), dot(v, b.ts), dot(v, b.ns)); }
+template <class LB> PG_DEV V3 local_to_world(const LobeBsdfT<LB> &b, V3 v) {
     return mk(b.ss.x * v.x + b.ts.x * v.y + b.ns.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ns.y * v.z,
               b.ss.z * v.x + b.ts.z * v.y + b.ns.z * v.z);
 }
@@ -1182,13 +1200,14 @@ PG_DEV int lobe_type(int type) {  // the BxDFType each constructor passes to BxD
     return 0;
 }
 PG_DEV bool lobe_matches(int lobe, int t) { const int type = lobe_type(lobe); return (type & t) == type; }  // reflection.h:225
-PG_DEV Spec lobe_fresnel(const PgBxDF &b, float cosI) {  // Fresnel::Evaluate, reflection.cpp:120-135
-    if (b.fresnel == PG_FRESNEL_DIELECTRIC) return sp(fr_dielectric(cosI, b.eta_a, b.eta_b));
-    if (b.fresnel == PG_FRESNEL_CONDUCTOR) return fr_conductor(fabsf(cosI), sp(1.f), sp_of(b.cond_eta), sp_of(b.cond_k));
+template <class LB> PG_DEV Spec lobe_fresnel(const LB &b, float cosI) {  // Fresnel::Evaluate, reflection.cpp:120-135
+    const int kind = lobe_fresnel_kind(b);
+    if (kind == PG_FRESNEL_DIELECTRIC) return sp(fr_dielectric(cosI, b.eta_a, b.eta_b));
+    if (kind == PG_FRESNEL_CONDUCTOR) return fr_conductor(fabsf(cosI), sp(1.f), sp_of(b.cond_eta), sp_of(b.cond_k));
     return sp(1.f);
 }
 PG_DEV float pow5f(float v) { return (v * v) * (v * v) * v; }
-PG_DEV Spec lobe_f(const PgBxDF &b, int lobe, V3 wo, V3 wi) {  // BxDF::f of the wrapped BxDF (lobe = b.type), local frame
+template <class LB> PG_DEV Spec lobe_f(const LB &b, int lobe, V3 wo, V3 wi) {  // BxDF::f of the wrapped BxDF (lobe = b.type), local frame
     const float ax = b.alpha_x, ay = b.alpha_y;
     switch (lobe) {
     case PG_BXDF_LAMBERT_R: return sp_of(b.R) * PG_INVPI;  // reflection.cpp:178-180
@@ -1245,7 +1264,7 @@ PG_DEV Spec lobe_f(const PgBxDF &b, int lobe, V3 wo, V3 wi) {  // BxDF::f of the
     }
     return sp(0);  // specular BxDFs: f() = 0
 }
-PG_DEV float lobe_pdf(const PgBxDF &b, int lobe, V3 wo, V3 wi) {
+template <class LB> PG_DEV float lobe_pdf(const LB &b, int lobe, V3 wo, V3 wi) {
     const float ax = b.alpha_x, ay = b.alpha_y;
     switch (lobe) {
     case PG_BXDF_LAMBERT_R: case PG_BXDF_OREN_NAYAR: return same_hemisphere(wo, wi) ? fabsf(wi.z) * PG_INVPI : 0;  // :392-394
@@ -1276,7 +1295,7 @@ PG_DEV float lobe_pdf(const PgBxDF &b, int lobe, V3 wo, V3 wi) {
 // BxDF::Sample_f of the wrapped BxDF; pdf keeps the caller's 0 on the reference's early `return 0` paths.  wantF = false: the
 // value of a NON-specular BxDF is not computed (0 is returned) -- BSDF::Sample_f throws it away and sums f() over all matching
 // BxDFs instead (reflection.cpp:768-775); direction, pdf and the specular BxDFs' values are what they always are
-PG_DEV Spec lobe_sample_f(const PgBxDF &b, int lobe, V3 wo, V3 &wi, float u0, float u1, float &pdf, int &sampledType, bool wantF = true) {
+template <class LB> PG_DEV Spec lobe_sample_f(const LB &b, int lobe, V3 wo, V3 &wi, float u0, float u1, float &pdf, int &sampledType, bool wantF = true) {
     const float ax = b.alpha_x, ay = b.alpha_y;
     switch (lobe) {
     case PG_BXDF_LAMBERT_R: case PG_BXDF_OREN_NAYAR:  // BxDF::Sample_f, :383-390
@@ -1360,18 +1379,28 @@ PG_DEV Spec lobe_scale(const PgBxDF &b, Spec f) {  // ScaledBxDF, reflection.cpp
     for (int i = 0; i < b.n_scales; ++i) f = sp_of(b.scale[i]) * f;
     return f;
 }
-PG_DEV int lbsdf_num_components(const LobeBsdf &b, int flags) {  // reflection.cpp:672-678
+PG_DEV Spec lobe_scale(const PkLobe &b, Spec f) {  // the factors: nine floats in the record behind the lobe's
+    const float *sc = reinterpret_cast<const float *>(&b + 1);
+    const int n = (int)((b.hdr >> 6) & 3u);
+    for (int i = 0; i < n; ++i) f = sp_of(sc + 3 * i) * f;
+    return f;
+}
+template <class LB> PG_DEV int lbsdf_num_components(const LobeBsdfT<LB> &b, int flags) {  // reflection.cpp:672-678
     int num = 0;
     for (int i = 0; i < b.n; ++i) if (lobe_matches(lbsdf_lobe(b, i), flags)) ++num;
     return num;
 }
-PG_DEV Spec lbsdf_scaled(const LobeBsdf &b, int i, Spec f) { return ((b.scaled >> i) & 1u) ? lobe_scale(b.lobes[i], f) : f; }
+template <class LB> PG_DEV Spec lbsdf_scaled(const LobeBsdfT<LB> &b, int i, Spec f) {
+    if (!((b.scaled >> i) & 1u)) return f;
+    const auto &L = lobe_at(b, i);
+    return lobe_scale(L, f);
+}
 // BxDF::f and BxDF::Pdf of one BxDF for the same pair of directions.  Each value is what lobe_f / lobe_pdf compute -- the same
 // operations in the same order --, but the microfacet BxDFs' half vector, D(wh) and Lambda(wo) are computed once for both (a path
 // vertex asks for f AND pdf of the other matching BxDFs inside both of its BSDF::Sample_f calls.  For the light's direction BSDF::f and
 // BSDF::Pdf stay two walks: fused there as well the kernel gained nothing on microfacet scenes and lost 20 % on an all-Lambert one --
 // a matter of what the register allocator makes of it, profiles/r04l_*).
-PG_DEV void lobe_f_pdf(const PgBxDF &b, int lobe, V3 wo, V3 wi, bool wantF, bool wantPdf, Spec &f, float &pdf) {
+template <class LB> PG_DEV void lobe_f_pdf(const LB &b, int lobe, V3 wo, V3 wi, bool wantF, bool wantPdf, Spec &f, float &pdf) {
     const float ax = b.alpha_x, ay = b.alpha_y;
     f = sp(0); pdf = 0;
     switch (lobe) {
@@ -1412,21 +1441,21 @@ PG_DEV void lobe_f_pdf(const PgBxDF &b, int lobe, V3 wo, V3 wi, bool wantF, bool
     if (wantF) f = lobe_f(b, lobe, wo, wi);
     if (wantPdf) pdf = lobe_pdf(b, lobe, wo, wi);
 }
-PG_DEV Spec lbsdf_f_local(const LobeBsdf &b, V3 wo, V3 wi, bool reflect, int flags) {
+template <class LB> PG_DEV Spec lbsdf_f_local(const LobeBsdfT<LB> &b, V3 wo, V3 wi, bool reflect, int flags) {
     Spec f = sp(0);
     for (int i = 0; i < b.n; ++i) {
         const int lobe = lbsdf_lobe(b, i), type = lobe_type(lobe);
         if ((type & flags) == type && ((reflect && (type & PG_BSDF_REFLECTION)) || (!reflect && (type & PG_BSDF_TRANSMISSION))))
-            f = f + lbsdf_scaled(b, i, lobe_f(b.lobes[i], lobe, wo, wi));
+            { const auto &L = lobe_at(b, i); f = f + lbsdf_scaled(b, i, lobe_f(L, lobe, wo, wi)); }
     }
     return f;
 }
-PG_DEV Spec lbsdf_f(const LobeBsdf &b, V3 woW, V3 wiW, int flags) {  // reflection.cpp:680-693
+template <class LB> PG_DEV Spec lbsdf_f(const LobeBsdfT<LB> &b, V3 woW, V3 wiW, int flags) {  // reflection.cpp:680-693
     V3 wi = world_to_local(b, wiW), wo = world_to_local(b, woW);
     if (wo.z == 0) return sp(0);
     return lbsdf_f_local(b, wo, wi, dot(wiW, b.ng) * dot(woW, b.ng) > 0, flags);
 }
-PG_DEV float lbsdf_pdf(const LobeBsdf &b, V3 woW, V3 wiW, int flags) {  // reflection.cpp:781-796
+template <class LB> PG_DEV float lbsdf_pdf(const LobeBsdfT<LB> &b, V3 woW, V3 wiW, int flags) {  // reflection.cpp:781-796
     if (b.n == 0) return 0.f;
     V3 wo = world_to_local(b, woW), wi = world_to_local(b, wiW);
     if (wo.z == 0) return 0.f;
@@ -1434,12 +1463,12 @@ PG_DEV float lbsdf_pdf(const LobeBsdf &b, V3 woW, V3 wiW, int flags) {  // refle
     int matchingComps = 0;
     for (int i = 0; i < b.n; ++i) {
         const int lobe = lbsdf_lobe(b, i);
-        if (lobe_matches(lobe, flags)) { ++matchingComps; pdf += lobe_pdf(b.lobes[i], lobe, wo, wi); }
+        if (lobe_matches(lobe, flags)) { ++matchingComps; const auto &L = lobe_at(b, i); pdf += lobe_pdf(L, lobe, wo, wi); }
     }
     return matchingComps > 0 ? pdf / matchingComps : 0.f;
 }
 // BSDF::Sample_f, reflection.cpp:714-779: returns f, pdf = 0 when there is no sample
-PG_DEV Spec lbsdf_sample_f(const LobeBsdf &b, V3 woWorld, V3 &wiWorld, float u0, float u1, float &pdf, int flags, int &sampledType) {
+template <class LB> PG_DEV Spec lbsdf_sample_f(const LobeBsdfT<LB> &b, V3 woWorld, V3 &wiWorld, float u0, float u1, float &pdf, int flags, int &sampledType) {
     const int matchingComps = lbsdf_num_components(b, flags);
     sampledType = 0;
     pdf = 0;
@@ -1449,7 +1478,7 @@ PG_DEV Spec lbsdf_sample_f(const LobeBsdf &b, V3 woWorld, V3 &wiWorld, float u0,
     int chosen = 0, count = comp;
     for (int i = 0; i < b.n; ++i)
         if (lobe_matches(lbsdf_lobe(b, i), flags) && count-- == 0) { chosen = i; break; }
-    const PgBxDF &bxdf = b.lobes[chosen];
+    const auto &bxdf = lobe_at(b, chosen);
     const int chosenLobe = lbsdf_lobe(b, chosen);
     const float uR0 = pmin(u0 * matchingComps - comp, PG_ONE_MINUS_EPS);
     V3 wi = mk(0, 0, 0), wo = world_to_local(b, woWorld);
@@ -1470,7 +1499,7 @@ PG_DEV Spec lbsdf_sample_f(const LobeBsdf &b, V3 woWorld, V3 &wiWorld, float u0,
             if (!(wantPdf || wantF)) continue;
             Spec fi;
             float pi;
-            lobe_f_pdf(b.lobes[i], lobe, wo, wi, wantF, wantPdf, fi, pi);
+            { const auto &L = lobe_at(b, i); lobe_f_pdf(L, lobe, wo, wi, wantF, wantPdf, fi, pi); }
             if (wantPdf) pdf += pi;
             if (wantF) f = f + lbsdf_scaled(b, i, fi);
         }
@@ -1494,19 +1523,43 @@ PG_DEV void lobe_tr(PgBxDF &b, float ax, float ay) { b.alpha_x = pmax(0.001f, ax
 // Material::ComputeScatteringFunctions of material `mat` at this hit (materials/): appends its BxDFs to out[n...]; eta receives
 // BSDF::eta.  D bounds the nesting of mix materials; cap = the room in out[] (PG_MAX_BXDFS, or the scene's largest list when the
 // list goes to k_material's buffer).
-template <int D, int W = 0> struct MatEval {
-    static PG_DEV_CALL void run(const DScene &sc, int mat, const TexHit &h, PgBxDF *out, int &n, float &eta, int capArg) {
+// Where MatEval puts a BxDF list: an array of PgBxDFs (the shading kernel's own, MODE 2) or k_material's packed records (LobeBsdfT)
+struct LobeOutRaw {
+    PgBxDF *p;
+    PG_DEV void put(int i, const PgBxDF &b) const { p[i] = b; }
+    PG_DEV void add_scale(int i, Spec s) const { if (p[i].n_scales < PG_MAX_BXDF_SCALES) { lobe_set(p[i].scale[p[i].n_scales], s); p[i].n_scales++; } }
+};
+struct LobeOutPacked {
+    float4 *rec;
+    int recStride;  // 2: the hit's material is a mix, every lobe is followed by the record of its scale factors
+    PG_DEV void put(int i, const PgBxDF &b) const {
+        float *q = reinterpret_cast<float *>(rec + 3 * i * recStride);
+        pg_pack_lobe(b, q);
+        if (recStride == 2) pg_pack_lobe_scales(b, q + 12);
+    }
+    PG_DEV void add_scale(int i, Spec s) const {  // ScaledBxDF around lobe i (mixmat.cpp:60-65): the next free factor of its scale record
+        float4 *q = rec + 3 * i * recStride;
+        const unsigned hdr = __float_as_uint(q[0].x), ns = (hdr >> 6) & 3u;
+        if (ns < PG_MAX_BXDF_SCALES) {
+            float *f = reinterpret_cast<float *>(q + 3) + 3 * ns;
+            f[0] = s.r; f[1] = s.g; f[2] = s.b;
+            q[0].x = __uint_as_float(hdr + (1u << 6));
+        }
+    }
+};
+template <int D, int W = 0, class OUT = LobeOutRaw> struct MatEval {
+    static PG_DEV_CALL void run(const DScene &sc, int mat, const TexHit &h, OUT out, int &n, float &eta, int capArg) {
         const int cap = W == 0 ? PG_MAX_BXDFS : capArg;  // (the shading kernel's own copies: a constant, no register held for it)
         const PgMaterial &m = sc.materials[mat];
         if (m.type != PG_MAT_TEXTURED) {  // constant parameters: the list the host built
-            for (int i = 0; i < m.n_bxdfs && n < cap; ++i) out[n++] = sc.bxdfs[m.first_bxdf + i];
+            for (int i = 0; i < m.n_bxdfs && n < cap; ++i) out.put(n++, sc.bxdfs[m.first_bxdf + i]);
             eta = m.bsdf_eta;
             return;
         }
         const PgTexturedMaterial &tm = sc.textured[m.textured_index];
         auto TS = [&](int i) { return TexEval<PG_TEX_DEPTH, W>::s(sc, tm.s[i], h); };
         auto TF = [&](int i) { return TexEval<PG_TEX_DEPTH, W>::f(sc, tm.f[i], h); };
-        auto push = [&](const PgBxDF &b) { if (n < cap) out[n++] = b; };
+        auto push = [&](const PgBxDF &b) { if (n < cap) out.put(n++, b); };
         PgBxDF b;
         eta = 1;
         switch (tm.kind) {
@@ -1626,22 +1679,21 @@ template <int D, int W = 0> struct MatEval {
             for (int j = 0; j < 2; ++j) {
                 const int first = n;
                 float subEta = 1;
-                MatEval<D - 1, W>::run(sc, tm.sub[j], h, out, n, subEta, cap);
+                MatEval<D - 1, W, OUT>::run(sc, tm.sub[j], h, out, n, subEta, cap);
                 if (j == 0) eta = subEta;  // si->bsdf stays m1's
                 const Spec scl = j == 0 ? s1 : s2;
-                for (int i = first; i < n; ++i)
-                    if (out[i].n_scales < PG_MAX_BXDF_SCALES) { lobe_set(out[i].scale[out[i].n_scales], scl); out[i].n_scales++; }
+                for (int i = first; i < n; ++i) out.add_scale(i, scl);
             }
             break;
         }
         }
     }
 };
-template <int W> struct MatEval<0, W> {  // below the deepest mix the host allows: only constant-parameter materials
-    static PG_DEV void run(const DScene &sc, int mat, const TexHit &, PgBxDF *out, int &n, float &eta, int capArg) {
+template <int W, class OUT> struct MatEval<0, W, OUT> {  // below the deepest mix the host allows: only constant-parameter materials
+    static PG_DEV void run(const DScene &sc, int mat, const TexHit &, OUT out, int &n, float &eta, int capArg) {
         const int cap = W == 0 ? PG_MAX_BXDFS : capArg;
         const PgMaterial &m = sc.materials[mat];
-        for (int i = 0; i < m.n_bxdfs && n < cap; ++i) out[n++] = sc.bxdfs[m.first_bxdf + i];
+        for (int i = 0; i < m.n_bxdfs && n < cap; ++i) out.put(n++, sc.bxdfs[m.first_bxdf + i]);
         eta = m.bsdf_eta;
     }
 };
@@ -2475,7 +2527,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
                     if (__ballot(!can || dim != dimU) == 0) { halton_batch<PG_NPRE>(sc, (uint32_t)index, dimU, pre); preDim0 = dimU; if constexpr (EXT) { s_pre[0][tid] = pre[3]; s_pre[1][tid] = pre[4]; s_pre[2][tid] = pre[5]; s_pre[3][tid] = pre[6]; } }
                 }
                 Bsdf bsdf;
-                LobeBsdf lb;
+                LobeBsdfT<typename std::conditional<PRE, PkLobe, PgBxDF>::type> lb;
                 int sssIdx = -1;  // SSS: index of the hit's BSSRDF, or none
                 PgBxDF lobeStore[TEX ? PG_MAX_BXDFS : 1];  // MODE 2: this hit's BxDF list (ComputeScatteringFunctions with textures)
                 if constexpr (EXT) {
@@ -2495,11 +2547,17 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
                     lb.ns = is.ns; lb.ng = is.n;
                     lb.ss = normalize(is.sdpdu);
                     lb.ts = cross(lb.ns, lb.ss);
-                    if (preEvaluated) lbsdf_bind(lb, rp.matPre.lobes + (size_t)i * rp.matPre.stride, __float_as_int(head1.w), head0.w);
-                    else if constexpr (TEX) {
+                    if constexpr (PRE) {
+                        if (preEvaluated)  // k_material's list: head1.w = the number of BxDFs, bit 8: a mix (scale records)
+                            lbsdf_bind(lb, reinterpret_cast<const PkLobe *>(rp.matPre.lobes) + (size_t)i * rp.matPre.stride, __float_as_int(head1.w) & 0xff, head0.w, (__float_as_int(head1.w) & 0x100) ? 2 : 1);
+                        else {  // a material with constant parameters: its list in the same records, packed once at pg_scene_create
+                            const int2 pk = sc.matPk[tri.material];
+                            lbsdf_bind(lb, reinterpret_cast<const PkLobe *>(sc.bxdfsPk) + pk.x, m.n_bxdfs, m.bsdf_eta, pk.y);
+                        }
+                    } else if constexpr (TEX) {
                         int nl = 0;
                         float etaL = 1;
-                        MatEval<2>::run(*sc.self, tri.material, th, lobeStore, nl, etaL, PG_MAX_BXDFS);
+                        MatEval<2>::run(*sc.self, tri.material, th, LobeOutRaw{lobeStore}, nl, etaL, PG_MAX_BXDFS);
                         lbsdf_bind(lb, lobeStore, nl, etaL);
                     } else lbsdf_bind(lb, sc.bxdfs + m.first_bxdf, m.n_bxdfs, m.bsdf_eta);
                     if constexpr (SSS) {  // si->bssrdf = TabulatedBSSRDF(...): subsurface.cpp:87-90, kdsubsurface.cpp:88-93
@@ -2870,9 +2928,12 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PG_MATERIAL_WAVES) void k_material(
     material_bump<1>(sc, tri.material, th, is);
     int nl = 0;
     float etaL = 1;
-    MatEval<2, 1>::run(*sc.self, tri.material, th, rp.matPre.lobes + (size_t)i * rp.matPre.stride, nl, etaL, rp.matPre.stride);
+    // the list in packed records (LobeBsdfT): stride = the records per entry; a mix's lobes take two each
+    const bool mix = sc.textured[sc.materials[tri.material].textured_index].kind == PG_KIND_MIX;
+    const LobeOutPacked out = {rp.matPre.lobes + (size_t)i * rp.matPre.stride * 3, mix ? 2 : 1};
+    MatEval<2, 1, LobeOutPacked>::run(*sc.self, tri.material, th, out, nl, etaL, mix ? rp.matPre.stride / 2 : rp.matPre.stride);
     rp.matPre.head[2 * (size_t)i] = make_float4(is.ns.x, is.ns.y, is.ns.z, etaL);
-    rp.matPre.head[2 * (size_t)i + 1] = make_float4(is.sdpdu.x, is.sdpdu.y, is.sdpdu.z, __int_as_float(nl));
+    rp.matPre.head[2 * (size_t)i + 1] = make_float4(is.sdpdu.x, is.sdpdu.y, is.sdpdu.z, __int_as_float(nl | (mix ? 0x100 : 0)));
 }
 static void launch_material(const DScene &sc, const RenderParams &rp, PathState st, VolState vs, RayQueue qin, const float4 *hits, const float *hitT, QueueState qi,
                             bool vol, hipStream_t s) {
