@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 25
+#define PG_ABI_VERSION 26
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -282,10 +282,24 @@ typedef struct PgObject {
     int32_t first_node, n_nodes; /* n_nodes == 0: a single primitive without an accelerator (api.cpp:1567) */
     int32_t first_prim, n_prims;
 } PgObject;
-typedef struct PgInstance {      /* TransformedPrimitive (primitive.h:92-117), start transform only */
-    float i2w[16], w2i[16];      /* InstanceToWorld and its inverse, row-major */
+typedef struct PgInstance {      /* TransformedPrimitive (primitive.h:92-117) */
+    float i2w[16], w2i[16];      /* InstanceToWorld (the AnimatedTransform's startTransform) and its inverse, row-major */
     int32_t object;
     int32_t identity;            /* Transform::IsIdentity() of InstanceToWorld (primitive.cpp:86-87) */
+    /* A moving instance or shape (api.cpp:1386-1419 wraps an animated shape's primitives in a TransformedPrimitive too, :1576-1586 an
+     * animated ObjectInstance): TransformedPrimitive::Intersect[P] interpolate PrimitiveToWorld at the ray's time (primitive.cpp:78-80,
+     * :99-101; AnimatedTransform::Interpolate, transform.cpp:1144-1169): the start transform up to time[0], the end transform from time[1]
+     * on, in between Translate(lerp T) * Slerp(R).ToTransform() * Transform(lerp S) -- whose inverse is the product of the three
+     * factors' inverses, Transform(lerp S)'s by Gauss-Jordan (transform.cpp:83-135) -- of the two decompositions (Decompose,
+     * :1103-1142), which the host computes once.  The top-level primitive's bounds are Union(start box, end box)
+     * (AnimatedTransform::MotionBounds without rotation, transform.cpp:1183-1192); a motion WITH rotation (Dot(R[0], R[1]) < 0.9995)
+     * needs the derivative-term bounds and is refused by the front end.  animated = 0: the fields below are unused. */
+    int32_t animated;            /* AnimatedTransform::actuallyAnimated */
+    float time[2];               /* startTime, endTime (the file's TransformTimes) */
+    float i2w_end[16], w2i_end[16]; /* endTransform and its inverse */
+    float T[2][3];
+    float R[2][4];               /* (v.x, v.y, v.z, w); R[1] already flipped onto R[0]'s hemisphere (transform.cpp:410) */
+    float S[2][9];               /* the upper 3x3 of S[0], S[1], row-major */
 } PgInstance;
 
 /* HomogeneousMedium (media/homogeneous.h:49-71) with its HenyeyGreenstein phase function (core/medium.h:86-100).

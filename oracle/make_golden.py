@@ -476,6 +476,39 @@ def with_many_lights(s, n=50):
     return s.replace(old, mesh)
 
 
+def moving(directives, end_motion, start_motion=""):
+    """`directives` (shapes, instances, materials) under an animated transformation: `start_motion` acts on the START transform only, `end_motion`
+    on the END transform only (ActiveTransform StartTime / EndTime, api.cpp:395-403), so the CTM's two ends differ and every Shape becomes a
+    TransformedPrimitive over an AnimatedTransform (api.cpp:1386-1419), every ObjectInstance too (:1576-1586)."""
+    pre = ("ActiveTransform StartTime\n" + start_motion + "\n") if start_motion else ""
+    return "AttributeBegin\n" + pre + "ActiveTransform EndTime\n" + end_motion + "\nActiveTransform All\n" + directives + "AttributeEnd\n"
+
+
+def with_moving_boxes(s, short_motion="Translate 70 0 -50", tall_motion="Translate -40 60 0\nScale 1 0.8 1", times=""):
+    """The two Cornell boxes move during the exposure: each mesh becomes a BVHAccel of its own under one TransformedPrimitive."""
+    i = s.index("# short box")
+    j = s.index("# tall box")
+    k = s.index("WorldEnd")
+    out = s[:i] + moving(s[i:j], short_motion) + moving('Material "plastic" "rgb Kd" [ 0.2 0.5 0.3 ] "float roughness" [ 0.2 ]\n' + s[j:k], tall_motion) + s[k:]
+    return out.replace("WorldBegin", times + "WorldBegin", 1) if times else out
+
+
+def with_moving_instances(s):
+    """with_instances' objects, some uses of them under a motion: a BVHAccel object, a lone sphere (a quadric inside a moving instance), a lone
+    triangle, and a moving SHAPE (a sphere, created at the identity) beside them."""
+    s = with_instances(s)
+    s = s.replace('AttributeBegin\n  Translate 50 230 -40\n  Rotate 25 0 1 0.2\n  Scale 0.45 0.45 0.45\n  ObjectInstance "boxes"\nAttributeEnd\n',
+                  'AttributeBegin\n  Translate 50 230 -40\n  Rotate 25 0 1 0.2\n  Scale 0.45 0.45 0.45\n  ActiveTransform EndTime\n  Translate 120 -80 60\n  ActiveTransform All\n  ObjectInstance "boxes"\nAttributeEnd\n')
+    s = s.replace('AttributeBegin\n  Translate 120 0 420\n  ObjectInstance "ball"\nAttributeEnd\n',
+                  'AttributeBegin\n  Translate 120 0 420\n  ActiveTransform EndTime\n  Translate 60 30 -90\n  Scale 1.3 0.8 1\n  ActiveTransform All\n  ObjectInstance "ball"\nAttributeEnd\n')
+    s = s.replace('AttributeBegin\n  Translate 330 380 300\n  Scale 1 -1 1\n  ObjectInstance "tri"\nAttributeEnd\n',
+                  'AttributeBegin\n  Translate 330 380 300\n  Scale 1 -1 1\n  ObjectInstance "tri"\nAttributeEnd\n'
+                  'AttributeBegin\n  Translate 300 300 250\n  Scale 1 1.2 1\n  ActiveTransform StartTime\n  Translate -50 0 0\n  ActiveTransform EndTime\n  Translate 40 -30 20\n  ActiveTransform All\n  ObjectInstance "tri"\nAttributeEnd\n'
+                  + moving('  Translate 300 90 60\n  Material "glass" "float index" [ 1.5 ]\n  Shape "sphere" "float radius" [ 45 ]\n', "Translate 0 120 0"))
+    assert s.count("ActiveTransform EndTime") == 4
+    return s
+
+
 def cam_anim(s, end_motion, times=""):
     """Give the camera an end-of-motion transform: the directives `end_motion` act on the END transform only (ActiveTransform
     EndTime, api.cpp:395-403) on top of the LookAt both share, so CameraToWorld[0] != CameraToWorld[1]."""
@@ -734,6 +767,22 @@ SCENES = {
     # Slerp normalises the blend (cosTheta > .9995); translation + rotation + scale with TransformTimes inside the shutter interval
     # (rays before the start time and after the end time take the end transforms themselves); then the rays' differentials through
     # the same interpolated transform (filtered image textures) under every sampler family, a lens, the other two cameras, and volpath.
+    # moving shapes and instances (TransformedPrimitive over an AnimatedTransform, primitive.cpp:76-103; api.cpp:1386-1419, :1576-1586): translation,
+    # scale, a rotation small enough to count as none (Dot(R[0], R[1]) >= 0.9995: the bounds stay the union of the ends, Interpolate still blends the
+    # quaternions), TransformTimes inside the shutter (the end transforms outside the motion), textures on a moving mesh, every sampler family (the
+    # ray's time comes from the camera sample), volpath, a camera that moves as well
+    "motion_boxes": with_moving_boxes(cornell(32, 32, 8)),
+    "motion_boxes_times": with_moving_boxes(cornell(32, 24, 8), times="TransformTimes 0.25 0.6\n"),
+    "motion_small_rotation": with_moving_boxes(cornell(24, 24, 8), short_motion="Rotate 2.5 0 1 0\nTranslate 30 0 0", tall_motion="Translate 0 40 0\nRotate -1.5 0.2 1 0"),
+    "motion_instances": with_moving_instances(cornell(40, 32, 8)),
+    "motion_instances_shutter": with_moving_instances(cornell(32, 32, 4)).replace('Camera "perspective"', 'Camera "perspective" "float shutteropen" [ 0.3 ] "float shutterclose" [ 0.8 ]'),
+    "motion_tex": with_moving_boxes(cornell(32, 32, 4, world_edit=lambda s: with_image_textures(s))),
+    "motion_sobol": with_moving_boxes(cornell(24, 24, 4)).replace('Sampler "halton"', 'Sampler "sobol"'),
+    "motion_random": with_sampler(with_moving_boxes(cornell(24, 24, 4, integrator='Integrator "path" "integer maxdepth" [ 3 ]')), '"random" "integer pixelsamples" [ 4 ]'),
+    "motion_stratified": with_sampler(with_moving_boxes(cornell(24, 24, 4, integrator='Integrator "path" "integer maxdepth" [ 4 ]')),
+                                      '"stratified" "integer xsamples" [ 2 ] "integer ysamples" [ 2 ] "integer dimensions" [ 14 ]'),
+    "motion_vol": with_moving_instances(cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 4 ]', world_edit=lambda s: with_fog(s))),
+    "motion_camera_too": cam_anim(with_moving_boxes(cornell(32, 24, 8)), "Translate 30 0 -40\nRotate 12 0.1 1 0.2"),
     "camanim_translate": cam_anim(cornell(32, 32, 8), "Translate 40 -20 60"),
     "camanim_rotate": cam_anim(cornell(32, 32, 8), "Translate 30 0 -40\nRotate 25 0.1 1 0.2"),
     "camanim_small_rotate": cam_anim(cornell(24, 24, 8), "Rotate 1 0 1 0"),

@@ -5,7 +5,7 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 25
+PG_ABI_VERSION = 26
 PG_SAMPLER_HALTON, PG_SAMPLER_SOBOL, PG_SAMPLER_RANDOM, PG_SAMPLER_STRATIFIED, PG_SAMPLER_ZEROTWO, PG_SAMPLER_MAXMINDIST = range(6)
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
@@ -93,7 +93,9 @@ class PgObject(C.Structure):
 
 
 class PgInstance(C.Structure):
-    _fields_ = [("i2w", C.c_float * 16), ("w2i", C.c_float * 16), ("object", C.c_int32), ("identity", C.c_int32)]
+    _fields_ = [("i2w", C.c_float * 16), ("w2i", C.c_float * 16), ("object", C.c_int32), ("identity", C.c_int32),
+                ("animated", C.c_int32), ("time", C.c_float * 2), ("i2w_end", C.c_float * 16), ("w2i_end", C.c_float * 16),
+                ("T", (C.c_float * 3) * 2), ("R", (C.c_float * 4) * 2), ("S", (C.c_float * 9) * 2)]
 
 
 class PgSceneDesc(C.Structure):

@@ -64,6 +64,7 @@ struct PgScene {
     int matStride = 0;               // the largest such list of this scene, 0: materials are evaluated inside the shading kernel
     DeviceBuffer shadeOrder, primClass, volPre;  // k_shade_order: the order buffer of the main queue, the primitives' material classes, volpath's pre-drawn medium samples
     bool volOrder = false;  // volpath launches shade medium vertices and surface vertices in separate waves (scenes with homogeneous media only)
+    DeviceBuffer animXf;  // scenes with moving instances: the interpolated matrices per closest-hit result
     DeviceBuffer qo[4], qd[4], counts, hitsMain, hitInst, occluded, stL, stBeta, stMeta, pdLight, pdMis, pdBeta, pdInfo, traceCn,
         lightTests, filmDev, straysDev, nStraysDev, cullGuard, cursors, cursors2;
     hipStream_t shadowStream = nullptr;  // any-hit launches run here, concurrently with the next closest-hit launch
@@ -300,6 +301,10 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         d.objects = (const DObject *)s->objects.p;
         d.instances = (const PgInstance *)s->instances.p;
         d.nInstances = s->instances.p ? desc->n_instances : 0;
+        d.hasMotion = 0; d.rayTimes = 0; d.animXf = nullptr;
+        for (int i = 0; i < d.nInstances; ++i) if (desc->instances[i].animated) d.hasMotion = d.rayTimes = 1;
+        if (d.hasMotion && (desc->n_bssrdfs > 0 || desc->n_grids > 0))
+            FAIL(PG_ERR_UNSUPPORTED, "moving shapes / instances together with BSSRDF materials or grid media (their kernels do not carry the rays' time): %d / %d", desc->n_bssrdfs, desc->n_grids);
         HIP_TRY_S(s->wnodes.alloc(sizeof(float4) * w.size()));
         if (!w.empty()) HIP_TRY_S(hipMemcpy(s->wnodes.p, w.data(), s->wnodes.bytes, hipMemcpyHostToDevice));
         d.wnodes = (const float4 *)s->wnodes.p;
@@ -895,14 +900,16 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
 
 static void traceClosest(PgScene *s, RayQueue q, float4 *hits, float *tOut, TraceCounters *cn, hipStream_t st) {
     DScene d = s->d;
-    d.hitInst = nullptr;  // the unit entry points report primitive, t and barycentrics only
+    d.hitInst = nullptr; d.animXf = nullptr; d.rayTimes = 0;  // the unit entry points report primitive, t and barycentrics only; their rays have time 0
     launch_closest(d, s->trace, q, hits, tOut, cn, (int *)s->cursors.p, (int *)s->cullGuard.p, st);
 }
 static void traceAnyhit(PgScene *s, RayQueue q, int *occluded, TraceCounters *cn, hipStream_t st) {
     // the unit entry point answers in the reference's visiting order: its counters are the reference's (tests compare them)
     TraceConfig c = s->trace;
     c.anyhitFree = 0;
-    launch_anyhit(s->d, c, q, occluded, cn, (int *)s->cursors.p, st);
+    DScene d = s->d;
+    d.rayTimes = 0;  // the unit entry points' rays have time 0 (their queues carry no times)
+    launch_anyhit(d, c, q, occluded, cn, (int *)s->cursors.p, st);
 }
 
 // k_trace's early-cull margin is exact while no ray accepts more than TR_MAX_ACCEPTED hits (pg_traverse.hip); otherwise
@@ -964,7 +971,8 @@ static int ensureWorkBuffers(PgScene *s, int capacity) {
     if (s->capacity >= capacity) return PG_OK;
     const size_t n = (size_t)regionCapFor(capacity, s->d.sparseLights != 0) * PG_REGIONS;  // >= capacity
     if (s->d.sparseLights) HIP_TRY(s->retryList.alloc(n * sizeof(int)));
-    for (int i = 0; i < 4; ++i) { HIP_TRY(s->qo[i].alloc(n * sizeof(float4))); HIP_TRY(s->qd[i].alloc(n * sizeof(float4))); }
+    // (scenes with moving instances: one float per entry behind `d`, the rays' times: PG_QUEUE_TIMES)
+    for (int i = 0; i < 4; ++i) { HIP_TRY(s->qo[i].alloc(n * sizeof(float4))); HIP_TRY(s->qd[i].alloc(n * (sizeof(float4) + (s->d.hasMotion ? sizeof(float) : 0)))); }
     HIP_TRY(s->counts.alloc(4 * PG_REGIONS * PG_COUNT_STRIDE * sizeof(int)));
     // (grid media: a third part -- the transmittance rays must leave the main rays' hits alone for the second shading phase)
     const size_t hitParts = s->d.nGrids > 0 ? 3 : 2;
@@ -983,7 +991,11 @@ static int ensureWorkBuffers(PgScene *s, int capacity) {
             s->matLobes.release(); s->matHead.release(); (void)hipGetLastError();
         }
     }
-    if (s->d.nInstances > 0) { HIP_TRY(s->hitInst.alloc(hitParts * n * sizeof(int))); s->d.hitInst = (int *)s->hitInst.p; }  // main-queue hits, then MIS-queue hits at offset n (one launch fills both)
+    if (s->d.nInstances > 0) { HIP_TRY(s->hitInst.alloc(hitParts * n * sizeof(int))); s->d.hitInst = (int *)s->hitInst.p; }
+    if (s->d.hasMotion) {  // InterpolatedPrimToWorld per closest-hit result on a moving instance (pg_motion.h)
+        HIP_TRY(s->animXf.alloc(hitParts * n * PG_XF_STRIDE * sizeof(float)));
+        s->d.animXf = (float *)s->animXf.p;
+    }  // main-queue hits, then MIS-queue hits at offset n (one launch fills both)
     HIP_TRY(s->occluded.alloc(n * sizeof(int)));
     HIP_TRY(s->stL.alloc(n * sizeof(float4)));
     HIP_TRY(s->stBeta.alloc(n * sizeof(float4)));
@@ -1121,7 +1133,7 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
     if (vol) {
         const size_t n = (size_t)regionCapFor(capacity, s->d.sparseLights != 0) * PG_REGIONS;
         if (s->volCapacity < capacity) {
-            for (int i = 0; i < 2; ++i) { HIP_TRY(s->vqo[i].alloc(n * sizeof(float4))); HIP_TRY(s->vqd[i].alloc(n * sizeof(float4))); HIP_TRY(s->trAcc[i].alloc(n * sizeof(float4))); }
+            for (int i = 0; i < 2; ++i) { HIP_TRY(s->vqo[i].alloc(n * sizeof(float4))); HIP_TRY(s->vqd[i].alloc(n * (sizeof(float4) + (s->d.hasMotion ? sizeof(float) : 0)))); HIP_TRY(s->trAcc[i].alloc(n * sizeof(float4))); }
             for (int i = 0; i < 3; ++i) HIP_TRY(s->volP1[i].alloc(n * sizeof(float4)));
             HIP_TRY(s->vCounts.alloc(2 * QSTRIDE * sizeof(int)));
             HIP_TRY(s->volMedium.alloc(n * sizeof(int)));

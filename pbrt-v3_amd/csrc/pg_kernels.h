@@ -76,6 +76,13 @@ struct DScene {
     const DObject *objects;
     int nInstances;
     int *hitInst;  // per closest-hit result: the instance the hit primitive was reached through, or -1 (written by k_trace<.., true>)
+    // Moving shapes / instances (PgInstance::animated; TransformedPrimitive over an AnimatedTransform): hasMotion says the scene has one -- every
+    // ray queue then carries its rays' times (RayQueue::time) and k_trace runs its XP_ANIM instantiation, which interpolates the instance's
+    // transform at the ray's time when it enters one and leaves, per closest-hit result on a moving instance, the interpolated matrices for the
+    // shading kernels: animXf[PG_XF_STRIDE * i] = InterpolatedPrimToWorld, + 16 its inverse, + 32 IsIdentity (pg_motion.h)
+    int hasMotion;
+    int rayTimes;  // the render's queues carry their rays' times (queue_times); 0 in the unit entry points' copy: their rays have time 0
+    float *animXf;
     const PgAlphaMask *alphas;           // alpha / shadow-alpha textures of meshes; triAlpha[k] indexes it for PG_TRI_ALPHA triangles
     const int *triAlpha;
     int hasAlpha;
@@ -157,6 +164,7 @@ struct DScene {
 // with ONE atomic per block, so no counter sees more than 1/8 of the blocks; consumers walk the regions the same way.
 #define PG_REGIONS 8
 #define PG_COUNT_STRIDE 32  // ints between two region counters (128 B)
+#define PG_XF_STRIDE 36  // floats per entry of DScene::animXf: matrix, inverse, IsIdentity (+ 3 of padding: 16-byte aligned entries)
 struct RayQueue {
     float4 *o;
     float4 *d;
@@ -164,6 +172,10 @@ struct RayQueue {
     int regionCap;  // entries per region (multiple of 256)
 };
 __host__ __device__ inline int queue_region_count(const RayQueue &q, int r) { return q.counts[r * PG_COUNT_STRIDE]; }
+// Ray::time per entry, in scenes with moving shapes / instances only: one float per entry BEHIND the queue's `d` array (the buffers are allocated
+// with that room, pg_abi.hip) -- not a member of RayQueue: four more pointers among the kernel arguments cost the still scenes' shading kernels
+// 30 - 60 spilled scalar registers each
+#define PG_QUEUE_TIMES(sc, q) ((sc).rayTimes ? reinterpret_cast<float *>((q).d + (size_t)(q).regionCap * PG_REGIONS) : nullptr)
 
 // Path state in QUEUE order (PathIntegrator only): entry i belongs to ray i of the main queue it accompanies, so the shading
 // kernel reads it with the ray (one coalesced, independent load) instead of gathering it by slot behind the ray's own load.

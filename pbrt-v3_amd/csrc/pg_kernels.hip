@@ -15,6 +15,7 @@
 #include "pg_sphere.h"
 #include "pg_kernels.h"
 #include "pg_texture.h"
+#include "pg_motion.h"
 #include "pg_bssrdf.h"
 #include "pg_grid.h"
 
@@ -520,52 +521,14 @@ PG_DEV bool slot_to_pixel(const RenderParams &rp, int slot, int &px, int &py, in
     return px >= rp.rd.pixel_bounds[0] && px < rp.rd.pixel_bounds[2] && py >= rp.rd.pixel_bounds[1] && py < rp.rd.pixel_bounds[3];
 }
 
-// r = m1 m2, Matrix4x4::Mul (transform.h:86-93): every entry the four products summed left to right
-PG_DEV void m4_mul(const float *m1, const float *m2, float *r) {
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j)
-            r[4 * i + j] = m1[4 * i] * m2[j] + m1[4 * i + 1] * m2[4 + j] + m1[4 * i + 2] * m2[8 + j] + m1[4 * i + 3] * m2[12 + j];
-}
 // The matrix AnimatedTransform CameraToWorld carries a ray of time `time` to world space with (AnimatedTransform::operator()(Ray),
-// transform.cpp:1171-1181): the start transform up to startTime, the end transform from endTime on, in between
-// Interpolate (:1144-1169) = Translate(lerp T) * Slerp(dt, R0, R1).ToTransform() * Transform(lerp S) -- only .m is formed: a ray is
-// transformed by m alone (transform.h:249-262), so Transform(scale)'s inverse is never looked at.  Quaternion arithmetic as
-// quaternion.h:52-99 spells it (v /= f multiplies by 1 / f, w /= f divides), Slerp quaternion.cpp:94-104, ToTransform :41-59.
+// transform.cpp:1171-1181): the start transform up to startTime, the end transform from endTime on, in between Interpolate (pg_motion.h)
+// -- only .m is formed: a ray is transformed by m alone (transform.h:249-262), so Transform(scale)'s inverse is never looked at.
 PG_DEV void camera_matrix_at(const PgRenderDesc &rd, float time, float *m) {
     if (!rd.camera_animated || time <= rd.camera_time[0]) { for (int k = 0; k < 16; ++k) m[k] = rd.camera_to_world[k]; return; }
     if (time >= rd.camera_time[1]) { for (int k = 0; k < 16; ++k) m[k] = rd.camera_to_world_end[k]; return; }
     const float dt = (time - rd.camera_time[0]) / (rd.camera_time[1] - rd.camera_time[0]);
-    const float tx = (1 - dt) * rd.camera_T[0][0] + dt * rd.camera_T[1][0], ty = (1 - dt) * rd.camera_T[0][1] + dt * rd.camera_T[1][1],
-                tz = (1 - dt) * rd.camera_T[0][2] + dt * rd.camera_T[1][2];
-    const float *q1 = rd.camera_R[0], *q2 = rd.camera_R[1];
-    const float cosTheta = (q1[0] * q2[0] + q1[1] * q2[1] + q1[2] * q2[2]) + q1[3] * q2[3];  // Dot(q1, q2) = Dot(q1.v, q2.v) + q1.w * q2.w
-    float qx, qy, qz, qw;
-    if (cosTheta > .9995f) {  // Normalize((1 - t) * q1 + t * q2)
-        const float a = 1 - dt;
-        const float sx = q1[0] * a + q2[0] * dt, sy = q1[1] * a + q2[1] * dt, sz = q1[2] * a + q2[2] * dt, sw = q1[3] * a + q2[3] * dt;
-        const float len = sqrtf((sx * sx + sy * sy + sz * sz) + sw * sw), inv = 1.f / len;
-        qx = sx * inv; qy = sy * inv; qz = sz * inv; qw = sw / len;
-    } else {
-        const float theta = pg_acosf(cosTheta < -1 ? -1.f : (cosTheta > 1 ? 1.f : cosTheta));
-        const float thetap = theta * dt;
-        // qperp = Normalize(q2 - q1 * cosTheta)
-        const float px = q2[0] - q1[0] * cosTheta, py = q2[1] - q1[1] * cosTheta, pz = q2[2] - q1[2] * cosTheta, pw = q2[3] - q1[3] * cosTheta;
-        const float len = sqrtf((px * px + py * py + pz * pz) + pw * pw), inv = 1.f / len;
-        const float ux = px * inv, uy = py * inv, uz = pz * inv, uw = pw / len;
-        float sn, cs;
-        pg_sincosf(thetap, &sn, &cs);
-        qx = q1[0] * cs + ux * sn; qy = q1[1] * cs + uy * sn; qz = q1[2] * cs + uz * sn; qw = q1[3] * cs + uw * sn;
-    }
-    const float xx = qx * qx, yy = qy * qy, zz = qz * qz, xy = qx * qy, xz = qx * qz, yz = qy * qz, wx = qx * qw, wy = qy * qw, wz = qz * qw;
-    // rotate.ToTransform().m = Transpose(the matrix of quaternion.cpp:47-55)
-    const float rot[16] = {1 - 2 * (yy + zz), 2 * (xy - wz), 2 * (xz + wy), 0, 2 * (xy + wz), 1 - 2 * (xx + zz), 2 * (yz - wx), 0,
-                           2 * (xz - wy), 2 * (yz + wx), 1 - 2 * (xx + yy), 0, 0, 0, 0, 1};
-    const float trn[16] = {1, 0, 0, tx, 0, 1, 0, ty, 0, 0, 1, tz, 0, 0, 0, 1};
-    float scl[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) scl[4 * i + j] = (1 - dt) * rd.camera_S[0][3 * i + j] + dt * rd.camera_S[1][3 * i + j];  // Lerp, pbrt.h:417
-    float tr[16];
-    m4_mul(trn, rot, tr);
-    m4_mul(tr, scl, m);
+    interpolate_trs<false>(rd.camera_T, rd.camera_R, rd.camera_S, dt, m, nullptr);
 }
 // CameraSample::time -> the ray's time, perspective.cpp:90 / :121: Lerp(sample.time, shutterOpen, shutterClose)
 PG_DEV float camera_time(const PgRenderDesc &rd, float u) { return (1 - u) * rd.shutter_open + u * rd.shutter_close; }
@@ -672,7 +635,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_generate(DScene sc, RenderParams r
     int px = 0, py = 0, sn = 0;
     if (valid) valid = slot_to_pixel(rp, slot, px, py, sn);
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
-    float tMax = PG_INF;
+    float tMax = PG_INF, rayTime = 0;
     if (valid) {
         const PgRenderDesc &rd = rp.rd;
         uint64_t index = sc.tsBatched ? 0 : sampler_index(sc, rd, px, py, (uint64_t)sn);
@@ -700,7 +663,8 @@ __global__ __launch_bounds__(PG_BLOCK) void k_generate(DScene sc, RenderParams r
         else if (rd.lens_radius > 0) { l0 = halton_sample(sc, rd, index, 3); l1 = halton_sample(sc, rd, index, 4); }
         if constexpr (ANIM) {
             float c2w[16];
-            camera_matrix_at(rd, camera_time(rd, uTime), c2w);
+            rayTime = camera_time(rd, uTime);
+            camera_matrix_at(rd, rayTime, c2w);
             camera_ray(rd, c2w, pFilmX, pFilmY, l0, l1, o, d, tMax);
         } else camera_ray(rd, rd.camera_to_world, pFilmX, pFilmY, l0, l1, o, d, tMax);
         st.L[slot] = make_float4(0, 0, 0, pFilmX);
@@ -715,13 +679,14 @@ __global__ __launch_bounds__(PG_BLOCK) void k_generate(DScene sc, RenderParams r
     if (valid) {
         q.o[pos] = make_float4(o.x, o.y, o.z, tMax);
         q.d[pos] = make_float4(d.x, d.y, d.z, __int_as_float(slot));
+        if (float *qt = PG_QUEUE_TIMES(sc, q)) qt[pos] = rayTime;  // Ray::time (perspective.cpp:90 / :121), read by k_trace at moving instances
         if (st.qs[0].L) { st.qs[0].L[pos] = st.L[slot]; st.qs[0].beta[pos] = st.beta[slot]; st.qs[0].meta[pos] = st.meta[slot]; }  // just written by this thread
         if (st.qs[0].medium) st.qs[0].medium[pos] = rp.rd.camera_medium + 1;  // volpath: camera rays start in the camera's medium (camera.h:78)
     }
 }
 void launch_generate(const DScene &sc, const RenderParams &rp, PathState st, RayQueue q, hipStream_t s) {
     int nblk = (rp.capacity + PG_BLOCK - 1) / PG_BLOCK;
-    if (rp.rd.camera_animated) hipLaunchKernelGGL(k_generate<true>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, q);
+    if (rp.rd.camera_animated || sc.hasMotion) hipLaunchKernelGGL(k_generate<true>  /* moving instances need the samples' times too */, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, q);
     else hipLaunchKernelGGL(k_generate<false>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, rp, st, q);
 }
 
@@ -731,7 +696,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_ts_generate(DScene sc, RenderParam
     const int local = blockIdx.x * PG_BLOCK + threadIdx.x;
     bool valid = local < rp.nTilesBatch && sc.ts[local].active;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
-    float tMax = PG_INF;
+    float tMax = PG_INF, rayTime = 0;
     if (valid) {
         const PgRenderDesc &rd = rp.rd;
         TileSamplerState &t = sc.ts[local];
@@ -743,7 +708,8 @@ __global__ __launch_bounds__(PG_BLOCK) void k_ts_generate(DScene sc, RenderParam
         t.lens0 = l0; t.lens1 = l1; t.time = uTime;
         const float pFilmX = (float)t.px + u0, pFilmY = (float)t.py + u1;
         float c2w[16];
-        camera_matrix_at(rd, camera_time(rd, uTime), c2w);
+        rayTime = camera_time(rd, uTime);
+        camera_matrix_at(rd, rayTime, c2w);
         camera_ray(rd, c2w, pFilmX, pFilmY, l0, l1, o, d, tMax);
         st.L[local] = make_float4(0, 0, 0, pFilmX);
         st.beta[local] = make_float4(1, 1, 1, pFilmY);
@@ -754,6 +720,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_ts_generate(DScene sc, RenderParam
     if (valid) {
         q.o[pos] = make_float4(o.x, o.y, o.z, tMax);
         q.d[pos] = make_float4(d.x, d.y, d.z, __int_as_float(local));
+        if (float *qt = PG_QUEUE_TIMES(sc, q)) qt[pos] = rayTime;
         if (st.qs[0].L) { st.qs[0].L[pos] = st.L[local]; st.qs[0].beta[pos] = st.beta[local]; st.qs[0].meta[pos] = st.meta[local]; }
         if (st.qs[0].medium) st.qs[0].medium[pos] = rp.rd.camera_medium + 1;
     }
@@ -2074,16 +2041,21 @@ PG_DEV void prim_interface(const DScene &sc, int prim, int rayMedium, int &mIn, 
     else mIn = mOut = rayMedium;
 }
 
+// InstanceToWorld, its inverse and IsIdentity of the instance closest-hit result `i` was reached through: the instance's own or -- a moving one --
+// PrimitiveToWorld.Interpolate(r.time), which k_trace<.., XP_ANIM> computed for the accepted hit's ray and left at animXf[i] (pg_motion.h)
+PG_DEV const float *inst_i2w(const DScene &sc, int inst, int i) { const PgInstance &in = sc.instances[inst]; return in.animated ? sc.animXf + (size_t)PG_XF_STRIDE * i : in.i2w; }
+PG_DEV const float *inst_w2i(const DScene &sc, int inst, int i) { const PgInstance &in = sc.instances[inst]; return in.animated ? sc.animXf + (size_t)PG_XF_STRIDE * i + 16 : in.w2i; }
+PG_DEV bool inst_identity(const DScene &sc, int inst, int i) { const PgInstance &in = sc.instances[inst]; return in.animated ? sc.animXf[(size_t)PG_XF_STRIDE * i + 32] != 0.f : in.identity != 0; }
 // InterpolatedPrimToWorld(*isect) of a hit reached through an object instance, transform.cpp:262-297
-PG_DEV void isect_to_world(const PgInstance &in, Isect &is) {
+PG_DEV void isect_to_world(const float *i2w, const float *w2i, Isect &is) {
     Isect w;
-    w.p = m4_point_err2(in.i2w, is.p, is.pError, w.pError);
-    w.n = normalize(m4_normal(in.w2i, is.n));
-    w.wo = normalize(m4_vec(in.i2w, is.wo));
-    w.sdpdu = m4_vec(in.i2w, is.sdpdu);
-    w.sdpdv = m4_vec(in.i2w, is.sdpdv);
-    w.sdndu = m4_normal(in.w2i, is.sdndu); w.sdndv = m4_normal(in.w2i, is.sdndv);
-    w.ns = normalize(m4_normal(in.w2i, is.ns));
+    w.p = m4_point_err2(i2w, is.p, is.pError, w.pError);
+    w.n = normalize(m4_normal(w2i, is.n));
+    w.wo = normalize(m4_vec(i2w, is.wo));
+    w.sdpdu = m4_vec(i2w, is.sdpdu);
+    w.sdpdv = m4_vec(i2w, is.sdpdv);
+    w.sdndu = m4_normal(w2i, is.sdndu); w.sdndv = m4_normal(w2i, is.sdndv);
+    w.ns = normalize(m4_normal(w2i, is.ns));
     if (dot(w.ns, w.n) < 0.f) w.ns = -w.ns;  // Faceforward(shading.n, n)
     is = w;
 }
@@ -2102,7 +2074,7 @@ PG_DEV void tex_hit_setup(const DScene &sc, const PgRenderDesc &rd, const RayQue
         th.u = h4.y * uv[0] + h4.z * uv[2] + h4.w * uv[4];  // uvHit, triangle.cpp:332
         th.v = h4.y * uv[1] + h4.z * uv[3] + h4.w * uv[5];
     }
-    if (inst >= 0 && !sc.instances[inst].identity) { gdpdu = m4_vec(sc.instances[inst].i2w, gdpdu); gdpdv = m4_vec(sc.instances[inst].i2w, gdpdv); }
+    if (inst >= 0 && !inst_identity(sc, inst, i)) { gdpdu = m4_vec(inst_i2w(sc, inst, i), gdpdu); gdpdv = m4_vec(inst_i2w(sc, inst, i), gdpdv); }
     th.dpdx = th.dpdy = mk(0, 0, 0);
     th.dudx = th.dvdx = th.dudy = th.dvdy = 0;
     if (meta.w & PG_META_HASDIFF) {  // SurfaceInteraction::ComputeDifferentials, interaction.cpp:101-147
@@ -2379,11 +2351,11 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
         // a hit reached through an object instance was computed on the instance-space ray (primitive.cpp:80-82)
         const int inst = (EXT && found && sc.hitInst) ? sc.hitInst[i] : -1;
         V3 shapeRayD = rayD;
-        if (inst >= 0) shapeRayD = m4_vec(sc.instances[inst].w2i, rayD);
+        if (inst >= 0) shapeRayD = m4_vec(inst_w2i(sc, inst, i), rayD);
         if (onSphere) {  // the hit record of a sphere carries tHit: Sphere::Intersect's interaction from the ray and the root
             const float4 o4 = qin.o[i];
             V3 shapeRayO = mk(o4.x, o4.y, o4.z);
-            if (inst >= 0) { float dt; instance_ray(sc.instances[inst].w2i, shapeRayO, rayD, shapeRayO, shapeRayD, dt); }
+            if (inst >= 0) { float dt; instance_ray(inst_w2i(sc, inst, i), shapeRayO, rayD, shapeRayO, shapeRayD, dt); }
             const SphereHit sh = sphere_interaction(sc.spheres[__float_as_int(tri.p0.x)], shapeRayO, shapeRayD, h4.y);
             is.p = sh.p; is.pError = sh.pError; is.wo = sh.wo; is.n = sh.n; is.ns = sh.n; is.sdpdu = sh.dpdu;
             is.sdpdv = sh.dpdv; is.sdndu = sh.dndu; is.sdndv = sh.dndv;
@@ -2501,7 +2473,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
         }
         if (alive && !handled) {
             if (!onSphere) is = make_isect(sc, prim, tri, h4.y, h4.z, h4.w, shapeRayD);
-            if (inst >= 0 && !sc.instances[inst].identity) isect_to_world(sc.instances[inst], is);
+            if (inst >= 0 && !inst_identity(sc, inst, i)) isect_to_world(inst_i2w(sc, inst, i), inst_w2i(sc, inst, i), is);
             const PgMaterial &m = mtl;
             int mIn = 0, mOut = 0;  // VOL: isect.mediumInterface
             if constexpr (VOL) prim_interface(sc, prim, med, mIn, mOut);
@@ -2837,6 +2809,12 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
     if (pushNext) { qnext.o[posNext] = s_ray[0][0][tid]; qnext.d[posNext] = s_ray[0][1][tid]; }
     if (pushShadow) { qshadow.o[posShadow] = s_ray[1][0][tid]; qshadow.d[posShadow] = s_ray[1][1][tid]; }
     if (pushMis) { qmis.o[posMis] = s_ray[2][0][tid]; qmis.d[posMis] = s_ray[2][1][tid]; }
+    if (sc.rayTimes) {  // scenes with moving shapes / instances: the spawned rays carry the interaction's time = the ray's (interaction.h:77-95)
+        const float t = valid ? PG_QUEUE_TIMES(sc, qin)[i] : 0.f;
+        if (pushNext) PG_QUEUE_TIMES(sc, qnext)[posNext] = t;
+        if (pushShadow) PG_QUEUE_TIMES(sc, qshadow)[posShadow] = t;
+        if (pushMis) PG_QUEUE_TIMES(sc, qmis)[posMis] = t;
+    }
     if constexpr (QSTATE) {
         if (valid && !deferred) {
             if (pushNext) {
@@ -2910,17 +2888,17 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PG_MATERIAL_WAVES) void k_material(
     const bool onSphere = (tri.flags & PG_PRIM_SPHERE) != 0;
     const int inst = sc.hitInst ? sc.hitInst[i] : -1;
     V3 shapeRayD = rayD;
-    if (inst >= 0) shapeRayD = m4_vec(sc.instances[inst].w2i, rayD);
+    if (inst >= 0) shapeRayD = m4_vec(inst_w2i(sc, inst, i), rayD);
     if (onSphere) {
         const float4 o4 = qin.o[i];
         V3 shapeRayO = mk(o4.x, o4.y, o4.z);
-        if (inst >= 0) { float dt; instance_ray(sc.instances[inst].w2i, shapeRayO, rayD, shapeRayO, shapeRayD, dt); }
+        if (inst >= 0) { float dt; instance_ray(inst_w2i(sc, inst, i), shapeRayO, rayD, shapeRayO, shapeRayD, dt); }
         const SphereHit sh = sphere_interaction(sc.spheres[__float_as_int(tri.p0.x)], shapeRayO, shapeRayD, h4.y);
         is.p = sh.p; is.pError = sh.pError; is.wo = sh.wo; is.n = sh.n; is.ns = sh.n; is.sdpdu = sh.dpdu;
         is.sdpdv = sh.dpdv; is.sdndu = sh.dndu; is.sdndv = sh.dndv;
         sphU = sh.u; sphV = sh.v; sphDpdu = sh.dpdu; sphDpdv = sh.dpdv;
     } else is = make_isect(sc, prim, tri, h4.y, h4.z, h4.w, shapeRayD);
-    if (inst >= 0 && !sc.instances[inst].identity) isect_to_world(sc.instances[inst], is);
+    if (inst >= 0 && !inst_identity(sc, inst, i)) isect_to_world(inst_i2w(sc, inst, i), inst_w2i(sc, inst, i), is);
     float filmX = 0, filmY = 0;  // the camera sample's pFilm, for the camera ray's differentials
     if (meta.w & PG_META_HASDIFF) { filmX = bySlot ? st.L[slot].w : qsIn.L[i].w; filmY = bySlot ? st.beta[slot].w : qsIn.beta[i].w; }
     TexHit th;
@@ -3127,22 +3105,21 @@ void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis,
 PG_DEV void through_point(const DScene &sc, int ri, float4 o4, V3 rayD, float4 h4, int prim, const Tri &tri, V3 &p, V3 &pError, V3 &n) {
     const int inst = sc.hitInst ? sc.hitInst[ri] : -1;
     V3 shapeRayD = rayD;
-    if (inst >= 0) shapeRayD = m4_vec(sc.instances[inst].w2i, rayD);
+    if (inst >= 0) shapeRayD = m4_vec(inst_w2i(sc, inst, ri), rayD);
     if (tri.flags & PG_PRIM_SPHERE) {
         V3 shapeRayO = mk(o4.x, o4.y, o4.z);
-        if (inst >= 0) { float dt; instance_ray(sc.instances[inst].w2i, shapeRayO, rayD, shapeRayO, shapeRayD, dt); }
+        if (inst >= 0) { float dt; instance_ray(inst_w2i(sc, inst, ri), shapeRayO, rayD, shapeRayO, shapeRayD, dt); }
         const SphereHit sh = sphere_interaction(sc.spheres[__float_as_int(tri.p0.x)], shapeRayO, shapeRayD, h4.y);
         p = sh.p; pError = sh.pError; n = sh.n;
     } else {
         const Isect is = make_isect(sc, prim, tri, h4.y, h4.z, h4.w, shapeRayD);
         p = is.p; pError = is.pError; n = is.n;
     }
-    if (inst >= 0 && !sc.instances[inst].identity) {
-        const PgInstance &in = sc.instances[inst];
+    if (inst >= 0 && !inst_identity(sc, inst, ri)) {
         V3 pe;
-        p = m4_point_err2(in.i2w, p, pError, pe);
+        p = m4_point_err2(inst_i2w(sc, inst, ri), p, pError, pe);
         pError = pe;
-        n = normalize(m4_normal(in.w2i, n));
+        n = normalize(m4_normal(inst_w2i(sc, inst, ri), n));
     }
 }
 // GRID: a segment inside a GridDensityMedium is attenuated by ratio tracking (grid.cpp:88-120), whose numbers come from the path's
@@ -3227,6 +3204,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_through(DScene sc, PathState st, V
     int pos;
     block_push<1, false>(&qout, &push, &pos);
     if (push) { qout.o[pos] = no; qout.d[pos] = nd; }
+    if (push && sc.rayTimes) PG_QUEUE_TIMES(sc, qout)[pos] = PG_QUEUE_TIMES(sc, qin)[i];
 }
 void launch_through(const DScene &sc, PathState st, VolState vs, int kind, RayQueue qin, const float4 *hits, const float *hitT, int hitBase,
                     RayQueue qout, hipStream_t s, const RenderParams *rpGrid) {

@@ -35,6 +35,7 @@
 #include <cstring>
 #include "pg_kernels.h"
 #include "pg_texture.h"
+#include "pg_motion.h"
 
 #ifndef TR_BLOCK
 #define TR_BLOCK 256
@@ -128,6 +129,7 @@ PG_DEV unsigned long long tr_wave_sum(unsigned long long v) {
 #define XP_QUADRIC 2
 #define XP_ALPHA 4
 #define XP_ALPHATEX 8
+#define XP_ANIM 16  // moving instances (PgInstance::animated): their transform is interpolated at the ray's time (with XP_INST only)
 #define XP_GENERAL (XP_INST | XP_QUADRIC | XP_ALPHATEX)
 
 // MIPMap<Float>::Lookup(st, 0 width) of a DAlphaTex = `triangle(0, st)` (mipmap.h:231-243) with Texel's wrap modes (:189-212): the
@@ -146,6 +148,13 @@ PG_DEV float alpha_lookup(const DScene &sc, const DAlphaTex &a, float u, float v
     const float ds = s - s0, dt = t - t0;
     return alpha_texel(sc, a, s0, t0) * ((1 - ds) * (1 - dt)) + alpha_texel(sc, a, s0, t0 + 1) * ((1 - ds) * dt) +
            alpha_texel(sc, a, s0 + 1, t0) * (ds * (1 - dt)) + alpha_texel(sc, a, s0 + 1, t0 + 1) * (ds * dt);
+}
+// Ray::time of entry `ray` of the traced queue(s); the unit entry points (pg_intersect / pg_intersect_p: origins, directions and tMax only) trace
+// rays of time 0, Ray's default (geometry.h:865-866)
+PG_DEV float trace_ray_time(const DScene &sc, const RayQueue &q0, const RayQueue &q1, int ray, int hitOffset1) {
+    if (!sc.rayTimes) return 0.f;
+    if (q1.regionCap > 0 && ray >= hitOffset1) return PG_QUEUE_TIMES(sc, q1)[ray - hitOffset1];
+    return PG_QUEUE_TIMES(sc, q0)[ray];
 }
 // KIND: 0 closest hit (BVHAccel::Intersect), 1 any hit in the reference's order (BVHAccel::IntersectP, counters exact),
 // 2 any hit in free order (same occlusion answers; the counters then say what THIS traversal read)
@@ -244,6 +253,12 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                 else {
                     hits[ray] = make_float4(__int_as_float(hitPrim), hb0, hb1, hb2);
                     if ((XP & XP_INST) && sc.hitInst) sc.hitInst[ray] = hitInstCur;
+                    if ((XP & XP_ANIM) && sc.animXf && hitInstCur >= 0 && sc.instances[hitInstCur].animated) {
+                        // InterpolatedPrimToWorld of the accepted hit's instance, for *isect = InterpolatedPrimToWorld(*isect) in the shading kernels
+                        float xf[PG_XF_STRIDE];
+                        instance_matrices_at(sc.instances[hitInstCur], trace_ray_time(sc, q0, q1, ray, hitOffset1), xf);
+                        for (int k = 0; k < 33; ++k) sc.animXf[(size_t)PG_XF_STRIDE * ray + k] = xf[k];
+                    }
                     if (tOut) tOut[ray] = tMax;
                 }
                 ray = -1;
@@ -340,9 +355,16 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                         const DObject &ob = sc.objects[in.object];
                         wtMax = tMax;
                         if (ANYHIT) { wvd = vd; wvmask = vmask; vd = 0; vmask = 0; }
-                        V3 oErr;
-                        V3 o = m4_point_err(in.w2i, mk(ox, oy, oz), oErr);
-                        const V3 dd = m4_vec(in.w2i, mk(d4.x, d4.y, d4.z));
+                        V3 oErr, o, dd;
+                        if ((XP & XP_ANIM) && in.animated) {  // PrimitiveToWorld.Interpolate(r.time, ...), primitive.cpp:78-80 / :99-101
+                            float xf[PG_XF_STRIDE];
+                            instance_matrices_at(in, trace_ray_time(sc, q0, q1, ray, hitOffset1), xf);
+                            o = m4_point_err(xf + 16, mk(ox, oy, oz), oErr);
+                            dd = m4_vec(xf + 16, mk(d4.x, d4.y, d4.z));
+                        } else {
+                            o = m4_point_err(in.w2i, mk(ox, oy, oz), oErr);
+                            dd = m4_vec(in.w2i, mk(d4.x, d4.y, d4.z));
+                        }
                         const float lengthSquared = lensq(dd);
                         if (lengthSquared > 0) {
                             const float dt = dot(vabs(dd), oErr) / lengthSquared;
@@ -396,7 +418,11 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                         const bool fromQ1 = q1.regionCap > 0 && ray >= hitOffset1;
                         const float4 d4 = fromQ1 ? q1.d[ray - hitOffset1] : q0.d[ray];
                         V3 dd = mk(d4.x, d4.y, d4.z);
-                        if (inInst >= 0) dd = m4_vec(sc.instances[inInst].w2i, dd);
+                        if ((XP & XP_ANIM) && inInst >= 0 && sc.instances[inInst].animated) {
+                            float xf[PG_XF_STRIDE];
+                            instance_matrices_at(sc.instances[inInst], trace_ray_time(sc, q0, q1, ray, hitOffset1), xf);
+                            dd = m4_vec(xf + 16, dd);
+                        } else if (inInst >= 0) dd = m4_vec(sc.instances[inInst].w2i, dd);
                         hit = sphere_test(sc.spheres[__float_as_int(a.x)], mk(ox, oy, oz), dd, tMax, t);
                         b0 = t; b1 = 0; b2 = 0;  // the hit record of a sphere carries tHit
                     } else
@@ -536,7 +562,9 @@ static void launch_trace(const DScene &sc, const TraceConfig &c, RayQueue q0, Ra
     (void)hipMemsetAsync(cursors, 0, 2 * PG_REGIONS * PG_COUNT_STRIDE * sizeof(int), s);
     // a "tail" launch: q0's cursors start where its regions ended before the latest entries were appended
     if (cursorInit) (void)hipMemcpyAsync(cursors, cursorInit, PG_REGIONS * PG_COUNT_STRIDE * sizeof(int), hipMemcpyDeviceToDevice, s);
-    const int xp = (sc.nInstances > 0 ? XP_INST : 0) | (sc.nSpheres > 0 ? XP_QUADRIC : 0) | (sc.hasAlpha ? (sc.alphaTex ? XP_ALPHA : XP_ALPHATEX) : 0);
+    int xp = (sc.nInstances > 0 ? XP_INST : 0) | (sc.nSpheres > 0 ? XP_QUADRIC : 0) | (sc.hasAlpha ? (sc.alphaTex ? XP_ALPHA : XP_ALPHATEX) : 0);
+    // moving instances: two instantiations only -- with quadrics, and the general one (any alpha mask) -- a moving scene pays for both features
+    if (sc.hasMotion) xp = XP_ANIM | (sc.hasAlpha ? XP_GENERAL : (XP_INST | XP_QUADRIC));
 #define TR_LAUNCH(XPV) hipLaunchKernelGGL((k_trace<KIND, XPV>), dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q0, q1, hits, hitOffset1, tOut, occluded, cn, \
                                           cursors, c.depth, c.segRays, KIND ? c.refillAtAny : c.refillAt, KIND ? c.triWAny : c.triW, KIND ? 1.f : c.cullK, cullGuard, c.maxAccepted)
     switch (xp) {
@@ -549,6 +577,8 @@ static void launch_trace(const DScene &sc, const TraceConfig &c, RayQueue q0, Ra
     case XP_QUADRIC | XP_INST: TR_LAUNCH(XP_QUADRIC | XP_INST); break;
     case XP_QUADRIC | XP_ALPHA: TR_LAUNCH(XP_QUADRIC | XP_ALPHA); break;
     case XP_QUADRIC | XP_INST | XP_ALPHA: TR_LAUNCH(XP_QUADRIC | XP_INST | XP_ALPHA); break;
+    case XP_ANIM | XP_INST | XP_QUADRIC: TR_LAUNCH(XP_ANIM | XP_INST | XP_QUADRIC); break;
+    case XP_ANIM | XP_GENERAL: TR_LAUNCH(XP_ANIM | XP_GENERAL); break;
     default: TR_LAUNCH(XP_GENERAL); break;  // masks that need the general texture evaluator
     }
 #undef TR_LAUNCH

@@ -68,6 +68,7 @@ struct GraphicsState {
 };
 struct RenderOptions {
     Float transformStartTime = 0, transformEndTime = 1;
+    bool anyMotion = false;  // a moving shape or instance (TransformedPrimitive over an AnimatedTransform that is actually animated)
     bool refused = false;  // the scene asks for something whose absence would change the image (animated shapes / instances / camera): no frame is rendered
     std::string FilterName = "box"; ParamSet FilterParams;
     std::string FilmName = "image"; ParamSet FilmParams;
@@ -1220,55 +1221,86 @@ static std::shared_ptr<TriangleMesh> CreateTriangleMeshShape(const Transform &o2
     return mesh;
 }
 
+// AnimatedTransform's constructor (transform.cpp:396-411) decides hasRotation from the two decompositions; with rotation the bounds of the
+// motion need the derivative terms (BoundPointMotion, transform.cpp:1194-1213), which this build does not restate
+static bool MotionHasRotation(const Transform &a, const Transform &b) {
+    Float T[3], R0[4], R1[4], S[9];
+    DecomposeTransform(a.GetMatrix(), T, R0, S);
+    DecomposeTransform(b.GetMatrix(), T, R1, S);
+    Float d = (R0[0] * R1[0] + R0[1] * R1[1] + R0[2] * R1[2]) + R0[3] * R1[3];
+    if (d < 0) { for (int i = 0; i < 4; ++i) R1[i] = -R1[i]; d = (R0[0] * R1[0] + R0[1] * R1[1] + R0[2] * R1[2]) + R0[3] * R1[3]; }
+    return d < 0.9995f;
+}
+// The TransformedPrimitive of a moving shape or instance (api.cpp:1399-1419, :1576-1586): false = outside the closed set, the frame is refused
+static bool MakeMotion(const char *what, const std::string &name, GeometricPrimitive::InstanceTransforms *xf) {
+    xf->InstanceToWorld = curTransform[0];
+    xf->WorldToInstance = Inverse(curTransform[0]);
+    if (!curTransform.IsAnimated()) return true;
+    if (MotionHasRotation(curTransform[0], curTransform[1])) {
+        Error("%s \"%s\" under an animated transformation that ROTATES (motion blur with rotation: its bounds need AnimatedTransform's derivative terms) "
+              "is outside this build's closed set; the scene will not be rendered.", what, name.c_str());
+        renderOptions->refused = true;
+        return false;
+    }
+    xf->animated = true;
+    xf->InstanceToWorldEnd = curTransform[1];
+    xf->WorldToInstanceEnd = Inverse(curTransform[1]);
+    xf->time[0] = renderOptions->transformStartTime; xf->time[1] = renderOptions->transformEndTime;
+    renderOptions->anyMotion = true;
+    return true;
+}
 void pbrtShape(const std::string &name, const ParamSet &params) {  // api.cpp:1329-1421
     VERIFY_WORLD("Shape");
-    // The reference wraps an animated shape in a TransformedPrimitive with an AnimatedTransform (api.cpp:1386-1419, primitive.cpp:76-96):
-    // the device has no per-ray interpolated transform, and a frame without the motion would be an approximation -- the frame is refused
-    if (curTransform.IsAnimated()) {
-        Error("Shape \"%s\" under an animated transformation (motion blur) is outside this build's closed set; the scene will not be rendered.", name.c_str());
+    // A shape under an animated transformation is created at the identity and its primitives -- under a BVHAccel of their own when there
+    // are several -- become ONE TransformedPrimitive over the AnimatedTransform (api.cpp:1386-1419, primitive.cpp:76-103)
+    const bool animated = curTransform.IsAnimated();
+    if (animated && renderOptions->currentInstance) {
+        Error("Shape \"%s\" under an animated transformation inside an object definition (a moving primitive inside an instance) is outside this "
+              "build's closed set; the scene will not be rendered.", name.c_str());
         renderOptions->refused = true;
     }
+    const Transform shapeToWorld = animated ? Transform() : curTransform[0];
     std::shared_ptr<TriangleMesh> mesh;
     std::shared_ptr<Sphere> sphere;
-    if (name == "trianglemesh") mesh = CreateTriangleMeshShape(curTransform[0], graphicsState.reverseOrientation, params);
-    else if (name == "plymesh") mesh = CreatePLYMesh(curTransform[0], graphicsState.reverseOrientation, params);
-    else if (name == "loopsubdiv") mesh = CreateLoopSubdiv(curTransform[0], graphicsState.reverseOrientation, params);
-    else if (name == "heightfield") mesh = CreateHeightfield(curTransform[0], graphicsState.reverseOrientation, params);
-    else if (name == "nurbs") mesh = CreateNURBS(curTransform[0], graphicsState.reverseOrientation, params);
+    if (name == "trianglemesh") mesh = CreateTriangleMeshShape(shapeToWorld, graphicsState.reverseOrientation, params);
+    else if (name == "plymesh") mesh = CreatePLYMesh(shapeToWorld, graphicsState.reverseOrientation, params);
+    else if (name == "loopsubdiv") mesh = CreateLoopSubdiv(shapeToWorld, graphicsState.reverseOrientation, params);
+    else if (name == "heightfield") mesh = CreateHeightfield(shapeToWorld, graphicsState.reverseOrientation, params);
+    else if (name == "nurbs") mesh = CreateNURBS(shapeToWorld, graphicsState.reverseOrientation, params);
     else if (name == "sphere") {  // CreateSphereShape, sphere.cpp:326-336
         Float radius = params.FindOneFloat("radius", 1.f);
         Float zmin = params.FindOneFloat("zmin", -radius);
         Float zmax = params.FindOneFloat("zmax", radius);
         Float phimax = params.FindOneFloat("phimax", 360.f);
-        sphere = std::make_shared<Sphere>(curTransform[0], Inverse(curTransform[0]), graphicsState.reverseOrientation, radius, zmin, zmax, phimax);
+        sphere = std::make_shared<Sphere>(shapeToWorld, Inverse(shapeToWorld), graphicsState.reverseOrientation, radius, zmin, zmax, phimax);
     } else if (name == "cylinder") {  // CreateCylinderShape, cylinder.cpp:225-235
         Float radius = params.FindOneFloat("radius", 1);
         Float zmin = params.FindOneFloat("zmin", -1);
         Float zmax = params.FindOneFloat("zmax", 1);
         Float phimax = params.FindOneFloat("phimax", 360);
-        sphere = Sphere::Cylinder(curTransform[0], Inverse(curTransform[0]), graphicsState.reverseOrientation, radius, zmin, zmax, phimax);
+        sphere = Sphere::Cylinder(shapeToWorld, Inverse(shapeToWorld), graphicsState.reverseOrientation, radius, zmin, zmax, phimax);
     } else if (name == "disk") {  // CreateDiskShape, disk.cpp:139-149
         Float height = params.FindOneFloat("height", 0.);
         Float radius = params.FindOneFloat("radius", 1);
         Float inner_radius = params.FindOneFloat("innerradius", 0);
         Float phimax = params.FindOneFloat("phimax", 360);
-        sphere = Sphere::Disk(curTransform[0], Inverse(curTransform[0]), graphicsState.reverseOrientation, height, radius, inner_radius, phimax);
+        sphere = Sphere::Disk(shapeToWorld, Inverse(shapeToWorld), graphicsState.reverseOrientation, height, radius, inner_radius, phimax);
     } else if (name == "cone") {  // CreateConeShape, cone.cpp:210-219
         Float radius = params.FindOneFloat("radius", 1);
         Float height = params.FindOneFloat("height", 1);
         Float phimax = params.FindOneFloat("phimax", 360);
-        sphere = Sphere::Cone(curTransform[0], Inverse(curTransform[0]), graphicsState.reverseOrientation, height, radius, phimax);
+        sphere = Sphere::Cone(shapeToWorld, Inverse(shapeToWorld), graphicsState.reverseOrientation, height, radius, phimax);
     } else if (name == "paraboloid") {  // CreateParaboloidShape, paraboloid.cpp:216-226
         Float radius = params.FindOneFloat("radius", 1);
         Float zmin = params.FindOneFloat("zmin", 0);
         Float zmax = params.FindOneFloat("zmax", 1);
         Float phimax = params.FindOneFloat("phimax", 360);
-        sphere = Sphere::Paraboloid(curTransform[0], Inverse(curTransform[0]), graphicsState.reverseOrientation, radius, zmin, zmax, phimax);
+        sphere = Sphere::Paraboloid(shapeToWorld, Inverse(shapeToWorld), graphicsState.reverseOrientation, radius, zmin, zmax, phimax);
     } else if (name == "hyperboloid") {  // CreateHyperboloidShape, hyperboloid.cpp:252-261
         Point3f p1 = params.FindOnePoint3f("p1", Point3f(0, 0, 0));
         Point3f p2 = params.FindOnePoint3f("p2", Point3f(1, 1, 1));
         Float phimax = params.FindOneFloat("phimax", 360);
-        sphere = Sphere::Hyperboloid(curTransform[0], Inverse(curTransform[0]), graphicsState.reverseOrientation, p1, p2, phimax);
+        sphere = Sphere::Hyperboloid(shapeToWorld, Inverse(shapeToWorld), graphicsState.reverseOrientation, p1, p2, phimax);
     } else Error("Shape \"%s\" is outside this build's closed set (trianglemesh, plymesh, loopsubdiv, heightfield, nurbs, sphere, cylinder, disk, cone, paraboloid, hyperboloid); ignoring.", name.c_str());
     if (!sphere && (!mesh || mesh->nTriangles == 0)) return;
     int mtl = GetMaterialForShape(params);
@@ -1276,7 +1308,9 @@ void pbrtShape(const std::string &name, const ParamSet &params) {  // api.cpp:13
     int firstLight = -1;
     PgLight lightProto;
     memset(&lightProto, 0, sizeof(lightProto));
-    if (graphicsState.areaLight != "" && sphere && !sphere->CanEmit())
+    if (animated) {
+        if (graphicsState.areaLight != "") Warning("Ignoring currently set area light when creating animated shape");  // api.cpp:1389-1391
+    } else if (graphicsState.areaLight != "" && sphere && !sphere->CanEmit())
         Error("Shape \"%s\" cannot be an area light: pbrt-v3 has no Sample() for it and aborts when the light is sampled. The shape is added without emission.", name.c_str());
     else if (graphicsState.areaLight != "") {
         // MakeAreaLight (api.cpp:752-768) + CreateDiffuseAreaLight (diffuse.cpp:135-146)
@@ -1294,6 +1328,7 @@ void pbrtShape(const std::string &name, const ParamSet &params) {  // api.cpp:13
     int mediumInside, mediumOutside;
     CreateMediumInterface(&mediumInside, &mediumOutside);  // api.cpp:1380
     const int nShapes = sphere ? 1 : mesh->nTriangles;
+    std::shared_ptr<ObjectDefinition> moving = animated ? std::make_shared<ObjectDefinition>() : nullptr;
     for (int i = 0; i < nShapes; ++i) {
         GeometricPrimitive prim;
         if (sphere) prim.sphere = sphere;
@@ -1308,8 +1343,22 @@ void pbrtShape(const std::string &name, const ParamSet &params) {  // api.cpp:13
             renderOptions->lights.push_back(l);
         }
         // api.cpp:1405-1418: to the scene, or to the instance definition being collected
-        if (renderOptions->currentInstance) renderOptions->currentInstance->prims.push_back(prim);
+        if (moving) moving->prims.push_back(prim);
+        else if (renderOptions->currentInstance) renderOptions->currentInstance->prims.push_back(prim);
         else renderOptions->primitives.push_back(prim);
+    }
+    if (moving) {
+        if (moving->prims.size() > 1) {  // std::make_shared<BVHAccel>(prims): the defaults (one primitive per leaf, SAH), whatever the file's Accelerator says
+            moving->accel = CreateDefaultBVHAccel(std::move(moving->prims));
+            moving->prims.clear();
+        }
+        auto xf = std::make_shared<GeometricPrimitive::InstanceTransforms>();
+        if (!MakeMotion("Shape", name, xf.get())) return;
+        GeometricPrimitive tp;
+        tp.object = moving;
+        tp.xf = xf;
+        if (!renderOptions->currentInstance) renderOptions->primitives.push_back(tp);
+        return;
     }
     if (firstLight >= 0 && renderOptions->currentInstance)
         Warning("Area lights not supported with object instancing");  // api.cpp:1407-1408 (here the shapes are added without emission)
@@ -1342,16 +1391,11 @@ void pbrtObjectInstance(const std::string &name) {  // api.cpp:1546-1588
         obj->accel = CreateBVHAccelerator(std::move(obj->prims), ro.AcceleratorName == "bvh" ? ro.AcceleratorParams : ParamSet());
         obj->prims.clear();
     }
-    if (curTransform.IsAnimated()) {  // TransformedPrimitive over an AnimatedTransform (api.cpp:1576-1586): refused, never rendered with one end of the motion
-        Error("Object instance \"%s\" under an animated transformation (motion blur) is outside this build's closed set; the scene will not be rendered.", name.c_str());
-        renderOptions->refused = true;
-    }
     GeometricPrimitive prim;
     prim.object = obj;
-    {
+    {   // TransformedPrimitive over the AnimatedTransform of the two current transformations (api.cpp:1576-1586)
         auto xf = std::make_shared<GeometricPrimitive::InstanceTransforms>();
-        xf->InstanceToWorld = curTransform[0];
-        xf->WorldToInstance = Inverse(curTransform[0]);
+        if (!MakeMotion("Object instance", name, xf.get())) return;
         prim.xf = xf;
     }
     renderOptions->primitives.push_back(prim);
@@ -1484,6 +1528,11 @@ void pbrtWorldEnd() {  // api.cpp:1590-1644
     std::unique_ptr<GpuPathIntegrator> integrator(MakeIntegrator());
     std::unique_ptr<Scene> scene(MakeScene());
     if (timing) fprintf(stderr, "pbrt host: MakeScene (BVH build) %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild).count());
+    if (renderOptions->anyMotion && (!renderOptions->bssrdfs.empty() || !renderOptions->grids.empty())) {
+        Error("Moving shapes / instances together with subsurface materials or a grid medium are outside this build's closed set "
+              "(the device's probe-chain and ratio-tracking kernels do not carry the rays' time); the scene will not be rendered.");
+        renderOptions->refused = true;
+    }
     if (renderOptions->refused) {
         Error("Scene not rendered: it uses features outside this build's closed set (see the errors above); no approximate image is written.");
         scene.reset(); integrator.reset();

@@ -114,8 +114,13 @@ Bounds3f ObjectDefinition::WorldBound() const {  // the BVHAccel's root bounds, 
     return prims.empty() ? Bounds3f() : prims[0].WorldBound();
 }
 Bounds3f GeometricPrimitive::WorldBound() const {
-    // TransformedPrimitive::WorldBound (primitive.h:107-109) -> AnimatedTransform::MotionBounds, not animated (transform.cpp:1190-1192)
-    if (object) return TransformBounds(xf->InstanceToWorld, object->WorldBound());
+    // TransformedPrimitive::WorldBound (primitive.h:107-109) -> AnimatedTransform::MotionBounds (transform.cpp:1183-1192): the start
+    // transform's box, or -- moving without rotation, the only motion the front end lets through -- the union of the two ends' boxes
+    if (object) {
+        const Bounds3f b = object->WorldBound();
+        if (xf->animated) return Union(TransformBounds(xf->InstanceToWorld, b), TransformBounds(xf->InstanceToWorldEnd, b));
+        return TransformBounds(xf->InstanceToWorld, b);
+    }
     return sphere ? sphere->WorldBound() : shape.WorldBound();
 }
 
@@ -502,6 +507,7 @@ BVHAccel::BuildNode *BVHAccel::buildUpperSAH(std::vector<BuildNode *> &treeletRo
     return node;
 }
 
+std::shared_ptr<BVHAccel> CreateDefaultBVHAccel(std::vector<GeometricPrimitive> prims) { return std::make_shared<BVHAccel>(std::move(prims)); }
 std::shared_ptr<BVHAccel> CreateBVHAccelerator(std::vector<GeometricPrimitive> prims, const ParamSet &ps) {
     // Accelerator "bvh": "string splitmethod" sah | hlbvh | middle | equal (default sah), "integer maxnodeprims" (default 4)
     static const struct { const char *name; BVHAccel::SplitMethod method; } kMethods[] = {

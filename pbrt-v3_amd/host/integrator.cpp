@@ -318,6 +318,17 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
             for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { inst.i2w[4 * r + c] = m.m[r][c]; inst.w2i[4 * r + c] = mi.m[r][c]; }
             inst.object = objectIndex[prim.object.get()];
             inst.identity = prim.xf->InstanceToWorld.IsIdentity() ? 1 : 0;
+            if (prim.xf->animated) {  // AnimatedTransform's constructor, transform.cpp:396-411
+                inst.animated = 1;
+                inst.time[0] = prim.xf->time[0]; inst.time[1] = prim.xf->time[1];
+                const Matrix4x4 &me = prim.xf->InstanceToWorldEnd.GetMatrix(), &mie = prim.xf->WorldToInstanceEnd.GetMatrix();
+                for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { inst.i2w_end[4 * r + c] = me.m[r][c]; inst.w2i_end[4 * r + c] = mie.m[r][c]; }
+                DecomposeTransform(m, inst.T[0], inst.R[0], inst.S[0]);
+                DecomposeTransform(me, inst.T[1], inst.R[1], inst.S[1]);
+                const float *q0 = inst.R[0];
+                float *q1 = inst.R[1];
+                if ((q0[0] * q1[0] + q0[1] * q1[1] + q0[2] * q1[2]) + q0[3] * q1[3] < 0) for (int i = 0; i < 4; ++i) q1[i] = -q1[i];  // the shortest path
+            }
             flat->indices[3 * k] = (int)flat->instances.size();
             flat->indices[3 * k + 1] = flat->indices[3 * k + 2] = 0;
             flat->triFlags[k] = PG_PRIM_INSTANCE;

@@ -73,7 +73,14 @@ struct GeometricPrimitive {
     std::shared_ptr<ObjectDefinition> object;
     // only object instances carry transforms; kept behind a pointer so that the millions of triangle primitives of a large
     // scene stay small (the accelerator build moves every one of them)
-    struct InstanceTransforms { Transform InstanceToWorld, WorldToInstance; };
+    // `animated`: TransformedPrimitive over an AnimatedTransform whose two ends differ (api.cpp:1386-1419 for a moving shape,
+    // :1576-1586 for a moving ObjectInstance); the ends' decompositions are taken when the scene is flattened (FlattenScene)
+    struct InstanceTransforms {
+        Transform InstanceToWorld, WorldToInstance;
+        bool animated = false;
+        Transform InstanceToWorldEnd, WorldToInstanceEnd;
+        Float time[2] = {0, 1};
+    };
     std::shared_ptr<const InstanceTransforms> xf;
     int material = -1;
     int areaLight = -1;
@@ -117,6 +124,7 @@ class BVHAccel {
     BuildNode *allocNode();
 };
 std::shared_ptr<BVHAccel> CreateBVHAccelerator(std::vector<GeometricPrimitive> prims, const ParamSet &ps);  // bvh.cpp:740-760
+std::shared_ptr<BVHAccel> CreateDefaultBVHAccel(std::vector<GeometricPrimitive> prims);  // std::make_shared<BVHAccel>(prims): one primitive per leaf, SAH (bvh.h:57-58)
 // With PbrtOptions.deviceBVH, "hlbvh" accelerators are built by the HIP back end (pg_hlbvh_build, include/pbrt_gpu.h):
 // same nodes and primitive order as HLBVHBuild here.  Returns false (after Error) when the back end is missing or fails.
 bool DeviceHLBVHBuild(int n, const float *bounds, int maxPrimsInNode, std::vector<PgBVHNode> *nodes, std::vector<int> *order);

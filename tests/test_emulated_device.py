@@ -79,6 +79,19 @@ def test_round5_kernels_on_the_emulated_device(emulated):
     assert " passed" in out and "failed" not in out
 
 
+def test_moving_shapes_and_instances_on_the_emulated_device(emulated):
+    """Round 5, last: TransformedPrimitive over an AnimatedTransform on the device -- the queues carry the rays' times, k_trace<., XP_ANIM>
+    interpolates a moving instance's transform (and inverts it: Gauss-Jordan of the blended scale) at the ray's time when it enters the
+    instance and leaves the accepted hit's matrices for the shading kernels (pg_motion.h).  Moving meshes (a BVH of their own under one
+    instance), TransformTimes inside the shutter, moving instances of a BVH object / a lone sphere / a lone triangle beside still and mirrored
+    ones, a moving quadric, volpath, a tile-serial sampler, a moving camera on top; and four random scenes of the fuzz generator."""
+    select = "test_golden_images and (motion_boxes_times or motion_instances or motion_vol or motion_random or motion_camera_too or motion_small_rotation)"
+    out = run_gpu_tests(emulated, ["tests/test_gpu_parity.py"], select, 1500)
+    assert " passed" in out and "failed" not in out
+    out = run_gpu_tests(emulated, ["tests/test_gpu_fuzz.py::test_random_scene_with_moving_shapes_and_instances[%d]" % k for k in (1, 2, 3, 4)], "moving_shapes", 1500)
+    assert " passed" in out and "failed" not in out
+
+
 def test_material_pass_on_the_emulated_device(emulated):
     """Round 4's k_material + k_shade<3, .> (materials with textured parameters evaluated ahead of the shading launch) against the
     evaluation inside the shading kernel (PG_MAT_PRE=0): same film, strays and counters -- bump maps, the divergent stand-ins (instances,

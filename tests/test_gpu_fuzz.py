@@ -4,6 +4,7 @@ random rays.  Traversal results, film buffers, stray samples and counters are co
 import os
 import subprocess
 
+import re
 import numpy as np
 import pytest
 
@@ -254,6 +255,45 @@ def random_scene_moving_camera(seed):
     head, rest = text.split("Camera ", 1)
     line, tail = rest.split("\n", 1)
     return head + times + "ActiveTransform EndTime\n" + "\n".join(motion) + "\nActiveTransform All\nCamera " + line + shutter + "\n" + tail
+
+
+def random_scene_motion(seed):
+    """One of the random scenes above with MOVING shapes and object instances (TransformedPrimitive over an AnimatedTransform, interpolated at
+    every ray's time: primitive.cpp:76-103): an end-of-motion translation, sometimes a scale, sometimes a rotation small enough to count as none
+    (Dot(R[0], R[1]) >= 0.9995), on quadrics, on instances of a BVH object and of a lone sphere; TransformTimes inside, across or outside the
+    shutter, every sampler family, volpath; every fourth scene under a moving camera as well.  (Mirrored instances are left still: the reference
+    takes the quaternion of an improper rotation, finds Dot(R[0], R[1]) < 0.9995 and bounds the motion as a rotating one, which the front end refuses.)"""
+    rng = np.random.default_rng(2000 + seed)
+    gen = (random_scene_ext, random_scene_vol, random_scene_ext, random_scene_pixel_sampler)[seed % 4]
+    text = random_scene_moving_camera(seed) if seed % 4 == 2 else gen(seed)
+    chunks = text.split("AttributeBegin\n")
+    moved = 0
+    for k in range(1, len(chunks)):
+        body = chunks[k].split("AttributeEnd", 1)[0]
+        if "LightSource" in body or re.search(r"Scale[^\n]*-", body) or not ('Shape "' in body or "ObjectInstance" in body): continue
+        if moved and rng.random() < 0.35: continue
+        motion = [" ActiveTransform EndTime", " Translate %.6g %.6g %.6g" % tuple(rng.normal(size=3) * 0.5)]
+        r = rng.random()
+        if r < 0.4: motion.append(" Scale %.6g %.6g %.6g" % tuple(0.8 + 0.5 * rng.random(3)))
+        elif r < 0.6: motion.append(" Rotate %.6g %.6g %.6g %.6g" % (rng.uniform(-1.5, 1.5), *(rng.normal(size=3) + np.array([0, 1e-3, 0]))))
+        motion.append(" ActiveTransform All")
+        lines = chunks[k].split("\n")
+        at = next(i for i, l in enumerate(lines) if l.lstrip().startswith(("Shape ", "ObjectInstance ")))
+        chunks[k] = "\n".join(lines[:at] + motion + lines[at:])
+        moved += 1
+    text = "AttributeBegin\n".join(chunks)
+    if moved == 0:  # (random_scene_pixel_sampler's scenes have no attribute blocks: move a sphere of our own)
+        text = text.replace("WorldEnd", 'AttributeBegin\n Translate 0.3 0.2 0\n ActiveTransform EndTime\n Translate 0.5 -0.3 0.4\n ActiveTransform All\n Material "plastic"\n'
+                            ' Shape "sphere" "float radius" [ 0.5 ]\nAttributeEnd\nWorldEnd')
+    if seed % 4 != 2 and seed % 3 == 1:
+        t0, t1 = sorted(rng.random(2) * 1.4 - 0.2)
+        text = text.replace("WorldBegin", "TransformTimes %.6g %.6g\nWorldBegin" % (t0, max(t1, t0 + 1e-3)), 1)
+    return text
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_scene_with_moving_shapes_and_instances(gpu, oracle, seed):
+    check_scene(gpu, oracle, random_scene_motion(seed), seed)
 
 
 @pytest.mark.parametrize("seed", range(48))

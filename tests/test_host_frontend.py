@@ -253,7 +253,7 @@ def test_every_golden_scene_loads_without_an_error_message(pkg):
     assert len(files) > 100
     # scenes that ask for the error path on purpose: an absent map name / texture file / named material, with the reference's fallback
     on_purpose = {"light_gonio_power", "light_projection", "mat_mix", "sampler_stratified_dims_tex", "sobol_tex_lens", "tex_image", "tex_image_lens",
-                  "camanim_lens_tex", "camanim_sobol_tex", "camanim_strat_dims_tex", "camanim_random_tex", "camanim_env"}
+                  "camanim_lens_tex", "camanim_sobol_tex", "camanim_strat_dims_tex", "camanim_random_tex", "camanim_env", "motion_tex"}
     for f in files:
         before = pkg.host_lib().pbrt_host_error_count()
         pkg.HostScene(f).close()
@@ -262,15 +262,34 @@ def test_every_golden_scene_loads_without_an_error_message(pkg):
         assert name in on_purpose or not reported, f"{name}: the host front end reported an Error() while loading"
 
 
-def test_animated_shapes_and_instances_are_refused_not_rendered_with_the_start_transform(pkg):
-    """The reference interpolates an AnimatedTransform per ray inside TransformedPrimitive::Intersect (primitive.cpp:76-96); the device
-    does not.  Such a scene is REFUSED (an Error, no frame, no image with one end of the motion).  A moving CAMERA is rendered (the
-    camanim_* goldens); textures and lights take the start transform in the reference itself (api.cpp WARN_IF_ANIMATED_TRANSFORM): a Warning."""
+def test_moving_shapes_and_instances_become_animated_instances_or_are_refused(pkg):
+    """The reference interpolates an AnimatedTransform per ray inside TransformedPrimitive::Intersect (primitive.cpp:76-103).  A motion without
+    rotation (Dot(R[0], R[1]) >= 0.9995: translation, scale, a rotation of a degree or two) becomes a PgInstance with the two ends' decompositions
+    (a moving SHAPE: an anonymous object created at the identity, api.cpp:1386-1419); a motion WITH rotation needs MotionBounds' derivative terms and
+    is REFUSED -- an Error, no frame, never an image with one end of the motion -- and so are a moving shape inside an object definition and motion
+    beside subsurface materials.  A moving CAMERA is rendered (the camanim_* goldens); textures and lights take the start transform in the
+    reference itself (api.cpp WARN_IF_ANIMATED_TRANSFORM): a Warning."""
     anim = 'ActiveTransform EndTime\nTranslate 0.3 0 0\nActiveTransform All\n'
+    spin = 'ActiveTransform EndTime\nRotate 40 0 1 0\nActiveTransform All\n'
     mini = MINI % (16, 16, 1)
-    for what, txt in (("shape", mini.replace("WorldEnd", "AttributeBegin\n" + anim + 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nAttributeEnd\nWorldEnd')),
-                      ("instance", mini.replace("WorldEnd", 'ObjectBegin "o"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nObjectEnd\nAttributeBegin\n' + anim + 'ObjectInstance "o"\nAttributeEnd\nWorldEnd')),
-                      ):
+    tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\n'
+    shape = lambda a: mini.replace("WorldEnd", "AttributeBegin\nTranslate 0 0 1\n" + a + tri + "AttributeEnd\nWorldEnd")
+    inst = lambda a: mini.replace("WorldEnd", 'ObjectBegin "o"\n' + tri + 'ObjectEnd\nAttributeBegin\n' + a + 'ObjectInstance "o"\nAttributeEnd\nWorldEnd')
+    before = pkg.host_lib().pbrt_host_error_count()
+    for what, txt in (("shape", shape(anim)), ("instance", inst(anim))):
+        s = pkg.HostScene(text=txt)
+        d = s.desc
+        moving = [d.instances[i] for i in range(d.n_instances) if d.instances[i].animated]
+        assert len(moving) == 1 and pkg.host_lib().pbrt_host_error_count() == before, what
+        m = moving[0]
+        assert list(m.time) == [0.0, 1.0] and abs((m.T[1][0] - m.T[0][0]) - 0.3) < 1e-6 and list(m.R[0]) == list(m.R[1]) and m.i2w_end[3] - m.i2w[3] == pytest.approx(0.3)
+        if what == "shape":  # created at the identity: the object's vertices are the file's, the transform carries the CTM
+            assert m.i2w[11] == 1.0 and d.objects[m.object].n_prims == 1 and d.objects[m.object].n_nodes == 0
+        s.close()
+    nested = mini.replace("WorldEnd", 'ObjectBegin "o"\n' + anim + tri + 'ObjectEnd\nObjectInstance "o"\nWorldEnd')
+    sss = shape(anim).replace("WorldEnd", 'Material "subsurface"\nShape "sphere" "float radius" [ 0.2 ]\nWorldEnd')
+    for what, txt in (("rotating shape", shape(spin)), ("rotating instance", inst(spin)), ("mirrored instance", inst("Scale 1 -1 1\n" + anim)),
+                      ("moving shape inside an object definition", nested), ("motion beside a BSSRDF material", sss)):
         before = pkg.host_lib().pbrt_host_error_count()
         with pytest.raises(pkg.PbrtGpuError):
             pkg.HostScene(text=txt)

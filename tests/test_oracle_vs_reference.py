@@ -89,8 +89,9 @@ def test_fuzz_scenes_live_when_reference_present(pkg, oracle, tmp_path):
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     scene_file, out = str(tmp_path / "fuzz.pbrt"), str(tmp_path / "ref.pfm")
-    for gen in (fz.random_scene, fz.random_scene_ext, fz.random_scene_vol, fz.random_scene_moving_camera):  # (the last: the same scenes under a moving camera)
-        for seed in (range(16) if gen in (fz.random_scene_vol, fz.random_scene_moving_camera) else range(0, 24, 2)):
+    # (the last two: the same scenes under a moving camera; with moving shapes and object instances)
+    for gen in (fz.random_scene, fz.random_scene_ext, fz.random_scene_vol, fz.random_scene_moving_camera, fz.random_scene_motion):
+        for seed in (range(16) if gen in (fz.random_scene_vol, fz.random_scene_moving_camera) else (range(24) if gen is fz.random_scene_motion else range(0, 24, 2))):
             open(scene_file, "w").write(gen(seed))
             oracle.run_reference(scene_file, out, nthreads=1)  # one thread: overlapping FilmTiles merge in tile order
             img, _ = oracle.render_image(pkg.HostScene(scene_file))
