@@ -203,6 +203,8 @@ struct Flat {
     std::vector<PgBxDF> bxdfs;
     std::vector<PgLight> lights;
     std::vector<PgSphere> spheres;
+    std::vector<PgObject> objects;      // the primitives TransformedPrimitives wrap: a BVHAccel's nodes / primitives appended, or one primitive
+    std::vector<PgInstance> instances;  // one per TransformedPrimitive of the scene's BVH
     std::vector<PgMedium> media;
     std::vector<int32_t> mediaGrid;   // per medium: index into grids, -1 = HomogeneousMedium
     std::vector<PgDensityGrid> grids;
@@ -260,7 +262,53 @@ void FlattenScene(const Scene &scene, int maxDepth, bool volumetric, const std::
     if (bvh->primitives.empty() || !bvh->nodes) Unsupported("an empty scene");
     const PgBVHNode *nodes = reinterpret_cast<const PgBVHNode *>(bvh->nodes);
     flat->nodes.assign(nodes, nodes + CountNodes(nodes));
-    const size_t n = bvh->primitives.size();
+    const size_t nTop = bvh->primitives.size();
+    const int nTopNodes = (int)flat->nodes.size();
+    // every primitive the device sees: the scene BVH's own (BVHAccel::primitives order), then -- once per distinct wrapped primitive -- what the
+    // TransformedPrimitives among them wrap (api.cpp:1399-1419 a moving shape's primitives, :1567-1586 an object instance): a BVHAccel's nodes
+    // and primitives appended verbatim, or a lone GeometricPrimitive (include/pbrt_gpu.h, PgObject / PgInstance)
+    std::vector<const Primitive *> all;
+    for (const auto &pr : bvh->primitives) all.push_back(pr.get());
+    std::map<const Primitive *, int> objectIndex;
+    std::vector<int> instanceOf(nTop, -1);
+    for (size_t k = 0; k < nTop; ++k) {
+        const TransformedPrimitive *tp = dynamic_cast<const TransformedPrimitive *>(all[k]);
+        if (!tp) continue;
+        const Primitive *inner = tp->primitive.get();
+        if (!objectIndex.count(inner)) {
+            PgObject o;
+            o.first_prim = (int)all.size(); o.first_node = (int)flat->nodes.size();
+            if (const BVHAccel *ob = dynamic_cast<const BVHAccel *>(inner)) {
+                const PgBVHNode *on = reinterpret_cast<const PgBVHNode *>(ob->nodes);
+                o.n_nodes = CountNodes(on); o.n_prims = (int)ob->primitives.size();
+                flat->nodes.insert(flat->nodes.end(), on, on + o.n_nodes);
+                for (const auto &pr : ob->primitives) all.push_back(pr.get());
+            } else if (dynamic_cast<const GeometricPrimitive *>(inner)) { o.n_nodes = 0; o.n_prims = 1; all.push_back(inner); }
+            else Unsupported("a TransformedPrimitive over something other than a BVHAccel or one GeometricPrimitive");
+            objectIndex[inner] = (int)flat->objects.size();
+            flat->objects.push_back(o);
+        }
+        PgInstance in;
+        memset(&in, 0, sizeof(in));
+        const AnimatedTransform &a = tp->PrimitiveToWorld;
+        CopyMatrix(a.startTransform->m, in.i2w); CopyMatrix(a.startTransform->mInv, in.w2i);
+        in.object = objectIndex[inner];
+        in.identity = a.startTransform->IsIdentity() ? 1 : 0;
+        if (a.actuallyAnimated) {  // the reference's own decomposition (AnimatedTransform's constructor, transform.cpp:396-411)
+            if (a.hasRotation) Unsupported("a TransformedPrimitive whose motion rotates (AnimatedTransform::hasRotation: MotionBounds' derivative terms)");
+            in.animated = 1;
+            in.time[0] = a.startTime; in.time[1] = a.endTime;
+            CopyMatrix(a.endTransform->m, in.i2w_end); CopyMatrix(a.endTransform->mInv, in.w2i_end);
+            for (int e = 0; e < 2; ++e) {
+                in.T[e][0] = a.T[e].x; in.T[e][1] = a.T[e].y; in.T[e][2] = a.T[e].z;
+                in.R[e][0] = a.R[e].v.x; in.R[e][1] = a.R[e].v.y; in.R[e][2] = a.R[e].v.z; in.R[e][3] = a.R[e].w;
+                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) in.S[e][3 * i + j] = a.S[e].m[i][j];
+            }
+        }
+        instanceOf[k] = (int)flat->instances.size();
+        flat->instances.push_back(in);
+    }
+    const size_t n = all.size();
     flat->indices.assign(3 * n, 0); flat->triFlags.assign(n, 0); flat->triMaterial.assign(n, 0); flat->triLight.assign(n, -1);
     std::map<const Light *, int> lightIndex;
     for (size_t i = 0; i < scene.lights.size(); ++i) lightIndex[scene.lights[i].get()] = (int)i;
@@ -272,8 +320,9 @@ void FlattenScene(const Scene &scene, int maxDepth, bool volumetric, const std::
     bool anyN = false, anyUV = false, anyS = false, anyMedium = false;
     // pass 1: vertex arrays of the meshes in first-use order
     for (size_t k = 0; k < n; ++k) {
-        const GeometricPrimitive *gp = dynamic_cast<const GeometricPrimitive *>(bvh->primitives[k].get());
-        if (!gp) Unsupported("object instancing (TransformedPrimitive) in this binding");
+        if (k < nTop && instanceOf[k] >= 0) continue;
+        const GeometricPrimitive *gp = dynamic_cast<const GeometricPrimitive *>(all[k]);
+        if (!gp) Unsupported("a primitive that is neither a GeometricPrimitive nor a top-level TransformedPrimitive (a nested instance)");
         if (const Triangle *tri = dynamic_cast<const Triangle *>(gp->shape.get())) {
             const TriangleMesh *m = tri->mesh.get();
             if (!meshBase.count(m)) {
@@ -299,7 +348,12 @@ void FlattenScene(const Scene &scene, int maxDepth, bool volumetric, const std::
     }
     // pass 2: primitives in BVHAccel::primitives (= orderedPrims) order
     for (size_t k = 0; k < n; ++k) {
-        const GeometricPrimitive *gp = static_cast<const GeometricPrimitive *>(bvh->primitives[k].get());
+        if (k < nTop && instanceOf[k] >= 0) {  // TransformedPrimitive: primitive.h:92-117
+            flat->indices[3 * k] = instanceOf[k];
+            flat->triFlags[k] = PG_PRIM_INSTANCE;
+            continue;
+        }
+        const GeometricPrimitive *gp = static_cast<const GeometricPrimitive *>(all[k]);
         const Shape *shape = gp->shape.get();
         if (const Triangle *tri = dynamic_cast<const Triangle *>(shape)) {
             const TriangleMesh *m = tri->mesh.get();
@@ -406,8 +460,10 @@ void FlattenScene(const Scene &scene, int maxDepth, bool volumetric, const std::
     PgSceneDesc &d = flat->desc;
     memset(&d, 0, sizeof(d));
     d.abi_version = PG_ABI_VERSION;
-    d.n_nodes = d.n_nodes_all = (int)flat->nodes.size(); d.nodes = flat->nodes.data();
-    d.n_tris = d.n_prims_all = (int)n; d.indices = flat->indices.data(); d.tri_flags = flat->triFlags.data();
+    d.n_nodes = nTopNodes; d.n_nodes_all = (int)flat->nodes.size(); d.nodes = flat->nodes.data();
+    d.n_tris = (int)nTop; d.n_prims_all = (int)n; d.indices = flat->indices.data(); d.tri_flags = flat->triFlags.data();
+    d.n_objects = (int)flat->objects.size(); d.objects = flat->objects.data();
+    d.n_instances = (int)flat->instances.size(); d.instances = flat->instances.data();
     d.tri_material = flat->triMaterial.data(); d.tri_light = flat->triLight.data();
     d.n_verts = (int)nVerts; d.P = flat->P.data();
     d.N = anyN ? flat->N.data() : nullptr; d.UV = anyUV ? flat->UV.data() : nullptr; d.S = anyS ? flat->S.data() : nullptr;

@@ -21,7 +21,11 @@ SCENES = ["cornell_32", "cornell_crop", "cornell_lens", "cornell_plastic", "corn
           "sobol_round_crop", "vol_fog", "vol_smoke", "vol_path_none_glass", "sobol_vol_smoke", "sampler_random", "sampler_stratified",
           "sampler_stratified_dims", "filter_02sequence_lens", "sampler_maxmindist", "sampler_lowdisc_vol", "many_lights",
           # a moving camera: the binding hands over the REFERENCE's own decomposition of the two camera transforms (AnimatedTransform's T / R / S)
-          "camanim_translate", "camanim_rotate", "camanim_small_rotate", "camanim_times_scale", "camanim_ortho", "camanim_vol"]
+          "camanim_translate", "camanim_rotate", "camanim_small_rotate", "camanim_times_scale", "camanim_ortho", "camanim_vol",
+          # TransformedPrimitives: object instances (a BVHAccel's nodes / primitives appended, a lone primitive), and MOVING shapes / instances --
+          # the reference's own AnimatedTransform (both ends, T / R / S, the times) handed over, interpolated per ray on the device
+          "instance_boxes", "instance_accel", "motion_boxes", "motion_boxes_times", "motion_small_rotation", "motion_instances",
+          "motion_instances_shutter", "motion_sobol", "motion_random", "motion_stratified", "motion_vol", "motion_camera_too"]
 
 
 def run_binding(pkg, scene_file, out):
