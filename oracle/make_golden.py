@@ -870,6 +870,10 @@ GRID_SCENES = {
     "grid_fog_camera": cornell(32, 24, 8, integrator='Integrator "volpath" "integer maxdepth" [ 4 ]',
                                world_edit=lambda s: with_grid_fog(s).replace("# light\nAttributeBegin", DELTA_POINT + "# light\nAttributeBegin")),
     "grid_transformed": cornell(32, 32, 8, integrator='Integrator "volpath" "integer maxdepth" [ 5 ] "float rrthreshold" [ 0.5 ]', world_edit=with_grid_transformed),
+    # a GridDensityMedium beside MOVING boxes: the transmittance rays of ratio tracking and both shading phases carry the rays' times
+    "grid_puff_motion": with_moving_boxes(cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 5 ]', world_edit=with_grid_puff)),
+    "grid_puff_motion_random": with_moving_boxes(cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 4 ]', world_edit=lambda s: with_grid_puff(s, dense=True)),
+                                                 times="TransformTimes 0.2 0.9\n").replace('Sampler "halton"', 'Sampler "random"'),
     "grid_puff_sobol": cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 5 ]', world_edit=with_grid_puff).replace('Sampler "halton"', 'Sampler "sobol"'),
     "grid_puff_random": cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 5 ]', world_edit=with_grid_puff).replace('Sampler "halton"', 'Sampler "random"'),
     "grid_puff_stratified": cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 5 ]', world_edit=lambda s: with_grid_puff(s, dense=True))
@@ -901,6 +905,16 @@ def with_sss(s, mat, tall=None):
     return s
 
 
+def with_moving_sss_boxes(s):
+    """Both Cornell boxes of ONE subsurface Material object (a named material), each moving on its own: a probe segment started on one box can
+    leave through the other (bssrdf.cpp:301), and both are TransformedPrimitives interpolated at the path's time."""
+    s = with_moving_boxes(s, tall_motion="Translate 30 0 -20")
+    assert SHORT_BOX_MATTE in s
+    s = s.replace(SHORT_BOX_MATTE, '# short box\nNamedMaterial "skin"', 1)
+    s = s.replace('Material "plastic" "rgb Kd" [ 0.2 0.5 0.3 ] "float roughness" [ 0.2 ]\n', 'NamedMaterial "skin"\n', 1)
+    return s.replace("WorldBegin\n", 'WorldBegin\nMakeNamedMaterial "skin" "string type" "subsurface" "rgb sigma_a" [ 0.002 0.004 0.008 ] "rgb sigma_s" [ 0.1 0.08 0.06 ] "float scale" [ 1 ] "float eta" [ 1.33 ]\n', 1)
+
+
 SSS_SCENES = {
     # both boxes share one SubsurfaceMaterial: probe rays started on one box may leave through the other (bssrdf.cpp:301)
     "sss_subsurface": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 6 ]', world_edit=lambda s: with_sss(s, SSS_PLAIN)),
@@ -908,6 +922,12 @@ SSS_SCENES = {
     "sss_two_materials": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 6 ]', world_edit=lambda s: with_sss(s, SSS_PLAIN, tall=SSS_PLAIN)),
     "sss_preset_volpath": cornell(32, 32, 8, integrator='Integrator "volpath" "integer maxdepth" [ 6 ]',
                                   world_edit=lambda s: with_fog(with_sss(s, 'Material "subsurface" "string name" "Skin1" "float scale" [ 0.05 ] "float eta" [ 1.4 ]', tall='Material "matte" "rgb Kd" [ 0.6 0.6 0.6 ]'))),
+    # MOVING boxes of a subsurface material: the probe rays of Sample_Sp enter the moving instance at the path's time, the exit vertex comes back
+    # through the transform interpolated for the chosen probe ray
+    "sss_motion": with_moving_sss_boxes(cornell(24, 24, 4, integrator='Integrator "path" "integer maxdepth" [ 5 ]')),
+    "sss_motion_volpath": with_moving_boxes(cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 5 ]',
+                                                    world_edit=lambda s: with_fog(with_sss(s, 'Material "subsurface" "string name" "Skin1" "float scale" [ 0.05 ] "float eta" [ 1.4 ]'))),
+                                            times="TransformTimes 0.1 0.8\n").replace('Sampler "halton"', 'Sampler "sobol"'),
     "sss_kd_rough": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 6 ]',
                             world_edit=lambda s: with_sss(s, 'Material "kdsubsurface" "rgb Kd" [ 0.6 0.4 0.3 ] "rgb mfp" [ 8 12 20 ] "float uroughness" [ 0.1 ] "float vroughness" [ 0.2 ] "float g" [ 0.3 ]',
                                                           tall='Material "kdsubsurface" "rgb Kd" [ 0.2 0.5 0.7 ] "rgb mfp" [ 30 30 30 ] "float scale" [ 0.5 ] "float eta" [ 1.2 ] "bool remaproughness" "false" "float uroughness" [ 0.05 ] "float vroughness" [ 0.05 ]')),

@@ -84,7 +84,7 @@ struct PgScene {
     DeviceBuffer bssrdfs, materialBssrdf, bssrdfTables;  // subsurface scattering (ABI 24)
     DeviceBuffer grids, mediaGrid, gridDensity, gridVertex;  // GridDensityMedium (ABI 23); the two-phase shading's per-slot vertex record
     // the BSSRDF branch of Li: per-slot state between entry and exit vertex (SssState), the job queue, two probe queues
-    DeviceBuffer sssPo, sssFrame[3], sssCoef[2], sssTarget, sssCount, sssHit, sssHitO, sssHitD, sssHitInst, sssMedium, sssQo[3], sssQd[3], sssCounts, sssTail;
+    DeviceBuffer sssPo, sssFrame[3], sssCoef[2], sssTarget, sssCount, sssHit, sssHitO, sssHitD, sssHitInst, sssHitXf, sssMedium, sssQo[3], sssQd[3], sssCounts, sssTail;
     int sssCapacity = 0;
     DeviceBuffer lightHot;  // DScene::lightHot
     DeviceBuffer haltonDims;  // DScene::haltonDims
@@ -303,8 +303,6 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         d.nInstances = s->instances.p ? desc->n_instances : 0;
         d.hasMotion = 0; d.rayTimes = 0; d.animXf = nullptr;
         for (int i = 0; i < d.nInstances; ++i) if (desc->instances[i].animated) d.hasMotion = d.rayTimes = 1;
-        if (d.hasMotion && (desc->n_bssrdfs > 0 || desc->n_grids > 0))
-            FAIL(PG_ERR_UNSUPPORTED, "moving shapes / instances together with BSSRDF materials or grid media (their kernels do not carry the rays' time): %d / %d", desc->n_bssrdfs, desc->n_grids);
         HIP_TRY_S(s->wnodes.alloc(sizeof(float4) * w.size()));
         if (!w.empty()) HIP_TRY_S(hipMemcpy(s->wnodes.p, w.data(), s->wnodes.bytes, hipMemcpyHostToDevice));
         d.wnodes = (const float4 *)s->wnodes.p;
@@ -1180,8 +1178,9 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
             for (int i = 0; i < 2; ++i) HIP_TRY(s->sssCoef[i].alloc(n * sizeof(float4)));
             HIP_TRY(s->sssHit.alloc(n * sizeof(float4))); HIP_TRY(s->sssHitO.alloc(n * sizeof(float4))); HIP_TRY(s->sssHitD.alloc(n * sizeof(float4)));
             HIP_TRY(s->sssHitInst.alloc(n * sizeof(int)));
+            if (s->d.hasMotion) HIP_TRY(s->sssHitXf.alloc(n * PG_XF_STRIDE * sizeof(float)));  // the chosen hit's interpolated instance matrices
             HIP_TRY(s->sssMedium.alloc(n * sizeof(int2)));
-            for (int i = 0; i < 3; ++i) { HIP_TRY(s->sssQo[i].alloc(n * sizeof(float4))); HIP_TRY(s->sssQd[i].alloc(n * sizeof(float4))); }
+            for (int i = 0; i < 3; ++i) { HIP_TRY(s->sssQo[i].alloc(n * sizeof(float4))); HIP_TRY(s->sssQd[i].alloc(n * (sizeof(float4) + (s->d.hasMotion ? sizeof(float) : 0)))); }  // (+ the probe rays' times: PG_QUEUE_TIMES)
             HIP_TRY(s->sssCounts.alloc(3 * QSTRIDE * sizeof(int)));
             HIP_TRY(s->sssTail.alloc(QSTRIDE * sizeof(int)));
             s->sssCapacity = capacity;
@@ -1189,7 +1188,7 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
         sq.po = (float4 *)s->sssPo.p; sq.target = (float4 *)s->sssTarget.p; sq.count = (int2 *)s->sssCount.p;
         for (int i = 0; i < 3; ++i) sq.frame[i] = (float4 *)s->sssFrame[i].p;
         for (int i = 0; i < 2; ++i) sq.coef[i] = (float4 *)s->sssCoef[i].p;
-        sq.hit = (float4 *)s->sssHit.p; sq.hitO = (float4 *)s->sssHitO.p; sq.hitD = (float4 *)s->sssHitD.p; sq.hitInst = (int *)s->sssHitInst.p; sq.medium = (int2 *)s->sssMedium.p;
+        sq.hit = (float4 *)s->sssHit.p; sq.hitO = (float4 *)s->sssHitO.p; sq.hitD = (float4 *)s->sssHitD.p; sq.hitInst = (int *)s->sssHitInst.p; sq.hitXf = (float *)s->sssHitXf.p; sq.medium = (int2 *)s->sssMedium.p;
         sq.qjob.o = (float4 *)s->sssQo[0].p; sq.qjob.d = (float4 *)s->sssQd[0].p; sq.qjob.counts = (int *)s->sssCounts.p;
         for (int i = 0; i < 2; ++i) { sssP[i].o = (float4 *)s->sssQo[1 + i].p; sssP[i].d = (float4 *)s->sssQd[1 + i].p; sssP[i].counts = (int *)s->sssCounts.p + (1 + i) * QSTRIDE; }
     }
@@ -1317,6 +1316,7 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                                     float4 *hk = (float4 *)s->hitsMain.p + off;
                                     DScene dk = dv;
                                     if (dk.hitInst) dk.hitInst += off;
+                                    if (dk.animXf) dk.animXf += off * PG_XF_STRIDE;
                                     PG_TIMED(0, stream, launch_closest(dk, s->trace, tk[tc], hk, hitT + off, cnClosest, (int *)s->cursors.p, (int *)s->cullGuard.p, stream));
                                     ++closestLaunches; closestRays += nk;
                                     HIP_TRY(hipMemsetAsync(tk[tc ^ 1].counts, 0, QSTRIDE * sizeof(int), stream));
@@ -1469,6 +1469,7 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                         const size_t n1 = (size_t)q[0].regionCap * PG_REGIONS;
                         DScene dprobe = s->d;  // the probe rays' hits go where the MIS rays' went (k_resolve is done with those)
                         if (dprobe.hitInst) dprobe.hitInst += n1;
+                        if (dprobe.animXf) dprobe.animXf += n1 * PG_XF_STRIDE;
                         for (int pass = 1; pass <= 2; ++pass) {
                             RayQueue curQ = sq.qjob;
                             uint64_t nRays = nJobs;

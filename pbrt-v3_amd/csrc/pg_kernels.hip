@@ -2834,6 +2834,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
         block_push<1, false, PG_SHADE_BLOCK>(&sss.qjob, &pushJob, &posJob);
         if (pushJob) {
             sss.qjob.o[posJob] = s_ray[0][0][tid]; sss.qjob.d[posJob] = s_ray[0][1][tid];
+            if (sc.rayTimes) PG_QUEUE_TIMES(sc, sss.qjob)[posJob] = PG_QUEUE_TIMES(sc, qin)[i];  // the probe rays' time: po's = the ray's (bssrdf.cpp:290-296)
             if constexpr (QSTATE) {
                 const float4 m4 = s_state[2][tid];
                 st.beta[slot] = s_state[1][tid];
@@ -3299,7 +3300,10 @@ __global__ __launch_bounds__(PG_BLOCK) void k_sss_probe(DScene sc, SssState sss,
                     selected = selected < 0 ? 0 : (selected > cnt.x - 1 ? cnt.x - 1 : selected);
                     if (cnt.y == selected) {
                         sss.hit[slot] = h4; sss.hitO[slot] = o4; sss.hitD[slot] = d4;
-                        sss.hitInst[slot] = sc.hitInst ? sc.hitInst[i] : -1;
+                        const int hInst = sc.hitInst ? sc.hitInst[i] : -1;
+                        sss.hitInst[slot] = hInst;
+                        if (sss.hitXf && hInst >= 0 && sc.instances[hInst].animated)  // a moving instance: the matrices k_trace interpolated for this probe ray
+                            for (int q = 0; q < 33; ++q) sss.hitXf[(size_t)PG_XF_STRIDE * slot + q] = sc.animXf[(size_t)PG_XF_STRIDE * i + q];
                         if constexpr (VOL) sss.medium[slot] = make_int2(rayMed, rayMed);
                         go = false;
                     }
@@ -3329,6 +3333,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_sss_probe(DScene sc, SssState sss,
     int pos;
     block_push<1, false>(&qout, &push, &pos);
     if (push) { qout.o[pos] = no; qout.d[pos] = nd; }
+    if (push && sc.rayTimes) PG_QUEUE_TIMES(sc, qout)[pos] = PG_QUEUE_TIMES(sc, qin)[i];
 }
 void launch_sss_probe(const DScene &sc, SssState sss, int pass, RayQueue qin, const float4 *hits, RayQueue qout, hipStream_t s, bool vol, bool first) {
     int nblk = PG_REGIONS * (qin.regionCap / PG_BLOCK);
@@ -3425,28 +3430,37 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_sss_exit(DScene sc, RenderPa
         // ---- pi: the chosen hit as a SurfaceInteraction (the tail of Triangle::Intersect / Sphere::Intersect, then the instance's transform)
         const float4 h4 = sss.hit[slot], o4 = sss.hitO[slot], d4 = sss.hitD[slot];
         const int prim = __float_as_int(h4.x), inst = sss.hitInst[slot];
+        // the chosen hit's instance transform: the instance's own, or -- a moving instance -- what k_sss_probe kept of k_trace's interpolation
+        const float *i2w = nullptr, *w2i = nullptr;
+        bool instIdentity = true;
+        if (inst >= 0) {
+            const PgInstance &in = sc.instances[inst];
+            const bool moving = in.animated && sss.hitXf;
+            i2w = moving ? sss.hitXf + (size_t)PG_XF_STRIDE * slot : in.i2w;
+            w2i = moving ? sss.hitXf + (size_t)PG_XF_STRIDE * slot + 16 : in.w2i;
+            instIdentity = moving ? sss.hitXf[(size_t)PG_XF_STRIDE * slot + 32] != 0.f : in.identity != 0;
+        }
         const V3 rayD = mk(d4.x, d4.y, d4.z);
         const Tri tri = load_tri(sc, prim);
         Isect is;
         V3 shapeRayD = rayD;
-        if (inst >= 0) shapeRayD = m4_vec(sc.instances[inst].w2i, rayD);
+        if (inst >= 0) shapeRayD = m4_vec(w2i, rayD);
         if (tri.flags & PG_PRIM_SPHERE) {
             V3 shapeRayO = mk(o4.x, o4.y, o4.z);
-            if (inst >= 0) { float dt; instance_ray(sc.instances[inst].w2i, shapeRayO, rayD, shapeRayO, shapeRayD, dt); }
+            if (inst >= 0) { float dt; instance_ray(w2i, shapeRayO, rayD, shapeRayO, shapeRayD, dt); }
             const SphereHit sh = sphere_interaction(sc.spheres[__float_as_int(tri.p0.x)], shapeRayO, shapeRayD, h4.y);
             is.p = sh.p; is.pError = sh.pError; is.wo = sh.wo; is.n = sh.n; is.ns = sh.n; is.sdpdu = sh.dpdu;
             is.sdpdv = sh.dpdv; is.sdndu = sh.dndu; is.sdndv = sh.dndv;
         } else is = make_isect(sc, prim, tri, h4.y, h4.z, h4.w, shapeRayD);
-        if (inst >= 0 && !sc.instances[inst].identity) {  // InterpolatedPrimToWorld(*isect), transform.cpp:262-297
-            const PgInstance &in = sc.instances[inst];
+        if (inst >= 0 && !instIdentity) {  // InterpolatedPrimToWorld(*isect), transform.cpp:262-297
             Isect w;
-            w.p = m4_point_err2(in.i2w, is.p, is.pError, w.pError);
-            w.n = normalize(m4_normal(in.w2i, is.n));
-            w.wo = normalize(m4_vec(in.i2w, is.wo));
-            w.sdpdu = m4_vec(in.i2w, is.sdpdu);
-            w.sdpdv = m4_vec(in.i2w, is.sdpdv);
-            w.sdndu = m4_normal(in.w2i, is.sdndu); w.sdndv = m4_normal(in.w2i, is.sdndv);
-            w.ns = normalize(m4_normal(in.w2i, is.ns));
+            w.p = m4_point_err2(i2w, is.p, is.pError, w.pError);
+            w.n = normalize(m4_normal(w2i, is.n));
+            w.wo = normalize(m4_vec(i2w, is.wo));
+            w.sdpdu = m4_vec(i2w, is.sdpdu);
+            w.sdpdv = m4_vec(i2w, is.sdpdv);
+            w.sdndu = m4_normal(w2i, is.sdndu); w.sdndv = m4_normal(w2i, is.sdndv);
+            w.ns = normalize(m4_normal(w2i, is.ns));
             if (dot(w.ns, w.n) < 0.f) w.ns = -w.ns;
             is = w;
         }
@@ -3610,6 +3624,12 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_sss_exit(DScene sc, RenderPa
     if (pushNext) { qnext.o[posNext] = s_ray[0][0][tid]; qnext.d[posNext] = s_ray[0][1][tid]; }
     if (pushShadow) { qshadow.o[posShadow] = s_ray[1][0][tid]; qshadow.d[posShadow] = s_ray[1][1][tid]; }
     if (pushMis) { qmis.o[posMis] = s_ray[2][0][tid]; qmis.d[posMis] = s_ray[2][1][tid]; }
+    if (sc.rayTimes) {  // the rays leaving pi carry the path's time (the job's probe ray has it)
+        const float t = j >= 0 ? PG_QUEUE_TIMES(sc, sss.qjob)[j] : 0.f;
+        if (pushNext) PG_QUEUE_TIMES(sc, qnext)[posNext] = t;
+        if (pushShadow) PG_QUEUE_TIMES(sc, qshadow)[posShadow] = t;
+        if (pushMis) PG_QUEUE_TIMES(sc, qmis)[posMis] = t;
+    }
     if (alive) {
         if constexpr (VOL) {  // by slot: L is there already (k_resolve_vol adds to it), beta and meta follow
             st.beta[slot] = outB; st.meta[slot] = outM;

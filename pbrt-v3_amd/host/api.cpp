@@ -1528,11 +1528,6 @@ void pbrtWorldEnd() {  // api.cpp:1590-1644
     std::unique_ptr<GpuPathIntegrator> integrator(MakeIntegrator());
     std::unique_ptr<Scene> scene(MakeScene());
     if (timing) fprintf(stderr, "pbrt host: MakeScene (BVH build) %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild).count());
-    if (renderOptions->anyMotion && (!renderOptions->bssrdfs.empty() || !renderOptions->grids.empty())) {
-        Error("Moving shapes / instances together with subsurface materials or a grid medium are outside this build's closed set "
-              "(the device's probe-chain and ratio-tracking kernels do not carry the rays' time); the scene will not be rendered.");
-        renderOptions->refused = true;
-    }
     if (renderOptions->refused) {
         Error("Scene not rendered: it uses features outside this build's closed set (see the errors above); no approximate image is written.");
         scene.reset(); integrator.reset();

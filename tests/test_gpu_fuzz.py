@@ -257,15 +257,8 @@ def random_scene_moving_camera(seed):
     return head + times + "ActiveTransform EndTime\n" + "\n".join(motion) + "\nActiveTransform All\nCamera " + line + shutter + "\n" + tail
 
 
-def random_scene_motion(seed):
-    """One of the random scenes above with MOVING shapes and object instances (TransformedPrimitive over an AnimatedTransform, interpolated at
-    every ray's time: primitive.cpp:76-103): an end-of-motion translation, sometimes a scale, sometimes a rotation small enough to count as none
-    (Dot(R[0], R[1]) >= 0.9995), on quadrics, on instances of a BVH object and of a lone sphere; TransformTimes inside, across or outside the
-    shutter, every sampler family, volpath; every fourth scene under a moving camera as well.  (Mirrored instances are left still: the reference
-    takes the quaternion of an improper rotation, finds Dot(R[0], R[1]) < 0.9995 and bounds the motion as a rotating one, which the front end refuses.)"""
-    rng = np.random.default_rng(2000 + seed)
-    gen = (random_scene_ext, random_scene_vol, random_scene_ext, random_scene_pixel_sampler)[seed % 4]
-    text = random_scene_moving_camera(seed) if seed % 4 == 2 else gen(seed)
+def add_motion(text, rng):
+    """Put attribute blocks of `text` that hold shapes or object instances (no lights, no mirroring) under an end-of-motion transform."""
     chunks = text.split("AttributeBegin\n")
     moved = 0
     for k in range(1, len(chunks)):
@@ -285,6 +278,19 @@ def random_scene_motion(seed):
     if moved == 0:  # (random_scene_pixel_sampler's scenes have no attribute blocks: move a sphere of our own)
         text = text.replace("WorldEnd", 'AttributeBegin\n Translate 0.3 0.2 0\n ActiveTransform EndTime\n Translate 0.5 -0.3 0.4\n ActiveTransform All\n Material "plastic"\n'
                             ' Shape "sphere" "float radius" [ 0.5 ]\nAttributeEnd\nWorldEnd')
+    return text
+
+
+def random_scene_motion(seed):
+    """One of the random scenes above with MOVING shapes and object instances (TransformedPrimitive over an AnimatedTransform, interpolated at
+    every ray's time: primitive.cpp:76-103): an end-of-motion translation, sometimes a scale, sometimes a rotation small enough to count as none
+    (Dot(R[0], R[1]) >= 0.9995), on quadrics, on instances of a BVH object and of a lone sphere; TransformTimes inside, across or outside the
+    shutter, every sampler family, volpath; every fourth scene under a moving camera as well.  (Mirrored instances are left still: the reference
+    takes the quaternion of an improper rotation, finds Dot(R[0], R[1]) < 0.9995 and bounds the motion as a rotating one, which the front end refuses.)"""
+    rng = np.random.default_rng(2000 + seed)
+    gen = (random_scene_ext, random_scene_vol, random_scene_ext, random_scene_pixel_sampler)[seed % 4]
+    text = random_scene_moving_camera(seed) if seed % 4 == 2 else gen(seed)
+    text = add_motion(text, rng)
     if seed % 4 != 2 and seed % 3 == 1:
         t0, t1 = sorted(rng.random(2) * 1.4 - 0.2)
         text = text.replace("WorldBegin", "TransformTimes %.6g %.6g\nWorldBegin" % (t0, max(t1, t0 + 1e-3)), 1)
@@ -294,6 +300,18 @@ def random_scene_motion(seed):
 @pytest.mark.parametrize("seed", range(48))
 def test_random_scene_with_moving_shapes_and_instances(gpu, oracle, seed):
     check_scene(gpu, oracle, random_scene_motion(seed), seed)
+
+
+def random_scene_motion_sss_grid(seed):
+    """Moving shapes and instances beside subsurface materials (the probe chains of Sample_Sp run at the path's time, the exit vertex comes back
+    through the moving instance's interpolated transform) or a GridDensityMedium (ratio tracking's transmittance rays, both shading phases)."""
+    rng = np.random.default_rng(3000 + seed)
+    return add_motion(random_scene_sss_grid(seed, ("sss", "grid", "both")[seed % 3] if seed % 3 != 2 else "sss"), rng)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_sss_or_grid_scene_with_moving_shapes(gpu, oracle, seed):
+    check_scene(gpu, oracle, random_scene_motion_sss_grid(seed), seed)
 
 
 @pytest.mark.parametrize("seed", range(48))

@@ -266,8 +266,7 @@ def test_moving_shapes_and_instances_become_animated_instances_or_are_refused(pk
     """The reference interpolates an AnimatedTransform per ray inside TransformedPrimitive::Intersect (primitive.cpp:76-103).  A motion without
     rotation (Dot(R[0], R[1]) >= 0.9995: translation, scale, a rotation of a degree or two) becomes a PgInstance with the two ends' decompositions
     (a moving SHAPE: an anonymous object created at the identity, api.cpp:1386-1419); a motion WITH rotation needs MotionBounds' derivative terms and
-    is REFUSED -- an Error, no frame, never an image with one end of the motion -- and so are a moving shape inside an object definition and motion
-    beside subsurface materials.  A moving CAMERA is rendered (the camanim_* goldens); textures and lights take the start transform in the
+    is REFUSED -- an Error, no frame, never an image with one end of the motion -- and so is a moving shape inside an object definition.  A moving CAMERA is rendered (the camanim_* goldens); textures and lights take the start transform in the
     reference itself (api.cpp WARN_IF_ANIMATED_TRANSFORM): a Warning."""
     anim = 'ActiveTransform EndTime\nTranslate 0.3 0 0\nActiveTransform All\n'
     spin = 'ActiveTransform EndTime\nRotate 40 0 1 0\nActiveTransform All\n'
@@ -287,9 +286,8 @@ def test_moving_shapes_and_instances_become_animated_instances_or_are_refused(pk
             assert m.i2w[11] == 1.0 and d.objects[m.object].n_prims == 1 and d.objects[m.object].n_nodes == 0
         s.close()
     nested = mini.replace("WorldEnd", 'ObjectBegin "o"\n' + anim + tri + 'ObjectEnd\nObjectInstance "o"\nWorldEnd')
-    sss = shape(anim).replace("WorldEnd", 'Material "subsurface"\nShape "sphere" "float radius" [ 0.2 ]\nWorldEnd')
     for what, txt in (("rotating shape", shape(spin)), ("rotating instance", inst(spin)), ("mirrored instance", inst("Scale 1 -1 1\n" + anim)),
-                      ("moving shape inside an object definition", nested), ("motion beside a BSSRDF material", sss)):
+                      ("moving shape inside an object definition", nested)):
         before = pkg.host_lib().pbrt_host_error_count()
         with pytest.raises(pkg.PbrtGpuError):
             pkg.HostScene(text=txt)
