@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box A/B of the packed lobe records: the previous commit's device library (tools/experiments/_ab/libpbrt_gpu_prev.so, built from bf5a47e)
-# against the tree's, alternating, on the two divergent stand-ins.
+# against the tree's, alternating, on the two divergent stand-ins.  (The previous library is not kept in the tree: rebuild it from that commit to repeat.)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; ulimit -c 0; export TMPDIR=/tmp
 OUT=gpurun_out/r05o; mkdir -p $OUT
 run() { # run TAG LIB bench-args
