@@ -286,7 +286,7 @@ typedef struct PgInstance {      /* TransformedPrimitive (primitive.h:92-117) */
     float i2w[16], w2i[16];      /* InstanceToWorld (the AnimatedTransform's startTransform) and its inverse, row-major */
     int32_t object;
     int32_t identity;            /* Transform::IsIdentity() of InstanceToWorld (primitive.cpp:86-87) */
-    /* A moving instance or shape (api.cpp:1386-1419 wraps an animated shape's primitives in a TransformedPrimitive too, :1576-1586 an
+    /* ABI 26 -- a moving instance or shape (api.cpp:1386-1419 wraps an animated shape's primitives in a TransformedPrimitive too, :1576-1586 an
      * animated ObjectInstance): TransformedPrimitive::Intersect[P] interpolate PrimitiveToWorld at the ray's time (primitive.cpp:78-80,
      * :99-101; AnimatedTransform::Interpolate, transform.cpp:1144-1169): the start transform up to time[0], the end transform from time[1]
      * on, in between Translate(lerp T) * Slerp(R).ToTransform() * Transform(lerp S) -- whose inverse is the product of the three
