@@ -782,6 +782,12 @@ SCENES = {
     "motion_stratified": with_sampler(with_moving_boxes(cornell(24, 24, 4, integrator='Integrator "path" "integer maxdepth" [ 4 ]')),
                                       '"stratified" "integer xsamples" [ 2 ] "integer ysamples" [ 2 ] "integer dimensions" [ 14 ]'),
     "motion_vol": with_moving_instances(cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 4 ]', world_edit=lambda s: with_fog(s))),
+    # a moving shape under a set AreaLightSource: the reference ignores the light (api.cpp:1389-1391) -- the box moves and does not emit; a moving
+    # shape placed through a named coordinate system whose two ends differ (CoordinateSystem / CoordSysTransform keep both transforms, api.cpp:478-500)
+    "motion_arealight_ignored": with_moving_boxes(cornell(24, 24, 4)).replace('# short box\n', '# short box\nAreaLightSource "diffuse" "rgb L" [ 30 5 5 ]\n', 1),
+    "motion_coordsys": cornell(24, 24, 4).replace("WorldBegin\n", 'WorldBegin\nAttributeBegin\nTranslate 100 250 150\nActiveTransform EndTime\nTranslate 80 -60 40\nScale 1.3 1 1\nActiveTransform All\n'
+                                                  'CoordinateSystem "mover"\nAttributeEnd\nAttributeBegin\nCoordSysTransform "mover"\nMaterial "metal" "float roughness" [ 0.1 ]\n'
+                                                  'Shape "sphere" "float radius" [ 50 ]\nTranslate 120 0 0\nShape "cylinder" "float radius" [ 25 ] "float zmin" [ -40 ] "float zmax" [ 40 ]\nAttributeEnd\n', 1),
     "motion_camera_too": cam_anim(with_moving_boxes(cornell(32, 24, 8)), "Translate 30 0 -40\nRotate 12 0.1 1 0.2"),
     "camanim_translate": cam_anim(cornell(32, 32, 8), "Translate 40 -20 60"),
     "camanim_rotate": cam_anim(cornell(32, 32, 8), "Translate 30 0 -40\nRotate 25 0.1 1 0.2"),
