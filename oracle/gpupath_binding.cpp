@@ -295,7 +295,6 @@ void FlattenScene(const Scene &scene, int maxDepth, bool volumetric, const std::
         in.object = objectIndex[inner];
         in.identity = a.startTransform->IsIdentity() ? 1 : 0;
         if (a.actuallyAnimated) {  // the reference's own decomposition (AnimatedTransform's constructor, transform.cpp:396-411)
-            if (a.hasRotation) Unsupported("a TransformedPrimitive whose motion rotates (AnimatedTransform::hasRotation: MotionBounds' derivative terms)");
             in.animated = 1;
             in.time[0] = a.startTime; in.time[1] = a.endTime;
             CopyMatrix(a.endTransform->m, in.i2w_end); CopyMatrix(a.endTransform->mInv, in.w2i_end);

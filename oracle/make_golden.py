@@ -493,18 +493,18 @@ def with_moving_boxes(s, short_motion="Translate 70 0 -50", tall_motion="Transla
     return out.replace("WorldBegin", times + "WorldBegin", 1) if times else out
 
 
-def with_moving_instances(s):
+def with_moving_instances(s, spin=("", "", "", "")):
     """with_instances' objects, some uses of them under a motion: a BVHAccel object, a lone sphere (a quadric inside a moving instance), a lone
-    triangle, and a moving SHAPE (a sphere, created at the identity) beside them."""
+    triangle, and a moving SHAPE (a sphere, created at the identity) beside them.  `spin`: directives added to the four END transforms."""
     s = with_instances(s)
     s = s.replace('AttributeBegin\n  Translate 50 230 -40\n  Rotate 25 0 1 0.2\n  Scale 0.45 0.45 0.45\n  ObjectInstance "boxes"\nAttributeEnd\n',
-                  'AttributeBegin\n  Translate 50 230 -40\n  Rotate 25 0 1 0.2\n  Scale 0.45 0.45 0.45\n  ActiveTransform EndTime\n  Translate 120 -80 60\n  ActiveTransform All\n  ObjectInstance "boxes"\nAttributeEnd\n')
+                  'AttributeBegin\n  Translate 50 230 -40\n  Rotate 25 0 1 0.2\n  Scale 0.45 0.45 0.45\n  ActiveTransform EndTime\n  Translate 120 -80 60\n' + spin[0] + '  ActiveTransform All\n  ObjectInstance "boxes"\nAttributeEnd\n')
     s = s.replace('AttributeBegin\n  Translate 120 0 420\n  ObjectInstance "ball"\nAttributeEnd\n',
-                  'AttributeBegin\n  Translate 120 0 420\n  ActiveTransform EndTime\n  Translate 60 30 -90\n  Scale 1.3 0.8 1\n  ActiveTransform All\n  ObjectInstance "ball"\nAttributeEnd\n')
+                  'AttributeBegin\n  Translate 120 0 420\n  ActiveTransform EndTime\n  Translate 60 30 -90\n  Scale 1.3 0.8 1\n' + spin[1] + '  ActiveTransform All\n  ObjectInstance "ball"\nAttributeEnd\n')
     s = s.replace('AttributeBegin\n  Translate 330 380 300\n  Scale 1 -1 1\n  ObjectInstance "tri"\nAttributeEnd\n',
                   'AttributeBegin\n  Translate 330 380 300\n  Scale 1 -1 1\n  ObjectInstance "tri"\nAttributeEnd\n'
-                  'AttributeBegin\n  Translate 300 300 250\n  Scale 1 1.2 1\n  ActiveTransform StartTime\n  Translate -50 0 0\n  ActiveTransform EndTime\n  Translate 40 -30 20\n  ActiveTransform All\n  ObjectInstance "tri"\nAttributeEnd\n'
-                  + moving('  Translate 300 90 60\n  Material "glass" "float index" [ 1.5 ]\n  Shape "sphere" "float radius" [ 45 ]\n', "Translate 0 120 0"))
+                  'AttributeBegin\n  Translate 300 300 250\n  Scale 1 1.2 1\n  ActiveTransform StartTime\n  Translate -50 0 0\n  ActiveTransform EndTime\n  Translate 40 -30 20\n' + spin[2] + '  ActiveTransform All\n  ObjectInstance "tri"\nAttributeEnd\n'
+                  + moving('  Translate 300 90 60\n  Material "glass" "float index" [ 1.5 ]\n  Shape "sphere" "float radius" [ 45 ]\n', "Translate 0 120 0\n" + spin[3]))
     assert s.count("ActiveTransform EndTime") == 4
     return s
 
@@ -788,6 +788,18 @@ SCENES = {
     "motion_coordsys": cornell(24, 24, 4).replace("WorldBegin\n", 'WorldBegin\nAttributeBegin\nTranslate 100 250 150\nActiveTransform EndTime\nTranslate 80 -60 40\nScale 1.3 1 1\nActiveTransform All\n'
                                                   'CoordinateSystem "mover"\nAttributeEnd\nAttributeBegin\nCoordSysTransform "mover"\nMaterial "metal" "float roughness" [ 0.1 ]\n'
                                                   'Shape "sphere" "float radius" [ 50 ]\nTranslate 120 0 0\nShape "cylinder" "float radius" [ 25 ] "float zmin" [ -40 ] "float zmax" [ 40 ]\nAttributeEnd\n', 1),
+    # motion that ROTATES (AnimatedTransform::hasRotation, transform.cpp:411): the TransformedPrimitive's box is the corners' paths bounded at the zeros
+    # of their derivatives (MotionBounds / BoundPointMotion / IntervalFindZeros, transform.cpp:1215-1247, :354-394) -- the top-level BVH and, through
+    # the scene's world bound, the distant and infinite lights and the spatial light grid depend on it; rays slerp the rotation at their own time
+    "motion_rotate_boxes": with_moving_boxes(cornell(32, 32, 8), short_motion="Rotate 35 0 1 0\nTranslate 30 0 0", tall_motion="Translate 0 40 0\nRotate -50 0.2 1 0.3\nScale 1 0.8 1.1"),
+    "motion_rotate_big_times": with_moving_boxes(cornell(32, 24, 8), short_motion="Translate 60 80 0\nRotate 170 0.1 1 0", tall_motion="Rotate 95 1 0.2 0.1\nTranslate 0 -60 30", times="TransformTimes 0.2 0.9\n"),
+    "motion_rotate_instances": with_moving_instances(cornell(40, 32, 8), spin=("  Rotate 40 0 1 0.2\n", "  Rotate -75 1 0 0\n", "  Rotate 120 0 0 1\n", "  Rotate 60 1 1 0\n")),
+    "motion_rotate_distant_spatial": with_moving_boxes(cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 5 ] "string lightsamplestrategy" "spatial"'),
+                                                       short_motion="Translate 0 250 -700\nRotate 80 1 0 0.3", tall_motion="Rotate 30 0 1 0")
+                                     .replace("# light\nAttributeBegin", 'LightSource "distant" "point from" [ 278 500 -600 ] "point to" [ 278 200 200 ] "rgb L" [ 2 2 1.5 ]\n# light\nAttributeBegin', 1),
+    "motion_rotate_vol": with_moving_instances(cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 4 ]', world_edit=lambda s: with_fog(s)),
+                                               spin=("  Rotate -30 0.3 1 0\n", "  Rotate 45 0 1 1\n", "", "  Rotate 90 0 0 1\n")),
+    "motion_rotate_camera_too": cam_anim(with_moving_boxes(cornell(32, 24, 8), short_motion="Rotate -60 0 1 0", tall_motion="Rotate 25 0 0 1\nTranslate 20 0 0"), "Translate 30 0 -40\nRotate 12 0.1 1 0.2"),
     "motion_camera_too": cam_anim(with_moving_boxes(cornell(32, 24, 8)), "Translate 30 0 -40\nRotate 12 0.1 1 0.2"),
     "camanim_translate": cam_anim(cornell(32, 32, 8), "Translate 40 -20 60"),
     "camanim_rotate": cam_anim(cornell(32, 32, 8), "Translate 30 0 -40\nRotate 25 0.1 1 0.2"),

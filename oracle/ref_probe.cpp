@@ -10,6 +10,9 @@
 // `envlight N` reads N lines `u0 u1` (float bit patterns, hex) from stdin and prints, per line, what a constant-radiance
 // InfiniteAreaLight (identity transform) returns: Sample_Li's wi (3) and pdf, then Pdf_Li(wi) -- all as bit patterns
 // (tests/test_oracle_vs_reference.py::test_infinite_light_sampling_vs_reference).
+// `motionbounds` reads lines of 40 float bit patterns (hex) from stdin -- start matrix (16, row-major), end matrix (16), startTime, endTime, a
+// Bounds3f (pMin, pMax) -- and prints per line whether the box differs from the union of the two ends' boxes (hasRotation itself is private) and the six
+// bit patterns of AnimatedTransform::MotionBounds (core/transform.cpp:1215-1247; tests/test_motion_bounds.py).
 // Build: make -C oracle -f Makefile.ref _ref/ref_probe
 #include "materials/metal.cpp"
 #include "sampling.h"
@@ -106,6 +109,25 @@ int main(int argc, char **argv) {
             PrintBits("sigma_s", rs, 3);
         }
         ParallelCleanup();
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "motionbounds")) {
+        char line[2048];
+        while (fgets(line, sizeof line, stdin)) {
+            Float v[40];
+            char *q = line;
+            for (int i = 0; i < 40; ++i) { unsigned u = (unsigned)strtoul(q, &q, 16); memcpy(&v[i], &u, 4); }
+            Matrix4x4 a, b;
+            for (int i = 0; i < 16; ++i) { a.m[i >> 2][i & 3] = v[i]; b.m[i >> 2][i & 3] = v[16 + i]; }
+            Transform ta(a), tb(b);
+            AnimatedTransform at(&ta, v[32], &tb, v[33]);
+            Bounds3f r = at.MotionBounds(Bounds3f(Point3f(v[34], v[35], v[36]), Point3f(v[37], v[38], v[39])));
+            Float o[6] = {r.pMin.x, r.pMin.y, r.pMin.z, r.pMax.x, r.pMax.y, r.pMax.z};
+            // HasScale / the interpolation are public, hasRotation is not: a rotation shows as a box that differs from the union of the ends'
+            Bounds3f ends = Union(ta(Bounds3f(Point3f(v[34], v[35], v[36]), Point3f(v[37], v[38], v[39]))), tb(Bounds3f(Point3f(v[34], v[35], v[36]), Point3f(v[37], v[38], v[39]))));
+            printf("%d", (ends.pMin != r.pMin || ends.pMax != r.pMax) ? 1 : 0);
+            PrintBits("", o, 6);
+        }
         return 0;
     }
     if (argc > 1 && !strcmp(argv[1], "presets")) {

@@ -206,6 +206,7 @@ HOST_SYMBOLS = {
     "pbrt_host_write_image": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int]),
     "pbrt_host_write_image_window": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "pbrt_host_error_count": (C.c_int, []),
+    "pbrt_host_motion_bounds": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "pbrt_host_hlbvh_build": (None, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
     "pbrt_host_set_device_bvh": (None, [C.c_int]),
 }

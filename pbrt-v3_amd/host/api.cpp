@@ -1221,24 +1221,18 @@ static std::shared_ptr<TriangleMesh> CreateTriangleMeshShape(const Transform &o2
     return mesh;
 }
 
-// AnimatedTransform's constructor (transform.cpp:396-411) decides hasRotation from the two decompositions; with rotation the bounds of the
-// motion need the derivative terms (BoundPointMotion, transform.cpp:1194-1213), which this build does not restate
-static bool MotionHasRotation(const Transform &a, const Transform &b) {
-    Float T[3], R0[4], R1[4], S[9];
-    DecomposeTransform(a.GetMatrix(), T, R0, S);
-    DecomposeTransform(b.GetMatrix(), T, R1, S);
-    Float d = (R0[0] * R1[0] + R0[1] * R1[1] + R0[2] * R1[2]) + R0[3] * R1[3];
-    if (d < 0) { for (int i = 0; i < 4; ++i) R1[i] = -R1[i]; d = (R0[0] * R1[0] + R0[1] * R1[1] + R0[2] * R1[2]) + R0[3] * R1[3]; }
-    return d < 0.9995f;
-}
-// The TransformedPrimitive of a moving shape or instance (api.cpp:1399-1419, :1576-1586): false = outside the closed set, the frame is refused
+// The TransformedPrimitive of a moving shape or instance (api.cpp:1399-1419, :1576-1586), with or without rotation (its bounds: host/motion_bounds.cpp).
+// false = outside the closed set, the frame is refused: a motion one of whose ends MIRRORS.  The reference takes the quaternion of the improper
+// rotation its polar decomposition finds (quaternion.cpp:61-92) -- not a unit quaternion -- and slerps it: the interpolated "rotation" is no rigid
+// motion, and the reference's own renders of such scenes abort (a path that never leaves a surface runs out of sample dimensions) or do not
+// terminate (8 of 41 random scenes, tests/test_gpu_fuzz.py::random_scene_rotating_motion before mirrored blocks were left still).
 static bool MakeMotion(const char *what, const std::string &name, GeometricPrimitive::InstanceTransforms *xf) {
     xf->InstanceToWorld = curTransform[0];
     xf->WorldToInstance = Inverse(curTransform[0]);
     if (!curTransform.IsAnimated()) return true;
-    if (MotionHasRotation(curTransform[0], curTransform[1])) {
-        Error("%s \"%s\" under an animated transformation that ROTATES (motion blur with rotation: its bounds need AnimatedTransform's derivative terms) "
-              "is outside this build's closed set; the scene will not be rendered.", what, name.c_str());
+    if (curTransform[0].SwapsHandedness() || curTransform[1].SwapsHandedness()) {
+        Error("%s \"%s\" under an animated transformation that MIRRORS (the reference slerps the non-unit quaternion of an improper rotation; its own "
+              "renders of such motions abort or do not terminate) is outside this build's closed set; the scene will not be rendered.", what, name.c_str());
         renderOptions->refused = true;
         return false;
     }

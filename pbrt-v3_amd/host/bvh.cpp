@@ -114,11 +114,12 @@ Bounds3f ObjectDefinition::WorldBound() const {  // the BVHAccel's root bounds, 
     return prims.empty() ? Bounds3f() : prims[0].WorldBound();
 }
 Bounds3f GeometricPrimitive::WorldBound() const {
-    // TransformedPrimitive::WorldBound (primitive.h:107-109) -> AnimatedTransform::MotionBounds (transform.cpp:1183-1192): the start
-    // transform's box, or -- moving without rotation, the only motion the front end lets through -- the union of the two ends' boxes
+    // TransformedPrimitive::WorldBound (primitive.h:107-109) -> AnimatedTransform::MotionBounds (transform.cpp:1215-1224): the start
+    // transform's box, the union of the two ends' boxes, or -- when the motion rotates -- the corners' paths bounded at the zeros of their
+    // derivatives (host/motion_bounds.cpp)
     if (object) {
         const Bounds3f b = object->WorldBound();
-        if (xf->animated) return Union(TransformBounds(xf->InstanceToWorld, b), TransformBounds(xf->InstanceToWorldEnd, b));
+        if (xf->animated) return MotionBounds(xf->InstanceToWorld, xf->time[0], xf->InstanceToWorldEnd, xf->time[1], b);
         return TransformBounds(xf->InstanceToWorld, b);
     }
     return sphere ? sphere->WorldBound() : shape.WorldBound();

@@ -84,6 +84,14 @@ void pbrt_host_hlbvh_build(int n, const float *bounds, int max_prims_in_node, Pg
     for (size_t i = 0; i < order.size(); ++i) ordered_prims[i] = order[i];
     *n_nodes = (int)nv.size();
 }
+int pbrt_host_motion_bounds(const float *start, const float *end, float start_time, float end_time, const float *bounds, float *out) {
+    Matrix4x4 a, b;
+    for (int i = 0; i < 16; ++i) { a.m[i >> 2][i & 3] = start[i]; b.m[i >> 2][i & 3] = end[i]; }
+    const Transform ta(a), tb(b);
+    const Bounds3f r = MotionBounds(ta, start_time, tb, end_time, Bounds3f(Point3f(bounds[0], bounds[1], bounds[2]), Point3f(bounds[3], bounds[4], bounds[5])));
+    out[0] = r.pMin.x; out[1] = r.pMin.y; out[2] = r.pMin.z; out[3] = r.pMax.x; out[4] = r.pMax.y; out[5] = r.pMax.z;
+    return MotionHasRotation(ta, tb) ? 1 : 0;
+}
 void pbrt_host_set_device_bvh(int on) { g_deviceBVH = on != 0; }
 int pbrt_host_error_count(void) { return ErrorCount(); }
 }

@@ -144,6 +144,9 @@ class Transform {  // transform.h:112-205
 // AnimatedTransform::Decompose (transform.cpp:1103-1142) with Quaternion(const Transform &) (quaternion.cpp:61-92): m = T * R * S,
 // R as (v.x, v.y, v.z, w), S's upper 3x3 row-major -- what AnimatedTransform::Interpolate blends per ray
 void DecomposeTransform(const Matrix4x4 &m, Float T[3], Float R[4], Float S[9]);
+// AnimatedTransform(start, startTime, end, endTime).MotionBounds(b) and its hasRotation (transform.cpp:1215-1247, :411): host/motion_bounds.cpp
+Bounds3f MotionBounds(const Transform &start, Float startTime, const Transform &end, Float endTime, const Bounds3f &b);
+bool MotionHasRotation(const Transform &start, const Transform &end);
 Transform Translate(const Vector3f &delta);
 Transform Scale(Float x, Float y, Float z);
 Transform Rotate(Float theta, const Vector3f &axis);

@@ -25,7 +25,10 @@ SCENES = ["cornell_32", "cornell_crop", "cornell_lens", "cornell_plastic", "corn
           # TransformedPrimitives: object instances (a BVHAccel's nodes / primitives appended, a lone primitive), and MOVING shapes / instances --
           # the reference's own AnimatedTransform (both ends, T / R / S, the times) handed over, interpolated per ray on the device
           "instance_boxes", "instance_accel", "motion_boxes", "motion_boxes_times", "motion_small_rotation", "motion_instances",
-          "motion_instances_shutter", "motion_sobol", "motion_random", "motion_stratified", "motion_vol", "motion_camera_too"]
+          "motion_instances_shutter", "motion_sobol", "motion_random", "motion_stratified", "motion_vol", "motion_camera_too",
+          # motions that rotate (hasRotation): the binding keeps the reference's own BVH, this repository's front end computes MotionBounds itself
+          "motion_rotate_boxes", "motion_rotate_big_times", "motion_rotate_instances", "motion_rotate_distant_spatial", "motion_rotate_vol",
+          "motion_rotate_camera_too"]
 
 
 def run_binding(pkg, scene_file, out):

@@ -257,8 +257,9 @@ def random_scene_moving_camera(seed):
     return head + times + "ActiveTransform EndTime\n" + "\n".join(motion) + "\nActiveTransform All\nCamera " + line + shutter + "\n" + tail
 
 
-def add_motion(text, rng):
-    """Put attribute blocks of `text` that hold shapes or object instances (no lights, no mirroring) under an end-of-motion transform."""
+def add_motion(text, rng, spin=False):
+    """Put attribute blocks of `text` that hold shapes or object instances (no lights, no mirroring; `spin`: rotations of any angle -- without it
+    rotations below the hasRotation threshold only) under an end-of-motion transform."""
     chunks = text.split("AttributeBegin\n")
     moved = 0
     for k in range(1, len(chunks)):
@@ -269,6 +270,9 @@ def add_motion(text, rng):
         r = rng.random()
         if r < 0.4: motion.append(" Scale %.6g %.6g %.6g" % tuple(0.8 + 0.5 * rng.random(3)))
         elif r < 0.6: motion.append(" Rotate %.6g %.6g %.6g %.6g" % (rng.uniform(-1.5, 1.5), *(rng.normal(size=3) + np.array([0, 1e-3, 0]))))
+        if spin and rng.random() < 0.8:  # (before or after the translation / scale: the end transform's decomposition sees a shear in the second case)
+            turn = " Rotate %.6g %.6g %.6g %.6g" % (rng.uniform(-175, 175) if rng.random() < 0.7 else rng.uniform(-6, 6), *(rng.normal(size=3) + np.array([0, 1e-3, 0])))
+            motion.insert(1 if rng.random() < 0.5 else len(motion), turn)
         motion.append(" ActiveTransform All")
         lines = chunks[k].split("\n")
         at = next(i for i, l in enumerate(lines) if l.lstrip().startswith(("Shape ", "ObjectInstance ")))
@@ -286,7 +290,7 @@ def random_scene_motion(seed):
     every ray's time: primitive.cpp:76-103): an end-of-motion translation, sometimes a scale, sometimes a rotation small enough to count as none
     (Dot(R[0], R[1]) >= 0.9995), on quadrics, on instances of a BVH object and of a lone sphere; TransformTimes inside, across or outside the
     shutter, every sampler family, volpath; every fourth scene under a moving camera as well.  (Mirrored instances are left still: the reference
-    takes the quaternion of an improper rotation, finds Dot(R[0], R[1]) < 0.9995 and bounds the motion as a rotating one, which the front end refuses.)"""
+    takes the quaternion of an improper rotation -- not a unit one -- and slerps it; the front end refuses such motions.)"""
     rng = np.random.default_rng(2000 + seed)
     gen = (random_scene_ext, random_scene_vol, random_scene_ext, random_scene_pixel_sampler)[seed % 4]
     text = random_scene_moving_camera(seed) if seed % 4 == 2 else gen(seed)
@@ -307,6 +311,29 @@ def random_scene_motion_sss_grid(seed):
     through the moving instance's interpolated transform) or a GridDensityMedium (ratio tracking's transmittance rays, both shading phases)."""
     rng = np.random.default_rng(3000 + seed)
     return add_motion(random_scene_sss_grid(seed, ("sss", "grid", "both")[seed % 3] if seed % 3 != 2 else "sss"), rng)
+
+
+def random_scene_rotating_motion(seed):
+    """random_scene_motion's scenes with motions that ROTATE (AnimatedTransform::hasRotation): every ray slerps the two rotations at its own time
+    inside TransformedPrimitive::Intersect[P]; the primitives' boxes in the top-level BVH are MotionBounds' (host/motion_bounds.cpp, pinned
+    against the reference in tests/test_motion_bounds.py).  Mirrored blocks stay still: the reference slerps the non-unit quaternion of an improper
+    rotation, and its own renders of such motions abort or do not terminate; the front end refuses them.  Every third scene with subsurface
+    materials or a grid medium."""
+    rng = np.random.default_rng(4000 + seed)
+    if seed % 3 == 2:
+        return add_motion(random_scene_sss_grid(seed, ("sss", "grid")[seed % 2]), rng, spin=True)
+    gen = (random_scene_ext, random_scene_vol, random_scene_ext, random_scene_pixel_sampler)[seed % 4]
+    text = random_scene_moving_camera(seed) if seed % 4 == 2 else gen(seed)
+    text = add_motion(text, rng, spin=True)
+    if seed % 4 != 2 and seed % 5 == 1:
+        t0, t1 = sorted(rng.random(2) * 1.4 - 0.2)
+        text = text.replace("WorldBegin", "TransformTimes %.6g %.6g\nWorldBegin" % (t0, max(t1, t0 + 1e-3)), 1)
+    return text
+
+
+@pytest.mark.parametrize("seed", range(36))
+def test_random_scene_with_rotating_shapes_and_instances(gpu, oracle, seed):
+    check_scene(gpu, oracle, random_scene_rotating_motion(seed), seed)
 
 
 @pytest.mark.parametrize("seed", range(24))

@@ -262,12 +262,12 @@ def test_every_golden_scene_loads_without_an_error_message(pkg):
         assert name in on_purpose or not reported, f"{name}: the host front end reported an Error() while loading"
 
 
-def test_moving_shapes_and_instances_become_animated_instances_or_are_refused(pkg):
-    """The reference interpolates an AnimatedTransform per ray inside TransformedPrimitive::Intersect (primitive.cpp:76-103).  A motion without
-    rotation (Dot(R[0], R[1]) >= 0.9995: translation, scale, a rotation of a degree or two) becomes a PgInstance with the two ends' decompositions
-    (a moving SHAPE: an anonymous object created at the identity, api.cpp:1386-1419); a motion WITH rotation needs MotionBounds' derivative terms and
-    is REFUSED -- an Error, no frame, never an image with one end of the motion -- and so is a moving shape inside an object definition.  A moving CAMERA is rendered (the camanim_* goldens); textures and lights take the start transform in the
-    reference itself (api.cpp WARN_IF_ANIMATED_TRANSFORM): a Warning."""
+def test_moving_shapes_and_instances_become_animated_instances(pkg):
+    """The reference interpolates an AnimatedTransform per ray inside TransformedPrimitive::Intersect (primitive.cpp:76-103).  A motion -- with or
+    without rotation (Dot(R[0], R[1]) < 0.9995; its bounds: host/motion_bounds.cpp, tests/test_motion_bounds.py) -- becomes a PgInstance with the two
+    ends' decompositions (a moving SHAPE: an anonymous object created at the identity, api.cpp:1386-1419).  A moving shape inside an object
+    definition and a motion that MIRRORS are REFUSED -- an Error, no frame, never an image with one end of the motion.  A moving CAMERA is rendered (the camanim_* goldens);
+    textures and lights take the start transform in the reference itself (api.cpp WARN_IF_ANIMATED_TRANSFORM): a Warning."""
     anim = 'ActiveTransform EndTime\nTranslate 0.3 0 0\nActiveTransform All\n'
     spin = 'ActiveTransform EndTime\nRotate 40 0 1 0\nActiveTransform All\n'
     mini = MINI % (16, 16, 1)
@@ -285,9 +285,17 @@ def test_moving_shapes_and_instances_become_animated_instances_or_are_refused(pk
         if what == "shape":  # created at the identity: the object's vertices are the file's, the transform carries the CTM
             assert m.i2w[11] == 1.0 and d.objects[m.object].n_prims == 1 and d.objects[m.object].n_nodes == 0
         s.close()
+    for what, txt in (("rotating shape", shape(spin)), ("rotating instance", inst(spin))):
+        s = pkg.HostScene(text=txt)
+        d = s.desc
+        moving = [d.instances[i] for i in range(d.n_instances) if d.instances[i].animated]
+        assert len(moving) == 1 and pkg.host_lib().pbrt_host_error_count() == before, what
+        q0, q1 = list(moving[0].R[0]), list(moving[0].R[1])
+        assert sum(a * b for a, b in zip(q0, q1)) < 0.9995, what
+        s.close()
     nested = mini.replace("WorldEnd", 'ObjectBegin "o"\n' + anim + tri + 'ObjectEnd\nObjectInstance "o"\nWorldEnd')
-    for what, txt in (("rotating shape", shape(spin)), ("rotating instance", inst(spin)), ("mirrored instance", inst("Scale 1 -1 1\n" + anim)),
-                      ("moving shape inside an object definition", nested)):
+    # (a mirrored motion: the reference slerps the non-unit quaternion of an improper rotation, and its own renders abort or do not terminate)
+    for what, txt in (("moving shape inside an object definition", nested), ("mirrored instance", inst("Scale 1 -1 1\n" + anim)), ("mirrored rotating shape", shape("Scale -1 1 1\n" + spin))):
         before = pkg.host_lib().pbrt_host_error_count()
         with pytest.raises(pkg.PbrtGpuError):
             pkg.HostScene(text=txt)

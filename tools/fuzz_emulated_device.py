@@ -27,7 +27,8 @@ def main():
     gens = {"random_scene": fz.random_scene, "random_scene_ext": fz.random_scene_ext, "random_scene_vol": fz.random_scene_vol,
             "random_scene_sss": lambda s: fz.random_scene_sss_grid(s, "sss"), "random_scene_grid": lambda s: fz.random_scene_sss_grid(s, "grid"),
             "random_scene_pixel_sampler": fz.random_scene_pixel_sampler, "random_scene_moving_camera": fz.random_scene_moving_camera,
-            "random_scene_motion": fz.random_scene_motion, "random_scene_motion_sss_grid": fz.random_scene_motion_sss_grid}
+            "random_scene_motion": fz.random_scene_motion, "random_scene_motion_sss_grid": fz.random_scene_motion_sss_grid,
+            "random_scene_rotating_motion": fz.random_scene_rotating_motion}
     if len(sys.argv) > 3: gens = {k: v for k, v in gens.items() if k == sys.argv[3]}
     bad = 0
     for name, gen in gens.items():
