@@ -180,12 +180,13 @@ def intersect_p(desc, o, d, tmax):
     return occ, cn.as_dict()
 
 
-def run_reference(scene_file, out_pfm, nthreads=None, quiet=True):
-    """Render scene_file with the UNMODIFIED reference binary (oracle/_ref/pbrt_oracle). Returns its stdout."""
+def run_reference(scene_file, out_pfm, nthreads=None, quiet=True, timeout=3600):
+    """Render scene_file with the UNMODIFIED reference binary (oracle/_ref/pbrt_oracle). Returns its stdout.  (`timeout`: the reference does not
+    terminate on some degenerate inputs -- a mirrored motion, for one -- and a sweep must not wait for it for ever.)"""
     if not os.path.exists(REF_BINARY):
         raise FileNotFoundError(f"{REF_BINARY} not built (make -C oracle ref; needs /root/reference)")
     cmd = [REF_BINARY, "--outfile", out_pfm]
     if nthreads:
         cmd += ["--nthreads", str(nthreads)]
     cmd.append(scene_file)
-    return subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
+    return subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=timeout).stdout

@@ -89,10 +89,12 @@ def test_fuzz_scenes_live_when_reference_present(pkg, oracle, tmp_path):
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     scene_file, out = str(tmp_path / "fuzz.pbrt"), str(tmp_path / "ref.pfm")
-    # (the last two: the same scenes under a moving camera; with moving shapes and object instances)
-    for gen in (fz.random_scene, fz.random_scene_ext, fz.random_scene_vol, fz.random_scene_moving_camera, fz.random_scene_motion, fz.random_scene_motion_sss_grid):
-        for seed in (range(16) if gen in (fz.random_scene_vol, fz.random_scene_moving_camera) else (range(24) if gen is fz.random_scene_motion else (range(12) if gen is fz.random_scene_motion_sss_grid else range(0, 24, 2)))):
+    # (the last four: the same scenes under a moving camera; with moving shapes and object instances; those beside subsurface materials / grid media;
+    # with motions that rotate -- the front end's own MotionBounds in the top-level BVH and the world bound)
+    for gen in (fz.random_scene, fz.random_scene_ext, fz.random_scene_vol, fz.random_scene_moving_camera, fz.random_scene_motion, fz.random_scene_motion_sss_grid,
+                fz.random_scene_rotating_motion):
+        for seed in (range(16) if gen in (fz.random_scene_vol, fz.random_scene_moving_camera) else (range(24) if gen in (fz.random_scene_motion, fz.random_scene_rotating_motion) else (range(12) if gen is fz.random_scene_motion_sss_grid else range(0, 24, 2)))):
             open(scene_file, "w").write(gen(seed))
-            oracle.run_reference(scene_file, out, nthreads=1)  # one thread: overlapping FilmTiles merge in tile order
+            oracle.run_reference(scene_file, out, nthreads=1, timeout=600)  # one thread: overlapping FilmTiles merge in tile order
             img, _ = oracle.render_image(pkg.HostScene(scene_file))
             assert np.array_equal(img, pkg.read_pfm(out)), (gen.__name__, seed)

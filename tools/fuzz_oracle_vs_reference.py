@@ -32,8 +32,8 @@ def main():
             for seed in range(a, b):
                 open(scene_file, "w").write(gen(seed))
                 try:
-                    oracle.run_reference(scene_file, out, nthreads=1)
-                except Exception as e:  # the reference aborts on some degenerate inputs (CHECK failures)
+                    oracle.run_reference(scene_file, out, nthreads=1, timeout=300)
+                except Exception as e:  # the reference aborts on some degenerate inputs (CHECK failures) and does not terminate on others (TimeoutExpired)
                     print(gen.__name__, seed, "reference failed:", str(e)[:80]); continue
                 img, _ = oracle.render_image(pkg.HostScene(scene_file))
                 ref = pkg.read_pfm(out)
