@@ -132,9 +132,6 @@ std::vector<uint32_t> pushedActiveTransformBits;
         Error("Scene description must be inside world block; \"%s\" not allowed. Ignoring.", func); \
         return;                                                                         \
     } else /* swallow trailing semicolon */
-#define FOR_ACTIVE_TRANSFORMS(expr)                  \
-    for (int i = 0; i < MaxTransforms; ++i)          \
-        if (activeTransformBits & (1 << i)) { expr }
 
 // ---- materials (api.cpp:537-620; matte.cpp:64-72; plastic.cpp:72-84) ---------------
 // Textures are restricted to constants: a "texture" parameter must name a
@@ -619,34 +616,28 @@ void pbrtCleanup() {  // api.cpp:888-897
     currentApiState = APIState::Uninitialized;
     renderOptions.reset();
 }
-void pbrtIdentity() { VERIFY_INITIALIZED("Identity"); FOR_ACTIVE_TRANSFORMS(curTransform[i] = Transform();) }
-void pbrtTranslate(Float dx, Float dy, Float dz) {
-    VERIFY_INITIALIZED("Translate");
-    FOR_ACTIVE_TRANSFORMS(curTransform[i] = curTransform[i] * Translate(Vector3f(dx, dy, dz));)
+// The CTM directives (api.cpp:899-963): each acts on the transforms ActiveTransform selected -- the start one, the end one or both.
+// `replace`: Identity / Transform set them; everything else post-multiplies.
+static void ActOnActiveTransforms(const char *directive, const Transform &t, bool replace = false) {
+    VERIFY_INITIALIZED(directive);
+    for (int which = 0; which < MaxTransforms; ++which) {
+        if (!(activeTransformBits & (1 << which))) continue;
+        curTransform[which] = replace ? t : curTransform[which] * t;
+    }
 }
-void pbrtTransform(Float tr[16]) {
-    VERIFY_INITIALIZED("Transform");
-    FOR_ACTIVE_TRANSFORMS(curTransform[i] = Transform(Matrix4x4(tr[0], tr[4], tr[8], tr[12], tr[1], tr[5], tr[9], tr[13],
-                                                               tr[2], tr[6], tr[10], tr[14], tr[3], tr[7], tr[11], tr[15]));)
+static Transform FromColumnMajor(const Float tr[16]) {  // the file gives a matrix column by column (api.cpp:918-921)
+    Matrix4x4 m;
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) m.m[r][c] = tr[4 * c + r];
+    return Transform(m);
 }
-void pbrtConcatTransform(Float tr[16]) {
-    VERIFY_INITIALIZED("ConcatTransform");
-    FOR_ACTIVE_TRANSFORMS(curTransform[i] = curTransform[i] *
-        Transform(Matrix4x4(tr[0], tr[4], tr[8], tr[12], tr[1], tr[5], tr[9], tr[13], tr[2], tr[6], tr[10], tr[14],
-                            tr[3], tr[7], tr[11], tr[15]));)
-}
-void pbrtRotate(Float angle, Float dx, Float dy, Float dz) {
-    VERIFY_INITIALIZED("Rotate");
-    FOR_ACTIVE_TRANSFORMS(curTransform[i] = curTransform[i] * Rotate(angle, Vector3f(dx, dy, dz));)
-}
-void pbrtScale(Float sx, Float sy, Float sz) {
-    VERIFY_INITIALIZED("Scale");
-    FOR_ACTIVE_TRANSFORMS(curTransform[i] = curTransform[i] * Scale(sx, sy, sz);)
-}
+void pbrtIdentity() { ActOnActiveTransforms("Identity", Transform(), true); }
+void pbrtTransform(Float tr[16]) { ActOnActiveTransforms("Transform", FromColumnMajor(tr), true); }
+void pbrtConcatTransform(Float tr[16]) { ActOnActiveTransforms("ConcatTransform", FromColumnMajor(tr)); }
+void pbrtTranslate(Float dx, Float dy, Float dz) { ActOnActiveTransforms("Translate", Translate(Vector3f(dx, dy, dz))); }
+void pbrtRotate(Float angle, Float dx, Float dy, Float dz) { ActOnActiveTransforms("Rotate", Rotate(angle, Vector3f(dx, dy, dz))); }
+void pbrtScale(Float sx, Float sy, Float sz) { ActOnActiveTransforms("Scale", Scale(sx, sy, sz)); }
 void pbrtLookAt(Float ex, Float ey, Float ez, Float lx, Float ly, Float lz, Float ux, Float uy, Float uz) {
-    VERIFY_INITIALIZED("LookAt");
-    Transform lookAt = LookAt(Point3f(ex, ey, ez), Point3f(lx, ly, lz), Vector3f(ux, uy, uz));
-    FOR_ACTIVE_TRANSFORMS(curTransform[i] = curTransform[i] * lookAt;)
+    ActOnActiveTransforms("LookAt", LookAt(Point3f(ex, ey, ez), Point3f(lx, ly, lz), Vector3f(ux, uy, uz)));
 }
 void pbrtCoordinateSystem(const std::string &name) { VERIFY_INITIALIZED("CoordinateSystem"); namedCoordinateSystems[name] = curTransform; }
 void pbrtCoordSysTransform(const std::string &name) {

@@ -11,9 +11,17 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 KAT = os.path.join(ROOT, "tests", "golden", "motion_bounds_kat.txt")
 PROBE = os.path.join(ROOT, "oracle", "_ref", "ref_probe")
+
+
+def kat_module():
+    """oracle/make_motion_kat.py (the case generator and the reference probe's caller), loaded by path: oracle/ itself stays off sys.path"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_motion_kat", os.path.join(ROOT, "oracle", "make_motion_kat.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def host_bounds(pkg, case):
@@ -41,7 +49,7 @@ def test_known_answers_from_the_reference(pkg):
 def test_fresh_cases_against_the_reference_live(pkg):
     if not os.path.exists(PROBE):
         pytest.skip("oracle/_ref/ref_probe is built only where /root/reference exists")
-    import make_motion_kat as mk
+    mk = kat_module()
     cs = mk.cases(7, 1500)
     for k, (c, a) in enumerate(zip(cs, mk.ask(cs))):
         _, got = host_bounds(pkg, c)
@@ -51,7 +59,7 @@ def test_fresh_cases_against_the_reference_live(pkg):
 def test_the_box_holds_the_moving_corners(pkg):
     """The reference's own test (tests/animatedtransform.cpp:38-60): points of the object box, moved to random times, lie inside MotionBounds
     (up to the float error of the interpolation, for which that test grows the box by 1e-4 of its diagonal)."""
-    import make_motion_kat as mk
+    mk = kat_module()
     rng = np.random.default_rng(3)
     checked = 0
     for c in mk.cases(11, 60):
