@@ -91,6 +91,10 @@ def test_moving_shapes_and_instances_on_the_emulated_device(emulated):
     assert " passed" in out and "failed" not in out
     out = run_gpu_tests(emulated, ["tests/test_gpu_fuzz.py::test_random_scene_with_moving_shapes_and_instances[1]"], "moving_shapes", 1500)
     assert " passed" in out and "failed" not in out
+    # motions that ROTATE (hasRotation: the slerp branch of instance_matrices_at, MotionBounds' boxes in the top-level BVH): two goldens above, two random scenes
+    out = run_gpu_tests(emulated, ["tests/test_gpu_fuzz.py::test_random_scene_with_rotating_shapes_and_instances[0]",
+                                   "tests/test_gpu_fuzz.py::test_random_scene_with_rotating_shapes_and_instances[1]"], "rotating_shapes", 1500)
+    assert "2 passed" in out and "failed" not in out
 
 
 def test_material_pass_on_the_emulated_device(emulated):
