@@ -291,9 +291,9 @@ typedef struct PgInstance {      /* TransformedPrimitive (primitive.h:92-117) */
      * :99-101; AnimatedTransform::Interpolate, transform.cpp:1144-1169): the start transform up to time[0], the end transform from time[1]
      * on, in between Translate(lerp T) * Slerp(R).ToTransform() * Transform(lerp S) -- whose inverse is the product of the three
      * factors' inverses, Transform(lerp S)'s by Gauss-Jordan (transform.cpp:83-135) -- of the two decompositions (Decompose,
-     * :1103-1142), which the host computes once.  The top-level primitive's bounds are Union(start box, end box)
-     * (AnimatedTransform::MotionBounds without rotation, transform.cpp:1183-1192); a motion WITH rotation (Dot(R[0], R[1]) < 0.9995)
-     * needs the derivative-term bounds and is refused by the front end.  animated = 0: the fields below are unused. */
+     * :1103-1142), which the host computes once.  The top-level primitive's bounds are AnimatedTransform::MotionBounds
+     * (transform.cpp:1215-1247): Union(start box, end box), or with rotation (Dot(R[0], R[1]) < 0.9995) the corners' paths bounded at the
+     * zeros of their derivatives -- pbrt_host_motion_bounds (pbrt_host.h) for a host that builds its own BVH.  animated = 0: the fields below are unused. */
     int32_t animated;            /* AnimatedTransform::actuallyAnimated */
     float time[2];               /* startTime, endTime (the file's TransformTimes) */
     float i2w_end[16], w2i_end[16]; /* endTransform and its inverse */
