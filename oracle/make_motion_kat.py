@@ -57,6 +57,17 @@ def cases(seed, n):
     return out
 
 
+def edge_cases():
+    """A singular end (Scale 0: the reference reports "Singular matrix in MatrixInvert" and carries on with what the elimination left), scales 40
+    orders of magnitude apart, half a turn and a hair less, a rotation of a thousandth of a degree."""
+    out = []
+    for sc0, sc1, d in (((0, 1, 1), (1, 1, 1), 40), ((1, 1, 1), (1, 0, 1), 90), ((1e-20, 1, 1), (1, 1, 1e20), 120), ((1, 1, 1), (1, 1, 1), 180),
+                        ((1, 1, 1), (1, 1, 1), 179.99), ((2, 2, 2), (2, 2, 2), 0.001)):
+        m0, m1 = trs((1, 2, 3), (0, 1, 0), 0, sc0), trs((4, 5, 6), (0.2, 1, 0.1), d, sc1)
+        out.append(np.concatenate([m0.ravel(), m1.ravel(), (0.0, 1.0), (-1, -1, -1), (1, 2, 3)]).astype(np.float32))
+    return out
+
+
 def ask(cs):
     text = "\n".join(" ".join("%08x" % u for u in c.view(np.uint32)) for c in cs) + "\n"
     res = subprocess.run([PROBE, "motionbounds"], input=text, capture_output=True, text=True, check=True).stdout.split("\n")
@@ -66,7 +77,7 @@ def ask(cs):
 def main():
     if not os.path.exists(PROBE):
         sys.exit("build oracle/_ref first: make -C oracle -f Makefile.ref")
-    cs = cases(20260925, 400)
+    cs = cases(20260925, 400) + edge_cases()
     ans = ask(cs)
     assert len(ans) == len(cs)
     with open(OUT, "w") as f:
