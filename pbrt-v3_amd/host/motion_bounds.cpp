@@ -57,6 +57,15 @@ const Programs &MotionPrograms() {
                 p.code[i] = b + 2; p.len[i] = n;
                 b += 2 + n;
                 ok = b <= end;
+                int depth = 0;  // every program is checked once, here: operands exist, the stack stays within RunProgram's, one value is left
+                for (int k = 0; k < n && ok; ++k) {
+                    const unsigned op = p.code[i][k];
+                    if (op < kVars || (op >= 64 && op < 64u + (unsigned)hdr[2])) ok = ++depth < 32;
+                    else if (op == 128) ok = depth >= 1;
+                    else if (op >= 129 && op <= 131) ok = --depth >= 1;
+                    else ok = false;
+                }
+                ok = ok && depth == 1;
             }
             ok = ok && b == end;
         }
@@ -65,7 +74,8 @@ const Programs &MotionPrograms() {
     }();
     return P;
 }
-// one polynomial: a postfix program over the 33 variables; every operation rounds to float once, in the order the reference's expression has
+// one polynomial: a postfix program over the 33 variables (validated when the blob was read); every operation rounds to float once, in the
+// order the reference's expression has
 Float RunProgram(const Programs &P, int i, const Float *vars) {
     Float stack[32];
     int sp = 0;
@@ -79,7 +89,6 @@ Float RunProgram(const Programs &P, int i, const Float *vars) {
             const Float b = stack[--sp], a = stack[sp - 1];
             stack[sp - 1] = op == 129 ? a + b : (op == 130 ? a - b : a * b);
         }
-        if (sp <= 0 || sp >= 32) { fprintf(stderr, "motion_terms.bin: program %d leaves its stack\n", i); abort(); }
     }
     return stack[0];
 }
