@@ -95,6 +95,13 @@ def test_fuzz_scenes_live_when_reference_present(pkg, oracle, tmp_path):
                 fz.random_scene_rotating_motion):
         for seed in (range(16) if gen in (fz.random_scene_vol, fz.random_scene_moving_camera) else (range(24) if gen in (fz.random_scene_motion, fz.random_scene_rotating_motion) else (range(12) if gen is fz.random_scene_motion_sss_grid else range(0, 24, 2)))):
             open(scene_file, "w").write(gen(seed))
-            oracle.run_reference(scene_file, out, nthreads=1, timeout=600)  # one thread: overlapping FilmTiles merge in tile order
+            txt = oracle.run_reference(scene_file, out, nthreads=1, timeout=600)  # one thread: overlapping FilmTiles merge in tile order
             img, _ = oracle.render_image(pkg.HostScene(scene_file))
             assert np.array_equal(img, pkg.read_pfm(out)), (gen.__name__, seed)
+            if gen is fz.random_scene_rotating_motion:  # the reference's own statistics too: the triangle tests count what the BVHs -- the top-level one
+                import re                               # over MotionBounds' boxes -- made the rays visit
+                g = lambda pat: int(re.search(pat, txt).group(1)) if re.search(pat, txt) else 0
+                sc = pkg.HostScene(scene_file)
+                _, _, cn = oracle.render(sc.desc, sc.render_desc())
+                assert (cn["closest_rays"], cn["shadow_rays"], cn["tri_tests"]) == (g(r"Regular ray intersection tests\s+(\d+)"), g(r"Shadow ray intersection tests\s+(\d+)"),
+                                                                                  g(r"Ray-triangle intersection tests\s+\d+ /\s+(\d+)")), (gen.__name__, seed)
