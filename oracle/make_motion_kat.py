@@ -57,6 +57,27 @@ def cases(seed, n):
     return out
 
 
+def composite_cases(seed, n):
+    """The motions of the reference's own test (src/tests/animatedtransform.cpp:9-28, RandomTransform): each end the product of ten random factors --
+    a scale by up to 10, a translation, a rotation by up to 200 degrees about a random axis -- so that the decompositions see shear; a random box."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        ends = []
+        for _e in range(2):
+            m = np.eye(4)
+            for _f in range(10):
+                k = rng.integers(0, 3)
+                r = lambda: rng.uniform(-10, 10)
+                if k == 0: m = m @ np.diag([abs(r()), abs(r()), abs(r()), 1.0])
+                elif k == 1: m = m @ trs((r(), r(), r()), (0, 1, 0), 0, (1, 1, 1))
+                else: m = m @ rot(rng.normal(size=3), r() * 20)
+            ends.append(m)
+        a, b = rng.uniform(-10, 10, 3), rng.uniform(-10, 10, 3)
+        out.append(np.concatenate([ends[0].ravel(), ends[1].ravel(), (0.0, 1.0), np.minimum(a, b), np.maximum(a, b)]).astype(np.float32))
+    return out
+
+
 def edge_cases():
     """A singular end (Scale 0: the reference reports "Singular matrix in MatrixInvert" and carries on with what the elimination left), scales 40
     orders of magnitude apart, half a turn and a hair less, a rotation of a thousandth of a degree."""

@@ -50,7 +50,7 @@ def test_fresh_cases_against_the_reference_live(pkg):
     if not os.path.exists(PROBE):
         pytest.skip("oracle/_ref/ref_probe is built only where /root/reference exists")
     mk = kat_module()
-    cs = mk.cases(7, 1500)
+    cs = mk.cases(7, 1500) + mk.composite_cases(5, 500)  # (the second kind: the motions of the reference's own tests/animatedtransform.cpp)
     for k, (c, a) in enumerate(zip(cs, mk.ask(cs))):
         _, got = host_bounds(pkg, c)
         assert ["%08x" % u for u in got.view(np.uint32)] == a.split()[1:], f"case {k}"
@@ -62,7 +62,7 @@ def test_the_box_holds_the_moving_corners(pkg):
     mk = kat_module()
     rng = np.random.default_rng(3)
     checked = 0
-    for c in mk.cases(11, 60):
+    for c in mk.cases(11, 60) + mk.composite_cases(13, 40):
         rot, box = host_bounds(pkg, c)
         if not rot:
             continue
@@ -102,4 +102,4 @@ def test_the_box_holds_the_moving_corners(pkg):
                           [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
             pw = (1 - dt) * T0 + dt * T1 + R @ (((1 - dt) * S0 + dt * S1) @ p)
             assert np.all(pw >= box[:3] - 1e-4 * diag) and np.all(pw <= box[3:] + 1e-4 * diag), (pw, box)
-    assert checked >= 20
+    assert checked >= 40
