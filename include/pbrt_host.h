@@ -51,7 +51,8 @@ int pbrt_host_write_image_window(const char *filename, const float *rgb, int wid
  * pg_hlbvh_build (pbrt_gpu.h), which must reproduce it bit for bit. */
 void pbrt_host_hlbvh_build(int n, const float *bounds, int max_prims_in_node, PgBVHNode *nodes, int *n_nodes, int *ordered_prims);
 /* AnimatedTransform(Transform(start), start_time, Transform(end), end_time).MotionBounds(bounds) (core/transform.cpp:1215-1247): the box of a
- * TransformedPrimitive whose object bound is `bounds` ({pMin, pMax}); start / end row-major 4 x 4.  Returns hasRotation (transform.cpp:411). */
+ * TransformedPrimitive whose object bound is `bounds` ({pMin, pMax}); start / end row-major 4 x 4.  Returns hasRotation (transform.cpp:411),
+ * or -1 (with an Error) where the reference's CHECK_LE ends its process: a motion derivative with more than 8 zeros (transform.cpp:385). */
 int pbrt_host_motion_bounds(const float *start, const float *end, float start_time, float end_time, const float *bounds, float *out);
 /* Build "hlbvh" accelerators of subsequently loaded scenes on the device (the CLI's --devicebvh). */
 void pbrt_host_set_device_bvh(int on);

@@ -54,7 +54,7 @@ struct PgScene {
     int device = 0;
     DScene d;
     TraceConfig trace;  // k_trace's tunables for THIS scene's launches (the exact-fallback retry changes them for one call)
-    DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, textures, textured, images, texels, ewaLut, envTables, alphas, alphaTex, triAlpha, triN, triS, uv, materials, lights, distTable, perms, permSums, primes, media, triMediumIn, triMediumOut, sobolMatrices, vdcSobol, vdcSobolInv, noisePerm;
+    DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, instEntry, textures, textured, images, texels, ewaLut, envTables, alphas, alphaTex, triAlpha, triN, triS, uv, materials, lights, distTable, perms, permSums, primes, media, triMediumIn, triMediumOut, sobolMatrices, vdcSobol, vdcSobolInv, noisePerm;
     // work buffers (sized on first render, reused)
     int capacity = 0;
     DeviceBuffer sceneCopy;  // DScene::self
@@ -297,6 +297,25 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         if (desc->n_instances > 0 && desc->instances) {
             HIP_TRY_S(s->instances.alloc(sizeof(PgInstance) * (size_t)desc->n_instances));
             HIP_TRY_S(hipMemcpy(s->instances.p, desc->instances, s->instances.bytes, hipMemcpyHostToDevice));
+        }
+        d.instEntry = nullptr;
+        if (desc->n_instances > 0 && desc->instances && !objs.empty()) {
+            std::vector<DInstEntry> ent((size_t)desc->n_instances);
+            for (int i = 0; i < desc->n_instances; ++i) {
+                const PgInstance &in = desc->instances[i];
+                DInstEntry &e = ent[i];
+                memset(&e, 0, sizeof(e));
+                if (in.object < 0 || in.object >= desc->n_objects) continue;  // (never referenced: the primitives' instances were checked above)
+                const DObject &ob = objs[in.object];
+                memcpy(e.w2i, in.w2i, sizeof(e.w2i));
+                memcpy(e.box, ob.box, sizeof(e.box));
+                e.rootRef = ob.rootRef; e.firstPrim = ob.firstPrim; e.nNodes = ob.nNodes;
+                const float last[4] = {0.f, 0.f, 0.f, 1.f};
+                e.affineStill = (!in.animated && memcmp(in.w2i + 12, last, sizeof(last)) == 0) ? 1 : 0;  // (bitwise: -0 is not 0 here)
+            }
+            HIP_TRY_S(s->instEntry.alloc(sizeof(DInstEntry) * ent.size()));
+            HIP_TRY_S(hipMemcpy(s->instEntry.p, ent.data(), s->instEntry.bytes, hipMemcpyHostToDevice));
+            d.instEntry = (const DInstEntry *)s->instEntry.p;
         }
         d.objects = (const DObject *)s->objects.p;
         d.instances = (const PgInstance *)s->instances.p;

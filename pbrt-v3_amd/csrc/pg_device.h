@@ -13,6 +13,13 @@
 
 #define PG_DEV __device__ __forceinline__
 #define PG_HD __host__ __device__ inline
+// nothing is scheduled across this point: keeps independent long sequences (three IEEE divisions, say) from being interleaved where their
+// temporaries together would set the kernel's register peak (a no-op for values, and for the host builds of tests/)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HIP_EMU_H)
+#define PG_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define PG_SCHED_BARRIER() ((void)0)
+#endif
 
 struct V3 { float x, y, z; };
 struct Spec { float r, g, b; };

@@ -28,6 +28,10 @@ struct DAlphaTex {
 };
 // One object definition (instancing) on the device: its BVHAccel's root, or its lone primitive when nNodes == 0.
 struct DObject { float box[6]; int rootRef; int firstPrim; int nNodes; int pad; };
+// What k_trace needs to enter a (still) instance, in one 96-byte record: rows 0 - 2 of WorldToInstance, its object's root box and references.
+// affine: row 3 of the matrix is (0, 0, 0, 1) -- the kernel then forms w from those constants (the same operations, no loads); a moving
+// instance or a projective matrix goes through PgInstance as before.
+struct DInstEntry { float w2i[12]; float box[6]; int rootRef; int firstPrim; int nNodes; int affineStill; int pad[2]; };
 #define TR_NO_ROOT 0x7fffffff
 
 // One tile's sampler when the sampler draws from one RNG stream per tile (PgSamplerKind 2 .. 5): the tile's PCG32 state
@@ -74,6 +78,7 @@ struct DScene {
     int nSpheres;
     const PgInstance *instances;  // TransformedPrimitives: tris[3*k] = (instance index, 0, 0, PG_PRIM_INSTANCE), top level only
     const DObject *objects;
+    const DInstEntry *instEntry;  // one per instance (see DInstEntry)
     int nInstances;
     int *hitInst;  // per closest-hit result: the instance the hit primitive was reached through, or -1 (written by k_trace<.., true>)
     // Moving shapes / instances (PgInstance::animated; TransformedPrimitive over an AnimatedTransform): hasMotion says the scene has one -- every
@@ -312,7 +317,8 @@ struct TraceCounters {
 // maxAccepted: accepted hits per ray beyond which the margin's proof no longer holds (<= 4096 for cullK = 1 + 2^-10)
 struct TraceConfig { int depth, segRays /* rays per chunk */, refillAt, triW; float cullK; int gridBlocks; int maxAccepted;
                      int refillAtAny, triWAny;  /* the same two for any-hit launches: their rays end at the first hit, a wave waits for more idle lanes and more leaf lanes (profiles/r03z_*) */
-                     int anyhitFree;  /* any-hit rays visit the nearer child first instead of the reference's order (same answers) */ };
+                     int anyhitFree;  /* any-hit rays visit the nearer child first instead of the reference's order (same answers) */
+                     int refillAtInst, triWInst, refillAtAnyInst;  /* scenes with object instances: closest-hit refill threshold and triangle-step weight, any-hit refill threshold */ };
 // The defaults, with the PG_TRACE_* environment overrides of experiments and tests applied.  Every scene carries its own copy
 // (PgScene::trace): the exact-fallback retry of one scene must not change what another host thread's launches use.
 TraceConfig default_trace_config();

@@ -82,6 +82,22 @@ PG_DEV V3 m4_point_err(const float *m, V3 p, V3 &pError) {  // transform.h:277-3
     if (wp == 1) return mk(xp, yp, zp);
     return vdiv(mk(xp, yp, zp), wp);
 }
+// the same with the homogeneous weight wp = (m[12] x + m[13] y) + (m[14] z + m[15]) formed by the caller (k_trace's instance entry: from row 3's
+// constants where the row is (0, 0, 0, 1)); m: rows 0 - 2
+PG_DEV V3 m4_point_err_w(const float *m, V3 p, float wp, V3 &pError) {
+    const float x = p.x, y = p.y, z = p.z;
+    const float xp = (m[0] * x + m[1] * y) + (m[2] * z + m[3]);
+    const float yp = (m[4] * x + m[5] * y) + (m[6] * z + m[7]);
+    const float zp = (m[8] * x + m[9] * y) + (m[10] * z + m[11]);
+    const float xAbsSum = (fabsf(m[0] * x) + fabsf(m[1] * y) + fabsf(m[2] * z) + fabsf(m[3]));
+    const float yAbsSum = (fabsf(m[4] * x) + fabsf(m[5] * y) + fabsf(m[6] * z) + fabsf(m[7]));
+    const float zAbsSum = (fabsf(m[8] * x) + fabsf(m[9] * y) + fabsf(m[10] * z) + fabsf(m[11]));
+    pError = mk(xAbsSum, yAbsSum, zAbsSum) * pgamma(3);
+    if (wp == 1) return mk(xp, yp, zp);
+    V3 r;  // a projective matrix (rare): one division after the other
+    r.x = xp / wp; PG_SCHED_BARRIER(); r.y = yp / wp; PG_SCHED_BARRIER(); r.z = zp / wp;
+    return r;
+}
 PG_DEV V3 m4_point_err2(const float *m, V3 pt, V3 ptError, V3 &absError) {  // transform.h:302-332
     const float x = pt.x, y = pt.y, z = pt.z;
     const float xp = (m[0] * x + m[1] * y) + (m[2] * z + m[3]);

@@ -50,18 +50,39 @@
 #ifndef TR_MIN_WAVES
 #define TR_MIN_WAVES 2
 #endif
-// instanced triangle scenes: 5 waves per SIMD (96 VGPRs; the kernels need 85 - 87).  Holding the allocator to 6 waves (80 VGPRs)
-// spills 7 - 10 registers and loses: 351 vs 303 ms per frame in k_trace<false> on the 5 M-triangle divergent stand-in
-// (profiles/r03d_xprim_register_diet.txt)
-#ifndef TR_FREE_EXTRA_WAVES  // the free-order any-hit kernel needs fewer registers: 78 - 81
-#define TR_FREE_EXTRA_WAVES 1
+// instanced triangle scenes: 7 waves per SIMD (72 VGPRs) since round 6 -- the kernels needed 85 - 87 registers (5 waves; held to 80 they spilled
+// 7 - 10 and lost, profiles/r03d_xprim_register_diet.txt) until the diet described at k_trace; each resident wave is worth 5 - 13 % of this
+// latency-bound kernel's time (4 / 5 / 6 / 7 waves: 335 / 292 / 259 / 244 ms of closest-hit traversal per frame of the config-4 stand-in,
+// profiles/r06_trace_inst_ab.txt).  The free-order any-hit kernel fits 8 waves (63 registers) but then needs the stack depth 10 that costs more.
+#ifndef TR_FREE_EXTRA_WAVES
+#define TR_FREE_EXTRA_WAVES 0
 #endif
 #ifndef TR_INST_WAVES
-#define TR_INST_WAVES 5
+#define TR_INST_WAVES 7
+#endif
+#ifndef TR_FLAT_WAVES  // triangle-only scenes (XP 0, XP_ALPHA)
+#define TR_FLAT_WAVES TR_MIN_WAVES
 #endif
 #define TR_MAX_ACCEPTED 4096  // (1+2^-24)^(3*4096) < 1+2^-10
 #ifndef TR_DEFAULT_DEPTH
 #define TR_DEFAULT_DEPTH 11
+#endif
+
+// TR_STATS (tools/trace_step_stats.py; never defined in the product build): where the lanes of a wave go -- per step kind the number of
+// wave steps and of lanes that took part, and what the other lanes were doing meanwhile.  Wave-uniform counts, added up once per wave.
+#ifdef TR_STATS
+enum { TS_ITER, TS_INT_STEPS, TS_INT_LANES, TS_TRI_STEPS, TS_TRI_LANES, TS_ALPHA_STEPS, TS_ALPHA_LANES, TS_ENTER_STEPS, TS_ENTER_LANES, TS_EXIT_STEPS,
+       TS_EXIT_LANES, TS_REFILL_STEPS, TS_REFILL_LANES, TS_WAIT_ENTER, TS_WAIT_EXIT, TS_IDLE, TS_INST_PRIM_LANES, TS_RAYS, TS_IN_INST_INT, TS_IN_INST_TRI,
+       TS_ALPHA_WAIT, TS_N };
+__device__ unsigned long long g_trStats[3][TS_N];
+#define TS_ADD(k, v) (ts[k] += (unsigned long long)(v))
+extern "C" int pg_debug_trace_stats(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trStats), sizeof(unsigned long long) * 3 * TS_N) != hipSuccess) return -1;
+    if (reset) { static const unsigned long long z[3][TS_N] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_trStats), z, sizeof(z)) != hipSuccess) return -1; }
+    return TS_N;
+}
+#else
+#define TS_ADD(k, v) ((void)0)
 #endif
 
 // Bounds3::IntersectP(ray, invDir, dirIsNeg), geometry.h:1412-1438, split into
@@ -134,8 +155,11 @@ PG_DEV unsigned long long tr_wave_sum(unsigned long long v) {
 
 // MIPMap<Float>::Lookup(st, 0 width) of a DAlphaTex = `triangle(0, st)` (mipmap.h:231-243) with Texel's wrap modes (:189-212): the
 // operations of mip_triangle / mip_texel (pg_texture.h) on the red channel, in the same order.
+// Mod(a, b) of pbrt.h:314-317 without the integer division (~40 vector instructions) where a is already inside [0, b): the four texels of a
+// lookup are, except at the map's border
+PG_DEV int alpha_mod(int a, int b) { if ((unsigned)a < (unsigned)b) return a; return mod_i(a, b); }
 PG_DEV float alpha_texel(const DScene &sc, const DAlphaTex &a, int s, int t) {
-    if (a.wrap == 0) { s = mod_i(s, a.width); t = mod_i(t, a.height); }
+    if (a.wrap == 0) { s = alpha_mod(s, a.width); t = alpha_mod(t, a.height); }
     else if (a.wrap == 2) { s = s < 0 ? 0 : (s > a.width - 1 ? a.width - 1 : s); t = t < 0 ? 0 : (t > a.height - 1 ? a.height - 1 : t); }
     else if (s < 0 || s >= a.width || t < 0 || t >= a.height) return 0.f;
     return sc.texels[a.offset + ((size_t)t * a.width + s)];
@@ -158,20 +182,29 @@ PG_DEV float trace_ray_time(const DScene &sc, const RayQueue &q0, const RayQueue
 }
 // KIND: 0 closest hit (BVHAccel::Intersect), 1 any hit in the reference's order (BVHAccel::IntersectP, counters exact),
 // 2 any hit in free order (same occlusion answers; the counters then say what THIS traversal read)
+// What keeps the instanced kernels' registers at 72 (7 resident waves; 87 and 5 before round 6: profiles/r06_trace_inst_ab.txt).  The triangle-only
+// kernels sit at 7 / 8 waves either way and are a little FASTER without the first two (config 3: 216.2 vs 219.2 ms per frame), so these are
+// per-instantiation switches:
+//   HITSTORE  the closest-hit record goes to memory when a hit is accepted (the last one stays) instead of waiting in four registers for the retire
+//   NOSZ      Sz = 1 / d[kz] of the triangle test is one of the slab test's three reciprocals: no register and no division of its own
+//   WCNT      the two statistics are counted per wave in scalar registers (a population count per step), not per lane
+#ifndef TR_FLAT_DIET
+#define TR_FLAT_DIET 0
+#endif
 #ifndef TR_INST_GROUP
 #define TR_INST_GROUP 8  // lanes waiting for an instance entry / exit step before the wave runs it (measured 4 / 8 / 12 / 20 / 32: profiles/r03x_*)
 #endif
 template <int KIND, int XP>
-__global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_ALPHA)) ? (KIND == 2 ? TR_INST_WAVES + TR_FREE_EXTRA_WAVES : TR_INST_WAVES) : TR_MIN_WAVES)) TR_SGPR_ATTR void k_trace(DScene sc, RayQueue q0, RayQueue q1, float4 *__restrict__ hits,
+__global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_ALPHA)) ? (KIND == 2 ? TR_INST_WAVES + TR_FREE_EXTRA_WAVES : TR_INST_WAVES) : ((XP == 0 || XP == XP_ALPHA) ? TR_FLAT_WAVES : TR_MIN_WAVES))) TR_SGPR_ATTR void k_trace(DScene sc, RayQueue q0, RayQueue q1, float4 *__restrict__ hits,
                                                     int hitOffset1, float *__restrict__ tOut, int *__restrict__ occluded,
                                                     TraceCounters *cn, int *__restrict__ cursors, int depth, int chunk, int refillAt, int triW,
                                                     float cullK, int *cullGuard, int maxAccepted) {
     constexpr bool ANYHIT = KIND != 0, FREE = KIND == 2;
+    constexpr bool DIET = (XP & XP_INST) || (TR_FLAT_DIET & 1), HITSTORE = !ANYHIT && ((XP & XP_INST) || (TR_FLAT_DIET & 2)), NOSZ = (XP & XP_INST) || (TR_FLAT_DIET & 4);
     extern __shared__ uint2 ldsStack[];  // [depth][TR_BLOCK]
     uint2 spill[TR_STACK_TOTAL];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const unsigned long long laneLt = (1ull << lane) - 1ull;
     // Work distribution: the queue is PG_REGIONS sub-queues, one per XCD (block b runs on XCD b % 8, and the producers
     // appended from that XCD, so each private L2 sees one coherent part of the queue); a wave takes `chunk` rays at a time
     // from its region's cursor and moves on to the next region when its own is drained.  Waves are persistent: the grid
@@ -198,25 +231,36 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
     int vd = 0;                       // ANYHIT: reference stack depth (real + culled entries)
     unsigned long long vmask = 0;     // ANYHIT: bit i set = the reference's entry at depth i was culled early
     unsigned int nodeVisits = 0, triTests = 0;
+    // every step is one kind of step for the whole wave, so what it adds to the two statistics is a population count of the step's lane mask:
+    // scalar registers and scalar adds instead of two vector registers and two vector adds per lane (only the reference-order any-hit walk counts
+    // a per-lane number of visits inside its pop loop and keeps the lane counter)
+    constexpr bool WCNT = KIND != 1 && DIET;
+    unsigned long long wNodes = 0, wTris = 0;
     int nAccepted = 0;  // hits accepted by this lane's current ray (bounds the rounding growth of tMax, see cullK below)
     // XP_INST: object instances.  While a lane traverses an instance's BVH its ray registers hold the instance-space ray
     // (TransformedPrimitive::Intersect, primitive.cpp:76-96); the world ray, the rest of the world leaf and (any-hit) the
     // world BVH's visit bookkeeping wait here.  Entries of the instance's traversal sit on the same stack above spBase.
     // Of the world ray only tMax is kept (it shrinks with every hit): origin, reciprocal direction and the triangle shear are
     // derived again from the queue entry when the lane comes back -- the same operations on the same inputs as at the refill,
-    // so the same bits -- which spares ten registers for the whole kernel (101 -> 5 resident waves per SIMD instead of 4).
+    // so the same bits -- which spares ten registers for the whole kernel.  (Round 6 measured the alternative of parking them in
+    // LDS behind the stack, 6 / 9 / 11 words per lane: the exit step loses its loads and divisions, the kernel a resident block or
+    // two stack entries; slower: profiles/r06_trace_inst_ab.txt.)
     int inInst = -1, hitInstCur = -1, spBase = 0, wvd = 0;
     // Entering and leaving an instance are steps of their own (like "expand an interior record" and "test a triangle"): a lane
-    // that meets an instance record in a leaf waits with pendInst >= 0, a lane that has finished an instance's BVH waits as it
-    // is, and the wave runs the entry / exit code when TR_INST_GROUP lanes wait for it or nothing else is left to do.  Run
-    // inline where they arose, the two blocks executed in half of all wave iterations of the instanced 5 M-triangle scene with
-    // 2.6 (exit) and 5.3 (entry) active lanes (profiles/r03w_trace_step_statistics.txt; the gain is 3 % closest hit, 10 % any hit).
-    int pendInst = -1;
+    // that meets an instance record in a leaf waits with cur = -2 - (the instance's index) -- between iterations cur is otherwise an
+    // interior record (>= 0) or TR_NONE --, a lane that has finished an instance's BVH waits as it is, and the wave runs the entry /
+    // exit code when TR_INST_GROUP lanes wait for it or nothing else is left to do.  Run inline where they arose, the two blocks
+    // executed in half of all wave iterations of the instanced 5 M-triangle scene with 2.6 (exit) and 5.3 (entry) active lanes
+    // (profiles/r03w_trace_step_statistics.txt; the gain is 3 % closest hit, 10 % any hit).  The alpha lookup as a third such step
+    // (candidate hits waiting in the stack slots above the lane's top) LOSES 3 - 6 % at group sizes 2 / 4 / 8: r06_trace_inst_ab.txt.
     unsigned wLeaf = 0;  // the rest of the world leaf: next primitive << (leafBits + 1) | primitives left
     bool instHit = false;
     float wtMax = 0;
     unsigned long long wvmask = 0;
     const int leafBits = sc.leafBits, leafMask = (1 << leafBits) - 1;
+#ifdef TR_STATS
+    unsigned long long ts[TS_N] = {};
+#endif
 
 #define TR_PUSH(ref_, t_) do { uint2 e_ = make_uint2((unsigned)(ref_), __float_as_uint(t_)); \
         if (sp < depth) ldsStack[sp * TR_BLOCK + tid] = e_; else spill[sp - depth] = e_; ++sp; } while (0)
@@ -233,6 +277,27 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
     // A negative reference is a leaf: unpack (first prim, count) into the lane's triangle state.
 #define TR_SETTLE() do { if (cur < 0 && cur != TR_NONE) { const int code_ = ~cur; triNext = code_ >> leafBits; triLeft = (code_ & leafMask) + 1; cur = TR_NONE; } } while (0)
 
+    // the accepted hit, written with selects (in place: a branch here makes the compiler copy the whole hit record aside before the test and
+    // back after it); HITSTORE: the record goes to memory now (the last accepted one stays), not from registers when the ray retires
+#define TR_ACCEPT_CLOSEST(hit_, prim_, t_, b0_, b1_, b2_) do { tMax = (hit_) ? (t_) : tMax; \
+        if (HITSTORE) { \
+            if (hit_) { hits[ray] = make_float4(__int_as_float(prim_), b0_, b1_, b2_); if ((XP & XP_INST) && sc.hitInst) sc.hitInst[ray] = inInst; } \
+            if (XP & XP_ANIM) hitInstCur = (hit_) ? inInst : hitInstCur; \
+        } else { \
+            hb0 = (hit_) ? (b0_) : hb0; hb1 = (hit_) ? (b1_) : hb1; hb2 = (hit_) ? (b2_) : hb2; \
+            if (XP & XP_INST) hitInstCur = (hit_) ? inInst : hitInstCur; \
+        } } while (0)
+#define TR_ACCEPT(hit_, prim_, t_, b0_, b1_, b2_) do { hitPrim = (hit_) ? (prim_) : hitPrim; \
+        if (ANYHIT) {  /* bvh.cpp:717: return true */ \
+            triLeft = (hit_) ? 0 : triLeft; sp = (hit_) ? 0 : sp; vd = (hit_) ? 0 : vd; \
+            if (XP & XP_INST) inInst = (hit_) ? -1 : inInst; \
+        } else {  /* primitive.cpp:123: r.tMax = tHit */ \
+            TR_ACCEPT_CLOSEST(hit_, prim_, t_, b0_, b1_, b2_); \
+            if (XP & XP_INST) instHit = instHit || (hit_); \
+            nAccepted += (hit_) ? 1 : 0; \
+            if ((hit_) && nAccepted == maxAccepted) atomicOr(cullGuard, 1); \
+        } } while (0)
+
     for (;;) {
         // ---- retire finished rays and refill idle lanes from this wave's segment.  A finished ray's result stays in its lane
         //      until the wave refills (>= refillAt idle lanes) or runs dry, so the stores run with many lanes active instead of
@@ -240,19 +305,22 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
         //      the hit here to spare the shading kernel its gather (+12 ms per frame here, no gain in k_shade); handing invDir
         //      and the triangle test's shear over from the ray's producer instead of deriving them at refill (no gain:
         //      the refill costs 9 % of this kernel's issue slots, but the extra 32 B per ray cost as much as the divisions).
-        const bool wantExit = (XP & XP_INST) && inInst >= 0 && cur == TR_NONE && triLeft == 0 && pendInst < 0;  // finished an instance's BVH
-        const bool wantEnter = (XP & XP_INST) && pendInst >= 0;
+        const bool wantExit = (XP & XP_INST) && inInst >= 0 && cur == TR_NONE && triLeft == 0;  // finished an instance's BVH
+        const bool wantEnter = (XP & XP_INST) && cur < 0 && cur != TR_NONE;
         const bool idle = cur == TR_NONE && triLeft == 0 && !wantExit && !wantEnter;
         const unsigned long long idleMask = __ballot(idle);
         const int nIdle = __popcll(idleMask);
+        TS_ADD(TS_ITER, 1); TS_ADD(TS_IDLE, nIdle);
         // one scalar comparison decides between the step and the (rarer) retire / refill path: the threshold is refillAt
         // while the queues still have rays and 64 -- every lane idle -- once they are exhausted
         if (nIdle >= idleThreshold) {
             if (idle && ray >= 0) {
                 if (ANYHIT) occluded[ray] = hitPrim >= 0 ? 1 : 0;
                 else {
-                    hits[ray] = make_float4(__int_as_float(hitPrim), hb0, hb1, hb2);
-                    if ((XP & XP_INST) && sc.hitInst) sc.hitInst[ray] = hitInstCur;
+                    if (!HITSTORE) {
+                        hits[ray] = make_float4(__int_as_float(hitPrim), hb0, hb1, hb2);
+                        if ((XP & XP_INST) && sc.hitInst) sc.hitInst[ray] = hitInstCur;
+                    }
                     if ((XP & XP_ANIM) && sc.animXf && hitInstCur >= 0 && sc.instances[hitInstCur].animated) {
                         // InterpolatedPrimToWorld of the accepted hit's instance, for *isect = InterpolatedPrimToWorld(*isect) in the shading kernels
                         float xf[PG_XF_STRIDE];
@@ -293,11 +361,14 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                 }
             }
             if (!exhausted) {
-                int idx = next + __popcll(idleMask & laneLt);
+                int idx = next + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idleMask, 0u));  // + the idle lanes below this one (v_mbcnt: no lane-mask registers)
                 next += nIdle;
+                TS_ADD(TS_REFILL_STEPS, 1); TS_ADD(TS_REFILL_LANES, __popcll(__ballot(idle && idx < segEnd)));
+                if (WCNT && sc.nNodes > 0) wNodes += __popcll(__ballot(idle && idx < segEnd));  // nodes[0]
                 if (idle && idx < segEnd) {
                     const float4 o4 = curQ ? q1.o[idx] : q0.o[idx], d4 = curQ ? q1.d[idx] : q0.d[idx];
                     ray = idx + (curQ ? hitOffset1 : 0);  // index of this ray's result
+                    if (HITSTORE) { hits[ray] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f); if ((XP & XP_INST) && sc.hitInst) sc.hitInst[ray] = -1; }  // "no hit" until one is accepted
                     ox = o4.x; oy = o4.y; oz = o4.z; tMax = o4.w;
                     tr = tri_ray_setup(mk(d4.x, d4.y, d4.z));
                     ix = 1 / d4.x; iy = 1 / d4.y; iz = 1 / d4.z;   // bvh.cpp:666
@@ -306,7 +377,7 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                     inInst = -1; hitInstCur = -1; spBase = 0;
                     sp = 0; vd = 0; vmask = 0;
                     if (sc.nNodes > 0) {
-                        ++nodeVisits;  // nodes[0]
+                        if (!WCNT) ++nodeVisits;  // nodes[0]
                         float t0;
                         if (slab_interval(sc.rootBox[0], sc.rootBox[3], sc.rootBox[1], sc.rootBox[4], sc.rootBox[2], sc.rootBox[5], ox, oy, oz,
                                           ix, iy, iz, nx, ny, nz, t0) && t0 < tMax) {
@@ -322,12 +393,14 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
         // ---- one step for the wave: either every lane holding an interior record expands it, or every lane
         //      holding a leaf tests its next triangle.  The larger group goes first (weighted by triW/16), so
         //      at least about half of the busy lanes are active in every step and neither group starves.
-        // ---- instance steps (see pendInst): leave, then enter, when enough lanes wait or no lane can do anything else
+        // ---- instance steps: leave, then enter, when enough lanes wait or no lane can do anything else
         if (XP & XP_INST) {
             const int nExit = __popcll(__ballot(wantExit)), nEnter = __popcll(__ballot(wantEnter));
+            TS_ADD(TS_WAIT_EXIT, nExit); TS_ADD(TS_WAIT_ENTER, nEnter);
             if (nExit | nEnter) {
                 const bool nothingElse = __ballot(cur >= 0 || triLeft > 0) == 0;
                 if (nExit > 0 && (nExit >= TR_INST_GROUP || nothingElse)) {
+                    TS_ADD(TS_EXIT_STEPS, 1); TS_ADD(TS_EXIT_LANES, nExit);
                     if (wantExit) {  // back to the world ray (primitive.cpp:83-88)
                         if (!ANYHIT && instHit) wtMax = tMax;  // r.tMax = ray.tMax
                         {
@@ -345,25 +418,47 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                     continue;
                 }
                 if (nEnter > 0 && (nEnter >= TR_INST_GROUP || nothingElse)) {
+                    TS_ADD(TS_ENTER_STEPS, 1); TS_ADD(TS_ENTER_LANES, nEnter);
+                    bool enteredBVH = false;
                     if (wantEnter) {
                         // TransformedPrimitive::Intersect[P]: carry the ray into the instance's space (Transform::operator()(Ray),
                         // transform.h:249-262) and start on its BVH
                         const bool fromQ1 = q1.regionCap > 0 && ray >= hitOffset1;
                         const float4 d4 = fromQ1 ? q1.d[ray - hitOffset1] : q0.d[ray];
-                        const int idx = pendInst;
-                        const PgInstance &in = sc.instances[idx];
-                        const DObject &ob = sc.objects[in.object];
+                        const int idx = -2 - cur;
+                        // one 96-byte record per instance (DInstEntry): the matrix rows the ray needs, the object's root box and references
+                        const DInstEntry *obp = sc.instEntry + idx;
+                        const DInstEntry &ob = *obp;
                         wtMax = tMax;
                         if (ANYHIT) { wvd = vd; wvmask = vmask; vd = 0; vmask = 0; }
                         V3 oErr, o, dd;
-                        if ((XP & XP_ANIM) && in.animated) {  // PrimitiveToWorld.Interpolate(r.time, ...), primitive.cpp:78-80 / :99-101
+                        if ((XP & XP_ANIM) && sc.instances[idx].animated) {  // PrimitiveToWorld.Interpolate(r.time, ...), primitive.cpp:78-80 / :99-101
                             float xf[PG_XF_STRIDE];
-                            instance_matrices_at(in, trace_ray_time(sc, q0, q1, ray, hitOffset1), xf);
+                            instance_matrices_at(sc.instances[idx], trace_ray_time(sc, q0, q1, ray, hitOffset1), xf);
                             o = m4_point_err(xf + 16, mk(ox, oy, oz), oErr);
                             dd = m4_vec(xf + 16, mk(d4.x, d4.y, d4.z));
                         } else {
-                            o = m4_point_err(in.w2i, mk(ox, oy, oz), oErr);
-                            dd = m4_vec(in.w2i, mk(d4.x, d4.y, d4.z));
+                            // Transform::operator()(Point3f, Vector3f *pError) with the homogeneous weight from row 3's constants (0, 0, 0, 1)
+                            // where that is the row (the same four products and three sums), from the PgInstance otherwise
+                            float wp;
+                            if (ob.affineStill) wp = (0.f * ox + 0.f * oy) + (0.f * oz + 1.f);
+                            else { const float *r3 = sc.instances[idx].w2i + 12; wp = (r3[0] * ox + r3[1] * oy) + (r3[2] * oz + r3[3]); }
+                            // row by row (Transform::operator() of the point with its error, transform.h:277-300, and of the vector, :233-239: the
+                            // same products and sums per component): a row is loaded when the previous one has been consumed, so four matrix
+                            // entries are live at a time instead of twelve
+                            float op[3], dp[3], ab[3];
+                            const float *mp = obp->w2i;
+                            for (int r = 0; r < 3; ++r) {
+                                const float4 row = *(const float4 *)(mp + 4 * r);
+                                dp[r] = row.x * d4.x + row.y * d4.y + row.z * d4.z;
+                                op[r] = (row.x * ox + row.y * oy) + (row.z * oz + row.w);
+                                ab[r] = (fabsf(row.x * ox) + fabsf(row.y * oy) + fabsf(row.z * oz) + fabsf(row.w));
+                                asm volatile("" : "+v"(mp), "+v"(dp[r]), "+v"(op[r]), "+v"(ab[r]));  // (the next row's address waits for this row's results)
+                            }
+                            oErr = mk(ab[0], ab[1], ab[2]) * pgamma(3);
+                            dd = mk(dp[0], dp[1], dp[2]);
+                            if (wp == 1) o = mk(op[0], op[1], op[2]);
+                            else { o.x = op[0] / wp; PG_SCHED_BARRIER(); o.y = op[1] / wp; PG_SCHED_BARRIER(); o.z = op[2] / wp; }
                         }
                         const float lengthSquared = lensq(dd);
                         if (lengthSquared > 0) {
@@ -375,19 +470,25 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                         tr = tri_ray_setup(dd);
                         ix = 1 / dd.x; iy = 1 / dd.y; iz = 1 / dd.z;
                         nx = ix < 0; ny = iy < 0; nz = iz < 0; negBits = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
-                        inInst = idx; spBase = sp; instHit = false; pendInst = -1;
+                        inInst = idx; spBase = sp; instHit = false;
                         triLeft = 0; cur = TR_NONE;
-                        if (ob.nNodes == 0) { triNext = ob.firstPrim; triLeft = 1; }  // a lone primitive, no accelerator (api.cpp:1567)
+                        // the record's second half (root box, references) is read HERE: without the barrier the compiler issues all six loads of the
+                        // record at the top of the step and the matrix and the box are live together -- the register peak of the whole kernel
+                        asm volatile("" : "+v"(obp));
+                        const DInstEntry &ob2 = *obp;
+                        if (ob2.nNodes == 0) { triNext = ob2.firstPrim; triLeft = 1; }  // a lone primitive, no accelerator (api.cpp:1567)
                         else {
-                            ++nodeVisits;  // the instance BVH's nodes[0]
+                            if (!WCNT) ++nodeVisits;  // the instance BVH's nodes[0]
+                            enteredBVH = true;
                             float t0;
-                            if (slab_interval(ob.box[0], ob.box[3], ob.box[1], ob.box[4], ob.box[2], ob.box[5], ox, oy, oz, ix, iy, iz, nx, ny, nz, t0) &&
+                            if (slab_interval(ob2.box[0], ob2.box[3], ob2.box[1], ob2.box[4], ob2.box[2], ob2.box[5], ox, oy, oz, ix, iy, iz, nx, ny, nz, t0) &&
                                 t0 < tMax) {
-                                cur = ob.rootRef;
+                                cur = ob2.rootRef;
                                 TR_SETTLE();
                             }
                         }
                     }
+                    if (WCNT) wNodes += __popcll(__ballot(enteredBVH));
                     continue;
                 }
             }
@@ -396,25 +497,34 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
         const int nInt = __popcll(__ballot(cur >= 0));
         const int nTri = __popcll(__ballot(triLeft > 0));
         if (nTri > 0 && (nInt == 0 || nTri * 16 >= nInt * triW)) {
+            TS_ADD(TS_TRI_STEPS, 1); TS_ADD(TS_TRI_LANES, nTri);
+            bool notTri = false;  // an instance or a quadric: not a triangle test for the reference's counter
+#ifdef TR_STATS
+            if (XP & XP_INST) TS_ADD(TS_IN_INST_TRI, __popcll(__ballot(triLeft > 0 && inInst >= 0)));
+            bool tsAlpha = false;
+#endif
             if (triLeft > 0) {  // Triangle::Intersect[P] on the leaf's next primitive, in order (bvh.cpp:677-680)
                 const int prim = triNext;
                 const float4 a = sc.tris[PG_TRI_STRIDE * prim], b = sc.tris[PG_TRI_STRIDE * prim + 1], c = sc.tris[PG_TRI_STRIDE * prim + 2];
-                ++triTests; ++triNext; --triLeft;
+                if (!WCNT) ++triTests;
+                ++triNext; --triLeft;
                 const uint32_t pflags = __float_as_uint(a.w);
                 if ((XP & XP_INST) && (pflags & PG_PRIM_INSTANCE)) {
                     // TransformedPrimitive::Intersect[P]: not a triangle test for the reference's counter; the lane waits for the
                     // wave's next entry step with the rest of the world leaf put aside
-                    --triTests;
-                    pendInst = __float_as_int(a.x);
+                    if (!WCNT) --triTests;
+                    notTri = true;
                     wLeaf = ((unsigned)triNext << (leafBits + 1)) | (unsigned)triLeft;
-                    triLeft = 0; cur = TR_NONE;
+                    triLeft = 0;
+                    cur = -2 - __float_as_int(a.x);
                 } else {
                     float t, b0, b1, b2;
                     bool hit;
                     if ((XP & XP_QUADRIC) && (pflags & PG_PRIM_SPHERE)) {
                         // Sphere::Intersect[P] (sphere.cpp:48-106): not a triangle test for the reference's counter; the ray's
                         // direction is not kept in registers (only its reciprocal and the triangle shear), so it is re-read
-                        --triTests;
+                        if (!WCNT) --triTests;
+                        notTri = true;
                         const bool fromQ1 = q1.regionCap > 0 && ray >= hitOffset1;
                         const float4 d4 = fromQ1 ? q1.d[ray - hitOffset1] : q0.d[ray];
                         V3 dd = mk(d4.x, d4.y, d4.z);
@@ -425,12 +535,18 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                         } else if (inInst >= 0) dd = m4_vec(sc.instances[inInst].w2i, dd);
                         hit = sphere_test(sc.spheres[__float_as_int(a.x)], mk(ox, oy, oz), dd, tMax, t);
                         b0 = t; b1 = 0; b2 = 0;  // the hit record of a sphere carries tHit
-                    } else
-                        hit = tri_test_pre(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), mk(ox, oy, oz), tr, tMax, t, b0, b1, b2) &&
+                    } else {
+                        TriRay trz = tr;
+                        if (NOSZ) trz.Sz = tr.kz == 0 ? ix : (tr.kz == 1 ? iy : iz);  // 1 / d[kz]: the same quotient as the slab test's reciprocal
+                        hit = tri_test_pre(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), mk(ox, oy, oz), trz, tMax, t, b0, b1, b2) &&
                               !(pflags & PG_TRI_BOGUS);
+                    }
                     if ((XP & (XP_ALPHA | XP_ALPHATEX)) && hit && (pflags & PG_TRI_ALPHA)) {
                         // the mesh's alpha / shadow-alpha textures at the hit (triangle.cpp:333-338, :531-569): point, (u, v),
                         // no differentials; a value of exactly 0 rejects the hit and the ray goes on
+#ifdef TR_STATS
+                        tsAlpha = true;
+#endif
                         float uv[6] = {0, 0, 1, 0, 1, 1};
                         if (sc.uv && (pflags & PG_TRI_HAS_UV)) for (int k = 0; k < 6; ++k) uv[k] = sc.uv[6 * prim + k];
                         const float hu = b0 * uv[0] + b1 * uv[2] + b2 * uv[4], hv = b0 * uv[1] + b1 * uv[3] + b2 * uv[5];
@@ -449,22 +565,22 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                             if (ANYHIT && hit && at[1].image != -2 && alpha_lookup(sc, at[1], hu, hv) == 0) hit = false;
                         }
                     }
-                    // the accepted hit, written with selects (in place: a branch here makes the compiler copy the whole hit
-                    // record aside before the test and back after it)
-                    hitPrim = hit ? prim : hitPrim;
-                    if (ANYHIT) {  // bvh.cpp:717: return true
-                        triLeft = hit ? 0 : triLeft; sp = hit ? 0 : sp; vd = hit ? 0 : vd;
-                        if (XP & XP_INST) inInst = hit ? -1 : inInst;
-                    } else {
-                        tMax = hit ? t : tMax; hb0 = hit ? b0 : hb0; hb1 = hit ? b1 : hb1; hb2 = hit ? b2 : hb2;  // primitive.cpp:123: r.tMax = tHit
-                        if (XP & XP_INST) { hitInstCur = hit ? inInst : hitInstCur; instHit = instHit || hit; }
-                        nAccepted += hit ? 1 : 0;
-                        if (hit && nAccepted == maxAccepted) atomicOr(cullGuard, 1);
-                    }
+                    TR_ACCEPT(hit, prim, t, b0, b1, b2);
                     needPop = triLeft == 0 && !(ANYHIT && hitPrim >= 0);
                 }
             }
-        } else if (cur >= 0) {
+            if (WCNT) wTris += nTri - (((XP & (XP_INST | XP_QUADRIC)) != 0) ? __popcll(__ballot(notTri)) : 0);
+#ifdef TR_STATS
+            { const int na = __popcll(__ballot(tsAlpha)); if (na) { TS_ADD(TS_ALPHA_STEPS, 1); TS_ADD(TS_ALPHA_LANES, na); } }
+#endif
+        } else {
+          // (wave-uniform: every lane reaches this point)
+          TS_ADD(TS_INT_STEPS, 1); TS_ADD(TS_INT_LANES, nInt);
+          if (WCNT) wNodes += 2 * nInt;  // closest hit: near now, far when the reference pops it (it always does); free order: both boxes were read
+          if (cur >= 0) {
+#ifdef TR_STATS
+            if (XP & XP_INST) TS_ADD(TS_IN_INST_INT, __popcll(__ballot(inInst >= 0)));
+#endif
             const float4 *rec = sc.wnodes + 4 * (size_t)cur;
             const float4 bx = rec[0], by = rec[1], bz = rec[2];
             const float4 rf = rec[3];
@@ -490,7 +606,7 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
             // exactly at pop time, and a ray that accepts more hits than that raises cullGuard so the host fails loudly.
             const bool farMaybe = __builtin_amdgcn_inverse_ballot_w64(mFar);
             if (!ANYHIT) {
-                nodeVisits += 2;  // near now, far when the reference pops it (it always does)
+                if (!WCNT) nodeVisits += 2;  // near now, far when the reference pops it (it always does)
                 if (farMaybe) TR_PUSH(farRef, farT);
             } else if (!FREE) {
                 nodeVisits += 1;
@@ -507,21 +623,28 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                 const int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y);
                 const bool first0 = h0 && (!h1 || t0 <= t1);
                 if (h0 && h1) TR_PUSH(first0 ? r1 : r0, 0.f);
-                nodeVisits += 2;  // both children's boxes were read and tested
+                if (!WCNT) nodeVisits += 2;  // both children's boxes were read and tested
                 if (h0 || h1) cur = first0 ? r0 : r1;
                 needPop = !(h0 || h1);
             }
             settle = true;
+          }
         }
         // the reference's "pop or finish" and the unpacking of a leaf reference, once for both kinds of step
         if (needPop) { TR_POP(); settle = true; }
         if (settle) TR_SETTLE();
     }
+#undef TR_ACCEPT
+#undef TR_ACCEPT_CLOSEST
 #undef TR_PUSH
 #undef TR_TOP
 #undef TR_POP
 #undef TR_SETTLE
+#ifdef TR_STATS
+    if (lane == 0) for (int k = 0; k < TS_N; ++k) if (ts[k]) atomicAdd(&g_trStats[KIND][k], ts[k]);
+#endif
     unsigned long long nv = tr_wave_sum(nodeVisits), nt = tr_wave_sum(triTests);
+    if (WCNT) { nv = wNodes; nt = wTris; }
     if (lane == 0 && cn) {
         atomicAdd(&cn->node_visits, nv);
         atomicAdd(&cn->tri_tests, nt);
@@ -530,13 +653,13 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
 
 // depth 11: 7 resident 256-thread blocks x 22.5 KB of stack fill the 160 KB LDS
 TraceConfig default_trace_config() {
-    TraceConfig tc = {TR_DEFAULT_DEPTH, 128, 16, 8, 1.0009765625f, 2048, TR_MAX_ACCEPTED, 32, 16, 1};
+    TraceConfig tc = {TR_DEFAULT_DEPTH, 128, 16, 8, 1.0009765625f, 2048, TR_MAX_ACCEPTED, 32, 16, 1, /* instanced scenes: */ 8, 12, 16};
     if (const char *e = getenv("PG_TRACE_DEPTH")) { int v = atoi(e); if (v >= 0 && v <= 64) tc.depth = v; }
     if (const char *e = getenv("PG_TRACE_SEG")) { int v = atoi(e); if (v >= 64) tc.segRays = v; }
-    if (const char *e = getenv("PG_TRACE_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) tc.refillAt = v; }
+    if (const char *e = getenv("PG_TRACE_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) tc.refillAt = tc.refillAtInst = v; }
     if (const char *e = getenv("PG_TRACE_GRID")) { int v = atoi(e); if (v >= 8) tc.gridBlocks = v; }
-    if (const char *e = getenv("PG_TRACE_TRIW")) { int v = atoi(e); if (v >= 0) tc.triW = v; }
-    if (const char *e = getenv("PG_TRACE_REFILL_ANY")) { int v = atoi(e); if (v >= 1 && v <= 64) tc.refillAtAny = v; }
+    if (const char *e = getenv("PG_TRACE_TRIW")) { int v = atoi(e); if (v >= 0) tc.triW = tc.triWInst = v; }
+    if (const char *e = getenv("PG_TRACE_REFILL_ANY")) { int v = atoi(e); if (v >= 1 && v <= 64) tc.refillAtAny = tc.refillAtAnyInst = v; }
     if (const char *e = getenv("PG_TRACE_TRIW_ANY")) { int v = atoi(e); if (v >= 0) tc.triWAny = v; }
     if (const char *e = getenv("PG_TRACE_MAXACC")) { int v = atoi(e); if (v >= 1 && v <= 4096) tc.maxAccepted = v; }  // tests: provoke the exact fallback
     if (const char *e = getenv("PG_TRACE_CULLK")) { float v = (float)atof(e); if (v >= 1.f) tc.cullK = v < 3e38f ? v : 3e38f; }  // finite: 0*inf would be NaN
@@ -565,8 +688,12 @@ static void launch_trace(const DScene &sc, const TraceConfig &c, RayQueue q0, Ra
     int xp = (sc.nInstances > 0 ? XP_INST : 0) | (sc.nSpheres > 0 ? XP_QUADRIC : 0) | (sc.hasAlpha ? (sc.alphaTex ? XP_ALPHA : XP_ALPHATEX) : 0);
     // moving instances: two instantiations only -- with quadrics, and the general one (any alpha mask) -- a moving scene pays for both features
     if (sc.hasMotion) xp = XP_ANIM | (sc.hasAlpha ? XP_GENERAL : (XP_INST | XP_QUADRIC));
+    // scenes with instances wait for fewer idle lanes before a refill and weigh the triangle step higher (entry / exit steps take lanes out of
+    // the two main steps: profiles/r06_trace_inst_ab.txt)
+    const bool inst = (xp & XP_INST) != 0;
+    const int refill = KIND ? (inst ? c.refillAtAnyInst : c.refillAtAny) : (inst ? c.refillAtInst : c.refillAt), triW = KIND ? c.triWAny : (inst ? c.triWInst : c.triW);
 #define TR_LAUNCH(XPV) hipLaunchKernelGGL((k_trace<KIND, XPV>), dim3(nblk), dim3(TR_BLOCK), lds, s, sc, q0, q1, hits, hitOffset1, tOut, occluded, cn, \
-                                          cursors, c.depth, c.segRays, KIND ? c.refillAtAny : c.refillAt, KIND ? c.triWAny : c.triW, KIND ? 1.f : c.cullK, cullGuard, c.maxAccepted)
+                                          cursors, c.depth, c.segRays, refill, triW, KIND ? 1.f : c.cullK, cullGuard, c.maxAccepted)
     switch (xp) {
     case 0: TR_LAUNCH(0); break;
     case XP_INST: TR_LAUNCH(XP_INST); break;

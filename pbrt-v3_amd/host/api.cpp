@@ -47,7 +47,9 @@ struct TransformSet {
     Transform t[MaxTransforms];
     Transform &operator[](int i) { return t[i]; }
     const Transform &operator[](int i) const { return t[i]; }
-    bool IsAnimated() const { return !(t[0].GetMatrix() == t[1].GetMatrix()); }
+    bool IsAnimated() const {  // t[i] != t[i + 1]: Transform::operator!= compares m AND mInv (transform.h:139-141, api.cpp:101-105)
+        return !(t[0].GetMatrix() == t[1].GetMatrix()) || !(t[0].GetInverseMatrix() == t[1].GetInverseMatrix());
+    }
 };
 TransformSet Inverse(const TransformSet &ts) {
     TransformSet r;
@@ -68,7 +70,6 @@ struct GraphicsState {
 };
 struct RenderOptions {
     Float transformStartTime = 0, transformEndTime = 1;
-    bool anyMotion = false;  // a moving shape or instance (TransformedPrimitive over an AnimatedTransform that is actually animated)
     bool refused = false;  // the scene asks for something whose absence would change the image (animated shapes / instances / camera): no frame is rendered
     std::string FilterName = "box"; ParamSet FilterParams;
     std::string FilmName = "image"; ParamSet FilmParams;
@@ -1231,7 +1232,6 @@ static bool MakeMotion(const char *what, const std::string &name, GeometricPrimi
     xf->InstanceToWorldEnd = curTransform[1];
     xf->WorldToInstanceEnd = Inverse(curTransform[1]);
     xf->time[0] = renderOptions->transformStartTime; xf->time[1] = renderOptions->transformEndTime;
-    renderOptions->anyMotion = true;
     return true;
 }
 void pbrtShape(const std::string &name, const ParamSet &params) {  // api.cpp:1329-1421
@@ -1511,7 +1511,12 @@ void pbrtWorldEnd() {  // api.cpp:1590-1644
     const bool timing = getenv("PBRT_HOST_TIMING") != nullptr;  // stderr: seconds spent building the accelerators
     auto tBuild = std::chrono::steady_clock::now();
     std::unique_ptr<GpuPathIntegrator> integrator(MakeIntegrator());
+    const int motionFailuresBefore = MotionBoundsFailures();
     std::unique_ptr<Scene> scene(MakeScene());
+    if (MotionBoundsFailures() != motionFailuresBefore) {  // (the reference's CHECK_LE(*nZeros, 8) ends its process here, transform.cpp:385)
+        Error("A rotating motion's derivative has more than 8 zeros in the shutter interval (AnimatedTransform::MotionBounds): its box cannot be the reference's");
+        renderOptions->refused = true;
+    }
     if (timing) fprintf(stderr, "pbrt host: MakeScene (BVH build) %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild).count());
     if (renderOptions->refused) {
         Error("Scene not rendered: it uses features outside this build's closed set (see the errors above); no approximate image is written.");

@@ -88,8 +88,13 @@ int pbrt_host_motion_bounds(const float *start, const float *end, float start_ti
     Matrix4x4 a, b;
     for (int i = 0; i < 16; ++i) { a.m[i >> 2][i & 3] = start[i]; b.m[i >> 2][i & 3] = end[i]; }
     const Transform ta(a), tb(b);
+    const int failuresBefore = MotionBoundsFailures();
     const Bounds3f r = MotionBounds(ta, start_time, tb, end_time, Bounds3f(Point3f(bounds[0], bounds[1], bounds[2]), Point3f(bounds[3], bounds[4], bounds[5])));
     out[0] = r.pMin.x; out[1] = r.pMin.y; out[2] = r.pMin.z; out[3] = r.pMax.x; out[4] = r.pMax.y; out[5] = r.pMax.z;
+    if (MotionBoundsFailures() != failuresBefore) {  // (the reference's CHECK_LE ends its process here)
+        Error("MotionBounds: a motion derivative has more than 8 zeros; the box is not the reference's");
+        return -1;
+    }
     return MotionHasRotation(ta, tb) ? 1 : 0;
 }
 void pbrt_host_set_device_bvh(int on) { g_deviceBVH = on != 0; }

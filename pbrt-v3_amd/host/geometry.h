@@ -146,6 +146,8 @@ class Transform {  // transform.h:112-205
 void DecomposeTransform(const Matrix4x4 &m, Float T[3], Float R[4], Float S[9]);
 // AnimatedTransform(start, startTime, end, endTime).MotionBounds(b) and its hasRotation (transform.cpp:1215-1247, :411): host/motion_bounds.cpp
 Bounds3f MotionBounds(const Transform &start, Float startTime, const Transform &end, Float endTime, const Bounds3f &b);
+// how many MotionBounds calls so far could not give the reference's box (where the reference aborts: more than 8 zeros of a motion derivative)
+int MotionBoundsFailures();
 bool MotionHasRotation(const Transform &start, const Transform &end);
 Transform Translate(const Vector3f &delta);
 Transform Scale(Float x, Float y, Float z);

@@ -16,6 +16,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include "error.h"
 #include "geometry.h"
 
 #ifndef PG_MOTION_BIN
@@ -33,8 +35,12 @@ extern "C" const unsigned char pg_motion_blob[], pg_motion_blob_end[];
 
 namespace pbrt {
 namespace {
+// MotionBounds calls that could not give the reference's box: a derivative with more than 8 zeros (the reference's CHECK_LE aborts there),
+// or the polynomial table unreadable.  The front end and pbrt_host_motion_bounds turn a rise of this count into an Error and a refused frame.
+std::atomic<int> g_motionBoundsFailures{0};
 enum { kVars = 33, kPrograms = 60 };
 struct Programs {
+    bool valid = true;
     float consts[64];
     const unsigned char *code[kPrograms];
     int len[kPrograms];
@@ -69,7 +75,8 @@ const Programs &MotionPrograms() {
             }
             ok = ok && b == end;
         }
-        if (!ok) { fprintf(stderr, "motion_terms.bin embedded in libpbrt_host.so is corrupt\n"); abort(); }
+        // a corrupt table makes every rotating MotionBounds fail (MotionBoundsFailures: the frame is refused); it does not end the host process
+        if (!ok) { Error("motion_terms.bin (the motion derivative's polynomials) is missing or corrupt: rotating motions cannot be bounded"); p.valid = false; }
         return p;
     }();
     return P;
@@ -136,7 +143,8 @@ void FindZeros(Float c1, Float c2, Float c3, Float c4, Float c5, Float theta, In
         t = t - f / fPrime;
     }
     if (t >= tI.low - 1e-3f && t < tI.high + 1e-3f) {
-        if (*nZeros >= 8) { fprintf(stderr, "MotionBounds: more than 8 zeros of a motion derivative (the reference's CHECK_LE)\n"); abort(); }
+        // the reference's CHECK_LE(*nZeros, 8) ends its process here; this library reports it and refuses the frame (MotionBoundsFailures)
+        if (*nZeros >= 8) { g_motionBoundsFailures.fetch_add(1); return; }
         zeros[(*nZeros)++] = t;
     }
 }
@@ -224,6 +232,7 @@ Bounds3f MotionBounds(const Transform &start, Float startTime, const Transform &
         for (int e = 0; e < 2; ++e) for (int i = 0; i < 9; ++i) vars[n++] = M.S[e][i];
         vars[n++] = M.theta;
         const Programs &P = MotionPrograms();
+        if (!P.valid) { g_motionBoundsFailures.fetch_add(1); return Union(ofEnds(start), ofEnds(end)); }
         for (int c = 0; c < 3; ++c) for (int term = 0; term < 5; ++term) for (int j = 0; j < 4; ++j) M.k[c][term][j] = RunProgram(P, (c * 5 + term) * 4 + j, vars);
     }
     Bounds3f bounds;
@@ -242,4 +251,5 @@ Bounds3f MotionBounds(const Transform &start, Float startTime, const Transform &
     }
     return bounds;
 }
+int MotionBoundsFailures() { return g_motionBoundsFailures.load(); }
 }  // namespace pbrt

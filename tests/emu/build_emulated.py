@@ -44,6 +44,7 @@ def patched_sources(out):
     old = "__hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)"
     assert t.count(old) == 1
     t = t.replace(old, "emu_readfirstlane(" + old + ")")
+    t = "\n".join(l for l in t.split("\n") if "asm volatile(\"\" : \"+v\"" not in l)  # register-scheduling barriers (no effect on values)
     open(os.path.join(out, "pg_traverse.hip"), "w").write(t)
 
     k = open(os.path.join(CS, "pg_kernels.hip")).read()

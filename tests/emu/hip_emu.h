@@ -92,6 +92,11 @@ template <class T> __host__ inline T emu_readfirstlane_div(T val, int site = __b
 __host__ inline bool emu_inverse_ballot(unsigned long long m) { return (m >> emu::lane()) & 1; }
 #define __builtin_amdgcn_readfirstlane(v) emu_readfirstlane(v)
 #define __builtin_amdgcn_inverse_ballot_w64(m) emu_inverse_ballot(m)
+// v_mbcnt_lo / _hi: base + the number of set mask bits that belong to lanes below this one (low / high half of the wave)
+__host__ inline unsigned emu_mbcnt_lo(unsigned mask, unsigned base) { const int l = emu::lane(); return base + (unsigned)__builtin_popcount(l >= 32 ? mask : (mask & ((1u << l) - 1u))); }
+__host__ inline unsigned emu_mbcnt_hi(unsigned mask, unsigned base) { const int l = emu::lane(); return base + (unsigned)(l > 32 ? __builtin_popcount(mask & ((1u << (l - 32)) - 1u)) : 0); }
+#define __builtin_amdgcn_mbcnt_lo(m, b) emu_mbcnt_lo(m, b)
+#define __builtin_amdgcn_mbcnt_hi(m, b) emu_mbcnt_hi(m, b)
 // atomics: one OS thread, lanes switch only at rendezvous points
 template <class T> __host__ inline T emu_atomic_add(T *p, T v) { T o = *p; *p = o + v; return o; }
 __host__ inline int atomicAdd(int *p, int v) { return emu_atomic_add(p, v); }
