@@ -40,6 +40,7 @@ L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth, 8 XCDs x 4 MiB (MI355X_MICROAR
 INFINITY_CACHE_BYTES = 256 << 20
 FOG = ('MakeNamedMedium "fog" "string type" "homogeneous" "rgb sigma_a" [ 0.02 0.03 0.04 ] "rgb sigma_s" [ 0.15 0.12 0.1 ] "float g" [ 0.4 ]\n'
        'MediumInterface "" "fog"\n')
+OPTIONAL_PMC = ("TA_BUSY_avr", "TCP_PENDING_STALL_CYCLES_sum")
 EMULATED = os.environ.get("PBRT_EMULATED_DEVICE") == "1"  # tests/emu: the device library compiled for the host (a functional check, never a measurement)
 
 
@@ -231,6 +232,7 @@ def run_workload(ctx, args, steps, warmup, keep_image=False, serial_frame=False)
     scene = pkg.HostScene(scene_file)
     t_parse = time.time() - t0
     gs = pkg.GpuScene(scene.desc, device=ctx.device_index)
+    gs.set_option(pkg.abi.PG_OPT_OVERLAP_SHADOW, 1 if getattr(args, "overlap", False) else 0)
     rd = scene.render_desc(tile_first=ctx.rank, tile_step=ctx.world)
     max_tiles = gs.tile_count(scene.render_desc(0, ctx.world))  # rank 0 owns the most
     # two shard buffers alternate, so that frame i's gather overlaps frame i+1's render (N = 1: one buffer, no gather)
@@ -269,14 +271,14 @@ def run_workload(ctx, args, steps, warmup, keep_image=False, serial_frame=False)
     # profiles/r04b_bench_overlap*.json); the figures the rooflines are made of come from ONE more frame, serialised, after the timed region.
     serial = None
     if serial_frame and steps > 0:
-        os.environ["PG_OVERLAP_SHADOW"] = "0"
+        gs.set_option(pkg.abi.PG_OPT_OVERLAP_SHADOW, 0)
         gs.counters_reset()
         ctx.device_sync()
         ts = time.perf_counter()
         step()
         ctx.device_sync()
         serial = types.SimpleNamespace(ms=(time.perf_counter() - ts) * 1e3, cn=gs.counters())
-        os.environ["PG_OVERLAP_SHADOW"] = "1"
+        gs.set_option(pkg.abi.PG_OPT_OVERLAP_SHADOW, 1)
     stats = torch.tensor([elapsed, float(cn["closest_rays"] + cn["shadow_rays"]), float(cn["camera_rays"])], dtype=torch.float64, device=ctx.comm_dev)
     per_rank = [local]
     if ctx.multi:
@@ -306,6 +308,17 @@ def run_workload(ctx, args, steps, warmup, keep_image=False, serial_frame=False)
     return m
 
 
+def shading_mode(cn):
+    """PgCounters.shading_modes in words: which k_shade<MODE> the timed frames ran -- and whether a textured scene ran the slower k_shade<2> only
+    because k_material's lists found no room in device memory (the silent cliff of pg_abi.hip's ensureWorkBuffers)."""
+    bits = int(cn.get("shading_modes", 0))
+    names = {0: "k_shade<0> (baked-in BxDF shapes)", 1: "k_shade<1> (BxDF lists)", 3: "k_material lists + k_shade<3>", 2: "k_shade<2> (material evaluators inside the shading kernel)"}
+    ran = [names[m] for m in (0, 1, 3, 2) if bits >> m & 1]
+    out = " + ".join(ran) if ran else "none"
+    if bits & 0x200: out += " -- FALLBACK: k_material's lists did not fit in device memory"
+    return out
+
+
 def describe(args, scene):
     integ = "VolPathIntegrator + HomogeneousMedium" if args.workload.endswith("-vol") else "PathIntegrator"
     what = {"cornell": "Cornell box, 36 triangles",
@@ -315,7 +328,9 @@ def describe(args, scene):
         if args.workload.startswith("divergent"):
             unique = max(d.n_tris, d.n_prims_all)
             inst = sum(d.objects[d.instances[i].object].n_prims for i in range(d.n_instances))
-            what = (f"PLY meshes under {d.n_instances} object instances ({d.n_tris - d.n_instances + inst} triangles after instancing, {unique - d.n_instances} unique), "
+            what = (("stand-in for BASELINE config 5 (San Miguel + medium: not in the reference mount): " if args.workload.endswith("-vol") else
+                     "stand-in for BASELINE config 4 (crown: not in the reference mount): ") +
+                    f"PLY meshes under {d.n_instances} object instances ({d.n_tris - d.n_instances + inst} triangles after instancing, {unique - d.n_instances} unique), "
                     "image / bump / alpha-mask textures, 8-material palette, environment + area light")
         else:
             what = f"synthetic heightfield-in-a-box, {d.n_tris} triangles"
@@ -344,6 +359,10 @@ def live_pmc(bench_args, passes, timeout=300):
             return None, f"rocprofv3 --pmc {' '.join(counters)}: {e}"
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if p.returncode != 0 or not files:
+            if counters[0] in OPTIONAL_PMC:  # a diagnostic pass this rocprofv3 refuses does not cost the run its traffic counters
+                sys.stderr.write(f"bench: optional PMC pass {' '.join(counters)} failed (rc {p.returncode}); skipped\n")
+                shutil.rmtree(d, ignore_errors=True)
+                continue
             return None, f"rocprofv3 --pmc {' '.join(counters)}: rc {p.returncode}, {len(files)} counter files; {p.stderr[-300:]}"
         for f in files:
             for r in csv.DictReader(open(f)):
@@ -360,6 +379,12 @@ def live_pmc(bench_args, passes, timeout=300):
         if h + mi > 0: e["l2_hit_rate"] = h / (h + mi)
         dr = tot.get("TCC_EA0_RDREQ_DRAM_32B_sum", {}).get(k)
         if dr is not None: e["dram_rd_32B_per_launch"] = dr[0] / max(1, len(dr[1]))
+        # the texture-addresser / vector-L1 pipeline: busy cycles (averaged over the TAs) per cycle the GPU was active in this kernel's dispatches,
+        # and the share of its L1-active cycles the L1 stalled on outstanding misses
+        ta, ga = tot.get("TA_BUSY_avr", {}).get(k), tot.get("GRBM_GUI_ACTIVE", {}).get(k)
+        if ta is not None and ga is not None and ga[0] > 0: e["ta_busy_frac"] = ta[0] / ga[0]
+        ps, ge = tot.get("TCP_PENDING_STALL_CYCLES_sum", {}).get(k), tot.get("TCP_GATE_EN1_sum", {}).get(k)
+        if ps is not None and ge is not None and ge[0] > 0: e["tcp_pending_stall_frac"] = ps[0] / ge[0]
         vi, vt = tot.get("SQ_INSTS_VALU", {}).get(k, (0.0, {0})), tot.get("SQ_THREAD_CYCLES_VALU", {}).get(k, (0.0, 0))[0]
         if vi[0] > 0:
             e["valu_insts_per_launch"] = vi[0] / max(1, len(vi[1])); e["valu_lanes_active"] = vt / vi[0]
@@ -456,6 +481,10 @@ def kernel_rooflines(m, workload, live=None):
             r["vector_issue"] = {"insts_per_launch": pk["valu_insts_per_launch"], "achieved": rate, "peak": VALU_ISSUE_PEAK, "unit": "wave instructions/s",
                                  "frac": rate / VALU_ISSUE_PEAK, "lanes_active_of_64": pk.get("valu_lanes_active"), "source": pmc_src,
                                  "note": ("instruction count replayed from a committed PMC pass of this workload" if replayed else "instruction count of this run's own PMC pass") + " (SQ_INSTS_VALU), divided by this run's kernel time"}
+        if pk is not None and pk.get("ta_busy_frac") is not None:
+            r["load_path"] = {"ta_busy_frac": pk["ta_busy_frac"], "tcp_pending_stall_frac": pk.get("tcp_pending_stall_frac"), "source": pmc_src,
+                              "note": "TA_BUSY_avr / GRBM_GUI_ACTIVE: the share of the kernel's time its texture-addresser (vector-memory address) units were busy; "
+                                      "TCP_PENDING_STALL_CYCLES / TCP_GATE_EN1: the share of the vector L1s' active cycles stalled on outstanding misses"}
         if served_on_die:
             r["note"] = (f"algorithmic rate above the HBM peak ({HBM_PEAK_GBS:.0f} GB/s) although the scene exceeds the Infinity Cache: the top of the tree is "
                          "served on-die (short traversals), so this kernel is priced against the L2")
@@ -562,7 +591,7 @@ def main():
     # GPU gains 1.2 % (profiles/r04b_bench_overlap*.json).  Per-kernel times then overlap, so a one-GPU run takes them -- and its
     # rooflines -- from one more frame, serialised, after the timed region (run_workload, serial_frame).
     overlap = not args.no_overlap and os.environ.get("PG_OVERLAP_SHADOW", "1") != "0"
-    os.environ["PG_OVERLAP_SHADOW"] = "1" if overlap else "0"
+    args.overlap = overlap  # (handed to every scene through pg_scene_set_option: the library reads the environment only at scene creation)
     pkg = load_package()
     one_gpu = ctx.world == 1 and not ctx.multi
     m = run_workload(ctx, args, args.steps, args.warmup, keep_image=bool(args.out), serial_frame=overlap and one_gpu)
@@ -595,7 +624,8 @@ def main():
         wl_args = ["--workload", args.workload, "--grid", str(args.grid), "--tris", str(args.tris), "--xres", str(args.xres), "--yres", str(args.yres),
                    "--spp", str(args.spp), "--filter", args.filter]
         if ctx.world == 1 and not ctx.multi and not EMULATED and not args.no_live_pmc:
-            live, live_why = live_pmc(wl_args, (["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"], ["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU"]))
+            live, live_why = live_pmc(wl_args, (["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"], ["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU"],
+                                                ["TA_BUSY_avr", "GRBM_GUI_ACTIVE"], ["TCP_PENDING_STALL_CYCLES_sum", "TCP_GATE_EN1_sum"]))
             if live is None: sys.stderr.write(f"bench: live PMC passes failed ({live_why}); replaying profiles/pmc_traffic.json\n")
             if hbm is not None and live is not None:
                 a5l = ["--workload", "synthetic", "--grid", str(hbm.args.grid), "--xres", str(args.xres), "--yres", str(args.yres), "--spp", str(args.spp), "--filter", args.filter]
@@ -608,6 +638,13 @@ def main():
         gather = gather_ceiling(km, working_set, pmc_kernels, pmc_src)
         roofline = dict(kernels[0]) if kernels else {"kernel": None, "bound": bound, "achieved": 0.0, "peak": peak, "unit": "GB/s", "frac": 0.0, "traffic": None}
         roofline["working_set_bytes"] = working_set
+        # every reading of the dominant kernel's rate at the top level: against the L2s' aggregate bandwidth, against the HBM peak (north star's
+        # yardstick; above 1 = the caches serve the gathers), and what the L2s' memory side moved against the HBM peak
+        if kernels:
+            roofline["frac_of_l2"] = roofline["achieved"] / L2_PEAK_GBS
+            roofline["frac_of_hbm_algorithmic"] = roofline["achieved"] / HBM_PEAK_GBS
+            roofline["cache_served"] = bool(roofline["bound"] == "l2")
+            if roofline.get("l2_memory_side"): roofline["l2_memory_side_frac_of_hbm"] = roofline["l2_memory_side"]["frac_of_hbm_peak"]
         if gather is not None:
             roofline["gather"] = gather
         roofline["bound_reason"] = (f"BVH + triangle records {working_set / 2**20:.0f} MiB " +
@@ -629,11 +666,13 @@ def main():
                     if t.get(f) is not None: roofline["hbm_regime"][f] = t[f]
         other_ms = {k: km.cn[k] for k in ("resolve_ms", "generate_ms", "film_ms")}
         if ctx.world == 1:
-            sharding = "one GPU renders every 16x16 film tile; no gather" + ("; any-hit launches beside the next closest-hit launches" if overlap else "")
+            sharding = ("one GPU renders every 16x16 film tile; " +
+                        ("ONE-RANK RCCL run (PBRT_BENCH_FORCE_DIST=1): the packed gather of the frame runs over RCCL with one rank" if ctx.multi else "no gather") +
+                        ("; any-hit launches beside the next closest-hit launches" if overlap else ""))
         else:
             sharding = (f"16x16 film tiles round-robin over {ctx.world} GPUs, one process per GPU; one packed gather per frame to rank 0 (" +
                         ("RCCL over xGMI" if ctx.backend == "nccl" else "PRE-FLIGHT: gloo on host copies") + "), overlapped with the next frame" +
-                        ("; any-hit launches beside the closest-hit launches (per-kernel times overlap)" if os.environ.get("PG_OVERLAP_SHADOW") == "1" else ""))
+                        ("; any-hit launches beside the closest-hit launches (per-kernel times overlap)" if overlap else ""))
         result = {
             "metric": "Mrays/s", "value": m.rays / m.elapsed / 1e6, "unit": "Mrays/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": m.elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -641,20 +680,22 @@ def main():
             "samples_per_s": m.samples / m.elapsed,
             "ranks_seen": dist.get_world_size() if ctx.multi else 1, "per_rank_ms": m.per_rank_ms,
             **({"per_rank_kernel_ms_per_step": m.per_rank_kernel_ms} if ctx.multi else {}),
-            "config": {"workload": workload, "sharding": sharding,
+            "config": {"workload": workload, "sharding": sharding, "shading_mode": shading_mode(m.cn),
                        "rays_per_sample": m.rays / max(1.0, m.samples), "host_parse_and_bvh_s": m.t_parse},
             "roofline": roofline,
             "roofline_kernels": kernels,
             "kernel_ms_per_step": {**{k["kernel"].split(" ")[0]: k["total_ms"] / ksteps for k in kernels},
                                    **{k[:-3]: v / ksteps for k, v in other_ms.items()}},
         }
+        if roofline.get("hbm_regime"):  # also at the top level of the line (a parser that keeps only known keys of `roofline` still sees it)
+            result["hbm_regime"] = roofline["hbm_regime"]
         if live:
             # the counters of this run's own PMC passes, kernel by kernel (the shading slot's roofline merges k_shade_order + k_material + k_shade<.>)
             result["pmc_by_kernel"] = {k.replace("void ", "")[:48]: {f: (round(v, 4) if isinstance(v, float) else v) for f, v in e.items()} for k, e in sorted(live.items())
                                        if e.get("fetch_KiB_per_launch", 0) * e.get("launches", 1) > 1e5}
         if m.serial is not None:
             result["kernel_times"] = {
-                "from": "ONE extra frame after the timed region with every kernel alone on the chip (PG_OVERLAP_SHADOW=0): kernel_ms_per_step, roofline and "
+                "from": "ONE extra frame after the timed region with every kernel alone on the chip (pg_scene_set_option PG_OPT_OVERLAP_SHADOW 0): kernel_ms_per_step, roofline and "
                         "roofline_kernels are that frame's HIP-event times; the timed frames (ms_per_step, value) run each any-hit launch beside the next "
                         "closest-hit launch, so they are shorter than the sum of the kernels",
                 "serialized_frame_ms": m.serial.ms, "sum_of_kernels_ms": sum(result["kernel_ms_per_step"].values()), "overlapped_frame_ms": result["ms_per_step"]}

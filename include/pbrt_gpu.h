@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 26
+#define PG_ABI_VERSION 27
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -592,7 +592,20 @@ typedef struct PgCounters {
     uint64_t shade_items; /* path vertices handed to the shading kernel (= main-queue rays traced) */
     uint64_t mis_rays;    /* of closest_rays: the BSDF-sampled rays of EstimateDirect (integrator.cpp:164-212) */
     double shade_ms, resolve_ms, generate_ms, film_ms;
+    /* ABI 27 -- which shading kernels the counted frames ran (a bit mask): bit m = k_shade<m, ...> (0 the baked-in BxDF shapes of matte /
+     * plastic / mirror / glass; 1 a material's BxDF list; 3 the packed lists k_material evaluated ahead of the launch; 2 the material
+     * evaluators inside the shading kernel: scenes with BSSRDF materials or grid media); PG_SHADING_MATERIAL_PREPASS = k_material ran;
+     * PG_SHADING_LISTS_DID_NOT_FIT = a textured scene ran k_shade<2> only because k_material's lists found no room in device memory --
+     * same image, about 1.5 x the shading time: a caller that measures should know (bench.py: config.shading_mode). */
+    uint64_t shading_modes;
 } PgCounters;
+#define PG_SHADING_MATERIAL_PREPASS 0x100u
+#define PG_SHADING_LISTS_DID_NOT_FIT 0x200u
+
+/* pg_scene_set_option: per-scene switches a host may change between frames (none changes an image).
+ * PG_OPT_OVERLAP_SHADOW (0 / 1): each bounce's any-hit launch on a second stream beside the next closest-hit launch (+1 % of a frame; the
+ * kernels' HIP-event times in PgCounters then overlap).  Default: the environment's PG_OVERLAP_SHADOW when the scene is created, else 0. */
+#define PG_OPT_OVERLAP_SHADOW 1
 
 typedef struct PgScene PgScene;
 
@@ -655,6 +668,7 @@ int pg_intersect_p(PgScene *scene, int32_t n, const float *o, const float *d,
 
 int pg_counters(PgScene *scene, PgCounters *out);
 int pg_counters_reset(PgScene *scene);
+int pg_scene_set_option(PgScene *scene, int32_t option, int32_t value);
 
 #ifdef __cplusplus
 }

@@ -37,3 +37,4 @@ int pg_render(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, PgStraySamp
 }
 int pg_counters(PgScene *s, PgCounters *out) { *out = s->counters; return PG_OK; }
 int pg_counters_reset(PgScene *s) { memset(&s->counters, 0, sizeof(s->counters)); return PG_OK; }
+int pg_scene_set_option(PgScene *s, int32_t option, int32_t value) { (void)s; (void)value; if (option != PG_OPT_OVERLAP_SHADOW) { g_err = "unknown option"; return PG_ERR_INVALID; } return PG_OK; }  /* nothing to overlap on the CPU */

@@ -257,6 +257,10 @@ class GpuScene:
     def counters_reset(self):
         _check(gpu_lib().pg_counters_reset(self._h), "pg_counters_reset")
 
+    def set_option(self, option, value):
+        """pg_scene_set_option (abi.PG_OPT_*): per-scene switches that never change an image."""
+        _check(gpu_lib().pg_scene_set_option(self._h, int(option), int(value)), "pg_scene_set_option")
+
 
 def render_sharded(gpu_scenes, rd, max_strays=None):
     """pg_render_sharded: the frame of rd (tile_first 0, tile_step 1) over the devices of gpu_scenes -- one host thread per

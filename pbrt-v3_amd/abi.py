@@ -5,10 +5,12 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 26
+PG_ABI_VERSION = 27
 PG_SAMPLER_HALTON, PG_SAMPLER_SOBOL, PG_SAMPLER_RANDOM, PG_SAMPLER_STRATIFIED, PG_SAMPLER_ZEROTWO, PG_SAMPLER_MAXMINDIST = range(6)
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
+PG_OPT_OVERLAP_SHADOW = 1
+PG_SHADING_MATERIAL_PREPASS, PG_SHADING_LISTS_DID_NOT_FIT = 0x100, 0x200
 PG_LIGHTS_UNIFORM, PG_LIGHTS_POWER, PG_LIGHTS_SPATIAL = 0, 1, 2
 PG_MAT_NONE, PG_MAT_MATTE, PG_MAT_PLASTIC, PG_MAT_MIRROR, PG_MAT_GLASS = 0, 1, 2, 3, 4
 PG_LIGHT_AREA, PG_LIGHT_POINT, PG_LIGHT_SPOT, PG_LIGHT_DISTANT, PG_LIGHT_INFINITE = 0, 1, 2, 3, 4
@@ -162,7 +164,7 @@ class PgCounters(C.Structure):
                 ("closest_ms", C.c_double), ("shadow_ms", C.c_double), ("render_ms", C.c_double),
                 ("shade_launches", C.c_uint64), ("resolve_launches", C.c_uint64), ("shade_items", C.c_uint64),
                 ("mis_rays", C.c_uint64), ("shade_ms", C.c_double), ("resolve_ms", C.c_double),
-                ("generate_ms", C.c_double), ("film_ms", C.c_double)]
+                ("generate_ms", C.c_double), ("film_ms", C.c_double), ("shading_modes", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -188,6 +190,7 @@ GPU_SYMBOLS = {
                                  C.c_void_p]),
     "pg_counters": (C.c_int, [C.c_void_p, C.POINTER(PgCounters)]),
     "pg_counters_reset": (C.c_int, [C.c_void_p]),
+    "pg_scene_set_option": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "pg_hlbvh_build": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
 }
 

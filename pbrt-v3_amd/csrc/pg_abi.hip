@@ -1052,8 +1052,8 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
     if (rd->spp <= 0 || rd->max_depth < 0 || rd->tile_step <= 0) return setError(PG_ERR_INVALID, "pg_render: bad spp/maxdepth/tile_step");
     if (rd->integrator != 0 && rd->integrator != 1) return setError(PG_ERR_INVALID, "pg_render: integrator %d (0 = path, 1 = volpath)", rd->integrator);
     const bool vol = rd->integrator == 1;
-    // read per frame: a caller (bench.py) times frames with the overlap and takes per-kernel times from a serialised frame of the same scene
-    if (const char *e = getenv("PG_OVERLAP_SHADOW")) s->overlapShadow = atoi(e) != 0;
+    // (overlapShadow: the environment's PG_OVERLAP_SHADOW at pg_scene_create, then pg_scene_set_option -- a caller such as bench.py times
+    // frames with the overlap and takes per-kernel times from a serialised frame of the same scene)
     if (rd->camera_medium < -1 || rd->camera_medium >= s->nMedia) return setError(PG_ERR_INVALID, "pg_render: camera_medium %d out of range", rd->camera_medium);
     if (rd->sampler < PG_SAMPLER_HALTON || rd->sampler > PG_SAMPLER_MAXMINDIST) return setError(PG_ERR_INVALID, "pg_render: sampler %d (PgSamplerKind 0 .. 5)", rd->sampler);
     // The PixelSamplers (stratified, 02sequence, maxmindist) fall back to their tile's RNG stream only for draws beyond their
@@ -1254,7 +1254,14 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
         return PG_OK;
     };
     uint64_t closestRays = 0, shadowRays = 0, cameraRays = 0, closestLaunches = 0, shadowLaunches = 0;
-    uint64_t shadeLaunches = 0, resolveLaunches = 0, shadeItems = 0, misRays = 0;
+    uint64_t shadeLaunches = 0, resolveLaunches = 0, shadeItems = 0, misRays = 0, shadingModes = 0;
+    // PgCounters::shading_modes: which k_shade<MODE> this frame's shading launches are (pg_shade_mode, the launch functions' own choice)
+    auto noteShading = [&](const DScene &dsc, bool vol, bool sss, bool gridPhase) {
+        const int mode = pg_shade_mode(dsc, rp, vol, sss, gridPhase);
+        shadingModes |= 1ull << mode;
+        if (mode == 3) shadingModes |= PG_SHADING_MATERIAL_PREPASS;
+        if (mode == 2 && !gridPhase && !(sss && dsc.nBssrdfs > 0) && s->matStride > 0) shadingModes |= PG_SHADING_LISTS_DID_NOT_FIT;
+    };
     std::vector<int> hostCounts;  // read back once per batch at the end (pinned copy not needed: tiny)
     DeviceBuffer countLog;        // per-bounce queue sizes, copied back after the batch for the ray statistics
     // (64-bit: maxdepth comes from the caller / the scene file.)  Bounce launches are enqueued without looking at the queues, so
@@ -1314,7 +1321,7 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                     rp.volPre = volPre;
                     rp.order = (s->d.primClass || volPre) ? (const int *)s->shadeOrder.p : nullptr;  // (the second phase of a grid scene takes the same order)
                     PG_TIMED(2, stream, (launch_shade_order_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, (int *)s->shadeOrder.p, volPre, stream, cur), launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream, sssArg, gridVertex, gridOn ? 1 : 0, cur)));
-                    ++shadeLaunches;
+                    ++shadeLaunches; noteShading(dv, true, sssArg != nullptr, gridOn);
                     if (int e = settleLightTables([&]() { launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream, sssArg, gridVertex, gridOn ? 1 : 0, cur); })) return e;
                     // through rays: kind 0 = light samples (q[2] <-> vq[0]), kind 1 = BSDF / phase samples (q[3] <-> vq[1]), re-traced
                     // until none is left under way
@@ -1438,7 +1445,7 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                 const SssState *sssArg = sssOn ? &sq : nullptr;
                 rp.order = s->d.primClass ? (const int *)s->shadeOrder.p : nullptr;
                 PG_TIMED(2, stream, (launch_shade_order(s->d, q[cur], (const float4 *)s->hitsMain.p, (int *)s->shadeOrder.p, stream), launch_shade(s->d, rp, ps, q[cur], (const float4 *)s->hitsMain.p, q[nxt], q[2], q[3], lightTests, stream, cur, sssArg)));
-                ++shadeLaunches;
+                ++shadeLaunches; noteShading(s->d, false, sssArg != nullptr, false);
                 if (int e = settleLightTables([&]() { launch_shade(s->d, rp, ps, q[cur], (const float4 *)s->hitsMain.p, q[nxt], q[2], q[3], lightTests, stream, cur, sssArg); })) return e;
                 // paths that reach maxdepth neither continue nor sample lights (path.cpp:104): nothing left to trace
                 const bool lastDepth = !s->hasNullMaterial && bounce >= rd->max_depth;
@@ -1645,6 +1652,7 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
     c.shadow_node_visits = tc[1].node_visits; c.shadow_tri_tests = tc[1].tri_tests;
     c.closest_launches += closestLaunches; c.shadow_launches += shadowLaunches;
     c.shade_launches += shadeLaunches; c.resolve_launches += resolveLaunches; c.shade_items += shadeItems; c.mis_rays += misRays;
+    c.shading_modes |= shadingModes;
     for (auto &te : timed) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, s->events[te.first], s->events[te.first + 1]) != hipSuccess) continue;
@@ -1746,10 +1754,16 @@ int pg_render_sharded(PgScene *const *scenes, int32_t n, const PgRenderDesc *des
     // one packed shard per rank, the same size for all: [film (filmMax) | strays | count]; the gathered frame is n of them in rank order
     const size_t strayOff = filmMax, countOff = strayOff + strayBytes, per = (countOff + sizeof(int) + 255) / 256 * 256;
     const size_t total = per * (size_t)n;
-    // one sharded render at a time per process: the communicators of a device list carry one collective at a time, and the scenes'
-    // shard / gather buffers are per scene
-    static std::mutex shardedMutex;
-    std::lock_guard<std::mutex> shardedLock(shardedMutex);
+    // one sharded render at a time per DEVICE: the communicators of a device list carry one collective at a time and the scenes' shard / gather
+    // buffers are per scene, so two calls that share a device wait for each other; calls over disjoint device sets run side by side.  The
+    // devices' locks are taken in ascending order of the device number (no two calls can hold them crosswise).
+    static std::mutex deviceMutex[64];
+    std::vector<int> lockOrder;
+    for (int r = 0; r < n; ++r) lockOrder.push_back(scenes[r]->device & 63);
+    std::sort(lockOrder.begin(), lockOrder.end());
+    lockOrder.erase(std::unique(lockOrder.begin(), lockOrder.end()), lockOrder.end());
+    std::vector<std::unique_lock<std::mutex>> deviceLocks;
+    for (int dev : lockOrder) deviceLocks.emplace_back(deviceMutex[dev]);
     HIP_TRY(hipSetDevice(root->device));
     if (root->gatherDev.bytes < total) HIP_TRY(root->gatherDev.alloc(total));  // kept between frames (hipFree + hipMalloc synchronise the device)
     char *gather = (char *)root->gatherDev.p;
@@ -1796,7 +1810,9 @@ int pg_render_sharded(PgScene *const *scenes, int32_t n, const PgRenderDesc *des
                 (void)hipGetLastError();
             }
         }
+#ifdef PG_TEST_HOOKS  // fault injection for tests/test_emulated_device.py: compiled into the emulated test build only, never into libpbrt_gpu.so
         if (const char *e = getenv("PG_TEST_FAIL_RANK")) if (atoi(e) == r) { status[r] = PG_ERR_DEVICE; message[r] = "PG_TEST_FAIL_RANK (a test's injected failure)"; return false; }
+#endif
         if (s->shardFilm.bytes < per && s->shardFilm.alloc(per) != hipSuccess) { status[r] = PG_ERR_DEVICE; message[r] = "out of device memory (packed shard)"; return false; }
         char *packed = (char *)s->shardFilm.p;
         int st = pg_render(s, &rd[r], (PgFilmPixel *)packed, (PgStraySample *)(packed + strayOff), maxStrays, (int32_t *)(packed + countOff), PG_MEM_DEVICE, nullptr);
@@ -1972,6 +1988,13 @@ int pg_counters(PgScene *s, PgCounters *out) {
     if (!s || !out) return setError(PG_ERR_INVALID, "pg_counters: null argument");
     *out = s->counters;
     return PG_OK;
+}
+int pg_scene_set_option(PgScene *s, int32_t option, int32_t value) {
+    if (!s) return setError(PG_ERR_INVALID, "pg_scene_set_option: null scene");
+    switch (option) {
+    case PG_OPT_OVERLAP_SHADOW: s->overlapShadow = value != 0; return PG_OK;
+    default: return setError(PG_ERR_INVALID, "pg_scene_set_option: unknown option %d", option);
+    }
 }
 int pg_counters_reset(PgScene *s) {
     if (!s) return setError(PG_ERR_INVALID, "pg_counters_reset: null argument");

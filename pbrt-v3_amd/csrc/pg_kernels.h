@@ -351,6 +351,14 @@ void launch_shade_order(const DScene &sc, RayQueue qin, const float4 *hits, int 
 // into a class of their own (class 13), so that a wave shades medium vertices or surface vertices, not both one after the other
 void launch_shade_order_vol(const DScene &sc, const RenderParams &rp, PathState st, VolState vs, RayQueue qin, const float4 *hits, const float *hitT,
                             int *order, float2 *volPre, hipStream_t s, int cur = 0);
+// Which k_shade<MODE, ...> launch_shade / launch_shade_vol run for a frame (PgCounters::shading_modes records it): 0 the baked-in BxDF shapes,
+// 1 a material's BxDF list, 3 the packed lists k_material wrote ahead of the launch, 2 the evaluators inside the shading kernel -- what scenes
+// with BSSRDF materials or grid media run, and what a textured scene FALLS BACK to when k_material's lists do not fit in memory.
+inline int pg_shade_mode(const DScene &sc, const RenderParams &rp, bool vol, bool sss, bool gridPhase) {
+    if (gridPhase || (sss && sc.nBssrdfs > 0)) return sc.hasTextured ? 2 : 1;
+    if (sc.hasTextured) return rp.matPre.lobes ? 3 : 2;
+    return (vol || sc.ext) ? 1 : 0;
+}
 void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQueue qin, const float4 *hits, RayQueue qnext,
                   RayQueue qshadow, RayQueue qmis, unsigned long long *lightTriTests, hipStream_t s, int cur = 0, const SssState *sss = nullptr);
 // Subsurface scattering: one step of the probe chains (pass 1: count the hits on the material; pass 2: stop at the chosen one) over

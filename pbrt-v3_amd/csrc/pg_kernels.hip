@@ -3011,14 +3011,15 @@ void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQue
     const QueueState qi = st.qs[cur], qo = st.qs[cur ^ 1];
     const SssState none = {};
     const GridShade gsh = {nullptr, 0};
+    const int mode = pg_shade_mode(sc, rp, false, sss != nullptr, false);  // (the branches below are that function's cases)
     if (sss && sc.nBssrdfs > 0) {  // materials with a BSSRDF are BxDF-list materials: the general kernels
-        if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, false, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, *sss, gsh);
+        if (mode == 2) hipLaunchKernelGGL((k_shade<2, false, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, *sss, gsh);
         else hipLaunchKernelGGL((k_shade<1, false, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, *sss, gsh);
-    } else if (sc.hasTextured && rp.matPre.lobes) {  // materials first (not again for the entries a sparse light table sent back: theirs are there)
+    } else if (mode == 3) {  // materials first (not again for the entries a sparse light table sent back: theirs are there)
         if (rp.retryCount == 0) launch_material(sc, rp, st, vs, qin, hits, noT, qi, false, s);
         hipLaunchKernelGGL((k_shade<3, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, none, gsh);
-    } else if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, none, gsh);
-    else if (sc.ext) hipLaunchKernelGGL((k_shade<1, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, none, gsh);
+    } else if (mode == 2) hipLaunchKernelGGL((k_shade<2, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, none, gsh);
+    else if (mode == 1) hipLaunchKernelGGL((k_shade<1, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, none, gsh);
     else hipLaunchKernelGGL((k_shade<0, false>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, noT, qi, qo, none, gsh);
 }
 void launch_shade_vol(const DScene &sc, const RenderParams &rp, PathState st, VolState vs, RayQueue qin, const float4 *hits, const float *hitT,
@@ -3030,18 +3031,19 @@ void launch_shade_vol(const DScene &sc, const RenderParams &rp, PathState st, Vo
     const QueueState qi = st.qs[cur], qo = st.qs[cur ^ 1];  // the plain kernels: path state in queue order
     const SssState nosss = {};
     const GridShade gsh = {gridVertex, phase};
+    const int mode = pg_shade_mode(sc, rp, true, sss != nullptr, phase != 0);
     if (phase != 0) {  // a scene with a grid medium: the two-phase kernels
-        if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, true, false, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss, gsh);
+        if (mode == 2) hipLaunchKernelGGL((k_shade<2, true, false, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss, gsh);
         else hipLaunchKernelGGL((k_shade<1, true, false, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss, gsh);
     } else if (sss && sc.nBssrdfs > 0) {
-        if (sc.hasTextured) hipLaunchKernelGGL((k_shade<2, true, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, *sss, gsh);
+        if (mode == 2) hipLaunchKernelGGL((k_shade<2, true, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, *sss, gsh);
         else hipLaunchKernelGGL((k_shade<1, true, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, *sss, gsh);
     } else {
 #define PG_LAUNCH_VOL(MODE_) hipLaunchKernelGGL((k_shade<MODE_, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, qi, qo, nosss, gsh)
-        if (sc.hasTextured && rp.matPre.lobes) {
+        if (mode == 3) {
             if (rp.retryCount == 0) launch_material(sc, rp, st, vs, qin, hits, hitT, qi, true, s);
             PG_LAUNCH_VOL(3);
-        } else if (sc.hasTextured) PG_LAUNCH_VOL(2);
+        } else if (mode == 2) PG_LAUNCH_VOL(2);
         else PG_LAUNCH_VOL(1);
 #undef PG_LAUNCH_VOL
     }

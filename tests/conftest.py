@@ -21,15 +21,6 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: minutes of host CPU time (the reference binary at full size); PBRT_SKIP_SLOW=1 skips")
 
 
-def pytest_collection_modifyitems(config, items):
-    """The rotating-motion goldens and random scenes were written after the round's GPU lease was spent: they have run on the emulated device and
-    against the reference binary, never on an MI355X.  They go to the END of a run, so that under `-x` an unforeseen failure of theirs on their first
-    hardware run does not keep the rest of the suite from being recorded."""
-    late = [it for it in items if "motion_rotate" in it.nodeid or "rotating" in it.nodeid]
-    if late:
-        items[:] = [it for it in items if it not in late] + late
-
-
 @pytest.fixture(scope="session")
 def pkg():
     """The product package; host library built on demand (g++, seconds)."""

@@ -64,7 +64,7 @@ def main():
     out = os.path.abspath(sys.argv[1])
     os.makedirs(out, exist_ok=True)
     patched_sources(out)
-    flags = ["--cuda-host-only", "-O1", "-ffp-contract=off", "-fPIC", "-w"] + os.environ.get("PBRT_EMU_DEFINES", "").split()  # e.g. -DPG_ORDER_WINDOW=1024: several windows on small scenes
+    flags = ["--cuda-host-only", "-O1", "-ffp-contract=off", "-fPIC", "-w", "-DPG_TEST_HOOKS"] + os.environ.get("PBRT_EMU_DEFINES", "").split()  # e.g. -DPG_ORDER_WINDOW=1024: several windows on small scenes
     procs = [subprocess.Popen([HIPCC, *flags, "-I" + CS, "-I" + EM, "-include", os.path.join(EM, "hip_emu.h"), "-c", os.path.join(out, f + ".hip"), "-o", os.path.join(out, f + ".o")])
              for f in ("pg_traverse", "pg_kernels", "pg_abi", "pg_hlbvh")]
     procs.append(subprocess.Popen([HIPCC, *flags, "-U_FORTIFY_SOURCE", "-D_FORTIFY_SOURCE=0", "-I" + EM, "-c", os.path.join(EM, "hip_emu.cpp"), "-o", os.path.join(out, "hip_emu.o")]))
