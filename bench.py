@@ -40,7 +40,7 @@ L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth, 8 XCDs x 4 MiB (MI355X_MICROAR
 INFINITY_CACHE_BYTES = 256 << 20
 FOG = ('MakeNamedMedium "fog" "string type" "homogeneous" "rgb sigma_a" [ 0.02 0.03 0.04 ] "rgb sigma_s" [ 0.15 0.12 0.1 ] "float g" [ 0.4 ]\n'
        'MediumInterface "" "fog"\n')
-OPTIONAL_PMC = ("TA_BUSY_avr", "TCP_PENDING_STALL_CYCLES_sum")
+OPTIONAL_PMC = ("GRBM_TA_BUSY", "TCP_PENDING_STALL_CYCLES_sum")
 EMULATED = os.environ.get("PBRT_EMULATED_DEVICE") == "1"  # tests/emu: the device library compiled for the host (a functional check, never a measurement)
 
 
@@ -381,7 +381,7 @@ def live_pmc(bench_args, passes, timeout=300):
         if dr is not None: e["dram_rd_32B_per_launch"] = dr[0] / max(1, len(dr[1]))
         # the texture-addresser / vector-L1 pipeline: busy cycles (averaged over the TAs) per cycle the GPU was active in this kernel's dispatches,
         # and the share of its L1-active cycles the L1 stalled on outstanding misses
-        ta, ga = tot.get("TA_BUSY_avr", {}).get(k), tot.get("GRBM_GUI_ACTIVE", {}).get(k)
+        ta, ga = tot.get("GRBM_TA_BUSY", {}).get(k), tot.get("GRBM_GUI_ACTIVE", {}).get(k)
         if ta is not None and ga is not None and ga[0] > 0: e["ta_busy_frac"] = ta[0] / ga[0]
         ps, ge = tot.get("TCP_PENDING_STALL_CYCLES_sum", {}).get(k), tot.get("TCP_GATE_EN1_sum", {}).get(k)
         if ps is not None and ge is not None and ge[0] > 0: e["tcp_pending_stall_frac"] = ps[0] / ge[0]
@@ -483,7 +483,7 @@ def kernel_rooflines(m, workload, live=None):
                                  "note": ("instruction count replayed from a committed PMC pass of this workload" if replayed else "instruction count of this run's own PMC pass") + " (SQ_INSTS_VALU), divided by this run's kernel time"}
         if pk is not None and pk.get("ta_busy_frac") is not None:
             r["load_path"] = {"ta_busy_frac": pk["ta_busy_frac"], "tcp_pending_stall_frac": pk.get("tcp_pending_stall_frac"), "source": pmc_src,
-                              "note": "TA_BUSY_avr / GRBM_GUI_ACTIVE: the share of the kernel's time its texture-addresser (vector-memory address) units were busy; "
+                              "note": "GRBM_TA_BUSY / GRBM_GUI_ACTIVE: the share of the kernel's time in which a texture-addresser (vector-memory address) unit was busy; "
                                       "TCP_PENDING_STALL_CYCLES / TCP_GATE_EN1: the share of the vector L1s' active cycles stalled on outstanding misses"}
         if served_on_die:
             r["note"] = (f"algorithmic rate above the HBM peak ({HBM_PEAK_GBS:.0f} GB/s) although the scene exceeds the Infinity Cache: the top of the tree is "
@@ -625,7 +625,7 @@ def main():
                    "--spp", str(args.spp), "--filter", args.filter]
         if ctx.world == 1 and not ctx.multi and not EMULATED and not args.no_live_pmc:
             live, live_why = live_pmc(wl_args, (["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"], ["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU"],
-                                                ["TA_BUSY_avr", "GRBM_GUI_ACTIVE"], ["TCP_PENDING_STALL_CYCLES_sum", "TCP_GATE_EN1_sum"]))
+                                                ["GRBM_TA_BUSY", "GRBM_GUI_ACTIVE"], ["TCP_PENDING_STALL_CYCLES_sum", "TCP_GATE_EN1_sum"]))
             if live is None: sys.stderr.write(f"bench: live PMC passes failed ({live_why}); replaying profiles/pmc_traffic.json\n")
             if hbm is not None and live is not None:
                 a5l = ["--workload", "synthetic", "--grid", str(hbm.args.grid), "--xres", str(args.xres), "--yres", str(args.yres), "--spp", str(args.spp), "--filter", args.filter]

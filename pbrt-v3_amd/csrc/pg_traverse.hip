@@ -341,6 +341,9 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                     const int count = cq.counts[rr * PG_COUNT_STRIDE];
                     int *cursor = &cursors[region * PG_COUNT_STRIDE];
                     // a drained region costs a load, not an atomic: cursors only grow, so a stale value can only under-report
+                    // (measured and removed, round 6: guided self-scheduling -- a region's last round handed out in shares of what is left, 16 / 32 /
+                    // 64 rays at least, instead of full chunks -- makes a 1 / 8 film shard SLOWER, 55.8 / 54.6 / 52.9 against 52.2 ms: a launch's
+                    // tail is its longest ray, not its last chunk; profiles/r06f_guided_chunks.txt)
                     bool drained = fresh && __hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= count;
                     if (!drained) {
                         int base = 0;

@@ -23,6 +23,9 @@ def main():
         gen_synthetic.write_scene(path, n=708, xres=1920, yres=1080, spp=spp)
         scene = pkg.HostScene(path)
         gs = pkg.GpuScene(scene.desc)
+        if os.environ.get("SHARD_OVERLAP") == "1":  # each any-hit launch beside the next closest-hit launch, as every bench.py run does
+            gs.set_option(pkg.abi.PG_OPT_OVERLAP_SHADOW, 1)
+            out["overlap"] = True
         t1 = None
         for n in (1, 2, 4, 8):
             rd = scene.render_desc(tile_first=0, tile_step=n)
