@@ -54,7 +54,9 @@ PG_DEV void tex_map2d(const PgTexture &t, const TexHit &h, float st[2], float ds
     }
 }
 // ---- MIPMap<T>::Lookup (core/mipmap.h:189-331) over the pyramid the host built; Spec carries 1 (r only) or 3 channels
-PG_DEV int mod_i(int a, int b) { int r = a - (a / b) * b; return (r < 0) ? r + b : r; }  // pbrt.h:314-317
+// Mod(a, b), pbrt.h:314-317.  A texel coordinate is inside [0, b) except at the map's border: there the result is a itself and the integer
+// division (about forty vector instructions, twice per texel) is skipped -- the same value either way.
+PG_DEV int mod_i(int a, int b) { if ((unsigned)a < (unsigned)b) return a; int r = a - (a / b) * b; return (r < 0) ? r + b : r; }
 PG_DEV Spec mip_texel(const DScene &sc, const PgImage &im, int level, int s, int t) {  // mipmap.h:189-212
     const int sRes = max(1, im.width >> level), tRes = max(1, im.height >> level);
     if (im.wrap == 0) { s = mod_i(s, sRes); t = mod_i(t, tRes); }

@@ -155,11 +155,8 @@ PG_DEV unsigned long long tr_wave_sum(unsigned long long v) {
 
 // MIPMap<Float>::Lookup(st, 0 width) of a DAlphaTex = `triangle(0, st)` (mipmap.h:231-243) with Texel's wrap modes (:189-212): the
 // operations of mip_triangle / mip_texel (pg_texture.h) on the red channel, in the same order.
-// Mod(a, b) of pbrt.h:314-317 without the integer division (~40 vector instructions) where a is already inside [0, b): the four texels of a
-// lookup are, except at the map's border
-PG_DEV int alpha_mod(int a, int b) { if ((unsigned)a < (unsigned)b) return a; return mod_i(a, b); }
 PG_DEV float alpha_texel(const DScene &sc, const DAlphaTex &a, int s, int t) {
-    if (a.wrap == 0) { s = alpha_mod(s, a.width); t = alpha_mod(t, a.height); }
+    if (a.wrap == 0) { s = mod_i(s, a.width); t = mod_i(t, a.height); }  // (mod_i skips its division where the texel is inside the map)
     else if (a.wrap == 2) { s = s < 0 ? 0 : (s > a.width - 1 ? a.width - 1 : s); t = t < 0 ? 0 : (t > a.height - 1 ? a.height - 1 : t); }
     else if (s < 0 || s >= a.width || t < 0 || t >= a.height) return 0.f;
     return sc.texels[a.offset + ((size_t)t * a.width + s)];
