@@ -1003,7 +1003,8 @@ static int ensureWorkBuffers(PgScene *s, int capacity) {
         const size_t want = n * ((size_t)s->matStride * recBytes + 2 * sizeof(float4)), have = s->matLobes.bytes + s->matHead.bytes;
         s->matLobes.release(); s->matHead.release();
         // (everything else of this function and the integrator's own state -- about 600 B per slot -- is still to be allocated)
-        const bool fits = want + n * 700 + ((size_t)1 << 30) <= freeB + have;
+        // (a list's record index r * plane + p is a 32-bit product in the kernels: plane * stride must stay below 2^31)
+        const bool fits = want + n * 700 + ((size_t)1 << 30) <= freeB + have && n * (size_t)s->matStride < ((size_t)1 << 31);
         if (!fits || s->matLobes.alloc(n * (size_t)s->matStride * recBytes) != hipSuccess || s->matHead.alloc(n * 2 * sizeof(float4)) != hipSuccess) {
             s->matLobes.release(); s->matHead.release(); (void)hipGetLastError();
         }

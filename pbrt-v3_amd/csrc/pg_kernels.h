@@ -273,11 +273,16 @@ __host__ __device__ inline void pg_pack_lobe_scales(const PgBxDF &b, float *q) {
 
 // Materials evaluated ahead of the shading launch (k_material, pg_kernels.hip): for every main-queue entry whose hit has a
 // material with textured parameters (PG_MAT_TEXTURED) and whose path is still alive, Material::ComputeScatteringFunctions' outputs
-// -- the BxDF list, BSDF::eta and the shading frame Material::Bump leaves -- at the ENTRY's index (the index of its hit record):
-//   head[2 e] = (shading.n, BSDF::eta)   head[2 e + 1] = (shading.dpdu, number of BxDFs | 0x100 for a mix, as int bits)   lobes[(e * stride + r) * 3 ..]
-// stride = the records the scene's largest list needs (PgScene: counted per material kind, <= PG_MAX_BXDFS lobes, two records per lobe of a mix).  lobes == nullptr: the scene has no
-// such material, or the buffers did not fit -- the shading kernel then evaluates materials itself (k_shade<2, .>).
-struct MatPre { float4 *lobes; float4 *head; int stride; };  // lobes: packed 48-B records (LobeBsdfT, pg_kernels.hip), `stride` RECORDS of three float4 per entry
+// -- the BxDF list, BSDF::eta and the shading frame Material::Bump leaves -- at the POSITION p the entry has in the launch's shading
+// order (RenderParams::order: k_material and the shading kernel walk the queue in the same order, thread for thread), one PLANE of
+// N = regionCap * PG_REGIONS records per record index:
+//   head[p] = (shading.n, BSDF::eta)   head[N + p] = (shading.dpdu, number of BxDFs | 0x100 for a mix, as int bits)   record r of the list = lobes[(r * N + p) * 3 ..]
+// Neighbouring lanes write and read neighbouring 48-B records, and a hit with one BxDF touches one plane: every line that moves is used
+// whole.  (Until round 6 a hit's records lay side by side at the stride of the scene's longest list, by entry: a one-lobe hit used 48 B
+// of the 240 its slot took, profiles/r06k_*.)  stride = the planes the scene's longest list needs (PgScene: counted per material kind,
+// <= PG_MAX_BXDFS lobes, two records per lobe of a mix).  lobes == nullptr: the scene has no such material, or the buffers did not fit
+// -- the shading kernel then evaluates materials itself (k_shade<2, .>).
+struct MatPre { float4 *lobes; float4 *head; int stride; };  // lobes: packed 48-B records (LobeBsdfT, pg_kernels.hip), `stride` planes
 
 #define PG_META_SPECULAR 0x10000
 #define PG_META_DONE 0x20000

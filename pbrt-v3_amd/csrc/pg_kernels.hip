@@ -95,6 +95,13 @@ PG_DEV int queue_item(const RayQueue &q) {
     return j < q.counts[r * PG_COUNT_STRIDE] ? r * q.regionCap + j : -1;
 }
 
+// A shading thread's POSITION in its launch's order (the index queue_item gave it, before RenderParams::order maps it to an entry; a
+// retry launch reads it back from the retry list): recomputed from the block and thread indices where it is needed, not kept in a register.
+PG_DEV int shade_position(const RenderParams &rp, const RayQueue &q) {
+    if (rp.retryCount > 0) return rp.retryList[blockIdx.x * PG_SHADE_BLOCK + threadIdx.x];
+    return (blockIdx.x & (PG_REGIONS - 1)) * q.regionCap + (blockIdx.x >> 3) * PG_SHADE_BLOCK + threadIdx.x;
+}
+
 PG_DEV unsigned long long wave_sum(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     return v;
@@ -1342,12 +1349,12 @@ template <class LB> PG_DEV Spec lobe_sample_f(const LB &b, int lobe, V3 wo, V3 &
     }
     return sp(0);
 }
-PG_DEV Spec lobe_scale(const PgBxDF &b, Spec f) {  // ScaledBxDF, reflection.cpp:98-107: innermost wrapper first
+PG_DEV Spec lobe_scale(const PgBxDF &b, Spec f, int) {  // ScaledBxDF, reflection.cpp:98-107: innermost wrapper first
     for (int i = 0; i < b.n_scales; ++i) f = sp_of(b.scale[i]) * f;
     return f;
 }
-PG_DEV Spec lobe_scale(const PkLobe &b, Spec f) {  // the factors: nine floats in the record behind the lobe's
-    const float *sc = reinterpret_cast<const float *>(&b + 1);
+PG_DEV Spec lobe_scale(const PkLobe &b, Spec f, int recStride) {  // the factors: nine floats in the record behind the lobe's (half a lobe's stride on: a scaled list has two records per lobe)
+    const float *sc = reinterpret_cast<const float *>(&b + (recStride >> 1));
     const int n = (int)((b.hdr >> 6) & 3u);
     for (int i = 0; i < n; ++i) f = sp_of(sc + 3 * i) * f;
     return f;
@@ -1360,7 +1367,7 @@ template <class LB> PG_DEV int lbsdf_num_components(const LobeBsdfT<LB> &b, int 
 template <class LB> PG_DEV Spec lbsdf_scaled(const LobeBsdfT<LB> &b, int i, Spec f) {
     if (!((b.scaled >> i) & 1u)) return f;
     const auto &L = lobe_at(b, i);
-    return lobe_scale(L, f);
+    return lobe_scale(L, f, b.recStride);
 }
 // BxDF::f and BxDF::Pdf of one BxDF for the same pair of directions.  Each value is what lobe_f / lobe_pdf compute -- the same
 // operations in the same order --, but the microfacet BxDFs' half vector, D(wh) and Lambda(wo) are computed once for both (a path
@@ -1497,18 +1504,19 @@ struct LobeOutRaw {
     PG_DEV void add_scale(int i, Spec s) const { if (p[i].n_scales < PG_MAX_BXDF_SCALES) { lobe_set(p[i].scale[p[i].n_scales], s); p[i].n_scales++; } }
 };
 struct LobeOutPacked {
-    float4 *rec;
+    float4 *rec;    // record 0 of this thread's list; record r lies r planes on (MatPre)
     int recStride;  // 2: the hit's material is a mix, every lobe is followed by the record of its scale factors
+    int plane;      // records per plane = the queue's entries
     PG_DEV void put(int i, const PgBxDF &b) const {
-        float *q = reinterpret_cast<float *>(rec + 3 * i * recStride);
-        pg_pack_lobe(b, q);
-        if (recStride == 2) pg_pack_lobe_scales(b, q + 12);
+        float4 *q = rec + 3 * ((size_t)(i * recStride) * plane);
+        pg_pack_lobe(b, reinterpret_cast<float *>(q));
+        if (recStride == 2) pg_pack_lobe_scales(b, reinterpret_cast<float *>(q + 3 * (size_t)plane));
     }
     PG_DEV void add_scale(int i, Spec s) const {  // ScaledBxDF around lobe i (mixmat.cpp:60-65): the next free factor of its scale record
-        float4 *q = rec + 3 * i * recStride;
+        float4 *q = rec + 3 * ((size_t)(i * recStride) * plane);
         const unsigned hdr = __float_as_uint(q[0].x), ns = (hdr >> 6) & 3u;
         if (ns < PG_MAX_BXDF_SCALES) {
-            float *f = reinterpret_cast<float *>(q + 3) + 3 * ns;
+            float *f = reinterpret_cast<float *>(q + 3 * (size_t)plane) + 3 * ns;
             f[0] = s.r; f[1] = s.g; f[2] = s.b;
             q[0].x = __uint_as_float(hdr + (1u << 6));
         }
@@ -2207,13 +2215,11 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
     // kernels (the probe chains, the two shading phases) find a path's state by its slot
     constexpr bool QSTATE = !VOL || (!SSS && !GRID);
     int i;
-    if (rp.retryCount > 0) {  // second pass over the entries that waited for a light-distribution voxel
+    if (rp.retryCount > 0) {  // second pass over the entries that waited for a light-distribution voxel (the list holds their POSITIONS in the shading order)
         const int j = blockIdx.x * PG_SHADE_BLOCK + threadIdx.x;
         i = j < rp.retryCount ? rp.retryList[j] : -1;
-    } else {
-        i = queue_item<PG_SHADE_BLOCK>(qin);
-        if (rp.order && i >= 0) i = rp.order[i];  // k_shade_order: the entries of a window grouped by material class
-    }
+    } else i = queue_item<PG_SHADE_BLOCK>(qin);
+    if (rp.order && i >= 0) i = rp.order[i];  // k_shade_order: the entries of a window grouped by material class
     bool deferred = false;  // sparse light tables: this vertex met a voxel without a distribution; nothing is committed
     unsigned long long tsState0 = 0;  // tile-serial samplers: the tile's stream position and dimension counters on entry
     int tsCur1D0 = 0, tsCur2D0 = 0;
@@ -2511,8 +2517,10 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
                     }
                     const bool preEvaluated = PRE && m.type == PG_MAT_TEXTURED;
                     float4 head0 = make_float4(0, 0, 0, 0), head1 = head0;
+                    const int plane = qin.regionCap * PG_REGIONS;  // PRE: k_material's records lie by POSITION in the shading order, one plane per record (MatPre)
                     if (preEvaluated) {  // the shading frame after Material::Bump, as k_material left it
-                        head0 = rp.matPre.head[2 * (size_t)i]; head1 = rp.matPre.head[2 * (size_t)i + 1];
+                        const int p = shade_position(rp, qin);
+                        head0 = rp.matPre.head[p]; head1 = rp.matPre.head[(size_t)plane + p];
                         is.ns = mk(head0.x, head0.y, head0.z);
                         is.sdpdu = mk(head1.x, head1.y, head1.z);
                     }
@@ -2521,7 +2529,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
                     lb.ts = cross(lb.ns, lb.ss);
                     if constexpr (PRE) {
                         if (preEvaluated)  // k_material's list: head1.w = the number of BxDFs, bit 8: a mix (scale records)
-                            lbsdf_bind(lb, reinterpret_cast<const PkLobe *>(rp.matPre.lobes) + (size_t)i * rp.matPre.stride, __float_as_int(head1.w) & 0xff, head0.w, (__float_as_int(head1.w) & 0x100) ? 2 : 1);
+                            lbsdf_bind(lb, reinterpret_cast<const PkLobe *>(rp.matPre.lobes) + shade_position(rp, qin), __float_as_int(head1.w) & 0xff, head0.w, ((__float_as_int(head1.w) & 0x100) ? 2 : 1) * plane);
                         else {  // a material with constant parameters: its list in the same records, packed once at pg_scene_create
                             const int2 pk = sc.matPk[tri.material];
                             lbsdf_bind(lb, reinterpret_cast<const PkLobe *>(sc.bxdfsPk) + pk.x, m.n_bxdfs, m.bsdf_eta, pk.y);
@@ -2765,7 +2773,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
     if (deferred) {  // retried once the voxel's distribution exists: no ray, no state, no pending term leaves this launch
         pushNext = pushShadow = misCand = false;
         if (rp.rd.sampler >= PG_SAMPLER_RANDOM) { sc.ts[slot].state = tsState0; sc.ts[slot].cur1D = tsCur1D0; sc.ts[slot].cur2D = tsCur2D0; }  // nor a draw from the tile's stream
-        rp.retryList[atomicAdd(&sc.voxelCounters[1], 1)] = i;
+        rp.retryList[atomicAdd(&sc.voxelCounters[1], 1)] = shade_position(rp, qin);
     }
     if (misCand) {
         // light.Pdf_Li -> Shape::Pdf(ref, wi): intersect the light's own triangle (shape.cpp:72-87, diffuse.cpp:83-87)
@@ -2860,9 +2868,9 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
 template <bool VOL>
 __global__ __launch_bounds__(PG_SHADE_BLOCK, PG_MATERIAL_WAVES) void k_material(DScene sc, RenderParams rp, PathState st, RayQueue qin, const float4 *__restrict__ hits,
                                                                                VolState vs, const float *__restrict__ hitT, QueueState qsIn) {
-    int i = queue_item<PG_SHADE_BLOCK>(qin);
-    if (i < 0) return;
-    if (rp.order) i = rp.order[i];
+    const int p = queue_item<PG_SHADE_BLOCK>(qin);  // the thread's position in the shading order: where its list goes (MatPre)
+    if (p < 0) return;
+    const int i = rp.order ? rp.order[p] : p;
     const float4 h4 = hits[i];
     const int prim = __float_as_int(h4.x);
     if (prim < 0) return;
@@ -2909,10 +2917,11 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PG_MATERIAL_WAVES) void k_material(
     float etaL = 1;
     // the list in packed records (LobeBsdfT): stride = the records per entry; a mix's lobes take two each
     const bool mix = sc.textured[sc.materials[tri.material].textured_index].kind == PG_KIND_MIX;
-    const LobeOutPacked out = {rp.matPre.lobes + (size_t)i * rp.matPre.stride * 3, mix ? 2 : 1};
+    const int plane = qin.regionCap * PG_REGIONS;
+    const LobeOutPacked out = {rp.matPre.lobes + (size_t)p * 3, mix ? 2 : 1, plane};
     MatEval<2, 1, LobeOutPacked>::run(*sc.self, tri.material, th, out, nl, etaL, mix ? rp.matPre.stride / 2 : rp.matPre.stride);
-    rp.matPre.head[2 * (size_t)i] = make_float4(is.ns.x, is.ns.y, is.ns.z, etaL);
-    rp.matPre.head[2 * (size_t)i + 1] = make_float4(is.sdpdu.x, is.sdpdu.y, is.sdpdu.z, __int_as_float(nl | (mix ? 0x100 : 0)));
+    rp.matPre.head[p] = make_float4(is.ns.x, is.ns.y, is.ns.z, etaL);
+    rp.matPre.head[(size_t)plane + p] = make_float4(is.sdpdu.x, is.sdpdu.y, is.sdpdu.z, __int_as_float(nl | (mix ? 0x100 : 0)));
 }
 static void launch_material(const DScene &sc, const RenderParams &rp, PathState st, VolState vs, RayQueue qin, const float4 *hits, const float *hitT, QueueState qi,
                             bool vol, hipStream_t s) {
