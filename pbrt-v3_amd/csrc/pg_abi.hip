@@ -54,7 +54,7 @@ struct PgScene {
     int device = 0;
     DScene d;
     TraceConfig trace;  // k_trace's tunables for THIS scene's launches (the exact-fallback retry changes them for one call)
-    DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, instEntry, textures, textured, images, texels, ewaLut, envTables, alphas, alphaTex, triAlpha, triN, triS, uv, materials, lights, distTable, perms, permSums, primes, media, triMediumIn, triMediumOut, sobolMatrices, vdcSobol, vdcSobolInv, noisePerm;
+    DeviceBuffer nodes, wnodes, tris, spheres, bxdfs, objects, instances, instEntry, textures, textured, images, texels, ewaLut, envTables, alphas, alphaTex, triAlpha, triAttr, triS, uv, materials, lights, distTable, perms, permSums, primes, media, triMediumIn, triMediumOut, sobolMatrices, vdcSobol, vdcSobolInv, noisePerm;
     // work buffers (sized on first render, reused)
     int capacity = 0;
     DeviceBuffer sceneCopy;  // DScene::self
@@ -382,22 +382,40 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         tris[PG_TRI_STRIDE * (size_t)k + 1] = make_float4(p[1].x, p[1].y, p[1].z, mw);
         tris[PG_TRI_STRIDE * (size_t)k + 2] = make_float4(p[2].x, p[2].y, p[2].z, lw);
     }
-    // per-vertex normals / tangents, de-indexed like the positions (only when some mesh has them)
-    for (int pass = 0; pass < 2; ++pass) {
-        const float *src = pass == 0 ? desc->N : desc->S;
-        const uint32_t bit = pass == 0 ? PG_TRI_HAS_N : PG_TRI_HAS_S;
-        bool any = false;
-        for (int k = 0; k < nt && src; ++k) any |= desc->tri_flags && (desc->tri_flags[k] & bit);
-        if (!any) continue;
+    // per-vertex normals and (u, v), de-indexed like the positions, one 64-byte record per triangle (DScene::triAttr; only when some mesh has either);
+    // tangents in an array of their own (only when some mesh has them)
+    bool anyN = false, anyS = false;
+    for (int k = 0; k < nt; ++k) {
+        anyN |= desc->N && desc->tri_flags && (desc->tri_flags[k] & PG_TRI_HAS_N);
+        anyS |= desc->S && desc->tri_flags && (desc->tri_flags[k] & PG_TRI_HAS_S);
+    }
+    if (anyN || anyUV) {
+        std::vector<float> a((size_t)nt * 16, 0.f);
+        for (int k = 0; k < nt; ++k) {
+            float *r = &a[16 * (size_t)k];
+            if (anyUV) memcpy(r + 10, &uv[(size_t)k * 6], 6 * sizeof(float));
+            if (!anyN || !(desc->tri_flags[k] & PG_TRI_HAS_N) || (desc->tri_flags[k] & (PG_PRIM_INSTANCE | PG_PRIM_SPHERE))) continue;
+            const int32_t *v = &desc->indices[3 * k];
+            for (int j = 0; j < 3; ++j) for (int c = 0; c < 3; ++c) r[3 * j + c] = desc->N[3 * v[j] + c];
+        }
+        bool anyAlpha = false;  // k_trace's alpha masks read the (u, v) alone: from the compact array (24 B per triangle) they had before the attribute records
+        for (int k = 0; k < nt && anyUV; ++k) anyAlpha |= (desc->tri_flags[k] & PG_TRI_ALPHA) != 0;
+        if (anyAlpha) {
+            HIP_TRY_S(s->uv.alloc(sizeof(float) * uv.size()));
+            HIP_TRY_S(hipMemcpy(s->uv.p, uv.data(), s->uv.bytes, hipMemcpyHostToDevice));
+        }
+        HIP_TRY_S(s->triAttr.alloc(sizeof(float) * a.size()));
+        HIP_TRY_S(hipMemcpy(s->triAttr.p, a.data(), s->triAttr.bytes, hipMemcpyHostToDevice));
+    }
+    if (anyS) {
         std::vector<float4> a((size_t)nt * 3, make_float4(0, 0, 0, 0));
         for (int k = 0; k < nt; ++k) {
-            if (!(desc->tri_flags[k] & bit)) continue;
+            if (!(desc->tri_flags[k] & PG_TRI_HAS_S) || (desc->tri_flags[k] & (PG_PRIM_INSTANCE | PG_PRIM_SPHERE))) continue;
             const int32_t *v = &desc->indices[3 * k];
-            for (int j = 0; j < 3; ++j) a[3 * (size_t)k + j] = make_float4(src[3 * v[j]], src[3 * v[j] + 1], src[3 * v[j] + 2], 0.f);
+            for (int j = 0; j < 3; ++j) a[3 * (size_t)k + j] = make_float4(desc->S[3 * v[j]], desc->S[3 * v[j] + 1], desc->S[3 * v[j] + 2], 0.f);
         }
-        DeviceBuffer &buf = pass == 0 ? s->triN : s->triS;
-        HIP_TRY_S(buf.alloc(sizeof(float4) * a.size()));
-        HIP_TRY_S(hipMemcpy(buf.p, a.data(), buf.bytes, hipMemcpyHostToDevice));
+        HIP_TRY_S(s->triS.alloc(sizeof(float4) * a.size()));
+        HIP_TRY_S(hipMemcpy(s->triS.p, a.data(), s->triS.bytes, hipMemcpyHostToDevice));
     }
     {  // texture graph: operands are earlier nodes (no cycles), nesting <= 3 levels (the unrolled evaluator of pg_kernels.hip)
         std::vector<int> depth((size_t)(desc->n_textures > 0 ? desc->n_textures : 0), 1);
@@ -470,10 +488,6 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     }
     HIP_TRY_S(s->tris.alloc(sizeof(float4) * tris.size()));
     if (nt) HIP_TRY_S(hipMemcpy(s->tris.p, tris.data(), s->tris.bytes, hipMemcpyHostToDevice));
-    if (anyUV) {
-        HIP_TRY_S(s->uv.alloc(sizeof(float) * uv.size()));
-        HIP_TRY_S(hipMemcpy(s->uv.p, uv.data(), s->uv.bytes, hipMemcpyHostToDevice));
-    }
     // --- materials / lights
     bool anyLobeMaterial = false, anyTextured = false;
     for (int i = 0; i < desc->n_materials; ++i) {
@@ -805,8 +819,8 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     {  // PG_FORCE_EXT=1 runs the general kernels on scenes that do not need them (tests: both paths agree bit for bit)
         const char *fe = getenv("PG_FORCE_EXT");
         d.ext = (d.hasTextured || d.nSpheres > 0 || d.nInstances > 0 || d.hasInfinite || anyImageLight || anyLobeMaterial || (fe && atoi(fe) != 0)) ? 1 : 0;
-    } d.uv = (const float *)s->uv.p;
-    d.triN = (const float4 *)s->triN.p; d.triS = (const float4 *)s->triS.p;
+    }
+    d.triAttr = (const float4 *)s->triAttr.p; d.triS = (const float4 *)s->triS.p; d.attrN = anyN ? 1 : 0; d.attrUV = anyUV ? 1 : 0; d.alphaUV = (const float *)s->uv.p;
     d.materials = (const PgMaterial *)s->materials.p; d.lights = (const PgLight *)s->lights.p;
     d.nNodes = desc->n_nodes; d.nTris = nt; d.nLights = desc->n_lights; d.nMaterials = desc->n_materials;
     d.perms = (const uint16_t *)s->perms.p; d.permSums = (const int32_t *)s->permSums.p; d.primes = (const int32_t *)s->primes.p; d.haltonDims = (const int4 *)s->haltonDims.p;

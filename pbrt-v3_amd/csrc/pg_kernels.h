@@ -64,9 +64,14 @@ struct DScene {
     // stored PG_TRI_STRIDE float4 apart: 4 puts every record into one 64-B line (of 48-B records packed back to back half
     // straddle two lines, and the traversal is bound by lines fetched)
     const float4 *tris;
-    // per-vertex shading normals N / tangents S de-indexed per triangle (3 float4 each, BVH order), or nullptr when no mesh has them
-    const float4 *triN, *triS;
-    const float *uv;  // 6 floats per triangle, or nullptr when no mesh has uv (default uv, triangle.h:104-106)
+    // per-vertex shading normals N and (u, v) de-indexed per triangle, BVH order, in ONE 64-byte record (one line where two arrays
+    // -- 48 B and 24 B per triangle, records straddling lines -- were 2.6 lines per hit: profiles/r06l_*):
+    //   sixteen floats: n0.xyz n1.xyz n2.xyz 0 | u0 v0 u1 v1 u2 v2   (the (u, v) alone -- k_trace's alpha masks -- are 24 contiguous bytes)
+    // nullptr when no mesh has either; attrN / attrUV: some mesh has normals / uv (a triangle's own PG_TRI_HAS_N / _UV bit says whether
+    // it has; default uv, triangle.h:104-106).  triS: per-vertex tangents S (3 float4 per triangle), or nullptr when no mesh has them
+    const float4 *triAttr, *triS;
+    int attrN, attrUV;
+    const float *alphaUV;  // the (u, v) once more, 6 floats per triangle, for k_trace's alpha masks (scenes with alpha-masked meshes), else nullptr
     const PgMaterial *materials;
     const PgLight *lights;
     // what the shading kernel needs of a light the moment it is chosen, 80 B per light, read in ONE round trip: h[0] = (type,
@@ -161,6 +166,19 @@ struct DScene {
     int *tsOverflow;
     const uint32_t *cmaxmin;  // CMaxMinDist [17][32]
 };
+
+// Triangle `prim`'s (u, v) / per-vertex normals from its attribute record (DScene::triAttr)
+__device__ __forceinline__ void tri_attr_uv(const DScene &sc, int prim, float uv[6]) {
+    const float4 *a = sc.triAttr + 4 * (size_t)prim;
+    const float2 q = *reinterpret_cast<const float2 *>(reinterpret_cast<const float *>(a) + 10);
+    const float4 r = a[3];
+    uv[0] = q.x; uv[1] = q.y; uv[2] = r.x; uv[3] = r.y; uv[4] = r.z; uv[5] = r.w;
+}
+__device__ __forceinline__ void tri_attr_normals(const DScene &sc, int prim, float n[9]) {
+    const float4 *a = sc.triAttr + 4 * (size_t)prim;
+    const float4 q0 = a[0], q1 = a[1];
+    n[0] = q0.x; n[1] = q0.y; n[2] = q0.z; n[3] = q0.w; n[4] = q1.x; n[5] = q1.y; n[6] = q1.z; n[7] = q1.w; n[8] = reinterpret_cast<const float *>(a)[8];
+}
 
 // A queue of rays in SoA float4 pairs: 32 B per ray
 //   o[i] = (o.x, o.y, o.z, tMax)   d[i] = (d.x, d.y, d.z, slot id bits)

@@ -747,14 +747,19 @@ PG_DEV V3 tri_normal(const Tri &t) {  // triangle.cpp:346-348
     return n;
 }
 PG_DEV void load_uv(const DScene &sc, int prim, uint32_t flags, float uv[6]) {  // triangle.h:98-108
-    if (sc.uv && (flags & PG_TRI_HAS_UV)) { for (int k = 0; k < 6; ++k) uv[k] = sc.uv[6 * prim + k]; }
+    if (sc.attrUV && (flags & PG_TRI_HAS_UV)) tri_attr_uv(sc, prim, uv);
     else { uv[0] = 0; uv[1] = 0; uv[2] = 1; uv[3] = 0; uv[4] = 1; uv[5] = 1; }
 }
 // The tail of Triangle::Intersect (triangle.cpp:293-348) for the surviving hit.
 // Per-vertex attribute a (N or S) of triangle prim interpolated with weights (w0, w1, w2): w0*a0 + w1*a1 + w2*a2.
 PG_DEV V3 tri_interp(const float4 *attr, int prim, float w0, float w1, float w2) {
-    const float4 a = attr[3 * prim], b = attr[3 * prim + 1], c = attr[3 * prim + 2];
+    const float4 a = attr[3 * (size_t)prim], b = attr[3 * (size_t)prim + 1], c = attr[3 * (size_t)prim + 2];
     return mk(a.x, a.y, a.z) * w0 + mk(b.x, b.y, b.z) * w1 + mk(c.x, c.y, c.z) * w2;
+}
+PG_DEV V3 tri_interp_normal(const DScene &sc, int prim, float w0, float w1, float w2) {  // the same with the per-vertex normals of DScene::triAttr
+    float n[9];
+    tri_attr_normals(sc, prim, n);
+    return mk(n[0], n[1], n[2]) * w0 + mk(n[3], n[4], n[5]) * w1 + mk(n[6], n[7], n[8]) * w2;
 }
 // Triangle::Intersect's geometric normal for a hit with barycentrics (b0,b1,b2): Normalize(Cross(dp02, dp12)), flipped by
 // reverseOrientation ^ transformSwapsHandedness (triangle.cpp:346-348), then made to face the interpolated shading normal
@@ -776,11 +781,11 @@ PG_DEV Isect make_isect(const DScene &sc, int prim, const Tri &t, float b0, floa
     is.ns = is.n;
     is.sdpdu = dpdu; is.sdpdv = dpdv;
     is.sdndu = is.sdndv = mk(0, 0, 0);
-    const bool hasN = sc.triN && (t.flags & PG_TRI_HAS_N), hasS = sc.triS && (t.flags & PG_TRI_HAS_S);
+    const bool hasN = sc.attrN && (t.flags & PG_TRI_HAS_N), hasS = sc.triS && (t.flags & PG_TRI_HAS_S);
     if (hasN || hasS) {  // shading geometry, triangle.cpp:350-419 (dndu/dndv only feed ray differentials)
         V3 ns = is.n, ss = normalize(dpdu), ts;
         if (hasN) {
-            V3 v = tri_interp(sc.triN, prim, b0, b1, b2);
+            V3 v = tri_interp_normal(sc, prim, b0, b1, b2);
             if (lensq(v) > 0) ns = normalize(v);
         }
         if (hasS) {
@@ -792,8 +797,9 @@ PG_DEV Isect make_isect(const DScene &sc, int prim, const Tri &t, float b0, floa
         else coordinate_system(ns, ss, ts);
         if (hasN) {  // dndu, dndv of the shading geometry, triangle.cpp:383-416
             const float d02x = uv[0] - uv[4], d02y = uv[1] - uv[5], d12x = uv[2] - uv[4], d12y = uv[3] - uv[5];
-            const float4 a4 = sc.triN[3 * prim], b4 = sc.triN[3 * prim + 1], c4 = sc.triN[3 * prim + 2];
-            const V3 n0 = mk(a4.x, a4.y, a4.z), n1 = mk(b4.x, b4.y, b4.z), n2 = mk(c4.x, c4.y, c4.z);
+            float nv[9];
+            tri_attr_normals(sc, prim, nv);
+            const V3 n0 = mk(nv[0], nv[1], nv[2]), n1 = mk(nv[3], nv[4], nv[5]), n2 = mk(nv[6], nv[7], nv[8]);
             const V3 dn1 = n0 - n2, dn2 = n1 - n2;
             const float determinant = d02x * d12y - d02y * d12x;
             if ((double)fabsf(determinant) < 1e-8) {
@@ -815,7 +821,7 @@ PG_DEV Isect make_isect(const DScene &sc, int prim, const Tri &t, float b0, floa
 }
 // The geometric normal alone, as make_isect leaves it in isect.n (for Le() at a hit that is not shaded further).
 PG_DEV V3 hit_normal(const DScene &sc, int prim, const Tri &t, float b0, float b1, float b2) {
-    if ((sc.triN && (t.flags & PG_TRI_HAS_N)) || (sc.triS && (t.flags & PG_TRI_HAS_S))) return make_isect(sc, prim, t, b0, b1, b2, mk(0, 0, 1)).n;
+    if ((sc.attrN && (t.flags & PG_TRI_HAS_N)) || (sc.triS && (t.flags & PG_TRI_HAS_S))) return make_isect(sc, prim, t, b0, b1, b2, mk(0, 0, 1)).n;
     return tri_normal(t);
 }
 
@@ -1788,8 +1794,8 @@ PG_DEV LightSample tri_sample_area(const DScene &sc, const Tri &t, int prim, flo
     float b2 = (1 - b0 - b1);
     ls.p = t.p0 * b0 + t.p1 * b1 + t.p2 * b2;
     ls.n = normalize(cross(t.p1 - t.p0, t.p2 - t.p0));
-    if (sc.triN && (t.flags & PG_TRI_HAS_N)) {  // triangle.cpp:593-597: orientation follows the shading normal
-        V3 ns = tri_interp(sc.triN, prim, b0, b1, b2);
+    if (sc.attrN && (t.flags & PG_TRI_HAS_N)) {  // triangle.cpp:593-597: orientation follows the shading normal
+        V3 ns = tri_interp_normal(sc, prim, b0, b1, b2);
         if (dot(ls.n, ns) < 0.f) ls.n = -ls.n;
     } else if (t.flags & PG_TRI_FLIP_NORMAL) ls.n = ls.n * -1.f;
     V3 pAbsSum = vabs(t.p0 * b0) + vabs(t.p1 * b1) + vabs(t.p2 * b2);

@@ -548,7 +548,7 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                         tsAlpha = true;
 #endif
                         float uv[6] = {0, 0, 1, 0, 1, 1};
-                        if (sc.uv && (pflags & PG_TRI_HAS_UV)) for (int k = 0; k < 6; ++k) uv[k] = sc.uv[6 * prim + k];
+                        if (sc.alphaUV && (pflags & PG_TRI_HAS_UV)) for (int k = 0; k < 6; ++k) uv[k] = sc.alphaUV[6 * prim + k];
                         const float hu = b0 * uv[0] + b1 * uv[2] + b2 * uv[4], hv = b0 * uv[1] + b1 * uv[3] + b2 * uv[5];
                         if (XP & XP_ALPHATEX) {
                             const PgAlphaMask &am = sc.alphas[sc.triAlpha[prim]];
