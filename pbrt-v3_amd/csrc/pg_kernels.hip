@@ -2657,6 +2657,13 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
                                 }
                             }
                         }
+                        // pending terms of this vertex, consumed by k_resolve (pdMis and the MIS weight follow below) -- stored HERE: held until after the
+                        // BSDF sample below they were five registers at the kernel's peak (tools/reg_pressure.py: lbsdf_sample_f's microfacet terms)
+                        pdLight.w = lightSelPdf;
+                        st.pdLight[pdi] = pdLight;
+                        st.pdBeta[pdi] = make_float4(beta.r, beta.g, beta.b, 0.f);
+                        // (beta waits in LDS, where it goes at the end anyway, while the BSDF is sampled: three more registers off the same peak)
+                        if constexpr (!TEX) { float *sb = reinterpret_cast<float *>(&s_state[1][tid]); sb[0] = beta.r; sb[1] = beta.g; sb[2] = beta.b; }
                         // BSDF sampling half of MIS (integrator.cpp:164-212): sample now, while the BSDF is live; the
                         // light.Pdf_Li triangle test runs at the end of the kernel, when little else is (register pressure)
                         V3 wi2 = wi;
@@ -2678,15 +2685,14 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
                                 misInside = lsph.shape != PG_SHAPE_SPHERE || sphere_ref_inside(lsph, is.p, is.pError, is.n);
                             }
                         }
-                        // pending terms of this vertex, consumed by k_resolve (pdMis and the MIS weight follow below)
-                        pdLight.w = lightSelPdf;
-                        st.pdLight[pdi] = pdLight;
-                        st.pdBeta[pdi] = make_float4(beta.r, beta.g, beta.b, 0.f);
+                        if constexpr (!TEX) { const volatile float *sb = reinterpret_cast<const volatile float *>(&s_state[1][tid]); beta = sp3(sb[0], sb[1], sb[2]); }
                     }
                 }
                 // ---- sample the BSDF for the next direction (path.cpp:130-150)
                 if (!phaseA) {
-                V3 wo = -rayD, wi;
+                // (the ray's direction once more from its queue entry: kept from the top of the kernel it was three registers at the peak above)
+                const float4 dNow = qin.d[i];
+                V3 wo = -mk(dNow.x, dNow.y, dNow.z), wi;
                 float pdf;
                 float u0, u1;
                 draw2(u0, u1);
