@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 27
+#define PG_ABI_VERSION 28
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -598,6 +598,15 @@ typedef struct PgCounters {
      * PG_SHADING_LISTS_DID_NOT_FIT = a textured scene ran k_shade<2> only because k_material's lists found no room in device memory --
      * same image, about 1.5 x the shading time: a caller that measures should know (bench.py: config.shading_mode). */
     uint64_t shading_modes;
+    /* ABI 28 -- the integrators' own statistics (path.cpp:45-46, volpath.cpp:45-47), as the reference prints them under "Integrator":
+     * "Zero-radiance paths" = paths_zero_radiance / paths_total (PathIntegrator: the vertices whose BSDF has a non-specular BxDF, and of
+     * those the ones whose direct lighting Ld came back black, path.cpp:119-126; volpath does not count them); "Path length" =
+     * path_length_sum / path_length_count avg [range path_length_min - path_length_max] over the Li calls' final `bounces`
+     * (ReportValue, path.cpp:186 / volpath.cpp:187; min / max are 0 while count is 0); "Volume interactions" / "Surface interactions"
+     * (volpath.cpp:87, :99). */
+    uint64_t paths_total, paths_zero_radiance;
+    uint64_t path_length_sum, path_length_count, path_length_min, path_length_max;
+    uint64_t volume_interactions, surface_interactions;
 } PgCounters;
 #define PG_SHADING_MATERIAL_PREPASS 0x100u
 #define PG_SHADING_LISTS_DID_NOT_FIT 0x200u

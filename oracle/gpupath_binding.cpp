@@ -58,6 +58,7 @@
 #include "primitive.h"
 #include "reflection.h"
 #include "sampler.h"
+#include "stats.h"
 #include "samplers/halton.h"
 #include "samplers/maxmin.h"
 #include "samplers/random.h"
@@ -605,6 +606,27 @@ void MergeIntoFilm(Film *film, const PgRenderDesc &rd, const std::vector<PgFilmP
     }
 }
 
+// The device's counters under the reference's own statistics: the counters Scene::Intersect[P], SamplerIntegrator::Render and the integrators' Li
+// keep (scene.cpp:40-42, integrator.cpp:48, path.cpp:45-46, volpath.cpp:45-47) are registered here once more under the SAME titles --
+// StatsAccumulator adds what carries one title (stats.h:62-118) -- and set from PgCounters, so that the statistics this binary prints after a
+// render are the ones the CPU integrator would have printed.  (Set on the thread that renders: pbrtWorldEnd reports its thread's statistics.)
+STAT_COUNTER("Intersections/Regular ray intersection tests", devIntersectionTests);
+STAT_COUNTER("Intersections/Shadow ray intersection tests", devShadowTests);
+STAT_COUNTER("Integrator/Camera rays traced", devCameraRays);
+STAT_PERCENT("Integrator/Zero-radiance paths", devZeroRadiancePaths, devTotalPaths);
+STAT_INT_DISTRIBUTION("Integrator/Path length", devPathLength);
+STAT_COUNTER("Integrator/Volume interactions", devVolumeInteractions);
+STAT_COUNTER("Integrator/Surface interactions", devSurfaceInteractions);
+static void ReportDeviceStats(const PgCounters &c) {
+    devIntersectionTests += (int64_t)c.closest_rays; devShadowTests += (int64_t)c.shadow_rays; devCameraRays += (int64_t)c.camera_rays;
+    devZeroRadiancePaths += (int64_t)c.paths_zero_radiance; devTotalPaths += (int64_t)c.paths_total;
+    devVolumeInteractions += (int64_t)c.volume_interactions; devSurfaceInteractions += (int64_t)c.surface_interactions;
+    if (c.path_length_count > 0) {  // ReportValue's four accumulators (stats.h:340-346), all of the frame's paths at once
+        devPathLengthsum += (int64_t)c.path_length_sum; devPathLengthcount += (int64_t)c.path_length_count;
+        devPathLengthmin = std::min(devPathLengthmin, (int64_t)c.path_length_min); devPathLengthmax = std::max(devPathLengthmax, (int64_t)c.path_length_max);
+    }
+}
+
 void RenderOnDevice(const Scene &scene, const Camera &camera, const Sampler &sampler, const Bounds2i &pixelBounds, int maxDepth, Float rrThreshold,
                     const std::string &strategy, bool volumetric) {
     static Abi abi;
@@ -628,6 +650,7 @@ void RenderOnDevice(const Scene &scene, const Camera &camera, const Sampler &sam
         Die();
     }
     PgCounters c;
+    if (abi.counters(dev, &c) == PG_OK) ReportDeviceStats(c);
     if (abi.counters(dev, &c) == PG_OK)
         fprintf(stderr, "gpupath binding: %llu camera rays, %llu regular + %llu shadow ray intersection tests, %.1f ms on the device\n",
                 (unsigned long long)c.camera_rays, (unsigned long long)c.closest_rays, (unsigned long long)c.shadow_rays, c.render_ms);

@@ -991,17 +991,55 @@ def run(name, scene_path, outdir=GOLD):
     # a tile boundary that is a sum whose order depends on which thread merges its tile first)
     nthreads = "1" if name.startswith("filter_") or "maxmindist" in name else "4"
     txt = subprocess.run([ref, "--nthreads", nthreads, "--outfile", out, scene_path], capture_output=True, text=True, check=True).stdout
-    g = lambda pat: int(re.search(pat, txt).group(1)) if re.search(pat, txt) else 0  # a counter that stayed 0 is not printed (stats.cpp)
-    stats = {"camera_rays": g(r"Camera rays traced\s+(\d+)"),
-             "closest_rays": g(r"Regular ray intersection tests\s+(\d+)"),
-             "shadow_rays": g(r"Shadow ray intersection tests\s+(\d+)"),
-             "tri_tests": g(r"Ray-triangle intersection tests\s+\d+ /\s+(\d+)")}
+    stats = parse_stats(txt)
     json.dump(stats, open(os.path.join(outdir, name + ".json"), "w"))
     print(name, stats)
 
 
+def parse_stats(txt):
+    """The reference's printed statistics a golden keeps (stats.cpp:108-186; a counter that stayed 0 is not printed)."""
+    g = lambda pat: int(re.search(pat, txt).group(1)) if re.search(pat, txt) else 0
+    stats = {"camera_rays": g(r"Camera rays traced\s+(\d+)"),
+             "closest_rays": g(r"Regular ray intersection tests\s+(\d+)"),
+             "shadow_rays": g(r"Shadow ray intersection tests\s+(\d+)"),
+             "tri_tests": g(r"Ray-triangle intersection tests\s+\d+ /\s+(\d+)"),
+             # the integrators' own (path.cpp:45-46, volpath.cpp:45-47): PgCounters since ABI 28
+             "paths_zero_radiance": g(r"Zero-radiance paths\s+(\d+) /"), "paths_total": g(r"Zero-radiance paths\s+\d+ /\s+(\d+)"),
+             "volume_interactions": g(r"Volume interactions\s+(\d+)"), "surface_interactions": g(r"Surface interactions\s+(\d+)")}
+    m = re.search(r"Path length\s+([0-9.]+) avg \[range (\d+) - (\d+)\]", txt)
+    if m: stats.update(path_length_avg=m.group(1), path_length_min=int(m.group(2)), path_length_max=int(m.group(3)))  # avg as printed: "%.3f" of sum / count
+    return stats
+
+
+def refresh_stats(paths):
+    """`make_golden.py --stats-only [scene.pbrt ...]`: re-run the reference on committed scenes and rewrite only their statistics (the image goes to a
+    scratch directory and must equal the committed one)."""
+    import tempfile
+    ref = os.path.join(HERE, "_ref", "pbrt_oracle")
+    for scene in paths:
+        name = os.path.basename(scene)[:-5]
+        with tempfile.TemporaryDirectory() as d:
+            out = os.path.join(d, name + ".pfm")
+            nthreads = "1" if name.startswith("filter_") or "maxmindist" in name else "4"
+            txt = subprocess.run([ref, "--nthreads", nthreads, "--outfile", out, scene], capture_output=True, text=True, check=True, timeout=1800).stdout
+            committed = scene[:-5] + ".pfm"
+            if os.path.exists(committed) and open(out, "rb").read() != open(committed, "rb").read():
+                sys.exit(f"{name}: the reference's image differs from the committed golden")
+        stats = parse_stats(txt)
+        old = json.load(open(scene[:-5] + ".json"))
+        for k in ("camera_rays", "closest_rays", "shadow_rays", "tri_tests"):
+            if old[k] != stats[k]: sys.exit(f"{name}: {k} {old[k]} -> {stats[k]}")
+        json.dump(stats, open(scene[:-5] + ".json", "w"))
+        print(name, {k: v for k, v in stats.items() if k.startswith(("path", "volume", "surface"))}, flush=True)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "--stats-only":
+        import glob
+        paths = sys.argv[2:] or sorted(glob.glob(os.path.join(GOLD, "*.pbrt")) + glob.glob(os.path.join(ROOT, "tests", "golden_large", "*.pbrt")) +
+                                       glob.glob(os.path.join(ROOT, "tests", "golden_large", "config0", "*.pbrt")))
+        return refresh_stats([q for q in paths if os.path.exists(q[:-5] + ".json")])  # (included geometry files have no statistics of their own)
     only = sys.argv[1:]
     write_test_images(GOLD)
     write_test_spds(GOLD)

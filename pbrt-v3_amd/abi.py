@@ -5,7 +5,7 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 27
+PG_ABI_VERSION = 28
 PG_SAMPLER_HALTON, PG_SAMPLER_SOBOL, PG_SAMPLER_RANDOM, PG_SAMPLER_STRATIFIED, PG_SAMPLER_ZEROTWO, PG_SAMPLER_MAXMINDIST = range(6)
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
@@ -164,7 +164,9 @@ class PgCounters(C.Structure):
                 ("closest_ms", C.c_double), ("shadow_ms", C.c_double), ("render_ms", C.c_double),
                 ("shade_launches", C.c_uint64), ("resolve_launches", C.c_uint64), ("shade_items", C.c_uint64),
                 ("mis_rays", C.c_uint64), ("shade_ms", C.c_double), ("resolve_ms", C.c_double),
-                ("generate_ms", C.c_double), ("film_ms", C.c_double), ("shading_modes", C.c_uint64)]
+                ("generate_ms", C.c_double), ("film_ms", C.c_double), ("shading_modes", C.c_uint64),
+                ("paths_total", C.c_uint64), ("paths_zero_radiance", C.c_uint64), ("path_length_sum", C.c_uint64), ("path_length_count", C.c_uint64),
+                ("path_length_min", C.c_uint64), ("path_length_max", C.c_uint64), ("volume_interactions", C.c_uint64), ("surface_interactions", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -1485,7 +1485,7 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                     if (overlap) HIP_TRY(hipEventRecord(s->evShadowed, sst));
                     if (int e = timedClosest(q[nxt], (float4 *)s->hitsMain.p, &q[3], hitsMis)) return e;
                     if (overlap) HIP_TRY(hipStreamWaitEvent(stream, s->evShadowed, 0));
-                    PG_TIMED(3, stream, launch_resolve(s->d, ps, q[cur], q[3], (const int *)s->occluded.p, (const float4 *)hitsMis, stream, cur));
+                    PG_TIMED(3, stream, launch_resolve(s->d, ps, q[cur], q[3], (const int *)s->occluded.p, (const float4 *)hitsMis, stream, cur, lightTests));
                     ++resolveLaunches;
                 }
                 // log this bounce's queue sizes
@@ -1657,6 +1657,18 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
         std::vector<unsigned long long> shards(PG_LIGHT_TEST_SHARDS * PG_LIGHT_TEST_STRIDE);
         HIP_TRY(hipMemcpy(shards.data(), lightTests, s->lightTests.bytes, hipMemcpyDeviceToHost));
         for (int i = 0; i < PG_LIGHT_TEST_SHARDS; ++i) lt += shards[(size_t)i * PG_LIGHT_TEST_STRIDE];
+        // the integrators' own statistics, words 1 .. 8 of the same shards (pg_kernels.h): like the light tests they run on from pg_counters_reset
+        PgCounters &c = s->counters;
+        c.paths_total = c.paths_zero_radiance = c.path_length_sum = c.path_length_count = c.path_length_min = c.path_length_max = c.volume_interactions = c.surface_interactions = 0;
+        unsigned long long minc = 0, maxp = 0;
+        for (int i = 0; i < PG_LIGHT_TEST_SHARDS; ++i) {
+            const unsigned long long *sh = &shards[(size_t)i * PG_LIGHT_TEST_STRIDE];
+            c.path_length_sum += sh[PG_STAT_LEN_SUM]; c.path_length_count += sh[PG_STAT_LEN_COUNT];
+            minc = std::max(minc, sh[PG_STAT_LEN_MINC]); maxp = std::max(maxp, sh[PG_STAT_LEN_MAXP]);
+            c.paths_total += sh[PG_STAT_PATHS]; c.paths_zero_radiance += sh[PG_STAT_PATHS_ZERO];
+            c.volume_interactions += sh[PG_STAT_VOLUME]; c.surface_interactions += sh[PG_STAT_SURFACE];
+        }
+        if (c.path_length_count > 0) { c.path_length_min = 0xffff - minc; c.path_length_max = maxp - 1; }
     }
     PgCounters &c = s->counters;
     c.camera_rays += cameraRays; c.closest_rays += closestRays; c.shadow_rays += shadowRays;

@@ -330,6 +330,17 @@ struct RenderParams {
 // atomics per launch on ONE word (about 88 per microsecond, MI355X_MICROARCH.md) had made k_shade wait for them for half its time.
 #define PG_LIGHT_TEST_SHARDS 256
 #define PG_LIGHT_TEST_STRIDE 16  // unsigned long longs between two shards (128 B)
+// The integrators' own statistics (PgCounters, ABI 28) in the same shards, words 1 .. 8 of a shard's line -- one set of atomics per WAVE
+// that has something to report, from wave-wide ballots / reductions: sums are added; the shortest path is kept as 65535 - length and the
+// longest as length + 1 under atomicMax, so that a zeroed shard means "no path yet"
+#define PG_STAT_LEN_SUM 1
+#define PG_STAT_LEN_COUNT 2
+#define PG_STAT_LEN_MINC 3
+#define PG_STAT_LEN_MAXP 4
+#define PG_STAT_PATHS 5
+#define PG_STAT_PATHS_ZERO 6
+#define PG_STAT_VOLUME 7
+#define PG_STAT_SURFACE 8
 struct TraceCounters {
     unsigned long long node_visits, tri_tests;
 };
@@ -391,7 +402,7 @@ void launch_sss_probe(const DScene &sc, SssState sss, int pass, RayQueue qin, co
 void launch_sss_exit(const DScene &sc, const RenderParams &rp, PathState st, SssState sss, RayQueue qnext, RayQueue qshadow, RayQueue qmis,
                      unsigned long long *lightTriTests, hipStream_t s, int nxt, bool vol, VolState vs);
 void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis, const int *occluded, const float4 *misHits, hipStream_t s,
-                    int cur = 0);
+                    int cur, unsigned long long *stats = nullptr);
 // VolPathIntegrator: the shading step with medium sampling (hitT = the hits' ray parameters), one step of the through rays of
 // `kind` (results of qin at hits[hitBase + i]; continued rays go to qout), and EstimateDirect's sums with transmittance
 // gridVertex / phase: scenes with a grid medium shade a vertex in two launches (phase 1, transmittance rays, resolve, phase 2); 0 = one pass

@@ -107,6 +107,25 @@ PG_DEV unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
+// ReportValue(pathLength, bounces) of the Li calls that end in this wave (path.cpp:186, volpath.cpp:187): every lane of the block calls it
+PG_DEV void stats_path_end(unsigned long long *shards, bool ended, int len) {
+    const unsigned long long m = __ballot(ended);
+    if (m == 0) return;
+    const unsigned long long sum = wave_sum(ended ? (unsigned long long)len : 0ull);
+    int mn = ended ? len : 0xffff, mx = ended ? len : -1;
+    for (int off = 32; off > 0; off >>= 1) { const int a = __shfl_down(mn, off), b = __shfl_down(mx, off); mn = a < mn ? a : mn; mx = b > mx ? b : mx; }
+    if (lane_id() == 0) {
+        unsigned long long *sh = shards + (blockIdx.x & (PG_LIGHT_TEST_SHARDS - 1)) * PG_LIGHT_TEST_STRIDE;
+        atomicAdd(sh + PG_STAT_LEN_SUM, sum); atomicAdd(sh + PG_STAT_LEN_COUNT, (unsigned long long)__popcll(m));
+        atomicMax(sh + PG_STAT_LEN_MINC, (unsigned long long)(0xffff - mn)); atomicMax(sh + PG_STAT_LEN_MAXP, (unsigned long long)(mx + 1));
+    }
+}
+// a counter of the same shards raised by the number of lanes for which `pred` holds
+PG_DEV void stats_count(unsigned long long *shards, int word, bool pred) {  // (the lanes that are active call it: the first of them for which pred holds adds)
+    const unsigned long long m = __ballot(pred);
+    if (m != 0 && lane_id() == __ffsll(m) - 1) atomicAdd(shards + (blockIdx.x & (PG_LIGHT_TEST_SHARDS - 1)) * PG_LIGHT_TEST_STRIDE + word, (unsigned long long)__popcll(m));
+}
+
 struct Tri { V3 p0, p1, p2; uint32_t flags; int material, light; };
 PG_DEV Tri load_tri(const DScene &sc, int prim) {
     float4 a = sc.tris[PG_TRI_STRIDE * prim], b = sc.tris[PG_TRI_STRIDE * prim + 1], c = sc.tris[PG_TRI_STRIDE * prim + 2];
@@ -2240,6 +2259,9 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
     // see below) the kernel stays at 159 - 161 registers without scratch (profiles/r04j_bxdf_list_ab.txt).  (Not MODE 0: 2 KB more LDS
     // per block would cost it a resident block)
     __shared__ float s_pre[EXT ? 4 : 1][PG_SHADE_BLOCK];
+    // for the integrator's statistics at the end of the kernel (nothing of them is held in a register across it): the bounce count the path arrived
+    // with, | 0x4000: this vertex is one of volpath's volumeInteractions, | 0x8000: of its surfaceInteractions
+    __shared__ unsigned short s_stat[PG_SHADE_BLOCK];
     const int tid = threadIdx.x;
     bool pushNext = false, pushShadow = false, pushMis = false;
     int slot = 0;
@@ -2297,6 +2319,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
         };
         float etaScale = __int_as_float(meta.z);  // path.cpp:79
         int bounces = meta.w & 0xffff;
+        s_stat[tid] = (unsigned short)bounces;
         const bool specularBounce = (meta.w & PG_META_SPECULAR) != 0;
         const bool found = prim >= 0;
         // VOL: the ray's medium (index + 1); volpath.cpp:76-78 samples it before anything else happens at the vertex
@@ -2398,6 +2421,8 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
         if constexpr (VOL) {
             if (volDead) alive = false;
             else if (inMedium) alive = bounces < rd.max_depth;  // volpath.cpp:83
+            // ++volumeInteractions / ++surfaceInteractions (volpath.cpp:87, :99): noted in LDS, counted at the end of the kernel
+            if (!phaseB && !volDead) s_stat[tid] = (unsigned short)(bounces | (inMedium ? (alive ? 0x4000 : 0) : 0x8000));
             if (phaseB) alive = vertexKind == 1 || vertexKind == 2;
             if (alive && inMedium) {
                 vertexKind = 1;
@@ -2613,6 +2638,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
                 if constexpr (EXT) hasNonSpecular = lbsdf_num_components(lb, nonSpecular) > 0;
                 else hasNonSpecular = bsdf.nBxDFs > 0 && !bsdf.specular;
                 // ---- direct lighting: UniformSampleOneLight (integrator.cpp:85-106) + EstimateDirect set-up
+                if (!VOL && hasNonSpecular && sc.nLights == 0) lightNum = -2;  // (still one of path.cpp:121's totalPaths -- and a zero-radiance one: k_resolve counts pdInfo.z != -1)
                 const bool wantLight = (VOL || hasNonSpecular) && sc.nLights > 0 && !phaseB;  // path.cpp:119: only with non-specular lobes (volpath.cpp:124-127: always)
                 const float *tab = wantLight ? light_distribution(sc, is.p) : nullptr;
                 if (wantLight && !tab) deferred = true;
@@ -2864,6 +2890,18 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
     }
     unsigned long long nl = wave_sum(nLightTests);
     if (lane_id() == 0 && nl) atomicAdd(lightTriTests + (blockIdx.x & (PG_LIGHT_TEST_SHARDS - 1)) * PG_LIGHT_TEST_STRIDE, nl);
+    {   // the integrator's statistics (PgCounters, ABI 28).  "Path length" of the paths that end at this vertex: ReportValue(pathLength, bounces), path.cpp:186,
+        // with `bounces` of the reference's loop = the count the path arrived with (a scattering vertex has raised the stored one since).  A path that goes on
+        // through a BSSRDF reports in k_sss_exit; a grid scene's vertex reports in the phase that finishes it
+        bool ended = valid && !deferred && !pushNext && !pushJob;
+        if constexpr (GRID) ended = ended && (phaseA ? vertexKind == 0 : vertexKind != 0);
+        const int code = valid ? s_stat[tid] : 0;
+        stats_path_end(lightTriTests, ended, code & 0x3fff);
+        if constexpr (VOL) {  // (a deferred vertex is shaded again by the retry launch)
+            stats_count(lightTriTests, PG_STAT_VOLUME, !deferred && (code & 0x4000));
+            stats_count(lightTriTests, PG_STAT_SURFACE, !deferred && (code & 0x8000));
+        }
+    }
 }
 // Material::ComputeScatteringFunctions ahead of the shading launch, for the main-queue entries whose hit has a material with
 // textured parameters: the interaction (as k_shade builds it), what textures read of it (tex_hit_setup), Material::Bump and the
@@ -3074,11 +3112,15 @@ void launch_shade_vol(const DScene &sc, const RenderParams &rp, PathState st, Vo
 // L += beta * Ld / lightPdf (integrator.cpp:104, path.cpp:122-126), once both rays are back.
 template <bool EXT>
 __global__ __launch_bounds__(PG_BLOCK) void k_resolve(DScene sc, PathState st, RayQueue qin, RayQueue qmis, const int *__restrict__ occluded,
-                                                       const float4 *__restrict__ misHits, QueueState qsNext) {
+                                                       const float4 *__restrict__ misHits, QueueState qsNext, unsigned long long *stats) {
+    // stats != nullptr: the launch over a bounce's main queue counts "Zero-radiance paths" (path.cpp:119-126): a vertex whose pdInfo names a light
+    // (k_shade chose one: its BSDF has non-specular BxDFs) is one of totalPaths, and one of zeroRadiancePaths when its Ld comes out black
     const int i = queue_item<>(qin);
-    if (i < 0) return;
-    const int4 info = st.pdInfo[i];  // the pending terms lie in queue order (PathState)
-    if (info.x < 0 && info.y < 0) return;  // Ld == 0: L += beta * 0 leaves L unchanged
+    int4 info = make_int4(-1, -1, -1, 0);
+    if (i >= 0) info = st.pdInfo[i];  // the pending terms lie in queue order (PathState)
+    const bool counted = stats && i >= 0 && info.z != -1;
+    bool black = true;
+    if (i >= 0 && !(info.x < 0 && info.y < 0)) {  // (else Ld == 0: L += beta * 0 leaves L unchanged)
     const float4 pl = st.pdLight[i], pm = st.pdMis[i], pb = st.pdBeta[i];
     Spec Ld = sp(0);
     if (info.x >= 0 && !occluded[info.x]) Ld = Ld + sp3(pl.x, pl.y, pl.z);
@@ -3108,15 +3150,22 @@ __global__ __launch_bounds__(PG_BLOCK) void k_resolve(DScene sc, PathState st, R
     // the path's L: with its ray in the next queue's state, or -- the path is over -- in its slot
     float4 *Lp = info.w >= 0 ? &qsNext.L[info.w] : &st.L[~info.w];
     const float4 L4 = *Lp;
-    const Spec L = sp3(L4.x, L4.y, L4.z) + sp3(pb.x, pb.y, pb.z) * (Ld / pl.w);
+    const Spec add = sp3(pb.x, pb.y, pb.z) * (Ld / pl.w);  // beta * UniformSampleOneLight(...)
+    black = is_black(add);
+    const Spec L = sp3(L4.x, L4.y, L4.z) + add;
     *Lp = make_float4(L.r, L.g, L.b, L4.w);
+    }
+    if (stats) {  // (uniform over the launch)
+        stats_count(stats, PG_STAT_PATHS, counted);
+        stats_count(stats, PG_STAT_PATHS_ZERO, counted && black);
+    }
 }
 void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis, const int *occluded, const float4 *misHits, hipStream_t s,
-                    int cur) {
+                    int cur, unsigned long long *stats) {
     int nblk = PG_REGIONS * (qin.regionCap / PG_BLOCK);
     if (nblk == 0) return;
-    if (sc.ext) hipLaunchKernelGGL(k_resolve<true>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, qin, qmis, occluded, misHits, st.qs[cur ^ 1]);
-    else hipLaunchKernelGGL(k_resolve<false>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, qin, qmis, occluded, misHits, st.qs[cur ^ 1]);
+    if (sc.ext) hipLaunchKernelGGL(k_resolve<true>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, qin, qmis, occluded, misHits, st.qs[cur ^ 1], stats);
+    else hipLaunchKernelGGL(k_resolve<false>, dim3(nblk), dim3(PG_BLOCK), 0, s, sc, st, qin, qmis, occluded, misHits, st.qs[cur ^ 1], stats);
 }
 
 // ===========================================================================
@@ -3664,6 +3713,9 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_sss_exit(DScene sc, RenderPa
     }
     unsigned long long nl = wave_sum(nLightTests);
     if (lane_id() == 0 && nl) atomicAdd(lightTriTests + (blockIdx.x & (PG_LIGHT_TEST_SHARDS - 1)) * PG_LIGHT_TEST_STRIDE, nl);
+    // "Path length" of the paths that end inside the BSSRDF branch (path.cpp:157-174: no probe hit, a black S or f, Russian roulette): the
+    // reference's `bounces` is the entry vertex's, the stored count less k_shade's increment
+    stats_path_end(lightTriTests, j >= 0 && !pushNext, j >= 0 ? (st.meta[slot].w & 0xffff) - 1 : 0);
 }
 void launch_sss_exit(const DScene &sc, const RenderParams &rp, PathState st, SssState sss, RayQueue qnext, RayQueue qshadow, RayQueue qmis,
                      unsigned long long *lightTriTests, hipStream_t s, int nxt, bool vol, VolState vs) {

@@ -45,6 +45,33 @@ def oracle(pkg):
     return o
 
 
+def check_integrator_stats(cn, stats):
+    """PgCounters' integrator statistics (ABI 28) against what the reference binary printed for a golden ("Integrator/Zero-radiance paths", "Path length",
+    "Volume interactions", "Surface interactions": path.cpp:45-46, volpath.cpp:45-47; oracle/make_golden.py parse_stats): exactly, the average as printed."""
+    if "paths_total" not in stats: return
+    for k in ("paths_total", "paths_zero_radiance", "volume_interactions", "surface_interactions"):
+        assert cn[k] == stats[k], (k, cn[k], stats[k])
+    if "path_length_avg" in stats:
+        assert cn["path_length_count"] > 0
+        got = "%.3f" % (cn["path_length_sum"] / cn["path_length_count"])  # stats.cpp:141-147
+        assert (got, cn["path_length_min"], cn["path_length_max"]) == (stats["path_length_avg"], stats["path_length_min"], stats["path_length_max"]), \
+            ("path length", got, cn["path_length_min"], cn["path_length_max"], stats)
+    else: assert cn["path_length_count"] == 0
+
+
+def parse_reference_stats(txt):
+    """What a run of the reference binary (or of the binding built on it) printed, in a golden's keys: oracle/make_golden.py parse_stats."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(ROOT, "oracle", "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.parse_stats(txt)
+
+
+INTEGRATOR_STATS = ("paths_total", "paths_zero_radiance", "path_length_sum", "path_length_count", "path_length_min", "path_length_max", "volume_interactions",
+                    "surface_interactions")  # PgCounters, ABI 28: device == CPU restatement, field for field
+
+
 def golden_names():
     return sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLD, "*.json")))
 

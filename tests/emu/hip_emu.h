@@ -106,6 +106,7 @@ __host__ inline float atomicAdd(float *p, float v) { return emu_atomic_add(p, v)
 __host__ inline int atomicOr(int *p, int v) { int o = *p; *p = o | v; return o; }
 __host__ inline unsigned atomicOr(unsigned *p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
 __host__ inline int atomicMax(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
+__host__ inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
 __host__ inline int atomicMin(int *p, int v) { int o = *p; if (v < o) *p = v; return o; }
 __host__ inline int atomicExch(int *p, int v) { int o = *p; *p = v; return o; }
 __host__ inline int atomicCAS(int *p, int c, int v) { int o = *p; if (o == c) *p = v; return o; }

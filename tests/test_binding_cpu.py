@@ -10,7 +10,9 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLD, ROOT
+import json
+
+from conftest import GOLD, ROOT, parse_reference_stats
 from test_gpu_binding import BINDING, SCENES
 
 SHIM = os.path.join(ROOT, "oracle", "liboracle_abi_shim.so")
@@ -34,6 +36,11 @@ def test_binding_flattening_is_exact(pkg, shim, name, tmp_path):
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     img, ref = pkg.read_pfm(out), pkg.read_pfm(os.path.join(GOLD, name + ".pfm"))
     assert img.shape == ref.shape and np.array_equal(img, ref), f"{(img != ref).any(axis=2).sum()} pixels differ, max |d| {np.abs(img - ref).max():.3e}"
+    # the statistics the reference prints after the render are the CPU integrator's: the binding hands PgCounters to the reference's own
+    # StatsAccumulator under the reference's titles (gpupath_binding.cpp ReportDeviceStats).  (Not the ray-triangle line: a hit count is not kept.)
+    printed, want = parse_reference_stats(p.stdout), json.load(open(os.path.join(GOLD, name + ".json")))
+    for k in want:
+        if k != "tri_tests": assert printed.get(k, 0 if isinstance(want[k], int) else None) == want[k], (k, printed.get(k), want[k])
 
 
 def test_binding_reports_what_it_cannot_flatten(shim, tmp_path):

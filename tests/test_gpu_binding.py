@@ -9,7 +9,9 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLD, ROOT
+import json
+
+from conftest import GOLD, ROOT, parse_reference_stats
 
 pytestmark = pytest.mark.gpu  # module-level constants are shared with tests/test_binding_cpu.py
 BINDING = os.path.join(ROOT, "oracle", "_ref", "pbrt_gpubind")
@@ -37,6 +39,7 @@ def run_binding(pkg, scene_file, out):
     env = dict(os.environ, PBRT_GPU_LIB=pkg.GPU_LIB_PATH)
     p = subprocess.run([BINDING, "--outfile", out, scene_file], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    run_binding.stdout = p.stdout
     return pkg.read_pfm(out)
 
 
@@ -47,6 +50,11 @@ def test_reference_front_end_plus_device_equals_reference_image(gpu, name, tmp_p
     assert img.shape == ref.shape
     # the unmodified reference's parser, scene construction, BVHAccel and Film around the device kernels: the reference's own image, bit for bit
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), f"{(img != ref).any(axis=2).sum()} pixels differ from the reference binary's image"
+    # and the reference's printed statistics (rays, zero-radiance paths, path length, volume / surface interactions): the device's counters under the
+    # reference's own titles (gpupath_binding.cpp ReportDeviceStats) = what the CPU integrator printed for the golden
+    printed, want = parse_reference_stats(run_binding.stdout), json.load(open(os.path.join(GOLD, name + ".json")))
+    for k in want:
+        if k != "tri_tests": assert printed.get(k, 0 if isinstance(want[k], int) else None) == want[k], (k, printed.get(k), want[k])
     # the same scene through this repository's own front end: identical film, bit for bit (same nodes, same primitive order,
     # same BxDF lists -- the specialised matte / plastic / mirror / glass kernels equal the BxDF-list kernels exactly)
     own, _ = gpu.render_scene(gpu.HostScene(os.path.join(GOLD, name + ".pbrt")))

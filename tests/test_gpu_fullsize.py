@@ -10,7 +10,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, check_integrator_stats
 
 pytestmark = pytest.mark.gpu
 LARGE = os.path.join(ROOT, "tests", "golden_large")
@@ -50,6 +50,7 @@ def test_million_triangle_geometry_matches_reference(gpu, synthetic_dir):
     stats = json.load(open(os.path.join(LARGE, "synthetic_1m.json")))
     for k in ("camera_rays", "closest_rays", "shadow_rays", "tri_tests"):
         assert cn[k] == stats[k], (k, cn[k], stats[k])
+    check_integrator_stats(cn, stats)
 
 
 def test_million_triangle_rays_bit_exact_vs_oracle(gpu, oracle, synthetic_dir):
@@ -121,6 +122,7 @@ def test_config2_cornell_quarter_size_vs_reference(gpu):
     stats = json.load(open(os.path.join(LARGE, "cornell_128.json")))
     for k in ("camera_rays", "closest_rays", "shadow_rays", "tri_tests"):
         assert cn[k] == stats[k], (k, cn[k], stats[k])
+    check_integrator_stats(cn, stats)
 
 
 CONFIG0 = os.path.join(LARGE, "config0", "config0.pbrt")
@@ -149,6 +151,7 @@ def test_config0_killeroo_simple_vs_reference(gpu, oracle, order, monkeypatch):
     stats = json.load(open(os.path.join(LARGE, "config0", "config0.json")))
     for k in ("camera_rays", "closest_rays", "shadow_rays") + (("tri_tests",) if order == "reference" else ()):
         assert cn[k] == stats[k], (k, cn[k], stats[k])
+    check_integrator_stats(cn, stats)
     ofilm, ostrays, ocn = oracle.render(scene.desc, rd)
     assert np.array_equal(film["rgb"], ofilm["rgb"]) and np.array_equal(film["weight"], ofilm["weight"]) and len(strays) == len(ostrays)
     if order == "reference":

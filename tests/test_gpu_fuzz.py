@@ -8,7 +8,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import GOLD, ROOT
+from conftest import GOLD, INTEGRATOR_STATS, ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -397,7 +397,7 @@ def check_scene(gpu, oracle, text, seed):
     assert len(a) == len(b)
     for f in ("px", "py", "src_px", "src_py", "weight", "rgb"):
         assert np.array_equal(a[f], b[f]), f
-    for k in ("camera_rays", "closest_rays", "shadow_rays", "tri_tests", "node_visits"):
+    for k in ("camera_rays", "closest_rays", "shadow_rays", "tri_tests", "node_visits") + INTEGRATOR_STATS:
         assert cn[k] == ocn[k], (k, cn[k], ocn[k])
     # the PRODUCT'S DEFAULT: shadow rays in free order (k_trace<2, .>: the child the ray enters first).  Same occlusion answers, so the
     # same film, strays and ray counts; only the two statistics that count what a traversal read (triangle tests, node visits) may differ.
@@ -414,7 +414,7 @@ def check_scene(gpu, oracle, text, seed):
     assert len(c) == len(b)
     for f in ("px", "py", "src_px", "src_py", "weight", "rgb"):
         assert np.array_equal(c[f], b[f]), f
-    for k in ("camera_rays", "closest_rays", "shadow_rays"):
+    for k in ("camera_rays", "closest_rays", "shadow_rays") + INTEGRATOR_STATS:
         assert fcn[k] == ocn[k], (k, fcn[k], ocn[k])
     # rays through the same soup: bit-exact, including the reference's counters
     rng = np.random.default_rng(1000 + seed)

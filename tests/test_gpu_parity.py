@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLD, golden_names
+from conftest import GOLD, INTEGRATOR_STATS, check_integrator_stats, golden_names
 from kat_util import jittered_sphere  # noqa: F401
 from test_reference_kats import quadric_reintersect_run, reintersect_cases, sphere_scene, watertight_rays
 
@@ -27,7 +27,7 @@ def rel_err(img, ref):
 @pytest.mark.parametrize("name", golden_names())
 def test_golden_images(gpu, oracle, name):
     """The device image against the image the UNMODIFIED reference binary rendered: IDENTICAL, every pixel, every bit -- and its
-    statistics (camera / regular / shadow rays, ray-triangle tests) equal the reference's printed counters exactly.  No tolerance and
+    statistics (camera / regular / shadow rays, ray-triangle tests, the integrator's path statistics) equal the reference's printed counters exactly.  No tolerance and
     no exempted pixels: until round 3 the device evaluated sinf / cosf / acosf / atan2f / logf / expf in double (correctly rounded),
     glibc's float versions are not, and a last-bit difference there could tip a discrete event of a sample a few bounces later
     (2 pixels per image were exempted, 0.5 - 2 % in the noise-bump and subsurface scenes, whole tiles under the tile-serial samplers).
@@ -41,6 +41,7 @@ def test_golden_images(gpu, oracle, name):
     stats = json.load(open(os.path.join(GOLD, name + ".json")))
     for k in ("camera_rays", "closest_rays", "shadow_rays", "tri_tests"):
         assert cn[k] == stats[k], (k, cn[k], stats[k])
+    check_integrator_stats(cn, stats)  # zero-radiance paths, path length, volume / surface interactions as the reference printed them
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -60,7 +61,7 @@ def test_film_bit_identical_to_oracle(gpu, oracle, name):
     assert len(a) == len(b)
     for f in ("px", "py", "src_px", "src_py", "weight", "rgb"):
         assert np.array_equal(a[f], b[f]), f
-    for k in ("camera_rays", "closest_rays", "shadow_rays", "tri_tests", "node_visits"):  # the reference's counters, exactly
+    for k in ("camera_rays", "closest_rays", "shadow_rays", "tri_tests", "node_visits") + INTEGRATOR_STATS:  # the reference's counters, exactly
         assert cn[k] == ocn[k], (k, cn[k], ocn[k])
     gs.close()
 
