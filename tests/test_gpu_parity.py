@@ -545,3 +545,26 @@ def test_exact_fallback_when_a_ray_outruns_the_cull_margin(gpu, oracle, monkeypa
     assert np.array_equal(prim, op) and np.array_equal(t, ot) and np.array_equal(bary, ob)
     assert gs.counters()["closest_node_visits"] == oc["node_visits"]
     gs.close()
+
+
+@pytest.mark.parametrize("name", ["cornell_32", "vol_fog"])
+def test_integrator_statistics_run_on_across_frames(gpu, name):
+    """PgCounters' integrator statistics (ABI 28) are folded from the device's shards after every frame: a second frame doubles the sums, leaves the
+    shortest / longest path where they were, pg_counters_reset zeroes all of them (the reference's statistics likewise run on until they are printed)."""
+    scene = gpu.HostScene(os.path.join(GOLD, name + ".pbrt"))
+    gs = gpu.GpuScene(scene.desc)
+    rd = scene.render_desc()
+    gs.render(rd)
+    one = gs.counters()
+    stats = json.load(open(os.path.join(GOLD, name + ".json")))
+    check_integrator_stats(one, stats)
+    gs.render(rd)
+    two = gs.counters()
+    for k in ("paths_total", "paths_zero_radiance", "path_length_sum", "path_length_count", "volume_interactions", "surface_interactions"):
+        assert two[k] == 2 * one[k], k
+    assert (two["path_length_min"], two["path_length_max"]) == (one["path_length_min"], one["path_length_max"])
+    gs.counters_reset()
+    assert all(gs.counters()[k] == 0 for k in INTEGRATOR_STATS)
+    gs.render(rd)
+    check_integrator_stats(gs.counters(), stats)
+    gs.close()
