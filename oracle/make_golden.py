@@ -904,6 +904,21 @@ GRID_SCENES = {
     # PathIntegrator ignores media (path.cpp): the "none" box is simply passed through
     "grid_path_ignores": cornell(24, 24, 4, world_edit=with_grid_puff),
 }
+# A GridDensityMedium AND subsurface materials in one scene (VolPathIntegrator::Li handles both in one loop, volpath.cpp:76-176; the device refused the
+# pair until round 6): the entry vertex's ratio-tracking draws come before its BSDF / Sample_S draws, the exit vertex's between its light sample and
+# its next direction.  (Defined below GRID_SCENES / SSS_SCENES' helpers; merged into GRID_SCENES at the end of the SSS block.)
+GRID_SSS_SCENES = lambda: {
+    "grid_sss_puff": cornell(32, 32, 8, integrator='Integrator "volpath" "integer maxdepth" [ 5 ]', world_edit=lambda s: with_sss(with_grid_puff(s), SSS_PLAIN)),
+    "grid_sss_dense_delta": cornell(32, 32, 8, integrator='Integrator "volpath" "integer maxdepth" [ 6 ] "string lightsamplestrategy" "uniform"',
+                                    world_edit=lambda s: with_sss(with_grid_puff(s, dense=True), SSS_PLAIN, tall='Material "matte" "rgb Kd" [ 0.6 0.6 0.3 ]')
+                                    .replace("# light\nAttributeBegin", DELTA_POINT + DELTA_SPOT + "# light\nAttributeBegin")),
+    "grid_sss_fog_camera": cornell(32, 24, 8, integrator='Integrator "volpath" "integer maxdepth" [ 5 ]', world_edit=lambda s: with_sss(with_grid_fog(s), SSS_PLAIN)),
+    "grid_sss_random": cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 5 ]', world_edit=lambda s: with_sss(with_grid_puff(s, dense=True), SSS_PLAIN))
+                       .replace('Sampler "halton"', 'Sampler "random"'),
+    "grid_sss_sobol": cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 6 ]', world_edit=lambda s: with_sss(with_grid_puff(s), SSS_PLAIN))
+                      .replace('Sampler "halton"', 'Sampler "sobol"'),
+    "grid_sss_motion": with_moving_boxes(cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 5 ]', world_edit=lambda s: with_sss(with_grid_puff(s), SSS_PLAIN))),
+}
 
 
 # ---- Subsurface scattering: SubsurfaceMaterial / KdSubsurfaceMaterial + the BSSRDF branch of PathIntegrator::Li / VolPathIntegrator::Li
@@ -981,6 +996,9 @@ SSS_SCENES = {
     "sss_stratified": cornell(24, 24, 4, integrator='Integrator "path" "integer maxdepth" [ 6 ]', world_edit=lambda s: with_sss(s, SSS_PLAIN))
                       .replace('Sampler "halton" "integer pixelsamples" [ 4 ]', 'Sampler "stratified" "integer xsamples" [ 2 ] "integer ysamples" [ 2 ] "integer dimensions" [ 6 ]'),
 }
+
+
+GRID_SCENES.update(GRID_SSS_SCENES())
 
 
 def run(name, scene_path, outdir=GOLD):

@@ -129,8 +129,6 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         return setError(PG_ERR_INVALID, "pg_scene_create: malformed geometry arrays");
     if (desc->n_grids < 0 || (desc->n_grids > 0 && (!desc->grids || !desc->media_grid || !desc->grid_density)))
         return setError(PG_ERR_INVALID, "pg_scene_create: malformed grid-medium tables");
-    if (desc->n_grids > 0 && desc->n_bssrdfs > 0)  // (each needs its own extra phase between a vertex's direct lighting and its next ray)
-        return setError(PG_ERR_UNSUPPORTED, "a scene with both a GridDensityMedium and subsurface (BSSRDF) materials");
     if (desc->n_bssrdfs < 0 || (desc->n_bssrdfs > 0 && (!desc->bssrdfs || !desc->material_bssrdf || !desc->bssrdf_tables)))
         return setError(PG_ERR_INVALID, "pg_scene_create: malformed BSSRDF tables");
     int ndev = 0;
@@ -1389,7 +1387,7 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                     PG_TIMED(3, stream, launch_resolve_vol(dv, ps, vs, q[cur], stream, cur));
                     ++resolveLaunches;
                     if (gridOn) {  // phase 2: the vertices' next directions, drawn behind the transmittance rays' numbers
-                        PG_TIMED(2, stream, launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream, nullptr, gridVertex, 2));
+                        PG_TIMED(2, stream, launch_shade_vol(dv, rp, ps, vs, q[cur], (const float4 *)s->hitsMain.p, hitT, q[nxt], q[2], q[3], lightTests, stream, sssArg, gridVertex, 2));
                         ++shadeLaunches;
                         if (int e = readCounts()) return e;
                     }
@@ -1423,11 +1421,14 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
                                 }
                             }
                             HIP_TRY(hipMemsetAsync(counts + 2 * QSTRIDE, 0, 2 * QSTRIDE * sizeof(int), stream));
-                            launch_sss_exit(dv, rp, ps, sq, q[nxt], q[2], q[3], lightTests, stream, nxt, true, vs);
+                            // (a grid medium's ratio tracking draws from the paths' samplers: the exit vertices' transmittance rays run between their direct
+                            // lighting and their next directions, as at k_shade's vertices -- k_sss_exit in two phases; gridVertex is free again by now)
+                            launch_sss_exit(dv, rp, ps, sq, q[nxt], q[2], q[3], lightTests, stream, nxt, true, vs, gridOn ? 1 : 0, gridVertex);
                             ++shadeLaunches; shadeItems += nJobs;
                             if (int e = throughRays()) return e;
                             launch_resolve_vol(dv, ps, vs, sq.qjob, stream);
                             ++resolveLaunches;
+                            if (gridOn) { launch_sss_exit(dv, rp, ps, sq, q[nxt], q[2], q[3], lightTests, stream, nxt, true, vs, 2, gridVertex); ++shadeLaunches; }
                         }
                         if (int e = readCounts()) return e;
                     }

@@ -400,7 +400,7 @@ void launch_shade(const DScene &sc, const RenderParams &rp, PathState st, RayQue
 // sss.qjob: Pdf_Sp / Sr, direct lighting (shadow / MIS rays, pending terms at the job's queue index) and the next ray (appended to qnext)
 void launch_sss_probe(const DScene &sc, SssState sss, int pass, RayQueue qin, const float4 *hits, RayQueue qout, hipStream_t s, bool vol = false, bool first = false);
 void launch_sss_exit(const DScene &sc, const RenderParams &rp, PathState st, SssState sss, RayQueue qnext, RayQueue qshadow, RayQueue qmis,
-                     unsigned long long *lightTriTests, hipStream_t s, int nxt, bool vol, VolState vs);
+                     unsigned long long *lightTriTests, hipStream_t s, int nxt, bool vol, VolState vs, int phase = 0, float4 *exitVertex = nullptr);
 void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis, const int *occluded, const float4 *misHits, hipStream_t s,
                     int cur, unsigned long long *stats = nullptr);
 // VolPathIntegrator: the shading step with medium sampling (hitT = the hits' ray parameters), one step of the through rays of

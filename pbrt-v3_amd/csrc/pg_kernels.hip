@@ -2231,7 +2231,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
     // MODE 3: MODE 1 over the lists k_material left for the hits on materials with textured parameters (rp.matPre)
     constexpr bool EXT = MODE >= 1, TEX = MODE == 2, PRE = MODE == 3;
     static_assert(!PRE || (!SSS && !GRID), "materials evaluated ahead: the plain path / volpath kernels");
-    static_assert(!GRID || (VOL && !SSS), "grid media: volpath, without BSSRDF materials");
+    static_assert(!GRID || VOL, "grid media: volpath");
     const bool phaseA = GRID && gsh.phase == 1, phaseB = GRID && gsh.phase == 2;
     int vertexKind = 0;  // GRID: what phase 1 found at this entry (phase 2 reads it back)
     static_assert(!SSS || EXT, "materials with a BSSRDF are BxDF-list materials");
@@ -3091,7 +3091,10 @@ void launch_shade_vol(const DScene &sc, const RenderParams &rp, PathState st, Vo
     const SssState nosss = {};
     const GridShade gsh = {gridVertex, phase};
     const int mode = pg_shade_mode(sc, rp, true, sss != nullptr, phase != 0);
-    if (phase != 0) {  // a scene with a grid medium: the two-phase kernels
+    if (phase != 0 && sss && sc.nBssrdfs > 0) {  // a grid medium AND BSSRDF materials: the second phase hands a path that goes on through a BSSRDF to the probe chains
+        if (mode == 2) hipLaunchKernelGGL((k_shade<2, true, true, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, *sss, gsh);
+        else hipLaunchKernelGGL((k_shade<1, true, true, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, *sss, gsh);
+    } else if (phase != 0) {  // a scene with a grid medium: the two-phase kernels
         if (mode == 2) hipLaunchKernelGGL((k_shade<2, true, false, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss, gsh);
         else hipLaunchKernelGGL((k_shade<1, true, false, true>), dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, qin, hits, qnext, qshadow, qmis, lightTriTests, vs, hitT, none, none, nosss, gsh);
     } else if (sss && sc.nBssrdfs > 0) {
@@ -3466,7 +3469,10 @@ PG_DEV Spec ad_sample_f(const AdapterBsdf &b, V3 woW, V3 &wiW, float u0, float u
 // stay apart for k_resolve_vol, every pending term and the path's state are indexed by slot -- and the next ray starts in pi.GetMedium(wi).
 template <bool VOL>
 __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_sss_exit(DScene sc, RenderParams rp, PathState st, SssState sss, RayQueue qnext, RayQueue qshadow,
-                                                            RayQueue qmis, unsigned long long *lightTriTests, QueueState qsOut, VolState vs) {
+                                                            RayQueue qmis, unsigned long long *lightTriTests, QueueState qsOut, VolState vs, int phase, float4 *exitVertex) {
+    // phase (VOL, a scene with a GridDensityMedium): 1 = up to the exit vertex's direct lighting -- its transmittance rays draw ratio tracking's numbers from the
+    // path's sampler BEFORE the next direction is drawn (integrator.cpp:146-150, then path.cpp:165-173), as at k_shade's vertices --, 2 = the next direction and
+    // Russian roulette, once those rays are through and k_resolve_vol has added the lighting; exitVertex[slot].w says which jobs phase 1 left alive.  0: all at once.
     const int j = queue_item<PG_SHADE_BLOCK>(sss.qjob);
     __shared__ float4 s_ray[3][2][PG_SHADE_BLOCK];
     const int tid = threadIdx.x;
@@ -3478,9 +3484,10 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_sss_exit(DScene sc, RenderPa
     bool alive = false;
     if (j >= 0) {
         slot = __float_as_int(sss.qjob.d[j].w);
-        st.pdInfo[VOL ? slot : j] = make_int4(-1, -1, -1, VOL ? 0 : ~slot);
+        if (phase != 2) st.pdInfo[VOL ? slot : j] = make_int4(-1, -1, -1, VOL ? 0 : ~slot);
         const int2 cnt = sss.count[slot];
         alive = cnt.x > 0;  // bssrdf.cpp:318: no hit on the material: Sample_Sp returns black and the path ends (its L is in its slot)
+        if (phase == 2) alive = __float_as_int(exitVertex[slot].w) == 1;
     }
     const int pdi = VOL ? slot : j;  // index of this vertex's pending direct-light terms
     float volWeight = 0;
@@ -3543,11 +3550,15 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_sss_exit(DScene sc, RenderPa
         const float4 cs = sss.coef[0][slot], cr = sss.coef[1][slot];
         b.sigma_t[0] = cs.x; b.sigma_t[1] = cs.y; b.sigma_t[2] = cs.z; b.rho[0] = cr.x; b.rho[1] = cr.y; b.rho[2] = cr.z;
         const int nFound = sss.count[slot].x;
-        float pdf = bssrdf_pdf_sp(b, mk(f1.x, f1.y, f1.z), mk(f2.x, f2.y, f2.z), mk(f0.x, f0.y, f0.z), poP, is.p, is.n) / nFound;
-        const Spec S = bssrdf_sr(b, sqrtf(lensq(poP - is.p)));
-        if (is_black(S) || pdf == 0) alive = false;
+        bool through = true;  // S and its pdf let the path through (phase 2: phase 1 found that, and beta has the factor)
+        if (phase != 2) {
+            const float pdf = bssrdf_pdf_sp(b, mk(f1.x, f1.y, f1.z), mk(f2.x, f2.y, f2.z), mk(f0.x, f0.y, f0.z), poP, is.p, is.n) / nFound;
+            const Spec S = bssrdf_sr(b, sqrtf(lensq(poP - is.p)));
+            through = !(is_black(S) || pdf == 0);
+            if (through) beta = beta * (S / pdf);
+        }
+        if (!through) alive = false;
         else {
-            beta = beta * (S / pdf);
             // Sample_S's BSDF at pi (bssrdf.cpp:243-248): shading frame of pi, the adapter; pi.wo = pi.shading.n
             AdapterBsdf ab;
             ab.ns = is.ns; ab.ng = is.n; ab.ss = normalize(is.sdpdu); ab.ts = cross(ab.ns, ab.ss); ab.eta = f0.w;
@@ -3556,6 +3567,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_sss_exit(DScene sc, RenderPa
             int mIn = 0, mOut = 0;  // VOL: pi's MediumInterface (the primitive's own, or the medium of the probe ray that found it)
             if constexpr (VOL) prim_interface(sc, prim, sss.medium[slot].y, mIn, mOut);
             // ---- L += beta * UniformSampleOneLight(pi, ...) (path.cpp:161-163; integrator.cpp:85-215)
+            if (phase != 2) {
             const float *tab = sc.nLights > 0 ? light_distribution(sc, is.p) : nullptr;
             bool misCand = false;
             V3 misRo = mk(0, 0, 0), misWi = mk(0, 0, 1);
@@ -3659,13 +3671,15 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_sss_exit(DScene sc, RenderPa
                     if constexpr (VOL) vs.trAcc[1][slot] = make_float4(1, 1, 1, __int_as_float(misMedium));
                 }
             }
+            }
+            int newFlags = phase == 1 ? (meta.w & 0xf0000) : 0;  // (phase 1 leaves the flags as they came)
+            if (phase != 1) {
             // ---- indirect illumination from pi (path.cpp:165-173), then Russian roulette (:176-184)
             V3 wi;
             float pdf2, u0, u1;
             draw2(u0, u1);
             int sampledType = 0;
             const Spec f = ad_sample_f(ab, is.wo, wi, u0, u1, pdf2, PG_BSDF_ALL, sampledType);
-            int newFlags = 0;
             if (!(is_black(f) || pdf2 == 0.f)) {
                 beta = beta * ((f * absdot(wi, ab.ns)) / pdf2);
                 if (sampledType & PG_BSDF_SPECULAR) newFlags |= PG_META_SPECULAR;
@@ -3682,6 +3696,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_sss_exit(DScene sc, RenderPa
                     if (draw1() < qq) pushNext = false;
                     else beta = beta / (1 - qq);
                 }
+            }
             }
             outL = make_float4(L.r, L.g, L.b, L4.w);
             outB = make_float4(beta.r, beta.g, beta.b, B4.w);
@@ -3705,7 +3720,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_sss_exit(DScene sc, RenderPa
     if (alive) {
         if constexpr (VOL) {  // by slot: L is there already (k_resolve_vol adds to it), beta and meta follow
             st.beta[slot] = outB; st.meta[slot] = outM;
-            st.pdInfo[slot] = make_int4(posShadow, posMis, lightNum, __float_as_int(volWeight));
+            if (phase != 2) st.pdInfo[slot] = make_int4(posShadow, posMis, lightNum, __float_as_int(volWeight));
         } else {
             if (pushNext) { qsOut.L[posNext] = outL; qsOut.beta[posNext] = outB; qsOut.meta[posNext] = outM; }  // (L itself already is in the slot)
             st.pdInfo[j] = make_int4(posShadow, posMis, lightNum, pushNext ? posNext : ~slot);
@@ -3715,14 +3730,16 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_sss_exit(DScene sc, RenderPa
     if (lane_id() == 0 && nl) atomicAdd(lightTriTests + (blockIdx.x & (PG_LIGHT_TEST_SHARDS - 1)) * PG_LIGHT_TEST_STRIDE, nl);
     // "Path length" of the paths that end inside the BSSRDF branch (path.cpp:157-174: no probe hit, a black S or f, Russian roulette): the
     // reference's `bounces` is the entry vertex's, the stored count less k_shade's increment
-    stats_path_end(lightTriTests, j >= 0 && !pushNext, j >= 0 ? (st.meta[slot].w & 0xffff) - 1 : 0);
+    // (two phases: a job reports where it ends -- in phase 1 when the exit vertex did not come about, in phase 2 otherwise)
+    if (VOL && phase == 1 && j >= 0) exitVertex[slot] = make_float4(0, 0, 0, __int_as_float(alive ? 1 : 0));
+    stats_path_end(lightTriTests, j >= 0 && !pushNext && (phase == 0 || (phase == 1) != alive), j >= 0 ? (st.meta[slot].w & 0xffff) - 1 : 0);
 }
 void launch_sss_exit(const DScene &sc, const RenderParams &rp, PathState st, SssState sss, RayQueue qnext, RayQueue qshadow, RayQueue qmis,
-                     unsigned long long *lightTriTests, hipStream_t s, int nxt, bool vol, VolState vs) {
+                     unsigned long long *lightTriTests, hipStream_t s, int nxt, bool vol, VolState vs, int phase, float4 *exitVertex) {
     int nblk = PG_REGIONS * (sss.qjob.regionCap / PG_SHADE_BLOCK);
     if (nblk == 0) return;
-    if (vol) hipLaunchKernelGGL(k_sss_exit<true>, dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, sss, qnext, qshadow, qmis, lightTriTests, st.qs[nxt], vs);
-    else hipLaunchKernelGGL(k_sss_exit<false>, dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, sss, qnext, qshadow, qmis, lightTriTests, st.qs[nxt], vs);
+    if (vol) hipLaunchKernelGGL(k_sss_exit<true>, dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, sss, qnext, qshadow, qmis, lightTriTests, st.qs[nxt], vs, phase, exitVertex);
+    else hipLaunchKernelGGL(k_sss_exit<false>, dim3(nblk), dim3(PG_SHADE_BLOCK), 0, s, sc, rp, st, sss, qnext, qshadow, qmis, lightTriTests, st.qs[nxt], vs, 0, (float4 *)nullptr);
 }
 
 // ===========================================================================

@@ -79,6 +79,17 @@ def test_round5_kernels_on_the_emulated_device(emulated):
     assert " passed" in out and "failed" not in out
 
 
+def test_round6_kernels_on_the_emulated_device(emulated):
+    """What round 6 changed on the device: a GridDensityMedium and BSSRDF materials in ONE scene (k_shade<., VOL, SSS, GRID>, k_sss_exit in two phases around the
+    exit vertex's transmittance rays), the integrator statistics of ABI 28 (test_golden_images compares them with the reference binary's printed ones), k_material's
+    lists by position in the shading order and the triangles' attribute records (the textured stand-in)."""
+    select = "test_golden_images and (grid_sss_sobol or grid_sss_motion or divergent_small or tex_image)"
+    out = run_gpu_tests(emulated, ["tests/test_gpu_parity.py"], select, 1500)
+    assert " passed" in out and "failed" not in out
+    out = run_gpu_tests(emulated, ["tests/test_gpu_parity.py"], "test_integrator_statistics_run_on", 600)
+    assert " passed" in out and "failed" not in out
+
+
 def test_moving_shapes_and_instances_on_the_emulated_device(emulated):
     """Round 5, last: TransformedPrimitive over an AnimatedTransform on the device -- the queues carry the rays' times, k_trace<., XP_ANIM>
     interpolates a moving instance's transform (and inverts it: Gauss-Jordan of the blended scale) at the ray's time when it enters the

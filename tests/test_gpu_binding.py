@@ -30,7 +30,9 @@ SCENES = ["cornell_32", "cornell_crop", "cornell_lens", "cornell_plastic", "corn
           "motion_instances_shutter", "motion_sobol", "motion_random", "motion_stratified", "motion_vol", "motion_camera_too",
           # motions that rotate (hasRotation): the binding keeps the reference's own BVH, this repository's front end computes MotionBounds itself
           "motion_rotate_boxes", "motion_rotate_big_times", "motion_rotate_instances", "motion_rotate_distant_spatial", "motion_rotate_vol",
-          "motion_rotate_camera_too"]
+          "motion_rotate_camera_too",
+          # a GridDensityMedium, BSSRDF materials, and both in one scene (round 6: the device refused the pair before)
+          "grid_puff", "sss_subsurface", "grid_sss_puff", "grid_sss_random"]
 
 
 def run_binding(pkg, scene_file, out):

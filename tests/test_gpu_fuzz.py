@@ -373,6 +373,13 @@ def test_random_sss_or_grid_scene_film_matches_oracle(gpu, oracle, seed):
     check_scene(gpu, oracle, random_scene_sss_grid(seed, "sss" if seed % 2 else "grid"), seed)
 
 
+@pytest.mark.parametrize("seed", range(48))
+def test_random_sss_and_grid_scene_film_matches_oracle(gpu, oracle, seed):
+    """BOTH in one scene (round 6; the device refused the pair before): VolPathIntegrator::Li's loop with medium sampling, ratio tracking and the BSSRDF branch
+    (volpath.cpp:76-176) -- the entry vertex in two shading phases, then the probe chains, then the exit vertex in two phases of its own (k_sss_exit)."""
+    check_scene(gpu, oracle, random_scene_sss_grid(seed, "both"), seed)
+
+
 @pytest.mark.parametrize("seed", [59, 68])
 def test_grid_scene_keeps_the_specular_flag_across_a_material_less_surface(gpu, oracle, seed):
     """Two scenes of a 300-scene sweep on the GPU (tools/fuzz_emulated_device.py): a path leaves a specular surface, crosses the
