@@ -20,6 +20,14 @@ const char *pg_last_error(void) { return g_err; }
 int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
     if (!desc || !out) { g_err = "pg_scene_create: null argument"; return PG_ERR_INVALID; }
     if (desc->abi_version != PG_ABI_VERSION) { g_err = "ABI version mismatch"; return PG_ERR_INVALID; }
+    for (int k = 0; k < desc->n_bssrdfs; ++k) {  /* what libpbrt_gpu.so refuses (pg_abi.hip, "BSSRDF %d: ... out of range"), refused here too: a host that passes the shim passes the device */
+        const PgBSSRDF *b = &desc->bssrdfs[k];
+        const int64_t need = (int64_t)b->n_rho + b->n_radius + 2 * (int64_t)b->n_rho * b->n_radius + b->n_rho;
+        if (b->n_rho < 2 || b->n_radius < 2 || b->table < 0 || b->table + need > desc->n_bssrdf_floats || b->match_material < 0 ||
+            b->match_material >= desc->n_materials || b->a.tex >= desc->n_textures || b->b.tex >= desc->n_textures) {
+            g_err = "BSSRDF: table / material / texture out of range"; return PG_ERR_INVALID;
+        }
+    }
     PgScene *s = (PgScene *)calloc(1, sizeof(PgScene));
     s->desc = desc;
     *out = s;

@@ -405,6 +405,7 @@ void FlattenScene(const Scene &scene, int maxDepth, bool volumetric, const std::
                     PgBSSRDF pb;
                     memset(&pb, 0, sizeof(pb));
                     pb.eta = sa.eta;
+                    pb.a.tex = pb.b.tex = -1;  // constants (textured == 0): sigma_t / rho below are final
                     for (int c = 0; c < 3; ++c) { pb.sigma_t[c] = sa.sigma_t[c]; pb.rho[c] = sa.rho[c]; }
                     const BSSRDFTable &t = *sa.table;
                     pb.n_rho = t.nRhoSamples; pb.n_radius = t.nRadiusSamples;
