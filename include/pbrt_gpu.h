@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 28
+#define PG_ABI_VERSION 29
 
 typedef enum PgStatus {
     PG_OK = 0,
@@ -61,7 +61,11 @@ typedef struct PgBVHNode {
 #define PG_TRI_HAS_S 16u      /* mesh has per-vertex tangents         */
 #define PG_PRIM_SPHERE 32u    /* not a triangle: spheres[indices[3*k]] (PgSphere below) */
 #define PG_TRI_ALPHA 128u      /* the mesh has an alpha / shadow-alpha texture: alphas[tri_alpha[k]] (triangle.cpp:333-338, :531-569) */
-#define PG_PRIM_INSTANCE 64u  /* a TransformedPrimitive: instances[indices[3*k]] (PgInstance below); top level only */
+#define PG_PRIM_INSTANCE 64u  /* a TransformedPrimitive: instances[indices[3*k]] (PgInstance below).  Among the top-level primitives, and -- ABI 29 --
+                                 among an object definition's: pbrtShape under an animated transformation between ObjectBegin and ObjectEnd adds its
+                                 TransformedPrimitive to the instance being defined (api.cpp:1386-1419), so a hit can lie under two transforms, the
+                                 ObjectInstance's around the moving shape's.  One level: the object such a primitive wraps holds shapes only (the
+                                 reference has no ObjectInstance inside a definition, api.cpp:1549-1552). */
 
 typedef enum PgMaterialType {
     PG_MAT_NONE = 0,   /* no material: primitive is a medium boundary (bsdf == nullptr) */
@@ -277,7 +281,8 @@ typedef struct PgSphere {       /* a quadric: the record began as the sphere's a
 /* Object instancing (api.cpp:1509-1588).  An object definition is a run of primitives in the primitive arrays after the
  * n_tris top-level ones and, when it has more than one primitive, its own BVHAccel: a run of nodes after the n_nodes
  * top-level ones, laid out exactly as that BVHAccel's LinearBVHNode array (child / primitive offsets relative to the
- * object's own first node / first primitive).  An instance is a top-level primitive with PG_PRIM_INSTANCE. */
+ * object's own first node / first primitive).  An instance is a primitive with PG_PRIM_INSTANCE: top-level, or (ABI 29) a moving
+ * shape's TransformedPrimitive inside another object definition's run. */
 typedef struct PgObject {
     int32_t first_node, n_nodes; /* n_nodes == 0: a single primitive without an accelerator (api.cpp:1567) */
     int32_t first_prim, n_prims;

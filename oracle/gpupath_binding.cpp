@@ -271,8 +271,11 @@ void FlattenScene(const Scene &scene, int maxDepth, bool volumetric, const std::
     std::vector<const Primitive *> all;
     for (const auto &pr : bvh->primitives) all.push_back(pr.get());
     std::map<const Primitive *, int> objectIndex;
-    std::vector<int> instanceOf(nTop, -1);
-    for (size_t k = 0; k < nTop; ++k) {
+    // (`all` grows inside the loop: a TransformedPrimitive among an object's primitives -- a moving shape inside an object definition,
+    // api.cpp:1386-1419 -- wraps an object of its own, found when the loop reaches it: PG_PRIM_INSTANCE inside an object's run, ABI 29)
+    std::vector<int> instanceOf;
+    for (size_t k = 0; k < all.size(); ++k) {
+        instanceOf.resize(all.size(), -1);
         const TransformedPrimitive *tp = dynamic_cast<const TransformedPrimitive *>(all[k]);
         if (!tp) continue;
         const Primitive *inner = tp->primitive.get();
@@ -284,7 +287,10 @@ void FlattenScene(const Scene &scene, int maxDepth, bool volumetric, const std::
                 o.n_nodes = CountNodes(on); o.n_prims = (int)ob->primitives.size();
                 flat->nodes.insert(flat->nodes.end(), on, on + o.n_nodes);
                 for (const auto &pr : ob->primitives) all.push_back(pr.get());
-            } else if (dynamic_cast<const GeometricPrimitive *>(inner)) { o.n_nodes = 0; o.n_prims = 1; all.push_back(inner); }
+            } else if (dynamic_cast<const GeometricPrimitive *>(inner) || (k < nTop && dynamic_cast<const TransformedPrimitive *>(inner))) {
+                // one primitive, no accelerator (api.cpp:1567) -- a shape, or the definition's only primitive is a moving shape's TransformedPrimitive
+                o.n_nodes = 0; o.n_prims = 1; all.push_back(inner);
+            }
             else Unsupported("a TransformedPrimitive over something other than a BVHAccel or one GeometricPrimitive");
             objectIndex[inner] = (int)flat->objects.size();
             flat->objects.push_back(o);
@@ -305,10 +311,12 @@ void FlattenScene(const Scene &scene, int maxDepth, bool volumetric, const std::
                 for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) in.S[e][3 * i + j] = a.S[e].m[i][j];
             }
         }
+        instanceOf.resize(all.size(), -1);
         instanceOf[k] = (int)flat->instances.size();
         flat->instances.push_back(in);
     }
     const size_t n = all.size();
+    instanceOf.resize(n, -1);
     flat->indices.assign(3 * n, 0); flat->triFlags.assign(n, 0); flat->triMaterial.assign(n, 0); flat->triLight.assign(n, -1);
     std::map<const Light *, int> lightIndex;
     for (size_t i = 0; i < scene.lights.size(); ++i) lightIndex[scene.lights[i].get()] = (int)i;
@@ -320,9 +328,9 @@ void FlattenScene(const Scene &scene, int maxDepth, bool volumetric, const std::
     bool anyN = false, anyUV = false, anyS = false, anyMedium = false;
     // pass 1: vertex arrays of the meshes in first-use order
     for (size_t k = 0; k < n; ++k) {
-        if (k < nTop && instanceOf[k] >= 0) continue;
+        if (instanceOf[k] >= 0) continue;
         const GeometricPrimitive *gp = dynamic_cast<const GeometricPrimitive *>(all[k]);
-        if (!gp) Unsupported("a primitive that is neither a GeometricPrimitive nor a top-level TransformedPrimitive (a nested instance)");
+        if (!gp) Unsupported("a primitive that is neither a GeometricPrimitive nor a TransformedPrimitive");
         if (const Triangle *tri = dynamic_cast<const Triangle *>(gp->shape.get())) {
             const TriangleMesh *m = tri->mesh.get();
             if (!meshBase.count(m)) {
@@ -348,7 +356,7 @@ void FlattenScene(const Scene &scene, int maxDepth, bool volumetric, const std::
     }
     // pass 2: primitives in BVHAccel::primitives (= orderedPrims) order
     for (size_t k = 0; k < n; ++k) {
-        if (k < nTop && instanceOf[k] >= 0) {  // TransformedPrimitive: primitive.h:92-117
+        if (instanceOf[k] >= 0) {  // TransformedPrimitive: primitive.h:92-117
             flat->indices[3 * k] = instanceOf[k];
             flat->triFlags[k] = PG_PRIM_INSTANCE;
             continue;

@@ -509,6 +509,22 @@ def with_moving_instances(s, spin=("", "", "", "")):
     return s
 
 
+def with_nested_motion(s, tall="  Translate 30 20 -40\n  Rotate 20 0 1 0\n", ball="  Translate 70 10 0\n", tri="  Translate 10 30 0\n"):
+    """Moving SHAPES inside the object definitions of an instanced scene (with_instances / with_moving_instances): pbrtShape under an animated
+    transformation between ObjectBegin and ObjectEnd adds its TransformedPrimitive to the definition (api.cpp:1386-1419), so every ObjectInstance
+    of it is a TransformedPrimitive around a TransformedPrimitive.  "boxes": the tall box (a BVHAccel of its own) moves beside the still short box;
+    "ball": a second, moving sphere beside the still one; "tri": the definition's ONLY primitive moves (no accelerator at either level)."""
+    n0 = s.count("ActiveTransform EndTime")
+    s = s.replace('# tall box\nShape', '# tall box: moves inside the object definition\nActiveTransform EndTime\n' + tall + 'ActiveTransform All\nShape', 1)
+    s = s.replace('  Shape "sphere" "float radius" [ 40 ]\nObjectEnd', '  Shape "sphere" "float radius" [ 40 ]\n  ActiveTransform StartTime\n' + ball +
+                  '  ActiveTransform All\n  Material "matte" "rgb Kd" [ 0.2 0.3 0.8 ]\n  Shape "sphere" "float radius" [ 25 ]\nObjectEnd', 1)
+    s = s.replace('  Shape "trianglemesh" "integer indices" [ 0 1 2 ] "point P" [ 0 0 0  90 0 0  0 120 30 ]\nObjectEnd',
+                  '  ActiveTransform EndTime\n' + tri + '  ActiveTransform All\n  Shape "trianglemesh" "integer indices" [ 0 1 2 ] "point P" [ 0 0 0  90 0 0  0 120 30 ]\nObjectEnd', 1)
+    assert s.count("ActiveTransform EndTime") == n0 + 2 and s.count("ActiveTransform StartTime") >= 1
+    return s
+
+
+
 def cam_anim(s, end_motion, times=""):
     """Give the camera an end-of-motion transform: the directives `end_motion` act on the END transform only (ActiveTransform
     EndTime, api.cpp:395-403) on top of the LookAt both share, so CameraToWorld[0] != CameraToWorld[1]."""
@@ -800,6 +816,15 @@ SCENES = {
     "motion_rotate_vol": with_moving_instances(cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 4 ]', world_edit=lambda s: with_fog(s)),
                                                spin=("  Rotate -30 0.3 1 0\n", "  Rotate 45 0 1 1\n", "", "  Rotate 90 0 0 1\n")),
     "motion_rotate_camera_too": cam_anim(with_moving_boxes(cornell(32, 24, 8), short_motion="Rotate -60 0 1 0", tall_motion="Rotate 25 0 0 1\nTranslate 20 0 0"), "Translate 30 0 -40\nRotate 12 0.1 1 0.2"),
+    # moving shapes INSIDE object definitions (round 6, ABI 29): a TransformedPrimitive under the TransformedPrimitive of every ObjectInstance -- still and
+    # moving instances around them, a rotating inner motion, a shutter inside the motion, volpath through fog, the samplers over one RNG stream per tile
+    "nest_motion": with_nested_motion(with_instances(cornell(40, 32, 8))),
+    "nest_motion_moving_instances": with_nested_motion(with_moving_instances(cornell(32, 32, 4))).replace('Camera "perspective"', 'Camera "perspective" "float shutteropen" [ 0.3 ] "float shutterclose" [ 0.8 ]'),
+    "nest_motion_rotate": with_nested_motion(with_moving_instances(cornell(32, 32, 8), spin=("  Rotate 40 0 1 0.2\n", "  Rotate -75 1 0 0\n", "  Rotate 120 0 0 1\n", "  Rotate 60 1 1 0\n")),
+                                             tall="  Rotate 65 0.1 1 0\n  Translate 20 0 -30\n", ball="  Rotate 100 0 0 1\n  Translate 60 0 0\n", tri="  Rotate -45 1 0 0.3\n"),
+    "nest_motion_vol": with_nested_motion(with_moving_instances(cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 4 ]', world_edit=lambda s: with_fog(s)))),
+    "nest_motion_sobol": with_nested_motion(with_instances(cornell(24, 24, 4))).replace('Sampler "halton"', 'Sampler "sobol"'),
+    "nest_motion_random": with_sampler(with_nested_motion(with_moving_instances(cornell(24, 24, 4, integrator='Integrator "path" "integer maxdepth" [ 3 ]'))), '"random" "integer pixelsamples" [ 4 ]'),
     "motion_camera_too": cam_anim(with_moving_boxes(cornell(32, 24, 8)), "Translate 30 0 -40\nRotate 12 0.1 1 0.2"),
     "camanim_translate": cam_anim(cornell(32, 32, 8), "Translate 40 -20 60"),
     "camanim_rotate": cam_anim(cornell(32, 32, 8), "Translate 30 0 -40\nRotate 25 0.1 1 0.2"),

@@ -5,7 +5,7 @@ sizeof() of every struct against values compiled from the headers.
 """
 import ctypes as C
 
-PG_ABI_VERSION = 28
+PG_ABI_VERSION = 29
 PG_SAMPLER_HALTON, PG_SAMPLER_SOBOL, PG_SAMPLER_RANDOM, PG_SAMPLER_STRATIFIED, PG_SAMPLER_ZEROTWO, PG_SAMPLER_MAXMINDIST = range(6)
 PG_OK = 0
 PG_MEM_HOST, PG_MEM_DEVICE = 0, 1
@@ -15,6 +15,7 @@ PG_LIGHTS_UNIFORM, PG_LIGHTS_POWER, PG_LIGHTS_SPATIAL = 0, 1, 2
 PG_MAT_NONE, PG_MAT_MATTE, PG_MAT_PLASTIC, PG_MAT_MIRROR, PG_MAT_GLASS = 0, 1, 2, 3, 4
 PG_LIGHT_AREA, PG_LIGHT_POINT, PG_LIGHT_SPOT, PG_LIGHT_DISTANT, PG_LIGHT_INFINITE = 0, 1, 2, 3, 4
 PG_TRI_FLIP_NORMAL, PG_TRI_REVERSE_ORIENTATION, PG_TRI_HAS_N, PG_TRI_HAS_UV, PG_TRI_HAS_S = 1, 2, 4, 8, 16
+PG_PRIM_SPHERE, PG_PRIM_INSTANCE, PG_TRI_ALPHA = 32, 64, 128  # (PG_PRIM_INSTANCE: also inside an object definition since ABI 29)
 
 
 class PgBVHNode(C.Structure):

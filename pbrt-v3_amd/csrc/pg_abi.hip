@@ -284,9 +284,27 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
             const uint32_t f = desc->tri_flags ? desc->tri_flags[k] : 0;
             if (!(f & PG_PRIM_INSTANCE)) continue;
             const int ii = desc->indices[3 * k];
-            if (k >= desc->n_tris) FAIL(PG_ERR_UNSUPPORTED, "primitive %d: an object definition cannot contain an object instance", k);
             if (ii < 0 || ii >= desc->n_instances || !desc->instances || desc->instances[ii].object < 0 || desc->instances[ii].object >= desc->n_objects)
                 FAIL(PG_ERR_INVALID, "primitive %d: instance %d / its object out of range", k, ii);
+            if (k >= desc->n_tris) {
+                // ABI 29: a TransformedPrimitive among an object definition's primitives (a moving shape inside ObjectBegin / ObjectEnd, api.cpp:1386-1419):
+                // ONE level -- what it wraps holds shapes only, as in the reference, whose ObjectInstance cannot appear inside a definition (api.cpp:1549-1552)
+                const PgObject &inner = desc->objects[desc->instances[ii].object];
+                for (int q = inner.first_prim; q < inner.first_prim + inner.n_prims; ++q)
+                    if (q < 0 || q >= nt || (desc->tri_flags[q] & PG_PRIM_INSTANCE))
+                        FAIL(PG_ERR_UNSUPPORTED, "primitive %d: a TransformedPrimitive inside an object definition wraps another one (more than two levels)", k);
+                if (k >= inner.first_prim && k < inner.first_prim + inner.n_prims) FAIL(PG_ERR_INVALID, "primitive %d: an object definition contains itself", k);
+                d.hasNest = 1;
+            }
+        }
+        if (d.hasNest) {
+            // hitInst = outer + n_instances * (inner + 1) in an int; three BVHs share k_trace's stack
+            if ((int64_t)desc->n_instances * ((int64_t)desc->n_instances + 1) >= ((int64_t)1 << 31))
+                FAIL(PG_ERR_UNSUPPORTED, "%d instances in a scene with TransformedPrimitives inside object definitions: the pair (outer, inner) does not fit a hit's instance word", desc->n_instances);
+            if (worldPending + 2 * objectPending > 64 + s->trace.depth)
+                FAIL(PG_ERR_UNSUPPORTED, "world BVH (%d levels) + two object BVHs (%d levels) exceed the traversal stack of %d entries", worldPending, objectPending, 64 + s->trace.depth);
+            if (desc->n_bssrdfs > 0)
+                FAIL(PG_ERR_UNSUPPORTED, "a moving shape inside an object definition in a scene with BSSRDF materials: the probe chains carry one instance transform");
         }
         if (!objs.empty()) {
             HIP_TRY_S(s->objects.alloc(sizeof(DObject) * objs.size()));
@@ -740,7 +758,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         // build, counted as the materials' ComputeScatteringFunctions add them (materials/*.cpp; MatEval, pg_kernels.hip).  Not for scenes
         // with BSSRDF materials or grid media (their kernels evaluate inside), PG_MAT_PRE=0: nowhere.
         const char *mp = getenv("PG_MAT_PRE");
-        if (anyTextured && desc->n_bssrdfs == 0 && d.nGrids == 0 && !(mp && atoi(mp) == 0)) {
+        if (anyTextured && desc->n_bssrdfs == 0 && d.nGrids == 0 && !d.hasNest && !(mp && atoi(mp) == 0)) {  // (hasNest: MODE 2 carries the second transform)
             std::function<int(int, int)> lobes = [&](int mi, int depth) -> int {
                 if (mi < 0 || mi >= desc->n_materials) return 0;
                 const PgMaterial &m = desc->materials[mi];
@@ -1023,8 +1041,9 @@ static int ensureWorkBuffers(PgScene *s, int capacity) {
     }
     if (s->d.nInstances > 0) { HIP_TRY(s->hitInst.alloc(hitParts * n * sizeof(int))); s->d.hitInst = (int *)s->hitInst.p; }
     if (s->d.hasMotion) {  // InterpolatedPrimToWorld per closest-hit result on a moving instance (pg_motion.h)
-        HIP_TRY(s->animXf.alloc(hitParts * n * PG_XF_STRIDE * sizeof(float)));
+        HIP_TRY(s->animXf.alloc((s->d.hasNest ? 2 : 1) * hitParts * n * PG_XF_STRIDE * sizeof(float)));  // (hasNest: a second half for the inner transform)
         s->d.animXf = (float *)s->animXf.p;
+        s->d.nestXfOff = (int)(hitParts * n);
     }  // main-queue hits, then MIS-queue hits at offset n (one launch fills both)
     HIP_TRY(s->occluded.alloc(n * sizeof(int)));
     HIP_TRY(s->stL.alloc(n * sizeof(float4)));

@@ -81,7 +81,7 @@ struct DScene {
     int nNodes, nTris, nLights, nMaterials;
     const PgSphere *spheres;  // Shape "sphere" primitives: tris[3*k] = (sphere index, 0, 0, flags | PG_PRIM_SPHERE)
     int nSpheres;
-    const PgInstance *instances;  // TransformedPrimitives: tris[3*k] = (instance index, 0, 0, PG_PRIM_INSTANCE), top level only
+    const PgInstance *instances;  // TransformedPrimitives: tris[3*k] = (instance index, 0, 0, PG_PRIM_INSTANCE); inside an object definition only with hasNest
     const DObject *objects;
     const DInstEntry *instEntry;  // one per instance (see DInstEntry)
     int nInstances;
@@ -93,6 +93,13 @@ struct DScene {
     int hasMotion;
     int rayTimes;  // the render's queues carry their rays' times (queue_times); 0 in the unit entry points' copy: their rays have time 0
     float *animXf;
+    // ABI 29 -- a moving shape inside an object definition (api.cpp:1405-1418): a TransformedPrimitive among an instance's primitives, i.e. a hit can
+    // lie under TWO transforms.  hasNest says the scene has one: k_trace runs its XP_NEST instantiation (a second saved traversal context), hitInst then
+    // holds outer + nInstances * (inner + 1) (PG_NEST_OUTER / PG_NEST_INNER below; inner = -1: a hit one level deep) and the inner instance's interpolated
+    // matrices wait at animXf[PG_XF_STRIDE * (nestXfOff + i)] -- the buffer has two halves, every pointer offset applied to it moves both alike.
+    // Shading runs in MODE 2 (pg_shade_mode), the one kernel family that carries the second transform.
+    int hasNest;
+    int nestXfOff;
     const PgAlphaMask *alphas;           // alpha / shadow-alpha textures of meshes; triAlpha[k] indexes it for PG_TRI_ALPHA triangles
     const int *triAlpha;
     int hasAlpha;
@@ -389,6 +396,7 @@ void launch_shade_order_vol(const DScene &sc, const RenderParams &rp, PathState 
 // 1 a material's BxDF list, 3 the packed lists k_material wrote ahead of the launch, 2 the evaluators inside the shading kernel -- what scenes
 // with BSSRDF materials or grid media run, and what a textured scene FALLS BACK to when k_material's lists do not fit in memory.
 inline int pg_shade_mode(const DScene &sc, const RenderParams &rp, bool vol, bool sss, bool gridPhase) {
+    if (sc.hasNest) return 2;  // hits under two transforms (a moving shape inside an object definition): the general kernels carry the second one
     if (gridPhase || (sss && sc.nBssrdfs > 0)) return sc.hasTextured ? 2 : 1;
     if (sc.hasTextured) return rp.matPre.lobes ? 3 : 2;
     return (vol || sc.ext) ? 1 : 0;

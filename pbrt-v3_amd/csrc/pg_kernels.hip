@@ -2076,9 +2076,12 @@ PG_DEV void prim_interface(const DScene &sc, int prim, int rayMedium, int &mIn, 
 
 // InstanceToWorld, its inverse and IsIdentity of the instance closest-hit result `i` was reached through: the instance's own or -- a moving one --
 // PrimitiveToWorld.Interpolate(r.time), which k_trace<.., XP_ANIM> computed for the accepted hit's ray and left at animXf[i] (pg_motion.h)
-PG_DEV const float *inst_i2w(const DScene &sc, int inst, int i) { const PgInstance &in = sc.instances[inst]; return in.animated ? sc.animXf + (size_t)PG_XF_STRIDE * i : in.i2w; }
-PG_DEV const float *inst_w2i(const DScene &sc, int inst, int i) { const PgInstance &in = sc.instances[inst]; return in.animated ? sc.animXf + (size_t)PG_XF_STRIDE * i + 16 : in.w2i; }
-PG_DEV bool inst_identity(const DScene &sc, int inst, int i) { const PgInstance &in = sc.instances[inst]; return in.animated ? sc.animXf[(size_t)PG_XF_STRIDE * i + 32] != 0.f : in.identity != 0; }
+// (inner: the TransformedPrimitive INSIDE the object of a hit two levels deep, DScene::hasNest: its matrices wait in the buffer's second half)
+PG_DEV const float *inst_i2w(const DScene &sc, int inst, int i, bool inner = false) { const PgInstance &in = sc.instances[inst]; return in.animated ? sc.animXf + (size_t)PG_XF_STRIDE * ((inner ? (size_t)sc.nestXfOff : 0) + i) : in.i2w; }
+PG_DEV const float *inst_w2i(const DScene &sc, int inst, int i, bool inner = false) { const PgInstance &in = sc.instances[inst]; return in.animated ? sc.animXf + (size_t)PG_XF_STRIDE * ((inner ? (size_t)sc.nestXfOff : 0) + i) + 16 : in.w2i; }
+PG_DEV bool inst_identity(const DScene &sc, int inst, int i, bool inner = false) { const PgInstance &in = sc.instances[inst]; return in.animated ? sc.animXf[(size_t)PG_XF_STRIDE * ((inner ? (size_t)sc.nestXfOff : 0) + i) + 32] != 0.f : in.identity != 0; }
+// DScene::hasNest: a closest hit's instance word is outer + nInstances * (inner + 1); inner = -1 for a hit one level deep
+PG_DEV void nest_decode(const DScene &sc, int &inst, int &inst2) { inst2 = -1; if (sc.hasNest && inst >= 0) { inst2 = inst / sc.nInstances - 1; inst = inst % sc.nInstances; } }
 // InterpolatedPrimToWorld(*isect) of a hit reached through an object instance, transform.cpp:262-297
 PG_DEV void isect_to_world(const float *i2w, const float *w2i, Isect &is) {
     Isect w;
@@ -2094,7 +2097,7 @@ PG_DEV void isect_to_world(const float *i2w, const float *w2i, Isect &is) {
 }
 // What textures read of the SurfaceInteraction at main-queue entry i: (u, v), p and ComputeDifferentials' outputs
 // (interaction.cpp:101-147).  sph*: a quadric hit's (u, v) and geometric dpdu / dpdv; filmX / filmY: the camera sample's pFilm
-PG_DEV void tex_hit_setup(const DScene &sc, const PgRenderDesc &rd, const RayQueue &qin, int i, int slot, int prim, const Tri &tri, float4 h4, V3 rayD, int inst,
+PG_DEV void tex_hit_setup(const DScene &sc, const PgRenderDesc &rd, const RayQueue &qin, int i, int slot, int prim, const Tri &tri, float4 h4, V3 rayD, int inst, int inst2,
                           bool onSphere, float sphU, float sphV, V3 sphDpdu, V3 sphDpdv, const Isect &is, int4 meta, float filmX, float filmY,
                           bool tileSerial, bool pixelArrays, uint64_t index, TexHit &th) {
     th.p = is.p;
@@ -2107,6 +2110,7 @@ PG_DEV void tex_hit_setup(const DScene &sc, const PgRenderDesc &rd, const RayQue
         th.u = h4.y * uv[0] + h4.z * uv[2] + h4.w * uv[4];  // uvHit, triangle.cpp:332
         th.v = h4.y * uv[1] + h4.z * uv[3] + h4.w * uv[5];
     }
+    if (inst2 >= 0 && !inst_identity(sc, inst2, i, true)) { gdpdu = m4_vec(inst_i2w(sc, inst2, i, true), gdpdu); gdpdv = m4_vec(inst_i2w(sc, inst2, i, true), gdpdv); }  // (the inner transform first)
     if (inst >= 0 && !inst_identity(sc, inst, i)) { gdpdu = m4_vec(inst_i2w(sc, inst, i), gdpdu); gdpdv = m4_vec(inst_i2w(sc, inst, i), gdpdv); }
     th.dpdx = th.dpdy = mk(0, 0, 0);
     th.dudx = th.dvdx = th.dudy = th.dvdy = 0;
@@ -2384,13 +2388,19 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
         V3 sphDpdu = mk(0, 0, 0), sphDpdv = mk(0, 0, 0);
         const bool onSphere = EXT && found && (tri.flags & PG_PRIM_SPHERE);
         // a hit reached through an object instance was computed on the instance-space ray (primitive.cpp:80-82)
-        const int inst = (EXT && found && sc.hitInst) ? sc.hitInst[i] : -1;
+        int inst = (EXT && found && sc.hitInst) ? sc.hitInst[i] : -1;
+        // MODE 2 also shades the scenes whose hits can lie under TWO transforms (DScene::hasNest: a moving shape inside an object definition): the
+        // outer instance's, then the inner TransformedPrimitive's on the way in; InterpolatedPrimToWorld of the inner, then of the outer, on the way out
+        int inst2 = -1;
+        if constexpr (TEX) nest_decode(sc, inst, inst2);
         V3 shapeRayD = rayD;
         if (inst >= 0) shapeRayD = m4_vec(inst_w2i(sc, inst, i), rayD);
+        if (TEX && inst2 >= 0) shapeRayD = m4_vec(inst_w2i(sc, inst2, i, true), shapeRayD);
         if (onSphere) {  // the hit record of a sphere carries tHit: Sphere::Intersect's interaction from the ray and the root
             const float4 o4 = qin.o[i];
             V3 shapeRayO = mk(o4.x, o4.y, o4.z);
             if (inst >= 0) { float dt; instance_ray(inst_w2i(sc, inst, i), shapeRayO, rayD, shapeRayO, shapeRayD, dt); }
+            if (TEX && inst2 >= 0) { float dt; instance_ray(inst_w2i(sc, inst2, i, true), shapeRayO, shapeRayD, shapeRayO, shapeRayD, dt); }
             const SphereHit sh = sphere_interaction(sc.spheres[__float_as_int(tri.p0.x)], shapeRayO, shapeRayD, h4.y);
             is.p = sh.p; is.pError = sh.pError; is.wo = sh.wo; is.n = sh.n; is.ns = sh.n; is.sdpdu = sh.dpdu;
             is.sdpdv = sh.dpdv; is.sdndu = sh.dndu; is.sdndv = sh.dndv;
@@ -2510,6 +2520,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
         }
         if (alive && !handled) {
             if (!onSphere) is = make_isect(sc, prim, tri, h4.y, h4.z, h4.w, shapeRayD);
+            if (TEX && inst2 >= 0 && !inst_identity(sc, inst2, i, true)) isect_to_world(inst_i2w(sc, inst2, i, true), inst_w2i(sc, inst2, i, true), is);
             if (inst >= 0 && !inst_identity(sc, inst, i)) isect_to_world(inst_i2w(sc, inst, i), inst_w2i(sc, inst, i), is);
             const PgMaterial &m = mtl;
             int mIn = 0, mOut = 0;  // VOL: isect.mediumInterface
@@ -2542,7 +2553,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, MODE == 0 ? PG_SHADE0_WAVES : (((MO
                 if constexpr (EXT) {
                     TexHit th;
                     if constexpr (TEX) {
-                        tex_hit_setup(sc, rd, qin, i, slot, prim, tri, h4, rayD, inst, onSphere, sphU, sphV, sphDpdu, sphDpdv, is, meta, L4.w, B4.w, tileSerial,
+                        tex_hit_setup(sc, rd, qin, i, slot, prim, tri, h4, rayD, inst, inst2, onSphere, sphU, sphV, sphDpdu, sphDpdv, is, meta, L4.w, B4.w, tileSerial,
                                       pixelArrays, index, th);
                         material_bump(sc, tri.material, th, is);
                     }
@@ -2961,7 +2972,7 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK, PG_MATERIAL_WAVES) void k_material(
     float filmX = 0, filmY = 0;  // the camera sample's pFilm, for the camera ray's differentials
     if (meta.w & PG_META_HASDIFF) { filmX = bySlot ? st.L[slot].w : qsIn.L[i].w; filmY = bySlot ? st.beta[slot].w : qsIn.beta[i].w; }
     TexHit th;
-    tex_hit_setup(sc, rd, qin, i, slot, prim, tri, h4, rayD, inst, onSphere, sphU, sphV, sphDpdu, sphDpdv, is, meta, filmX, filmY, tileSerial, pixelArrays, index, th);
+    tex_hit_setup(sc, rd, qin, i, slot, prim, tri, h4, rayD, inst, -1, onSphere, sphU, sphV, sphDpdu, sphDpdv, is, meta, filmX, filmY, tileSerial, pixelArrays, index, th);
     material_bump<1>(sc, tri.material, th, is);
     int nl = 0;
     float etaL = 1;
@@ -3178,18 +3189,29 @@ void launch_resolve(const DScene &sc, PathState st, RayQueue qin, RayQueue qmis,
 // ===========================================================================
 // p, pError and n of the SurfaceInteraction of a closest hit (Triangle::Intersect / Sphere::Intersect, then the instance's
 // InterpolatedPrimToWorld), as k_shade builds them
+// NEST: the caller can meet hits under two transforms (k_through; the probe chains cannot: scenes with BSSRDF materials and such hits are refused)
+template <bool NEST>
 PG_DEV void through_point(const DScene &sc, int ri, float4 o4, V3 rayD, float4 h4, int prim, const Tri &tri, V3 &p, V3 &pError, V3 &n) {
-    const int inst = sc.hitInst ? sc.hitInst[ri] : -1;
+    int inst = sc.hitInst ? sc.hitInst[ri] : -1, inst2 = -1;
+    if constexpr (NEST) nest_decode(sc, inst, inst2);
     V3 shapeRayD = rayD;
     if (inst >= 0) shapeRayD = m4_vec(inst_w2i(sc, inst, ri), rayD);
+    if (inst2 >= 0) shapeRayD = m4_vec(inst_w2i(sc, inst2, ri, true), shapeRayD);
     if (tri.flags & PG_PRIM_SPHERE) {
         V3 shapeRayO = mk(o4.x, o4.y, o4.z);
         if (inst >= 0) { float dt; instance_ray(inst_w2i(sc, inst, ri), shapeRayO, rayD, shapeRayO, shapeRayD, dt); }
+        if (inst2 >= 0) { float dt; instance_ray(inst_w2i(sc, inst2, ri, true), shapeRayO, shapeRayD, shapeRayO, shapeRayD, dt); }
         const SphereHit sh = sphere_interaction(sc.spheres[__float_as_int(tri.p0.x)], shapeRayO, shapeRayD, h4.y);
         p = sh.p; pError = sh.pError; n = sh.n;
     } else {
         const Isect is = make_isect(sc, prim, tri, h4.y, h4.z, h4.w, shapeRayD);
         p = is.p; pError = is.pError; n = is.n;
+    }
+    if (inst2 >= 0 && !inst_identity(sc, inst2, ri, true)) {
+        V3 pe;
+        p = m4_point_err2(inst_i2w(sc, inst2, ri, true), p, pError, pe);
+        pError = pe;
+        n = normalize(m4_normal(inst_w2i(sc, inst2, ri, true), n));
     }
     if (inst >= 0 && !inst_identity(sc, inst, ri)) {
         V3 pe;
@@ -3252,7 +3274,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_through(DScene sc, PathState st, V
             } else if (surface) {
                 // a surface without a material: step over it (light.cpp:79 isect.SpawnRayTo(p1), scene.cpp:68 isect.SpawnRay(ray.d))
                 V3 p, pError, n;
-                through_point(sc, ri, o4, rayD, h4, prim, tri, p, pError, n);
+                through_point<true>(sc, ri, o4, rayD, h4, prim, tri, p, pError, n);
                 int mIn, mOut;
                 prim_interface(sc, prim, med, mIn, mOut);
                 V3 origin, d;
@@ -3388,7 +3410,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_sss_probe(DScene sc, SssState sss,
             }
             if (go) {  // base = next->si; base.SpawnRayTo(pTarget): interaction.h:65-71
                 V3 p, pError, n;
-                through_point(sc, i, o4, rayD, h4, prim, tri, p, pError, n);
+                through_point<false>(sc, i, o4, rayD, h4, prim, tri, p, pError, n);
                 const float4 tg = sss.target[slot];
                 const V3 d = mk(tg.x, tg.y, tg.z) - p;
                 if (!(d.x == 0 && d.y == 0 && d.z == 0)) {

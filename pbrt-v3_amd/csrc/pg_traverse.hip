@@ -152,6 +152,10 @@ PG_DEV unsigned long long tr_wave_sum(unsigned long long v) {
 #define XP_ALPHATEX 8
 #define XP_ANIM 16  // moving instances (PgInstance::animated): their transform is interpolated at the ray's time (with XP_INST only)
 #define XP_GENERAL (XP_INST | XP_QUADRIC | XP_ALPHATEX)
+// ABI 29: TransformedPrimitives inside object definitions (a moving shape between ObjectBegin and ObjectEnd, api.cpp:1386-1419): a lane keeps a SECOND saved
+// context (the rest of the instance's leaf, the instance ray's tMax, the visit bookkeeping, the stack floor) while it walks the inner object, and comes back
+// to the instance's ray by deriving it again from the queue entry and the outer transform.  With XP_ANIM | XP_GENERAL only: the feature's own instantiation.
+#define XP_NEST 32
 
 // MIPMap<Float>::Lookup(st, 0 width) of a DAlphaTex = `triangle(0, st)` (mipmap.h:231-243) with Texel's wrap modes (:189-212): the
 // operations of mip_triangle / mip_texel (pg_texture.h) on the red channel, in the same order.
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                                                     int hitOffset1, float *__restrict__ tOut, int *__restrict__ occluded,
                                                     TraceCounters *cn, int *__restrict__ cursors, int depth, int chunk, int refillAt, int triW,
                                                     float cullK, int *cullGuard, int maxAccepted) {
-    constexpr bool ANYHIT = KIND != 0, FREE = KIND == 2;
+    constexpr bool ANYHIT = KIND != 0, FREE = KIND == 2, NEST = (XP & XP_NEST) != 0;
     constexpr bool DIET = (XP & XP_INST) || (TR_FLAT_DIET & 1), HITSTORE = !ANYHIT && ((XP & XP_INST) || (TR_FLAT_DIET & 2)), NOSZ = (XP & XP_INST) || (TR_FLAT_DIET & 4);
     extern __shared__ uint2 ldsStack[];  // [depth][TR_BLOCK]
     uint2 spill[TR_STACK_TOTAL];
@@ -251,6 +255,12 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
     // (profiles/r03w_trace_step_statistics.txt; the gain is 3 % closest hit, 10 % any hit).  The alpha lookup as a third such step
     // (candidate hits waiting in the stack slots above the lane's top) LOSES 3 - 6 % at group sizes 2 / 4 / 8: r06_trace_inst_ab.txt.
     unsigned wLeaf = 0;  // the rest of the world leaf: next primitive << (leafBits + 1) | primitives left
+    // XP_NEST: the same one level further in -- the inner TransformedPrimitive's index, and what waits of the instance around it
+    int inInst2 = -1, hitInst2Cur = -1, spBase1 = 0, w2vd = 0;
+    unsigned w2Leaf = 0;
+    float w2tMax = 0;
+    bool instHit1 = false;
+    unsigned long long w2vmask = 0;
     bool instHit = false;
     float wtMax = 0;
     unsigned long long wvmask = 0;
@@ -278,8 +288,10 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
     // back after it); HITSTORE: the record goes to memory now (the last accepted one stays), not from registers when the ray retires
 #define TR_ACCEPT_CLOSEST(hit_, prim_, t_, b0_, b1_, b2_) do { tMax = (hit_) ? (t_) : tMax; \
         if (HITSTORE) { \
-            if (hit_) { hits[ray] = make_float4(__int_as_float(prim_), b0_, b1_, b2_); if ((XP & XP_INST) && sc.hitInst) sc.hitInst[ray] = inInst; } \
+            if (hit_) { hits[ray] = make_float4(__int_as_float(prim_), b0_, b1_, b2_); \
+                        if ((XP & XP_INST) && sc.hitInst) sc.hitInst[ray] = (NEST && inInst >= 0) ? inInst + sc.nInstances * (inInst2 + 1) : inInst; } \
             if (XP & XP_ANIM) hitInstCur = (hit_) ? inInst : hitInstCur; \
+            if (NEST) hitInst2Cur = (hit_) ? inInst2 : hitInst2Cur; \
         } else { \
             hb0 = (hit_) ? (b0_) : hb0; hb1 = (hit_) ? (b1_) : hb1; hb2 = (hit_) ? (b2_) : hb2; \
             if (XP & XP_INST) hitInstCur = (hit_) ? inInst : hitInstCur; \
@@ -288,6 +300,7 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
         if (ANYHIT) {  /* bvh.cpp:717: return true */ \
             triLeft = (hit_) ? 0 : triLeft; sp = (hit_) ? 0 : sp; vd = (hit_) ? 0 : vd; \
             if (XP & XP_INST) inInst = (hit_) ? -1 : inInst; \
+            if (NEST) inInst2 = (hit_) ? -1 : inInst2; \
         } else {  /* primitive.cpp:123: r.tMax = tHit */ \
             TR_ACCEPT_CLOSEST(hit_, prim_, t_, b0_, b1_, b2_); \
             if (XP & XP_INST) instHit = instHit || (hit_); \
@@ -323,6 +336,11 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                         float xf[PG_XF_STRIDE];
                         instance_matrices_at(sc.instances[hitInstCur], trace_ray_time(sc, q0, q1, ray, hitOffset1), xf);
                         for (int k = 0; k < 33; ++k) sc.animXf[(size_t)PG_XF_STRIDE * ray + k] = xf[k];
+                    }
+                    if (NEST && sc.animXf && hitInst2Cur >= 0 && sc.instances[hitInst2Cur].animated) {  // the inner transform of a hit two levels deep: the buffer's second half
+                        float xf[PG_XF_STRIDE];
+                        instance_matrices_at(sc.instances[hitInst2Cur], trace_ray_time(sc, q0, q1, ray, hitOffset1), xf);
+                        for (int k = 0; k < 33; ++k) sc.animXf[(size_t)PG_XF_STRIDE * ((size_t)sc.nestXfOff + ray) + k] = xf[k];
                     }
                     if (tOut) tOut[ray] = tMax;
                 }
@@ -375,6 +393,7 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                     nx = ix < 0; ny = iy < 0; nz = iz < 0; negBits = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);   // bvh.cpp:667
                     hitPrim = -1; hb0 = hb1 = hb2 = 0; nAccepted = 0;
                     inInst = -1; hitInstCur = -1; spBase = 0;
+                    if (NEST) { inInst2 = -1; hitInst2Cur = -1; }
                     sp = 0; vd = 0; vmask = 0;
                     if (sc.nNodes > 0) {
                         if (!WCNT) ++nodeVisits;  // nodes[0]
@@ -401,6 +420,29 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                 const bool nothingElse = __ballot(cur >= 0 || triLeft > 0) == 0;
                 if (nExit > 0 && (nExit >= TR_INST_GROUP || nothingElse)) {
                     TS_ADD(TS_EXIT_STEPS, 1); TS_ADD(TS_EXIT_LANES, nExit);
+                    if (NEST && wantExit && inInst2 >= 0) {
+                        // out of the inner TransformedPrimitive, back to the ray of the instance around it: the world ray carried into that instance
+                        // again (the entry step's operations on the entry step's inputs: the same bits), its tMax the saved one or the hit's
+                        if (!ANYHIT && instHit) w2tMax = tMax;  // r.tMax = ray.tMax (primitive.cpp:84)
+                        const bool fromQ1 = q1.regionCap > 0 && ray >= hitOffset1;
+                        const float4 o4 = fromQ1 ? q1.o[ray - hitOffset1] : q0.o[ray], d4 = fromQ1 ? q1.d[ray - hitOffset1] : q0.d[ray];
+                        float xf[PG_XF_STRIDE];
+                        const PgInstance &in1 = sc.instances[inInst];
+                        V3 o1, d1;
+                        float dt1;
+                        if (in1.animated) {
+                            instance_matrices_at(in1, trace_ray_time(sc, q0, q1, ray, hitOffset1), xf);
+                            instance_ray(xf + 16, mk(o4.x, o4.y, o4.z), mk(d4.x, d4.y, d4.z), o1, d1, dt1);
+                        } else instance_ray(in1.w2i, mk(o4.x, o4.y, o4.z), mk(d4.x, d4.y, d4.z), o1, d1, dt1);
+                        ox = o1.x; oy = o1.y; oz = o1.z; tMax = w2tMax;
+                        tr = tri_ray_setup(d1);
+                        ix = 1 / d1.x; iy = 1 / d1.y; iz = 1 / d1.z;
+                        nx = ix < 0; ny = iy < 0; nz = iz < 0; negBits = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+                        if (ANYHIT) { vd = w2vd; vmask = w2vmask; }
+                        triNext = (int)(w2Leaf >> (leafBits + 1)); triLeft = (int)(w2Leaf & ((2u << leafBits) - 1u)); inInst2 = -1; spBase = spBase1;
+                        instHit = instHit1 || instHit;  // a hit inside is a hit of the instance around it
+                        if (triLeft == 0) { TR_POP(); TR_SETTLE(); }
+                    } else
                     if (wantExit) {  // back to the world ray (primitive.cpp:83-88)
                         if (!ANYHIT && instHit) wtMax = tMax;  // r.tMax = ray.tMax
                         {
@@ -424,13 +466,28 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                         // TransformedPrimitive::Intersect[P]: carry the ray into the instance's space (Transform::operator()(Ray),
                         // transform.h:249-262) and start on its BVH
                         const bool fromQ1 = q1.regionCap > 0 && ray >= hitOffset1;
-                        const float4 d4 = fromQ1 ? q1.d[ray - hitOffset1] : q0.d[ray];
+                        float4 d4 = fromQ1 ? q1.d[ray - hitOffset1] : q0.d[ray];
                         const int idx = -2 - cur;
                         // one 96-byte record per instance (DInstEntry): the matrix rows the ray needs, the object's root box and references
                         const DInstEntry *obp = sc.instEntry + idx;
                         const DInstEntry &ob = *obp;
+                        const bool inner = NEST && inInst >= 0;  // a TransformedPrimitive met inside an instance: the ray to carry over is the instance's
+                        if (inner) {
+                            w2tMax = tMax;
+                            if (ANYHIT) { w2vd = vd; w2vmask = vmask; vd = 0; vmask = 0; }
+                            // its origin is in the registers; its direction is the world direction under the outer transform, once more
+                            const PgInstance &in1 = sc.instances[inInst];
+                            V3 d1;
+                            if (in1.animated) {
+                                float xf1[PG_XF_STRIDE];
+                                instance_matrices_at(in1, trace_ray_time(sc, q0, q1, ray, hitOffset1), xf1);
+                                d1 = m4_vec(xf1 + 16, mk(d4.x, d4.y, d4.z));
+                            } else d1 = m4_vec(in1.w2i, mk(d4.x, d4.y, d4.z));
+                            d4.x = d1.x; d4.y = d1.y; d4.z = d1.z;
+                        } else {
                         wtMax = tMax;
                         if (ANYHIT) { wvd = vd; wvmask = vmask; vd = 0; vmask = 0; }
+                        }
                         V3 oErr, o, dd;
                         if ((XP & XP_ANIM) && sc.instances[idx].animated) {  // PrimitiveToWorld.Interpolate(r.time, ...), primitive.cpp:78-80 / :99-101
                             float xf[PG_XF_STRIDE];
@@ -470,7 +527,9 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                         tr = tri_ray_setup(dd);
                         ix = 1 / dd.x; iy = 1 / dd.y; iz = 1 / dd.z;
                         nx = ix < 0; ny = iy < 0; nz = iz < 0; negBits = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
-                        inInst = idx; spBase = sp; instHit = false;
+                        if (inner) { inInst2 = idx; spBase1 = spBase; instHit1 = instHit; }
+                        else inInst = idx;
+                        spBase = sp; instHit = false;
                         triLeft = 0; cur = TR_NONE;
                         // the record's second half (root box, references) is read HERE: without the barrier the compiler issues all six loads of the
                         // record at the top of the step and the matrix and the box are live together -- the register peak of the whole kernel
@@ -514,7 +573,8 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                     // wave's next entry step with the rest of the world leaf put aside
                     if (!WCNT) --triTests;
                     notTri = true;
-                    wLeaf = ((unsigned)triNext << (leafBits + 1)) | (unsigned)triLeft;
+                    if (NEST && inInst >= 0) w2Leaf = ((unsigned)triNext << (leafBits + 1)) | (unsigned)triLeft;
+                    else wLeaf = ((unsigned)triNext << (leafBits + 1)) | (unsigned)triLeft;
                     triLeft = 0;
                     cur = -2 - __float_as_int(a.x);
                 } else {
@@ -533,6 +593,13 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                             instance_matrices_at(sc.instances[inInst], trace_ray_time(sc, q0, q1, ray, hitOffset1), xf);
                             dd = m4_vec(xf + 16, dd);
                         } else if (inInst >= 0) dd = m4_vec(sc.instances[inInst].w2i, dd);
+                        if (NEST && inInst2 >= 0) {
+                            if (sc.instances[inInst2].animated) {
+                                float xf[PG_XF_STRIDE];
+                                instance_matrices_at(sc.instances[inInst2], trace_ray_time(sc, q0, q1, ray, hitOffset1), xf);
+                                dd = m4_vec(xf + 16, dd);
+                            } else dd = m4_vec(sc.instances[inInst2].w2i, dd);
+                        }
                         hit = sphere_test(sc.spheres[__float_as_int(a.x)], mk(ox, oy, oz), dd, tMax, t);
                         b0 = t; b1 = 0; b2 = 0;  // the hit record of a sphere carries tHit
                     } else {
@@ -688,6 +755,7 @@ static void launch_trace(const DScene &sc, const TraceConfig &c, RayQueue q0, Ra
     int xp = (sc.nInstances > 0 ? XP_INST : 0) | (sc.nSpheres > 0 ? XP_QUADRIC : 0) | (sc.hasAlpha ? (sc.alphaTex ? XP_ALPHA : XP_ALPHATEX) : 0);
     // moving instances: two instantiations only -- with quadrics, and the general one (any alpha mask) -- a moving scene pays for both features
     if (sc.hasMotion) xp = XP_ANIM | (sc.hasAlpha ? XP_GENERAL : (XP_INST | XP_QUADRIC));
+    if (sc.hasNest) xp = XP_NEST | XP_ANIM | XP_GENERAL;  // TransformedPrimitives inside object definitions: one instantiation with everything
     // scenes with instances wait for fewer idle lanes before a refill and weigh the triangle step higher (entry / exit steps take lanes out of
     // the two main steps: profiles/r06_trace_inst_ab.txt)
     const bool inst = (xp & XP_INST) != 0;
@@ -706,6 +774,7 @@ static void launch_trace(const DScene &sc, const TraceConfig &c, RayQueue q0, Ra
     case XP_QUADRIC | XP_INST | XP_ALPHA: TR_LAUNCH(XP_QUADRIC | XP_INST | XP_ALPHA); break;
     case XP_ANIM | XP_INST | XP_QUADRIC: TR_LAUNCH(XP_ANIM | XP_INST | XP_QUADRIC); break;
     case XP_ANIM | XP_GENERAL: TR_LAUNCH(XP_ANIM | XP_GENERAL); break;
+    case XP_NEST | XP_ANIM | XP_GENERAL: TR_LAUNCH(XP_NEST | XP_ANIM | XP_GENERAL); break;
     default: TR_LAUNCH(XP_GENERAL); break;  // masks that need the general texture evaluator
     }
 #undef TR_LAUNCH

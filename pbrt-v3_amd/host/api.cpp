@@ -1239,11 +1239,6 @@ void pbrtShape(const std::string &name, const ParamSet &params) {  // api.cpp:13
     // A shape under an animated transformation is created at the identity and its primitives -- under a BVHAccel of their own when there
     // are several -- become ONE TransformedPrimitive over the AnimatedTransform (api.cpp:1386-1419, primitive.cpp:76-103)
     const bool animated = curTransform.IsAnimated();
-    if (animated && renderOptions->currentInstance) {
-        Error("Shape \"%s\" under an animated transformation inside an object definition (a moving primitive inside an instance) is outside this "
-              "build's closed set; the scene will not be rendered.", name.c_str());
-        renderOptions->refused = true;
-    }
     const Transform shapeToWorld = animated ? Transform() : curTransform[0];
     std::shared_ptr<TriangleMesh> mesh;
     std::shared_ptr<Sphere> sphere;
@@ -1342,7 +1337,10 @@ void pbrtShape(const std::string &name, const ParamSet &params) {  // api.cpp:13
         GeometricPrimitive tp;
         tp.object = moving;
         tp.xf = xf;
-        if (!renderOptions->currentInstance) renderOptions->primitives.push_back(tp);
+        // api.cpp:1405-1418: inside an object definition the moving shape's TransformedPrimitive is one of the instance's primitives -- a
+        // TransformedPrimitive under the TransformedPrimitive of every ObjectInstance (PG_PRIM_INSTANCE inside an object's run, ABI 29)
+        if (renderOptions->currentInstance) renderOptions->currentInstance->prims.push_back(tp);
+        else renderOptions->primitives.push_back(tp);
         return;
     }
     if (firstLight >= 0 && renderOptions->currentInstance)

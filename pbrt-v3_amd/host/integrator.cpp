@@ -237,7 +237,8 @@ void GpuPathIntegrator::Flatten(const Scene &scene, FlatScene *flat) const {
     for (const auto &prim : bvh.primitives) all.push_back(&prim);
     flat->nodes = bvh.nodes;
     std::map<const ObjectDefinition *, int> objectIndex;
-    for (const auto &prim : bvh.primitives) {
+    for (size_t pi = 0; pi < all.size(); ++pi) {  // (`all` grows: a moving shape inside an object definition is an object of its own, found here)
+        const GeometricPrimitive &prim = *all[pi];
         if (!prim.object) continue;
         const ObjectDefinition *od = prim.object.get();
         if (!objectIndex.count(od)) {

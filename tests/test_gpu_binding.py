@@ -32,7 +32,9 @@ SCENES = ["cornell_32", "cornell_crop", "cornell_lens", "cornell_plastic", "corn
           "motion_rotate_boxes", "motion_rotate_big_times", "motion_rotate_instances", "motion_rotate_distant_spatial", "motion_rotate_vol",
           "motion_rotate_camera_too",
           # a GridDensityMedium, BSSRDF materials, and both in one scene (round 6: the device refused the pair before)
-          "grid_puff", "sss_subsurface", "grid_sss_puff", "grid_sss_random"]
+          "grid_puff", "sss_subsurface", "grid_sss_puff", "grid_sss_random",
+          # moving shapes inside object definitions (ABI 29): the reference's TransformedPrimitive under a TransformedPrimitive, flattened
+          "nest_motion", "nest_motion_moving_instances", "nest_motion_rotate", "nest_motion_vol", "nest_motion_random"]
 
 
 def run_binding(pkg, scene_file, out):

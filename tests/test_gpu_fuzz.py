@@ -336,6 +336,40 @@ def test_random_scene_with_rotating_shapes_and_instances(gpu, oracle, seed):
     check_scene(gpu, oracle, random_scene_rotating_motion(seed), seed)
 
 
+def add_nested_motion(text, rng, spin=False):
+    """Put shapes INSIDE the object definitions of `text` under an end-of-motion transform: pbrtShape then adds a TransformedPrimitive to the definition
+    (api.cpp:1386-1419) and every ObjectInstance of it is a TransformedPrimitive around a TransformedPrimitive (PG_PRIM_INSTANCE inside an object's run,
+    ABI 29).  Before a definition's first shape every shape of it moves (the CTM keeps its two ends until ObjectEnd), before a later one the earlier stay still."""
+    parts = text.split('ObjectBegin "')
+    for k in range(1, len(parts)):
+        body, rest = parts[k].split("ObjectEnd", 1)
+        lines = body.split("\n")
+        shapes = [i for i, l in enumerate(lines) if l.lstrip().startswith("Shape ")]
+        if not shapes or (k > 1 and rng.random() < 0.25): continue
+        at = shapes[int(rng.integers(len(shapes)))]
+        motion = [" ActiveTransform EndTime", " Translate %.6g %.6g %.6g" % tuple(rng.normal(size=3) * 0.4)]
+        if rng.random() < 0.4: motion.append(" Scale %.6g %.6g %.6g" % tuple(0.8 + 0.5 * rng.random(3)))
+        if spin and rng.random() < 0.8: motion.insert(1 if rng.random() < 0.5 else len(motion), " Rotate %.6g %.6g %.6g %.6g" % (rng.uniform(-175, 175), *(rng.normal(size=3) + np.array([0, 1e-3, 0]))))
+        motion.append(" ActiveTransform All")
+        parts[k] = "\n".join(lines[:at] + motion + lines[at:]) + "ObjectEnd" + rest
+    return 'ObjectBegin "'.join(parts)
+
+
+def random_scene_nested_motion(seed):
+    """The random scenes above -- extended, volumetric, with moving / rotating instances and shapes, under a moving camera, every sampler family -- with
+    moving shapes inside their object definitions as well: a soup with alpha masks and a sphere, a lone sphere, a medium boundary."""
+    rng = np.random.default_rng(6000 + seed)
+    base = (random_scene_ext, random_scene_vol, random_scene_motion, random_scene_rotating_motion)[seed % 4]
+    text = base(seed if seed % 4 < 2 or seed % 3 != 2 else seed + 1)  # (random_scene_rotating_motion's every third scene has BSSRDF materials: refused beside nested motion)
+    assert "subsurface" not in text
+    return add_nested_motion(text, rng, spin=seed % 2 == 1)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_scene_with_moving_shapes_inside_object_definitions(gpu, oracle, seed):
+    check_scene(gpu, oracle, random_scene_nested_motion(seed), seed)
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_random_sss_or_grid_scene_with_moving_shapes(gpu, oracle, seed):
     check_scene(gpu, oracle, random_scene_motion_sss_grid(seed), seed)

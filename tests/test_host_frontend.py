@@ -266,7 +266,8 @@ def test_moving_shapes_and_instances_become_animated_instances(pkg):
     """The reference interpolates an AnimatedTransform per ray inside TransformedPrimitive::Intersect (primitive.cpp:76-103).  A motion -- with or
     without rotation (Dot(R[0], R[1]) < 0.9995; its bounds: host/motion_bounds.cpp, tests/test_motion_bounds.py) -- becomes a PgInstance with the two
     ends' decompositions (a moving SHAPE: an anonymous object created at the identity, api.cpp:1386-1419).  A moving shape inside an object
-    definition and a motion that MIRRORS are REFUSED -- an Error, no frame, never an image with one end of the motion.  A moving CAMERA is rendered (the camanim_* goldens);
+    definition is a TransformedPrimitive among that object's primitives (PG_PRIM_INSTANCE inside the object's run, ABI 29: the nest_motion* goldens).
+    A motion that MIRRORS is REFUSED -- an Error, no frame, never an image with one end of the motion.  A moving CAMERA is rendered (the camanim_* goldens);
     textures and lights take the start transform in the reference itself (api.cpp WARN_IF_ANIMATED_TRANSFORM): a Warning."""
     anim = 'ActiveTransform EndTime\nTranslate 0.3 0 0\nActiveTransform All\n'
     spin = 'ActiveTransform EndTime\nRotate 40 0 1 0\nActiveTransform All\n'
@@ -295,7 +296,17 @@ def test_moving_shapes_and_instances_become_animated_instances(pkg):
         s.close()
     nested = mini.replace("WorldEnd", 'ObjectBegin "o"\n' + anim + tri + 'ObjectEnd\nObjectInstance "o"\nWorldEnd')
     # (a mirrored motion: the reference slerps the non-unit quaternion of an improper rotation, and its own renders abort or do not terminate)
-    for what, txt in (("moving shape inside an object definition", nested), ("mirrored instance", inst("Scale 1 -1 1\n" + anim)), ("mirrored rotating shape", shape("Scale -1 1 1\n" + spin))):
+    s = pkg.HostScene(text=nested)  # the object "o" holds ONE primitive: the moving shape's TransformedPrimitive over an object of its own
+    d = s.desc
+    assert d.n_instances == 2 and d.n_objects == 2 and pkg.host_lib().pbrt_host_error_count() == before
+    outer = [k for k in range(d.n_tris) if d.tri_flags[k] & pkg.abi.PG_PRIM_INSTANCE]
+    inner = [k for k in range(d.n_tris, d.n_prims_all) if d.tri_flags[k] & pkg.abi.PG_PRIM_INSTANCE]
+    assert len(outer) == 1 and len(inner) == 1
+    io, ii = d.instances[d.indices[3 * outer[0]]], d.instances[d.indices[3 * inner[0]]]
+    assert not io.animated and ii.animated and d.objects[io.object].first_prim == inner[0] and d.objects[io.object].n_prims == 1
+    assert d.objects[ii.object].n_prims == 1 and not (d.tri_flags[d.objects[ii.object].first_prim] & pkg.abi.PG_PRIM_INSTANCE)
+    s.close()
+    for what, txt in (("mirrored instance", inst("Scale 1 -1 1\n" + anim)), ("mirrored rotating shape", shape("Scale -1 1 1\n" + spin))):
         before = pkg.host_lib().pbrt_host_error_count()
         with pytest.raises(pkg.PbrtGpuError):
             pkg.HostScene(text=txt)

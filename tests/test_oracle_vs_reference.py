@@ -92,14 +92,15 @@ def test_fuzz_scenes_live_when_reference_present(pkg, oracle, tmp_path):
     scene_file, out = str(tmp_path / "fuzz.pbrt"), str(tmp_path / "ref.pfm")
     # (the last four: the same scenes under a moving camera; with moving shapes and object instances; those beside subsurface materials / grid media;
     # with motions that rotate -- the front end's own MotionBounds in the top-level BVH and the world bound)
+    # (and: moving shapes INSIDE object definitions -- a TransformedPrimitive under every ObjectInstance's TransformedPrimitive, ABI 29)
     for gen in (fz.random_scene, fz.random_scene_ext, fz.random_scene_vol, fz.random_scene_moving_camera, fz.random_scene_motion, fz.random_scene_motion_sss_grid,
-                fz.random_scene_rotating_motion):
-        for seed in (range(16) if gen in (fz.random_scene_vol, fz.random_scene_moving_camera) else (range(24) if gen in (fz.random_scene_motion, fz.random_scene_rotating_motion) else (range(12) if gen is fz.random_scene_motion_sss_grid else range(0, 24, 2)))):
+                fz.random_scene_rotating_motion, fz.random_scene_nested_motion):
+        for seed in (range(16) if gen in (fz.random_scene_vol, fz.random_scene_moving_camera, fz.random_scene_nested_motion) else (range(24) if gen in (fz.random_scene_motion, fz.random_scene_rotating_motion) else (range(12) if gen is fz.random_scene_motion_sss_grid else range(0, 24, 2)))):
             open(scene_file, "w").write(gen(seed))
             txt = oracle.run_reference(scene_file, out, nthreads=1, timeout=600)  # one thread: overlapping FilmTiles merge in tile order
             img, _ = oracle.render_image(pkg.HostScene(scene_file))
             assert np.array_equal(img, pkg.read_pfm(out)), (gen.__name__, seed)
-            if gen is fz.random_scene_rotating_motion:  # the reference's own statistics too: the triangle tests count what the BVHs -- the top-level one
+            if gen in (fz.random_scene_rotating_motion, fz.random_scene_nested_motion):  # the reference's own statistics too: the triangle tests count what the BVHs -- the top-level one
                 import re                               # over MotionBounds' boxes -- made the rays visit
                 g = lambda pat: int(re.search(pat, txt).group(1)) if re.search(pat, txt) else 0
                 sc = pkg.HostScene(scene_file)
