@@ -973,6 +973,18 @@ def with_moving_sss_boxes(s):
     return s.replace("WorldBegin\n", 'WorldBegin\nMakeNamedMaterial "skin" "string type" "subsurface" "rgb sigma_a" [ 0.002 0.004 0.008 ] "rgb sigma_s" [ 0.1 0.08 0.06 ] "float scale" [ 1 ] "float eta" [ 1.33 ]\n', 1)
 
 
+def with_nested_sss(s):
+    """with_nested_motion's scene with ONE subsurface Material object on both boxes of "boxes" (the still short one and the tall one that moves inside the
+    definition) and on the moving sphere inside "ball": probe chains run through hits under two transforms, started on one box they can leave through the other."""
+    skin = 'NamedMaterial "skin"'
+    n = s.count(skin)
+    s = s.replace('# short box\nMaterial "matte" "rgb Kd" [ 0.73 0.73 0.73 ]', '# short box\n' + skin, 1)
+    s = s.replace('Material "glass" "float index" [ 1.4 ]\n# tall box', skin + '\n# tall box', 1)
+    s = s.replace('  Material "matte" "rgb Kd" [ 0.2 0.3 0.8 ]\n  Shape "sphere" "float radius" [ 25 ]', '  ' + skin + '\n  Shape "sphere" "float radius" [ 25 ]', 1)
+    assert s.count(skin) == n + 3
+    return s.replace("WorldBegin\n", 'WorldBegin\nMakeNamedMaterial "skin" "string type" "subsurface" "rgb sigma_a" [ 0.002 0.004 0.008 ] "rgb sigma_s" [ 0.1 0.08 0.06 ] "float scale" [ 1 ] "float eta" [ 1.33 ]\n', 1)
+
+
 SSS_SCENES = {
     # both boxes share one SubsurfaceMaterial: probe rays started on one box may leave through the other (bssrdf.cpp:301)
     "sss_subsurface": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 6 ]', world_edit=lambda s: with_sss(s, SSS_PLAIN)),
@@ -986,6 +998,10 @@ SSS_SCENES = {
     "sss_motion_volpath": with_moving_boxes(cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 5 ]',
                                                     world_edit=lambda s: with_fog(with_sss(s, 'Material "subsurface" "string name" "Skin1" "float scale" [ 0.05 ] "float eta" [ 1.4 ]'))),
                                             times="TransformTimes 0.1 0.8\n").replace('Sampler "halton"', 'Sampler "sobol"'),
+    # moving shapes of a subsurface material INSIDE object definitions (ABI 29): the probe chains' hits lie under two transforms
+    "sss_nest_motion": with_nested_sss(with_nested_motion(with_moving_instances(cornell(24, 24, 4, integrator='Integrator "path" "integer maxdepth" [ 5 ]')))),
+    "sss_nest_motion_volpath": with_nested_sss(with_nested_motion(with_moving_instances(cornell(24, 24, 4, integrator='Integrator "volpath" "integer maxdepth" [ 5 ]', world_edit=lambda s: with_fog(s)),
+                                                                                     spin=("  Rotate 40 0 1 0.2\n", "  Rotate -75 1 0 0\n", "  Rotate 120 0 0 1\n", "  Rotate 60 1 1 0\n")))).replace('Sampler "halton"', 'Sampler "sobol"'),
     "sss_kd_rough": cornell(32, 32, 8, integrator='Integrator "path" "integer maxdepth" [ 6 ]',
                             world_edit=lambda s: with_sss(s, 'Material "kdsubsurface" "rgb Kd" [ 0.6 0.4 0.3 ] "rgb mfp" [ 8 12 20 ] "float uroughness" [ 0.1 ] "float vroughness" [ 0.2 ] "float g" [ 0.3 ]',
                                                           tall='Material "kdsubsurface" "rgb Kd" [ 0.2 0.5 0.7 ] "rgb mfp" [ 30 30 30 ] "float scale" [ 0.5 ] "float eta" [ 1.2 ] "bool remaproughness" "false" "float uroughness" [ 0.05 ] "float vroughness" [ 0.05 ]')),

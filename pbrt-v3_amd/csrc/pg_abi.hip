@@ -303,8 +303,6 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
                 FAIL(PG_ERR_UNSUPPORTED, "%d instances in a scene with TransformedPrimitives inside object definitions: the pair (outer, inner) does not fit a hit's instance word", desc->n_instances);
             if (worldPending + 2 * objectPending > 64 + s->trace.depth)
                 FAIL(PG_ERR_UNSUPPORTED, "world BVH (%d levels) + two object BVHs (%d levels) exceed the traversal stack of %d entries", worldPending, objectPending, 64 + s->trace.depth);
-            if (desc->n_bssrdfs > 0)
-                FAIL(PG_ERR_UNSUPPORTED, "a moving shape inside an object definition in a scene with BSSRDF materials: the probe chains carry one instance transform");
         }
         if (!objs.empty()) {
             HIP_TRY_S(s->objects.alloc(sizeof(DObject) * objs.size()));
@@ -1229,7 +1227,7 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
             for (int i = 0; i < 2; ++i) HIP_TRY(s->sssCoef[i].alloc(n * sizeof(float4)));
             HIP_TRY(s->sssHit.alloc(n * sizeof(float4))); HIP_TRY(s->sssHitO.alloc(n * sizeof(float4))); HIP_TRY(s->sssHitD.alloc(n * sizeof(float4)));
             HIP_TRY(s->sssHitInst.alloc(n * sizeof(int)));
-            if (s->d.hasMotion) HIP_TRY(s->sssHitXf.alloc(n * PG_XF_STRIDE * sizeof(float)));  // the chosen hit's interpolated instance matrices
+            if (s->d.hasMotion) HIP_TRY(s->sssHitXf.alloc((s->d.hasNest ? 2 : 1) * n * PG_XF_STRIDE * sizeof(float)));  // the chosen hit's interpolated instance matrices
             HIP_TRY(s->sssMedium.alloc(n * sizeof(int2)));
             for (int i = 0; i < 3; ++i) { HIP_TRY(s->sssQo[i].alloc(n * sizeof(float4))); HIP_TRY(s->sssQd[i].alloc(n * (sizeof(float4) + (s->d.hasMotion ? sizeof(float) : 0)))); }  // (+ the probe rays' times: PG_QUEUE_TIMES)
             HIP_TRY(s->sssCounts.alloc(3 * QSTRIDE * sizeof(int)));
@@ -1239,7 +1237,7 @@ static int renderFrame(PgScene *s, const PgRenderDesc *rd, PgFilmPixel *film, Pg
         sq.po = (float4 *)s->sssPo.p; sq.target = (float4 *)s->sssTarget.p; sq.count = (int2 *)s->sssCount.p;
         for (int i = 0; i < 3; ++i) sq.frame[i] = (float4 *)s->sssFrame[i].p;
         for (int i = 0; i < 2; ++i) sq.coef[i] = (float4 *)s->sssCoef[i].p;
-        sq.hit = (float4 *)s->sssHit.p; sq.hitO = (float4 *)s->sssHitO.p; sq.hitD = (float4 *)s->sssHitD.p; sq.hitInst = (int *)s->sssHitInst.p; sq.hitXf = (float *)s->sssHitXf.p; sq.medium = (int2 *)s->sssMedium.p;
+        sq.hit = (float4 *)s->sssHit.p; sq.hitO = (float4 *)s->sssHitO.p; sq.hitD = (float4 *)s->sssHitD.p; sq.hitInst = (int *)s->sssHitInst.p; sq.hitXf = (float *)s->sssHitXf.p; sq.hitXfNest = (int)n; sq.medium = (int2 *)s->sssMedium.p;
         sq.qjob.o = (float4 *)s->sssQo[0].p; sq.qjob.d = (float4 *)s->sssQd[0].p; sq.qjob.counts = (int *)s->sssCounts.p;
         for (int i = 0; i < 2; ++i) { sssP[i].o = (float4 *)s->sssQo[1 + i].p; sssP[i].d = (float4 *)s->sssQd[1 + i].p; sssP[i].counts = (int *)s->sssCounts.p + (1 + i) * QSTRIDE; }
     }

@@ -260,6 +260,7 @@ struct SssState {
     float4 *hitO, *hitD;
     int *hitInst;
     float *hitXf;      // scenes with moving instances: the chosen hit's interpolated instance matrices (PG_XF_STRIDE floats per slot, as DScene::animXf), else nullptr
+    int hitXfNest;     // DScene::hasNest: the inner TransformedPrimitive's matrices of a chosen hit two levels deep wait at hitXf[PG_XF_STRIDE * (hitXfNest + slot)]
     int2 *medium;      // volpath: (medium of the probe ray under way, medium of the probe ray that found the chosen hit); index + 1, 0 = none
     RayQueue qjob;     // the first probe ray of every path that entered this branch at the current bounce (appended by k_shade)
 };

@@ -3369,7 +3369,8 @@ void launch_fill_int(int *p, int value, int n, hipStream_t s) {
 // pass 1 counts the hits on the material, pass 2 stops at the chosen one.  Each step is one k_trace<0, .> launch over the
 // chains still under way followed by k_sss_probe.
 // ===========================================================================
-template <int PASS, bool VOL>
+// NEST: DScene::hasNest -- the chain's hits can lie under two transforms (a moving shape inside an object definition)
+template <int PASS, bool VOL, bool NEST = false>
 __global__ __launch_bounds__(PG_BLOCK) void k_sss_probe(DScene sc, SssState sss, RayQueue qin, const float4 *__restrict__ hits, RayQueue qout, int first) {
     const int i = queue_item<>(qin);
     bool push = false;
@@ -3397,10 +3398,13 @@ __global__ __launch_bounds__(PG_BLOCK) void k_sss_probe(DScene sc, SssState sss,
                     selected = selected < 0 ? 0 : (selected > cnt.x - 1 ? cnt.x - 1 : selected);
                     if (cnt.y == selected) {
                         sss.hit[slot] = h4; sss.hitO[slot] = o4; sss.hitD[slot] = d4;
-                        const int hInst = sc.hitInst ? sc.hitInst[i] : -1;
-                        sss.hitInst[slot] = hInst;
+                        int hInst = sc.hitInst ? sc.hitInst[i] : -1, hInst2 = -1;
+                        sss.hitInst[slot] = hInst;  // (NEST: the pair as k_trace wrote it)
+                        if constexpr (NEST) nest_decode(sc, hInst, hInst2);
                         if (sss.hitXf && hInst >= 0 && sc.instances[hInst].animated)  // a moving instance: the matrices k_trace interpolated for this probe ray
                             for (int q = 0; q < 33; ++q) sss.hitXf[(size_t)PG_XF_STRIDE * slot + q] = sc.animXf[(size_t)PG_XF_STRIDE * i + q];
+                        if (NEST && sss.hitXf && hInst2 >= 0 && sc.instances[hInst2].animated)
+                            for (int q = 0; q < 33; ++q) sss.hitXf[(size_t)PG_XF_STRIDE * ((size_t)sss.hitXfNest + slot) + q] = sc.animXf[(size_t)PG_XF_STRIDE * ((size_t)sc.nestXfOff + i) + q];
                         if constexpr (VOL) sss.medium[slot] = make_int2(rayMed, rayMed);
                         go = false;
                     }
@@ -3410,7 +3414,7 @@ __global__ __launch_bounds__(PG_BLOCK) void k_sss_probe(DScene sc, SssState sss,
             }
             if (go) {  // base = next->si; base.SpawnRayTo(pTarget): interaction.h:65-71
                 V3 p, pError, n;
-                through_point<false>(sc, i, o4, rayD, h4, prim, tri, p, pError, n);
+                through_point<NEST>(sc, i, o4, rayD, h4, prim, tri, p, pError, n);
                 const float4 tg = sss.target[slot];
                 const V3 d = mk(tg.x, tg.y, tg.z) - p;
                 if (!(d.x == 0 && d.y == 0 && d.z == 0)) {
@@ -3436,7 +3440,13 @@ void launch_sss_probe(const DScene &sc, SssState sss, int pass, RayQueue qin, co
     int nblk = PG_REGIONS * (qin.regionCap / PG_BLOCK);
     if (nblk == 0) return;
     const int f = first ? 1 : 0;
-    if (vol) {
+    if (sc.hasNest) {  // (hits under two transforms: instantiations of their own, the others keep their registers)
+        if (vol) {
+            if (pass == 1) hipLaunchKernelGGL((k_sss_probe<1, true, true>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, sss, qin, hits, qout, f);
+            else hipLaunchKernelGGL((k_sss_probe<2, true, true>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, sss, qin, hits, qout, f);
+        } else if (pass == 1) hipLaunchKernelGGL((k_sss_probe<1, false, true>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, sss, qin, hits, qout, f);
+        else hipLaunchKernelGGL((k_sss_probe<2, false, true>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, sss, qin, hits, qout, f);
+    } else if (vol) {
         if (pass == 1) hipLaunchKernelGGL((k_sss_probe<1, true>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, sss, qin, hits, qout, f);
         else hipLaunchKernelGGL((k_sss_probe<2, true>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, sss, qin, hits, qout, f);
     } else if (pass == 1) hipLaunchKernelGGL((k_sss_probe<1, false>), dim3(nblk), dim3(PG_BLOCK), 0, s, sc, sss, qin, hits, qout, f);
@@ -3530,7 +3540,19 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_sss_exit(DScene sc, RenderPa
         };
         // ---- pi: the chosen hit as a SurfaceInteraction (the tail of Triangle::Intersect / Sphere::Intersect, then the instance's transform)
         const float4 h4 = sss.hit[slot], o4 = sss.hitO[slot], d4 = sss.hitD[slot];
-        const int prim = __float_as_int(h4.x), inst = sss.hitInst[slot];
+        const int prim = __float_as_int(h4.x);
+        int inst = sss.hitInst[slot], inst2;
+        nest_decode(sc, inst, inst2);  // (DScene::hasNest: the chosen hit may lie under two transforms)
+        const float *i2wIn = nullptr, *w2iIn = nullptr;  // the inner TransformedPrimitive's, as below
+        bool innerIdentity = true;
+        if (inst2 >= 0) {
+            const PgInstance &in2 = sc.instances[inst2];
+            const bool moving2 = in2.animated && sss.hitXf;
+            const float *xf2 = sss.hitXf + (size_t)PG_XF_STRIDE * ((size_t)sss.hitXfNest + slot);
+            i2wIn = moving2 ? xf2 : in2.i2w;
+            w2iIn = moving2 ? xf2 + 16 : in2.w2i;
+            innerIdentity = moving2 ? xf2[32] != 0.f : in2.identity != 0;
+        }
         // the chosen hit's instance transform: the instance's own, or -- a moving instance -- what k_sss_probe kept of k_trace's interpolation
         const float *i2w = nullptr, *w2i = nullptr;
         bool instIdentity = true;
@@ -3546,13 +3568,16 @@ __global__ __launch_bounds__(PG_SHADE_BLOCK) void k_sss_exit(DScene sc, RenderPa
         Isect is;
         V3 shapeRayD = rayD;
         if (inst >= 0) shapeRayD = m4_vec(w2i, rayD);
+        if (inst2 >= 0) shapeRayD = m4_vec(w2iIn, shapeRayD);
         if (tri.flags & PG_PRIM_SPHERE) {
             V3 shapeRayO = mk(o4.x, o4.y, o4.z);
             if (inst >= 0) { float dt; instance_ray(w2i, shapeRayO, rayD, shapeRayO, shapeRayD, dt); }
+            if (inst2 >= 0) { float dt; instance_ray(w2iIn, shapeRayO, shapeRayD, shapeRayO, shapeRayD, dt); }
             const SphereHit sh = sphere_interaction(sc.spheres[__float_as_int(tri.p0.x)], shapeRayO, shapeRayD, h4.y);
             is.p = sh.p; is.pError = sh.pError; is.wo = sh.wo; is.n = sh.n; is.ns = sh.n; is.sdpdu = sh.dpdu;
             is.sdpdv = sh.dpdv; is.sdndu = sh.dndu; is.sdndv = sh.dndv;
         } else is = make_isect(sc, prim, tri, h4.y, h4.z, h4.w, shapeRayD);
+        if (inst2 >= 0 && !innerIdentity) isect_to_world(i2wIn, w2iIn, is);  // (the inner transform first)
         if (inst >= 0 && !instIdentity) {  // InterpolatedPrimToWorld(*isect), transform.cpp:262-297
             Isect w;
             w.p = m4_point_err2(i2w, is.p, is.pError, w.pError);

@@ -112,9 +112,9 @@ def test_moving_shapes_inside_object_definitions_on_the_emulated_device(emulated
     """Round 6, ABI 29: a TransformedPrimitive among an object definition's primitives (pbrtShape under an animated transformation between ObjectBegin and
     ObjectEnd, api.cpp:1386-1419) -- k_trace<., XP_NEST> keeps a second saved context and derives the instance's ray again when it leaves the inner
     object, the hit's instance word carries (outer, inner), k_shade<2> applies InterpolatedPrimToWorld of the inner and then of the outer.  Two goldens
-    from the reference binary (a BVH object, a lone sphere and a lone triangle with moving shapes inside, under still and moving instances; volpath) and
-    one random scene; all six goldens and forty random scenes went through the emulated device once (profiles/r06s_nested_motion.txt)."""
-    out = run_gpu_tests(emulated, ["tests/test_gpu_parity.py"], "test_golden_images and (nest_motion_moving_instances or nest_motion_vol)", 1500)
+    from the reference binary (a BVH object, a lone sphere and a lone triangle with moving shapes inside, under moving instances; one subsurface material on
+    still and moving parts under volpath) and one random scene; all eight goldens and 64 random scenes went through the emulated device once (profiles/r06s_nested_motion.txt)."""
+    out = run_gpu_tests(emulated, ["tests/test_gpu_parity.py"], "test_golden_images and (nest_motion_moving_instances or sss_nest_motion_volpath)", 1500)  # (the second: a subsurface material on still and moving parts, volpath, Sobol')
     assert "2 passed" in out and "failed" not in out
     out = run_gpu_tests(emulated, ["tests/test_gpu_fuzz.py::test_random_scene_with_moving_shapes_inside_object_definitions[1]"], "inside_object", 1500)
     assert "1 passed" in out and "failed" not in out

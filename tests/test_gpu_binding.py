@@ -34,7 +34,7 @@ SCENES = ["cornell_32", "cornell_crop", "cornell_lens", "cornell_plastic", "corn
           # a GridDensityMedium, BSSRDF materials, and both in one scene (round 6: the device refused the pair before)
           "grid_puff", "sss_subsurface", "grid_sss_puff", "grid_sss_random",
           # moving shapes inside object definitions (ABI 29): the reference's TransformedPrimitive under a TransformedPrimitive, flattened
-          "nest_motion", "nest_motion_moving_instances", "nest_motion_rotate", "nest_motion_vol", "nest_motion_random"]
+          "nest_motion", "nest_motion_moving_instances", "nest_motion_rotate", "nest_motion_vol", "nest_motion_random", "sss_nest_motion", "sss_nest_motion_volpath"]
 
 
 def run_binding(pkg, scene_file, out):

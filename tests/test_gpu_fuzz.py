@@ -370,6 +370,20 @@ def test_random_scene_with_moving_shapes_inside_object_definitions(gpu, oracle, 
     check_scene(gpu, oracle, random_scene_nested_motion(seed), seed)
 
 
+def random_scene_nested_motion_sss_grid(seed):
+    """Moving shapes inside object definitions beside subsurface materials (the probe chains' hits lie under two transforms: k_sss_probe<., ., NEST>, k_sss_exit), a
+    GridDensityMedium (both shading phases around the transmittance rays), or both; every other scene with moving / rotating instances around them."""
+    rng = np.random.default_rng(7000 + seed)
+    text = random_scene_sss_grid(seed, ("sss", "grid", "both", "sss")[seed % 4])
+    if seed % 2: text = add_motion(text, rng, spin=seed % 4 == 3)
+    return add_nested_motion(text, rng, spin=seed % 3 == 0)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_sss_or_grid_scene_with_moving_shapes_inside_object_definitions(gpu, oracle, seed):
+    check_scene(gpu, oracle, random_scene_nested_motion_sss_grid(seed), seed)
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_random_sss_or_grid_scene_with_moving_shapes(gpu, oracle, seed):
     check_scene(gpu, oracle, random_scene_motion_sss_grid(seed), seed)

@@ -26,7 +26,7 @@ def main():
     with tempfile.TemporaryDirectory() as d:
         scene_file, out = os.path.join(d, "fuzz.pbrt"), os.path.join(d, "ref.pfm")
         gens = (fz.random_scene, fz.random_scene_ext, fz.random_scene_vol, fz.random_scene_sss_grid, fz.random_scene_moving_camera, fz.random_scene_motion,
-                fz.random_scene_motion_sss_grid, fz.random_scene_rotating_motion, fz.random_scene_nested_motion)
+                fz.random_scene_motion_sss_grid, fz.random_scene_rotating_motion, fz.random_scene_nested_motion, fz.random_scene_nested_motion_sss_grid)
         if len(sys.argv) > 3: gens = [g for g in gens if g.__name__ == sys.argv[3]]
         for gen in gens:
             for seed in range(a, b):
