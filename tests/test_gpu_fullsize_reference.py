@@ -32,3 +32,20 @@ def test_full_size_image_matches_reference_binary(gpu, oracle, config):
         assert r["device_counters"][k] == r["reference_counters"][k], (k, r["device_counters"][k], r["reference_counters"][k])
     assert r["pixels_differing"] == 0 and r["bit_identical_pixel_share"] == 1.0 and r["max_rel_err"] == 0.0, r
     assert r["outside_window_black"]
+
+
+@pytest.mark.parametrize("config", [41, 51])
+def test_whole_frame_of_a_stand_in_equals_the_reference_fingerprint(gpu, config):
+    """The config 4 / 5 stand-ins over the WHOLE 1920x1080 frame at their own 256 / 128 spp (the windows above are 256x144): the reference binary rendered
+    both frames once where host time is free (12 - 16 minutes on 8 threads; tools/fullsize_parity.py --reference-only) and its image is committed as a
+    fingerprint -- SHA-256 of the float image, a CRC-32 per 16x16 tile, its ray counters, the SHA-256 of the scene file it read
+    (tests/golden_large/fullframe_reference_fingerprint_config{41,51}.json).  The device renders the frame here (about 2 s): equal SHA-256 = every pixel
+    identical, bit for bit; the ray counts are the reference's.  (this comparison was a builder-run tool until round 6.)"""
+    import fullsize_parity
+    fp = json.load(open(os.path.join(ROOT, "tests", "golden_large", f"fullframe_reference_fingerprint_config{config}.json")))
+    r = fullsize_parity.run(config, fp)
+    assert r["same_scene_file"], "the generated scene file is not the one the reference rendered"
+    assert r["sha256_equal"] and r["tiles_differing"] == 0 and r["pixels_differing"] == 0, r
+    assert r["compared_pixels"] == 1920 * 1080 and r["window"] is None and r["tiles"] == 8160
+    for k in ("camera_rays", "closest_rays", "shadow_rays"):
+        assert r["device_counters"][k] == fp["reference_counters"][k], k

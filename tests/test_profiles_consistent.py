@@ -164,10 +164,11 @@ def test_round5_event_timing_agrees_with_the_rocprof_summary():
     assert "l2_memory_side" in h and "hbm_side" not in h
 
 
-def test_round5_whole_frame_parity_of_configs_4_and_5():
-    """profiles/r05z_fullframe_parity_config4_5.json: the device's whole 1920x1080 frame of both stand-ins at their own 256 / 128 spp against the
+@pytest.mark.parametrize("tag", ["r05z", "r06z"])
+def test_whole_frame_parity_of_configs_4_and_5(tag):
+    """profiles/r0{5,6}z_fullframe_parity_config4_5.json (the closing trees of rounds 5 and 6): the device's whole 1920x1080 frame of both stand-ins at their own 256 / 128 spp against the
     fingerprint of the reference binary's image (tests/golden_large/fullframe_reference_fingerprint_config{41,51}.json)."""
-    res = json.load(open(os.path.join(PROF, "r05z_fullframe_parity_config4_5.json")))
+    res = json.load(open(os.path.join(PROF, tag + "_fullframe_parity_config4_5.json")))
     assert [r["config"] for r in res] == [41, 51]
     for r in res:
         fp = json.load(open(os.path.join(ROOT, "tests", "golden_large", f"fullframe_reference_fingerprint_config{r['config']}.json")))
