@@ -255,6 +255,7 @@ int pg_scene_create(const PgSceneDesc *desc, PgScene **out) {
         s->trace = default_trace_config();
         const int topRef = buildRecords(0, nn, 0);
         // object definitions (instancing): each with its own records, root box and root reference
+        if (desc->n_objects > 0 && !desc->objects) FAIL(PG_ERR_INVALID, "pg_scene_create: n_objects = %d without an objects array", desc->n_objects);
         std::vector<DObject> objs((size_t)(desc->n_objects > 0 ? desc->n_objects : 0));
         for (size_t k = 0; k < objs.size(); ++k) {
             const PgObject &o = desc->objects[k];

@@ -388,6 +388,41 @@ def test_malformed_or_too_deep_bvh_is_refused(gpu, oracle):
     gs.close()
 
 
+def test_transformed_primitives_inside_object_definitions_are_validated(gpu):
+    """ABI 29: PG_PRIM_INSTANCE may stand among an object definition's primitives, ONE level -- what such a primitive wraps holds shapes only (the
+    reference has no ObjectInstance inside a definition, api.cpp:1549-1552).  A third level, a definition that contains itself and an instance index
+    out of range are refused by pg_scene_create before anything is indexed by them; the scene as the front end flattened it is accepted."""
+    scene = gpu.HostScene(os.path.join(GOLD, "nest_motion.pbrt"))
+    desc = scene.desc
+    n = desc.n_prims_all
+    nested = [k for k in range(desc.n_tris, n) if desc.tri_flags[k] & gpu.abi.PG_PRIM_INSTANCE]
+    assert len(nested) == 3 and desc.n_prims_all > desc.n_tris  # the tall box, the second sphere, the lone triangle
+    gpu.GpuScene(desc).close()
+    k = nested[0]
+    inner = desc.objects[desc.instances[desc.indices[3 * k]].object]
+    flags = (C.c_uint32 * n)(*[desc.tri_flags[i] for i in range(n)])
+    idx = (C.c_int32 * (3 * n))(*[desc.indices[i] for i in range(3 * n)])
+    # what the nested primitive wraps contains a TransformedPrimitive itself: three levels
+    flags[inner.first_prim] = gpu.abi.PG_PRIM_INSTANCE
+    idx[3 * inner.first_prim] = desc.indices[3 * nested[1]]
+    bad = gpu.abi.PgSceneDesc.from_buffer_copy(desc)
+    bad.tri_flags, bad.indices = flags, idx
+    with pytest.raises(gpu.PbrtGpuError, match="more than two levels"):
+        gpu.GpuScene(bad)
+    # an instance index out of range inside a definition
+    idx2 = (C.c_int32 * (3 * n))(*[desc.indices[i] for i in range(3 * n)])
+    idx2[3 * k] = desc.n_instances
+    bad2 = gpu.abi.PgSceneDesc.from_buffer_copy(desc)
+    bad2.indices = idx2
+    with pytest.raises(gpu.PbrtGpuError, match="its object out of range"):
+        gpu.GpuScene(bad2)
+    # objects without an objects array
+    bad3 = gpu.abi.PgSceneDesc.from_buffer_copy(desc)
+    bad3.objects = None
+    with pytest.raises(gpu.PbrtGpuError, match="without an objects array"):
+        gpu.GpuScene(bad3)
+
+
 def test_invalid_media_and_sampler_descriptions_fail_loudly(gpu):
     """The v15 / v16 additions to the ABI are validated like the rest: out-of-range medium indices, an unknown integrator or
     sampler, a Sobol' render on a scene created without the tables, inconsistent Sobol' resolutions."""
