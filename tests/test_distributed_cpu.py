@@ -47,7 +47,8 @@ def _run(name, world, tmp_path, port):
 def test_two_rank_sharded_render_matches_golden(pkg, tmp_path):
     # box filter; a crop window; a deep BVH; the volumetric integrator with the Sobol' sampler (sample indices depend on the
     # full-frame sample bounds, not on the shard); moving instances and shapes whose motion rotates (every rank builds the same MotionBounds boxes)
-    for i, name in enumerate(("cornell_40x24", "cornell_crop", "synthetic_n40", "sobol_vol_smoke", "sobol_round_crop", "motion_rotate_instances")):
+    for i, name in enumerate(("cornell_40x24", "cornell_crop", "synthetic_n40", "sobol_vol_smoke", "sobol_round_crop", "motion_rotate_instances",
+                              "nest_motion_moving_instances")):  # (and moving shapes inside object definitions under moving instances, a shutter inside the motion)
         img = _run(name, 2, tmp_path, 29531 + i)
         assert np.array_equal(img, pkg.read_pfm(os.path.join(GOLD, name + ".pfm"))), name
 
