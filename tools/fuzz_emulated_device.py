@@ -28,7 +28,8 @@ def main():
             "random_scene_sss": lambda s: fz.random_scene_sss_grid(s, "sss"), "random_scene_grid": lambda s: fz.random_scene_sss_grid(s, "grid"),
             "random_scene_pixel_sampler": fz.random_scene_pixel_sampler, "random_scene_moving_camera": fz.random_scene_moving_camera,
             "random_scene_motion": fz.random_scene_motion, "random_scene_motion_sss_grid": fz.random_scene_motion_sss_grid,
-            "random_scene_rotating_motion": fz.random_scene_rotating_motion}
+            "random_scene_rotating_motion": fz.random_scene_rotating_motion,
+            "random_scene_nested_motion": fz.random_scene_nested_motion, "random_scene_nested_motion_sss_grid": fz.random_scene_nested_motion_sss_grid}
     if len(sys.argv) > 3: gens = {k: v for k, v in gens.items() if k == sys.argv[3]}
     bad = 0
     for name, gen in gens.items():
