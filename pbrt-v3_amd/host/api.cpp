@@ -278,7 +278,10 @@ static int MakeMaterial(const std::string &name, const ParamSet &geom, const Par
                             name != "substrate" && name != "translucent" && name != "mix" && name != "subsurface" && name != "kdsubsurface")) {
         if (name != "matte") {
             if (name == "hair" || name == "disney" || name == "fourier")
-                Error("Material \"%s\" is outside this build's closed set (matte, plastic, mirror, glass, uber, metal, substrate, translucent, mix, subsurface, kdsubsurface); using matte.", name.c_str());
+            {   // a material the REFERENCE renders and this build does not: no frame with a stand-in (the scene is refused at WorldEnd)
+                Error("Material \"%s\" is outside this build's closed set (matte, plastic, mirror, glass, uber, metal, substrate, translucent, mix, subsurface, kdsubsurface); the scene will not be rendered.", name.c_str());
+                renderOptions->refused = true;
+            }
             else Warning("Material \"%s\" unknown. Using \"matte\".", name.c_str());  // api.cpp:588-591
         }
         m.type = PG_MAT_MATTE;  // matte.cpp:45-72
@@ -537,8 +540,10 @@ static int MakeMaterial(const std::string &name, const ParamSet &geom, const Par
         auto bssrdfOf = [&](int mi) { return mi < (int)renderOptions->materialBssrdf.size() ? renderOptions->materialBssrdf[mi] : -1; };
         if (bssrdfOf(sub[0]) >= 0) {
             const PgBSSRDF comp = renderOptions->bssrdfs[bssrdfOf(sub[0])];
-            if (comp.textured || anyTexture) Error("mix: a textured subsurface component (or a textured mix around one) is outside this build's closed set; the mix is rendered without the BSSRDF.");
-            else {
+            if (comp.textured || anyTexture) {
+                Error("mix: a textured subsurface component (or a textured mix around one) is outside this build's closed set; the scene will not be rendered.");
+                renderOptions->refused = true;  // (no frame with the mix's BSSRDF left out)
+            } else {
                 mat.ReportUnused();
                 m.n_bxdfs = (int)lobes.size();
                 m.first_bxdf = (int)renderOptions->bxdfs.size();
@@ -928,8 +933,11 @@ void pbrtTexture(const std::string &name, const std::string &type, const std::st
         t.tex1 = operand("inside", 1.f); t.tex2 = operand("outside", 0.f);
         renderOptions->usesNoise = true;
     } else {
-        Error("Texture \"%s\": class \"%s\" is outside this build's closed set (constant, scale, mix, checkerboard, uv, bilerp, imagemap, fbm, wrinkled, windy, marble, dots); ignoring.",
-              name.c_str(), texname.c_str());
+        if (texname == "ptex") {  // the one texture class of the reference (api.cpp:603-697) this build has not: no frame without it
+            Error("Texture \"%s\": class \"ptex\" is outside this build's closed set (constant, scale, mix, checkerboard, uv, bilerp, imagemap, fbm, wrinkled, windy, marble, dots); the scene will not be rendered.",
+                  name.c_str());
+            renderOptions->refused = true;
+        } else Warning("%s texture \"%s\" unknown.", isFloat ? "Float" : "Spectrum", texname.c_str());  // api.cpp:640, :676 (the reference's own message for a class it does not know)
         return;
     }
     ref.tex = (int)renderOptions->textures.size();
@@ -1126,7 +1134,9 @@ void pbrtLightSource(const std::string &name, const ParamSet &params) {
         float *mrow = &tab[base + rowStride * height];
         dist1d(marginalFunc.data(), height, mrow, mrow + height, mrow + 2 * height + 1);
     } else {
-        Error("LightSource \"%s\" is outside this build's closed set (point, spot, distant, projection, goniometric, infinite, and diffuse area lights); ignoring.", name.c_str());
+        // (every light class of the reference is built above: an unknown name is the file's mistake, reported as the reference reports it)
+        Warning("Light \"%s\" unknown.", name.c_str());  // api.cpp:750
+        Error("LightSource: light type \"%s\" unknown.", name.c_str());  // api.cpp:1308
         return;
     }
     params.ReportUnused();
@@ -1281,7 +1291,10 @@ void pbrtShape(const std::string &name, const ParamSet &params) {  // api.cpp:13
         Point3f p2 = params.FindOnePoint3f("p2", Point3f(1, 1, 1));
         Float phimax = params.FindOneFloat("phimax", 360);
         sphere = Sphere::Hyperboloid(shapeToWorld, Inverse(shapeToWorld), graphicsState.reverseOrientation, p1, p2, phimax);
-    } else Error("Shape \"%s\" is outside this build's closed set (trianglemesh, plymesh, loopsubdiv, heightfield, nurbs, sphere, cylinder, disk, cone, paraboloid, hyperboloid); ignoring.", name.c_str());
+    } else if (name == "curve") {  // the one shape of the reference (api.cpp:469-533) this build has not: no frame without it
+        Error("Shape \"curve\" is outside this build's closed set (trianglemesh, plymesh, loopsubdiv, heightfield, nurbs, sphere, cylinder, disk, cone, paraboloid, hyperboloid); the scene will not be rendered.");
+        renderOptions->refused = true;
+    } else Warning("Shape \"%s\" unknown.", name.c_str());  // api.cpp:531
     if (!sphere && (!mesh || mesh->nTriangles == 0)) return;
     int mtl = GetMaterialForShape(params);
     params.ReportUnused();

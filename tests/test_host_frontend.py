@@ -84,9 +84,9 @@ def test_split_methods_give_same_image(pkg, oracle, split):
 
 def test_errors_are_reported_not_thrown(pkg):
     before = pkg.host_lib().pbrt_host_error_count()
-    s = pkg.HostScene(text=(MINI % (16, 16, 1)).replace("WorldEnd", 'Shape "curve"\nLightSource "infinite" "string mapname" "sky.exr"\nTexture "t" "spectrum" "imagemap"\nWorldEnd'))
-    assert s.desc.n_tris == 3  # unsupported plugins are skipped, the scene still loads (error.cpp:62-102 semantics)
-    assert pkg.host_lib().pbrt_host_error_count() >= before + 3
+    s = pkg.HostScene(text=(MINI % (16, 16, 1)).replace("WorldEnd", 'Shape "teapot"\nLightSource "infinite" "string mapname" "sky.exr"\nTexture "t" "spectrum" "imagemap"\nWorldEnd'))
+    assert s.desc.n_tris == 3  # an unknown shape and unreadable assets are reported as the reference reports them, the scene still loads (error.cpp:62-102 semantics)
+    assert pkg.host_lib().pbrt_host_error_count() >= before + 2  # (a shape the REFERENCE has and this build has not -- "curve" -- refuses the frame: the last test of this file)
     with pytest.raises(pkg.PbrtGpuError):
         pkg.HostScene(text="WorldBegin\nWorldEnd\n" if False else "Camera \"perspective\"\n")  # no WorldEnd => nothing to render
 
@@ -318,3 +318,25 @@ def test_moving_shapes_and_instances_become_animated_instances(pkg):
     rd = s.render_desc()
     assert rd.camera_animated == 1 and pkg.host_lib().pbrt_host_error_count() == before
     assert list(rd.camera_time) == [0.0, 1.0] and abs(rd.camera_T[1][0] - rd.camera_T[0][0]) > 0.2 and list(rd.camera_R[0]) == list(rd.camera_R[1])
+
+
+def test_features_of_the_reference_outside_the_closed_set_refuse_the_frame(pkg):
+    """What the REFERENCE renders and this build does not -- hair / disney / fourier materials, curve shapes, Ptex textures, a textured subsurface component
+    inside a mix -- is an Error() and NO frame: never an image with a stand-in (matte for the material, the shape left out, the BSSRDF dropped).  A name the
+    reference does not know either gets the reference's own Warning and fallback (api.cpp:531, :590, :640, :676, :750)."""
+    mini = MINI % (16, 16, 1)
+    tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\n'
+    sss_mix = ('Texture "chk" "spectrum" "checkerboard"\nMakeNamedMaterial "wax" "string type" "kdsubsurface" "texture Kd" "chk"\nMakeNamedMaterial "paint" "string type" "matte"\n'
+               'Material "mix" "string namedmaterial1" "wax" "string namedmaterial2" "paint"\n' + tri)
+    for what, extra in (("disney", 'Material "disney"\n' + tri), ("hair", 'Material "hair"\n' + tri), ("fourier", 'Material "fourier" "string bsdffile" "none.bsdf"\n' + tri),
+                        ("curve", 'Shape "curve" "point P" [0 0 0 1 0 0 1 1 0 0 1 0]\n'), ("ptex", 'Texture "p" "spectrum" "ptex" "string filename" "none.ptx"\n' + tri),
+                        ("textured subsurface in a mix", sss_mix)):
+        before = pkg.host_lib().pbrt_host_error_count()
+        with pytest.raises(pkg.PbrtGpuError):
+            pkg.HostScene(text=mini.replace("WorldEnd", "AttributeBegin\n" + extra + "AttributeEnd\nWorldEnd"))
+        assert pkg.host_lib().pbrt_host_error_count() > before, what
+    # names nobody knows: the reference's warnings, the scene loads (matte for the material, nothing for the shape / texture)
+    before = pkg.host_lib().pbrt_host_error_count()
+    s = pkg.HostScene(text=mini.replace("WorldEnd", 'AttributeBegin\nMaterial "velvet"\n' + tri + 'Shape "teapot"\nTexture "t" "float" "plaid"\nAttributeEnd\nWorldEnd'))
+    assert pkg.host_lib().pbrt_host_error_count() == before and s.desc.n_tris >= 1
+    s.close()
