@@ -531,7 +531,10 @@ static int MakeMaterial(const std::string &name, const ParamSet &geom, const Par
                 if ((int)lobes.size() < PG_MAX_BXDFS) lobes.push_back(b); else bad = true;
             }
         }
-        if (bad) Error("mix: more than %d BxDFs or more than %d nested mixes; the excess is dropped.", PG_MAX_BXDFS, PG_MAX_BXDF_SCALES);
+        if (bad) {  // (the reference's BSDF::Add stops the process at more than MaxBxDFs, reflection.h:176-179; deeper nesting it renders: no frame with lobes left out)
+            Error("mix: more than %d BxDFs or more than %d nested mixes; the scene will not be rendered.", PG_MAX_BXDFS, PG_MAX_BXDF_SCALES);
+            renderOptions->refused = true;
+        }
         tm.sub[0] = sub[0]; tm.sub[1] = sub[1];
         for (int j = 0; j < 2; ++j) if (renderOptions->materials[sub[j]].type == PG_MAT_TEXTURED) anyTexture = true;
         // si->bssrdf stays what the FIRST component's ComputeScatteringFunctions set (mixmat.cpp:52-53; the second one works on a copy
