@@ -442,8 +442,7 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                         triNext = (int)(w2Leaf >> (leafBits + 1)); triLeft = (int)(w2Leaf & ((2u << leafBits) - 1u)); inInst2 = -1; spBase = spBase1;
                         instHit = instHit1 || instHit;  // a hit inside is a hit of the instance around it
                         if (triLeft == 0) { TR_POP(); TR_SETTLE(); }
-                    } else
-                    if (wantExit) {  // back to the world ray (primitive.cpp:83-88)
+                    } else if (wantExit) {  // back to the world ray (primitive.cpp:83-88)
                         if (!ANYHIT && instHit) wtMax = tMax;  // r.tMax = ray.tMax
                         {
                             const bool fromQ1 = q1.regionCap > 0 && ray >= hitOffset1;
@@ -485,8 +484,8 @@ __global__ __launch_bounds__(TR_BLOCK, ((XP == XP_INST || XP == (XP_INST | XP_AL
                             } else d1 = m4_vec(in1.w2i, mk(d4.x, d4.y, d4.z));
                             d4.x = d1.x; d4.y = d1.y; d4.z = d1.z;
                         } else {
-                        wtMax = tMax;
-                        if (ANYHIT) { wvd = vd; wvmask = vmask; vd = 0; vmask = 0; }
+                            wtMax = tMax;
+                            if (ANYHIT) { wvd = vd; wvmask = vmask; vd = 0; vmask = 0; }
                         }
                         V3 oErr, o, dd;
                         if ((XP & XP_ANIM) && sc.instances[idx].animated) {  // PrimitiveToWorld.Interpolate(r.time, ...), primitive.cpp:78-80 / :99-101
