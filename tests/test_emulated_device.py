@@ -28,7 +28,10 @@ def emulated(tmp_path_factory):
 
 def run_gpu_tests(lib, files, select, timeout):
     env = dict(os.environ, PBRT_GPU_LIB=lib, PBRT_EMULATED_DEVICE="1")
-    p = subprocess.run([sys.executable, "-m", "pytest", *files, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", select], cwd=ROOT, env=env,
+    # (several tests selected: three worker processes -- the emulated device is host code, the tests are independent; PBRT_EMULATE_WORKERS=0: serial)
+    workers = os.environ.get("PBRT_EMULATE_WORKERS", "3")
+    par = ["-n", workers] if workers != "0" and not any("::" in f for f in files) else []
+    p = subprocess.run([sys.executable, "-m", "pytest", *files, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", *par, "-k", select], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=timeout)
     tail = p.stdout[-3000:] + p.stderr[-1500:]
     assert p.returncode == 0, tail
